@@ -1,0 +1,535 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see grid.hpp header).
+//
+// hydro_sim.hpp: restatement of the hydro part of the level-0 driver
+//   reference src/QuokkaSimulation.hpp:885-990   advanceHydroAtLevelWithRetries
+//   reference src/QuokkaSimulation.hpp:992-1013  isCflViolated
+//   reference src/QuokkaSimulation.hpp:1032-1322 advanceHydroAtLevel (RK2-SSP + FOFC)
+//   reference src/QuokkaSimulation.hpp:1324-1368 replaceFluxes
+//   reference src/QuokkaSimulation.hpp:1403-1490 computeHydroFluxes
+//   reference src/QuokkaSimulation.hpp:1492-1517 hydroFluxFunction
+//   reference src/QuokkaSimulation.hpp:1519-1568 computeFOHydroFluxes / hydroFOFluxFunction
+//   reference src/QuokkaSimulation.hpp:408-441   computeMaxSignalLocal (hydro-only branch)
+//   reference src/simulation.hpp:703-818         computeTimestepAtLevel / computeTimestep
+//   reference src/simulation.hpp:827-981         evolve (time loop + figure of merit)
+// Uniform grid only (max_level = 0): no flux registers, no subcycling, no regrid.
+#ifndef ORACLE_HYDRO_SIM_HPP_
+#define ORACLE_HYDRO_SIM_HPP_
+
+#include <array>
+#include <cmath>
+#include <cstdio>
+#include <limits>
+#include <utility>
+#include <vector>
+
+#include "boundary.hpp"
+#include "grid.hpp"
+#include "hydro.hpp"
+
+namespace oracle
+{
+
+using FluxArrays = std::array<MultiFab, 3>;
+
+struct HydroSim {
+	// --- configuration (public data members of AMRSimulation / QuokkaSimulation) ---
+	HydroSystem hydro;
+	Geometry geom;
+	std::vector<Box> grids;
+	std::vector<BCRec> BCs_cc;
+	CustomBCFunc customBC;
+
+	int ncomp_cc = kNumHydroVars;		 // Physics_Indices::nvarTotal_cc
+	int nghost_cc = 4;			 // simulation.hpp:363
+	double stopTime_ = 1.0;			 // simulation.hpp:153
+	double cflNumber_ = 0.3;		 // simulation.hpp:154
+	long maxTimesteps_ = 10000;		 // simulation.hpp:157
+	double maxDt_ = std::numeric_limits<double>::max();
+	double initDt_ = std::numeric_limits<double>::max();
+	double constantDt_ = 0.0;
+	double densityFloor_ = 0.0;
+	double tempFloor_ = 0.0;
+	int integratorOrder_ = 2;		 // QuokkaSimulation.hpp:136
+	int reconstructionOrder_ = 3;		 // :137
+	int useDualEnergy_ = 1;			 // :139
+	int abortOnFofcFailure_ = 1;		 // :140
+	double artificialViscosityK_ = 0.;	 // :141
+	int verbose = 0;
+
+	// --- state ---
+	MultiFab state_old_cc_;
+	MultiFab state_new_cc_;
+	double tNew_ = 0.0;
+	double dt_ = 1.e100; // simulation.hpp:449
+	long istep = 0;
+	long cellUpdates_ = 0;
+	// diagnostics (counters the tests look at)
+	long fofc1_cells = 0, fofc2_cells = 0, retries = 0;
+
+	[[nodiscard]] auto ndim() const -> int { return geom.ndim; }
+	[[nodiscard]] auto ncompHydro() const -> int { return hydro.tr.nvar(); }
+
+	void define()
+	{
+		state_old_cc_ = MultiFab(grids, ncomp_cc, nghost_cc, ndim());
+		state_new_cc_ = MultiFab(grids, ncomp_cc, nghost_cc, ndim());
+	}
+
+	[[nodiscard]] auto CountCells() const -> long
+	{
+		long n = 0;
+		for (auto const &b : grids) {
+			n += b.numPts();
+		}
+		return n;
+	}
+
+	void fillBC(MultiFab &state, double time) { fillBoundaryConditions(state, geom, BCs_cc, customBC, time); }
+
+	// simulation.hpp:1608-1626 (after the user's setInitialConditionsOnGrid has filled state_new_cc_)
+	void finishInitialConditions()
+	{
+		fillBC(state_new_cc_, 0.0);
+		state_old_cc_ = state_new_cc_;
+	}
+
+	// QuokkaSimulation.hpp:1492-1517
+	void hydroFluxFunction(int dir, MultiFab const &primVar, MultiFab &leftState, MultiFab &rightState, MultiFab &flux, MultiFab &faceVel,
+			       MultiFab const &x1Flat, MultiFab const &x2Flat, MultiFab const &x3Flat, int ng_reconstruct, int nvars) const
+	{
+		for (int b = 0; b < primVar.size(); ++b) {
+			Box const cellRange = grow(primVar.valid[b], ng_reconstruct, ndim());
+			if (reconstructionOrder_ == 3) {
+				ReconstructStatesPPM(dir, primVar.const_array(b), leftState.array(b), rightState.array(b), cellRange, nvars);
+			} else if (reconstructionOrder_ == 2) {
+				ReconstructStatesPLM(dir, lim_minmod, primVar.const_array(b), leftState.array(b), rightState.array(b), cellRange, nvars);
+			} else {
+				ReconstructStatesConstant(dir, primVar.const_array(b), leftState.array(b), rightState.array(b), cellRange, nvars);
+			}
+			hydro.FlattenShocks(dir, primVar.const_array(b), x1Flat.const_array(b), x2Flat.const_array(b), x3Flat.const_array(b),
+					    leftState.array(b), rightState.array(b), cellRange, nvars);
+			hydro.ComputeFluxes(riemann_HLLC, dir, flux.array(b), faceVel.array(b), leftState.const_array(b), rightState.const_array(b),
+					    primVar.const_array(b), artificialViscosityK_, flux.validbox(b));
+		}
+	}
+
+	// QuokkaSimulation.hpp:1403-1490
+	auto computeHydroFluxes(MultiFab const &consVar, int nvars) const -> std::pair<FluxArrays, FluxArrays>
+	{
+		const int flatteningGhost = 2;
+		const int reconstructGhost = 1;
+		MultiFab primVar(grids, nvars, nghost_cc, ndim());
+		std::array<MultiFab, 3> flatCoefs;
+		FluxArrays flux, facevel, leftState, rightState;
+		for (int idim = 0; idim < 3; ++idim) {
+			flatCoefs[idim] = MultiFab(grids, 1, flatteningGhost, ndim());
+		}
+		for (int idim = 0; idim < ndim(); ++idim) {
+			leftState[idim] = MultiFab(grids, nvars, reconstructGhost, ndim(), idim);
+			rightState[idim] = MultiFab(grids, nvars, reconstructGhost, ndim(), idim);
+			flux[idim] = MultiFab(grids, nvars, 0, ndim(), idim);
+			facevel[idim] = MultiFab(grids, 1, 0, ndim(), idim);
+		}
+		for (int b = 0; b < consVar.size(); ++b) {
+			hydro.ConservedToPrimitive(consVar.const_array(b), primVar.array(b), grow(grids[b], nghost_cc, ndim()));
+		}
+		for (int idim = 0; idim < ndim(); ++idim) {
+			for (int b = 0; b < consVar.size(); ++b) {
+				hydro.ComputeFlatteningCoefficients(idim, primVar.const_array(b), flatCoefs[idim].array(b), grow(grids[b], flatteningGhost, ndim()));
+			}
+		}
+		for (int idim = 0; idim < ndim(); ++idim) {
+			hydroFluxFunction(idim, primVar, leftState[idim], rightState[idim], flux[idim], facevel[idim], flatCoefs[0], flatCoefs[1], flatCoefs[2],
+					  reconstructGhost, nvars);
+		}
+		return std::make_pair(std::move(flux), std::move(facevel));
+	}
+
+	// QuokkaSimulation.hpp:1519-1568
+	auto computeFOHydroFluxes(MultiFab const &consVar, int nvars) const -> std::pair<FluxArrays, FluxArrays>
+	{
+		const int reconstructRange = 1;
+		MultiFab primVar(grids, nvars, nghost_cc, ndim());
+		FluxArrays flux, facevel, leftState, rightState;
+		for (int idim = 0; idim < ndim(); ++idim) {
+			leftState[idim] = MultiFab(grids, nvars, reconstructRange, ndim(), idim);
+			rightState[idim] = MultiFab(grids, nvars, reconstructRange, ndim(), idim);
+			flux[idim] = MultiFab(grids, nvars, 0, ndim(), idim);
+			facevel[idim] = MultiFab(grids, 1, 0, ndim(), idim);
+		}
+		for (int b = 0; b < consVar.size(); ++b) {
+			hydro.ConservedToPrimitive(consVar.const_array(b), primVar.array(b), grow(grids[b], nghost_cc, ndim()));
+		}
+		for (int idim = 0; idim < ndim(); ++idim) {
+			for (int b = 0; b < consVar.size(); ++b) {
+				Box const cellRange = grow(grids[b], reconstructRange, ndim());
+				ReconstructStatesConstant(idim, primVar.const_array(b), leftState[idim].array(b), rightState[idim].array(b), cellRange, nvars);
+				hydro.ComputeFluxes(riemann_LLF, idim, flux[idim].array(b), facevel[idim].array(b), leftState[idim].const_array(b),
+						    rightState[idim].const_array(b), primVar.const_array(b), artificialViscosityK_, flux[idim].validbox(b));
+			}
+		}
+		return std::make_pair(std::move(flux), std::move(facevel));
+	}
+
+	// MultiFab::Saxpy(dst, a, src, 0, 0, ncomp, 0): dst += a*src on valid (face) boxes
+	static void Saxpy(MultiFab &dst, double a, MultiFab const &src, int ncomp)
+	{
+		for (int b = 0; b < dst.size(); ++b) {
+			auto d = dst.array(b);
+			auto s = src.const_array(b);
+			Box const r = dst.validbox(b);
+			for (int n = 0; n < ncomp; ++n) {
+				for (int k = r.lo[2]; k <= r.hi[2]; ++k) {
+					for (int j = r.lo[1]; j <= r.hi[1]; ++j) {
+						for (int i = r.lo[0]; i <= r.hi[0]; ++i) {
+							d(i, j, k, n) += a * s(i, j, k, n);
+						}
+					}
+				}
+			}
+		}
+	}
+
+	// QuokkaSimulation.hpp:1324-1368 (redoFlag has 1 ghost cell, filled by FillBoundary)
+	void replaceFluxes(FluxArrays &fluxes, FluxArrays const &FOfluxes, iMultiFab const &redoFlag) const
+	{
+		for (int idim = 0; idim < ndim(); ++idim) {
+			int const ncomp = fluxes[idim].nc;
+			for (int b = 0; b < redoFlag.size(); ++b) {
+				auto flux_arr = fluxes[idim].array(b);
+				auto FO_arr = FOfluxes[idim].const_array(b);
+				auto flag = redoFlag.const_array(b);
+				Box const r = grow(redoFlag.valid[b], 1, ndim());
+				for (int n = 0; n < ncomp; ++n) {
+					for (int k = r.lo[2]; k <= r.hi[2]; ++k) {
+						for (int j = r.lo[1]; j <= r.hi[1]; ++j) {
+							for (int i = r.lo[0]; i <= r.hi[0]; ++i) {
+								if (flag(i, j, k) == redo_redo) {
+									if (flux_arr.contains(i, j, k)) {
+										flux_arr(i, j, k, n) = FO_arr(i, j, k, n);
+									}
+									int const ip = i + (idim == 0 ? 1 : 0);
+									int const jp = j + (idim == 1 ? 1 : 0);
+									int const kp = k + (idim == 2 ? 1 : 0);
+									if (flux_arr.contains(ip, jp, kp)) {
+										flux_arr(ip, jp, kp, n) = FO_arr(ip, jp, kp, n);
+									}
+								}
+							}
+						}
+					}
+				}
+			}
+		}
+	}
+
+	static auto sumFlags(iMultiFab const &redoFlag) -> long
+	{
+		long s = 0;
+		for (int b = 0; b < redoFlag.size(); ++b) {
+			auto f = redoFlag.const_array(b);
+			Box const &r = redoFlag.valid[b];
+			for (int k = r.lo[2]; k <= r.hi[2]; ++k) {
+				for (int j = r.lo[1]; j <= r.hi[1]; ++j) {
+					for (int i = r.lo[0]; i <= r.hi[0]; ++i) {
+						s += f(i, j, k);
+					}
+				}
+			}
+		}
+		return s;
+	}
+
+	void rhsPdvPredict(MultiFab &rhs, FluxArrays const &fluxes, FluxArrays const &faceVel, MultiFab const &stateOld, MultiFab &stateNew, double dt_lev,
+			   iMultiFab &redoFlag) const
+	{
+		for (int b = 0; b < rhs.size(); ++b) {
+			std::array<Array4<const double>, 3> f{}, v{};
+			for (int d = 0; d < ndim(); ++d) {
+				f[d] = fluxes[d].const_array(b);
+				v[d] = faceVel[d].const_array(b);
+			}
+			Box const &r = grids[b];
+			hydro.ComputeRhsFromFluxes(rhs.array(b), f, geom.dx, ncompHydro(), r);
+			hydro.AddInternalEnergyPdV(rhs.array(b), stateOld.const_array(b), geom.dx, v, redoFlag.const_array(b), r);
+			hydro.PredictStep(stateOld.const_array(b), stateNew.array(b), rhs.const_array(b), dt_lev, ncompHydro(), redoFlag.array(b), r);
+		}
+	}
+
+	void limitsAndSync(MultiFab &state) const
+	{
+		for (int b = 0; b < state.size(); ++b) {
+			hydro.EnforceLimits(densityFloor_, tempFloor_, state.array(b), grids[b]);
+		}
+		if (useDualEnergy_ == 1) {
+			for (int b = 0; b < state.size(); ++b) {
+				hydro.SyncDualEnergy(state.array(b), grids[b]);
+			}
+		}
+	}
+
+	// QuokkaSimulation.hpp:992-1013
+	auto isCflViolated(double dt_actual) const -> bool
+	{
+		double max_signal = -std::numeric_limits<double>::infinity();
+		for (int b = 0; b < state_new_cc_.size(); ++b) {
+			max_signal = std::max(max_signal, hydro.maxSignalSpeedLocal(state_new_cc_.const_array(b), grids[b]));
+		}
+		const double dx_min = minDx();
+		const double dt_cfl = cflNumber_ * (dx_min / max_signal);
+		const double max_factor = 1.1;
+		return dt_actual > (max_factor * dt_cfl);
+	}
+
+	[[nodiscard]] auto minDx() const -> double
+	{
+		double m = geom.dx[0];
+		for (int d = 1; d < ndim(); ++d) {
+			m = std::min(m, geom.dx[d]);
+		}
+		return m;
+	}
+
+	// QuokkaSimulation.hpp:1032-1322 (no Strang sources, no flux registers, no tracers)
+	auto advanceHydroAtLevel(MultiFab &state_old_cc_tmp, double time, double dt_lev) -> bool
+	{
+		const int nc = ncompHydro();
+		MultiFab state_inter_cc_(grids, ncomp_cc, nghost_cc, ndim());
+		state_inter_cc_.setVal(0);
+
+		FluxArrays flux_rk2, avgFaceVel;
+		// The reference allocates avgFaceVel with 2 ghost faces "for tracer particles"
+		// (QuokkaSimulation.hpp:1061); the ghosts only feed tracers (out of scope) and make
+		// replaceFluxes read FOfaceVel out of bounds (:1352 `contains` on the ghosted array), so
+		// the oracle allocates none.  Valid faces are unaffected.
+		const int nghost_vel = 0;
+		for (int idim = 0; idim < ndim(); ++idim) {
+			flux_rk2[idim] = MultiFab(grids, nc, 0, ndim(), idim);
+			flux_rk2[idim].setVal(0);
+			avgFaceVel[idim] = MultiFab(grids, 1, nghost_vel, ndim(), idim);
+			avgFaceVel[idim].setVal(0);
+		}
+
+		// :1076 update ghost zones [old timestep]
+		fillBC(state_old_cc_tmp, time);
+
+		// :1096
+		auto [FOfluxArrays, FOfaceVel] = computeFOHydroFluxes(state_old_cc_tmp, nc);
+
+		// Stage 1 of RK2-SSP (:1099-1198)
+		{
+			auto const &stateOld = state_old_cc_tmp;
+			auto &stateNew = state_inter_cc_;
+			auto [fluxArrays, faceVel] = computeHydroFluxes(stateOld, nc);
+
+			for (int idim = 0; idim < ndim(); ++idim) {
+				Saxpy(flux_rk2[idim], 0.5, fluxArrays[idim], nc);
+				Saxpy(avgFaceVel[idim], 0.5, faceVel[idim], 1);
+			}
+
+			MultiFab rhs(grids, nc, 0, ndim());
+			iMultiFab redoFlag(grids, 1, 1, ndim());
+			redoFlag.setVal(redo_none);
+
+			rhsPdvPredict(rhs, fluxArrays, faceVel, stateOld, stateNew, dt_lev, redoFlag);
+
+			long const ncells_bad = sumFlags(redoFlag);
+			if (ncells_bad > 0) {
+				fofc1_cells += ncells_bad;
+				if (verbose != 0) {
+					std::printf("[FOFC-1] flux correcting %ld cells\n", ncells_bad);
+				}
+				FillBoundary(redoFlag, geom);
+				replaceFluxes(fluxArrays, FOfluxArrays, redoFlag);
+				replaceFluxes(faceVel, FOfaceVel, redoFlag);
+				rhsPdvPredict(rhs, fluxArrays, faceVel, stateOld, stateNew, dt_lev, redoFlag);
+				long const ncells_bad2 = sumFlags(redoFlag);
+				if (ncells_bad2 > 0) {
+					if (abortOnFofcFailure_ != 0) {
+						return false;
+					}
+				}
+			}
+			limitsAndSync(stateNew);
+		}
+
+		// Stage 2 of RK2-SSP (:1202-1287)
+		if (integratorOrder_ == 2) {
+			fillBC(state_inter_cc_, time + dt_lev);
+
+			auto const &stateOld = state_old_cc_tmp;
+			auto const &stateInter = state_inter_cc_;
+			auto &stateFinal = state_new_cc_;
+			auto [fluxArrays, faceVel] = computeHydroFluxes(stateInter, nc);
+
+			for (int idim = 0; idim < ndim(); ++idim) {
+				Saxpy(flux_rk2[idim], 0.5, fluxArrays[idim], nc);
+				Saxpy(avgFaceVel[idim], 0.5, faceVel[idim], 1);
+			}
+
+			MultiFab rhs(grids, nc, 0, ndim());
+			iMultiFab redoFlag(grids, 1, 1, ndim());
+			redoFlag.setVal(redo_none);
+
+			rhsPdvPredict(rhs, flux_rk2, avgFaceVel, stateOld, stateFinal, dt_lev, redoFlag);
+
+			long const ncells_bad = sumFlags(redoFlag);
+			if (ncells_bad > 0) {
+				fofc2_cells += ncells_bad;
+				if (verbose != 0) {
+					std::printf("[FOFC-2] flux correcting %ld cells\n", ncells_bad);
+				}
+				FillBoundary(redoFlag, geom);
+				replaceFluxes(flux_rk2, FOfluxArrays, redoFlag);
+				replaceFluxes(avgFaceVel, FOfaceVel, redoFlag);
+				rhsPdvPredict(rhs, flux_rk2, avgFaceVel, stateOld, stateFinal, dt_lev, redoFlag);
+				long const ncells_bad2 = sumFlags(redoFlag);
+				if (ncells_bad2 > 0) {
+					if (abortOnFofcFailure_ != 0) {
+						return false;
+					}
+				}
+			}
+			limitsAndSync(stateFinal);
+		} else {
+			// :1289 forward Euler: copy hydro comps of the valid region
+			copyValid(state_new_cc_, state_inter_cc_, nc);
+		}
+
+		// :1321
+		return !isCflViolated(dt_lev);
+	}
+
+	void copyValid(MultiFab &dst, MultiFab const &src, int ncomp) const
+	{
+		for (int b = 0; b < dst.size(); ++b) {
+			auto d = dst.array(b);
+			auto s = src.const_array(b);
+			Box const &r = grids[b];
+			for (int n = 0; n < ncomp; ++n) {
+				for (int k = r.lo[2]; k <= r.hi[2]; ++k) {
+					for (int j = r.lo[1]; j <= r.hi[1]; ++j) {
+						for (int i = r.lo[0]; i <= r.hi[0]; ++i) {
+							d(i, j, k, n) = s(i, j, k, n);
+						}
+					}
+				}
+			}
+		}
+	}
+
+	// QuokkaSimulation.hpp:885-990
+	auto advanceHydroAtLevelWithRetries(double time, double dt_lev) -> bool
+	{
+		const int max_retries = 6;
+		bool success = false;
+		for (int retry_count = 0; retry_count <= max_retries; ++retry_count) {
+			const int nsubsteps = static_cast<int>(std::pow(2, retry_count));
+			const double dt_step = dt_lev / nsubsteps;
+			if (retry_count > 0) {
+				++retries;
+			}
+			// :939-940 temporary copy of the old state (with ghosts)
+			MultiFab state_old_cc_tmp = state_old_cc_;
+			for (int substep = 0; substep < nsubsteps; ++substep) {
+				if (substep > 0) {
+					// :947 amrex::Copy(state_old_cc_tmp, state_new_cc_, 0, 0, ncompHydro_, nghost_cc_)
+					for (int b = 0; b < state_old_cc_tmp.size(); ++b) {
+						auto d = state_old_cc_tmp.array(b);
+						auto s = state_new_cc_.const_array(b);
+						Box const r = state_old_cc_tmp.fabs[b].bx;
+						for (int n = 0; n < ncompHydro(); ++n) {
+							for (int k = r.lo[2]; k <= r.hi[2]; ++k) {
+								for (int j = r.lo[1]; j <= r.hi[1]; ++j) {
+									for (int i = r.lo[0]; i <= r.hi[0]; ++i) {
+										d(i, j, k, n) = s(i, j, k, n);
+									}
+								}
+							}
+						}
+					}
+				}
+				success = advanceHydroAtLevel(state_old_cc_tmp, time, dt_step);
+				if (!success) {
+					break;
+				}
+			}
+			if (success) {
+				break;
+			}
+		}
+		return success;
+	}
+
+	// simulation.hpp:703-720 with QuokkaSimulation.hpp:408-441 (hydro-only branch) and norminf
+	[[nodiscard]] auto computeTimestepAtLevel() const -> double
+	{
+		double domain_signal_max = 0.0; // norminf of a non-negative field
+		for (int b = 0; b < state_new_cc_.size(); ++b) {
+			Fab<double> maxSignal(grids[b], 1);
+			hydro.ComputeMaxSignalSpeed(state_new_cc_.const_array(b), maxSignal.array(), grids[b]);
+			for (double v : maxSignal.d) {
+				domain_signal_max = std::max(domain_signal_max, std::abs(v));
+			}
+		}
+		const double dx_min = minDx();
+		return cflNumber_ * (dx_min / domain_signal_max);
+	}
+
+	// simulation.hpp:722-818 (single level)
+	void computeTimestep()
+	{
+		double dt_tmp = computeTimestepAtLevel();
+		constexpr double change_max = 1.1;
+		dt_tmp = std::min(dt_tmp, change_max * dt_);
+
+		double dt_0 = dt_tmp;
+		dt_0 = std::min(dt_0, 1.0 * dt_tmp); // n_factor * dt_tmp[0], n_factor = 1
+		dt_0 = std::min(dt_0, maxDt_);
+		if (tNew_ == 0.0) {
+			dt_0 = std::min(dt_0, initDt_);
+		}
+		if (constantDt_ > 0.0) {
+			dt_0 = constantDt_;
+		}
+		const double eps = 1.e-3 * dt_0;
+		if (tNew_ + dt_0 > stopTime_ - eps) {
+			dt_0 = stopTime_ - tNew_;
+		}
+		dt_ = dt_0;
+	}
+
+	// one coarse step: simulation.hpp:866-890 + :1276-1286 + QuokkaSimulation.hpp:653-707
+	auto step() -> bool
+	{
+		computeTimestep();
+		double const time = tNew_;
+		tNew_ += dt_;
+		std::swap(state_old_cc_, state_new_cc_);
+		bool const ok = advanceHydroAtLevelWithRetries(time, dt_);
+		++istep;
+		cellUpdates_ += CountCells();
+		return ok;
+	}
+
+	// simulation.hpp:856-951 time loop
+	auto evolve() -> bool
+	{
+		double cur_time = tNew_;
+		for (long s = istep; s < maxTimesteps_ && cur_time < stopTime_; ++s) {
+			if (!step()) {
+				return false;
+			}
+			cur_time += dt_;
+			tNew_ = cur_time;
+			if (cur_time >= stopTime_ - 1.e-6 * dt_) {
+				break;
+			}
+		}
+		return true;
+	}
+};
+
+} // namespace oracle
+
+#endif // ORACLE_HYDRO_SIM_HPP_

@@ -1,0 +1,212 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see grid.hpp header).
+//
+// oracle_capi.cpp: extern "C" entry points so tests/ (ctypes + numpy) can drive the CPU
+// restatement.  Arrays are Fortran-order, component outermost (amrex::Array4 layout), FP64.
+#include <cstring>
+#include <memory>
+
+#include "hydro_sim.hpp"
+#include "problems.hpp"
+
+using namespace oracle;
+
+extern "C" {
+
+struct orc_hydro_traits {
+	double gamma;
+	double cs_isothermal;
+	double mean_molecular_weight;
+	double boltzmann_constant;
+	int reconstruct_eint;
+	int nscalars;
+	int ndim;
+};
+
+static auto makeSystem(orc_hydro_traits const *t) -> HydroSystem
+{
+	HydroSystem h;
+	h.tr.eos.tr.gamma = t->gamma;
+	h.tr.eos.tr.cs_isothermal = t->cs_isothermal;
+	h.tr.eos.tr.mean_molecular_weight = t->mean_molecular_weight;
+	h.tr.eos.tr.boltzmann_constant = t->boltzmann_constant;
+	h.tr.reconstruct_eint = (t->reconstruct_eint != 0);
+	h.tr.nscalars = t->nscalars;
+	h.tr.ndim = t->ndim;
+	return h;
+}
+
+static auto mkbox(int const lo[3], int const hi[3]) -> Box
+{
+	Box b;
+	for (int d = 0; d < 3; ++d) {
+		b.lo[d] = lo[d];
+		b.hi[d] = hi[d];
+	}
+	return b;
+}
+
+int orc_eos_variant() { return kEosVariant; }
+
+// ------------------------------------------------------------------ per-operator entry points
+// `cons`/`prim` live on `gbox` = valid box grown by nghost (in the first ndim dims).
+
+void orc_cons_to_prim(orc_hydro_traits const *t, double const *cons, double *prim, int const glo[3], int const ghi[3])
+{
+	HydroSystem h = makeSystem(t);
+	Box g = mkbox(glo, ghi);
+	h.ConservedToPrimitive(Array4<const double>(cons, g, h.tr.nvar()), Array4<double>(prim, g, h.tr.nvar()), g);
+}
+
+void orc_flattening_coefficients(orc_hydro_traits const *t, int dir, double const *prim, int const glo[3], int const ghi[3], double *chi,
+				 int const clo[3], int const chi_hi[3])
+{
+	HydroSystem h = makeSystem(t);
+	Box g = mkbox(glo, ghi);
+	Box c = mkbox(clo, chi_hi);
+	h.ComputeFlatteningCoefficients(dir, Array4<const double>(prim, g, h.tr.nvar()), Array4<double>(chi, c, 1), c);
+}
+
+// Full flux evaluation for one box exactly as computeHydroFluxes / computeFOHydroFluxes do it.
+// order: 1/2/3 -> donor/PLM-minmod/PPM with flattening + HLLC ; order = 0 -> first-order LLF path
+// (computeFOHydroFluxes).  flux_d: face box (nodal in d) x nvar ; fvel_d: face box x 1.
+void orc_compute_hydro_fluxes(orc_hydro_traits const *t, int order, double K_visc, double const *cons, int const vlo[3], int const vhi[3], int nghost,
+			      double *flux0, double *flux1, double *flux2, double *fvel0, double *fvel1, double *fvel2)
+{
+	HydroSim sim;
+	sim.hydro = makeSystem(t);
+	sim.geom.ndim = t->ndim;
+	sim.grids = {mkbox(vlo, vhi)};
+	sim.nghost_cc = nghost;
+	sim.ncomp_cc = sim.hydro.tr.nvar();
+	sim.artificialViscosityK_ = K_visc;
+	sim.reconstructionOrder_ = (order == 0) ? 1 : order;
+	int const nv = sim.hydro.tr.nvar();
+	MultiFab consMF(sim.grids, nv, nghost, t->ndim);
+	std::memcpy(consMF.fabs[0].d.data(), cons, consMF.fabs[0].d.size() * sizeof(double));
+	auto result = (order == 0) ? sim.computeFOHydroFluxes(consMF, nv) : sim.computeHydroFluxes(consMF, nv);
+	double *fo[3] = {flux0, flux1, flux2};
+	double *vo[3] = {fvel0, fvel1, fvel2};
+	for (int d = 0; d < t->ndim; ++d) {
+		std::memcpy(fo[d], result.first[d].fabs[0].d.data(), result.first[d].fabs[0].d.size() * sizeof(double));
+		std::memcpy(vo[d], result.second[d].fabs[0].d.data(), result.second[d].fabs[0].d.size() * sizeof(double));
+	}
+}
+
+// ------------------------------------------------------------------ whole-simulation handle
+struct orc_sim_config {
+	int problem; // 0 = Sod, 1 = contact, 2 = Sedov
+	int ndim;
+	int n_cell[3];
+	int max_grid_size[3];
+	double prob_lo[3];
+	double prob_hi[3];
+	int periodic[3];
+	// overrides (< 0 / NaN = keep the problem's default)
+	double cfl;
+	double stop_time;
+	long max_timesteps;
+	int reconstruction_order;
+	int nscalars;
+};
+
+void *orc_sim_create(orc_sim_config const *c)
+{
+	auto sim = std::make_unique<HydroSim>();
+	setupGeometry(*sim, c->ndim, c->n_cell, c->prob_lo, c->prob_hi, c->periodic, c->max_grid_size);
+	if (c->problem == 0) {
+		setupSod(*sim);
+	} else if (c->problem == 1) {
+		setupContact(*sim, c->nscalars > 0 ? c->nscalars : 0);
+	} else if (c->problem == 2) {
+		setupSedov(*sim);
+	} else {
+		return nullptr;
+	}
+	if (c->cfl > 0) {
+		sim->cflNumber_ = c->cfl;
+	}
+	if (c->stop_time > 0) {
+		sim->stopTime_ = c->stop_time;
+	}
+	if (c->max_timesteps >= 0) {
+		sim->maxTimesteps_ = c->max_timesteps;
+	}
+	if (c->reconstruction_order > 0) {
+		sim->reconstructionOrder_ = c->reconstruction_order;
+	}
+	return sim.release();
+}
+
+void orc_sim_destroy(void *p) { delete static_cast<HydroSim *>(p); }
+int orc_sim_nboxes(void *p) { return static_cast<HydroSim *>(p)->state_new_cc_.size(); }
+int orc_sim_ncomp(void *p) { return static_cast<HydroSim *>(p)->ncomp_cc; }
+int orc_sim_nghost(void *p) { return static_cast<HydroSim *>(p)->nghost_cc; }
+void orc_sim_box(void *p, int b, int lo[3], int hi[3])
+{
+	auto *s = static_cast<HydroSim *>(p);
+	for (int d = 0; d < 3; ++d) {
+		lo[d] = s->grids[b].lo[d];
+		hi[d] = s->grids[b].hi[d];
+	}
+}
+// copy the whole fab (valid + ghosts) of state_new_cc_ / state_old_cc_
+void orc_sim_get_state(void *p, int which, int b, double *out)
+{
+	auto *s = static_cast<HydroSim *>(p);
+	auto const &mf = (which == 0) ? s->state_new_cc_ : s->state_old_cc_;
+	std::memcpy(out, mf.fabs[b].d.data(), mf.fabs[b].d.size() * sizeof(double));
+}
+void orc_sim_set_state(void *p, int which, int b, double const *in)
+{
+	auto *s = static_cast<HydroSim *>(p);
+	auto &mf = (which == 0) ? s->state_new_cc_ : s->state_old_cc_;
+	std::memcpy(mf.fabs[b].d.data(), in, mf.fabs[b].d.size() * sizeof(double));
+}
+void orc_sim_fill_ghosts(void *p, int which, double time)
+{
+	auto *s = static_cast<HydroSim *>(p);
+	s->fillBC((which == 0) ? s->state_new_cc_ : s->state_old_cc_, time);
+}
+double orc_sim_time(void *p) { return static_cast<HydroSim *>(p)->tNew_; }
+double orc_sim_dt(void *p) { return static_cast<HydroSim *>(p)->dt_; }
+long orc_sim_istep(void *p) { return static_cast<HydroSim *>(p)->istep; }
+long orc_sim_cell_updates(void *p) { return static_cast<HydroSim *>(p)->cellUpdates_; }
+double orc_sim_compute_dt(void *p)
+{
+	auto *s = static_cast<HydroSim *>(p);
+	double const save = s->dt_;
+	s->computeTimestep();
+	double const r = s->dt_;
+	s->dt_ = save;
+	return r;
+}
+void orc_sim_counters(void *p, long out[3])
+{
+	auto *s = static_cast<HydroSim *>(p);
+	out[0] = s->fofc1_cells;
+	out[1] = s->fofc2_cells;
+	out[2] = s->retries;
+}
+// one coarse step with the reference's own dt control; returns 1 on success
+int orc_sim_step(void *p)
+{
+	auto *s = static_cast<HydroSim *>(p);
+	bool const ok = s->step();
+	return ok ? 1 : 0;
+}
+// one hydro advance with a caller-supplied dt (no dt control): old <- new, advance
+int orc_sim_advance_fixed_dt(void *p, double dt)
+{
+	auto *s = static_cast<HydroSim *>(p);
+	double const time = s->tNew_;
+	s->dt_ = dt;
+	s->tNew_ += dt;
+	std::swap(s->state_old_cc_, s->state_new_cc_);
+	bool const ok = s->advanceHydroAtLevelWithRetries(time, dt);
+	++s->istep;
+	s->cellUpdates_ += s->CountCells();
+	return ok ? 1 : 0;
+}
+int orc_sim_evolve(void *p) { return static_cast<HydroSim *>(p)->evolve() ? 1 : 0; }
+
+} // extern "C"

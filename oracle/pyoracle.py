@@ -1,0 +1,229 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+ctypes/numpy binding of oracle/liboracle.so (the CPU restatement of the reference algorithm).
+Only tests/, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this.
+Arrays are Fortran-order with the component index outermost (amrex::Array4 layout), i.e. a numpy
+array of shape (ncomp, nz, ny, nx) in C order.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+K_B = 1.380649e-16
+M_U = 1.6605390666e-24
+
+SOD, CONTACT, SEDOV = 0, 1, 2
+
+
+def build(force: bool = False) -> None:
+    """Compile the oracle with gcc (seconds)."""
+    lib = os.path.join(_HERE, "liboracle.so")
+    if force or not os.path.exists(lib):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+
+
+class HydroTraits(C.Structure):
+    _fields_ = [
+        ("gamma", C.c_double),
+        ("cs_isothermal", C.c_double),
+        ("mean_molecular_weight", C.c_double),
+        ("boltzmann_constant", C.c_double),
+        ("reconstruct_eint", C.c_int),
+        ("nscalars", C.c_int),
+        ("ndim", C.c_int),
+    ]
+
+
+def traits(gamma=1.4, reconstruct_eint=True, ndim=3, nscalars=0, mean_molecular_weight=M_U, boltzmann_constant=K_B,
+           cs_isothermal=float("nan")) -> HydroTraits:
+    return HydroTraits(gamma, cs_isothermal, mean_molecular_weight, boltzmann_constant, int(reconstruct_eint), nscalars, ndim)
+
+
+class SimConfig(C.Structure):
+    _fields_ = [
+        ("problem", C.c_int),
+        ("ndim", C.c_int),
+        ("n_cell", C.c_int * 3),
+        ("max_grid_size", C.c_int * 3),
+        ("prob_lo", C.c_double * 3),
+        ("prob_hi", C.c_double * 3),
+        ("periodic", C.c_int * 3),
+        ("cfl", C.c_double),
+        ("stop_time", C.c_double),
+        ("max_timesteps", C.c_long),
+        ("reconstruction_order", C.c_int),
+        ("nscalars", C.c_int),
+    ]
+
+
+_I3 = C.c_int * 3
+
+
+def _i3(v):
+    return _I3(*[int(x) for x in v])
+
+
+def _dp(a: np.ndarray):
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Oracle:
+    def __init__(self, variant: str = "direct"):
+        build()
+        name = "liboracle.so" if variant == "direct" else "liboracle_eosT.so"
+        self.lib = C.CDLL(os.path.join(_HERE, name))
+        L = self.lib
+        L.orc_sim_create.restype = C.c_void_p
+        L.orc_sim_create.argtypes = [C.POINTER(SimConfig)]
+        for f in ("orc_sim_destroy",):
+            getattr(L, f).argtypes = [C.c_void_p]
+        for f in ("orc_sim_nboxes", "orc_sim_ncomp", "orc_sim_nghost", "orc_sim_step", "orc_sim_evolve"):
+            getattr(L, f).argtypes = [C.c_void_p]
+            getattr(L, f).restype = C.c_int
+        for f in ("orc_sim_time", "orc_sim_dt", "orc_sim_compute_dt"):
+            getattr(L, f).argtypes = [C.c_void_p]
+            getattr(L, f).restype = C.c_double
+        for f in ("orc_sim_istep", "orc_sim_cell_updates"):
+            getattr(L, f).argtypes = [C.c_void_p]
+            getattr(L, f).restype = C.c_long
+        L.orc_sim_box.argtypes = [C.c_void_p, C.c_int, _I3, _I3]
+        L.orc_sim_get_state.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        L.orc_sim_set_state.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        L.orc_sim_fill_ghosts.argtypes = [C.c_void_p, C.c_int, C.c_double]
+        L.orc_sim_counters.argtypes = [C.c_void_p, C.c_long * 3]
+        L.orc_sim_advance_fixed_dt.argtypes = [C.c_void_p, C.c_double]
+        L.orc_sim_advance_fixed_dt.restype = C.c_int
+        L.orc_eos_variant.restype = C.c_int
+
+    # ---------------------------------------------------------------- per-operator
+    def cons_to_prim(self, t: HydroTraits, cons: np.ndarray, glo, ghi) -> np.ndarray:
+        prim = np.empty_like(cons)
+        self.lib.orc_cons_to_prim(C.byref(t), _dp(cons), _dp(prim), _i3(glo), _i3(ghi))
+        return prim
+
+    def flattening_coefficients(self, t: HydroTraits, d: int, prim: np.ndarray, glo, ghi, clo, chi) -> np.ndarray:
+        shape = tuple(int(chi[a] - clo[a] + 1) for a in (2, 1, 0))
+        out = np.empty(shape, dtype=np.float64)
+        self.lib.orc_flattening_coefficients(C.byref(t), int(d), _dp(prim), _i3(glo), _i3(ghi), _dp(out), _i3(clo), _i3(chi))
+        return out
+
+    def compute_hydro_fluxes(self, t: HydroTraits, order: int, cons: np.ndarray, vlo, vhi, nghost=4, K_visc=0.0):
+        """cons: (nvar, ...) on the valid box grown by nghost. Returns ([flux_d], [facevel_d])."""
+        nv = 6 + t.nscalars
+        fl, fv = [], []
+        for d in range(3):
+            if d < t.ndim:
+                n = [int(vhi[a] - vlo[a] + 1) for a in range(3)]
+                n[d] += 1
+                fl.append(np.empty((nv, n[2], n[1], n[0]), dtype=np.float64))
+                fv.append(np.empty((n[2], n[1], n[0]), dtype=np.float64))
+            else:
+                fl.append(np.empty((0,), dtype=np.float64))
+                fv.append(np.empty((0,), dtype=np.float64))
+        self.lib.orc_compute_hydro_fluxes(C.byref(t), int(order), C.c_double(K_visc), _dp(cons), _i3(vlo), _i3(vhi), int(nghost),
+                                          _dp(fl[0]), _dp(fl[1]), _dp(fl[2]), _dp(fv[0]), _dp(fv[1]), _dp(fv[2]))
+        return fl[: t.ndim], fv[: t.ndim]
+
+    # ---------------------------------------------------------------- whole simulation
+    def sim(self, problem, ndim, n_cell, prob_lo, prob_hi, periodic, max_grid_size=None, cfl=-1.0, stop_time=-1.0,
+            max_timesteps=-1, reconstruction_order=-1, nscalars=0) -> "OracleSim":
+        n_cell = list(n_cell) + [1] * (3 - len(n_cell))
+        mgs = list(max_grid_size) if max_grid_size is not None else list(n_cell)
+        mgs = mgs + [1] * (3 - len(mgs))
+        cfg = SimConfig(problem, ndim, _i3(n_cell), _i3(mgs), (C.c_double * 3)(*prob_lo), (C.c_double * 3)(*prob_hi), _i3(periodic),
+                        cfl, stop_time, max_timesteps, reconstruction_order, nscalars)
+        h = self.lib.orc_sim_create(C.byref(cfg))
+        assert h, "oracle: unknown problem"
+        return OracleSim(self, h, ndim)
+
+
+@dataclass
+class OracleSim:
+    o: Oracle
+    h: int
+    ndim: int
+
+    def __del__(self):
+        try:
+            self.o.lib.orc_sim_destroy(self.h)
+        except Exception:
+            pass
+
+    @property
+    def nboxes(self):
+        return self.o.lib.orc_sim_nboxes(self.h)
+
+    @property
+    def ncomp(self):
+        return self.o.lib.orc_sim_ncomp(self.h)
+
+    @property
+    def nghost(self):
+        return self.o.lib.orc_sim_nghost(self.h)
+
+    @property
+    def time(self):
+        return self.o.lib.orc_sim_time(self.h)
+
+    @property
+    def dt(self):
+        return self.o.lib.orc_sim_dt(self.h)
+
+    @property
+    def istep(self):
+        return self.o.lib.orc_sim_istep(self.h)
+
+    def box(self, b):
+        lo, hi = _I3(), _I3()
+        self.o.lib.orc_sim_box(self.h, b, lo, hi)
+        return list(lo), list(hi)
+
+    def fab_shape(self, b):
+        lo, hi = self.box(b)
+        ng = self.nghost
+        n = [hi[d] - lo[d] + 1 + (2 * ng if d < self.ndim else 0) for d in range(3)]
+        return (self.ncomp, n[2], n[1], n[0])
+
+    def state(self, b=0, which=0) -> np.ndarray:
+        """Whole fab (valid + ghosts) as (ncomp, nz, ny, nx)."""
+        a = np.empty(self.fab_shape(b), dtype=np.float64)
+        self.o.lib.orc_sim_get_state(self.h, which, b, _dp(a))
+        return a
+
+    def valid(self, b=0, which=0) -> np.ndarray:
+        a = self.state(b, which)
+        ng = self.nghost
+        sl = [slice(None)] + [slice(ng, -ng) if d < self.ndim else slice(None) for d in (2, 1, 0)]
+        return np.ascontiguousarray(a[tuple(sl)])
+
+    def set_state(self, a: np.ndarray, b=0, which=0):
+        assert a.shape == self.fab_shape(b)
+        self.o.lib.orc_sim_set_state(self.h, which, b, _dp(np.ascontiguousarray(a)))
+
+    def fill_ghosts(self, which=0, time=0.0):
+        self.o.lib.orc_sim_fill_ghosts(self.h, which, time)
+
+    def compute_dt(self) -> float:
+        return self.o.lib.orc_sim_compute_dt(self.h)
+
+    def step(self) -> bool:
+        return bool(self.o.lib.orc_sim_step(self.h))
+
+    def advance_fixed_dt(self, dt: float) -> bool:
+        return bool(self.o.lib.orc_sim_advance_fixed_dt(self.h, dt))
+
+    def evolve(self) -> bool:
+        return bool(self.o.lib.orc_sim_evolve(self.h))
+
+    def counters(self):
+        out = (C.c_long * 3)()
+        self.o.lib.orc_sim_counters(self.h, out)
+        return {"fofc1_cells": out[0], "fofc2_cells": out[1], "retries": out[2]}
