@@ -1,0 +1,232 @@
+/* quokka_amd.h — C-ABI of the MI355X-native hydro / radiation hot path.
+ *
+ * Drop-in boundary for the reference's operator surface.  The reference has no FFI:
+ * its "operator API" is a set of static C++ template methods of HydroSystem<problem_t>,
+ * HyperbolicSystem<problem_t>, RadSystem<problem_t> taking AMReX MultiFabs, plus the level-0 branch
+ * of AMRSimulation::fillBoundaryConditions.  Every entry point below replaces exactly one of those
+ * methods (cited as `reference file:line`), takes plain pointers and sizes, never throws, returns
+ * 0 on success or a negative qk_status, allocates nothing the caller did not hand over (scratch is
+ * caller-provided), is asynchronous on the supplied HIP stream and keeps no global mutable state
+ * outside the opaque qk_ctx.
+ *
+ * Data contract (== amrex::MultiFab on device):
+ *   - one FP64 array per box, Fortran order, component index outermost, ghost cells included;
+ *   - a MultiFab argument is a DEVICE pointer to `nboxes` qk_array4 descriptors.  qk_array4 is
+ *     binary-compatible with amrex::Array4<double> (AMReX_Array4.H: p, jstride, kstride, nstride,
+ *     begin, end, ncomp), so `mf.arrays()` (a device MultiArray4) can be passed as is;
+ *   - launch geometry comes from a qk_level (the BoxArray of valid boxes), built once.
+ *
+ * All kernels are compiled with -ffp-contract=off and keep the reference's association order
+ * (reference CMakeLists.txt:31 DISABLE_FMAD=ON).
+ */
+#ifndef QUOKKA_AMD_H_
+#define QUOKKA_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct qk_ctx qk_ctx;
+typedef struct qk_level qk_level;
+typedef void *qk_stream; /* hipStream_t */
+
+typedef enum qk_status {
+	QK_OK = 0,
+	QK_ERR_INVALID = -1,	 /* bad argument (null pointer, unknown enum, mismatched sizes) */
+	QK_ERR_HIP = -2,	 /* a HIP runtime call failed; see qk_last_error() */
+	QK_ERR_UNSUPPORTED = -3, /* valid reference feature this build does not cover (e.g. mass scalars) */
+	QK_ERR_STATE = -4	 /* physical state error the reference treats as fatal (rho <= 0 in SyncDualEnergy) */
+} qk_status;
+
+/* == amrex::Array4<double> */
+typedef struct qk_array4 {
+	double *p;
+	int64_t jstride, kstride, nstride;
+	int begin[3]; /* inclusive lower corner (with ghosts) */
+	int end[3];   /* exclusive upper corner (hi + 1) */
+	int ncomp;
+} qk_array4;
+
+/* == amrex::Array4<int> (iMultiFab redoFlag) */
+typedef struct qk_iarray4 {
+	int *p;
+	int64_t jstride, kstride, nstride;
+	int begin[3];
+	int end[3];
+	int ncomp;
+} qk_iarray4;
+
+typedef struct qk_box {
+	int lo[3];
+	int hi[3]; /* inclusive */
+} qk_box;
+
+/* compile-time traits of the reference, as run-time data:
+ * quokka::EOS_Traits<P> (src/hydro/EOS.hpp:32-37), HydroSystem_Traits<P> (src/hydro/hydro_system.hpp:38-41),
+ * Physics_Traits<P> (src/physics_info.hpp:8-17), AMREX_SPACEDIM. */
+typedef struct qk_hydro_traits {
+	double gamma;
+	double cs_isothermal;
+	double mean_molecular_weight;
+	double boltzmann_constant;
+	int reconstruct_eint;
+	int nscalars;  /* passive scalars: must be 0 in this build (QK_ERR_UNSUPPORTED otherwise) */
+	int nmscalars; /* mass scalars: must be 0 */
+	int ndim;      /* 1 or 3 */
+} qk_hydro_traits;
+
+enum { QK_DIR_X1 = 0, QK_DIR_X2 = 1, QK_DIR_X3 = 2 };
+enum { QK_RIEMANN_HLLC = 0, QK_RIEMANN_LLF = 1 };
+enum { QK_LIMITER_MINMOD = 0, QK_LIMITER_MC = 1 };
+/* amrex::BCType values */
+enum { QK_BC_REFLECT_ODD = -1, QK_BC_INT_DIR = 0, QK_BC_REFLECT_EVEN = 1, QK_BC_FOEXTRAP = 2, QK_BC_EXT_DIR = 3 };
+
+/* ------------------------------------------------------------------ context / level */
+int qk_ctx_create(qk_ctx **ctx, int device);
+int qk_ctx_destroy(qk_ctx *ctx);
+const char *qk_last_error(qk_ctx *ctx);
+const char *qk_version(void);
+
+/* BoxArray of one level owned by this rank (valid, cell-centred boxes). */
+int qk_level_create(qk_ctx *ctx, qk_level **lev, int ndim, int nboxes, const qk_box *valid_boxes);
+int qk_level_destroy(qk_level *lev);
+
+/* Convenience for callers that hold host-side descriptors: copies `n` descriptors into device
+ * memory owned by the context; the returned pointer stays valid until qk_ctx_destroy. */
+int qk_upload_array4_table(qk_ctx *ctx, int n, const qk_array4 *host_table, qk_array4 **device_table);
+int qk_upload_iarray4_table(qk_ctx *ctx, int n, const qk_iarray4 *host_table, qk_iarray4 **device_table);
+
+/* ------------------------------------------------------------------ HyperbolicSystem<problem_t> */
+/* ReconstructStatesConstant<DIR>(q, leftState, rightState, nghost, nvars)   reference src/hyperbolic_system.hpp:129-147 */
+int qk_ReconstructStatesConstant(qk_level *lev, qk_stream s, int dir, const qk_array4 *q, qk_array4 *leftState, qk_array4 *rightState, int nghost,
+				 int nvars);
+/* ReconstructStatesPLM<DIR,limiter>(...)                                   reference src/hyperbolic_system.hpp:183-201 */
+int qk_ReconstructStatesPLM(qk_level *lev, qk_stream s, int dir, int limiter, const qk_array4 *q, qk_array4 *leftState, qk_array4 *rightState,
+			    int nghost, int nvars);
+/* ReconstructStatesPPM<DIR>(q, leftState, rightState, nghost, nvars, iReadFrom, iWriteFrom)   reference src/hyperbolic_system.hpp:295-316 */
+int qk_ReconstructStatesPPM(qk_level *lev, qk_stream s, int dir, const qk_array4 *q, qk_array4 *leftState, qk_array4 *rightState, int nghost,
+			    int nvars, int iReadFrom, int iWriteFrom);
+
+/* ------------------------------------------------------------------ HydroSystem<problem_t> */
+/* ConservedToPrimitive(cons, primVar, nghost)                               reference src/hydro/hydro_system.hpp:138-196 */
+int qk_hydro_ConservedToPrimitive(qk_level *lev, qk_stream s, const qk_hydro_traits *t, const qk_array4 *cons, qk_array4 *primVar, int nghost);
+/* ComputeFlatteningCoefficients<DIR>(primVar, x1Chi, nghost)                reference src/hydro/hydro_system.hpp:531-626 */
+int qk_hydro_ComputeFlatteningCoefficients(qk_level *lev, qk_stream s, const qk_hydro_traits *t, int dir, const qk_array4 *primVar, qk_array4 *x1Chi,
+					   int nghost);
+/* FlattenShocks<DIR>(q, x1Chi, x2Chi, x3Chi, x1LeftState, x1RightState, nghost, nvars)   reference src/hydro/hydro_system.hpp:628-694 */
+int qk_hydro_FlattenShocks(qk_level *lev, qk_stream s, const qk_hydro_traits *t, int dir, const qk_array4 *q, const qk_array4 *x1Chi,
+			   const qk_array4 *x2Chi, const qk_array4 *x3Chi, qk_array4 *x1LeftState, qk_array4 *x1RightState, int nghost, int nvars);
+/* ComputeFluxes<RIEMANN,DIR>(x1Flux, x1FaceVel, x1LeftState, x1RightState, primVar, K_visc)   reference src/hydro/hydro_system.hpp:852-1112
+ * (HLLC: src/hydro/HLLC.hpp:22-153, LLF: src/hydro/LLF.hpp:16-43) */
+int qk_hydro_ComputeFluxes(qk_level *lev, qk_stream s, const qk_hydro_traits *t, int riemann, int dir, qk_array4 *x1Flux, qk_array4 *x1FaceVel,
+			   const qk_array4 *x1LeftState, const qk_array4 *x1RightState, const qk_array4 *primVar, double K_visc);
+/* ComputeRhsFromFluxes(rhs, fluxArray, dx, nvars)                           reference src/hydro/hydro_system.hpp:448-473 */
+int qk_hydro_ComputeRhsFromFluxes(qk_level *lev, qk_stream s, const qk_hydro_traits *t, qk_array4 *rhs, const qk_array4 *const fluxArray[3],
+				  const double dx[3], int nvars);
+/* AddInternalEnergyPdV(rhs, consVar, dx, faceVelArray, redoFlag)            reference src/hydro/hydro_system.hpp:775-814 */
+int qk_hydro_AddInternalEnergyPdV(qk_level *lev, qk_stream s, const qk_hydro_traits *t, qk_array4 *rhs, const qk_array4 *consVar, const double dx[3],
+				  const qk_array4 *const faceVelArray[3], const qk_iarray4 *redoFlag);
+/* PredictStep(consVarOld, consVarNew, rhs, dt, nvars, redoFlag)             reference src/hydro/hydro_system.hpp:475-497
+ * `d_redo_count` (device int64, may be NULL) is incremented by the number of flagged cells: it replaces the
+ * separate redoFlag.sum(0) reduction of reference src/QuokkaSimulation.hpp:1146. */
+int qk_hydro_PredictStep(qk_level *lev, qk_stream s, const qk_hydro_traits *t, const qk_array4 *consVarOld, qk_array4 *consVarNew,
+			 const qk_array4 *rhs, double dt, int nvars, qk_iarray4 *redoFlag, int64_t *d_redo_count);
+/* EnforceLimits(densityFloor, tempFloor, state)                             reference src/hydro/hydro_system.hpp:696-773 */
+int qk_hydro_EnforceLimits(qk_level *lev, qk_stream s, const qk_hydro_traits *t, double densityFloor, double tempFloor, qk_array4 *state);
+/* SyncDualEnergy(consVar)                                                   reference src/hydro/hydro_system.hpp:816-850
+ * rho <= 0 is fatal in the reference (amrex::Abort); here the kernel raises `d_error_flag` (device int, may
+ * be NULL) and leaves the cell untouched; the host driver turns that into QK_ERR_STATE. */
+int qk_hydro_SyncDualEnergy(qk_level *lev, qk_stream s, const qk_hydro_traits *t, qk_array4 *consVar, int *d_error_flag);
+/* ComputeMaxSignalSpeed(cons, maxSignal, indexRange) per box                reference src/hydro/hydro_system.hpp:223-252 */
+int qk_hydro_ComputeMaxSignalSpeed(qk_level *lev, qk_stream s, const qk_hydro_traits *t, const qk_array4 *cons, qk_array4 *maxSignal);
+/* maxSignalSpeedLocal(cons) (ParReduce max over valid cells)                reference src/hydro/hydro_system.hpp:198-221
+ * and max_signal_speed_.norminf()                                          reference src/simulation.hpp:710
+ * which = 0: cs + sqrt(2 KE / rho) (maxSignalSpeedLocal) ; which = 1: cs + |v| (ComputeMaxSignalSpeed + norminf).
+ * Result: *d_result (device double) = max over all local valid cells; deterministic (max is exact). */
+int qk_hydro_maxSignalSpeedLocal(qk_level *lev, qk_stream s, const qk_hydro_traits *t, int which, const qk_array4 *cons, double *d_result);
+
+/* ------------------------------------------------------------------ QuokkaSimulation<problem_t> helpers on the path */
+/* replaceFluxes(fluxes, FOfluxes, redoFlag) for one direction               reference src/QuokkaSimulation.hpp:1324-1368
+ * `face_ncomp` = nvars for fluxes, 1 for face velocities. redoFlag must have >= 1 filled ghost cell. */
+int qk_replaceFluxes(qk_level *lev, qk_stream s, int dir, qk_array4 *flux, const qk_array4 *FOflux, const qk_iarray4 *redoFlag, int face_ncomp);
+/* MultiFab::Saxpy(dst, a, src, 0, 0, ncomp, 0) on the face boxes of `dir` (dir = -1: cell boxes)   reference src/QuokkaSimulation.hpp:1105-1108 */
+int qk_Saxpy(qk_level *lev, qk_stream s, int dir, qk_array4 *dst, double a, const qk_array4 *src, int ncomp);
+
+/* ------------------------------------------------------------------ fused fast path (MI355X design; same results) */
+typedef struct qk_hydro_stage_args {
+	/* inputs */
+	const qk_array4 *U_in;	 /* ghost-filled state the fluxes are evaluated on (stage 1: U^n, stage 2: U^1) */
+	const qk_array4 *U_old;	 /* U^n (update base and pressure for the PdV term)                       */
+	qk_array4 *U_out;	 /* stage 1: U^1 ; stage 2: U^{n+1}  (valid cells only)                      */
+	qk_array4 *halfFlux[3];	 /* stage 1: written with F1_d (face, nvar); stage 2: read                  */
+	qk_array4 *halfVel[3];	 /* stage 1: written with v1_d (face, 1);   stage 2: read                   */
+	qk_iarray4 *redoFlag;	 /* written: 0 / 1 per valid cell                                           */
+	int64_t *d_redo_count;	 /* device counter, incremented by the number of flagged cells              */
+	int *d_error_flag;	 /* device int, set to 1 if SyncDualEnergy meets rho <= 0                   */
+	/* scratch: caller-owned, at least qk_hydro_stage_scratch_bytes() */
+	void *scratch;
+	int64_t scratch_bytes;
+	/* parameters */
+	double dx[3];
+	double dt;
+	int stage;		 /* 1 or 2 */
+	int reconstruction_order; /* 1, 2, 3 */
+	double densityFloor, tempFloor;
+	int use_dual_energy;
+	double K_visc;		 /* artificial viscosity: the fused path requires 0 (QK_ERR_UNSUPPORTED otherwise) */
+} qk_hydro_stage_args;
+
+/* One RK stage of advanceHydroAtLevel (reference src/QuokkaSimulation.hpp:1099-1198 / 1202-1287) WITHOUT the
+ * FOFC branch: computeHydroFluxes + Saxpy + ComputeRhsFromFluxes + AddInternalEnergyPdV + PredictStep +
+ * EnforceLimits + SyncDualEnergy, fused per sweep direction.  If *d_redo_count > 0 afterwards the caller runs
+ * the reference-shaped operators above for the FOFC correction (results are bit-identical where no flux is
+ * replaced). */
+int64_t qk_hydro_stage_scratch_bytes(qk_level *lev, const qk_hydro_traits *t);
+int qk_hydro_stage_fused(qk_level *lev, qk_stream s, const qk_hydro_traits *t, const qk_hydro_stage_args *a);
+
+/* ------------------------------------------------------------------ level-0 ghost fill */
+/* AMRSimulation::fillBoundaryConditions, level-0 branch                     reference src/simulation.hpp:1751-1776
+ *   1. state.FillBoundary(geom.periodicity()) for neighbours on the same GPU (copy kernel)
+ *      + pack / unpack of the strips exchanged with other GPUs (RCCL p2p is done by the caller);
+ *   2. PhysBCFunct: amrex FilccCell (reflect_even/odd, foextrap) then the user functor
+ *      (closed set: constant Dirichlet state per face, as HydroShocktube's setCustomBoundaryConditions). */
+typedef struct qk_geometry {
+	qk_box domain;
+	int periodic[3];
+	int ndim;
+} qk_geometry;
+
+typedef struct qk_bcrec {
+	int lo[3];
+	int hi[3];
+} qk_bcrec; /* == amrex::BCRec per component */
+
+/* user functor model: cells beyond face (dim,side) get the constant state `values[ncomp]` (all comps) */
+typedef struct qk_dirichlet_face {
+	int enabled;
+	double values[16];
+} qk_dirichlet_face;
+
+typedef struct qk_ghost_plan qk_ghost_plan;
+/* Build the exchange plan for `nghost` ghost cells.  `all_boxes`/`owner_rank` describe the whole level
+ * (every rank builds the same plan); boxes with owner_rank == my_rank must be the level's boxes, in order. */
+int qk_ghost_plan_create(qk_level *lev, qk_ghost_plan **plan, const qk_geometry *geom, int nghost, int ncomp, int n_all_boxes,
+			 const qk_box *all_boxes, const int *owner_rank, int my_rank);
+int qk_ghost_plan_destroy(qk_ghost_plan *plan);
+/* remote traffic description: number of peers, and for peer k its rank and the number of doubles sent/received */
+int qk_ghost_plan_num_peers(qk_ghost_plan *plan);
+int qk_ghost_plan_peer(qk_ghost_plan *plan, int k, int *rank, int64_t *send_count, int64_t *recv_count);
+/* on-GPU copies (same-rank neighbours and periodic images) */
+int qk_FillBoundary_local(qk_ghost_plan *plan, qk_stream s, qk_array4 *state);
+/* pack the strips for peer k into `sendbuf` (device, send_count doubles) / unpack `recvbuf` */
+int qk_FillBoundary_pack(qk_ghost_plan *plan, qk_stream s, int k, const qk_array4 *state, double *sendbuf);
+int qk_FillBoundary_unpack(qk_ghost_plan *plan, qk_stream s, int k, qk_array4 *state, const double *recvbuf);
+/* physical boundaries (after FillBoundary): bcs[ncomp]; dirichlet[dim][side] may be NULL */
+int qk_FillPhysicalBoundary(qk_ghost_plan *plan, qk_stream s, qk_array4 *state, const qk_bcrec *bcs, const qk_dirichlet_face *dirichlet);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QUOKKA_AMD_H_ */

@@ -1,0 +1,144 @@
+"""ctypes binding of libquokka_amd.so (the C-ABI declared in include/quokka_amd.h).
+
+This module is plumbing only: it loads the HIP library and declares prototypes.  There is NO CPU
+fallback — if the library (or a GPU) is missing, importing the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libquokka_amd.so")
+
+QK_OK, QK_ERR_INVALID, QK_ERR_HIP, QK_ERR_UNSUPPORTED, QK_ERR_STATE = 0, -1, -2, -3, -4
+DIR_X1, DIR_X2, DIR_X3 = 0, 1, 2
+RIEMANN_HLLC, RIEMANN_LLF = 0, 1
+LIMITER_MINMOD, LIMITER_MC = 0, 1
+BC_REFLECT_ODD, BC_INT_DIR, BC_REFLECT_EVEN, BC_FOEXTRAP, BC_EXT_DIR = -1, 0, 1, 2, 3
+
+K_B = 1.380649e-16
+M_U = 1.6605390666e-24
+
+
+class Array4(C.Structure):
+    """== qk_array4 == amrex::Array4<double>"""
+    _fields_ = [("p", C.c_void_p), ("jstride", C.c_int64), ("kstride", C.c_int64), ("nstride", C.c_int64),
+                ("begin", C.c_int * 3), ("end", C.c_int * 3), ("ncomp", C.c_int)]
+
+
+class Box(C.Structure):
+    _fields_ = [("lo", C.c_int * 3), ("hi", C.c_int * 3)]
+
+
+class HydroTraits(C.Structure):
+    _fields_ = [("gamma", C.c_double), ("cs_isothermal", C.c_double), ("mean_molecular_weight", C.c_double),
+                ("boltzmann_constant", C.c_double), ("reconstruct_eint", C.c_int), ("nscalars", C.c_int),
+                ("nmscalars", C.c_int), ("ndim", C.c_int)]
+
+
+class Geometry(C.Structure):
+    _fields_ = [("domain", Box), ("periodic", C.c_int * 3), ("ndim", C.c_int)]
+
+
+class BCRec(C.Structure):
+    _fields_ = [("lo", C.c_int * 3), ("hi", C.c_int * 3)]
+
+
+class DirichletFace(C.Structure):
+    _fields_ = [("enabled", C.c_int), ("values", C.c_double * 16)]
+
+
+class StageArgs(C.Structure):
+    _fields_ = [("U_in", C.c_void_p), ("U_old", C.c_void_p), ("U_out", C.c_void_p),
+                ("halfFlux", C.c_void_p * 3), ("halfVel", C.c_void_p * 3),
+                ("redoFlag", C.c_void_p), ("d_redo_count", C.c_void_p), ("d_error_flag", C.c_void_p),
+                ("scratch", C.c_void_p), ("scratch_bytes", C.c_int64),
+                ("dx", C.c_double * 3), ("dt", C.c_double), ("stage", C.c_int), ("reconstruction_order", C.c_int),
+                ("densityFloor", C.c_double), ("tempFloor", C.c_double), ("use_dual_energy", C.c_int), ("K_visc", C.c_double)]
+
+
+def traits(gamma=1.4, reconstruct_eint=True, ndim=3, mean_molecular_weight=M_U, boltzmann_constant=K_B,
+           cs_isothermal=float("nan"), nscalars=0, nmscalars=0) -> HydroTraits:
+    return HydroTraits(gamma, cs_isothermal, mean_molecular_weight, boltzmann_constant, int(reconstruct_eint), nscalars, nmscalars, ndim)
+
+
+class QkError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libquokka_amd.so; raise loudly if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise QkError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(hipcc --offload-arch=gfx950). The hot path has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, ci, cd = C.c_void_p, C.c_int, C.c_double
+    P = C.POINTER
+    L.qk_version.restype = C.c_char_p
+    L.qk_last_error.restype = C.c_char_p
+    L.qk_last_error.argtypes = [vp]
+    L.qk_ctx_create.argtypes = [P(vp), ci]
+    L.qk_ctx_destroy.argtypes = [vp]
+    L.qk_level_create.argtypes = [vp, P(vp), ci, ci, P(Box)]
+    L.qk_level_destroy.argtypes = [vp]
+    L.qk_upload_array4_table.argtypes = [vp, ci, P(Array4), P(vp)]
+    L.qk_upload_iarray4_table.argtypes = [vp, ci, P(Array4), P(vp)]
+    T = P(HydroTraits)
+    L.qk_ReconstructStatesConstant.argtypes = [vp, vp, ci, vp, vp, vp, ci, ci]
+    L.qk_ReconstructStatesPLM.argtypes = [vp, vp, ci, ci, vp, vp, vp, ci, ci]
+    L.qk_ReconstructStatesPPM.argtypes = [vp, vp, ci, vp, vp, vp, ci, ci, ci, ci]
+    L.qk_hydro_ConservedToPrimitive.argtypes = [vp, vp, T, vp, vp, ci]
+    L.qk_hydro_ComputeFlatteningCoefficients.argtypes = [vp, vp, T, ci, vp, vp, ci]
+    L.qk_hydro_FlattenShocks.argtypes = [vp, vp, T, ci, vp, vp, vp, vp, vp, vp, ci, ci]
+    L.qk_hydro_ComputeFluxes.argtypes = [vp, vp, T, ci, ci, vp, vp, vp, vp, vp, cd]
+    L.qk_hydro_ComputeRhsFromFluxes.argtypes = [vp, vp, T, vp, P(vp), P(cd), ci]
+    L.qk_hydro_AddInternalEnergyPdV.argtypes = [vp, vp, T, vp, vp, P(cd), P(vp), vp]
+    L.qk_hydro_PredictStep.argtypes = [vp, vp, T, vp, vp, vp, cd, ci, vp, vp]
+    L.qk_hydro_EnforceLimits.argtypes = [vp, vp, T, cd, cd, vp]
+    L.qk_hydro_SyncDualEnergy.argtypes = [vp, vp, T, vp, vp]
+    L.qk_hydro_ComputeMaxSignalSpeed.argtypes = [vp, vp, T, vp, vp]
+    L.qk_hydro_maxSignalSpeedLocal.argtypes = [vp, vp, T, ci, vp, vp]
+    L.qk_replaceFluxes.argtypes = [vp, vp, ci, vp, vp, vp, ci]
+    L.qk_Saxpy.argtypes = [vp, vp, ci, vp, cd, vp, ci]
+    if hasattr(L, "qk_hydro_stage_fused"):
+        L.qk_hydro_stage_scratch_bytes.argtypes = [vp, T]
+        L.qk_hydro_stage_scratch_bytes.restype = C.c_int64
+        L.qk_hydro_stage_fused.argtypes = [vp, vp, T, P(StageArgs)]
+    if hasattr(L, "qk_ghost_plan_create"):
+        L.qk_ghost_plan_create.argtypes = [vp, P(vp), P(Geometry), ci, ci, ci, P(Box), P(ci), ci]
+        L.qk_ghost_plan_destroy.argtypes = [vp]
+        L.qk_ghost_plan_num_peers.argtypes = [vp]
+        L.qk_ghost_plan_peer.argtypes = [vp, ci, P(ci), P(C.c_int64), P(C.c_int64)]
+        L.qk_FillBoundary_local.argtypes = [vp, vp, vp]
+        L.qk_FillBoundary_pack.argtypes = [vp, vp, ci, vp, vp]
+        L.qk_FillBoundary_unpack.argtypes = [vp, vp, ci, vp, vp]
+        L.qk_FillPhysicalBoundary.argtypes = [vp, vp, vp, P(BCRec), P(DirichletFace)]
+    _lib = L
+    return L
+
+
+# every symbol include/quokka_amd.h declares (checked by the CPU test-suite without a GPU)
+DECLARED_SYMBOLS = [
+    "qk_ctx_create", "qk_ctx_destroy", "qk_last_error", "qk_version", "qk_level_create", "qk_level_destroy",
+    "qk_upload_array4_table", "qk_upload_iarray4_table",
+    "qk_ReconstructStatesConstant", "qk_ReconstructStatesPLM", "qk_ReconstructStatesPPM",
+    "qk_hydro_ConservedToPrimitive", "qk_hydro_ComputeFlatteningCoefficients", "qk_hydro_FlattenShocks",
+    "qk_hydro_ComputeFluxes", "qk_hydro_ComputeRhsFromFluxes", "qk_hydro_AddInternalEnergyPdV", "qk_hydro_PredictStep",
+    "qk_hydro_EnforceLimits", "qk_hydro_SyncDualEnergy", "qk_hydro_ComputeMaxSignalSpeed", "qk_hydro_maxSignalSpeedLocal",
+    "qk_replaceFluxes", "qk_Saxpy", "qk_hydro_stage_scratch_bytes", "qk_hydro_stage_fused",
+    "qk_ghost_plan_create", "qk_ghost_plan_destroy", "qk_ghost_plan_num_peers", "qk_ghost_plan_peer",
+    "qk_FillBoundary_local", "qk_FillBoundary_pack", "qk_FillBoundary_unpack", "qk_FillPhysicalBoundary",
+]
+
+
+def check(ctx, rc: int, what: str = "") -> None:
+    if rc != QK_OK:
+        msg = lib().qk_last_error(ctx).decode() if ctx else ""
+        raise QkError(f"{what} failed with status {rc}: {msg}")

@@ -1,0 +1,471 @@
+// qk_device.hpp — per-cell / per-face device arithmetic of the hydro hot path, written for gfx950.
+//
+// Every function is the device-side counterpart of one reference routine (cited per function) and
+// keeps the reference's floating-point association order; the translation unit is compiled with
+// -ffp-contract=off.  Differences from the reference that are value-preserving by construction:
+//   * nvar = 6, no passive / mass scalars: quokka::valarray<6> ops are written out per component
+//     and the multiplications by the literal zeros of D_L/D_R/D_star (HLLC.hpp:116-118) are dropped
+//     (x + 0.0 == x up to the sign of a zero);
+//   * HLLC selects the Riemann-fan side FIRST and evaluates only that side's F / F* (the reference
+//     evaluates all four and selects, HLLC.hpp:132-150) — same values, about half the divisions;
+//   * std::pow(cs, 2) (hydro_system.hpp:602) is cs*cs.
+#ifndef QK_DEVICE_HPP_
+#define QK_DEVICE_HPP_
+
+#include <hip/hip_runtime.h>
+
+#include "quokka_amd.h"
+
+#define QK_DEV __device__ __forceinline__
+
+namespace qk
+{
+
+constexpr int NVAR = 6;
+// HydroSystem::consVarIndex / primVarIndex (hydro_system.hpp:54-72)
+enum { RHO = 0, MX = 1, MY = 2, MZ = 3, ENE = 4, EINT = 5 };
+enum { PRHO = 0, PVX = 1, PVY = 2, PVZ = 3, PPRES = 4, PEINT = 5 };
+
+// amrex::Array4 accessor over the binary-compatible descriptor
+template <typename T, typename D> struct A4 {
+	T *p;
+	int64_t js, ks, ns;
+	int bx, by, bz;
+	QK_DEV explicit A4(D const &d) : p(d.p), js(d.jstride), ks(d.kstride), ns(d.nstride), bx(d.begin[0]), by(d.begin[1]), bz(d.begin[2]) {}
+	QK_DEV auto idx(int i, int j, int k) const -> int64_t { return (i - bx) + js * (j - by) + ks * (k - bz); }
+	QK_DEV auto operator()(int i, int j, int k, int n = 0) const -> T & { return p[idx(i, j, k) + ns * n]; }
+};
+using RA4 = A4<const double, qk_array4>;
+using WA4 = A4<double, qk_array4>;
+using IA4 = A4<int, qk_iarray4>;
+using CIA4 = A4<const int, qk_iarray4>;
+
+// loop index -> view index (ArrayView_3d.hpp:22-28) expressed as a unit offset: a view step of
+// (di, dj, dk) is the array step (i + di*e[dir]) + ..., i.e. axis `dir` is the normal, the next two
+// (cyclically) are view-j and view-k.
+template <int DIR> struct Axes {
+	static constexpr int n = DIR;		 // array axis of view-i (normal)
+	static constexpr int v = (DIR + 1) % 3;	 // array axis of view-j
+	static constexpr int w = (DIR + 2) % 3;	 // array axis of view-k
+};
+
+QK_DEV auto unit(int axis, int comp) -> int { return axis == comp ? 1 : 0; }
+
+// quokka::EOS<problem_t>, gamma-law, direct association (oracle/eos.hpp variant 0)
+struct Eos {
+	double gamma, gm1, cs_iso, mu, kB_ratio_num, kB_user; // mu = mean_molecular_weight / m_u
+	bool isothermal;
+	static constexpr double k_B = 1.380649e-16;
+	static constexpr double m_u = 1.6605390666e-24;
+
+	__host__ __device__ explicit Eos(qk_hydro_traits const &t)
+	    : gamma(t.gamma), gm1(t.gamma - 1.0), cs_iso(t.cs_isothermal), mu(t.mean_molecular_weight / m_u), kB_ratio_num(k_B),
+	      kB_user(t.boltzmann_constant), isothermal(t.gamma == 1.0)
+	{
+	}
+	// EOS.hpp:304-348 : e = Eint/rho (0 if rho == 0) ; p = (gamma-1) rho e
+	QK_DEV auto pressure(double rho, double Eint) const -> double
+	{
+		const double e = (rho == 0.0) ? 0.0 : Eint / rho;
+		return gm1 * rho * e;
+	}
+	// EOS.hpp:350-383 : cs = sqrt(gamma p / rho)
+	QK_DEV auto soundSpeed(double rho, double P) const -> double { return sqrt(gamma * P / rho); }
+	// EOS.hpp:161-200 : Eint = (p / ((gamma-1) rho)) * rho
+	QK_DEV auto eintFromPres(double rho, double P) const -> double { return (P / (gm1 * rho)) * rho; }
+	// EOS.hpp:74-114
+	QK_DEV auto tgasFromEint(double rho, double Eint) const -> double
+	{
+		const double e = Eint / rho;
+		const double T = e * mu * m_u * gm1 / k_B;
+		return T * k_B / kB_user;
+	}
+	// EOS.hpp:116-159
+	QK_DEV auto eintFromTgas(double rho, double T) const -> double
+	{
+		const double p = rho * T * k_B / (mu * m_u);
+		const double e = p / (gm1 * rho);
+		return e * rho * kB_user / k_B;
+	}
+};
+
+// hydro_system.hpp:349-372 ComputePressure(cons, i,j,k) from the six conserved values
+QK_DEV auto consPressure(Eos const &eos, double rho, double px, double py, double pz, double E) -> double
+{
+	const double vx = px / rho;
+	const double vy = py / rho;
+	const double vz = pz / rho;
+	const double kinetic_energy = 0.5 * rho * (vx * vx + vy * vy + vz * vz);
+	const double thermal_energy = E - kinetic_energy;
+	if (eos.isothermal) {
+		return rho * eos.cs_iso * eos.cs_iso;
+	}
+	return eos.pressure(rho, thermal_energy);
+}
+
+QK_DEV auto sgn(double v) -> int { return static_cast<int>(0.0 < v) - static_cast<int>(v < 0.0); }
+QK_DEV auto clampd(double v, double lo, double hi) -> double { return (v < lo) ? lo : (hi < v) ? hi : v; }
+// std::min / std::max semantics (return first argument on ties / NaN in second)
+QK_DEV auto smin(double a, double b) -> double { return (b < a) ? b : a; }
+QK_DEV auto smax(double a, double b) -> double { return (a < b) ? b : a; }
+
+// hyperbolic_system.hpp:58-66
+QK_DEV auto MC(double a, double b) -> double { return 0.5 * (sgn(a) + sgn(b)) * smin(0.5 * fabs(a + b), smin(2.0 * fabs(a), 2.0 * fabs(b))); }
+QK_DEV auto minmod(double a, double b) -> double { return 0.5 * (sgn(a) + sgn(b)) * smin(fabs(a), fabs(b)); }
+
+// hyperbolic_system.hpp:337-433 : PPM edges of cell i from q(i-2..i+2).
+//   am -> rightState(i) (left edge of the cell), ap -> leftState(i+1) (right edge)
+QK_DEV void ppmEdges(double qm2, double qm1, double q0, double qp1, double qp2, double &am, double &ap)
+{
+	// std::minmax({q0, qm1, qp1})
+	double lo = q0, hi = q0;
+	if (qm1 < lo) {
+		lo = qm1;
+	}
+	if (!(qm1 < hi)) {
+		hi = qm1;
+	}
+	if (qp1 < lo) {
+		lo = qp1;
+	}
+	if (!(qp1 < hi)) {
+		hi = qp1;
+	}
+	const double coef_1 = (7. / 12.);
+	const double coef_2 = (-1. / 12.);
+	const double a_minus = (coef_1 * q0 + coef_2 * qp1) + (coef_1 * qm1 + coef_2 * qm2);
+	const double a_plus = (coef_1 * qp1 + coef_2 * qp2) + (coef_1 * q0 + coef_2 * qm1);
+	double new_a_minus = clampd(a_minus, lo, hi);
+	double new_a_plus = clampd(a_plus, lo, hi);
+	const double a = q0;
+	const double dq_minus = (a - new_a_minus);
+	const double dq_plus = (new_a_plus - a);
+	const double qa = dq_plus * dq_minus;
+	if (qa <= 0.0) {
+		const double dq0 = MC(qp1 - q0, q0 - qm1);
+		new_a_minus = a - 0.5 * dq0;
+		new_a_plus = a + 0.5 * dq0;
+	} else {
+		if (fabs(dq_minus) >= 2.0 * fabs(dq_plus)) {
+			new_a_minus = a - 2.0 * dq_plus;
+		}
+		if (fabs(dq_plus) >= 2.0 * fabs(dq_minus)) {
+			new_a_plus = a + 2.0 * dq_minus;
+		}
+	}
+	am = new_a_minus;
+	ap = new_a_plus;
+}
+
+// hyperbolic_system.hpp:218-247 : PLM. For cell-centred bookkeeping: the right edge of cell i is
+// leftState(i+1) = q(i) + 0.25*lim(q(i+1)-q(i), q(i)-q(i-1)); the left edge is
+// rightState(i) = q(i) - 0.25*lim(q(i+1)-q(i), q(i)-q(i-1)).
+template <int LIMITER> QK_DEV void plmEdges(double qm1, double q0, double qp1, double &am, double &ap)
+{
+	const double slope = (LIMITER == QK_LIMITER_MINMOD) ? minmod(qp1 - q0, q0 - qm1) : MC(qp1 - q0, q0 - qm1);
+	ap = q0 + 0.25 * slope;
+	am = q0 - 0.25 * slope;
+}
+
+// hydro_system.hpp:588-622 : flattening coefficient from P(i-2..i+2), rho(i), vn(i-1), vn(i+1)
+QK_DEV auto flatteningChi(Eos const &eos, double Pm2, double Pm1, double P, double Pp1, double Pp2, double rho, double vm1, double vp1) -> double
+{
+	constexpr double beta_max = 0.85;
+	constexpr double beta_min = 0.75;
+	constexpr double Zmax = 0.75;
+	constexpr double Zmin = 0.25;
+	const double beta_denom = fabs(Pp2 - Pm2);
+	const double beta = (beta_denom != 0) ? (fabs(Pp1 - Pm1) / beta_denom) : 0;
+	const double chi_min = smax(0., smin(1., (beta_max - beta) / (beta_max - beta_min)));
+	double K_S;
+	if (eos.isothermal) {
+		K_S = rho * eos.cs_iso * eos.cs_iso;
+	} else {
+		const double cs = eos.soundSpeed(rho, P);
+		K_S = (cs * cs) * rho;
+	}
+	const double Z = fabs(Pp1 - Pm1) / K_S;
+	double chi = 1.0;
+	if (vp1 < vm1) {
+		chi = smax(chi_min, smin(1., (Zmax - Z) / (Zmax - Zmin)));
+	}
+	return chi;
+}
+
+// HydroState.hpp:10-23 (no scalars, no B field)
+struct HState {
+	double rho, u, v, w, P, cs, E, Eint;
+};
+
+// hydro_system.hpp:881-1003 : build the canonical (normal-first) Riemann state from one reconstructed
+// primitive state q[6] = (rho, vx, vy, vz, P|e, Eint|e_aux).  DIR fixes (u,v,w) <- (vN, vV, vW) with the
+// 3-D mapping X1:(x,y,z) X2:(y,z,x) X3:(z,x,y)  (:954-976).
+template <int DIR> QK_DEV auto makeState(Eos const &eos, bool reconstruct_eint, const double q[NVAR]) -> HState
+{
+	HState s;
+	const double rho = q[PRHO];
+	const double vx = q[PVX], vy = q[PVY], vz = q[PVZ];
+	const double ke = 0.5 * rho * (vx * vx + vy * vy + vz * vz);
+	double P, Eint, cs, E;
+	if (eos.isothermal) {
+		P = rho * (eos.cs_iso * eos.cs_iso);
+		cs = eos.cs_iso;
+		// E_L, Eint_L stay NaN in the reference (:898-905); their fluxes are zeroed (:1084-1087)
+		E = __builtin_nan("");
+		Eint = __builtin_nan("");
+	} else {
+		if (reconstruct_eint) {
+			P = eos.pressure(rho, q[PPRES] * rho);
+			Eint = rho * q[PEINT];
+		} else {
+			P = q[PPRES];
+			Eint = q[PEINT];
+		}
+		cs = eos.soundSpeed(rho, P);
+		E = eos.eintFromPres(rho, P) + ke;
+	}
+	s.rho = rho;
+	s.u = q[PVX + Axes<DIR>::n];
+	s.v = q[PVX + Axes<DIR>::v];
+	s.w = q[PVX + Axes<DIR>::w];
+	s.P = P;
+	s.cs = cs;
+	s.E = E;
+	s.Eint = Eint;
+	return s;
+}
+
+// HLLC.hpp:22-153. F[6] in canonical order (rho, mom_n, mom_v, mom_w, E, Eint).
+QK_DEV void hllc(Eos const &eos, HState const &sL, HState const &sR, double du, double dw, double F[NVAR])
+{
+	const double wl = sqrt(sL.rho);
+	const double wr = sqrt(sR.rho);
+	const double norm = 1. / (wl + wr);
+	const double u_tilde = (wl * sL.u + wr * sR.u) * norm;
+	const double dU = sL.u - sR.u;
+	double S_L, S_R;
+	if (!eos.isothermal) {
+		const double v_tilde = (wl * sL.v + wr * sR.v) * norm;
+		const double w_tilde = (wl * sL.w + wr * sR.w) * norm;
+		const double vsq_tilde = u_tilde * u_tilde + v_tilde * v_tilde + w_tilde * w_tilde;
+		const double H_L = (sL.E + sL.P) / sL.rho;
+		const double H_R = (sR.E + sR.P) / sR.rho;
+		const double H_tilde = (wl * H_L + wr * H_R) * norm;
+		// ComputeOtherDerivatives (EOS.hpp:246-302) with the direct gamma-law forms:
+		//   dedr = 0, dedp = 1/dpde = 1/((gamma-1) rho), drdp = 1/((p/rho) * k_B / k_B_user), G = (gamma+1)/2
+		const double dedp_L = 1.0 / (eos.gm1 * sL.rho);
+		const double dedp_R = 1.0 / (eos.gm1 * sR.rho);
+		const double drdp_L = 1.0 / ((sL.P / sL.rho) * Eos::k_B / eos.kB_user);
+		const double drdp_R = 1.0 / ((sR.P / sR.rho) * Eos::k_B / eos.kB_user);
+		const double G = 0.5 * (1.0 + eos.gamma);
+		const double eL = sL.Eint / sL.rho;
+		const double eR = sR.Eint / sR.rho;
+		const double C_tilde_rho = 0.5 * (eL + eR); // + rho*dedr with dedr = 0
+		const double C_tilde_P = 0.5 * (eL * drdp_L + eR * drdp_R + sL.rho * dedp_L + sR.rho * dedp_R);
+		const double cs_exp = H_tilde - 0.5 * vsq_tilde - C_tilde_rho;
+		double cs_tilde;
+		if (cs_exp <= 0) {
+			cs_tilde = 0.5 * (sL.cs + sR.cs);
+		} else {
+			cs_tilde = sqrt(cs_exp / C_tilde_P);
+		}
+		const double s_NL = 0.5 * G * smax(dU, 0.);
+		const double s_NR = 0.5 * G * smax(dU, 0.);
+		S_L = smin(sL.u - (sL.cs + s_NL), u_tilde - (cs_tilde + s_NL));
+		S_R = smax(sR.u + (sR.cs + s_NR), u_tilde + (cs_tilde + s_NR));
+	} else {
+		const double cs_tilde = 0.5 * (sL.cs + sR.cs);
+		const double G_L = 0.5 * (1.0 + 1.);
+		const double s_NL = 0.5 * G_L * smax(dU, 0.);
+		const double s_NR = s_NL;
+		S_L = smin(sL.u - (sL.cs + s_NL), u_tilde - (cs_tilde + s_NL));
+		S_R = smax(sR.u + (sR.cs + s_NR), u_tilde + (cs_tilde + s_NR));
+	}
+
+	// :91-93 carbuncle switch
+	const double cs_max = smax(sL.cs, sR.cs);
+	const double tp = smin(1., (cs_max - smin(du, 0.)) / (cs_max - smin(dw, 0.)));
+	const double theta = tp * tp * tp * tp;
+
+	// :97-98
+	const double S_star =
+	    (theta * (sR.P - sL.P) + (sL.rho * sL.u * (S_L - sL.u) - sR.rho * sR.u * (S_R - sR.u))) / (sL.rho * (S_L - sL.u) - sR.rho * (S_R - sR.u));
+
+	// :102-107
+	const double vmag_L = sqrt(sL.u * sL.u + sL.v * sL.v + sL.w * sL.w);
+	const double vmag_R = sqrt(sR.u * sR.u + sR.v * sR.v + sR.w * sR.w);
+	const double chi = smin(1., smax(vmag_L, vmag_R) / cs_max);
+	const double phi = chi * (2. - chi);
+	const double P_LR = 0.5 * (sL.P + sR.P) + 0.5 * phi * (sL.rho * (S_L - sL.u) * (S_star - sL.u) + sR.rho * (S_R - sR.u) * (S_star - sR.u));
+
+	// :142-150 fan selection, done before evaluating the fluxes
+	const bool caseA = (S_L > 0.0);
+	const bool caseB = !caseA && ((S_star > 0.0) && (S_L <= 0.0));
+	const bool caseC = !caseA && !caseB && ((S_star <= 0.0) && (S_R >= 0.0));
+	const bool left = caseA || caseB;
+	const bool star = caseB || caseC;
+
+	const double rho = left ? sL.rho : sR.rho;
+	const double u = left ? sL.u : sR.u;
+	const double v = left ? sL.v : sR.v;
+	const double w = left ? sL.w : sR.w;
+	const double P = left ? sL.P : sR.P;
+	const double E = left ? sL.E : sR.E;
+	const double Eint = left ? sL.Eint : sR.Eint;
+	const double S_K = left ? S_L : S_R;
+
+	// U_K (:120-121), F_K = u U_K + P D_K (:132-133)
+	const double U0 = rho, U1 = rho * u, U2 = rho * v, U3 = rho * w, U4 = E, U5 = Eint;
+	const double F0 = u * U0;
+	const double F1 = u * U1 + P;
+	const double F2 = u * U2;
+	const double F3 = u * U3;
+	const double F4 = u * U4 + P * u;
+	const double F5 = u * U5;
+
+	// F*_K = (S* (S_K U_K - F_K) + (S_K P_LR) D*) / (S_K - S*)   (:135-136)
+	const double SKP = S_K * P_LR;
+	const double den = S_K - S_star;
+	const double G0 = (S_star * (S_K * U0 - F0)) / den;
+	const double G1 = (S_star * (S_K * U1 - F1) + SKP) / den;
+	const double G2 = (S_star * (S_K * U2 - F2)) / den;
+	const double G3 = (S_star * (S_K * U3 - F3)) / den;
+	const double G4 = (S_star * (S_K * U4 - F4) + SKP * S_star) / den;
+	const double G5 = (S_star * (S_K * U5 - F5)) / den;
+
+	F[0] = star ? G0 : F0;
+	F[1] = star ? G1 : F1;
+	F[2] = star ? G2 : F2;
+	F[3] = star ? G3 : F3;
+	F[4] = star ? G4 : F4;
+	F[5] = star ? G5 : F5;
+}
+
+// LLF.hpp:16-43
+QK_DEV void llf(HState const &sL, HState const &sR, double F[NVAR])
+{
+	const double Sp = smax(fabs(sL.u) + sL.cs, fabs(sR.u) + sR.cs);
+	const double UL[NVAR] = {sL.rho, sL.rho * sL.u, sL.rho * sL.v, sL.rho * sL.w, sL.E, sL.Eint};
+	const double UR[NVAR] = {sR.rho, sR.rho * sR.u, sR.rho * sR.v, sR.rho * sR.w, sR.E, sR.Eint};
+	double FL[NVAR], FR[NVAR];
+	FL[0] = sL.u * UL[0];
+	FL[1] = sL.u * UL[1] + sL.P;
+	FL[2] = sL.u * UL[2];
+	FL[3] = sL.u * UL[3];
+	FL[4] = sL.u * UL[4] + sL.P * sL.u;
+	FL[5] = sL.u * UL[5];
+	FR[0] = sR.u * UR[0];
+	FR[1] = sR.u * UR[1] + sR.P;
+	FR[2] = sR.u * UR[2];
+	FR[3] = sR.u * UR[3];
+	FR[4] = sR.u * UR[4] + sR.P * sR.u;
+	FR[5] = sR.u * UR[5];
+	const double hS = 0.5 * Sp;
+#pragma unroll
+	for (int n = 0; n < NVAR; ++n) {
+		F[n] = 0.5 * (FL[n] + FR[n]) - hS * (UR[n] - UL[n]);
+	}
+}
+
+// hydro_system.hpp:1037-1110 : Riemann solve + artificial viscosity + momentum un-permutation + face velocity.
+// qL/qR: reconstructed primitive states at the face; du, dvl.. the velocity differences of :1019-1034.
+// Fout[6] is in ARRAY component order (rho, px, py, pz, E, Eint).
+template <int DIR, int RIEMANN>
+QK_DEV void faceFlux(Eos const &eos, bool reconstruct_eint, int ndim, const double qL[NVAR], const double qR[NVAR], double du, double dvl, double dvr,
+		     double dwl, double dwr, double K_visc, double Fout[NVAR], double &v_norm)
+{
+	const HState sL = makeState<DIR>(eos, reconstruct_eint, qL);
+	const HState sR = makeState<DIR>(eos, reconstruct_eint, qR);
+	double dw = 0.;
+	if (ndim >= 2) {
+		dw = smin(dvl, dvr);
+	}
+	if (ndim == 3) {
+		dw = smin(smin(dwl, dwr), dw);
+	}
+	double Fc[NVAR];
+	if (RIEMANN == QK_RIEMANN_HLLC) {
+		hllc(eos, sL, sR, du, dw, Fc);
+	} else {
+		llf(sL, sR, Fc);
+	}
+	// :1054-1076 artificial viscosity (momentum components are overwritten below, :1079-1081)
+	double div_v = du;
+	if (ndim >= 2) {
+		div_v = div_v + 0.5 * (dvl + dvr);
+	}
+	if (ndim == 3) {
+		div_v = div_v + 0.5 * (dwl + dwr);
+	}
+	const double viscosity = K_visc * smax(-div_v, 0.);
+	double F[NVAR];
+	F[RHO] = Fc[0] + viscosity * (sL.rho - sR.rho);
+	F[ENE] = Fc[4] + viscosity * (sL.E - sR.E);
+	F[EINT] = Fc[5] + viscosity * (sL.Eint - sR.Eint);
+	F[MX + Axes<DIR>::n] = Fc[1];
+	F[MX + Axes<DIR>::v] = Fc[2];
+	F[MX + Axes<DIR>::w] = Fc[3];
+	if (eos.isothermal) {
+		F[ENE] = 0;
+		F[EINT] = 0;
+	}
+	// :1090
+	v_norm = (F[RHO] >= 0.) ? (F[RHO] / sR.rho) : (F[RHO] / sL.rho);
+#pragma unroll
+	for (int n = 0; n < NVAR; ++n) {
+		Fout[n] = F[n];
+	}
+}
+
+// hydro_system.hpp:702-771 EnforceLimits for one cell (no scalars). U in array order.
+QK_DEV void enforceLimits(Eos const &eos, double densityFloor, double tempFloor, double U[NVAR])
+{
+	double rho_new = U[RHO];
+	if (U[RHO] < densityFloor) {
+		rho_new = densityFloor;
+		U[RHO] = rho_new;
+	}
+	if ((rho_new > 2.2250738585072014e-308) && !eos.isothermal) {
+		const double vx1 = U[MX] / rho_new;
+		const double vx2 = U[MY] / rho_new;
+		const double vx3 = U[MZ] / rho_new;
+		const double Ekin = 0.5 * rho_new * (vx1 * vx1 + vx2 * vx2 + vx3 * vx3);
+		const double Etot = U[ENE];
+		const double primTemp = eos.tgasFromEint(rho_new, (Etot - Ekin));
+		if (primTemp < tempFloor) {
+			const double prim_eint = eos.eintFromTgas(rho_new, tempFloor);
+			U[ENE] = Ekin + prim_eint;
+		}
+		const double auxEint = U[EINT];
+		const double auxTemp = eos.tgasFromEint(rho_new, auxEint);
+		if (auxTemp < tempFloor) {
+			U[EINT] = eos.eintFromTgas(rho_new, tempFloor);
+		}
+	}
+}
+
+// hydro_system.hpp:825-849 SyncDualEnergy for one cell; returns false if rho <= 0 (fatal in the reference)
+QK_DEV auto syncDualEnergy(double U[NVAR]) -> bool
+{
+	const double eta = 1.0e-3;
+	const double rho = U[RHO];
+	if (rho <= 0.) {
+		return false;
+	}
+	const double px = U[MX], py = U[MY], pz = U[MZ];
+	const double Etot = U[ENE];
+	const double Eint_aux = U[EINT];
+	const double Ekin = (px * px + py * py + pz * pz) / (2.0 * rho);
+	const double Eint_cons = Etot - Ekin;
+	if (Eint_cons > eta * Etot) {
+		U[EINT] = Eint_cons;
+	} else {
+		U[EINT] = Eint_aux;
+		U[ENE] = Eint_aux + Ekin;
+	}
+	return true;
+}
+
+} // namespace qk
+
+#endif // QK_DEVICE_HPP_

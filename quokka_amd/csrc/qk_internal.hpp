@@ -1,0 +1,98 @@
+// qk_internal.hpp — host-side internals shared by the translation units of libquokka_amd.so.
+#ifndef QK_INTERNAL_HPP_
+#define QK_INTERNAL_HPP_
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "quokka_amd.h"
+
+struct qk_ctx {
+	int device = 0;
+	std::string last_error;
+	std::vector<void *> owned; // device allocations released in qk_ctx_destroy
+	std::mutex mtx;
+};
+
+struct qk_level {
+	qk_ctx *ctx = nullptr;
+	int ndim = 3;
+	int nboxes = 0;
+	std::vector<qk_box> boxes; // host copy
+	qk_box *d_boxes = nullptr; // device copy
+	int maxlen[3] = {0, 0, 0}; // max valid-box length per dim
+};
+
+namespace qk
+{
+
+inline auto setError(qk_ctx *ctx, int code, const char *what, const char *detail = "") -> int
+{
+	if (ctx != nullptr) {
+		std::lock_guard<std::mutex> lock(ctx->mtx);
+		ctx->last_error = std::string(what) + (detail[0] != 0 ? ": " : "") + detail;
+	}
+	return code;
+}
+
+#define QK_HIP_CHECK(ctx, expr)                                                                                                                      \
+	do {                                                                                                                                         \
+		hipError_t qk_e_ = (expr);                                                                                                           \
+		if (qk_e_ != hipSuccess) {                                                                                                           \
+			return qk::setError((ctx), QK_ERR_HIP, #expr, hipGetErrorString(qk_e_));                                                     \
+		}                                                                                                                                    \
+	} while (0)
+
+#define QK_REQUIRE(ctx, cond, msg)                                                                                                                   \
+	do {                                                                                                                                         \
+		if (!(cond)) {                                                                                                                       \
+			return qk::setError((ctx), QK_ERR_INVALID, msg);                                                                             \
+		}                                                                                                                                    \
+	} while (0)
+
+inline auto checkTraits(qk_ctx *ctx, const qk_hydro_traits *t) -> int
+{
+	if (t == nullptr) {
+		return setError(ctx, QK_ERR_INVALID, "traits is NULL");
+	}
+	if (t->nscalars != 0 || t->nmscalars != 0) {
+		return setError(ctx, QK_ERR_UNSUPPORTED, "passive/mass scalars are not built (nvar = 6 only)");
+	}
+	if (t->ndim != 1 && t->ndim != 3) {
+		return setError(ctx, QK_ERR_UNSUPPORTED, "ndim must be 1 or 3");
+	}
+	return QK_OK;
+}
+
+// launch geometry for "one thread per cell of box b grown by ng (+1 face in direction facedir)"
+struct CellLaunch {
+	dim3 grid;
+	dim3 block;
+};
+
+inline auto cellLaunch(const qk_level *lev, int ng, int facedir) -> CellLaunch
+{
+	int64_t n = 1;
+	for (int d = 0; d < 3; ++d) {
+		int len = lev->maxlen[d];
+		if (d < lev->ndim) {
+			len += 2 * ng;
+		}
+		if (d == facedir) {
+			len += 1;
+		}
+		n *= len;
+	}
+	CellLaunch L;
+	L.block = dim3(256, 1, 1);
+	L.grid = dim3(static_cast<unsigned>((n + 255) / 256), static_cast<unsigned>(lev->nboxes), 1);
+	return L;
+}
+
+} // namespace qk
+
+#endif // QK_INTERNAL_HPP_

@@ -1,0 +1,131 @@
+"""Device containers mirroring the AMReX objects on the hot path (BoxArray -> Level, MultiFab,
+iMultiFab).  PyTorch is used only as the device allocator / stream provider; the data layout is
+the amrex::MultiFab one (per box: Fortran order, component outermost, ghost cells included) and
+the descriptor table handed to the C-ABI is an array of amrex::Array4-compatible structs.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import capi
+
+_A4_DTYPE = np.dtype([("p", np.uint64), ("jstride", np.int64), ("kstride", np.int64), ("nstride", np.int64),
+                      ("begin", np.int32, 3), ("end", np.int32, 3), ("ncomp", np.int32)], align=True)
+assert _A4_DTYPE.itemsize == C.sizeof(capi.Array4) == 64
+
+
+class Context:
+    """qk_ctx: one per process / GPU."""
+
+    def __init__(self, device: int = 0):
+        if not torch.cuda.is_available():
+            raise capi.QkError("no GPU visible: the quokka_amd hot path has no CPU fallback")
+        self.L = capi.lib()
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        h = C.c_void_p()
+        rc = self.L.qk_ctx_create(C.byref(h), device)
+        if rc != capi.QK_OK:
+            raise capi.QkError(f"qk_ctx_create failed ({rc})")
+        self.h = h
+
+    def stream(self) -> C.c_void_p:
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def check(self, rc: int, what: str = ""):
+        capi.check(self.h, rc, what)
+
+    def __del__(self):
+        try:
+            self.L.qk_ctx_destroy(self.h)
+        except Exception:
+            pass
+
+
+def _box_struct(lo, hi) -> capi.Box:
+    return capi.Box((C.c_int * 3)(*[int(x) for x in lo]), (C.c_int * 3)(*[int(x) for x in hi]))
+
+
+class Level:
+    """qk_level: the valid (cell-centred) boxes of one AMR level owned by this rank."""
+
+    def __init__(self, ctx: Context, ndim: int, boxes: Sequence[Sequence[Sequence[int]]]):
+        self.ctx = ctx
+        self.ndim = ndim
+        self.boxes = [([int(x) for x in lo], [int(x) for x in hi]) for lo, hi in boxes]
+        arr = (capi.Box * len(self.boxes))(*[_box_struct(lo, hi) for lo, hi in self.boxes])
+        h = C.c_void_p()
+        ctx.check(ctx.L.qk_level_create(ctx.h, C.byref(h), ndim, len(self.boxes), arr), "qk_level_create")
+        self.h = h
+
+    @property
+    def nboxes(self) -> int:
+        return len(self.boxes)
+
+    def num_cells(self) -> int:
+        return sum(int(np.prod([hi[d] - lo[d] + 1 for d in range(3)])) for lo, hi in self.boxes)
+
+    def __del__(self):
+        try:
+            self.ctx.L.qk_level_destroy(self.h)
+        except Exception:
+            pass
+
+
+class MultiFab:
+    """amrex::MultiFab (dtype float64) / iMultiFab (dtype int32) on the GPU.
+
+    facedir = -1: cell-centred; 0/1/2: nodal in that direction (amrex::convert(ba, e_d)).
+    One contiguous allocation holds all boxes (288 GB of HBM: size for few, large allocations).
+    """
+
+    def __init__(self, level: Level, ncomp: int, nghost: int, facedir: int = -1, dtype=torch.float64, fill: Optional[float] = None):
+        self.level, self.ncomp, self.nghost, self.facedir, self.dtype = level, ncomp, nghost, facedir, dtype
+        ctx = level.ctx
+        self.shapes, self.begins, offsets, total = [], [], [], 0
+        for lo, hi in level.boxes:
+            n = [hi[d] - lo[d] + 1 + (1 if d == facedir else 0) + (2 * nghost if d < level.ndim else 0) for d in range(3)]
+            self.shapes.append((ncomp, n[2], n[1], n[0]))
+            self.begins.append([lo[d] - (nghost if d < level.ndim else 0) for d in range(3)])
+            offsets.append(total)
+            total += ncomp * n[0] * n[1] * n[2]
+        self.storage = torch.empty(total, dtype=dtype, device=ctx.device)
+        if fill is not None:
+            self.storage.fill_(fill)
+        self.fabs: List[torch.Tensor] = [self.storage[o:o + int(np.prod(s))].view(s) for o, s in zip(offsets, self.shapes)]
+        tab = np.zeros(level.nboxes, dtype=_A4_DTYPE)
+        for b, (fab, shp, beg) in enumerate(zip(self.fabs, self.shapes, self.begins)):
+            nx, ny, nz = shp[3], shp[2], shp[1]
+            tab[b]["p"] = fab.data_ptr()
+            tab[b]["jstride"], tab[b]["kstride"], tab[b]["nstride"] = nx, nx * ny, nx * ny * nz
+            tab[b]["begin"] = beg
+            tab[b]["end"] = [beg[0] + nx, beg[1] + ny, beg[2] + nz]
+            tab[b]["ncomp"] = ncomp
+        self.host_table = tab
+        self.table = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(ctx.device)
+
+    @property
+    def ptr(self) -> C.c_void_p:
+        """device pointer to the qk_array4[nboxes] table (== MultiFab::arrays())"""
+        return C.c_void_p(self.table.data_ptr())
+
+    def valid_slices(self, b: int):
+        ng, nd = self.nghost, self.level.ndim
+        return tuple([slice(None)] + [slice(ng, -ng) if (d < nd and ng > 0) else slice(None) for d in (2, 1, 0)])
+
+    def valid(self, b: int) -> torch.Tensor:
+        return self.fabs[b][self.valid_slices(b)]
+
+    def set_fab(self, b: int, a: np.ndarray):
+        assert tuple(a.shape) == tuple(self.shapes[b]), (a.shape, self.shapes[b])
+        self.fabs[b].copy_(torch.from_numpy(np.ascontiguousarray(a)).to(self.dtype))
+
+    def fab_numpy(self, b: int) -> np.ndarray:
+        return self.fabs[b].cpu().numpy()
+
+    def copy_from(self, other: "MultiFab"):
+        self.storage.copy_(other.storage)
