@@ -220,6 +220,8 @@ int qk_ghost_plan_num_peers(qk_ghost_plan *plan);
 int qk_ghost_plan_peer(qk_ghost_plan *plan, int k, int *rank, int64_t *send_count, int64_t *recv_count);
 /* on-GPU copies (same-rank neighbours and periodic images) */
 int qk_FillBoundary_local(qk_ghost_plan *plan, qk_stream s, qk_array4 *state);
+/* iMultiFab flavour for redoFlag.FillBoundary (reference src/QuokkaSimulation.hpp:1157); plan built with ncomp = 1, nghost = 1 */
+int qk_FillBoundary_local_int(qk_ghost_plan *plan, qk_stream s, qk_iarray4 *state);
 /* pack the strips for peer k into `sendbuf` (device, send_count doubles) / unpack `recvbuf` */
 int qk_FillBoundary_pack(qk_ghost_plan *plan, qk_stream s, int k, const qk_array4 *state, double *sendbuf);
 int qk_FillBoundary_unpack(qk_ghost_plan *plan, qk_stream s, int k, qk_array4 *state, const double *recvbuf);

@@ -117,6 +117,7 @@ def lib() -> C.CDLL:
         L.qk_ghost_plan_num_peers.argtypes = [vp]
         L.qk_ghost_plan_peer.argtypes = [vp, ci, P(ci), P(C.c_int64), P(C.c_int64)]
         L.qk_FillBoundary_local.argtypes = [vp, vp, vp]
+        L.qk_FillBoundary_local_int.argtypes = [vp, vp, vp]
         L.qk_FillBoundary_pack.argtypes = [vp, vp, ci, vp, vp]
         L.qk_FillBoundary_unpack.argtypes = [vp, vp, ci, vp, vp]
         L.qk_FillPhysicalBoundary.argtypes = [vp, vp, vp, P(BCRec), P(DirichletFace)]
@@ -134,7 +135,7 @@ DECLARED_SYMBOLS = [
     "qk_hydro_EnforceLimits", "qk_hydro_SyncDualEnergy", "qk_hydro_ComputeMaxSignalSpeed", "qk_hydro_maxSignalSpeedLocal",
     "qk_replaceFluxes", "qk_Saxpy", "qk_hydro_stage_scratch_bytes", "qk_hydro_stage_fused",
     "qk_ghost_plan_create", "qk_ghost_plan_destroy", "qk_ghost_plan_num_peers", "qk_ghost_plan_peer",
-    "qk_FillBoundary_local", "qk_FillBoundary_pack", "qk_FillBoundary_unpack", "qk_FillPhysicalBoundary",
+    "qk_FillBoundary_local", "qk_FillBoundary_local_int", "qk_FillBoundary_pack", "qk_FillBoundary_unpack", "qk_FillPhysicalBoundary",
 ]
 
 

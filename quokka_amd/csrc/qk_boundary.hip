@@ -1,0 +1,448 @@
+// qk_boundary.hip — level-0 ghost fill (reference src/simulation.hpp:1751-1776):
+//   state.FillBoundary(geom.periodicity())  ->  plan (host) + on-GPU copy kernel for same-rank neighbours
+//                                               + pack / unpack kernels for strips that cross GPUs
+//   PhysBCFunct(FilccCell + user functor)   ->  one kernel over the ghost shell
+// The plan is pure host logic (box intersections with periodic shifts) and is the same on every rank;
+// the wire order of a (sender, receiver) pair is (dst global box, src global box, shift) ascending on
+// both sides, so the caller only has to move `send_count` doubles with RCCL p2p.
+#include <algorithm>
+#include <array>
+#include <map>
+#include <vector>
+
+#include "qk_device.hpp"
+#include "qk_internal.hpp"
+
+using namespace qk;
+
+namespace
+{
+
+struct CopyItem {
+	int dst_box; // local index (receiver side) or -1
+	int src_box; // local index (sender side) or -1
+	int lo[3], hi[3]; // region in the DESTINATION index space
+	int shift[3];	  // source index = destination index - shift
+	int64_t offset;	  // offset (in doubles) into the peer buffer; unused for local copies
+};
+
+struct PeerPlan {
+	int rank = -1;
+	std::vector<CopyItem> send, recv;
+	int64_t send_count = 0, recv_count = 0;
+	CopyItem *d_send = nullptr, *d_recv = nullptr;
+	int max_send_cells = 0, max_recv_cells = 0;
+};
+
+inline auto regionCells(CopyItem const &c) -> int64_t
+{
+	return static_cast<int64_t>(c.hi[0] - c.lo[0] + 1) * (c.hi[1] - c.lo[1] + 1) * (c.hi[2] - c.lo[2] + 1);
+}
+
+} // namespace
+
+struct qk_ghost_plan {
+	qk_level *lev = nullptr;
+	qk_geometry geom{};
+	int nghost = 0, ncomp = 0;
+	std::vector<CopyItem> local;
+	CopyItem *d_local = nullptr;
+	int max_local_cells = 0;
+	std::vector<PeerPlan> peers;
+	qk_bcrec *d_bcs = nullptr;
+	int d_bcs_n = 0;
+	qk_dirichlet_face *d_dir = nullptr;
+};
+
+namespace
+{
+
+enum CopyMode { MODE_LOCAL = 0, MODE_PACK = 1, MODE_UNPACK = 2 };
+
+// blockIdx.y = item; grid-stride over region cells x ncomp
+template <int MODE, typename T = double, typename D = qk_array4>
+__global__ void __launch_bounds__(256) k_copy(const CopyItem *items, const D *state_t, T *buf, int ncomp)
+{
+	const CopyItem it = items[blockIdx.y];
+	const int n0 = it.hi[0] - it.lo[0] + 1, n1 = it.hi[1] - it.lo[1] + 1, n2 = it.hi[2] - it.lo[2] + 1;
+	const int64_t ncell = static_cast<int64_t>(n0) * n1 * n2;
+	const int64_t total = ncell * ncomp;
+	for (int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < total; t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+		const int n = static_cast<int>(t / ncell);
+		const int64_t c = t - n * ncell;
+		const int k = static_cast<int>(c / (static_cast<int64_t>(n0) * n1));
+		const int r = static_cast<int>(c - static_cast<int64_t>(k) * n0 * n1);
+		const int j = r / n0;
+		const int i = r - j * n0;
+		const int di = it.lo[0] + i, dj = it.lo[1] + j, dk = it.lo[2] + k;
+		if (MODE == MODE_LOCAL) {
+			A4<T, D> Dst(state_t[it.dst_box]);
+			A4<T, D> Src(state_t[it.src_box]);
+			Dst(di, dj, dk, n) = Src(di - it.shift[0], dj - it.shift[1], dk - it.shift[2], n);
+		} else if (MODE == MODE_PACK) {
+			A4<T, D> Src(state_t[it.src_box]);
+			buf[it.offset + t] = Src(di - it.shift[0], dj - it.shift[1], dk - it.shift[2], n);
+		} else {
+			A4<T, D> Dst(state_t[it.dst_box]);
+			Dst(di, dj, dk, n) = buf[it.offset + t];
+		}
+	}
+}
+
+// PhysBCFunct: FilccCell (AMReX_FilCC_3D_C.H) composed over dimensions + constant-Dirichlet user functor.
+__global__ void __launch_bounds__(256) k_physbc(const qk_box *boxes, qk_array4 *state_t, qk_geometry geom, int ng, int ncomp, const qk_bcrec *bcs,
+						const qk_dirichlet_face *dirichlet)
+{
+	const int b = blockIdx.y;
+	const qk_box bx = boxes[b];
+	int lo[3], len[3];
+#pragma unroll
+	for (int d = 0; d < 3; ++d) {
+		const int g = (d < geom.ndim) ? ng : 0;
+		lo[d] = bx.lo[d] - g;
+		len[d] = bx.hi[d] - bx.lo[d] + 1 + 2 * g;
+	}
+	const int64_t ncell = static_cast<int64_t>(len[0]) * len[1] * len[2];
+	WA4 A(state_t[b]);
+	for (int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < ncell; t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+		const int k = static_cast<int>(t / (static_cast<int64_t>(len[0]) * len[1]));
+		const int r = static_cast<int>(t - static_cast<int64_t>(k) * len[0] * len[1]);
+		const int j = r / len[0];
+		const int i = r - j * len[0];
+		const int idx[3] = {lo[0] + i, lo[1] + j, lo[2] + k};
+		int side[3] = {0, 0, 0};
+		bool out = false;
+#pragma unroll
+		for (int d = 0; d < 3; ++d) {
+			if (d < geom.ndim && geom.periodic[d] == 0) {
+				if (idx[d] < geom.domain.lo[d]) {
+					side[d] = -1;
+					out = true;
+				} else if (idx[d] > geom.domain.hi[d]) {
+					side[d] = 1;
+					out = true;
+				}
+			}
+		}
+		if (!out) {
+			continue;
+		}
+		// user functor (closed set): constant state beyond an enabled face; x faces first, as a
+		// setCustomBoundaryConditions written like HydroShocktube's (test_hydro_shocktube.cpp:94-144)
+		const qk_dirichlet_face *df = nullptr;
+		if (dirichlet != nullptr) {
+#pragma unroll
+			for (int d = 0; d < 3; ++d) {
+				if (df == nullptr && side[d] != 0) {
+					const qk_dirichlet_face *cand = &dirichlet[2 * d + (side[d] > 0 ? 1 : 0)];
+					if (cand->enabled != 0) {
+						df = cand;
+					}
+				}
+			}
+		}
+		if (df != nullptr) {
+			for (int n = 0; n < ncomp; ++n) {
+				A(idx[0], idx[1], idx[2], n) = df->values[n];
+			}
+			continue;
+		}
+		for (int n = 0; n < ncomp; ++n) {
+			const qk_bcrec bc = bcs[n];
+			int src[3] = {idx[0], idx[1], idx[2]};
+			bool neg = false;
+			bool any = false;
+#pragma unroll
+			for (int d = 0; d < 3; ++d) {
+				if (side[d] == 0) {
+					continue;
+				}
+				const int type = (side[d] < 0) ? bc.lo[d] : bc.hi[d];
+				const int edge = (side[d] < 0) ? geom.domain.lo[d] : geom.domain.hi[d];
+				if (type == QK_BC_FOEXTRAP) {
+					src[d] = edge;
+					any = true;
+				} else if (type == QK_BC_REFLECT_EVEN || type == QK_BC_REFLECT_ODD) {
+					src[d] = (side[d] < 0) ? (2 * edge - idx[d] - 1) : (2 * edge - idx[d] + 1);
+					neg = neg != (type == QK_BC_REFLECT_ODD);
+					any = true;
+				}
+			}
+			if (any) {
+				const double v = A(src[0], src[1], src[2], n);
+				A(idx[0], idx[1], idx[2], n) = neg ? -v : v;
+			}
+		}
+	}
+}
+
+auto uploadItems(qk_ctx *ctx, std::vector<CopyItem> const &v, CopyItem **d) -> int
+{
+	*d = nullptr;
+	if (v.empty()) {
+		return QK_OK;
+	}
+	QK_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void **>(d), sizeof(CopyItem) * v.size()));
+	QK_HIP_CHECK(ctx, hipMemcpy(*d, v.data(), sizeof(CopyItem) * v.size(), hipMemcpyHostToDevice));
+	return QK_OK;
+}
+
+inline auto gridFor(int64_t cells, int nitems) -> dim3
+{
+	const int64_t gx = std::max<int64_t>(1, std::min<int64_t>((cells + 255) / 256, 256));
+	return dim3(static_cast<unsigned>(gx), static_cast<unsigned>(nitems), 1);
+}
+
+} // namespace
+
+extern "C" {
+
+int qk_ghost_plan_create(qk_level *lev, qk_ghost_plan **plan_out, const qk_geometry *geom, int nghost, int ncomp, int n_all, const qk_box *all_boxes,
+			 const int *owner, int my_rank)
+{
+	if (lev == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	qk_ctx *ctx = lev->ctx;
+	QK_REQUIRE(ctx, plan_out && geom && all_boxes && owner && n_all > 0, "qk_ghost_plan_create: NULL argument");
+	QK_REQUIRE(ctx, nghost >= 0 && ncomp > 0, "qk_ghost_plan_create: bad nghost/ncomp");
+	// local index of every global box
+	std::vector<int> local_of(n_all, -1);
+	int nl = 0;
+	for (int g = 0; g < n_all; ++g) {
+		if (owner[g] == my_rank) {
+			QK_REQUIRE(ctx, nl < lev->nboxes, "qk_ghost_plan_create: more owned boxes than the level holds");
+			for (int d = 0; d < 3; ++d) {
+				QK_REQUIRE(ctx, lev->boxes[nl].lo[d] == all_boxes[g].lo[d] && lev->boxes[nl].hi[d] == all_boxes[g].hi[d],
+					   "qk_ghost_plan_create: owned boxes must be the level's boxes, in order");
+			}
+			local_of[g] = nl++;
+		}
+	}
+	QK_REQUIRE(ctx, nl == lev->nboxes, "qk_ghost_plan_create: level has boxes this rank does not own");
+
+	auto *P = new qk_ghost_plan;
+	P->lev = lev;
+	P->geom = *geom;
+	P->nghost = nghost;
+	P->ncomp = ncomp;
+
+	// periodic shifts
+	std::vector<std::array<int, 3>> shifts;
+	int rng[3] = {0, 0, 0};
+	for (int d = 0; d < geom->ndim; ++d) {
+		rng[d] = (geom->periodic[d] != 0) ? 1 : 0;
+	}
+	for (int sz = -rng[2]; sz <= rng[2]; ++sz) {
+		for (int sy = -rng[1]; sy <= rng[1]; ++sy) {
+			for (int sx = -rng[0]; sx <= rng[0]; ++sx) {
+				shifts.push_back({sx * (geom->domain.hi[0] - geom->domain.lo[0] + 1), sy * (geom->domain.hi[1] - geom->domain.lo[1] + 1),
+						  sz * (geom->domain.hi[2] - geom->domain.lo[2] + 1)});
+			}
+		}
+	}
+
+	std::map<int, PeerPlan> peers;
+	// canonical order: dst global box, src global box, shift
+	for (int gd = 0; gd < n_all; ++gd) {
+		qk_box grown = all_boxes[gd];
+		for (int d = 0; d < geom->ndim; ++d) {
+			grown.lo[d] -= nghost;
+			grown.hi[d] += nghost;
+		}
+		for (int gs = 0; gs < n_all; ++gs) {
+			const bool dst_mine = owner[gd] == my_rank;
+			const bool src_mine = owner[gs] == my_rank;
+			if (!dst_mine && !src_mine) {
+				continue;
+			}
+			for (auto const &s : shifts) {
+				if (gd == gs && s[0] == 0 && s[1] == 0 && s[2] == 0) {
+					continue;
+				}
+				CopyItem it{};
+				bool ok = true;
+				for (int d = 0; d < 3; ++d) {
+					it.lo[d] = std::max(grown.lo[d], all_boxes[gs].lo[d] + s[d]);
+					it.hi[d] = std::min(grown.hi[d], all_boxes[gs].hi[d] + s[d]);
+					it.shift[d] = s[d];
+					ok = ok && (it.hi[d] >= it.lo[d]);
+				}
+				if (!ok) {
+					continue;
+				}
+				it.dst_box = local_of[gd];
+				it.src_box = local_of[gs];
+				if (dst_mine && src_mine) {
+					P->local.push_back(it);
+					P->max_local_cells = std::max<int64_t>(P->max_local_cells, regionCells(it));
+				} else if (dst_mine) {
+					PeerPlan &pp = peers[owner[gs]];
+					pp.rank = owner[gs];
+					it.offset = pp.recv_count;
+					pp.recv_count += regionCells(it) * ncomp;
+					pp.max_recv_cells = std::max<int64_t>(pp.max_recv_cells, regionCells(it));
+					pp.recv.push_back(it);
+				} else {
+					PeerPlan &pp = peers[owner[gd]];
+					pp.rank = owner[gd];
+					it.offset = pp.send_count;
+					pp.send_count += regionCells(it) * ncomp;
+					pp.max_send_cells = std::max<int64_t>(pp.max_send_cells, regionCells(it));
+					pp.send.push_back(it);
+				}
+			}
+		}
+	}
+	int rc = uploadItems(ctx, P->local, &P->d_local);
+	for (auto &kv : peers) {
+		if (rc == QK_OK) {
+			rc = uploadItems(ctx, kv.second.send, &kv.second.d_send);
+		}
+		if (rc == QK_OK) {
+			rc = uploadItems(ctx, kv.second.recv, &kv.second.d_recv);
+		}
+		P->peers.push_back(kv.second);
+	}
+	if (rc != QK_OK) {
+		qk_ghost_plan_destroy(P);
+		return rc;
+	}
+	*plan_out = P;
+	return QK_OK;
+}
+
+int qk_ghost_plan_destroy(qk_ghost_plan *plan)
+{
+	if (plan == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	(void)hipFree(plan->d_local);
+	for (auto &p : plan->peers) {
+		(void)hipFree(p.d_send);
+		(void)hipFree(p.d_recv);
+	}
+	(void)hipFree(plan->d_bcs);
+	(void)hipFree(plan->d_dir);
+	delete plan;
+	return QK_OK;
+}
+
+int qk_ghost_plan_num_peers(qk_ghost_plan *plan) { return plan == nullptr ? QK_ERR_INVALID : static_cast<int>(plan->peers.size()); }
+
+int qk_ghost_plan_peer(qk_ghost_plan *plan, int k, int *rank, int64_t *send_count, int64_t *recv_count)
+{
+	if (plan == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	QK_REQUIRE(plan->lev->ctx, k >= 0 && k < static_cast<int>(plan->peers.size()) && rank && send_count && recv_count, "qk_ghost_plan_peer: bad index");
+	*rank = plan->peers[k].rank;
+	*send_count = plan->peers[k].send_count;
+	*recv_count = plan->peers[k].recv_count;
+	return QK_OK;
+}
+
+int qk_FillBoundary_local(qk_ghost_plan *plan, qk_stream s, qk_array4 *state_t)
+{
+	if (plan == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	qk_ctx *ctx = plan->lev->ctx;
+	QK_REQUIRE(ctx, state_t, "FillBoundary_local: NULL state");
+	if (plan->local.empty()) {
+		return QK_OK;
+	}
+	hipLaunchKernelGGL(k_copy<MODE_LOCAL>, gridFor(static_cast<int64_t>(plan->max_local_cells) * plan->ncomp, static_cast<int>(plan->local.size())),
+			   dim3(256), 0, static_cast<hipStream_t>(s), plan->d_local, state_t, static_cast<double *>(nullptr), plan->ncomp);
+	QK_HIP_CHECK(ctx, hipGetLastError());
+	return QK_OK;
+}
+
+// iMultiFab flavour (redoFlag.FillBoundary, reference src/QuokkaSimulation.hpp:1157)
+int qk_FillBoundary_local_int(qk_ghost_plan *plan, qk_stream s, qk_iarray4 *state_t)
+{
+	if (plan == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	qk_ctx *ctx = plan->lev->ctx;
+	QK_REQUIRE(ctx, state_t, "FillBoundary_local_int: NULL state");
+	if (plan->local.empty()) {
+		return QK_OK;
+	}
+	hipLaunchKernelGGL((k_copy<MODE_LOCAL, int, qk_iarray4>),
+			   gridFor(static_cast<int64_t>(plan->max_local_cells) * plan->ncomp, static_cast<int>(plan->local.size())), dim3(256), 0,
+			   static_cast<hipStream_t>(s), plan->d_local, state_t, static_cast<int *>(nullptr), plan->ncomp);
+	QK_HIP_CHECK(ctx, hipGetLastError());
+	return QK_OK;
+}
+
+int qk_FillBoundary_pack(qk_ghost_plan *plan, qk_stream s, int k, const qk_array4 *state_t, double *sendbuf)
+{
+	if (plan == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	qk_ctx *ctx = plan->lev->ctx;
+	QK_REQUIRE(ctx, k >= 0 && k < static_cast<int>(plan->peers.size()) && state_t && sendbuf, "FillBoundary_pack: bad argument");
+	PeerPlan const &pp = plan->peers[k];
+	if (pp.send.empty()) {
+		return QK_OK;
+	}
+	hipLaunchKernelGGL(k_copy<MODE_PACK>, gridFor(static_cast<int64_t>(pp.max_send_cells) * plan->ncomp, static_cast<int>(pp.send.size())), dim3(256), 0,
+			   static_cast<hipStream_t>(s), pp.d_send, const_cast<qk_array4 *>(state_t), sendbuf, plan->ncomp);
+	QK_HIP_CHECK(ctx, hipGetLastError());
+	return QK_OK;
+}
+
+int qk_FillBoundary_unpack(qk_ghost_plan *plan, qk_stream s, int k, qk_array4 *state_t, const double *recvbuf)
+{
+	if (plan == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	qk_ctx *ctx = plan->lev->ctx;
+	QK_REQUIRE(ctx, k >= 0 && k < static_cast<int>(plan->peers.size()) && state_t && recvbuf, "FillBoundary_unpack: bad argument");
+	PeerPlan const &pp = plan->peers[k];
+	if (pp.recv.empty()) {
+		return QK_OK;
+	}
+	hipLaunchKernelGGL(k_copy<MODE_UNPACK>, gridFor(static_cast<int64_t>(pp.max_recv_cells) * plan->ncomp, static_cast<int>(pp.recv.size())), dim3(256), 0,
+			   static_cast<hipStream_t>(s), pp.d_recv, state_t, const_cast<double *>(recvbuf), plan->ncomp);
+	QK_HIP_CHECK(ctx, hipGetLastError());
+	return QK_OK;
+}
+
+int qk_FillPhysicalBoundary(qk_ghost_plan *plan, qk_stream s, qk_array4 *state_t, const qk_bcrec *bcs, const qk_dirichlet_face *dirichlet)
+{
+	if (plan == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	qk_level *lev = plan->lev;
+	qk_ctx *ctx = lev->ctx;
+	QK_REQUIRE(ctx, state_t && bcs, "FillPhysicalBoundary: NULL argument");
+	bool allPeriodic = true;
+	for (int d = 0; d < plan->geom.ndim; ++d) {
+		allPeriodic = allPeriodic && (plan->geom.periodic[d] != 0);
+	}
+	if (allPeriodic) { // simulation.hpp:1757
+		return QK_OK;
+	}
+	// BCRecs / Dirichlet model are tiny: keep a device copy in the plan (refreshed on every call, stream-ordered)
+	if (plan->d_bcs == nullptr) {
+		QK_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void **>(&plan->d_bcs), sizeof(qk_bcrec) * plan->ncomp));
+		QK_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void **>(&plan->d_dir), sizeof(qk_dirichlet_face) * 6));
+	}
+	QK_HIP_CHECK(ctx, hipMemcpyAsync(plan->d_bcs, bcs, sizeof(qk_bcrec) * plan->ncomp, hipMemcpyHostToDevice, static_cast<hipStream_t>(s)));
+	if (dirichlet != nullptr) {
+		QK_HIP_CHECK(ctx, hipMemcpyAsync(plan->d_dir, dirichlet, sizeof(qk_dirichlet_face) * 6, hipMemcpyHostToDevice, static_cast<hipStream_t>(s)));
+	}
+	int64_t ncell = 1;
+	for (int d = 0; d < 3; ++d) {
+		ncell *= lev->maxlen[d] + ((d < lev->ndim) ? 2 * plan->nghost : 0);
+	}
+	const dim3 grid(static_cast<unsigned>(std::min<int64_t>((ncell + 255) / 256, 2048)), static_cast<unsigned>(lev->nboxes), 1);
+	hipLaunchKernelGGL(k_physbc, grid, dim3(256), 0, static_cast<hipStream_t>(s), lev->d_boxes, state_t, plan->geom, plan->nghost, plan->ncomp,
+			   plan->d_bcs, dirichlet != nullptr ? plan->d_dir : nullptr);
+	QK_HIP_CHECK(ctx, hipGetLastError());
+	return QK_OK;
+}
+
+} // extern "C"

@@ -86,6 +86,7 @@ int qk_level_destroy(qk_level *lev)
 		return QK_ERR_INVALID;
 	}
 	(void)hipFree(lev->d_boxes);
+	(void)hipFree(lev->d_sgeom);
 	delete lev;
 	return QK_OK;
 }

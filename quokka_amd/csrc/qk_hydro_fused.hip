@@ -1,0 +1,649 @@
+// qk_hydro_fused.hip — the throughput path: one RK stage of the hydro update as six launches
+//   k_prim   U -> primitive variables (valid+4)                        [HydroSystem::ConservedToPrimitive]
+//   k_chi3   flattening coefficients of the three directions (valid+2) [ComputeFlatteningCoefficients<DIR> x3]
+//   k_aux    chi = min over the 3x3 axis neighbours, transverse velocity differences D_x,D_y,D_z (valid+1)
+//   k_sweep_x / k_sweep_march<Y> / k_sweep_march<Z>:
+//            PPM (or PLM / donor) reconstruction + shock flattening + HLLC + flux divergence + face-velocity
+//            divergence, fused per sweep direction; nothing but the per-direction half-step fluxes F1 (needed
+//            bit-exactly by stage 2: flux_rk2 = 0.5 F1 + 0.5 F2) and a 7-component rhs accumulator touches HBM.
+//            The Z sweep carries the epilogue: P dV term, PredictStep, validity flag, EnforceLimits, SyncDualEnergy.
+//
+// MI355X mapping
+//   * X sweep: the pencil direction is the contiguous one, so one thread owns one cell of a flat, row-contiguous
+//     slab (rows j = lo..hi of one k-plane are adjacent in memory); +-2 stencil values, right-edge states and face
+//     fluxes move between neighbouring lanes through LDS (40 KB per 256-thread workgroup -> 4 workgroups per CU).
+//   * Y / Z sweeps: lanes stay along x (coalesced 512-B wave loads), each thread MARCHES along the sweep direction
+//     with a 5-cell primitive window, the previous right-edge state and the previous face flux in registers: every
+//     face flux is evaluated exactly once, no LDS, no barriers.
+//   * all arithmetic in qk_device.hpp, shared with the reference-shaped operators -> identical bits.
+#include "qk_device.hpp"
+#include "qk_internal.hpp"
+
+using namespace qk;
+
+namespace
+{
+
+constexpr int NG = 4; // nghost_cc_ (reference src/simulation.hpp:363)
+
+// geometry of the ghost-4 scratch fab of one box
+struct SGeom {
+	int64_t off;   // offset of this box in cells (scratch arrays are [array][box][comp][cell])
+	int glo[3];    // lower corner including ghosts
+	int n[3];      // extent including ghosts
+	int64_t ncell; // n0*n1*n2
+};
+
+// scratch arrays (in units of "components over total_cells")
+enum { S_PRIM = 0, S_CHI3 = 6, S_AUX = 9, S_RHS = 13, S_NCOMP = 20 };
+// S_AUX + 0: chi (combined), +1..3: D_x, D_y, D_z ;  S_RHS + 0..5: flux divergence, +6: div v
+
+struct SweepArgs {
+	const qk_box *boxes;
+	const SGeom *geom;
+	double *scratch;
+	int64_t total_cells;
+	const qk_array4 *U_in;
+	const qk_array4 *U_old;
+	qk_array4 *U_out;
+	qk_array4 *halfFlux; // of this sweep's direction
+	qk_array4 *halfVel;
+	qk_iarray4 *redoFlag;
+	unsigned long long *redo_count;
+	int *error_flag;
+	double inv_dx; // 1/dx of the sweep direction
+	double dx;
+	double dt;
+	double densityFloor, tempFloor;
+	double K_visc;
+	int use_dual_energy;
+	bool reconstruct_eint;
+};
+
+QK_DEV auto sarr(SweepArgs const &a, int comp) -> double * { return a.scratch + static_cast<int64_t>(comp) * a.total_cells; }
+
+// ---------------------------------------------------------------------------------------------- pre-passes
+__global__ void __launch_bounds__(256) k_prim(const qk_box *boxes, const SGeom *geom, const qk_array4 *U_t, double *scratch, int64_t total, Eos eos,
+					      bool re)
+{
+	const int b = blockIdx.y;
+	const SGeom g = geom[b];
+	RA4 U(U_t[b]);
+	for (int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; c < g.ncell; c += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+		const int k = static_cast<int>(c / (static_cast<int64_t>(g.n[0]) * g.n[1]));
+		const int r = static_cast<int>(c - static_cast<int64_t>(k) * g.n[0] * g.n[1]);
+		const int j = r / g.n[0];
+		const int i = r - j * g.n[0];
+		const int64_t u = U.idx(g.glo[0] + i, g.glo[1] + j, g.glo[2] + k);
+		const double rho = U.p[u + U.ns * RHO];
+		const double px = U.p[u + U.ns * MX];
+		const double py = U.p[u + U.ns * MY];
+		const double pz = U.p[u + U.ns * MZ];
+		const double E = U.p[u + U.ns * ENE];
+		const double Eint_aux = U.p[u + U.ns * EINT];
+		const double vx = px / rho;
+		const double vy = py / rho;
+		const double vz = pz / rho;
+		const double kinetic_energy = 0.5 * rho * (vx * vx + vy * vy + vz * vz);
+		const double Eint_cons = E - kinetic_energy;
+		double *q = scratch + g.off + c;
+		q[(S_PRIM + PRHO) * total] = rho;
+		q[(S_PRIM + PVX) * total] = vx;
+		q[(S_PRIM + PVY) * total] = vy;
+		q[(S_PRIM + PVZ) * total] = vz;
+		if (re) {
+			q[(S_PRIM + PPRES) * total] = Eint_cons / rho;
+			q[(S_PRIM + PEINT) * total] = Eint_aux / rho;
+		} else {
+			q[(S_PRIM + PPRES) * total] = eos.isothermal ? rho * eos.cs_iso * eos.cs_iso : eos.pressure(rho, Eint_cons);
+			q[(S_PRIM + PEINT) * total] = Eint_aux;
+		}
+	}
+}
+
+// cells of the box grown by `grow` (<= NG), one thread per cell, blockIdx.y = box
+template <class F> __global__ void __launch_bounds__(256) k_grown(const qk_box *boxes, const SGeom *geom, int grow, F f)
+{
+	const int b = blockIdx.y;
+	const qk_box bx = boxes[b];
+	const SGeom g = geom[b];
+	const int l0 = bx.hi[0] - bx.lo[0] + 1 + 2 * grow, l1 = bx.hi[1] - bx.lo[1] + 1 + 2 * grow, l2 = bx.hi[2] - bx.lo[2] + 1 + 2 * grow;
+	const int64_t n = static_cast<int64_t>(l0) * l1 * l2;
+	for (int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < n; t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+		const int k = static_cast<int>(t / (static_cast<int64_t>(l0) * l1));
+		const int r = static_cast<int>(t - static_cast<int64_t>(k) * l0 * l1);
+		const int j = r / l0;
+		const int i = r - j * l0;
+		// index inside the ghost-4 scratch fab
+		const int64_t c = (i + NG - grow) + static_cast<int64_t>(g.n[0]) * ((j + NG - grow) + static_cast<int64_t>(g.n[1]) * (k + NG - grow));
+		f(g, c);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------- shared sweep pieces
+template <int ORDER> QK_DEV void cellEdges(const double qm2, const double qm1, const double q0, const double qp1, const double qp2, double &am, double &ap)
+{
+	if (ORDER == 3) {
+		ppmEdges(qm2, qm1, q0, qp1, qp2, am, ap);
+	} else if (ORDER == 2) {
+		plmEdges<QK_LIMITER_MINMOD>(qm1, q0, qp1, am, ap); // hydroFluxFunction uses minmod (QuokkaSimulation.hpp:1501)
+	} else {
+		am = q0;
+		ap = q0;
+	}
+}
+
+// hydro_system.hpp:679-685
+QK_DEV void flattenEdges(double chi, double mean, double &am, double &ap)
+{
+	am = chi * am + (1. - chi) * mean;
+	ap = chi * ap + (1. - chi) * mean;
+}
+
+// epilogue of one cell (AddInternalEnergyPdV + PredictStep + EnforceLimits + SyncDualEnergy)
+QK_DEV void updateCell(SweepArgs const &a, Eos const &eos, int b, int i, int j, int k, const double rhs[NVAR], double div_v)
+{
+	RA4 Uo(a.U_old[b]);
+	WA4 Un(a.U_out[b]);
+	IA4 flag(a.redoFlag[b]);
+	const int64_t co = Uo.idx(i, j, k);
+	double U[NVAR];
+#pragma unroll
+	for (int n = 0; n < NVAR; ++n) {
+		U[n] = Uo.p[co + Uo.ns * n];
+	}
+	// hydro_system.hpp:797-812 (redoFlag == none branch)
+	const double Pgas = consPressure(eos, U[RHO], U[MX], U[MY], U[MZ], U[ENE]);
+	double r[NVAR];
+#pragma unroll
+	for (int n = 0; n < NVAR; ++n) {
+		r[n] = rhs[n];
+	}
+	r[EINT] += -Pgas * div_v;
+	// hydro_system.hpp:487-495
+#pragma unroll
+	for (int n = 0; n < NVAR; ++n) {
+		U[n] = U[n] + a.dt * r[n];
+	}
+	const int bad = (U[RHO] > 0.) ? 0 : 1;
+	flag(i, j, k) = bad;
+	if (bad != 0) {
+		atomicAdd(a.redo_count, 1ULL);
+	} else {
+		enforceLimits(eos, a.densityFloor, a.tempFloor, U);
+		if (a.use_dual_energy != 0) {
+			if (!syncDualEnergy(U)) {
+				*a.error_flag = 1;
+			}
+		}
+	}
+	const int64_t cn = Un.idx(i, j, k);
+#pragma unroll
+	for (int n = 0; n < NVAR; ++n) {
+		Un.p[cn + Un.ns * n] = U[n];
+	}
+}
+
+// ---------------------------------------------------------------------------------------------- X sweep (flat + LDS)
+constexpr int XB = 256;	 // threads per workgroup
+constexpr int XOUT = 250; // cells updated per workgroup (3 halo cells on each side)
+
+template <int ORDER, int STAGE> __global__ void __launch_bounds__(XB) k_sweep_x(SweepArgs a, Eos eos)
+{
+	__shared__ double s_q[NVAR][XB];  // primitives, later reused for the face fluxes
+	__shared__ double s_e[NVAR][XB];  // right-edge states a_plus
+	__shared__ double s_d[3][XB];	  // D_V, D_W, face velocity
+
+	const int b = blockIdx.z;
+	const qk_box bx = a.boxes[b];
+	const SGeom g = a.geom[b];
+	const int t = threadIdx.x;
+	const int k = bx.lo[2] + blockIdx.y;
+	if (k > bx.hi[2]) {
+		return; // uniform for the whole workgroup
+	}
+	// flat slab: rows j = lo.y .. hi.y of plane k are contiguous
+	const int64_t rowlen = g.n[0];
+	const int64_t slab0 = rowlen * ((bx.lo[1] - g.glo[1]) + static_cast<int64_t>(g.n[1]) * (k - g.glo[2]));
+	const int64_t slablen = rowlen * (bx.hi[1] - bx.lo[1] + 1);
+	const int64_t f = static_cast<int64_t>(blockIdx.x) * XOUT + t - 3; // flat position inside the slab
+	const bool inside = (f >= 0) && (f < slablen);
+	const int64_t c = slab0 + (inside ? f : 0);
+	const int jj = static_cast<int>((inside ? f : 0) / rowlen);
+	const int i = g.glo[0] + static_cast<int>((inside ? f : 0) - jj * rowlen);
+	const int j = bx.lo[1] + jj;
+
+	const double *S = a.scratch + g.off;
+	const int64_t T = a.total_cells;
+	double q0[NVAR];
+#pragma unroll
+	for (int n = 0; n < NVAR; ++n) {
+		q0[n] = S[(S_PRIM + n) * T + c];
+		s_q[n][t] = q0[n];
+	}
+	const double chi = S[(S_AUX + 0) * T + c];
+	const double dV = S[(S_AUX + 2) * T + c]; // view-j axis of X1 is y
+	const double dW = S[(S_AUX + 3) * T + c]; // view-k axis is z
+	s_d[0][t] = dV;
+	s_d[1][t] = dW;
+	__syncthreads();
+
+	// reconstruct my cell (needs t-2 .. t+2)
+	double am[NVAR], ap[NVAR];
+	const int tm2 = max(t - 2, 0), tm1 = max(t - 1, 0), tp1 = min(t + 1, XB - 1), tp2 = min(t + 2, XB - 1);
+#pragma unroll
+	for (int n = 0; n < NVAR; ++n) {
+		cellEdges<ORDER>(s_q[n][tm2], s_q[n][tm1], q0[n], s_q[n][tp1], s_q[n][tp2], am[n], ap[n]);
+		flattenEdges(chi, q0[n], am[n], ap[n]);
+		s_e[n][t] = ap[n];
+	}
+	__syncthreads();
+
+	// flux at my left face
+	double qL[NVAR];
+#pragma unroll
+	for (int n = 0; n < NVAR; ++n) {
+		qL[n] = s_e[n][tm1];
+	}
+	const double du = q0[PVX] - s_q[PVX][tm1];
+	const double dvl = s_d[0][tm1], dwl = s_d[1][tm1];
+	double F[NVAR], vf;
+	faceFlux<0, QK_RIEMANN_HLLC>(eos, a.reconstruct_eint, 3, qL, am, du, dvl, dV, dwl, dW, a.K_visc, F, vf);
+
+	const bool validRow = inside;
+	const bool isFace = validRow && (i >= bx.lo[0]) && (i <= bx.hi[0] + 1) && (t >= 3) && (t <= XB - 3);
+	if (STAGE == 1) {
+		if (isFace) {
+			WA4 HF(a.halfFlux[b]);
+			WA4 HV(a.halfVel[b]);
+			const int64_t o = HF.idx(i, j, k);
+#pragma unroll
+			for (int n = 0; n < NVAR; ++n) {
+				HF.p[o + HF.ns * n] = F[n];
+			}
+			HV(i, j, k) = vf;
+		}
+	} else {
+		if (isFace) {
+			RA4 HF(a.halfFlux[b]);
+			RA4 HV(a.halfVel[b]);
+			const int64_t o = HF.idx(i, j, k);
+			// flux_rk2 = (0 + 0.5 F1) + 0.5 F2   (QuokkaSimulation.hpp:1106, :1220)
+#pragma unroll
+			for (int n = 0; n < NVAR; ++n) {
+				F[n] = 0.5 * HF.p[o + HF.ns * n] + 0.5 * F[n];
+			}
+			vf = 0.5 * HV(i, j, k) + 0.5 * vf;
+		}
+	}
+	__syncthreads(); // everyone is done with s_q (primitives)
+#pragma unroll
+	for (int n = 0; n < NVAR; ++n) {
+		s_q[n][t] = F[n];
+	}
+	s_d[2][t] = vf;
+	__syncthreads();
+
+	const bool isCell = validRow && (i >= bx.lo[0]) && (i <= bx.hi[0]) && (t >= 3) && (t < 3 + XOUT);
+	if (isCell) {
+		double *R = a.scratch + g.off + c;
+#pragma unroll
+		for (int n = 0; n < NVAR; ++n) {
+			// hydro_system.hpp:469
+			R[(S_RHS + n) * T] = a.inv_dx * (F[n] - s_q[n][tp1]);
+		}
+		// hydro_system.hpp:803
+		R[(S_RHS + 6) * T] = (s_d[2][tp1] - vf) / a.dx;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------- Y / Z sweeps (marching)
+template <int DIR, int ORDER, int STAGE, bool LAST> __global__ void __launch_bounds__(256) k_sweep_march(SweepArgs a, Eos eos)
+{
+	static_assert(DIR == 1 || DIR == 2, "marching sweeps are the strided directions");
+	const int b = blockIdx.z;
+	const qk_box bx = a.boxes[b];
+	const SGeom g = a.geom[b];
+	constexpr int OT = (DIR == 1) ? 2 : 1; // the other transverse axis (besides x)
+	const int i = bx.lo[0] + blockIdx.x * 64 + threadIdx.x;
+	const int ot = bx.lo[OT] + blockIdx.y * 4 + threadIdx.y;
+	if (i > bx.hi[0] || ot > bx.hi[OT]) {
+		return;
+	}
+	const int64_t T = a.total_cells;
+	const int64_t st[3] = {1, g.n[0], static_cast<int64_t>(g.n[0]) * g.n[1]};
+	const int64_t ms = st[DIR]; // march stride
+	const int lo = bx.lo[DIR], hi = bx.hi[DIR];
+	const int nvalid = hi - lo + 1;
+	// scratch index of march position p = lo - 3
+	int pos[3];
+	pos[0] = i;
+	pos[OT] = ot;
+	pos[DIR] = lo - 3;
+	int64_t c = (pos[0] - g.glo[0]) * st[0] + (pos[1] - g.glo[1]) * st[1] + (pos[2] - g.glo[2]) * st[2];
+	const double *S = a.scratch + g.off;
+	double *Sw = a.scratch + g.off;
+
+	constexpr int AV = Axes<DIR>::v, AW = Axes<DIR>::w;
+	double q[5][NVAR];
+	double apPrev[NVAR], Fprev[NVAR];
+	double vfPrev = 0., dVprev = 0., dWprev = 0.;
+#pragma unroll
+	for (int n = 0; n < NVAR; ++n) {
+		apPrev[n] = 0.;
+		Fprev[n] = 0.;
+#pragma unroll
+		for (int m = 0; m < 5; ++m) {
+			q[m][n] = 0.;
+		}
+	}
+
+	for (int step = 0; step < nvalid + 6; ++step, c += ms) {
+		// shift the window and load prim(p)
+#pragma unroll
+		for (int n = 0; n < NVAR; ++n) {
+			q[0][n] = q[1][n];
+			q[1][n] = q[2][n];
+			q[2][n] = q[3][n];
+			q[3][n] = q[4][n];
+			q[4][n] = S[(S_PRIM + n) * T + c];
+		}
+		if (step < 4) {
+			continue;
+		}
+		// cell cc = p - 2 in [lo-1, hi+1]
+		const int64_t cc = c - 2 * ms;
+		const double chi = S[(S_AUX + 0) * T + cc];
+		const double dV = S[(S_AUX + 1 + AV) * T + cc];
+		const double dW = S[(S_AUX + 1 + AW) * T + cc];
+		double am[NVAR], ap[NVAR];
+#pragma unroll
+		for (int n = 0; n < NVAR; ++n) {
+			cellEdges<ORDER>(q[0][n], q[1][n], q[2][n], q[3][n], q[4][n], am[n], ap[n]);
+			flattenEdges(chi, q[2][n], am[n], ap[n]);
+		}
+		if (step >= 5) {
+			// face between cells cc-1 and cc, index = (march coordinate of cc)
+			const double du = q[2][PVX + DIR] - q[1][PVX + DIR];
+			double F[NVAR], vf;
+			faceFlux<DIR, QK_RIEMANN_HLLC>(eos, a.reconstruct_eint, 3, apPrev, am, du, dVprev, dV, dWprev, dW, a.K_visc, F, vf);
+			int fidx[3];
+			fidx[0] = i;
+			fidx[OT] = ot;
+			fidx[DIR] = lo + (step - 5);
+			if (STAGE == 1) {
+				WA4 HF(a.halfFlux[b]);
+				WA4 HV(a.halfVel[b]);
+				const int64_t o = HF.idx(fidx[0], fidx[1], fidx[2]);
+#pragma unroll
+				for (int n = 0; n < NVAR; ++n) {
+					HF.p[o + HF.ns * n] = F[n];
+				}
+				HV(fidx[0], fidx[1], fidx[2]) = vf;
+			} else {
+				RA4 HF(a.halfFlux[b]);
+				RA4 HV(a.halfVel[b]);
+				const int64_t o = HF.idx(fidx[0], fidx[1], fidx[2]);
+#pragma unroll
+				for (int n = 0; n < NVAR; ++n) {
+					F[n] = 0.5 * HF.p[o + HF.ns * n] + 0.5 * F[n];
+				}
+				vf = 0.5 * HV(fidx[0], fidx[1], fidx[2]) + 0.5 * vf;
+			}
+			if (step >= 6) {
+				// update cell u = cc - 1 (march coordinate lo + step - 6)
+				const int64_t cu = cc - ms;
+				double rhs[NVAR];
+#pragma unroll
+				for (int n = 0; n < NVAR; ++n) {
+					rhs[n] = S[(S_RHS + n) * T + cu] + a.inv_dx * (Fprev[n] - F[n]);
+				}
+				const double div_v = S[(S_RHS + 6) * T + cu] + (vf - vfPrev) / a.dx;
+				if (LAST) {
+					int u[3];
+					u[0] = i;
+					u[OT] = ot;
+					u[DIR] = lo + (step - 6);
+					updateCell(a, eos, b, u[0], u[1], u[2], rhs, div_v);
+				} else {
+#pragma unroll
+					for (int n = 0; n < NVAR; ++n) {
+						Sw[(S_RHS + n) * T + cu] = rhs[n];
+					}
+					Sw[(S_RHS + 6) * T + cu] = div_v;
+				}
+			}
+#pragma unroll
+			for (int n = 0; n < NVAR; ++n) {
+				Fprev[n] = F[n];
+			}
+			vfPrev = vf;
+		}
+#pragma unroll
+		for (int n = 0; n < NVAR; ++n) {
+			apPrev[n] = ap[n];
+		}
+		dVprev = dV;
+		dWprev = dW;
+	}
+}
+
+auto buildGeom(qk_level *lev) -> int
+{
+	if (lev->d_sgeom != nullptr) {
+		return QK_OK;
+	}
+	std::vector<SGeom> g(lev->nboxes);
+	int64_t off = 0;
+	for (int b = 0; b < lev->nboxes; ++b) {
+		g[b].off = off;
+		g[b].ncell = 1;
+		for (int d = 0; d < 3; ++d) {
+			g[b].glo[d] = lev->boxes[b].lo[d] - NG;
+			g[b].n[d] = lev->boxes[b].hi[d] - lev->boxes[b].lo[d] + 1 + 2 * NG;
+			g[b].ncell *= g[b].n[d];
+		}
+		off += g[b].ncell;
+	}
+	void *d = nullptr;
+	QK_HIP_CHECK(lev->ctx, hipMalloc(&d, sizeof(SGeom) * lev->nboxes));
+	QK_HIP_CHECK(lev->ctx, hipMemcpy(d, g.data(), sizeof(SGeom) * lev->nboxes, hipMemcpyHostToDevice));
+	lev->d_sgeom = d;
+	lev->sgeom_total_cells = off;
+	return QK_OK;
+}
+
+template <int ORDER, int STAGE> void launchSweeps(qk_level *lev, hipStream_t s, SweepArgs a, Eos eos, const qk_hydro_stage_args *args)
+{
+	// X
+	{
+		SweepArgs ax = a;
+		ax.halfFlux = args->halfFlux[0];
+		ax.halfVel = args->halfVel[0];
+		ax.inv_dx = 1.0 / args->dx[0];
+		ax.dx = args->dx[0];
+		const int64_t slab = static_cast<int64_t>(lev->maxlen[0] + 2 * NG) * lev->maxlen[1];
+		const dim3 grid(static_cast<unsigned>((slab + XOUT - 1) / XOUT), static_cast<unsigned>(lev->maxlen[2]), static_cast<unsigned>(lev->nboxes));
+		hipLaunchKernelGGL((k_sweep_x<ORDER, STAGE>), grid, dim3(XB), 0, s, ax, eos);
+	}
+	// Y
+	{
+		SweepArgs ay = a;
+		ay.halfFlux = args->halfFlux[1];
+		ay.halfVel = args->halfVel[1];
+		ay.inv_dx = 1.0 / args->dx[1];
+		ay.dx = args->dx[1];
+		const dim3 grid((lev->maxlen[0] + 63) / 64, (lev->maxlen[2] + 3) / 4, lev->nboxes);
+		hipLaunchKernelGGL((k_sweep_march<1, ORDER, STAGE, false>), grid, dim3(64, 4), 0, s, ay, eos);
+	}
+	// Z (+ epilogue)
+	{
+		SweepArgs az = a;
+		az.halfFlux = args->halfFlux[2];
+		az.halfVel = args->halfVel[2];
+		az.inv_dx = 1.0 / args->dx[2];
+		az.dx = args->dx[2];
+		const dim3 grid((lev->maxlen[0] + 63) / 64, (lev->maxlen[1] + 3) / 4, lev->nboxes);
+		hipLaunchKernelGGL((k_sweep_march<2, ORDER, STAGE, true>), grid, dim3(64, 4), 0, s, az, eos);
+	}
+}
+
+} // namespace
+
+extern "C" {
+
+int64_t qk_hydro_stage_scratch_bytes(qk_level *lev, const qk_hydro_traits *t)
+{
+	if (lev == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	if (int rc = checkTraits(lev->ctx, t); rc != QK_OK) {
+		return rc;
+	}
+	int64_t cells = 0;
+	for (int b = 0; b < lev->nboxes; ++b) {
+		int64_t n = 1;
+		for (int d = 0; d < 3; ++d) {
+			n *= lev->boxes[b].hi[d] - lev->boxes[b].lo[d] + 1 + 2 * NG;
+		}
+		cells += n;
+	}
+	return cells * S_NCOMP * static_cast<int64_t>(sizeof(double));
+}
+
+int qk_hydro_stage_fused(qk_level *lev, qk_stream stream, const qk_hydro_traits *t, const qk_hydro_stage_args *args)
+{
+	if (lev == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	qk_ctx *ctx = lev->ctx;
+	if (int rc = checkTraits(ctx, t); rc != QK_OK) {
+		return rc;
+	}
+	QK_REQUIRE(ctx, args != nullptr, "qk_hydro_stage_fused: NULL args");
+	if (t->ndim != 3) {
+		return setError(ctx, QK_ERR_UNSUPPORTED, "qk_hydro_stage_fused: 3-D only (use the reference-shaped operators in 1-D)");
+	}
+	if (args->K_visc != 0.0) {
+		return setError(ctx, QK_ERR_UNSUPPORTED, "qk_hydro_stage_fused: artificial viscosity is only built in the reference-shaped path");
+	}
+	QK_REQUIRE(ctx, args->stage == 1 || args->stage == 2, "qk_hydro_stage_fused: stage must be 1 or 2");
+	QK_REQUIRE(ctx, args->reconstruction_order >= 1 && args->reconstruction_order <= 3, "qk_hydro_stage_fused: reconstruction_order must be 1..3");
+	QK_REQUIRE(ctx, args->U_in && args->U_old && args->U_out && args->redoFlag && args->d_redo_count && args->d_error_flag && args->scratch,
+		   "qk_hydro_stage_fused: NULL array");
+	for (int d = 0; d < 3; ++d) {
+		QK_REQUIRE(ctx, args->halfFlux[d] && args->halfVel[d], "qk_hydro_stage_fused: NULL halfFlux/halfVel");
+		QK_REQUIRE(ctx, lev->maxlen[d] >= 1, "qk_hydro_stage_fused: empty box");
+	}
+	QK_REQUIRE(ctx, args->scratch_bytes >= qk_hydro_stage_scratch_bytes(lev, t), "qk_hydro_stage_fused: scratch too small");
+
+	if (int rc = buildGeom(lev); rc != QK_OK) {
+		return rc;
+	}
+	auto s = static_cast<hipStream_t>(stream);
+	const Eos eos(*t);
+	const bool re = (t->reconstruct_eint != 0);
+	auto *scratch = static_cast<double *>(args->scratch);
+	const int64_t T = lev->sgeom_total_cells;
+	const SGeom *geom = static_cast<const SGeom *>(lev->d_sgeom);
+	const qk_box *boxes = lev->d_boxes;
+
+	int64_t maxcell = 1;
+	for (int d = 0; d < 3; ++d) {
+		maxcell *= lev->maxlen[d] + 2 * NG;
+	}
+	const dim3 gridAll(static_cast<unsigned>(std::min<int64_t>((maxcell + 255) / 256, 4096)), lev->nboxes, 1);
+
+	// 1. primitives on valid + 4
+	hipLaunchKernelGGL(k_prim, gridAll, dim3(256), 0, s, boxes, geom, args->U_in, scratch, T, eos, re);
+
+	// 2. flattening coefficients of all three directions on valid + 2 (hydro_system.hpp:550-625)
+	{
+		auto f = [=] __device__(SGeom const &g, int64_t c) {
+			const double *S = scratch + g.off;
+			const int64_t st[3] = {1, g.n[0], static_cast<int64_t>(g.n[0]) * g.n[1]};
+			const double rho0 = S[(S_PRIM + PRHO) * T + c];
+#pragma unroll
+			for (int d = 0; d < 3; ++d) {
+				double P[5];
+#pragma unroll
+				for (int m = -2; m <= 2; ++m) {
+					const int64_t cm = c + m * st[d];
+					double Pm = S[(S_PRIM + PPRES) * T + cm];
+					const double rho = S[(S_PRIM + PRHO) * T + cm];
+					if (re) {
+						Pm = eos.pressure(rho, rho * Pm);
+					}
+					if (eos.isothermal) {
+						Pm = rho * (eos.cs_iso * eos.cs_iso);
+					}
+					P[m + 2] = Pm;
+				}
+				const double vm1 = S[(S_PRIM + PVX + d) * T + c - st[d]];
+				const double vp1 = S[(S_PRIM + PVX + d) * T + c + st[d]];
+				(scratch + g.off)[(S_CHI3 + d) * T + c] = flatteningChi(eos, P[0], P[1], P[2], P[3], P[4], rho0, vm1, vp1);
+			}
+		};
+		hipLaunchKernelGGL(k_grown<decltype(f)>, gridAll, dim3(256), 0, s, boxes, geom, 2, f);
+	}
+
+	// 3. combined flattening coefficient (hydro_system.hpp:655-669) and transverse velocity differences
+	//    D_a(c) = min(v_a(c+e_a) - v_a(c), v_a(c) - v_a(c-e_a))  (the per-cell pieces of hydro_system.hpp:1025-1033)
+	{
+		auto f = [=] __device__(SGeom const &g, int64_t c) {
+			const double *S = scratch + g.off;
+			double *W = scratch + g.off;
+			const int64_t st[3] = {1, g.n[0], static_cast<int64_t>(g.n[0]) * g.n[1]};
+			double chi = smin(smin(S[(S_CHI3 + 0) * T + c - st[0]], S[(S_CHI3 + 0) * T + c]), S[(S_CHI3 + 0) * T + c + st[0]]);
+			chi = smin(smin(smin(chi, S[(S_CHI3 + 1) * T + c - st[1]]), S[(S_CHI3 + 1) * T + c]), S[(S_CHI3 + 1) * T + c + st[1]]);
+			chi = smin(smin(smin(chi, S[(S_CHI3 + 2) * T + c - st[2]]), S[(S_CHI3 + 2) * T + c]), S[(S_CHI3 + 2) * T + c + st[2]]);
+			W[(S_AUX + 0) * T + c] = chi;
+#pragma unroll
+			for (int d = 0; d < 3; ++d) {
+				const double v0 = S[(S_PRIM + PVX + d) * T + c];
+				const double vp = S[(S_PRIM + PVX + d) * T + c + st[d]];
+				const double vm = S[(S_PRIM + PVX + d) * T + c - st[d]];
+				W[(S_AUX + 1 + d) * T + c] = smin(vp - v0, v0 - vm);
+			}
+		};
+		hipLaunchKernelGGL(k_grown<decltype(f)>, gridAll, dim3(256), 0, s, boxes, geom, 1, f);
+	}
+
+	// 4. sweeps
+	SweepArgs a{};
+	a.boxes = boxes;
+	a.geom = geom;
+	a.scratch = scratch;
+	a.total_cells = T;
+	a.U_in = args->U_in;
+	a.U_old = args->U_old;
+	a.U_out = args->U_out;
+	a.redoFlag = args->redoFlag;
+	a.redo_count = reinterpret_cast<unsigned long long *>(args->d_redo_count);
+	a.error_flag = args->d_error_flag;
+	a.dt = args->dt;
+	a.densityFloor = args->densityFloor;
+	a.tempFloor = args->tempFloor;
+	a.K_visc = args->K_visc;
+	a.use_dual_energy = args->use_dual_energy;
+	a.reconstruct_eint = re;
+
+#define QK_LAUNCH(ORDER)                                                                                                                             \
+	if (args->stage == 1) {                                                                                                                      \
+		launchSweeps<ORDER, 1>(lev, s, a, eos, args);                                                                                        \
+	} else {                                                                                                                                     \
+		launchSweeps<ORDER, 2>(lev, s, a, eos, args);                                                                                        \
+	}
+	if (args->reconstruction_order == 3) {
+		QK_LAUNCH(3)
+	} else if (args->reconstruction_order == 2) {
+		QK_LAUNCH(2)
+	} else {
+		QK_LAUNCH(1)
+	}
+#undef QK_LAUNCH
+	QK_HIP_CHECK(ctx, hipGetLastError());
+	return QK_OK;
+}
+
+} // extern "C"

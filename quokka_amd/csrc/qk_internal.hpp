@@ -25,6 +25,9 @@ struct qk_level {
 	std::vector<qk_box> boxes; // host copy
 	qk_box *d_boxes = nullptr; // device copy
 	int maxlen[3] = {0, 0, 0}; // max valid-box length per dim
+	// cache of the fused path (ghost-4 scratch geometry of every box), built on first use
+	void *d_sgeom = nullptr;
+	int64_t sgeom_total_cells = 0;
 };
 
 namespace qk
