@@ -1,0 +1,163 @@
+#!/usr/bin/env python
+"""bench.py — Mcell-updates/s of the 3-D Sedov blast on a uniform grid (BASELINE.json `metric`).
+
+A "step" is one full RK2 hydro step of every cell (both ghost fills, both fused flux/update stages, the CFL
+reduction and the dt control), counted exactly like the reference's figure of merit
+(reference src/simulation.hpp:1285, 972-977).  At N = 1 the workload is BASELINE config 2:
+tests/blast_unigrid_256.in — 256^3 cells in 128^3 boxes, gamma = 1.4, PPM + HLLC, CFL 0.3, reflecting
+octant.  For N > 1 every rank keeps 256^3 cells (8 boxes of 128^3): the domain is doubled along x, y, z in turn
+(weak scaling), boxes are block-distributed and the ghost strips travel as RCCL point-to-point messages.
+
+Output: ONE JSON line on rank 0 (see the contract in the task statement), including
+  roofline     — algorithmic bytes of the dominant fused sweep kernel / its HIP-event duration vs 8 TB/s HBM
+  cpu_baseline — the CPU oracle (a port of the reference algorithm, NOT the reference binary) on the host cores
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+# algorithmic bytes per cell-sweep of the fused PPM+HLLC sweep kernels
+ALG_BYTES = {"k_sweep_x": 128.0, "k_sweep_y": 184.0, "k_sweep_z": 184.0}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--ncell", type=int, default=256, help="cells per dimension PER GPU (256 = blast_unigrid_256.in)")
+    ap.add_argument("--max-grid-size", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-ncell", type=int, default=128)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    return ap.parse_args()
+
+
+def weak_scaled_cells(n: int, ngpus: int):
+    cells = [n, n, n]
+    d, r = 0, ngpus
+    while r > 1:
+        assert r % 2 == 0, "GPU count must be a power of two"
+        cells[d % 3] *= 2
+        d += 1
+        r //= 2
+    return cells
+
+
+def cpu_baseline(ncell: int, steps: int):
+    """Oracle (port of the reference algorithm, built with gcc -O2 -ffp-contract=off -fopenmp) on the host cores."""
+    from oracle.pyoracle import SEDOV, Oracle
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    o = Oracle("direct")
+    s = o.sim(SEDOV, 3, [ncell] * 3, [0, 0, 0], [1.2] * 3, [0, 0, 0], max_grid_size=[32] * 3)
+    threads = min(cores, s.nboxes)
+    assert s.step()  # warm-up (page-in)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        assert s.step()
+    el = time.perf_counter() - t0
+    return {"value": ncell ** 3 * steps / el / 1e6, "unit": "Mcell-updates/s", "cores": threads, "kind": "port",
+            "sample": f"Sedov {ncell}^3 in 32^3 boxes, {steps} RK2 steps, OpenMP over boxes ({threads} threads of {cores} cores); "
+                      "CPU restatement of the reference algorithm, not the reference binary"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from quokka_amd.multifab import Context
+    from quokka_amd.simulation import sedov_problem
+
+    ctx = Context(local_rank)
+    n_cell = weak_scaled_cells(args.ncell, world)
+    sim = sedov_problem(ctx, args.ncell, max_grid_size=args.max_grid_size, rank=rank, nranks=world, n_cell=n_cell)
+    sim.maxTimesteps_ = 10 ** 9
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        assert sim.step()
+    L = ctx.L
+    L.qk_profile_reset(ctx.h)
+    L.qk_profile_enable(ctx.h, 1)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        assert sim.step(), "hydro advance failed"
+    barrier()
+    elapsed = time.perf_counter() - t0
+    L.qk_profile_enable(ctx.h, 0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel HIP-event durations recorded on the launch stream during the timed region
+    kernels = {}
+    for k in range(L.qk_profile_num_kernels(ctx.h)):
+        name, cnt, ms = C.c_char_p(), C.c_long(), C.c_double()
+        L.qk_profile_get(ctx.h, k, C.byref(name), C.byref(cnt), C.byref(ms))
+        kernels[name.value.decode()] = (cnt.value, ms.value)
+    cells_local = sim.lev.num_cells()
+    total_cells = n_cell[0] * n_cell[1] * n_cell[2]
+    dom = max((k for k in kernels if k in ALG_BYTES), key=lambda k: kernels[k][1], default=None)
+    roofline = None
+    if dom is not None and kernels[dom][0] > 0:
+        avg_s = kernels[dom][1] / kernels[dom][0] * 1e-3
+        achieved = ALG_BYTES[dom] * cells_local / avg_s / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": None, "alg_bytes_per_launch": ALG_BYTES[dom] * cells_local, "avg_launch_ms": avg_s * 1e3,
+                    "launches": kernels[dom][0],
+                    "all_kernels_ms_per_launch": {k: v[1] / max(v[0], 1) for k, v in sorted(kernels.items())}}
+
+    if rank == 0:
+        value = total_cells * args.steps / elapsed / 1e6
+        out = {
+            "metric": "Mcell-updates/s on 3D Sedov unigrid", "value": value, "unit": "Mcell-updates/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"3D Sedov blast {n_cell[0]}x{n_cell[1]}x{n_cell[2]} unigrid (tests/blast_unigrid_256.in per GPU), "
+                                   f"{args.max_grid_size}^3 boxes, PPM+HLLC RK2, gamma=1.4, CFL 0.3, reflecting octant",
+                       "cells_per_gpu": args.ncell ** 3, "boxes_per_gpu": sim.lev.nboxes, "parallelism": f"box-decomposition x{world}",
+                       "fofc_stages": sim.counters["fofc1_stages"] + sim.counters["fofc2_stages"], "retries": sim.counters["retries"],
+                       "sim_time": sim.tNew_},
+            "roofline": roofline,
+            # context only (other hardware, reference implementation): paper/performance_a100.csv:2 = 254.05 Mzones/s on 1x A100
+            "reference_published_a100_1gpu": 254.05,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_ncell, args.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

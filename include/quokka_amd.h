@@ -89,6 +89,13 @@ int qk_ctx_destroy(qk_ctx *ctx);
 const char *qk_last_error(qk_ctx *ctx);
 const char *qk_version(void);
 
+/* Optional per-kernel timing with HIP events recorded on the launch stream (used by bench.py for the roofline
+ * figure).  qk_profile_num_kernels / qk_profile_get synchronise on the recorded events. */
+int qk_profile_enable(qk_ctx *ctx, int on);
+int qk_profile_reset(qk_ctx *ctx);
+int qk_profile_num_kernels(qk_ctx *ctx);
+int qk_profile_get(qk_ctx *ctx, int k, const char **name, long *count, double *total_ms);
+
 /* BoxArray of one level owned by this rank (valid, cell-centred boxes). */
 int qk_level_create(qk_ctx *ctx, qk_level **lev, int ndim, int nboxes, const qk_box *valid_boxes);
 int qk_level_destroy(qk_level *lev);

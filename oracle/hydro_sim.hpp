@@ -97,6 +97,7 @@ struct HydroSim {
 	void hydroFluxFunction(int dir, MultiFab const &primVar, MultiFab &leftState, MultiFab &rightState, MultiFab &flux, MultiFab &faceVel,
 			       MultiFab const &x1Flat, MultiFab const &x2Flat, MultiFab const &x3Flat, int ng_reconstruct, int nvars) const
 	{
+		_Pragma("omp parallel for schedule(dynamic)")
 		for (int b = 0; b < primVar.size(); ++b) {
 			Box const cellRange = grow(primVar.valid[b], ng_reconstruct, ndim());
 			if (reconstructionOrder_ == 3) {
@@ -130,10 +131,12 @@ struct HydroSim {
 			flux[idim] = MultiFab(grids, nvars, 0, ndim(), idim);
 			facevel[idim] = MultiFab(grids, 1, 0, ndim(), idim);
 		}
+		_Pragma("omp parallel for schedule(dynamic)")
 		for (int b = 0; b < consVar.size(); ++b) {
 			hydro.ConservedToPrimitive(consVar.const_array(b), primVar.array(b), grow(grids[b], nghost_cc, ndim()));
 		}
 		for (int idim = 0; idim < ndim(); ++idim) {
+			_Pragma("omp parallel for schedule(dynamic)")
 			for (int b = 0; b < consVar.size(); ++b) {
 				hydro.ComputeFlatteningCoefficients(idim, primVar.const_array(b), flatCoefs[idim].array(b), grow(grids[b], flatteningGhost, ndim()));
 			}
@@ -157,10 +160,12 @@ struct HydroSim {
 			flux[idim] = MultiFab(grids, nvars, 0, ndim(), idim);
 			facevel[idim] = MultiFab(grids, 1, 0, ndim(), idim);
 		}
+		_Pragma("omp parallel for schedule(dynamic)")
 		for (int b = 0; b < consVar.size(); ++b) {
 			hydro.ConservedToPrimitive(consVar.const_array(b), primVar.array(b), grow(grids[b], nghost_cc, ndim()));
 		}
 		for (int idim = 0; idim < ndim(); ++idim) {
+			_Pragma("omp parallel for schedule(dynamic)")
 			for (int b = 0; b < consVar.size(); ++b) {
 				Box const cellRange = grow(grids[b], reconstructRange, ndim());
 				ReconstructStatesConstant(idim, primVar.const_array(b), leftState[idim].array(b), rightState[idim].array(b), cellRange, nvars);
@@ -174,6 +179,7 @@ struct HydroSim {
 	// MultiFab::Saxpy(dst, a, src, 0, 0, ncomp, 0): dst += a*src on valid (face) boxes
 	static void Saxpy(MultiFab &dst, double a, MultiFab const &src, int ncomp)
 	{
+		_Pragma("omp parallel for schedule(dynamic)")
 		for (int b = 0; b < dst.size(); ++b) {
 			auto d = dst.array(b);
 			auto s = src.const_array(b);
@@ -243,6 +249,7 @@ struct HydroSim {
 	void rhsPdvPredict(MultiFab &rhs, FluxArrays const &fluxes, FluxArrays const &faceVel, MultiFab const &stateOld, MultiFab &stateNew, double dt_lev,
 			   iMultiFab &redoFlag) const
 	{
+		_Pragma("omp parallel for schedule(dynamic)")
 		for (int b = 0; b < rhs.size(); ++b) {
 			std::array<Array4<const double>, 3> f{}, v{};
 			for (int d = 0; d < ndim(); ++d) {
@@ -258,10 +265,12 @@ struct HydroSim {
 
 	void limitsAndSync(MultiFab &state) const
 	{
+		_Pragma("omp parallel for schedule(dynamic)")
 		for (int b = 0; b < state.size(); ++b) {
 			hydro.EnforceLimits(densityFloor_, tempFloor_, state.array(b), grids[b]);
 		}
 		if (useDualEnergy_ == 1) {
+			_Pragma("omp parallel for schedule(dynamic)")
 			for (int b = 0; b < state.size(); ++b) {
 				hydro.SyncDualEnergy(state.array(b), grids[b]);
 			}
@@ -272,6 +281,7 @@ struct HydroSim {
 	auto isCflViolated(double dt_actual) const -> bool
 	{
 		double max_signal = -std::numeric_limits<double>::infinity();
+		_Pragma("omp parallel for schedule(dynamic) reduction(max : max_signal)")
 		for (int b = 0; b < state_new_cc_.size(); ++b) {
 			max_signal = std::max(max_signal, hydro.maxSignalSpeedLocal(state_new_cc_.const_array(b), grids[b]));
 		}
@@ -402,6 +412,7 @@ struct HydroSim {
 
 	void copyValid(MultiFab &dst, MultiFab const &src, int ncomp) const
 	{
+		_Pragma("omp parallel for schedule(dynamic)")
 		for (int b = 0; b < dst.size(); ++b) {
 			auto d = dst.array(b);
 			auto s = src.const_array(b);
@@ -465,6 +476,7 @@ struct HydroSim {
 	[[nodiscard]] auto computeTimestepAtLevel() const -> double
 	{
 		double domain_signal_max = 0.0; // norminf of a non-negative field
+		_Pragma("omp parallel for schedule(dynamic) reduction(max : domain_signal_max)")
 		for (int b = 0; b < state_new_cc_.size(); ++b) {
 			Fab<double> maxSignal(grids[b], 1);
 			hydro.ComputeMaxSignalSpeed(state_new_cc_.const_array(b), maxSignal.array(), grids[b]);

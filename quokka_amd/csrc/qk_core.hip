@@ -91,6 +91,61 @@ int qk_level_destroy(qk_level *lev)
 	return QK_OK;
 }
 
+int qk_profile_enable(qk_ctx *ctx, int on)
+{
+	if (ctx == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	ctx->profiling = (on != 0);
+	return QK_OK;
+}
+
+// folds finished event pairs into the per-kernel totals (synchronises on the recorded events)
+static void profCollect(qk_ctx *ctx)
+{
+	for (auto &p : ctx->prof_pending) {
+		float ms = 0.f;
+		if (hipEventSynchronize(p.stop) == hipSuccess && hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
+			ctx->prof_slots[p.slot].count += 1;
+			ctx->prof_slots[p.slot].total_ms += ms;
+		}
+		ctx->prof_free_events.push_back(p.start);
+		ctx->prof_free_events.push_back(p.stop);
+	}
+	ctx->prof_pending.clear();
+}
+
+int qk_profile_reset(qk_ctx *ctx)
+{
+	if (ctx == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	profCollect(ctx);
+	ctx->prof_slots.clear();
+	return QK_OK;
+}
+
+int qk_profile_num_kernels(qk_ctx *ctx)
+{
+	if (ctx == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	profCollect(ctx);
+	return static_cast<int>(ctx->prof_slots.size());
+}
+
+int qk_profile_get(qk_ctx *ctx, int k, const char **name, long *count, double *total_ms)
+{
+	if (ctx == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	QK_REQUIRE(ctx, k >= 0 && k < static_cast<int>(ctx->prof_slots.size()) && name && count && total_ms, "qk_profile_get: bad index");
+	*name = ctx->prof_slots[k].name.c_str();
+	*count = ctx->prof_slots[k].count;
+	*total_ms = ctx->prof_slots[k].total_ms;
+	return QK_OK;
+}
+
 static int uploadTable(qk_ctx *ctx, int n, const void *host, size_t elem, void **dev)
 {
 	if (ctx == nullptr) {

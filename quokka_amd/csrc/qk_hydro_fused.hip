@@ -464,6 +464,7 @@ template <int ORDER, int STAGE> void launchSweeps(qk_level *lev, hipStream_t s, 
 		ax.dx = args->dx[0];
 		const int64_t slab = static_cast<int64_t>(lev->maxlen[0] + 2 * NG) * lev->maxlen[1];
 		const dim3 grid(static_cast<unsigned>((slab + XOUT - 1) / XOUT), static_cast<unsigned>(lev->maxlen[2]), static_cast<unsigned>(lev->nboxes));
+		ProfScope ps(lev->ctx, s, "k_sweep_x");
 		hipLaunchKernelGGL((k_sweep_x<ORDER, STAGE>), grid, dim3(XB), 0, s, ax, eos);
 	}
 	// Y
@@ -474,6 +475,7 @@ template <int ORDER, int STAGE> void launchSweeps(qk_level *lev, hipStream_t s, 
 		ay.inv_dx = 1.0 / args->dx[1];
 		ay.dx = args->dx[1];
 		const dim3 grid((lev->maxlen[0] + 63) / 64, (lev->maxlen[2] + 3) / 4, lev->nboxes);
+		ProfScope ps(lev->ctx, s, "k_sweep_y");
 		hipLaunchKernelGGL((k_sweep_march<1, ORDER, STAGE, false>), grid, dim3(64, 4), 0, s, ay, eos);
 	}
 	// Z (+ epilogue)
@@ -484,6 +486,7 @@ template <int ORDER, int STAGE> void launchSweeps(qk_level *lev, hipStream_t s, 
 		az.inv_dx = 1.0 / args->dx[2];
 		az.dx = args->dx[2];
 		const dim3 grid((lev->maxlen[0] + 63) / 64, (lev->maxlen[1] + 3) / 4, lev->nboxes);
+		ProfScope ps(lev->ctx, s, "k_sweep_z");
 		hipLaunchKernelGGL((k_sweep_march<2, ORDER, STAGE, true>), grid, dim3(64, 4), 0, s, az, eos);
 	}
 }
@@ -555,7 +558,10 @@ int qk_hydro_stage_fused(qk_level *lev, qk_stream stream, const qk_hydro_traits 
 	const dim3 gridAll(static_cast<unsigned>(std::min<int64_t>((maxcell + 255) / 256, 4096)), lev->nboxes, 1);
 
 	// 1. primitives on valid + 4
-	hipLaunchKernelGGL(k_prim, gridAll, dim3(256), 0, s, boxes, geom, args->U_in, scratch, T, eos, re);
+	{
+		ProfScope ps(ctx, s, "k_prim");
+		hipLaunchKernelGGL(k_prim, gridAll, dim3(256), 0, s, boxes, geom, args->U_in, scratch, T, eos, re);
+	}
 
 	// 2. flattening coefficients of all three directions on valid + 2 (hydro_system.hpp:550-625)
 	{
@@ -584,6 +590,7 @@ int qk_hydro_stage_fused(qk_level *lev, qk_stream stream, const qk_hydro_traits 
 				(scratch + g.off)[(S_CHI3 + d) * T + c] = flatteningChi(eos, P[0], P[1], P[2], P[3], P[4], rho0, vm1, vp1);
 			}
 		};
+		ProfScope ps(ctx, s, "k_chi3");
 		hipLaunchKernelGGL(k_grown<decltype(f)>, gridAll, dim3(256), 0, s, boxes, geom, 2, f);
 	}
 
@@ -606,6 +613,7 @@ int qk_hydro_stage_fused(qk_level *lev, qk_stream stream, const qk_hydro_traits 
 				W[(S_AUX + 1 + d) * T + c] = smin(vp - v0, v0 - vm);
 			}
 		};
+		ProfScope ps(ctx, s, "k_aux");
 		hipLaunchKernelGGL(k_grown<decltype(f)>, gridAll, dim3(256), 0, s, boxes, geom, 1, f);
 	}
 

@@ -546,16 +546,13 @@ QK_DEV auto signalSpeed(Eos const &eos, int which, double rho, double px, double
 	return cs + vel_mag;
 }
 
-// atomic max on a non-negative double through its (order-preserving) bit pattern
+// atomic max on a non-negative double through its (order-preserving) bit pattern.  NaNs never win a
+// std::max(result, v) comparison in the reference's serial reduction, so they are skipped here too.
 QK_DEV void atomicMaxNonNeg(double *addr, double v)
 {
-	if (!(v >= 0.0)) { // NaN or negative: propagate NaN as +inf-like poison so the host sees it
-		if (v != v) {
-			atomicMax(reinterpret_cast<unsigned long long *>(addr), 0x7ff8000000000000ULL);
-		}
-		return;
+	if (v > 0.0) {
+		atomicMax(reinterpret_cast<unsigned long long *>(addr), static_cast<unsigned long long>(__double_as_longlong(v)));
 	}
-	atomicMax(reinterpret_cast<unsigned long long *>(addr), static_cast<unsigned long long>(__double_as_longlong(v)));
 }
 
 __global__ void __launch_bounds__(256) k_maxSignal(const qk_box *boxes, const qk_array4 *cons_t, Eos eos, int which, double *result)
@@ -566,7 +563,6 @@ __global__ void __launch_bounds__(256) k_maxSignal(const qk_box *boxes, const qk
 	const int64_t ncell = static_cast<int64_t>(len0) * len1 * len2;
 	RA4 U(cons_t[b]);
 	double m = 0.0;
-	bool poisoned = false;
 	for (int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < ncell; t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
 		const int k = static_cast<int>(t / (static_cast<int64_t>(len0) * len1));
 		const int r = static_cast<int>(t - static_cast<int64_t>(k) * len0 * len1);
@@ -574,17 +570,11 @@ __global__ void __launch_bounds__(256) k_maxSignal(const qk_box *boxes, const qk
 		const int i = r - j * len0;
 		const int64_t c = U.idx(bx.lo[0] + i, bx.lo[1] + j, bx.lo[2] + k);
 		const double v = signalSpeed(eos, which, U.p[c + U.ns * RHO], U.p[c + U.ns * MX], U.p[c + U.ns * MY], U.p[c + U.ns * MZ], U.p[c + U.ns * ENE]);
-		if (v != v) {
-			poisoned = true;
-		}
 		m = smax(m, v);
 	}
 	// wave reduction (64 lanes), then one atomic per wave
 	for (int off = 32; off > 0; off >>= 1) {
 		m = smax(m, __shfl_xor(m, off));
-	}
-	if (__any(poisoned)) {
-		m = __builtin_nan("");
 	}
 	if ((threadIdx.x & 63) == 0) {
 		atomicMaxNonNeg(result, m);

@@ -11,11 +11,26 @@
 
 #include "quokka_amd.h"
 
+struct qk_prof_pending {
+	int slot;
+	hipEvent_t start, stop;
+};
+struct qk_prof_slot {
+	std::string name;
+	long count = 0;
+	double total_ms = 0.0;
+};
+
 struct qk_ctx {
 	int device = 0;
 	std::string last_error;
 	std::vector<void *> owned; // device allocations released in qk_ctx_destroy
 	std::mutex mtx;
+	// optional per-kernel HIP-event timing (qk_profile_*): events are recorded on the launch stream
+	bool profiling = false;
+	std::vector<qk_prof_slot> prof_slots;
+	std::vector<qk_prof_pending> prof_pending;
+	std::vector<hipEvent_t> prof_free_events;
 };
 
 struct qk_level {
@@ -95,6 +110,49 @@ inline auto cellLaunch(const qk_level *lev, int ng, int facedir) -> CellLaunch
 	L.grid = dim3(static_cast<unsigned>((n + 255) / 256), static_cast<unsigned>(lev->nboxes), 1);
 	return L;
 }
+
+// RAII scope: records a start/stop HIP event pair around the launches issued inside it (no-op unless profiling)
+struct ProfScope {
+	qk_ctx *ctx;
+	hipStream_t s;
+	int idx = -1;
+	ProfScope(qk_ctx *c, hipStream_t stream, const char *name) : ctx(c), s(stream)
+	{
+		if (ctx == nullptr || !ctx->profiling) {
+			return;
+		}
+		int slot = -1;
+		for (size_t i = 0; i < ctx->prof_slots.size(); ++i) {
+			if (ctx->prof_slots[i].name == name) {
+				slot = static_cast<int>(i);
+			}
+		}
+		if (slot < 0) {
+			ctx->prof_slots.push_back({name, 0, 0.0});
+			slot = static_cast<int>(ctx->prof_slots.size()) - 1;
+		}
+		auto getEvent = [&]() {
+			hipEvent_t e = nullptr;
+			if (!ctx->prof_free_events.empty()) {
+				e = ctx->prof_free_events.back();
+				ctx->prof_free_events.pop_back();
+			} else {
+				(void)hipEventCreate(&e);
+			}
+			return e;
+		};
+		qk_prof_pending p{slot, getEvent(), getEvent()};
+		(void)hipEventRecord(p.start, s);
+		ctx->prof_pending.push_back(p);
+		idx = static_cast<int>(ctx->prof_pending.size()) - 1;
+	}
+	~ProfScope()
+	{
+		if (idx >= 0) {
+			(void)hipEventRecord(ctx->prof_pending[idx].stop, s);
+		}
+	}
+};
 
 } // namespace qk
 

@@ -469,7 +469,7 @@ class HydroSimulation:
 def sedov_problem(ctx: Context, n: int, max_grid_size: int = 128, rank=0, nranks=1, use_fused=True, n_cell=None) -> HydroSimulation:
     """reference src/problems/HydroBlast3D/test_hydro3d_blast.cpp + tests/blast_unigrid_*.in"""
     n_cell = list(n_cell) if n_cell is not None else [n, n, n]
-    geom = Geometry(3, n_cell, [0.0, 0.0, 0.0], [1.2 * n_cell[d] / n_cell[0] for d in range(3)], [0, 0, 0])
+    geom = Geometry(3, n_cell, [0.0, 0.0, 0.0], [1.2 * n_cell[d] / n for d in range(3)], [0, 0, 0])
     bcs = []
     for c in range(6):
         lo = [capi.BC_REFLECT_ODD if c == 1 + d else capi.BC_REFLECT_EVEN for d in range(3)]
