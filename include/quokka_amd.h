@@ -172,6 +172,10 @@ typedef struct qk_hydro_stage_args {
 	qk_iarray4 *redoFlag;	 /* written: 0 / 1 per valid cell                                           */
 	int64_t *d_redo_count;	 /* device counter, incremented by the number of flagged cells              */
 	int *d_error_flag;	 /* device int, set to 1 if SyncDualEnergy meets rho <= 0                   */
+	double *d_max_signal;	 /* optional device double[2] (caller zeroes): max over the valid cells of U_out of
+				  * [0] cs + sqrt(2 KE / rho)  (maxSignalSpeedLocal, used by isCflViolated) and
+				  * [1] cs + |v|               (ComputeMaxSignalSpeed + norminf, used by computeTimestep),
+				  * folded into the epilogue so the two reduction passes over the new state disappear */
 	/* scratch: caller-owned, at least qk_hydro_stage_scratch_bytes() */
 	void *scratch;
 	int64_t scratch_bytes;

@@ -52,7 +52,7 @@ class DirichletFace(C.Structure):
 class StageArgs(C.Structure):
     _fields_ = [("U_in", C.c_void_p), ("U_old", C.c_void_p), ("U_out", C.c_void_p),
                 ("halfFlux", C.c_void_p * 3), ("halfVel", C.c_void_p * 3),
-                ("redoFlag", C.c_void_p), ("d_redo_count", C.c_void_p), ("d_error_flag", C.c_void_p),
+                ("redoFlag", C.c_void_p), ("d_redo_count", C.c_void_p), ("d_error_flag", C.c_void_p), ("d_max_signal", C.c_void_p),
                 ("scratch", C.c_void_p), ("scratch_bytes", C.c_int64),
                 ("dx", C.c_double * 3), ("dt", C.c_double), ("stage", C.c_int), ("reconstruction_order", C.c_int),
                 ("densityFloor", C.c_double), ("tempFloor", C.c_double), ("use_dual_energy", C.c_int), ("K_visc", C.c_double)]

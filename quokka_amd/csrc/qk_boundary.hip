@@ -49,6 +49,10 @@ struct qk_ghost_plan {
 	CopyItem *d_local = nullptr;
 	int max_local_cells = 0;
 	std::vector<PeerPlan> peers;
+	// ghost slabs outside the domain in a non-periodic dimension (dst_box, lo, hi used)
+	std::vector<CopyItem> shells;
+	CopyItem *d_shells = nullptr;
+	int max_shell_cells = 0;
 	qk_bcrec *d_bcs = nullptr;
 	int d_bcs_n = 0;
 	qk_dirichlet_face *d_dir = nullptr;
@@ -90,20 +94,18 @@ __global__ void __launch_bounds__(256) k_copy(const CopyItem *items, const D *st
 }
 
 // PhysBCFunct: FilccCell (AMReX_FilCC_3D_C.H) composed over dimensions + constant-Dirichlet user functor.
-__global__ void __launch_bounds__(256) k_physbc(const qk_box *boxes, qk_array4 *state_t, qk_geometry geom, int ng, int ncomp, const qk_bcrec *bcs,
+__global__ void __launch_bounds__(256) k_physbc(const CopyItem *items, qk_array4 *state_t, qk_geometry geom, int ncomp, const qk_bcrec *bcs,
 						const qk_dirichlet_face *dirichlet)
 {
-	const int b = blockIdx.y;
-	const qk_box bx = boxes[b];
+	const CopyItem it = items[blockIdx.y];
 	int lo[3], len[3];
 #pragma unroll
 	for (int d = 0; d < 3; ++d) {
-		const int g = (d < geom.ndim) ? ng : 0;
-		lo[d] = bx.lo[d] - g;
-		len[d] = bx.hi[d] - bx.lo[d] + 1 + 2 * g;
+		lo[d] = it.lo[d];
+		len[d] = it.hi[d] - it.lo[d] + 1;
 	}
 	const int64_t ncell = static_cast<int64_t>(len[0]) * len[1] * len[2];
-	WA4 A(state_t[b]);
+	WA4 A(state_t[it.dst_box]);
 	for (int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < ncell; t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
 		const int k = static_cast<int>(t / (static_cast<int64_t>(len[0]) * len[1]));
 		const int r = static_cast<int>(t - static_cast<int64_t>(k) * len[0] * len[1]);
@@ -294,7 +296,41 @@ int qk_ghost_plan_create(qk_level *lev, qk_ghost_plan **plan_out, const qk_geome
 			}
 		}
 	}
+	// ghost slabs beyond the domain faces (overlaps at edges/corners are written twice with the same value)
+	for (int b = 0; b < lev->nboxes; ++b) {
+		qk_box grown = lev->boxes[b];
+		for (int d = 0; d < geom->ndim; ++d) {
+			grown.lo[d] -= nghost;
+			grown.hi[d] += nghost;
+		}
+		for (int d = 0; d < geom->ndim; ++d) {
+			if (geom->periodic[d] != 0) {
+				continue;
+			}
+			for (int side = 0; side < 2; ++side) {
+				CopyItem it{};
+				it.dst_box = b;
+				it.src_box = b;
+				for (int e = 0; e < 3; ++e) {
+					it.lo[e] = grown.lo[e];
+					it.hi[e] = grown.hi[e];
+				}
+				if (side == 0) {
+					it.hi[d] = std::min(grown.hi[d], geom->domain.lo[d] - 1);
+				} else {
+					it.lo[d] = std::max(grown.lo[d], geom->domain.hi[d] + 1);
+				}
+				if (it.hi[d] >= it.lo[d]) {
+					P->shells.push_back(it);
+					P->max_shell_cells = std::max<int64_t>(P->max_shell_cells, regionCells(it));
+				}
+			}
+		}
+	}
 	int rc = uploadItems(ctx, P->local, &P->d_local);
+	if (rc == QK_OK) {
+		rc = uploadItems(ctx, P->shells, &P->d_shells);
+	}
 	for (auto &kv : peers) {
 		if (rc == QK_OK) {
 			rc = uploadItems(ctx, kv.second.send, &kv.second.d_send);
@@ -318,6 +354,7 @@ int qk_ghost_plan_destroy(qk_ghost_plan *plan)
 		return QK_ERR_INVALID;
 	}
 	(void)hipFree(plan->d_local);
+	(void)hipFree(plan->d_shells);
 	for (auto &p : plan->peers) {
 		(void)hipFree(p.d_send);
 		(void)hipFree(p.d_recv);
@@ -425,6 +462,7 @@ int qk_FillPhysicalBoundary(qk_ghost_plan *plan, qk_stream s, qk_array4 *state_t
 	if (allPeriodic) { // simulation.hpp:1757
 		return QK_OK;
 	}
+	(void)lev;
 	// BCRecs / Dirichlet model are tiny: keep a device copy in the plan (refreshed on every call, stream-ordered)
 	if (plan->d_bcs == nullptr) {
 		QK_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void **>(&plan->d_bcs), sizeof(qk_bcrec) * plan->ncomp));
@@ -434,13 +472,11 @@ int qk_FillPhysicalBoundary(qk_ghost_plan *plan, qk_stream s, qk_array4 *state_t
 	if (dirichlet != nullptr) {
 		QK_HIP_CHECK(ctx, hipMemcpyAsync(plan->d_dir, dirichlet, sizeof(qk_dirichlet_face) * 6, hipMemcpyHostToDevice, static_cast<hipStream_t>(s)));
 	}
-	int64_t ncell = 1;
-	for (int d = 0; d < 3; ++d) {
-		ncell *= lev->maxlen[d] + ((d < lev->ndim) ? 2 * plan->nghost : 0);
+	if (plan->shells.empty()) {
+		return QK_OK;
 	}
-	const dim3 grid(static_cast<unsigned>(std::min<int64_t>((ncell + 255) / 256, 2048)), static_cast<unsigned>(lev->nboxes), 1);
-	hipLaunchKernelGGL(k_physbc, grid, dim3(256), 0, static_cast<hipStream_t>(s), lev->d_boxes, state_t, plan->geom, plan->nghost, plan->ncomp,
-			   plan->d_bcs, dirichlet != nullptr ? plan->d_dir : nullptr);
+	hipLaunchKernelGGL(k_physbc, gridFor(plan->max_shell_cells, static_cast<int>(plan->shells.size())), dim3(256), 0, static_cast<hipStream_t>(s),
+			   plan->d_shells, state_t, plan->geom, plan->ncomp, plan->d_bcs, dirichlet != nullptr ? plan->d_dir : nullptr);
 	QK_HIP_CHECK(ctx, hipGetLastError());
 	return QK_OK;
 }

@@ -466,6 +466,44 @@ QK_DEV auto syncDualEnergy(double U[NVAR]) -> bool
 	return true;
 }
 
+// which = 0: maxSignalSpeedLocal (hydro_system.hpp:206-219); which = 1: ComputeMaxSignalSpeed (:227-250)
+QK_DEV auto signalSpeed(Eos const &eos, int which, double rho, double px, double py, double pz, double E) -> double
+{
+	double cs;
+	if (eos.isothermal) {
+		cs = eos.cs_iso;
+	} else {
+		// ComputeSoundSpeed(cons,i,j,k) (:374-394): P from (rho, E - KE) then cs(rho, P)
+		const double vx = px / rho;
+		const double vy = py / rho;
+		const double vz = pz / rho;
+		const double kinetic_energy = 0.5 * rho * (vx * vx + vy * vy + vz * vz);
+		const double thermal_energy = E - kinetic_energy;
+		const double P = eos.pressure(rho, thermal_energy);
+		cs = eos.soundSpeed(rho, P);
+	}
+	if (which == 0) {
+		const double kinetic_energy = (px * px + py * py + pz * pz) / (2.0 * rho);
+		const double abs_vel = sqrt(2.0 * kinetic_energy / rho);
+		return cs + abs_vel;
+	}
+	const double vx = px / rho;
+	const double vy = py / rho;
+	const double vz = pz / rho;
+	const double vel_mag = sqrt(vx * vx + vy * vy + vz * vz);
+	return cs + vel_mag;
+}
+
+
+// atomic max on a non-negative double through its (order-preserving) bit pattern.  NaNs never win a
+// std::max(result, v) comparison in the reference's serial reduction, so they are skipped here too.
+QK_DEV void atomicMaxNonNeg(double *addr, double v)
+{
+	if (v > 0.0) {
+		atomicMax(reinterpret_cast<unsigned long long *>(addr), static_cast<unsigned long long>(__double_as_longlong(v)));
+	}
+}
+
 } // namespace qk
 
 #endif // QK_DEVICE_HPP_

@@ -51,6 +51,7 @@ struct SweepArgs {
 	qk_iarray4 *redoFlag;
 	unsigned long long *redo_count;
 	int *error_flag;
+	double *max_signal; // optional double[2], see qk_hydro_stage_args::d_max_signal
 	double inv_dx; // 1/dx of the sweep direction
 	double dx;
 	double dt;
@@ -141,7 +142,7 @@ QK_DEV void flattenEdges(double chi, double mean, double &am, double &ap)
 }
 
 // epilogue of one cell (AddInternalEnergyPdV + PredictStep + EnforceLimits + SyncDualEnergy)
-QK_DEV void updateCell(SweepArgs const &a, Eos const &eos, int b, int i, int j, int k, const double rhs[NVAR], double div_v)
+QK_DEV void updateCell(SweepArgs const &a, Eos const &eos, int b, int i, int j, int k, const double rhs[NVAR], double div_v, double &sig0, double &sig1)
 {
 	RA4 Uo(a.U_old[b]);
 	WA4 Un(a.U_out[b]);
@@ -181,6 +182,10 @@ QK_DEV void updateCell(SweepArgs const &a, Eos const &eos, int b, int i, int j, 
 #pragma unroll
 	for (int n = 0; n < NVAR; ++n) {
 		Un.p[cn + Un.ns * n] = U[n];
+	}
+	if (a.max_signal != nullptr) {
+		sig0 = smax(sig0, signalSpeed(eos, 0, U[RHO], U[MX], U[MY], U[MZ], U[ENE]));
+		sig1 = smax(sig1, signalSpeed(eos, 1, U[RHO], U[MX], U[MY], U[MZ], U[ENE]));
 	}
 }
 
@@ -305,11 +310,13 @@ template <int DIR, int ORDER, int STAGE, bool LAST> __global__ void __launch_bou
 	const qk_box bx = a.boxes[b];
 	const SGeom g = a.geom[b];
 	constexpr int OT = (DIR == 1) ? 2 : 1; // the other transverse axis (besides x)
-	const int i = bx.lo[0] + blockIdx.x * 64 + threadIdx.x;
-	const int ot = bx.lo[OT] + blockIdx.y * 4 + threadIdx.y;
-	if (i > bx.hi[0] || ot > bx.hi[OT]) {
-		return;
-	}
+	const int i_raw = bx.lo[0] + blockIdx.x * 64 + threadIdx.x;
+	const int ot_raw = bx.lo[OT] + blockIdx.y * 4 + threadIdx.y;
+	// lanes beyond the box stay in the wave (clamped addresses, masked stores) so that wave reductions are well defined
+	const bool live = (i_raw <= bx.hi[0]) && (ot_raw <= bx.hi[OT]);
+	const int i = min(i_raw, bx.hi[0]);
+	const int ot = min(ot_raw, bx.hi[OT]);
+	double sig0 = 0., sig1 = 0.;
 	const int64_t T = a.total_cells;
 	const int64_t st[3] = {1, g.n[0], static_cast<int64_t>(g.n[0]) * g.n[1]};
 	const int64_t ms = st[DIR]; // march stride
@@ -372,14 +379,16 @@ template <int DIR, int ORDER, int STAGE, bool LAST> __global__ void __launch_bou
 			fidx[OT] = ot;
 			fidx[DIR] = lo + (step - 5);
 			if (STAGE == 1) {
-				WA4 HF(a.halfFlux[b]);
-				WA4 HV(a.halfVel[b]);
-				const int64_t o = HF.idx(fidx[0], fidx[1], fidx[2]);
+				if (live) {
+					WA4 HF(a.halfFlux[b]);
+					WA4 HV(a.halfVel[b]);
+					const int64_t o = HF.idx(fidx[0], fidx[1], fidx[2]);
 #pragma unroll
-				for (int n = 0; n < NVAR; ++n) {
-					HF.p[o + HF.ns * n] = F[n];
+					for (int n = 0; n < NVAR; ++n) {
+						HF.p[o + HF.ns * n] = F[n];
+					}
+					HV(fidx[0], fidx[1], fidx[2]) = vf;
 				}
-				HV(fidx[0], fidx[1], fidx[2]) = vf;
 			} else {
 				RA4 HF(a.halfFlux[b]);
 				RA4 HV(a.halfVel[b]);
@@ -404,8 +413,10 @@ template <int DIR, int ORDER, int STAGE, bool LAST> __global__ void __launch_bou
 					u[0] = i;
 					u[OT] = ot;
 					u[DIR] = lo + (step - 6);
-					updateCell(a, eos, b, u[0], u[1], u[2], rhs, div_v);
-				} else {
+					if (live) {
+						updateCell(a, eos, b, u[0], u[1], u[2], rhs, div_v, sig0, sig1);
+					}
+				} else if (live) {
 #pragma unroll
 					for (int n = 0; n < NVAR; ++n) {
 						Sw[(S_RHS + n) * T + cu] = rhs[n];
@@ -425,6 +436,17 @@ template <int DIR, int ORDER, int STAGE, bool LAST> __global__ void __launch_bou
 		}
 		dVprev = dV;
 		dWprev = dW;
+	}
+	if (LAST && a.max_signal != nullptr) {
+		// wave reduction (64 lanes), one atomic per wave; max is exact, so the result is deterministic
+		for (int off = 32; off > 0; off >>= 1) {
+			sig0 = smax(sig0, __shfl_xor(sig0, off));
+			sig1 = smax(sig1, __shfl_xor(sig1, off));
+		}
+		if (threadIdx.x == 0) {
+			atomicMaxNonNeg(&a.max_signal[0], sig0);
+			atomicMaxNonNeg(&a.max_signal[1], sig1);
+		}
 	}
 }
 
@@ -629,6 +651,7 @@ int qk_hydro_stage_fused(qk_level *lev, qk_stream stream, const qk_hydro_traits 
 	a.redoFlag = args->redoFlag;
 	a.redo_count = reinterpret_cast<unsigned long long *>(args->d_redo_count);
 	a.error_flag = args->d_error_flag;
+	a.max_signal = args->d_max_signal;
 	a.dt = args->dt;
 	a.densityFloor = args->densityFloor;
 	a.tempFloor = args->tempFloor;

@@ -207,6 +207,9 @@ class HydroSimulation:
         self.dev_counters = torch.zeros(2, dtype=torch.int64, device=ctx.device)  # [redo_count, (unused)]
         self.dev_error = torch.zeros(1, dtype=torch.int32, device=ctx.device)
         self.dev_max = torch.zeros(1, dtype=torch.float64, device=ctx.device)
+        # [0] max(cs + sqrt(2KE/rho)), [1] max(cs + |v|) over state_new_cc_, written by the final fused stage
+        self.dev_signal = torch.zeros(2, dtype=torch.float64, device=ctx.device)
+        self._signal_of_state_new = None  # (sig0, sig1) if the device values describe the current state_new_cc_
         self.scratch = None
         if self.use_fused:
             nbytes = ctx.L.qk_hydro_stage_scratch_bytes(lev.h, C.byref(traits))
@@ -251,7 +254,10 @@ class HydroSimulation:
 
     # ------------------------------------------------------------------ time step control
     def computeTimestepAtLevel(self) -> float:
-        m = float(self.hydro.maxSignalSpeedLocal(self.lev, self.state_new_cc_, which=1, out=self.dev_max).item())
+        if self._signal_of_state_new is not None:
+            m = self._signal_of_state_new[1]
+        else:
+            m = float(self.hydro.maxSignalSpeedLocal(self.lev, self.state_new_cc_, which=1, out=self.dev_max).item())
         m = self._allreduce_max(m)
         return self.cflNumber_ * (self.min_dx() / m)
 
@@ -270,7 +276,10 @@ class HydroSimulation:
         self.dt_ = dt_0
 
     def isCflViolated(self, dt_actual: float) -> bool:
-        m = float(self.hydro.maxSignalSpeedLocal(self.lev, self.state_new_cc_, which=0, out=self.dev_max).item())
+        if self._signal_of_state_new is not None:
+            m = self._signal_of_state_new[0]
+        else:
+            m = float(self.hydro.maxSignalSpeedLocal(self.lev, self.state_new_cc_, which=0, out=self.dev_max).item())
         m = self._allreduce_max(m)
         dt_cfl = self.cflNumber_ * (self.min_dx() / m)
         return dt_actual > 1.1 * dt_cfl
@@ -387,13 +396,21 @@ class HydroSimulation:
         self.dev_counters.zero_()
         a.d_redo_count = C.c_void_p(self.dev_counters.data_ptr())
         a.d_error_flag = C.c_void_p(self.dev_error.data_ptr())
+        final = (stage == 2) or (self.integratorOrder_ == 1)
+        if final:
+            self.dev_signal.zero_()
+            a.d_max_signal = C.c_void_p(self.dev_signal.data_ptr())
         a.scratch = C.c_void_p(self.scratch.data_ptr())
         a.scratch_bytes = self.scratch.numel() * 8
         a.dt, a.stage, a.reconstruction_order = dt, stage, self.reconstructionOrder_
         a.densityFloor, a.tempFloor, a.use_dual_energy, a.K_visc = self.densityFloor_, self.tempFloor_, self.useDualEnergy_, 0.0
         c = self.ctx
         c.check(c.L.qk_hydro_stage_fused(self.lev.h, c.stream(), C.byref(self.traits), C.byref(a)), "qk_hydro_stage_fused")
-        return self._allreduce_sum(int(self.dev_counters[0].item()))
+        nbad = self._allreduce_sum(int(self.dev_counters[0].item()))
+        if final and nbad == 0:
+            sig = self.dev_signal.tolist()
+            self._signal_of_state_new = (sig[0], sig[1])
+        return nbad
 
     def _stage(self, stage, U_in, U_old, U_out, dt) -> bool:
         if self.use_fused and self.artificialViscosityK_ == 0.0:
@@ -405,6 +422,7 @@ class HydroSimulation:
 
     # ------------------------------------------------------------------ advance
     def advanceHydroAtLevel(self, state_old_tmp: MultiFab, dt_lev: float) -> bool:
+        self._signal_of_state_new = None  # state_new_cc_ is about to be overwritten
         self.fillBoundaryConditions(state_old_tmp)
         if not self._stage(1, state_old_tmp, state_old_tmp, self.state_inter_cc_, dt_lev):
             return False
@@ -427,11 +445,16 @@ class HydroSimulation:
             dt_step = dt_lev / nsubsteps
             if retry_count > 0:
                 self.counters["retries"] += 1
-            self.state_old_tmp.copy_from(self.state_old_cc_)
+            # The reference advances a ghost-filled COPY of the old state (QuokkaSimulation.hpp:939-940).  The advance
+            # only ever writes the ghost cells of that array, so the first attempt works on state_old_cc_ in place and
+            # the 966 MB copy is paid only by retries with substeps.
+            old = self.state_old_cc_ if nsubsteps == 1 else self.state_old_tmp
+            if nsubsteps > 1:
+                self.state_old_tmp.copy_from(self.state_old_cc_)
             for substep in range(nsubsteps):
                 if substep > 0:
                     self.state_old_tmp.copy_from(self.state_new_cc_)
-                success = self.advanceHydroAtLevel(self.state_old_tmp, dt_step)
+                success = self.advanceHydroAtLevel(old, dt_step)
                 if not success:
                     break
             if success:
