@@ -25,6 +25,7 @@
 #include "boundary.hpp"
 #include "grid.hpp"
 #include "hydro.hpp"
+#include "radiation.hpp"
 
 namespace oracle
 {
@@ -55,6 +56,18 @@ struct HydroSim {
 	int abortOnFofcFailure_ = 1;		 // :140
 	double artificialViscosityK_ = 0.;	 // :141
 	int verbose = 0;
+
+	// --- radiation (QuokkaSimulation.hpp:125-133; Physics_Traits::is_radiation_enabled) ---
+	bool is_radiation_enabled = false;
+	RadSystem rad;
+	double radiationCflNumber_ = 0.3;
+	int maxSubsteps_ = 10;
+	int radiationReconstructionOrder_ = 3;
+	// RadSystem<problem_t>::SetRadEnergySource(radEnergySource, indexRange, dx, prob_lo, prob_hi, time): user hook
+	std::function<void(Array4<double> const &, Box const &, Geometry const &, double)> SetRadEnergySource;
+	long radiationCellUpdates_ = 0;
+	long rad_iteration_counter[4] = {0, 0, 0, 0};	      // solves, Newton iterations, max Newton iterations, (decoupled)
+	long rad_iteration_failure_counter[3] = {0, 0, 0}; // coupling, dust, outer
 
 	// --- state ---
 	MultiFab state_old_cc_;
@@ -481,6 +494,11 @@ struct HydroSim {
 			Fab<double> maxSignal(grids[b], 1);
 			hydro.ComputeMaxSignalSpeed(state_new_cc_.const_array(b), maxSignal.array(), grids[b]);
 			for (double v : maxSignal.d) {
+				if (is_radiation_enabled) {
+					// QuokkaSimulation.hpp:421-434: RadSystem::ComputeMaxSignalSpeed = c_hat (radiation_system.hpp:616-624)
+					const double maxSignalRadiation = rad.rt.c_hat / static_cast<double>(maxSubsteps_);
+					v = std::max(maxSignalRadiation, v);
+				}
 				domain_signal_max = std::max(domain_signal_max, std::abs(v));
 			}
 		}
@@ -511,6 +529,153 @@ struct HydroSim {
 		dt_ = dt_0;
 	}
 
+
+	// ------------------------------------------------------------------ radiation (QuokkaSimulation.hpp:397-406, 1570-1961)
+	[[nodiscard]] auto computeNumberOfRadiationSubsteps(double dt_lev_hydro) const -> int
+	{
+		double const c_hat = rad.rt.c_hat;
+		double const dx_min = minDx();
+		double const dtrad_tmp = radiationCflNumber_ * (dx_min / c_hat);
+		int const nsubSteps = static_cast<int>(std::ceil(dt_lev_hydro / dtrad_tmp));
+		return nsubSteps;
+	}
+
+	// fluxFunction<DIR> + computeRadiationFluxes for one box (QuokkaSimulation.hpp:1884-1961)
+	struct RadFluxes {
+		std::array<Fab<double>, 3> flux, fluxDiffusive;
+	};
+	[[nodiscard]] auto computeRadiationFluxes(Array4<const double> const &consVar, Box const &indexRange) const -> RadFluxes
+	{
+		RadFluxes out;
+		const int nvars = kNumRadVars;
+		for (int dir = 0; dir < ndim(); ++dir) {
+			Box const ghostRange = grow(indexRange, nghost_cc, ndim());
+			Box const reconstructRange = grow(indexRange, 1, ndim());
+			Box const x1ReconstructRange = faceBox(reconstructRange, dir);
+			Fab<double> primVar(ghostRange, nvars);
+			Fab<double> x1LeftState(x1ReconstructRange, nvars);
+			Fab<double> x1RightState(x1ReconstructRange, nvars);
+			rad.ConservedToPrimitive(consVar, primVar.array(), ghostRange);
+			if (radiationReconstructionOrder_ == 3) {
+				ReconstructStatesPPM(dir, primVar.const_array(), x1LeftState.array(), x1RightState.array(), reconstructRange, nvars);
+			} else if (radiationReconstructionOrder_ == 2) {
+				ReconstructStatesPLM(dir, lim_MC, primVar.const_array(), x1LeftState.array(), x1RightState.array(), x1ReconstructRange, nvars);
+			} else {
+				ReconstructStatesConstant(dir, primVar.const_array(), x1LeftState.array(), x1RightState.array(), x1ReconstructRange, nvars);
+			}
+			Box const x1FluxRange = faceBox(indexRange, dir);
+			out.flux[dir] = Fab<double>(x1FluxRange, nvars);
+			out.fluxDiffusive[dir] = Fab<double>(x1FluxRange, nvars);
+			rad.ComputeFluxes(dir, out.flux[dir].array(), out.fluxDiffusive[dir].array(), x1LeftState.const_array(), x1RightState.const_array(),
+					  x1FluxRange, consVar);
+		}
+		return out;
+	}
+
+	// QuokkaSimulation.hpp:1790-1821
+	void advanceRadiationForwardEuler(double time, double dt_radiation)
+	{
+		fillBC(state_old_cc_, time);
+		_Pragma("omp parallel for schedule(dynamic)")
+		for (int b = 0; b < state_new_cc_.size(); ++b) {
+			auto fl = computeRadiationFluxes(state_old_cc_.const_array(b), grids[b]);
+			std::array<Array4<const double>, 3> f{};
+			for (int d = 0; d < ndim(); ++d) {
+				f[d] = fl.flux[d].const_array();
+			}
+			rad.PredictStep(state_old_cc_.const_array(b), state_new_cc_.array(b), f, dt_radiation, geom.dx, grids[b]);
+		}
+	}
+
+	// QuokkaSimulation.hpp:1823-1857
+	void advanceRadiationMidpointRK2(double time, double dt_radiation)
+	{
+		fillBC(state_new_cc_, time + dt_radiation);
+		_Pragma("omp parallel for schedule(dynamic)")
+		for (int b = 0; b < state_new_cc_.size(); ++b) {
+			auto flOld = computeRadiationFluxes(state_old_cc_.const_array(b), grids[b]);
+			auto fl = computeRadiationFluxes(state_new_cc_.const_array(b), grids[b]);
+			std::array<Array4<const double>, 3> f0{}, f1{};
+			for (int d = 0; d < ndim(); ++d) {
+				f0[d] = flOld.flux[d].const_array();
+				f1[d] = fl.flux[d].const_array();
+			}
+			rad.AddFluxesRK2(state_new_cc_.array(b), state_old_cc_.const_array(b), state_new_cc_.const_array(b), f0, f1, dt_radiation, geom.dx,
+					 grids[b]);
+		}
+	}
+
+	// QuokkaSimulation.hpp:1859-1882
+	void operatorSplitSourceTerms(double time, double dt, int stage)
+	{
+		for (int b = 0; b < state_new_cc_.size(); ++b) {
+			Fab<double> radEnergySource(grids[b], 1, 0.0);
+			if (SetRadEnergySource) {
+				SetRadEnergySource(radEnergySource.array(), grids[b], geom, time + dt);
+			}
+			int counter[4] = {0, 0, 0, 0};
+			int failure[3] = {0, 0, 0};
+			rad.AddSourceTermsSingleGroup(state_new_cc_.array(b), radEnergySource.const_array(), grids[b], dt, stage, counter, failure);
+			rad_iteration_counter[0] += counter[0];
+			rad_iteration_counter[1] += counter[1];
+			rad_iteration_counter[2] = std::max<long>(rad_iteration_counter[2], counter[2]);
+			for (int n = 0; n < 3; ++n) {
+				rad_iteration_failure_counter[n] += failure[n];
+			}
+		}
+	}
+
+	// QuokkaSimulation.hpp:1576-1722
+	auto subcycleRadiationAtLevel(double time, double dt_lev_hydro) -> bool
+	{
+		int nsubSteps = 0;
+		double dt_radiation = NAN;
+		if (!(constantDt_ > 0.)) {
+			nsubSteps = computeNumberOfRadiationSubsteps(dt_lev_hydro);
+			dt_radiation = dt_lev_hydro / static_cast<double>(nsubSteps);
+		} else {
+			dt_radiation = dt_lev_hydro;
+			nsubSteps = 1;
+		}
+		if (!(nsubSteps >= 1 && nsubSteps <= (maxSubsteps_ + 1) && dt_radiation > 0.0)) {
+			std::fprintf(stderr, "radiation substep assertion failed: nsubSteps = %d\n", nsubSteps);
+			return false;
+		}
+		double time_subcycle = time;
+		for (int i = 0; i < nsubSteps; ++i) {
+			if (i > 0) {
+				// swapRadiationState (:1570-1574): copy radiation comps of the valid region new -> old
+				for (int b = 0; b < state_old_cc_.size(); ++b) {
+					auto d = state_old_cc_.array(b);
+					auto s = state_new_cc_.const_array(b);
+					Box const &r = grids[b];
+					for (int n = rad.nstartHyperbolic_; n < rad.nstartHyperbolic_ + kNumRadVars; ++n) {
+						for (int k = r.lo[2]; k <= r.hi[2]; ++k) {
+							for (int j = r.lo[1]; j <= r.hi[1]; ++j) {
+								for (int ii = r.lo[0]; ii <= r.hi[0]; ++ii) {
+									d(ii, j, k, n) = s(ii, j, k, n);
+								}
+							}
+						}
+					}
+				}
+			}
+			advanceRadiationForwardEuler(time_subcycle, dt_radiation);
+			if (IMEX_a22 > 0.0) {
+				operatorSplitSourceTerms(time_subcycle, dt_radiation, 1);
+			}
+			advanceRadiationMidpointRK2(time_subcycle, dt_radiation);
+			operatorSplitSourceTerms(time_subcycle, dt_radiation, 2);
+			if (rad_iteration_failure_counter[0] > 0 || rad_iteration_failure_counter[1] > 0 || rad_iteration_failure_counter[2] > 0) {
+				std::fprintf(stderr, "Newton-Raphson / outer iteration for matter-radiation coupling failed to converge!\n");
+				return false;
+			}
+			time_subcycle += dt_radiation;
+			radiationCellUpdates_ += CountCells();
+		}
+		return true;
+	}
+
 	// one coarse step: simulation.hpp:866-890 + :1276-1286 + QuokkaSimulation.hpp:653-707
 	auto step() -> bool
 	{
@@ -518,7 +683,10 @@ struct HydroSim {
 		double const time = tNew_;
 		tNew_ += dt_;
 		std::swap(state_old_cc_, state_new_cc_);
-		bool const ok = advanceHydroAtLevelWithRetries(time, dt_);
+		bool ok = advanceHydroAtLevelWithRetries(time, dt_);
+		if (ok && is_radiation_enabled) {
+			ok = subcycleRadiationAtLevel(time, dt_); // QuokkaSimulation.hpp:689-692
+		}
 		++istep;
 		cellUpdates_ += CountCells();
 		return ok;

@@ -107,6 +107,10 @@ struct orc_sim_config {
 	long max_timesteps;
 	int reconstruction_order;
 	int nscalars;
+	// problem 3 (radiation-driven shell): the three columns of extern/dust_shell/initial_conditions.txt
+	int table_len;
+	double const *table_r, *table_Erad, *table_Frad;
+	int rad_pow_mode; // RadTraits::pow_mode
 };
 
 void *orc_sim_create(orc_sim_config const *c)
@@ -119,6 +123,9 @@ void *orc_sim_create(orc_sim_config const *c)
 		setupContact(*sim, c->nscalars > 0 ? c->nscalars : 0);
 	} else if (c->problem == 2) {
 		setupSedov(*sim);
+	} else if (c->problem == 3) {
+		setupShell(*sim, c->table_len, c->table_r, c->table_Erad, c->table_Frad);
+		sim->rad.rt.pow_mode = c->rad_pow_mode;
 	} else {
 		return nullptr;
 	}
@@ -206,6 +213,29 @@ int orc_sim_advance_fixed_dt(void *p, double dt)
 	++s->istep;
 	s->cellUpdates_ += s->CountCells();
 	return ok ? 1 : 0;
+}
+void orc_sim_rad_counters(void *p, long out[8])
+{
+	auto *s = static_cast<HydroSim *>(p);
+	for (int n = 0; n < 4; ++n) {
+		out[n] = s->rad_iteration_counter[n];
+	}
+	for (int n = 0; n < 3; ++n) {
+		out[4 + n] = s->rad_iteration_failure_counter[n];
+	}
+	out[7] = s->radiationCellUpdates_;
+}
+// fills `out` (valid box of box b, 1 comp) with SetRadEnergySource at `time`
+void orc_sim_rad_source(void *p, int b, double time, double *out)
+{
+	auto *s = static_cast<HydroSim *>(p);
+	Array4<double> a(out, s->grids[b], 1);
+	for (int64_t n = 0; n < s->grids[b].numPts(); ++n) {
+		out[n] = 0.0;
+	}
+	if (s->SetRadEnergySource) {
+		s->SetRadEnergySource(a, s->grids[b], s->geom, time);
+	}
 }
 int orc_sim_evolve(void *p) { return static_cast<HydroSim *>(p)->evolve() ? 1 : 0; }
 

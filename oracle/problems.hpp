@@ -227,6 +227,198 @@ inline void setupSedov(HydroSim &sim)
 	sim.finishInitialConditions();
 }
 
+// ---------------------------------------------------------------- math/interpolate.cpp:32-158
+inline auto binary_search_with_guess(const double key, const double *arr, int64_t len, int64_t guess) -> int64_t
+{
+	constexpr int64_t LIKELY_IN_CACHE_SIZE = 8;
+	int64_t imin = 0;
+	int64_t imax = len;
+	if (key > arr[len - 1]) {
+		return len;
+	}
+	if (key < arr[0]) {
+		return -1;
+	}
+	if (len <= 4) {
+		int64_t i = 1;
+		for (; i < len && key >= arr[i]; ++i) {
+		}
+		return i - 1;
+	}
+	if (guess > len - 3) {
+		guess = len - 3;
+	}
+	if (guess < 1) {
+		guess = 1;
+	}
+	if (key < arr[guess]) {
+		if (key < arr[guess - 1]) {
+			imax = guess - 1;
+			if (guess > LIKELY_IN_CACHE_SIZE && key >= arr[guess - LIKELY_IN_CACHE_SIZE]) {
+				imin = guess - LIKELY_IN_CACHE_SIZE;
+			}
+		} else {
+			return guess - 1;
+		}
+	} else {
+		if (key < arr[guess + 1]) {
+			return guess;
+		}
+		if (key < arr[guess + 2]) {
+			return guess + 1;
+		}
+		imin = guess + 2;
+		if (guess < len - LIKELY_IN_CACHE_SIZE - 1 && key < arr[guess + LIKELY_IN_CACHE_SIZE]) {
+			imax = guess + LIKELY_IN_CACHE_SIZE;
+		}
+	}
+	while (imin < imax) {
+		const int64_t imid = imin + ((imax - imin) >> 1);
+		if (key >= arr[imid]) {
+			imin = imid + 1;
+		} else {
+			imax = imid;
+		}
+	}
+	return imin - 1;
+}
+
+inline auto interpolate_value(double x, double const *arr_x, double const *arr_y, int arr_len) -> double
+{
+	int64_t j = binary_search_with_guess(x, arr_x, arr_len, 0);
+	double y = NAN;
+	if (j == -1) {
+		y = NAN;
+	} else if (j == arr_len) {
+		y = NAN;
+	} else if (j == arr_len - 1) {
+		y = arr_y[j];
+	} else if (x == arr_x[j]) {
+		y = arr_y[j];
+	} else {
+		const double slope = (arr_y[j + 1] - arr_y[j]) / (arr_x[j + 1] - arr_x[j]);
+		y = slope * (x - arr_x[j]) + arr_y[j];
+	}
+	return y;
+}
+
+// ---------------------------------------------------------------- radiation-driven shell
+// reference src/problems/RadhydroShell/test_radhydro_shell.cpp:34-260,363-443, tests/radhydro_shell_256.in
+struct ShellConstants {
+	static constexpr double a_rad = 7.5646e-15;
+	static constexpr double c = 2.99792458e10;
+	static constexpr double a0 = 2.0e5;
+	static constexpr double chat = 860. * a0;
+	static constexpr double gamma_gas = 5. / 3.;
+	static constexpr double Msun = 2.0e33;
+	static constexpr double parsec_in_cm = 3.086e18;
+	static constexpr double specific_luminosity = 2000.;
+	static constexpr double GMC_mass = 1.0e6 * Msun;
+	static constexpr double epsilon = 0.5;
+	static constexpr double M_shell = (1 - epsilon) * GMC_mass;
+	static constexpr double L_star = (epsilon * GMC_mass) * specific_luminosity;
+	static constexpr double r_0 = 5.0 * parsec_in_cm;
+	static constexpr double sigma_star = 0.3 * r_0;
+	static constexpr double H_shell = 0.3 * r_0;
+	static constexpr double kappa0 = 20.0;
+	static constexpr double rho_0 = M_shell / ((4. / 3.) * M_PI * r_0 * r_0 * r_0);
+	static constexpr double P_0 = gamma_gas * rho_0 * (a0 * a0);
+	static constexpr double c_v = C::k_B / ((2.2 * C::m_u) * (gamma_gas - 1.0));
+};
+
+// r_over_r0, Erad, Frad columns of extern/dust_shell/initial_conditions.txt (rows = table_len)
+inline void setupShell(HydroSim &sim, int table_len, double const *r_over_r0, double const *Erad_tab, double const *Frad_tab)
+{
+	using S = ShellConstants;
+	sim.hydro.tr.eos.tr.gamma = S::gamma_gas; // :46-50
+	sim.hydro.tr.eos.tr.mean_molecular_weight = 2.2 * C::m_u;
+	sim.hydro.tr.eos.tr.boltzmann_constant = C::k_B;
+	sim.hydro.tr.reconstruct_eint = false; // :60-62
+	sim.hydro.tr.nscalars = 0;
+	sim.ncomp_cc = kNumHydroVars + kNumRadVars;
+	sim.is_radiation_enabled = true;
+	sim.rad.rt.c_light = S::c; // :52-58
+	sim.rad.rt.c_hat = S::chat;
+	sim.rad.rt.radiation_constant = S::a_rad;
+	sim.rad.rt.Erad_floor = 0.;
+	sim.rad.rt.beta_order = 1;
+	sim.rad.eos = sim.hydro.tr.eos;
+	sim.rad.ndim = sim.geom.ndim;
+	sim.rad.nstartHyperbolic_ = kNumHydroVars;
+	// :127-136 (ComputeEnergyMeanOpacity is not specialised -> Planck)
+	sim.rad.ComputePlanckOpacity = [](double, double) { return S::kappa0; };
+	sim.rad.ComputeFluxMeanOpacity = [](double, double) { return S::kappa0; };
+	sim.rad.ComputeEnergyMeanOpacity = [](double, double) { return S::kappa0; };
+
+	sim.BCs_cc.assign(sim.ncomp_cc, BCRec{}); // periodic (:389-394)
+	// :409-431
+	sim.cflNumber_ = 0.3;
+	sim.densityFloor_ = 1.0e-8 * S::rho_0;
+	sim.reconstructionOrder_ = 2;
+	sim.radiationReconstructionOrder_ = 2;
+	sim.integratorOrder_ = 2;
+	sim.stopTime_ = 0.125 * (S::r_0 / S::a0);
+	sim.maxTimesteps_ = 50;
+
+	// :98-125 point-like source
+	sim.SetRadEnergySource = [](Array4<double> const &radEnergy, Box const &indexRange, Geometry const &g, double /*time*/) {
+		const double x0 = g.prob_lo[0] + 0.5 * (g.prob_hi[0] - g.prob_lo[0]);
+		const double y0 = g.prob_lo[1] + 0.5 * (g.prob_hi[1] - g.prob_lo[1]);
+		const double z0 = g.prob_lo[2] + 0.5 * (g.prob_hi[2] - g.prob_lo[2]);
+		const double source_norm = (1.0 / S::c) * S::L_star / std::pow(2.0 * M_PI * S::sigma_star * S::sigma_star, 1.5);
+		for (int k = indexRange.lo[2]; k <= indexRange.hi[2]; ++k) {
+			for (int j = indexRange.lo[1]; j <= indexRange.hi[1]; ++j) {
+				for (int i = indexRange.lo[0]; i <= indexRange.hi[0]; ++i) {
+					double const x = g.prob_lo[0] + (i + 0.5) * g.dx[0];
+					double const y = g.prob_lo[1] + (j + 0.5) * g.dx[1];
+					double const z = g.prob_lo[2] + (k + 0.5) * g.dx[2];
+					double const r = std::sqrt((x - x0) * (x - x0) + (y - y0) * (y - y0) + (z - z0) * (z - z0));
+					radEnergy(i, j, k) = source_norm * std::exp(-(r * r) / (2.0 * S::sigma_star * S::sigma_star));
+				}
+			}
+		}
+	};
+
+	sim.define();
+	// preCalculateInitialConditions :149-183
+	std::vector<double> r_arr(table_len), E_arr(Erad_tab, Erad_tab + table_len), F_arr(Frad_tab, Frad_tab + table_len);
+	for (int n = 0; n < table_len; ++n) {
+		r_arr[n] = r_over_r0[n] * S::r_0;
+	}
+	// setInitialConditionsOnGrid :185-249
+	Geometry const g = sim.geom;
+	forEachValidCell(sim, [&](Array4<double> const &state_cc, int i, int j, int k) {
+		const double x0 = g.prob_lo[0] + 0.5 * (g.prob_hi[0] - g.prob_lo[0]);
+		const double y0 = g.prob_lo[1] + 0.5 * (g.prob_hi[1] - g.prob_lo[1]);
+		const double z0 = g.prob_lo[2] + 0.5 * (g.prob_hi[2] - g.prob_lo[2]);
+		double const x = g.prob_lo[0] + (i + 0.5) * g.dx[0];
+		double const y = g.prob_lo[1] + (j + 0.5) * g.dx[1];
+		double const z = g.prob_lo[2] + (k + 0.5) * g.dx[2];
+		double const r = std::sqrt((x - x0) * (x - x0) + (y - y0) * (y - y0) + (z - z0) * (z - z0));
+		double sigma_sh = S::H_shell / (2.0 * std::sqrt(2.0 * std::log(2.0)));
+		double rho_norm = S::M_shell / (4.0 * M_PI * r * r * std::sqrt(2.0 * M_PI * sigma_sh * sigma_sh));
+		double rho_shell = rho_norm * std::exp(-((r - S::r_0) * (r - S::r_0)) / (2.0 * sigma_sh * sigma_sh));
+		double rho = std::max(rho_shell, 1.0e-8 * S::rho_0);
+		const double Frad = interpolate_value(r, r_arr.data(), F_arr.data(), table_len);
+		const double Erad = interpolate_value(r, r_arr.data(), E_arr.data(), table_len);
+		const double Trad = std::pow(Erad / S::a_rad, 1. / 4.);
+		const double Tgas = Trad;
+		const double Eint = rho * S::c_v * Tgas;
+		for (int n = 0; n < state_cc.ncomp; ++n) {
+			state_cc(i, j, k, n) = 0.;
+		}
+		state_cc(i, j, k, density_index) = rho;
+		state_cc(i, j, k, energy_index) = Eint;
+		const double Frad_xyz = Frad / std::sqrt(3.0);
+		state_cc(i, j, k, internalEnergy_index) = Eint;
+		state_cc(i, j, k, kNumHydroVars + 0) = Erad;
+		state_cc(i, j, k, kNumHydroVars + 1) = Frad_xyz;
+		state_cc(i, j, k, kNumHydroVars + 2) = Frad_xyz;
+		state_cc(i, j, k, kNumHydroVars + 3) = Frad_xyz;
+	});
+	sim.finishInitialConditions();
+}
+
 } // namespace oracle
 
 #endif // ORACLE_PROBLEMS_HPP_

@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 K_B = 1.380649e-16
 M_U = 1.6605390666e-24
 
-SOD, CONTACT, SEDOV = 0, 1, 2
+SOD, CONTACT, SEDOV, SHELL = 0, 1, 2, 3
 
 
 def build(force: bool = False) -> None:
@@ -60,6 +60,11 @@ class SimConfig(C.Structure):
         ("max_timesteps", C.c_long),
         ("reconstruction_order", C.c_int),
         ("nscalars", C.c_int),
+        ("table_len", C.c_int),
+        ("table_r", C.POINTER(C.c_double)),
+        ("table_Erad", C.POINTER(C.c_double)),
+        ("table_Frad", C.POINTER(C.c_double)),
+        ("rad_pow_mode", C.c_int),
     ]
 
 
@@ -102,6 +107,8 @@ class Oracle:
         L.orc_sim_advance_fixed_dt.argtypes = [C.c_void_p, C.c_double]
         L.orc_sim_advance_fixed_dt.restype = C.c_int
         L.orc_eos_variant.restype = C.c_int
+        L.orc_sim_rad_counters.argtypes = [C.c_void_p, C.c_long * 8]
+        L.orc_sim_rad_source.argtypes = [C.c_void_p, C.c_int, C.c_double, C.POINTER(C.c_double)]
 
     # ---------------------------------------------------------------- per-operator
     def cons_to_prim(self, t: HydroTraits, cons: np.ndarray, glo, ghi) -> np.ndarray:
@@ -134,12 +141,18 @@ class Oracle:
 
     # ---------------------------------------------------------------- whole simulation
     def sim(self, problem, ndim, n_cell, prob_lo, prob_hi, periodic, max_grid_size=None, cfl=-1.0, stop_time=-1.0,
-            max_timesteps=-1, reconstruction_order=-1, nscalars=0) -> "OracleSim":
+            max_timesteps=-1, reconstruction_order=-1, nscalars=0, table=None, rad_pow_mode=0) -> "OracleSim":
         n_cell = list(n_cell) + [1] * (3 - len(n_cell))
         mgs = list(max_grid_size) if max_grid_size is not None else list(n_cell)
         mgs = mgs + [1] * (3 - len(mgs))
         cfg = SimConfig(problem, ndim, _i3(n_cell), _i3(mgs), (C.c_double * 3)(*prob_lo), (C.c_double * 3)(*prob_hi), _i3(periodic),
                         cfl, stop_time, max_timesteps, reconstruction_order, nscalars)
+        if table is not None:  # (r_over_r0, Erad, Frad) columns
+            cols = [np.ascontiguousarray(c, dtype=np.float64) for c in table]
+            cfg.table_len = len(cols[0])
+            cfg.table_r, cfg.table_Erad, cfg.table_Frad = (_dp(c) for c in cols)
+            self._keepalive = cols
+        cfg.rad_pow_mode = rad_pow_mode
         h = self.lib.orc_sim_create(C.byref(cfg))
         assert h, "oracle: unknown problem"
         return OracleSim(self, h, ndim)
@@ -222,6 +235,18 @@ class OracleSim:
 
     def evolve(self) -> bool:
         return bool(self.o.lib.orc_sim_evolve(self.h))
+
+    def rad_counters(self):
+        out = (C.c_long * 8)()
+        self.o.lib.orc_sim_rad_counters(self.h, out)
+        keys = ["solves", "newton_iterations", "max_newton_iterations", "decoupled", "fail_coupling", "fail_dust", "fail_outer", "rad_cell_updates"]
+        return dict(zip(keys, list(out)))
+
+    def rad_source(self, b=0, time=0.0) -> np.ndarray:
+        lo, hi = self.box(b)
+        a = np.empty((hi[2] - lo[2] + 1, hi[1] - lo[1] + 1, hi[0] - lo[0] + 1), dtype=np.float64)
+        self.o.lib.orc_sim_rad_source(self.h, b, C.c_double(time), _dp(a))
+        return a
 
     def counters(self):
         out = (C.c_long * 3)()
