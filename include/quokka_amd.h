@@ -197,6 +197,41 @@ typedef struct qk_hydro_stage_args {
 int64_t qk_hydro_stage_scratch_bytes(qk_level *lev, const qk_hydro_traits *t);
 int qk_hydro_stage_fused(qk_level *lev, qk_stream s, const qk_hydro_traits *t, const qk_hydro_stage_args *a);
 
+/* ------------------------------------------------------------------ RadSystem<problem_t> (single group, M1 closure) */
+/* RadSystem_Traits<P> (reference src/radiation/radiation_system.hpp:73-82) + the device hooks a problem specialises
+ * (ComputePlanckOpacity / ComputeEnergyMeanOpacity / ComputeFluxMeanOpacity, :1141-1154) as a closed parametrised set. */
+typedef struct qk_rad_traits {
+	double c_light, c_hat, radiation_constant, Erad_floor;
+	int beta_order;	   /* 0..3 */
+	int opacity_model; /* 0: constants kappaP, kappaE, kappaF [cm^2 g^-1] (what RadhydroShell needs) */
+	double kappaP, kappaE, kappaF;
+	int pow_mode; /* 0: pow(T,4), pow(T,3) as the reference's std::pow; 1: repeated multiplication (bit-level tests) */
+} qk_rad_traits;
+/* State layout: Physics_Indices (reference src/physics_info.hpp:20-47): comps 0..5 hydro, 6..9 = (E_r, F_x, F_y, F_z). */
+
+/* ConservedToPrimitive(cons, primVar, indexRange = valid grown by nghost); primVar has 4 comps   reference src/radiation/radiation_system.hpp:589-614 */
+int qk_rad_ConservedToPrimitive(qk_level *lev, qk_stream s, const qk_rad_traits *rt, const qk_array4 *cons, qk_array4 *primVar, int nghost);
+/* ComputeFluxes<DIR>(x1Flux, x1FluxDiffusive (unused downstream: not produced), x1LeftState, x1RightState, x1FluxRange, consVar, dx,
+ * use_wavespeed_correction = false)                                                              reference src/radiation/radiation_system.hpp:985-1139 */
+int qk_rad_ComputeFluxes(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int dir, qk_array4 *x1Flux, const qk_array4 *x1LeftState,
+			 const qk_array4 *x1RightState, const qk_array4 *consVar);
+/* computeRadiationFluxes + fluxFunction<DIR> fused: cons -> (prim, reconstruction of `order` 1/2(MC)/3, HLL flux) in one kernel per direction
+ *                                                                                                reference src/QuokkaSimulation.hpp:1884-1961 */
+int qk_rad_computeRadiationFluxes(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int ndim, int reconstruction_order, const qk_array4 *consVar,
+				  qk_array4 *const flux[3]);
+/* PredictStep(consVarOld, consVarNew, fluxArray, dt, dx, indexRange)                             reference src/radiation/radiation_system.hpp:667-710 */
+int qk_rad_PredictStep(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int ndim, const qk_array4 *consVarOld, qk_array4 *consVarNew,
+		       const qk_array4 *const fluxArray[3], double dt, const double dx[3]);
+/* AddFluxesRK2(U_new, U0, U1, fluxArrayOld, fluxArray, dt, dx, indexRange)                       reference src/radiation/radiation_system.hpp:712-771 */
+int qk_rad_AddFluxesRK2(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int ndim, qk_array4 *U_new, const qk_array4 *U0, const qk_array4 *U1,
+			const qk_array4 *const fluxArrayOld[3], const qk_array4 *const fluxArray[3], double dt, const double dx[3]);
+/* AddSourceTermsSingleGroup(consVar, radEnergySource, indexRange, dt, stage, dustGasCoeff, p_iteration_counter, p_iteration_failure_counter)
+ *                                                                                                reference src/radiation/source_terms_single_group.hpp:10-564
+ * d_iteration_counter: device int[4] (solves, Newton iterations, max Newton iterations, unused); d_failure_counter: device int[3]
+ * (Newton failures, dust (unused), outer-iteration failures) — counted, never aborted, exactly as the reference. */
+int qk_rad_AddSourceTermsSingleGroup(qk_level *lev, qk_stream s, const qk_rad_traits *rt, const qk_hydro_traits *t, qk_array4 *consVar,
+				     const qk_array4 *radEnergySource, double dt, int stage, int *d_iteration_counter, int *d_failure_counter);
+
 /* ------------------------------------------------------------------ level-0 ghost fill */
 /* AMRSimulation::fillBoundaryConditions, level-0 branch                     reference src/simulation.hpp:1751-1776
  *   1. state.FillBoundary(geom.periodicity()) for neighbours on the same GPU (copy kernel)

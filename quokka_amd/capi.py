@@ -49,6 +49,12 @@ class DirichletFace(C.Structure):
     _fields_ = [("enabled", C.c_int), ("values", C.c_double * 16)]
 
 
+class RadTraits(C.Structure):
+    _fields_ = [("c_light", C.c_double), ("c_hat", C.c_double), ("radiation_constant", C.c_double), ("Erad_floor", C.c_double),
+                ("beta_order", C.c_int), ("opacity_model", C.c_int), ("kappaP", C.c_double), ("kappaE", C.c_double), ("kappaF", C.c_double),
+                ("pow_mode", C.c_int)]
+
+
 class StageArgs(C.Structure):
     _fields_ = [("U_in", C.c_void_p), ("U_old", C.c_void_p), ("U_out", C.c_void_p),
                 ("halfFlux", C.c_void_p * 3), ("halfVel", C.c_void_p * 3),
@@ -111,6 +117,13 @@ def lib() -> C.CDLL:
     L.qk_hydro_maxSignalSpeedLocal.argtypes = [vp, vp, T, ci, vp, vp]
     L.qk_replaceFluxes.argtypes = [vp, vp, ci, vp, vp, vp, ci]
     L.qk_Saxpy.argtypes = [vp, vp, ci, vp, cd, vp, ci]
+    R = P(RadTraits)
+    L.qk_rad_ConservedToPrimitive.argtypes = [vp, vp, R, vp, vp, ci]
+    L.qk_rad_ComputeFluxes.argtypes = [vp, vp, R, ci, vp, vp, vp, vp]
+    L.qk_rad_computeRadiationFluxes.argtypes = [vp, vp, R, ci, ci, vp, P(vp)]
+    L.qk_rad_PredictStep.argtypes = [vp, vp, R, ci, vp, vp, P(vp), cd, P(cd)]
+    L.qk_rad_AddFluxesRK2.argtypes = [vp, vp, R, ci, vp, vp, vp, P(vp), P(vp), cd, P(cd)]
+    L.qk_rad_AddSourceTermsSingleGroup.argtypes = [vp, vp, R, T, vp, vp, cd, ci, vp, vp]
     if hasattr(L, "qk_hydro_stage_fused"):
         L.qk_hydro_stage_scratch_bytes.argtypes = [vp, T]
         L.qk_hydro_stage_scratch_bytes.restype = C.c_int64
@@ -138,6 +151,8 @@ DECLARED_SYMBOLS = [
     "qk_hydro_ComputeFluxes", "qk_hydro_ComputeRhsFromFluxes", "qk_hydro_AddInternalEnergyPdV", "qk_hydro_PredictStep",
     "qk_hydro_EnforceLimits", "qk_hydro_SyncDualEnergy", "qk_hydro_ComputeMaxSignalSpeed", "qk_hydro_maxSignalSpeedLocal",
     "qk_replaceFluxes", "qk_Saxpy", "qk_hydro_stage_scratch_bytes", "qk_hydro_stage_fused",
+    "qk_rad_ConservedToPrimitive", "qk_rad_ComputeFluxes", "qk_rad_computeRadiationFluxes", "qk_rad_PredictStep", "qk_rad_AddFluxesRK2",
+    "qk_rad_AddSourceTermsSingleGroup",
     "qk_ghost_plan_create", "qk_ghost_plan_destroy", "qk_ghost_plan_num_peers", "qk_ghost_plan_peer",
     "qk_FillBoundary_local", "qk_FillBoundary_local_int", "qk_FillBoundary_pack", "qk_FillBoundary_unpack", "qk_FillPhysicalBoundary",
 ]

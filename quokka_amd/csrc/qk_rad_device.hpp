@@ -1,0 +1,449 @@
+// qk_rad_device.hpp — per-cell / per-face device arithmetic of the single-group two-moment radiation path.
+// Counterparts (same association order, -ffp-contract=off):
+//   reference src/radiation/radiation_system.hpp            RadSystem<problem_t>
+//   reference src/radiation/source_terms_single_group.hpp   AddSourceTermsSingleGroup
+// nGroups = 1, OpacityModel::single_group, no dust / photoelectric / cooling models (ISM_Traits defaults).
+#ifndef QK_RAD_DEVICE_HPP_
+#define QK_RAD_DEVICE_HPP_
+
+#include "qk_device.hpp"
+
+namespace qk
+{
+
+constexpr int NRAD = 4;	  // Physics_NumVars::numRadVars
+constexpr int RAD0 = 6;	  // Physics_Indices::radFirstIndex (no passive scalars)
+constexpr double IMEX_a32 = 0.5; // radiation_system.hpp:52
+
+struct Rad {
+	double c, chat, arad, Erad_floor;
+	double kappaP0, kappaE0, kappaF0;
+	int beta_order, pow_mode;
+	__host__ __device__ explicit Rad(qk_rad_traits const &t)
+	    : c(t.c_light), chat(t.c_hat), arad(t.radiation_constant), Erad_floor(t.Erad_floor), kappaP0(t.kappaP), kappaE0(t.kappaE), kappaF0(t.kappaF),
+	      beta_order(t.beta_order), pow_mode(t.pow_mode)
+	{
+	}
+	// problem hooks ComputePlanckOpacity / ComputeEnergyMeanOpacity / ComputeFluxMeanOpacity (radiation_system.hpp:1141-1154):
+	// closed set, model 0 = constants
+	QK_DEV auto kappaP(double /*rho*/, double /*T*/) const -> double { return kappaP0; }
+	QK_DEV auto kappaE(double /*rho*/, double /*T*/) const -> double { return kappaE0; }
+	QK_DEV auto kappaF(double /*rho*/, double /*T*/) const -> double { return kappaF0; }
+	QK_DEV auto pow4(double T) const -> double { return (pow_mode == 0) ? pow(T, 4.0) : (T * T) * (T * T); }
+	QK_DEV auto pow3(double T) const -> double { return (pow_mode == 0) ? pow(T, 3.0) : (T * T) * T; }
+	// radiation_system.hpp:471-479, :499-503
+	QK_DEV auto thermalRadiation(double T) const -> double
+	{
+		double power = arad * pow4(T);
+		if (power < Erad_floor) {
+			power = Erad_floor;
+		}
+		return power;
+	}
+	QK_DEV auto thermalRadiationTempDerivative(double T) const -> double { return 4. * arad * pow3(T); }
+};
+
+// radiation_system.hpp:773-790
+QK_DEV auto eddingtonFactor(double f_in) -> double
+{
+	const double f = clampd(f_in, 0., 1.);
+	const double f_fac = sqrt(4.0 - 3.0 * (f * f));
+	return (3.0 + 4.0 * (f * f)) / (5.0 + 2.0 * f_fac);
+}
+
+// radiation_system.hpp:873-916: row `row` of the Eddington tensor, plus T[row][row] via Tn[row]
+QK_DEV void eddingtonTensor(double fx, double fy, double fz, double T[3][3])
+{
+	const double f = sqrt(fx * fx + fy * fy + fz * fz);
+	const double fv[3] = {fx, fy, fz};
+	double n[3];
+#pragma unroll
+	for (int ii = 0; ii < 3; ++ii) {
+		n[ii] = (f > 0.) ? (fv[ii] / f) : 0.;
+	}
+	const double chi = eddingtonFactor(f);
+	const double Tdiag = (1.0 - chi) / 2.0;
+	const double Tf = (3.0 * chi - 1.0) / 2.0;
+#pragma unroll
+	for (int ii = 0; ii < 3; ++ii) {
+#pragma unroll
+		for (int jj = 0; jj < 3; ++jj) {
+			const double delta_ij = (ii == jj) ? 1 : 0;
+			T[ii][jj] = Tdiag * delta_ij + Tf * (n[ii] * n[jj]);
+		}
+	}
+}
+
+// radiation_system.hpp:918-983 + :1054-1131: HLL flux at one face from the L/R primitive states (E, fx, fy, fz);
+// `consL/consR` are the cell-centred conserved radiation states either side (first-order fallback).
+template <int DIR> QK_DEV void radFaceFlux(Rad const &r, const double pL[NRAD], const double pR[NRAD], const double consL[NRAD], const double consR[NRAD], double F[NRAD])
+{
+	double erad_L = pL[0], erad_R = pR[0];
+	double fx_L = pL[1], fx_R = pR[1];
+	double fy_L = pL[2], fy_R = pR[2];
+	double fz_L = pL[3], fz_R = pR[3];
+	double f_L = sqrt(fx_L * fx_L + fy_L * fy_L + fz_L * fz_L);
+	double f_R = sqrt(fx_R * fx_R + fy_R * fy_R + fz_R * fz_R);
+	double Fx_L = fx_L * (r.c * erad_L);
+	double Fx_R = fx_R * (r.c * erad_R);
+	double Fy_L = fy_L * (r.c * erad_L);
+	double Fy_R = fy_R * (r.c * erad_R);
+	double Fz_L = fz_L * (r.c * erad_L);
+	double Fz_R = fz_R * (r.c * erad_R);
+	if ((erad_L <= 0.) || (erad_R <= 0.) || (f_L >= 1.) || (f_R >= 1.)) {
+		erad_L = consL[0];
+		erad_R = consR[0];
+		Fx_L = consL[1];
+		Fx_R = consR[1];
+		Fy_L = consL[2];
+		Fy_R = consR[2];
+		Fz_L = consL[3];
+		Fz_R = consR[3];
+		fx_L = Fx_L / (r.c * erad_L);
+		fx_R = Fx_R / (r.c * erad_R);
+		fy_L = Fy_L / (r.c * erad_L);
+		fy_R = Fy_R / (r.c * erad_R);
+		fz_L = Fz_L / (r.c * erad_L);
+		fz_R = Fz_R / (r.c * erad_R);
+		f_L = sqrt(fx_L * fx_L + fy_L * fy_L + fz_L * fz_L);
+		f_R = sqrt(fx_R * fx_R + fy_R * fy_R + fz_R * fz_R);
+	}
+	double TL[3][3], TR[3][3];
+	eddingtonTensor(fx_L, fy_L, fz_L, TL);
+	eddingtonTensor(fx_R, fy_R, fz_R, TR);
+	const double FnL = (DIR == 0) ? Fx_L : (DIR == 1) ? Fy_L : Fz_L;
+	const double FnR = (DIR == 0) ? Fx_R : (DIR == 1) ? Fy_R : Fz_R;
+	double FL[NRAD] = {FnL, TL[DIR][0] * erad_L, TL[DIR][1] * erad_L, TL[DIR][2] * erad_L};
+	double FR[NRAD] = {FnR, TR[DIR][0] * erad_R, TR[DIR][1] * erad_R, TR[DIR][2] * erad_R};
+	double S_L = smax(0.1, sqrt(TL[DIR][DIR]));
+	double S_R = smax(0.1, sqrt(TR[DIR][DIR]));
+	S_L *= -1.;
+	FL[0] *= r.chat / r.c;
+	FR[0] *= r.chat / r.c;
+#pragma unroll
+	for (int n = 1; n < NRAD; ++n) {
+		FL[n] *= r.chat * r.c;
+		FR[n] *= r.chat * r.c;
+	}
+	S_L *= r.chat;
+	S_R *= r.chat;
+	const double UL[NRAD] = {erad_L, Fx_L, Fy_L, Fz_L};
+	const double UR[NRAD] = {erad_R, Fx_R, Fy_R, Fz_R};
+#pragma unroll
+	for (int n = 0; n < NRAD; ++n) {
+		// :1116-1117 with epsilon = 1 (use_wavespeed_correction = false)
+		F[n] = (S_R / (S_R - S_L)) * FL[n] - (S_L / (S_R - S_L)) * FR[n] + 1.0 * (S_R * S_L / (S_R - S_L)) * (UR[n] - UL[n]);
+	}
+}
+
+// radiation_system.hpp:626-665
+QK_DEV auto radStateValid(Rad const &r, const double U[NRAD]) -> bool
+{
+	const double Fnorm = sqrt(U[1] * U[1] + U[2] * U[2] + U[3] * U[3]);
+	const double f = Fnorm / (r.c * U[0]);
+	return (U[0] > 0.) && (f <= 1.);
+}
+QK_DEV void amendRadState(Rad const &r, double U[NRAD])
+{
+	double E_r = U[0];
+	if (E_r < r.Erad_floor) {
+		E_r = r.Erad_floor;
+		U[0] = r.Erad_floor;
+	}
+	const double Fx = U[1], Fy = U[2], Fz = U[3];
+	if (Fx * Fx + Fy * Fy + Fz * Fz > r.c * r.c * E_r * E_r) {
+		const double Fnorm = sqrt(Fx * Fx + Fy * Fy + Fz * Fz);
+		U[1] = Fx / Fnorm * r.c * E_r;
+		U[2] = Fy / Fnorm * r.c * E_r;
+		U[3] = Fz / Fnorm * r.c * E_r;
+	}
+}
+
+// EOS.hpp:202-244 with the direct gamma-law forms
+QK_DEV auto eintTempDerivative(Eos const &eos, double rho, double T) -> double
+{
+	const double p = rho * T * Eos::k_B / (eos.mu * Eos::m_u);
+	const double e = p / (eos.gm1 * rho);
+	const double dedT = e / T;
+	return dedT * rho * eos.kB_user / Eos::k_B;
+}
+
+QK_DEV auto eintFromEgas(double rho, double px, double py, double pz, double Etot) -> double
+{
+	const double p_sq = px * px + py * py + pz * pz;
+	const double Ekin = p_sq / (2.0 * rho);
+	return Etot - Ekin;
+}
+QK_DEV auto egasFromEint(double rho, double px, double py, double pz, double Eint) -> double
+{
+	const double p_sq = px * px + py * py + pz * pz;
+	const double Ekin = p_sq / (2.0 * rho);
+	return Eint + Ekin;
+}
+
+// source_terms_single_group.hpp:29-563 for one cell.  U[10] in place; counters as in the reference:
+// it_counter[0] += 1, [1] += n+1, [2] = max(n+1); fail[0] Newton failure, fail[2] outer-iteration failure.
+QK_DEV void radSourceCell(Rad const &r, Eos const &eos, double U[10], double srcval, double dt_radiation, int stage, int &n_newton_total, int &n_newton_max,
+			  int &n_solves, int &fail_newton, int &fail_outer)
+{
+	double dt = dt_radiation;
+	if (stage == 2) {
+		dt = (1.0 - IMEX_a32) * dt_radiation;
+	}
+	const double c = r.c;
+	const double chat = r.chat;
+	const double rho = U[RHO];
+	const double x1GasMom0 = U[MX], x2GasMom0 = U[MY], x3GasMom0 = U[MZ];
+	const double gasMtm0[3] = {x1GasMom0, x2GasMom0, x3GasMom0};
+	const double Egastot0 = U[ENE];
+	const double Erad0 = U[RAD0];
+	const double Src = srcval * dt * chat;
+	const double Frad_t0[3] = {U[RAD0 + 1], U[RAD0 + 2], U[RAD0 + 3]};
+	const bool gamma_ne_1 = !eos.isothermal;
+	const int beta_order = r.beta_order;
+
+	double Egas0 = __builtin_nan(""), Ekin0 = __builtin_nan(""), Etot0 = __builtin_nan(""), Egas_guess = __builtin_nan("");
+	double T_gas = __builtin_nan(""), T_d = __builtin_nan("");
+	double lorentz_factor = __builtin_nan(""), lorentz_factor_v = __builtin_nan(""), lorentz_factor_v_v = __builtin_nan("");
+	double fourPiBoverC = __builtin_nan(""), Erad_guess = __builtin_nan(""), kappaP = __builtin_nan(""), kappaE = __builtin_nan("");
+	double kappaF = __builtin_nan(""), kappaPoverE = __builtin_nan("");
+	double work = 0.0, work_prev = 0.0;
+	double dMomentum[3] = {0., 0., 0.};
+	double Frad_t1[3] = {0., 0., 0.};
+	const double cscale = c / chat;
+
+	if (gamma_ne_1) {
+		Egas0 = eintFromEgas(rho, x1GasMom0, x2GasMom0, x3GasMom0, Egastot0);
+		Etot0 = Egas0 + cscale * (Erad0 + Src);
+	}
+	double gas_update_factor = 1.0;
+	if (stage == 1) {
+		gas_update_factor = IMEX_a32;
+	}
+
+	const int max_ite = 5;
+	int ite = 0;
+	for (; ite < max_ite; ++ite) {
+		double R = __builtin_nan("");
+		Erad_guess = Erad0;
+		if (gamma_ne_1) {
+			double tau0 = __builtin_nan("");
+			double tau = __builtin_nan("");
+			Egas_guess = Egas0;
+			Ekin0 = Egastot0 - Egas0;
+			const double betaSqr = (x1GasMom0 * x1GasMom0 + x2GasMom0 * x2GasMom0 + x3GasMom0 * x3GasMom0) / (rho * rho * c * c);
+			if ((beta_order == 0) || (beta_order == 1)) {
+				lorentz_factor = 1.0;
+				lorentz_factor_v = 1.0;
+			} else if (beta_order == 2) {
+				lorentz_factor = 1.0 + 0.5 * betaSqr;
+				lorentz_factor_v = 1.0;
+				lorentz_factor_v_v = 1.0;
+			} else if (beta_order == 3) {
+				lorentz_factor = 1.0 + 0.5 * betaSqr;
+				lorentz_factor_v = 1.0 + 0.5 * betaSqr;
+				lorentz_factor_v_v = 1.0;
+			} else {
+				lorentz_factor = 1.0 / sqrt(1.0 - betaSqr);
+				lorentz_factor_v = lorentz_factor;
+				lorentz_factor_v_v = lorentz_factor;
+			}
+
+			double F_G, deltaEgas, deltaR, F_D;
+			const double resid_tol = 1.0e-11;
+			const int maxIter = 100;
+			int n = 0;
+			for (; n < maxIter; ++n) {
+				T_gas = eos.tgasFromEint(rho, Egas_guess);
+				T_d = T_gas;
+				fourPiBoverC = r.thermalRadiation(T_d);
+				kappaP = r.kappaP(rho, T_d);
+				kappaE = r.kappaE(rho, T_d);
+				if (kappaE > 0.0) {
+					kappaPoverE = kappaP / kappaE;
+				} else {
+					kappaPoverE = 1.0;
+				}
+				if (n == 0) {
+					kappaF = r.kappaF(rho, T_d);
+					if (beta_order != 0) { // include_work_term_in_source = true
+						if (ite == 0) {
+							work = (x1GasMom0 * Frad_t0[0] + x2GasMom0 * Frad_t0[1] + x3GasMom0 * Frad_t0[2]) * (2.0 * kappaE - kappaF) * chat /
+							       (c * c) * lorentz_factor_v * dt;
+						}
+					}
+					tau0 = dt * rho * kappaP * chat * lorentz_factor;
+					tau = tau0;
+					R = (fourPiBoverC - Erad_guess / kappaPoverE) * tau0 + work;
+					tau0 = smax(tau0, 1.0);
+				} else {
+					tau = dt * rho * kappaP * chat * lorentz_factor;
+					if (tau > 0.0) {
+						Erad_guess = kappaPoverE * (fourPiBoverC - (R - work) / tau);
+					}
+				}
+				const double cooling = 0.0;
+				const double cooling_derivative = 0.0;
+				const double CR_heating = 0.0 * dt;
+				F_G = Egas_guess - Egas0 + cscale * R + cooling * dt - CR_heating;
+				F_D = Erad_guess - Erad0 - (R + Src);
+				double F_D_abs;
+				if (tau > 0.0) {
+					F_D_abs = fabs(F_D);
+				} else {
+					F_D_abs = fabs(F_D + R);
+				}
+				if ((fabs(F_G) < resid_tol * Etot0) && (cscale * F_D_abs < resid_tol * Etot0)) {
+					break;
+				}
+				const double c_v = eintTempDerivative(eos, rho, T_gas);
+				const double d_fourpiboverc_d_t = r.thermalRadiationTempDerivative(T_d);
+				const double dEg_dT = kappaPoverE * d_fourpiboverc_d_t;
+				const double J00 = 1.0 + cooling_derivative * dt / c_v;
+				const double J01 = cscale;
+				const double J10 = 1.0 / c_v * dEg_dT - (1 / cscale) * cooling_derivative * dt;
+				double J11;
+				if (tau <= 0.0) {
+					J11 = -__builtin_inf();
+				} else {
+					J11 = -1.0 * kappaPoverE / tau - 1.0;
+				}
+				const double y0 = -F_G;
+				const double y1 = -1. * F_D;
+				const double det = J00 * J11 - J01 * J10;
+				deltaEgas = (J11 * y0 - J01 * y1) / det;
+				deltaR = (J00 * y1 - J10 * y0) / det;
+				// enable_dE_constrain = true (radiation_system.hpp:44)
+				const double T_rad = sqrt(sqrt(Erad_guess / r.arad));
+				if (deltaEgas / c_v > smax(T_gas, T_rad)) {
+					Egas_guess = eos.eintFromTgas(rho, T_rad);
+				} else {
+					Egas_guess += deltaEgas;
+					R += deltaR;
+				}
+			}
+			if (n >= maxIter) {
+				fail_newton += 1;
+			}
+			n_solves += 1;
+			n_newton_total += n + 1;
+			n_newton_max = max(n_newton_max, n + 1);
+			// cooling_tend = 0 * dt: Erad_guess += (1/cscale) * 0
+			Erad_guess += (1 / cscale) * (0.0 * dt);
+			if (n > 0) {
+				kappaF = r.kappaF(rho, T_d);
+			}
+		} else {
+			T_d = T_gas;
+			kappaF = r.kappaF(rho, T_d);
+		}
+
+		// 2. radiation flux update
+		dMomentum[0] = dMomentum[1] = dMomentum[2] = 0.;
+		if (gamma_ne_1 && (beta_order != 0)) {
+			const double erad = Erad_guess;
+			double v_terms[3];
+			const double fx = Frad_t0[0] / (r.c * erad);
+			const double fy = Frad_t0[1] / (r.c * erad);
+			const double fz = Frad_t0[2] / (r.c * erad);
+			const double F_coeff = chat * rho * kappaF * dt * lorentz_factor;
+			double Tedd[3][3];
+			eddingtonTensor(fx, fy, fz, Tedd);
+#pragma unroll
+			for (int n = 0; n < 3; ++n) {
+				double Planck_term = kappaP * fourPiBoverC * lorentz_factor_v;
+				if (kappaF != kappaE) {
+					Planck_term += (kappaF - kappaE) * erad * pow(lorentz_factor_v, 3.0);
+				}
+				Planck_term *= chat * dt * gasMtm0[n];
+				double pressure_term = 0.0;
+#pragma unroll
+				for (int z = 0; z < 3; ++z) {
+					pressure_term += gasMtm0[z] * Tedd[n][z] * erad;
+				}
+				pressure_term *= chat * dt * kappaF * lorentz_factor_v;
+				v_terms[n] = Planck_term + pressure_term;
+			}
+			if (beta_order == 1 || kappaF == kappaE) {
+#pragma unroll
+				for (int n = 0; n < 3; ++n) {
+					Frad_t1[n] = (Frad_t0[n] + v_terms[n]) / (1.0 + F_coeff);
+					dMomentum[n] += -(Frad_t1[n] - Frad_t0[n]) / (c * chat);
+				}
+			} else {
+				// Solve3x3matrix (radiation_system.hpp:560-579) with gasVel = 0 as in the reference (:437, never assigned)
+				const double K0 = 2.0 * rho * chat * dt * (kappaF - kappaE) / c / c * pow(lorentz_factor_v_v, 3.0);
+				const double C00 = 1.0 + F_coeff + K0 * 0. * 0., C11 = C00, C22 = C00;
+				const double C01 = K0 * 0. * 0., C02 = C01, C10 = C01, C12 = C01, C20 = C01, C21 = C01;
+				const double Y0 = v_terms[0] + Frad_t0[0], Y1 = v_terms[1] + Frad_t0[1], Y2 = v_terms[2] + Frad_t0[2];
+				const double E11 = C11 - C01 * C10 / C00;
+				const double E12 = C12 - C02 * C10 / C00;
+				const double E21 = C21 - C01 * C20 / C00;
+				const double E22 = C22 - C02 * C20 / C00;
+				const double Z1 = Y1 - Y0 * C10 / C00;
+				const double Z2 = Y2 - Y0 * C20 / C00;
+				const double X2 = (Z2 - Z1 * E21 / E11) / (E22 - E12 * E21 / E11);
+				const double X1 = (Z1 - E12 * X2) / E11;
+				const double X0 = (Y0 - C01 * X1 - C02 * X2) / C00;
+				Frad_t1[0] = X0;
+				Frad_t1[1] = X1;
+				Frad_t1[2] = X2;
+#pragma unroll
+				for (int n = 0; n < 3; ++n) {
+					dMomentum[n] += -(Frad_t1[n] - Frad_t0[n]) / (c * chat);
+				}
+			}
+		} else {
+#pragma unroll
+			for (int n = 0; n < 3; ++n) {
+				Frad_t1[n] = Frad_t0[n] / (1.0 + rho * kappaF * chat * dt);
+				dMomentum[n] += -(Frad_t1[n] - Frad_t0[n]) / (c * chat);
+			}
+		}
+		const double x1GasMom1 = U[MX] + dMomentum[0];
+		const double x2GasMom1 = U[MY] + dMomentum[1];
+		const double x3GasMom1 = U[MZ] + dMomentum[2];
+
+		// 3. work term
+		if (gamma_ne_1 && (beta_order != 0)) {
+			const double Egastot1 = egasFromEint(rho, x1GasMom1, x2GasMom1, x3GasMom1, Egas_guess);
+			const double Ekin1 = Egastot1 - Egas_guess;
+			const double dEkin_work = Ekin1 - Ekin0;
+			Egas_guess -= dEkin_work;
+		}
+		if ((beta_order == 0) || !gamma_ne_1) {
+			break;
+		}
+		work_prev = work;
+		work = (x1GasMom1 * Frad_t1[0] + x2GasMom1 * Frad_t1[1] + x3GasMom1 * Frad_t1[2]) * chat / (c * c) * lorentz_factor_v * (2.0 * kappaE - kappaF) * dt;
+		const double lag_tol = 1.0e-13;
+		if ((fabs(work) == 0.0) || (cscale * fabs(work - work_prev) < lag_tol * Etot0) || (fabs(work - work_prev) <= lag_tol * R) ||
+		    (fabs(work - work_prev) <= 1.0e-8 * fabs(work))) {
+			break;
+		}
+	}
+	if (ite >= max_ite) {
+		fail_outer += 1;
+	}
+
+	// 4b. store
+	const double x1GasMom1 = U[MX] + dMomentum[0] * gas_update_factor;
+	const double x2GasMom1 = U[MY] + dMomentum[1] * gas_update_factor;
+	const double x3GasMom1 = U[MZ] + dMomentum[2] * gas_update_factor;
+	U[MX] = x1GasMom1;
+	U[MY] = x2GasMom1;
+	U[MZ] = x3GasMom1;
+	if (gamma_ne_1) {
+		Egas_guess = Egas0 + (Egas_guess - Egas0) * gas_update_factor;
+		U[EINT] = Egas_guess;
+		U[ENE] = egasFromEint(rho, x1GasMom1, x2GasMom1, x3GasMom1, Egas_guess);
+		U[RAD0] = Erad_guess;
+	}
+	U[RAD0 + 1] = Frad_t1[0];
+	U[RAD0 + 2] = Frad_t1[1];
+	U[RAD0 + 3] = Frad_t1[2];
+}
+
+} // namespace qk
+
+#endif // QK_RAD_DEVICE_HPP_

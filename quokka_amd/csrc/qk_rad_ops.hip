@@ -1,0 +1,398 @@
+// qk_rad_ops.hip — single-group two-moment radiation operators (RadSystem<problem_t>) behind the C-ABI.
+// One launch covers all local boxes.  Arithmetic in qk_rad_device.hpp.
+#include "qk_internal.hpp"
+#include "qk_rad_device.hpp"
+
+using namespace qk;
+
+namespace
+{
+
+template <class F> __global__ void __launch_bounds__(256) k_rad_cells(const qk_box *boxes, int ndim, int ng, int facedir, F f)
+{
+	const int b = blockIdx.y;
+	const qk_box bx = boxes[b];
+	int lo[3], len[3];
+#pragma unroll
+	for (int d = 0; d < 3; ++d) {
+		const int g = (d < ndim) ? ng : 0;
+		lo[d] = bx.lo[d] - g;
+		len[d] = bx.hi[d] - bx.lo[d] + 1 + 2 * g + ((d == facedir) ? 1 : 0);
+	}
+	const int64_t t_raw = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+	const int64_t n01 = static_cast<int64_t>(len[0]) * len[1];
+	// lanes past the end stay alive with a clamped index and valid = false (wave reductions need every lane)
+	const bool valid = t_raw < n01 * len[2];
+	const int64_t t = valid ? t_raw : 0;
+	const int k = static_cast<int>(t / n01);
+	const int r = static_cast<int>(t - k * n01);
+	const int j = r / len[0];
+	const int i = r - j * len[0];
+	f(b, lo[0] + i, lo[1] + j, lo[2] + k, valid);
+}
+
+template <class F> void launchRad(qk_level *lev, qk_stream s, int ng, int facedir, const char *name, F f)
+{
+	const CellLaunch L = cellLaunch(lev, ng, facedir);
+	ProfScope ps(lev->ctx, static_cast<hipStream_t>(s), name);
+	hipLaunchKernelGGL(k_rad_cells<F>, L.grid, L.block, 0, static_cast<hipStream_t>(s), lev->d_boxes, lev->ndim, ng, facedir, f);
+}
+
+inline auto radStatus(qk_level *lev, const char *name) -> int
+{
+	const hipError_t e = hipGetLastError();
+	if (e != hipSuccess) {
+		return setError(lev->ctx, QK_ERR_HIP, name, hipGetErrorString(e));
+	}
+	return QK_OK;
+}
+
+inline auto checkRad(qk_ctx *ctx, const qk_rad_traits *rt) -> int
+{
+	if (rt == nullptr) {
+		return setError(ctx, QK_ERR_INVALID, "rad traits is NULL");
+	}
+	if (rt->opacity_model != 0) {
+		return setError(ctx, QK_ERR_UNSUPPORTED, "only opacity_model 0 (constant kappa) is built");
+	}
+	if (rt->beta_order < 0 || rt->beta_order > 3) {
+		return setError(ctx, QK_ERR_INVALID, "beta_order must be 0..3");
+	}
+	return QK_OK;
+}
+
+template <int DIR> void launchRadComputeFluxes(qk_level *lev, qk_stream s, Rad rad, qk_array4 *flux_t, const qk_array4 *left_t, const qk_array4 *right_t, const qk_array4 *cons_t)
+{
+	launchRad(lev, s, 0, DIR, "rad_ComputeFluxes", [=] __device__(int b, int i, int j, int k, bool valid) {
+		if (!valid) {
+			return;
+		}
+		RA4 L(left_t[b]);
+		RA4 R(right_t[b]);
+		RA4 U(cons_t[b]);
+		WA4 F(flux_t[b]);
+		const int im = i - unit(DIR, 0), jm = j - unit(DIR, 1), km = k - unit(DIR, 2);
+		double pL[NRAD], pR[NRAD], cL[NRAD], cR[NRAD], Fo[NRAD];
+#pragma unroll
+		for (int n = 0; n < NRAD; ++n) {
+			pL[n] = L(i, j, k, n);
+			pR[n] = R(i, j, k, n);
+			cL[n] = U(im, jm, km, RAD0 + n);
+			cR[n] = U(i, j, k, RAD0 + n);
+		}
+		radFaceFlux<DIR>(rad, pL, pR, cL, cR, Fo);
+#pragma unroll
+		for (int n = 0; n < NRAD; ++n) {
+			F(i, j, k, n) = Fo[n];
+		}
+	});
+}
+
+// cons -> prim of one cell (radiation_system.hpp:603-610)
+QK_DEV void radPrim(Rad const &r, const double c[NRAD], double p[NRAD])
+{
+	p[0] = c[0];
+	p[1] = c[1] / (r.c * c[0]);
+	p[2] = c[2] / (r.c * c[0]);
+	p[3] = c[3] / (r.c * c[0]);
+}
+
+template <int DIR, int ORDER> void launchRadFusedFlux(qk_level *lev, qk_stream s, Rad rad, const qk_array4 *cons_t, qk_array4 *flux_t)
+{
+	launchRad(lev, s, 0, DIR, "rad_fluxFunction", [=] __device__(int b, int i, int j, int k, bool valid) {
+		if (!valid) {
+			return;
+		}
+		RA4 U(cons_t[b]);
+		WA4 F(flux_t[b]);
+		const int dx = unit(DIR, 0), dy = unit(DIR, 1), dz = unit(DIR, 2);
+		// cells i-3 .. i+2 along DIR
+		double c[6][NRAD], p[6][NRAD];
+		constexpr int M0 = (ORDER == 3) ? 0 : (ORDER == 2) ? 1 : 2;
+		constexpr int M1 = (ORDER == 3) ? 5 : (ORDER == 2) ? 4 : 3;
+#pragma unroll
+		for (int m = M0; m <= M1; ++m) {
+			const int64_t o = U.idx(i + (m - 3) * dx, j + (m - 3) * dy, k + (m - 3) * dz);
+#pragma unroll
+			for (int n = 0; n < NRAD; ++n) {
+				c[m][n] = U.p[o + U.ns * (RAD0 + n)];
+			}
+			radPrim(rad, c[m], p[m]);
+		}
+		double pL[NRAD], pR[NRAD], Fo[NRAD];
+#pragma unroll
+		for (int n = 0; n < NRAD; ++n) {
+			if (ORDER == 3) {
+				double am, ap;
+				ppmEdges(p[0][n], p[1][n], p[2][n], p[3][n], p[4][n], am, ap); // cell i-1: right edge -> leftState(i)
+				pL[n] = ap;
+				ppmEdges(p[1][n], p[2][n], p[3][n], p[4][n], p[5][n], am, ap); // cell i: left edge -> rightState(i)
+				pR[n] = am;
+			} else if (ORDER == 2) {
+				// hyperbolic_system.hpp:243-246 with the MC limiter (QuokkaSimulation.hpp:1948)
+				const double lslope = MC(p[3][n] - p[2][n], p[2][n] - p[1][n]);
+				const double rslope = MC(p[4][n] - p[3][n], p[3][n] - p[2][n]);
+				pL[n] = p[2][n] + 0.25 * lslope;
+				pR[n] = p[3][n] - 0.25 * rslope;
+			} else {
+				pL[n] = p[2][n];
+				pR[n] = p[3][n];
+			}
+		}
+		radFaceFlux<DIR>(rad, pL, pR, c[2], c[3], Fo);
+		const int64_t o = F.idx(i, j, k);
+#pragma unroll
+		for (int n = 0; n < NRAD; ++n) {
+			F.p[o + F.ns * n] = Fo[n];
+		}
+	});
+}
+
+} // namespace
+
+extern "C" {
+
+int qk_rad_ConservedToPrimitive(qk_level *lev, qk_stream s, const qk_rad_traits *rt, const qk_array4 *cons_t, qk_array4 *prim_t, int nghost)
+{
+	if (lev == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	if (int rc = checkRad(lev->ctx, rt); rc != QK_OK) {
+		return rc;
+	}
+	QK_REQUIRE(lev->ctx, cons_t && prim_t, "rad ConservedToPrimitive: NULL array");
+	const Rad rad(*rt);
+	launchRad(lev, s, nghost, -1, "rad_ConservedToPrimitive", [=] __device__(int b, int i, int j, int k, bool valid) {
+		if (!valid) {
+			return;
+		}
+		RA4 U(cons_t[b]);
+		WA4 P(prim_t[b]);
+		double c[NRAD], p[NRAD];
+#pragma unroll
+		for (int n = 0; n < NRAD; ++n) {
+			c[n] = U(i, j, k, RAD0 + n);
+		}
+		radPrim(rad, c, p);
+#pragma unroll
+		for (int n = 0; n < NRAD; ++n) {
+			P(i, j, k, n) = p[n];
+		}
+	});
+	return radStatus(lev, "rad ConservedToPrimitive");
+}
+
+int qk_rad_ComputeFluxes(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int dir, qk_array4 *flux_t, const qk_array4 *left_t,
+			 const qk_array4 *right_t, const qk_array4 *cons_t)
+{
+	if (lev == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	if (int rc = checkRad(lev->ctx, rt); rc != QK_OK) {
+		return rc;
+	}
+	QK_REQUIRE(lev->ctx, flux_t && left_t && right_t && cons_t, "rad ComputeFluxes: NULL array");
+	const Rad rad(*rt);
+	switch (dir) {
+	case 0:
+		launchRadComputeFluxes<0>(lev, s, rad, flux_t, left_t, right_t, cons_t);
+		break;
+	case 1:
+		launchRadComputeFluxes<1>(lev, s, rad, flux_t, left_t, right_t, cons_t);
+		break;
+	case 2:
+		launchRadComputeFluxes<2>(lev, s, rad, flux_t, left_t, right_t, cons_t);
+		break;
+	default:
+		return setError(lev->ctx, QK_ERR_INVALID, "rad ComputeFluxes: bad direction");
+	}
+	return radStatus(lev, "rad ComputeFluxes");
+}
+
+int qk_rad_computeRadiationFluxes(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int ndim, int order, const qk_array4 *cons_t,
+				  qk_array4 *const flux[3])
+{
+	if (lev == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	if (int rc = checkRad(lev->ctx, rt); rc != QK_OK) {
+		return rc;
+	}
+	QK_REQUIRE(lev->ctx, cons_t && flux && flux[0] && (ndim < 3 || (flux[1] && flux[2])), "computeRadiationFluxes: NULL array");
+	QK_REQUIRE(lev->ctx, order >= 1 && order <= 3, "computeRadiationFluxes: reconstruction order must be 1..3");
+	QK_REQUIRE(lev->ctx, ndim == lev->ndim, "computeRadiationFluxes: ndim mismatch");
+	const Rad rad(*rt);
+#define QK_RAD_DIR(D)                                                                                                                                \
+	if (order == 3) {                                                                                                                            \
+		launchRadFusedFlux<D, 3>(lev, s, rad, cons_t, flux[D]);                                                                              \
+	} else if (order == 2) {                                                                                                                     \
+		launchRadFusedFlux<D, 2>(lev, s, rad, cons_t, flux[D]);                                                                              \
+	} else {                                                                                                                                     \
+		launchRadFusedFlux<D, 1>(lev, s, rad, cons_t, flux[D]);                                                                              \
+	}
+	QK_RAD_DIR(0)
+	if (ndim == 3) {
+		QK_RAD_DIR(1)
+		QK_RAD_DIR(2)
+	}
+#undef QK_RAD_DIR
+	return radStatus(lev, "computeRadiationFluxes");
+}
+
+int qk_rad_PredictStep(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int ndim, const qk_array4 *old_t, qk_array4 *new_t,
+		       const qk_array4 *const fluxArray[3], double dt, const double dx_in[3])
+{
+	if (lev == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	if (int rc = checkRad(lev->ctx, rt); rc != QK_OK) {
+		return rc;
+	}
+	QK_REQUIRE(lev->ctx, old_t && new_t && fluxArray && dx_in && fluxArray[0] && (ndim < 3 || (fluxArray[1] && fluxArray[2])), "rad PredictStep: NULL");
+	const Rad rad(*rt);
+	const qk_array4 *f0 = fluxArray[0], *f1 = (ndim == 3) ? fluxArray[1] : nullptr, *f2 = (ndim == 3) ? fluxArray[2] : nullptr;
+	const double dx0 = dx_in[0], dx1 = dx_in[1], dx2 = dx_in[2];
+	launchRad(lev, s, 0, -1, "rad_PredictStep", [=] __device__(int b, int i, int j, int k, bool valid) {
+		if (!valid) {
+			return;
+		}
+		RA4 Uo(old_t[b]);
+		WA4 Un(new_t[b]);
+		RA4 x1(f0[b]);
+		double cons[NRAD];
+#pragma unroll
+		for (int n = 0; n < NRAD; ++n) {
+			double d = (dt / dx0) * (x1(i, j, k, n) - x1(i + 1, j, k, n));
+			if (ndim == 3) {
+				RA4 x2(f1[b]);
+				RA4 x3(f2[b]);
+				d = d + (dt / dx1) * (x2(i, j, k, n) - x2(i, j + 1, k, n));
+				d = d + (dt / dx2) * (x3(i, j, k, n) - x3(i, j, k + 1, n));
+			}
+			cons[n] = Uo(i, j, k, RAD0 + n) + d;
+		}
+		if (!radStateValid(rad, cons)) {
+			amendRadState(rad, cons);
+		}
+#pragma unroll
+		for (int n = 0; n < NRAD; ++n) {
+			Un(i, j, k, RAD0 + n) = cons[n];
+		}
+	});
+	return radStatus(lev, "rad PredictStep");
+}
+
+int qk_rad_AddFluxesRK2(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int ndim, qk_array4 *new_t, const qk_array4 *U0_t, const qk_array4 *U1_t,
+			const qk_array4 *const fluxArrayOld[3], const qk_array4 *const fluxArray[3], double dt, const double dx_in[3])
+{
+	if (lev == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	if (int rc = checkRad(lev->ctx, rt); rc != QK_OK) {
+		return rc;
+	}
+	QK_REQUIRE(lev->ctx, new_t && U0_t && U1_t && fluxArrayOld && fluxArray && dx_in && fluxArrayOld[0] && fluxArray[0], "rad AddFluxesRK2: NULL");
+	QK_REQUIRE(lev->ctx, ndim < 3 || (fluxArrayOld[1] && fluxArrayOld[2] && fluxArray[1] && fluxArray[2]), "rad AddFluxesRK2: NULL flux");
+	const Rad rad(*rt);
+	const qk_array4 *o0 = fluxArrayOld[0], *o1 = (ndim == 3) ? fluxArrayOld[1] : nullptr, *o2 = (ndim == 3) ? fluxArrayOld[2] : nullptr;
+	const qk_array4 *f0 = fluxArray[0], *f1 = (ndim == 3) ? fluxArray[1] : nullptr, *f2 = (ndim == 3) ? fluxArray[2] : nullptr;
+	const double dx0 = dx_in[0], dx1 = dx_in[1], dx2 = dx_in[2];
+	launchRad(lev, s, 0, -1, "rad_AddFluxesRK2", [=] __device__(int b, int i, int j, int k, bool valid) {
+		if (!valid) {
+			return;
+		}
+		WA4 Un(new_t[b]);
+		RA4 U0(U0_t[b]);
+		RA4 U1(U1_t[b]);
+		RA4 xo(o0[b]);
+		RA4 xn(f0[b]);
+		double cons[NRAD];
+#pragma unroll
+		for (int n = 0; n < NRAD; ++n) {
+			const double U_0 = U0(i, j, k, RAD0 + n);
+			const double U_1 = U1(i, j, k, RAD0 + n);
+			double s0 = (dt / dx0) * (xo(i, j, k, n) - xo(i + 1, j, k, n));
+			double s1 = (dt / dx0) * (xn(i, j, k, n) - xn(i + 1, j, k, n));
+			if (ndim == 3) {
+				RA4 yo(o1[b]);
+				RA4 zo(o2[b]);
+				RA4 yn(f1[b]);
+				RA4 zn(f2[b]);
+				s0 = s0 + (dt / dx1) * (yo(i, j, k, n) - yo(i, j + 1, k, n));
+				s1 = s1 + (dt / dx1) * (yn(i, j, k, n) - yn(i, j + 1, k, n));
+				s0 = s0 + (dt / dx2) * (zo(i, j, k, n) - zo(i, j, k + 1, n));
+				s1 = s1 + (dt / dx2) * (zn(i, j, k, n) - zn(i, j, k + 1, n));
+			}
+			// radiation_system.hpp:758-759
+			cons[n] = (1.0 - IMEX_a32) * U_0 + IMEX_a32 * U_1 + ((0.5 - IMEX_a32) * (s0)) + (0.5 * (s1));
+		}
+		if (!radStateValid(rad, cons)) {
+			amendRadState(rad, cons);
+		}
+#pragma unroll
+		for (int n = 0; n < NRAD; ++n) {
+			Un(i, j, k, RAD0 + n) = cons[n];
+		}
+	});
+	return radStatus(lev, "rad AddFluxesRK2");
+}
+
+int qk_rad_AddSourceTermsSingleGroup(qk_level *lev, qk_stream s, const qk_rad_traits *rt, const qk_hydro_traits *t, qk_array4 *cons_t,
+				     const qk_array4 *src_t, double dt, int stage, int *d_iteration_counter, int *d_failure_counter)
+{
+	if (lev == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	if (int rc = checkRad(lev->ctx, rt); rc != QK_OK) {
+		return rc;
+	}
+	if (int rc = checkTraits(lev->ctx, t); rc != QK_OK) {
+		return rc;
+	}
+	QK_REQUIRE(lev->ctx, cons_t && src_t && d_iteration_counter && d_failure_counter, "AddSourceTermsSingleGroup: NULL");
+	QK_REQUIRE(lev->ctx, stage == 1 || stage == 2, "AddSourceTermsSingleGroup: stage must be 1 or 2");
+	const Rad rad(*rt);
+	const Eos eos(*t);
+	launchRad(lev, s, 0, -1, "rad_AddSourceTerms", [=] __device__(int b, int i, int j, int k, bool valid) {
+		int ntot = 0, nmax = 0, nsolve = 0, fnewton = 0, fouter = 0;
+		if (valid) {
+			WA4 S(cons_t[b]);
+			RA4 Q(src_t[b]);
+			const int64_t c = S.idx(i, j, k);
+			double U[10];
+#pragma unroll
+			for (int n = 0; n < 10; ++n) {
+				U[n] = S.p[c + S.ns * n];
+			}
+			radSourceCell(rad, eos, U, Q(i, j, k), dt, stage, ntot, nmax, nsolve, fnewton, fouter);
+			// rho (comp 0) is never modified
+#pragma unroll
+			for (int n = 1; n < 10; ++n) {
+				S.p[c + S.ns * n] = U[n];
+			}
+		}
+		// counters: wave-level reduction, then one atomic per wave (the reference issues 3 atomics per cell, :344-346)
+		int wsolve = nsolve, wtot = ntot, wmax = nmax, wfn = fnewton, wfo = fouter;
+		for (int off = 32; off > 0; off >>= 1) {
+			wsolve += __shfl_xor(wsolve, off);
+			wtot += __shfl_xor(wtot, off);
+			wmax = max(wmax, __shfl_xor(wmax, off));
+			wfn += __shfl_xor(wfn, off);
+			wfo += __shfl_xor(wfo, off);
+		}
+		if ((threadIdx.x & 63) == 0) {
+			atomicAdd(&d_iteration_counter[0], wsolve);
+			atomicAdd(&d_iteration_counter[1], wtot);
+			atomicMax(&d_iteration_counter[2], wmax);
+			if (wfn != 0) {
+				atomicAdd(&d_failure_counter[0], wfn);
+			}
+			if (wfo != 0) {
+				atomicAdd(&d_failure_counter[2], wfo);
+			}
+		}
+	});
+	return radStatus(lev, "AddSourceTermsSingleGroup");
+}
+
+} // extern "C"

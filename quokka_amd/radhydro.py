@@ -1,0 +1,252 @@
+"""Radiation-hydrodynamics level-0 driver over the C-ABI: the radiation half of QuokkaSimulation<problem_t>
+
+  computeNumberOfRadiationSubsteps   reference src/QuokkaSimulation.hpp:397-406
+  computeMaxSignalLocal (radhydro)   reference src/QuokkaSimulation.hpp:408-441
+  subcycleRadiationAtLevel           reference src/QuokkaSimulation.hpp:1576-1722  (IMEX PD-ARS)
+  advanceRadiationForwardEuler       reference src/QuokkaSimulation.hpp:1790-1821
+  advanceRadiationMidpointRK2        reference src/QuokkaSimulation.hpp:1823-1857
+  operatorSplitSourceTerms           reference src/QuokkaSimulation.hpp:1859-1882
+
+State layout (Physics_Indices): comps 0..5 hydro, 6..9 = (E_r, F_x, F_y, F_z).  Host orchestration only.
+Differences from the reference that do not change results: the fluxes of the old radiation state are evaluated
+once per substep and reused by the midpoint stage (the reference recomputes them, :1836); prim + reconstruction +
+HLL flux run as one kernel per direction; Newton counters are reduced per wave and read once per substep.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Callable, Optional
+
+import numpy as np
+import torch
+
+from . import capi
+from .multifab import Context, MultiFab
+from .simulation import NGHOST_CC, Geometry, HydroSimulation
+
+RAD0 = 6
+
+
+def _p3(mfs):
+    arr = (C.c_void_p * 3)()
+    for d in range(3):
+        arr[d] = mfs[d].ptr if d < len(mfs) else None
+    return arr
+
+
+def _d3(v):
+    return (C.c_double * 3)(*[float(x) for x in (list(v) + [1.0, 1.0, 1.0])[:3]])
+
+
+class RadhydroSimulation(HydroSimulation):
+    def __init__(self, ctx: Context, geom: Geometry, traits: capi.HydroTraits, rad_traits: capi.RadTraits, bcs, max_grid_size=None,
+                 rank: int = 0, nranks: int = 1, use_fused: bool = True):
+        self.ncomp_override = 10
+        super().__init__(ctx, geom, traits, bcs, max_grid_size, None, rank, nranks, use_fused, ncomp_cc=10)
+        self.rad_traits = rad_traits
+        self.radiationCflNumber_ = 0.3
+        self.maxSubsteps_ = 10
+        self.radiationReconstructionOrder_ = 3
+        self.radiationCellUpdates_ = 0
+        lev, nd = self.lev, geom.ndim
+        self.radFluxOld = [MultiFab(lev, 4, 0, facedir=d) for d in range(nd)]
+        self.radFlux = [MultiFab(lev, 4, 0, facedir=d) for d in range(nd)]
+        self.radEnergySource = MultiFab(lev, 1, 0, fill=0.0)
+        self.SetRadEnergySource: Optional[Callable] = None  # fn(i, j, k, time) -> array on the valid box
+        self._source_time_independent = True
+        self._source_set = False
+        self.dev_rad_counter = torch.zeros(4, dtype=torch.int32, device=ctx.device)
+        self.dev_rad_failure = torch.zeros(3, dtype=torch.int32, device=ctx.device)
+        self.rad_counters = {"solves": 0, "newton_iterations": 0, "max_newton_iterations": 0}
+
+    # ------------------------------------------------------------------ dt
+    def computeTimestepAtLevel(self) -> float:
+        if self._signal_of_state_new is not None:
+            m = self._signal_of_state_new[1]
+        else:
+            m = float(self.hydro.maxSignalSpeedLocal(self.lev, self.state_new_cc_, which=1, out=self.dev_max).item())
+        # QuokkaSimulation.hpp:421-434: per cell max(c_hat / maxSubsteps, hydro signal); max over cells commutes
+        m = max(self.rad_traits.c_hat / float(self.maxSubsteps_), m)
+        m = self._allreduce_max(m)
+        return self.cflNumber_ * (self.min_dx() / m)
+
+    def computeNumberOfRadiationSubsteps(self, dt_lev_hydro: float) -> int:
+        dtrad_tmp = self.radiationCflNumber_ * (self.min_dx() / self.rad_traits.c_hat)
+        return int(math.ceil(dt_lev_hydro / dtrad_tmp))
+
+    # ------------------------------------------------------------------ pieces
+    def _rad_fluxes(self, state: MultiFab, out):
+        c = self.ctx
+        c.check(c.L.qk_rad_computeRadiationFluxes(self.lev.h, c.stream(), C.byref(self.rad_traits), self.geom.ndim,
+                                                  self.radiationReconstructionOrder_, state.ptr, _p3(out)), "qk_rad_computeRadiationFluxes")
+
+    def _fill_source(self, time: float):
+        if self.SetRadEnergySource is None or (self._source_set and self._source_time_independent):
+            return
+        for b, (lo, hi) in enumerate(self.my_boxes):
+            k, j, i = np.meshgrid(np.arange(lo[2], hi[2] + 1), np.arange(lo[1], hi[1] + 1), np.arange(lo[0], hi[0] + 1), indexing="ij")
+            self.radEnergySource.fabs[b][0].copy_(torch.from_numpy(np.ascontiguousarray(self.SetRadEnergySource(i, j, k, time))))
+        self._source_set = True
+
+    def operatorSplitSourceTerms(self, time: float, dt: float, stage: int):
+        self._fill_source(time + dt)
+        c = self.ctx
+        c.check(c.L.qk_rad_AddSourceTermsSingleGroup(self.lev.h, c.stream(), C.byref(self.rad_traits), C.byref(self.traits), self.state_new_cc_.ptr,
+                                                     self.radEnergySource.ptr, float(dt), stage, C.c_void_p(self.dev_rad_counter.data_ptr()),
+                                                     C.c_void_p(self.dev_rad_failure.data_ptr())), "qk_rad_AddSourceTermsSingleGroup")
+
+    def advanceRadiationForwardEuler(self, dt_radiation: float):
+        self.fillBoundaryConditions(self.state_old_cc_)
+        self._rad_fluxes(self.state_old_cc_, self.radFluxOld)
+        c = self.ctx
+        c.check(c.L.qk_rad_PredictStep(self.lev.h, c.stream(), C.byref(self.rad_traits), self.geom.ndim, self.state_old_cc_.ptr, self.state_new_cc_.ptr,
+                                       _p3(self.radFluxOld), float(dt_radiation), _d3(self.geom.dx)), "qk_rad_PredictStep")
+
+    def advanceRadiationMidpointRK2(self, dt_radiation: float):
+        self.fillBoundaryConditions(self.state_new_cc_)
+        # fluxes of the old state: identical to the ones of the forward-Euler stage (state_old_cc_ and its ghosts are unchanged)
+        self._rad_fluxes(self.state_new_cc_, self.radFlux)
+        c = self.ctx
+        c.check(c.L.qk_rad_AddFluxesRK2(self.lev.h, c.stream(), C.byref(self.rad_traits), self.geom.ndim, self.state_new_cc_.ptr, self.state_old_cc_.ptr,
+                                        self.state_new_cc_.ptr, _p3(self.radFluxOld), _p3(self.radFlux), float(dt_radiation), _d3(self.geom.dx)),
+                "qk_rad_AddFluxesRK2")
+
+    def swapRadiationState(self):
+        for b in range(self.lev.nboxes):
+            self.state_old_cc_.valid(b)[RAD0:RAD0 + 4].copy_(self.state_new_cc_.valid(b)[RAD0:RAD0 + 4])
+
+    def subcycleRadiationAtLevel(self, time: float, dt_lev_hydro: float) -> bool:
+        if not (self.constantDt_ > 0.0):
+            nsub = self.computeNumberOfRadiationSubsteps(dt_lev_hydro)
+            dt_rad = dt_lev_hydro / float(nsub)
+        else:
+            nsub, dt_rad = 1, dt_lev_hydro
+        if not (1 <= nsub <= self.maxSubsteps_ + 1 and dt_rad > 0.0):
+            raise capi.QkError(f"radiation substep assertion failed: nsubSteps = {nsub} (reference src/QuokkaSimulation.hpp:1596-1598)")
+        self._signal_of_state_new = None  # the source terms change the gas state
+        time_subcycle = time
+        for i in range(nsub):
+            if i > 0:
+                self.swapRadiationState()
+            self.dev_rad_counter.zero_()
+            self.dev_rad_failure.zero_()
+            self.advanceRadiationForwardEuler(dt_rad)
+            self.operatorSplitSourceTerms(time_subcycle, dt_rad, 1)  # IMEX_a22 > 0
+            self.advanceRadiationMidpointRK2(dt_rad)
+            self.operatorSplitSourceTerms(time_subcycle, dt_rad, 2)
+            fail = self._allreduce_sum_list(self.dev_rad_failure.tolist())
+            cnt = self.dev_rad_counter.tolist()
+            self.rad_counters["solves"] += cnt[0]
+            self.rad_counters["newton_iterations"] += cnt[1]
+            self.rad_counters["max_newton_iterations"] = max(self.rad_counters["max_newton_iterations"], cnt[2])
+            if fail[1] > 0:
+                raise capi.QkError("Newton-Raphson iteration for dust temperature failed to converge or dust temperature is negative!")
+            if fail[0] > 0:
+                raise capi.QkError("Newton-Raphson iteration for matter-radiation coupling failed to converge!")
+            if fail[2] > 0:
+                raise capi.QkError("Outer iteration for matter-radiation coupling failed to converge!")
+            time_subcycle += dt_rad
+            self.radiationCellUpdates_ += self.CountCells()
+        return True
+
+    def _allreduce_sum_list(self, vals):
+        if self.nranks > 1:
+            import torch.distributed as dist
+            t = torch.tensor(vals, dtype=torch.int64, device=self.ctx.device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return [int(x) for x in t.tolist()]
+        return vals
+
+    # advanceSingleTimestepAtLevel (reference src/QuokkaSimulation.hpp:653-707): hydro, then the radiation subcycle
+    def step(self, dt: Optional[float] = None) -> bool:
+        if dt is None:
+            self.computeTimestep()
+        else:
+            self.dt_ = dt
+        time = self.tNew_
+        self.tNew_ += self.dt_
+        self.state_old_cc_, self.state_new_cc_ = self.state_new_cc_, self.state_old_cc_
+        ok = self.advanceHydroAtLevelWithRetries(self.dt_)
+        if ok:
+            ok = self.subcycleRadiationAtLevel(time, self.dt_)
+        self.istep += 1
+        self.cellUpdates_ += self.CountCells()
+        return ok
+
+
+# ---------------------------------------------------------------------- RadhydroShell problem generator
+class ShellConstants:
+    """reference src/problems/RadhydroShell/test_radhydro_shell.cpp:39-95"""
+    a_rad = 7.5646e-15
+    c = 2.99792458e10
+    a0 = 2.0e5
+    chat = 860.0 * a0
+    gamma_gas = 5.0 / 3.0
+    Msun = 2.0e33
+    parsec_in_cm = 3.086e18
+    specific_luminosity = 2000.0
+    GMC_mass = 1.0e6 * Msun
+    epsilon = 0.5
+    M_shell = (1 - epsilon) * GMC_mass
+    L_star = (epsilon * GMC_mass) * specific_luminosity
+    r_0 = 5.0 * parsec_in_cm
+    sigma_star = 0.3 * r_0
+    H_shell = 0.3 * r_0
+    kappa0 = 20.0
+    rho_0 = M_shell / ((4.0 / 3.0) * math.pi * r_0 * r_0 * r_0)
+    c_v = capi.K_B / ((2.2 * capi.M_U) * (gamma_gas - 1.0))
+    L_box = 6.172e19  # tests/radhydro_shell_256.in
+
+
+def shell_problem(ctx: Context, n: int, table, max_grid_size: int = 128, rank=0, nranks=1, pow_mode: int = 0) -> RadhydroSimulation:
+    """reference src/problems/RadhydroShell/test_radhydro_shell.cpp + tests/radhydro_shell_256.in.
+    `table`: (r_over_r0, Erad, Frad) columns of extern/dust_shell/initial_conditions.txt."""
+    S = ShellConstants
+    geom = Geometry(3, [n, n, n], [0.0, 0.0, 0.0], [S.L_box] * 3, [1, 1, 1])
+    bcs = [([capi.BC_INT_DIR] * 3, [capi.BC_INT_DIR] * 3) for _ in range(10)]
+    traits = capi.traits(S.gamma_gas, False, 3, mean_molecular_weight=2.2 * capi.M_U, boltzmann_constant=capi.K_B)
+    rt = capi.RadTraits(S.c, S.chat, S.a_rad, 0.0, 1, 0, S.kappa0, S.kappa0, S.kappa0, pow_mode)
+    sim = RadhydroSimulation(ctx, geom, traits, rt, bcs, [max_grid_size] * 3, rank=rank, nranks=nranks)
+    # problem_main :409-431
+    sim.cflNumber_ = 0.3
+    sim.densityFloor_ = 1.0e-8 * S.rho_0
+    sim.reconstructionOrder_ = 2
+    sim.radiationReconstructionOrder_ = 2
+    sim.integratorOrder_ = 2
+    sim.stopTime_ = 0.125 * (S.r_0 / S.a0)
+    sim.maxTimesteps_ = 50
+    r_arr = np.asarray(table[0], dtype=np.float64) * S.r_0
+    E_arr, F_arr = np.asarray(table[1], dtype=np.float64), np.asarray(table[2], dtype=np.float64)
+    dx, lo, hi = geom.dx, geom.prob_lo, geom.prob_hi
+    x0 = [lo[d] + 0.5 * (hi[d] - lo[d]) for d in range(3)]
+
+    def radius(i, j, k):
+        x = lo[0] + (i + 0.5) * dx[0]
+        y = lo[1] + (j + 0.5) * dx[1]
+        z = lo[2] + (k + 0.5) * dx[2]
+        return np.sqrt((x - x0[0]) * (x - x0[0]) + (y - x0[1]) * (y - x0[1]) + (z - x0[2]) * (z - x0[2]))
+
+    def ic(i, j, k):  # setInitialConditionsOnGrid :185-249
+        r = radius(i, j, k)
+        sigma_sh = S.H_shell / (2.0 * math.sqrt(2.0 * math.log(2.0)))
+        rho_norm = S.M_shell / (4.0 * math.pi * r * r * math.sqrt(2.0 * math.pi * sigma_sh * sigma_sh))
+        rho_shell = rho_norm * np.exp(-((r - S.r_0) * (r - S.r_0)) / (2.0 * sigma_sh * sigma_sh))
+        rho = np.maximum(rho_shell, 1.0e-8 * S.rho_0)
+        Frad = np.interp(r, r_arr, F_arr)
+        Erad = np.interp(r, r_arr, E_arr)
+        Tgas = np.power(Erad / S.a_rad, 1.0 / 4.0)
+        Eint = rho * S.c_v * Tgas
+        U = np.zeros((10,) + i.shape)
+        U[0], U[4], U[5], U[6] = rho, Eint, Eint, Erad
+        U[7] = U[8] = U[9] = Frad / math.sqrt(3.0)
+        return U
+
+    def source(i, j, k, time):  # SetRadEnergySource :98-125
+        r = radius(i, j, k)
+        source_norm = (1.0 / S.c) * S.L_star / math.pow(2.0 * math.pi * S.sigma_star * S.sigma_star, 1.5)
+        return source_norm * np.exp(-(r * r) / (2.0 * S.sigma_star * S.sigma_star))
+
+    sim.SetRadEnergySource = source
+    sim.set_initial_conditions(ic)
+    return sim

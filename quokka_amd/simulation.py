@@ -157,11 +157,11 @@ class HydroSimulation:
     """QuokkaSimulation<problem_t> for a hydro-only, uniform-grid problem."""
 
     def __init__(self, ctx: Context, geom: Geometry, traits: capi.HydroTraits, bcs, max_grid_size=None, dirichlet=None,
-                 rank: int = 0, nranks: int = 1, use_fused: bool = True):
+                 rank: int = 0, nranks: int = 1, use_fused: bool = True, ncomp_cc: int = 6):
         self.ctx, self.geom, self.traits = ctx, geom, traits
         self.rank, self.nranks = rank, nranks
         self.hydro = HydroSystem(traits)
-        self.ncomp_cc = 6
+        self.ncomp_cc = ncomp_cc  # Physics_Indices::nvarTotal_cc (6 hydro, +4 with radiation)
         mgs = list(max_grid_size) if max_grid_size is not None else list(geom.n_cell)
         mgs = (mgs + [1, 1, 1])[:3]
         for d in range(geom.ndim, 3):
@@ -432,7 +432,7 @@ class HydroSimulation:
                 return False
         else:
             for b in range(self.lev.nboxes):
-                self.state_new_cc_.valid(b).copy_(self.state_inter_cc_.valid(b))
+                self.state_new_cc_.valid(b)[0:6].copy_(self.state_inter_cc_.valid(b)[0:6])  # ncompHydro_ comps only (QuokkaSimulation.hpp:1289)
         if int(self.dev_error.item()) != 0:
             raise capi.QkError("density is negative in SyncDualEnergy! abort!! (reference src/hydro/hydro_system.hpp:834-836)")
         return not self.isCflViolated(dt_lev)
@@ -453,7 +453,8 @@ class HydroSimulation:
                 self.state_old_tmp.copy_from(self.state_old_cc_)
             for substep in range(nsubsteps):
                 if substep > 0:
-                    self.state_old_tmp.copy_from(self.state_new_cc_)
+                    for b in range(self.lev.nboxes):  # amrex::Copy(tmp, state_new, 0, 0, ncompHydro_, nghost) (QuokkaSimulation.hpp:947)
+                        self.state_old_tmp.fabs[b][0:6].copy_(self.state_new_cc_.fabs[b][0:6])
                 success = self.advanceHydroAtLevel(old, dt_step)
                 if not success:
                     break
