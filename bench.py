@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--ncell", type=int, default=256, help="cells per dimension PER GPU (256 = blast_unigrid_256.in)")
     ap.add_argument("--max-grid-size", type=int, default=128)
+    ap.add_argument("--workload", choices=["sedov", "shell"], default="sedov",
+                    help="sedov = BASELINE metric (default); shell = RadhydroShell 256^3 radiation-hydro (BASELINE config 4), reported as a secondary line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-ncell", type=int, default=128)
     ap.add_argument("--cpu-steps", type=int, default=3)
@@ -92,7 +94,14 @@ def main():
 
     ctx = Context(local_rank)
     n_cell = weak_scaled_cells(args.ncell, world)
-    sim = sedov_problem(ctx, args.ncell, max_grid_size=args.max_grid_size, rank=rank, nranks=world, n_cell=n_cell)
+    if args.workload == "shell":
+        import numpy as np
+        from quokka_amd.radhydro import shell_problem
+        assert world == 1, "the shell line is single-GPU"
+        tab = np.loadtxt(os.path.join(ROOT, "tests", "golden", "dust_shell_initial_conditions.txt"), skiprows=1)
+        sim = shell_problem(ctx, args.ncell, (tab[:, 0], tab[:, 2], tab[:, 3]), max_grid_size=args.max_grid_size)
+    else:
+        sim = sedov_problem(ctx, args.ncell, max_grid_size=args.max_grid_size, rank=rank, nranks=world, n_cell=n_cell)
     sim.maxTimesteps_ = 10 ** 9
 
     def barrier():
@@ -136,7 +145,17 @@ def main():
                     "launches": kernels[dom][0],
                     "all_kernels_ms_per_launch": {k: v[1] / max(v[0], 1) for k, v in sorted(kernels.items())}}
 
-    if rank == 0:
+    if rank == 0 and args.workload == "shell":
+        print(json.dumps({"metric": "Mcell-updates/s on RadhydroShell (one update = hydro RK2 + all radiation substeps)",
+                          "value": total_cells * args.steps / elapsed / 1e6, "unit": "Mcell-updates/s", "n_gpus": 1, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "dtype": "f64", "data": "synthetic",
+                          "config": {"workload": f"RadhydroShell {args.ncell}^3 (tests/radhydro_shell_256.in), PLM, 1 group, kappa=20",
+                                     "radiation_substeps_per_step": sim.radiationCellUpdates_ / max(sim.cellUpdates_, 1),
+                                     "newton_iterations_per_solve": sim.rad_counters["newton_iterations"] / max(sim.rad_counters["solves"], 1)},
+                          "kernels_ms_per_launch": {k: v[1] / max(v[0], 1) for k, v in sorted(kernels.items())},
+                          "kernels_launches": {k: v[0] for k, v in sorted(kernels.items())},
+                          "reference_published_a100_1gpu": 39.04}), flush=True)
+    elif rank == 0:
         value = total_cells * args.steps / elapsed / 1e6
         out = {
             "metric": "Mcell-updates/s on 3D Sedov unigrid", "value": value, "unit": "Mcell-updates/s", "n_gpus": world,

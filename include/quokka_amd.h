@@ -84,6 +84,7 @@ enum { QK_LIMITER_MINMOD = 0, QK_LIMITER_MC = 1 };
 enum { QK_BC_REFLECT_ODD = -1, QK_BC_INT_DIR = 0, QK_BC_REFLECT_EVEN = 1, QK_BC_FOEXTRAP = 2, QK_BC_EXT_DIR = 3 };
 
 /* ------------------------------------------------------------------ context / level */
+#define QK_DEVICE_HOST_PLANNING (-1) /* planning-only context: host box / ghost-plan logic, no kernels (multi-rank CPU tests) */
 int qk_ctx_create(qk_ctx **ctx, int device);
 int qk_ctx_destroy(qk_ctx *ctx);
 const char *qk_last_error(qk_ctx *ctx);
@@ -264,6 +265,11 @@ int qk_ghost_plan_destroy(qk_ghost_plan *plan);
 /* remote traffic description: number of peers, and for peer k its rank and the number of doubles sent/received */
 int qk_ghost_plan_num_peers(qk_ghost_plan *plan);
 int qk_ghost_plan_peer(qk_ghost_plan *plan, int k, int *rank, int64_t *send_count, int64_t *recv_count);
+/* plan introspection (host-side; what the kernels below execute).  kind 0: same-rank copies, 1: strips packed for peer k,
+ * 2: strips unpacked from peer k, 3: ghost slabs beyond non-periodic domain faces.  Regions are in the DESTINATION index
+ * space; source index = destination index - shift; offset = position (in elements) inside the peer buffer. */
+int qk_ghost_plan_num_items(qk_ghost_plan *plan, int kind, int k);
+int qk_ghost_plan_item(qk_ghost_plan *plan, int kind, int k, int idx, int *dst_box, int *src_box, int lo[3], int hi[3], int shift[3], int64_t *offset);
 /* on-GPU copies (same-rank neighbours and periodic images) */
 int qk_FillBoundary_local(qk_ghost_plan *plan, qk_stream s, qk_array4 *state);
 /* iMultiFab flavour for redoFlag.FillBoundary (reference src/QuokkaSimulation.hpp:1157); plan built with ncomp = 1, nghost = 1 */

@@ -133,6 +133,8 @@ def lib() -> C.CDLL:
         L.qk_ghost_plan_destroy.argtypes = [vp]
         L.qk_ghost_plan_num_peers.argtypes = [vp]
         L.qk_ghost_plan_peer.argtypes = [vp, ci, P(ci), P(C.c_int64), P(C.c_int64)]
+        L.qk_ghost_plan_num_items.argtypes = [vp, ci, ci]
+        L.qk_ghost_plan_item.argtypes = [vp, ci, ci, ci, P(ci), P(ci), ci * 3, ci * 3, ci * 3, P(C.c_int64)]
         L.qk_FillBoundary_local.argtypes = [vp, vp, vp]
         L.qk_FillBoundary_local_int.argtypes = [vp, vp, vp]
         L.qk_FillBoundary_pack.argtypes = [vp, vp, ci, vp, vp]
@@ -153,7 +155,7 @@ DECLARED_SYMBOLS = [
     "qk_replaceFluxes", "qk_Saxpy", "qk_hydro_stage_scratch_bytes", "qk_hydro_stage_fused",
     "qk_rad_ConservedToPrimitive", "qk_rad_ComputeFluxes", "qk_rad_computeRadiationFluxes", "qk_rad_PredictStep", "qk_rad_AddFluxesRK2",
     "qk_rad_AddSourceTermsSingleGroup",
-    "qk_ghost_plan_create", "qk_ghost_plan_destroy", "qk_ghost_plan_num_peers", "qk_ghost_plan_peer",
+    "qk_ghost_plan_create", "qk_ghost_plan_destroy", "qk_ghost_plan_num_peers", "qk_ghost_plan_peer", "qk_ghost_plan_num_items", "qk_ghost_plan_item",
     "qk_FillBoundary_local", "qk_FillBoundary_local_int", "qk_FillBoundary_pack", "qk_FillBoundary_unpack", "qk_FillPhysicalBoundary",
 ]
 

@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(256) k_physbc(const CopyItem *items, qk_array4
 auto uploadItems(qk_ctx *ctx, std::vector<CopyItem> const &v, CopyItem **d) -> int
 {
 	*d = nullptr;
-	if (v.empty()) {
+	if (v.empty() || ctx->device < 0) { // planning-only context keeps the plan on the host
 		return QK_OK;
 	}
 	QK_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void **>(d), sizeof(CopyItem) * v.size()));
@@ -376,6 +376,50 @@ int qk_ghost_plan_peer(qk_ghost_plan *plan, int k, int *rank, int64_t *send_coun
 	*rank = plan->peers[k].rank;
 	*send_count = plan->peers[k].send_count;
 	*recv_count = plan->peers[k].recv_count;
+	return QK_OK;
+}
+
+// plan introspection (host): kind 0 = same-rank copies, 1 = sends to peer k, 2 = receives from peer k, 3 = physical-boundary slabs
+static auto planItems(qk_ghost_plan *plan, int kind, int k) -> std::vector<CopyItem> const *
+{
+	if (kind == 0) {
+		return &plan->local;
+	}
+	if (kind == 3) {
+		return &plan->shells;
+	}
+	if (k < 0 || k >= static_cast<int>(plan->peers.size())) {
+		return nullptr;
+	}
+	return (kind == 1) ? &plan->peers[k].send : (kind == 2) ? &plan->peers[k].recv : nullptr;
+}
+
+int qk_ghost_plan_num_items(qk_ghost_plan *plan, int kind, int k)
+{
+	if (plan == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	auto const *v = planItems(plan, kind, k);
+	return v == nullptr ? QK_ERR_INVALID : static_cast<int>(v->size());
+}
+
+int qk_ghost_plan_item(qk_ghost_plan *plan, int kind, int k, int idx, int *dst_box, int *src_box, int lo[3], int hi[3], int shift[3], int64_t *offset)
+{
+	if (plan == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	auto const *v = planItems(plan, kind, k);
+	QK_REQUIRE(plan->lev->ctx, v != nullptr && idx >= 0 && idx < static_cast<int>(v->size()) && dst_box && src_box && lo && hi && shift && offset,
+		   "qk_ghost_plan_item: bad argument");
+	CopyItem const &it = (*v)[idx];
+	*dst_box = it.dst_box;
+	*src_box = it.src_box;
+	for (int d = 0; d < 3; ++d) {
+		lo[d] = it.lo[d];
+		hi[d] = it.hi[d];
+		shift[d] = it.shift[d];
+	}
+	*offset = it.offset;
 	return QK_OK;
 }
 

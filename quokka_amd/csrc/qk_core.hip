@@ -13,6 +13,14 @@ int qk_ctx_create(qk_ctx **ctx, int device)
 	if (ctx == nullptr) {
 		return QK_ERR_INVALID;
 	}
+	if (device == QK_DEVICE_HOST_PLANNING) {
+		// planning-only context: box/ghost-plan logic (pure host code) without a GPU; every kernel entry point
+		// fails with QK_ERR_HIP on such a context.  Used by the multi-rank CPU (gloo) tests of the exchange protocol.
+		auto *c = new qk_ctx;
+		c->device = -1;
+		*ctx = c;
+		return QK_OK;
+	}
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
 		// fail loudly: there is no CPU fallback in the product path
@@ -67,6 +75,10 @@ int qk_level_create(qk_ctx *ctx, qk_level **lev, int ndim, int nboxes, const qk_
 		for (int d = 0; d < 3; ++d) {
 			L->maxlen[d] = std::max(L->maxlen[d], valid_boxes[b].hi[d] - valid_boxes[b].lo[d] + 1);
 		}
+	}
+	if (ctx->device < 0) { // planning-only context: no device copy
+		*lev = L;
+		return QK_OK;
 	}
 	hipError_t e = hipMalloc(reinterpret_cast<void **>(&L->d_boxes), sizeof(qk_box) * nboxes);
 	if (e == hipSuccess) {

@@ -46,6 +46,32 @@ class Context:
             pass
 
 
+class PlanningContext:
+    """qk_ctx with QK_DEVICE_HOST_PLANNING: box / ghost-plan logic on the host, no kernels.  Only the multi-rank CPU
+    (gloo) tests of the exchange protocol use it; the product path always runs on a Context."""
+
+    def __init__(self):
+        self.L = capi.lib()
+        self.device = torch.device("cpu")
+        h = C.c_void_p()
+        rc = self.L.qk_ctx_create(C.byref(h), -1)
+        if rc != capi.QK_OK:
+            raise capi.QkError(f"qk_ctx_create(planning) failed ({rc})")
+        self.h = h
+
+    def stream(self):
+        return None
+
+    def check(self, rc: int, what: str = ""):
+        capi.check(self.h, rc, what)
+
+    def __del__(self):
+        try:
+            self.L.qk_ctx_destroy(self.h)
+        except Exception:
+            pass
+
+
 def _box_struct(lo, hi) -> capi.Box:
     return capi.Box((C.c_int * 3)(*[int(x) for x in lo]), (C.c_int * 3)(*[int(x) for x in hi]))
 

@@ -124,27 +124,58 @@ class GhostExchange:
             self.peers.append((k, r.value, torch.empty(ns.value, dtype=dtype, device=ctx.device), torch.empty(nr.value, dtype=dtype, device=ctx.device)))
 
     def fill(self, state: MultiFab):
-        import torch.distributed as dist
+        """The product path: every copy is a HIP kernel behind the C-ABI."""
         ctx = self.lev.ctx
         L = ctx.L
         s = ctx.stream()
+
+        def pack(k, sbuf):
+            ctx.check(L.qk_FillBoundary_pack(self.h, s, k, state.ptr, C.c_void_p(sbuf.data_ptr())), "FillBoundary_pack")
+
+        def local():
+            ctx.check(L.qk_FillBoundary_local(self.h, s, state.ptr), "FillBoundary_local")
+
+        def unpack(k, rbuf):
+            ctx.check(L.qk_FillBoundary_unpack(self.h, s, k, state.ptr, C.c_void_p(rbuf.data_ptr())), "FillBoundary_unpack")
+
+        def physbc():
+            ctx.check(L.qk_FillPhysicalBoundary(self.h, s, state.ptr, self.bcs, self.dirichlet), "FillPhysicalBoundary")
+
+        self.fill_with(pack, local, unpack, physbc)
+
+    def fill_with(self, pack, local, unpack, physbc):
+        """Exchange protocol, independent of who moves the bytes inside a rank (HIP kernels in the product; numpy in the
+        world_size-2 gloo tests): pack -> one send/recv pair per peer -> same-rank copies while the wire is busy -> wait ->
+        unpack -> physical boundaries (reference src/simulation.hpp:1755-1773)."""
+        import torch.distributed as dist
         reqs = []
         if self.peers:
             for k, r, sbuf, rbuf in self.peers:
-                ctx.check(L.qk_FillBoundary_pack(self.h, s, k, state.ptr, C.c_void_p(sbuf.data_ptr())), "FillBoundary_pack")
+                pack(k, sbuf)
+            # (RCCL work is stream-ordered after the pack kernels by torch's ProcessGroupNCCL: no host sync here)
             ops = []
             for k, r, sbuf, rbuf in self.peers:
                 ops.append(dist.P2POp(dist.isend, sbuf, r))
                 ops.append(dist.P2POp(dist.irecv, rbuf, r))
             reqs = dist.batch_isend_irecv(ops)
-        # same-GPU neighbours while the wire is busy
-        ctx.check(L.qk_FillBoundary_local(self.h, s, state.ptr), "FillBoundary_local")
+        local()
         for q in reqs:
             q.wait()
         for k, r, sbuf, rbuf in self.peers:
-            ctx.check(L.qk_FillBoundary_unpack(self.h, s, k, state.ptr, C.c_void_p(rbuf.data_ptr())), "FillBoundary_unpack")
+            unpack(k, rbuf)
         if not self.geom.is_all_periodic():
-            ctx.check(L.qk_FillPhysicalBoundary(self.h, s, state.ptr, self.bcs, self.dirichlet), "FillPhysicalBoundary")
+            physbc()
+
+    def items(self, kind: int, k: int = 0):
+        """Plan introspection: list of (dst_box, src_box, lo, hi, shift, offset)."""
+        L = self.lev.ctx.L
+        out = []
+        for idx in range(L.qk_ghost_plan_num_items(self.h, kind, k)):
+            db, sb, off = C.c_int(), C.c_int(), C.c_int64()
+            lo, hi, sh = (C.c_int * 3)(), (C.c_int * 3)(), (C.c_int * 3)()
+            self.lev.ctx.check(L.qk_ghost_plan_item(self.h, kind, k, idx, C.byref(db), C.byref(sb), lo, hi, sh, C.byref(off)), "qk_ghost_plan_item")
+            out.append((db.value, sb.value, list(lo), list(hi), list(sh), off.value))
+        return out
 
     def __del__(self):
         try:

@@ -1,0 +1,141 @@
+"""world_size-2 (and 4) CPU test of the N > 1 path: box -> rank map, ghost-exchange plan (host logic of the C-ABI),
+wire order and the torch.distributed exchange protocol of GhostExchange.fill_with, plus the scalar all-reduces of the
+driver.  The bytes inside a rank are moved by numpy here (the GPU box moves them with the pack/copy/unpack kernels that
+execute the very same plan items); the result must equal the oracle's single-process ghost fill, cell for cell."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def region(fab, begin, lo, hi, shift=(0, 0, 0)):
+    """numpy view of fab[(ncomp), z, y, x] over the index region [lo, hi] shifted by -shift"""
+    sl = [slice(None)]
+    for d in (2, 1, 0):
+        sl.append(slice(lo[d] - shift[d] - begin[d], hi[d] - shift[d] - begin[d] + 1))
+    return fab[tuple(sl)]
+
+
+def worker(rank, world, port, problem, N, mgs, periodic, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.pyoracle import SEDOV, Oracle
+        from quokka_amd import capi
+        from quokka_amd.multifab import Level, PlanningContext
+        from quokka_amd.simulation import GhostExchange, Geometry, chop_domain, distribute_boxes
+
+        ng, nc = 4, 6
+        # reference solution: the oracle fills ALL boxes in one process
+        o = Oracle("direct")
+        so = o.sim(problem, 3, [N] * 3, [0, 0, 0], [1.2] * 3, periodic, max_grid_size=[mgs] * 3)
+        for _ in range(2):
+            assert so.step()
+        unfilled = [so.state(b).copy() for b in range(so.nboxes)]
+        so.fill_ghosts(0, so.time)
+        filled = [so.state(b) for b in range(so.nboxes)]
+
+        geom = Geometry(3, [N] * 3, [0.0] * 3, [1.2] * 3, list(periodic))
+        all_boxes = chop_domain(geom.n_cell, [mgs] * 3)
+        owner = distribute_boxes(all_boxes, world, geom.n_cell, [mgs] * 3)
+        assert sorted(set(owner)) == list(range(world)), owner
+        mine = [g for g, r in enumerate(owner) if r == rank]
+        ctx = PlanningContext()
+        lev = Level(ctx, 3, [all_boxes[g] for g in mine])
+        bcs = []
+        for c in range(nc):
+            lo = [capi.BC_REFLECT_ODD if c == 1 + d else capi.BC_REFLECT_EVEN for d in range(3)]
+            bcs.append((lo, list(lo)))
+        ex = GhostExchange(lev, geom, nc, ng, all_boxes, owner, rank, bcs)
+        assert len(ex.peers) == world - 1 or N // mgs > 2
+
+        fabs = [unfilled[g].copy() for g in mine]  # (nc, z, y, x) with ghosts
+        begins = [[all_boxes[g][0][d] - ng for d in range(3)] for g in mine]
+
+        def pack(k, sbuf):
+            buf = sbuf.numpy()
+            for db, sb, lo, hi, sh, off in ex.items(1, k):
+                r = region(fabs[sb], begins[sb], lo, hi, sh)
+                buf[off:off + r.size] = r.reshape(-1)
+
+        def local():
+            for db, sb, lo, hi, sh, off in ex.items(0):
+                region(fabs[db], begins[db], lo, hi)[...] = region(fabs[sb], begins[sb], lo, hi, sh)
+
+        def unpack(k, rbuf):
+            buf = rbuf.numpy()
+            for db, sb, lo, hi, sh, off in ex.items(2, k):
+                r = region(fabs[db], begins[db], lo, hi)
+                r[...] = buf[off:off + r.size].reshape(r.shape)
+
+        def physbc():
+            dom_hi = N - 1
+            for db, sb, lo, hi, sh, off in ex.items(3):
+                f = fabs[db]
+                for k in range(lo[2], hi[2] + 1):
+                    for j in range(lo[1], hi[1] + 1):
+                        for i in range(lo[0], hi[0] + 1):
+                            idx, src, sign = (i, j, k), [i, j, k], np.ones(nc)
+                            for d in range(3):
+                                if idx[d] < 0:
+                                    src[d] = -idx[d] - 1
+                                    sign[1 + d] *= -1.0
+                                elif idx[d] > dom_hi:
+                                    src[d] = 2 * dom_hi - idx[d] + 1
+                                    sign[1 + d] *= -1.0
+                            b0 = begins[db]
+                            f[:, k - b0[2], j - b0[1], i - b0[0]] = sign * f[:, src[2] - b0[2], src[1] - b0[1], src[0] - b0[0]]
+
+        ex.fill_with(pack, local, unpack, physbc)
+        ok = all(np.array_equal(fabs[n], filled[g]) for n, g in enumerate(mine))
+        nbad = sum(int((fabs[n] != filled[g]).sum()) for n, g in enumerate(mine))
+
+        # scalar collectives of the driver (dt / CFL max, FOFC redo count)
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        c = torch.tensor([rank + 10], dtype=torch.int64)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        ok = ok and float(t.item()) == float(world) and int(c.item()) == sum(r + 10 for r in range(world))
+        q.put((rank, ok, nbad, len(ex.peers)))
+    finally:
+        dist.destroy_process_group()
+
+
+def run(world, problem, N, mgs, periodic):
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    port = free_port()
+    procs = [mpctx.Process(target=worker, args=(r, world, port, problem, N, mgs, periodic, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return sorted(results)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_ghost_exchange_reflecting_octant(world):
+    """Sedov octant (reflecting walls), 16^3 in 8^3 boxes: 8 boxes over 2 / 4 ranks"""
+    from oracle.pyoracle import SEDOV
+    for rank, ok, nbad, npeers in run(world, SEDOV, 16, 8, [0, 0, 0]):
+        assert ok, f"rank {rank}: {nbad} ghost cells differ from the single-process fill"
+        assert npeers >= 1
