@@ -1,0 +1,933 @@
+// quokka_host.hpp — C++17 host mirror of the reference's operator surface on the hydro path:
+//   Physics_Traits / Physics_Indices            reference src/physics_info.hpp:8-47
+//   quokka::EOS_Traits, HydroSystem_Traits       reference src/hydro/EOS.hpp:32-37, src/hydro/hydro_system.hpp:38-41
+//   HyperbolicSystem<problem_t>, HydroSystem<problem_t>   static methods with the reference's names and arguments; every body is ONE
+//                                                call into the C-ABI (include/quokka_amd.h) — no arithmetic on the host
+//   AMRSimulation<problem_t> / QuokkaSimulation<problem_t>   uniform-grid (max_level = 0) evolve loop, dt control, level-0 ghost fill,
+//                                                RK2 + FOFC + retries (reference src/simulation.hpp:703-981,1704-1785, src/QuokkaSimulation.hpp:885-1568)
+// Problems specialise the same trait structs and member templates as in the reference (setInitialConditionsOnGrid,
+// setCustomBoundaryConditions, computeAfterEvolve, ...).  Device hooks are evaluated on host staging data: ICs run on a host
+// buffer that is uploaded; setCustomBoundaryConditions is sampled to build the constant-Dirichlet face model of the C-ABI.
+#ifndef QK_HOST_QUOKKA_HOST_HPP_
+#define QK_HOST_QUOKKA_HOST_HPP_
+
+#include <chrono>
+#include <limits>
+#include <memory>
+
+#include "amrex_mini.hpp"
+
+// Microphysics fundamental_constants.H (CODATA 2018, cgs)
+namespace C
+{
+constexpr double k_B = 1.380649e-16;
+constexpr double m_u = 1.6605390666e-24;
+constexpr double c_light = 2.99792458e10;
+constexpr double a_rad = 4.0 * 5.670374419e-5 / c_light;
+} // namespace C
+
+using Real = amrex::Real;
+
+struct Physics_NumVars {
+	static const int numHydroVars = 6;
+	static const int numRadVars = 4;
+};
+
+template <typename problem_t> struct Physics_Traits {
+	static constexpr bool is_hydro_enabled = false;
+	static constexpr int numMassScalars = 0;
+	static constexpr int numPassiveScalars = numMassScalars + 0;
+	static constexpr bool is_radiation_enabled = false;
+	static constexpr bool is_mhd_enabled = false;
+	static constexpr int nGroups = 1;
+};
+
+template <typename problem_t> struct Physics_Indices {
+	static constexpr int nvarTotal_cc = Physics_Traits<problem_t>::numPassiveScalars + Physics_NumVars::numHydroVars +
+					    (Physics_Traits<problem_t>::is_radiation_enabled ? Physics_NumVars::numRadVars * Physics_Traits<problem_t>::nGroups : 0);
+	static const int hydroFirstIndex = 0;
+	static const int pscalarFirstIndex = Physics_NumVars::numHydroVars;
+	static const int radFirstIndex = pscalarFirstIndex + Physics_Traits<problem_t>::numPassiveScalars;
+};
+
+namespace quokka
+{
+template <typename problem_t> struct EOS_Traits {
+	static constexpr double gamma = 5. / 3.;
+	static constexpr double cs_isothermal = std::numeric_limits<double>::quiet_NaN();
+	static constexpr double mean_molecular_weight = std::numeric_limits<double>::quiet_NaN();
+	static constexpr double boltzmann_constant = C::k_B;
+};
+enum class centering { cc = 0, fc };
+enum class direction { na = -1, x, y, z };
+// reference src/grid.hpp
+struct grid {
+	amrex::Array4<double> array_;
+	amrex::Box indexRange_;
+	amrex::GpuArray<double, AMREX_SPACEDIM> dx_, prob_lo_, prob_hi_;
+};
+} // namespace quokka
+
+template <typename problem_t> struct HydroSystem_Traits {
+	static constexpr bool reconstruct_eint = true;
+};
+
+enum class FluxDir { X1 = 0, X2 = 1, X3 = 2 };
+enum SlopeLimiter { minmod = 0, MC };
+enum class RiemannSolver { HLLC, LLF, HLLD };
+
+// process-wide C-ABI handles (amrex::Initialize analogue)
+namespace qkhost
+{
+struct Runtime {
+	qk_ctx *ctx = nullptr;
+	qk_level *lev = nullptr; // level 0
+	static auto get() -> Runtime &
+	{
+		static Runtime r;
+		return r;
+	}
+};
+inline void check(int rc, const char *what)
+{
+	if (rc != QK_OK) {
+		amrex::Abort(std::string(what) + ": " + qk_last_error(Runtime::get().ctx));
+	}
+}
+inline auto tab(amrex::MultiFab const &mf) -> qk_array4 * { return reinterpret_cast<qk_array4 *>(mf.arrays()); }
+inline auto itab(amrex::iMultiFab const &mf) -> qk_iarray4 * { return reinterpret_cast<qk_iarray4 *>(mf.arrays()); }
+template <typename problem_t> auto traits() -> qk_hydro_traits
+{
+	return {quokka::EOS_Traits<problem_t>::gamma,
+		quokka::EOS_Traits<problem_t>::cs_isothermal,
+		quokka::EOS_Traits<problem_t>::mean_molecular_weight,
+		quokka::EOS_Traits<problem_t>::boltzmann_constant,
+		HydroSystem_Traits<problem_t>::reconstruct_eint ? 1 : 0,
+		Physics_Traits<problem_t>::numPassiveScalars,
+		Physics_Traits<problem_t>::numMassScalars,
+		AMREX_SPACEDIM};
+}
+} // namespace qkhost
+
+template <typename problem_t> class HyperbolicSystem
+{
+      public:
+	template <FluxDir DIR> static void ReconstructStatesConstant(amrex::MultiFab const &q, amrex::MultiFab &l, amrex::MultiFab &r, int nghost, int nvars)
+	{
+		qkhost::check(qk_ReconstructStatesConstant(qkhost::Runtime::get().lev, nullptr, static_cast<int>(DIR), qkhost::tab(q), qkhost::tab(l), qkhost::tab(r),
+							   nghost, nvars),
+			      "ReconstructStatesConstant");
+	}
+	template <FluxDir DIR, SlopeLimiter limiter>
+	static void ReconstructStatesPLM(amrex::MultiFab const &q, amrex::MultiFab &l, amrex::MultiFab &r, int nghost, int nvars)
+	{
+		qkhost::check(qk_ReconstructStatesPLM(qkhost::Runtime::get().lev, nullptr, static_cast<int>(DIR), static_cast<int>(limiter), qkhost::tab(q),
+						      qkhost::tab(l), qkhost::tab(r), nghost, nvars),
+			      "ReconstructStatesPLM");
+	}
+	template <FluxDir DIR>
+	static void ReconstructStatesPPM(amrex::MultiFab const &q, amrex::MultiFab &l, amrex::MultiFab &r, int nghost, int nvars, int iReadFrom = 0,
+					 int iWriteFrom = 0)
+	{
+		qkhost::check(qk_ReconstructStatesPPM(qkhost::Runtime::get().lev, nullptr, static_cast<int>(DIR), qkhost::tab(q), qkhost::tab(l), qkhost::tab(r), nghost,
+						      nvars, iReadFrom, iWriteFrom),
+			      "ReconstructStatesPPM");
+	}
+};
+
+template <typename problem_t> class HydroSystem : public HyperbolicSystem<problem_t>
+{
+      public:
+	static constexpr int nmscalars_ = Physics_Traits<problem_t>::numMassScalars;
+	static constexpr int nscalars_ = Physics_Traits<problem_t>::numPassiveScalars;
+	static constexpr int nvar_ = Physics_NumVars::numHydroVars + nscalars_;
+	enum consVarIndex { density_index = 0, x1Momentum_index, x2Momentum_index, x3Momentum_index, energy_index, internalEnergy_index, scalar0_index };
+	enum primVarIndex { primDensity_index = 0, x1Velocity_index, x2Velocity_index, x3Velocity_index, pressure_index, primEint_index, primScalar0_index };
+	static constexpr double gamma_ = quokka::EOS_Traits<problem_t>::gamma;
+	static constexpr bool reconstruct_eint = HydroSystem_Traits<problem_t>::reconstruct_eint;
+
+	static auto lev() -> qk_level * { return qkhost::Runtime::get().lev; }
+
+	static void ConservedToPrimitive(amrex::MultiFab const &cons, amrex::MultiFab &prim, int nghost)
+	{
+		auto t = qkhost::traits<problem_t>();
+		qkhost::check(qk_hydro_ConservedToPrimitive(lev(), nullptr, &t, qkhost::tab(cons), qkhost::tab(prim), nghost), "ConservedToPrimitive");
+	}
+	template <FluxDir DIR> static void ComputeFlatteningCoefficients(amrex::MultiFab const &prim, amrex::MultiFab &chi, int nghost)
+	{
+		auto t = qkhost::traits<problem_t>();
+		qkhost::check(qk_hydro_ComputeFlatteningCoefficients(lev(), nullptr, &t, static_cast<int>(DIR), qkhost::tab(prim), qkhost::tab(chi), nghost),
+			      "ComputeFlatteningCoefficients");
+	}
+	template <FluxDir DIR>
+	static void FlattenShocks(amrex::MultiFab const &q, amrex::MultiFab const &c1, amrex::MultiFab const &c2, amrex::MultiFab const &c3, amrex::MultiFab &l,
+				  amrex::MultiFab &r, int nghost, int nvars)
+	{
+		auto t = qkhost::traits<problem_t>();
+		qkhost::check(qk_hydro_FlattenShocks(lev(), nullptr, &t, static_cast<int>(DIR), qkhost::tab(q), qkhost::tab(c1), qkhost::tab(c2), qkhost::tab(c3),
+						     qkhost::tab(l), qkhost::tab(r), nghost, nvars),
+			      "FlattenShocks");
+	}
+	template <RiemannSolver RIEMANN, FluxDir DIR>
+	static void ComputeFluxes(amrex::MultiFab &flux, amrex::MultiFab &fvel, amrex::MultiFab const &l, amrex::MultiFab const &r, amrex::MultiFab const &prim,
+				  amrex::Real K_visc)
+	{
+		static_assert(RIEMANN != RiemannSolver::HLLD, "MHD is out of scope");
+		auto t = qkhost::traits<problem_t>();
+		qkhost::check(qk_hydro_ComputeFluxes(lev(), nullptr, &t, RIEMANN == RiemannSolver::LLF ? QK_RIEMANN_LLF : QK_RIEMANN_HLLC, static_cast<int>(DIR),
+						     qkhost::tab(flux), qkhost::tab(fvel), qkhost::tab(l), qkhost::tab(r), qkhost::tab(prim), K_visc),
+			      "ComputeFluxes");
+	}
+	static void ComputeRhsFromFluxes(amrex::MultiFab &rhs, std::array<amrex::MultiFab, AMREX_SPACEDIM> const &fluxArray,
+					 amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> dx, int nvars)
+	{
+		auto t = qkhost::traits<problem_t>();
+		const qk_array4 *f[3] = {nullptr, nullptr, nullptr};
+		double d3[3] = {1, 1, 1};
+		for (int d = 0; d < AMREX_SPACEDIM; ++d) {
+			f[d] = qkhost::tab(fluxArray[d]);
+			d3[d] = dx[d];
+		}
+		qkhost::check(qk_hydro_ComputeRhsFromFluxes(lev(), nullptr, &t, qkhost::tab(rhs), f, d3, nvars), "ComputeRhsFromFluxes");
+	}
+	static void AddInternalEnergyPdV(amrex::MultiFab &rhs, amrex::MultiFab const &cons, amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> dx,
+					 std::array<amrex::MultiFab, AMREX_SPACEDIM> const &faceVel, amrex::iMultiFab const &redoFlag)
+	{
+		auto t = qkhost::traits<problem_t>();
+		const qk_array4 *v[3] = {nullptr, nullptr, nullptr};
+		double d3[3] = {1, 1, 1};
+		for (int d = 0; d < AMREX_SPACEDIM; ++d) {
+			v[d] = qkhost::tab(faceVel[d]);
+			d3[d] = dx[d];
+		}
+		qkhost::check(qk_hydro_AddInternalEnergyPdV(lev(), nullptr, &t, qkhost::tab(rhs), qkhost::tab(cons), d3, v, qkhost::itab(redoFlag)),
+			      "AddInternalEnergyPdV");
+	}
+	static void PredictStep(amrex::MultiFab const &old, amrex::MultiFab &neu, amrex::MultiFab const &rhs, double dt, int nvars, amrex::iMultiFab &redoFlag,
+				int64_t *d_redo_count = nullptr)
+	{
+		auto t = qkhost::traits<problem_t>();
+		qkhost::check(qk_hydro_PredictStep(lev(), nullptr, &t, qkhost::tab(old), qkhost::tab(neu), qkhost::tab(rhs), dt, nvars, qkhost::itab(redoFlag),
+						   d_redo_count),
+			      "PredictStep");
+	}
+	static void EnforceLimits(amrex::Real densityFloor, amrex::Real tempFloor, amrex::MultiFab &state)
+	{
+		auto t = qkhost::traits<problem_t>();
+		qkhost::check(qk_hydro_EnforceLimits(lev(), nullptr, &t, densityFloor, tempFloor, qkhost::tab(state)), "EnforceLimits");
+	}
+	static void SyncDualEnergy(amrex::MultiFab &cons, int *d_error_flag = nullptr)
+	{
+		auto t = qkhost::traits<problem_t>();
+		qkhost::check(qk_hydro_SyncDualEnergy(lev(), nullptr, &t, qkhost::tab(cons), d_error_flag), "SyncDualEnergy");
+	}
+	// ParReduce max over the local valid cells (result on the host)
+	static auto maxSignalSpeedLocal(amrex::MultiFab const &cons, int which = 0) -> amrex::Real
+	{
+		auto t = qkhost::traits<problem_t>();
+		static double *d_res = nullptr;
+		if (d_res == nullptr) {
+			QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_res), sizeof(double)));
+		}
+		qkhost::check(qk_hydro_maxSignalSpeedLocal(lev(), nullptr, &t, which, qkhost::tab(cons), d_res), "maxSignalSpeedLocal");
+		double h = 0;
+		QK_HOST_HIP(hipMemcpy(&h, d_res, sizeof(double), hipMemcpyDeviceToHost));
+		return h;
+	}
+};
+
+// gas / radiation variable indices problems refer to (reference src/radiation/radiation_system.hpp:171-188)
+template <typename problem_t> class RadSystem
+{
+      public:
+	enum gasVarIndex { gasDensity_index = 0, x1GasMomentum_index, x2GasMomentum_index, x3GasMomentum_index, gasEnergy_index, gasInternalEnergy_index, scalar0_index };
+	static constexpr int nstartHyperbolic_ = Physics_Indices<problem_t>::radFirstIndex;
+	enum radVarIndex { radEnergy_index = nstartHyperbolic_, x1RadFlux_index, x2RadFlux_index, x3RadFlux_index };
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+template <typename problem_t> class AMRSimulation
+{
+      public:
+	// public data members (reference src/simulation.hpp:144-173)
+	amrex::Real maxDt_ = std::numeric_limits<double>::max();
+	amrex::Real initDt_ = std::numeric_limits<double>::max();
+	amrex::Real constantDt_ = 0.0;
+	amrex::Real stopTime_ = 1.0;
+	amrex::Real cflNumber_ = 0.3;
+	amrex::Long maxTimesteps_ = 10000;
+	int plotfileInterval_ = -1;
+	int checkpointInterval_ = -1;
+	amrex::Real densityFloor_ = 0.0;
+	amrex::Real tempFloor_ = 0.0;
+	amrex::Vector<amrex::Real> tNew_{0.0};
+	amrex::Vector<amrex::Real> dt_{1.e100};
+	amrex::Vector<int> istep{0};
+	amrex::Long cellUpdates_ = 0;
+	int nghost_cc_ = 4;
+	bool areInitialConditionsDefined_ = false;
+
+	amrex::Vector<amrex::Geometry> geom{1};
+	std::vector<amrex::Box> grids_; // level-0 BoxArray
+	amrex::Vector<amrex::BCRec> BCs_cc_;
+	amrex::Vector<amrex::MultiFab> state_new_cc_{1}, state_old_cc_{1};
+
+	explicit AMRSimulation(amrex::Vector<amrex::BCRec> &BCs_cc) : BCs_cc_(BCs_cc) { initialize(); }
+	virtual ~AMRSimulation()
+	{
+		if (plan_ != nullptr) {
+			qk_ghost_plan_destroy(plan_);
+		}
+	}
+
+	// device hook a problem may specialise (reference src/simulation.hpp:1550-1561); evaluated on host staging data
+	static void setCustomBoundaryConditions(const amrex::IntVect & /*iv*/, amrex::Array4<amrex::Real> const & /*dest*/, int /*dcomp*/, int /*numcomp*/,
+						amrex::GeometryData const & /*geom*/, amrex::Real /*time*/, const amrex::BCRec * /*bcr*/, int /*bcomp*/,
+						int /*orig_comp*/)
+	{
+	}
+
+	void initialize()
+	{
+		readParameters();
+		auto &rt = qkhost::Runtime::get();
+		if (rt.ctx == nullptr) {
+			qkhost::check(qk_ctx_create(&rt.ctx, 0), "qk_ctx_create");
+		}
+		// geometry + BoxArray from the deck (amrex.n_cell, geometry.*, amr.max_grid_size)
+		amrex::ParmParse pg("geometry");
+		amrex::ParmParse pa("amr");
+		std::vector<double> plo{0, 0, 0}, phi{1, 1, 1};
+		std::vector<int> per{0, 0, 0}, ncell{32, 32, 32}, mgs;
+		pg.queryarr("prob_lo", plo);
+		pg.queryarr("prob_hi", phi);
+		pg.queryarr("is_periodic", per);
+		pa.queryarr("n_cell", ncell);
+		if (!pa.queryarr("max_grid_size", mgs) || mgs.empty()) {
+			mgs = {128};
+		}
+		while (mgs.size() < 3) {
+			mgs.push_back(mgs.back());
+		}
+		auto &g = geom[0];
+		for (int d = 0; d < 3; ++d) {
+			bool const active = d < AMREX_SPACEDIM;
+			g.domain.lo[d] = 0;
+			g.domain.hi[d] = active ? ncell[d] - 1 : 0;
+			g.periodic[d] = active ? per[d] : 0;
+			if (active) {
+				g.prob_lo[d] = plo[d];
+				g.prob_hi[d] = phi[d];
+				g.dx[d] = (phi[d] - plo[d]) / ncell[d];
+			}
+		}
+		grids_.clear();
+		int nb[3];
+		for (int d = 0; d < 3; ++d) {
+			nb[d] = (d < AMREX_SPACEDIM) ? (g.domain.length(d) + mgs[d] - 1) / mgs[d] : 1;
+		}
+		for (int kb = 0; kb < nb[2]; ++kb) {
+			for (int jb = 0; jb < nb[1]; ++jb) {
+				for (int ib = 0; ib < nb[0]; ++ib) {
+					int const idx[3] = {ib, jb, kb};
+					amrex::Box b;
+					for (int d = 0; d < 3; ++d) {
+						int const len = g.domain.length(d);
+						int const base = len / nb[d], rem = len % nb[d];
+						b.lo[d] = idx[d] * base + std::min(idx[d], rem);
+						b.hi[d] = b.lo[d] + base + (idx[d] < rem ? 1 : 0) - 1;
+					}
+					grids_.push_back(b);
+				}
+			}
+		}
+		std::vector<qk_box> qb;
+		for (auto const &b : grids_) {
+			qb.push_back({{b.lo[0], b.lo[1], b.lo[2]}, {b.hi[0], b.hi[1], b.hi[2]}});
+		}
+		if (rt.lev != nullptr) {
+			qk_level_destroy(rt.lev);
+		}
+		qkhost::check(qk_level_create(rt.ctx, &rt.lev, AMREX_SPACEDIM, static_cast<int>(qb.size()), qb.data()), "qk_level_create");
+		int const nc = Physics_Indices<problem_t>::nvarTotal_cc;
+		state_new_cc_[0].define(grids_, nc, nghost_cc_);
+		state_old_cc_[0].define(grids_, nc, nghost_cc_);
+		// ghost-exchange plan (single rank: every box is local)
+		qk_geometry qg{};
+		for (int d = 0; d < 3; ++d) {
+			qg.domain.lo[d] = g.domain.lo[d];
+			qg.domain.hi[d] = g.domain.hi[d];
+			qg.periodic[d] = g.periodic[d];
+		}
+		qg.ndim = AMREX_SPACEDIM;
+		std::vector<int> owner(qb.size(), 0);
+		qkhost::check(qk_ghost_plan_create(rt.lev, &plan_, &qg, nghost_cc_, nc, static_cast<int>(qb.size()), qb.data(), owner.data(), 0),
+			      "qk_ghost_plan_create");
+	}
+
+	void readParameters() // reference src/simulation.hpp:541-636 (the keys the config decks use)
+	{
+		amrex::ParmParse pp;
+		pp.query("max_timesteps", maxTimesteps_);
+		pp.query("cfl", cflNumber_);
+		pp.query("stop_time", stopTime_);
+		pp.query("plotfile_interval", plotfileInterval_);
+		pp.query("checkpoint_interval", checkpointInterval_);
+		pp.query("density_floor", densityFloor_);
+		pp.query("temperature_floor", tempFloor_);
+	}
+
+	[[nodiscard]] auto CountCells(int /*lev*/) const -> amrex::Long
+	{
+		amrex::Long n = 0;
+		for (auto const &b : grids_) {
+			n += b.numPts();
+		}
+		return n;
+	}
+
+	// user hooks (specialised per problem)
+	virtual void setInitialConditionsOnGrid(quokka::grid const &grid_elem) = 0;
+	virtual void preCalculateInitialConditions() {}
+	virtual void computeAfterEvolve(amrex::Vector<amrex::Real> & /*initSumCons*/) {}
+
+	// reference src/simulation.hpp:1608-1626
+	void setInitialConditions()
+	{
+		preCalculateInitialConditions();
+		auto &mf = state_new_cc_[0];
+		for (int b = 0; b < mf.size(); ++b) {
+			std::vector<double> h(static_cast<size_t>(mf.fabbox(b).numPts()) * mf.nComp(), 0.0);
+			quokka::grid grid_elem{amrex::Array4<double>(h.data(), mf.fabbox(b), mf.nComp()), mf.validbox(b), geom[0].CellSizeArray(),
+					       geom[0].ProbLoArray(), geom[0].ProbHiArray()};
+			setInitialConditionsOnGrid(grid_elem);
+			mf.copyFromHost(b, h);
+		}
+		buildDirichletModel();
+		fillBoundaryConditions(state_new_cc_[0]);
+		amrex::MultiFab::Copy(state_old_cc_[0], state_new_cc_[0]);
+		areInitialConditionsDefined_ = true;
+	}
+
+	// level-0 branch of fillBoundaryConditions (reference src/simulation.hpp:1751-1776)
+	void fillBoundaryConditions(amrex::MultiFab &state)
+	{
+		qkhost::check(qk_FillBoundary_local(plan_, nullptr, qkhost::tab(state)), "FillBoundary");
+		if (!geom[0].isAllPeriodic()) {
+			std::vector<qk_bcrec> bcs(BCs_cc_.size());
+			for (size_t n = 0; n < BCs_cc_.size(); ++n) {
+				for (int d = 0; d < 3; ++d) {
+					bcs[n].lo[d] = (d < AMREX_SPACEDIM) ? BCs_cc_[n].lo(d) : 0;
+					bcs[n].hi[d] = (d < AMREX_SPACEDIM) ? BCs_cc_[n].hi(d) : 0;
+				}
+			}
+			qkhost::check(qk_FillPhysicalBoundary(plan_, nullptr, qkhost::tab(state), bcs.data(), hasDirichlet_ ? dirichlet_ : nullptr),
+				      "FillPhysicalBoundary");
+		}
+	}
+
+      protected:
+	qk_ghost_plan *plan_ = nullptr;
+	qk_dirichlet_face dirichlet_[6] = {};
+	bool hasDirichlet_ = false;
+
+	// Sample the problem's setCustomBoundaryConditions on host staging cells beyond each non-periodic face: if it writes a state
+	// there (as HydroShocktube's does), that face becomes a constant-Dirichlet face of the C-ABI's closed model.
+	void buildDirichletModel()
+	{
+		int const nc = Physics_Indices<problem_t>::nvarTotal_cc;
+		auto const &g = geom[0];
+		double const sentinel = -7.7e300;
+		for (int d = 0; d < AMREX_SPACEDIM; ++d) {
+			if (g.isPeriodic(d)) {
+				continue;
+			}
+			for (int side = 0; side < 2; ++side) {
+				double vals[2][16];
+				for (int probe = 0; probe < 2; ++probe) { // two different ghost cells: the model requires a constant state
+					amrex::IntVect iv(g.domain.lo[0], g.domain.lo[1], g.domain.lo[2]);
+					iv[d] = (side == 0) ? g.domain.lo[d] - 1 - probe : g.domain.hi[d] + 1 + probe;
+					amrex::Box cell(iv, iv);
+					std::vector<double> h(static_cast<size_t>(nc), sentinel);
+					amrex::Array4<double> a(h.data(), cell, nc);
+					AMRSimulation<problem_t>::setCustomBoundaryConditions(iv, a, 0, nc, g.data(), 0.0, BCs_cc_.data(), 0, 0);
+					for (int n = 0; n < nc; ++n) {
+						vals[probe][n] = h[n];
+					}
+				}
+				bool wrote = false, constant = true;
+				for (int n = 0; n < nc; ++n) {
+					wrote = wrote || (vals[0][n] != sentinel);
+					constant = constant && (vals[0][n] == vals[1][n]);
+				}
+				if (wrote) {
+					if (!constant) {
+						amrex::Abort("setCustomBoundaryConditions is not a constant state per face: not expressible in the C-ABI's closed BC set");
+					}
+					auto &f = dirichlet_[2 * d + side];
+					f.enabled = 1;
+					for (int n = 0; n < nc; ++n) {
+						f.values[n] = vals[0][n];
+					}
+					hasDirichlet_ = true;
+				}
+			}
+		}
+	}
+};
+
+template <typename problem_t> class QuokkaSimulation : public AMRSimulation<problem_t>
+{
+      public:
+	using B = AMRSimulation<problem_t>;
+	using B::BCs_cc_;
+	using B::cflNumber_;
+	using B::densityFloor_;
+	using B::dt_;
+	using B::geom;
+	using B::grids_;
+	using B::istep;
+	using B::maxTimesteps_;
+	using B::nghost_cc_;
+	using B::state_new_cc_;
+	using B::state_old_cc_;
+	using B::stopTime_;
+	using B::tempFloor_;
+	using B::tNew_;
+
+	// reference src/QuokkaSimulation.hpp:125-144
+	int integratorOrder_ = 2;
+	int reconstructionOrder_ = 3;
+	int radiationReconstructionOrder_ = 3;
+	int useDualEnergy_ = 1;
+	int abortOnFofcFailure_ = 1;
+	amrex::Real artificialViscosityK_ = 0.;
+	bool computeReferenceSolution_ = false;
+	amrex::Real errorNorm_ = std::numeric_limits<double>::quiet_NaN();
+	amrex::Real pressureFloor_ = 0.;
+	long fofcStages_ = 0, retries_ = 0;
+	double elapsedSeconds_ = 0.0;
+
+	static constexpr int ncompHydro_ = HydroSystem<problem_t>::nvar_;
+
+	explicit QuokkaSimulation(amrex::Vector<amrex::BCRec> &BCs_cc) : AMRSimulation<problem_t>(BCs_cc)
+	{
+		amrex::ParmParse hpp("hydro"); // reference src/QuokkaSimulation.hpp:340-350
+		hpp.query("rk_integrator_order", integratorOrder_);
+		hpp.query("reconstruction_order", reconstructionOrder_);
+		hpp.query("use_dual_energy", useDualEnergy_);
+		hpp.query("abort_on_fofc_failure", abortOnFofcFailure_);
+		hpp.query("artificial_viscosity_coefficient", artificialViscosityK_);
+		allocate();
+	}
+
+	void setInitialConditionsOnGrid(quokka::grid const &grid_elem) override;
+	void preCalculateInitialConditions() override;
+	void computeAfterEvolve(amrex::Vector<amrex::Real> &initSumCons) override;
+	void computeReferenceSolution(amrex::MultiFab & /*ref*/, amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> const & /*dx*/,
+				      amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> const & /*prob_lo*/)
+	{
+	}
+
+	// ------------------------------------------------------------------ dt (reference src/simulation.hpp:703-818)
+	void computeTimestep()
+	{
+		double const m = (haveSignal_ ? signal_[1] : HydroSystem<problem_t>::maxSignalSpeedLocal(state_new_cc_[0], 1));
+		double dt_tmp = cflNumber_ * (minDx() / m);
+		dt_tmp = std::min(dt_tmp, 1.1 * dt_[0]);
+		double dt_0 = std::min(dt_tmp, 1.0 * dt_tmp);
+		dt_0 = std::min(dt_0, this->maxDt_);
+		if (tNew_[0] == 0.0) {
+			dt_0 = std::min(dt_0, this->initDt_);
+		}
+		if (this->constantDt_ > 0.0) {
+			dt_0 = this->constantDt_;
+		}
+		double const eps = 1.e-3 * dt_0;
+		if (tNew_[0] + dt_0 > stopTime_ - eps) {
+			dt_0 = stopTime_ - tNew_[0];
+		}
+		dt_[0] = dt_0;
+	}
+
+	// ------------------------------------------------------------------ evolve (reference src/simulation.hpp:827-981)
+	void evolve()
+	{
+		AMREX_ALWAYS_ASSERT(this->areInitialConditionsDefined_);
+		int const nc = Physics_Indices<problem_t>::nvarTotal_cc;
+		double const vol = AMREX_D_TERM(geom[0].dx[0], *geom[0].dx[1], *geom[0].dx[2]);
+		amrex::Vector<amrex::Real> init_sum_cons(nc);
+		for (int n = 0; n < nc; ++n) {
+			init_sum_cons[n] = state_new_cc_[0].sum(n) * vol;
+		}
+		QK_HOST_HIP(hipDeviceSynchronize());
+		auto const t0 = std::chrono::steady_clock::now();
+		double cur_time = tNew_[0];
+		for (int step = istep[0]; step < maxTimesteps_ && cur_time < stopTime_; ++step) {
+			computeTimestep();
+			double const time = tNew_[0];
+			tNew_[0] += dt_[0];
+			std::swap(state_old_cc_[0], state_new_cc_[0]);
+			if (!advanceHydroAtLevelWithRetries(time, dt_[0])) {
+				amrex::Abort("QUOKKA FATAL ERROR: Hydro update exceeded max_retries on level 0");
+			}
+			++istep[0];
+			this->cellUpdates_ += this->CountCells(0);
+			cur_time += dt_[0];
+			tNew_[0] = cur_time;
+			if (cur_time >= stopTime_ - 1.e-6 * dt_[0]) {
+				break;
+			}
+		}
+		QK_HOST_HIP(hipDeviceSynchronize());
+		elapsedSeconds_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+		this->computeAfterEvolve(init_sum_cons);
+		double const microseconds_per_update = 1.0e6 * elapsedSeconds_ / static_cast<double>(this->cellUpdates_);
+		amrex::Print() << "Performance figure-of-merit: " << microseconds_per_update << " μs/zone-update [" << 1.0 / microseconds_per_update
+			       << " Mupdates/s]\n";
+	}
+
+	// ------------------------------------------------------------------ hydro advance (reference src/QuokkaSimulation.hpp:885-1322)
+	auto advanceHydroAtLevelWithRetries(double time, double dt_lev) -> bool
+	{
+		const int max_retries = 6;
+		bool success = false;
+		for (int retry_count = 0; retry_count <= max_retries; ++retry_count) {
+			const int nsubsteps = 1 << retry_count;
+			const double dt_step = dt_lev / nsubsteps;
+			if (retry_count > 0) {
+				++retries_;
+			}
+			amrex::MultiFab::Copy(state_old_tmp_, state_old_cc_[0]);
+			for (int substep = 0; substep < nsubsteps; ++substep) {
+				if (substep > 0) {
+					amrex::MultiFab::Copy(state_old_tmp_, state_new_cc_[0]);
+				}
+				success = advanceHydroAtLevel(state_old_tmp_, time, dt_step);
+				if (!success) {
+					break;
+				}
+			}
+			if (success) {
+				break;
+			}
+		}
+		return success;
+	}
+
+	auto advanceHydroAtLevel(amrex::MultiFab &state_old_cc_tmp, double /*time*/, double dt_lev) -> bool
+	{
+		haveSignal_ = false;
+		this->fillBoundaryConditions(state_old_cc_tmp);
+		if (!stage(1, state_old_cc_tmp, state_old_cc_tmp, state_inter_cc_, dt_lev)) {
+			return false;
+		}
+		if (integratorOrder_ == 2) {
+			this->fillBoundaryConditions(state_inter_cc_);
+			if (!stage(2, state_inter_cc_, state_old_cc_tmp, state_new_cc_[0], dt_lev)) {
+				return false;
+			}
+		} else {
+			amrex::MultiFab::Copy(state_new_cc_[0], state_inter_cc_);
+		}
+		int err = 0;
+		QK_HOST_HIP(hipMemcpy(&err, d_error_, sizeof(int), hipMemcpyDeviceToHost));
+		if (err != 0) {
+			amrex::Abort("density is negative in SyncDualEnergy! abort!!");
+		}
+		return !isCflViolated(dt_lev);
+	}
+
+	auto isCflViolated(double dt_actual) -> bool // reference src/QuokkaSimulation.hpp:992-1013
+	{
+		double const max_signal = haveSignal_ ? signal_[0] : HydroSystem<problem_t>::maxSignalSpeedLocal(state_new_cc_[0], 0);
+		double const dt_cfl = cflNumber_ * (minDx() / max_signal);
+		return dt_actual > (1.1 * dt_cfl);
+	}
+
+      private:
+	amrex::MultiFab state_old_tmp_, state_inter_cc_, primVar_, rhs_;
+	std::array<amrex::MultiFab, 3> flatCoefs_;
+	std::array<amrex::MultiFab, AMREX_SPACEDIM> halfFlux_, halfVel_, flux_, vel_, FOflux_, FOvel_, rk2flux_, rk2vel_, leftState_, rightState_;
+	amrex::iMultiFab redoFlag_;
+	qk_ghost_plan *flagPlan_ = nullptr;
+	int64_t *d_count_ = nullptr;
+	int *d_error_ = nullptr;
+	double *d_signal_ = nullptr;
+	void *scratch_ = nullptr;
+	int64_t scratchBytes_ = 0;
+	double signal_[2] = {0, 0};
+	bool haveSignal_ = false;
+
+	[[nodiscard]] auto minDx() const -> double
+	{
+		double m = geom[0].dx[0];
+		for (int d = 1; d < AMREX_SPACEDIM; ++d) {
+			m = std::min(m, geom[0].dx[d]);
+		}
+		return m;
+	}
+
+	void allocate()
+	{
+		int const nc = Physics_Indices<problem_t>::nvarTotal_cc;
+		state_old_tmp_.define(grids_, nc, nghost_cc_);
+		state_inter_cc_.define(grids_, nc, nghost_cc_);
+		state_inter_cc_.setVal(0);
+		primVar_.define(grids_, ncompHydro_, nghost_cc_);
+		rhs_.define(grids_, ncompHydro_, 0);
+		redoFlag_.define(grids_, 1, 1);
+		redoFlag_.setVal(0);
+		for (int d = 0; d < 3; ++d) {
+			flatCoefs_[d].define(grids_, 1, 2);
+			flatCoefs_[d].setVal(1.0);
+		}
+		for (int d = 0; d < AMREX_SPACEDIM; ++d) {
+			for (auto *f : {&halfFlux_[d], &flux_[d], &FOflux_[d], &rk2flux_[d]}) {
+				f->define(grids_, ncompHydro_, 0, d);
+			}
+			for (auto *v : {&halfVel_[d], &vel_[d], &FOvel_[d], &rk2vel_[d]}) {
+				v->define(grids_, 1, 0, d);
+			}
+			leftState_[d].define(grids_, ncompHydro_, 1, d);
+			rightState_[d].define(grids_, ncompHydro_, 1, d);
+		}
+		QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_count_), sizeof(int64_t)));
+		QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_error_), sizeof(int)));
+		QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_signal_), 2 * sizeof(double)));
+		QK_HOST_HIP(hipMemset(d_error_, 0, sizeof(int)));
+		auto t = qkhost::traits<problem_t>();
+		if (AMREX_SPACEDIM == 3) {
+			scratchBytes_ = qk_hydro_stage_scratch_bytes(qkhost::Runtime::get().lev, &t);
+			QK_HOST_HIP(hipMalloc(&scratch_, static_cast<size_t>(scratchBytes_)));
+		}
+		// redoFlag.FillBoundary plan (1 ghost, 1 comp)
+		auto const &g = geom[0];
+		qk_geometry qg{};
+		std::vector<qk_box> qb;
+		for (auto const &b : grids_) {
+			qb.push_back({{b.lo[0], b.lo[1], b.lo[2]}, {b.hi[0], b.hi[1], b.hi[2]}});
+		}
+		for (int d = 0; d < 3; ++d) {
+			qg.domain.lo[d] = g.domain.lo[d];
+			qg.domain.hi[d] = g.domain.hi[d];
+			qg.periodic[d] = g.periodic[d];
+		}
+		qg.ndim = AMREX_SPACEDIM;
+		std::vector<int> owner(qb.size(), 0);
+		qkhost::check(qk_ghost_plan_create(qkhost::Runtime::get().lev, &flagPlan_, &qg, 1, 1, static_cast<int>(qb.size()), qb.data(), owner.data(), 0),
+			      "qk_ghost_plan_create(redoFlag)");
+	}
+
+	auto readCount() -> int64_t
+	{
+		int64_t c = 0;
+		QK_HOST_HIP(hipMemcpy(&c, d_count_, sizeof(int64_t), hipMemcpyDeviceToHost));
+		return c;
+	}
+
+	// computeHydroFluxes / hydroFluxFunction (reference src/QuokkaSimulation.hpp:1403-1517)
+	template <FluxDir DIR> void hydroFluxFunction(int d)
+	{
+		if (reconstructionOrder_ == 3) {
+			HyperbolicSystem<problem_t>::template ReconstructStatesPPM<DIR>(primVar_, leftState_[d], rightState_[d], 1, ncompHydro_);
+		} else if (reconstructionOrder_ == 2) {
+			HyperbolicSystem<problem_t>::template ReconstructStatesPLM<DIR, SlopeLimiter::minmod>(primVar_, leftState_[d], rightState_[d], 1, ncompHydro_);
+		} else {
+			HyperbolicSystem<problem_t>::template ReconstructStatesConstant<DIR>(primVar_, leftState_[d], rightState_[d], 1, ncompHydro_);
+		}
+		HydroSystem<problem_t>::template FlattenShocks<DIR>(primVar_, flatCoefs_[0], flatCoefs_[1], flatCoefs_[2], leftState_[d], rightState_[d], 1, ncompHydro_);
+		HydroSystem<problem_t>::template ComputeFluxes<RiemannSolver::HLLC, DIR>(flux_[d], vel_[d], leftState_[d], rightState_[d], primVar_,
+											 artificialViscosityK_);
+	}
+	void computeHydroFluxes(amrex::MultiFab const &consVar)
+	{
+		HydroSystem<problem_t>::ConservedToPrimitive(consVar, primVar_, nghost_cc_);
+		AMREX_D_TERM(HydroSystem<problem_t>::template ComputeFlatteningCoefficients<FluxDir::X1>(primVar_, flatCoefs_[0], 2);
+			     , HydroSystem<problem_t>::template ComputeFlatteningCoefficients<FluxDir::X2>(primVar_, flatCoefs_[1], 2);
+			     , HydroSystem<problem_t>::template ComputeFlatteningCoefficients<FluxDir::X3>(primVar_, flatCoefs_[2], 2);)
+		AMREX_D_TERM(hydroFluxFunction<FluxDir::X1>(0);, hydroFluxFunction<FluxDir::X2>(1);, hydroFluxFunction<FluxDir::X3>(2);)
+	}
+	template <FluxDir DIR> void hydroFOFluxFunction(int d)
+	{
+		HyperbolicSystem<problem_t>::template ReconstructStatesConstant<DIR>(primVar_, leftState_[d], rightState_[d], 1, ncompHydro_);
+		HydroSystem<problem_t>::template ComputeFluxes<RiemannSolver::LLF, DIR>(FOflux_[d], FOvel_[d], leftState_[d], rightState_[d], primVar_,
+											artificialViscosityK_);
+	}
+	void computeFOHydroFluxes(amrex::MultiFab const &consVar) // reference src/QuokkaSimulation.hpp:1519-1568
+	{
+		HydroSystem<problem_t>::ConservedToPrimitive(consVar, primVar_, nghost_cc_);
+		AMREX_D_TERM(hydroFOFluxFunction<FluxDir::X1>(0);, hydroFOFluxFunction<FluxDir::X2>(1);, hydroFOFluxFunction<FluxDir::X3>(2);)
+	}
+
+	auto rhsPdvPredict(std::array<amrex::MultiFab, AMREX_SPACEDIM> const &fl, std::array<amrex::MultiFab, AMREX_SPACEDIM> const &vl,
+			   amrex::MultiFab const &stateOld, amrex::MultiFab &stateNew, double dt) -> int64_t
+	{
+		QK_HOST_HIP(hipMemset(d_count_, 0, sizeof(int64_t)));
+		HydroSystem<problem_t>::ComputeRhsFromFluxes(rhs_, fl, geom[0].CellSizeArray(), ncompHydro_);
+		HydroSystem<problem_t>::AddInternalEnergyPdV(rhs_, stateOld, geom[0].CellSizeArray(), vl, redoFlag_);
+		HydroSystem<problem_t>::PredictStep(stateOld, stateNew, rhs_, dt, ncompHydro_, redoFlag_, d_count_);
+		return readCount();
+	}
+
+	// one RK stage exactly as the reference (src/QuokkaSimulation.hpp:1099-1198 / 1202-1287), reference-shaped operators
+	auto stageUnfused(int stageNo, amrex::MultiFab const &U_in, amrex::MultiFab const &U_old, amrex::MultiFab &U_out, double dt) -> bool
+	{
+		auto *lev = qkhost::Runtime::get().lev;
+		computeHydroFluxes(U_in);
+		auto *fl = &flux_;
+		auto *vl = &vel_;
+		if (stageNo == 1) {
+			for (int d = 0; d < AMREX_SPACEDIM; ++d) {
+				amrex::MultiFab::Copy(halfFlux_[d], flux_[d]);
+				amrex::MultiFab::Copy(halfVel_[d], vel_[d]);
+			}
+		} else {
+			for (int d = 0; d < AMREX_SPACEDIM; ++d) {
+				rk2flux_[d].setVal(0);
+				rk2vel_[d].setVal(0);
+				qkhost::check(qk_Saxpy(lev, nullptr, d, qkhost::tab(rk2flux_[d]), 0.5, qkhost::tab(halfFlux_[d]), ncompHydro_), "Saxpy");
+				qkhost::check(qk_Saxpy(lev, nullptr, d, qkhost::tab(rk2vel_[d]), 0.5, qkhost::tab(halfVel_[d]), 1), "Saxpy");
+				qkhost::check(qk_Saxpy(lev, nullptr, d, qkhost::tab(rk2flux_[d]), 0.5, qkhost::tab(flux_[d]), ncompHydro_), "Saxpy");
+				qkhost::check(qk_Saxpy(lev, nullptr, d, qkhost::tab(rk2vel_[d]), 0.5, qkhost::tab(vel_[d]), 1), "Saxpy");
+			}
+			fl = &rk2flux_;
+			vl = &rk2vel_;
+		}
+		redoFlag_.setVal(0);
+		int64_t nbad = rhsPdvPredict(*fl, *vl, U_old, U_out, dt);
+		if (nbad > 0) { // first-order flux correction
+			++fofcStages_;
+			computeFOHydroFluxes(U_old);
+			qkhost::check(qk_FillBoundary_local_int(flagPlan_, nullptr, qkhost::itab(redoFlag_)), "redoFlag.FillBoundary");
+			for (int d = 0; d < AMREX_SPACEDIM; ++d) {
+				qkhost::check(qk_replaceFluxes(lev, nullptr, d, qkhost::tab((*fl)[d]), qkhost::tab(FOflux_[d]), qkhost::itab(redoFlag_), ncompHydro_),
+					      "replaceFluxes");
+				qkhost::check(qk_replaceFluxes(lev, nullptr, d, qkhost::tab((*vl)[d]), qkhost::tab(FOvel_[d]), qkhost::itab(redoFlag_), 1), "replaceFluxes");
+			}
+			nbad = rhsPdvPredict(*fl, *vl, U_old, U_out, dt);
+			if (nbad > 0 && abortOnFofcFailure_ != 0) {
+				return false;
+			}
+		}
+		HydroSystem<problem_t>::EnforceLimits(densityFloor_, tempFloor_, U_out);
+		if (useDualEnergy_ == 1) {
+			HydroSystem<problem_t>::SyncDualEnergy(U_out, d_error_);
+		}
+		return true;
+	}
+
+	auto stage(int stageNo, amrex::MultiFab const &U_in, amrex::MultiFab const &U_old, amrex::MultiFab &U_out, double dt) -> bool
+	{
+		if (AMREX_SPACEDIM == 3 && artificialViscosityK_ == 0.0) {
+			auto t = qkhost::traits<problem_t>();
+			qk_hydro_stage_args a{};
+			a.U_in = qkhost::tab(U_in);
+			a.U_old = qkhost::tab(U_old);
+			a.U_out = qkhost::tab(U_out);
+			for (int d = 0; d < 3; ++d) {
+				a.halfFlux[d] = qkhost::tab(halfFlux_[d]);
+				a.halfVel[d] = qkhost::tab(halfVel_[d]);
+				a.dx[d] = geom[0].dx[d];
+			}
+			a.redoFlag = qkhost::itab(redoFlag_);
+			QK_HOST_HIP(hipMemset(d_count_, 0, sizeof(int64_t)));
+			a.d_redo_count = d_count_;
+			a.d_error_flag = d_error_;
+			bool const final_stage = (stageNo == 2) || (integratorOrder_ == 1);
+			if (final_stage) {
+				QK_HOST_HIP(hipMemset(d_signal_, 0, 2 * sizeof(double)));
+				a.d_max_signal = d_signal_;
+			}
+			a.scratch = scratch_;
+			a.scratch_bytes = scratchBytes_;
+			a.dt = dt;
+			a.stage = stageNo;
+			a.reconstruction_order = reconstructionOrder_;
+			a.densityFloor = densityFloor_;
+			a.tempFloor = tempFloor_;
+			a.use_dual_energy = useDualEnergy_;
+			a.K_visc = 0.0;
+			qkhost::check(qk_hydro_stage_fused(qkhost::Runtime::get().lev, nullptr, &t, &a), "qk_hydro_stage_fused");
+			if (readCount() == 0) {
+				if (final_stage) {
+					QK_HOST_HIP(hipMemcpy(signal_, d_signal_, 2 * sizeof(double), hipMemcpyDeviceToHost));
+					haveSignal_ = true;
+				}
+				return true;
+			}
+		}
+		return stageUnfused(stageNo, U_in, U_old, U_out, dt);
+	}
+};
+
+template <typename problem_t> void QuokkaSimulation<problem_t>::preCalculateInitialConditions() {}
+
+// generic computeAfterEvolve: relative rms L1 error norm vs the problem's reference solution (reference src/QuokkaSimulation.hpp:620-644)
+template <typename problem_t> void QuokkaSimulation<problem_t>::computeAfterEvolve(amrex::Vector<amrex::Real> & /*initSumCons*/)
+{
+	if (!computeReferenceSolution_) {
+		return;
+	}
+	int const ncomp = state_new_cc_[0].nComp();
+	amrex::MultiFab ref(grids_, ncomp, 0);
+	computeReferenceSolution(ref, geom[0].CellSizeArray(), geom[0].ProbLoArray());
+	double sol_norm = 0., err_norm = 0.;
+	for (int n = 0; n < ncomp; ++n) {
+		double rn = 0., en = 0.;
+		for (int b = 0; b < ref.size(); ++b) {
+			auto hr = ref.copyToHost(b);
+			auto hs = state_new_cc_[0].copyToHost(b);
+			amrex::Array4<double> r(hr.data(), ref.fabbox(b), ncomp);
+			amrex::Array4<double> s(hs.data(), state_new_cc_[0].fabbox(b), ncomp);
+			amrex::ParallelFor(ref.validbox(b), [&](int i, int j, int k) {
+				rn += std::abs(r(i, j, k, n));
+				en += std::abs(r(i, j, k, n) - s(i, j, k, n));
+			});
+		}
+		sol_norm += rn * rn;
+		err_norm += en * en;
+	}
+	errorNorm_ = std::sqrt(err_norm) / std::sqrt(sol_norm);
+	amrex::Print() << "Relative rms L1 error norm = " << errorNorm_ << "\n";
+}
+
+// test hook: `qk.dump_state = <file>` writes the valid cells of state_new_cc_ (double, [box][comp][k][j][i]) after evolve()
+template <typename problem_t> void qkDumpState(QuokkaSimulation<problem_t> &sim)
+{
+	std::string path;
+	amrex::ParmParse pp("qk");
+	if (!pp.query("dump_state", path)) {
+		return;
+	}
+	std::ofstream f(path, std::ios::binary);
+	auto &mf = sim.state_new_cc_[0];
+	for (int b = 0; b < mf.size(); ++b) {
+		auto h = mf.copyToHost(b);
+		amrex::Array4<double> a(h.data(), mf.fabbox(b), mf.nComp());
+		auto const &vb = mf.validbox(b);
+		for (int n = 0; n < mf.nComp(); ++n) {
+			for (int k = vb.lo[2]; k <= vb.hi[2]; ++k) {
+				for (int j = vb.lo[1]; j <= vb.hi[1]; ++j) {
+					f.write(reinterpret_cast<const char *>(&a(vb.lo[0], j, k, n)), static_cast<std::streamsize>(sizeof(double)) * vb.length(0));
+				}
+			}
+		}
+	}
+	std::ofstream meta(path + ".meta");
+	meta.precision(17);
+	meta << sim.istep[0] << " " << sim.tNew_[0] << " " << sim.dt_[0] << " " << sim.fofcStages_ << " " << sim.retries_ << " " << sim.errorNorm_ << "\n";
+}
+
+// every problem executable: amrex::Initialize analogue + problem_main()
+auto problem_main() -> int;
+#ifndef QK_HOST_NO_MAIN
+int main(int argc, char **argv)
+{
+	amrex::ParmParse::Initialize(argc, argv);
+	int const rc = problem_main();
+	return rc;
+}
+#endif
+
+#endif // QK_HOST_QUOKKA_HOST_HPP_
