@@ -1,7 +1,8 @@
 // qk_hydro_fused.hip — the throughput path: one RK stage of the hydro update as six launches
-//   k_prim   U -> primitive variables (valid+4)                        [HydroSystem::ConservedToPrimitive]
-//   k_chi3   flattening coefficients of the three directions (valid+2) [ComputeFlatteningCoefficients<DIR> x3]
-//   k_aux    chi = min over the 3x3 axis neighbours, transverse velocity differences D_x,D_y,D_z (valid+1)
+//   k_pre_x  U -> primitive variables (valid+4)                        [HydroSystem::ConservedToPrimitive]
+//            + x flattening coefficient, its 3-cell min and D_x        [ComputeFlatteningCoefficients<X1>]
+//   k_pre_march<Y>, <Z>  flattening coefficient of the direction, running min over the 3x3 axis neighbours
+//            (-> the combined chi of FlattenShocks) and the velocity differences D_y, D_z (valid+1)
 //   k_sweep_x / k_sweep_march<Y> / k_sweep_march<Z>:
 //            PPM (or PLM / donor) reconstruction + shock flattening + HLLC + flux divergence + face-velocity
 //            divergence, fused per sweep direction; nothing but the per-direction half-step fluxes F1 (needed
@@ -63,61 +64,138 @@ struct SweepArgs {
 
 QK_DEV auto sarr(SweepArgs const &a, int comp) -> double * { return a.scratch + static_cast<int64_t>(comp) * a.total_cells; }
 
-// ---------------------------------------------------------------------------------------------- pre-passes
-__global__ void __launch_bounds__(256) k_prim(const qk_box *boxes, const SGeom *geom, const qk_array4 *U_t, double *scratch, int64_t total, Eos eos,
-					      bool re)
+// ---------------------------------------------------------------------------------------------- pencil pre-passes
+// The flattening coefficient of direction d and the velocity difference D_d only couple cells ALONG d, so the three
+// directions are three pencil passes that each stream the data once:
+//   k_pre_x      U -> prim (valid+4), chi_x, m_x = min(chi_x(i-1), chi_x(i), chi_x(i+1)), D_x          [flat, LDS]
+//   k_pre_march  Y then Z: rolling 5-cell pressure window in registers -> chi_d, m_d, D_d;  m <- min(m, m_d)
+// after the Z pass m is the combined coefficient of FlattenShocks (hydro_system.hpp:655-669).
+constexpr int PXB = 256, PXOUT = 250;
+
+__global__ void __launch_bounds__(PXB) k_pre_x(const SGeom *geom, const qk_array4 *U_t, double *scratch, int64_t total, Eos eos, bool re)
 {
+	__shared__ double s_P[PXB], s_v[PXB], s_chi[PXB];
 	const int b = blockIdx.y;
 	const SGeom g = geom[b];
 	RA4 U(U_t[b]);
-	for (int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; c < g.ncell; c += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-		const int k = static_cast<int>(c / (static_cast<int64_t>(g.n[0]) * g.n[1]));
-		const int r = static_cast<int>(c - static_cast<int64_t>(k) * g.n[0] * g.n[1]);
-		const int j = r / g.n[0];
-		const int i = r - j * g.n[0];
-		const int64_t u = U.idx(g.glo[0] + i, g.glo[1] + j, g.glo[2] + k);
-		const double rho = U.p[u + U.ns * RHO];
-		const double px = U.p[u + U.ns * MX];
-		const double py = U.p[u + U.ns * MY];
-		const double pz = U.p[u + U.ns * MZ];
-		const double E = U.p[u + U.ns * ENE];
-		const double Eint_aux = U.p[u + U.ns * EINT];
-		const double vx = px / rho;
-		const double vy = py / rho;
-		const double vz = pz / rho;
-		const double kinetic_energy = 0.5 * rho * (vx * vx + vy * vy + vz * vz);
-		const double Eint_cons = E - kinetic_energy;
-		double *q = scratch + g.off + c;
+	const int t = threadIdx.x;
+	const int64_t f = static_cast<int64_t>(blockIdx.x) * PXOUT + t - 3;
+	const bool inb = (f >= 0) && (f < g.ncell);
+	const int64_t c = f < 0 ? 0 : (f >= g.ncell ? g.ncell - 1 : f);
+	const bool owned = inb && (t >= 3) && (t < 3 + PXOUT);
+
+	const int k = static_cast<int>(c / (static_cast<int64_t>(g.n[0]) * g.n[1]));
+	const int r = static_cast<int>(c - static_cast<int64_t>(k) * g.n[0] * g.n[1]);
+	const int j = r / g.n[0];
+	const int i = r - j * g.n[0];
+	const int64_t u = U.idx(g.glo[0] + i, g.glo[1] + j, g.glo[2] + k);
+	const double rho = U.p[u + U.ns * RHO];
+	const double px = U.p[u + U.ns * MX];
+	const double py = U.p[u + U.ns * MY];
+	const double pz = U.p[u + U.ns * MZ];
+	const double E = U.p[u + U.ns * ENE];
+	const double Eint_aux = U.p[u + U.ns * EINT];
+	const double vx = px / rho;
+	const double vy = py / rho;
+	const double vz = pz / rho;
+	const double kinetic_energy = 0.5 * rho * (vx * vx + vy * vy + vz * vz);
+	const double Eint_cons = E - kinetic_energy;
+	double *q = scratch + g.off + c;
+	double Pphys;
+	if (re) {
+		const double e = Eint_cons / rho;
+		Pphys = eos.pressure(rho, rho * e);
+		if (owned) {
+			q[(S_PRIM + PPRES) * total] = e;
+			q[(S_PRIM + PEINT) * total] = Eint_aux / rho;
+		}
+	} else {
+		Pphys = eos.isothermal ? rho * eos.cs_iso * eos.cs_iso : eos.pressure(rho, Eint_cons);
+		if (owned) {
+			q[(S_PRIM + PPRES) * total] = Pphys;
+			q[(S_PRIM + PEINT) * total] = Eint_aux;
+		}
+	}
+	if (eos.isothermal) {
+		Pphys = rho * (eos.cs_iso * eos.cs_iso);
+	}
+	if (owned) {
 		q[(S_PRIM + PRHO) * total] = rho;
 		q[(S_PRIM + PVX) * total] = vx;
 		q[(S_PRIM + PVY) * total] = vy;
 		q[(S_PRIM + PVZ) * total] = vz;
-		if (re) {
-			q[(S_PRIM + PPRES) * total] = Eint_cons / rho;
-			q[(S_PRIM + PEINT) * total] = Eint_aux / rho;
-		} else {
-			q[(S_PRIM + PPRES) * total] = eos.isothermal ? rho * eos.cs_iso * eos.cs_iso : eos.pressure(rho, Eint_cons);
-			q[(S_PRIM + PEINT) * total] = Eint_aux;
-		}
+	}
+	s_P[t] = Pphys;
+	s_v[t] = vx;
+	__syncthreads();
+	double chi = 1.0;
+	if (t >= 2 && t < PXB - 2) {
+		chi = flatteningChi(eos, s_P[t - 2], s_P[t - 1], Pphys, s_P[t + 1], s_P[t + 2], rho, s_v[t - 1], s_v[t + 1]);
+	}
+	s_chi[t] = chi;
+	__syncthreads();
+	if (owned) {
+		q[(S_AUX + 0) * total] = smin(smin(s_chi[t - 1], chi), s_chi[t + 1]);
+		q[(S_AUX + 1) * total] = smin(s_v[t + 1] - vx, vx - s_v[t - 1]);
 	}
 }
 
-// cells of the box grown by `grow` (<= NG), one thread per cell, blockIdx.y = box
-template <class F> __global__ void __launch_bounds__(256) k_grown(const qk_box *boxes, const SGeom *geom, int grow, F f)
+template <int DIR> __global__ void __launch_bounds__(256) k_pre_march(const qk_box *boxes, const SGeom *geom, double *scratch, int64_t T, Eos eos, bool re)
 {
-	const int b = blockIdx.y;
+	constexpr int OT = 3 - DIR;
+	const int b = blockIdx.z;
 	const qk_box bx = boxes[b];
 	const SGeom g = geom[b];
-	const int l0 = bx.hi[0] - bx.lo[0] + 1 + 2 * grow, l1 = bx.hi[1] - bx.lo[1] + 1 + 2 * grow, l2 = bx.hi[2] - bx.lo[2] + 1 + 2 * grow;
-	const int64_t n = static_cast<int64_t>(l0) * l1 * l2;
-	for (int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < n; t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-		const int k = static_cast<int>(t / (static_cast<int64_t>(l0) * l1));
-		const int r = static_cast<int>(t - static_cast<int64_t>(k) * l0 * l1);
-		const int j = r / l0;
-		const int i = r - j * l0;
-		// index inside the ghost-4 scratch fab
-		const int64_t c = (i + NG - grow) + static_cast<int64_t>(g.n[0]) * ((j + NG - grow) + static_cast<int64_t>(g.n[1]) * (k + NG - grow));
-		f(g, c);
+	const int i = bx.lo[0] - 1 + static_cast<int>(blockIdx.x * 64 + threadIdx.x);
+	const int ot = bx.lo[OT] - 1 + static_cast<int>(blockIdx.y * 4 + threadIdx.y);
+	if (i > bx.hi[0] + 1 || ot > bx.hi[OT] + 1) {
+		return;
+	}
+	const int lo = bx.lo[DIR];
+	const int nvalid = bx.hi[DIR] - lo + 1;
+	const int64_t st[3] = {1, g.n[0], static_cast<int64_t>(g.n[0]) * g.n[1]};
+	const int64_t ms = st[DIR];
+	int pos[3];
+	pos[0] = i;
+	pos[OT] = ot;
+	pos[DIR] = lo - 4;
+	int64_t c = (pos[0] - g.glo[0]) * st[0] + (pos[1] - g.glo[1]) * st[1] + (pos[2] - g.glo[2]) * st[2];
+	double *S = scratch + g.off;
+
+	double P[5] = {0., 0., 0., 0., 0.}, v[5] = {0., 0., 0., 0., 0.}, rh[3] = {1., 1., 1.}, ch[3] = {1., 1., 1.};
+	// p = lo-4+step is the newest cell of the window;  chi(p-2), then m and D of cell p-3
+	for (int step = 0; step < nvalid + 9; ++step, c += ms) {
+#pragma unroll
+		for (int m = 0; m < 4; ++m) {
+			P[m] = P[m + 1];
+			v[m] = v[m + 1];
+		}
+		rh[0] = rh[1];
+		rh[1] = rh[2];
+		const double rho = S[(S_PRIM + PRHO) * T + c];
+		double Pm = S[(S_PRIM + PPRES) * T + c];
+		if (re) {
+			Pm = eos.pressure(rho, rho * Pm);
+		}
+		if (eos.isothermal) {
+			Pm = rho * (eos.cs_iso * eos.cs_iso);
+		}
+		P[4] = Pm;
+		rh[2] = rho;
+		v[4] = S[(S_PRIM + PVX + DIR) * T + c];
+		if (step < 4) {
+			continue;
+		}
+		ch[0] = ch[1];
+		ch[1] = ch[2];
+		ch[2] = flatteningChi(eos, P[0], P[1], P[2], P[3], P[4], rh[0], v[1], v[3]);
+		if (step < 6) {
+			continue;
+		}
+		const int64_t cc = c - 3 * ms;
+		const double m_in = S[(S_AUX + 0) * T + cc];
+		S[(S_AUX + 0) * T + cc] = smin(smin(smin(m_in, ch[0]), ch[1]), ch[2]);
+		S[(S_AUX + 1 + DIR) * T + cc] = smin(v[2] - v[1], v[1] - v[0]);
 	}
 }
 
@@ -577,66 +655,22 @@ int qk_hydro_stage_fused(qk_level *lev, qk_stream stream, const qk_hydro_traits 
 	for (int d = 0; d < 3; ++d) {
 		maxcell *= lev->maxlen[d] + 2 * NG;
 	}
-	const dim3 gridAll(static_cast<unsigned>(std::min<int64_t>((maxcell + 255) / 256, 4096)), lev->nboxes, 1);
 
-	// 1. primitives on valid + 4
+	// 1.-3. pencil pre-passes: primitives (valid + 4), combined flattening coefficient and velocity differences (valid + 1)
 	{
-		ProfScope ps(ctx, s, "k_prim");
-		hipLaunchKernelGGL(k_prim, gridAll, dim3(256), 0, s, boxes, geom, args->U_in, scratch, T, eos, re);
+		ProfScope ps(ctx, s, "k_pre_x");
+		const dim3 grid(static_cast<unsigned>((maxcell + PXOUT - 1 + 3) / PXOUT), lev->nboxes, 1);
+		hipLaunchKernelGGL(k_pre_x, grid, dim3(PXB), 0, s, geom, args->U_in, scratch, T, eos, re);
 	}
-
-	// 2. flattening coefficients of all three directions on valid + 2 (hydro_system.hpp:550-625)
 	{
-		auto f = [=] __device__(SGeom const &g, int64_t c) {
-			const double *S = scratch + g.off;
-			const int64_t st[3] = {1, g.n[0], static_cast<int64_t>(g.n[0]) * g.n[1]};
-			const double rho0 = S[(S_PRIM + PRHO) * T + c];
-#pragma unroll
-			for (int d = 0; d < 3; ++d) {
-				double P[5];
-#pragma unroll
-				for (int m = -2; m <= 2; ++m) {
-					const int64_t cm = c + m * st[d];
-					double Pm = S[(S_PRIM + PPRES) * T + cm];
-					const double rho = S[(S_PRIM + PRHO) * T + cm];
-					if (re) {
-						Pm = eos.pressure(rho, rho * Pm);
-					}
-					if (eos.isothermal) {
-						Pm = rho * (eos.cs_iso * eos.cs_iso);
-					}
-					P[m + 2] = Pm;
-				}
-				const double vm1 = S[(S_PRIM + PVX + d) * T + c - st[d]];
-				const double vp1 = S[(S_PRIM + PVX + d) * T + c + st[d]];
-				(scratch + g.off)[(S_CHI3 + d) * T + c] = flatteningChi(eos, P[0], P[1], P[2], P[3], P[4], rho0, vm1, vp1);
-			}
-		};
-		ProfScope ps(ctx, s, "k_chi3");
-		hipLaunchKernelGGL(k_grown<decltype(f)>, gridAll, dim3(256), 0, s, boxes, geom, 2, f);
+		ProfScope ps(ctx, s, "k_pre_y");
+		const dim3 grid((lev->maxlen[0] + 2 + 63) / 64, (lev->maxlen[2] + 2 + 3) / 4, lev->nboxes);
+		hipLaunchKernelGGL(k_pre_march<1>, grid, dim3(64, 4), 0, s, boxes, geom, scratch, T, eos, re);
 	}
-
-	// 3. combined flattening coefficient (hydro_system.hpp:655-669) and transverse velocity differences
-	//    D_a(c) = min(v_a(c+e_a) - v_a(c), v_a(c) - v_a(c-e_a))  (the per-cell pieces of hydro_system.hpp:1025-1033)
 	{
-		auto f = [=] __device__(SGeom const &g, int64_t c) {
-			const double *S = scratch + g.off;
-			double *W = scratch + g.off;
-			const int64_t st[3] = {1, g.n[0], static_cast<int64_t>(g.n[0]) * g.n[1]};
-			double chi = smin(smin(S[(S_CHI3 + 0) * T + c - st[0]], S[(S_CHI3 + 0) * T + c]), S[(S_CHI3 + 0) * T + c + st[0]]);
-			chi = smin(smin(smin(chi, S[(S_CHI3 + 1) * T + c - st[1]]), S[(S_CHI3 + 1) * T + c]), S[(S_CHI3 + 1) * T + c + st[1]]);
-			chi = smin(smin(smin(chi, S[(S_CHI3 + 2) * T + c - st[2]]), S[(S_CHI3 + 2) * T + c]), S[(S_CHI3 + 2) * T + c + st[2]]);
-			W[(S_AUX + 0) * T + c] = chi;
-#pragma unroll
-			for (int d = 0; d < 3; ++d) {
-				const double v0 = S[(S_PRIM + PVX + d) * T + c];
-				const double vp = S[(S_PRIM + PVX + d) * T + c + st[d]];
-				const double vm = S[(S_PRIM + PVX + d) * T + c - st[d]];
-				W[(S_AUX + 1 + d) * T + c] = smin(vp - v0, v0 - vm);
-			}
-		};
-		ProfScope ps(ctx, s, "k_aux");
-		hipLaunchKernelGGL(k_grown<decltype(f)>, gridAll, dim3(256), 0, s, boxes, geom, 1, f);
+		ProfScope ps(ctx, s, "k_pre_z");
+		const dim3 grid((lev->maxlen[0] + 2 + 63) / 64, (lev->maxlen[1] + 2 + 3) / 4, lev->nboxes);
+		hipLaunchKernelGGL(k_pre_march<2>, grid, dim3(64, 4), 0, s, boxes, geom, scratch, T, eos, re);
 	}
 
 	// 4. sweeps
