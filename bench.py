@@ -27,6 +27,13 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 # algorithmic bytes per cell-sweep of the fused PPM+HLLC sweep kernels
 ALG_BYTES = {"k_sweep_x": 128.0, "k_sweep_y": 184.0, "k_sweep_z": 184.0}
+# measured HBM bytes per cell and launch (average of the two RK stages) for 128^3 boxes: rocprofv3 --pmc FETCH_SIZE and
+# --pmc WRITE_SIZE in separate passes, FETCH_SIZE x2 (gfx950 correction, calibrated on a pure streaming kernel), summaries in
+# profiles/round1/v2_sedov256_pmc_*.txt.  bench.py cannot collect PMC counters itself; the figure is reported only for the
+# profiled box size.  It includes what SURVEY's per-sweep figure leaves out: the stage-1 face fluxes kept for stage 2
+# (56 B), and for k_sweep_z the fused epilogue (old state in, new state + redo flag out).
+PMC_BYTES_PER_CELL = {"k_sweep_x": 198.5, "k_sweep_y": 275.7, "k_sweep_z": 332.2}
+PMC_SOURCE = "profiles/round1/v2_sedov256_pmc_FETCH_SIZE.txt (x2) + v2_sedov256_pmc_WRITE_SIZE.txt"
 
 
 def parse():
@@ -141,8 +148,14 @@ def main():
         avg_s = kernels[dom][1] / kernels[dom][0] * 1e-3
         achieved = ALG_BYTES[dom] * cells_local / avg_s / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": None, "alg_bytes_per_launch": ALG_BYTES[dom] * cells_local, "avg_launch_ms": avg_s * 1e3,
+                    "traffic": PMC_BYTES_PER_CELL[dom] * cells_local if args.max_grid_size == 128 else None,
+                    "traffic_unit": "bytes per launch", "traffic_source": PMC_SOURCE,
+                    "traffic_rate_GBs": PMC_BYTES_PER_CELL[dom] * cells_local / avg_s / 1e9 if args.max_grid_size == 128 else None,
+                    "alg_bytes_per_launch": ALG_BYTES[dom] * cells_local, "avg_launch_ms": avg_s * 1e3,
                     "launches": kernels[dom][0],
+                    "whole_step": {"alg_bytes_per_cell_update": 1496.0,
+                                   "achieved_GBs": 1496.0 * total_cells * args.steps / elapsed / 1e9 / world,
+                                   "frac": 1496.0 * total_cells * args.steps / elapsed / 1e9 / world / HBM_PEAK_GBS},
                     "all_kernels_ms_per_launch": {k: v[1] / max(v[0], 1) for k, v in sorted(kernels.items())}}
 
     if rank == 0 and args.workload == "shell":

@@ -106,6 +106,7 @@ QK_DEV auto consPressure(Eos const &eos, double rho, double px, double py, doubl
 QK_DEV auto sgn(double v) -> int { return static_cast<int>(0.0 < v) - static_cast<int>(v < 0.0); }
 QK_DEV auto clampd(double v, double lo, double hi) -> double { return (v < lo) ? lo : (hi < v) ? hi : v; }
 // std::min / std::max semantics (return first argument on ties / NaN in second)
+// (v_min_f64 / v_max_f64 via fmin/fmax were measured: same bits on every parity case, 5-20 % slower sweeps)
 QK_DEV auto smin(double a, double b) -> double { return (b < a) ? b : a; }
 QK_DEV auto smax(double a, double b) -> double { return (a < b) ? b : a; }
 

@@ -12,10 +12,16 @@
 // MI355X mapping
 //   * X sweep: the pencil direction is the contiguous one, so one thread owns one cell of a flat, row-contiguous
 //     slab (rows j = lo..hi of one k-plane are adjacent in memory); +-2 stencil values, right-edge states and face
-//     fluxes move between neighbouring lanes through LDS (40 KB per 256-thread workgroup -> 4 workgroups per CU).
+//     fluxes move between neighbouring lanes through LDS (30 KB per 256-thread workgroup, 82 VGPRs -> 5 waves per
+//     SIMD).  The kernel is FP64-issue bound (~1500 VALU slots per cell, 31 divisions + 6 square roots per face).
 //   * Y / Z sweeps: lanes stay along x (coalesced 512-B wave loads), each thread MARCHES along the sweep direction
 //     with a 5-cell primitive window, the previous right-edge state and the previous face flux in registers: every
 //     face flux is evaluated exactly once, no LDS, no barriers.
+//     The ~105 doubles of per-thread state hold these kernels at 2 waves per SIMD; the x-sweep body throttled to
+//     2 waves per SIMD runs at the same 0.97 ms, i.e. they are bound by FP64 dependency chains, not by HBM.
+//     (Measured and rejected, see DESIGN.md §6: next-step prefetch into LDS with global_load_lds_dwordx4 and a rotated
+//      loop — bit-exact, +-2 %, i.e. nothing left to hide; 8-wide x tiles with LDS exchange along y/z — 64-byte row
+//      segments are 2-4x slower; a 168-VGPR cap for 3 waves per SIMD — spills; fmin/fmax for min/max — slower.)
 //   * all arithmetic in qk_device.hpp, shared with the reference-shaped operators -> identical bits.
 #include "qk_device.hpp"
 #include "qk_internal.hpp"
@@ -36,7 +42,7 @@ struct SGeom {
 };
 
 // scratch arrays (in units of "components over total_cells")
-enum { S_PRIM = 0, S_CHI3 = 6, S_AUX = 9, S_RHS = 13, S_NCOMP = 20 };
+enum { S_PRIM = 0, S_AUX = 6, S_RHS = 10, S_NCOMP = 17 };
 // S_AUX + 0: chi (combined), +1..3: D_x, D_y, D_z ;  S_RHS + 0..5: flux divergence, +6: div v
 
 struct SweepArgs {
@@ -220,17 +226,12 @@ QK_DEV void flattenEdges(double chi, double mean, double &am, double &ap)
 }
 
 // epilogue of one cell (AddInternalEnergyPdV + PredictStep + EnforceLimits + SyncDualEnergy)
-QK_DEV void updateCell(SweepArgs const &a, Eos const &eos, int b, int i, int j, int k, const double rhs[NVAR], double div_v, double &sig0, double &sig1)
+// U holds the old state of the cell on entry
+QK_DEV void updateCellFrom(SweepArgs const &a, Eos const &eos, int b, int i, int j, int k, double U[NVAR], const double rhs[NVAR], double div_v, double &sig0,
+			   double &sig1)
 {
-	RA4 Uo(a.U_old[b]);
 	WA4 Un(a.U_out[b]);
 	IA4 flag(a.redoFlag[b]);
-	const int64_t co = Uo.idx(i, j, k);
-	double U[NVAR];
-#pragma unroll
-	for (int n = 0; n < NVAR; ++n) {
-		U[n] = Uo.p[co + Uo.ns * n];
-	}
 	// hydro_system.hpp:797-812 (redoFlag == none branch)
 	const double Pgas = consPressure(eos, U[RHO], U[MX], U[MY], U[MZ], U[ENE]);
 	double r[NVAR];
@@ -265,6 +266,18 @@ QK_DEV void updateCell(SweepArgs const &a, Eos const &eos, int b, int i, int j, 
 		sig0 = smax(sig0, signalSpeed(eos, 0, U[RHO], U[MX], U[MY], U[MZ], U[ENE]));
 		sig1 = smax(sig1, signalSpeed(eos, 1, U[RHO], U[MX], U[MY], U[MZ], U[ENE]));
 	}
+}
+
+QK_DEV void updateCell(SweepArgs const &a, Eos const &eos, int b, int i, int j, int k, const double rhs[NVAR], double div_v, double &sig0, double &sig1)
+{
+	RA4 Uo(a.U_old[b]);
+	const int64_t co = Uo.idx(i, j, k);
+	double U[NVAR];
+#pragma unroll
+	for (int n = 0; n < NVAR; ++n) {
+		U[n] = Uo.p[co + Uo.ns * n];
+	}
+	updateCellFrom(a, eos, b, i, j, k, U, rhs, div_v, sig0, sig1);
 }
 
 // ---------------------------------------------------------------------------------------------- X sweep (flat + LDS)

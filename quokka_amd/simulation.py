@@ -529,7 +529,8 @@ def sedov_problem(ctx: Context, n: int, max_grid_size: int = 128, rank=0, nranks
     for c in range(6):
         lo = [capi.BC_REFLECT_ODD if c == 1 + d else capi.BC_REFLECT_EVEN for d in range(3)]
         bcs.append((lo, list(lo)))
-    sim = HydroSimulation(ctx, geom, capi.traits(1.4, False, 3), bcs, [max_grid_size] * 3, rank=rank, nranks=nranks, use_fused=use_fused)
+    sim = HydroSimulation(ctx, geom, capi.traits(1.4, False, 3), bcs, list(max_grid_size) if isinstance(max_grid_size, (list, tuple)) else [max_grid_size] * 3, rank=rank, nranks=nranks,
+                          use_fused=use_fused)
     sim.reconstructionOrder_, sim.stopTime_, sim.cflNumber_ = 3, 1.0, 0.3
     E_blast = 0.851072 / 8.0
     cell_vol = geom.dx[0] * geom.dx[1] * geom.dx[2]

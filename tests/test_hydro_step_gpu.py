@@ -49,6 +49,18 @@ def test_sedov_steps_bit_exact(ctx, oracle, fused, mgs):
     assert so.time == sg.tNew_
 
 
+def test_sedov_anisotropic_boxes_bit_exact(ctx, oracle):
+    """non-cubic boxes (64 x 32 x 32): full 64-lane waves along x, several boxes along y and z"""
+    N, nsteps = 64, 6
+    so = oracle.sim(SEDOV, 3, [N] * 3, [0, 0, 0], [1.2] * 3, [0, 0, 0], max_grid_size=[64, 32, 32])
+    sg = sedov_problem(ctx, N, max_grid_size=[64, 32, 32])
+    for it in range(nsteps):
+        assert so.step() and sg.step()
+        assert so.dt == sg.dt_, f"dt differs at step {it}: {so.dt} vs {sg.dt_}"
+    Uo, Ug = gather_oracle(so, N), gather_gpu(sg, N)
+    assert np.array_equal(Uo, Ug), f"max abs diff {np.abs(Uo - Ug).max()}"
+
+
 def test_ghost_fill_matches_oracle(ctx, oracle):
     """FillBoundary between 8 boxes + reflecting walls: every ghost cell, every component."""
     N, mgs = 16, 8
