@@ -279,6 +279,19 @@ int qk_FillBoundary_pack(qk_ghost_plan *plan, qk_stream s, int k, const qk_array
 int qk_FillBoundary_unpack(qk_ghost_plan *plan, qk_stream s, int k, qk_array4 *state, const double *recvbuf);
 /* physical boundaries (after FillBoundary): bcs[ncomp]; dirichlet[dim][side] may be NULL */
 int qk_FillPhysicalBoundary(qk_ghost_plan *plan, qk_stream s, qk_array4 *state, const qk_bcrec *bcs, const qk_dirichlet_face *dirichlet);
+/* Overlap of the exchange with the update (north_star: "FillBoundary ... overlapped with interior-cell updates"; the
+ * reference's FillBoundary, src/simulation.hpp:1755, is blocking).  A local box is "remote dependent" if any of its ghost
+ * cells is filled from another rank.  The other boxes are complete after qk_FillBoundary_local + the LOCAL_ONLY subset
+ * of the physical boundaries and can be advanced while the strips of the peers are on the wire; the REMOTE_DEPENDENT
+ * subset runs after the unpack. */
+#define QK_BOXES_ALL 0
+#define QK_BOXES_LOCAL_ONLY 1
+#define QK_BOXES_REMOTE_DEPENDENT 2
+int qk_ghost_plan_box_is_remote(qk_ghost_plan *plan, int local_box); /* 1 / 0, < 0 on error */
+/* move a box into / out of the late group by hand (load balancing between the two launches; single-GPU tests of the split) */
+int qk_ghost_plan_set_box_remote(qk_ghost_plan *plan, int local_box, int flag);
+int qk_FillPhysicalBoundary_subset(qk_ghost_plan *plan, qk_stream s, qk_array4 *state, const qk_bcrec *bcs, const qk_dirichlet_face *dirichlet,
+				   int which);
 
 #ifdef __cplusplus
 }

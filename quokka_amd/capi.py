@@ -140,11 +140,16 @@ def lib() -> C.CDLL:
         L.qk_FillBoundary_pack.argtypes = [vp, vp, ci, vp, vp]
         L.qk_FillBoundary_unpack.argtypes = [vp, vp, ci, vp, vp]
         L.qk_FillPhysicalBoundary.argtypes = [vp, vp, vp, P(BCRec), P(DirichletFace)]
+        L.qk_FillPhysicalBoundary_subset.argtypes = [vp, vp, vp, P(BCRec), P(DirichletFace), C.c_int]
+        L.qk_ghost_plan_box_is_remote.argtypes = [vp, C.c_int]
+        L.qk_ghost_plan_set_box_remote.argtypes = [vp, C.c_int, C.c_int]
     _lib = L
     return L
 
 
 # every symbol include/quokka_amd.h declares (checked by the CPU test-suite without a GPU)
+BOXES_ALL, BOXES_LOCAL_ONLY, BOXES_REMOTE_DEPENDENT = 0, 1, 2
+
 DECLARED_SYMBOLS = [
     "qk_ctx_create", "qk_ctx_destroy", "qk_last_error", "qk_version", "qk_level_create", "qk_level_destroy",
     "qk_upload_array4_table", "qk_upload_iarray4_table", "qk_profile_enable", "qk_profile_reset", "qk_profile_num_kernels", "qk_profile_get",
@@ -157,6 +162,7 @@ DECLARED_SYMBOLS = [
     "qk_rad_AddSourceTermsSingleGroup",
     "qk_ghost_plan_create", "qk_ghost_plan_destroy", "qk_ghost_plan_num_peers", "qk_ghost_plan_peer", "qk_ghost_plan_num_items", "qk_ghost_plan_item",
     "qk_FillBoundary_local", "qk_FillBoundary_local_int", "qk_FillBoundary_pack", "qk_FillBoundary_unpack", "qk_FillPhysicalBoundary",
+    "qk_FillPhysicalBoundary_subset", "qk_ghost_plan_box_is_remote", "qk_ghost_plan_set_box_remote",
 ]
 
 

@@ -50,9 +50,11 @@ struct qk_ghost_plan {
 	int max_local_cells = 0;
 	std::vector<PeerPlan> peers;
 	// ghost slabs outside the domain in a non-periodic dimension (dst_box, lo, hi used)
-	std::vector<CopyItem> shells;
+	std::vector<CopyItem> shells; // slabs of boxes without remote-filled ghost cells first (n_shells_indep of them)
 	CopyItem *d_shells = nullptr;
 	int max_shell_cells = 0;
+	int n_shells_indep = 0;
+	std::vector<char> box_remote; // per local box: 1 if any ghost cell of the box is filled from another rank
 	qk_bcrec *d_bcs = nullptr;
 	int d_bcs_n = 0;
 	qk_dirichlet_face *d_dir = nullptr;
@@ -60,6 +62,13 @@ struct qk_ghost_plan {
 
 namespace
 {
+
+void partitionShells(qk_ghost_plan *P)
+{
+	auto indep = [&](CopyItem const &it) { return P->box_remote[it.dst_box] == 0; };
+	std::stable_partition(P->shells.begin(), P->shells.end(), indep);
+	P->n_shells_indep = static_cast<int>(std::count_if(P->shells.begin(), P->shells.end(), indep));
+}
 
 enum CopyMode { MODE_LOCAL = 0, MODE_PACK = 1, MODE_UNPACK = 2 };
 
@@ -327,6 +336,15 @@ int qk_ghost_plan_create(qk_level *lev, qk_ghost_plan **plan_out, const qk_geome
 			}
 		}
 	}
+	// boxes whose ghost cells depend on another rank; their physical-boundary slabs go last so that the slabs of the
+	// independent boxes can be filled (and those boxes advanced) while the exchange is in flight
+	P->box_remote.assign(lev->nboxes, 0);
+	for (auto &kv : peers) {
+		for (auto const &it : kv.second.recv) {
+			P->box_remote[it.dst_box] = 1;
+		}
+	}
+	partitionShells(P);
 	int rc = uploadItems(ctx, P->local, &P->d_local);
 	if (rc == QK_OK) {
 		rc = uploadItems(ctx, P->shells, &P->d_shells);
@@ -491,7 +509,35 @@ int qk_FillBoundary_unpack(qk_ghost_plan *plan, qk_stream s, int k, qk_array4 *s
 	return QK_OK;
 }
 
+int qk_ghost_plan_box_is_remote(qk_ghost_plan *plan, int local_box)
+{
+	if (plan == nullptr || local_box < 0 || local_box >= plan->lev->nboxes) {
+		return QK_ERR_INVALID;
+	}
+	return plan->box_remote[local_box];
+}
+
+int qk_ghost_plan_set_box_remote(qk_ghost_plan *plan, int local_box, int flag)
+{
+	if (plan == nullptr || local_box < 0 || local_box >= plan->lev->nboxes) {
+		return QK_ERR_INVALID;
+	}
+	qk_ctx *ctx = plan->lev->ctx;
+	plan->box_remote[local_box] = (flag != 0) ? 1 : 0;
+	partitionShells(plan);
+	if (plan->d_shells != nullptr && !plan->shells.empty()) {
+		QK_HIP_CHECK(ctx, hipMemcpy(plan->d_shells, plan->shells.data(), sizeof(CopyItem) * plan->shells.size(), hipMemcpyHostToDevice));
+	}
+	return QK_OK;
+}
+
 int qk_FillPhysicalBoundary(qk_ghost_plan *plan, qk_stream s, qk_array4 *state_t, const qk_bcrec *bcs, const qk_dirichlet_face *dirichlet)
+{
+	return qk_FillPhysicalBoundary_subset(plan, s, state_t, bcs, dirichlet, QK_BOXES_ALL);
+}
+
+int qk_FillPhysicalBoundary_subset(qk_ghost_plan *plan, qk_stream s, qk_array4 *state_t, const qk_bcrec *bcs, const qk_dirichlet_face *dirichlet,
+				   int which)
 {
 	if (plan == nullptr) {
 		return QK_ERR_INVALID;
@@ -516,11 +562,15 @@ int qk_FillPhysicalBoundary(qk_ghost_plan *plan, qk_stream s, qk_array4 *state_t
 	if (dirichlet != nullptr) {
 		QK_HIP_CHECK(ctx, hipMemcpyAsync(plan->d_dir, dirichlet, sizeof(qk_dirichlet_face) * 6, hipMemcpyHostToDevice, static_cast<hipStream_t>(s)));
 	}
-	if (plan->shells.empty()) {
+	QK_REQUIRE(ctx, which == QK_BOXES_ALL || which == QK_BOXES_LOCAL_ONLY || which == QK_BOXES_REMOTE_DEPENDENT, "FillPhysicalBoundary: bad subset");
+	const int nall = static_cast<int>(plan->shells.size());
+	const int first = (which == QK_BOXES_REMOTE_DEPENDENT) ? plan->n_shells_indep : 0;
+	const int count = (which == QK_BOXES_ALL) ? nall : (which == QK_BOXES_LOCAL_ONLY ? plan->n_shells_indep : nall - plan->n_shells_indep);
+	if (count == 0) {
 		return QK_OK;
 	}
-	hipLaunchKernelGGL(k_physbc, gridFor(plan->max_shell_cells, static_cast<int>(plan->shells.size())), dim3(256), 0, static_cast<hipStream_t>(s),
-			   plan->d_shells, state_t, plan->geom, plan->ncomp, plan->d_bcs, dirichlet != nullptr ? plan->d_dir : nullptr);
+	hipLaunchKernelGGL(k_physbc, gridFor(plan->max_shell_cells, count), dim3(256), 0, static_cast<hipStream_t>(s), plan->d_shells + first, state_t,
+			   plan->geom, plan->ncomp, plan->d_bcs, dirichlet != nullptr ? plan->d_dir : nullptr);
 	QK_HIP_CHECK(ctx, hipGetLastError());
 	return QK_OK;
 }

@@ -139,6 +139,14 @@ class MultiFab:
         """device pointer to the qk_array4[nboxes] table (== MultiFab::arrays())"""
         return C.c_void_p(self.table.data_ptr())
 
+    def subset_ptr(self, boxes: Sequence[int]) -> C.c_void_p:
+        """descriptor table of a subset of the boxes (same memory), for launches over a sub-level"""
+        key = tuple(boxes)
+        cache = self.__dict__.setdefault("_subtables", {})
+        if key not in cache:
+            cache[key] = self.table.view(-1, 64)[torch.tensor(list(key), dtype=torch.long, device=self.table.device)].contiguous()
+        return C.c_void_p(cache[key].data_ptr())
+
     def valid_slices(self, b: int):
         ng, nd = self.nghost, self.level.ndim
         return tuple([slice(None)] + [slice(ng, -ng) if (d < nd and ng > 0) else slice(None) for d in (2, 1, 0)])

@@ -123,8 +123,9 @@ class GhostExchange:
             ctx.check(L.qk_ghost_plan_peer(h, k, C.byref(r), C.byref(ns), C.byref(nr)), "qk_ghost_plan_peer")
             self.peers.append((k, r.value, torch.empty(ns.value, dtype=dtype, device=ctx.device), torch.empty(nr.value, dtype=dtype, device=ctx.device)))
 
-    def fill(self, state: MultiFab):
-        """The product path: every copy is a HIP kernel behind the C-ABI."""
+    def fill(self, state: MultiFab, between=None):
+        """The product path: every copy is a HIP kernel behind the C-ABI.  `between` (optional) is called while the strips
+        of the peers are on the wire, after the boxes that do not depend on them have been completed."""
         ctx = self.lev.ctx
         L = ctx.L
         s = ctx.stream()
@@ -138,15 +139,17 @@ class GhostExchange:
         def unpack(k, rbuf):
             ctx.check(L.qk_FillBoundary_unpack(self.h, s, k, state.ptr, C.c_void_p(rbuf.data_ptr())), "FillBoundary_unpack")
 
-        def physbc():
-            ctx.check(L.qk_FillPhysicalBoundary(self.h, s, state.ptr, self.bcs, self.dirichlet), "FillPhysicalBoundary")
+        def physbc(which):
+            ctx.check(L.qk_FillPhysicalBoundary_subset(self.h, s, state.ptr, self.bcs, self.dirichlet, which), "FillPhysicalBoundary")
 
-        self.fill_with(pack, local, unpack, physbc)
+        self.fill_with(pack, local, unpack, physbc, between)
 
-    def fill_with(self, pack, local, unpack, physbc):
+    def fill_with(self, pack, local, unpack, physbc, between=None):
         """Exchange protocol, independent of who moves the bytes inside a rank (HIP kernels in the product; numpy in the
-        world_size-2 gloo tests): pack -> one send/recv pair per peer -> same-rank copies while the wire is busy -> wait ->
-        unpack -> physical boundaries (reference src/simulation.hpp:1755-1773)."""
+        world_size-2 gloo tests): pack -> one send/recv pair per peer -> same-rank copies while the wire is busy
+        [-> physical boundaries of the boxes without remote ghosts -> between()] -> wait -> unpack -> (remaining) physical
+        boundaries (reference src/simulation.hpp:1755-1773).  RCCL runs the transfers on its own stream, ordered after the
+        pack kernels; the work enqueued by `between` on the compute stream overlaps them."""
         import torch.distributed as dist
         reqs = []
         if self.peers:
@@ -159,12 +162,25 @@ class GhostExchange:
                 ops.append(dist.P2POp(dist.irecv, rbuf, r))
             reqs = dist.batch_isend_irecv(ops)
         local()
+        bc = not self.geom.is_all_periodic()
+        if between is not None:
+            if bc:
+                physbc(capi.BOXES_LOCAL_ONLY)
+            between()
         for q in reqs:
             q.wait()
         for k, r, sbuf, rbuf in self.peers:
             unpack(k, rbuf)
-        if not self.geom.is_all_periodic():
-            physbc()
+        if bc:
+            physbc(capi.BOXES_REMOTE_DEPENDENT if between is not None else capi.BOXES_ALL)
+
+    def remote_boxes(self) -> List[int]:
+        """local boxes with ghost cells filled from another rank (the late group of an overlapped fill)"""
+        L = self.lev.ctx.L
+        return [b for b in range(self.lev.nboxes) if L.qk_ghost_plan_box_is_remote(self.h, b) == 1]
+
+    def set_box_remote(self, b: int, flag: bool):
+        self.lev.ctx.check(self.lev.ctx.L.qk_ghost_plan_set_box_remote(self.h, b, int(flag)), "qk_ghost_plan_set_box_remote")
 
     def items(self, kind: int, k: int = 0):
         """Plan introspection: list of (dst_box, src_box, lo, hi, shift, offset)."""
@@ -216,6 +232,7 @@ class HydroSimulation:
         self.useDualEnergy_ = 1
         self.abortOnFofcFailure_ = 1
         self.artificialViscosityK_ = 0.0
+        self.min_overlap_cells = 8 * 128 ** 3
         self.use_fused = use_fused and geom.ndim == 3
         # state
         lev = self.lev
@@ -286,10 +303,9 @@ class HydroSimulation:
     # ------------------------------------------------------------------ time step control
     def computeTimestepAtLevel(self) -> float:
         if self._signal_of_state_new is not None:
-            m = self._signal_of_state_new[1]
+            m = self._signal_of_state_new[1]  # already reduced over ranks
         else:
-            m = float(self.hydro.maxSignalSpeedLocal(self.lev, self.state_new_cc_, which=1, out=self.dev_max).item())
-        m = self._allreduce_max(m)
+            m = self._allreduce_max(float(self.hydro.maxSignalSpeedLocal(self.lev, self.state_new_cc_, which=1, out=self.dev_max).item()))
         return self.cflNumber_ * (self.min_dx() / m)
 
     def computeTimestep(self):
@@ -308,10 +324,9 @@ class HydroSimulation:
 
     def isCflViolated(self, dt_actual: float) -> bool:
         if self._signal_of_state_new is not None:
-            m = self._signal_of_state_new[0]
+            m = self._signal_of_state_new[0]  # already reduced over ranks
         else:
-            m = float(self.hydro.maxSignalSpeedLocal(self.lev, self.state_new_cc_, which=0, out=self.dev_max).item())
-        m = self._allreduce_max(m)
+            m = self._allreduce_max(float(self.hydro.maxSignalSpeedLocal(self.lev, self.state_new_cc_, which=0, out=self.dev_max).item()))
         dt_cfl = self.cflNumber_ * (self.min_dx() / m)
         return dt_actual > 1.1 * dt_cfl
 
@@ -416,32 +431,89 @@ class HydroSimulation:
         self._limits_and_sync(U_out)
         return True
 
-    def _stage_fused(self, stage: int, U_in, U_old, U_out, dt) -> int:
-        a = capi.StageArgs()
-        a.U_in, a.U_old, a.U_out = U_in.ptr, U_old.ptr, U_out.ptr
-        for d in range(3):
-            a.halfFlux[d] = self.halfFlux[d].ptr
-            a.halfVel[d] = self.halfVel[d].ptr
-            a.dx[d] = self.geom.dx[d]
-        a.redoFlag = self.redoFlag.ptr
+    def _is_final(self, stage: int) -> bool:
+        return (stage == 2) or (self.integratorOrder_ == 1)
+
+    def _fused_begin(self, stage: int):
         self.dev_counters.zero_()
+        if self._is_final(stage):
+            self.dev_signal.zero_()
+
+    def _fused_launch(self, stage: int, U_in, U_old, U_out, dt, group=None):
+        """one fused stage over all local boxes (group None) or over a sub-level (Level, [local box indices])"""
+        lev, idx = (self.lev, None) if group is None else group
+        tab = (lambda mf: mf.ptr) if idx is None else (lambda mf: mf.subset_ptr(idx))
+        a = capi.StageArgs()
+        a.U_in, a.U_old, a.U_out = tab(U_in), tab(U_old), tab(U_out)
+        for d in range(3):
+            a.halfFlux[d] = tab(self.halfFlux[d])
+            a.halfVel[d] = tab(self.halfVel[d])
+            a.dx[d] = self.geom.dx[d]
+        a.redoFlag = tab(self.redoFlag)
         a.d_redo_count = C.c_void_p(self.dev_counters.data_ptr())
         a.d_error_flag = C.c_void_p(self.dev_error.data_ptr())
-        final = (stage == 2) or (self.integratorOrder_ == 1)
-        if final:
-            self.dev_signal.zero_()
+        if self._is_final(stage):
             a.d_max_signal = C.c_void_p(self.dev_signal.data_ptr())
         a.scratch = C.c_void_p(self.scratch.data_ptr())
         a.scratch_bytes = self.scratch.numel() * 8
         a.dt, a.stage, a.reconstruction_order = dt, stage, self.reconstructionOrder_
         a.densityFloor, a.tempFloor, a.use_dual_energy, a.K_visc = self.densityFloor_, self.tempFloor_, self.useDualEnergy_, 0.0
         c = self.ctx
-        c.check(c.L.qk_hydro_stage_fused(self.lev.h, c.stream(), C.byref(self.traits), C.byref(a)), "qk_hydro_stage_fused")
-        nbad = self._allreduce_sum(int(self.dev_counters[0].item()))
+        c.check(c.L.qk_hydro_stage_fused(lev.h, c.stream(), C.byref(self.traits), C.byref(a)), "qk_hydro_stage_fused")
+
+    def _fused_end(self, stage: int) -> int:
+        """redo count of the stage (only ever compared with 0) and, after the final stage, the two CFL maxima: ONE
+        device->host copy, and with several ranks ONE all-reduce(MAX) of [sig0, sig1, count] instead of the three scalar
+        collectives of the reference (dt, CFL check, redo count)"""
+        final = self._is_final(stage)
+        v = torch.cat([self.dev_signal, self.dev_counters[0:1].to(torch.float64)]) if final else self.dev_counters[0:1].to(torch.float64)
+        if self.nranks > 1:
+            import torch.distributed as dist
+            dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        vals = v.tolist()
+        nbad = int(vals[-1])
         if final and nbad == 0:
-            sig = self.dev_signal.tolist()
-            self._signal_of_state_new = (sig[0], sig[1])
+            self._signal_of_state_new = (vals[0], vals[1])  # global maxima
         return nbad
+
+    def _stage_fused(self, stage: int, U_in, U_old, U_out, dt) -> int:
+        self._fused_begin(stage)
+        self._fused_launch(stage, U_in, U_old, U_out, dt)
+        return self._fused_end(stage)
+
+    def overlap_groups(self):
+        """(early, late) sub-levels for the overlapped ghost fill: boxes whose ghost cells are all filled on this GPU /
+        boxes that wait for strips from other ranks.  None if either group is empty (nothing to overlap)."""
+        late = self.ghost.remote_boxes()
+        key = tuple(late)
+        if getattr(self, "_groups_key", None) != key:
+            early = [b for b in range(self.lev.nboxes) if b not in set(late)]
+            self._groups = None
+            cells = lambda idx: sum(int(np.prod([self.my_boxes[b][1][d] - self.my_boxes[b][0][d] + 1 for d in range(3)])) for b in idx)
+            # a launch needs >= min_overlap_cells to fill the GPU (the marching sweeps expose one wave per 64 x-cells of a
+            # pencil: 2048 resident waves <-> 8 boxes of 128^3); smaller groups would serialise two under-filled launches,
+            # which costs more than the exposed exchange
+            if early and late and min(cells(early), cells(late)) >= self.min_overlap_cells:
+                mk = lambda idx: (Level(self.ctx, self.geom.ndim, [self.my_boxes[b] for b in idx]), idx)
+                self._groups = (mk(early), mk(late))
+            self._groups_key = key
+        return self._groups
+
+    def _fill_and_stage(self, stage, U_in, U_old, U_out, dt) -> bool:
+        """fillBoundaryConditions(U_in) + one RK stage.  With more than one rank the boxes that need nothing from other
+        ranks are advanced while the strips of the others are on the wire (north_star: FillBoundary overlapped with the
+        update on a second stream — RCCL's); the reference's fill is blocking (src/QuokkaSimulation.hpp:1099, :1202)."""
+        groups = self.overlap_groups() if (self.use_fused and self.artificialViscosityK_ == 0.0) else None
+        if groups is None:
+            self.fillBoundaryConditions(U_in)
+            return self._stage(stage, U_in, U_old, U_out, dt)
+        early, late = groups
+        self._fused_begin(stage)
+        self.ghost.fill(U_in, between=lambda: self._fused_launch(stage, U_in, U_old, U_out, dt, early))
+        self._fused_launch(stage, U_in, U_old, U_out, dt, late)
+        if self._fused_end(stage) == 0:
+            return True
+        return self._stage_unfused(stage, U_in, U_old, U_out, dt, with_fofc=True)
 
     def _stage(self, stage, U_in, U_old, U_out, dt) -> bool:
         if self.use_fused and self.artificialViscosityK_ == 0.0:
@@ -454,12 +526,10 @@ class HydroSimulation:
     # ------------------------------------------------------------------ advance
     def advanceHydroAtLevel(self, state_old_tmp: MultiFab, dt_lev: float) -> bool:
         self._signal_of_state_new = None  # state_new_cc_ is about to be overwritten
-        self.fillBoundaryConditions(state_old_tmp)
-        if not self._stage(1, state_old_tmp, state_old_tmp, self.state_inter_cc_, dt_lev):
+        if not self._fill_and_stage(1, state_old_tmp, state_old_tmp, self.state_inter_cc_, dt_lev):
             return False
         if self.integratorOrder_ == 2:
-            self.fillBoundaryConditions(self.state_inter_cc_)
-            if not self._stage(2, self.state_inter_cc_, state_old_tmp, self.state_new_cc_, dt_lev):
+            if not self._fill_and_stage(2, self.state_inter_cc_, state_old_tmp, self.state_new_cc_, dt_lev):
                 return False
         else:
             for b in range(self.lev.nboxes):

@@ -61,6 +61,29 @@ def test_sedov_anisotropic_boxes_bit_exact(ctx, oracle):
     assert np.array_equal(Uo, Ug), f"max abs diff {np.abs(Uo - Ug).max()}"
 
 
+def test_overlapped_fill_split_stage_bit_exact(ctx, oracle):
+    """the multi-GPU schedule on one GPU: boxes 1, 4, 6 are declared 'remote dependent' by hand, so every stage runs as
+    early group -> (exchange) -> late group with the physical boundaries split the same way; the result must not change"""
+    N, mgs, nsteps = 32, 16, 8
+    so = oracle.sim(SEDOV, 3, [N] * 3, [0, 0, 0], [1.2] * 3, [0, 0, 0], max_grid_size=[mgs] * 3)
+    sg = sedov_problem(ctx, N, max_grid_size=mgs)
+    sg.min_overlap_cells = 1  # (production: only groups that fill the GPU on their own are split)
+    assert sg.overlap_groups() is None
+    for b in (1, 4, 6):
+        sg.ghost.set_box_remote(b, True)
+    groups = sg.overlap_groups()
+    assert groups is not None and groups[1][1] == [1, 4, 6] and len(groups[0][1]) == 5
+    for it in range(nsteps):
+        assert so.step() and sg.step()
+        assert so.dt == sg.dt_
+    assert np.array_equal(gather_oracle(so, N), gather_gpu(sg, N))
+    # ghost cells too (stage inputs of the next step)
+    so.fill_ghosts(0, so.time)
+    sg.fillBoundaryConditions(sg.state_new_cc_)
+    for b in range(sg.lev.nboxes):
+        assert np.array_equal(so.state(b), sg.state_new_cc_.fab_numpy(b))
+
+
 def test_ghost_fill_matches_oracle(ctx, oracle):
     """FillBoundary between 8 boxes + reflecting walls: every ghost cell, every component."""
     N, mgs = 16, 8

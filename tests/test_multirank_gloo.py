@@ -33,7 +33,7 @@ def region(fab, begin, lo, hi, shift=(0, 0, 0)):
     return fab[tuple(sl)]
 
 
-def worker(rank, world, port, problem, N, mgs, periodic, q):
+def worker(rank, world, port, problem, N, mgs, periodic, overlapped, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -85,9 +85,13 @@ def worker(rank, world, port, problem, N, mgs, periodic, q):
                 r = region(fabs[db], begins[db], lo, hi)
                 r[...] = buf[off:off + r.size].reshape(r.shape)
 
-        def physbc():
+        late = set(ex.remote_boxes())
+
+        def physbc(which):
             dom_hi = N - 1
             for db, sb, lo, hi, sh, off in ex.items(3):
+                if (which == capi.BOXES_LOCAL_ONLY and db in late) or (which == capi.BOXES_REMOTE_DEPENDENT and db not in late):
+                    continue
                 f = fabs[db]
                 for k in range(lo[2], hi[2] + 1):
                     for j in range(lo[1], hi[1] + 1):
@@ -103,9 +107,18 @@ def worker(rank, world, port, problem, N, mgs, periodic, q):
                             b0 = begins[db]
                             f[:, k - b0[2], j - b0[1], i - b0[0]] = sign * f[:, src[2] - b0[2], src[1] - b0[1], src[0] - b0[0]]
 
-        ex.fill_with(pack, local, unpack, physbc)
-        ok = all(np.array_equal(fabs[n], filled[g]) for n, g in enumerate(mine))
+        # overlapped protocol: the boxes that need nothing from other ranks must be complete while the wire is busy
+        early_ok = []
+
+        def between():
+            early_ok.extend(np.array_equal(fabs[n], filled[g]) for n, g in enumerate(mine) if n not in late)
+
+        ex.fill_with(pack, local, unpack, physbc, between if overlapped else None)
+        ok = all(np.array_equal(fabs[n], filled[g]) for n, g in enumerate(mine)) and all(early_ok)
+        if overlapped:
+            ok = ok and len(early_ok) == len(mine) - len(late)
         nbad = sum(int((fabs[n] != filled[g]).sum()) for n, g in enumerate(mine))
+        n_early = len(mine) - len(late)
 
         # scalar collectives of the driver (dt / CFL max, FOFC redo count)
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
@@ -113,16 +126,16 @@ def worker(rank, world, port, problem, N, mgs, periodic, q):
         c = torch.tensor([rank + 10], dtype=torch.int64)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         ok = ok and float(t.item()) == float(world) and int(c.item()) == sum(r + 10 for r in range(world))
-        q.put((rank, ok, nbad, len(ex.peers)))
+        q.put((rank, ok, nbad, len(ex.peers), n_early))
     finally:
         dist.destroy_process_group()
 
 
-def run(world, problem, N, mgs, periodic):
+def run(world, problem, N, mgs, periodic, overlapped=False):
     mpctx = mp.get_context("spawn")
     q = mpctx.Queue()
     port = free_port()
-    procs = [mpctx.Process(target=worker, args=(r, world, port, problem, N, mgs, periodic, q)) for r in range(world)]
+    procs = [mpctx.Process(target=worker, args=(r, world, port, problem, N, mgs, periodic, overlapped, q)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=300) for _ in range(world)]
@@ -136,6 +149,17 @@ def run(world, problem, N, mgs, periodic):
 def test_ghost_exchange_reflecting_octant(world):
     """Sedov octant (reflecting walls), 16^3 in 8^3 boxes: 8 boxes over 2 / 4 ranks"""
     from oracle.pyoracle import SEDOV
-    for rank, ok, nbad, npeers in run(world, SEDOV, 16, 8, [0, 0, 0]):
+    for rank, ok, nbad, npeers, n_early in run(world, SEDOV, 16, 8, [0, 0, 0]):
         assert ok, f"rank {rank}: {nbad} ghost cells differ from the single-process fill"
         assert npeers >= 1
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_overlapped_fill_completes_local_boxes_early(world):
+    """Sedov octant, 32^3 in 8^3 boxes (64 boxes): boxes without remote ghost cells are complete (local copies + their
+    physical boundaries) before the strips of the peers are waited for; the final state equals the blocking fill"""
+    from oracle.pyoracle import SEDOV
+    res = run(world, SEDOV, 32, 8, [0, 0, 0], overlapped=True)
+    for rank, ok, nbad, npeers, n_early in res:
+        assert ok, f"rank {rank}: {nbad} ghost cells differ from the single-process fill"
+    assert sum(r[4] for r in res) > 0, "no rank had an early (remote-independent) box"
