@@ -277,6 +277,9 @@ int qk_FillBoundary_local_int(qk_ghost_plan *plan, qk_stream s, qk_iarray4 *stat
 /* pack the strips for peer k into `sendbuf` (device, send_count doubles) / unpack `recvbuf` */
 int qk_FillBoundary_pack(qk_ghost_plan *plan, qk_stream s, int k, const qk_array4 *state, double *sendbuf);
 int qk_FillBoundary_unpack(qk_ghost_plan *plan, qk_stream s, int k, qk_array4 *state, const double *recvbuf);
+/* iMultiFab flavours (redoFlag strips between GPUs; counts of qk_ghost_plan_peer are elements, here 4-byte ints) */
+int qk_FillBoundary_pack_int(qk_ghost_plan *plan, qk_stream s, int k, const qk_iarray4 *state, int *sendbuf);
+int qk_FillBoundary_unpack_int(qk_ghost_plan *plan, qk_stream s, int k, qk_iarray4 *state, const int *recvbuf);
 /* physical boundaries (after FillBoundary): bcs[ncomp]; dirichlet[dim][side] may be NULL */
 int qk_FillPhysicalBoundary(qk_ghost_plan *plan, qk_stream s, qk_array4 *state, const qk_bcrec *bcs, const qk_dirichlet_face *dirichlet);
 /* Overlap of the exchange with the update (north_star: "FillBoundary ... overlapped with interior-cell updates"; the

@@ -139,6 +139,8 @@ def lib() -> C.CDLL:
         L.qk_FillBoundary_local_int.argtypes = [vp, vp, vp]
         L.qk_FillBoundary_pack.argtypes = [vp, vp, ci, vp, vp]
         L.qk_FillBoundary_unpack.argtypes = [vp, vp, ci, vp, vp]
+        L.qk_FillBoundary_pack_int.argtypes = [vp, vp, ci, vp, vp]
+        L.qk_FillBoundary_unpack_int.argtypes = [vp, vp, ci, vp, vp]
         L.qk_FillPhysicalBoundary.argtypes = [vp, vp, vp, P(BCRec), P(DirichletFace)]
         L.qk_FillPhysicalBoundary_subset.argtypes = [vp, vp, vp, P(BCRec), P(DirichletFace), C.c_int]
         L.qk_ghost_plan_box_is_remote.argtypes = [vp, C.c_int]
@@ -161,7 +163,7 @@ DECLARED_SYMBOLS = [
     "qk_rad_ConservedToPrimitive", "qk_rad_ComputeFluxes", "qk_rad_computeRadiationFluxes", "qk_rad_PredictStep", "qk_rad_AddFluxesRK2",
     "qk_rad_AddSourceTermsSingleGroup",
     "qk_ghost_plan_create", "qk_ghost_plan_destroy", "qk_ghost_plan_num_peers", "qk_ghost_plan_peer", "qk_ghost_plan_num_items", "qk_ghost_plan_item",
-    "qk_FillBoundary_local", "qk_FillBoundary_local_int", "qk_FillBoundary_pack", "qk_FillBoundary_unpack", "qk_FillPhysicalBoundary",
+    "qk_FillBoundary_local", "qk_FillBoundary_local_int", "qk_FillBoundary_pack", "qk_FillBoundary_unpack", "qk_FillBoundary_pack_int", "qk_FillBoundary_unpack_int", "qk_FillPhysicalBoundary",
     "qk_FillPhysicalBoundary_subset", "qk_ghost_plan_box_is_remote", "qk_ghost_plan_set_box_remote",
 ]
 

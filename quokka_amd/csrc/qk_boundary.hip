@@ -475,6 +475,40 @@ int qk_FillBoundary_local_int(qk_ghost_plan *plan, qk_stream s, qk_iarray4 *stat
 	return QK_OK;
 }
 
+int qk_FillBoundary_pack_int(qk_ghost_plan *plan, qk_stream s, int k, const qk_iarray4 *state_t, int *sendbuf)
+{
+	if (plan == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	qk_ctx *ctx = plan->lev->ctx;
+	QK_REQUIRE(ctx, k >= 0 && k < static_cast<int>(plan->peers.size()) && state_t && sendbuf, "FillBoundary_pack_int: bad argument");
+	PeerPlan const &pp = plan->peers[k];
+	if (pp.send.empty()) {
+		return QK_OK;
+	}
+	hipLaunchKernelGGL((k_copy<MODE_PACK, int, qk_iarray4>), gridFor(static_cast<int64_t>(pp.max_send_cells) * plan->ncomp, static_cast<int>(pp.send.size())),
+			   dim3(256), 0, static_cast<hipStream_t>(s), pp.d_send, const_cast<qk_iarray4 *>(state_t), sendbuf, plan->ncomp);
+	QK_HIP_CHECK(ctx, hipGetLastError());
+	return QK_OK;
+}
+
+int qk_FillBoundary_unpack_int(qk_ghost_plan *plan, qk_stream s, int k, qk_iarray4 *state_t, const int *recvbuf)
+{
+	if (plan == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	qk_ctx *ctx = plan->lev->ctx;
+	QK_REQUIRE(ctx, k >= 0 && k < static_cast<int>(plan->peers.size()) && state_t && recvbuf, "FillBoundary_unpack_int: bad argument");
+	PeerPlan const &pp = plan->peers[k];
+	if (pp.recv.empty()) {
+		return QK_OK;
+	}
+	hipLaunchKernelGGL((k_copy<MODE_UNPACK, int, qk_iarray4>), gridFor(static_cast<int64_t>(pp.max_recv_cells) * plan->ncomp, static_cast<int>(pp.recv.size())),
+			   dim3(256), 0, static_cast<hipStream_t>(s), pp.d_recv, state_t, const_cast<int *>(recvbuf), plan->ncomp);
+	QK_HIP_CHECK(ctx, hipGetLastError());
+	return QK_OK;
+}
+
 int qk_FillBoundary_pack(qk_ghost_plan *plan, qk_stream s, int k, const qk_array4 *state_t, double *sendbuf)
 {
 	if (plan == nullptr) {

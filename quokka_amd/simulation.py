@@ -393,9 +393,11 @@ class HydroSimulation:
             self.flag_ghost = GhostExchange(self.lev, self.geom, 1, 1, self.all_boxes, self.owner, self.rank, per, None, dtype=torch.int32)
         # redoFlag.FillBoundary(periodicity) only (QuokkaSimulation.hpp:1157): no physical BCs
         g = self.flag_ghost
-        ctx, L, s = self.ctx, self.ctx.L, self.ctx.stream()
-        assert not g.peers, "multi-GPU FOFC flag exchange: int32 strips travel as float64 payloads (not wired yet)"
-        ctx.check(L.qk_FillBoundary_local_int(g.h, s, self.redoFlag.ptr), "FillBoundary_local_int(redoFlag)")
+        ctx, L, s, flag = self.ctx, self.ctx.L, self.ctx.stream(), self.redoFlag
+        g.fill_with(lambda k, sbuf: ctx.check(L.qk_FillBoundary_pack_int(g.h, s, k, flag.ptr, C.c_void_p(sbuf.data_ptr())), "FillBoundary_pack_int"),
+                    lambda: ctx.check(L.qk_FillBoundary_local_int(g.h, s, flag.ptr), "FillBoundary_local_int(redoFlag)"),
+                    lambda k, rbuf: ctx.check(L.qk_FillBoundary_unpack_int(g.h, s, k, flag.ptr, C.c_void_p(rbuf.data_ptr())), "FillBoundary_unpack_int"),
+                    lambda which: None)
 
     # ------------------------------------------------------------------ one RK stage
     def _stage_unfused(self, stage: int, U_in, U_old, U_out, dt, with_fofc: bool) -> bool:
