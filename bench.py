@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--max-grid-size", type=int, default=128)
     ap.add_argument("--workload", choices=["sedov", "shell"], default="sedov",
                     help="sedov = BASELINE metric (default); shell = RadhydroShell 256^3 radiation-hydro (BASELINE config 4), reported as a secondary line")
+    ap.add_argument("--pow-mode", type=int, default=1, help="shell workload: 0 = libm pow(T,4) as the reference's std::pow, 1 = repeated multiplication")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-ncell", type=int, default=128)
     ap.add_argument("--cpu-steps", type=int, default=3)
@@ -106,7 +107,7 @@ def main():
         from quokka_amd.radhydro import shell_problem
         assert world == 1, "the shell line is single-GPU"
         tab = np.loadtxt(os.path.join(ROOT, "tests", "golden", "dust_shell_initial_conditions.txt"), skiprows=1)
-        sim = shell_problem(ctx, args.ncell, (tab[:, 0], tab[:, 2], tab[:, 3]), max_grid_size=args.max_grid_size)
+        sim = shell_problem(ctx, args.ncell, (tab[:, 0], tab[:, 2], tab[:, 3]), max_grid_size=args.max_grid_size, pow_mode=args.pow_mode)
     else:
         sim = sedov_problem(ctx, args.ncell, max_grid_size=args.max_grid_size, rank=rank, nranks=world, n_cell=n_cell)
     sim.maxTimesteps_ = 10 ** 9
@@ -164,7 +165,9 @@ def main():
                           "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "dtype": "f64", "data": "synthetic",
                           "config": {"workload": f"RadhydroShell {args.ncell}^3 (tests/radhydro_shell_256.in), PLM, 1 group, kappa=20",
                                      "radiation_substeps_per_step": sim.radiationCellUpdates_ / max(sim.cellUpdates_, 1),
-                                     "newton_iterations_per_solve": sim.rad_counters["newton_iterations"] / max(sim.rad_counters["solves"], 1)},
+                                     "newton_iterations_per_solve": sim.rad_counters["newton_iterations"] / max(sim.rad_counters["solves"], 1),
+                                     "solves_per_cell_and_source_call": sim.rad_counters["solves"] / max(2 * sim.radiationCellUpdates_, 1),
+                                     "max_newton_iterations": sim.rad_counters["max_newton_iterations"], "pow_mode": args.pow_mode},
                           "kernels_ms_per_launch": {k: v[1] / max(v[0], 1) for k, v in sorted(kernels.items())},
                           "kernels_launches": {k: v[0] for k, v in sorted(kernels.items())},
                           "reference_published_a100_1gpu": 39.04}), flush=True)

@@ -31,6 +31,7 @@ struct qk_ctx {
 	std::vector<qk_prof_slot> prof_slots;
 	std::vector<qk_prof_pending> prof_pending;
 	std::vector<hipEvent_t> prof_free_events;
+	int *counter_slots = nullptr; // qk_rad_ops.hip: spread iteration / failure counters (owned)
 };
 
 struct qk_level {
