@@ -64,7 +64,7 @@ def weak_scaled_cells(n: int, ngpus: int):
 
 
 def cpu_baseline(ncell: int, steps: int):
-    """Oracle (port of the reference algorithm, built with gcc -O2 -ffp-contract=off -fopenmp) on the host cores."""
+    """Oracle (port of the reference algorithm, built with g++ -O3 -ffp-contract=off -fopenmp) on the host cores."""
     from oracle.pyoracle import SEDOV, Oracle
     cores = os.cpu_count() or 1
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))

@@ -43,6 +43,8 @@ template <typename T> inline void FillBoundary(MultiFabT<T> &mf, Geometry const 
 			}
 		}
 	}
+	// ghost cells of `dst` are written from VALID cells of the sources: destinations are independent
+	_Pragma("omp parallel for schedule(dynamic)")
 	for (int dst = 0; dst < nb; ++dst) {
 		auto darr = mf.array(dst);
 		Box const dbox = mf.fabs[dst].bx;
@@ -83,6 +85,7 @@ template <typename T> inline void FillBoundary(MultiFabT<T> &mf, Geometry const 
 inline void FillPhysicalBoundary(MultiFab &mf, Geometry const &geom, std::vector<BCRec> const &bcs, CustomBCFunc const &userFunc, double time)
 {
 	Box const &dom = geom.domain;
+	_Pragma("omp parallel for schedule(dynamic)")
 	for (int b = 0; b < mf.size(); ++b) {
 		auto arr = mf.array(b);
 		Box const fb = mf.fabs[b].bx;

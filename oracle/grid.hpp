@@ -133,10 +133,14 @@ template <typename T> struct MultiFabT {
 	MultiFabT(std::vector<Box> const &ba, int ncomp, int nghost, int ndim_in, int facedir_in = -1, T init = T(0))
 	    : valid(ba), ng(nghost), nc(ncomp), ndim(ndim_in), facedir(facedir_in)
 	{
-		fabs.reserve(ba.size());
-		for (auto const &b : ba) {
-			Box fb = (facedir >= 0) ? faceBox(b, facedir) : b;
-			fabs.emplace_back(grow(fb, ng, ndim), nc, init);
+		// one thread per box allocates AND first-touches its fab (cpu_baseline leg of bench.py: the reference's
+		// ~130 temporaries per step are otherwise initialised by one core)
+		fabs.resize(ba.size());
+		const int n = static_cast<int>(ba.size());
+		_Pragma("omp parallel for schedule(static)")
+		for (int b = 0; b < n; ++b) {
+			Box fb = (facedir >= 0) ? faceBox(ba[b], facedir) : ba[b];
+			fabs[b] = Fab<T>(grow(fb, ng, ndim), nc, init);
 		}
 	}
 	[[nodiscard]] auto size() const -> int { return static_cast<int>(valid.size()); }
@@ -146,8 +150,10 @@ template <typename T> struct MultiFabT {
 	auto const_array(int b) const -> Array4<const T> { return fabs[b].const_array(); }
 	void setVal(T v)
 	{
-		for (auto &f : fabs) {
-			f.setVal(v);
+		const int n = static_cast<int>(fabs.size());
+		_Pragma("omp parallel for schedule(static)")
+		for (int b = 0; b < n; ++b) {
+			fabs[b].setVal(v);
 		}
 	}
 };
