@@ -395,6 +395,17 @@ template <typename T> class FabArrayT
 	{
 		QK_HOST_HIP(hipMemcpy(dst.d_data_, src.d_data_, sizeof(T) * src.total_, hipMemcpyDeviceToDevice));
 	}
+	// MultiFab::Copy(dst, src, srccomp, dstcomp, numcomp, nghost).  Components are outermost, so the copy is one contiguous
+	// block per box; it always carries the ghost cells along (AMReX copies valid + nghost cells) — every caller refills the
+	// ghost cells of `dst` before reading them.
+	static void Copy(FabArrayT &dst, FabArrayT const &src, int srccomp, int dstcomp, int numcomp, int /*nghost*/)
+	{
+		for (int b = 0; b < src.size(); ++b) {
+			size_t const n = static_cast<size_t>(src.fabboxes_[b].numPts());
+			QK_HOST_HIP(hipMemcpy(dst.d_data_ + dst.offsets_[b] + n * dstcomp, src.d_data_ + src.offsets_[b] + n * srccomp, sizeof(T) * n * numcomp,
+					      hipMemcpyDeviceToDevice));
+		}
+	}
 	// sum / norm over valid cells of component n (host reduction: diagnostics only, not on the timed path)
 	[[nodiscard]] auto sum(int n) const -> double
 	{

@@ -1,10 +1,12 @@
-// quokka_host.hpp — C++17 host mirror of the reference's operator surface on the hydro path:
+// quokka_host.hpp — C++17 host mirror of the reference's operator surface on the hydro and radiation path:
 //   Physics_Traits / Physics_Indices            reference src/physics_info.hpp:8-47
 //   quokka::EOS_Traits, HydroSystem_Traits       reference src/hydro/EOS.hpp:32-37, src/hydro/hydro_system.hpp:38-41
 //   HyperbolicSystem<problem_t>, HydroSystem<problem_t>   static methods with the reference's names and arguments; every body is ONE
 //                                                call into the C-ABI (include/quokka_amd.h) — no arithmetic on the host
+//   RadSystem_Traits, RadSystem<problem_t>       indices, constants, opacity / source hooks, radiation operators (reference src/radiation/radiation_system.hpp)
 //   AMRSimulation<problem_t> / QuokkaSimulation<problem_t>   uniform-grid (max_level = 0) evolve loop, dt control, level-0 ghost fill,
-//                                                RK2 + FOFC + retries (reference src/simulation.hpp:703-981,1704-1785, src/QuokkaSimulation.hpp:885-1568)
+//                                                RK2 + FOFC + retries, radiation subcycle
+//                                                (reference src/simulation.hpp:703-981,1704-1785, src/QuokkaSimulation.hpp:885-1961)
 // Problems specialise the same trait structs and member templates as in the reference (setInitialConditionsOnGrid,
 // setCustomBoundaryConditions, computeAfterEvolve, ...).  Device hooks are evaluated on host staging data: ICs run on a host
 // buffer that is uploaded; setCustomBoundaryConditions is sampled to build the constant-Dirichlet face model of the C-ABI.
@@ -236,14 +238,142 @@ template <typename problem_t> class HydroSystem : public HyperbolicSystem<proble
 	}
 };
 
-// gas / radiation variable indices problems refer to (reference src/radiation/radiation_system.hpp:171-188)
-template <typename problem_t> class RadSystem
+// this struct is specialized by the user application code (reference src/radiation/radiation_system.hpp:73-82)
+template <typename problem_t> struct RadSystem_Traits {
+	static constexpr double c_light = C::c_light;
+	static constexpr double c_hat = C::c_light;
+	static constexpr double radiation_constant = C::a_rad;
+	static constexpr double Erad_floor = 0.;
+	static constexpr double beta_order = 1;
+};
+
+// RadSystem<problem_t>: indices, constants, the problem's device hooks and the operators of the radiation update, each ONE
+// call into the C-ABI (reference src/radiation/radiation_system.hpp:150-330).  Single group, OpacityModel::single_group.
+template <typename problem_t> class RadSystem : public HyperbolicSystem<problem_t>
 {
       public:
+	using array_t = amrex::Array4<amrex::Real>;
+	using arrayconst_t = amrex::Array4<const amrex::Real>;
 	enum gasVarIndex { gasDensity_index = 0, x1GasMomentum_index, x2GasMomentum_index, x3GasMomentum_index, gasEnergy_index, gasInternalEnergy_index, scalar0_index };
+	static constexpr int nvarHyperbolic_ = Physics_NumVars::numRadVars * Physics_Traits<problem_t>::nGroups;
 	static constexpr int nstartHyperbolic_ = Physics_Indices<problem_t>::radFirstIndex;
+	static constexpr int nvar_ = nstartHyperbolic_ + nvarHyperbolic_;
 	enum radVarIndex { radEnergy_index = nstartHyperbolic_, x1RadFlux_index, x2RadFlux_index, x3RadFlux_index };
+
+	static constexpr double c_light_ = RadSystem_Traits<problem_t>::c_light;
+	static constexpr double c_hat_ = RadSystem_Traits<problem_t>::c_hat;
+	static constexpr double radiation_constant_ = RadSystem_Traits<problem_t>::radiation_constant;
+	static constexpr double Erad_floor_ = RadSystem_Traits<problem_t>::Erad_floor;
+	static constexpr int beta_order_ = static_cast<int>(RadSystem_Traits<problem_t>::beta_order);
+
+	// device hooks a problem may specialise (:1141-1154, :582-587)
+	static auto ComputePlanckOpacity(double rho, double Tgas) -> amrex::Real;
+	static auto ComputeFluxMeanOpacity(double rho, double Tgas) -> amrex::Real;
+	static auto ComputeEnergyMeanOpacity(double rho, double Tgas) -> amrex::Real;
+	static void SetRadEnergySource(array_t &radEnergySource, amrex::Box const &indexRange, amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> const &dx,
+				       amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> const &prob_lo, amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> const &prob_hi,
+				       amrex::Real time);
+
+	// The opacity hooks run on the device in the reference; the C-ABI carries them as a closed, parametrised set (model 0:
+	// constants).  The hooks are sampled on the host: anything that is not constant in (rho, T) is refused, never approximated.
+	static auto traits() -> qk_rad_traits
+	{
+		static_assert(Physics_Traits<problem_t>::nGroups == 1, "multigroup radiation is not built (SURVEY 8f rank 2)");
+		const double rs[3] = {1.0e-24, 3.7e-19, 2.0e-3}, Ts[3] = {3.0, 1.1e3, 4.0e7};
+		const double kP = ComputePlanckOpacity(rs[0], Ts[0]), kE = ComputeEnergyMeanOpacity(rs[0], Ts[0]), kF = ComputeFluxMeanOpacity(rs[0], Ts[0]);
+		for (double r : rs) {
+			for (double T : Ts) {
+				if (ComputePlanckOpacity(r, T) != kP || ComputeEnergyMeanOpacity(r, T) != kE || ComputeFluxMeanOpacity(r, T) != kF) {
+					amrex::Abort("RadSystem: opacity hooks that depend on (rho, T) are not expressible in the C-ABI's closed opacity set");
+				}
+			}
+		}
+		int pow_mode = 0;
+		amrex::ParmParse pp("radiation");
+		pp.query("pow_mode", pow_mode); // 0: pow(T, 4) like the reference's std::pow; 1: repeated multiplication
+		return {c_light_, c_hat_, radiation_constant_, Erad_floor_, beta_order_, 0, kP, kE, kF, pow_mode};
+	}
+	static auto lev() -> qk_level * { return qkhost::Runtime::get().lev; }
+	static void flux3(std::array<amrex::MultiFab, AMREX_SPACEDIM> const &f, qk_array4 *out[3])
+	{
+		for (int d = 0; d < 3; ++d) {
+			out[d] = (d < AMREX_SPACEDIM) ? qkhost::tab(f[d]) : nullptr;
+		}
+	}
+	static void dx3(amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> const &dx, double out[3])
+	{
+		for (int d = 0; d < 3; ++d) {
+			out[d] = (d < AMREX_SPACEDIM) ? dx[d] : 1.0;
+		}
+	}
+
+	// computeRadiationFluxes + fluxFunction<DIR> (reference src/QuokkaSimulation.hpp:1884-1961): cons -> prim, reconstruction, HLL
+	static void computeRadiationFluxes(amrex::MultiFab const &consVar, std::array<amrex::MultiFab, AMREX_SPACEDIM> &flux, int reconstructionOrder)
+	{
+		auto rt = traits();
+		qk_array4 *f[3];
+		flux3(flux, f);
+		qkhost::check(qk_rad_computeRadiationFluxes(lev(), nullptr, &rt, AMREX_SPACEDIM, reconstructionOrder, qkhost::tab(consVar), f),
+			      "RadSystem::computeRadiationFluxes");
+	}
+	// :667-710
+	static void PredictStep(amrex::MultiFab const &consVarOld, amrex::MultiFab &consVarNew, std::array<amrex::MultiFab, AMREX_SPACEDIM> const &fluxArray,
+				double dt, amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> dx)
+	{
+		auto rt = traits();
+		qk_array4 *f[3];
+		double d3[3];
+		flux3(fluxArray, f);
+		dx3(dx, d3);
+		qkhost::check(qk_rad_PredictStep(lev(), nullptr, &rt, AMREX_SPACEDIM, qkhost::tab(consVarOld), qkhost::tab(consVarNew), f, dt, d3),
+			      "RadSystem::PredictStep");
+	}
+	// :712-771
+	static void AddFluxesRK2(amrex::MultiFab &U_new, amrex::MultiFab const &U0, amrex::MultiFab const &U1,
+				 std::array<amrex::MultiFab, AMREX_SPACEDIM> const &fluxArrayOld, std::array<amrex::MultiFab, AMREX_SPACEDIM> const &fluxArray, double dt,
+				 amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> dx)
+	{
+		auto rt = traits();
+		qk_array4 *f0[3], *f1[3];
+		double d3[3];
+		flux3(fluxArrayOld, f0);
+		flux3(fluxArray, f1);
+		dx3(dx, d3);
+		qkhost::check(qk_rad_AddFluxesRK2(lev(), nullptr, &rt, AMREX_SPACEDIM, qkhost::tab(U_new), qkhost::tab(U0), qkhost::tab(U1), f0, f1, dt, d3),
+			      "RadSystem::AddFluxesRK2");
+	}
+	// src/radiation/source_terms_single_group.hpp:10-564
+	static void AddSourceTermsSingleGroup(amrex::MultiFab &consVar, amrex::MultiFab const &radEnergySource, double dt, int stage, int *p_iteration_counter,
+					      int *p_iteration_failure_counter)
+	{
+		auto rt = traits();
+		auto t = qkhost::traits<problem_t>();
+		qkhost::check(qk_rad_AddSourceTermsSingleGroup(lev(), nullptr, &rt, &t, qkhost::tab(consVar), qkhost::tab(radEnergySource), dt, stage,
+							       p_iteration_counter, p_iteration_failure_counter),
+			      "RadSystem::AddSourceTermsSingleGroup");
+	}
 };
+
+template <typename problem_t> auto RadSystem<problem_t>::ComputePlanckOpacity(const double /*rho*/, const double /*Tgas*/) -> amrex::Real
+{
+	return std::numeric_limits<double>::quiet_NaN();
+}
+template <typename problem_t> auto RadSystem<problem_t>::ComputeFluxMeanOpacity(const double rho, const double Tgas) -> amrex::Real
+{
+	return ComputePlanckOpacity(rho, Tgas);
+}
+template <typename problem_t> auto RadSystem<problem_t>::ComputeEnergyMeanOpacity(const double rho, const double Tgas) -> amrex::Real
+{
+	return ComputePlanckOpacity(rho, Tgas);
+}
+template <typename problem_t>
+void RadSystem<problem_t>::SetRadEnergySource(array_t & /*radEnergySource*/, amrex::Box const & /*indexRange*/,
+					      amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> const & /*dx*/,
+					      amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> const & /*prob_lo*/,
+					      amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> const & /*prob_hi*/, amrex::Real /*time*/)
+{
+	// do nothing -- user implemented
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 template <typename problem_t> class AMRSimulation
@@ -507,6 +637,13 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	amrex::Real pressureFloor_ = 0.;
 	long fofcStages_ = 0, retries_ = 0;
 	double elapsedSeconds_ = 0.0;
+	// radiation (reference src/QuokkaSimulation.hpp:127-131)
+	amrex::Real radiationCflNumber_ = 0.3;
+	int maxSubsteps_ = 10;
+	amrex::Long radiationCellUpdates_ = 0;
+	long radSolves_ = 0, radNewtonIterations_ = 0;
+	int radMaxNewtonIterations_ = 0;
+	static constexpr bool is_radiation_enabled_ = Physics_Traits<problem_t>::is_radiation_enabled;
 
 	static constexpr int ncompHydro_ = HydroSystem<problem_t>::nvar_;
 
@@ -518,6 +655,10 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		hpp.query("use_dual_energy", useDualEnergy_);
 		hpp.query("abort_on_fofc_failure", abortOnFofcFailure_);
 		hpp.query("artificial_viscosity_coefficient", artificialViscosityK_);
+		amrex::ParmParse rpp("radiation"); // reference src/QuokkaSimulation.hpp:353-358
+		rpp.query("reconstruction_order", radiationReconstructionOrder_);
+		rpp.query("cfl", radiationCflNumber_);
+		rpp.query("max_substeps", maxSubsteps_);
 		allocate();
 	}
 
@@ -532,7 +673,11 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	// ------------------------------------------------------------------ dt (reference src/simulation.hpp:703-818)
 	void computeTimestep()
 	{
-		double const m = (haveSignal_ ? signal_[1] : HydroSystem<problem_t>::maxSignalSpeedLocal(state_new_cc_[0], 1));
+		double m = (haveSignal_ ? signal_[1] : HydroSystem<problem_t>::maxSignalSpeedLocal(state_new_cc_[0], 1));
+		if constexpr (is_radiation_enabled_) {
+			// reference src/QuokkaSimulation.hpp:421-434: per cell max(c_hat / maxSubsteps, hydro signal); the max over cells commutes
+			m = std::max(RadSystem<problem_t>::c_hat_ / static_cast<double>(maxSubsteps_), m);
+		}
 		double dt_tmp = cflNumber_ * (minDx() / m);
 		dt_tmp = std::min(dt_tmp, 1.1 * dt_[0]);
 		double dt_0 = std::min(dt_tmp, 1.0 * dt_tmp);
@@ -570,6 +715,9 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 			std::swap(state_old_cc_[0], state_new_cc_[0]);
 			if (!advanceHydroAtLevelWithRetries(time, dt_[0])) {
 				amrex::Abort("QUOKKA FATAL ERROR: Hydro update exceeded max_retries on level 0");
+			}
+			if constexpr (is_radiation_enabled_) { // advanceSingleTimestepAtLevel (reference src/QuokkaSimulation.hpp:653-707)
+				subcycleRadiationAtLevel(time, dt_[0]);
 			}
 			++istep[0];
 			this->cellUpdates_ += this->CountCells(0);
@@ -645,6 +793,101 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		return dt_actual > (1.1 * dt_cfl);
 	}
 
+	// ------------------------------------------------------------------ radiation subcycle (reference src/QuokkaSimulation.hpp:397-406,1576-1882)
+	[[nodiscard]] auto computeNumberOfRadiationSubsteps(double dt_lev_hydro) const -> int
+	{
+		double const dtrad_tmp = radiationCflNumber_ * (minDx() / RadSystem<problem_t>::c_hat_);
+		return static_cast<int>(std::ceil(dt_lev_hydro / dtrad_tmp));
+	}
+
+	// operatorSplitSourceTerms (:1859-1882).  SetRadEnergySource is a host-evaluated hook here: it is sampled at two times on
+	// the first box; a time-independent source (RadhydroShell) is evaluated once and kept on the device.
+	void fillRadEnergySource(double time)
+	{
+		auto const &g = geom[0];
+		auto eval = [&](int b, double t) {
+			std::vector<double> h(static_cast<size_t>(radEnergySource_.fabbox(b).numPts()), 0.0);
+			amrex::Array4<double> a(h.data(), radEnergySource_.fabbox(b), 1);
+			RadSystem<problem_t>::SetRadEnergySource(a, radEnergySource_.validbox(b), g.CellSizeArray(), g.ProbLoArray(), g.ProbHiArray(), t);
+			return h;
+		};
+		if (radSourceState_ == 0) {
+			radSourceState_ = (eval(0, 0.0) == eval(0, 0.37 * stopTime_ + 1.0)) ? 1 : 2; // 1: time independent
+			radSourceFilled_ = false;
+		}
+		if (radSourceState_ == 1 && radSourceFilled_) {
+			return;
+		}
+		for (int b = 0; b < radEnergySource_.size(); ++b) {
+			radEnergySource_.copyFromHost(b, eval(b, time));
+		}
+		radSourceFilled_ = true;
+	}
+
+	void operatorSplitSourceTerms(double time, double dt, int stage)
+	{
+		fillRadEnergySource(time + dt);
+		RadSystem<problem_t>::AddSourceTermsSingleGroup(state_new_cc_[0], radEnergySource_, dt, stage, d_radCounter_, d_radFailure_);
+	}
+
+	void advanceRadiationForwardEuler(double dt_radiation) // :1790-1821
+	{
+		this->fillBoundaryConditions(state_old_cc_[0]);
+		RadSystem<problem_t>::computeRadiationFluxes(state_old_cc_[0], radFluxOld_, radiationReconstructionOrder_);
+		RadSystem<problem_t>::PredictStep(state_old_cc_[0], state_new_cc_[0], radFluxOld_, dt_radiation, geom[0].CellSizeArray());
+	}
+
+	void advanceRadiationMidpointRK2(double dt_radiation) // :1823-1857 (the fluxes of the old state are reused, not recomputed)
+	{
+		this->fillBoundaryConditions(state_new_cc_[0]);
+		RadSystem<problem_t>::computeRadiationFluxes(state_new_cc_[0], radFlux_, radiationReconstructionOrder_);
+		RadSystem<problem_t>::AddFluxesRK2(state_new_cc_[0], state_old_cc_[0], state_new_cc_[0], radFluxOld_, radFlux_, dt_radiation, geom[0].CellSizeArray());
+	}
+
+	void subcycleRadiationAtLevel(double time, double dt_lev_hydro)
+	{
+		int nsubSteps = 1;
+		double dt_radiation = dt_lev_hydro;
+		if (!(this->constantDt_ > 0.0)) {
+			nsubSteps = computeNumberOfRadiationSubsteps(dt_lev_hydro);
+			dt_radiation = dt_lev_hydro / static_cast<double>(nsubSteps);
+		}
+		if (!(nsubSteps >= 1 && nsubSteps <= maxSubsteps_ + 1 && dt_radiation > 0.0)) {
+			amrex::Abort("radiation substep assertion failed (reference src/QuokkaSimulation.hpp:1596-1598)");
+		}
+		haveSignal_ = false; // the source terms change the gas state
+		double time_subcycle = time;
+		int const r0 = RadSystem<problem_t>::nstartHyperbolic_;
+		for (int i = 0; i < nsubSteps; ++i) {
+			if (i > 0) { // swapRadiationState (:1783-1788)
+				amrex::MultiFab::Copy(state_old_cc_[0], state_new_cc_[0], r0, r0, RadSystem<problem_t>::nvarHyperbolic_, 0);
+			}
+			QK_HOST_HIP(hipMemset(d_radCounter_, 0, 4 * sizeof(int)));
+			QK_HOST_HIP(hipMemset(d_radFailure_, 0, 3 * sizeof(int)));
+			advanceRadiationForwardEuler(dt_radiation);
+			operatorSplitSourceTerms(time_subcycle, dt_radiation, 1); // IMEX_a22 > 0
+			advanceRadiationMidpointRK2(dt_radiation);
+			operatorSplitSourceTerms(time_subcycle, dt_radiation, 2);
+			int cnt[4], fail[3];
+			QK_HOST_HIP(hipMemcpy(cnt, d_radCounter_, sizeof(cnt), hipMemcpyDeviceToHost));
+			QK_HOST_HIP(hipMemcpy(fail, d_radFailure_, sizeof(fail), hipMemcpyDeviceToHost));
+			radSolves_ += cnt[0];
+			radNewtonIterations_ += cnt[1];
+			radMaxNewtonIterations_ = std::max(radMaxNewtonIterations_, cnt[2]);
+			if (fail[1] > 0) {
+				amrex::Abort("Newton-Raphson iteration for dust temperature failed to converge or dust temperature is negative!");
+			}
+			if (fail[0] > 0) {
+				amrex::Abort("Newton-Raphson iteration for matter-radiation coupling failed to converge!");
+			}
+			if (fail[2] > 0) {
+				amrex::Abort("Outer iteration for matter-radiation coupling failed to converge!");
+			}
+			time_subcycle += dt_radiation;
+			radiationCellUpdates_ += this->CountCells(0);
+		}
+	}
+
       private:
 	amrex::MultiFab state_old_tmp_, state_inter_cc_, primVar_, rhs_;
 	std::array<amrex::MultiFab, 3> flatCoefs_;
@@ -658,6 +901,11 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	int64_t scratchBytes_ = 0;
 	double signal_[2] = {0, 0};
 	bool haveSignal_ = false;
+	std::array<amrex::MultiFab, AMREX_SPACEDIM> radFluxOld_, radFlux_;
+	amrex::MultiFab radEnergySource_;
+	int *d_radCounter_ = nullptr, *d_radFailure_ = nullptr;
+	int radSourceState_ = 0; // 0: unknown, 1: time independent, 2: evaluated every call
+	bool radSourceFilled_ = false;
 
 	[[nodiscard]] auto minDx() const -> double
 	{
@@ -691,6 +939,16 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 			}
 			leftState_[d].define(grids_, ncompHydro_, 1, d);
 			rightState_[d].define(grids_, ncompHydro_, 1, d);
+		}
+		if constexpr (is_radiation_enabled_) {
+			for (int d = 0; d < AMREX_SPACEDIM; ++d) {
+				radFluxOld_[d].define(grids_, RadSystem<problem_t>::nvarHyperbolic_, 0, d);
+				radFlux_[d].define(grids_, RadSystem<problem_t>::nvarHyperbolic_, 0, d);
+			}
+			radEnergySource_.define(grids_, 1, 0);
+			radEnergySource_.setVal(0);
+			QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_radCounter_), 4 * sizeof(int)));
+			QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_radFailure_), 3 * sizeof(int)));
 		}
 		QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_count_), sizeof(int64_t)));
 		QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_error_), sizeof(int)));
