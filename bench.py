@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--pow-mode", type=int, default=1, help="shell workload: 0 = libm pow(T,4) as the reference's std::pow, 1 = repeated multiplication")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-ncell", type=int, default=128)
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=8)
     return ap.parse_args()
 
 
@@ -63,21 +63,38 @@ def weak_scaled_cells(n: int, ngpus: int):
     return cells
 
 
+def usable_cores():
+    """(threads to use, description): the affinity mask, capped by the cgroup CPU quota (the GPU boxes show 256 CPUs but
+    grant 16 CPUs' worth of time; running more threads than ~2x the quota gets throttled and is slower)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    note = f"{n} schedulable CPUs"
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            q = float(quota) / float(period)
+            note += f", cgroup quota {q:g} CPUs"
+            n = max(1, min(n, int(round(2 * q))))
+    except (OSError, ValueError):
+        pass
+    return n, note
+
+
 def cpu_baseline(ncell: int, steps: int):
     """Oracle (port of the reference algorithm, built with g++ -O3 -ffp-contract=off -fopenmp) on the host cores."""
     from oracle.pyoracle import SEDOV, Oracle
-    cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    threads, note = usable_cores()
+    if "OMP_NUM_THREADS" in os.environ:
+        threads = int(os.environ["OMP_NUM_THREADS"])
+    os.environ["OMP_NUM_THREADS"] = str(threads)
     o = Oracle("direct")
     s = o.sim(SEDOV, 3, [ncell] * 3, [0, 0, 0], [1.2] * 3, [0, 0, 0], max_grid_size=[32] * 3)
-    threads = min(cores, s.nboxes)
     assert s.step()  # warm-up (page-in)
     t0 = time.perf_counter()
     for _ in range(steps):
         assert s.step()
     el = time.perf_counter() - t0
     return {"value": ncell ** 3 * steps / el / 1e6, "unit": "Mcell-updates/s", "cores": threads, "kind": "port",
-            "sample": f"Sedov {ncell}^3 in 32^3 boxes, {steps} RK2 steps, OpenMP over boxes ({threads} threads of {cores} cores); "
+            "sample": f"Sedov {ncell}^3 in 32^3 boxes, {steps} RK2 steps in {el:.1f} s, OpenMP over (box, 4-plane slab) tasks, {threads} threads ({note}); "
                       "CPU restatement of the reference algorithm, not the reference binary"}
 
 

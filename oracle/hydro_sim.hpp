@@ -15,6 +15,7 @@
 #ifndef ORACLE_HYDRO_SIM_HPP_
 #define ORACLE_HYDRO_SIM_HPP_
 
+#include <functional>
 #include <array>
 #include <cmath>
 #include <cstdio>
@@ -31,6 +32,25 @@ namespace oracle
 {
 
 using FluxArrays = std::array<MultiFab, 3>;
+
+// (box, sub-range) tasks for OpenMP: the range of every box cut into slabs along its slowest active dimension.  Every
+// operator below writes each output cell / face from exactly one loop index, so disjoint sub-ranges never race, and the
+// arithmetic per cell is unchanged.  (cpu_baseline leg of bench.py: 64 boxes alone cannot occupy a 256-core host.)
+inline auto slabTasks(int nboxes, std::function<Box(int)> const &rangeOf, int ndim, int slab = 4) -> std::vector<std::pair<int, Box>>
+{
+	std::vector<std::pair<int, Box>> tasks;
+	const int d = ndim - 1;
+	for (int b = 0; b < nboxes; ++b) {
+		Box const r = rangeOf(b);
+		for (int lo = r.lo[d]; lo <= r.hi[d]; lo += slab) {
+			Box piece = r;
+			piece.lo[d] = lo;
+			piece.hi[d] = std::min(lo + slab - 1, r.hi[d]);
+			tasks.emplace_back(b, piece);
+		}
+	}
+	return tasks;
+}
 
 struct HydroSim {
 	// --- configuration (public data members of AMRSimulation / QuokkaSimulation) ---
@@ -110,9 +130,11 @@ struct HydroSim {
 	void hydroFluxFunction(int dir, MultiFab const &primVar, MultiFab &leftState, MultiFab &rightState, MultiFab &flux, MultiFab &faceVel,
 			       MultiFab const &x1Flat, MultiFab const &x2Flat, MultiFab const &x3Flat, int ng_reconstruct, int nvars) const
 	{
+		auto const cells = slabTasks(primVar.size(), [&](int b) { return grow(primVar.valid[b], ng_reconstruct, ndim()); }, ndim());
 		_Pragma("omp parallel for schedule(dynamic)")
-		for (int b = 0; b < primVar.size(); ++b) {
-			Box const cellRange = grow(primVar.valid[b], ng_reconstruct, ndim());
+		for (size_t t = 0; t < cells.size(); ++t) {
+			int const b = cells[t].first;
+			Box const &cellRange = cells[t].second;
 			if (reconstructionOrder_ == 3) {
 				ReconstructStatesPPM(dir, primVar.const_array(b), leftState.array(b), rightState.array(b), cellRange, nvars);
 			} else if (reconstructionOrder_ == 2) {
@@ -120,10 +142,19 @@ struct HydroSim {
 			} else {
 				ReconstructStatesConstant(dir, primVar.const_array(b), leftState.array(b), rightState.array(b), cellRange, nvars);
 			}
+		}
+		_Pragma("omp parallel for schedule(dynamic)")
+		for (size_t t = 0; t < cells.size(); ++t) {
+			int const b = cells[t].first;
 			hydro.FlattenShocks(dir, primVar.const_array(b), x1Flat.const_array(b), x2Flat.const_array(b), x3Flat.const_array(b),
-					    leftState.array(b), rightState.array(b), cellRange, nvars);
+					    leftState.array(b), rightState.array(b), cells[t].second, nvars);
+		}
+		auto const faces = slabTasks(primVar.size(), [&](int b) { return flux.validbox(b); }, ndim());
+		_Pragma("omp parallel for schedule(dynamic)")
+		for (size_t t = 0; t < faces.size(); ++t) {
+			int const b = faces[t].first;
 			hydro.ComputeFluxes(riemann_HLLC, dir, flux.array(b), faceVel.array(b), leftState.const_array(b), rightState.const_array(b),
-					    primVar.const_array(b), artificialViscosityK_, flux.validbox(b));
+					    primVar.const_array(b), artificialViscosityK_, faces[t].second);
 		}
 	}
 
@@ -144,14 +175,16 @@ struct HydroSim {
 			flux[idim] = MultiFab(grids, nvars, 0, ndim(), idim);
 			facevel[idim] = MultiFab(grids, 1, 0, ndim(), idim);
 		}
+		auto const all = slabTasks(consVar.size(), [&](int b) { return grow(grids[b], nghost_cc, ndim()); }, ndim());
 		_Pragma("omp parallel for schedule(dynamic)")
-		for (int b = 0; b < consVar.size(); ++b) {
-			hydro.ConservedToPrimitive(consVar.const_array(b), primVar.array(b), grow(grids[b], nghost_cc, ndim()));
+		for (size_t t = 0; t < all.size(); ++t) {
+			hydro.ConservedToPrimitive(consVar.const_array(all[t].first), primVar.array(all[t].first), all[t].second);
 		}
+		auto const flat = slabTasks(consVar.size(), [&](int b) { return grow(grids[b], flatteningGhost, ndim()); }, ndim());
 		for (int idim = 0; idim < ndim(); ++idim) {
 			_Pragma("omp parallel for schedule(dynamic)")
-			for (int b = 0; b < consVar.size(); ++b) {
-				hydro.ComputeFlatteningCoefficients(idim, primVar.const_array(b), flatCoefs[idim].array(b), grow(grids[b], flatteningGhost, ndim()));
+			for (size_t t = 0; t < flat.size(); ++t) {
+				hydro.ComputeFlatteningCoefficients(idim, primVar.const_array(flat[t].first), flatCoefs[idim].array(flat[t].first), flat[t].second);
 			}
 		}
 		for (int idim = 0; idim < ndim(); ++idim) {
@@ -173,17 +206,24 @@ struct HydroSim {
 			flux[idim] = MultiFab(grids, nvars, 0, ndim(), idim);
 			facevel[idim] = MultiFab(grids, 1, 0, ndim(), idim);
 		}
+		auto const all = slabTasks(consVar.size(), [&](int b) { return grow(grids[b], nghost_cc, ndim()); }, ndim());
 		_Pragma("omp parallel for schedule(dynamic)")
-		for (int b = 0; b < consVar.size(); ++b) {
-			hydro.ConservedToPrimitive(consVar.const_array(b), primVar.array(b), grow(grids[b], nghost_cc, ndim()));
+		for (size_t t = 0; t < all.size(); ++t) {
+			hydro.ConservedToPrimitive(consVar.const_array(all[t].first), primVar.array(all[t].first), all[t].second);
 		}
+		auto const cells = slabTasks(consVar.size(), [&](int b) { return grow(grids[b], reconstructRange, ndim()); }, ndim());
 		for (int idim = 0; idim < ndim(); ++idim) {
 			_Pragma("omp parallel for schedule(dynamic)")
-			for (int b = 0; b < consVar.size(); ++b) {
-				Box const cellRange = grow(grids[b], reconstructRange, ndim());
-				ReconstructStatesConstant(idim, primVar.const_array(b), leftState[idim].array(b), rightState[idim].array(b), cellRange, nvars);
+			for (size_t t = 0; t < cells.size(); ++t) {
+				int const b = cells[t].first;
+				ReconstructStatesConstant(idim, primVar.const_array(b), leftState[idim].array(b), rightState[idim].array(b), cells[t].second, nvars);
+			}
+			auto const faces = slabTasks(consVar.size(), [&](int b) { return flux[idim].validbox(b); }, ndim());
+			_Pragma("omp parallel for schedule(dynamic)")
+			for (size_t t = 0; t < faces.size(); ++t) {
+				int const b = faces[t].first;
 				hydro.ComputeFluxes(riemann_LLF, idim, flux[idim].array(b), facevel[idim].array(b), leftState[idim].const_array(b),
-						    rightState[idim].const_array(b), primVar.const_array(b), artificialViscosityK_, flux[idim].validbox(b));
+						    rightState[idim].const_array(b), primVar.const_array(b), artificialViscosityK_, faces[t].second);
 			}
 		}
 		return std::make_pair(std::move(flux), std::move(facevel));
@@ -262,14 +302,16 @@ struct HydroSim {
 	void rhsPdvPredict(MultiFab &rhs, FluxArrays const &fluxes, FluxArrays const &faceVel, MultiFab const &stateOld, MultiFab &stateNew, double dt_lev,
 			   iMultiFab &redoFlag) const
 	{
+		auto const tasks = slabTasks(rhs.size(), [&](int b) { return grids[b]; }, ndim());
 		_Pragma("omp parallel for schedule(dynamic)")
-		for (int b = 0; b < rhs.size(); ++b) {
+		for (size_t t = 0; t < tasks.size(); ++t) {
+			int const b = tasks[t].first;
 			std::array<Array4<const double>, 3> f{}, v{};
 			for (int d = 0; d < ndim(); ++d) {
 				f[d] = fluxes[d].const_array(b);
 				v[d] = faceVel[d].const_array(b);
 			}
-			Box const &r = grids[b];
+			Box const &r = tasks[t].second;
 			hydro.ComputeRhsFromFluxes(rhs.array(b), f, geom.dx, ncompHydro(), r);
 			hydro.AddInternalEnergyPdV(rhs.array(b), stateOld.const_array(b), geom.dx, v, redoFlag.const_array(b), r);
 			hydro.PredictStep(stateOld.const_array(b), stateNew.array(b), rhs.const_array(b), dt_lev, ncompHydro(), redoFlag.array(b), r);
@@ -278,14 +320,15 @@ struct HydroSim {
 
 	void limitsAndSync(MultiFab &state) const
 	{
+		auto const tasks = slabTasks(state.size(), [&](int b) { return grids[b]; }, ndim());
 		_Pragma("omp parallel for schedule(dynamic)")
-		for (int b = 0; b < state.size(); ++b) {
-			hydro.EnforceLimits(densityFloor_, tempFloor_, state.array(b), grids[b]);
+		for (size_t t = 0; t < tasks.size(); ++t) {
+			hydro.EnforceLimits(densityFloor_, tempFloor_, state.array(tasks[t].first), tasks[t].second);
 		}
 		if (useDualEnergy_ == 1) {
 			_Pragma("omp parallel for schedule(dynamic)")
-			for (int b = 0; b < state.size(); ++b) {
-				hydro.SyncDualEnergy(state.array(b), grids[b]);
+			for (size_t t = 0; t < tasks.size(); ++t) {
+				hydro.SyncDualEnergy(state.array(tasks[t].first), tasks[t].second);
 			}
 		}
 	}
