@@ -142,6 +142,10 @@ class Oracle:
     # ---------------------------------------------------------------- whole simulation
     def sim(self, problem, ndim, n_cell, prob_lo, prob_hi, periodic, max_grid_size=None, cfl=-1.0, stop_time=-1.0,
             max_timesteps=-1, reconstruction_order=-1, nscalars=0, table=None, rad_pow_mode=0) -> "OracleSim":
+        if ndim == 2:
+            # AMREX_SPACEDIM == 2 builds of the reference use util/ArrayView_2d.hpp (X2 view = index SWAP, velV = vx, velW = vz),
+            # not the cyclic permutation of ArrayView_3d.hpp restated here: a 2-D oracle would not be the reference's algorithm
+            raise NotImplementedError("the oracle restates the 1-D / 3-D builds of the reference only")
         n_cell = list(n_cell) + [1] * (3 - len(n_cell))
         mgs = list(max_grid_size) if max_grid_size is not None else list(n_cell)
         mgs = mgs + [1] * (3 - len(mgs))
