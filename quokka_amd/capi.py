@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libquokka_amd.so")
+LIB_PATH = os.environ.get("QK_LIB_PATH", os.path.join(_HERE, "lib", "libquokka_amd.so"))  # (override: A/B runs of two builds on one box)
 
 QK_OK, QK_ERR_INVALID, QK_ERR_HIP, QK_ERR_UNSUPPORTED, QK_ERR_STATE = 0, -1, -2, -3, -4
 DIR_X1, DIR_X2, DIR_X3 = 0, 1, 2

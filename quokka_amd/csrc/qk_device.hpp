@@ -110,6 +110,38 @@ QK_DEV auto clampd(double v, double lo, double hi) -> double { return (v < lo) ?
 QK_DEV auto smin(double a, double b) -> double { return (b < a) ? b : a; }
 QK_DEV auto smax(double a, double b) -> double { return (a < b) ? b : a; }
 
+// Correctly rounded FP64 division with the refined reciprocal of the denominator SHARED between numerators.
+// hipcc expands `n / d` to  div_scale x2, rcp, two Newton steps (4 fma), q = n * r, e = fma(-d, q, n), div_fmas(e, r, q),
+// div_fixup  — 11 instructions, one of them quarter rate, in one dependency chain.  The Riemann solver divides 4 numerators
+// by rho_L, 4 by rho_R, 2 + 2 by (gamma-1) rho and 6 by S_K - S*: with the reciprocal refined once per denominator every
+// further quotient is mul + 2 fma, the SAME three operations on the SAME operands as the tail of the expansion, hence the
+// same bits whenever div_scale does not rescale and div_fixup does not intervene: denominator and quotient in the normal
+// range (roughly |d|, |n / d| in [2^-1020, 2^1020] with exponents of n and d less than 768 apart).  Outside it: a zero
+// quotient may come out as +0 where IEEE gives -0; a zero, infinite or subnormal DENOMINATOR (rho, (gamma-1) rho, S_K - S*)
+// yields NaN where IEEE gives +-inf or a rounded subnormal quotient — such a state is invalid in the reference as well (the
+// cell is flagged and the step retried), it just fails with a different non-number.  A per-face range guard with a plain-
+// division fallback was measured: the second code path costs more than the shared reciprocals save.
+struct Recip {
+	double d, r;
+};
+QK_DEV auto recipOf(double d) -> Recip
+{
+	Recip R;
+	R.d = d;
+	const double r0 = __builtin_amdgcn_rcp(d);
+	double e = __builtin_fma(-d, r0, 1.0);
+	const double r1 = __builtin_fma(r0, e, r0);
+	e = __builtin_fma(-d, r1, 1.0);
+	R.r = __builtin_fma(r1, e, r1);
+	return R;
+}
+QK_DEV auto divBy(double n, Recip const &R) -> double
+{
+	const double q = n * R.r;
+	const double e = __builtin_fma(-R.d, q, n);
+	return __builtin_fma(e, R.r, q);
+}
+
 // hyperbolic_system.hpp:58-66
 QK_DEV auto MC(double a, double b) -> double { return 0.5 * (sgn(a) + sgn(b)) * smin(0.5 * fabs(a + b), smin(2.0 * fabs(a), 2.0 * fabs(b))); }
 QK_DEV auto minmod(double a, double b) -> double { return 0.5 * (sgn(a) + sgn(b)) * smin(fabs(a), fabs(b)); }
@@ -201,7 +233,8 @@ struct HState {
 // hydro_system.hpp:881-1003 : build the canonical (normal-first) Riemann state from one reconstructed
 // primitive state q[6] = (rho, vx, vy, vz, P|e, Eint|e_aux).  DIR fixes (u,v,w) <- (vN, vV, vW) with the
 // 3-D mapping X1:(x,y,z) X2:(y,z,x) X3:(z,x,y)  (:954-976).
-template <int DIR> QK_DEV auto makeState(Eos const &eos, bool reconstruct_eint, const double q[NVAR]) -> HState
+// Rrho = recipOf(rho), Rg = recipOf((gamma-1) rho): shared with the divisions of hllc()
+template <int DIR> QK_DEV auto makeState(Eos const &eos, bool reconstruct_eint, const double q[NVAR], Recip const &Rrho, Recip const &Rg) -> HState
 {
 	HState s;
 	const double rho = q[PRHO];
@@ -216,14 +249,16 @@ template <int DIR> QK_DEV auto makeState(Eos const &eos, bool reconstruct_eint, 
 		Eint = __builtin_nan("");
 	} else {
 		if (reconstruct_eint) {
-			P = eos.pressure(rho, q[PPRES] * rho);
+			// eos.pressure(rho, Eint): e = Eint / rho (0 if rho == 0), p = (gamma-1) rho e
+			const double e = (rho == 0.0) ? 0.0 : divBy(q[PPRES] * rho, Rrho);
+			P = eos.gm1 * rho * e;
 			Eint = rho * q[PEINT];
 		} else {
 			P = q[PPRES];
 			Eint = q[PEINT];
 		}
-		cs = eos.soundSpeed(rho, P);
-		E = eos.eintFromPres(rho, P) + ke;
+		cs = sqrt(divBy(eos.gamma * P, Rrho)); // eos.soundSpeed
+		E = divBy(P, Rg) * rho + ke;	     // eos.eintFromPres
 	}
 	s.rho = rho;
 	s.u = q[PVX + Axes<DIR>::n];
@@ -237,7 +272,8 @@ template <int DIR> QK_DEV auto makeState(Eos const &eos, bool reconstruct_eint, 
 }
 
 // HLLC.hpp:22-153. F[6] in canonical order (rho, mom_n, mom_v, mom_w, E, Eint).
-QK_DEV void hllc(Eos const &eos, HState const &sL, HState const &sR, double du, double dw, double F[NVAR])
+QK_DEV void hllc(Eos const &eos, HState const &sL, HState const &sR, double du, double dw, double F[NVAR], Recip const &RL, Recip const &RR,
+		 Recip const &GL, Recip const &GR)
 {
 	const double wl = sqrt(sL.rho);
 	const double wr = sqrt(sR.rho);
@@ -249,18 +285,18 @@ QK_DEV void hllc(Eos const &eos, HState const &sL, HState const &sR, double du, 
 		const double v_tilde = (wl * sL.v + wr * sR.v) * norm;
 		const double w_tilde = (wl * sL.w + wr * sR.w) * norm;
 		const double vsq_tilde = u_tilde * u_tilde + v_tilde * v_tilde + w_tilde * w_tilde;
-		const double H_L = (sL.E + sL.P) / sL.rho;
-		const double H_R = (sR.E + sR.P) / sR.rho;
+		const double H_L = divBy(sL.E + sL.P, RL);
+		const double H_R = divBy(sR.E + sR.P, RR);
 		const double H_tilde = (wl * H_L + wr * H_R) * norm;
 		// ComputeOtherDerivatives (EOS.hpp:246-302) with the direct gamma-law forms:
 		//   dedr = 0, dedp = 1/dpde = 1/((gamma-1) rho), drdp = 1/((p/rho) * k_B / k_B_user), G = (gamma+1)/2
-		const double dedp_L = 1.0 / (eos.gm1 * sL.rho);
-		const double dedp_R = 1.0 / (eos.gm1 * sR.rho);
-		const double drdp_L = 1.0 / ((sL.P / sL.rho) * Eos::k_B / eos.kB_user);
-		const double drdp_R = 1.0 / ((sR.P / sR.rho) * Eos::k_B / eos.kB_user);
+		const double dedp_L = divBy(1.0, GL);
+		const double dedp_R = divBy(1.0, GR);
+		const double drdp_L = 1.0 / (divBy(sL.P, RL) * Eos::k_B / eos.kB_user);
+		const double drdp_R = 1.0 / (divBy(sR.P, RR) * Eos::k_B / eos.kB_user);
 		const double G = 0.5 * (1.0 + eos.gamma);
-		const double eL = sL.Eint / sL.rho;
-		const double eR = sR.Eint / sR.rho;
+		const double eL = divBy(sL.Eint, RL);
+		const double eR = divBy(sR.Eint, RR);
 		const double C_tilde_rho = 0.5 * (eL + eR); // + rho*dedr with dedr = 0
 		const double C_tilde_P = 0.5 * (eL * drdp_L + eR * drdp_R + sL.rho * dedp_L + sR.rho * dedp_R);
 		const double cs_exp = H_tilde - 0.5 * vsq_tilde - C_tilde_rho;
@@ -327,12 +363,19 @@ QK_DEV void hllc(Eos const &eos, HState const &sL, HState const &sR, double du, 
 	// F*_K = (S* (S_K U_K - F_K) + (S_K P_LR) D*) / (S_K - S*)   (:135-136)
 	const double SKP = S_K * P_LR;
 	const double den = S_K - S_star;
-	const double G0 = (S_star * (S_K * U0 - F0)) / den;
-	const double G1 = (S_star * (S_K * U1 - F1) + SKP) / den;
-	const double G2 = (S_star * (S_K * U2 - F2)) / den;
-	const double G3 = (S_star * (S_K * U3 - F3)) / den;
-	const double G4 = (S_star * (S_K * U4 - F4) + SKP * S_star) / den;
-	const double G5 = (S_star * (S_K * U5 - F5)) / den;
+	const double N0 = S_star * (S_K * U0 - F0);
+	const double N1 = S_star * (S_K * U1 - F1) + SKP;
+	const double N2 = S_star * (S_K * U2 - F2);
+	const double N3 = S_star * (S_K * U3 - F3);
+	const double N4 = S_star * (S_K * U4 - F4) + SKP * S_star;
+	const double N5 = S_star * (S_K * U5 - F5);
+	const Recip RD = recipOf(den);
+	const double G0 = divBy(N0, RD);
+	const double G1 = divBy(N1, RD);
+	const double G2 = divBy(N2, RD);
+	const double G3 = divBy(N3, RD);
+	const double G4 = divBy(N4, RD);
+	const double G5 = divBy(N5, RD);
 
 	F[0] = star ? G0 : F0;
 	F[1] = star ? G1 : F1;
@@ -375,8 +418,10 @@ template <int DIR, int RIEMANN>
 QK_DEV void faceFlux(Eos const &eos, bool reconstruct_eint, int ndim, const double qL[NVAR], const double qR[NVAR], double du, double dvl, double dvr,
 		     double dwl, double dwr, double K_visc, double Fout[NVAR], double &v_norm)
 {
-	const HState sL = makeState<DIR>(eos, reconstruct_eint, qL);
-	const HState sR = makeState<DIR>(eos, reconstruct_eint, qR);
+	const Recip RL = recipOf(qL[PRHO]), RR = recipOf(qR[PRHO]);
+	const Recip GL = recipOf(eos.gm1 * qL[PRHO]), GR = recipOf(eos.gm1 * qR[PRHO]);
+	const HState sL = makeState<DIR>(eos, reconstruct_eint, qL, RL, GL);
+	const HState sR = makeState<DIR>(eos, reconstruct_eint, qR, RR, GR);
 	double dw = 0.;
 	if (ndim >= 2) {
 		dw = smin(dvl, dvr);
@@ -386,7 +431,7 @@ QK_DEV void faceFlux(Eos const &eos, bool reconstruct_eint, int ndim, const doub
 	}
 	double Fc[NVAR];
 	if (RIEMANN == QK_RIEMANN_HLLC) {
-		hllc(eos, sL, sR, du, dw, Fc);
+		hllc(eos, sL, sR, du, dw, Fc, RL, RR, GL, GR);
 	} else {
 		llf(sL, sR, Fc);
 	}
@@ -411,7 +456,7 @@ QK_DEV void faceFlux(Eos const &eos, bool reconstruct_eint, int ndim, const doub
 		F[EINT] = 0;
 	}
 	// :1090
-	v_norm = (F[RHO] >= 0.) ? (F[RHO] / sR.rho) : (F[RHO] / sL.rho);
+	v_norm = (F[RHO] >= 0.) ? divBy(F[RHO], RR) : divBy(F[RHO], RL);
 #pragma unroll
 	for (int n = 0; n < NVAR; ++n) {
 		Fout[n] = F[n];
