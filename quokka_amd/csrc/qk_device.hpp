@@ -8,7 +8,10 @@
 //     (x + 0.0 == x up to the sign of a zero);
 //   * HLLC selects the Riemann-fan side FIRST and evaluates only that side's F / F* (the reference
 //     evaluates all four and selects, HLLC.hpp:132-150) — same values, about half the divisions;
-//   * std::pow(cs, 2) (hydro_system.hpp:602) is cs*cs.
+//   * std::pow(cs, 2) (hydro_system.hpp:602) is cs*cs;
+//   * the divisions of the Riemann path that share a denominator share its refined reciprocal (recipOf / divBy below):
+//     the same operations on the same operands as the compiler's expansion of `/`, i.e. the same bits for normal-range
+//     operands; a zero quotient may differ in sign, a zero / subnormal / infinite denominator gives NaN instead of +-inf.
 #ifndef QK_DEVICE_HPP_
 #define QK_DEVICE_HPP_
 
