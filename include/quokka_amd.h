@@ -296,6 +296,33 @@ int qk_ghost_plan_set_box_remote(qk_ghost_plan *plan, int local_box, int flag);
 int qk_FillPhysicalBoundary_subset(qk_ghost_plan *plan, qk_stream s, qk_array4 *state, const qk_bcrec *bcs, const qk_dirichlet_face *dirichlet,
 				   int which);
 
+/* ------------------------------------------------------------------ AMR level machinery: data-parallel pieces */
+/* == amrex::Array4<char> (TagBox) */
+typedef struct qk_carray4 {
+	char *p;
+	int64_t jstride, kstride, nstride;
+	int begin[3];
+	int end[3];
+	int ncomp;
+} qk_carray4;
+enum { QK_TAG_CLEAR = 0, QK_TAG_BUF = 1, QK_TAG_SET = 2 }; /* amrex::TagBox::TagVal */
+#define QK_TAGFIELD_PRESSURE (-1)			    /* HydroSystem<problem_t>::ComputePressure(state, i, j, k) */
+/* QuokkaSimulation<problem_t>::ErrorEst of the gradient-threshold family
+ *   reference src/problems/HydroBlast3D/test_hydro3d_blast.cpp:118-151 (field = pressure, P > P_min)
+ *             src/problems/RadhydroShell/test_radhydro_shell.cpp:337-371 (field = density component, rho >= rho_min)
+ * tags(i,j,k) = SET where  max_d max(|q(+e_d) - q|, |q - q(-e_d)|) / q > eta_threshold  and  q > q_min (>= if min_inclusive);
+ * other cells are left untouched.  `state` needs one ghost cell.  field: QK_TAGFIELD_PRESSURE or a component index. */
+int qk_tag_relative_gradient(qk_level *lev, qk_stream s, const qk_hydro_traits *t, const qk_array4 *state, qk_carray4 *tags, int field,
+			     double eta_threshold, double q_min, int min_inclusive);
+/* AMRSimulation::AverageDownTo -> amrex::average_down(fine, crse, ...)     reference src/simulation.hpp:1949-1964
+ * crse = (1 / (rx ry rz)) * sum of the fine cells under it, summed with the x index fastest (amrex_avgdown); only coarse cells
+ * covered by a fine box are written.  The plan pairs every fine box with the coarse boxes it overlaps (same rank). */
+typedef struct qk_avgdown_plan qk_avgdown_plan;
+int qk_avgdown_plan_create(qk_level *crse, qk_level *fine, const int ratio[3], qk_avgdown_plan **plan);
+int qk_avgdown_plan_destroy(qk_avgdown_plan *plan);
+int qk_avgdown_plan_num_items(qk_avgdown_plan *plan);
+int qk_average_down(qk_avgdown_plan *plan, qk_stream s, const qk_array4 *fine, qk_array4 *crse, int scomp, int ncomp);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,6 +5,7 @@
 #include <cstring>
 #include <memory>
 
+#include "amr.hpp"
 #include "hydro_sim.hpp"
 #include "problems.hpp"
 
@@ -238,5 +239,31 @@ void orc_sim_rad_source(void *p, int b, double time, double *out)
 	}
 }
 int orc_sim_evolve(void *p) { return static_cast<HydroSim *>(p)->evolve() ? 1 : 0; }
+
+// ErrorEst of the gradient-threshold family on the (ghost-filled) new state of box b; `tags` covers the valid box, 1 char per cell
+void orc_sim_tag_relative_gradient(void *p, int b, int field, double eta_threshold, double q_min, int min_inclusive, char *tags)
+{
+	auto *s = static_cast<HydroSim *>(p);
+	Array4<char> t(tags, s->grids[b], 1);
+	tagRelativeGradient(s->hydro, s->state_new_cc_.const_array(b), t, s->grids[b], s->ndim(), field, eta_threshold, q_min, min_inclusive != 0);
+}
+
+// amrex::average_down of one fine array onto one coarse array; boxes as lo[3], hi[3] (with ghosts = the arrays' extents); region in coarse indices
+void orc_average_down(const double *fine, const int *flo, const int *fhi, double *crse, const int *clo, const int *chi, int ncomp_total, const int *rlo,
+		      const int *rhi, int scomp, int ncomp, const int *ratio)
+{
+	Box fb, cb, region;
+	for (int d = 0; d < 3; ++d) {
+		fb.lo[d] = flo[d];
+		fb.hi[d] = fhi[d];
+		cb.lo[d] = clo[d];
+		cb.hi[d] = chi[d];
+		region.lo[d] = rlo[d];
+		region.hi[d] = rhi[d];
+	}
+	Array4<const double> f(fine, fb, ncomp_total);
+	Array4<double> c(crse, cb, ncomp_total);
+	averageDown(f, c, region, scomp, ncomp, ratio);
+}
 
 } // extern "C"

@@ -108,6 +108,7 @@ class Oracle:
         L.orc_sim_advance_fixed_dt.restype = C.c_int
         L.orc_eos_variant.restype = C.c_int
         L.orc_sim_rad_counters.argtypes = [C.c_void_p, C.c_long * 8]
+        L.orc_sim_tag_relative_gradient.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p]
         L.orc_sim_rad_source.argtypes = [C.c_void_p, C.c_int, C.c_double, C.POINTER(C.c_double)]
 
     # ---------------------------------------------------------------- per-operator
@@ -140,6 +141,17 @@ class Oracle:
         return fl[: t.ndim], fv[: t.ndim]
 
     # ---------------------------------------------------------------- whole simulation
+    def average_down(self, fine: np.ndarray, flo, crse: np.ndarray, clo, region, scomp: int, ncomp: int, ratio=(2, 2, 2)):
+        """amrex::average_down restated: fine / crse are (ncomp_total, nz, ny, nx) float64 arrays whose lower corners are flo / clo;
+        region = (lo, hi) in coarse indices; crse is modified in place"""
+        assert fine.dtype == np.float64 and crse.dtype == np.float64 and fine.flags["C_CONTIGUOUS"] and crse.flags["C_CONTIGUOUS"]
+        fhi = [flo[d] + fine.shape[3 - d] - 1 for d in range(3)]
+        chi = [clo[d] + crse.shape[3 - d] - 1 for d in range(3)]
+        L = self.lib
+        L.orc_average_down.argtypes = [C.c_void_p, _I3, _I3, C.c_void_p, _I3, _I3, C.c_int, _I3, _I3, C.c_int, C.c_int, _I3]
+        L.orc_average_down(fine.ctypes.data_as(C.c_void_p), _i3(flo), _i3(fhi), crse.ctypes.data_as(C.c_void_p), _i3(clo), _i3(chi), fine.shape[0],
+                           _i3(region[0]), _i3(region[1]), scomp, ncomp, _i3(ratio))
+
     def sim(self, problem, ndim, n_cell, prob_lo, prob_hi, periodic, max_grid_size=None, cfl=-1.0, stop_time=-1.0,
             max_timesteps=-1, reconstruction_order=-1, nscalars=0, table=None, rad_pow_mode=0) -> "OracleSim":
         if ndim == 2:
@@ -245,6 +257,14 @@ class OracleSim:
         self.o.lib.orc_sim_rad_counters(self.h, out)
         keys = ["solves", "newton_iterations", "max_newton_iterations", "decoupled", "fail_coupling", "fail_dust", "fail_outer", "rad_cell_updates"]
         return dict(zip(keys, list(out)))
+
+    def tag_relative_gradient(self, b: int, field: int, eta_threshold: float, q_min: float, min_inclusive: bool) -> np.ndarray:
+        """ErrorEst (gradient-threshold family) on the ghost-filled new state of box b: int8 array over the valid box (2 = TagBox::SET)"""
+        lo, hi = self.box(b)
+        t = np.zeros((hi[2] - lo[2] + 1, hi[1] - lo[1] + 1, hi[0] - lo[0] + 1), dtype=np.int8)
+        self.o.lib.orc_sim_tag_relative_gradient(self.h, b, int(field), C.c_double(eta_threshold), C.c_double(q_min), int(bool(min_inclusive)),
+                                                 t.ctypes.data_as(C.c_void_p))
+        return t
 
     def rad_source(self, b=0, time=0.0) -> np.ndarray:
         lo, hi = self.box(b)

@@ -145,12 +145,20 @@ def lib() -> C.CDLL:
         L.qk_FillPhysicalBoundary_subset.argtypes = [vp, vp, vp, P(BCRec), P(DirichletFace), C.c_int]
         L.qk_ghost_plan_box_is_remote.argtypes = [vp, C.c_int]
         L.qk_ghost_plan_set_box_remote.argtypes = [vp, C.c_int, C.c_int]
+    if hasattr(L, "qk_tag_relative_gradient"):
+        L.qk_tag_relative_gradient.argtypes = [vp, vp, T, vp, vp, ci, C.c_double, C.c_double, ci]
+        L.qk_avgdown_plan_create.argtypes = [vp, vp, ci * 3, P(vp)]
+        L.qk_avgdown_plan_destroy.argtypes = [vp]
+        L.qk_avgdown_plan_num_items.argtypes = [vp]
+        L.qk_average_down.argtypes = [vp, vp, vp, vp, ci, ci]
     _lib = L
     return L
 
 
 # every symbol include/quokka_amd.h declares (checked by the CPU test-suite without a GPU)
 BOXES_ALL, BOXES_LOCAL_ONLY, BOXES_REMOTE_DEPENDENT = 0, 1, 2
+TAG_CLEAR, TAG_BUF, TAG_SET = 0, 1, 2
+TAGFIELD_PRESSURE = -1
 
 DECLARED_SYMBOLS = [
     "qk_ctx_create", "qk_ctx_destroy", "qk_last_error", "qk_version", "qk_level_create", "qk_level_destroy",
@@ -165,6 +173,7 @@ DECLARED_SYMBOLS = [
     "qk_ghost_plan_create", "qk_ghost_plan_destroy", "qk_ghost_plan_num_peers", "qk_ghost_plan_peer", "qk_ghost_plan_num_items", "qk_ghost_plan_item",
     "qk_FillBoundary_local", "qk_FillBoundary_local_int", "qk_FillBoundary_pack", "qk_FillBoundary_unpack", "qk_FillBoundary_pack_int", "qk_FillBoundary_unpack_int", "qk_FillPhysicalBoundary",
     "qk_FillPhysicalBoundary_subset", "qk_ghost_plan_box_is_remote", "qk_ghost_plan_set_box_remote",
+    "qk_tag_relative_gradient", "qk_avgdown_plan_create", "qk_avgdown_plan_destroy", "qk_avgdown_plan_num_items", "qk_average_down",
 ]
 
 

@@ -1,0 +1,213 @@
+// qk_amr_ops.hip — the data-parallel pieces of the AMR level machinery, one kernel each:
+//   qk_tag_relative_gradient   the gradient-threshold ErrorEst of the reference's problems
+//                              (src/problems/HydroBlast3D/test_hydro3d_blast.cpp:118-151, RadhydroShell/test_radhydro_shell.cpp:337-371)
+//   qk_average_down            AMRSimulation::AverageDownTo -> amrex::average_down (src/simulation.hpp:1949-1964), cell-centred,
+//                              conservative mean of the ratio^3 fine cells under a coarse cell
+// Grid generation, FillPatch interpolation, flux registers and the subcycling driver are not built yet.
+#include <algorithm>
+#include <vector>
+
+#include "qk_device.hpp"
+#include "qk_internal.hpp"
+
+using namespace qk;
+
+struct AvgItem {
+	int crse_box, fine_box;
+	int lo[3], hi[3]; // region in COARSE index space
+};
+
+struct qk_avgdown_plan {
+	qk_level *crse = nullptr;
+	qk_level *fine = nullptr;
+	int ratio[3] = {2, 2, 2};
+	std::vector<AvgItem> items;
+	AvgItem *d_items = nullptr;
+	int64_t max_cells = 0;
+};
+
+namespace
+{
+
+using CA4 = A4<char, qk_carray4>;
+
+template <class F> __global__ void __launch_bounds__(256) k_valid_cells(const qk_box *boxes, F f)
+{
+	const int b = blockIdx.y;
+	const qk_box bx = boxes[b];
+	const int l0 = bx.hi[0] - bx.lo[0] + 1, l1 = bx.hi[1] - bx.lo[1] + 1, l2 = bx.hi[2] - bx.lo[2] + 1;
+	const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+	if (t >= static_cast<int64_t>(l0) * l1 * l2) {
+		return;
+	}
+	const int k = static_cast<int>(t / (static_cast<int64_t>(l0) * l1));
+	const int r = static_cast<int>(t - static_cast<int64_t>(k) * l0 * l1);
+	const int j = r / l0;
+	f(b, bx.lo[0] + (r - j * l0), bx.lo[1] + j, bx.lo[2] + k);
+}
+
+__global__ void __launch_bounds__(256) k_average_down(const AvgItem *items, const qk_array4 *fine_t, qk_array4 *crse_t, int scomp, int ncomp, int r0, int r1,
+						      int r2)
+{
+	const AvgItem it = items[blockIdx.y];
+	const int n0 = it.hi[0] - it.lo[0] + 1, n1 = it.hi[1] - it.lo[1] + 1, n2 = it.hi[2] - it.lo[2] + 1;
+	const int64_t ncell = static_cast<int64_t>(n0) * n1 * n2;
+	RA4 F(fine_t[it.fine_box]);
+	WA4 Cc(crse_t[it.crse_box]);
+	// amrex_avgdown: volfrac = 1 / (rx ry rz);  c = sum over kref, jref, iref (iref fastest);  crse = volfrac * c
+	const double volfrac = 1.0 / static_cast<double>(r0 * r1 * r2);
+	for (int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < ncell * ncomp; t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+		const int n = static_cast<int>(t / ncell);
+		const int64_t c = t - n * ncell;
+		const int k = static_cast<int>(c / (static_cast<int64_t>(n0) * n1));
+		const int r = static_cast<int>(c - static_cast<int64_t>(k) * n0 * n1);
+		const int j = r / n0;
+		const int i = it.lo[0] + (r - j * n0), jj = it.lo[1] + j, kk = it.lo[2] + k;
+		double sum = 0.0;
+		for (int kr = 0; kr < r2; ++kr) {
+			for (int jr = 0; jr < r1; ++jr) {
+				for (int ir = 0; ir < r0; ++ir) {
+					sum += F(i * r0 + ir, jj * r1 + jr, kk * r2 + kr, scomp + n);
+				}
+			}
+		}
+		Cc(i, jj, kk, scomp + n) = volfrac * sum;
+	}
+}
+
+} // namespace
+
+extern "C" {
+
+int qk_tag_relative_gradient(qk_level *lev, qk_stream s, const qk_hydro_traits *t, const qk_array4 *state_t, qk_carray4 *tags_t, int field, double eta_threshold,
+			     double q_min, int min_inclusive)
+{
+	if (lev == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	if (int rc = checkTraits(lev->ctx, t); rc != QK_OK) {
+		return rc;
+	}
+	QK_REQUIRE(lev->ctx, state_t && tags_t, "tag_relative_gradient: NULL array");
+	QK_REQUIRE(lev->ctx, field == QK_TAGFIELD_PRESSURE || (field >= 0 && field < 64), "tag_relative_gradient: unknown field");
+	const Eos eos(*t);
+	const int ndim = lev->ndim;
+	int64_t maxcells = 1;
+	for (int d = 0; d < 3; ++d) {
+		maxcells *= lev->maxlen[d];
+	}
+	const dim3 grid(static_cast<unsigned>((maxcells + 255) / 256), static_cast<unsigned>(lev->nboxes), 1);
+	auto f = [=] __device__(int b, int i, int j, int k) {
+		RA4 U(state_t[b]);
+		CA4 tag(tags_t[b]);
+		auto q = [&](int ii, int jj, int kk) -> double {
+			if (field == QK_TAGFIELD_PRESSURE) { // HydroSystem::ComputePressure(state, i, j, k)
+				return consPressure(eos, U(ii, jj, kk, RHO), U(ii, jj, kk, MX), U(ii, jj, kk, MY), U(ii, jj, kk, MZ), U(ii, jj, kk, ENE));
+			}
+			return U(ii, jj, kk, field);
+		};
+		const double c = q(i, j, k);
+		// del_d = max(|q+ - q|, |q - q-|);  indicator = max(del_x, del_y, del_z) / q   (std::max: first argument on ties)
+		double del = smax(fabs(q(i + 1, j, k) - c), fabs(c - q(i - 1, j, k)));
+		if (ndim >= 2) {
+			del = smax(del, smax(fabs(q(i, j + 1, k) - c), fabs(c - q(i, j - 1, k))));
+		}
+		if (ndim == 3) {
+			del = smax(del, smax(fabs(q(i, j, k + 1) - c), fabs(c - q(i, j, k - 1))));
+		}
+		const double gradient_indicator = del / c;
+		const bool above = (min_inclusive != 0) ? (c >= q_min) : (c > q_min);
+		if ((gradient_indicator > eta_threshold) && above) {
+			tag(i, j, k) = static_cast<char>(QK_TAG_SET);
+		}
+	};
+	hipLaunchKernelGGL(k_valid_cells<decltype(f)>, grid, dim3(256), 0, static_cast<hipStream_t>(s), lev->d_boxes, f);
+	QK_HIP_CHECK(lev->ctx, hipGetLastError());
+	return QK_OK;
+}
+
+int qk_avgdown_plan_create(qk_level *crse, qk_level *fine, const int ratio[3], qk_avgdown_plan **plan)
+{
+	if (crse == nullptr || fine == nullptr || plan == nullptr || ratio == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	qk_ctx *ctx = crse->ctx;
+	QK_REQUIRE(ctx, crse->ctx == fine->ctx && crse->ndim == fine->ndim, "avgdown_plan_create: levels of different contexts / dimensions");
+	auto *P = new qk_avgdown_plan;
+	P->crse = crse;
+	P->fine = fine;
+	for (int d = 0; d < 3; ++d) {
+		P->ratio[d] = (d < crse->ndim) ? ratio[d] : 1;
+		if (P->ratio[d] < 1) {
+			delete P;
+			return setError(ctx, QK_ERR_INVALID, "avgdown_plan_create: refinement ratio < 1");
+		}
+	}
+	auto fdiv = [](int a, int r) { return (a >= 0) ? a / r : -((-a + r - 1) / r); }; // amrex::coarsen (floor division)
+	for (int f = 0; f < fine->nboxes; ++f) {
+		qk_box cf{};
+		for (int d = 0; d < 3; ++d) {
+			cf.lo[d] = fdiv(fine->boxes[f].lo[d], P->ratio[d]);
+			cf.hi[d] = fdiv(fine->boxes[f].hi[d], P->ratio[d]);
+			// a fine box must cover whole coarse cells (blocking_factor >= ratio): anything else is not conservative
+			if (fine->boxes[f].lo[d] != cf.lo[d] * P->ratio[d] || fine->boxes[f].hi[d] != cf.hi[d] * P->ratio[d] + P->ratio[d] - 1) {
+				delete P;
+				return setError(ctx, QK_ERR_INVALID, "avgdown_plan_create: fine box not aligned with the refinement ratio");
+			}
+		}
+		for (int c = 0; c < crse->nboxes; ++c) {
+			AvgItem it{};
+			it.crse_box = c;
+			it.fine_box = f;
+			bool ok = true;
+			for (int d = 0; d < 3; ++d) {
+				it.lo[d] = std::max(cf.lo[d], crse->boxes[c].lo[d]);
+				it.hi[d] = std::min(cf.hi[d], crse->boxes[c].hi[d]);
+				ok = ok && (it.lo[d] <= it.hi[d]);
+			}
+			if (ok) {
+				P->items.push_back(it);
+				P->max_cells = std::max<int64_t>(P->max_cells, static_cast<int64_t>(it.hi[0] - it.lo[0] + 1) * (it.hi[1] - it.lo[1] + 1) * (it.hi[2] - it.lo[2] + 1));
+			}
+		}
+	}
+	if (!P->items.empty() && ctx->device != QK_DEVICE_HOST_PLANNING) {
+		if (hipMalloc(reinterpret_cast<void **>(&P->d_items), sizeof(AvgItem) * P->items.size()) != hipSuccess ||
+		    hipMemcpy(P->d_items, P->items.data(), sizeof(AvgItem) * P->items.size(), hipMemcpyHostToDevice) != hipSuccess) {
+			delete P;
+			return setError(ctx, QK_ERR_HIP, "avgdown_plan_create: upload failed");
+		}
+	}
+	*plan = P;
+	return QK_OK;
+}
+
+int qk_avgdown_plan_destroy(qk_avgdown_plan *plan)
+{
+	if (plan != nullptr) {
+		(void)hipFree(plan->d_items);
+		delete plan;
+	}
+	return QK_OK;
+}
+
+int qk_avgdown_plan_num_items(qk_avgdown_plan *plan) { return plan == nullptr ? QK_ERR_INVALID : static_cast<int>(plan->items.size()); }
+
+int qk_average_down(qk_avgdown_plan *plan, qk_stream s, const qk_array4 *fine_t, qk_array4 *crse_t, int scomp, int ncomp)
+{
+	if (plan == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	qk_ctx *ctx = plan->crse->ctx;
+	QK_REQUIRE(ctx, fine_t && crse_t && scomp >= 0 && ncomp >= 1, "average_down: bad argument");
+	if (plan->items.empty()) {
+		return QK_OK;
+	}
+	const dim3 grid(static_cast<unsigned>(std::min<int64_t>((plan->max_cells * ncomp + 255) / 256, 8192)), static_cast<unsigned>(plan->items.size()), 1);
+	hipLaunchKernelGGL(k_average_down, grid, dim3(256), 0, static_cast<hipStream_t>(s), plan->d_items, fine_t, crse_t, scomp, ncomp, plan->ratio[0], plan->ratio[1],
+			   plan->ratio[2]);
+	QK_HIP_CHECK(ctx, hipGetLastError());
+	return QK_OK;
+}
+
+} // extern "C"

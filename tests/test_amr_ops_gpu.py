@@ -1,0 +1,73 @@
+"""GPU parity of the data-parallel AMR pieces (C-ABI) against the CPU oracle: tags are integers (bit-exact by definition),
+average-down sums in the same order (bit-exact)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.pyoracle import SEDOV
+from quokka_amd import capi
+from quokka_amd.amr import AverageDown, TagBoxArray, tag_relative_gradient
+from quokka_amd.multifab import Level, MultiFab
+from quokka_amd.simulation import sedov_problem
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("field,eta,qmin,inclusive", [(capi.TAGFIELD_PRESSURE, 0.1, 1.0e-3, False), (0, 0.1, 1.0e-2, True), (4, 0.05, 0.0, False)])
+def test_error_est_tags_match_oracle(ctx, oracle, field, eta, qmin, inclusive):
+    """ErrorEst of HydroBlast3D (pressure, eta 0.1, P > 1e-3) and of RadhydroShell's form (density component, rho >= rho_min) on a Sedov
+    state after 12 steps, 8 boxes: every tag"""
+    N, mgs = 32, 16
+    so = oracle.sim(SEDOV, 3, [N] * 3, [0, 0, 0], [1.2] * 3, [0, 0, 0], max_grid_size=[mgs] * 3)
+    sg = sedov_problem(ctx, N, max_grid_size=mgs)
+    for _ in range(12):
+        assert so.step() and sg.step()
+    so.fill_ghosts(0, so.time)
+    sg.fillBoundaryConditions(sg.state_new_cc_)
+    tags = TagBoxArray(sg.lev)
+    tag_relative_gradient(sg.lev, sg.traits, sg.state_new_cc_, tags, field, eta, qmin, inclusive)
+    nset = 0
+    for b in range(so.nboxes):
+        want = so.tag_relative_gradient(b, field, eta, qmin, inclusive)
+        got = tags.fab_numpy(b)[0]
+        assert got.dtype == np.int8 and np.array_equal(got, want), f"box {b}: {int((got != want).sum())} tags differ"
+        nset += int((want == capi.TAG_SET).sum())
+    assert 0 < nset < N ** 3, nset
+
+
+def test_average_down_matches_oracle(ctx, oracle):
+    """two coarse boxes (16^3 each, side by side), three fine boxes straddling them (ratio 2): conservative mean, same summation order"""
+    crse_boxes = [([0, 0, 0], [15, 15, 15]), ([16, 0, 0], [31, 15, 15])]
+    fine_boxes = [([8, 8, 8], [39, 23, 23]), ([40, 8, 8], [55, 23, 23]), ([16, 24, 0], [39, 31, 15])]
+    nc, ng = 6, 4
+    crse, fine = Level(ctx, 3, crse_boxes), Level(ctx, 3, fine_boxes)
+    rng = np.random.default_rng(3)
+    U_c, U_f = MultiFab(crse, nc, ng), MultiFab(fine, nc, ng)
+    c_np = [rng.standard_normal(s) for s in U_c.shapes]
+    f_np = [rng.standard_normal(s) * 10.0 ** rng.integers(-3, 4) for s in U_f.shapes]
+    for b, a in enumerate(c_np):
+        U_c.set_fab(b, a)
+    for b, a in enumerate(f_np):
+        U_f.set_fab(b, a)
+    avg = AverageDown(crse, fine)
+    assert avg.num_items() == 5  # fine 0 overlaps both coarse boxes, fine 1 only the second, fine 2 both
+    avg(U_f, U_c, 1, 4)
+    torch.cuda.synchronize()
+    want = [a.copy() for a in c_np]
+    for fb, (flo, fhi) in enumerate(fine_boxes):
+        for cb, (clo, chi) in enumerate(crse_boxes):
+            lo = [max(flo[d] // 2, clo[d]) for d in range(3)]
+            hi = [min(fhi[d] // 2, chi[d]) for d in range(3)]
+            if all(lo[d] <= hi[d] for d in range(3)):
+                oracle.average_down(f_np[fb], U_f.begins[fb], want[cb], U_c.begins[cb], (lo, hi), 1, 4)
+    for b in range(2):
+        got = U_c.fab_numpy(b)
+        assert np.array_equal(got, want[b]), f"coarse box {b}: max diff {np.abs(got - want[b]).max()}"
+        assert not np.array_equal(got, c_np[b])
+    # conservative: the coarse sum over the region covered by fine box 1 is 1/8 of the fine sum (up to rounding)
+    flo, fhi = fine_boxes[1]
+    fsum = f_np[1][2, ng:-ng, ng:-ng, ng:-ng].sum()
+    c1 = U_c.fab_numpy(1)[2]
+    b0 = U_c.begins[1]
+    csum = c1[flo[2] // 2 - b0[2]:fhi[2] // 2 - b0[2] + 1, flo[1] // 2 - b0[1]:fhi[1] // 2 - b0[1] + 1, flo[0] // 2 - b0[0]:fhi[0] // 2 - b0[0] + 1].sum()
+    assert abs(csum - fsum / 8.0) <= 1e-12 * abs(fsum / 8.0) + 1e-12
