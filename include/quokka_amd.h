@@ -314,6 +314,10 @@ enum { QK_TAG_CLEAR = 0, QK_TAG_BUF = 1, QK_TAG_SET = 2 }; /* amrex::TagBox::Tag
  * other cells are left untouched.  `state` needs one ghost cell.  field: QK_TAGFIELD_PRESSURE or a component index. */
 int qk_tag_relative_gradient(qk_level *lev, qk_stream s, const qk_hydro_traits *t, const qk_array4 *state, qk_carray4 *tags, int field,
 			     double eta_threshold, double q_min, int min_inclusive);
+/* QuokkaSimulation::PreInterpState / PostInterpState(mf, scomp, ncomp)     reference src/QuokkaSimulation.hpp:804-841
+ * around the coarse-to-fine interpolation: E <- (E - |p|^2/(2 rho)) / rho on every valid cell of `mf`, and back (E <- rho e + KE). */
+int qk_PreInterpState(qk_level *lev, qk_stream s, qk_array4 *mf);
+int qk_PostInterpState(qk_level *lev, qk_stream s, qk_array4 *mf);
 /* AMRSimulation::AverageDownTo -> amrex::average_down(fine, crse, ...)     reference src/simulation.hpp:1949-1964
  * crse = (1 / (rx ry rz)) * sum of the fine cells under it, summed with the x index fastest (amrex_avgdown); only coarse cells
  * covered by a fine box are written.  The plan pairs every fine box with the coarse boxes it overlaps (same rank). */

@@ -2,6 +2,7 @@
 
   tag_relative_gradient   QuokkaSimulation<problem_t>::ErrorEst of the gradient-threshold family
                           (reference src/problems/HydroBlast3D/test_hydro3d_blast.cpp:118-151, RadhydroShell:337-371)
+  Pre/PostInterpState     QuokkaSimulation::PreInterpState / PostInterpState (reference src/QuokkaSimulation.hpp:804-841)
   AverageDown             AMRSimulation::AverageDownTo -> amrex::average_down (reference src/simulation.hpp:1949-1964)
 
 Grid generation, FillPatch interpolation, flux registers and the subcycling driver are not built yet.
@@ -26,6 +27,14 @@ def tag_relative_gradient(lev: Level, traits: capi.HydroTraits, state: MultiFab,
     ctx = lev.ctx
     ctx.check(ctx.L.qk_tag_relative_gradient(lev.h, ctx.stream(), C.byref(traits), state.ptr, tags.ptr, int(field), float(eta_threshold), float(q_min),
                                              int(bool(min_inclusive))), "qk_tag_relative_gradient")
+
+
+def PreInterpState(lev: Level, mf: MultiFab):
+    lev.ctx.check(lev.ctx.L.qk_PreInterpState(lev.h, lev.ctx.stream(), mf.ptr), "qk_PreInterpState")
+
+
+def PostInterpState(lev: Level, mf: MultiFab):
+    lev.ctx.check(lev.ctx.L.qk_PostInterpState(lev.h, lev.ctx.stream(), mf.ptr), "qk_PostInterpState")
 
 
 class AverageDown:

@@ -151,6 +151,8 @@ def lib() -> C.CDLL:
         L.qk_avgdown_plan_destroy.argtypes = [vp]
         L.qk_avgdown_plan_num_items.argtypes = [vp]
         L.qk_average_down.argtypes = [vp, vp, vp, vp, ci, ci]
+        L.qk_PreInterpState.argtypes = [vp, vp, vp]
+        L.qk_PostInterpState.argtypes = [vp, vp, vp]
     _lib = L
     return L
 
@@ -173,7 +175,7 @@ DECLARED_SYMBOLS = [
     "qk_ghost_plan_create", "qk_ghost_plan_destroy", "qk_ghost_plan_num_peers", "qk_ghost_plan_peer", "qk_ghost_plan_num_items", "qk_ghost_plan_item",
     "qk_FillBoundary_local", "qk_FillBoundary_local_int", "qk_FillBoundary_pack", "qk_FillBoundary_unpack", "qk_FillBoundary_pack_int", "qk_FillBoundary_unpack_int", "qk_FillPhysicalBoundary",
     "qk_FillPhysicalBoundary_subset", "qk_ghost_plan_box_is_remote", "qk_ghost_plan_set_box_remote",
-    "qk_tag_relative_gradient", "qk_avgdown_plan_create", "qk_avgdown_plan_destroy", "qk_avgdown_plan_num_items", "qk_average_down",
+    "qk_tag_relative_gradient", "qk_avgdown_plan_create", "qk_avgdown_plan_destroy", "qk_avgdown_plan_num_items", "qk_average_down", "qk_PreInterpState", "qk_PostInterpState",
 ]
 
 

@@ -3,7 +3,8 @@
 //                              (src/problems/HydroBlast3D/test_hydro3d_blast.cpp:118-151, RadhydroShell/test_radhydro_shell.cpp:337-371)
 //   qk_average_down            AMRSimulation::AverageDownTo -> amrex::average_down (src/simulation.hpp:1949-1964), cell-centred,
 //                              conservative mean of the ratio^3 fine cells under a coarse cell
-// Grid generation, FillPatch interpolation, flux registers and the subcycling driver are not built yet.
+//   qk_PreInterpState / qk_PostInterpState   QuokkaSimulation::PreInterpState / PostInterpState (src/QuokkaSimulation.hpp:804-841)
+// Grid generation, the FillPatch interpolation itself, flux registers and the subcycling driver are not built yet.
 #include <algorithm>
 #include <vector>
 
@@ -125,6 +126,42 @@ int qk_tag_relative_gradient(qk_level *lev, qk_stream s, const qk_hydro_traits *
 	QK_HIP_CHECK(lev->ctx, hipGetLastError());
 	return QK_OK;
 }
+
+// PreInterpState / PostInterpState: total energy <-> specific internal energy around the coarse-to-fine interpolation
+static int interpState(qk_level *lev, qk_stream s, qk_array4 *mf_t, bool pre)
+{
+	if (lev == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	QK_REQUIRE(lev->ctx, mf_t, "Pre/PostInterpState: NULL array");
+	int64_t maxcells = 1;
+	for (int d = 0; d < 3; ++d) {
+		maxcells *= lev->maxlen[d];
+	}
+	const dim3 grid(static_cast<unsigned>((maxcells + 255) / 256), static_cast<unsigned>(lev->nboxes), 1);
+	auto f = [=] __device__(int b, int i, int j, int k) {
+		WA4 cons(mf_t[b]);
+		const double rho = cons(i, j, k, RHO);
+		const double px = cons(i, j, k, MX);
+		const double py = cons(i, j, k, MY);
+		const double pz = cons(i, j, k, MZ);
+		const double kinetic_energy = (px * px + py * py + pz * pz) / (2.0 * rho);
+		if (pre) {
+			const double Etot = cons(i, j, k, ENE);
+			cons(i, j, k, ENE) = (Etot - kinetic_energy) / rho; // specific internal energy
+		} else {
+			const double e = cons(i, j, k, ENE);
+			const double Eint = rho * e;
+			cons(i, j, k, ENE) = Eint + kinetic_energy;
+		}
+	};
+	hipLaunchKernelGGL(k_valid_cells<decltype(f)>, grid, dim3(256), 0, static_cast<hipStream_t>(s), lev->d_boxes, f);
+	QK_HIP_CHECK(lev->ctx, hipGetLastError());
+	return QK_OK;
+}
+
+int qk_PreInterpState(qk_level *lev, qk_stream s, qk_array4 *mf) { return interpState(lev, s, mf, true); }
+int qk_PostInterpState(qk_level *lev, qk_stream s, qk_array4 *mf) { return interpState(lev, s, mf, false); }
 
 int qk_avgdown_plan_create(qk_level *crse, qk_level *fine, const int ratio[3], qk_avgdown_plan **plan)
 {

@@ -6,7 +6,7 @@ import torch
 
 from oracle.pyoracle import SEDOV
 from quokka_amd import capi
-from quokka_amd.amr import AverageDown, TagBoxArray, tag_relative_gradient
+from quokka_amd.amr import AverageDown, PostInterpState, PreInterpState, TagBoxArray, tag_relative_gradient
 from quokka_amd.multifab import Level, MultiFab
 from quokka_amd.simulation import sedov_problem
 
@@ -71,3 +71,31 @@ def test_average_down_matches_oracle(ctx, oracle):
     b0 = U_c.begins[1]
     csum = c1[flo[2] // 2 - b0[2]:fhi[2] // 2 - b0[2] + 1, flo[1] // 2 - b0[1]:fhi[1] // 2 - b0[1] + 1, flo[0] // 2 - b0[0]:fhi[0] // 2 - b0[0] + 1].sum()
     assert abs(csum - fsum / 8.0) <= 1e-12 * abs(fsum / 8.0) + 1e-12
+
+
+def test_pre_post_interp_state(ctx):
+    """PreInterpState: E -> (E - |p|^2 / (2 rho)) / rho on valid cells, PostInterpState: back; numpy restatement with the reference's
+    association order (src/QuokkaSimulation.hpp:804-841), ghost cells untouched"""
+    from test_hydro_ops_gpu import random_state
+    boxes = [([0, 0, 0], [15, 11, 7]), ([16, 0, 0], [23, 11, 7])]
+    lev = Level(ctx, 3, boxes)
+    mf = MultiFab(lev, 6, 2)
+    rng = np.random.default_rng(11)
+    src = [random_state(rng, s[1:]) for s in mf.shapes]
+    for b, a in enumerate(src):
+        mf.set_fab(b, a)
+    PreInterpState(lev, mf)
+    pre = [mf.fab_numpy(b) for b in range(2)]
+    PostInterpState(lev, mf)
+    post = [mf.fab_numpy(b) for b in range(2)]
+    for b, U in enumerate(src):
+        v = (slice(None), slice(2, -2), slice(2, -2), slice(2, -2))
+        rho, px, py, pz, E = (U[n] for n in range(5))
+        ke = (px * px + py * py + pz * pz) / (2.0 * rho)
+        want = U.copy()
+        want[4][v[1:]] = ((E - ke) / rho)[v[1:]]
+        assert np.array_equal(pre[b], want), f"PreInterpState, box {b}"
+        back = want.copy()
+        back[4][v[1:]] = (rho * want[4] + ke)[v[1:]]
+        assert np.array_equal(post[b], back), f"PostInterpState, box {b}"
+        assert np.allclose(post[b][4], U[4], rtol=1e-14)
