@@ -56,10 +56,11 @@ QK_DEV void eddingtonTensor(double fx, double fy, double fz, double T[3][3])
 {
 	const double f = sqrt(fx * fx + fy * fy + fz * fz);
 	const double fv[3] = {fx, fy, fz};
+	const Recip Rf = recipOf(f); // (f == 0: the NaN quotients are discarded by the select below)
 	double n[3];
 #pragma unroll
 	for (int ii = 0; ii < 3; ++ii) {
-		n[ii] = (f > 0.) ? (fv[ii] / f) : 0.;
+		n[ii] = (f > 0.) ? divBy(fv[ii], Rf) : 0.;
 	}
 	const double chi = eddingtonFactor(f);
 	const double Tdiag = (1.0 - chi) / 2.0;
@@ -129,10 +130,12 @@ template <int DIR> QK_DEV void radFaceFlux(Rad const &r, const double pL[NRAD], 
 	S_R *= r.chat;
 	const double UL[NRAD] = {erad_L, Fx_L, Fy_L, Fz_L};
 	const double UR[NRAD] = {erad_R, Fx_R, Fy_R, Fz_R};
+	const Recip RS = recipOf(S_R - S_L);
+	const double sR_over = divBy(S_R, RS), sL_over = divBy(S_L, RS), sRL_over = divBy(S_R * S_L, RS);
 #pragma unroll
 	for (int n = 0; n < NRAD; ++n) {
 		// :1116-1117 with epsilon = 1 (use_wavespeed_correction = false)
-		F[n] = (S_R / (S_R - S_L)) * FL[n] - (S_L / (S_R - S_L)) * FR[n] + 1.0 * (S_R * S_L / (S_R - S_L)) * (UR[n] - UL[n]);
+		F[n] = sR_over * FL[n] - sL_over * FR[n] + 1.0 * sRL_over * (UR[n] - UL[n]);
 	}
 }
 
@@ -211,6 +214,7 @@ QK_DEV void radSourceCell(Rad const &r, Eos const &eos, double U[10], double src
 	double dMomentum[3] = {0., 0., 0.};
 	double Frad_t1[3] = {0., 0., 0.};
 	const double cscale = c / chat;
+	const Recip Rcc = recipOf(c * chat);
 
 	if (gamma_ne_1) {
 		Egas0 = eintFromEgas(rho, x1GasMom0, x2GasMom0, x3GasMom0, Egastot0);
@@ -311,6 +315,7 @@ QK_DEV void radSourceCell(Rad const &r, Eos const &eos, double U[10], double src
 				const double y0 = -F_G;
 				const double y1 = -1. * F_D;
 				const double det = J00 * J11 - J01 * J10;
+				// (plain divisions: det = -inf when tau <= 0, where IEEE inf arithmetic is part of the algorithm)
 				deltaEgas = (J11 * y0 - J01 * y1) / det;
 				deltaR = (J00 * y1 - J10 * y0) / det;
 				// enable_dE_constrain = true (radiation_system.hpp:44)
@@ -343,9 +348,10 @@ QK_DEV void radSourceCell(Rad const &r, Eos const &eos, double U[10], double src
 		if (gamma_ne_1 && (beta_order != 0)) {
 			const double erad = Erad_guess;
 			double v_terms[3];
-			const double fx = Frad_t0[0] / (r.c * erad);
-			const double fy = Frad_t0[1] / (r.c * erad);
-			const double fz = Frad_t0[2] / (r.c * erad);
+			const Recip RcE = recipOf(r.c * erad);
+			const double fx = divBy(Frad_t0[0], RcE);
+			const double fy = divBy(Frad_t0[1], RcE);
+			const double fz = divBy(Frad_t0[2], RcE);
 			const double F_coeff = chat * rho * kappaF * dt * lorentz_factor;
 			double Tedd[3][3];
 			eddingtonTensor(fx, fy, fz, Tedd);
@@ -365,10 +371,11 @@ QK_DEV void radSourceCell(Rad const &r, Eos const &eos, double U[10], double src
 				v_terms[n] = Planck_term + pressure_term;
 			}
 			if (beta_order == 1 || kappaF == kappaE) {
+				const Recip R1F = recipOf(1.0 + F_coeff);
 #pragma unroll
 				for (int n = 0; n < 3; ++n) {
-					Frad_t1[n] = (Frad_t0[n] + v_terms[n]) / (1.0 + F_coeff);
-					dMomentum[n] += -(Frad_t1[n] - Frad_t0[n]) / (c * chat);
+					Frad_t1[n] = divBy(Frad_t0[n] + v_terms[n], R1F);
+					dMomentum[n] += divBy(-(Frad_t1[n] - Frad_t0[n]), Rcc);
 				}
 			} else {
 				// Solve3x3matrix (radiation_system.hpp:560-579) with gasVel = 0 as in the reference (:437, never assigned)

@@ -150,9 +150,10 @@ template <int DIR> void launchRadComputeFluxes(qk_level *lev, qk_stream s, Rad r
 QK_DEV void radPrim(Rad const &r, const double c[NRAD], double p[NRAD])
 {
 	p[0] = c[0];
-	p[1] = c[1] / (r.c * c[0]);
-	p[2] = c[2] / (r.c * c[0]);
-	p[3] = c[3] / (r.c * c[0]);
+	const Recip RcE = recipOf(r.c * c[0]); // three quotients, one refined reciprocal (qk_device.hpp: same bits as three `/`)
+	p[1] = divBy(c[1], RcE);
+	p[2] = divBy(c[2], RcE);
+	p[3] = divBy(c[3], RcE);
 }
 
 template <int DIR, int ORDER> void launchRadFusedFlux(qk_level *lev, qk_stream s, Rad rad, const qk_array4 *cons_t, qk_array4 *flux_t)
