@@ -327,6 +327,23 @@ int qk_avgdown_plan_destroy(qk_avgdown_plan *plan);
 int qk_avgdown_plan_num_items(qk_avgdown_plan *plan);
 int qk_average_down(qk_avgdown_plan *plan, qk_stream s, const qk_array4 *fine, qk_array4 *crse, int scomp, int ncomp);
 
+/* Coarse -> fine part of AMRSimulation::FillPatchWithData / amrex::FillPatchTwoLevels       reference src/simulation.hpp:1789-1858
+ * Fine cells that no fine box covers (ghost cells inside the domain or beyond a periodic face; whole_fab != 0: every cell of
+ * the grown fine boxes, used when a level is (re)made) are interpolated from  w_old * crse_old + w_new * crse_new
+ * (FillPatch time interpolation; pass the same table twice and w_new = 0 for a single time level):
+ *   method 1 = amrex::mf_linear_slope_minmax_interp, 0 = amrex::mf_pc_interp (amrInterpMethod_, src/simulation.hpp:1389-1401);
+ *   energy_hooks != 0 wraps the interpolation in QuokkaSimulation::PreInterpState / PostInterpState (src/QuokkaSimulation.hpp:804-841).
+ * The coarse arrays need their ghost cells filled (stencil: one coarse cell around the parent cell).  AMReX's interpolater is
+ * restated from its documentation: parity with the reference is unpinned for this entry point. */
+typedef struct qk_interp_plan qk_interp_plan;
+int qk_interp_plan_create(qk_level *crse, qk_level *fine, const qk_geometry *fine_geom, int nghost, const int ratio[3], int whole_fab,
+			  qk_interp_plan **plan);
+int qk_interp_plan_destroy(qk_interp_plan *plan);
+int qk_interp_plan_num_items(qk_interp_plan *plan);
+int qk_interp_plan_item(qk_interp_plan *plan, int idx, int *fine_box, int *crse_box, int lo[3], int hi[3]);
+int qk_InterpFromCoarse(qk_interp_plan *plan, qk_stream s, qk_array4 *fine, const qk_array4 *crse_old, const qk_array4 *crse_new, double w_old,
+			double w_new, int ncomp, int method, int energy_hooks);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,6 +70,89 @@ inline void averageDown(Array4<const double> const &fine, Array4<double> const &
 	}
 }
 
+// amrex::mf_linear_slope_minmax_interp (method 1) / mf_pc_interp (method 0) with PreInterpState / PostInterpState, restated
+// from AMReX's documentation exactly as quokka_amd/csrc/qk_amr_fill.hip does (parity with the reference UNPINNED):
+// fine cells of `region` (fine index space) from  w_old * crse_old + w_new * crse_new.
+inline void interpFromCoarse(Array4<double> const &fine, Array4<const double> const &crse_old, Array4<const double> const &crse_new, Box const &region,
+			     double w_old, double w_new, int ncomp, int method, bool hooks, int ndim, const int ratio[3])
+{
+	constexpr int RHO = 0, MX = 1, MY = 2, MZ = 3, ENE = 4;
+	auto tv = [&](int i, int j, int k, int c) -> double {
+		double const a = crse_old(i, j, k, c);
+		if (w_new == 0.0) {
+			return a;
+		}
+		return w_old * a + w_new * crse_new(i, j, k, c);
+	};
+	auto cv = [&](int i, int j, int k, int n) -> double {
+		if (hooks && n == ENE) {
+			double const rho = tv(i, j, k, RHO), px = tv(i, j, k, MX), py = tv(i, j, k, MY), pz = tv(i, j, k, MZ), Etot = tv(i, j, k, ENE);
+			double const kinetic_energy = (px * px + py * py + pz * pz) / (2.0 * rho);
+			return (Etot - kinetic_energy) / rho;
+		}
+		return tv(i, j, k, n);
+	};
+	auto fdiv = [](int a, int r) { return (a >= 0) ? a / r : -((-a + r - 1) / r); };
+	for (int k = region.lo[2]; k <= region.hi[2]; ++k) {
+		for (int j = region.lo[1]; j <= region.hi[1]; ++j) {
+			for (int i = region.lo[0]; i <= region.hi[0]; ++i) {
+				int const idx[3] = {i, j, k};
+				int ic[3];
+				double off[3];
+				for (int d = 0; d < 3; ++d) {
+					ic[d] = fdiv(idx[d], ratio[d]);
+					off[d] = (idx[d] - ic[d] * ratio[d] + 0.5) / ratio[d] - 0.5;
+				}
+				for (int n = 0; n < ncomp; ++n) {
+					double const u = cv(ic[0], ic[1], ic[2], n);
+					double val = u;
+					if (method == 1) {
+						double umax = u, umin = u;
+						int const k0 = (ndim == 3) ? -1 : 0, k1 = (ndim == 3) ? 1 : 0, j0 = (ndim >= 2) ? -1 : 0, j1 = (ndim >= 2) ? 1 : 0;
+						for (int c = k0; c <= k1; ++c) {
+							for (int b = j0; b <= j1; ++b) {
+								for (int a = -1; a <= 1; ++a) {
+									double const v = cv(ic[0] + a, ic[1] + b, ic[2] + c, n);
+									umax = std::max(umax, v);
+									umin = std::min(umin, v);
+								}
+							}
+						}
+						double s[3] = {0.5 * (cv(ic[0] + 1, ic[1], ic[2], n) - cv(ic[0] - 1, ic[1], ic[2], n)), 0., 0.};
+						if (ndim >= 2) {
+							s[1] = 0.5 * (cv(ic[0], ic[1] + 1, ic[2], n) - cv(ic[0], ic[1] - 1, ic[2], n));
+						}
+						if (ndim == 3) {
+							s[2] = 0.5 * (cv(ic[0], ic[1], ic[2] + 1, n) - cv(ic[0], ic[1], ic[2] - 1, n));
+						}
+						double alpha = 1.0;
+						if (s[0] != 0.0 || s[1] != 0.0 || s[2] != 0.0) {
+							double const dumax = std::abs(s[0]) * static_cast<double>(ratio[0] - 1) / (2.0 * ratio[0]) +
+									     std::abs(s[1]) * static_cast<double>(ratio[1] - 1) / (2.0 * ratio[1]) +
+									     std::abs(s[2]) * static_cast<double>(ratio[2] - 1) / (2.0 * ratio[2]);
+							if (dumax * alpha > (umax - u)) {
+								alpha = (umax - u) / dumax;
+							}
+							if (dumax * alpha > (u - umin)) {
+								alpha = (u - umin) / dumax;
+							}
+						}
+						val = u + off[0] * (s[0] * alpha) + off[1] * (s[1] * alpha) + off[2] * (s[2] * alpha);
+					}
+					fine(i, j, k, n) = val;
+				}
+				if (hooks && ncomp > ENE) {
+					double const rho = fine(i, j, k, RHO), px = fine(i, j, k, MX), py = fine(i, j, k, MY), pz = fine(i, j, k, MZ);
+					double const e = fine(i, j, k, ENE);
+					double const Eint = rho * e;
+					double const kinetic_energy = (px * px + py * py + pz * pz) / (2.0 * rho);
+					fine(i, j, k, ENE) = Eint + kinetic_energy;
+				}
+			}
+		}
+	}
+}
+
 } // namespace oracle
 
 #endif

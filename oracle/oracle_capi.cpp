@@ -248,6 +248,24 @@ void orc_sim_tag_relative_gradient(void *p, int b, int field, double eta_thresho
 	tagRelativeGradient(s->hydro, s->state_new_cc_.const_array(b), t, s->grids[b], s->ndim(), field, eta_threshold, q_min, min_inclusive != 0);
 }
 
+// coarse -> fine interpolation of `region` (fine indices); arrays given with their lower / upper corners
+void orc_interp_from_coarse(double *fine, const int *flo, const int *fhi, const double *crse_old, const double *crse_new, const int *clo, const int *chi,
+			    int ncomp_total, const int *rlo, const int *rhi, double w_old, double w_new, int ncomp, int method, int hooks, int ndim, const int *ratio)
+{
+	Box fb, cb, region;
+	for (int d = 0; d < 3; ++d) {
+		fb.lo[d] = flo[d];
+		fb.hi[d] = fhi[d];
+		cb.lo[d] = clo[d];
+		cb.hi[d] = chi[d];
+		region.lo[d] = rlo[d];
+		region.hi[d] = rhi[d];
+	}
+	Array4<double> f(fine, fb, ncomp_total);
+	Array4<const double> co(crse_old, cb, ncomp_total), cn(crse_new, cb, ncomp_total);
+	interpFromCoarse(f, co, cn, region, w_old, w_new, ncomp, method, hooks != 0, ndim, ratio);
+}
+
 // amrex::average_down of one fine array onto one coarse array; boxes as lo[3], hi[3] (with ghosts = the arrays' extents); region in coarse indices
 void orc_average_down(const double *fine, const int *flo, const int *fhi, double *crse, const int *clo, const int *chi, int ncomp_total, const int *rlo,
 		      const int *rhi, int scomp, int ncomp, const int *ratio)

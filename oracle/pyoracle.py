@@ -152,6 +152,19 @@ class Oracle:
         L.orc_average_down(fine.ctypes.data_as(C.c_void_p), _i3(flo), _i3(fhi), crse.ctypes.data_as(C.c_void_p), _i3(clo), _i3(chi), fine.shape[0],
                            _i3(region[0]), _i3(region[1]), scomp, ncomp, _i3(ratio))
 
+    def interp_from_coarse(self, fine: np.ndarray, flo, crse_old: np.ndarray, crse_new: np.ndarray, clo, region, w_old: float, w_new: float, ncomp: int,
+                           method: int = 1, hooks: bool = True, ndim: int = 3, ratio=(2, 2, 2)):
+        """coarse -> fine interpolation restated (oracle/amr.hpp): fills `region` = (lo, hi) (fine indices) of `fine` in place"""
+        for a in (fine, crse_old, crse_new):
+            assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+        fhi = [flo[d] + fine.shape[3 - d] - 1 for d in range(3)]
+        chi = [clo[d] + crse_old.shape[3 - d] - 1 for d in range(3)]
+        L = self.lib
+        L.orc_interp_from_coarse.argtypes = [C.c_void_p, _I3, _I3, C.c_void_p, C.c_void_p, _I3, _I3, C.c_int, _I3, _I3, C.c_double, C.c_double, C.c_int, C.c_int,
+                                             C.c_int, C.c_int, _I3]
+        L.orc_interp_from_coarse(fine.ctypes.data_as(C.c_void_p), _i3(flo), _i3(fhi), crse_old.ctypes.data_as(C.c_void_p), crse_new.ctypes.data_as(C.c_void_p),
+                                 _i3(clo), _i3(chi), fine.shape[0], _i3(region[0]), _i3(region[1]), w_old, w_new, ncomp, method, int(hooks), ndim, _i3(ratio))
+
     def sim(self, problem, ndim, n_cell, prob_lo, prob_hi, periodic, max_grid_size=None, cfl=-1.0, stop_time=-1.0,
             max_timesteps=-1, reconstruction_order=-1, nscalars=0, table=None, rad_pow_mode=0) -> "OracleSim":
         if ndim == 2:

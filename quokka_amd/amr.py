@@ -56,3 +56,37 @@ class AverageDown:
             self.crse.ctx.L.qk_avgdown_plan_destroy(self.h)
         except Exception:
             pass
+
+
+class InterpFromCoarse:
+    """coarse -> fine part of FillPatchTwoLevels (reference src/simulation.hpp:1789-1858): interpolates the fine cells that no fine
+    box covers (whole_fab: every cell of the grown fine boxes) from w_old * crse_old + w_new * crse_new"""
+
+    def __init__(self, crse: Level, fine: Level, fine_geom, nghost: int, ratio=(2, 2, 2), whole_fab: bool = False):
+        self.crse, self.fine = crse, fine
+        self._geom_c = fine_geom.c_struct()
+        h = C.c_void_p()
+        crse.ctx.check(crse.ctx.L.qk_interp_plan_create(crse.h, fine.h, C.byref(self._geom_c), nghost, (C.c_int * 3)(*ratio), int(whole_fab), C.byref(h)),
+                       "qk_interp_plan_create")
+        self.h = h
+
+    def items(self):
+        L, out = self.crse.ctx.L, []
+        for idx in range(L.qk_interp_plan_num_items(self.h)):
+            fb, cb = C.c_int(), C.c_int()
+            lo, hi = (C.c_int * 3)(), (C.c_int * 3)()
+            self.crse.ctx.check(L.qk_interp_plan_item(self.h, idx, C.byref(fb), C.byref(cb), lo, hi), "qk_interp_plan_item")
+            out.append((fb.value, cb.value, list(lo), list(hi)))
+        return out
+
+    def __call__(self, fine_mf: MultiFab, crse_old: MultiFab, crse_new: MultiFab, w_old: float, w_new: float, ncomp: int, method: int = 1,
+                 energy_hooks: bool = True):
+        ctx = self.crse.ctx
+        ctx.check(ctx.L.qk_InterpFromCoarse(self.h, ctx.stream(), fine_mf.ptr, crse_old.ptr, crse_new.ptr, float(w_old), float(w_new), ncomp, method,
+                                            int(energy_hooks)), "qk_InterpFromCoarse")
+
+    def __del__(self):
+        try:
+            self.crse.ctx.L.qk_interp_plan_destroy(self.h)
+        except Exception:
+            pass

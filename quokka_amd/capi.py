@@ -151,6 +151,11 @@ def lib() -> C.CDLL:
         L.qk_avgdown_plan_destroy.argtypes = [vp]
         L.qk_avgdown_plan_num_items.argtypes = [vp]
         L.qk_average_down.argtypes = [vp, vp, vp, vp, ci, ci]
+        L.qk_interp_plan_create.argtypes = [vp, vp, P(Geometry), ci, ci * 3, ci, P(vp)]
+        L.qk_interp_plan_destroy.argtypes = [vp]
+        L.qk_interp_plan_num_items.argtypes = [vp]
+        L.qk_interp_plan_item.argtypes = [vp, ci, P(ci), P(ci), ci * 3, ci * 3]
+        L.qk_InterpFromCoarse.argtypes = [vp, vp, vp, vp, vp, C.c_double, C.c_double, ci, ci, ci]
         L.qk_PreInterpState.argtypes = [vp, vp, vp]
         L.qk_PostInterpState.argtypes = [vp, vp, vp]
     _lib = L
@@ -176,6 +181,7 @@ DECLARED_SYMBOLS = [
     "qk_FillBoundary_local", "qk_FillBoundary_local_int", "qk_FillBoundary_pack", "qk_FillBoundary_unpack", "qk_FillBoundary_pack_int", "qk_FillBoundary_unpack_int", "qk_FillPhysicalBoundary",
     "qk_FillPhysicalBoundary_subset", "qk_ghost_plan_box_is_remote", "qk_ghost_plan_set_box_remote",
     "qk_tag_relative_gradient", "qk_avgdown_plan_create", "qk_avgdown_plan_destroy", "qk_avgdown_plan_num_items", "qk_average_down", "qk_PreInterpState", "qk_PostInterpState",
+    "qk_interp_plan_create", "qk_interp_plan_destroy", "qk_interp_plan_num_items", "qk_interp_plan_item", "qk_InterpFromCoarse",
 ]
 
 

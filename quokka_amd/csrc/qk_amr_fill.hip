@@ -1,0 +1,331 @@
+// qk_amr_fill.hip — coarse -> fine interpolation of the AMR level machinery:
+//   the part of AMRSimulation::FillPatchWithData / amrex::FillPatchTwoLevels (reference src/simulation.hpp:1789-1858) that
+//   fills fine cells no fine box covers from the time-interpolated coarse state, with
+//     amrInterpMethod_ = 1: amrex::mf_linear_slope_minmax_interp (src/simulation.hpp:1389-1401) — conservative linear
+//       interpolation, central slopes scaled by one factor per coarse cell and component so that no fine value leaves the
+//       range of the 3x3x3 coarse neighbourhood;  amrInterpMethod_ = 0: piecewise constant (mf_pc_interp)
+//     QuokkaSimulation::PreInterpState / PostInterpState (src/QuokkaSimulation.hpp:804-841) applied to the coarse stencil / the
+//       new fine cell: the gas energy is interpolated as specific internal energy.
+//   AMReX is not vendored under /root/reference: the interpolater is restated from its published description (AMReX
+//   MFInterpolater docs) — parity with the reference is UNPINNED for this file; oracle/amr.hpp holds the same restatement.
+// The plan (host) lists, per fine box, the boxes of ghost cells to fill: grown box minus every fine valid box (and its
+// periodic images) minus cells beyond a non-periodic domain face, cut by the coarse boxes that provide the stencil.
+#include <algorithm>
+#include <vector>
+
+#include "qk_device.hpp"
+#include "qk_internal.hpp"
+
+using namespace qk;
+
+struct InterpItem {
+	int fine_box, crse_box;
+	int lo[3], hi[3]; // fine index space
+};
+
+struct qk_interp_plan {
+	qk_level *crse = nullptr;
+	qk_level *fine = nullptr;
+	int ratio[3] = {2, 2, 2};
+	std::vector<InterpItem> items;
+	InterpItem *d_items = nullptr;
+	int64_t max_cells = 0;
+};
+
+namespace
+{
+
+struct HBox {
+	int lo[3], hi[3];
+	[[nodiscard]] auto ok() const -> bool { return lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2]; }
+};
+
+auto isect(HBox const &a, HBox const &b) -> HBox
+{
+	HBox r{};
+	for (int d = 0; d < 3; ++d) {
+		r.lo[d] = std::max(a.lo[d], b.lo[d]);
+		r.hi[d] = std::min(a.hi[d], b.hi[d]);
+	}
+	return r;
+}
+
+// a \ b as disjoint boxes
+void boxDiff(HBox a, HBox const &b, std::vector<HBox> &out)
+{
+	HBox const c = isect(a, b);
+	if (!c.ok()) {
+		out.push_back(a);
+		return;
+	}
+	for (int d = 0; d < 3; ++d) {
+		if (a.lo[d] < c.lo[d]) {
+			HBox p = a;
+			p.hi[d] = c.lo[d] - 1;
+			out.push_back(p);
+			a.lo[d] = c.lo[d];
+		}
+		if (a.hi[d] > c.hi[d]) {
+			HBox p = a;
+			p.lo[d] = c.hi[d] + 1;
+			out.push_back(p);
+			a.hi[d] = c.hi[d];
+		}
+	}
+}
+
+auto floorDiv(int a, int r) -> int { return (a >= 0) ? a / r : -((-a + r - 1) / r); }
+
+// one coarse stencil value of component n, time-interpolated, with PreInterpState applied to the energy
+QK_DEV auto crseValue(RA4 const &Co, RA4 const &Cn, double w_old, double w_new, int i, int j, int k, int n, bool hooks) -> double
+{
+	auto tv = [&](int c) -> double {
+		const double a = Co(i, j, k, c);
+		if (w_new == 0.0) {
+			return a;
+		}
+		return w_old * a + w_new * Cn(i, j, k, c);
+	};
+	if (hooks && n == ENE) {
+		const double rho = tv(RHO), px = tv(MX), py = tv(MY), pz = tv(MZ), Etot = tv(ENE);
+		const double kinetic_energy = (px * px + py * py + pz * pz) / (2.0 * rho);
+		return (Etot - kinetic_energy) / rho;
+	}
+	return tv(n);
+}
+
+__global__ void __launch_bounds__(256) k_interp(const InterpItem *items, qk_array4 *fine_t, const qk_array4 *crse_old_t, const qk_array4 *crse_new_t,
+						double w_old, double w_new, int ncomp, int method, int hooks, int ndim, int r0, int r1, int r2)
+{
+	const InterpItem it = items[blockIdx.y];
+	const int n0 = it.hi[0] - it.lo[0] + 1, n1 = it.hi[1] - it.lo[1] + 1, n2 = it.hi[2] - it.lo[2] + 1;
+	const int64_t ncell = static_cast<int64_t>(n0) * n1 * n2;
+	WA4 F(fine_t[it.fine_box]);
+	RA4 Co(crse_old_t[it.crse_box]);
+	RA4 Cn(crse_new_t[it.crse_box]);
+	const int rr[3] = {r0, r1, r2};
+	for (int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < ncell; t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+		const int kk = static_cast<int>(t / (static_cast<int64_t>(n0) * n1));
+		const int r = static_cast<int>(t - static_cast<int64_t>(kk) * n0 * n1);
+		const int jj = r / n0;
+		const int idx[3] = {it.lo[0] + (r - jj * n0), it.lo[1] + jj, it.lo[2] + kk};
+		int ic[3];
+		double off[3];
+		for (int d = 0; d < 3; ++d) {
+			ic[d] = (idx[d] >= 0) ? idx[d] / rr[d] : -((-idx[d] + rr[d] - 1) / rr[d]);
+			off[d] = (idx[d] - ic[d] * rr[d] + 0.5) / rr[d] - 0.5;
+		}
+		for (int n = 0; n < ncomp; ++n) {
+			const bool hk = (hooks != 0);
+			const double u = crseValue(Co, Cn, w_old, w_new, ic[0], ic[1], ic[2], n, hk);
+			double val = u;
+			if (method == 1) {
+				double s[3] = {0., 0., 0.};
+				double umax = u, umin = u;
+				const int k0 = (ndim == 3) ? -1 : 0, k1 = (ndim == 3) ? 1 : 0;
+				const int j0 = (ndim >= 2) ? -1 : 0, j1 = (ndim >= 2) ? 1 : 0;
+				double nb[3][3][3];
+				for (int c = k0; c <= k1; ++c) {
+					for (int b = j0; b <= j1; ++b) {
+						for (int a = -1; a <= 1; ++a) {
+							const double v = (a == 0 && b == 0 && c == 0) ? u : crseValue(Co, Cn, w_old, w_new, ic[0] + a, ic[1] + b, ic[2] + c, n, hk);
+							nb[c + 1][b + 1][a + 1] = v;
+							umax = smax(umax, v);
+							umin = smin(umin, v);
+						}
+					}
+				}
+				s[0] = 0.5 * (nb[1][1][2] - nb[1][1][0]);
+				if (ndim >= 2) {
+					s[1] = 0.5 * (nb[1][2][1] - nb[1][0][1]);
+				}
+				if (ndim == 3) {
+					s[2] = 0.5 * (nb[2][1][1] - nb[0][1][1]);
+				}
+				double alpha = 1.0;
+				if (s[0] != 0.0 || s[1] != 0.0 || s[2] != 0.0) {
+					const double dumax = fabs(s[0]) * static_cast<double>(rr[0] - 1) / (2.0 * rr[0]) + fabs(s[1]) * static_cast<double>(rr[1] - 1) / (2.0 * rr[1]) +
+							     fabs(s[2]) * static_cast<double>(rr[2] - 1) / (2.0 * rr[2]);
+					if (dumax * alpha > (umax - u)) {
+						alpha = (umax - u) / dumax;
+					}
+					if (dumax * alpha > (u - umin)) {
+						alpha = (u - umin) / dumax;
+					}
+				}
+				val = u + off[0] * (s[0] * alpha) + off[1] * (s[1] * alpha) + off[2] * (s[2] * alpha);
+			}
+			F(idx[0], idx[1], idx[2], n) = val;
+		}
+		if (hooks != 0 && ncomp > ENE) { // PostInterpState on the new fine cell
+			const double rho = F(idx[0], idx[1], idx[2], RHO);
+			const double px = F(idx[0], idx[1], idx[2], MX), py = F(idx[0], idx[1], idx[2], MY), pz = F(idx[0], idx[1], idx[2], MZ);
+			const double e = F(idx[0], idx[1], idx[2], ENE);
+			const double Eint = rho * e;
+			const double kinetic_energy = (px * px + py * py + pz * pz) / (2.0 * rho);
+			F(idx[0], idx[1], idx[2], ENE) = Eint + kinetic_energy;
+		}
+	}
+}
+
+} // namespace
+
+extern "C" {
+
+int qk_interp_plan_create(qk_level *crse, qk_level *fine, const qk_geometry *fine_geom, int nghost, const int ratio[3], int whole_fab, qk_interp_plan **plan)
+{
+	if (crse == nullptr || fine == nullptr || plan == nullptr || ratio == nullptr || fine_geom == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	qk_ctx *ctx = crse->ctx;
+	QK_REQUIRE(ctx, crse->ctx == fine->ctx && crse->ndim == fine->ndim && nghost >= 0, "interp_plan_create: bad argument");
+	auto *P = new qk_interp_plan;
+	P->crse = crse;
+	P->fine = fine;
+	const int ndim = fine->ndim;
+	for (int d = 0; d < 3; ++d) {
+		P->ratio[d] = (d < ndim) ? ratio[d] : 1;
+	}
+	HBox dom{};
+	int len[3];
+	for (int d = 0; d < 3; ++d) {
+		dom.lo[d] = fine_geom->domain.lo[d];
+		dom.hi[d] = fine_geom->domain.hi[d];
+		len[d] = dom.hi[d] - dom.lo[d] + 1;
+	}
+	// fine valid boxes and their periodic images
+	std::vector<HBox> covered;
+	int rng[3];
+	for (int d = 0; d < 3; ++d) {
+		rng[d] = (d < ndim && fine_geom->periodic[d] != 0) ? 1 : 0;
+	}
+	if (whole_fab == 0) {
+		for (int b = 0; b < fine->nboxes; ++b) {
+			for (int sz = -rng[2]; sz <= rng[2]; ++sz) {
+				for (int sy = -rng[1]; sy <= rng[1]; ++sy) {
+					for (int sx = -rng[0]; sx <= rng[0]; ++sx) {
+						HBox v{};
+						const int sh[3] = {sx * len[0], sy * len[1], sz * len[2]};
+						for (int d = 0; d < 3; ++d) {
+							v.lo[d] = fine->boxes[b].lo[d] + sh[d];
+							v.hi[d] = fine->boxes[b].hi[d] + sh[d];
+						}
+						covered.push_back(v);
+					}
+				}
+			}
+		}
+	}
+	for (int b = 0; b < fine->nboxes; ++b) {
+		HBox g{};
+		for (int d = 0; d < 3; ++d) {
+			const int ng = (d < ndim) ? nghost : 0;
+			g.lo[d] = fine->boxes[b].lo[d] - ng;
+			g.hi[d] = fine->boxes[b].hi[d] + ng;
+			if (d < ndim && fine_geom->periodic[d] == 0) { // beyond a physical boundary: PhysBCFunct, not interpolation
+				g.lo[d] = std::max(g.lo[d], dom.lo[d]);
+				g.hi[d] = std::min(g.hi[d], dom.hi[d]);
+			}
+		}
+		std::vector<HBox> todo{g};
+		for (auto const &c : covered) {
+			std::vector<HBox> next;
+			for (auto const &t : todo) {
+				boxDiff(t, c, next);
+			}
+			todo.swap(next);
+		}
+		// cut by the coarse boxes that hold the stencil: valid region first, then (periodic images) the ghost region
+		for (int pass = 0; pass < 2 && !todo.empty(); ++pass) {
+			for (int c = 0; c < crse->nboxes && !todo.empty(); ++c) {
+				HBox rc{}; // fine cells whose coarse cell lies in the coarse valid box (pass 0) / within 2 ghost cells (pass 1)
+				for (int d = 0; d < 3; ++d) {
+					const int g2 = (pass == 1 && d < ndim) ? nghost / P->ratio[d] + ((nghost % P->ratio[d]) != 0 ? 1 : 0) : 0;
+					rc.lo[d] = (crse->boxes[c].lo[d] - g2) * P->ratio[d];
+					rc.hi[d] = (crse->boxes[c].hi[d] + g2) * P->ratio[d] + P->ratio[d] - 1;
+				}
+				std::vector<HBox> rest;
+				for (auto const &t : todo) {
+					HBox const piece = isect(t, rc);
+					if (piece.ok()) {
+						InterpItem it{};
+						it.fine_box = b;
+						it.crse_box = c;
+						for (int d = 0; d < 3; ++d) {
+							it.lo[d] = piece.lo[d];
+							it.hi[d] = piece.hi[d];
+						}
+						P->items.push_back(it);
+						P->max_cells = std::max<int64_t>(P->max_cells, static_cast<int64_t>(piece.hi[0] - piece.lo[0] + 1) * (piece.hi[1] - piece.lo[1] + 1) *
+												       (piece.hi[2] - piece.lo[2] + 1));
+						boxDiff(t, rc, rest);
+					} else {
+						rest.push_back(t);
+					}
+				}
+				todo.swap(rest);
+			}
+		}
+		if (!todo.empty()) {
+			delete P;
+			return setError(ctx, QK_ERR_INVALID, "interp_plan_create: a fine ghost cell has no coarse cell underneath (level not properly nested)");
+		}
+	}
+	if (!P->items.empty() && ctx->device != QK_DEVICE_HOST_PLANNING) {
+		if (hipMalloc(reinterpret_cast<void **>(&P->d_items), sizeof(InterpItem) * P->items.size()) != hipSuccess ||
+		    hipMemcpy(P->d_items, P->items.data(), sizeof(InterpItem) * P->items.size(), hipMemcpyHostToDevice) != hipSuccess) {
+			delete P;
+			return setError(ctx, QK_ERR_HIP, "interp_plan_create: upload failed");
+		}
+	}
+	*plan = P;
+	return QK_OK;
+}
+
+int qk_interp_plan_destroy(qk_interp_plan *plan)
+{
+	if (plan != nullptr) {
+		(void)hipFree(plan->d_items);
+		delete plan;
+	}
+	return QK_OK;
+}
+
+int qk_interp_plan_num_items(qk_interp_plan *plan) { return plan == nullptr ? QK_ERR_INVALID : static_cast<int>(plan->items.size()); }
+
+int qk_interp_plan_item(qk_interp_plan *plan, int idx, int *fine_box, int *crse_box, int lo[3], int hi[3])
+{
+	if (plan == nullptr || idx < 0 || idx >= static_cast<int>(plan->items.size())) {
+		return QK_ERR_INVALID;
+	}
+	auto const &it = plan->items[idx];
+	*fine_box = it.fine_box;
+	*crse_box = it.crse_box;
+	for (int d = 0; d < 3; ++d) {
+		lo[d] = it.lo[d];
+		hi[d] = it.hi[d];
+	}
+	return QK_OK;
+}
+
+int qk_InterpFromCoarse(qk_interp_plan *plan, qk_stream s, qk_array4 *fine_t, const qk_array4 *crse_old_t, const qk_array4 *crse_new_t, double w_old,
+			double w_new, int ncomp, int method, int energy_hooks)
+{
+	if (plan == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	qk_ctx *ctx = plan->crse->ctx;
+	QK_REQUIRE(ctx, fine_t && crse_old_t && crse_new_t && ncomp >= 1, "InterpFromCoarse: bad argument");
+	QK_REQUIRE(ctx, method == 0 || method == 1, "InterpFromCoarse: interpolation method must be 0 (piecewise constant) or 1 (linear, min/max limited)");
+	QK_REQUIRE(ctx, energy_hooks == 0 || ncomp > ENE, "InterpFromCoarse: the energy hooks need the hydro components");
+	if (plan->items.empty()) {
+		return QK_OK;
+	}
+	const dim3 grid(static_cast<unsigned>(std::min<int64_t>((plan->max_cells + 255) / 256, 4096)), static_cast<unsigned>(plan->items.size()), 1);
+	hipLaunchKernelGGL(k_interp, grid, dim3(256), 0, static_cast<hipStream_t>(s), plan->d_items, fine_t, crse_old_t, crse_new_t, w_old, w_new, ncomp, method,
+			   energy_hooks, plan->crse->ndim, plan->ratio[0], plan->ratio[1], plan->ratio[2]);
+	QK_HIP_CHECK(ctx, hipGetLastError());
+	return QK_OK;
+}
+
+} // extern "C"

@@ -99,3 +99,70 @@ def test_pre_post_interp_state(ctx):
         back[4][v[1:]] = (rho * want[4] + ke)[v[1:]]
         assert np.array_equal(post[b], back), f"PostInterpState, box {b}"
         assert np.allclose(post[b][4], U[4], rtol=1e-14)
+
+
+@pytest.mark.parametrize("periodic", [[0, 0, 0], [1, 1, 0]])
+@pytest.mark.parametrize("method,hooks,w", [(1, True, (0.25, 0.75)), (1, False, (1.0, 0.0)), (0, True, (0.5, 0.5))])
+def test_interp_from_coarse_matches_oracle(ctx, oracle, periodic, method, hooks, w):
+    """FillPatchTwoLevels' coarse part on a 2-level hierarchy: 32x16x16 coarse domain in two boxes, three fine boxes (one touching the
+    low-x domain face).  (1) the plan covers every fine ghost cell that is inside the (periodic) domain and under no fine box exactly
+    once; (2) the interpolated values equal the oracle's restatement bit for bit; (3) the mean of the 8 children equals the parent."""
+    from quokka_amd.amr import InterpFromCoarse
+    from quokka_amd.simulation import Geometry
+    from test_hydro_ops_gpu import random_state
+    ng, nc = 4, 6
+    crse_boxes = [([0, 0, 0], [15, 15, 15]), ([16, 0, 0], [31, 15, 15])]
+    fine_boxes = [([0, 8, 8], [15, 23, 23]), ([16, 8, 8], [39, 23, 23]), ([24, 0, 8], [47, 7, 15])]
+    crse, fine = Level(ctx, 3, crse_boxes), Level(ctx, 3, fine_boxes)
+    fgeom = Geometry(3, [64, 32, 32], [0.0] * 3, [2.0, 1.0, 1.0], periodic)
+    plan = InterpFromCoarse(crse, fine, fgeom, ng)
+    items = plan.items()
+    # (1) coverage
+    count = [np.zeros(s[1:], dtype=np.int32) for s in MultiFab(fine, 1, ng).shapes]
+    Uf = MultiFab(fine, nc, ng, fill=-7.0)
+    for fb, cb, lo, hi in items:
+        b0 = Uf.begins[fb]
+        count[fb][lo[2] - b0[2]:hi[2] - b0[2] + 1, lo[1] - b0[1]:hi[1] - b0[1] + 1, lo[0] - b0[0]:hi[0] - b0[0] + 1] += 1
+    dom = [64, 32, 32]
+    for fb, (flo, fhi) in enumerate(fine_boxes):
+        b0 = Uf.begins[fb]
+        kk, jj, ii = np.meshgrid(*[np.arange(b0[d], b0[d] + count[fb].shape[2 - d]) for d in (2, 1, 0)], indexing="ij")
+        idx = [ii, jj, kk]
+        inside = np.ones_like(ii, dtype=bool)
+        for d in range(3):
+            if not periodic[d]:
+                inside &= (idx[d] >= 0) & (idx[d] < dom[d])
+        covered = np.zeros_like(inside)
+        for lo, hi in fine_boxes:
+            for sx in (-1, 0, 1):
+                for sy in (-1, 0, 1):
+                    sh = [sx * dom[0] * periodic[0], sy * dom[1] * periodic[1], 0]
+                    covered |= np.logical_and.reduce([(idx[d] >= lo[d] + sh[d]) & (idx[d] <= hi[d] + sh[d]) for d in range(3)])
+        want = (inside & ~covered).astype(np.int32)
+        assert np.array_equal(count[fb], want), f"fine box {fb}: plan covers {int(count[fb].sum())} cells, expected {int(want.sum())}"
+    # (2) values
+    rng = np.random.default_rng(5)
+    Co, Cn = MultiFab(crse, nc, ng), MultiFab(crse, nc, ng)
+    co_np = [random_state(rng, s[1:]) for s in Co.shapes]
+    cn_np = [a * (1.0 + 0.05 * rng.standard_normal(a.shape)) for a in co_np]
+    for b in range(2):
+        Co.set_fab(b, co_np[b])
+        Cn.set_fab(b, cn_np[b])
+    plan(Uf, Co, Cn, w[0], w[1], nc, method, hooks)
+    torch.cuda.synchronize()
+    want = [np.full(s, -7.0) for s in Uf.shapes]
+    for fb, cb, lo, hi in items:
+        oracle.interp_from_coarse(want[fb], Uf.begins[fb], co_np[cb], cn_np[cb], Co.begins[cb], (lo, hi), w[0], w[1], nc, method, hooks)
+    for fb in range(3):
+        got = Uf.fab_numpy(fb)
+        assert np.array_equal(got, want[fb]), f"fine box {fb}: max diff {np.nanmax(np.abs(got - want[fb]))}"
+    # (3) conservative: density children average to the (time-interpolated) parent
+    fb, cb, lo, hi = max(items, key=lambda it: np.prod([it[3][d] - it[2][d] + 1 for d in range(3)]))
+    if all((hi[d] - lo[d] + 1) >= 2 for d in range(3)):
+        l2 = [lo[d] + (lo[d] % 2) for d in range(3)]
+        b0, c0 = Uf.begins[fb], Co.begins[cb]
+        kids = Uf.fab_numpy(fb)[0, l2[2] - b0[2]:l2[2] - b0[2] + 2, l2[1] - b0[1]:l2[1] - b0[1] + 2, l2[0] - b0[0]:l2[0] - b0[0] + 2]
+        par_o = co_np[cb][0, l2[2] // 2 - c0[2], l2[1] // 2 - c0[1], l2[0] // 2 - c0[0]]
+        par_n = cn_np[cb][0, l2[2] // 2 - c0[2], l2[1] // 2 - c0[1], l2[0] // 2 - c0[0]]
+        parent = par_o if w[1] == 0.0 else w[0] * par_o + w[1] * par_n
+        assert abs(kids.mean() - parent) <= 1e-13 * abs(parent)
