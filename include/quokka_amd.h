@@ -344,6 +344,21 @@ int qk_interp_plan_item(qk_interp_plan *plan, int idx, int *fine_box, int *crse_
 int qk_InterpFromCoarse(qk_interp_plan *plan, qk_stream s, qk_array4 *fine, const qk_array4 *crse_old, const qk_array4 *crse_new, double w_old,
 			double w_new, int ncomp, int method, int energy_hooks);
 
+/* amrex::YAFluxRegister between a coarse level and the next finer one, as driven by AMRSimulation::incrementFluxRegisters
+ * (reference src/simulation.hpp:1345-1387: CrseAdd / FineAdd with the level's fluxes, cell size and dt) and
+ * timeStepWithSubcycling (:1308: Reflux(state_new_cc_[lev])).  Register cells: coarse cells just outside a fine box, not under
+ * another fine box, inside the (periodic) domain.  See qk_amr_fluxreg.hip for the accumulated expression.  Parity unpinned
+ * (AMReX's kernel is restated). */
+typedef struct qk_fluxreg qk_fluxreg;
+int qk_fluxreg_create(qk_level *crse, qk_level *fine, const qk_geometry *crse_geom, const int ratio[3], int ncomp, qk_fluxreg **fr);
+int qk_fluxreg_destroy(qk_fluxreg *fr);
+int qk_fluxreg_num_items(qk_fluxreg *fr);
+int qk_fluxreg_item(qk_fluxreg *fr, int idx, int *dir, int *side, int *fine_box, int *crse_box, int lo[3], int hi[3], int shift[3]);
+int qk_fluxreg_reset(qk_fluxreg *fr, qk_stream s);
+int qk_fluxreg_CrseAdd(qk_fluxreg *fr, qk_stream s, const qk_array4 *const flux[3], const double dx[3], double dt);
+int qk_fluxreg_FineAdd(qk_fluxreg *fr, qk_stream s, const qk_array4 *const flux[3], const double dx_fine[3], double dt);
+int qk_fluxreg_Reflux(qk_fluxreg *fr, qk_stream s, qk_array4 *crse_state);
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,3 +90,52 @@ class InterpFromCoarse:
             self.crse.ctx.L.qk_interp_plan_destroy(self.h)
         except Exception:
             pass
+
+
+class FluxRegister:
+    """amrex::YAFluxRegister between `crse` and the next finer level `fine` (reference src/simulation.hpp:1345-1387, :1308)"""
+
+    def __init__(self, crse: Level, fine: Level, crse_geom, ncomp: int, ratio=(2, 2, 2)):
+        self.crse, self.fine, self.ncomp = crse, fine, ncomp
+        self._geom_c = crse_geom.c_struct()
+        h = C.c_void_p()
+        crse.ctx.check(crse.ctx.L.qk_fluxreg_create(crse.h, fine.h, C.byref(self._geom_c), (C.c_int * 3)(*ratio), ncomp, C.byref(h)), "qk_fluxreg_create")
+        self.h = h
+
+    def items(self):
+        L, out = self.crse.ctx.L, []
+        for idx in range(L.qk_fluxreg_num_items(self.h)):
+            d, sd, fb, cb = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+            lo, hi, sh = (C.c_int * 3)(), (C.c_int * 3)(), (C.c_int * 3)()
+            self.crse.ctx.check(L.qk_fluxreg_item(self.h, idx, C.byref(d), C.byref(sd), C.byref(fb), C.byref(cb), lo, hi, sh), "qk_fluxreg_item")
+            out.append((d.value, sd.value, fb.value, cb.value, list(lo), list(hi), list(sh)))
+        return out
+
+    @staticmethod
+    def _p3(mfs):
+        arr = (C.c_void_p * 3)()
+        for d in range(3):
+            arr[d] = mfs[d].ptr if d < len(mfs) else None
+        return arr
+
+    def reset(self):
+        ctx = self.crse.ctx
+        ctx.check(ctx.L.qk_fluxreg_reset(self.h, ctx.stream()), "qk_fluxreg_reset")
+
+    def CrseAdd(self, flux, dx, dt: float):
+        ctx = self.crse.ctx
+        ctx.check(ctx.L.qk_fluxreg_CrseAdd(self.h, ctx.stream(), self._p3(flux), (C.c_double * 3)(*[float(x) for x in dx]), float(dt)), "qk_fluxreg_CrseAdd")
+
+    def FineAdd(self, flux, dx_fine, dt: float):
+        ctx = self.crse.ctx
+        ctx.check(ctx.L.qk_fluxreg_FineAdd(self.h, ctx.stream(), self._p3(flux), (C.c_double * 3)(*[float(x) for x in dx_fine]), float(dt)), "qk_fluxreg_FineAdd")
+
+    def Reflux(self, crse_state: MultiFab):
+        ctx = self.crse.ctx
+        ctx.check(ctx.L.qk_fluxreg_Reflux(self.h, ctx.stream(), crse_state.ptr), "qk_fluxreg_Reflux")
+
+    def __del__(self):
+        try:
+            self.crse.ctx.L.qk_fluxreg_destroy(self.h)
+        except Exception:
+            pass
