@@ -1,0 +1,434 @@
+"""Block-structured AMR driver over the C-ABI: the level machinery of AMRSimulation / QuokkaSimulation
+
+  timeStepWithSubcycling            reference src/simulation.hpp:1220-1343   (recursive subcycling, refinement ratio 2)
+  regrid / MakeNewLevelFromCoarse / RemakeLevel   :1656-1702 + amrex::AmrCore (ErrorEst -> tags -> grids)
+  FillPatch / fillBoundaryConditions  :1704-1858                             (fine-fine copy + coarse interpolation + physical BCs)
+  incrementFluxRegisters / Reflux / AverageDownTo / FixupState   :1345-1387, :1308, :1949-1964, src/QuokkaSimulation.hpp:761-770
+  computeTimestep over levels        :744-818
+
+Host orchestration only: every cell is touched by a kernel behind include/quokka_amd.h (quokka_amd/amr.py wraps them).
+Grid generation is NOT AMReX's Berger-Rigoutsos clustering (AMReX is not vendored under /root/reference: unpinned): tagged
+cells are buffered by n_error_buf, every blocking_factor-aligned tile that holds a tag is refined, and tiles are merged
+greedily into boxes of at most max_grid_size — valid, properly nested grids, generally more refined cells than AMReX's.
+Single rank (the multi-GPU exchange of GhostExchange covers one level; inter-level transfers across ranks are not built).
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import capi
+from .amr import AverageDown, FluxRegister, InterpFromCoarse
+from .multifab import Context, Level, MultiFab
+from .simulation import NGHOST_CC, Geometry, HydroSimulation, chop_domain
+
+Box = Tuple[List[int], List[int]]
+
+
+# ------------------------------------------------------------------------------------------------ grid generation (host, numpy)
+def dilate(mask: np.ndarray, n: int, ndim: int) -> np.ndarray:
+    """tag buffering (amr.n_error_buf): every cell within n cells (max norm) of a tag; mask is indexed [k, j, i]"""
+    out = mask.copy()
+    for ax in range(3):
+        d = 2 - ax
+        if d >= ndim or n == 0:
+            continue
+        acc = out.copy()
+        for s in range(1, n + 1):
+            sl_to, sl_from = [slice(None)] * 3, [slice(None)] * 3
+            sl_to[ax], sl_from[ax] = slice(s, None), slice(None, -s)
+            acc[tuple(sl_to)] |= out[tuple(sl_from)]
+            acc[tuple(sl_from)] |= out[tuple(sl_to)]
+        out = acc
+    return out
+
+
+def boxes_from_tags(tags: np.ndarray, ndim: int, n_error_buf: int, blocking_factor: int, max_grid_size: int, ratio: int = 2,
+                    allowed: Optional[np.ndarray] = None) -> List[Box]:
+    """tags[k, j, i] (bool, over the coarse level's index space) -> fine boxes (fine index space): buffered tags, blocking-factor tiles,
+    greedy merge.  `allowed` (same shape): coarse cells a fine box may cover (proper nesting); a tile is kept only if it is allowed."""
+    buf = dilate(tags.astype(bool), n_error_buf, ndim)
+    tile = [max(blocking_factor // ratio, 1) if d < ndim else 1 for d in range(3)]  # tile edge in coarse cells
+    nz, ny, nx = buf.shape
+    for d, n in enumerate((nx, ny, nz)):
+        assert n % tile[d] == 0, "domain must be divisible by blocking_factor / ratio"
+    tz, ty, tx = nz // tile[2], ny // tile[1], nx // tile[0]
+    t = buf.reshape(tz, tile[2], ty, tile[1], tx, tile[0]).any(axis=(1, 3, 5))
+    if allowed is not None:
+        t &= allowed.reshape(tz, tile[2], ty, tile[1], tx, tile[0]).all(axis=(1, 3, 5))
+    maxt = [max(max_grid_size // blocking_factor, 1) if d < ndim else 1 for d in range(3)]  # tiles per box edge
+    used = np.zeros_like(t)
+    boxes: List[Box] = []
+    for k in range(tz):
+        for j in range(ty):
+            for i in range(tx):
+                if not t[k, j, i] or used[k, j, i]:
+                    continue
+                i1 = i
+                while i1 + 1 < tx and i1 + 1 - i < maxt[0] and t[k, j, i1 + 1] and not used[k, j, i1 + 1]:
+                    i1 += 1
+                j1 = j
+                while j1 + 1 < ty and j1 + 1 - j < maxt[1] and t[k, j1 + 1, i:i1 + 1].all() and not used[k, j1 + 1, i:i1 + 1].any():
+                    j1 += 1
+                k1 = k
+                while k1 + 1 < tz and k1 + 1 - k < maxt[2] and t[k1 + 1, j:j1 + 1, i:i1 + 1].all() and not used[k1 + 1, j:j1 + 1, i:i1 + 1].any():
+                    k1 += 1
+                used[k:k1 + 1, j:j1 + 1, i:i1 + 1] = True
+                lo = [i * tile[0] * ratio, j * tile[1] * ratio, k * tile[2] * ratio]
+                hi = [(i1 + 1) * tile[0] * ratio - 1, (j1 + 1) * tile[1] * ratio - 1, (k1 + 1) * tile[2] * ratio - 1]
+                for d in range(ndim, 3):
+                    lo[d], hi[d] = 0, 0
+                boxes.append((lo, hi))
+    return boxes
+
+
+def covered_mask(boxes: Sequence[Box], shape) -> np.ndarray:
+    m = np.zeros(shape, dtype=bool)
+    for lo, hi in boxes:
+        m[lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1] = True
+    return m
+
+
+# ------------------------------------------------------------------------------------------------ one level
+class AmrLevelSim(HydroSimulation):
+    """HydroSimulation over the boxes of one AMR level: same advance (fused stages, FOFC, retries); the ghost fill of a refined level
+    adds the coarse -> fine interpolation, and every successful advance feeds the flux registers."""
+
+    def __init__(self, amr: "AmrSimulation", lev: int, boxes: Sequence[Box]):
+        self.amr, self.ilev = amr, lev
+        g0 = amr.geom0
+        geom = Geometry(g0.ndim, [g0.n_cell[d] * (2 ** lev if d < g0.ndim else 1) for d in range(3)], list(g0.prob_lo), list(g0.prob_hi), list(g0.periodic))
+        super().__init__(amr.ctx, geom, amr.traits, amr.bcs, None, amr.dirichlet, boxes=boxes)
+        self.store_flux_rk2 = True
+        self.t_old = self.t_new = 0.0
+        self._fill_time = 0.0
+        self.cf_interp: Optional[InterpFromCoarse] = None
+        self.fluxreg: Optional[FluxRegister] = None  # between level lev-1 and this level
+        self.avgdown: Optional[AverageDown] = None
+        for name in ("cflNumber_", "densityFloor_", "tempFloor_", "reconstructionOrder_", "integratorOrder_", "useDualEnergy_", "abortOnFofcFailure_"):
+            setattr(self, name, getattr(amr, name))
+
+    def link_to_parent(self, parent: "AmrLevelSim"):
+        self.cf_interp = InterpFromCoarse(parent.lev, self.lev, self.geom, NGHOST_CC)
+        self.fluxreg = FluxRegister(parent.lev, self.lev, parent.geom, 6)
+        self.avgdown = AverageDown(parent.lev, self.lev)
+
+    # --- ghost fill (FillPatchTwoLevels)
+    def fillBoundaryConditions(self, state: MultiFab):
+        if self.ilev == 0:
+            super().fillBoundaryConditions(state)
+        else:
+            self.ghost.fill(state, before_physbc=lambda: self._interp_from_parent(state, self._fill_time, self.cf_interp))
+
+    def _interp_from_parent(self, state: MultiFab, time: float, plan: InterpFromCoarse):
+        p = self.amr.levels[self.ilev - 1]
+        t0, t1 = p.t_old, p.t_new
+        eps = 1.0e-10 * max(abs(t1 - t0), 1.0e-300)
+        if abs(time - t1) <= eps or t1 == t0:
+            plan(state, p.state_new_cc_, p.state_new_cc_, 1.0, 0.0, 6, self.amr.amrInterpMethod_, True)
+        elif abs(time - t0) <= eps:
+            plan(state, p.state_old_cc_, p.state_old_cc_, 1.0, 0.0, 6, self.amr.amrInterpMethod_, True)
+        else:  # amrex::FillPatch time interpolation: ((t1 - t) old + (t - t0) new) / (t1 - t0)
+            plan(state, p.state_old_cc_, p.state_new_cc_, (t1 - time) / (t1 - t0), (time - t0) / (t1 - t0), 6, self.amr.amrInterpMethod_, True)
+
+    def _fill_and_stage(self, stage, U_in, U_old, U_out, dt) -> bool:
+        self._fill_time = self._t_adv + (dt if stage == 2 else 0.0)  # reference src/QuokkaSimulation.hpp:1076, :1204
+        return super()._fill_and_stage(stage, U_in, U_old, U_out, dt)
+
+    def advanceHydroAtLevel(self, state_old_tmp: MultiFab, dt_lev: float) -> bool:
+        ok = super().advanceHydroAtLevel(state_old_tmp, dt_lev)
+        if ok:  # incrementFluxRegisters (reference src/QuokkaSimulation.hpp:1303-1306, src/simulation.hpp:1369-1386)
+            amr, l = self.amr, self.ilev
+            if amr.do_reflux and l < amr.finest_level:
+                amr.levels[l + 1].fluxreg.CrseAdd(self.halfFlux, self.geom.dx, dt_lev)
+            if amr.do_reflux and l > 0:
+                self.fluxreg.FineAdd(self.halfFlux, self.geom.dx, dt_lev)
+        self._t_adv += dt_lev
+        return ok
+
+    def advance_level(self, time: float, dt_lev: float) -> bool:
+        """advanceSingleTimestepAtLevel: state_new <- advance(state_old = previous state_new), with the retries of
+        advanceHydroAtLevelWithRetries (reference src/QuokkaSimulation.hpp:885-990); every attempt restarts at `time`"""
+        self._signal_of_state_new = None
+        self.state_old_cc_, self.state_new_cc_ = self.state_new_cc_, self.state_old_cc_
+        for retry_count in range(7):
+            nsubsteps = 2 ** retry_count
+            dt_step = dt_lev / nsubsteps
+            if retry_count > 0:
+                self.counters["retries"] += 1
+            self._t_adv = time
+            old = self.state_old_cc_ if nsubsteps == 1 else self.state_old_tmp
+            if nsubsteps > 1:
+                self.state_old_tmp.copy_from(self.state_old_cc_)
+            success = True
+            for substep in range(nsubsteps):
+                if substep > 0:
+                    for b in range(self.lev.nboxes):
+                        self.state_old_tmp.fabs[b][0:6].copy_(self.state_new_cc_.fabs[b][0:6])
+                success = self.advanceHydroAtLevel(old, dt_step)
+                if not success:
+                    break
+            if success:
+                return True
+        return False
+
+    def FixupState(self):
+        self._limits_and_sync(self.state_new_cc_)
+        self._signal_of_state_new = None
+
+
+# ------------------------------------------------------------------------------------------------ the hierarchy
+class AmrSimulation:
+    def __init__(self, ctx: Context, geom0: Geometry, traits: capi.HydroTraits, bcs, max_level: int, max_grid_size: int = 128, blocking_factor: int = 32,
+                 n_error_buf: int = 3, regrid_int: int = 2, dirichlet=None):
+        assert geom0.ndim == 3, "the AMR driver runs the fused 3-D path"
+        self.ctx, self.geom0, self.traits, self.bcs, self.dirichlet = ctx, geom0, traits, bcs, dirichlet
+        self.max_level, self.max_grid_size, self.blocking_factor = max_level, max_grid_size, blocking_factor
+        self.n_error_buf, self.regrid_int = n_error_buf, regrid_int
+        self.do_reflux, self.do_subcycle = True, True
+        self.amrInterpMethod_ = 1
+        self.cflNumber_, self.densityFloor_, self.tempFloor_ = 0.3, 0.0, 0.0
+        self.reconstructionOrder_, self.integratorOrder_, self.useDualEnergy_, self.abortOnFofcFailure_ = 3, 2, 1, 1
+        self.stopTime_, self.maxTimesteps_ = 1.0, 10 ** 9
+        self.levels: List[AmrLevelSim] = []
+        self.istep = [0] * (max_level + 1)
+        self.last_regrid_step = [0] * (max_level + 1)
+        self.dt_ = [1.0e100] * (max_level + 1)
+        self.tNew_ = 0.0
+        self.cellUpdates_ = 0
+        self.cellUpdatesEachLevel_ = [0] * (max_level + 1)
+        self.ErrorEst: Optional[Callable[["AmrSimulation", int, MultiFab], None]] = None  # (amr, lev, tags) -> sets tags on level lev
+        self.initial_conditions: Optional[Callable] = None  # fn(geom_of_level) -> fn(i, j, k) -> conserved state on index grids
+        self.static_fine_boxes: Optional[List[List[Box]]] = None  # [lev-1] -> boxes of level lev: fixed grids instead of ErrorEst
+
+    @property
+    def finest_level(self) -> int:
+        return len(self.levels) - 1
+
+    def CountCells(self, lev: int) -> int:
+        return self.levels[lev].CountCells()
+
+    # ------------------------------------------------------------------ hierarchy construction
+    def _tags_on_level(self, lev: int) -> np.ndarray:
+        from .amr import TagBoxArray
+        for l in range(lev + 1):  # ghost cells of every level up to lev (a refined level interpolates from its parent's ghost-filled state)
+            self.levels[l]._fill_time = self.levels[l].t_new
+            self.levels[l].fillBoundaryConditions(self.levels[l].state_new_cc_)
+        L = self.levels[lev]
+        tags = TagBoxArray(L.lev)
+        self.ErrorEst(self, lev, tags)
+        n = L.geom.n_cell
+        dense = np.zeros((n[2], n[1], n[0]), dtype=bool)
+        for b, (lo, hi) in enumerate(L.my_boxes):
+            dense[lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1] = tags.fab_numpy(b)[0] == capi.TAG_SET
+        return dense
+
+    def _new_grids(self, lev: int, finer_boxes: Optional[List[Box]]) -> List[Box]:
+        """boxes of level lev+1 from the tags on level lev (+ the cells under an already chosen level lev+2, buffered: proper nesting)"""
+        if self.static_fine_boxes is not None:
+            return self.static_fine_boxes[lev] if lev < len(self.static_fine_boxes) else []
+        L = self.levels[lev]
+        tags = self._tags_on_level(lev)
+        if finer_boxes:  # level lev+2 boxes -> coarsen twice, buffer so that their ghost + stencil region stays inside level lev+1
+            m = covered_mask([([l // 4 for l in lo], [h // 4 for h in hi]) for lo, hi in finer_boxes], tags.shape)
+            tags |= dilate(m, 2, 3)
+        allowed = None
+        if lev > 0:  # a fine box (and its 2-coarse-cell ghost reach + 1 stencil cell) must sit on level-lev cells or beyond the domain
+            n = L.geom.n_cell
+            cov = np.ones((n[2] + 8, n[1] + 8, n[0] + 8), dtype=bool)  # padded: outside the domain counts as available
+            cov[4:-4, 4:-4, 4:-4] = covered_mask(L.my_boxes, (n[2], n[1], n[0]))
+            allowed = ~dilate(~cov, 4, 3)[4:-4, 4:-4, 4:-4]
+        return boxes_from_tags(tags, 3, self.n_error_buf, self.blocking_factor, self.max_grid_size, 2, allowed)
+
+    def _make_level(self, lev: int, boxes: List[Box]) -> AmrLevelSim:
+        L = AmrLevelSim(self, lev, boxes)
+        if lev > 0:
+            L.link_to_parent(self.levels[lev - 1])
+        return L
+
+    def setInitialConditions(self):
+        """AmrCore::InitFromScratch: level 0, then finer levels from the tags of the initial conditions (MakeNewLevelFromScratch uses
+        the problem's initial conditions on every level, reference src/simulation.hpp:1656-1702), then AverageDown"""
+        g0 = self.geom0
+        self.levels = [self._make_level(0, chop_domain(g0.n_cell, [self.max_grid_size] * 3))]
+        self._set_level_ic(0)
+        for lev in range(self.max_level):
+            boxes = self._new_grids(lev, None)
+            if not boxes:
+                break
+            self.levels.append(self._make_level(lev + 1, boxes))
+            self._set_level_ic(lev + 1)
+        for lev in range(self.finest_level - 1, -1, -1):
+            self.AverageDownTo(lev)
+
+    def _set_level_ic(self, lev: int):
+        L = self.levels[lev]
+        fn = self.initial_conditions(L.geom)
+        for b, (lo, hi) in enumerate(L.my_boxes):
+            k, j, i = np.meshgrid(np.arange(lo[2], hi[2] + 1), np.arange(lo[1], hi[1] + 1), np.arange(lo[0], hi[0] + 1), indexing="ij")
+            L.state_new_cc_.valid(b).copy_(torch.from_numpy(np.ascontiguousarray(fn(i, j, k))))
+        L.state_old_cc_.copy_from(L.state_new_cc_)
+        L.t_old = L.t_new = self.tNew_
+
+    def regrid(self, base: int):
+        """amrex::AmrCore::regrid(base, time): new grids for levels base+1 .. ; data from the old level where it exists, interpolated from
+        the coarser level elsewhere (RemakeLevel / MakeNewLevelFromCoarse, reference src/simulation.hpp:1656-1702)"""
+        if self.static_fine_boxes is not None:
+            return
+        new_boxes: dict = {}
+        top = min(self.finest_level + 1, self.max_level)
+        finer = None
+        for lev in range(top - 1, base - 1, -1):  # finest first, so that coarser levels can enclose the finer ones
+            if lev > self.finest_level:
+                continue
+            boxes = self._new_grids(lev, finer if lev + 2 <= self.max_level else None)
+            new_boxes[lev + 1] = boxes
+            finer = boxes if boxes else None
+        for lev in range(base + 1, self.max_level + 1):
+            boxes = new_boxes.get(lev, [])
+            if not boxes:
+                del self.levels[lev:]
+                break
+            old = self.levels[lev] if lev <= self.finest_level else None
+            if old is not None and sorted(map(str, old.my_boxes)) == sorted(map(str, boxes)):
+                continue
+            new = self._make_level(lev, boxes)
+            parent = self.levels[lev - 1]
+            parent._fill_time = parent.t_new
+            parent.fillBoundaryConditions(parent.state_new_cc_)
+            whole = InterpFromCoarse(parent.lev, new.lev, new.geom, NGHOST_CC, whole_fab=True)
+            whole(new.state_new_cc_, parent.state_new_cc_, parent.state_new_cc_, 1.0, 0.0, 6, self.amrInterpMethod_, True)
+            if old is not None:
+                _copy_overlap(old.state_new_cc_, old.my_boxes, new.state_new_cc_, new.my_boxes)
+            new.state_old_cc_.copy_from(new.state_new_cc_)
+            new.t_old, new.t_new = parent.t_new, parent.t_new
+            new.dt_ = old.dt_ if old is not None else 1.0e100
+            if lev <= self.finest_level:
+                self.levels[lev] = new
+            else:
+                self.levels.append(new)
+            if lev + 1 <= self.finest_level:  # the child of a remade level keeps its grids but needs new inter-level plans
+                self.levels[lev + 1].link_to_parent(new)
+
+    # ------------------------------------------------------------------ inter-level operators
+    def AverageDownTo(self, crse_lev: int):
+        f = self.levels[crse_lev + 1]
+        f.avgdown(f.state_new_cc_, self.levels[crse_lev].state_new_cc_, 0, 6)
+
+    # ------------------------------------------------------------------ time stepping
+    def computeTimestep(self):
+        """reference src/simulation.hpp:744-818 with do_subcycle = 1: dt_0 = min_l (n_factor_l * dt_cfl_l), growth <= 1.1x, dt_l = dt_0 / 2^l"""
+        dt_tmp = [self.levels[l].computeTimestepAtLevel() for l in range(self.finest_level + 1)]
+        dt_0, n_factor = dt_tmp[0], 1
+        for l in range(self.finest_level + 1):
+            if l > 0:
+                n_factor *= 2
+            dt_tmp[l] = min(dt_tmp[l], 1.1 * self.dt_[l])
+            dt_0 = min(dt_0, n_factor * dt_tmp[l])
+        eps = 1.0e-3 * dt_0
+        if self.tNew_ + dt_0 > self.stopTime_ - eps:
+            dt_0 = self.stopTime_ - self.tNew_
+        self.dt_[0] = dt_0
+        for l in range(1, self.max_level + 1):
+            self.dt_[l] = self.dt_[l - 1] / 2.0
+
+    def timeStepWithSubcycling(self, lev: int, time: float):
+        if self.regrid_int > 0 and lev < self.max_level and self.istep[lev] > self.last_regrid_step[lev] and self.istep[lev] % self.regrid_int == 0:
+            self.regrid(lev)
+            for k in range(lev, self.finest_level + 1):
+                self.last_regrid_step[k] = self.istep[k]
+        L = self.levels[lev]
+        L.t_old = L.t_new
+        L.t_new = L.t_new + self.dt_[lev]
+        if self.do_reflux and lev < self.finest_level:
+            self.levels[lev + 1].fluxreg.reset()
+        if not L.advance_level(time, self.dt_[lev]):
+            raise capi.QkError(f"QUOKKA FATAL ERROR: Hydro update exceeded max_retries on level {lev}")
+        self.istep[lev] += 1
+        self.cellUpdates_ += self.CountCells(lev)
+        self.cellUpdatesEachLevel_[lev] += self.CountCells(lev)
+        if lev < self.finest_level:
+            # the children interpolate their ghost cells from this level's old and new states: both need their own ghost cells
+            for st, t in ((L.state_old_cc_, L.t_old), (L.state_new_cc_, L.t_new)):
+                L._fill_time = t
+                L.fillBoundaryConditions(st)
+            for i in range(2):
+                if lev < self.finest_level:
+                    self.timeStepWithSubcycling(lev + 1, time + i * self.dt_[lev + 1])
+            if lev < self.finest_level:
+                if self.do_reflux:
+                    self.levels[lev + 1].fluxreg.Reflux(L.state_new_cc_)
+                self.AverageDownTo(lev)
+                L.FixupState()
+
+    def step(self):
+        self.computeTimestep()
+        self.timeStepWithSubcycling(0, self.tNew_)
+        self.tNew_ += self.dt_[0]
+
+    def evolve(self):
+        while self.istep[0] < self.maxTimesteps_ and self.tNew_ < self.stopTime_:
+            self.step()
+            if self.tNew_ >= self.stopTime_ - 1.0e-6 * self.dt_[0]:
+                break
+
+    # ------------------------------------------------------------------ diagnostics
+    def composite_sum(self, comp: int) -> float:
+        """volume integral of a conserved component over the composite grid (cells under a finer level are not counted)"""
+        total = 0.0
+        for l, L in enumerate(self.levels):
+            vol = L.geom.dx[0] * L.geom.dx[1] * L.geom.dx[2]
+            n = L.geom.n_cell
+            mask = np.ones((n[2], n[1], n[0]), dtype=bool)
+            if l < self.finest_level:
+                mask &= ~covered_mask([([x // 2 for x in lo], [x // 2 for x in hi]) for lo, hi in self.levels[l + 1].my_boxes], mask.shape)
+            for b, (lo, hi) in enumerate(L.my_boxes):
+                v = L.state_new_cc_.valid(b)[comp].cpu().numpy()
+                total += float((v * mask[lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1]).sum()) * vol
+        return total
+
+
+def _copy_overlap(src: MultiFab, src_boxes, dst: MultiFab, dst_boxes):
+    """valid cells of the old level that the new level still covers (RemakeLevel: FillPatch copies the fine data where it exists)"""
+    for sb, (slo, shi) in enumerate(src_boxes):
+        for db, (dlo, dhi) in enumerate(dst_boxes):
+            lo = [max(slo[d], dlo[d]) for d in range(3)]
+            hi = [min(shi[d], dhi[d]) for d in range(3)]
+            if any(lo[d] > hi[d] for d in range(3)):
+                continue
+            s0, d0 = src.begins[sb], dst.begins[db]
+            dst.fabs[db][:, lo[2] - d0[2]:hi[2] - d0[2] + 1, lo[1] - d0[1]:hi[1] - d0[1] + 1, lo[0] - d0[0]:hi[0] - d0[0] + 1] = \
+                src.fabs[sb][:, lo[2] - s0[2]:hi[2] - s0[2] + 1, lo[1] - s0[1]:hi[1] - s0[1] + 1, lo[0] - s0[0]:hi[0] - s0[0] + 1]
+
+
+def sedov_amr_problem(ctx: Context, n: int, max_level: int, max_grid_size: int = 128, blocking_factor: int = 32, static_fine_boxes=None) -> AmrSimulation:
+    """reference src/problems/HydroBlast3D/test_hydro3d_blast.cpp + tests/blast_amr_maxlev2.in (BASELINE config 5)"""
+    geom = Geometry(3, [n, n, n], [0.0, 0.0, 0.0], [1.2, 1.2, 1.2], [0, 0, 0])
+    bcs = []
+    for c in range(6):
+        lo = [capi.BC_REFLECT_ODD if c == 1 + d else capi.BC_REFLECT_EVEN for d in range(3)]
+        bcs.append((lo, list(lo)))
+    amr = AmrSimulation(ctx, geom, capi.traits(1.4, False, 3), bcs, max_level, max_grid_size, blocking_factor)
+    amr.static_fine_boxes = static_fine_boxes
+    E_blast = 0.851072 / 8.0
+
+    def ic_for(geom_l: Geometry):
+        cell_vol = geom_l.dx[0] * geom_l.dx[1] * geom_l.dx[2]
+
+        def ic(i, j, k):
+            U = np.zeros((6,) + i.shape)
+            U[0] = 1.0
+            U[4] = np.where((i == 0) & (j == 0) & (k == 0), E_blast / cell_vol, 1.0e-10 * (E_blast / cell_vol))
+            return U
+        return ic
+
+    def error_est(a: AmrSimulation, lev: int, tags: MultiFab):  # test_hydro3d_blast.cpp:118-151
+        from .amr import tag_relative_gradient
+        L = a.levels[lev]
+        tag_relative_gradient(L.lev, L.traits, L.state_new_cc_, tags, capi.TAGFIELD_PRESSURE, 0.1, 1.0e-3, False)
+
+    amr.initial_conditions, amr.ErrorEst = ic_for, error_est
+    amr.setInitialConditions()
+    return amr

@@ -66,6 +66,7 @@ struct SweepArgs {
 	double K_visc;
 	int use_dual_energy;
 	bool reconstruct_eint;
+	bool store_rk2; // stage 2: write flux_rk2 back over F1
 };
 
 QK_DEV auto sarr(SweepArgs const &a, int comp) -> double * { return a.scratch + static_cast<int64_t>(comp) * a.total_cells; }
@@ -361,8 +362,8 @@ template <int ORDER, int STAGE> __global__ void __launch_bounds__(XB) k_sweep_x(
 		}
 	} else {
 		if (isFace) {
-			RA4 HF(a.halfFlux[b]);
-			RA4 HV(a.halfVel[b]);
+			WA4 HF(a.halfFlux[b]);
+			WA4 HV(a.halfVel[b]);
 			const int64_t o = HF.idx(i, j, k);
 			// flux_rk2 = (0 + 0.5 F1) + 0.5 F2   (QuokkaSimulation.hpp:1106, :1220)
 #pragma unroll
@@ -370,6 +371,13 @@ template <int ORDER, int STAGE> __global__ void __launch_bounds__(XB) k_sweep_x(
 				F[n] = 0.5 * HF.p[o + HF.ns * n] + 0.5 * F[n];
 			}
 			vf = 0.5 * HV(i, j, k) + 0.5 * vf;
+			if (a.store_rk2) {
+#pragma unroll
+				for (int n = 0; n < NVAR; ++n) {
+					HF.p[o + HF.ns * n] = F[n];
+				}
+				HV(i, j, k) = vf;
+			}
 		}
 	}
 	__syncthreads(); // everyone is done with s_q (primitives)
@@ -481,14 +489,21 @@ template <int DIR, int ORDER, int STAGE, bool LAST> __global__ void __launch_bou
 					HV(fidx[0], fidx[1], fidx[2]) = vf;
 				}
 			} else {
-				RA4 HF(a.halfFlux[b]);
-				RA4 HV(a.halfVel[b]);
+				WA4 HF(a.halfFlux[b]);
+				WA4 HV(a.halfVel[b]);
 				const int64_t o = HF.idx(fidx[0], fidx[1], fidx[2]);
 #pragma unroll
 				for (int n = 0; n < NVAR; ++n) {
 					F[n] = 0.5 * HF.p[o + HF.ns * n] + 0.5 * F[n];
 				}
 				vf = 0.5 * HV(fidx[0], fidx[1], fidx[2]) + 0.5 * vf;
+				if (a.store_rk2 && live) {
+#pragma unroll
+					for (int n = 0; n < NVAR; ++n) {
+						HF.p[o + HF.ns * n] = F[n];
+					}
+					HV(fidx[0], fidx[1], fidx[2]) = vf;
+				}
 			}
 			if (step >= 6) {
 				// update cell u = cc - 1 (march coordinate lo + step - 6)
@@ -705,6 +720,7 @@ int qk_hydro_stage_fused(qk_level *lev, qk_stream stream, const qk_hydro_traits 
 	a.K_visc = args->K_visc;
 	a.use_dual_energy = args->use_dual_energy;
 	a.reconstruct_eint = re;
+	a.store_rk2 = (args->store_flux_rk2 != 0);
 
 #define QK_LAUNCH(ORDER)                                                                                                                             \
 	if (args->stage == 1) {                                                                                                                      \

@@ -123,7 +123,7 @@ class GhostExchange:
             ctx.check(L.qk_ghost_plan_peer(h, k, C.byref(r), C.byref(ns), C.byref(nr)), "qk_ghost_plan_peer")
             self.peers.append((k, r.value, torch.empty(ns.value, dtype=dtype, device=ctx.device), torch.empty(nr.value, dtype=dtype, device=ctx.device)))
 
-    def fill(self, state: MultiFab, between=None):
+    def fill(self, state: MultiFab, between=None, before_physbc=None):
         """The product path: every copy is a HIP kernel behind the C-ABI.  `between` (optional) is called while the strips
         of the peers are on the wire, after the boxes that do not depend on them have been completed."""
         ctx = self.lev.ctx
@@ -142,9 +142,9 @@ class GhostExchange:
         def physbc(which):
             ctx.check(L.qk_FillPhysicalBoundary_subset(self.h, s, state.ptr, self.bcs, self.dirichlet, which), "FillPhysicalBoundary")
 
-        self.fill_with(pack, local, unpack, physbc, between)
+        self.fill_with(pack, local, unpack, physbc, between, before_physbc)
 
-    def fill_with(self, pack, local, unpack, physbc, between=None):
+    def fill_with(self, pack, local, unpack, physbc, between=None, before_physbc=None):
         """Exchange protocol, independent of who moves the bytes inside a rank (HIP kernels in the product; numpy in the
         world_size-2 gloo tests): pack -> one send/recv pair per peer -> same-rank copies while the wire is busy
         [-> physical boundaries of the boxes without remote ghosts -> between()] -> wait -> unpack -> (remaining) physical
@@ -171,6 +171,9 @@ class GhostExchange:
             q.wait()
         for k, r, sbuf, rbuf in self.peers:
             unpack(k, rbuf)
+        if before_physbc is not None:  # AMR: coarse -> fine interpolation of the ghost cells no fine box covers (FillPatchTwoLevels)
+            assert between is None
+            before_physbc()
         if bc:
             physbc(capi.BOXES_REMOTE_DEPENDENT if between is not None else capi.BOXES_ALL)
 
@@ -204,7 +207,7 @@ class HydroSimulation:
     """QuokkaSimulation<problem_t> for a hydro-only, uniform-grid problem."""
 
     def __init__(self, ctx: Context, geom: Geometry, traits: capi.HydroTraits, bcs, max_grid_size=None, dirichlet=None,
-                 rank: int = 0, nranks: int = 1, use_fused: bool = True, ncomp_cc: int = 6):
+                 rank: int = 0, nranks: int = 1, use_fused: bool = True, ncomp_cc: int = 6, boxes=None):
         self.ctx, self.geom, self.traits = ctx, geom, traits
         self.rank, self.nranks = rank, nranks
         self.hydro = HydroSystem(traits)
@@ -213,7 +216,8 @@ class HydroSimulation:
         mgs = (mgs + [1, 1, 1])[:3]
         for d in range(geom.ndim, 3):
             mgs[d] = 1
-        self.all_boxes = chop_domain(geom.n_cell, mgs)
+        # `boxes`: an explicit BoxArray (a refined AMR level, which does not cover the domain) instead of the chopped domain
+        self.all_boxes = [(list(lo), list(hi)) for lo, hi in boxes] if boxes is not None else chop_domain(geom.n_cell, mgs)
         self.owner = distribute_boxes(self.all_boxes, nranks, geom.n_cell, mgs) if nranks > 1 else [0] * len(self.all_boxes)
         self.my_boxes = [b for b, o in zip(self.all_boxes, self.owner) if o == rank]
         assert self.my_boxes, "rank owns no boxes"
@@ -431,6 +435,10 @@ class HydroSimulation:
             if nbad > 0 and self.abortOnFofcFailure_ != 0:
                 return False
         self._limits_and_sync(U_out)
+        if stage == 2 and getattr(self, "store_flux_rk2", False):
+            for d in range(nd):  # what the flux registers accumulate (possibly FOFC-corrected), as the fused stage leaves it
+                self.halfFlux[d].copy_from(fl[d])
+                self.halfVel[d].copy_from(vl[d])
         return True
 
     def _is_final(self, stage: int) -> bool:
@@ -460,6 +468,7 @@ class HydroSimulation:
         a.scratch_bytes = self.scratch.numel() * 8
         a.dt, a.stage, a.reconstruction_order = dt, stage, self.reconstructionOrder_
         a.densityFloor, a.tempFloor, a.use_dual_energy, a.K_visc = self.densityFloor_, self.tempFloor_, self.useDualEnergy_, 0.0
+        a.store_flux_rk2 = int(getattr(self, "store_flux_rk2", False))
         c = self.ctx
         c.check(c.L.qk_hydro_stage_fused(lev.h, c.stream(), C.byref(self.traits), C.byref(a)), "qk_hydro_stage_fused")
 

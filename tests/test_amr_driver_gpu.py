@@ -1,0 +1,90 @@
+"""The AMR level machinery end to end (quokka_amd/amr_simulation.py) through size-independent properties: a refined level that covers
+the whole domain must reproduce the uniform fine-grid run bit for bit (subcycling, level bookkeeping, fine-fine fill, average-down);
+with partial refinement the composite mass and energy are conserved to rounding only if the flux registers do their job."""
+import numpy as np
+import pytest
+import torch
+
+from quokka_amd.amr_simulation import boxes_from_tags, sedov_amr_problem
+from quokka_amd.simulation import chop_domain, sedov_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def test_full_coverage_equals_uniform_fine_run(ctx):
+    """level 1 = the whole domain at twice the resolution (static grids): its evolution is the uniform 32^3 run driven with the same
+    time steps, and level 0 is the average of its children after every coarse step"""
+    N = 16
+    fine_boxes = chop_domain([2 * N] * 3, [16] * 3)
+    amr = sedov_amr_problem(ctx, N, 1, max_grid_size=16, blocking_factor=8, static_fine_boxes=[fine_boxes])
+    assert amr.finest_level == 1 and amr.levels[1].cf_interp.items() == [] and amr.levels[1].fluxreg.items() == []
+    uni = sedov_problem(ctx, 2 * N, max_grid_size=16)
+    f = amr.levels[1]
+    for b in range(f.lev.nboxes):
+        assert np.array_equal(f.state_new_cc_.valid(b).cpu().numpy(), uni.state_new_cc_.valid(b).cpu().numpy())
+    for it in range(4):
+        amr.step()
+        for _ in range(2):
+            assert uni.step(amr.dt_[1])
+        for b in range(f.lev.nboxes):
+            assert np.array_equal(f.state_new_cc_.valid(b).cpu().numpy(), uni.state_new_cc_.valid(b).cpu().numpy()), f"step {it}, box {b}"
+    assert amr.tNew_ == uni.tNew_ or abs(amr.tNew_ - uni.tNew_) <= 4e-16 * amr.tNew_
+    # coarse level = conservative average of the fine level (then FixupState, which only acts on floors / dual energy)
+    c = amr.levels[0]
+    fine = np.zeros((6, 2 * N, 2 * N, 2 * N))
+    for (lo, hi), v in zip(f.my_boxes, f.gather_valid_local()):
+        fine[:, lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1] = v
+    crse = np.zeros((6, N, N, N))
+    for (lo, hi), v in zip(c.my_boxes, c.gather_valid_local()):
+        crse[:, lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1] = v
+    avg = fine.reshape(6, N, 2, N, 2, N, 2).mean(axis=(2, 4, 6))
+    assert np.allclose(crse[:4], avg[:4], rtol=1e-13, atol=1e-300)
+
+
+@pytest.mark.parametrize("reflux", [True, False])
+def test_partial_refinement_conserves_with_reflux(ctx, reflux):
+    """static 2-level hierarchy: the blast corner refined (32^3 fine cells over the 16^3 coarse corner of a 32^3 domain), reflecting
+    walls.  With the flux registers the composite mass and total energy stay constant to rounding while the shock crosses the
+    coarse-fine interface; without Reflux they drift by orders of magnitude more."""
+    N = 32
+    amr = sedov_amr_problem(ctx, N, 1, max_grid_size=32, blocking_factor=16, static_fine_boxes=[[([0, 0, 0], [31, 31, 31])]])
+    amr.do_reflux = reflux
+    assert len(amr.levels[1].cf_interp.items()) > 0 and len(amr.levels[1].fluxreg.items()) == 3
+    m0, e0 = amr.composite_sum(0), amr.composite_sum(4)
+    for _ in range(30):
+        amr.step()
+    m1, e1 = amr.composite_sum(0), amr.composite_sum(4)
+    # the blast must have reached the interface for the test to mean anything
+    c = amr.levels[0]
+    outside = max(float(c.state_new_cc_.valid(b)[1:4].abs().max().item()) for b in range(c.lev.nboxes))
+    assert outside > 1e-3, outside
+    dm, de = abs(m1 - m0) / m0, abs(e1 - e0) / e0
+    if reflux:
+        assert dm <= 5e-14 and de <= 5e-14, (dm, de)
+    else:
+        assert max(dm, de) > 1e-11, (dm, de)  # (observed: the mass drifts by ~1e-9)
+
+
+def test_dynamic_regrid_tracks_the_blast(ctx):
+    """ErrorEst-driven grids (pressure-gradient tags of HydroBlast3D, n_error_buf 3, blocking factor 8): the refined region follows the
+    shock, every tagged cell is refined, grids stay inside the domain and disjoint, mass and energy are conserved across regrids"""
+    N = 32
+    amr = sedov_amr_problem(ctx, N, 1, max_grid_size=32, blocking_factor=8)
+    assert amr.finest_level == 1
+    m0, e0 = amr.composite_sum(0), amr.composite_sum(4)
+    grids = [sorted(map(str, amr.levels[1].my_boxes))]
+    for _ in range(12):
+        amr.step()
+        grids.append(sorted(map(str, amr.levels[1].my_boxes)))
+    assert any(g != grids[0] for g in grids[1:]), "the grids never changed"
+    boxes = amr.levels[1].my_boxes
+    cov = np.zeros((2 * N,) * 3, dtype=np.int32)
+    for lo, hi in boxes:
+        assert all(0 <= lo[d] and hi[d] < 2 * N and lo[d] % 8 == 0 and (hi[d] + 1) % 8 == 0 for d in range(3))
+        cov[lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1] += 1
+    assert cov.max() == 1
+    tags = amr._tags_on_level(0)
+    refined = cov.reshape(N, 2, N, 2, N, 2).max(axis=(1, 3, 5)) > 0
+    assert tags.sum() > 0 and not (tags & ~refined).any(), "a tagged cell is not refined"
+    m1, e1 = amr.composite_sum(0), amr.composite_sum(4)
+    assert abs(m1 - m0) / m0 <= 1e-13 and abs(e1 - e0) / e0 <= 1e-13, (abs(m1 - m0) / m0, abs(e1 - e0) / e0)
