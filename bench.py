@@ -43,8 +43,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--ncell", type=int, default=256, help="cells per dimension PER GPU (256 = blast_unigrid_256.in)")
     ap.add_argument("--max-grid-size", type=int, default=128)
-    ap.add_argument("--workload", choices=["sedov", "shell"], default="sedov",
-                    help="sedov = BASELINE metric (default); shell = RadhydroShell 256^3 radiation-hydro (BASELINE config 4), reported as a secondary line")
+    ap.add_argument("--workload", choices=["sedov", "shell", "amr"], default="sedov",
+                    help="sedov = BASELINE metric (default); shell = RadhydroShell 256^3 radiation-hydro (BASELINE config 4) and amr = Sedov with "
+                         "max_level 2 (BASELINE config 5 geometry), each reported as a secondary line")
     ap.add_argument("--pow-mode", type=int, default=1, help="shell workload: 0 = libm pow(T,4) as the reference's std::pow, 1 = repeated multiplication")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-ncell", type=int, default=128)
@@ -119,6 +120,26 @@ def main():
 
     ctx = Context(local_rank)
     n_cell = weak_scaled_cells(args.ncell, world)
+    if args.workload == "amr":
+        from quokka_amd.amr_simulation import sedov_amr_problem
+        assert world == 1, "the AMR line is single-GPU (inter-level transfers across ranks are not built)"
+        amr = sedov_amr_problem(ctx, args.ncell, 2, max_grid_size=128, blocking_factor=32)
+        for _ in range(args.warmup):
+            amr.step()
+        torch.cuda.synchronize()
+        u0, t0 = amr.cellUpdates_, time.perf_counter()
+        for _ in range(args.steps):
+            amr.step()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        print(json.dumps({"metric": "Mcell-updates/s on 3D Sedov AMR (sum over levels, subcycled)", "value": (amr.cellUpdates_ - u0) / elapsed / 1e6,
+                          "unit": "Mcell-updates/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                          "dtype": "f64", "data": "synthetic",
+                          "config": {"workload": f"3D Sedov blast {args.ncell}^3 base grid, max_level 2, blocking_factor 32, max_grid_size 128 "
+                                                 "(tests/blast_amr_maxlev2.in), subcycling + reflux, tile clustering instead of Berger-Rigoutsos",
+                                     "boxes_per_level": [L.lev.nboxes for L in amr.levels], "cells_per_level": [amr.CountCells(l) for l in range(amr.finest_level + 1)],
+                                     "sim_time": amr.tNew_}}))
+        return
     if args.workload == "shell":
         import numpy as np
         from quokka_amd.radhydro import shell_problem

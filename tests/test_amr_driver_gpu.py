@@ -88,3 +88,26 @@ def test_dynamic_regrid_tracks_the_blast(ctx):
     assert tags.sum() > 0 and not (tags & ~refined).any(), "a tagged cell is not refined"
     m1, e1 = amr.composite_sum(0), amr.composite_sum(4)
     assert abs(m1 - m0) / m0 <= 1e-13 and abs(e1 - e0) / e0 <= 1e-13, (abs(m1 - m0) / m0, abs(e1 - e0) / e0)
+
+
+def test_three_levels_nested_and_conservative(ctx):
+    """max_level = 2 as in BASELINE config 5 (tests/blast_amr_maxlev2.in), small: level 2 nests inside level 1 with room for its ghost
+    cells and interpolation stencil, both finer levels follow the blast, the composite mass and energy are conserved"""
+    N = 32
+    amr = sedov_amr_problem(ctx, N, 2, max_grid_size=32, blocking_factor=8)
+    assert amr.finest_level == 2, amr.finest_level
+    m0, e0 = amr.composite_sum(0), amr.composite_sum(4)
+    for _ in range(8):
+        amr.step()
+    assert amr.finest_level == 2
+    assert amr.istep == [8, 16, 32]
+    l1 = np.zeros((2 * N,) * 3, dtype=bool)
+    for lo, hi in amr.levels[1].my_boxes:
+        l1[lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1] = True
+    for lo, hi in amr.levels[2].my_boxes:  # level-2 box grown by its ghost cells (4 fine = 2 level-1 cells) + 1 stencil cell, clipped to the domain
+        c_lo = [max(lo[d] // 2 - 3, 0) for d in range(3)]
+        c_hi = [min(hi[d] // 2 + 3, 2 * N - 1) for d in range(3)]
+        assert l1[c_lo[2]:c_hi[2] + 1, c_lo[1]:c_hi[1] + 1, c_lo[0]:c_hi[0] + 1].all(), (lo, hi)
+    m1, e1 = amr.composite_sum(0), amr.composite_sum(4)
+    assert abs(m1 - m0) / m0 <= 2e-13 and abs(e1 - e0) / e0 <= 2e-13, (abs(m1 - m0) / m0, abs(e1 - e0) / e0)
+    assert amr.cellUpdatesEachLevel_[2] > 0
