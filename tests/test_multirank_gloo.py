@@ -163,3 +163,39 @@ def test_overlapped_fill_completes_local_boxes_early(world):
     for rank, ok, nbad, npeers, n_early in res:
         assert ok, f"rank {rank}: {nbad} ghost cells differ from the single-process fill"
     assert sum(r[4] for r in res) > 0, "no rank had an early (remote-independent) box"
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_bench_geometry_plans_are_consistent(world):
+    """the exact decomposition bench.py uses at N GPUs (256^3 cells per GPU in 128^3 boxes, bricks of 8 boxes): every box owned once,
+    8 boxes per rank, at most 7 peers, and for every pair of ranks what one side packs is what the other side expects (counts per
+    peer and the ordered list of strips, which fixes the wire format)"""
+    import bench
+    from quokka_amd import capi
+    from quokka_amd.multifab import Level, PlanningContext
+    from quokka_amd.simulation import GhostExchange, Geometry, chop_domain, distribute_boxes
+    n_cell = bench.weak_scaled_cells(256, world)
+    geom = Geometry(3, n_cell, [0.0] * 3, [1.2 * n_cell[d] / 256 for d in range(3)], [0, 0, 0])
+    boxes = chop_domain(n_cell, [128] * 3)
+    owner = distribute_boxes(boxes, world, n_cell, [128] * 3)
+    assert sorted(owner.count(r) for r in range(world)) == [8] * world
+    bcs = [([capi.BC_REFLECT_EVEN] * 3, [capi.BC_REFLECT_EVEN] * 3)] * 6
+    ctx = PlanningContext()
+    plans = []
+    for r in range(world):
+        mine = [g for g, o in enumerate(owner) if o == r]
+        lev = Level(ctx, 3, [boxes[g] for g in mine])
+        ex = GhostExchange(lev, geom, 6, 4, boxes, owner, r, bcs)
+        assert len(ex.peers) <= 7
+        plans.append((mine, ex))
+    for r, (mine, ex) in enumerate(plans):
+        for k, peer, sbuf, rbuf in ex.peers:
+            pmine, pex = plans[peer]
+            kk = [q for q, (_, pr, _, _) in enumerate(pex.peers) if pr == r]
+            assert len(kk) == 1, f"rank {peer} does not list rank {r} as a peer"
+            _, _, psbuf, prbuf = pex.peers[kk[0]]
+            assert sbuf.numel() == prbuf.numel() and rbuf.numel() == psbuf.numel()
+            # strip by strip: (global dst box, global src box, region in the destination index space, shift, offset)
+            sent = [(tuple(lo), tuple(hi), tuple(sh), off) for db, sb, lo, hi, sh, off in ex.items(1, k)]
+            recv = [(tuple(lo), tuple(hi), tuple(sh), off) for db, sb, lo, hi, sh, off in pex.items(2, kk[0])]
+            assert sent == recv, f"wire order differs between ranks {r} -> {peer}"
