@@ -361,6 +361,15 @@ int qk_fluxreg_CrseAdd(qk_fluxreg *fr, qk_stream s, const qk_array4 *const flux[
 int qk_fluxreg_FineAdd(qk_fluxreg *fr, qk_stream s, const qk_array4 *const flux[3], const double dx_fine[3], double dt);
 int qk_fluxreg_Reflux(qk_fluxreg *fr, qk_stream s, qk_array4 *crse_state);
 
+/* Grid generation (amrex::AmrCore::MakeNewGrids is Berger-Rigoutsos clustering and not vendored; this is a simpler rule with the same
+ * inputs amr.n_error_buf / amr.blocking_factor / amr.max_grid_size — grids differ from AMReX's, parity unpinned):
+ *   qk_amr_tile_flags    tags (TagBox::SET) buffered by n_error_buf cells -> one int per tile of `tile` cells on a side (level index
+ *                        space of `tags`, domain starting at 0), copied to the HOST array tile_flags_host[ntz][nty][ntx]; synchronises s
+ *   qk_amr_cluster_tiles host: flagged tiles (tile = blocking_factor FINE cells) -> fine boxes, greedy merge x, y, z up to max_grid_size */
+int qk_amr_tile_flags(qk_level *lev, qk_stream s, const qk_carray4 *tags, const qk_box *domain, int n_error_buf, int tile, int *tile_flags_host);
+int qk_amr_cluster_tiles(const int *tiles, const int ntiles[3], int ndim, int blocking_factor, int max_grid_size, int parent_align, qk_box *boxes,
+			 int max_boxes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,36 +61,19 @@ def boxes_from_tags(tags: np.ndarray, ndim: int, n_error_buf: int, blocking_fact
     return boxes_from_tiles(t, ndim, blocking_factor, max_grid_size, ratio)
 
 
-def boxes_from_tiles(t: np.ndarray, ndim: int, blocking_factor: int, max_grid_size: int, ratio: int = 2) -> List[Box]:
-    """t[k, j, i]: tiles (blocking_factor fine cells = blocking_factor / ratio coarse cells on a side) to refine -> fine boxes, merged
-    greedily (x, then y, then z) up to max_grid_size"""
-    t = t.copy()
-    tz, ty, tx = t.shape
-    tile = [max(blocking_factor // ratio, 1) if d < ndim else 1 for d in range(3)]
-    maxt = [max(max_grid_size // blocking_factor, 1) if d < ndim else 1 for d in range(3)]  # tiles per box edge
-    used = np.zeros_like(t)
-    boxes: List[Box] = []
-    for k, j, i in (tuple(int(x) for x in idx) for idx in np.argwhere(t)):  # (z, y, x) order; only flagged tiles are visited
-        if True:
-            if True:
-                if used[k, j, i]:
-                    continue
-                i1 = i
-                while i1 + 1 < tx and i1 + 1 - i < maxt[0] and t[k, j, i1 + 1] and not used[k, j, i1 + 1]:
-                    i1 += 1
-                j1 = j
-                while j1 + 1 < ty and j1 + 1 - j < maxt[1] and t[k, j1 + 1, i:i1 + 1].all() and not used[k, j1 + 1, i:i1 + 1].any():
-                    j1 += 1
-                k1 = k
-                while k1 + 1 < tz and k1 + 1 - k < maxt[2] and t[k1 + 1, j:j1 + 1, i:i1 + 1].all() and not used[k1 + 1, j:j1 + 1, i:i1 + 1].any():
-                    k1 += 1
-                used[k:k1 + 1, j:j1 + 1, i:i1 + 1] = True
-                lo = [i * tile[0] * ratio, j * tile[1] * ratio, k * tile[2] * ratio]
-                hi = [(i1 + 1) * tile[0] * ratio - 1, (j1 + 1) * tile[1] * ratio - 1, (k1 + 1) * tile[2] * ratio - 1]
-                for d in range(ndim, 3):
-                    lo[d], hi[d] = 0, 0
-                boxes.append((lo, hi))
-    return boxes
+def boxes_from_tiles(t: np.ndarray, ndim: int, blocking_factor: int, max_grid_size: int, ratio: int = 2, parent_align: int = 0) -> List[Box]:
+    """t[k, j, i]: tiles (blocking_factor fine cells on a side) to refine -> fine boxes, merged greedily (x, then y, then z) up to
+    max_grid_size by the library's host function qk_amr_cluster_tiles (shared with the C++ host)"""
+    import ctypes as C
+    assert ratio == 2
+    flags = np.ascontiguousarray(t, dtype=np.int32)
+    tz, ty, tx = flags.shape
+    cap = int(flags.sum()) + 1
+    out = (capi.Box * cap)()
+    n = capi.lib().qk_amr_cluster_tiles(flags.ctypes.data_as(C.c_void_p), (C.c_int * 3)(tx, ty, tz), ndim, blocking_factor, max_grid_size, parent_align, out, cap)
+    if n < 0:
+        raise capi.QkError(f"qk_amr_cluster_tiles failed ({n})")
+    return [([out[b].lo[d] for d in range(3)], [out[b].hi[d] for d in range(3)]) for b in range(n)]
 
 
 def covered_mask(boxes: Sequence[Box], shape) -> np.ndarray:
@@ -235,9 +218,9 @@ class AmrSimulation:
         return dense
 
     def _tile_flags(self, lev: int) -> np.ndarray:
-        """ErrorEst on level lev -> tags buffered by n_error_buf (max-pool on the GPU) -> one flag per blocking-factor tile (host).
-        Only the tile flags leave the device: a dense tag array of a 512^3 level never reaches numpy."""
-        import torch.nn.functional as F
+        """ErrorEst on level lev -> tags buffered by n_error_buf -> one flag per blocking-factor tile (qk_amr_tile_flags: only the tile
+        flags leave the device)"""
+        import ctypes as C
         from .amr import TagBoxArray
         for l in range(lev + 1):
             self.levels[l]._fill_time = self.levels[l].t_new
@@ -245,21 +228,13 @@ class AmrSimulation:
         L = self.levels[lev]
         tags = TagBoxArray(L.lev)
         self.ErrorEst(self, lev, tags)
-        n = L.geom.n_cell
-        dense = torch.zeros((n[2], n[1], n[0]), dtype=torch.float16, device=self.ctx.device)
-        for b, (lo, hi) in enumerate(L.my_boxes):
-            dense[lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1] = (tags.fabs[b][0] == capi.TAG_SET).to(torch.float16)
-        nb, tile = self.n_error_buf, self.blocking_factor // 2
-        x = dense[None, None]
-        x = F.max_pool3d(x, kernel_size=tile, stride=tile) if nb == 0 else x
-        if nb > 0:  # max-norm dilation is separable: three 1-D pools (21 instead of 343 reads per cell), the last two on the tile-reduced axes
-            x = F.max_pool3d(x, kernel_size=(1, 1, 2 * nb + 1), stride=1, padding=(0, 0, nb))
-            x = F.max_pool3d(x, kernel_size=(1, 1, tile), stride=(1, 1, tile))
-            x = F.max_pool3d(x, kernel_size=(1, 2 * nb + 1, 1), stride=1, padding=(0, nb, 0))
-            x = F.max_pool3d(x, kernel_size=(1, tile, 1), stride=(1, tile, 1))
-            x = F.max_pool3d(x, kernel_size=(2 * nb + 1, 1, 1), stride=1, padding=(nb, 0, 0))
-            x = F.max_pool3d(x, kernel_size=(tile, 1, 1), stride=(tile, 1, 1))
-        return (x[0, 0] > 0).cpu().numpy()
+        n, tile = L.geom.n_cell, self.blocking_factor // 2
+        nt = [n[d] // tile for d in range(3)]
+        flags = np.zeros((nt[2], nt[1], nt[0]), dtype=np.int32)
+        dom = capi.Box((C.c_int * 3)(0, 0, 0), (C.c_int * 3)(n[0] - 1, n[1] - 1, n[2] - 1))
+        self.ctx.check(self.ctx.L.qk_amr_tile_flags(L.lev.h, self.ctx.stream(), tags.ptr, C.byref(dom), self.n_error_buf, tile, flags.ctypes.data_as(C.c_void_p)),
+                       "qk_amr_tile_flags")
+        return flags != 0
 
     def _new_grids(self, lev: int, finer_boxes: Optional[List[Box]]) -> List[Box]:
         """boxes of level lev+1 from the tags on level lev (+ the cells under an already chosen level lev+2, buffered: proper nesting)"""

@@ -248,3 +248,160 @@ int qk_average_down(qk_avgdown_plan *plan, qk_stream s, const qk_array4 *fine_t,
 }
 
 } // extern "C"
+
+// ---------------------------------------------------------------------------------------------- grid generation pieces
+// amrex::AmrCore::MakeNewGrids turns tags into boxes with the Berger-Rigoutsos algorithm; AMReX is not vendored under
+// /root/reference, so this repository uses a simpler rule with the same inputs (amr.n_error_buf, amr.blocking_factor,
+// amr.max_grid_size): buffer the tags, refine every blocking-factor tile that holds a buffered tag, merge tiles greedily.
+namespace
+{
+__global__ void __launch_bounds__(256) k_tags_to_tiles(const qk_box *boxes, const qk_carray4 *tags_t, int n_error_buf, int tile, int ndim, int n0, int n1, int n2,
+						       int tx, int ty, int tz, int *flags)
+{
+	const int b = blockIdx.y;
+	const qk_box bx = boxes[b];
+	const int l0 = bx.hi[0] - bx.lo[0] + 1, l1 = bx.hi[1] - bx.lo[1] + 1, l2 = bx.hi[2] - bx.lo[2] + 1;
+	const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+	if (t >= static_cast<int64_t>(l0) * l1 * l2) {
+		return;
+	}
+	const int k = static_cast<int>(t / (static_cast<int64_t>(l0) * l1));
+	const int r = static_cast<int>(t - static_cast<int64_t>(k) * l0 * l1);
+	const int j = r / l0;
+	const int c[3] = {bx.lo[0] + (r - j * l0), bx.lo[1] + j, bx.lo[2] + k};
+	A4<const char, qk_carray4> tag(tags_t[b]);
+	if (tag(c[0], c[1], c[2]) != static_cast<char>(QK_TAG_SET)) {
+		return;
+	}
+	// every tile that meets the cube of half-width n_error_buf around the tagged cell (clipped to the domain)
+	const int n[3] = {n0, n1, n2}, nt[3] = {tx, ty, tz};
+	int a[3], e[3];
+	for (int d = 0; d < 3; ++d) {
+		const int nb = (d < ndim) ? n_error_buf : 0;
+		const int lo = max(c[d] - nb, 0), hi = min(c[d] + nb, n[d] - 1);
+		a[d] = (d < ndim) ? lo / tile : 0;
+		e[d] = (d < ndim) ? min(hi / tile, nt[d] - 1) : 0;
+	}
+	for (int kk = a[2]; kk <= e[2]; ++kk) {
+		for (int jj = a[1]; jj <= e[1]; ++jj) {
+			for (int ii = a[0]; ii <= e[0]; ++ii) {
+				flags[ii + tx * (jj + ty * kk)] = 1; // benign race: every writer stores 1
+			}
+		}
+	}
+}
+} // namespace
+
+extern "C" {
+
+int qk_amr_tile_flags(qk_level *lev, qk_stream s, const qk_carray4 *tags_t, const qk_box *domain, int n_error_buf, int tile, int *tile_flags_host)
+{
+	if (lev == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	qk_ctx *ctx = lev->ctx;
+	QK_REQUIRE(ctx, tags_t && domain && tile_flags_host && tile >= 1 && n_error_buf >= 0, "amr_tile_flags: bad argument");
+	int n[3], nt[3];
+	for (int d = 0; d < 3; ++d) {
+		QK_REQUIRE(ctx, domain->lo[d] == 0, "amr_tile_flags: the domain must start at index 0");
+		n[d] = domain->hi[d] + 1;
+		nt[d] = (d < lev->ndim) ? (n[d] + tile - 1) / tile : 1;
+	}
+	const size_t bytes = sizeof(int) * static_cast<size_t>(nt[0]) * nt[1] * nt[2];
+	int *d_flags = nullptr;
+	QK_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void **>(&d_flags), bytes));
+	auto st = static_cast<hipStream_t>(s);
+	int rc = QK_OK;
+	if (hipMemsetAsync(d_flags, 0, bytes, st) != hipSuccess) {
+		rc = setError(ctx, QK_ERR_HIP, "amr_tile_flags: memset failed");
+	}
+	if (rc == QK_OK) {
+		int64_t maxcells = 1;
+		for (int d = 0; d < 3; ++d) {
+			maxcells *= lev->maxlen[d];
+		}
+		const dim3 grid(static_cast<unsigned>((maxcells + 255) / 256), static_cast<unsigned>(lev->nboxes), 1);
+		hipLaunchKernelGGL(k_tags_to_tiles, grid, dim3(256), 0, st, lev->d_boxes, tags_t, n_error_buf, tile, lev->ndim, n[0], n[1], n[2], nt[0], nt[1], nt[2], d_flags);
+		if (hipGetLastError() != hipSuccess || hipMemcpyAsync(tile_flags_host, d_flags, bytes, hipMemcpyDeviceToHost, st) != hipSuccess ||
+		    hipStreamSynchronize(st) != hipSuccess) {
+			rc = setError(ctx, QK_ERR_HIP, "amr_tile_flags: kernel or copy failed");
+		}
+	}
+	(void)hipFree(d_flags);
+	return rc;
+}
+
+// tiles[k][j][i] != 0 (tile = blocking_factor fine cells) -> fine boxes, merged greedily along x, then y, then z up to max_grid_size
+// and never across a multiple of `parent_align` fine cells (0: no such restriction).  Returns the number of boxes (<= max_boxes)
+// or a negative status; boxes are written in fine index space.
+int qk_amr_cluster_tiles(const int *tiles, const int ntiles[3], int ndim, int blocking_factor, int max_grid_size, int parent_align, qk_box *boxes, int max_boxes)
+{
+	if (tiles == nullptr || ntiles == nullptr || boxes == nullptr || blocking_factor < 1 || max_grid_size < blocking_factor) {
+		return QK_ERR_INVALID;
+	}
+	const int tx = ntiles[0], ty = ntiles[1], tz = ntiles[2];
+	int maxt[3];
+	for (int d = 0; d < 3; ++d) {
+		maxt[d] = (d < ndim) ? std::max(max_grid_size / blocking_factor, 1) : 1;
+	}
+	const int align = (parent_align > 0) ? std::max(parent_align / blocking_factor, 1) : 0; // in tiles
+	std::vector<char> used(static_cast<size_t>(tx) * ty * tz, 0);
+	auto at = [&](int i, int j, int k) { return static_cast<size_t>(i) + static_cast<size_t>(tx) * (j + static_cast<size_t>(ty) * k); };
+	auto free_tile = [&](int i, int j, int k) { return tiles[at(i, j, k)] != 0 && used[at(i, j, k)] == 0; };
+	auto crosses = [&](int first, int next) { return align > 0 && (next / align) != (first / align); };
+	int nb = 0;
+	for (int k = 0; k < tz; ++k) {
+		for (int j = 0; j < ty; ++j) {
+			for (int i = 0; i < tx; ++i) {
+				if (!free_tile(i, j, k)) {
+					continue;
+				}
+				int i1 = i, j1 = j, k1 = k;
+				while (i1 + 1 < tx && i1 + 1 - i < maxt[0] && !crosses(i, i1 + 1) && free_tile(i1 + 1, j, k)) {
+					++i1;
+				}
+				auto row_free = [&](int jj, int kk) {
+					for (int ii = i; ii <= i1; ++ii) {
+						if (!free_tile(ii, jj, kk)) {
+							return false;
+						}
+					}
+					return true;
+				};
+				while (j1 + 1 < ty && j1 + 1 - j < maxt[1] && !crosses(j, j1 + 1) && row_free(j1 + 1, k)) {
+					++j1;
+				}
+				auto plane_free = [&](int kk) {
+					for (int jj = j; jj <= j1; ++jj) {
+						if (!row_free(jj, kk)) {
+							return false;
+						}
+					}
+					return true;
+				};
+				while (k1 + 1 < tz && k1 + 1 - k < maxt[2] && !crosses(k, k1 + 1) && plane_free(k1 + 1)) {
+					++k1;
+				}
+				for (int kk = k; kk <= k1; ++kk) {
+					for (int jj = j; jj <= j1; ++jj) {
+						for (int ii = i; ii <= i1; ++ii) {
+							used[at(ii, jj, kk)] = 1;
+						}
+					}
+				}
+				if (nb >= max_boxes) {
+					return QK_ERR_INVALID;
+				}
+				const int a[3] = {i, j, k}, e[3] = {i1, j1, k1};
+				for (int d = 0; d < 3; ++d) {
+					boxes[nb].lo[d] = (d < ndim) ? a[d] * blocking_factor : 0;
+					boxes[nb].hi[d] = (d < ndim) ? (e[d] + 1) * blocking_factor - 1 : 0;
+				}
+				++nb;
+			}
+		}
+	}
+	return nb;
+}
+
+} // extern "C"
