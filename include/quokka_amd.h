@@ -361,6 +361,9 @@ int qk_fluxreg_CrseAdd(qk_fluxreg *fr, qk_stream s, const qk_array4 *const flux[
 int qk_fluxreg_FineAdd(qk_fluxreg *fr, qk_stream s, const qk_array4 *const flux[3], const double dx_fine[3], double dt);
 int qk_fluxreg_Reflux(qk_fluxreg *fr, qk_stream s, qk_array4 *crse_state);
 
+/* copy the region [lo, hi] (same index space) between two arrays given by HOST copies of their descriptors (device data):
+ * the old-level data a remade level keeps (RemakeLevel's FillPatch copies fine data where it exists, reference src/simulation.hpp:1672-1685) */
+int qk_copy_box(qk_ctx *ctx, qk_stream s, const qk_array4 *src, const qk_array4 *dst, const int lo[3], const int hi[3], int scomp, int dcomp, int ncomp);
 /* Grid generation (amrex::AmrCore::MakeNewGrids is Berger-Rigoutsos clustering and not vendored; this is a simpler rule with the same
  * inputs amr.n_error_buf / amr.blocking_factor / amr.max_grid_size — grids differ from AMReX's, parity unpinned):
  *   qk_amr_tile_flags    tags (TagBox::SET) buffered by n_error_buf cells -> one int per tile of `tile` cells on a side (level index

@@ -327,6 +327,8 @@ class AmrSimulation:
                 self.levels.append(new)
             if lev + 1 <= self.finest_level:  # the child of a remade level keeps its grids but needs new inter-level plans
                 self.levels[lev + 1].link_to_parent(new)
+        for k in range(base, self.finest_level + 1):  # reference src/simulation.hpp:1257-1259
+            self.levels[k].FixupState()
 
     # ------------------------------------------------------------------ inter-level operators
     def AverageDownTo(self, crse_lev: int):

@@ -1,1 +1,1 @@
-#include "quokka_host.hpp"
+#include "quokka_amr.hpp"

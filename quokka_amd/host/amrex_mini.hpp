@@ -376,6 +376,8 @@ template <typename T> class FabArrayT
 	[[nodiscard]] auto boxArray() const -> std::vector<Box> const & { return boxes_; }
 	[[nodiscard]] auto validbox(int b) const -> Box const & { return boxes_[b]; }
 	[[nodiscard]] auto fabbox(int b) const -> Box const & { return fabboxes_[b]; }
+	// host copy of one descriptor (device data pointer)
+	[[nodiscard]] auto array(int b) const -> Array4<T> { return Array4<T>(d_data_ + offsets_[b], fabboxes_[b], ncomp_); }
 	// device pointer to the descriptor table (MultiFab::arrays())
 	[[nodiscard]] auto arrays() const -> Array4<T> * { return d_table_; }
 	void setVal(T v)
@@ -445,6 +447,11 @@ template <typename T> class FabArrayT
 };
 using MultiFab = FabArrayT<Real>;
 using iMultiFab = FabArrayT<int>;
+// amrex::TagBoxArray: one char per cell (amrex::TagBox::CLEAR = 0, BUF = 1, SET = 2)
+using TagBoxArray = FabArrayT<char>;
+struct TagBox {
+	enum TagVal : char { CLEAR = 0, BUF = 1, SET = 2 };
+};
 
 } // namespace amrex
 

@@ -71,6 +71,15 @@ template <> void QuokkaSimulation<SedovProblem>::setInitialConditionsOnGrid(quok
 	});
 }
 
+template <> void QuokkaSimulation<SedovProblem>::ErrorEst(int /*lev*/, amrex::TagBoxArray &tags, amrex::Real /*time*/, int /*ngrow*/)
+{
+	// tag cells for refinement: relative pressure gradient (the reference evaluates this in a device lambda; the host mirror
+	// provides the gradient-threshold family as one call into the C-ABI, see quokka_host.hpp)
+	const amrex::Real eta_threshold = 0.1; // gradient refinement threshold
+	const amrex::Real P_min = 1.0e-3;      // minimum pressure for refinement
+	tagRelativeGradient(tags, QK_TAGFIELD_PRESSURE, eta_threshold, P_min, /*min_inclusive=*/false);
+}
+
 template <> void QuokkaSimulation<SedovProblem>::computeAfterEvolve(amrex::Vector<amrex::Real> &initSumCons)
 {
 	amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> const &dx0 = geom[0].CellSizeArray();

@@ -1,0 +1,553 @@
+// quokka_amr.hpp — the AMR level machinery of AMRSimulation / QuokkaSimulation for the C++ host mirror:
+//   timeStepWithSubcycling, regrid, computeTimestep over levels   reference src/simulation.hpp:744-818,1220-1343
+//   FillPatch on refined levels                                     src/simulation.hpp:1704-1858
+//   incrementFluxRegisters / Reflux / AverageDownTo / FixupState    :1345-1387, :1308, :1949-1964, src/QuokkaSimulation.hpp:761-770
+// Level l of the hierarchy is one QuokkaSimulation<problem_t> object built from a LevelSpec (its own geometry, boxes, state, ghost
+// plan, stage scratch); the base object (level 0, built from the deck) owns the finer ones through this driver.  Every cell is
+// touched by a kernel behind include/quokka_amd.h; the grids come from qk_amr_tile_flags + qk_amr_cluster_tiles (tile clustering,
+// not AMReX's Berger-Rigoutsos: unpinned).  Same algorithm as quokka_amd/amr_simulation.py, which the GPU tests pin by
+// properties (full-coverage == uniform fine run, conservation with reflux, nesting); single rank.
+#ifndef QK_HOST_QUOKKA_AMR_HPP_
+#define QK_HOST_QUOKKA_AMR_HPP_
+
+#include <memory>
+
+#include "quokka_host.hpp"
+
+template <typename problem_t> class AmrDriver
+{
+      public:
+	using Sim = QuokkaSimulation<problem_t>;
+
+	explicit AmrDriver(Sim &base) : base_(base)
+	{
+		amrex::ParmParse pa("amr");
+		pa.query("max_level", max_level);
+		pa.query("blocking_factor", blocking_factor);
+		pa.query("n_error_buf", n_error_buf);
+		pa.query("regrid_int", regrid_int);
+		std::vector<int> mgs;
+		if (pa.queryarr("max_grid_size", mgs) && !mgs.empty()) {
+			max_grid_size = mgs[0];
+		}
+		amrex::ParmParse pp;
+		pp.query("do_reflux", do_reflux);
+		istep.assign(max_level + 1, 0);
+		last_regrid_step.assign(max_level + 1, 0);
+		dt_.assign(max_level + 1, 1.e100);
+		cellUpdatesEachLevel_.assign(max_level + 1, 0);
+		base_.storeFluxRk2_ = (max_level > 0);
+	}
+
+	int max_level = 0, blocking_factor = 8, n_error_buf = 1, regrid_int = 2, max_grid_size = 128, do_reflux = 1;
+	int amrInterpMethod_ = 1;
+	std::vector<int> istep, last_regrid_step;
+	std::vector<double> dt_;
+	std::vector<amrex::Long> cellUpdatesEachLevel_;
+	amrex::Long cellUpdates_ = 0;
+	double tNew_ = 0.0, elapsedSeconds_ = 0.0;
+
+	[[nodiscard]] auto finestLevel() const -> int { return static_cast<int>(finer_.size()); }
+	auto level(int l) -> Sim & { return l == 0 ? base_ : *finer_[l - 1]->sim; }
+
+	// AmrCore::InitFromScratch + AverageDown (reference src/simulation.hpp:1656-1702)
+	void setInitialConditions()
+	{
+		base_.AMRSimulation<problem_t>::setInitialConditions(); // level 0: problem ICs, ghost cells, state_old = state_new
+		for (int lev = 0; lev < max_level; ++lev) {
+			auto boxes = newGrids(lev, nullptr);
+			if (boxes.empty()) {
+				break;
+			}
+			makeLevel(lev + 1, boxes);
+			level(lev + 1).setInitialConditionsAtLevel();
+		}
+		for (int lev = finestLevel() - 1; lev >= 0; --lev) {
+			averageDownTo(lev);
+		}
+	}
+
+	void evolve()
+	{
+		int const nc = Physics_Indices<problem_t>::nvarTotal_cc;
+		double const vol = AMREX_D_TERM(base_.geom[0].dx[0], *base_.geom[0].dx[1], *base_.geom[0].dx[2]);
+		amrex::Vector<amrex::Real> init_sum_cons(nc);
+		for (int n = 0; n < nc; ++n) { // level 0 holds the average of every finer level: its sum is the composite integral
+			init_sum_cons[n] = base_.state_new_cc_[0].sum(n) * vol;
+		}
+		QK_HOST_HIP(hipDeviceSynchronize());
+		auto const t0 = std::chrono::steady_clock::now();
+		tNew_ = base_.tNew_[0];
+		while (istep[0] < base_.maxTimesteps_ && tNew_ < base_.stopTime_) {
+			computeTimestep();
+			timeStepWithSubcycling(0, tNew_);
+			tNew_ += dt_[0];
+			base_.tNew_[0] = tNew_;
+			base_.dt_[0] = dt_[0];
+			base_.istep[0] = istep[0];
+			if (tNew_ >= base_.stopTime_ - 1.e-6 * dt_[0]) {
+				break;
+			}
+		}
+		QK_HOST_HIP(hipDeviceSynchronize());
+		elapsedSeconds_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+		base_.elapsedSeconds_ = elapsedSeconds_;
+		base_.cellUpdates_ = cellUpdates_;
+		base_.computeAfterEvolve(init_sum_cons);
+		double const us = 1.0e6 * elapsedSeconds_ / static_cast<double>(cellUpdates_);
+		amrex::Print() << "Performance figure-of-merit: " << us << " μs/zone-update [" << 1.0 / us << " Mupdates/s]\n";
+		for (int l = 0; l <= finestLevel(); ++l) {
+			amrex::Print() << "Zone-updates on level " << l << ": " << cellUpdatesEachLevel_[l] << " (" << level(l).grids_.size() << " grids)\n";
+		}
+	}
+
+	// volume integral of a conserved component over the composite grid (coarse cells under a finer level are not counted)
+	auto compositeSum(int comp) -> double
+	{
+		double total = 0;
+		for (int l = 0; l <= finestLevel(); ++l) {
+			auto &S = level(l);
+			auto const &g = S.geom[0];
+			double const vol = AMREX_D_TERM(g.dx[0], *g.dx[1], *g.dx[2]);
+			auto &mf = S.state_new_cc_[0];
+			for (int b = 0; b < mf.size(); ++b) {
+				auto h = mf.copyToHost(b);
+				amrex::Array4<double> a(h.data(), mf.fabbox(b), mf.nComp());
+				double s = 0, c = 0;
+				amrex::ParallelFor(mf.validbox(b), [&](int i, int j, int k) {
+					if (l < finestLevel()) {
+						for (auto const &fb : level(l + 1).grids_) {
+							if (fb.contains(2 * i, 2 * j, 2 * k)) {
+								return;
+							}
+						}
+					}
+					double const y = a(i, j, k, comp) - c;
+					double const t = s + y;
+					c = (t - s) - y;
+					s = t;
+				});
+				total += s * vol;
+			}
+		}
+		return total;
+	}
+
+      private:
+	struct Finer {
+		std::unique_ptr<Sim> sim;
+		qk_interp_plan *interp = nullptr;
+		qk_fluxreg *fluxreg = nullptr;
+		qk_avgdown_plan *avgdown = nullptr;
+		~Finer()
+		{
+			qk_interp_plan_destroy(interp);
+			qk_fluxreg_destroy(fluxreg);
+			qk_avgdown_plan_destroy(avgdown);
+		}
+	};
+	Sim &base_;
+	std::vector<std::unique_ptr<Finer>> finerOwned_;
+	std::vector<Finer *> finer_; // finer_[l-1] = level l
+
+	static auto qgeom(amrex::Geometry const &g) -> qk_geometry
+	{
+		qk_geometry q{};
+		for (int d = 0; d < 3; ++d) {
+			q.domain.lo[d] = g.domain.lo[d];
+			q.domain.hi[d] = g.domain.hi[d];
+			q.periodic[d] = g.periodic[d];
+		}
+		q.ndim = AMREX_SPACEDIM;
+		return q;
+	}
+
+	auto specFor(int lev, std::vector<amrex::Box> const &boxes) -> LevelSpec
+	{
+		LevelSpec s;
+		s.geom = base_.geom[0];
+		for (int d = 0; d < AMREX_SPACEDIM; ++d) {
+			s.geom.domain.hi[d] = (base_.geom[0].domain.hi[d] + 1) * (1 << lev) - 1;
+			s.geom.dx[d] = base_.geom[0].dx[d] / (1 << lev);
+		}
+		s.boxes = boxes;
+		s.level = lev;
+		return s;
+	}
+
+	void linkToParent(Finer &f, int lev)
+	{
+		qk_interp_plan_destroy(f.interp);
+		qk_fluxreg_destroy(f.fluxreg);
+		qk_avgdown_plan_destroy(f.avgdown);
+		f.interp = nullptr;
+		f.fluxreg = nullptr;
+		f.avgdown = nullptr;
+		Sim &parent = level(lev - 1);
+		Sim &me = *f.sim;
+		int const ratio[3] = {2, 2, 2};
+		auto gf = qgeom(me.geom[0]);
+		auto gc = qgeom(parent.geom[0]);
+		qkhost::check(qk_interp_plan_create(parent.levelHandle(), me.levelHandle(), &gf, me.nghost_cc_, ratio, 0, &f.interp), "qk_interp_plan_create");
+		qkhost::check(qk_fluxreg_create(parent.levelHandle(), me.levelHandle(), &gc, ratio, Sim::ncompHydro_, &f.fluxreg), "qk_fluxreg_create");
+		qkhost::check(qk_avgdown_plan_create(parent.levelHandle(), me.levelHandle(), ratio, &f.avgdown), "qk_avgdown_plan_create");
+		Finer *fp = &f;
+		// FillPatchTwoLevels: the ghost cells no fine box covers come from the parent, interpolated in space and time
+		me.beforePhysBC_ = [this, fp, lev](amrex::MultiFab &state) { interpFromParent(*fp, lev, state, fp->sim->fillTime_, fp->interp); };
+		// incrementFluxRegisters: this level as the fine side of its register and as the coarse side of its child's
+		me.afterAdvance_ = [this, lev](double dt) { incrementFluxRegisters(lev, dt); };
+		me.storeFluxRk2_ = true;
+	}
+
+	void interpFromParent(Finer & /*f*/, int lev, amrex::MultiFab &state, double time, qk_interp_plan *plan)
+	{
+		Sim &p = level(lev - 1);
+		double const t0 = p.tOldLev_, t1 = p.tNewLev_;
+		double const eps = 1.0e-10 * std::max(std::abs(t1 - t0), 1.0e-300);
+		auto *fs = qkhost::tab(state);
+		auto *pn = qkhost::tab(p.state_new_cc_[0]);
+		auto *po = qkhost::tab(p.state_old_cc_[0]);
+		int const nc = Sim::ncompHydro_;
+		if (std::abs(time - t1) <= eps || t1 == t0) {
+			qkhost::check(qk_InterpFromCoarse(plan, nullptr, fs, pn, pn, 1.0, 0.0, nc, amrInterpMethod_, 1), "qk_InterpFromCoarse");
+		} else if (std::abs(time - t0) <= eps) {
+			qkhost::check(qk_InterpFromCoarse(plan, nullptr, fs, po, po, 1.0, 0.0, nc, amrInterpMethod_, 1), "qk_InterpFromCoarse");
+		} else {
+			qkhost::check(qk_InterpFromCoarse(plan, nullptr, fs, po, pn, (t1 - time) / (t1 - t0), (time - t0) / (t1 - t0), nc, amrInterpMethod_, 1),
+				      "qk_InterpFromCoarse");
+		}
+	}
+
+	void incrementFluxRegisters(int lev, double dt)
+	{
+		if (do_reflux == 0) {
+			return;
+		}
+		Sim &S = level(lev);
+		qk_array4 *f[3];
+		double dx[3];
+		for (int d = 0; d < 3; ++d) {
+			f[d] = (d < AMREX_SPACEDIM) ? qkhost::tab(S.halfFlux()[d]) : nullptr;
+			dx[d] = (d < AMREX_SPACEDIM) ? S.geom[0].dx[d] : 1.0;
+		}
+		if (lev < finestLevel()) {
+			qkhost::check(qk_fluxreg_CrseAdd(finer_[lev]->fluxreg, nullptr, f, dx, dt), "qk_fluxreg_CrseAdd");
+		}
+		if (lev > 0) {
+			qkhost::check(qk_fluxreg_FineAdd(finer_[lev - 1]->fluxreg, nullptr, f, dx, dt), "qk_fluxreg_FineAdd");
+		}
+	}
+
+	void makeLevel(int lev, std::vector<amrex::Box> const &boxes)
+	{
+		auto f = std::make_unique<Finer>();
+		auto spec = specFor(lev, boxes);
+		f->sim = std::make_unique<Sim>(base_.BCs_cc_, spec);
+		Sim &me = *f->sim;
+		me.cflNumber_ = base_.cflNumber_;
+		me.densityFloor_ = base_.densityFloor_;
+		me.tempFloor_ = base_.tempFloor_;
+		me.reconstructionOrder_ = base_.reconstructionOrder_;
+		me.integratorOrder_ = base_.integratorOrder_;
+		me.useDualEnergy_ = base_.useDualEnergy_;
+		me.tOldLev_ = me.tNewLev_ = tNew_;
+		Finer *raw = f.get();
+		if (lev - 1 < static_cast<int>(finer_.size())) {
+			finer_[lev - 1] = raw;
+			finerOwned_[lev - 1] = std::move(f);
+		} else {
+			finer_.push_back(raw);
+			finerOwned_.push_back(std::move(f));
+		}
+		linkToParent(*raw, lev);
+		if (lev == 1) {
+			base_.afterAdvance_ = [this](double dt) { incrementFluxRegisters(0, dt); };
+		}
+	}
+
+	void fillGhosts(int lev, amrex::MultiFab &state, double time)
+	{
+		Sim &S = level(lev);
+		S.fillTime_ = time;
+		S.fillBoundaryConditions(state);
+	}
+
+	// ErrorEst -> buffered tags -> blocking-factor tiles -> boxes of level lev+1
+	auto newGrids(int lev, std::vector<amrex::Box> const *finerBoxes) -> std::vector<amrex::Box>
+	{
+		for (int l = 0; l <= lev; ++l) {
+			fillGhosts(l, level(l).state_new_cc_[0], level(l).tNewLev_);
+		}
+		Sim &S = level(lev);
+		amrex::TagBoxArray tags;
+		tags.define(S.grids_, 1, 0);
+		tags.setVal(amrex::TagBox::CLEAR);
+		S.ErrorEst(lev, tags, S.tNewLev_, 0);
+		int const tile = blocking_factor / 2;
+		auto const &dom = S.geom[0].domain;
+		AMREX_ALWAYS_ASSERT(tile >= 4);
+		int nt[3];
+		for (int d = 0; d < 3; ++d) {
+			nt[d] = (d < AMREX_SPACEDIM) ? dom.length(d) / tile : 1;
+		}
+		std::vector<int> flags(static_cast<size_t>(nt[0]) * nt[1] * nt[2], 0);
+		qk_box qd{{dom.lo[0], dom.lo[1], dom.lo[2]}, {dom.hi[0], dom.hi[1], dom.hi[2]}};
+		qkhost::check(qk_amr_tile_flags(S.levelHandle(), nullptr, reinterpret_cast<qk_carray4 *>(tags.arrays()), &qd, n_error_buf, tile, flags.data()),
+			      "qk_amr_tile_flags");
+		auto at = [&](int i, int j, int k) -> int & { return flags[static_cast<size_t>(i) + static_cast<size_t>(nt[0]) * (j + static_cast<size_t>(nt[1]) * k)]; };
+		if (finerBoxes != nullptr) { // level lev+2 boxes: their level-lev footprint grown by 2 cells must be refined (proper nesting)
+			for (auto const &b : *finerBoxes) {
+				int a[3], e[3];
+				for (int d = 0; d < 3; ++d) {
+					a[d] = std::max((fdiv(b.lo[d], 4) - 2) / tile, 0);
+					e[d] = std::min((fdiv(b.hi[d], 4) + 2) / tile, nt[d] - 1);
+				}
+				for (int k = a[2]; k <= e[2]; ++k) {
+					for (int j = a[1]; j <= e[1]; ++j) {
+						for (int i = a[0]; i <= e[0]; ++i) {
+							at(i, j, k) = 1;
+						}
+					}
+				}
+			}
+		}
+		if (lev > 0) { // a tile and its 26 neighbours lie on level-lev cells or beyond the domain
+			std::vector<char> cov(static_cast<size_t>(nt[0] + 2) * (nt[1] + 2) * (nt[2] + 2), 1);
+			auto cv = [&](int i, int j, int k) -> char & {
+				return cov[static_cast<size_t>(i + 1) + static_cast<size_t>(nt[0] + 2) * ((j + 1) + static_cast<size_t>(nt[1] + 2) * (k + 1))];
+			};
+			for (int k = 0; k < nt[2]; ++k) {
+				for (int j = 0; j < nt[1]; ++j) {
+					for (int i = 0; i < nt[0]; ++i) {
+						cv(i, j, k) = 0;
+					}
+				}
+			}
+			for (auto const &b : S.grids_) {
+				for (int k = b.lo[2] / tile; k <= b.hi[2] / tile; ++k) {
+					for (int j = b.lo[1] / tile; j <= b.hi[1] / tile; ++j) {
+						for (int i = b.lo[0] / tile; i <= b.hi[0] / tile; ++i) {
+							cv(i, j, k) = 1;
+						}
+					}
+				}
+			}
+			for (int k = 0; k < nt[2]; ++k) {
+				for (int j = 0; j < nt[1]; ++j) {
+					for (int i = 0; i < nt[0]; ++i) {
+						bool ok = true;
+						for (int c = -1; c <= 1 && ok; ++c) {
+							for (int b2 = -1; b2 <= 1 && ok; ++b2) {
+								for (int a2 = -1; a2 <= 1 && ok; ++a2) {
+									ok = cv(i + a2, j + b2, k + c) != 0;
+								}
+							}
+						}
+						if (!ok) {
+							at(i, j, k) = 0;
+						}
+					}
+				}
+			}
+		}
+		std::vector<qk_box> out(flags.size() + 1);
+		int const n = qk_amr_cluster_tiles(flags.data(), nt, AMREX_SPACEDIM, blocking_factor, max_grid_size, 0, out.data(), static_cast<int>(out.size()));
+		AMREX_ALWAYS_ASSERT(n >= 0);
+		std::vector<amrex::Box> boxes(n);
+		for (int b = 0; b < n; ++b) {
+			for (int d = 0; d < 3; ++d) {
+				boxes[b].lo[d] = out[b].lo[d];
+				boxes[b].hi[d] = out[b].hi[d];
+			}
+		}
+		return boxes;
+	}
+	static auto fdiv(int a, int r) -> int { return (a >= 0) ? a / r : -((-a + r - 1) / r); }
+
+	static auto sameBoxes(std::vector<amrex::Box> const &a, std::vector<amrex::Box> const &b) -> bool
+	{
+		if (a.size() != b.size()) {
+			return false;
+		}
+		for (size_t n = 0; n < a.size(); ++n) {
+			for (int d = 0; d < 3; ++d) {
+				if (a[n].lo[d] != b[n].lo[d] || a[n].hi[d] != b[n].hi[d]) {
+					return false;
+				}
+			}
+		}
+		return true;
+	}
+
+	// amrex::AmrCore::regrid(base, time) with RemakeLevel / MakeNewLevelFromCoarse / ClearLevel
+	void regrid(int baseLev)
+	{
+		int const top = std::min(finestLevel() + 1, max_level);
+		std::vector<std::vector<amrex::Box>> newBoxes(max_level + 2);
+		std::vector<amrex::Box> const *finerB = nullptr;
+		for (int lev = top - 1; lev >= baseLev; --lev) {
+			if (lev > finestLevel()) {
+				continue;
+			}
+			newBoxes[lev + 1] = newGrids(lev, (lev + 2 <= max_level) ? finerB : nullptr);
+			finerB = newBoxes[lev + 1].empty() ? nullptr : &newBoxes[lev + 1];
+		}
+		for (int lev = baseLev + 1; lev <= max_level; ++lev) {
+			auto const &boxes = newBoxes[lev];
+			if (boxes.empty()) {
+				finer_.resize(lev - 1);
+				finerOwned_.resize(lev - 1);
+				break;
+			}
+			bool const existed = lev <= finestLevel();
+			if (existed && sameBoxes(level(lev).grids_, boxes)) {
+				continue;
+			}
+			std::unique_ptr<Finer> old;
+			if (existed) {
+				old = std::move(finerOwned_[lev - 1]);
+			}
+			makeLevel(lev, boxes);
+			Sim &me = level(lev);
+			Sim &parent = level(lev - 1);
+			fillGhosts(lev - 1, parent.state_new_cc_[0], parent.tNewLev_);
+			int const ratio[3] = {2, 2, 2};
+			auto gf = qgeom(me.geom[0]);
+			qk_interp_plan *whole = nullptr;
+			qkhost::check(qk_interp_plan_create(parent.levelHandle(), me.levelHandle(), &gf, me.nghost_cc_, ratio, 1, &whole), "qk_interp_plan_create(whole)");
+			auto *pn = qkhost::tab(parent.state_new_cc_[0]);
+			qkhost::check(qk_InterpFromCoarse(whole, nullptr, qkhost::tab(me.state_new_cc_[0]), pn, pn, 1.0, 0.0, Sim::ncompHydro_, amrInterpMethod_, 1),
+				      "qk_InterpFromCoarse(whole)");
+			qk_interp_plan_destroy(whole);
+			if (old) { // keep the old fine data where the new level still covers it
+				Sim &o = *old->sim;
+				for (int sb = 0; sb < o.state_new_cc_[0].size(); ++sb) {
+					for (int db = 0; db < me.state_new_cc_[0].size(); ++db) {
+						int lo[3], hi[3];
+						bool ok = true;
+						for (int d = 0; d < 3; ++d) {
+							lo[d] = std::max(o.grids_[sb].lo[d], me.grids_[db].lo[d]);
+							hi[d] = std::min(o.grids_[sb].hi[d], me.grids_[db].hi[d]);
+							ok = ok && lo[d] <= hi[d];
+						}
+						if (!ok) {
+							continue;
+						}
+						auto sa = o.state_new_cc_[0].array(sb);
+						auto da = me.state_new_cc_[0].array(db);
+						qkhost::check(qk_copy_box(qkhost::Runtime::get().ctx, nullptr, reinterpret_cast<qk_array4 *>(&sa), reinterpret_cast<qk_array4 *>(&da), lo, hi,
+									  0, 0, me.state_new_cc_[0].nComp()),
+							      "qk_copy_box");
+					}
+				}
+			}
+			amrex::MultiFab::Copy(me.state_old_cc_[0], me.state_new_cc_[0]);
+			me.tOldLev_ = me.tNewLev_ = parent.tNewLev_;
+			QK_HOST_HIP(hipDeviceSynchronize()); // `old` is released below
+			if (lev + 1 <= finestLevel()) {
+				linkToParent(*finer_[lev], lev + 1);
+			}
+		}
+		for (int lev = baseLev; lev <= finestLevel(); ++lev) {
+			level(lev).FixupState(); // reference src/simulation.hpp:1257-1259
+		}
+	}
+
+	void averageDownTo(int crseLev)
+	{
+		Sim &f = level(crseLev + 1);
+		Sim &c = level(crseLev);
+		qkhost::check(qk_average_down(finer_[crseLev]->avgdown, nullptr, qkhost::tab(f.state_new_cc_[0]), qkhost::tab(c.state_new_cc_[0]), 0, Sim::ncompHydro_),
+			      "qk_average_down");
+	}
+
+	// reference src/simulation.hpp:744-818 with do_subcycle = 1
+	void computeTimestep()
+	{
+		std::vector<double> dt_tmp(finestLevel() + 1);
+		for (int l = 0; l <= finestLevel(); ++l) {
+			dt_tmp[l] = level(l).computeTimestepAtLevel();
+		}
+		double dt_0 = dt_tmp[0];
+		int n_factor = 1;
+		for (int l = 0; l <= finestLevel(); ++l) {
+			if (l > 0) {
+				n_factor *= 2;
+			}
+			dt_tmp[l] = std::min(dt_tmp[l], 1.1 * dt_[l]);
+			dt_0 = std::min(dt_0, n_factor * dt_tmp[l]);
+		}
+		double const eps = 1.e-3 * dt_0;
+		if (tNew_ + dt_0 > base_.stopTime_ - eps) {
+			dt_0 = base_.stopTime_ - tNew_;
+		}
+		dt_[0] = dt_0;
+		for (int l = 1; l <= max_level; ++l) {
+			dt_[l] = dt_[l - 1] / 2.0;
+		}
+	}
+
+	void timeStepWithSubcycling(int lev, double time)
+	{
+		if (regrid_int > 0 && lev < max_level && istep[lev] > last_regrid_step[lev] && istep[lev] % regrid_int == 0) {
+			regrid(lev);
+			for (int k = lev; k <= finestLevel(); ++k) {
+				last_regrid_step[k] = istep[k];
+			}
+		}
+		Sim &S = level(lev);
+		S.tOldLev_ = S.tNewLev_;
+		S.tNewLev_ += dt_[lev];
+		if (do_reflux != 0 && lev < finestLevel()) {
+			qkhost::check(qk_fluxreg_reset(finer_[lev]->fluxreg, nullptr), "qk_fluxreg_reset");
+		}
+		if (!S.advanceLevel(time, dt_[lev])) {
+			amrex::Abort("QUOKKA FATAL ERROR: Hydro update exceeded max_retries on level " + std::to_string(lev));
+		}
+		++istep[lev];
+		cellUpdates_ += S.CountCells(0);
+		cellUpdatesEachLevel_[lev] += S.CountCells(0);
+		if (lev < finestLevel()) {
+			// the children interpolate their ghost cells from this level's old and new states: both need their own ghost cells
+			fillGhosts(lev, S.state_old_cc_[0], S.tOldLev_);
+			fillGhosts(lev, S.state_new_cc_[0], S.tNewLev_);
+			for (int i = 1; i <= 2; ++i) {
+				if (lev < finestLevel()) {
+					timeStepWithSubcycling(lev + 1, time + (i - 1) * dt_[lev + 1]);
+				}
+			}
+			if (lev < finestLevel()) {
+				if (do_reflux != 0) {
+					qkhost::check(qk_fluxreg_Reflux(finer_[lev]->fluxreg, nullptr, qkhost::tab(S.state_new_cc_[0])), "qk_fluxreg_Reflux");
+				}
+				averageDownTo(lev);
+				S.FixupState();
+			}
+		}
+	}
+};
+
+// ------------------------------------------------------------------ QuokkaSimulation entry points: uniform grid or hierarchy
+template <typename problem_t> void QuokkaSimulation<problem_t>::setInitialConditions()
+{
+	int max_level = 0;
+	amrex::ParmParse pa("amr");
+	pa.query("max_level", max_level);
+	if (max_level > 0 && AMREX_SPACEDIM == 3) {
+		amr_ = std::make_shared<AmrDriver<problem_t>>(*this);
+		amr_->setInitialConditions();
+	} else {
+		AMRSimulation<problem_t>::setInitialConditions();
+	}
+}
+
+template <typename problem_t> void QuokkaSimulation<problem_t>::evolve()
+{
+	if (amr_) {
+		amr_->evolve();
+	} else {
+		evolveSingleLevel();
+	}
+}
+
+#endif // QK_HOST_QUOKKA_AMR_HPP_

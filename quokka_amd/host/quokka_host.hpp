@@ -14,6 +14,7 @@
 #define QK_HOST_QUOKKA_HOST_HPP_
 
 #include <chrono>
+#include <functional>
 #include <limits>
 #include <memory>
 
@@ -83,7 +84,7 @@ namespace qkhost
 {
 struct Runtime {
 	qk_ctx *ctx = nullptr;
-	qk_level *lev = nullptr; // level 0
+	qk_level *lev = nullptr; // the level the static operators act on (every simulation object activates its own before it launches)
 	static auto get() -> Runtime &
 	{
 		static Runtime r;
@@ -375,6 +376,15 @@ void RadSystem<problem_t>::SetRadEnergySource(array_t & /*radEnergySource*/, amr
 	// do nothing -- user implemented
 }
 
+template <typename problem_t> class AmrDriver; // quokka_amr.hpp
+
+// one refinement level handed to a simulation object by the AMR driver (quokka_amr.hpp): geometry of that level and its boxes
+struct LevelSpec {
+	amrex::Geometry geom;
+	std::vector<amrex::Box> boxes;
+	int level = 0;
+};
+
 // ---------------------------------------------------------------------------------------------------------------
 template <typename problem_t> class AMRSimulation
 {
@@ -402,13 +412,26 @@ template <typename problem_t> class AMRSimulation
 	amrex::Vector<amrex::BCRec> BCs_cc_;
 	amrex::Vector<amrex::MultiFab> state_new_cc_{1}, state_old_cc_{1};
 
-	explicit AMRSimulation(amrex::Vector<amrex::BCRec> &BCs_cc) : BCs_cc_(BCs_cc) { initialize(); }
+	explicit AMRSimulation(amrex::Vector<amrex::BCRec> &BCs_cc) : BCs_cc_(BCs_cc) { initialize(nullptr); }
+	AMRSimulation(amrex::Vector<amrex::BCRec> &BCs_cc, LevelSpec const &spec) : BCs_cc_(BCs_cc) { initialize(&spec); }
 	virtual ~AMRSimulation()
 	{
 		if (plan_ != nullptr) {
 			qk_ghost_plan_destroy(plan_);
 		}
+		if (myLev_ != nullptr) {
+			if (qkhost::Runtime::get().lev == myLev_) {
+				qkhost::Runtime::get().lev = nullptr;
+			}
+			qk_level_destroy(myLev_);
+		}
 	}
+	// the static operators (HydroSystem<problem_t>::..., RadSystem<problem_t>::...) act on the active level
+	void activate() const { qkhost::Runtime::get().lev = myLev_; }
+	[[nodiscard]] auto levelHandle() const -> qk_level * { return myLev_; }
+	int amrLevel_ = 0;
+	// called between FillBoundary and the physical boundaries: the AMR driver interpolates the uncovered ghost cells here
+	std::function<void(amrex::MultiFab &)> beforePhysBC_;
 
 	// device hook a problem may specialise (reference src/simulation.hpp:1550-1561); evaluated on host staging data
 	static void setCustomBoundaryConditions(const amrex::IntVect & /*iv*/, amrex::Array4<amrex::Real> const & /*dest*/, int /*dcomp*/, int /*numcomp*/,
@@ -417,57 +440,63 @@ template <typename problem_t> class AMRSimulation
 	{
 	}
 
-	void initialize()
+	void initialize(LevelSpec const *spec)
 	{
 		readParameters();
 		auto &rt = qkhost::Runtime::get();
 		if (rt.ctx == nullptr) {
 			qkhost::check(qk_ctx_create(&rt.ctx, 0), "qk_ctx_create");
 		}
-		// geometry + BoxArray from the deck (amrex.n_cell, geometry.*, amr.max_grid_size)
-		amrex::ParmParse pg("geometry");
-		amrex::ParmParse pa("amr");
-		std::vector<double> plo{0, 0, 0}, phi{1, 1, 1};
-		std::vector<int> per{0, 0, 0}, ncell{32, 32, 32}, mgs;
-		pg.queryarr("prob_lo", plo);
-		pg.queryarr("prob_hi", phi);
-		pg.queryarr("is_periodic", per);
-		pa.queryarr("n_cell", ncell);
-		if (!pa.queryarr("max_grid_size", mgs) || mgs.empty()) {
-			mgs = {128};
-		}
-		while (mgs.size() < 3) {
-			mgs.push_back(mgs.back());
-		}
 		auto &g = geom[0];
-		for (int d = 0; d < 3; ++d) {
-			bool const active = d < AMREX_SPACEDIM;
-			g.domain.lo[d] = 0;
-			g.domain.hi[d] = active ? ncell[d] - 1 : 0;
-			g.periodic[d] = active ? per[d] : 0;
-			if (active) {
-				g.prob_lo[d] = plo[d];
-				g.prob_hi[d] = phi[d];
-				g.dx[d] = (phi[d] - plo[d]) / ncell[d];
-			}
-		}
 		grids_.clear();
-		int nb[3];
-		for (int d = 0; d < 3; ++d) {
-			nb[d] = (d < AMREX_SPACEDIM) ? (g.domain.length(d) + mgs[d] - 1) / mgs[d] : 1;
-		}
-		for (int kb = 0; kb < nb[2]; ++kb) {
-			for (int jb = 0; jb < nb[1]; ++jb) {
-				for (int ib = 0; ib < nb[0]; ++ib) {
-					int const idx[3] = {ib, jb, kb};
-					amrex::Box b;
-					for (int d = 0; d < 3; ++d) {
-						int const len = g.domain.length(d);
-						int const base = len / nb[d], rem = len % nb[d];
-						b.lo[d] = idx[d] * base + std::min(idx[d], rem);
-						b.hi[d] = b.lo[d] + base + (idx[d] < rem ? 1 : 0) - 1;
+		if (spec != nullptr) {
+			g = spec->geom;
+			grids_ = spec->boxes;
+			amrLevel_ = spec->level;
+		} else {
+			// geometry + BoxArray from the deck (amrex.n_cell, geometry.*, amr.max_grid_size)
+			amrex::ParmParse pg("geometry");
+			amrex::ParmParse pa("amr");
+			std::vector<double> plo{0, 0, 0}, phi{1, 1, 1};
+			std::vector<int> per{0, 0, 0}, ncell{32, 32, 32}, mgs;
+			pg.queryarr("prob_lo", plo);
+			pg.queryarr("prob_hi", phi);
+			pg.queryarr("is_periodic", per);
+			pa.queryarr("n_cell", ncell);
+			if (!pa.queryarr("max_grid_size", mgs) || mgs.empty()) {
+				mgs = {128};
+			}
+			while (mgs.size() < 3) {
+				mgs.push_back(mgs.back());
+			}
+			for (int d = 0; d < 3; ++d) {
+				bool const active = d < AMREX_SPACEDIM;
+				g.domain.lo[d] = 0;
+				g.domain.hi[d] = active ? ncell[d] - 1 : 0;
+				g.periodic[d] = active ? per[d] : 0;
+				if (active) {
+					g.prob_lo[d] = plo[d];
+					g.prob_hi[d] = phi[d];
+					g.dx[d] = (phi[d] - plo[d]) / ncell[d];
+				}
+			}
+			int nb[3];
+			for (int d = 0; d < 3; ++d) {
+				nb[d] = (d < AMREX_SPACEDIM) ? (g.domain.length(d) + mgs[d] - 1) / mgs[d] : 1;
+			}
+			for (int kb = 0; kb < nb[2]; ++kb) {
+				for (int jb = 0; jb < nb[1]; ++jb) {
+					for (int ib = 0; ib < nb[0]; ++ib) {
+						int const idx[3] = {ib, jb, kb};
+						amrex::Box b;
+						for (int d = 0; d < 3; ++d) {
+							int const len = g.domain.length(d);
+							int const base = len / nb[d], rem = len % nb[d];
+							b.lo[d] = idx[d] * base + std::min(idx[d], rem);
+							b.hi[d] = b.lo[d] + base + (idx[d] < rem ? 1 : 0) - 1;
+						}
+						grids_.push_back(b);
 					}
-					grids_.push_back(b);
 				}
 			}
 		}
@@ -475,10 +504,8 @@ template <typename problem_t> class AMRSimulation
 		for (auto const &b : grids_) {
 			qb.push_back({{b.lo[0], b.lo[1], b.lo[2]}, {b.hi[0], b.hi[1], b.hi[2]}});
 		}
-		if (rt.lev != nullptr) {
-			qk_level_destroy(rt.lev);
-		}
-		qkhost::check(qk_level_create(rt.ctx, &rt.lev, AMREX_SPACEDIM, static_cast<int>(qb.size()), qb.data()), "qk_level_create");
+		qkhost::check(qk_level_create(rt.ctx, &myLev_, AMREX_SPACEDIM, static_cast<int>(qb.size()), qb.data()), "qk_level_create");
+		rt.lev = myLev_;
 		int const nc = Physics_Indices<problem_t>::nvarTotal_cc;
 		state_new_cc_[0].define(grids_, nc, nghost_cc_);
 		state_old_cc_[0].define(grids_, nc, nghost_cc_);
@@ -491,7 +518,7 @@ template <typename problem_t> class AMRSimulation
 		}
 		qg.ndim = AMREX_SPACEDIM;
 		std::vector<int> owner(qb.size(), 0);
-		qkhost::check(qk_ghost_plan_create(rt.lev, &plan_, &qg, nghost_cc_, nc, static_cast<int>(qb.size()), qb.data(), owner.data(), 0),
+		qkhost::check(qk_ghost_plan_create(myLev_, &plan_, &qg, nghost_cc_, nc, static_cast<int>(qb.size()), qb.data(), owner.data(), 0),
 			      "qk_ghost_plan_create");
 	}
 
@@ -539,10 +566,29 @@ template <typename problem_t> class AMRSimulation
 		areInitialConditionsDefined_ = true;
 	}
 
+	// setInitialConditionsAtLevel_cc (reference src/simulation.hpp:1608-1626): the problem's initial conditions on this level's boxes
+	void setInitialConditionsAtLevel()
+	{
+		auto &mf = state_new_cc_[0];
+		for (int b = 0; b < mf.size(); ++b) {
+			std::vector<double> h(static_cast<size_t>(mf.fabbox(b).numPts()) * mf.nComp(), 0.0);
+			quokka::grid grid_elem{amrex::Array4<double>(h.data(), mf.fabbox(b), mf.nComp()), mf.validbox(b), geom[0].CellSizeArray(),
+					       geom[0].ProbLoArray(), geom[0].ProbHiArray()};
+			setInitialConditionsOnGrid(grid_elem);
+			mf.copyFromHost(b, h);
+		}
+		amrex::MultiFab::Copy(state_old_cc_[0], state_new_cc_[0]);
+		areInitialConditionsDefined_ = true;
+	}
+
 	// level-0 branch of fillBoundaryConditions (reference src/simulation.hpp:1751-1776)
 	void fillBoundaryConditions(amrex::MultiFab &state)
 	{
+		activate();
 		qkhost::check(qk_FillBoundary_local(plan_, nullptr, qkhost::tab(state)), "FillBoundary");
+		if (beforePhysBC_) {
+			beforePhysBC_(state);
+		}
 		if (!geom[0].isAllPeriodic()) {
 			std::vector<qk_bcrec> bcs(BCs_cc_.size());
 			for (size_t n = 0; n < BCs_cc_.size(); ++n) {
@@ -557,6 +603,7 @@ template <typename problem_t> class AMRSimulation
 	}
 
       protected:
+	qk_level *myLev_ = nullptr;
 	qk_ghost_plan *plan_ = nullptr;
 	qk_dirichlet_face dirichlet_[6] = {};
 	bool hasDirichlet_ = false;
@@ -647,7 +694,53 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 
 	static constexpr int ncompHydro_ = HydroSystem<problem_t>::nvar_;
 
-	explicit QuokkaSimulation(amrex::Vector<amrex::BCRec> &BCs_cc) : AMRSimulation<problem_t>(BCs_cc)
+	explicit QuokkaSimulation(amrex::Vector<amrex::BCRec> &BCs_cc) : AMRSimulation<problem_t>(BCs_cc) { construct(); }
+	// one level of an AMR hierarchy (quokka_amr.hpp)
+	QuokkaSimulation(amrex::Vector<amrex::BCRec> &BCs_cc, LevelSpec const &spec) : AMRSimulation<problem_t>(BCs_cc, spec) { construct(); }
+
+	// --- AMR level bookkeeping (used by quokka_amr.hpp; a uniform-grid run leaves the defaults)
+	double tOldLev_ = 0.0, tNewLev_ = 0.0; // tOld_[lev], tNew_[lev]
+	double fillTime_ = 0.0;		       // the time a ghost fill refers to (coarse data are interpolated to it)
+	bool storeFluxRk2_ = false;	       // leave flux_rk2 in halfFlux_ for the flux registers
+	std::function<void(double)> afterAdvance_; // incrementFluxRegisters(dt) after every successful advanceHydroAtLevel
+	[[nodiscard]] auto halfFlux() -> std::array<amrex::MultiFab, AMREX_SPACEDIM> & { return halfFlux_; }
+	// ErrorEst(lev, tags, time, ngrow): problem hook (reference src/QuokkaSimulation.hpp:213).  Device lambdas cannot be compiled
+	// against the C-ABI; the gradient-threshold family of the reference's problems is one library call: tagRelativeGradient below.
+	virtual void ErrorEst(int /*lev*/, amrex::TagBoxArray & /*tags*/, amrex::Real /*time*/, int /*ngrow*/) {}
+	// field: QK_TAGFIELD_PRESSURE or a component index;  tags SET where max_d max(|q+ - q|, |q - q-|) / q > eta and q > qmin (>= if inclusive)
+	void tagRelativeGradient(amrex::TagBoxArray &tags, int field, double eta_threshold, double q_min, bool min_inclusive)
+	{
+		this->activate();
+		auto t = qkhost::traits<problem_t>();
+		qkhost::check(qk_tag_relative_gradient(this->levelHandle(), nullptr, &t, qkhost::tab(state_new_cc_[0]), reinterpret_cast<qk_carray4 *>(tags.arrays()), field,
+						       eta_threshold, q_min, min_inclusive ? 1 : 0),
+			      "qk_tag_relative_gradient");
+	}
+	void FixupState() // reference src/QuokkaSimulation.hpp:761-770
+	{
+		this->activate();
+		HydroSystem<problem_t>::EnforceLimits(densityFloor_, tempFloor_, state_new_cc_[0]);
+		if (useDualEnergy_ == 1) {
+			HydroSystem<problem_t>::SyncDualEnergy(state_new_cc_[0], d_error_);
+		}
+		haveSignal_ = false;
+	}
+	// CFL time step of this level alone (reference src/simulation.hpp:703-720)
+	[[nodiscard]] auto computeTimestepAtLevel() -> double
+	{
+		this->activate();
+		double const m = (haveSignal_ ? signal_[1] : HydroSystem<problem_t>::maxSignalSpeedLocal(state_new_cc_[0], 1));
+		return cflNumber_ * (minDx() / m);
+	}
+	// advanceSingleTimestepAtLevel for a hydro level of a hierarchy: state_new <- advance(previous state_new) starting at `time`
+	auto advanceLevel(double time, double dt_lev) -> bool
+	{
+		std::swap(state_old_cc_[0], state_new_cc_[0]);
+		return advanceHydroAtLevelWithRetries(time, dt_lev);
+	}
+
+      private:
+	void construct()
 	{
 		amrex::ParmParse hpp("hydro"); // reference src/QuokkaSimulation.hpp:340-350
 		hpp.query("rk_integrator_order", integratorOrder_);
@@ -661,6 +754,8 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		rpp.query("max_substeps", maxSubsteps_);
 		allocate();
 	}
+
+      public:
 
 	void setInitialConditionsOnGrid(quokka::grid const &grid_elem) override;
 	void preCalculateInitialConditions() override;
@@ -695,8 +790,13 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		dt_[0] = dt_0;
 	}
 
+	// amr.max_level > 0: the level machinery of quokka_amr.hpp takes over (this object is level 0); defined there
+	void setInitialConditions();
+	void evolve();
+	std::shared_ptr<AmrDriver<problem_t>> amr_;
+
 	// ------------------------------------------------------------------ evolve (reference src/simulation.hpp:827-981)
-	void evolve()
+	void evolveSingleLevel()
 	{
 		AMREX_ALWAYS_ASSERT(this->areInitialConditionsDefined_);
 		int const nc = Physics_Indices<problem_t>::nvarTotal_cc;
@@ -741,6 +841,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	// ------------------------------------------------------------------ hydro advance (reference src/QuokkaSimulation.hpp:885-1322)
 	auto advanceHydroAtLevelWithRetries(double time, double dt_lev) -> bool
 	{
+		this->activate();
 		const int max_retries = 6;
 		bool success = false;
 		for (int retry_count = 0; retry_count <= max_retries; ++retry_count) {
@@ -754,7 +855,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 				if (substep > 0) {
 					amrex::MultiFab::Copy(state_old_tmp_, state_new_cc_[0]);
 				}
-				success = advanceHydroAtLevel(state_old_tmp_, time, dt_step);
+				success = advanceHydroAtLevel(state_old_tmp_, time + substep * dt_step, dt_step);
 				if (!success) {
 					break;
 				}
@@ -766,14 +867,16 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		return success;
 	}
 
-	auto advanceHydroAtLevel(amrex::MultiFab &state_old_cc_tmp, double /*time*/, double dt_lev) -> bool
+	auto advanceHydroAtLevel(amrex::MultiFab &state_old_cc_tmp, double time, double dt_lev) -> bool
 	{
 		haveSignal_ = false;
+		fillTime_ = time; // reference src/QuokkaSimulation.hpp:1076 (stage 1), :1204 (stage 2: time + dt_lev)
 		this->fillBoundaryConditions(state_old_cc_tmp);
 		if (!stage(1, state_old_cc_tmp, state_old_cc_tmp, state_inter_cc_, dt_lev)) {
 			return false;
 		}
 		if (integratorOrder_ == 2) {
+			fillTime_ = time + dt_lev;
 			this->fillBoundaryConditions(state_inter_cc_);
 			if (!stage(2, state_inter_cc_, state_old_cc_tmp, state_new_cc_[0], dt_lev)) {
 				return false;
@@ -786,7 +889,11 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		if (err != 0) {
 			amrex::Abort("density is negative in SyncDualEnergy! abort!!");
 		}
-		return !isCflViolated(dt_lev);
+		bool const ok = !isCflViolated(dt_lev);
+		if (ok && afterAdvance_) {
+			afterAdvance_(dt_lev); // incrementFluxRegisters (reference src/QuokkaSimulation.hpp:1303-1306)
+		}
+		return ok;
 	}
 
 	auto isCflViolated(double dt_actual) -> bool // reference src/QuokkaSimulation.hpp:992-1013
@@ -1075,6 +1182,11 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		if (useDualEnergy_ == 1) {
 			HydroSystem<problem_t>::SyncDualEnergy(U_out, d_error_);
 		}
+		if (stageNo == 2 && storeFluxRk2_) { // what the flux registers accumulate (possibly FOFC-corrected), as the fused stage leaves it
+			for (int d = 0; d < AMREX_SPACEDIM; ++d) {
+				amrex::MultiFab::Copy(halfFlux_[d], (*fl)[d]);
+			}
+		}
 		return true;
 	}
 
@@ -1109,6 +1221,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 			a.tempFloor = tempFloor_;
 			a.use_dual_energy = useDualEnergy_;
 			a.K_visc = 0.0;
+			a.store_flux_rk2 = storeFluxRk2_ ? 1 : 0;
 			qkhost::check(qk_hydro_stage_fused(qkhost::Runtime::get().lev, nullptr, &t, &a), "qk_hydro_stage_fused");
 			if (readCount() == 0) {
 				if (final_stage) {

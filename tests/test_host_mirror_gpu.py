@@ -77,3 +77,26 @@ def test_radhydro_shell_executable_matches_oracle(tmp_path, oracle):
     print(f"shell C++ mirror vs oracle: worst relative L1 = {worst:.3e}")
     cnt = so.rad_counters()
     assert f"{cnt['solves']} solves" in out or worst > 0.0
+
+
+def test_sedov_amr_executable_matches_python_driver(tmp_path, ctx):
+    """BASELINE config 5 (Sedov, amr.max_level = 2, subcycling + reflux) through the C++ mirror's level machinery (quokka_amr.hpp) at
+    32^3 base resolution: the level-0 state after 8 coarse steps equals the Python driver's (quokka_amd/amr_simulation.py), which
+    tests/test_amr_driver_gpu.py pins by properties — same kernels, same grid generation (library), same schedule."""
+    from quokka_amd.amr_simulation import sedov_amr_problem
+    N, nsteps = 32, 8
+    data, meta, out = run("test_hydro3d_blast", ["geometry.prob_lo=0 0 0", "geometry.prob_hi=1.2 1.2 1.2", "geometry.is_periodic=0 0 0", f"amr.n_cell={N} {N} {N}",
+                                                 "amr.max_level=2", "amr.max_grid_size=32", "amr.blocking_factor=8", "amr.n_error_buf=3", "do_reflux=1",
+                                                 f"max_timesteps={nsteps}"], tmp_path, allow_fail=True)
+    assert int(meta[0]) == nsteps and "Zone-updates on level 2" in out, out[-1500:]
+    amr = sedov_amr_problem(ctx, N, 2, max_grid_size=32, blocking_factor=8)
+    for _ in range(nsteps):
+        amr.step()
+    assert amr.tNew_ == meta[1], (amr.tNew_, meta[1])
+    want = np.zeros((6, N, N, N))
+    c = amr.levels[0]
+    for (lo, hi), v in zip(c.my_boxes, c.gather_valid_local()):
+        want[:, lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1] = v
+    assert np.array_equal(data.reshape(6, N, N, N), want), f"max abs diff {np.abs(data.reshape(6, N, N, N) - want).max()}"
+    for l in range(3):
+        assert f"Zone-updates on level {l}: {amr.cellUpdatesEachLevel_[l]} " in out
