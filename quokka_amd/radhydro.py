@@ -153,8 +153,9 @@ class RadhydroSimulation(HydroSimulation):
     def _allreduce_sum_list(self, vals):
         if self.nranks > 1:
             import torch.distributed as dist
+            from . import comm
             t = torch.tensor(vals, dtype=torch.int64, device=self.ctx.device)
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            comm.all_reduce(t, dist.ReduceOp.SUM)
             return [int(x) for x in t.tolist()]
         return vals
 

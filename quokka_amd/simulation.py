@@ -150,25 +150,21 @@ class GhostExchange:
         [-> physical boundaries of the boxes without remote ghosts -> between()] -> wait -> unpack -> (remaining) physical
         boundaries (reference src/simulation.hpp:1755-1773).  RCCL runs the transfers on its own stream, ordered after the
         pack kernels; the work enqueued by `between` on the compute stream overlaps them."""
-        import torch.distributed as dist
-        reqs = []
+        pending = None
         if self.peers:
+            from . import comm
             for k, r, sbuf, rbuf in self.peers:
                 pack(k, sbuf)
             # (RCCL work is stream-ordered after the pack kernels by torch's ProcessGroupNCCL: no host sync here)
-            ops = []
-            for k, r, sbuf, rbuf in self.peers:
-                ops.append(dist.P2POp(dist.isend, sbuf, r))
-                ops.append(dist.P2POp(dist.irecv, rbuf, r))
-            reqs = dist.batch_isend_irecv(ops)
+            pending = comm.exchange([(r, sbuf, rbuf) for k, r, sbuf, rbuf in self.peers])
         local()
         bc = not self.geom.is_all_periodic()
         if between is not None:
             if bc:
                 physbc(capi.BOXES_LOCAL_ONLY)
             between()
-        for q in reqs:
-            q.wait()
+        if pending is not None:
+            pending.wait()
         for k, r, sbuf, rbuf in self.peers:
             unpack(k, rbuf)
         if before_physbc is not None:  # AMR: coarse -> fine interpolation of the ghost cells no fine box covers (FillPatchTwoLevels)
@@ -288,16 +284,18 @@ class HydroSimulation:
     def _allreduce_max(self, x: float) -> float:
         if self.nranks > 1:
             import torch.distributed as dist
+            from . import comm
             t = torch.tensor([x], dtype=torch.float64, device=self.ctx.device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            comm.all_reduce(t, dist.ReduceOp.MAX)
             return float(t.item())
         return x
 
     def _allreduce_sum(self, x: int) -> int:
         if self.nranks > 1:
             import torch.distributed as dist
+            from . import comm
             t = torch.tensor([x], dtype=torch.int64, device=self.ctx.device)
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            comm.all_reduce(t, dist.ReduceOp.SUM)
             return int(t.item())
         return x
 
@@ -480,7 +478,8 @@ class HydroSimulation:
         v = torch.cat([self.dev_signal, self.dev_counters[0:1].to(torch.float64)]) if final else self.dev_counters[0:1].to(torch.float64)
         if self.nranks > 1:
             import torch.distributed as dist
-            dist.all_reduce(v, op=dist.ReduceOp.MAX)
+            from . import comm
+            comm.all_reduce(v, dist.ReduceOp.MAX)
         vals = v.tolist()
         nbad = int(vals[-1])
         if final and nbad == 0:
