@@ -282,6 +282,12 @@ int qk_FillBoundary_unpack(qk_ghost_plan *plan, qk_stream s, int k, qk_array4 *s
 /* iMultiFab flavours (redoFlag strips between GPUs; counts of qk_ghost_plan_peer are elements, here 4-byte ints) */
 int qk_FillBoundary_pack_int(qk_ghost_plan *plan, qk_stream s, int k, const qk_iarray4 *state, int *sendbuf);
 int qk_FillBoundary_unpack_int(qk_ghost_plan *plan, qk_stream s, int k, qk_iarray4 *state, const int *recvbuf);
+/* amrex::FabArray::SumBoundary with the same plan: every ghost value is ADDED to the valid cell it is a copy of.  Across ranks the wire
+ * runs backwards: pack takes the strips this rank receives in FillBoundary (buffer of recv_count doubles), unpack adds a buffer of
+ * send_count doubles to the valid cells this rank sends.  (Used for the reflux increments that land in ghost cells of a coarse box.) */
+int qk_SumBoundary_local(qk_ghost_plan *plan, qk_stream s, qk_array4 *state);
+int qk_SumBoundary_pack(qk_ghost_plan *plan, qk_stream s, int k, const qk_array4 *state, double *buf);
+int qk_SumBoundary_unpack(qk_ghost_plan *plan, qk_stream s, int k, qk_array4 *state, const double *buf);
 /* physical boundaries (after FillBoundary): bcs[ncomp]; dirichlet[dim][side] may be NULL */
 int qk_FillPhysicalBoundary(qk_ghost_plan *plan, qk_stream s, qk_array4 *state, const qk_bcrec *bcs, const qk_dirichlet_face *dirichlet);
 /* Overlap of the exchange with the update (north_star: "FillBoundary ... overlapped with interior-cell updates"; the

@@ -140,6 +140,9 @@ def lib() -> C.CDLL:
         L.qk_FillBoundary_local_int.argtypes = [vp, vp, vp]
         L.qk_FillBoundary_pack.argtypes = [vp, vp, ci, vp, vp]
         L.qk_FillBoundary_unpack.argtypes = [vp, vp, ci, vp, vp]
+        L.qk_SumBoundary_local.argtypes = [vp, vp, vp]
+        L.qk_SumBoundary_pack.argtypes = [vp, vp, ci, vp, vp]
+        L.qk_SumBoundary_unpack.argtypes = [vp, vp, ci, vp, vp]
         L.qk_FillBoundary_pack_int.argtypes = [vp, vp, ci, vp, vp]
         L.qk_FillBoundary_unpack_int.argtypes = [vp, vp, ci, vp, vp]
         L.qk_FillPhysicalBoundary.argtypes = [vp, vp, vp, P(BCRec), P(DirichletFace)]
@@ -190,7 +193,7 @@ DECLARED_SYMBOLS = [
     "qk_rad_ConservedToPrimitive", "qk_rad_ComputeFluxes", "qk_rad_computeRadiationFluxes", "qk_rad_PredictStep", "qk_rad_AddFluxesRK2",
     "qk_rad_AddSourceTermsSingleGroup",
     "qk_ghost_plan_create", "qk_ghost_plan_destroy", "qk_ghost_plan_num_peers", "qk_ghost_plan_peer", "qk_ghost_plan_num_items", "qk_ghost_plan_item",
-    "qk_FillBoundary_local", "qk_FillBoundary_local_int", "qk_FillBoundary_pack", "qk_FillBoundary_unpack", "qk_FillBoundary_pack_int", "qk_FillBoundary_unpack_int", "qk_FillPhysicalBoundary",
+    "qk_FillBoundary_local", "qk_FillBoundary_local_int", "qk_FillBoundary_pack", "qk_FillBoundary_unpack", "qk_FillBoundary_pack_int", "qk_FillBoundary_unpack_int", "qk_SumBoundary_local", "qk_SumBoundary_pack", "qk_SumBoundary_unpack", "qk_FillPhysicalBoundary",
     "qk_FillPhysicalBoundary_subset", "qk_ghost_plan_box_is_remote", "qk_ghost_plan_set_box_remote",
     "qk_tag_relative_gradient", "qk_avgdown_plan_create", "qk_avgdown_plan_destroy", "qk_avgdown_plan_num_items", "qk_average_down", "qk_PreInterpState", "qk_PostInterpState",
     "qk_interp_plan_create", "qk_interp_plan_destroy", "qk_interp_plan_num_items", "qk_interp_plan_item", "qk_InterpFromCoarse",

@@ -70,7 +70,7 @@ void partitionShells(qk_ghost_plan *P)
 	P->n_shells_indep = static_cast<int>(std::count_if(P->shells.begin(), P->shells.end(), indep));
 }
 
-enum CopyMode { MODE_LOCAL = 0, MODE_PACK = 1, MODE_UNPACK = 2 };
+enum CopyMode { MODE_LOCAL = 0, MODE_PACK = 1, MODE_UNPACK = 2, MODE_SUM_LOCAL = 3, MODE_SUM_PACK = 4, MODE_SUM_UNPACK = 5 };
 
 // blockIdx.y = item; grid-stride over region cells x ncomp
 template <int MODE, typename T = double, typename D = qk_array4>
@@ -95,9 +95,19 @@ __global__ void __launch_bounds__(256) k_copy(const CopyItem *items, const D *st
 		} else if (MODE == MODE_PACK) {
 			A4<T, D> Src(state_t[it.src_box]);
 			buf[it.offset + t] = Src(di - it.shift[0], dj - it.shift[1], dk - it.shift[2], n);
-		} else {
+		} else if (MODE == MODE_UNPACK) {
 			A4<T, D> Dst(state_t[it.dst_box]);
 			Dst(di, dj, dk, n) = buf[it.offset + t];
+		} else if (MODE == MODE_SUM_LOCAL) { // SumBoundary: the ghost copy is added to the valid cell it mirrors
+			A4<T, D> Dst(state_t[it.dst_box]);
+			A4<T, D> Src(state_t[it.src_box]);
+			atomicAdd(&Src(di - it.shift[0], dj - it.shift[1], dk - it.shift[2], n), Dst(di, dj, dk, n));
+		} else if (MODE == MODE_SUM_PACK) { // items = the strips this rank RECEIVES in FillBoundary: their ghost values go back
+			A4<T, D> Dst(state_t[it.dst_box]);
+			buf[it.offset + t] = Dst(di, dj, dk, n);
+		} else { // items = the strips this rank SENDS in FillBoundary: add what came back to the valid cells
+			A4<T, D> Src(state_t[it.src_box]);
+			atomicAdd(&Src(di - it.shift[0], dj - it.shift[1], dk - it.shift[2], n), buf[it.offset + t]);
 		}
 	}
 }
@@ -471,6 +481,57 @@ int qk_FillBoundary_local_int(qk_ghost_plan *plan, qk_stream s, qk_iarray4 *stat
 	hipLaunchKernelGGL((k_copy<MODE_LOCAL, int, qk_iarray4>),
 			   gridFor(static_cast<int64_t>(plan->max_local_cells) * plan->ncomp, static_cast<int>(plan->local.size())), dim3(256), 0,
 			   static_cast<hipStream_t>(s), plan->d_local, state_t, static_cast<int *>(nullptr), plan->ncomp);
+	QK_HIP_CHECK(ctx, hipGetLastError());
+	return QK_OK;
+}
+
+// amrex::FabArray::SumBoundary: every ghost value is added to the valid cell it is a copy of (same plan as FillBoundary, roles swapped)
+int qk_SumBoundary_local(qk_ghost_plan *plan, qk_stream s, qk_array4 *state_t)
+{
+	if (plan == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	qk_ctx *ctx = plan->lev->ctx;
+	QK_REQUIRE(ctx, state_t, "SumBoundary_local: NULL state");
+	if (plan->local.empty()) {
+		return QK_OK;
+	}
+	hipLaunchKernelGGL(k_copy<MODE_SUM_LOCAL>, gridFor(static_cast<int64_t>(plan->max_local_cells) * plan->ncomp, static_cast<int>(plan->local.size())), dim3(256), 0,
+			   static_cast<hipStream_t>(s), plan->d_local, state_t, static_cast<double *>(nullptr), plan->ncomp);
+	QK_HIP_CHECK(ctx, hipGetLastError());
+	return QK_OK;
+}
+
+int qk_SumBoundary_pack(qk_ghost_plan *plan, qk_stream s, int k, const qk_array4 *state_t, double *buf)
+{
+	if (plan == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	qk_ctx *ctx = plan->lev->ctx;
+	QK_REQUIRE(ctx, k >= 0 && k < static_cast<int>(plan->peers.size()) && state_t && buf, "SumBoundary_pack: bad argument");
+	PeerPlan const &pp = plan->peers[k];
+	if (pp.recv.empty()) {
+		return QK_OK;
+	}
+	hipLaunchKernelGGL(k_copy<MODE_SUM_PACK>, gridFor(static_cast<int64_t>(pp.max_recv_cells) * plan->ncomp, static_cast<int>(pp.recv.size())), dim3(256), 0,
+			   static_cast<hipStream_t>(s), pp.d_recv, const_cast<qk_array4 *>(state_t), buf, plan->ncomp);
+	QK_HIP_CHECK(ctx, hipGetLastError());
+	return QK_OK;
+}
+
+int qk_SumBoundary_unpack(qk_ghost_plan *plan, qk_stream s, int k, qk_array4 *state_t, const double *buf)
+{
+	if (plan == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	qk_ctx *ctx = plan->lev->ctx;
+	QK_REQUIRE(ctx, k >= 0 && k < static_cast<int>(plan->peers.size()) && state_t && buf, "SumBoundary_unpack: bad argument");
+	PeerPlan const &pp = plan->peers[k];
+	if (pp.send.empty()) {
+		return QK_OK;
+	}
+	hipLaunchKernelGGL(k_copy<MODE_SUM_UNPACK>, gridFor(static_cast<int64_t>(pp.max_send_cells) * plan->ncomp, static_cast<int>(pp.send.size())), dim3(256), 0,
+			   static_cast<hipStream_t>(s), pp.d_send, state_t, const_cast<double *>(buf), plan->ncomp);
 	QK_HIP_CHECK(ctx, hipGetLastError());
 	return QK_OK;
 }

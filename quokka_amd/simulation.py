@@ -173,6 +173,23 @@ class GhostExchange:
         if bc:
             physbc(capi.BOXES_REMOTE_DEPENDENT if between is not None else capi.BOXES_ALL)
 
+    def sum_boundary(self, state: MultiFab):
+        """amrex::FabArray::SumBoundary: every ghost value is added to the valid cell it is a copy of; across ranks the strips travel in the
+        opposite direction of fill() (receive buffers are sent, send buffers receive)."""
+        ctx = self.lev.ctx
+        L, s = ctx.L, ctx.stream()
+        pending = None
+        if self.peers:
+            from . import comm
+            for k, r, sbuf, rbuf in self.peers:
+                ctx.check(L.qk_SumBoundary_pack(self.h, s, k, state.ptr, C.c_void_p(rbuf.data_ptr())), "SumBoundary_pack")
+            pending = comm.exchange([(r, rbuf, sbuf) for k, r, sbuf, rbuf in self.peers])
+        ctx.check(L.qk_SumBoundary_local(self.h, s, state.ptr), "SumBoundary_local")
+        if pending is not None:
+            pending.wait()
+        for k, r, sbuf, rbuf in self.peers:
+            ctx.check(L.qk_SumBoundary_unpack(self.h, s, k, state.ptr, C.c_void_p(sbuf.data_ptr())), "SumBoundary_unpack")
+
     def remote_boxes(self) -> List[int]:
         """local boxes with ghost cells filled from another rank (the late group of an overlapped fill)"""
         L = self.lev.ctx.L

@@ -200,3 +200,33 @@ def test_sedov_ragged_boxes_bit_exact(ctx, oracle):
         assert so.step() and sg.step()
         assert so.dt == sg.dt_, f"dt differs at step {it}"
     assert np.array_equal(gather_oracle(so, N), gather_gpu(sg, N))
+
+
+@pytest.mark.parametrize("periodic", [[0, 0, 0], [1, 1, 1]])
+def test_sum_boundary_is_the_transpose_of_fill_boundary(ctx, periodic):
+    """SumBoundary adds every ghost value to the valid cell it mirrors: checked item by item against the FillBoundary plan (integer-valued
+    data, so the order of the additions cannot matter)"""
+    from quokka_amd import capi
+    from quokka_amd.multifab import Level, MultiFab
+    from quokka_amd.simulation import GhostExchange, Geometry, chop_domain
+    N, mgs, ng, nc = 16, 8, 1, 2
+    geom = Geometry(3, [N] * 3, [0.0] * 3, [1.0] * 3, periodic)
+    boxes = chop_domain([N] * 3, [mgs] * 3)
+    lev = Level(ctx, 3, boxes)
+    bcs = [([capi.BC_INT_DIR] * 3, [capi.BC_INT_DIR] * 3)] * nc
+    ex = GhostExchange(lev, geom, nc, ng, boxes, [0] * len(boxes), 0, bcs)
+    mf = MultiFab(lev, nc, ng)
+    rng = np.random.default_rng(4)
+    host = [rng.integers(-50, 50, size=s).astype(np.float64) for s in mf.shapes]
+    for b, a in enumerate(host):
+        mf.set_fab(b, a)
+    ex.sum_boundary(mf)
+    torch.cuda.synchronize()
+    want = [a.copy() for a in host]
+    for db, sb, lo, hi, sh, off in ex.items(0):
+        d0, s0 = mf.begins[db], mf.begins[sb]
+        g = host[db][:, lo[2] - d0[2]:hi[2] - d0[2] + 1, lo[1] - d0[1]:hi[1] - d0[1] + 1, lo[0] - d0[0]:hi[0] - d0[0] + 1]
+        want[sb][:, lo[2] - sh[2] - s0[2]:hi[2] - sh[2] - s0[2] + 1, lo[1] - sh[1] - s0[1]:hi[1] - sh[1] - s0[1] + 1, lo[0] - sh[0] - s0[0]:hi[0] - sh[0] - s0[0] + 1] += g
+    for b in range(len(boxes)):
+        assert np.array_equal(mf.fab_numpy(b), want[b]), f"box {b}"
+    assert any(not np.array_equal(want[b], host[b]) for b in range(len(boxes)))
