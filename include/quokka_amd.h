@@ -344,8 +344,10 @@ int qk_average_down(qk_avgdown_plan *plan, qk_stream s, const qk_array4 *fine, q
  * The coarse arrays need their ghost cells filled (stencil: one coarse cell around the parent cell).  AMReX's interpolater is
  * restated from its documentation: parity with the reference is unpinned for this entry point. */
 typedef struct qk_interp_plan qk_interp_plan;
-int qk_interp_plan_create(qk_level *crse, qk_level *fine, const qk_geometry *fine_geom, int nghost, const int ratio[3], int whole_fab,
-			  qk_interp_plan **plan);
+/* all_fine (n_all_fine boxes, may be NULL = the boxes of `fine`): the fine boxes of ALL ranks — ghost cells under a remote fine box
+ * are filled by the fine-fine exchange, not by interpolation */
+int qk_interp_plan_create(qk_level *crse, qk_level *fine, const qk_geometry *fine_geom, int nghost, const int ratio[3], int whole_fab, int n_all_fine,
+			  const qk_box *all_fine, qk_interp_plan **plan);
 int qk_interp_plan_destroy(qk_interp_plan *plan);
 int qk_interp_plan_num_items(qk_interp_plan *plan);
 int qk_interp_plan_item(qk_interp_plan *plan, int idx, int *fine_box, int *crse_box, int lo[3], int hi[3]);
@@ -358,7 +360,11 @@ int qk_InterpFromCoarse(qk_interp_plan *plan, qk_stream s, qk_array4 *fine, cons
  * another fine box, inside the (periodic) domain.  See qk_amr_fluxreg.hip for the accumulated expression.  Parity unpinned
  * (AMReX's kernel is restated). */
 typedef struct qk_fluxreg qk_fluxreg;
-int qk_fluxreg_create(qk_level *crse, qk_level *fine, const qk_geometry *crse_geom, const int ratio[3], int ncomp, qk_fluxreg **fr);
+/* all_fine as for qk_interp_plan_create.  reg_nghost > 0: a register cell owned by another rank is kept in a ghost cell (within
+ * reg_nghost) of a local coarse box; Reflux must then target a zeroed increment array with that many ghost cells, to be folded with
+ * qk_SumBoundary_* and added to the state (quokka_amd/amr_simulation.py).  reg_nghost = 0: single rank, Reflux straight into the state. */
+int qk_fluxreg_create(qk_level *crse, qk_level *fine, const qk_geometry *crse_geom, const int ratio[3], int ncomp, int n_all_fine, const qk_box *all_fine,
+		      int reg_nghost, qk_fluxreg **fr);
 int qk_fluxreg_destroy(qk_fluxreg *fr);
 int qk_fluxreg_num_items(qk_fluxreg *fr);
 int qk_fluxreg_item(qk_fluxreg *fr, int idx, int *dir, int *side, int *fine_box, int *crse_box, int lo[3], int hi[3], int shift[3]);

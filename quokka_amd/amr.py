@@ -17,6 +17,14 @@ from . import capi
 from .multifab import Level, MultiFab
 
 
+def _box_array(boxes):
+    """(n, ctypes array | None) for an optional global box list"""
+    if boxes is None:
+        return 0, None
+    arr = (capi.Box * max(len(boxes), 1))(*[capi.Box((C.c_int * 3)(*[int(x) for x in lo]), (C.c_int * 3)(*[int(x) for x in hi])) for lo, hi in boxes])
+    return len(boxes), arr
+
+
 def TagBoxArray(lev: Level) -> MultiFab:
     """amrex::TagBoxArray: one char per cell, no ghost cells, cleared"""
     return MultiFab(lev, 1, 0, dtype=torch.int8, fill=capi.TAG_CLEAR)
@@ -62,12 +70,13 @@ class InterpFromCoarse:
     """coarse -> fine part of FillPatchTwoLevels (reference src/simulation.hpp:1789-1858): interpolates the fine cells that no fine
     box covers (whole_fab: every cell of the grown fine boxes) from w_old * crse_old + w_new * crse_new"""
 
-    def __init__(self, crse: Level, fine: Level, fine_geom, nghost: int, ratio=(2, 2, 2), whole_fab: bool = False):
+    def __init__(self, crse: Level, fine: Level, fine_geom, nghost: int, ratio=(2, 2, 2), whole_fab: bool = False, all_fine_boxes=None):
         self.crse, self.fine = crse, fine
         self._geom_c = fine_geom.c_struct()
         h = C.c_void_p()
-        crse.ctx.check(crse.ctx.L.qk_interp_plan_create(crse.h, fine.h, C.byref(self._geom_c), nghost, (C.c_int * 3)(*ratio), int(whole_fab), C.byref(h)),
-                       "qk_interp_plan_create")
+        n_all, arr = _box_array(all_fine_boxes)
+        crse.ctx.check(crse.ctx.L.qk_interp_plan_create(crse.h, fine.h, C.byref(self._geom_c), nghost, (C.c_int * 3)(*ratio), int(whole_fab), n_all, arr,
+                                                        C.byref(h)), "qk_interp_plan_create")
         self.h = h
 
     def items(self):
@@ -95,11 +104,13 @@ class InterpFromCoarse:
 class FluxRegister:
     """amrex::YAFluxRegister between `crse` and the next finer level `fine` (reference src/simulation.hpp:1345-1387, :1308)"""
 
-    def __init__(self, crse: Level, fine: Level, crse_geom, ncomp: int, ratio=(2, 2, 2)):
+    def __init__(self, crse: Level, fine: Level, crse_geom, ncomp: int, ratio=(2, 2, 2), all_fine_boxes=None, reg_nghost: int = 0):
         self.crse, self.fine, self.ncomp = crse, fine, ncomp
         self._geom_c = crse_geom.c_struct()
         h = C.c_void_p()
-        crse.ctx.check(crse.ctx.L.qk_fluxreg_create(crse.h, fine.h, C.byref(self._geom_c), (C.c_int * 3)(*ratio), ncomp, C.byref(h)), "qk_fluxreg_create")
+        n_all, arr = _box_array(all_fine_boxes)
+        crse.ctx.check(crse.ctx.L.qk_fluxreg_create(crse.h, fine.h, C.byref(self._geom_c), (C.c_int * 3)(*ratio), ncomp, n_all, arr, reg_nghost, C.byref(h)),
+                       "qk_fluxreg_create")
         self.h = h
 
     def items(self):

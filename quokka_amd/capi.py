@@ -155,12 +155,12 @@ def lib() -> C.CDLL:
         L.qk_avgdown_plan_destroy.argtypes = [vp]
         L.qk_avgdown_plan_num_items.argtypes = [vp]
         L.qk_average_down.argtypes = [vp, vp, vp, vp, ci, ci]
-        L.qk_interp_plan_create.argtypes = [vp, vp, P(Geometry), ci, ci * 3, ci, P(vp)]
+        L.qk_interp_plan_create.argtypes = [vp, vp, P(Geometry), ci, ci * 3, ci, ci, vp, P(vp)]
         L.qk_interp_plan_destroy.argtypes = [vp]
         L.qk_interp_plan_num_items.argtypes = [vp]
         L.qk_interp_plan_item.argtypes = [vp, ci, P(ci), P(ci), ci * 3, ci * 3]
         L.qk_InterpFromCoarse.argtypes = [vp, vp, vp, vp, vp, C.c_double, C.c_double, ci, ci, ci]
-        L.qk_fluxreg_create.argtypes = [vp, vp, P(Geometry), ci * 3, ci, P(vp)]
+        L.qk_fluxreg_create.argtypes = [vp, vp, P(Geometry), ci * 3, ci, ci, vp, ci, P(vp)]
         L.qk_fluxreg_destroy.argtypes = [vp]
         L.qk_fluxreg_num_items.argtypes = [vp]
         L.qk_fluxreg_item.argtypes = [vp, ci, P(ci), P(ci), P(ci), P(ci), ci * 3, ci * 3, ci * 3]

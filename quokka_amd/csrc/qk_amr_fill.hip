@@ -172,7 +172,8 @@ __global__ void __launch_bounds__(256) k_interp(const InterpItem *items, qk_arra
 
 extern "C" {
 
-int qk_interp_plan_create(qk_level *crse, qk_level *fine, const qk_geometry *fine_geom, int nghost, const int ratio[3], int whole_fab, qk_interp_plan **plan)
+int qk_interp_plan_create(qk_level *crse, qk_level *fine, const qk_geometry *fine_geom, int nghost, const int ratio[3], int whole_fab, int n_all_fine,
+			  const qk_box *all_fine, qk_interp_plan **plan)
 {
 	if (crse == nullptr || fine == nullptr || plan == nullptr || ratio == nullptr || fine_geom == nullptr) {
 		return QK_ERR_INVALID;
@@ -199,16 +200,19 @@ int qk_interp_plan_create(qk_level *crse, qk_level *fine, const qk_geometry *fin
 	for (int d = 0; d < 3; ++d) {
 		rng[d] = (d < ndim && fine_geom->periodic[d] != 0) ? 1 : 0;
 	}
+	// the fine boxes of ALL ranks cover ghost cells (those are filled by the fine-fine exchange); default: this rank's boxes
+	const int ncov = (all_fine != nullptr) ? n_all_fine : fine->nboxes;
+	const qk_box *cov = (all_fine != nullptr) ? all_fine : fine->boxes.data();
 	if (whole_fab == 0) {
-		for (int b = 0; b < fine->nboxes; ++b) {
+		for (int b = 0; b < ncov; ++b) {
 			for (int sz = -rng[2]; sz <= rng[2]; ++sz) {
 				for (int sy = -rng[1]; sy <= rng[1]; ++sy) {
 					for (int sx = -rng[0]; sx <= rng[0]; ++sx) {
 						HBox v{};
 						const int sh[3] = {sx * len[0], sy * len[1], sz * len[2]};
 						for (int d = 0; d < 3; ++d) {
-							v.lo[d] = fine->boxes[b].lo[d] + sh[d];
-							v.hi[d] = fine->boxes[b].hi[d] + sh[d];
+							v.lo[d] = cov[b].lo[d] + sh[d];
+							v.hi[d] = cov[b].hi[d] + sh[d];
 						}
 						covered.push_back(v);
 					}

@@ -139,7 +139,8 @@ __global__ void __launch_bounds__(256) k_fluxreg(const FrItem *items, double *re
 
 extern "C" {
 
-int qk_fluxreg_create(qk_level *crse, qk_level *fine, const qk_geometry *crse_geom, const int ratio[3], int ncomp, qk_fluxreg **fr)
+int qk_fluxreg_create(qk_level *crse, qk_level *fine, const qk_geometry *crse_geom, const int ratio[3], int ncomp, int n_all_fine, const qk_box *all_fine,
+		      int reg_nghost, qk_fluxreg **fr)
 {
 	if (crse == nullptr || fine == nullptr || fr == nullptr || ratio == nullptr || crse_geom == nullptr) {
 		return QK_ERR_INVALID;
@@ -160,17 +161,27 @@ int qk_fluxreg_create(qk_level *crse, qk_level *fine, const qk_geometry *crse_ge
 		len[d] = dom.hi[d] - dom.lo[d] + 1;
 		rng[d] = (d < ndim && crse_geom->periodic[d] != 0) ? 1 : 0;
 	}
-	// coarsened fine boxes and their periodic images
+	// coarsened fine boxes: the local ones own registers; the boxes of ALL ranks (and their periodic images) mask cells that are refined
 	std::vector<HBox> cfine(fine->nboxes), covered;
-	for (int b = 0; b < fine->nboxes; ++b) {
+	auto coarsenBox = [&](qk_box const &b) {
+		HBox c{};
 		for (int d = 0; d < 3; ++d) {
-			cfine[b].lo[d] = floorDiv(fine->boxes[b].lo[d], P->ratio[d]);
-			cfine[b].hi[d] = floorDiv(fine->boxes[b].hi[d], P->ratio[d]);
+			c.lo[d] = floorDiv(b.lo[d], P->ratio[d]);
+			c.hi[d] = floorDiv(b.hi[d], P->ratio[d]);
 		}
+		return c;
+	};
+	for (int b = 0; b < fine->nboxes; ++b) {
+		cfine[b] = coarsenBox(fine->boxes[b]);
+	}
+	const int ncov = (all_fine != nullptr) ? n_all_fine : fine->nboxes;
+	const qk_box *cov = (all_fine != nullptr) ? all_fine : fine->boxes.data();
+	for (int b = 0; b < ncov; ++b) {
+		HBox const cb = coarsenBox(cov[b]);
 		for (int sz = -rng[2]; sz <= rng[2]; ++sz) {
 			for (int sy = -rng[1]; sy <= rng[1]; ++sy) {
 				for (int sx = -rng[0]; sx <= rng[0]; ++sx) {
-					HBox v = cfine[b];
+					HBox v = cb;
 					const int sh[3] = {sx * len[0], sy * len[1], sz * len[2]};
 					for (int d = 0; d < 3; ++d) {
 						v.lo[d] += sh[d];
@@ -181,12 +192,38 @@ int qk_fluxreg_create(qk_level *crse, qk_level *fine, const qk_geometry *crse_ge
 			}
 		}
 	}
+	auto addItem = [&](int d, int side, int b, int c, HBox const &piece, const int sh[3]) {
+		FrItem it{};
+		it.dir = d;
+		it.side = side;
+		it.fine_box = b;
+		it.crse_box = c;
+		for (int e = 0; e < 3; ++e) {
+			it.lo[e] = piece.lo[e] - sh[e];
+			it.hi[e] = piece.hi[e] - sh[e];
+			it.shift[e] = sh[e];
+		}
+		it.offset = P->total_cells;
+		const int64_t n = static_cast<int64_t>(piece.hi[0] - piece.lo[0] + 1) * (piece.hi[1] - piece.lo[1] + 1) * (piece.hi[2] - piece.lo[2] + 1);
+		P->total_cells += n;
+		P->max_cells = std::max(P->max_cells, n);
+		P->items.push_back(it);
+	};
 	for (int d = 0; d < ndim; ++d) {
 		for (int side = 0; side < 2; ++side) {
 			P->group_begin[2 * d + side] = static_cast<int>(P->items.size());
 			for (int b = 0; b < fine->nboxes; ++b) {
 				HBox slab = cfine[b];
 				slab.lo[d] = slab.hi[d] = (side == 0) ? cfine[b].lo[d] - 1 : cfine[b].hi[d] + 1;
+				for (int e = 0; e < ndim; ++e) { // no reflux through a physical boundary
+					if (crse_geom->periodic[e] == 0) {
+						slab.lo[e] = std::max(slab.lo[e], dom.lo[e]);
+						slab.hi[e] = std::min(slab.hi[e], dom.hi[e]);
+					}
+				}
+				if (!slab.ok()) {
+					continue;
+				}
 				std::vector<HBox> todo{slab};
 				for (auto const &c : covered) {
 					std::vector<HBox> next;
@@ -195,46 +232,64 @@ int qk_fluxreg_create(qk_level *crse, qk_level *fine, const qk_geometry *crse_ge
 					}
 					todo.swap(next);
 				}
-				// wrap into the domain (periodic) or drop (physical boundary), then cut by the coarse boxes
-				for (auto const &t : todo) {
-					for (int sz = -rng[2]; sz <= rng[2]; ++sz) {
-						for (int sy = -rng[1]; sy <= rng[1]; ++sy) {
-							for (int sx = -rng[0]; sx <= rng[0]; ++sx) {
-								const int sh[3] = {sx * len[0], sy * len[1], sz * len[2]};
-								HBox w = t;
+				// pass 0: the cell (wrapped into the domain if it lies beyond a periodic face) is a valid cell of a local coarse box
+				std::vector<HBox> rest = todo;
+				for (int sz = -rng[2]; sz <= rng[2]; ++sz) {
+					for (int sy = -rng[1]; sy <= rng[1]; ++sy) {
+						for (int sx = -rng[0]; sx <= rng[0]; ++sx) {
+							const int sh[3] = {sx * len[0], sy * len[1], sz * len[2]};
+							for (int c = 0; c < crse->nboxes; ++c) {
+								HBox cb{};
 								for (int e = 0; e < 3; ++e) {
-									w.lo[e] += sh[e];
-									w.hi[e] += sh[e];
+									cb.lo[e] = crse->boxes[c].lo[e] - sh[e]; // the coarse box in the unwrapped frame of the slab
+									cb.hi[e] = crse->boxes[c].hi[e] - sh[e];
 								}
-								for (int c = 0; c < crse->nboxes; ++c) {
-									HBox cb{};
-									for (int e = 0; e < 3; ++e) {
-										cb.lo[e] = crse->boxes[c].lo[e];
-										cb.hi[e] = crse->boxes[c].hi[e];
+								std::vector<HBox> next;
+								for (auto const &t : rest) {
+									HBox const piece = isect(t, cb);
+									if (piece.ok()) {
+										HBox w = piece;
+										for (int e = 0; e < 3; ++e) {
+											w.lo[e] += sh[e];
+											w.hi[e] += sh[e];
+										}
+										addItem(d, side, b, c, w, sh);
+										boxDiff(t, cb, next);
+									} else {
+										next.push_back(t);
 									}
-									HBox const piece = isect(w, cb);
-									if (!piece.ok()) {
-										continue;
-									}
-									FrItem it{};
-									it.dir = d;
-									it.side = side;
-									it.fine_box = b;
-									it.crse_box = c;
-									for (int e = 0; e < 3; ++e) {
-										it.lo[e] = piece.lo[e] - sh[e];
-										it.hi[e] = piece.hi[e] - sh[e];
-										it.shift[e] = sh[e];
-									}
-									it.offset = P->total_cells;
-									const int64_t n = static_cast<int64_t>(piece.hi[0] - piece.lo[0] + 1) * (piece.hi[1] - piece.lo[1] + 1) * (piece.hi[2] - piece.lo[2] + 1);
-									P->total_cells += n;
-									P->max_cells = std::max(P->max_cells, n);
-									P->items.push_back(it);
 								}
+								rest.swap(next);
 							}
 						}
 					}
+				}
+				// pass 1: owned by another rank — accumulate in a ghost cell of a local coarse box; SumBoundary carries it to the owner
+				if (reg_nghost > 0) {
+					const int zero[3] = {0, 0, 0};
+					for (int c = 0; c < crse->nboxes && !rest.empty(); ++c) {
+						HBox gb{};
+						for (int e = 0; e < 3; ++e) {
+							const int g = (e < ndim) ? reg_nghost : 0;
+							gb.lo[e] = crse->boxes[c].lo[e] - g;
+							gb.hi[e] = crse->boxes[c].hi[e] + g;
+						}
+						std::vector<HBox> next;
+						for (auto const &t : rest) {
+							HBox const piece = isect(t, gb);
+							if (piece.ok()) {
+								addItem(d, side, b, c, piece, zero);
+								boxDiff(t, gb, next);
+							} else {
+								next.push_back(t);
+							}
+						}
+						rest.swap(next);
+					}
+				}
+				if (!rest.empty() && all_fine != nullptr) {
+					delete P;
+					return setError(ctx, QK_ERR_INVALID, "fluxreg_create: a register cell is neither in a local coarse box nor in its ghost region");
 				}
 			}
 		}

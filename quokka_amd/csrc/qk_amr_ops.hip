@@ -91,6 +91,9 @@ int qk_tag_relative_gradient(qk_level *lev, qk_stream s, const qk_hydro_traits *
 	}
 	QK_REQUIRE(lev->ctx, state_t && tags_t, "tag_relative_gradient: NULL array");
 	QK_REQUIRE(lev->ctx, field == QK_TAGFIELD_PRESSURE || (field >= 0 && field < 64), "tag_relative_gradient: unknown field");
+	if (lev->nboxes == 0) {
+		return QK_OK;
+	}
 	const Eos eos(*t);
 	const int ndim = lev->ndim;
 	int64_t maxcells = 1;
@@ -134,6 +137,9 @@ static int interpState(qk_level *lev, qk_stream s, qk_array4 *mf_t, bool pre)
 		return QK_ERR_INVALID;
 	}
 	QK_REQUIRE(lev->ctx, mf_t, "Pre/PostInterpState: NULL array");
+	if (lev->nboxes == 0) {
+		return QK_OK;
+	}
 	int64_t maxcells = 1;
 	for (int d = 0; d < 3; ++d) {
 		maxcells *= lev->maxlen[d];
@@ -351,13 +357,15 @@ int qk_amr_tile_flags(qk_level *lev, qk_stream s, const qk_carray4 *tags_t, cons
 	if (hipMemsetAsync(d_flags, 0, bytes, st) != hipSuccess) {
 		rc = setError(ctx, QK_ERR_HIP, "amr_tile_flags: memset failed");
 	}
-	if (rc == QK_OK) {
+	if (rc == QK_OK && lev->nboxes > 0) {
 		int64_t maxcells = 1;
 		for (int d = 0; d < 3; ++d) {
 			maxcells *= lev->maxlen[d];
 		}
 		const dim3 grid(static_cast<unsigned>((maxcells + 255) / 256), static_cast<unsigned>(lev->nboxes), 1);
 		hipLaunchKernelGGL(k_tags_to_tiles, grid, dim3(256), 0, st, lev->d_boxes, tags_t, n_error_buf, tile, lev->ndim, n[0], n[1], n[2], nt[0], nt[1], nt[2], d_flags);
+	}
+	if (rc == QK_OK) {
 		if (hipGetLastError() != hipSuccess || hipMemcpyAsync(tile_flags_host, d_flags, bytes, hipMemcpyDeviceToHost, st) != hipSuccess ||
 		    hipStreamSynchronize(st) != hipSuccess) {
 			rc = setError(ctx, QK_ERR_HIP, "amr_tile_flags: kernel or copy failed");

@@ -64,7 +64,8 @@ int qk_level_create(qk_ctx *ctx, qk_level **lev, int ndim, int nboxes, const qk_
 	if (ctx == nullptr || lev == nullptr) {
 		return QK_ERR_INVALID;
 	}
-	QK_REQUIRE(ctx, valid_boxes != nullptr && nboxes > 0, "qk_level_create: no boxes");
+	QK_REQUIRE(ctx, nboxes >= 0 && (valid_boxes != nullptr || nboxes == 0), "qk_level_create: bad box list");
+	// nboxes == 0 is a rank that owns no box of this level (AMR): every operator on such a level is a no-op
 	QK_REQUIRE(ctx, ndim == 1 || ndim == 3, "qk_level_create: ndim must be 1 or 3");
 	auto *L = new qk_level;
 	L->ctx = ctx;
@@ -80,9 +81,9 @@ int qk_level_create(qk_ctx *ctx, qk_level **lev, int ndim, int nboxes, const qk_
 		*lev = L;
 		return QK_OK;
 	}
-	hipError_t e = hipMalloc(reinterpret_cast<void **>(&L->d_boxes), sizeof(qk_box) * nboxes);
+	hipError_t e = hipMalloc(reinterpret_cast<void **>(&L->d_boxes), sizeof(qk_box) * (nboxes > 0 ? nboxes : 1));
 	if (e == hipSuccess) {
-		e = hipMemcpy(L->d_boxes, valid_boxes, sizeof(qk_box) * nboxes, hipMemcpyHostToDevice);
+		e = (nboxes > 0) ? hipMemcpy(L->d_boxes, valid_boxes, sizeof(qk_box) * nboxes, hipMemcpyHostToDevice) : hipSuccess;
 	}
 	if (e != hipSuccess) {
 		delete L;

@@ -668,6 +668,9 @@ int qk_hydro_stage_fused(qk_level *lev, qk_stream stream, const qk_hydro_traits 
 	}
 	QK_REQUIRE(ctx, args->scratch_bytes >= qk_hydro_stage_scratch_bytes(lev, t), "qk_hydro_stage_fused: scratch too small");
 
+	if (lev->nboxes == 0) {
+		return QK_OK; // a rank without boxes on this level
+	}
 	if (int rc = buildGeom(lev); rc != QK_OK) {
 		return rc;
 	}

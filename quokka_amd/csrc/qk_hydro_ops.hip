@@ -37,6 +37,9 @@ template <class F> __global__ void __launch_bounds__(256) k_box_cells(const qk_b
 
 template <class F> void launchCells(qk_level *lev, qk_stream s, int ng, int facedir, F f)
 {
+	if (lev->nboxes == 0) {
+		return; // a rank without boxes on this level
+	}
 	const CellLaunch L = cellLaunch(lev, ng, facedir);
 	hipLaunchKernelGGL(k_box_cells<F>, L.grid, L.block, 0, static_cast<hipStream_t>(s), lev->d_boxes, lev->ndim, ng, facedir, f);
 }
@@ -579,6 +582,9 @@ int qk_hydro_maxSignalSpeedLocal(qk_level *lev, qk_stream s, const qk_hydro_trai
 	QK_HIP_CHECK(lev->ctx, hipMemsetAsync(d_result, 0, sizeof(double), static_cast<hipStream_t>(s)));
 	const int64_t ncell = static_cast<int64_t>(lev->maxlen[0]) * lev->maxlen[1] * lev->maxlen[2];
 	const unsigned gx = static_cast<unsigned>(std::min<int64_t>((ncell + 255) / 256, 1024));
+	if (lev->nboxes == 0) {
+		return QK_OK;
+	}
 	hipLaunchKernelGGL(k_maxSignal, dim3(gx, lev->nboxes, 1), dim3(256, 1, 1), 0, static_cast<hipStream_t>(s), lev->d_boxes, cons_t, eos, which,
 			   d_result);
 	return launchStatus(lev, "maxSignalSpeedLocal");

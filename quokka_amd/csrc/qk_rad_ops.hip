@@ -91,6 +91,9 @@ auto counterSlots(qk_ctx *ctx) -> int *
 
 template <class F> void launchRad(qk_level *lev, qk_stream s, int ng, int facedir, const char *name, F f)
 {
+	if (lev->nboxes == 0) {
+		return; // a rank without boxes on this level
+	}
 	const CellLaunch L = cellLaunch(lev, ng, facedir);
 	ProfScope ps(lev->ctx, static_cast<hipStream_t>(s), name);
 	hipLaunchKernelGGL(k_rad_cells<F>, L.grid, L.block, 0, static_cast<hipStream_t>(s), lev->d_boxes, lev->ndim, ng, facedir, f);

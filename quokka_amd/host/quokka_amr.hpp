@@ -188,8 +188,8 @@ template <typename problem_t> class AmrDriver
 		int const ratio[3] = {2, 2, 2};
 		auto gf = qgeom(me.geom[0]);
 		auto gc = qgeom(parent.geom[0]);
-		qkhost::check(qk_interp_plan_create(parent.levelHandle(), me.levelHandle(), &gf, me.nghost_cc_, ratio, 0, &f.interp), "qk_interp_plan_create");
-		qkhost::check(qk_fluxreg_create(parent.levelHandle(), me.levelHandle(), &gc, ratio, Sim::ncompHydro_, &f.fluxreg), "qk_fluxreg_create");
+		qkhost::check(qk_interp_plan_create(parent.levelHandle(), me.levelHandle(), &gf, me.nghost_cc_, ratio, 0, 0, nullptr, &f.interp), "qk_interp_plan_create");
+		qkhost::check(qk_fluxreg_create(parent.levelHandle(), me.levelHandle(), &gc, ratio, Sim::ncompHydro_, 0, nullptr, 0, &f.fluxreg), "qk_fluxreg_create");
 		qkhost::check(qk_avgdown_plan_create(parent.levelHandle(), me.levelHandle(), ratio, &f.avgdown), "qk_avgdown_plan_create");
 		Finer *fp = &f;
 		// FillPatchTwoLevels: the ghost cells no fine box covers come from the parent, interpolated in space and time
@@ -414,7 +414,7 @@ template <typename problem_t> class AmrDriver
 			int const ratio[3] = {2, 2, 2};
 			auto gf = qgeom(me.geom[0]);
 			qk_interp_plan *whole = nullptr;
-			qkhost::check(qk_interp_plan_create(parent.levelHandle(), me.levelHandle(), &gf, me.nghost_cc_, ratio, 1, &whole), "qk_interp_plan_create(whole)");
+			qkhost::check(qk_interp_plan_create(parent.levelHandle(), me.levelHandle(), &gf, me.nghost_cc_, ratio, 1, 0, nullptr, &whole), "qk_interp_plan_create(whole)");
 			auto *pn = qkhost::tab(parent.state_new_cc_[0]);
 			qkhost::check(qk_InterpFromCoarse(whole, nullptr, qkhost::tab(me.state_new_cc_[0]), pn, pn, 1.0, 0.0, Sim::ncompHydro_, amrInterpMethod_, 1),
 				      "qk_InterpFromCoarse(whole)");
