@@ -88,12 +88,15 @@ class AmrLevelSim(HydroSimulation):
     """HydroSimulation over the boxes of one AMR level: same advance (fused stages, FOFC, retries); the ghost fill of a refined level
     adds the coarse -> fine interpolation, and every successful advance feeds the flux registers."""
 
-    def __init__(self, amr: "AmrSimulation", lev: int, boxes: Sequence[Box]):
+    def __init__(self, amr: "AmrSimulation", lev: int, boxes: Sequence[Box], owner: Sequence[int]):
         self.amr, self.ilev = amr, lev
         g0 = amr.geom0
         geom = Geometry(g0.ndim, [g0.n_cell[d] * (2 ** lev if d < g0.ndim else 1) for d in range(3)], list(g0.prob_lo), list(g0.prob_hi), list(g0.periodic))
-        super().__init__(amr.ctx, geom, amr.traits, amr.bcs, None, amr.dirichlet, boxes=boxes)
+        super().__init__(amr.ctx, geom, amr.traits, amr.bcs, None, amr.dirichlet, rank=amr.rank, nranks=amr.nranks, boxes=boxes, owner=owner)
+        self.min_overlap_cells = 1 << 62  # the early/late split of the uniform-grid exchange is not combined with the coarse-fine fill
         self.store_flux_rk2 = True
+        self.reflux_inc: Optional[MultiFab] = None  # several ranks: reflux increments of THIS level (valid + 1 ghost cell), folded by SumBoundary
+        self.reflux_ghost = None
         self.t_old = self.t_new = 0.0
         self._fill_time = 0.0
         self.cf_interp: Optional[InterpFromCoarse] = None
@@ -103,9 +106,28 @@ class AmrLevelSim(HydroSimulation):
             setattr(self, name, getattr(amr, name))
 
     def link_to_parent(self, parent: "AmrLevelSim"):
-        self.cf_interp = InterpFromCoarse(parent.lev, self.lev, self.geom, NGHOST_CC)
-        self.fluxreg = FluxRegister(parent.lev, self.lev, parent.geom, 6)
+        multi = self.amr.nranks > 1
+        self.cf_interp = InterpFromCoarse(parent.lev, self.lev, self.geom, NGHOST_CC, all_fine_boxes=self.all_boxes if multi else None)
+        self.fluxreg = FluxRegister(parent.lev, self.lev, parent.geom, 6, all_fine_boxes=self.all_boxes if multi else None, reg_nghost=1 if multi else 0)
         self.avgdown = AverageDown(parent.lev, self.lev)
+        if multi and parent.reflux_inc is None:
+            from .simulation import GhostExchange
+            parent.reflux_inc = MultiFab(parent.lev, 6, 1, fill=0.0)
+            per = [([capi.BC_INT_DIR] * 3, [capi.BC_INT_DIR] * 3)] * 6
+            parent.reflux_ghost = GhostExchange(parent.lev, parent.geom, 6, 1, parent.all_boxes, parent.owner, self.amr.rank, per)
+
+    def reflux_from(self, child: "AmrLevelSim"):
+        """flux_reg_[lev+1]->Reflux(state_new_cc_[lev]) (reference src/simulation.hpp:1308).  One rank: straight into the state.  Several
+        ranks: the increments land in a zeroed array with one ghost cell (a register cell may belong to a neighbouring rank's box),
+        SumBoundary carries them to their owners, then state += increments."""
+        if self.reflux_inc is None:
+            child.fluxreg.Reflux(self.state_new_cc_)
+            return
+        from .hydro_system import Saxpy
+        self.reflux_inc.storage.zero_()
+        child.fluxreg.Reflux(self.reflux_inc)
+        self.reflux_ghost.sum_boundary(self.reflux_inc)
+        Saxpy(self.lev, -1, self.state_new_cc_, 1.0, self.reflux_inc, 6)
 
     # --- ghost fill (FillPatchTwoLevels)
     def fillBoundaryConditions(self, state: MultiFab):
@@ -174,9 +196,14 @@ class AmrLevelSim(HydroSimulation):
 # ------------------------------------------------------------------------------------------------ the hierarchy
 class AmrSimulation:
     def __init__(self, ctx: Context, geom0: Geometry, traits: capi.HydroTraits, bcs, max_level: int, max_grid_size: int = 128, blocking_factor: int = 32,
-                 n_error_buf: int = 3, regrid_int: int = 2, dirichlet=None):
+                 n_error_buf: int = 3, regrid_int: int = 2, dirichlet=None, rank: int = 0, nranks: int = 1, cluster_within_parent: Optional[bool] = None):
         assert geom0.ndim == 3, "the AMR driver runs the fused 3-D path"
         self.ctx, self.geom0, self.traits, self.bcs, self.dirichlet = ctx, geom0, traits, bcs, dirichlet
+        self.rank, self.nranks = rank, nranks
+        # Several ranks: a fine box lives on the rank of the level-0 box it sits in (so interpolation, average-down and regrid copies are
+        # local and only the reflux increments and the ordinary ghost exchange cross ranks); grids are therefore clustered inside each
+        # parent box.  One rank clusters globally unless asked to mimic that (tests compare the two).
+        self.cluster_within_parent = (nranks > 1) if cluster_within_parent is None else cluster_within_parent
         self.max_level, self.max_grid_size, self.blocking_factor = max_level, max_grid_size, blocking_factor
         self.n_error_buf, self.regrid_int = n_error_buf, regrid_int
         self.do_reflux, self.do_subcycle = True, True
@@ -200,7 +227,7 @@ class AmrSimulation:
         return len(self.levels) - 1
 
     def CountCells(self, lev: int) -> int:
-        return self.levels[lev].CountCells()
+        return self.levels[lev].CountCells()  # all boxes of the level (every rank counts the global work, as the reference does)
 
     # ------------------------------------------------------------------ hierarchy construction
     def _tags_on_level(self, lev: int) -> np.ndarray:
@@ -234,6 +261,12 @@ class AmrSimulation:
         dom = capi.Box((C.c_int * 3)(0, 0, 0), (C.c_int * 3)(n[0] - 1, n[1] - 1, n[2] - 1))
         self.ctx.check(self.ctx.L.qk_amr_tile_flags(L.lev.h, self.ctx.stream(), tags.ptr, C.byref(dom), self.n_error_buf, tile, flags.ctypes.data_as(C.c_void_p)),
                        "qk_amr_tile_flags")
+        if self.nranks > 1:  # every rank clusters the same global flags
+            import torch.distributed as dist
+            from . import comm
+            t = torch.from_numpy(flags).to(self.ctx.device)
+            comm.all_reduce(t, dist.ReduceOp.MAX)
+            flags = t.cpu().numpy()
         return flags != 0
 
     def _new_grids(self, lev: int, finer_boxes: Optional[List[Box]]) -> List[Box]:
@@ -253,13 +286,40 @@ class AmrSimulation:
         if lev > 0:  # proper nesting: a tile and its 26 neighbours (>= 4 cells: ghost reach 2 + stencil 1) lie on level-lev cells or beyond the domain
             cov = np.ones((tz + 2, ty + 2, tx + 2), dtype=bool)
             cov[1:-1, 1:-1, 1:-1] = False
-            for lo, hi in L.my_boxes:
+            for lo, hi in L.all_boxes:
                 cov[lo[2] // tile + 1:hi[2] // tile + 2, lo[1] // tile + 1:hi[1] // tile + 2, lo[0] // tile + 1:hi[0] // tile + 2] = True
             t &= ~dilate(~cov, 1, 3)[1:-1, 1:-1, 1:-1]
-        return boxes_from_tiles(t, 3, self.blocking_factor, self.max_grid_size, 2)
+        if not self.cluster_within_parent:
+            return boxes_from_tiles(t, 3, self.blocking_factor, self.max_grid_size, 2)
+        boxes: List[Box] = []
+        for lo, hi in L.all_boxes:  # the parent boxes of ALL ranks, in the same order everywhere
+            a = [lo[d] // tile for d in range(3)]
+            b = [hi[d] // tile for d in range(3)]
+            sub = t[a[2]:b[2] + 1, a[1]:b[1] + 1, a[0]:b[0] + 1]
+            for blo, bhi in boxes_from_tiles(sub, 3, self.blocking_factor, self.max_grid_size, 2):
+                boxes.append(([blo[d] + 2 * lo[d] for d in range(3)], [bhi[d] + 2 * lo[d] for d in range(3)]))
+        return boxes
+
+    def _owners_of(self, lev: int, boxes: List[Box]) -> List[int]:
+        """a box of level lev >= 1 lives on the rank of the level-(lev-1) box that contains it (hence of its level-0 ancestor)"""
+        if self.nranks == 1:
+            return [0] * len(boxes)
+        P = self.levels[lev - 1]
+        out = []
+        for lo, hi in boxes:
+            c = [lo[d] // 2 for d in range(3)]
+            owner = next((o for (plo, phi), o in zip(P.all_boxes, P.owner) if all(plo[d] <= c[d] <= phi[d] for d in range(3))), None)
+            assert owner is not None, "fine box without a parent box"
+            out.append(owner)
+        return out
 
     def _make_level(self, lev: int, boxes: List[Box]) -> AmrLevelSim:
-        L = AmrLevelSim(self, lev, boxes)
+        if lev == 0:
+            from .simulation import distribute_boxes
+            owner = distribute_boxes(boxes, self.nranks, self.geom0.n_cell, [self.max_grid_size] * 3) if self.nranks > 1 else [0] * len(boxes)
+        else:
+            owner = self._owners_of(lev, boxes)
+        L = AmrLevelSim(self, lev, boxes, owner)
         if lev > 0:
             L.link_to_parent(self.levels[lev - 1])
         return L
@@ -308,7 +368,7 @@ class AmrSimulation:
                 del self.levels[lev:]
                 break
             old = self.levels[lev] if lev <= self.finest_level else None
-            if old is not None and sorted(map(str, old.my_boxes)) == sorted(map(str, boxes)):
+            if old is not None and sorted(map(str, old.all_boxes)) == sorted(map(str, [(list(lo), list(hi)) for lo, hi in boxes])):
                 continue
             new = self._make_level(lev, boxes)
             parent = self.levels[lev - 1]
@@ -377,7 +437,7 @@ class AmrSimulation:
                     self.timeStepWithSubcycling(lev + 1, time + i * self.dt_[lev + 1])
             if lev < self.finest_level:
                 if self.do_reflux:
-                    self.levels[lev + 1].fluxreg.Reflux(L.state_new_cc_)
+                    L.reflux_from(self.levels[lev + 1])
                 self.AverageDownTo(lev)
                 L.FixupState()
 
@@ -401,10 +461,16 @@ class AmrSimulation:
             n = L.geom.n_cell
             mask = np.ones((n[2], n[1], n[0]), dtype=bool)
             if l < self.finest_level:
-                mask &= ~covered_mask([([x // 2 for x in lo], [x // 2 for x in hi]) for lo, hi in self.levels[l + 1].my_boxes], mask.shape)
+                mask &= ~covered_mask([([x // 2 for x in lo], [x // 2 for x in hi]) for lo, hi in self.levels[l + 1].all_boxes], mask.shape)
             for b, (lo, hi) in enumerate(L.my_boxes):
                 v = L.state_new_cc_.valid(b)[comp].cpu().numpy()
                 total += float((v * mask[lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1]).sum()) * vol
+        if self.nranks > 1:
+            import torch.distributed as dist
+            from . import comm
+            t = torch.tensor([total], dtype=torch.float64, device=self.ctx.device)
+            comm.all_reduce(t, dist.ReduceOp.SUM)
+            total = float(t.item())
         return total
 
 
@@ -421,14 +487,16 @@ def _copy_overlap(src: MultiFab, src_boxes, dst: MultiFab, dst_boxes):
                 src.fabs[sb][:, lo[2] - s0[2]:hi[2] - s0[2] + 1, lo[1] - s0[1]:hi[1] - s0[1] + 1, lo[0] - s0[0]:hi[0] - s0[0] + 1]
 
 
-def sedov_amr_problem(ctx: Context, n: int, max_level: int, max_grid_size: int = 128, blocking_factor: int = 32, static_fine_boxes=None) -> AmrSimulation:
+def sedov_amr_problem(ctx: Context, n: int, max_level: int, max_grid_size: int = 128, blocking_factor: int = 32, static_fine_boxes=None, rank: int = 0,
+                      nranks: int = 1, cluster_within_parent=None) -> AmrSimulation:
     """reference src/problems/HydroBlast3D/test_hydro3d_blast.cpp + tests/blast_amr_maxlev2.in (BASELINE config 5)"""
     geom = Geometry(3, [n, n, n], [0.0, 0.0, 0.0], [1.2, 1.2, 1.2], [0, 0, 0])
     bcs = []
     for c in range(6):
         lo = [capi.BC_REFLECT_ODD if c == 1 + d else capi.BC_REFLECT_EVEN for d in range(3)]
         bcs.append((lo, list(lo)))
-    amr = AmrSimulation(ctx, geom, capi.traits(1.4, False, 3), bcs, max_level, max_grid_size, blocking_factor)
+    amr = AmrSimulation(ctx, geom, capi.traits(1.4, False, 3), bcs, max_level, max_grid_size, blocking_factor, rank=rank, nranks=nranks,
+                        cluster_within_parent=cluster_within_parent)
     amr.static_fine_boxes = static_fine_boxes
     E_blast = 0.851072 / 8.0
 

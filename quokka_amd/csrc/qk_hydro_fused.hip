@@ -652,6 +652,9 @@ int qk_hydro_stage_fused(qk_level *lev, qk_stream stream, const qk_hydro_traits 
 		return rc;
 	}
 	QK_REQUIRE(ctx, args != nullptr, "qk_hydro_stage_fused: NULL args");
+	if (lev->nboxes == 0) {
+		return QK_OK; // a rank without boxes on this level
+	}
 	if (t->ndim != 3) {
 		return setError(ctx, QK_ERR_UNSUPPORTED, "qk_hydro_stage_fused: 3-D only (use the reference-shaped operators in 1-D)");
 	}
@@ -668,9 +671,6 @@ int qk_hydro_stage_fused(qk_level *lev, qk_stream stream, const qk_hydro_traits 
 	}
 	QK_REQUIRE(ctx, args->scratch_bytes >= qk_hydro_stage_scratch_bytes(lev, t), "qk_hydro_stage_fused: scratch too small");
 
-	if (lev->nboxes == 0) {
-		return QK_OK; // a rank without boxes on this level
-	}
 	if (int rc = buildGeom(lev); rc != QK_OK) {
 		return rc;
 	}

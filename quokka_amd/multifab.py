@@ -119,11 +119,11 @@ class MultiFab:
             self.begins.append([lo[d] - (nghost if d < level.ndim else 0) for d in range(3)])
             offsets.append(total)
             total += ncomp * n[0] * n[1] * n[2]
-        self.storage = torch.empty(total, dtype=dtype, device=ctx.device)
+        self.storage = torch.empty(max(total, 1), dtype=dtype, device=ctx.device)  # (never a NULL pointer, also for a rank without boxes)
         if fill is not None:
             self.storage.fill_(fill)
         self.fabs: List[torch.Tensor] = [self.storage[o:o + int(np.prod(s))].view(s) for o, s in zip(offsets, self.shapes)]
-        tab = np.zeros(level.nboxes, dtype=_A4_DTYPE)
+        tab = np.zeros(max(level.nboxes, 1), dtype=_A4_DTYPE)
         for b, (fab, shp, beg) in enumerate(zip(self.fabs, self.shapes, self.begins)):
             nx, ny, nz = shp[3], shp[2], shp[1]
             tab[b]["p"] = fab.data_ptr()

@@ -220,7 +220,7 @@ class HydroSimulation:
     """QuokkaSimulation<problem_t> for a hydro-only, uniform-grid problem."""
 
     def __init__(self, ctx: Context, geom: Geometry, traits: capi.HydroTraits, bcs, max_grid_size=None, dirichlet=None,
-                 rank: int = 0, nranks: int = 1, use_fused: bool = True, ncomp_cc: int = 6, boxes=None):
+                 rank: int = 0, nranks: int = 1, use_fused: bool = True, ncomp_cc: int = 6, boxes=None, owner=None):
         self.ctx, self.geom, self.traits = ctx, geom, traits
         self.rank, self.nranks = rank, nranks
         self.hydro = HydroSystem(traits)
@@ -231,9 +231,12 @@ class HydroSimulation:
             mgs[d] = 1
         # `boxes`: an explicit BoxArray (a refined AMR level, which does not cover the domain) instead of the chopped domain
         self.all_boxes = [(list(lo), list(hi)) for lo, hi in boxes] if boxes is not None else chop_domain(geom.n_cell, mgs)
-        self.owner = distribute_boxes(self.all_boxes, nranks, geom.n_cell, mgs) if nranks > 1 else [0] * len(self.all_boxes)
+        if owner is not None:  # explicit box -> rank map (AMR levels: a box lives where its parent lives)
+            self.owner = list(owner)
+        else:
+            self.owner = distribute_boxes(self.all_boxes, nranks, geom.n_cell, mgs) if nranks > 1 else [0] * len(self.all_boxes)
         self.my_boxes = [b for b, o in zip(self.all_boxes, self.owner) if o == rank]
-        assert self.my_boxes, "rank owns no boxes"
+        assert self.my_boxes or owner is not None, "rank owns no boxes"
         self.lev = Level(ctx, geom.ndim, self.my_boxes)
         # public data members (reference src/simulation.hpp:144-173, src/QuokkaSimulation.hpp:125-144)
         self.stopTime_ = 1.0
@@ -278,8 +281,8 @@ class HydroSimulation:
         self.scratch = None
         if self.use_fused:
             nbytes = ctx.L.qk_hydro_stage_scratch_bytes(lev.h, C.byref(traits))
-            assert nbytes > 0
-            self.scratch = torch.empty(nbytes // 8, dtype=torch.float64, device=ctx.device)
+            assert nbytes > 0 or not self.my_boxes
+            self.scratch = torch.empty(max(nbytes // 8, 1), dtype=torch.float64, device=ctx.device)
         self._unfused_tmp = None
 
     # ------------------------------------------------------------------ helpers

@@ -26,6 +26,37 @@ def free_port():
     return p
 
 
+def collect(procs, q, world, timeout=240):
+    """results of all ranks; a rank that fails reports its traceback, and the others (blocked in a collective) are terminated"""
+    results = []
+    try:
+        for _ in range(world):
+            r = q.get(timeout=timeout)
+            if isinstance(r, tuple) and r and r[0] == "error":
+                raise AssertionError(f"rank {r[1]} failed:\n{r[2]}")
+            results.append(r)
+    finally:
+        for p in procs:
+            p.join(timeout=20)
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+    return results
+
+
+def guarded(fn):
+    def wrapper(rank, *args):
+        q = args[-1]
+        try:
+            fn(rank, *args)
+        except BaseException:  # noqa: BLE001 - report and let the parent tear the group down
+            import traceback
+            q.put(("error", rank, traceback.format_exc()))
+            os._exit(1)
+    wrapper.__name__ = fn.__name__
+    return wrapper
+
+
 def worker(rank, world, port, N, mgs, nsteps, overlap, q):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -48,6 +79,14 @@ def worker(rank, world, port, N, mgs, nsteps, overlap, q):
         dist.destroy_process_group()
 
 
+def run_worker(rank, *args):
+    guarded(worker)(rank, *args)
+
+
+def run_amr_worker(rank, *args):
+    guarded(amr_worker)(rank, *args)
+
+
 @pytest.mark.parametrize("world,overlap", [(2, False), (4, True), (8, False)])
 def test_ranks_sharing_one_gpu_reproduce_the_single_process_run(ctx, world, overlap):
     from quokka_amd.simulation import sedov_problem
@@ -63,13 +102,10 @@ def test_ranks_sharing_one_gpu_reproduce_the_single_process_run(ctx, world, over
     mpctx = mp.get_context("spawn")
     q = mpctx.Queue()
     port = free_port()
-    procs = [mpctx.Process(target=worker, args=(r, world, port, N, mgs, nsteps, overlap, q)) for r in range(world)]
+    procs = [mpctx.Process(target=run_worker, args=(r, world, port, N, mgs, nsteps, overlap, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=600) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    results = collect(procs, q, world)
     got = np.full((6, N, N, N), np.nan)
     for rank, boxes, vals, dts, npeers, groups in results:
         assert dts == ref_dts, f"rank {rank}: time steps differ"
@@ -80,3 +116,71 @@ def test_ranks_sharing_one_gpu_reproduce_the_single_process_run(ctx, world, over
             got[:, lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1] = v
     assert not np.isnan(got).any(), "some box is owned by no rank"
     assert np.array_equal(got, want), f"max abs diff {np.abs(got - want).max()}"
+
+
+def amr_worker(rank, world, port, N, nsteps, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from quokka_amd.amr_simulation import sedov_amr_problem
+        from quokka_amd.multifab import Context
+        ctx = Context(0)
+        amr = sedov_amr_problem(ctx, N, 2, max_grid_size=16, blocking_factor=8, rank=rank, nranks=world)
+        m0, e0 = amr.composite_sum(0), amr.composite_sum(4)
+        for _ in range(nsteps):
+            amr.step()
+        m1, e1 = amr.composite_sum(0), amr.composite_sum(4)
+        out = []
+        for L in amr.levels:
+            out.append(([(lo, hi) for lo, hi in L.all_boxes], list(L.owner), [(lo, hi) for lo, hi in L.my_boxes], [v.copy() for v in L.gather_valid_local()]))
+        q.put((rank, out, amr.tNew_, (abs(m1 - m0) / m0, abs(e1 - e0) / e0), list(amr.istep)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_amr_hierarchy_across_ranks_matches_one_rank(ctx, world):
+    """Sedov, max_level = 2, 32^3 base grid in 16^3 boxes (8 level-0 boxes over 2 / 4 ranks): fine boxes live on the rank of their level-0
+    ancestor, reflux increments cross ranks through SumBoundary.  Same grids and time steps as the single-rank run with the same
+    per-parent clustering; states agree to rounding (the reflux additions are reassociated), mass and energy are conserved."""
+    from quokka_amd.amr_simulation import sedov_amr_problem
+    N, nsteps = 32, 6
+    ref = sedov_amr_problem(ctx, N, 2, max_grid_size=16, blocking_factor=8, cluster_within_parent=True)
+    for _ in range(nsteps):
+        ref.step()
+    assert ref.finest_level == 2
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    port = free_port()
+    procs = [mpctx.Process(target=run_amr_worker, args=(r, world, port, N, nsteps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = collect(procs, q, world)
+    results.sort(key=lambda r: r[0])
+    for rank, levels, tnew, drift, istep in results:
+        assert tnew == ref.tNew_ and istep == ref.istep, f"rank {rank}: time stepping differs"
+        assert len(levels) == 3
+        assert drift[0] <= 2e-13 and drift[1] <= 2e-13, f"rank {rank}: composite mass / energy drift {drift}"
+    worst = 0.0
+    for l, L in enumerate(ref.levels):
+        n = L.geom.n_cell
+        want = np.full((6, n[2], n[1], n[0]), np.nan)
+        for (lo, hi), v in zip(L.my_boxes, L.gather_valid_local()):
+            want[:, lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1] = v
+        got = np.full_like(want, np.nan)
+        owners_seen = set()
+        for rank, levels, *_ in results:
+            all_boxes, owner, mine, vals = levels[l]
+            assert sorted(map(str, all_boxes)) == sorted(map(str, [(list(lo), list(hi)) for lo, hi in L.all_boxes])), f"level {l}: grids differ on rank {rank}"
+            assert [b for b, o in zip(all_boxes, owner) if o == rank] == mine
+            owners_seen.update(owner)
+            for (lo, hi), v in zip(mine, vals):
+                got[:, lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1] = v
+        assert np.array_equal(np.isnan(got), np.isnan(want)), f"level {l}: coverage differs"
+        m = ~np.isnan(want)
+        scale = np.abs(want[m]).max()
+        worst = max(worst, float(np.abs(got[m] - want[m]).max() / scale))
+        if l == 0:
+            assert len(owners_seen) == world
+    assert worst <= 1e-13, worst
