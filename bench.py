@@ -122,19 +122,30 @@ def main():
     n_cell = weak_scaled_cells(args.ncell, world)
     if args.workload == "amr":
         from quokka_amd.amr_simulation import sedov_amr_problem
-        assert world == 1, "the AMR line is single-GPU (inter-level transfers across ranks are not built)"
-        amr = sedov_amr_problem(ctx, args.ncell, 2, max_grid_size=128, blocking_factor=32)
+        # several GPUs: the SAME 256^3-base hierarchy (strong scaling); fine boxes live on the rank of their level-0 ancestor
+        amr = sedov_amr_problem(ctx, args.ncell, 2, max_grid_size=128, blocking_factor=32, rank=rank, nranks=world)
         for _ in range(args.warmup):
             amr.step()
-        torch.cuda.synchronize()
+        def sync():
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+        sync()
         u0, t0 = amr.cellUpdates_, time.perf_counter()
         for _ in range(args.steps):
             amr.step()
-        torch.cuda.synchronize()
+        sync()
         elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        if rank != 0:
+            return
         print(json.dumps({"metric": "Mcell-updates/s on 3D Sedov AMR (sum over levels, subcycled)", "value": (amr.cellUpdates_ - u0) / elapsed / 1e6,
-                          "unit": "Mcell-updates/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-                          "dtype": "f64", "data": "synthetic",
+                          "unit": "Mcell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                          "scaling": "strong", "dtype": "f64", "data": "synthetic",
                           "config": {"workload": f"3D Sedov blast {args.ncell}^3 base grid, max_level 2, blocking_factor 32, max_grid_size 128 "
                                                  "(tests/blast_amr_maxlev2.in), subcycling + reflux, tile clustering instead of Berger-Rigoutsos",
                                      "boxes_per_level": [L.lev.nboxes for L in amr.levels], "cells_per_level": [amr.CountCells(l) for l in range(amr.finest_level + 1)],
