@@ -21,7 +21,7 @@ import torch
 
 from . import capi
 from .amr import AverageDown, FluxRegister, InterpFromCoarse
-from .multifab import Context, Level, MultiFab
+from .multifab import Context, MultiFab
 from .simulation import NGHOST_CC, Geometry, HydroSimulation, chop_domain
 
 Box = Tuple[List[int], List[int]]

@@ -11,7 +11,7 @@ from typing import Sequence
 import torch
 
 from . import capi
-from .multifab import Context, Level, MultiFab
+from .multifab import Level, MultiFab
 
 
 def _p3(mfs: Sequence[MultiFab]):

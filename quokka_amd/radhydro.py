@@ -23,7 +23,7 @@ import torch
 
 from . import capi
 from .multifab import Context, MultiFab
-from .simulation import NGHOST_CC, Geometry, HydroSimulation
+from .simulation import Geometry, HydroSimulation
 
 RAD0 = 6
 
