@@ -100,3 +100,14 @@ def test_sedov_amr_executable_matches_python_driver(tmp_path, ctx):
     assert np.array_equal(data.reshape(6, N, N, N), want), f"max abs diff {np.abs(data.reshape(6, N, N, N) - want).max()}"
     for l in range(3):
         assert f"Zone-updates on level {l}: {amr.cellUpdatesEachLevel_[l]} " in out
+
+
+def test_sedov_128_meets_the_reference_ctest_criteria(tmp_path):
+    """the reference's HydroBlast3D ctest (src/problems/HydroBlast3D/test_hydro3d_blast.cpp:181-212, tests/blast_unigrid_128.in): run to
+    t = 1 and require |dE/E| <= 2e-15 and |E_kin/E - 0.218729| <= 0.01; the executable's exit status IS that criterion (~50 s)"""
+    subprocess.check_call(["make", "-s", "-C", HOST])
+    cmd = [os.path.join(HOST, "bin", "test_hydro3d_blast"), os.path.join(HOST, "decks", "blast_unigrid_256.in"), "amr.n_cell=128 128 128",
+           "amr.max_grid_size=128", "max_timesteps=20000"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=560)
+    assert "Energy conservation is OK." in p.stdout and "Kinetic energy production is OK." in p.stdout, p.stdout[-1500:]
+    assert p.returncode == 0
