@@ -322,6 +322,10 @@ enum { QK_TAG_CLEAR = 0, QK_TAG_BUF = 1, QK_TAG_SET = 2 }; /* amrex::TagBox::Tag
  * other cells are left untouched.  `state` needs one ghost cell.  field: QK_TAGFIELD_PRESSURE or a component index. */
 int qk_tag_relative_gradient(qk_level *lev, qk_stream s, const qk_hydro_traits *t, const qk_array4 *state, qk_carray4 *tags, int field,
 			     double eta_threshold, double q_min, int min_inclusive);
+/* ErrorEst of HydroShocktube (reference src/problems/HydroShocktube/test_hydro_shocktube.cpp:146-170): centred difference of component
+ * `comp` along `dir`:  del = (q(+1) - q(-1)) / (2 dx);  SET where sqrt(del^2) / q > eta_threshold and q >= q_min (> if !min_inclusive) */
+int qk_tag_centered_gradient(qk_level *lev, qk_stream s, const qk_array4 *state, qk_carray4 *tags, int comp, int dir, double dx, double eta_threshold,
+			     double q_min, int min_inclusive);
 /* QuokkaSimulation::PreInterpState / PostInterpState(mf, scomp, ncomp)     reference src/QuokkaSimulation.hpp:804-841
  * around the coarse-to-fine interpolation: E <- (E - |p|^2/(2 rho)) / rho on every valid cell of `mf`, and back (E <- rho e + KE). */
 int qk_PreInterpState(qk_level *lev, qk_stream s, qk_array4 *mf);

@@ -1,6 +1,7 @@
 // amr.hpp — CPU restatement of the data-parallel AMR pieces (test infrastructure, see oracle/__init__.py):
 //   tagRelativeGradient   QuokkaSimulation<problem_t>::ErrorEst of src/problems/HydroBlast3D/test_hydro3d_blast.cpp:118-151
 //                         (pressure, P > P_min) and src/problems/RadhydroShell/test_radhydro_shell.cpp:337-371 (density, rho >= rho_min)
+//   tagCenteredGradient   ErrorEst of src/problems/HydroShocktube/test_hydro_shocktube.cpp:146-170 (centred density difference / (2 dx))
 //   averageDown           amrex::average_down / amrex_avgdown as called from AMRSimulation::AverageDownTo (src/simulation.hpp:1949-1964).
 //                         AMReX is not vendored in /root/reference: the kernel is restated from its published form
 //                         (crse = volfrac * sum over kref, jref, iref of the fine cells) — parity unpinned beyond that.
@@ -40,6 +41,26 @@ inline void tagRelativeGradient(HydroSystem const &hydro, Array4<const double> c
 				double const gradient_indicator = del / P;
 				bool const above = min_inclusive ? (P >= q_min) : (P > q_min);
 				if ((gradient_indicator > eta_threshold) && above) {
+					tag(i, j, k) = TagBox_SET;
+				}
+			}
+		}
+	}
+}
+
+// del = (q(+1) - q(-1)) / (2 dx) along `dir`; SET where sqrt(del^2) / q > eta and q >= q_min
+inline void tagCenteredGradient(Array4<const double> const &state, Array4<char> const &tag, Box const &box, int comp, int dir, double dx, double eta_threshold,
+				double q_min, bool min_inclusive)
+{
+	int const e[3] = {dir == 0 ? 1 : 0, dir == 1 ? 1 : 0, dir == 2 ? 1 : 0};
+	for (int k = box.lo[2]; k <= box.hi[2]; ++k) {
+		for (int j = box.lo[1]; j <= box.hi[1]; ++j) {
+			for (int i = box.lo[0]; i <= box.hi[0]; ++i) {
+				double const rho = state(i, j, k, comp);
+				double const del_x = (state(i + e[0], j + e[1], k + e[2], comp) - state(i - e[0], j - e[1], k - e[2], comp)) / (2.0 * dx);
+				double const gradient_indicator = std::sqrt(del_x * del_x) / rho;
+				bool const above = min_inclusive ? (rho >= q_min) : (rho > q_min);
+				if (gradient_indicator > eta_threshold && above) {
 					tag(i, j, k) = TagBox_SET;
 				}
 			}

@@ -248,6 +248,13 @@ void orc_sim_tag_relative_gradient(void *p, int b, int field, double eta_thresho
 	tagRelativeGradient(s->hydro, s->state_new_cc_.const_array(b), t, s->grids[b], s->ndim(), field, eta_threshold, q_min, min_inclusive != 0);
 }
 
+void orc_sim_tag_centered_gradient(void *p, int b, int comp, int dir, double dx, double eta_threshold, double q_min, int min_inclusive, char *tags)
+{
+	auto *s = static_cast<HydroSim *>(p);
+	Array4<char> t(tags, s->grids[b], 1);
+	tagCenteredGradient(s->state_new_cc_.const_array(b), t, s->grids[b], comp, dir, dx, eta_threshold, q_min, min_inclusive != 0);
+}
+
 // coarse -> fine interpolation of `region` (fine indices); arrays given with their lower / upper corners
 void orc_interp_from_coarse(double *fine, const int *flo, const int *fhi, const double *crse_old, const double *crse_new, const int *clo, const int *chi,
 			    int ncomp_total, const int *rlo, const int *rhi, double w_old, double w_new, int ncomp, int method, int hooks, int ndim, const int *ratio)

@@ -109,6 +109,7 @@ class Oracle:
         L.orc_eos_variant.restype = C.c_int
         L.orc_sim_rad_counters.argtypes = [C.c_void_p, C.c_long * 8]
         L.orc_sim_tag_relative_gradient.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p]
+        L.orc_sim_tag_centered_gradient.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p]
         L.orc_sim_rad_source.argtypes = [C.c_void_p, C.c_int, C.c_double, C.POINTER(C.c_double)]
 
     # ---------------------------------------------------------------- per-operator
@@ -277,6 +278,14 @@ class OracleSim:
         t = np.zeros((hi[2] - lo[2] + 1, hi[1] - lo[1] + 1, hi[0] - lo[0] + 1), dtype=np.int8)
         self.o.lib.orc_sim_tag_relative_gradient(self.h, b, int(field), C.c_double(eta_threshold), C.c_double(q_min), int(bool(min_inclusive)),
                                                  t.ctypes.data_as(C.c_void_p))
+        return t
+
+    def tag_centered_gradient(self, b: int, comp: int, direction: int, dx: float, eta_threshold: float, q_min: float, min_inclusive: bool) -> np.ndarray:
+        """ErrorEst of HydroShocktube (centred difference / (2 dx)) on the ghost-filled new state of box b"""
+        lo, hi = self.box(b)
+        t = np.zeros((hi[2] - lo[2] + 1, hi[1] - lo[1] + 1, hi[0] - lo[0] + 1), dtype=np.int8)
+        self.o.lib.orc_sim_tag_centered_gradient(self.h, b, int(comp), int(direction), C.c_double(dx), C.c_double(eta_threshold), C.c_double(q_min),
+                                                 int(bool(min_inclusive)), t.ctypes.data_as(C.c_void_p))
         return t
 
     def rad_source(self, b=0, time=0.0) -> np.ndarray:

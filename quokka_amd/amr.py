@@ -37,6 +37,14 @@ def tag_relative_gradient(lev: Level, traits: capi.HydroTraits, state: MultiFab,
                                              int(bool(min_inclusive))), "qk_tag_relative_gradient")
 
 
+def tag_centered_gradient(lev: Level, state: MultiFab, tags: MultiFab, comp: int, direction: int, dx: float, eta_threshold: float, q_min: float,
+                          min_inclusive: bool):
+    """ErrorEst of HydroShocktube (reference src/problems/HydroShocktube/test_hydro_shocktube.cpp:146-170)"""
+    ctx = lev.ctx
+    ctx.check(ctx.L.qk_tag_centered_gradient(lev.h, ctx.stream(), state.ptr, tags.ptr, int(comp), int(direction), float(dx), float(eta_threshold), float(q_min),
+                                             int(bool(min_inclusive))), "qk_tag_centered_gradient")
+
+
 def PreInterpState(lev: Level, mf: MultiFab):
     lev.ctx.check(lev.ctx.L.qk_PreInterpState(lev.h, lev.ctx.stream(), mf.ptr), "qk_PreInterpState")
 

@@ -130,6 +130,40 @@ int qk_tag_relative_gradient(qk_level *lev, qk_stream s, const qk_hydro_traits *
 	return QK_OK;
 }
 
+// ErrorEst of HydroShocktube (src/problems/HydroShocktube/test_hydro_shocktube.cpp:146-170): centred difference along one direction,
+//   del = (q(i+1) - q(i-1)) / (2 dx);  indicator = sqrt(del * del) / q;  SET where indicator > eta and q >= q_min (> if !min_inclusive)
+int qk_tag_centered_gradient(qk_level *lev, qk_stream s, const qk_array4 *state_t, qk_carray4 *tags_t, int comp, int dir, double dx, double eta_threshold,
+			     double q_min, int min_inclusive)
+{
+	if (lev == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	QK_REQUIRE(lev->ctx, state_t && tags_t && comp >= 0 && dir >= 0 && dir < lev->ndim && dx > 0.0, "tag_centered_gradient: bad argument");
+	if (lev->nboxes == 0) {
+		return QK_OK;
+	}
+	int64_t maxcells = 1;
+	for (int d = 0; d < 3; ++d) {
+		maxcells *= lev->maxlen[d];
+	}
+	const dim3 grid(static_cast<unsigned>((maxcells + 255) / 256), static_cast<unsigned>(lev->nboxes), 1);
+	auto f = [=] __device__(int b, int i, int j, int k) {
+		RA4 U(state_t[b]);
+		CA4 tag(tags_t[b]);
+		const int ex = (dir == 0), ey = (dir == 1), ez = (dir == 2);
+		const double q = U(i, j, k, comp);
+		const double del = (U(i + ex, j + ey, k + ez, comp) - U(i - ex, j - ey, k - ez, comp)) / (2.0 * dx);
+		const double gradient_indicator = sqrt(del * del) / q;
+		const bool above = (min_inclusive != 0) ? (q >= q_min) : (q > q_min);
+		if (gradient_indicator > eta_threshold && above) {
+			tag(i, j, k) = static_cast<char>(QK_TAG_SET);
+		}
+	};
+	hipLaunchKernelGGL(k_valid_cells<decltype(f)>, grid, dim3(256), 0, static_cast<hipStream_t>(s), lev->d_boxes, f);
+	QK_HIP_CHECK(lev->ctx, hipGetLastError());
+	return QK_OK;
+}
+
 // PreInterpState / PostInterpState: total energy <-> specific internal energy around the coarse-to-fine interpolation
 static int interpState(qk_level *lev, qk_stream s, qk_array4 *mf_t, bool pre)
 {

@@ -716,6 +716,14 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 						       eta_threshold, q_min, min_inclusive ? 1 : 0),
 			      "qk_tag_relative_gradient");
 	}
+	// centred-difference form (HydroShocktube): SET where sqrt(((q(+1) - q(-1)) / (2 dx))^2) / q > eta and q >= qmin (> if !inclusive)
+	void tagCenteredGradient(amrex::TagBoxArray &tags, int comp, int dir, double eta_threshold, double q_min, bool min_inclusive)
+	{
+		this->activate();
+		qkhost::check(qk_tag_centered_gradient(this->levelHandle(), nullptr, qkhost::tab(state_new_cc_[0]), reinterpret_cast<qk_carray4 *>(tags.arrays()), comp, dir,
+						       geom[0].dx[dir], eta_threshold, q_min, min_inclusive ? 1 : 0),
+			      "qk_tag_centered_gradient");
+	}
 	void FixupState() // reference src/QuokkaSimulation.hpp:761-770
 	{
 		this->activate();

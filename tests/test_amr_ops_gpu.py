@@ -6,7 +6,7 @@ import torch
 
 from oracle.pyoracle import SEDOV
 from quokka_amd import capi
-from quokka_amd.amr import AverageDown, PostInterpState, PreInterpState, TagBoxArray, tag_relative_gradient
+from quokka_amd.amr import AverageDown, PostInterpState, PreInterpState, TagBoxArray, tag_centered_gradient, tag_relative_gradient
 from quokka_amd.multifab import Level, MultiFab
 from quokka_amd.simulation import sedov_problem
 
@@ -31,6 +31,27 @@ def test_error_est_tags_match_oracle(ctx, oracle, field, eta, qmin, inclusive):
         want = so.tag_relative_gradient(b, field, eta, qmin, inclusive)
         got = tags.fab_numpy(b)[0]
         assert got.dtype == np.int8 and np.array_equal(got, want), f"box {b}: {int((got != want).sum())} tags differ"
+        nset += int((want == capi.TAG_SET).sum())
+    assert 0 < nset < N ** 3, nset
+
+
+@pytest.mark.parametrize("direction", [0, 1, 2])
+def test_centered_gradient_tags_match_oracle(ctx, oracle, direction):
+    """ErrorEst of HydroShocktube (centred density difference / (2 dx), rho >= 0.01) evaluated along each direction of a Sedov state"""
+    N, mgs = 32, 16
+    so = oracle.sim(SEDOV, 3, [N] * 3, [0, 0, 0], [1.2] * 3, [0, 0, 0], max_grid_size=[mgs] * 3)
+    sg = sedov_problem(ctx, N, max_grid_size=mgs)
+    for _ in range(12):
+        assert so.step() and sg.step()
+    so.fill_ghosts(0, so.time)
+    sg.fillBoundaryConditions(sg.state_new_cc_)
+    tags = TagBoxArray(sg.lev)
+    dx, eta = 1.2 / N, 2.0
+    tag_centered_gradient(sg.lev, sg.state_new_cc_, tags, 0, direction, dx, eta, 0.01, True)
+    nset = 0
+    for b in range(so.nboxes):
+        want = so.tag_centered_gradient(b, 0, direction, dx, eta, 0.01, True)
+        assert np.array_equal(tags.fab_numpy(b)[0], want)
         nset += int((want == capi.TAG_SET).sum())
     assert 0 < nset < N ** 3, nset
 

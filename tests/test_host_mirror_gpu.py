@@ -33,6 +33,17 @@ def test_sod_shocktube_executable(tmp_path):
     assert "Performance figure-of-merit" in out
 
 
+def test_sod_shocktube_amr_meets_the_reference_ctest_criterion(tmp_path):
+    """The reference's own ctest configuration of the Sod tube (tests/shocktube.in: one refined level on the density gradient,
+    subcycled, refluxed): relative L1 error of the level-0 state vs the exact solution <= 0.002, exit status 0."""
+    exact = os.path.join(ROOT, "tests", "golden", "ppm1d_sod_exact.txt")
+    data, meta, out = run("test_hydro_shocktube", [os.path.join(HOST, "decks", "shocktube_amr.in"), f"qk.sod_exact={exact}"], tmp_path)
+    assert abs(meta[1] - 0.4) < 1e-12 and meta[5] <= 0.002, meta
+    # the refined level must have done real work (its cells count in the figure of merit) and the coarse state differs from the unrefined run
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "sod_1024_final.npy"))
+    assert not np.array_equal(data.reshape(6, 1024), gold)
+
+
 def test_sedov_executable_matches_golden(tmp_path):
     """32^3 Sedov, 10 steps, through the C++ mirror (3-D build, fused path) == committed oracle state"""
     data, meta, out = run("test_hydro3d_blast", ["geometry.prob_lo=0 0 0", "geometry.prob_hi=1.2 1.2 1.2", "geometry.is_periodic=0 0 0",
