@@ -53,7 +53,11 @@ template <typename problem_t> class AmrDriver
 	// AmrCore::InitFromScratch + AverageDown (reference src/simulation.hpp:1656-1702)
 	void setInitialConditions()
 	{
-		base_.AMRSimulation<problem_t>::setInitialConditions(); // level 0: problem ICs, ghost cells, state_old = state_new
+		base_.AMRSimulation<problem_t>::setInitialConditions(); // level 0: problem ICs (or the checkpoint's level 0), ghost cells, state_old = state_new
+		if (!base_.restart_chkfile.empty()) {
+			readCheckpointLevels();
+			return;
+		}
 		for (int lev = 0; lev < max_level; ++lev) {
 			auto boxes = newGrids(lev, nullptr);
 			if (boxes.empty()) {
@@ -85,12 +89,17 @@ template <typename problem_t> class AmrDriver
 			base_.tNew_[0] = tNew_;
 			base_.dt_[0] = dt_[0];
 			base_.istep[0] = istep[0];
+			base_.outputAfterStep(istep[0] - 1);
 			if (tNew_ >= base_.stopTime_ - 1.e-6 * dt_[0]) {
+				break;
+			}
+			if (base_.walltimeExceeded(t0)) {
 				break;
 			}
 		}
 		QK_HOST_HIP(hipDeviceSynchronize());
 		elapsedSeconds_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+		base_.outputAfterEvolve();
 		base_.elapsedSeconds_ = elapsedSeconds_;
 		base_.cellUpdates_ = cellUpdates_;
 		base_.computeAfterEvolve(init_sum_cons);
@@ -98,6 +107,28 @@ template <typename problem_t> class AmrDriver
 		amrex::Print() << "Performance figure-of-merit: " << us << " μs/zone-update [" << 1.0 / us << " Mupdates/s]\n";
 		for (int l = 0; l <= finestLevel(); ++l) {
 			amrex::Print() << "Zone-updates on level " << l << ": " << cellUpdatesEachLevel_[l] << " (" << level(l).grids_.size() << " grids)\n";
+		}
+	}
+
+	// the refined levels of AMRSimulation::ReadCheckpointFile (reference src/simulation.hpp:2676-2801): BoxArrays from the Header, data read
+	// fab by fab; flux registers, interpolation and average-down plans are rebuilt by makeLevel
+	void readCheckpointLevels()
+	{
+		auto const h = quokka::io::ReadCheckpointHeader(base_.restart_chkfile);
+		AMREX_ALWAYS_ASSERT(h.finest_level <= max_level);
+		tNew_ = h.tNew.at(0);
+		base_.tOldLev_ = base_.tNewLev_ = tNew_;
+		for (int lev = 0; lev <= max_level && lev < static_cast<int>(h.istep.size()); ++lev) {
+			istep[lev] = h.istep[lev];
+			dt_[lev] = h.dt[lev];
+		}
+		for (int lev = 1; lev <= h.finest_level; ++lev) {
+			makeLevel(lev, h.grids[lev]);
+			Sim &me = level(lev);
+			quokka::io::VisMFReadInto(me.state_new_cc_[0], base_.restart_chkfile + "/Level_" + std::to_string(lev) + "/Cell");
+			amrex::MultiFab::Copy(me.state_old_cc_[0], me.state_new_cc_[0]);
+			me.tOldLev_ = me.tNewLev_ = h.tNew.at(lev);
+			me.areInitialConditionsDefined_ = true;
 		}
 	}
 
@@ -539,6 +570,51 @@ template <typename problem_t> void QuokkaSimulation<problem_t>::setInitialCondit
 	} else {
 		AMRSimulation<problem_t>::setInitialConditions();
 	}
+	outputAfterInitialConditions();
+}
+
+// AMRSimulation::WritePlotFile (reference src/simulation.hpp:2294-2336): state_new_cc_ of every level, no derived variables
+template <typename problem_t> void QuokkaSimulation<problem_t>::WritePlotFile()
+{
+	int const nlev = amr_ ? amr_->finestLevel() + 1 : 1;
+	std::vector<amrex::MultiFab const *> mf;
+	std::vector<amrex::Geometry> geoms;
+	std::vector<int> steps;
+	for (int l = 0; l < nlev; ++l) {
+		auto &S = amr_ ? amr_->level(l) : *this;
+		mf.push_back(&S.state_new_cc_[0]);
+		geoms.push_back(S.geom[0]);
+		steps.push_back(amr_ ? amr_->istep[l] : istep[0]);
+	}
+	std::string const name = quokka::io::Concatenate(this->plot_file, istep[0], 5);
+	amrex::Print() << "Writing plotfile " << name << "\n";
+	QK_HOST_HIP(hipDeviceSynchronize());
+	quokka::io::WriteMultiLevelPlotfile(name, nlev, mf, this->componentNames_cc_, geoms, tNew_[0], steps);
+	quokka::io::WriteMetadataFile(name + "/metadata.yaml");
+}
+
+// AMRSimulation::WriteCheckpointFile (reference src/simulation.hpp:2564-2666)
+template <typename problem_t> void QuokkaSimulation<problem_t>::WriteCheckpointFile()
+{
+	quokka::io::CheckpointHeader h;
+	h.finest_level = amr_ ? amr_->finestLevel() : 0;
+	int const nmax = amr_ ? amr_->max_level + 1 : 1; // istep, dt_, tNew_ have one entry per level that may exist
+	std::vector<amrex::MultiFab const *> state;
+	for (int l = 0; l < nmax; ++l) {
+		bool const live = l <= h.finest_level;
+		h.istep.push_back(amr_ ? amr_->istep[l] : istep[0]);
+		h.dt.push_back(amr_ ? amr_->dt_[l] : dt_[0]);
+		h.tNew.push_back(live ? (amr_ ? amr_->level(l).tNewLev_ : tNew_[0]) : 0.0);
+		if (live) {
+			auto &S = amr_ ? amr_->level(l) : *this;
+			h.grids.push_back(S.grids_);
+			state.push_back(&S.state_new_cc_[0]);
+		}
+	}
+	std::string const name = quokka::io::Concatenate(this->chk_file, istep[0], 5);
+	amrex::Print() << "Writing checkpoint " << name << "\n";
+	QK_HOST_HIP(hipDeviceSynchronize());
+	quokka::io::WriteCheckpointFile(name, h, state);
 }
 
 template <typename problem_t> void QuokkaSimulation<problem_t>::evolve()

@@ -19,6 +19,7 @@
 #include <memory>
 
 #include "amrex_mini.hpp"
+#include "quokka_io.hpp"
 
 // Microphysics fundamental_constants.H (CODATA 2018, cgs)
 namespace C
@@ -396,8 +397,12 @@ template <typename problem_t> class AMRSimulation
 	amrex::Real stopTime_ = 1.0;
 	amrex::Real cflNumber_ = 0.3;
 	amrex::Long maxTimesteps_ = 10000;
-	int plotfileInterval_ = -1;
-	int checkpointInterval_ = -1;
+	int plotfileInterval_ = -1;   // -1 == no output
+	int checkpointInterval_ = -1; // -1 == no output
+	std::string plot_file{"plt"}; // plotfile prefix
+	std::string chk_file{"chk"};  // checkpoint prefix
+	std::string restart_chkfile;  // `restartfile = <checkpoint directory>`
+	amrex::Vector<std::string> componentNames_cc_;
 	amrex::Real densityFloor_ = 0.0;
 	amrex::Real tempFloor_ = 0.0;
 	amrex::Vector<amrex::Real> tNew_{0.0};
@@ -530,6 +535,9 @@ template <typename problem_t> class AMRSimulation
 		pp.query("stop_time", stopTime_);
 		pp.query("plotfile_interval", plotfileInterval_);
 		pp.query("checkpoint_interval", checkpointInterval_);
+		pp.query("plotfile_prefix", plot_file);
+		pp.query("checkpoint_prefix", chk_file);
+		pp.query("restartfile", restart_chkfile);
 		pp.query("density_floor", densityFloor_);
 		pp.query("temperature_floor", tempFloor_);
 	}
@@ -553,12 +561,22 @@ template <typename problem_t> class AMRSimulation
 	{
 		preCalculateInitialConditions();
 		auto &mf = state_new_cc_[0];
-		for (int b = 0; b < mf.size(); ++b) {
-			std::vector<double> h(static_cast<size_t>(mf.fabbox(b).numPts()) * mf.nComp(), 0.0);
-			quokka::grid grid_elem{amrex::Array4<double>(h.data(), mf.fabbox(b), mf.nComp()), mf.validbox(b), geom[0].CellSizeArray(),
-					       geom[0].ProbLoArray(), geom[0].ProbHiArray()};
-			setInitialConditionsOnGrid(grid_elem);
-			mf.copyFromHost(b, h);
+		if (restart_chkfile.empty()) {
+			for (int b = 0; b < mf.size(); ++b) {
+				std::vector<double> h(static_cast<size_t>(mf.fabbox(b).numPts()) * mf.nComp(), 0.0);
+				quokka::grid grid_elem{amrex::Array4<double>(h.data(), mf.fabbox(b), mf.nComp()), mf.validbox(b), geom[0].CellSizeArray(),
+						       geom[0].ProbLoArray(), geom[0].ProbHiArray()};
+				setInitialConditionsOnGrid(grid_elem);
+				mf.copyFromHost(b, h);
+			}
+		} else {
+			// level 0 of ReadCheckpointFile (reference src/simulation.hpp:2736-2801): the BoxArray comes from the deck, the data by
+			// ParallelCopy from the file's boxes
+			auto const h = quokka::io::ReadCheckpointHeader(restart_chkfile);
+			istep[0] = h.istep.at(0);
+			dt_[0] = h.dt.at(0);
+			tNew_[0] = h.tNew.at(0);
+			quokka::io::VisMFReadInto(mf, restart_chkfile + "/Level_0/Cell");
 		}
 		buildDirichletModel();
 		fillBoundaryConditions(state_new_cc_[0]);
@@ -760,10 +778,71 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		rpp.query("reconstruction_order", radiationReconstructionOrder_);
 		rpp.query("cfl", radiationCflNumber_);
 		rpp.query("max_substeps", maxSubsteps_);
+		std::string walltime;
+		if (amrex::ParmParse().query("max_walltime", walltime)) { // H:M:S (reference src/simulation.hpp:618-628)
+			int h = 0, m = 0, sec = 0;
+			if (std::sscanf(walltime.c_str(), "%d:%d:%d", &h, &m, &sec) == 3) {
+				maxWalltime_ = 3600L * h + 60L * m + sec;
+			}
+		}
+		defineComponentNames();
 		allocate();
 	}
 
       public:
+	// reference src/QuokkaSimulation.hpp:283-310 (no passive scalars in this build)
+	void defineComponentNames()
+	{
+		this->componentNames_cc_ = {"gasDensity", "x-GasMomentum", "y-GasMomentum", "z-GasMomentum", "gasEnergy", "gasInternalEnergy"};
+		if constexpr (is_radiation_enabled_) {
+			for (int i = 0; i < Physics_Traits<problem_t>::nGroups; ++i) {
+				for (auto const *name : {"radEnergy-Group", "x-RadFlux-Group", "y-RadFlux-Group", "z-RadFlux-Group"}) {
+					this->componentNames_cc_.push_back(name + std::to_string(i));
+				}
+			}
+		}
+	}
+
+	// on-disk formats (quokka_io.hpp); all levels of the hierarchy, defined in quokka_amr.hpp
+	void WritePlotFile();	    // reference src/simulation.hpp:2294-2336
+	void WriteCheckpointFile(); // reference src/simulation.hpp:2564-2666
+	long maxWalltime_ = 0;	    // seconds, 0: no limit
+	int lastPlotFileStep_ = 0, lastChkFileStep_ = 0;
+	// output schedule of AMRSimulation::setInitialConditions / evolve (reference src/simulation.hpp:657-684, 910-941, 983-1003)
+	void outputAfterInitialConditions()
+	{
+		if (this->restart_chkfile.empty() && this->checkpointInterval_ > 0) {
+			WriteCheckpointFile();
+		}
+		if (this->plotfileInterval_ > 0) {
+			WritePlotFile();
+		}
+		lastPlotFileStep_ = lastChkFileStep_ = istep[0];
+	}
+	void outputAfterStep(int step)
+	{
+		if (this->plotfileInterval_ > 0 && (step + 1) % this->plotfileInterval_ == 0) {
+			lastPlotFileStep_ = step + 1;
+			WritePlotFile();
+		}
+		if (this->checkpointInterval_ > 0 && (step + 1) % this->checkpointInterval_ == 0) { // after the plotfile, like the reference
+			lastChkFileStep_ = step + 1;
+			WriteCheckpointFile();
+		}
+	}
+	void outputAfterEvolve()
+	{
+		if (this->plotfileInterval_ > 0 && istep[0] > lastPlotFileStep_) {
+			WritePlotFile();
+		}
+		if (this->checkpointInterval_ > 0 && istep[0] > lastChkFileStep_) {
+			WriteCheckpointFile();
+		}
+	}
+	[[nodiscard]] auto walltimeExceeded(std::chrono::steady_clock::time_point t0) const -> bool
+	{
+		return maxWalltime_ > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.9 * static_cast<double>(maxWalltime_);
+	}
 
 	void setInitialConditionsOnGrid(quokka::grid const &grid_elem) override;
 	void preCalculateInitialConditions() override;
@@ -834,12 +913,17 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 			this->cellUpdates_ += this->CountCells(0);
 			cur_time += dt_[0];
 			tNew_[0] = cur_time;
+			outputAfterStep(step);
 			if (cur_time >= stopTime_ - 1.e-6 * dt_[0]) {
+				break;
+			}
+			if (walltimeExceeded(t0)) {
 				break;
 			}
 		}
 		QK_HOST_HIP(hipDeviceSynchronize());
 		elapsedSeconds_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+		outputAfterEvolve();
 		this->computeAfterEvolve(init_sum_cons);
 		double const microseconds_per_update = 1.0e6 * elapsedSeconds_ / static_cast<double>(this->cellUpdates_);
 		amrex::Print() << "Performance figure-of-merit: " << microseconds_per_update << " μs/zone-update [" << 1.0 / microseconds_per_update

@@ -12,11 +12,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "quokka_amd", "host")
 
 
-def run(exe, args, tmp_path, allow_fail=False):
+def run(exe, args, tmp_path, allow_fail=False, cwd=None):
     subprocess.check_call(["make", "-s", "-C", HOST])
     dump = str(tmp_path / "state.bin")
     cmd = [os.path.join(HOST, "bin", exe)] + args + [f"qk.dump_state={dump}"]
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=cwd)
     assert allow_fail or p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     meta = [float(x) for x in open(dump + ".meta").read().split()]
     return np.fromfile(dump, dtype=np.float64), meta, p.stdout
@@ -98,7 +98,7 @@ def test_sedov_amr_executable_matches_python_driver(tmp_path, ctx):
     N, nsteps = 32, 8
     data, meta, out = run("test_hydro3d_blast", ["geometry.prob_lo=0 0 0", "geometry.prob_hi=1.2 1.2 1.2", "geometry.is_periodic=0 0 0", f"amr.n_cell={N} {N} {N}",
                                                  "amr.max_level=2", "amr.max_grid_size=32", "amr.blocking_factor=8", "amr.n_error_buf=3", "do_reflux=1",
-                                                 f"max_timesteps={nsteps}"], tmp_path, allow_fail=True)
+                                                 f"max_timesteps={nsteps}", "plotfile_interval=100"], tmp_path, allow_fail=True, cwd=str(tmp_path))
     assert int(meta[0]) == nsteps and "Zone-updates on level 2" in out, out[-1500:]
     amr = sedov_amr_problem(ctx, N, 2, max_grid_size=32, blocking_factor=8)
     for _ in range(nsteps):
@@ -111,6 +111,14 @@ def test_sedov_amr_executable_matches_python_driver(tmp_path, ctx):
     assert np.array_equal(data.reshape(6, N, N, N), want), f"max abs diff {np.abs(data.reshape(6, N, N, N) - want).max()}"
     for l in range(3):
         assert f"Zone-updates on level {l}: {amr.cellUpdatesEachLevel_[l]} " in out
+    # both drivers' plotfile writers: same grids on every level, same data in every cell, same header fields
+    from quokka_amd import plotfile
+    plotfile.WritePlotFile(amr, str(tmp_path / "py_plt00008"))
+    diff = plotfile.compare_plotfiles(str(tmp_path / "plt00008"), str(tmp_path / "py_plt00008"))
+    assert all(v == 0.0 for v in diff.values()), diff
+    cpp, py = plotfile.read_plotfile(str(tmp_path / "plt00008")), plotfile.read_plotfile(str(tmp_path / "py_plt00008"))
+    assert cpp.finest_level == 2 and (cpp.time, cpp.level_steps, cpp.dx, cpp.domains) == (py.time, py.level_steps, py.dx, py.domains)
+    assert open(tmp_path / "plt00008" / "Header").read() == open(tmp_path / "py_plt00008" / "Header").read()
 
 
 def test_sedov_128_meets_the_reference_ctest_criteria(tmp_path):
@@ -122,3 +130,39 @@ def test_sedov_128_meets_the_reference_ctest_criteria(tmp_path):
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=560)
     assert "Energy conservation is OK." in p.stdout and "Kinetic energy production is OK." in p.stdout, p.stdout[-1500:]
     assert p.returncode == 0
+
+
+BLAST32 = ["geometry.prob_lo=0 0 0", "geometry.prob_hi=1.2 1.2 1.2", "geometry.is_periodic=0 0 0", "amr.n_cell=32 32 32", "amr.max_grid_size=16"]
+
+
+@pytest.mark.parametrize("amr", [[], ["amr.max_level=2", "amr.blocking_factor=8", "amr.n_error_buf=1"]], ids=["unigrid", "amr"])
+def test_checkpoint_restart_reproduces_the_plotfile(tmp_path, amr):
+    """The reference's checkpoint_restart_test.sh (tests/checkpoint_restart_test.sh), made stricter: run to step 12 writing a checkpoint at
+    step 6; restart from `last_chk`-style directory chk00006 and run to step 12 again; the second plt00012 must equal the first one
+    (kept as plt00012.old.*, as AMReX renames it) in every bit of every level.  Also: the plotfile holds exactly the dumped state."""
+    from quokka_amd import plotfile
+    wd = str(tmp_path)
+    common = BLAST32 + amr + ["plotfile_interval=100", "checkpoint_interval=6"]
+    data, meta, out = run("test_hydro3d_blast", common + ["max_timesteps=12"], tmp_path, allow_fail=True, cwd=wd)
+    assert int(meta[0]) == 12 and "Writing checkpoint chk00006" in out and "Writing plotfile plt00012" in out
+    assert os.path.islink(os.path.join(wd, "last_chk")) and os.readlink(os.path.join(wd, "last_chk")) == "chk00012"
+    first = plotfile.read_plotfile(os.path.join(wd, "plt00012"))
+    assert first.varnames == plotfile.HYDRO_NAMES and first.ndim == 3 and first.level_steps[0] == 12
+    assert first.finest_level == (2 if amr else 0) and abs(first.time - meta[1]) < 1e-15
+    lvl0 = first.levels[0]
+    assert lvl0.nghost == 0 and len(lvl0.boxes) == 8
+    state = data.reshape(8, 6, 16, 16, 16)
+    for b in range(8):
+        assert np.array_equal(lvl0.fabs[b], state[b])
+        assert np.array_equal(lvl0.minima[b], state[b].reshape(6, -1).min(axis=1))
+    h, lev = plotfile.read_checkpoint(os.path.join(wd, "chk00006"))
+    assert h.istep[0] == 6 and h.finest_level == first.finest_level or amr  # (the hierarchy may have a different depth at step 6)
+    assert lev[0].nghost == 4 and lev[0].fabs[0].shape == (6, 24, 24, 24)
+
+    data2, meta2, out2 = run("test_hydro3d_blast", common + ["max_timesteps=12", "restartfile=chk00006"], tmp_path, allow_fail=True, cwd=wd)
+    assert int(meta2[0]) == 12 and meta2[1] == meta[1]
+    olds = [d for d in os.listdir(wd) if d.startswith("plt00012.old.")]
+    assert len(olds) == 1
+    diff = plotfile.compare_plotfiles(os.path.join(wd, "plt00012"), os.path.join(wd, olds[0]))
+    assert all(v == 0.0 for v in diff.values()), diff
+    assert np.array_equal(data, data2)
