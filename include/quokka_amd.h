@@ -206,9 +206,11 @@ int qk_hydro_stage_fused(qk_level *lev, qk_stream s, const qk_hydro_traits *t, c
 typedef struct qk_rad_traits {
 	double c_light, c_hat, radiation_constant, Erad_floor;
 	int beta_order;	   /* 0..3 */
-	int opacity_model; /* 0: constants kappaP, kappaE, kappaF [cm^2 g^-1] (what RadhydroShell needs) */
+	int opacity_model; /* 0: constants kappaP, kappaE, kappaF [cm^2 g^-1] (what RadhydroShell needs);
+			    * 1: kappa = kappaX / rho, a constant absorption coefficient [cm^-1] (RadhydroShockCGS, test_radhydro_shock_cgs.cpp:78-86) */
 	double kappaP, kappaE, kappaF;
 	int pow_mode; /* 0: pow(T,4), pow(T,3) as the reference's std::pow; 1: repeated multiplication (bit-level tests) */
+	int eddington_model; /* the ComputeEddingtonFactor hook: 0 Levermore closure (radiation_system.hpp:773-790), 1 chi = 1/3 */
 } qk_rad_traits;
 /* State layout: Physics_Indices (reference src/physics_info.hpp:20-47): comps 0..5 hydro, 6..9 = (E_r, F_x, F_y, F_z). */
 

@@ -24,6 +24,8 @@ namespace C
 {
 constexpr double k_B = 1.380649e-16;
 constexpr double m_u = 1.6605390666e-24;
+constexpr double m_p = 1.67262192369e-24; // CODATA 2018, as Microphysics' fundamental_constants.H (not vendored)
+constexpr double m_e = 9.1093837015e-28;
 constexpr double c_light = 2.99792458e10;
 constexpr double sigma_SB = 5.670374419e-5;
 constexpr double a_rad = 4.0 * sigma_SB / c_light;

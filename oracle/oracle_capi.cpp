@@ -3,6 +3,9 @@
 // oracle_capi.cpp: extern "C" entry points so tests/ (ctypes + numpy) can drive the CPU
 // restatement.  Arrays are Fortran-order, component outermost (amrex::Array4 layout), FP64.
 #include <cstring>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <memory>
 
 #include "amr.hpp"
@@ -114,6 +117,17 @@ struct orc_sim_config {
 	int rad_pow_mode; // RadTraits::pow_mode
 };
 
+// OpenMP team size for everything that follows (small problems run faster on one thread: every parallel region costs a barrier over
+// the team, and a box that grants fewer CPUs than it shows makes an oversized team spin)
+void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+	omp_set_num_threads(n > 0 ? n : 1);
+#else
+	(void)n;
+#endif
+}
+
 void *orc_sim_create(orc_sim_config const *c)
 {
 	auto sim = std::make_unique<HydroSim>();
@@ -126,6 +140,9 @@ void *orc_sim_create(orc_sim_config const *c)
 		setupSedov(*sim);
 	} else if (c->problem == 3) {
 		setupShell(*sim, c->table_len, c->table_r, c->table_Erad, c->table_Frad);
+		sim->rad.rt.pow_mode = c->rad_pow_mode;
+	} else if (c->problem == 4) {
+		setupRadShock(*sim);
 		sim->rad.rt.pow_mode = c->rad_pow_mode;
 	} else {
 		return nullptr;

@@ -419,6 +419,126 @@ inline void setupShell(HydroSim &sim, int table_len, double const *r_over_r0, do
 	sim.finishInitialConditions();
 }
 
+
+// ---------------------------------------------------------------- radiative shock, cgs (src/problems/RadhydroShockCGS/test_radhydro_shock_cgs.cpp)
+struct RadShockConstants { // :22-56
+	static constexpr double a_rad = 7.5646e-15;
+	static constexpr double c = 2.99792458e10;
+	static constexpr double k_B = C::k_B;
+	static constexpr double c_s0 = 1.73e7;
+	static constexpr double kappa = 577.0; // rho * kappa [cm^-1]
+	static constexpr double gamma_gas = (5. / 3.);
+	static constexpr double c_v = k_B / ((C::m_p + C::m_e) * (gamma_gas - 1.0));
+	static constexpr double T0 = 2.18e6, rho0 = 5.69, v0 = 5.19e7;
+	static constexpr double T1 = 7.98e6, rho1 = 17.1, v1 = 1.73e7;
+	static constexpr double chat = 10.0 * (v0 + c_s0);
+	static constexpr double Erad0 = a_rad * (T0 * T0 * T0 * T0);
+	static constexpr double Egas0 = rho0 * c_v * T0;
+	static constexpr double Erad1 = a_rad * (T1 * T1 * T1 * T1);
+	static constexpr double Egas1 = rho1 * c_v * T1;
+	static constexpr double shock_position = 0.01305;
+	static constexpr double Lx = 0.01575;
+};
+
+inline void setupRadShock(HydroSim &sim)
+{
+	using S = RadShockConstants;
+	sim.hydro.tr.eos.tr.gamma = S::gamma_gas; // :66-70
+	sim.hydro.tr.eos.tr.mean_molecular_weight = C::m_p + C::m_e;
+	sim.hydro.tr.eos.tr.boltzmann_constant = S::k_B;
+	sim.hydro.tr.reconstruct_eint = true; // HydroSystem_Traits is not specialised
+	sim.hydro.tr.nscalars = 0;
+	sim.ncomp_cc = kNumHydroVars + kNumRadVars;
+	sim.is_radiation_enabled = true;
+	sim.rad.rt.c_light = S::c; // :58-64
+	sim.rad.rt.c_hat = S::chat;
+	sim.rad.rt.radiation_constant = S::a_rad;
+	sim.rad.rt.Erad_floor = 0.;
+	sim.rad.rt.beta_order = 1;
+	sim.rad.rt.eddington_model = 1; // :88-91 ComputeEddingtonFactor = 1/3
+	sim.rad.eos = sim.hydro.tr.eos;
+	sim.rad.ndim = sim.geom.ndim;
+	sim.rad.nstartHyperbolic_ = kNumHydroVars;
+	// :78-86
+	sim.rad.ComputePlanckOpacity = [](double rho, double) { return S::kappa / rho; };
+	sim.rad.ComputeFluxMeanOpacity = [](double rho, double) { return S::kappa / rho; };
+	sim.rad.ComputeEnergyMeanOpacity = [](double rho, double) { return S::kappa / rho; };
+
+	// problem_main :237-262
+	sim.BCs_cc.assign(sim.ncomp_cc, BCRec{});
+	for (int n = 0; n < sim.ncomp_cc; ++n) {
+		sim.BCs_cc[n].lo[0] = ext_dir;
+		sim.BCs_cc[n].hi[0] = ext_dir;
+	}
+	sim.cflNumber_ = 0.4;
+	sim.radiationCflNumber_ = 0.4;
+	sim.maxTimesteps_ = 20000;
+	sim.stopTime_ = 1.0e-9;
+
+	// setCustomBoundaryConditions :93-158
+	sim.customBC = [](int i, int j, int k, Array4<double> const &consVar, Box const &dom, double /*time*/) {
+		if (i < dom.lo[0]) {
+			const double px_L = S::rho0 * S::v0;
+			const double Egas_L = S::Egas0;
+			consVar(i, j, k, density_index) = S::rho0;
+			consVar(i, j, k, x1Momentum_index) = px_L;
+			consVar(i, j, k, x2Momentum_index) = 0.;
+			consVar(i, j, k, x3Momentum_index) = 0.;
+			consVar(i, j, k, energy_index) = Egas_L + (px_L * px_L) / (2 * S::rho0);
+			consVar(i, j, k, internalEnergy_index) = Egas_L;
+			consVar(i, j, k, kNumHydroVars + 0) = S::Erad0;
+			consVar(i, j, k, kNumHydroVars + 1) = 0;
+			consVar(i, j, k, kNumHydroVars + 2) = 0;
+			consVar(i, j, k, kNumHydroVars + 3) = 0;
+		} else if (i >= dom.hi[0]) {
+			const double px_R = S::rho1 * S::v1;
+			const double Egas_R = S::Egas1;
+			consVar(i, j, k, density_index) = S::rho1;
+			consVar(i, j, k, x1Momentum_index) = px_R;
+			consVar(i, j, k, x2Momentum_index) = 0.;
+			consVar(i, j, k, x3Momentum_index) = 0.;
+			consVar(i, j, k, energy_index) = Egas_R + (px_R * px_R) / (2 * S::rho1);
+			consVar(i, j, k, internalEnergy_index) = Egas_R;
+			consVar(i, j, k, kNumHydroVars + 0) = S::Erad1;
+			consVar(i, j, k, kNumHydroVars + 1) = 0;
+			consVar(i, j, k, kNumHydroVars + 2) = 0;
+			consVar(i, j, k, kNumHydroVars + 3) = 0;
+		}
+	};
+
+	sim.define();
+	// setInitialConditionsOnGrid :160-219
+	Geometry const g = sim.geom;
+	forEachValidCell(sim, [&](Array4<double> const &state_cc, int i, int j, int k) {
+		double const x = g.prob_lo[0] + (i + 0.5) * g.dx[0];
+		double radEnergy = NAN, x1RadFlux = NAN, energy = NAN, density = NAN, x1Momentum = NAN;
+		if (x < S::shock_position) {
+			radEnergy = S::Erad0;
+			x1RadFlux = 0.0;
+			energy = S::Egas0 + 0.5 * S::rho0 * (S::v0 * S::v0);
+			density = S::rho0;
+			x1Momentum = S::rho0 * S::v0;
+		} else {
+			radEnergy = S::Erad1;
+			x1RadFlux = 0.0;
+			energy = S::Egas1 + 0.5 * S::rho1 * (S::v1 * S::v1);
+			density = S::rho1;
+			x1Momentum = S::rho1 * S::v1;
+		}
+		state_cc(i, j, k, density_index) = density;
+		state_cc(i, j, k, x1Momentum_index) = x1Momentum;
+		state_cc(i, j, k, x2Momentum_index) = 0;
+		state_cc(i, j, k, x3Momentum_index) = 0;
+		state_cc(i, j, k, energy_index) = energy;
+		state_cc(i, j, k, internalEnergy_index) = energy - (x1Momentum * x1Momentum) / (2 * density);
+		state_cc(i, j, k, kNumHydroVars + 0) = radEnergy;
+		state_cc(i, j, k, kNumHydroVars + 1) = x1RadFlux;
+		state_cc(i, j, k, kNumHydroVars + 2) = 0;
+		state_cc(i, j, k, kNumHydroVars + 3) = 0;
+	});
+	sim.finishInitialConditions();
+}
+
 } // namespace oracle
 
 #endif // ORACLE_PROBLEMS_HPP_

@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 K_B = 1.380649e-16
 M_U = 1.6605390666e-24
 
-SOD, CONTACT, SEDOV, SHELL = 0, 1, 2, 3
+SOD, CONTACT, SEDOV, SHELL, RADSHOCK = 0, 1, 2, 3, 4
 
 
 def build(force: bool = False) -> None:
@@ -78,6 +78,20 @@ def _i3(v):
 def _dp(a: np.ndarray):
     assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
     return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def usable_cores() -> int:
+    """threads worth using: the affinity mask, capped by twice the cgroup CPU quota (the GPU boxes show 256 CPUs and grant 16)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(round(2 * float(quota) / float(period)))))
+    except (OSError, ValueError):
+        pass
+    if "OMP_NUM_THREADS" in os.environ:
+        n = int(os.environ["OMP_NUM_THREADS"])
+    return n
 
 
 class Oracle:
@@ -183,6 +197,9 @@ class Oracle:
             cfg.table_r, cfg.table_Erad, cfg.table_Frad = (_dp(c) for c in cols)
             self._keepalive = cols
         cfg.rad_pow_mode = rad_pow_mode
+        # team size by problem size: ~16k cells per thread at least (a 1-D 512-cell run makes ~10^5 tiny parallel regions per second)
+        ncells = int(np.prod(n_cell[:ndim]))
+        self.lib.orc_set_num_threads(int(max(1, min(usable_cores(), ncells // 16384))))
         h = self.lib.orc_sim_create(C.byref(cfg))
         assert h, "oracle: unknown problem"
         return OracleSim(self, h, ndim)

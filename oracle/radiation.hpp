@@ -42,6 +42,9 @@ struct RadTraits {
 	// 0: std::pow(T, 4) / std::pow(T, 3) as in the reference; 1: repeated multiplication (used by tests that want
 	// bit-level agreement with the device build, whose libm differs from glibc by <= 1 ulp in pow)
 	int pow_mode = 0;
+	// the ComputeEddingtonFactor hook (radiation_system.hpp:773-790 is the default, Levermore's closure); problems that specialise it
+	// use the Eddington approximation chi = 1/3 (e.g. src/problems/RadhydroShockCGS/test_radhydro_shock_cgs.cpp:88-91)
+	int eddington_model = 0; // 0: Levermore, 1: chi = 1/3
 };
 
 struct RadSystem {
@@ -91,8 +94,11 @@ struct RadSystem {
 	}
 
 	// :773-790 Levermore closure
-	[[nodiscard]] static auto ComputeEddingtonFactor(double f_in) -> double
+	[[nodiscard]] auto ComputeEddingtonFactor(double f_in) const -> double
 	{
+		if (rt.eddington_model == 1) {
+			return (1. / 3.);
+		}
 		const double f = clamp(f_in, 0., 1.);
 		const double f_fac = std::sqrt(4.0 - 3.0 * (f * f));
 		const double chi = (3.0 + 4.0 * (f * f)) / (5.0 + 2.0 * f_fac);
@@ -100,7 +106,7 @@ struct RadSystem {
 	}
 
 	// :873-916
-	[[nodiscard]] static auto ComputeEddingtonTensor(const double fx, const double fy, const double fz) -> std::array<std::array<double, 3>, 3>
+	[[nodiscard]] auto ComputeEddingtonTensor(const double fx, const double fy, const double fz) const -> std::array<std::array<double, 3>, 3>
 	{
 		auto f = std::sqrt(fx * fx + fy * fy + fz * fz);
 		std::array<double, 3> fvec = {fx, fy, fz};
@@ -127,8 +133,8 @@ struct RadSystem {
 	};
 
 	// :918-983
-	[[nodiscard]] static auto ComputeRadPressure(int dir, const double erad, const double Fx, const double Fy, const double Fz, const double fx,
-						     const double fy, const double fz) -> RadPressureResult
+	[[nodiscard]] auto ComputeRadPressure(int dir, const double erad, const double Fx, const double Fy, const double Fz, const double fx,
+					      const double fy, const double fz) const -> RadPressureResult
 	{
 		auto T = ComputeEddingtonTensor(fx, fy, fz);
 		const double Tnormal = T[dir][dir];

@@ -18,17 +18,28 @@ constexpr double IMEX_a32 = 0.5; // radiation_system.hpp:52
 struct Rad {
 	double c, chat, arad, Erad_floor;
 	double kappaP0, kappaE0, kappaF0;
-	int beta_order, pow_mode;
+	int beta_order, pow_mode, opacity_model, eddington_model;
 	__host__ __device__ explicit Rad(qk_rad_traits const &t)
 	    : c(t.c_light), chat(t.c_hat), arad(t.radiation_constant), Erad_floor(t.Erad_floor), kappaP0(t.kappaP), kappaE0(t.kappaE), kappaF0(t.kappaF),
-	      beta_order(t.beta_order), pow_mode(t.pow_mode)
+	      beta_order(t.beta_order), pow_mode(t.pow_mode), opacity_model(t.opacity_model), eddington_model(t.eddington_model)
 	{
 	}
 	// problem hooks ComputePlanckOpacity / ComputeEnergyMeanOpacity / ComputeFluxMeanOpacity (radiation_system.hpp:1141-1154):
-	// closed set, model 0 = constants
-	QK_DEV auto kappaP(double /*rho*/, double /*T*/) const -> double { return kappaP0; }
-	QK_DEV auto kappaE(double /*rho*/, double /*T*/) const -> double { return kappaE0; }
-	QK_DEV auto kappaF(double /*rho*/, double /*T*/) const -> double { return kappaF0; }
+	// closed set.  Model 0: constants [cm^2 g^-1]; model 1: constant absorption coefficient rho * kappa, i.e. kappa = k0 / rho
+	// (src/problems/RadhydroShockCGS/test_radhydro_shock_cgs.cpp:78-86)
+	QK_DEV auto kappaP(double rho, double /*T*/) const -> double { return (opacity_model == 0) ? kappaP0 : kappaP0 / rho; }
+	QK_DEV auto kappaE(double rho, double /*T*/) const -> double { return (opacity_model == 0) ? kappaE0 : kappaE0 / rho; }
+	QK_DEV auto kappaF(double rho, double /*T*/) const -> double { return (opacity_model == 0) ? kappaF0 : kappaF0 / rho; }
+	// the ComputeEddingtonFactor hook: 0 = Levermore closure (radiation_system.hpp:773-790, the default), 1 = Eddington approximation
+	QK_DEV auto eddingtonFactor(double f_in) const -> double
+	{
+		if (eddington_model == 1) {
+			return (1. / 3.);
+		}
+		const double f = clampd(f_in, 0., 1.);
+		const double f_fac = sqrt(4.0 - 3.0 * (f * f));
+		return (3.0 + 4.0 * (f * f)) / (5.0 + 2.0 * f_fac);
+	}
 	QK_DEV auto pow4(double T) const -> double { return (pow_mode == 0) ? pow(T, 4.0) : (T * T) * (T * T); }
 	QK_DEV auto pow3(double T) const -> double { return (pow_mode == 0) ? pow(T, 3.0) : (T * T) * T; }
 	// radiation_system.hpp:471-479, :499-503
@@ -43,16 +54,8 @@ struct Rad {
 	QK_DEV auto thermalRadiationTempDerivative(double T) const -> double { return 4. * arad * pow3(T); }
 };
 
-// radiation_system.hpp:773-790
-QK_DEV auto eddingtonFactor(double f_in) -> double
-{
-	const double f = clampd(f_in, 0., 1.);
-	const double f_fac = sqrt(4.0 - 3.0 * (f * f));
-	return (3.0 + 4.0 * (f * f)) / (5.0 + 2.0 * f_fac);
-}
-
 // radiation_system.hpp:873-916: row `row` of the Eddington tensor, plus T[row][row] via Tn[row]
-QK_DEV void eddingtonTensor(double fx, double fy, double fz, double T[3][3])
+QK_DEV void eddingtonTensor(Rad const &r, double fx, double fy, double fz, double T[3][3])
 {
 	const double f = sqrt(fx * fx + fy * fy + fz * fz);
 	const double fv[3] = {fx, fy, fz};
@@ -62,7 +65,7 @@ QK_DEV void eddingtonTensor(double fx, double fy, double fz, double T[3][3])
 	for (int ii = 0; ii < 3; ++ii) {
 		n[ii] = (f > 0.) ? divBy(fv[ii], Rf) : 0.;
 	}
-	const double chi = eddingtonFactor(f);
+	const double chi = r.eddingtonFactor(f);
 	const double Tdiag = (1.0 - chi) / 2.0;
 	const double Tf = (3.0 * chi - 1.0) / 2.0;
 #pragma unroll
@@ -110,8 +113,8 @@ template <int DIR> QK_DEV void radFaceFlux(Rad const &r, const double pL[NRAD], 
 		f_R = sqrt(fx_R * fx_R + fy_R * fy_R + fz_R * fz_R);
 	}
 	double TL[3][3], TR[3][3];
-	eddingtonTensor(fx_L, fy_L, fz_L, TL);
-	eddingtonTensor(fx_R, fy_R, fz_R, TR);
+	eddingtonTensor(r, fx_L, fy_L, fz_L, TL);
+	eddingtonTensor(r, fx_R, fy_R, fz_R, TR);
 	const double FnL = (DIR == 0) ? Fx_L : (DIR == 1) ? Fy_L : Fz_L;
 	const double FnR = (DIR == 0) ? Fx_R : (DIR == 1) ? Fy_R : Fz_R;
 	double FL[NRAD] = {FnL, TL[DIR][0] * erad_L, TL[DIR][1] * erad_L, TL[DIR][2] * erad_L};
@@ -354,7 +357,7 @@ QK_DEV void radSourceCell(Rad const &r, Eos const &eos, double U[10], double src
 			const double fz = divBy(Frad_t0[2], RcE);
 			const double F_coeff = chat * rho * kappaF * dt * lorentz_factor;
 			double Tedd[3][3];
-			eddingtonTensor(fx, fy, fz, Tedd);
+			eddingtonTensor(r, fx, fy, fz, Tedd);
 #pragma unroll
 			for (int n = 0; n < 3; ++n) {
 				double Planck_term = kappaP * fourPiBoverC * lorentz_factor_v;

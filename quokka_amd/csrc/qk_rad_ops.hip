@@ -113,8 +113,8 @@ inline auto checkRad(qk_ctx *ctx, const qk_rad_traits *rt) -> int
 	if (rt == nullptr) {
 		return setError(ctx, QK_ERR_INVALID, "rad traits is NULL");
 	}
-	if (rt->opacity_model != 0) {
-		return setError(ctx, QK_ERR_UNSUPPORTED, "only opacity_model 0 (constant kappa) is built");
+	if (rt->opacity_model < 0 || rt->opacity_model > 1 || rt->eddington_model < 0 || rt->eddington_model > 1) {
+		return setError(ctx, QK_ERR_UNSUPPORTED, "opacity_model must be 0 (constant kappa) or 1 (constant rho * kappa), eddington_model 0 (Levermore) or 1 (1/3)");
 	}
 	if (rt->beta_order < 0 || rt->beta_order > 3) {
 		return setError(ctx, QK_ERR_INVALID, "beta_order must be 0..3");

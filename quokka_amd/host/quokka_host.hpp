@@ -26,6 +26,8 @@ namespace C
 {
 constexpr double k_B = 1.380649e-16;
 constexpr double m_u = 1.6605390666e-24;
+constexpr double m_p = 1.67262192369e-24;
+constexpr double m_e = 9.1093837015e-28;
 constexpr double c_light = 2.99792458e10;
 constexpr double a_rad = 4.0 * 5.670374419e-5 / c_light;
 } // namespace C
@@ -272,28 +274,52 @@ template <typename problem_t> class RadSystem : public HyperbolicSystem<problem_
 	static auto ComputePlanckOpacity(double rho, double Tgas) -> amrex::Real;
 	static auto ComputeFluxMeanOpacity(double rho, double Tgas) -> amrex::Real;
 	static auto ComputeEnergyMeanOpacity(double rho, double Tgas) -> amrex::Real;
+	static auto ComputeEddingtonFactor(double f) -> double; // :773-790 (default: Levermore closure)
 	static void SetRadEnergySource(array_t &radEnergySource, amrex::Box const &indexRange, amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> const &dx,
 				       amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> const &prob_lo, amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> const &prob_hi,
 				       amrex::Real time);
 
-	// The opacity hooks run on the device in the reference; the C-ABI carries them as a closed, parametrised set (model 0:
-	// constants).  The hooks are sampled on the host: anything that is not constant in (rho, T) is refused, never approximated.
+	// The opacity and closure hooks run on the device in the reference; the C-ABI carries them as a closed, parametrised set
+	// (opacity model 0: constants, model 1: kappa = k0 / rho; closure 0: Levermore, 1: chi = 1/3).  The hooks are sampled on the host:
+	// anything outside the set is refused, never approximated.
 	static auto traits() -> qk_rad_traits
 	{
 		static_assert(Physics_Traits<problem_t>::nGroups == 1, "multigroup radiation is not built (SURVEY 8f rank 2)");
-		const double rs[3] = {1.0e-24, 3.7e-19, 2.0e-3}, Ts[3] = {3.0, 1.1e3, 4.0e7};
+		const double rs[4] = {1.0, 1.0e-24, 3.7e-19, 2.0e-3}, Ts[3] = {3.0, 1.1e3, 4.0e7};
 		const double kP = ComputePlanckOpacity(rs[0], Ts[0]), kE = ComputeEnergyMeanOpacity(rs[0], Ts[0]), kF = ComputeFluxMeanOpacity(rs[0], Ts[0]);
-		for (double r : rs) {
-			for (double T : Ts) {
-				if (ComputePlanckOpacity(r, T) != kP || ComputeEnergyMeanOpacity(r, T) != kE || ComputeFluxMeanOpacity(r, T) != kF) {
-					amrex::Abort("RadSystem: opacity hooks that depend on (rho, T) are not expressible in the C-ABI's closed opacity set");
+		int opacity_model = -1;
+		for (int model = 0; model < 2 && opacity_model < 0; ++model) {
+			bool ok = true;
+			for (double r : rs) {
+				for (double T : Ts) {
+					double const d = (model == 0) ? 1.0 : r;
+					ok = ok && ComputePlanckOpacity(r, T) == kP / d && ComputeEnergyMeanOpacity(r, T) == kE / d && ComputeFluxMeanOpacity(r, T) == kF / d;
 				}
 			}
+			if (ok) {
+				opacity_model = model;
+			}
+		}
+		if (opacity_model < 0) {
+			amrex::Abort("RadSystem: these opacity hooks are not expressible in the C-ABI's closed opacity set (constant kappa, constant rho * kappa)");
+		}
+		int eddington_model = -1;
+		{
+			bool lev = true, third = true;
+			for (double f : {0.0, 0.3, 0.77, 1.0}) {
+				double const ff = std::sqrt(4.0 - 3.0 * (f * f));
+				lev = lev && ComputeEddingtonFactor(f) == (3.0 + 4.0 * (f * f)) / (5.0 + 2.0 * ff);
+				third = third && ComputeEddingtonFactor(f) == (1. / 3.);
+			}
+			eddington_model = lev ? 0 : (third ? 1 : -1);
+		}
+		if (eddington_model < 0) {
+			amrex::Abort("RadSystem: ComputeEddingtonFactor is neither the Levermore closure nor the Eddington approximation");
 		}
 		int pow_mode = 0;
 		amrex::ParmParse pp("radiation");
 		pp.query("pow_mode", pow_mode); // 0: pow(T, 4) like the reference's std::pow; 1: repeated multiplication
-		return {c_light_, c_hat_, radiation_constant_, Erad_floor_, beta_order_, 0, kP, kE, kF, pow_mode};
+		return {c_light_, c_hat_, radiation_constant_, Erad_floor_, beta_order_, opacity_model, kP, kE, kF, pow_mode, eddington_model};
 	}
 	static auto lev() -> qk_level * { return qkhost::Runtime::get().lev; }
 	static void flux3(std::array<amrex::MultiFab, AMREX_SPACEDIM> const &f, qk_array4 *out[3])
@@ -367,6 +393,13 @@ template <typename problem_t> auto RadSystem<problem_t>::ComputeFluxMeanOpacity(
 template <typename problem_t> auto RadSystem<problem_t>::ComputeEnergyMeanOpacity(const double rho, const double Tgas) -> amrex::Real
 {
 	return ComputePlanckOpacity(rho, Tgas);
+}
+template <typename problem_t> auto RadSystem<problem_t>::ComputeEddingtonFactor(double f_in) -> double
+{
+	// f is the reduced flux == |F|/cE; compute Levermore (1984) closure [Eq. 25] (reference src/radiation/radiation_system.hpp:773-790)
+	const double f = std::clamp(f_in, 0., 1.);
+	const double f_fac = std::sqrt(4.0 - 3.0 * (f * f));
+	return (3.0 + 4.0 * (f * f)) / (5.0 + 2.0 * f_fac);
 }
 template <typename problem_t>
 void RadSystem<problem_t>::SetRadEnergySource(array_t & /*radEnergySource*/, amrex::Box const & /*indexRange*/,

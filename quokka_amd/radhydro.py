@@ -41,9 +41,9 @@ def _d3(v):
 
 class RadhydroSimulation(HydroSimulation):
     def __init__(self, ctx: Context, geom: Geometry, traits: capi.HydroTraits, rad_traits: capi.RadTraits, bcs, max_grid_size=None,
-                 rank: int = 0, nranks: int = 1, use_fused: bool = True):
+                 rank: int = 0, nranks: int = 1, use_fused: bool = True, dirichlet=None):
         self.ncomp_override = 10
-        super().__init__(ctx, geom, traits, bcs, max_grid_size, None, rank, nranks, use_fused, ncomp_cc=10)
+        super().__init__(ctx, geom, traits, bcs, max_grid_size, dirichlet, rank, nranks, use_fused, ncomp_cc=10)
         self.rad_traits = rad_traits
         self.radiationCflNumber_ = 0.3
         self.maxSubsteps_ = 10
@@ -249,5 +249,57 @@ def shell_problem(ctx: Context, n: int, table, max_grid_size: int = 128, rank=0,
         return source_norm * np.exp(-(r * r) / (2.0 * S.sigma_star * S.sigma_star))
 
     sim.SetRadEnergySource = source
+    sim.set_initial_conditions(ic)
+    return sim
+
+
+class RadShockConstants:
+    """reference src/problems/RadhydroShockCGS/test_radhydro_shock_cgs.cpp:22-56 (Skinner et al. 2019, Sec. 9.5)"""
+    a_rad = 7.5646e-15
+    c = 2.99792458e10
+    k_B = capi.K_B
+    c_s0 = 1.73e7
+    kappa = 577.0  # rho * kappa [cm^-1]
+    gamma_gas = 5.0 / 3.0
+    m_p, m_e = 1.67262192369e-24, 9.1093837015e-28
+    c_v = k_B / ((m_p + m_e) * (gamma_gas - 1.0))
+    T0, rho0, v0 = 2.18e6, 5.69, 5.19e7
+    T1, rho1, v1 = 7.98e6, 17.1, 1.73e7
+    chat = 10.0 * (v0 + c_s0)
+    Erad0 = a_rad * (T0 * T0 * T0 * T0)
+    Egas0 = rho0 * c_v * T0
+    Erad1 = a_rad * (T1 * T1 * T1 * T1)
+    Egas1 = rho1 * c_v * T1
+    shock_position = 0.01305
+    Lx = 0.01575
+
+
+def radshock_problem(ctx: Context, nx: int = 512, pow_mode: int = 0) -> RadhydroSimulation:
+    """reference src/problems/RadhydroShockCGS/test_radhydro_shock_cgs.cpp + tests/radshock.in (1-D build): a steady subcritical
+    radiative shock; Eddington approximation, constant absorption coefficient, constant states beyond both x faces."""
+    S = RadShockConstants
+    geom = Geometry(1, [nx], [0.0, 0.0, 0.0], [S.Lx, 1.0, 1.0], [0, 1, 1])
+    bcs = [([capi.BC_EXT_DIR, 0, 0], [capi.BC_EXT_DIR, 0, 0]) for _ in range(10)]
+    traits = capi.traits(S.gamma_gas, True, 1, mean_molecular_weight=S.m_p + S.m_e, boltzmann_constant=S.k_B)
+    rt = capi.RadTraits(S.c, S.chat, S.a_rad, 0.0, 1, 1, S.kappa, S.kappa, S.kappa, pow_mode, 1)
+    pxL, pxR = S.rho0 * S.v0, S.rho1 * S.v1
+    left = [S.rho0, pxL, 0.0, 0.0, S.Egas0 + (pxL * pxL) / (2 * S.rho0), S.Egas0, S.Erad0, 0.0, 0.0, 0.0]
+    right = [S.rho1, pxR, 0.0, 0.0, S.Egas1 + (pxR * pxR) / (2 * S.rho1), S.Egas1, S.Erad1, 0.0, 0.0, 0.0]
+    sim = RadhydroSimulation(ctx, geom, traits, rt, bcs, [nx, 1, 1], use_fused=False, dirichlet={(0, 0): left, (0, 1): right})
+    sim.cflNumber_ = sim.radiationCflNumber_ = 0.4  # problem_main :222-262
+    sim.maxTimesteps_, sim.stopTime_ = 20000, 1.0e-9
+    dx = geom.dx[0]
+
+    def ic(i, j, k):  # setInitialConditionsOnGrid :160-219
+        x = (i + 0.5) * dx
+        pre = x < S.shock_position
+        U = np.zeros((10,) + i.shape)
+        U[0] = np.where(pre, S.rho0, S.rho1)
+        U[1] = np.where(pre, S.rho0 * S.v0, S.rho1 * S.v1)
+        U[4] = np.where(pre, S.Egas0 + 0.5 * S.rho0 * (S.v0 * S.v0), S.Egas1 + 0.5 * S.rho1 * (S.v1 * S.v1))
+        U[5] = U[4] - (U[1] * U[1]) / (2 * U[0])
+        U[6] = np.where(pre, S.Erad0, S.Erad1)
+        return U
+
     sim.set_initial_conditions(ic)
     return sim

@@ -166,3 +166,20 @@ def test_checkpoint_restart_reproduces_the_plotfile(tmp_path, amr):
     diff = plotfile.compare_plotfiles(os.path.join(wd, "plt00012"), os.path.join(wd, olds[0]))
     assert all(v == 0.0 for v in diff.values()), diff
     assert np.array_equal(data, data2)
+
+
+def test_radiative_shock_executable_meets_the_reference_criterion_and_matches_oracle(tmp_path, oracle):
+    """The reference's RadhydroShockCGS ctest through the C++ mirror (1-D build; opacity kappa = k0 / rho and the Eddington
+    approximation sampled from the problem's hooks, Dirichlet states from setCustomBoundaryConditions): exit status 0 == relative L1
+    error of T_rad against Lowrie & Edwards' solution <= 0.005 after ~6000 hydro steps x 10 radiation substeps — and, with the shared
+    T^4 evaluation, the final state equals the oracle's full run in every bit."""
+    from oracle.pyoracle import RADSHOCK
+    exact = os.path.join(ROOT, "tests", "golden", "LowrieEdwards_shock.txt")
+    data, meta, out = run("test_radhydro_shock_cgs", [os.path.join(HOST, "decks", "radshock.in"), f"qk.shock_exact={exact}", "radiation.pow_mode=1"], tmp_path)
+    assert abs(meta[1] - 1.0e-9) < 1e-24 and meta[5] <= 0.005, meta
+    so = oracle.sim(RADSHOCK, 1, [512, 1, 1], [0, 0, 0], [0.01575, 1, 1], [0, 1, 1], max_grid_size=[512, 1, 1], rad_pow_mode=1)
+    assert so.evolve()
+    assert so.istep == int(meta[0]) and so.time == meta[1]
+    want = so.valid(0).reshape(10, 512)
+    got = data.reshape(10, 512)
+    assert np.array_equal(got, want), [float(np.abs(got[n] - want[n]).sum() / max(np.abs(want[n]).sum(), 1e-300)) for n in range(10)]

@@ -93,3 +93,33 @@ def test_sedov_conservation_symmetry_and_box_invariance(oracle):
     assert np.abs(U1[1] - U1[2].transpose(0, 2, 1)).max() <= 1e-15
     gold = np.load(os.path.join(HERE, "golden", "sedov_32_step10.npy"))
     assert np.array_equal(gold, U1)
+
+
+def radshock_error(Erad_row):
+    """the pass criterion of the reference's RadhydroShockCGS ctest (src/problems/RadhydroShockCGS/test_radhydro_shock_cgs.cpp:264-343):
+    relative L1 error of T_rad / T0 against the semi-analytic solution of Lowrie & Edwards (extern/LowrieEdwards/shock.txt, committed
+    as data in tests/golden/), interpolated onto the exact solution's points inside the domain"""
+    from quokka_amd.radhydro import RadShockConstants as S
+    nx = Erad_row.shape[-1]
+    xs = S.Lx * ((np.arange(nx) + 0.5) / nx)
+    Trad = np.power(Erad_row / S.a_rad, 1.0 / 4.0) / S.T0
+    ex = np.loadtxt(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "LowrieEdwards_shock.txt"))
+    m = (ex[:, 0] > 0.0) & (ex[:, 0] < S.Lx)
+    interp = np.interp(ex[m, 0], xs, Trad)
+    return float(np.abs(interp - ex[m, 4]).sum() / np.abs(ex[m, 4]).sum())
+
+
+def test_radiative_shock_meets_the_reference_criterion(oracle):
+    """Pins the RADIATION restatement (oracle/radiation.hpp: M1 transport with HLL fluxes, the Newton-Raphson matter-radiation
+    exchange, the IMEX subcycle, the v/c work and pressure terms) and its coupling to the hydro update on a reference known-answer
+    test: RadhydroShockCGS to t = 1e-9 s on 512 cells must reproduce the Lowrie-Edwards shock structure within 0.005 (the reference's
+    tolerance).  ~6000 hydro steps x 10 radiation substeps, ~40 s."""
+    from oracle.pyoracle import RADSHOCK
+    s = oracle.sim(RADSHOCK, 1, [512, 1, 1], [0, 0, 0], [0.01575, 1, 1], [0, 1, 1], max_grid_size=[512, 1, 1])
+    assert s.evolve()
+    assert abs(s.time - 1.0e-9) < 1e-24
+    c = s.rad_counters()
+    assert c["fail_coupling"] == c["fail_outer"] == 0 and c["rad_cell_updates"] >= 10 * 512 * s.istep * 0.9
+    err = radshock_error(s.valid(0)[6, 0, 0, :])
+    assert err < 0.005, err
+    assert err > 1e-4  # (a discretised shock: an implausibly small error would mean the comparison is not looking at the solution)

@@ -94,3 +94,22 @@ def test_radhydro_steps_within_1e12_with_libm_pow(ctx, oracle):
         assert err[n] <= 1e-12, (n, err)
     for n in (1, 2, 3):
         assert np.abs(Ug[n] - Uo[n]).sum() <= 1e-12 * scale, (n, err)
+
+
+def test_radiative_shock_steps_match_oracle(ctx, oracle):
+    """RadhydroShockCGS (1-D, Dirichlet states beyond both faces, kappa = k0 / rho, Eddington approximation — the second members of
+    the closed opacity / closure sets): 150 coupled steps, bit for bit with the shared T^4 evaluation"""
+    from oracle.pyoracle import RADSHOCK
+    from quokka_amd.radhydro import radshock_problem
+    nx, nsteps = 512, 150
+    so = oracle.sim(RADSHOCK, 1, [nx, 1, 1], [0, 0, 0], [0.01575, 1, 1], [0, 1, 1], max_grid_size=[nx, 1, 1], rad_pow_mode=1)
+    sg = radshock_problem(ctx, nx, pow_mode=1)
+    assert np.array_equal(so.valid(0), sg.state_new_cc_.valid(0).cpu().numpy())  # the generators agree exactly (no libm calls)
+    for it in range(nsteps):
+        assert so.step() and sg.step()
+        assert so.dt == sg.dt_, (it, so.dt, sg.dt_)
+    Uo, Ug = so.valid(0), sg.state_new_cc_.valid(0).cpu().numpy()
+    assert np.array_equal(Uo, Ug), f"rel L1 per component {rel_l1(Ug, Uo)}"
+    co = so.rad_counters()
+    assert sg.rad_counters["solves"] == co["solves"] and sg.rad_counters["newton_iterations"] == co["newton_iterations"]
+    assert co["fail_coupling"] == co["fail_outer"] == 0
