@@ -79,6 +79,7 @@ struct HydroSim {
 
 	// --- radiation (QuokkaSimulation.hpp:125-133; Physics_Traits::is_radiation_enabled) ---
 	bool is_radiation_enabled = false;
+	bool is_hydro_enabled = true; // Physics_Traits::is_hydro_enabled (false: radiation-only problems, e.g. RadStreaming)
 	RadSystem rad;
 	double radiationCflNumber_ = 0.3;
 	int maxSubsteps_ = 10;
@@ -535,6 +536,10 @@ struct HydroSim {
 		_Pragma("omp parallel for schedule(dynamic) reduction(max : domain_signal_max)")
 		for (int b = 0; b < state_new_cc_.size(); ++b) {
 			Fab<double> maxSignal(grids[b], 1);
+			if (!is_hydro_enabled) { // QuokkaSimulation.hpp:421-424, radiation only: RadSystem::ComputeMaxSignalSpeed = c_hat in every cell
+				domain_signal_max = std::max(domain_signal_max, std::abs(rad.rt.c_hat));
+				continue;
+			}
 			hydro.ComputeMaxSignalSpeed(state_new_cc_.const_array(b), maxSignal.array(), grids[b]);
 			for (double v : maxSignal.d) {
 				if (is_radiation_enabled) {
@@ -726,7 +731,17 @@ struct HydroSim {
 		double const time = tNew_;
 		tNew_ += dt_;
 		std::swap(state_old_cc_, state_new_cc_);
-		bool ok = advanceHydroAtLevelWithRetries(time, dt_);
+		bool ok = true;
+		if (is_hydro_enabled) {
+			ok = advanceHydroAtLevelWithRetries(time, dt_);
+		} else { // QuokkaSimulation.hpp:681-685: copy hydro vars from state_old_cc_ to state_new_cc_
+			for (int b = 0; b < state_new_cc_.size(); ++b) {
+				auto const &src = state_old_cc_.fabs[b].d;
+				auto &dst = state_new_cc_.fabs[b].d;
+				size_t const n = src.size() / static_cast<size_t>(ncomp_cc) * kNumHydroVars;
+				std::copy(src.begin(), src.begin() + static_cast<long>(n), dst.begin());
+			}
+		}
 		if (ok && is_radiation_enabled) {
 			ok = subcycleRadiationAtLevel(time, dt_); // QuokkaSimulation.hpp:689-692
 		}

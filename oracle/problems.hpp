@@ -539,6 +539,92 @@ inline void setupRadShock(HydroSim &sim)
 	sim.finishInitialConditions();
 }
 
+
+// ---------------------------------------------------------------- free-streaming radiation front (src/problems/RadStreaming/test_radiation_streaming.cpp)
+struct StreamingConstants { // :24-31
+	static constexpr double initial_Erad = 1.0e-5;
+	static constexpr double initial_Egas = 1.0e-5;
+	static constexpr double c = 1.0;
+	static constexpr double chat = 0.2;
+	static constexpr double kappa0 = 1.0e-10;
+	static constexpr double rho = 1.0;
+};
+
+inline void setupStreaming(HydroSim &sim)
+{
+	using S = StreamingConstants;
+	sim.hydro.tr.eos.tr.gamma = 5. / 3.; // :33-37
+	sim.hydro.tr.eos.tr.mean_molecular_weight = 1.0;
+	sim.hydro.tr.eos.tr.boltzmann_constant = 1.0;
+	sim.hydro.tr.reconstruct_eint = true;
+	sim.hydro.tr.nscalars = 0;
+	sim.ncomp_cc = kNumHydroVars + kNumRadVars;
+	sim.is_radiation_enabled = true; // :39-49
+	sim.is_hydro_enabled = false;
+	sim.rad.rt.c_light = S::c; // :51-57
+	sim.rad.rt.c_hat = S::chat;
+	sim.rad.rt.radiation_constant = 1.0;
+	sim.rad.rt.Erad_floor = S::initial_Erad;
+	sim.rad.rt.beta_order = 0;
+	sim.rad.eos = sim.hydro.tr.eos;
+	sim.rad.ndim = sim.geom.ndim;
+	sim.rad.nstartHyperbolic_ = kNumHydroVars;
+	sim.rad.ComputePlanckOpacity = [](double, double) { return S::kappa0; }; // :59-67
+	sim.rad.ComputeFluxMeanOpacity = [](double, double) { return S::kappa0; };
+	sim.rad.ComputeEnergyMeanOpacity = [](double, double) { return S::kappa0; };
+
+	// problem_main :167-195
+	sim.BCs_cc.assign(sim.ncomp_cc, BCRec{});
+	for (int n = 0; n < sim.ncomp_cc; ++n) {
+		sim.BCs_cc[n].lo[0] = ext_dir;
+		sim.BCs_cc[n].hi[0] = foextrap;
+	}
+	sim.radiationReconstructionOrder_ = 3;
+	sim.stopTime_ = 1.0;
+	sim.radiationCflNumber_ = 0.8;
+	sim.maxDt_ = 1e-2;
+	sim.maxTimesteps_ = 5000;
+
+	// setCustomBoundaryConditions :100-165 (it does not look at the BCRec: the foextrap fill of the upper face is overwritten too)
+	sim.customBC = [](int i, int j, int k, Array4<double> const &consVar, Box const &dom, double /*time*/) {
+		if (i < dom.lo[0]) {
+			const double Erad = 1.0;
+			const double Frad = S::c * Erad;
+			consVar(i, j, k, kNumHydroVars + 0) = Erad;
+			consVar(i, j, k, kNumHydroVars + 1) = Frad;
+			consVar(i, j, k, kNumHydroVars + 2) = 0;
+			consVar(i, j, k, kNumHydroVars + 3) = 0;
+		} else if (i >= dom.hi[0]) {
+			consVar(i, j, k, kNumHydroVars + 0) = S::initial_Erad;
+			consVar(i, j, k, kNumHydroVars + 1) = 0;
+			consVar(i, j, k, kNumHydroVars + 2) = 0;
+			consVar(i, j, k, kNumHydroVars + 3) = 0;
+		}
+		consVar(i, j, k, energy_index) = S::initial_Egas;
+		consVar(i, j, k, density_index) = S::rho;
+		consVar(i, j, k, internalEnergy_index) = S::initial_Egas;
+		consVar(i, j, k, x1Momentum_index) = 0.;
+		consVar(i, j, k, x2Momentum_index) = 0.;
+		consVar(i, j, k, x3Momentum_index) = 0.;
+	};
+
+	sim.define();
+	// setInitialConditionsOnGrid :69-98
+	forEachValidCell(sim, [&](Array4<double> const &state_cc, int i, int j, int k) {
+		state_cc(i, j, k, kNumHydroVars + 0) = S::initial_Erad;
+		state_cc(i, j, k, kNumHydroVars + 1) = 0;
+		state_cc(i, j, k, kNumHydroVars + 2) = 0;
+		state_cc(i, j, k, kNumHydroVars + 3) = 0;
+		state_cc(i, j, k, energy_index) = S::initial_Egas;
+		state_cc(i, j, k, density_index) = S::rho;
+		state_cc(i, j, k, internalEnergy_index) = S::initial_Egas;
+		state_cc(i, j, k, x1Momentum_index) = 0.;
+		state_cc(i, j, k, x2Momentum_index) = 0.;
+		state_cc(i, j, k, x3Momentum_index) = 0.;
+	});
+	sim.finishInitialConditions();
+}
+
 } // namespace oracle
 
 #endif // ORACLE_PROBLEMS_HPP_

@@ -888,8 +888,14 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	// ------------------------------------------------------------------ dt (reference src/simulation.hpp:703-818)
 	void computeTimestep()
 	{
-		double m = (haveSignal_ ? signal_[1] : HydroSystem<problem_t>::maxSignalSpeedLocal(state_new_cc_[0], 1));
-		if constexpr (is_radiation_enabled_) {
+		double m = 0.0;
+		if constexpr (!Physics_Traits<problem_t>::is_hydro_enabled) { // radiation only (reference src/QuokkaSimulation.hpp:421-424): c_hat in every cell
+			static_assert(is_radiation_enabled_, "At least one of hydro or radiation must be enabled! Cannot compute a time step.");
+			m = RadSystem<problem_t>::c_hat_;
+		} else {
+			m = (haveSignal_ ? signal_[1] : HydroSystem<problem_t>::maxSignalSpeedLocal(state_new_cc_[0], 1));
+		}
+		if constexpr (is_radiation_enabled_ && Physics_Traits<problem_t>::is_hydro_enabled) {
 			// reference src/QuokkaSimulation.hpp:421-434: per cell max(c_hat / maxSubsteps, hydro signal); the max over cells commutes
 			m = std::max(RadSystem<problem_t>::c_hat_ / static_cast<double>(maxSubsteps_), m);
 		}
@@ -936,8 +942,12 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 			double const time = tNew_[0];
 			tNew_[0] += dt_[0];
 			std::swap(state_old_cc_[0], state_new_cc_[0]);
-			if (!advanceHydroAtLevelWithRetries(time, dt_[0])) {
-				amrex::Abort("QUOKKA FATAL ERROR: Hydro update exceeded max_retries on level 0");
+			if constexpr (Physics_Traits<problem_t>::is_hydro_enabled) {
+				if (!advanceHydroAtLevelWithRetries(time, dt_[0])) {
+					amrex::Abort("QUOKKA FATAL ERROR: Hydro update exceeded max_retries on level 0");
+				}
+			} else { // copy hydro vars from state_old_cc_ to state_new_cc_ (reference src/QuokkaSimulation.hpp:681-685)
+				amrex::MultiFab::Copy(state_new_cc_[0], state_old_cc_[0], 0, 0, ncompHydro_, 0);
 			}
 			if constexpr (is_radiation_enabled_) { // advanceSingleTimestepAtLevel (reference src/QuokkaSimulation.hpp:653-707)
 				subcycleRadiationAtLevel(time, dt_[0]);

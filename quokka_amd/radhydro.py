@@ -45,6 +45,7 @@ class RadhydroSimulation(HydroSimulation):
         self.ncomp_override = 10
         super().__init__(ctx, geom, traits, bcs, max_grid_size, dirichlet, rank, nranks, use_fused, ncomp_cc=10)
         self.rad_traits = rad_traits
+        self.is_hydro_enabled = True  # Physics_Traits::is_hydro_enabled (False: radiation-only problems)
         self.radiationCflNumber_ = 0.3
         self.maxSubsteps_ = 10
         self.radiationReconstructionOrder_ = 3
@@ -62,6 +63,8 @@ class RadhydroSimulation(HydroSimulation):
 
     # ------------------------------------------------------------------ dt
     def computeTimestepAtLevel(self) -> float:
+        if not self.is_hydro_enabled:  # QuokkaSimulation.hpp:421-424, radiation only: the signal speed is c_hat in every cell
+            return self.cflNumber_ * (self.min_dx() / self.rad_traits.c_hat)
         if self._signal_of_state_new is not None:
             m = self._signal_of_state_new[1]
         else:
@@ -168,7 +171,12 @@ class RadhydroSimulation(HydroSimulation):
         time = self.tNew_
         self.tNew_ += self.dt_
         self.state_old_cc_, self.state_new_cc_ = self.state_new_cc_, self.state_old_cc_
-        ok = self.advanceHydroAtLevelWithRetries(self.dt_)
+        if self.is_hydro_enabled:
+            ok = self.advanceHydroAtLevelWithRetries(self.dt_)
+        else:  # QuokkaSimulation.hpp:681-685: copy hydro vars from state_old_cc_ to state_new_cc_
+            for b in range(self.lev.nboxes):
+                self.state_new_cc_.fabs[b][:RAD0].copy_(self.state_old_cc_.fabs[b][:RAD0])
+            ok = True
         if ok:
             ok = self.subcycleRadiationAtLevel(time, self.dt_)
         self.istep += 1
@@ -299,6 +307,40 @@ def radshock_problem(ctx: Context, nx: int = 512, pow_mode: int = 0) -> Radhydro
         U[4] = np.where(pre, S.Egas0 + 0.5 * S.rho0 * (S.v0 * S.v0), S.Egas1 + 0.5 * S.rho1 * (S.v1 * S.v1))
         U[5] = U[4] - (U[1] * U[1]) / (2 * U[0])
         U[6] = np.where(pre, S.Erad0, S.Erad1)
+        return U
+
+    sim.set_initial_conditions(ic)
+    return sim
+
+
+class StreamingConstants:
+    """reference src/problems/RadStreaming/test_radiation_streaming.cpp:24-31"""
+    initial_Erad = 1.0e-5
+    initial_Egas = 1.0e-5
+    c = 1.0
+    chat = 0.2
+    kappa0 = 1.0e-10
+    rho = 1.0
+
+
+def streaming_problem(ctx: Context, nx: int = 1000, pow_mode: int = 0) -> RadhydroSimulation:
+    """reference src/problems/RadStreaming/test_radiation_streaming.cpp + tests/RadStreaming.in (1-D build): a radiation front entering
+    an optically thin medium at the (reduced) speed of light; radiation only, Levermore closure at f = 1, beta_order = 0."""
+    S = StreamingConstants
+    geom = Geometry(1, [nx], [0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [0, 1, 1])
+    bcs = [([capi.BC_EXT_DIR, 0, 0], [capi.BC_FOEXTRAP, 0, 0]) for _ in range(10)]
+    traits = capi.traits(5.0 / 3.0, True, 1, mean_molecular_weight=1.0, boltzmann_constant=1.0)
+    rt = capi.RadTraits(S.c, S.chat, 1.0, S.initial_Erad, 0, 0, S.kappa0, S.kappa0, S.kappa0, pow_mode, 0)
+    gas = [S.rho, 0.0, 0.0, 0.0, S.initial_Egas, S.initial_Egas]
+    # setCustomBoundaryConditions :100-165 writes both ends whatever the BCRec says: the foextrap fill of the upper face is overwritten
+    sim = RadhydroSimulation(ctx, geom, traits, rt, bcs, [nx, 1, 1], use_fused=False,
+                             dirichlet={(0, 0): gas + [1.0, S.c * 1.0, 0.0, 0.0], (0, 1): gas + [S.initial_Erad, 0.0, 0.0, 0.0]})
+    sim.is_hydro_enabled = False
+    sim.radiationReconstructionOrder_, sim.stopTime_, sim.radiationCflNumber_, sim.maxDt_, sim.maxTimesteps_ = 3, 1.0, 0.8, 1e-2, 5000
+
+    def ic(i, j, k):
+        U = np.zeros((10,) + i.shape)
+        U[0], U[4], U[5], U[6] = S.rho, S.initial_Egas, S.initial_Egas, S.initial_Erad
         return U
 
     sim.set_initial_conditions(ic)

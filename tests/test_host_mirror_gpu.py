@@ -183,3 +183,10 @@ def test_radiative_shock_executable_meets_the_reference_criterion_and_matches_or
     want = so.valid(0).reshape(10, 512)
     got = data.reshape(10, 512)
     assert np.array_equal(got, want), [float(np.abs(got[n] - want[n]).sum() / max(np.abs(want[n]).sum(), 1e-300)) for n in range(10)]
+
+
+def test_streaming_executable_meets_the_reference_criterion(tmp_path):
+    """the reference's RadStreaming ctest through the C++ mirror (1-D build, hydro disabled): exit status 0 == error < 0.01"""
+    data, meta, out = run("test_radiation_streaming", [os.path.join(HOST, "decks", "RadStreaming.in")], tmp_path)
+    assert int(meta[0]) == 667 and meta[1] == 1.0 and meta[5] < 0.01, meta
+    assert np.array_equal(data.reshape(10, 1000)[0], np.ones(1000))

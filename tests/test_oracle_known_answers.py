@@ -123,3 +123,18 @@ def test_radiative_shock_meets_the_reference_criterion(oracle):
     err = radshock_error(s.valid(0)[6, 0, 0, :])
     assert err < 0.005, err
     assert err > 1e-4  # (a discretised shock: an implausibly small error would mean the comparison is not looking at the solution)
+
+
+def test_streaming_radiation_front_meets_the_reference_criterion(oracle):
+    """RadStreaming (src/problems/RadStreaming/test_radiation_streaming.cpp:197-222): radiation only, Levermore closure at reduced
+    flux 1, beta_order 0, an incident flux F = cE at the lower face; E_rad after t = 1 against the step function at x = c_hat t,
+    relative L1 error < 0.01 on 1000 cells."""
+    from oracle.pyoracle import STREAMING
+    s = oracle.sim(STREAMING, 1, [1000, 1, 1], [0, 0, 0], [1.0, 1, 1], [0, 1, 1], max_grid_size=[1000, 1, 1])
+    assert s.evolve() and s.time == 1.0 and s.istep == 667  # dt = 0.3 dx / c_hat: cflNumber_ stays at its default (only radiationCflNumber_ is set)
+    U = s.valid(0)
+    x = (np.arange(1000) + 0.5) / 1000
+    exact = np.where(x <= 0.2 * 1.0, 1.0, 0.0)
+    err = float(np.abs(U[6, 0, 0] - exact).sum() / np.abs(exact).sum())
+    assert err < 0.01, err
+    assert np.array_equal(U[0], np.ones_like(U[0])) and np.allclose(U[4], 1e-5, rtol=1e-3, atol=0)  # kappa ~ 0: the gas barely notices

@@ -113,3 +113,19 @@ def test_radiative_shock_steps_match_oracle(ctx, oracle):
     co = so.rad_counters()
     assert sg.rad_counters["solves"] == co["solves"] and sg.rad_counters["newton_iterations"] == co["newton_iterations"]
     assert co["fail_coupling"] == co["fail_outer"] == 0
+
+
+def test_streaming_front_matches_oracle_and_the_reference_criterion(ctx, oracle):
+    """RadStreaming, the full run (667 steps; radiation only: the hydro variables are copied, dt from c_hat alone): every bit of the
+    final state equals the oracle's, and the reference's criterion (relative L1 error < 0.01 against the step function) holds"""
+    from oracle.pyoracle import STREAMING
+    from quokka_amd.radhydro import streaming_problem
+    so = oracle.sim(STREAMING, 1, [1000, 1, 1], [0, 0, 0], [1.0, 1, 1], [0, 1, 1], max_grid_size=[1000, 1, 1], rad_pow_mode=1)
+    sg = streaming_problem(ctx, 1000, pow_mode=1)
+    assert so.evolve() and sg.evolve()
+    assert (so.istep, so.time) == (sg.istep, sg.tNew_) == (667, 1.0)
+    Uo, Ug = so.valid(0), sg.state_new_cc_.valid(0).cpu().numpy()
+    assert np.array_equal(Uo, Ug), f"rel L1 per component {rel_l1(Ug, Uo)}"
+    x = (np.arange(1000) + 0.5) / 1000
+    exact = np.where(x <= 0.2, 1.0, 0.0)
+    assert np.abs(Ug[6, 0, 0] - exact).sum() / exact.sum() < 0.01
