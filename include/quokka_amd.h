@@ -66,13 +66,15 @@ typedef struct qk_box {
 /* compile-time traits of the reference, as run-time data:
  * quokka::EOS_Traits<P> (src/hydro/EOS.hpp:32-37), HydroSystem_Traits<P> (src/hydro/hydro_system.hpp:38-41),
  * Physics_Traits<P> (src/physics_info.hpp:8-17), AMREX_SPACEDIM. */
+#define QK_MAX_SCALARS 8
 typedef struct qk_hydro_traits {
 	double gamma;
 	double cs_isothermal;
 	double mean_molecular_weight;
 	double boltzmann_constant;
 	int reconstruct_eint;
-	int nscalars;  /* passive scalars: must be 0 in this build (QK_ERR_UNSUPPORTED otherwise) */
+	int nscalars;  /* Physics_Traits::numPassiveScalars, 0..QK_MAX_SCALARS: carried by the reference-shaped operators (state / flux arrays hold
+			* 6 + nscalars components); the fused stage refuses nscalars > 0 (QK_ERR_UNSUPPORTED) */
 	int nmscalars; /* mass scalars: must be 0 */
 	int ndim;      /* 1 or 3 */
 } qk_hydro_traits;

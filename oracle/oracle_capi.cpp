@@ -141,6 +141,8 @@ void *orc_sim_create(orc_sim_config const *c)
 	} else if (c->problem == 3) {
 		setupShell(*sim, c->table_len, c->table_r, c->table_Erad, c->table_Frad);
 		sim->rad.rt.pow_mode = c->rad_pow_mode;
+	} else if (c->problem == 6) {
+		setupScalarContact(*sim, c->nscalars > 0 ? c->nscalars : 1);
 	} else if (c->problem == 5) {
 		setupStreaming(*sim);
 		sim->rad.rt.pow_mode = c->rad_pow_mode;

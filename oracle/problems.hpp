@@ -178,6 +178,49 @@ inline void setupContact(HydroSim &sim, int nscalars = 0)
 	sim.finishInitialConditions();
 }
 
+// ---------------------------------------------------------------- advected contact + passive scalar (src/problems/PassiveScalar/test_scalars.cpp)
+inline void setupScalarContact(HydroSim &sim, int nscalars)
+{
+	sim.hydro.tr.eos.tr.gamma = 1.4; // :25-29
+	sim.hydro.tr.eos.tr.mean_molecular_weight = C::m_u;
+	sim.hydro.tr.eos.tr.boltzmann_constant = C::k_B;
+	sim.hydro.tr.reconstruct_eint = true;
+	sim.hydro.tr.nscalars = nscalars; // the reference has one (:34); more repeat the step with other amplitudes
+	sim.ncomp_cc = kNumHydroVars + nscalars;
+	sim.BCs_cc.assign(sim.ncomp_cc, BCRec{}); // periodic (:243-253)
+	sim.stopTime_ = 2.0;			  // tests/PassiveScalar.in
+	sim.cflNumber_ = 0.2;
+	sim.maxTimesteps_ = 15000;
+
+	sim.define();
+	double const dx0 = sim.geom.dx[0];
+	double const lo0 = sim.geom.prob_lo[0];
+	int const ncomp = sim.ncomp_cc;
+	EOS const eos = sim.hydro.tr.eos;
+	const double v_contact = 2.0; // :43
+	// :45-87
+	forEachValidCell(sim, [=](Array4<double> const &state_cc, int i, int j, int k) {
+		double const x = lo0 + (i + 0.5) * dx0;
+		bool const left = x < 0.5;
+		double const rho = left ? 1.4 : 1.0;
+		double const vx = v_contact;
+		double const P = 1.0;
+		for (int n = 0; n < ncomp; ++n) {
+			state_cc(i, j, k, n) = 0.;
+		}
+		state_cc(i, j, k, density_index) = rho;
+		state_cc(i, j, k, x1Momentum_index) = rho * vx;
+		state_cc(i, j, k, x2Momentum_index) = 0.;
+		state_cc(i, j, k, x3Momentum_index) = 0.;
+		state_cc(i, j, k, energy_index) = eos.ComputeEintFromPres(rho, P) + 0.5 * rho * (vx * vx);
+		state_cc(i, j, k, internalEnergy_index) = eos.ComputeEintFromPres(rho, P);
+		for (int n = 0; n < ncomp - kNumHydroVars; ++n) {
+			state_cc(i, j, k, scalar0_index + n) = left ? 1.0 + n : 0.0;
+		}
+	});
+	sim.finishInitialConditions();
+}
+
 // ---------------------------------------------------------------- Sedov blast (octant)
 inline void setupSedov(HydroSim &sim)
 {

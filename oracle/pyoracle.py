@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 K_B = 1.380649e-16
 M_U = 1.6605390666e-24
 
-SOD, CONTACT, SEDOV, SHELL, RADSHOCK, STREAMING = 0, 1, 2, 3, 4, 5
+SOD, CONTACT, SEDOV, SHELL, RADSHOCK, STREAMING, SCALARS = 0, 1, 2, 3, 4, 5, 6
 
 
 def build(force: bool = False) -> None:

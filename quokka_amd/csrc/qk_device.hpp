@@ -274,9 +274,34 @@ template <int DIR> QK_DEV auto makeState(Eos const &eos, bool reconstruct_eint, 
 	return s;
 }
 
+// What a passive scalar needs from the Riemann solve of its face: scalars ride on the same waves, with D = 0 in F = u U + P D
+// (HLLC.hpp:126-136, LLF.hpp:30-41), and take the same artificial viscosity (hydro_system.hpp:1054-1076).
+struct Wave {
+	bool left, star;  // HLLC: side of the contact, inside the fan
+	double u, S_K, S_star; // HLLC: normal velocity and outer wave speed of that side, contact speed
+	Recip RD;	  // HLLC: 1 / (S_K - S_star)
+	double uL, uR, hS; // LLF: normal velocities, 0.5 * Sp
+	double viscosity;
+};
+
+// flux of a passive scalar with face states (qL, qR) through a face whose Riemann solve left `wv` behind
+template <int RIEMANN> QK_DEV auto scalarFlux(Wave const &wv, double qL, double qR) -> double
+{
+	double Fc;
+	if (RIEMANN == QK_RIEMANN_HLLC) {
+		const double U = wv.left ? qL : qR;
+		const double F_K = wv.u * U;
+		const double N = wv.S_star * (wv.S_K * U - F_K);
+		Fc = wv.star ? divBy(N, wv.RD) : F_K;
+	} else {
+		Fc = 0.5 * (wv.uL * qL + wv.uR * qR) - wv.hS * (qR - qL);
+	}
+	return Fc + wv.viscosity * (qL - qR);
+}
+
 // HLLC.hpp:22-153. F[6] in canonical order (rho, mom_n, mom_v, mom_w, E, Eint).
 QK_DEV void hllc(Eos const &eos, HState const &sL, HState const &sR, double du, double dw, double F[NVAR], Recip const &RL, Recip const &RR,
-		 Recip const &GL, Recip const &GR)
+		 Recip const &GL, Recip const &GR, Wave *wv = nullptr)
 {
 	const double wl = sqrt(sL.rho);
 	const double wr = sqrt(sR.rho);
@@ -386,12 +411,25 @@ QK_DEV void hllc(Eos const &eos, HState const &sL, HState const &sR, double du, 
 	F[3] = star ? G3 : F3;
 	F[4] = star ? G4 : F4;
 	F[5] = star ? G5 : F5;
+	if (wv != nullptr) {
+		wv->left = left;
+		wv->star = star;
+		wv->u = u;
+		wv->S_K = S_K;
+		wv->S_star = S_star;
+		wv->RD = RD;
+	}
 }
 
 // LLF.hpp:16-43
-QK_DEV void llf(HState const &sL, HState const &sR, double F[NVAR])
+QK_DEV void llf(HState const &sL, HState const &sR, double F[NVAR], Wave *wv = nullptr)
 {
 	const double Sp = smax(fabs(sL.u) + sL.cs, fabs(sR.u) + sR.cs);
+	if (wv != nullptr) {
+		wv->uL = sL.u;
+		wv->uR = sR.u;
+		wv->hS = 0.5 * Sp;
+	}
 	const double UL[NVAR] = {sL.rho, sL.rho * sL.u, sL.rho * sL.v, sL.rho * sL.w, sL.E, sL.Eint};
 	const double UR[NVAR] = {sR.rho, sR.rho * sR.u, sR.rho * sR.v, sR.rho * sR.w, sR.E, sR.Eint};
 	double FL[NVAR], FR[NVAR];
@@ -419,7 +457,7 @@ QK_DEV void llf(HState const &sL, HState const &sR, double F[NVAR])
 // Fout[6] is in ARRAY component order (rho, px, py, pz, E, Eint).
 template <int DIR, int RIEMANN>
 QK_DEV void faceFlux(Eos const &eos, bool reconstruct_eint, int ndim, const double qL[NVAR], const double qR[NVAR], double du, double dvl, double dvr,
-		     double dwl, double dwr, double K_visc, double Fout[NVAR], double &v_norm)
+		     double dwl, double dwr, double K_visc, double Fout[NVAR], double &v_norm, Wave *wv = nullptr)
 {
 	const Recip RL = recipOf(qL[PRHO]), RR = recipOf(qR[PRHO]);
 	const Recip GL = recipOf(eos.gm1 * qL[PRHO]), GR = recipOf(eos.gm1 * qR[PRHO]);
@@ -434,9 +472,9 @@ QK_DEV void faceFlux(Eos const &eos, bool reconstruct_eint, int ndim, const doub
 	}
 	double Fc[NVAR];
 	if (RIEMANN == QK_RIEMANN_HLLC) {
-		hllc(eos, sL, sR, du, dw, Fc, RL, RR, GL, GR);
+		hllc(eos, sL, sR, du, dw, Fc, RL, RR, GL, GR, wv);
 	} else {
-		llf(sL, sR, Fc);
+		llf(sL, sR, Fc, wv);
 	}
 	// :1054-1076 artificial viscosity (momentum components are overwritten below, :1079-1081)
 	double div_v = du;
@@ -447,6 +485,9 @@ QK_DEV void faceFlux(Eos const &eos, bool reconstruct_eint, int ndim, const doub
 		div_v = div_v + 0.5 * (dwl + dwr);
 	}
 	const double viscosity = K_visc * smax(-div_v, 0.);
+	if (wv != nullptr) {
+		wv->viscosity = viscosity;
+	}
 	double F[NVAR];
 	F[RHO] = Fc[0] + viscosity * (sL.rho - sR.rho);
 	F[ENE] = Fc[4] + viscosity * (sL.E - sR.E);

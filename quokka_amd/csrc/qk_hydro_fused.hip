@@ -655,6 +655,9 @@ int qk_hydro_stage_fused(qk_level *lev, qk_stream stream, const qk_hydro_traits 
 	if (lev->nboxes == 0) {
 		return QK_OK; // a rank without boxes on this level
 	}
+	if (t->nscalars != 0) {
+		return setError(ctx, QK_ERR_UNSUPPORTED, "qk_hydro_stage_fused: no passive scalars (use the reference-shaped operators)");
+	}
 	if (t->ndim != 3) {
 		return setError(ctx, QK_ERR_UNSUPPORTED, "qk_hydro_stage_fused: 3-D only (use the reference-shaped operators in 1-D)");
 	}

@@ -163,10 +163,14 @@ int qk_hydro_ConservedToPrimitive(qk_level *lev, qk_stream s, const qk_hydro_tra
 	QK_REQUIRE(lev->ctx, cons_t && prim_t, "ConservedToPrimitive: NULL array");
 	const Eos eos(*t);
 	const bool re = (t->reconstruct_eint != 0);
+	const int nscalars = t->nscalars;
 	launchCells(lev, s, nghost, -1, [=] __device__(int b, int i, int j, int k) {
 		RA4 cons(cons_t[b]);
 		WA4 prim(prim_t[b]);
 		const int64_t c = cons.idx(i, j, k);
+		for (int n = 0; n < nscalars; ++n) { // hydro_system.hpp:340-343: passive scalars are reconstructed as they are stored
+			prim(i, j, k, NVAR + n) = cons.p[c + cons.ns * (NVAR + n)];
+		}
 		const double rho = cons.p[c + cons.ns * RHO];
 		const double px = cons.p[c + cons.ns * MX];
 		const double py = cons.p[c + cons.ns * MY];
@@ -284,6 +288,7 @@ void launchComputeFluxes(qk_level *lev, qk_stream s, const qk_hydro_traits *t, q
 	const Eos eos(*t);
 	const bool re = (t->reconstruct_eint != 0);
 	const int ndim = t->ndim;
+	const int nscalars = t->nscalars;
 	launchCells(lev, s, 0, DIR, [=] __device__(int b, int i, int j, int k) {
 		RA4 L(left_t[b]);
 		RA4 R(right_t[b]);
@@ -318,11 +323,15 @@ void launchComputeFluxes(qk_level *lev, qk_stream s, const qk_hydro_traits *t, q
 			dwr = smin(q(i + wx, j + wy, k + wz, c) - q(i, j, k, c), q(i, j, k, c) - q(i - wx, j - wy, k - wz, c));
 		}
 		double Fo[NVAR], vn;
-		faceFlux<DIR, RIEMANN>(eos, re, ndim, qL, qR, du, dvl, dvr, dwl, dwr, K_visc, Fo, vn);
+		Wave wv;
+		faceFlux<DIR, RIEMANN>(eos, re, ndim, qL, qR, du, dvl, dvr, dwl, dwr, K_visc, Fo, vn, (nscalars > 0) ? &wv : nullptr);
 		const int64_t o = F.idx(i, j, k);
 #pragma unroll
 		for (int n = 0; n < NVAR; ++n) {
 			F.p[o + F.ns * n] = Fo[n];
+		}
+		for (int n = 0; n < nscalars; ++n) { // hydro_system.hpp:1062-1076, HLLC.hpp:126-136 / LLF.hpp:30-41
+			F.p[o + F.ns * (NVAR + n)] = scalarFlux<RIEMANN>(wv, L.p[cl + L.ns * (NVAR + n)], R.p[cr + R.ns * (NVAR + n)]);
 		}
 		V(i, j, k) = vn;
 	});
@@ -472,6 +481,7 @@ int qk_hydro_EnforceLimits(qk_level *lev, qk_stream s, const qk_hydro_traits *t,
 	}
 	QK_REQUIRE(lev->ctx, state_t, "EnforceLimits: NULL array");
 	const Eos eos(*t);
+	const int nscalars = t->nscalars;
 	launchCells(lev, s, 0, -1, [=] __device__(int b, int i, int j, int k) {
 		WA4 S(state_t[b]);
 		const int64_t c = S.idx(i, j, k);
@@ -479,6 +489,12 @@ int qk_hydro_EnforceLimits(qk_level *lev, qk_stream s, const qk_hydro_traits *t,
 #pragma unroll
 		for (int n = 0; n < NVAR; ++n) {
 			U[n] = S.p[c + S.ns * n];
+		}
+		if (nscalars > 0 && U[RHO] < densityFloor) { // hydro_system.hpp:713-722: the scalars keep their mass when the density is floored
+			for (int n = 0; n < nscalars; ++n) {
+				double &q = S.p[c + S.ns * (NVAR + n)];
+				q = (densityFloor == 0.0) ? 0.0 : q * (U[RHO] / densityFloor);
+			}
 		}
 		enforceLimits(eos, densityFloor, tempFloor, U);
 		S.p[c + S.ns * RHO] = U[RHO];

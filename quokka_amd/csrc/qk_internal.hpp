@@ -78,8 +78,8 @@ inline auto checkTraits(qk_ctx *ctx, const qk_hydro_traits *t) -> int
 	if (t == nullptr) {
 		return setError(ctx, QK_ERR_INVALID, "traits is NULL");
 	}
-	if (t->nscalars != 0 || t->nmscalars != 0) {
-		return setError(ctx, QK_ERR_UNSUPPORTED, "passive/mass scalars are not built (nvar = 6 only)");
+	if (t->nscalars < 0 || t->nscalars > QK_MAX_SCALARS || t->nmscalars != 0) {
+		return setError(ctx, QK_ERR_UNSUPPORTED, "0..QK_MAX_SCALARS passive scalars, no mass scalars (nmscalars = 0)");
 	}
 	if (t->ndim != 1 && t->ndim != 3) {
 		return setError(ctx, QK_ERR_UNSUPPORTED, "ndim must be 1 or 3");

@@ -64,6 +64,34 @@ template <typename problem_t> struct EOS_Traits {
 	static constexpr double mean_molecular_weight = std::numeric_limits<double>::quiet_NaN();
 	static constexpr double boltzmann_constant = C::k_B;
 };
+// quokka::EOS<problem_t> (reference src/hydro/EOS.hpp:40-244), host side, for problem generators: the direct gamma-law forms the
+// kernels use (p = (gamma - 1) rho e, e = p / ((gamma - 1) rho); DESIGN.md section 4 on the un-vendored Microphysics EOS)
+template <typename problem_t> struct EOS {
+	static constexpr double gamma_ = EOS_Traits<problem_t>::gamma;
+	static constexpr double mu_ = EOS_Traits<problem_t>::mean_molecular_weight / C::m_u;
+	static constexpr double kB_ = EOS_Traits<problem_t>::boltzmann_constant;
+	static auto ComputeEintFromPres(double rho, double Pressure) -> double
+	{
+		double const e = Pressure / ((gamma_ - 1.0) * rho);
+		return e * rho;
+	}
+	static auto ComputePressure(double rho, double Eint) -> double
+	{
+		double const e = Eint / rho;
+		return ((gamma_ - 1.0) * rho * e) * kB_ / C::k_B;
+	}
+	static auto ComputeTgasFromEint(double rho, double Eint) -> double
+	{
+		double const e = Eint / rho;
+		return (e * mu_ * C::m_u * (gamma_ - 1.0) / C::k_B) * C::k_B / kB_;
+	}
+	static auto ComputeEintFromTgas(double rho, double Tgas) -> double
+	{
+		double const p = rho * Tgas * C::k_B / (mu_ * C::m_u);
+		double const e = p / ((gamma_ - 1.0) * rho);
+		return e * rho * kB_ / C::k_B;
+	}
+};
 enum class centering { cc = 0, fc };
 enum class direction { na = -1, x, y, z };
 // reference src/grid.hpp
@@ -768,11 +796,12 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 			      "qk_tag_relative_gradient");
 	}
 	// centred-difference form (HydroShocktube): SET where sqrt(((q(+1) - q(-1)) / (2 dx))^2) / q > eta and q >= qmin (> if !inclusive)
-	void tagCenteredGradient(amrex::TagBoxArray &tags, int comp, int dir, double eta_threshold, double q_min, bool min_inclusive)
+	// (dx <= 0: the level's cell size, as HydroShocktube divides by it; PassiveScalar's form has no dx: pass 1)
+	void tagCenteredGradient(amrex::TagBoxArray &tags, int comp, int dir, double eta_threshold, double q_min, bool min_inclusive, double dx = -1.0)
 	{
 		this->activate();
 		qkhost::check(qk_tag_centered_gradient(this->levelHandle(), nullptr, qkhost::tab(state_new_cc_[0]), reinterpret_cast<qk_carray4 *>(tags.arrays()), comp, dir,
-						       geom[0].dx[dir], eta_threshold, q_min, min_inclusive ? 1 : 0),
+						       dx > 0.0 ? dx : geom[0].dx[dir], eta_threshold, q_min, min_inclusive ? 1 : 0),
 			      "qk_tag_centered_gradient");
 	}
 	void FixupState() // reference src/QuokkaSimulation.hpp:761-770
@@ -1327,7 +1356,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 
 	auto stage(int stageNo, amrex::MultiFab const &U_in, amrex::MultiFab const &U_old, amrex::MultiFab &U_out, double dt) -> bool
 	{
-		if (AMREX_SPACEDIM == 3 && artificialViscosityK_ == 0.0) {
+		if (AMREX_SPACEDIM == 3 && artificialViscosityK_ == 0.0 && HydroSystem<problem_t>::nscalars_ == 0) {
 			auto t = qkhost::traits<problem_t>();
 			qk_hydro_stage_args a{};
 			a.U_in = qkhost::tab(U_in);

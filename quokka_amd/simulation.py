@@ -253,7 +253,7 @@ class HydroSimulation:
         self.abortOnFofcFailure_ = 1
         self.artificialViscosityK_ = 0.0
         self.min_overlap_cells = 8 * 128 ** 3
-        self.use_fused = use_fused and geom.ndim == 3
+        self.use_fused = use_fused and geom.ndim == 3 and traits.nscalars == 0  # the fused stage carries the six hydro components only
         # state
         lev = self.lev
         self.state_old_cc_ = MultiFab(lev, self.ncomp_cc, NGHOST_CC, fill=0.0)
@@ -269,7 +269,7 @@ class HydroSimulation:
         self.flag_ghost = None  # built lazily: only FOFC needs redoFlag.FillBoundary
         nd = geom.ndim
         # half-step fluxes / face velocities of stage 1 (flux_rk2 / avgFaceVel of QuokkaSimulation.hpp:1056-1073)
-        self.halfFlux = [MultiFab(lev, 6, 0, facedir=d) for d in range(nd)]
+        self.halfFlux = [MultiFab(lev, self.hydro.nvar_, 0, facedir=d) for d in range(nd)]
         self.halfVel = [MultiFab(lev, 1, 0, facedir=d) for d in range(nd)]
         self.redoFlag = MultiFab(lev, 1, 1, dtype=torch.int32, fill=0)
         self.dev_counters = torch.zeros(2, dtype=torch.int64, device=ctx.device)  # [redo_count, (unused)]
@@ -357,17 +357,17 @@ class HydroSimulation:
         if self._unfused_tmp is None:
             lev, nd = self.lev, self.geom.ndim
             t = {}
-            t["prim"] = MultiFab(lev, 6, NGHOST_CC)
+            t["prim"] = MultiFab(lev, self.hydro.nvar_, NGHOST_CC)
             t["chi"] = [MultiFab(lev, 1, 2, fill=1.0) for _ in range(3)]
-            t["L"] = [MultiFab(lev, 6, 1, facedir=d) for d in range(nd)]
-            t["R"] = [MultiFab(lev, 6, 1, facedir=d) for d in range(nd)]
-            t["flux"] = [MultiFab(lev, 6, 0, facedir=d) for d in range(nd)]
+            t["L"] = [MultiFab(lev, self.hydro.nvar_, 1, facedir=d) for d in range(nd)]
+            t["R"] = [MultiFab(lev, self.hydro.nvar_, 1, facedir=d) for d in range(nd)]
+            t["flux"] = [MultiFab(lev, self.hydro.nvar_, 0, facedir=d) for d in range(nd)]
             t["vel"] = [MultiFab(lev, 1, 0, facedir=d) for d in range(nd)]
-            t["FOflux"] = [MultiFab(lev, 6, 0, facedir=d) for d in range(nd)]
+            t["FOflux"] = [MultiFab(lev, self.hydro.nvar_, 0, facedir=d) for d in range(nd)]
             t["FOvel"] = [MultiFab(lev, 1, 0, facedir=d) for d in range(nd)]
-            t["rk2flux"] = [MultiFab(lev, 6, 0, facedir=d) for d in range(nd)]
+            t["rk2flux"] = [MultiFab(lev, self.hydro.nvar_, 0, facedir=d) for d in range(nd)]
             t["rk2vel"] = [MultiFab(lev, 1, 0, facedir=d) for d in range(nd)]
-            t["rhs"] = MultiFab(lev, 6, 0)
+            t["rhs"] = MultiFab(lev, self.hydro.nvar_, 0)
             self._unfused_tmp = t
         return self._unfused_tmp
 
@@ -379,13 +379,13 @@ class HydroSimulation:
             hs.ComputeFlatteningCoefficients(lev, d, t["prim"], t["chi"][d], 2)
         for d in range(nd):
             if self.reconstructionOrder_ == 3:
-                HyperbolicSystem.ReconstructStatesPPM(lev, d, t["prim"], t["L"][d], t["R"][d], 1, 6)
+                HyperbolicSystem.ReconstructStatesPPM(lev, d, t["prim"], t["L"][d], t["R"][d], 1, self.hydro.nvar_)
             elif self.reconstructionOrder_ == 2:
-                HyperbolicSystem.ReconstructStatesPLM(lev, d, capi.LIMITER_MINMOD, t["prim"], t["L"][d], t["R"][d], 1, 6)
+                HyperbolicSystem.ReconstructStatesPLM(lev, d, capi.LIMITER_MINMOD, t["prim"], t["L"][d], t["R"][d], 1, self.hydro.nvar_)
             else:
-                HyperbolicSystem.ReconstructStatesConstant(lev, d, t["prim"], t["L"][d], t["R"][d], 1, 6)
+                HyperbolicSystem.ReconstructStatesConstant(lev, d, t["prim"], t["L"][d], t["R"][d], 1, self.hydro.nvar_)
             hs.FlattenShocks(lev, d, t["prim"], t["chi"][0], t["chi"][1] if nd > 1 else None, t["chi"][2] if nd > 2 else None,
-                             t["L"][d], t["R"][d], 1, 6)
+                             t["L"][d], t["R"][d], 1, self.hydro.nvar_)
             hs.ComputeFluxes(lev, capi.RIEMANN_HLLC, d, flux[d], vel[d], t["L"][d], t["R"][d], t["prim"], self.artificialViscosityK_)
 
     def computeFOHydroFluxes(self, consVar: MultiFab, flux, vel):
@@ -393,15 +393,15 @@ class HydroSimulation:
         t, lev, hs, nd = self._tmp(), self.lev, self.hydro, self.geom.ndim
         hs.ConservedToPrimitive(lev, consVar, t["prim"], NGHOST_CC)
         for d in range(nd):
-            HyperbolicSystem.ReconstructStatesConstant(lev, d, t["prim"], t["L"][d], t["R"][d], 1, 6)
+            HyperbolicSystem.ReconstructStatesConstant(lev, d, t["prim"], t["L"][d], t["R"][d], 1, self.hydro.nvar_)
             hs.ComputeFluxes(lev, capi.RIEMANN_LLF, d, flux[d], vel[d], t["L"][d], t["R"][d], t["prim"], self.artificialViscosityK_)
 
     def _rhs_pdv_predict(self, fluxes, vels, stateOld, stateNew, dt) -> int:
         t, lev, hs = self._tmp(), self.lev, self.hydro
         self.dev_counters.zero_()
-        hs.ComputeRhsFromFluxes(lev, t["rhs"], fluxes, self.geom.dx, 6)
+        hs.ComputeRhsFromFluxes(lev, t["rhs"], fluxes, self.geom.dx, self.hydro.nvar_)
         hs.AddInternalEnergyPdV(lev, t["rhs"], stateOld, self.geom.dx, vels, self.redoFlag)
-        hs.PredictStep(lev, stateOld, stateNew, t["rhs"], dt, 6, self.redoFlag, self.dev_counters[0:1])
+        hs.PredictStep(lev, stateOld, stateNew, t["rhs"], dt, self.hydro.nvar_, self.redoFlag, self.dev_counters[0:1])
         return self._allreduce_sum(int(self.dev_counters[0].item()))
 
     def _limits_and_sync(self, state):
@@ -435,9 +435,9 @@ class HydroSimulation:
             for d in range(nd):
                 t["rk2flux"][d].storage.zero_()
                 t["rk2vel"][d].storage.zero_()
-                Saxpy(lev, d, t["rk2flux"][d], 0.5, self.halfFlux[d], 6)
+                Saxpy(lev, d, t["rk2flux"][d], 0.5, self.halfFlux[d], self.hydro.nvar_)
                 Saxpy(lev, d, t["rk2vel"][d], 0.5, self.halfVel[d], 1)
-                Saxpy(lev, d, t["rk2flux"][d], 0.5, t["flux"][d], 6)
+                Saxpy(lev, d, t["rk2flux"][d], 0.5, t["flux"][d], self.hydro.nvar_)
                 Saxpy(lev, d, t["rk2vel"][d], 0.5, t["vel"][d], 1)
             fl, vl = t["rk2flux"], t["rk2vel"]
         self.redoFlag.storage.zero_()
@@ -447,7 +447,7 @@ class HydroSimulation:
             self.computeFOHydroFluxes(U_old, t["FOflux"], t["FOvel"])
             self._fill_flag_ghosts()
             for d in range(nd):
-                replaceFluxes(lev, d, fl[d], t["FOflux"][d], self.redoFlag, 6)
+                replaceFluxes(lev, d, fl[d], t["FOflux"][d], self.redoFlag, self.hydro.nvar_)
                 replaceFluxes(lev, d, vl[d], t["FOvel"][d], self.redoFlag, 1)
             nbad = self._rhs_pdv_predict(fl, vl, U_old, U_out, dt)
             if nbad > 0 and self.abortOnFofcFailure_ != 0:
@@ -585,7 +585,7 @@ class HydroSimulation:
             for substep in range(nsubsteps):
                 if substep > 0:
                     for b in range(self.lev.nboxes):  # amrex::Copy(tmp, state_new, 0, 0, ncompHydro_, nghost) (QuokkaSimulation.hpp:947)
-                        self.state_old_tmp.fabs[b][0:6].copy_(self.state_new_cc_.fabs[b][0:6])
+                        self.state_old_tmp.fabs[b][0:self.hydro.nvar_].copy_(self.state_new_cc_.fabs[b][0:self.hydro.nvar_])
                 success = self.advanceHydroAtLevel(old, dt_step)
                 if not success:
                     break
@@ -663,6 +663,35 @@ def sod_problem(ctx: Context, nx: int = 1024, use_fused=False) -> HydroSimulatio
         rho = np.where(x < 2.0, 10.0, 1.0)
         P = np.where(x < 2.0, 100.0, 1.0)
         U[0], U[4], U[5] = rho, P / (g - 1.0), P / (g - 1.0)
+        return U
+
+    sim.set_initial_conditions(ic)
+    return sim
+
+
+def scalar_contact_problem(ctx: Context, nx: int = 128, nscalars: int = 1, ndim: int = 1, max_grid_size=None) -> HydroSimulation:
+    """reference src/problems/PassiveScalar/test_scalars.cpp (+ tests/PassiveScalar.in without the refined level): a contact
+    discontinuity and a passive-scalar step advected with v = 2 through a periodic box"""
+    n_cell = [nx] + [16] * (ndim - 1)
+    geom = Geometry(ndim, n_cell, [0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [1, 1, 1])
+    nc = 6 + nscalars
+    bcs = [([capi.BC_INT_DIR] * 3, [capi.BC_INT_DIR] * 3) for _ in range(nc)]
+    g = 1.4
+    mgs = list(max_grid_size) if max_grid_size is not None else (n_cell + [1, 1])[:3]
+    sim = HydroSimulation(ctx, geom, capi.traits(g, True, ndim, nscalars=nscalars), bcs, mgs, ncomp_cc=nc)
+    sim.cflNumber_, sim.stopTime_, sim.maxTimesteps_ = 0.2, 2.0, 15000
+    dx = geom.dx[0]
+
+    def ic(i, j, k):
+        x = (i + 0.5) * dx
+        left = x < 0.5
+        U = np.zeros((nc,) + i.shape)
+        rho, vx, P = np.where(left, 1.4, 1.0), 2.0, 1.0
+        U[0], U[1] = rho, rho * vx
+        U[5] = P / (g - 1.0) + 0.0 * rho
+        U[4] = U[5] + 0.5 * rho * (vx * vx)
+        for n in range(nscalars):
+            U[6 + n] = np.where(left, 1.0 + n, 0.0)
         return U
 
     sim.set_initial_conditions(ic)

@@ -190,3 +190,13 @@ def test_streaming_executable_meets_the_reference_criterion(tmp_path):
     data, meta, out = run("test_radiation_streaming", [os.path.join(HOST, "decks", "RadStreaming.in")], tmp_path)
     assert int(meta[0]) == 667 and meta[1] == 1.0 and meta[5] < 0.01, meta
     assert np.array_equal(data.reshape(10, 1000)[0], np.ones(1000))
+
+
+def test_passive_scalar_executable_meets_the_reference_criteria(tmp_path):
+    """the reference's PassiveScalar ctest (tests/PassiveScalar.in: one refined level on the density gradient, subcycled, refluxed;
+    src/problems/PassiveScalar/test_scalars.cpp): scalar conserved to 1e-14 and relative rms L1 error <= 0.008 after four box
+    crossings — exit status 0.  Seven components (6 + 1 passive scalar) through interpolation, flux registers and average-down."""
+    data, meta, out = run("test_scalars", [os.path.join(HOST, "decks", "PassiveScalar.in")], tmp_path)
+    assert abs(meta[1] - 2.0) < 1e-12 and meta[5] <= 0.008, meta
+    assert "Passive scalar is conserved" in out and "Zone-updates on level 1" in out
+    assert data.size == 7 * 128

@@ -138,3 +138,16 @@ def test_streaming_radiation_front_meets_the_reference_criterion(oracle):
     err = float(np.abs(U[6, 0, 0] - exact).sum() / np.abs(exact).sum())
     assert err < 0.01, err
     assert np.array_equal(U[0], np.ones_like(U[0])) and np.allclose(U[4], 1e-5, rtol=1e-3, atol=0)  # kappa ~ 0: the gas barely notices
+
+
+def test_passive_scalar_advection_meets_the_reference_criteria(oracle):
+    """PassiveScalar (src/problems/PassiveScalar/test_scalars.cpp:131-141, :263): after t = 2 (four crossings of the periodic box at
+    v = 2) the scalar's sum is conserved to 1e-14 and the state is within 0.008 (relative rms L1) of the initial one.  The reference's
+    deck adds one refined level; the unrefined 128-cell grid already meets both."""
+    from oracle.pyoracle import SCALARS
+    s = oracle.sim(SCALARS, 1, [128, 1, 1], [0, 0, 0], [1.0, 1, 1], [1, 1, 1], max_grid_size=[64, 1, 1], nscalars=1)
+    U0 = np.concatenate([s.valid(b) for b in range(s.nboxes)], axis=-1)
+    assert s.evolve() and abs(s.time - 2.0) < 1e-13
+    U = np.concatenate([s.valid(b) for b in range(s.nboxes)], axis=-1)
+    assert abs(U[6].sum() - U0[6].sum()) / U0[6].sum() < 1.0e-14
+    assert rel_rms_l1(U0, U) < 0.008
