@@ -115,6 +115,9 @@ struct orc_sim_config {
 	int table_len;
 	double const *table_r, *table_Erad, *table_Frad;
 	int rad_pow_mode; // RadTraits::pow_mode
+	// problem 7 (parametrised 1-D hydro test): gamma, x_split, left[3], right[3], cfl, max_dt, init_dt, stop_time | profile, dirichlet
+	double h1d[12];
+	int h1d_i[2];
 };
 
 // OpenMP team size for everything that follows (small problems run faster on one thread: every parallel region costs a barrier over
@@ -141,6 +144,22 @@ void *orc_sim_create(orc_sim_config const *c)
 	} else if (c->problem == 3) {
 		setupShell(*sim, c->table_len, c->table_r, c->table_Erad, c->table_Frad);
 		sim->rad.rt.pow_mode = c->rad_pow_mode;
+	} else if (c->problem == 7) {
+		Hydro1DSpec p{};
+		p.gamma = c->h1d[0];
+		p.x_split = c->h1d[1];
+		for (int n = 0; n < 3; ++n) {
+			p.left[n] = c->h1d[2 + n];
+			p.right[n] = c->h1d[5 + n];
+		}
+		p.cfl = c->h1d[8];
+		p.max_dt = c->h1d[9];
+		p.init_dt = c->h1d[10];
+		p.stop_time = c->h1d[11];
+		p.profile = c->h1d_i[0];
+		p.dirichlet = c->h1d_i[1];
+		p.max_timesteps = c->max_timesteps >= 0 ? c->max_timesteps : 100000;
+		setupHydro1D(*sim, p);
 	} else if (c->problem == 6) {
 		setupScalarContact(*sim, c->nscalars > 0 ? c->nscalars : 1);
 	} else if (c->problem == 5) {

@@ -668,6 +668,95 @@ inline void setupStreaming(HydroSim &sim)
 	sim.finishInitialConditions();
 }
 
+
+// ---------------------------------------------------------------- 1-D hydro test family with a tabulated reference solution
+// HydroLeblanc, HydroVacuum, HydroShuOsher, HydroHighMach (src/problems/Hydro{Leblanc,Vacuum,ShuOsher,HighMach}/*.cpp) share one
+// shape: gamma-law gas, P / (gamma - 1) energies, an initial profile, constant states written beyond both x faces by
+// setCustomBoundaryConditions (or a periodic box), a few driver settings.  The numbers come from the caller (tests cite the lines).
+struct Hydro1DSpec {
+	double gamma;
+	int profile;		// 0: two states split at x_split; 1: Shu-Osher (left state | 1 + 0.2 sin(5x), 0, 1); 2: high-Mach sinusoid
+	double x_split;
+	double left[3], right[3]; // (rho, vx, P): initial states and the states beyond the lower / upper x face
+	int dirichlet;		// 1: constant states beyond both x faces (the problem's custom BC), 0: periodic
+	double cfl, max_dt, init_dt, stop_time;
+	long max_timesteps;
+};
+
+inline void setupHydro1D(HydroSim &sim, Hydro1DSpec const &p)
+{
+	sim.hydro.tr.eos.tr.gamma = p.gamma;
+	sim.hydro.tr.eos.tr.mean_molecular_weight = C::m_u;
+	sim.hydro.tr.eos.tr.boltzmann_constant = C::k_B;
+	sim.hydro.tr.reconstruct_eint = true; // none of the four specialises HydroSystem_Traits
+	sim.hydro.tr.nscalars = 0;
+	sim.ncomp_cc = kNumHydroVars;
+	sim.BCs_cc.assign(sim.ncomp_cc, BCRec{});
+	if (p.dirichlet != 0) { // the reference sets BCs_cc[0] only (sic); its functor writes every component of every ghost cell
+		sim.BCs_cc[0].lo[0] = ext_dir;
+		sim.BCs_cc[0].hi[0] = ext_dir;
+	}
+	sim.cflNumber_ = p.cfl;
+	if (p.max_dt > 0) {
+		sim.maxDt_ = p.max_dt;
+	}
+	if (p.init_dt > 0) {
+		sim.initDt_ = p.init_dt;
+	}
+	sim.stopTime_ = p.stop_time;
+	sim.maxTimesteps_ = p.max_timesteps;
+
+	double const gamma = p.gamma;
+	auto put = [gamma](Array4<double> const &U, int i, int j, int k, double rho, double vx, double P) {
+		for (int n = 0; n < U.ncomp; ++n) {
+			U(i, j, k, n) = 0.;
+		}
+		U(i, j, k, density_index) = rho;
+		U(i, j, k, x1Momentum_index) = rho * vx;
+		U(i, j, k, x2Momentum_index) = 0.;
+		U(i, j, k, x3Momentum_index) = 0.;
+		U(i, j, k, energy_index) = P / (gamma - 1.) + 0.5 * rho * (vx * vx);
+		U(i, j, k, internalEnergy_index) = P / (gamma - 1.);
+	};
+	if (p.dirichlet != 0) {
+		Hydro1DSpec const q = p;
+		sim.customBC = [put, q](int i, int j, int k, Array4<double> const &consVar, Box const &dom, double /*time*/) {
+			if (i < dom.lo[0]) {
+				put(consVar, i, j, k, q.left[0], q.left[1], q.left[2]);
+			} else if (i >= dom.hi[0]) {
+				put(consVar, i, j, k, q.right[0], q.right[1], q.right[2]);
+			}
+		};
+	}
+	sim.define();
+	double const dx0 = sim.geom.dx[0];
+	double const lo0 = sim.geom.prob_lo[0];
+	forEachValidCell(sim, [=](Array4<double> const &state_cc, int i, int j, int k) {
+		double const x = lo0 + (i + 0.5) * dx0;
+		double rho = NAN, vx = NAN, P = NAN;
+		if (p.profile == 2) { // test_hydro_highmach.cpp:57-62
+			double const norm = 1. / (2.0 * M_PI);
+			vx = norm * std::sin(2.0 * M_PI * x);
+			rho = 1.0;
+			P = 1.0e-10;
+		} else if (x < p.x_split) {
+			rho = p.left[0];
+			vx = p.left[1];
+			P = p.left[2];
+		} else if (p.profile == 1) { // test_hydro_shuosher.cpp:43-47
+			rho = 1.0 + 0.2 * std::sin(5.0 * x);
+			vx = 0.0;
+			P = 1.0;
+		} else {
+			rho = p.right[0];
+			vx = p.right[1];
+			P = p.right[2];
+		}
+		put(state_cc, i, j, k, rho, vx, P);
+	});
+	sim.finishInitialConditions();
+}
+
 } // namespace oracle
 
 #endif // ORACLE_PROBLEMS_HPP_

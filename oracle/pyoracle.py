@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 K_B = 1.380649e-16
 M_U = 1.6605390666e-24
 
-SOD, CONTACT, SEDOV, SHELL, RADSHOCK, STREAMING, SCALARS = 0, 1, 2, 3, 4, 5, 6
+SOD, CONTACT, SEDOV, SHELL, RADSHOCK, STREAMING, SCALARS, HYDRO1D = 0, 1, 2, 3, 4, 5, 6, 7
 
 
 def build(force: bool = False) -> None:
@@ -65,6 +65,8 @@ class SimConfig(C.Structure):
         ("table_Erad", C.POINTER(C.c_double)),
         ("table_Frad", C.POINTER(C.c_double)),
         ("rad_pow_mode", C.c_int),
+        ("h1d", C.c_double * 12),
+        ("h1d_i", C.c_int * 2),
     ]
 
 
@@ -181,7 +183,7 @@ class Oracle:
                                  _i3(clo), _i3(chi), fine.shape[0], _i3(region[0]), _i3(region[1]), w_old, w_new, ncomp, method, int(hooks), ndim, _i3(ratio))
 
     def sim(self, problem, ndim, n_cell, prob_lo, prob_hi, periodic, max_grid_size=None, cfl=-1.0, stop_time=-1.0,
-            max_timesteps=-1, reconstruction_order=-1, nscalars=0, table=None, rad_pow_mode=0) -> "OracleSim":
+            max_timesteps=-1, reconstruction_order=-1, nscalars=0, table=None, rad_pow_mode=0, hydro1d=None) -> "OracleSim":
         if ndim == 2:
             # AMREX_SPACEDIM == 2 builds of the reference use util/ArrayView_2d.hpp (X2 view = index SWAP, velV = vx, velW = vz),
             # not the cyclic permutation of ArrayView_3d.hpp restated here: a 2-D oracle would not be the reference's algorithm
@@ -197,6 +199,12 @@ class Oracle:
             cfg.table_r, cfg.table_Erad, cfg.table_Frad = (_dp(c) for c in cols)
             self._keepalive = cols
         cfg.rad_pow_mode = rad_pow_mode
+        if hydro1d is not None:  # dict: gamma, profile, x_split, left, right, dirichlet, cfl, max_dt, init_dt, stop_time (see oracle/problems.hpp Hydro1DSpec)
+            h = hydro1d
+            vals = [h["gamma"], h.get("x_split", 0.0)] + list(h.get("left", [0, 0, 0])) + list(h.get("right", [0, 0, 0])) + \
+                   [h["cfl"], h.get("max_dt", -1.0), h.get("init_dt", -1.0), h["stop_time"]]
+            cfg.h1d = (C.c_double * 12)(*[float(v) for v in vals])
+            cfg.h1d_i = (C.c_int * 2)(int(h.get("profile", 0)), int(h.get("dirichlet", 1)))
         # team size by problem size: ~16k cells per thread at least (a 1-D 512-cell run makes ~10^5 tiny parallel regions per second)
         ncells = int(np.prod(n_cell[:ndim]))
         self.lib.orc_set_num_threads(int(max(1, min(usable_cores(), ncells // 16384))))

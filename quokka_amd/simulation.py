@@ -696,3 +696,45 @@ def scalar_contact_problem(ctx: Context, nx: int = 128, nscalars: int = 1, ndim:
 
     sim.set_initial_conditions(ic)
     return sim
+
+
+def hydro1d_problem(ctx: Context, spec: dict, nx: int, hi: float, max_timesteps: int, max_grid_size: Optional[int] = None) -> HydroSimulation:
+    """The 1-D hydro test family of the reference with tabulated solutions (HydroLeblanc, HydroVacuum, HydroShuOsher, HydroHighMach;
+    src/problems/Hydro*/): gamma-law gas, P / (gamma - 1) energies, constant states beyond both x faces or a periodic box.
+    `spec` as oracle/problems.hpp::Hydro1DSpec (tests/hydro1d_cases.py holds the four cases with their reference lines)."""
+    g = spec["gamma"]
+    dirichlet = None
+    bcs = [([capi.BC_INT_DIR] * 3, [capi.BC_INT_DIR] * 3) for _ in range(6)]
+
+    def cons(rho, vx, P):
+        return [rho, rho * vx, 0.0, 0.0, P / (g - 1.0) + 0.5 * rho * (vx * vx), P / (g - 1.0)]
+
+    if spec.get("dirichlet", 1):
+        bcs[0] = ([capi.BC_EXT_DIR, 0, 0], [capi.BC_EXT_DIR, 0, 0])
+        dirichlet = {(0, 0): cons(*spec["left"]), (0, 1): cons(*spec["right"])}
+    geom = Geometry(1, [nx], [0.0, 0.0, 0.0], [hi, 1.0, 1.0], [0 if dirichlet else 1, 1, 1])
+    sim = HydroSimulation(ctx, geom, capi.traits(g, True, 1), bcs, [max_grid_size or nx, 1, 1], dirichlet=dirichlet, use_fused=False)
+    sim.cflNumber_, sim.stopTime_, sim.maxTimesteps_ = spec["cfl"], spec["stop_time"], max_timesteps
+    if spec.get("max_dt", -1.0) > 0:
+        sim.maxDt_ = spec["max_dt"]
+    if spec.get("init_dt", -1.0) > 0:
+        sim.initDt_ = spec["init_dt"]
+    dx = geom.dx[0]
+
+    def ic(i, j, k):
+        x = (i + 0.5) * dx
+        prof = spec.get("profile", 0)
+        if prof == 2:
+            rho, vx, P = np.ones_like(x), (1.0 / (2.0 * np.pi)) * np.sin(2.0 * np.pi * x), 1.0e-10 * np.ones_like(x)
+        else:
+            left = x < spec["x_split"]
+            r = (1.0 + 0.2 * np.sin(5.0 * x), 0.0, 1.0) if prof == 1 else spec["right"]
+            rho, vx, P = (np.where(left, spec["left"][n], r[n]) for n in range(3))
+        U = np.zeros((6,) + i.shape)
+        U[0], U[1] = rho, rho * vx
+        U[4] = P / (g - 1.0) + 0.5 * rho * (vx * vx)
+        U[5] = P / (g - 1.0)
+        return U
+
+    sim.set_initial_conditions(ic)
+    return sim

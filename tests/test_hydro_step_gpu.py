@@ -258,3 +258,27 @@ def test_passive_scalars_match_oracle(ctx, oracle, ndim, nscalars, nsteps):
     s1 = sum(float(sg.state_new_cc_.valid(b)[6].sum()) for b in range(sg.lev.nboxes))
     assert abs(s1 - s0) <= 1e-13 * abs(s0)
     assert float(sg.state_new_cc_.valid(0)[6].max()) > 0.9  # the step is still there
+
+
+@pytest.mark.parametrize("name", ["vacuum", "shuosher", "highmach", "leblanc"])
+def test_tabulated_1d_known_answers_on_the_gpu_path(ctx, oracle, name):
+    """The reference's four 1-D hydro tests with tabulated solutions (tests/hydro1d_cases.py), run to their stop times through the
+    C-ABI: the final state equals the oracle's in every bit (same initial state: sin() of the generators differs by an ulp between
+    libms), so the reference's tolerance is met by the GPU path exactly as by the oracle.  Exercises Dirichlet faces, dt control
+    (maxDt, initDt), strong rarefactions / shocks, the dual-energy switch and (HighMach) the retry path."""
+    import hydro1d_cases as H
+    from quokka_amd.simulation import hydro1d_problem
+    c = H.CASES[name]
+    so = H.oracle_sim(oracle, name)
+    sg = hydro1d_problem(ctx, c["spec"], c["nx"], c["hi"], c["max_timesteps"], c.get("mgs"))
+    for b in range(so.nboxes):
+        assert np.allclose(sg.state_new_cc_.fab_numpy(b), so.state(b, 0), rtol=1e-14, atol=1e-300)  # the generators agree to libm accuracy
+        sg.state_new_cc_.set_fab(b, so.state(b, 0))
+        sg.state_old_cc_.set_fab(b, so.state(b, 1))
+    assert so.evolve() and sg.evolve()
+    assert (so.istep, so.time) == (sg.istep, sg.tNew_)
+    Uo = H.gather_x(so)
+    Ug = np.concatenate([sg.state_new_cc_.valid(b).cpu().numpy()[:, 0, 0, :] for b in range(sg.lev.nboxes)], axis=-1)
+    assert np.array_equal(Uo, Ug), [float(np.abs(Uo[n] - Ug[n]).max()) for n in range(6)]
+    assert sg.counters["retries"] == so.counters()["retries"]
+    assert H.error_norm(H.reference_state(name), Ug) < c["tol"]

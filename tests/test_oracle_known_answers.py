@@ -151,3 +151,18 @@ def test_passive_scalar_advection_meets_the_reference_criteria(oracle):
     U = np.concatenate([s.valid(b) for b in range(s.nboxes)], axis=-1)
     assert abs(U[6].sum() - U0[6].sum()) / U0[6].sum() < 1.0e-14
     assert rel_rms_l1(U0, U) < 0.008
+
+
+@pytest.mark.parametrize("name", ["leblanc", "vacuum", "shuosher", "highmach"])
+def test_tabulated_1d_hydro_known_answers(oracle, name):
+    """HydroLeblanc (extern/ppm1d/leblanc.dat, 0.002), HydroVacuum (extern/Toro/e1rpex.out, 0.015), HydroShuOsher
+    (extern/ShuOsher_athena_3c_hllc_vl.txt, 0.01), HydroHighMach (extern/highmach_reference.txt, 0.26): the oracle run to the problem's
+    stop time meets the reference's tolerance on the relative rms L1 error norm against the tabulated solution."""
+    import hydro1d_cases as H
+    s = H.oracle_sim(oracle, name)
+    assert s.evolve()
+    c = H.CASES[name]
+    assert abs(s.time - c["spec"]["stop_time"]) < 1e-12 * c["spec"]["stop_time"] and s.istep < c["max_timesteps"]
+    err = H.error_norm(H.reference_state(name), H.gather_x(s))
+    print(name, "steps", s.istep, "error", err, "retries/fofc", s.counters())
+    assert err < c["tol"], err
