@@ -129,3 +129,16 @@ def test_streaming_front_matches_oracle_and_the_reference_criterion(ctx, oracle)
     x = (np.arange(1000) + 0.5) / 1000
     exact = np.where(x <= 0.2, 1.0, 0.0)
     assert np.abs(Ug[6, 0, 0] - exact).sum() / exact.sum() < 0.01
+
+
+def test_shell_accelerates_as_the_thin_shell_solution_predicts(ctx):
+    """The physics check the reference has for RadhydroShell (extern/dust_shell/analyze.py:50-57 plots it; no tolerance there): the
+    density-weighted mean speed of the shell against the thin-shell solution M(R) = sqrt(2) M0 sqrt(1 - 1/R).  At 128^3 the shell
+    follows it from below (finite thickness, tau ~ 7): 0.85 +- 0.02 of the analytic speed up to T = 0.125 (profiles/tools/
+    shell_velocity.py); checked here at T = 0.025 (230 steps x 10 radiation substeps)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "profiles", "tools"))
+    import shell_velocity
+    (T, mach, analytic), = shell_velocity.run(128, 1, t_end=0.025)
+    assert abs(T - 0.025) < 1e-12
+    assert 0.82 < mach / analytic < 0.92, (mach, analytic)
