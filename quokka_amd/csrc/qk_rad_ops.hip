@@ -8,7 +8,8 @@ using namespace qk;
 namespace
 {
 
-template <class F> __global__ void __launch_bounds__(256) k_rad_cells(const qk_box *boxes, int ndim, int ng, int facedir, F f)
+// MINW: waves per SIMD the register allocation must leave room for (__launch_bounds__'s second argument on AMD GPUs)
+template <int MINW, class F> __global__ void __launch_bounds__(256, MINW) k_rad_cells(const qk_box *boxes, int ndim, int ng, int facedir, F f)
 {
 	const int b = blockIdx.y;
 	const qk_box bx = boxes[b];
@@ -33,6 +34,10 @@ template <class F> __global__ void __launch_bounds__(256) k_rad_cells(const qk_b
 
 // Newton-iteration / failure counters: NSLOT slots of one 128-byte line each, folded into the caller's words by one block
 constexpr int NSLOT = 1024, SLOT_STRIDE = 32;
+
+#ifndef QK_RAD_SRC_WAVES
+#define QK_RAD_SRC_WAVES 2
+#endif
 
 __global__ void __launch_bounds__(NSLOT) k_counters_finish(int *slots, int *it, int *fail)
 {
@@ -89,14 +94,14 @@ auto counterSlots(qk_ctx *ctx) -> int *
 	return ctx->counter_slots;
 }
 
-template <class F> void launchRad(qk_level *lev, qk_stream s, int ng, int facedir, const char *name, F f)
+template <int MINW = 1, class F> void launchRad(qk_level *lev, qk_stream s, int ng, int facedir, const char *name, F f)
 {
 	if (lev->nboxes == 0) {
 		return; // a rank without boxes on this level
 	}
 	const CellLaunch L = cellLaunch(lev, ng, facedir);
 	ProfScope ps(lev->ctx, static_cast<hipStream_t>(s), name);
-	hipLaunchKernelGGL(k_rad_cells<F>, L.grid, L.block, 0, static_cast<hipStream_t>(s), lev->d_boxes, lev->ndim, ng, facedir, f);
+	hipLaunchKernelGGL((k_rad_cells<MINW, F>), L.grid, L.block, 0, static_cast<hipStream_t>(s), lev->d_boxes, lev->ndim, ng, facedir, f);
 }
 
 inline auto radStatus(qk_level *lev, const char *name) -> int
@@ -417,7 +422,7 @@ int qk_rad_AddSourceTermsSingleGroup(qk_level *lev, qk_stream s, const qk_rad_tr
 	const Eos eos(*t);
 	int *slots = counterSlots(lev->ctx);
 	QK_REQUIRE(lev->ctx, slots != nullptr, "AddSourceTermsSingleGroup: cannot allocate the counter slots");
-	launchRad(lev, s, 0, -1, "rad_AddSourceTerms", [=] __device__(int b, int i, int j, int k, bool valid) {
+	launchRad<QK_RAD_SRC_WAVES>(lev, s, 0, -1, "rad_AddSourceTerms", [=] __device__(int b, int i, int j, int k, bool valid) {
 		int ntot = 0, nmax = 0, nsolve = 0, fnewton = 0, fouter = 0;
 		if (valid) {
 			WA4 S(cons_t[b]);

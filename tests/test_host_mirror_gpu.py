@@ -200,3 +200,14 @@ def test_passive_scalar_executable_meets_the_reference_criteria(tmp_path):
     assert abs(meta[1] - 2.0) < 1e-12 and meta[5] <= 0.008, meta
     assert "Passive scalar is conserved" in out and "Zone-updates on level 1" in out
     assert data.size == 7 * 128
+
+
+def test_contact_wave_executable_error_is_exactly_zero(tmp_path):
+    """the reference's HydroContact ctest (src/problems/HydroContact/test_hydro_contact.cpp:213-216) through the C++ mirror: after
+    t = 2 the relative L1 error norm against the initial state must be 0.0 — not small: zero — and the exit status says so.  Two
+    passive scalars (all zero) ride along as in the reference; every component of the final state equals the initial one."""
+    data, meta, out = run("test_hydro_contact", [os.path.join(HOST, "decks", "contact_wave.in")], tmp_path)
+    assert meta[5] == 0.0 and abs(meta[1] - 2.0) < 1e-12, meta
+    U = data.reshape(8, 100)
+    assert np.array_equal(U[0], np.where((np.arange(100) + 0.5) / 100 < 0.5, 1.4, 1.0))
+    assert not U[1:4].any() and not U[6:].any() and np.array_equal(U[4], U[5])
