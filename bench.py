@@ -122,8 +122,11 @@ def main():
     n_cell = weak_scaled_cells(args.ncell, world)
     if args.workload == "amr":
         from quokka_amd.amr_simulation import sedov_amr_problem
-        # several GPUs: the SAME 256^3-base hierarchy (strong scaling); fine boxes live on the rank of their level-0 ancestor
-        amr = sedov_amr_problem(ctx, args.ncell, 2, max_grid_size=128, blocking_factor=32, rank=rank, nranks=world)
+        # several GPUs: the SAME 256^3-base hierarchy (strong scaling).  Fine boxes live on the rank of their level-0 ancestor, so the
+        # level-0 boxes are made smaller (64^3 instead of the deck's 128^3) and interleaved over the ranks: the refined shell around
+        # the blast then spreads over all of them (amr_simulation.py, level0_distribution)
+        mgs = 128 if world == 1 else 64
+        amr = sedov_amr_problem(ctx, args.ncell, 2, max_grid_size=mgs, blocking_factor=32, rank=rank, nranks=world)
         for _ in range(args.warmup):
             amr.step()
         def sync():
@@ -146,9 +149,9 @@ def main():
         print(json.dumps({"metric": "Mcell-updates/s on 3D Sedov AMR (sum over levels, subcycled)", "value": (amr.cellUpdates_ - u0) / elapsed / 1e6,
                           "unit": "Mcell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                           "scaling": "strong", "dtype": "f64", "data": "synthetic",
-                          "config": {"workload": f"3D Sedov blast {args.ncell}^3 base grid, max_level 2, blocking_factor 32, max_grid_size 128 "
+                          "config": {"workload": f"3D Sedov blast {args.ncell}^3 base grid, max_level 2, blocking_factor 32, max_grid_size {mgs} "
                                                  "(tests/blast_amr_maxlev2.in), subcycling + reflux, tile clustering instead of Berger-Rigoutsos",
-                                     "boxes_per_level": [L.lev.nboxes for L in amr.levels], "cells_per_level": [amr.CountCells(l) for l in range(amr.finest_level + 1)],
+                                     "boxes_per_level_rank0": [L.lev.nboxes for L in amr.levels], "boxes_per_level": [len(L.all_boxes) for L in amr.levels], "cells_per_level": [amr.CountCells(l) for l in range(amr.finest_level + 1)],
                                      "sim_time": amr.tNew_}}))
         return
     if args.workload == "shell":

@@ -204,6 +204,10 @@ class AmrSimulation:
         # local and only the reflux increments and the ordinary ghost exchange cross ranks); grids are therefore clustered inside each
         # parent box.  One rank clusters globally unless asked to mimic that (tests compare the two).
         self.cluster_within_parent = (nranks > 1) if cluster_within_parent is None else cluster_within_parent
+        # Load balance under that rule: no box migrates, so the level-0 map decides where refined work lands.  "interleaved" (rank =
+        # Morton index of the level-0 box mod nranks) puts every neighbourhood of level-0 boxes on all ranks; "bricks" keeps level 0
+        # compact (cheapest level-0 exchange) and leaves a localised refined region on one rank.
+        self.level0_distribution = "interleaved"
         self.max_level, self.max_grid_size, self.blocking_factor = max_level, max_grid_size, blocking_factor
         self.n_error_buf, self.regrid_int = n_error_buf, regrid_int
         self.do_reflux, self.do_subcycle = True, True
@@ -315,8 +319,9 @@ class AmrSimulation:
 
     def _make_level(self, lev: int, boxes: List[Box]) -> AmrLevelSim:
         if lev == 0:
-            from .simulation import distribute_boxes
-            owner = distribute_boxes(boxes, self.nranks, self.geom0.n_cell, [self.max_grid_size] * 3) if self.nranks > 1 else [0] * len(boxes)
+            from .simulation import distribute_boxes, distribute_boxes_interleaved
+            fn = distribute_boxes_interleaved if self.level0_distribution == "interleaved" else distribute_boxes
+            owner = fn(boxes, self.nranks, self.geom0.n_cell, [self.max_grid_size] * 3) if self.nranks > 1 else [0] * len(boxes)
         else:
             owner = self._owners_of(lev, boxes)
         L = AmrLevelSim(self, lev, boxes, owner)
@@ -488,7 +493,7 @@ def _copy_overlap(src: MultiFab, src_boxes, dst: MultiFab, dst_boxes):
 
 
 def sedov_amr_problem(ctx: Context, n: int, max_level: int, max_grid_size: int = 128, blocking_factor: int = 32, static_fine_boxes=None, rank: int = 0,
-                      nranks: int = 1, cluster_within_parent=None) -> AmrSimulation:
+                      nranks: int = 1, cluster_within_parent=None, level0_distribution: str = "interleaved") -> AmrSimulation:
     """reference src/problems/HydroBlast3D/test_hydro3d_blast.cpp + tests/blast_amr_maxlev2.in (BASELINE config 5)"""
     geom = Geometry(3, [n, n, n], [0.0, 0.0, 0.0], [1.2, 1.2, 1.2], [0, 0, 0])
     bcs = []
@@ -497,6 +502,7 @@ def sedov_amr_problem(ctx: Context, n: int, max_level: int, max_grid_size: int =
         bcs.append((lo, list(lo)))
     amr = AmrSimulation(ctx, geom, capi.traits(1.4, False, 3), bcs, max_level, max_grid_size, blocking_factor, rank=rank, nranks=nranks,
                         cluster_within_parent=cluster_within_parent)
+    amr.level0_distribution = level0_distribution
     amr.static_fine_boxes = static_fine_boxes
     E_blast = 0.851072 / 8.0
 

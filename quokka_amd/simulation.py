@@ -47,6 +47,22 @@ def chop_domain(n_cell: Sequence[int], max_grid_size: Sequence[int]) -> List[Tup
     return boxes
 
 
+def distribute_boxes_interleaved(boxes, nranks: int, n_cell, max_grid_size) -> List[int]:
+    """Box -> rank map that spreads every neighbourhood of the box lattice over all ranks: rank = Morton index of the box mod nranks
+    (for 8 ranks the parity of (ib, jb, kb)).  The opposite of a locality-preserving map — level 0 pays with remote ghost strips —
+    used for the level-0 boxes of an AMR hierarchy whose refined boxes stay on the rank of their level-0 ancestor: a refined region
+    then lands on every rank instead of on the one that owns that corner of the domain."""
+    nb = [(n_cell[d] + max_grid_size[d] - 1) // max_grid_size[d] for d in range(3)]
+
+    def morton(i, j, k):
+        m = 0
+        for bit in range(10):
+            m |= ((i >> bit) & 1) << (3 * bit) | ((j >> bit) & 1) << (3 * bit + 1) | ((k >> bit) & 1) << (3 * bit + 2)
+        return m
+
+    return [morton(ib, jb, kb) % nranks for kb in range(nb[2]) for jb in range(nb[1]) for ib in range(nb[0])]
+
+
 def distribute_boxes(boxes, nranks: int, n_cell, max_grid_size) -> List[int]:
     """Locality-preserving box -> rank map (the role of AMReX's SFC DistributionMapping): the box lattice is cut
     into `nranks` bricks by repeatedly halving its longest axis (2x2x2 bricks for 8 ranks)."""

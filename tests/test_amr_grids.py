@@ -45,3 +45,21 @@ def test_allowed_mask_and_tiles():
     tags[1, 1, 1] = True
     allowed = np.zeros_like(tags)
     assert boxes_from_tags(tags, 3, 0, 8, 16, allowed=allowed) == []
+
+
+def test_interleaved_level0_map_spreads_every_neighbourhood():
+    """level-0 box -> rank map of the multi-rank AMR driver: any 2x2x2 block of neighbouring level-0 boxes lies on min(8, nranks)
+    different ranks (refined boxes stay with their level-0 ancestor, so a localised refined region is shared by all ranks), and
+    the boxes are split evenly"""
+    from quokka_amd.simulation import chop_domain, distribute_boxes_interleaved
+    n_cell, mgs = [256, 256, 256], [64, 64, 64]
+    boxes = chop_domain(n_cell, mgs)
+    for nranks in (2, 4, 8):
+        owner = distribute_boxes_interleaved(boxes, nranks, n_cell, mgs)
+        assert sorted(set(owner)) == list(range(nranks)) and max(owner.count(r) for r in range(nranks)) == len(boxes) // nranks
+        at = {tuple(lo[d] // 64 for d in range(3)): o for (lo, hi), o in zip(boxes, owner)}
+        for k in range(3):
+            for j in range(3):
+                for i in range(3):
+                    block = {at[(i + a, j + b, k + c)] for a in (0, 1) for b in (0, 1) for c in (0, 1)}
+                    assert len(block) == min(8, nranks)

@@ -118,7 +118,7 @@ def test_ranks_sharing_one_gpu_reproduce_the_single_process_run(ctx, world, over
     assert np.array_equal(got, want), f"max abs diff {np.abs(got - want).max()}"
 
 
-def amr_worker(rank, world, port, N, nsteps, q):
+def amr_worker(rank, world, port, N, nsteps, q, distribution="interleaved"):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -126,7 +126,7 @@ def amr_worker(rank, world, port, N, nsteps, q):
         from quokka_amd.amr_simulation import sedov_amr_problem
         from quokka_amd.multifab import Context
         ctx = Context(0)
-        amr = sedov_amr_problem(ctx, N, 2, max_grid_size=16, blocking_factor=8, rank=rank, nranks=world)
+        amr = sedov_amr_problem(ctx, N, 2, max_grid_size=16, blocking_factor=8, rank=rank, nranks=world, level0_distribution=distribution)
         m0, e0 = amr.composite_sum(0), amr.composite_sum(4)
         for _ in range(nsteps):
             amr.step()
@@ -139,8 +139,8 @@ def amr_worker(rank, world, port, N, nsteps, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_amr_hierarchy_across_ranks_matches_one_rank(ctx, world):
+@pytest.mark.parametrize("world,distribution", [(2, "interleaved"), (4, "interleaved"), (4, "bricks")])
+def test_amr_hierarchy_across_ranks_matches_one_rank(ctx, world, distribution):
     """Sedov, max_level = 2, 32^3 base grid in 16^3 boxes (8 level-0 boxes over 2 / 4 ranks): fine boxes live on the rank of their level-0
     ancestor, reflux increments cross ranks through SumBoundary.  Same grids and time steps as the single-rank run with the same
     per-parent clustering; states agree to rounding (the reflux additions are reassociated), mass and energy are conserved."""
@@ -153,7 +153,7 @@ def test_amr_hierarchy_across_ranks_matches_one_rank(ctx, world):
     mpctx = mp.get_context("spawn")
     q = mpctx.Queue()
     port = free_port()
-    procs = [mpctx.Process(target=run_amr_worker, args=(r, world, port, N, nsteps, q)) for r in range(world)]
+    procs = [mpctx.Process(target=run_amr_worker, args=(r, world, port, N, nsteps, q, distribution)) for r in range(world)]
     for p in procs:
         p.start()
     results = collect(procs, q, world)
