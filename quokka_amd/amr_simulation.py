@@ -273,10 +273,14 @@ class AmrSimulation:
             flags = t.cpu().numpy()
         return flags != 0
 
-    def _new_grids(self, lev: int, finer_boxes: Optional[List[Box]]) -> List[Box]:
-        """boxes of level lev+1 from the tags on level lev (+ the cells under an already chosen level lev+2, buffered: proper nesting)"""
+    def _new_grids(self, lev: int, finer_boxes: Optional[List[Box]], base: Optional[int] = None) -> List[Box]:
+        """boxes of level lev+1 from the tags on level lev (+ the cells under an already chosen level lev+2, buffered: proper nesting).
+        `base`: the level whose regrid this is (AmrCore::regrid(base)): levels above it are being rebuilt together, finest first, so
+        the nesting domain of level lev+1 comes from the grids of `base` (which stay), not from the old level-lev grids — level lev
+        is rebuilt afterwards around the new level lev+1.  Otherwise the finest level could never leave the old extent of its parent."""
         if self.static_fine_boxes is not None:
             return self.static_fine_boxes[lev] if lev < len(self.static_fine_boxes) else []
+        base = lev if base is None else base
         L = self.levels[lev]
         tile = self.blocking_factor // 2  # tile edge in level-lev cells
         assert tile >= 4 and all(L.geom.n_cell[d] % tile == 0 for d in range(3)), "blocking_factor must be >= 8 and divide the domain"
@@ -287,16 +291,20 @@ class AmrSimulation:
                 a = [max((lo[d] // 4 - 2) // tile, 0) for d in range(3)]
                 b = [min((hi[d] // 4 + 2) // tile, (tx, ty, tz)[d] - 1) for d in range(3)]
                 t[a[2]:b[2] + 1, a[1]:b[1] + 1, a[0]:b[0] + 1] = True
-        if lev > 0:  # proper nesting: a tile and its 26 neighbours (>= 4 cells: ghost reach 2 + stencil 1) lie on level-lev cells or beyond the domain
+        if base > 0:  # proper nesting: a tile and its 26 neighbours (>= 4 cells: ghost reach 2 + stencil 1) lie on cells of `base` (refined) or beyond the domain
+            r = 2 ** (lev - base)
             cov = np.ones((tz + 2, ty + 2, tx + 2), dtype=bool)
             cov[1:-1, 1:-1, 1:-1] = False
-            for lo, hi in L.all_boxes:
-                cov[lo[2] // tile + 1:hi[2] // tile + 2, lo[1] // tile + 1:hi[1] // tile + 2, lo[0] // tile + 1:hi[0] // tile + 2] = True
+            for lo, hi in self.levels[base].all_boxes:
+                cov[lo[2] * r // tile + 1:(hi[2] * r + r - 1) // tile + 2, lo[1] * r // tile + 1:(hi[1] * r + r - 1) // tile + 2,
+                    lo[0] * r // tile + 1:(hi[0] * r + r - 1) // tile + 2] = True
             t &= ~dilate(~cov, 1, 3)[1:-1, 1:-1, 1:-1]
         if not self.cluster_within_parent:
             return boxes_from_tiles(t, 3, self.blocking_factor, self.max_grid_size, 2)
         boxes: List[Box] = []
-        for lo, hi in L.all_boxes:  # the parent boxes of ALL ranks, in the same order everywhere
+        s = 2 ** lev  # level-0 boxes in level-lev index space: every level is clustered inside its level-0 ancestors (one rank each)
+        for lo0, hi0 in self.levels[0].all_boxes:  # the level-0 boxes of ALL ranks, in the same order everywhere
+            lo, hi = [x * s for x in lo0], [x * s + s - 1 for x in hi0]
             a = [lo[d] // tile for d in range(3)]
             b = [hi[d] // tile for d in range(3)]
             sub = t[a[2]:b[2] + 1, a[1]:b[1] + 1, a[0]:b[0] + 1]
@@ -305,15 +313,16 @@ class AmrSimulation:
         return boxes
 
     def _owners_of(self, lev: int, boxes: List[Box]) -> List[int]:
-        """a box of level lev >= 1 lives on the rank of the level-(lev-1) box that contains it (hence of its level-0 ancestor)"""
+        """a box of level lev >= 1 lives on the rank of the level-0 box that contains it"""
         if self.nranks == 1:
             return [0] * len(boxes)
-        P = self.levels[lev - 1]
+        P = self.levels[0]
+        s = 2 ** lev
         out = []
         for lo, hi in boxes:
-            c = [lo[d] // 2 for d in range(3)]
+            c = [lo[d] // s for d in range(3)]
             owner = next((o for (plo, phi), o in zip(P.all_boxes, P.owner) if all(plo[d] <= c[d] <= phi[d] for d in range(3))), None)
-            assert owner is not None, "fine box without a parent box"
+            assert owner is not None, "fine box without a level-0 ancestor"
             out.append(owner)
         return out
 
@@ -364,7 +373,7 @@ class AmrSimulation:
         for lev in range(top - 1, base - 1, -1):  # finest first, so that coarser levels can enclose the finer ones
             if lev > self.finest_level:
                 continue
-            boxes = self._new_grids(lev, finer if lev + 2 <= self.max_level else None)
+            boxes = self._new_grids(lev, finer if lev + 2 <= self.max_level else None, base)
             new_boxes[lev + 1] = boxes
             finer = boxes if boxes else None
         for lev in range(base + 1, self.max_level + 1):
@@ -459,17 +468,22 @@ class AmrSimulation:
 
     # ------------------------------------------------------------------ diagnostics
     def composite_sum(self, comp: int) -> float:
-        """volume integral of a conserved component over the composite grid (cells under a finer level are not counted)"""
+        """volume integral of a conserved component over the composite grid (cells under a finer level are not counted): every level's
+        own sum minus, for each (local box, box of the next level) pair, the part of the local box that the finer box covers — the
+        boxes of a level are disjoint, so nothing is subtracted twice.  Device reductions, one number per box pair to the host."""
         total = 0.0
         for l, L in enumerate(self.levels):
             vol = L.geom.dx[0] * L.geom.dx[1] * L.geom.dx[2]
-            n = L.geom.n_cell
-            mask = np.ones((n[2], n[1], n[0]), dtype=bool)
-            if l < self.finest_level:
-                mask &= ~covered_mask([([x // 2 for x in lo], [x // 2 for x in hi]) for lo, hi in self.levels[l + 1].all_boxes], mask.shape)
+            finer = [([x // 2 for x in lo], [x // 2 for x in hi]) for lo, hi in self.levels[l + 1].all_boxes] if l < self.finest_level else []
             for b, (lo, hi) in enumerate(L.my_boxes):
-                v = L.state_new_cc_.valid(b)[comp].cpu().numpy()
-                total += float((v * mask[lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1]).sum()) * vol
+                v = L.state_new_cc_.valid(b)[comp]
+                s = float(v.sum(dtype=torch.float64))
+                for flo, fhi in finer:
+                    a = [max(lo[d], flo[d]) for d in range(3)]
+                    e = [min(hi[d], fhi[d]) for d in range(3)]
+                    if all(a[d] <= e[d] for d in range(3)):
+                        s -= float(v[a[2] - lo[2]:e[2] - lo[2] + 1, a[1] - lo[1]:e[1] - lo[1] + 1, a[0] - lo[0]:e[0] - lo[0] + 1].sum(dtype=torch.float64))
+                total += s * vol
         if self.nranks > 1:
             import torch.distributed as dist
             from . import comm

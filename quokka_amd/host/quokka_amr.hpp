@@ -303,9 +303,12 @@ template <typename problem_t> class AmrDriver
 		S.fillBoundaryConditions(state);
 	}
 
-	// ErrorEst -> buffered tags -> blocking-factor tiles -> boxes of level lev+1
-	auto newGrids(int lev, std::vector<amrex::Box> const *finerBoxes) -> std::vector<amrex::Box>
+	// ErrorEst -> buffered tags -> blocking-factor tiles -> boxes of level lev+1.  baseLev: the level whose regrid this is (AmrCore::regrid):
+	// the levels above it are rebuilt together, finest first, so the nesting domain of level lev+1 comes from the grids of baseLev
+	// (which stay) — level lev is rebuilt afterwards around the new level lev+1.  Default: lev itself (its grids stay).
+	auto newGrids(int lev, std::vector<amrex::Box> const *finerBoxes, int baseLev = -1) -> std::vector<amrex::Box>
 	{
+		int const base = (baseLev < 0) ? lev : baseLev;
 		for (int l = 0; l <= lev; ++l) {
 			fillGhosts(l, level(l).state_new_cc_[0], level(l).tNewLev_);
 		}
@@ -342,7 +345,8 @@ template <typename problem_t> class AmrDriver
 				}
 			}
 		}
-		if (lev > 0) { // a tile and its 26 neighbours lie on level-lev cells or beyond the domain
+		if (base > 0) { // a tile and its 26 neighbours lie on cells of level `base` (refined to this level) or beyond the domain
+			int const r = 1 << (lev - base);
 			std::vector<char> cov(static_cast<size_t>(nt[0] + 2) * (nt[1] + 2) * (nt[2] + 2), 1);
 			auto cv = [&](int i, int j, int k) -> char & {
 				return cov[static_cast<size_t>(i + 1) + static_cast<size_t>(nt[0] + 2) * ((j + 1) + static_cast<size_t>(nt[1] + 2) * (k + 1))];
@@ -354,10 +358,10 @@ template <typename problem_t> class AmrDriver
 					}
 				}
 			}
-			for (auto const &b : S.grids_) {
-				for (int k = b.lo[2] / tile; k <= b.hi[2] / tile; ++k) {
-					for (int j = b.lo[1] / tile; j <= b.hi[1] / tile; ++j) {
-						for (int i = b.lo[0] / tile; i <= b.hi[0] / tile; ++i) {
+			for (auto const &b : level(base).grids_) {
+				for (int k = b.lo[2] * r / tile; k <= (b.hi[2] * r + r - 1) / tile; ++k) {
+					for (int j = b.lo[1] * r / tile; j <= (b.hi[1] * r + r - 1) / tile; ++j) {
+						for (int i = b.lo[0] * r / tile; i <= (b.hi[0] * r + r - 1) / tile; ++i) {
 							cv(i, j, k) = 1;
 						}
 					}
@@ -420,7 +424,7 @@ template <typename problem_t> class AmrDriver
 			if (lev > finestLevel()) {
 				continue;
 			}
-			newBoxes[lev + 1] = newGrids(lev, (lev + 2 <= max_level) ? finerB : nullptr);
+			newBoxes[lev + 1] = newGrids(lev, (lev + 2 <= max_level) ? finerB : nullptr, baseLev);
 			finerB = newBoxes[lev + 1].empty() ? nullptr : &newBoxes[lev + 1];
 		}
 		for (int lev = baseLev + 1; lev <= max_level; ++lev) {
