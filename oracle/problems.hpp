@@ -675,7 +675,9 @@ inline void setupStreaming(HydroSim &sim)
 // setCustomBoundaryConditions (or a periodic box), a few driver settings.  The numbers come from the caller (tests cite the lines).
 struct Hydro1DSpec {
 	double gamma;
-	int profile;		// 0: two states split at x_split; 1: Shu-Osher (left state | 1 + 0.2 sin(5x), 0, 1); 2: high-Mach sinusoid
+	int profile;		// 0: two states split at x_split; 1: Shu-Osher (left state | 1 + 0.2 sin(5x), 0, 1); 2: high-Mach sinusoid;
+				// 3: two states given as (rho, m, E) with Eint = E - m^2 / (2 rho) (HydroSMS);
+				// 4: cell-averaged sound-wave eigenmode of amplitude 1e-6 on (rho0, P0) = (1, 1/gamma) (HydroWave)
 	double x_split;
 	double left[3], right[3]; // (rho, vx, P): initial states and the states beyond the lower / upper x face
 	int dirichlet;		// 1: constant states beyond both x faces (the problem's custom BC), 0: periodic
@@ -718,13 +720,25 @@ inline void setupHydro1D(HydroSim &sim, Hydro1DSpec const &p)
 		U(i, j, k, energy_index) = P / (gamma - 1.) + 0.5 * rho * (vx * vx);
 		U(i, j, k, internalEnergy_index) = P / (gamma - 1.);
 	};
+	auto putCons = [](Array4<double> const &U, int i, int j, int k, double rho, double m, double E) { // test_hydro_sms.cpp:66-78
+		double const Eint = E - 0.5 * (m * m) / rho;
+		for (int n = 0; n < U.ncomp; ++n) {
+			U(i, j, k, n) = 0.;
+		}
+		U(i, j, k, density_index) = rho;
+		U(i, j, k, x1Momentum_index) = m;
+		U(i, j, k, x2Momentum_index) = 0.;
+		U(i, j, k, x3Momentum_index) = 0.;
+		U(i, j, k, energy_index) = E;
+		U(i, j, k, internalEnergy_index) = Eint;
+	};
 	if (p.dirichlet != 0) {
 		Hydro1DSpec const q = p;
-		sim.customBC = [put, q](int i, int j, int k, Array4<double> const &consVar, Box const &dom, double /*time*/) {
+		sim.customBC = [put, putCons, q](int i, int j, int k, Array4<double> const &consVar, Box const &dom, double /*time*/) {
 			if (i < dom.lo[0]) {
-				put(consVar, i, j, k, q.left[0], q.left[1], q.left[2]);
+				(q.profile == 3) ? putCons(consVar, i, j, k, q.left[0], q.left[1], q.left[2]) : put(consVar, i, j, k, q.left[0], q.left[1], q.left[2]);
 			} else if (i >= dom.hi[0]) {
-				put(consVar, i, j, k, q.right[0], q.right[1], q.right[2]);
+				(q.profile == 3) ? putCons(consVar, i, j, k, q.right[0], q.right[1], q.right[2]) : put(consVar, i, j, k, q.right[0], q.right[1], q.right[2]);
 			}
 		};
 	}
@@ -734,6 +748,25 @@ inline void setupHydro1D(HydroSim &sim, Hydro1DSpec const &p)
 	forEachValidCell(sim, [=](Array4<double> const &state_cc, int i, int j, int k) {
 		double const x = lo0 + (i + 0.5) * dx0;
 		double rho = NAN, vx = NAN, P = NAN;
+		if (p.profile == 4) { // test_hydro_wave.cpp:38-71
+			double const rho0 = 1.0, P0 = 1.0 / gamma, v0 = 0., A = 1.0e-6;
+			double const x_L = lo0 + (i + 0.0) * dx0;
+			double const x_R = lo0 + (i + 1.0) * dx0;
+			double const R[3] = {1.0, -1.0, 1.5}; // right eigenvector of the sound wave
+			double const U_0[3] = {rho0, rho0 * v0, P0 / (gamma - 1.0) + 0.5 * rho0 * std::pow(v0, 2)};
+			double const shape = std::cos(2.0 * M_PI * x_L) - std::cos(2.0 * M_PI * x_R);
+			double U[3];
+			for (int n = 0; n < 3; ++n) {
+				U[n] = U_0[n] + (A * R[n] / (2.0 * M_PI * dx0)) * shape;
+			}
+			putCons(state_cc, i, j, k, U[0], U[1], U[2]);
+			return;
+		}
+		if (p.profile == 3) {
+			double const *st = (x < p.x_split) ? p.left : p.right;
+			putCons(state_cc, i, j, k, st[0], st[1], st[2]);
+			return;
+		}
 		if (p.profile == 2) { // test_hydro_highmach.cpp:57-62
 			double const norm = 1. / (2.0 * M_PI);
 			vx = norm * std::sin(2.0 * M_PI * x);

@@ -723,6 +723,8 @@ def hydro1d_problem(ctx: Context, spec: dict, nx: int, hi: float, max_timesteps:
     bcs = [([capi.BC_INT_DIR] * 3, [capi.BC_INT_DIR] * 3) for _ in range(6)]
 
     def cons(rho, vx, P):
+        if spec.get("profile", 0) == 3:  # the state is given as (rho, m, E) (HydroSMS)
+            return [rho, vx, 0.0, 0.0, P, P - 0.5 * (vx * vx) / rho]
         return [rho, rho * vx, 0.0, 0.0, P / (g - 1.0) + 0.5 * rho * (vx * vx), P / (g - 1.0)]
 
     if spec.get("dirichlet", 1):
@@ -740,6 +742,21 @@ def hydro1d_problem(ctx: Context, spec: dict, nx: int, hi: float, max_timesteps:
     def ic(i, j, k):
         x = (i + 0.5) * dx
         prof = spec.get("profile", 0)
+        if prof == 4:  # HydroWave: cell-averaged sound-wave eigenmode
+            xL, xR = i * dx, (i + 1.0) * dx
+            shape = np.cos(2.0 * np.pi * xL) - np.cos(2.0 * np.pi * xR)
+            U0 = (1.0, 0.0, (1.0 / g) / (g - 1.0))
+            rho, m, E = (U0[n] + (1.0e-6 * r / (2.0 * np.pi * dx)) * shape for n, r in enumerate((1.0, -1.0, 1.5)))
+            U = np.zeros((6,) + i.shape)
+            U[0], U[1], U[4], U[5] = rho, m, E, E - 0.5 * (m * m) / rho
+            return U
+        if prof == 3:
+            left = x < spec["x_split"]
+            U = np.zeros((6,) + i.shape)
+            for n, (a, b) in zip((0, 1, 4, 5), zip(cons(*spec["left"])[0:1] + cons(*spec["left"])[1:2] + cons(*spec["left"])[4:6],
+                                                   cons(*spec["right"])[0:1] + cons(*spec["right"])[1:2] + cons(*spec["right"])[4:6])):
+                U[n] = np.where(left, a, b)
+            return U
         if prof == 2:
             rho, vx, P = np.ones_like(x), (1.0 / (2.0 * np.pi)) * np.sin(2.0 * np.pi * x), 1.0e-10 * np.ones_like(x)
         else:

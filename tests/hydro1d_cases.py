@@ -25,13 +25,37 @@ CASES = {
     # max_grid_size 64); extern/highmach_reference.txt columns (x, density, velocity, pressure), one header line
     "highmach": dict(spec=dict(gamma=5.0 / 3.0, profile=2, dirichlet=0, cfl=0.4, stop_time=3.0), max_timesteps=100000, nx=128, hi=1.0, mgs=64,
                      table=("highmach_reference.txt", 1, (0, 1, 2, 3)), tol=0.26),
+    # src/problems/HydroSMS/test_hydro_sms.cpp:17, :57-66 (states given as rho, m, E), :96-105, :237-240, :294; tests/SlowMovingShock.in
+    # (100 cells on [0, 1]); exact solution :136-151: the shock at 0.5 + 0.1096 t between (3.86, -0.81, 10.3334) and (1, -3.44, 1)
+    "sms": dict(spec=dict(gamma=1.4, profile=3, x_split=0.5, left=[3.86, -3.1266, 27.0913], right=[1.0, -3.44, 8.4168], dirichlet=1, cfl=0.2,
+                          stop_time=1.0), max_timesteps=20000, nx=100, hi=1.0, exact=dict(vshock=0.1096, left=[3.86, -0.81, 10.3334], right=[1.0, -3.44, 1.0]),
+                tol=0.005),
+    # src/problems/HydroWave/test_hydro_wave.cpp:16 (gamma), :38-71 (eigenmode), :99-101 (driver), :124-141 (error: rms over the components
+    # except the auxiliary internal energy of the mean |U(t=1) - U(0)|), err_tol 1e-8 for Nx = 100; tests/hydro_wave.in (100 cells, periodic)
+    "wave": dict(spec=dict(gamma=5.0 / 3.0, profile=4, dirichlet=0, cfl=0.1, stop_time=1.0), max_timesteps=20000, nx=100, hi=1.0, tol=1.0e-8),
 }
+
+
+def wave_error(U0, U1):
+    """test_hydro_wave.cpp:124-141"""
+    return float(np.sqrt(sum(np.abs(U1[n] - U0[n]).mean() ** 2 for n in range(6) if n != 5)))
 
 
 def reference_state(name, nx=None):
     """computeReferenceSolution of the four problems: the table interpolated to the cell centres, as conserved variables"""
     c = CASES[name]
     nx = nx or c["nx"]
+    if "exact" in c:  # a moving discontinuity between two constant states
+        e = c["exact"]
+        xs = (np.arange(nx) + 0.5) * (c["hi"] / nx)
+        left = xs < (c["spec"]["x_split"] + e["vshock"] * c["spec"]["stop_time"])
+        rho, v, P = (np.where(left, e["left"][n], e["right"][n]) for n in range(3))
+        g = c["spec"]["gamma"]
+        U = np.zeros((6, nx))
+        U[0], U[1] = rho, rho * v
+        U[4] = P / (g - 1.0) + 0.5 * rho * (v * v)
+        U[5] = P / (g - 1.0)
+        return U
     fname, skip, (cx, crho, cv, cP) = c["table"]
     tab = np.loadtxt(os.path.join(GOLDEN, fname), skiprows=skip, comments=None if skip else "#")
     order = np.argsort(tab[:, cx], kind="stable")

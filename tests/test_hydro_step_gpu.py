@@ -260,7 +260,7 @@ def test_passive_scalars_match_oracle(ctx, oracle, ndim, nscalars, nsteps):
     assert float(sg.state_new_cc_.valid(0)[6].max()) > 0.9  # the step is still there
 
 
-@pytest.mark.parametrize("name", ["vacuum", "shuosher", "highmach", "leblanc"])
+@pytest.mark.parametrize("name", ["vacuum", "shuosher", "highmach", "sms", "leblanc"])
 def test_tabulated_1d_known_answers_on_the_gpu_path(ctx, oracle, name):
     """The reference's four 1-D hydro tests with tabulated solutions (tests/hydro1d_cases.py), run to their stop times through the
     C-ABI: the final state equals the oracle's in every bit (same initial state: sin() of the generators differs by an ulp between
@@ -282,3 +282,21 @@ def test_tabulated_1d_known_answers_on_the_gpu_path(ctx, oracle, name):
     assert np.array_equal(Uo, Ug), [float(np.abs(Uo[n] - Ug[n]).max()) for n in range(6)]
     assert sg.counters["retries"] == so.counters()["retries"]
     assert H.error_norm(H.reference_state(name), Ug) < c["tol"]
+
+
+def test_linear_sound_wave_on_the_gpu_path(ctx, oracle):
+    """HydroWave through the C-ABI: bit for bit with the oracle after one period (2998 steps at CFL 0.1), hence the same error
+    (rms of mean |U(1) - U(0)| < 1e-8, the reference's criterion for 100 cells)"""
+    import hydro1d_cases as H
+    from quokka_amd.simulation import hydro1d_problem
+    c = H.CASES["wave"]
+    so = H.oracle_sim(oracle, "wave")
+    sg = hydro1d_problem(ctx, c["spec"], c["nx"], c["hi"], c["max_timesteps"])
+    assert np.allclose(sg.state_new_cc_.fab_numpy(0), so.state(0, 0), rtol=1e-13, atol=1e-300)
+    sg.state_new_cc_.set_fab(0, so.state(0, 0))
+    sg.state_old_cc_.set_fab(0, so.state(0, 1))
+    U0 = H.gather_x(so)
+    assert so.evolve() and sg.evolve()
+    Ug = sg.state_new_cc_.valid(0).cpu().numpy()[:, 0, 0, :]
+    assert np.array_equal(H.gather_x(so), Ug) and so.istep == sg.istep
+    assert H.wave_error(U0, Ug) < c["tol"]

@@ -153,7 +153,7 @@ def test_passive_scalar_advection_meets_the_reference_criteria(oracle):
     assert rel_rms_l1(U0, U) < 0.008
 
 
-@pytest.mark.parametrize("name", ["leblanc", "vacuum", "shuosher", "highmach"])
+@pytest.mark.parametrize("name", ["leblanc", "vacuum", "shuosher", "highmach", "sms"])
 def test_tabulated_1d_hydro_known_answers(oracle, name):
     """HydroLeblanc (extern/ppm1d/leblanc.dat, 0.002), HydroVacuum (extern/Toro/e1rpex.out, 0.015), HydroShuOsher
     (extern/ShuOsher_athena_3c_hllc_vl.txt, 0.01), HydroHighMach (extern/highmach_reference.txt, 0.26): the oracle run to the problem's
@@ -166,3 +166,15 @@ def test_tabulated_1d_hydro_known_answers(oracle, name):
     err = H.error_norm(H.reference_state(name), H.gather_x(s))
     print(name, "steps", s.istep, "error", err, "retries/fofc", s.counters())
     assert err < c["tol"], err
+
+
+def test_linear_sound_wave_returns_to_its_initial_state(oracle):
+    """HydroWave (src/problems/HydroWave/test_hydro_wave.cpp): a sound-wave eigenmode of amplitude 1e-6 after one period on 100 cells:
+    rms of the component-wise mean |U(1) - U(0)| below 1e-8"""
+    import hydro1d_cases as H
+    s = H.oracle_sim(oracle, "wave")
+    U0 = H.gather_x(s)
+    assert s.evolve() and abs(s.time - 1.0) < 1e-13
+    err = H.wave_error(U0, H.gather_x(s))
+    assert err < H.CASES["wave"]["tol"], err
+    assert err > 1e-12
