@@ -77,6 +77,11 @@ typedef struct qk_hydro_traits {
 			* 6 + nscalars components); the fused stage refuses nscalars > 0 (QK_ERR_UNSUPPORTED) */
 	int nmscalars; /* mass scalars: must be 0 */
 	int ndim;      /* 1 or 3 */
+	/* the quokka::EOS<P> temperature hooks a problem may specialise (ComputeTgasFromEint / ComputeEintFromTgas / ComputeEintTempDerivative,
+	 * reference src/hydro/EOS.hpp:74-244), closed set used by the radiation source terms:
+	 * 0: the gamma-law forms; 1: E_int = (eos_alpha / 4) T^4 (Su & Olson 1997; RadMatterCoupling, RadSuOlson, RadMarshak) */
+	int eos_temperature_model;
+	double eos_alpha;
 } qk_hydro_traits;
 
 enum { QK_DIR_X1 = 0, QK_DIR_X2 = 1, QK_DIR_X3 = 2 };

@@ -44,6 +44,11 @@ constexpr int kEosVariant = ORACLE_EOS_VARIANT;
 
 // runtime stand-in for quokka::EOS_Traits<problem_t> (reference EOS.hpp:32-37)
 struct EOSTraits {
+	// temperature hooks a problem may specialise (EOS.hpp:74-244): 0 gamma law; 1 E_int = (alpha / 4) T^4, the Su-Olson material of
+	// RadMatterCoupling / RadSuOlson / RadMarshak (e.g. src/problems/RadMatterCoupling/test_radiation_matter_coupling.cpp:72-103).
+	// The fourth root is taken as two square roots (the reference calls std::pow(x, 1. / 4.)): identical in the GPU build.
+	int temperature_model = 0;
+	double alpha = 0.0;
 	double gamma = 5. / 3.;
 	double cs_isothermal = std::numeric_limits<double>::quiet_NaN();
 	double mean_molecular_weight = std::numeric_limits<double>::quiet_NaN();
@@ -119,6 +124,9 @@ struct EOS {
 	// EOS.hpp:74-114
 	[[nodiscard]] auto ComputeTgasFromEint(double rho, double Eint) const -> double
 	{
+		if (tr.temperature_model == 1) {
+			return std::sqrt(std::sqrt(4.0 * Eint / tr.alpha));
+		}
 		double Tgas = NAN;
 		if (tr.gamma != 1.0) {
 			eos_state estate;
@@ -134,6 +142,9 @@ struct EOS {
 	// EOS.hpp:116-159
 	[[nodiscard]] auto ComputeEintFromTgas(double rho, double Tgas) const -> double
 	{
+		if (tr.temperature_model == 1) {
+			return (tr.alpha / 4.0) * ((Tgas * Tgas) * (Tgas * Tgas));
+		}
 		double Eint = NAN;
 		if (tr.gamma != 1.0) {
 			eos_state estate;
@@ -164,6 +175,9 @@ struct EOS {
 	// EOS.hpp:202-244
 	[[nodiscard]] auto ComputeEintTempDerivative(double rho, double Tgas) const -> double
 	{
+		if (tr.temperature_model == 1) {
+			return tr.alpha * ((Tgas * Tgas) * Tgas);
+		}
 		double dEint_dT = NAN;
 		if (tr.gamma != 1.0) {
 			eos_state estate;

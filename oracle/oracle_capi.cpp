@@ -144,6 +144,12 @@ void *orc_sim_create(orc_sim_config const *c)
 	} else if (c->problem == 3) {
 		setupShell(*sim, c->table_len, c->table_r, c->table_Erad, c->table_Frad);
 		sim->rad.rt.pow_mode = c->rad_pow_mode;
+	} else if (c->problem == 8) {
+		setupMatterCoupling(*sim);
+		sim->rad.rt.pow_mode = c->rad_pow_mode;
+	} else if (c->problem == 9) {
+		setupSuOlson(*sim);
+		sim->rad.rt.pow_mode = c->rad_pow_mode;
 	} else if (c->problem == 7) {
 		Hydro1DSpec p{};
 		p.gamma = c->h1d[0];
@@ -243,6 +249,32 @@ int orc_sim_step(void *p)
 	bool const ok = s->step();
 	return ok ? 1 : 0;
 }
+// nsteps coarse steps, recording after each one the time and all components of the valid cell (i, j, k) of box b
+// (what computeAfterTimestep of RadMatterCoupling collects); returns the number of steps taken
+long orc_sim_run_record(void *p, long nsteps, int b, int i, int j, int k, double *out_t, double *out_u)
+{
+	auto *s = static_cast<HydroSim *>(p);
+	long n = 0;
+	double cur_time = s->tNew_;
+	for (; n < nsteps && cur_time < s->stopTime_; ++n) {
+		if (!s->step()) {
+			break;
+		}
+		cur_time += s->dt_;
+		s->tNew_ = cur_time;
+		auto const a = s->state_new_cc_.const_array(b);
+		out_t[n] = s->tNew_;
+		for (int c = 0; c < s->ncomp_cc; ++c) {
+			out_u[n * s->ncomp_cc + c] = a(i, j, k, c);
+		}
+		if (cur_time >= s->stopTime_ - 1.e-6 * s->dt_) {
+			++n;
+			break;
+		}
+	}
+	return n;
+}
+
 // one hydro advance with a caller-supplied dt (no dt control): old <- new, advance
 int orc_sim_advance_fixed_dt(void *p, double dt)
 {

@@ -790,6 +790,157 @@ inline void setupHydro1D(HydroSim &sim, Hydro1DSpec const &p)
 	sim.finishInitialConditions();
 }
 
+
+// ---------------------------------------------------------------- matter-radiation equilibration (src/problems/RadMatterCoupling/test_radiation_matter_coupling.cpp)
+struct CouplingConstants { // :24-27, :113-115
+	static constexpr double eps_SuOlson = 1.0;
+	static constexpr double a_rad = 7.5646e-15;
+	static constexpr double alpha_SuOlson = 4.0 * a_rad / eps_SuOlson;
+	static constexpr double Erad0 = 1.0e12, Egas0 = 1.0e2, rho0 = 1.0e-7;
+};
+
+inline void setupMatterCoupling(HydroSim &sim)
+{
+	using S = CouplingConstants;
+	sim.hydro.tr.eos.tr.gamma = 5. / 3.; // :35-39
+	sim.hydro.tr.eos.tr.mean_molecular_weight = C::m_u;
+	sim.hydro.tr.eos.tr.boltzmann_constant = C::k_B;
+	sim.hydro.tr.eos.tr.temperature_model = 1; // :72-103: T = (4 E / alpha)^(1/4), E = alpha / 4 T^4, dE/dT = alpha T^3
+	sim.hydro.tr.eos.tr.alpha = S::alpha_SuOlson;
+	sim.hydro.tr.reconstruct_eint = true;
+	sim.hydro.tr.nscalars = 0;
+	sim.ncomp_cc = kNumHydroVars + kNumRadVars;
+	sim.is_radiation_enabled = true; // :49-59
+	sim.is_hydro_enabled = false;
+	sim.rad.rt.c_light = C::c_light; // :41-47
+	sim.rad.rt.c_hat = C::c_light;
+	sim.rad.rt.radiation_constant = C::a_rad;
+	sim.rad.rt.Erad_floor = 0.;
+	sim.rad.rt.beta_order = 1;
+	sim.rad.eos = sim.hydro.tr.eos;
+	sim.rad.ndim = sim.geom.ndim;
+	sim.rad.nstartHyperbolic_ = kNumHydroVars;
+	sim.rad.ComputePlanckOpacity = [](double, double) { return 1.0; }; // :61-69
+	sim.rad.ComputeFluxMeanOpacity = [](double, double) { return 1.0; };
+	sim.rad.ComputeEnergyMeanOpacity = [](double, double) { return 1.0; };
+	// problem_main :147-172
+	sim.BCs_cc.assign(sim.ncomp_cc, BCRec{});
+	for (int n = 0; n < sim.ncomp_cc; ++n) {
+		for (int d = 0; d < sim.geom.ndim; ++d) {
+			sim.BCs_cc[n].lo[d] = foextrap;
+			sim.BCs_cc[n].hi[d] = foextrap;
+		}
+	}
+	sim.cflNumber_ = 1.0;
+	sim.radiationCflNumber_ = 1.0;
+	sim.constantDt_ = 1.0e-8;
+	sim.maxTimesteps_ = 1000000;
+	sim.stopTime_ = 1.0e-2;
+	sim.define();
+	forEachValidCell(sim, [&](Array4<double> const &state_cc, int i, int j, int k) { // :117-137
+		state_cc(i, j, k, kNumHydroVars + 0) = S::Erad0;
+		state_cc(i, j, k, kNumHydroVars + 1) = 0;
+		state_cc(i, j, k, kNumHydroVars + 2) = 0;
+		state_cc(i, j, k, kNumHydroVars + 3) = 0;
+		state_cc(i, j, k, energy_index) = S::Egas0;
+		state_cc(i, j, k, internalEnergy_index) = S::Egas0;
+		state_cc(i, j, k, density_index) = S::rho0;
+		state_cc(i, j, k, x1Momentum_index) = 0.;
+		state_cc(i, j, k, x2Momentum_index) = 0.;
+		state_cc(i, j, k, x3Momentum_index) = 0.;
+	});
+	sim.finishInitialConditions();
+}
+
+// ---------------------------------------------------------------- Su & Olson (1997) non-equilibrium source problem (src/problems/RadSuOlson/test_radiation_SuOlson.cpp)
+struct SuOlsonConstants { // :21-33
+	static constexpr double eps_SuOlson = 1.0, kappa = 1.0, rho0 = 1.0, T_hohlraum = 1.0, x0 = 0.5, t0 = 10.0;
+	static constexpr double a_rad = 1.0, c = 1.0;
+	static constexpr double alpha_SuOlson = 4.0 * a_rad / eps_SuOlson;
+	static constexpr double Q = (1.0 / (2.0 * x0));
+	static constexpr double S = Q * (a_rad * (T_hohlraum * T_hohlraum * T_hohlraum * T_hohlraum));
+};
+
+inline void setupSuOlson(HydroSim &sim)
+{
+	using S = SuOlsonConstants;
+	sim.hydro.tr.eos.tr.gamma = 5. / 3.; // :46-50
+	sim.hydro.tr.eos.tr.mean_molecular_weight = 1.0;
+	sim.hydro.tr.eos.tr.boltzmann_constant = 1.0;
+	sim.hydro.tr.eos.tr.temperature_model = 1; // :73-97
+	sim.hydro.tr.eos.tr.alpha = S::alpha_SuOlson;
+	sim.hydro.tr.reconstruct_eint = true;
+	sim.hydro.tr.nscalars = 0;
+	sim.ncomp_cc = kNumHydroVars + kNumRadVars;
+	sim.is_radiation_enabled = true; // :52-60
+	sim.is_hydro_enabled = false;
+	sim.rad.rt.c_light = S::c; // :35-44
+	sim.rad.rt.c_hat = S::c;
+	sim.rad.rt.radiation_constant = S::a_rad;
+	sim.rad.rt.Erad_floor = 0.;
+	sim.rad.rt.beta_order = 0;
+	sim.rad.eos = sim.hydro.tr.eos;
+	sim.rad.ndim = sim.geom.ndim;
+	sim.rad.nstartHyperbolic_ = kNumHydroVars;
+	sim.rad.ComputePlanckOpacity = [](double rho, double) { return S::kappa / rho; }; // :62-70
+	sim.rad.ComputeFluxMeanOpacity = [](double rho, double) { return S::kappa / rho; };
+	sim.rad.ComputeEnergyMeanOpacity = [](double rho, double) { return S::kappa / rho; };
+	// problem_main :172-206: reflecting walls
+	sim.BCs_cc.assign(sim.ncomp_cc, BCRec{});
+	for (int n = 0; n < sim.ncomp_cc; ++n) {
+		for (int d = 0; d < sim.geom.ndim; ++d) {
+			bool const normal = (n == kNumHydroVars + 1 + d) || (n == x1Momentum_index + d);
+			sim.BCs_cc[n].lo[d] = normal ? reflect_odd : reflect_even;
+			sim.BCs_cc[n].hi[d] = normal ? reflect_odd : reflect_even;
+		}
+	}
+	sim.cflNumber_ = 0.4;
+	sim.radiationCflNumber_ = 0.4;
+	sim.stopTime_ = 10.0;
+	sim.maxTimesteps_ = 12000;
+	sim.maxDt_ = 1e-2;
+	sim.initDt_ = 1e-9;
+	// :115-145 the source is on inside x < x0 until t0
+	sim.SetRadEnergySource = [](Array4<double> const &radEnergySource, Box const &indexRange, Geometry const &g, double time) {
+		for (int k = indexRange.lo[2]; k <= indexRange.hi[2]; ++k) {
+			for (int j = indexRange.lo[1]; j <= indexRange.hi[1]; ++j) {
+				for (int i = indexRange.lo[0]; i <= indexRange.hi[0]; ++i) {
+					double const xl = (i + 0.) * g.dx[0];
+					double const xr = (i + 1.) * g.dx[0];
+					double dx_frac = 0.0;
+					if ((xl < S::x0) && (xr <= S::x0)) {
+						dx_frac = 1.0;
+					} else if ((xl < S::x0) && (xr > S::x0)) {
+						dx_frac = (S::x0 - xl) / (xr - xl);
+					}
+					double src = 0.;
+					if (time < S::t0) {
+						src = S::S * dx_frac;
+					}
+					radEnergySource(i, j, k) = src;
+				}
+			}
+		}
+	};
+	sim.define();
+	EOS const eos = sim.hydro.tr.eos;
+	double const initial_Egas = 1e-10 * eos.ComputeEintFromTgas(S::rho0, S::T_hohlraum); // :99-100
+	double const initial_Erad = 1e-10 * (S::a_rad * (S::T_hohlraum * S::T_hohlraum * S::T_hohlraum * S::T_hohlraum));
+	forEachValidCell(sim, [&](Array4<double> const &state_cc, int i, int j, int k) { // :147-169
+		state_cc(i, j, k, kNumHydroVars + 0) = initial_Erad;
+		state_cc(i, j, k, kNumHydroVars + 1) = 0;
+		state_cc(i, j, k, kNumHydroVars + 2) = 0;
+		state_cc(i, j, k, kNumHydroVars + 3) = 0;
+		state_cc(i, j, k, energy_index) = initial_Egas;
+		state_cc(i, j, k, density_index) = S::rho0;
+		state_cc(i, j, k, internalEnergy_index) = initial_Egas;
+		state_cc(i, j, k, x1Momentum_index) = 0.;
+		state_cc(i, j, k, x2Momentum_index) = 0.;
+		state_cc(i, j, k, x3Momentum_index) = 0.;
+	});
+	sim.finishInitialConditions();
+}
+
 } // namespace oracle
 
 #endif // ORACLE_PROBLEMS_HPP_

@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 K_B = 1.380649e-16
 M_U = 1.6605390666e-24
 
-SOD, CONTACT, SEDOV, SHELL, RADSHOCK, STREAMING, SCALARS, HYDRO1D = 0, 1, 2, 3, 4, 5, 6, 7
+SOD, CONTACT, SEDOV, SHELL, RADSHOCK, STREAMING, SCALARS, HYDRO1D, COUPLING, SUOLSON = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 
 
 def build(force: bool = False) -> None:
@@ -290,6 +290,16 @@ class OracleSim:
 
     def evolve(self) -> bool:
         return bool(self.o.lib.orc_sim_evolve(self.h))
+
+    def run_record(self, nsteps: int, b=0, cell=(0, 0, 0)):
+        """nsteps steps; returns (times, states[nsteps, ncomp]) of one valid cell after every step"""
+        t = np.zeros(nsteps)
+        u = np.zeros((nsteps, self.ncomp))
+        f = self.o.lib.orc_sim_run_record
+        f.restype = C.c_long
+        f.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        n = f(self.h, nsteps, int(b), int(cell[0]), int(cell[1]), int(cell[2]), _dp(t), _dp(u))
+        return t[:n], u[:n]
 
     def rad_counters(self):
         out = (C.c_long * 8)()

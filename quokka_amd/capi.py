@@ -34,7 +34,7 @@ class Box(C.Structure):
 class HydroTraits(C.Structure):
     _fields_ = [("gamma", C.c_double), ("cs_isothermal", C.c_double), ("mean_molecular_weight", C.c_double),
                 ("boltzmann_constant", C.c_double), ("reconstruct_eint", C.c_int), ("nscalars", C.c_int),
-                ("nmscalars", C.c_int), ("ndim", C.c_int)]
+                ("nmscalars", C.c_int), ("ndim", C.c_int), ("eos_temperature_model", C.c_int), ("eos_alpha", C.c_double)]
 
 
 class Geometry(C.Structure):
@@ -66,8 +66,9 @@ class StageArgs(C.Structure):
 
 
 def traits(gamma=1.4, reconstruct_eint=True, ndim=3, mean_molecular_weight=M_U, boltzmann_constant=K_B,
-           cs_isothermal=float("nan"), nscalars=0, nmscalars=0) -> HydroTraits:
-    return HydroTraits(gamma, cs_isothermal, mean_molecular_weight, boltzmann_constant, int(reconstruct_eint), nscalars, nmscalars, ndim)
+           cs_isothermal=float("nan"), nscalars=0, nmscalars=0, eos_temperature_model=0, eos_alpha=0.0) -> HydroTraits:
+    return HydroTraits(gamma, cs_isothermal, mean_molecular_weight, boltzmann_constant, int(reconstruct_eint), nscalars, nmscalars, ndim,
+                       int(eos_temperature_model), float(eos_alpha))
 
 
 class QkError(RuntimeError):

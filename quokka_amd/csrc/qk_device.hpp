@@ -58,12 +58,14 @@ QK_DEV auto unit(int axis, int comp) -> int { return axis == comp ? 1 : 0; }
 struct Eos {
 	double gamma, gm1, cs_iso, mu, kB_ratio_num, kB_user; // mu = mean_molecular_weight / m_u
 	bool isothermal;
+	int tmodel;   // temperature hooks: 0 gamma-law, 1 E_int = (alpha / 4) T^4
+	double alpha;
 	static constexpr double k_B = 1.380649e-16;
 	static constexpr double m_u = 1.6605390666e-24;
 
 	__host__ __device__ explicit Eos(qk_hydro_traits const &t)
 	    : gamma(t.gamma), gm1(t.gamma - 1.0), cs_iso(t.cs_isothermal), mu(t.mean_molecular_weight / m_u), kB_ratio_num(k_B),
-	      kB_user(t.boltzmann_constant), isothermal(t.gamma == 1.0)
+	      kB_user(t.boltzmann_constant), isothermal(t.gamma == 1.0), tmodel(t.eos_temperature_model), alpha(t.eos_alpha)
 	{
 	}
 	// EOS.hpp:304-348 : e = Eint/rho (0 if rho == 0) ; p = (gamma-1) rho e
@@ -79,6 +81,9 @@ struct Eos {
 	// EOS.hpp:74-114
 	QK_DEV auto tgasFromEint(double rho, double Eint) const -> double
 	{
+		if (tmodel == 1) { // (4 E / alpha)^(1/4) as two correctly rounded square roots (the reference calls std::pow(x, 1./4.))
+			return sqrt(sqrt(4.0 * Eint / alpha));
+		}
 		const double e = Eint / rho;
 		const double T = e * mu * m_u * gm1 / k_B;
 		return T * k_B / kB_user;
@@ -86,6 +91,9 @@ struct Eos {
 	// EOS.hpp:116-159
 	QK_DEV auto eintFromTgas(double rho, double T) const -> double
 	{
+		if (tmodel == 1) {
+			return (alpha / 4.0) * ((T * T) * (T * T));
+		}
 		const double p = rho * T * k_B / (mu * m_u);
 		const double e = p / (gm1 * rho);
 		return e * rho * kB_user / k_B;

@@ -168,6 +168,9 @@ QK_DEV void amendRadState(Rad const &r, double U[NRAD])
 // EOS.hpp:202-244 with the direct gamma-law forms
 QK_DEV auto eintTempDerivative(Eos const &eos, double rho, double T) -> double
 {
+	if (eos.tmodel == 1) { // the heat capacity of the Su-Olson material: alpha T^3
+		return eos.alpha * ((T * T) * T);
+	}
 	const double p = rho * T * Eos::k_B / (eos.mu * Eos::m_u);
 	const double e = p / (eos.gm1 * rho);
 	const double dedT = e / T;

@@ -139,7 +139,9 @@ template <typename problem_t> auto traits() -> qk_hydro_traits
 		HydroSystem_Traits<problem_t>::reconstruct_eint ? 1 : 0,
 		Physics_Traits<problem_t>::numPassiveScalars,
 		Physics_Traits<problem_t>::numMassScalars,
-		AMREX_SPACEDIM};
+		AMREX_SPACEDIM,
+		0,
+		0.0};
 }
 } // namespace qkhost
 

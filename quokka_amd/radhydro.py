@@ -345,3 +345,79 @@ def streaming_problem(ctx: Context, nx: int = 1000, pow_mode: int = 0) -> Radhyd
 
     sim.set_initial_conditions(ic)
     return sim
+
+
+class SuOlsonConstants:
+    """reference src/problems/RadSuOlson/test_radiation_SuOlson.cpp:21-33"""
+    eps_SuOlson, kappa, rho0, T_hohlraum, x0, t0 = 1.0, 1.0, 1.0, 1.0, 0.5, 10.0
+    a_rad, c = 1.0, 1.0
+    alpha_SuOlson = 4.0 * a_rad / eps_SuOlson
+    Q = 1.0 / (2.0 * x0)
+    S = Q * (a_rad * (T_hohlraum * T_hohlraum * T_hohlraum * T_hohlraum))
+
+
+def suolson_problem(ctx: Context, nx: int = 1500, pow_mode: int = 0) -> RadhydroSimulation:
+    """reference src/problems/RadSuOlson/test_radiation_SuOlson.cpp + tests/SuOlson.in (1-D build): a radiation source switched on in
+    x < x0 heats a cold half-space with heat capacity alpha T^3 (the material of Su & Olson 1997: E = alpha / 4 T^4); radiation only,
+    reflecting walls, kappa = 1 / rho, beta_order 0."""
+    S = SuOlsonConstants
+    geom = Geometry(1, [nx], [0.0, 0.0, 0.0], [30.0, 1.0, 1.0], [0, 0, 0])
+    bcs = []
+    for n in range(10):
+        odd = n in (1, RAD0 + 1)
+        bcs.append(([capi.BC_REFLECT_ODD if odd else capi.BC_REFLECT_EVEN, 0, 0], [capi.BC_REFLECT_ODD if odd else capi.BC_REFLECT_EVEN, 0, 0]))
+    traits = capi.traits(5.0 / 3.0, True, 1, mean_molecular_weight=1.0, boltzmann_constant=1.0, eos_temperature_model=1, eos_alpha=S.alpha_SuOlson)
+    rt = capi.RadTraits(S.c, S.c, S.a_rad, 0.0, 0, 1, S.kappa, S.kappa, S.kappa, pow_mode, 0)
+    sim = RadhydroSimulation(ctx, geom, traits, rt, bcs, [nx, 1, 1], use_fused=False)
+    sim.is_hydro_enabled = False
+    sim.cflNumber_ = sim.radiationCflNumber_ = 0.4
+    sim.stopTime_, sim.maxTimesteps_, sim.maxDt_, sim.initDt_ = 10.0, 12000, 1e-2, 1e-9
+    dx = geom.dx[0]
+    initial_Egas = 1e-10 * ((S.alpha_SuOlson / 4.0) * ((S.T_hohlraum * S.T_hohlraum) * (S.T_hohlraum * S.T_hohlraum)))
+    initial_Erad = 1e-10 * (S.a_rad * (S.T_hohlraum * S.T_hohlraum * S.T_hohlraum * S.T_hohlraum))
+
+    def ic(i, j, k):
+        U = np.zeros((10,) + i.shape)
+        U[0], U[4], U[5], U[6] = S.rho0, initial_Egas, initial_Egas, initial_Erad
+        return U
+
+    def source(i, j, k, time):  # SetRadEnergySource :115-145
+        xl, xr = (i + 0.0) * dx, (i + 1.0) * dx
+        frac = np.where((xl < S.x0) & (xr <= S.x0), 1.0, np.where((xl < S.x0) & (xr > S.x0), (S.x0 - xl) / (xr - xl), 0.0))
+        return (S.S * frac) if time < S.t0 else 0.0 * frac
+
+    sim.SetRadEnergySource = source
+    sim._source_time_independent = False
+    sim.set_initial_conditions(ic)
+    return sim
+
+
+class CouplingConstants:
+    """reference src/problems/RadMatterCoupling/test_radiation_matter_coupling.cpp:24-27, :113-115"""
+    a_rad = 7.5646e-15
+    alpha_SuOlson = 4.0 * a_rad / 1.0
+    Erad0, Egas0, rho0 = 1.0e12, 1.0e2, 1.0e-7
+    c_light = 2.99792458e10
+    a_rad_cgs = 4.0 * 5.670374419e-5 / c_light  # C::a_rad: the radiation constant the solver uses
+
+
+def matter_coupling_problem(ctx: Context, n: int = 4, pow_mode: int = 0) -> RadhydroSimulation:
+    """reference src/problems/RadMatterCoupling/test_radiation_matter_coupling.cpp + tests/energyexchange.in (1-D build): gas and
+    radiation of a uniform medium relax to a common temperature; constant dt = 1e-8 s, kappa = 1, E_gas = alpha / 4 T^4."""
+    S = CouplingConstants
+    geom = Geometry(1, [n], [0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [0, 0, 0])
+    bcs = [([capi.BC_FOEXTRAP, 0, 0], [capi.BC_FOEXTRAP, 0, 0]) for _ in range(10)]
+    traits = capi.traits(5.0 / 3.0, True, 1, eos_temperature_model=1, eos_alpha=S.alpha_SuOlson)
+    rt = capi.RadTraits(S.c_light, S.c_light, S.a_rad_cgs, 0.0, 1, 0, 1.0, 1.0, 1.0, pow_mode, 0)
+    sim = RadhydroSimulation(ctx, geom, traits, rt, bcs, [n, 1, 1], use_fused=False)
+    sim.is_hydro_enabled = False
+    sim.cflNumber_ = sim.radiationCflNumber_ = 1.0
+    sim.constantDt_, sim.maxTimesteps_, sim.stopTime_ = 1.0e-8, 1000000, 1.0e-2
+
+    def ic(i, j, k):
+        U = np.zeros((10,) + i.shape)
+        U[0], U[4], U[5], U[6] = S.rho0, S.Egas0, S.Egas0, S.Erad0
+        return U
+
+    sim.set_initial_conditions(ic)
+    return sim

@@ -178,3 +178,54 @@ def test_linear_sound_wave_returns_to_its_initial_state(oracle):
     err = H.wave_error(U0, H.gather_x(s))
     assert err < H.CASES["wave"]["tol"], err
     assert err > 1e-12
+
+
+def test_matter_radiation_equilibration_follows_the_exact_solution(oracle):
+    """RadMatterCoupling (src/problems/RadMatterCoupling/test_radiation_matter_coupling.cpp:174-226): the gas temperature after every
+    one of the 10^6 steps of dt = 1e-8 s against the exact solution of the relaxation ODE for the material E = alpha / 4 T^4; relative
+    L1 error over all steps below 2e-5.  Pins the Newton-Raphson exchange solve (and the T^4 member of the EOS hook set)."""
+    from oracle.pyoracle import COUPLING
+    s = oracle.sim(COUPLING, 1, [4, 1, 1], [0, 0, 0], [1.0, 1, 1], [0, 0, 0], max_grid_size=[4, 1, 1])
+    t, U = s.run_record(1000000, cell=(1, 0, 0))
+    assert len(t) == 1000000 and abs(t[-1] - 1.0e-2) < 1e-12
+    alpha, arad, c = 4.0 * 7.5646e-15, 4.0 * 5.670374419e-5 / 2.99792458e10, 2.99792458e10
+    Erad0, Egas0, rho0, kappa = 1.0e12, 1.0e2, 1.0e-7, 1.0
+    Eint = U[:, 4] - (U[:, 1] ** 2 + U[:, 2] ** 2 + U[:, 3] ** 2) / (2.0 * U[:, 0])
+    Tgas = np.power(4.0 * Eint / alpha, 0.25)
+    T0_4 = 4.0 * Egas0 / alpha
+    E0 = (Erad0 + Egas0) / (arad + alpha / 4.0)
+    T4 = (T0_4 - E0) * np.exp(-(4.0 / alpha) * (arad + alpha / 4.0) * kappa * rho0 * c * t) + E0
+    Texact = np.power(T4, 0.25)
+    err = float(np.abs(Tgas - Texact).sum() / np.abs(Texact).sum())
+    assert err < 2e-5, err
+    c_ = s.rad_counters()
+    assert c_["fail_coupling"] == c_["fail_outer"] == 0
+
+
+SUOLSON_X = [0.01, 0.1, 0.17783, 0.31623, 0.45, 0.5, 0.56234, 0.75, 1.0, 1.33352, 1.77828, 3.16228, 5.62341]
+SUOLSON_EGAS_T10 = [2.11186, 2.09585, 2.06052, 1.94365, 1.74291, 1.61536, 1.46027, 1.16591, 0.88992, 0.62521, 0.38688, 0.07642, 0.00253]
+
+
+def suolson_error(U):
+    """src/problems/RadSuOlson/test_radiation_SuOlson.cpp:242-293: gas temperature at t = 10 against the transport solution tabulated by
+    Su & Olson (1997) (the table is data of the reference's test), interpolated to the table's points"""
+    nx = U.shape[-1]
+    xs = (np.arange(nx) + 0.5) * (30.0 / nx)
+    Eint = U[4] - (U[1] * U[1]) / (2.0 * U[0])
+    Tgas = np.power(4.0 * Eint / 4.0, 0.25)
+    Te = np.power(4.0 * np.array(SUOLSON_EGAS_T10) / 4.0, 0.25)
+    return float(np.abs(np.interp(SUOLSON_X, xs, Tgas) - Te).sum() / np.abs(Te).sum())
+
+
+def test_su_olson_source_problem_meets_the_reference_criterion(oracle):
+    """RadSuOlson: a radiation source in x < 0.5 heats a cold half-space (time-dependent SetRadEnergySource, reflecting walls,
+    kappa = 1 / rho, beta_order 0, 1500 cells to t = 10): relative L1 error of the gas temperature below 0.03; the energy in
+    radiation + gas internal energy equals the energy emitted (the gas also picks up momentum from the radiation force, which
+    with beta_order = 0 is not debited — the reference evaluates E - p^2 / 2 rho as well)"""
+    from oracle.pyoracle import SUOLSON
+    s = oracle.sim(SUOLSON, 1, [1500, 1, 1], [0, 0, 0], [30.0, 1, 1], [0, 0, 0], max_grid_size=[1500, 1, 1])
+    assert s.evolve() and abs(s.time - 10.0) < 1e-12 and s.istep < 12000
+    U = s.valid(0)[:, 0, 0, :]
+    assert suolson_error(U) < 0.03
+    Eint = U[4] - (U[1] * U[1]) / (2.0 * U[0])
+    assert abs((Eint.sum() + U[6].sum()) * 0.02 - 5.0) < 0.01

@@ -142,3 +142,27 @@ def test_shell_accelerates_as_the_thin_shell_solution_predicts(ctx):
     (T, mach, analytic), = shell_velocity.run(128, 1, t_end=0.025)
     assert abs(T - 0.025) < 1e-12
     assert 0.82 < mach / analytic < 0.92, (mach, analytic)
+
+
+def test_su_olson_and_matter_coupling_match_oracle(ctx, oracle):
+    """The T^4 member of the EOS hook set (`eos_temperature_model = 1`), a time-dependent radiation source, reflecting walls and a
+    constant time step through the C-ABI: RadSuOlson for 400 steps and RadMatterCoupling for 3000 steps, bit for bit (shared T^4
+    evaluation); the reference's criteria are evaluated on the oracle's full runs in tests/test_oracle_known_answers.py."""
+    from oracle.pyoracle import COUPLING, SUOLSON
+    from quokka_amd.radhydro import matter_coupling_problem, suolson_problem
+    so = oracle.sim(SUOLSON, 1, [1500, 1, 1], [0, 0, 0], [30.0, 1, 1], [0, 0, 0], max_grid_size=[1500, 1, 1], rad_pow_mode=1)
+    sg = suolson_problem(ctx, 1500, pow_mode=1)
+    assert np.array_equal(so.valid(0), sg.state_new_cc_.valid(0).cpu().numpy())
+    for it in range(400):
+        assert so.step() and sg.step()
+        assert so.dt == sg.dt_, (it, so.dt, sg.dt_)
+    assert np.array_equal(so.valid(0), sg.state_new_cc_.valid(0).cpu().numpy())
+    assert so.time > 1.5  # well into the regime where the wave has left the source region
+
+    so = oracle.sim(COUPLING, 1, [4, 1, 1], [0, 0, 0], [1.0, 1, 1], [0, 0, 0], max_grid_size=[4, 1, 1], rad_pow_mode=1)
+    sg = matter_coupling_problem(ctx, 4, pow_mode=1)
+    assert np.array_equal(so.valid(0), sg.state_new_cc_.valid(0).cpu().numpy())
+    for it in range(3000):
+        assert so.step() and sg.step()
+    assert sg.dt_ == 1.0e-8 and np.array_equal(so.valid(0), sg.state_new_cc_.valid(0).cpu().numpy())
+    assert sg.state_new_cc_.valid(0)[4, 0, 0, 1].item() > 1.0e4  # the gas has heated by orders of magnitude
