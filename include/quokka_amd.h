@@ -195,8 +195,10 @@ typedef struct qk_hydro_stage_args {
 	double densityFloor, tempFloor;
 	int use_dual_energy;
 	double K_visc;		 /* artificial viscosity: the fused path requires 0 (QK_ERR_UNSUPPORTED otherwise) */
-	int store_flux_rk2;	 /* stage 2 only: overwrite halfFlux / halfVel with flux_rk2 = 0.5 F1 + 0.5 F2 (what the flux registers of an
-				  * AMR hierarchy accumulate, reference src/QuokkaSimulation.hpp:1303-1306); 0: leave F1 in place */
+	int store_flux_rk2;	 /* stage 2 only: write flux_rk2 = 0.5 F1 + 0.5 F2 (what the flux registers of an AMR hierarchy accumulate,
+				  * reference src/QuokkaSimulation.hpp:1303-1306) into fluxRk2[d]; 0: not stored */
+	qk_array4 *fluxRk2[3];	 /* face-centred like halfFlux, 6 components; required when store_flux_rk2 != 0.  Separate from halfFlux: the x
+				  * sweep evaluates the face between two of its tiles in both of them, and both need the stage-1 flux intact */
 } qk_hydro_stage_args;
 
 /* One RK stage of advanceHydroAtLevel (reference src/QuokkaSimulation.hpp:1099-1198 / 1202-1287) WITHOUT the

@@ -156,9 +156,9 @@ class AmrLevelSim(HydroSimulation):
         if ok:  # incrementFluxRegisters (reference src/QuokkaSimulation.hpp:1303-1306, src/simulation.hpp:1369-1386)
             amr, l = self.amr, self.ilev
             if amr.do_reflux and l < amr.finest_level:
-                amr.levels[l + 1].fluxreg.CrseAdd(self.halfFlux, self.geom.dx, dt_lev)
+                amr.levels[l + 1].fluxreg.CrseAdd(self.fluxRk2(), self.geom.dx, dt_lev)
             if amr.do_reflux and l > 0:
-                self.fluxreg.FineAdd(self.halfFlux, self.geom.dx, dt_lev)
+                self.fluxreg.FineAdd(self.fluxRk2(), self.geom.dx, dt_lev)
         self._t_adv += dt_lev
         return ok
 

@@ -113,9 +113,19 @@ __global__ void __launch_bounds__(256) k_copy(const CopyItem *items, const D *st
 }
 
 // PhysBCFunct: FilccCell (AMReX_FilCC_3D_C.H) composed over dimensions + constant-Dirichlet user functor.
-__global__ void __launch_bounds__(256) k_physbc(const CopyItem *items, qk_array4 *state_t, qk_geometry geom, int ncomp, const qk_bcrec *bcs,
-						const qk_dirichlet_face *dirichlet)
+// The BCRecs and the Dirichlet model travel BY VALUE in the kernel arguments: the caller's arrays may be temporaries, and nothing of
+// this call may depend on host memory after it returns.
+constexpr int PHYSBC_MAX_COMP = 16;
+struct PhysBcArgs {
+	qk_bcrec bcs[PHYSBC_MAX_COMP];
+	qk_dirichlet_face dir[6];
+	int has_dirichlet;
+};
+
+__global__ void __launch_bounds__(256) k_physbc(const CopyItem *items, qk_array4 *state_t, qk_geometry geom, int ncomp, PhysBcArgs pa)
 {
+	const qk_bcrec *bcs = pa.bcs;
+	const qk_dirichlet_face *dirichlet = (pa.has_dirichlet != 0) ? pa.dir : nullptr;
 	const CopyItem it = items[blockIdx.y];
 	int lo[3], len[3];
 #pragma unroll
@@ -648,14 +658,18 @@ int qk_FillPhysicalBoundary_subset(qk_ghost_plan *plan, qk_stream s, qk_array4 *
 		return QK_OK;
 	}
 	(void)lev;
-	// BCRecs / Dirichlet model are tiny: keep a device copy in the plan (refreshed on every call, stream-ordered)
-	if (plan->d_bcs == nullptr) {
-		QK_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void **>(&plan->d_bcs), sizeof(qk_bcrec) * plan->ncomp));
-		QK_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void **>(&plan->d_dir), sizeof(qk_dirichlet_face) * 6));
+	// BCRecs / Dirichlet model are tiny and go by value into the kernel arguments (an asynchronous upload from the caller's arrays would
+	// read them after this call has returned — they may be temporaries)
+	QK_REQUIRE(ctx, plan->ncomp <= PHYSBC_MAX_COMP, "FillPhysicalBoundary: more than 16 components");
+	PhysBcArgs pa{};
+	for (int n = 0; n < plan->ncomp; ++n) {
+		pa.bcs[n] = bcs[n];
 	}
-	QK_HIP_CHECK(ctx, hipMemcpyAsync(plan->d_bcs, bcs, sizeof(qk_bcrec) * plan->ncomp, hipMemcpyHostToDevice, static_cast<hipStream_t>(s)));
+	pa.has_dirichlet = (dirichlet != nullptr) ? 1 : 0;
 	if (dirichlet != nullptr) {
-		QK_HIP_CHECK(ctx, hipMemcpyAsync(plan->d_dir, dirichlet, sizeof(qk_dirichlet_face) * 6, hipMemcpyHostToDevice, static_cast<hipStream_t>(s)));
+		for (int f = 0; f < 6; ++f) {
+			pa.dir[f] = dirichlet[f];
+		}
 	}
 	QK_REQUIRE(ctx, which == QK_BOXES_ALL || which == QK_BOXES_LOCAL_ONLY || which == QK_BOXES_REMOTE_DEPENDENT, "FillPhysicalBoundary: bad subset");
 	const int nall = static_cast<int>(plan->shells.size());
@@ -665,7 +679,7 @@ int qk_FillPhysicalBoundary_subset(qk_ghost_plan *plan, qk_stream s, qk_array4 *
 		return QK_OK;
 	}
 	hipLaunchKernelGGL(k_physbc, gridFor(plan->max_shell_cells, count), dim3(256), 0, static_cast<hipStream_t>(s), plan->d_shells + first, state_t,
-			   plan->geom, plan->ncomp, plan->d_bcs, dirichlet != nullptr ? plan->d_dir : nullptr);
+			   plan->geom, plan->ncomp, pa);
 	QK_HIP_CHECK(ctx, hipGetLastError());
 	return QK_OK;
 }

@@ -66,7 +66,8 @@ struct SweepArgs {
 	double K_visc;
 	int use_dual_energy;
 	bool reconstruct_eint;
-	bool store_rk2; // stage 2: write flux_rk2 back over F1
+	bool store_rk2; // stage 2: write flux_rk2 = 0.5 F1 + 0.5 F2 to rk2Flux (never over F1: tile-boundary faces of the x sweep are evaluated twice)
+	qk_array4 *rk2Flux;
 };
 
 QK_DEV auto sarr(SweepArgs const &a, int comp) -> double * { return a.scratch + static_cast<int64_t>(comp) * a.total_cells; }
@@ -372,11 +373,12 @@ template <int ORDER, int STAGE> __global__ void __launch_bounds__(XB) k_sweep_x(
 			}
 			vf = 0.5 * HV(i, j, k) + 0.5 * vf;
 			if (a.store_rk2) {
+				WA4 RF(a.rk2Flux[b]);
+				const int64_t o2 = RF.idx(i, j, k);
 #pragma unroll
 				for (int n = 0; n < NVAR; ++n) {
-					HF.p[o + HF.ns * n] = F[n];
+					RF.p[o2 + RF.ns * n] = F[n];
 				}
-				HV(i, j, k) = vf;
 			}
 		}
 	}
@@ -498,11 +500,12 @@ template <int DIR, int ORDER, int STAGE, bool LAST> __global__ void __launch_bou
 				}
 				vf = 0.5 * HV(fidx[0], fidx[1], fidx[2]) + 0.5 * vf;
 				if (a.store_rk2 && live) {
+					WA4 RF(a.rk2Flux[b]);
+					const int64_t o2 = RF.idx(fidx[0], fidx[1], fidx[2]);
 #pragma unroll
 					for (int n = 0; n < NVAR; ++n) {
-						HF.p[o + HF.ns * n] = F[n];
+						RF.p[o2 + RF.ns * n] = F[n];
 					}
-					HV(fidx[0], fidx[1], fidx[2]) = vf;
 				}
 			}
 			if (step >= 6) {
@@ -588,6 +591,7 @@ template <int ORDER, int STAGE> void launchSweeps(qk_level *lev, hipStream_t s, 
 		SweepArgs ax = a;
 		ax.halfFlux = args->halfFlux[0];
 		ax.halfVel = args->halfVel[0];
+		ax.rk2Flux = args->fluxRk2[0];
 		ax.inv_dx = 1.0 / args->dx[0];
 		ax.dx = args->dx[0];
 		const int64_t slab = static_cast<int64_t>(lev->maxlen[0] + 2 * NG) * lev->maxlen[1];
@@ -600,6 +604,7 @@ template <int ORDER, int STAGE> void launchSweeps(qk_level *lev, hipStream_t s, 
 		SweepArgs ay = a;
 		ay.halfFlux = args->halfFlux[1];
 		ay.halfVel = args->halfVel[1];
+		ay.rk2Flux = args->fluxRk2[1];
 		ay.inv_dx = 1.0 / args->dx[1];
 		ay.dx = args->dx[1];
 		const dim3 grid((lev->maxlen[0] + 63) / 64, (lev->maxlen[2] + 3) / 4, lev->nboxes);
@@ -611,6 +616,7 @@ template <int ORDER, int STAGE> void launchSweeps(qk_level *lev, hipStream_t s, 
 		SweepArgs az = a;
 		az.halfFlux = args->halfFlux[2];
 		az.halfVel = args->halfVel[2];
+		az.rk2Flux = args->fluxRk2[2];
 		az.inv_dx = 1.0 / args->dx[2];
 		az.dx = args->dx[2];
 		const dim3 grid((lev->maxlen[0] + 63) / 64, (lev->maxlen[1] + 3) / 4, lev->nboxes);
@@ -670,6 +676,8 @@ int qk_hydro_stage_fused(qk_level *lev, qk_stream stream, const qk_hydro_traits 
 		   "qk_hydro_stage_fused: NULL array");
 	for (int d = 0; d < 3; ++d) {
 		QK_REQUIRE(ctx, args->halfFlux[d] && args->halfVel[d], "qk_hydro_stage_fused: NULL halfFlux/halfVel");
+		QK_REQUIRE(ctx, args->store_flux_rk2 == 0 || args->stage != 2 || (args->fluxRk2[d] != nullptr && args->fluxRk2[d] != args->halfFlux[d]),
+			   "qk_hydro_stage_fused: store_flux_rk2 needs fluxRk2[d], distinct from halfFlux[d]");
 		QK_REQUIRE(ctx, lev->maxlen[d] >= 1, "qk_hydro_stage_fused: empty box");
 	}
 	QK_REQUIRE(ctx, args->scratch_bytes >= qk_hydro_stage_scratch_bytes(lev, t), "qk_hydro_stage_fused: scratch too small");

@@ -364,6 +364,9 @@ template <typename T> class FabArrayT
 			total_ += fb.numPts() * ncomp;
 		}
 		QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_data_), sizeof(T) * std::max<Long>(total_, 1)));
+		// fresh storage reads as zero (what the Python drivers' MultiFab(fill = 0) gives); QK_POISON=1 fills it with NaN bit patterns
+		// instead, which makes any read of a cell that was never written visible in the results (debugging aid)
+		QK_HOST_HIP(hipMemset(d_data_, std::getenv("QK_POISON") != nullptr ? 0xFF : 0, sizeof(T) * std::max<Long>(total_, 1)));
 		for (size_t n = 0; n < ba.size(); ++n) {
 			tab.emplace_back(d_data_ + offsets_[n], fabboxes_[n], ncomp);
 		}

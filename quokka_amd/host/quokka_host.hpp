@@ -782,9 +782,10 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	// --- AMR level bookkeeping (used by quokka_amr.hpp; a uniform-grid run leaves the defaults)
 	double tOldLev_ = 0.0, tNewLev_ = 0.0; // tOld_[lev], tNew_[lev]
 	double fillTime_ = 0.0;		       // the time a ghost fill refers to (coarse data are interpolated to it)
-	bool storeFluxRk2_ = false;	       // leave flux_rk2 in halfFlux_ for the flux registers
+	bool storeFluxRk2_ = false;	       // keep flux_rk2 = 0.5 F1 + 0.5 F2 (rk2flux_) for the flux registers
 	std::function<void(double)> afterAdvance_; // incrementFluxRegisters(dt) after every successful advanceHydroAtLevel
-	[[nodiscard]] auto halfFlux() -> std::array<amrex::MultiFab, AMREX_SPACEDIM> & { return halfFlux_; }
+	// what the flux registers accumulate after a level advance (reference src/QuokkaSimulation.hpp:1303-1306)
+	[[nodiscard]] auto halfFlux() -> std::array<amrex::MultiFab, AMREX_SPACEDIM> & { return (integratorOrder_ == 2) ? rk2flux_ : halfFlux_; }
 	// ErrorEst(lev, tags, time, ngrow): problem hook (reference src/QuokkaSimulation.hpp:213).  Device lambdas cannot be compiled
 	// against the C-ABI; the gradient-threshold family of the reference's problems is one library call: tagRelativeGradient below.
 	virtual void ErrorEst(int /*lev*/, amrex::TagBoxArray & /*tags*/, amrex::Real /*time*/, int /*ngrow*/) {}
@@ -1348,11 +1349,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		if (useDualEnergy_ == 1) {
 			HydroSystem<problem_t>::SyncDualEnergy(U_out, d_error_);
 		}
-		if (stageNo == 2 && storeFluxRk2_) { // what the flux registers accumulate (possibly FOFC-corrected), as the fused stage leaves it
-			for (int d = 0; d < AMREX_SPACEDIM; ++d) {
-				amrex::MultiFab::Copy(halfFlux_[d], (*fl)[d]);
-			}
-		}
+		// (stage 2: *fl IS rk2flux_, possibly FOFC-corrected — where the fused stage leaves flux_rk2 as well)
 		return true;
 	}
 
@@ -1388,6 +1385,9 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 			a.use_dual_energy = useDualEnergy_;
 			a.K_visc = 0.0;
 			a.store_flux_rk2 = storeFluxRk2_ ? 1 : 0;
+			for (int d = 0; d < 3; ++d) {
+				a.fluxRk2[d] = storeFluxRk2_ ? qkhost::tab(rk2flux_[d]) : nullptr;
+			}
 			qkhost::check(qk_hydro_stage_fused(qkhost::Runtime::get().lev, nullptr, &t, &a), "qk_hydro_stage_fused");
 			if (readCount() == 0) {
 				if (final_stage) {

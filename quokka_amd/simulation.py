@@ -470,10 +470,16 @@ class HydroSimulation:
                 return False
         self._limits_and_sync(U_out)
         if stage == 2 and getattr(self, "store_flux_rk2", False):
-            for d in range(nd):  # what the flux registers accumulate (possibly FOFC-corrected), as the fused stage leaves it
-                self.halfFlux[d].copy_from(fl[d])
-                self.halfVel[d].copy_from(vl[d])
+            for d in range(nd):  # what the flux registers accumulate (possibly FOFC-corrected), where the fused stage leaves it
+                self.fluxRk2()[d].copy_from(fl[d])
         return True
+
+    def fluxRk2(self):
+        """flux_rk2 = 0.5 F1 + 0.5 F2 of the last stage 2 (reference src/QuokkaSimulation.hpp:1303-1306), what the flux registers of an AMR
+        hierarchy accumulate; separate from halfFlux (F1), which both evaluations of a tile-boundary face of the x sweep must find intact"""
+        if getattr(self, "_fluxRk2", None) is None:
+            self._fluxRk2 = [MultiFab(self.lev, self.hydro.nvar_, 0, facedir=d, fill=0.0) for d in range(self.geom.ndim)]
+        return self._fluxRk2
 
     def _is_final(self, stage: int) -> bool:
         return (stage == 2) or (self.integratorOrder_ == 1)
@@ -503,6 +509,9 @@ class HydroSimulation:
         a.dt, a.stage, a.reconstruction_order = dt, stage, self.reconstructionOrder_
         a.densityFloor, a.tempFloor, a.use_dual_energy, a.K_visc = self.densityFloor_, self.tempFloor_, self.useDualEnergy_, 0.0
         a.store_flux_rk2 = int(getattr(self, "store_flux_rk2", False))
+        if a.store_flux_rk2:
+            for d in range(3):
+                a.fluxRk2[d] = tab(self.fluxRk2()[d])
         c = self.ctx
         c.check(c.L.qk_hydro_stage_fused(lev.h, c.stream(), C.byref(self.traits), C.byref(a)), "qk_hydro_stage_fused")
 
