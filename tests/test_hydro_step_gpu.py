@@ -300,3 +300,46 @@ def test_linear_sound_wave_on_the_gpu_path(ctx, oracle):
     Ug = sg.state_new_cc_.valid(0).cpu().numpy()[:, 0, 0, :]
     assert np.array_equal(H.gather_x(so), Ug) and so.istep == sg.istep
     assert H.wave_error(U0, Ug) < c["tol"]
+
+
+def test_flux_rk2_of_the_fused_stage_is_race_free_and_equals_the_operator_path(ctx):
+    """`store_flux_rk2` (what the flux registers of an AMR hierarchy accumulate): the stage-2 x sweep evaluates the face between two of
+    its 250-cell tiles in both tiles; the first version averaged F1 in place there, so the second evaluation could read the averaged
+    value.  flux_rk2 now goes to separate arrays: on rows long enough to span several tiles, repeated runs give the operator path's
+    0.5 F1 + 0.5 F2 bit for bit in every face, the new state is unaffected, F1 is left intact, and aliasing the two is refused."""
+    from quokka_amd import capi
+    from quokka_amd.simulation import Geometry, HydroSimulation
+    from test_hydro_ops_gpu import random_state
+    N = (96, 20, 8)  # flat slab rows of (96 + 8) x 20 cells: eight tile boundaries per plane
+    geom = Geometry(3, list(N), [0.0] * 3, [1.0, 0.25, 0.125], [1, 1, 1])
+    tr = capi.traits(1.4, False, 3)
+    bcs = [([capi.BC_INT_DIR] * 3, [capi.BC_INT_DIR] * 3)] * 6
+    U0 = random_state(np.random.default_rng(11), (N[2], N[1], N[0]))
+
+    def run(fused):
+        sim = HydroSimulation(ctx, geom, tr, bcs, list(N), use_fused=fused)
+        sim.store_flux_rk2 = True
+        sim.set_initial_conditions(lambda i, j, k: U0[:, k, j, i])
+        dt = 1.0e-4
+        old, inter, new = sim.state_old_cc_, sim.state_inter_cc_, sim.state_new_cc_
+        sim.fillBoundaryConditions(old)
+        assert sim._stage(1, old, old, inter, dt)
+        f1 = [sim.halfFlux[d].fab_numpy(0).copy() for d in range(3)]
+        sim.fillBoundaryConditions(inter)
+        assert sim._stage(2, inter, old, new, dt)
+        if fused:
+            for d in range(3):
+                assert np.array_equal(sim.halfFlux[d].fab_numpy(0), f1[d]), "stage 2 must leave the stage-1 flux alone"
+        return [sim.fluxRk2()[d].fab_numpy(0) for d in range(3)], new.valid(0).cpu().numpy(), sim
+
+    want, new_want, _ = run(False)
+    for rep in range(12):
+        got, new_got, sim = run(True)
+        for d in range(3):
+            assert np.array_equal(got[d], want[d]), (rep, d, float(np.abs(got[d] - want[d]).max()))
+        assert np.array_equal(new_got, new_want)
+    # aliasing flux_rk2 with the stage-1 flux is refused by the library
+    sim._fluxRk2 = sim.halfFlux
+    sim.fillBoundaryConditions(sim.state_inter_cc_)
+    with pytest.raises(capi.QkError, match="fluxRk2"):
+        sim._stage(2, sim.state_inter_cc_, sim.state_old_cc_, sim.state_new_cc_, 1.0e-4)
