@@ -24,6 +24,9 @@
 //      segments are 2-4x slower; a 168-VGPR cap for 3 waves per SIMD — spills; fmin/fmax for min/max — slower.)
 //   * all arithmetic in qk_device.hpp, shared with the reference-shaped operators -> identical bits.
 #include "qk_device.hpp"
+#include <algorithm>
+#include <cstdlib>
+
 #include "qk_internal.hpp"
 
 using namespace qk;
@@ -68,6 +71,7 @@ struct SweepArgs {
 	bool reconstruct_eint;
 	bool store_rk2; // stage 2: write flux_rk2 = 0.5 F1 + 0.5 F2 to rk2Flux (never over F1: tile-boundary faces of the x sweep are evaluated twice)
 	qk_array4 *rk2Flux;
+	int nseg; // segments along the march axis (marching sweeps; see k_pre_march)
 };
 
 QK_DEV auto sarr(SweepArgs const &a, int comp) -> double * { return a.scratch + static_cast<int64_t>(comp) * a.total_cells; }
@@ -148,10 +152,14 @@ __global__ void __launch_bounds__(PXB) k_pre_x(const SGeom *geom, const qk_array
 	}
 }
 
-template <int DIR> __global__ void __launch_bounds__(256) k_pre_march(const qk_box *boxes, const SGeom *geom, double *scratch, int64_t T, Eos eos, bool re)
+// nseg > 1: the march axis is cut into nseg segments, each marched by its own thread (with its own warm-up of the window) — levels with
+// few columns (small AMR levels) would otherwise leave most of the chip idle behind one long dependent chain per column.  Every output
+// cell belongs to exactly one segment; the arithmetic per cell is unchanged.
+template <int DIR> __global__ void __launch_bounds__(256) k_pre_march(const qk_box *boxes, const SGeom *geom, double *scratch, int64_t T, Eos eos, bool re, int nseg)
 {
 	constexpr int OT = 3 - DIR;
-	const int b = blockIdx.z;
+	const int b = static_cast<int>(blockIdx.z) / nseg;
+	const int seg = static_cast<int>(blockIdx.z) - b * nseg;
 	const qk_box bx = boxes[b];
 	const SGeom g = geom[b];
 	const int i = bx.lo[0] - 1 + static_cast<int>(blockIdx.x * 64 + threadIdx.x);
@@ -159,8 +167,16 @@ template <int DIR> __global__ void __launch_bounds__(256) k_pre_march(const qk_b
 	if (i > bx.hi[0] + 1 || ot > bx.hi[OT] + 1) {
 		return;
 	}
-	const int lo = bx.lo[DIR];
-	const int nvalid = bx.hi[DIR] - lo + 1;
+	// output cells lo-1 .. hi+2 of the box, this segment's share [first, first + nout - 1]
+	const int nall = bx.hi[DIR] - bx.lo[DIR] + 1 + 3;
+	const int seglen = (nall + nseg - 1) / nseg;
+	const int first = bx.lo[DIR] - 1 + seg * seglen;
+	const int nout = min(seglen, bx.lo[DIR] - 1 + nall - first);
+	if (nout <= 0) {
+		return;
+	}
+	const int lo = first + 1;      // (for a whole box: lo = bx.lo, nvalid = box length)
+	const int nvalid = nout - 3;
 	const int64_t st[3] = {1, g.n[0], static_cast<int64_t>(g.n[0]) * g.n[1]};
 	const int64_t ms = st[DIR];
 	int pos[3];
@@ -407,7 +423,8 @@ template <int ORDER, int STAGE> __global__ void __launch_bounds__(XB) k_sweep_x(
 template <int DIR, int ORDER, int STAGE, bool LAST> __global__ void __launch_bounds__(256) k_sweep_march(SweepArgs a, Eos eos)
 {
 	static_assert(DIR == 1 || DIR == 2, "marching sweeps are the strided directions");
-	const int b = blockIdx.z;
+	const int b = static_cast<int>(blockIdx.z) / a.nseg;
+	const int seg = static_cast<int>(blockIdx.z) - b * a.nseg;
 	const qk_box bx = a.boxes[b];
 	const SGeom g = a.geom[b];
 	constexpr int OT = (DIR == 1) ? 2 : 1; // the other transverse axis (besides x)
@@ -421,8 +438,14 @@ template <int DIR, int ORDER, int STAGE, bool LAST> __global__ void __launch_bou
 	const int64_t T = a.total_cells;
 	const int64_t st[3] = {1, g.n[0], static_cast<int64_t>(g.n[0]) * g.n[1]};
 	const int64_t ms = st[DIR]; // march stride
-	const int lo = bx.lo[DIR], hi = bx.hi[DIR];
+	// this segment's cells [lo, hi] of the box's march range; its faces lo .. hi+1 (a face between two segments is evaluated by both:
+	// same value, stage-1 flux read-only in stage 2)
+	const int seglen = (bx.hi[DIR] - bx.lo[DIR] + 1 + a.nseg - 1) / a.nseg;
+	const int lo = bx.lo[DIR] + seg * seglen, hi = min(lo + seglen - 1, bx.hi[DIR]);
 	const int nvalid = hi - lo + 1;
+	if (nvalid <= 0) {
+		return; // uniform for the workgroup
+	}
 	// scratch index of march position p = lo - 3
 	int pos[3];
 	pos[0] = i;
@@ -559,6 +582,19 @@ template <int DIR, int ORDER, int STAGE, bool LAST> __global__ void __launch_bou
 	}
 }
 
+// segments along the march axis `dir` (transverse axes 0 and `ot`): enough threads to fill the chip when the level has few columns, at
+// least 16 cells per segment (each segment re-marches 6 cells of warm-up); 1 for the large levels (one column per thread is enough)
+auto marchSegments(const qk_level *lev, int dir, int ot) -> int
+{
+	if (const char *e = std::getenv("QK_MARCH_SEGMENTS")) {
+		return std::max(1, std::atoi(e));
+	}
+	const int64_t cols = static_cast<int64_t>(lev->nboxes) * lev->maxlen[0] * lev->maxlen[ot];
+	const int64_t want = (131072 + cols - 1) / std::max<int64_t>(cols, 1);
+	const int cap = std::max(1, lev->maxlen[dir] / 16);
+	return static_cast<int>(std::min<int64_t>(std::max<int64_t>(want, 1), std::min(cap, 16)));
+}
+
 auto buildGeom(qk_level *lev) -> int
 {
 	if (lev->d_sgeom != nullptr) {
@@ -607,7 +643,8 @@ template <int ORDER, int STAGE> void launchSweeps(qk_level *lev, hipStream_t s, 
 		ay.rk2Flux = args->fluxRk2[1];
 		ay.inv_dx = 1.0 / args->dx[1];
 		ay.dx = args->dx[1];
-		const dim3 grid((lev->maxlen[0] + 63) / 64, (lev->maxlen[2] + 3) / 4, lev->nboxes);
+		ay.nseg = marchSegments(lev, 1, 2);
+		const dim3 grid((lev->maxlen[0] + 63) / 64, (lev->maxlen[2] + 3) / 4, lev->nboxes * ay.nseg);
 		ProfScope ps(lev->ctx, s, "k_sweep_y");
 		hipLaunchKernelGGL((k_sweep_march<1, ORDER, STAGE, false>), grid, dim3(64, 4), 0, s, ay, eos);
 	}
@@ -619,7 +656,8 @@ template <int ORDER, int STAGE> void launchSweeps(qk_level *lev, hipStream_t s, 
 		az.rk2Flux = args->fluxRk2[2];
 		az.inv_dx = 1.0 / args->dx[2];
 		az.dx = args->dx[2];
-		const dim3 grid((lev->maxlen[0] + 63) / 64, (lev->maxlen[1] + 3) / 4, lev->nboxes);
+		az.nseg = marchSegments(lev, 2, 1);
+		const dim3 grid((lev->maxlen[0] + 63) / 64, (lev->maxlen[1] + 3) / 4, lev->nboxes * az.nseg);
 		ProfScope ps(lev->ctx, s, "k_sweep_z");
 		hipLaunchKernelGGL((k_sweep_march<2, ORDER, STAGE, true>), grid, dim3(64, 4), 0, s, az, eos);
 	}
@@ -706,13 +744,15 @@ int qk_hydro_stage_fused(qk_level *lev, qk_stream stream, const qk_hydro_traits 
 	}
 	{
 		ProfScope ps(ctx, s, "k_pre_y");
-		const dim3 grid((lev->maxlen[0] + 2 + 63) / 64, (lev->maxlen[2] + 2 + 3) / 4, lev->nboxes);
-		hipLaunchKernelGGL(k_pre_march<1>, grid, dim3(64, 4), 0, s, boxes, geom, scratch, T, eos, re);
+		const int nseg = marchSegments(lev, 1, 2);
+		const dim3 grid((lev->maxlen[0] + 2 + 63) / 64, (lev->maxlen[2] + 2 + 3) / 4, lev->nboxes * nseg);
+		hipLaunchKernelGGL(k_pre_march<1>, grid, dim3(64, 4), 0, s, boxes, geom, scratch, T, eos, re, nseg);
 	}
 	{
 		ProfScope ps(ctx, s, "k_pre_z");
-		const dim3 grid((lev->maxlen[0] + 2 + 63) / 64, (lev->maxlen[1] + 2 + 3) / 4, lev->nboxes);
-		hipLaunchKernelGGL(k_pre_march<2>, grid, dim3(64, 4), 0, s, boxes, geom, scratch, T, eos, re);
+		const int nseg = marchSegments(lev, 2, 1);
+		const dim3 grid((lev->maxlen[0] + 2 + 63) / 64, (lev->maxlen[1] + 2 + 3) / 4, lev->nboxes * nseg);
+		hipLaunchKernelGGL(k_pre_march<2>, grid, dim3(64, 4), 0, s, boxes, geom, scratch, T, eos, re, nseg);
 	}
 
 	// 4. sweeps
