@@ -194,7 +194,7 @@ typedef struct qk_hydro_stage_args {
 	int reconstruction_order; /* 1, 2, 3 */
 	double densityFloor, tempFloor;
 	int use_dual_energy;
-	double K_visc;		 /* artificial viscosity: the fused path requires 0 (QK_ERR_UNSUPPORTED otherwise) */
+	double K_visc;		 /* artificial-viscosity coefficient (hydro.artificial_viscosity_coefficient, reference hydro_system.hpp:1054-1076), >= 0 */
 	int store_flux_rk2;	 /* stage 2 only: write flux_rk2 = 0.5 F1 + 0.5 F2 (what the flux registers of an AMR hierarchy accumulate,
 				  * reference src/QuokkaSimulation.hpp:1303-1306) into fluxRk2[d]; 0: not stored */
 	qk_array4 *fluxRk2[3];	 /* face-centred like halfFlux, 6 components; required when store_flux_rk2 != 0.  Separate from halfFlux: the x

@@ -705,9 +705,7 @@ int qk_hydro_stage_fused(qk_level *lev, qk_stream stream, const qk_hydro_traits 
 	if (t->ndim != 3) {
 		return setError(ctx, QK_ERR_UNSUPPORTED, "qk_hydro_stage_fused: 3-D only (use the reference-shaped operators in 1-D)");
 	}
-	if (args->K_visc != 0.0) {
-		return setError(ctx, QK_ERR_UNSUPPORTED, "qk_hydro_stage_fused: artificial viscosity is only built in the reference-shaped path");
-	}
+	QK_REQUIRE(ctx, args->K_visc >= 0.0, "qk_hydro_stage_fused: negative artificial-viscosity coefficient");
 	QK_REQUIRE(ctx, args->stage == 1 || args->stage == 2, "qk_hydro_stage_fused: stage must be 1 or 2");
 	QK_REQUIRE(ctx, args->reconstruction_order >= 1 && args->reconstruction_order <= 3, "qk_hydro_stage_fused: reconstruction_order must be 1..3");
 	QK_REQUIRE(ctx, args->U_in && args->U_old && args->U_out && args->redoFlag && args->d_redo_count && args->d_error_flag && args->scratch,

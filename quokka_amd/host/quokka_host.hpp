@@ -1355,7 +1355,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 
 	auto stage(int stageNo, amrex::MultiFab const &U_in, amrex::MultiFab const &U_old, amrex::MultiFab &U_out, double dt) -> bool
 	{
-		if (AMREX_SPACEDIM == 3 && artificialViscosityK_ == 0.0 && HydroSystem<problem_t>::nscalars_ == 0) {
+		if (AMREX_SPACEDIM == 3 && HydroSystem<problem_t>::nscalars_ == 0) {
 			auto t = qkhost::traits<problem_t>();
 			qk_hydro_stage_args a{};
 			a.U_in = qkhost::tab(U_in);
@@ -1383,7 +1383,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 			a.densityFloor = densityFloor_;
 			a.tempFloor = tempFloor_;
 			a.use_dual_energy = useDualEnergy_;
-			a.K_visc = 0.0;
+			a.K_visc = artificialViscosityK_;
 			a.store_flux_rk2 = storeFluxRk2_ ? 1 : 0;
 			for (int d = 0; d < 3; ++d) {
 				a.fluxRk2[d] = storeFluxRk2_ ? qkhost::tab(rk2flux_[d]) : nullptr;

@@ -507,7 +507,7 @@ class HydroSimulation:
         a.scratch = C.c_void_p(self.scratch.data_ptr())
         a.scratch_bytes = self.scratch.numel() * 8
         a.dt, a.stage, a.reconstruction_order = dt, stage, self.reconstructionOrder_
-        a.densityFloor, a.tempFloor, a.use_dual_energy, a.K_visc = self.densityFloor_, self.tempFloor_, self.useDualEnergy_, 0.0
+        a.densityFloor, a.tempFloor, a.use_dual_energy, a.K_visc = self.densityFloor_, self.tempFloor_, self.useDualEnergy_, float(self.artificialViscosityK_)
         a.store_flux_rk2 = int(getattr(self, "store_flux_rk2", False))
         if a.store_flux_rk2:
             for d in range(3):
@@ -558,7 +558,7 @@ class HydroSimulation:
         """fillBoundaryConditions(U_in) + one RK stage.  With more than one rank the boxes that need nothing from other
         ranks are advanced while the strips of the others are on the wire (north_star: FillBoundary overlapped with the
         update on a second stream — RCCL's); the reference's fill is blocking (src/QuokkaSimulation.hpp:1099, :1202)."""
-        groups = self.overlap_groups() if (self.use_fused and self.artificialViscosityK_ == 0.0) else None
+        groups = self.overlap_groups() if self.use_fused else None
         if groups is None:
             self.fillBoundaryConditions(U_in)
             return self._stage(stage, U_in, U_old, U_out, dt)
@@ -571,7 +571,7 @@ class HydroSimulation:
         return self._stage_unfused(stage, U_in, U_old, U_out, dt, with_fofc=True)
 
     def _stage(self, stage, U_in, U_old, U_out, dt) -> bool:
-        if self.use_fused and self.artificialViscosityK_ == 0.0:
+        if self.use_fused:
             nbad = self._stage_fused(stage, U_in, U_old, U_out, dt)
             if nbad == 0:
                 return True

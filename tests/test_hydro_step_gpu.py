@@ -147,6 +147,16 @@ def test_sedov_conservation_gpu(ctx):
 @pytest.mark.parametrize("reconstruct_eint", [False, True])
 @pytest.mark.parametrize("order", [3, 2, 1])
 def test_fused_stage_equals_reference_shaped_operators(ctx, order, reconstruct_eint, isothermal):
+    _fused_vs_operators(ctx, order, reconstruct_eint, isothermal, 0.0)
+
+
+@pytest.mark.parametrize("order", [3, 1])
+def test_fused_stage_with_artificial_viscosity_equals_operators(ctx, order):
+    """hydro.artificial_viscosity_coefficient > 0 (Colella & Woodward eq. 4.2, hydro_system.hpp:1054-1076) in the fused sweeps"""
+    _fused_vs_operators(ctx, order, False, False, 0.1)
+
+
+def _fused_vs_operators(ctx, order, reconstruct_eint, isothermal, K_visc):
     """Every template combination of the fused stage kernels (reconstruction order x reconstruct_eint x gamma-law /
     isothermal) against the reference-shaped operator chain — which tests/test_hydro_ops_gpu.py pins to the oracle — on a
     random shocked state, two boxes, periodic: both RK stages, new state, stage-1 face fluxes and redo flags bit for bit."""
@@ -166,6 +176,7 @@ def test_fused_stage_equals_reference_shaped_operators(ctx, order, reconstruct_e
     def run(fused):
         sim = HydroSimulation(ctx, geom, tr, bcs, [16, 24, 16], use_fused=fused)
         sim.reconstructionOrder_ = order
+        sim.artificialViscosityK_ = K_visc
         sim.set_initial_conditions(lambda i, j, k: U0[:, k, j, i])
         dt = 2.0e-4
         old, inter, new = sim.state_old_cc_, sim.state_inter_cc_, sim.state_new_cc_
