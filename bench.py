@@ -29,11 +29,11 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 ALG_BYTES = {"k_sweep_x": 128.0, "k_sweep_y": 184.0, "k_sweep_z": 184.0}
 # measured HBM bytes per cell and launch (average of the two RK stages) for 128^3 boxes: rocprofv3 --pmc FETCH_SIZE and
 # --pmc WRITE_SIZE in separate passes, FETCH_SIZE x2 (gfx950 correction, calibrated on a pure streaming kernel), summaries in
-# profiles/round1/v3_sedov256_pmc_*.txt (unchanged since v2).  bench.py cannot collect PMC counters itself; the figure is reported only for the
+# profiles/round1/v4_sedov256_pmc_*.txt (unchanged since v2).  bench.py cannot collect PMC counters itself; the figure is reported only for the
 # profiled box size.  It includes what SURVEY's per-sweep figure leaves out: the stage-1 face fluxes kept for stage 2
 # (56 B), and for k_sweep_z the fused epilogue (old state in, new state + redo flag out).
 PMC_BYTES_PER_CELL = {"k_sweep_x": 198.5, "k_sweep_y": 275.7, "k_sweep_z": 332.2}
-PMC_SOURCE = "profiles/round1/v3_sedov256_pmc_FETCH_SIZE.txt (x2) + v3_sedov256_pmc_WRITE_SIZE.txt"
+PMC_SOURCE = "profiles/round1/v4_sedov256_pmc_FETCH_SIZE.txt (x2) + v4_sedov256_pmc_WRITE_SIZE.txt"
 
 
 def parse():
