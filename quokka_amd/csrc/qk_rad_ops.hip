@@ -371,27 +371,37 @@ int qk_rad_AddFluxesRK2(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int
 		WA4 Un(new_t[b]);
 		RA4 U0(U0_t[b]);
 		RA4 U1(U1_t[b]);
-		RA4 xo(o0[b]);
 		RA4 xn(f0[b]);
 		double cons[NRAD];
+		// The old-state fluxes enter with the weight (0.5 - IMEX_a32), which is exactly 0 for the PD-ARS scheme (a32 = 0.5): the term is
+		// +-0 for finite fluxes and adding it can only change the sign of a zero result — they are not read (12 of the 36 words this kernel
+		// would otherwise stream).  Any other a32 takes the general form.
+		constexpr bool useOld = (0.5 - IMEX_a32) != 0.0;
 #pragma unroll
 		for (int n = 0; n < NRAD; ++n) {
 			const double U_0 = U0(i, j, k, RAD0 + n);
 			const double U_1 = U1(i, j, k, RAD0 + n);
-			double s0 = (dt / dx0) * (xo(i, j, k, n) - xo(i + 1, j, k, n));
+			double s0 = 0.0;
 			double s1 = (dt / dx0) * (xn(i, j, k, n) - xn(i + 1, j, k, n));
+			if (useOld) {
+				RA4 xo(o0[b]);
+				s0 = (dt / dx0) * (xo(i, j, k, n) - xo(i + 1, j, k, n));
+			}
 			if (ndim == 3) {
-				RA4 yo(o1[b]);
-				RA4 zo(o2[b]);
 				RA4 yn(f1[b]);
 				RA4 zn(f2[b]);
-				s0 = s0 + (dt / dx1) * (yo(i, j, k, n) - yo(i, j + 1, k, n));
 				s1 = s1 + (dt / dx1) * (yn(i, j, k, n) - yn(i, j + 1, k, n));
-				s0 = s0 + (dt / dx2) * (zo(i, j, k, n) - zo(i, j, k + 1, n));
 				s1 = s1 + (dt / dx2) * (zn(i, j, k, n) - zn(i, j, k + 1, n));
+				if (useOld) {
+					RA4 yo(o1[b]);
+					RA4 zo(o2[b]);
+					s0 = s0 + (dt / dx1) * (yo(i, j, k, n) - yo(i, j + 1, k, n));
+					s0 = s0 + (dt / dx2) * (zo(i, j, k, n) - zo(i, j, k + 1, n));
+				}
 			}
 			// radiation_system.hpp:758-759
-			cons[n] = (1.0 - IMEX_a32) * U_0 + IMEX_a32 * U_1 + ((0.5 - IMEX_a32) * (s0)) + (0.5 * (s1));
+			cons[n] = useOld ? (1.0 - IMEX_a32) * U_0 + IMEX_a32 * U_1 + ((0.5 - IMEX_a32) * (s0)) + (0.5 * (s1))
+					 : (1.0 - IMEX_a32) * U_0 + IMEX_a32 * U_1 + (0.5 * (s1));
 		}
 		if (!radStateValid(rad, cons)) {
 			amendRadState(rad, cons);
