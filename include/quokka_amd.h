@@ -301,6 +301,9 @@ int qk_SumBoundary_pack(qk_ghost_plan *plan, qk_stream s, int k, const qk_array4
 int qk_SumBoundary_unpack(qk_ghost_plan *plan, qk_stream s, int k, qk_array4 *state, const double *buf);
 /* physical boundaries (after FillBoundary): bcs[ncomp]; dirichlet[dim][side] may be NULL */
 int qk_FillPhysicalBoundary(qk_ghost_plan *plan, qk_stream s, qk_array4 *state, const qk_bcrec *bcs, const qk_dirichlet_face *dirichlet);
+/* fillBoundaryConditions fills state.nComp() components (reference src/simulation.hpp:1755); the radiation substeps read only the radiation
+ * components of the ghost cells: restrict the same-rank copies and the physical BCs that follow to [scomp, scomp + ncomp) (ncomp < 0: all) */
+int qk_ghost_plan_set_components(qk_ghost_plan *plan, int scomp, int ncomp);
 /* Overlap of the exchange with the update (north_star: "FillBoundary ... overlapped with interior-cell updates"; the
  * reference's FillBoundary, src/simulation.hpp:1755, is blocking).  A local box is "remote dependent" if any of its ghost
  * cells is filled from another rank.  The other boxes are complete after qk_FillBoundary_local + the LOCAL_ONLY subset

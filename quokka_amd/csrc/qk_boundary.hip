@@ -55,6 +55,7 @@ struct qk_ghost_plan {
 	int max_shell_cells = 0;
 	int n_shells_indep = 0;
 	std::vector<char> box_remote; // per local box: 1 if any ghost cell of the box is filled from another rank
+	int active_scomp = 0, active_ncomp = -1; // component range of the same-rank copies and the physical BCs (-1: all)
 	qk_bcrec *d_bcs = nullptr;
 	int d_bcs_n = 0;
 	qk_dirichlet_face *d_dir = nullptr;
@@ -74,7 +75,7 @@ enum CopyMode { MODE_LOCAL = 0, MODE_PACK = 1, MODE_UNPACK = 2, MODE_SUM_LOCAL =
 
 // blockIdx.y = item; grid-stride over region cells x ncomp
 template <int MODE, typename T = double, typename D = qk_array4>
-__global__ void __launch_bounds__(256) k_copy(const CopyItem *items, const D *state_t, T *buf, int ncomp)
+__global__ void __launch_bounds__(256) k_copy(const CopyItem *items, const D *state_t, T *buf, int ncomp, int scomp = 0)
 {
 	const CopyItem it = items[blockIdx.y];
 	const int n0 = it.hi[0] - it.lo[0] + 1, n1 = it.hi[1] - it.lo[1] + 1, n2 = it.hi[2] - it.lo[2] + 1;
@@ -91,7 +92,7 @@ __global__ void __launch_bounds__(256) k_copy(const CopyItem *items, const D *st
 		if (MODE == MODE_LOCAL) {
 			A4<T, D> Dst(state_t[it.dst_box]);
 			A4<T, D> Src(state_t[it.src_box]);
-			Dst(di, dj, dk, n) = Src(di - it.shift[0], dj - it.shift[1], dk - it.shift[2], n);
+			Dst(di, dj, dk, scomp + n) = Src(di - it.shift[0], dj - it.shift[1], dk - it.shift[2], scomp + n);
 		} else if (MODE == MODE_PACK) {
 			A4<T, D> Src(state_t[it.src_box]);
 			buf[it.offset + t] = Src(di - it.shift[0], dj - it.shift[1], dk - it.shift[2], n);
@@ -122,7 +123,7 @@ struct PhysBcArgs {
 	int has_dirichlet;
 };
 
-__global__ void __launch_bounds__(256) k_physbc(const CopyItem *items, qk_array4 *state_t, qk_geometry geom, int ncomp, PhysBcArgs pa)
+__global__ void __launch_bounds__(256) k_physbc(const CopyItem *items, qk_array4 *state_t, qk_geometry geom, int ncomp, PhysBcArgs pa, int scomp = 0)
 {
 	const qk_bcrec *bcs = pa.bcs;
 	const qk_dirichlet_face *dirichlet = (pa.has_dirichlet != 0) ? pa.dir : nullptr;
@@ -173,12 +174,12 @@ __global__ void __launch_bounds__(256) k_physbc(const CopyItem *items, qk_array4
 			}
 		}
 		if (df != nullptr) {
-			for (int n = 0; n < ncomp; ++n) {
+			for (int n = scomp; n < scomp + ncomp; ++n) {
 				A(idx[0], idx[1], idx[2], n) = df->values[n];
 			}
 			continue;
 		}
-		for (int n = 0; n < ncomp; ++n) {
+		for (int n = scomp; n < scomp + ncomp; ++n) {
 			const qk_bcrec bc = bcs[n];
 			int src[3] = {idx[0], idx[1], idx[2]};
 			bool neg = false;
@@ -471,8 +472,9 @@ int qk_FillBoundary_local(qk_ghost_plan *plan, qk_stream s, qk_array4 *state_t)
 	if (plan->local.empty()) {
 		return QK_OK;
 	}
-	hipLaunchKernelGGL(k_copy<MODE_LOCAL>, gridFor(static_cast<int64_t>(plan->max_local_cells) * plan->ncomp, static_cast<int>(plan->local.size())),
-			   dim3(256), 0, static_cast<hipStream_t>(s), plan->d_local, state_t, static_cast<double *>(nullptr), plan->ncomp);
+	const int nc = (plan->active_ncomp < 0) ? plan->ncomp : plan->active_ncomp;
+	hipLaunchKernelGGL(k_copy<MODE_LOCAL>, gridFor(static_cast<int64_t>(plan->max_local_cells) * nc, static_cast<int>(plan->local.size())), dim3(256), 0,
+			   static_cast<hipStream_t>(s), plan->d_local, state_t, static_cast<double *>(nullptr), nc, plan->active_scomp);
 	QK_HIP_CHECK(ctx, hipGetLastError());
 	return QK_OK;
 }
@@ -641,6 +643,19 @@ int qk_FillPhysicalBoundary(qk_ghost_plan *plan, qk_stream s, qk_array4 *state_t
 	return qk_FillPhysicalBoundary_subset(plan, s, state_t, bcs, dirichlet, QK_BOXES_ALL);
 }
 
+// Component range of the following qk_FillBoundary_local / qk_FillPhysicalBoundary* calls (ncomp < 0: all components again).  The strips
+// exchanged with other ranks always carry every component.  The radiation substeps only read the radiation components of the ghost cells.
+int qk_ghost_plan_set_components(qk_ghost_plan *plan, int scomp, int ncomp)
+{
+	if (plan == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	QK_REQUIRE(plan->lev->ctx, ncomp < 0 || (scomp >= 0 && ncomp >= 1 && scomp + ncomp <= plan->ncomp), "ghost_plan_set_components: bad range");
+	plan->active_scomp = (ncomp < 0) ? 0 : scomp;
+	plan->active_ncomp = ncomp;
+	return QK_OK;
+}
+
 int qk_FillPhysicalBoundary_subset(qk_ghost_plan *plan, qk_stream s, qk_array4 *state_t, const qk_bcrec *bcs, const qk_dirichlet_face *dirichlet,
 				   int which)
 {
@@ -679,7 +694,7 @@ int qk_FillPhysicalBoundary_subset(qk_ghost_plan *plan, qk_stream s, qk_array4 *
 		return QK_OK;
 	}
 	hipLaunchKernelGGL(k_physbc, gridFor(plan->max_shell_cells, count), dim3(256), 0, static_cast<hipStream_t>(s), plan->d_shells + first, state_t,
-			   plan->geom, plan->ncomp, pa);
+			   plan->geom, (plan->active_ncomp < 0) ? plan->ncomp : plan->active_ncomp, pa, plan->active_scomp);
 	QK_HIP_CHECK(ctx, hipGetLastError());
 	return QK_OK;
 }

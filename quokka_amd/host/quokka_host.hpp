@@ -662,6 +662,14 @@ template <typename problem_t> class AMRSimulation
 		areInitialConditionsDefined_ = true;
 	}
 
+	// fillBoundaryConditions for the radiation transport kernels, which read only the radiation components of the ghost cells
+	void fillRadiationGhosts(amrex::MultiFab &state)
+	{
+		int const first = Physics_Indices<problem_t>::radFirstIndex;
+		qkhost::check(qk_ghost_plan_set_components(plan_, first, state.nComp() - first), "qk_ghost_plan_set_components");
+		fillBoundaryConditions(state);
+		qkhost::check(qk_ghost_plan_set_components(plan_, 0, -1), "qk_ghost_plan_set_components");
+	}
 	// level-0 branch of fillBoundaryConditions (reference src/simulation.hpp:1751-1776)
 	void fillBoundaryConditions(amrex::MultiFab &state)
 	{
@@ -1109,14 +1117,14 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 
 	void advanceRadiationForwardEuler(double dt_radiation) // :1790-1821
 	{
-		this->fillBoundaryConditions(state_old_cc_[0]);
+		this->fillRadiationGhosts(state_old_cc_[0]);
 		RadSystem<problem_t>::computeRadiationFluxes(state_old_cc_[0], radFluxOld_, radiationReconstructionOrder_);
 		RadSystem<problem_t>::PredictStep(state_old_cc_[0], state_new_cc_[0], radFluxOld_, dt_radiation, geom[0].CellSizeArray());
 	}
 
 	void advanceRadiationMidpointRK2(double dt_radiation) // :1823-1857 (the fluxes of the old state are reused, not recomputed)
 	{
-		this->fillBoundaryConditions(state_new_cc_[0]);
+		this->fillRadiationGhosts(state_new_cc_[0]);
 		RadSystem<problem_t>::computeRadiationFluxes(state_new_cc_[0], radFlux_, radiationReconstructionOrder_);
 		RadSystem<problem_t>::AddFluxesRK2(state_new_cc_[0], state_old_cc_[0], state_new_cc_[0], radFluxOld_, radFlux_, dt_radiation, geom[0].CellSizeArray());
 	}

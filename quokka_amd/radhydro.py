@@ -99,15 +99,25 @@ class RadhydroSimulation(HydroSimulation):
                                                      self.radEnergySource.ptr, float(dt), stage, C.c_void_p(self.dev_rad_counter.data_ptr()),
                                                      C.c_void_p(self.dev_rad_failure.data_ptr())), "qk_rad_AddSourceTermsSingleGroup")
 
+    def _fill_rad_ghosts(self, state: MultiFab):
+        """fillBoundaryConditions for the transport kernels, which read only the radiation components of the ghost cells: the same-rank
+        copies and the physical BCs are restricted to them (strips to other ranks carry everything; the reference fills all components)"""
+        L, h = self.ctx.L, self.ghost.h
+        self.ctx.check(L.qk_ghost_plan_set_components(h, RAD0, 4), "qk_ghost_plan_set_components")
+        try:
+            self.fillBoundaryConditions(state)
+        finally:
+            self.ctx.check(L.qk_ghost_plan_set_components(h, 0, -1), "qk_ghost_plan_set_components")
+
     def advanceRadiationForwardEuler(self, dt_radiation: float):
-        self.fillBoundaryConditions(self.state_old_cc_)
+        self._fill_rad_ghosts(self.state_old_cc_)
         self._rad_fluxes(self.state_old_cc_, self.radFluxOld)
         c = self.ctx
         c.check(c.L.qk_rad_PredictStep(self.lev.h, c.stream(), C.byref(self.rad_traits), self.geom.ndim, self.state_old_cc_.ptr, self.state_new_cc_.ptr,
                                        _p3(self.radFluxOld), float(dt_radiation), _d3(self.geom.dx)), "qk_rad_PredictStep")
 
     def advanceRadiationMidpointRK2(self, dt_radiation: float):
-        self.fillBoundaryConditions(self.state_new_cc_)
+        self._fill_rad_ghosts(self.state_new_cc_)
         # fluxes of the old state: identical to the ones of the forward-Euler stage (state_old_cc_ and its ghosts are unchanged)
         self._rad_fluxes(self.state_new_cc_, self.radFlux)
         c = self.ctx
