@@ -215,6 +215,113 @@ template <int DIR, int ORDER> void launchRadFusedFlux(qk_level *lev, qk_stream s
 	});
 }
 
+// Y / Z sweeps: one thread marches a strip of STRIP faces along DIR with a rolling window of cells, so that every cell's primitives and
+// edge states are evaluated once per strip instead of once per face that touches it (the per-face kernel above is FP64-issue bound:
+// 4-6 cons->prim conversions and two reconstructions per face).  Same functions, same operands: identical fluxes.
+template <int DIR, int ORDER, int STRIP>
+__global__ void __launch_bounds__(256) k_rad_flux_march(const qk_box *boxes, Rad rad, const qk_array4 *cons_t, qk_array4 *flux_t, int notb)
+{
+	static_assert(DIR == 1 || DIR == 2, "marching flux kernel: strided directions only");
+	constexpr int OT = 3 - DIR;
+	const int b = blockIdx.z;
+	const qk_box bx = boxes[b];
+	const int i = bx.lo[0] + static_cast<int>(blockIdx.x) * 64 + static_cast<int>(threadIdx.x);
+	const int oblk = static_cast<int>(blockIdx.y) % notb, strip = static_cast<int>(blockIdx.y) / notb;
+	const int ot = bx.lo[OT] + oblk * 4 + static_cast<int>(threadIdx.y);
+	const int f0 = bx.lo[DIR] + strip * STRIP;
+	if (i > bx.hi[0] || ot > bx.hi[OT] || f0 > bx.hi[DIR] + 1) {
+		return;
+	}
+	RA4 U(cons_t[b]);
+	WA4 F(flux_t[b]);
+	constexpr int M0 = (ORDER == 3) ? 0 : (ORDER == 2) ? 1 : 2;
+	constexpr int M1 = (ORDER == 3) ? 5 : (ORDER == 2) ? 4 : 3;
+	double c[6][NRAD], p[6][NRAD]; // cells face-3 .. face+2 along DIR (only M0..M1 are live)
+	double carry[NRAD];	       // PPM: right edge of cell face-1; PLM: its limited slope
+	int pos[3];
+	pos[0] = i;
+	pos[OT] = ot;
+	auto load = [&](int m, int face) {
+		pos[DIR] = face + (m - 3);
+		const int64_t o = U.idx(pos[0], pos[1], pos[2]);
+#pragma unroll
+		for (int n = 0; n < NRAD; ++n) {
+			c[m][n] = U.p[o + U.ns * (RAD0 + n)];
+		}
+		radPrim(rad, c[m], p[m]);
+	};
+	const int nface = min(STRIP, bx.hi[DIR] + 1 - f0 + 1);
+	for (int sI = 0; sI < nface; ++sI) {
+		const int face = f0 + sI;
+		if (sI == 0) {
+#pragma unroll
+			for (int m = M0; m <= M1; ++m) {
+				load(m, face);
+			}
+#pragma unroll
+			for (int n = 0; n < NRAD; ++n) {
+				if (ORDER == 3) {
+					double am, ap;
+					ppmEdges(p[0][n], p[1][n], p[2][n], p[3][n], p[4][n], am, ap);
+					carry[n] = ap;
+				} else if (ORDER == 2) {
+					carry[n] = MC(p[3][n] - p[2][n], p[2][n] - p[1][n]);
+				}
+			}
+		} else {
+#pragma unroll
+			for (int m = M0; m < M1; ++m) {
+#pragma unroll
+				for (int n = 0; n < NRAD; ++n) {
+					c[m][n] = c[m + 1][n];
+					p[m][n] = p[m + 1][n];
+				}
+			}
+			load(M1, face);
+		}
+		double pL[NRAD], pR[NRAD], Fo[NRAD];
+#pragma unroll
+		for (int n = 0; n < NRAD; ++n) {
+			if (ORDER == 3) {
+				double am, ap;
+				ppmEdges(p[1][n], p[2][n], p[3][n], p[4][n], p[5][n], am, ap); // cell `face`
+				pL[n] = carry[n];
+				pR[n] = am;
+				carry[n] = ap;
+			} else if (ORDER == 2) {
+				const double rslope = MC(p[4][n] - p[3][n], p[3][n] - p[2][n]); // slope of cell `face`
+				pL[n] = p[2][n] + 0.25 * carry[n];
+				pR[n] = p[3][n] - 0.25 * rslope;
+				carry[n] = rslope;
+			} else {
+				pL[n] = p[2][n];
+				pR[n] = p[3][n];
+			}
+		}
+		radFaceFlux<DIR>(rad, pL, pR, c[2], c[3], Fo);
+		pos[DIR] = face;
+		const int64_t o = F.idx(pos[0], pos[1], pos[2]);
+#pragma unroll
+		for (int n = 0; n < NRAD; ++n) {
+			F.p[o + F.ns * n] = Fo[n];
+		}
+	}
+}
+
+template <int DIR, int ORDER> void launchRadMarchFlux(qk_level *lev, qk_stream s, Rad rad, const qk_array4 *cons_t, qk_array4 *flux_t)
+{
+	if (lev->nboxes == 0) {
+		return;
+	}
+	constexpr int STRIP = 8;
+	constexpr int OT = 3 - DIR;
+	const int notb = (lev->maxlen[OT] + 3) / 4;
+	const int nstrips = (lev->maxlen[DIR] + 1 + STRIP - 1) / STRIP;
+	const dim3 grid((lev->maxlen[0] + 63) / 64, notb * nstrips, lev->nboxes);
+	ProfScope ps(lev->ctx, static_cast<hipStream_t>(s), "rad_fluxFunction");
+	hipLaunchKernelGGL((k_rad_flux_march<DIR, ORDER, STRIP>), grid, dim3(64, 4), 0, static_cast<hipStream_t>(s), lev->d_boxes, rad, cons_t, flux_t, notb);
+}
+
 } // namespace
 
 extern "C" {
@@ -298,11 +405,20 @@ int qk_rad_computeRadiationFluxes(qk_level *lev, qk_stream s, const qk_rad_trait
 		launchRadFusedFlux<D, 1>(lev, s, rad, cons_t, flux[D]);                                                                              \
 	}
 	QK_RAD_DIR(0)
-	if (ndim == 3) {
-		QK_RAD_DIR(1)
-		QK_RAD_DIR(2)
-	}
 #undef QK_RAD_DIR
+#define QK_RAD_MARCH(D)                                                                                                                              \
+	if (order == 3) {                                                                                                                            \
+		launchRadMarchFlux<D, 3>(lev, s, rad, cons_t, flux[D]);                                                                              \
+	} else if (order == 2) {                                                                                                                     \
+		launchRadMarchFlux<D, 2>(lev, s, rad, cons_t, flux[D]);                                                                              \
+	} else {                                                                                                                                     \
+		launchRadMarchFlux<D, 1>(lev, s, rad, cons_t, flux[D]);                                                                              \
+	}
+	if (ndim == 3) {
+		QK_RAD_MARCH(1)
+		QK_RAD_MARCH(2)
+	}
+#undef QK_RAD_MARCH
 	return radStatus(lev, "computeRadiationFluxes");
 }
 
