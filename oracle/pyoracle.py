@@ -291,6 +291,10 @@ class OracleSim:
     def evolve(self) -> bool:
         return bool(self.o.lib.orc_sim_evolve(self.h))
 
+    def set_rad_reconstruction_order(self, order: int):
+        self.o.lib.orc_sim_set_rad_reconstruction_order.argtypes = [C.c_void_p, C.c_int]
+        self.o.lib.orc_sim_set_rad_reconstruction_order(self.h, int(order))
+
     def run_record(self, nsteps: int, b=0, cell=(0, 0, 0)):
         """nsteps steps; returns (times, states[nsteps, ncomp]) of one valid cell after every step"""
         t = np.zeros(nsteps)

@@ -308,6 +308,99 @@ __global__ void __launch_bounds__(256) k_rad_flux_march(const qk_box *boxes, Rad
 	}
 }
 
+// X sweep: one thread per cell of a flat slab (rows j = lo.y .. hi.y of plane k are contiguous, ghost cells included), primitives and
+// edge states exchanged through LDS, each thread evaluates the flux at the left face of its cell: one cons->prim and one reconstruction per
+// cell instead of 4-6 and 2 per face.  250 faces per 256-thread workgroup (3 halo cells on each side).  Same functions, same operands.
+constexpr int RXB = 256, RXOUT = 250;
+
+template <int ORDER> __global__ void __launch_bounds__(RXB) k_rad_flux_x(const qk_box *boxes, Rad rad, const qk_array4 *cons_t, qk_array4 *flux_t)
+{
+	__shared__ double s_p[NRAD][RXB]; // primitives
+	__shared__ double s_e[NRAD][RXB]; // PPM: right edge a_plus of the cell; PLM: its limited slope
+	__shared__ double s_c[NRAD][RXB]; // conserved radiation state (the first-order fallback of the HLL flux needs it)
+	const int b = blockIdx.z;
+	const qk_box bx = boxes[b];
+	const int k = bx.lo[2] + static_cast<int>(blockIdx.y);
+	if (k > bx.hi[2]) {
+		return; // uniform for the workgroup
+	}
+	RA4 U(cons_t[b]);
+	const int t = threadIdx.x;
+	const int64_t rowlen = U.js; // x extent of the array, ghost cells included
+	const int64_t slablen = rowlen * (bx.hi[1] - bx.lo[1] + 1);
+	const int64_t f = static_cast<int64_t>(blockIdx.x) * RXOUT + t - 3; // flat position inside the slab of plane k
+	const bool inside = (f >= 0) && (f < slablen);
+	const int64_t fc = inside ? f : 0;
+	const int jj = static_cast<int>(fc / rowlen);
+	const int i = U.bx + static_cast<int>(fc - jj * rowlen);
+	const int j = bx.lo[1] + jj;
+	const int64_t o = U.idx(i, j, k);
+	double c0[NRAD], p0[NRAD];
+#pragma unroll
+	for (int n = 0; n < NRAD; ++n) {
+		c0[n] = U.p[o + U.ns * (RAD0 + n)];
+	}
+	radPrim(rad, c0, p0);
+#pragma unroll
+	for (int n = 0; n < NRAD; ++n) {
+		s_c[n][t] = c0[n];
+		s_p[n][t] = p0[n];
+	}
+	__syncthreads();
+	const int tm2 = max(t - 2, 0), tm1 = max(t - 1, 0), tp1 = min(t + 1, RXB - 1), tp2 = min(t + 2, RXB - 1);
+	double edgeL[NRAD]; // left edge state of my cell = rightState of my left face
+#pragma unroll
+	for (int n = 0; n < NRAD; ++n) {
+		if (ORDER == 3) {
+			double am, ap;
+			ppmEdges(s_p[n][tm2], s_p[n][tm1], p0[n], s_p[n][tp1], s_p[n][tp2], am, ap);
+			edgeL[n] = am;
+			s_e[n][t] = ap;
+		} else if (ORDER == 2) {
+			const double slope = MC(s_p[n][tp1] - p0[n], p0[n] - s_p[n][tm1]); // hyperbolic_system.hpp:243-246, MC limiter
+			edgeL[n] = p0[n] - 0.25 * slope;
+			s_e[n][t] = slope;
+		} else {
+			edgeL[n] = p0[n];
+		}
+	}
+	__syncthreads();
+	const bool isFace = inside && (i >= bx.lo[0]) && (i <= bx.hi[0] + 1) && (t >= 3) && (t <= RXB - 3);
+	if (!isFace) {
+		return;
+	}
+	double pL[NRAD], cL[NRAD], Fo[NRAD];
+#pragma unroll
+	for (int n = 0; n < NRAD; ++n) {
+		cL[n] = s_c[n][tm1];
+		if (ORDER == 3) {
+			pL[n] = s_e[n][tm1];
+		} else if (ORDER == 2) {
+			pL[n] = s_p[n][tm1] + 0.25 * s_e[n][tm1];
+		} else {
+			pL[n] = s_p[n][tm1];
+		}
+	}
+	radFaceFlux<0>(rad, pL, edgeL, cL, c0, Fo);
+	WA4 F(flux_t[b]);
+	const int64_t of = F.idx(i, j, k);
+#pragma unroll
+	for (int n = 0; n < NRAD; ++n) {
+		F.p[of + F.ns * n] = Fo[n];
+	}
+}
+
+template <int ORDER> void launchRadXFlux(qk_level *lev, qk_stream s, Rad rad, const qk_array4 *cons_t, qk_array4 *flux_t, int nghost)
+{
+	if (lev->nboxes == 0) {
+		return;
+	}
+	const int64_t slab = static_cast<int64_t>(lev->maxlen[0] + 2 * nghost) * lev->maxlen[1];
+	const dim3 grid(static_cast<unsigned>((slab + RXOUT - 1) / RXOUT), static_cast<unsigned>(lev->maxlen[2]), static_cast<unsigned>(lev->nboxes));
+	ProfScope ps(lev->ctx, static_cast<hipStream_t>(s), "rad_fluxFunction");
+	hipLaunchKernelGGL((k_rad_flux_x<ORDER>), grid, dim3(RXB), 0, static_cast<hipStream_t>(s), lev->d_boxes, rad, cons_t, flux_t);
+}
+
 template <int DIR, int ORDER> void launchRadMarchFlux(qk_level *lev, qk_stream s, Rad rad, const qk_array4 *cons_t, qk_array4 *flux_t)
 {
 	if (lev->nboxes == 0) {
@@ -404,7 +497,17 @@ int qk_rad_computeRadiationFluxes(qk_level *lev, qk_stream s, const qk_rad_trait
 	} else {                                                                                                                                     \
 		launchRadFusedFlux<D, 1>(lev, s, rad, cons_t, flux[D]);                                                                              \
 	}
-	QK_RAD_DIR(0)
+	if (ndim == 3) { // (state arrays carry nghost_cc = 4 ghost cells throughout the library; the slab below is sized for that)
+		if (order == 3) {
+			launchRadXFlux<3>(lev, s, rad, cons_t, flux[0], 4);
+		} else if (order == 2) {
+			launchRadXFlux<2>(lev, s, rad, cons_t, flux[0], 4);
+		} else {
+			launchRadXFlux<1>(lev, s, rad, cons_t, flux[0], 4);
+		}
+	} else {
+		QK_RAD_DIR(0)
+	}
 #undef QK_RAD_DIR
 #define QK_RAD_MARCH(D)                                                                                                                              \
 	if (order == 3) {                                                                                                                            \

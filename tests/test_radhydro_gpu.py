@@ -58,10 +58,13 @@ def test_shell_generators_match_oracle(ctx, oracle):
         assert np.allclose(so.rad_source(b, 0.0), sg.radEnergySource.fabs[b][0].cpu().numpy(), rtol=1e-13, atol=0.0)
 
 
-@pytest.mark.parametrize("mgs", [16, 8])
-def test_radhydro_steps_bit_exact_with_shared_pow(ctx, oracle, mgs):
+@pytest.mark.parametrize("mgs,rad_order", [(16, 2), (8, 2), (8, 3), (16, 1)])
+def test_radhydro_steps_bit_exact_with_shared_pow(ctx, oracle, mgs, rad_order):
+    """(rad_order: the problem uses PLM = 2; 3 and 1 exercise the PPM and donor-cell variants of the three flux kernels in 3-D)"""
     N, nsteps = 16, 3
     so, sg = make_pair(ctx, oracle, N, mgs, 1)
+    so.set_rad_reconstruction_order(rad_order)
+    sg.radiationReconstructionOrder_ = rad_order
     seed_from_oracle(so, sg)
     for it in range(nsteps):
         assert so.step() and sg.step()
