@@ -166,6 +166,9 @@ void *orc_sim_create(orc_sim_config const *c)
 		p.dirichlet = c->h1d_i[1];
 		p.max_timesteps = c->max_timesteps >= 0 ? c->max_timesteps : 100000;
 		setupHydro1D(*sim, p);
+	} else if (c->problem == 10) {
+		setupUniformAdvecting(*sim);
+		sim->rad.rt.pow_mode = c->rad_pow_mode;
 	} else if (c->problem == 6) {
 		setupScalarContact(*sim, c->nscalars > 0 ? c->nscalars : 1);
 	} else if (c->problem == 5) {
@@ -176,6 +179,9 @@ void *orc_sim_create(orc_sim_config const *c)
 		sim->rad.rt.pow_mode = c->rad_pow_mode;
 	} else {
 		return nullptr;
+	}
+	if ((c->problem == 4 || c->problem == 10) && c->h1d_i[0] > 0) {
+		sim->rad.rt.beta_order = c->h1d_i[0]; // parity variants: the same problem with the O(beta^n) terms of another order
 	}
 	if (c->cfl > 0) {
 		sim->cflNumber_ = c->cfl;

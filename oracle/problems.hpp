@@ -941,6 +941,71 @@ inline void setupSuOlson(HydroSim &sim)
 	sim.finishInitialConditions();
 }
 
+
+// ---------------------------------------------------------------- uniformly advecting radiating gas
+// src/problems/RadhydroUniformAdvecting/test_radhydro_uniform_advecting.cpp
+struct AdvectingConstants { // "model 3" :44-57
+	static constexpr double c = 1.0e8;
+	static constexpr int beta_order = 2;
+	static constexpr double v0 = 1e-2 * c;
+	static constexpr double kappa0 = 1.0e5;
+	static constexpr double chat = 1.0e8;
+	static constexpr double T0 = 1.0, rho0 = 1.0, a_rad = 1.0, mu = 1.0, k_B = 1.0;
+	static constexpr double max_time = 10.0 / v0;
+	static constexpr double Erad0 = a_rad * T0 * T0 * T0 * T0;
+	static constexpr double Erad_beta2 = (1. + 4. / 3. * (v0 * v0) / (c * c)) * Erad0;
+};
+
+inline void setupUniformAdvecting(HydroSim &sim)
+{
+	using S = AdvectingConstants;
+	sim.hydro.tr.eos.tr.gamma = 5. / 3.; // :59-77
+	sim.hydro.tr.eos.tr.mean_molecular_weight = S::mu;
+	sim.hydro.tr.eos.tr.boltzmann_constant = S::k_B;
+	sim.hydro.tr.reconstruct_eint = true;
+	sim.hydro.tr.nscalars = 0;
+	sim.ncomp_cc = kNumHydroVars + kNumRadVars;
+	sim.is_radiation_enabled = true;
+	sim.rad.rt.c_light = S::c;
+	sim.rad.rt.c_hat = S::chat;
+	sim.rad.rt.radiation_constant = S::a_rad;
+	sim.rad.rt.Erad_floor = 0.;
+	sim.rad.rt.beta_order = S::beta_order;
+	sim.rad.eos = sim.hydro.tr.eos;
+	sim.rad.ndim = sim.geom.ndim;
+	sim.rad.nstartHyperbolic_ = kNumHydroVars;
+	sim.rad.ComputePlanckOpacity = [](double, double) { return S::kappa0; };
+	sim.rad.ComputeFluxMeanOpacity = [](double, double) { return S::kappa0; };
+	sim.rad.ComputeEnergyMeanOpacity = [](double, double) { return S::kappa0; };
+	// problem_main :139-165
+	sim.BCs_cc.assign(sim.ncomp_cc, BCRec{}); // int_dir on every face: periodic
+	sim.radiationReconstructionOrder_ = 3;
+	sim.stopTime_ = S::max_time;
+	sim.radiationCflNumber_ = 8.0;
+	sim.cflNumber_ = 0.8;
+	sim.maxDt_ = 1.0;
+	sim.maxTimesteps_ = 1000000;
+	sim.define();
+	// setInitialConditionsOnGrid :84-126 (the beta_order_ == 2 branch)
+	EOS const eos = sim.hydro.tr.eos;
+	double const Egas = eos.ComputeEintFromTgas(S::rho0, S::T0);
+	double const erad = S::Erad_beta2;
+	double const frad = 4. / 3. * S::v0 * S::Erad0;
+	forEachValidCell(sim, [&](Array4<double> const &state_cc, int i, int j, int k) {
+		state_cc(i, j, k, kNumHydroVars + 0) = erad;
+		state_cc(i, j, k, kNumHydroVars + 1) = frad;
+		state_cc(i, j, k, kNumHydroVars + 2) = 0;
+		state_cc(i, j, k, kNumHydroVars + 3) = 0;
+		state_cc(i, j, k, energy_index) = Egas + 0.5 * S::rho0 * S::v0 * S::v0;
+		state_cc(i, j, k, density_index) = S::rho0;
+		state_cc(i, j, k, internalEnergy_index) = Egas;
+		state_cc(i, j, k, x1Momentum_index) = S::v0 * S::rho0;
+		state_cc(i, j, k, x2Momentum_index) = 0.;
+		state_cc(i, j, k, x3Momentum_index) = 0.;
+	});
+	sim.finishInitialConditions();
+}
+
 } // namespace oracle
 
 #endif // ORACLE_PROBLEMS_HPP_

@@ -292,14 +292,14 @@ class RadShockConstants:
     Lx = 0.01575
 
 
-def radshock_problem(ctx: Context, nx: int = 512, pow_mode: int = 0) -> RadhydroSimulation:
+def radshock_problem(ctx: Context, nx: int = 512, pow_mode: int = 0, beta_order: int = 1) -> RadhydroSimulation:
     """reference src/problems/RadhydroShockCGS/test_radhydro_shock_cgs.cpp + tests/radshock.in (1-D build): a steady subcritical
     radiative shock; Eddington approximation, constant absorption coefficient, constant states beyond both x faces."""
     S = RadShockConstants
     geom = Geometry(1, [nx], [0.0, 0.0, 0.0], [S.Lx, 1.0, 1.0], [0, 1, 1])
     bcs = [([capi.BC_EXT_DIR, 0, 0], [capi.BC_EXT_DIR, 0, 0]) for _ in range(10)]
     traits = capi.traits(S.gamma_gas, True, 1, mean_molecular_weight=S.m_p + S.m_e, boltzmann_constant=S.k_B)
-    rt = capi.RadTraits(S.c, S.chat, S.a_rad, 0.0, 1, 1, S.kappa, S.kappa, S.kappa, pow_mode, 1)
+    rt = capi.RadTraits(S.c, S.chat, S.a_rad, 0.0, beta_order, 1, S.kappa, S.kappa, S.kappa, pow_mode, 1)  # reference: beta_order 1
     pxL, pxR = S.rho0 * S.v0, S.rho1 * S.v1
     left = [S.rho0, pxL, 0.0, 0.0, S.Egas0 + (pxL * pxL) / (2 * S.rho0), S.Egas0, S.Erad0, 0.0, 0.0, 0.0]
     right = [S.rho1, pxR, 0.0, 0.0, S.Egas1 + (pxR * pxR) / (2 * S.rho1), S.Egas1, S.Erad1, 0.0, 0.0, 0.0]
@@ -427,6 +427,42 @@ def matter_coupling_problem(ctx: Context, n: int = 4, pow_mode: int = 0) -> Radh
     def ic(i, j, k):
         U = np.zeros((10,) + i.shape)
         U[0], U[4], U[5], U[6] = S.rho0, S.Egas0, S.Egas0, S.Erad0
+        return U
+
+    sim.set_initial_conditions(ic)
+    return sim
+
+
+class AdvectingConstants:
+    """reference src/problems/RadhydroUniformAdvecting/test_radhydro_uniform_advecting.cpp:44-57 ("model 3")"""
+    c = 1.0e8
+    chat = 1.0e8
+    v0 = 1e-2 * c
+    kappa0 = 1.0e5
+    T0 = rho0 = a_rad = mu = k_B = 1.0
+    max_time = 10.0 / v0
+    Erad0 = a_rad * T0 * T0 * T0 * T0
+    Erad_beta2 = (1.0 + 4.0 / 3.0 * (v0 * v0) / (c * c)) * Erad0
+
+
+def uniform_advecting_problem(ctx: Context, nx: int = 64, pow_mode: int = 0) -> RadhydroSimulation:
+    """reference src/problems/RadhydroUniformAdvecting/test_radhydro_uniform_advecting.cpp + tests/RadhydroUniformAdvecting.in (1-D
+    build): gas and radiation in equilibrium advect at 0.01 c through a periodic box with beta_order = 2; T_gas must stay at T0."""
+    S = AdvectingConstants
+    geom = Geometry(1, [nx], [0.0, 0.0, 0.0], [64.0, 1.0, 1.0], [1, 1, 1])
+    bcs = [([capi.BC_INT_DIR, 0, 0], [capi.BC_INT_DIR, 0, 0]) for _ in range(10)]
+    traits = capi.traits(5.0 / 3.0, True, 1, mean_molecular_weight=S.mu, boltzmann_constant=S.k_B)
+    rt = capi.RadTraits(S.c, S.chat, S.a_rad, 0.0, 2, 0, S.kappa0, S.kappa0, S.kappa0, pow_mode, 0)
+    sim = RadhydroSimulation(ctx, geom, traits, rt, bcs, [nx, 1, 1], use_fused=False)
+    sim.radiationReconstructionOrder_ = 3  # problem_main :139-165
+    sim.stopTime_, sim.radiationCflNumber_, sim.cflNumber_, sim.maxDt_, sim.maxTimesteps_ = S.max_time, 8.0, 0.8, 1.0, 1000000
+    Egas = S.rho0 * S.T0 * S.k_B / S.mu / ((5.0 / 3.0 - 1.0) * S.rho0) * S.rho0  # EOS.hpp:116-159 with the gamma-law network
+
+    def ic(i, j, k):  # setInitialConditionsOnGrid :84-126, the beta_order_ == 2 branch
+        U = np.zeros((10,) + i.shape)
+        U[0], U[1] = S.rho0, S.v0 * S.rho0
+        U[4], U[5] = Egas + 0.5 * S.rho0 * S.v0 * S.v0, Egas
+        U[6], U[7] = S.Erad_beta2, 4.0 / 3.0 * S.v0 * S.Erad0
         return U
 
     sim.set_initial_conditions(ic)

@@ -192,6 +192,17 @@ def test_streaming_executable_meets_the_reference_criterion(tmp_path):
     assert np.array_equal(data.reshape(10, 1000)[0], np.ones(1000))
 
 
+def test_uniform_advecting_executable_matches_oracle(tmp_path, oracle):
+    """the reference's RadhydroUniformAdvecting ctest through the C++ mirror (beta_order = 2, radiation CFL 8, periodic): exit status
+    0 == T_gas within 1e-10 of T0; the final state equals the oracle's bit for bit."""
+    from oracle.pyoracle import ADVECTING
+    data, meta, out = run("test_radhydro_uniform_advecting", [os.path.join(HOST, "decks", "RadhydroUniformAdvecting.in")], tmp_path)
+    assert int(meta[0]) == 125 and meta[5] < 1.0e-10, meta
+    so = oracle.sim(ADVECTING, 1, [64, 1, 1], [0, 0, 0], [64.0, 1, 1], [1, 1, 1], max_grid_size=[64, 1, 1], rad_pow_mode=1)
+    assert so.evolve() and so.time == meta[1]
+    assert np.array_equal(data.reshape(10, 64), so.valid(0).reshape(10, 64))
+
+
 def test_passive_scalar_executable_meets_the_reference_criteria(tmp_path):
     """the reference's PassiveScalar ctest (tests/PassiveScalar.in: one refined level on the density gradient, subcycled, refluxed;
     src/problems/PassiveScalar/test_scalars.cpp): scalar conserved to 1e-14 and relative rms L1 error <= 0.008 after four box

@@ -229,3 +229,29 @@ def test_su_olson_source_problem_meets_the_reference_criterion(oracle):
     assert suolson_error(U) < 0.03
     Eint = U[4] - (U[1] * U[1]) / (2.0 * U[0])
     assert abs((Eint.sum() + U[6].sum()) * 0.02 - 5.0) < 0.01
+
+
+def advecting_error(U):
+    """RadhydroUniformAdvecting's error norm (test_radhydro_uniform_advecting.cpp:184-226): relative L1 of T_gas / T0 against 1, T_gas
+    from the internal-energy component with gamma = 5/3, mu = k_B = 1: T = (gamma - 1) E_int / rho."""
+    T = (5.0 / 3.0 - 1.0) * U[5, 0, 0] / U[0, 0, 0]
+    return float(np.abs(T - 1.0).sum() / T.size)
+
+
+def test_uniformly_advecting_radiating_gas_stays_in_equilibrium(oracle):
+    """RadhydroUniformAdvecting (src/problems/RadhydroUniformAdvecting/test_radhydro_uniform_advecting.cpp:139-229): gas in thermal
+    equilibrium with its radiation moves at 0.01 c through a periodic box, kappa = 1e5, beta_order = 2, radiation CFL 8.  With the
+    O(beta^2) terms kept the lab-frame moments (E = (1 + 4/3 beta^2) E0, F = 4/3 v E0) are an exact steady state of the
+    exchange step, so T_gas must stay at T0 to 1e-10 ("to machine accuracy") over ten crossing times.  Pins the beta_order = 2
+    branches of the Newton-Raphson exchange and of the work terms, which no other known-answer test reaches."""
+    from oracle.pyoracle import ADVECTING
+    s = oracle.sim(ADVECTING, 1, [64, 1, 1], [0, 0, 0], [64.0, 1, 1], [1, 1, 1], max_grid_size=[64, 1, 1])
+    assert s.evolve()
+    # dt = 0.8 dx / max(c_hat / maxSubsteps, |v| + c_s) = 8e-8 (QuokkaSimulation.hpp:421-434): 125 steps, one radiation substep each
+    assert abs(s.time - 1.0e-5) < 1e-20 and s.istep == 125
+    c = s.rad_counters()
+    assert c["fail_coupling"] == c["fail_outer"] == 0
+    U = s.valid(0)
+    err = advecting_error(U)
+    assert err < 1.0e-10, err
+    assert np.allclose(U[1, 0, 0] / U[0, 0, 0], 1.0e6, rtol=1e-10, atol=0)  # still moving at v0

@@ -169,3 +169,35 @@ def test_su_olson_and_matter_coupling_match_oracle(ctx, oracle):
         assert so.step() and sg.step()
     assert sg.dt_ == 1.0e-8 and np.array_equal(so.valid(0), sg.state_new_cc_.valid(0).cpu().numpy())
     assert sg.state_new_cc_.valid(0)[4, 0, 0, 1].item() > 1.0e4  # the gas has heated by orders of magnitude
+
+
+def test_uniform_advecting_beta_order_2_matches_oracle(ctx, oracle):
+    """RadhydroUniformAdvecting through the C-ABI: the whole run (125 steps) of the reference problem bit for bit and within its
+    1e-10 criterion.  The uniform state sits at the fixed point of the O(beta^2) terms, so the same terms are also compared on a
+    state with gradients: the radiative shock with RadSystem_Traits::beta_order overridden to 2 and to 3, 120 steps each."""
+    from oracle.pyoracle import ADVECTING, RADSHOCK
+    from quokka_amd.radhydro import radshock_problem, uniform_advecting_problem
+    so = oracle.sim(ADVECTING, 1, [64, 1, 1], [0, 0, 0], [64.0, 1, 1], [1, 1, 1], max_grid_size=[64, 1, 1], rad_pow_mode=1)
+    sg = uniform_advecting_problem(ctx, 64, pow_mode=1)
+    assert np.array_equal(so.valid(0), sg.state_new_cc_.valid(0).cpu().numpy())
+    assert so.evolve() and sg.evolve()
+    assert so.istep == sg.istep_ == 125 and so.time == sg.tNew_
+    U = sg.state_new_cc_.valid(0).cpu().numpy()
+    assert np.array_equal(so.valid(0), U)
+    T = (5.0 / 3.0 - 1.0) * U[5, 0, 0] / U[0, 0, 0]
+    assert float(np.abs(T - 1.0).sum() / T.size) < 1.0e-10
+
+    ref = None
+    for beta_order in (1, 2, 3):
+        so = oracle.sim(RADSHOCK, 1, [256, 1, 1], [0, 0, 0], [0.01575, 1, 1], [0, 1, 1], max_grid_size=[256, 1, 1], rad_pow_mode=1,
+                        beta_order=beta_order)
+        sg = radshock_problem(ctx, 256, pow_mode=1, beta_order=beta_order)
+        for it in range(120):
+            assert so.step() and sg.step()
+            assert so.dt == sg.dt_, (beta_order, it, so.dt, sg.dt_)
+        U = sg.state_new_cc_.valid(0).cpu().numpy()
+        assert np.array_equal(so.valid(0), U), beta_order
+        if ref is None:
+            ref = U
+        else:
+            assert not np.array_equal(ref, U)  # the higher-order terms did act
