@@ -456,7 +456,11 @@ def uniform_advecting_problem(ctx: Context, nx: int = 64, pow_mode: int = 0) -> 
     sim = RadhydroSimulation(ctx, geom, traits, rt, bcs, [nx, 1, 1], use_fused=False)
     sim.radiationReconstructionOrder_ = 3  # problem_main :139-165
     sim.stopTime_, sim.radiationCflNumber_, sim.cflNumber_, sim.maxDt_, sim.maxTimesteps_ = S.max_time, 8.0, 0.8, 1.0, 1000000
-    Egas = S.rho0 * S.T0 * S.k_B / S.mu / ((5.0 / 3.0 - 1.0) * S.rho0) * S.rho0  # EOS.hpp:116-159 with the gamma-law network
+    # quokka::EOS::ComputeEintFromTgas (EOS.hpp:116-159) with the gamma-law network, in its order of operations (the CGS constants cancel
+    # up to rounding, which the bit-for-bit comparison sees)
+    mu_ = S.mu / capi.M_U
+    pres = S.rho0 * S.T0 * capi.K_B / (mu_ * capi.M_U)
+    Egas = pres / ((5.0 / 3.0 - 1.0) * S.rho0) * S.rho0 * S.k_B / capi.K_B
 
     def ic(i, j, k):  # setInitialConditionsOnGrid :84-126, the beta_order_ == 2 branch
         U = np.zeros((10,) + i.shape)

@@ -181,7 +181,7 @@ def test_uniform_advecting_beta_order_2_matches_oracle(ctx, oracle):
     sg = uniform_advecting_problem(ctx, 64, pow_mode=1)
     assert np.array_equal(so.valid(0), sg.state_new_cc_.valid(0).cpu().numpy())
     assert so.evolve() and sg.evolve()
-    assert so.istep == sg.istep_ == 125 and so.time == sg.tNew_
+    assert so.istep == sg.istep == 125 and so.time == sg.tNew_
     U = sg.state_new_cc_.valid(0).cpu().numpy()
     assert np.array_equal(so.valid(0), U)
     T = (5.0 / 3.0 - 1.0) * U[5, 0, 0] / U[0, 0, 0]
