@@ -263,10 +263,18 @@ typedef struct qk_bcrec {
 	int hi[3];
 } qk_bcrec; /* == amrex::BCRec per component */
 
-/* user functor model: cells beyond face (dim,side) get the constant state `values[ncomp]` (all comps) */
+/* user functor model (closed set): cells beyond face (dim,side) get the constant state `values[ncomp]` (all comps).
+ * marshak != 0 (lower faces only): the Marshak half-range condition of the reference's RadMarshak family
+ * (src/problems/RadMarshak/test_radiation_marshak.cpp:125-141): after the constant state, the normal radiation flux of the ghost cell
+ * becomes  0.5 c E_inc - 0.5 (c E_0 + 2 F_0)  with E_inc = values[marshak_energy_comp] and (E_0, F_0) = components
+ * (marshak_energy_comp, marshak_flux_comp) of the first valid cell inside the face (same transverse indices). */
 typedef struct qk_dirichlet_face {
 	int enabled;
 	double values[16];
+	int marshak;
+	int marshak_energy_comp;
+	int marshak_flux_comp;
+	double marshak_c;
 } qk_dirichlet_face;
 
 typedef struct qk_ghost_plan qk_ghost_plan;

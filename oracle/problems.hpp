@@ -1006,6 +1006,97 @@ inline void setupUniformAdvecting(HydroSim &sim)
 	sim.finishInitialConditions();
 }
 
+
+// ---------------------------------------------------------------- Marshak wave of Su & Olson (1996) (src/problems/RadMarshak/test_radiation_marshak.cpp)
+struct MarshakConstants { // :22-31
+	static constexpr double eps_SuOlson = 1.0, kappa = 1.0, rho0 = 1.0, T_hohlraum = 1.0, a_rad = 1.0, c = 1.0;
+	static constexpr double alpha_SuOlson = 4.0 * a_rad / eps_SuOlson;
+	static constexpr double T_initial = 1.0e-2;
+};
+
+inline void setupMarshak(HydroSim &sim)
+{
+	using S = MarshakConstants;
+	sim.hydro.tr.eos.tr.gamma = 5. / 3.; // :33-37
+	sim.hydro.tr.eos.tr.mean_molecular_weight = 1.0;
+	sim.hydro.tr.eos.tr.boltzmann_constant = 1.0;
+	sim.hydro.tr.eos.tr.temperature_model = 1; // :69-99
+	sim.hydro.tr.eos.tr.alpha = S::alpha_SuOlson;
+	sim.hydro.tr.reconstruct_eint = true;
+	sim.hydro.tr.nscalars = 0;
+	sim.ncomp_cc = kNumHydroVars + kNumRadVars;
+	sim.is_radiation_enabled = true; // :47-57
+	sim.is_hydro_enabled = false;
+	sim.rad.rt.c_light = S::c; // :39-45
+	sim.rad.rt.c_hat = S::c;
+	sim.rad.rt.radiation_constant = S::a_rad;
+	sim.rad.rt.Erad_floor = 0.;
+	sim.rad.rt.beta_order = 0;
+	sim.rad.eos = sim.hydro.tr.eos;
+	sim.rad.ndim = sim.geom.ndim;
+	sim.rad.nstartHyperbolic_ = kNumHydroVars;
+	sim.rad.ComputePlanckOpacity = [](double, double) { return S::kappa; }; // :59-67
+	sim.rad.ComputeFluxMeanOpacity = [](double, double) { return S::kappa; };
+	sim.rad.ComputeEnergyMeanOpacity = [](double, double) { return S::kappa; };
+	// problem_main :185-218
+	sim.BCs_cc.assign(sim.ncomp_cc, BCRec{});
+	for (int n = 0; n < sim.ncomp_cc; ++n) {
+		sim.BCs_cc[n].lo[0] = ext_dir;
+		sim.BCs_cc[n].hi[0] = foextrap;
+	}
+	double const chi = S::rho0 * S::kappa;
+	sim.radiationCflNumber_ = 0.4;
+	sim.stopTime_ = 10.0 / (S::eps_SuOlson * S::c * chi);
+	sim.maxDt_ = 1e-3 / (S::eps_SuOlson * S::c * chi);
+	sim.initDt_ = 1e-9 / (S::eps_SuOlson * S::c * chi);
+	sim.maxTimesteps_ = 20000;
+
+	EOS const eos = sim.hydro.tr.eos;
+	double const Egas = eos.ComputeEintFromTgas(S::rho0, S::T_initial);
+	double const Erad_initial = S::a_rad * std::pow(S::T_initial, 4);
+	// setCustomBoundaryConditions :101-160: Marshak half-range condition beyond the lower face (the ghost flux follows the first
+	// valid cell), constant state beyond the upper one (the function does not consult that side's BCRec)
+	sim.customBC = [Egas, Erad_initial](int i, int j, int k, Array4<double> const &consVar, Box const &dom, double /*time*/) {
+		if (i < dom.lo[0]) {
+			const double T_H = S::T_hohlraum;
+			const double E_inc = S::a_rad * std::pow(T_H, 4);
+			const double E_0 = consVar(dom.lo[0], j, k, kNumHydroVars + 0);
+			const double F_0 = consVar(dom.lo[0], j, k, kNumHydroVars + 1);
+			const double F_bdry = 0.5 * S::c * E_inc - 0.5 * (S::c * E_0 + 2.0 * F_0);
+			consVar(i, j, k, kNumHydroVars + 0) = E_inc;
+			consVar(i, j, k, kNumHydroVars + 1) = F_bdry;
+			consVar(i, j, k, kNumHydroVars + 2) = 0.;
+			consVar(i, j, k, kNumHydroVars + 3) = 0.;
+		} else {
+			consVar(i, j, k, kNumHydroVars + 0) = Erad_initial;
+			consVar(i, j, k, kNumHydroVars + 1) = 0;
+			consVar(i, j, k, kNumHydroVars + 2) = 0;
+			consVar(i, j, k, kNumHydroVars + 3) = 0;
+		}
+		consVar(i, j, k, energy_index) = Egas;
+		consVar(i, j, k, density_index) = S::rho0;
+		consVar(i, j, k, internalEnergy_index) = Egas;
+		consVar(i, j, k, x1Momentum_index) = 0.;
+		consVar(i, j, k, x2Momentum_index) = 0.;
+		consVar(i, j, k, x3Momentum_index) = 0.;
+	};
+
+	sim.define();
+	forEachValidCell(sim, [&](Array4<double> const &state_cc, int i, int j, int k) { // :162-183
+		state_cc(i, j, k, kNumHydroVars + 0) = Erad_initial;
+		state_cc(i, j, k, kNumHydroVars + 1) = 0;
+		state_cc(i, j, k, kNumHydroVars + 2) = 0;
+		state_cc(i, j, k, kNumHydroVars + 3) = 0;
+		state_cc(i, j, k, density_index) = S::rho0;
+		state_cc(i, j, k, energy_index) = Egas;
+		state_cc(i, j, k, internalEnergy_index) = Egas;
+		state_cc(i, j, k, x1Momentum_index) = 0.;
+		state_cc(i, j, k, x2Momentum_index) = 0.;
+		state_cc(i, j, k, x3Momentum_index) = 0.;
+	});
+	sim.finishInitialConditions();
+}
+
 } // namespace oracle
 
 #endif // ORACLE_PROBLEMS_HPP_

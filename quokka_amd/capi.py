@@ -46,7 +46,8 @@ class BCRec(C.Structure):
 
 
 class DirichletFace(C.Structure):
-    _fields_ = [("enabled", C.c_int), ("values", C.c_double * 16)]
+    _fields_ = [("enabled", C.c_int), ("values", C.c_double * 16),
+                ("marshak", C.c_int), ("marshak_energy_comp", C.c_int), ("marshak_flux_comp", C.c_int), ("marshak_c", C.c_double)]
 
 
 class RadTraits(C.Structure):

@@ -177,6 +177,17 @@ __global__ void __launch_bounds__(256) k_physbc(const CopyItem *items, qk_array4
 			for (int n = scomp; n < scomp + ncomp; ++n) {
 				A(idx[0], idx[1], idx[2], n) = df->values[n];
 			}
+			if (df->marshak != 0 && df->marshak_flux_comp >= scomp && df->marshak_flux_comp < scomp + ncomp) {
+				// RadMarshak's setCustomBoundaryConditions (test_radiation_marshak.cpp:125-141), in its order of operations
+				const int fd = static_cast<int>((df - dirichlet) / 2);
+				int in[3] = {idx[0], idx[1], idx[2]};
+				in[fd] = geom.domain.lo[fd];
+				const double c = df->marshak_c;
+				const double E_inc = df->values[df->marshak_energy_comp];
+				const double E_0 = A(in[0], in[1], in[2], df->marshak_energy_comp);
+				const double F_0 = A(in[0], in[1], in[2], df->marshak_flux_comp);
+				A(idx[0], idx[1], idx[2], df->marshak_flux_comp) = 0.5 * c * E_inc - 0.5 * (c * E_0 + 2.0 * F_0);
+			}
 			continue;
 		}
 		for (int n = scomp; n < scomp + ncomp; ++n) {
@@ -684,6 +695,14 @@ int qk_FillPhysicalBoundary_subset(qk_ghost_plan *plan, qk_stream s, qk_array4 *
 	if (dirichlet != nullptr) {
 		for (int f = 0; f < 6; ++f) {
 			pa.dir[f] = dirichlet[f];
+			if (dirichlet[f].enabled != 0 && dirichlet[f].marshak != 0) {
+				QK_REQUIRE(ctx, (f % 2) == 0, "FillPhysicalBoundary: the Marshak condition is defined for lower faces only");
+				QK_REQUIRE(ctx,
+					   dirichlet[f].marshak_energy_comp >= 0 && dirichlet[f].marshak_energy_comp < plan->ncomp &&
+					       dirichlet[f].marshak_flux_comp >= 0 && dirichlet[f].marshak_flux_comp < plan->ncomp &&
+					       dirichlet[f].marshak_flux_comp != dirichlet[f].marshak_energy_comp && dirichlet[f].marshak_c > 0.0,
+					   "FillPhysicalBoundary: bad Marshak face description");
+			}
 		}
 	}
 	QK_REQUIRE(ctx, which == QK_BOXES_ALL || which == QK_BOXES_LOCAL_ONLY || which == QK_BOXES_REMOTE_DEPENDENT, "FillPhysicalBoundary: bad subset");

@@ -41,4 +41,12 @@ inline auto interpolate_value(double x, double const *arr_x, double const *arr_y
 	return slope * (x - arr_x[j]) + arr_y[j];
 }
 
+// interpolate_arrays of the reference (src/math/interpolate.cpp:107-133): y[i] = table(x[i]) for a sorted table; NaN outside it
+inline void interpolate_arrays(double const *x, double *y, int len, double const *arr_x, double const *arr_y, int arr_len)
+{
+	for (int i = 0; i < len; ++i) {
+		y[i] = interpolate_value(x[i], arr_x, arr_y, arr_len);
+	}
+}
+
 #endif

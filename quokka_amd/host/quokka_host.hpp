@@ -85,7 +85,15 @@ template <typename problem_t> struct EOS {
 		double const e = Eint / rho;
 		return (e * mu_ * C::m_u * (gamma_ - 1.0) / C::k_B) * C::k_B / kB_;
 	}
-	static auto ComputeEintFromTgas(double rho, double Tgas) -> double
+	static auto ComputeEintFromTgas(double rho, double Tgas) -> double { return gammaLawEintFromTgas(rho, Tgas); }
+	static auto ComputeEintTempDerivative(double rho, double Tgas) -> double
+	{
+		double const p = rho * Tgas * C::k_B / (mu_ * C::m_u);
+		double const e = p / ((gamma_ - 1.0) * rho);
+		return (e / Tgas) * rho * kB_ / C::k_B;
+	}
+	// (not a hook: what ComputeEintFromTgas is unless a problem specialises it — qkhost::traits() tells the two apart with it)
+	static auto gammaLawEintFromTgas(double rho, double Tgas) -> double
 	{
 		double const p = rho * Tgas * C::k_B / (mu_ * C::m_u);
 		double const e = p / ((gamma_ - 1.0) * rho);
@@ -130,6 +138,33 @@ inline void check(int rc, const char *what)
 }
 inline auto tab(amrex::MultiFab const &mf) -> qk_array4 * { return reinterpret_cast<qk_array4 *>(mf.arrays()); }
 inline auto itab(amrex::iMultiFab const &mf) -> qk_iarray4 * { return reinterpret_cast<qk_iarray4 *>(mf.arrays()); }
+// The temperature hooks of quokka::EOS<problem_t> (reference src/hydro/EOS.hpp:74-244) run on the device in the reference; the C-ABI carries
+// them as a closed set (qk_hydro_traits::eos_temperature_model 0: gamma law; 1: E_int = alpha / 4 T^4, the Su & Olson material).  They
+// are sampled on the host; anything outside the set is refused.
+template <typename problem_t> auto eosTemperatureModel() -> std::pair<int, double>
+{
+	using E = quokka::EOS<problem_t>;
+	const double rs[3] = {1.0, 7.0, 2.0e-7}, Ts[3] = {1.0, 2.0, 3.0e3};
+	bool gammaLaw = true, fourth = true;
+	double const alpha = 4.0 * E::ComputeEintFromTgas(rs[0], Ts[0]);
+	for (double r : rs) {
+		for (double T : Ts) {
+			double const e = E::ComputeEintFromTgas(r, T);
+			gammaLaw = gammaLaw && (e == E::gammaLawEintFromTgas(r, T) || (std::isnan(e) && std::isnan(E::gammaLawEintFromTgas(r, T))));
+			double const want = (alpha / 4.0) * std::pow(T, 4);
+			fourth = fourth && std::abs(e - want) <= 1e-14 * std::abs(want) && std::abs(E::ComputeEintTempDerivative(r, T) - alpha * std::pow(T, 3)) <= 1e-14 * alpha * std::pow(T, 3) &&
+				 std::abs(E::ComputeTgasFromEint(r, e) - T) <= 1e-13 * T;
+		}
+	}
+	if (gammaLaw) {
+		return {0, 0.0};
+	}
+	if (fourth && alpha > 0.0) {
+		return {1, alpha};
+	}
+	amrex::Abort("quokka::EOS: these temperature hooks are not expressible in the C-ABI's closed set (gamma law, E = alpha / 4 T^4)");
+	return {0, 0.0};
+}
 template <typename problem_t> auto traits() -> qk_hydro_traits
 {
 	return {quokka::EOS_Traits<problem_t>::gamma,
@@ -140,8 +175,8 @@ template <typename problem_t> auto traits() -> qk_hydro_traits
 		Physics_Traits<problem_t>::numPassiveScalars,
 		Physics_Traits<problem_t>::numMassScalars,
 		AMREX_SPACEDIM,
-		0,
-		0.0};
+		eosTemperatureModel<problem_t>().first,
+		eosTemperatureModel<problem_t>().second};
 }
 } // namespace qkhost
 
@@ -698,44 +733,98 @@ template <typename problem_t> class AMRSimulation
 	bool hasDirichlet_ = false;
 
 	// Sample the problem's setCustomBoundaryConditions on host staging cells beyond each non-periodic face: if it writes a state
-	// there (as HydroShocktube's does), that face becomes a constant-Dirichlet face of the C-ABI's closed model.
+	// there (as HydroShocktube's does), that face becomes a Dirichlet face of the C-ABI's closed model.  The staging array reaches
+	// the first valid cell inside the face, which a Marshak condition reads (RadMarshak): probing that cell with three
+	// (E_0, F_0) pairs tells a constant state from the half-range form 0.5 c E_inc - 0.5 (c E_0 + 2 F_0), the only dependence
+	// on the interior the closed set knows.
 	void buildDirichletModel()
 	{
 		int const nc = Physics_Indices<problem_t>::nvarTotal_cc;
 		auto const &g = geom[0];
 		double const sentinel = -7.7e300;
+		constexpr bool hasRad = Physics_Traits<problem_t>::is_radiation_enabled;
+		int const eComp = Physics_Indices<problem_t>::radFirstIndex;
 		for (int d = 0; d < AMREX_SPACEDIM; ++d) {
 			if (g.isPeriodic(d)) {
 				continue;
 			}
 			for (int side = 0; side < 2; ++side) {
-				double vals[2][16];
-				for (int probe = 0; probe < 2; ++probe) { // two different ghost cells: the model requires a constant state
-					amrex::IntVect iv(g.domain.lo[0], g.domain.lo[1], g.domain.lo[2]);
-					iv[d] = (side == 0) ? g.domain.lo[d] - 1 - probe : g.domain.hi[d] + 1 + probe;
-					amrex::Box cell(iv, iv);
-					std::vector<double> h(static_cast<size_t>(nc), sentinel);
-					amrex::Array4<double> a(h.data(), cell, nc);
-					AMRSimulation<problem_t>::setCustomBoundaryConditions(iv, a, 0, nc, g.data(), 0.0, BCs_cc_.data(), 0, 0);
-					for (int n = 0; n < nc; ++n) {
-						vals[probe][n] = h[n];
+				// [probe cell][interior probe]: ghost cells 1 and 2 beyond the face; interior (E_0, F_0) = (0,0), (1,0), (0,1)
+				double vals[2][3][16];
+				double const probes[3][2] = {{0.0, 0.0}, {1.0, 0.0}, {0.0, 1.0}};
+				for (int probe = 0; probe < 2; ++probe) {
+					for (int q = 0; q < 3; ++q) {
+						amrex::IntVect lo(g.domain.lo[0], g.domain.lo[1], g.domain.lo[2]);
+						amrex::IntVect hi = lo;
+						amrex::IntVect iv = lo;
+						if (side == 0) {
+							lo[d] = g.domain.lo[d] - 2;
+							hi[d] = g.domain.lo[d];
+							iv[d] = g.domain.lo[d] - 1 - probe;
+						} else {
+							lo[d] = g.domain.hi[d];
+							hi[d] = g.domain.hi[d] + 2;
+							iv[d] = g.domain.hi[d] + 1 + probe;
+						}
+						amrex::Box strip(lo, hi);
+						std::vector<double> h(static_cast<size_t>(nc) * 3, sentinel);
+						amrex::Array4<double> a(h.data(), strip, nc);
+						amrex::IntVect in = iv;
+						in[d] = (side == 0) ? g.domain.lo[d] : g.domain.hi[d];
+						for (int n = 0; n < nc; ++n) {
+							a(in[0], in[1], in[2], n) = 0.0;
+						}
+						if constexpr (hasRad) {
+							a(in[0], in[1], in[2], eComp) = probes[q][0];
+							a(in[0], in[1], in[2], eComp + 1 + d) = probes[q][1];
+						}
+						AMRSimulation<problem_t>::setCustomBoundaryConditions(iv, a, 0, nc, g.data(), 0.0, BCs_cc_.data(), 0, 0);
+						for (int n = 0; n < nc; ++n) {
+							vals[probe][q][n] = a(iv[0], iv[1], iv[2], n);
+						}
 					}
 				}
-				bool wrote = false, constant = true;
+				bool wrote = false, constant = true, interiorDependent = false;
 				for (int n = 0; n < nc; ++n) {
-					wrote = wrote || (vals[0][n] != sentinel);
-					constant = constant && (vals[0][n] == vals[1][n]);
+					wrote = wrote || (vals[0][0][n] != sentinel);
+					constant = constant && (vals[0][0][n] == vals[1][0][n]);
+					interiorDependent = interiorDependent || (vals[0][1][n] != vals[0][0][n]) || (vals[0][2][n] != vals[0][0][n]);
 				}
-				if (wrote) {
-					if (!constant) {
-						amrex::Abort("setCustomBoundaryConditions is not a constant state per face: not expressible in the C-ABI's closed BC set");
+				if (!wrote) {
+					continue;
+				}
+				if (!constant) {
+					amrex::Abort("setCustomBoundaryConditions is not a constant state per face: not expressible in the C-ABI's closed BC set");
+				}
+				auto &f = dirichlet_[2 * d + side];
+				f.enabled = 1;
+				for (int n = 0; n < nc; ++n) {
+					f.values[n] = vals[0][0][n];
+				}
+				hasDirichlet_ = true;
+				if (interiorDependent) {
+					bool ok = hasRad && side == 0;
+					if constexpr (hasRad) {
+						double const c = RadSystem_Traits<problem_t>::c_light;
+						int const fComp = eComp + 1 + d;
+						double const E_inc = vals[0][0][eComp];
+						for (int n = 0; n < nc; ++n) { // only the normal flux may follow the interior
+							ok = ok && (n == fComp || (vals[0][1][n] == vals[0][0][n] && vals[0][2][n] == vals[0][0][n]));
+						}
+						for (int q = 0; q < 3; ++q) {
+							double const want = 0.5 * c * E_inc - 0.5 * (c * probes[q][0] + 2.0 * probes[q][1]);
+							ok = ok && (vals[0][q][fComp] == want);
+						}
+						f.marshak = 1;
+						f.marshak_energy_comp = eComp;
+						f.marshak_flux_comp = fComp;
+						f.marshak_c = c;
+						f.values[fComp] = 0.0;
 					}
-					auto &f = dirichlet_[2 * d + side];
-					f.enabled = 1;
-					for (int n = 0; n < nc; ++n) {
-						f.values[n] = vals[0][n];
+					if (!ok) {
+						amrex::Abort("setCustomBoundaryConditions reads the interior in a way the C-ABI's closed BC set does not know (only "
+							     "the Marshak half-range flux on a lower face)");
 					}
-					hasDirichlet_ = true;
 				}
 			}
 		}

@@ -471,3 +471,48 @@ def uniform_advecting_problem(ctx: Context, nx: int = 64, pow_mode: int = 0) -> 
 
     sim.set_initial_conditions(ic)
     return sim
+
+
+class MarshakConstants:
+    """reference src/problems/RadMarshak/test_radiation_marshak.cpp:22-31"""
+    eps_SuOlson = 1.0
+    kappa = 1.0
+    rho0 = 1.0
+    T_hohlraum = 1.0
+    a_rad = 1.0
+    c = 1.0
+    alpha_SuOlson = 4.0 * a_rad / eps_SuOlson
+    T_initial = 1.0e-2
+
+
+def marshak_problem(ctx: Context, nx: int = 80, pow_mode: int = 0) -> RadhydroSimulation:
+    """reference src/problems/RadMarshak/test_radiation_marshak.cpp + tests/Marshak.in (1-D build): the Su & Olson (1996) Marshak wave:
+    a half-space of the E = alpha / 4 T^4 material lit through its lower face by a hohlraum at T_H (Marshak half-range condition on
+    the ghost flux), constant state beyond the upper face; radiation only, kappa = 1, beta_order 0."""
+    S = MarshakConstants
+    geom = Geometry(1, [nx], [0.0, 0.0, 0.0], [20.0, 1.0, 1.0], [0, 1, 1])
+    bcs = [([capi.BC_EXT_DIR, 0, 0], [capi.BC_FOEXTRAP, 0, 0]) for _ in range(10)]
+    traits = capi.traits(5.0 / 3.0, True, 1, mean_molecular_weight=1.0, boltzmann_constant=1.0, eos_temperature_model=1, eos_alpha=S.alpha_SuOlson)
+    rt = capi.RadTraits(S.c, S.c, S.a_rad, 0.0, 0, 0, S.kappa, S.kappa, S.kappa, pow_mode, 0)
+    Egas = (S.alpha_SuOlson / 4.0) * ((S.T_initial * S.T_initial) * (S.T_initial * S.T_initial))  # quokka::EOS::ComputeEintFromTgas hook :73-79
+    Erad = S.a_rad * math.pow(S.T_initial, 4)
+    E_inc = S.a_rad * math.pow(S.T_hohlraum, 4)
+    gas = [S.rho0, 0.0, 0.0, 0.0, Egas, Egas]
+    # setCustomBoundaryConditions :101-160 (it does not consult the side's BCRec: the cells beyond the upper face get the constant state)
+    dirichlet = {(0, 0): {"values": gas + [E_inc, 0.0, 0.0, 0.0], "marshak": (RAD0, RAD0 + 1, S.c)}, (0, 1): gas + [Erad, 0.0, 0.0, 0.0]}
+    sim = RadhydroSimulation(ctx, geom, traits, rt, bcs, [nx, 1, 1], use_fused=False, dirichlet=dirichlet)
+    sim.is_hydro_enabled = False
+    chi = S.rho0 * S.kappa  # problem_main :181-218
+    sim.radiationCflNumber_ = 0.4
+    sim.stopTime_ = 10.0 / (S.eps_SuOlson * S.c * chi)
+    sim.maxDt_ = 1e-3 / (S.eps_SuOlson * S.c * chi)
+    sim.initDt_ = 1e-9 / (S.eps_SuOlson * S.c * chi)
+    sim.maxTimesteps_ = 20000
+
+    def ic(i, j, k):  # setInitialConditionsOnGrid :162-183
+        U = np.zeros((10,) + i.shape)
+        U[0], U[4], U[5], U[6] = S.rho0, Egas, Egas, Erad
+        return U
+
+    sim.set_initial_conditions(ic)
+    return sim

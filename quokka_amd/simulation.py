@@ -131,6 +131,10 @@ class GhostExchange:
             for (dim, side), vals in dirichlet.items():
                 f = self.dirichlet[2 * dim + side]
                 f.enabled = 1
+                if isinstance(vals, dict):  # {"values": [...], "marshak": (energy_comp, flux_comp, c)}: qk_dirichlet_face::marshak
+                    f.marshak = 1
+                    f.marshak_energy_comp, f.marshak_flux_comp, f.marshak_c = vals["marshak"]
+                    vals = vals["values"]
                 for n, v in enumerate(vals):
                     f.values[n] = v
         self.peers = []

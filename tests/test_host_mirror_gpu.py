@@ -196,11 +196,24 @@ def test_uniform_advecting_executable_matches_oracle(tmp_path, oracle):
     """the reference's RadhydroUniformAdvecting ctest through the C++ mirror (beta_order = 2, radiation CFL 8, periodic): exit status
     0 == T_gas within 1e-10 of T0; the final state equals the oracle's bit for bit."""
     from oracle.pyoracle import ADVECTING
-    data, meta, out = run("test_radhydro_uniform_advecting", [os.path.join(HOST, "decks", "RadhydroUniformAdvecting.in")], tmp_path)
+    data, meta, out = run("test_radhydro_uniform_advecting", [os.path.join(HOST, "decks", "RadhydroUniformAdvecting.in"), "radiation.pow_mode=1"], tmp_path)
     assert int(meta[0]) == 125 and meta[5] < 1.0e-10, meta
     so = oracle.sim(ADVECTING, 1, [64, 1, 1], [0, 0, 0], [64.0, 1, 1], [1, 1, 1], max_grid_size=[64, 1, 1], rad_pow_mode=1)
     assert so.evolve() and so.time == meta[1]
     assert np.array_equal(data.reshape(10, 64), so.valid(0).reshape(10, 64))
+
+
+def test_marshak_executable_meets_the_reference_criterion_and_matches_oracle(tmp_path, oracle):
+    """the reference's RadMarshak ctest through the C++ mirror: the mirror recognises the Marshak half-range condition and the T^4
+    material by sampling the problem's hooks (quokka_host.hpp buildDirichletModel / eosTemperatureModel); exit status 0 == radiation
+    temperature within 2 per cent of Su & Olson's solution; the final state after 10135 steps equals the oracle's bit for bit."""
+    from oracle.pyoracle import MARSHAK
+    table = os.path.join(ROOT, "tests", "golden", "SuOlson_100pt_tau10p0.dat")
+    data, meta, out = run("test_radiation_marshak", [os.path.join(HOST, "decks", "Marshak.in"), f"marshak.solution_file={table}", "radiation.pow_mode=1"], tmp_path)
+    assert int(meta[0]) == 10135 and abs(meta[1] - 10.0) < 1e-12 and 1e-4 < meta[5] < 0.02, meta
+    so = oracle.sim(MARSHAK, 1, [80, 1, 1], [0, 0, 0], [20.0, 1, 1], [0, 1, 1], max_grid_size=[80, 1, 1], rad_pow_mode=1)
+    assert so.evolve() and so.time == meta[1]
+    assert np.array_equal(data.reshape(10, 80), so.valid(0).reshape(10, 80))
 
 
 def test_passive_scalar_executable_meets_the_reference_criteria(tmp_path):

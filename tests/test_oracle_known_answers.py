@@ -255,3 +255,30 @@ def test_uniformly_advecting_radiating_gas_stays_in_equilibrium(oracle):
     err = advecting_error(U)
     assert err < 1.0e-10, err
     assert np.allclose(U[1, 0, 0] / U[0, 0, 0], 1.0e6, rtol=1e-10, atol=0)  # still moving at v0
+
+
+def marshak_error(U, time, nx=80, Lx=20.0):
+    """RadMarshak's error norm (test_radiation_marshak.cpp:228-301): radiation temperature (E_rad / a_rad)^(1/4) against the
+    tabulated solution of Su & Olson (1996) (extern/SuOlson/100pt_tau10p0.dat, columns x and Trad / T_H) in the scaled coordinate
+    sqrt(3) x, relative L1 over the cells with sqrt(3) x < c t."""
+    tab = np.loadtxt(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "SuOlson_100pt_tau10p0.dat"), skiprows=1)
+    xs = np.sqrt(3.0) * (np.arange(nx) + 0.5) * (Lx / nx)
+    Trad = np.power(U[6, 0, 0] / 1.0, 0.25)
+    interp = np.interp(xs, np.sqrt(3.0) * tab[:, 1], tab[:, 4])
+    m = xs < 1.0 * time
+    return float(np.abs(Trad[m] - interp[m]).sum() / np.abs(interp[m]).sum())
+
+
+def test_marshak_wave_meets_the_reference_criterion(oracle):
+    """RadMarshak (src/problems/RadMarshak/test_radiation_marshak.cpp, deck tests/Marshak.in): the Marshak half-range boundary
+    condition (ghost flux 0.5 c E_inc - 0.5 (c E_0 + 2 F_0) from the first valid cell) drives a wave into the E = alpha/4 T^4
+    material; radiation temperature at tau = 10 within 2 per cent of Su & Olson's solution on 80 cells."""
+    from oracle.pyoracle import MARSHAK
+    s = oracle.sim(MARSHAK, 1, [80, 1, 1], [0, 0, 0], [20.0, 1, 1], [0, 1, 1], max_grid_size=[80, 1, 1])
+    assert s.evolve()
+    assert abs(s.time - 10.0) < 1e-12 and 10000 <= s.istep < 10400  # dt ramps from 1e-9 by 10 % a step up to max_dt = 1e-3
+    c = s.rad_counters()
+    assert c["fail_coupling"] == c["fail_outer"] == 0
+    err = marshak_error(s.valid(0), s.time)
+    assert err < 0.02, err
+    assert err > 1e-4

@@ -201,3 +201,35 @@ def test_uniform_advecting_beta_order_2_matches_oracle(ctx, oracle):
             ref = U
         else:
             assert not np.array_equal(ref, U)  # the higher-order terms did act
+
+
+def test_marshak_boundary_condition_matches_oracle(ctx, oracle):
+    """RadMarshak through the C-ABI: the Marshak member of the closed boundary set (`qk_dirichlet_face::marshak`: the ghost flux follows
+    the first valid cell), radiation only, T^4 material — 1500 steps (the dt ramp and ~1.3 time units of the wave) bit for bit."""
+    from oracle.pyoracle import MARSHAK
+    from quokka_amd.radhydro import marshak_problem
+    so = oracle.sim(MARSHAK, 1, [80, 1, 1], [0, 0, 0], [20.0, 1, 1], [0, 1, 1], max_grid_size=[80, 1, 1], rad_pow_mode=1)
+    sg = marshak_problem(ctx, 80, pow_mode=1)
+    assert np.array_equal(so.valid(0), sg.state_new_cc_.valid(0).cpu().numpy())
+    for it in range(1500):
+        assert so.step() and sg.step()
+        assert so.dt == sg.dt_, (it, so.dt, sg.dt_)
+    U = sg.state_new_cc_.valid(0).cpu().numpy()
+    assert np.array_equal(so.valid(0), U)
+    assert so.time > 1.0 and U[6, 0, 0, 0] > 0.3 and U[6, 0, 0, -1] < 2e-8  # the wave has entered; the far side is still cold
+
+
+def test_marshak_face_is_validated(ctx):
+    """the library refuses a Marshak description on an upper face or with bad component indices"""
+    from quokka_amd.radhydro import RAD0, RadhydroSimulation
+    from quokka_amd.simulation import Geometry
+    from quokka_amd import capi
+    geom = Geometry(1, [16], [0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [0, 1, 1])
+    bcs = [([capi.BC_EXT_DIR, 0, 0], [capi.BC_EXT_DIR, 0, 0]) for _ in range(10)]
+    tr = capi.traits(5.0 / 3.0, True, 1, mean_molecular_weight=1.0, boltzmann_constant=1.0)
+    rt = capi.RadTraits(1.0, 1.0, 1.0, 0.0, 0, 0, 1.0, 1.0, 1.0, 0, 0)
+    for face, spec in (((0, 1), (RAD0, RAD0 + 1, 1.0)), ((0, 0), (RAD0, RAD0, 1.0)), ((0, 0), (RAD0, 12, 1.0)), ((0, 0), (RAD0, RAD0 + 1, 0.0))):
+        sim = RadhydroSimulation(ctx, geom, tr, rt, bcs, [16, 1, 1], use_fused=False, dirichlet={face: {"values": [1.0] * 10, "marshak": spec}})
+        with pytest.raises(capi.QkError):
+            sim.set_initial_conditions(lambda i, j, k: np.ones((10,) + i.shape))
+            sim.fillBoundaryConditions(sim.state_new_cc_)
