@@ -146,6 +146,9 @@ void *orc_sim_create(orc_sim_config const *c)
 		sim->rad.rt.pow_mode = c->rad_pow_mode;
 	} else if (c->problem == 8) {
 		setupMatterCoupling(*sim);
+		if (c->h1d[0] > 0) { // RadMatterCouplingRSLA (test_radiation_matter_coupling_rsla.cpp:22,43): c_hat = 0.1 c, nothing else differs
+			sim->rad.rt.c_hat = c->h1d[0] * sim->rad.rt.c_light;
+		}
 		sim->rad.rt.pow_mode = c->rad_pow_mode;
 	} else if (c->problem == 9) {
 		setupSuOlson(*sim);

@@ -183,7 +183,7 @@ class Oracle:
                                  _i3(clo), _i3(chi), fine.shape[0], _i3(region[0]), _i3(region[1]), w_old, w_new, ncomp, method, int(hooks), ndim, _i3(ratio))
 
     def sim(self, problem, ndim, n_cell, prob_lo, prob_hi, periodic, max_grid_size=None, cfl=-1.0, stop_time=-1.0,
-            max_timesteps=-1, reconstruction_order=-1, nscalars=0, table=None, rad_pow_mode=0, hydro1d=None, beta_order=0) -> "OracleSim":
+            max_timesteps=-1, reconstruction_order=-1, nscalars=0, table=None, rad_pow_mode=0, hydro1d=None, beta_order=0, c_hat_factor=0.0) -> "OracleSim":
         if ndim == 2:
             # AMREX_SPACEDIM == 2 builds of the reference use util/ArrayView_2d.hpp (X2 view = index SWAP, velV = vx, velW = vz),
             # not the cyclic permutation of ArrayView_3d.hpp restated here: a 2-D oracle would not be the reference's algorithm
@@ -205,6 +205,8 @@ class Oracle:
                    [h["cfl"], h.get("max_dt", -1.0), h.get("init_dt", -1.0), h["stop_time"]]
             cfg.h1d = (C.c_double * 12)(*[float(v) for v in vals])
             cfg.h1d_i = (C.c_int * 2)(int(h.get("profile", 0)), int(h.get("dirichlet", 1)))
+        if c_hat_factor > 0:  # COUPLING: the reduced-speed-of-light variant (RadMatterCouplingRSLA)
+            cfg.h1d[0] = float(c_hat_factor)
         if beta_order > 0:  # RADSHOCK / ADVECTING parity variants: override RadSystem_Traits::beta_order
             cfg.h1d_i[0] = int(beta_order)
         # team size by problem size: ~16k cells per thread at least (a 1-D 512-cell run makes ~10^5 tiny parallel regions per second)

@@ -411,14 +411,15 @@ class CouplingConstants:
     a_rad_cgs = 4.0 * 5.670374419e-5 / c_light  # C::a_rad: the radiation constant the solver uses
 
 
-def matter_coupling_problem(ctx: Context, n: int = 4, pow_mode: int = 0) -> RadhydroSimulation:
+def matter_coupling_problem(ctx: Context, n: int = 4, pow_mode: int = 0, c_hat_factor: float = 1.0) -> RadhydroSimulation:
     """reference src/problems/RadMatterCoupling/test_radiation_matter_coupling.cpp + tests/energyexchange.in (1-D build): gas and
     radiation of a uniform medium relax to a common temperature; constant dt = 1e-8 s, kappa = 1, E_gas = alpha / 4 T^4."""
     S = CouplingConstants
     geom = Geometry(1, [n], [0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [0, 0, 0])
     bcs = [([capi.BC_FOEXTRAP, 0, 0], [capi.BC_FOEXTRAP, 0, 0]) for _ in range(10)]
     traits = capi.traits(5.0 / 3.0, True, 1, eos_temperature_model=1, eos_alpha=S.alpha_SuOlson)
-    rt = capi.RadTraits(S.c_light, S.c_light, S.a_rad_cgs, 0.0, 1, 0, 1.0, 1.0, 1.0, pow_mode, 0)
+    # c_hat_factor = 0.1: RadMatterCouplingRSLA (test_radiation_matter_coupling_rsla.cpp:22,43), the same problem with a reduced speed of light
+    rt = capi.RadTraits(S.c_light, c_hat_factor * S.c_light, S.a_rad_cgs, 0.0, 1, 0, 1.0, 1.0, 1.0, pow_mode, 0)
     sim = RadhydroSimulation(ctx, geom, traits, rt, bcs, [n, 1, 1], use_fused=False)
     sim.is_hydro_enabled = False
     sim.cflNumber_ = sim.radiationCflNumber_ = 1.0

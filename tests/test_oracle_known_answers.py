@@ -202,6 +202,31 @@ def test_matter_radiation_equilibration_follows_the_exact_solution(oracle):
     assert c_["fail_coupling"] == c_["fail_outer"] == 0
 
 
+
+def test_matter_radiation_equilibration_with_reduced_speed_of_light(oracle):
+    """RadMatterCouplingRSLA (src/problems/RadMatterCouplingRSLA/test_radiation_matter_coupling_rsla.cpp:186-240): the same relaxation
+    with c_hat = 0.1 c against the exact solution of the reduced-speed-of-light equations; relative L1 error below 5e-5.  Pins the
+    c_hat / c factors of the exchange solve, which are 1 in every other radiation known-answer test but the shell."""
+    from oracle.pyoracle import COUPLING
+    s = oracle.sim(COUPLING, 1, [4, 1, 1], [0, 0, 0], [1.0, 1, 1], [0, 0, 0], max_grid_size=[4, 1, 1], c_hat_factor=0.1)
+    t, U = s.run_record(1000000, cell=(1, 0, 0))
+    assert len(t) == 1000000 and abs(t[-1] - 1.0e-2) < 1e-12
+    a_rad = 7.5646e-15
+    alpha, c = 4.0 * a_rad, 2.99792458e10
+    c_rsla = 0.1 * c
+    Erad0, Egas0, rho0, kappa = 1.0e12, 1.0e2, 1.0e-7, 1.0
+    Eint = U[:, 4] - (U[:, 1] ** 2 + U[:, 2] ** 2 + U[:, 3] ** 2) / (2.0 * U[:, 0])
+    Tgas = np.power(4.0 * Eint / alpha, 0.25)
+    T0_4 = 4.0 * Egas0 / alpha
+    E0 = ((c / c_rsla) * Erad0 + Egas0) / (a_rad + (c_rsla / c) * alpha / 4.0)
+    T4 = (T0_4 - (c_rsla / c) * E0) * np.exp(-(4.0 / alpha) * (a_rad + (c_rsla / c) * alpha / 4.0) * kappa * rho0 * c * t) + (c_rsla / c) * E0
+    Texact = np.power(T4, 0.25)
+    err = float(np.abs(Tgas - Texact).sum() / np.abs(Texact).sum())
+    assert err < 5e-5, err
+    c_ = s.rad_counters()
+    assert c_["fail_coupling"] == c_["fail_outer"] == 0
+
+
 SUOLSON_X = [0.01, 0.1, 0.17783, 0.31623, 0.45, 0.5, 0.56234, 0.75, 1.0, 1.33352, 1.77828, 3.16228, 5.62341]
 SUOLSON_EGAS_T10 = [2.11186, 2.09585, 2.06052, 1.94365, 1.74291, 1.61536, 1.46027, 1.16591, 0.88992, 0.62521, 0.38688, 0.07642, 0.00253]
 

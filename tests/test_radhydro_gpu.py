@@ -170,6 +170,14 @@ def test_su_olson_and_matter_coupling_match_oracle(ctx, oracle):
     assert sg.dt_ == 1.0e-8 and np.array_equal(so.valid(0), sg.state_new_cc_.valid(0).cpu().numpy())
     assert sg.state_new_cc_.valid(0)[4, 0, 0, 1].item() > 1.0e4  # the gas has heated by orders of magnitude
 
+    # RadMatterCouplingRSLA: the same with c_hat = 0.1 c
+    so = oracle.sim(COUPLING, 1, [4, 1, 1], [0, 0, 0], [1.0, 1, 1], [0, 0, 0], max_grid_size=[4, 1, 1], rad_pow_mode=1, c_hat_factor=0.1)
+    sr = matter_coupling_problem(ctx, 4, pow_mode=1, c_hat_factor=0.1)
+    for it in range(3000):
+        assert so.step() and sr.step()
+    U = sr.state_new_cc_.valid(0).cpu().numpy()
+    assert np.array_equal(so.valid(0), U) and not np.array_equal(U, sg.state_new_cc_.valid(0).cpu().numpy())
+
 
 def test_uniform_advecting_beta_order_2_matches_oracle(ctx, oracle):
     """RadhydroUniformAdvecting through the C-ABI: the whole run (125 steps) of the reference problem bit for bit and within its
