@@ -1097,6 +1097,90 @@ inline void setupMarshak(HydroSim &sim)
 	sim.finishInitialConditions();
 }
 
+
+// ---------------------------------------------------------------- radiation-driven isothermal wind (src/problems/RadForce/test_radiation_force.cpp)
+struct RadForceConstants { // :33-46
+	static constexpr double kappa0 = 5.0;
+	static constexpr double mu = 2.33 * C::m_u;
+	static constexpr double gamma_gas = 1.0; // isothermal
+	static constexpr double a0 = 0.2e5;
+	static constexpr double tau = 1.0e-6;
+	static constexpr double rho0 = 1.0e5 * mu;
+	static constexpr double Mach0 = 1.1;
+	static constexpr double Mach1 = 2.128410288469465339;
+	static constexpr double Frad0 = rho0 * a0 * C::c_light / tau;
+	static constexpr double g0 = kappa0 * Frad0 / C::c_light;
+	static constexpr double Lx = (a0 * a0) / g0;
+};
+
+inline void setupRadForce(HydroSim &sim)
+{
+	using S = RadForceConstants;
+	sim.hydro.tr.eos.tr.gamma = S::gamma_gas; // :48-53
+	sim.hydro.tr.eos.tr.mean_molecular_weight = S::mu;
+	sim.hydro.tr.eos.tr.boltzmann_constant = C::k_B;
+	sim.hydro.tr.eos.tr.cs_isothermal = S::a0;
+	sim.hydro.tr.reconstruct_eint = true;
+	sim.hydro.tr.nscalars = 0;
+	sim.ncomp_cc = kNumHydroVars + kNumRadVars;
+	sim.is_radiation_enabled = true; // :55-66
+	sim.rad.rt.c_light = C::c_light; // :68-75
+	sim.rad.rt.c_hat = 10. * (S::Mach1 * S::a0);
+	sim.rad.rt.radiation_constant = C::a_rad;
+	sim.rad.rt.Erad_floor = 0.;
+	sim.rad.rt.beta_order = 1;
+	sim.rad.eos = sim.hydro.tr.eos;
+	sim.rad.ndim = sim.geom.ndim;
+	sim.rad.nstartHyperbolic_ = kNumHydroVars;
+	sim.rad.ComputePlanckOpacity = [](double, double) { return 0.; }; // :77-82 (the energy mean defaults to the Planck mean)
+	sim.rad.ComputeEnergyMeanOpacity = [](double, double) { return 0.; };
+	sim.rad.ComputeFluxMeanOpacity = [](double, double) { return S::kappa0; };
+	// problem_main :166-205
+	sim.BCs_cc.assign(sim.ncomp_cc, BCRec{});
+	for (int n = 0; n < sim.ncomp_cc; ++n) {
+		sim.BCs_cc[n].lo[0] = ext_dir;
+		sim.BCs_cc[n].hi[0] = foextrap;
+	}
+	sim.radiationReconstructionOrder_ = 3;
+	sim.reconstructionOrder_ = 3;
+	sim.stopTime_ = 10.0 * (S::Lx / S::a0);
+	sim.cflNumber_ = 0.4;
+	sim.radiationCflNumber_ = 0.4;
+	sim.maxTimesteps_ = 1000000;
+	sim.maxDt_ = 1.0e10; // tests/RadForce.in
+	// setCustomBoundaryConditions :116-164: inflow at Mach0 with the incident flux beyond the lower face; nothing beyond the upper one
+	sim.customBC = [](int i, int j, int k, Array4<double> const &consVar, Box const &dom, double /*time*/) {
+		if (i < dom.lo[0]) {
+			double const rho = S::rho0;
+			double const vel = S::Mach0 * S::a0;
+			consVar(i, j, k, kNumHydroVars + 0) = S::Frad0 / C::c_light;
+			consVar(i, j, k, kNumHydroVars + 1) = S::Frad0;
+			consVar(i, j, k, kNumHydroVars + 2) = 0.;
+			consVar(i, j, k, kNumHydroVars + 3) = 0.;
+			consVar(i, j, k, density_index) = rho;
+			consVar(i, j, k, energy_index) = 0.;
+			consVar(i, j, k, internalEnergy_index) = 0.;
+			consVar(i, j, k, x1Momentum_index) = rho * vel;
+			consVar(i, j, k, x2Momentum_index) = 0.;
+			consVar(i, j, k, x3Momentum_index) = 0.;
+		}
+	};
+	sim.define();
+	forEachValidCell(sim, [&](Array4<double> const &state_cc, int i, int j, int k) { // :84-114
+		state_cc(i, j, k, kNumHydroVars + 0) = S::Frad0 * 1.0 / C::c_light;
+		state_cc(i, j, k, kNumHydroVars + 1) = S::Frad0 * 1.0;
+		state_cc(i, j, k, kNumHydroVars + 2) = 0;
+		state_cc(i, j, k, kNumHydroVars + 3) = 0;
+		state_cc(i, j, k, density_index) = S::rho0;
+		state_cc(i, j, k, x1Momentum_index) = 0;
+		state_cc(i, j, k, x2Momentum_index) = 0;
+		state_cc(i, j, k, x3Momentum_index) = 0;
+		state_cc(i, j, k, energy_index) = 0;
+		state_cc(i, j, k, internalEnergy_index) = 0.;
+	});
+	sim.finishInitialConditions();
+}
+
 } // namespace oracle
 
 #endif // ORACLE_PROBLEMS_HPP_

@@ -307,11 +307,15 @@ template <typename problem_t> class HydroSystem : public HyperbolicSystem<proble
 	}
 };
 
+// physical constants in CGS units, as problem files name them (reference src/radiation/radiation_system.hpp:58-59)
+static constexpr double c_light_cgs_ = C::c_light;
+static constexpr double radiation_constant_cgs_ = C::a_rad;
+
 // this struct is specialized by the user application code (reference src/radiation/radiation_system.hpp:73-82)
 template <typename problem_t> struct RadSystem_Traits {
-	static constexpr double c_light = C::c_light;
-	static constexpr double c_hat = C::c_light;
-	static constexpr double radiation_constant = C::a_rad;
+	static constexpr double c_light = c_light_cgs_;
+	static constexpr double c_hat = c_light_cgs_;
+	static constexpr double radiation_constant = radiation_constant_cgs_;
 	static constexpr double Erad_floor = 0.;
 	static constexpr double beta_order = 1;
 };

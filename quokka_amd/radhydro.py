@@ -517,3 +517,46 @@ def marshak_problem(ctx: Context, nx: int = 80, pow_mode: int = 0) -> RadhydroSi
 
     sim.set_initial_conditions(ic)
     return sim
+
+
+class RadForceConstants:
+    """reference src/problems/RadForce/test_radiation_force.cpp:33-46"""
+    c_light = 2.99792458e10
+    a_rad = 4.0 * 5.670374419e-5 / c_light
+    kappa0 = 5.0
+    mu = 2.33 * capi.M_U
+    a0 = 0.2e5
+    tau = 1.0e-6
+    rho0 = 1.0e5 * mu
+    Mach0 = 1.1
+    Mach1 = 2.128410288469465339
+    Frad0 = rho0 * a0 * c_light / tau
+    g0 = kappa0 * Frad0 / c_light
+    Lx = (a0 * a0) / g0
+
+
+def radforce_problem(ctx: Context, nx: int = 128, pow_mode: int = 0) -> RadhydroSimulation:
+    """reference src/problems/RadForce/test_radiation_force.cpp + tests/RadForce.in (1-D build): an isothermal gas (gamma = 1,
+    cs_isothermal = a0) entering at Mach 1.1 is accelerated by the force of an optically thin radiation flux (Planck opacity 0,
+    flux-mean opacity 5) to the steady wind solution; inflow state beyond the lower face, extrapolation beyond the upper one."""
+    S = RadForceConstants
+    geom = Geometry(1, [nx], [0.0, 0.0, 0.0], [1.0263747986171498e16, 1.0, 1.0], [0, 1, 1])  # tests/RadForce.in
+    bcs = [([capi.BC_EXT_DIR, 0, 0], [capi.BC_FOEXTRAP, 0, 0]) for _ in range(10)]
+    traits = capi.traits(1.0, True, 1, mean_molecular_weight=S.mu, boltzmann_constant=capi.K_B, cs_isothermal=S.a0)
+    rt = capi.RadTraits(S.c_light, 10.0 * (S.Mach1 * S.a0), S.a_rad, 0.0, 1, 0, 0.0, 0.0, S.kappa0, pow_mode, 0)
+    inflow = [S.rho0, S.rho0 * (S.Mach0 * S.a0), 0.0, 0.0, 0.0, 0.0, S.Frad0 / S.c_light, S.Frad0, 0.0, 0.0]
+    sim = RadhydroSimulation(ctx, geom, traits, rt, bcs, [nx, 1, 1], use_fused=False, dirichlet={(0, 0): inflow})
+    sim.radiationReconstructionOrder_ = 3  # problem_main :166-205
+    sim.reconstructionOrder_ = 3
+    sim.stopTime_ = 10.0 * (S.Lx / S.a0)
+    sim.cflNumber_ = sim.radiationCflNumber_ = 0.4
+    sim.maxTimesteps_, sim.maxDt_ = 1000000, 1.0e10
+
+    def ic(i, j, k):  # setInitialConditionsOnGrid :84-114
+        U = np.zeros((10,) + i.shape)
+        U[0] = S.rho0
+        U[6], U[7] = S.Frad0 * 1.0 / S.c_light, S.Frad0 * 1.0
+        return U
+
+    sim.set_initial_conditions(ic)
+    return sim

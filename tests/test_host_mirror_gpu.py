@@ -216,6 +216,19 @@ def test_marshak_executable_meets_the_reference_criterion_and_matches_oracle(tmp
     assert np.array_equal(data.reshape(10, 80), so.valid(0).reshape(10, 80))
 
 
+def test_radiation_force_executable_meets_the_reference_criterion_and_matches_oracle(tmp_path, oracle):
+    """the reference's RadForce ctest through the C++ mirror: isothermal EOS_Traits (gamma = 1, cs_isothermal), Planck opacity 0 with a
+    flux-mean opacity, inflow face sampled from setCustomBoundaryConditions (the upper face stays with its BCRec); exit status 0 ==
+    Mach number within 0.002 of the steady wind; the final state after 9520 steps equals the oracle's bit for bit."""
+    from oracle.pyoracle import RADFORCE
+    table = os.path.join(ROOT, "tests", "golden", "optically_thin_wind.txt")
+    data, meta, out = run("test_radiation_force", [os.path.join(HOST, "decks", "RadForce.in"), f"radforce.solution_file={table}", "radiation.pow_mode=1"], tmp_path)
+    assert int(meta[0]) == 9520 and 1e-5 < meta[5] < 0.002, meta
+    so = oracle.sim(RADFORCE, 1, [128, 1, 1], [0, 0, 0], [1.0263747986171498e16, 1, 1], [0, 1, 1], max_grid_size=[128, 1, 1], rad_pow_mode=1)
+    assert so.evolve() and so.time == meta[1]
+    assert np.array_equal(data.reshape(10, 128), so.valid(0).reshape(10, 128))
+
+
 def test_passive_scalar_executable_meets_the_reference_criteria(tmp_path):
     """the reference's PassiveScalar ctest (tests/PassiveScalar.in: one refined level on the density gradient, subcycled, refluxed;
     src/problems/PassiveScalar/test_scalars.cpp): scalar conserved to 1e-14 and relative rms L1 error <= 0.008 after four box

@@ -307,3 +307,28 @@ def test_marshak_wave_meets_the_reference_criterion(oracle):
     err = marshak_error(s.valid(0), s.time)
     assert err < 0.02, err
     assert err > 1e-4
+
+
+def radforce_error(U, nx=128):
+    """RadForce's error norm (test_radiation_force.cpp:214-262): Mach number v / a0 against the steady wind solution tabulated in
+    extern/pressure_tube/optically_thin_wind.txt (columns x / Lx, density, Mach), relative L1."""
+    tab = np.loadtxt(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "optically_thin_wind.txt"), skiprows=1)
+    x = (np.arange(nx) + 0.5) / nx
+    mach = U[1, 0, 0] / U[0, 0, 0] / 0.2e5
+    exact = np.interp(x, tab[:, 0], tab[:, 2])
+    return float(np.abs(mach - exact).sum() / np.abs(exact).sum())
+
+
+def test_radiation_driven_isothermal_wind_meets_the_reference_criterion(oracle):
+    """RadForce (src/problems/RadForce/test_radiation_force.cpp, deck tests/RadForce.in): pins the ISOTHERMAL branches (gamma = 1:
+    no energy equation in the Riemann solver, pressure = rho a0^2, the matter-radiation energy exchange skipped) together with the
+    radiation force on the gas (flux-mean opacity only, beta_order 1, c_hat << c): Mach number of the steady wind within 0.002 of
+    the tabulated solution after 10 sound-crossing times (9520 steps with ~7 radiation substeps each)."""
+    from oracle.pyoracle import RADFORCE
+    s = oracle.sim(RADFORCE, 1, [128, 1, 1], [0, 0, 0], [1.0263747986171498e16, 1, 1], [0, 1, 1], max_grid_size=[128, 1, 1])
+    assert s.evolve() and s.istep == 9520
+    U = s.valid(0)
+    err = radforce_error(U)
+    assert err < 0.002, err
+    assert err > 1e-5
+    assert U[1, 0, 0, -1] / U[0, 0, 0, -1] / 0.2e5 > 2.0  # accelerated from Mach 1.1 to beyond 2

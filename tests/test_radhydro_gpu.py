@@ -241,3 +241,24 @@ def test_marshak_face_is_validated(ctx):
         with pytest.raises(capi.QkError):
             sim.set_initial_conditions(lambda i, j, k: np.ones((10,) + i.shape))
             sim.fillBoundaryConditions(sim.state_new_cc_)
+
+
+def test_radiation_driven_isothermal_wind_matches_oracle(ctx, oracle):
+    """RadForce through the C-ABI: isothermal EOS (`gamma = 1`, `cs_isothermal`) in the reference-shaped hydro operators and in the
+    radiation source update (no energy exchange, radiation force only), inflow face + extrapolation — 1200 steps bit for bit, then
+    the reference's criterion on the GPU's own full run."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_oracle_known_answers import radforce_error
+    from oracle.pyoracle import RADFORCE
+    from quokka_amd.radhydro import radforce_problem
+    so = oracle.sim(RADFORCE, 1, [128, 1, 1], [0, 0, 0], [1.0263747986171498e16, 1, 1], [0, 1, 1], max_grid_size=[128, 1, 1], rad_pow_mode=1)
+    sg = radforce_problem(ctx, 128, pow_mode=1)
+    assert np.array_equal(so.valid(0), sg.state_new_cc_.valid(0).cpu().numpy())
+    for it in range(1200):
+        assert so.step() and sg.step()
+        assert so.dt == sg.dt_, (it, so.dt, sg.dt_)
+    assert np.array_equal(so.valid(0), sg.state_new_cc_.valid(0).cpu().numpy())
+    assert sg.evolve() and sg.istep == 9520
+    err = radforce_error(sg.state_new_cc_.valid(0).cpu().numpy())
+    assert 1e-5 < err < 0.002, err
