@@ -216,10 +216,15 @@ typedef struct qk_rad_traits {
 	double c_light, c_hat, radiation_constant, Erad_floor;
 	int beta_order;	   /* 0..3 */
 	int opacity_model; /* 0: constants kappaP, kappaE, kappaF [cm^2 g^-1] (what RadhydroShell needs);
-			    * 1: kappa = kappaX / rho, a constant absorption coefficient [cm^-1] (RadhydroShockCGS, test_radhydro_shock_cgs.cpp:78-86) */
+			    * 1: kappa = kappaX / rho, a constant absorption coefficient [cm^-1] (RadhydroShockCGS, test_radhydro_shock_cgs.cpp:78-86)
+			    * 2: temperature power law  kappa = kappaX * max(pow(T / opacity_T_ref, opacity_T_exponent), opacity_pow_floor) / rho
+			    *    (RadMarshakAsymptotic test_radiation_marshak_asymptotic.cpp:55-59: exponent -3; RadhydroPulseGrey: -3.5 with
+			    *    different Planck and flux means; RadPulse: +3 with floor 1) */
 	double kappaP, kappaE, kappaF;
-	int pow_mode; /* 0: pow(T,4), pow(T,3) as the reference's std::pow; 1: repeated multiplication (bit-level tests) */
+	int pow_mode; /* 0: pow(T,4), pow(T,3) as the reference's std::pow; 1: repeated multiplication (bit-level tests; opacity exponents
+		       * 3, -3 and -3.5 are then products / square roots as well) */
 	int eddington_model; /* the ComputeEddingtonFactor hook: 0 Levermore closure (radiation_system.hpp:773-790), 1 chi = 1/3 */
+	double opacity_T_ref, opacity_T_exponent, opacity_pow_floor; /* opacity_model 2 only (floor 0: none) */
 } qk_rad_traits;
 /* State layout: Physics_Indices (reference src/physics_info.hpp:20-47): comps 0..5 hydro, 6..9 = (E_r, F_x, F_y, F_z). */
 

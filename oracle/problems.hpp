@@ -1181,6 +1181,107 @@ inline void setupRadForce(HydroSim &sim)
 	sim.finishInitialConditions();
 }
 
+
+// ---------------------------------------------------------------- Marshak wave in the asymptotic diffusion limit
+// src/problems/RadMarshakAsymptotic/test_radiation_marshak_asymptotic.cpp (McClarren & Lowrie 2008): opacity ~ T^-3
+struct MarshakAsymptoticConstants { // :19-28
+	static constexpr double kappa = 300.0;
+	static constexpr double rho0 = 2.0879373766122384;
+	static constexpr double T_hohlraum = 1.1604448449e7;
+	static constexpr double T_initial = T_hohlraum * 0.001;
+	static constexpr double a_rad = C::a_rad;
+	static constexpr double Erad_floor_ = a_rad * T_initial * T_initial * T_initial * T_initial;
+};
+
+inline void setupMarshakAsymptotic(HydroSim &sim)
+{
+	using S = MarshakAsymptoticConstants;
+	sim.hydro.tr.eos.tr.gamma = 5. / 3.; // :30-34
+	sim.hydro.tr.eos.tr.mean_molecular_weight = C::m_u;
+	sim.hydro.tr.eos.tr.boltzmann_constant = C::k_B;
+	sim.hydro.tr.reconstruct_eint = true;
+	sim.hydro.tr.nscalars = 0;
+	sim.ncomp_cc = kNumHydroVars + kNumRadVars;
+	sim.is_radiation_enabled = true; // :44-53
+	sim.is_hydro_enabled = false;
+	sim.rad.rt.c_light = C::c_light; // :36-42
+	sim.rad.rt.c_hat = C::c_light;
+	sim.rad.rt.radiation_constant = C::a_rad;
+	sim.rad.rt.Erad_floor = S::Erad_floor_;
+	sim.rad.rt.beta_order = 0;
+	sim.rad.rt.eddington_model = 1; // :67-70 Eddington approximation
+	sim.rad.eos = sim.hydro.tr.eos;
+	sim.rad.ndim = sim.geom.ndim;
+	sim.rad.nstartHyperbolic_ = kNumHydroVars;
+	// :55-65  sigma = kappa (T / T_H)^-3 [cm^-1], kappa = sigma / rho; with pow_mode 1 (bit-level tests) the power is a product
+	HydroSim *const simp = &sim;
+	auto opacity = [simp](double rho, double Tgas) {
+		double const x = Tgas / S::T_hohlraum;
+		double const pw = (simp->rad.rt.pow_mode == 1) ? 1.0 / ((x * x) * x) : std::pow(x, -3);
+		double const sigma = S::kappa * pw;
+		return sigma / rho;
+	};
+	sim.rad.ComputePlanckOpacity = opacity;
+	sim.rad.ComputeFluxMeanOpacity = opacity;
+	sim.rad.ComputeEnergyMeanOpacity = opacity;
+	// problem_main :200-250
+	sim.BCs_cc.assign(sim.ncomp_cc, BCRec{});
+	for (int n = 0; n < sim.ncomp_cc; ++n) {
+		sim.BCs_cc[n].lo[0] = ext_dir;
+		sim.BCs_cc[n].hi[0] = foextrap;
+	}
+	sim.radiationReconstructionOrder_ = 3;
+	sim.stopTime_ = 10.0e-9;
+	sim.initDt_ = 5.0e-12;
+	sim.maxDt_ = 5.0;
+	sim.radiationCflNumber_ = 10.0;
+	sim.maxTimesteps_ = 1000000;
+
+	EOS const eos = sim.hydro.tr.eos;
+	double const Egas = eos.ComputeEintFromTgas(S::rho0, S::T_initial);
+	double const Erad_initial = S::a_rad * std::pow(S::T_initial, 4);
+	// setCustomBoundaryConditions :72-140: Marshak condition beyond the lower face, constant state beyond the upper one
+	sim.customBC = [Egas, Erad_initial](int i, int j, int k, Array4<double> const &consVar, Box const &dom, double /*time*/) {
+		if (i < dom.lo[0]) {
+			const double T_H = S::T_hohlraum;
+			const double E_inc = C::a_rad * std::pow(T_H, 4);
+			const double c = C::c_light;
+			const double E_0 = consVar(dom.lo[0], j, k, kNumHydroVars + 0);
+			const double F_0 = consVar(dom.lo[0], j, k, kNumHydroVars + 1);
+			const double F_bdry = 0.5 * c * E_inc - 0.5 * (c * E_0 + 2.0 * F_0);
+			consVar(i, j, k, kNumHydroVars + 0) = E_inc;
+			consVar(i, j, k, kNumHydroVars + 1) = F_bdry;
+			consVar(i, j, k, kNumHydroVars + 2) = 0.;
+			consVar(i, j, k, kNumHydroVars + 3) = 0.;
+		} else {
+			consVar(i, j, k, kNumHydroVars + 0) = Erad_initial;
+			consVar(i, j, k, kNumHydroVars + 1) = 0;
+			consVar(i, j, k, kNumHydroVars + 2) = 0;
+			consVar(i, j, k, kNumHydroVars + 3) = 0;
+		}
+		consVar(i, j, k, energy_index) = Egas;
+		consVar(i, j, k, density_index) = S::rho0;
+		consVar(i, j, k, internalEnergy_index) = Egas;
+		consVar(i, j, k, x1Momentum_index) = 0.;
+		consVar(i, j, k, x2Momentum_index) = 0.;
+		consVar(i, j, k, x3Momentum_index) = 0.;
+	};
+	sim.define();
+	forEachValidCell(sim, [&](Array4<double> const &state_cc, int i, int j, int k) { // :142-164
+		state_cc(i, j, k, kNumHydroVars + 0) = Erad_initial;
+		state_cc(i, j, k, kNumHydroVars + 1) = 0;
+		state_cc(i, j, k, kNumHydroVars + 2) = 0;
+		state_cc(i, j, k, kNumHydroVars + 3) = 0;
+		state_cc(i, j, k, density_index) = S::rho0;
+		state_cc(i, j, k, energy_index) = Egas;
+		state_cc(i, j, k, internalEnergy_index) = Egas;
+		state_cc(i, j, k, x1Momentum_index) = 0.;
+		state_cc(i, j, k, x2Momentum_index) = 0.;
+		state_cc(i, j, k, x3Momentum_index) = 0.;
+	});
+	sim.finishInitialConditions();
+}
+
 } // namespace oracle
 
 #endif // ORACLE_PROBLEMS_HPP_

@@ -53,7 +53,8 @@ class DirichletFace(C.Structure):
 class RadTraits(C.Structure):
     _fields_ = [("c_light", C.c_double), ("c_hat", C.c_double), ("radiation_constant", C.c_double), ("Erad_floor", C.c_double),
                 ("beta_order", C.c_int), ("opacity_model", C.c_int), ("kappaP", C.c_double), ("kappaE", C.c_double), ("kappaF", C.c_double),
-                ("pow_mode", C.c_int), ("eddington_model", C.c_int)]
+                ("pow_mode", C.c_int), ("eddington_model", C.c_int),
+                ("opacity_T_ref", C.c_double), ("opacity_T_exponent", C.c_double), ("opacity_pow_floor", C.c_double)]
 
 
 class StageArgs(C.Structure):

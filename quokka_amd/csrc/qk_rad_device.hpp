@@ -18,18 +18,45 @@ constexpr double IMEX_a32 = 0.5; // radiation_system.hpp:52
 struct Rad {
 	double c, chat, arad, Erad_floor;
 	double kappaP0, kappaE0, kappaF0;
+	double kT_ref, kT_exp, kT_floor;
 	int beta_order, pow_mode, opacity_model, eddington_model;
 	__host__ __device__ explicit Rad(qk_rad_traits const &t)
 	    : c(t.c_light), chat(t.c_hat), arad(t.radiation_constant), Erad_floor(t.Erad_floor), kappaP0(t.kappaP), kappaE0(t.kappaE), kappaF0(t.kappaF),
-	      beta_order(t.beta_order), pow_mode(t.pow_mode), opacity_model(t.opacity_model), eddington_model(t.eddington_model)
+	      kT_ref(t.opacity_T_ref), kT_exp(t.opacity_T_exponent), kT_floor(t.opacity_pow_floor), beta_order(t.beta_order), pow_mode(t.pow_mode),
+	      opacity_model(t.opacity_model), eddington_model(t.eddington_model)
 	{
 	}
 	// problem hooks ComputePlanckOpacity / ComputeEnergyMeanOpacity / ComputeFluxMeanOpacity (radiation_system.hpp:1141-1154):
 	// closed set.  Model 0: constants [cm^2 g^-1]; model 1: constant absorption coefficient rho * kappa, i.e. kappa = k0 / rho
 	// (src/problems/RadhydroShockCGS/test_radhydro_shock_cgs.cpp:78-86)
-	QK_DEV auto kappaP(double rho, double /*T*/) const -> double { return (opacity_model == 0) ? kappaP0 : kappaP0 / rho; }
-	QK_DEV auto kappaE(double rho, double /*T*/) const -> double { return (opacity_model == 0) ? kappaE0 : kappaE0 / rho; }
-	QK_DEV auto kappaF(double rho, double /*T*/) const -> double { return (opacity_model == 0) ? kappaF0 : kappaF0 / rho; }
+	// Model 2 (TDEP instantiation of the source kernel only, so that the constant-opacity kernel keeps its registers): temperature
+	// power law  k0 * max((T / T_ref)^p, floor) / rho  (src/problems/RadMarshakAsymptotic/test_radiation_marshak_asymptotic.cpp:55-59)
+	QK_DEV auto opacityPow(double T) const -> double
+	{
+		const double x = T / kT_ref;
+		double pw;
+		if (pow_mode == 1 && kT_exp == 3.0) {
+			pw = (x * x) * x;
+		} else if (pow_mode == 1 && kT_exp == -3.0) {
+			pw = 1.0 / ((x * x) * x);
+		} else if (pow_mode == 1 && kT_exp == -3.5) {
+			pw = 1.0 / (((x * x) * x) * sqrt(x));
+		} else {
+			pw = pow(x, kT_exp);
+		}
+		return (pw > kT_floor) ? pw : kT_floor;
+	}
+	template <bool TDEP> QK_DEV auto kappaX(double k0, double rho, double T) const -> double
+	{
+		if constexpr (TDEP) {
+			return (k0 * opacityPow(T)) / rho;
+		} else {
+			return (opacity_model == 0) ? k0 : k0 / rho;
+		}
+	}
+	template <bool TDEP = false> QK_DEV auto kappaP(double rho, double T) const -> double { return kappaX<TDEP>(kappaP0, rho, T); }
+	template <bool TDEP = false> QK_DEV auto kappaE(double rho, double T) const -> double { return kappaX<TDEP>(kappaE0, rho, T); }
+	template <bool TDEP = false> QK_DEV auto kappaF(double rho, double T) const -> double { return kappaX<TDEP>(kappaF0, rho, T); }
 	// the ComputeEddingtonFactor hook: 0 = Levermore closure (radiation_system.hpp:773-790, the default), 1 = Eddington approximation
 	QK_DEV auto eddingtonFactor(double f_in) const -> double
 	{
@@ -192,6 +219,7 @@ QK_DEV auto egasFromEint(double rho, double px, double py, double pz, double Ein
 
 // source_terms_single_group.hpp:29-563 for one cell.  U[10] in place; counters as in the reference:
 // it_counter[0] += 1, [1] += n+1, [2] = max(n+1); fail[0] Newton failure, fail[2] outer-iteration failure.
+template <bool TDEP = false>
 QK_DEV void radSourceCell(Rad const &r, Eos const &eos, double U[10], double srcval, double dt_radiation, int stage, int &n_newton_total, int &n_newton_max,
 			  int &n_solves, int &fail_newton, int &fail_outer)
 {
@@ -267,15 +295,15 @@ QK_DEV void radSourceCell(Rad const &r, Eos const &eos, double U[10], double src
 				T_gas = eos.tgasFromEint(rho, Egas_guess);
 				T_d = T_gas;
 				fourPiBoverC = r.thermalRadiation(T_d);
-				kappaP = r.kappaP(rho, T_d);
-				kappaE = r.kappaE(rho, T_d);
+				kappaP = r.template kappaP<TDEP>(rho, T_d);
+				kappaE = r.template kappaE<TDEP>(rho, T_d);
 				if (kappaE > 0.0) {
 					kappaPoverE = kappaP / kappaE;
 				} else {
 					kappaPoverE = 1.0;
 				}
 				if (n == 0) {
-					kappaF = r.kappaF(rho, T_d);
+					kappaF = r.template kappaF<TDEP>(rho, T_d);
 					if (beta_order != 0) { // include_work_term_in_source = true
 						if (ite == 0) {
 							work = (x1GasMom0 * Frad_t0[0] + x2GasMom0 * Frad_t0[1] + x3GasMom0 * Frad_t0[2]) * (2.0 * kappaE - kappaF) * chat /
@@ -342,11 +370,11 @@ QK_DEV void radSourceCell(Rad const &r, Eos const &eos, double U[10], double src
 			// cooling_tend = 0 * dt: Erad_guess += (1/cscale) * 0
 			Erad_guess += (1 / cscale) * (0.0 * dt);
 			if (n > 0) {
-				kappaF = r.kappaF(rho, T_d);
+				kappaF = r.template kappaF<TDEP>(rho, T_d);
 			}
 		} else {
 			T_d = T_gas;
-			kappaF = r.kappaF(rho, T_d);
+			kappaF = r.template kappaF<TDEP>(rho, T_d);
 		}
 
 		// 2. radiation flux update

@@ -118,8 +118,12 @@ inline auto checkRad(qk_ctx *ctx, const qk_rad_traits *rt) -> int
 	if (rt == nullptr) {
 		return setError(ctx, QK_ERR_INVALID, "rad traits is NULL");
 	}
-	if (rt->opacity_model < 0 || rt->opacity_model > 1 || rt->eddington_model < 0 || rt->eddington_model > 1) {
-		return setError(ctx, QK_ERR_UNSUPPORTED, "opacity_model must be 0 (constant kappa) or 1 (constant rho * kappa), eddington_model 0 (Levermore) or 1 (1/3)");
+	if (rt->opacity_model == 2 && !(rt->opacity_T_ref > 0.0 && rt->opacity_pow_floor >= 0.0 && rt->opacity_T_exponent == rt->opacity_T_exponent)) {
+		return setError(ctx, QK_ERR_INVALID, "opacity_model 2 needs opacity_T_ref > 0, a finite opacity_T_exponent and opacity_pow_floor >= 0");
+	}
+	if (rt->opacity_model < 0 || rt->opacity_model > 2 || rt->eddington_model < 0 || rt->eddington_model > 1) {
+		return setError(ctx, QK_ERR_UNSUPPORTED,
+				"opacity_model must be 0 (constant kappa), 1 (constant rho * kappa) or 2 (temperature power law), eddington_model 0 (Levermore) or 1 (1/3)");
 	}
 	if (rt->beta_order < 0 || rt->beta_order > 3) {
 		return setError(ctx, QK_ERR_INVALID, "beta_order must be 0..3");
@@ -633,20 +637,12 @@ int qk_rad_AddFluxesRK2(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int
 	return radStatus(lev, "rad AddFluxesRK2");
 }
 
-int qk_rad_AddSourceTermsSingleGroup(qk_level *lev, qk_stream s, const qk_rad_traits *rt, const qk_hydro_traits *t, qk_array4 *cons_t,
-				     const qk_array4 *src_t, double dt, int stage, int *d_iteration_counter, int *d_failure_counter)
+} // extern "C"
+
+template <bool TDEP>
+static auto radSourceImpl(qk_level *lev, qk_stream s, const qk_rad_traits *rt, const qk_hydro_traits *t, qk_array4 *cons_t, const qk_array4 *src_t, double dt,
+			  int stage, int *d_iteration_counter, int *d_failure_counter) -> int
 {
-	if (lev == nullptr) {
-		return QK_ERR_INVALID;
-	}
-	if (int rc = checkRad(lev->ctx, rt); rc != QK_OK) {
-		return rc;
-	}
-	if (int rc = checkTraits(lev->ctx, t); rc != QK_OK) {
-		return rc;
-	}
-	QK_REQUIRE(lev->ctx, cons_t && src_t && d_iteration_counter && d_failure_counter, "AddSourceTermsSingleGroup: NULL");
-	QK_REQUIRE(lev->ctx, stage == 1 || stage == 2, "AddSourceTermsSingleGroup: stage must be 1 or 2");
 	const Rad rad(*rt);
 	const Eos eos(*t);
 	int *slots = counterSlots(lev->ctx);
@@ -662,7 +658,7 @@ int qk_rad_AddSourceTermsSingleGroup(qk_level *lev, qk_stream s, const qk_rad_tr
 			for (int n = 0; n < 10; ++n) {
 				U[n] = S.p[c + S.ns * n];
 			}
-			radSourceCell(rad, eos, U, Q(i, j, k), dt, stage, ntot, nmax, nsolve, fnewton, fouter);
+			radSourceCell<TDEP>(rad, eos, U, Q(i, j, k), dt, stage, ntot, nmax, nsolve, fnewton, fouter);
 			// rho (comp 0) is never modified
 #pragma unroll
 			for (int n = 1; n < 10; ++n) {
@@ -696,6 +692,27 @@ int qk_rad_AddSourceTermsSingleGroup(qk_level *lev, qk_stream s, const qk_rad_tr
 	});
 	hipLaunchKernelGGL(k_counters_finish, dim3(1), dim3(NSLOT), 0, static_cast<hipStream_t>(s), slots, d_iteration_counter, d_failure_counter);
 	return radStatus(lev, "AddSourceTermsSingleGroup");
+}
+
+extern "C" {
+
+int qk_rad_AddSourceTermsSingleGroup(qk_level *lev, qk_stream s, const qk_rad_traits *rt, const qk_hydro_traits *t, qk_array4 *cons_t,
+				     const qk_array4 *src_t, double dt, int stage, int *d_iteration_counter, int *d_failure_counter)
+{
+	if (lev == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	if (int rc = checkRad(lev->ctx, rt); rc != QK_OK) {
+		return rc;
+	}
+	if (int rc = checkTraits(lev->ctx, t); rc != QK_OK) {
+		return rc;
+	}
+	QK_REQUIRE(lev->ctx, cons_t && src_t && d_iteration_counter && d_failure_counter, "AddSourceTermsSingleGroup: NULL");
+	QK_REQUIRE(lev->ctx, stage == 1 || stage == 2, "AddSourceTermsSingleGroup: stage must be 1 or 2");
+	// the temperature-dependent opacities get their own instantiation: the constant-opacity kernel keeps its register budget
+	return (rt->opacity_model == 2) ? radSourceImpl<true>(lev, s, rt, t, cons_t, src_t, dt, stage, d_iteration_counter, d_failure_counter)
+					: radSourceImpl<false>(lev, s, rt, t, cons_t, src_t, dt, stage, d_iteration_counter, d_failure_counter);
 }
 
 } // extern "C"

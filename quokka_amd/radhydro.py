@@ -560,3 +560,45 @@ def radforce_problem(ctx: Context, nx: int = 128, pow_mode: int = 0) -> Radhydro
 
     sim.set_initial_conditions(ic)
     return sim
+
+
+class MarshakAsymptoticConstants:
+    """reference src/problems/RadMarshakAsymptotic/test_radiation_marshak_asymptotic.cpp:19-28"""
+    kappa = 300.0
+    rho0 = 2.0879373766122384
+    T_hohlraum = 1.1604448449e7
+    T_initial = T_hohlraum * 0.001
+    c_light = 2.99792458e10
+    a_rad = 4.0 * 5.670374419e-5 / c_light
+    Erad_floor = a_rad * T_initial * T_initial * T_initial * T_initial
+
+
+def marshak_asymptotic_problem(ctx: Context, nx: int = 60, pow_mode: int = 0) -> RadhydroSimulation:
+    """reference src/problems/RadMarshakAsymptotic/test_radiation_marshak_asymptotic.cpp + tests/MarshakAsymptotic.in (1-D build): a
+    Marshak wave in the equilibrium-diffusion limit (McClarren & Lowrie 2008): gamma-law gas, absorption coefficient
+    300 (T / T_H)^-3 cm^-1 (`opacity_model = 2`), Eddington approximation, Marshak condition on the lower face, radiation only."""
+    S = MarshakAsymptoticConstants
+    geom = Geometry(1, [nx], [0.0, 0.0, 0.0], [0.66, 1.0, 1.0], [0, 1, 1])
+    bcs = [([capi.BC_EXT_DIR, 0, 0], [capi.BC_FOEXTRAP, 0, 0]) for _ in range(10)]
+    traits = capi.traits(5.0 / 3.0, True, 1, mean_molecular_weight=capi.M_U, boltzmann_constant=capi.K_B)
+    rt = capi.RadTraits(S.c_light, S.c_light, S.a_rad, S.Erad_floor, 0, 2, S.kappa, S.kappa, S.kappa, pow_mode, 1, S.T_hohlraum, -3.0, 0.0)
+    # quokka::EOS::ComputeEintFromTgas (EOS.hpp:116-159) in its order of operations
+    mu_ = capi.M_U / capi.M_U
+    pres = S.rho0 * S.T_initial * capi.K_B / (mu_ * capi.M_U)
+    Egas = pres / ((5.0 / 3.0 - 1.0) * S.rho0) * S.rho0 * capi.K_B / capi.K_B
+    Erad = S.a_rad * math.pow(S.T_initial, 4)
+    E_inc = S.a_rad * math.pow(S.T_hohlraum, 4)
+    gas = [S.rho0, 0.0, 0.0, 0.0, Egas, Egas]
+    dirichlet = {(0, 0): {"values": gas + [E_inc, 0.0, 0.0, 0.0], "marshak": (RAD0, RAD0 + 1, S.c_light)}, (0, 1): gas + [Erad, 0.0, 0.0, 0.0]}
+    sim = RadhydroSimulation(ctx, geom, traits, rt, bcs, [nx, 1, 1], use_fused=False, dirichlet=dirichlet)
+    sim.is_hydro_enabled = False
+    sim.radiationReconstructionOrder_ = 3  # problem_main :200-250
+    sim.stopTime_, sim.initDt_, sim.maxDt_, sim.radiationCflNumber_, sim.maxTimesteps_ = 10.0e-9, 5.0e-12, 5.0, 10.0, 1000000
+
+    def ic(i, j, k):  # setInitialConditionsOnGrid :142-164
+        U = np.zeros((10,) + i.shape)
+        U[0], U[4], U[5], U[6] = S.rho0, Egas, Egas, Erad
+        return U
+
+    sim.set_initial_conditions(ic)
+    return sim

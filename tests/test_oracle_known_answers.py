@@ -332,3 +332,27 @@ def test_radiation_driven_isothermal_wind_meets_the_reference_criterion(oracle):
     assert err < 0.002, err
     assert err > 1e-5
     assert U[1, 0, 0, -1] / U[0, 0, 0, -1] / 0.2e5 > 2.0  # accelerated from Mach 1.1 to beyond 2
+
+
+def marshak_asymptotic_error(U, nx=60, Lx=0.66):
+    """RadMarshakAsymptotic's error norm (test_radiation_marshak_asymptotic.cpp:255-315): gas temperature / T_H interpolated onto the
+    points of the similarity solution extern/marshak_similarity.csv (whose first row the reference skips as a header), relative L1."""
+    tab = np.loadtxt(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "marshak_similarity.csv"), skiprows=1)
+    x = (np.arange(nx) + 0.5) * (Lx / nx)
+    Eint = U[4, 0, 0] - U[1, 0, 0] ** 2 / (2.0 * U[0, 0, 0])
+    T = (5.0 / 3.0 - 1.0) * Eint * 1.6605390666e-24 / (U[0, 0, 0] * 1.380649e-16) / 1.1604448449e7
+    Ti = np.interp(tab[:, 0], x, T)
+    return float(np.abs(Ti - tab[:, 1]).sum() / np.abs(tab[:, 1]).sum())
+
+
+def test_marshak_wave_in_the_diffusion_limit_meets_the_reference_criterion(oracle):
+    """RadMarshakAsymptotic (deck tests/MarshakAsymptotic.in): a temperature-dependent opacity (absorption coefficient 300 (T/T_H)^-3
+    per cm, re-evaluated inside the Newton-Raphson / outer iterations of the exchange solve), Eddington approximation, Marshak boundary;
+    90847 steps on 60 cells; gas temperature within 9 per cent (the reference's tolerance) of the similarity solution."""
+    from oracle.pyoracle import MARSHAK_ASYMPTOTIC
+    s = oracle.sim(MARSHAK_ASYMPTOTIC, 1, [60, 1, 1], [0, 0, 0], [0.66, 1, 1], [0, 1, 1], max_grid_size=[60, 1, 1])
+    assert s.evolve() and s.istep == 90847
+    c = s.rad_counters()
+    assert c["fail_coupling"] == c["fail_outer"] == 0 and c["max_newton_iterations"] >= 3
+    err = marshak_asymptotic_error(s.valid(0))
+    assert 1e-3 < err < 0.09, err
