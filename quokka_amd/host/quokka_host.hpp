@@ -369,8 +369,38 @@ template <typename problem_t> class RadSystem : public HyperbolicSystem<problem_
 				opacity_model = model;
 			}
 		}
+		double kT_ref = 0.0, kT_exp = 0.0;
+		double k0[3] = {kP, kE, kF};
 		if (opacity_model < 0) {
-			amrex::Abort("RadSystem: these opacity hooks are not expressible in the C-ABI's closed opacity set (constant kappa, constant rho * kappa)");
+			// model 2: kappa_X = k0_X (T / T_ref)^p / rho with one exponent for the three means.  T_ref and k0 cannot be told apart by
+			// sampling: T_ref = 1 K is used and k0 = rho * kappa(rho, 1 K); the exponent is taken as the nearest multiple of 1/2
+			// (the product form differs from the problem's own expression by rounding only — checked to 1e-12 on the sample grid)
+			double const T1 = 1.0e3, T2 = 1.0e6;
+			double const slope = std::log(ComputePlanckOpacity(1.0, T2) / ComputePlanckOpacity(1.0, T1)) / std::log(T2 / T1);
+			double const p = std::round(2.0 * slope) / 2.0;
+			double const kk[3] = {ComputePlanckOpacity(1.0, T1) / std::pow(T1, p), ComputeEnergyMeanOpacity(1.0, T1) / std::pow(T1, p),
+					      ComputeFluxMeanOpacity(1.0, T1) / std::pow(T1, p)};
+			bool ok = std::isfinite(p) && std::abs(slope - p) < 1e-9;
+			for (double r : rs) {
+				for (double T : Ts) {
+					double const pw = std::pow(T, p);
+					auto close = [](double a, double b) { return std::abs(a - b) <= 1e-12 * std::abs(b); };
+					ok = ok && close(ComputePlanckOpacity(r, T), kk[0] * pw / r) && close(ComputeEnergyMeanOpacity(r, T), kk[1] * pw / r) &&
+					     close(ComputeFluxMeanOpacity(r, T), kk[2] * pw / r);
+				}
+			}
+			if (ok) {
+				opacity_model = 2;
+				kT_ref = 1.0;
+				kT_exp = p;
+				k0[0] = kk[0];
+				k0[1] = kk[1];
+				k0[2] = kk[2];
+			}
+		}
+		if (opacity_model < 0) {
+			amrex::Abort("RadSystem: these opacity hooks are not expressible in the C-ABI's closed opacity set (constant kappa, constant rho * "
+				     "kappa, temperature power law of rho * kappa)");
 		}
 		int eddington_model = -1;
 		{
@@ -388,7 +418,7 @@ template <typename problem_t> class RadSystem : public HyperbolicSystem<problem_
 		int pow_mode = 0;
 		amrex::ParmParse pp("radiation");
 		pp.query("pow_mode", pow_mode); // 0: pow(T, 4) like the reference's std::pow; 1: repeated multiplication
-		return {c_light_, c_hat_, radiation_constant_, Erad_floor_, beta_order_, opacity_model, kP, kE, kF, pow_mode, eddington_model};
+		return {c_light_, c_hat_, radiation_constant_, Erad_floor_, beta_order_, opacity_model, k0[0], k0[1], k0[2], pow_mode, eddington_model, kT_ref, kT_exp, 0.0};
 	}
 	static auto lev() -> qk_level * { return qkhost::Runtime::get().lev; }
 	static void flux3(std::array<amrex::MultiFab, AMREX_SPACEDIM> const &f, qk_array4 *out[3])

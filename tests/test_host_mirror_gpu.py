@@ -229,6 +229,22 @@ def test_radiation_force_executable_meets_the_reference_criterion_and_matches_or
     assert np.array_equal(data.reshape(10, 128), so.valid(0).reshape(10, 128))
 
 
+def test_marshak_asymptotic_executable_meets_the_reference_criterion(tmp_path, oracle):
+    """the reference's RadMarshakAsymptotic ctest through the C++ mirror: the temperature power law of the opacity hooks is recognised by
+    sampling (opacity_model 2; T_ref = 1 K, so the product differs from the problem's own expression by rounding — no bit-level claim
+    here, that is tests/test_radhydro_gpu.py's); exit status 0 == gas temperature within 9 per cent of the similarity solution after
+    90847 steps, and the state agrees with the oracle's to 1e-6."""
+    from oracle.pyoracle import MARSHAK_ASYMPTOTIC
+    table = os.path.join(ROOT, "tests", "golden", "marshak_similarity.csv")
+    data, meta, out = run("test_radiation_marshak_asymptotic", [os.path.join(HOST, "decks", "MarshakAsymptotic.in"), f"marshak.solution_file={table}"], tmp_path)
+    assert int(meta[0]) == 90847 and 1e-3 < meta[5] < 0.09, meta
+    so = oracle.sim(MARSHAK_ASYMPTOTIC, 1, [60, 1, 1], [0, 0, 0], [0.66, 1, 1], [0, 1, 1], max_grid_size=[60, 1, 1])
+    assert so.evolve()
+    A, B = data.reshape(10, 60), so.valid(0).reshape(10, 60)
+    for n in (4, 6):
+        assert float(np.abs(A[n] - B[n]).sum() / np.abs(B[n]).sum()) < 1e-6
+
+
 def test_passive_scalar_executable_meets_the_reference_criteria(tmp_path):
     """the reference's PassiveScalar ctest (tests/PassiveScalar.in: one refined level on the density gradient, subcycled, refluxed;
     src/problems/PassiveScalar/test_scalars.cpp): scalar conserved to 1e-14 and relative rms L1 error <= 0.008 after four box
