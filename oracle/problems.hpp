@@ -1282,6 +1282,86 @@ inline void setupMarshakAsymptotic(HydroSim &sim)
 	sim.finishInitialConditions();
 }
 
+
+// ---------------------------------------------------------------- linear diffusion of a Gaussian pulse (src/problems/RadPulse/test_radiation_pulse.cpp)
+struct RadPulseConstants { // :20-29
+	static constexpr double kappa0 = 1.0e5, T0 = 1.0, rho0 = 1.0, a_rad = 4.0e-10, c = 1.0e8, chat = 1.0e7;
+	static constexpr double erad_floor = a_rad * (1.0e-10);
+	static constexpr double initial_time = 1.0e-8;
+};
+
+// :58-68 diffusion solution for the Gaussian pulse
+inline auto radPulseExactTrad(double x, double t) -> double
+{
+	using S = RadPulseConstants;
+	const double sigma = 0.025;
+	const double D = 4.0 * S::c * S::a_rad * std::pow(S::T0, 3) / (3.0 * S::kappa0);
+	const double width_sq = (sigma * sigma + D * t);
+	const double normfac = 1.0 / (2.0 * std::sqrt(M_PI * width_sq));
+	return 0.5 * normfac * std::exp(-(x * x) / (4.0 * width_sq));
+}
+
+inline void setupRadPulse(HydroSim &sim)
+{
+	using S = RadPulseConstants;
+	sim.hydro.tr.eos.tr.gamma = 5. / 3.; // :31-35
+	sim.hydro.tr.eos.tr.mean_molecular_weight = 1.0;
+	sim.hydro.tr.eos.tr.boltzmann_constant = (2. / 3.);
+	sim.hydro.tr.reconstruct_eint = true;
+	sim.hydro.tr.nscalars = 0;
+	sim.ncomp_cc = kNumHydroVars + kNumRadVars;
+	sim.is_radiation_enabled = true; // :45-55
+	sim.is_hydro_enabled = false;
+	sim.rad.rt.c_light = S::c; // :37-43
+	sim.rad.rt.c_hat = S::chat;
+	sim.rad.rt.radiation_constant = S::a_rad;
+	sim.rad.rt.Erad_floor = S::erad_floor;
+	sim.rad.rt.beta_order = 0;
+	sim.rad.eos = sim.hydro.tr.eos;
+	sim.rad.ndim = sim.geom.ndim;
+	sim.rad.nstartHyperbolic_ = kNumHydroVars;
+	// :70-79  kappa = (kappa0 / rho) max((T / T0)^3, 1): the diffusion equation is linear in T above T0; pow_mode 1: the cube as a product
+	HydroSim *const simp = &sim;
+	auto opacity = [simp](double rho, double Tgas) {
+		double const x = Tgas / S::T0;
+		double const pw = (simp->rad.rt.pow_mode == 1) ? (x * x) * x : std::pow(x, 3);
+		return (S::kappa0 / rho) * std::max(pw, 1.0);
+	};
+	sim.rad.ComputePlanckOpacity = opacity;
+	sim.rad.ComputeFluxMeanOpacity = opacity;
+	sim.rad.ComputeEnergyMeanOpacity = opacity;
+	// problem_main :121-150
+	sim.BCs_cc.assign(sim.ncomp_cc, BCRec{});
+	for (int n = 0; n < sim.ncomp_cc; ++n) {
+		sim.BCs_cc[n].lo[0] = foextrap;
+		sim.BCs_cc[n].hi[0] = foextrap;
+	}
+	sim.radiationReconstructionOrder_ = 3;
+	sim.stopTime_ = 1.0e-4;
+	sim.radiationCflNumber_ = 0.8;
+	sim.maxDt_ = 1e-3;
+	sim.maxTimesteps_ = 100000;
+	sim.define();
+	EOS const eos = sim.hydro.tr.eos;
+	double const x0 = sim.geom.prob_lo[0] + 0.5 * (sim.geom.prob_hi[0] - sim.geom.prob_lo[0]);
+	forEachValidCell(sim, [&](Array4<double> const &state_cc, int i, int j, int k) { // :81-108
+		double const x = sim.geom.prob_lo[0] + (i + 0.5) * sim.geom.dx[0];
+		double const Trad = radPulseExactTrad(x - x0, S::initial_time);
+		double const Egas = eos.ComputeEintFromTgas(S::rho0, Trad);
+		state_cc(i, j, k, kNumHydroVars + 0) = S::erad_floor;
+		state_cc(i, j, k, kNumHydroVars + 1) = 0;
+		state_cc(i, j, k, kNumHydroVars + 2) = 0;
+		state_cc(i, j, k, kNumHydroVars + 3) = 0;
+		state_cc(i, j, k, energy_index) = Egas;
+		state_cc(i, j, k, density_index) = S::rho0;
+		state_cc(i, j, k, internalEnergy_index) = Egas;
+		state_cc(i, j, k, x1Momentum_index) = 0.;
+		state_cc(i, j, k, x2Momentum_index) = 0.;
+		state_cc(i, j, k, x3Momentum_index) = 0.;
+	});
+	sim.finishInitialConditions();
+}
+
 } // namespace oracle
 
 #endif // ORACLE_PROBLEMS_HPP_

@@ -602,3 +602,52 @@ def marshak_asymptotic_problem(ctx: Context, nx: int = 60, pow_mode: int = 0) ->
 
     sim.set_initial_conditions(ic)
     return sim
+
+
+class RadPulseConstants:
+    """reference src/problems/RadPulse/test_radiation_pulse.cpp:20-29"""
+    kappa0, T0, rho0, a_rad, c, chat = 1.0e5, 1.0, 1.0, 4.0e-10, 1.0e8, 1.0e7
+    erad_floor = a_rad * (1.0e-10)
+    initial_time = 1.0e-8
+
+
+def radpulse_exact_Trad(x, t):
+    """compute_exact_Trad (test_radiation_pulse.cpp:58-68): the diffusion solution for the Gaussian pulse"""
+    S = RadPulseConstants
+    sigma = 0.025
+    D = 4.0 * S.c * S.a_rad * math.pow(S.T0, 3) / (3.0 * S.kappa0)
+    width_sq = sigma * sigma + D * t
+    normfac = 1.0 / (2.0 * np.sqrt(np.pi * width_sq))
+    return 0.5 * normfac * np.exp(-(x * x) / (4.0 * width_sq))
+
+
+def radpulse_problem(ctx: Context, nx: int = 32, pow_mode: int = 0, initial_state=None) -> RadhydroSimulation:
+    """reference src/problems/RadPulse/test_radiation_pulse.cpp + tests/RadPulse.in (1-D build): a Gaussian temperature pulse diffusing
+    in a medium with kappa = (kappa0 / rho) max((T / T0)^3, 1) — `opacity_model = 2` with exponent 3 and floor 1 —, optical depth
+    ~1e5 per cell at the peak; radiation only, c_hat = c / 10, extrapolation at both faces.  `initial_state` (10, 1, 1, nx): start from
+    a given state instead of evaluating the Gaussian here (numpy's exp and libm's may differ in the last place)."""
+    S = RadPulseConstants
+    geom = Geometry(1, [nx], [0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [0, 1, 1])
+    bcs = [([capi.BC_FOEXTRAP, 0, 0], [capi.BC_FOEXTRAP, 0, 0]) for _ in range(10)]
+    traits = capi.traits(5.0 / 3.0, True, 1, mean_molecular_weight=1.0, boltzmann_constant=2.0 / 3.0)
+    rt = capi.RadTraits(S.c, S.chat, S.a_rad, S.erad_floor, 0, 2, S.kappa0, S.kappa0, S.kappa0, pow_mode, 0, S.T0, 3.0, 1.0)
+    sim = RadhydroSimulation(ctx, geom, traits, rt, bcs, [nx, 1, 1], use_fused=False)
+    sim.is_hydro_enabled = False
+    sim.radiationReconstructionOrder_ = 3  # problem_main :121-150
+    sim.stopTime_, sim.radiationCflNumber_, sim.maxDt_, sim.maxTimesteps_ = 1.0e-4, 0.8, 1e-3, 100000
+    dx = geom.dx[0]
+
+    def ic(i, j, k):  # setInitialConditionsOnGrid :81-108
+        if initial_state is not None:
+            return np.asarray(initial_state)[:, k, j, i]
+        x = (i + 0.5) * dx
+        Trad = radpulse_exact_Trad(x - 0.5, S.initial_time)
+        mu_ = 1.0 / capi.M_U  # quokka::EOS::ComputeEintFromTgas in its order of operations
+        pres = S.rho0 * Trad * capi.K_B / (mu_ * capi.M_U)
+        Egas = pres / ((5.0 / 3.0 - 1.0) * S.rho0) * S.rho0 * (2.0 / 3.0) / capi.K_B
+        U = np.zeros((10,) + i.shape)
+        U[0], U[4], U[5], U[6] = S.rho0, Egas, Egas, S.erad_floor
+        return U
+
+    sim.set_initial_conditions(ic)
+    return sim

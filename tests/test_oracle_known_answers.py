@@ -356,3 +356,20 @@ def test_marshak_wave_in_the_diffusion_limit_meets_the_reference_criterion(oracl
     assert c["fail_coupling"] == c["fail_outer"] == 0 and c["max_newton_iterations"] >= 3
     err = marshak_asymptotic_error(s.valid(0))
     assert 1e-3 < err < 0.09, err
+
+
+def test_linear_diffusion_of_a_radiation_pulse_meets_the_reference_criterion(oracle):
+    """RadPulse (src/problems/RadPulse/test_radiation_pulse.cpp, deck tests/RadPulse.in): opacity (kappa0 / rho) max((T / T0)^3, 1) — the
+    floored member of the power-law opacities —, ~1e5 optical depths per cell: the asymptotic-preserving limit of the IMEX scheme.
+    The run ends at max_timesteps = 1e5 (t = 9.375e-5 < 1e-4, as the reference's would); radiation temperature within 1 per cent of the
+    diffusion solution at that time."""
+    from oracle.pyoracle import RADPULSE
+    from quokka_amd.radhydro import radpulse_exact_Trad
+    s = oracle.sim(RADPULSE, 1, [32, 1, 1], [0, 0, 0], [1.0, 1, 1], [0, 1, 1], max_grid_size=[32, 1, 1])
+    assert s.evolve() and s.istep == 100000 and 9.3e-5 < s.time < 9.4e-5
+    U = s.valid(0)
+    x = (np.arange(32) + 0.5) / 32 - 0.5
+    exact = radpulse_exact_Trad(x, 1.0e-8 + s.time)
+    Trad = np.power(U[6, 0, 0] / 4.0e-10, 0.25)
+    err = float(np.abs(Trad - exact).sum() / np.abs(exact).sum())
+    assert 1e-4 < err < 0.01, err

@@ -287,3 +287,27 @@ def test_temperature_dependent_opacity_matches_oracle(ctx, oracle):
         assert sp.step()
     V = sp.state_new_cc_.valid(0).cpu().numpy()
     assert np.allclose(V, U, rtol=1e-9, atol=0)
+
+
+def test_floored_power_law_opacity_matches_oracle(ctx, oracle):
+    """RadPulse through the C-ABI: `opacity_model = 2` with exponent +3 and floor 1 (cells on both sides of the floor), c_hat = c / 10,
+    starting from the oracle's initial state — 3000 steps bit for bit; and from the Python evaluation of the Gaussian to 1e-10."""
+    from oracle.pyoracle import RADPULSE
+    from quokka_amd.radhydro import radpulse_problem
+    so = oracle.sim(RADPULSE, 1, [32, 1, 1], [0, 0, 0], [1.0, 1, 1], [0, 1, 1], max_grid_size=[32, 1, 1], rad_pow_mode=1)
+    U0 = so.valid(0).copy()
+    T0 = U0[5, 0, 0] / U0[0, 0, 0]  # k_B = 2/3, mu = 1, gamma = 5/3: T = E_int / rho
+    assert T0.max() > 1.0 > T0.min()  # the floor max((T / T0)^3, 1) is active in the wings only
+    sg = radpulse_problem(ctx, 32, pow_mode=1, initial_state=U0)
+    assert np.array_equal(U0, sg.state_new_cc_.valid(0).cpu().numpy())
+    for it in range(3000):
+        assert so.step() and sg.step()
+        assert so.dt == sg.dt_, (it, so.dt, sg.dt_)
+    U = sg.state_new_cc_.valid(0).cpu().numpy()
+    assert np.array_equal(so.valid(0), U)
+    assert U[6, 0, 0].max() > 1e3 * 4.0e-20  # radiation has come into equilibrium with the hot gas
+    sp = radpulse_problem(ctx, 32, pow_mode=1)
+    assert np.allclose(sp.state_new_cc_.valid(0).cpu().numpy(), U0, rtol=1e-14, atol=0)
+    for it in range(3000):
+        assert sp.step()
+    assert np.allclose(sp.state_new_cc_.valid(0).cpu().numpy(), U, rtol=1e-10, atol=0)
