@@ -75,7 +75,9 @@ typedef struct qk_hydro_traits {
 	int reconstruct_eint;
 	int nscalars;  /* Physics_Traits::numPassiveScalars, 0..QK_MAX_SCALARS: carried by the reference-shaped operators (state / flux arrays hold
 			* 6 + nscalars components); the fused stage refuses nscalars > 0 (QK_ERR_UNSUPPORTED) */
-	int nmscalars; /* mass scalars: must be 0 */
+	int nmscalars; /* Physics_Traits::numMassScalars, 0..nscalars: the first nmscalars passive scalars are partial densities — consistent
+			* multi-fluid advection of their fluxes (hydro_system.hpp:1062-1073,1094-1104), non-negativity in isStateValid (:430-441),
+			* floor and renormalisation in EnforceLimits (:725-744; small_x = 1e-30) */
 	int ndim;      /* 1 or 3 */
 	/* the quokka::EOS<P> temperature hooks a problem may specialise (ComputeTgasFromEint / ComputeEintFromTgas / ComputeEintTempDerivative,
 	 * reference src/hydro/EOS.hpp:74-244), closed set used by the radiation source terms:

@@ -40,6 +40,7 @@ struct HydroTraits {
 	EOS eos;			 // quokka::EOS_Traits<problem_t>
 	bool reconstruct_eint = true;	 // HydroSystem_Traits<problem_t> (hydro_system.hpp:38-41)
 	int nscalars = 0;		 // Physics_Traits::numPassiveScalars
+	int nmscalars = 0;		 // Physics_Traits::numMassScalars (the first nmscalars passive scalars are partial densities)
 	int ndim = 3;			 // AMREX_SPACEDIM of the build
 	[[nodiscard]] auto nvar() const -> int { return kNumHydroVars + nscalars; }
 	[[nodiscard]] auto is_eos_isothermal() const -> bool { return eos.tr.gamma == 1.0; } // hydro_system.hpp:133
@@ -279,10 +280,18 @@ struct HydroSystem {
 	}
 
 	// hydro_system.hpp:423-446 (nmscalars = 0)
-	[[nodiscard]] static auto isStateValid(Array4<const double> const &cons, int i, int j, int k) -> bool
+	[[nodiscard]] auto isStateValid(Array4<const double> const &cons, int i, int j, int k) const -> bool
 	{
 		const double rho = cons(i, j, k, density_index);
-		return (rho > 0.);
+		bool const isDensityPositive = (rho > 0.);
+		bool isMassScalarPositive = true; // :430-441
+		for (int idx = 0; idx < tr.nmscalars; ++idx) {
+			if (cons(i, j, k, scalar0_index + idx) < 0.0) {
+				isMassScalarPositive = false;
+				break;
+			}
+		}
+		return isDensityPositive && isMassScalarPositive;
 	}
 
 	// hydro_system.hpp:138-196; launched over valid + nghost
@@ -668,7 +677,25 @@ struct HydroSystem {
 					const double v_norm = (F[density_index] >= 0.) ? (F[density_index] / rho_R) : (F[density_index] / rho_L);
 					x1FaceVel(i, j, k) = v_norm;
 
-					// :1094-1104 mass-scalar renormalisation: nmscalars = 0, no-op
+					// :1094-1104 consistent multi-fluid advection (Plewa & Mueller 1999): the partial-density fluxes are the mass
+					// flux split in the proportions of the upwind state, so that they sum to it
+					if (tr.nmscalars > 0) {
+						double fluxSum_U_L = 0, fluxSum_U_R = 0; // :1062-1073
+						const int nstart = nvar_ - nscalars_;
+						for (int n = 0; n < tr.nmscalars; ++n) {
+							fluxSum_U_L += U_L[nstart + n];
+							fluxSum_U_R += U_R[nstart + n];
+						}
+						if (F[density_index] >= 0.) {
+							for (int n = 0; n < tr.nmscalars; ++n) {
+								F[nstart + n] = F[density_index] * U_L[nstart + n] / fluxSum_U_L;
+							}
+						} else {
+							for (int n = 0; n < tr.nmscalars; ++n) {
+								F[nstart + n] = F[density_index] * U_R[nstart + n] / fluxSum_U_R;
+							}
+						}
+					}
 
 					// :1107-1110
 					for (int nc = 0; nc < nvar_; ++nc) {
@@ -755,7 +782,7 @@ struct HydroSystem {
 		}
 	}
 
-	// hydro_system.hpp:696-773 (nmscalars = 0)
+	// hydro_system.hpp:696-773
 	void EnforceLimits(double const densityFloor, double const tempFloor, Array4<double> const &state, Box const &range) const
 	{
 		for (int k = range.lo[2]; k <= range.hi[2]; ++k) {
@@ -774,6 +801,22 @@ struct HydroSystem {
 								} else {
 									state(i, j, k, scalar0_index + n) *= rho / rho_new;
 								}
+							}
+						}
+					}
+					// :725-744 mass-scalar floor and renormalisation (network_rp::small_x of the un-vendored Microphysics: its default 1e-30)
+					if (tr.nmscalars > 0) {
+						double sp_sum = 0.0;
+						for (int idx = 0; idx < tr.nmscalars; ++idx) {
+							if (state(i, j, k, scalar0_index + idx) < 0.0) {
+								state(i, j, k, scalar0_index + idx) = 1.0e-30 * rho_new;
+							}
+							sp_sum += state(i, j, k, scalar0_index + idx);
+						}
+						if ((sp_sum > std::numeric_limits<double>::min()) && (rho_new > std::numeric_limits<double>::min())) {
+							sp_sum /= rho_new;
+							for (int idx = 0; idx < tr.nmscalars; ++idx) {
+								state(i, j, k, scalar0_index + idx) /= sp_sum;
 							}
 						}
 					}

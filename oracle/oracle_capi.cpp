@@ -169,6 +169,8 @@ void *orc_sim_create(orc_sim_config const *c)
 		p.dirichlet = c->h1d_i[1];
 		p.max_timesteps = c->max_timesteps >= 0 ? c->max_timesteps : 100000;
 		setupHydro1D(*sim, p);
+	} else if (c->problem == 15) {
+		setupShocktubeCMA(*sim);
 	} else if (c->problem == 14) {
 		setupRadPulse(*sim);
 		sim->rad.rt.pow_mode = c->rad_pow_mode;

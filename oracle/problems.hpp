@@ -1362,6 +1362,106 @@ inline void setupRadPulse(HydroSim &sim)
 	sim.finishInitialConditions();
 }
 
+
+// ---------------------------------------------------------------- Sod tube with three species, consistent multi-fluid advection
+// src/problems/HydroShocktubeCMA/test_hydro_shocktube_cma.cpp, deck tests/shocktube_cma.in (restated on the unrefined grid: the
+// reference's deck adds one AMR level)
+// left- and right-side states :51-55 (Plewa & Mueller 1999)
+constexpr double cma_rho_L = 1.0, cma_P_L = 1.0, cma_rho_R = 0.125, cma_P_R = 0.1;
+
+inline void setupShocktubeCMA(HydroSim &sim)
+{
+	sim.hydro.tr.eos.tr.gamma = 1.4; // :34-38
+	sim.hydro.tr.eos.tr.mean_molecular_weight = C::m_u;
+	sim.hydro.tr.eos.tr.boltzmann_constant = C::k_B;
+	sim.hydro.tr.reconstruct_eint = true;
+	sim.hydro.tr.nscalars = 3; // :40-49
+	sim.hydro.tr.nmscalars = 3;
+	sim.ncomp_cc = kNumHydroVars + 3;
+	// problem_main :248-268 and the deck
+	sim.BCs_cc.assign(sim.ncomp_cc, BCRec{});
+	sim.BCs_cc[0].lo[0] = ext_dir; // only BCs_cc[0] is set in the reference loop (sic)
+	sim.BCs_cc[0].hi[0] = ext_dir;
+	sim.cflNumber_ = 0.6;
+	sim.reconstructionOrder_ = 3;
+	sim.artificialViscosityK_ = 0.1;
+	sim.stopTime_ = 1.0;
+	sim.maxTimesteps_ = 80000;
+
+	const double gamma = 1.4;
+	// setCustomBoundaryConditions :118-177 (the third species beyond either face is `1 - X0 - X1 rho`, sic)
+	sim.customBC = [gamma](int i, int j, int k, Array4<double> const &consVar, Box const &dom, double /*time*/) {
+		int const numcomp = consVar.ncomp;
+		if (i < dom.lo[0]) {
+			for (int n = 0; n < numcomp; ++n) {
+				consVar(i, j, k, n) = 0;
+			}
+			consVar(i, j, k, energy_index) = cma_P_L / (gamma - 1.);
+			consVar(i, j, k, internalEnergy_index) = cma_P_L / (gamma - 1.);
+			consVar(i, j, k, density_index) = cma_rho_L;
+			consVar(i, j, k, x1Momentum_index) = 0.;
+			consVar(i, j, k, x2Momentum_index) = 0.;
+			consVar(i, j, k, x3Momentum_index) = 0.;
+			consVar(i, j, k, scalar0_index + 0) = 0.8 * cma_rho_L;
+			consVar(i, j, k, scalar0_index + 1) = 0.3 * std::pow(std::sin(20 * 3.14 * 0), 2) * cma_rho_L;
+			consVar(i, j, k, scalar0_index + 2) = 1 - 0.8 - 0.3 * std::pow(std::sin(20 * 3.14 * 0), 2) * cma_rho_L;
+		} else if (i >= dom.hi[0]) {
+			for (int n = 0; n < numcomp; ++n) {
+				consVar(i, j, k, n) = 0;
+			}
+			consVar(i, j, k, energy_index) = cma_P_R / (gamma - 1.);
+			consVar(i, j, k, internalEnergy_index) = cma_P_R / (gamma - 1.);
+			consVar(i, j, k, density_index) = cma_rho_R;
+			consVar(i, j, k, x1Momentum_index) = 0.;
+			consVar(i, j, k, x2Momentum_index) = 0.;
+			consVar(i, j, k, x3Momentum_index) = 0.;
+			consVar(i, j, k, scalar0_index + 0) = 0.1 * cma_rho_R;
+			consVar(i, j, k, scalar0_index + 1) = 0.3 * std::pow(std::sin(20 * 3.14 * 1), 2) * cma_rho_R;
+			consVar(i, j, k, scalar0_index + 2) = 1 - 0.1 - 0.3 * std::pow(std::sin(20 * 3.14 * 1), 2) * cma_rho_R;
+		}
+	};
+
+	sim.define();
+	double const dx0 = sim.geom.dx[0];
+	double const lo0 = sim.geom.prob_lo[0];
+	int const ncomp = sim.ncomp_cc;
+	forEachValidCell(sim, [=](Array4<double> const &state_cc, int i, int j, int k) { // :51-116
+		double const x = lo0 + (i + 0.5) * dx0;
+		double const vx = 0.0;
+		double rho = NAN, P = NAN;
+		double specie[3] = {-1.0, 0.0, 0.0};
+		if (x <= 0.5) { // Plewa & Mueller (1999)
+			rho = cma_rho_L;
+			P = cma_P_L;
+		} else {
+			rho = cma_rho_R;
+			P = cma_P_R;
+		}
+		if (x <= 0.5) {
+			specie[0] = 0.8;
+		} else if (x > 0.5 && x <= 0.75) {
+			specie[0] = 0.3;
+		} else {
+			specie[0] = 0.1;
+		}
+		specie[1] = 0.15 * std::pow(std::sin(20 * 3.14 * x), 2);
+		specie[2] = 1 - specie[0] - specie[1];
+		for (int n = 0; n < ncomp; ++n) {
+			state_cc(i, j, k, n) = 0.;
+		}
+		state_cc(i, j, k, density_index) = rho;
+		state_cc(i, j, k, x1Momentum_index) = rho * vx;
+		state_cc(i, j, k, x2Momentum_index) = 0.;
+		state_cc(i, j, k, x3Momentum_index) = 0.;
+		state_cc(i, j, k, energy_index) = P / (gamma - 1.) + 0.5 * rho * (vx * vx);
+		state_cc(i, j, k, internalEnergy_index) = P / (gamma - 1.);
+		for (int nn = 0; nn < 3; ++nn) {
+			state_cc(i, j, k, scalar0_index + nn) = specie[nn] * rho;
+		}
+	});
+	sim.finishInitialConditions();
+}
+
 } // namespace oracle
 
 #endif // ORACLE_PROBLEMS_HPP_

@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 K_B = 1.380649e-16
 M_U = 1.6605390666e-24
 
-SOD, CONTACT, SEDOV, SHELL, RADSHOCK, STREAMING, SCALARS, HYDRO1D, COUPLING, SUOLSON, ADVECTING, MARSHAK, RADFORCE, MARSHAK_ASYMPTOTIC, RADPULSE = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14
+SOD, CONTACT, SEDOV, SHELL, RADSHOCK, STREAMING, SCALARS, HYDRO1D, COUPLING, SUOLSON, ADVECTING, MARSHAK, RADFORCE, MARSHAK_ASYMPTOTIC, RADPULSE, SHOCKTUBE_CMA = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15
 
 
 def build(force: bool = False) -> None:

@@ -289,6 +289,7 @@ void launchComputeFluxes(qk_level *lev, qk_stream s, const qk_hydro_traits *t, q
 	const bool re = (t->reconstruct_eint != 0);
 	const int ndim = t->ndim;
 	const int nscalars = t->nscalars;
+	const int nmscalars = t->nmscalars;
 	launchCells(lev, s, 0, DIR, [=] __device__(int b, int i, int j, int k) {
 		RA4 L(left_t[b]);
 		RA4 R(right_t[b]);
@@ -332,6 +333,18 @@ void launchComputeFluxes(qk_level *lev, qk_stream s, const qk_hydro_traits *t, q
 		}
 		for (int n = 0; n < nscalars; ++n) { // hydro_system.hpp:1062-1076, HLLC.hpp:126-136 / LLF.hpp:30-41
 			F.p[o + F.ns * (NVAR + n)] = scalarFlux<RIEMANN>(wv, L.p[cl + L.ns * (NVAR + n)], R.p[cr + R.ns * (NVAR + n)]);
+		}
+		if (nmscalars > 0) { // :1062-1073, :1094-1104 consistent multi-fluid advection: partial-density fluxes = mass flux x upwind proportions
+			double fluxSum_U_L = 0, fluxSum_U_R = 0;
+			for (int n = 0; n < nmscalars; ++n) {
+				fluxSum_U_L += L.p[cl + L.ns * (NVAR + n)];
+				fluxSum_U_R += R.p[cr + R.ns * (NVAR + n)];
+			}
+			const bool fromLeft = (Fo[RHO] >= 0.);
+			for (int n = 0; n < nmscalars; ++n) {
+				const double U_up = fromLeft ? L.p[cl + L.ns * (NVAR + n)] : R.p[cr + R.ns * (NVAR + n)];
+				F.p[o + F.ns * (NVAR + n)] = Fo[RHO] * U_up / (fromLeft ? fluxSum_U_L : fluxSum_U_R);
+			}
 		}
 		V(i, j, k) = vn;
 	});
@@ -448,6 +461,7 @@ int qk_hydro_PredictStep(qk_level *lev, qk_stream s, const qk_hydro_traits *t, c
 		return rc;
 	}
 	QK_REQUIRE(lev->ctx, old_t && new_t && rhs_t && redo_t, "PredictStep: NULL array");
+	const int nmscalars = (nvars >= NVAR + t->nmscalars) ? t->nmscalars : 0;
 	launchCells(lev, s, 0, -1, [=] __device__(int b, int i, int j, int k) {
 		RA4 Uo(old_t[b]);
 		WA4 Un(new_t[b]);
@@ -461,8 +475,13 @@ int qk_hydro_PredictStep(qk_level *lev, qk_stream s, const qk_hydro_traits *t, c
 				rho_new = v;
 			}
 		}
-		// hydro_system.hpp:423-446 isStateValid: rho > 0
-		const int bad = (rho_new > 0.) ? 0 : 1;
+		// hydro_system.hpp:423-446 isStateValid: rho > 0 and no negative mass scalar
+		int bad = (rho_new > 0.) ? 0 : 1;
+		for (int idx = 0; idx < nmscalars; ++idx) {
+			if (Un(i, j, k, NVAR + idx) < 0.0) {
+				bad = 1;
+			}
+		}
 		flag(i, j, k) = bad;
 		if (d_redo_count != nullptr && bad != 0) {
 			atomicAdd(reinterpret_cast<unsigned long long *>(d_redo_count), 1ULL);
@@ -482,6 +501,7 @@ int qk_hydro_EnforceLimits(qk_level *lev, qk_stream s, const qk_hydro_traits *t,
 	QK_REQUIRE(lev->ctx, state_t, "EnforceLimits: NULL array");
 	const Eos eos(*t);
 	const int nscalars = t->nscalars;
+	const int nmscalars = t->nmscalars;
 	launchCells(lev, s, 0, -1, [=] __device__(int b, int i, int j, int k) {
 		WA4 S(state_t[b]);
 		const int64_t c = S.idx(i, j, k);
@@ -494,6 +514,23 @@ int qk_hydro_EnforceLimits(qk_level *lev, qk_stream s, const qk_hydro_traits *t,
 			for (int n = 0; n < nscalars; ++n) {
 				double &q = S.p[c + S.ns * (NVAR + n)];
 				q = (densityFloor == 0.0) ? 0.0 : q * (U[RHO] / densityFloor);
+			}
+		}
+		if (nmscalars > 0) { // hydro_system.hpp:725-744: negative partial densities -> small_x rho (Microphysics' default 1e-30), then sum = rho
+			const double rho_new = (U[RHO] < densityFloor) ? densityFloor : U[RHO];
+			double sp_sum = 0.0;
+			for (int idx = 0; idx < nmscalars; ++idx) {
+				double &q = S.p[c + S.ns * (NVAR + idx)];
+				if (q < 0.0) {
+					q = 1.0e-30 * rho_new;
+				}
+				sp_sum += q;
+			}
+			if ((sp_sum > 2.2250738585072014e-308) && (rho_new > 2.2250738585072014e-308)) {
+				sp_sum /= rho_new;
+				for (int idx = 0; idx < nmscalars; ++idx) {
+					S.p[c + S.ns * (NVAR + idx)] /= sp_sum;
+				}
 			}
 		}
 		enforceLimits(eos, densityFloor, tempFloor, U);

@@ -78,8 +78,8 @@ inline auto checkTraits(qk_ctx *ctx, const qk_hydro_traits *t) -> int
 	if (t == nullptr) {
 		return setError(ctx, QK_ERR_INVALID, "traits is NULL");
 	}
-	if (t->nscalars < 0 || t->nscalars > QK_MAX_SCALARS || t->nmscalars != 0) {
-		return setError(ctx, QK_ERR_UNSUPPORTED, "0..QK_MAX_SCALARS passive scalars, no mass scalars (nmscalars = 0)");
+	if (t->nscalars < 0 || t->nscalars > QK_MAX_SCALARS || t->nmscalars < 0 || t->nmscalars > t->nscalars) {
+		return setError(ctx, QK_ERR_UNSUPPORTED, "0..QK_MAX_SCALARS passive scalars, of which the first nmscalars (0..nscalars) are mass scalars");
 	}
 	if (t->eos_temperature_model < 0 || t->eos_temperature_model > 1 || (t->eos_temperature_model == 1 && !(t->eos_alpha > 0.0))) {
 		return setError(ctx, QK_ERR_UNSUPPORTED, "eos_temperature_model must be 0 (gamma law) or 1 (E = alpha / 4 T^4, alpha > 0)");

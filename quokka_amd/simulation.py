@@ -784,3 +784,36 @@ def hydro1d_problem(ctx: Context, spec: dict, nx: int, hi: float, max_timesteps:
 
     sim.set_initial_conditions(ic)
     return sim
+
+
+def shocktube_cma_problem(ctx: Context, nx: int = 1024, initial_state=None) -> HydroSimulation:
+    """reference src/problems/HydroShocktubeCMA/test_hydro_shocktube_cma.cpp + tests/shocktube_cma.in (1-D build, unrefined grid): the Sod
+    tube carrying three species as mass scalars (partial densities; Plewa & Mueller 1999 consistent multi-fluid advection), artificial
+    viscosity 0.1.  `initial_state` (9, 1, 1, nx): start from a given state (numpy's sin and libm's may differ in the last place)."""
+    rho_L, P_L, rho_R, P_R, g = 1.0, 1.0, 0.125, 0.1, 1.4
+    geom = Geometry(1, [nx], [0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [0, 1, 1])
+    bcs = [([capi.BC_EXT_DIR if n == 0 else capi.BC_INT_DIR, 0, 0], [capi.BC_EXT_DIR if n == 0 else capi.BC_INT_DIR, 0, 0]) for n in range(9)]
+    s0, s1 = math.pow(math.sin(20 * 3.14 * 0), 2), math.pow(math.sin(20 * 3.14 * 1), 2)
+    # setCustomBoundaryConditions :118-177 (third species `1 - X0 - 0.3 sin^2 rho`, sic)
+    left = [rho_L, 0.0, 0.0, 0.0, P_L / (g - 1.0), P_L / (g - 1.0), 0.8 * rho_L, 0.3 * s0 * rho_L, 1 - 0.8 - 0.3 * s0 * rho_L]
+    right = [rho_R, 0.0, 0.0, 0.0, P_R / (g - 1.0), P_R / (g - 1.0), 0.1 * rho_R, 0.3 * s1 * rho_R, 1 - 0.1 - 0.3 * s1 * rho_R]
+    sim = HydroSimulation(ctx, geom, capi.traits(g, True, 1, nscalars=3, nmscalars=3), bcs, [nx, 1, 1], dirichlet={(0, 0): left, (0, 1): right},
+                          use_fused=False, ncomp_cc=9)
+    sim.cflNumber_, sim.reconstructionOrder_, sim.artificialViscosityK_, sim.stopTime_, sim.maxTimesteps_ = 0.6, 3, 0.1, 1.0, 80000
+    dx = geom.dx[0]
+
+    def ic(i, j, k):  # setInitialConditionsOnGrid :51-116
+        if initial_state is not None:
+            return np.asarray(initial_state)[:, k, j, i]
+        x = (i + 0.5) * dx
+        rho = np.where(x <= 0.5, rho_L, rho_R)
+        P = np.where(x <= 0.5, P_L, P_R)
+        X0 = np.where(x <= 0.5, 0.8, np.where(x <= 0.75, 0.3, 0.1))
+        X1 = 0.15 * np.power(np.sin(20 * 3.14 * x), 2)
+        U = np.zeros((9,) + i.shape)
+        U[0], U[4], U[5] = rho, P / (g - 1.0), P / (g - 1.0)
+        U[6], U[7], U[8] = X0 * rho, X1 * rho, (1 - X0 - X1) * rho
+        return U
+
+    sim.set_initial_conditions(ic)
+    return sim

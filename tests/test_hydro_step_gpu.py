@@ -354,3 +354,26 @@ def test_flux_rk2_of_the_fused_stage_is_race_free_and_equals_the_operator_path(c
     sim.fillBoundaryConditions(sim.state_inter_cc_)
     with pytest.raises(capi.QkError, match="fluxRk2"):
         sim._stage(2, sim.state_inter_cc_, sim.state_old_cc_, sim.state_new_cc_, 1.0e-4)
+
+
+def test_mass_scalars_cma_match_oracle(ctx, oracle):
+    """HydroShocktubeCMA through the C-ABI (`nmscalars = 3`): consistent multi-fluid advection of the partial-density fluxes, the
+    non-negativity check of isStateValid and the renormalisation in EnforceLimits, with artificial viscosity — 1500 steps from the
+    oracle's initial state bit for bit, the reference's 1e-13 criterion after every step on the GPU state."""
+    from oracle.pyoracle import SHOCKTUBE_CMA
+    from quokka_amd.simulation import shocktube_cma_problem
+    so = oracle.sim(SHOCKTUBE_CMA, 1, [1024, 1, 1], [0, 0, 0], [1.0, 1, 1], [0, 1, 1], max_grid_size=[1024, 1, 1])
+    U0 = so.valid(0).copy()
+    sg = shocktube_cma_problem(ctx, 1024, initial_state=U0)
+    assert np.array_equal(U0, sg.state_new_cc_.valid(0).cpu().numpy())
+    worst = 0.0
+    for it in range(1500):
+        assert so.step() and sg.step()
+        assert so.dt == sg.dt_, (it, so.dt, sg.dt_)
+        if it % 50 == 0 or it == 1499:
+            U = sg.state_new_cc_.valid(0).cpu().numpy()
+            assert np.array_equal(so.valid(0), U), it
+            worst = max(worst, float(np.abs(1.0 - U[6:9, 0, 0].sum(axis=0) / U[0, 0, 0]).max()))
+    assert worst < 1.0e-13
+    sp = shocktube_cma_problem(ctx, 1024)  # the Python evaluation of the initial profile: equal to rounding
+    assert np.allclose(sp.state_new_cc_.valid(0).cpu().numpy(), U0, rtol=1e-13, atol=1e-16)
