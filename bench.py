@@ -3,21 +3,31 @@
 
 A "step" is one full RK2 hydro step of every cell (both ghost fills, both fused flux/update stages, the CFL
 reduction and the dt control), counted exactly like the reference's figure of merit
-(reference src/simulation.hpp:1285, 972-977).  At N = 1 the workload is BASELINE config 2:
-tests/blast_unigrid_256.in — 256^3 cells in 128^3 boxes, gamma = 1.4, PPM + HLLC, CFL 0.3, reflecting
-octant.  For N > 1 every rank keeps 256^3 cells (8 boxes of 128^3): the domain is doubled along x, y, z in turn
-(weak scaling), boxes are block-distributed and the ghost strips travel as RCCL point-to-point messages.
+(reference src/simulation.hpp:1285, 972-977).
+
+  N = 1   BASELINE config 2: tests/blast_unigrid_256.in — 256^3 cells in 128^3 boxes, gamma = 1.4, PPM + HLLC, CFL 0.3,
+          reflecting octant.  The same line carries two secondary figures measured after the timed region:
+          `ncell512` (512^3 on the one GPU, the size north_star quotes the roofline target on; `--ncell 512` makes it the headline)
+          and `long_run` (>= 100 steps after >= 100 warm-up steps of the 256^3 run).
+  N > 1   `python bench.py --gpus N` starts its own N ranks (torch.distributed.run, one per GPU, backend nccl = RCCL); under a
+          launcher that already set WORLD_SIZE it just joins.  Every rank holds 512^3 cells (64 boxes of 128^3): N = 8 is
+          BASELINE config 3, the 1024^3 blast; N = 2 / 4 are 1024x512x512 / 1024x1024x512.  Boxes are cut into bricks (2x2x2
+          for 8 ranks), ghost strips travel as RCCL point-to-point messages overlapped with the update of the boxes that need
+          nothing remote.  `weak_256_per_gpu` is the same measurement with 256^3 cells per rank.
 
 Output: ONE JSON line on rank 0 (see the contract in the task statement), including
-  roofline     — algorithmic bytes of the dominant fused sweep kernel / its HIP-event duration vs 8 TB/s HBM
-  cpu_baseline — the CPU oracle (a port of the reference algorithm, NOT the reference binary) on the host cores
+  roofline     — algorithmic bytes of the dominant fused sweep kernel / its HIP-event duration vs 8 TB/s HBM, every sweep listed
+  cpu_baseline — the CPU oracle (a port of the reference algorithm, NOT the reference binary) on the host cores (N = 1 only)
 """
 from __future__ import annotations
 
 import argparse
 import ctypes as C
+import glob
 import json
 import os
+import re
+import socket
 import sys
 import time
 
@@ -25,15 +35,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-# algorithmic bytes per cell-sweep of the fused PPM+HLLC sweep kernels
+# algorithmic bytes per cell-sweep of the fused PPM+HLLC sweep kernels and of the flattening pre-pass
 ALG_BYTES = {"k_sweep_x": 128.0, "k_sweep_y": 184.0, "k_sweep_z": 184.0}
-# measured HBM bytes per cell and launch (average of the two RK stages) for 128^3 boxes: rocprofv3 --pmc FETCH_SIZE and
-# --pmc WRITE_SIZE in separate passes, FETCH_SIZE x2 (gfx950 correction, calibrated on a pure streaming kernel), summaries in
-# profiles/round1/v4_sedov256_pmc_*.txt (unchanged since v2).  bench.py cannot collect PMC counters itself; the figure is reported only for the
-# profiled box size.  It includes what SURVEY's per-sweep figure leaves out: the stage-1 face fluxes kept for stage 2
-# (56 B), and for k_sweep_z the fused epilogue (old state in, new state + redo flag out).
-PMC_BYTES_PER_CELL = {"k_sweep_x": 198.5, "k_sweep_y": 275.7, "k_sweep_z": 332.2}
-PMC_SOURCE = "profiles/round1/v4_sedov256_pmc_FETCH_SIZE.txt (x2) + v4_sedov256_pmc_WRITE_SIZE.txt"
+ALG_BYTES_PRE = 72.0
+ALG_BYTES_STEP = 1496.0
 
 
 def parse():
@@ -41,16 +46,37 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--ncell", type=int, default=256, help="cells per dimension PER GPU (256 = blast_unigrid_256.in)")
+    ap.add_argument("--ncell", type=int, default=None,
+                    help="cells per dimension PER GPU: default 256 at N = 1 (blast_unigrid_256.in), 512 at N > 1 (N = 8: the 1024^3 blast); "
+                         "--ncell 512 at N = 1 is the single-GPU size of the roofline target")
     ap.add_argument("--max-grid-size", type=int, default=128)
     ap.add_argument("--workload", choices=["sedov", "shell", "amr"], default="sedov",
                     help="sedov = BASELINE metric (default); shell = RadhydroShell 256^3 radiation-hydro (BASELINE config 4) and amr = Sedov with "
                          "max_level 2 (BASELINE config 5 geometry), each reported as a secondary line")
-    ap.add_argument("--pow-mode", type=int, default=1, help="shell workload: 0 = libm pow(T,4) as the reference's std::pow, 1 = repeated multiplication")
+    ap.add_argument("--pow-mode", type=int, default=0, help="shell workload: 0 = libm pow(T,4) as the reference's std::pow (default), 1 = repeated multiplication")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (ncell512, long_run, weak_256_per_gpu)")
+    ap.add_argument("--long-steps", type=int, default=100, help="steps (and warm-up steps) of the long_run secondary figure")
     ap.add_argument("--cpu-ncell", type=int, default=128)
     ap.add_argument("--cpu-steps", type=int, default=8)
     return ap.parse_args()
+
+
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run ... bench.py <same arguments>`"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: the only mode the host driver supports (RCCL over xGMI)
+    os.environ.setdefault("OMP_NUM_THREADS", "4")
+    os.execv(sys.executable, cmd)
 
 
 def weak_scaled_cells(n: int, ngpus: int):
@@ -99,8 +125,124 @@ def cpu_baseline(ncell: int, steps: int):
                       "CPU restatement of the reference algorithm, not the reference binary"}
 
 
+# ---------------------------------------------------------------------------------------------------------------- PMC traffic
+def kernel_key(name: str):
+    """bench.py's name of a fused-stage kernel from its rocprofv3 display name"""
+    if "k_sweep_x" in name:
+        return "k_sweep_x"
+    m = re.search(r"k_sweep_march<(\d)", name)
+    if m:
+        return {"1": "k_sweep_y", "2": "k_sweep_z"}.get(m.group(1))
+    if "k_pre" in name:
+        return "k_pre"
+    return None
+
+
+def pmc_traffic(ncell: int):
+    """HBM bytes per launch of every fused-stage kernel from the NEWEST committed rocprofv3 PMC summaries of this box size
+    (profiles/round*/<tag>_sedov<ncell>_pmc_{FETCH,WRITE}_SIZE.txt, written by profiles/tools/profile_bench.sh): the average over the
+    kernel's dispatches of FETCH_SIZE x 2 (gfx950: wide coalesced reads are tallied at half their bytes, MI355X_MICROARCH.md §HBM) +
+    WRITE_SIZE, KiB -> bytes.  bench.py cannot collect PMC counters itself; None when no summary of that size exists."""
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "round*", f"*_sedov{ncell}_pmc_FETCH_SIZE.txt")):
+        w = f.replace("FETCH_SIZE", "WRITE_SIZE")
+        if not os.path.exists(w):
+            continue
+        m = re.search(r"round(\d+)[/\\]v?(\d+)", f)
+        key = (int(m.group(1)), int(m.group(2))) if m else (0, 0)
+        if best is None or key > best[0]:
+            best = (key, f, w)
+    if best is None:
+        return None, None
+
+    def read(path, counter):
+        acc = {}
+        for line in open(path):
+            m = re.match(rf"(.*?)\s+{counter}\s+dispatches=\s*(\d+)\s+avg=\s*([\d.]+)", line)
+            if m and kernel_key(m.group(1)):
+                n, v = int(m.group(2)), float(m.group(3))
+                a = acc.setdefault(kernel_key(m.group(1)), [0, 0.0])
+                a[0] += n
+                a[1] += n * v
+        return {k: v[1] / v[0] for k, v in acc.items() if v[0] > 0}
+
+    fe, wr = read(best[1], "FETCH_SIZE"), read(best[2], "WRITE_SIZE")
+    out = {k: (2.0 * fe[k] + wr[k]) * 1024.0 for k in fe if k in wr}
+    return out, f"{os.path.relpath(best[1], ROOT)} (x2) + {os.path.relpath(best[2], ROOT)}"
+
+
+# ---------------------------------------------------------------------------------------------------------------- Sedov runs
+def run_sedov(ctx, torch, dist, rank, world, ncell, mgs, steps, warmup, profile=True):
+    """build the problem, `warmup` untimed steps, then EXACTLY `steps` timed steps between barrier + synchronize pairs; max over ranks"""
+    from quokka_amd.simulation import sedov_problem
+    n_cell = weak_scaled_cells(ncell, world)
+    sim = sedov_problem(ctx, ncell, max_grid_size=mgs, rank=rank, nranks=world, n_cell=n_cell)
+    sim.maxTimesteps_ = 10 ** 9
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        assert sim.step()
+    L = ctx.L
+    if profile:
+        L.qk_profile_reset(ctx.h)
+        L.qk_profile_enable(ctx.h, 1)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        assert sim.step(), "hydro advance failed"
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if profile:
+        L.qk_profile_enable(ctx.h, 0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernels = {}
+    if profile:  # per-kernel HIP-event durations recorded on the launch stream during the timed region
+        for k in range(L.qk_profile_num_kernels(ctx.h)):
+            name, cnt, ms = C.c_char_p(), C.c_long(), C.c_double()
+            L.qk_profile_get(ctx.h, k, C.byref(name), C.byref(cnt), C.byref(ms))
+            kernels[name.value.decode()] = (cnt.value, ms.value)
+    return sim, n_cell, elapsed, kernels
+
+
+def roofline_of(kernels, cells_local, total_cells, steps, elapsed, world, ncell, mgs):
+    sweeps = {}
+    for k, alg in ALG_BYTES.items():
+        if k in kernels and kernels[k][0] > 0:
+            avg_s = kernels[k][1] / kernels[k][0] * 1e-3
+            sweeps[k] = {"alg_bytes_per_cell": alg, "avg_launch_ms": avg_s * 1e3, "launches": kernels[k][0],
+                         "achieved_GBs": alg * cells_local / avg_s / 1e9, "frac": alg * cells_local / avg_s / 1e9 / HBM_PEAK_GBS}
+    if not sweeps:
+        return None
+    dom = max(sweeps, key=lambda k: sweeps[k]["avg_launch_ms"])
+    traffic, source = pmc_traffic(ncell) if mgs == 128 else (None, None)
+    pre_ms = sum(v[1] / max(v[0], 1) for k, v in kernels.items() if k.startswith("k_pre"))
+    d = sweeps[dom]
+    r = {"bound": "hbm", "kernel": dom, "achieved": d["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["frac"],
+         "traffic": traffic.get(dom) if traffic else None, "traffic_unit": "bytes per launch (PMC, FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": source,
+         "alg_bytes_per_launch": d["alg_bytes_per_cell"] * cells_local, "avg_launch_ms": d["avg_launch_ms"], "launches": d["launches"],
+         "sweeps": sweeps,
+         "pre_pass": {"alg_bytes_per_cell": ALG_BYTES_PRE, "ms_per_stage": pre_ms,
+                      "frac": (ALG_BYTES_PRE * cells_local / (pre_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if pre_ms > 0 else None},
+         "traffic_all_kernels": traffic,
+         "whole_step": {"alg_bytes_per_cell_update": ALG_BYTES_STEP,
+                        "achieved_GBs": ALG_BYTES_STEP * total_cells * steps / elapsed / 1e9 / world,
+                        "frac": ALG_BYTES_STEP * total_cells * steps / elapsed / 1e9 / world / HBM_PEAK_GBS},
+         "all_kernels_ms_per_launch": {k: v[1] / max(v[0], 1) for k, v in sorted(kernels.items())}}
+    return r
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     import torch
     import torch.distributed as dist
 
@@ -109,26 +251,31 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if torch.cuda.device_count() < (local_rank + 1):
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPUs are visible (one rank per GPU)")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        world = dist.get_world_size()  # n_gpus below = the ranks RCCL actually connected
 
     from quokka_amd.multifab import Context
-    from quokka_amd.simulation import sedov_problem
 
     ctx = Context(local_rank)
-    n_cell = weak_scaled_cells(args.ncell, world)
+    ncell = args.ncell if args.ncell is not None else (256 if world == 1 else 512)
     if args.workload == "amr":
         from quokka_amd.amr_simulation import sedov_amr_problem
         # several GPUs: the SAME 256^3-base hierarchy (strong scaling).  Fine boxes live on the rank of their level-0 ancestor, so the
         # level-0 boxes are made smaller (64^3 instead of the deck's 128^3) and interleaved over the ranks: the refined shell around
         # the blast then spreads over all of them (amr_simulation.py, level0_distribution)
+        ncell = args.ncell if args.ncell is not None else 256
         mgs = 128 if world == 1 else 64
-        amr = sedov_amr_problem(ctx, args.ncell, 2, max_grid_size=mgs, blocking_factor=32, rank=rank, nranks=world)
+        amr = sedov_amr_problem(ctx, ncell, 2, max_grid_size=mgs, blocking_factor=32, rank=rank, nranks=world)
         for _ in range(args.warmup):
             amr.step()
+
         def sync():
             torch.cuda.synchronize()
             if world > 1:
@@ -144,106 +291,143 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        if rank != 0:
-            return
-        print(json.dumps({"metric": "Mcell-updates/s on 3D Sedov AMR (sum over levels, subcycled)", "value": (amr.cellUpdates_ - u0) / elapsed / 1e6,
-                          "unit": "Mcell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-                          "scaling": "strong", "dtype": "f64", "data": "synthetic",
-                          "config": {"workload": f"3D Sedov blast {args.ncell}^3 base grid, max_level 2, blocking_factor 32, max_grid_size {mgs} "
-                                                 "(tests/blast_amr_maxlev2.in), subcycling + reflux, tile clustering instead of Berger-Rigoutsos",
-                                     "boxes_per_level_rank0": [L.lev.nboxes for L in amr.levels], "boxes_per_level": [len(L.all_boxes) for L in amr.levels], "cells_per_level": [amr.CountCells(l) for l in range(amr.finest_level + 1)],
-                                     "sim_time": amr.tNew_}}))
+        if rank == 0:
+            print(json.dumps({"metric": "Mcell-updates/s on 3D Sedov AMR (sum over levels, subcycled)", "value": (amr.cellUpdates_ - u0) / elapsed / 1e6,
+                              "unit": "Mcell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                              "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                              "config": {"workload": f"3D Sedov blast {ncell}^3 base grid, max_level 2, blocking_factor 32, max_grid_size {mgs} "
+                                                     "(tests/blast_amr_maxlev2.in), subcycling + reflux",
+                                         "clustering": getattr(amr, "clustering", "tiles"),
+                                         "boxes_per_level_rank0": [L.lev.nboxes for L in amr.levels], "boxes_per_level": [len(L.all_boxes) for L in amr.levels],
+                                         "cells_per_level": [amr.CountCells(l) for l in range(amr.finest_level + 1)], "sim_time": amr.tNew_}}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
         return
+
     if args.workload == "shell":
         import numpy as np
         from quokka_amd.radhydro import shell_problem
         assert world == 1, "the shell line is single-GPU"
+        ncell = args.ncell if args.ncell is not None else 256
         tab = np.loadtxt(os.path.join(ROOT, "tests", "golden", "dust_shell_initial_conditions.txt"), skiprows=1)
-        sim = shell_problem(ctx, args.ncell, (tab[:, 0], tab[:, 2], tab[:, 3]), max_grid_size=args.max_grid_size, pow_mode=args.pow_mode)
-    else:
-        sim = sedov_problem(ctx, args.ncell, max_grid_size=args.max_grid_size, rank=rank, nranks=world, n_cell=n_cell)
-    sim.maxTimesteps_ = 10 ** 9
-
-    def barrier():
+        sim = shell_problem(ctx, ncell, (tab[:, 0], tab[:, 2], tab[:, 3]), max_grid_size=args.max_grid_size, pow_mode=args.pow_mode)
+        sim.maxTimesteps_ = 10 ** 9
+        for _ in range(args.warmup):
+            assert sim.step()
+        L = ctx.L
+        L.qk_profile_reset(ctx.h)
+        L.qk_profile_enable(ctx.h, 1)
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            assert sim.step(), "radhydro advance failed"
         torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        L.qk_profile_enable(ctx.h, 0)
+        kernels = {}
+        for k in range(L.qk_profile_num_kernels(ctx.h)):
+            name, cnt, ms = C.c_char_p(), C.c_long(), C.c_double()
+            L.qk_profile_get(ctx.h, k, C.byref(name), C.byref(cnt), C.byref(ms))
+            kernels[name.value.decode()] = (cnt.value, ms.value)
+        total_cells = ncell ** 3
+        per = {k: v[1] / max(v[0], 1) for k, v in sorted(kernels.items())}
+        # the radiation update kernels stream (HBM roofline); the Newton-Raphson exchange kernel is arithmetic-bound: its ceiling is the
+        # FP64 vector rate without FMA contraction (39.3 T op/s = 256 CUs x 64 lanes x 2.4 GHz; MI355X public spec 78.6 TFLOP/s with FMA)
+        roof = {}
+        for k, words in (("rad_PredictStep", 22), ("rad_AddFluxesRK2", 24)):  # doubles per cell: state in/out + face fluxes of three directions
+            if k in per and per[k] > 0:
+                roof[k] = {"bound": "hbm", "alg_bytes_per_cell": 8.0 * words, "frac": 8.0 * words * total_cells / (per[k] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        out = {"metric": "Mcell-updates/s on RadhydroShell (one update = hydro RK2 + all radiation substeps)",
+               "value": total_cells * args.steps / elapsed / 1e6, "unit": "Mcell-updates/s", "n_gpus": 1, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f64", "data": "synthetic",
+               "config": {"workload": f"RadhydroShell {ncell}^3 (tests/radhydro_shell_256.in), PLM, 1 group, kappa=20",
+                          "radiation_substeps_per_step": sim.radiationCellUpdates_ / max(sim.cellUpdates_, 1),
+                          "newton_iterations_per_solve": sim.rad_counters["newton_iterations"] / max(sim.rad_counters["solves"], 1),
+                          "solves_per_cell_and_source_call": sim.rad_counters["solves"] / max(2 * sim.radiationCellUpdates_, 1),
+                          "max_newton_iterations": sim.rad_counters["max_newton_iterations"], "pow_mode": args.pow_mode},
+               "roofline": {"streaming_kernels": roof, "note": "the Newton-Raphson kernel (rad_AddSourceTerms) is FP64-issue bound, not HBM bound"},
+               "kernels_ms_per_launch": per, "kernels_launches": {k: v[0] for k, v in sorted(kernels.items())},
+               "reference_published_a100_1gpu": 39.04}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_shell()
+        print(json.dumps(out), flush=True)
+        return
 
-    for _ in range(args.warmup):
-        assert sim.step()
-    L = ctx.L
-    L.qk_profile_reset(ctx.h)
-    L.qk_profile_enable(ctx.h, 1)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        assert sim.step(), "hydro advance failed"
-    barrier()
-    elapsed = time.perf_counter() - t0
-    L.qk_profile_enable(ctx.h, 0)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # per-kernel HIP-event durations recorded on the launch stream during the timed region
-    kernels = {}
-    for k in range(L.qk_profile_num_kernels(ctx.h)):
-        name, cnt, ms = C.c_char_p(), C.c_long(), C.c_double()
-        L.qk_profile_get(ctx.h, k, C.byref(name), C.byref(cnt), C.byref(ms))
-        kernels[name.value.decode()] = (cnt.value, ms.value)
+    # ------------------------------------------------------------------------------------------------------------ Sedov (headline)
+    mgs = args.max_grid_size
+    sim, n_cell, elapsed, kernels = run_sedov(ctx, torch, dist, rank, world, ncell, mgs, args.steps, args.warmup)
     cells_local = sim.lev.num_cells()
     total_cells = n_cell[0] * n_cell[1] * n_cell[2]
-    dom = max((k for k in kernels if k in ALG_BYTES), key=lambda k: kernels[k][1], default=None)
-    roofline = None
-    if dom is not None and kernels[dom][0] > 0:
-        avg_s = kernels[dom][1] / kernels[dom][0] * 1e-3
-        achieved = ALG_BYTES[dom] * cells_local / avg_s / 1e9
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": PMC_BYTES_PER_CELL[dom] * cells_local if args.max_grid_size == 128 else None,
-                    "traffic_unit": "bytes per launch", "traffic_source": PMC_SOURCE,
-                    "traffic_rate_GBs": PMC_BYTES_PER_CELL[dom] * cells_local / avg_s / 1e9 if args.max_grid_size == 128 else None,
-                    "alg_bytes_per_launch": ALG_BYTES[dom] * cells_local, "avg_launch_ms": avg_s * 1e3,
-                    "launches": kernels[dom][0],
-                    "whole_step": {"alg_bytes_per_cell_update": 1496.0,
-                                   "achieved_GBs": 1496.0 * total_cells * args.steps / elapsed / 1e9 / world,
-                                   "frac": 1496.0 * total_cells * args.steps / elapsed / 1e9 / world / HBM_PEAK_GBS},
-                    "all_kernels_ms_per_launch": {k: v[1] / max(v[0], 1) for k, v in sorted(kernels.items())}}
-
-    if rank == 0 and args.workload == "shell":
-        print(json.dumps({"metric": "Mcell-updates/s on RadhydroShell (one update = hydro RK2 + all radiation substeps)",
-                          "value": total_cells * args.steps / elapsed / 1e6, "unit": "Mcell-updates/s", "n_gpus": 1, "steps": args.steps,
-                          "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "dtype": "f64", "data": "synthetic",
-                          "config": {"workload": f"RadhydroShell {args.ncell}^3 (tests/radhydro_shell_256.in), PLM, 1 group, kappa=20",
-                                     "radiation_substeps_per_step": sim.radiationCellUpdates_ / max(sim.cellUpdates_, 1),
-                                     "newton_iterations_per_solve": sim.rad_counters["newton_iterations"] / max(sim.rad_counters["solves"], 1),
-                                     "solves_per_cell_and_source_call": sim.rad_counters["solves"] / max(2 * sim.radiationCellUpdates_, 1),
-                                     "max_newton_iterations": sim.rad_counters["max_newton_iterations"], "pow_mode": args.pow_mode},
-                          "kernels_ms_per_launch": {k: v[1] / max(v[0], 1) for k, v in sorted(kernels.items())},
-                          "kernels_launches": {k: v[0] for k, v in sorted(kernels.items())},
-                          "reference_published_a100_1gpu": 39.04}), flush=True)
-    elif rank == 0:
-        value = total_cells * args.steps / elapsed / 1e6
-        out = {
-            "metric": "Mcell-updates/s on 3D Sedov unigrid", "value": value, "unit": "Mcell-updates/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"3D Sedov blast {n_cell[0]}x{n_cell[1]}x{n_cell[2]} unigrid (tests/blast_unigrid_256.in per GPU), "
-                                   f"{args.max_grid_size}^3 boxes, PPM+HLLC RK2, gamma=1.4, CFL 0.3, reflecting octant",
-                       "cells_per_gpu": args.ncell ** 3, "boxes_per_gpu": sim.lev.nboxes, "parallelism": f"box-decomposition x{world}",
-                       "fofc_stages": sim.counters["fofc1_stages"] + sim.counters["fofc2_stages"], "retries": sim.counters["retries"],
-                       "sim_time": sim.tNew_},
-            "roofline": roofline,
-            # context only (other hardware, reference implementation): paper/performance_a100.csv:2 = 254.05 Mzones/s on 1x A100
-            "reference_published_a100_1gpu": 254.05,
-        }
+    roofline = roofline_of(kernels, cells_local, total_cells, args.steps, elapsed, world, ncell, mgs)
+    groups = sim.overlap_groups() if world > 1 else None
+    out = {
+        "metric": "Mcell-updates/s on 3D Sedov unigrid", "value": total_cells * args.steps / elapsed / 1e6, "unit": "Mcell-updates/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"3D Sedov blast {n_cell[0]}x{n_cell[1]}x{n_cell[2]} unigrid (tests/blast_unigrid_256.in scaled to {ncell}^3 cells per GPU), "
+                               f"{mgs}^3 boxes, PPM+HLLC RK2, gamma=1.4, CFL 0.3, reflecting octant",
+                   "cells_per_gpu": ncell ** 3, "boxes_per_gpu": sim.lev.nboxes, "parallelism": f"box-decomposition x{world}",
+                   "ghost_exchange": None if world == 1 else {"backend": dist.get_backend(), "peers_rank0": len(sim.ghost.peers),
+                                                              "overlap_early_late_boxes_rank0": None if groups is None else [len(groups[0][1]), len(groups[1][1])]},
+                   "fofc_stages": sim.counters["fofc1_stages"] + sim.counters["fofc2_stages"], "retries": sim.counters["retries"],
+                   "sim_time": sim.tNew_,
+                   "note": "N = 1 runs BASELINE config 2 (256^3); N > 1 runs 512^3 cells per GPU (N = 8: config 3, 1024^3); "
+                           "weak_256_per_gpu is the same geometry as N = 1 on every rank"},
+        "roofline": roofline,
+        # context only (other hardware, reference implementation): paper/performance_a100.csv:2 = 254.05 Mzones/s on 1x A100
+        "reference_published_a100_1gpu": 254.05,
+    }
+    del sim
+    torch.cuda.empty_cache()
+    if not args.no_secondary:
+        if world == 1 and ncell == 256:
+            # (a) developed-run figure: the default timed region sits at sim-time ~6e-5; >= 100 + 100 steps moves the shock further out
+            simL, _, elL, _ = run_sedov(ctx, torch, dist, rank, world, 256, mgs, args.long_steps, args.long_steps, profile=False)
+            out["long_run"] = {"value": 256 ** 3 * args.long_steps / elL / 1e6, "unit": "Mcell-updates/s", "steps": args.long_steps, "warmup": args.long_steps,
+                               "ms_per_step": elL / args.long_steps * 1e3, "sim_time": simL.tNew_,
+                               "fofc_stages": simL.counters["fofc1_stages"] + simL.counters["fofc2_stages"]}
+            del simL
+            torch.cuda.empty_cache()
+            # (b) 512^3 on the one GPU: the size of north_star's roofline target
+            s5, n5, el5, k5 = run_sedov(ctx, torch, dist, rank, world, 512, mgs, 8, 2)
+            out["ncell512"] = {"value": 512 ** 3 * 8 / el5 / 1e6, "unit": "Mcell-updates/s", "steps": 8, "warmup": 2, "ms_per_step": el5 / 8 * 1e3,
+                               "boxes": s5.lev.nboxes, "roofline": roofline_of(k5, s5.lev.num_cells(), 512 ** 3, 8, el5, 1, 512, mgs)}
+            del s5
+            torch.cuda.empty_cache()
+        elif world > 1 and ncell != 256:
+            sW, nW, elW, _ = run_sedov(ctx, torch, dist, rank, world, 256, mgs, args.steps, args.warmup, profile=False)
+            out["weak_256_per_gpu"] = {"value": nW[0] * nW[1] * nW[2] * args.steps / elW / 1e6, "unit": "Mcell-updates/s", "ms_per_step": elW / args.steps * 1e3,
+                                       "workload": f"{nW[0]}x{nW[1]}x{nW[2]}, 8 boxes of 128^3 per GPU"}
+            del sW
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_ncell, args.cpu_steps)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def cpu_baseline_shell(ncell: int = 32, steps: int = 3):
+    """the oracle's RadhydroShell (same deck, 32^3 sample) on the host cores"""
+    import numpy as np
+    from oracle.pyoracle import Oracle
+    threads, note = usable_cores()
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    o = Oracle("direct")
+    tab = np.loadtxt(os.path.join(ROOT, "tests", "golden", "dust_shell_initial_conditions.txt"), skiprows=1)
+    s = o.shell_sim(ncell, tab) if hasattr(o, "shell_sim") else None
+    if s is None:
+        return None
+    assert s.step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        assert s.step()
+    el = time.perf_counter() - t0
+    return {"value": ncell ** 3 * steps / el / 1e6, "unit": "Mcell-updates/s", "cores": threads, "kind": "port",
+            "sample": f"RadhydroShell {ncell}^3, {steps} steps in {el:.1f} s ({note}); CPU restatement of the reference algorithm"}
 
 
 if __name__ == "__main__":

@@ -3,7 +3,7 @@
 #   gpurun -- 'bash profiles/tools/ab_bench.sh A B'
 for r in 1 2; do
   for v in "$@"; do
-    QK_LIB_PATH=$PWD/quokka_amd/lib/libqk_$v.so python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 |
+    QK_LIB_PATH=$PWD/quokka_amd/lib/libqk_$v.so python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary 2>&1 | tail -1 |
       python -c "import sys,json; d=json.loads(sys.stdin.read()); k=d['roofline']['all_kernels_ms_per_launch']; print('$v', round(d['value'],1), {n: round(t,3) for n,t in k.items()})"
   done
 done

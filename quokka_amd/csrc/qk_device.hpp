@@ -115,11 +115,46 @@ QK_DEV auto consPressure(Eos const &eos, double rho, double px, double py, doubl
 }
 
 QK_DEV auto sgn(double v) -> int { return static_cast<int>(0.0 < v) - static_cast<int>(v < 0.0); }
-QK_DEV auto clampd(double v, double lo, double hi) -> double { return (v < lo) ? lo : (hi < v) ? hi : v; }
-// std::min / std::max semantics (return first argument on ties / NaN in second)
-// (v_min_f64 / v_max_f64 via fmin/fmax were measured: same bits on every parity case, 5-20 % slower sweeps)
-QK_DEV auto smin(double a, double b) -> double { return (b < a) ? b : a; }
-QK_DEV auto smax(double a, double b) -> double { return (a < b) ? b : a; }
+// std::min / std::max as ONE v_min_f64 / v_max_f64 each.  `(b < a) ? b : a` compiles to v_cmp_lt_f64 + s_nop + 2 x v_cndmask_b32 (a 64-bit
+// select is two 32-bit ones), four issue slots where the hardware has a one-slot instruction; the sweeps are issue-bound and a PPM
+// reconstruction + HLLC solve holds ~60 min/max per cell (profiles/round2/ubench_*.txt: v_min_f64 1.9 ns, the select form 6.3 ns per
+// wave-instruction per SIMD).  Written as inline assembly because fmin()/fmax() add a canonicalising v_max_f64(x, x) per operand in IEEE
+// mode (the variant round 1 measured as slower).  Same value as std::min / std::max for ordered operands; differences, none of which a
+// valid state reaches: a tie between +0 and -0 may return the other zero, and a NaN in the FIRST argument is dropped (std::min returns it)
+// — the second-argument NaN cases the reference relies on (min(1., 0./0.) = 1. in the carbuncle / low-Mach factors) behave identically.
+QK_DEV auto smin(double a, double b) -> double
+{
+	double r;
+	asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+}
+QK_DEV auto smax(double a, double b) -> double
+{
+	double r;
+	asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+}
+// min / max against the inline constants 0 and 1 (no register for the constant)
+QK_DEV auto smin0(double a) -> double
+{
+	double r;
+	asm("v_min_f64 %0, %1, 0" : "=v"(r) : "v"(a));
+	return r;
+}
+QK_DEV auto smax0(double a) -> double
+{
+	double r;
+	asm("v_max_f64 %0, %1, 0" : "=v"(r) : "v"(a));
+	return r;
+}
+QK_DEV auto smin1(double a) -> double
+{
+	double r;
+	asm("v_min_f64 %0, 1.0, %1" : "=v"(r) : "v"(a));
+	return r;
+}
+// (v < lo) ? lo : (hi < v) ? hi : v for lo <= hi
+QK_DEV auto clampd(double v, double lo, double hi) -> double { return smin(smax(v, lo), hi); }
 
 // Correctly rounded FP64 division with the refined reciprocal of the denominator SHARED between numerators.
 // hipcc expands `n / d` to  div_scale x2, rcp, two Newton steps (4 fma), q = n * r, e = fma(-d, q, n), div_fmas(e, r, q),
@@ -153,6 +188,35 @@ QK_DEV auto divBy(double n, Recip const &R) -> double
 	return __builtin_fma(e, R.r, q);
 }
 
+// hydro_system.hpp:138-196 ConservedToPrimitive for one cell: q = (rho, vx, vy, vz, P | e, Eint | e_aux); the quotients by rho share its
+// refined reciprocal (same bits as `/` for a normal-range rho, see recipOf)
+QK_DEV void consToPrim(Eos const &eos, bool reconstruct_eint, const double U[NVAR], double q[NVAR])
+{
+	const double rho = U[RHO];
+	const Recip R = recipOf(rho);
+	const double vx = divBy(U[MX], R);
+	const double vy = divBy(U[MY], R);
+	const double vz = divBy(U[MZ], R);
+	const double kinetic_energy = 0.5 * rho * (vx * vx + vy * vy + vz * vz);
+	const double Eint_cons = U[ENE] - kinetic_energy;
+	q[PRHO] = rho;
+	q[PVX] = vx;
+	q[PVY] = vy;
+	q[PVZ] = vz;
+	if (reconstruct_eint) {
+		q[PPRES] = divBy(Eint_cons, R);
+		q[PEINT] = divBy(U[EINT], R);
+	} else {
+		if (eos.isothermal) {
+			q[PPRES] = rho * eos.cs_iso * eos.cs_iso;
+		} else {
+			const double e = (rho == 0.0) ? 0.0 : divBy(Eint_cons, R);
+			q[PPRES] = eos.gm1 * rho * e;
+		}
+		q[PEINT] = U[EINT];
+	}
+}
+
 // hyperbolic_system.hpp:58-66
 QK_DEV auto MC(double a, double b) -> double { return 0.5 * (sgn(a) + sgn(b)) * smin(0.5 * fabs(a + b), smin(2.0 * fabs(a), 2.0 * fabs(b))); }
 QK_DEV auto minmod(double a, double b) -> double { return 0.5 * (sgn(a) + sgn(b)) * smin(fabs(a), fabs(b)); }
@@ -162,19 +226,8 @@ QK_DEV auto minmod(double a, double b) -> double { return 0.5 * (sgn(a) + sgn(b)
 QK_DEV void ppmEdges(double qm2, double qm1, double q0, double qp1, double qp2, double &am, double &ap)
 {
 	// std::minmax({q0, qm1, qp1})
-	double lo = q0, hi = q0;
-	if (qm1 < lo) {
-		lo = qm1;
-	}
-	if (!(qm1 < hi)) {
-		hi = qm1;
-	}
-	if (qp1 < lo) {
-		lo = qp1;
-	}
-	if (!(qp1 < hi)) {
-		hi = qp1;
-	}
+	const double lo = smin(smin(q0, qm1), qp1);
+	const double hi = smax(smax(q0, qm1), qp1);
 	const double coef_1 = (7. / 12.);
 	const double coef_2 = (-1. / 12.);
 	const double a_minus = (coef_1 * q0 + coef_2 * qp1) + (coef_1 * qm1 + coef_2 * qm2);
@@ -211,8 +264,17 @@ template <int LIMITER> QK_DEV void plmEdges(double qm1, double q0, double qp1, d
 	am = q0 - 0.25 * slope;
 }
 
-// hydro_system.hpp:588-622 : flattening coefficient from P(i-2..i+2), rho(i), vn(i-1), vn(i+1)
-QK_DEV auto flatteningChi(Eos const &eos, double Pm2, double Pm1, double P, double Pp1, double Pp2, double rho, double vm1, double vp1) -> double
+// hydro_system.hpp:588-622 : flattening coefficient from P(i-2..i+2), rho(i), vn(i-1), vn(i+1).  K_S = rho c_s^2 depends on the centre cell
+// only (:600-604) and is shared between the directions by the fused pre-pass.
+QK_DEV auto flatteningKS(Eos const &eos, double rho, double P) -> double
+{
+	if (eos.isothermal) {
+		return rho * eos.cs_iso * eos.cs_iso;
+	}
+	const double cs = eos.soundSpeed(rho, P);
+	return (cs * cs) * rho;
+}
+QK_DEV auto flatteningChiKS(double Pm2, double Pm1, double Pp1, double Pp2, double K_S, double vm1, double vp1) -> double
 {
 	constexpr double beta_max = 0.85;
 	constexpr double beta_min = 0.75;
@@ -220,20 +282,14 @@ QK_DEV auto flatteningChi(Eos const &eos, double Pm2, double Pm1, double P, doub
 	constexpr double Zmin = 0.25;
 	const double beta_denom = fabs(Pp2 - Pm2);
 	const double beta = (beta_denom != 0) ? (fabs(Pp1 - Pm1) / beta_denom) : 0;
-	const double chi_min = smax(0., smin(1., (beta_max - beta) / (beta_max - beta_min)));
-	double K_S;
-	if (eos.isothermal) {
-		K_S = rho * eos.cs_iso * eos.cs_iso;
-	} else {
-		const double cs = eos.soundSpeed(rho, P);
-		K_S = (cs * cs) * rho;
-	}
+	const double chi_min = smax0(smin1((beta_max - beta) / (beta_max - beta_min)));
 	const double Z = fabs(Pp1 - Pm1) / K_S;
-	double chi = 1.0;
-	if (vp1 < vm1) {
-		chi = smax(chi_min, smin(1., (Zmax - Z) / (Zmax - Zmin)));
-	}
-	return chi;
+	const double chi_shock = smax(chi_min, smin1((Zmax - Z) / (Zmax - Zmin)));
+	return (vp1 < vm1) ? chi_shock : 1.0;
+}
+QK_DEV auto flatteningChi(Eos const &eos, double Pm2, double Pm1, double P, double Pp1, double Pp2, double rho, double vm1, double vp1) -> double
+{
+	return flatteningChiKS(Pm2, Pm1, Pp1, Pp2, flatteningKS(eos, rho, P), vm1, vp1);
 }
 
 // HydroState.hpp:10-23 (no scalars, no B field)
@@ -342,14 +398,14 @@ QK_DEV void hllc(Eos const &eos, HState const &sL, HState const &sR, double du, 
 		} else {
 			cs_tilde = sqrt(cs_exp / C_tilde_P);
 		}
-		const double s_NL = 0.5 * G * smax(dU, 0.);
-		const double s_NR = 0.5 * G * smax(dU, 0.);
+		const double s_NL = 0.5 * G * smax0(dU);
+		const double s_NR = s_NL;
 		S_L = smin(sL.u - (sL.cs + s_NL), u_tilde - (cs_tilde + s_NL));
 		S_R = smax(sR.u + (sR.cs + s_NR), u_tilde + (cs_tilde + s_NR));
 	} else {
 		const double cs_tilde = 0.5 * (sL.cs + sR.cs);
 		const double G_L = 0.5 * (1.0 + 1.);
-		const double s_NL = 0.5 * G_L * smax(dU, 0.);
+		const double s_NL = 0.5 * G_L * smax0(dU);
 		const double s_NR = s_NL;
 		S_L = smin(sL.u - (sL.cs + s_NL), u_tilde - (cs_tilde + s_NL));
 		S_R = smax(sR.u + (sR.cs + s_NR), u_tilde + (cs_tilde + s_NR));
@@ -357,7 +413,7 @@ QK_DEV void hllc(Eos const &eos, HState const &sL, HState const &sR, double du, 
 
 	// :91-93 carbuncle switch
 	const double cs_max = smax(sL.cs, sR.cs);
-	const double tp = smin(1., (cs_max - smin(du, 0.)) / (cs_max - smin(dw, 0.)));
+	const double tp = smin1((cs_max - smin0(du)) / (cs_max - smin0(dw)));
 	const double theta = tp * tp * tp * tp;
 
 	// :97-98
@@ -367,7 +423,7 @@ QK_DEV void hllc(Eos const &eos, HState const &sL, HState const &sR, double du, 
 	// :102-107
 	const double vmag_L = sqrt(sL.u * sL.u + sL.v * sL.v + sL.w * sL.w);
 	const double vmag_R = sqrt(sR.u * sR.u + sR.v * sR.v + sR.w * sR.w);
-	const double chi = smin(1., smax(vmag_L, vmag_R) / cs_max);
+	const double chi = smin1(smax(vmag_L, vmag_R) / cs_max);
 	const double phi = chi * (2. - chi);
 	const double P_LR = 0.5 * (sL.P + sR.P) + 0.5 * phi * (sL.rho * (S_L - sL.u) * (S_star - sL.u) + sR.rho * (S_R - sR.u) * (S_star - sR.u));
 
@@ -492,7 +548,7 @@ QK_DEV void faceFlux(Eos const &eos, bool reconstruct_eint, int ndim, const doub
 	if (ndim == 3) {
 		div_v = div_v + 0.5 * (dwl + dwr);
 	}
-	const double viscosity = K_visc * smax(-div_v, 0.);
+	const double viscosity = K_visc * smax0(-div_v);
 	if (wv != nullptr) {
 		wv->viscosity = viscosity;
 	}

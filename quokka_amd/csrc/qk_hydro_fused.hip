@@ -45,7 +45,7 @@ struct SGeom {
 };
 
 // scratch arrays (in units of "components over total_cells")
-enum { S_PRIM = 0, S_AUX = 6, S_RHS = 10, S_NCOMP = 17 };
+enum { S_AUX = 0, S_RHS = 4, S_NCOMP = 11 };
 // S_AUX + 0: chi (combined), +1..3: D_x, D_y, D_z ;  S_RHS + 0..5: flux divergence, +6: div v
 
 struct SweepArgs {
@@ -76,150 +76,209 @@ struct SweepArgs {
 
 QK_DEV auto sarr(SweepArgs const &a, int comp) -> double * { return a.scratch + static_cast<int64_t>(comp) * a.total_cells; }
 
-// ---------------------------------------------------------------------------------------------- pencil pre-passes
-// The flattening coefficient of direction d and the velocity difference D_d only couple cells ALONG d, so the three
-// directions are three pencil passes that each stream the data once:
-//   k_pre_x      U -> prim (valid+4), chi_x, m_x = min(chi_x(i-1), chi_x(i), chi_x(i+1)), D_x          [flat, LDS]
-//   k_pre_march  Y then Z: rolling 5-cell pressure window in registers -> chi_d, m_d, D_d;  m <- min(m, m_d)
-// after the Z pass m is the combined coefficient of FlattenShocks (hydro_system.hpp:655-669).
-constexpr int PXB = 256, PXOUT = 250;
+// ---------------------------------------------------------------------------------------------- flattening pre-pass
+// ONE kernel produces what the sweeps need besides the state itself: the combined flattening coefficient of FlattenShocks
+// (hydro_system.hpp:655-669) and the velocity differences D_x, D_y, D_z of the carbuncle switch (:1019-1034) on valid+1.  Round 1 did this
+// with three pencil passes that also materialised the primitive variables (272 B of HBM traffic per cell against 80 B here: U in, four
+// doubles out; the sweeps now convert U to primitives themselves, 3 quotients sharing one reciprocal per cell and sweep).
+//
+// A cell's result needs pressure / velocity from a plus-shaped stencil: P at +-3 and v_d at +-2 along each axis d (chi_d at +-1, each
+// from P +-2 and v_d +-1), nothing diagonal.  Mapping: a workgroup owns an x-y tile of PT_X x PT_Y cells and MARCHES along z —
+//   * z direction: rolling register windows (P 5 deep, v_z 5, rho 3, chi_z 3), as the marching sweeps do;
+//   * x and y directions: the plane's P, rho, v_x, v_y go through LDS with the plus-shaped halo (3 columns / 3 rows beyond the tile, no
+//     corners), chi_x / chi_y of the tile and of its one-cell rim are exchanged through LDS as well; the in-plane results wait three
+//     planes in a register FIFO until the z window has caught up with them.
+// Halo cells are converted by the threads left over after every thread converted its own cell (900 conversions per 462 outputs and
+// plane); their loads hit L2 (the neighbouring tiles read the same rows), so HBM sees each conserved value about once.
+constexpr int PT_X = 66, PT_Y = 7, PT_THREADS = 512; // 2 x-tiles cover the 130 columns of a 128-cell box + rim
+constexpr int PT_OWN = PT_X * PT_Y;		     // 462 threads own a column
+constexpr int PT_HALO_Y = 6 * PT_X;		     // rows -3..-1 and PT_Y..PT_Y+2
+constexpr int PT_HALO = PT_HALO_Y + 6 * PT_Y;	     // + columns -3..-1 and PT_X..PT_X+2 of the tile's rows
+static_assert(PT_HALO <= PT_THREADS && PT_OWN <= PT_THREADS, "one halo cell per thread");
 
-__global__ void __launch_bounds__(PXB) k_pre_x(const SGeom *geom, const qk_array4 *U_t, double *scratch, int64_t total, Eos eos, bool re)
+struct PlaneCell {
+	double rho, vx, vy, vz, P;
+};
+
+// hydro_system.hpp:138-196 + the pressure ComputeFlatteningCoefficients works with (:560-586): one cell of U -> (rho, v, P)
+struct PlaneRaw {
+	double rho, mx, my, mz, E;
+};
+QK_DEV auto planeLoad(RA4 const &U, int64_t u) -> PlaneRaw
 {
-	__shared__ double s_P[PXB], s_v[PXB], s_chi[PXB];
-	const int b = blockIdx.y;
-	const SGeom g = geom[b];
-	RA4 U(U_t[b]);
-	const int t = threadIdx.x;
-	const int64_t f = static_cast<int64_t>(blockIdx.x) * PXOUT + t - 3;
-	const bool inb = (f >= 0) && (f < g.ncell);
-	const int64_t c = f < 0 ? 0 : (f >= g.ncell ? g.ncell - 1 : f);
-	const bool owned = inb && (t >= 3) && (t < 3 + PXOUT);
-
-	const int k = static_cast<int>(c / (static_cast<int64_t>(g.n[0]) * g.n[1]));
-	const int r = static_cast<int>(c - static_cast<int64_t>(k) * g.n[0] * g.n[1]);
-	const int j = r / g.n[0];
-	const int i = r - j * g.n[0];
-	const int64_t u = U.idx(g.glo[0] + i, g.glo[1] + j, g.glo[2] + k);
-	const double rho = U.p[u + U.ns * RHO];
-	const double px = U.p[u + U.ns * MX];
-	const double py = U.p[u + U.ns * MY];
-	const double pz = U.p[u + U.ns * MZ];
-	const double E = U.p[u + U.ns * ENE];
-	const double Eint_aux = U.p[u + U.ns * EINT];
-	const double vx = px / rho;
-	const double vy = py / rho;
-	const double vz = pz / rho;
-	const double kinetic_energy = 0.5 * rho * (vx * vx + vy * vy + vz * vz);
-	const double Eint_cons = E - kinetic_energy;
-	double *q = scratch + g.off + c;
-	double Pphys;
-	if (re) {
-		const double e = Eint_cons / rho;
-		Pphys = eos.pressure(rho, rho * e);
-		if (owned) {
-			q[(S_PRIM + PPRES) * total] = e;
-			q[(S_PRIM + PEINT) * total] = Eint_aux / rho;
-		}
-	} else {
-		Pphys = eos.isothermal ? rho * eos.cs_iso * eos.cs_iso : eos.pressure(rho, Eint_cons);
-		if (owned) {
-			q[(S_PRIM + PPRES) * total] = Pphys;
-			q[(S_PRIM + PEINT) * total] = Eint_aux;
-		}
-	}
+	PlaneRaw r;
+	r.rho = U.p[u + U.ns * RHO];
+	r.mx = U.p[u + U.ns * MX];
+	r.my = U.p[u + U.ns * MY];
+	r.mz = U.p[u + U.ns * MZ];
+	r.E = U.p[u + U.ns * ENE];
+	return r;
+}
+QK_DEV auto planeCell(Eos const &eos, bool re, PlaneRaw const &r) -> PlaneCell
+{
+	PlaneCell c;
+	c.rho = r.rho;
+	const Recip R = recipOf(c.rho);
+	c.vx = divBy(r.mx, R);
+	c.vy = divBy(r.my, R);
+	c.vz = divBy(r.mz, R);
 	if (eos.isothermal) {
-		Pphys = rho * (eos.cs_iso * eos.cs_iso);
+		c.P = c.rho * (eos.cs_iso * eos.cs_iso);
+		return c;
 	}
-	if (owned) {
-		q[(S_PRIM + PRHO) * total] = rho;
-		q[(S_PRIM + PVX) * total] = vx;
-		q[(S_PRIM + PVY) * total] = vy;
-		q[(S_PRIM + PVZ) * total] = vz;
+	const double kinetic_energy = 0.5 * c.rho * (c.vx * c.vx + c.vy * c.vy + c.vz * c.vz);
+	const double Eint_cons = r.E - kinetic_energy;
+	if (re) {
+		// the primitive is e = Eint / rho; the pressure is eos.pressure(rho, rho * e)
+		const double e = divBy(Eint_cons, R);
+		const double e2 = (c.rho == 0.0) ? 0.0 : divBy(c.rho * e, R);
+		c.P = eos.gm1 * c.rho * e2;
+	} else {
+		const double e = (c.rho == 0.0) ? 0.0 : divBy(Eint_cons, R);
+		c.P = eos.gm1 * c.rho * e;
 	}
-	s_P[t] = Pphys;
-	s_v[t] = vx;
-	__syncthreads();
-	double chi = 1.0;
-	if (t >= 2 && t < PXB - 2) {
-		chi = flatteningChi(eos, s_P[t - 2], s_P[t - 1], Pphys, s_P[t + 1], s_P[t + 2], rho, s_v[t - 1], s_v[t + 1]);
-	}
-	s_chi[t] = chi;
-	__syncthreads();
-	if (owned) {
-		q[(S_AUX + 0) * total] = smin(smin(s_chi[t - 1], chi), s_chi[t + 1]);
-		q[(S_AUX + 1) * total] = smin(s_v[t + 1] - vx, vx - s_v[t - 1]);
-	}
+	return c;
 }
 
-// nseg > 1: the march axis is cut into nseg segments, each marched by its own thread (with its own warm-up of the window) — levels with
-// few columns (small AMR levels) would otherwise leave most of the chip idle behind one long dependent chain per column.  Every output
-// cell belongs to exactly one segment; the arithmetic per cell is unchanged.
-template <int DIR> __global__ void __launch_bounds__(256) k_pre_march(const qk_box *boxes, const SGeom *geom, double *scratch, int64_t T, Eos eos, bool re, int nseg)
+__global__ void __launch_bounds__(PT_THREADS, 4) k_pre3(const qk_box *boxes, const SGeom *geom, const qk_array4 *U_t, double *scratch, int64_t T, Eos eos, bool re, int nseg)
 {
-	constexpr int OT = 3 - DIR;
+	// LDS planes, indexed [row + 3][column + 3] (P), [row][column + 2] (v_x), [row + 2][column] (v_y)
+	__shared__ double s_P[PT_Y + 6][PT_X + 6];
+	__shared__ double s_vx[PT_Y][PT_X + 4], s_vy[PT_Y + 4][PT_X];
+	__shared__ double s_cx[PT_Y][PT_X + 2], s_cy[PT_Y + 2][PT_X]; // chi_x at columns -1..PT_X, chi_y at rows -1..PT_Y
+
 	const int b = static_cast<int>(blockIdx.z) / nseg;
 	const int seg = static_cast<int>(blockIdx.z) - b * nseg;
 	const qk_box bx = boxes[b];
 	const SGeom g = geom[b];
-	const int i = bx.lo[0] - 1 + static_cast<int>(blockIdx.x * 64 + threadIdx.x);
-	const int ot = bx.lo[OT] - 1 + static_cast<int>(blockIdx.y * 4 + threadIdx.y);
-	if (i > bx.hi[0] + 1 || ot > bx.hi[OT] + 1) {
-		return;
+	RA4 U(U_t[b]);
+	const int t = threadIdx.x;
+	const int x0 = bx.lo[0] - 1 + static_cast<int>(blockIdx.x) * PT_X; // tile origin (first rim cell of the box for tile 0)
+	const int y0 = bx.lo[1] - 1 + static_cast<int>(blockIdx.y) * PT_Y;
+	if (x0 > bx.hi[0] + 1 || y0 > bx.hi[1] + 1) {
+		return; // uniform for the workgroup
 	}
-	// output cells lo-1 .. hi+2 of the box, this segment's share [first, first + nout - 1]
-	const int nall = bx.hi[DIR] - bx.lo[DIR] + 1 + 3;
+	// output planes lo-1 .. hi+1 of the box, this segment's share [zfirst, zlast]
+	const int nall = bx.hi[2] - bx.lo[2] + 3;
 	const int seglen = (nall + nseg - 1) / nseg;
-	const int first = bx.lo[DIR] - 1 + seg * seglen;
-	const int nout = min(seglen, bx.lo[DIR] - 1 + nall - first);
-	if (nout <= 0) {
+	const int zfirst = bx.lo[2] - 1 + seg * seglen;
+	const int zlast = min(zfirst + seglen - 1, bx.hi[2] + 1);
+	if (zlast < zfirst) {
 		return;
 	}
-	const int lo = first + 1;      // (for a whole box: lo = bx.lo, nvalid = box length)
-	const int nvalid = nout - 3;
-	const int64_t st[3] = {1, g.n[0], static_cast<int64_t>(g.n[0]) * g.n[1]};
-	const int64_t ms = st[DIR];
-	int pos[3];
-	pos[0] = i;
-	pos[OT] = ot;
-	pos[DIR] = lo - 4;
-	int64_t c = (pos[0] - g.glo[0]) * st[0] + (pos[1] - g.glo[1]) * st[1] + (pos[2] - g.glo[2]) * st[2];
-	double *S = scratch + g.off;
+	// fab bounds (valid + 4): conversions outside feed only outputs outside valid + 1
+	const int flo[2] = {bx.lo[0] - NG, bx.lo[1] - NG}, fhi[2] = {bx.hi[0] + NG, bx.hi[1] + NG};
 
-	double P[5] = {0., 0., 0., 0., 0.}, v[5] = {0., 0., 0., 0., 0.}, rh[3] = {1., 1., 1.}, ch[3] = {1., 1., 1.};
-	// p = lo-4+step is the newest cell of the window;  chi(p-2), then m and D of cell p-3
-	for (int step = 0; step < nvalid + 9; ++step, c += ms) {
+	const bool own = t < PT_OWN;
+	const int ty = own ? t / PT_X : 0;
+	const int tx = own ? t - ty * PT_X : 0;
+	const int oi = x0 + tx, oj = y0 + ty;
+	const bool ownIn = own && oi <= fhi[0] && oj <= fhi[1];
+	const bool ownOut = own && oi <= bx.hi[0] + 1 && oj <= bx.hi[1] + 1;
+	// the halo cell of this thread (threads PT_THREADS - PT_HALO .. PT_THREADS - 1)
+	const int h = t - (PT_THREADS - PT_HALO);
+	int hx = 0, hy = 0;
+	if (h >= 0) {
+		if (h < PT_HALO_Y) {
+			const int r = h / PT_X;
+			hx = h - r * PT_X;
+			hy = (r < 3) ? r - 3 : PT_Y + r - 3;
+		} else {
+			const int r = (h - PT_HALO_Y) / 6, c = (h - PT_HALO_Y) - r * 6;
+			hy = r;
+			hx = (c < 3) ? c - 3 : PT_X + c - 3;
+		}
+	}
+	const int hi_ = x0 + hx, hj = y0 + hy;
+	const bool haloIn = (h >= 0) && hi_ >= flo[0] && hi_ <= fhi[0] && hj >= flo[1] && hj <= fhi[1];
+	// rim coefficients (chi_x of columns -1 | PT_X, chi_y of rows -1 | PT_Y) are evaluated by the thread that converted that halo cell
+	const bool rimX = (h >= 0) && (hx == -1 || hx == PT_X);
+	const bool rimY = (h >= 0) && (hy == -1 || hy == PT_Y);
+	const int rx = hx, ry = hy;
+
+	double Pz[5] = {1., 1., 1., 1., 1.}, vzw[5] = {0., 0., 0., 0., 0.}, ksz[3] = {1., 1., 1.}, chz[3] = {1., 1., 1.};
+	double fm[4] = {1., 1., 1., 1.}, fdx[4] = {0., 0., 0., 0.}, fdy[4] = {0., 0., 0., 0.}; // in-plane results of planes k-3 .. k
+	double *Sout = scratch + g.off;
+	// (requesting the next plane's conserved values one plane ahead was measured: +20 registers, spills under the 128-register cap that two
+	// workgroups per CU need, 15 % slower — the kernel is issue-bound, not latency-bound)
+	const PlaneRaw neutral{1., 0., 0., 0., 1. / eos.gm1};
+	int64_t uo = ownIn ? U.idx(oi, oj, zfirst - 3) : 0;
+	int64_t uh = haloIn ? U.idx(hi_, hj, zfirst - 3) : 0;
+
+	for (int k = zfirst - 3; k <= zlast + 3; ++k, uo += U.ks, uh += U.ks) {
+		const bool inPlane = (k >= zfirst) && (k <= zlast); // uniform: this plane's x / y results are somebody's output
+		const PlaneCell c = planeCell(eos, re, ownIn ? planeLoad(U, uo) : neutral);
 #pragma unroll
 		for (int m = 0; m < 4; ++m) {
-			P[m] = P[m + 1];
-			v[m] = v[m + 1];
+			Pz[m] = Pz[m + 1];
+			vzw[m] = vzw[m + 1];
 		}
-		rh[0] = rh[1];
-		rh[1] = rh[2];
-		const double rho = S[(S_PRIM + PRHO) * T + c];
-		double Pm = S[(S_PRIM + PPRES) * T + c];
-		if (re) {
-			Pm = eos.pressure(rho, rho * Pm);
+		Pz[4] = c.P;
+		vzw[4] = c.vz;
+		// rho c_s^2 of the cell: the denominator of the shock-strength ratio, the same for chi_x, chi_y (this plane) and chi_z (two planes on)
+		const double KS = flatteningKS(eos, c.rho, c.P);
+		ksz[0] = ksz[1];
+		ksz[1] = ksz[2];
+		ksz[2] = KS;
+#pragma unroll
+		for (int m = 0; m < 3; ++m) {
+			fm[m] = fm[m + 1];
+			fdx[m] = fdx[m + 1];
+			fdy[m] = fdy[m + 1];
 		}
-		if (eos.isothermal) {
-			Pm = rho * (eos.cs_iso * eos.cs_iso);
+		if (inPlane) {
+			PlaneCell hc{1., 0., 0., 0., 1.};
+			if (own) {
+				s_P[ty + 3][tx + 3] = c.P;
+				s_vx[ty][tx + 2] = c.vx;
+				s_vy[ty + 2][tx] = c.vy;
+			}
+			if (h >= 0) {
+				hc = planeCell(eos, re, haloIn ? planeLoad(U, uh) : neutral);
+				s_P[hy + 3][hx + 3] = hc.P;
+				if (hy >= 0 && hy < PT_Y && hx >= -2 && hx < PT_X + 2) {
+					s_vx[hy][hx + 2] = hc.vx;
+				}
+				if (hx >= 0 && hx < PT_X && hy >= -2 && hy < PT_Y + 2) {
+					s_vy[hy + 2][hx] = hc.vy;
+				}
+			}
+			__syncthreads();
+			if (own) {
+				const double *Pr = &s_P[ty + 3][tx + 3];
+				s_cx[ty][tx + 1] = flatteningChiKS(Pr[-2], Pr[-1], Pr[1], Pr[2], KS, s_vx[ty][tx + 1], s_vx[ty][tx + 3]);
+				s_cy[ty + 1][tx] = flatteningChiKS(s_P[ty + 1][tx + 3], s_P[ty + 2][tx + 3], s_P[ty + 4][tx + 3], s_P[ty + 5][tx + 3], KS, s_vy[ty + 1][tx], s_vy[ty + 3][tx]);
+			}
+			if (rimX) {
+				const double *Pr = &s_P[ry + 3][rx + 3];
+				s_cx[ry][rx + 1] = flatteningChiKS(Pr[-2], Pr[-1], Pr[1], Pr[2], flatteningKS(eos, hc.rho, hc.P), s_vx[ry][rx + 1], s_vx[ry][rx + 3]);
+			} else if (rimY) {
+				s_cy[ry + 1][rx] = flatteningChiKS(s_P[ry + 1][rx + 3], s_P[ry + 2][rx + 3], s_P[ry + 4][rx + 3], s_P[ry + 5][rx + 3], flatteningKS(eos, hc.rho, hc.P),
+								   s_vy[ry + 1][rx], s_vy[ry + 3][rx]);
+			}
+			__syncthreads();
+			if (own) {
+				const double mx = smin(smin(s_cx[ty][tx], s_cx[ty][tx + 1]), s_cx[ty][tx + 2]);
+				const double my = smin(smin(s_cy[ty][tx], s_cy[ty + 1][tx]), s_cy[ty + 2][tx]);
+				fm[3] = smin(mx, my);
+				fdx[3] = smin(s_vx[ty][tx + 3] - c.vx, c.vx - s_vx[ty][tx + 1]);
+				fdy[3] = smin(s_vy[ty + 3][tx] - c.vy, c.vy - s_vy[ty + 1][tx]);
+			}
+			__syncthreads(); // the next plane overwrites the LDS planes
 		}
-		P[4] = Pm;
-		rh[2] = rho;
-		v[4] = S[(S_PRIM + PVX + DIR) * T + c];
-		if (step < 4) {
-			continue;
+		// z direction: chi_z of plane k-2 from P(k-4, k-3, k-1, k), rho c_s^2 (k-2), v_z(k-3), v_z(k-1)
+		chz[0] = chz[1];
+		chz[1] = chz[2];
+		chz[2] = flatteningChiKS(Pz[0], Pz[1], Pz[3], Pz[4], ksz[0], vzw[1], vzw[3]);
+		const int ko = k - 3;
+		if (ko >= zfirst && ko <= zlast && ownOut) {
+			const int64_t cc = (oi - g.glo[0]) + static_cast<int64_t>(g.n[0]) * ((oj - g.glo[1]) + static_cast<int64_t>(g.n[1]) * (ko - g.glo[2]));
+			Sout[(S_AUX + 0) * T + cc] = smin(fm[0], smin(smin(chz[0], chz[1]), chz[2]));
+			Sout[(S_AUX + 1) * T + cc] = fdx[0];
+			Sout[(S_AUX + 2) * T + cc] = fdy[0];
+			// D_z of plane ko = k-3: v_z(k-2) - v_z(k-3), v_z(k-3) - v_z(k-4)
+			Sout[(S_AUX + 3) * T + cc] = smin(vzw[2] - vzw[1], vzw[1] - vzw[0]);
 		}
-		ch[0] = ch[1];
-		ch[1] = ch[2];
-		ch[2] = flatteningChi(eos, P[0], P[1], P[2], P[3], P[4], rh[0], v[1], v[3]);
-		if (step < 6) {
-			continue;
-		}
-		const int64_t cc = c - 3 * ms;
-		const double m_in = S[(S_AUX + 0) * T + cc];
-		S[(S_AUX + 0) * T + cc] = smin(smin(smin(m_in, ch[0]), ch[1]), ch[2]);
-		S[(S_AUX + 1 + DIR) * T + cc] = smin(v[2] - v[1], v[1] - v[0]);
 	}
 }
 
@@ -330,9 +389,18 @@ template <int ORDER, int STAGE> __global__ void __launch_bounds__(XB) k_sweep_x(
 	const double *S = a.scratch + g.off;
 	const int64_t T = a.total_cells;
 	double q0[NVAR];
+	{
+		RA4 U(a.U_in[b]);
+		const int64_t u = U.idx(i, j, k);
+		double Uc[NVAR];
+#pragma unroll
+		for (int n = 0; n < NVAR; ++n) {
+			Uc[n] = U.p[u + U.ns * n];
+		}
+		consToPrim(eos, a.reconstruct_eint, Uc, q0);
+	}
 #pragma unroll
 	for (int n = 0; n < NVAR; ++n) {
-		q0[n] = S[(S_PRIM + n) * T + c];
 		s_q[n][t] = q0[n];
 	}
 	const double chi = S[(S_AUX + 0) * T + c];
@@ -454,6 +522,9 @@ template <int DIR, int ORDER, int STAGE, bool LAST> __global__ void __launch_bou
 	int64_t c = (pos[0] - g.glo[0]) * st[0] + (pos[1] - g.glo[1]) * st[1] + (pos[2] - g.glo[2]) * st[2];
 	const double *S = a.scratch + g.off;
 	double *Sw = a.scratch + g.off;
+	RA4 Uin(a.U_in[b]);
+	int64_t u = Uin.idx(pos[0], pos[1], pos[2]);
+	const int64_t ums = (DIR == 1) ? Uin.js : Uin.ks;
 
 	constexpr int AV = Axes<DIR>::v, AW = Axes<DIR>::w;
 	double q[5][NVAR];
@@ -469,15 +540,22 @@ template <int DIR, int ORDER, int STAGE, bool LAST> __global__ void __launch_bou
 		}
 	}
 
-	for (int step = 0; step < nvalid + 6; ++step, c += ms) {
-		// shift the window and load prim(p)
+	for (int step = 0; step < nvalid + 6; ++step, c += ms, u += ums) {
+		// shift the window; U(p) -> primitives of the newest cell
 #pragma unroll
 		for (int n = 0; n < NVAR; ++n) {
 			q[0][n] = q[1][n];
 			q[1][n] = q[2][n];
 			q[2][n] = q[3][n];
 			q[3][n] = q[4][n];
-			q[4][n] = S[(S_PRIM + n) * T + c];
+		}
+		{
+			double Uc[NVAR];
+#pragma unroll
+			for (int n = 0; n < NVAR; ++n) {
+				Uc[n] = Uin.p[u + Uin.ns * n];
+			}
+			consToPrim(eos, a.reconstruct_eint, Uc, q[4]);
 		}
 		if (step < 4) {
 			continue;
@@ -487,6 +565,31 @@ template <int DIR, int ORDER, int STAGE, bool LAST> __global__ void __launch_bou
 		const double chi = S[(S_AUX + 0) * T + cc];
 		const double dV = S[(S_AUX + 1 + AV) * T + cc];
 		const double dW = S[(S_AUX + 1 + AW) * T + cc];
+		// The accumulator of cell cc-1 (and in stage 2 the stage-1 flux of this step's face) are requested BEFORE the reconstruction and the
+		// Riemann solve instead of where they are used: behind the face-flux stores they could not be hoisted by the compiler (may-alias),
+		// and a wave parked on them for a full memory round trip per step (SQ_WAIT_ANY 59 % of the wave cycles at 2 waves per SIMD).
+		double rhs_in[NVAR + 1], F1[NVAR + 1];
+		int fidx[3];
+		fidx[0] = i;
+		fidx[OT] = ot;
+		fidx[DIR] = lo + (step - 5);
+		if (step >= 6) {
+			const int64_t cu = cc - ms;
+#pragma unroll
+			for (int n = 0; n < NVAR + 1; ++n) {
+				rhs_in[n] = S[(S_RHS + n) * T + cu];
+			}
+		}
+		if (STAGE == 2 && step >= 5) {
+			RA4 HF(a.halfFlux[b]);
+			RA4 HV(a.halfVel[b]);
+			const int64_t o = HF.idx(fidx[0], fidx[1], fidx[2]);
+#pragma unroll
+			for (int n = 0; n < NVAR; ++n) {
+				F1[n] = HF.p[o + HF.ns * n];
+			}
+			F1[NVAR] = HV(fidx[0], fidx[1], fidx[2]);
+		}
 		double am[NVAR], ap[NVAR];
 #pragma unroll
 		for (int n = 0; n < NVAR; ++n) {
@@ -498,10 +601,6 @@ template <int DIR, int ORDER, int STAGE, bool LAST> __global__ void __launch_bou
 			const double du = q[2][PVX + DIR] - q[1][PVX + DIR];
 			double F[NVAR], vf;
 			faceFlux<DIR, QK_RIEMANN_HLLC>(eos, a.reconstruct_eint, 3, apPrev, am, du, dVprev, dV, dWprev, dW, a.K_visc, F, vf);
-			int fidx[3];
-			fidx[0] = i;
-			fidx[OT] = ot;
-			fidx[DIR] = lo + (step - 5);
 			if (STAGE == 1) {
 				if (live) {
 					WA4 HF(a.halfFlux[b]);
@@ -514,14 +613,11 @@ template <int DIR, int ORDER, int STAGE, bool LAST> __global__ void __launch_bou
 					HV(fidx[0], fidx[1], fidx[2]) = vf;
 				}
 			} else {
-				WA4 HF(a.halfFlux[b]);
-				WA4 HV(a.halfVel[b]);
-				const int64_t o = HF.idx(fidx[0], fidx[1], fidx[2]);
 #pragma unroll
 				for (int n = 0; n < NVAR; ++n) {
-					F[n] = 0.5 * HF.p[o + HF.ns * n] + 0.5 * F[n];
+					F[n] = 0.5 * F1[n] + 0.5 * F[n];
 				}
-				vf = 0.5 * HV(fidx[0], fidx[1], fidx[2]) + 0.5 * vf;
+				vf = 0.5 * F1[NVAR] + 0.5 * vf;
 				if (a.store_rk2 && live) {
 					WA4 RF(a.rk2Flux[b]);
 					const int64_t o2 = RF.idx(fidx[0], fidx[1], fidx[2]);
@@ -537,9 +633,9 @@ template <int DIR, int ORDER, int STAGE, bool LAST> __global__ void __launch_bou
 				double rhs[NVAR];
 #pragma unroll
 				for (int n = 0; n < NVAR; ++n) {
-					rhs[n] = S[(S_RHS + n) * T + cu] + a.inv_dx * (Fprev[n] - F[n]);
+					rhs[n] = rhs_in[n] + a.inv_dx * (Fprev[n] - F[n]);
 				}
-				const double div_v = S[(S_RHS + 6) * T + cu] + (vf - vfPrev) / a.dx;
+				const double div_v = rhs_in[NVAR] + (vf - vfPrev) / a.dx;
 				if (LAST) {
 					int u[3];
 					u[0] = i;
@@ -729,28 +825,18 @@ int qk_hydro_stage_fused(qk_level *lev, qk_stream stream, const qk_hydro_traits 
 	const SGeom *geom = static_cast<const SGeom *>(lev->d_sgeom);
 	const qk_box *boxes = lev->d_boxes;
 
-	int64_t maxcell = 1;
-	for (int d = 0; d < 3; ++d) {
-		maxcell *= lev->maxlen[d] + 2 * NG;
-	}
-
-	// 1.-3. pencil pre-passes: primitives (valid + 4), combined flattening coefficient and velocity differences (valid + 1)
+	// 1. flattening coefficient and velocity differences (valid + 1), one pass over U
 	{
-		ProfScope ps(ctx, s, "k_pre_x");
-		const dim3 grid(static_cast<unsigned>((maxcell + PXOUT - 1 + 3) / PXOUT), lev->nboxes, 1);
-		hipLaunchKernelGGL(k_pre_x, grid, dim3(PXB), 0, s, geom, args->U_in, scratch, T, eos, re);
-	}
-	{
-		ProfScope ps(ctx, s, "k_pre_y");
-		const int nseg = marchSegments(lev, 1, 2);
-		const dim3 grid((lev->maxlen[0] + 2 + 63) / 64, (lev->maxlen[2] + 2 + 3) / 4, lev->nboxes * nseg);
-		hipLaunchKernelGGL(k_pre_march<1>, grid, dim3(64, 4), 0, s, boxes, geom, scratch, T, eos, re, nseg);
-	}
-	{
-		ProfScope ps(ctx, s, "k_pre_z");
-		const int nseg = marchSegments(lev, 2, 1);
-		const dim3 grid((lev->maxlen[0] + 2 + 63) / 64, (lev->maxlen[1] + 2 + 3) / 4, lev->nboxes * nseg);
-		hipLaunchKernelGGL(k_pre_march<2>, grid, dim3(64, 4), 0, s, boxes, geom, scratch, T, eos, re, nseg);
+		ProfScope ps(ctx, s, "k_pre");
+		const int xt = (lev->maxlen[0] + 2 + PT_X - 1) / PT_X, yt = (lev->maxlen[1] + 2 + PT_Y - 1) / PT_Y;
+		// enough workgroups for ~4 per CU; every z segment pays 6 planes of warm-up (own columns only), so keep >= 24 planes per segment
+		int nseg = static_cast<int>(std::min<int64_t>((1024 + static_cast<int64_t>(xt) * yt * lev->nboxes - 1) / (static_cast<int64_t>(xt) * yt * lev->nboxes),
+							      std::max(1, (lev->maxlen[2] + 2) / 24)));
+		if (const char *e = std::getenv("QK_PRE_SEGMENTS")) {
+			nseg = std::max(1, std::atoi(e));
+		}
+		const dim3 grid(xt, yt, lev->nboxes * nseg);
+		hipLaunchKernelGGL(k_pre3, grid, dim3(PT_THREADS), 0, s, boxes, geom, args->U_in, scratch, T, eos, re, nseg);
 	}
 
 	// 4. sweeps
