@@ -107,13 +107,13 @@ __global__ void __launch_bounds__(256) k_copy(const CopyItem *items, const D *st
 		} else if (MODE == MODE_SUM_LOCAL) { // SumBoundary: the ghost copy is added to the valid cell it mirrors
 			A4<T, D> Dst(state_t[it.dst_box]);
 			A4<T, D> Src(state_t[it.src_box]);
-			atomicAdd(&Src(di - it.shift[0], dj - it.shift[1], dk - it.shift[2], n), Dst(di, dj, dk, n));
+			atomicAdd(Src.ptr(di - it.shift[0], dj - it.shift[1], dk - it.shift[2], n), Dst(di, dj, dk, n));
 		} else if (MODE == MODE_SUM_PACK) { // items = the strips this rank RECEIVES in FillBoundary: their ghost values go back
 			A4<T, D> Dst(state_t[it.dst_box]);
 			buf[it.offset + t] = Dst(di, dj, dk, n);
 		} else { // items = the strips this rank SENDS in FillBoundary: add what came back to the valid cells
 			A4<T, D> Src(state_t[it.src_box]);
-			atomicAdd(&Src(di - it.shift[0], dj - it.shift[1], dk - it.shift[2], n), buf[it.offset + t]);
+			atomicAdd(Src.ptr(di - it.shift[0], dj - it.shift[1], dk - it.shift[2], n), buf[it.offset + t]);
 		}
 	}
 }

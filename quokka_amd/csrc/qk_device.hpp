@@ -29,14 +29,21 @@ constexpr int NVAR = 6;
 enum { RHO = 0, MX = 1, MY = 2, MZ = 3, ENE = 4, EINT = 5 };
 enum { PRHO = 0, PVX = 1, PVY = 2, PVZ = 3, PPRES = 4, PEINT = 5 };
 
-// amrex::Array4 accessor over the binary-compatible descriptor
+// A pointer that was LOADED from memory (the data pointer of an array descriptor) is a generic pointer to the compiler: every access through
+// it becomes a FLAT instruction, which counts in vmcnt AND lgkmcnt and may return out of order, so hipcc waits for everything
+// (s_waitcnt vmcnt(0) lgkmcnt(0)) before the first use of any such load — including the stores a loop issued just before.  All arrays of the
+// C-ABI are device allocations (global_load / global_store, in-order vmcnt).
+// The pointer is therefore kept with its address space (1 = global) in the accessor.
 template <typename T, typename D> struct A4 {
-	T *p;
+	using GT = __attribute__((address_space(1))) T;
+	GT *p;
 	int64_t js, ks, ns;
 	int bx, by, bz;
-	QK_DEV explicit A4(D const &d) : p(d.p), js(d.jstride), ks(d.kstride), ns(d.nstride), bx(d.begin[0]), by(d.begin[1]), bz(d.begin[2]) {}
+	QK_DEV explicit A4(D const &d) : p((GT *)d.p), js(d.jstride), ks(d.kstride), ns(d.nstride), bx(d.begin[0]), by(d.begin[1]), bz(d.begin[2]) {}
 	QK_DEV auto idx(int i, int j, int k) const -> int64_t { return (i - bx) + js * (j - by) + ks * (k - bz); }
-	QK_DEV auto operator()(int i, int j, int k, int n = 0) const -> T & { return p[idx(i, j, k) + ns * n]; }
+	QK_DEV auto operator()(int i, int j, int k, int n = 0) const -> GT & { return p[idx(i, j, k) + ns * n]; }
+	// generic pointer to one element (for the atomic* functions of the HIP headers, which take generic pointers)
+	QK_DEV auto ptr(int i, int j, int k, int n = 0) const -> T * { return (T *)&p[idx(i, j, k) + ns * n]; }
 };
 using RA4 = A4<const double, qk_array4>;
 using WA4 = A4<double, qk_array4>;

@@ -302,15 +302,61 @@ QK_DEV void flattenEdges(double chi, double mean, double &am, double &ap)
 	ap = chi * ap + (1. - chi) * mean;
 }
 
-// epilogue of one cell (AddInternalEnergyPdV + PredictStep + EnforceLimits + SyncDualEnergy)
+// epilogue of one cell (AddInternalEnergyPdV + PredictStep + EnforceLimits + SyncDualEnergy + the two CFL signal speeds), same operations
+// as the per-cell functions of qk_device.hpp (which the reference-shaped operators call) with the ~30 divisions grouped by denominator:
+// rho_old x4, rho_new x12, 2 rho_new x1, k_B and k_B_user (constants: their reciprocals are refined once per thread, EpiConst) — every further
+// quotient is mul + 2 fma on the refined reciprocal, the same bits as `/` for normal-range operands (recipOf in qk_device.hpp).
+struct EpiConst {
+	Recip RkB, RkBu, Rmu; // 1 / k_B, 1 / k_B_user, 1 / (mu m_u)
+};
+QK_DEV auto epiConst(Eos const &eos) -> EpiConst
+{
+	EpiConst c;
+	c.RkB = recipOf(Eos::k_B);
+	c.RkBu = recipOf(eos.kB_user);
+	c.Rmu = recipOf(eos.mu * Eos::m_u);
+	return c;
+}
+// Eos::tgasFromEint / eintFromTgas (EOS.hpp:74-159) with the shared reciprocals
+QK_DEV auto epiTgas(Eos const &eos, EpiConst const &ec, Recip const &Rrho, double Eint) -> double
+{
+	if (eos.tmodel == 1) {
+		return sqrt(sqrt(4.0 * Eint / eos.alpha));
+	}
+	const double e = divBy(Eint, Rrho);
+	const double T = divBy(e * eos.mu * Eos::m_u * eos.gm1, ec.RkB);
+	return divBy(T * Eos::k_B, ec.RkBu);
+}
+QK_DEV auto epiEint(Eos const &eos, EpiConst const &ec, double rho, double T) -> double
+{
+	if (eos.tmodel == 1) {
+		return (eos.alpha / 4.0) * ((T * T) * (T * T));
+	}
+	const double p = divBy(rho * T * Eos::k_B, ec.Rmu);
+	const double e = p / (eos.gm1 * rho);
+	return divBy(e * rho * eos.kB_user, ec.RkB);
+}
+
 // U holds the old state of the cell on entry
-QK_DEV void updateCellFrom(SweepArgs const &a, Eos const &eos, int b, int i, int j, int k, double U[NVAR], const double rhs[NVAR], double div_v, double &sig0,
-			   double &sig1)
+QK_DEV void updateCellFrom(SweepArgs const &a, Eos const &eos, EpiConst const &ec, int b, int i, int j, int k, double U[NVAR], const double rhs[NVAR], double div_v,
+			   double &sig0, double &sig1)
 {
 	WA4 Un(a.U_out[b]);
 	IA4 flag(a.redoFlag[b]);
-	// hydro_system.hpp:797-812 (redoFlag == none branch)
-	const double Pgas = consPressure(eos, U[RHO], U[MX], U[MY], U[MZ], U[ENE]);
+	// hydro_system.hpp:797-812 (redoFlag == none branch): P(U_old) = ComputePressure(cons)
+	double Pgas;
+	{
+		const double rho = U[RHO];
+		if (eos.isothermal) {
+			Pgas = rho * eos.cs_iso * eos.cs_iso;
+		} else {
+			const Recip Ro = recipOf(rho);
+			const double vx = divBy(U[MX], Ro), vy = divBy(U[MY], Ro), vz = divBy(U[MZ], Ro);
+			const double thermal_energy = U[ENE] - 0.5 * rho * (vx * vx + vy * vy + vz * vz);
+			const double e = (rho == 0.0) ? 0.0 : divBy(thermal_energy, Ro);
+			Pgas = eos.gm1 * rho * e;
+		}
+	}
 	double r[NVAR];
 #pragma unroll
 	for (int n = 0; n < NVAR; ++n) {
@@ -326,12 +372,39 @@ QK_DEV void updateCellFrom(SweepArgs const &a, Eos const &eos, int b, int i, int
 	flag(i, j, k) = bad;
 	if (bad != 0) {
 		atomicAdd(a.redo_count, 1ULL);
-	} else {
-		enforceLimits(eos, a.densityFloor, a.tempFloor, U);
-		if (a.use_dual_energy != 0) {
-			if (!syncDualEnergy(U)) {
-				*a.error_flag = 1;
+	}
+	// EnforceLimits (hydro_system.hpp:702-771) : density floor, then the temperature floors on E and on the auxiliary internal energy
+	double rho_new = U[RHO];
+	if (bad == 0 && U[RHO] < a.densityFloor) {
+		rho_new = a.densityFloor;
+		U[RHO] = rho_new;
+	}
+	const Recip Rn = recipOf(rho_new);
+	const double px = U[MX], py = U[MY], pz = U[MZ];
+	const double vx = divBy(px, Rn), vy = divBy(py, Rn), vz = divBy(pz, Rn);
+	if (bad == 0) {
+		if ((rho_new > 2.2250738585072014e-308) && !eos.isothermal) {
+			const double Ekin = 0.5 * rho_new * (vx * vx + vy * vy + vz * vz);
+			const double Etot = U[ENE];
+			if (epiTgas(eos, ec, Rn, Etot - Ekin) < a.tempFloor) {
+				U[ENE] = Ekin + epiEint(eos, ec, rho_new, a.tempFloor);
 			}
+			if (epiTgas(eos, ec, Rn, U[EINT]) < a.tempFloor) {
+				U[EINT] = epiEint(eos, ec, rho_new, a.tempFloor);
+			}
+		}
+	}
+	// SyncDualEnergy (:825-849)
+	const double Ekin2 = (px * px + py * py + pz * pz) / (2.0 * rho_new);
+	if (bad == 0 && a.use_dual_energy != 0) {
+		const double Etot = U[ENE];
+		const double Eint_aux = U[EINT];
+		const double Eint_cons = Etot - Ekin2;
+		if (Eint_cons > 1.0e-3 * Etot) {
+			U[EINT] = Eint_cons;
+		} else {
+			U[EINT] = Eint_aux;
+			U[ENE] = Eint_aux + Ekin2;
 		}
 	}
 	const int64_t cn = Un.idx(i, j, k);
@@ -340,21 +413,19 @@ QK_DEV void updateCellFrom(SweepArgs const &a, Eos const &eos, int b, int i, int
 		Un.p[cn + Un.ns * n] = U[n];
 	}
 	if (a.max_signal != nullptr) {
-		sig0 = smax(sig0, signalSpeed(eos, 0, U[RHO], U[MX], U[MY], U[MZ], U[ENE]));
-		sig1 = smax(sig1, signalSpeed(eos, 1, U[RHO], U[MX], U[MY], U[MZ], U[ENE]));
+		// maxSignalSpeedLocal (:206-219) and ComputeMaxSignalSpeed (:227-250) of the new state
+		double cs;
+		if (eos.isothermal) {
+			cs = eos.cs_iso;
+		} else {
+			const double thermal_energy = U[ENE] - 0.5 * rho_new * (vx * vx + vy * vy + vz * vz);
+			const double e = (rho_new == 0.0) ? 0.0 : divBy(thermal_energy, Rn);
+			const double P = eos.gm1 * rho_new * e;
+			cs = sqrt(divBy(eos.gamma * P, Rn));
+		}
+		sig0 = smax(sig0, cs + sqrt(divBy(2.0 * Ekin2, Rn)));
+		sig1 = smax(sig1, cs + sqrt(vx * vx + vy * vy + vz * vz));
 	}
-}
-
-QK_DEV void updateCell(SweepArgs const &a, Eos const &eos, int b, int i, int j, int k, const double rhs[NVAR], double div_v, double &sig0, double &sig1)
-{
-	RA4 Uo(a.U_old[b]);
-	const int64_t co = Uo.idx(i, j, k);
-	double U[NVAR];
-#pragma unroll
-	for (int n = 0; n < NVAR; ++n) {
-		U[n] = Uo.p[co + Uo.ns * n];
-	}
-	updateCellFrom(a, eos, b, i, j, k, U, rhs, div_v, sig0, sig1);
 }
 
 // ---------------------------------------------------------------------------------------------- X sweep (flat + LDS)
@@ -523,6 +594,8 @@ template <int DIR, int ORDER, int STAGE, bool LAST> __global__ void __launch_bou
 	const double *S = a.scratch + g.off;
 	double *Sw = a.scratch + g.off;
 	RA4 Uin(a.U_in[b]);
+	RA4 Uold(a.U_old[b]);
+	const EpiConst ec = epiConst(eos);
 	int64_t u = Uin.idx(pos[0], pos[1], pos[2]);
 	const int64_t ums = (DIR == 1) ? Uin.js : Uin.ks;
 
@@ -573,11 +646,23 @@ template <int DIR, int ORDER, int STAGE, bool LAST> __global__ void __launch_bou
 		fidx[0] = i;
 		fidx[OT] = ot;
 		fidx[DIR] = lo + (step - 5);
+		double Uo[NVAR];
 		if (step >= 6) {
 			const int64_t cu = cc - ms;
 #pragma unroll
 			for (int n = 0; n < NVAR + 1; ++n) {
 				rhs_in[n] = S[(S_RHS + n) * T + cu];
+			}
+			if (LAST) { // the old state of the cell this step completes
+				int uc[3];
+				uc[0] = i;
+				uc[OT] = ot;
+				uc[DIR] = lo + (step - 6);
+				const int64_t co = Uold.idx(uc[0], uc[1], uc[2]);
+#pragma unroll
+				for (int n = 0; n < NVAR; ++n) {
+					Uo[n] = Uold.p[co + Uold.ns * n];
+				}
 			}
 		}
 		if (STAGE == 2 && step >= 5) {
@@ -642,7 +727,7 @@ template <int DIR, int ORDER, int STAGE, bool LAST> __global__ void __launch_bou
 					u[OT] = ot;
 					u[DIR] = lo + (step - 6);
 					if (live) {
-						updateCell(a, eos, b, u[0], u[1], u[2], rhs, div_v, sig0, sig1);
+						updateCellFrom(a, eos, ec, b, u[0], u[1], u[2], Uo, rhs, div_v, sig0, sig1);
 					}
 				} else if (live) {
 #pragma unroll

@@ -512,7 +512,7 @@ int qk_hydro_EnforceLimits(qk_level *lev, qk_stream s, const qk_hydro_traits *t,
 		}
 		if (nscalars > 0 && U[RHO] < densityFloor) { // hydro_system.hpp:713-722: the scalars keep their mass when the density is floored
 			for (int n = 0; n < nscalars; ++n) {
-				double &q = S.p[c + S.ns * (NVAR + n)];
+				auto &q = S.p[c + S.ns * (NVAR + n)];
 				q = (densityFloor == 0.0) ? 0.0 : q * (U[RHO] / densityFloor);
 			}
 		}
@@ -520,7 +520,7 @@ int qk_hydro_EnforceLimits(qk_level *lev, qk_stream s, const qk_hydro_traits *t,
 			const double rho_new = (U[RHO] < densityFloor) ? densityFloor : U[RHO];
 			double sp_sum = 0.0;
 			for (int idx = 0; idx < nmscalars; ++idx) {
-				double &q = S.p[c + S.ns * (NVAR + idx)];
+				auto &q = S.p[c + S.ns * (NVAR + idx)];
 				if (q < 0.0) {
 					q = 1.0e-30 * rho_new;
 				}
