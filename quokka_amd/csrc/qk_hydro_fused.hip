@@ -140,21 +140,29 @@ QK_DEV auto planeCell(Eos const &eos, bool re, PlaneRaw const &r) -> PlaneCell
 	return c;
 }
 
-__global__ void __launch_bounds__(PT_THREADS, 4) k_pre3(const qk_box *boxes, const SGeom *geom, const qk_array4 *U_t, double *scratch, int64_t T, Eos eos, bool re, int nseg)
+// Workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2; tiles that are neighbours in y read each other's halo rows.  The
+// linear id is remapped so that every XCD works through one contiguous run of tiles (x fastest, then y, then box / segment): the halo rows
+// of a tile are then found in the L2 of the XCD that just read them for the tile before.
+__global__ void __launch_bounds__(PT_THREADS, 4) k_pre3(const qk_box *boxes, const SGeom *geom, const qk_array4 *U_t, double *scratch, int64_t T, Eos eos, bool re, int nseg,
+							    int xt, int yt)
 {
+	const unsigned nblk = gridDim.x, lin = blockIdx.x;
+	const unsigned q8 = nblk / 8, r8 = nblk % 8, xcd = lin % 8, slot = lin / 8;
+	const unsigned logical = (xcd < r8) ? xcd * (q8 + 1) + slot : r8 * (q8 + 1) + (xcd - r8) * q8 + slot;
+	const int bix = static_cast<int>(logical % xt), biy = static_cast<int>((logical / xt) % yt), biz = static_cast<int>(logical / (xt * yt));
 	// LDS planes, indexed [row + 3][column + 3] (P), [row][column + 2] (v_x), [row + 2][column] (v_y)
 	__shared__ double s_P[PT_Y + 6][PT_X + 6];
 	__shared__ double s_vx[PT_Y][PT_X + 4], s_vy[PT_Y + 4][PT_X];
 	__shared__ double s_cx[PT_Y][PT_X + 2], s_cy[PT_Y + 2][PT_X]; // chi_x at columns -1..PT_X, chi_y at rows -1..PT_Y
 
-	const int b = static_cast<int>(blockIdx.z) / nseg;
-	const int seg = static_cast<int>(blockIdx.z) - b * nseg;
+	const int b = biz / nseg;
+	const int seg = biz - b * nseg;
 	const qk_box bx = boxes[b];
 	const SGeom g = geom[b];
 	RA4 U(U_t[b]);
 	const int t = threadIdx.x;
-	const int x0 = bx.lo[0] - 1 + static_cast<int>(blockIdx.x) * PT_X; // tile origin (first rim cell of the box for tile 0)
-	const int y0 = bx.lo[1] - 1 + static_cast<int>(blockIdx.y) * PT_Y;
+	const int x0 = bx.lo[0] - 1 + bix * PT_X; // tile origin (first rim cell of the box for tile 0)
+	const int y0 = bx.lo[1] - 1 + biy * PT_Y;
 	if (x0 > bx.hi[0] + 1 || y0 > bx.hi[1] + 1) {
 		return; // uniform for the workgroup
 	}
@@ -920,8 +928,8 @@ int qk_hydro_stage_fused(qk_level *lev, qk_stream stream, const qk_hydro_traits 
 		if (const char *e = std::getenv("QK_PRE_SEGMENTS")) {
 			nseg = std::max(1, std::atoi(e));
 		}
-		const dim3 grid(xt, yt, lev->nboxes * nseg);
-		hipLaunchKernelGGL(k_pre3, grid, dim3(PT_THREADS), 0, s, boxes, geom, args->U_in, scratch, T, eos, re, nseg);
+		const dim3 grid(static_cast<unsigned>(xt) * yt * lev->nboxes * nseg);
+		hipLaunchKernelGGL(k_pre3, grid, dim3(PT_THREADS), 0, s, boxes, geom, args->U_in, scratch, T, eos, re, nseg, xt, yt);
 	}
 
 	// 4. sweeps

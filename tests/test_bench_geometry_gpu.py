@@ -1,0 +1,100 @@
+"""Parity with the CPU oracle AT THE BENCHMARKED GEOMETRY: 128^3 boxes (X tiles of 250 flat cells crossing rows, one march segment per
+128-cell column, 8 boxes per launch, the plane-marching pre-pass with two x tiles per box), started from a DEVELOPED state — a strong
+spherical shock that crosses x-tile, march-segment and box boundaries — so that the PPM extremum / flattening / HLLC fan branches all fire.
+(The timed region of bench.py sits at sim-time ~6e-5, where >99.9 % of the cells are ambient gas; round 1's one real bug, a read-modify-write
+race of the fused stage, was invisible on the <= 32^3 boxes of the other parity tests.)  The oracle does ~4 M cell-updates/s: seconds per test.
+
+RadhydroShell at 64^3 in 32^3 boxes, >= 5 coupled steps: <= 1e-12 relative L1 with the reference's std::pow (pow_mode 0), bit for bit with the
+shared T^4 evaluation (pow_mode 1)."""
+import numpy as np
+import pytest
+
+from oracle.pyoracle import SEDOV
+from quokka_amd.simulation import sedov_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def developed_state(N, lo, hi, ng=4, R=0.62):
+    """(6, nz, ny, nx) conserved state of the ghosted fab [lo-ng, hi+ng]: a dense shell of radius R (in units of the domain edge) running
+    outwards at Mach ~3 into ambient gas, hot inside, with a 1e-3 random ripple (same numbers for both sides: the array is handed to the
+    oracle and to the GPU).  Ghost values are overwritten by the first ghost fill."""
+    idx = [np.arange(lo[d] - ng, hi[d] + ng + 1) for d in range(3)]
+    k, j, i = np.meshgrid(idx[2], idx[1], idx[0], indexing="ij")
+    x, y, z = ((a + 0.5) / N for a in (i, j, k))
+    r = np.sqrt(x * x + y * y + z * z)
+    w = 2.5 / N
+    shell = np.exp(-((r - R) / w) ** 2)
+    inside = 0.5 * (1.0 - np.tanh((r - R) / w))
+    # the ripple is a function of the GLOBAL cell index, so that every box sees the same field
+    h = (i * 73856093) ^ (j * 19349663) ^ (k * 83492791)
+    ripple = 1.0 + 1.0e-3 * (((h % 2001) - 1000) / 1000.0)
+    rho = (1.0 + 3.0 * shell) * ripple
+    vr = 1.8 * inside * (r / R) + 2.5 * shell
+    rs = np.maximum(r, 1e-12)
+    vx, vy, vz = vr * x / rs, vr * y / rs, vr * z / rs
+    P = 0.05 + 2.0 * inside + 1.0 * shell
+    U = np.zeros((6,) + r.shape)
+    U[0] = rho
+    U[1], U[2], U[3] = rho * vx, rho * vy, rho * vz
+    U[5] = P / 0.4
+    U[4] = U[5] + 0.5 * rho * (vx * vx + vy * vy + vz * vz)
+    return U
+
+
+def gather(boxes, vals, N):
+    U = np.zeros((6, N, N, N))
+    for (lo, hi), v in zip(boxes, vals):
+        U[:, lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1] = v
+    return U
+
+
+@pytest.mark.parametrize("N,nsteps", [(128, 4), (256, 3)])
+def test_fused_stage_at_128_cubed_boxes_matches_oracle(ctx, oracle, N, nsteps):
+    mgs = 128
+    so = oracle.sim(SEDOV, 3, [N] * 3, [0, 0, 0], [1.2] * 3, [0, 0, 0], max_grid_size=[mgs] * 3)
+    sg = sedov_problem(ctx, N, max_grid_size=mgs)
+    assert sg.use_fused and sg.lev.nboxes == (N // mgs) ** 3 == so.nboxes
+    for b in range(so.nboxes):
+        lo, hi = so.box(b)
+        assert (lo, hi) == (sg.my_boxes[b][0], sg.my_boxes[b][1])
+        U0 = developed_state(N, lo, hi)
+        so.set_state(U0, b, 0)
+        sg.state_new_cc_.set_fab(b, U0)
+    sg._signal_of_state_new = None
+    for it in range(nsteps):
+        assert so.step() and sg.step(), f"advance failed at step {it}"
+        assert so.dt == sg.dt_, f"dt differs at step {it}: {so.dt} vs {sg.dt_}"
+    # the fused path must have carried every step (no silent detour through the reference-shaped operators)
+    assert sg.counters["fofc1_stages"] == sg.counters["fofc2_stages"] == sg.counters["retries"] == 0
+    Uo = gather([so.box(b) for b in range(so.nboxes)], [so.valid(b) for b in range(so.nboxes)], N)
+    Ug = gather(sg.my_boxes, sg.gather_valid_local(), N)
+    # the state is developed: a strong compression front sits on tile and (at 256^3) box boundaries
+    assert Uo[0].max() > 2.0 and Uo[0].min() < 1.1
+    if N == 256:
+        assert np.abs(np.diff(Uo[0][:, :, 126:130], axis=2)).max() > 1e-2, "no structure across the box boundary at i = 128"
+    assert np.array_equal(Uo, Ug), f"max abs diff {np.abs(Uo - Ug).max()} (rel L1 {np.abs(Uo - Ug).sum() / np.abs(Uo).sum()})"
+
+
+@pytest.mark.parametrize("pow_mode", [0, 1])
+def test_shell_64_cubed_in_32_cubed_boxes(ctx, oracle, pow_mode):
+    import test_radhydro_gpu as T
+    N, mgs, nsteps = 64, 32, 5
+    so, sg = T.make_pair(ctx, oracle, N, mgs, pow_mode)
+    T.seed_from_oracle(so, sg)
+    for it in range(nsteps):
+        assert so.step() and sg.step(), f"advance failed at step {it}"
+        if pow_mode == 1:
+            assert so.dt == sg.dt_, (it, so.dt, sg.dt_)
+    Uo = T.gather([so.box(b) for b in range(so.nboxes)], [so.valid(b) for b in range(so.nboxes)], N)
+    Ug = T.gather(sg.my_boxes, sg.gather_valid_local(), N)
+    assert not np.isnan(Ug).any()
+    if pow_mode == 1:
+        assert np.array_equal(Uo, Ug), f"rel L1 per component {T.rel_l1(Ug, Uo)}"
+        return
+    err = T.rel_l1(Ug, Uo)
+    scale = np.abs(Uo[0]).sum() * T.ShellConstants.a0  # momenta sum to ~0 over a symmetric shell: absolute measure for them
+    for n in (0, 4, 5, 6, 7, 8, 9):
+        assert err[n] <= 1e-12, (n, err)
+    for n in (1, 2, 3):
+        assert np.abs(Ug[n] - Uo[n]).sum() <= 1e-12 * scale, (n, err)
