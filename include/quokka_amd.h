@@ -402,6 +402,10 @@ int qk_fluxreg_destroy(qk_fluxreg *fr);
 int qk_fluxreg_num_items(qk_fluxreg *fr);
 int qk_fluxreg_item(qk_fluxreg *fr, int idx, int *dir, int *side, int *fine_box, int *crse_box, int lo[3], int hi[3], int shift[3]);
 int qk_fluxreg_reset(qk_fluxreg *fr, qk_stream s);
+/* fr_as_fine->getFineData() saved before the retry loop of the fine level and copied back at every retry
+ * (reference src/QuokkaSimulation.hpp:894-900, :926-928); the copy lives inside the register object */
+int qk_fluxreg_save(qk_fluxreg *fr, qk_stream s);
+int qk_fluxreg_restore(qk_fluxreg *fr, qk_stream s);
 int qk_fluxreg_CrseAdd(qk_fluxreg *fr, qk_stream s, const qk_array4 *const flux[3], const double dx[3], double dt);
 int qk_fluxreg_FineAdd(qk_fluxreg *fr, qk_stream s, const qk_array4 *const flux[3], const double dx_fine[3], double dt);
 int qk_fluxreg_Reflux(qk_fluxreg *fr, qk_stream s, qk_array4 *crse_state);

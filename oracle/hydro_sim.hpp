@@ -678,7 +678,7 @@ struct HydroSim {
 	{
 		int nsubSteps = 0;
 		double dt_radiation = NAN;
-		if (!(constantDt_ > 0.)) {
+		if (is_hydro_enabled && !(constantDt_ > 0.)) { // :1583 — radiation-only problems take one radiation step of dt_lev
 			nsubSteps = computeNumberOfRadiationSubsteps(dt_lev_hydro);
 			dt_radiation = dt_lev_hydro / static_cast<double>(nsubSteps);
 		} else {

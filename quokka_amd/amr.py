@@ -141,6 +141,15 @@ class FluxRegister:
         ctx = self.crse.ctx
         ctx.check(ctx.L.qk_fluxreg_reset(self.h, ctx.stream()), "qk_fluxreg_reset")
 
+    def save(self):
+        """the register as it is before a level's retry loop (reference src/QuokkaSimulation.hpp:894-900)"""
+        ctx = self.crse.ctx
+        ctx.check(ctx.L.qk_fluxreg_save(self.h, ctx.stream()), "qk_fluxreg_save")
+
+    def restore(self):
+        ctx = self.crse.ctx
+        ctx.check(ctx.L.qk_fluxreg_restore(self.h, ctx.stream()), "qk_fluxreg_restore")
+
     def CrseAdd(self, flux, dx, dt: float):
         ctx = self.crse.ctx
         ctx.check(ctx.L.qk_fluxreg_CrseAdd(self.h, ctx.stream(), self._p3(flux), (C.c_double * 3)(*[float(x) for x in dx]), float(dt)), "qk_fluxreg_CrseAdd")

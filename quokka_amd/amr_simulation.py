@@ -155,10 +155,12 @@ class AmrLevelSim(HydroSimulation):
         ok = super().advanceHydroAtLevel(state_old_tmp, dt_lev)
         if ok:  # incrementFluxRegisters (reference src/QuokkaSimulation.hpp:1303-1306, src/simulation.hpp:1369-1386)
             amr, l = self.amr, self.ilev
+            # integratorOrder_ == 1: the step's fluxes are the stage-1 fluxes (scale 1), which stay in halfFlux
+            flux = self.fluxRk2() if self.integratorOrder_ == 2 else self.halfFlux
             if amr.do_reflux and l < amr.finest_level:
-                amr.levels[l + 1].fluxreg.CrseAdd(self.fluxRk2(), self.geom.dx, dt_lev)
+                amr.levels[l + 1].fluxreg.CrseAdd(flux, self.geom.dx, dt_lev)
             if amr.do_reflux and l > 0:
-                self.fluxreg.FineAdd(self.fluxRk2(), self.geom.dx, dt_lev)
+                self.fluxreg.FineAdd(flux, self.geom.dx, dt_lev)
         self._t_adv += dt_lev
         return ok
 
@@ -167,11 +169,22 @@ class AmrLevelSim(HydroSimulation):
         advanceHydroAtLevelWithRetries (reference src/QuokkaSimulation.hpp:885-990); every attempt restarts at `time`"""
         self._signal_of_state_new = None
         self.state_old_cc_, self.state_new_cc_ = self.state_new_cc_, self.state_old_cc_
+        amr, l = self.amr, self.ilev
+        fr_as_fine = self.fluxreg if (amr.do_reflux and l > 0) else None
+        fr_as_crse = amr.levels[l + 1].fluxreg if (amr.do_reflux and l < amr.finest_level) else None
+        if fr_as_fine is not None:
+            fr_as_fine.save()  # originalFineData (reference src/QuokkaSimulation.hpp:894-900)
         for retry_count in range(7):
             nsubsteps = 2 ** retry_count
             dt_step = dt_lev / nsubsteps
             if retry_count > 0:
                 self.counters["retries"] += 1
+                # the substeps of the failed attempt that succeeded have already been added to the registers: back to the pre-advance
+                # state, or Reflux would count them twice (reference src/QuokkaSimulation.hpp:919-929)
+                if fr_as_crse is not None:
+                    fr_as_crse.reset()
+                if fr_as_fine is not None:
+                    fr_as_fine.restore()
             self._t_adv = time
             old = self.state_old_cc_ if nsubsteps == 1 else self.state_old_tmp
             if nsubsteps > 1:

@@ -170,6 +170,8 @@ def lib() -> C.CDLL:
         L.qk_fluxreg_num_items.argtypes = [vp]
         L.qk_fluxreg_item.argtypes = [vp, ci, P(ci), P(ci), P(ci), P(ci), ci * 3, ci * 3, ci * 3]
         L.qk_fluxreg_reset.argtypes = [vp, vp]
+        L.qk_fluxreg_save.argtypes = [vp, vp]
+        L.qk_fluxreg_restore.argtypes = [vp, vp]
         L.qk_fluxreg_CrseAdd.argtypes = [vp, vp, vp * 3, C.c_double * 3, C.c_double]
         L.qk_fluxreg_FineAdd.argtypes = [vp, vp, vp * 3, C.c_double * 3, C.c_double]
         L.qk_fluxreg_Reflux.argtypes = [vp, vp, vp]
@@ -202,7 +204,7 @@ DECLARED_SYMBOLS = [
     "qk_FillPhysicalBoundary_subset", "qk_ghost_plan_set_components", "qk_ghost_plan_box_is_remote", "qk_ghost_plan_set_box_remote",
     "qk_tag_relative_gradient", "qk_tag_centered_gradient", "qk_avgdown_plan_create", "qk_avgdown_plan_destroy", "qk_avgdown_plan_num_items", "qk_average_down", "qk_PreInterpState", "qk_PostInterpState",
     "qk_interp_plan_create", "qk_interp_plan_destroy", "qk_interp_plan_num_items", "qk_interp_plan_item", "qk_InterpFromCoarse",
-    "qk_fluxreg_create", "qk_fluxreg_destroy", "qk_fluxreg_num_items", "qk_fluxreg_item", "qk_fluxreg_reset", "qk_fluxreg_CrseAdd", "qk_fluxreg_FineAdd",
+    "qk_fluxreg_create", "qk_fluxreg_destroy", "qk_fluxreg_num_items", "qk_fluxreg_item", "qk_fluxreg_reset", "qk_fluxreg_save", "qk_fluxreg_restore", "qk_fluxreg_CrseAdd", "qk_fluxreg_FineAdd",
     "qk_fluxreg_Reflux", "qk_amr_tile_flags", "qk_amr_cluster_tiles", "qk_copy_box",
 ]
 

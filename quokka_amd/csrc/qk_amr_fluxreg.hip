@@ -36,6 +36,7 @@ struct qk_fluxreg {
 	int64_t total_cells = 0;
 	int64_t max_cells = 0;
 	double *d_reg = nullptr;
+	double *d_saved = nullptr; // qk_fluxreg_save / qk_fluxreg_restore (retries of the level that is the FINE side of this register)
 };
 
 namespace
@@ -315,6 +316,7 @@ int qk_fluxreg_destroy(qk_fluxreg *fr)
 	if (fr != nullptr) {
 		(void)hipFree(fr->d_items);
 		(void)hipFree(fr->d_reg);
+		(void)hipFree(fr->d_saved);
 		delete fr;
 	}
 	return QK_OK;
@@ -348,6 +350,41 @@ int qk_fluxreg_reset(qk_fluxreg *fr, qk_stream s)
 	if (fr->d_reg != nullptr) {
 		QK_HIP_CHECK(fr->crse->ctx, hipMemsetAsync(fr->d_reg, 0, sizeof(double) * static_cast<size_t>(fr->total_cells) * fr->ncomp, static_cast<hipStream_t>(s)));
 	}
+	return QK_OK;
+}
+
+// amrex::Copy(originalFineData, fr_as_fine->getFineData()) before the retry loop of a level and the copy back at every retry
+// (reference src/QuokkaSimulation.hpp:894-900, :926-928).  Coarse and fine contributions share one array here; the coarse ones do not
+// change while the fine level advances, so saving and restoring the whole register is the same operation.
+int qk_fluxreg_save(qk_fluxreg *fr, qk_stream s)
+{
+	if (fr == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	const size_t bytes = sizeof(double) * static_cast<size_t>(fr->total_cells) * fr->ncomp;
+	if (fr->d_reg == nullptr || bytes == 0) {
+		return QK_OK;
+	}
+	if (fr->d_saved == nullptr) {
+		QK_HIP_CHECK(fr->crse->ctx, hipMalloc(reinterpret_cast<void **>(&fr->d_saved), bytes));
+	}
+	QK_HIP_CHECK(fr->crse->ctx, hipMemcpyAsync(fr->d_saved, fr->d_reg, bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(s)));
+	return QK_OK;
+}
+
+int qk_fluxreg_restore(qk_fluxreg *fr, qk_stream s)
+{
+	if (fr == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	const size_t bytes = sizeof(double) * static_cast<size_t>(fr->total_cells) * fr->ncomp;
+	if (fr->d_reg == nullptr || bytes == 0) {
+		return QK_OK;
+	}
+	if (fr->d_saved == nullptr) {
+		return qk::setError(fr->crse->ctx, QK_ERR_INVALID, "qk_fluxreg_restore: nothing saved");
+	}
+	QK_HIP_CHECK(fr->crse->ctx, hipMemcpyAsync(fr->d_reg, fr->d_saved, bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(s)));
 	return QK_OK;
 }
 

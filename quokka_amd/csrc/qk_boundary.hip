@@ -725,8 +725,10 @@ int qk_FillPhysicalBoundary_subset(qk_ghost_plan *plan, qk_stream s, qk_array4 *
 		QK_HIP_CHECK(ctx, hipMalloc(&plan->d_physbc, sizeof(PhysBcArgs)));
 	}
 	if (plan->h_physbc.size() != sizeof(PhysBcArgs) || std::memcmp(plan->h_physbc.data(), &pa, sizeof(PhysBcArgs)) != 0) {
+		// stream-ordered on `s`, then waited for: the copy is behind every kernel of this plan already queued on `s` and ahead of the launch
+		// below also when `s` is a non-blocking stream (a plan is used from one stream at a time, include/quokka_amd.h)
+		QK_HIP_CHECK(ctx, hipMemcpyAsync(plan->d_physbc, &pa, sizeof(PhysBcArgs), hipMemcpyHostToDevice, static_cast<hipStream_t>(s)));
 		QK_HIP_CHECK(ctx, hipStreamSynchronize(static_cast<hipStream_t>(s)));
-		QK_HIP_CHECK(ctx, hipMemcpy(plan->d_physbc, &pa, sizeof(PhysBcArgs), hipMemcpyHostToDevice));
 		plan->h_physbc.assign(reinterpret_cast<const unsigned char *>(&pa), reinterpret_cast<const unsigned char *>(&pa) + sizeof(PhysBcArgs));
 	}
 	hipLaunchKernelGGL(k_physbc, gridFor(plan->max_shell_cells, count), dim3(256), 0, static_cast<hipStream_t>(s), plan->d_shells + first, state_t,

@@ -227,6 +227,7 @@ template <typename problem_t> class AmrDriver
 		me.beforePhysBC_ = [this, fp, lev](amrex::MultiFab &state) { interpFromParent(*fp, lev, state, fp->sim->fillTime_, fp->interp); };
 		// incrementFluxRegisters: this level as the fine side of its register and as the coarse side of its child's
 		me.afterAdvance_ = [this, lev](double dt) { incrementFluxRegisters(lev, dt); };
+		me.beforeAttempt_ = [this, lev](int retry) { resetFluxRegistersForAttempt(lev, retry); };
 		me.storeFluxRk2_ = true;
 	}
 
@@ -246,6 +247,22 @@ template <typename problem_t> class AmrDriver
 		} else {
 			qkhost::check(qk_InterpFromCoarse(plan, nullptr, fs, po, pn, (t1 - time) / (t1 - t0), (time - t0) / (t1 - t0), nc, amrInterpMethod_, 1),
 				      "qk_InterpFromCoarse");
+		}
+	}
+
+	// advanceHydroAtLevelWithRetries: the register this level is the fine side of is saved before the first attempt and copied back at every
+	// retry; the one it is the coarse side of is reset (reference src/QuokkaSimulation.hpp:894-900, :919-929) — the substeps of a failed
+	// attempt that succeeded have already been added
+	void resetFluxRegistersForAttempt(int lev, int retry)
+	{
+		if (do_reflux == 0) {
+			return;
+		}
+		if (lev > 0 && finer_[lev - 1] && finer_[lev - 1]->fluxreg != nullptr) {
+			qkhost::check(retry == 0 ? qk_fluxreg_save(finer_[lev - 1]->fluxreg, nullptr) : qk_fluxreg_restore(finer_[lev - 1]->fluxreg, nullptr), "qk_fluxreg_save/restore");
+		}
+		if (retry > 0 && lev < finestLevel() && finer_[lev] && finer_[lev]->fluxreg != nullptr) {
+			qkhost::check(qk_fluxreg_reset(finer_[lev]->fluxreg, nullptr), "qk_fluxreg_reset");
 		}
 	}
 
@@ -293,6 +310,7 @@ template <typename problem_t> class AmrDriver
 		linkToParent(*raw, lev);
 		if (lev == 1) {
 			base_.afterAdvance_ = [this](double dt) { incrementFluxRegisters(0, dt); };
+			base_.beforeAttempt_ = [this](int retry) { resetFluxRegistersForAttempt(0, retry); };
 		}
 	}
 

@@ -915,6 +915,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	double fillTime_ = 0.0;		       // the time a ghost fill refers to (coarse data are interpolated to it)
 	bool storeFluxRk2_ = false;	       // keep flux_rk2 = 0.5 F1 + 0.5 F2 (rk2flux_) for the flux registers
 	std::function<void(double)> afterAdvance_; // incrementFluxRegisters(dt) after every successful advanceHydroAtLevel
+	std::function<void(int)> beforeAttempt_;   // flux registers: save before the retry loop (0), back to that state at every retry (>0)
 	// what the flux registers accumulate after a level advance (reference src/QuokkaSimulation.hpp:1303-1306)
 	[[nodiscard]] auto halfFlux() -> std::array<amrex::MultiFab, AMREX_SPACEDIM> & { return (integratorOrder_ == 2) ? rk2flux_ : halfFlux_; }
 	// ErrorEst(lev, tags, time, ngrow): problem hook (reference src/QuokkaSimulation.hpp:213).  Device lambdas cannot be compiled
@@ -1148,6 +1149,9 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 			if (retry_count > 0) {
 				++retries_;
 			}
+			if (beforeAttempt_) {
+				beforeAttempt_(retry_count); // reference src/QuokkaSimulation.hpp:894-900 (save), :919-929 (reset / restore)
+			}
 			amrex::MultiFab::Copy(state_old_tmp_, state_old_cc_[0]);
 			for (int substep = 0; substep < nsubsteps; ++substep) {
 				if (substep > 0) {
@@ -1256,7 +1260,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	{
 		int nsubSteps = 1;
 		double dt_radiation = dt_lev_hydro;
-		if (!(this->constantDt_ > 0.0)) {
+		if (Physics_Traits<problem_t>::is_hydro_enabled && !(this->constantDt_ > 0.0)) { // reference src/QuokkaSimulation.hpp:1583
 			nsubSteps = computeNumberOfRadiationSubsteps(dt_lev_hydro);
 			dt_radiation = dt_lev_hydro / static_cast<double>(nsubSteps);
 		}

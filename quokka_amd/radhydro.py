@@ -130,7 +130,7 @@ class RadhydroSimulation(HydroSimulation):
             self.state_old_cc_.valid(b)[RAD0:RAD0 + 4].copy_(self.state_new_cc_.valid(b)[RAD0:RAD0 + 4])
 
     def subcycleRadiationAtLevel(self, time: float, dt_lev_hydro: float) -> bool:
-        if not (self.constantDt_ > 0.0):
+        if self.is_hydro_enabled and not (self.constantDt_ > 0.0):  # reference src/QuokkaSimulation.hpp:1583: radiation-only problems take ONE step
             nsub = self.computeNumberOfRadiationSubsteps(dt_lev_hydro)
             dt_rad = dt_lev_hydro / float(nsub)
         else:

@@ -476,6 +476,9 @@ class HydroSimulation:
         if stage == 2 and getattr(self, "store_flux_rk2", False):
             for d in range(nd):  # what the flux registers accumulate (possibly FOFC-corrected), where the fused stage leaves it
                 self.fluxRk2()[d].copy_from(fl[d])
+        elif stage == 1 and self.integratorOrder_ == 1 and getattr(self, "store_flux_rk2", False):
+            for d in range(nd):  # forward Euler: the (FOFC-corrected) stage-1 fluxes are the step's fluxes (QuokkaSimulation.hpp:1291-1297)
+                self.halfFlux[d].copy_from(fl[d])
         return True
 
     def fluxRk2(self):
