@@ -297,3 +297,52 @@ def test_flux_register_matches_numpy_restatement(ctx, periodic):
         got_u = U.fab_numpy(b)
         assert np.array_equal(got_u, want[b]), f"coarse box {b}: max diff {np.abs(got_u - want[b]).max()}"
     assert sum(int((w != 0).sum()) for w in want) > 0
+
+
+def test_flux_register_save_restore_for_retries(ctx):
+    """advanceHydroAtLevelWithRetries (reference src/QuokkaSimulation.hpp:894-929): a failed attempt of the FINE level whose first substep
+    succeeded has already been added to the register; restore() must bring back exactly the state save() saw (coarse contribution + the
+    fine substeps of earlier, successful advances), so that Reflux counts every flux once."""
+    from quokka_amd.amr import FluxRegister
+    from quokka_amd.simulation import Geometry
+    nc = 6
+    crse_boxes = [([0, 0, 0], [15, 15, 15])]
+    fine_boxes = [([8, 8, 8], [23, 23, 23])]
+    crse, fine = Level(ctx, 3, crse_boxes), Level(ctx, 3, fine_boxes)
+    cgeom = Geometry(3, [16, 16, 16], [0.0] * 3, [1.0, 1.0, 1.0], [0, 0, 0])
+    dxc, dxf = cgeom.dx, [x / 2 for x in cgeom.dx]
+    rng_ = np.random.default_rng(3)
+
+    def rand_faces(lev):
+        mfs = [MultiFab(lev, nc, 0, facedir=d) for d in range(3)]
+        for d in range(3):
+            for b in range(lev.nboxes):
+                mfs[d].set_fab(b, rng_.standard_normal(mfs[d].shapes[b]))
+        return mfs
+
+    Fc, Ff1, Ff2, Fbad = rand_faces(crse), rand_faces(fine), rand_faces(fine), rand_faces(fine)
+
+    def reflux_of(sequence):
+        fr = FluxRegister(crse, fine, cgeom, nc)
+        fr.reset()
+        sequence(fr)
+        U = MultiFab(crse, nc, 4, fill=0.0)
+        fr.Reflux(U)
+        return U.fab_numpy(0)
+
+    def clean(fr):  # coarse step, first fine step, second fine step: no retry anywhere
+        fr.CrseAdd(Fc, dxc, 0.4)
+        fr.FineAdd(Ff1, dxf, 0.2)
+        fr.FineAdd(Ff2, dxf, 0.2)
+
+    def with_retry(fr):  # the second fine step fails after its first half-substep was added, is retried and succeeds
+        fr.CrseAdd(Fc, dxc, 0.4)
+        fr.FineAdd(Ff1, dxf, 0.2)
+        fr.save()
+        fr.FineAdd(Fbad, dxf, 0.1)  # substep 1 of the failed attempt (substep 2 failed: nothing added)
+        fr.restore()
+        fr.FineAdd(Ff2, dxf, 0.2)
+
+    want, got = reflux_of(clean), reflux_of(with_retry)
+    assert np.abs(want).max() > 0.0
+    assert np.array_equal(want, got)
