@@ -421,6 +421,13 @@ int qk_copy_box(qk_ctx *ctx, qk_stream s, const qk_array4 *src, const qk_array4 
 int qk_amr_tile_flags(qk_level *lev, qk_stream s, const qk_carray4 *tags, const qk_box *domain, int n_error_buf, int tile, int *tile_flags_host);
 int qk_amr_cluster_tiles(const int *tiles, const int ntiles[3], int ndim, int blocking_factor, int max_grid_size, int parent_align, qk_box *boxes,
 			 int max_boxes);
+/* host: the same flagged tiles -> fine boxes by Berger-Rigoutsos point clustering with efficiency grid_eff (amr.grid_eff), then
+ * BoxList::simplify and BoxList::maxSize(max_grid_size) — the steps of amrex::AmrMesh::MakeNewGrids after the tags have been buffered and
+ * coarsened by blocking_factor / ref_ratio (reference tests/blast_amr_maxlev2.in:16-21; AMReX not vendored: restated, parity unpinned).
+ * `allowed` (NULL: everywhere): tiles where refinement may go (the proper-nesting domain); a cluster box holding a forbidden tile is bisected
+ * until every piece is allowed (ClusterList::intersect).  Returns the number of boxes (fine index space, edges multiples of blocking_factor) or a negative error code. */
+int qk_amr_cluster_berger_rigoutsos(const int *tiles, const int *allowed, const int ntiles[3], int ndim, int blocking_factor, int max_grid_size, double grid_eff,
+				    qk_box *boxes, int max_boxes);
 
 #ifdef __cplusplus
 }

@@ -61,18 +61,27 @@ def boxes_from_tags(tags: np.ndarray, ndim: int, n_error_buf: int, blocking_fact
     return boxes_from_tiles(t, ndim, blocking_factor, max_grid_size, ratio)
 
 
-def boxes_from_tiles(t: np.ndarray, ndim: int, blocking_factor: int, max_grid_size: int, ratio: int = 2, parent_align: int = 0) -> List[Box]:
-    """t[k, j, i]: tiles (blocking_factor fine cells on a side) to refine -> fine boxes, merged greedily (x, then y, then z) up to
-    max_grid_size by the library's host function qk_amr_cluster_tiles (shared with the C++ host)"""
+def boxes_from_tiles(t: np.ndarray, ndim: int, blocking_factor: int, max_grid_size: int, ratio: int = 2, parent_align: int = 0,
+                     grid_eff: Optional[float] = None, allowed: Optional[np.ndarray] = None) -> List[Box]:
+    """t[k, j, i]: tiles (blocking_factor fine cells on a side) to refine -> fine boxes by the library's host functions (shared with the
+    C++ host): grid_eff given -> Berger-Rigoutsos clustering + simplify + maxSize (qk_amr_cluster_berger_rigoutsos, the steps of
+    amrex::AmrMesh::MakeNewGrids); None -> the round-1 rule, tiles merged greedily (x, then y, then z) up to max_grid_size"""
     import ctypes as C
     assert ratio == 2
     flags = np.ascontiguousarray(t, dtype=np.int32)
     tz, ty, tx = flags.shape
     cap = int(flags.sum()) + 1
     out = (capi.Box * cap)()
-    n = capi.lib().qk_amr_cluster_tiles(flags.ctypes.data_as(C.c_void_p), (C.c_int * 3)(tx, ty, tz), ndim, blocking_factor, max_grid_size, parent_align, out, cap)
+    if grid_eff is not None:
+        cap = int(flags.size) + 1
+        out = (capi.Box * cap)()
+        ok = None if allowed is None else np.ascontiguousarray(allowed, dtype=np.int32)
+        n = capi.lib().qk_amr_cluster_berger_rigoutsos(flags.ctypes.data_as(C.c_void_p), None if ok is None else ok.ctypes.data_as(C.c_void_p),
+                                                       (C.c_int * 3)(tx, ty, tz), ndim, blocking_factor, max_grid_size, float(grid_eff), out, cap)
+    else:
+        n = capi.lib().qk_amr_cluster_tiles(flags.ctypes.data_as(C.c_void_p), (C.c_int * 3)(tx, ty, tz), ndim, blocking_factor, max_grid_size, parent_align, out, cap)
     if n < 0:
-        raise capi.QkError(f"qk_amr_cluster_tiles failed ({n})")
+        raise capi.QkError(f"tile clustering failed ({n})")
     return [([out[b].lo[d] for d in range(3)], [out[b].hi[d] for d in range(3)]) for b in range(n)]
 
 
@@ -223,6 +232,9 @@ class AmrSimulation:
         self.level0_distribution = "interleaved"
         self.max_level, self.max_grid_size, self.blocking_factor = max_level, max_grid_size, blocking_factor
         self.n_error_buf, self.regrid_int = n_error_buf, regrid_int
+        # amr.grid_eff (reference tests/blast_amr_maxlev2.in: 0.7): Berger-Rigoutsos clustering as amrex::AmrMesh::MakeNewGrids does it.
+        # clustering = "tiles": the round-1 rule (every flagged tile refined, greedy merge) — more refined cells, no efficiency parameter
+        self.grid_eff, self.clustering = 0.7, "berger_rigoutsos"
         self.do_reflux, self.do_subcycle = True, True
         self.amrInterpMethod_ = 1
         self.cflNumber_, self.densityFloor_, self.tempFloor_ = 0.3, 0.0, 0.0
@@ -304,6 +316,7 @@ class AmrSimulation:
                 a = [max((lo[d] // 4 - 2) // tile, 0) for d in range(3)]
                 b = [min((hi[d] // 4 + 2) // tile, (tx, ty, tz)[d] - 1) for d in range(3)]
                 t[a[2]:b[2] + 1, a[1]:b[1] + 1, a[0]:b[0] + 1] = True
+        allowed = np.ones_like(t)
         if base > 0:  # proper nesting: a tile and its 26 neighbours (>= 4 cells: ghost reach 2 + stencil 1) lie on cells of `base` (refined) or beyond the domain
             r = 2 ** (lev - base)
             cov = np.ones((tz + 2, ty + 2, tx + 2), dtype=bool)
@@ -311,9 +324,11 @@ class AmrSimulation:
             for lo, hi in self.levels[base].all_boxes:
                 cov[lo[2] * r // tile + 1:(hi[2] * r + r - 1) // tile + 2, lo[1] * r // tile + 1:(hi[1] * r + r - 1) // tile + 2,
                     lo[0] * r // tile + 1:(hi[0] * r + r - 1) // tile + 2] = True
-            t &= ~dilate(~cov, 1, 3)[1:-1, 1:-1, 1:-1]
+            allowed = ~dilate(~cov, 1, 3)[1:-1, 1:-1, 1:-1]
+            t &= allowed
+        eff = self.grid_eff if self.clustering == "berger_rigoutsos" else None
         if not self.cluster_within_parent:
-            return boxes_from_tiles(t, 3, self.blocking_factor, self.max_grid_size, 2)
+            return boxes_from_tiles(t, 3, self.blocking_factor, self.max_grid_size, 2, grid_eff=eff, allowed=allowed)
         boxes: List[Box] = []
         s = 2 ** lev  # level-0 boxes in level-lev index space: every level is clustered inside its level-0 ancestors (one rank each)
         for lo0, hi0 in self.levels[0].all_boxes:  # the level-0 boxes of ALL ranks, in the same order everywhere
@@ -321,7 +336,8 @@ class AmrSimulation:
             a = [lo[d] // tile for d in range(3)]
             b = [hi[d] // tile for d in range(3)]
             sub = t[a[2]:b[2] + 1, a[1]:b[1] + 1, a[0]:b[0] + 1]
-            for blo, bhi in boxes_from_tiles(sub, 3, self.blocking_factor, self.max_grid_size, 2):
+            for blo, bhi in boxes_from_tiles(sub, 3, self.blocking_factor, self.max_grid_size, 2, grid_eff=eff,
+                                             allowed=allowed[a[2]:b[2] + 1, a[1]:b[1] + 1, a[0]:b[0] + 1]):
                 boxes.append(([blo[d] + 2 * lo[d] for d in range(3)], [bhi[d] + 2 * lo[d] for d in range(3)]))
         return boxes
 

@@ -483,3 +483,284 @@ int qk_amr_cluster_tiles(const int *tiles, const int ntiles[3], int ndim, int bl
 }
 
 } // extern "C"
+
+// ---------------------------------------------------------------------------------------------- Berger-Rigoutsos clustering (host)
+// amrex::AmrMesh::MakeNewGrids clusters the tagged cells, coarsened by blocking_factor / ref_ratio, with the point-clustering algorithm of
+// Berger & Rigoutsos (1991) — amrex::ClusterList::chop(grid_eff) — refines the boxes back, merges what can be merged and cuts them to
+// max_grid_size (reference tests/blast_amr_maxlev2.in:16-21 sets grid_eff = 0.7, blocking_factor = 32, n_error_buf = 3).  AMReX is an empty
+// submodule under /root/reference; this restates the published algorithm with AMReX's documented choices (parity unpinned):
+//   * a cluster = a set of tagged tiles with its bounding box; efficiency = tiles / volume of the box; clusters below grid_eff are cut in two;
+//   * cut per direction from the signature (tagged tiles per plane): a hole (empty plane, the one nearest the middle) beats an inflection
+//     (largest jump of the second difference across a sign change, at least 2 planes from either end, magnitude > 2) beats a bisection;
+//     among the directions with the best kind of cut, the one whose cut leaves the longer shorter side (ties: the later direction);
+//   * the boxes of all clusters are merged pairwise where two abut with equal cross-sections (BoxList::simplify) and cut into
+//     ceil(len / max) nearly equal pieces per direction (BoxList::maxSize), everything in units of tiles, so every box edge is a multiple
+//     of blocking_factor.
+namespace
+{
+struct TPoint {
+	int c[3];
+};
+struct TCluster {
+	std::vector<TPoint> pts;
+	int lo[3], hi[3];
+	void minBox()
+	{
+		for (int d = 0; d < 3; ++d) {
+			lo[d] = pts[0].c[d];
+			hi[d] = pts[0].c[d];
+		}
+		for (auto const &p : pts) {
+			for (int d = 0; d < 3; ++d) {
+				lo[d] = std::min(lo[d], p.c[d]);
+				hi[d] = std::max(hi[d], p.c[d]);
+			}
+		}
+	}
+	[[nodiscard]] auto eff() const -> double
+	{
+		double vol = 1.0;
+		for (int d = 0; d < 3; ++d) {
+			vol *= static_cast<double>(hi[d] - lo[d] + 1);
+		}
+		return static_cast<double>(pts.size()) / vol;
+	}
+};
+enum CutStatus { HoleCut = 0, SteepCut, BisectCut, InvalidCut };
+
+auto findCut(std::vector<int> const &hist, int lo, int hi, CutStatus &status) -> int
+{
+	const int MINOFF = 2, CUT_THRESH = 2;
+	const int len = hi - lo + 1;
+	status = InvalidCut;
+	if (len <= 1) {
+		return lo;
+	}
+	const int mid = len / 2;
+	int cutpoint = -1;
+	for (int i = 0; i < len; ++i) { // the empty plane nearest the middle
+		if (hist[i] == 0) {
+			status = HoleCut;
+			if (std::abs(cutpoint - mid) > std::abs(i - mid)) {
+				cutpoint = i;
+				if (i > mid) {
+					break;
+				}
+			}
+		}
+	}
+	if (status == HoleCut) {
+		return lo + cutpoint;
+	}
+	std::vector<int> dhist(len, 0);
+	for (int i = 1; i < len - 1; ++i) {
+		dhist[i] = hist[i + 1] - 2 * hist[i] + hist[i - 1];
+	}
+	int locmax = -1;
+	for (int i = MINOFF; i < len - MINOFF; ++i) {
+		const int iprev = dhist[i - 1], icur = dhist[i], locdif = std::abs(iprev - icur);
+		if (iprev * icur < 0 && locdif >= locmax) {
+			if (locdif > locmax) {
+				status = SteepCut;
+				cutpoint = i;
+				locmax = locdif;
+			} else if (std::abs(i - mid) < std::abs(cutpoint - mid)) {
+				cutpoint = i;
+			}
+		}
+	}
+	if (locmax <= CUT_THRESH) {
+		cutpoint = mid;
+		status = BisectCut;
+	}
+	return lo + cutpoint;
+}
+
+// cut `cl` in two; the upper part is returned, the lower part stays (both with their minimal boxes)
+auto chopCluster(TCluster &cl, int ndim) -> TCluster
+{
+	std::vector<int> hist[3];
+	for (int d = 0; d < 3; ++d) {
+		hist[d].assign(cl.hi[d] - cl.lo[d] + 1, 0);
+	}
+	for (auto const &p : cl.pts) {
+		for (int d = 0; d < 3; ++d) {
+			++hist[d][p.c[d] - cl.lo[d]];
+		}
+	}
+	CutStatus status[3] = {InvalidCut, InvalidCut, InvalidCut}, mincut = InvalidCut;
+	int cut[3] = {0, 0, 0};
+	for (int d = 0; d < ndim; ++d) {
+		cut[d] = findCut(hist[d], cl.lo[d], cl.hi[d], status[d]);
+		if (status[d] < mincut) {
+			mincut = status[d];
+		}
+	}
+	int dir = -1, minlen = -1;
+	for (int d = 0; d < ndim; ++d) {
+		if (status[d] == mincut) {
+			const int mincutlen = std::min(cut[d] - cl.lo[d], cl.hi[d] - cut[d]);
+			if (mincutlen >= minlen) {
+				dir = d;
+				minlen = mincutlen;
+			}
+		}
+	}
+	TCluster up;
+	if (dir < 0 || mincut == InvalidCut) {
+		return up; // a single tile: cannot be cut (its efficiency is 1 anyway)
+	}
+	std::vector<TPoint> low;
+	for (auto const &p : cl.pts) {
+		(p.c[dir] < cut[dir] ? low : up.pts).push_back(p);
+	}
+	if (low.empty() || up.pts.empty()) { // (a hole cut at the first plane cannot happen for a minimal box; guard against an endless loop)
+		up.pts.clear();
+		return up;
+	}
+	cl.pts.swap(low);
+	cl.minBox();
+	up.minBox();
+	return up;
+}
+} // namespace
+
+extern "C" int qk_amr_cluster_berger_rigoutsos(const int *tiles, const int *allowed, const int ntiles[3], int ndim, int blocking_factor, int max_grid_size, double grid_eff,
+					       qk_box *boxes, int max_boxes)
+{
+	if (tiles == nullptr || ntiles == nullptr || boxes == nullptr || blocking_factor < 1 || max_grid_size < blocking_factor || !(grid_eff > 0.0 && grid_eff <= 1.0)) {
+		return QK_ERR_INVALID;
+	}
+	const int tx = ntiles[0], ty = ntiles[1], tz = ntiles[2];
+	TCluster all;
+	for (int k = 0; k < tz; ++k) {
+		for (int j = 0; j < ty; ++j) {
+			for (int i = 0; i < tx; ++i) {
+				if (tiles[static_cast<size_t>(i) + static_cast<size_t>(tx) * (j + static_cast<size_t>(ty) * k)] != 0) {
+					all.pts.push_back(TPoint{{i, j, k}});
+				}
+			}
+		}
+	}
+	if (all.pts.empty()) {
+		return 0;
+	}
+	all.minBox();
+	// ClusterList::chop(eff): a cluster below the efficiency is cut; the part cut off goes to the end of the list, the rest is looked at again
+	std::vector<TCluster> list;
+	list.push_back(std::move(all));
+	for (size_t n = 0; n < list.size();) {
+		if (list[n].eff() < grid_eff) {
+			TCluster up = chopCluster(list[n], ndim);
+			if (up.pts.empty()) {
+				++n;
+			} else {
+				list.push_back(std::move(up));
+			}
+		} else {
+			++n;
+		}
+	}
+	struct TB {
+		int lo[3], hi[3];
+	};
+	std::vector<TB> bl;
+	for (auto const &c : list) {
+		TB b{};
+		for (int d = 0; d < 3; ++d) {
+			b.lo[d] = c.lo[d];
+			b.hi[d] = c.hi[d];
+		}
+		bl.push_back(b);
+	}
+	// ClusterList::intersect(proper-nesting domain): a cluster box may hold unflagged tiles, and such a tile may lie where refinement is not
+	// allowed.  A box with a forbidden tile is bisected along its longest edge until every piece is allowed; pieces without a flagged tile
+	// are dropped (a flagged tile is always allowed, so this ends at single tiles at the latest).
+	if (allowed != nullptr) {
+		auto at = [&](int i, int j, int k) { return static_cast<size_t>(i) + static_cast<size_t>(tx) * (j + static_cast<size_t>(ty) * k); };
+		std::vector<TB> keep, stack(bl.rbegin(), bl.rend());
+		while (!stack.empty()) {
+			const TB b = stack.back();
+			stack.pop_back();
+			bool anyFlag = false, allOk = true;
+			for (int k = b.lo[2]; k <= b.hi[2]; ++k) {
+				for (int j = b.lo[1]; j <= b.hi[1]; ++j) {
+					for (int i = b.lo[0]; i <= b.hi[0]; ++i) {
+						anyFlag = anyFlag || tiles[at(i, j, k)] != 0;
+						allOk = allOk && allowed[at(i, j, k)] != 0;
+					}
+				}
+			}
+			if (!anyFlag) {
+				continue;
+			}
+			if (allOk) {
+				keep.push_back(b);
+				continue;
+			}
+			int d = 0;
+			for (int e = 1; e < 3; ++e) {
+				if (b.hi[e] - b.lo[e] > b.hi[d] - b.lo[d]) {
+					d = e;
+				}
+			}
+			const int mid = (b.lo[d] + b.hi[d] + 1) / 2; // first tile of the upper half
+			TB lower = b, upper = b;
+			lower.hi[d] = mid - 1;
+			upper.lo[d] = mid;
+			stack.push_back(upper);
+			stack.push_back(lower);
+		}
+		bl.swap(keep);
+	}
+	// BoxList::simplify: merge two boxes that abut along one direction with identical extents in the others, until nothing merges
+	for (bool merged = true; merged;) {
+		merged = false;
+		for (size_t a = 0; a < bl.size() && !merged; ++a) {
+			for (size_t b = a + 1; b < bl.size() && !merged; ++b) {
+				for (int d = 0; d < ndim && !merged; ++d) {
+					bool same = true;
+					for (int e = 0; e < 3; ++e) {
+						same = same && (e == d || (bl[a].lo[e] == bl[b].lo[e] && bl[a].hi[e] == bl[b].hi[e]));
+					}
+					if (same && (bl[a].hi[d] + 1 == bl[b].lo[d] || bl[b].hi[d] + 1 == bl[a].lo[d])) {
+						bl[a].lo[d] = std::min(bl[a].lo[d], bl[b].lo[d]);
+						bl[a].hi[d] = std::max(bl[a].hi[d], bl[b].hi[d]);
+						bl.erase(bl.begin() + static_cast<long>(b));
+						merged = true;
+					}
+				}
+			}
+		}
+	}
+	// BoxList::maxSize: ceil(len / max) pieces per direction, the first (len mod pieces) one tile longer
+	const int maxt = std::max(max_grid_size / blocking_factor, 1);
+	int nb = 0;
+	for (auto const &b : bl) {
+		int npc[3], bs[3], ex[3];
+		for (int d = 0; d < 3; ++d) {
+			const int len = b.hi[d] - b.lo[d] + 1;
+			npc[d] = (d < ndim) ? (len + maxt - 1) / maxt : 1;
+			bs[d] = len / npc[d];
+			ex[d] = len - bs[d] * npc[d];
+		}
+		for (int kk = 0; kk < npc[2]; ++kk) {
+			for (int jj = 0; jj < npc[1]; ++jj) {
+				for (int ii = 0; ii < npc[0]; ++ii) {
+					if (nb >= max_boxes) {
+						return QK_ERR_INVALID;
+					}
+					const int idx[3] = {ii, jj, kk};
+					for (int d = 0; d < 3; ++d) {
+						const int first = b.lo[d] + idx[d] * bs[d] + std::min(idx[d], ex[d]);
+						const int n = bs[d] + (idx[d] < ex[d] ? 1 : 0);
+						boxes[nb].lo[d] = (d < ndim) ? first * blocking_factor : 0;
+						boxes[nb].hi[d] = (d < ndim) ? (first + n) * blocking_factor - 1 : 0;
+					}
+					++nb;
+				}
+			}
+		}
+	}
+	return nb;
+}

@@ -32,6 +32,7 @@ template <typename problem_t> class AmrDriver
 		}
 		amrex::ParmParse pp;
 		pp.query("do_reflux", do_reflux);
+		pp.query("grid_eff", grid_eff);
 		istep.assign(max_level + 1, 0);
 		last_regrid_step.assign(max_level + 1, 0);
 		dt_.assign(max_level + 1, 1.e100);
@@ -40,6 +41,7 @@ template <typename problem_t> class AmrDriver
 	}
 
 	int max_level = 0, blocking_factor = 8, n_error_buf = 1, regrid_int = 2, max_grid_size = 128, do_reflux = 1;
+	double grid_eff = 0.7; // AMReX's default
 	int amrInterpMethod_ = 1;
 	std::vector<int> istep, last_regrid_step;
 	std::vector<double> dt_;
@@ -363,6 +365,7 @@ template <typename problem_t> class AmrDriver
 				}
 			}
 		}
+		std::vector<int> allowed(flags.size(), 1); // the proper-nesting domain, in tiles
 		if (base > 0) { // a tile and its 26 neighbours lie on cells of level `base` (refined to this level) or beyond the domain
 			int const r = 1 << (lev - base);
 			std::vector<char> cov(static_cast<size_t>(nt[0] + 2) * (nt[1] + 2) * (nt[2] + 2), 1);
@@ -398,13 +401,17 @@ template <typename problem_t> class AmrDriver
 						}
 						if (!ok) {
 							at(i, j, k) = 0;
+							allowed[static_cast<size_t>(i) + static_cast<size_t>(nt[0]) * (j + static_cast<size_t>(nt[1]) * k)] = 0;
 						}
 					}
 				}
 			}
 		}
 		std::vector<qk_box> out(flags.size() + 1);
-		int const n = qk_amr_cluster_tiles(flags.data(), nt, AMREX_SPACEDIM, blocking_factor, max_grid_size, 0, out.data(), static_cast<int>(out.size()));
+		// amr.grid_eff > 0: Berger-Rigoutsos clustering as amrex::AmrMesh::MakeNewGrids (default, the deck's 0.7); <= 0: the round-1 tile rule
+		int const n = (grid_eff > 0.0) ? qk_amr_cluster_berger_rigoutsos(flags.data(), allowed.data(), nt, AMREX_SPACEDIM, blocking_factor, max_grid_size, grid_eff, out.data(),
+										   static_cast<int>(out.size()))
+					       : qk_amr_cluster_tiles(flags.data(), nt, AMREX_SPACEDIM, blocking_factor, max_grid_size, 0, out.data(), static_cast<int>(out.size()));
 		AMREX_ALWAYS_ASSERT(n >= 0);
 		std::vector<amrex::Box> boxes(n);
 		for (int b = 0; b < n; ++b) {

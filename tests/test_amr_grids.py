@@ -63,3 +63,77 @@ def test_interleaved_level0_map_spreads_every_neighbourhood():
                 for i in range(3):
                     block = {at[(i + a, j + b, k + c)] for a in (0, 1) for b in (0, 1) for c in (0, 1)}
                     assert len(block) == min(8, nranks)
+
+
+# ------------------------------------------------------------------------------------------------ Berger-Rigoutsos clustering
+def _check_boxes(t, boxes, bf, mgs):
+    """boxes are disjoint, blocking-factor aligned, <= max_grid_size, and cover every flagged tile; returns the efficiency"""
+    tz, ty, tx = t.shape
+    cover = np.zeros_like(t, dtype=np.int32)
+    for lo, hi in boxes:
+        assert all(lo[d] % bf == 0 and (hi[d] + 1) % bf == 0 and hi[d] - lo[d] + 1 <= mgs for d in range(3)), (lo, hi)
+        cover[lo[2] // bf:hi[2] // bf + 1, lo[1] // bf:hi[1] // bf + 1, lo[0] // bf:hi[0] // bf + 1] += 1
+    assert cover.max() <= 1, "boxes overlap"
+    assert not (t & (cover == 0)).any(), "a flagged tile is not covered"
+    return t.sum() / max(cover.sum(), 1)
+
+
+def test_berger_rigoutsos_hole_cut_separates_two_blobs():
+    """two blobs separated by empty planes: one hole cut, two boxes, efficiency 1"""
+    t = np.zeros((8, 8, 8), dtype=bool)
+    t[0:2, 0:2, 0:3] = True
+    t[5:8, 4:8, 6:8] = True
+    boxes = boxes_from_tiles(t, 3, 8, 64, grid_eff=0.7)
+    assert sorted(boxes) == [([0, 0, 0], [23, 15, 15]), ([48, 32, 40], [63, 63, 63])]
+    assert _check_boxes(t, boxes, 8, 64) == 1.0
+
+
+def test_berger_rigoutsos_l_shape_meets_the_efficiency():
+    """an L of tiles: the bounding box has efficiency 7/16 < 0.7; the inflection / bisection cuts must bring every box above grid_eff"""
+    t = np.zeros((1, 4, 4), dtype=bool)
+    t[0, 0, :] = True
+    t[0, :, 0] = True
+    boxes = boxes_from_tiles(t, 3, 8, 64, grid_eff=0.7)
+    eff = _check_boxes(t, boxes, 8, 64)
+    assert eff >= 0.7, (eff, boxes)
+    # a full block stays one box, cut only by max_grid_size (ceil(len / max) nearly equal pieces)
+    full = np.ones((2, 2, 5), dtype=bool)
+    boxes = boxes_from_tiles(full, 3, 8, 16, grid_eff=0.7)
+    assert len(boxes) == 3 and sorted(hi[0] - lo[0] + 1 for lo, hi in boxes) == [8, 16, 16]
+    assert _check_boxes(full, boxes, 8, 16) == 1.0
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_berger_rigoutsos_random_shells(seed):
+    """a thick spherical shell of flagged tiles (what a blast wave tags): every box meets grid_eff (single tiles are exempt by
+    construction), nothing flagged is lost, and the rule refines fewer tiles than the bounding box and no more than ~1/grid_eff of them"""
+    rng = np.random.default_rng(seed)
+    n = 16
+    k, j, i = np.meshgrid(*(np.arange(n),) * 3, indexing="ij")
+    r = np.sqrt((i + 0.5) ** 2 + (j + 0.5) ** 2 + (k + 0.5) ** 2)
+    R = 6.0 + 6.0 * rng.random()
+    t = (np.abs(r - R) < 1.2)
+    boxes = boxes_from_tiles(t, 3, 32, 128, grid_eff=0.7)
+    eff = _check_boxes(t, boxes, 32, 128)
+    assert eff >= 0.7 * 0.95, eff  # (max_grid_size cuts do not change the covered set; simplify never lowers the efficiency)
+    greedy = boxes_from_tiles(t, 3, 32, 128)
+    assert _check_boxes(t, greedy, 32, 128) == 1.0  # the round-1 rule refines exactly the flagged tiles, in many more boxes
+    assert len(boxes) <= len(greedy)
+
+
+def test_berger_rigoutsos_respects_the_nesting_domain():
+    """a cluster box may hold unflagged tiles; where such a tile lies outside the allowed (proper-nesting) region the box is bisected until
+    every piece is allowed, and nothing flagged is lost"""
+    t = np.zeros((1, 4, 4), dtype=bool)
+    t[0, 0:3, 0:4] = True
+    t[0, 1, 1] = False  # 11 of 12: efficiency 0.92, one box with a hole ...
+    allowed = np.ones_like(t)
+    allowed[0, 1, 1] = False  # ... which is forbidden
+    free = boxes_from_tiles(t, 3, 8, 64, grid_eff=0.7)
+    assert free == [([0, 0, 0], [31, 23, 7])]
+    boxes = boxes_from_tiles(t, 3, 8, 64, grid_eff=0.7, allowed=allowed)
+    assert _check_boxes(t, boxes, 8, 64) == 1.0
+    cover = np.zeros_like(t)
+    for lo, hi in boxes:
+        cover[lo[2] // 8:hi[2] // 8 + 1, lo[1] // 8:hi[1] // 8 + 1, lo[0] // 8:hi[0] // 8 + 1] = True
+    assert not cover[0, 1, 1]
