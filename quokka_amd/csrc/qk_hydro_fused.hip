@@ -45,8 +45,10 @@ struct SGeom {
 };
 
 // scratch arrays (in units of "components over total_cells")
-enum { S_AUX = 0, S_RHS = 4, S_NCOMP = 11 };
-// S_AUX + 0: chi (combined), +1..3: D_x, D_y, D_z ;  S_RHS + 0..5: flux divergence, +6: div v
+enum { S_AUX = 0, S_RHS = 4 };
+// S_AUX + 0: chi (combined), +1..3: D_x, D_y, D_z ;  S_RHS + 0..nv-1: flux divergence (nv = 6 + passive scalars), + nv: div v
+constexpr auto scratchComps(int nscalars) -> int { return S_RHS + NVAR + nscalars + 1; }
+constexpr int QK_FUSED_MAX_SCALARS = 3; // the fused sweeps are instantiated for 0..3 passive scalars (PassiveScalar 1, HydroContact 2, ...)
 
 struct SweepArgs {
 	const qk_box *boxes;
@@ -346,8 +348,9 @@ QK_DEV auto epiEint(Eos const &eos, EpiConst const &ec, double rho, double T) ->
 }
 
 // U holds the old state of the cell on entry
-QK_DEV void updateCellFrom(SweepArgs const &a, Eos const &eos, EpiConst const &ec, int b, int i, int j, int k, double U[NVAR], const double rhs[NVAR], double div_v,
-			   double &sig0, double &sig1)
+template <int NS>
+QK_DEV void updateCellFrom(SweepArgs const &a, Eos const &eos, EpiConst const &ec, int b, int i, int j, int k, double U[NVAR + NS], const double rhs[NVAR + NS],
+			   double div_v, double &sig0, double &sig1)
 {
 	WA4 Un(a.U_out[b]);
 	IA4 flag(a.redoFlag[b]);
@@ -376,6 +379,10 @@ QK_DEV void updateCellFrom(SweepArgs const &a, Eos const &eos, EpiConst const &e
 	for (int n = 0; n < NVAR; ++n) {
 		U[n] = U[n] + a.dt * r[n];
 	}
+#pragma unroll
+	for (int n = NVAR; n < NVAR + NS; ++n) { // passive scalars: PredictStep loops over all hydro variables
+		U[n] = U[n] + a.dt * rhs[n];
+	}
 	const int bad = (U[RHO] > 0.) ? 0 : 1;
 	flag(i, j, k) = bad;
 	if (bad != 0) {
@@ -384,6 +391,10 @@ QK_DEV void updateCellFrom(SweepArgs const &a, Eos const &eos, EpiConst const &e
 	// EnforceLimits (hydro_system.hpp:702-771) : density floor, then the temperature floors on E and on the auxiliary internal energy
 	double rho_new = U[RHO];
 	if (bad == 0 && U[RHO] < a.densityFloor) {
+#pragma unroll
+		for (int n = NVAR; n < NVAR + NS; ++n) { // hydro_system.hpp:713-722 (as the reference-shaped operator, qk_hydro_EnforceLimits)
+			U[n] = (a.densityFloor == 0.0) ? 0.0 : U[n] * (U[RHO] / a.densityFloor);
+		}
 		rho_new = a.densityFloor;
 		U[RHO] = rho_new;
 	}
@@ -417,7 +428,7 @@ QK_DEV void updateCellFrom(SweepArgs const &a, Eos const &eos, EpiConst const &e
 	}
 	const int64_t cn = Un.idx(i, j, k);
 #pragma unroll
-	for (int n = 0; n < NVAR; ++n) {
+	for (int n = 0; n < NVAR + NS; ++n) {
 		Un.p[cn + Un.ns * n] = U[n];
 	}
 	if (a.max_signal != nullptr) {
@@ -440,10 +451,12 @@ QK_DEV void updateCellFrom(SweepArgs const &a, Eos const &eos, EpiConst const &e
 constexpr int XB = 256;	 // threads per workgroup
 constexpr int XOUT = 250; // cells updated per workgroup (3 halo cells on each side)
 
-template <int ORDER, int STAGE> __global__ void __launch_bounds__(XB) k_sweep_x(SweepArgs a, Eos eos)
+template <int ORDER, int STAGE, int NS> __global__ void __launch_bounds__(XB) k_sweep_x(SweepArgs a, Eos eos)
 {
-	__shared__ double s_q[NVAR][XB];  // primitives, later reused for the face fluxes
-	__shared__ double s_e[NVAR][XB];  // right-edge states a_plus
+	constexpr int NV = NVAR + NS; // hydro variables + passive scalars
+	constexpr int RHS_DIVV = S_RHS + NV;
+	__shared__ double s_q[NV][XB];  // primitives, later reused for the face fluxes
+	__shared__ double s_e[NV][XB];  // right-edge states a_plus
 	__shared__ double s_d[3][XB];	  // D_V, D_W, face velocity
 
 	const int b = blockIdx.z;
@@ -467,7 +480,7 @@ template <int ORDER, int STAGE> __global__ void __launch_bounds__(XB) k_sweep_x(
 
 	const double *S = a.scratch + g.off;
 	const int64_t T = a.total_cells;
-	double q0[NVAR];
+	double q0[NV];
 	{
 		RA4 U(a.U_in[b]);
 		const int64_t u = U.idx(i, j, k);
@@ -477,9 +490,13 @@ template <int ORDER, int STAGE> __global__ void __launch_bounds__(XB) k_sweep_x(
 			Uc[n] = U.p[u + U.ns * n];
 		}
 		consToPrim(eos, a.reconstruct_eint, Uc, q0);
+#pragma unroll
+		for (int n = NVAR; n < NV; ++n) { // hydro_system.hpp:340-343: passive scalars are reconstructed as they are stored
+			q0[n] = U.p[u + U.ns * n];
+		}
 	}
 #pragma unroll
-	for (int n = 0; n < NVAR; ++n) {
+	for (int n = 0; n < NV; ++n) {
 		s_q[n][t] = q0[n];
 	}
 	const double chi = S[(S_AUX + 0) * T + c];
@@ -490,10 +507,10 @@ template <int ORDER, int STAGE> __global__ void __launch_bounds__(XB) k_sweep_x(
 	__syncthreads();
 
 	// reconstruct my cell (needs t-2 .. t+2)
-	double am[NVAR], ap[NVAR];
+	double am[NV], ap[NV];
 	const int tm2 = max(t - 2, 0), tm1 = max(t - 1, 0), tp1 = min(t + 1, XB - 1), tp2 = min(t + 2, XB - 1);
 #pragma unroll
-	for (int n = 0; n < NVAR; ++n) {
+	for (int n = 0; n < NV; ++n) {
 		cellEdges<ORDER>(s_q[n][tm2], s_q[n][tm1], q0[n], s_q[n][tp1], s_q[n][tp2], am[n], ap[n]);
 		flattenEdges(chi, q0[n], am[n], ap[n]);
 		s_e[n][t] = ap[n];
@@ -501,15 +518,22 @@ template <int ORDER, int STAGE> __global__ void __launch_bounds__(XB) k_sweep_x(
 	__syncthreads();
 
 	// flux at my left face
-	double qL[NVAR];
+	double qL[NV];
 #pragma unroll
-	for (int n = 0; n < NVAR; ++n) {
+	for (int n = 0; n < NV; ++n) {
 		qL[n] = s_e[n][tm1];
 	}
 	const double du = q0[PVX] - s_q[PVX][tm1];
 	const double dvl = s_d[0][tm1], dwl = s_d[1][tm1];
-	double F[NVAR], vf;
-	faceFlux<0, QK_RIEMANN_HLLC>(eos, a.reconstruct_eint, 3, qL, am, du, dvl, dV, dwl, dW, a.K_visc, F, vf);
+	double F[NV], vf;
+	{
+		Wave wv;
+		faceFlux<0, QK_RIEMANN_HLLC>(eos, a.reconstruct_eint, 3, qL, am, du, dvl, dV, dwl, dW, a.K_visc, F, vf, NS > 0 ? &wv : nullptr);
+#pragma unroll
+		for (int n = NVAR; n < NV; ++n) { // hydro_system.hpp:1062-1076, HLLC.hpp:126-136
+			F[n] = scalarFlux<QK_RIEMANN_HLLC>(wv, qL[n], am[n]);
+		}
+	}
 
 	const bool validRow = inside;
 	const bool isFace = validRow && (i >= bx.lo[0]) && (i <= bx.hi[0] + 1) && (t >= 3) && (t <= XB - 3);
@@ -519,7 +543,7 @@ template <int ORDER, int STAGE> __global__ void __launch_bounds__(XB) k_sweep_x(
 			WA4 HV(a.halfVel[b]);
 			const int64_t o = HF.idx(i, j, k);
 #pragma unroll
-			for (int n = 0; n < NVAR; ++n) {
+			for (int n = 0; n < NV; ++n) {
 				HF.p[o + HF.ns * n] = F[n];
 			}
 			HV(i, j, k) = vf;
@@ -531,7 +555,7 @@ template <int ORDER, int STAGE> __global__ void __launch_bounds__(XB) k_sweep_x(
 			const int64_t o = HF.idx(i, j, k);
 			// flux_rk2 = (0 + 0.5 F1) + 0.5 F2   (QuokkaSimulation.hpp:1106, :1220)
 #pragma unroll
-			for (int n = 0; n < NVAR; ++n) {
+			for (int n = 0; n < NV; ++n) {
 				F[n] = 0.5 * HF.p[o + HF.ns * n] + 0.5 * F[n];
 			}
 			vf = 0.5 * HV(i, j, k) + 0.5 * vf;
@@ -539,7 +563,7 @@ template <int ORDER, int STAGE> __global__ void __launch_bounds__(XB) k_sweep_x(
 				WA4 RF(a.rk2Flux[b]);
 				const int64_t o2 = RF.idx(i, j, k);
 #pragma unroll
-				for (int n = 0; n < NVAR; ++n) {
+				for (int n = 0; n < NV; ++n) {
 					RF.p[o2 + RF.ns * n] = F[n];
 				}
 			}
@@ -547,7 +571,7 @@ template <int ORDER, int STAGE> __global__ void __launch_bounds__(XB) k_sweep_x(
 	}
 	__syncthreads(); // everyone is done with s_q (primitives)
 #pragma unroll
-	for (int n = 0; n < NVAR; ++n) {
+	for (int n = 0; n < NV; ++n) {
 		s_q[n][t] = F[n];
 	}
 	s_d[2][t] = vf;
@@ -557,18 +581,20 @@ template <int ORDER, int STAGE> __global__ void __launch_bounds__(XB) k_sweep_x(
 	if (isCell) {
 		double *R = a.scratch + g.off + c;
 #pragma unroll
-		for (int n = 0; n < NVAR; ++n) {
+		for (int n = 0; n < NV; ++n) {
 			// hydro_system.hpp:469
 			R[(S_RHS + n) * T] = a.inv_dx * (F[n] - s_q[n][tp1]);
 		}
 		// hydro_system.hpp:803
-		R[(S_RHS + 6) * T] = (s_d[2][tp1] - vf) / a.dx;
+		R[RHS_DIVV * T] = (s_d[2][tp1] - vf) / a.dx;
 	}
 }
 
 // ---------------------------------------------------------------------------------------------- Y / Z sweeps (marching)
-template <int DIR, int ORDER, int STAGE, bool LAST> __global__ void __launch_bounds__(256) k_sweep_march(SweepArgs a, Eos eos)
+template <int DIR, int ORDER, int STAGE, bool LAST, int NS> __global__ void __launch_bounds__(256) k_sweep_march(SweepArgs a, Eos eos)
 {
+	constexpr int NV = NVAR + NS; // hydro variables + passive scalars
+	constexpr int RHS_DIVV = S_RHS + NV;
 	static_assert(DIR == 1 || DIR == 2, "marching sweeps are the strided directions");
 	const int b = static_cast<int>(blockIdx.z) / a.nseg;
 	const int seg = static_cast<int>(blockIdx.z) - b * a.nseg;
@@ -608,11 +634,11 @@ template <int DIR, int ORDER, int STAGE, bool LAST> __global__ void __launch_bou
 	const int64_t ums = (DIR == 1) ? Uin.js : Uin.ks;
 
 	constexpr int AV = Axes<DIR>::v, AW = Axes<DIR>::w;
-	double q[5][NVAR];
-	double apPrev[NVAR], Fprev[NVAR];
+	double q[5][NV];
+	double apPrev[NV], Fprev[NV];
 	double vfPrev = 0., dVprev = 0., dWprev = 0.;
 #pragma unroll
-	for (int n = 0; n < NVAR; ++n) {
+	for (int n = 0; n < NV; ++n) {
 		apPrev[n] = 0.;
 		Fprev[n] = 0.;
 #pragma unroll
@@ -624,7 +650,7 @@ template <int DIR, int ORDER, int STAGE, bool LAST> __global__ void __launch_bou
 	for (int step = 0; step < nvalid + 6; ++step, c += ms, u += ums) {
 		// shift the window; U(p) -> primitives of the newest cell
 #pragma unroll
-		for (int n = 0; n < NVAR; ++n) {
+		for (int n = 0; n < NV; ++n) {
 			q[0][n] = q[1][n];
 			q[1][n] = q[2][n];
 			q[2][n] = q[3][n];
@@ -637,6 +663,10 @@ template <int DIR, int ORDER, int STAGE, bool LAST> __global__ void __launch_bou
 				Uc[n] = Uin.p[u + Uin.ns * n];
 			}
 			consToPrim(eos, a.reconstruct_eint, Uc, q[4]);
+#pragma unroll
+			for (int n = NVAR; n < NV; ++n) { // passive scalars are reconstructed as they are stored
+				q[4][n] = Uin.p[u + Uin.ns * n];
+			}
 		}
 		if (step < 4) {
 			continue;
@@ -649,16 +679,16 @@ template <int DIR, int ORDER, int STAGE, bool LAST> __global__ void __launch_bou
 		// The accumulator of cell cc-1 (and in stage 2 the stage-1 flux of this step's face) are requested BEFORE the reconstruction and the
 		// Riemann solve instead of where they are used: behind the face-flux stores they could not be hoisted by the compiler (may-alias),
 		// and a wave parked on them for a full memory round trip per step (SQ_WAIT_ANY 59 % of the wave cycles at 2 waves per SIMD).
-		double rhs_in[NVAR + 1], F1[NVAR + 1];
+		double rhs_in[NV + 1], F1[NV + 1];
 		int fidx[3];
 		fidx[0] = i;
 		fidx[OT] = ot;
 		fidx[DIR] = lo + (step - 5);
-		double Uo[NVAR];
+		double Uo[NV];
 		if (step >= 6) {
 			const int64_t cu = cc - ms;
 #pragma unroll
-			for (int n = 0; n < NVAR + 1; ++n) {
+			for (int n = 0; n < NV + 1; ++n) {
 				rhs_in[n] = S[(S_RHS + n) * T + cu];
 			}
 			if (LAST) { // the old state of the cell this step completes
@@ -668,7 +698,7 @@ template <int DIR, int ORDER, int STAGE, bool LAST> __global__ void __launch_bou
 				uc[DIR] = lo + (step - 6);
 				const int64_t co = Uold.idx(uc[0], uc[1], uc[2]);
 #pragma unroll
-				for (int n = 0; n < NVAR; ++n) {
+				for (int n = 0; n < NV; ++n) {
 					Uo[n] = Uold.p[co + Uold.ns * n];
 				}
 			}
@@ -678,44 +708,51 @@ template <int DIR, int ORDER, int STAGE, bool LAST> __global__ void __launch_bou
 			RA4 HV(a.halfVel[b]);
 			const int64_t o = HF.idx(fidx[0], fidx[1], fidx[2]);
 #pragma unroll
-			for (int n = 0; n < NVAR; ++n) {
+			for (int n = 0; n < NV; ++n) {
 				F1[n] = HF.p[o + HF.ns * n];
 			}
-			F1[NVAR] = HV(fidx[0], fidx[1], fidx[2]);
+			F1[NV] = HV(fidx[0], fidx[1], fidx[2]);
 		}
-		double am[NVAR], ap[NVAR];
+		double am[NV], ap[NV];
 #pragma unroll
-		for (int n = 0; n < NVAR; ++n) {
+		for (int n = 0; n < NV; ++n) {
 			cellEdges<ORDER>(q[0][n], q[1][n], q[2][n], q[3][n], q[4][n], am[n], ap[n]);
 			flattenEdges(chi, q[2][n], am[n], ap[n]);
 		}
 		if (step >= 5) {
 			// face between cells cc-1 and cc, index = (march coordinate of cc)
 			const double du = q[2][PVX + DIR] - q[1][PVX + DIR];
-			double F[NVAR], vf;
-			faceFlux<DIR, QK_RIEMANN_HLLC>(eos, a.reconstruct_eint, 3, apPrev, am, du, dVprev, dV, dWprev, dW, a.K_visc, F, vf);
+			double F[NV], vf;
+			{
+				Wave wv;
+				faceFlux<DIR, QK_RIEMANN_HLLC>(eos, a.reconstruct_eint, 3, apPrev, am, du, dVprev, dV, dWprev, dW, a.K_visc, F, vf, NS > 0 ? &wv : nullptr);
+#pragma unroll
+				for (int n = NVAR; n < NV; ++n) {
+					F[n] = scalarFlux<QK_RIEMANN_HLLC>(wv, apPrev[n], am[n]);
+				}
+			}
 			if (STAGE == 1) {
 				if (live) {
 					WA4 HF(a.halfFlux[b]);
 					WA4 HV(a.halfVel[b]);
 					const int64_t o = HF.idx(fidx[0], fidx[1], fidx[2]);
 #pragma unroll
-					for (int n = 0; n < NVAR; ++n) {
+					for (int n = 0; n < NV; ++n) {
 						HF.p[o + HF.ns * n] = F[n];
 					}
 					HV(fidx[0], fidx[1], fidx[2]) = vf;
 				}
 			} else {
 #pragma unroll
-				for (int n = 0; n < NVAR; ++n) {
+				for (int n = 0; n < NV; ++n) {
 					F[n] = 0.5 * F1[n] + 0.5 * F[n];
 				}
-				vf = 0.5 * F1[NVAR] + 0.5 * vf;
+				vf = 0.5 * F1[NV] + 0.5 * vf;
 				if (a.store_rk2 && live) {
 					WA4 RF(a.rk2Flux[b]);
 					const int64_t o2 = RF.idx(fidx[0], fidx[1], fidx[2]);
 #pragma unroll
-					for (int n = 0; n < NVAR; ++n) {
+					for (int n = 0; n < NV; ++n) {
 						RF.p[o2 + RF.ns * n] = F[n];
 					}
 				}
@@ -723,36 +760,36 @@ template <int DIR, int ORDER, int STAGE, bool LAST> __global__ void __launch_bou
 			if (step >= 6) {
 				// update cell u = cc - 1 (march coordinate lo + step - 6)
 				const int64_t cu = cc - ms;
-				double rhs[NVAR];
+				double rhs[NV];
 #pragma unroll
-				for (int n = 0; n < NVAR; ++n) {
+				for (int n = 0; n < NV; ++n) {
 					rhs[n] = rhs_in[n] + a.inv_dx * (Fprev[n] - F[n]);
 				}
-				const double div_v = rhs_in[NVAR] + (vf - vfPrev) / a.dx;
+				const double div_v = rhs_in[NV] + (vf - vfPrev) / a.dx;
 				if (LAST) {
 					int u[3];
 					u[0] = i;
 					u[OT] = ot;
 					u[DIR] = lo + (step - 6);
 					if (live) {
-						updateCellFrom(a, eos, ec, b, u[0], u[1], u[2], Uo, rhs, div_v, sig0, sig1);
+						updateCellFrom<NS>(a, eos, ec, b, u[0], u[1], u[2], Uo, rhs, div_v, sig0, sig1);
 					}
 				} else if (live) {
 #pragma unroll
-					for (int n = 0; n < NVAR; ++n) {
+					for (int n = 0; n < NV; ++n) {
 						Sw[(S_RHS + n) * T + cu] = rhs[n];
 					}
-					Sw[(S_RHS + 6) * T + cu] = div_v;
+					Sw[RHS_DIVV * T + cu] = div_v;
 				}
 			}
 #pragma unroll
-			for (int n = 0; n < NVAR; ++n) {
+			for (int n = 0; n < NV; ++n) {
 				Fprev[n] = F[n];
 			}
 			vfPrev = vf;
 		}
 #pragma unroll
-		for (int n = 0; n < NVAR; ++n) {
+		for (int n = 0; n < NV; ++n) {
 			apPrev[n] = ap[n];
 		}
 		dVprev = dV;
@@ -809,7 +846,7 @@ auto buildGeom(qk_level *lev) -> int
 	return QK_OK;
 }
 
-template <int ORDER, int STAGE> void launchSweeps(qk_level *lev, hipStream_t s, SweepArgs a, Eos eos, const qk_hydro_stage_args *args)
+template <int ORDER, int STAGE, int NS> void launchSweeps(qk_level *lev, hipStream_t s, SweepArgs a, Eos eos, const qk_hydro_stage_args *args)
 {
 	// X
 	{
@@ -822,7 +859,7 @@ template <int ORDER, int STAGE> void launchSweeps(qk_level *lev, hipStream_t s, 
 		const int64_t slab = static_cast<int64_t>(lev->maxlen[0] + 2 * NG) * lev->maxlen[1];
 		const dim3 grid(static_cast<unsigned>((slab + XOUT - 1) / XOUT), static_cast<unsigned>(lev->maxlen[2]), static_cast<unsigned>(lev->nboxes));
 		ProfScope ps(lev->ctx, s, "k_sweep_x");
-		hipLaunchKernelGGL((k_sweep_x<ORDER, STAGE>), grid, dim3(XB), 0, s, ax, eos);
+		hipLaunchKernelGGL((k_sweep_x<ORDER, STAGE, NS>), grid, dim3(XB), 0, s, ax, eos);
 	}
 	// Y
 	{
@@ -835,7 +872,7 @@ template <int ORDER, int STAGE> void launchSweeps(qk_level *lev, hipStream_t s, 
 		ay.nseg = marchSegments(lev, 1, 2);
 		const dim3 grid((lev->maxlen[0] + 63) / 64, (lev->maxlen[2] + 3) / 4, lev->nboxes * ay.nseg);
 		ProfScope ps(lev->ctx, s, "k_sweep_y");
-		hipLaunchKernelGGL((k_sweep_march<1, ORDER, STAGE, false>), grid, dim3(64, 4), 0, s, ay, eos);
+		hipLaunchKernelGGL((k_sweep_march<1, ORDER, STAGE, false, NS>), grid, dim3(64, 4), 0, s, ay, eos);
 	}
 	// Z (+ epilogue)
 	{
@@ -848,7 +885,7 @@ template <int ORDER, int STAGE> void launchSweeps(qk_level *lev, hipStream_t s, 
 		az.nseg = marchSegments(lev, 2, 1);
 		const dim3 grid((lev->maxlen[0] + 63) / 64, (lev->maxlen[1] + 3) / 4, lev->nboxes * az.nseg);
 		ProfScope ps(lev->ctx, s, "k_sweep_z");
-		hipLaunchKernelGGL((k_sweep_march<2, ORDER, STAGE, true>), grid, dim3(64, 4), 0, s, az, eos);
+		hipLaunchKernelGGL((k_sweep_march<2, ORDER, STAGE, true, NS>), grid, dim3(64, 4), 0, s, az, eos);
 	}
 }
 
@@ -872,7 +909,7 @@ int64_t qk_hydro_stage_scratch_bytes(qk_level *lev, const qk_hydro_traits *t)
 		}
 		cells += n;
 	}
-	return cells * S_NCOMP * static_cast<int64_t>(sizeof(double));
+	return cells * scratchComps(t->nscalars) * static_cast<int64_t>(sizeof(double));
 }
 
 int qk_hydro_stage_fused(qk_level *lev, qk_stream stream, const qk_hydro_traits *t, const qk_hydro_stage_args *args)
@@ -888,8 +925,8 @@ int qk_hydro_stage_fused(qk_level *lev, qk_stream stream, const qk_hydro_traits 
 	if (lev->nboxes == 0) {
 		return QK_OK; // a rank without boxes on this level
 	}
-	if (t->nscalars != 0) {
-		return setError(ctx, QK_ERR_UNSUPPORTED, "qk_hydro_stage_fused: no passive scalars (use the reference-shaped operators)");
+	if (t->nscalars > QK_FUSED_MAX_SCALARS || t->nmscalars != 0) {
+		return setError(ctx, QK_ERR_UNSUPPORTED, "qk_hydro_stage_fused: up to 3 passive scalars, no mass scalars (use the reference-shaped operators)");
 	}
 	if (t->ndim != 3) {
 		return setError(ctx, QK_ERR_UNSUPPORTED, "qk_hydro_stage_fused: 3-D only (use the reference-shaped operators in 1-D)");
@@ -953,11 +990,22 @@ int qk_hydro_stage_fused(qk_level *lev, qk_stream stream, const qk_hydro_traits 
 	a.reconstruct_eint = re;
 	a.store_rk2 = (args->store_flux_rk2 != 0);
 
-#define QK_LAUNCH(ORDER)                                                                                                                             \
+#define QK_LAUNCH_NS(ORDER, NS)                                                                                                                      \
 	if (args->stage == 1) {                                                                                                                      \
-		launchSweeps<ORDER, 1>(lev, s, a, eos, args);                                                                                        \
+		launchSweeps<ORDER, 1, NS>(lev, s, a, eos, args);                                                                                    \
 	} else {                                                                                                                                     \
-		launchSweeps<ORDER, 2>(lev, s, a, eos, args);                                                                                        \
+		launchSweeps<ORDER, 2, NS>(lev, s, a, eos, args);                                                                                    \
+	}
+#define QK_LAUNCH(ORDER)                                                                                                                             \
+	switch (t->nscalars) {                                                                                                                       \
+	case 0:                                                                                                                                      \
+		QK_LAUNCH_NS(ORDER, 0) break;                                                                                                        \
+	case 1:                                                                                                                                      \
+		QK_LAUNCH_NS(ORDER, 1) break;                                                                                                        \
+	case 2:                                                                                                                                      \
+		QK_LAUNCH_NS(ORDER, 2) break;                                                                                                        \
+	default:                                                                                                                                     \
+		QK_LAUNCH_NS(ORDER, 3) break;                                                                                                        \
 	}
 	if (args->reconstruction_order == 3) {
 		QK_LAUNCH(3)
@@ -966,6 +1014,7 @@ int qk_hydro_stage_fused(qk_level *lev, qk_stream stream, const qk_hydro_traits 
 	} else {
 		QK_LAUNCH(1)
 	}
+#undef QK_LAUNCH_NS
 #undef QK_LAUNCH
 	QK_HIP_CHECK(ctx, hipGetLastError());
 	return QK_OK;

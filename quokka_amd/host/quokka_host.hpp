@@ -1490,7 +1490,8 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 
 	auto stage(int stageNo, amrex::MultiFab const &U_in, amrex::MultiFab const &U_old, amrex::MultiFab &U_out, double dt) -> bool
 	{
-		if (AMREX_SPACEDIM == 3 && HydroSystem<problem_t>::nscalars_ == 0) {
+		// the fused stage carries up to 3 passive scalars; mass scalars take the reference-shaped operators
+		if (AMREX_SPACEDIM == 3 && HydroSystem<problem_t>::nscalars_ <= 3 && Physics_Traits<problem_t>::numMassScalars == 0) {
 			auto t = qkhost::traits<problem_t>();
 			qk_hydro_stage_args a{};
 			a.U_in = qkhost::tab(U_in);

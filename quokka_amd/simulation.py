@@ -273,7 +273,8 @@ class HydroSimulation:
         self.abortOnFofcFailure_ = 1
         self.artificialViscosityK_ = 0.0
         self.min_overlap_cells = 8 * 128 ** 3
-        self.use_fused = use_fused and geom.ndim == 3 and traits.nscalars == 0  # the fused stage carries the six hydro components only
+        # the fused stage is instantiated for 0..3 passive scalars; mass scalars (consistent multi-fluid advection) take the operator path
+        self.use_fused = use_fused and geom.ndim == 3 and traits.nscalars <= 3 and traits.nmscalars == 0
         # state
         lev = self.lev
         self.state_old_cc_ = MultiFab(lev, self.ncomp_cc, NGHOST_CC, fill=0.0)

@@ -243,7 +243,7 @@ def test_sum_boundary_is_the_transpose_of_fill_boundary(ctx, periodic):
     assert any(not np.array_equal(want[b], host[b]) for b in range(len(boxes)))
 
 
-@pytest.mark.parametrize("ndim,nscalars,nsteps", [(1, 1, 300), (3, 2, 12)])
+@pytest.mark.parametrize("ndim,nscalars,nsteps", [(1, 1, 300), (3, 2, 12), (3, 1, 6), (3, 3, 6)])
 def test_passive_scalars_match_oracle(ctx, oracle, ndim, nscalars, nsteps):
     """Passive scalars through the reference-shaped operators (hydro_system.hpp:340-343 cons->prim, HLLC.hpp:126-136 flux,
     hydro_system.hpp:1062-1076 viscosity term, :713-722 density floor): the advected contact of the PassiveScalar problem,
@@ -254,18 +254,32 @@ def test_passive_scalars_match_oracle(ctx, oracle, ndim, nscalars, nsteps):
     mgs = [64, 1, 1] if ndim == 1 else [16, 16, 16]
     so = oracle.sim(SCALARS, ndim, n_cell, [0, 0, 0], [1.0, 1.0, 1.0], [1, 1, 1], max_grid_size=mgs, nscalars=nscalars)
     sg = scalar_contact_problem(ctx, n_cell[0], nscalars=nscalars, ndim=ndim, max_grid_size=mgs)
-    assert not sg.use_fused and sg.state_new_cc_.ncomp == 6 + nscalars
+    # 3-D: the fused stage (instantiated for up to 3 passive scalars); 1-D: the reference-shaped operators
+    assert sg.use_fused == (ndim == 3) and sg.state_new_cc_.ncomp == 6 + nscalars
+    sg_ops = None
+    if sg.use_fused:  # the same run through the operator path: must agree with the fused stage in every bit
+        sg_ops = scalar_contact_problem(ctx, n_cell[0], nscalars=nscalars, ndim=ndim, max_grid_size=mgs)
+        sg_ops.use_fused = False
     for b in range(so.nboxes):
         assert sg.my_boxes[b] == tuple(so.box(b)) or list(sg.my_boxes[b][0]) == list(so.box(b)[0])
         sg.state_new_cc_.set_fab(b, so.state(b, 0))
         sg.state_old_cc_.set_fab(b, so.state(b, 1))
+        if sg_ops is not None:
+            sg_ops.state_new_cc_.set_fab(b, so.state(b, 0))
+            sg_ops.state_old_cc_.set_fab(b, so.state(b, 1))
     s0 = sum(float(sg.state_new_cc_.valid(b)[6].sum()) for b in range(sg.lev.nboxes))
     for it in range(nsteps):
         assert so.step() and sg.step()
         assert so.dt == sg.dt_, (it, so.dt, sg.dt_)
+        if sg_ops is not None:
+            assert sg_ops.step() and sg_ops.dt_ == sg.dt_
+    if sg.use_fused:
+        assert sg.counters["fofc1_stages"] == sg.counters["fofc2_stages"] == 0  # every stage was carried by the fused kernels
     for b in range(so.nboxes):
         a, g = so.valid(b), sg.state_new_cc_.valid(b).cpu().numpy()
         assert np.array_equal(a, g), (b, [float(np.abs(a[n] - g[n]).max()) for n in range(6 + nscalars)])
+        if sg_ops is not None:
+            assert np.array_equal(g, sg_ops.state_new_cc_.valid(b).cpu().numpy()), b
     s1 = sum(float(sg.state_new_cc_.valid(b)[6].sum()) for b in range(sg.lev.nboxes))
     assert abs(s1 - s0) <= 1e-13 * abs(s0)
     assert float(sg.state_new_cc_.valid(0)[6].max()) > 0.9  # the step is still there
