@@ -3,13 +3,27 @@
 // on host staging buffers, Print / Abort).  AMReX is an un-vendored submodule of the reference and is absent from this
 // image, so problem generators written against the reference's surface are compiled against this header instead.
 // Device data live in HIP allocations; the descriptor table of a MultiFab (`arrays()`) is what the C-ABI consumes
-// (qk_array4 == amrex::Array4<Real>).  Host C++17, no kernels here.
+// (qk_array4 == amrex::Array4<Real>).
+//
+// Two ways to compile a problem file against it:
+//   * host mode (plain C++17, the adapted problem files under problems/): AMREX_GPU_DEVICE is empty, ParallelFor is a host loop over
+//     staging buffers that the driver uploads;
+//   * device mode (-x hip -DQK_DEVICE_LAMBDAS, what `make refproblem P=<dir>` uses to compile the reference's problem files UNCHANGED, read in
+//     place from /root/reference/src/problems): AMREX_GPU_DEVICE is __device__, ParallelFor launches the lambda as a HIP kernel over device
+//     arrays (MFIter / array(mfi) / const_array(mfi) / Gpu::DeviceVector / ReduceSum as the reference uses them), initial conditions,
+//     ErrorEst, setCustomBoundaryConditions and the analysis lambdas of a problem run on the GPU exactly as written.  This is problem-side
+//     glue (one backend: HIP); the hot path stays behind include/quokka_amd.h.
 #ifndef QK_HOST_AMREX_MINI_HPP_
 #define QK_HOST_AMREX_MINI_HPP_
 
+#if defined(QK_DEVICE_LAMBDAS)
+#include <hip/hip_runtime.h>
+#else
 #include <hip/hip_runtime_api.h>
+#endif
 
 #include <algorithm>
+#include <cassert>
 #include <array>
 #include <cmath>
 #include <cstdint>
@@ -18,9 +32,13 @@
 #include <fstream>
 #include <iostream>
 #include <map>
+#include <optional>
+#include <tuple>
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "quokka_amd.h"
@@ -28,9 +46,28 @@
 #ifndef AMREX_SPACEDIM
 #define AMREX_SPACEDIM 3
 #endif
+#if defined(QK_DEVICE_LAMBDAS)
+#define AMREX_GPU_DEVICE __device__
+#define AMREX_GPU_HOST_DEVICE __host__ __device__
+#define AMREX_GPU_HOST __host__
+#define QK_HD __host__ __device__
+#define AMREX_USE_GPU 1
+#define AMREX_USE_HIP 1
+#else
 #define AMREX_GPU_DEVICE
 #define AMREX_GPU_HOST_DEVICE
+#define AMREX_GPU_HOST
+#define QK_HD
+#endif
+#if defined(QK_DEVICE_LAMBDAS)
+#define AMREX_GPU_MANAGED __managed__
+#else
+#define AMREX_GPU_MANAGED
+#endif
 #define AMREX_FORCE_INLINE inline
+#define AMREX_INLINE inline
+#define AMREX_NO_INLINE
+#define AMREX_RESTRICT __restrict__
 #define AMREX_ASSERT(x) ((void)0)
 #define AMREX_ALWAYS_ASSERT(x)                                                                                                                       \
 	do {                                                                                                                                         \
@@ -38,6 +75,13 @@
 			amrex::Abort("assertion failed: " #x);                                                                                       \
 		}                                                                                                                                    \
 	} while (0)
+#define AMREX_ALWAYS_ASSERT_WITH_MESSAGE(x, msg)                                                                                                     \
+	do {                                                                                                                                         \
+		if (!(x)) {                                                                                                                          \
+			amrex::Abort(std::string("assertion failed: " #x " : ") + (msg));                                                            \
+		}                                                                                                                                    \
+	} while (0)
+#define AMREX_ASSERT_WITH_MESSAGE(x, msg) ((void)0)
 #if AMREX_SPACEDIM == 1
 #define AMREX_D_DECL(a, b, c) a
 #define AMREX_D_TERM(a, b, c) a
@@ -55,6 +99,10 @@ using Real = double;
 using Long = long;
 template <typename T> using Vector = std::vector<T>;
 
+#if defined(QK_DEVICE_LAMBDAS)
+// inside kernels: stop the wave (the reference's device-side amrex::Abort traps as well)
+__device__ inline void Abort(char const * /*msg*/) { __builtin_trap(); }
+#endif
 [[noreturn]] inline void Abort(std::string const &msg)
 {
 	std::fprintf(stderr, "amrex::Abort: %s\n", msg.c_str());
@@ -80,15 +128,48 @@ struct Dim3 {
 	int x, y, z;
 };
 
+template <typename T, int N> struct GpuArray {
+	T arr[N > 0 ? N : 1];
+	QK_HD auto operator[](int i) const -> T const & { return arr[i]; }
+	QK_HD auto operator[](int i) -> T & { return arr[i]; }
+	[[nodiscard]] QK_HD auto begin() const -> T const * { return arr; }
+	[[nodiscard]] QK_HD auto end() const -> T const * { return arr + N; }
+	[[nodiscard]] QK_HD auto data() const -> T const * { return arr; }
+	[[nodiscard]] QK_HD auto data() -> T * { return arr; }
+	[[nodiscard]] QK_HD static constexpr auto size() -> unsigned { return N; }
+	QK_HD void fill(T const &v)
+	{
+		for (int i = 0; i < N; ++i) {
+			arr[i] = v;
+		}
+	}
+};
+
+} // namespace amrex
+namespace std
+{
+template <typename T, int N> struct tuple_size<amrex::GpuArray<T, N>> : integral_constant<size_t, static_cast<size_t>(N)> {
+};
+template <size_t I, typename T, int N> struct tuple_element<I, amrex::GpuArray<T, N>> {
+	using type = T;
+};
+} // namespace std
+namespace amrex
+{
+template <size_t I, typename T, int N> QK_HD auto get(GpuArray<T, N> const &a) -> T const & { return a.arr[I]; }
+template <size_t I, typename T, int N> QK_HD auto get(GpuArray<T, N> &a) -> T & { return a.arr[I]; }
+template <size_t I, typename T, int N> QK_HD auto get(GpuArray<T, N> &&a) -> T && { return static_cast<T &&>(a.arr[I]); }
+
 struct IntVect {
 	int v[3] = {0, 0, 0};
 	IntVect() = default;
-	IntVect(int i, int j = 0, int k = 0) : v{i, j, k} {}
-	auto operator[](int d) const -> int { return v[d]; }
-	auto operator[](int d) -> int & { return v[d]; }
-	[[nodiscard]] auto toArray() const -> std::array<int, AMREX_SPACEDIM>
+	QK_HD IntVect(int i, int j = 0, int k = 0) : v{i, j, k} {}
+	QK_HD auto operator[](int d) const -> int { return v[d]; }
+	QK_HD auto operator[](int d) -> int & { return v[d]; }
+	[[nodiscard]] QK_HD auto dim3() const -> Dim3 { return {v[0], v[1], v[2]}; }
+	[[nodiscard]] QK_HD auto toArray() const -> GpuArray<int, AMREX_SPACEDIM>
 	{
-		std::array<int, AMREX_SPACEDIM> a{};
+		GpuArray<int, AMREX_SPACEDIM> a{};
 		for (int d = 0; d < AMREX_SPACEDIM; ++d) {
 			a[d] = v[d];
 		}
@@ -96,13 +177,6 @@ struct IntVect {
 	}
 };
 
-template <typename T, int N> struct GpuArray {
-	T arr[N > 0 ? N : 1];
-	auto operator[](int i) const -> T const & { return arr[i]; }
-	auto operator[](int i) -> T & { return arr[i]; }
-	[[nodiscard]] auto begin() const -> T const * { return arr; }
-	[[nodiscard]] auto data() const -> T const * { return arr; }
-};
 
 class Box
 {
@@ -117,13 +191,15 @@ class Box
 			hi[d] = b[d];
 		}
 	}
-	[[nodiscard]] auto smallEnd(int d) const -> int { return lo[d]; }
-	[[nodiscard]] auto bigEnd(int d) const -> int { return hi[d]; }
-	[[nodiscard]] auto length(int d) const -> int { return hi[d] - lo[d] + 1; }
-	[[nodiscard]] auto numPts() const -> Long { return static_cast<Long>(length(0)) * length(1) * length(2); }
-	[[nodiscard]] auto loVect3d() const -> GpuArray<int, 3> { return {{lo[0], lo[1], lo[2]}}; }
-	[[nodiscard]] auto hiVect3d() const -> GpuArray<int, 3> { return {{hi[0], hi[1], hi[2]}}; }
-	[[nodiscard]] auto contains(int i, int j, int k) const -> bool
+	[[nodiscard]] QK_HD auto smallEnd(int d) const -> int { return lo[d]; }
+	[[nodiscard]] QK_HD auto bigEnd(int d) const -> int { return hi[d]; }
+	[[nodiscard]] QK_HD auto smallEnd() const -> IntVect { return {lo[0], lo[1], lo[2]}; }
+	[[nodiscard]] QK_HD auto bigEnd() const -> IntVect { return {hi[0], hi[1], hi[2]}; }
+	[[nodiscard]] QK_HD auto length(int d) const -> int { return hi[d] - lo[d] + 1; }
+	[[nodiscard]] QK_HD auto numPts() const -> Long { return static_cast<Long>(length(0)) * length(1) * length(2); }
+	[[nodiscard]] QK_HD auto loVect3d() const -> GpuArray<int, 3> { return {{lo[0], lo[1], lo[2]}}; }
+	[[nodiscard]] QK_HD auto hiVect3d() const -> GpuArray<int, 3> { return {{hi[0], hi[1], hi[2]}}; }
+	[[nodiscard]] QK_HD auto contains(int i, int j, int k) const -> bool
 	{
 		return i >= lo[0] && i <= hi[0] && j >= lo[1] && j <= hi[1] && k >= lo[2] && k <= hi[2];
 	}
@@ -145,23 +221,29 @@ template <typename T> struct Array4 {
 	Dim3 end{0, 0, 0};
 	int ncomp = 0;
 	Array4() = default;
-	Array4(T *ptr, Box const &bx, int nc) : p(ptr), begin{bx.lo[0], bx.lo[1], bx.lo[2]}, end{bx.hi[0] + 1, bx.hi[1] + 1, bx.hi[2] + 1}, ncomp(nc)
+	QK_HD Array4(T *ptr, Box const &bx, int nc) : p(ptr), begin{bx.lo[0], bx.lo[1], bx.lo[2]}, end{bx.hi[0] + 1, bx.hi[1] + 1, bx.hi[2] + 1}, ncomp(nc)
 	{
 		jstride = bx.length(0);
 		kstride = jstride * bx.length(1);
 		nstride = kstride * bx.length(2);
 	}
-	auto operator()(int i, int j, int k, int n = 0) const -> T & { return p[(i - begin.x) + jstride * (j - begin.y) + kstride * (k - begin.z) + nstride * n]; }
-	[[nodiscard]] auto nComp() const -> int { return ncomp; }
-	[[nodiscard]] auto contains(int i, int j, int k) const -> bool
+	// Array4<T const> from Array4<T>
+	template <typename U, std::enable_if_t<std::is_same_v<std::remove_const_t<T>, U> && std::is_const_v<T>, int> = 0>
+	QK_HD Array4(Array4<U> const &o) : p(o.p), jstride(o.jstride), kstride(o.kstride), nstride(o.nstride), begin(o.begin), end(o.end), ncomp(o.ncomp)
+	{
+	}
+	QK_HD auto operator()(int i, int j, int k, int n = 0) const -> T & { return p[(i - begin.x) + jstride * (j - begin.y) + kstride * (k - begin.z) + nstride * n]; }
+	QK_HD auto operator()(IntVect const &iv, int n = 0) const -> T & { return (*this)(iv[0], iv[1], iv[2], n); }
+	[[nodiscard]] QK_HD auto nComp() const -> int { return ncomp; }
+	[[nodiscard]] QK_HD auto contains(int i, int j, int k) const -> bool
 	{
 		return i >= begin.x && i < end.x && j >= begin.y && j < end.y && k >= begin.z && k < end.z;
 	}
 };
 static_assert(sizeof(Array4<Real>) == sizeof(qk_array4), "amrex::Array4<Real> must match qk_array4");
 
-// host-side loops standing in for the device ParallelFor on staging buffers
-template <typename F> void ParallelFor(Box const &bx, F &&f)
+// plain host loop over a box (diagnostics on staging copies; in host mode also what ParallelFor is)
+template <typename F> void HostFor(Box const &bx, F &&f)
 {
 	for (int k = bx.lo[2]; k <= bx.hi[2]; ++k) {
 		for (int j = bx.lo[1]; j <= bx.hi[1]; ++j) {
@@ -171,6 +253,88 @@ template <typename F> void ParallelFor(Box const &bx, F &&f)
 		}
 	}
 }
+// amrex::Loop: a serial loop over a box, callable inside kernels
+template <typename F> QK_HD void Loop(Box const &bx, F const &f)
+{
+	for (int k = bx.lo[2]; k <= bx.hi[2]; ++k) {
+		for (int j = bx.lo[1]; j <= bx.hi[1]; ++j) {
+			for (int i = bx.lo[0]; i <= bx.hi[0]; ++i) {
+				f(i, j, k);
+			}
+		}
+	}
+}
+#if defined(QK_DEVICE_LAMBDAS)
+// amrex::ParallelFor on the GPU: one thread per cell of the box, the lambda by value in the kernel arguments (default stream: ordered with
+// the C-ABI calls of the driver, which use the same stream)
+template <typename F> __global__ void qk_parfor_kernel(Box bx, F f)
+{
+	const Long n = static_cast<Long>(blockIdx.x) * blockDim.x + threadIdx.x;
+	if (n >= bx.numPts()) {
+		return;
+	}
+	const int nx = bx.length(0), ny = bx.length(1);
+	const int k = static_cast<int>(n / (static_cast<Long>(nx) * ny));
+	const int r = static_cast<int>(n - static_cast<Long>(k) * nx * ny);
+	const int j = r / nx;
+	f(bx.lo[0] + (r - j * nx), bx.lo[1] + j, bx.lo[2] + k);
+}
+template <typename F> __global__ void qk_parfor_kernel_n(Box bx, int ncomp, F f)
+{
+	const Long n = static_cast<Long>(blockIdx.x) * blockDim.x + threadIdx.x;
+	if (n >= bx.numPts() * ncomp) {
+		return;
+	}
+	const int nx = bx.length(0), ny = bx.length(1);
+	const Long cell = n % bx.numPts();
+	const int comp = static_cast<int>(n / bx.numPts());
+	const int k = static_cast<int>(cell / (static_cast<Long>(nx) * ny));
+	const int r = static_cast<int>(cell - static_cast<Long>(k) * nx * ny);
+	const int j = r / nx;
+	f(bx.lo[0] + (r - j * nx), bx.lo[1] + j, bx.lo[2] + k, comp);
+}
+template <typename F> void ParallelFor(Box const &bx, F const &f)
+{
+	const Long n = bx.numPts();
+	if (n <= 0) {
+		return;
+	}
+	hipLaunchKernelGGL(qk_parfor_kernel<F>, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, nullptr, bx, f);
+}
+template <typename F> void ParallelFor(Box const &bx, int ncomp, F const &f)
+{
+	const Long n = bx.numPts() * ncomp;
+	if (n <= 0) {
+		return;
+	}
+	hipLaunchKernelGGL(qk_parfor_kernel_n<F>, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, nullptr, bx, ncomp, f);
+}
+// amrex::ParallelForRNG / amrex::Random: one counter-based stream per cell (splitmix64 of the flat cell index and a draw counter)
+struct RandomEngine {
+	unsigned long long key = 0, ctr = 0;
+};
+QK_HD inline auto Random(RandomEngine const &e) -> Real
+{
+	auto &m = const_cast<RandomEngine &>(e);
+	unsigned long long z = m.key + 0x9E3779B97F4A7C15ULL * (++m.ctr);
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+	z ^= z >> 31;
+	return static_cast<Real>(z >> 11) * (1.0 / 9007199254740992.0);
+}
+template <typename F> void ParallelForRNG(Box const &bx, F const &f)
+{
+	ParallelFor(bx, [=] __device__(int i, int j, int k) {
+		RandomEngine e;
+		e.key = (static_cast<unsigned long long>(static_cast<unsigned>(i)) << 42) ^ (static_cast<unsigned long long>(static_cast<unsigned>(j)) << 21) ^
+			static_cast<unsigned long long>(static_cast<unsigned>(k));
+		f(i, j, k, e);
+	});
+}
+#else
+// host mode: the device ParallelFor of the reference runs as a host loop over staging buffers
+template <typename F> void ParallelFor(Box const &bx, F &&f) { HostFor(bx, f); }
+#endif
 
 namespace BCType
 {
@@ -183,16 +347,20 @@ class BCRec
 	int bc[6] = {0, 0, 0, 0, 0, 0};
 	void setLo(int dir, int type) { bc[dir] = type; }
 	void setHi(int dir, int type) { bc[3 + dir] = type; }
-	[[nodiscard]] auto lo(int dir) const -> int { return bc[dir]; }
-	[[nodiscard]] auto hi(int dir) const -> int { return bc[3 + dir]; }
+	[[nodiscard]] QK_HD auto lo(int dir) const -> int { return bc[dir]; }
+	[[nodiscard]] QK_HD auto hi(int dir) const -> int { return bc[3 + dir]; }
 };
 
 struct GeometryData {
 	Box domain;
 	GpuArray<Real, AMREX_SPACEDIM> prob_lo{}, prob_hi{}, dx{};
-	[[nodiscard]] auto Domain() const -> Box const & { return domain; }
-	[[nodiscard]] auto ProbLo(int d) const -> Real { return prob_lo[d]; }
-	[[nodiscard]] auto CellSize(int d) const -> Real { return dx[d]; }
+	[[nodiscard]] QK_HD auto Domain() const -> Box const & { return domain; }
+	[[nodiscard]] QK_HD auto ProbLo(int d) const -> Real { return prob_lo[d]; }
+	[[nodiscard]] QK_HD auto ProbHi(int d) const -> Real { return prob_hi[d]; }
+	[[nodiscard]] QK_HD auto ProbLo() const -> Real const * { return prob_lo.data(); }
+	[[nodiscard]] QK_HD auto ProbHi() const -> Real const * { return prob_hi.data(); }
+	[[nodiscard]] QK_HD auto CellSize(int d) const -> Real { return dx[d]; }
+	[[nodiscard]] QK_HD auto CellSize() const -> Real const * { return dx.data(); }
 };
 
 class Geometry
@@ -307,6 +475,7 @@ class ParmParse
 	[[nodiscard]] auto full(std::string const &n) const -> std::string { return prefix_.empty() ? n : prefix_ + "." + n; }
 };
 
+#define QK_HOST_HIP_DEFINED_BELOW 1
 #define QK_HOST_HIP(expr)                                                                                                                            \
 	do {                                                                                                                                         \
 		hipError_t e_ = (expr);                                                                                                              \
@@ -315,12 +484,136 @@ class ParmParse
 		}                                                                                                                                    \
 	} while (0)
 
+struct DistributionMapping {
+	DistributionMapping() = default;
+	template <typename BA> explicit DistributionMapping(BA const & /*ba*/) {}
+};
+
+// amrex::Gpu: host / device vectors and copies as the reference's problem files use them for their interpolation tables
+namespace Gpu
+{
+template <typename T> using HostVector = std::vector<T>;
+struct HostToDevice {
+};
+struct DeviceToHost {
+};
+struct DeviceToDevice {
+};
+static constexpr HostToDevice hostToDevice{};
+static constexpr DeviceToHost deviceToHost{};
+static constexpr DeviceToDevice deviceToDevice{};
+template <typename T> class DeviceVector
+{
+      public:
+	DeviceVector() = default;
+	explicit DeviceVector(size_t n) { resize(n); }
+	DeviceVector(DeviceVector const &) = delete;
+	auto operator=(DeviceVector const &) -> DeviceVector & = delete;
+	~DeviceVector()
+	{
+		if (p_ != nullptr) {
+			(void)hipFree(p_);
+		}
+	}
+	void resize(size_t n)
+	{
+		if (n > cap_) {
+			T *q = nullptr;
+			QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&q), sizeof(T) * n));
+			if (p_ != nullptr) {
+				QK_HOST_HIP(hipMemcpy(q, p_, sizeof(T) * n_, hipMemcpyDeviceToDevice));
+				(void)hipFree(p_);
+			}
+			p_ = q;
+			cap_ = n;
+		}
+		n_ = n;
+	}
+	[[nodiscard]] auto size() const -> size_t { return n_; }
+	[[nodiscard]] auto data() -> T * { return p_; }
+	[[nodiscard]] auto data() const -> T const * { return p_; }
+	[[nodiscard]] auto dataPtr() -> T * { return p_; }
+	[[nodiscard]] auto dataPtr() const -> T const * { return p_; }
+	[[nodiscard]] auto begin() -> T * { return p_; }
+	[[nodiscard]] auto end() -> T * { return p_ + n_; }
+	[[nodiscard]] auto begin() const -> T const * { return p_; }
+	[[nodiscard]] auto end() const -> T const * { return p_ + n_; }
+
+      private:
+	T *p_ = nullptr;
+	size_t n_ = 0, cap_ = 0;
+};
+template <typename It, typename Out> void copy(HostToDevice /*tag*/, It first, It last, Out out)
+{
+	auto const n = static_cast<size_t>(last - first);
+	if (n > 0) {
+		QK_HOST_HIP(hipMemcpy(&*out, &*first, sizeof(*first) * n, hipMemcpyHostToDevice));
+	}
+}
+template <typename It, typename Out> void copy(DeviceToHost /*tag*/, It first, It last, Out out)
+{
+	auto const n = static_cast<size_t>(last - first);
+	if (n > 0) {
+		QK_HOST_HIP(hipMemcpy(&*out, &*first, sizeof(*first) * n, hipMemcpyDeviceToHost));
+	}
+}
+template <typename Tag, typename It, typename Out> void copyAsync(Tag tag, It first, It last, Out out) { copy(tag, first, last, out); }
+inline void htod_memcpy(void *dst, void const *src, size_t bytes) { QK_HOST_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); }
+inline void dtoh_memcpy(void *dst, void const *src, size_t bytes) { QK_HOST_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); }
+inline void htod_memcpy_async(void *dst, void const *src, size_t bytes) { htod_memcpy(dst, src, bytes); }
+inline void streamSynchronize() { QK_HOST_HIP(hipDeviceSynchronize()); }
+inline void streamSynchronizeAll() { QK_HOST_HIP(hipDeviceSynchronize()); }
+inline void synchronize() { QK_HOST_HIP(hipDeviceSynchronize()); }
+struct Device {
+	static void streamSynchronize() { QK_HOST_HIP(hipDeviceSynchronize()); }
+	static void synchronize() { QK_HOST_HIP(hipDeviceSynchronize()); }
+};
+} // namespace Gpu
+
+// one process per GPU; the problem-side reductions of the reference are over one rank here
+namespace ParallelDescriptor
+{
+inline auto IOProcessor() -> bool { return true; }
+inline auto IOProcessorNumber() -> int { return 0; }
+inline auto MyProc() -> int { return 0; }
+inline auto NProcs() -> int { return 1; }
+inline void Barrier() {}
+template <typename T> void ReduceRealSum(T & /*v*/) {}
+template <typename T> void ReduceRealMax(T & /*v*/) {}
+template <typename T> void ReduceRealMin(T & /*v*/) {}
+inline void ReduceIntSum(int & /*v*/) {}
+inline void ReduceLongSum(long & /*v*/) {}
+inline void Abort() { std::exit(2); }
+} // namespace ParallelDescriptor
+namespace ParallelContext
+{
+inline auto CommunicatorSub() -> int { return 0; }
+inline auto IOProcessorSub() -> bool { return true; }
+} // namespace ParallelContext
+namespace ParallelAllReduce
+{
+template <typename T> void Sum(T & /*v*/, int /*comm*/) {}
+template <typename T> void Max(T & /*v*/, int /*comm*/) {}
+template <typename T> void Min(T & /*v*/, int /*comm*/) {}
+} // namespace ParallelAllReduce
+template <typename F> void LoopOnCpu(Box const &bx, F &&f) { HostFor(bx, f); }
+class BoxArray : public std::vector<Box>
+{
+      public:
+	using std::vector<Box>::vector;
+	BoxArray() = default;
+	BoxArray(std::vector<Box> const &v) : std::vector<Box>(v) {} // NOLINT
+	explicit BoxArray(Box const &b) : std::vector<Box>{b} {}
+	void maxSize(int /*n*/) {}
+};
+
 // FabArray<T> with device storage: one allocation for all boxes + the device table of Array4 descriptors
 template <typename T> class FabArrayT
 {
       public:
 	FabArrayT() = default;
 	FabArrayT(std::vector<Box> const &ba, int ncomp, int nghost, int facedir = -1) { define(ba, ncomp, nghost, facedir); }
+	FabArrayT(std::vector<Box> const &ba, DistributionMapping const & /*dm*/, int ncomp, int nghost) { define(ba, ncomp, nghost, -1); }
 	FabArrayT(FabArrayT const &) = delete;
 	auto operator=(FabArrayT const &) -> FabArrayT & = delete;
 	FabArrayT(FabArrayT &&o) noexcept { *this = std::move(o); }
@@ -381,6 +674,13 @@ template <typename T> class FabArrayT
 	[[nodiscard]] auto fabbox(int b) const -> Box const & { return fabboxes_[b]; }
 	// host copy of one descriptor (device data pointer)
 	[[nodiscard]] auto array(int b) const -> Array4<T> { return Array4<T>(d_data_ + offsets_[b], fabboxes_[b], ncomp_); }
+	[[nodiscard]] auto const_array(int b) const -> Array4<T const> { return Array4<T const>(d_data_ + offsets_[b], fabboxes_[b], ncomp_); }
+	template <typename It, typename = decltype(std::declval<It>().index())> [[nodiscard]] auto array(It const &mfi) const -> Array4<T> { return array(mfi.index()); }
+	template <typename It, typename = decltype(std::declval<It>().index())> [[nodiscard]] auto const_array(It const &mfi) const -> Array4<T const>
+	{
+		return const_array(mfi.index());
+	}
+	[[nodiscard]] auto DistributionMap() const -> int { return 0; }
 	// device pointer to the descriptor table (MultiFab::arrays())
 	[[nodiscard]] auto arrays() const -> Array4<T> * { return d_table_; }
 	void setVal(T v)
@@ -419,7 +719,7 @@ template <typename T> class FabArrayT
 		for (int b = 0; b < size(); ++b) {
 			auto h = copyToHost(b);
 			Array4<T> a(h.data(), fabboxes_[b], ncomp_);
-			ParallelFor(boxes_[b], [&](int i, int j, int k) {
+			HostFor(boxes_[b], [&](int i, int j, int k) {
 				double const y = static_cast<double>(a(i, j, k, n)) - comp;
 				double const t = s + y;
 				comp = (t - s) - y;
@@ -447,6 +747,23 @@ template <typename T> class FabArrayT
 	Long total_ = 0;
 	T *d_data_ = nullptr;
 	Array4<T> *d_table_ = nullptr;
+};
+// amrex::MFIter over the local boxes of a FabArray
+class MFIter
+{
+      public:
+	template <typename FA> explicit MFIter(FA const &fa, bool /*tiling*/ = false) : n_(fa.size()), boxes_(&fa.boxArray()), ng_(fa.nGrow()) {}
+	[[nodiscard]] auto isValid() const -> bool { return i_ < n_; }
+	void operator++() { ++i_; }
+	[[nodiscard]] auto index() const -> int { return i_; }
+	[[nodiscard]] auto validbox() const -> Box const & { return (*boxes_)[i_]; }
+	[[nodiscard]] auto tilebox() const -> Box const & { return (*boxes_)[i_]; }
+	[[nodiscard]] auto fabbox() const -> Box { return grow((*boxes_)[i_], ng_); }
+
+      private:
+	int i_ = 0, n_ = 0;
+	std::vector<Box> const *boxes_ = nullptr;
+	int ng_ = 0;
 };
 using MultiFab = FabArrayT<Real>;
 using iMultiFab = FabArrayT<int>;

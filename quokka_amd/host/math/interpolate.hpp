@@ -7,8 +7,10 @@
 #include <cmath>
 #include <cstdint>
 
+#include "../amrex_mini.hpp" // QK_HD: the tables are read inside device lambdas in device mode
+
 // index j with arr[j] <= key < arr[j + 1];  -1 below the table, len above it
-inline auto qk_bracket(double key, double const *arr, int64_t len) -> int64_t
+QK_HD inline auto qk_bracket(double key, double const *arr, int64_t len) -> int64_t
 {
 	if (key > arr[len - 1]) {
 		return len;
@@ -28,7 +30,7 @@ inline auto qk_bracket(double key, double const *arr, int64_t len) -> int64_t
 	return lo;
 }
 
-inline auto interpolate_value(double x, double const *arr_x, double const *arr_y, int arr_len) -> double
+QK_HD inline auto interpolate_value(double x, double const *arr_x, double const *arr_y, int arr_len) -> double
 {
 	int64_t const j = qk_bracket(x, arr_x, arr_len);
 	if (j == -1 || j == arr_len) {
@@ -42,7 +44,7 @@ inline auto interpolate_value(double x, double const *arr_x, double const *arr_y
 }
 
 // interpolate_arrays of the reference (src/math/interpolate.cpp:107-133): y[i] = table(x[i]) for a sorted table; NaN outside it
-inline void interpolate_arrays(double const *x, double *y, int len, double const *arr_x, double const *arr_y, int arr_len)
+QK_HD inline void interpolate_arrays(double const *x, double *y, int len, double const *arr_x, double const *arr_y, int arr_len)
 {
 	for (int i = 0; i < len; ++i) {
 		y[i] = interpolate_value(x[i], arr_x, arr_y, arr_len);

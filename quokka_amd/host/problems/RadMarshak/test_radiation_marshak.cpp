@@ -58,15 +58,15 @@ template <> auto RadSystem<SuOlsonProblem>::ComputePlanckOpacity(const double /*
 template <> auto RadSystem<SuOlsonProblem>::ComputeFluxMeanOpacity(const double /*rho*/, const double /*Tgas*/) -> amrex::Real { return kappa; }
 
 // the material of the exact solution: E_int = alpha / 4 T^4, heat capacity alpha T^3
-template <> auto quokka::EOS<SuOlsonProblem>::ComputeTgasFromEint(const double /*rho*/, const double Egas) -> double
+template <> auto quokka::EOS<SuOlsonProblem>::ComputeTgasFromEint(const double /*rho*/, const double Egas, MassScalars const & /*massScalars*/) -> double
 {
 	return std::pow(4.0 * Egas / alpha_SuOlson, 1. / 4.);
 }
-template <> auto quokka::EOS<SuOlsonProblem>::ComputeEintFromTgas(const double /*rho*/, const double Tgas) -> double
+template <> auto quokka::EOS<SuOlsonProblem>::ComputeEintFromTgas(const double /*rho*/, const double Tgas, MassScalars const & /*massScalars*/) -> double
 {
 	return (alpha_SuOlson / 4.0) * std::pow(Tgas, 4);
 }
-template <> auto quokka::EOS<SuOlsonProblem>::ComputeEintTempDerivative(const double /*rho*/, const double Tgas) -> double
+template <> auto quokka::EOS<SuOlsonProblem>::ComputeEintTempDerivative(const double /*rho*/, const double Tgas, MassScalars const & /*massScalars*/) -> double
 {
 	return alpha_SuOlson * std::pow(Tgas, 3);
 }

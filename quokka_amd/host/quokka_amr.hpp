@@ -147,7 +147,7 @@ template <typename problem_t> class AmrDriver
 				auto h = mf.copyToHost(b);
 				amrex::Array4<double> a(h.data(), mf.fabbox(b), mf.nComp());
 				double s = 0, c = 0;
-				amrex::ParallelFor(mf.validbox(b), [&](int i, int j, int k) {
+				amrex::HostFor(mf.validbox(b), [&](int i, int j, int k) {
 					if (l < finestLevel()) {
 						for (auto const &fb : level(l + 1).grids_) {
 							if (fb.contains(2 * i, 2 * j, 2 * k)) {
@@ -653,6 +653,7 @@ template <typename problem_t> void QuokkaSimulation<problem_t>::evolve()
 	} else {
 		evolveSingleLevel();
 	}
+	qkDumpState(*this); // test hook `qk.dump_state=<file>` (no-op without it): also for problem files that are compiled unchanged
 }
 
 #endif // QK_HOST_QUOKKA_AMR_HPP_

@@ -28,11 +28,30 @@ constexpr double k_B = 1.380649e-16;
 constexpr double m_u = 1.6605390666e-24;
 constexpr double m_p = 1.67262192369e-24;
 constexpr double m_e = 9.1093837015e-28;
+constexpr double m_n = 1.67492749804e-24;
 constexpr double c_light = 2.99792458e10;
-constexpr double a_rad = 4.0 * 5.670374419e-5 / c_light;
+constexpr double sigma_SB = 5.670374419e-5;
+constexpr double a_rad = 4.0 * sigma_SB / c_light;
+constexpr double hplanck = 6.62607015e-27;
+constexpr double hbar = 1.054571817e-27;
+constexpr double n_A = 6.02214076e23;
+constexpr double q_e = 4.80320471e-10;
+constexpr double Gconst = 6.67430e-8;
+constexpr double ev2erg = 1.602176634e-12;
+constexpr double MeV2eV = 1.0e6;
+constexpr double MeV2erg = MeV2eV * ev2erg;
+constexpr double parsec = 3.085677581467192e18;
+constexpr double AU = 1.495978707e13;
+constexpr double M_solar = 1.98841e33;
+constexpr double R_solar = 6.957e10;
+constexpr double L_solar = 3.828e33;
 } // namespace C
 
 using Real = amrex::Real;
+
+// reference src/math/math_impl.hpp:15-18
+AMREX_GPU_HOST_DEVICE inline auto clamp(double v, double lo, double hi) -> double { return (v < lo) ? lo : (hi < v) ? hi : v; }
+template <typename T> AMREX_GPU_HOST_DEVICE constexpr auto sgn(T val) -> int { return (T(0) < val) - (val < T(0)); }
 
 struct Physics_NumVars {
 	static const int numHydroVars = 6;
@@ -67,33 +86,38 @@ template <typename problem_t> struct EOS_Traits {
 // quokka::EOS<problem_t> (reference src/hydro/EOS.hpp:40-244), host side, for problem generators: the direct gamma-law forms the
 // kernels use (p = (gamma - 1) rho e, e = p / ((gamma - 1) rho); DESIGN.md section 4 on the un-vendored Microphysics EOS)
 template <typename problem_t> struct EOS {
+	static constexpr int nmscalars_ = Physics_Traits<problem_t>::numMassScalars;
+	using MassScalars = std::optional<amrex::GpuArray<amrex::Real, nmscalars_>>; // EOS.hpp:45-66 (the gamma-law EOS ignores them)
 	static constexpr double gamma_ = EOS_Traits<problem_t>::gamma;
 	static constexpr double mu_ = EOS_Traits<problem_t>::mean_molecular_weight / C::m_u;
 	static constexpr double kB_ = EOS_Traits<problem_t>::boltzmann_constant;
-	static auto ComputeEintFromPres(double rho, double Pressure) -> double
+	AMREX_GPU_HOST_DEVICE static auto ComputeEintFromPres(double rho, double Pressure, MassScalars const & /*massScalars*/ = {}) -> double
 	{
 		double const e = Pressure / ((gamma_ - 1.0) * rho);
 		return e * rho;
 	}
-	static auto ComputePressure(double rho, double Eint) -> double
+	AMREX_GPU_HOST_DEVICE static auto ComputePressure(double rho, double Eint, MassScalars const & /*massScalars*/ = {}) -> double
 	{
 		double const e = Eint / rho;
 		return ((gamma_ - 1.0) * rho * e) * kB_ / C::k_B;
 	}
-	static auto ComputeTgasFromEint(double rho, double Eint) -> double
+	AMREX_GPU_HOST_DEVICE static auto ComputeTgasFromEint(double rho, double Eint, MassScalars const & /*massScalars*/ = {}) -> double
 	{
 		double const e = Eint / rho;
 		return (e * mu_ * C::m_u * (gamma_ - 1.0) / C::k_B) * C::k_B / kB_;
 	}
-	static auto ComputeEintFromTgas(double rho, double Tgas) -> double { return gammaLawEintFromTgas(rho, Tgas); }
-	static auto ComputeEintTempDerivative(double rho, double Tgas) -> double
+	AMREX_GPU_HOST_DEVICE static auto ComputeEintFromTgas(double rho, double Tgas, MassScalars const & /*massScalars*/ = {}) -> double
+	{
+		return gammaLawEintFromTgas(rho, Tgas);
+	}
+	AMREX_GPU_HOST_DEVICE static auto ComputeEintTempDerivative(double rho, double Tgas, MassScalars const & /*massScalars*/ = {}) -> double
 	{
 		double const p = rho * Tgas * C::k_B / (mu_ * C::m_u);
 		double const e = p / ((gamma_ - 1.0) * rho);
 		return (e / Tgas) * rho * kB_ / C::k_B;
 	}
 	// (not a hook: what ComputeEintFromTgas is unless a problem specialises it — qkhost::traits() tells the two apart with it)
-	static auto gammaLawEintFromTgas(double rho, double Tgas) -> double
+	AMREX_GPU_HOST_DEVICE static auto gammaLawEintFromTgas(double rho, double Tgas) -> double
 	{
 		double const p = rho * Tgas * C::k_B / (mu_ * C::m_u);
 		double const e = p / ((gamma_ - 1.0) * rho);
@@ -165,12 +189,31 @@ template <typename problem_t> auto eosTemperatureModel() -> std::pair<int, doubl
 	amrex::Abort("quokka::EOS: these temperature hooks are not expressible in the C-ABI's closed set (gamma law, E = alpha / 4 T^4)");
 	return {0, 0.0};
 }
+// members a problem's EOS_Traits specialisation may leave out (the reference only reads them in the branches that need them)
+template <typename T, typename = void> struct CsIsoOf {
+	static constexpr double value = std::numeric_limits<double>::quiet_NaN();
+};
+template <typename T> struct CsIsoOf<T, std::void_t<decltype(T::cs_isothermal)>> {
+	static constexpr double value = T::cs_isothermal;
+};
+template <typename T, typename = void> struct MuOf {
+	static constexpr double value = std::numeric_limits<double>::quiet_NaN();
+};
+template <typename T> struct MuOf<T, std::void_t<decltype(T::mean_molecular_weight)>> {
+	static constexpr double value = T::mean_molecular_weight;
+};
+template <typename T, typename = void> struct KbOf {
+	static constexpr double value = C::k_B;
+};
+template <typename T> struct KbOf<T, std::void_t<decltype(T::boltzmann_constant)>> {
+	static constexpr double value = T::boltzmann_constant;
+};
 template <typename problem_t> auto traits() -> qk_hydro_traits
 {
 	return {quokka::EOS_Traits<problem_t>::gamma,
-		quokka::EOS_Traits<problem_t>::cs_isothermal,
-		quokka::EOS_Traits<problem_t>::mean_molecular_weight,
-		quokka::EOS_Traits<problem_t>::boltzmann_constant,
+		CsIsoOf<quokka::EOS_Traits<problem_t>>::value,
+		MuOf<quokka::EOS_Traits<problem_t>>::value,
+		KbOf<quokka::EOS_Traits<problem_t>>::value,
 		HydroSystem_Traits<problem_t>::reconstruct_eint ? 1 : 0,
 		Physics_Traits<problem_t>::numPassiveScalars,
 		Physics_Traits<problem_t>::numMassScalars,
@@ -218,6 +261,42 @@ template <typename problem_t> class HydroSystem : public HyperbolicSystem<proble
 	static constexpr bool reconstruct_eint = HydroSystem_Traits<problem_t>::reconstruct_eint;
 
 	static auto lev() -> qk_level * { return qkhost::Runtime::get().lev; }
+
+	// per-cell functions problems call inside their own device lambdas (ErrorEst, diagnostics): hydro_system.hpp:349-394, with the direct
+	// gamma-law forms of the library (qk_device.hpp consPressure / Eos::soundSpeed)
+	AMREX_GPU_HOST_DEVICE static auto ComputePressure(amrex::Array4<const amrex::Real> const &cons, int i, int j, int k) -> amrex::Real
+	{
+		const auto rho = cons(i, j, k, density_index);
+		if constexpr (gamma_ == 1.0) {
+			return rho * qkhost::CsIsoOf<quokka::EOS_Traits<problem_t>>::value * qkhost::CsIsoOf<quokka::EOS_Traits<problem_t>>::value;
+		}
+		const auto vx = cons(i, j, k, x1Momentum_index) / rho;
+		const auto vy = cons(i, j, k, x2Momentum_index) / rho;
+		const auto vz = cons(i, j, k, x3Momentum_index) / rho;
+		const auto kinetic_energy = 0.5 * rho * (vx * vx + vy * vy + vz * vz);
+		const auto thermal_energy = cons(i, j, k, energy_index) - kinetic_energy;
+		const auto e = (rho == 0.0) ? 0.0 : thermal_energy / rho;
+		return (gamma_ - 1.0) * rho * e;
+	}
+	AMREX_GPU_HOST_DEVICE static auto ComputeSoundSpeed(amrex::Array4<const amrex::Real> const &cons, int i, int j, int k) -> amrex::Real
+	{
+		if constexpr (gamma_ == 1.0) {
+			return qkhost::CsIsoOf<quokka::EOS_Traits<problem_t>>::value;
+		}
+		return std::sqrt(gamma_ * ComputePressure(cons, i, j, k) / cons(i, j, k, density_index));
+	}
+	AMREX_GPU_HOST_DEVICE static auto ComputeVelocityX1(amrex::Array4<const amrex::Real> const &cons, int i, int j, int k) -> amrex::Real
+	{
+		return cons(i, j, k, x1Momentum_index) / cons(i, j, k, density_index);
+	}
+	AMREX_GPU_HOST_DEVICE static auto ComputeVelocityX2(amrex::Array4<const amrex::Real> const &cons, int i, int j, int k) -> amrex::Real
+	{
+		return cons(i, j, k, x2Momentum_index) / cons(i, j, k, density_index);
+	}
+	AMREX_GPU_HOST_DEVICE static auto ComputeVelocityX3(amrex::Array4<const amrex::Real> const &cons, int i, int j, int k) -> amrex::Real
+	{
+		return cons(i, j, k, x3Momentum_index) / cons(i, j, k, density_index);
+	}
 
 	static void ConservedToPrimitive(amrex::MultiFab const &cons, amrex::MultiFab &prim, int nghost)
 	{
@@ -312,6 +391,16 @@ static constexpr double c_light_cgs_ = C::c_light;
 static constexpr double radiation_constant_cgs_ = C::a_rad;
 
 // this struct is specialized by the user application code (reference src/radiation/radiation_system.hpp:73-82)
+// radiation_system.hpp:63-70
+enum class OpacityModel { single_group = 0, piecewise_constant_opacity, PPL_opacity_fixed_slope_spectrum, PPL_opacity_full_spectrum };
+
+// radiation_system.hpp:86-90
+template <typename problem_t> struct ISM_Traits {
+	static constexpr bool enable_dust_gas_thermal_coupling_model = false;
+	static constexpr bool enable_photoelectric_heating = false;
+	static constexpr double gas_dust_coupling_threshold = 1.0e-6;
+};
+
 template <typename problem_t> struct RadSystem_Traits {
 	static constexpr double c_light = c_light_cgs_;
 	static constexpr double c_hat = c_light_cgs_;
@@ -340,10 +429,22 @@ template <typename problem_t> class RadSystem : public HyperbolicSystem<problem_
 	static constexpr int beta_order_ = static_cast<int>(RadSystem_Traits<problem_t>::beta_order);
 
 	// device hooks a problem may specialise (:1141-1154, :582-587)
-	static auto ComputePlanckOpacity(double rho, double Tgas) -> amrex::Real;
-	static auto ComputeFluxMeanOpacity(double rho, double Tgas) -> amrex::Real;
-	static auto ComputeEnergyMeanOpacity(double rho, double Tgas) -> amrex::Real;
-	static auto ComputeEddingtonFactor(double f) -> double; // :773-790 (default: Levermore closure)
+	static constexpr int nGroups_ = Physics_Traits<problem_t>::nGroups;
+	// radiation_system.hpp:1289-1308
+	AMREX_GPU_HOST_DEVICE static auto ComputeEintFromEgas(double density, double X1GasMom, double X2GasMom, double X3GasMom, double Etot) -> double
+	{
+		const double p_sq = X1GasMom * X1GasMom + X2GasMom * X2GasMom + X3GasMom * X3GasMom;
+		return Etot - p_sq / (2.0 * density);
+	}
+	AMREX_GPU_HOST_DEVICE static auto ComputeEgasFromEint(double density, double X1GasMom, double X2GasMom, double X3GasMom, double Eint) -> double
+	{
+		const double p_sq = X1GasMom * X1GasMom + X2GasMom * X2GasMom + X3GasMom * X3GasMom;
+		return Eint + p_sq / (2.0 * density);
+	}
+	AMREX_GPU_HOST_DEVICE static auto ComputePlanckOpacity(double rho, double Tgas) -> amrex::Real;
+	AMREX_GPU_HOST_DEVICE static auto ComputeFluxMeanOpacity(double rho, double Tgas) -> amrex::Real;
+	AMREX_GPU_HOST_DEVICE static auto ComputeEnergyMeanOpacity(double rho, double Tgas) -> amrex::Real;
+	AMREX_GPU_HOST_DEVICE static auto ComputeEddingtonFactor(double f) -> double; // :773-790 (default: Levermore closure)
 	static void SetRadEnergySource(array_t &radEnergySource, amrex::Box const &indexRange, amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> const &dx,
 				       amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> const &prob_lo, amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> const &prob_hi,
 				       amrex::Real time);
@@ -481,19 +582,19 @@ template <typename problem_t> class RadSystem : public HyperbolicSystem<problem_
 	}
 };
 
-template <typename problem_t> auto RadSystem<problem_t>::ComputePlanckOpacity(const double /*rho*/, const double /*Tgas*/) -> amrex::Real
+template <typename problem_t> AMREX_GPU_HOST_DEVICE auto RadSystem<problem_t>::ComputePlanckOpacity(const double /*rho*/, const double /*Tgas*/) -> amrex::Real
 {
 	return std::numeric_limits<double>::quiet_NaN();
 }
-template <typename problem_t> auto RadSystem<problem_t>::ComputeFluxMeanOpacity(const double rho, const double Tgas) -> amrex::Real
+template <typename problem_t> AMREX_GPU_HOST_DEVICE auto RadSystem<problem_t>::ComputeFluxMeanOpacity(const double rho, const double Tgas) -> amrex::Real
 {
 	return ComputePlanckOpacity(rho, Tgas);
 }
-template <typename problem_t> auto RadSystem<problem_t>::ComputeEnergyMeanOpacity(const double rho, const double Tgas) -> amrex::Real
+template <typename problem_t> AMREX_GPU_HOST_DEVICE auto RadSystem<problem_t>::ComputeEnergyMeanOpacity(const double rho, const double Tgas) -> amrex::Real
 {
 	return ComputePlanckOpacity(rho, Tgas);
 }
-template <typename problem_t> auto RadSystem<problem_t>::ComputeEddingtonFactor(double f_in) -> double
+template <typename problem_t> AMREX_GPU_HOST_DEVICE auto RadSystem<problem_t>::ComputeEddingtonFactor(double f_in) -> double
 {
 	// f is the reduced flux == |F|/cE; compute Levermore (1984) closure [Eq. 25] (reference src/radiation/radiation_system.hpp:773-790)
 	const double f = std::clamp(f_in, 0., 1.);
@@ -509,7 +610,40 @@ void RadSystem<problem_t>::SetRadEnergySource(array_t & /*radEnergySource*/, amr
 	// do nothing -- user implemented
 }
 
+// per-problem user data a problem may specialise (reference src/simulation.hpp: SimulationData<problem_t> userData_)
+template <typename problem_t> struct SimulationData {
+};
+
 template <typename problem_t> class AmrDriver; // quokka_amr.hpp
+template <typename problem_t> class AMRSimulation;
+
+#if defined(QK_DEVICE_LAMBDAS)
+namespace qkhost
+{
+template <typename problem_t>
+__global__ void customBcKernel(amrex::Array4<amrex::Real> dest, amrex::Box fab, amrex::GeometryData geom, amrex::Real time, const amrex::BCRec *bcr, int ncomp, int per0,
+			       int per1, int per2)
+{
+	const amrex::Long n = static_cast<amrex::Long>(blockIdx.x) * blockDim.x + threadIdx.x;
+	if (n >= fab.numPts()) {
+		return;
+	}
+	const int nx = fab.length(0), ny = fab.length(1);
+	const int k = static_cast<int>(n / (static_cast<amrex::Long>(nx) * ny));
+	const int r = static_cast<int>(n - static_cast<amrex::Long>(k) * nx * ny);
+	const int j = r / nx;
+	const amrex::IntVect iv(fab.lo[0] + (r - j * nx), fab.lo[1] + j, fab.lo[2] + k);
+	const int per[3] = {per0, per1, per2};
+	bool outside = false;
+	for (int d = 0; d < AMREX_SPACEDIM; ++d) {
+		outside = outside || (per[d] == 0 && (iv[d] < geom.domain.lo[d] || iv[d] > geom.domain.hi[d]));
+	}
+	if (outside) {
+		AMRSimulation<problem_t>::setCustomBoundaryConditions(iv, dest, 0, ncomp, geom, time, bcr, 0, 0);
+	}
+}
+} // namespace qkhost
+#endif
 
 // one refinement level handed to a simulation object by the AMR driver (quokka_amr.hpp): geometry of that level and its boxes
 struct LevelSpec {
@@ -547,7 +681,22 @@ template <typename problem_t> class AMRSimulation
 	amrex::Vector<amrex::Geometry> geom{1};
 	std::vector<amrex::Box> grids_; // level-0 BoxArray
 	amrex::Vector<amrex::BCRec> BCs_cc_;
-	amrex::Vector<amrex::MultiFab> state_new_cc_{1}, state_old_cc_{1};
+	// One simulation object holds ONE level (the AMR driver of quokka_amr.hpp owns one object per level): whatever level index a
+	// problem's hook uses (state_new_cc_[lev] inside ErrorEst(lev, ...), geom[lev]) addresses this object's level.
+	template <typename T> struct ThisLevel {
+		T item;
+		auto operator[](int /*lev*/) -> T & { return item; }
+		auto operator[](int /*lev*/) const -> T const & { return item; }
+		[[nodiscard]] auto size() const -> int { return 1; }
+	};
+	ThisLevel<amrex::MultiFab> state_new_cc_, state_old_cc_;
+	[[nodiscard]] auto boxArray(int /*lev*/ = 0) const -> std::vector<amrex::Box> const & { return grids_; }
+	[[nodiscard]] auto DistributionMap(int /*lev*/ = 0) const -> amrex::DistributionMapping { return {}; }
+	[[nodiscard]] auto finestLevel() const -> int { return 0; }
+	[[nodiscard]] auto Geom(int /*lev*/ = 0) const -> amrex::Geometry const & { return geom[0]; }
+	[[nodiscard]] auto Geom(int /*lev*/ = 0) -> amrex::Geometry & { return geom[0]; }
+	SimulationData<problem_t> userData_;
+	static constexpr int nvarTotal_cc_ = Physics_Indices<problem_t>::nvarTotal_cc;
 
 	explicit AMRSimulation(amrex::Vector<amrex::BCRec> &BCs_cc) : BCs_cc_(BCs_cc) { initialize(nullptr); }
 	AMRSimulation(amrex::Vector<amrex::BCRec> &BCs_cc, LevelSpec const &spec) : BCs_cc_(BCs_cc) { initialize(&spec); }
@@ -570,8 +719,8 @@ template <typename problem_t> class AMRSimulation
 	// called between FillBoundary and the physical boundaries: the AMR driver interpolates the uncovered ghost cells here
 	std::function<void(amrex::MultiFab &)> beforePhysBC_;
 
-	// device hook a problem may specialise (reference src/simulation.hpp:1550-1561); evaluated on host staging data
-	static void setCustomBoundaryConditions(const amrex::IntVect & /*iv*/, amrex::Array4<amrex::Real> const & /*dest*/, int /*dcomp*/, int /*numcomp*/,
+	// device hook a problem may specialise (reference src/simulation.hpp:1550-1561); host mode: evaluated on host staging data
+	AMREX_GPU_DEVICE static void setCustomBoundaryConditions(const amrex::IntVect & /*iv*/, amrex::Array4<amrex::Real> const & /*dest*/, int /*dcomp*/, int /*numcomp*/,
 						amrex::GeometryData const & /*geom*/, amrex::Real /*time*/, const amrex::BCRec * /*bcr*/, int /*bcomp*/,
 						int /*orig_comp*/)
 	{
@@ -695,11 +844,17 @@ template <typename problem_t> class AMRSimulation
 		auto &mf = state_new_cc_[0];
 		if (restart_chkfile.empty()) {
 			for (int b = 0; b < mf.size(); ++b) {
+#if defined(QK_DEVICE_LAMBDAS)
+				// device mode: the problem's ParallelFor runs as a kernel on the level's own arrays
+				quokka::grid grid_elem{mf.array(b), mf.validbox(b), geom[0].CellSizeArray(), geom[0].ProbLoArray(), geom[0].ProbHiArray()};
+				setInitialConditionsOnGrid(grid_elem);
+#else
 				std::vector<double> h(static_cast<size_t>(mf.fabbox(b).numPts()) * mf.nComp(), 0.0);
 				quokka::grid grid_elem{amrex::Array4<double>(h.data(), mf.fabbox(b), mf.nComp()), mf.validbox(b), geom[0].CellSizeArray(),
 						       geom[0].ProbLoArray(), geom[0].ProbHiArray()};
 				setInitialConditionsOnGrid(grid_elem);
 				mf.copyFromHost(b, h);
+#endif
 			}
 		} else {
 			// level 0 of ReadCheckpointFile (reference src/simulation.hpp:2736-2801): the BoxArray comes from the deck, the data by
@@ -721,11 +876,16 @@ template <typename problem_t> class AMRSimulation
 	{
 		auto &mf = state_new_cc_[0];
 		for (int b = 0; b < mf.size(); ++b) {
+#if defined(QK_DEVICE_LAMBDAS)
+			quokka::grid grid_elem{mf.array(b), mf.validbox(b), geom[0].CellSizeArray(), geom[0].ProbLoArray(), geom[0].ProbHiArray()};
+			setInitialConditionsOnGrid(grid_elem);
+#else
 			std::vector<double> h(static_cast<size_t>(mf.fabbox(b).numPts()) * mf.nComp(), 0.0);
 			quokka::grid grid_elem{amrex::Array4<double>(h.data(), mf.fabbox(b), mf.nComp()), mf.validbox(b), geom[0].CellSizeArray(),
 					       geom[0].ProbLoArray(), geom[0].ProbHiArray()};
 			setInitialConditionsOnGrid(grid_elem);
 			mf.copyFromHost(b, h);
+#endif
 		}
 		amrex::MultiFab::Copy(state_old_cc_[0], state_new_cc_[0]);
 		areInitialConditionsDefined_ = true;
@@ -757,8 +917,44 @@ template <typename problem_t> class AMRSimulation
 			}
 			qkhost::check(qk_FillPhysicalBoundary(plan_, nullptr, qkhost::tab(state), bcs.data(), hasDirichlet_ ? dirichlet_ : nullptr),
 				      "FillPhysicalBoundary");
+#if defined(QK_DEVICE_LAMBDAS)
+			customBoundaryConditionsOnDevice(state);
+#endif
 		}
 	}
+#if defined(QK_DEVICE_LAMBDAS)
+	// setCustomBoundaryConditions as the reference runs it (simulation.hpp:297-299, :1550-1561; amrex::GpuBndryFuncFab): the problem's
+	// DEVICE function is called for every ghost cell that lies outside the domain in a non-periodic direction, after the mathematical
+	// boundary types have been filled.  One kernel instantiated with the problem type per box — arbitrary boundary code, not the closed
+	// Dirichlet / Marshak set of the C-ABI (which host-mode problems are sampled into).
+	void customBoundaryConditionsOnDevice(amrex::MultiFab &state)
+	{
+		if (d_bcrec_ == nullptr) {
+			QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_bcrec_), sizeof(amrex::BCRec) * BCs_cc_.size()));
+			QK_HOST_HIP(hipMemcpy(d_bcrec_, BCs_cc_.data(), sizeof(amrex::BCRec) * BCs_cc_.size(), hipMemcpyHostToDevice));
+		}
+		auto const gd = geom[0].data();
+		int per[3] = {1, 1, 1};
+		for (int d = 0; d < AMREX_SPACEDIM; ++d) {
+			per[d] = geom[0].isPeriodic(d) ? 1 : 0;
+		}
+		for (int b = 0; b < state.size(); ++b) {
+			amrex::Box const fb = state.fabbox(b);
+			bool touches = false;
+			for (int d = 0; d < AMREX_SPACEDIM; ++d) {
+				touches = touches || (per[d] == 0 && (fb.lo[d] < gd.domain.lo[d] || fb.hi[d] > gd.domain.hi[d]));
+			}
+			if (!touches) {
+				continue;
+			}
+			amrex::Long const n = fb.numPts();
+			hipLaunchKernelGGL(qkhost::customBcKernel<problem_t>, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, nullptr, state.array(b), fb, gd,
+					   bcFillTime(), d_bcrec_, state.nComp(), per[0], per[1], per[2]);
+		}
+	}
+	amrex::BCRec *d_bcrec_ = nullptr;
+#endif
+	[[nodiscard]] virtual auto bcFillTime() const -> double { return tNew_[0]; }
 
       protected:
 	qk_level *myLev_ = nullptr;
@@ -773,6 +969,10 @@ template <typename problem_t> class AMRSimulation
 	// on the interior the closed set knows.
 	void buildDirichletModel()
 	{
+#if defined(QK_DEVICE_LAMBDAS)
+		// device mode: setCustomBoundaryConditions is device code and runs as a kernel after every fill (customBoundaryConditionsOnDevice)
+		return;
+#else
 		int const nc = Physics_Indices<problem_t>::nvarTotal_cc;
 		auto const &g = geom[0];
 		double const sentinel = -7.7e300;
@@ -862,6 +1062,7 @@ template <typename problem_t> class AMRSimulation
 				}
 			}
 		}
+	#endif
 	}
 };
 
@@ -912,7 +1113,9 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 
 	// --- AMR level bookkeeping (used by quokka_amr.hpp; a uniform-grid run leaves the defaults)
 	double tOldLev_ = 0.0, tNewLev_ = 0.0; // tOld_[lev], tNew_[lev]
+	bool use_wavespeed_correction_ = false; // QuokkaSimulation.hpp:133 (not implemented: must stay false)
 	double fillTime_ = 0.0;		       // the time a ghost fill refers to (coarse data are interpolated to it)
+	[[nodiscard]] auto bcFillTime() const -> double override { return fillTime_; }
 	bool storeFluxRk2_ = false;	       // keep flux_rk2 = 0.5 F1 + 0.5 F2 (rk2flux_) for the flux registers
 	std::function<void(double)> afterAdvance_; // incrementFluxRegisters(dt) after every successful advanceHydroAtLevel
 	std::function<void(int)> beforeAttempt_;   // flux registers: save before the retry loop (0), back to that state at every retry (>0)
@@ -1044,6 +1247,12 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	void setInitialConditionsOnGrid(quokka::grid const &grid_elem) override;
 	void preCalculateInitialConditions() override;
 	void computeAfterEvolve(amrex::Vector<amrex::Real> &initSumCons) override;
+	void computeAfterTimestep(); // reference src/simulation.hpp:228, :890 (default: nothing)
+	// Strang-split source terms a problem may add (QuokkaSimulation.hpp:235): called with dt/2 on the old state before the hydro update and on
+	// the new state after it (:1048, :1318)
+	void addStrangSplitSources(amrex::MultiFab &state, int lev, amrex::Real time, amrex::Real dt_lev);
+	void createInitialParticles();
+	void computeBeforeTimestep();
 	void computeReferenceSolution(amrex::MultiFab & /*ref*/, amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> const & /*dx*/,
 				      amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> const & /*prob_lo*/)
 	{
@@ -1172,6 +1381,8 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	auto advanceHydroAtLevel(amrex::MultiFab &state_old_cc_tmp, double time, double dt_lev) -> bool
 	{
 		haveSignal_ = false;
+		// first half of the Strang-split source terms, on the (temporary) old state (reference src/QuokkaSimulation.hpp:1048)
+		addStrangSplitSources(state_old_cc_tmp, 0, time, 0.5 * dt_lev);
 		fillTime_ = time; // reference src/QuokkaSimulation.hpp:1076 (stage 1), :1204 (stage 2: time + dt_lev)
 		this->fillBoundaryConditions(state_old_cc_tmp);
 		if (!stage(1, state_old_cc_tmp, state_old_cc_tmp, state_inter_cc_, dt_lev)) {
@@ -1192,6 +1403,10 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 			amrex::Abort("density is negative in SyncDualEnergy! abort!!");
 		}
 		bool const ok = !isCflViolated(dt_lev);
+		if (ok) { // second half, on the new state (:1318)
+			addStrangSplitSources(state_new_cc_[0], 0, time + dt_lev, 0.5 * dt_lev);
+			haveSignal_ = false;
+		}
 		if (ok && afterAdvance_) {
 			afterAdvance_(dt_lev); // incrementFluxRegisters (reference src/QuokkaSimulation.hpp:1303-1306)
 		}
@@ -1217,6 +1432,14 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	void fillRadEnergySource(double time)
 	{
 		auto const &g = geom[0];
+#if defined(QK_DEVICE_LAMBDAS)
+		// device mode: the problem's SetRadEnergySource launches its own kernel on the source array, every call (as the reference does)
+		for (int b = 0; b < radEnergySource_.size(); ++b) {
+			auto arr = radEnergySource_.array(b);
+			RadSystem<problem_t>::SetRadEnergySource(arr, radEnergySource_.validbox(b), g.CellSizeArray(), g.ProbLoArray(), g.ProbHiArray(), time);
+		}
+		return;
+#endif
 		auto eval = [&](int b, double t) {
 			std::vector<double> h(static_cast<size_t>(radEnergySource_.fabbox(b).numPts()), 0.0);
 			amrex::Array4<double> a(h.data(), radEnergySource_.fabbox(b), 1);
@@ -1539,6 +1762,14 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 
 template <typename problem_t> void QuokkaSimulation<problem_t>::preCalculateInitialConditions() {}
 
+template <typename problem_t> void QuokkaSimulation<problem_t>::computeAfterTimestep() {}
+template <typename problem_t> void QuokkaSimulation<problem_t>::computeBeforeTimestep() {}
+template <typename problem_t> void QuokkaSimulation<problem_t>::createInitialParticles() {}
+template <typename problem_t>
+void QuokkaSimulation<problem_t>::addStrangSplitSources(amrex::MultiFab & /*state*/, int /*lev*/, amrex::Real /*time*/, amrex::Real /*dt_lev*/)
+{
+}
+
 // generic computeAfterEvolve: relative rms L1 error norm vs the problem's reference solution (reference src/QuokkaSimulation.hpp:620-644)
 template <typename problem_t> void QuokkaSimulation<problem_t>::computeAfterEvolve(amrex::Vector<amrex::Real> & /*initSumCons*/)
 {
@@ -1556,7 +1787,7 @@ template <typename problem_t> void QuokkaSimulation<problem_t>::computeAfterEvol
 			auto hs = state_new_cc_[0].copyToHost(b);
 			amrex::Array4<double> r(hr.data(), ref.fabbox(b), ncomp);
 			amrex::Array4<double> s(hs.data(), state_new_cc_[0].fabbox(b), ncomp);
-			amrex::ParallelFor(ref.validbox(b), [&](int i, int j, int k) {
+			amrex::HostFor(ref.validbox(b), [&](int i, int j, int k) {
 				rn += std::abs(r(i, j, k, n));
 				en += std::abs(r(i, j, k, n) - s(i, j, k, n));
 			});

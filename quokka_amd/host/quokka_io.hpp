@@ -160,7 +160,7 @@ inline void VisMFWrite(amrex::MultiFab const &mf, std::string const &prefix, boo
 		amrex::Array4<double> s(h.data(), src, nc), d(buf.data(), out, nc);
 		std::vector<double> mn(nc, std::numeric_limits<double>::max()), mx(nc, std::numeric_limits<double>::lowest());
 		for (int n = 0; n < nc; ++n) {
-			amrex::ParallelFor(out, [&](int i, int j, int k) {
+			amrex::HostFor(out, [&](int i, int j, int k) {
 				double const v = s(i, j, k, n);
 				d(i, j, k, n) = v;
 				mn[n] = std::min(mn[n], v);
@@ -312,7 +312,7 @@ inline void VisMFReadInto(amrex::MultiFab &dst, std::string const &prefix)
 				}
 				amrex::Array4<const double> s(src.fabs[f].data(), src.fabboxes[f], nc);
 				for (int n = 0; n < nc; ++n) {
-					amrex::ParallelFor(isect, [&](int i, int j, int k) { d(i, j, k, n) = s(i, j, k, n); });
+					amrex::HostFor(isect, [&](int i, int j, int k) { d(i, j, k, n) = s(i, j, k, n); });
 				}
 			}
 		}
