@@ -27,6 +27,7 @@
 #include "grid.hpp"
 #include "hydro.hpp"
 #include "radiation.hpp"
+#include "radiation_multigroup.hpp"
 
 namespace oracle
 {
@@ -595,7 +596,7 @@ struct HydroSim {
 	[[nodiscard]] auto computeRadiationFluxes(Array4<const double> const &consVar, Box const &indexRange) const -> RadFluxes
 	{
 		RadFluxes out;
-		const int nvars = kNumRadVars;
+		const int nvars = rad.nRadComps(); // Physics_NumVars::numRadVars * nGroups
 		for (int dir = 0; dir < ndim(); ++dir) {
 			Box const ghostRange = grow(indexRange, nghost_cc, ndim());
 			Box const reconstructRange = grow(indexRange, 1, ndim());
@@ -657,13 +658,17 @@ struct HydroSim {
 	void operatorSplitSourceTerms(double time, double dt, int stage)
 	{
 		for (int b = 0; b < state_new_cc_.size(); ++b) {
-			Fab<double> radEnergySource(grids[b], 1, 0.0);
+			Fab<double> radEnergySource(grids[b], rad.nGroups_(), 0.0); // :1866-1869 (nGroups components)
 			if (SetRadEnergySource) {
 				SetRadEnergySource(radEnergySource.array(), grids[b], geom, time + dt);
 			}
 			int counter[4] = {0, 0, 0, 0};
 			int failure[3] = {0, 0, 0};
-			rad.AddSourceTermsSingleGroup(state_new_cc_.array(b), radEnergySource.const_array(), grids[b], dt, stage, counter, failure);
+			if (rad.nGroups_() <= 1) { // :1875-1881
+				rad.AddSourceTermsSingleGroup(state_new_cc_.array(b), radEnergySource.const_array(), grids[b], dt, stage, counter, failure);
+			} else {
+				mg::MG(rad).AddSourceTermsMultiGroup(state_new_cc_.array(b), radEnergySource.const_array(), grids[b], dt, stage, counter, failure);
+			}
 			rad_iteration_counter[0] += counter[0];
 			rad_iteration_counter[1] += counter[1];
 			rad_iteration_counter[2] = std::max<long>(rad_iteration_counter[2], counter[2]);
@@ -697,7 +702,7 @@ struct HydroSim {
 					auto d = state_old_cc_.array(b);
 					auto s = state_new_cc_.const_array(b);
 					Box const &r = grids[b];
-					for (int n = rad.nstartHyperbolic_; n < rad.nstartHyperbolic_ + kNumRadVars; ++n) {
+					for (int n = rad.nstartHyperbolic_; n < rad.nstartHyperbolic_ + rad.nRadComps(); ++n) {
 						for (int k = r.lo[2]; k <= r.hi[2]; ++k) {
 							for (int j = r.lo[1]; j <= r.hi[1]; ++j) {
 								for (int ii = r.lo[0]; ii <= r.hi[0]; ++ii) {

@@ -96,6 +96,76 @@ void orc_compute_hydro_fluxes(orc_hydro_traits const *t, int order, double K_vis
 	}
 }
 
+// ------------------------------------------------------------------ multigroup helper functions (unit checks against independent formulas)
+double orc_planck_integral(double x) { return planck::integrate_planck_from_0_to_x(x); }
+double orc_planck_table_entry(int j) { return planck::Y_interp[j]; }
+
+static auto mgSystem(int ngroups, double const *boundaries, double energy_unit, double k_B, double a_rad, double Erad_floor, int opacity_model) -> RadSystem
+{
+	RadSystem rs;
+	rs.rt.nGroups = ngroups;
+	rs.rt.radBoundaries.assign(boundaries, boundaries + ngroups + 1);
+	rs.rt.energy_unit = energy_unit;
+	rs.rt.radiation_constant = a_rad;
+	rs.rt.Erad_floor = Erad_floor;
+	rs.rt.opacity_model = opacity_model;
+	rs.eos.tr.boltzmann_constant = k_B;
+	return rs;
+}
+// ComputePlanckEnergyFractions / ComputeThermalRadiationMultiGroup (fractions, then E_g = max(a T^4 fraction_g, floor / nGroups))
+void orc_planck_fractions(int ngroups, double const *boundaries, double energy_unit, double k_B, double a_rad, double Erad_floor, double T, double *fractions,
+			  double *Erad_g)
+{
+	RadSystem const rs = mgSystem(ngroups, boundaries, energy_unit, k_B, a_rad, Erad_floor, 1);
+	mg::MG const m(rs);
+	auto const f = m.ComputePlanckEnergyFractions(m.boundaries(), T);
+	auto const E = m.ComputeThermalRadiationMultiGroup(T, m.boundaries());
+	for (int g = 0; g < ngroups; ++g) {
+		fractions[g] = f[g];
+		Erad_g[g] = E[g];
+	}
+}
+double orc_planck_function(double energy_unit, double k_B, double a_rad, double nu, double T)
+{
+	double const b[2] = {1., 2.};
+	RadSystem const rs = mgSystem(1, b, energy_unit, k_B, a_rad, 0., 1);
+	return mg::MG(rs).PlanckFunction(nu, T);
+}
+void orc_group_mean_opacity(int ngroups, double const *boundaries, double const *expo, double const *lower, double const *alpha_quant, double *kappa)
+{
+	RadSystem const rs = mgSystem(ngroups, boundaries, 1., 1., 1., 0., 2);
+	mg::MG const m(rs);
+	mg::KappaExpoLower kel;
+	kel.expo = mg::VA(ngroups + 1);
+	kel.lower = mg::VA(ngroups + 1);
+	mg::VA ratios(ngroups), alpha(ngroups);
+	for (int g = 0; g < ngroups + 1; ++g) {
+		kel.expo[g] = expo[g];
+		kel.lower[g] = lower[g];
+	}
+	for (int g = 0; g < ngroups; ++g) {
+		ratios[g] = boundaries[g + 1] / boundaries[g];
+		alpha[g] = alpha_quant[g];
+	}
+	auto const k = m.ComputeGroupMeanOpacity(kel, ratios, alpha);
+	for (int g = 0; g < ngroups; ++g) {
+		kappa[g] = k[g];
+	}
+}
+void orc_rad_quantity_exponents(int ngroups, double const *boundaries, double const *quant, double *exponents)
+{
+	RadSystem const rs = mgSystem(ngroups, boundaries, 1., 1., 1., 0., 3);
+	mg::MG const m(rs);
+	mg::VA q(ngroups);
+	for (int g = 0; g < ngroups; ++g) {
+		q[g] = quant[g];
+	}
+	auto const e = m.ComputeRadQuantityExponents(q, m.boundaries());
+	for (int g = 0; g < ngroups; ++g) {
+		exponents[g] = e[g];
+	}
+}
+
 // ------------------------------------------------------------------ whole-simulation handle
 struct orc_sim_config {
 	int problem; // 0 = Sod, 1 = contact, 2 = Sedov
@@ -118,6 +188,8 @@ struct orc_sim_config {
 	// problem 7 (parametrised 1-D hydro test): gamma, x_split, left[3], right[3], cfl, max_dt, init_dt, stop_time | profile, dirichlet
 	double h1d[12];
 	int h1d_i[2];
+	double const *table_extra; // problem 17 (RadTube): fourth column of extern/pressure_tube/initial_conditions.txt (x, rho, Pgas, Erad)
+	int opacity_model;	   // problems 16 / 18: OpacityModel override (<= 0: the problem file's choice)
 };
 
 // OpenMP team size for everything that follows (small problems run faster on one thread: every parallel region costs a barrier over
@@ -193,6 +265,18 @@ void *orc_sim_create(orc_sim_config const *c)
 		sim->rad.rt.pow_mode = c->rad_pow_mode;
 	} else if (c->problem == 4) {
 		setupRadShock(*sim);
+		sim->rad.rt.pow_mode = c->rad_pow_mode;
+	} else if (c->problem == 16) {
+		setupRadShockMG(*sim, c->opacity_model > 0 ? c->opacity_model : static_cast<int>(PPL_opacity_fixed_slope_spectrum));
+		sim->rad.rt.pow_mode = c->rad_pow_mode;
+	} else if (c->problem == 17) {
+		setupRadTube(*sim, c->table_len, c->table_r, c->table_Erad, c->table_Frad, c->table_extra);
+		sim->rad.rt.pow_mode = c->rad_pow_mode;
+	} else if (c->problem == 18) {
+		setupMarshakVaytet(*sim, c->opacity_model > 0 ? c->opacity_model : static_cast<int>(PPL_opacity_full_spectrum));
+		sim->rad.rt.pow_mode = c->rad_pow_mode;
+	} else if (c->problem == 19 || c->problem == 20) {
+		setupPulseMG(*sim, c->problem == 19);
 		sim->rad.rt.pow_mode = c->rad_pow_mode;
 	} else {
 		return nullptr;

@@ -1464,4 +1464,6 @@ inline void setupShocktubeCMA(HydroSim &sim)
 
 } // namespace oracle
 
+#include "problems_multigroup.hpp"
+
 #endif // ORACLE_PROBLEMS_HPP_

@@ -20,6 +20,10 @@ K_B = 1.380649e-16
 M_U = 1.6605390666e-24
 
 SOD, CONTACT, SEDOV, SHELL, RADSHOCK, STREAMING, SCALARS, HYDRO1D, COUPLING, SUOLSON, ADVECTING, MARSHAK, RADFORCE, MARSHAK_ASYMPTOTIC, RADPULSE, SHOCKTUBE_CMA = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15
+# multigroup radiation (oracle/problems_multigroup.hpp); PULSE_MG = the advecting 4-group run, PULSE_MG_GREY = the static grey run of the same file
+RADSHOCK_MG, RADTUBE, MARSHAK_VAYTET, PULSE_MG, PULSE_MG_GREY = 16, 17, 18, 19, 20
+# OpacityModel (radiation_system.hpp:64-71)
+PIECEWISE_CONSTANT, PPL_FIXED_SLOPE, PPL_FULL_SPECTRUM = 1, 2, 3
 
 
 def build(force: bool = False) -> None:
@@ -67,6 +71,8 @@ class SimConfig(C.Structure):
         ("rad_pow_mode", C.c_int),
         ("h1d", C.c_double * 12),
         ("h1d_i", C.c_int * 2),
+        ("table_extra", C.POINTER(C.c_double)),
+        ("opacity_model", C.c_int),
     ]
 
 
@@ -127,6 +133,42 @@ class Oracle:
         L.orc_sim_tag_relative_gradient.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p]
         L.orc_sim_tag_centered_gradient.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p]
         L.orc_sim_rad_source.argtypes = [C.c_void_p, C.c_int, C.c_double, C.POINTER(C.c_double)]
+        D, DP = C.c_double, C.POINTER(C.c_double)
+        L.orc_planck_integral.argtypes, L.orc_planck_integral.restype = [D], D
+        L.orc_planck_table_entry.argtypes, L.orc_planck_table_entry.restype = [C.c_int], D
+        L.orc_planck_fractions.argtypes = [C.c_int, DP, D, D, D, D, D, DP, DP]
+        L.orc_planck_function.argtypes, L.orc_planck_function.restype = [D, D, D, D, D], D
+        L.orc_group_mean_opacity.argtypes = [C.c_int, DP, DP, DP, DP, DP]
+        L.orc_rad_quantity_exponents.argtypes = [C.c_int, DP, DP, DP]
+
+    # ---------------------------------------------------------------- multigroup helper functions
+    def planck_integral(self, x: float) -> float:
+        return self.lib.orc_planck_integral(float(x))
+
+    def planck_table(self) -> np.ndarray:
+        return np.array([self.lib.orc_planck_table_entry(j) for j in range(1000)])
+
+    def planck_fractions(self, boundaries, energy_unit, k_B, a_rad, Erad_floor, T):
+        b = np.ascontiguousarray(boundaries, dtype=np.float64)
+        n = len(b) - 1
+        f, E = np.empty(n), np.empty(n)
+        self.lib.orc_planck_fractions(n, _dp(b), energy_unit, k_B, a_rad, Erad_floor, T, _dp(f), _dp(E))
+        return f, E
+
+    def planck_function(self, energy_unit, k_B, a_rad, nu, T) -> float:
+        return self.lib.orc_planck_function(energy_unit, k_B, a_rad, nu, T)
+
+    def group_mean_opacity(self, boundaries, expo, lower, alpha_quant) -> np.ndarray:
+        b, e, l, a = (np.ascontiguousarray(v, dtype=np.float64) for v in (boundaries, expo, lower, alpha_quant))
+        k = np.empty(len(b) - 1)
+        self.lib.orc_group_mean_opacity(len(b) - 1, _dp(b), _dp(e), _dp(l), _dp(a), _dp(k))
+        return k
+
+    def rad_quantity_exponents(self, boundaries, quant) -> np.ndarray:
+        b, q = (np.ascontiguousarray(v, dtype=np.float64) for v in (boundaries, quant))
+        e = np.empty(len(q))
+        self.lib.orc_rad_quantity_exponents(len(q), _dp(b), _dp(q), _dp(e))
+        return e
 
     # ---------------------------------------------------------------- per-operator
     def cons_to_prim(self, t: HydroTraits, cons: np.ndarray, glo, ghi) -> np.ndarray:
@@ -183,7 +225,8 @@ class Oracle:
                                  _i3(clo), _i3(chi), fine.shape[0], _i3(region[0]), _i3(region[1]), w_old, w_new, ncomp, method, int(hooks), ndim, _i3(ratio))
 
     def sim(self, problem, ndim, n_cell, prob_lo, prob_hi, periodic, max_grid_size=None, cfl=-1.0, stop_time=-1.0,
-            max_timesteps=-1, reconstruction_order=-1, nscalars=0, table=None, rad_pow_mode=0, hydro1d=None, beta_order=0, c_hat_factor=0.0) -> "OracleSim":
+            max_timesteps=-1, reconstruction_order=-1, nscalars=0, table=None, rad_pow_mode=0, hydro1d=None, beta_order=0, c_hat_factor=0.0,
+            opacity_model=0) -> "OracleSim":
         if ndim == 2:
             # AMREX_SPACEDIM == 2 builds of the reference use util/ArrayView_2d.hpp (X2 view = index SWAP, velV = vx, velW = vz),
             # not the cyclic permutation of ArrayView_3d.hpp restated here: a 2-D oracle would not be the reference's algorithm
@@ -196,9 +239,12 @@ class Oracle:
         if table is not None:  # (r_over_r0, Erad, Frad) columns
             cols = [np.ascontiguousarray(c, dtype=np.float64) for c in table]
             cfg.table_len = len(cols[0])
-            cfg.table_r, cfg.table_Erad, cfg.table_Frad = (_dp(c) for c in cols)
+            cfg.table_r, cfg.table_Erad, cfg.table_Frad = (_dp(c) for c in cols[:3])
+            if len(cols) > 3:  # RADTUBE: (x, rho, Pgas, Erad)
+                cfg.table_extra = _dp(cols[3])
             self._keepalive = cols
         cfg.rad_pow_mode = rad_pow_mode
+        cfg.opacity_model = int(opacity_model)
         if hydro1d is not None:  # dict: gamma, profile, x_split, left, right, dirichlet, cfl, max_dt, init_dt, stop_time (see oracle/problems.hpp Hydro1DSpec)
             h = hydro1d
             vals = [h["gamma"], h.get("x_split", 0.0)] + list(h.get("left", [0, 0, 0])) + list(h.get("right", [0, 0, 0])) + \

@@ -1,11 +1,13 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see grid.hpp header).
 //
-// radiation.hpp: restatement of the single-group two-moment (M1) radiation operators
+// radiation.hpp: restatement of the two-moment (M1) radiation operators
 //   reference src/radiation/radiation_system.hpp            (RadSystem<problem_t>, line refs per function)
 //   reference src/radiation/source_terms_single_group.hpp   (AddSourceTermsSingleGroup)
-// nGroups = 1, no dust / photoelectric / line-cooling models (ISM_Traits defaults), OpacityModel::single_group.
-// The device hooks a problem specialises (ComputePlanckOpacity / ComputeEnergyMeanOpacity / ComputeFluxMeanOpacity)
-// are std::function members here.
+// The transport operators (ConservedToPrimitive, ComputeFluxes, PredictStep, AddFluxesRK2) run over rt.nGroups photon groups, group g
+// occupying components nstartHyperbolic_ + 4 g .. + 4 g + 3 (Physics_Indices, physics_info.hpp:20-47).  The single-group source term is
+// here; the multigroup one (source_terms_multi_group.hpp) is in radiation_multigroup.hpp.  No dust / photoelectric / line-cooling models
+// (ISM_Traits defaults).  The device hooks a problem specialises (ComputePlanckOpacity / ComputeEnergyMeanOpacity /
+// ComputeFluxMeanOpacity / DefineOpacityExponentsAndLowerValues) are std::function members here.
 #ifndef ORACLE_RADIATION_HPP_
 #define ORACLE_RADIATION_HPP_
 
@@ -13,6 +15,7 @@
 #include <cmath>
 #include <functional>
 #include <limits>
+#include <vector>
 
 #include "eos.hpp"
 #include "grid.hpp"
@@ -31,6 +34,10 @@ constexpr bool include_work_term_in_source = true;
 constexpr bool enable_dE_constrain = true; // :44
 
 constexpr int kNumRadVars = 4; // physics_numVars.hpp:9
+constexpr int kMaxGroups = 64;  // (oracle storage bound; the reference's nGroups is a compile-time constant)
+
+// OpacityModel (radiation_system.hpp:64-71)
+enum OpacityModel { single_group = 0, piecewise_constant_opacity = 1, PPL_opacity_fixed_slope_spectrum = 2, PPL_opacity_full_spectrum = 3 };
 
 // runtime stand-in for RadSystem_Traits<problem_t> (radiation_system.hpp:73-82)
 struct RadTraits {
@@ -45,6 +52,11 @@ struct RadTraits {
 	// the ComputeEddingtonFactor hook (radiation_system.hpp:773-790 is the default, Levermore's closure); problems that specialise it
 	// use the Eddington approximation chi = 1/3 (e.g. src/problems/RadhydroShockCGS/test_radhydro_shock_cgs.cpp:88-91)
 	int eddington_model = 0; // 0: Levermore, 1: chi = 1/3
+	// multigroup (Physics_Traits::nGroups, RadSystem_Traits::radBoundaries / energy_unit / opacity_model; radiation_system.hpp:201-223)
+	int nGroups = 1;
+	std::vector<double> radBoundaries; // nGroups + 1 group edges, in units of energy_unit / h ... (energy = energy_unit * boundary)
+	double energy_unit = C::hplanck;
+	int opacity_model = single_group;
 };
 
 struct RadSystem {
@@ -55,6 +67,13 @@ struct RadSystem {
 	std::function<double(double, double)> ComputePlanckOpacity;	 // radiation_system.hpp:1141
 	std::function<double(double, double)> ComputeFluxMeanOpacity;	 // :1146 (default: Planck)
 	std::function<double(double, double)> ComputeEnergyMeanOpacity; // :1151 (default: Planck)
+	// :1155-1167 DefineOpacityExponentsAndLowerValues(rad_boundaries, rho, Tgas) -> (exponents[nGroups+1], lower values[nGroups+1])
+	std::function<void(double const *rad_boundaries, double rho, double Tgas, double *exponents, double *lower_values)> DefineOpacityExponentsAndLowerValues;
+
+	[[nodiscard]] auto nGroups_() const -> int { return rt.nGroups; }
+	[[nodiscard]] auto nRadComps() const -> int { return kNumRadVars * rt.nGroups; }
+	// :211
+	[[nodiscard]] auto Erad_floor_() const -> double { return rt.Erad_floor / rt.nGroups; }
 
 	// radVarIndex (radiation_system.hpp:183)
 	[[nodiscard]] auto radEnergy_index() const -> int { return nstartHyperbolic_; }
@@ -69,8 +88,8 @@ struct RadSystem {
 	[[nodiscard]] auto ComputeThermalRadiationSingleGroup(double temperature) const -> double
 	{
 		double power = rt.radiation_constant * pow4(temperature);
-		if (power < rt.Erad_floor) {
-			power = rt.Erad_floor;
+		if (power < Erad_floor_()) {
+			power = Erad_floor_();
 		}
 		return power;
 	}
@@ -154,49 +173,59 @@ struct RadSystem {
 		for (int k = indexRange.lo[2]; k <= indexRange.hi[2]; ++k) {
 			for (int j = indexRange.lo[1]; j <= indexRange.hi[1]; ++j) {
 				for (int i = indexRange.lo[0]; i <= indexRange.hi[0]; ++i) {
-					const auto E_r = cons(i, j, k, radEnergy_index());
-					const auto Fx = cons(i, j, k, x1RadFlux_index());
-					const auto Fy = cons(i, j, k, x2RadFlux_index());
-					const auto Fz = cons(i, j, k, x3RadFlux_index());
-					primVar(i, j, k, 0) = E_r;
-					primVar(i, j, k, 1) = Fx / (rt.c_light * E_r);
-					primVar(i, j, k, 2) = Fy / (rt.c_light * E_r);
-					primVar(i, j, k, 3) = Fz / (rt.c_light * E_r);
+					for (int g = 0; g < nGroups_(); ++g) {
+						const auto E_r = cons(i, j, k, radEnergy_index() + kNumRadVars * g);
+						const auto Fx = cons(i, j, k, x1RadFlux_index() + kNumRadVars * g);
+						const auto Fy = cons(i, j, k, x2RadFlux_index() + kNumRadVars * g);
+						const auto Fz = cons(i, j, k, x3RadFlux_index() + kNumRadVars * g);
+						primVar(i, j, k, 0 + kNumRadVars * g) = E_r;
+						primVar(i, j, k, 1 + kNumRadVars * g) = Fx / (rt.c_light * E_r);
+						primVar(i, j, k, 2 + kNumRadVars * g) = Fy / (rt.c_light * E_r);
+						primVar(i, j, k, 3 + kNumRadVars * g) = Fz / (rt.c_light * E_r);
+					}
 				}
 			}
 		}
 	}
 
+	using RadCons = std::array<double, kNumRadVars * kMaxGroups>; // std::array<Real, nvarHyperbolic_>
+
 	// :626-644
-	[[nodiscard]] auto isStateValid(std::array<double, 4> const &cons) const -> bool
+	[[nodiscard]] auto isStateValid(RadCons const &cons) const -> bool
 	{
-		const auto E_r = cons[0];
-		const auto Fx = cons[1];
-		const auto Fy = cons[2];
-		const auto Fz = cons[3];
-		const auto Fnorm = std::sqrt(Fx * Fx + Fy * Fy + Fz * Fz);
-		const auto f = Fnorm / (rt.c_light * E_r);
-		bool isNonNegative = (E_r > 0.);
-		bool isFluxCausal = (f <= 1.);
-		return (isNonNegative && isFluxCausal);
+		bool isValid = true;
+		for (int g = 0; g < nGroups_(); ++g) {
+			const auto E_r = cons[0 + kNumRadVars * g];
+			const auto Fx = cons[1 + kNumRadVars * g];
+			const auto Fy = cons[2 + kNumRadVars * g];
+			const auto Fz = cons[3 + kNumRadVars * g];
+			const auto Fnorm = std::sqrt(Fx * Fx + Fy * Fy + Fz * Fz);
+			const auto f = Fnorm / (rt.c_light * E_r);
+			bool isNonNegative = (E_r > 0.);
+			bool isFluxCausal = (f <= 1.);
+			isValid = (isValid && isNonNegative && isFluxCausal);
+		}
+		return isValid;
 	}
 
 	// :646-665
-	void amendRadState(std::array<double, 4> &cons) const
+	void amendRadState(RadCons &cons) const
 	{
-		auto E_r = cons[0];
-		if (E_r < rt.Erad_floor) {
-			E_r = rt.Erad_floor;
-			cons[0] = rt.Erad_floor;
-		}
-		const auto Fx = cons[1];
-		const auto Fy = cons[2];
-		const auto Fz = cons[3];
-		if (Fx * Fx + Fy * Fy + Fz * Fz > rt.c_light * rt.c_light * E_r * E_r) {
-			const auto Fnorm = std::sqrt(Fx * Fx + Fy * Fy + Fz * Fz);
-			cons[1] = Fx / Fnorm * rt.c_light * E_r;
-			cons[2] = Fy / Fnorm * rt.c_light * E_r;
-			cons[3] = Fz / Fnorm * rt.c_light * E_r;
+		for (int g = 0; g < nGroups_(); ++g) {
+			auto E_r = cons[0 + kNumRadVars * g];
+			if (E_r < Erad_floor_()) {
+				E_r = Erad_floor_();
+				cons[0 + kNumRadVars * g] = Erad_floor_();
+			}
+			const auto Fx = cons[1 + kNumRadVars * g];
+			const auto Fy = cons[2 + kNumRadVars * g];
+			const auto Fz = cons[3 + kNumRadVars * g];
+			if (Fx * Fx + Fy * Fy + Fz * Fz > rt.c_light * rt.c_light * E_r * E_r) {
+				const auto Fnorm = std::sqrt(Fx * Fx + Fy * Fy + Fz * Fz);
+				cons[1 + kNumRadVars * g] = Fx / Fnorm * rt.c_light * E_r;
+				cons[2 + kNumRadVars * g] = Fy / Fnorm * rt.c_light * E_r;
+				cons[3 + kNumRadVars * g] = Fz / Fnorm * rt.c_light * E_r;
+			}
 		}
 	}
 
@@ -217,71 +246,75 @@ struct RadSystem {
 				for (int i_in = indexRange.lo[0]; i_in <= indexRange.hi[0]; ++i_in) {
 					auto [i, j, k] = reorderMultiIndex(dir, i_in, j_in, k_in);
 
-					double erad_L = x1LeftState(i, j, k, 0);
-					double erad_R = x1RightState(i, j, k, 0);
-					double fx_L = x1LeftState(i, j, k, 1);
-					double fx_R = x1RightState(i, j, k, 1);
-					double fy_L = x1LeftState(i, j, k, 2);
-					double fy_R = x1RightState(i, j, k, 2);
-					double fz_L = x1LeftState(i, j, k, 3);
-					double fz_R = x1RightState(i, j, k, 3);
+					for (int g = 0; g < nGroups_(); ++g) {
+						const int pg = kNumRadVars * g; // component offset of group g
 
-					double f_L = std::sqrt(fx_L * fx_L + fy_L * fy_L + fz_L * fz_L);
-					double f_R = std::sqrt(fx_R * fx_R + fy_R * fy_R + fz_R * fz_R);
+						double erad_L = x1LeftState(i, j, k, pg + 0);
+						double erad_R = x1RightState(i, j, k, pg + 0);
+						double fx_L = x1LeftState(i, j, k, pg + 1);
+						double fx_R = x1RightState(i, j, k, pg + 1);
+						double fy_L = x1LeftState(i, j, k, pg + 2);
+						double fy_R = x1RightState(i, j, k, pg + 2);
+						double fz_L = x1LeftState(i, j, k, pg + 3);
+						double fz_R = x1RightState(i, j, k, pg + 3);
 
-					double Fx_L = fx_L * (c_light_ * erad_L);
-					double Fx_R = fx_R * (c_light_ * erad_R);
-					double Fy_L = fy_L * (c_light_ * erad_L);
-					double Fy_R = fy_R * (c_light_ * erad_R);
-					double Fz_L = fz_L * (c_light_ * erad_L);
-					double Fz_R = fz_R * (c_light_ * erad_R);
+						double f_L = std::sqrt(fx_L * fx_L + fy_L * fy_L + fz_L * fz_L);
+						double f_R = std::sqrt(fx_R * fx_R + fy_R * fy_R + fz_R * fz_R);
 
-					// :1054-1079 first-order fallback
-					if ((erad_L <= 0.) || (erad_R <= 0.) || (f_L >= 1.) || (f_R >= 1.)) {
-						erad_L = consVar(i - 1, j, k, radEnergy_index());
-						erad_R = consVar(i, j, k, radEnergy_index());
-						Fx_L = consVar(i - 1, j, k, x1RadFlux_index());
-						Fx_R = consVar(i, j, k, x1RadFlux_index());
-						Fy_L = consVar(i - 1, j, k, x2RadFlux_index());
-						Fy_R = consVar(i, j, k, x2RadFlux_index());
-						Fz_L = consVar(i - 1, j, k, x3RadFlux_index());
-						Fz_R = consVar(i, j, k, x3RadFlux_index());
-						fx_L = Fx_L / (c_light_ * erad_L);
-						fx_R = Fx_R / (c_light_ * erad_R);
-						fy_L = Fy_L / (c_light_ * erad_L);
-						fy_R = Fy_R / (c_light_ * erad_R);
-						fz_L = Fz_L / (c_light_ * erad_L);
-						fz_R = Fz_R / (c_light_ * erad_R);
-						f_L = std::sqrt(fx_L * fx_L + fy_L * fy_L + fz_L * fz_L);
-						f_R = std::sqrt(fx_R * fx_R + fy_R * fy_R + fz_R * fz_R);
-					}
+						double Fx_L = fx_L * (c_light_ * erad_L);
+						double Fx_R = fx_R * (c_light_ * erad_R);
+						double Fy_L = fy_L * (c_light_ * erad_L);
+						double Fy_R = fy_R * (c_light_ * erad_R);
+						double Fz_L = fz_L * (c_light_ * erad_L);
+						double Fz_R = fz_R * (c_light_ * erad_R);
 
-					auto [F_L, S_L] = ComputeRadPressure(dir, erad_L, Fx_L, Fy_L, Fz_L, fx_L, fy_L, fz_L);
-					S_L *= -1.;
-					auto [F_R, S_R] = ComputeRadPressure(dir, erad_R, Fx_R, Fy_R, Fz_R, fx_R, fy_R, fz_R);
+						// :1054-1079 first-order fallback
+						if ((erad_L <= 0.) || (erad_R <= 0.) || (f_L >= 1.) || (f_R >= 1.)) {
+							erad_L = consVar(i - 1, j, k, radEnergy_index() + pg);
+							erad_R = consVar(i, j, k, radEnergy_index() + pg);
+							Fx_L = consVar(i - 1, j, k, x1RadFlux_index() + pg);
+							Fx_R = consVar(i, j, k, x1RadFlux_index() + pg);
+							Fy_L = consVar(i - 1, j, k, x2RadFlux_index() + pg);
+							Fy_R = consVar(i, j, k, x2RadFlux_index() + pg);
+							Fz_L = consVar(i - 1, j, k, x3RadFlux_index() + pg);
+							Fz_R = consVar(i, j, k, x3RadFlux_index() + pg);
+							fx_L = Fx_L / (c_light_ * erad_L);
+							fx_R = Fx_R / (c_light_ * erad_R);
+							fy_L = Fy_L / (c_light_ * erad_L);
+							fy_R = Fy_R / (c_light_ * erad_R);
+							fz_L = Fz_L / (c_light_ * erad_L);
+							fz_R = Fz_R / (c_light_ * erad_R);
+							f_L = std::sqrt(fx_L * fx_L + fy_L * fy_L + fz_L * fz_L);
+							f_R = std::sqrt(fx_R * fx_R + fy_R * fy_R + fz_R * fz_R);
+						}
 
-					// :1087-1094
-					F_L[0] *= c_hat_ / c_light_;
-					F_R[0] *= c_hat_ / c_light_;
-					for (int n = 1; n < kNumRadVars; ++n) {
-						F_L[n] *= c_hat_ * c_light_;
-						F_R[n] *= c_hat_ * c_light_;
-					}
-					S_L *= c_hat_;
-					S_R *= c_hat_;
+						auto [F_L, S_L] = ComputeRadPressure(dir, erad_L, Fx_L, Fy_L, Fz_L, fx_L, fy_L, fz_L);
+						S_L *= -1.;
+						auto [F_R, S_R] = ComputeRadPressure(dir, erad_R, Fx_R, Fy_R, Fz_R, fx_R, fy_R, fz_R);
 
-					const std::array<double, 4> U_L = {erad_L, Fx_L, Fy_L, Fz_L};
-					const std::array<double, 4> U_R = {erad_R, Fx_R, Fy_R, Fz_R};
-					const std::array<double, 4> epsilon = {1.0, 1.0, 1.0, 1.0};
+						// :1087-1094
+						F_L[0] *= c_hat_ / c_light_;
+						F_R[0] *= c_hat_ / c_light_;
+						for (int n = 1; n < kNumRadVars; ++n) {
+							F_L[n] *= c_hat_ * c_light_;
+							F_R[n] *= c_hat_ * c_light_;
+						}
+						S_L *= c_hat_;
+						S_R *= c_hat_;
 
-					// :1116-1117, :1130-1131
-					for (int n = 0; n < kNumRadVars; ++n) {
-						const double F = (S_R / (S_R - S_L)) * F_L[n] - (S_L / (S_R - S_L)) * F_R[n] +
-								 epsilon[n] * (S_R * S_L / (S_R - S_L)) * (U_R[n] - U_L[n]);
-						const double diffusiveF =
-						    (S_R / (S_R - S_L)) * F_L[n] - (S_L / (S_R - S_L)) * F_R[n] + (S_R * S_L / (S_R - S_L)) * (U_R[n] - U_L[n]);
-						x1Flux(i, j, k, n) = F;
-						x1FluxDiffusive(i, j, k, n) = diffusiveF;
+						const std::array<double, 4> U_L = {erad_L, Fx_L, Fy_L, Fz_L};
+						const std::array<double, 4> U_R = {erad_R, Fx_R, Fy_R, Fz_R};
+						const std::array<double, 4> epsilon = {1.0, 1.0, 1.0, 1.0};
+
+						// :1116-1117, :1130-1131
+						for (int n = 0; n < kNumRadVars; ++n) {
+							const double F = (S_R / (S_R - S_L)) * F_L[n] - (S_L / (S_R - S_L)) * F_R[n] +
+									 epsilon[n] * (S_R * S_L / (S_R - S_L)) * (U_R[n] - U_L[n]);
+							const double diffusiveF =
+							    (S_R / (S_R - S_L)) * F_L[n] - (S_L / (S_R - S_L)) * F_R[n] + (S_R * S_L / (S_R - S_L)) * (U_R[n] - U_L[n]);
+							x1Flux(i, j, k, pg + n) = F;
+							x1FluxDiffusive(i, j, k, pg + n) = diffusiveF;
+						}
 					}
 				}
 			}
@@ -295,8 +328,8 @@ struct RadSystem {
 		for (int k = indexRange.lo[2]; k <= indexRange.hi[2]; ++k) {
 			for (int j = indexRange.lo[1]; j <= indexRange.hi[1]; ++j) {
 				for (int i = indexRange.lo[0]; i <= indexRange.hi[0]; ++i) {
-					std::array<double, 4> cons{};
-					for (int n = 0; n < kNumRadVars; ++n) {
+					RadCons cons{};
+					for (int n = 0; n < nRadComps(); ++n) {
 						double d = (dt / dx_in[0]) * (fluxArray[0](i, j, k, n) - fluxArray[0](i + 1, j, k, n));
 						if (ndim >= 2) {
 							d = d + (dt / dx_in[1]) * (fluxArray[1](i, j, k, n) - fluxArray[1](i, j + 1, k, n));
@@ -309,7 +342,7 @@ struct RadSystem {
 					if (!isStateValid(cons)) {
 						amendRadState(cons);
 					}
-					for (int n = 0; n < kNumRadVars; ++n) {
+					for (int n = 0; n < nRadComps(); ++n) {
 						consVarNew(i, j, k, nstartHyperbolic_ + n) = cons[n];
 					}
 				}
@@ -325,8 +358,8 @@ struct RadSystem {
 		for (int k = indexRange.lo[2]; k <= indexRange.hi[2]; ++k) {
 			for (int j = indexRange.lo[1]; j <= indexRange.hi[1]; ++j) {
 				for (int i = indexRange.lo[0]; i <= indexRange.hi[0]; ++i) {
-					std::array<double, 4> cons_new{};
-					for (int n = 0; n < kNumRadVars; ++n) {
+					RadCons cons_new{};
+					for (int n = 0; n < nRadComps(); ++n) {
 						const double U_0 = U0(i, j, k, nstartHyperbolic_ + n);
 						const double U_1 = U1(i, j, k, nstartHyperbolic_ + n);
 						double s0 = (dt / dx_in[0]) * (fluxArrayOld[0](i, j, k, n) - fluxArrayOld[0](i + 1, j, k, n));
@@ -345,7 +378,7 @@ struct RadSystem {
 					if (!isStateValid(cons_new)) {
 						amendRadState(cons_new);
 					}
-					for (int n = 0; n < kNumRadVars; ++n) {
+					for (int n = 0; n < nRadComps(); ++n) {
 						U_new(i, j, k, nstartHyperbolic_ + n) = cons_new[n];
 					}
 				}
@@ -380,7 +413,7 @@ struct RadSystem {
 		}
 		const double gamma_ = eos.tr.gamma;
 		const int beta_order_ = rt.beta_order;
-		const double Erad_floor_ = rt.Erad_floor;
+		const double Erad_floor_ = this->Erad_floor_();
 		const double radiation_constant_ = rt.radiation_constant;
 		const double c_light_ = rt.c_light;
 
