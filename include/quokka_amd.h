@@ -211,13 +211,16 @@ typedef struct qk_hydro_stage_args {
 int64_t qk_hydro_stage_scratch_bytes(qk_level *lev, const qk_hydro_traits *t);
 int qk_hydro_stage_fused(qk_level *lev, qk_stream s, const qk_hydro_traits *t, const qk_hydro_stage_args *a);
 
-/* ------------------------------------------------------------------ RadSystem<problem_t> (single group, M1 closure) */
-/* RadSystem_Traits<P> (reference src/radiation/radiation_system.hpp:73-82) + the device hooks a problem specialises
- * (ComputePlanckOpacity / ComputeEnergyMeanOpacity / ComputeFluxMeanOpacity, :1141-1154) as a closed parametrised set. */
+/* ------------------------------------------------------------------ RadSystem<problem_t> (M1 closure, 1 .. QK_MAX_GROUPS photon groups) */
+#define QK_MAX_GROUPS 8
+/* RadSystem_Traits<P> (reference src/radiation/radiation_system.hpp:73-82, :201-223) + the device hooks a problem specialises
+ * (ComputePlanckOpacity / ComputeEnergyMeanOpacity / ComputeFluxMeanOpacity, :1141-1154; DefineOpacityExponentsAndLowerValues, :1155-1167)
+ * as closed parametrised sets. */
 typedef struct qk_rad_traits {
 	double c_light, c_hat, radiation_constant, Erad_floor;
-	int beta_order;	   /* 0..3 */
-	int opacity_model; /* 0: constants kappaP, kappaE, kappaF [cm^2 g^-1] (what RadhydroShell needs);
+	int beta_order;	   /* 0..3 (multigroup: 0 or 1, source_terms_multi_group.hpp:526) */
+	int opacity_model; /* SINGLE GROUP (ngroups == 1, OpacityModel::single_group):
+			    * 0: constants kappaP, kappaE, kappaF [cm^2 g^-1] (what RadhydroShell needs);
 			    * 1: kappa = kappaX / rho, a constant absorption coefficient [cm^-1] (RadhydroShockCGS, test_radhydro_shock_cgs.cpp:78-86)
 			    * 2: temperature power law  kappa = kappaX * max(pow(T / opacity_T_ref, opacity_T_exponent), opacity_pow_floor) / rho
 			    *    (RadMarshakAsymptotic test_radiation_marshak_asymptotic.cpp:55-59: exponent -3; RadhydroPulseGrey: -3.5 with
@@ -227,10 +230,24 @@ typedef struct qk_rad_traits {
 		       * 3, -3 and -3.5 are then products / square roots as well) */
 	int eddington_model; /* the ComputeEddingtonFactor hook: 0 Levermore closure (radiation_system.hpp:773-790), 1 chi = 1/3 */
 	double opacity_T_ref, opacity_T_exponent, opacity_pow_floor; /* opacity_model 2 only (floor 0: none) */
+	/* MULTIGROUP (Physics_Traits<P>::nGroups > 1; 0 is read as 1).  Group g owns state components radFirstIndex + 4 g .. + 4 g + 3. */
+	int ngroups;
+	int mg_opacity_model; /* OpacityModel (radiation_system.hpp:64-71): 1 piecewise_constant_opacity, 2 PPL_opacity_fixed_slope_spectrum,
+			       * 3 PPL_opacity_full_spectrum */
+	double energy_unit;			   /* RadSystem_Traits<P>::energy_unit: photon energy = energy_unit * boundary value */
+	double rad_boundaries[QK_MAX_GROUPS + 1]; /* RadSystem_Traits<P>::radBoundaries (ngroups + 1 increasing edges) */
+	/* DefineOpacityExponentsAndLowerValues(rad_boundaries, rho, T) as a closed set: for g = 0 .. ngroups
+	 *   exponent[g]    = mg_kappa_exponent[g]
+	 *   lower_value[g] = mg_kappa_lower[g] * pow(rho, mg_kappa_rho_exponent) * pow(T / mg_kappa_T_ref, mg_kappa_T_exponent)
+	 * (either power with exponent 0 is skipped, exponent -1 on rho is a division).  Covers RadhydroShockMultigroup (577 / rho, exponent 0),
+	 * RadTube / RadhydroPulseMGconst (constant), RadMarshakVaytet the_model 0 / 1 / 2 / 10 (kappa0 (nu_g / nu_pivot)^-2, exponent -2). */
+	double mg_kappa_exponent[QK_MAX_GROUPS + 1], mg_kappa_lower[QK_MAX_GROUPS + 1];
+	double mg_kappa_rho_exponent, mg_kappa_T_ref, mg_kappa_T_exponent;
 } qk_rad_traits;
-/* State layout: Physics_Indices (reference src/physics_info.hpp:20-47): comps 0..5 hydro, 6..9 = (E_r, F_x, F_y, F_z). */
+/* State layout: Physics_Indices (reference src/physics_info.hpp:20-47): comps 0..5 hydro, 6 + 4 g .. 9 + 4 g = (E_r, F_x, F_y, F_z) of group g.
+ * The operators below act on all groups (primVar / flux arrays carry 4 * ngroups components, group-major like the state). */
 
-/* ConservedToPrimitive(cons, primVar, indexRange = valid grown by nghost); primVar has 4 comps   reference src/radiation/radiation_system.hpp:589-614 */
+/* ConservedToPrimitive(cons, primVar, indexRange = valid grown by nghost); primVar has 4 * ngroups comps   reference src/radiation/radiation_system.hpp:589-614 */
 int qk_rad_ConservedToPrimitive(qk_level *lev, qk_stream s, const qk_rad_traits *rt, const qk_array4 *cons, qk_array4 *primVar, int nghost);
 /* ComputeFluxes<DIR>(x1Flux, x1FluxDiffusive (unused downstream: not produced), x1LeftState, x1RightState, x1FluxRange, consVar, dx,
  * use_wavespeed_correction = false)                                                              reference src/radiation/radiation_system.hpp:985-1139 */
@@ -246,12 +263,21 @@ int qk_rad_PredictStep(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int 
 /* AddFluxesRK2(U_new, U0, U1, fluxArrayOld, fluxArray, dt, dx, indexRange)                       reference src/radiation/radiation_system.hpp:712-771 */
 int qk_rad_AddFluxesRK2(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int ndim, qk_array4 *U_new, const qk_array4 *U0, const qk_array4 *U1,
 			const qk_array4 *const fluxArrayOld[3], const qk_array4 *const fluxArray[3], double dt, const double dx[3]);
-/* AddSourceTermsSingleGroup(consVar, radEnergySource, indexRange, dt, stage, dustGasCoeff, p_iteration_counter, p_iteration_failure_counter)
- *                                                                                                reference src/radiation/source_terms_single_group.hpp:10-564
+/* AddSourceTermsSingleGroup / AddSourceTermsMultiGroup(consVar, radEnergySource, indexRange, dt, stage, dustGasCoeff, p_iteration_counter,
+ * p_iteration_failure_counter)                                                                   reference src/radiation/source_terms_single_group.hpp:10-564
+ *                                                                                                reference src/radiation/source_terms_multi_group.hpp:522-813
+ * radEnergySource carries ngroups components.
  * d_iteration_counter: device int[4] (solves, Newton iterations, max Newton iterations, unused); d_failure_counter: device int[3]
  * (Newton failures, dust (unused), outer-iteration failures) — counted, never aborted, exactly as the reference. */
 int qk_rad_AddSourceTermsSingleGroup(qk_level *lev, qk_stream s, const qk_rad_traits *rt, const qk_hydro_traits *t, qk_array4 *consVar,
 				     const qk_array4 *radEnergySource, double dt, int stage, int *d_iteration_counter, int *d_failure_counter);
+/* ngroups in {2, 3, 4, 5, 6, 8} (each is its own kernel instantiation: the per-group vectors live in registers); gas + radiation only (no dust /
+ * photoelectric / cooling models, ISM_Traits defaults) */
+int qk_rad_AddSourceTermsMultiGroup(qk_level *lev, qk_stream s, const qk_rad_traits *rt, const qk_hydro_traits *t, qk_array4 *consVar,
+				    const qk_array4 *radEnergySource, double dt, int stage, int *d_iteration_counter, int *d_failure_counter);
+/* device-side helper functions of the multigroup path, exposed for unit checks (host arrays in, host arrays out; one tiny launch each):
+ * ComputePlanckEnergyFractions + ComputeThermalRadiationMultiGroup at temperature T (radiation_system.hpp:430-461, :483-497); kB = EOS_Traits::boltzmann_constant */
+int qk_rad_mg_planck_fractions(qk_ctx *ctx, const qk_rad_traits *rt, double kB, int n, const double *T, double *fractions, double *Erad_g);
 
 /* ------------------------------------------------------------------ level-0 ghost fill */
 /* AMRSimulation::fillBoundaryConditions, level-0 branch                     reference src/simulation.hpp:1751-1776
@@ -275,13 +301,20 @@ typedef struct qk_bcrec {
  * (src/problems/RadMarshak/test_radiation_marshak.cpp:125-141): after the constant state, the normal radiation flux of the ghost cell
  * becomes  0.5 c E_inc - 0.5 (c E_0 + 2 F_0)  with E_inc = values[marshak_energy_comp] and (E_0, F_0) = components
  * (marshak_energy_comp, marshak_flux_comp) of the first valid cell inside the face (same transverse indices). */
+#define QK_MAX_STATE_COMPS 48 /* 6 hydro + 3 scalars + 4 * QK_MAX_GROUPS radiation, rounded up */
 typedef struct qk_dirichlet_face {
 	int enabled;
-	double values[16];
+	double values[QK_MAX_STATE_COMPS];
 	int marshak;
 	int marshak_energy_comp;
 	int marshak_flux_comp;
 	double marshak_c;
+	/* RadTube's functor (src/problems/RadTube/test_radiation_tube.cpp:184-252): a component whose bit is set in interior_mask takes, instead of
+	 * the constant, the value of the first valid cell inside the face (same transverse indices) — there the normal momentum and the normal
+	 * radiation flux of every group.  kinetic_from_interior != 0: the total-energy component (4) becomes
+	 * values[5] + 0.5 m^2 / values[0], m = the momentum of that cell normal to the face (values[5] = the constant internal energy). */
+	uint64_t interior_mask;
+	int kinetic_from_interior;
 } qk_dirichlet_face;
 
 typedef struct qk_ghost_plan qk_ghost_plan;

@@ -350,6 +350,14 @@ void orc_sim_counters(void *p, long out[3])
 	out[1] = s->fofc2_cells;
 	out[2] = s->retries;
 }
+// the two transport stages of one radiation substep without the source terms (advanceRadiationForwardEuler + advanceRadiationMidpointRK2,
+// QuokkaSimulation.hpp:1790-1857), state_old = state_new on entry as after swapRadiationState
+void orc_sim_rad_transport_only(void *p, double dt_radiation)
+{
+	auto *s = static_cast<HydroSim *>(p);
+	s->advanceRadiationForwardEuler(s->tNew_, dt_radiation);
+	s->advanceRadiationMidpointRK2(s->tNew_, dt_radiation);
+}
 // one coarse step with the reference's own dt control; returns 1 on success
 int orc_sim_step(void *p)
 {

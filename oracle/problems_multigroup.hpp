@@ -332,8 +332,8 @@ inline void setupMarshakVaytet(HydroSim &sim, int opacity_model = PPL_opacity_fu
 
 	HydroSim *const simp = &sim;
 	EOS const eos = sim.hydro.tr.eos;
-	// setCustomBoundaryConditions :167-219 (both branches run whatever the BCRec of that side says; the upper side is foextrap, for which
-	// the functor is not called)
+	// setCustomBoundaryConditions :167-219 (the functor runs on every cell outside the domain and does not consult the BCRec: the foextrap
+	// record of the upper face is overwritten by the 300 K state)
 	sim.customBC = [simp, ng, eos](int i, int j, int k, Array4<double> const &consVar, Box const &dom, double /*time*/) {
 		if (i < dom.lo[0] || i >= dom.hi[0]) {
 			mg::MG const m(simp->rad);

@@ -133,6 +133,7 @@ class Oracle:
         L.orc_sim_tag_relative_gradient.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p]
         L.orc_sim_tag_centered_gradient.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p]
         L.orc_sim_rad_source.argtypes = [C.c_void_p, C.c_int, C.c_double, C.POINTER(C.c_double)]
+        L.orc_sim_rad_transport_only.argtypes = [C.c_void_p, C.c_double]
         D, DP = C.c_double, C.POINTER(C.c_double)
         L.orc_planck_integral.argtypes, L.orc_planck_integral.restype = [D], D
         L.orc_planck_table_entry.argtypes, L.orc_planck_table_entry.restype = [C.c_int], D
@@ -340,6 +341,9 @@ class OracleSim:
 
     def evolve(self) -> bool:
         return bool(self.o.lib.orc_sim_evolve(self.h))
+
+    def rad_transport_only(self, dt_radiation: float):
+        self.o.lib.orc_sim_rad_transport_only(self.h, float(dt_radiation))
 
     def set_rad_reconstruction_order(self, order: int):
         self.o.lib.orc_sim_set_rad_reconstruction_order.argtypes = [C.c_void_p, C.c_int]

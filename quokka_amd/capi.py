@@ -45,16 +45,38 @@ class BCRec(C.Structure):
     _fields_ = [("lo", C.c_int * 3), ("hi", C.c_int * 3)]
 
 
+MAX_GROUPS = 8        # QK_MAX_GROUPS
+MAX_STATE_COMPS = 48  # QK_MAX_STATE_COMPS
+
+
 class DirichletFace(C.Structure):
-    _fields_ = [("enabled", C.c_int), ("values", C.c_double * 16),
-                ("marshak", C.c_int), ("marshak_energy_comp", C.c_int), ("marshak_flux_comp", C.c_int), ("marshak_c", C.c_double)]
+    _fields_ = [("enabled", C.c_int), ("values", C.c_double * MAX_STATE_COMPS),
+                ("marshak", C.c_int), ("marshak_energy_comp", C.c_int), ("marshak_flux_comp", C.c_int), ("marshak_c", C.c_double),
+                ("interior_mask", C.c_uint64), ("kinetic_from_interior", C.c_int)]
 
 
 class RadTraits(C.Structure):
     _fields_ = [("c_light", C.c_double), ("c_hat", C.c_double), ("radiation_constant", C.c_double), ("Erad_floor", C.c_double),
                 ("beta_order", C.c_int), ("opacity_model", C.c_int), ("kappaP", C.c_double), ("kappaE", C.c_double), ("kappaF", C.c_double),
                 ("pow_mode", C.c_int), ("eddington_model", C.c_int),
-                ("opacity_T_ref", C.c_double), ("opacity_T_exponent", C.c_double), ("opacity_pow_floor", C.c_double)]
+                ("opacity_T_ref", C.c_double), ("opacity_T_exponent", C.c_double), ("opacity_pow_floor", C.c_double),
+                # multigroup (include/quokka_amd.h): Physics_Traits::nGroups, OpacityModel, energy_unit, radBoundaries and the
+                # DefineOpacityExponentsAndLowerValues closed set
+                ("ngroups", C.c_int), ("mg_opacity_model", C.c_int), ("energy_unit", C.c_double), ("rad_boundaries", C.c_double * (MAX_GROUPS + 1)),
+                ("mg_kappa_exponent", C.c_double * (MAX_GROUPS + 1)), ("mg_kappa_lower", C.c_double * (MAX_GROUPS + 1)),
+                ("mg_kappa_rho_exponent", C.c_double), ("mg_kappa_T_ref", C.c_double), ("mg_kappa_T_exponent", C.c_double)]
+
+    def set_groups(self, boundaries, energy_unit, opacity_model, kappa_exponent, kappa_lower, rho_exponent=0.0, T_ref=0.0, T_exponent=0.0):
+        """RadSystem_Traits<P>::radBoundaries / energy_unit / opacity_model + the DefineOpacityExponentsAndLowerValues hook (closed set)"""
+        ng = len(boundaries) - 1
+        assert 2 <= ng <= MAX_GROUPS and len(kappa_exponent) == len(kappa_lower) == ng + 1
+        self.ngroups, self.mg_opacity_model, self.energy_unit = ng, int(opacity_model), float(energy_unit)
+        for g in range(ng + 1):
+            self.rad_boundaries[g] = float(boundaries[g])
+            self.mg_kappa_exponent[g] = float(kappa_exponent[g])
+            self.mg_kappa_lower[g] = float(kappa_lower[g])
+        self.mg_kappa_rho_exponent, self.mg_kappa_T_ref, self.mg_kappa_T_exponent = float(rho_exponent), float(T_ref), float(T_exponent)
+        return self
 
 
 class StageArgs(C.Structure):
@@ -128,6 +150,8 @@ def lib() -> C.CDLL:
     L.qk_rad_PredictStep.argtypes = [vp, vp, R, ci, vp, vp, P(vp), cd, P(cd)]
     L.qk_rad_AddFluxesRK2.argtypes = [vp, vp, R, ci, vp, vp, vp, P(vp), P(vp), cd, P(cd)]
     L.qk_rad_AddSourceTermsSingleGroup.argtypes = [vp, vp, R, T, vp, vp, cd, ci, vp, vp]
+    L.qk_rad_AddSourceTermsMultiGroup.argtypes = [vp, vp, R, T, vp, vp, cd, ci, vp, vp]
+    L.qk_rad_mg_planck_fractions.argtypes = [vp, R, cd, ci, P(cd), P(cd), P(cd)]
     if hasattr(L, "qk_hydro_stage_fused"):
         L.qk_hydro_stage_scratch_bytes.argtypes = [vp, T]
         L.qk_hydro_stage_scratch_bytes.restype = C.c_int64
@@ -199,7 +223,7 @@ DECLARED_SYMBOLS = [
     "qk_hydro_EnforceLimits", "qk_hydro_SyncDualEnergy", "qk_hydro_ComputeMaxSignalSpeed", "qk_hydro_maxSignalSpeedLocal",
     "qk_replaceFluxes", "qk_Saxpy", "qk_hydro_stage_scratch_bytes", "qk_hydro_stage_fused",
     "qk_rad_ConservedToPrimitive", "qk_rad_ComputeFluxes", "qk_rad_computeRadiationFluxes", "qk_rad_PredictStep", "qk_rad_AddFluxesRK2",
-    "qk_rad_AddSourceTermsSingleGroup",
+    "qk_rad_AddSourceTermsSingleGroup", "qk_rad_AddSourceTermsMultiGroup", "qk_rad_mg_planck_fractions",
     "qk_ghost_plan_create", "qk_ghost_plan_destroy", "qk_ghost_plan_num_peers", "qk_ghost_plan_peer", "qk_ghost_plan_num_items", "qk_ghost_plan_item",
     "qk_FillBoundary_local", "qk_FillBoundary_local_int", "qk_FillBoundary_pack", "qk_FillBoundary_unpack", "qk_FillBoundary_pack_int", "qk_FillBoundary_unpack_int", "qk_SumBoundary_local", "qk_SumBoundary_pack", "qk_SumBoundary_unpack", "qk_FillPhysicalBoundary",
     "qk_FillPhysicalBoundary_subset", "qk_ghost_plan_set_components", "qk_ghost_plan_box_is_remote", "qk_ghost_plan_set_box_remote",

@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(256) k_copy(const CopyItem *items, const D *st
 // PhysBCFunct: FilccCell (AMReX_FilCC_3D_C.H) composed over dimensions + constant-Dirichlet user functor.
 // The BCRecs and the Dirichlet model travel BY VALUE in the kernel arguments: the caller's arrays may be temporaries, and nothing of
 // this call may depend on host memory after it returns.
-constexpr int PHYSBC_MAX_COMP = 16;
+constexpr int PHYSBC_MAX_COMP = QK_MAX_STATE_COMPS;
 struct PhysBcArgs {
 	qk_bcrec bcs[PHYSBC_MAX_COMP];
 	qk_dirichlet_face dir[6];
@@ -181,6 +181,23 @@ __global__ void __launch_bounds__(256) k_physbc(const CopyItem *items, qk_array4
 		if (df != nullptr) {
 			for (int n = scomp; n < scomp + ncomp; ++n) {
 				A(idx[0], idx[1], idx[2], n) = df->values[n];
+			}
+			if (df->interior_mask != 0 || df->kinetic_from_interior != 0) {
+				// RadTube's setCustomBoundaryConditions (test_radiation_tube.cpp:184-252)
+				const int fd = static_cast<int>((df - dirichlet) / 2);
+				const bool upper = ((df - dirichlet) & 1) != 0;
+				int in[3] = {idx[0], idx[1], idx[2]};
+				in[fd] = upper ? geom.domain.hi[fd] : geom.domain.lo[fd];
+				for (int n = scomp; n < scomp + ncomp; ++n) {
+					if (((df->interior_mask >> n) & 1ull) != 0) {
+						A(idx[0], idx[1], idx[2], n) = A(in[0], in[1], in[2], n);
+					}
+				}
+				if (df->kinetic_from_interior != 0 && ENE >= scomp && ENE < scomp + ncomp) {
+					const double mom = A(in[0], in[1], in[2], MX + fd);
+					const double Ekin = 0.5 * (mom * mom) / df->values[RHO];
+					A(idx[0], idx[1], idx[2], ENE) = df->values[EINT] + Ekin;
+				}
 			}
 			if (df->marshak != 0 && df->marshak_flux_comp >= scomp && df->marshak_flux_comp < scomp + ncomp) {
 				// RadMarshak's setCustomBoundaryConditions (test_radiation_marshak.cpp:125-141), in its order of operations
@@ -692,7 +709,7 @@ int qk_FillPhysicalBoundary_subset(qk_ghost_plan *plan, qk_stream s, qk_array4 *
 	(void)lev;
 	// BCRecs / Dirichlet model are tiny and go by value into the kernel arguments (an asynchronous upload from the caller's arrays would
 	// read them after this call has returned — they may be temporaries)
-	QK_REQUIRE(ctx, plan->ncomp <= PHYSBC_MAX_COMP, "FillPhysicalBoundary: more than 16 components");
+	QK_REQUIRE(ctx, plan->ncomp <= PHYSBC_MAX_COMP, "FillPhysicalBoundary: more than QK_MAX_STATE_COMPS (48) components");
 	PhysBcArgs pa{};
 	for (int n = 0; n < plan->ncomp; ++n) {
 		pa.bcs[n] = bcs[n];

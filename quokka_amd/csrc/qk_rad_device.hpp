@@ -1,8 +1,9 @@
-// qk_rad_device.hpp — per-cell / per-face device arithmetic of the single-group two-moment radiation path.
+// qk_rad_device.hpp — per-cell / per-face device arithmetic of the two-moment radiation path.
 // Counterparts (same association order, -ffp-contract=off):
 //   reference src/radiation/radiation_system.hpp            RadSystem<problem_t>
 //   reference src/radiation/source_terms_single_group.hpp   AddSourceTermsSingleGroup
-// nGroups = 1, OpacityModel::single_group, no dust / photoelectric / cooling models (ISM_Traits defaults).
+// The face flux and the state repair act on one photon group at a time (the transport of the groups is independent); the single-group source
+// term is here, the multigroup one in qk_rad_mg_device.hpp.  No dust / photoelectric / cooling models (ISM_Traits defaults).
 #ifndef QK_RAD_DEVICE_HPP_
 #define QK_RAD_DEVICE_HPP_
 
@@ -20,10 +21,13 @@ struct Rad {
 	double kappaP0, kappaE0, kappaF0;
 	double kT_ref, kT_exp, kT_floor;
 	int beta_order, pow_mode, opacity_model, eddington_model;
+	int ngroups; // Physics_Traits::nGroups
 	__host__ __device__ explicit Rad(qk_rad_traits const &t)
-	    : c(t.c_light), chat(t.c_hat), arad(t.radiation_constant), Erad_floor(t.Erad_floor), kappaP0(t.kappaP), kappaE0(t.kappaE), kappaF0(t.kappaF),
-	      kT_ref(t.opacity_T_ref), kT_exp(t.opacity_T_exponent), kT_floor(t.opacity_pow_floor), beta_order(t.beta_order), pow_mode(t.pow_mode),
-	      opacity_model(t.opacity_model), eddington_model(t.eddington_model)
+	    : c(t.c_light), chat(t.c_hat), arad(t.radiation_constant),
+	      Erad_floor(t.Erad_floor / ((t.ngroups > 1) ? t.ngroups : 1)), // Erad_floor_ = RadSystem_Traits::Erad_floor / nGroups_ (radiation_system.hpp:211)
+	      kappaP0(t.kappaP), kappaE0(t.kappaE), kappaF0(t.kappaF), kT_ref(t.opacity_T_ref), kT_exp(t.opacity_T_exponent), kT_floor(t.opacity_pow_floor),
+	      beta_order(t.beta_order), pow_mode(t.pow_mode), opacity_model(t.opacity_model), eddington_model(t.eddington_model),
+	      ngroups((t.ngroups > 1) ? t.ngroups : 1)
 	{
 	}
 	// problem hooks ComputePlanckOpacity / ComputeEnergyMeanOpacity / ComputeFluxMeanOpacity (radiation_system.hpp:1141-1154):

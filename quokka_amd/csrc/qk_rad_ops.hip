@@ -1,5 +1,6 @@
-// qk_rad_ops.hip — single-group two-moment radiation operators (RadSystem<problem_t>) behind the C-ABI.
-// One launch covers all local boxes.  Arithmetic in qk_rad_device.hpp.
+// qk_rad_ops.hip — two-moment radiation operators (RadSystem<problem_t>) behind the C-ABI: transport for 1 .. QK_MAX_GROUPS photon groups
+// (the groups are independent there: the group index is a grid dimension), the single-group source term.  The multigroup source term is in
+// qk_rad_mg.hip.  One launch covers all local boxes.  Arithmetic in qk_rad_device.hpp.
 #include "qk_internal.hpp"
 #include "qk_rad_device.hpp"
 
@@ -94,12 +95,14 @@ auto counterSlots(qk_ctx *ctx) -> int *
 	return ctx->counter_slots;
 }
 
-template <int MINW = 1, class F> void launchRad(qk_level *lev, qk_stream s, int ng, int facedir, const char *name, F f)
+// nz: third grid dimension (the photon group of the per-group kernels, read as blockIdx.z inside `f`)
+template <int MINW = 1, class F> void launchRad(qk_level *lev, qk_stream s, int ng, int facedir, const char *name, F f, int nz = 1)
 {
 	if (lev->nboxes == 0) {
 		return; // a rank without boxes on this level
 	}
-	const CellLaunch L = cellLaunch(lev, ng, facedir);
+	CellLaunch L = cellLaunch(lev, ng, facedir);
+	L.grid.z = static_cast<unsigned>(nz);
 	ProfScope ps(lev->ctx, static_cast<hipStream_t>(s), name);
 	hipLaunchKernelGGL((k_rad_cells<MINW, F>), L.grid, L.block, 0, static_cast<hipStream_t>(s), lev->d_boxes, lev->ndim, ng, facedir, f);
 }
@@ -128,6 +131,9 @@ inline auto checkRad(qk_ctx *ctx, const qk_rad_traits *rt) -> int
 	if (rt->beta_order < 0 || rt->beta_order > 3) {
 		return setError(ctx, QK_ERR_INVALID, "beta_order must be 0..3");
 	}
+	if (rt->ngroups < 0 || rt->ngroups > QK_MAX_GROUPS) {
+		return setError(ctx, QK_ERR_UNSUPPORTED, "ngroups must be 1 .. QK_MAX_GROUPS (8)");
+	}
 	return QK_OK;
 }
 
@@ -142,20 +148,21 @@ template <int DIR> void launchRadComputeFluxes(qk_level *lev, qk_stream s, Rad r
 		RA4 U(cons_t[b]);
 		WA4 F(flux_t[b]);
 		const int im = i - unit(DIR, 0), jm = j - unit(DIR, 1), km = k - unit(DIR, 2);
+		const int pg = NRAD * static_cast<int>(blockIdx.z); // component offset of this block's photon group
 		double pL[NRAD], pR[NRAD], cL[NRAD], cR[NRAD], Fo[NRAD];
 #pragma unroll
 		for (int n = 0; n < NRAD; ++n) {
-			pL[n] = L(i, j, k, n);
-			pR[n] = R(i, j, k, n);
-			cL[n] = U(im, jm, km, RAD0 + n);
-			cR[n] = U(i, j, k, RAD0 + n);
+			pL[n] = L(i, j, k, pg + n);
+			pR[n] = R(i, j, k, pg + n);
+			cL[n] = U(im, jm, km, RAD0 + pg + n);
+			cR[n] = U(i, j, k, RAD0 + pg + n);
 		}
 		radFaceFlux<DIR>(rad, pL, pR, cL, cR, Fo);
 #pragma unroll
 		for (int n = 0; n < NRAD; ++n) {
-			F(i, j, k, n) = Fo[n];
+			F(i, j, k, pg + n) = Fo[n];
 		}
-	});
+	}, rad.ngroups);
 }
 
 // cons -> prim of one cell (radiation_system.hpp:603-610)
@@ -177,6 +184,7 @@ template <int DIR, int ORDER> void launchRadFusedFlux(qk_level *lev, qk_stream s
 		RA4 U(cons_t[b]);
 		WA4 F(flux_t[b]);
 		const int dx = unit(DIR, 0), dy = unit(DIR, 1), dz = unit(DIR, 2);
+		const int pg = NRAD * static_cast<int>(blockIdx.z); // component offset of this block's photon group
 		// cells i-3 .. i+2 along DIR
 		double c[6][NRAD], p[6][NRAD];
 		constexpr int M0 = (ORDER == 3) ? 0 : (ORDER == 2) ? 1 : 2;
@@ -186,7 +194,7 @@ template <int DIR, int ORDER> void launchRadFusedFlux(qk_level *lev, qk_stream s
 			const int64_t o = U.idx(i + (m - 3) * dx, j + (m - 3) * dy, k + (m - 3) * dz);
 #pragma unroll
 			for (int n = 0; n < NRAD; ++n) {
-				c[m][n] = U.p[o + U.ns * (RAD0 + n)];
+				c[m][n] = U.p[o + U.ns * (RAD0 + pg + n)];
 			}
 			radPrim(rad, c[m], p[m]);
 		}
@@ -214,9 +222,9 @@ template <int DIR, int ORDER> void launchRadFusedFlux(qk_level *lev, qk_stream s
 		const int64_t o = F.idx(i, j, k);
 #pragma unroll
 		for (int n = 0; n < NRAD; ++n) {
-			F.p[o + F.ns * n] = Fo[n];
+			F.p[o + F.ns * (pg + n)] = Fo[n];
 		}
-	});
+	}, rad.ngroups);
 }
 
 // Y / Z sweeps: one thread marches a strip of STRIP faces along DIR with a rolling window of cells, so that every cell's primitives and
@@ -227,7 +235,8 @@ __global__ void __launch_bounds__(256) k_rad_flux_march(const qk_box *boxes, Rad
 {
 	static_assert(DIR == 1 || DIR == 2, "marching flux kernel: strided directions only");
 	constexpr int OT = 3 - DIR;
-	const int b = blockIdx.z;
+	const int b = static_cast<int>(blockIdx.z) / rad.ngroups;
+	const int pg = NRAD * (static_cast<int>(blockIdx.z) % rad.ngroups); // component offset of this block's photon group
 	const qk_box bx = boxes[b];
 	const int i = bx.lo[0] + static_cast<int>(blockIdx.x) * 64 + static_cast<int>(threadIdx.x);
 	const int oblk = static_cast<int>(blockIdx.y) % notb, strip = static_cast<int>(blockIdx.y) / notb;
@@ -250,7 +259,7 @@ __global__ void __launch_bounds__(256) k_rad_flux_march(const qk_box *boxes, Rad
 		const int64_t o = U.idx(pos[0], pos[1], pos[2]);
 #pragma unroll
 		for (int n = 0; n < NRAD; ++n) {
-			c[m][n] = U.p[o + U.ns * (RAD0 + n)];
+			c[m][n] = U.p[o + U.ns * (RAD0 + pg + n)];
 		}
 		radPrim(rad, c[m], p[m]);
 	};
@@ -307,7 +316,7 @@ __global__ void __launch_bounds__(256) k_rad_flux_march(const qk_box *boxes, Rad
 		const int64_t o = F.idx(pos[0], pos[1], pos[2]);
 #pragma unroll
 		for (int n = 0; n < NRAD; ++n) {
-			F.p[o + F.ns * n] = Fo[n];
+			F.p[o + F.ns * (pg + n)] = Fo[n];
 		}
 	}
 }
@@ -322,7 +331,8 @@ template <int ORDER> __global__ void __launch_bounds__(RXB) k_rad_flux_x(const q
 	__shared__ double s_p[NRAD][RXB]; // primitives
 	__shared__ double s_e[NRAD][RXB]; // PPM: right edge a_plus of the cell; PLM: its limited slope
 	__shared__ double s_c[NRAD][RXB]; // conserved radiation state (the first-order fallback of the HLL flux needs it)
-	const int b = blockIdx.z;
+	const int b = static_cast<int>(blockIdx.z) / rad.ngroups;
+	const int pg = NRAD * (static_cast<int>(blockIdx.z) % rad.ngroups); // component offset of this block's photon group
 	const qk_box bx = boxes[b];
 	const int k = bx.lo[2] + static_cast<int>(blockIdx.y);
 	if (k > bx.hi[2]) {
@@ -342,7 +352,7 @@ template <int ORDER> __global__ void __launch_bounds__(RXB) k_rad_flux_x(const q
 	double c0[NRAD], p0[NRAD];
 #pragma unroll
 	for (int n = 0; n < NRAD; ++n) {
-		c0[n] = U.p[o + U.ns * (RAD0 + n)];
+		c0[n] = U.p[o + U.ns * (RAD0 + pg + n)];
 	}
 	radPrim(rad, c0, p0);
 #pragma unroll
@@ -390,7 +400,7 @@ template <int ORDER> __global__ void __launch_bounds__(RXB) k_rad_flux_x(const q
 	const int64_t of = F.idx(i, j, k);
 #pragma unroll
 	for (int n = 0; n < NRAD; ++n) {
-		F.p[of + F.ns * n] = Fo[n];
+		F.p[of + F.ns * (pg + n)] = Fo[n];
 	}
 }
 
@@ -400,7 +410,8 @@ template <int ORDER> void launchRadXFlux(qk_level *lev, qk_stream s, Rad rad, co
 		return;
 	}
 	const int64_t slab = static_cast<int64_t>(lev->maxlen[0] + 2 * nghost) * lev->maxlen[1];
-	const dim3 grid(static_cast<unsigned>((slab + RXOUT - 1) / RXOUT), static_cast<unsigned>(lev->maxlen[2]), static_cast<unsigned>(lev->nboxes));
+	const dim3 grid(static_cast<unsigned>((slab + RXOUT - 1) / RXOUT), static_cast<unsigned>(lev->maxlen[2]),
+			static_cast<unsigned>(lev->nboxes * rad.ngroups));
 	ProfScope ps(lev->ctx, static_cast<hipStream_t>(s), "rad_fluxFunction");
 	hipLaunchKernelGGL((k_rad_flux_x<ORDER>), grid, dim3(RXB), 0, static_cast<hipStream_t>(s), lev->d_boxes, rad, cons_t, flux_t);
 }
@@ -414,7 +425,7 @@ template <int DIR, int ORDER> void launchRadMarchFlux(qk_level *lev, qk_stream s
 	constexpr int OT = 3 - DIR;
 	const int notb = (lev->maxlen[OT] + 3) / 4;
 	const int nstrips = (lev->maxlen[DIR] + 1 + STRIP - 1) / STRIP;
-	const dim3 grid((lev->maxlen[0] + 63) / 64, notb * nstrips, lev->nboxes);
+	const dim3 grid((lev->maxlen[0] + 63) / 64, notb * nstrips, lev->nboxes * rad.ngroups);
 	ProfScope ps(lev->ctx, static_cast<hipStream_t>(s), "rad_fluxFunction");
 	hipLaunchKernelGGL((k_rad_flux_march<DIR, ORDER, STRIP>), grid, dim3(64, 4), 0, static_cast<hipStream_t>(s), lev->d_boxes, rad, cons_t, flux_t, notb);
 }
@@ -439,17 +450,18 @@ int qk_rad_ConservedToPrimitive(qk_level *lev, qk_stream s, const qk_rad_traits 
 		}
 		RA4 U(cons_t[b]);
 		WA4 P(prim_t[b]);
+		const int pg = NRAD * static_cast<int>(blockIdx.z); // component offset of this block's photon group
 		double c[NRAD], p[NRAD];
 #pragma unroll
 		for (int n = 0; n < NRAD; ++n) {
-			c[n] = U(i, j, k, RAD0 + n);
+			c[n] = U(i, j, k, RAD0 + pg + n);
 		}
 		radPrim(rad, c, p);
 #pragma unroll
 		for (int n = 0; n < NRAD; ++n) {
-			P(i, j, k, n) = p[n];
+			P(i, j, k, pg + n) = p[n];
 		}
-	});
+	}, rad.ngroups);
 	return radStatus(lev, "rad ConservedToPrimitive");
 }
 
@@ -549,24 +561,43 @@ int qk_rad_PredictStep(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int 
 		RA4 Uo(old_t[b]);
 		WA4 Un(new_t[b]);
 		RA4 x1(f0[b]);
-		double cons[NRAD];
+		// one photon group: the state with the flux divergence added
+		auto update = [&](int pg, double cons[NRAD]) {
 #pragma unroll
-		for (int n = 0; n < NRAD; ++n) {
-			double d = (dt / dx0) * (x1(i, j, k, n) - x1(i + 1, j, k, n));
-			if (ndim == 3) {
-				RA4 x2(f1[b]);
-				RA4 x3(f2[b]);
-				d = d + (dt / dx1) * (x2(i, j, k, n) - x2(i, j + 1, k, n));
-				d = d + (dt / dx2) * (x3(i, j, k, n) - x3(i, j, k + 1, n));
+			for (int n = 0; n < NRAD; ++n) {
+				double d = (dt / dx0) * (x1(i, j, k, pg + n) - x1(i + 1, j, k, pg + n));
+				if (ndim == 3) {
+					RA4 x2(f1[b]);
+					RA4 x3(f2[b]);
+					d = d + (dt / dx1) * (x2(i, j, k, pg + n) - x2(i, j + 1, k, pg + n));
+					d = d + (dt / dx2) * (x3(i, j, k, pg + n) - x3(i, j, k + 1, pg + n));
+				}
+				cons[n] = Uo(i, j, k, RAD0 + pg + n) + d;
 			}
-			cons[n] = Uo(i, j, k, RAD0 + n) + d;
+		};
+		// isStateValid is a property of the whole cell (radiation_system.hpp:626-644: every group), amendRadState then repairs every group
+		// (:646-665: a valid group below its floor is lifted as well).  Several groups: one pass for the verdict, one to store.
+		bool cellValid = true;
+		double cons[NRAD];
+		if (rad.ngroups > 1) {
+			for (int g = 0; g < rad.ngroups; ++g) {
+				update(NRAD * g, cons);
+				cellValid = cellValid && radStateValid(rad, cons);
+			}
 		}
-		if (!radStateValid(rad, cons)) {
-			amendRadState(rad, cons);
-		}
+		for (int g = 0; g < rad.ngroups; ++g) {
+			const int pg = NRAD * g;
+			update(pg, cons);
+			if (rad.ngroups == 1) {
+				cellValid = radStateValid(rad, cons);
+			}
+			if (!cellValid) {
+				amendRadState(rad, cons);
+			}
 #pragma unroll
-		for (int n = 0; n < NRAD; ++n) {
-			Un(i, j, k, RAD0 + n) = cons[n];
+			for (int n = 0; n < NRAD; ++n) {
+				Un(i, j, k, RAD0 + pg + n) = cons[n];
+			}
 		}
 	});
 	return radStatus(lev, "rad PredictStep");
@@ -595,43 +626,60 @@ int qk_rad_AddFluxesRK2(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int
 		RA4 U0(U0_t[b]);
 		RA4 U1(U1_t[b]);
 		RA4 xn(f0[b]);
-		double cons[NRAD];
 		// The old-state fluxes enter with the weight (0.5 - IMEX_a32), which is exactly 0 for the PD-ARS scheme (a32 = 0.5): the term is
 		// +-0 for finite fluxes and adding it can only change the sign of a zero result — they are not read (12 of the 36 words this kernel
 		// would otherwise stream).  Any other a32 takes the general form.
 		constexpr bool useOld = (0.5 - IMEX_a32) != 0.0;
+		auto update = [&](int pg, double cons[NRAD]) {
 #pragma unroll
-		for (int n = 0; n < NRAD; ++n) {
-			const double U_0 = U0(i, j, k, RAD0 + n);
-			const double U_1 = U1(i, j, k, RAD0 + n);
-			double s0 = 0.0;
-			double s1 = (dt / dx0) * (xn(i, j, k, n) - xn(i + 1, j, k, n));
-			if (useOld) {
-				RA4 xo(o0[b]);
-				s0 = (dt / dx0) * (xo(i, j, k, n) - xo(i + 1, j, k, n));
-			}
-			if (ndim == 3) {
-				RA4 yn(f1[b]);
-				RA4 zn(f2[b]);
-				s1 = s1 + (dt / dx1) * (yn(i, j, k, n) - yn(i, j + 1, k, n));
-				s1 = s1 + (dt / dx2) * (zn(i, j, k, n) - zn(i, j, k + 1, n));
+			for (int n = 0; n < NRAD; ++n) {
+				const double U_0 = U0(i, j, k, RAD0 + pg + n);
+				const double U_1 = U1(i, j, k, RAD0 + pg + n);
+				double s0 = 0.0;
+				double s1 = (dt / dx0) * (xn(i, j, k, pg + n) - xn(i + 1, j, k, pg + n));
 				if (useOld) {
-					RA4 yo(o1[b]);
-					RA4 zo(o2[b]);
-					s0 = s0 + (dt / dx1) * (yo(i, j, k, n) - yo(i, j + 1, k, n));
-					s0 = s0 + (dt / dx2) * (zo(i, j, k, n) - zo(i, j, k + 1, n));
+					RA4 xo(o0[b]);
+					s0 = (dt / dx0) * (xo(i, j, k, pg + n) - xo(i + 1, j, k, pg + n));
 				}
+				if (ndim == 3) {
+					RA4 yn(f1[b]);
+					RA4 zn(f2[b]);
+					s1 = s1 + (dt / dx1) * (yn(i, j, k, pg + n) - yn(i, j + 1, k, pg + n));
+					s1 = s1 + (dt / dx2) * (zn(i, j, k, pg + n) - zn(i, j, k + 1, pg + n));
+					if (useOld) {
+						RA4 yo(o1[b]);
+						RA4 zo(o2[b]);
+						s0 = s0 + (dt / dx1) * (yo(i, j, k, pg + n) - yo(i, j + 1, k, pg + n));
+						s0 = s0 + (dt / dx2) * (zo(i, j, k, pg + n) - zo(i, j, k + 1, pg + n));
+					}
+				}
+				// radiation_system.hpp:758-759
+				cons[n] = useOld ? (1.0 - IMEX_a32) * U_0 + IMEX_a32 * U_1 + ((0.5 - IMEX_a32) * (s0)) + (0.5 * (s1))
+						 : (1.0 - IMEX_a32) * U_0 + IMEX_a32 * U_1 + (0.5 * (s1));
 			}
-			// radiation_system.hpp:758-759
-			cons[n] = useOld ? (1.0 - IMEX_a32) * U_0 + IMEX_a32 * U_1 + ((0.5 - IMEX_a32) * (s0)) + (0.5 * (s1))
-					 : (1.0 - IMEX_a32) * U_0 + IMEX_a32 * U_1 + (0.5 * (s1));
+		};
+		// whole-cell validity, then every group repaired (see PredictStep); U_new may alias U1: nothing is stored before the verdict
+		bool cellValid = true;
+		double cons[NRAD];
+		if (rad.ngroups > 1) {
+			for (int g = 0; g < rad.ngroups; ++g) {
+				update(NRAD * g, cons);
+				cellValid = cellValid && radStateValid(rad, cons);
+			}
 		}
-		if (!radStateValid(rad, cons)) {
-			amendRadState(rad, cons);
-		}
+		for (int g = 0; g < rad.ngroups; ++g) {
+			const int pg = NRAD * g;
+			update(pg, cons);
+			if (rad.ngroups == 1) {
+				cellValid = radStateValid(rad, cons);
+			}
+			if (!cellValid) {
+				amendRadState(rad, cons);
+			}
 #pragma unroll
-		for (int n = 0; n < NRAD; ++n) {
-			Un(i, j, k, RAD0 + n) = cons[n];
+			for (int n = 0; n < NRAD; ++n) {
+				Un(i, j, k, RAD0 + pg + n) = cons[n];
+			}
 		}
 	});
 	return radStatus(lev, "rad AddFluxesRK2");

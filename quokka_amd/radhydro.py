@@ -42,8 +42,10 @@ def _d3(v):
 class RadhydroSimulation(HydroSimulation):
     def __init__(self, ctx: Context, geom: Geometry, traits: capi.HydroTraits, rad_traits: capi.RadTraits, bcs, max_grid_size=None,
                  rank: int = 0, nranks: int = 1, use_fused: bool = True, dirichlet=None):
-        self.ncomp_override = 10
-        super().__init__(ctx, geom, traits, bcs, max_grid_size, dirichlet, rank, nranks, use_fused, ncomp_cc=10)
+        self.nGroups = max(int(rad_traits.ngroups), 1)  # Physics_Traits::nGroups
+        self.nrad = 4 * self.nGroups                      # Physics_NumVars::numRadVars * nGroups
+        self.ncomp_override = RAD0 + self.nrad
+        super().__init__(ctx, geom, traits, bcs, max_grid_size, dirichlet, rank, nranks, use_fused, ncomp_cc=RAD0 + self.nrad)
         self.rad_traits = rad_traits
         self.is_hydro_enabled = True  # Physics_Traits::is_hydro_enabled (False: radiation-only problems)
         self.radiationCflNumber_ = 0.3
@@ -51,9 +53,9 @@ class RadhydroSimulation(HydroSimulation):
         self.radiationReconstructionOrder_ = 3
         self.radiationCellUpdates_ = 0
         lev, nd = self.lev, geom.ndim
-        self.radFluxOld = [MultiFab(lev, 4, 0, facedir=d) for d in range(nd)]
-        self.radFlux = [MultiFab(lev, 4, 0, facedir=d) for d in range(nd)]
-        self.radEnergySource = MultiFab(lev, 1, 0, fill=0.0)
+        self.radFluxOld = [MultiFab(lev, self.nrad, 0, facedir=d) for d in range(nd)]
+        self.radFlux = [MultiFab(lev, self.nrad, 0, facedir=d) for d in range(nd)]
+        self.radEnergySource = MultiFab(lev, self.nGroups, 0, fill=0.0)  # QuokkaSimulation.hpp:1866-1869
         self.SetRadEnergySource: Optional[Callable] = None  # fn(i, j, k, time) -> array on the valid box
         self._source_time_independent = True
         self._source_set = False
@@ -89,21 +91,27 @@ class RadhydroSimulation(HydroSimulation):
             return
         for b, (lo, hi) in enumerate(self.my_boxes):
             k, j, i = np.meshgrid(np.arange(lo[2], hi[2] + 1), np.arange(lo[1], hi[1] + 1), np.arange(lo[0], hi[0] + 1), indexing="ij")
-            self.radEnergySource.fabs[b][0].copy_(torch.from_numpy(np.ascontiguousarray(self.SetRadEnergySource(i, j, k, time))))
+            src = np.ascontiguousarray(self.SetRadEnergySource(i, j, k, time))  # (nz, ny, nx) or (nGroups, nz, ny, nx)
+            if src.ndim == 3:
+                self.radEnergySource.fabs[b][0].copy_(torch.from_numpy(src))
+            else:
+                self.radEnergySource.fabs[b].copy_(torch.from_numpy(src))
         self._source_set = True
 
     def operatorSplitSourceTerms(self, time: float, dt: float, stage: int):
         self._fill_source(time + dt)
         c = self.ctx
-        c.check(c.L.qk_rad_AddSourceTermsSingleGroup(self.lev.h, c.stream(), C.byref(self.rad_traits), C.byref(self.traits), self.state_new_cc_.ptr,
-                                                     self.radEnergySource.ptr, float(dt), stage, C.c_void_p(self.dev_rad_counter.data_ptr()),
-                                                     C.c_void_p(self.dev_rad_failure.data_ptr())), "qk_rad_AddSourceTermsSingleGroup")
+        # QuokkaSimulation.hpp:1875-1881
+        fn, name = ((c.L.qk_rad_AddSourceTermsSingleGroup, "qk_rad_AddSourceTermsSingleGroup") if self.nGroups <= 1
+                    else (c.L.qk_rad_AddSourceTermsMultiGroup, "qk_rad_AddSourceTermsMultiGroup"))
+        c.check(fn(self.lev.h, c.stream(), C.byref(self.rad_traits), C.byref(self.traits), self.state_new_cc_.ptr, self.radEnergySource.ptr, float(dt), stage,
+                   C.c_void_p(self.dev_rad_counter.data_ptr()), C.c_void_p(self.dev_rad_failure.data_ptr())), name)
 
     def _fill_rad_ghosts(self, state: MultiFab):
         """fillBoundaryConditions for the transport kernels, which read only the radiation components of the ghost cells: the same-rank
         copies and the physical BCs are restricted to them (strips to other ranks carry everything; the reference fills all components)"""
         L, h = self.ctx.L, self.ghost.h
-        self.ctx.check(L.qk_ghost_plan_set_components(h, RAD0, 4), "qk_ghost_plan_set_components")
+        self.ctx.check(L.qk_ghost_plan_set_components(h, RAD0, self.nrad), "qk_ghost_plan_set_components")
         try:
             self.fillBoundaryConditions(state)
         finally:
@@ -127,7 +135,7 @@ class RadhydroSimulation(HydroSimulation):
 
     def swapRadiationState(self):
         for b in range(self.lev.nboxes):
-            self.state_old_cc_.valid(b)[RAD0:RAD0 + 4].copy_(self.state_new_cc_.valid(b)[RAD0:RAD0 + 4])
+            self.state_old_cc_.valid(b)[RAD0:RAD0 + self.nrad].copy_(self.state_new_cc_.valid(b)[RAD0:RAD0 + self.nrad])
 
     def subcycleRadiationAtLevel(self, time: float, dt_lev_hydro: float) -> bool:
         if self.is_hydro_enabled and not (self.constantDt_ > 0.0):  # reference src/QuokkaSimulation.hpp:1583: radiation-only problems take ONE step

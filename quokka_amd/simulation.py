@@ -132,8 +132,15 @@ class GhostExchange:
                 f = self.dirichlet[2 * dim + side]
                 f.enabled = 1
                 if isinstance(vals, dict):  # {"values": [...], "marshak": (energy_comp, flux_comp, c)}: qk_dirichlet_face::marshak
-                    f.marshak = 1
-                    f.marshak_energy_comp, f.marshak_flux_comp, f.marshak_c = vals["marshak"]
+                    if "marshak" in vals:
+                        f.marshak = 1
+                        f.marshak_energy_comp, f.marshak_flux_comp, f.marshak_c = vals["marshak"]
+                    if "interior" in vals:  # components that follow the first valid cell inside the face: qk_dirichlet_face::interior_mask
+                        mask = 0
+                        for n in vals["interior"]:
+                            mask |= 1 << int(n)
+                        f.interior_mask = mask
+                        f.kinetic_from_interior = int(bool(vals.get("kinetic_from_interior", False)))
                     vals = vals["values"]
                 for n, v in enumerate(vals):
                     f.values[n] = v
