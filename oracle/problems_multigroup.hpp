@@ -5,6 +5,7 @@
 //   src/problems/RadTube/test_radiation_tube.cpp
 //   src/problems/RadMarshakVaytet/test_radiation_marshak_Vaytet.cpp
 //   src/problems/RadhydroPulseMGconst/test_radhydro_pulse_MG_const_kappa.cpp
+//   src/problems/RadDust/test_rad_dust.cpp (single group, dust-gas thermal coupling)
 #ifndef ORACLE_PROBLEMS_MULTIGROUP_HPP_
 #define ORACLE_PROBLEMS_MULTIGROUP_HPP_
 
@@ -489,6 +490,76 @@ inline void setupPulseMG(HydroSim &sim, bool multigroup)
 			state_cc(i, j, k, internalEnergy_index) = Egas;
 			state_cc(i, j, k, x1Momentum_index) = 0.;
 		}
+		state_cc(i, j, k, x2Momentum_index) = 0.;
+		state_cc(i, j, k, x3Momentum_index) = 0.;
+	});
+	sim.finishInitialConditions();
+}
+
+// ---------------------------------------------------------------- gas-dust-radiation relaxation with linearised emission
+// (src/problems/RadDust/test_rad_dust.cpp, deck tests/RadDust.in: 8 x 4 x 4 cells, periodic, radiation.cfl = 8, dust_gas_interaction_coeff = 1e6)
+struct RadDustConstants { // :19-34
+	static constexpr double c = 1.0e8;
+	static constexpr double chat = c;
+	static constexpr double v0 = 0.0;
+	static constexpr double chi0 = 10000.0;
+	static constexpr double T0 = 1.0;
+	static constexpr double rho0 = 1.0;
+	static constexpr double a_rad = 1.0;
+	static constexpr double mu = 1.0;
+	static constexpr double k_B = 1.0;
+	static constexpr double max_time = 1.0e-5;
+	static constexpr double delta_time = 1.0e-8;
+	static constexpr double Erad0 = a_rad * T0 * T0 * T0 * T0;
+	static constexpr double erad_floor = 1.0e-20 * Erad0;
+};
+
+inline void setupRadDust(HydroSim &sim)
+{
+	using S = RadDustConstants;
+	sim.hydro.tr.eos.tr.gamma = 5. / 3.; // :42-46
+	sim.hydro.tr.eos.tr.mean_molecular_weight = S::mu;
+	sim.hydro.tr.eos.tr.boltzmann_constant = S::k_B;
+	sim.hydro.tr.reconstruct_eint = true;
+	sim.hydro.tr.nscalars = 0;
+	sim.ncomp_cc = kNumHydroVars + kNumRadVars;
+	sim.is_radiation_enabled = true;
+	sim.rad.rt.c_light = S::c; // :48-54
+	sim.rad.rt.c_hat = S::chat;
+	sim.rad.rt.radiation_constant = S::a_rad;
+	sim.rad.rt.Erad_floor = S::erad_floor;
+	sim.rad.rt.beta_order = 1;
+	sim.rad.rt.enable_dust_gas_thermal_coupling_model = true; // :56-60
+	sim.rad.rt.dustGasInteractionCoeff = 1.0e6;		    // the deck
+	sim.rad.rt.thermal_model = 1;				    // :86-97
+	sim.rad.eos = sim.hydro.tr.eos;
+	sim.rad.ndim = sim.geom.ndim;
+	sim.rad.nstartHyperbolic_ = kNumHydroVars;
+	sim.rad.ComputePlanckOpacity = [](double rho, double) { return S::chi0 / rho; }; // :74-84
+	sim.rad.ComputeFluxMeanOpacity = [](double rho, double) { return S::chi0 / rho; };
+	sim.rad.ComputeEnergyMeanOpacity = [](double rho, double) { return S::chi0 / rho; };
+
+	sim.BCs_cc.assign(sim.ncomp_cc, BCRec{}); // problem_main :145-170 (periodic)
+	sim.radiationReconstructionOrder_ = 3;
+	sim.stopTime_ = S::max_time;
+	sim.cflNumber_ = 0.8;
+	sim.radiationCflNumber_ = 8.0; // the deck
+	sim.maxTimesteps_ = 1000000;
+	sim.initDt_ = S::delta_time;
+	sim.maxDt_ = S::delta_time;
+
+	sim.define();
+	EOS const eos = sim.hydro.tr.eos;
+	const double Egas = eos.ComputeEintFromTgas(S::rho0, S::T0);
+	forEachValidCell(sim, [&](Array4<double> const &state_cc, int i, int j, int k) { // :99-122
+		state_cc(i, j, k, kNumHydroVars + 0) = S::erad_floor;
+		state_cc(i, j, k, kNumHydroVars + 1) = 0;
+		state_cc(i, j, k, kNumHydroVars + 2) = 0;
+		state_cc(i, j, k, kNumHydroVars + 3) = 0;
+		state_cc(i, j, k, energy_index) = Egas + 0.5 * S::rho0 * S::v0 * S::v0;
+		state_cc(i, j, k, density_index) = S::rho0;
+		state_cc(i, j, k, internalEnergy_index) = Egas;
+		state_cc(i, j, k, x1Momentum_index) = S::v0 * S::rho0;
 		state_cc(i, j, k, x2Momentum_index) = 0.;
 		state_cc(i, j, k, x3Momentum_index) = 0.;
 	});

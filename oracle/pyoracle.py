@@ -21,7 +21,7 @@ M_U = 1.6605390666e-24
 
 SOD, CONTACT, SEDOV, SHELL, RADSHOCK, STREAMING, SCALARS, HYDRO1D, COUPLING, SUOLSON, ADVECTING, MARSHAK, RADFORCE, MARSHAK_ASYMPTOTIC, RADPULSE, SHOCKTUBE_CMA = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15
 # multigroup radiation (oracle/problems_multigroup.hpp); PULSE_MG = the advecting 4-group run, PULSE_MG_GREY = the static grey run of the same file
-RADSHOCK_MG, RADTUBE, MARSHAK_VAYTET, PULSE_MG, PULSE_MG_GREY = 16, 17, 18, 19, 20
+RADSHOCK_MG, RADTUBE, MARSHAK_VAYTET, PULSE_MG, PULSE_MG_GREY, RADDUST = 16, 17, 18, 19, 20, 21
 # OpacityModel (radiation_system.hpp:64-71)
 PIECEWISE_CONSTANT, PPL_FIXED_SLOPE, PPL_FULL_SPECTRUM = 1, 2, 3
 

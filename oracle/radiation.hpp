@@ -52,6 +52,13 @@ struct RadTraits {
 	// the ComputeEddingtonFactor hook (radiation_system.hpp:773-790 is the default, Levermore's closure); problems that specialise it
 	// use the Eddington approximation chi = 1/3 (e.g. src/problems/RadhydroShockCGS/test_radhydro_shock_cgs.cpp:88-91)
 	int eddington_model = 0; // 0: Levermore, 1: chi = 1/3
+	// ISM_Traits<problem_t>::enable_dust_gas_thermal_coupling_model (radiation_system.hpp:84-98) and QuokkaSimulation::dustGasInteractionCoeff_
+	// (QuokkaSimulation.hpp:127, deck key radiation.dust_gas_interaction_coeff)
+	bool enable_dust_gas_thermal_coupling_model = false;
+	double dustGasInteractionCoeff = 2.5e-34;
+	// the ComputeThermalRadiationSingleGroup / ...TempDerivativeSingleGroup hooks: 0 the default a T^4 / 4 a T^3 (:471-479, :499-503);
+	// 1: a T / a, the linearised emission of RadDust (src/problems/RadDust/test_rad_dust.cpp:86-97)
+	int thermal_model = 0;
 	// multigroup (Physics_Traits::nGroups, RadSystem_Traits::radBoundaries / energy_unit / opacity_model; radiation_system.hpp:201-223)
 	int nGroups = 1;
 	std::vector<double> radBoundaries; // nGroups + 1 group edges, in units of energy_unit / h ... (energy = energy_unit * boundary)
@@ -87,6 +94,9 @@ struct RadSystem {
 	// radiation_system.hpp:471-479
 	[[nodiscard]] auto ComputeThermalRadiationSingleGroup(double temperature) const -> double
 	{
+		if (rt.thermal_model == 1) {
+			return rt.radiation_constant * temperature;
+		}
 		double power = rt.radiation_constant * pow4(temperature);
 		if (power < Erad_floor_()) {
 			power = Erad_floor_();
@@ -96,7 +106,62 @@ struct RadSystem {
 	// :499-503
 	[[nodiscard]] auto ComputeThermalRadiationTempDerivativeSingleGroup(double temperature) const -> double
 	{
+		if (rt.thermal_model == 1) {
+			return rt.radiation_constant;
+		}
 		return 4. * rt.radiation_constant * pow3(temperature);
+	}
+
+	// :1387-1418 BackwardEulerOneVariable
+	template <typename RHSFunction, typename JacFunction>
+	[[nodiscard]] static auto BackwardEulerOneVariable(RHSFunction const &rhs, JacFunction const &jac, const double x0, const double compare) -> double
+	{
+		double x = x0;
+		const double rel_tol = 1.0e-8;
+		const double rel_change_tol = 1.0e-6;
+		const int max_iter_td = 100;
+		int iter_Td = 0;
+		for (; iter_Td < max_iter_td; ++iter_Td) {
+			const auto the_rhs = rhs(x);
+			if (std::abs(the_rhs) < rel_tol * compare) {
+				break;
+			}
+			const double dT = -the_rhs / jac(x);
+			x += dT;
+			if (iter_Td > 0) {
+				if (std::abs(dT) < rel_change_tol * std::abs(x)) {
+					break;
+				}
+			}
+		}
+		if (iter_Td >= max_iter_td) {
+			x = -1.0;
+		}
+		return x;
+	}
+
+	// :1420-1483 ComputeDustTemperatureBateKeto, nGroups_ == 1
+	[[nodiscard]] auto ComputeDustTemperatureBateKeto(double const T_gas, double const T_d_init, double const rho, double const Erad0, double N_d, double dt,
+							  double R_sum, int n_step) const -> double
+	{
+		if (n_step > 0) {
+			const auto T_d = T_gas - R_sum / (N_d * std::sqrt(T_gas));
+			return T_d;
+		}
+		const double c_hat_ = rt.c_hat;
+		auto rhs = [=](double T_d) -> double {
+			const auto fourPiBoverC = ComputeThermalRadiationSingleGroup(T_d);
+			const auto kappaE = ComputeEnergyMeanOpacity(rho, T_d);
+			const auto kappaP = ComputePlanckOpacity(rho, T_d);
+			return c_hat_ * dt * rho * (kappaE * Erad0 - kappaP * fourPiBoverC) + N_d * std::sqrt(T_gas) * (T_gas - T_d);
+		};
+		auto jac = [=](double T_d) -> double {
+			const auto kappaP = ComputePlanckOpacity(rho, T_d);
+			const auto d_fourpib_over_c_d_t = ComputeThermalRadiationTempDerivativeSingleGroup(T_d);
+			return -c_hat_ * dt * rho * (kappaP * d_fourpib_over_c_d_t) - N_d * std::sqrt(T_gas);
+		};
+		const double Lambda_compare = N_d * std::sqrt(T_gas) * T_gas;
+		return BackwardEulerOneVariable(rhs, jac, T_d_init, Lambda_compare);
 	}
 	// :1289-1308
 	[[nodiscard]] static auto ComputeEintFromEgas(double density, double X1GasMom, double X2GasMom, double X3GasMom, double Etot) -> double
@@ -452,6 +517,13 @@ struct RadSystem {
 						gas_update_factor = IMEX_a32;
 					}
 
+					// :89-98
+					double coeff_n = NAN;
+					const double H_num_den = rho / eos.tr.mean_molecular_weight; // ComputeNumberDensityH (:463-467)
+					if (rt.enable_dust_gas_thermal_coupling_model) {
+						coeff_n = dt * rt.dustGasInteractionCoeff * H_num_den * H_num_den / cscale;
+					}
+
 					const int max_ite = 5;
 					int ite = 0;
 					for (; ite < max_ite; ++ite) {
@@ -490,7 +562,15 @@ struct RadSystem {
 							int n = 0;
 							for (; n < maxIter; ++n) {
 								T_gas = eos.ComputeTgasFromEint(rho, Egas_guess);
-								T_d = T_gas;
+								// dust temperature (:165-175)
+								if (!rt.enable_dust_gas_thermal_coupling_model) {
+									T_d = T_gas;
+								} else {
+									T_d = ComputeDustTemperatureBateKeto(T_gas, T_gas, rho, Erad_guess, coeff_n, dt, R, n);
+									if (T_d < 0.0) {
+										p_iteration_failure_counter[1] += 1;
+									}
+								}
 								fourPiBoverC = ComputeThermalRadiationSingleGroup(T_d);
 								kappaP = ComputePlanckOpacity(rho, T_d);
 								kappaE = ComputeEnergyMeanOpacity(rho, T_d);
@@ -549,14 +629,32 @@ struct RadSystem {
 								const auto d_fourpiboverc_d_t = ComputeThermalRadiationTempDerivativeSingleGroup(T_d);
 								auto dEg_dT = kappaPoverE * d_fourpiboverc_d_t;
 
-								double J00 = 1.0 + cooling_derivative * dt / c_v;
-								double J01 = cscale;
-								double J10 = 1.0 / c_v * dEg_dT - (1 / cscale) * cooling_derivative * dt;
+								double J00 = NAN;
+								double J01 = NAN;
+								double J10 = NAN;
 								double J11 = NAN;
-								if (tau <= 0.0) {
-									J11 = -std::numeric_limits<double>::infinity();
-								} else {
-									J11 = -1.0 * kappaPoverE / tau - 1.0;
+								if (!rt.enable_dust_gas_thermal_coupling_model) {
+									J00 = 1.0 + cooling_derivative * dt / c_v;
+									J01 = cscale;
+									J10 = 1.0 / c_v * dEg_dT - (1 / cscale) * cooling_derivative * dt;
+									if (tau <= 0.0) {
+										J11 = -std::numeric_limits<double>::infinity();
+									} else {
+										J11 = -1.0 * kappaPoverE / tau - 1.0;
+									}
+								} else { // :293-305
+									const double LARGE = 1.0e100; // :7
+									const double d_Td_d_T = 3. / 2. - T_d / (2. * T_gas);
+									dEg_dT *= d_Td_d_T;
+									const double dTd_dRg = -1.0 / (coeff_n * std::sqrt(T_gas));
+									J00 = 1.0;
+									J01 = cscale;
+									J10 = 1.0 / c_v * dEg_dT;
+									if (tau <= 0.0) {
+										J11 = -LARGE;
+									} else {
+										J11 = kappaPoverE * d_fourpiboverc_d_t * dTd_dRg - kappaPoverE / tau - 1.0;
+									}
 								}
 
 								const double y0 = -F_G;

@@ -22,12 +22,15 @@ struct Rad {
 	double kT_ref, kT_exp, kT_floor;
 	int beta_order, pow_mode, opacity_model, eddington_model;
 	int ngroups; // Physics_Traits::nGroups
+	double dust_coeff; // QuokkaSimulation::dustGasInteractionCoeff_ (DUST instantiation of the source kernel only)
+	double mean_molecular_mass = 0.; // EOS_Traits::mean_molecular_weight as given (ComputeNumberDensityH; set by the source-term launcher)
+	int thermal_model; // 0: a T^4; 1: a T (RadDust's hooks; DUST instantiation only)
 	__host__ __device__ explicit Rad(qk_rad_traits const &t)
 	    : c(t.c_light), chat(t.c_hat), arad(t.radiation_constant),
 	      Erad_floor(t.Erad_floor / ((t.ngroups > 1) ? t.ngroups : 1)), // Erad_floor_ = RadSystem_Traits::Erad_floor / nGroups_ (radiation_system.hpp:211)
 	      kappaP0(t.kappaP), kappaE0(t.kappaE), kappaF0(t.kappaF), kT_ref(t.opacity_T_ref), kT_exp(t.opacity_T_exponent), kT_floor(t.opacity_pow_floor),
 	      beta_order(t.beta_order), pow_mode(t.pow_mode), opacity_model(t.opacity_model), eddington_model(t.eddington_model),
-	      ngroups((t.ngroups > 1) ? t.ngroups : 1)
+	      ngroups((t.ngroups > 1) ? t.ngroups : 1), dust_coeff(t.dust_gas_interaction_coeff), thermal_model(t.thermal_model)
 	{
 	}
 	// problem hooks ComputePlanckOpacity / ComputeEnergyMeanOpacity / ComputeFluxMeanOpacity (radiation_system.hpp:1141-1154):
@@ -83,6 +86,9 @@ struct Rad {
 		return power;
 	}
 	QK_DEV auto thermalRadiationTempDerivative(double T) const -> double { return 4. * arad * pow3(T); }
+	// the same two hooks as RadDust specialises them (test_rad_dust.cpp:86-97) when thermal_model == 1
+	QK_DEV auto thermalRadiationHook(double T) const -> double { return (thermal_model == 1) ? arad * T : thermalRadiation(T); }
+	QK_DEV auto thermalRadiationTempDerivativeHook(double T) const -> double { return (thermal_model == 1) ? arad : thermalRadiationTempDerivative(T); }
 };
 
 // radiation_system.hpp:873-916: row `row` of the Eddington tensor, plus T[row][row] via Tn[row]
@@ -223,9 +229,45 @@ QK_DEV auto egasFromEint(double rho, double px, double py, double pz, double Ein
 
 // source_terms_single_group.hpp:29-563 for one cell.  U[10] in place; counters as in the reference:
 // it_counter[0] += 1, [1] += n+1, [2] = max(n+1); fail[0] Newton failure, fail[2] outer-iteration failure.
-template <bool TDEP = false>
+// radiation_system.hpp:1420-1483 (nGroups_ == 1) with BackwardEulerOneVariable (:1387-1418): the dust temperature between gas and radiation
+template <bool TDEP> QK_DEV auto dustTemperatureBateKeto(Rad const &r, double T_gas, double T_d_init, double rho, double Erad0, double N_d, double dt, double R_sum, int n_step) -> double
+{
+	if (n_step > 0) {
+		return T_gas - R_sum / (N_d * sqrt(T_gas));
+	}
+	const double Lambda_compare = N_d * sqrt(T_gas) * T_gas;
+	double x = T_d_init;
+	const double rel_tol = 1.0e-8;
+	const double rel_change_tol = 1.0e-6;
+	const int max_iter_td = 100;
+	int iter_Td = 0;
+	for (; iter_Td < max_iter_td; ++iter_Td) {
+		const double fourPiBoverC = r.thermalRadiationHook(x);
+		const double kE = r.template kappaE<TDEP>(rho, x);
+		const double kP = r.template kappaP<TDEP>(rho, x);
+		const double the_rhs = r.chat * dt * rho * (kE * Erad0 - kP * fourPiBoverC) + N_d * sqrt(T_gas) * (T_gas - x);
+		if (fabs(the_rhs) < rel_tol * Lambda_compare) {
+			break;
+		}
+		const double jac = -r.chat * dt * rho * (r.template kappaP<TDEP>(rho, x) * r.thermalRadiationTempDerivativeHook(x)) - N_d * sqrt(T_gas);
+		const double dT = -the_rhs / jac;
+		x += dT;
+		if (iter_Td > 0) {
+			if (fabs(dT) < rel_change_tol * fabs(x)) {
+				break;
+			}
+		}
+	}
+	if (iter_Td >= max_iter_td) {
+		x = -1.0;
+	}
+	return x;
+}
+
+// DUST: ISM_Traits::enable_dust_gas_thermal_coupling_model (its own instantiation: the gas-radiation kernel keeps its registers)
+template <bool TDEP = false, bool DUST = false>
 QK_DEV void radSourceCell(Rad const &r, Eos const &eos, double U[10], double srcval, double dt_radiation, int stage, int &n_newton_total, int &n_newton_max,
-			  int &n_solves, int &fail_newton, int &fail_outer)
+			  int &n_solves, int &fail_newton, int &fail_outer, int *fail_dust = nullptr)
 {
 	double dt = dt_radiation;
 	if (stage == 2) {
@@ -262,6 +304,12 @@ QK_DEV void radSourceCell(Rad const &r, Eos const &eos, double U[10], double src
 	if (stage == 1) {
 		gas_update_factor = IMEX_a32;
 	}
+	// source_terms_single_group.hpp:89-98
+	double coeff_n = __builtin_nan("");
+	if constexpr (DUST) {
+		const double H_num_den = rho / r.mean_molecular_mass; // ComputeNumberDensityH (radiation_system.hpp:463-467)
+		coeff_n = dt * r.dust_coeff * H_num_den * H_num_den / cscale;
+	}
 
 	const int max_ite = 5;
 	int ite = 0;
@@ -297,8 +345,16 @@ QK_DEV void radSourceCell(Rad const &r, Eos const &eos, double U[10], double src
 			int n = 0;
 			for (; n < maxIter; ++n) {
 				T_gas = eos.tgasFromEint(rho, Egas_guess);
-				T_d = T_gas;
-				fourPiBoverC = r.thermalRadiation(T_d);
+				if constexpr (!DUST) {
+					T_d = T_gas;
+					fourPiBoverC = r.thermalRadiation(T_d);
+				} else { // :165-177
+					T_d = dustTemperatureBateKeto<TDEP>(r, T_gas, T_gas, rho, Erad_guess, coeff_n, dt, R, n);
+					if (T_d < 0.0 && fail_dust != nullptr) {
+						*fail_dust += 1;
+					}
+					fourPiBoverC = r.thermalRadiationHook(T_d);
+				}
 				kappaP = r.template kappaP<TDEP>(rho, T_d);
 				kappaE = r.template kappaE<TDEP>(rho, T_d);
 				if (kappaE > 0.0) {
@@ -339,16 +395,30 @@ QK_DEV void radSourceCell(Rad const &r, Eos const &eos, double U[10], double src
 					break;
 				}
 				const double c_v = eintTempDerivative(eos, rho, T_gas);
-				const double d_fourpiboverc_d_t = r.thermalRadiationTempDerivative(T_d);
-				const double dEg_dT = kappaPoverE * d_fourpiboverc_d_t;
-				const double J00 = 1.0 + cooling_derivative * dt / c_v;
-				const double J01 = cscale;
-				const double J10 = 1.0 / c_v * dEg_dT - (1 / cscale) * cooling_derivative * dt;
-				double J11;
-				if (tau <= 0.0) {
-					J11 = -__builtin_inf();
-				} else {
-					J11 = -1.0 * kappaPoverE / tau - 1.0;
+				const double d_fourpiboverc_d_t = DUST ? r.thermalRadiationTempDerivativeHook(T_d) : r.thermalRadiationTempDerivative(T_d);
+				double dEg_dT = kappaPoverE * d_fourpiboverc_d_t;
+				double J00, J01, J10, J11;
+				if constexpr (!DUST) {
+					J00 = 1.0 + cooling_derivative * dt / c_v;
+					J01 = cscale;
+					J10 = 1.0 / c_v * dEg_dT - (1 / cscale) * cooling_derivative * dt;
+					if (tau <= 0.0) {
+						J11 = -__builtin_inf();
+					} else {
+						J11 = -1.0 * kappaPoverE / tau - 1.0;
+					}
+				} else { // :293-305
+					const double d_Td_d_T = 3. / 2. - T_d / (2. * T_gas);
+					dEg_dT *= d_Td_d_T;
+					const double dTd_dRg = -1.0 / (coeff_n * sqrt(T_gas));
+					J00 = 1.0;
+					J01 = cscale;
+					J10 = 1.0 / c_v * dEg_dT;
+					if (tau <= 0.0) {
+						J11 = -1.0e100; // LARGE (:7)
+					} else {
+						J11 = kappaPoverE * d_fourpiboverc_d_t * dTd_dRg - kappaPoverE / tau - 1.0;
+					}
 				}
 				const double y0 = -F_G;
 				const double y1 = -1. * F_D;

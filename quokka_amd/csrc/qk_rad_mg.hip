@@ -175,6 +175,9 @@ auto checkMG(qk_ctx *ctx, const qk_rad_traits *rt) -> int
 	if (rt->beta_order != 0 && rt->beta_order != 1) {
 		return setError(ctx, QK_ERR_UNSUPPORTED, "multigroup source term: beta_order must be 0 or 1 (source_terms_multi_group.hpp:526)");
 	}
+	if (rt->enable_dust_gas_thermal_coupling_model != 0 || rt->thermal_model != 0) {
+		return setError(ctx, QK_ERR_UNSUPPORTED, "multigroup source term: the dust-gas coupling model (radiation_dust_system.hpp) is not built");
+	}
 	if (!(rt->energy_unit > 0.0)) {
 		return setError(ctx, QK_ERR_INVALID, "multigroup: energy_unit must be positive");
 	}

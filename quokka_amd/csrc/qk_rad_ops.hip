@@ -687,16 +687,17 @@ int qk_rad_AddFluxesRK2(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int
 
 } // extern "C"
 
-template <bool TDEP>
+template <bool TDEP, bool DUST = false>
 static auto radSourceImpl(qk_level *lev, qk_stream s, const qk_rad_traits *rt, const qk_hydro_traits *t, qk_array4 *cons_t, const qk_array4 *src_t, double dt,
 			  int stage, int *d_iteration_counter, int *d_failure_counter) -> int
 {
-	const Rad rad(*rt);
+	Rad rad(*rt);
+	rad.mean_molecular_mass = t->mean_molecular_weight;
 	const Eos eos(*t);
 	int *slots = counterSlots(lev->ctx);
 	QK_REQUIRE(lev->ctx, slots != nullptr, "AddSourceTermsSingleGroup: cannot allocate the counter slots");
 	launchRad<QK_RAD_SRC_WAVES>(lev, s, 0, -1, "rad_AddSourceTerms", [=] __device__(int b, int i, int j, int k, bool valid) {
-		int ntot = 0, nmax = 0, nsolve = 0, fnewton = 0, fouter = 0;
+		int ntot = 0, nmax = 0, nsolve = 0, fnewton = 0, fouter = 0, fdust = 0;
 		if (valid) {
 			WA4 S(cons_t[b]);
 			RA4 Q(src_t[b]);
@@ -706,7 +707,10 @@ static auto radSourceImpl(qk_level *lev, qk_stream s, const qk_rad_traits *rt, c
 			for (int n = 0; n < 10; ++n) {
 				U[n] = S.p[c + S.ns * n];
 			}
-			radSourceCell<TDEP>(rad, eos, U, Q(i, j, k), dt, stage, ntot, nmax, nsolve, fnewton, fouter);
+			radSourceCell<TDEP, DUST>(rad, eos, U, Q(i, j, k), dt, stage, ntot, nmax, nsolve, fnewton, fouter, DUST ? &fdust : nullptr);
+			if (DUST && fdust != 0) {
+				atomicAdd(&d_failure_counter[1], fdust); // (rare: a negative dust temperature; the reference counts it the same way, :172-174)
+			}
 			// rho (comp 0) is never modified
 #pragma unroll
 			for (int n = 1; n < 10; ++n) {
@@ -758,6 +762,13 @@ int qk_rad_AddSourceTermsSingleGroup(qk_level *lev, qk_stream s, const qk_rad_tr
 	}
 	QK_REQUIRE(lev->ctx, cons_t && src_t && d_iteration_counter && d_failure_counter, "AddSourceTermsSingleGroup: NULL");
 	QK_REQUIRE(lev->ctx, stage == 1 || stage == 2, "AddSourceTermsSingleGroup: stage must be 1 or 2");
+	QK_REQUIRE(lev->ctx, rt->thermal_model == 0 || (rt->thermal_model == 1 && rt->enable_dust_gas_thermal_coupling_model != 0),
+		   "AddSourceTermsSingleGroup: thermal_model must be 0, or 1 together with the dust model");
+	if (rt->enable_dust_gas_thermal_coupling_model != 0) {
+		QK_REQUIRE(lev->ctx, rt->dust_gas_interaction_coeff > 0.0 && t->mean_molecular_weight > 0.0, "dust model: needs dust_gas_interaction_coeff > 0");
+		return (rt->opacity_model == 2) ? radSourceImpl<true, true>(lev, s, rt, t, cons_t, src_t, dt, stage, d_iteration_counter, d_failure_counter)
+						: radSourceImpl<false, true>(lev, s, rt, t, cons_t, src_t, dt, stage, d_iteration_counter, d_failure_counter);
+	}
 	// the temperature-dependent opacities get their own instantiation: the constant-opacity kernel keeps its register budget
 	return (rt->opacity_model == 2) ? radSourceImpl<true>(lev, s, rt, t, cons_t, src_t, dt, stage, d_iteration_counter, d_failure_counter)
 					: radSourceImpl<false>(lev, s, rt, t, cons_t, src_t, dt, stage, d_iteration_counter, d_failure_counter);

@@ -6,6 +6,7 @@ problems on the HIP operators.  Planck energy fractions in initial and boundary 
   src/problems/RadTube/test_radiation_tube.cpp                              radtube_problem
   src/problems/RadMarshakVaytet/test_radiation_marshak_Vaytet.cpp           marshak_vaytet_problem
   src/problems/RadhydroPulseMGconst/test_radhydro_pulse_MG_const_kappa.cpp  pulse_mg_problem
+  src/problems/RadDust/test_rad_dust.cpp (single group + dust)              raddust_problem
 """
 import ctypes as C
 import math
@@ -263,6 +264,41 @@ def pulse_mg_problem(ctx: Context, multigroup: bool, nx: int = 64, pow_mode: int
         else:
             U[RAD0] = S.a_rad * T * T * T * T
             U[0], U[4], U[5] = rho, Egas, Egas
+        return U
+
+    sim.set_initial_conditions(ic)
+    return sim
+
+
+# ---------------------------------------------------------------------- RadDust
+class RadDustConstants:
+    """test_rad_dust.cpp:19-34"""
+    c = chat = 1.0e8
+    chi0, T0, rho0, a_rad, mu, k_B = 10000.0, 1.0, 1.0, 1.0, 1.0, 1.0
+    max_time, delta_time = 1.0e-5, 1.0e-8
+    erad_floor = 1.0e-20 * (a_rad * T0 * T0 * T0 * T0)
+    dust_gas_interaction_coeff = 1.0e6  # tests/RadDust.in
+
+
+def raddust_problem(ctx: Context, nx: int = 8) -> RadhydroSimulation:
+    """Gas, dust and radiation of a uniform medium relaxing to a common temperature: ISM_Traits::enable_dust_gas_thermal_coupling_model, emission
+    linear in T_dust (the problem's ComputeThermalRadiationSingleGroup hook), kappa = chi0 / rho; constant dt = 1e-8 s, 1000 steps
+    (deck tests/RadDust.in: 8 cells, periodic, radiation.cfl = 8, dust_gas_interaction_coeff = 1e6)."""
+    S = RadDustConstants
+    geom = Geometry(1, [nx], [0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [1, 1, 1])
+    bcs = [([capi.BC_INT_DIR, 0, 0], [capi.BC_INT_DIR, 0, 0]) for _ in range(10)]
+    traits = capi.traits(5.0 / 3.0, True, 1, mean_molecular_weight=S.mu, boltzmann_constant=S.k_B)
+    rt = capi.RadTraits(S.c, S.chat, S.a_rad, S.erad_floor, 1, 1, S.chi0, S.chi0, S.chi0, 0, 0)
+    rt.enable_dust_gas_thermal_coupling_model, rt.dust_gas_interaction_coeff, rt.thermal_model = 1, S.dust_gas_interaction_coeff, 1
+    sim = RadhydroSimulation(ctx, geom, traits, rt, bcs, [nx, 1, 1], use_fused=False)
+    sim.radiationReconstructionOrder_ = 3  # problem_main :145-170
+    sim.stopTime_, sim.cflNumber_, sim.radiationCflNumber_, sim.maxTimesteps_ = S.max_time, 0.8, 8.0, 1000000
+    sim.initDt_ = sim.maxDt_ = S.delta_time
+    Egas = eint_from_tgas(S.rho0, S.T0, S.mu, kB=S.k_B)
+
+    def ic(i, j, k):  # setInitialConditionsOnGrid :99-122
+        U = rad_state(10, i.shape)
+        U[0], U[4], U[5], U[RAD0] = S.rho0, Egas, Egas, S.erad_floor
         return U
 
     sim.set_initial_conditions(ic)

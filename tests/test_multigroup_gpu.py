@@ -10,9 +10,9 @@ import numpy as np
 import pytest
 import torch
 
-from oracle.pyoracle import (MARSHAK_VAYTET, PIECEWISE_CONSTANT, PPL_FIXED_SLOPE, PPL_FULL_SPECTRUM, PULSE_MG, PULSE_MG_GREY, RADSHOCK_MG,
-                             RADTUBE)
-from test_multigroup_oracle import A_RAD, H_PLANCK, K_B, pulse_mg_error, radshock_mg_error, tube_table
+from oracle.pyoracle import (MARSHAK_VAYTET, PIECEWISE_CONSTANT, PPL_FIXED_SLOPE, PPL_FULL_SPECTRUM, PULSE_MG, PULSE_MG_GREY, RADDUST,
+                             RADSHOCK_MG, RADTUBE)
+from test_multigroup_oracle import A_RAD, H_PLANCK, K_B, pulse_mg_error, raddust_error, radshock_mg_error, tube_table
 
 pytestmark = pytest.mark.gpu
 
@@ -223,3 +223,24 @@ def test_multigroup_transport_in_3d_is_bit_exact(ctx, oracle):
         for b in range(so.nboxes):
             a, g_ = so.valid(b), sg.state_new_cc_.valid(b).cpu().numpy()
             assert np.array_equal(a[6:], g_[6:]), (order, b, np.abs(a[6:] - g_[6:]).max())
+
+
+def test_dust_model_steps_match_oracle_and_criterion(ctx, oracle):
+    """RadDust: the DUST instantiation of the single-group exchange kernel (no libm beyond sqrt: bit for bit), and the reference's criterion"""
+    from quokka_amd.radhydro_multigroup import raddust_problem
+    so = oracle.sim(RADDUST, 1, [8, 1, 1], [0, 0, 0], [1.0, 1, 1], [1, 1, 1], max_grid_size=[8, 1, 1])
+    sg = raddust_problem(ctx)
+    assert np.array_equal(so.valid(0), sg.state_new_cc_.valid(0).cpu().numpy())
+    ts, us = [], []
+    for it in range(1000):
+        assert so.step() and sg.step(), it
+        assert so.dt == sg.dt_
+        ts.append(sg.tNew_)
+        us.append(sg.state_new_cc_.valid(0).cpu().numpy()[:, 0, 0, 0])
+        if it in (0, 9, 99, 999):
+            assert np.array_equal(so.valid(0), sg.state_new_cc_.valid(0).cpu().numpy()), it
+    co = so.rad_counters()
+    assert sg.rad_counters["solves"] == co["solves"] and sg.rad_counters["newton_iterations"] == co["newton_iterations"]
+    assert co["fail_coupling"] == co["fail_dust"] == co["fail_outer"] == 0
+    err = raddust_error(np.array(ts), np.array(us))
+    assert err < 0.0008, err

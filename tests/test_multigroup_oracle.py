@@ -8,8 +8,8 @@ import re
 import numpy as np
 import pytest
 
-from oracle.pyoracle import (MARSHAK_VAYTET, PIECEWISE_CONSTANT, PPL_FIXED_SLOPE, PPL_FULL_SPECTRUM, PULSE_MG, PULSE_MG_GREY, RADSHOCK_MG,
-                             RADTUBE)
+from oracle.pyoracle import (MARSHAK_VAYTET, PIECEWISE_CONSTANT, PPL_FIXED_SLOPE, PPL_FULL_SPECTRUM, PULSE_MG, PULSE_MG_GREY, RADDUST,
+                             RADSHOCK_MG, RADTUBE)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 K_B, H_PLANCK, C_LIGHT = 1.380649e-16, 6.62607015e-27, 2.99792458e10
@@ -240,3 +240,30 @@ def test_marshak_wave_with_frequency_dependent_opacity_runs_clean(oracle):
     assert depth[3] > depth[2] > depth[1], depth
     # hydro is off: the density never changes; the gas still collects the momentum the radiation deposits (x only)
     assert np.all(U[0] == 1.0e-3) and np.all(U[2:4] == 0.0) and np.all(U[1] >= 0.0) and U[1, 0] > 0.0
+
+
+def raddust_error(t, u):
+    """test_rad_dust.cpp:172-222: T_gas and T_rad (= E_rad / a_rad: the problem linearises the emission) of cell 0 after every step against
+    extern/data/dust/rad_dust_exact.csv (committed as data in tests/golden/), tolerance 0.0008"""
+    ex = np.loadtxt(os.path.join(HERE, "golden", "rad_dust_exact.csv"), delimiter=",", skiprows=1)
+    m = ex[:, 0] > 0.0
+    rho = u[:, 0]
+    Eint = u[:, 4] - 0.5 * (u[:, 1] ** 2 + u[:, 2] ** 2 + u[:, 3] ** 2) / rho
+    Tgas = Eint / (rho * 1.0 / (1.0 * (5.0 / 3.0 - 1.0)))  # c_v = rho k_B / (mu (gamma - 1)) with k_B = mu = 1
+    Trad = u[:, 6] / 1.0
+    Tg, Tr = np.interp(t, ex[m, 0], ex[m, 1]), np.interp(t, ex[m, 0], ex[m, 2])
+    return float((np.abs(Tgas - Tg).sum() + np.abs(Trad - Tr).sum()) / (np.abs(Tg).sum() + np.abs(Tr).sum()))
+
+
+def test_gas_dust_radiation_relaxation_meets_the_reference_criterion(oracle):
+    """RadDust: the single-group exchange with the dust-gas thermal coupling model (dust temperature of Bate & Keto by a scalar Newton iteration,
+    then the 2 x 2 Newton-Raphson with the dust terms in the Jacobian), 1000 steps of 1e-8 s"""
+    s = oracle.sim(RADDUST, 1, [8, 1, 1], [0, 0, 0], [1.0, 1, 1], [1, 1, 1], max_grid_size=[8, 1, 1])
+    t, u = s.run_record(2000, 0, (0, 0, 0))
+    assert len(t) == 1000 and abs(t[-1] - 1.0e-5) < 1e-18
+    c = s.rad_counters()
+    assert c["fail_coupling"] == c["fail_dust"] == c["fail_outer"] == 0
+    err = raddust_error(t, u)
+    assert err < 0.0008, err
+    # gas, dust and radiation end at the common temperature 0.6 (energy conservation: c_v T + a T = 1.5 + 0)
+    assert abs(u[-1, 6] - 0.6) < 1e-5 and abs(u[-1, 5] / 1.5 - 0.6) < 1e-5
