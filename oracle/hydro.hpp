@@ -555,14 +555,20 @@ struct HydroSystem {
 						E_R = tr.eos.ComputeEintFromPres(rho_R, P_R) + ke_R;
 					}
 
-					// :954-976 (3-D mapping; in 1-D only X1 occurs; 2-D mapping :963-966 not built here)
+					// :954-976 (in 1-D only X1 occurs; X2: the swap of a 2-D build :963-966, the cyclic permutation of a 3-D build :967-970)
 					int velN_index = x1Velocity_index;
 					int velV_index = x2Velocity_index;
 					int velW_index = x3Velocity_index;
 					if (dir == X2) {
-						velN_index = x2Velocity_index;
-						velV_index = x3Velocity_index;
-						velW_index = x1Velocity_index;
+						if (g_spacedim == 2) {
+							velN_index = x2Velocity_index;
+							velV_index = x1Velocity_index;
+							velW_index = x3Velocity_index; // unchanged in 2D
+						} else {
+							velN_index = x2Velocity_index;
+							velV_index = x3Velocity_index;
+							velW_index = x1Velocity_index;
+						}
 					} else if (dir == X3) {
 						velN_index = x3Velocity_index;
 						velV_index = x1Velocity_index;

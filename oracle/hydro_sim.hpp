@@ -106,6 +106,7 @@ struct HydroSim {
 
 	void define()
 	{
+		g_spacedim = ndim();
 		state_old_cc_ = MultiFab(grids, ncomp_cc, nghost_cc, ndim());
 		state_new_cc_ = MultiFab(grids, ncomp_cc, nghost_cc, ndim());
 	}
@@ -732,6 +733,7 @@ struct HydroSim {
 	// one coarse step: simulation.hpp:866-890 + :1276-1286 + QuokkaSimulation.hpp:653-707
 	auto step() -> bool
 	{
+		g_spacedim = ndim(); // (the reference's AMREX_SPACEDIM: a 2-D build permutes the X2 views differently, hyperbolic.hpp)
 		computeTimestep();
 		double const time = tNew_;
 		tNew_ += dt_;

@@ -28,7 +28,11 @@ inline auto clamp(double v, double lo, double hi) -> double { return (v < lo) ? 
 // math_impl.hpp:18
 inline auto sgn(double val) -> int { return static_cast<int>(0.0 < val) - static_cast<int>(val < 0.0); }
 
-// ArrayView_3d.hpp:22-28. Loop index (i_in,j_in,k_in) -> view index (i,j,k)
+// AMREX_SPACEDIM of the reference build being restated: a compile-time global there, a process-wide variable here (set by the simulation that
+// is about to run; 1-D and 3-D builds share ArrayView_3d.hpp, a 2-D build uses ArrayView_2d.hpp, where X2 is an index SWAP)
+inline int g_spacedim = 3;
+
+// ArrayView_3d.hpp:22-28 / ArrayView_2d.hpp:13-17. Loop index (i_in,j_in,k_in) -> view index (i,j,k)
 struct Idx3 {
 	int i, j, k;
 };
@@ -38,22 +42,30 @@ inline auto reorderMultiIndex(int dir, int i, int j, int k) -> Idx3
 		return {i, j, k};
 	}
 	if (dir == X2) {
+		if (g_spacedim == 2) {
+			return {j, i, k};
+		}
 		return {j, k, i};
 	}
 	return {k, i, j};
 }
 
 // ArrayView_3d.hpp:30-113. view(i,j,k,n): X1 arr(i,j,k,n); X2 arr(k,i,j,n); X3 arr(j,k,i,n)
+// ArrayView_2d.hpp:27-77.  view(i,j,k,n): X1 arr(i,j,k,n); X2 arr(j,i,k,n)
 template <typename T> struct View {
 	Array4<T> a;
 	int dir;
-	View(Array4<T> arr, int d) : a(arr), dir(d) {}
+	bool swap2d;
+	View(Array4<T> arr, int d) : a(arr), dir(d), swap2d(g_spacedim == 2) {}
 	auto operator()(int i, int j, int k, int n = 0) const -> T &
 	{
 		if (dir == X1) {
 			return a(i, j, k, n);
 		}
 		if (dir == X2) {
+			if (swap2d) {
+				return a(j, i, k, n);
+			}
 			return a(k, i, j, n);
 		}
 		return a(j, k, i, n);

@@ -64,6 +64,7 @@ void orc_cons_to_prim(orc_hydro_traits const *t, double const *cons, double *pri
 void orc_flattening_coefficients(orc_hydro_traits const *t, int dir, double const *prim, int const glo[3], int const ghi[3], double *chi,
 				 int const clo[3], int const chi_hi[3])
 {
+	g_spacedim = t->ndim;
 	HydroSystem h = makeSystem(t);
 	Box g = mkbox(glo, ghi);
 	Box c = mkbox(clo, chi_hi);
@@ -76,6 +77,7 @@ void orc_flattening_coefficients(orc_hydro_traits const *t, int dir, double cons
 void orc_compute_hydro_fluxes(orc_hydro_traits const *t, int order, double K_visc, double const *cons, int const vlo[3], int const vhi[3], int nghost,
 			      double *flux0, double *flux1, double *flux2, double *fvel0, double *fvel1, double *fvel2)
 {
+	g_spacedim = t->ndim;
 	HydroSim sim;
 	sim.hydro = makeSystem(t);
 	sim.geom.ndim = t->ndim;
@@ -275,6 +277,10 @@ void *orc_sim_create(orc_sim_config const *c)
 	} else if (c->problem == 18) {
 		setupMarshakVaytet(*sim, c->opacity_model > 0 ? c->opacity_model : static_cast<int>(PPL_opacity_full_spectrum));
 		sim->rad.rt.pow_mode = c->rad_pow_mode;
+	} else if (c->problem == 23) {
+		setupBlast2D(*sim);
+	} else if (c->problem == 22) {
+		setupQuirk(*sim);
 	} else if (c->problem == 21) {
 		setupRadDust(*sim);
 		sim->rad.rt.pow_mode = c->rad_pow_mode;
@@ -358,6 +364,7 @@ void orc_sim_counters(void *p, long out[3])
 void orc_sim_rad_transport_only(void *p, double dt_radiation)
 {
 	auto *s = static_cast<HydroSim *>(p);
+	g_spacedim = s->ndim();
 	s->advanceRadiationForwardEuler(s->tNew_, dt_radiation);
 	s->advanceRadiationMidpointRK2(s->tNew_, dt_radiation);
 }
@@ -398,6 +405,7 @@ long orc_sim_run_record(void *p, long nsteps, int b, int i, int j, int k, double
 int orc_sim_advance_fixed_dt(void *p, double dt)
 {
 	auto *s = static_cast<HydroSim *>(p);
+	g_spacedim = s->ndim();
 	double const time = s->tNew_;
 	s->dt_ = dt;
 	s->tNew_ += dt;

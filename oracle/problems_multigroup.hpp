@@ -6,6 +6,7 @@
 //   src/problems/RadMarshakVaytet/test_radiation_marshak_Vaytet.cpp
 //   src/problems/RadhydroPulseMGconst/test_radhydro_pulse_MG_const_kappa.cpp
 //   src/problems/RadDust/test_rad_dust.cpp (single group, dust-gas thermal coupling)
+// and the 2-D hydro pin src/problems/HydroQuirk/test_quirk.cpp
 #ifndef ORACLE_PROBLEMS_MULTIGROUP_HPP_
 #define ORACLE_PROBLEMS_MULTIGROUP_HPP_
 
@@ -562,6 +563,135 @@ inline void setupRadDust(HydroSim &sim)
 		state_cc(i, j, k, x1Momentum_index) = S::v0 * S::rho0;
 		state_cc(i, j, k, x2Momentum_index) = 0.;
 		state_cc(i, j, k, x3Momentum_index) = 0.;
+	});
+	sim.finishInitialConditions();
+}
+
+// ---------------------------------------------------------------- Quirk's odd-even decoupling test (src/problems/HydroQuirk/test_quirk.cpp,
+// deck tests/quirk.in: 128 x 16 (x 16) cells on 1 x 0.125; built for AMREX_SPACEDIM >= 2) — the 2-D pin of the hydro path
+struct QuirkConstants { // :58-63
+	static constexpr double dl = 3.692, ul = -0.625, pl = 26.85;
+	static constexpr double dr = 1.0, ur = -5.0, pr = 0.6;
+};
+
+inline void setupQuirk(HydroSim &sim)
+{
+	using S = QuirkConstants;
+	sim.hydro.tr.eos.tr.gamma = 5. / 3.; // :38-46
+	sim.hydro.tr.eos.tr.mean_molecular_weight = C::m_u;
+	sim.hydro.tr.eos.tr.boltzmann_constant = C::k_B;
+	sim.hydro.tr.reconstruct_eint = false;
+	sim.hydro.tr.nscalars = 0;
+	sim.ncomp_cc = kNumHydroVars;
+	// problem_main :248-272 (only component 0 carries ext_dir there; the functor fills every component of every ghost cell beyond x)
+	sim.BCs_cc.assign(sim.ncomp_cc, BCRec{});
+	for (int n = 0; n < sim.ncomp_cc; ++n) {
+		sim.BCs_cc[n].lo[0] = ext_dir;
+		sim.BCs_cc[n].hi[0] = ext_dir;
+	}
+	sim.reconstructionOrder_ = 2; // PLM
+	sim.stopTime_ = 0.4;
+	sim.cflNumber_ = 0.4;
+	sim.maxTimesteps_ = 2000;
+	const double gamma = sim.hydro.tr.eos.tr.gamma;
+	// setCustomBoundaryConditions :203-246
+	sim.customBC = [gamma](int i, int j, int k, Array4<double> const &consVar, Box const &dom, double /*time*/) {
+		if (i < dom.lo[0]) {
+			consVar(i, j, k, energy_index) = S::pl / (gamma - 1.) + 0.5 * S::dl * S::ul * S::ul;
+			consVar(i, j, k, internalEnergy_index) = S::pl / (gamma - 1.);
+			consVar(i, j, k, density_index) = S::dl;
+			consVar(i, j, k, x1Momentum_index) = S::dl * S::ul;
+			consVar(i, j, k, x2Momentum_index) = 0.;
+			consVar(i, j, k, x3Momentum_index) = 0.;
+		} else if (i >= dom.hi[0]) {
+			consVar(i, j, k, energy_index) = S::pr / (gamma - 1.) + 0.5 * S::dr * S::ur * S::ur;
+			consVar(i, j, k, internalEnergy_index) = S::pr / (gamma - 1.);
+			consVar(i, j, k, density_index) = S::dr;
+			consVar(i, j, k, x1Momentum_index) = S::dr * S::ur;
+			consVar(i, j, k, x2Momentum_index) = 0.;
+			consVar(i, j, k, x3Momentum_index) = 0.;
+		}
+	};
+	sim.define();
+	Geometry const g = sim.geom;
+	EOS const eos = sim.hydro.tr.eos;
+	// setInitialConditionsOnGrid :66-127
+	double const xshock = 0.4;
+	int ishock = 0;
+	for (ishock = 0; (g.prob_lo[0] + g.dx[0] * (ishock + 0.5)) < xshock; ++ishock) {
+	}
+	ishock--;
+	double const dd = S::dl - 0.135;
+	double const ud = S::ul + 0.219;
+	double const pd = S::pl - 1.31;
+	forEachValidCell(sim, [&](Array4<double> const &state_cc, int i, int j, int k) {
+		double vx = NAN, vy = 0., vz = 0., rho = NAN, P = NAN;
+		if (i <= ishock) {
+			rho = S::dl;
+			vx = S::ul;
+			P = S::pl;
+		} else {
+			rho = S::dr;
+			vx = S::ur;
+			P = S::pr;
+		}
+		if ((i == ishock) && (j % 2 == 0)) {
+			rho = dd;
+			vx = ud;
+			P = pd;
+		}
+		const auto v_sq = vx * vx + vy * vy + vz * vz;
+		state_cc(i, j, k, density_index) = rho;
+		state_cc(i, j, k, x1Momentum_index) = rho * vx;
+		state_cc(i, j, k, x2Momentum_index) = rho * vy;
+		state_cc(i, j, k, x3Momentum_index) = rho * vz;
+		state_cc(i, j, k, energy_index) = eos.ComputeEintFromPres(rho, P) + 0.5 * rho * v_sq;
+		state_cc(i, j, k, internalEnergy_index) = eos.ComputeEintFromPres(rho, P);
+	});
+	sim.finishInitialConditions();
+}
+
+// ---------------------------------------------------------------- circular blast in a reflecting box (src/problems/HydroBlast2D/test_hydro2d_blast.cpp,
+// deck tests/blast2d.in).  Runs as a 2-D build (x-y) or as a 3-D build whose z direction is uniform: with v_z = 0 the two builds perform the same
+// arithmetic on every x-y plane (the X2 view is an index swap in one and a cyclic permutation in the other; the z sweep adds exact zeros), which
+// ties the 2-D restatement to the 3-D one that the reference's known-answer tests pin.
+inline void setupBlast2D(HydroSim &sim)
+{
+	sim.hydro.tr.eos.tr.gamma = 5. / 3.; // :28-32
+	sim.hydro.tr.eos.tr.mean_molecular_weight = C::m_u;
+	sim.hydro.tr.eos.tr.boltzmann_constant = C::k_B;
+	sim.hydro.tr.reconstruct_eint = true;
+	sim.hydro.tr.nscalars = 0;
+	sim.ncomp_cc = kNumHydroVars;
+	// problem_main :127-164: reflecting walls
+	sim.BCs_cc.assign(sim.ncomp_cc, BCRec{});
+	for (int n = 0; n < sim.ncomp_cc; ++n) {
+		for (int d = 0; d < sim.geom.ndim; ++d) {
+			bool const normal = (n == x1Momentum_index + d);
+			sim.BCs_cc[n].lo[d] = normal ? reflect_odd : reflect_even;
+			sim.BCs_cc[n].hi[d] = normal ? reflect_odd : reflect_even;
+		}
+	}
+	sim.stopTime_ = 0.1;
+	sim.cflNumber_ = 0.3;
+	sim.maxTimesteps_ = 20000;
+	sim.define();
+	Geometry const g = sim.geom;
+	double const x0 = g.prob_lo[0] + 0.5 * (g.prob_hi[0] - g.prob_lo[0]);
+	double const y0 = g.prob_lo[1] + 0.5 * (g.prob_hi[1] - g.prob_lo[1]);
+	double const gamma = sim.hydro.tr.eos.tr.gamma;
+	forEachValidCell(sim, [&](Array4<double> const &state_cc, int i, int j, int k) { // :44-91 (the internal energy is left to the first sync)
+		double const x = g.prob_lo[0] + (i + 0.5) * g.dx[0];
+		double const y = g.prob_lo[1] + (j + 0.5) * g.dx[1];
+		double const R = std::sqrt(std::pow(x - x0, 2) + std::pow(y - y0, 2));
+		double const rho = 1.0;
+		double const P = (R < 0.1) ? 10. : 0.1;
+		state_cc(i, j, k, density_index) = rho;
+		state_cc(i, j, k, x1Momentum_index) = 0.;
+		state_cc(i, j, k, x2Momentum_index) = 0.;
+		state_cc(i, j, k, x3Momentum_index) = 0.;
+		state_cc(i, j, k, energy_index) = P / (gamma - 1.) + 0.5 * rho * 0.;
+		state_cc(i, j, k, internalEnergy_index) = 0.;
 	});
 	sim.finishInitialConditions();
 }

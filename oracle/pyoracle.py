@@ -22,6 +22,8 @@ M_U = 1.6605390666e-24
 SOD, CONTACT, SEDOV, SHELL, RADSHOCK, STREAMING, SCALARS, HYDRO1D, COUPLING, SUOLSON, ADVECTING, MARSHAK, RADFORCE, MARSHAK_ASYMPTOTIC, RADPULSE, SHOCKTUBE_CMA = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15
 # multigroup radiation (oracle/problems_multigroup.hpp); PULSE_MG = the advecting 4-group run, PULSE_MG_GREY = the static grey run of the same file
 RADSHOCK_MG, RADTUBE, MARSHAK_VAYTET, PULSE_MG, PULSE_MG_GREY, RADDUST = 16, 17, 18, 19, 20, 21
+QUIRK = 22  # HydroQuirk: the 2-D (or 3-D) odd-even decoupling test
+BLAST2D = 23  # HydroBlast2D: circular blast in a reflecting box, as a 2-D build or as a 3-D build uniform in z
 # OpacityModel (radiation_system.hpp:64-71)
 PIECEWISE_CONSTANT, PPL_FIXED_SLOPE, PPL_FULL_SPECTRUM = 1, 2, 3
 
@@ -228,10 +230,6 @@ class Oracle:
     def sim(self, problem, ndim, n_cell, prob_lo, prob_hi, periodic, max_grid_size=None, cfl=-1.0, stop_time=-1.0,
             max_timesteps=-1, reconstruction_order=-1, nscalars=0, table=None, rad_pow_mode=0, hydro1d=None, beta_order=0, c_hat_factor=0.0,
             opacity_model=0) -> "OracleSim":
-        if ndim == 2:
-            # AMREX_SPACEDIM == 2 builds of the reference use util/ArrayView_2d.hpp (X2 view = index SWAP, velV = vx, velW = vz),
-            # not the cyclic permutation of ArrayView_3d.hpp restated here: a 2-D oracle would not be the reference's algorithm
-            raise NotImplementedError("the oracle restates the 1-D / 3-D builds of the reference only")
         n_cell = list(n_cell) + [1] * (3 - len(n_cell))
         mgs = list(max_grid_size) if max_grid_size is not None else list(n_cell)
         mgs = mgs + [1] * (3 - len(mgs))

@@ -66,7 +66,7 @@ int qk_level_create(qk_ctx *ctx, qk_level **lev, int ndim, int nboxes, const qk_
 	}
 	QK_REQUIRE(ctx, nboxes >= 0 && (valid_boxes != nullptr || nboxes == 0), "qk_level_create: bad box list");
 	// nboxes == 0 is a rank that owns no box of this level (AMR): every operator on such a level is a no-op
-	QK_REQUIRE(ctx, ndim == 1 || ndim == 3, "qk_level_create: ndim must be 1 or 3");
+	QK_REQUIRE(ctx, ndim >= 1 && ndim <= 3, "qk_level_create: ndim must be 1, 2 or 3");
 	auto *L = new qk_level;
 	L->ctx = ctx;
 	L->ndim = ndim;

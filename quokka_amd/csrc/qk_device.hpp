@@ -53,10 +53,12 @@ using CIA4 = A4<const int, qk_iarray4>;
 // loop index -> view index (ArrayView_3d.hpp:22-28) expressed as a unit offset: a view step of
 // (di, dj, dk) is the array step (i + di*e[dir]) + ..., i.e. axis `dir` is the normal, the next two
 // (cyclically) are view-j and view-k.
-template <int DIR> struct Axes {
-	static constexpr int n = DIR;		 // array axis of view-i (normal)
-	static constexpr int v = (DIR + 1) % 3;	 // array axis of view-j
-	static constexpr int w = (DIR + 2) % 3;	 // array axis of view-k
+// TWOD: the X2 view of an AMREX_SPACEDIM == 2 build is an index SWAP (ArrayView_2d.hpp:13-17, velocity components hydro_system.hpp:963-966):
+// view-j is the x axis, view-k stays z.
+template <int DIR, bool TWOD = false> struct Axes {
+	static constexpr int n = DIR;					       // array axis of view-i (normal)
+	static constexpr int v = (TWOD && DIR == 1) ? 0 : (DIR + 1) % 3;       // array axis of view-j
+	static constexpr int w = (TWOD && DIR == 1) ? 2 : (DIR + 2) % 3;       // array axis of view-k
 };
 
 QK_DEV auto unit(int axis, int comp) -> int { return axis == comp ? 1 : 0; }
@@ -308,7 +310,7 @@ struct HState {
 // primitive state q[6] = (rho, vx, vy, vz, P|e, Eint|e_aux).  DIR fixes (u,v,w) <- (vN, vV, vW) with the
 // 3-D mapping X1:(x,y,z) X2:(y,z,x) X3:(z,x,y)  (:954-976).
 // Rrho = recipOf(rho), Rg = recipOf((gamma-1) rho): shared with the divisions of hllc()
-template <int DIR> QK_DEV auto makeState(Eos const &eos, bool reconstruct_eint, const double q[NVAR], Recip const &Rrho, Recip const &Rg) -> HState
+template <int DIR, bool TWOD = false> QK_DEV auto makeState(Eos const &eos, bool reconstruct_eint, const double q[NVAR], Recip const &Rrho, Recip const &Rg) -> HState
 {
 	HState s;
 	const double rho = q[PRHO];
@@ -335,9 +337,9 @@ template <int DIR> QK_DEV auto makeState(Eos const &eos, bool reconstruct_eint, 
 		E = divBy(P, Rg) * rho + ke;	     // eos.eintFromPres
 	}
 	s.rho = rho;
-	s.u = q[PVX + Axes<DIR>::n];
-	s.v = q[PVX + Axes<DIR>::v];
-	s.w = q[PVX + Axes<DIR>::w];
+	s.u = q[PVX + Axes<DIR, TWOD>::n];
+	s.v = q[PVX + Axes<DIR, TWOD>::v];
+	s.w = q[PVX + Axes<DIR, TWOD>::w];
 	s.P = P;
 	s.cs = cs;
 	s.E = E;
@@ -526,14 +528,14 @@ QK_DEV void llf(HState const &sL, HState const &sR, double F[NVAR], Wave *wv = n
 // hydro_system.hpp:1037-1110 : Riemann solve + artificial viscosity + momentum un-permutation + face velocity.
 // qL/qR: reconstructed primitive states at the face; du, dvl.. the velocity differences of :1019-1034.
 // Fout[6] is in ARRAY component order (rho, px, py, pz, E, Eint).
-template <int DIR, int RIEMANN>
+template <int DIR, int RIEMANN, bool TWOD = false>
 QK_DEV void faceFlux(Eos const &eos, bool reconstruct_eint, int ndim, const double qL[NVAR], const double qR[NVAR], double du, double dvl, double dvr,
 		     double dwl, double dwr, double K_visc, double Fout[NVAR], double &v_norm, Wave *wv = nullptr)
 {
 	const Recip RL = recipOf(qL[PRHO]), RR = recipOf(qR[PRHO]);
 	const Recip GL = recipOf(eos.gm1 * qL[PRHO]), GR = recipOf(eos.gm1 * qR[PRHO]);
-	const HState sL = makeState<DIR>(eos, reconstruct_eint, qL, RL, GL);
-	const HState sR = makeState<DIR>(eos, reconstruct_eint, qR, RR, GR);
+	const HState sL = makeState<DIR, TWOD>(eos, reconstruct_eint, qL, RL, GL);
+	const HState sR = makeState<DIR, TWOD>(eos, reconstruct_eint, qR, RR, GR);
 	double dw = 0.;
 	if (ndim >= 2) {
 		dw = smin(dvl, dvr);
@@ -563,9 +565,9 @@ QK_DEV void faceFlux(Eos const &eos, bool reconstruct_eint, int ndim, const doub
 	F[RHO] = Fc[0] + viscosity * (sL.rho - sR.rho);
 	F[ENE] = Fc[4] + viscosity * (sL.E - sR.E);
 	F[EINT] = Fc[5] + viscosity * (sL.Eint - sR.Eint);
-	F[MX + Axes<DIR>::n] = Fc[1];
-	F[MX + Axes<DIR>::v] = Fc[2];
-	F[MX + Axes<DIR>::w] = Fc[3];
+	F[MX + Axes<DIR, TWOD>::n] = Fc[1];
+	F[MX + Axes<DIR, TWOD>::v] = Fc[2];
+	F[MX + Axes<DIR, TWOD>::w] = Fc[3];
 	if (eos.isothermal) {
 		F[ENE] = 0;
 		F[EINT] = 0;

@@ -281,7 +281,7 @@ int qk_hydro_FlattenShocks(qk_level *lev, qk_stream s, const qk_hydro_traits *t,
 
 namespace
 {
-template <int DIR, int RIEMANN>
+template <int DIR, int RIEMANN, bool TWOD = false>
 void launchComputeFluxes(qk_level *lev, qk_stream s, const qk_hydro_traits *t, qk_array4 *flux_t, qk_array4 *fvel_t, const qk_array4 *left_t,
 			 const qk_array4 *right_t, const qk_array4 *prim_t, double K_visc)
 {
@@ -305,7 +305,7 @@ void launchComputeFluxes(qk_level *lev, qk_stream s, const qk_hydro_traits *t, q
 			qR[n] = R.p[cr + R.ns * n];
 		}
 		// unit steps of the permuted view: e_n (normal), e_v (view-j), e_w (view-k)
-		constexpr int AN = Axes<DIR>::n, AV = Axes<DIR>::v, AW = Axes<DIR>::w;
+		constexpr int AN = Axes<DIR, TWOD>::n, AV = Axes<DIR, TWOD>::v, AW = Axes<DIR, TWOD>::w;
 		const int nx = unit(AN, 0), ny = unit(AN, 1), nz = unit(AN, 2);
 		const int vx = unit(AV, 0), vy = unit(AV, 1), vz = unit(AV, 2);
 		const int wx = unit(AW, 0), wy = unit(AW, 1), wz = unit(AW, 2);
@@ -325,7 +325,7 @@ void launchComputeFluxes(qk_level *lev, qk_stream s, const qk_hydro_traits *t, q
 		}
 		double Fo[NVAR], vn;
 		Wave wv;
-		faceFlux<DIR, RIEMANN>(eos, re, ndim, qL, qR, du, dvl, dvr, dwl, dwr, K_visc, Fo, vn, (nscalars > 0) ? &wv : nullptr);
+		faceFlux<DIR, RIEMANN, TWOD>(eos, re, ndim, qL, qR, du, dvl, dvr, dwl, dwr, K_visc, Fo, vn, (nscalars > 0) ? &wv : nullptr);
 		const int64_t o = F.idx(i, j, k);
 #pragma unroll
 		for (int n = 0; n < NVAR; ++n) {
@@ -364,7 +364,15 @@ int qk_hydro_ComputeFluxes(qk_level *lev, qk_stream s, const qk_hydro_traits *t,
 	}
 	QK_REQUIRE(lev->ctx, flux_t && fvel_t && left_t && right_t && prim_t, "ComputeFluxes: NULL array");
 	QK_REQUIRE(lev->ctx, riemann == QK_RIEMANN_HLLC || riemann == QK_RIEMANN_LLF, "ComputeFluxes: unknown Riemann solver");
-	QK_REQUIRE(lev->ctx, t->ndim == 3 || dir == QK_DIR_X1, "ComputeFluxes: only X1 exists in a 1-D build");
+	QK_REQUIRE(lev->ctx, dir >= 0 && dir < t->ndim, "ComputeFluxes: the direction does not exist in a build of this dimension");
+	if (t->ndim == 2 && dir == QK_DIR_X2) { // the X2 view of a 2-D build: index swap instead of the cyclic permutation
+		if (riemann == QK_RIEMANN_HLLC) {
+			launchComputeFluxes<1, QK_RIEMANN_HLLC, true>(lev, s, t, flux_t, fvel_t, left_t, right_t, prim_t, K_visc);
+		} else {
+			launchComputeFluxes<1, QK_RIEMANN_LLF, true>(lev, s, t, flux_t, fvel_t, left_t, right_t, prim_t, K_visc);
+		}
+		return launchStatus(lev, "ComputeFluxes");
+	}
 	if (riemann == QK_RIEMANN_HLLC) {
 		QK_DISPATCH_DIR(dir, (launchComputeFluxes<DIR, QK_RIEMANN_HLLC>(lev, s, t, flux_t, fvel_t, left_t, right_t, prim_t, K_visc)));
 	} else {
@@ -383,9 +391,9 @@ int qk_hydro_ComputeRhsFromFluxes(qk_level *lev, qk_stream s, const qk_hydro_tra
 		return rc;
 	}
 	const int ndim = t->ndim;
-	QK_REQUIRE(lev->ctx, rhs_t && fluxArray && dx_in && fluxArray[0] && (ndim < 3 || (fluxArray[1] && fluxArray[2])), "ComputeRhsFromFluxes: NULL");
+	QK_REQUIRE(lev->ctx, rhs_t && fluxArray && dx_in && fluxArray[0] && (ndim < 2 || fluxArray[1]) && (ndim < 3 || fluxArray[2]), "ComputeRhsFromFluxes: NULL");
 	const qk_array4 *f0 = fluxArray[0];
-	const qk_array4 *f1 = (ndim == 3) ? fluxArray[1] : nullptr;
+	const qk_array4 *f1 = (ndim >= 2) ? fluxArray[1] : nullptr;
 	const qk_array4 *f2 = (ndim == 3) ? fluxArray[2] : nullptr;
 	const double dx0 = dx_in[0], dx1 = dx_in[1], dx2 = dx_in[2];
 	launchCells(lev, s, 0, -1, [=] __device__(int b, int i, int j, int k) {
@@ -394,10 +402,12 @@ int qk_hydro_ComputeRhsFromFluxes(qk_level *lev, qk_stream s, const qk_hydro_tra
 		for (int n = 0; n < nvars; ++n) {
 			// hydro_system.hpp:469-471
 			double r = (1.0 / dx0) * (x1(i, j, k, n) - x1(i + 1, j, k, n));
-			if (ndim == 3) {
+			if (ndim >= 2) {
 				RA4 x2(f1[b]);
-				RA4 x3(f2[b]);
 				r = r + (1.0 / dx1) * (x2(i, j, k, n) - x2(i, j + 1, k, n));
+			}
+			if (ndim == 3) {
+				RA4 x3(f2[b]);
 				r = r + (1.0 / dx2) * (x3(i, j, k, n) - x3(i, j, k + 1, n));
 			}
 			rhs(i, j, k, n) = r;
@@ -416,11 +426,11 @@ int qk_hydro_AddInternalEnergyPdV(qk_level *lev, qk_stream s, const qk_hydro_tra
 		return rc;
 	}
 	const int ndim = t->ndim;
-	QK_REQUIRE(lev->ctx, rhs_t && cons_t && dx_in && faceVelArray && redo_t && faceVelArray[0] && (ndim < 3 || (faceVelArray[1] && faceVelArray[2])),
+	QK_REQUIRE(lev->ctx, rhs_t && cons_t && dx_in && faceVelArray && redo_t && faceVelArray[0] && (ndim < 2 || faceVelArray[1]) && (ndim < 3 || faceVelArray[2]),
 		   "AddInternalEnergyPdV: NULL");
 	const Eos eos(*t);
 	const qk_array4 *v0 = faceVelArray[0];
-	const qk_array4 *v1 = (ndim == 3) ? faceVelArray[1] : nullptr;
+	const qk_array4 *v1 = (ndim >= 2) ? faceVelArray[1] : nullptr;
 	const qk_array4 *v2 = (ndim == 3) ? faceVelArray[2] : nullptr;
 	const double dx0 = dx_in[0], dx1 = dx_in[1], dx2 = dx_in[2];
 	launchCells(lev, s, 0, -1, [=] __device__(int b, int i, int j, int k) {
@@ -432,16 +442,20 @@ int qk_hydro_AddInternalEnergyPdV(qk_level *lev, qk_stream s, const qk_hydro_tra
 		if (flag(i, j, k) == 0) { // hydro_system.hpp:802-804
 			RA4 vx(v0[b]);
 			div_v = (vx(i + 1, j, k) - vx(i, j, k)) / dx0;
-			if (ndim == 3) {
+			if (ndim >= 2) {
 				RA4 vy(v1[b]);
-				RA4 vz(v2[b]);
 				div_v = div_v + (vy(i, j + 1, k) - vy(i, j, k)) / dx1;
+			}
+			if (ndim == 3) {
+				RA4 vz(v2[b]);
 				div_v = div_v + (vz(i, j, k + 1) - vz(i, j, k)) / dx2;
 			}
 		} else { // :806-808
 			double sum = (U(i + 1, j, k, MX) / U(i + 1, j, k, RHO) - U(i - 1, j, k, MX) / U(i - 1, j, k, RHO)) / dx0;
-			if (ndim == 3) {
+			if (ndim >= 2) {
 				sum = sum + (U(i, j + 1, k, MY) / U(i, j + 1, k, RHO) - U(i, j - 1, k, MY) / U(i, j - 1, k, RHO)) / dx1;
+			}
+			if (ndim == 3) {
 				sum = sum + (U(i, j, k + 1, MZ) / U(i, j, k + 1, RHO) - U(i, j, k - 1, MZ) / U(i, j, k - 1, RHO)) / dx2;
 			}
 			div_v = 0.5 * sum;

@@ -84,8 +84,8 @@ inline auto checkTraits(qk_ctx *ctx, const qk_hydro_traits *t) -> int
 	if (t->eos_temperature_model < 0 || t->eos_temperature_model > 1 || (t->eos_temperature_model == 1 && !(t->eos_alpha > 0.0))) {
 		return setError(ctx, QK_ERR_UNSUPPORTED, "eos_temperature_model must be 0 (gamma law) or 1 (E = alpha / 4 T^4, alpha > 0)");
 	}
-	if (t->ndim != 1 && t->ndim != 3) {
-		return setError(ctx, QK_ERR_UNSUPPORTED, "ndim must be 1 or 3");
+	if (t->ndim < 1 || t->ndim > 3) {
+		return setError(ctx, QK_ERR_UNSUPPORTED, "ndim must be 1, 2 or 3");
 	}
 	return QK_OK;
 }

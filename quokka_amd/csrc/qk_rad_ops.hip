@@ -503,6 +503,7 @@ int qk_rad_computeRadiationFluxes(qk_level *lev, qk_stream s, const qk_rad_trait
 	}
 	QK_REQUIRE(lev->ctx, cons_t && flux && flux[0] && (ndim < 3 || (flux[1] && flux[2])), "computeRadiationFluxes: NULL array");
 	QK_REQUIRE(lev->ctx, order >= 1 && order <= 3, "computeRadiationFluxes: reconstruction order must be 1..3");
+	QK_REQUIRE(lev->ctx, lev->ndim != 2, "computeRadiationFluxes: the radiation operators exist for 1-D and 3-D builds");
 	QK_REQUIRE(lev->ctx, ndim == lev->ndim, "computeRadiationFluxes: ndim mismatch");
 	const Rad rad(*rt);
 #define QK_RAD_DIR(D)                                                                                                                                \
@@ -551,6 +552,7 @@ int qk_rad_PredictStep(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int 
 		return rc;
 	}
 	QK_REQUIRE(lev->ctx, old_t && new_t && fluxArray && dx_in && fluxArray[0] && (ndim < 3 || (fluxArray[1] && fluxArray[2])), "rad PredictStep: NULL");
+	QK_REQUIRE(lev->ctx, ndim != 2, "rad PredictStep: the radiation operators exist for 1-D and 3-D builds");
 	const Rad rad(*rt);
 	const qk_array4 *f0 = fluxArray[0], *f1 = (ndim == 3) ? fluxArray[1] : nullptr, *f2 = (ndim == 3) ? fluxArray[2] : nullptr;
 	const double dx0 = dx_in[0], dx1 = dx_in[1], dx2 = dx_in[2];
@@ -614,6 +616,7 @@ int qk_rad_AddFluxesRK2(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int
 	}
 	QK_REQUIRE(lev->ctx, new_t && U0_t && U1_t && fluxArrayOld && fluxArray && dx_in && fluxArrayOld[0] && fluxArray[0], "rad AddFluxesRK2: NULL");
 	QK_REQUIRE(lev->ctx, ndim < 3 || (fluxArrayOld[1] && fluxArrayOld[2] && fluxArray[1] && fluxArray[2]), "rad AddFluxesRK2: NULL flux");
+	QK_REQUIRE(lev->ctx, ndim != 2, "rad AddFluxesRK2: the radiation operators exist for 1-D and 3-D builds");
 	const Rad rad(*rt);
 	const qk_array4 *o0 = fluxArrayOld[0], *o1 = (ndim == 3) ? fluxArrayOld[1] : nullptr, *o2 = (ndim == 3) ? fluxArrayOld[2] : nullptr;
 	const qk_array4 *f0 = fluxArray[0], *f1 = (ndim == 3) ? fluxArray[1] : nullptr, *f2 = (ndim == 3) ? fluxArray[2] : nullptr;

@@ -685,6 +685,70 @@ def sedov_problem(ctx: Context, n: int, max_grid_size: int = 128, rank=0, nranks
     return sim
 
 
+def blast2d_problem(ctx: Context, n: int = 64, ndim: int = 2, nz: int = 4, max_grid_size=None) -> HydroSimulation:
+    """reference src/problems/HydroBlast2D/test_hydro2d_blast.cpp + tests/blast2d.in: a circular blast (P = 10 inside R < 0.1, 0.1 outside) in a
+    reflecting unit box; ndim = 2: the AMREX_SPACEDIM == 2 build (X2 view = index swap, ArrayView_2d.hpp); ndim = 3: the same problem uniform
+    in z on nz cells (reference-shaped operators: the comparison of the two builds is the point)."""
+    n_cell = [n, n, nz if ndim == 3 else 1]
+    geom = Geometry(ndim, n_cell[:ndim] if ndim == 2 else n_cell, [0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [0, 0, 0])
+    bcs = []
+    for c in range(6):
+        lo = [(capi.BC_REFLECT_ODD if c == 1 + d else capi.BC_REFLECT_EVEN) if d < ndim else capi.BC_INT_DIR for d in range(3)]
+        bcs.append((lo, list(lo)))
+    mgs = list(max_grid_size) if max_grid_size is not None else n_cell
+    sim = HydroSimulation(ctx, geom, capi.traits(5.0 / 3.0, True, ndim), bcs, mgs, use_fused=False)
+    sim.reconstructionOrder_, sim.stopTime_, sim.cflNumber_, sim.maxTimesteps_ = 3, 0.1, 0.3, 20000
+    dx, dy = geom.dx[0], geom.dx[1]
+    g = 5.0 / 3.0
+
+    def ic(i, j, k):
+        x, y = (i + 0.5) * dx, (j + 0.5) * dy
+        R = np.sqrt(np.power(x - 0.5, 2) + np.power(y - 0.5, 2))
+        U = np.zeros((6,) + i.shape)
+        U[0] = 1.0
+        U[4] = np.where(R < 0.1, 10.0, 0.1) / (g - 1.0) + 0.5 * 1.0 * 0.0
+        return U
+
+    sim.set_initial_conditions(ic)
+    return sim
+
+
+def quirk_problem(ctx: Context, ndim: int = 2) -> HydroSimulation:
+    """reference src/problems/HydroQuirk/test_quirk.cpp + tests/quirk.in: a Mach-5ish shock on 128 x 16 (x 16) cells with a sawtooth perturbation
+    of the post-shock column (odd-even decoupling test), PLM, constant states beyond both x faces, periodic in y (and z)."""
+    n_cell = [128, 16, 16 if ndim == 3 else 1]
+    geom = Geometry(ndim, n_cell[:ndim] if ndim == 2 else n_cell, [0.0, 0.0, 0.0], [1.0, 0.125, 1.0], [0, 1, 1])
+    bcs = [([capi.BC_EXT_DIR, capi.BC_INT_DIR, capi.BC_INT_DIR], [capi.BC_EXT_DIR, capi.BC_INT_DIR, capi.BC_INT_DIR]) for _ in range(6)]
+    g = 5.0 / 3.0
+    dl, ul, pl, dr, ur, pr = 3.692, -0.625, 26.85, 1.0, -5.0, 0.6
+    left = [dl, dl * ul, 0.0, 0.0, pl / (g - 1.0) + 0.5 * dl * ul * ul, pl / (g - 1.0)]
+    right = [dr, dr * ur, 0.0, 0.0, pr / (g - 1.0) + 0.5 * dr * ur * ur, pr / (g - 1.0)]
+    sim = HydroSimulation(ctx, geom, capi.traits(g, False, ndim), bcs, [128, 16, 16], dirichlet={(0, 0): left, (0, 1): right}, use_fused=False)
+    sim.reconstructionOrder_, sim.stopTime_, sim.cflNumber_, sim.maxTimesteps_ = 2, 0.4, 0.4, 2000
+    dx = geom.dx[0]
+    ishock = 0
+    while (dx * (ishock + 0.5)) < 0.4:
+        ishock += 1
+    ishock -= 1
+    dd, ud, pd = dl - 0.135, ul + 0.219, pl - 1.31
+
+    def ic(i, j, k):
+        post = i <= ishock
+        saw = (i == ishock) & (j % 2 == 0)
+        rho = np.where(saw, dd, np.where(post, dl, dr))
+        vx = np.where(saw, ud, np.where(post, ul, ur))
+        P = np.where(saw, pd, np.where(post, pl, pr))
+        U = np.zeros((6,) + i.shape)
+        # quokka::EOS::ComputeEintFromPres (gamma law): P / (gamma - 1)
+        U[0], U[1] = rho, rho * vx
+        U[5] = P / (g - 1.0)
+        U[4] = U[5] + 0.5 * rho * (vx * vx + 0.0 + 0.0)
+        return U
+
+    sim.set_initial_conditions(ic)
+    return sim
+
+
 def sod_problem(ctx: Context, nx: int = 1024, use_fused=False) -> HydroSimulation:
     """reference src/problems/HydroShocktube/test_hydro_shocktube.cpp + tests/shocktube.in (1-D build, one box)"""
     geom = Geometry(1, [nx], [0.0, 0.0, 0.0], [5.0, 1.0, 1.0], [0, 1, 1])
