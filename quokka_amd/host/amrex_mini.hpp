@@ -130,8 +130,8 @@ struct Dim3 {
 
 template <typename T, int N> struct GpuArray {
 	T arr[N > 0 ? N : 1];
-	QK_HD auto operator[](int i) const -> T const & { return arr[i]; }
-	QK_HD auto operator[](int i) -> T & { return arr[i]; }
+	QK_HD constexpr auto operator[](int i) const -> T const & { return arr[i]; }
+	QK_HD constexpr auto operator[](int i) -> T & { return arr[i]; }
 	[[nodiscard]] QK_HD auto begin() const -> T const * { return arr; }
 	[[nodiscard]] QK_HD auto end() const -> T const * { return arr + N; }
 	[[nodiscard]] QK_HD auto data() const -> T const * { return arr; }

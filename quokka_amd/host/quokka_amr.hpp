@@ -91,6 +91,7 @@ template <typename problem_t> class AmrDriver
 			base_.tNew_[0] = tNew_;
 			base_.dt_[0] = dt_[0];
 			base_.istep[0] = istep[0];
+			base_.computeAfterTimestep(); // reference src/simulation.hpp:890
 			base_.outputAfterStep(istep[0] - 1);
 			if (tNew_ >= base_.stopTime_ - 1.e-6 * dt_[0]) {
 				break;

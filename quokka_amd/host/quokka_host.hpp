@@ -19,6 +19,8 @@
 #include <memory>
 
 #include "amrex_mini.hpp"
+#include "compat/planck_integral.hpp"
+#include "compat/util_compat.hpp"
 #include "quokka_io.hpp"
 
 // Microphysics fundamental_constants.H (CODATA 2018, cgs)
@@ -386,9 +388,10 @@ template <typename problem_t> class HydroSystem : public HyperbolicSystem<proble
 	}
 };
 
-// physical constants in CGS units, as problem files name them (reference src/radiation/radiation_system.hpp:58-59)
+// physical constants in CGS units, as problem files name them (reference src/radiation/radiation_system.hpp:58-61)
 static constexpr double c_light_cgs_ = C::c_light;
 static constexpr double radiation_constant_cgs_ = C::a_rad;
+static constexpr double inf = std::numeric_limits<double>::max();
 
 // this struct is specialized by the user application code (reference src/radiation/radiation_system.hpp:73-82)
 // radiation_system.hpp:63-70
@@ -406,8 +409,33 @@ template <typename problem_t> struct RadSystem_Traits {
 	static constexpr double c_hat = c_light_cgs_;
 	static constexpr double radiation_constant = radiation_constant_cgs_;
 	static constexpr double Erad_floor = 0.;
+	static constexpr double energy_unit = C::ev2erg;
+	static constexpr amrex::GpuArray<double, Physics_Traits<problem_t>::nGroups + 1> radBoundaries = {0., inf};
 	static constexpr double beta_order = 1;
+	static constexpr OpacityModel opacity_model = OpacityModel::single_group;
 };
+
+// members a specialisation of RadSystem_Traits may leave out (reference radiation_system.hpp:147-154 does this for opacity_model)
+namespace qkhost
+{
+template <typename P, typename = void> struct RadHasOpacityModel : std::false_type {
+};
+template <typename P> struct RadHasOpacityModel<P, std::void_t<decltype(RadSystem_Traits<P>::opacity_model)>> : std::true_type {
+};
+template <typename P, typename = void> struct RadHasEnergyUnit : std::false_type {
+};
+template <typename P> struct RadHasEnergyUnit<P, std::void_t<decltype(RadSystem_Traits<P>::energy_unit)>> : std::true_type {
+};
+template <typename P> constexpr auto radEnergyUnit() -> double
+{
+	if constexpr (RadHasEnergyUnit<P>::value) {
+		return RadSystem_Traits<P>::energy_unit;
+	} else {
+		return C::ev2erg;
+	}
+}
+} // namespace qkhost
+template <typename problem_t> using RadSystem_Has_Opacity_Model = qkhost::RadHasOpacityModel<problem_t>;
 
 // RadSystem<problem_t>: indices, constants, the problem's device hooks and the operators of the radiation update, each ONE
 // call into the C-ABI (reference src/radiation/radiation_system.hpp:150-330).  Single group, OpacityModel::single_group.
@@ -425,11 +453,129 @@ template <typename problem_t> class RadSystem : public HyperbolicSystem<problem_
 	static constexpr double c_light_ = RadSystem_Traits<problem_t>::c_light;
 	static constexpr double c_hat_ = RadSystem_Traits<problem_t>::c_hat;
 	static constexpr double radiation_constant_ = RadSystem_Traits<problem_t>::radiation_constant;
-	static constexpr double Erad_floor_ = RadSystem_Traits<problem_t>::Erad_floor;
 	static constexpr int beta_order_ = static_cast<int>(RadSystem_Traits<problem_t>::beta_order);
+	static constexpr int numRadVars_ = Physics_NumVars::numRadVars;
+	static constexpr int nmscalars_ = Physics_Traits<problem_t>::numMassScalars;
+	enum primVarIndex { primRadEnergy_index = 0, x1ReducedFlux_index, x2ReducedFlux_index, x3ReducedFlux_index };
 
-	// device hooks a problem may specialise (:1141-1154, :582-587)
+	// :195-231
+	static constexpr bool enable_dust_gas_thermal_coupling_model_ = ISM_Traits<problem_t>::enable_dust_gas_thermal_coupling_model;
+	static constexpr bool enable_photoelectric_heating_ = ISM_Traits<problem_t>::enable_photoelectric_heating;
 	static constexpr int nGroups_ = Physics_Traits<problem_t>::nGroups;
+	static constexpr amrex::GpuArray<double, nGroups_ + 1> radBoundaries_ = []() constexpr {
+		if constexpr (nGroups_ > 1) {
+			return RadSystem_Traits<problem_t>::radBoundaries;
+		} else {
+			amrex::GpuArray<double, 2> boundaries{0., inf};
+			return boundaries;
+		}
+	}();
+	static constexpr double Erad_floor_ = RadSystem_Traits<problem_t>::Erad_floor / nGroups_;
+	static constexpr OpacityModel opacity_model_ = []() constexpr {
+		if constexpr (RadSystem_Has_Opacity_Model<problem_t>::value) {
+			return RadSystem_Traits<problem_t>::opacity_model;
+		} else {
+			return OpacityModel::single_group;
+		}
+	}();
+	static_assert(((nGroups_ > 1 && opacity_model_ != OpacityModel::single_group) || (nGroups_ == 1 && opacity_model_ == OpacityModel::single_group)),
+		      "OpacityModel::single_group MUST be used when nGroups_ == 1. If nGroups_ > 1, you MUST set opacity_model.");
+	static_assert(!(nGroups_ < 3 && opacity_model_ == OpacityModel::PPL_opacity_full_spectrum), "PPL_opacity_full_spectrum requires at least 3 photon groups.");
+	static constexpr double mean_molecular_mass_ = quokka::EOS_Traits<problem_t>::mean_molecular_weight;
+	static constexpr double boltzmann_constant_ = quokka::EOS_Traits<problem_t>::boltzmann_constant;
+	static constexpr double gamma_ = quokka::EOS_Traits<problem_t>::gamma;
+	static constexpr double energy_unit_ = qkhost::radEnergyUnit<problem_t>();
+
+	// device hooks a problem may specialise (:1141-1167, :471-513, :582-587)
+	// multigroup: exponents and lower values of the piecewise power-law opacity at the group edges (default: NaN, :1155-1167)
+	AMREX_GPU_HOST_DEVICE static auto DefineOpacityExponentsAndLowerValues(amrex::GpuArray<double, nGroups_ + 1> rad_boundaries, double rho, double Tgas)
+	    -> amrex::GpuArray<amrex::GpuArray<double, nGroups_ + 1>, 2>;
+	AMREX_GPU_HOST_DEVICE static auto ComputeThermalRadiationSingleGroup(amrex::Real temperature) -> amrex::Real;
+	AMREX_GPU_HOST_DEVICE static auto ComputeThermalRadiationTempDerivativeSingleGroup(amrex::Real temperature) -> amrex::Real;
+	// :430-461: energy fractions of a Planck spectrum in the groups (what problem files call for initial and boundary states)
+	AMREX_GPU_HOST_DEVICE static auto ComputePlanckEnergyFractions(amrex::GpuArray<double, nGroups_ + 1> const &boundaries, amrex::Real temperature)
+	    -> quokka::valarray<amrex::Real, nGroups_>
+	{
+		quokka::valarray<amrex::Real, nGroups_> radEnergyFractions{};
+		if constexpr (nGroups_ == 1) {
+			radEnergyFractions[0] = 1.0;
+			return radEnergyFractions;
+		} else {
+			amrex::Real const energy_unit_over_kT = energy_unit_ / (boltzmann_constant_ * temperature);
+			amrex::Real y = NAN;
+			amrex::Real previous = 0.0;
+			for (int g = 0; g < nGroups_ - 1; ++g) {
+				const amrex::Real x = boundaries[g + 1] * energy_unit_over_kT;
+				y = (x >= 100.) ? 1.0 : integrate_planck_from_0_to_x(x);
+				radEnergyFractions[g] = y - previous;
+				previous = y;
+			}
+			y = 1.0;
+			radEnergyFractions[nGroups_ - 1] = y - previous;
+			return radEnergyFractions;
+		}
+	}
+	// :483-497
+	AMREX_GPU_HOST_DEVICE static auto ComputeThermalRadiationMultiGroup(amrex::Real temperature, amrex::GpuArray<double, nGroups_ + 1> const &boundaries)
+	    -> quokka::valarray<amrex::Real, nGroups_>
+	{
+		const double power = radiation_constant_ * std::pow(temperature, 4);
+		const auto radEnergyFractions = ComputePlanckEnergyFractions(boundaries, temperature);
+		auto Erad_g = power * radEnergyFractions;
+		for (int g = 0; g < nGroups_; ++g) {
+			if (Erad_g[g] < Erad_floor_) {
+				Erad_g[g] = Erad_floor_;
+			}
+		}
+		return Erad_g;
+	}
+	// :505-513
+	AMREX_GPU_HOST_DEVICE static auto ComputeThermalRadiationTempDerivativeMultiGroup(amrex::Real temperature,
+											  amrex::GpuArray<double, nGroups_ + 1> const &boundaries)
+	    -> quokka::valarray<amrex::Real, nGroups_>
+	{
+		auto radEnergyFractions = ComputePlanckEnergyFractions(boundaries, temperature);
+		double d_power_dt = 4. * radiation_constant_ * std::pow(temperature, 3);
+		return d_power_dt * radEnergyFractions;
+	}
+	// :1311-1326 (4 pi B(nu) / c)
+	AMREX_GPU_HOST_DEVICE static auto PlanckFunction(const double nu, const double T) -> double
+	{
+		double const coeff = energy_unit_ / (boltzmann_constant_ * T);
+		double const x = coeff * nu;
+		if (x > 100.) {
+			return 0.0;
+		}
+		double const planck_integral = (x <= 1.0e-10) ? x * x - x * x * x / 2. : std::pow(x, 3) / (std::exp(x) - 1.0);
+		return coeff / (std::pow(PI, 4) / 15.0) * (radiation_constant_ * std::pow(T, 4)) * planck_integral;
+	}
+	// :1367-1385: the radiation flux of each group in the diffusion limit for gas moving at `vel`
+	AMREX_GPU_HOST_DEVICE static auto ComputeFluxInDiffusionLimit(const amrex::GpuArray<double, nGroups_ + 1> rad_boundaries, const double T, const double vel)
+	    -> amrex::GpuArray<double, nGroups_>
+	{
+		double const coeff = energy_unit_ / (boltzmann_constant_ * T);
+		amrex::GpuArray<double, nGroups_ + 1> edge_values{};
+		amrex::GpuArray<double, nGroups_> flux{};
+		for (int g = 0; g < nGroups_ + 1; ++g) {
+			auto x = coeff * rad_boundaries[g];
+			edge_values[g] = 4. / 3. * integrate_planck_from_0_to_x(x) - 1. / 3. * x * (std::pow(x, 3) / (std::exp(x) - 1.0)) / gInf;
+		}
+		for (int g = 0; g < nGroups_; ++g) {
+			flux[g] = vel * radiation_constant_ * std::pow(T, 4) * (edge_values[g + 1] - edge_values[g]);
+		}
+		return flux;
+	}
+	// :1354-1365
+	AMREX_GPU_HOST_DEVICE static auto ComputeBinCenterOpacity(amrex::GpuArray<double, nGroups_ + 1> rad_boundaries,
+								  amrex::GpuArray<amrex::GpuArray<double, nGroups_ + 1>, 2> kappa_expo_and_lower_value)
+	    -> quokka::valarray<double, nGroups_>
+	{
+		quokka::valarray<double, nGroups_> kappa_center{};
+		for (int g = 0; g < nGroups_; ++g) {
+			kappa_center[g] = kappa_expo_and_lower_value[1][g] * std::pow(rad_boundaries[g + 1] / rad_boundaries[g], 0.5 * kappa_expo_and_lower_value[0][g]);
+		}
+		return kappa_center;
+	}
 	// radiation_system.hpp:1289-1308
 	AMREX_GPU_HOST_DEVICE static auto ComputeEintFromEgas(double density, double X1GasMom, double X2GasMom, double X3GasMom, double Etot) -> double
 	{
@@ -452,9 +598,92 @@ template <typename problem_t> class RadSystem : public HyperbolicSystem<problem_
 	// The opacity and closure hooks run on the device in the reference; the C-ABI carries them as a closed, parametrised set
 	// (opacity model 0: constants, model 1: kappa = k0 / rho; closure 0: Levermore, 1: chi = 1/3).  The hooks are sampled on the host:
 	// anything outside the set is refused, never approximated.
+	// closure hook -> closed set (0: Levermore, 1: chi = 1/3); pow_mode from the deck
+	static auto closureAndPowMode(int &eddington_model, int &pow_mode) -> void
+	{
+		bool lev = true, third = true;
+		for (double f : {0.0, 0.3, 0.77, 1.0}) {
+			double const ff = std::sqrt(4.0 - 3.0 * (f * f));
+			lev = lev && ComputeEddingtonFactor(f) == (3.0 + 4.0 * (f * f)) / (5.0 + 2.0 * ff);
+			third = third && ComputeEddingtonFactor(f) == (1. / 3.);
+		}
+		eddington_model = lev ? 0 : (third ? 1 : -1);
+		if (eddington_model < 0) {
+			amrex::Abort("RadSystem: ComputeEddingtonFactor is neither the Levermore closure nor the Eddington approximation");
+		}
+		pow_mode = 0;
+		amrex::ParmParse pp("radiation");
+		pp.query("pow_mode", pow_mode); // 0: pow(T, 4) like the reference's std::pow; 1: repeated multiplication
+	}
+
+	// Multigroup: RadSystem_Traits::radBoundaries / energy_unit / opacity_model and the DefineOpacityExponentsAndLowerValues hook sampled on
+	// the host into the C-ABI's closed set (exponent per edge; lower value = k_g rho^a (T / 1 K)^b with a in {0, -1}); anything else is refused.
+	static auto multigroupTraits() -> qk_rad_traits
+	{
+		static_assert(nGroups_ <= QK_MAX_GROUPS, "at most QK_MAX_GROUPS photon groups");
+		qk_rad_traits rt{};
+		rt.c_light = c_light_;
+		rt.c_hat = c_hat_;
+		rt.radiation_constant = radiation_constant_;
+		rt.Erad_floor = RadSystem_Traits<problem_t>::Erad_floor;
+		rt.beta_order = beta_order_;
+		closureAndPowMode(rt.eddington_model, rt.pow_mode);
+		rt.ngroups = nGroups_;
+		rt.mg_opacity_model = static_cast<int>(opacity_model_);
+		rt.energy_unit = energy_unit_;
+		for (int g = 0; g < nGroups_ + 1; ++g) {
+			rt.rad_boundaries[g] = radBoundaries_[g];
+		}
+		const bool pc = (opacity_model_ == OpacityModel::piecewise_constant_opacity); // (its last edge entry is never read and may be unset)
+		const int nedge = pc ? nGroups_ : nGroups_ + 1;
+		const double r0 = 1.0, T0 = 1.0e3;
+		auto const base = DefineOpacityExponentsAndLowerValues(radBoundaries_, r0, T0);
+		auto close = [](double a, double b) { return a == b || std::abs(a - b) <= 1e-12 * std::abs(b); };
+		// density exponent: 0 or -1; temperature exponent: nearest multiple of 1/2 of the sampled slope
+		auto const r2 = DefineOpacityExponentsAndLowerValues(radBoundaries_, 2.0 * r0, T0);
+		auto const T2 = DefineOpacityExponentsAndLowerValues(radBoundaries_, r0, 1.0e6);
+		double a = std::numeric_limits<double>::quiet_NaN();
+		if (close(r2[1][0], base[1][0])) {
+			a = 0.0;
+		} else if (close(r2[1][0], 0.5 * base[1][0])) {
+			a = -1.0;
+		}
+		const double slope = std::log(T2[1][0] / base[1][0]) / std::log(1.0e6 / T0);
+		const double b = std::round(2.0 * slope) / 2.0;
+		bool ok = std::isfinite(a) && std::isfinite(b) && std::abs(slope - b) < 1e-9;
+		rt.mg_kappa_rho_exponent = a;
+		rt.mg_kappa_T_ref = 1.0;
+		rt.mg_kappa_T_exponent = b;
+		for (int g = 0; g < nedge && ok; ++g) {
+			rt.mg_kappa_exponent[g] = base[0][g];
+			rt.mg_kappa_lower[g] = base[1][g] / (std::pow(r0, a) * std::pow(T0, b));
+		}
+		for (double r : {1.0, 1.0e-24, 3.7e-19, 2.0e-3}) {
+			for (double T : {3.0, 1.1e3, 4.0e7}) {
+				auto const v = DefineOpacityExponentsAndLowerValues(radBoundaries_, r, T);
+				for (int g = 0; g < nedge && ok; ++g) {
+					const double expect = (a == -1.0 && b == 0.0) ? rt.mg_kappa_lower[g] / r
+									     : (a == 0.0 && b == 0.0) ? rt.mg_kappa_lower[g]
+												       : rt.mg_kappa_lower[g] * std::pow(r, a) * std::pow(T, b);
+					ok = ok && v[0][g] == base[0][g] && close(v[1][g], expect);
+				}
+			}
+		}
+		if (!ok) {
+			amrex::Abort("RadSystem: DefineOpacityExponentsAndLowerValues is not expressible in the C-ABI's closed set (exponents independent of "
+				     "rho and T; lower values k_g rho^a T^b with a = 0 or -1)");
+		}
+		if (enable_dust_gas_thermal_coupling_model_) {
+			amrex::Abort("RadSystem: the multigroup dust-gas coupling model (radiation_dust_system.hpp) is not built");
+		}
+		return rt;
+	}
+
 	static auto traits() -> qk_rad_traits
 	{
-		static_assert(Physics_Traits<problem_t>::nGroups == 1, "multigroup radiation is not built (SURVEY 8f rank 2)");
+		if constexpr (nGroups_ > 1) {
+			return multigroupTraits();
+		}
 		const double rs[4] = {1.0, 1.0e-24, 3.7e-19, 2.0e-3}, Ts[3] = {3.0, 1.1e3, 4.0e7};
 		const double kP = ComputePlanckOpacity(rs[0], Ts[0]), kE = ComputeEnergyMeanOpacity(rs[0], Ts[0]), kF = ComputeFluxMeanOpacity(rs[0], Ts[0]);
 		int opacity_model = -1;
@@ -503,23 +732,32 @@ template <typename problem_t> class RadSystem : public HyperbolicSystem<problem_
 			amrex::Abort("RadSystem: these opacity hooks are not expressible in the C-ABI's closed opacity set (constant kappa, constant rho * "
 				     "kappa, temperature power law of rho * kappa)");
 		}
-		int eddington_model = -1;
+		int eddington_model = -1, pow_mode = 0;
+		closureAndPowMode(eddington_model, pow_mode);
+		qk_rad_traits rt{c_light_, c_hat_, radiation_constant_, Erad_floor_, beta_order_, opacity_model, k0[0], k0[1], k0[2], pow_mode, eddington_model,
+				 kT_ref,   kT_exp, 0.0};
+		// the thermal-emission hooks (:471-479, :499-503): the default a T^4 (floored) / 4 a T^3, or RadDust's linearised a T / a
 		{
-			bool lev = true, third = true;
-			for (double f : {0.0, 0.3, 0.77, 1.0}) {
-				double const ff = std::sqrt(4.0 - 3.0 * (f * f));
-				lev = lev && ComputeEddingtonFactor(f) == (3.0 + 4.0 * (f * f)) / (5.0 + 2.0 * ff);
-				third = third && ComputeEddingtonFactor(f) == (1. / 3.);
+			bool quartic = true, linear = true;
+			for (double T : {0.7, 3.0e2, 4.0e6}) {
+				const double e = ComputeThermalRadiationSingleGroup(T), d = ComputeThermalRadiationTempDerivativeSingleGroup(T);
+				quartic = quartic && e == std::max(radiation_constant_ * std::pow(T, 4), Erad_floor_) && d == 4. * radiation_constant_ * std::pow(T, 3);
+				linear = linear && e == radiation_constant_ * T && d == radiation_constant_;
 			}
-			eddington_model = lev ? 0 : (third ? 1 : -1);
+			if (!quartic && !linear) {
+				amrex::Abort("RadSystem: the ComputeThermalRadiationSingleGroup hooks are neither a T^4 nor RadDust's linearised a T");
+			}
+			rt.thermal_model = quartic ? 0 : 1;
 		}
-		if (eddington_model < 0) {
-			amrex::Abort("RadSystem: ComputeEddingtonFactor is neither the Levermore closure nor the Eddington approximation");
+		if (enable_dust_gas_thermal_coupling_model_) { // ISM_Traits; the coefficient is QuokkaSimulation::dustGasInteractionCoeff_ (QuokkaSimulation.hpp:127, :392)
+			rt.enable_dust_gas_thermal_coupling_model = 1;
+			rt.dust_gas_interaction_coeff = 2.5e-34;
+			amrex::ParmParse rpp("radiation");
+			rpp.query("dust_gas_interaction_coeff", rt.dust_gas_interaction_coeff);
+		} else if (rt.thermal_model != 0) {
+			amrex::Abort("RadSystem: the linearised thermal-emission hook is carried by the C-ABI together with the dust model only");
 		}
-		int pow_mode = 0;
-		amrex::ParmParse pp("radiation");
-		pp.query("pow_mode", pow_mode); // 0: pow(T, 4) like the reference's std::pow; 1: repeated multiplication
-		return {c_light_, c_hat_, radiation_constant_, Erad_floor_, beta_order_, opacity_model, k0[0], k0[1], k0[2], pow_mode, eddington_model, kT_ref, kT_exp, 0.0};
+		return rt;
 	}
 	static auto lev() -> qk_level * { return qkhost::Runtime::get().lev; }
 	static void flux3(std::array<amrex::MultiFab, AMREX_SPACEDIM> const &f, qk_array4 *out[3])
@@ -580,7 +818,42 @@ template <typename problem_t> class RadSystem : public HyperbolicSystem<problem_
 							       p_iteration_counter, p_iteration_failure_counter),
 			      "RadSystem::AddSourceTermsSingleGroup");
 	}
+	// src/radiation/source_terms_multi_group.hpp:522-813
+	static void AddSourceTermsMultiGroup(amrex::MultiFab &consVar, amrex::MultiFab const &radEnergySource, double dt, int stage, int *p_iteration_counter,
+					     int *p_iteration_failure_counter)
+	{
+		auto rt = traits();
+		auto t = qkhost::traits<problem_t>();
+		qkhost::check(qk_rad_AddSourceTermsMultiGroup(lev(), nullptr, &rt, &t, qkhost::tab(consVar), qkhost::tab(radEnergySource), dt, stage,
+							      p_iteration_counter, p_iteration_failure_counter),
+			      "RadSystem::AddSourceTermsMultiGroup");
+	}
 };
+
+// the defaults of the hooks (reference radiation_system.hpp:471-479, :499-503, :1155-1167)
+template <typename problem_t> AMREX_GPU_HOST_DEVICE auto RadSystem<problem_t>::ComputeThermalRadiationSingleGroup(amrex::Real temperature) -> amrex::Real
+{
+	double power = radiation_constant_ * std::pow(temperature, 4);
+	if (power < Erad_floor_) {
+		power = Erad_floor_;
+	}
+	return power;
+}
+template <typename problem_t> AMREX_GPU_HOST_DEVICE auto RadSystem<problem_t>::ComputeThermalRadiationTempDerivativeSingleGroup(amrex::Real temperature) -> amrex::Real
+{
+	return 4. * radiation_constant_ * std::pow(temperature, 3);
+}
+template <typename problem_t>
+AMREX_GPU_HOST_DEVICE auto RadSystem<problem_t>::DefineOpacityExponentsAndLowerValues(amrex::GpuArray<double, nGroups_ + 1> /*rad_boundaries*/, const double /*rho*/,
+										      const double /*Tgas*/) -> amrex::GpuArray<amrex::GpuArray<double, nGroups_ + 1>, 2>
+{
+	amrex::GpuArray<amrex::GpuArray<double, nGroups_ + 1>, 2> exponents_and_values{};
+	for (int g = 0; g < nGroups_ + 1; ++g) {
+		exponents_and_values[0][g] = NAN;
+		exponents_and_values[1][g] = NAN;
+	}
+	return exponents_and_values;
+}
 
 template <typename problem_t> AMREX_GPU_HOST_DEVICE auto RadSystem<problem_t>::ComputePlanckOpacity(const double /*rho*/, const double /*Tgas*/) -> amrex::Real
 {
@@ -1329,6 +1602,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 			this->cellUpdates_ += this->CountCells(0);
 			cur_time += dt_[0];
 			tNew_[0] = cur_time;
+			computeAfterTimestep(); // reference src/simulation.hpp:890
 			outputAfterStep(step);
 			if (cur_time >= stopTime_ - 1.e-6 * dt_[0]) {
 				break;
@@ -1441,8 +1715,8 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		return;
 #endif
 		auto eval = [&](int b, double t) {
-			std::vector<double> h(static_cast<size_t>(radEnergySource_.fabbox(b).numPts()), 0.0);
-			amrex::Array4<double> a(h.data(), radEnergySource_.fabbox(b), 1);
+			std::vector<double> h(static_cast<size_t>(radEnergySource_.fabbox(b).numPts()) * radEnergySource_.nComp(), 0.0);
+			amrex::Array4<double> a(h.data(), radEnergySource_.fabbox(b), radEnergySource_.nComp());
 			RadSystem<problem_t>::SetRadEnergySource(a, radEnergySource_.validbox(b), g.CellSizeArray(), g.ProbLoArray(), g.ProbHiArray(), t);
 			return h;
 		};
@@ -1462,7 +1736,11 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	void operatorSplitSourceTerms(double time, double dt, int stage)
 	{
 		fillRadEnergySource(time + dt);
-		RadSystem<problem_t>::AddSourceTermsSingleGroup(state_new_cc_[0], radEnergySource_, dt, stage, d_radCounter_, d_radFailure_);
+		if constexpr (Physics_Traits<problem_t>::nGroups <= 1) { // :1875-1881
+			RadSystem<problem_t>::AddSourceTermsSingleGroup(state_new_cc_[0], radEnergySource_, dt, stage, d_radCounter_, d_radFailure_);
+		} else {
+			RadSystem<problem_t>::AddSourceTermsMultiGroup(state_new_cc_[0], radEnergySource_, dt, stage, d_radCounter_, d_radFailure_);
+		}
 	}
 
 	void advanceRadiationForwardEuler(double dt_radiation) // :1790-1821
@@ -1580,7 +1858,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 				radFluxOld_[d].define(grids_, RadSystem<problem_t>::nvarHyperbolic_, 0, d);
 				radFlux_[d].define(grids_, RadSystem<problem_t>::nvarHyperbolic_, 0, d);
 			}
-			radEnergySource_.define(grids_, 1, 0);
+			radEnergySource_.define(grids_, Physics_Traits<problem_t>::nGroups, 0); // :1866-1869
 			radEnergySource_.setVal(0);
 			QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_radCounter_), 4 * sizeof(int)));
 			QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_radFailure_), 3 * sizeof(int)));
