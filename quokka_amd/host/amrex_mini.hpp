@@ -351,9 +351,16 @@ class BCRec
 	[[nodiscard]] QK_HD auto hi(int dir) const -> int { return bc[3 + dir]; }
 };
 
+struct RealBoxData { // amrex::RealBox as GeometryData::prob_domain carries it
+	GpuArray<Real, AMREX_SPACEDIM> xlo{}, xhi{};
+	[[nodiscard]] QK_HD auto length(int d) const -> Real { return xhi[d] - xlo[d]; }
+	[[nodiscard]] QK_HD auto lo(int d) const -> Real { return xlo[d]; }
+	[[nodiscard]] QK_HD auto hi(int d) const -> Real { return xhi[d]; }
+};
 struct GeometryData {
 	Box domain;
 	GpuArray<Real, AMREX_SPACEDIM> prob_lo{}, prob_hi{}, dx{};
+	RealBoxData prob_domain{};
 	[[nodiscard]] QK_HD auto Domain() const -> Box const & { return domain; }
 	[[nodiscard]] QK_HD auto ProbLo(int d) const -> Real { return prob_lo[d]; }
 	[[nodiscard]] QK_HD auto ProbHi(int d) const -> Real { return prob_hi[d]; }
@@ -384,7 +391,7 @@ class Geometry
 		}
 		return a;
 	}
-	[[nodiscard]] auto data() const -> GeometryData { return {domain, prob_lo, prob_hi, dx}; }
+	[[nodiscard]] auto data() const -> GeometryData { return {domain, prob_lo, prob_hi, dx, RealBoxData{prob_lo, prob_hi}}; }
 };
 
 // ParmParse: `key = v1 v2 ...` decks (# comments) + command-line overrides, with prefixes

@@ -103,6 +103,10 @@ template <typename problem_t> struct EOS {
 		double const e = Eint / rho;
 		return ((gamma_ - 1.0) * rho * e) * kB_ / C::k_B;
 	}
+	AMREX_GPU_HOST_DEVICE static auto ComputeSoundSpeed(double rho, double Pressure, MassScalars const & /*massScalars*/ = {}) -> double
+	{
+		return std::sqrt(gamma_ * Pressure / rho); // EOS.hpp:143-175 for the gamma law
+	}
 	AMREX_GPU_HOST_DEVICE static auto ComputeTgasFromEint(double rho, double Eint, MassScalars const & /*massScalars*/ = {}) -> double
 	{
 		double const e = Eint / rho;
@@ -279,6 +283,30 @@ template <typename problem_t> class HydroSystem : public HyperbolicSystem<proble
 		const auto thermal_energy = cons(i, j, k, energy_index) - kinetic_energy;
 		const auto e = (rho == 0.0) ? 0.0 : thermal_energy / rho;
 		return (gamma_ - 1.0) * rho * e;
+	}
+	// hydro_system.hpp:294-347: primitive <-> conserved state of one cell (boundary functors: NSCBC)
+	AMREX_GPU_HOST_DEVICE static auto ComputePrimVars(amrex::Array4<const amrex::Real> const &cons, int i, int j, int k) -> quokka::valarray<amrex::Real, nvar_>
+	{
+		const auto rho = cons(i, j, k, density_index);
+		const auto vx = cons(i, j, k, x1Momentum_index) / rho;
+		const auto vy = cons(i, j, k, x2Momentum_index) / rho;
+		const auto vz = cons(i, j, k, x3Momentum_index) / rho;
+		quokka::valarray<amrex::Real, nvar_> primVars{rho, vx, vy, vz, ComputePressure(cons, i, j, k), cons(i, j, k, internalEnergy_index)};
+		for (int n = 0; n < nscalars_; ++n) {
+			primVars[primScalar0_index + n] = cons(i, j, k, scalar0_index + n);
+		}
+		return primVars;
+	}
+	AMREX_GPU_HOST_DEVICE static auto ComputeConsVars(quokka::valarray<amrex::Real, nvar_> const &prim) -> quokka::valarray<amrex::Real, nvar_>
+	{
+		amrex::Real const rho = prim[0], v1 = prim[1], v2 = prim[2], v3 = prim[3];
+		amrex::Real const Eint = quokka::EOS<problem_t>::ComputeEintFromPres(rho, prim[4]);
+		amrex::Real const Egas = Eint + 0.5 * rho * (v1 * v1 + v2 * v2 + v3 * v3);
+		quokka::valarray<amrex::Real, nvar_> consVars{rho, rho * v1, rho * v2, rho * v3, Egas, prim[5]};
+		for (int n = 0; n < nscalars_; ++n) {
+			consVars[scalar0_index + n] = prim[primScalar0_index + n];
+		}
+		return consVars;
 	}
 	AMREX_GPU_HOST_DEVICE static auto ComputeSoundSpeed(amrex::Array4<const amrex::Real> const &cons, int i, int j, int k) -> amrex::Real
 	{

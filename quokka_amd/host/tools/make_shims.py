@@ -14,7 +14,8 @@ AMReX_Random.H AMReX_RandomEngine.H AMReX_GpuLaunch.H AMReX_Utility.H AMReX_INT.
 QUOKKA = ["QuokkaSimulation.hpp", "simulation.hpp", "physics_info.hpp", "hydro/hydro_system.hpp", "hydro/EOS.hpp", "hydro/HydroState.hpp",
           "radiation/radiation_system.hpp", "fundamental_constants.H", "hyperbolic_system.hpp", "grid.hpp", "math/math_impl.hpp"]
 COMPAT = {"util/fextract.hpp": "compat/util_compat.hpp", "util/ArrayUtil.hpp": "compat/util_compat.hpp", "util/valarray.hpp": "compat/util_compat.hpp",
-          "fmt/format.h": "compat/mini_fmt.hpp", "fmt/core.h": "compat/mini_fmt.hpp", "radiation/planck_integral.hpp": "compat/planck_integral.hpp"}
+          "fmt/format.h": "compat/mini_fmt.hpp", "fmt/core.h": "compat/mini_fmt.hpp", "radiation/planck_integral.hpp": "compat/planck_integral.hpp",
+          "hydro/NSCBC_inflow.hpp": "compat/nscbc.hpp", "hydro/NSCBC_outflow.hpp": "compat/nscbc.hpp"}
 EMPTY = ["util/matplotlibcpp.h"]
 
 

@@ -131,3 +131,29 @@ def test_unmodified_vaytet_marshak_wave_runs_to_the_end(tmp_path):
     rc, out = run([exe("ref_RadMarshakVaytet"), os.path.join(HOST, "decks", "MarshakVaytet.in")], str(tmp_path), timeout=1500)
     assert rc == 0, out[-2500:]
     assert os.path.exists(tmp_path / "marshak_wave_Vaytet.csv")
+
+
+def test_unmodified_nscbc_channel_meets_the_reference_criterion(tmp_path):
+    """NSCBC/channel.cpp, unchanged (ctest ChannelFlow): a subsonic channel flow driven from 2e3 to 4e3 cm/s through a characteristic inflow
+    (relaxation to the target temperature / velocity / scalar) and a characteristic outflow (far-field pressure), one passive scalar.  The
+    boundary functor calls NSCBC::setInflowX1Lower / setOutflowBoundary — the host mirror's own characteristic formulation
+    (quokka_amd/host/compat/nscbc.hpp) — inside the boundary kernel.  Exit status 0 = the rms of the component-wise relative L1 errors against
+    the steady state (density, velocity, pressure, scalar) is below 3e-5 after t = 0.1 s."""
+    rc, out = run([exe("ref_NSCBC_channel"), os.path.join(HOST, "decks", "NSCBC_Channel.in")], str(tmp_path), timeout=1500)
+    assert rc == 0, out[-2500:]
+    assert "rms of component-wise relative L1 error norms" in out
+
+
+def test_unmodified_nscbc_vortex_runs_in_2d(tmp_path):
+    """NSCBC/vortex.cpp, unchanged, as the 2-D build (AMREX_SPACEDIM = 2) of the host mirror: a vortex convected at 1e4 cm/s through characteristic
+    outflow faces in x (transverse terms active: the flow has gradients along the boundary), periodic in y.  The reference's problem has no error
+    norm (returns 0); here: it reaches t_end, the state is finite, the pressure stays within 1 % of the far field and the vortex is still there."""
+    dump = str(tmp_path / "v.bin")
+    rc, out = run([exe("ref_NSCBC_vortex"), os.path.join(HOST, "decks", "NSCBC_Vortex.in"), f"qk.dump_state={dump}"], str(tmp_path))
+    assert rc == 0, out[-2500:]
+    U = np.fromfile(dump, dtype=np.float64).reshape(7, 128, 128)
+    assert np.isfinite(U).all()
+    rho, px, py = U[0], U[1], U[2]
+    P = (1.4 - 1.0) * (U[4] - 0.5 * (px * px + py * py) / rho)
+    assert np.abs(P / 1.01325e6 - 1.0).max() < 0.01
+    assert np.abs(py / rho).max() > 50.0 and np.abs(px / rho - 1.0e4).max() < 1.0e3
