@@ -93,6 +93,8 @@
 #define AMREX_D_TERM(a, b, c) a b c
 #endif
 
+#include "qk_comm.hpp"
+
 namespace amrex
 {
 using Real = double;
@@ -578,30 +580,32 @@ struct Device {
 } // namespace Gpu
 
 // one process per GPU; the problem-side reductions of the reference are over one rank here
+// one process per GPU: the reductions a problem file or the driver performs over ranks go through qkhost::Comm (qk_comm.hpp); with one rank
+// every function returns its argument
 namespace ParallelDescriptor
 {
-inline auto IOProcessor() -> bool { return true; }
+inline auto IOProcessor() -> bool { return qkhost::Comm::get().rank == 0; }
 inline auto IOProcessorNumber() -> int { return 0; }
-inline auto MyProc() -> int { return 0; }
-inline auto NProcs() -> int { return 1; }
-inline void Barrier() {}
-template <typename T> void ReduceRealSum(T & /*v*/) {}
-template <typename T> void ReduceRealMax(T & /*v*/) {}
-template <typename T> void ReduceRealMin(T & /*v*/) {}
-inline void ReduceIntSum(int & /*v*/) {}
-inline void ReduceLongSum(long & /*v*/) {}
+inline auto MyProc() -> int { return qkhost::Comm::get().rank; }
+inline auto NProcs() -> int { return qkhost::Comm::get().size; }
+inline void Barrier() { qkhost::Comm::get().barrier(); }
+template <typename T> void ReduceRealSum(T &v) { v = static_cast<T>(qkhost::Comm::get().allReduceSum(static_cast<double>(v))); }
+template <typename T> void ReduceRealMax(T &v) { v = static_cast<T>(qkhost::Comm::get().allReduceMax(static_cast<double>(v))); }
+template <typename T> void ReduceRealMin(T &v) { v = static_cast<T>(qkhost::Comm::get().allReduceMin(static_cast<double>(v))); }
+inline void ReduceIntSum(int &v) { v = static_cast<int>(qkhost::Comm::get().allReduceSum(static_cast<int64_t>(v))); }
+inline void ReduceLongSum(long &v) { v = static_cast<long>(qkhost::Comm::get().allReduceSum(static_cast<int64_t>(v))); }
 inline void Abort() { std::exit(2); }
 } // namespace ParallelDescriptor
 namespace ParallelContext
 {
 inline auto CommunicatorSub() -> int { return 0; }
-inline auto IOProcessorSub() -> bool { return true; }
+inline auto IOProcessorSub() -> bool { return qkhost::Comm::get().rank == 0; }
 } // namespace ParallelContext
 namespace ParallelAllReduce
 {
-template <typename T> void Sum(T & /*v*/, int /*comm*/) {}
-template <typename T> void Max(T & /*v*/, int /*comm*/) {}
-template <typename T> void Min(T & /*v*/, int /*comm*/) {}
+template <typename T> void Sum(T &v, int /*comm*/) { ParallelDescriptor::ReduceRealSum(v); }
+template <typename T> void Max(T &v, int /*comm*/) { ParallelDescriptor::ReduceRealMax(v); }
+template <typename T> void Min(T &v, int /*comm*/) { ParallelDescriptor::ReduceRealMin(v); }
 } // namespace ParallelAllReduce
 template <typename F> void LoopOnCpu(Box const &bx, F &&f) { HostFor(bx, f); }
 class BoxArray : public std::vector<Box>
@@ -733,7 +737,7 @@ template <typename T> class FabArrayT
 				s = t;
 			});
 		}
-		return s;
+		return qkhost::Comm::get().allReduceSum(s); // (MultiFab::sum reduces over all ranks)
 	}
 
       private:

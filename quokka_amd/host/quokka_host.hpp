@@ -21,6 +21,7 @@
 #include "amrex_mini.hpp"
 #include "compat/planck_integral.hpp"
 #include "compat/util_compat.hpp"
+#include "qk_comm.hpp"
 #include "quokka_io.hpp"
 
 // Microphysics fundamental_constants.H (CODATA 2018, cgs)
@@ -412,7 +413,7 @@ template <typename problem_t> class HydroSystem : public HyperbolicSystem<proble
 		qkhost::check(qk_hydro_maxSignalSpeedLocal(lev(), nullptr, &t, which, qkhost::tab(cons), d_res), "maxSignalSpeedLocal");
 		double h = 0;
 		QK_HOST_HIP(hipMemcpy(&h, d_res, sizeof(double), hipMemcpyDeviceToHost));
-		return h;
+		return qkhost::Comm::get().allReduceMax(h); // ParallelDescriptor::ReduceRealMax (reference src/simulation.hpp:1003)
 	}
 };
 
@@ -911,6 +912,81 @@ void RadSystem<problem_t>::SetRadEnergySource(array_t & /*radEnergySource*/, amr
 	// do nothing -- user implemented
 }
 
+namespace qkhost
+{
+// Locality-preserving box -> rank map (the role of AMReX's SFC DistributionMapping; the same rule as quokka_amd/simulation.py
+// distribute_boxes): the box lattice nb[0] x nb[1] x nb[2] is cut into `nranks` bricks by repeatedly halving its longest axis
+// (2 x 2 x 2 bricks for 8 ranks); lattices that cannot be cut that way fall back to contiguous blocks of boxes.
+inline auto distributeBoxes(int const nb[3], int nranks) -> std::vector<int>
+{
+	int const nboxes = nb[0] * nb[1] * nb[2];
+	std::vector<int> owner(static_cast<size_t>(nboxes), 0);
+	if (nranks <= 1) {
+		return owner;
+	}
+	int parts[3] = {1, 1, 1};
+	int r = nranks;
+	while (r > 1) {
+		int d = 0;
+		for (int a = 1; a < 3; ++a) {
+			if (static_cast<double>(nb[a]) / parts[a] > static_cast<double>(nb[d]) / parts[d]) {
+				d = a;
+			}
+		}
+		if (r % 2 != 0 || nb[d] / (parts[d] * 2) < 1) {
+			break;
+		}
+		parts[d] *= 2;
+		r /= 2;
+	}
+	if (parts[0] * parts[1] * parts[2] != nranks) {
+		int const per = (nboxes + nranks - 1) / nranks;
+		for (int i = 0; i < nboxes; ++i) {
+			owner[i] = std::min(i / per, nranks - 1);
+		}
+		return owner;
+	}
+	int n = 0;
+	for (int kb = 0; kb < nb[2]; ++kb) {
+		for (int jb = 0; jb < nb[1]; ++jb) {
+			for (int ib = 0; ib < nb[0]; ++ib) {
+				int const idx[3] = {ib, jb, kb};
+				int p[3];
+				for (int d = 0; d < 3; ++d) {
+					p[d] = std::min(idx[d] * parts[d] / nb[d], parts[d] - 1);
+				}
+				owner[n++] = p[0] + parts[0] * (p[1] + parts[1] * p[2]);
+			}
+		}
+	}
+	return owner;
+}
+
+// device send / receive buffers for the peers of a ghost plan (qk_ghost_plan_peer: rank and strip sizes in elements)
+struct PeerBuffers {
+	std::vector<int> peer;
+	std::vector<void *> send, recv;
+	std::vector<int64_t> nsend, nrecv;
+	void build(qk_ghost_plan *plan, size_t elemBytes)
+	{
+		int const np = qk_ghost_plan_num_peers(plan);
+		for (int k = 0; k < np; ++k) {
+			int r = 0;
+			int64_t ns = 0, nr = 0;
+			check(qk_ghost_plan_peer(plan, k, &r, &ns, &nr), "qk_ghost_plan_peer");
+			void *s = nullptr, *rv = nullptr;
+			QK_HOST_HIP(hipMalloc(&s, std::max<size_t>(static_cast<size_t>(ns) * elemBytes, 8)));
+			QK_HOST_HIP(hipMalloc(&rv, std::max<size_t>(static_cast<size_t>(nr) * elemBytes, 8)));
+			peer.push_back(r);
+			send.push_back(s);
+			recv.push_back(rv);
+			nsend.push_back(ns);
+			nrecv.push_back(nr);
+		}
+	}
+};
+} // namespace qkhost
+
 // per-problem user data a problem may specialise (reference src/simulation.hpp: SimulationData<problem_t> userData_)
 template <typename problem_t> struct SimulationData {
 };
@@ -1030,12 +1106,20 @@ template <typename problem_t> class AMRSimulation
 	void initialize(LevelSpec const *spec)
 	{
 		readParameters();
+		auto &comm = qkhost::Comm::get();
+		comm.init(); // one process per GPU: selects this rank's device (reference src/main.cpp:22-46)
 		auto &rt = qkhost::Runtime::get();
 		if (rt.ctx == nullptr) {
-			qkhost::check(qk_ctx_create(&rt.ctx, 0), "qk_ctx_create");
+			int dev = 0;
+			QK_HOST_HIP(hipGetDevice(&dev));
+			qkhost::check(qk_ctx_create(&rt.ctx, dev), "qk_ctx_create");
 		}
 		auto &g = geom[0];
 		grids_.clear();
+		int nb[3] = {1, 1, 1};
+		if (spec != nullptr && comm.size > 1) {
+			amrex::Abort("the AMR driver of the host mirror is single-rank (uniform-grid runs distribute their boxes over the ranks)");
+		}
 		if (spec != nullptr) {
 			g = spec->geom;
 			grids_ = spec->boxes;
@@ -1067,7 +1151,6 @@ template <typename problem_t> class AMRSimulation
 					g.dx[d] = (phi[d] - plo[d]) / ncell[d];
 				}
 			}
-			int nb[3];
 			for (int d = 0; d < 3; ++d) {
 				nb[d] = (d < AMREX_SPACEDIM) ? (g.domain.length(d) + mgs[d] - 1) / mgs[d] : 1;
 			}
@@ -1087,27 +1170,47 @@ template <typename problem_t> class AMRSimulation
 				}
 			}
 		}
+		// the whole level and its box -> rank map (every rank computes the same); this rank keeps the boxes it owns, in global order
+		allGrids_ = grids_;
+		owner_ = (spec != nullptr) ? std::vector<int>(allGrids_.size(), 0) : qkhost::distributeBoxes(nb, comm.size);
+		allBoxes_.clear();
+		for (auto const &b : allGrids_) {
+			allBoxes_.push_back({{b.lo[0], b.lo[1], b.lo[2]}, {b.hi[0], b.hi[1], b.hi[2]}});
+		}
+		grids_.clear();
 		std::vector<qk_box> qb;
-		for (auto const &b : grids_) {
-			qb.push_back({{b.lo[0], b.lo[1], b.lo[2]}, {b.hi[0], b.hi[1], b.hi[2]}});
+		for (size_t n = 0; n < allGrids_.size(); ++n) {
+			if (owner_[n] == comm.rank) {
+				grids_.push_back(allGrids_[n]);
+				qb.push_back(allBoxes_[n]);
+			}
+		}
+		if (grids_.empty()) {
+			amrex::Abort("this rank owns no boxes: fewer boxes than ranks (lower amr.max_grid_size)");
 		}
 		qkhost::check(qk_level_create(rt.ctx, &myLev_, AMREX_SPACEDIM, static_cast<int>(qb.size()), qb.data()), "qk_level_create");
 		rt.lev = myLev_;
 		int const nc = Physics_Indices<problem_t>::nvarTotal_cc;
 		state_new_cc_[0].define(grids_, nc, nghost_cc_);
 		state_old_cc_[0].define(grids_, nc, nghost_cc_);
-		// ghost-exchange plan (single rank: every box is local)
-		qk_geometry qg{};
+		// ghost-exchange plan: same-rank copies, strips packed for / unpacked from the peers, physical-boundary shells
 		for (int d = 0; d < 3; ++d) {
-			qg.domain.lo[d] = g.domain.lo[d];
-			qg.domain.hi[d] = g.domain.hi[d];
-			qg.periodic[d] = g.periodic[d];
+			qgeom_.domain.lo[d] = g.domain.lo[d];
+			qgeom_.domain.hi[d] = g.domain.hi[d];
+			qgeom_.periodic[d] = g.periodic[d];
 		}
-		qg.ndim = AMREX_SPACEDIM;
-		std::vector<int> owner(qb.size(), 0);
-		qkhost::check(qk_ghost_plan_create(myLev_, &plan_, &qg, nghost_cc_, nc, static_cast<int>(qb.size()), qb.data(), owner.data(), 0),
+		qgeom_.ndim = AMREX_SPACEDIM;
+		qkhost::check(qk_ghost_plan_create(myLev_, &plan_, &qgeom_, nghost_cc_, nc, static_cast<int>(allBoxes_.size()), allBoxes_.data(), owner_.data(),
+						   comm.rank),
 			      "qk_ghost_plan_create");
+		peers_.build(plan_, sizeof(double));
 	}
+	// level description shared by every plan of this level
+	std::vector<amrex::Box> allGrids_;
+	std::vector<qk_box> allBoxes_;
+	std::vector<int> owner_;
+	qk_geometry qgeom_{};
+	qkhost::PeerBuffers peers_;
 
 	void readParameters() // reference src/simulation.hpp:541-636 (the keys the config decks use)
 	{
@@ -1124,10 +1227,10 @@ template <typename problem_t> class AMRSimulation
 		pp.query("temperature_floor", tempFloor_);
 	}
 
-	[[nodiscard]] auto CountCells(int /*lev*/) const -> amrex::Long
+	[[nodiscard]] auto CountCells(int /*lev*/) const -> amrex::Long // (all ranks)
 	{
 		amrex::Long n = 0;
-		for (auto const &b : grids_) {
+		for (auto const &b : allGrids_) {
 			n += b.numPts();
 		}
 		return n;
@@ -1204,7 +1307,19 @@ template <typename problem_t> class AMRSimulation
 	void fillBoundaryConditions(amrex::MultiFab &state)
 	{
 		activate();
+		// state.FillBoundary(geom.periodicity()) (reference src/simulation.hpp:1755): strips for the other ranks are packed, sent peer to peer
+		// while the same-rank copies run, and unpacked
+		for (size_t k = 0; k < peers_.peer.size(); ++k) {
+			qkhost::check(qk_FillBoundary_pack(plan_, nullptr, static_cast<int>(k), qkhost::tab(state), static_cast<double *>(peers_.send[k])),
+				      "FillBoundary_pack");
+		}
+		qkhost::Comm::get().exchangeBegin(peers_.peer, peers_.send, peers_.nsend, peers_.recv, peers_.nrecv, sizeof(double), nullptr);
 		qkhost::check(qk_FillBoundary_local(plan_, nullptr, qkhost::tab(state)), "FillBoundary");
+		qkhost::Comm::get().exchangeEnd(nullptr);
+		for (size_t k = 0; k < peers_.peer.size(); ++k) {
+			qkhost::check(qk_FillBoundary_unpack(plan_, nullptr, static_cast<int>(k), qkhost::tab(state), static_cast<const double *>(peers_.recv[k])),
+				      "FillBoundary_unpack");
+		}
 		if (beforePhysBC_) {
 			beforePhysBC_(state);
 		}
@@ -1701,6 +1816,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		}
 		int err = 0;
 		QK_HOST_HIP(hipMemcpy(&err, d_error_, sizeof(int), hipMemcpyDeviceToHost));
+		err = qkhost::Comm::get().allReduceMax(err);
 		if (err != 0) {
 			amrex::Abort("density is negative in SyncDualEnergy! abort!!");
 		}
@@ -1812,6 +1928,16 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 			int cnt[4], fail[3];
 			QK_HOST_HIP(hipMemcpy(cnt, d_radCounter_, sizeof(cnt), hipMemcpyDeviceToHost));
 			QK_HOST_HIP(hipMemcpy(fail, d_radFailure_, sizeof(fail), hipMemcpyDeviceToHost));
+			if (qkhost::Comm::get().size > 1) { // counters over all ranks (the reference reduces them when it prints them, QuokkaSimulation.hpp:1690-1720)
+				double v[7] = {double(cnt[0]), double(cnt[1]), double(fail[0]), double(fail[1]), double(fail[2]), 0, 0};
+				qkhost::Comm::get().allReduce(v, 5, qkhost::Comm::Op::sum);
+				cnt[0] = int(v[0]);
+				cnt[1] = int(v[1]);
+				fail[0] = int(v[2]);
+				fail[1] = int(v[3]);
+				fail[2] = int(v[4]);
+				cnt[2] = qkhost::Comm::get().allReduceMax(cnt[2]);
+			}
 			radSolves_ += cnt[0];
 			radNewtonIterations_ += cnt[1];
 			radMaxNewtonIterations_ = std::max(radMaxNewtonIterations_, cnt[2]);
@@ -1913,16 +2039,20 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 			qg.periodic[d] = g.periodic[d];
 		}
 		qg.ndim = AMREX_SPACEDIM;
-		std::vector<int> owner(qb.size(), 0);
-		qkhost::check(qk_ghost_plan_create(qkhost::Runtime::get().lev, &flagPlan_, &qg, 1, 1, static_cast<int>(qb.size()), qb.data(), owner.data(), 0),
+		(void)qg;
+		(void)qb;
+		qkhost::check(qk_ghost_plan_create(qkhost::Runtime::get().lev, &flagPlan_, &this->qgeom_, 1, 1, static_cast<int>(this->allBoxes_.size()),
+						   this->allBoxes_.data(), this->owner_.data(), qkhost::Comm::get().rank),
 			      "qk_ghost_plan_create(redoFlag)");
+		flagPeers_.build(flagPlan_, sizeof(int));
 	}
 
-	auto readCount() -> int64_t
+	qkhost::PeerBuffers flagPeers_;
+	auto readCount() -> int64_t // cells flagged on ALL ranks: every rank takes the same branch of the FOFC / retry logic
 	{
 		int64_t c = 0;
 		QK_HOST_HIP(hipMemcpy(&c, d_count_, sizeof(int64_t), hipMemcpyDeviceToHost));
-		return c;
+		return qkhost::Comm::get().allReduceSum(c);
 	}
 
 	// computeHydroFluxes / hydroFluxFunction (reference src/QuokkaSimulation.hpp:1403-1517)
@@ -1998,7 +2128,19 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		if (nbad > 0) { // first-order flux correction
 			++fofcStages_;
 			computeFOHydroFluxes(U_old);
+			// redoFlag.FillBoundary(geom.periodicity()) (reference src/QuokkaSimulation.hpp:1157), across ranks as the state's
+			for (size_t k = 0; k < flagPeers_.peer.size(); ++k) {
+				qkhost::check(qk_FillBoundary_pack_int(flagPlan_, nullptr, static_cast<int>(k), qkhost::itab(redoFlag_), static_cast<int *>(flagPeers_.send[k])),
+					      "redoFlag pack");
+			}
+			qkhost::Comm::get().exchangeBegin(flagPeers_.peer, flagPeers_.send, flagPeers_.nsend, flagPeers_.recv, flagPeers_.nrecv, sizeof(int), nullptr);
 			qkhost::check(qk_FillBoundary_local_int(flagPlan_, nullptr, qkhost::itab(redoFlag_)), "redoFlag.FillBoundary");
+			qkhost::Comm::get().exchangeEnd(nullptr);
+			for (size_t k = 0; k < flagPeers_.peer.size(); ++k) {
+				qkhost::check(qk_FillBoundary_unpack_int(flagPlan_, nullptr, static_cast<int>(k), qkhost::itab(redoFlag_),
+									 static_cast<const int *>(flagPeers_.recv[k])),
+					      "redoFlag unpack");
+			}
 			for (int d = 0; d < AMREX_SPACEDIM; ++d) {
 				qkhost::check(qk_replaceFluxes(lev, nullptr, d, qkhost::tab((*fl)[d]), qkhost::tab(FOflux_[d]), qkhost::itab(redoFlag_), ncompHydro_),
 					      "replaceFluxes");
@@ -2057,6 +2199,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 			if (readCount() == 0) {
 				if (final_stage) {
 					QK_HOST_HIP(hipMemcpy(signal_, d_signal_, 2 * sizeof(double), hipMemcpyDeviceToHost));
+					qkhost::Comm::get().allReduce(signal_, 2, qkhost::Comm::Op::max);
 					haveSignal_ = true;
 				}
 				return true;
@@ -2112,6 +2255,9 @@ template <typename problem_t> void qkDumpState(QuokkaSimulation<problem_t> &sim)
 	amrex::ParmParse pp("qk");
 	if (!pp.query("dump_state", path)) {
 		return;
+	}
+	if (qkhost::Comm::get().size > 1) { // one file per rank: its boxes in global order
+		path += ".rank" + std::to_string(qkhost::Comm::get().rank);
 	}
 	std::ofstream f(path, std::ios::binary);
 	auto &mf = sim.state_new_cc_[0];
