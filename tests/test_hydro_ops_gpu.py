@@ -133,8 +133,8 @@ def test_artificial_viscosity_path(ctx, oracle):
 def test_unsupported_and_invalid_arguments_fail_loudly(ctx):
     lev = Level(ctx, 3, [([0, 0, 0], [7, 7, 7])])
     mf = MultiFab(lev, 6, 4, fill=1.0)
-    for bad in (capi.traits(1.4, True, 3, nscalars=9), capi.traits(1.4, True, 3, nscalars=1, nmscalars=2), capi.traits(1.4, True, 2),
-                capi.traits(1.4, True, 3, eos_temperature_model=1, eos_alpha=0.0)):  # > QK_MAX_SCALARS, mass scalars, 2-D, T^4 material without alpha
+    for bad in (capi.traits(1.4, True, 3, nscalars=9), capi.traits(1.4, True, 3, nscalars=1, nmscalars=2), capi.traits(1.4, True, 4),
+                capi.traits(1.4, True, 3, eos_temperature_model=1, eos_alpha=0.0)):  # > QK_MAX_SCALARS, more mass than passive scalars, ndim 4, T^4 material without alpha
         with pytest.raises(capi.QkError):
             HydroSystem(bad).ConservedToPrimitive(lev, mf, mf, 4)
     with pytest.raises(capi.QkError):
