@@ -74,8 +74,29 @@ struct Rad {
 		const double f_fac = sqrt(4.0 - 3.0 * (f * f));
 		return (3.0 + 4.0 * (f * f)) / (5.0 + 2.0 * f_fac);
 	}
-	QK_DEV auto pow4(double T) const -> double { return (pow_mode == 0) ? pow(T, 4.0) : (T * T) * (T * T); }
-	QK_DEV auto pow3(double T) const -> double { return (pow_mode == 0) ? pow(T, 3.0) : (T * T) * T; }
+	// pow_mode 0 stands for the reference's std::pow(T, 4) / std::pow(T, 3), which glibc rounds correctly in all but a vanishing fraction of
+	// cases.  Evaluated here as compensated products (T^2 = hi + lo exactly by one fma; the product of the pair carried with its rounding
+	// error): faithfully rounded, i.e. within 0.5 ulp + 2^-100 of the exact power — the same bits as a correctly rounded pow except in
+	// near-tie cases — at a dozen instructions instead of the ~200 of the device libm's general pow (which is only accurate to ~1 ulp).
+	// pow_mode 1: plain repeated multiplication (what the bit-level tests share with the oracle).
+	QK_DEV static auto pow4Faithful(double T) -> double
+	{
+		const double hi = T * T;
+		const double lo = __builtin_fma(T, T, -hi);
+		const double r = hi * hi;
+		const double e = __builtin_fma(hi, hi, -r);
+		return r + (e + 2.0 * (hi * lo));
+	}
+	QK_DEV static auto pow3Faithful(double T) -> double
+	{
+		const double hi = T * T;
+		const double lo = __builtin_fma(T, T, -hi);
+		const double r = hi * T;
+		const double e = __builtin_fma(hi, T, -r);
+		return r + (e + lo * T);
+	}
+	QK_DEV auto pow4(double T) const -> double { return (pow_mode == 0) ? pow4Faithful(T) : (T * T) * (T * T); }
+	QK_DEV auto pow3(double T) const -> double { return (pow_mode == 0) ? pow3Faithful(T) : (T * T) * T; }
 	// radiation_system.hpp:471-479, :499-503
 	QK_DEV auto thermalRadiation(double T) const -> double
 	{
@@ -358,7 +379,8 @@ QK_DEV void radSourceCell(Rad const &r, Eos const &eos, double U[10], double src
 				kappaP = r.template kappaP<TDEP>(rho, T_d);
 				kappaE = r.template kappaE<TDEP>(rho, T_d);
 				if (kappaE > 0.0) {
-					kappaPoverE = kappaP / kappaE;
+					// (x / x is exactly 1 for finite x: equal Planck and energy means — the common case — skip the division)
+					kappaPoverE = (kappaP == kappaE) ? 1.0 : kappaP / kappaE;
 				} else {
 					kappaPoverE = 1.0;
 				}
@@ -372,7 +394,7 @@ QK_DEV void radSourceCell(Rad const &r, Eos const &eos, double U[10], double src
 					}
 					tau0 = dt * rho * kappaP * chat * lorentz_factor;
 					tau = tau0;
-					R = (fourPiBoverC - Erad_guess / kappaPoverE) * tau0 + work;
+					R = (fourPiBoverC - ((kappaPoverE == 1.0) ? Erad_guess : Erad_guess / kappaPoverE)) * tau0 + work; // (y / 1 is y exactly)
 					tau0 = smax(tau0, 1.0);
 				} else {
 					tau = dt * rho * kappaP * chat * lorentz_factor;
@@ -426,11 +448,19 @@ QK_DEV void radSourceCell(Rad const &r, Eos const &eos, double U[10], double src
 				// (plain divisions: det = -inf when tau <= 0, where IEEE inf arithmetic is part of the algorithm)
 				deltaEgas = (J11 * y0 - J01 * y1) / det;
 				deltaR = (J00 * y1 - J10 * y0) / det;
-				// enable_dE_constrain = true (radiation_system.hpp:44)
-				const double T_rad = sqrt(sqrt(Erad_guess / r.arad));
-				if (deltaEgas / c_v > smax(T_gas, T_rad)) {
-					Egas_guess = eos.eintFromTgas(rho, T_rad);
-				} else {
+				// enable_dE_constrain = true (radiation_system.hpp:44): the step is cut when deltaEgas / c_v > max(T_gas, T_rad).  The radiation
+				// temperature (a division and two square roots) can only matter when the quotient already exceeds T_gas: evaluated then, not
+				// in every iteration — the same decision and the same values.
+				const double dT_step = deltaEgas / c_v;
+				bool cut = false;
+				if (dT_step > T_gas) {
+					const double T_rad = sqrt(sqrt(Erad_guess / r.arad));
+					if (dT_step > smax(T_gas, T_rad)) {
+						cut = true;
+						Egas_guess = eos.eintFromTgas(rho, T_rad);
+					}
+				}
+				if (!cut) {
 					Egas_guess += deltaEgas;
 					R += deltaR;
 				}

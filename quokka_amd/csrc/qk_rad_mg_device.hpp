@@ -224,10 +224,11 @@ template <int NG> QK_DEV auto planckFunction(Rad const &r, RadMG<NG> const &m, d
 	if (x <= 1.0e-10) {
 		planck_integral = x * x - x * x * x / 2.;
 	} else {
-		planck_integral = pow(x, 3.0) / (exp(x) - 1.0);
+		planck_integral = Rad::pow3Faithful(x) / (exp(x) - 1.0); // std::pow(x, 3), faithfully rounded (qk_rad_device.hpp)
 	}
 	constexpr double PI = 3.14159265358979323846;
-	return coeff / (pow(PI, 4.0) / 15.0) * (r.arad * pow(T, 4.0)) * planck_integral;
+	constexpr double PI4 = 97.40909103400242; // std::pow(M_PI, 4): the fourth power of the double nearest pi, correctly rounded
+	return coeff / (PI4 / 15.0) * (r.arad * Rad::pow4Faithful(T)) * planck_integral;
 }
 
 template <int NG> struct OpacityTermsMG {
