@@ -235,6 +235,39 @@ QK_DEV auto eintTempDerivative(Eos const &eos, double rho, double T) -> double
 	return dedT * rho * eos.kB_user / Eos::k_B;
 }
 
+// quokka::EOS for ONE cell inside the Newton iteration: Eos::tgasFromEint and eintTempDerivative above with the quotients whose denominators do
+// not change from one iteration to the next — rho, (gamma - 1) rho, k_B, mu m_u, the user's k_B — taken through their refined reciprocals
+// (divBy: the same bits as `/` for normal-range operands, qk_device.hpp).  Ten of the ~14 divisions of a Newton iteration are of this kind
+// or share a denominator; an FP64 division costs ~14 issue slots, divBy three.
+struct EosCell {
+	Eos const &eos;
+	double rho;
+	Recip Rrho, Rg, RkB, Rmu, RkBu;
+	QK_DEV EosCell(Eos const &e, double rho_)
+	    : eos(e), rho(rho_), Rrho(recipOf(rho_)), Rg(recipOf(e.gm1 * rho_)), RkB(recipOf(Eos::k_B)), Rmu(recipOf(e.mu * Eos::m_u)), RkBu(recipOf(e.kB_user))
+	{
+	}
+	QK_DEV auto tgasFromEint(double Eint) const -> double
+	{
+		if (eos.tmodel == 1) {
+			return eos.tgasFromEint(rho, Eint);
+		}
+		const double e = divBy(Eint, Rrho);
+		const double T = divBy(e * eos.mu * Eos::m_u * eos.gm1, RkB);
+		return divBy(T * Eos::k_B, RkBu);
+	}
+	QK_DEV auto eintTempDerivative(double T) const -> double
+	{
+		if (eos.tmodel == 1) {
+			return eos.alpha * ((T * T) * T);
+		}
+		const double p = divBy(rho * T * Eos::k_B, Rmu);
+		const double e = divBy(p, Rg);
+		const double dedT = e / T;
+		return divBy(dedT * rho * eos.kB_user, RkB);
+	}
+};
+
 QK_DEV auto eintFromEgas(double rho, double px, double py, double pz, double Etot) -> double
 {
 	const double p_sq = px * px + py * py + pz * pz;
@@ -316,6 +349,7 @@ QK_DEV void radSourceCell(Rad const &r, Eos const &eos, double U[10], double src
 	double Frad_t1[3] = {0., 0., 0.};
 	const double cscale = c / chat;
 	const Recip Rcc = recipOf(c * chat);
+	const EosCell ec(eos, rho);
 
 	if (gamma_ne_1) {
 		Egas0 = eintFromEgas(rho, x1GasMom0, x2GasMom0, x3GasMom0, Egastot0);
@@ -340,6 +374,7 @@ QK_DEV void radSourceCell(Rad const &r, Eos const &eos, double U[10], double src
 		if (gamma_ne_1) {
 			double tau0 = __builtin_nan("");
 			double tau = __builtin_nan("");
+			Recip Rtau{1.0, 1.0};
 			Egas_guess = Egas0;
 			Ekin0 = Egastot0 - Egas0;
 			const double betaSqr = (x1GasMom0 * x1GasMom0 + x2GasMom0 * x2GasMom0 + x3GasMom0 * x3GasMom0) / (rho * rho * c * c);
@@ -365,7 +400,7 @@ QK_DEV void radSourceCell(Rad const &r, Eos const &eos, double U[10], double src
 			const int maxIter = 100;
 			int n = 0;
 			for (; n < maxIter; ++n) {
-				T_gas = eos.tgasFromEint(rho, Egas_guess);
+				T_gas = ec.tgasFromEint(Egas_guess);
 				if constexpr (!DUST) {
 					T_d = T_gas;
 					fourPiBoverC = r.thermalRadiation(T_d);
@@ -394,12 +429,16 @@ QK_DEV void radSourceCell(Rad const &r, Eos const &eos, double U[10], double src
 					}
 					tau0 = dt * rho * kappaP * chat * lorentz_factor;
 					tau = tau0;
+					if (tau > 0.0) {
+						Rtau = recipOf(tau);
+					}
 					R = (fourPiBoverC - ((kappaPoverE == 1.0) ? Erad_guess : Erad_guess / kappaPoverE)) * tau0 + work; // (y / 1 is y exactly)
 					tau0 = smax(tau0, 1.0);
 				} else {
 					tau = dt * rho * kappaP * chat * lorentz_factor;
 					if (tau > 0.0) {
-						Erad_guess = kappaPoverE * (fourPiBoverC - (R - work) / tau);
+						Rtau = recipOf(tau); // (also divides kappaPoverE in the Jacobian below)
+						Erad_guess = kappaPoverE * (fourPiBoverC - divBy(R - work, Rtau));
 					}
 				}
 				const double cooling = 0.0;
@@ -416,18 +455,19 @@ QK_DEV void radSourceCell(Rad const &r, Eos const &eos, double U[10], double src
 				if ((fabs(F_G) < resid_tol * Etot0) && (cscale * F_D_abs < resid_tol * Etot0)) {
 					break;
 				}
-				const double c_v = eintTempDerivative(eos, rho, T_gas);
+				const double c_v = ec.eintTempDerivative(T_gas);
+				const Recip Rcv = recipOf(c_v);
 				const double d_fourpiboverc_d_t = DUST ? r.thermalRadiationTempDerivativeHook(T_d) : r.thermalRadiationTempDerivative(T_d);
 				double dEg_dT = kappaPoverE * d_fourpiboverc_d_t;
 				double J00, J01, J10, J11;
 				if constexpr (!DUST) {
-					J00 = 1.0 + cooling_derivative * dt / c_v;
+					J00 = 1.0 + divBy(cooling_derivative * dt, Rcv);
 					J01 = cscale;
-					J10 = 1.0 / c_v * dEg_dT - (1 / cscale) * cooling_derivative * dt;
+					J10 = divBy(1.0, Rcv) * dEg_dT - (1 / cscale) * cooling_derivative * dt;
 					if (tau <= 0.0) {
 						J11 = -__builtin_inf();
 					} else {
-						J11 = -1.0 * kappaPoverE / tau - 1.0;
+						J11 = divBy(-1.0 * kappaPoverE, Rtau) - 1.0;
 					}
 				} else { // :293-305
 					const double d_Td_d_T = 3. / 2. - T_d / (2. * T_gas);
@@ -435,23 +475,28 @@ QK_DEV void radSourceCell(Rad const &r, Eos const &eos, double U[10], double src
 					const double dTd_dRg = -1.0 / (coeff_n * sqrt(T_gas));
 					J00 = 1.0;
 					J01 = cscale;
-					J10 = 1.0 / c_v * dEg_dT;
+					J10 = divBy(1.0, Rcv) * dEg_dT;
 					if (tau <= 0.0) {
 						J11 = -1.0e100; // LARGE (:7)
 					} else {
-						J11 = kappaPoverE * d_fourpiboverc_d_t * dTd_dRg - kappaPoverE / tau - 1.0;
+						J11 = kappaPoverE * d_fourpiboverc_d_t * dTd_dRg - divBy(kappaPoverE, Rtau) - 1.0;
 					}
 				}
 				const double y0 = -F_G;
 				const double y1 = -1. * F_D;
 				const double det = J00 * J11 - J01 * J10;
-				// (plain divisions: det = -inf when tau <= 0, where IEEE inf arithmetic is part of the algorithm)
-				deltaEgas = (J11 * y0 - J01 * y1) / det;
-				deltaR = (J00 * y1 - J10 * y0) / det;
+				if (tau > 0.0) { // det is finite: both quotients through its reciprocal
+					const Recip Rdet = recipOf(det);
+					deltaEgas = divBy(J11 * y0 - J01 * y1, Rdet);
+					deltaR = divBy(J00 * y1 - J10 * y0, Rdet);
+				} else { // plain divisions: det = -inf (or -LARGE), where IEEE inf arithmetic is part of the algorithm
+					deltaEgas = (J11 * y0 - J01 * y1) / det;
+					deltaR = (J00 * y1 - J10 * y0) / det;
+				}
 				// enable_dE_constrain = true (radiation_system.hpp:44): the step is cut when deltaEgas / c_v > max(T_gas, T_rad).  The radiation
 				// temperature (a division and two square roots) can only matter when the quotient already exceeds T_gas: evaluated then, not
 				// in every iteration — the same decision and the same values.
-				const double dT_step = deltaEgas / c_v;
+				const double dT_step = divBy(deltaEgas, Rcv);
 				bool cut = false;
 				if (dT_step > T_gas) {
 					const double T_rad = sqrt(sqrt(Erad_guess / r.arad));

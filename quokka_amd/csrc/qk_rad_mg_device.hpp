@@ -348,6 +348,7 @@ QK_DEV void solveGasRadiationEnergyExchange(Rad const &r, RadMG<NG> const &m, Eo
 	const double chat = r.chat;
 	const double cscale = c / chat;
 	const double Etot0 = Egas0 + cscale * (sumOf<NG>(Erad0Vec) + sumOf<NG>(Src));
+	const EosCell ec(eos, rho); // (qk_rad_device.hpp: the EOS quotients with unchanging denominators through their reciprocals, same bits)
 
 	double T_gas = __builtin_nan(""), T_d = __builtin_nan("");
 	double Rvec[NG], tau[NG], work_local[NG], fourPiBoverC[NG], ratios[NG], frac[NG];
@@ -372,7 +373,7 @@ QK_DEV void solveGasRadiationEnergyExchange(Rad const &r, RadMG<NG> const &m, Eo
 	const int maxIter = 100;
 	int n = 0;
 	for (; n < maxIter; ++n) {
-		T_gas = eos.tgasFromEint(rho, Egas_guess);
+		T_gas = ec.tgasFromEint(Egas_guess);
 		T_d = T_gas;
 		planckEnergyFractions<NG>(m, T_d, frac);
 		thermalRadiationMG<NG>(r, frac, T_d, fourPiBoverC);
@@ -419,7 +420,7 @@ QK_DEV void solveGasRadiationEnergyExchange(Rad const &r, RadMG<NG> const &m, Eo
 
 		double d_fourpiboverc_d_t[NG];
 		thermalRadiationTempDerivativeMG<NG>(r, frac, T_d, d_fourpiboverc_d_t);
-		const double c_v = eintTempDerivative(eos, rho, T_gas);
+		const double c_v = ec.eintTempDerivative(T_gas);
 
 		// ComputeJacobianForGas
 		const double Egas_diff = Egas_guess - Egas0;
