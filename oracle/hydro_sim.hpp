@@ -673,6 +673,7 @@ struct HydroSim {
 			rad_iteration_counter[0] += counter[0];
 			rad_iteration_counter[1] += counter[1];
 			rad_iteration_counter[2] = std::max<long>(rad_iteration_counter[2], counter[2]);
+			rad_iteration_counter[3] += counter[3];
 			for (int n = 0; n < 3; ++n) {
 				rad_iteration_failure_counter[n] += failure[n];
 			}

@@ -277,12 +277,15 @@ void *orc_sim_create(orc_sim_config const *c)
 	} else if (c->problem == 18) {
 		setupMarshakVaytet(*sim, c->opacity_model > 0 ? c->opacity_model : static_cast<int>(PPL_opacity_full_spectrum));
 		sim->rad.rt.pow_mode = c->rad_pow_mode;
+	} else if (c->problem == 25) {
+		setupMarshakDust(*sim);
+		sim->rad.rt.pow_mode = c->rad_pow_mode;
 	} else if (c->problem == 23) {
 		setupBlast2D(*sim);
 	} else if (c->problem == 22) {
 		setupQuirk(*sim);
-	} else if (c->problem == 21) {
-		setupRadDust(*sim);
+	} else if (c->problem == 21 || c->problem == 24) {
+		setupRadDust(*sim, c->problem == 24);
 		sim->rad.rt.pow_mode = c->rad_pow_mode;
 	} else if (c->problem == 19 || c->problem == 20) {
 		setupPulseMG(*sim, c->problem == 19);

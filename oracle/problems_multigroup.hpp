@@ -515,7 +515,9 @@ struct RadDustConstants { // :19-34
 	static constexpr double erad_floor = 1.0e-20 * Erad0;
 };
 
-inline void setupRadDust(HydroSim &sim)
+// multigroup = true: src/problems/RadDustMG/test_rad_dust_MG.cpp (4 groups over 1e-3 .. 1e3 in units of k_B T, PPL_opacity_fixed_slope_spectrum,
+// the same exact solution and tolerance: the emission is linear in T_dust and grey, so the group sum obeys the single-group equations)
+inline void setupRadDust(HydroSim &sim, bool multigroup = false)
 {
 	using S = RadDustConstants;
 	sim.hydro.tr.eos.tr.gamma = 5. / 3.; // :42-46
@@ -533,6 +535,16 @@ inline void setupRadDust(HydroSim &sim)
 	sim.rad.rt.enable_dust_gas_thermal_coupling_model = true; // :56-60
 	sim.rad.rt.dustGasInteractionCoeff = 1.0e6;		    // the deck
 	sim.rad.rt.thermal_model = 1;				    // :86-97
+	if (multigroup) { // test_rad_dust_MG.cpp:52-81
+		setRadGroups(sim, {1.0e-3, 0.1, 1.0, 10.0, 1.0e3}, 1., PPL_opacity_fixed_slope_spectrum);
+		const int ng = sim.rad.rt.nGroups;
+		sim.rad.DefineOpacityExponentsAndLowerValues = [ng](double const *, double rho, double, double *expo, double *lower) {
+			for (int i = 0; i < ng + 1; ++i) {
+				expo[i] = 0.0;
+				lower[i] = S::chi0 / rho;
+			}
+		};
+	}
 	sim.rad.eos = sim.hydro.tr.eos;
 	sim.rad.ndim = sim.geom.ndim;
 	sim.rad.nstartHyperbolic_ = kNumHydroVars;
@@ -552,15 +564,113 @@ inline void setupRadDust(HydroSim &sim)
 	sim.define();
 	EOS const eos = sim.hydro.tr.eos;
 	const double Egas = eos.ComputeEintFromTgas(S::rho0, S::T0);
-	forEachValidCell(sim, [&](Array4<double> const &state_cc, int i, int j, int k) { // :99-122
-		state_cc(i, j, k, kNumHydroVars + 0) = S::erad_floor;
-		state_cc(i, j, k, kNumHydroVars + 1) = 0;
-		state_cc(i, j, k, kNumHydroVars + 2) = 0;
-		state_cc(i, j, k, kNumHydroVars + 3) = 0;
+	const int ngroups = sim.rad.rt.nGroups;
+	forEachValidCell(sim, [&](Array4<double> const &state_cc, int i, int j, int k) { // :99-122 (MG :106-129: the floor in EVERY group)
+		for (int g = 0; g < ngroups; ++g) {
+			state_cc(i, j, k, kNumHydroVars + 0 + kNumRadVars * g) = S::erad_floor;
+			state_cc(i, j, k, kNumHydroVars + 1 + kNumRadVars * g) = 0;
+			state_cc(i, j, k, kNumHydroVars + 2 + kNumRadVars * g) = 0;
+			state_cc(i, j, k, kNumHydroVars + 3 + kNumRadVars * g) = 0;
+		}
 		state_cc(i, j, k, energy_index) = Egas + 0.5 * S::rho0 * S::v0 * S::v0;
 		state_cc(i, j, k, density_index) = S::rho0;
 		state_cc(i, j, k, internalEnergy_index) = Egas;
 		state_cc(i, j, k, x1Momentum_index) = S::v0 * S::rho0;
+		state_cc(i, j, k, x2Momentum_index) = 0.;
+		state_cc(i, j, k, x3Momentum_index) = 0.;
+	});
+	sim.finishInitialConditions();
+}
+
+// ---------------------------------------------------------------- two-group Marshak wave with dust (src/problems/RadMarshakDust/test_radiation_marshak_dust.cpp,
+// deck tests/RadMarshakDust.in: 256 cells, dust_gas_interaction_coeff = 1e-2, kappa1 = 1e10 (IR), kappa2 = 1 (FUV), stop_time = 0.5)
+struct MarshakDustConstants { // :19-37
+	static constexpr double c = 1.0, chat = 1.0, rho0 = 1.0, CV = 1.0;
+	static constexpr double mu = 1.5 / CV;
+	static constexpr double initial_T = 1.0;
+	static constexpr double a_rad = 1.0e10;
+	static constexpr double erad_floor = 1.0e-10;
+	static constexpr double initial_Trad = 1.0e-5;
+	static constexpr double T_rad_L = 1.0e-2;
+	static constexpr double EradL = a_rad * T_rad_L * T_rad_L * T_rad_L * T_rad_L;
+	static constexpr double kappa1 = 1.0e10, kappa2 = 1.0; // the deck
+};
+
+inline void setupMarshakDust(HydroSim &sim)
+{
+	using S = MarshakDustConstants;
+	sim.hydro.tr.eos.tr.gamma = 5. / 3.; // :41-45
+	sim.hydro.tr.eos.tr.mean_molecular_weight = S::mu;
+	sim.hydro.tr.eos.tr.boltzmann_constant = 1.0;
+	sim.hydro.tr.reconstruct_eint = true;
+	sim.hydro.tr.nscalars = 0;
+	sim.is_radiation_enabled = true; // :47-57
+	sim.is_hydro_enabled = false;
+	sim.rad.rt.c_light = S::c; // :59-68
+	sim.rad.rt.c_hat = S::chat;
+	sim.rad.rt.radiation_constant = S::a_rad;
+	sim.rad.rt.Erad_floor = S::erad_floor;
+	sim.rad.rt.beta_order = 0;
+	sim.rad.rt.enable_dust_gas_thermal_coupling_model = true; // :70-74
+	sim.rad.rt.gas_dust_coupling_threshold = 1.0e-5;
+	sim.rad.rt.dustGasInteractionCoeff = 1e-2; // the deck
+	setRadGroups(sim, {1e-10, 100, 1e4}, 1.0, piecewise_constant_opacity);
+	sim.rad.eos = sim.hydro.tr.eos;
+	sim.rad.ndim = sim.geom.ndim;
+	sim.rad.nstartHyperbolic_ = kNumHydroVars;
+	const int ng = sim.rad.rt.nGroups;
+	sim.rad.DefineOpacityExponentsAndLowerValues = [ng](double const *, double, double, double *expo, double *lower) { // :86-102
+		for (int i = 0; i < ng + 1; ++i) {
+			expo[i] = 0.0;
+			lower[i] = (i == 0) ? S::kappa1 : S::kappa2;
+		}
+	};
+	// problem_main :186-212
+	sim.BCs_cc.assign(sim.ncomp_cc, BCRec{});
+	for (int n = 0; n < sim.ncomp_cc; ++n) {
+		sim.BCs_cc[n].lo[0] = ext_dir;
+		sim.BCs_cc[n].hi[0] = foextrap;
+	}
+	sim.radiationReconstructionOrder_ = 3;
+	sim.radiationCflNumber_ = 0.8;
+	sim.maxDt_ = 1;
+	sim.maxTimesteps_ = 5000;
+	sim.stopTime_ = 0.5; // the deck
+	// setCustomBoundaryConditions :126-176: the radiation state beyond the lower face streams in at c (F = c E in the FUV group); the gas state is
+	// written on EVERY cell outside the domain (the functor runs beyond the extrapolating upper face as well)
+	sim.customBC = [ng](int i, int j, int k, Array4<double> const &consVar, Box const &dom, double /*time*/) {
+		const double Erads[2] = {S::erad_floor, S::EradL};
+		if (i < dom.lo[0]) {
+			for (int g = 0; g < ng; ++g) {
+				consVar(i, j, k, kNumHydroVars + 0 + kNumRadVars * g) = Erads[g];
+				consVar(i, j, k, kNumHydroVars + 1 + kNumRadVars * g) = Erads[g] * S::c;
+				consVar(i, j, k, kNumHydroVars + 2 + kNumRadVars * g) = 0;
+				consVar(i, j, k, kNumHydroVars + 3 + kNumRadVars * g) = 0;
+			}
+		}
+		const double Egas = S::initial_T * S::CV;
+		consVar(i, j, k, energy_index) = Egas;
+		consVar(i, j, k, density_index) = S::rho0;
+		consVar(i, j, k, internalEnergy_index) = Egas;
+		consVar(i, j, k, x1Momentum_index) = 0.;
+		consVar(i, j, k, x2Momentum_index) = 0.;
+		consVar(i, j, k, x3Momentum_index) = 0.;
+	};
+	sim.define();
+	mg::MG const m(sim.rad);
+	const auto Erads0 = m.ComputeThermalRadiationMultiGroup(S::initial_Trad, m.boundaries());
+	forEachValidCell(sim, [&](Array4<double> const &state_cc, int i, int j, int k) { // :104-124
+		const double Egas0 = S::initial_T * S::CV;
+		for (int g = 0; g < m.nGroups_; ++g) {
+			state_cc(i, j, k, kNumHydroVars + 0 + kNumRadVars * g) = Erads0[g];
+			state_cc(i, j, k, kNumHydroVars + 1 + kNumRadVars * g) = 0;
+			state_cc(i, j, k, kNumHydroVars + 2 + kNumRadVars * g) = 0;
+			state_cc(i, j, k, kNumHydroVars + 3 + kNumRadVars * g) = 0;
+		}
+		state_cc(i, j, k, energy_index) = Egas0;
+		state_cc(i, j, k, density_index) = S::rho0;
+		state_cc(i, j, k, internalEnergy_index) = Egas0;
+		state_cc(i, j, k, x1Momentum_index) = 0.;
 		state_cc(i, j, k, x2Momentum_index) = 0.;
 		state_cc(i, j, k, x3Momentum_index) = 0.;
 	});

@@ -23,6 +23,8 @@ SOD, CONTACT, SEDOV, SHELL, RADSHOCK, STREAMING, SCALARS, HYDRO1D, COUPLING, SUO
 # multigroup radiation (oracle/problems_multigroup.hpp); PULSE_MG = the advecting 4-group run, PULSE_MG_GREY = the static grey run of the same file
 RADSHOCK_MG, RADTUBE, MARSHAK_VAYTET, PULSE_MG, PULSE_MG_GREY, RADDUST = 16, 17, 18, 19, 20, 21
 QUIRK = 22  # HydroQuirk: the 2-D (or 3-D) odd-even decoupling test
+RADDUST_MG = 24  # RadDustMG: the same relaxation with 4 photon groups (multigroup dust exchange)
+MARSHAK_DUST = 25  # RadMarshakDust: two groups (IR / FUV), dust model with the decoupled branch
 BLAST2D = 23  # HydroBlast2D: circular blast in a reflecting box, as a 2-D build or as a 3-D build uniform in z
 # OpacityModel (radiation_system.hpp:64-71)
 PIECEWISE_CONSTANT, PPL_FIXED_SLOPE, PPL_FULL_SPECTRUM = 1, 2, 3

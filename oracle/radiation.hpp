@@ -56,6 +56,7 @@ struct RadTraits {
 	// (QuokkaSimulation.hpp:127, deck key radiation.dust_gas_interaction_coeff)
 	bool enable_dust_gas_thermal_coupling_model = false;
 	double dustGasInteractionCoeff = 2.5e-34;
+	double gas_dust_coupling_threshold = 1.0e-6; // ISM_Traits (multigroup: below it gas and dust are treated as decoupled)
 	// the ComputeThermalRadiationSingleGroup / ...TempDerivativeSingleGroup hooks: 0 the default a T^4 / 4 a T^3 (:471-479, :499-503);
 	// 1: a T / a, the linearised emission of RadDust (src/problems/RadDust/test_rad_dust.cpp:86-97)
 	int thermal_model = 0;

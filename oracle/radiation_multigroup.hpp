@@ -9,8 +9,10 @@
 //                                                           ComputeRadQuantityExponents :1169-1250, ComputeGroupMeanOpacity :1252-1287,
 //                                                           PlanckFunction :1311-1326, ComputeDiffusionFluxMeanOpacity :1328-1352)
 //   reference src/radiation/planck_integral.hpp            (interpolate_planck_integral, integrate_planck_from_0_to_x)
-// Gas + radiation only: no dust / photoelectric / line-cooling / cosmic-ray models (ISM_Traits defaults; the `enable_dust_gas_thermal_coupling_model_`
-// branches of the reference are not restated).
+//   reference src/radiation/radiation_dust_system.hpp      (ComputeJacobianForGasAndDust :22-83, ...Decoupled :85-128, SolveGasDustRadiationEnergyExchange :228-576;
+//                                                           ComputeDustTemperatureBateKeto, radiation_system.hpp:1420-1483, nGroups > 1 branch)
+// Gas + radiation, and gas + dust + radiation (ISM_Traits::enable_dust_gas_thermal_coupling_model).  No photoelectric heating / line cooling /
+// cosmic-ray heating (their hooks default to zero and are written as zeros; SolveGasDustRadiationEnergyExchangeWithPE is not restated).
 //
 // The 1000-point table of the incomplete Planck integral is quokka_amd/data/planck_integral_table.inc, computed from the definition by
 // tools/make_planck_table.py (17 digits).  The reference lists the same function to 15 digits; the two agree to <= 5e-14 relative
@@ -242,6 +244,11 @@ struct MG {
 	// :483-497
 	[[nodiscard]] auto ComputeThermalRadiationMultiGroup(double temperature, VA const &bnd) const -> VA
 	{
+		if (rs.rt.thermal_model == 1) { // RadDustMG's specialisation (src/problems/RadDustMG/test_rad_dust_MG.cpp:83-93): a T, no floor
+			auto radEnergyFractions = ComputePlanckEnergyFractions(bnd, temperature);
+			const double power = rs.rt.radiation_constant * temperature;
+			return power * radEnergyFractions;
+		}
 		const double power = rs.rt.radiation_constant * rs.pow4(temperature);
 		const auto radEnergyFractions = ComputePlanckEnergyFractions(bnd, temperature);
 		auto Erad_g = power * radEnergyFractions;
@@ -257,6 +264,10 @@ struct MG {
 	[[nodiscard]] auto ComputeThermalRadiationTempDerivativeMultiGroup(double temperature, VA const &bnd) const -> VA
 	{
 		auto radEnergyFractions = ComputePlanckEnergyFractions(bnd, temperature);
+		if (rs.rt.thermal_model == 1) { // test_rad_dust_MG.cpp:95-104
+			const double d_power_dt = rs.rt.radiation_constant;
+			return d_power_dt * radEnergyFractions;
+		}
 		double d_power_dt = 4. * rs.rt.radiation_constant * rs.pow3(temperature);
 		return d_power_dt * radEnergyFractions;
 	}
@@ -614,6 +625,276 @@ struct MG {
 		return result;
 	}
 
+	// radiation_system.hpp:1420-1483, nGroups_ > 1
+	[[nodiscard]] auto ComputeDustTemperatureBateKeto(double const T_gas, double const T_d_init, double const rho, VA const &Erad, double N_d, double dt,
+							  double R_sum, int n_step, VA const &rad_boundaries) const -> double
+	{
+		if (n_step > 0) {
+			return T_gas - R_sum / (N_d * std::sqrt(T_gas));
+		}
+		VA rad_boundary_ratios(nGroups_);
+		if (rs.rt.opacity_model != piecewise_constant_opacity) {
+			for (int g = 0; g < nGroups_; ++g) {
+				rad_boundary_ratios[g] = rad_boundaries[g + 1] / rad_boundaries[g];
+			}
+		}
+		const double c_hat_ = rs.rt.c_hat;
+		VA const zero(nGroups_);
+		auto rhs = [&](double T_d) -> double {
+			const auto fourPiBoverC = ComputeThermalRadiationMultiGroup(T_d, rad_boundaries);
+			const auto opacity_terms = ComputeModelDependentKappaEAndKappaP(T_d, rho, rad_boundaries, rad_boundary_ratios, fourPiBoverC, Erad, 0, zero, zero);
+			return c_hat_ * dt * rho * sum(opacity_terms.kappaE * Erad - opacity_terms.kappaP * fourPiBoverC) + N_d * std::sqrt(T_gas) * (T_gas - T_d);
+		};
+		auto jac = [&](double T_d) -> double {
+			const auto fourPiBoverC = ComputeThermalRadiationMultiGroup(T_d, rad_boundaries);
+			const auto opacity_terms = ComputeModelDependentKappaEAndKappaP(T_d, rho, rad_boundaries, rad_boundary_ratios, fourPiBoverC, Erad, 0, zero, zero);
+			const auto d_fourpib_over_c_d_t = ComputeThermalRadiationTempDerivativeMultiGroup(T_d, rad_boundaries);
+			return -c_hat_ * dt * rho * sum(opacity_terms.kappaP * d_fourpib_over_c_d_t) - N_d * std::sqrt(T_gas);
+		};
+		const double Lambda_compare = N_d * std::sqrt(T_gas) * T_gas;
+		return RadSystem::BackwardEulerOneVariable(rhs, jac, T_d_init, Lambda_compare);
+	}
+
+	// radiation_dust_system.hpp:22-83 (DefineNetCoolingRate / ...TempDerivative / DefineCosmicRayHeatingRate: the defaults, zero)
+	[[nodiscard]] auto ComputeJacobianForGasAndDust(double T_gas, double T_d, double Egas_diff, VA const &Erad_diff, VA const &Rvec, VA const &Src, double coeff_n,
+							VA const &tau, double c_v, VA const &kappaPoverE, VA const &d_fourpiboverc_d_t, const double dt) const
+	    -> JacobianResult
+	{
+		JacobianResult result;
+		const double cscale = rs.rt.c_light / rs.rt.c_hat;
+		VA cooling(nGroups_), cooling_derivative(nGroups_);
+		cooling = cooling * dt;
+		cooling_derivative = cooling_derivative * dt;
+		const double CR_heating = 0.0 * dt;
+		result.F0 = Egas_diff + cscale * sum(Rvec) + sum(cooling) - CR_heating;
+		result.Fg = Erad_diff - (Rvec + Src);
+		result.Fg_abs_sum = 0.0;
+		for (int g = 0; g < nGroups_; ++g) {
+			if (tau[g] > 0.0) {
+				result.Fg_abs_sum += std::abs(result.Fg[g]);
+			} else {
+				result.Fg_abs_sum += std::abs(result.Fg[g] + Rvec[g]);
+			}
+		}
+		auto dEg_dT = kappaPoverE * d_fourpiboverc_d_t;
+		result.J00 = 1.0 + sum(cooling_derivative) / c_v;
+		result.J0g = VA(nGroups_);
+		result.J0g.fillin(cscale);
+		const double d_Td_d_T = 3. / 2. - T_d / (2. * T_gas);
+		dEg_dT = dEg_dT * d_Td_d_T;
+		const double dTd_dRg = -1.0 / (coeff_n * std::sqrt(T_gas));
+		const auto rg = kappaPoverE * d_fourpiboverc_d_t * dTd_dRg;
+		result.Jg0 = 1.0 / c_v * dEg_dT - (1 / cscale) * cooling_derivative - 1.0 / cscale * rg * result.J00;
+		result.Fg = result.Fg - 1.0 / cscale * rg * result.F0;
+		result.Jgg = VA(nGroups_);
+		for (int g = 0; g < nGroups_; ++g) {
+			if (tau[g] <= 0.0) {
+				result.Jgg[g] = -std::numeric_limits<double>::infinity();
+			} else {
+				result.Jgg[g] = -1.0 * kappaPoverE[g] / tau[g] - 1.0;
+			}
+		}
+		return result;
+	}
+
+	// radiation_dust_system.hpp:85-128
+	[[nodiscard]] auto ComputeJacobianForGasAndDustDecoupled(VA const &Erad_diff, VA const &Rvec, VA const &Src, VA const &tau, double lambda_gd_time_dt,
+								 VA const &kappaPoverE, VA const &d_fourpiboverc_d_t) const -> JacobianResult
+	{
+		JacobianResult result;
+		result.F0 = -lambda_gd_time_dt + sum(Rvec);
+		result.Fg = Erad_diff - (Rvec + Src);
+		result.Fg_abs_sum = 0.0;
+		for (int g = 0; g < nGroups_; ++g) {
+			if (tau[g] > 0.0) {
+				result.Fg_abs_sum += std::abs(result.Fg[g]);
+			}
+		}
+		auto dEg_dT = kappaPoverE * d_fourpiboverc_d_t;
+		result.J00 = 0.0;
+		result.J0g = VA(nGroups_);
+		result.J0g.fillin(1.0);
+		result.Jg0 = dEg_dT;
+		result.Jgg = VA(nGroups_);
+		for (int g = 0; g < nGroups_; ++g) {
+			if (tau[g] <= 0.0) {
+				result.Jgg[g] = -std::numeric_limits<double>::infinity();
+			} else {
+				result.Jgg[g] = -1.0 * kappaPoverE[g] / tau[g] - 1.0;
+			}
+		}
+		return result;
+	}
+
+	// radiation_dust_system.hpp:228-576.  p_iteration_counter[3] counts the decoupled solves
+	[[nodiscard]] auto SolveGasDustRadiationEnergyExchange(double const Egas0, VA const &Erad0Vec, double const rho, double const coeff_n, double const dt,
+							       int const n_outer_iter, VA const &work, VA const &vel_times_F, VA const &Src, VA const &rad_boundaries,
+							       int *p_iteration_counter, int *p_iteration_failure_counter) const -> NewtonIterationResult
+	{
+		const double c = rs.rt.c_light;
+		const double chat = rs.rt.c_hat;
+		const double cscale = c / chat;
+
+		int dust_model = 1;
+		double T_d0 = NAN;
+		double lambda_gd_times_dt = NAN;
+		const double T_gas0 = rs.eos.ComputeTgasFromEint(rho, Egas0);
+		T_d0 = ComputeDustTemperatureBateKeto(T_gas0, T_gas0, rho, Erad0Vec, coeff_n, dt, NAN, 0, rad_boundaries);
+		if (T_d0 < 0.0) {
+			p_iteration_failure_counter[1] += 1;
+		}
+		const double max_Gamma_gd = coeff_n * std::max(std::sqrt(T_gas0) * T_gas0, std::sqrt(T_d0) * T_d0);
+		if (cscale * max_Gamma_gd < rs.rt.gas_dust_coupling_threshold * Egas0) {
+			dust_model = 2;
+			lambda_gd_times_dt = coeff_n * std::sqrt(T_gas0) * (T_gas0 - T_d0);
+		}
+		double Etot0 = NAN;
+		if (dust_model == 1) {
+			Etot0 = Egas0 + cscale * (sum(Erad0Vec) + sum(Src));
+		} else {
+			const double fourPiBoverC = sum(ComputeThermalRadiationMultiGroup(T_d0, rad_boundaries));
+			Etot0 = std::abs(lambda_gd_times_dt) + fourPiBoverC + (sum(Erad0Vec) + sum(Src));
+		}
+
+		double T_gas = NAN;
+		double T_d = NAN;
+		double delta_x = NAN;
+		VA delta_R(nGroups_), Rvec(nGroups_), tau0(nGroups_), tau(nGroups_), work_local(nGroups_), fourPiBoverC(nGroups_);
+		VA rad_boundary_ratios(nGroups_);
+		KappaExpoLower kappa_expo_and_lower_value;
+		OpacityTerms opacity_terms{};
+		opacity_terms.alpha_E = VA(nGroups_);
+		opacity_terms.alpha_P = VA(nGroups_);
+		if (rs.rt.opacity_model != piecewise_constant_opacity) {
+			for (int g = 0; g < nGroups_; ++g) {
+				rad_boundary_ratios[g] = rad_boundaries[g + 1] / rad_boundaries[g];
+			}
+		}
+		double Egas_guess = Egas0;
+		auto EradVec_guess = Erad0Vec;
+		T_gas = rs.eos.ComputeTgasFromEint(rho, Egas_guess);
+
+		const double resid_tol = 1.0e-11;
+		const int maxIter = 100;
+		int n = 0;
+		for (; n < maxIter; ++n) {
+			if (n > 0) {
+				T_gas = rs.eos.ComputeTgasFromEint(rho, Egas_guess);
+			}
+			if (dust_model == 1) {
+				if (n == 0) {
+					T_d = T_d0;
+				} else {
+					T_d = T_gas - sum(Rvec) / (coeff_n * std::sqrt(T_gas));
+				}
+			} else {
+				if (n == 0) {
+					T_d = T_d0;
+				}
+			}
+			if (T_d < 0.0) {
+				p_iteration_failure_counter[1] += 1;
+			}
+
+			fourPiBoverC = ComputeThermalRadiationMultiGroup(T_d, rad_boundaries);
+			opacity_terms = ComputeModelDependentKappaEAndKappaP(T_d, rho, rad_boundaries, rad_boundary_ratios, fourPiBoverC, EradVec_guess, n,
+									     opacity_terms.alpha_E, opacity_terms.alpha_P);
+			if (n == 0) {
+				ComputeModelDependentKappaFAndDeltaTerms(T_d, rho, rad_boundaries, fourPiBoverC, opacity_terms);
+			}
+			if (n == 0) {
+				if ((rs.rt.beta_order == 1) && (include_work_term_in_source)) {
+					if (n_outer_iter == 0) {
+						for (int g = 0; g < nGroups_; ++g) {
+							if (rs.rt.opacity_model == piecewise_constant_opacity) {
+								work_local[g] = vel_times_F[g] * opacity_terms.kappaF[g] * chat / (c * c) * dt;
+							} else {
+								kappa_expo_and_lower_value = DefineOpacityExponentsAndLowerValues(rad_boundaries, rho, T_d);
+								work_local[g] = vel_times_F[g] * opacity_terms.kappaF[g] * chat / (c * c) * dt *
+										(1.0 + kappa_expo_and_lower_value.expo[g]);
+							}
+						}
+					} else {
+						work_local = work;
+					}
+				} else {
+					work_local.fillin(0.0);
+				}
+				tau0 = dt * rho * opacity_terms.kappaP * chat;
+				tau = tau0;
+				Rvec = (fourPiBoverC - EradVec_guess / opacity_terms.kappaPoverE) * tau0 + work_local;
+			} else {
+				tau = dt * rho * opacity_terms.kappaP * chat;
+				for (int g = 0; g < nGroups_; ++g) {
+					if (tau[g] > 0.0) {
+						EradVec_guess[g] = opacity_terms.kappaPoverE[g] * (fourPiBoverC[g] - (Rvec[g] - work_local[g]) / tau[g]);
+					}
+				}
+			}
+
+			const auto d_fourpiboverc_d_t = ComputeThermalRadiationTempDerivativeMultiGroup(T_d, rad_boundaries);
+			const double c_v = rs.eos.ComputeEintTempDerivative(rho, T_gas);
+			const auto Egas_diff = Egas_guess - Egas0;
+			const auto Erad_diff = EradVec_guess - Erad0Vec;
+
+			JacobianResult jacobian;
+			if (dust_model == 1) {
+				jacobian = ComputeJacobianForGasAndDust(T_gas, T_d, Egas_diff, Erad_diff, Rvec, Src, coeff_n, tau, c_v, opacity_terms.kappaPoverE,
+									d_fourpiboverc_d_t, dt);
+			} else {
+				jacobian = ComputeJacobianForGasAndDustDecoupled(Erad_diff, Rvec, Src, tau, lambda_gd_times_dt, opacity_terms.kappaPoverE, d_fourpiboverc_d_t);
+			}
+			if ((std::abs(jacobian.F0 / Etot0) < resid_tol) && (cscale * jacobian.Fg_abs_sum / Etot0 < resid_tol)) {
+				break;
+			}
+			SolveLinearEqs(jacobian, delta_x, delta_R);
+			if (dust_model == 2) {
+				T_d += delta_x;
+				Rvec = Rvec + delta_R;
+			} else {
+				const double T_rad = std::sqrt(std::sqrt(sum(EradVec_guess) / rs.rt.radiation_constant));
+				if (enable_dE_constrain && delta_x / c_v > std::max(T_gas, T_rad)) {
+					Egas_guess = rs.eos.ComputeEintFromTgas(rho, T_rad);
+				} else {
+					Egas_guess += delta_x;
+					Rvec = Rvec + delta_R;
+				}
+			}
+		}
+
+		VA cooling_tend(nGroups_); // DefineNetCoolingRate(T_gas, H_num_den) * dt: zero
+		if (dust_model == 2) {
+			const double CR_heating = 0.0 * dt;
+			const double compare = Egas_guess + cscale * lambda_gd_times_dt + sum(abs(cooling_tend)) + CR_heating;
+			auto rhs = [&](double Egas_) -> double { return Egas_ - Egas0 + cscale * lambda_gd_times_dt + 0.0 - CR_heating; };
+			auto jac = [&](double /*Egas_*/) -> double { return 1.0 + 0.0; };
+			Egas_guess = RadSystem::BackwardEulerOneVariable(rhs, jac, Egas0, compare);
+		}
+		EradVec_guess = EradVec_guess + (1 / cscale) * cooling_tend;
+
+		if (n >= maxIter) {
+			p_iteration_failure_counter[0] += 1;
+		}
+		p_iteration_counter[0] += 1;
+		p_iteration_counter[1] += n + 1;
+		p_iteration_counter[2] = std::max(p_iteration_counter[2], n + 1);
+		if (dust_model == 2) {
+			p_iteration_counter[3] += 1;
+		}
+
+		NewtonIterationResult result;
+		if (n > 0) {
+			ComputeModelDependentKappaFAndDeltaTerms(T_d, rho, rad_boundaries, fourPiBoverC, opacity_terms);
+		}
+		result.Egas = Egas_guess;
+		result.EradVec = EradVec_guess;
+		result.work = work_local;
+		result.T_gas = T_gas;
+		result.T_d = T_d;
+		result.opacity_terms = opacity_terms;
+		return result;
+	}
+
 	// source_terms_multi_group.hpp:360-520
 	[[nodiscard]] auto UpdateFlux(int const i, int const j, int const k, Array4<const double> const &consPrev, NewtonIterationResult &energy, double const dt,
 				      double const gas_update_factor, double const Ekin0) const -> FluxUpdateResult
@@ -787,6 +1068,13 @@ struct MG {
 					if (stage == 1) {
 						gas_update_factor = IMEX_a32;
 					}
+					// :612-617
+					const double H_num_den = rho / rs.eos.tr.mean_molecular_weight;
+					const double cscale = c / chat;
+					double coeff_n = NAN;
+					if (rs.rt.enable_dust_gas_thermal_coupling_model) {
+						coeff_n = dt * rs.rt.dustGasInteractionCoeff * H_num_den * H_num_den / cscale;
+					}
 
 					const int max_iter = 5;
 					int iter = 0;
@@ -808,8 +1096,15 @@ struct MG {
 								}
 							}
 
-							updated_energy = SolveGasRadiationEnergyExchange(Egas0, Erad0Vec, rho, dt, iter, work, vel_times_F, Src,
-													 radBoundaries_g_copy, p_iteration_counter, p_iteration_failure_counter);
+							if (!rs.rt.enable_dust_gas_thermal_coupling_model) { // :706-723
+								updated_energy = SolveGasRadiationEnergyExchange(Egas0, Erad0Vec, rho, dt, iter, work, vel_times_F, Src,
+														 radBoundaries_g_copy, p_iteration_counter,
+														 p_iteration_failure_counter);
+							} else {
+								updated_energy = SolveGasDustRadiationEnergyExchange(Egas0, Erad0Vec, rho, coeff_n, dt, iter, work, vel_times_F, Src,
+														     radBoundaries_g_copy, p_iteration_counter,
+														     p_iteration_failure_counter);
+							}
 
 							Egas_guess = updated_energy.Egas;
 							for (int g = 0; g < nGroups_; ++g) {

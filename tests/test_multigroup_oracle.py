@@ -8,7 +8,7 @@ import re
 import numpy as np
 import pytest
 
-from oracle.pyoracle import (MARSHAK_VAYTET, PIECEWISE_CONSTANT, PPL_FIXED_SLOPE, PPL_FULL_SPECTRUM, PULSE_MG, PULSE_MG_GREY, RADDUST,
+from oracle.pyoracle import (MARSHAK_DUST, MARSHAK_VAYTET, PIECEWISE_CONSTANT, PPL_FIXED_SLOPE, PPL_FULL_SPECTRUM, PULSE_MG, PULSE_MG_GREY, RADDUST, RADDUST_MG,
                              RADSHOCK_MG, RADTUBE)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -242,15 +242,15 @@ def test_marshak_wave_with_frequency_dependent_opacity_runs_clean(oracle):
     assert np.all(U[0] == 1.0e-3) and np.all(U[2:4] == 0.0) and np.all(U[1] >= 0.0) and U[1, 0] > 0.0
 
 
-def raddust_error(t, u):
-    """test_rad_dust.cpp:172-222: T_gas and T_rad (= E_rad / a_rad: the problem linearises the emission) of cell 0 after every step against
-    extern/data/dust/rad_dust_exact.csv (committed as data in tests/golden/), tolerance 0.0008"""
+def raddust_error(t, u, ngroups=1):
+    """test_rad_dust.cpp:172-222 (test_rad_dust_MG.cpp:186-240 sums the groups): T_gas and T_rad (= E_rad / a_rad: the problem linearises
+    the emission) of cell 0 after every step against extern/data/dust/rad_dust_exact.csv (committed as data in tests/golden/), tolerance 0.0008"""
     ex = np.loadtxt(os.path.join(HERE, "golden", "rad_dust_exact.csv"), delimiter=",", skiprows=1)
     m = ex[:, 0] > 0.0
     rho = u[:, 0]
     Eint = u[:, 4] - 0.5 * (u[:, 1] ** 2 + u[:, 2] ** 2 + u[:, 3] ** 2) / rho
     Tgas = Eint / (rho * 1.0 / (1.0 * (5.0 / 3.0 - 1.0)))  # c_v = rho k_B / (mu (gamma - 1)) with k_B = mu = 1
-    Trad = u[:, 6] / 1.0
+    Trad = sum(u[:, 6 + 4 * g] for g in range(ngroups)) / 1.0
     Tg, Tr = np.interp(t, ex[m, 0], ex[m, 1]), np.interp(t, ex[m, 0], ex[m, 2])
     return float((np.abs(Tgas - Tg).sum() + np.abs(Trad - Tr).sum()) / (np.abs(Tg).sum() + np.abs(Tr).sum()))
 
@@ -267,3 +267,43 @@ def test_gas_dust_radiation_relaxation_meets_the_reference_criterion(oracle):
     assert err < 0.0008, err
     # gas, dust and radiation end at the common temperature 0.6 (energy conservation: c_v T + a T = 1.5 + 0)
     assert abs(u[-1, 6] - 0.6) < 1e-5 and abs(u[-1, 5] / 1.5 - 0.6) < 1e-5
+
+
+def test_multigroup_gas_dust_radiation_relaxation_meets_the_reference_criterion(oracle):
+    """RadDustMG: the same relaxation with four photon groups through radiation_dust_system.hpp's coupled branch (gas, dust and every group in
+    one Newton-Raphson system)"""
+    s = oracle.sim(RADDUST_MG, 1, [8, 1, 1], [0, 0, 0], [1.0, 1, 1], [1, 1, 1], max_grid_size=[8, 1, 1])
+    t, u = s.run_record(2000, 0, (0, 0, 0))
+    assert len(t) == 1000 and abs(t[-1] - 1.0e-5) < 1e-18
+    c = s.rad_counters()
+    assert c["fail_coupling"] == c["fail_dust"] == c["fail_outer"] == 0 and c["decoupled"] == 0
+    err = raddust_error(t, u, ngroups=4)
+    assert err < 0.0008, err
+    Erad = sum(u[-1, 6 + 4 * g] for g in range(4))
+    assert abs(Erad - 0.6) < 1e-5 and abs(u[-1, 5] / 1.5 - 0.6) < 1e-5
+
+
+def marshak_dust_error(U, t):
+    """test_radiation_marshak_dust.cpp:225-268: gas temperature (stays 1), the IR group E_1 = E_L e^{-x} (t - x) and the FUV group E_2 = E_L e^{-x}
+    behind the front x < t, the floor ahead of it; the first cell is skipped; tolerance 0.01"""
+    n = U.shape[1]
+    x = (np.arange(n) + 0.5) / n
+    EL, floor = 1.0e10 * 1.0e-2 ** 4, 1.0e-10
+    e2 = np.where(x < t, EL * np.exp(-x), floor)
+    e1 = np.where(x < t, EL * np.exp(-x) * (t - x), floor)
+    T = U[5] / 1.0  # rho = C_V = 1
+    num = np.abs(T[1:] - 1.0).sum() + np.abs(U[6][1:] - e1[1:]).sum() + np.abs(U[10][1:] - e2[1:]).sum()
+    return float(num / (float(n - 1) + np.abs(e1[1:]).sum() + np.abs(e2[1:]).sum()))
+
+
+def test_two_group_marshak_wave_with_dust_meets_the_reference_criterion(oracle):
+    """RadMarshakDust: FUV streams in from the left and is absorbed by dust that re-emits in the (optically very thick) IR group; the weak
+    dust-gas coupling puts every solve on the DECOUPLED branch of radiation_dust_system.hpp (dust_model 2)"""
+    s = oracle.sim(MARSHAK_DUST, 1, [256, 1, 1], [0, 0, 0], [1.0, 1, 1], [0, 1, 1], max_grid_size=[256, 1, 1])
+    assert s.evolve() and abs(s.time - 0.5) < 1e-14
+    c = s.rad_counters()
+    assert c["fail_coupling"] == c["fail_dust"] == c["fail_outer"] == 0
+    assert c["decoupled"] == c["solves"] > 0
+    U = s.valid(0)[:, 0, 0, :]
+    err = marshak_dust_error(U, s.time)
+    assert err < 0.01, err
