@@ -243,7 +243,7 @@ typedef struct qk_rad_traits {
 	 * RadTube / RadhydroPulseMGconst (constant), RadMarshakVaytet the_model 0 / 1 / 2 / 10 (kappa0 (nu_g / nu_pivot)^-2, exponent -2). */
 	double mg_kappa_exponent[QK_MAX_GROUPS + 1], mg_kappa_lower[QK_MAX_GROUPS + 1];
 	double mg_kappa_rho_exponent, mg_kappa_T_ref, mg_kappa_T_exponent;
-	/* ISM_Traits<P>::enable_dust_gas_thermal_coupling_model (radiation_system.hpp:84-98; single group): the dust temperature of Bate & Keto
+	/* ISM_Traits<P>::enable_dust_gas_thermal_coupling_model (radiation_system.hpp:84-98): the dust temperature of Bate & Keto
 	 * between gas and radiation (ComputeDustTemperatureBateKeto, :1420-1483) and its Jacobian (source_terms_single_group.hpp:165-175, :293-305).
 	 * dust_gas_interaction_coeff = QuokkaSimulation::dustGasInteractionCoeff_ (QuokkaSimulation.hpp:127, default 2.5e-34 erg cm^3 s^-1 K^-3/2). */
 	int enable_dust_gas_thermal_coupling_model;
@@ -251,6 +251,9 @@ typedef struct qk_rad_traits {
 	/* the ComputeThermalRadiationSingleGroup / ...TempDerivativeSingleGroup hooks: 0 = a T^4 / 4 a T^3 (:471-479, :499-503); 1 = a T / a, the
 	 * linearised emission of RadDust (src/problems/RadDust/test_rad_dust.cpp:86-97; accepted together with the dust model only) */
 	int thermal_model;
+	/* ISM_Traits<P>::gas_dust_coupling_threshold (radiation_system.hpp:89, default 1e-6; multigroup dust model only): when
+	 * (c / c_hat) max(Gamma_gd) < threshold * E_gas the solve treats gas and dust as decoupled (radiation_dust_system.hpp:258-272) */
+	double gas_dust_coupling_threshold;
 } qk_rad_traits;
 /* State layout: Physics_Indices (reference src/physics_info.hpp:20-47): comps 0..5 hydro, 6 + 4 g .. 9 + 4 g = (E_r, F_x, F_y, F_z) of group g.
  * The operators below act on all groups (primVar / flux arrays carry 4 * ngroups components, group-major like the state). */

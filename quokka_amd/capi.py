@@ -66,7 +66,8 @@ class RadTraits(C.Structure):
                 ("mg_kappa_exponent", C.c_double * (MAX_GROUPS + 1)), ("mg_kappa_lower", C.c_double * (MAX_GROUPS + 1)),
                 ("mg_kappa_rho_exponent", C.c_double), ("mg_kappa_T_ref", C.c_double), ("mg_kappa_T_exponent", C.c_double),
                 # ISM_Traits::enable_dust_gas_thermal_coupling_model, QuokkaSimulation::dustGasInteractionCoeff_, thermal-emission hook
-                ("enable_dust_gas_thermal_coupling_model", C.c_int), ("dust_gas_interaction_coeff", C.c_double), ("thermal_model", C.c_int)]
+                ("enable_dust_gas_thermal_coupling_model", C.c_int), ("dust_gas_interaction_coeff", C.c_double), ("thermal_model", C.c_int),
+                ("gas_dust_coupling_threshold", C.c_double)]
 
     def set_groups(self, boundaries, energy_unit, opacity_model, kappa_exponent, kappa_lower, rho_exponent=0.0, T_ref=0.0, T_exponent=0.0):
         """RadSystem_Traits<P>::radBoundaries / energy_unit / opacity_model + the DefineOpacityExponentsAndLowerValues hook (closed set)"""

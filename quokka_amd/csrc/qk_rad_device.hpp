@@ -23,6 +23,7 @@ struct Rad {
 	int beta_order, pow_mode, opacity_model, eddington_model;
 	int ngroups; // Physics_Traits::nGroups
 	double dust_coeff; // QuokkaSimulation::dustGasInteractionCoeff_ (DUST instantiation of the source kernel only)
+	double dust_threshold; // ISM_Traits::gas_dust_coupling_threshold (multigroup dust model)
 	double mean_molecular_mass = 0.; // EOS_Traits::mean_molecular_weight as given (ComputeNumberDensityH; set by the source-term launcher)
 	int thermal_model; // 0: a T^4; 1: a T (RadDust's hooks; DUST instantiation only)
 	__host__ __device__ explicit Rad(qk_rad_traits const &t)
@@ -30,7 +31,8 @@ struct Rad {
 	      Erad_floor(t.Erad_floor / ((t.ngroups > 1) ? t.ngroups : 1)), // Erad_floor_ = RadSystem_Traits::Erad_floor / nGroups_ (radiation_system.hpp:211)
 	      kappaP0(t.kappaP), kappaE0(t.kappaE), kappaF0(t.kappaF), kT_ref(t.opacity_T_ref), kT_exp(t.opacity_T_exponent), kT_floor(t.opacity_pow_floor),
 	      beta_order(t.beta_order), pow_mode(t.pow_mode), opacity_model(t.opacity_model), eddington_model(t.eddington_model),
-	      ngroups((t.ngroups > 1) ? t.ngroups : 1), dust_coeff(t.dust_gas_interaction_coeff), thermal_model(t.thermal_model)
+	      ngroups((t.ngroups > 1) ? t.ngroups : 1), dust_coeff(t.dust_gas_interaction_coeff), dust_threshold(t.gas_dust_coupling_threshold),
+	      thermal_model(t.thermal_model)
 	{
 	}
 	// problem hooks ComputePlanckOpacity / ComputeEnergyMeanOpacity / ComputeFluxMeanOpacity (radiation_system.hpp:1141-1154):

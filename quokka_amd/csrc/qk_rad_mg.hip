@@ -66,9 +66,9 @@ auto mgCounterSlots(qk_ctx *ctx) -> int *
 	return ctx->counter_slots;
 }
 
-template <int NG>
+template <int NG, bool DUST>
 __global__ void __launch_bounds__(256, 1) k_rad_source_mg(const qk_box *boxes, Rad rad, RadMG<NG> mg, Eos eos, qk_array4 *cons_t, const qk_array4 *src_t, double dt, int stage,
-							   int *slots)
+							   int *slots, int *d_iteration_counter, int *d_failure_counter)
 {
 	const int b = blockIdx.y;
 	const qk_box bx = boxes[b];
@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(256, 1) k_rad_source_mg(const qk_box *boxes, R
 	const int rr = static_cast<int>(t - k * n01);
 	const int j = rr / len0;
 	const int i = rr - j * len0;
-	int ntot = 0, nmax = 0, nsolve = 0, fnewton = 0, fouter = 0;
+	int ntot = 0, nmax = 0, nsolve = 0, fnewton = 0, fouter = 0, ndecoupled = 0, fdust = 0;
 	if (valid) {
 		WA4 S(cons_t[b]);
 		RA4 Q(src_t[b]);
@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(256, 1) k_rad_source_mg(const qk_box *boxes, R
 		for (int g = 0; g < NG; ++g) {
 			srcval[g] = Q(bx.lo[0] + i, bx.lo[1] + j, bx.lo[2] + k, g);
 		}
-		radSourceCellMG<NG>(rad, mg, eos, U, srcval, dt, stage, ntot, nmax, nsolve, fnewton, fouter);
+		radSourceCellMG<NG, DUST>(rad, mg, eos, U, srcval, dt, stage, ntot, nmax, nsolve, fnewton, fouter, &ndecoupled, &fdust);
 #pragma unroll
 		for (int n = 1; n < NC; ++n) { // rho (comp 0) is never modified
 			S.p[c + S.ns * n] = U[n];
@@ -123,18 +123,40 @@ __global__ void __launch_bounds__(256, 1) k_rad_source_mg(const qk_box *boxes, R
 			atomicAdd(&slot[4], wfo);
 		}
 	}
+	if constexpr (DUST) { // p_iteration_counter[3] (decoupled solves) and p_iteration_failure_counter[1] (negative dust temperature), one atomic per wave
+		int wdec = ndecoupled, wfd = fdust;
+		for (int off = 32; off > 0; off >>= 1) {
+			wdec += __shfl_xor(wdec, off);
+			wfd += __shfl_xor(wfd, off);
+		}
+		if ((threadIdx.x & 63) == 0) {
+			if (wdec != 0) {
+				atomicAdd(&d_iteration_counter[3], wdec);
+			}
+			if (wfd != 0) {
+				atomicAdd(&d_failure_counter[1], wfd);
+			}
+		}
+	}
 }
 
 template <int NG>
 auto launchSourceMG(qk_level *lev, qk_stream s, const qk_rad_traits *rt, const qk_hydro_traits *t, qk_array4 *cons_t, const qk_array4 *src_t, double dt, int stage,
-		    int *slots) -> void
+		    int *slots, int *d_it, int *d_fail) -> void
 {
-	const Rad rad(*rt);
+	Rad rad(*rt);
+	rad.mean_molecular_mass = t->mean_molecular_weight;
 	const RadMG<NG> mg(*rt, t->boltzmann_constant);
 	const Eos eos(*t);
 	const CellLaunch L = cellLaunch(lev, 0, -1);
 	ProfScope ps(lev->ctx, static_cast<hipStream_t>(s), "rad_AddSourceTermsMultiGroup");
-	hipLaunchKernelGGL((k_rad_source_mg<NG>), L.grid, L.block, 0, static_cast<hipStream_t>(s), lev->d_boxes, rad, mg, eos, cons_t, src_t, dt, stage, slots);
+	if (rt->enable_dust_gas_thermal_coupling_model != 0) {
+		hipLaunchKernelGGL((k_rad_source_mg<NG, true>), L.grid, L.block, 0, static_cast<hipStream_t>(s), lev->d_boxes, rad, mg, eos, cons_t, src_t, dt, stage, slots,
+				   d_it, d_fail);
+	} else {
+		hipLaunchKernelGGL((k_rad_source_mg<NG, false>), L.grid, L.block, 0, static_cast<hipStream_t>(s), lev->d_boxes, rad, mg, eos, cons_t, src_t, dt, stage, slots,
+				   d_it, d_fail);
+	}
 }
 
 template <int NG> __global__ void k_mg_planck_fractions(Rad rad, RadMG<NG> mg, int n, const double *T, double *frac_out, double *E_out)
@@ -175,8 +197,11 @@ auto checkMG(qk_ctx *ctx, const qk_rad_traits *rt) -> int
 	if (rt->beta_order != 0 && rt->beta_order != 1) {
 		return setError(ctx, QK_ERR_UNSUPPORTED, "multigroup source term: beta_order must be 0 or 1 (source_terms_multi_group.hpp:526)");
 	}
-	if (rt->enable_dust_gas_thermal_coupling_model != 0 || rt->thermal_model != 0) {
-		return setError(ctx, QK_ERR_UNSUPPORTED, "multigroup source term: the dust-gas coupling model (radiation_dust_system.hpp) is not built");
+	if (rt->thermal_model != 0 && !(rt->thermal_model == 1 && rt->enable_dust_gas_thermal_coupling_model != 0)) {
+		return setError(ctx, QK_ERR_UNSUPPORTED, "multigroup source term: thermal_model must be 0, or 1 together with the dust model");
+	}
+	if (rt->enable_dust_gas_thermal_coupling_model != 0 && !(rt->dust_gas_interaction_coeff > 0.0 && rt->gas_dust_coupling_threshold >= 0.0)) {
+		return setError(ctx, QK_ERR_INVALID, "multigroup dust model: dust_gas_interaction_coeff must be positive, gas_dust_coupling_threshold not negative");
 	}
 	if (!(rt->energy_unit > 0.0)) {
 		return setError(ctx, QK_ERR_INVALID, "multigroup: energy_unit must be positive");
@@ -242,7 +267,7 @@ int qk_rad_AddSourceTermsMultiGroup(qk_level *lev, qk_stream s, const qk_rad_tra
 	int *slots = mgCounterSlots(lev->ctx);
 	QK_REQUIRE(lev->ctx, slots != nullptr, "AddSourceTermsMultiGroup: cannot allocate the counter slots");
 	if (lev->nboxes > 0) {
-		QK_MG_DISPATCH(rt->ngroups, (launchSourceMG<NG>(lev, s, rt, t, cons_t, src_t, dt, stage, slots)))
+		QK_MG_DISPATCH(rt->ngroups, (launchSourceMG<NG>(lev, s, rt, t, cons_t, src_t, dt, stage, slots, d_iteration_counter, d_failure_counter)))
 	}
 	hipLaunchKernelGGL(k_mg_counters_finish, dim3(1), dim3(NSLOT), 0, static_cast<hipStream_t>(s), slots, d_iteration_counter, d_failure_counter);
 	const hipError_t e = hipGetLastError();

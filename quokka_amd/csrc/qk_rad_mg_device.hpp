@@ -126,8 +126,19 @@ template <int NG> QK_DEV void planckEnergyFractions(RadMG<NG> const &m, double T
 }
 
 // :483-497 and :505-513 from one set of fractions (the reference evaluates the fractions twice at the same temperature)
-template <int NG> QK_DEV void thermalRadiationMG(Rad const &r, const double frac[NG], double T, double E[NG])
+// HOOKS (the dust instantiations): thermal_model 1 is RadDustMG's specialisation of the two functions (test_rad_dust_MG.cpp:83-104): a T, no floor
+template <int NG, bool HOOKS = false> QK_DEV void thermalRadiationMG(Rad const &r, const double frac[NG], double T, double E[NG])
 {
+	if constexpr (HOOKS) {
+		if (r.thermal_model == 1) {
+			const double power = r.arad * T;
+#pragma unroll
+			for (int g = 0; g < NG; ++g) {
+				E[g] = power * frac[g];
+			}
+			return;
+		}
+	}
 	const double power = r.arad * r.pow4(T);
 #pragma unroll
 	for (int g = 0; g < NG; ++g) {
@@ -137,9 +148,14 @@ template <int NG> QK_DEV void thermalRadiationMG(Rad const &r, const double frac
 		}
 	}
 }
-template <int NG> QK_DEV void thermalRadiationTempDerivativeMG(Rad const &r, const double frac[NG], double T, double dE[NG])
+template <int NG, bool HOOKS = false> QK_DEV void thermalRadiationTempDerivativeMG(Rad const &r, const double frac[NG], double T, double dE[NG])
 {
-	const double d_power_dt = 4. * r.arad * r.pow3(T);
+	double d_power_dt = 4. * r.arad * r.pow3(T);
+	if constexpr (HOOKS) {
+		if (r.thermal_model == 1) {
+			d_power_dt = r.arad;
+		}
+	}
 #pragma unroll
 	for (int g = 0; g < NG; ++g) {
 		dE[g] = d_power_dt * frac[g];
@@ -226,7 +242,6 @@ template <int NG> QK_DEV auto planckFunction(Rad const &r, RadMG<NG> const &m, d
 	} else {
 		planck_integral = Rad::pow3Faithful(x) / (exp(x) - 1.0); // std::pow(x, 3), faithfully rounded (qk_rad_device.hpp)
 	}
-	constexpr double PI = 3.14159265358979323846;
 	constexpr double PI4 = 97.40909103400242; // std::pow(M_PI, 4): the fourth power of the double nearest pi, correctly rounded
 	return coeff / (PI4 / 15.0) * (r.arad * Rad::pow4Faithful(T)) * planck_integral;
 }
@@ -501,10 +516,340 @@ QK_DEV void solveGasRadiationEnergyExchange(Rad const &r, RadMG<NG> const &m, Eo
 	}
 }
 
-// source_terms_multi_group.hpp:522-813 for one cell (UpdateFlux :360-520 in line).  U[6 + 4 NG] in place; counters as in the reference.
+// radiation_system.hpp:1420-1483 (nGroups_ > 1), n_step == 0: the dust temperature at which absorption, emission and the gas-dust exchange balance,
+// by BackwardEulerOneVariable (:1387-1418)
 template <int NG>
+QK_DEV auto dustTemperatureBateKetoMG(Rad const &r, RadMG<NG> const &m, double T_gas, double T_d_init, double rho, const double Erad[NG], double N_d, double dt,
+				      const double ratios[NG]) -> double
+{
+	const double Lambda_compare = N_d * sqrt(T_gas) * T_gas;
+	double x = T_d_init;
+	const double rel_tol = 1.0e-8;
+	const double rel_change_tol = 1.0e-6;
+	const int max_iter_td = 100;
+	int iter_Td = 0;
+	OpacityTermsMG<NG> ot;
+	double frac[NG], fourPiBoverC[NG], dB[NG];
+	for (; iter_Td < max_iter_td; ++iter_Td) {
+#pragma unroll
+		for (int g = 0; g < NG; ++g) {
+			ot.alpha_E[g] = 0.;
+			ot.alpha_P[g] = 0.;
+		}
+		planckEnergyFractions<NG>(m, x, frac);
+		thermalRadiationMG<NG, true>(r, frac, x, fourPiBoverC);
+		kappaEAndKappaP<NG>(m, x, rho, ratios, fourPiBoverC, Erad, 0, ot);
+		double s = 0;
+#pragma unroll
+		for (int g = 0; g < NG; ++g) {
+			s += ot.kappaE[g] * Erad[g] - ot.kappaP[g] * fourPiBoverC[g];
+		}
+		const double the_rhs = r.chat * dt * rho * s + N_d * sqrt(T_gas) * (T_gas - x);
+		if (fabs(the_rhs) < rel_tol * Lambda_compare) {
+			break;
+		}
+		thermalRadiationTempDerivativeMG<NG, true>(r, frac, x, dB);
+		double sj = 0;
+#pragma unroll
+		for (int g = 0; g < NG; ++g) {
+			sj += ot.kappaP[g] * dB[g];
+		}
+		const double jac = -r.chat * dt * rho * sj - N_d * sqrt(T_gas);
+		const double dT = -the_rhs / jac;
+		x += dT;
+		if (iter_Td > 0) {
+			if (fabs(dT) < rel_change_tol * fabs(x)) {
+				break;
+			}
+		}
+	}
+	if (iter_Td >= max_iter_td) {
+		x = -1.0;
+	}
+	return x;
+}
+
+// radiation_dust_system.hpp:228-576 (+ ComputeJacobianForGasAndDust :22-83, ...Decoupled :85-128, SolveLinearEqs in line; net cooling and cosmic-ray
+// heating are the defaults, zero).  dust_model 1: gas, dust and the groups in one system; dust_model 2 (weak gas-dust exchange): the dust temperature and
+// the groups are iterated with the exchange rate frozen, the gas energy follows from it afterwards.
+template <int NG>
+QK_DEV void solveGasDustRadiationEnergyExchange(Rad const &r, RadMG<NG> const &m, Eos const &eos, double Egas0, const double Erad0Vec[NG], double rho, double coeff_n,
+						double dt, int n_outer_iter, const double work[NG], const double vel_times_F[NG], const double Src[NG],
+						NewtonResultMG<NG> &res, int &n_newton_total, int &n_newton_max, int &n_solves, int &n_decoupled, int &fail_newton,
+						int &fail_dust)
+{
+	const double c = r.c;
+	const double chat = r.chat;
+	const double cscale = c / chat;
+	const EosCell ec(eos, rho);
+
+	double ratios[NG], frac[NG];
+#pragma unroll
+	for (int g = 0; g < NG; ++g) {
+		ratios[g] = m.bnd[g + 1] / m.bnd[g];
+	}
+	int dust_model = 1;
+	double lambda_gd_times_dt = __builtin_nan("");
+	const double T_gas0 = ec.tgasFromEint(Egas0);
+	const double T_d0 = dustTemperatureBateKetoMG<NG>(r, m, T_gas0, T_gas0, rho, Erad0Vec, coeff_n, dt, ratios);
+	if (T_d0 < 0.0) {
+		fail_dust += 1;
+	}
+	const double max_Gamma_gd = coeff_n * fmax(sqrt(T_gas0) * T_gas0, sqrt(T_d0) * T_d0);
+	if (cscale * max_Gamma_gd < r.dust_threshold * Egas0) {
+		dust_model = 2;
+		lambda_gd_times_dt = coeff_n * sqrt(T_gas0) * (T_gas0 - T_d0);
+	}
+	double Etot0;
+	if (dust_model == 1) {
+		Etot0 = Egas0 + cscale * (sumOf<NG>(Erad0Vec) + sumOf<NG>(Src));
+	} else {
+		double B0[NG];
+		planckEnergyFractions<NG>(m, T_d0, frac);
+		thermalRadiationMG<NG, true>(r, frac, T_d0, B0);
+		Etot0 = fabs(lambda_gd_times_dt) + sumOf<NG>(B0) + (sumOf<NG>(Erad0Vec) + sumOf<NG>(Src));
+	}
+
+	double T_gas = __builtin_nan(""), T_d = __builtin_nan("");
+	double Rvec[NG], tau[NG], work_local[NG], fourPiBoverC[NG];
+	OpacityTermsMG<NG> &ot = res.ot;
+#pragma unroll
+	for (int g = 0; g < NG; ++g) {
+		ot.alpha_E[g] = 0.;
+		ot.alpha_P[g] = 0.;
+		Rvec[g] = 0.;
+		tau[g] = 0.;
+		work_local[g] = 0.;
+	}
+	double Egas_guess = Egas0;
+	double EradVec_guess[NG];
+#pragma unroll
+	for (int g = 0; g < NG; ++g) {
+		EradVec_guess[g] = Erad0Vec[g];
+	}
+	T_gas = T_gas0;
+
+	const double resid_tol = 1.0e-11;
+	const int maxIter = 100;
+	int n = 0;
+	for (; n < maxIter; ++n) {
+		if (n > 0) {
+			T_gas = ec.tgasFromEint(Egas_guess);
+		}
+		if (dust_model == 1) {
+			if (n == 0) {
+				T_d = T_d0;
+			} else {
+				T_d = T_gas - sumOf<NG>(Rvec) / (coeff_n * sqrt(T_gas));
+			}
+		} else {
+			if (n == 0) {
+				T_d = T_d0;
+			}
+		}
+		if (T_d < 0.0) {
+			fail_dust += 1;
+		}
+		planckEnergyFractions<NG>(m, T_d, frac);
+		thermalRadiationMG<NG, true>(r, frac, T_d, fourPiBoverC);
+		kappaEAndKappaP<NG>(m, T_d, rho, ratios, fourPiBoverC, EradVec_guess, n, ot);
+		if (n == 0) {
+			kappaFAndDeltaTerms<NG>(r, m, T_d, rho, fourPiBoverC, ot);
+			if (r.beta_order == 1) { // include_work_term_in_source
+				if (n_outer_iter == 0) {
+#pragma unroll
+					for (int g = 0; g < NG; ++g) {
+						if (m.model == MG_PIECEWISE_CONSTANT) {
+							work_local[g] = vel_times_F[g] * ot.kappaF[g] * chat / (c * c) * dt;
+						} else {
+							work_local[g] = vel_times_F[g] * ot.kappaF[g] * chat / (c * c) * dt * (1.0 + m.kexp[g]);
+						}
+					}
+				} else {
+#pragma unroll
+					for (int g = 0; g < NG; ++g) {
+						work_local[g] = work[g];
+					}
+				}
+			} else {
+#pragma unroll
+				for (int g = 0; g < NG; ++g) {
+					work_local[g] = 0.0;
+				}
+			}
+#pragma unroll
+			for (int g = 0; g < NG; ++g) {
+				const double tau0 = dt * rho * ot.kappaP[g] * chat;
+				tau[g] = tau0;
+				Rvec[g] = (fourPiBoverC[g] - EradVec_guess[g] / ot.kappaPoverE[g]) * tau0 + work_local[g];
+			}
+		} else {
+#pragma unroll
+			for (int g = 0; g < NG; ++g) {
+				tau[g] = dt * rho * ot.kappaP[g] * chat;
+				if (tau[g] > 0.0) {
+					EradVec_guess[g] = ot.kappaPoverE[g] * (fourPiBoverC[g] - (Rvec[g] - work_local[g]) / tau[g]);
+				}
+			}
+		}
+
+		double d_fourpiboverc_d_t[NG];
+		thermalRadiationTempDerivativeMG<NG, true>(r, frac, T_d, d_fourpiboverc_d_t);
+		const double c_v = ec.eintTempDerivative(T_gas);
+		const double Egas_diff = Egas_guess - Egas0;
+
+		double F0, J00, J0g;
+		double Fg[NG], Jg0[NG], Jgg[NG];
+		double Fg_abs_sum = 0.0;
+		if (dust_model == 1) { // ComputeJacobianForGasAndDust (cooling = cooling_derivative = 0: their sums add +0.0, the products vanish)
+			const double cooling_sum = 0.0 * dt * NG * 0.0;
+			const double CR_heating = 0.0 * dt;
+			F0 = Egas_diff + cscale * sumOf<NG>(Rvec) + cooling_sum - CR_heating;
+#pragma unroll
+			for (int g = 0; g < NG; ++g) {
+				const double Erad_diff = EradVec_guess[g] - Erad0Vec[g];
+				Fg[g] = Erad_diff - (Rvec[g] + Src[g]);
+				if (tau[g] > 0.0) {
+					Fg_abs_sum += fabs(Fg[g]);
+				} else {
+					Fg_abs_sum += fabs(Fg[g] + Rvec[g]);
+				}
+			}
+			J00 = 1.0 + 0.0 / c_v;
+			J0g = cscale;
+			const double d_Td_d_T = 3. / 2. - T_d / (2. * T_gas);
+			const double dTd_dRg = -1.0 / (coeff_n * sqrt(T_gas));
+#pragma unroll
+			for (int g = 0; g < NG; ++g) {
+				const double dEg_dT = ot.kappaPoverE[g] * d_fourpiboverc_d_t[g] * d_Td_d_T;
+				const double rg = ot.kappaPoverE[g] * d_fourpiboverc_d_t[g] * dTd_dRg;
+				Jg0[g] = 1.0 / c_v * dEg_dT - (1 / cscale) * 0.0 - 1.0 / cscale * rg * J00;
+				Fg[g] = Fg[g] - 1.0 / cscale * rg * F0;
+			}
+		} else { // ComputeJacobianForGasAndDustDecoupled
+			F0 = -lambda_gd_times_dt + sumOf<NG>(Rvec);
+#pragma unroll
+			for (int g = 0; g < NG; ++g) {
+				const double Erad_diff = EradVec_guess[g] - Erad0Vec[g];
+				Fg[g] = Erad_diff - (Rvec[g] + Src[g]);
+				if (tau[g] > 0.0) {
+					Fg_abs_sum += fabs(Fg[g]);
+				}
+				Jg0[g] = ot.kappaPoverE[g] * d_fourpiboverc_d_t[g];
+			}
+			J00 = 0.0;
+			J0g = 1.0;
+		}
+#pragma unroll
+		for (int g = 0; g < NG; ++g) {
+			if (tau[g] <= 0.0) {
+				Jgg[g] = -__builtin_inf();
+			} else {
+				Jgg[g] = -1.0 * ot.kappaPoverE[g] / tau[g] - 1.0;
+			}
+		}
+
+		if ((fabs(F0 / Etot0) < resid_tol) && (cscale * Fg_abs_sum / Etot0 < resid_tol)) {
+			break;
+		}
+
+		// SolveLinearEqs
+		double s1 = 0, s2 = 0;
+		double ratio[NG];
+#pragma unroll
+		for (int g = 0; g < NG; ++g) {
+			ratio[g] = J0g / Jgg[g];
+		}
+#pragma unroll
+		for (int g = 0; g < NG; ++g) {
+			s1 += ratio[g] * Fg[g];
+		}
+#pragma unroll
+		for (int g = 0; g < NG; ++g) {
+			s2 += ratio[g] * Jg0[g];
+		}
+		const double delta_x = (s1 - F0) / (-s2 + J00);
+
+		if (dust_model == 2) {
+			T_d += delta_x;
+#pragma unroll
+			for (int g = 0; g < NG; ++g) {
+				const double delta_R = (-1.0 * Fg[g] - Jg0[g] * delta_x) / Jgg[g];
+				Rvec[g] = Rvec[g] + delta_R;
+			}
+		} else {
+			const double T_rad = sqrt(sqrt(sumOf<NG>(EradVec_guess) / r.arad));
+			if (delta_x / c_v > smax(T_gas, T_rad)) { // enable_dE_constrain
+				Egas_guess = eos.eintFromTgas(rho, T_rad);
+			} else {
+				Egas_guess += delta_x;
+#pragma unroll
+				for (int g = 0; g < NG; ++g) {
+					const double delta_R = (-1.0 * Fg[g] - Jg0[g] * delta_x) / Jgg[g];
+					Rvec[g] = Rvec[g] + delta_R;
+				}
+			}
+		}
+	}
+
+	if (dust_model == 2) { // :516-555: backward Euler on E - E0 + cscale lambda dt = 0 (the Jacobian is 1: one step lands on the root, the second confirms it)
+		const double CR_heating = 0.0 * dt;
+		const double compare = Egas_guess + cscale * lambda_gd_times_dt + 0.0 + CR_heating;
+		double x = Egas0;
+		const int max_iter_td = 100;
+		int it = 0;
+		for (; it < max_iter_td; ++it) {
+			const double the_rhs = x - Egas0 + cscale * lambda_gd_times_dt + 0.0 - CR_heating;
+			if (fabs(the_rhs) < 1.0e-8 * compare) {
+				break;
+			}
+			const double dT = -the_rhs / (1.0 + 0.0);
+			x += dT;
+			if (it > 0) {
+				if (fabs(dT) < 1.0e-6 * fabs(x)) {
+					break;
+				}
+			}
+		}
+		if (it >= max_iter_td) {
+			x = -1.0;
+		}
+		Egas_guess = x;
+	}
+#pragma unroll
+	for (int g = 0; g < NG; ++g) {
+		EradVec_guess[g] = EradVec_guess[g] + (1 / cscale) * 0.0; // cooling_tend
+	}
+
+	if (n >= maxIter) {
+		fail_newton += 1;
+	}
+	n_solves += 1;
+	n_newton_total += n + 1;
+	n_newton_max = max(n_newton_max, n + 1);
+	if (dust_model == 2) {
+		n_decoupled += 1;
+	}
+
+	if (n > 0) {
+		kappaFAndDeltaTerms<NG>(r, m, T_d, rho, fourPiBoverC, ot);
+	}
+	res.Egas = Egas_guess;
+	res.T_gas = T_gas;
+	res.T_d = T_d;
+#pragma unroll
+	for (int g = 0; g < NG; ++g) {
+		res.EradVec[g] = EradVec_guess[g];
+		res.work[g] = work_local[g];
+	}
+}
+
+// source_terms_multi_group.hpp:522-813 for one cell (UpdateFlux :360-520 in line).  U[6 + 4 NG] in place; counters as in the reference.
+// DUST: ISM_Traits::enable_dust_gas_thermal_coupling_model (its own instantiation, as in the single-group kernel)
+template <int NG, bool DUST = false>
 QK_DEV void radSourceCellMG(Rad const &r, RadMG<NG> const &m, Eos const &eos, double U[RAD0 + NRAD * NG], const double srcval[NG], double dt_radiation, int stage,
-			    int &n_newton_total, int &n_newton_max, int &n_solves, int &fail_newton, int &fail_outer)
+			    int &n_newton_total, int &n_newton_max, int &n_solves, int &fail_newton, int &fail_outer, int *n_decoupled = nullptr,
+			    int *fail_dust = nullptr)
 {
 	double dt = dt_radiation;
 	if (stage == 2) {
@@ -558,8 +903,15 @@ QK_DEV void radSourceCellMG(Rad const &r, RadMG<NG> const &m, Eos const &eos, do
 					vel_times_F[g] = (x1GasMom0 * U[RAD0 + NRAD * g + 1] + x2GasMom0 * U[RAD0 + NRAD * g + 2] + x3GasMom0 * U[RAD0 + NRAD * g + 3]);
 				}
 			}
-			solveGasRadiationEnergyExchange<NG>(r, m, eos, Egas0, Erad0Vec, rho, dt, iter, work, vel_times_F, Src, en, n_newton_total, n_newton_max, n_solves,
-							    fail_newton);
+			if constexpr (DUST) { // :612-617, :706-723
+				const double H_num_den = rho / r.mean_molecular_mass;
+				const double coeff_n = dt * r.dust_coeff * H_num_den * H_num_den / (c / chat);
+				solveGasDustRadiationEnergyExchange<NG>(r, m, eos, Egas0, Erad0Vec, rho, coeff_n, dt, iter, work, vel_times_F, Src, en, n_newton_total,
+									n_newton_max, n_solves, *n_decoupled, fail_newton, *fail_dust);
+			} else {
+				solveGasRadiationEnergyExchange<NG>(r, m, eos, Egas0, Erad0Vec, rho, dt, iter, work, vel_times_F, Src, en, n_newton_total, n_newton_max,
+								    n_solves, fail_newton);
+			}
 			Egas_guess = en.Egas;
 #pragma unroll
 			for (int g = 0; g < NG; ++g) {
@@ -609,7 +961,7 @@ QK_DEV void radSourceCellMG(Rad const &r, RadMG<NG> const &m, Eos const &eos, do
 		} else {
 			double frac[NG], fourPiBoverC[NG];
 			planckEnergyFractions<NG>(m, en.T_d, frac);
-			thermalRadiationMG<NG>(r, frac, en.T_d, fourPiBoverC);
+			thermalRadiationMG<NG, DUST>(r, frac, en.T_d, fourPiBoverC);
 #pragma unroll
 			for (int g = 0; g < NG; ++g) {
 				const double Frad_t0[3] = {U[RAD0 + NRAD * g + 1], U[RAD0 + NRAD * g + 2], U[RAD0 + NRAD * g + 3]};

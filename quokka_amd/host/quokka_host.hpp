@@ -702,8 +702,32 @@ template <typename problem_t> class RadSystem : public HyperbolicSystem<problem_
 			amrex::Abort("RadSystem: DefineOpacityExponentsAndLowerValues is not expressible in the C-ABI's closed set (exponents independent of "
 				     "rho and T; lower values k_g rho^a T^b with a = 0 or -1)");
 		}
-		if (enable_dust_gas_thermal_coupling_model_) {
-			amrex::Abort("RadSystem: the multigroup dust-gas coupling model (radiation_dust_system.hpp) is not built");
+		// the thermal-emission hooks (:483-497, :505-513): the defaults, or RadDustMG's linearised a T / a (test_rad_dust_MG.cpp:83-104)
+		{
+			bool quartic = true, linear = true;
+			for (double T : {0.7, 3.0e2, 4.0e6}) {
+				auto const e = ComputeThermalRadiationMultiGroup(T, radBoundaries_);
+				auto const d = ComputeThermalRadiationTempDerivativeMultiGroup(T, radBoundaries_);
+				auto const f = ComputePlanckEnergyFractions(radBoundaries_, T);
+				for (int g = 0; g < nGroups_; ++g) {
+					quartic = quartic && e[g] == std::max(radiation_constant_ * std::pow(T, 4) * f[g], Erad_floor_) &&
+						  d[g] == 4. * radiation_constant_ * std::pow(T, 3) * f[g];
+					linear = linear && e[g] == radiation_constant_ * T * f[g] && d[g] == radiation_constant_ * f[g];
+				}
+			}
+			if (!quartic && !linear) {
+				amrex::Abort("RadSystem: the ComputeThermalRadiationMultiGroup hooks are neither a T^4 nor RadDustMG's linearised a T");
+			}
+			rt.thermal_model = quartic ? 0 : 1;
+		}
+		if (enable_dust_gas_thermal_coupling_model_) { // radiation_dust_system.hpp; the coefficient is QuokkaSimulation::dustGasInteractionCoeff_
+			rt.enable_dust_gas_thermal_coupling_model = 1;
+			rt.gas_dust_coupling_threshold = ISM_Traits<problem_t>::gas_dust_coupling_threshold;
+			rt.dust_gas_interaction_coeff = 2.5e-34;
+			amrex::ParmParse rpp("radiation");
+			rpp.query("dust_gas_interaction_coeff", rt.dust_gas_interaction_coeff);
+		} else if (rt.thermal_model != 0) {
+			amrex::Abort("RadSystem: the linearised thermal-emission hook is carried by the C-ABI together with the dust model only");
 		}
 		return rt;
 	}

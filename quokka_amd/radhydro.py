@@ -61,7 +61,7 @@ class RadhydroSimulation(HydroSimulation):
         self._source_set = False
         self.dev_rad_counter = torch.zeros(4, dtype=torch.int32, device=ctx.device)
         self.dev_rad_failure = torch.zeros(3, dtype=torch.int32, device=ctx.device)
-        self.rad_counters = {"solves": 0, "newton_iterations": 0, "max_newton_iterations": 0}
+        self.rad_counters = {"solves": 0, "newton_iterations": 0, "max_newton_iterations": 0, "decoupled": 0}
 
     # ------------------------------------------------------------------ dt
     def computeTimestepAtLevel(self) -> float:
@@ -161,6 +161,7 @@ class RadhydroSimulation(HydroSimulation):
             self.rad_counters["solves"] += cnt[0]
             self.rad_counters["newton_iterations"] += cnt[1]
             self.rad_counters["max_newton_iterations"] = max(self.rad_counters["max_newton_iterations"], cnt[2])
+            self.rad_counters["decoupled"] += cnt[3]  # multigroup dust model: solves on the decoupled gas-dust branch
             if fail[1] > 0:
                 raise capi.QkError("Newton-Raphson iteration for dust temperature failed to converge or dust temperature is negative!")
             if fail[0] > 0:

@@ -280,25 +280,82 @@ class RadDustConstants:
     dust_gas_interaction_coeff = 1.0e6  # tests/RadDust.in
 
 
-def raddust_problem(ctx: Context, nx: int = 8) -> RadhydroSimulation:
+def raddust_problem(ctx: Context, nx: int = 8, multigroup: bool = False) -> RadhydroSimulation:
     """Gas, dust and radiation of a uniform medium relaxing to a common temperature: ISM_Traits::enable_dust_gas_thermal_coupling_model, emission
     linear in T_dust (the problem's ComputeThermalRadiationSingleGroup hook), kappa = chi0 / rho; constant dt = 1e-8 s, 1000 steps
-    (deck tests/RadDust.in: 8 cells, periodic, radiation.cfl = 8, dust_gas_interaction_coeff = 1e6)."""
+    (deck tests/RadDust.in: 8 cells, periodic, radiation.cfl = 8, dust_gas_interaction_coeff = 1e6).  multigroup: RadDustMG
+    (test_rad_dust_MG.cpp: 4 groups with edges 1e-3, 0.1, 1, 10, 1e3 in units of k_B T = 1, PPL_opacity_fixed_slope_spectrum, the floor in every group)."""
     S = RadDustConstants
+    ng = 4 if multigroup else 1
+    ncomp = RAD0 + 4 * ng
     geom = Geometry(1, [nx], [0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [1, 1, 1])
-    bcs = [([capi.BC_INT_DIR, 0, 0], [capi.BC_INT_DIR, 0, 0]) for _ in range(10)]
+    bcs = [([capi.BC_INT_DIR, 0, 0], [capi.BC_INT_DIR, 0, 0]) for _ in range(ncomp)]
     traits = capi.traits(5.0 / 3.0, True, 1, mean_molecular_weight=S.mu, boltzmann_constant=S.k_B)
     rt = capi.RadTraits(S.c, S.chat, S.a_rad, S.erad_floor, 1, 1, S.chi0, S.chi0, S.chi0, 0, 0)
     rt.enable_dust_gas_thermal_coupling_model, rt.dust_gas_interaction_coeff, rt.thermal_model = 1, S.dust_gas_interaction_coeff, 1
+    rt.gas_dust_coupling_threshold = 1.0e-6  # ISM_Traits default (radiation_system.hpp:89)
+    if multigroup:  # test_rad_dust_MG.cpp:52-81
+        rt.set_groups([1.0e-3, 0.1, 1.0, 10.0, 1.0e3], 1.0, PPL_FIXED_SLOPE, [0.0] * (ng + 1), [S.chi0] * (ng + 1), rho_exponent=-1.0)
     sim = RadhydroSimulation(ctx, geom, traits, rt, bcs, [nx, 1, 1], use_fused=False)
     sim.radiationReconstructionOrder_ = 3  # problem_main :145-170
     sim.stopTime_, sim.cflNumber_, sim.radiationCflNumber_, sim.maxTimesteps_ = S.max_time, 0.8, 8.0, 1000000
     sim.initDt_ = sim.maxDt_ = S.delta_time
     Egas = eint_from_tgas(S.rho0, S.T0, S.mu, kB=S.k_B)
 
-    def ic(i, j, k):  # setInitialConditionsOnGrid :99-122
-        U = rad_state(10, i.shape)
-        U[0], U[4], U[5], U[RAD0] = S.rho0, Egas, Egas, S.erad_floor
+    def ic(i, j, k):  # setInitialConditionsOnGrid :99-122 (MG :106-129)
+        U = rad_state(ncomp, i.shape)
+        U[0], U[4], U[5] = S.rho0, Egas, Egas
+        for g in range(ng):
+            U[RAD0 + 4 * g] = S.erad_floor
+        return U
+
+    sim.set_initial_conditions(ic)
+    return sim
+
+
+# ---------------------------------------------------------------------- RadMarshakDust
+class MarshakDustConstants:
+    """test_radiation_marshak_dust.cpp:19-37 and the deck tests/RadMarshakDust.in"""
+    c = chat = 1.0
+    rho0, CV, initial_T = 1.0, 1.0, 1.0
+    mu = 1.5 / CV
+    a_rad, erad_floor, initial_Trad, T_rad_L = 1.0e10, 1.0e-10, 1.0e-5, 1.0e-2
+    EradL = a_rad * T_rad_L * T_rad_L * T_rad_L * T_rad_L
+    kappa1, kappa2 = 1.0e10, 1.0
+    dust_gas_interaction_coeff, gas_dust_coupling_threshold = 1.0e-2, 1.0e-5
+    boundaries = [1e-10, 100.0, 1e4]
+
+
+def marshak_dust_problem(ctx: Context, nx: int = 256, pow_mode: int = 0) -> RadhydroSimulation:
+    """FUV radiation (group 2, kappa = 1) streaming in through the lower face, absorbed by dust that re-emits it in the IR (group 1, kappa = 1e10):
+    radiation only, beta_order 0, the weak gas-dust exchange puts every cell on the decoupled branch of radiation_dust_system.hpp.  The gas
+    state is written on every cell outside the domain, the radiation state only beyond the lower face (setCustomBoundaryConditions :126-176):
+    beyond the extrapolating upper face the radiation components follow the first cell inside."""
+    S = MarshakDustConstants
+    ng = 2
+    ncomp = RAD0 + 4 * ng
+    geom = Geometry(1, [nx], [0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [0, 1, 1])
+    bcs = [([capi.BC_EXT_DIR, 0, 0], [capi.BC_FOEXTRAP, 0, 0]) for _ in range(ncomp)]
+    traits = capi.traits(5.0 / 3.0, True, 1, mean_molecular_weight=S.mu, boltzmann_constant=1.0)
+    rt = capi.RadTraits(S.c, S.chat, S.a_rad, S.erad_floor, 0, 0, 0.0, 0.0, 0.0, pow_mode, 0)
+    rt.enable_dust_gas_thermal_coupling_model, rt.dust_gas_interaction_coeff = 1, S.dust_gas_interaction_coeff
+    rt.gas_dust_coupling_threshold = S.gas_dust_coupling_threshold
+    rt.set_groups(S.boundaries, 1.0, PIECEWISE_CONSTANT, [0.0] * (ng + 1), [S.kappa1, S.kappa2, S.kappa2])  # :86-102
+    Egas = S.initial_T * S.CV
+    gas = [S.rho0, 0.0, 0.0, 0.0, Egas, Egas]
+    left = gas + [S.erad_floor, S.erad_floor * S.c, 0.0, 0.0, S.EradL, S.EradL * S.c, 0.0, 0.0]
+    right = {"values": gas + [0.0] * (4 * ng), "interior": list(range(RAD0, ncomp))}
+    sim = RadhydroSimulation(ctx, geom, traits, rt, bcs, [nx, 1, 1], use_fused=False, dirichlet={(0, 0): left, (0, 1): right})
+    sim.is_hydro_enabled = False
+    sim.radiationReconstructionOrder_ = 3  # problem_main :186-212
+    sim.stopTime_, sim.maxDt_, sim.radiationCflNumber_, sim.maxTimesteps_ = 0.5, 1.0, 0.8, 5000
+    _, Eg = planck_fractions(ctx, rt, 1.0, [S.initial_Trad])
+
+    def ic(i, j, k):  # setInitialConditionsOnGrid :104-124
+        U = rad_state(ncomp, i.shape)
+        U[0], U[4], U[5] = S.rho0, Egas, Egas
+        for g in range(ng):
+            U[RAD0 + 4 * g] = Eg[0][g]
         return U
 
     sim.set_initial_conditions(ic)

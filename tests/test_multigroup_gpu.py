@@ -10,9 +10,9 @@ import numpy as np
 import pytest
 import torch
 
-from oracle.pyoracle import (MARSHAK_VAYTET, PIECEWISE_CONSTANT, PPL_FIXED_SLOPE, PPL_FULL_SPECTRUM, PULSE_MG, PULSE_MG_GREY, RADDUST,
+from oracle.pyoracle import (MARSHAK_DUST, MARSHAK_VAYTET, PIECEWISE_CONSTANT, PPL_FIXED_SLOPE, PPL_FULL_SPECTRUM, PULSE_MG, PULSE_MG_GREY, RADDUST, RADDUST_MG,
                              RADSHOCK_MG, RADTUBE)
-from test_multigroup_oracle import A_RAD, H_PLANCK, K_B, pulse_mg_error, raddust_error, radshock_mg_error, tube_table
+from test_multigroup_oracle import A_RAD, H_PLANCK, K_B, marshak_dust_error, pulse_mg_error, raddust_error, radshock_mg_error, tube_table
 
 pytestmark = pytest.mark.gpu
 
@@ -244,3 +244,53 @@ def test_dust_model_steps_match_oracle_and_criterion(ctx, oracle):
     assert co["fail_coupling"] == co["fail_dust"] == co["fail_outer"] == 0
     err = raddust_error(np.array(ts), np.array(us))
     assert err < 0.0008, err
+
+
+def test_multigroup_dust_model_coupled_branch_matches_oracle_and_criterion(ctx, oracle):
+    """RadDustMG: the DUST instantiation of the multigroup exchange kernel on the coupled branch of radiation_dust_system.hpp (gas, dust and the
+    four groups in one Newton-Raphson system; the Planck fractions call exp / the table: tolerance, not bits)"""
+    from quokka_amd.radhydro_multigroup import raddust_problem
+    so = oracle.sim(RADDUST_MG, 1, [8, 1, 1], [0, 0, 0], [1.0, 1, 1], [1, 1, 1], max_grid_size=[8, 1, 1])
+    sg = raddust_problem(ctx, multigroup=True)
+    assert np.array_equal(so.valid(0), sg.state_new_cc_.valid(0).cpu().numpy())
+    ts, us = [], []
+    for it in range(1000):
+        assert so.step() and sg.step(), it
+        assert so.dt == sg.dt_
+        ts.append(sg.tNew_)
+        us.append(sg.state_new_cc_.valid(0).cpu().numpy()[:, 0, 0, 0])
+        if it in (0, 9, 99, 999):
+            compare(so, sg, tol=1e-11, mom_scale=flux_scales(so.valid(0), 1.0e8, cs=1.0, fscale=1e-6))
+    co = so.rad_counters()
+    assert sg.rad_counters["solves"] == co["solves"] and abs(sg.rad_counters["newton_iterations"] - co["newton_iterations"]) <= 0.01 * co["newton_iterations"]  # (8 identical cells: a cell one iteration apart near the residual tolerance counts 8 times)
+    assert sg.rad_counters["decoupled"] == co["decoupled"] == 0
+    err = raddust_error(np.array(ts), np.array(us), ngroups=4)
+    assert err < 0.0008, err
+
+
+def test_multigroup_dust_model_decoupled_branch_matches_oracle_and_criterion(ctx, oracle):
+    """RadMarshakDust: two groups, every solve on the decoupled branch (dust temperature and the groups iterated with the gas-dust exchange rate
+    frozen, the gas energy updated afterwards); the partial boundary functor (gas state everywhere, radiation state beyond the lower face only)
+    through qk_dirichlet_face::interior_mask"""
+    from quokka_amd.radhydro_multigroup import marshak_dust_problem
+    so = oracle.sim(MARSHAK_DUST, 1, [256, 1, 1], [0, 0, 0], [1.0, 1, 1], [0, 1, 1], max_grid_size=[256, 1, 1])
+    sg = marshak_dust_problem(ctx, 256)
+    assert np.allclose(so.valid(0), sg.state_new_cc_.valid(0).cpu().numpy(), rtol=1e-13, atol=0.0)
+    seed(so, sg)
+    for it in range(60):
+        assert so.step() and sg.step(), it
+        assert so.dt == sg.dt_
+    compare(so, sg, tol=1e-11, mom_scale=flux_scales(so.valid(0), 1.0, cs=1.0, fscale=1e-6))
+    # ghost cells: gas state and (lower face) the streaming radiation state from the functor, the radiation state of the upper face from inside
+    sg.fillBoundaryConditions(sg.state_new_cc_)
+    so.fill_ghosts(0, so.time)
+    Go, Gg = so.state(0, 0)[:, 0, 0, :], sg.state_new_cc_.fabs[0].cpu().numpy()[:, 0, 0, :]
+    assert np.array_equal(Go[:6, :4], Gg[:6, :4]) and np.array_equal(Go[:6, -4:], Gg[:6, -4:]) and np.array_equal(Go[6:, :4], Gg[6:, :4])
+    assert np.all(Gg[6:, -4:] == Gg[6:, -5:-4]) and np.allclose(Go[6:, -4:], Gg[6:, -4:], rtol=1e-9, atol=1e-30)
+    assert so.evolve() and sg.evolve() and so.istep == sg.istep
+    compare(so, sg, tol=1e-10, mom_scale=flux_scales(so.valid(0), 1.0, cs=1.0, fscale=1e-6))
+    co = so.rad_counters()
+    assert sg.rad_counters["solves"] == co["solves"] == co["decoupled"]
+    assert sg.rad_counters["decoupled"] == co["decoupled"]
+    err = marshak_dust_error(sg.state_new_cc_.valid(0).cpu().numpy()[:, 0, 0, :], sg.tNew_)
+    assert err < 0.01, err

@@ -120,6 +120,23 @@ def test_unmodified_dust_problem_meets_the_reference_criterion(tmp_path):
     assert rc == 0, out[-2500:]
 
 
+def test_unmodified_multigroup_dust_problem_meets_the_reference_criterion(tmp_path):
+    """RadDustMG, unchanged (it includes radiation/radiation_dust_system.hpp): four groups, the problem's own ComputeThermalRadiationMultiGroup hooks
+    (detected as the linearised emission), ISM_Traits::gas_dust_coupling_threshold; the coupled branch of the multigroup dust solve.
+    Exit status 0 = within 0.0008 of extern/data/dust/rad_dust_exact.csv."""
+    cwd = extern_tree(tmp_path, {"data/dust/rad_dust_exact.csv": "rad_dust_exact.csv"})
+    rc, out = run([exe("ref_RadDustMG"), os.path.join(HOST, "decks", "RadDust.in")], cwd)
+    assert rc == 0, out[-2500:]
+
+
+def test_unmodified_two_group_marshak_wave_with_dust_meets_the_reference_criterion(tmp_path):
+    """RadMarshakDust, unchanged: two groups with kappa1 / kappa2 read from the deck by the problem itself (amrex::ParmParse in problem_main, stored in
+    managed globals the opacity hook reads), a boundary functor that writes the gas state on every outside cell and the streaming radiation
+    state beyond the lower face only; every solve on the decoupled branch.  Exit status 0 = within 0.01 of the analytic solution."""
+    rc, out = run([exe("ref_RadMarshakDust"), os.path.join(HOST, "decks", "RadMarshakDust.in")], str(tmp_path))
+    assert rc == 0, out[-2500:]
+
+
 def test_unmodified_multigroup_pulse_meets_the_reference_criterion(tmp_path):
     """RadhydroPulseMGconst, unchanged: two simulations in one executable (grey at rest, 4 groups advected), compared with each other; 0.006"""
     rc, out = run([exe("ref_RadhydroPulseMGconst"), os.path.join(HOST, "decks", "RadhydroPulse.in")], str(tmp_path))
