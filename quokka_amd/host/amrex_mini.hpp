@@ -205,7 +205,20 @@ class Box
 	{
 		return i >= lo[0] && i <= hi[0] && j >= lo[1] && j <= hi[1] && k >= lo[2] && k <= hi[2];
 	}
+	[[nodiscard]] QK_HD auto contains(IntVect const &c) const -> bool { return contains(c[0], c[1], c[2]); }
+	[[nodiscard]] QK_HD auto ok() const -> bool { return hi[0] >= lo[0] && hi[1] >= lo[1] && hi[2] >= lo[2]; }
+	// intersection (empty: ok() is false)
+	[[nodiscard]] QK_HD auto operator&(Box const &o) const -> Box
+	{
+		Box r;
+		for (int d = 0; d < 3; ++d) {
+			r.lo[d] = lo[d] > o.lo[d] ? lo[d] : o.lo[d];
+			r.hi[d] = hi[d] < o.hi[d] ? hi[d] : o.hi[d];
+		}
+		return r;
+	}
 };
+inline auto makeSingleCellBox(int i, int j, int k) -> Box { return Box(IntVect(i, j, k), IntVect(i, j, k)); }
 inline auto grow(Box b, int ng) -> Box
 {
 	for (int d = 0; d < AMREX_SPACEDIM; ++d) {
@@ -493,6 +506,31 @@ class ParmParse
 		}                                                                                                                                    \
 	} while (0)
 
+#if defined(QK_DEVICE_LAMBDAS)
+// amrex::launch(box, f(Box const &tbx)): the reference uses it on single-cell boxes; one thread gets the whole box
+template <typename F> __global__ void qk_launch_kernel(Box bx, F f) { f(bx); }
+template <typename F> void launch(Box const &bx, F const &f) { hipLaunchKernelGGL(qk_launch_kernel<F>, dim3(1), dim3(1), 0, nullptr, bx, f); }
+// amrex::AsyncArray<T>: a device copy of a host array that lives as long as the object
+template <typename T> class AsyncArray
+{
+      public:
+	AsyncArray(T const *h, std::size_t n) : n_(n)
+	{
+		QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_), sizeof(T) * (n > 0 ? n : 1)));
+		QK_HOST_HIP(hipMemcpy(d_, h, sizeof(T) * n, hipMemcpyHostToDevice));
+	}
+	AsyncArray(AsyncArray const &) = delete;
+	auto operator=(AsyncArray const &) -> AsyncArray & = delete;
+	~AsyncArray() { (void)hipFree(d_); }
+	[[nodiscard]] auto data() const -> T * { return d_; }
+	void copyToHost(T *h, std::size_t n) const { QK_HOST_HIP(hipMemcpy(h, d_, sizeof(T) * n, hipMemcpyDeviceToHost)); }
+
+      private:
+	T *d_ = nullptr;
+	std::size_t n_ = 0;
+};
+#endif
+
 struct DistributionMapping {
 	DistributionMapping() = default;
 	template <typename BA> explicit DistributionMapping(BA const & /*ba*/) {}
@@ -694,6 +732,7 @@ template <typename T> class FabArrayT
 	[[nodiscard]] auto DistributionMap() const -> int { return 0; }
 	// device pointer to the descriptor table (MultiFab::arrays())
 	[[nodiscard]] auto arrays() const -> Array4<T> * { return d_table_; }
+	[[nodiscard]] auto const_arrays() const -> Array4<T const> const * { return reinterpret_cast<Array4<T const> const *>(d_table_); }
 	void setVal(T v)
 	{
 		std::vector<T> h(static_cast<size_t>(total_), v);
@@ -707,6 +746,8 @@ template <typename T> class FabArrayT
 		return h;
 	}
 	void copyFromHost(int b, std::vector<T> const &h) { QK_HOST_HIP(hipMemcpy(d_data_ + offsets_[b], h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice)); }
+	// FabArray::ParallelCopy(src): valid cells of `src` into the cells of this array they cover (all components; boxes of this rank)
+	void ParallelCopy(FabArrayT const &src);
 	static void Copy(FabArrayT &dst, FabArrayT const &src)
 	{
 		QK_HOST_HIP(hipMemcpy(dst.d_data_, src.d_data_, sizeof(T) * src.total_, hipMemcpyDeviceToDevice));
@@ -776,6 +817,39 @@ class MFIter
 	std::vector<Box> const *boxes_ = nullptr;
 	int ng_ = 0;
 };
+#if defined(QK_DEVICE_LAMBDAS)
+// amrex::ParallelFor(mf, f(box_no, i, j, k)) / (mf, nghost, f): every valid (grown) cell of every local box
+template <typename T, typename F> void ParallelFor(FabArrayT<T> const &mf, IntVect const &ng, F const &f)
+{
+	for (int b = 0; b < mf.size(); ++b) {
+		Box bx = mf.validbox(b);
+		for (int d = 0; d < AMREX_SPACEDIM; ++d) {
+			bx.lo[d] -= ng[d];
+			bx.hi[d] += ng[d];
+		}
+		ParallelFor(bx, [=] __device__(int i, int j, int k) { f(b, i, j, k); });
+	}
+}
+template <typename T, typename F> void ParallelFor(FabArrayT<T> const &mf, F const &f) { ParallelFor(mf, IntVect(0, 0, 0), f); }
+template <typename T> void FabArrayT<T>::ParallelCopy(FabArrayT<T> const &src)
+{
+	if (qkhost::Comm::get().size > 1) {
+		Abort("FabArray::ParallelCopy: not carried across ranks by the host mirror");
+	}
+	const int nc = ncomp_ < src.ncomp_ ? ncomp_ : src.ncomp_;
+	for (int d = 0; d < size(); ++d) {
+		for (int s = 0; s < src.size(); ++s) {
+			Box const is = fabboxes_[d] & src.boxes_[s];
+			if (!is.ok()) {
+				continue;
+			}
+			auto const to = array(d);
+			auto const from = src.const_array(s);
+			ParallelFor(is, nc, [=] __device__(int i, int j, int k, int n) { to(i, j, k, n) = from(i, j, k, n); });
+		}
+	}
+}
+#endif
 using MultiFab = FabArrayT<Real>;
 using iMultiFab = FabArrayT<int>;
 // amrex::TagBoxArray: one char per cell (amrex::TagBox::CLEAR = 0, BUF = 1, SET = 2)

@@ -51,6 +51,11 @@ template <typename problem_t> class AmrDriver
 
 	[[nodiscard]] auto finestLevel() const -> int { return static_cast<int>(finer_.size()); }
 	auto level(int l) -> Sim & { return l == 0 ? base_ : *finer_[l - 1]->sim; }
+	// amrex::average_down of an auxiliary cell-centred field living on the grids of levels crseLev + 1 and crseLev
+	void averageDownField(int crseLev, amrex::MultiFab const &fine, amrex::MultiFab &crse)
+	{
+		qkhost::check(qk_average_down(finer_[crseLev]->avgdown, nullptr, qkhost::tab(fine), qkhost::tab(crse), 0, crse.nComp()), "qk_average_down");
+	}
 
 	// AmrCore::InitFromScratch + AverageDown (reference src/simulation.hpp:1656-1702)
 	void setInitialConditions()
@@ -646,6 +651,48 @@ template <typename problem_t> void QuokkaSimulation<problem_t>::WriteCheckpointF
 	QK_HOST_HIP(hipDeviceSynchronize());
 	quokka::io::WriteCheckpointFile(name, h, state);
 }
+
+#if defined(QK_DEVICE_LAMBDAS)
+template <typename problem_t>
+template <typename F>
+auto QuokkaSimulation<problem_t>::computeAxisAlignedProfile(const int axis, F const &user_f) -> amrex::Gpu::HostVector<amrex::Real>
+{
+	int const finest = amr_ ? amr_->finestLevel() : 0;
+	std::vector<amrex::MultiFab> q(finest + 1);
+	for (int lev = 0; lev <= finest; ++lev) {
+		auto &S = (lev == 0) ? *this : amr_->level(lev);
+		q[lev].define(S.grids_, 1, 0);
+		for (int b = 0; b < q[lev].size(); ++b) {
+			auto const state = S.state_new_cc_[0].const_array(b);
+			auto const result = q[lev].array(b);
+			amrex::ParallelFor(q[lev].validbox(b), [=] AMREX_GPU_DEVICE(int i, int j, int k) { result(i, j, k) = user_f(i, j, k, state); });
+		}
+	}
+	for (int crse = finest - 1; crse >= 0; --crse) {
+		amr_->averageDownField(crse, q[crse + 1], q[crse]);
+	}
+	// amrex::sumToLine over the level-0 boxes of this rank, then over ranks (a diagnostic: host reduction)
+	amrex::Box const domain = this->geom[0].Domain();
+	amrex::Gpu::HostVector<amrex::Real> profile(static_cast<size_t>(domain.length(axis)), 0.0);
+	QK_HOST_HIP(hipDeviceSynchronize());
+	for (int b = 0; b < q[0].size(); ++b) {
+		auto h = q[0].copyToHost(b);
+		amrex::Array4<amrex::Real> a(h.data(), q[0].fabbox(b), 1);
+		amrex::HostFor(q[0].validbox(b), [&](int i, int j, int k) {
+			int const idx[3] = {i, j, k};
+			profile[static_cast<size_t>(idx[axis] - domain.lo[axis])] += a(i, j, k);
+		});
+	}
+	for (double &bin : profile) {
+		bin = qkhost::Comm::get().allReduceSum(bin);
+	}
+	amrex::Long const numCells = domain.numPts() / domain.length(axis);
+	for (double &bin : profile) {
+		bin /= static_cast<amrex::Real>(numCells);
+	}
+	return profile;
+}
+#endif
 
 template <typename problem_t> void QuokkaSimulation<problem_t>::evolve()
 {

@@ -1688,6 +1688,11 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	void preCalculateInitialConditions() override;
 	void computeAfterEvolve(amrex::Vector<amrex::Real> &initSumCons) override;
 	void computeAfterTimestep(); // reference src/simulation.hpp:228, :890 (default: nothing)
+#if defined(QK_DEVICE_LAMBDAS)
+	// the mean of user_f(i, j, k, state) over the planes normal to `axis` (QuokkaSimulation.hpp:843-881): evaluated on every level, averaged
+	// down, summed on level 0.  Defined in quokka_amr.hpp.
+	template <typename F> auto computeAxisAlignedProfile(int axis, F const &user_f) -> amrex::Gpu::HostVector<amrex::Real>;
+#endif
 	// Strang-split source terms a problem may add (QuokkaSimulation.hpp:235): called with dt/2 on the old state before the hydro update and on
 	// the new state after it (:1048, :1318)
 	void addStrangSplitSources(amrex::MultiFab &state, int lev, amrex::Real time, amrex::Real dt_lev);

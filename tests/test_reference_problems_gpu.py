@@ -174,3 +174,46 @@ def test_unmodified_nscbc_vortex_runs_in_2d(tmp_path):
     P = (1.4 - 1.0) * (U[4] - 0.5 * (px * px + py * py) / rho)
     assert np.abs(P / 1.01325e6 - 1.0).max() < 0.01
     assert np.abs(py / rho).max() > 50.0 and np.abs(px / rho - 1.0e4).max() < 1.0e3
+
+
+def test_unmodified_quirk_problem_meets_the_reference_criterion_and_matches_the_python_driver(tmp_path, ctx):
+    """HydroQuirk, unchanged, as the 2-D build the reference's CMake enables it for: its computeAfterTimestep locates the shock's box with
+    MFIter / Box::contains(IntVect) and evaluates the entropy jump with amrex::launch on a single-cell box into an amrex::AsyncArray; exit
+    status 0 = max |delta s| <= 0.06 (no carbuncle).  The final state equals the Python driver's (which tests/test_hydro_2d.py ties to the
+    oracle bit for bit), 772 steps later."""
+    from quokka_amd.simulation import quirk_problem
+    dump = str(tmp_path / "q.bin")
+    rc, out = run([exe("ref_HydroQuirk"), os.path.join(HOST, "decks", "quirk.in"), f"qk.dump_state={dump}"], str(tmp_path))
+    assert rc == 0 and "looks stable against the Carbuncle" in out, out[-2500:]
+    U = np.fromfile(dump, dtype=np.float64).reshape(6, 16, 128)
+    sg = quirk_problem(ctx, 2)
+    assert sg.evolve() and sg.istep == 772
+    assert np.array_equal(U, sg.state_new_cc_.valid(0).cpu().numpy()[:, 0])
+
+
+def test_unmodified_implosion_problem_keeps_its_exact_diagonal_symmetry(tmp_path):
+    """HydroRichtmeyerMeshkov, unchanged (2-D): after EVERY step the problem gathers the state with FabArray::ParallelCopy and aborts unless
+    U(i, j) == U(j, i) exactly (momenta swapped) — which holds only if the y sweep of the 2-D build performs the x sweep's arithmetic on
+    swapped indices (ArrayView_2d's index swap).  Four boxes, reflecting walls, run to the problem's own t = 2.5."""
+    rc, out = run([exe("ref_HydroRichtmeyerMeshkov"), os.path.join(HOST, "decks", "implosion2d.in"), "amr.n_cell=32 32 8", "amr.max_grid_size=16", "amr.blocking_factor=16"],
+                  str(tmp_path))
+    assert rc == 0 and "Finished." in out and "not symmetric" not in out, out[-2500:]
+
+
+def test_unmodified_rayleigh_taylor_problem_runs_with_its_strang_split_gravity(tmp_path):
+    """RayleighTaylor3D, unchanged: gravity through addStrangSplitSources written as amrex::ParallelFor(MultiFab, f(box, i, j, k)) over
+    MultiFab::arrays(), random initial velocities (ParallelForRNG), a passive scalar, reflecting walls in z, the mixing profile through
+    QuokkaSimulation::computeAxisAlignedProfile.  No pass criterion in the file (returns 0); here: mass and scalar are conserved, the
+    hydrostatic state holds (|v_z| stays at the size of the seeded perturbation) and the profile is the step 0 -> 1 of the scalar."""
+    dump = str(tmp_path / "rt.bin")
+    rc, out = run([exe("ref_RayleighTaylor3D"), os.path.join(HOST, "decks", "RT3D.in"), "amr.n_cell=64 64 64", "amr.max_grid_size=32", "max_timesteps=60",
+                   f"qk.dump_state={dump}"], str(tmp_path))
+    assert rc == 0 and "Performance figure-of-merit" in out, out[-2500:]
+    U = np.fromfile(dump, dtype=np.float64).reshape(8, 7, 32, 32, 32)
+    assert np.isfinite(U).all()
+    n = 64 ** 3
+    assert abs(U[:, 0].sum() / n - 1.5) < 1e-12 and abs(U[:, 6].sum() / n - 0.5) < 1e-12
+    assert np.abs(U[:, 3] / U[:, 0]).max() < 0.02 and np.abs(U[:, 1]).max() < 0.02
+    prof = np.loadtxt(os.path.join(str(tmp_path), "profile.txt"))
+    # (the scalar is a conserved density: it is compressed with the heavy gas settling in the field, a few 1e-3)
+    assert prof.shape == (64,) and np.all(prof[:28] < 1e-6) and np.all(np.abs(prof[36:] - 1.0) < 0.01)
