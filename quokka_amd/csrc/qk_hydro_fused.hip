@@ -71,6 +71,7 @@ struct SweepArgs {
 	double K_visc;
 	int use_dual_energy;
 	bool reconstruct_eint;
+	bool same_old; // U_old is U_in (stage 1): the final sweep keeps the conserved state of its last three march positions in LDS instead of re-reading it
 	bool store_rk2; // stage 2: write flux_rk2 = 0.5 F1 + 0.5 F2 to rk2Flux (never over F1: tile-boundary faces of the x sweep are evaluated twice)
 	qk_array4 *rk2Flux;
 	int nseg; // segments along the march axis (marching sweeps; see k_pre_march)
@@ -637,6 +638,14 @@ template <int DIR, int ORDER, int STAGE, bool LAST, int NS> __global__ void __la
 	double q[5][NV];
 	double apPrev[NV], Fprev[NV];
 	double vfPrev = 0., dVprev = 0., dWprev = 0.;
+	// The cell a step completes (march position p - 3) was loaded as the newest cell three steps earlier: when the old state IS the input
+	// state (stage 1) its conserved values wait in a per-lane ring of three LDS slots (no barriers: a lane only touches its own slots).
+	constexpr bool RING = LAST && (STAGE == 1);
+	__shared__ double s_ring[RING ? 3 : 1][RING ? NV : 1][RING ? 256 : 1];
+	const int tid = threadIdx.y * 64 + threadIdx.x;
+	const bool ring = RING && a.same_old;
+	int slot = 0;
+	double Uo[NV];
 #pragma unroll
 	for (int n = 0; n < NV; ++n) {
 		apPrev[n] = 0.;
@@ -667,6 +676,16 @@ template <int DIR, int ORDER, int STAGE, bool LAST, int NS> __global__ void __la
 			for (int n = NVAR; n < NV; ++n) { // passive scalars are reconstructed as they are stored
 				q[4][n] = Uin.p[u + Uin.ns * n];
 			}
+			if constexpr (RING) {
+				if (ring) {
+#pragma unroll
+					for (int n = 0; n < NV; ++n) {
+						Uo[n] = s_ring[slot][n][tid];
+						s_ring[slot][n][tid] = (n < NVAR) ? Uc[n] : q[4][n];
+					}
+					slot = (slot == 2) ? 0 : slot + 1;
+				}
+			}
 		}
 		if (step < 4) {
 			continue;
@@ -684,14 +703,13 @@ template <int DIR, int ORDER, int STAGE, bool LAST, int NS> __global__ void __la
 		fidx[0] = i;
 		fidx[OT] = ot;
 		fidx[DIR] = lo + (step - 5);
-		double Uo[NV];
 		if (step >= 6) {
 			const int64_t cu = cc - ms;
 #pragma unroll
 			for (int n = 0; n < NV + 1; ++n) {
 				rhs_in[n] = S[(S_RHS + n) * T + cu];
 			}
-			if (LAST) { // the old state of the cell this step completes
+			if (LAST && !ring) { // the old state of the cell this step completes
 				int uc[3];
 				uc[0] = i;
 				uc[OT] = ot;
@@ -877,6 +895,7 @@ template <int ORDER, int STAGE, int NS> void launchSweeps(qk_level *lev, hipStre
 	// Z (+ epilogue)
 	{
 		SweepArgs az = a;
+		az.same_old = (args->U_in == args->U_old);
 		az.halfFlux = args->halfFlux[2];
 		az.halfVel = args->halfVel[2];
 		az.rk2Flux = args->fluxRk2[2];
