@@ -284,6 +284,12 @@ void *orc_sim_create(orc_sim_config const *c)
 		setupBlast2D(*sim);
 	} else if (c->problem == 22) {
 		setupQuirk(*sim);
+	} else if (c->problem == 26 || c->problem == 27) { // h1d[1]: radiation.dust_gas_interaction_coeff of the deck
+		setupLineCooling(*sim, c->problem == 27, c->h1d[1]);
+		sim->rad.rt.pow_mode = c->rad_pow_mode;
+	} else if (c->problem == 28) {
+		setupMarshakDustPE(*sim, c->h1d[1]);
+		sim->rad.rt.pow_mode = c->rad_pow_mode;
 	} else if (c->problem == 21 || c->problem == 24) {
 		setupRadDust(*sim, c->problem == 24);
 		sim->rad.rt.pow_mode = c->rad_pow_mode;

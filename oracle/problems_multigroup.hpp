@@ -677,6 +677,191 @@ inline void setupMarshakDust(HydroSim &sim)
 	sim.finishInitialConditions();
 }
 
+// ---------------------------------------------------------------- line cooling, cosmic-ray and photoelectric heating of a uniform medium
+// (src/problems/RadLineCooling/test_rad_line_cooling.cpp: one group; src/problems/RadLineCoolingMG/test_rad_line_cooling_MG.cpp: four groups with
+// photoelectric heating by the last one; decks tests/RadLineCooling.in (dust_gas_interaction_coeff = 1e-20) and RadLineCoolingCoupled.in (1e20))
+struct LineCoolingConstants { // test_rad_line_cooling.cpp:19-36, ..._MG.cpp:19-42
+	static constexpr double cooling_rate = 0.1, CR_heating_rate = 0.03, PE_rate = 0.02;
+	static constexpr double c = 1.0, chat = c, v0 = 0.0, kappa0 = 0.0;
+	static constexpr double T0 = 1.0, rho0 = 1.0, a_rad = 1.0, mu = 1.5, C_V = 1.0, k_B = 1.0, nu_unit = 1.0;
+	static constexpr double erad_floor = a_rad * 1e-20;
+	static constexpr double Erad_FUV = a_rad * T0 * T0 * T0 * T0;
+	static constexpr double max_time = 10.0, the_dt = 1.0e-2;
+	static constexpr int line_index = 0;
+};
+
+inline void setupLineCooling(HydroSim &sim, bool multigroup, double dust_coeff)
+{
+	using S = LineCoolingConstants;
+	sim.hydro.tr.eos.tr.gamma = 5. / 3.;
+	sim.hydro.tr.eos.tr.mean_molecular_weight = S::mu;
+	sim.hydro.tr.eos.tr.boltzmann_constant = S::k_B;
+	sim.hydro.tr.reconstruct_eint = true;
+	sim.hydro.tr.nscalars = 0;
+	sim.is_radiation_enabled = true;
+	sim.rad.rt.c_light = S::c;
+	sim.rad.rt.c_hat = S::chat;
+	sim.rad.rt.radiation_constant = S::a_rad;
+	sim.rad.rt.Erad_floor = S::erad_floor;
+	sim.rad.rt.beta_order = 0;
+	sim.rad.rt.enable_dust_gas_thermal_coupling_model = true; // ISM_Traits
+	sim.rad.rt.gas_dust_coupling_threshold = 1.0e-6;
+	sim.rad.rt.dustGasInteractionCoeff = dust_coeff; // the deck
+	int ng = 1;
+	if (multigroup) { // ..._MG.cpp:22-23, :64-83
+		setRadGroups(sim, {1.00000000e-03, 1.77827941e-02, 3.16227766e-01, 5.62341325e+00, 1.00000000e+02}, S::nu_unit, piecewise_constant_opacity);
+		sim.rad.rt.enable_photoelectric_heating = true;
+		ng = sim.rad.rt.nGroups;
+		sim.rad.DefinePhotoelectricHeatingE1Derivative = [](double, double) { return S::PE_rate / S::Erad_FUV; }; // :86-91
+	} else {
+		sim.ncomp_cc = kNumHydroVars + kNumRadVars;
+	}
+	sim.rad.DefineOpacityExponentsAndLowerValues = [ng](double const *, double, double, double *expo, double *lower) {
+		for (int i = 0; i < ng + 1; ++i) {
+			expo[i] = 0.0;
+			lower[i] = S::kappa0;
+		}
+	};
+	sim.rad.DefineNetCoolingRate = [ng](double temperature, double, double *cooling) { // :77-86 / MG :93-101
+		for (int g = 0; g < ng; ++g) {
+			cooling[g] = 0.0;
+		}
+		cooling[S::line_index] = S::cooling_rate * temperature;
+	};
+	sim.rad.DefineNetCoolingRateTempDerivative = [ng](double, double, double *cooling) {
+		for (int g = 0; g < ng; ++g) {
+			cooling[g] = 0.0;
+		}
+		cooling[S::line_index] = S::cooling_rate;
+	};
+	sim.rad.DefineCosmicRayHeatingRate = [](double) { return S::CR_heating_rate; };
+	sim.rad.eos = sim.hydro.tr.eos;
+	sim.rad.ndim = sim.geom.ndim;
+	sim.rad.nstartHyperbolic_ = kNumHydroVars;
+	sim.rad.ComputePlanckOpacity = [](double, double) { return S::kappa0; };
+	sim.rad.ComputeFluxMeanOpacity = [](double, double) { return S::kappa0; };
+	sim.rad.ComputeEnergyMeanOpacity = [](double, double) { return S::kappa0; };
+
+	sim.BCs_cc.assign(sim.ncomp_cc, BCRec{}); // problem_main: periodic
+	sim.radiationReconstructionOrder_ = 3;
+	sim.stopTime_ = S::max_time;
+	sim.radiationCflNumber_ = 0.8;
+	sim.cflNumber_ = 0.8;
+	sim.initDt_ = S::the_dt;
+	sim.maxDt_ = S::the_dt;
+	sim.maxTimesteps_ = 1000000;
+
+	sim.define();
+	EOS const eos = sim.hydro.tr.eos;
+	const double Egas = eos.ComputeEintFromTgas(S::rho0, S::T0);
+	forEachValidCell(sim, [&](Array4<double> const &state_cc, int i, int j, int k) {
+		for (int g = 0; g < ng; ++g) {
+			// one group: the floor; four groups: E_FUV in the last group, the floor elsewhere (MG :142-148)
+			state_cc(i, j, k, kNumHydroVars + 0 + kNumRadVars * g) = (multigroup && g == ng - 1) ? S::Erad_FUV : S::erad_floor;
+			state_cc(i, j, k, kNumHydroVars + 1 + kNumRadVars * g) = 0;
+			state_cc(i, j, k, kNumHydroVars + 2 + kNumRadVars * g) = 0;
+			state_cc(i, j, k, kNumHydroVars + 3 + kNumRadVars * g) = 0;
+		}
+		state_cc(i, j, k, energy_index) = Egas + 0.5 * S::rho0 * S::v0 * S::v0;
+		state_cc(i, j, k, density_index) = S::rho0;
+		state_cc(i, j, k, internalEnergy_index) = Egas;
+		state_cc(i, j, k, x1Momentum_index) = S::v0 * S::rho0;
+		state_cc(i, j, k, x2Momentum_index) = 0.;
+		state_cc(i, j, k, x3Momentum_index) = 0.;
+	});
+	sim.finishInitialConditions();
+}
+
+// ---------------------------------------------------------------- FUV front heating the gas photoelectrically (src/problems/RadMarshakDustPE/
+// test_radiation_marshak_dust_and_PE.cpp; decks tests/RadMarshakDustPEcoupled.in / ...decoupled.in: kappa1 = kappa2 = 1e-20,
+// dust_gas_interaction_coeff = 1e20 / 1e-20, stop_time = 0.5)
+struct MarshakDustPEConstants { // :19-36
+	static constexpr double PE_rate = 1.0;
+	static constexpr double c = 1.0, chat = 1.0, rho0 = 1.0, CV = 1.0;
+	static constexpr double mu = 1.5 / CV;
+	static constexpr double initial_T = 1.0, a_rad = 1.0, erad_floor = 1.0e-6, T_rad_L = 1.0;
+	static constexpr double EradL = a_rad * T_rad_L * T_rad_L * T_rad_L * T_rad_L;
+	static constexpr double kappa1 = 1e-20, kappa2 = 1e-20; // the decks
+};
+
+inline void setupMarshakDustPE(HydroSim &sim, double dust_coeff)
+{
+	using S = MarshakDustPEConstants;
+	sim.hydro.tr.eos.tr.gamma = 5. / 3.;
+	sim.hydro.tr.eos.tr.mean_molecular_weight = S::mu;
+	sim.hydro.tr.eos.tr.boltzmann_constant = 1.0;
+	sim.hydro.tr.reconstruct_eint = true;
+	sim.hydro.tr.nscalars = 0;
+	sim.is_radiation_enabled = true;
+	sim.is_hydro_enabled = false;
+	sim.rad.rt.c_light = S::c;
+	sim.rad.rt.c_hat = S::chat;
+	sim.rad.rt.radiation_constant = S::a_rad;
+	sim.rad.rt.Erad_floor = S::erad_floor;
+	sim.rad.rt.beta_order = 1;
+	sim.rad.rt.enable_dust_gas_thermal_coupling_model = true; // :70-74
+	sim.rad.rt.gas_dust_coupling_threshold = 1.0e-4;
+	sim.rad.rt.enable_photoelectric_heating = true;
+	sim.rad.rt.dustGasInteractionCoeff = dust_coeff;
+	setRadGroups(sim, {1e-10, 30, 1e4}, 1.0, piecewise_constant_opacity);
+	sim.rad.eos = sim.hydro.tr.eos;
+	sim.rad.ndim = sim.geom.ndim;
+	sim.rad.nstartHyperbolic_ = kNumHydroVars;
+	const int ng = sim.rad.rt.nGroups;
+	sim.rad.DefinePhotoelectricHeatingE1Derivative = [](double, double) { return S::PE_rate; }; // :76-88
+	sim.rad.DefineOpacityExponentsAndLowerValues = [ng](double const *, double, double, double *expo, double *lower) { // :90-106
+		for (int i = 0; i < ng + 1; ++i) {
+			expo[i] = 0.0;
+			lower[i] = (i == 0) ? S::kappa1 : S::kappa2;
+		}
+	};
+	sim.BCs_cc.assign(sim.ncomp_cc, BCRec{}); // problem_main :180-215
+	for (int n = 0; n < sim.ncomp_cc; ++n) {
+		sim.BCs_cc[n].lo[0] = ext_dir;
+		sim.BCs_cc[n].hi[0] = foextrap;
+	}
+	sim.radiationReconstructionOrder_ = 3;
+	sim.radiationCflNumber_ = 0.8;
+	sim.maxDt_ = 1;
+	sim.maxTimesteps_ = 5000;
+	sim.stopTime_ = 0.5; // the decks
+	sim.customBC = [ng](int i, int j, int k, Array4<double> const &consVar, Box const &dom, double /*time*/) { // :130-178
+		const double Erads[2] = {S::erad_floor, S::EradL};
+		if (i < dom.lo[0]) {
+			for (int g = 0; g < ng; ++g) {
+				consVar(i, j, k, kNumHydroVars + 0 + kNumRadVars * g) = Erads[g];
+				consVar(i, j, k, kNumHydroVars + 1 + kNumRadVars * g) = Erads[g] * S::c;
+				consVar(i, j, k, kNumHydroVars + 2 + kNumRadVars * g) = 0;
+				consVar(i, j, k, kNumHydroVars + 3 + kNumRadVars * g) = 0;
+			}
+		}
+		const double Egas = S::initial_T * S::CV;
+		consVar(i, j, k, energy_index) = Egas;
+		consVar(i, j, k, density_index) = S::rho0;
+		consVar(i, j, k, internalEnergy_index) = Egas;
+		consVar(i, j, k, x1Momentum_index) = 0.;
+		consVar(i, j, k, x2Momentum_index) = 0.;
+		consVar(i, j, k, x3Momentum_index) = 0.;
+	};
+	sim.define();
+	forEachValidCell(sim, [&](Array4<double> const &state_cc, int i, int j, int k) { // :108-128
+		const double Egas0 = S::initial_T * S::CV;
+		for (int g = 0; g < ng; ++g) {
+			state_cc(i, j, k, kNumHydroVars + 0 + kNumRadVars * g) = S::erad_floor;
+			state_cc(i, j, k, kNumHydroVars + 1 + kNumRadVars * g) = 0;
+			state_cc(i, j, k, kNumHydroVars + 2 + kNumRadVars * g) = 0;
+			state_cc(i, j, k, kNumHydroVars + 3 + kNumRadVars * g) = 0;
+		}
+		state_cc(i, j, k, energy_index) = Egas0;
+		state_cc(i, j, k, density_index) = S::rho0;
+		state_cc(i, j, k, internalEnergy_index) = Egas0;
+		state_cc(i, j, k, x1Momentum_index) = 0.;
+		state_cc(i, j, k, x2Momentum_index) = 0.;
+		state_cc(i, j, k, x3Momentum_index) = 0.;
+	});
+	sim.finishInitialConditions();
+}
+
 // ---------------------------------------------------------------- Quirk's odd-even decoupling test (src/problems/HydroQuirk/test_quirk.cpp,
 // deck tests/quirk.in: 128 x 16 (x 16) cells on 1 x 0.125; built for AMREX_SPACEDIM >= 2) — the 2-D pin of the hydro path
 struct QuirkConstants { // :58-63

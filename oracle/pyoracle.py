@@ -24,6 +24,9 @@ SOD, CONTACT, SEDOV, SHELL, RADSHOCK, STREAMING, SCALARS, HYDRO1D, COUPLING, SUO
 RADSHOCK_MG, RADTUBE, MARSHAK_VAYTET, PULSE_MG, PULSE_MG_GREY, RADDUST = 16, 17, 18, 19, 20, 21
 QUIRK = 22  # HydroQuirk: the 2-D (or 3-D) odd-even decoupling test
 RADDUST_MG = 24  # RadDustMG: the same relaxation with 4 photon groups (multigroup dust exchange)
+LINE_COOLING = 26  # RadLineCooling: one group, line cooling linear in T + cosmic-ray heating (dust_coeff = the deck's coefficient)
+LINE_COOLING_MG = 27  # RadLineCoolingMG: four groups + photoelectric heating by the last group
+MARSHAK_DUST_PE = 28  # RadMarshakDustPE: FUV front heating the gas photoelectrically
 MARSHAK_DUST = 25  # RadMarshakDust: two groups (IR / FUV), dust model with the decoupled branch
 BLAST2D = 23  # HydroBlast2D: circular blast in a reflecting box, as a 2-D build or as a 3-D build uniform in z
 # OpacityModel (radiation_system.hpp:64-71)
@@ -231,7 +234,7 @@ class Oracle:
 
     def sim(self, problem, ndim, n_cell, prob_lo, prob_hi, periodic, max_grid_size=None, cfl=-1.0, stop_time=-1.0,
             max_timesteps=-1, reconstruction_order=-1, nscalars=0, table=None, rad_pow_mode=0, hydro1d=None, beta_order=0, c_hat_factor=0.0,
-            opacity_model=0) -> "OracleSim":
+            opacity_model=0, dust_coeff=0.0) -> "OracleSim":
         n_cell = list(n_cell) + [1] * (3 - len(n_cell))
         mgs = list(max_grid_size) if max_grid_size is not None else list(n_cell)
         mgs = mgs + [1] * (3 - len(mgs))
@@ -254,6 +257,8 @@ class Oracle:
             cfg.h1d_i = (C.c_int * 2)(int(h.get("profile", 0)), int(h.get("dirichlet", 1)))
         if c_hat_factor > 0:  # COUPLING: the reduced-speed-of-light variant (RadMatterCouplingRSLA)
             cfg.h1d[0] = float(c_hat_factor)
+        if dust_coeff > 0:  # LINE_COOLING*, MARSHAK_DUST_PE: radiation.dust_gas_interaction_coeff of the deck
+            cfg.h1d[1] = float(dust_coeff)
         if beta_order > 0:  # RADSHOCK / ADVECTING parity variants: override RadSystem_Traits::beta_order
             cfg.h1d_i[0] = int(beta_order)
         # team size by problem size: ~16k cells per thread at least (a 1-D 512-cell run makes ~10^5 tiny parallel regions per second)

@@ -56,6 +56,7 @@ struct RadTraits {
 	// (QuokkaSimulation.hpp:127, deck key radiation.dust_gas_interaction_coeff)
 	bool enable_dust_gas_thermal_coupling_model = false;
 	double dustGasInteractionCoeff = 2.5e-34;
+	bool enable_photoelectric_heating = false; // ISM_Traits (multigroup dust model: SolveGasDustRadiationEnergyExchangeWithPE)
 	double gas_dust_coupling_threshold = 1.0e-6; // ISM_Traits (multigroup: below it gas and dust are treated as decoupled)
 	// the ComputeThermalRadiationSingleGroup / ...TempDerivativeSingleGroup hooks: 0 the default a T^4 / 4 a T^3 (:471-479, :499-503);
 	// 1: a T / a, the linearised emission of RadDust (src/problems/RadDust/test_rad_dust.cpp:86-97)
@@ -77,6 +78,33 @@ struct RadSystem {
 	std::function<double(double, double)> ComputeEnergyMeanOpacity; // :1151 (default: Planck)
 	// :1155-1167 DefineOpacityExponentsAndLowerValues(rad_boundaries, rho, Tgas) -> (exponents[nGroups+1], lower values[nGroups+1])
 	std::function<void(double const *rad_boundaries, double rho, double Tgas, double *exponents, double *lower_values)> DefineOpacityExponentsAndLowerValues;
+	// the ISM heating / cooling hooks (radiation_system.hpp:344-353; defaults :524-545 and radiation_dust_system.hpp:7-12: zero)
+	std::function<void(double temperature, double num_density, double *cooling_per_group)> DefineNetCoolingRate;
+	std::function<void(double temperature, double num_density, double *dcooling_dT_per_group)> DefineNetCoolingRateTempDerivative;
+	std::function<double(double num_density)> DefineCosmicRayHeatingRate;
+	std::function<double(double temperature, double num_density)> DefinePhotoelectricHeatingE1Derivative;
+	[[nodiscard]] auto crHeatingRate(double n) const -> double { return DefineCosmicRayHeatingRate ? DefineCosmicRayHeatingRate(n) : 0.0; }
+	[[nodiscard]] auto peHeatingE1Derivative(double T, double n) const -> double
+	{
+		return DefinePhotoelectricHeatingE1Derivative ? DefinePhotoelectricHeatingE1Derivative(T, n) : 0.0;
+	}
+	// group 0 of the two cooling hooks (the single-group scheme reads [0])
+	[[nodiscard]] auto netCoolingRate0(double T, double n) const -> double
+	{
+		double v[kMaxGroups] = {};
+		if (DefineNetCoolingRate) {
+			DefineNetCoolingRate(T, n, v);
+		}
+		return v[0];
+	}
+	[[nodiscard]] auto netCoolingRateTempDerivative0(double T, double n) const -> double
+	{
+		double v[kMaxGroups] = {};
+		if (DefineNetCoolingRateTempDerivative) {
+			DefineNetCoolingRateTempDerivative(T, n, v);
+		}
+		return v[0];
+	}
 
 	[[nodiscard]] auto nGroups_() const -> int { return rt.nGroups; }
 	[[nodiscard]] auto nRadComps() const -> int { return kNumRadVars * rt.nGroups; }
@@ -611,7 +639,11 @@ struct RadSystem {
 
 								double cooling = 0.0;
 								double cooling_derivative = 0.0;
-								const double CR_heating = 0.0 * dt; // DefineCosmicRayHeatingRate default (:542-545)
+								const double CR_heating = crHeatingRate(H_num_den) * dt;
+								if (rt.enable_dust_gas_thermal_coupling_model) { // :234-237
+									cooling = netCoolingRate0(T_gas, H_num_den);
+									cooling_derivative = netCoolingRateTempDerivative0(T_gas, H_num_den);
+								}
 
 								F_G = Egas_guess - Egas0 + cscale * R + cooling * dt - CR_heating;
 								F_D = Erad_guess - Erad0 - (R + Src);
@@ -686,7 +718,7 @@ struct RadSystem {
 							p_iteration_counter[2] = std::max(p_iteration_counter[2], n + 1);
 
 							if (!add_line_cooling_to_radiation_in_jac) {
-								const auto cooling_tend = 0.0 * dt; // DefineNetCoolingRate default (:524-530)
+								const auto cooling_tend = netCoolingRate0(T_gas, H_num_den) * dt; // :351-356
 								Erad_guess += (1 / cscale) * cooling_tend;
 							}
 							if (n > 0) {

@@ -181,6 +181,7 @@ struct NewtonIterationResult {
 struct JacobianResult {
 	double J00 = NAN, F0 = NAN, Fg_abs_sum = NAN;
 	VA J0g, Jg0, Jgg, Fg;
+	VA Jg1; // photoelectric heating: the column of the last (FUV) group
 };
 struct FluxUpdateResult {
 	VA Erad;
@@ -192,6 +193,24 @@ struct MG {
 	RadSystem const &rs;
 	int nGroups_;
 	explicit MG(RadSystem const &r) : rs(r), nGroups_(r.rt.nGroups) {}
+
+	// DefineNetCoolingRate / ...TempDerivative (radiation_system.hpp:348-351; defaults :524-540: zero)
+	[[nodiscard]] auto netCoolingRate(double T, double num_den) const -> VA
+	{
+		VA v(nGroups_);
+		if (rs.DefineNetCoolingRate) {
+			rs.DefineNetCoolingRate(T, num_den, v.v.data());
+		}
+		return v;
+	}
+	[[nodiscard]] auto netCoolingRateTempDerivative(double T, double num_den) const -> VA
+	{
+		VA v(nGroups_);
+		if (rs.DefineNetCoolingRateTempDerivative) {
+			rs.DefineNetCoolingRateTempDerivative(T, num_den, v.v.data());
+		}
+		return v;
+	}
 
 	[[nodiscard]] auto boundaries() const -> VA
 	{
@@ -472,11 +491,11 @@ struct MG {
 
 	// source_terms_multi_group.hpp:98-147
 	[[nodiscard]] auto ComputeJacobianForGas(double /*T_d*/, double Egas_diff, VA const &Erad_diff, VA const &Rvec, VA const &Src, VA const &tau, double c_v,
-						 VA const &kappaPoverE, VA const &d_fourpiboverc_d_t, double const /*num_den*/, double const dt) const -> JacobianResult
+						 VA const &kappaPoverE, VA const &d_fourpiboverc_d_t, double const num_den, double const dt) const -> JacobianResult
 	{
 		JacobianResult result;
 		const double cscale = rs.rt.c_light / rs.rt.c_hat;
-		const double CR_heating = 0.0 * dt; // DefineCosmicRayHeatingRate default (radiation_system.hpp:542-545)
+		const double CR_heating = rs.crHeatingRate(num_den) * dt;
 		result.F0 = Egas_diff + cscale * sum(Rvec) - CR_heating;
 		result.Fg = Erad_diff - (Rvec + Src);
 		result.Fg_abs_sum = 0.0;
@@ -655,17 +674,16 @@ struct MG {
 		return RadSystem::BackwardEulerOneVariable(rhs, jac, T_d_init, Lambda_compare);
 	}
 
-	// radiation_dust_system.hpp:22-83 (DefineNetCoolingRate / ...TempDerivative / DefineCosmicRayHeatingRate: the defaults, zero)
+	// radiation_dust_system.hpp:22-83
 	[[nodiscard]] auto ComputeJacobianForGasAndDust(double T_gas, double T_d, double Egas_diff, VA const &Erad_diff, VA const &Rvec, VA const &Src, double coeff_n,
-							VA const &tau, double c_v, VA const &kappaPoverE, VA const &d_fourpiboverc_d_t, const double dt) const
-	    -> JacobianResult
+							VA const &tau, double c_v, VA const &kappaPoverE, VA const &d_fourpiboverc_d_t, const double num_den,
+							const double dt) const -> JacobianResult
 	{
 		JacobianResult result;
 		const double cscale = rs.rt.c_light / rs.rt.c_hat;
-		VA cooling(nGroups_), cooling_derivative(nGroups_);
-		cooling = cooling * dt;
-		cooling_derivative = cooling_derivative * dt;
-		const double CR_heating = 0.0 * dt;
+		const auto cooling = netCoolingRate(T_gas, num_den) * dt;
+		const auto cooling_derivative = netCoolingRateTempDerivative(T_gas, num_den) * dt;
+		const double CR_heating = rs.crHeatingRate(num_den) * dt;
 		result.F0 = Egas_diff + cscale * sum(Rvec) + sum(cooling) - CR_heating;
 		result.Fg = Erad_diff - (Rvec + Src);
 		result.Fg_abs_sum = 0.0;
@@ -697,6 +715,76 @@ struct MG {
 		return result;
 	}
 
+	// radiation_dust_system.hpp:130-196: with photoelectric heating proportional to the energy density of the LAST group (FUV)
+	[[nodiscard]] auto ComputeJacobianForGasAndDustWithPE(double T_gas, double T_d, double Egas_diff, VA const &Erad, VA const &Erad0,
+							      double PE_heating_energy_derivative, VA const &Rvec, VA const &Src, double coeff_n, VA const &tau, double c_v,
+							      VA const &kappaPoverE, VA const &d_fourpiboverc_d_t, double const num_den, double const dt) const
+	    -> JacobianResult
+	{
+		constexpr double LARGE = 1.0e100; // radiation_system.hpp:48
+		JacobianResult result;
+		const double cscale = rs.rt.c_light / rs.rt.c_hat;
+		const auto cooling = netCoolingRate(T_gas, num_den) * dt;
+		const auto cooling_derivative = netCoolingRateTempDerivative(T_gas, num_den) * dt;
+		const double CR_heating = rs.crHeatingRate(num_den) * dt;
+		result.F0 = Egas_diff + cscale * sum(Rvec) + sum(cooling) - PE_heating_energy_derivative * Erad[nGroups_ - 1] - CR_heating;
+		result.Fg = Erad - Erad0 - (Rvec + Src);
+		result.Fg_abs_sum = 0.0;
+		for (int g = 0; g < nGroups_; ++g) {
+			if (tau[g] > 0.0) {
+				result.Fg_abs_sum += std::abs(result.Fg[g]);
+			} else {
+				result.Fg_abs_sum += std::abs(result.Fg[g] + Rvec[g]);
+			}
+		}
+		auto d_Eg_d_Rg = -1.0 * kappaPoverE;
+		for (int g = 0; g < nGroups_; ++g) {
+			if (tau[g] <= 0.0) {
+				d_Eg_d_Rg[g] = -LARGE;
+			} else {
+				d_Eg_d_Rg[g] /= tau[g];
+			}
+		}
+		result.J00 = 1.0 + sum(cooling_derivative) / c_v;
+		result.J0g = VA(nGroups_);
+		result.J0g.fillin(cscale);
+		result.J0g[nGroups_ - 1] -= PE_heating_energy_derivative * d_Eg_d_Rg[nGroups_ - 1];
+		const double d_Td_d_T = 3. / 2. - T_d / (2. * T_gas);
+		const auto dEg_dT = kappaPoverE * d_fourpiboverc_d_t * d_Td_d_T;
+		const double dTd_dRg = -1.0 / (coeff_n * std::sqrt(T_gas));
+		const auto rg = kappaPoverE * d_fourpiboverc_d_t * dTd_dRg;
+		result.Jg0 = 1.0 / c_v * dEg_dT - (1 / cscale) * cooling_derivative - 1.0 / cscale * rg * result.J00;
+		result.Fg = result.Fg - 1.0 / cscale * rg * result.F0;
+		result.Jgg = d_Eg_d_Rg + (-1.0);
+		result.Jgg[nGroups_ - 1] += rg[nGroups_ - 1] - (rg[nGroups_ - 1] / cscale) * PE_heating_energy_derivative * d_Eg_d_Rg[nGroups_ - 1];
+		result.Jg1 = rg - 1.0 / cscale * rg * result.J0g[nGroups_ - 1];
+		return result;
+	}
+
+	// radiation_dust_system.hpp:198-226: first row, first column, diagonal and the column of the last group
+	static void SolveLinearEqsWithLastColumn(JacobianResult const &jacobian, double &x0, VA &xi)
+	{
+		const int nG = jacobian.Jgg.n;
+		const int pe_index = nG - 1;
+		const auto ratios = jacobian.J0g / jacobian.Jgg;
+		const auto a00_new = jacobian.J00 - sum(ratios * jacobian.Jg0);
+		const auto y0_new = jacobian.F0 - sum(ratios * jacobian.Fg);
+		auto a01_new = jacobian.J0g[pe_index] - sum(ratios * jacobian.Jg1);
+		a01_new = a01_new + ratios[pe_index] * jacobian.Jg1[pe_index] - ratios[pe_index] * jacobian.Jgg[pe_index];
+		const auto a10 = jacobian.Jg0[pe_index];
+		const auto a11 = jacobian.Jgg[pe_index];
+		const auto y1 = jacobian.Fg[pe_index];
+		x0 = (y0_new - a01_new / a11 * y1) / (a00_new - a01_new / a11 * a10);
+		const auto x1 = (y1 - a10 * x0) / a11;
+		xi = VA(nG);
+		xi[pe_index] = x1;
+		for (int g = 0; g < pe_index; ++g) {
+			xi[g] = (jacobian.Fg[g] - jacobian.Jg0[g] * x0 - jacobian.Jg1[g] * x1) / jacobian.Jgg[g];
+		}
+		x0 *= -1.0;
+		xi = xi * -1.0;
+	}
+
 	// radiation_dust_system.hpp:85-128
 	[[nodiscard]] auto ComputeJacobianForGasAndDustDecoupled(VA const &Erad_diff, VA const &Rvec, VA const &Src, VA const &tau, double lambda_gd_time_dt,
 								 VA const &kappaPoverE, VA const &d_fourpiboverc_d_t) const -> JacobianResult
@@ -726,10 +814,12 @@ struct MG {
 		return result;
 	}
 
-	// radiation_dust_system.hpp:228-576.  p_iteration_counter[3] counts the decoupled solves
+	// radiation_dust_system.hpp:228-576, and with `with_PE` the photoelectric-heating variant :578-933 (SolveGasDustRadiationEnergyExchangeWithPE: the same
+	// text except for the five places marked PE).  p_iteration_counter[3] counts the decoupled solves
 	[[nodiscard]] auto SolveGasDustRadiationEnergyExchange(double const Egas0, VA const &Erad0Vec, double const rho, double const coeff_n, double const dt,
 							       int const n_outer_iter, VA const &work, VA const &vel_times_F, VA const &Src, VA const &rad_boundaries,
-							       int *p_iteration_counter, int *p_iteration_failure_counter) const -> NewtonIterationResult
+							       int *p_iteration_counter, int *p_iteration_failure_counter, bool const with_PE = false) const
+	    -> NewtonIterationResult
 	{
 		const double c = rs.rt.c_light;
 		const double chat = rs.rt.c_hat;
@@ -751,9 +841,11 @@ struct MG {
 		double Etot0 = NAN;
 		if (dust_model == 1) {
 			Etot0 = Egas0 + cscale * (sum(Erad0Vec) + sum(Src));
-		} else {
+		} else if (!with_PE) {
 			const double fourPiBoverC = sum(ComputeThermalRadiationMultiGroup(T_d0, rad_boundaries));
 			Etot0 = std::abs(lambda_gd_times_dt) + fourPiBoverC + (sum(Erad0Vec) + sum(Src));
+		} else { // PE (:631)
+			Etot0 = std::abs(lambda_gd_times_dt) + (sum(Erad0Vec) + sum(Src));
 		}
 
 		double T_gas = NAN;
@@ -773,6 +865,9 @@ struct MG {
 		double Egas_guess = Egas0;
 		auto EradVec_guess = Erad0Vec;
 		T_gas = rs.eos.ComputeTgasFromEint(rho, Egas_guess);
+		const double H_num_den = rho / rs.eos.tr.mean_molecular_weight; // ComputeNumberDensityH
+		// PE (:683-685): evaluated once, at the initial gas temperature
+		const double PE_heating_energy_derivative = with_PE ? dt * rs.peHeatingE1Derivative(T_gas, H_num_den) : 0.0;
 
 		const double resid_tol = 1.0e-11;
 		const int maxIter = 100;
@@ -839,15 +934,24 @@ struct MG {
 
 			JacobianResult jacobian;
 			if (dust_model == 1) {
-				jacobian = ComputeJacobianForGasAndDust(T_gas, T_d, Egas_diff, Erad_diff, Rvec, Src, coeff_n, tau, c_v, opacity_terms.kappaPoverE,
-									d_fourpiboverc_d_t, dt);
+				if (!with_PE) {
+					jacobian = ComputeJacobianForGasAndDust(T_gas, T_d, Egas_diff, Erad_diff, Rvec, Src, coeff_n, tau, c_v, opacity_terms.kappaPoverE,
+										d_fourpiboverc_d_t, H_num_den, dt);
+				} else { // PE (:790-792)
+					jacobian = ComputeJacobianForGasAndDustWithPE(T_gas, T_d, Egas_diff, EradVec_guess, Erad0Vec, PE_heating_energy_derivative, Rvec, Src,
+										      coeff_n, tau, c_v, opacity_terms.kappaPoverE, d_fourpiboverc_d_t, H_num_den, dt);
+				}
 			} else {
 				jacobian = ComputeJacobianForGasAndDustDecoupled(Erad_diff, Rvec, Src, tau, lambda_gd_times_dt, opacity_terms.kappaPoverE, d_fourpiboverc_d_t);
 			}
 			if ((std::abs(jacobian.F0 / Etot0) < resid_tol) && (cscale * jacobian.Fg_abs_sum / Etot0 < resid_tol)) {
 				break;
 			}
-			SolveLinearEqs(jacobian, delta_x, delta_R);
+			if (with_PE) { // PE (:836)
+				SolveLinearEqsWithLastColumn(jacobian, delta_x, delta_R);
+			} else {
+				SolveLinearEqs(jacobian, delta_x, delta_R);
+			}
 			if (dust_model == 2) {
 				T_d += delta_x;
 				Rvec = Rvec + delta_R;
@@ -862,15 +966,27 @@ struct MG {
 			}
 		}
 
-		VA cooling_tend(nGroups_); // DefineNetCoolingRate(T_gas, H_num_den) * dt: zero
-		if (dust_model == 2) {
-			const double CR_heating = 0.0 * dt;
+		const auto cooling_tend = netCoolingRate(T_gas, H_num_den) * dt; // :515
+		if (dust_model == 2) { // :516-537 (PE :868-891): line cooling / heating and cosmic-ray heating update the gas energy implicitly
+			const double CR_heating = rs.crHeatingRate(H_num_den) * dt;
 			const double compare = Egas_guess + cscale * lambda_gd_times_dt + sum(abs(cooling_tend)) + CR_heating;
-			auto rhs = [&](double Egas_) -> double { return Egas_ - Egas0 + cscale * lambda_gd_times_dt + 0.0 - CR_heating; };
-			auto jac = [&](double /*Egas_*/) -> double { return 1.0 + 0.0; };
+			const double pe_term = with_PE ? PE_heating_energy_derivative * EradVec_guess[nGroups_ - 1] : 0.0;
+			auto rhs = [&](double Egas_) -> double {
+				const double T_gas_ = rs.eos.ComputeTgasFromEint(rho, Egas_);
+				const auto cooling_ = netCoolingRate(T_gas_, H_num_den) * dt;
+				if (with_PE) {
+					return Egas_ - Egas0 + cscale * lambda_gd_times_dt + sum(cooling_) - pe_term - CR_heating;
+				}
+				return Egas_ - Egas0 + cscale * lambda_gd_times_dt + sum(cooling_) - CR_heating;
+			};
+			auto jac = [&](double Egas_) -> double {
+				const double T_gas_ = rs.eos.ComputeTgasFromEint(rho, Egas_);
+				const auto d_cooling_d_Tgas_ = netCoolingRateTempDerivative(T_gas_, H_num_den) * dt;
+				return 1.0 + sum(d_cooling_d_Tgas_);
+			};
 			Egas_guess = RadSystem::BackwardEulerOneVariable(rhs, jac, Egas0, compare);
 		}
-		EradVec_guess = EradVec_guess + (1 / cscale) * cooling_tend;
+		EradVec_guess = EradVec_guess + (1 / cscale) * cooling_tend; // :539-543
 
 		if (n >= maxIter) {
 			p_iteration_failure_counter[0] += 1;
@@ -1103,7 +1219,7 @@ struct MG {
 							} else {
 								updated_energy = SolveGasDustRadiationEnergyExchange(Egas0, Erad0Vec, rho, coeff_n, dt, iter, work, vel_times_F, Src,
 														     radBoundaries_g_copy, p_iteration_counter,
-														     p_iteration_failure_counter);
+														     p_iteration_failure_counter, rs.rt.enable_photoelectric_heating);
 							}
 
 							Egas_guess = updated_energy.Egas;

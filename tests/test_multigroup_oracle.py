@@ -8,7 +8,7 @@ import re
 import numpy as np
 import pytest
 
-from oracle.pyoracle import (MARSHAK_DUST, MARSHAK_VAYTET, PIECEWISE_CONSTANT, PPL_FIXED_SLOPE, PPL_FULL_SPECTRUM, PULSE_MG, PULSE_MG_GREY, RADDUST, RADDUST_MG,
+from oracle.pyoracle import (LINE_COOLING, LINE_COOLING_MG, MARSHAK_DUST, MARSHAK_DUST_PE, MARSHAK_VAYTET, PIECEWISE_CONSTANT, PPL_FIXED_SLOPE, PPL_FULL_SPECTRUM, PULSE_MG, PULSE_MG_GREY, RADDUST, RADDUST_MG,
                              RADSHOCK_MG, RADTUBE)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -306,4 +306,64 @@ def test_two_group_marshak_wave_with_dust_meets_the_reference_criterion(oracle):
     assert c["decoupled"] == c["solves"] > 0
     U = s.valid(0)[:, 0, 0, :]
     err = marshak_dust_error(U, s.time)
+    assert err < 0.01, err
+
+
+def line_cooling_error(t, u, heating_rate):
+    """test_rad_line_cooling.cpp:228-262 (..._MG.cpp:236-303 interpolates the same curve from 1000 samples): T_gas and the energy density of the
+    line group of cell 0 after every step against  C_V dT/dt = -0.1 T + heating,  E_line = the energy the gas lost to the line; tolerance 0.0005"""
+    E = np.exp(-0.1 * t) * (0.1 * 1.0 - heating_rate + heating_rate * np.exp(0.1 * t)) / 0.1
+    Er = -(E - 1.0 - heating_rate * t)
+    T = u[:, 5] / 1.0  # rho = C_V = 1, gas at rest
+    return float((np.abs(T - E).sum() + np.abs(u[:, 6] - Er).sum()) / (np.abs(E).sum() + np.abs(Er).sum()))
+
+
+def test_line_cooling_and_cosmic_ray_heating_meet_the_reference_criterion(oracle):
+    """RadLineCooling: one group, kappa = 0, dust model on with a vanishing coupling coefficient; the DefineNetCoolingRate /
+    DefineCosmicRayHeatingRate hooks in the single-group Newton-Raphson residual and the cooled energy handed to the radiation afterwards"""
+    s = oracle.sim(LINE_COOLING, 1, [8, 1, 1], [0, 0, 0], [64.0, 1, 1], [1, 1, 1], max_grid_size=[8, 1, 1], dust_coeff=1e-20)
+    t, u = s.run_record(2000, 0, (0, 0, 0))
+    assert len(t) == 1000 and abs(t[-1] - 10.0) < 1e-12
+    c = s.rad_counters()
+    assert c["fail_coupling"] == c["fail_dust"] == c["fail_outer"] == 0
+    err = line_cooling_error(np.array(t), np.array(u), 0.03)
+    assert err < 0.0005, err
+
+
+@pytest.mark.parametrize("dust_coeff,decoupled", [(1e-20, True), (1e20, False)])
+def test_multigroup_line_cooling_with_photoelectric_heating_meets_the_reference_criterion(oracle, dust_coeff, decoupled):
+    """RadLineCoolingMG with both of its decks: SolveGasDustRadiationEnergyExchangeWithPE on its decoupled branch (the gas energy from the scalar
+    backward-Euler solve with cooling, cosmic-ray and photoelectric terms) and on its coupled branch (the Jacobian with the extra FUV column,
+    SolveLinearEqsWithLastColumn)"""
+    s = oracle.sim(LINE_COOLING_MG, 1, [8, 1, 1], [0, 0, 0], [64.0, 1, 1], [1, 1, 1], max_grid_size=[8, 1, 1], dust_coeff=dust_coeff)
+    t, u = s.run_record(2000, 0, (0, 0, 0))
+    assert len(t) == 1000 and abs(t[-1] - 10.0) < 1e-12
+    c = s.rad_counters()
+    assert c["fail_coupling"] == c["fail_dust"] == c["fail_outer"] == 0
+    assert c["decoupled"] == (c["solves"] if decoupled else 0)
+    err = line_cooling_error(np.array(t), np.array(u), 0.03 + 0.02)
+    assert err < 0.0005, err
+    assert np.all(np.abs(np.array(u)[:, 6 + 4 * 3] - 1.0) < 1e-12)  # the FUV group is not absorbed (kappa = 0): its energy stays 1
+
+
+def marshak_dust_pe_error(U, t):
+    """test_radiation_marshak_dust_and_PE.cpp:232-262: T = 1 + (t - x) behind the FUV front, E_IR = 0, E_FUV = 1 behind / the floor ahead; the
+    first cell is skipped; tolerance 0.01"""
+    n = U.shape[1]
+    x = (np.arange(n) + 0.5) / n
+    Tex = np.where(x < t, 1.0 + 1.0 * (t - x), 1.0)
+    e2 = np.where(x < t, 1.0, 1.0e-6)
+    num = np.abs(U[5][1:] - Tex[1:]).sum() + np.abs(U[6][1:]).sum() + np.abs(U[10][1:] - e2[1:]).sum()
+    return float(num / (np.abs(Tex[1:]).sum() + np.abs(e2[1:]).sum()))
+
+
+@pytest.mark.parametrize("dust_coeff,decoupled", [(1e20, False), (1e-20, True)])
+def test_photoelectric_heating_behind_a_streaming_front_meets_the_reference_criterion(oracle, dust_coeff, decoupled):
+    """RadMarshakDustPE-coupled / -decoupled: transparent gas (kappa = 1e-20) heated at the rate PE_rate * E_FUV behind a free-streaming front"""
+    s = oracle.sim(MARSHAK_DUST_PE, 1, [256, 1, 1], [0, 0, 0], [1.0, 1, 1], [0, 1, 1], max_grid_size=[256, 1, 1], dust_coeff=dust_coeff)
+    assert s.evolve() and abs(s.time - 0.5) < 1e-14
+    c = s.rad_counters()
+    assert c["fail_coupling"] == c["fail_dust"] == c["fail_outer"] == 0
+    assert c["decoupled"] == (c["solves"] if decoupled else 0)
+    err = marshak_dust_pe_error(s.valid(0)[:, 0, 0, :], s.time)
     assert err < 0.01, err
