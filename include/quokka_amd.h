@@ -254,6 +254,16 @@ typedef struct qk_rad_traits {
 	/* ISM_Traits<P>::gas_dust_coupling_threshold (radiation_system.hpp:89, default 1e-6; multigroup dust model only): when
 	 * (c / c_hat) max(Gamma_gd) < threshold * E_gas the solve treats gas and dust as decoupled (radiation_dust_system.hpp:258-272) */
 	double gas_dust_coupling_threshold;
+	/* The ISM heating / cooling hooks of RadSystem<P> (radiation_system.hpp:344-353; defaults zero), as the closed set the reference's problems use
+	 * (RadLineCooling, RadLineCoolingMG, RadMarshakDustPE); accepted together with the dust model only:
+	 *   DefineNetCoolingRate(T, n)[g]               = cooling_linear_coeff[g] * T     (...TempDerivative = cooling_linear_coeff[g])
+	 *   DefineCosmicRayHeatingRate(n)               = cr_heating_rate
+	 *   DefinePhotoelectricHeatingE1Derivative(T, n) = pe_heating_E1_derivative, with ISM_Traits::enable_photoelectric_heating (multigroup: the
+	 *   heating is proportional to the energy density of the LAST group; radiation_dust_system.hpp:578-933) */
+	double cooling_linear_coeff[QK_MAX_GROUPS];
+	double cr_heating_rate;
+	int enable_photoelectric_heating;
+	double pe_heating_E1_derivative;
 } qk_rad_traits;
 /* State layout: Physics_Indices (reference src/physics_info.hpp:20-47): comps 0..5 hydro, 6 + 4 g .. 9 + 4 g = (E_r, F_x, F_y, F_z) of group g.
  * The operators below act on all groups (primVar / flux arrays carry 4 * ngroups components, group-major like the state). */

@@ -67,7 +67,10 @@ class RadTraits(C.Structure):
                 ("mg_kappa_rho_exponent", C.c_double), ("mg_kappa_T_ref", C.c_double), ("mg_kappa_T_exponent", C.c_double),
                 # ISM_Traits::enable_dust_gas_thermal_coupling_model, QuokkaSimulation::dustGasInteractionCoeff_, thermal-emission hook
                 ("enable_dust_gas_thermal_coupling_model", C.c_int), ("dust_gas_interaction_coeff", C.c_double), ("thermal_model", C.c_int),
-                ("gas_dust_coupling_threshold", C.c_double)]
+                ("gas_dust_coupling_threshold", C.c_double),
+                # ISM hooks (closed set): line cooling linear in T per group, cosmic-ray heating, photoelectric heating by the last group
+                ("cooling_linear_coeff", C.c_double * MAX_GROUPS), ("cr_heating_rate", C.c_double), ("enable_photoelectric_heating", C.c_int),
+                ("pe_heating_E1_derivative", C.c_double)]
 
     def set_groups(self, boundaries, energy_unit, opacity_model, kappa_exponent, kappa_lower, rho_exponent=0.0, T_ref=0.0, T_exponent=0.0):
         """RadSystem_Traits<P>::radBoundaries / energy_unit / opacity_model + the DefineOpacityExponentsAndLowerValues hook (closed set)"""

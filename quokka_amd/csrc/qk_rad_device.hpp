@@ -3,7 +3,7 @@
 //   reference src/radiation/radiation_system.hpp            RadSystem<problem_t>
 //   reference src/radiation/source_terms_single_group.hpp   AddSourceTermsSingleGroup
 // The face flux and the state repair act on one photon group at a time (the transport of the groups is independent); the single-group source
-// term is here, the multigroup one in qk_rad_mg_device.hpp.  No dust / photoelectric / cooling models (ISM_Traits defaults).
+// term is here, the multigroup one in qk_rad_mg_device.hpp.
 #ifndef QK_RAD_DEVICE_HPP_
 #define QK_RAD_DEVICE_HPP_
 
@@ -24,6 +24,8 @@ struct Rad {
 	int ngroups; // Physics_Traits::nGroups
 	double dust_coeff; // QuokkaSimulation::dustGasInteractionCoeff_ (DUST instantiation of the source kernel only)
 	double dust_threshold; // ISM_Traits::gas_dust_coupling_threshold (multigroup dust model)
+	double cool0, cr_heat, pe_rate; // ISM hooks, closed set: net cooling rate of group 0 = cool0 * T; cosmic-ray heating rate; photoelectric E1 derivative
+	int pe_on; // ISM_Traits::enable_photoelectric_heating
 	double mean_molecular_mass = 0.; // EOS_Traits::mean_molecular_weight as given (ComputeNumberDensityH; set by the source-term launcher)
 	int thermal_model; // 0: a T^4; 1: a T (RadDust's hooks; DUST instantiation only)
 	__host__ __device__ explicit Rad(qk_rad_traits const &t)
@@ -32,6 +34,7 @@ struct Rad {
 	      kappaP0(t.kappaP), kappaE0(t.kappaE), kappaF0(t.kappaF), kT_ref(t.opacity_T_ref), kT_exp(t.opacity_T_exponent), kT_floor(t.opacity_pow_floor),
 	      beta_order(t.beta_order), pow_mode(t.pow_mode), opacity_model(t.opacity_model), eddington_model(t.eddington_model),
 	      ngroups((t.ngroups > 1) ? t.ngroups : 1), dust_coeff(t.dust_gas_interaction_coeff), dust_threshold(t.gas_dust_coupling_threshold),
+	      cool0(t.cooling_linear_coeff[0]), cr_heat(t.cr_heating_rate), pe_rate(t.pe_heating_E1_derivative), pe_on(t.enable_photoelectric_heating),
 	      thermal_model(t.thermal_model)
 	{
 	}
@@ -443,9 +446,14 @@ QK_DEV void radSourceCell(Rad const &r, Eos const &eos, double U[10], double src
 						Erad_guess = kappaPoverE * (fourPiBoverC - divBy(R - work, Rtau));
 					}
 				}
-				const double cooling = 0.0;
-				const double cooling_derivative = 0.0;
-				const double CR_heating = 0.0 * dt;
+				// the ISM hooks (closed set, carried with the dust model): net line cooling linear in T into the group, constant cosmic-ray heating
+				double cooling = 0.0;
+				const double cooling_derivative = 0.0; // (:284-287: read by the gas-only Jacobian, where the cooling hook is not evaluated)
+				double CR_heating = 0.0 * dt;
+				if constexpr (DUST) { // :233-237
+					CR_heating = r.cr_heat * dt;
+					cooling = r.cool0 * T_gas;
+				}
 				F_G = Egas_guess - Egas0 + cscale * R + cooling * dt - CR_heating;
 				F_D = Erad_guess - Erad0 - (R + Src);
 				double F_D_abs;
@@ -518,8 +526,13 @@ QK_DEV void radSourceCell(Rad const &r, Eos const &eos, double U[10], double src
 			n_solves += 1;
 			n_newton_total += n + 1;
 			n_newton_max = max(n_newton_max, n + 1);
-			// cooling_tend = 0 * dt: Erad_guess += (1/cscale) * 0
-			Erad_guess += (1 / cscale) * (0.0 * dt);
+			// :351-356: the energy the line cooled away goes to the radiation
+			if constexpr (DUST) {
+				const double cooling_tend = (r.cool0 * T_gas) * dt;
+				Erad_guess += (1 / cscale) * cooling_tend;
+			} else {
+				Erad_guess += (1 / cscale) * (0.0 * dt);
+			}
 			if (n > 0) {
 				kappaF = r.template kappaF<TDEP>(rho, T_d);
 			}

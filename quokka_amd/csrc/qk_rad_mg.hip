@@ -203,6 +203,16 @@ auto checkMG(qk_ctx *ctx, const qk_rad_traits *rt) -> int
 	if (rt->enable_dust_gas_thermal_coupling_model != 0 && !(rt->dust_gas_interaction_coeff > 0.0 && rt->gas_dust_coupling_threshold >= 0.0)) {
 		return setError(ctx, QK_ERR_INVALID, "multigroup dust model: dust_gas_interaction_coeff must be positive, gas_dust_coupling_threshold not negative");
 	}
+	if (rt->enable_dust_gas_thermal_coupling_model == 0) {
+		bool hooks = (rt->cr_heating_rate != 0.0) || (rt->enable_photoelectric_heating != 0);
+		for (int g = 0; g < ng; ++g) {
+			hooks = hooks || (rt->cooling_linear_coeff[g] != 0.0);
+		}
+		if (hooks) {
+			return setError(ctx, QK_ERR_UNSUPPORTED,
+					"multigroup source term: the line-cooling / cosmic-ray / photoelectric heating hooks are carried together with the dust model only");
+		}
+	}
 	if (!(rt->energy_unit > 0.0)) {
 		return setError(ctx, QK_ERR_INVALID, "multigroup: energy_unit must be positive");
 	}

@@ -67,6 +67,7 @@ template <int NG> struct RadMG {
 	double kexp[NG + 1], klow[NG + 1];
 	double energy_unit, kB; // RadSystem_Traits::energy_unit, EOS_Traits::boltzmann_constant
 	double k_rho_exp, k_T_ref, k_T_exp;
+	double cool[NG]; // DefineNetCoolingRate(T, n)[g] = cool[g] * T (closed set; the dust instantiations)
 	int model;
 	__host__ RadMG(qk_rad_traits const &t, double kB_user) : energy_unit(t.energy_unit), kB(kB_user), k_rho_exp(t.mg_kappa_rho_exponent), k_T_ref(t.mg_kappa_T_ref),
 								 k_T_exp(t.mg_kappa_T_exponent), model(t.mg_opacity_model)
@@ -75,6 +76,9 @@ template <int NG> struct RadMG {
 			bnd[g] = t.rad_boundaries[g];
 			kexp[g] = t.mg_kappa_exponent[g];
 			klow[g] = t.mg_kappa_lower[g];
+		}
+		for (int g = 0; g < NG; ++g) {
+			cool[g] = t.cooling_linear_coeff[g];
 		}
 	}
 	// DefineOpacityExponentsAndLowerValues(rad_boundaries, rho, Tgas): the factor every lower value carries
@@ -603,11 +607,13 @@ QK_DEV void solveGasDustRadiationEnergyExchange(Rad const &r, RadMG<NG> const &m
 	double Etot0;
 	if (dust_model == 1) {
 		Etot0 = Egas0 + cscale * (sumOf<NG>(Erad0Vec) + sumOf<NG>(Src));
-	} else {
+	} else if (r.pe_on == 0) {
 		double B0[NG];
 		planckEnergyFractions<NG>(m, T_d0, frac);
 		thermalRadiationMG<NG, true>(r, frac, T_d0, B0);
 		Etot0 = fabs(lambda_gd_times_dt) + sumOf<NG>(B0) + (sumOf<NG>(Erad0Vec) + sumOf<NG>(Src));
+	} else { // ...WithPE (:631)
+		Etot0 = fabs(lambda_gd_times_dt) + (sumOf<NG>(Erad0Vec) + sumOf<NG>(Src));
 	}
 
 	double T_gas = __builtin_nan(""), T_d = __builtin_nan("");
@@ -628,6 +634,10 @@ QK_DEV void solveGasDustRadiationEnergyExchange(Rad const &r, RadMG<NG> const &m
 		EradVec_guess[g] = Erad0Vec[g];
 	}
 	T_gas = T_gas0;
+	// ...WithPE (:683-685): the photoelectric heating rate per unit FUV energy density, evaluated once
+	const bool with_PE = (r.pe_on != 0);
+	const double PE_heating_energy_derivative = with_PE ? dt * r.pe_rate : 0.0;
+	const double CR_heating = r.cr_heat * dt;
 
 	const double resid_tol = 1.0e-11;
 	const int maxIter = 100;
@@ -698,13 +708,22 @@ QK_DEV void solveGasDustRadiationEnergyExchange(Rad const &r, RadMG<NG> const &m
 		const double c_v = ec.eintTempDerivative(T_gas);
 		const double Egas_diff = Egas_guess - Egas0;
 
-		double F0, J00, J0g;
+		double F0, J00;
+		double J0g[NG], Jg1[NG];
 		double Fg[NG], Jg0[NG], Jgg[NG];
 		double Fg_abs_sum = 0.0;
-		if (dust_model == 1) { // ComputeJacobianForGasAndDust (cooling = cooling_derivative = 0: their sums add +0.0, the products vanish)
-			const double cooling_sum = 0.0 * dt * NG * 0.0;
-			const double CR_heating = 0.0 * dt;
-			F0 = Egas_diff + cscale * sumOf<NG>(Rvec) + cooling_sum - CR_heating;
+		if (dust_model == 1) { // ComputeJacobianForGasAndDust (:22-83) / ...WithPE (:130-196)
+			double cooling[NG], cooling_derivative[NG];
+#pragma unroll
+			for (int g = 0; g < NG; ++g) {
+				cooling[g] = (m.cool[g] * T_gas) * dt;
+				cooling_derivative[g] = m.cool[g] * dt;
+			}
+			if (with_PE) {
+				F0 = Egas_diff + cscale * sumOf<NG>(Rvec) + sumOf<NG>(cooling) - PE_heating_energy_derivative * EradVec_guess[NG - 1] - CR_heating;
+			} else {
+				F0 = Egas_diff + cscale * sumOf<NG>(Rvec) + sumOf<NG>(cooling) - CR_heating;
+			}
 #pragma unroll
 			for (int g = 0; g < NG; ++g) {
 				const double Erad_diff = EradVec_guess[g] - Erad0Vec[g];
@@ -715,18 +734,47 @@ QK_DEV void solveGasDustRadiationEnergyExchange(Rad const &r, RadMG<NG> const &m
 					Fg_abs_sum += fabs(Fg[g] + Rvec[g]);
 				}
 			}
-			J00 = 1.0 + 0.0 / c_v;
-			J0g = cscale;
+			J00 = 1.0 + sumOf<NG>(cooling_derivative) / c_v;
 			const double d_Td_d_T = 3. / 2. - T_d / (2. * T_gas);
 			const double dTd_dRg = -1.0 / (coeff_n * sqrt(T_gas));
+			double rg[NG], d_Eg_d_Rg[NG];
+#pragma unroll
+			for (int g = 0; g < NG; ++g) {
+				J0g[g] = cscale;
+				rg[g] = ot.kappaPoverE[g] * d_fourpiboverc_d_t[g] * dTd_dRg;
+				if (with_PE) {
+					d_Eg_d_Rg[g] = -1.0 * ot.kappaPoverE[g];
+					if (tau[g] <= 0.0) {
+						d_Eg_d_Rg[g] = -1.0e100; // LARGE
+					} else {
+						d_Eg_d_Rg[g] /= tau[g];
+					}
+				}
+			}
+			if (with_PE) {
+				J0g[NG - 1] -= PE_heating_energy_derivative * d_Eg_d_Rg[NG - 1];
+			}
 #pragma unroll
 			for (int g = 0; g < NG; ++g) {
 				const double dEg_dT = ot.kappaPoverE[g] * d_fourpiboverc_d_t[g] * d_Td_d_T;
-				const double rg = ot.kappaPoverE[g] * d_fourpiboverc_d_t[g] * dTd_dRg;
-				Jg0[g] = 1.0 / c_v * dEg_dT - (1 / cscale) * 0.0 - 1.0 / cscale * rg * J00;
-				Fg[g] = Fg[g] - 1.0 / cscale * rg * F0;
+				Jg0[g] = 1.0 / c_v * dEg_dT - (1 / cscale) * cooling_derivative[g] - 1.0 / cscale * rg[g] * J00;
+				Fg[g] = Fg[g] - 1.0 / cscale * rg[g] * F0;
+				if (with_PE) {
+					Jgg[g] = d_Eg_d_Rg[g] + (-1.0);
+					Jg1[g] = rg[g] - 1.0 / cscale * rg[g] * J0g[NG - 1];
+				} else {
+					Jg1[g] = 0.0;
+					if (tau[g] <= 0.0) {
+						Jgg[g] = -__builtin_inf();
+					} else {
+						Jgg[g] = -1.0 * ot.kappaPoverE[g] / tau[g] - 1.0;
+					}
+				}
 			}
-		} else { // ComputeJacobianForGasAndDustDecoupled
+			if (with_PE) {
+				Jgg[NG - 1] += rg[NG - 1] - (rg[NG - 1] / cscale) * PE_heating_energy_derivative * d_Eg_d_Rg[NG - 1];
+			}
+		} else { // ComputeJacobianForGasAndDustDecoupled (:85-128)
 			F0 = -lambda_gd_times_dt + sumOf<NG>(Rvec);
 #pragma unroll
 			for (int g = 0; g < NG; ++g) {
@@ -736,46 +784,85 @@ QK_DEV void solveGasDustRadiationEnergyExchange(Rad const &r, RadMG<NG> const &m
 					Fg_abs_sum += fabs(Fg[g]);
 				}
 				Jg0[g] = ot.kappaPoverE[g] * d_fourpiboverc_d_t[g];
+				J0g[g] = 1.0;
+				Jg1[g] = 0.0;
+				if (tau[g] <= 0.0) {
+					Jgg[g] = -__builtin_inf();
+				} else {
+					Jgg[g] = -1.0 * ot.kappaPoverE[g] / tau[g] - 1.0;
+				}
 			}
 			J00 = 0.0;
-			J0g = 1.0;
-		}
-#pragma unroll
-		for (int g = 0; g < NG; ++g) {
-			if (tau[g] <= 0.0) {
-				Jgg[g] = -__builtin_inf();
-			} else {
-				Jgg[g] = -1.0 * ot.kappaPoverE[g] / tau[g] - 1.0;
-			}
 		}
 
 		if ((fabs(F0 / Etot0) < resid_tol) && (cscale * Fg_abs_sum / Etot0 < resid_tol)) {
 			break;
 		}
 
-		// SolveLinearEqs
-		double s1 = 0, s2 = 0;
+		double delta_x;
+		double delta_R[NG];
 		double ratio[NG];
 #pragma unroll
 		for (int g = 0; g < NG; ++g) {
-			ratio[g] = J0g / Jgg[g];
+			ratio[g] = J0g[g] / Jgg[g];
 		}
+		if (with_PE) { // SolveLinearEqsWithLastColumn (:198-226)
+			constexpr int pe = NG - 1;
+			double sa = 0, sy = 0, s1 = 0;
 #pragma unroll
-		for (int g = 0; g < NG; ++g) {
-			s1 += ratio[g] * Fg[g];
-		}
+			for (int g = 0; g < NG; ++g) {
+				sa += ratio[g] * Jg0[g];
+			}
 #pragma unroll
-		for (int g = 0; g < NG; ++g) {
-			s2 += ratio[g] * Jg0[g];
+			for (int g = 0; g < NG; ++g) {
+				sy += ratio[g] * Fg[g];
+			}
+#pragma unroll
+			for (int g = 0; g < NG; ++g) {
+				s1 += ratio[g] * Jg1[g];
+			}
+			const double a00_new = J00 - sa;
+			const double y0_new = F0 - sy;
+			double a01_new = J0g[pe] - s1;
+			a01_new = a01_new + ratio[pe] * Jg1[pe] - ratio[pe] * Jgg[pe];
+			const double a10 = Jg0[pe];
+			const double a11 = Jgg[pe];
+			const double y1 = Fg[pe];
+			double x0 = (y0_new - a01_new / a11 * y1) / (a00_new - a01_new / a11 * a10);
+			const double x1 = (y1 - a10 * x0) / a11;
+			delta_R[pe] = x1;
+#pragma unroll
+			for (int g = 0; g < pe; ++g) {
+				delta_R[g] = (Fg[g] - Jg0[g] * x0 - Jg1[g] * x1) / Jgg[g];
+			}
+			x0 *= -1.0;
+#pragma unroll
+			for (int g = 0; g < NG; ++g) {
+				delta_R[g] = delta_R[g] * -1.0;
+			}
+			delta_x = x0;
+		} else { // SolveLinearEqs (radiation_system.hpp:547-558)
+			double s1 = 0, s2 = 0;
+#pragma unroll
+			for (int g = 0; g < NG; ++g) {
+				s1 += ratio[g] * Fg[g];
+			}
+#pragma unroll
+			for (int g = 0; g < NG; ++g) {
+				s2 += ratio[g] * Jg0[g];
+			}
+			delta_x = (s1 - F0) / (-s2 + J00);
+#pragma unroll
+			for (int g = 0; g < NG; ++g) {
+				delta_R[g] = (-1.0 * Fg[g] - Jg0[g] * delta_x) / Jgg[g];
+			}
 		}
-		const double delta_x = (s1 - F0) / (-s2 + J00);
 
 		if (dust_model == 2) {
 			T_d += delta_x;
 #pragma unroll
 			for (int g = 0; g < NG; ++g) {
-				const double delta_R = (-1.0 * Fg[g] - Jg0[g] * delta_x) / Jgg[g];
-				Rvec[g] = Rvec[g] + delta_R;
+				Rvec[g] = Rvec[g] + delta_R[g];
 			}
 		} else {
 			const double T_rad = sqrt(sqrt(sumOf<NG>(EradVec_guess) / r.arad));
@@ -785,25 +872,51 @@ QK_DEV void solveGasDustRadiationEnergyExchange(Rad const &r, RadMG<NG> const &m
 				Egas_guess += delta_x;
 #pragma unroll
 				for (int g = 0; g < NG; ++g) {
-					const double delta_R = (-1.0 * Fg[g] - Jg0[g] * delta_x) / Jgg[g];
-					Rvec[g] = Rvec[g] + delta_R;
+					Rvec[g] = Rvec[g] + delta_R[g];
 				}
 			}
 		}
 	}
 
-	if (dust_model == 2) { // :516-555: backward Euler on E - E0 + cscale lambda dt = 0 (the Jacobian is 1: one step lands on the root, the second confirms it)
-		const double CR_heating = 0.0 * dt;
-		const double compare = Egas_guess + cscale * lambda_gd_times_dt + 0.0 + CR_heating;
+	// :515-543 (PE :867-897): the line-cooling tendency at the last gas temperature; decoupled: the gas energy from a scalar backward-Euler solve of
+	// E - E0 + cscale lambda dt + sum(cooling(T(E))) dt [- PE E_FUV] - CR = 0
+	double cooling_tend[NG];
+#pragma unroll
+	for (int g = 0; g < NG; ++g) {
+		cooling_tend[g] = (m.cool[g] * T_gas) * dt;
+	}
+	if (dust_model == 2) {
+		double sabs = 0;
+#pragma unroll
+		for (int g = 0; g < NG; ++g) {
+			sabs += fabs(cooling_tend[g]);
+		}
+		const double compare = Egas_guess + cscale * lambda_gd_times_dt + sabs + CR_heating;
+		const double pe_term = PE_heating_energy_derivative * EradVec_guess[NG - 1];
 		double x = Egas0;
 		const int max_iter_td = 100;
 		int it = 0;
 		for (; it < max_iter_td; ++it) {
-			const double the_rhs = x - Egas0 + cscale * lambda_gd_times_dt + 0.0 - CR_heating;
+			const double T_gas_ = ec.tgasFromEint(x);
+			double sc = 0, sd = 0;
+#pragma unroll
+			for (int g = 0; g < NG; ++g) {
+				sc += (m.cool[g] * T_gas_) * dt;
+			}
+#pragma unroll
+			for (int g = 0; g < NG; ++g) {
+				sd += m.cool[g] * dt;
+			}
+			double the_rhs;
+			if (with_PE) {
+				the_rhs = x - Egas0 + cscale * lambda_gd_times_dt + sc - pe_term - CR_heating;
+			} else {
+				the_rhs = x - Egas0 + cscale * lambda_gd_times_dt + sc - CR_heating;
+			}
 			if (fabs(the_rhs) < 1.0e-8 * compare) {
 				break;
 			}
-			const double dT = -the_rhs / (1.0 + 0.0);
+			const double dT = -the_rhs / (1.0 + sd);
 			x += dT;
 			if (it > 0) {
 				if (fabs(dT) < 1.0e-6 * fabs(x)) {
@@ -818,7 +931,7 @@ QK_DEV void solveGasDustRadiationEnergyExchange(Rad const &r, RadMG<NG> const &m
 	}
 #pragma unroll
 	for (int g = 0; g < NG; ++g) {
-		EradVec_guess[g] = EradVec_guess[g] + (1 / cscale) * 0.0; // cooling_tend
+		EradVec_guess[g] = EradVec_guess[g] + (1 / cscale) * cooling_tend[g];
 	}
 
 	if (n >= maxIter) {

@@ -767,6 +767,9 @@ int qk_rad_AddSourceTermsSingleGroup(qk_level *lev, qk_stream s, const qk_rad_tr
 	QK_REQUIRE(lev->ctx, stage == 1 || stage == 2, "AddSourceTermsSingleGroup: stage must be 1 or 2");
 	QK_REQUIRE(lev->ctx, rt->thermal_model == 0 || (rt->thermal_model == 1 && rt->enable_dust_gas_thermal_coupling_model != 0),
 		   "AddSourceTermsSingleGroup: thermal_model must be 0, or 1 together with the dust model");
+	QK_REQUIRE(lev->ctx, rt->enable_dust_gas_thermal_coupling_model != 0 || (rt->cooling_linear_coeff[0] == 0.0 && rt->cr_heating_rate == 0.0),
+		   "AddSourceTermsSingleGroup: the line-cooling / cosmic-ray heating hooks are carried together with the dust model only");
+	QK_REQUIRE(lev->ctx, rt->enable_photoelectric_heating == 0, "AddSourceTermsSingleGroup: photoelectric heating is a multigroup model (radiation_dust_system.hpp)");
 	if (rt->enable_dust_gas_thermal_coupling_model != 0) {
 		QK_REQUIRE(lev->ctx, rt->dust_gas_interaction_coeff > 0.0 && t->mean_molecular_weight > 0.0, "dust model: needs dust_gas_interaction_coeff > 0");
 		return (rt->opacity_model == 2) ? radSourceImpl<true, true>(lev, s, rt, t, cons_t, src_t, dt, stage, d_iteration_counter, d_failure_counter)

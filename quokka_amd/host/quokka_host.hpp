@@ -617,6 +617,47 @@ template <typename problem_t> class RadSystem : public HyperbolicSystem<problem_
 		return Eint + p_sq / (2.0 * density);
 	}
 	AMREX_GPU_HOST_DEVICE static auto ComputePlanckOpacity(double rho, double Tgas) -> amrex::Real;
+	// the ISM heating / cooling hooks (radiation_system.hpp:344-353; defaults zero, :524-545 and radiation_dust_system.hpp:7-12)
+	AMREX_GPU_HOST_DEVICE static auto DefinePhotoelectricHeatingE1Derivative(amrex::Real temperature, amrex::Real num_density) -> amrex::Real;
+	AMREX_GPU_HOST_DEVICE static auto DefineNetCoolingRate(amrex::Real temperature, amrex::Real num_density) -> quokka::valarray<double, nGroups_>;
+	AMREX_GPU_HOST_DEVICE static auto DefineNetCoolingRateTempDerivative(amrex::Real temperature, amrex::Real num_density) -> quokka::valarray<double, nGroups_>;
+	AMREX_GPU_HOST_DEVICE static auto DefineCosmicRayHeatingRate(amrex::Real num_density) -> double;
+	// ... sampled on the host into the closed set of qk_rad_traits (cooling linear in T, the two heating rates constant); aborts otherwise
+	static void ismHooks(qk_rad_traits &rt)
+	{
+		auto close = [](double a, double b) { return a == b || std::abs(a - b) <= 1e-13 * std::abs(b); };
+		bool ok = true, any = false;
+		auto const c1 = DefineNetCoolingRate(1.0, 1.0);
+		double const cr = DefineCosmicRayHeatingRate(1.0);
+		double const pe = DefinePhotoelectricHeatingE1Derivative(1.0, 1.0);
+		for (int g = 0; g < nGroups_; ++g) {
+			rt.cooling_linear_coeff[g] = c1[g];
+			any = any || c1[g] != 0.0;
+		}
+		for (double T : {0.3, 7.0, 4.0e4}) {
+			for (double n : {1.0e-3, 1.0, 5.0e7}) {
+				auto const c = DefineNetCoolingRate(T, n);
+				auto const d = DefineNetCoolingRateTempDerivative(T, n);
+				for (int g = 0; g < nGroups_; ++g) {
+					ok = ok && close(c[g], c1[g] * T) && close(d[g], c1[g]);
+				}
+				ok = ok && DefineCosmicRayHeatingRate(n) == cr && DefinePhotoelectricHeatingE1Derivative(T, n) == pe;
+			}
+		}
+		if (!ok) {
+			amrex::Abort("RadSystem: the DefineNetCoolingRate / DefineCosmicRayHeatingRate / DefinePhotoelectricHeatingE1Derivative hooks are not in "
+				     "the C-ABI's closed set (cooling linear in T, constant heating rates)");
+		}
+		rt.cr_heating_rate = cr;
+		rt.enable_photoelectric_heating = enable_photoelectric_heating_ ? 1 : 0;
+		rt.pe_heating_E1_derivative = enable_photoelectric_heating_ ? pe : 0.0;
+		if ((any || cr != 0.0 || enable_photoelectric_heating_) && !enable_dust_gas_thermal_coupling_model_) {
+			amrex::Abort("RadSystem: the ISM heating / cooling hooks are carried by the C-ABI together with the dust model only");
+		}
+		if (enable_photoelectric_heating_ && nGroups_ == 1) {
+			amrex::Abort("RadSystem: photoelectric heating is a multigroup model (radiation_dust_system.hpp)");
+		}
+	}
 	AMREX_GPU_HOST_DEVICE static auto ComputeFluxMeanOpacity(double rho, double Tgas) -> amrex::Real;
 	AMREX_GPU_HOST_DEVICE static auto ComputeEnergyMeanOpacity(double rho, double Tgas) -> amrex::Real;
 	AMREX_GPU_HOST_DEVICE static auto ComputeEddingtonFactor(double f) -> double; // :773-790 (default: Levermore closure)
@@ -671,13 +712,17 @@ template <typename problem_t> class RadSystem : public HyperbolicSystem<problem_
 		// density exponent: 0 or -1; temperature exponent: nearest multiple of 1/2 of the sampled slope
 		auto const r2 = DefineOpacityExponentsAndLowerValues(radBoundaries_, 2.0 * r0, T0);
 		auto const T2 = DefineOpacityExponentsAndLowerValues(radBoundaries_, r0, 1.0e6);
+		int e = 0; // the probe: the first edge with a non-zero lower value (all zero — a transparent medium — is the constant 0)
+		while (e < nedge - 1 && base[1][e] == 0.0) {
+			++e;
+		}
 		double a = std::numeric_limits<double>::quiet_NaN();
-		if (close(r2[1][0], base[1][0])) {
+		if (close(r2[1][e], base[1][e])) {
 			a = 0.0;
-		} else if (close(r2[1][0], 0.5 * base[1][0])) {
+		} else if (close(r2[1][e], 0.5 * base[1][e])) {
 			a = -1.0;
 		}
-		const double slope = std::log(T2[1][0] / base[1][0]) / std::log(1.0e6 / T0);
+		const double slope = (base[1][e] == 0.0 && T2[1][e] == 0.0) ? 0.0 : std::log(T2[1][e] / base[1][e]) / std::log(1.0e6 / T0);
 		const double b = std::round(2.0 * slope) / 2.0;
 		bool ok = std::isfinite(a) && std::isfinite(b) && std::abs(slope - b) < 1e-9;
 		rt.mg_kappa_rho_exponent = a;
@@ -729,6 +774,7 @@ template <typename problem_t> class RadSystem : public HyperbolicSystem<problem_
 		} else if (rt.thermal_model != 0) {
 			amrex::Abort("RadSystem: the linearised thermal-emission hook is carried by the C-ABI together with the dust model only");
 		}
+		ismHooks(rt);
 		return rt;
 	}
 
@@ -810,6 +856,7 @@ template <typename problem_t> class RadSystem : public HyperbolicSystem<problem_
 		} else if (rt.thermal_model != 0) {
 			amrex::Abort("RadSystem: the linearised thermal-emission hook is carried by the C-ABI together with the dust model only");
 		}
+		ismHooks(rt);
 		return rt;
 	}
 	static auto lev() -> qk_level * { return qkhost::Runtime::get().lev; }
@@ -907,6 +954,29 @@ AMREX_GPU_HOST_DEVICE auto RadSystem<problem_t>::DefineOpacityExponentsAndLowerV
 	}
 	return exponents_and_values;
 }
+
+template <typename problem_t>
+AMREX_GPU_HOST_DEVICE auto RadSystem<problem_t>::DefinePhotoelectricHeatingE1Derivative(amrex::Real const /*temperature*/, amrex::Real const /*num_density*/) -> amrex::Real
+{
+	return 0.0;
+}
+template <typename problem_t>
+AMREX_GPU_HOST_DEVICE auto RadSystem<problem_t>::DefineNetCoolingRate(amrex::Real const /*temperature*/, amrex::Real const /*num_density*/)
+    -> quokka::valarray<double, nGroups_>
+{
+	quokka::valarray<double, nGroups_> cooling{};
+	cooling.fillin(0.0);
+	return cooling;
+}
+template <typename problem_t>
+AMREX_GPU_HOST_DEVICE auto RadSystem<problem_t>::DefineNetCoolingRateTempDerivative(amrex::Real const /*temperature*/, amrex::Real const /*num_density*/)
+    -> quokka::valarray<double, nGroups_>
+{
+	quokka::valarray<double, nGroups_> cooling{};
+	cooling.fillin(0.0);
+	return cooling;
+}
+template <typename problem_t> AMREX_GPU_HOST_DEVICE auto RadSystem<problem_t>::DefineCosmicRayHeatingRate(amrex::Real const /*num_density*/) -> double { return 0.0; }
 
 template <typename problem_t> AMREX_GPU_HOST_DEVICE auto RadSystem<problem_t>::ComputePlanckOpacity(const double /*rho*/, const double /*Tgas*/) -> amrex::Real
 {
@@ -1539,6 +1609,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	double elapsedSeconds_ = 0.0;
 	// radiation (reference src/QuokkaSimulation.hpp:127-131)
 	amrex::Real radiationCflNumber_ = 0.3;
+	amrex::Real dustGasInteractionCoeff_ = 2.5e-34; // erg cm^3 s^-1 K^-3/2 (QuokkaSimulation.hpp:127; radiation.dust_gas_interaction_coeff, :392)
 	int maxSubsteps_ = 10;
 	amrex::Long radiationCellUpdates_ = 0;
 	long radSolves_ = 0, radNewtonIterations_ = 0;
@@ -1617,6 +1688,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		amrex::ParmParse rpp("radiation"); // reference src/QuokkaSimulation.hpp:353-358
 		rpp.query("reconstruction_order", radiationReconstructionOrder_);
 		rpp.query("cfl", radiationCflNumber_);
+		rpp.query("dust_gas_interaction_coeff", dustGasInteractionCoeff_);
 		rpp.query("max_substeps", maxSubsteps_);
 		std::string walltime;
 		if (amrex::ParmParse().query("max_walltime", walltime)) { // H:M:S (reference src/simulation.hpp:618-628)

@@ -360,3 +360,94 @@ def marshak_dust_problem(ctx: Context, nx: int = 256, pow_mode: int = 0) -> Radh
 
     sim.set_initial_conditions(ic)
     return sim
+
+
+# ---------------------------------------------------------------------- RadLineCooling / RadLineCoolingMG
+class LineCoolingConstants:
+    """test_rad_line_cooling.cpp:19-36, test_rad_line_cooling_MG.cpp:19-42"""
+    cooling_rate, CR_heating_rate, PE_rate = 0.1, 0.03, 0.02
+    c = chat = 1.0
+    kappa0, T0, rho0, a_rad, mu, k_B, nu_unit = 0.0, 1.0, 1.0, 1.0, 1.5, 1.0, 1.0
+    erad_floor = a_rad * 1e-20
+    Erad_FUV = a_rad * T0 * T0 * T0 * T0
+    max_time, the_dt, line_index = 10.0, 1.0e-2, 0
+    boundaries = [1.00000000e-03, 1.77827941e-02, 3.16227766e-01, 5.62341325e+00, 1.00000000e+02]
+
+
+def line_cooling_problem(ctx: Context, multigroup: bool, dust_coeff: float, nx: int = 8) -> RadhydroSimulation:
+    """A uniform transparent medium (kappa = 0) cooled by a line (rate 0.1 T into group 0), heated by cosmic rays (0.03) and — four groups —
+    photoelectrically by the FUV group (0.02 E_FUV): the ISM hooks of the dust exchange.  dust_coeff: radiation.dust_gas_interaction_coeff of
+    the deck (tests/RadLineCooling.in: 1e-20, the decoupled branch; RadLineCoolingCoupled.in: 1e20)."""
+    S = LineCoolingConstants
+    ng = 4 if multigroup else 1
+    ncomp = RAD0 + 4 * ng
+    geom = Geometry(1, [nx], [0.0, 0.0, 0.0], [64.0, 1.0, 1.0], [1, 1, 1])
+    bcs = [([capi.BC_INT_DIR, 0, 0], [capi.BC_INT_DIR, 0, 0]) for _ in range(ncomp)]
+    traits = capi.traits(5.0 / 3.0, True, 1, mean_molecular_weight=S.mu, boltzmann_constant=S.k_B)
+    rt = capi.RadTraits(S.c, S.chat, S.a_rad, S.erad_floor, 0, 0, S.kappa0, S.kappa0, S.kappa0, 0, 0)
+    rt.enable_dust_gas_thermal_coupling_model, rt.dust_gas_interaction_coeff, rt.gas_dust_coupling_threshold = 1, float(dust_coeff), 1.0e-6
+    rt.cooling_linear_coeff[S.line_index] = S.cooling_rate
+    rt.cr_heating_rate = S.CR_heating_rate
+    if multigroup:
+        rt.set_groups(S.boundaries, S.nu_unit, PIECEWISE_CONSTANT, [0.0] * (ng + 1), [S.kappa0] * (ng + 1))
+        rt.enable_photoelectric_heating, rt.pe_heating_E1_derivative = 1, S.PE_rate / S.Erad_FUV
+    sim = RadhydroSimulation(ctx, geom, traits, rt, bcs, [nx, 1, 1], use_fused=False)
+    sim.radiationReconstructionOrder_ = 3
+    sim.stopTime_, sim.cflNumber_, sim.radiationCflNumber_, sim.maxTimesteps_ = S.max_time, 0.8, 0.8, 1000000
+    sim.initDt_ = sim.maxDt_ = S.the_dt
+    Egas = eint_from_tgas(S.rho0, S.T0, S.mu, kB=S.k_B)
+
+    def ic(i, j, k):
+        U = rad_state(ncomp, i.shape)
+        U[0], U[4], U[5] = S.rho0, Egas, Egas
+        for g in range(ng):
+            U[RAD0 + 4 * g] = S.Erad_FUV if (multigroup and g == ng - 1) else S.erad_floor
+        return U
+
+    sim.set_initial_conditions(ic)
+    return sim
+
+
+# ---------------------------------------------------------------------- RadMarshakDustPE
+class MarshakDustPEConstants:
+    """test_radiation_marshak_dust_and_PE.cpp:19-36 and the decks tests/RadMarshakDustPE{coupled,decoupled}.in"""
+    PE_rate = 1.0
+    c = chat = 1.0
+    rho0, CV, initial_T, a_rad, erad_floor, T_rad_L = 1.0, 1.0, 1.0, 1.0, 1.0e-6, 1.0
+    mu = 1.5 / CV
+    EradL = a_rad * T_rad_L * T_rad_L * T_rad_L * T_rad_L
+    kappa1 = kappa2 = 1e-20
+    boundaries = [1e-10, 30.0, 1e4]
+
+
+def marshak_dust_pe_problem(ctx: Context, dust_coeff: float, nx: int = 256) -> RadhydroSimulation:
+    """FUV radiation streaming freely (kappa = 1e-20) through gas it heats photoelectrically at the rate PE_rate * E_FUV; dust_coeff 1e20 / 1e-20
+    selects the coupled / decoupled branch of SolveGasDustRadiationEnergyExchangeWithPE.  Boundary functor as RadMarshakDust's."""
+    S = MarshakDustPEConstants
+    ng = 2
+    ncomp = RAD0 + 4 * ng
+    geom = Geometry(1, [nx], [0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [0, 1, 1])
+    bcs = [([capi.BC_EXT_DIR, 0, 0], [capi.BC_FOEXTRAP, 0, 0]) for _ in range(ncomp)]
+    traits = capi.traits(5.0 / 3.0, True, 1, mean_molecular_weight=S.mu, boltzmann_constant=1.0)
+    rt = capi.RadTraits(S.c, S.chat, S.a_rad, S.erad_floor, 1, 0, 0.0, 0.0, 0.0, 0, 0)
+    rt.enable_dust_gas_thermal_coupling_model, rt.dust_gas_interaction_coeff, rt.gas_dust_coupling_threshold = 1, float(dust_coeff), 1.0e-4
+    rt.enable_photoelectric_heating, rt.pe_heating_E1_derivative = 1, S.PE_rate
+    rt.set_groups(S.boundaries, 1.0, PIECEWISE_CONSTANT, [0.0] * (ng + 1), [S.kappa1, S.kappa2, S.kappa2])
+    Egas = S.initial_T * S.CV
+    gas = [S.rho0, 0.0, 0.0, 0.0, Egas, Egas]
+    left = gas + [S.erad_floor, S.erad_floor * S.c, 0.0, 0.0, S.EradL, S.EradL * S.c, 0.0, 0.0]
+    right = {"values": gas + [0.0] * (4 * ng), "interior": list(range(RAD0, ncomp))}
+    sim = RadhydroSimulation(ctx, geom, traits, rt, bcs, [nx, 1, 1], use_fused=False, dirichlet={(0, 0): left, (0, 1): right})
+    sim.is_hydro_enabled = False
+    sim.radiationReconstructionOrder_ = 3
+    sim.stopTime_, sim.maxDt_, sim.radiationCflNumber_, sim.maxTimesteps_ = 0.5, 1.0, 0.8, 5000
+
+    def ic(i, j, k):
+        U = rad_state(ncomp, i.shape)
+        U[0], U[4], U[5] = S.rho0, Egas, Egas
+        for g in range(ng):
+            U[RAD0 + 4 * g] = S.erad_floor
+        return U
+
+    sim.set_initial_conditions(ic)
+    return sim

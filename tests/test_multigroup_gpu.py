@@ -10,9 +10,9 @@ import numpy as np
 import pytest
 import torch
 
-from oracle.pyoracle import (MARSHAK_DUST, MARSHAK_VAYTET, PIECEWISE_CONSTANT, PPL_FIXED_SLOPE, PPL_FULL_SPECTRUM, PULSE_MG, PULSE_MG_GREY, RADDUST, RADDUST_MG,
+from oracle.pyoracle import (LINE_COOLING, LINE_COOLING_MG, MARSHAK_DUST, MARSHAK_DUST_PE, MARSHAK_VAYTET, PIECEWISE_CONSTANT, PPL_FIXED_SLOPE, PPL_FULL_SPECTRUM, PULSE_MG, PULSE_MG_GREY, RADDUST, RADDUST_MG,
                              RADSHOCK_MG, RADTUBE)
-from test_multigroup_oracle import A_RAD, H_PLANCK, K_B, marshak_dust_error, pulse_mg_error, raddust_error, radshock_mg_error, tube_table
+from test_multigroup_oracle import (A_RAD, H_PLANCK, K_B, line_cooling_error, marshak_dust_error, marshak_dust_pe_error, pulse_mg_error, raddust_error, radshock_mg_error, tube_table)
 
 pytestmark = pytest.mark.gpu
 
@@ -24,7 +24,8 @@ def seed(so, sg):
     sg._signal_of_state_new = None
 
 
-def compare(so, sg, tol=1e-12, mom_scale=None):
+def compare(so, sg, tol=1e-12, mom_scale=None, energy_scale=None):
+    """energy_scale: a group that only holds its floor (|E_g| << the radiation energy of the problem) is compared on that scale"""
     Uo = so.valid(0)
     Ug = sg.state_new_cc_.valid(0).cpu().numpy()
     assert not np.isnan(Ug).any()
@@ -37,6 +38,8 @@ def compare(so, sg, tol=1e-12, mom_scale=None):
         elif mom_scale is not None and (n in (1, 2, 3) or (n >= 6 and (n - 6) % 4 != 0)):
             # momenta / radiation fluxes that cancel over the domain: absolute measure on the scale of the matching energy-like quantity
             assert num <= tol * max(den, mom_scale[n]), (n, num, den)
+        elif energy_scale is not None and n >= 6 and (n - 6) % 4 == 0:
+            assert num <= tol * max(den, energy_scale), (n, num, den)
         else:
             assert num <= tol * den, (n, num / den)
     return Uo, Ug
@@ -293,4 +296,47 @@ def test_multigroup_dust_model_decoupled_branch_matches_oracle_and_criterion(ctx
     assert sg.rad_counters["solves"] == co["solves"] == co["decoupled"]
     assert sg.rad_counters["decoupled"] == co["decoupled"]
     err = marshak_dust_error(sg.state_new_cc_.valid(0).cpu().numpy()[:, 0, 0, :], sg.tNew_)
+    assert err < 0.01, err
+
+
+@pytest.mark.parametrize("multigroup,dust_coeff", [(False, 1e-20), (True, 1e-20), (True, 1e20)])
+def test_line_cooling_problems_match_oracle_and_criterion(ctx, oracle, multigroup, dust_coeff):
+    """RadLineCooling (one group: the cooling / cosmic-ray terms of the DUST instantiation of the single-group kernel) and RadLineCoolingMG with
+    both decks (the decoupled and the coupled branch of the multigroup solve with photoelectric heating); kappa = 0: no libm beyond sqrt and the
+    Planck fractions of a state that does not emit"""
+    from quokka_amd.radhydro_multigroup import line_cooling_problem
+    so = oracle.sim(LINE_COOLING_MG if multigroup else LINE_COOLING, 1, [8, 1, 1], [0, 0, 0], [64.0, 1, 1], [1, 1, 1], max_grid_size=[8, 1, 1], dust_coeff=dust_coeff)
+    sg = line_cooling_problem(ctx, multigroup, dust_coeff)
+    assert np.array_equal(so.valid(0), sg.state_new_cc_.valid(0).cpu().numpy())
+    ts, us = [], []
+    for it in range(1000):
+        assert so.step() and sg.step(), it
+        assert so.dt == sg.dt_
+        ts.append(sg.tNew_)
+        us.append(sg.state_new_cc_.valid(0).cpu().numpy()[:, 0, 0, 0])
+        if it in (0, 9, 99, 999):
+            compare(so, sg, tol=1e-12, mom_scale=flux_scales(so.valid(0), 1.0, cs=1.0, fscale=1e-6))
+    co = so.rad_counters()
+    assert sg.rad_counters["solves"] == co["solves"] and sg.rad_counters["decoupled"] == co["decoupled"]
+    assert sg.rad_counters["newton_iterations"] == co["newton_iterations"]
+    err = line_cooling_error(np.array(ts), np.array(us), 0.05 if multigroup else 0.03)
+    assert err < 0.0005, err
+
+
+@pytest.mark.parametrize("dust_coeff", [1e20, 1e-20])
+def test_photoelectric_heating_front_matches_oracle_and_criterion(ctx, oracle, dust_coeff):
+    """RadMarshakDustPE with its two decks: the Jacobian with the FUV column and SolveLinearEqsWithLastColumn (coupled), the scalar gas-energy solve
+    with the photoelectric term (decoupled)"""
+    from quokka_amd.radhydro_multigroup import marshak_dust_pe_problem
+    so = oracle.sim(MARSHAK_DUST_PE, 1, [256, 1, 1], [0, 0, 0], [1.0, 1, 1], [0, 1, 1], max_grid_size=[256, 1, 1], dust_coeff=dust_coeff)
+    sg = marshak_dust_pe_problem(ctx, dust_coeff)
+    assert np.array_equal(so.valid(0), sg.state_new_cc_.valid(0).cpu().numpy())
+    assert so.evolve() and sg.evolve() and so.istep == sg.istep
+    # (the IR group holds its floor, 1e-6 of the FUV energy density: compared on the scale of the FUV group)
+    ms = flux_scales(so.valid(0), 1.0, cs=1.0, fscale=1e-6)
+    ms[7] = ms[8] = ms[9] = 1.0 * np.abs(so.valid(0)[10]).sum()  # c * sum E_FUV: the IR group is rounding noise around its floor
+    compare(so, sg, tol=1e-11, mom_scale=ms, energy_scale=np.abs(so.valid(0)[10]).sum())
+    co = so.rad_counters()
+    assert sg.rad_counters["solves"] == co["solves"] and sg.rad_counters["decoupled"] == co["decoupled"]
+    err = marshak_dust_pe_error(sg.state_new_cc_.valid(0).cpu().numpy()[:, 0, 0, :], sg.tNew_)
     assert err < 0.01, err

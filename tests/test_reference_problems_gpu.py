@@ -137,6 +137,28 @@ def test_unmodified_two_group_marshak_wave_with_dust_meets_the_reference_criteri
     assert rc == 0, out[-2500:]
 
 
+def test_unmodified_line_cooling_problem_meets_the_reference_criterion(tmp_path):
+    """RadLineCooling, unchanged: the problem's DefineNetCoolingRate / ...TempDerivative / DefineCosmicRayHeatingRate specialisations are sampled on the
+    host into the closed set (cooling linear in T, constant heating).  Exit status 0 = within 0.0005 of the analytic cooling curve."""
+    rc, out = run([exe("ref_RadLineCooling"), os.path.join(HOST, "decks", "RadLineCooling.in")], str(tmp_path))
+    assert rc == 0, out[-2500:]
+
+
+@pytest.mark.parametrize("coeff", ["1e-20", "1e20"])
+def test_unmodified_multigroup_line_cooling_problem_meets_the_reference_criterion(tmp_path, coeff):
+    """RadLineCoolingMG, unchanged, with both of the reference's decks (RadLineCooling.in: decoupled gas and dust; RadLineCoolingCoupled.in):
+    ISM_Traits::enable_photoelectric_heating, DefinePhotoelectricHeatingE1Derivative.  Exit status 0 = within 0.0005."""
+    rc, out = run([exe("ref_RadLineCoolingMG"), os.path.join(HOST, "decks", "RadLineCooling.in"), f"radiation.dust_gas_interaction_coeff={coeff}"], str(tmp_path))
+    assert rc == 0, out[-2500:]
+
+
+@pytest.mark.parametrize("coeff", ["1e20", "1e-20"])
+def test_unmodified_photoelectric_heating_front_meets_the_reference_criterion(tmp_path, coeff):
+    """RadMarshakDustPE, unchanged, with both decks (coupled / decoupled).  Exit status 0 = within 0.01 of T = 1 + (t - x), E_FUV = 1 behind the front."""
+    rc, out = run([exe("ref_RadMarshakDustPE"), os.path.join(HOST, "decks", "RadMarshakDustPE.in"), f"radiation.dust_gas_interaction_coeff={coeff}"], str(tmp_path))
+    assert rc == 0, out[-2500:]
+
+
 def test_unmodified_multigroup_pulse_meets_the_reference_criterion(tmp_path):
     """RadhydroPulseMGconst, unchanged: two simulations in one executable (grey at rest, 4 groups advected), compared with each other; 0.006"""
     rc, out = run([exe("ref_RadhydroPulseMGconst"), os.path.join(HOST, "decks", "RadhydroPulse.in")], str(tmp_path))
