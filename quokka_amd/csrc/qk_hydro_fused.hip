@@ -592,7 +592,11 @@ template <int ORDER, int STAGE, int NS> __global__ void __launch_bounds__(XB) k_
 }
 
 // ---------------------------------------------------------------------------------------------- Y / Z sweeps (marching)
-template <int DIR, int ORDER, int STAGE, bool LAST, int NS> __global__ void __launch_bounds__(256) k_sweep_march(SweepArgs a, Eos eos)
+#ifndef QK_MARCH_BY
+#define QK_MARCH_BY 4
+#endif
+constexpr int MARCH_BY = QK_MARCH_BY; // rows of the other transverse axis per workgroup (64 x MARCH_BY threads)
+template <int DIR, int ORDER, int STAGE, bool LAST, int NS> __global__ void __launch_bounds__(64 * MARCH_BY) k_sweep_march(SweepArgs a, Eos eos)
 {
 	constexpr int NV = NVAR + NS; // hydro variables + passive scalars
 	constexpr int RHS_DIVV = S_RHS + NV;
@@ -603,7 +607,7 @@ template <int DIR, int ORDER, int STAGE, bool LAST, int NS> __global__ void __la
 	const SGeom g = a.geom[b];
 	constexpr int OT = (DIR == 1) ? 2 : 1; // the other transverse axis (besides x)
 	const int i_raw = bx.lo[0] + blockIdx.x * 64 + threadIdx.x;
-	const int ot_raw = bx.lo[OT] + blockIdx.y * 4 + threadIdx.y;
+	const int ot_raw = bx.lo[OT] + blockIdx.y * MARCH_BY + threadIdx.y;
 	// lanes beyond the box stay in the wave (clamped addresses, masked stores) so that wave reductions are well defined
 	const bool live = (i_raw <= bx.hi[0]) && (ot_raw <= bx.hi[OT]);
 	const int i = min(i_raw, bx.hi[0]);
@@ -641,7 +645,7 @@ template <int DIR, int ORDER, int STAGE, bool LAST, int NS> __global__ void __la
 	// The cell a step completes (march position p - 3) was loaded as the newest cell three steps earlier: when the old state IS the input
 	// state (stage 1) its conserved values wait in a per-lane ring of three LDS slots (no barriers: a lane only touches its own slots).
 	constexpr bool RING = LAST && (STAGE == 1);
-	__shared__ double s_ring[RING ? 3 : 1][RING ? NV : 1][RING ? 256 : 1];
+	__shared__ double s_ring[RING ? 3 : 1][RING ? NV : 1][RING ? 64 * MARCH_BY : 1];
 	const int tid = threadIdx.y * 64 + threadIdx.x;
 	const bool ring = RING && a.same_old;
 	int slot = 0;
@@ -888,9 +892,9 @@ template <int ORDER, int STAGE, int NS> void launchSweeps(qk_level *lev, hipStre
 		ay.inv_dx = 1.0 / args->dx[1];
 		ay.dx = args->dx[1];
 		ay.nseg = marchSegments(lev, 1, 2);
-		const dim3 grid((lev->maxlen[0] + 63) / 64, (lev->maxlen[2] + 3) / 4, lev->nboxes * ay.nseg);
+		const dim3 grid((lev->maxlen[0] + 63) / 64, (lev->maxlen[2] + MARCH_BY - 1) / MARCH_BY, lev->nboxes * ay.nseg);
 		ProfScope ps(lev->ctx, s, "k_sweep_y");
-		hipLaunchKernelGGL((k_sweep_march<1, ORDER, STAGE, false, NS>), grid, dim3(64, 4), 0, s, ay, eos);
+		hipLaunchKernelGGL((k_sweep_march<1, ORDER, STAGE, false, NS>), grid, dim3(64, MARCH_BY), 0, s, ay, eos);
 	}
 	// Z (+ epilogue)
 	{
@@ -902,9 +906,9 @@ template <int ORDER, int STAGE, int NS> void launchSweeps(qk_level *lev, hipStre
 		az.inv_dx = 1.0 / args->dx[2];
 		az.dx = args->dx[2];
 		az.nseg = marchSegments(lev, 2, 1);
-		const dim3 grid((lev->maxlen[0] + 63) / 64, (lev->maxlen[1] + 3) / 4, lev->nboxes * az.nseg);
+		const dim3 grid((lev->maxlen[0] + 63) / 64, (lev->maxlen[1] + MARCH_BY - 1) / MARCH_BY, lev->nboxes * az.nseg);
 		ProfScope ps(lev->ctx, s, "k_sweep_z");
-		hipLaunchKernelGGL((k_sweep_march<2, ORDER, STAGE, true, NS>), grid, dim3(64, 4), 0, s, az, eos);
+		hipLaunchKernelGGL((k_sweep_march<2, ORDER, STAGE, true, NS>), grid, dim3(64, MARCH_BY), 0, s, az, eos);
 	}
 }
 
