@@ -262,8 +262,8 @@ void *orc_sim_create(orc_sim_config const *c)
 		sim->rad.rt.pow_mode = c->rad_pow_mode;
 	} else if (c->problem == 6) {
 		setupScalarContact(*sim, c->nscalars > 0 ? c->nscalars : 1);
-	} else if (c->problem == 5) {
-		setupStreaming(*sim);
+	} else if (c->problem == 5 || c->problem == 29) {
+		setupStreaming(*sim, c->problem == 29 ? 1 : 0);
 		sim->rad.rt.pow_mode = c->rad_pow_mode;
 	} else if (c->problem == 4) {
 		setupRadShock(*sim);

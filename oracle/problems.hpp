@@ -593,7 +593,9 @@ struct StreamingConstants { // :24-31
 	static constexpr double rho = 1.0;
 };
 
-inline void setupStreaming(HydroSim &sim)
+// direction 1: src/problems/RadStreamingY/test_radiation_streaming_y.cpp (built for AMREX_SPACEDIM >= 2; c_hat = c there, max_time = 0.2 from
+// tests/RadStreamingY.in): the same front entering through the lower y face of a domain periodic in x
+inline void setupStreaming(HydroSim &sim, int direction = 0)
 {
 	using S = StreamingConstants;
 	sim.hydro.tr.eos.tr.gamma = 5. / 3.; // :33-37
@@ -605,7 +607,7 @@ inline void setupStreaming(HydroSim &sim)
 	sim.is_radiation_enabled = true; // :39-49
 	sim.is_hydro_enabled = false;
 	sim.rad.rt.c_light = S::c; // :51-57
-	sim.rad.rt.c_hat = S::chat;
+	sim.rad.rt.c_hat = (direction == 0) ? S::chat : S::c; // (test_radiation_streaming_y.cpp:25)
 	sim.rad.rt.radiation_constant = 1.0;
 	sim.rad.rt.Erad_floor = S::initial_Erad;
 	sim.rad.rt.beta_order = 0;
@@ -619,25 +621,26 @@ inline void setupStreaming(HydroSim &sim)
 	// problem_main :167-195
 	sim.BCs_cc.assign(sim.ncomp_cc, BCRec{});
 	for (int n = 0; n < sim.ncomp_cc; ++n) {
-		sim.BCs_cc[n].lo[0] = ext_dir;
-		sim.BCs_cc[n].hi[0] = foextrap;
+		sim.BCs_cc[n].lo[direction] = ext_dir;
+		sim.BCs_cc[n].hi[direction] = foextrap;
 	}
 	sim.radiationReconstructionOrder_ = 3;
-	sim.stopTime_ = 1.0;
+	sim.stopTime_ = (direction == 0) ? 1.0 : 0.2;
 	sim.radiationCflNumber_ = 0.8;
 	sim.maxDt_ = 1e-2;
 	sim.maxTimesteps_ = 5000;
 
 	// setCustomBoundaryConditions :100-165 (it does not look at the BCRec: the foextrap fill of the upper face is overwritten too)
-	sim.customBC = [](int i, int j, int k, Array4<double> const &consVar, Box const &dom, double /*time*/) {
-		if (i < dom.lo[0]) {
+	sim.customBC = [direction](int i, int j, int k, Array4<double> const &consVar, Box const &dom, double /*time*/) {
+		const int idx[3] = {i, j, k};
+		if (idx[direction] < dom.lo[direction]) {
 			const double Erad = 1.0;
 			const double Frad = S::c * Erad;
 			consVar(i, j, k, kNumHydroVars + 0) = Erad;
-			consVar(i, j, k, kNumHydroVars + 1) = Frad;
-			consVar(i, j, k, kNumHydroVars + 2) = 0;
+			consVar(i, j, k, kNumHydroVars + 1) = (direction == 0) ? Frad : 0.;
+			consVar(i, j, k, kNumHydroVars + 2) = (direction == 1) ? Frad : 0.;
 			consVar(i, j, k, kNumHydroVars + 3) = 0;
-		} else if (i >= dom.hi[0]) {
+		} else if (idx[direction] >= dom.hi[direction]) {
 			consVar(i, j, k, kNumHydroVars + 0) = S::initial_Erad;
 			consVar(i, j, k, kNumHydroVars + 1) = 0;
 			consVar(i, j, k, kNumHydroVars + 2) = 0;

@@ -27,6 +27,7 @@ RADDUST_MG = 24  # RadDustMG: the same relaxation with 4 photon groups (multigro
 LINE_COOLING = 26  # RadLineCooling: one group, line cooling linear in T + cosmic-ray heating (dust_coeff = the deck's coefficient)
 LINE_COOLING_MG = 27  # RadLineCoolingMG: four groups + photoelectric heating by the last group
 MARSHAK_DUST_PE = 28  # RadMarshakDustPE: FUV front heating the gas photoelectrically
+STREAMING_Y = 29  # RadStreamingY: the streaming front along y in a 2-D build
 MARSHAK_DUST = 25  # RadMarshakDust: two groups (IR / FUV), dust model with the decoupled branch
 BLAST2D = 23  # HydroBlast2D: circular blast in a reflecting box, as a 2-D build or as a 3-D build uniform in z
 # OpacityModel (radiation_system.hpp:64-71)

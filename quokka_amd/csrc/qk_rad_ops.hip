@@ -501,9 +501,8 @@ int qk_rad_computeRadiationFluxes(qk_level *lev, qk_stream s, const qk_rad_trait
 	if (int rc = checkRad(lev->ctx, rt); rc != QK_OK) {
 		return rc;
 	}
-	QK_REQUIRE(lev->ctx, cons_t && flux && flux[0] && (ndim < 3 || (flux[1] && flux[2])), "computeRadiationFluxes: NULL array");
+	QK_REQUIRE(lev->ctx, cons_t && flux && flux[0] && (ndim < 2 || flux[1]) && (ndim < 3 || flux[2]), "computeRadiationFluxes: NULL array");
 	QK_REQUIRE(lev->ctx, order >= 1 && order <= 3, "computeRadiationFluxes: reconstruction order must be 1..3");
-	QK_REQUIRE(lev->ctx, lev->ndim != 2, "computeRadiationFluxes: the radiation operators exist for 1-D and 3-D builds");
 	QK_REQUIRE(lev->ctx, ndim == lev->ndim, "computeRadiationFluxes: ndim mismatch");
 	const Rad rad(*rt);
 #define QK_RAD_DIR(D)                                                                                                                                \
@@ -514,7 +513,9 @@ int qk_rad_computeRadiationFluxes(qk_level *lev, qk_stream s, const qk_rad_trait
 	} else {                                                                                                                                     \
 		launchRadFusedFlux<D, 1>(lev, s, rad, cons_t, flux[D]);                                                                              \
 	}
-	if (ndim == 3) { // (state arrays carry nghost_cc = 4 ghost cells throughout the library; the slab below is sized for that)
+	// 2-D builds: the radiation fluxes do not permute components with the direction (radiation_system.hpp:1026-1040), so the X2 view of
+	// ArrayView_2d.hpp and the cyclic one of the 3-D build address the same cells: the 3-D kernels on a single plane.
+	if (ndim >= 2) { // (state arrays carry nghost_cc = 4 ghost cells throughout the library; the slab below is sized for that)
 		if (order == 3) {
 			launchRadXFlux<3>(lev, s, rad, cons_t, flux[0], 4);
 		} else if (order == 2) {
@@ -534,8 +535,10 @@ int qk_rad_computeRadiationFluxes(qk_level *lev, qk_stream s, const qk_rad_trait
 	} else {                                                                                                                                     \
 		launchRadMarchFlux<D, 1>(lev, s, rad, cons_t, flux[D]);                                                                              \
 	}
-	if (ndim == 3) {
+	if (ndim >= 2) {
 		QK_RAD_MARCH(1)
+	}
+	if (ndim == 3) {
 		QK_RAD_MARCH(2)
 	}
 #undef QK_RAD_MARCH
@@ -551,10 +554,9 @@ int qk_rad_PredictStep(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int 
 	if (int rc = checkRad(lev->ctx, rt); rc != QK_OK) {
 		return rc;
 	}
-	QK_REQUIRE(lev->ctx, old_t && new_t && fluxArray && dx_in && fluxArray[0] && (ndim < 3 || (fluxArray[1] && fluxArray[2])), "rad PredictStep: NULL");
-	QK_REQUIRE(lev->ctx, ndim != 2, "rad PredictStep: the radiation operators exist for 1-D and 3-D builds");
+	QK_REQUIRE(lev->ctx, old_t && new_t && fluxArray && dx_in && fluxArray[0] && (ndim < 2 || fluxArray[1]) && (ndim < 3 || fluxArray[2]), "rad PredictStep: NULL");
 	const Rad rad(*rt);
-	const qk_array4 *f0 = fluxArray[0], *f1 = (ndim == 3) ? fluxArray[1] : nullptr, *f2 = (ndim == 3) ? fluxArray[2] : nullptr;
+	const qk_array4 *f0 = fluxArray[0], *f1 = (ndim >= 2) ? fluxArray[1] : nullptr, *f2 = (ndim == 3) ? fluxArray[2] : nullptr;
 	const double dx0 = dx_in[0], dx1 = dx_in[1], dx2 = dx_in[2];
 	launchRad(lev, s, 0, -1, "rad_PredictStep", [=] __device__(int b, int i, int j, int k, bool valid) {
 		if (!valid) {
@@ -568,10 +570,12 @@ int qk_rad_PredictStep(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int 
 #pragma unroll
 			for (int n = 0; n < NRAD; ++n) {
 				double d = (dt / dx0) * (x1(i, j, k, pg + n) - x1(i + 1, j, k, pg + n));
-				if (ndim == 3) {
+				if (ndim >= 2) { // radiation_system.hpp:681-690
 					RA4 x2(f1[b]);
-					RA4 x3(f2[b]);
 					d = d + (dt / dx1) * (x2(i, j, k, pg + n) - x2(i, j + 1, k, pg + n));
+				}
+				if (ndim == 3) {
+					RA4 x3(f2[b]);
 					d = d + (dt / dx2) * (x3(i, j, k, pg + n) - x3(i, j, k + 1, pg + n));
 				}
 				cons[n] = Uo(i, j, k, RAD0 + pg + n) + d;
@@ -615,11 +619,10 @@ int qk_rad_AddFluxesRK2(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int
 		return rc;
 	}
 	QK_REQUIRE(lev->ctx, new_t && U0_t && U1_t && fluxArrayOld && fluxArray && dx_in && fluxArrayOld[0] && fluxArray[0], "rad AddFluxesRK2: NULL");
-	QK_REQUIRE(lev->ctx, ndim < 3 || (fluxArrayOld[1] && fluxArrayOld[2] && fluxArray[1] && fluxArray[2]), "rad AddFluxesRK2: NULL flux");
-	QK_REQUIRE(lev->ctx, ndim != 2, "rad AddFluxesRK2: the radiation operators exist for 1-D and 3-D builds");
+	QK_REQUIRE(lev->ctx, (ndim < 2 || (fluxArrayOld[1] && fluxArray[1])) && (ndim < 3 || (fluxArrayOld[2] && fluxArray[2])), "rad AddFluxesRK2: NULL flux");
 	const Rad rad(*rt);
-	const qk_array4 *o0 = fluxArrayOld[0], *o1 = (ndim == 3) ? fluxArrayOld[1] : nullptr, *o2 = (ndim == 3) ? fluxArrayOld[2] : nullptr;
-	const qk_array4 *f0 = fluxArray[0], *f1 = (ndim == 3) ? fluxArray[1] : nullptr, *f2 = (ndim == 3) ? fluxArray[2] : nullptr;
+	const qk_array4 *o0 = fluxArrayOld[0], *o1 = (ndim >= 2) ? fluxArrayOld[1] : nullptr, *o2 = (ndim == 3) ? fluxArrayOld[2] : nullptr;
+	const qk_array4 *f0 = fluxArray[0], *f1 = (ndim >= 2) ? fluxArray[1] : nullptr, *f2 = (ndim == 3) ? fluxArray[2] : nullptr;
 	const double dx0 = dx_in[0], dx1 = dx_in[1], dx2 = dx_in[2];
 	launchRad(lev, s, 0, -1, "rad_AddFluxesRK2", [=] __device__(int b, int i, int j, int k, bool valid) {
 		if (!valid) {
@@ -644,15 +647,19 @@ int qk_rad_AddFluxesRK2(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int
 					RA4 xo(o0[b]);
 					s0 = (dt / dx0) * (xo(i, j, k, pg + n) - xo(i + 1, j, k, pg + n));
 				}
-				if (ndim == 3) {
+				if (ndim >= 2) { // radiation_system.hpp:728-757
 					RA4 yn(f1[b]);
-					RA4 zn(f2[b]);
 					s1 = s1 + (dt / dx1) * (yn(i, j, k, pg + n) - yn(i, j + 1, k, pg + n));
-					s1 = s1 + (dt / dx2) * (zn(i, j, k, pg + n) - zn(i, j, k + 1, pg + n));
 					if (useOld) {
 						RA4 yo(o1[b]);
-						RA4 zo(o2[b]);
 						s0 = s0 + (dt / dx1) * (yo(i, j, k, pg + n) - yo(i, j + 1, k, pg + n));
+					}
+				}
+				if (ndim == 3) {
+					RA4 zn(f2[b]);
+					s1 = s1 + (dt / dx2) * (zn(i, j, k, pg + n) - zn(i, j, k + 1, pg + n));
+					if (useOld) {
+						RA4 zo(o2[b]);
 						s0 = s0 + (dt / dx2) * (zo(i, j, k, pg + n) - zo(i, j, k + 1, pg + n));
 					}
 				}

@@ -366,6 +366,29 @@ def streaming_problem(ctx: Context, nx: int = 1000, pow_mode: int = 0) -> Radhyd
     return sim
 
 
+def streaming_y_problem(ctx: Context, n_cell=(4, 100), pow_mode: int = 0, max_grid_size=None) -> RadhydroSimulation:
+    """reference src/problems/RadStreamingY/test_radiation_streaming_y.cpp + tests/RadStreamingY.in (a 2-D build; c_hat = c, max_time = 0.2): the
+    same front entering through the lower y face of a domain periodic in x — the radiation operators on an AMREX_SPACEDIM == 2 level."""
+    S = StreamingConstants
+    geom = Geometry(2, list(n_cell), [0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [1, 0, 1])
+    bcs = [([capi.BC_INT_DIR, capi.BC_EXT_DIR, 0], [capi.BC_INT_DIR, capi.BC_FOEXTRAP, 0]) for _ in range(10)]
+    traits = capi.traits(5.0 / 3.0, True, 2, mean_molecular_weight=1.0, boltzmann_constant=1.0)
+    rt = capi.RadTraits(S.c, S.c, 1.0, S.initial_Erad, 0, 0, S.kappa0, S.kappa0, S.kappa0, pow_mode, 0)
+    gas = [S.rho, 0.0, 0.0, 0.0, S.initial_Egas, S.initial_Egas]
+    sim = RadhydroSimulation(ctx, geom, traits, rt, bcs, list(max_grid_size) if max_grid_size else [n_cell[0], n_cell[1], 1], use_fused=False,
+                             dirichlet={(1, 0): gas + [1.0, 0.0, S.c * 1.0, 0.0], (1, 1): gas + [S.initial_Erad, 0.0, 0.0, 0.0]})
+    sim.is_hydro_enabled = False
+    sim.radiationReconstructionOrder_, sim.stopTime_, sim.radiationCflNumber_, sim.maxDt_, sim.maxTimesteps_ = 3, 0.2, 0.8, 1e-2, 5000
+
+    def ic(i, j, k):
+        U = np.zeros((10,) + i.shape)
+        U[0], U[4], U[5], U[6] = S.rho, S.initial_Egas, S.initial_Egas, S.initial_Erad
+        return U
+
+    sim.set_initial_conditions(ic)
+    return sim
+
+
 class SuOlsonConstants:
     """reference src/problems/RadSuOlson/test_radiation_SuOlson.cpp:21-33"""
     eps_SuOlson, kappa, rho0, T_hohlraum, x0, t0 = 1.0, 1.0, 1.0, 1.0, 0.5, 10.0

@@ -125,6 +125,20 @@ def test_radiative_shock_meets_the_reference_criterion(oracle):
     assert err > 1e-4  # (a discretised shock: an implausibly small error would mean the comparison is not looking at the solution)
 
 
+def test_streaming_front_along_y_in_a_2d_build_meets_the_reference_criterion(oracle):
+    """RadStreamingY (src/problems/RadStreamingY/test_radiation_streaming_y.cpp:222-247, built for AMREX_SPACEDIM >= 2; deck tests/RadStreamingY.in:
+    4 x 100 cells, max_time = 0.2): the front enters through the lower y face; relative L1 error < 0.05; every x column carries the same profile"""
+    from oracle.pyoracle import STREAMING_Y
+    s = oracle.sim(STREAMING_Y, 2, [4, 100, 1], [0, 0, 0], [1.0, 1.0, 1.0], [1, 0, 1], max_grid_size=[4, 100, 1])
+    assert s.evolve() and abs(s.time - 0.2) < 1e-15
+    U = s.valid(0)
+    y = (np.arange(100) + 0.5) / 100
+    exact = np.where(y <= 1.0 * 0.2, 1.0, 0.0)
+    err = float(np.abs(U[6, 0, :, 0] - exact).sum() / np.abs(exact).sum())
+    assert err < 0.05, err
+    assert all(np.array_equal(U[:, 0, :, 0], U[:, 0, :, i]) for i in range(1, 4)) and np.all(U[7] == 0.0) and U[8].max() > 0.5
+
+
 def test_streaming_radiation_front_meets_the_reference_criterion(oracle):
     """RadStreaming (src/problems/RadStreaming/test_radiation_streaming.cpp:197-222): radiation only, Levermore closure at reduced
     flux 1, beta_order 0, an incident flux F = cE at the lower face; E_rad after t = 1 against the step function at x = c_hat t,

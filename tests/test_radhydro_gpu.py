@@ -134,6 +134,26 @@ def test_streaming_front_matches_oracle_and_the_reference_criterion(ctx, oracle)
     assert np.abs(Ug[6, 0, 0] - exact).sum() / exact.sum() < 0.01
 
 
+def test_streaming_front_along_y_in_a_2d_build_matches_oracle_and_criterion(ctx, oracle):
+    """RadStreamingY: the radiation operators on an AMREX_SPACEDIM == 2 level (LDS slab kernel along x, marching kernel along y on the single
+    plane; PredictStep / AddFluxesRK2 with the x and y terms; Dirichlet faces in y) — two boxes, bit for bit, and the reference's criterion"""
+    from oracle.pyoracle import STREAMING_Y
+    from quokka_amd.radhydro import streaming_y_problem
+    so = oracle.sim(STREAMING_Y, 2, [8, 100, 1], [0, 0, 0], [1.0, 1.0, 1.0], [1, 0, 1], max_grid_size=[8, 50, 1], rad_pow_mode=1)
+    sg = streaming_y_problem(ctx, (8, 100), pow_mode=1, max_grid_size=[8, 50, 1])
+    assert so.nboxes == sg.lev.nboxes == 2
+    assert so.evolve() and sg.evolve()
+    assert (so.istep, so.time) == (sg.istep, sg.tNew_)
+    for b in range(so.nboxes):
+        Uo, Ug = so.valid(b), sg.state_new_cc_.valid(b).cpu().numpy()
+        assert np.array_equal(Uo, Ug), (b, rel_l1(Ug, Uo))
+    U = np.concatenate([sg.state_new_cc_.valid(b).cpu().numpy() for b in range(sg.lev.nboxes)], axis=2) if sg.lev.nboxes > 1 else sg.state_new_cc_.valid(0).cpu().numpy()
+    y = (np.arange(100) + 0.5) / 100
+    exact = np.where(y <= 0.2, 1.0, 0.0)
+    assert np.abs(U[6, 0, :, 0] - exact).sum() / exact.sum() < 0.05
+    assert np.all(U[7] == 0.0) and U[8].max() > 0.5
+
+
 def test_shell_accelerates_as_the_thin_shell_solution_predicts(ctx):
     """The physics check the reference has for RadhydroShell (extern/dust_shell/analyze.py:50-57 plots it; no tolerance there): the
     density-weighted mean speed of the shell against the thin-shell solution M(R) = sqrt(2) M0 sqrt(1 - 1/R).  At 128^3 the shell

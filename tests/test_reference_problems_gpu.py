@@ -198,6 +198,13 @@ def test_unmodified_nscbc_vortex_runs_in_2d(tmp_path):
     assert np.abs(py / rho).max() > 50.0 and np.abs(px / rho - 1.0e4).max() < 1.0e3
 
 
+def test_unmodified_streaming_front_along_y_meets_the_reference_criterion(tmp_path):
+    """RadStreamingY, unchanged, as the 2-D build its CMakeLists.txt asks for: the radiation operators on an AMREX_SPACEDIM == 2 level, Dirichlet
+    faces in y written by the problem's own boundary functor.  Exit status 0 = within 0.05 of the step function at y = c t."""
+    rc, out = run([exe("ref_RadStreamingY"), os.path.join(HOST, "decks", "RadStreamingY.in")], str(tmp_path))
+    assert rc == 0, out[-2500:]
+
+
 def test_unmodified_quirk_problem_meets_the_reference_criterion_and_matches_the_python_driver(tmp_path, ctx):
     """HydroQuirk, unchanged, as the 2-D build the reference's CMake enables it for: its computeAfterTimestep locates the shock's box with
     MFIter / Box::contains(IntVect) and evaluates the entropy jump with amrex::launch on a single-cell box into an amrex::AsyncArray; exit
