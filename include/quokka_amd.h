@@ -74,11 +74,11 @@ typedef struct qk_hydro_traits {
 	double boltzmann_constant;
 	int reconstruct_eint;
 	int nscalars;  /* Physics_Traits::numPassiveScalars, 0..QK_MAX_SCALARS: carried by the reference-shaped operators (state / flux arrays hold
-			* 6 + nscalars components); the fused stage refuses nscalars > 0 (QK_ERR_UNSUPPORTED) */
+			* 6 + nscalars components); the fused stage carries up to 3 passive scalars and refuses more, or mass scalars (QK_ERR_UNSUPPORTED) */
 	int nmscalars; /* Physics_Traits::numMassScalars, 0..nscalars: the first nmscalars passive scalars are partial densities — consistent
 			* multi-fluid advection of their fluxes (hydro_system.hpp:1062-1073,1094-1104), non-negativity in isStateValid (:430-441),
 			* floor and renormalisation in EnforceLimits (:725-744; small_x = 1e-30) */
-	int ndim;      /* 1 or 3 */
+	int ndim;      /* AMREX_SPACEDIM of the build: 1, 2 (X2 = the index-swap view of ArrayView_2d.hpp) or 3 */
 	/* the quokka::EOS<P> temperature hooks a problem may specialise (ComputeTgasFromEint / ComputeEintFromTgas / ComputeEintTempDerivative,
 	 * reference src/hydro/EOS.hpp:74-244), closed set used by the radiation source terms:
 	 * 0: the gamma-law forms; 1: E_int = (eos_alpha / 4) T^4 (Su & Olson 1997; RadMatterCoupling, RadSuOlson, RadMarshak) */
