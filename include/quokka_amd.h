@@ -463,6 +463,9 @@ int qk_fluxreg_restore(qk_fluxreg *fr, qk_stream s);
 int qk_fluxreg_CrseAdd(qk_fluxreg *fr, qk_stream s, const qk_array4 *const flux[3], const double dx[3], double dt);
 int qk_fluxreg_FineAdd(qk_fluxreg *fr, qk_stream s, const qk_array4 *const flux[3], const double dx_fine[3], double dt);
 int qk_fluxreg_Reflux(qk_fluxreg *fr, qk_stream s, qk_array4 *crse_state);
+/* A register that covers a component range of the state (the radiation block: the reference's expandFluxArrays, QuokkaSimulation.hpp:1758, places
+ * the radiation fluxes at nstartHyperbolic_ of a full-width flux array): Reflux adds register component n to state component comp0 + n. */
+int qk_fluxreg_set_state_component(qk_fluxreg *fr, int comp0);
 
 /* copy the region [lo, hi] (same index space) between two arrays given by HOST copies of their descriptors (device data):
  * the old-level data a remade level keeps (RemakeLevel's FillPatch copies fine data where it exists, reference src/simulation.hpp:1672-1685) */

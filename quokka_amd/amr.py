@@ -158,6 +158,11 @@ class FluxRegister:
         ctx = self.crse.ctx
         ctx.check(ctx.L.qk_fluxreg_FineAdd(self.h, ctx.stream(), self._p3(flux), (C.c_double * 3)(*[float(x) for x in dx_fine]), float(dt)), "qk_fluxreg_FineAdd")
 
+    def set_state_component(self, comp0: int):
+        """register component n <-> state component comp0 + n in Reflux (the radiation block of a radiation-hydro state)"""
+        ctx = self.crse.ctx
+        ctx.check(ctx.L.qk_fluxreg_set_state_component(self.h, int(comp0)), "qk_fluxreg_set_state_component")
+
     def Reflux(self, crse_state: MultiFab):
         ctx = self.crse.ctx
         ctx.check(ctx.L.qk_fluxreg_Reflux(self.h, ctx.stream(), crse_state.ptr), "qk_fluxreg_Reflux")

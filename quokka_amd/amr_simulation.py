@@ -7,10 +7,9 @@
   computeTimestep over levels        :744-818
 
 Host orchestration only: every cell is touched by a kernel behind include/quokka_amd.h (quokka_amd/amr.py wraps them).
-Grid generation is NOT AMReX's Berger-Rigoutsos clustering (AMReX is not vendored under /root/reference: unpinned): tagged
-cells are buffered by n_error_buf, every blocking_factor-aligned tile that holds a tag is refined, and tiles are merged
-greedily into boxes of at most max_grid_size — valid, properly nested grids, generally more refined cells than AMReX's.
-Single rank (the multi-GPU exchange of GhostExchange covers one level; inter-level transfers across ranks are not built).
+Grid generation: Berger-Rigoutsos clustering with amr.grid_eff on the device-buffered tags (qk_amr_cluster_berger_rigoutsos; "tiles" keeps the
+round-1 rule).  Several ranks: a fine box lives on the rank of its level-0 ancestor (AmrSimulation.__init__).  With rad_traits the levels are
+RadAmrLevelSim: hydro advance + radiation subcycle + a second flux register for the radiation block (one rank).
 """
 from __future__ import annotations
 
@@ -22,6 +21,7 @@ import torch
 from . import capi
 from .amr import AverageDown, FluxRegister, InterpFromCoarse
 from .multifab import Context, MultiFab
+from .radhydro import RAD0, RadhydroSimulation
 from .simulation import NGHOST_CC, Geometry, HydroSimulation, chop_domain
 
 Box = Tuple[List[int], List[int]]
@@ -101,7 +101,7 @@ class AmrLevelSim(HydroSimulation):
         self.amr, self.ilev = amr, lev
         g0 = amr.geom0
         geom = Geometry(g0.ndim, [g0.n_cell[d] * (2 ** lev if d < g0.ndim else 1) for d in range(3)], list(g0.prob_lo), list(g0.prob_hi), list(g0.periodic))
-        super().__init__(amr.ctx, geom, amr.traits, amr.bcs, None, amr.dirichlet, rank=amr.rank, nranks=amr.nranks, boxes=boxes, owner=owner)
+        self._init_simulation(geom, boxes, owner)
         self.min_overlap_cells = 1 << 62  # the early/late split of the uniform-grid exchange is not combined with the coarse-fine fill
         self.store_flux_rk2 = True
         self.reflux_inc: Optional[MultiFab] = None  # several ranks: reflux increments of THIS level (valid + 1 ghost cell), folded by SumBoundary
@@ -113,6 +113,10 @@ class AmrLevelSim(HydroSimulation):
         self.avgdown: Optional[AverageDown] = None
         for name in ("cflNumber_", "densityFloor_", "tempFloor_", "reconstructionOrder_", "integratorOrder_", "useDualEnergy_", "abortOnFofcFailure_"):
             setattr(self, name, getattr(amr, name))
+
+    def _init_simulation(self, geom, boxes, owner):
+        amr = self.amr
+        HydroSimulation.__init__(self, amr.ctx, geom, amr.traits, amr.bcs, None, amr.dirichlet, rank=amr.rank, nranks=amr.nranks, boxes=boxes, owner=owner)
 
     def link_to_parent(self, parent: "AmrLevelSim"):
         multi = self.amr.nranks > 1
@@ -150,11 +154,11 @@ class AmrLevelSim(HydroSimulation):
         t0, t1 = p.t_old, p.t_new
         eps = 1.0e-10 * max(abs(t1 - t0), 1.0e-300)
         if abs(time - t1) <= eps or t1 == t0:
-            plan(state, p.state_new_cc_, p.state_new_cc_, 1.0, 0.0, 6, self.amr.amrInterpMethod_, True)
+            plan(state, p.state_new_cc_, p.state_new_cc_, 1.0, 0.0, self.ncomp_cc, self.amr.amrInterpMethod_, True)
         elif abs(time - t0) <= eps:
-            plan(state, p.state_old_cc_, p.state_old_cc_, 1.0, 0.0, 6, self.amr.amrInterpMethod_, True)
+            plan(state, p.state_old_cc_, p.state_old_cc_, 1.0, 0.0, self.ncomp_cc, self.amr.amrInterpMethod_, True)
         else:  # amrex::FillPatch time interpolation: ((t1 - t) old + (t - t0) new) / (t1 - t0)
-            plan(state, p.state_old_cc_, p.state_new_cc_, (t1 - time) / (t1 - t0), (time - t0) / (t1 - t0), 6, self.amr.amrInterpMethod_, True)
+            plan(state, p.state_old_cc_, p.state_new_cc_, (t1 - time) / (t1 - t0), (time - t0) / (t1 - t0), self.ncomp_cc, self.amr.amrInterpMethod_, True)
 
     def _fill_and_stage(self, stage, U_in, U_old, U_out, dt) -> bool:
         self._fill_time = self._t_adv + (dt if stage == 2 else 0.0)  # reference src/QuokkaSimulation.hpp:1076, :1204
@@ -215,12 +219,77 @@ class AmrLevelSim(HydroSimulation):
         self._signal_of_state_new = None
 
 
+class RadAmrLevelSim(AmrLevelSim, RadhydroSimulation):
+    """One AMR level of a radiation-hydrodynamics run: the hydro advance of AmrLevelSim, then the radiation subcycle of RadhydroSimulation
+    (reference src/QuokkaSimulation.hpp:653-707) with ghost cells interpolated from the parent at the substep's time and the radiation fluxes
+    of both stages added to the flux registers with weight dt_radiation / 2 (:1726-1860, expandFluxArrays: the register of the radiation block)."""
+
+    def _init_simulation(self, geom, boxes, owner):
+        amr = self.amr
+        RadhydroSimulation.__init__(self, amr.ctx, geom, amr.traits, amr.rad_traits, amr.bcs, None, rank=amr.rank, nranks=amr.nranks, dirichlet=amr.dirichlet,
+                                    boxes=boxes, owner=owner)
+        self.fluxreg_rad: Optional[FluxRegister] = None
+        self.is_hydro_enabled = amr.is_hydro_enabled
+        for name in ("radiationCflNumber_", "maxSubsteps_", "radiationReconstructionOrder_"):
+            setattr(self, name, getattr(amr, name))
+        self._rad_time = 0.0
+
+    def link_to_parent(self, parent: "AmrLevelSim"):
+        AmrLevelSim.link_to_parent(self, parent)
+        self.fluxreg_rad = FluxRegister(parent.lev, self.lev, parent.geom, self.nrad)
+        self.fluxreg_rad.set_state_component(RAD0)
+
+    def reflux_from(self, child: "AmrLevelSim"):
+        AmrLevelSim.reflux_from(self, child)
+        child.fluxreg_rad.Reflux(self.state_new_cc_)
+
+    def _rad_registers(self, flux, dt_radiation: float):
+        amr, l = self.amr, self.ilev
+        if amr.do_reflux and l < amr.finest_level:
+            amr.levels[l + 1].fluxreg_rad.CrseAdd(flux, self.geom.dx, 0.5 * dt_radiation)
+        if amr.do_reflux and l > 0:
+            self.fluxreg_rad.FineAdd(flux, self.geom.dx, 0.5 * dt_radiation)
+
+    def advanceRadiationForwardEuler(self, dt_radiation: float):
+        self._fill_time = self._rad_time  # :1743 fillBoundaryConditions(state_old, ..., time)
+        RadhydroSimulation.advanceRadiationForwardEuler(self, dt_radiation)
+        self._rad_registers(self.radFluxOld, dt_radiation)
+
+    def advanceRadiationMidpointRK2(self, dt_radiation: float):
+        self._fill_time = self._rad_time + dt_radiation  # :1764 (time + dt_radiation)
+        RadhydroSimulation.advanceRadiationMidpointRK2(self, dt_radiation)
+        self._rad_registers(self.radFlux, dt_radiation)
+        self._rad_time += dt_radiation
+
+    def advance_level(self, time: float, dt_lev: float) -> bool:
+        if self.is_hydro_enabled:
+            if not AmrLevelSim.advance_level(self, time, dt_lev):
+                return False
+        else:  # :681-685: the hydro variables are carried over
+            self._signal_of_state_new = None
+            self.state_old_cc_, self.state_new_cc_ = self.state_new_cc_, self.state_old_cc_
+            for b in range(self.lev.nboxes):
+                self.state_new_cc_.fabs[b][:RAD0].copy_(self.state_old_cc_.fabs[b][:RAD0])
+        self._rad_time = time
+        return self.subcycleRadiationAtLevel(time, dt_lev)
+
+    def FixupState(self):
+        if self.is_hydro_enabled:
+            AmrLevelSim.FixupState(self)
+
+
 # ------------------------------------------------------------------------------------------------ the hierarchy
 class AmrSimulation:
     def __init__(self, ctx: Context, geom0: Geometry, traits: capi.HydroTraits, bcs, max_level: int, max_grid_size: int = 128, blocking_factor: int = 32,
-                 n_error_buf: int = 3, regrid_int: int = 2, dirichlet=None, rank: int = 0, nranks: int = 1, cluster_within_parent: Optional[bool] = None):
+                 n_error_buf: int = 3, regrid_int: int = 2, dirichlet=None, rank: int = 0, nranks: int = 1, cluster_within_parent: Optional[bool] = None,
+                 rad_traits: Optional[capi.RadTraits] = None):
         assert geom0.ndim == 3, "the AMR driver runs the fused 3-D path"
         self.ctx, self.geom0, self.traits, self.bcs, self.dirichlet = ctx, geom0, traits, bcs, dirichlet
+        # radiation on every level (reference src/QuokkaSimulation.hpp:653-707, :1577-1722): the levels are RadAmrLevelSim
+        self.rad_traits = rad_traits
+        self.is_hydro_enabled = True
+        self.radiationCflNumber_, self.maxSubsteps_, self.radiationReconstructionOrder_ = 0.3, 10, 3
+        assert rad_traits is None or nranks == 1, "radiation on refined levels: one rank (the reflux increments of the radiation block are not exchanged)"
         self.rank, self.nranks = rank, nranks
         # Several ranks: a fine box lives on the rank of the level-0 box it sits in (so interpolation, average-down and regrid copies are
         # local and only the reflux increments and the ordinary ghost exchange cross ranks); grids are therefore clustered inside each
@@ -362,7 +431,7 @@ class AmrSimulation:
             owner = fn(boxes, self.nranks, self.geom0.n_cell, [self.max_grid_size] * 3) if self.nranks > 1 else [0] * len(boxes)
         else:
             owner = self._owners_of(lev, boxes)
-        L = AmrLevelSim(self, lev, boxes, owner)
+        L = (RadAmrLevelSim if self.rad_traits is not None else AmrLevelSim)(self, lev, boxes, owner)
         if lev > 0:
             L.link_to_parent(self.levels[lev - 1])
         return L
@@ -418,7 +487,7 @@ class AmrSimulation:
             parent._fill_time = parent.t_new
             parent.fillBoundaryConditions(parent.state_new_cc_)
             whole = InterpFromCoarse(parent.lev, new.lev, new.geom, NGHOST_CC, whole_fab=True)
-            whole(new.state_new_cc_, parent.state_new_cc_, parent.state_new_cc_, 1.0, 0.0, 6, self.amrInterpMethod_, True)
+            whole(new.state_new_cc_, parent.state_new_cc_, parent.state_new_cc_, 1.0, 0.0, new.ncomp_cc, self.amrInterpMethod_, True)
             if old is not None:
                 _copy_overlap(old.state_new_cc_, old.my_boxes, new.state_new_cc_, new.my_boxes)
             new.state_old_cc_.copy_from(new.state_new_cc_)
@@ -436,7 +505,7 @@ class AmrSimulation:
     # ------------------------------------------------------------------ inter-level operators
     def AverageDownTo(self, crse_lev: int):
         f = self.levels[crse_lev + 1]
-        f.avgdown(f.state_new_cc_, self.levels[crse_lev].state_new_cc_, 0, 6)
+        f.avgdown(f.state_new_cc_, self.levels[crse_lev].state_new_cc_, 0, f.ncomp_cc)
 
     # ------------------------------------------------------------------ time stepping
     def computeTimestep(self):
@@ -465,6 +534,8 @@ class AmrSimulation:
         L.t_new = L.t_new + self.dt_[lev]
         if self.do_reflux and lev < self.finest_level:
             self.levels[lev + 1].fluxreg.reset()
+            if self.rad_traits is not None:
+                self.levels[lev + 1].fluxreg_rad.reset()
         if not L.advance_level(time, self.dt_[lev]):
             raise capi.QkError(f"QUOKKA FATAL ERROR: Hydro update exceeded max_retries on level {lev}")
         self.istep[lev] += 1
@@ -563,6 +634,44 @@ def sedov_amr_problem(ctx: Context, n: int, max_level: int, max_grid_size: int =
         from .amr import tag_relative_gradient
         L = a.levels[lev]
         tag_relative_gradient(L.lev, L.traits, L.state_new_cc_, tags, capi.TAGFIELD_PRESSURE, 0.1, 1.0e-3, False)
+
+    amr.initial_conditions, amr.ErrorEst = ic_for, error_est
+    amr.setInitialConditions()
+    return amr
+
+
+def rad_pulse_amr_problem(ctx: Context, n: int, max_level: int, max_grid_size: int = 32, blocking_factor: int = 8, static_fine_boxes=None,
+                          hydro: bool = False, kappa: float = 4.0) -> AmrSimulation:
+    """A radiation pulse in a periodic box of gas at rest (units c = c_hat = a_rad = k_B = mu = 1, rho = 1, T = 1, kappa constant): a Gaussian excess
+    of radiation energy at the centre spreads across the coarse-fine interfaces and heats the gas — the radiation operators, the exchange and the
+    radiation flux registers on every level.  Not a reference problem: a property test (see tests/test_amr_radiation_gpu.py)."""
+    geom = Geometry(3, [n, n, n], [0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [1, 1, 1])
+    bcs = [([capi.BC_INT_DIR] * 3, [capi.BC_INT_DIR] * 3) for _ in range(10)]
+    traits = capi.traits(5.0 / 3.0, True, 3, mean_molecular_weight=1.0, boltzmann_constant=1.0)
+    rt = capi.RadTraits(1.0, 1.0, 1.0, 1.0e-10, 1 if hydro else 0, 0, kappa, kappa, kappa, 1, 0)
+    amr = AmrSimulation(ctx, geom, traits, bcs, max_level, max_grid_size, blocking_factor, rad_traits=rt)
+    amr.is_hydro_enabled = hydro
+    amr.static_fine_boxes = static_fine_boxes
+    amr.radiationCflNumber_ = 0.3
+
+    def ic_for(geom_l: Geometry):
+        dx = geom_l.dx
+
+        def ic(i, j, k):
+            x, y, z = (i + 0.5) * dx[0] - 0.5, (j + 0.5) * dx[1] - 0.5, (k + 0.5) * dx[2] - 0.5
+            U = np.zeros((10,) + i.shape)
+            U[0] = 1.0
+            U[4] = U[5] = 1.5  # rho c_v T, c_v = 1 / (gamma - 1) / mu
+            U[6] = 1.0 + 3.0 * np.exp(-(x * x + y * y + z * z) / (2.0 * 0.08 ** 2))
+            return U
+        return ic
+
+    def error_est(a: AmrSimulation, lev: int, tags: MultiFab):  # (only used without static grids) radiation energy above tag_threshold
+        L = a.levels[lev]
+        for b in range(L.lev.nboxes):
+            tags.valid(b)[0][L.state_new_cc_.valid(b)[6] > a.tag_threshold] = capi.TAG_SET
+
+    amr.tag_threshold = 1.5
 
     amr.initial_conditions, amr.ErrorEst = ic_for, error_est
     amr.setInitialConditions()

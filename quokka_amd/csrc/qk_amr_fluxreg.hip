@@ -36,6 +36,7 @@ struct qk_fluxreg {
 	int64_t total_cells = 0;
 	int64_t max_cells = 0;
 	double *d_reg = nullptr;
+	int state_comp0 = 0; // Reflux: register component n is state component state_comp0 + n (qk_fluxreg_set_state_component)
 	double *d_saved = nullptr; // qk_fluxreg_save / qk_fluxreg_restore (retries of the level that is the FINE side of this register)
 };
 
@@ -84,7 +85,7 @@ enum { FR_CRSE_ADD = 0, FR_FINE_ADD = 1, FR_REFLUX = 2 };
 // blockIdx.y = item of one (dir, side) group
 template <int MODE>
 __global__ void __launch_bounds__(256) k_fluxreg(const FrItem *items, double *reg, int64_t total_cells, int ncomp, const qk_array4 *flux_t, qk_array4 *state_t,
-						 double fac, int r0, int r1, int r2)
+						 double fac, int r0, int r1, int r2, int scomp)
 {
 	const FrItem it = items[blockIdx.y];
 	const int n0 = it.hi[0] - it.lo[0] + 1, n1 = it.hi[1] - it.lo[1] + 1, n2 = it.hi[2] - it.lo[2] + 1;
@@ -131,7 +132,7 @@ __global__ void __launch_bounds__(256) k_fluxreg(const FrItem *items, double *re
 			*slot = (it.side == 0) ? (*slot - v) : (*slot + v);
 		} else {
 			WA4 U(state_t[it.crse_box]);
-			U(o[0] + it.shift[0], o[1] + it.shift[1], o[2] + it.shift[2], n) += *slot;
+			U(o[0] + it.shift[0], o[1] + it.shift[1], o[2] + it.shift[2], scomp + n) += *slot;
 		}
 	}
 }
@@ -401,13 +402,13 @@ static int frLaunch(qk_fluxreg *fr, qk_stream s, int mode, const qk_array4 *cons
 		auto st = static_cast<hipStream_t>(s);
 		if (mode == FR_CRSE_ADD) {
 			hipLaunchKernelGGL(k_fluxreg<FR_CRSE_ADD>, grid, dim3(256), 0, st, fr->d_items + first, fr->d_reg, fr->total_cells, fr->ncomp, flux[d], nullptr, fac[d],
-					   fr->ratio[0], fr->ratio[1], fr->ratio[2]);
+					   fr->ratio[0], fr->ratio[1], fr->ratio[2], fr->state_comp0);
 		} else if (mode == FR_FINE_ADD) {
 			hipLaunchKernelGGL(k_fluxreg<FR_FINE_ADD>, grid, dim3(256), 0, st, fr->d_items + first, fr->d_reg, fr->total_cells, fr->ncomp, flux[d], nullptr, fac[d],
-					   fr->ratio[0], fr->ratio[1], fr->ratio[2]);
+					   fr->ratio[0], fr->ratio[1], fr->ratio[2], fr->state_comp0);
 		} else {
 			hipLaunchKernelGGL(k_fluxreg<FR_REFLUX>, grid, dim3(256), 0, st, fr->d_items + first, fr->d_reg, fr->total_cells, fr->ncomp, nullptr, state, 0.0,
-					   fr->ratio[0], fr->ratio[1], fr->ratio[2]);
+					   fr->ratio[0], fr->ratio[1], fr->ratio[2], fr->state_comp0);
 		}
 	}
 	QK_HIP_CHECK(ctx, hipGetLastError());
@@ -433,6 +434,16 @@ int qk_fluxreg_FineAdd(qk_fluxreg *fr, qk_stream s, const qk_array4 *const flux[
 	const double rvol = static_cast<double>(fr->ratio[0] * fr->ratio[1] * fr->ratio[2]);
 	const double fac[3] = {dt / (dx_fine[0] * rvol), dt / (dx_fine[1] * rvol), dt / (dx_fine[2] * rvol)};
 	return frLaunch(fr, s, FR_FINE_ADD, flux, nullptr, fac);
+}
+
+int qk_fluxreg_set_state_component(qk_fluxreg *fr, int comp0)
+{
+	if (fr == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	QK_REQUIRE(fr->crse->ctx, comp0 >= 0 && comp0 + fr->ncomp <= QK_MAX_STATE_COMPS, "fluxreg_set_state_component: component range");
+	fr->state_comp0 = comp0;
+	return QK_OK;
 }
 
 int qk_fluxreg_Reflux(qk_fluxreg *fr, qk_stream s, qk_array4 *crse_state)

@@ -41,11 +41,12 @@ def _d3(v):
 
 class RadhydroSimulation(HydroSimulation):
     def __init__(self, ctx: Context, geom: Geometry, traits: capi.HydroTraits, rad_traits: capi.RadTraits, bcs, max_grid_size=None,
-                 rank: int = 0, nranks: int = 1, use_fused: bool = True, dirichlet=None):
+                 rank: int = 0, nranks: int = 1, use_fused: bool = True, dirichlet=None, boxes=None, owner=None):
         self.nGroups = max(int(rad_traits.ngroups), 1)  # Physics_Traits::nGroups
         self.nrad = 4 * self.nGroups                      # Physics_NumVars::numRadVars * nGroups
         self.ncomp_override = RAD0 + self.nrad
-        super().__init__(ctx, geom, traits, bcs, max_grid_size, dirichlet, rank, nranks, use_fused, ncomp_cc=RAD0 + self.nrad)
+        HydroSimulation.__init__(self, ctx, geom, traits, bcs, max_grid_size, dirichlet, rank, nranks, use_fused, ncomp_cc=RAD0 + self.nrad,
+                                 boxes=boxes, owner=owner)
         self.rad_traits = rad_traits
         self.is_hydro_enabled = True  # Physics_Traits::is_hydro_enabled (False: radiation-only problems)
         self.radiationCflNumber_ = 0.3
