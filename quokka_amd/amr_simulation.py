@@ -288,6 +288,7 @@ class AmrSimulation:
         # radiation on every level (reference src/QuokkaSimulation.hpp:653-707, :1577-1722): the levels are RadAmrLevelSim
         self.rad_traits = rad_traits
         self.is_hydro_enabled = True
+        self.rad_source: Optional[Callable] = None  # SetRadEnergySource of the problem, per level geometry
         self.radiationCflNumber_, self.maxSubsteps_, self.radiationReconstructionOrder_ = 0.3, 10, 3
         assert rad_traits is None or nranks == 1, "radiation on refined levels: one rank (the reflux increments of the radiation block are not exchanged)"
         self.rank, self.nranks = rank, nranks
@@ -432,6 +433,8 @@ class AmrSimulation:
         else:
             owner = self._owners_of(lev, boxes)
         L = (RadAmrLevelSim if self.rad_traits is not None else AmrLevelSim)(self, lev, boxes, owner)
+        if self.rad_traits is not None and self.rad_source is not None:
+            L.SetRadEnergySource = self.rad_source(L.geom)  # fn(geom of the level) -> fn(i, j, k, time)
         if lev > 0:
             L.link_to_parent(self.levels[lev - 1])
         return L
@@ -674,5 +677,35 @@ def rad_pulse_amr_problem(ctx: Context, n: int, max_level: int, max_grid_size: i
     amr.tag_threshold = 1.5
 
     amr.initial_conditions, amr.ErrorEst = ic_for, error_est
+    amr.setInitialConditions()
+    return amr
+
+
+def shell_amr_problem(ctx: Context, n: int, max_level: int, table, max_grid_size: int = 128, blocking_factor: int = 32, pow_mode: int = 0) -> AmrSimulation:
+    """reference src/problems/RadhydroShell/test_radhydro_shell.cpp + tests/radhydro_shell_amr.in: the radiation-driven shell on a refined
+    hierarchy (tags: relative density jump to a neighbour > 0.1 where rho >= 0.01 rho_0, :321-357)"""
+    from .radhydro import ShellConstants as S, shell_functions, shell_settings
+    geom = Geometry(3, [n, n, n], [0.0, 0.0, 0.0], [S.L_box] * 3, [1, 1, 1])
+    bcs = [([capi.BC_INT_DIR] * 3, [capi.BC_INT_DIR] * 3) for _ in range(10)]
+    traits = capi.traits(S.gamma_gas, False, 3, mean_molecular_weight=2.2 * capi.M_U, boltzmann_constant=capi.K_B)
+    rt = capi.RadTraits(S.c, S.chat, S.a_rad, 0.0, 1, 0, S.kappa0, S.kappa0, S.kappa0, pow_mode)
+    amr = AmrSimulation(ctx, geom, traits, bcs, max_level, max_grid_size, blocking_factor, rad_traits=rt)
+    for name, value in shell_settings().items():
+        setattr(amr, name, value)
+    amr.initial_conditions = lambda g: shell_functions(g, table)[0]
+    amr.rad_source = lambda g: shell_functions(g, table)[1]
+
+    def error_est(a: AmrSimulation, lev: int, tags: MultiFab):
+        L, g = a.levels[lev], NGHOST_CC
+        for b in range(L.lev.nboxes):
+            rho = L.state_new_cc_.fabs[b][0]
+            c = rho[g:-g, g:-g, g:-g]
+            d = torch.zeros_like(c)
+            for ax in range(3):
+                sl = lambda o: tuple(slice(g + (o if a_ == ax else 0), rho.shape[a_] - g + (o if a_ == ax else 0)) for a_ in range(3))
+                d = torch.maximum(d, torch.maximum((rho[sl(1)] - c).abs(), (c - rho[sl(-1)]).abs()))
+            tags.valid(b)[0][((d / c) > 0.1) & (c >= 1.0e-2 * S.rho_0)] = capi.TAG_SET
+
+    amr.ErrorEst = error_est
     amr.setInitialConditions()
     return amr

@@ -111,6 +111,7 @@ template <typename problem_t> class AmrDriver
 		base_.elapsedSeconds_ = elapsedSeconds_;
 		base_.cellUpdates_ = cellUpdates_;
 		base_.computeAfterEvolve(init_sum_cons);
+		base_.printConservation(init_sum_cons, vol); // reference src/simulation.hpp:959-970
 		double const us = 1.0e6 * elapsedSeconds_ / static_cast<double>(cellUpdates_);
 		amrex::Print() << "Performance figure-of-merit: " << us << " μs/zone-update [" << 1.0 / us << " Mupdates/s]\n";
 		for (int l = 0; l <= finestLevel(); ++l) {
@@ -177,11 +178,13 @@ template <typename problem_t> class AmrDriver
 		std::unique_ptr<Sim> sim;
 		qk_interp_plan *interp = nullptr;
 		qk_fluxreg *fluxreg = nullptr;
+		qk_fluxreg *fluxregRad = nullptr; // the radiation block of the state (expandFluxArrays, reference src/QuokkaSimulation.hpp:1758)
 		qk_avgdown_plan *avgdown = nullptr;
 		~Finer()
 		{
 			qk_interp_plan_destroy(interp);
 			qk_fluxreg_destroy(fluxreg);
+			qk_fluxreg_destroy(fluxregRad);
 			qk_avgdown_plan_destroy(avgdown);
 		}
 	};
@@ -218,9 +221,11 @@ template <typename problem_t> class AmrDriver
 	{
 		qk_interp_plan_destroy(f.interp);
 		qk_fluxreg_destroy(f.fluxreg);
+		qk_fluxreg_destroy(f.fluxregRad);
 		qk_avgdown_plan_destroy(f.avgdown);
 		f.interp = nullptr;
 		f.fluxreg = nullptr;
+		f.fluxregRad = nullptr;
 		f.avgdown = nullptr;
 		Sim &parent = level(lev - 1);
 		Sim &me = *f.sim;
@@ -230,6 +235,11 @@ template <typename problem_t> class AmrDriver
 		qkhost::check(qk_interp_plan_create(parent.levelHandle(), me.levelHandle(), &gf, me.nghost_cc_, ratio, 0, 0, nullptr, &f.interp), "qk_interp_plan_create");
 		qkhost::check(qk_fluxreg_create(parent.levelHandle(), me.levelHandle(), &gc, ratio, Sim::ncompHydro_, 0, nullptr, 0, &f.fluxreg), "qk_fluxreg_create");
 		qkhost::check(qk_avgdown_plan_create(parent.levelHandle(), me.levelHandle(), ratio, &f.avgdown), "qk_avgdown_plan_create");
+		if constexpr (Physics_Traits<problem_t>::is_radiation_enabled) {
+			qkhost::check(qk_fluxreg_create(parent.levelHandle(), me.levelHandle(), &gc, ratio, RadSystem<problem_t>::nvarHyperbolic_, 0, nullptr, 0, &f.fluxregRad),
+				      "qk_fluxreg_create");
+			qkhost::check(qk_fluxreg_set_state_component(f.fluxregRad, RadSystem<problem_t>::nstartHyperbolic_), "qk_fluxreg_set_state_component");
+		}
 		Finer *fp = &f;
 		// FillPatchTwoLevels: the ghost cells no fine box covers come from the parent, interpolated in space and time
 		me.beforePhysBC_ = [this, fp, lev](amrex::MultiFab &state) { interpFromParent(*fp, lev, state, fp->sim->fillTime_, fp->interp); };
@@ -237,6 +247,33 @@ template <typename problem_t> class AmrDriver
 		me.afterAdvance_ = [this, lev](double dt) { incrementFluxRegisters(lev, dt); };
 		me.beforeAttempt_ = [this, lev](int retry) { resetFluxRegistersForAttempt(lev, retry); };
 		me.storeFluxRk2_ = true;
+		installRadiationHook(lev);
+		installRadiationHook(lev - 1);
+	}
+
+	// incrementFluxRegisters of the radiation stages (:1818, :1854): weight dt_radiation / 2 for each of the two stages
+	void installRadiationHook(int lev)
+	{
+		if constexpr (Physics_Traits<problem_t>::is_radiation_enabled) {
+			level(lev).afterRadStage_ = [this, lev](std::array<amrex::MultiFab, AMREX_SPACEDIM> &flux, double dt_radiation) {
+				if (do_reflux == 0) {
+					return;
+				}
+				Sim &S = level(lev);
+				qk_array4 *f[3];
+				double dx[3];
+				for (int d = 0; d < 3; ++d) {
+					f[d] = (d < AMREX_SPACEDIM) ? qkhost::tab(flux[d]) : nullptr;
+					dx[d] = (d < AMREX_SPACEDIM) ? S.geom[0].dx[d] : 1.0;
+				}
+				if (lev < finestLevel() && finer_[lev] != nullptr && finer_[lev]->fluxregRad != nullptr) {
+					qkhost::check(qk_fluxreg_CrseAdd(finer_[lev]->fluxregRad, nullptr, f, dx, 0.5 * dt_radiation), "qk_fluxreg_CrseAdd(rad)");
+				}
+				if (lev > 0 && finer_[lev - 1]->fluxregRad != nullptr) {
+					qkhost::check(qk_fluxreg_FineAdd(finer_[lev - 1]->fluxregRad, nullptr, f, dx, 0.5 * dt_radiation), "qk_fluxreg_FineAdd(rad)");
+				}
+			};
+		}
 	}
 
 	void interpFromParent(Finer & /*f*/, int lev, amrex::MultiFab &state, double time, qk_interp_plan *plan)
@@ -247,7 +284,7 @@ template <typename problem_t> class AmrDriver
 		auto *fs = qkhost::tab(state);
 		auto *pn = qkhost::tab(p.state_new_cc_[0]);
 		auto *po = qkhost::tab(p.state_old_cc_[0]);
-		int const nc = Sim::ncompHydro_;
+		int const nc = Physics_Indices<problem_t>::nvarTotal_cc; // hydro + radiation blocks
 		if (std::abs(time - t1) <= eps || t1 == t0) {
 			qkhost::check(qk_InterpFromCoarse(plan, nullptr, fs, pn, pn, 1.0, 0.0, nc, amrInterpMethod_, 1), "qk_InterpFromCoarse");
 		} else if (std::abs(time - t0) <= eps) {
@@ -306,6 +343,13 @@ template <typename problem_t> class AmrDriver
 		me.reconstructionOrder_ = base_.reconstructionOrder_;
 		me.integratorOrder_ = base_.integratorOrder_;
 		me.useDualEnergy_ = base_.useDualEnergy_;
+		me.abortOnFofcFailure_ = base_.abortOnFofcFailure_;
+		me.artificialViscosityK_ = base_.artificialViscosityK_;
+		me.radiationCflNumber_ = base_.radiationCflNumber_; // (the problem sets these on the level-0 object in problem_main)
+		me.radiationReconstructionOrder_ = base_.radiationReconstructionOrder_;
+		me.maxSubsteps_ = base_.maxSubsteps_;
+		me.dustGasInteractionCoeff_ = base_.dustGasInteractionCoeff_;
+		me.constantDt_ = base_.constantDt_;
 		me.tOldLev_ = me.tNewLev_ = tNew_;
 		Finer *raw = f.get();
 		if (lev - 1 < static_cast<int>(finer_.size())) {
@@ -482,7 +526,7 @@ template <typename problem_t> class AmrDriver
 			qk_interp_plan *whole = nullptr;
 			qkhost::check(qk_interp_plan_create(parent.levelHandle(), me.levelHandle(), &gf, me.nghost_cc_, ratio, 1, 0, nullptr, &whole), "qk_interp_plan_create(whole)");
 			auto *pn = qkhost::tab(parent.state_new_cc_[0]);
-			qkhost::check(qk_InterpFromCoarse(whole, nullptr, qkhost::tab(me.state_new_cc_[0]), pn, pn, 1.0, 0.0, Sim::ncompHydro_, amrInterpMethod_, 1),
+			qkhost::check(qk_InterpFromCoarse(whole, nullptr, qkhost::tab(me.state_new_cc_[0]), pn, pn, 1.0, 0.0, Physics_Indices<problem_t>::nvarTotal_cc, amrInterpMethod_, 1),
 				      "qk_InterpFromCoarse(whole)");
 			qk_interp_plan_destroy(whole);
 			if (old) { // keep the old fine data where the new level still covers it
@@ -523,7 +567,7 @@ template <typename problem_t> class AmrDriver
 	{
 		Sim &f = level(crseLev + 1);
 		Sim &c = level(crseLev);
-		qkhost::check(qk_average_down(finer_[crseLev]->avgdown, nullptr, qkhost::tab(f.state_new_cc_[0]), qkhost::tab(c.state_new_cc_[0]), 0, Sim::ncompHydro_),
+		qkhost::check(qk_average_down(finer_[crseLev]->avgdown, nullptr, qkhost::tab(f.state_new_cc_[0]), qkhost::tab(c.state_new_cc_[0]), 0, Physics_Indices<problem_t>::nvarTotal_cc),
 			      "qk_average_down");
 	}
 
@@ -566,6 +610,9 @@ template <typename problem_t> class AmrDriver
 		S.tNewLev_ += dt_[lev];
 		if (do_reflux != 0 && lev < finestLevel()) {
 			qkhost::check(qk_fluxreg_reset(finer_[lev]->fluxreg, nullptr), "qk_fluxreg_reset");
+			if (finer_[lev]->fluxregRad != nullptr) {
+				qkhost::check(qk_fluxreg_reset(finer_[lev]->fluxregRad, nullptr), "qk_fluxreg_reset(rad)");
+			}
 		}
 		if (!S.advanceLevel(time, dt_[lev])) {
 			amrex::Abort("QUOKKA FATAL ERROR: Hydro update exceeded max_retries on level " + std::to_string(lev));
@@ -585,6 +632,9 @@ template <typename problem_t> class AmrDriver
 			if (lev < finestLevel()) {
 				if (do_reflux != 0) {
 					qkhost::check(qk_fluxreg_Reflux(finer_[lev]->fluxreg, nullptr, qkhost::tab(S.state_new_cc_[0])), "qk_fluxreg_Reflux");
+					if (finer_[lev]->fluxregRad != nullptr) {
+						qkhost::check(qk_fluxreg_Reflux(finer_[lev]->fluxregRad, nullptr, qkhost::tab(S.state_new_cc_[0])), "qk_fluxreg_Reflux(rad)");
+					}
 				}
 				averageDownTo(lev);
 				S.FixupState();

@@ -1629,6 +1629,9 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	[[nodiscard]] auto bcFillTime() const -> double override { return fillTime_; }
 	bool storeFluxRk2_ = false;	       // keep flux_rk2 = 0.5 F1 + 0.5 F2 (rk2flux_) for the flux registers
 	std::function<void(double)> afterAdvance_; // incrementFluxRegisters(dt) after every successful advanceHydroAtLevel
+	// a level of a hierarchy with radiation: the radiation fluxes of a stage go to the flux registers of the radiation block
+	std::function<void(std::array<amrex::MultiFab, AMREX_SPACEDIM> &, double)> afterRadStage_;
+	double radTime_ = 0.0; // start of the current radiation substep
 	std::function<void(int)> beforeAttempt_;   // flux registers: save before the retry loop (0), back to that state at every retry (>0)
 	// what the flux registers accumulate after a level advance (reference src/QuokkaSimulation.hpp:1303-1306)
 	[[nodiscard]] auto halfFlux() -> std::array<amrex::MultiFab, AMREX_SPACEDIM> & { return (integratorOrder_ == 2) ? rk2flux_ : halfFlux_; }
@@ -1655,6 +1658,9 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	}
 	void FixupState() // reference src/QuokkaSimulation.hpp:761-770
 	{
+		if constexpr (!Physics_Traits<problem_t>::is_hydro_enabled) {
+			return;
+		}
 		this->activate();
 		HydroSystem<problem_t>::EnforceLimits(densityFloor_, tempFloor_, state_new_cc_[0]);
 		if (useDualEnergy_ == 1) {
@@ -1666,14 +1672,32 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	[[nodiscard]] auto computeTimestepAtLevel() -> double
 	{
 		this->activate();
-		double const m = (haveSignal_ ? signal_[1] : HydroSystem<problem_t>::maxSignalSpeedLocal(state_new_cc_[0], 1));
+		double m = 0.0;
+		if constexpr (!Physics_Traits<problem_t>::is_hydro_enabled) { // radiation only (reference src/QuokkaSimulation.hpp:421-424)
+			m = RadSystem<problem_t>::c_hat_;
+		} else {
+			m = (haveSignal_ ? signal_[1] : HydroSystem<problem_t>::maxSignalSpeedLocal(state_new_cc_[0], 1));
+		}
+		if constexpr (is_radiation_enabled_ && Physics_Traits<problem_t>::is_hydro_enabled) { // :421-434
+			m = std::max(RadSystem<problem_t>::c_hat_ / static_cast<double>(maxSubsteps_), m);
+		}
 		return cflNumber_ * (minDx() / m);
 	}
 	// advanceSingleTimestepAtLevel for a hydro level of a hierarchy: state_new <- advance(previous state_new) starting at `time`
 	auto advanceLevel(double time, double dt_lev) -> bool
 	{
 		std::swap(state_old_cc_[0], state_new_cc_[0]);
-		return advanceHydroAtLevelWithRetries(time, dt_lev);
+		if constexpr (Physics_Traits<problem_t>::is_hydro_enabled) {
+			if (!advanceHydroAtLevelWithRetries(time, dt_lev)) {
+				return false;
+			}
+		} else { // reference src/QuokkaSimulation.hpp:681-685
+			amrex::MultiFab::Copy(state_new_cc_[0], state_old_cc_[0], 0, 0, ncompHydro_, 0);
+		}
+		if constexpr (is_radiation_enabled_) { // :693
+			subcycleRadiationAtLevel(time, dt_lev);
+		}
+		return true;
 	}
 
       private:
@@ -1806,6 +1830,24 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		dt_[0] = dt_0;
 	}
 
+	// the conservation report at the end of evolve (reference src/simulation.hpp:959-970): level 0 holds the average of every finer level, so
+	// its sum is the composite integral
+	void printConservation(amrex::Vector<amrex::Real> const &init_sum_cons, double vol)
+	{
+		int const nc = Physics_Indices<problem_t>::nvarTotal_cc;
+		for (int n = 0; n < nc && n < static_cast<int>(init_sum_cons.size()); ++n) {
+			amrex::Real const final_sum = state_new_cc_[0].sum(n) * vol;
+			amrex::Real const abs_err = (final_sum - init_sum_cons[n]);
+			std::string const name = n < static_cast<int>(this->componentNames_cc_.size()) ? this->componentNames_cc_[n] : ("component" + std::to_string(n));
+			amrex::Print() << "Initial " << name << " = " << init_sum_cons[n] << "\n";
+			amrex::Print() << "\tabsolute conservation error = " << abs_err << "\n";
+			if (init_sum_cons[n] != 0.0) {
+				amrex::Print() << "\trelative conservation error = " << abs_err / init_sum_cons[n] << "\n";
+			}
+			amrex::Print() << "\n";
+		}
+	}
+
 	// amr.max_level > 0: the level machinery of quokka_amr.hpp takes over (this object is level 0); defined there
 	void setInitialConditions();
 	void evolve();
@@ -1859,6 +1901,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		elapsedSeconds_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 		outputAfterEvolve();
 		this->computeAfterEvolve(init_sum_cons);
+		printConservation(init_sum_cons, AMREX_D_TERM(geom[0].dx[0], *geom[0].dx[1], *geom[0].dx[2]));
 		double const microseconds_per_update = 1.0e6 * elapsedSeconds_ / static_cast<double>(this->cellUpdates_);
 		amrex::Print() << "Performance figure-of-merit: " << microseconds_per_update << " μs/zone-update [" << 1.0 / microseconds_per_update
 			       << " Mupdates/s]\n";
@@ -1990,16 +2033,24 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 
 	void advanceRadiationForwardEuler(double dt_radiation) // :1790-1821
 	{
+		fillTime_ = radTime_; // (a refined level: its ghost cells come from the parent at the time of the substep, :1743)
 		this->fillRadiationGhosts(state_old_cc_[0]);
 		RadSystem<problem_t>::computeRadiationFluxes(state_old_cc_[0], radFluxOld_, radiationReconstructionOrder_);
 		RadSystem<problem_t>::PredictStep(state_old_cc_[0], state_new_cc_[0], radFluxOld_, dt_radiation, geom[0].CellSizeArray());
+		if (afterRadStage_) {
+			afterRadStage_(radFluxOld_, dt_radiation); // incrementFluxRegisters(..., 0.5 * dt_radiation) (:1818)
+		}
 	}
 
 	void advanceRadiationMidpointRK2(double dt_radiation) // :1823-1857 (the fluxes of the old state are reused, not recomputed)
 	{
+		fillTime_ = radTime_ + dt_radiation; // :1764
 		this->fillRadiationGhosts(state_new_cc_[0]);
 		RadSystem<problem_t>::computeRadiationFluxes(state_new_cc_[0], radFlux_, radiationReconstructionOrder_);
 		RadSystem<problem_t>::AddFluxesRK2(state_new_cc_[0], state_old_cc_[0], state_new_cc_[0], radFluxOld_, radFlux_, dt_radiation, geom[0].CellSizeArray());
+		if (afterRadStage_) {
+			afterRadStage_(radFlux_, dt_radiation); // :1854
+		}
 	}
 
 	void subcycleRadiationAtLevel(double time, double dt_lev_hydro)
@@ -2022,6 +2073,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 			}
 			QK_HOST_HIP(hipMemset(d_radCounter_, 0, 4 * sizeof(int)));
 			QK_HOST_HIP(hipMemset(d_radFailure_, 0, 3 * sizeof(int)));
+			radTime_ = time_subcycle;
 			advanceRadiationForwardEuler(dt_radiation);
 			operatorSplitSourceTerms(time_subcycle, dt_radiation, 1); // IMEX_a22 > 0
 			advanceRadiationMidpointRK2(dt_radiation);

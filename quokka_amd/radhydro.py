@@ -238,13 +238,24 @@ def shell_problem(ctx: Context, n: int, table, max_grid_size: int = 128, rank=0,
     rt = capi.RadTraits(S.c, S.chat, S.a_rad, 0.0, 1, 0, S.kappa0, S.kappa0, S.kappa0, pow_mode)
     sim = RadhydroSimulation(ctx, geom, traits, rt, bcs, [max_grid_size] * 3, rank=rank, nranks=nranks)
     # problem_main :409-431
-    sim.cflNumber_ = 0.3
-    sim.densityFloor_ = 1.0e-8 * S.rho_0
-    sim.reconstructionOrder_ = 2
-    sim.radiationReconstructionOrder_ = 2
-    sim.integratorOrder_ = 2
-    sim.stopTime_ = 0.125 * (S.r_0 / S.a0)
-    sim.maxTimesteps_ = 50
+    for name, value in shell_settings().items():
+        setattr(sim, name, value)
+    ic, source = shell_functions(geom, table)
+    sim.SetRadEnergySource = source
+    sim.set_initial_conditions(ic)
+    return sim
+
+
+def shell_settings() -> dict:
+    """problem_main of test_radhydro_shell.cpp (:409-431)"""
+    S = ShellConstants
+    return {"cflNumber_": 0.3, "densityFloor_": 1.0e-8 * S.rho_0, "reconstructionOrder_": 2, "radiationReconstructionOrder_": 2, "integratorOrder_": 2,
+            "stopTime_": 0.125 * (S.r_0 / S.a0), "maxTimesteps_": 50}
+
+
+def shell_functions(geom: Geometry, table):
+    """(initial conditions, radiation source) of RadhydroShell on the index space of `geom` (a level of a hierarchy has its own)"""
+    S = ShellConstants
     r_arr = np.asarray(table[0], dtype=np.float64) * S.r_0
     E_arr, F_arr = np.asarray(table[1], dtype=np.float64), np.asarray(table[2], dtype=np.float64)
     dx, lo, hi = geom.dx, geom.prob_lo, geom.prob_hi
@@ -276,9 +287,7 @@ def shell_problem(ctx: Context, n: int, table, max_grid_size: int = 128, rank=0,
         source_norm = (1.0 / S.c) * S.L_star / math.pow(2.0 * math.pi * S.sigma_star * S.sigma_star, 1.5)
         return source_norm * np.exp(-(r * r) / (2.0 * S.sigma_star * S.sigma_star))
 
-    sim.SetRadEnergySource = source
-    sim.set_initial_conditions(ic)
-    return sim
+    return ic, source
 
 
 class RadShockConstants:

@@ -81,6 +81,31 @@ def test_unmodified_shell_problem_matches_the_adapted_one(tmp_path):
         assert np.abs(a[:, n] - b[:, n]).sum() <= 1e-11 * np.abs(b[:, n]).sum(), n
 
 
+def test_unmodified_shell_problem_on_a_refined_hierarchy(tmp_path, ctx):
+    """RadhydroShell with the reference's AMR deck (tests/radhydro_shell_amr.in, scaled to 32^3 + one level): radiation on refined levels in the
+    C++ host — the radiation subcycle of every level with coarse-fine ghost cells interpolated at the substep's time, the radiation fluxes of both
+    stages in the flux register of the radiation block, the problem's own ErrorEst (density jump) as a device lambda.  No pass criterion in the
+    file; here: the same number of refined cell-updates and the same level-0 state (to 1e-12: host / device libm in the initial conditions) as
+    the Python AMR driver, whose radiation levels tests/test_amr_radiation_gpu.py pins by bit-equality with uniform runs and by conservation."""
+    import re
+    from quokka_amd.amr_simulation import shell_amr_problem
+    shutil.copy(os.path.join(ROOT, "tests", "golden", "dust_shell_initial_conditions.txt"), tmp_path / "initial_conditions.txt")
+    dump = str(tmp_path / "shell_amr.bin")
+    rc, out = run([exe("ref_RadhydroShell"), os.path.join(HOST, "decks", "radhydro_shell_amr.in"), "amr.n_cell=32 32 32", "amr.max_level=1",
+                   "amr.blocking_factor=8", "amr.max_grid_size=32", f"qk.dump_state={dump}"], str(tmp_path))
+    assert rc == 0 and "Finished." in out, out[-2500:]
+    m = re.search(r"Zone-updates on level 1: (\d+) \((\d+) grids\)", out)
+    assert m and int(m.group(1)) > 10 ** 7
+    tab = np.loadtxt(os.path.join(ROOT, "tests", "golden", "dust_shell_initial_conditions.txt"), skiprows=1)
+    amr = shell_amr_problem(ctx, 32, 1, (tab[:, 0], tab[:, 2], tab[:, 3]), max_grid_size=32, blocking_factor=8)
+    amr.evolve()
+    a = np.fromfile(dump, dtype=np.float64).reshape(10, 32, 32, 32)
+    b = amr.levels[0].state_new_cc_.valid(0).cpu().numpy()
+    assert amr.istep[0] == 50 and amr.cellUpdatesEachLevel_[1] == int(m.group(1))
+    for n in (0, 4, 5, 6):
+        assert np.abs(a[n] - b[n]).sum() <= 1e-12 * np.abs(b[n]).sum(), (n, np.abs(a[n] - b[n]).sum() / np.abs(b[n]).sum())
+
+
 def extern_tree(tmp_path, files):
     """the reference's problem files open `../extern/...` relative to their working directory (its tests/ directory): put the committed copies of
     those data tables where the unmodified problem looks for them"""
