@@ -848,6 +848,9 @@ template <typename T> void FabArrayT<T>::ParallelCopy(FabArrayT<T> const &src)
 			ParallelFor(is, nc, [=] __device__(int i, int j, int k, int n) { to(i, j, k, n) = from(i, j, k, n); });
 		}
 	}
+	// amrex::FabArray::ParallelCopy returns with the data in place: the callers read the destination on the host straight away
+	// (HydroRichtmeyerMeshkov's symmetry check does)
+	QK_HOST_HIP(hipDeviceSynchronize());
 }
 #endif
 using MultiFab = FabArrayT<Real>;
