@@ -236,12 +236,27 @@ class RadAmrLevelSim(AmrLevelSim, RadhydroSimulation):
 
     def link_to_parent(self, parent: "AmrLevelSim"):
         AmrLevelSim.link_to_parent(self, parent)
-        self.fluxreg_rad = FluxRegister(parent.lev, self.lev, parent.geom, self.nrad)
-        self.fluxreg_rad.set_state_component(RAD0)
+        multi = self.amr.nranks > 1
+        self.fluxreg_rad = FluxRegister(parent.lev, self.lev, parent.geom, self.nrad, all_fine_boxes=self.all_boxes if multi else None,
+                                        reg_nghost=1 if multi else 0)
+        if not multi:
+            self.fluxreg_rad.set_state_component(RAD0)
+        elif getattr(parent, "reflux_inc_rad", None) is None:  # several ranks: the increments of the radiation block, folded by SumBoundary
+            from .simulation import GhostExchange
+            parent.reflux_inc_rad = MultiFab(parent.lev, self.nrad, 1, fill=0.0)
+            per = [([capi.BC_INT_DIR] * 3, [capi.BC_INT_DIR] * 3)] * self.nrad
+            parent.reflux_ghost_rad = GhostExchange(parent.lev, parent.geom, self.nrad, 1, parent.all_boxes, parent.owner, self.amr.rank, per)
 
     def reflux_from(self, child: "AmrLevelSim"):
         AmrLevelSim.reflux_from(self, child)
-        child.fluxreg_rad.Reflux(self.state_new_cc_)
+        if getattr(self, "reflux_inc_rad", None) is None:
+            child.fluxreg_rad.Reflux(self.state_new_cc_)
+            return
+        self.reflux_inc_rad.storage.zero_()
+        child.fluxreg_rad.Reflux(self.reflux_inc_rad)
+        self.reflux_ghost_rad.sum_boundary(self.reflux_inc_rad)
+        for b in range(self.lev.nboxes):
+            self.state_new_cc_.valid(b)[RAD0:RAD0 + self.nrad] += self.reflux_inc_rad.valid(b)
 
     def _rad_registers(self, flux, dt_radiation: float):
         amr, l = self.amr, self.ilev
@@ -290,7 +305,6 @@ class AmrSimulation:
         self.is_hydro_enabled = True
         self.rad_source: Optional[Callable] = None  # SetRadEnergySource of the problem, per level geometry
         self.radiationCflNumber_, self.maxSubsteps_, self.radiationReconstructionOrder_ = 0.3, 10, 3
-        assert rad_traits is None or nranks == 1, "radiation on refined levels: one rank (the reflux increments of the radiation block are not exchanged)"
         self.rank, self.nranks = rank, nranks
         # Several ranks: a fine box lives on the rank of the level-0 box it sits in (so interpolation, average-down and regrid copies are
         # local and only the reflux increments and the ordinary ghost exchange cross ranks); grids are therefore clustered inside each
@@ -644,7 +658,8 @@ def sedov_amr_problem(ctx: Context, n: int, max_level: int, max_grid_size: int =
 
 
 def rad_pulse_amr_problem(ctx: Context, n: int, max_level: int, max_grid_size: int = 32, blocking_factor: int = 8, static_fine_boxes=None,
-                          hydro: bool = False, kappa: float = 4.0) -> AmrSimulation:
+                          hydro: bool = False, kappa: float = 4.0, rank: int = 0, nranks: int = 1, cluster_within_parent=None,
+                          tag_threshold: float = 1.5) -> AmrSimulation:
     """A radiation pulse in a periodic box of gas at rest (units c = c_hat = a_rad = k_B = mu = 1, rho = 1, T = 1, kappa constant): a Gaussian excess
     of radiation energy at the centre spreads across the coarse-fine interfaces and heats the gas — the radiation operators, the exchange and the
     radiation flux registers on every level.  Not a reference problem: a property test (see tests/test_amr_radiation_gpu.py)."""
@@ -652,7 +667,8 @@ def rad_pulse_amr_problem(ctx: Context, n: int, max_level: int, max_grid_size: i
     bcs = [([capi.BC_INT_DIR] * 3, [capi.BC_INT_DIR] * 3) for _ in range(10)]
     traits = capi.traits(5.0 / 3.0, True, 3, mean_molecular_weight=1.0, boltzmann_constant=1.0)
     rt = capi.RadTraits(1.0, 1.0, 1.0, 1.0e-10, 1 if hydro else 0, 0, kappa, kappa, kappa, 1, 0)
-    amr = AmrSimulation(ctx, geom, traits, bcs, max_level, max_grid_size, blocking_factor, rad_traits=rt)
+    amr = AmrSimulation(ctx, geom, traits, bcs, max_level, max_grid_size, blocking_factor, rad_traits=rt, rank=rank, nranks=nranks,
+                        cluster_within_parent=cluster_within_parent)
     amr.is_hydro_enabled = hydro
     amr.static_fine_boxes = static_fine_boxes
     amr.radiationCflNumber_ = 0.3
@@ -674,7 +690,7 @@ def rad_pulse_amr_problem(ctx: Context, n: int, max_level: int, max_grid_size: i
         for b in range(L.lev.nboxes):
             tags.valid(b)[0][L.state_new_cc_.valid(b)[6] > a.tag_threshold] = capi.TAG_SET
 
-    amr.tag_threshold = 1.5
+    amr.tag_threshold = tag_threshold
 
     amr.initial_conditions, amr.ErrorEst = ic_for, error_est
     amr.setInitialConditions()

@@ -184,3 +184,70 @@ def test_amr_hierarchy_across_ranks_matches_one_rank(ctx, world, distribution):
         if l == 0:
             assert len(owners_seen) == world
     assert worst <= 1e-13, worst
+
+
+def rad_amr_worker(rank, world, port, N, nsteps, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from quokka_amd.amr_simulation import rad_pulse_amr_problem
+        from quokka_amd.multifab import Context
+        ctx = Context(0)
+        amr = rad_pulse_amr_problem(ctx, N, 1, max_grid_size=16, blocking_factor=8, rank=rank, nranks=world, tag_threshold=1.02)
+        e0 = amr.composite_sum(5) + amr.composite_sum(6)
+        for _ in range(nsteps):
+            amr.step()
+        e1 = amr.composite_sum(5) + amr.composite_sum(6)
+        out = []
+        for L in amr.levels:
+            out.append(([(lo, hi) for lo, hi in L.all_boxes], list(L.owner), [(lo, hi) for lo, hi in L.my_boxes], [v.copy() for v in L.gather_valid_local()]))
+        q.put((rank, out, amr.tNew_, abs(e1 - e0) / e0, list(amr.istep)))
+    finally:
+        dist.destroy_process_group()
+
+
+def run_rad_amr_worker(rank, *args):
+    guarded(rad_amr_worker)(rank, *args)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_radiation_amr_hierarchy_across_ranks_matches_one_rank(ctx, world):
+    """The radiation pulse on a dynamically refined hierarchy (32^3 base grid in 16^3 boxes over 2 / 4 ranks): the reflux increments of the
+    radiation block cross ranks through their own SumBoundary.  Same grids and time steps as one rank with per-parent clustering, states to
+    rounding, E_int + E_rad of the composite grid at the Newton tolerance."""
+    from quokka_amd.amr_simulation import rad_pulse_amr_problem
+    N, nsteps = 32, 8
+    ref = rad_pulse_amr_problem(ctx, N, 1, max_grid_size=16, blocking_factor=8, cluster_within_parent=True, tag_threshold=1.02)
+    for _ in range(nsteps):
+        ref.step()
+    assert ref.finest_level == 1
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    port = free_port()
+    procs = [mpctx.Process(target=run_rad_amr_worker, args=(r, world, port, N, nsteps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = collect(procs, q, world)
+    results.sort(key=lambda r: r[0])
+    worst = 0.0
+    for rank, levels, tnew, drift, istep in results:
+        assert tnew == ref.tNew_ and istep == ref.istep, f"rank {rank}: time stepping differs"
+        assert len(levels) == 2 and drift <= 1e-11, (rank, drift)
+    for l, L in enumerate(ref.levels):
+        n = L.geom.n_cell
+        want = np.full((10, n[2], n[1], n[0]), np.nan)
+        for (lo, hi), v in zip(L.my_boxes, L.gather_valid_local()):
+            want[:, lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1] = v
+        got = np.full_like(want, np.nan)
+        for rank, levels, *_ in results:
+            all_boxes, owner, mine, vals = levels[l]
+            assert sorted(map(str, all_boxes)) == sorted(map(str, [(list(lo), list(hi)) for lo, hi in L.all_boxes])), f"level {l}: grids differ on rank {rank}"
+            for (lo, hi), v in zip(mine, vals):
+                got[:, lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1] = v
+        assert np.array_equal(np.isnan(got), np.isnan(want)), f"level {l}: coverage differs"
+        m = ~np.isnan(want)
+        for c in (0, 4, 5, 6):
+            mc = m[c]
+            worst = max(worst, float(np.abs(got[c][mc] - want[c][mc]).max() / np.abs(want[c][mc]).max()))
+    assert worst <= 1e-13, worst
