@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (ncell512, long_run, weak_256_per_gpu)")
     ap.add_argument("--long-steps", type=int, default=100, help="steps (and warm-up steps) of the long_run secondary figure")
     ap.add_argument("--cpu-ncell", type=int, default=128)
-    ap.add_argument("--cpu-steps", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=24)  # ~15 s of CPU work on 16 cores
     return ap.parse_args()
 
 
