@@ -558,6 +558,9 @@ int qk_rad_PredictStep(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int 
 	const Rad rad(*rt);
 	const qk_array4 *f0 = fluxArray[0], *f1 = (ndim >= 2) ? fluxArray[1] : nullptr, *f2 = (ndim == 3) ? fluxArray[2] : nullptr;
 	const double dx0 = dx_in[0], dx1 = dx_in[1], dx2 = dx_in[2];
+	// (the build dimension is a compile-time constant of the kernel: with run-time branches the y and z flux loads of a cell wait for one another)
+	auto run = [&](auto ND) {
+	constexpr int NDIM = decltype(ND)::value;
 	launchRad(lev, s, 0, -1, "rad_PredictStep", [=] __device__(int b, int i, int j, int k, bool valid) {
 		if (!valid) {
 			return;
@@ -565,17 +568,17 @@ int qk_rad_PredictStep(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int 
 		RA4 Uo(old_t[b]);
 		WA4 Un(new_t[b]);
 		RA4 x1(f0[b]);
+		RA4 x2((NDIM >= 2) ? f1[b] : f0[b]); // (descriptors read once per cell, outside the component loops)
+		RA4 x3((NDIM == 3) ? f2[b] : f0[b]);
 		// one photon group: the state with the flux divergence added
 		auto update = [&](int pg, double cons[NRAD]) {
 #pragma unroll
 			for (int n = 0; n < NRAD; ++n) {
 				double d = (dt / dx0) * (x1(i, j, k, pg + n) - x1(i + 1, j, k, pg + n));
-				if (ndim >= 2) { // radiation_system.hpp:681-690
-					RA4 x2(f1[b]);
+				if constexpr (NDIM >= 2) { // radiation_system.hpp:681-690
 					d = d + (dt / dx1) * (x2(i, j, k, pg + n) - x2(i, j + 1, k, pg + n));
 				}
-				if (ndim == 3) {
-					RA4 x3(f2[b]);
+				if constexpr (NDIM == 3) {
 					d = d + (dt / dx2) * (x3(i, j, k, pg + n) - x3(i, j, k + 1, pg + n));
 				}
 				cons[n] = Uo(i, j, k, RAD0 + pg + n) + d;
@@ -606,6 +609,14 @@ int qk_rad_PredictStep(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int 
 			}
 		}
 	});
+	};
+	if (ndim == 3) {
+		run(std::integral_constant<int, 3>{});
+	} else if (ndim == 2) {
+		run(std::integral_constant<int, 2>{});
+	} else {
+		run(std::integral_constant<int, 1>{});
+	}
 	return radStatus(lev, "rad PredictStep");
 }
 
@@ -624,6 +635,8 @@ int qk_rad_AddFluxesRK2(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int
 	const qk_array4 *o0 = fluxArrayOld[0], *o1 = (ndim >= 2) ? fluxArrayOld[1] : nullptr, *o2 = (ndim == 3) ? fluxArrayOld[2] : nullptr;
 	const qk_array4 *f0 = fluxArray[0], *f1 = (ndim >= 2) ? fluxArray[1] : nullptr, *f2 = (ndim == 3) ? fluxArray[2] : nullptr;
 	const double dx0 = dx_in[0], dx1 = dx_in[1], dx2 = dx_in[2];
+	auto run = [&](auto ND) {
+	constexpr int NDIM = decltype(ND)::value;
 	launchRad(lev, s, 0, -1, "rad_AddFluxesRK2", [=] __device__(int b, int i, int j, int k, bool valid) {
 		if (!valid) {
 			return;
@@ -632,6 +645,8 @@ int qk_rad_AddFluxesRK2(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int
 		RA4 U0(U0_t[b]);
 		RA4 U1(U1_t[b]);
 		RA4 xn(f0[b]);
+		RA4 yn((NDIM >= 2) ? f1[b] : f0[b]); // (descriptors read once per cell, outside the component loops)
+		RA4 zn((NDIM == 3) ? f2[b] : f0[b]);
 		// The old-state fluxes enter with the weight (0.5 - IMEX_a32), which is exactly 0 for the PD-ARS scheme (a32 = 0.5): the term is
 		// +-0 for finite fluxes and adding it can only change the sign of a zero result — they are not read (12 of the 36 words this kernel
 		// would otherwise stream).  Any other a32 takes the general form.
@@ -647,16 +662,14 @@ int qk_rad_AddFluxesRK2(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int
 					RA4 xo(o0[b]);
 					s0 = (dt / dx0) * (xo(i, j, k, pg + n) - xo(i + 1, j, k, pg + n));
 				}
-				if (ndim >= 2) { // radiation_system.hpp:728-757
-					RA4 yn(f1[b]);
+				if constexpr (NDIM >= 2) { // radiation_system.hpp:728-757
 					s1 = s1 + (dt / dx1) * (yn(i, j, k, pg + n) - yn(i, j + 1, k, pg + n));
 					if (useOld) {
 						RA4 yo(o1[b]);
 						s0 = s0 + (dt / dx1) * (yo(i, j, k, pg + n) - yo(i, j + 1, k, pg + n));
 					}
 				}
-				if (ndim == 3) {
-					RA4 zn(f2[b]);
+				if constexpr (NDIM == 3) {
 					s1 = s1 + (dt / dx2) * (zn(i, j, k, pg + n) - zn(i, j, k + 1, pg + n));
 					if (useOld) {
 						RA4 zo(o2[b]);
@@ -692,6 +705,14 @@ int qk_rad_AddFluxesRK2(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int
 			}
 		}
 	});
+	};
+	if (ndim == 3) {
+		run(std::integral_constant<int, 3>{});
+	} else if (ndim == 2) {
+		run(std::integral_constant<int, 2>{});
+	} else {
+		run(std::integral_constant<int, 1>{});
+	}
 	return radStatus(lev, "rad AddFluxesRK2");
 }
 
