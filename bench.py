@@ -55,6 +55,9 @@ def parse():
                          "max_level 2 (BASELINE config 5 geometry) and shell_amr = RadhydroShell with max_level 2 (tests/radhydro_shell_amr.in, the "
                          "reference paper's strong-scaling problem), each reported as a secondary line")
     ap.add_argument("--pow-mode", type=int, default=0, help="shell workload: 0 = libm pow(T,4) as the reference's std::pow (default), 1 = repeated multiplication")
+    ap.add_argument("--rk2-mode", choices=["exact", "carry"], default="exact",
+                    help="exact: flux_rk2 = 0.5 F1 + 0.5 F2 face by face as the reference (bit-identical to the oracle); carry: the RK2 average on the "
+                         "cell's right-hand side (qk_hydro_stage_args::rk2_carry_rhs, <= 1e-12 relative L1; fewer bytes per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (ncell512, long_run, weak_256_per_gpu)")
     ap.add_argument("--long-steps", type=int, default=100, help="steps (and warm-up steps) of the long_run secondary figure")
@@ -173,12 +176,13 @@ def pmc_traffic(ncell: int):
 
 
 # ---------------------------------------------------------------------------------------------------------------- Sedov runs
-def run_sedov(ctx, torch, dist, rank, world, ncell, mgs, steps, warmup, profile=True):
+def run_sedov(ctx, torch, dist, rank, world, ncell, mgs, steps, warmup, profile=True, carry=False):
     """build the problem, `warmup` untimed steps, then EXACTLY `steps` timed steps between barrier + synchronize pairs; max over ranks"""
     from quokka_amd.simulation import sedov_problem
     n_cell = weak_scaled_cells(ncell, world)
     sim = sedov_problem(ctx, ncell, max_grid_size=mgs, rank=rank, nranks=world, n_cell=n_cell)
     sim.maxTimesteps_ = 10 ** 9
+    sim.rk2_carry_rhs = bool(carry)
 
     def barrier():
         torch.cuda.synchronize()
@@ -384,7 +388,7 @@ def main():
 
     # ------------------------------------------------------------------------------------------------------------ Sedov (headline)
     mgs = args.max_grid_size
-    sim, n_cell, elapsed, kernels = run_sedov(ctx, torch, dist, rank, world, ncell, mgs, args.steps, args.warmup)
+    sim, n_cell, elapsed, kernels = run_sedov(ctx, torch, dist, rank, world, ncell, mgs, args.steps, args.warmup, carry=(args.rk2_mode == "carry"))
     cells_local = sim.lev.num_cells()
     total_cells = n_cell[0] * n_cell[1] * n_cell[2]
     roofline = roofline_of(kernels, cells_local, total_cells, args.steps, elapsed, world, ncell, mgs)
@@ -398,6 +402,7 @@ def main():
                    "cells_per_gpu": ncell ** 3, "boxes_per_gpu": sim.lev.nboxes, "parallelism": f"box-decomposition x{world}",
                    "ghost_exchange": None if world == 1 else {"backend": dist.get_backend(), "peers_rank0": len(sim.ghost.peers),
                                                               "overlap_early_late_boxes_rank0": None if groups is None else [len(groups[0][1]), len(groups[1][1])]},
+                   "rk2_mode": args.rk2_mode,
                    "fofc_stages": sim.counters["fofc1_stages"] + sim.counters["fofc2_stages"], "retries": sim.counters["retries"],
                    "sim_time": sim.tNew_,
                    "note": "N = 1 runs BASELINE config 2 (256^3); N > 1 runs 512^3 cells per GPU (N = 8: config 3, 1024^3); "

@@ -201,6 +201,14 @@ typedef struct qk_hydro_stage_args {
 				  * reference src/QuokkaSimulation.hpp:1303-1306) into fluxRk2[d]; 0: not stored */
 	qk_array4 *fluxRk2[3];	 /* face-centred like halfFlux, 6 components; required when store_flux_rk2 != 0.  Separate from halfFlux: the x
 				  * sweep evaluates the face between two of its tiles in both of them, and both need the stage-1 flux intact */
+	int rk2_carry_rhs;	 /* 0: flux_rk2 = 0.5 F1 + 0.5 F2 face by face, as the reference forms it (QuokkaSimulation.hpp:1106, :1220) — bit-identical
+				  *    to the reference-shaped operators;
+				  * 1: the RK2 average is taken on the cell's right-hand side instead: stage 1 stores div F1 and div v1 in `rhs1`,
+				  *    stage 2 updates with 0.5 rhs1 + 0.5 rhs2.  Equal in exact arithmetic, rounded differently (~1e-16 relative per
+				  *    step; within the 1e-12 of the parity contract, tests/test_hydro_step_gpu.py); the face arrays halfFlux /
+				  *    halfVel are neither written nor read (they may be NULL), so flux_rk2 does not exist: excludes store_flux_rk2,
+				  *    and a stage-2 first-order flux correction must recompute F1 from U_old with qk_hydro_ComputeFluxes */
+	qk_array4 *rhs1;	 /* rk2_carry_rhs: cell-centred, no ghost cells, 6 + nscalars + 1 components; must survive from stage 1 to stage 2 */
 } qk_hydro_stage_args;
 
 /* One RK stage of advanceHydroAtLevel (reference src/QuokkaSimulation.hpp:1099-1198 / 1202-1287) WITHOUT the

@@ -1,28 +1,19 @@
-// qk_hydro_fused.hip — the throughput path: one RK stage of the hydro update as six launches
-//   k_pre_x  U -> primitive variables (valid+4)                        [HydroSystem::ConservedToPrimitive]
-//            + x flattening coefficient, its 3-cell min and D_x        [ComputeFlatteningCoefficients<X1>]
-//   k_pre_march<Y>, <Z>  flattening coefficient of the direction, running min over the 3x3 axis neighbours
-//            (-> the combined chi of FlattenShocks) and the velocity differences D_y, D_z (valid+1)
-//   k_sweep_x / k_sweep_march<Y> / k_sweep_march<Z>:
-//            PPM (or PLM / donor) reconstruction + shock flattening + HLLC + flux divergence + face-velocity
-//            divergence, fused per sweep direction; nothing but the per-direction half-step fluxes F1 (needed
-//            bit-exactly by stage 2: flux_rk2 = 0.5 F1 + 0.5 F2) and a 7-component rhs accumulator touches HBM.
-//            The Z sweep carries the epilogue: P dV term, PredictStep, validity flag, EnforceLimits, SyncDualEnergy.
-//
-// MI355X mapping
-//   * X sweep: the pencil direction is the contiguous one, so one thread owns one cell of a flat, row-contiguous
-//     slab (rows j = lo..hi of one k-plane are adjacent in memory); +-2 stencil values, right-edge states and face
-//     fluxes move between neighbouring lanes through LDS (30 KB per 256-thread workgroup, 82 VGPRs -> 5 waves per
-//     SIMD).  The kernel is FP64-issue bound (~1500 VALU slots per cell, 31 divisions + 6 square roots per face).
-//   * Y / Z sweeps: lanes stay along x (coalesced 512-B wave loads), each thread MARCHES along the sweep direction
-//     with a 5-cell primitive window, the previous right-edge state and the previous face flux in registers: every
-//     face flux is evaluated exactly once, no LDS, no barriers.
-//     The ~105 doubles of per-thread state hold these kernels at 2 waves per SIMD; the x-sweep body throttled to
-//     2 waves per SIMD runs at the same 0.97 ms, i.e. they are bound by FP64 dependency chains, not by HBM.
-//     (Measured and rejected, see DESIGN.md §6: next-step prefetch into LDS with global_load_lds_dwordx4 and a rotated
-//      loop — bit-exact, +-2 %, i.e. nothing left to hide; 8-wide x tiles with LDS exchange along y/z — 64-byte row
-//      segments are 2-4x slower; a 168-VGPR cap for 3 waves per SIMD — spills; fmin/fmax for min/max — slower.)
-//   * all arithmetic in qk_device.hpp, shared with the reference-shaped operators -> identical bits.
+// qk_hydro_fused.hip — the throughput path: one RK stage of the hydro update as FOUR launches over all boxes of a level
+//   k_pre3           U -> the combined flattening coefficient of FlattenShocks [ComputeFlatteningCoefficients<X1,X2,X3> + FlattenShocks]
+//                    and the velocity differences D_x, D_y, D_z of the carbuncle switch, on valid + 1: x-y tile + march along z
+//   k_sweep_x        PPM (or PLM / donor) reconstruction + shock flattening + HLLC + flux divergence + face-velocity divergence along x:
+//                    one thread per cell of a row-contiguous slab, +-2 stencil, edge states and fluxes through LDS
+//   k_sweep_march<Y> the same along y: lanes along x, each thread marches along y with a 5-cell primitive window in registers
+//   k_sweep_march<Z> the same along z + the epilogue: P dV term, PredictStep, validity flag, EnforceLimits, SyncDualEnergy, CFL maxima
+// Every sweep converts U to primitives itself (no primitive arrays in HBM); a 7-double right-hand-side accumulator travels X -> Y -> Z.
+// Two ways to form the RK2 average (qk_hydro_stage_args::rk2_carry_rhs):
+//   0  the reference's: flux_rk2 = 0.5 F1 + 0.5 F2 face by face — stage 1 stores F1 (7 doubles per face and direction), stage 2 reads
+//      it back; bit-identical to the reference-shaped operators, needed when flux registers or the first-order correction consume flux_rk2;
+//   1  carried right-hand side: stage 1 stores div F1 and div v1 per CELL (7 doubles once instead of 3 x 7), stage 2 averages
+//      0.5 rhs1 + 0.5 rhs2 — the same quantity in exact arithmetic, a different rounding (~1e-16 per step; north_star allows 1e-12).
+// Measured characteristics (profiles/round2, round3): the X sweep is FP64-issue bound (~1160 VALU instructions per cell at
+// 5 waves per SIMD), the marching sweeps (228-251 VGPRs, 2 waves per SIMD) move their real HBM traffic at ~5 TB/s.
+// All arithmetic lives in qk_device.hpp, shared with the reference-shaped operators -> identical bits.
 #include "qk_device.hpp"
 #include <algorithm>
 #include <cstdlib>
@@ -74,6 +65,7 @@ struct SweepArgs {
 	bool same_old; // U_old is U_in (stage 1): the final sweep keeps the conserved state of its last three march positions in LDS instead of re-reading it
 	bool store_rk2; // stage 2: write flux_rk2 = 0.5 F1 + 0.5 F2 to rk2Flux (never over F1: tile-boundary faces of the x sweep are evaluated twice)
 	qk_array4 *rk2Flux;
+	qk_array4 *rhs1; // carried right-hand side (rk2_carry_rhs): per cell div F1 (nv components) + div v1, written by stage 1, read by stage 2
 	int nseg; // segments along the march axis (marching sweeps; see k_pre_march)
 };
 
@@ -349,12 +341,35 @@ QK_DEV auto epiEint(Eos const &eos, EpiConst const &ec, double rho, double T) ->
 }
 
 // U holds the old state of the cell on entry
-template <int NS>
-QK_DEV void updateCellFrom(SweepArgs const &a, Eos const &eos, EpiConst const &ec, int b, int i, int j, int k, double U[NVAR + NS], const double rhs[NVAR + NS],
-			   double div_v, double &sig0, double &sig1)
+// CS (carry stage): 0 the reference's flux average (rhs already holds div flux_rk2); 1: stage 1 of the carried-rhs mode, rhs / div_v are
+// stored for stage 2; 2: stage 2, `rhs1` holds what stage 1 stored and the update uses 0.5 rhs1 + 0.5 rhs
+template <int NS, int CS>
+QK_DEV void updateCellFrom(SweepArgs const &a, Eos const &eos, EpiConst const &ec, int b, int i, int j, int k, double U[NVAR + NS], const double rhs_sweeps[NVAR + NS],
+			   double div_v, const double rhs1[NVAR + NS + 1], double &sig0, double &sig1)
 {
 	WA4 Un(a.U_out[b]);
 	IA4 flag(a.redoFlag[b]);
+	double rhs[NVAR + NS];
+#pragma unroll
+	for (int n = 0; n < NVAR + NS; ++n) {
+		rhs[n] = rhs_sweeps[n];
+	}
+	if (CS == 1) {
+		WA4 R1(a.rhs1[b]);
+		const int64_t c1 = R1.idx(i, j, k);
+#pragma unroll
+		for (int n = 0; n < NVAR + NS; ++n) {
+			R1.p[c1 + R1.ns * n] = rhs[n];
+		}
+		R1.p[c1 + R1.ns * (NVAR + NS)] = div_v;
+	}
+	if (CS == 2) {
+#pragma unroll
+		for (int n = 0; n < NVAR + NS; ++n) {
+			rhs[n] = 0.5 * rhs1[n] + 0.5 * rhs[n];
+		}
+		div_v = 0.5 * rhs1[NVAR + NS] + 0.5 * div_v;
+	}
 	// hydro_system.hpp:797-812 (redoFlag == none branch): P(U_old) = ComputePressure(cons)
 	double Pgas;
 	{
@@ -452,7 +467,7 @@ QK_DEV void updateCellFrom(SweepArgs const &a, Eos const &eos, EpiConst const &e
 constexpr int XB = 256;	 // threads per workgroup
 constexpr int XOUT = 250; // cells updated per workgroup (3 halo cells on each side)
 
-template <int ORDER, int STAGE, int NS> __global__ void __launch_bounds__(XB) k_sweep_x(SweepArgs a, Eos eos)
+template <int ORDER, int STAGE, int NS, bool CARRY> __global__ void __launch_bounds__(XB) k_sweep_x(SweepArgs a, Eos eos)
 {
 	constexpr int NV = NVAR + NS; // hydro variables + passive scalars
 	constexpr int RHS_DIVV = S_RHS + NV;
@@ -538,7 +553,9 @@ template <int ORDER, int STAGE, int NS> __global__ void __launch_bounds__(XB) k_
 
 	const bool validRow = inside;
 	const bool isFace = validRow && (i >= bx.lo[0]) && (i <= bx.hi[0] + 1) && (t >= 3) && (t <= XB - 3);
-	if (STAGE == 1) {
+	if (CARRY) {
+		// carried right-hand side: neither stage touches the face arrays
+	} else if (STAGE == 1) {
 		if (isFace) {
 			WA4 HF(a.halfFlux[b]);
 			WA4 HV(a.halfVel[b]);
@@ -596,7 +613,7 @@ template <int ORDER, int STAGE, int NS> __global__ void __launch_bounds__(XB) k_
 #define QK_MARCH_BY 4
 #endif
 constexpr int MARCH_BY = QK_MARCH_BY; // rows of the other transverse axis per workgroup (64 x MARCH_BY threads)
-template <int DIR, int ORDER, int STAGE, bool LAST, int NS> __global__ void __launch_bounds__(64 * MARCH_BY) k_sweep_march(SweepArgs a, Eos eos)
+template <int DIR, int ORDER, int STAGE, bool LAST, int NS, bool CARRY> __global__ void __launch_bounds__(64 * MARCH_BY) k_sweep_march(SweepArgs a, Eos eos)
 {
 	constexpr int NV = NVAR + NS; // hydro variables + passive scalars
 	constexpr int RHS_DIVV = S_RHS + NV;
@@ -724,8 +741,20 @@ template <int DIR, int ORDER, int STAGE, bool LAST, int NS> __global__ void __la
 					Uo[n] = Uold.p[co + Uold.ns * n];
 				}
 			}
+			if (CARRY && LAST && STAGE == 2) { // what stage 1 stored for this cell (F1[] is free in this mode)
+				RA4 R1(a.rhs1[b]);
+				int uc[3];
+				uc[0] = i;
+				uc[OT] = ot;
+				uc[DIR] = lo + (step - 6);
+				const int64_t c1 = R1.idx(uc[0], uc[1], uc[2]);
+#pragma unroll
+				for (int n = 0; n < NV + 1; ++n) {
+					F1[n] = R1.p[c1 + R1.ns * n];
+				}
+			}
 		}
-		if (STAGE == 2 && step >= 5) {
+		if (!CARRY && STAGE == 2 && step >= 5) {
 			RA4 HF(a.halfFlux[b]);
 			RA4 HV(a.halfVel[b]);
 			const int64_t o = HF.idx(fidx[0], fidx[1], fidx[2]);
@@ -753,7 +782,9 @@ template <int DIR, int ORDER, int STAGE, bool LAST, int NS> __global__ void __la
 					F[n] = scalarFlux<QK_RIEMANN_HLLC>(wv, apPrev[n], am[n]);
 				}
 			}
-			if (STAGE == 1) {
+			if (CARRY) {
+				// carried right-hand side: no face arrays
+			} else if (STAGE == 1) {
 				if (live) {
 					WA4 HF(a.halfFlux[b]);
 					WA4 HV(a.halfVel[b]);
@@ -794,7 +825,7 @@ template <int DIR, int ORDER, int STAGE, bool LAST, int NS> __global__ void __la
 					u[OT] = ot;
 					u[DIR] = lo + (step - 6);
 					if (live) {
-						updateCellFrom<NS>(a, eos, ec, b, u[0], u[1], u[2], Uo, rhs, div_v, sig0, sig1);
+						updateCellFrom<NS, CARRY ? STAGE : 0>(a, eos, ec, b, u[0], u[1], u[2], Uo, rhs, div_v, F1, sig0, sig1);
 					}
 				} else if (live) {
 #pragma unroll
@@ -868,7 +899,7 @@ auto buildGeom(qk_level *lev) -> int
 	return QK_OK;
 }
 
-template <int ORDER, int STAGE, int NS> void launchSweeps(qk_level *lev, hipStream_t s, SweepArgs a, Eos eos, const qk_hydro_stage_args *args)
+template <int ORDER, int STAGE, int NS, bool CARRY> void launchSweeps(qk_level *lev, hipStream_t s, SweepArgs a, Eos eos, const qk_hydro_stage_args *args)
 {
 	// X
 	{
@@ -881,7 +912,7 @@ template <int ORDER, int STAGE, int NS> void launchSweeps(qk_level *lev, hipStre
 		const int64_t slab = static_cast<int64_t>(lev->maxlen[0] + 2 * NG) * lev->maxlen[1];
 		const dim3 grid(static_cast<unsigned>((slab + XOUT - 1) / XOUT), static_cast<unsigned>(lev->maxlen[2]), static_cast<unsigned>(lev->nboxes));
 		ProfScope ps(lev->ctx, s, "k_sweep_x");
-		hipLaunchKernelGGL((k_sweep_x<ORDER, STAGE, NS>), grid, dim3(XB), 0, s, ax, eos);
+		hipLaunchKernelGGL((k_sweep_x<ORDER, STAGE, NS, CARRY>), grid, dim3(XB), 0, s, ax, eos);
 	}
 	// Y
 	{
@@ -894,7 +925,7 @@ template <int ORDER, int STAGE, int NS> void launchSweeps(qk_level *lev, hipStre
 		ay.nseg = marchSegments(lev, 1, 2);
 		const dim3 grid((lev->maxlen[0] + 63) / 64, (lev->maxlen[2] + MARCH_BY - 1) / MARCH_BY, lev->nboxes * ay.nseg);
 		ProfScope ps(lev->ctx, s, "k_sweep_y");
-		hipLaunchKernelGGL((k_sweep_march<1, ORDER, STAGE, false, NS>), grid, dim3(64, MARCH_BY), 0, s, ay, eos);
+		hipLaunchKernelGGL((k_sweep_march<1, ORDER, STAGE, false, NS, CARRY>), grid, dim3(64, MARCH_BY), 0, s, ay, eos);
 	}
 	// Z (+ epilogue)
 	{
@@ -908,7 +939,7 @@ template <int ORDER, int STAGE, int NS> void launchSweeps(qk_level *lev, hipStre
 		az.nseg = marchSegments(lev, 2, 1);
 		const dim3 grid((lev->maxlen[0] + 63) / 64, (lev->maxlen[1] + MARCH_BY - 1) / MARCH_BY, lev->nboxes * az.nseg);
 		ProfScope ps(lev->ctx, s, "k_sweep_z");
-		hipLaunchKernelGGL((k_sweep_march<2, ORDER, STAGE, true, NS>), grid, dim3(64, MARCH_BY), 0, s, az, eos);
+		hipLaunchKernelGGL((k_sweep_march<2, ORDER, STAGE, true, NS, CARRY>), grid, dim3(64, MARCH_BY), 0, s, az, eos);
 	}
 }
 
@@ -959,8 +990,10 @@ int qk_hydro_stage_fused(qk_level *lev, qk_stream stream, const qk_hydro_traits 
 	QK_REQUIRE(ctx, args->reconstruction_order >= 1 && args->reconstruction_order <= 3, "qk_hydro_stage_fused: reconstruction_order must be 1..3");
 	QK_REQUIRE(ctx, args->U_in && args->U_old && args->U_out && args->redoFlag && args->d_redo_count && args->d_error_flag && args->scratch,
 		   "qk_hydro_stage_fused: NULL array");
+	QK_REQUIRE(ctx, args->rk2_carry_rhs == 0 || (args->rhs1 != nullptr && args->store_flux_rk2 == 0),
+		   "qk_hydro_stage_fused: rk2_carry_rhs needs rhs1 and excludes store_flux_rk2 (flux_rk2 is never formed in that mode)");
 	for (int d = 0; d < 3; ++d) {
-		QK_REQUIRE(ctx, args->halfFlux[d] && args->halfVel[d], "qk_hydro_stage_fused: NULL halfFlux/halfVel");
+		QK_REQUIRE(ctx, args->rk2_carry_rhs != 0 || (args->halfFlux[d] && args->halfVel[d]), "qk_hydro_stage_fused: NULL halfFlux/halfVel");
 		QK_REQUIRE(ctx, args->store_flux_rk2 == 0 || args->stage != 2 || (args->fluxRk2[d] != nullptr && args->fluxRk2[d] != args->halfFlux[d]),
 			   "qk_hydro_stage_fused: store_flux_rk2 needs fluxRk2[d], distinct from halfFlux[d]");
 		QK_REQUIRE(ctx, lev->maxlen[d] >= 1, "qk_hydro_stage_fused: empty box");
@@ -1012,12 +1045,19 @@ int qk_hydro_stage_fused(qk_level *lev, qk_stream stream, const qk_hydro_traits 
 	a.use_dual_energy = args->use_dual_energy;
 	a.reconstruct_eint = re;
 	a.store_rk2 = (args->store_flux_rk2 != 0);
+	a.rhs1 = args->rhs1;
 
 #define QK_LAUNCH_NS(ORDER, NS)                                                                                                                      \
-	if (args->stage == 1) {                                                                                                                      \
-		launchSweeps<ORDER, 1, NS>(lev, s, a, eos, args);                                                                                    \
+	if (args->rk2_carry_rhs != 0) {                                                                                                              \
+		if (args->stage == 1) {                                                                                                              \
+			launchSweeps<ORDER, 1, NS, true>(lev, s, a, eos, args);                                                                      \
+		} else {                                                                                                                             \
+			launchSweeps<ORDER, 2, NS, true>(lev, s, a, eos, args);                                                                      \
+		}                                                                                                                                    \
+	} else if (args->stage == 1) {                                                                                                               \
+		launchSweeps<ORDER, 1, NS, false>(lev, s, a, eos, args);                                                                             \
 	} else {                                                                                                                                     \
-		launchSweeps<ORDER, 2, NS>(lev, s, a, eos, args);                                                                                    \
+		launchSweeps<ORDER, 2, NS, false>(lev, s, a, eos, args);                                                                             \
 	}
 #define QK_LAUNCH(ORDER)                                                                                                                             \
 	switch (t->nscalars) {                                                                                                                       \

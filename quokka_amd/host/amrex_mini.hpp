@@ -1,26 +1,19 @@
 // amrex_mini.hpp — the slice of the AMReX API that the reference's hot-path callers and the three config problems use
 // (Box, IntVect, Array4, GpuArray, BCRec, Geometry, MultiFab / iMultiFab with device storage, ParmParse, ParallelFor
-// on host staging buffers, Print / Abort).  AMReX is an un-vendored submodule of the reference and is absent from this
+// as HIP kernels, Print / Abort).  AMReX is an un-vendored submodule of the reference and is absent from this
 // image, so problem generators written against the reference's surface are compiled against this header instead.
 // Device data live in HIP allocations; the descriptor table of a MultiFab (`arrays()`) is what the C-ABI consumes
 // (qk_array4 == amrex::Array4<Real>).
 //
-// Two ways to compile a problem file against it:
-//   * host mode (plain C++17, the adapted problem files under problems/): AMREX_GPU_DEVICE is empty, ParallelFor is a host loop over
-//     staging buffers that the driver uploads;
-//   * device mode (-x hip -DQK_DEVICE_LAMBDAS, what `make refproblem P=<dir>` uses to compile the reference's problem files UNCHANGED, read in
-//     place from /root/reference/src/problems): AMREX_GPU_DEVICE is __device__, ParallelFor launches the lambda as a HIP kernel over device
-//     arrays (MFIter / array(mfi) / const_array(mfi) / Gpu::DeviceVector / ReduceSum as the reference uses them), initial conditions,
-//     ErrorEst, setCustomBoundaryConditions and the analysis lambdas of a problem run on the GPU exactly as written.  This is problem-side
-//     glue (one backend: HIP); the hot path stays behind include/quokka_amd.h.
+// One way to compile a problem file against it: as HIP (`-x hip`, what `make refproblem P=<dir>` uses to compile the reference's problem
+// files UNCHANGED, read in place from /root/reference/src/problems): AMREX_GPU_DEVICE is __device__, ParallelFor launches the lambda as a HIP
+// kernel over device arrays (MFIter / array(mfi) / const_array(mfi) / Gpu::DeviceVector / ReduceSum as the reference uses them); initial
+// conditions, ErrorEst, setCustomBoundaryConditions and the analysis lambdas of a problem run on the GPU exactly as written.  This is
+// problem-side glue (one backend: HIP); the hot path stays behind include/quokka_amd.h.
 #ifndef QK_HOST_AMREX_MINI_HPP_
 #define QK_HOST_AMREX_MINI_HPP_
 
-#if defined(QK_DEVICE_LAMBDAS)
 #include <hip/hip_runtime.h>
-#else
-#include <hip/hip_runtime_api.h>
-#endif
 
 #include <algorithm>
 #include <cassert>
@@ -46,24 +39,13 @@
 #ifndef AMREX_SPACEDIM
 #define AMREX_SPACEDIM 3
 #endif
-#if defined(QK_DEVICE_LAMBDAS)
 #define AMREX_GPU_DEVICE __device__
 #define AMREX_GPU_HOST_DEVICE __host__ __device__
 #define AMREX_GPU_HOST __host__
 #define QK_HD __host__ __device__
 #define AMREX_USE_GPU 1
 #define AMREX_USE_HIP 1
-#else
-#define AMREX_GPU_DEVICE
-#define AMREX_GPU_HOST_DEVICE
-#define AMREX_GPU_HOST
-#define QK_HD
-#endif
-#if defined(QK_DEVICE_LAMBDAS)
 #define AMREX_GPU_MANAGED __managed__
-#else
-#define AMREX_GPU_MANAGED
-#endif
 #define AMREX_FORCE_INLINE inline
 #define AMREX_INLINE inline
 #define AMREX_NO_INLINE
@@ -101,16 +83,23 @@ using Real = double;
 using Long = long;
 template <typename T> using Vector = std::vector<T>;
 
-#if defined(QK_DEVICE_LAMBDAS)
 // inside kernels: stop the wave (the reference's device-side amrex::Abort traps as well)
 __device__ inline void Abort(char const * /*msg*/) { __builtin_trap(); }
-#endif
 [[noreturn]] inline void Abort(std::string const &msg)
 {
 	std::fprintf(stderr, "amrex::Abort: %s\n", msg.c_str());
 	std::exit(2);
 }
 inline void ignore_unused(...) {}
+// after every kernel launch of this header: a lambda that cannot be launched (too many registers, invalid configuration) must not go unnoticed
+inline void qk_check_launch(char const *what)
+{
+	hipError_t const e = hipGetLastError();
+	if (e != hipSuccess) {
+		std::fprintf(stderr, "%s: %s\n", what, hipGetErrorString(e));
+		std::exit(2);
+	}
+}
 
 struct PrintStream {
 	template <typename T> auto operator<<(T const &v) -> PrintStream &
@@ -279,7 +268,6 @@ template <typename F> QK_HD void Loop(Box const &bx, F const &f)
 		}
 	}
 }
-#if defined(QK_DEVICE_LAMBDAS)
 // amrex::ParallelFor on the GPU: one thread per cell of the box, the lambda by value in the kernel arguments (default stream: ordered with
 // the C-ABI calls of the driver, which use the same stream)
 template <typename F> __global__ void qk_parfor_kernel(Box bx, F f)
@@ -315,6 +303,7 @@ template <typename F> void ParallelFor(Box const &bx, F const &f)
 		return;
 	}
 	hipLaunchKernelGGL(qk_parfor_kernel<F>, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, nullptr, bx, f);
+	qk_check_launch("amrex::ParallelFor");
 }
 template <typename F> void ParallelFor(Box const &bx, int ncomp, F const &f)
 {
@@ -323,6 +312,7 @@ template <typename F> void ParallelFor(Box const &bx, int ncomp, F const &f)
 		return;
 	}
 	hipLaunchKernelGGL(qk_parfor_kernel_n<F>, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, nullptr, bx, ncomp, f);
+	qk_check_launch("amrex::ParallelFor");
 }
 // amrex::ParallelForRNG / amrex::Random: one counter-based stream per cell (splitmix64 of the flat cell index and a draw counter)
 struct RandomEngine {
@@ -337,19 +327,34 @@ QK_HD inline auto Random(RandomEngine const &e) -> Real
 	z ^= z >> 31;
 	return static_cast<Real>(z >> 11) * (1.0 / 9007199254740992.0);
 }
+// key of a cell's stream: splitmix64 over (launch number, i, j, k) — every ParallelForRNG call draws a different field (a global launch counter,
+// the same on every rank as long as the ranks make the same calls; the cell index is global, so the field does not depend on the box layout),
+// negative / ghost indices and indices beyond 2^21 do not alias
+QK_HD inline auto qk_mix64(unsigned long long z) -> unsigned long long
+{
+	z += 0x9E3779B97F4A7C15ULL;
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+	return z ^ (z >> 31);
+}
+inline auto qk_rng_launch_counter() -> unsigned long long &
+{
+	static unsigned long long n = 0;
+	return n;
+}
 template <typename F> void ParallelForRNG(Box const &bx, F const &f)
 {
+	unsigned long long const launch = ++qk_rng_launch_counter();
 	ParallelFor(bx, [=] __device__(int i, int j, int k) {
 		RandomEngine e;
-		e.key = (static_cast<unsigned long long>(static_cast<unsigned>(i)) << 42) ^ (static_cast<unsigned long long>(static_cast<unsigned>(j)) << 21) ^
-			static_cast<unsigned long long>(static_cast<unsigned>(k));
+		unsigned long long h = qk_mix64(launch);
+		h = qk_mix64(h ^ static_cast<unsigned long long>(static_cast<long long>(i)));
+		h = qk_mix64(h ^ static_cast<unsigned long long>(static_cast<long long>(j)));
+		h = qk_mix64(h ^ static_cast<unsigned long long>(static_cast<long long>(k)));
+		e.key = h;
 		f(i, j, k, e);
 	});
 }
-#else
-// host mode: the device ParallelFor of the reference runs as a host loop over staging buffers
-template <typename F> void ParallelFor(Box const &bx, F &&f) { HostFor(bx, f); }
-#endif
 
 namespace BCType
 {
@@ -506,10 +511,13 @@ class ParmParse
 		}                                                                                                                                    \
 	} while (0)
 
-#if defined(QK_DEVICE_LAMBDAS)
 // amrex::launch(box, f(Box const &tbx)): the reference uses it on single-cell boxes; one thread gets the whole box
 template <typename F> __global__ void qk_launch_kernel(Box bx, F f) { f(bx); }
-template <typename F> void launch(Box const &bx, F const &f) { hipLaunchKernelGGL(qk_launch_kernel<F>, dim3(1), dim3(1), 0, nullptr, bx, f); }
+template <typename F> void launch(Box const &bx, F const &f)
+{
+	hipLaunchKernelGGL(qk_launch_kernel<F>, dim3(1), dim3(1), 0, nullptr, bx, f);
+	qk_check_launch("amrex::launch");
+}
 // amrex::AsyncArray<T>: a device copy of a host array that lives as long as the object
 template <typename T> class AsyncArray
 {
@@ -529,7 +537,6 @@ template <typename T> class AsyncArray
 	T *d_ = nullptr;
 	std::size_t n_ = 0;
 };
-#endif
 
 struct DistributionMapping {
 	DistributionMapping() = default;
@@ -817,7 +824,6 @@ class MFIter
 	std::vector<Box> const *boxes_ = nullptr;
 	int ng_ = 0;
 };
-#if defined(QK_DEVICE_LAMBDAS)
 // amrex::ParallelFor(mf, f(box_no, i, j, k)) / (mf, nghost, f): every valid (grown) cell of every local box
 template <typename T, typename F> void ParallelFor(FabArrayT<T> const &mf, IntVect const &ng, F const &f)
 {
@@ -852,7 +858,6 @@ template <typename T> void FabArrayT<T>::ParallelCopy(FabArrayT<T> const &src)
 	// (HydroRichtmeyerMeshkov's symmetry check does)
 	QK_HOST_HIP(hipDeviceSynchronize());
 }
-#endif
 using MultiFab = FabArrayT<Real>;
 using iMultiFab = FabArrayT<int>;
 // amrex::TagBoxArray: one char per cell (amrex::TagBox::CLEAR = 0, BUF = 1, SET = 2)

@@ -91,12 +91,15 @@ template <typename problem_t> class AmrDriver
 		tNew_ = base_.tNew_[0];
 		while (istep[0] < base_.maxTimesteps_ && tNew_ < base_.stopTime_) {
 			computeTimestep();
+			base_.callBeforeTimestep(); // reference src/simulation.hpp:864-867
+			dropSignalsIfHooked(base_.beforeTimestepIsDefault_);
 			timeStepWithSubcycling(0, tNew_);
 			tNew_ += dt_[0];
 			base_.tNew_[0] = tNew_;
 			base_.dt_[0] = dt_[0];
 			base_.istep[0] = istep[0];
-			base_.computeAfterTimestep(); // reference src/simulation.hpp:890
+			base_.callAfterTimestep(); // reference src/simulation.hpp:890
+			dropSignalsIfHooked(base_.afterTimestepIsDefault_);
 			base_.outputAfterStep(istep[0] - 1);
 			if (tNew_ >= base_.stopTime_ - 1.e-6 * dt_[0]) {
 				break;
@@ -191,6 +194,17 @@ template <typename problem_t> class AmrDriver
 	Sim &base_;
 	std::vector<std::unique_ptr<Finer>> finerOwned_;
 	std::vector<Finer *> finer_; // finer_[l-1] = level l
+	// a specialised user hook may have changed the state of any level: none of them may reuse the signal speeds its last stage cached
+	void dropSignalsIfHooked(bool hookIsDefault)
+	{
+		if (!hookIsDefault) {
+			for (auto *f : finer_) {
+				if (f != nullptr) {
+					f->sim->dropCachedSignal();
+				}
+			}
+		}
+	}
 
 	static auto qgeom(amrex::Geometry const &g) -> qk_geometry
 	{
@@ -348,6 +362,7 @@ template <typename problem_t> class AmrDriver
 		me.radiationCflNumber_ = base_.radiationCflNumber_; // (the problem sets these on the level-0 object in problem_main)
 		me.radiationReconstructionOrder_ = base_.radiationReconstructionOrder_;
 		me.maxSubsteps_ = base_.maxSubsteps_;
+		me.radSourceTimeIndependent_ = base_.radSourceTimeIndependent_;
 		me.dustGasInteractionCoeff_ = base_.dustGasInteractionCoeff_;
 		me.constantDt_ = base_.constantDt_;
 		me.tOldLev_ = me.tNewLev_ = tNew_;
@@ -702,7 +717,6 @@ template <typename problem_t> void QuokkaSimulation<problem_t>::WriteCheckpointF
 	quokka::io::WriteCheckpointFile(name, h, state);
 }
 
-#if defined(QK_DEVICE_LAMBDAS)
 template <typename problem_t>
 template <typename F>
 auto QuokkaSimulation<problem_t>::computeAxisAlignedProfile(const int axis, F const &user_f) -> amrex::Gpu::HostVector<amrex::Real>
@@ -742,7 +756,6 @@ auto QuokkaSimulation<problem_t>::computeAxisAlignedProfile(const int axis, F co
 	}
 	return profile;
 }
-#endif
 
 template <typename problem_t> void QuokkaSimulation<problem_t>::evolve()
 {

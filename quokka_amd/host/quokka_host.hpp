@@ -1088,7 +1088,6 @@ template <typename problem_t> struct SimulationData {
 template <typename problem_t> class AmrDriver; // quokka_amr.hpp
 template <typename problem_t> class AMRSimulation;
 
-#if defined(QK_DEVICE_LAMBDAS)
 namespace qkhost
 {
 template <typename problem_t>
@@ -1114,7 +1113,6 @@ __global__ void customBcKernel(amrex::Array4<amrex::Real> dest, amrex::Box fab, 
 	}
 }
 } // namespace qkhost
-#endif
 
 // one refinement level handed to a simulation object by the AMR driver (quokka_amr.hpp): geometry of that level and its boxes
 struct LevelSpec {
@@ -1342,17 +1340,9 @@ template <typename problem_t> class AMRSimulation
 		auto &mf = state_new_cc_[0];
 		if (restart_chkfile.empty()) {
 			for (int b = 0; b < mf.size(); ++b) {
-#if defined(QK_DEVICE_LAMBDAS)
 				// device mode: the problem's ParallelFor runs as a kernel on the level's own arrays
 				quokka::grid grid_elem{mf.array(b), mf.validbox(b), geom[0].CellSizeArray(), geom[0].ProbLoArray(), geom[0].ProbHiArray()};
 				setInitialConditionsOnGrid(grid_elem);
-#else
-				std::vector<double> h(static_cast<size_t>(mf.fabbox(b).numPts()) * mf.nComp(), 0.0);
-				quokka::grid grid_elem{amrex::Array4<double>(h.data(), mf.fabbox(b), mf.nComp()), mf.validbox(b), geom[0].CellSizeArray(),
-						       geom[0].ProbLoArray(), geom[0].ProbHiArray()};
-				setInitialConditionsOnGrid(grid_elem);
-				mf.copyFromHost(b, h);
-#endif
 			}
 		} else {
 			// level 0 of ReadCheckpointFile (reference src/simulation.hpp:2736-2801): the BoxArray comes from the deck, the data by
@@ -1363,7 +1353,6 @@ template <typename problem_t> class AMRSimulation
 			tNew_[0] = h.tNew.at(0);
 			quokka::io::VisMFReadInto(mf, restart_chkfile + "/Level_0/Cell");
 		}
-		buildDirichletModel();
 		fillBoundaryConditions(state_new_cc_[0]);
 		amrex::MultiFab::Copy(state_old_cc_[0], state_new_cc_[0]);
 		areInitialConditionsDefined_ = true;
@@ -1374,16 +1363,8 @@ template <typename problem_t> class AMRSimulation
 	{
 		auto &mf = state_new_cc_[0];
 		for (int b = 0; b < mf.size(); ++b) {
-#if defined(QK_DEVICE_LAMBDAS)
 			quokka::grid grid_elem{mf.array(b), mf.validbox(b), geom[0].CellSizeArray(), geom[0].ProbLoArray(), geom[0].ProbHiArray()};
 			setInitialConditionsOnGrid(grid_elem);
-#else
-			std::vector<double> h(static_cast<size_t>(mf.fabbox(b).numPts()) * mf.nComp(), 0.0);
-			quokka::grid grid_elem{amrex::Array4<double>(h.data(), mf.fabbox(b), mf.nComp()), mf.validbox(b), geom[0].CellSizeArray(),
-					       geom[0].ProbLoArray(), geom[0].ProbHiArray()};
-			setInitialConditionsOnGrid(grid_elem);
-			mf.copyFromHost(b, h);
-#endif
 		}
 		amrex::MultiFab::Copy(state_old_cc_[0], state_new_cc_[0]);
 		areInitialConditionsDefined_ = true;
@@ -1425,14 +1406,11 @@ template <typename problem_t> class AMRSimulation
 					bcs[n].hi[d] = (d < AMREX_SPACEDIM) ? BCs_cc_[n].hi(d) : 0;
 				}
 			}
-			qkhost::check(qk_FillPhysicalBoundary(plan_, nullptr, qkhost::tab(state), bcs.data(), hasDirichlet_ ? dirichlet_ : nullptr),
+			qkhost::check(qk_FillPhysicalBoundary(plan_, nullptr, qkhost::tab(state), bcs.data(), nullptr),
 				      "FillPhysicalBoundary");
-#if defined(QK_DEVICE_LAMBDAS)
 			customBoundaryConditionsOnDevice(state);
-#endif
 		}
 	}
-#if defined(QK_DEVICE_LAMBDAS)
 	// setCustomBoundaryConditions as the reference runs it (simulation.hpp:297-299, :1550-1561; amrex::GpuBndryFuncFab): the problem's
 	// DEVICE function is called for every ghost cell that lies outside the domain in a non-periodic direction, after the mathematical
 	// boundary types have been filled.  One kernel instantiated with the problem type per box — arbitrary boundary code, not the closed
@@ -1463,117 +1441,11 @@ template <typename problem_t> class AMRSimulation
 		}
 	}
 	amrex::BCRec *d_bcrec_ = nullptr;
-#endif
 	[[nodiscard]] virtual auto bcFillTime() const -> double { return tNew_[0]; }
 
       protected:
 	qk_level *myLev_ = nullptr;
 	qk_ghost_plan *plan_ = nullptr;
-	qk_dirichlet_face dirichlet_[6] = {};
-	bool hasDirichlet_ = false;
-
-	// Sample the problem's setCustomBoundaryConditions on host staging cells beyond each non-periodic face: if it writes a state
-	// there (as HydroShocktube's does), that face becomes a Dirichlet face of the C-ABI's closed model.  The staging array reaches
-	// the first valid cell inside the face, which a Marshak condition reads (RadMarshak): probing that cell with three
-	// (E_0, F_0) pairs tells a constant state from the half-range form 0.5 c E_inc - 0.5 (c E_0 + 2 F_0), the only dependence
-	// on the interior the closed set knows.
-	void buildDirichletModel()
-	{
-#if defined(QK_DEVICE_LAMBDAS)
-		// device mode: setCustomBoundaryConditions is device code and runs as a kernel after every fill (customBoundaryConditionsOnDevice)
-		return;
-#else
-		int const nc = Physics_Indices<problem_t>::nvarTotal_cc;
-		auto const &g = geom[0];
-		double const sentinel = -7.7e300;
-		constexpr bool hasRad = Physics_Traits<problem_t>::is_radiation_enabled;
-		int const eComp = Physics_Indices<problem_t>::radFirstIndex;
-		for (int d = 0; d < AMREX_SPACEDIM; ++d) {
-			if (g.isPeriodic(d)) {
-				continue;
-			}
-			for (int side = 0; side < 2; ++side) {
-				// [probe cell][interior probe]: ghost cells 1 and 2 beyond the face; interior (E_0, F_0) = (0,0), (1,0), (0,1)
-				double vals[2][3][16];
-				double const probes[3][2] = {{0.0, 0.0}, {1.0, 0.0}, {0.0, 1.0}};
-				for (int probe = 0; probe < 2; ++probe) {
-					for (int q = 0; q < 3; ++q) {
-						amrex::IntVect lo(g.domain.lo[0], g.domain.lo[1], g.domain.lo[2]);
-						amrex::IntVect hi = lo;
-						amrex::IntVect iv = lo;
-						if (side == 0) {
-							lo[d] = g.domain.lo[d] - 2;
-							hi[d] = g.domain.lo[d];
-							iv[d] = g.domain.lo[d] - 1 - probe;
-						} else {
-							lo[d] = g.domain.hi[d];
-							hi[d] = g.domain.hi[d] + 2;
-							iv[d] = g.domain.hi[d] + 1 + probe;
-						}
-						amrex::Box strip(lo, hi);
-						std::vector<double> h(static_cast<size_t>(nc) * 3, sentinel);
-						amrex::Array4<double> a(h.data(), strip, nc);
-						amrex::IntVect in = iv;
-						in[d] = (side == 0) ? g.domain.lo[d] : g.domain.hi[d];
-						for (int n = 0; n < nc; ++n) {
-							a(in[0], in[1], in[2], n) = 0.0;
-						}
-						if constexpr (hasRad) {
-							a(in[0], in[1], in[2], eComp) = probes[q][0];
-							a(in[0], in[1], in[2], eComp + 1 + d) = probes[q][1];
-						}
-						AMRSimulation<problem_t>::setCustomBoundaryConditions(iv, a, 0, nc, g.data(), 0.0, BCs_cc_.data(), 0, 0);
-						for (int n = 0; n < nc; ++n) {
-							vals[probe][q][n] = a(iv[0], iv[1], iv[2], n);
-						}
-					}
-				}
-				bool wrote = false, constant = true, interiorDependent = false;
-				for (int n = 0; n < nc; ++n) {
-					wrote = wrote || (vals[0][0][n] != sentinel);
-					constant = constant && (vals[0][0][n] == vals[1][0][n]);
-					interiorDependent = interiorDependent || (vals[0][1][n] != vals[0][0][n]) || (vals[0][2][n] != vals[0][0][n]);
-				}
-				if (!wrote) {
-					continue;
-				}
-				if (!constant) {
-					amrex::Abort("setCustomBoundaryConditions is not a constant state per face: not expressible in the C-ABI's closed BC set");
-				}
-				auto &f = dirichlet_[2 * d + side];
-				f.enabled = 1;
-				for (int n = 0; n < nc; ++n) {
-					f.values[n] = vals[0][0][n];
-				}
-				hasDirichlet_ = true;
-				if (interiorDependent) {
-					bool ok = hasRad && side == 0;
-					if constexpr (hasRad) {
-						double const c = RadSystem_Traits<problem_t>::c_light;
-						int const fComp = eComp + 1 + d;
-						double const E_inc = vals[0][0][eComp];
-						for (int n = 0; n < nc; ++n) { // only the normal flux may follow the interior
-							ok = ok && (n == fComp || (vals[0][1][n] == vals[0][0][n] && vals[0][2][n] == vals[0][0][n]));
-						}
-						for (int q = 0; q < 3; ++q) {
-							double const want = 0.5 * c * E_inc - 0.5 * (c * probes[q][0] + 2.0 * probes[q][1]);
-							ok = ok && (vals[0][q][fComp] == want);
-						}
-						f.marshak = 1;
-						f.marshak_energy_comp = eComp;
-						f.marshak_flux_comp = fComp;
-						f.marshak_c = c;
-						f.values[fComp] = 0.0;
-					}
-					if (!ok) {
-						amrex::Abort("setCustomBoundaryConditions reads the interior in a way the C-ABI's closed BC set does not know (only "
-							     "the Marshak half-range flux on a lower face)");
-					}
-				}
-			}
-		}
-	#endif
-	}
 };
 
 template <typename problem_t> class QuokkaSimulation : public AMRSimulation<problem_t>
@@ -1611,6 +1483,8 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	amrex::Real radiationCflNumber_ = 0.3;
 	amrex::Real dustGasInteractionCoeff_ = 2.5e-34; // erg cm^3 s^-1 K^-3/2 (QuokkaSimulation.hpp:127; radiation.dust_gas_interaction_coeff, :392)
 	int maxSubsteps_ = 10;
+	bool afterTimestepIsDefault_ = false, beforeTimestepIsDefault_ = false; // set by the default computeAfterTimestep / computeBeforeTimestep
+	bool radSourceTimeIndependent_ = false; // deck: radiation.source_is_time_independent (fillRadEnergySource)
 	amrex::Long radiationCellUpdates_ = 0;
 	long radSolves_ = 0, radNewtonIterations_ = 0;
 	int radMaxNewtonIterations_ = 0;
@@ -1714,6 +1588,11 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		rpp.query("cfl", radiationCflNumber_);
 		rpp.query("dust_gas_interaction_coeff", dustGasInteractionCoeff_);
 		rpp.query("max_substeps", maxSubsteps_);
+		{
+			int ti = 0;
+			rpp.query("source_is_time_independent", ti);
+			radSourceTimeIndependent_ = (ti != 0);
+		}
 		std::string walltime;
 		if (amrex::ParmParse().query("max_walltime", walltime)) { // H:M:S (reference src/simulation.hpp:618-628)
 			int h = 0, m = 0, sec = 0;
@@ -1784,16 +1663,30 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	void preCalculateInitialConditions() override;
 	void computeAfterEvolve(amrex::Vector<amrex::Real> &initSumCons) override;
 	void computeAfterTimestep(); // reference src/simulation.hpp:228, :890 (default: nothing)
-#if defined(QK_DEVICE_LAMBDAS)
 	// the mean of user_f(i, j, k, state) over the planes normal to `axis` (QuokkaSimulation.hpp:843-881): evaluated on every level, averaged
 	// down, summed on level 0.  Defined in quokka_amr.hpp.
 	template <typename F> auto computeAxisAlignedProfile(int axis, F const &user_f) -> amrex::Gpu::HostVector<amrex::Real>;
-#endif
 	// Strang-split source terms a problem may add (QuokkaSimulation.hpp:235): called with dt/2 on the old state before the hydro update and on
 	// the new state after it (:1048, :1318)
 	void addStrangSplitSources(amrex::MultiFab &state, int lev, amrex::Real time, amrex::Real dt_lev);
 	void createInitialParticles();
 	void computeBeforeTimestep();
+	// the two user hooks as the drivers call them: a specialised hook may change the state, so the signal speeds cached by the last stage are dropped
+	void dropCachedSignal() { haveSignal_ = false; }
+	void callAfterTimestep()
+	{
+		computeAfterTimestep();
+		if (!afterTimestepIsDefault_) {
+			haveSignal_ = false;
+		}
+	}
+	void callBeforeTimestep()
+	{
+		computeBeforeTimestep();
+		if (!beforeTimestepIsDefault_) {
+			haveSignal_ = false;
+		}
+	}
 	void computeReferenceSolution(amrex::MultiFab & /*ref*/, amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> const & /*dx*/,
 				      amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> const & /*prob_lo*/)
 	{
@@ -1871,6 +1764,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		double cur_time = tNew_[0];
 		for (int step = istep[0]; step < maxTimesteps_ && cur_time < stopTime_; ++step) {
 			computeTimestep();
+			callBeforeTimestep(); // reference src/simulation.hpp:864-867: after computeTimestep
 			double const time = tNew_[0];
 			tNew_[0] += dt_[0];
 			std::swap(state_old_cc_[0], state_new_cc_[0]);
@@ -1888,7 +1782,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 			this->cellUpdates_ += this->CountCells(0);
 			cur_time += dt_[0];
 			tNew_[0] = cur_time;
-			computeAfterTimestep(); // reference src/simulation.hpp:890
+			callAfterTimestep(); // reference src/simulation.hpp:890
 			outputAfterStep(step);
 			if (cur_time >= stopTime_ - 1.e-6 * dt_[0]) {
 				break;
@@ -1994,56 +1888,19 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		return static_cast<int>(std::ceil(dt_lev_hydro / dtrad_tmp));
 	}
 
-	// operatorSplitSourceTerms (:1859-1882).  SetRadEnergySource is a host-evaluated hook here: it is sampled at two times on
-	// the first box; a time-independent source (RadhydroShell) is evaluated once and kept on the device.
+	// operatorSplitSourceTerms (:1859-1882).  The problem's SetRadEnergySource launches its own kernel on the source array before every
+	// source-term call, as the reference does (:1866-1873).  A deck may declare the source time-independent
+	// (`radiation.source_is_time_independent = 1`, an extension of this host; default 0): it is then evaluated once — the kernel was 9 % of a
+	// RadhydroShell step (160 launches per step).  Nothing is inferred: a source that is switched off at some time (RadSuOlson) needs the default.
 	void fillRadEnergySource(double time)
 	{
+		if (radSourceTimeIndependent_ && radSourceFilled_) {
+			return;
+		}
 		auto const &g = geom[0];
-#if defined(QK_DEVICE_LAMBDAS)
-		// device mode: the problem's SetRadEnergySource launches its own kernel on the source array.  The reference does so before every
-		// source-term call; a source that does not depend on time (found by evaluating box 0 at two times, once) is kept instead — the
-		// kernel was 9 % of a RadhydroShell step (160 launches per step).
-		auto launch = [&](int b, double t) {
+		for (int b = 0; b < radEnergySource_.size(); ++b) {
 			auto arr = radEnergySource_.array(b);
-			RadSystem<problem_t>::SetRadEnergySource(arr, radEnergySource_.validbox(b), g.CellSizeArray(), g.ProbLoArray(), g.ProbHiArray(), t);
-		};
-		if (radSourceState_ == 0) {
-			double same = 1.0;
-			if (radEnergySource_.size() > 0) {
-				launch(0, 0.0);
-				auto const a0 = radEnergySource_.copyToHost(0);
-				launch(0, 0.37 * stopTime_ + 1.0);
-				auto const a1 = radEnergySource_.copyToHost(0);
-				same = (a0 == a1) ? 1.0 : 0.0;
-			}
-			same = qkhost::Comm::get().allReduceMin(same); // (every rank takes the same branch, also one without boxes)
-			radSourceState_ = (same == 1.0) ? 1 : 2;
-			radSourceFilled_ = false;
-		}
-		if (radSourceState_ == 1 && radSourceFilled_) {
-			return;
-		}
-		for (int b = 0; b < radEnergySource_.size(); ++b) {
-			launch(b, time);
-		}
-		radSourceFilled_ = true;
-		return;
-#endif
-		auto eval = [&](int b, double t) {
-			std::vector<double> h(static_cast<size_t>(radEnergySource_.fabbox(b).numPts()) * radEnergySource_.nComp(), 0.0);
-			amrex::Array4<double> a(h.data(), radEnergySource_.fabbox(b), radEnergySource_.nComp());
-			RadSystem<problem_t>::SetRadEnergySource(a, radEnergySource_.validbox(b), g.CellSizeArray(), g.ProbLoArray(), g.ProbHiArray(), t);
-			return h;
-		};
-		if (radSourceState_ == 0) {
-			radSourceState_ = (eval(0, 0.0) == eval(0, 0.37 * stopTime_ + 1.0)) ? 1 : 2; // 1: time independent
-			radSourceFilled_ = false;
-		}
-		if (radSourceState_ == 1 && radSourceFilled_) {
-			return;
-		}
-		for (int b = 0; b < radEnergySource_.size(); ++b) {
-			radEnergySource_.copyFromHost(b, eval(b, time));
+			RadSystem<problem_t>::SetRadEnergySource(arr, radEnergySource_.validbox(b), g.CellSizeArray(), g.ProbLoArray(), g.ProbHiArray(), time);
 		}
 		radSourceFilled_ = true;
 	}
@@ -2155,7 +2012,6 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	std::array<amrex::MultiFab, AMREX_SPACEDIM> radFluxOld_, radFlux_;
 	amrex::MultiFab radEnergySource_;
 	int *d_radCounter_ = nullptr, *d_radFailure_ = nullptr;
-	int radSourceState_ = 0; // 0: unknown, 1: time independent, 2: evaluated every call
 	bool radSourceFilled_ = false;
 
 	[[nodiscard]] auto minDx() const -> double
@@ -2331,6 +2187,13 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 				qkhost::check(qk_replaceFluxes(lev, nullptr, d, qkhost::tab((*vl)[d]), qkhost::tab(FOvel_[d]), qkhost::itab(redoFlag_), 1), "replaceFluxes");
 			}
 			nbad = rhsPdvPredict(*fl, *vl, U_old, U_out, dt);
+			if (stageNo == 1 && integratorOrder_ == 1) {
+				// forward Euler: halfFlux() hands halfFlux_ to incrementFluxRegisters — it must be the flux the state was updated
+				// with, i.e. the CORRECTED one (the reference increments with the corrected fluxArrays, QuokkaSimulation.hpp:1160-1196)
+				for (int d = 0; d < AMREX_SPACEDIM; ++d) {
+					amrex::MultiFab::Copy(halfFlux_[d], flux_[d]);
+				}
+			}
 			if (nbad > 0 && abortOnFofcFailure_ != 0) {
 				return false;
 			}
@@ -2395,8 +2258,9 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 
 template <typename problem_t> void QuokkaSimulation<problem_t>::preCalculateInitialConditions() {}
 
-template <typename problem_t> void QuokkaSimulation<problem_t>::computeAfterTimestep() {}
-template <typename problem_t> void QuokkaSimulation<problem_t>::computeBeforeTimestep() {}
+// (a problem that specialises one of these hooks never sets the flag: the driver then drops its cached signal speeds after the call)
+template <typename problem_t> void QuokkaSimulation<problem_t>::computeAfterTimestep() { afterTimestepIsDefault_ = true; }
+template <typename problem_t> void QuokkaSimulation<problem_t>::computeBeforeTimestep() { beforeTimestepIsDefault_ = true; }
 template <typename problem_t> void QuokkaSimulation<problem_t>::createInitialParticles() {}
 template <typename problem_t>
 void QuokkaSimulation<problem_t>::addStrangSplitSources(amrex::MultiFab & /*state*/, int /*lev*/, amrex::Real /*time*/, amrex::Real /*dt_lev*/)

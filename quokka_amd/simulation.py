@@ -496,6 +496,17 @@ class HydroSimulation:
             self._fluxRk2 = [MultiFab(self.lev, self.hydro.nvar_, 0, facedir=d, fill=0.0) for d in range(self.geom.ndim)]
         return self._fluxRk2
 
+    def _carry_active(self) -> bool:
+        """the carried-right-hand-side form of the RK2 average (qk_hydro_stage_args::rk2_carry_rhs; `rk2_carry_rhs` attribute, default off):
+        only where nothing consumes flux_rk2 (no flux registers) and the integrator has two stages"""
+        return bool(getattr(self, "rk2_carry_rhs", False)) and self.integratorOrder_ == 2 and not getattr(self, "store_flux_rk2", False)
+
+    def rhs1(self):
+        """div F1 and div v1 per cell, written by stage 1 and read by stage 2 in the carried-rhs mode"""
+        if getattr(self, "_rhs1", None) is None:
+            self._rhs1 = MultiFab(self.lev, self.hydro.nvar_ + 1, 0, fill=0.0)
+        return self._rhs1
+
     def _is_final(self, stage: int) -> bool:
         return (stage == 2) or (self.integratorOrder_ == 1)
 
@@ -527,6 +538,9 @@ class HydroSimulation:
         if a.store_flux_rk2:
             for d in range(3):
                 a.fluxRk2[d] = tab(self.fluxRk2()[d])
+        if self._carry_active():
+            a.rk2_carry_rhs = 1
+            a.rhs1 = tab(self.rhs1())
         c = self.ctx
         c.check(c.L.qk_hydro_stage_fused(lev.h, c.stream(), C.byref(self.traits), C.byref(a)), "qk_hydro_stage_fused")
 
@@ -582,15 +596,27 @@ class HydroSimulation:
         self.ghost.fill(U_in, between=lambda: self._fused_launch(stage, U_in, U_old, U_out, dt, early))
         self._fused_launch(stage, U_in, U_old, U_out, dt, late)
         if self._fused_end(stage) == 0:
+            self._stage1_left_F1 = (stage == 1 and not self._carry_active())
             return True
-        return self._stage_unfused(stage, U_in, U_old, U_out, dt, with_fofc=True)
+        return self._redo_stage_unfused(stage, U_in, U_old, U_out, dt)
 
     def _stage(self, stage, U_in, U_old, U_out, dt) -> bool:
         if self.use_fused:
             nbad = self._stage_fused(stage, U_in, U_old, U_out, dt)
             if nbad == 0:
+                self._stage1_left_F1 = (stage == 1 and not self._carry_active())
                 return True
             # first-order flux correction needed: redo the stage with the reference-shaped operators
+        return self._redo_stage_unfused(stage, U_in, U_old, U_out, dt)
+
+    def _redo_stage_unfused(self, stage, U_in, U_old, U_out, dt) -> bool:
+        """a stage whose fused attempt flagged cells, on the reference-shaped operators.  Stage 2 forms 0.5 F1 + 0.5 F2 from halfFlux: after a
+        fused stage 1 in the carried-rhs mode F1 was never stored and is evaluated again from the old state (ghost cells still filled; the
+        operators and the fused sweeps share their device functions, so these are the values stage 1 used)."""
+        if stage == 2 and self.use_fused and not getattr(self, "_stage1_left_F1", True):
+            self.computeHydroFluxes(U_old, self.halfFlux, self.halfVel)
+        if stage == 1:
+            self._stage1_left_F1 = True  # _stage_unfused(1) writes halfFlux
         return self._stage_unfused(stage, U_in, U_old, U_out, dt, with_fofc=True)
 
     # ------------------------------------------------------------------ advance

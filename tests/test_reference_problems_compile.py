@@ -1,5 +1,4 @@
-"""How many of the reference's problem files compile UNCHANGED against the host mirror (device mode: hipcc -fsyntax-only -x hip
--DQK_DEVICE_LAMBDAS -I quokka_amd/host).  The sources are read in place from /root/reference (nothing is copied); skipped where the
+"""How many of the reference's problem files compile UNCHANGED against the host mirror (hipcc -fsyntax-only -x hip -I quokka_amd/host).  The sources are read in place from /root/reference (nothing is copied); skipped where the
 reference tree does not exist (the GPU box).  The three problems of BASELINE.json's configs must compile; the total is reported and must
 not fall below the count this round reached."""
 import concurrent.futures as cf
@@ -31,7 +30,7 @@ def compiles(pdir):
     srcs = sorted(glob.glob(os.path.join(pdir, "*.cpp")))
     if not srcs:
         return None
-    cmd = ["/opt/rocm/bin/hipcc", "-fsyntax-only", "-std=c++17", "-x", "hip", "--offload-arch=gfx950", "-DQK_DEVICE_LAMBDAS", "-I" + HOST,
+    cmd = ["/opt/rocm/bin/hipcc", "-fsyntax-only", "-std=c++17", "-x", "hip", "--offload-arch=gfx950", "-I" + HOST,
            "-I" + os.path.join(HOST, ".shims"), "-I" + os.path.join(ROOT, "include"), "-I" + pdir, f"-DAMREX_SPACEDIM={spacedim(pdir)}", "-w"] + srcs
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     first = next((l for l in p.stderr.splitlines() if "error" in l), "")
