@@ -39,6 +39,12 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 ALG_BYTES = {"k_sweep_x": 128.0, "k_sweep_y": 184.0, "k_sweep_z": 184.0}
 ALG_BYTES_PRE = 72.0
 ALG_BYTES_STEP = 1496.0
+FP64_VALU_PEAK = 256 * 64 * 2.4e9  # FP64 vector lane-instructions per second without FMA contraction (256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz)
+# radiation transport update kernels: doubles per cell they must move (state in / out + the face fluxes of three directions)
+RAD_STREAM_WORDS = {"rad_PredictStep": 22, "rad_AddFluxesRK2": 24}
+# Newton-Raphson exchange kernel (radSourceCell, single group, constant opacity): VALU instructions per cell outside / inside the Newton loop,
+# counted in the gfx950 ISA of qk_rad_ops.hip (profiles/round3/README.md)
+RAD_SOURCE_VALU_FIXED, RAD_SOURCE_VALU_PER_ITERATION = 900.0, 420.0
 
 
 def parse():
@@ -55,9 +61,13 @@ def parse():
                          "max_level 2 (BASELINE config 5 geometry) and shell_amr = RadhydroShell with max_level 2 (tests/radhydro_shell_amr.in, the "
                          "reference paper's strong-scaling problem), each reported as a secondary line")
     ap.add_argument("--pow-mode", type=int, default=0, help="shell workload: 0 = libm pow(T,4) as the reference's std::pow (default), 1 = repeated multiplication")
-    ap.add_argument("--rk2-mode", choices=["exact", "carry"], default="exact",
+    ap.add_argument("--rk2-mode", choices=["exact", "carry"], default="carry",
                     help="exact: flux_rk2 = 0.5 F1 + 0.5 F2 face by face as the reference (bit-identical to the oracle); carry: the RK2 average on the "
                          "cell's right-hand side (qk_hydro_stage_args::rk2_carry_rhs, <= 1e-12 relative L1; fewer bytes per step)")
+    ap.add_argument("--selftest", action="store_true",
+                    help="N > 1: a small blast (64^3 cells per rank in 32^3 boxes, 4 steps, early / late overlap forced on) on all ranks over RCCL, "
+                         "per-box digests compared with a one-rank run of the same global problem on rank 0; prints one JSON verdict and exits "
+                         "(a watchdog turns a hang into a FAIL line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (ncell512, long_run, weak_256_per_gpu)")
     ap.add_argument("--long-steps", type=int, default=100, help="steps (and warm-up steps) of the long_run secondary figure")
@@ -175,6 +185,174 @@ def pmc_traffic(ncell: int):
     return out, f"{os.path.relpath(best[1], ROOT)} (x2) + {os.path.relpath(best[2], ROOT)}"
 
 
+# ---------------------------------------------------------------------------------------------------------------- BASELINE configs 4 and 5
+def read_profile(ctx):
+    L = ctx.L
+    kernels = {}
+    for k in range(L.qk_profile_num_kernels(ctx.h)):
+        name, cnt, ms = C.c_char_p(), C.c_long(), C.c_double()
+        L.qk_profile_get(ctx.h, k, C.byref(name), C.byref(cnt), C.byref(ms))
+        kernels[name.value.decode()] = (cnt.value, ms.value)
+    return kernels
+
+
+def run_shell(ctx, torch, ncell, mgs, steps, warmup, pow_mode):
+    """BASELINE config 4: RadhydroShell (tests/radhydro_shell_256.in; the reference problem runs 50 steps, test_radhydro_shell.cpp:431), one update =
+    hydro RK2 + all radiation substeps.  Returns the JSON object of the line (headline with --workload shell, `shell256` block otherwise)."""
+    import numpy as np
+    from quokka_amd.radhydro import shell_problem
+    tab = np.loadtxt(os.path.join(ROOT, "tests", "golden", "dust_shell_initial_conditions.txt"), skiprows=1)
+    sim = shell_problem(ctx, ncell, (tab[:, 0], tab[:, 2], tab[:, 3]), max_grid_size=mgs, pow_mode=pow_mode)
+    sim.maxTimesteps_ = 10 ** 9
+    mass0 = sum(float(sim.state_new_cc_.valid(b)[0].sum().item()) for b in range(sim.lev.nboxes))
+    for _ in range(warmup):
+        assert sim.step()
+    L = ctx.L
+    L.qk_profile_reset(ctx.h)
+    L.qk_profile_enable(ctx.h, 1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        assert sim.step(), "radhydro advance failed"
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    L.qk_profile_enable(ctx.h, 0)
+    kernels = read_profile(ctx)
+    mass1 = sum(float(sim.state_new_cc_.valid(b)[0].sum().item()) for b in range(sim.lev.nboxes))
+    total_cells = ncell ** 3
+    per = {k: v[1] / max(v[0], 1) for k, v in sorted(kernels.items())}
+    launches = {k: v[0] for k, v in sorted(kernels.items())}
+    # per-kernel ceilings: the radiation update kernels stream (HBM roofline, doubles per cell: state in / out + face fluxes of three directions);
+    # the Newton-Raphson exchange kernel is arithmetic-bound: its ceiling is the FP64 vector rate without FMA contraction
+    # (39.3 T lane-instructions/s = 256 CUs x 64 lanes x 2.4 GHz; MI355X public spec 78.6 TFLOP/s counts an FMA as two)
+    roof = {}
+    for k, words in RAD_STREAM_WORDS.items():
+        if k in per and per[k] > 0:
+            roof[k] = {"bound": "hbm", "alg_bytes_per_cell": 8.0 * words, "ms_per_launch": per[k], "launches": launches[k],
+                       "frac": 8.0 * words * total_cells / (per[k] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    if per.get("rad_AddSourceTerms", 0) > 0:
+        it = sim.rad_counters["newton_iterations"] / max(sim.rad_counters["solves"], 1)
+        ops = RAD_SOURCE_VALU_FIXED + RAD_SOURCE_VALU_PER_ITERATION * it
+        roof["rad_AddSourceTerms"] = {"bound": "fp64-valu", "valu_instructions_per_cell_estimate": ops, "newton_iterations_per_solve": it,
+                                      "ms_per_launch": per["rad_AddSourceTerms"], "launches": launches["rad_AddSourceTerms"],
+                                      "frac": ops * total_cells / (per["rad_AddSourceTerms"] * 1e-3) / FP64_VALU_PEAK}
+    return {"metric": "Mcell-updates/s on RadhydroShell (one update = hydro RK2 + all radiation substeps)",
+            "value": total_cells * steps / elapsed / 1e6, "unit": "Mcell-updates/s", "n_gpus": 1, "steps": steps,
+            "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"RadhydroShell {ncell}^3 (tests/radhydro_shell_256.in), {mgs}^3 boxes, PLM, 1 group, kappa=20",
+                       "radiation_substeps_per_step": sim.radiationCellUpdates_ / max(sim.cellUpdates_, 1),
+                       "newton_iterations_per_solve": sim.rad_counters["newton_iterations"] / max(sim.rad_counters["solves"], 1),
+                       "solves_per_cell_and_source_call": sim.rad_counters["solves"] / max(2 * sim.radiationCellUpdates_, 1),
+                       "max_newton_iterations": sim.rad_counters["max_newton_iterations"], "pow_mode": pow_mode, "sim_time": sim.tNew_,
+                       "relative_mass_change": abs(mass1 - mass0) / mass0},
+            "roofline": {"kernels": roof, "note": "streaming kernels against 8 TB/s HBM; the Newton-Raphson kernel against the FP64 VALU issue rate"},
+            "kernels_ms_per_launch": per, "kernels_launches": launches,
+            "reference_published_a100_1gpu": 39.04}
+
+
+def run_amr(ctx, torch, dist, rank, world, ncell, steps, warmup):
+    """BASELINE config 5 geometry: tests/blast_amr_maxlev2.in (256^3 base grid, max_level 2, blocking_factor 32, subcycling + reflux).
+    Several GPUs: the SAME hierarchy (strong scaling).  Fine boxes live on the rank of their level-0 ancestor, so the level-0 boxes are made
+    smaller (64^3 instead of the deck's 128^3) and interleaved over the ranks: the refined shell around the blast then spreads over all of
+    them (amr_simulation.py, level0_distribution)."""
+    from quokka_amd.amr_simulation import sedov_amr_problem
+    mgs = 128 if world == 1 else 64
+    amr = sedov_amr_problem(ctx, ncell, 2, max_grid_size=mgs, blocking_factor=32, rank=rank, nranks=world)
+    E0, M0 = amr.composite_sum(4), amr.composite_sum(0)
+    for _ in range(warmup):
+        amr.step()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    sync()
+    u0, t0 = amr.cellUpdates_, time.perf_counter()
+    for _ in range(steps):
+        amr.step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    E1, M1 = amr.composite_sum(4), amr.composite_sum(0)
+    return {"metric": "Mcell-updates/s on 3D Sedov AMR (sum over levels, subcycled)", "value": (amr.cellUpdates_ - u0) / elapsed / 1e6,
+            "unit": "Mcell-updates/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"3D Sedov blast {ncell}^3 base grid, max_level 2, blocking_factor 32, max_grid_size {mgs} "
+                                   "(tests/blast_amr_maxlev2.in), subcycling + reflux",
+                       "clustering": getattr(amr, "clustering", "tiles"),
+                       "boxes_per_level_rank0": [L.lev.nboxes for L in amr.levels], "boxes_per_level": [len(L.all_boxes) for L in amr.levels],
+                       "cells_per_level": [amr.CountCells(l) for l in range(amr.finest_level + 1)], "sim_time": amr.tNew_,
+                       "coarse_steps_total": steps + warmup,
+                       "composite_energy_relative_change": abs(E1 - E0) / abs(E0), "composite_mass_relative_change": abs(M1 - M0) / abs(M0)}}
+
+
+def compact(block, keep=("value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline", "kernels_ms_per_launch")):
+    """a secondary block of the default line: the figures of a workload's own line without the contract boilerplate"""
+    return {k: block[k] for k in keep if k in block}
+
+
+
+# ---------------------------------------------------------------------------------------------------------------- N > 1 self-test
+def selftest(ctx, torch, dist, rank, world, carry):
+    """the first thing to run on a multi-GPU lease: does the RCCL path (strip pack -> P2P send / recv -> unpack, early / late schedule, fused
+    all-reduce of dt and counters) reproduce the one-rank state bit for bit?  A hang becomes a FAIL line after `limit` seconds."""
+    import hashlib
+    import signal
+    from quokka_amd.simulation import sedov_problem
+    limit = 240
+
+    def on_alarm(signum, frame):
+        print(json.dumps({"selftest": "FAIL", "reason": f"rank {rank}: no result after {limit} s (hang in the exchange?)", "n_gpus": world}), flush=True)
+        os._exit(3)
+    signal.signal(signal.SIGALRM, on_alarm)
+    signal.alarm(limit)
+    ncell, mgs, steps = 64, 32, 4
+    n_cell = weak_scaled_cells(ncell, world)
+
+    def digests(sim):
+        return {tuple(lo): hashlib.sha256(v.tobytes()).hexdigest() for (lo, hi), v in zip(sim.my_boxes, sim.gather_valid_local())}
+
+    sim = sedov_problem(ctx, ncell, max_grid_size=mgs, rank=rank, nranks=world, n_cell=n_cell)
+    sim.rk2_carry_rhs = carry
+    sim.min_overlap_cells = 1  # the early / late split even on this small problem
+    dts = []
+    for _ in range(steps):
+        assert sim.step(), "hydro advance failed"
+        dts.append(sim.dt_)
+    mine = digests(sim)
+    groups = sim.overlap_groups()
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (mine, dts))
+    verdict = None
+    if rank == 0:
+        one = sedov_problem(ctx, ncell, max_grid_size=mgs, rank=0, nranks=1, n_cell=n_cell)
+        one.rk2_carry_rhs = carry
+        dts1 = []
+        for _ in range(steps):
+            assert one.step()
+            dts1.append(one.dt_)
+        want = digests(one)
+        got = {}
+        for d, _ in gathered:
+            got.update(d)
+        bad = sorted(k for k in want if got.get(k) != want[k])
+        dt_ok = all(g[1] == dts1 for g in gathered)
+        verdict = {"selftest": "PASS" if (not bad and dt_ok and len(got) == len(want)) else "FAIL", "n_gpus": world, "backend": dist.get_backend(),
+                   "workload": f"3D Sedov {n_cell[0]}x{n_cell[1]}x{n_cell[2]}, {mgs}^3 boxes, {steps} steps, rk2_mode {'carry' if carry else 'exact'}",
+                   "boxes": len(want), "boxes_differing_from_one_rank": len(bad), "first_differing_boxes": bad[:4], "dt_equal_on_all_ranks": dt_ok,
+                   "peers_rank0": len(sim.ghost.peers), "early_late_boxes_rank0": None if groups is None else [len(groups[0][1]), len(groups[1][1])]}
+        print(json.dumps(verdict), flush=True)
+    signal.alarm(0)
+    dist.barrier()
+    dist.destroy_process_group()
+    return verdict
+
+
 # ---------------------------------------------------------------------------------------------------------------- Sedov runs
 def run_sedov(ctx, torch, dist, rank, world, ncell, mgs, steps, warmup, profile=True, carry=False):
     """build the problem, `warmup` untimed steps, then EXACTLY `steps` timed steps between barrier + synchronize pairs; max over ranks"""
@@ -258,17 +436,34 @@ def main():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    # QK_BENCH_ONE_GPU_TEST=1 (tests/test_multirank_one_gpu.py only): all ranks share cuda:0 and talk over gloo with host-staged buffers
+    # (quokka_amd/comm.py) — RCCL refuses two ranks on one device.  Never a measurement: refused unless --selftest.
+    share = os.environ.get("QK_BENCH_ONE_GPU_TEST") == "1"
+    if share:
+        if not args.selftest:
+            raise SystemExit("QK_BENCH_ONE_GPU_TEST is for --selftest only")
+        local_rank = 0
     if torch.cuda.device_count() < (local_rank + 1):
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPUs are visible (one rank per GPU)")
     torch.cuda.set_device(local_rank)
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
+                                    timeout=datetime.timedelta(seconds=600))
         world = dist.get_world_size()  # n_gpus below = the ranks RCCL actually connected
 
     from quokka_amd.multifab import Context
 
     ctx = Context(local_rank)
+    if args.selftest:
+        if world == 1:
+            raise SystemExit("--selftest compares N > 1 ranks with one rank: use --gpus N")
+        v = selftest(ctx, torch, dist, rank, world, carry=(args.rk2_mode == "carry"))
+        sys.exit(0 if (rank != 0 or v["selftest"] == "PASS") else 1)
     ncell = args.ncell if args.ncell is not None else (256 if world == 1 else 512)
     if args.workload == "shell_amr":
         import numpy as np
@@ -297,90 +492,17 @@ def main():
                           "reference_published_v100_4gpu": 19.82}), flush=True)
         return
     if args.workload == "amr":
-        from quokka_amd.amr_simulation import sedov_amr_problem
-        # several GPUs: the SAME 256^3-base hierarchy (strong scaling).  Fine boxes live on the rank of their level-0 ancestor, so the
-        # level-0 boxes are made smaller (64^3 instead of the deck's 128^3) and interleaved over the ranks: the refined shell around
-        # the blast then spreads over all of them (amr_simulation.py, level0_distribution)
-        ncell = args.ncell if args.ncell is not None else 256
-        mgs = 128 if world == 1 else 64
-        amr = sedov_amr_problem(ctx, ncell, 2, max_grid_size=mgs, blocking_factor=32, rank=rank, nranks=world)
-        for _ in range(args.warmup):
-            amr.step()
-
-        def sync():
-            torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
-            torch.cuda.synchronize()
-        sync()
-        u0, t0 = amr.cellUpdates_, time.perf_counter()
-        for _ in range(args.steps):
-            amr.step()
-        sync()
-        elapsed = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+        out = run_amr(ctx, torch, dist, rank, world, args.ncell if args.ncell is not None else 256, args.steps, args.warmup)
         if rank == 0:
-            print(json.dumps({"metric": "Mcell-updates/s on 3D Sedov AMR (sum over levels, subcycled)", "value": (amr.cellUpdates_ - u0) / elapsed / 1e6,
-                              "unit": "Mcell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-                              "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                              "config": {"workload": f"3D Sedov blast {ncell}^3 base grid, max_level 2, blocking_factor 32, max_grid_size {mgs} "
-                                                     "(tests/blast_amr_maxlev2.in), subcycling + reflux",
-                                         "clustering": getattr(amr, "clustering", "tiles"),
-                                         "boxes_per_level_rank0": [L.lev.nboxes for L in amr.levels], "boxes_per_level": [len(L.all_boxes) for L in amr.levels],
-                                         "cells_per_level": [amr.CountCells(l) for l in range(amr.finest_level + 1)], "sim_time": amr.tNew_}}), flush=True)
+            print(json.dumps(out), flush=True)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
         return
 
     if args.workload == "shell":
-        import numpy as np
-        from quokka_amd.radhydro import shell_problem
         assert world == 1, "the shell line is single-GPU"
-        ncell = args.ncell if args.ncell is not None else 256
-        tab = np.loadtxt(os.path.join(ROOT, "tests", "golden", "dust_shell_initial_conditions.txt"), skiprows=1)
-        sim = shell_problem(ctx, ncell, (tab[:, 0], tab[:, 2], tab[:, 3]), max_grid_size=args.max_grid_size, pow_mode=args.pow_mode)
-        sim.maxTimesteps_ = 10 ** 9
-        for _ in range(args.warmup):
-            assert sim.step()
-        L = ctx.L
-        L.qk_profile_reset(ctx.h)
-        L.qk_profile_enable(ctx.h, 1)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            assert sim.step(), "radhydro advance failed"
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        L.qk_profile_enable(ctx.h, 0)
-        kernels = {}
-        for k in range(L.qk_profile_num_kernels(ctx.h)):
-            name, cnt, ms = C.c_char_p(), C.c_long(), C.c_double()
-            L.qk_profile_get(ctx.h, k, C.byref(name), C.byref(cnt), C.byref(ms))
-            kernels[name.value.decode()] = (cnt.value, ms.value)
-        total_cells = ncell ** 3
-        per = {k: v[1] / max(v[0], 1) for k, v in sorted(kernels.items())}
-        # the radiation update kernels stream (HBM roofline); the Newton-Raphson exchange kernel is arithmetic-bound: its ceiling is the
-        # FP64 vector rate without FMA contraction (39.3 T op/s = 256 CUs x 64 lanes x 2.4 GHz; MI355X public spec 78.6 TFLOP/s with FMA)
-        roof = {}
-        for k, words in (("rad_PredictStep", 22), ("rad_AddFluxesRK2", 24)):  # doubles per cell: state in/out + face fluxes of three directions
-            if k in per and per[k] > 0:
-                roof[k] = {"bound": "hbm", "alg_bytes_per_cell": 8.0 * words, "frac": 8.0 * words * total_cells / (per[k] * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        out = {"metric": "Mcell-updates/s on RadhydroShell (one update = hydro RK2 + all radiation substeps)",
-               "value": total_cells * args.steps / elapsed / 1e6, "unit": "Mcell-updates/s", "n_gpus": 1, "steps": args.steps,
-               "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f64", "data": "synthetic",
-               "config": {"workload": f"RadhydroShell {ncell}^3 (tests/radhydro_shell_256.in), PLM, 1 group, kappa=20",
-                          "radiation_substeps_per_step": sim.radiationCellUpdates_ / max(sim.cellUpdates_, 1),
-                          "newton_iterations_per_solve": sim.rad_counters["newton_iterations"] / max(sim.rad_counters["solves"], 1),
-                          "solves_per_cell_and_source_call": sim.rad_counters["solves"] / max(2 * sim.radiationCellUpdates_, 1),
-                          "max_newton_iterations": sim.rad_counters["max_newton_iterations"], "pow_mode": args.pow_mode},
-               "roofline": {"streaming_kernels": roof, "note": "the Newton-Raphson kernel (rad_AddSourceTerms) is FP64-issue bound, not HBM bound"},
-               "kernels_ms_per_launch": per, "kernels_launches": {k: v[0] for k, v in sorted(kernels.items())},
-               "reference_published_a100_1gpu": 39.04}
+        out = run_shell(ctx, torch, args.ncell if args.ncell is not None else 256, args.max_grid_size, args.steps, args.warmup, args.pow_mode)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_shell()
         print(json.dumps(out), flush=True)
@@ -427,6 +549,22 @@ def main():
             out["ncell512"] = {"value": 512 ** 3 * 8 / el5 / 1e6, "unit": "Mcell-updates/s", "steps": 8, "warmup": 2, "ms_per_step": el5 / 8 * 1e3,
                                "boxes": s5.lev.nboxes, "roofline": roofline_of(k5, s5.lev.num_cells(), 512 ** 3, 8, el5, 1, 512, mgs)}
             del s5
+            torch.cuda.empty_cache()
+            # (c) the other form of the RK2 average, same run (headline: --rk2-mode, default carry; `rk2_other_mode`: the remaining one)
+            other = "exact" if args.rk2_mode == "carry" else "carry"
+            sO, _, elO, kO = run_sedov(ctx, torch, dist, rank, world, 256, mgs, args.steps, args.warmup, carry=(other == "carry"))
+            out["rk2_other_mode"] = {"rk2_mode": other, "value": 256 ** 3 * args.steps / elO / 1e6, "unit": "Mcell-updates/s", "ms_per_step": elO / args.steps * 1e3,
+                                     "kernels_ms_per_launch": {k: v[1] / max(v[0], 1) for k, v in sorted(kO.items())},
+                                     "note": "exact = flux_rk2 = 0.5 F1 + 0.5 F2 face by face (bit-identical to the CPU oracle); carry = the average taken on the "
+                                             "cell's right-hand side (<= 1e-12 relative L1 per conserved component, tests/test_hydro_step_gpu.py, "
+                                             "tests/test_bench_geometry_gpu.py)"}
+            del sO
+            torch.cuda.empty_cache()
+            # (d) BASELINE config 4 at its full size: RadhydroShell 256^3, the 50 steps the reference problem runs (test_radhydro_shell.cpp:431)
+            out["shell256"] = compact(run_shell(ctx, torch, 256, 128, 50, 2, 0))
+            torch.cuda.empty_cache()
+            # (e) BASELINE config 5 geometry at its full size on the one GPU: blast_amr_maxlev2.in, 256^3 base grid + 2 levels
+            out["amr_maxlev2"] = compact(run_amr(ctx, torch, dist, rank, world, 256, 50, 5))
             torch.cuda.empty_cache()
         elif world > 1 and ncell != 256:
             sW, nW, elW, _ = run_sedov(ctx, torch, dist, rank, world, 256, mgs, args.steps, args.warmup, profile=False)

@@ -251,3 +251,21 @@ def test_radiation_amr_hierarchy_across_ranks_matches_one_rank(ctx, world):
             mc = m[c]
             worst = max(worst, float(np.abs(got[c][mc] - want[c][mc]).max() / np.abs(want[c][mc]).max()))
     assert worst <= 1e-13, worst
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_selftest_passes_on_ranks_sharing_the_gpu(world):
+    """`python bench.py --gpus N --selftest` — the command to run first on a multi-GPU lease — through the real launcher
+    (torch.distributed.run), with the ranks sharing this GPU over gloo (QK_BENCH_ONE_GPU_TEST; on N GPUs the same command goes over RCCL):
+    per-box digests of the N-rank run == the one-rank run, dt equal on all ranks, early / late schedule active."""
+    import json
+    import subprocess
+    env = dict(os.environ, QK_BENCH_ONE_GPU_TEST="1", OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--selftest"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{") and "selftest" in l]
+    assert p.returncode == 0 and len(lines) == 1, p.stdout[-1500:] + p.stderr[-1500:]
+    v = json.loads(lines[0])
+    assert v["selftest"] == "PASS" and v["n_gpus"] == world and v["boxes_differing_from_one_rank"] == 0 and v["dt_equal_on_all_ranks"], v
+    assert v["boxes"] == 8 * world and v["early_late_boxes_rank0"] is not None, v
