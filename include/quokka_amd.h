@@ -67,6 +67,11 @@ typedef struct qk_box {
  * quokka::EOS_Traits<P> (src/hydro/EOS.hpp:32-37), HydroSystem_Traits<P> (src/hydro/hydro_system.hpp:38-41),
  * Physics_Traits<P> (src/physics_info.hpp:8-17), AMREX_SPACEDIM. */
 #define QK_MAX_SCALARS 8
+/* value of qk_hydro_traits::eos_temperature_model, qk_rad_traits::opacity_model and qk_rad_traits::thermal_model that stands for "this hook
+ * is the problem's own compiled device function": only meaningful to the kernels a problem's translation unit instantiates itself
+ * (quokka_amd/host/qk_problem_kernels.hpp); every entry point of this library that would have to EVALUATE such a hook returns
+ * QK_ERR_UNSUPPORTED, the others ignore the field. */
+#define QK_HOOK_COMPILED 100
 typedef struct qk_hydro_traits {
 	double gamma;
 	double cs_isothermal;
@@ -170,6 +175,17 @@ int qk_hydro_maxSignalSpeedLocal(qk_level *lev, qk_stream s, const qk_hydro_trai
 int qk_replaceFluxes(qk_level *lev, qk_stream s, int dir, qk_array4 *flux, const qk_array4 *FOflux, const qk_iarray4 *redoFlag, int face_ncomp);
 /* MultiFab::Saxpy(dst, a, src, 0, 0, ncomp, 0) on the face boxes of `dir` (dir = -1: cell boxes)   reference src/QuokkaSimulation.hpp:1105-1108 */
 int qk_Saxpy(qk_level *lev, qk_stream s, int dir, qk_array4 *dst, double a, const qk_array4 *src, int ncomp);
+
+/* ------------------------------------------------------------------ LinearAdvectionSystem<problem_t> (reference src/linear_advection/linear_advection.hpp)
+ * the scalar advection solver shares HyperbolicSystem's reconstruction (qk_ReconstructStates*); its own operators: */
+/* ComputeFluxes<DIR>(x1Flux, x1LeftState, x1RightState, advectionVx, nvars): the upwind state times the velocity   linear_advection.hpp:165-198 */
+int qk_advect_ComputeFluxes(qk_level *lev, qk_stream s, int dir, qk_array4 *flux, const qk_array4 *left, const qk_array4 *right, double advectionVx, int nvars);
+/* PredictStep(consVarOld, consVarNew, fluxArray, dt, dx, nvars)                                                   linear_advection.hpp:82-118 */
+int qk_advect_PredictStep(qk_level *lev, qk_stream s, const qk_array4 *consVarOld, qk_array4 *consVarNew, const qk_array4 *const fluxArray[3], double dt,
+			  const double dx[3], int nvars);
+/* AddFluxesRK2(U_new, U0, U1, fluxArray, dt, dx, nvars) (U_new may alias U1)                                       linear_advection.hpp:120-163 */
+int qk_advect_AddFluxesRK2(qk_level *lev, qk_stream s, qk_array4 *U_new, const qk_array4 *U0, const qk_array4 *U1, const qk_array4 *const fluxArray[3], double dt,
+			   const double dx[3], int nvars);
 
 /* ------------------------------------------------------------------ fused fast path (MI355X design; same results) */
 typedef struct qk_hydro_stage_args {

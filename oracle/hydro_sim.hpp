@@ -91,6 +91,11 @@ struct HydroSim {
 	long rad_iteration_counter[4] = {0, 0, 0, 0};	      // solves, Newton iterations, max Newton iterations, (decoupled)
 	long rad_iteration_failure_counter[3] = {0, 0, 0}; // coupling, dust, outer
 
+	// --- linear advection (reference src/linear_advection/AdvectionSimulation.hpp:89-96): one scalar carried at (advectionVx_, Vy_, Vz_); the
+	// hydro / radiation members above are unused in this mode
+	bool is_advection = false;
+	double advectionV[3] = {1.0, 0.0, 0.0};
+
 	// --- state ---
 	MultiFab state_old_cc_;
 	MultiFab state_new_cc_;
@@ -535,6 +540,10 @@ struct HydroSim {
 	[[nodiscard]] auto computeTimestepAtLevel() const -> double
 	{
 		double domain_signal_max = 0.0; // norminf of a non-negative field
+		if (is_advection) { // LinearAdvectionSystem::ComputeMaxSignalSpeed (linear_advection.hpp:47-60): the same value in every cell
+			domain_signal_max = std::sqrt(advectionV[0] * advectionV[0] + advectionV[1] * advectionV[1] + advectionV[2] * advectionV[2]);
+			return cflNumber_ * (minDx() / domain_signal_max);
+		}
 		_Pragma("omp parallel for schedule(dynamic) reduction(max : domain_signal_max)")
 		for (int b = 0; b < state_new_cc_.size(); ++b) {
 			Fab<double> maxSignal(grids[b], 1);
@@ -732,6 +741,105 @@ struct HydroSim {
 	}
 
 	// one coarse step: simulation.hpp:866-890 + :1276-1286 + QuokkaSimulation.hpp:653-707
+	// ------------------------------------------------------------------ linear advection
+	// AdvectionSimulation::computeFluxes + fluxFunction<DIR> (AdvectionSimulation.hpp:385-434): ConservedToPrimitive is the identity
+	// (linear_advection.hpp:62-70), PPM reconstruction, upwind flux (linear_advection.hpp:165-198).  One Fab per box and direction.
+	[[nodiscard]] auto advectionFluxes(MultiFab const &consVar) const -> std::vector<std::array<Fab<double>, 3>>
+	{
+		std::vector<std::array<Fab<double>, 3>> out(static_cast<size_t>(consVar.size()));
+		const int nvars = ncomp_cc;
+		const int reconstructRange = 1;
+		for (int b = 0; b < consVar.size(); ++b) {
+			Box const &valid = grids[b];
+			for (int dir = 0; dir < ndim(); ++dir) {
+				Box const cellRange = grow(valid, reconstructRange, ndim());
+				Box const faceRange = faceBox(cellRange, dir);
+				Fab<double> left(faceRange, nvars), right(faceRange, nvars);
+				ReconstructStatesPPM(dir, consVar.const_array(b), left.array(), right.array(), cellRange, nvars);
+				out[static_cast<size_t>(b)][static_cast<size_t>(dir)] = Fab<double>(faceBox(valid, dir), nvars);
+				auto F = out[static_cast<size_t>(b)][static_cast<size_t>(dir)].array();
+				auto L = left.const_array();
+				auto R = right.const_array();
+				double const vx = advectionV[dir];
+				Box const fb = faceBox(valid, dir);
+				for (int n = 0; n < nvars; ++n) {
+					for (int k = fb.lo[2]; k <= fb.hi[2]; ++k) {
+						for (int j = fb.lo[1]; j <= fb.hi[1]; ++j) {
+							for (int i = fb.lo[0]; i <= fb.hi[0]; ++i) {
+								// upwind side of the interface (the array element of a face is the same in every view)
+								F(i, j, k, n) = (vx < 0.0) ? vx * R(i, j, k, n) : vx * L(i, j, k, n);
+							}
+						}
+					}
+				}
+			}
+		}
+		return out;
+	}
+
+	// AdvectionSimulation::advanceSingleTimestepAtLevel (AdvectionSimulation.hpp:236-383, single level, integratorOrder_ = 2; the swap of
+	// old and new state happened in step())
+	void advanceAdvectionAtLevel(double time, double dt_lev)
+	{
+		const int nvars = ncomp_cc;
+		double const dtdx[3] = {dt_lev / geom.dx[0], dt_lev / geom.dx[1], dt_lev / geom.dx[2]};
+		auto diff = [&](Array4<const double> const &F, int dir, int i, int j, int k, int n) {
+			return F(i, j, k, n) - F(i + (dir == 0 ? 1 : 0), j + (dir == 1 ? 1 : 0), k + (dir == 2 ? 1 : 0), n);
+		};
+		fillBC(state_old_cc_, time);
+		{ // LinearAdvectionSystem::PredictStep (linear_advection.hpp:82-118)
+			auto const flux = advectionFluxes(state_old_cc_);
+			for (int b = 0; b < state_new_cc_.size(); ++b) {
+				auto Uo = state_old_cc_.const_array(b);
+				auto Un = state_new_cc_.array(b);
+				Box const &r = grids[b];
+				for (int n = 0; n < nvars; ++n) {
+					for (int k = r.lo[2]; k <= r.hi[2]; ++k) {
+						for (int j = r.lo[1]; j <= r.hi[1]; ++j) {
+							for (int i = r.lo[0]; i <= r.hi[0]; ++i) {
+								double s = dtdx[0] * diff(flux[static_cast<size_t>(b)][0].const_array(), 0, i, j, k, n);
+								if (ndim() >= 2) {
+									s = s + dtdx[1] * diff(flux[static_cast<size_t>(b)][1].const_array(), 1, i, j, k, n);
+								}
+								if (ndim() == 3) {
+									s = s + dtdx[2] * diff(flux[static_cast<size_t>(b)][2].const_array(), 2, i, j, k, n);
+								}
+								Un(i, j, k, n) = Uo(i, j, k, n) + s;
+							}
+						}
+					}
+				}
+			}
+		}
+		fillBC(state_new_cc_, time + dt_lev);
+		{ // LinearAdvectionSystem::AddFluxesRK2 (linear_advection.hpp:120-163): U_new = (0.5 U_0 + 0.5 U_1) + (0.5 FxU_1 + 0.5 FyU_1 + 0.5 FzU_1)
+			auto const flux = advectionFluxes(state_new_cc_);
+			for (int b = 0; b < state_new_cc_.size(); ++b) {
+				auto U0 = state_old_cc_.const_array(b);
+				auto Un = state_new_cc_.array(b);
+				Box const &r = grids[b];
+				for (int n = 0; n < nvars; ++n) {
+					for (int k = r.lo[2]; k <= r.hi[2]; ++k) {
+						for (int j = r.lo[1]; j <= r.hi[1]; ++j) {
+							for (int i = r.lo[0]; i <= r.hi[0]; ++i) {
+								double const U_0 = U0(i, j, k, n);
+								double const U_1 = Un(i, j, k, n);
+								double s = 0.5 * (dtdx[0] * diff(flux[static_cast<size_t>(b)][0].const_array(), 0, i, j, k, n));
+								if (ndim() >= 2) {
+									s = s + 0.5 * (dtdx[1] * diff(flux[static_cast<size_t>(b)][1].const_array(), 1, i, j, k, n));
+								}
+								if (ndim() == 3) {
+									s = s + 0.5 * (dtdx[2] * diff(flux[static_cast<size_t>(b)][2].const_array(), 2, i, j, k, n));
+								}
+								Un(i, j, k, n) = (0.5 * U_0 + 0.5 * U_1) + s;
+							}
+						}
+					}
+				}
+			}
+		}
+	}
+
 	auto step() -> bool
 	{
 		g_spacedim = ndim(); // (the reference's AMREX_SPACEDIM: a 2-D build permutes the X2 views differently, hyperbolic.hpp)
@@ -740,6 +848,12 @@ struct HydroSim {
 		tNew_ += dt_;
 		std::swap(state_old_cc_, state_new_cc_);
 		bool ok = true;
+		if (is_advection) {
+			advanceAdvectionAtLevel(time, dt_);
+			++istep;
+			cellUpdates_ += CountCells();
+			return true;
+		}
 		if (is_hydro_enabled) {
 			ok = advanceHydroAtLevelWithRetries(time, dt_);
 		} else { // QuokkaSimulation.hpp:681-685: copy hydro vars from state_old_cc_ to state_new_cc_

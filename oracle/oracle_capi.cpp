@@ -260,6 +260,11 @@ void *orc_sim_create(orc_sim_config const *c)
 	} else if (c->problem == 10) {
 		setupUniformAdvecting(*sim);
 		sim->rad.rt.pow_mode = c->rad_pow_mode;
+	} else if (c->problem >= 31 && c->problem <= 33) {
+		setupAdvection(*sim, c->problem - 31);
+	} else if (c->problem == 30) {
+		setupGeneralOpacity(*sim);
+		sim->rad.rt.pow_mode = c->rad_pow_mode;
 	} else if (c->problem == 6) {
 		setupScalarContact(*sim, c->nscalars > 0 ? c->nscalars : 1);
 	} else if (c->problem == 5 || c->problem == 29) {

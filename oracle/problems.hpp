@@ -1465,6 +1465,125 @@ inline void setupShocktubeCMA(HydroSim &sim)
 	sim.finishInitialConditions();
 }
 
+// ---------------------------------------------------------------- linear advection of a scalar
+// src/problems/Advection/test_advection.cpp (sawtooth), AdvectionSemiellipse/test_advection_semiellipse.cpp, Advection2D/test_advection2d.cpp
+// (square, unrefined): AdvectionSimulation<problem_t> with PPM + upwind fluxes + RK2, periodic box, one variable.
+inline void setupAdvection(HydroSim &sim, int variant)
+{
+	sim.is_advection = true;
+	sim.is_hydro_enabled = false;
+	sim.ncomp_cc = 1; // Physics_Indices::nvarTotal_cc_adv (physics_info.hpp:22)
+	sim.BCs_cc.assign(1, BCRec{}); // int_dir: periodic
+	sim.reconstructionOrder_ = 3;
+	sim.cflNumber_ = 0.4;
+	sim.stopTime_ = 1.0;
+	sim.maxTimesteps_ = 10000;
+	if (variant == 0) { // test_advection.cpp:126-158
+		sim.maxDt_ = 1.0e-4;
+		sim.advectionV[0] = 1.0;
+		sim.advectionV[1] = 1.0; // (the reference sets advectionVy_ too; it enters the time step even in a 1-D build)
+		sim.advectionV[2] = 0.0;
+	} else if (variant == 1) { // test_advection_semiellipse.cpp:125-150
+		sim.maxDt_ = 1.0e-4;
+		sim.advectionV[0] = 1.0;
+		sim.advectionV[1] = 0.0;
+		sim.advectionV[2] = 0.0;
+	} else { // test_advection2d.cpp:129-153
+		sim.advectionV[0] = 1.0;
+		sim.advectionV[1] = 1.0;
+		sim.advectionV[2] = 0.0;
+	}
+	sim.define();
+	Geometry const &g = sim.geom;
+	forEachValidCell(sim, [&](Array4<double> const &state_cc, int i, int j, int k) {
+		double const x = g.prob_lo[0] + (i + 0.5) * g.dx[0];
+		double v = 0.0;
+		if (variant == 0) { // test_advection.cpp:38-46
+			double const x_length = g.prob_hi[0] - g.prob_lo[0];
+			v = std::fmod(x + 0.5 * x_length, x_length);
+		} else if (variant == 1) { // test_advection_semiellipse.cpp:38-46
+			if (std::abs(x - 0.2) <= 0.15) {
+				v = std::sqrt(1.0 - std::pow((x - 0.2) / 0.15, 2));
+			}
+		} else { // test_advection2d.cpp:44-58
+			double const y = g.prob_lo[1] + (j + 0.5) * g.dx[1];
+			double const x0 = g.prob_lo[0] + 0.5 * (g.prob_hi[0] - g.prob_lo[0]);
+			double const y0 = g.prob_lo[1] + 0.5 * (g.prob_hi[1] - g.prob_lo[1]);
+			if ((std::abs(x - x0) < 0.1) && (std::abs(y - y0) < 0.1)) {
+				v = 1.;
+			}
+		}
+		state_cc(i, j, k, 0) = v;
+	});
+	sim.finishInitialConditions();
+}
+
+// ---------------------------------------------------------------- a general opacity law (no reference problem: the pin of the compiled hooks)
+// kappa_P = kappa_E = kappa_F = kappa0 rho^0.3 (T / T0)^-1.7 — an expression outside every closed opacity set of the C-ABI — on a periodic 1-D
+// box with sinusoidal density and temperature, gas out of equilibrium with its radiation, moving at 1e-3 c; hydro + M1 transport + the
+// Newton-Raphson exchange with the opacity re-evaluated inside the iteration.  The C++ counterpart is quokka_amd/host/drivers/general_opacity.cpp:
+// its hooks are compiled into the source-term kernel of that translation unit (tests/test_compiled_hooks_gpu.py).
+struct GeneralOpacityConstants {
+	static constexpr double c = 1.0e8, chat = 1.0e7, a_rad = 1.0, mu = 1.0, k_B = 1.0;
+	static constexpr double rho0 = 1.0, T0 = 1.0, kappa0 = 2.0e-3, L = 64.0, v0 = 1.0e-3 * c;
+	static constexpr double gamma = 5. / 3.;
+};
+
+inline void setupGeneralOpacity(HydroSim &sim)
+{
+	using S = GeneralOpacityConstants;
+	sim.hydro.tr.eos.tr.gamma = S::gamma;
+	sim.hydro.tr.eos.tr.mean_molecular_weight = S::mu;
+	sim.hydro.tr.eos.tr.boltzmann_constant = S::k_B;
+	sim.hydro.tr.reconstruct_eint = true;
+	sim.hydro.tr.nscalars = 0;
+	sim.ncomp_cc = kNumHydroVars + kNumRadVars;
+	sim.is_radiation_enabled = true;
+	sim.rad.rt.c_light = S::c;
+	sim.rad.rt.c_hat = S::chat;
+	sim.rad.rt.radiation_constant = S::a_rad;
+	sim.rad.rt.Erad_floor = 0.;
+	sim.rad.rt.beta_order = 1;
+	sim.rad.eos = sim.hydro.tr.eos;
+	sim.rad.ndim = sim.geom.ndim;
+	sim.rad.nstartHyperbolic_ = kNumHydroVars;
+	auto opacity = [](double rho, double T) { return S::kappa0 * std::pow(rho, 0.3) * std::pow(T / S::T0, -1.7); };
+	sim.rad.ComputePlanckOpacity = opacity;
+	sim.rad.ComputeFluxMeanOpacity = opacity;
+	sim.rad.ComputeEnergyMeanOpacity = opacity;
+	sim.BCs_cc.assign(sim.ncomp_cc, BCRec{}); // periodic
+	sim.reconstructionOrder_ = 3;
+	sim.radiationReconstructionOrder_ = 3;
+	sim.stopTime_ = 1.0e300;
+	sim.radiationCflNumber_ = 0.3;
+	sim.cflNumber_ = 0.3;
+	sim.maxTimesteps_ = 40;
+	sim.define();
+	EOS const eos = sim.hydro.tr.eos;
+	double const dx = sim.geom.dx[0], x_lo = sim.geom.prob_lo[0];
+	double const twopi = 2.0 * 3.14159265358979323846;
+	forEachValidCell(sim, [&](Array4<double> const &state_cc, int i, int j, int k) {
+		double const x = x_lo + (i + 0.5) * dx;
+		double const s = std::sin(twopi * x / S::L), co = std::cos(twopi * x / S::L);
+		double const rho = S::rho0 * (1.0 + 0.3 * s);
+		double const T = S::T0 * (1.0 + 0.2 * co);
+		double const Trad = S::T0 * (1.0 - 0.1 * s);
+		double const Egas = eos.ComputeEintFromTgas(rho, T);
+		double const erad = S::a_rad * ((Trad * Trad) * (Trad * Trad));
+		state_cc(i, j, k, kNumHydroVars + 0) = erad;
+		state_cc(i, j, k, kNumHydroVars + 1) = 0.05 * S::c * erad * co;
+		state_cc(i, j, k, kNumHydroVars + 2) = 0;
+		state_cc(i, j, k, kNumHydroVars + 3) = 0;
+		state_cc(i, j, k, energy_index) = Egas + 0.5 * rho * S::v0 * S::v0;
+		state_cc(i, j, k, density_index) = rho;
+		state_cc(i, j, k, internalEnergy_index) = Egas;
+		state_cc(i, j, k, x1Momentum_index) = S::v0 * rho;
+		state_cc(i, j, k, x2Momentum_index) = 0.;
+		state_cc(i, j, k, x3Momentum_index) = 0.;
+	});
+	sim.finishInitialConditions();
+}
+
 } // namespace oracle
 
 #include "problems_multigroup.hpp"

@@ -28,6 +28,8 @@ LINE_COOLING = 26  # RadLineCooling: one group, line cooling linear in T + cosmi
 LINE_COOLING_MG = 27  # RadLineCoolingMG: four groups + photoelectric heating by the last group
 MARSHAK_DUST_PE = 28  # RadMarshakDustPE: FUV front heating the gas photoelectrically
 STREAMING_Y = 29  # RadStreamingY: the streaming front along y in a 2-D build
+ADVECTION_SAWTOOTH, ADVECTION_SEMIELLIPSE, ADVECTION_SQUARE_2D = 31, 32, 33  # linear advection of a scalar (AdvectionSimulation)
+GENERAL_OPACITY = 30  # kappa = kappa0 rho^0.3 T^-1.7 (no reference problem: the pin of the compiled opacity hooks of the C++ host)
 MARSHAK_DUST = 25  # RadMarshakDust: two groups (IR / FUV), dust model with the decoupled branch
 BLAST2D = 23  # HydroBlast2D: circular blast in a reflecting box, as a 2-D build or as a 3-D build uniform in z
 # OpacityModel (radiation_system.hpp:64-71)

@@ -12,6 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("QK_LIB_PATH", os.path.join(_HERE, "lib", "libquokka_amd.so"))  # (override: A/B runs of two builds on one box)
 
 QK_OK, QK_ERR_INVALID, QK_ERR_HIP, QK_ERR_UNSUPPORTED, QK_ERR_STATE = 0, -1, -2, -3, -4
+ERR_UNSUPPORTED = QK_ERR_UNSUPPORTED
+HOOK_COMPILED = 100  # QK_HOOK_COMPILED: a hook that is the problem's own compiled device function (the library entry points refuse to evaluate it)
 DIR_X1, DIR_X2, DIR_X3 = 0, 1, 2
 RIEMANN_HLLC, RIEMANN_LLF = 0, 1
 LIMITER_MINMOD, LIMITER_MC = 0, 1

@@ -975,6 +975,9 @@ int qk_hydro_stage_fused(qk_level *lev, qk_stream stream, const qk_hydro_traits 
 	if (int rc = checkTraits(ctx, t); rc != QK_OK) {
 		return rc;
 	}
+	if (int rc = needsLibraryEos(ctx, t, "qk_hydro_stage_fused (EnforceLimits)"); rc != QK_OK) {
+		return rc;
+	}
 	QK_REQUIRE(ctx, args != nullptr, "qk_hydro_stage_fused: NULL args");
 	if (lev->nboxes == 0) {
 		return QK_OK; // a rank without boxes on this level

@@ -512,6 +512,9 @@ int qk_hydro_EnforceLimits(qk_level *lev, qk_stream s, const qk_hydro_traits *t,
 	if (int rc = checkTraits(lev->ctx, t); rc != QK_OK) {
 		return rc;
 	}
+	if (int rc = needsLibraryEos(lev->ctx, t, "EnforceLimits"); rc != QK_OK) {
+		return rc;
+	}
 	QK_REQUIRE(lev->ctx, state_t, "EnforceLimits: NULL array");
 	const Eos eos(*t);
 	const int nscalars = t->nscalars;
@@ -713,6 +716,96 @@ int qk_Saxpy(qk_level *lev, qk_stream s, int dir, qk_array4 *dst_t, double a, co
 		}
 	});
 	return launchStatus(lev, "Saxpy");
+}
+
+// ------------------------------------------------------------------ LinearAdvectionSystem<problem_t> (reference src/linear_advection/linear_advection.hpp)
+// The scalar advection solver of the reference shares HyperbolicSystem's reconstruction (qk_ReconstructStates* above); its own three operators:
+
+// ComputeFluxes<DIR>(x1Flux, x1LeftState, x1RightState, advectionVx, nvars)   linear_advection.hpp:165-198: the upwind side of the interface
+// (the array element of a face is the same in every permuted view, and a scalar flux permutes no components: no view needed)
+int qk_advect_ComputeFluxes(qk_level *lev, qk_stream s, int dir, qk_array4 *flux_t, const qk_array4 *left_t, const qk_array4 *right_t, double vx, int nvars)
+{
+	if (lev == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	QK_REQUIRE(lev->ctx, flux_t && left_t && right_t, "advect ComputeFluxes: NULL array");
+	QK_REQUIRE(lev->ctx, dir >= 0 && dir < lev->ndim && nvars >= 1, "advect ComputeFluxes: bad direction / nvars");
+	launchCells(lev, s, 0, dir, [=] __device__(int b, int i, int j, int k) {
+		WA4 F(flux_t[b]);
+		RA4 L(left_t[b]);
+		RA4 R(right_t[b]);
+		for (int n = 0; n < nvars; ++n) {
+			F(i, j, k, n) = (vx < 0.0) ? vx * R(i, j, k, n) : vx * L(i, j, k, n);
+		}
+	});
+	return launchStatus(lev, "advect ComputeFluxes");
+}
+
+// PredictStep(consVarOld, consVarNew, fluxArray, dt, dx, nvars)                linear_advection.hpp:82-118
+int qk_advect_PredictStep(qk_level *lev, qk_stream s, const qk_array4 *old_t, qk_array4 *new_t, const qk_array4 *const flux_t[3], double dt, const double dx[3],
+			  int nvars)
+{
+	if (lev == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	QK_REQUIRE(lev->ctx, old_t && new_t && flux_t && flux_t[0], "advect PredictStep: NULL array");
+	const int ndim = lev->ndim;
+	QK_REQUIRE(lev->ctx, (ndim < 2 || flux_t[1]) && (ndim < 3 || flux_t[2]), "advect PredictStep: NULL flux array");
+	const qk_array4 *fx = flux_t[0], *fy = flux_t[1], *fz = flux_t[2];
+	const double dtdx = dt / dx[0], dtdy = (ndim >= 2) ? dt / dx[1] : 0.0, dtdz = (ndim == 3) ? dt / dx[2] : 0.0;
+	launchCells(lev, s, 0, -1, [=] __device__(int b, int i, int j, int k) {
+		RA4 Uo(old_t[b]);
+		WA4 Un(new_t[b]);
+		RA4 Fx(fx[b]);
+		for (int n = 0; n < nvars; ++n) {
+			double sum = dtdx * (Fx(i, j, k, n) - Fx(i + 1, j, k, n));
+			if (ndim >= 2) {
+				RA4 Fy(fy[b]);
+				sum = sum + dtdy * (Fy(i, j, k, n) - Fy(i, j + 1, k, n));
+			}
+			if (ndim == 3) {
+				RA4 Fz(fz[b]);
+				sum = sum + dtdz * (Fz(i, j, k, n) - Fz(i, j, k + 1, n));
+			}
+			Un(i, j, k, n) = Uo(i, j, k, n) + sum;
+		}
+	});
+	return launchStatus(lev, "advect PredictStep");
+}
+
+// AddFluxesRK2(U_new, U0, U1, fluxArray, dt, dx, nvars)                        linear_advection.hpp:120-163 (U_new may be U1)
+int qk_advect_AddFluxesRK2(qk_level *lev, qk_stream s, qk_array4 *new_t, const qk_array4 *U0_t, const qk_array4 *U1_t, const qk_array4 *const flux_t[3], double dt,
+			   const double dx[3], int nvars)
+{
+	if (lev == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	QK_REQUIRE(lev->ctx, new_t && U0_t && U1_t && flux_t && flux_t[0], "advect AddFluxesRK2: NULL array");
+	const int ndim = lev->ndim;
+	QK_REQUIRE(lev->ctx, (ndim < 2 || flux_t[1]) && (ndim < 3 || flux_t[2]), "advect AddFluxesRK2: NULL flux array");
+	const qk_array4 *fx = flux_t[0], *fy = flux_t[1], *fz = flux_t[2];
+	const double dtdx = dt / dx[0], dtdy = (ndim >= 2) ? dt / dx[1] : 0.0, dtdz = (ndim == 3) ? dt / dx[2] : 0.0;
+	launchCells(lev, s, 0, -1, [=] __device__(int b, int i, int j, int k) {
+		RA4 U0(U0_t[b]);
+		RA4 U1(U1_t[b]);
+		WA4 Un(new_t[b]);
+		RA4 Fx(fx[b]);
+		for (int n = 0; n < nvars; ++n) {
+			const double U_0 = U0(i, j, k, n);
+			const double U_1 = U1(i, j, k, n);
+			double sum = 0.5 * (dtdx * (Fx(i, j, k, n) - Fx(i + 1, j, k, n)));
+			if (ndim >= 2) {
+				RA4 Fy(fy[b]);
+				sum = sum + 0.5 * (dtdy * (Fy(i, j, k, n) - Fy(i, j + 1, k, n)));
+			}
+			if (ndim == 3) {
+				RA4 Fz(fz[b]);
+				sum = sum + 0.5 * (dtdz * (Fz(i, j, k, n) - Fz(i, j, k + 1, n)));
+			}
+			Un(i, j, k, n) = (0.5 * U_0 + 0.5 * U_1) + sum;
+		}
+	});
+	return launchStatus(lev, "advect AddFluxesRK2");
 }
 
 } // extern "C"

@@ -81,11 +81,23 @@ inline auto checkTraits(qk_ctx *ctx, const qk_hydro_traits *t) -> int
 	if (t->nscalars < 0 || t->nscalars > QK_MAX_SCALARS || t->nmscalars < 0 || t->nmscalars > t->nscalars) {
 		return setError(ctx, QK_ERR_UNSUPPORTED, "0..QK_MAX_SCALARS passive scalars, of which the first nmscalars (0..nscalars) are mass scalars");
 	}
-	if (t->eos_temperature_model < 0 || t->eos_temperature_model > 1 || (t->eos_temperature_model == 1 && !(t->eos_alpha > 0.0))) {
-		return setError(ctx, QK_ERR_UNSUPPORTED, "eos_temperature_model must be 0 (gamma law) or 1 (E = alpha / 4 T^4, alpha > 0)");
+	if (t->eos_temperature_model != QK_HOOK_COMPILED &&
+	    (t->eos_temperature_model < 0 || t->eos_temperature_model > 1 || (t->eos_temperature_model == 1 && !(t->eos_alpha > 0.0)))) {
+		return setError(ctx, QK_ERR_UNSUPPORTED, "eos_temperature_model must be 0 (gamma law), 1 (E = alpha / 4 T^4, alpha > 0) or QK_HOOK_COMPILED");
 	}
 	if (t->ndim < 1 || t->ndim > 3) {
 		return setError(ctx, QK_ERR_UNSUPPORTED, "ndim must be 1, 2 or 3");
+	}
+	return QK_OK;
+}
+
+// an entry point that evaluates the temperature hooks of quokka::EOS cannot serve a problem whose hooks are compiled device code
+inline auto needsLibraryEos(qk_ctx *ctx, const qk_hydro_traits *t, const char *who) -> int
+{
+	if (t->eos_temperature_model == QK_HOOK_COMPILED) {
+		return setError(ctx, QK_ERR_UNSUPPORTED, who,
+				"the quokka::EOS temperature hooks of this problem are compiled device code: instantiate the kernel in the problem's translation unit "
+				"(quokka_amd/host/qk_problem_kernels.hpp)");
 	}
 	return QK_OK;
 }

@@ -271,6 +271,9 @@ int qk_rad_AddSourceTermsMultiGroup(qk_level *lev, qk_stream s, const qk_rad_tra
 	if (int rc = checkTraits(lev->ctx, t); rc != QK_OK) {
 		return rc;
 	}
+	if (int rc = needsLibraryEos(lev->ctx, t, "AddSourceTermsMultiGroup"); rc != QK_OK) {
+		return rc;
+	}
 	QK_REQUIRE(lev->ctx, cons_t && src_t && d_iteration_counter && d_failure_counter, "AddSourceTermsMultiGroup: NULL");
 	QK_REQUIRE(lev->ctx, stage == 1 || stage == 2, "AddSourceTermsMultiGroup: stage must be 1 or 2");
 	QK_REQUIRE(lev->ctx, t->nscalars == 0 && t->nmscalars == 0, "AddSourceTermsMultiGroup: radFirstIndex is 6 (no passive scalars beside radiation)");

@@ -3,118 +3,12 @@
 // qk_rad_mg.hip.  One launch covers all local boxes.  Arithmetic in qk_rad_device.hpp.
 #include "qk_internal.hpp"
 #include "qk_rad_device.hpp"
+#include "qk_rad_source_launch.hpp"
 
 using namespace qk;
 
 namespace
 {
-
-// MINW: waves per SIMD the register allocation must leave room for (__launch_bounds__'s second argument on AMD GPUs)
-template <int MINW, class F> __global__ void __launch_bounds__(256, MINW) k_rad_cells(const qk_box *boxes, int ndim, int ng, int facedir, F f)
-{
-	const int b = blockIdx.y;
-	const qk_box bx = boxes[b];
-	int lo[3], len[3];
-#pragma unroll
-	for (int d = 0; d < 3; ++d) {
-		const int g = (d < ndim) ? ng : 0;
-		lo[d] = bx.lo[d] - g;
-		len[d] = bx.hi[d] - bx.lo[d] + 1 + 2 * g + ((d == facedir) ? 1 : 0);
-	}
-	const int64_t t_raw = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-	const int64_t n01 = static_cast<int64_t>(len[0]) * len[1];
-	// lanes past the end stay alive with a clamped index and valid = false (wave reductions need every lane)
-	const bool valid = t_raw < n01 * len[2];
-	const int64_t t = valid ? t_raw : 0;
-	const int k = static_cast<int>(t / n01);
-	const int r = static_cast<int>(t - k * n01);
-	const int j = r / len[0];
-	const int i = r - j * len[0];
-	f(b, lo[0] + i, lo[1] + j, lo[2] + k, valid);
-}
-
-// Newton-iteration / failure counters: NSLOT slots of one 128-byte line each, folded into the caller's words by one block
-constexpr int NSLOT = 1024, SLOT_STRIDE = 32;
-
-#ifndef QK_RAD_SRC_WAVES
-#define QK_RAD_SRC_WAVES 2
-#endif
-
-__global__ void __launch_bounds__(NSLOT) k_counters_finish(int *slots, int *it, int *fail)
-{
-	__shared__ int red[NSLOT / 64][5];
-	int *slot = slots + static_cast<size_t>(threadIdx.x) * SLOT_STRIDE;
-	int v[5];
-#pragma unroll
-	for (int n = 0; n < 5; ++n) {
-		v[n] = slot[n];
-		slot[n] = 0; // ready for the next launch (stream ordered)
-	}
-	for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-		for (int n = 0; n < 5; ++n) {
-			const int o = __shfl_xor(v[n], off);
-			v[n] = (n == 2) ? max(v[n], o) : v[n] + o;
-		}
-	}
-	if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-		for (int n = 0; n < 5; ++n) {
-			red[threadIdx.x / 64][n] = v[n];
-		}
-	}
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		int t[5] = {0, 0, 0, 0, 0};
-		for (int w = 0; w < NSLOT / 64; ++w) {
-#pragma unroll
-			for (int n = 0; n < 5; ++n) {
-				t[n] = (n == 2) ? max(t[n], red[w][n]) : t[n] + red[w][n];
-			}
-		}
-		it[0] += t[0];
-		it[1] += t[1];
-		it[2] = max(it[2], t[2]);
-		fail[0] += t[3];
-		fail[2] += t[4];
-	}
-}
-
-auto counterSlots(qk_ctx *ctx) -> int *
-{
-	std::lock_guard<std::mutex> lock(ctx->mtx);
-	if (ctx->counter_slots == nullptr) {
-		void *p = nullptr;
-		const size_t bytes = sizeof(int) * NSLOT * SLOT_STRIDE;
-		if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess) {
-			return nullptr;
-		}
-		ctx->owned.push_back(p);
-		ctx->counter_slots = static_cast<int *>(p);
-	}
-	return ctx->counter_slots;
-}
-
-// nz: third grid dimension (the photon group of the per-group kernels, read as blockIdx.z inside `f`)
-template <int MINW = 1, class F> void launchRad(qk_level *lev, qk_stream s, int ng, int facedir, const char *name, F f, int nz = 1)
-{
-	if (lev->nboxes == 0) {
-		return; // a rank without boxes on this level
-	}
-	CellLaunch L = cellLaunch(lev, ng, facedir);
-	L.grid.z = static_cast<unsigned>(nz);
-	ProfScope ps(lev->ctx, static_cast<hipStream_t>(s), name);
-	hipLaunchKernelGGL((k_rad_cells<MINW, F>), L.grid, L.block, 0, static_cast<hipStream_t>(s), lev->d_boxes, lev->ndim, ng, facedir, f);
-}
-
-inline auto radStatus(qk_level *lev, const char *name) -> int
-{
-	const hipError_t e = hipGetLastError();
-	if (e != hipSuccess) {
-		return setError(lev->ctx, QK_ERR_HIP, name, hipGetErrorString(e));
-	}
-	return QK_OK;
-}
 
 inline auto checkRad(qk_ctx *ctx, const qk_rad_traits *rt) -> int
 {
@@ -124,7 +18,12 @@ inline auto checkRad(qk_ctx *ctx, const qk_rad_traits *rt) -> int
 	if (rt->opacity_model == 2 && !(rt->opacity_T_ref > 0.0 && rt->opacity_pow_floor >= 0.0 && rt->opacity_T_exponent == rt->opacity_T_exponent)) {
 		return setError(ctx, QK_ERR_INVALID, "opacity_model 2 needs opacity_T_ref > 0, a finite opacity_T_exponent and opacity_pow_floor >= 0");
 	}
-	if (rt->opacity_model < 0 || rt->opacity_model > 2 || rt->eddington_model < 0 || rt->eddington_model > 1) {
+	if (rt->opacity_model == QK_HOOK_COMPILED) {
+		// the problem's opacities are compiled device code: the transport operators never evaluate them; the source term refuses below
+	} else if (rt->opacity_model < 0 || rt->opacity_model > 2) {
+		return setError(ctx, QK_ERR_UNSUPPORTED, "opacity_model must be 0 (constant kappa), 1 (constant rho * kappa), 2 (temperature power law) or QK_HOOK_COMPILED");
+	}
+	if (rt->eddington_model < 0 || rt->eddington_model > 1) {
 		return setError(ctx, QK_ERR_UNSUPPORTED,
 				"opacity_model must be 0 (constant kappa), 1 (constant rho * kappa) or 2 (temperature power law), eddington_model 0 (Levermore) or 1 (1/3)");
 	}
@@ -718,65 +617,6 @@ int qk_rad_AddFluxesRK2(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int
 
 } // extern "C"
 
-template <bool TDEP, bool DUST = false>
-static auto radSourceImpl(qk_level *lev, qk_stream s, const qk_rad_traits *rt, const qk_hydro_traits *t, qk_array4 *cons_t, const qk_array4 *src_t, double dt,
-			  int stage, int *d_iteration_counter, int *d_failure_counter) -> int
-{
-	Rad rad(*rt);
-	rad.mean_molecular_mass = t->mean_molecular_weight;
-	const Eos eos(*t);
-	int *slots = counterSlots(lev->ctx);
-	QK_REQUIRE(lev->ctx, slots != nullptr, "AddSourceTermsSingleGroup: cannot allocate the counter slots");
-	launchRad<QK_RAD_SRC_WAVES>(lev, s, 0, -1, "rad_AddSourceTerms", [=] __device__(int b, int i, int j, int k, bool valid) {
-		int ntot = 0, nmax = 0, nsolve = 0, fnewton = 0, fouter = 0, fdust = 0;
-		if (valid) {
-			WA4 S(cons_t[b]);
-			RA4 Q(src_t[b]);
-			const int64_t c = S.idx(i, j, k);
-			double U[10];
-#pragma unroll
-			for (int n = 0; n < 10; ++n) {
-				U[n] = S.p[c + S.ns * n];
-			}
-			radSourceCell<TDEP, DUST>(rad, eos, U, Q(i, j, k), dt, stage, ntot, nmax, nsolve, fnewton, fouter, DUST ? &fdust : nullptr);
-			if (DUST && fdust != 0) {
-				atomicAdd(&d_failure_counter[1], fdust); // (rare: a negative dust temperature; the reference counts it the same way, :172-174)
-			}
-			// rho (comp 0) is never modified
-#pragma unroll
-			for (int n = 1; n < 10; ++n) {
-				S.p[c + S.ns * n] = U[n];
-			}
-		}
-		// counters: wave-level reduction, then one atomic set per wave into one of NSLOT cache-line-sized slots.  (The
-		// reference issues 3 atomics per cell on 3 addresses, :344-346.  Even one set per wave on the same three words
-		// serialises in L2: measured 8.9 ms per launch against 1.4 ms for the arithmetic of the whole kernel.)
-		int wsolve = nsolve, wtot = ntot, wmax = nmax, wfn = fnewton, wfo = fouter;
-		for (int off = 32; off > 0; off >>= 1) {
-			wsolve += __shfl_xor(wsolve, off);
-			wtot += __shfl_xor(wtot, off);
-			wmax = max(wmax, __shfl_xor(wmax, off));
-			wfn += __shfl_xor(wfn, off);
-			wfo += __shfl_xor(wfo, off);
-		}
-		if ((threadIdx.x & 63) == 0) {
-			const unsigned wave = (blockIdx.x + gridDim.x * blockIdx.y) * (blockDim.x / 64) + threadIdx.x / 64;
-			int *slot = slots + static_cast<size_t>(wave % NSLOT) * SLOT_STRIDE;
-			atomicAdd(&slot[0], wsolve);
-			atomicAdd(&slot[1], wtot);
-			atomicMax(&slot[2], wmax);
-			if (wfn != 0) {
-				atomicAdd(&slot[3], wfn);
-			}
-			if (wfo != 0) {
-				atomicAdd(&slot[4], wfo);
-			}
-		}
-	});
-	hipLaunchKernelGGL(k_counters_finish, dim3(1), dim3(NSLOT), 0, static_cast<hipStream_t>(s), slots, d_iteration_counter, d_failure_counter);
-	return radStatus(lev, "AddSourceTermsSingleGroup");
-}
-
 extern "C" {
 
 int qk_rad_AddSourceTermsSingleGroup(qk_level *lev, qk_stream s, const qk_rad_traits *rt, const qk_hydro_traits *t, qk_array4 *cons_t,
@@ -790,6 +630,14 @@ int qk_rad_AddSourceTermsSingleGroup(qk_level *lev, qk_stream s, const qk_rad_tr
 	}
 	if (int rc = checkTraits(lev->ctx, t); rc != QK_OK) {
 		return rc;
+	}
+	if (int rc = needsLibraryEos(lev->ctx, t, "AddSourceTermsSingleGroup"); rc != QK_OK) {
+		return rc;
+	}
+	if (rt->opacity_model == QK_HOOK_COMPILED || rt->thermal_model == QK_HOOK_COMPILED) {
+		return setError(lev->ctx, QK_ERR_UNSUPPORTED, "AddSourceTermsSingleGroup",
+				"the opacity / emission hooks of this problem are compiled device code: instantiate the kernel in the problem's translation unit "
+				"(quokka_amd/host/qk_problem_kernels.hpp)");
 	}
 	QK_REQUIRE(lev->ctx, cons_t && src_t && d_iteration_counter && d_failure_counter, "AddSourceTermsSingleGroup: NULL");
 	QK_REQUIRE(lev->ctx, stage == 1 || stage == 2, "AddSourceTermsSingleGroup: stage must be 1 or 2");

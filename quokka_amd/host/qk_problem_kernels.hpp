@@ -1,0 +1,84 @@
+// qk_problem_kernels.hpp — the kernels of the hot path that call a problem's DEVICE hooks, instantiated in the problem's own translation unit
+// (SURVEY §8(b) option (ii)).  The reference declares
+//     RadSystem<P>::ComputePlanckOpacity / ComputeEnergyMeanOpacity / ComputeFluxMeanOpacity            radiation_system.hpp:1141-1154
+//     RadSystem<P>::ComputeThermalRadiationSingleGroup / ...TempDerivativeSingleGroup                    radiation_system.hpp:471-479, :499-503
+//     RadSystem<P>::DefineNetCoolingRate / DefineCosmicRayHeatingRate                                    radiation_system.hpp:344-353
+//     quokka::EOS<P>::ComputeTgasFromEint / ComputeEintFromTgas / ComputeEintTempDerivative              EOS.hpp:74-244
+// as AMREX_GPU_HOST_DEVICE functions a problem specialises with arbitrary code; its source-term kernel calls them inside the Newton-Raphson
+// iteration.  libquokka_amd.so carries closed, parametrised sets of these hooks (qk_rad_traits: what the Python host and the C-ABI tests drive);
+// a problem file compiled against this host mirror instead gets the SAME kernel (qk::radSourceImpl / qk::radSourceCell of
+// quokka_amd/csrc/qk_rad_source_launch.hpp, qk_rad_device.hpp) instantiated with objects whose members CALL the problem's hooks — nothing is
+// sampled or fitted; a problem with kappa ~ rho^0.3 T^-1.7 runs exactly that expression (tests/test_compiled_hooks_gpu.py).
+//
+// What still selects the library's own arithmetic: a hook the problem did NOT specialise.  The mirror's default emission (a T^4, floored) and
+// default quokka::EOS (gamma law) are recognised by exact agreement with their defining formulas on probe points, and then evaluated by the
+// library's members, which honour `radiation.pow_mode` (0: faithfully rounded T^4; 1: the product form the bit-level tests share with the CPU
+// oracle).  Anything else is the compiled hook.
+#ifndef QK_PROBLEM_KERNELS_HPP_
+#define QK_PROBLEM_KERNELS_HPP_
+
+#include "../csrc/qk_rad_source_launch.hpp"
+
+namespace qkhost
+{
+
+// qk_rad_traits::thermal_model / opacity_model and qk_hydro_traits::eos_temperature_model values that mean "call the compiled hook" (the entry
+// points of the library refuse them: they are only meaningful to the instantiations below)
+constexpr int kHookCompiled = QK_HOOK_COMPILED;
+
+template <typename problem_t> struct ProblemRad : qk::Rad {
+	using RS = RadSystem<problem_t>;
+	__host__ __device__ explicit ProblemRad(qk_rad_traits const &t) : qk::Rad(t) {}
+	template <bool> QK_DEV auto kappaP(double rho, double T) const -> double { return RS::ComputePlanckOpacity(rho, T); }
+	template <bool> QK_DEV auto kappaE(double rho, double T) const -> double { return RS::ComputeEnergyMeanOpacity(rho, T); }
+	template <bool> QK_DEV auto kappaF(double rho, double T) const -> double { return RS::ComputeFluxMeanOpacity(rho, T); }
+	QK_DEV auto thermalRadiation(double T) const -> double
+	{
+		return (thermal_model == kHookCompiled) ? RS::ComputeThermalRadiationSingleGroup(T) : qk::Rad::thermalRadiationHook(T);
+	}
+	QK_DEV auto thermalRadiationTempDerivative(double T) const -> double
+	{
+		return (thermal_model == kHookCompiled) ? RS::ComputeThermalRadiationTempDerivativeSingleGroup(T) : qk::Rad::thermalRadiationTempDerivativeHook(T);
+	}
+	QK_DEV auto thermalRadiationHook(double T) const -> double { return thermalRadiation(T); }
+	QK_DEV auto thermalRadiationTempDerivativeHook(double T) const -> double { return thermalRadiationTempDerivative(T); }
+	QK_DEV auto cosmicRayHeatingRate(double num_density) const -> double { return RS::DefineCosmicRayHeatingRate(num_density); }
+	QK_DEV auto netCoolingRate(double T, double num_density) const -> double { return RS::DefineNetCoolingRate(T, num_density)[0]; }
+};
+
+// quokka::EOS<problem_t> for one cell of the Newton-Raphson iteration
+template <typename problem_t> struct ProblemEosCell {
+	using E = quokka::EOS<problem_t>;
+	qk::EosCell lib; // the library's gamma-law / T^4-material arithmetic (shared reciprocals), used unless the problem specialised the hooks
+	QK_DEV ProblemEosCell(qk::Eos const &e, double rho) : lib(e, rho) {}
+	QK_DEV auto tgasFromEint(double Eint) const -> double { return (lib.eos.tmodel == kHookCompiled) ? E::ComputeTgasFromEint(lib.rho, Eint) : lib.tgasFromEint(Eint); }
+	QK_DEV auto eintFromTgas(double T) const -> double { return (lib.eos.tmodel == kHookCompiled) ? E::ComputeEintFromTgas(lib.rho, T) : lib.eintFromTgas(T); }
+	QK_DEV auto eintTempDerivative(double T) const -> double
+	{
+		return (lib.eos.tmodel == kHookCompiled) ? E::ComputeEintTempDerivative(lib.rho, T) : lib.eintTempDerivative(T);
+	}
+};
+
+// RadSystem<problem_t>::AddSourceTermsSingleGroup (reference src/radiation/source_terms_single_group.hpp:10-564) with the problem's hooks
+template <typename problem_t>
+auto addSourceTermsSingleGroup(qk_level *lev, const qk_rad_traits *rt, const qk_hydro_traits *t, qk_array4 *cons_t, const qk_array4 *src_t, double dt, int stage,
+			       int *d_iteration_counter, int *d_failure_counter) -> int
+{
+	using R = ProblemRad<problem_t>;
+	using EC = ProblemEosCell<problem_t>;
+	if (lev == nullptr || rt == nullptr || t == nullptr || cons_t == nullptr || src_t == nullptr || d_iteration_counter == nullptr || d_failure_counter == nullptr ||
+	    (stage != 1 && stage != 2)) {
+		return QK_ERR_INVALID;
+	}
+	if (rt->enable_dust_gas_thermal_coupling_model != 0) {
+		if (!(rt->dust_gas_interaction_coeff > 0.0 && t->mean_molecular_weight > 0.0)) {
+			return qk::setError(lev->ctx, QK_ERR_INVALID, "dust model: needs dust_gas_interaction_coeff > 0 and a mean molecular weight");
+		}
+		return qk::radSourceImpl<true, true, R, EC>(lev, nullptr, rt, t, cons_t, src_t, dt, stage, d_iteration_counter, d_failure_counter);
+	}
+	return qk::radSourceImpl<true, false, R, EC>(lev, nullptr, rt, t, cons_t, src_t, dt, stage, d_iteration_counter, d_failure_counter);
+}
+
+} // namespace qkhost
+
+#endif // QK_PROBLEM_KERNELS_HPP_

@@ -169,9 +169,10 @@ inline void check(int rc, const char *what)
 }
 inline auto tab(amrex::MultiFab const &mf) -> qk_array4 * { return reinterpret_cast<qk_array4 *>(mf.arrays()); }
 inline auto itab(amrex::iMultiFab const &mf) -> qk_iarray4 * { return reinterpret_cast<qk_iarray4 *>(mf.arrays()); }
-// The temperature hooks of quokka::EOS<problem_t> (reference src/hydro/EOS.hpp:74-244) run on the device in the reference; the C-ABI carries
-// them as a closed set (qk_hydro_traits::eos_temperature_model 0: gamma law; 1: E_int = alpha / 4 T^4, the Su & Olson material).  They
-// are sampled on the host; anything outside the set is refused.
+// The temperature hooks of quokka::EOS<problem_t> (reference src/hydro/EOS.hpp:74-244) run on the device in the reference.  A problem that did
+// not specialise them — or specialised them to the Su & Olson material E_int = alpha / 4 T^4 — is recognised on probe points and served by the
+// library's own arithmetic (qk_hydro_traits::eos_temperature_model 0 / 1: shared reciprocals, bit-identical to the CPU oracle); any other
+// specialisation is compiled into the source-term kernel of the problem's translation unit (QK_HOOK_COMPILED, qk_problem_kernels.hpp).
 template <typename problem_t> auto eosTemperatureModel() -> std::pair<int, double>
 {
 	using E = quokka::EOS<problem_t>;
@@ -193,8 +194,8 @@ template <typename problem_t> auto eosTemperatureModel() -> std::pair<int, doubl
 	if (fourth && alpha > 0.0) {
 		return {1, alpha};
 	}
-	amrex::Abort("quokka::EOS: these temperature hooks are not expressible in the C-ABI's closed set (gamma law, E = alpha / 4 T^4)");
-	return {0, 0.0};
+	// anything else: the problem's compiled hooks (qk_problem_kernels.hpp); the library entry points that would have to evaluate them refuse
+	return {QK_HOOK_COMPILED, 0.0};
 }
 // members a problem's EOS_Traits specialisation may leave out (the reference only reads them in the branches that need them)
 template <typename T, typename = void> struct CsIsoOf {
@@ -468,6 +469,9 @@ template <typename problem_t> using RadSystem_Has_Opacity_Model = qkhost::RadHas
 
 // RadSystem<problem_t>: indices, constants, the problem's device hooks and the operators of the radiation update, each ONE
 // call into the C-ABI (reference src/radiation/radiation_system.hpp:150-330).  Single group, OpacityModel::single_group.
+template <typename problem_t> class RadSystem;
+#include "qk_problem_kernels.hpp" // the source-term kernel instantiated with this problem's compiled hooks
+
 template <typename problem_t> class RadSystem : public HyperbolicSystem<problem_t>
 {
       public:
@@ -783,81 +787,30 @@ template <typename problem_t> class RadSystem : public HyperbolicSystem<problem_
 		if constexpr (nGroups_ > 1) {
 			return multigroupTraits();
 		}
-		const double rs[4] = {1.0, 1.0e-24, 3.7e-19, 2.0e-3}, Ts[3] = {3.0, 1.1e3, 4.0e7};
-		const double kP = ComputePlanckOpacity(rs[0], Ts[0]), kE = ComputeEnergyMeanOpacity(rs[0], Ts[0]), kF = ComputeFluxMeanOpacity(rs[0], Ts[0]);
-		int opacity_model = -1;
-		for (int model = 0; model < 2 && opacity_model < 0; ++model) {
-			bool ok = true;
-			for (double r : rs) {
-				for (double T : Ts) {
-					double const d = (model == 0) ? 1.0 : r;
-					ok = ok && ComputePlanckOpacity(r, T) == kP / d && ComputeEnergyMeanOpacity(r, T) == kE / d && ComputeFluxMeanOpacity(r, T) == kF / d;
-				}
-			}
-			if (ok) {
-				opacity_model = model;
-			}
-		}
-		double kT_ref = 0.0, kT_exp = 0.0;
-		double k0[3] = {kP, kE, kF};
-		if (opacity_model < 0) {
-			// model 2: kappa_X = k0_X (T / T_ref)^p / rho with one exponent for the three means.  T_ref and k0 cannot be told apart by
-			// sampling: T_ref = 1 K is used and k0 = rho * kappa(rho, 1 K); the exponent is taken as the nearest multiple of 1/2
-			// (the product form differs from the problem's own expression by rounding only — checked to 1e-12 on the sample grid)
-			double const T1 = 1.0e3, T2 = 1.0e6;
-			double const slope = std::log(ComputePlanckOpacity(1.0, T2) / ComputePlanckOpacity(1.0, T1)) / std::log(T2 / T1);
-			double const p = std::round(2.0 * slope) / 2.0;
-			double const kk[3] = {ComputePlanckOpacity(1.0, T1) / std::pow(T1, p), ComputeEnergyMeanOpacity(1.0, T1) / std::pow(T1, p),
-					      ComputeFluxMeanOpacity(1.0, T1) / std::pow(T1, p)};
-			bool ok = std::isfinite(p) && std::abs(slope - p) < 1e-9;
-			for (double r : rs) {
-				for (double T : Ts) {
-					double const pw = std::pow(T, p);
-					auto close = [](double a, double b) { return std::abs(a - b) <= 1e-12 * std::abs(b); };
-					ok = ok && close(ComputePlanckOpacity(r, T), kk[0] * pw / r) && close(ComputeEnergyMeanOpacity(r, T), kk[1] * pw / r) &&
-					     close(ComputeFluxMeanOpacity(r, T), kk[2] * pw / r);
-				}
-			}
-			if (ok) {
-				opacity_model = 2;
-				kT_ref = 1.0;
-				kT_exp = p;
-				k0[0] = kk[0];
-				k0[1] = kk[1];
-				k0[2] = kk[2];
-			}
-		}
-		if (opacity_model < 0) {
-			amrex::Abort("RadSystem: these opacity hooks are not expressible in the C-ABI's closed opacity set (constant kappa, constant rho * "
-				     "kappa, temperature power law of rho * kappa)");
-		}
+		// Single group: the opacity hooks are compiled into the source-term kernel of this translation unit (qk_problem_kernels.hpp): nothing to
+		// describe to the library, whose transport operators never evaluate an opacity.
 		int eddington_model = -1, pow_mode = 0;
 		closureAndPowMode(eddington_model, pow_mode);
-		qk_rad_traits rt{c_light_, c_hat_, radiation_constant_, Erad_floor_, beta_order_, opacity_model, k0[0], k0[1], k0[2], pow_mode, eddington_model,
-				 kT_ref,   kT_exp, 0.0};
-		// the thermal-emission hooks (:471-479, :499-503): the default a T^4 (floored) / 4 a T^3, or RadDust's linearised a T / a
+		double const nan = std::numeric_limits<double>::quiet_NaN();
+		qk_rad_traits rt{c_light_, c_hat_, radiation_constant_, Erad_floor_, beta_order_, QK_HOOK_COMPILED, nan, nan, nan, pow_mode, eddington_model, 0.0, 0.0, 0.0};
+		// the thermal-emission hooks (:471-479, :499-503): a problem that did not specialise them gets the library's a T^4 (floored) / 4 a T^3,
+		// which honours radiation.pow_mode — recognised by exact agreement with the defining formula on probe points; anything else is the
+		// problem's compiled hook
 		{
-			bool quartic = true, linear = true;
+			bool quartic = true;
 			for (double T : {0.7, 3.0e2, 4.0e6}) {
 				const double e = ComputeThermalRadiationSingleGroup(T), d = ComputeThermalRadiationTempDerivativeSingleGroup(T);
 				quartic = quartic && e == std::max(radiation_constant_ * std::pow(T, 4), Erad_floor_) && d == 4. * radiation_constant_ * std::pow(T, 3);
-				linear = linear && e == radiation_constant_ * T && d == radiation_constant_;
 			}
-			if (!quartic && !linear) {
-				amrex::Abort("RadSystem: the ComputeThermalRadiationSingleGroup hooks are neither a T^4 nor RadDust's linearised a T");
-			}
-			rt.thermal_model = quartic ? 0 : 1;
+			rt.thermal_model = quartic ? 0 : QK_HOOK_COMPILED;
 		}
 		if (enable_dust_gas_thermal_coupling_model_) { // ISM_Traits; the coefficient is QuokkaSimulation::dustGasInteractionCoeff_ (QuokkaSimulation.hpp:127, :392)
 			rt.enable_dust_gas_thermal_coupling_model = 1;
 			rt.dust_gas_interaction_coeff = 2.5e-34;
 			amrex::ParmParse rpp("radiation");
 			rpp.query("dust_gas_interaction_coeff", rt.dust_gas_interaction_coeff);
-		} else if (rt.thermal_model != 0) {
-			amrex::Abort("RadSystem: the linearised thermal-emission hook is carried by the C-ABI together with the dust model only");
 		}
-		ismHooks(rt);
-		return rt;
+		return rt; // (the ISM heating / cooling hooks of the single-group source term are compiled as well)
 	}
 	static auto lev() -> qk_level * { return qkhost::Runtime::get().lev; }
 	static void flux3(std::array<amrex::MultiFab, AMREX_SPACEDIM> const &f, qk_array4 *out[3])
@@ -914,8 +867,9 @@ template <typename problem_t> class RadSystem : public HyperbolicSystem<problem_
 	{
 		auto rt = traits();
 		auto t = qkhost::traits<problem_t>();
-		qkhost::check(qk_rad_AddSourceTermsSingleGroup(lev(), nullptr, &rt, &t, qkhost::tab(consVar), qkhost::tab(radEnergySource), dt, stage,
-							       p_iteration_counter, p_iteration_failure_counter),
+		// the kernel is instantiated HERE, with this problem's compiled opacity / emission / EOS / ISM hooks (qk_problem_kernels.hpp)
+		qkhost::check(qkhost::addSourceTermsSingleGroup<problem_t>(lev(), &rt, &t, qkhost::tab(consVar), qkhost::tab(radEnergySource), dt, stage,
+									    p_iteration_counter, p_iteration_failure_counter),
 			      "RadSystem::AddSourceTermsSingleGroup");
 	}
 	// src/radiation/source_terms_multi_group.hpp:522-813
