@@ -71,8 +71,18 @@ template <typename problem_t> struct Physics_Traits {
 };
 
 template <typename problem_t> struct Physics_Indices {
-	static constexpr int nvarTotal_cc = Physics_Traits<problem_t>::numPassiveScalars + Physics_NumVars::numHydroVars +
-					    (Physics_Traits<problem_t>::is_radiation_enabled ? Physics_NumVars::numRadVars * Physics_Traits<problem_t>::nGroups : 0);
+	// reference src/physics_info.hpp:20-38: neither hydro nor radiation -> the single variable of an advection problem
+	static constexpr int nvarTotal_cc_adv = 1;
+	static constexpr int nvarTotal_cc_radhydro = []() constexpr {
+		if constexpr (Physics_Traits<problem_t>::is_radiation_enabled) { // (nGroups is only read where radiation is on: advection problems do not define it)
+			return Physics_Traits<problem_t>::numPassiveScalars + Physics_NumVars::numHydroVars + Physics_NumVars::numRadVars * Physics_Traits<problem_t>::nGroups;
+		} else if constexpr (Physics_Traits<problem_t>::is_hydro_enabled) {
+			return Physics_Traits<problem_t>::numPassiveScalars + Physics_NumVars::numHydroVars;
+		} else {
+			return 0;
+		}
+	}();
+	static constexpr int nvarTotal_cc = nvarTotal_cc_radhydro > 0 ? nvarTotal_cc_radhydro : nvarTotal_cc_adv;
 	static const int hydroFirstIndex = 0;
 	static const int pscalarFirstIndex = Physics_NumVars::numHydroVars;
 	static const int radFirstIndex = pscalarFirstIndex + Physics_Traits<problem_t>::numPassiveScalars;
@@ -2252,7 +2262,7 @@ template <typename problem_t> void QuokkaSimulation<problem_t>::computeAfterEvol
 }
 
 // test hook: `qk.dump_state = <file>` writes the valid cells of state_new_cc_ (double, [box][comp][k][j][i]) after evolve()
-template <typename problem_t> void qkDumpState(QuokkaSimulation<problem_t> &sim)
+inline void qkDumpFields(amrex::MultiFab &mf, int istep, double tNew, double dt, long fofcStages, long retries, double errorNorm)
 {
 	std::string path;
 	amrex::ParmParse pp("qk");
@@ -2263,7 +2273,6 @@ template <typename problem_t> void qkDumpState(QuokkaSimulation<problem_t> &sim)
 		path += ".rank" + std::to_string(qkhost::Comm::get().rank);
 	}
 	std::ofstream f(path, std::ios::binary);
-	auto &mf = sim.state_new_cc_[0];
 	for (int b = 0; b < mf.size(); ++b) {
 		auto h = mf.copyToHost(b);
 		amrex::Array4<double> a(h.data(), mf.fabbox(b), mf.nComp());
@@ -2278,7 +2287,11 @@ template <typename problem_t> void qkDumpState(QuokkaSimulation<problem_t> &sim)
 	}
 	std::ofstream meta(path + ".meta");
 	meta.precision(17);
-	meta << sim.istep[0] << " " << sim.tNew_[0] << " " << sim.dt_[0] << " " << sim.fofcStages_ << " " << sim.retries_ << " " << sim.errorNorm_ << "\n";
+	meta << istep << " " << tNew << " " << dt << " " << fofcStages << " " << retries << " " << errorNorm << "\n";
+}
+template <typename problem_t> void qkDumpState(QuokkaSimulation<problem_t> &sim)
+{
+	qkDumpFields(sim.state_new_cc_[0], sim.istep[0], sim.tNew_[0], sim.dt_[0], sim.fofcStages_, sim.retries_, sim.errorNorm_);
 }
 
 // every problem executable: amrex::Initialize analogue + problem_main()

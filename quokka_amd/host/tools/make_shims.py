@@ -16,6 +16,7 @@ QUOKKA = ["QuokkaSimulation.hpp", "simulation.hpp", "physics_info.hpp", "hydro/h
 COMPAT = {"util/fextract.hpp": "compat/util_compat.hpp", "util/ArrayUtil.hpp": "compat/util_compat.hpp", "util/valarray.hpp": "compat/util_compat.hpp",
           "fmt/format.h": "compat/mini_fmt.hpp", "fmt/core.h": "compat/mini_fmt.hpp", "radiation/planck_integral.hpp": "compat/planck_integral.hpp",
           "hydro/NSCBC_inflow.hpp": "compat/nscbc.hpp", "hydro/NSCBC_outflow.hpp": "compat/nscbc.hpp"}
+ADVECTION = ["linear_advection/AdvectionSimulation.hpp", "linear_advection/linear_advection.hpp"]
 EMPTY = ["util/matplotlibcpp.h"]
 
 
@@ -33,6 +34,8 @@ def main():
         write(n, f'#include "{up(n)}amrex_mini.hpp"\n')
     for n in QUOKKA:
         write(n, f'#include "{up(n)}quokka_host.hpp"\n#include "{up(n)}quokka_amr.hpp"\n')
+    for n in ADVECTION:
+        write(n, f'#include "{up(n)}quokka_advection.hpp"\n')
     for n, target in COMPAT.items():
         write(n, f'#include "{up(n)}{target}"\n')
     for n in EMPTY:

@@ -404,3 +404,15 @@ def test_mass_scalars_stay_consistent_with_the_density(oracle):
         worst = max(worst, float(np.abs(1.0 - U[6:9, 0, 0].sum(axis=0) / U[0, 0, 0]).max()))
     assert worst < 1.0e-13, worst
     assert U[6:9].min() >= 0.0 and s.istep > 3000
+
+
+@pytest.mark.parametrize("problem", ["ADVECTION_SAWTOOTH", "ADVECTION_SEMIELLIPSE"])
+def test_scalar_advection_meets_the_reference_criterion(oracle, problem):
+    """reference ctests ScalarAdvection (src/problems/Advection/test_advection.cpp:160-166) and ScalarAdvectionSemiEllipse: PPM + upwind flux +
+    RK2 (src/linear_advection), 400 cells, one period in 10 000 steps (max_dt 1e-4); relative L1 error vs the initial profile <= 0.015"""
+    import oracle.pyoracle as po
+    s = oracle.sim(getattr(po, problem), 1, [400, 1, 1], [0, 0, 0], [1.0, 1, 1], [1, 1, 1], max_grid_size=[400, 1, 1])
+    U0 = s.valid(0).copy()
+    assert s.evolve() and s.istep == 10000 and abs(s.time - 1.0) < 1e-12
+    err = np.abs(s.valid(0) - U0).sum() / np.abs(U0).sum()
+    assert 1e-3 < err <= 0.015, err

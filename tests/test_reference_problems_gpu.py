@@ -279,3 +279,41 @@ def test_unmodified_rayleigh_taylor_problem_runs_with_its_strang_split_gravity(t
     prof = np.loadtxt(os.path.join(str(tmp_path), "profile.txt"))
     # (the scalar is a conserved density: it is compressed with the heavy gas settling in the field, a few 1e-3)
     assert prof.shape == (64,) and np.all(prof[:28] < 1e-6) and np.all(np.abs(prof[36:] - 1.0) < 0.01)
+
+
+@pytest.mark.parametrize("name,problem,ncell", [("ref_Advection", "ADVECTION_SAWTOOTH", 400), ("ref_AdvectionSemiellipse", "ADVECTION_SEMIELLIPSE", 400)])
+def test_unmodified_advection_problems_meet_the_reference_criterion_and_match_the_oracle(tmp_path, oracle, name, problem, ncell):
+    """Advection / AdvectionSemiellipse, unchanged (ctests ScalarAdvection, ScalarAdvectionSemiEllipse): AdvectionSimulation<problem_t> and
+    LinearAdvectionSystem<problem_t> of the host mirror (quokka_advection.hpp) on qk_ReconstructStatesPPM + qk_advect_*; 10 000 RK2 steps, one period.
+    Exit status 0 = relative L1 error <= 0.015 (test_advection.cpp:160-166); the final state equals the oracle's (oracle/hydro_sim.hpp
+    advanceAdvectionAtLevel) in every bit (sawtooth) / to 1e-12 (semi-ellipse: libm in its initial condition)."""
+    import oracle.pyoracle as po
+    dump = str(tmp_path / "adv.bin")
+    rc, out = run([exe(name), os.path.join(HOST, "decks", "advection_sawtooth.in"), f"qk.dump_state={dump}"], str(tmp_path))
+    assert rc == 0 and "Relative rms L1 error norm" in out, out[-2000:]
+    meta = [float(x) for x in open(dump + ".meta").read().split()]
+    so = oracle.sim(getattr(po, problem), 1, [ncell, 1, 1], [0, 0, 0], [1.0, 1, 1], [1, 1, 1], max_grid_size=[ncell, 1, 1])
+    assert so.evolve()
+    assert int(meta[0]) == so.istep == 10000 and meta[1] == so.time and 1e-3 < meta[5] <= 0.015
+    got, want = np.fromfile(dump, dtype=np.float64), so.valid(0).ravel()
+    if problem == "ADVECTION_SAWTOOTH":
+        assert np.array_equal(got, want)
+    else:  # the semi-ellipse is initialised with std::sqrt(1 - std::pow(z, 2)) inside a device lambda: device libm vs glibc, an ulp in the initial state
+        assert np.abs(got - want).sum() <= 1e-12 * np.abs(want).sum()
+
+
+def test_unmodified_advection2d_problem_on_the_unrefined_grid_matches_the_oracle(tmp_path, oracle):
+    """Advection2D, unchanged, as the 2-D build: four boxes, both sweeps of the advection solver (the y sweep through the 2-D index-swap view of
+    qk_ReconstructStatesPPM).  Its ctest refines three levels to reach its 0.15 criterion; the advection solver of this host runs level 0 only,
+    where the error is 0.34 on oracle and GPU alike (exit status 1): the comparison with the oracle is the test — every bit after 227 steps."""
+    from oracle.pyoracle import ADVECTION_SQUARE_2D
+    dump = str(tmp_path / "adv2d.bin")
+    rc, out = run([exe("ref_Advection2D"), os.path.join(HOST, "decks", "advection2d.in"), f"qk.dump_state={dump}"], str(tmp_path))
+    assert rc in (0, 1) and "Relative rms L1 error norm" in out, out[-2000:]
+    meta = [float(x) for x in open(dump + ".meta").read().split()]
+    so = oracle.sim(ADVECTION_SQUARE_2D, 2, [64, 64, 1], [0, 0, 0], [1.0, 1.0, 1], [1, 1, 1], max_grid_size=[32, 32, 1])
+    assert so.evolve()
+    assert int(meta[0]) == so.istep and meta[1] == so.time
+    got = np.fromfile(dump, dtype=np.float64).reshape(4, 32, 32)
+    for b in range(4):
+        assert np.array_equal(got[b], so.valid(b).reshape(32, 32)), b
