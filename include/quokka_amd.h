@@ -92,7 +92,7 @@ typedef struct qk_hydro_traits {
 } qk_hydro_traits;
 
 enum { QK_DIR_X1 = 0, QK_DIR_X2 = 1, QK_DIR_X3 = 2 };
-enum { QK_RIEMANN_HLLC = 0, QK_RIEMANN_LLF = 1 };
+enum { QK_RIEMANN_HLLC = 0, QK_RIEMANN_LLF = 1, QK_RIEMANN_HLLD = 2 /* reference-shaped operator only; the MHD stub of hydro_system.hpp:987-1003: B = 0 */ };
 enum { QK_LIMITER_MINMOD = 0, QK_LIMITER_MC = 1 };
 /* amrex::BCType values */
 enum { QK_BC_REFLECT_ODD = -1, QK_BC_INT_DIR = 0, QK_BC_REFLECT_EVEN = 1, QK_BC_FOEXTRAP = 2, QK_BC_EXT_DIR = 3 };

@@ -32,7 +32,7 @@ enum consVarIndex { density_index = 0, x1Momentum_index, x2Momentum_index, x3Mom
 // HydroSystem::primVarIndex (hydro_system.hpp:64-72)
 enum primVarIndex { primDensity_index = 0, x1Velocity_index, x2Velocity_index, x3Velocity_index, pressure_index, primEint_index, primScalar0_index };
 
-enum RiemannSolver : int { riemann_HLLC = 0, riemann_LLF = 1 };
+enum RiemannSolver : int { riemann_HLLC = 0, riemann_LLF = 1, riemann_HLLD = 2 }; // hydro_system.hpp:43
 enum redoFlagVal : int { redo_none = 0, redo_redo = 1 }; // hyperbolic_system.hpp:34
 
 // runtime stand-in for the compile-time traits a problem supplies
@@ -186,6 +186,193 @@ inline auto HLLC(HydroTraits const &tr, HydroState const &sL, HydroState const &
 		}
 	}
 	return F;
+}
+
+// HLLD.hpp:26-334 (Miyoshi & Kusano 2005 as Athena++ codes it).  The reference calls it with bx = 0 and sL.by = sL.bz = sR.by = sR.bz = 0
+// (hydro_system.hpp:987-1003, :1044-1048: "set to zero to test that the HLLD solver works with hydro only"); restated for general fields.
+// Returns {rho, mx, my, mz, E, 0.0}: no flux of the auxiliary internal energy, none of the passive scalars (:331-332).
+struct ConsHydro1D { // HLLD.hpp:21-29
+	double rho, mx, my, mz, E, by, bz;
+};
+inline auto FastMagnetoSonicSpeed(double gamma, HydroState const &state, const double bx) -> double // HLLD.hpp:31-42
+{
+	double gp = gamma * state.P;
+	double bx_sq = bx * bx;
+	double byz_sq = state.by * state.by + state.bz * state.bz;
+	double b_sq = bx_sq + byz_sq;
+	double bgp_p = b_sq + gp;
+	double bgp_m = b_sq - gp;
+	return std::sqrt(0.5 * (bgp_p + std::sqrt(bgp_m * bgp_m + 4.0 * gp * byz_sq)) / state.rho);
+}
+inline auto HLLD(HydroState const &sL, HydroState const &sR, const double gamma, const double bx) -> valarray
+{
+	constexpr double DELTA = 1.0e-4; // :18
+	auto SQUARE = [](double x) { return x * x; };
+	ConsHydro1D u_L{}, u_R{}, f_x{}, f_L{}, f_R{}, u_star_L{}, u_dstar_L{}, u_dstar_R{}, u_star_R{};
+	std::array<double, 5> spds{};
+	double const bx_sq = SQUARE(bx);
+	// :75-96 left and right conserved states
+	double const pb_L = 0.5 * (bx_sq + (SQUARE(sL.by) + SQUARE(sL.bz)));
+	double const pb_R = 0.5 * (bx_sq + (SQUARE(sR.by) + SQUARE(sR.bz)));
+	double const ke_L = 0.5 * sL.rho * (SQUARE(sL.u) + (SQUARE(sL.v) + SQUARE(sL.w)));
+	double const ke_R = 0.5 * sR.rho * (SQUARE(sR.u) + (SQUARE(sR.v) + SQUARE(sR.w)));
+	u_L.rho = sL.rho;
+	u_L.mx = sL.u * u_L.rho;
+	u_L.my = sL.v * u_L.rho;
+	u_L.mz = sL.w * u_L.rho;
+	u_L.E = ke_L + pb_L + sL.P / (gamma - 1.0);
+	u_L.by = sL.by;
+	u_L.bz = sL.bz;
+	u_R.rho = sR.rho;
+	u_R.mx = sR.u * u_R.rho;
+	u_R.my = sR.v * u_R.rho;
+	u_R.mz = sR.w * u_R.rho;
+	u_R.E = ke_R + pb_R + sR.P / (gamma - 1.0);
+	u_R.by = sR.by;
+	u_R.bz = sR.bz;
+	// :100-104 outer wave speeds
+	const double cfs_L = FastMagnetoSonicSpeed(gamma, sL, bx);
+	const double cfs_R = FastMagnetoSonicSpeed(gamma, sR, bx);
+	spds[0] = std::min(sL.u - cfs_L, sR.u - cfs_R);
+	spds[4] = std::max(sL.u + cfs_L, sR.u + cfs_R);
+	// :108-125 left and right fluxes
+	double ptot_L = sL.P + pb_L;
+	double ptot_R = sR.P + pb_R;
+	f_L.rho = u_L.mx;
+	f_L.mx = u_L.mx * sL.u + ptot_L - bx_sq;
+	f_L.my = u_L.my * sL.u + bx * u_L.by;
+	f_L.mz = u_L.mz * sL.u + bx * u_L.bz;
+	f_L.E = sL.u * (u_L.E + ptot_L - bx_sq) - bx * (sL.v * u_L.by + sL.w * u_L.bz);
+	f_L.by = u_L.by * sL.u - bx * sL.v;
+	f_L.bz = u_L.bz * sL.u - bx * sL.w;
+	f_R.rho = u_R.mx;
+	f_R.mx = u_R.mx * sR.u + ptot_R - bx_sq;
+	f_R.my = u_R.my * sR.u + bx * u_R.by;
+	f_R.mz = u_R.mz * sR.u + bx * u_R.bz;
+	f_R.E = sR.u * (u_R.E + ptot_R - bx_sq) - bx * (sR.v * u_R.by + sR.w * u_R.bz);
+	f_R.by = u_R.by * sR.u - bx * sR.v;
+	f_R.bz = u_R.bz * sR.u - bx * sR.w;
+	// :129-145 middle and Alfven wave speeds
+	double siui_L = spds[0] - sL.u;
+	double siui_R = spds[4] - sR.u;
+	spds[2] = (siui_R * u_R.mx - siui_L * u_L.mx + (ptot_L - ptot_R)) / (siui_R * u_R.rho - siui_L * u_L.rho);
+	double sism_L = spds[0] - spds[2];
+	double sism_R = spds[4] - spds[2];
+	double sism_inv_L = 1.0 / sism_L;
+	double sism_inv_R = 1.0 / sism_R;
+	u_star_L.rho = u_L.rho * siui_L * sism_inv_L;
+	u_star_R.rho = u_R.rho * siui_R * sism_inv_R;
+	double u_star_rho_inv_L = 1.0 / u_star_L.rho;
+	double u_star_rho_inv_R = 1.0 / u_star_R.rho;
+	double rho_sqrt_L = std::sqrt(u_star_L.rho);
+	double rho_sqrt_R = std::sqrt(u_star_R.rho);
+	spds[1] = spds[2] - std::abs(bx) / rho_sqrt_L;
+	spds[3] = spds[2] + std::abs(bx) / rho_sqrt_R;
+	// :149-152 star-region total pressure
+	double ptot_star_L = ptot_L - u_L.rho * siui_L * (spds[2] - sL.u);
+	double ptot_star_R = ptot_R - u_R.rho * siui_R * (spds[2] - sR.u);
+	double ptot_star = 0.5 * (ptot_star_L + ptot_star_R);
+	// :154-174 left star state
+	u_star_L.mx = u_star_L.rho * spds[2];
+	if (std::abs(u_L.rho * siui_L * sism_L - bx_sq) < (DELTA)*ptot_star) {
+		u_star_L.my = u_star_L.rho * sL.v;
+		u_star_L.mz = u_star_L.rho * sL.w;
+		u_star_L.by = u_L.by;
+		u_star_L.bz = u_L.bz;
+	} else {
+		double tmp = bx * (siui_L - sism_L) / (u_L.rho * siui_L * sism_L - bx_sq);
+		u_star_L.my = u_star_L.rho * (sL.v - u_L.by * tmp);
+		u_star_L.mz = u_star_L.rho * (sL.w - u_L.bz * tmp);
+		tmp = (u_L.rho * SQUARE(siui_L) - bx_sq) / (u_L.rho * siui_L * sism_L - bx_sq);
+		u_star_L.by = u_L.by * tmp;
+		u_star_L.bz = u_L.bz * tmp;
+	}
+	double vb_star_L = (u_star_L.mx * bx + (u_star_L.my * u_star_L.by + u_star_L.mz * u_star_L.bz)) * u_star_rho_inv_L;
+	u_star_L.E = (siui_L * u_L.E - ptot_L * sL.u + ptot_star * spds[2] + bx * (sL.u * bx + (sL.v * u_L.by + sL.w * u_L.bz) - vb_star_L)) * sism_inv_L;
+	// :176-196 right star state
+	u_star_R.mx = u_star_R.rho * spds[2];
+	if (std::abs(u_R.rho * siui_R * sism_R - bx_sq) < (DELTA)*ptot_star) {
+		u_star_R.my = u_star_R.rho * sR.v;
+		u_star_R.mz = u_star_R.rho * sR.w;
+		u_star_R.by = u_R.by;
+		u_star_R.bz = u_R.bz;
+	} else {
+		double tmp = bx * (siui_R - sism_R) / (u_R.rho * siui_R * sism_R - bx_sq);
+		u_star_R.my = u_star_R.rho * (sR.v - u_R.by * tmp);
+		u_star_R.mz = u_star_R.rho * (sR.w - u_R.bz * tmp);
+		tmp = (u_R.rho * SQUARE(siui_R) - bx_sq) / (u_R.rho * siui_R * sism_R - bx_sq);
+		u_star_R.by = u_R.by * tmp;
+		u_star_R.bz = u_R.bz * tmp;
+	}
+	double vb_star_R = (u_star_R.mx * bx + (u_star_R.my * u_star_R.by + u_star_R.mz * u_star_R.bz)) * u_star_rho_inv_R;
+	u_star_R.E = (siui_R * u_R.E - ptot_R * sR.u + ptot_star * spds[2] + bx * (sR.u * bx + (sR.v * u_R.by + sR.w * u_R.bz) - vb_star_R)) * sism_inv_R;
+	// :198-237 double-star states
+	if (0.5 * bx_sq < (DELTA)*ptot_star) {
+		u_dstar_L = u_star_L;
+		u_dstar_R = u_star_R;
+	} else {
+		double rho_sum_inv = 1.0 / (rho_sqrt_L + rho_sqrt_R);
+		double bx_sign = (bx > 0.0 ? 1.0 : -1.0);
+		u_dstar_L.rho = u_star_L.rho;
+		u_dstar_R.rho = u_star_R.rho;
+		u_dstar_L.mx = u_star_L.mx;
+		u_dstar_R.mx = u_star_R.mx;
+		double tmp = rho_sum_inv * (rho_sqrt_L * (u_star_L.my * u_star_rho_inv_L) + rho_sqrt_R * (u_star_R.my * u_star_rho_inv_R) +
+					    bx_sign * (u_star_R.by - u_star_L.by));
+		u_dstar_L.my = u_dstar_L.rho * tmp;
+		u_dstar_R.my = u_dstar_R.rho * tmp;
+		tmp = rho_sum_inv *
+		      (rho_sqrt_L * (u_star_L.mz * u_star_rho_inv_L) + rho_sqrt_R * (u_star_R.mz * u_star_rho_inv_R) + bx_sign * (u_star_R.bz - u_star_L.bz));
+		u_dstar_L.mz = u_dstar_L.rho * tmp;
+		u_dstar_R.mz = u_dstar_R.rho * tmp;
+		tmp = rho_sum_inv * (rho_sqrt_L * u_star_R.by + rho_sqrt_R * u_star_L.by +
+				     bx_sign * rho_sqrt_L * rho_sqrt_R * ((u_star_R.my * u_star_rho_inv_R) - (u_star_L.my * u_star_rho_inv_L)));
+		u_dstar_L.by = tmp;
+		u_dstar_R.by = tmp;
+		tmp = rho_sum_inv * (rho_sqrt_L * u_star_R.bz + rho_sqrt_R * u_star_L.bz +
+				     bx_sign * rho_sqrt_L * rho_sqrt_R * ((u_star_R.mz * u_star_rho_inv_R) - (u_star_L.mz * u_star_rho_inv_L)));
+		u_dstar_L.bz = tmp;
+		u_dstar_R.bz = tmp;
+		tmp = spds[2] * bx + (u_dstar_L.my * u_dstar_L.by + u_dstar_L.mz * u_dstar_L.bz) / u_dstar_L.rho;
+		u_dstar_L.E = u_star_L.E - rho_sqrt_L * bx_sign * (vb_star_L - tmp);
+		u_dstar_R.E = u_star_R.E + rho_sqrt_R * bx_sign * (vb_star_R - tmp);
+	}
+	// :241-271 flux increments across the waves (the states are overwritten by them)
+	auto jump = [](double s, ConsHydro1D const &a, ConsHydro1D const &b) {
+		return ConsHydro1D{s * (a.rho - b.rho), s * (a.mx - b.mx), s * (a.my - b.my), s * (a.mz - b.mz), s * (a.E - b.E), s * (a.by - b.by), s * (a.bz - b.bz)};
+	};
+	u_dstar_L = jump(spds[1], u_dstar_L, u_star_L);
+	u_star_L = jump(spds[0], u_star_L, u_L);
+	u_dstar_R = jump(spds[3], u_dstar_R, u_star_R);
+	u_star_R = jump(spds[4], u_star_R, u_R);
+	// :273-329 the flux at the interface
+	auto add2 = [](ConsHydro1D const &a, ConsHydro1D const &b) {
+		return ConsHydro1D{a.rho + b.rho, a.mx + b.mx, a.my + b.my, a.mz + b.mz, a.E + b.E, a.by + b.by, a.bz + b.bz};
+	};
+	auto add3 = [](ConsHydro1D const &a, ConsHydro1D const &b, ConsHydro1D const &c) {
+		return ConsHydro1D{a.rho + b.rho + c.rho, a.mx + b.mx + c.mx, a.my + b.my + c.my, a.mz + b.mz + c.mz, a.E + b.E + c.E, a.by + b.by + c.by, a.bz + b.bz + c.bz};
+	};
+	if (spds[0] >= 0.0) {
+		f_x = f_L;
+	} else if (spds[4] <= 0.0) {
+		f_x = f_R;
+	} else if (spds[1] >= 0.0) {
+		f_x = add2(f_L, u_star_L);
+	} else if (spds[2] >= 0.0) {
+		f_x = add3(f_L, u_star_L, u_dstar_L);
+	} else if (spds[3] > 0.0) {
+		f_x = add3(f_R, u_star_R, u_dstar_R);
+	} else {
+		f_x = add2(f_R, u_star_R);
+	}
+	valarray F_hydro{};
+	F_hydro[0] = f_x.rho;
+	F_hydro[1] = f_x.mx;
+	F_hydro[2] = f_x.my;
+	F_hydro[3] = f_x.mz;
+	F_hydro[4] = f_x.E;
+	F_hydro[5] = 0.0;
+	return F_hydro;
 }
 
 // LLF.hpp:16-43
@@ -628,8 +815,10 @@ struct HydroSystem {
 					valarray F_canonical{};
 					if (riemann == riemann_HLLC) {
 						F_canonical = HLLC(tr, sL, sR, gamma_, du, dw);
-					} else {
+					} else if (riemann == riemann_LLF) {
 						F_canonical = LLF(tr, sL, sR);
+					} else { // :1044-1048: bx = 0 "for testing purposes" (the reference's MHD stub; sL / sR carry by = bz = 0)
+						F_canonical = HLLD(sL, sR, gamma_, 0.0);
 					}
 					valarray F = F_canonical;
 

@@ -93,6 +93,7 @@ struct HydroSim {
 
 	// --- linear advection (reference src/linear_advection/AdvectionSimulation.hpp:89-96): one scalar carried at (advectionVx_, Vy_, Vz_); the
 	// hydro / radiation members above are unused in this mode
+	bool is_mhd_enabled = false; // Physics_Traits::is_mhd_enabled: selects HLLD in hydroFluxFunction (QuokkaSimulation.hpp:1512)
 	bool is_advection = false;
 	double advectionV[3] = {1.0, 0.0, 0.0};
 
@@ -161,7 +162,8 @@ struct HydroSim {
 		_Pragma("omp parallel for schedule(dynamic)")
 		for (size_t t = 0; t < faces.size(); ++t) {
 			int const b = faces[t].first;
-			hydro.ComputeFluxes(riemann_HLLC, dir, flux.array(b), faceVel.array(b), leftState.const_array(b), rightState.const_array(b),
+			// QuokkaSimulation.hpp:1512-1516: HLLD for MHD problems (the reference's stub: B = 0), HLLC otherwise
+			hydro.ComputeFluxes(is_mhd_enabled ? riemann_HLLD : riemann_HLLC, dir, flux.array(b), faceVel.array(b), leftState.const_array(b), rightState.const_array(b),
 					    primVar.const_array(b), artificialViscosityK_, faces[t].second);
 		}
 	}

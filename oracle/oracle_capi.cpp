@@ -85,7 +85,9 @@ void orc_compute_hydro_fluxes(orc_hydro_traits const *t, int order, double K_vis
 	sim.nghost_cc = nghost;
 	sim.ncomp_cc = sim.hydro.tr.nvar();
 	sim.artificialViscosityK_ = K_visc;
-	sim.reconstructionOrder_ = (order == 0) ? 1 : order;
+	sim.reconstructionOrder_ = (order == 0) ? 1 : (order % 10);
+	sim.is_mhd_enabled = (order >= 10); // order + 10: the fluxes of an MHD problem (HLLD with the reference's B = 0 stub)
+	order = order % 10;
 	int const nv = sim.hydro.tr.nvar();
 	MultiFab consMF(sim.grids, nv, nghost, t->ndim);
 	std::memcpy(consMF.fabs[0].d.data(), cons, consMF.fabs[0].d.size() * sizeof(double));

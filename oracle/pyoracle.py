@@ -193,8 +193,12 @@ class Oracle:
         self.lib.orc_flattening_coefficients(C.byref(t), int(d), _dp(prim), _i3(glo), _i3(ghi), _dp(out), _i3(clo), _i3(chi))
         return out
 
-    def compute_hydro_fluxes(self, t: HydroTraits, order: int, cons: np.ndarray, vlo, vhi, nghost=4, K_visc=0.0):
-        """cons: (nvar, ...) on the valid box grown by nghost. Returns ([flux_d], [facevel_d])."""
+    def compute_hydro_fluxes(self, t: HydroTraits, order: int, cons: np.ndarray, vlo, vhi, nghost=4, K_visc=0.0, mhd_stub=False):
+        """cons: (nvar, ...) on the valid box grown by nghost. Returns ([flux_d], [facevel_d]).  mhd_stub: Physics_Traits::is_mhd_enabled — the
+        interface fluxes come from HLLD with the reference's B = 0 stub (hydro_system.hpp:987-1003) instead of HLLC"""
+        if mhd_stub:
+            assert order in (1, 2, 3)
+            order = order + 10
         nv = 6 + t.nscalars
         fl, fv = [], []
         for d in range(3):

@@ -15,7 +15,7 @@ QK_OK, QK_ERR_INVALID, QK_ERR_HIP, QK_ERR_UNSUPPORTED, QK_ERR_STATE = 0, -1, -2,
 ERR_UNSUPPORTED = QK_ERR_UNSUPPORTED
 HOOK_COMPILED = 100  # QK_HOOK_COMPILED: a hook that is the problem's own compiled device function (the library entry points refuse to evaluate it)
 DIR_X1, DIR_X2, DIR_X3 = 0, 1, 2
-RIEMANN_HLLC, RIEMANN_LLF = 0, 1
+RIEMANN_HLLC, RIEMANN_LLF, RIEMANN_HLLD = 0, 1, 2
 LIMITER_MINMOD, LIMITER_MC = 0, 1
 BC_REFLECT_ODD, BC_INT_DIR, BC_REFLECT_EVEN, BC_FOEXTRAP, BC_EXT_DIR = -1, 0, 1, 2, 3
 

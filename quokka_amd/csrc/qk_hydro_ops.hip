@@ -363,11 +363,13 @@ int qk_hydro_ComputeFluxes(qk_level *lev, qk_stream s, const qk_hydro_traits *t,
 		return rc;
 	}
 	QK_REQUIRE(lev->ctx, flux_t && fvel_t && left_t && right_t && prim_t, "ComputeFluxes: NULL array");
-	QK_REQUIRE(lev->ctx, riemann == QK_RIEMANN_HLLC || riemann == QK_RIEMANN_LLF, "ComputeFluxes: unknown Riemann solver");
+	QK_REQUIRE(lev->ctx, riemann == QK_RIEMANN_HLLC || riemann == QK_RIEMANN_LLF || riemann == QK_RIEMANN_HLLD, "ComputeFluxes: unknown Riemann solver");
 	QK_REQUIRE(lev->ctx, dir >= 0 && dir < t->ndim, "ComputeFluxes: the direction does not exist in a build of this dimension");
 	if (t->ndim == 2 && dir == QK_DIR_X2) { // the X2 view of a 2-D build: index swap instead of the cyclic permutation
 		if (riemann == QK_RIEMANN_HLLC) {
 			launchComputeFluxes<1, QK_RIEMANN_HLLC, true>(lev, s, t, flux_t, fvel_t, left_t, right_t, prim_t, K_visc);
+		} else if (riemann == QK_RIEMANN_HLLD) {
+			launchComputeFluxes<1, QK_RIEMANN_HLLD, true>(lev, s, t, flux_t, fvel_t, left_t, right_t, prim_t, K_visc);
 		} else {
 			launchComputeFluxes<1, QK_RIEMANN_LLF, true>(lev, s, t, flux_t, fvel_t, left_t, right_t, prim_t, K_visc);
 		}
@@ -375,6 +377,8 @@ int qk_hydro_ComputeFluxes(qk_level *lev, qk_stream s, const qk_hydro_traits *t,
 	}
 	if (riemann == QK_RIEMANN_HLLC) {
 		QK_DISPATCH_DIR(dir, (launchComputeFluxes<DIR, QK_RIEMANN_HLLC>(lev, s, t, flux_t, fvel_t, left_t, right_t, prim_t, K_visc)));
+	} else if (riemann == QK_RIEMANN_HLLD) {
+		QK_DISPATCH_DIR(dir, (launchComputeFluxes<DIR, QK_RIEMANN_HLLD>(lev, s, t, flux_t, fvel_t, left_t, right_t, prim_t, K_visc)));
 	} else {
 		QK_DISPATCH_DIR(dir, (launchComputeFluxes<DIR, QK_RIEMANN_LLF>(lev, s, t, flux_t, fvel_t, left_t, right_t, prim_t, K_visc)));
 	}

@@ -364,9 +364,10 @@ template <typename problem_t> class HydroSystem : public HyperbolicSystem<proble
 	static void ComputeFluxes(amrex::MultiFab &flux, amrex::MultiFab &fvel, amrex::MultiFab const &l, amrex::MultiFab const &r, amrex::MultiFab const &prim,
 				  amrex::Real K_visc)
 	{
-		static_assert(RIEMANN != RiemannSolver::HLLD, "MHD is out of scope");
+		// (HLLD: the reference's MHD stub — zero magnetic field, hydro_system.hpp:987-1003, :1044-1048)
+		constexpr int riemann = (RIEMANN == RiemannSolver::LLF) ? QK_RIEMANN_LLF : (RIEMANN == RiemannSolver::HLLD) ? QK_RIEMANN_HLLD : QK_RIEMANN_HLLC;
 		auto t = qkhost::traits<problem_t>();
-		qkhost::check(qk_hydro_ComputeFluxes(lev(), nullptr, &t, RIEMANN == RiemannSolver::LLF ? QK_RIEMANN_LLF : QK_RIEMANN_HLLC, static_cast<int>(DIR),
+		qkhost::check(qk_hydro_ComputeFluxes(lev(), nullptr, &t, riemann, static_cast<int>(DIR),
 						     qkhost::tab(flux), qkhost::tab(fvel), qkhost::tab(l), qkhost::tab(r), qkhost::tab(prim), K_visc),
 			      "ComputeFluxes");
 	}

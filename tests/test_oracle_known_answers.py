@@ -416,3 +416,19 @@ def test_scalar_advection_meets_the_reference_criterion(oracle, problem):
     assert s.evolve() and s.istep == 10000 and abs(s.time - 1.0) < 1e-12
     err = np.abs(s.valid(0) - U0).sum() / np.abs(U0).sum()
     assert 1e-3 < err <= 0.015, err
+
+
+def test_hlld_is_consistent_and_upwinds(oracle):
+    """properties every Riemann flux has, checked on the oracle's HLLD (CPU): F(U, U) = f(U); a supersonic state to the right takes the left
+    flux.  (No reference test exercises HLLD: these and the bit-level GPU comparison above are its pins.)"""
+    from oracle import pyoracle
+    tr = pyoracle.traits(1.4, False, 1)
+    n, ng = 8, 4
+    for vx, rho, P in ((0.3, 1.0, 1.0), (5.0, 2.0, 0.5), (-4.0, 0.7, 0.2)):
+        U = np.zeros((6, 1, 1, n + 2 * ng))
+        U[0], U[1] = rho, rho * vx
+        U[4] = P / 0.4 + 0.5 * rho * vx * vx
+        U[5] = P / 0.4
+        F, V = oracle.compute_hydro_fluxes(tr, 1, U, [0, 0, 0], [n - 1, 0, 0], mhd_stub=True)
+        f = np.array([rho * vx, rho * vx * vx + P, 0.0, 0.0, vx * (U[4].flat[0] + P)])
+        assert np.allclose(F[0][:5, 0, 0, :], f[:, None], rtol=1e-13, atol=1e-13), (vx, F[0][:5, 0, 0, 0], f)
