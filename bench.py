@@ -291,6 +291,26 @@ def run_amr(ctx, torch, dist, rank, world, ncell, steps, warmup):
                        "composite_energy_relative_change": abs(E1 - E0) / abs(E0), "composite_mass_relative_change": abs(M1 - M0) / abs(M0)}}
 
 
+def cxx_host_block(args, ncell):
+    """bin/sedov_bench (built by __graft_entry__.build()) with the deck of BASELINE config 2: W warm-up + K timed steps, its JSON line"""
+    import subprocess
+    host = os.path.join(ROOT, "quokka_amd", "host")
+    exe = os.path.join(host, "bin", "sedov_bench")
+    if not os.path.exists(exe):
+        return {"error": "quokka_amd/host/bin/sedov_bench is not built (python -c 'import __graft_entry__ as g; g.build()')"}
+    cmd = [exe, os.path.join(host, "decks", "blast_unigrid_256.in"), f"amr.n_cell={ncell} {ncell} {ncell}", f"bench.warmup={args.warmup}", f"bench.steps={args.steps}",
+           f"hydro.rk2_carry_rhs={1 if args.rk2_mode == 'carry' else 0}", "max_timesteps=1000000"]
+    try:
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        line = next(l for l in p.stdout.splitlines() if l.startswith("{") and "cxx_host" in l)
+        blk = json.loads(line)
+    except Exception as e:  # noqa: BLE001 - a secondary block must not take the headline down
+        return {"error": f"{type(e).__name__}: {e}"}
+    blk["rk2_mode"] = args.rk2_mode
+    blk["driver"] = "quokka_amd/host/drivers/sedov_bench.cpp through QuokkaSimulation<problem_t> (C++17 host mirror), deck blast_unigrid_256.in"
+    return blk
+
+
 def compact(block, keep=("value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline", "kernels_ms_per_launch")):
     """a secondary block of the default line: the figures of a workload's own line without the contract boilerplate"""
     return {k: block[k] for k in keep if k in block}
@@ -560,6 +580,9 @@ def main():
                                              "tests/test_bench_geometry_gpu.py)"}
             del sO
             torch.cuda.empty_cache()
+            # (c2) the same measurement through the C++17 host mirror (quokka_amd/host: QuokkaSimulation<problem_t> as a problem file drives it;
+            # builder-authored driver quokka_amd/host/drivers/sedov_bench.cpp, its own process)
+            out["cxx_host"] = cxx_host_block(args, 256)
             # (d) BASELINE config 4 at its full size: RadhydroShell 256^3, the 50 steps the reference problem runs (test_radhydro_shell.cpp:431)
             out["shell256"] = compact(run_shell(ctx, torch, 256, 128, 50, 2, 0))
             torch.cuda.empty_cache()

@@ -165,6 +165,19 @@ namespace qkhost
 struct Runtime {
 	qk_ctx *ctx = nullptr;
 	qk_level *lev = nullptr; // the level the static operators act on (every simulation object activates its own before it launches)
+	// The compute stream of the ghost fill and the fused stages.  A BLOCKING stream: the legacy default stream — which the problem files'
+	// ParallelFor lambdas and the reference-shaped operators use — orders itself against it in both directions, so nothing else needs to know;
+	// the communication stream of qk_comm.hpp is non-blocking and is ordered against this one by events only (exchangeBegin / exchangeEnd).
+	hipStream_t compute = nullptr;
+	auto computeStream() -> hipStream_t
+	{
+		if (compute == nullptr) {
+			if (hipStreamCreate(&compute) != hipSuccess) {
+				amrex::Abort("hipStreamCreate (compute stream) failed");
+			}
+		}
+		return compute;
+	}
 	static auto get() -> Runtime &
 	{
 		static Runtime r;
@@ -1343,44 +1356,56 @@ template <typename problem_t> class AMRSimulation
 		fillBoundaryConditions(state);
 		qkhost::check(qk_ghost_plan_set_components(plan_, 0, -1), "qk_ghost_plan_set_components");
 	}
-	// level-0 branch of fillBoundaryConditions (reference src/simulation.hpp:1751-1776)
-	void fillBoundaryConditions(amrex::MultiFab &state)
+	// level-0 branch of fillBoundaryConditions (reference src/simulation.hpp:1751-1776).
+	// `between` (optional; the multi-GPU schedule of north_star): called while the strips of the other ranks are on the wire — RCCL moves them on
+	// its own HIP stream (qk_comm.hpp) —, after the boxes that receive nothing remote have been completed (same-rank copies + their own
+	// physical-boundary slabs).  The caller advances exactly those boxes in it; the rest follows after the unpack.
+	void fillBoundaryConditions(amrex::MultiFab &state, std::function<void()> const &between = {})
 	{
 		activate();
+		hipStream_t const cs = qkhost::Runtime::get().computeStream();
 		// state.FillBoundary(geom.periodicity()) (reference src/simulation.hpp:1755): strips for the other ranks are packed, sent peer to peer
 		// while the same-rank copies run, and unpacked
 		for (size_t k = 0; k < peers_.peer.size(); ++k) {
-			qkhost::check(qk_FillBoundary_pack(plan_, nullptr, static_cast<int>(k), qkhost::tab(state), static_cast<double *>(peers_.send[k])),
+			qkhost::check(qk_FillBoundary_pack(plan_, cs, static_cast<int>(k), qkhost::tab(state), static_cast<double *>(peers_.send[k])),
 				      "FillBoundary_pack");
 		}
-		qkhost::Comm::get().exchangeBegin(peers_.peer, peers_.send, peers_.nsend, peers_.recv, peers_.nrecv, sizeof(double), nullptr);
-		qkhost::check(qk_FillBoundary_local(plan_, nullptr, qkhost::tab(state)), "FillBoundary");
-		qkhost::Comm::get().exchangeEnd(nullptr);
+		qkhost::Comm::get().exchangeBegin(peers_.peer, peers_.send, peers_.nsend, peers_.recv, peers_.nrecv, sizeof(double), cs);
+		qkhost::check(qk_FillBoundary_local(plan_, cs, qkhost::tab(state)), "FillBoundary");
+		bool const physical = !geom[0].isAllPeriodic();
+		std::vector<qk_bcrec> bcs(BCs_cc_.size());
+		for (size_t n = 0; n < BCs_cc_.size(); ++n) {
+			for (int d = 0; d < 3; ++d) {
+				bcs[n].lo[d] = (d < AMREX_SPACEDIM) ? BCs_cc_[n].lo(d) : 0;
+				bcs[n].hi[d] = (d < AMREX_SPACEDIM) ? BCs_cc_[n].hi(d) : 0;
+			}
+		}
+		auto physbc = [&](int which) {
+			if (physical) {
+				qkhost::check(qk_FillPhysicalBoundary_subset(plan_, cs, qkhost::tab(state), bcs.data(), nullptr, which), "FillPhysicalBoundary");
+				customBoundaryConditionsOnDevice(state, which);
+			}
+		};
+		if (between) {
+			AMREX_ALWAYS_ASSERT(!beforePhysBC_); // (a refined level interpolates its uncovered ghost cells first: no split there)
+			physbc(QK_BOXES_LOCAL_ONLY);
+			between();
+		}
+		qkhost::Comm::get().exchangeEnd(cs);
 		for (size_t k = 0; k < peers_.peer.size(); ++k) {
-			qkhost::check(qk_FillBoundary_unpack(plan_, nullptr, static_cast<int>(k), qkhost::tab(state), static_cast<const double *>(peers_.recv[k])),
+			qkhost::check(qk_FillBoundary_unpack(plan_, cs, static_cast<int>(k), qkhost::tab(state), static_cast<const double *>(peers_.recv[k])),
 				      "FillBoundary_unpack");
 		}
 		if (beforePhysBC_) {
 			beforePhysBC_(state);
 		}
-		if (!geom[0].isAllPeriodic()) {
-			std::vector<qk_bcrec> bcs(BCs_cc_.size());
-			for (size_t n = 0; n < BCs_cc_.size(); ++n) {
-				for (int d = 0; d < 3; ++d) {
-					bcs[n].lo[d] = (d < AMREX_SPACEDIM) ? BCs_cc_[n].lo(d) : 0;
-					bcs[n].hi[d] = (d < AMREX_SPACEDIM) ? BCs_cc_[n].hi(d) : 0;
-				}
-			}
-			qkhost::check(qk_FillPhysicalBoundary(plan_, nullptr, qkhost::tab(state), bcs.data(), nullptr),
-				      "FillPhysicalBoundary");
-			customBoundaryConditionsOnDevice(state);
-		}
+		physbc(between ? QK_BOXES_REMOTE_DEPENDENT : QK_BOXES_ALL);
 	}
 	// setCustomBoundaryConditions as the reference runs it (simulation.hpp:297-299, :1550-1561; amrex::GpuBndryFuncFab): the problem's
 	// DEVICE function is called for every ghost cell that lies outside the domain in a non-periodic direction, after the mathematical
 	// boundary types have been filled.  One kernel instantiated with the problem type per box — arbitrary boundary code, not the closed
 	// Dirichlet / Marshak set of the C-ABI (which host-mode problems are sampled into).
-	void customBoundaryConditionsOnDevice(amrex::MultiFab &state)
+	void customBoundaryConditionsOnDevice(amrex::MultiFab &state, int which = QK_BOXES_ALL)
 	{
 		if (d_bcrec_ == nullptr) {
 			QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_bcrec_), sizeof(amrex::BCRec) * BCs_cc_.size()));
@@ -1400,8 +1425,11 @@ template <typename problem_t> class AMRSimulation
 			if (!touches) {
 				continue;
 			}
+			if (which != QK_BOXES_ALL && (qk_ghost_plan_box_is_remote(plan_, b) == 1) != (which == QK_BOXES_REMOTE_DEPENDENT)) {
+				continue; // the other group of an overlapped fill
+			}
 			amrex::Long const n = fb.numPts();
-			hipLaunchKernelGGL(qkhost::customBcKernel<problem_t>, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, nullptr, state.array(b), fb, gd,
+			hipLaunchKernelGGL(qkhost::customBcKernel<problem_t>, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, qkhost::Runtime::get().computeStream(), state.array(b), fb, gd,
 					   bcFillTime(), d_bcrec_, state.nComp(), per[0], per[1], per[2]);
 		}
 	}
@@ -1548,6 +1576,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		hpp.query("use_dual_energy", useDualEnergy_);
 		hpp.query("abort_on_fofc_failure", abortOnFofcFailure_);
 		hpp.query("artificial_viscosity_coefficient", artificialViscosityK_);
+		hpp.query("rk2_carry_rhs", rk2CarryRhs_); // extension of this host: the carried-rhs form of the RK2 average (<= 1e-12; quokka_amd.h)
 		amrex::ParmParse rpp("radiation"); // reference src/QuokkaSimulation.hpp:353-358
 		rpp.query("reconstruction_order", radiationReconstructionOrder_);
 		rpp.query("cfl", radiationCflNumber_);
@@ -1807,14 +1836,12 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		// first half of the Strang-split source terms, on the (temporary) old state (reference src/QuokkaSimulation.hpp:1048)
 		addStrangSplitSources(state_old_cc_tmp, 0, time, 0.5 * dt_lev);
 		fillTime_ = time; // reference src/QuokkaSimulation.hpp:1076 (stage 1), :1204 (stage 2: time + dt_lev)
-		this->fillBoundaryConditions(state_old_cc_tmp);
-		if (!stage(1, state_old_cc_tmp, state_old_cc_tmp, state_inter_cc_, dt_lev)) {
+		if (!fillAndStage(1, state_old_cc_tmp, state_old_cc_tmp, state_inter_cc_, dt_lev)) {
 			return false;
 		}
 		if (integratorOrder_ == 2) {
 			fillTime_ = time + dt_lev;
-			this->fillBoundaryConditions(state_inter_cc_);
-			if (!stage(2, state_inter_cc_, state_old_cc_tmp, state_new_cc_[0], dt_lev)) {
+			if (!fillAndStage(2, state_inter_cc_, state_old_cc_tmp, state_new_cc_[0], dt_lev)) {
 				return false;
 			}
 		} else {
@@ -2171,54 +2198,193 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		return true;
 	}
 
-	auto stage(int stageNo, amrex::MultiFab const &U_in, amrex::MultiFab const &U_old, amrex::MultiFab &U_out, double dt) -> bool
+	// ------------------------------------------------------------------ the fused stage (qk_hydro_stage_fused) and the multi-GPU schedule
+	// the fused stage carries up to 3 passive scalars; mass scalars take the reference-shaped operators
+	[[nodiscard]] static constexpr auto fusedEligible() -> bool
 	{
-		// the fused stage carries up to 3 passive scalars; mass scalars take the reference-shaped operators
-		if (AMREX_SPACEDIM == 3 && HydroSystem<problem_t>::nscalars_ <= 3 && Physics_Traits<problem_t>::numMassScalars == 0) {
-			auto t = qkhost::traits<problem_t>();
-			qk_hydro_stage_args a{};
-			a.U_in = qkhost::tab(U_in);
-			a.U_old = qkhost::tab(U_old);
-			a.U_out = qkhost::tab(U_out);
-			for (int d = 0; d < 3; ++d) {
-				a.halfFlux[d] = qkhost::tab(halfFlux_[d]);
-				a.halfVel[d] = qkhost::tab(halfVel_[d]);
-				a.dx[d] = geom[0].dx[d];
-			}
-			a.redoFlag = qkhost::itab(redoFlag_);
-			QK_HOST_HIP(hipMemset(d_count_, 0, sizeof(int64_t)));
-			a.d_redo_count = d_count_;
-			a.d_error_flag = d_error_;
-			bool const final_stage = (stageNo == 2) || (integratorOrder_ == 1);
-			if (final_stage) {
-				QK_HOST_HIP(hipMemset(d_signal_, 0, 2 * sizeof(double)));
-				a.d_max_signal = d_signal_;
-			}
-			a.scratch = scratch_;
-			a.scratch_bytes = scratchBytes_;
-			a.dt = dt;
-			a.stage = stageNo;
-			a.reconstruction_order = reconstructionOrder_;
-			a.densityFloor = densityFloor_;
-			a.tempFloor = tempFloor_;
-			a.use_dual_energy = useDualEnergy_;
-			a.K_visc = artificialViscosityK_;
-			a.store_flux_rk2 = storeFluxRk2_ ? 1 : 0;
-			for (int d = 0; d < 3; ++d) {
-				a.fluxRk2[d] = storeFluxRk2_ ? qkhost::tab(rk2flux_[d]) : nullptr;
-			}
-			qkhost::check(qk_hydro_stage_fused(qkhost::Runtime::get().lev, nullptr, &t, &a), "qk_hydro_stage_fused");
-			if (readCount() == 0) {
-				if (final_stage) {
-					QK_HOST_HIP(hipMemcpy(signal_, d_signal_, 2 * sizeof(double), hipMemcpyDeviceToHost));
-					qkhost::Comm::get().allReduce(signal_, 2, qkhost::Comm::Op::max);
-					haveSignal_ = true;
+		return AMREX_SPACEDIM == 3 && HydroSystem<problem_t>::nscalars_ <= 3 && Physics_Traits<problem_t>::numMassScalars == 0;
+	}
+	[[nodiscard]] auto isFinalStage(int stageNo) const -> bool { return (stageNo == 2) || (integratorOrder_ == 1); }
+	// the carried-right-hand-side form of the RK2 average (qk_hydro_stage_args::rk2_carry_rhs; deck: hydro.rk2_carry_rhs = 1, default 0): only
+	// where nothing consumes flux_rk2 (no flux registers) and the integrator has two stages
+	[[nodiscard]] auto carryActive() const -> bool { return rk2CarryRhs_ != 0 && integratorOrder_ == 2 && !storeFluxRk2_; }
+
+	// Boxes of this rank in two groups for the overlapped ghost fill: [0] early — every ghost cell is filled on this GPU —, [1] late — waits
+	// for strips from other ranks (qk_ghost_plan_box_is_remote).  Each group is a sub-level whose descriptor tables alias the level's arrays.
+	struct OverlapGroup {
+		std::vector<int> idx;
+		qk_level *lev = nullptr;
+		std::map<const void *, void *> tables; // descriptor table of a MultiFab -> the same descriptors of this group's boxes, contiguous
+	};
+	OverlapGroup groups_[2];
+	int overlapState_ = 0; // 0: not examined, 1: active, 2: not worth it / not possible
+	amrex::Long minOverlapCells_ = 8L * 128 * 128 * 128; // a launch fills the chip from ~8 boxes of 128^3 on (the marching sweeps expose one wave per 64 cells of a pencil)
+
+	auto overlapActive() -> bool
+	{
+		if (overlapState_ == 0) {
+			overlapState_ = 2;
+			amrex::ParmParse pq("qk");
+			pq.query("min_overlap_cells", minOverlapCells_); // (tests: 1 forces the split on small problems)
+			if (!this->beforePhysBC_ && fusedEligible()) {
+				amrex::Long cells[2] = {0, 0};
+				for (int b = 0; b < static_cast<int>(grids_.size()); ++b) {
+					int const g = (qk_ghost_plan_box_is_remote(this->plan_, b) == 1) ? 1 : 0;
+					groups_[g].idx.push_back(b);
+					cells[g] += grids_[b].numPts();
 				}
-				return true;
+				if (!groups_[0].idx.empty() && !groups_[1].idx.empty() && std::min(cells[0], cells[1]) >= minOverlapCells_) {
+					for (auto &g : groups_) {
+						std::vector<qk_box> qb;
+						for (int b : g.idx) {
+							qb.push_back({{grids_[b].lo[0], grids_[b].lo[1], grids_[b].lo[2]}, {grids_[b].hi[0], grids_[b].hi[1], grids_[b].hi[2]}});
+						}
+						qkhost::check(qk_level_create(qkhost::Runtime::get().ctx, &g.lev, AMREX_SPACEDIM, static_cast<int>(qb.size()), qb.data()), "qk_level_create");
+					}
+					overlapState_ = 1;
+					std::cout << "rank " << qkhost::Comm::get().rank << ": overlapped ghost fill: " << groups_[0].idx.size() << " early / " << groups_[1].idx.size()
+						  << " late boxes\n";
+				}
 			}
+		}
+		return overlapState_ == 1;
+	}
+	// the descriptors of group g's boxes out of a MultiFab's table (64 bytes each), gathered once per table
+	template <typename D> auto groupTable(int g, D *full) -> D *
+	{
+		if (full == nullptr) {
+			return nullptr;
+		}
+		auto &m = groups_[g].tables;
+		auto it = m.find(full);
+		if (it == m.end()) {
+			void *p = nullptr;
+			QK_HOST_HIP(hipMalloc(&p, sizeof(D) * groups_[g].idx.size()));
+			for (size_t n = 0; n < groups_[g].idx.size(); ++n) {
+				QK_HOST_HIP(hipMemcpy(static_cast<D *>(p) + n, full + groups_[g].idx[n], sizeof(D), hipMemcpyDeviceToDevice));
+			}
+			it = m.emplace(full, p).first;
+		}
+		return static_cast<D *>(it->second);
+	}
+
+	void fusedBegin(int stageNo)
+	{
+		hipStream_t const cs = qkhost::Runtime::get().computeStream();
+		QK_HOST_HIP(hipMemsetAsync(d_count_, 0, sizeof(int64_t), cs));
+		if (isFinalStage(stageNo)) {
+			QK_HOST_HIP(hipMemsetAsync(d_signal_, 0, 2 * sizeof(double), cs));
+		}
+	}
+	// one fused stage over all local boxes (group < 0) or over one group of the overlapped fill
+	void fusedLaunch(int stageNo, amrex::MultiFab const &U_in, amrex::MultiFab const &U_old, amrex::MultiFab &U_out, double dt, int group = -1)
+	{
+		auto t = qkhost::traits<problem_t>();
+		auto sel = [&](qk_array4 *full) { return group < 0 ? full : groupTable(group, full); };
+		qk_hydro_stage_args a{};
+		a.U_in = sel(qkhost::tab(U_in));
+		a.U_old = sel(qkhost::tab(U_old));
+		a.U_out = sel(qkhost::tab(U_out));
+		for (int d = 0; d < 3; ++d) {
+			a.halfFlux[d] = sel(qkhost::tab(halfFlux_[d]));
+			a.halfVel[d] = sel(qkhost::tab(halfVel_[d]));
+			a.dx[d] = geom[0].dx[d];
+		}
+		a.redoFlag = group < 0 ? qkhost::itab(redoFlag_) : groupTable(group, qkhost::itab(redoFlag_));
+		a.d_redo_count = d_count_;
+		a.d_error_flag = d_error_;
+		if (isFinalStage(stageNo)) {
+			a.d_max_signal = d_signal_;
+		}
+		a.scratch = scratch_;
+		a.scratch_bytes = scratchBytes_;
+		a.dt = dt;
+		a.stage = stageNo;
+		a.reconstruction_order = reconstructionOrder_;
+		a.densityFloor = densityFloor_;
+		a.tempFloor = tempFloor_;
+		a.use_dual_energy = useDualEnergy_;
+		a.K_visc = artificialViscosityK_;
+		a.store_flux_rk2 = storeFluxRk2_ ? 1 : 0;
+		for (int d = 0; d < 3; ++d) {
+			a.fluxRk2[d] = storeFluxRk2_ ? sel(qkhost::tab(rk2flux_[d])) : nullptr;
+		}
+		if (carryActive()) {
+			if (rhs1_.size() == 0) {
+				rhs1_.define(grids_, ncompHydro_ + 1, 0);
+			}
+			a.rk2_carry_rhs = 1;
+			a.rhs1 = sel(qkhost::tab(rhs1_));
+		}
+		qkhost::check(qk_hydro_stage_fused(group < 0 ? qkhost::Runtime::get().lev : groups_[group].lev, qkhost::Runtime::get().computeStream(), &t, &a),
+			      "qk_hydro_stage_fused");
+	}
+	// flagged cells of the stage (all ranks); after a clean final stage the two CFL maxima are kept for computeTimestep / isCflViolated
+	auto fusedEnd(int stageNo) -> int64_t
+	{
+		int64_t const nbad = readCount();
+		if (nbad == 0) {
+			stage1LeftF1_ = (stageNo == 1) ? !carryActive() : stage1LeftF1_;
+			if (isFinalStage(stageNo)) {
+				QK_HOST_HIP(hipMemcpy(signal_, d_signal_, 2 * sizeof(double), hipMemcpyDeviceToHost));
+				qkhost::Comm::get().allReduce(signal_, 2, qkhost::Comm::Op::max);
+				haveSignal_ = true;
+			}
+		}
+		return nbad;
+	}
+	// a stage whose fused attempt flagged cells, on the reference-shaped operators.  Stage 2 forms 0.5 F1 + 0.5 F2 from halfFlux_: after a fused
+	// stage 1 in the carried-rhs mode F1 was never stored and is evaluated again from the old state (ghost cells still filled; same device
+	// functions, same values)
+	auto redoStageUnfused(int stageNo, amrex::MultiFab const &U_in, amrex::MultiFab const &U_old, amrex::MultiFab &U_out, double dt) -> bool
+	{
+		if (stageNo == 2 && !stage1LeftF1_) {
+			computeHydroFluxes(U_old);
+			for (int d = 0; d < AMREX_SPACEDIM; ++d) {
+				amrex::MultiFab::Copy(halfFlux_[d], flux_[d]);
+				amrex::MultiFab::Copy(halfVel_[d], vel_[d]);
+			}
+		}
+		if (stageNo == 1) {
+			stage1LeftF1_ = true;
 		}
 		return stageUnfused(stageNo, U_in, U_old, U_out, dt);
 	}
+
+	auto stage(int stageNo, amrex::MultiFab const &U_in, amrex::MultiFab const &U_old, amrex::MultiFab &U_out, double dt) -> bool
+	{
+		if constexpr (fusedEligible()) {
+			fusedBegin(stageNo);
+			fusedLaunch(stageNo, U_in, U_old, U_out, dt);
+			if (fusedEnd(stageNo) == 0) {
+				return true;
+			}
+		}
+		return redoStageUnfused(stageNo, U_in, U_old, U_out, dt);
+	}
+
+	// fillBoundaryConditions(U_in) + one RK stage.  With boxes on other ranks the early group is advanced while the strips of the late group are
+	// on the wire (north_star: FillBoundary overlapped with the update on a second HIP stream — RCCL's); the reference's fill is blocking
+	// (src/QuokkaSimulation.hpp:1076, :1204).  Same arithmetic per cell: bit-identical to the blocking schedule.
+	auto fillAndStage(int stageNo, amrex::MultiFab &U_in, amrex::MultiFab const &U_old, amrex::MultiFab &U_out, double dt) -> bool
+	{
+		if constexpr (fusedEligible()) {
+			if (overlapActive()) {
+				fusedBegin(stageNo);
+				this->fillBoundaryConditions(U_in, [&]() { fusedLaunch(stageNo, U_in, U_old, U_out, dt, 0); });
+				fusedLaunch(stageNo, U_in, U_old, U_out, dt, 1);
+				if (fusedEnd(stageNo) == 0) {
+					return true;
+				}
+				return redoStageUnfused(stageNo, U_in, U_old, U_out, dt);
+			}
+		}
+		this->fillBoundaryConditions(U_in);
+		return stage(stageNo, U_in, U_old, U_out, dt);
+	}
+	int rk2CarryRhs_ = 0;	   // deck: hydro.rk2_carry_rhs
+	bool stage1LeftF1_ = true; // halfFlux_ holds the stage-1 fluxes of the current step
+	amrex::MultiFab rhs1_;
 };
 
 template <typename problem_t> void QuokkaSimulation<problem_t>::preCalculateInitialConditions() {}

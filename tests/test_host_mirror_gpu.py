@@ -292,6 +292,31 @@ def test_sedov_on_several_ranks_equals_one_rank(tmp_path, nranks):
     assert "Energy conservation is OK." in outs[0] and "Energy conservation is OK." in outs1[0]
 
 
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_overlapped_fill_schedule_of_the_cxx_host_equals_one_rank(tmp_path, nranks):
+    """north_star's schedule in the C++17 host (quokka_host.hpp fillAndStage): the boxes whose ghost cells are all filled on this rank are advanced
+    by a fused launch over a sub-level while the strips of the others travel (RCCL's stream in production; the shm test transport here keeps the
+    ORDER of the schedule: pack -> send -> same-rank copies -> physical boundaries of the early group -> early launch -> receive -> unpack ->
+    boundaries of the late group -> late launch).  64^3 in 64 boxes of 16^3, the split forced on (qk.min_overlap_cells = 1): the union of the
+    ranks' boxes equals the one-rank run in every bit, also in the carried-rhs mode."""
+    from quokka_amd.simulation import chop_domain, distribute_boxes
+    for extra in ([], ["hydro.rk2_carry_rhs=1"]):
+        args = ["geometry.prob_lo=0 0 0", "geometry.prob_hi=1.2 1.2 1.2", "geometry.is_periodic=0 0 0", "amr.n_cell=64 64 64", "amr.max_grid_size=16",
+                "max_timesteps=10"] + extra
+        (one,), outs1 = run_ranks("ref_HydroBlast3D", args, tmp_path, 1, 29651)
+        parts, outs = run_ranks("ref_HydroBlast3D", args + ["qk.min_overlap_cells=1"], tmp_path, nranks, 29651 + nranks)
+        assert all("overlapped ghost fill:" in o for o in outs), outs[0][-1500:]
+        assert "overlapped ghost fill:" not in outs1[0]
+        boxes = chop_domain([64, 64, 64], [16, 16, 16])
+        owner = distribute_boxes(boxes, nranks, [64, 64, 64], [16, 16, 16])
+        one = one.reshape(64, 6, 16, 16, 16)
+        cursor = [0] * nranks
+        for b, r in enumerate(owner):
+            chunk = parts[r][cursor[r]:cursor[r] + 6 * 16 ** 3].reshape(6, 16, 16, 16)
+            cursor[r] += 6 * 16 ** 3
+            assert np.array_equal(chunk, one[b]), (extra, b, r, np.abs(chunk - one[b]).max())
+
+
 def test_sedov_on_several_gpus_over_rccl(tmp_path):
     """the production transport (ncclSend / ncclRecv on the library-owned stream, ncclAllReduce): needs one GPU per rank — skipped on a
     one-GPU box, where the test above covers everything but the transport itself"""
