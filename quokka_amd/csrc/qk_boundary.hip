@@ -83,16 +83,21 @@ template <int MODE, typename T = double, typename D = qk_array4>
 __global__ void __launch_bounds__(256) k_copy(const CopyItem *items, const D *state_t, T *buf, int ncomp, int scomp = 0)
 {
 	const CopyItem it = items[blockIdx.y];
-	const int n0 = it.hi[0] - it.lo[0] + 1, n1 = it.hi[1] - it.lo[1] + 1, n2 = it.hi[2] - it.lo[2] + 1;
-	const int64_t ncell = static_cast<int64_t>(n0) * n1 * n2;
-	const int64_t total = ncell * ncomp;
-	for (int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < total; t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-		const int n = static_cast<int>(t / ncell);
-		const int64_t c = t - n * ncell;
-		const int k = static_cast<int>(c / (static_cast<int64_t>(n0) * n1));
-		const int r = static_cast<int>(c - static_cast<int64_t>(k) * n0 * n1);
-		const int j = r / n0;
-		const int i = r - j * n0;
+	// 32-bit index arithmetic: a region holds fewer than 2^31 values (checked when the plan is made); a 64-bit division costs ~10x a 32-bit one
+	// and there were four per element (the copy kernels were bound by them: round-3 profile, 56 -> us per launch at 256^3)
+	const unsigned n0 = static_cast<unsigned>(it.hi[0] - it.lo[0] + 1), n1 = static_cast<unsigned>(it.hi[1] - it.lo[1] + 1),
+		       n2 = static_cast<unsigned>(it.hi[2] - it.lo[2] + 1);
+	const unsigned n01 = n0 * n1;
+	const unsigned ncell = n01 * n2;
+	const unsigned total = ncell * static_cast<unsigned>(ncomp);
+	for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+		const unsigned un = t / ncell;
+		const unsigned c = t - un * ncell;
+		const unsigned uk = c / n01;
+		const unsigned r = c - uk * n01;
+		const unsigned uj = r / n0;
+		const int n = static_cast<int>(un), k = static_cast<int>(uk), j = static_cast<int>(uj);
+		const int i = static_cast<int>(r - uj * n0);
 		const int di = it.lo[0] + i, dj = it.lo[1] + j, dk = it.lo[2] + k;
 		if (MODE == MODE_LOCAL) {
 			A4<T, D> Dst(state_t[it.dst_box]);
@@ -142,13 +147,15 @@ __global__ void __launch_bounds__(256) k_physbc(const CopyItem *items, qk_array4
 		lo[d] = it.lo[d];
 		len[d] = it.hi[d] - it.lo[d] + 1;
 	}
-	const int64_t ncell = static_cast<int64_t>(len[0]) * len[1] * len[2];
+	const unsigned l0 = static_cast<unsigned>(len[0]), l01 = l0 * static_cast<unsigned>(len[1]);
+	const unsigned ncell = l01 * static_cast<unsigned>(len[2]); // (< 2^31: checked when the plan is made; 32-bit divisions, see k_copy)
 	WA4 A(state_t[it.dst_box]);
-	for (int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < ncell; t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-		const int k = static_cast<int>(t / (static_cast<int64_t>(len[0]) * len[1]));
-		const int r = static_cast<int>(t - static_cast<int64_t>(k) * len[0] * len[1]);
-		const int j = r / len[0];
-		const int i = r - j * len[0];
+	for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < ncell; t += gridDim.x * blockDim.x) {
+		const unsigned uk = t / l01;
+		const unsigned r = t - uk * l01;
+		const unsigned uj = r / l0;
+		const int k = static_cast<int>(uk), j = static_cast<int>(uj);
+		const int i = static_cast<int>(r - uj * l0);
 		const int idx[3] = {lo[0] + i, lo[1] + j, lo[2] + k};
 		int side[3] = {0, 0, 0};
 		bool out = false;
@@ -402,6 +409,16 @@ int qk_ghost_plan_create(qk_level *lev, qk_ghost_plan **plan_out, const qk_geome
 		}
 	}
 	partitionShells(P);
+	{ // the copy kernels index a region with 32-bit arithmetic
+		int64_t biggest = std::max<int64_t>(P->max_local_cells, P->max_shell_cells);
+		for (auto &kv : peers) {
+			biggest = std::max<int64_t>(biggest, std::max<int64_t>(kv.second.max_recv_cells, kv.second.max_send_cells));
+		}
+		if (biggest * ncomp >= (int64_t{1} << 31)) {
+			delete P;
+			return setError(ctx, QK_ERR_UNSUPPORTED, "qk_ghost_plan_create: a ghost region holds 2^31 or more values");
+		}
+	}
 	int rc = uploadItems(ctx, P->local, &P->d_local);
 	if (rc == QK_OK) {
 		rc = uploadItems(ctx, P->shells, &P->d_shells);
@@ -510,6 +527,7 @@ int qk_FillBoundary_local(qk_ghost_plan *plan, qk_stream s, qk_array4 *state_t)
 		return QK_OK;
 	}
 	const int nc = (plan->active_ncomp < 0) ? plan->ncomp : plan->active_ncomp;
+	ProfScope ps(ctx, static_cast<hipStream_t>(s), "ghost_copy_local");
 	hipLaunchKernelGGL(k_copy<MODE_LOCAL>, gridFor(static_cast<int64_t>(plan->max_local_cells) * nc, static_cast<int>(plan->local.size())), dim3(256), 0,
 			   static_cast<hipStream_t>(s), plan->d_local, state_t, static_cast<double *>(nullptr), nc, plan->active_scomp);
 	QK_HIP_CHECK(ctx, hipGetLastError());
@@ -751,6 +769,7 @@ int qk_FillPhysicalBoundary_subset(qk_ghost_plan *plan, qk_stream s, qk_array4 *
 		QK_HIP_CHECK(ctx, hipStreamSynchronize(static_cast<hipStream_t>(s)));
 		plan->h_physbc.assign(reinterpret_cast<const unsigned char *>(&pa), reinterpret_cast<const unsigned char *>(&pa) + sizeof(PhysBcArgs));
 	}
+	ProfScope ps(ctx, static_cast<hipStream_t>(s), "ghost_physbc");
 	if (pa.has_dirichlet != 0) {
 		hipLaunchKernelGGL(k_physbc<true>, gridFor(plan->max_shell_cells, count), dim3(256), 0, static_cast<hipStream_t>(s), plan->d_shells + first, state_t,
 				   plan->geom, (plan->active_ncomp < 0) ? plan->ncomp : plan->active_ncomp, static_cast<const PhysBcArgs *>(plan->d_physbc),
