@@ -138,8 +138,10 @@ QK_DEV auto planeCell(Eos const &eos, bool re, PlaneRaw const &r) -> PlaneCell
 // Workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2; tiles that are neighbours in y read each other's halo rows.  The
 // linear id is remapped so that every XCD works through one contiguous run of tiles (x fastest, then y, then box / segment): the halo rows
 // of a tile are then found in the L2 of the XCD that just read them for the tile before.
+// ndim < 3: the fab has no ghost cells in the inactive dimensions — rows / planes outside it take the neutral state and the flattening coefficient of
+// an inactive direction is 1 (FlattenShocks takes the minimum over the AMREX_SPACEDIM active directions only, hydro_system.hpp:655-669).
 __global__ void __launch_bounds__(PT_THREADS, 4) k_pre3(const qk_box *boxes, const SGeom *geom, const qk_array4 *U_t, double *scratch, int64_t T, Eos eos, bool re, int nseg,
-							    int xt, int yt)
+							    int xt, int yt, int ndim)
 {
 	const unsigned nblk = gridDim.x, lin = blockIdx.x;
 	const unsigned q8 = nblk / 8, r8 = nblk % 8, xcd = lin % 8, slot = lin / 8;
@@ -169,14 +171,16 @@ __global__ void __launch_bounds__(PT_THREADS, 4) k_pre3(const qk_box *boxes, con
 	if (zlast < zfirst) {
 		return;
 	}
-	// fab bounds (valid + 4): conversions outside feed only outputs outside valid + 1
-	const int flo[2] = {bx.lo[0] - NG, bx.lo[1] - NG}, fhi[2] = {bx.hi[0] + NG, bx.hi[1] + NG};
+	// fab bounds (valid + 4 in the active dimensions): conversions outside feed only outputs outside valid + 1
+	const int ngy = (ndim >= 2) ? NG : 0, ngz = (ndim == 3) ? NG : 0;
+	const int flo[2] = {bx.lo[0] - NG, bx.lo[1] - ngy}, fhi[2] = {bx.hi[0] + NG, bx.hi[1] + ngy};
+	const int fzlo = bx.lo[2] - ngz, fzhi = bx.hi[2] + ngz;
 
 	const bool own = t < PT_OWN;
 	const int ty = own ? t / PT_X : 0;
 	const int tx = own ? t - ty * PT_X : 0;
 	const int oi = x0 + tx, oj = y0 + ty;
-	const bool ownIn = own && oi <= fhi[0] && oj <= fhi[1];
+	const bool ownIn = own && oi <= fhi[0] && oj >= flo[1] && oj <= fhi[1];
 	const bool ownOut = own && oi <= bx.hi[0] + 1 && oj <= bx.hi[1] + 1;
 	// the halo cell of this thread (threads PT_THREADS - PT_HALO .. PT_THREADS - 1)
 	const int h = t - (PT_THREADS - PT_HALO);
@@ -210,7 +214,8 @@ __global__ void __launch_bounds__(PT_THREADS, 4) k_pre3(const qk_box *boxes, con
 
 	for (int k = zfirst - 3; k <= zlast + 3; ++k, uo += U.ks, uh += U.ks) {
 		const bool inPlane = (k >= zfirst) && (k <= zlast); // uniform: this plane's x / y results are somebody's output
-		const PlaneCell c = planeCell(eos, re, ownIn ? planeLoad(U, uo) : neutral);
+		const bool kIn = (k >= fzlo) && (k <= fzhi);	      // uniform: the plane exists in the fab
+		const PlaneCell c = planeCell(eos, re, (ownIn && kIn) ? planeLoad(U, uo) : neutral);
 #pragma unroll
 		for (int m = 0; m < 4; ++m) {
 			Pz[m] = Pz[m + 1];
@@ -237,7 +242,7 @@ __global__ void __launch_bounds__(PT_THREADS, 4) k_pre3(const qk_box *boxes, con
 				s_vy[ty + 2][tx] = c.vy;
 			}
 			if (h >= 0) {
-				hc = planeCell(eos, re, haloIn ? planeLoad(U, uh) : neutral);
+				hc = planeCell(eos, re, (haloIn && kIn) ? planeLoad(U, uh) : neutral);
 				s_P[hy + 3][hx + 3] = hc.P;
 				if (hy >= 0 && hy < PT_Y && hx >= -2 && hx < PT_X + 2) {
 					s_vx[hy][hx + 2] = hc.vx;
@@ -250,14 +255,16 @@ __global__ void __launch_bounds__(PT_THREADS, 4) k_pre3(const qk_box *boxes, con
 			if (own) {
 				const double *Pr = &s_P[ty + 3][tx + 3];
 				s_cx[ty][tx + 1] = flatteningChiKS(Pr[-2], Pr[-1], Pr[1], Pr[2], KS, s_vx[ty][tx + 1], s_vx[ty][tx + 3]);
-				s_cy[ty + 1][tx] = flatteningChiKS(s_P[ty + 1][tx + 3], s_P[ty + 2][tx + 3], s_P[ty + 4][tx + 3], s_P[ty + 5][tx + 3], KS, s_vy[ty + 1][tx], s_vy[ty + 3][tx]);
+				s_cy[ty + 1][tx] = (ndim >= 2) ? flatteningChiKS(s_P[ty + 1][tx + 3], s_P[ty + 2][tx + 3], s_P[ty + 4][tx + 3], s_P[ty + 5][tx + 3], KS, s_vy[ty + 1][tx], s_vy[ty + 3][tx])
+							     : 1.0;
 			}
 			if (rimX) {
 				const double *Pr = &s_P[ry + 3][rx + 3];
 				s_cx[ry][rx + 1] = flatteningChiKS(Pr[-2], Pr[-1], Pr[1], Pr[2], flatteningKS(eos, hc.rho, hc.P), s_vx[ry][rx + 1], s_vx[ry][rx + 3]);
 			} else if (rimY) {
-				s_cy[ry + 1][rx] = flatteningChiKS(s_P[ry + 1][rx + 3], s_P[ry + 2][rx + 3], s_P[ry + 4][rx + 3], s_P[ry + 5][rx + 3], flatteningKS(eos, hc.rho, hc.P),
-								   s_vy[ry + 1][rx], s_vy[ry + 3][rx]);
+				s_cy[ry + 1][rx] = (ndim >= 2) ? flatteningChiKS(s_P[ry + 1][rx + 3], s_P[ry + 2][rx + 3], s_P[ry + 4][rx + 3], s_P[ry + 5][rx + 3],
+										 flatteningKS(eos, hc.rho, hc.P), s_vy[ry + 1][rx], s_vy[ry + 3][rx])
+							       : 1.0;
 			}
 			__syncthreads();
 			if (own) {
@@ -272,7 +279,7 @@ __global__ void __launch_bounds__(PT_THREADS, 4) k_pre3(const qk_box *boxes, con
 		// z direction: chi_z of plane k-2 from P(k-4, k-3, k-1, k), rho c_s^2 (k-2), v_z(k-3), v_z(k-1)
 		chz[0] = chz[1];
 		chz[1] = chz[2];
-		chz[2] = flatteningChiKS(Pz[0], Pz[1], Pz[3], Pz[4], ksz[0], vzw[1], vzw[3]);
+		chz[2] = (ndim == 3) ? flatteningChiKS(Pz[0], Pz[1], Pz[3], Pz[4], ksz[0], vzw[1], vzw[3]) : 1.0;
 		const int ko = k - 3;
 		if (ko >= zfirst && ko <= zlast && ownOut) {
 			const int64_t cc = (oi - g.glo[0]) + static_cast<int64_t>(g.n[0]) * ((oj - g.glo[1]) + static_cast<int64_t>(g.n[1]) * (ko - g.glo[2]));
@@ -467,7 +474,9 @@ QK_DEV void updateCellFrom(SweepArgs const &a, Eos const &eos, EpiConst const &e
 constexpr int XB = 256;	 // threads per workgroup
 constexpr int XOUT = 250; // cells updated per workgroup (3 halo cells on each side)
 
-template <int ORDER, int STAGE, int NS, bool CARRY> __global__ void __launch_bounds__(XB) k_sweep_x(SweepArgs a, Eos eos)
+// NDIM: AMREX_SPACEDIM of the build.  In a 1-D build the x sweep is the only one and carries the epilogue (P dV, PredictStep, flags, limits, dual
+// energy, CFL maxima) the z sweep carries in 3-D; in 2-D the y sweep does (k_sweep_march<1, ..., LAST, TWOD>).
+template <int ORDER, int STAGE, int NS, bool CARRY, int NDIM = 3> __global__ void __launch_bounds__(XB) k_sweep_x(SweepArgs a, Eos eos)
 {
 	constexpr int NV = NVAR + NS; // hydro variables + passive scalars
 	constexpr int RHS_DIVV = S_RHS + NV;
@@ -544,7 +553,7 @@ template <int ORDER, int STAGE, int NS, bool CARRY> __global__ void __launch_bou
 	double F[NV], vf;
 	{
 		Wave wv;
-		faceFlux<0, QK_RIEMANN_HLLC>(eos, a.reconstruct_eint, 3, qL, am, du, dvl, dV, dwl, dW, a.K_visc, F, vf, NS > 0 ? &wv : nullptr);
+		faceFlux<0, QK_RIEMANN_HLLC>(eos, a.reconstruct_eint, NDIM, qL, am, du, dvl, dV, dwl, dW, a.K_visc, F, vf, NS > 0 ? &wv : nullptr);
 #pragma unroll
 		for (int n = NVAR; n < NV; ++n) { // hydro_system.hpp:1062-1076, HLLC.hpp:126-136
 			F[n] = scalarFlux<QK_RIEMANN_HLLC>(wv, qL[n], am[n]);
@@ -596,7 +605,47 @@ template <int ORDER, int STAGE, int NS, bool CARRY> __global__ void __launch_bou
 	__syncthreads();
 
 	const bool isCell = validRow && (i >= bx.lo[0]) && (i <= bx.hi[0]) && (t >= 3) && (t < 3 + XOUT);
-	if (isCell) {
+	if constexpr (NDIM == 1) {
+		// the only sweep of a 1-D build: finish the cell here (same per-cell function as the z sweep of a 3-D build)
+		double sig0 = 0., sig1 = 0.;
+		if (isCell) {
+			double rhs[NV], r1[NV + 1];
+#pragma unroll
+			for (int n = 0; n < NV; ++n) {
+				rhs[n] = a.inv_dx * (F[n] - s_q[n][tp1]); // hydro_system.hpp:469
+				r1[n] = 0.;
+			}
+			r1[NV] = 0.;
+			const double div_v = (s_d[2][tp1] - vf) / a.dx; // :803
+			RA4 Uold(a.U_old[b]);
+			const int64_t co = Uold.idx(i, j, k);
+			double Uo[NV];
+#pragma unroll
+			for (int n = 0; n < NV; ++n) {
+				Uo[n] = Uold.p[co + Uold.ns * n];
+			}
+			if (CARRY && STAGE == 2) {
+				RA4 R1(a.rhs1[b]);
+				const int64_t c1 = R1.idx(i, j, k);
+#pragma unroll
+				for (int n = 0; n < NV + 1; ++n) {
+					r1[n] = R1.p[c1 + R1.ns * n];
+				}
+			}
+			const EpiConst ec = epiConst(eos);
+			updateCellFrom<NS, CARRY ? STAGE : 0>(a, eos, ec, b, i, j, k, Uo, rhs, div_v, r1, sig0, sig1);
+		}
+		if (a.max_signal != nullptr) { // every lane takes part in the wave reduction (no early exit above for lanes of a live workgroup)
+			for (int off = 32; off > 0; off >>= 1) {
+				sig0 = smax(sig0, __shfl_xor(sig0, off));
+				sig1 = smax(sig1, __shfl_xor(sig1, off));
+			}
+			if ((threadIdx.x & 63) == 0) {
+				atomicMaxNonNeg(&a.max_signal[0], sig0);
+				atomicMaxNonNeg(&a.max_signal[1], sig1);
+			}
+		}
+	} else if (isCell) {
 		double *R = a.scratch + g.off + c;
 #pragma unroll
 		for (int n = 0; n < NV; ++n) {
@@ -613,8 +662,11 @@ template <int ORDER, int STAGE, int NS, bool CARRY> __global__ void __launch_bou
 #define QK_MARCH_BY 4
 #endif
 constexpr int MARCH_BY = QK_MARCH_BY; // rows of the other transverse axis per workgroup (64 x MARCH_BY threads)
-template <int DIR, int ORDER, int STAGE, bool LAST, int NS, bool CARRY> __global__ void __launch_bounds__(64 * MARCH_BY) k_sweep_march(SweepArgs a, Eos eos)
+// TWOD: the y sweep of an AMREX_SPACEDIM == 2 build — the X2 view is the index swap of ArrayView_2d.hpp (view-j = x, view-k = z), and it is the last sweep
+template <int DIR, int ORDER, int STAGE, bool LAST, int NS, bool CARRY, bool TWOD = false>
+__global__ void __launch_bounds__(64 * MARCH_BY) k_sweep_march(SweepArgs a, Eos eos)
 {
+	static_assert(!TWOD || (DIR == 1 && LAST), "the 2-D build has one marching sweep: y, carrying the epilogue");
 	constexpr int NV = NVAR + NS; // hydro variables + passive scalars
 	constexpr int RHS_DIVV = S_RHS + NV;
 	static_assert(DIR == 1 || DIR == 2, "marching sweeps are the strided directions");
@@ -655,7 +707,7 @@ template <int DIR, int ORDER, int STAGE, bool LAST, int NS, bool CARRY> __global
 	int64_t u = Uin.idx(pos[0], pos[1], pos[2]);
 	const int64_t ums = (DIR == 1) ? Uin.js : Uin.ks;
 
-	constexpr int AV = Axes<DIR>::v, AW = Axes<DIR>::w;
+	constexpr int AV = Axes<DIR, TWOD>::v, AW = Axes<DIR, TWOD>::w;
 	double q[5][NV];
 	double apPrev[NV], Fprev[NV];
 	double vfPrev = 0., dVprev = 0., dWprev = 0.;
@@ -776,7 +828,8 @@ template <int DIR, int ORDER, int STAGE, bool LAST, int NS, bool CARRY> __global
 			double F[NV], vf;
 			{
 				Wave wv;
-				faceFlux<DIR, QK_RIEMANN_HLLC>(eos, a.reconstruct_eint, 3, apPrev, am, du, dVprev, dV, dWprev, dW, a.K_visc, F, vf, NS > 0 ? &wv : nullptr);
+				faceFlux<DIR, QK_RIEMANN_HLLC, TWOD>(eos, a.reconstruct_eint, TWOD ? 2 : 3, apPrev, am, du, dVprev, dV, dWprev, dW, a.K_visc, F, vf,
+								     NS > 0 ? &wv : nullptr);
 #pragma unroll
 				for (int n = NVAR; n < NV; ++n) {
 					F[n] = scalarFlux<QK_RIEMANN_HLLC>(wv, apPrev[n], am[n]);
@@ -912,7 +965,34 @@ template <int ORDER, int STAGE, int NS, bool CARRY> void launchSweeps(qk_level *
 		const int64_t slab = static_cast<int64_t>(lev->maxlen[0] + 2 * NG) * lev->maxlen[1];
 		const dim3 grid(static_cast<unsigned>((slab + XOUT - 1) / XOUT), static_cast<unsigned>(lev->maxlen[2]), static_cast<unsigned>(lev->nboxes));
 		ProfScope ps(lev->ctx, s, "k_sweep_x");
-		hipLaunchKernelGGL((k_sweep_x<ORDER, STAGE, NS, CARRY>), grid, dim3(XB), 0, s, ax, eos);
+		if (lev->ndim == 3) {
+			hipLaunchKernelGGL((k_sweep_x<ORDER, STAGE, NS, CARRY, 3>), grid, dim3(XB), 0, s, ax, eos);
+		} else if constexpr (!CARRY) { // (1-D / 2-D builds: the reference's form of the RK2 average only)
+			if (lev->ndim == 2) {
+				hipLaunchKernelGGL((k_sweep_x<ORDER, STAGE, NS, false, 2>), grid, dim3(XB), 0, s, ax, eos);
+			} else {
+				hipLaunchKernelGGL((k_sweep_x<ORDER, STAGE, NS, false, 1>), grid, dim3(XB), 0, s, ax, eos); // + epilogue: the stage is complete
+			}
+		}
+	}
+	if (lev->ndim == 1) {
+		return;
+	}
+	if (lev->ndim == 2) { // Y of a 2-D build (index-swap view) + epilogue
+		if constexpr (!CARRY) {
+			SweepArgs ay = a;
+			ay.same_old = (args->U_in == args->U_old);
+			ay.halfFlux = args->halfFlux[1];
+			ay.halfVel = args->halfVel[1];
+			ay.rk2Flux = args->fluxRk2[1];
+			ay.inv_dx = 1.0 / args->dx[1];
+			ay.dx = args->dx[1];
+			ay.nseg = marchSegments(lev, 1, 2);
+			const dim3 grid((lev->maxlen[0] + 63) / 64, (lev->maxlen[2] + MARCH_BY - 1) / MARCH_BY, lev->nboxes * ay.nseg);
+			ProfScope ps(lev->ctx, s, "k_sweep_y");
+			hipLaunchKernelGGL((k_sweep_march<1, ORDER, STAGE, true, NS, false, true>), grid, dim3(64, MARCH_BY), 0, s, ay, eos);
+		}
+		return;
 	}
 	// Y
 	{
@@ -985,8 +1065,11 @@ int qk_hydro_stage_fused(qk_level *lev, qk_stream stream, const qk_hydro_traits 
 	if (t->nscalars > QK_FUSED_MAX_SCALARS || t->nmscalars != 0) {
 		return setError(ctx, QK_ERR_UNSUPPORTED, "qk_hydro_stage_fused: up to 3 passive scalars, no mass scalars (use the reference-shaped operators)");
 	}
-	if (t->ndim != 3) {
-		return setError(ctx, QK_ERR_UNSUPPORTED, "qk_hydro_stage_fused: 3-D only (use the reference-shaped operators in 1-D)");
+	if (t->ndim != lev->ndim) {
+		return setError(ctx, QK_ERR_INVALID, "qk_hydro_stage_fused: traits.ndim differs from the level's dimension");
+	}
+	if (t->ndim != 3 && args->rk2_carry_rhs != 0) {
+		return setError(ctx, QK_ERR_UNSUPPORTED, "qk_hydro_stage_fused: rk2_carry_rhs is instantiated for 3-D builds");
 	}
 	QK_REQUIRE(ctx, args->K_visc >= 0.0, "qk_hydro_stage_fused: negative artificial-viscosity coefficient");
 	QK_REQUIRE(ctx, args->stage == 1 || args->stage == 2, "qk_hydro_stage_fused: stage must be 1 or 2");
@@ -995,7 +1078,7 @@ int qk_hydro_stage_fused(qk_level *lev, qk_stream stream, const qk_hydro_traits 
 		   "qk_hydro_stage_fused: NULL array");
 	QK_REQUIRE(ctx, args->rk2_carry_rhs == 0 || (args->rhs1 != nullptr && args->store_flux_rk2 == 0),
 		   "qk_hydro_stage_fused: rk2_carry_rhs needs rhs1 and excludes store_flux_rk2 (flux_rk2 is never formed in that mode)");
-	for (int d = 0; d < 3; ++d) {
+	for (int d = 0; d < t->ndim; ++d) {
 		QK_REQUIRE(ctx, args->rk2_carry_rhs != 0 || (args->halfFlux[d] && args->halfVel[d]), "qk_hydro_stage_fused: NULL halfFlux/halfVel");
 		QK_REQUIRE(ctx, args->store_flux_rk2 == 0 || args->stage != 2 || (args->fluxRk2[d] != nullptr && args->fluxRk2[d] != args->halfFlux[d]),
 			   "qk_hydro_stage_fused: store_flux_rk2 needs fluxRk2[d], distinct from halfFlux[d]");
@@ -1025,7 +1108,7 @@ int qk_hydro_stage_fused(qk_level *lev, qk_stream stream, const qk_hydro_traits 
 			nseg = std::max(1, std::atoi(e));
 		}
 		const dim3 grid(static_cast<unsigned>(xt) * yt * lev->nboxes * nseg);
-		hipLaunchKernelGGL(k_pre3, grid, dim3(PT_THREADS), 0, s, boxes, geom, args->U_in, scratch, T, eos, re, nseg, xt, yt);
+		hipLaunchKernelGGL(k_pre3, grid, dim3(PT_THREADS), 0, s, boxes, geom, args->U_in, scratch, T, eos, re, nseg, xt, yt, t->ndim);
 	}
 
 	// 4. sweeps

@@ -2054,7 +2054,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_signal_), 2 * sizeof(double)));
 		QK_HOST_HIP(hipMemset(d_error_, 0, sizeof(int)));
 		auto t = qkhost::traits<problem_t>();
-		if (AMREX_SPACEDIM == 3) {
+		if constexpr (HydroSystem<problem_t>::nscalars_ <= 3 && Physics_Traits<problem_t>::numMassScalars == 0 && Physics_Traits<problem_t>::is_hydro_enabled) {
 			scratchBytes_ = qk_hydro_stage_scratch_bytes(qkhost::Runtime::get().lev, &t);
 			QK_HOST_HIP(hipMalloc(&scratch_, static_cast<size_t>(scratchBytes_)));
 		}
@@ -2202,12 +2202,13 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	// the fused stage carries up to 3 passive scalars; mass scalars take the reference-shaped operators
 	[[nodiscard]] static constexpr auto fusedEligible() -> bool
 	{
-		return AMREX_SPACEDIM == 3 && HydroSystem<problem_t>::nscalars_ <= 3 && Physics_Traits<problem_t>::numMassScalars == 0;
+		// (any AMREX_SPACEDIM since round 3: in a 1-D build the x sweep carries the epilogue, in a 2-D build the y sweep)
+		return HydroSystem<problem_t>::nscalars_ <= 3 && Physics_Traits<problem_t>::numMassScalars == 0;
 	}
 	[[nodiscard]] auto isFinalStage(int stageNo) const -> bool { return (stageNo == 2) || (integratorOrder_ == 1); }
 	// the carried-right-hand-side form of the RK2 average (qk_hydro_stage_args::rk2_carry_rhs; deck: hydro.rk2_carry_rhs = 1, default 0): only
 	// where nothing consumes flux_rk2 (no flux registers) and the integrator has two stages
-	[[nodiscard]] auto carryActive() const -> bool { return rk2CarryRhs_ != 0 && integratorOrder_ == 2 && !storeFluxRk2_; }
+	[[nodiscard]] auto carryActive() const -> bool { return AMREX_SPACEDIM == 3 && rk2CarryRhs_ != 0 && integratorOrder_ == 2 && !storeFluxRk2_; }
 
 	// Boxes of this rank in two groups for the overlapped ghost fill: [0] early — every ghost cell is filled on this GPU —, [1] late — waits
 	// for strips from other ranks (qk_ghost_plan_box_is_remote).  Each group is a sub-level whose descriptor tables alias the level's arrays.
@@ -2286,9 +2287,9 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		a.U_old = sel(qkhost::tab(U_old));
 		a.U_out = sel(qkhost::tab(U_out));
 		for (int d = 0; d < 3; ++d) {
-			a.halfFlux[d] = sel(qkhost::tab(halfFlux_[d]));
-			a.halfVel[d] = sel(qkhost::tab(halfVel_[d]));
-			a.dx[d] = geom[0].dx[d];
+			a.halfFlux[d] = (d < AMREX_SPACEDIM) ? sel(qkhost::tab(halfFlux_[d])) : nullptr;
+			a.halfVel[d] = (d < AMREX_SPACEDIM) ? sel(qkhost::tab(halfVel_[d])) : nullptr;
+			a.dx[d] = (d < AMREX_SPACEDIM) ? geom[0].dx[d] : 1.0;
 		}
 		a.redoFlag = group < 0 ? qkhost::itab(redoFlag_) : groupTable(group, qkhost::itab(redoFlag_));
 		a.d_redo_count = d_count_;
@@ -2307,7 +2308,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		a.K_visc = artificialViscosityK_;
 		a.store_flux_rk2 = storeFluxRk2_ ? 1 : 0;
 		for (int d = 0; d < 3; ++d) {
-			a.fluxRk2[d] = storeFluxRk2_ ? sel(qkhost::tab(rk2flux_[d])) : nullptr;
+			a.fluxRk2[d] = (storeFluxRk2_ && d < AMREX_SPACEDIM) ? sel(qkhost::tab(rk2flux_[d])) : nullptr;
 		}
 		if (carryActive()) {
 			if (rhs1_.size() == 0) {

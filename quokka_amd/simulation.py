@@ -281,7 +281,8 @@ class HydroSimulation:
         self.artificialViscosityK_ = 0.0
         self.min_overlap_cells = 8 * 128 ** 3
         # the fused stage is instantiated for 0..3 passive scalars; mass scalars (consistent multi-fluid advection) take the operator path
-        self.use_fused = use_fused and geom.ndim == 3 and traits.nscalars <= 3 and traits.nmscalars == 0
+        # (1-D / 2-D builds: the x sweep resp. the y sweep carries the epilogue; the carried-rhs form of the RK2 average is a 3-D instantiation)
+        self.use_fused = use_fused and traits.nscalars <= 3 and traits.nmscalars == 0
         # state
         lev = self.lev
         self.state_old_cc_ = MultiFab(lev, self.ncomp_cc, NGHOST_CC, fill=0.0)
@@ -499,7 +500,8 @@ class HydroSimulation:
     def _carry_active(self) -> bool:
         """the carried-right-hand-side form of the RK2 average (qk_hydro_stage_args::rk2_carry_rhs; `rk2_carry_rhs` attribute, default off):
         only where nothing consumes flux_rk2 (no flux registers) and the integrator has two stages"""
-        return bool(getattr(self, "rk2_carry_rhs", False)) and self.integratorOrder_ == 2 and not getattr(self, "store_flux_rk2", False)
+        return (bool(getattr(self, "rk2_carry_rhs", False)) and self.integratorOrder_ == 2 and not getattr(self, "store_flux_rk2", False)
+                and self.geom.ndim == 3)
 
     def rhs1(self):
         """div F1 and div v1 per cell, written by stage 1 and read by stage 2 in the carried-rhs mode"""
@@ -521,10 +523,11 @@ class HydroSimulation:
         tab = (lambda mf: mf.ptr) if idx is None else (lambda mf: mf.subset_ptr(idx))
         a = capi.StageArgs()
         a.U_in, a.U_old, a.U_out = tab(U_in), tab(U_old), tab(U_out)
+        nd = self.geom.ndim
         for d in range(3):
-            a.halfFlux[d] = tab(self.halfFlux[d])
-            a.halfVel[d] = tab(self.halfVel[d])
-            a.dx[d] = self.geom.dx[d]
+            a.halfFlux[d] = tab(self.halfFlux[d]) if d < nd else None
+            a.halfVel[d] = tab(self.halfVel[d]) if d < nd else None
+            a.dx[d] = self.geom.dx[d] if d < nd else 1.0
         a.redoFlag = tab(self.redoFlag)
         a.d_redo_count = C.c_void_p(self.dev_counters.data_ptr())
         a.d_error_flag = C.c_void_p(self.dev_error.data_ptr())
@@ -536,7 +539,7 @@ class HydroSimulation:
         a.densityFloor, a.tempFloor, a.use_dual_energy, a.K_visc = self.densityFloor_, self.tempFloor_, self.useDualEnergy_, float(self.artificialViscosityK_)
         a.store_flux_rk2 = int(getattr(self, "store_flux_rk2", False))
         if a.store_flux_rk2:
-            for d in range(3):
+            for d in range(nd):
                 a.fluxRk2[d] = tab(self.fluxRk2()[d])
         if self._carry_active():
             a.rk2_carry_rhs = 1
@@ -711,7 +714,7 @@ def sedov_problem(ctx: Context, n: int, max_grid_size: int = 128, rank=0, nranks
     return sim
 
 
-def blast2d_problem(ctx: Context, n: int = 64, ndim: int = 2, nz: int = 4, max_grid_size=None) -> HydroSimulation:
+def blast2d_problem(ctx: Context, n: int = 64, ndim: int = 2, nz: int = 4, max_grid_size=None, use_fused=False) -> HydroSimulation:
     """reference src/problems/HydroBlast2D/test_hydro2d_blast.cpp + tests/blast2d.in: a circular blast (P = 10 inside R < 0.1, 0.1 outside) in a
     reflecting unit box; ndim = 2: the AMREX_SPACEDIM == 2 build (X2 view = index swap, ArrayView_2d.hpp); ndim = 3: the same problem uniform
     in z on nz cells (reference-shaped operators: the comparison of the two builds is the point)."""
@@ -722,7 +725,7 @@ def blast2d_problem(ctx: Context, n: int = 64, ndim: int = 2, nz: int = 4, max_g
         lo = [(capi.BC_REFLECT_ODD if c == 1 + d else capi.BC_REFLECT_EVEN) if d < ndim else capi.BC_INT_DIR for d in range(3)]
         bcs.append((lo, list(lo)))
     mgs = list(max_grid_size) if max_grid_size is not None else n_cell
-    sim = HydroSimulation(ctx, geom, capi.traits(5.0 / 3.0, True, ndim), bcs, mgs, use_fused=False)
+    sim = HydroSimulation(ctx, geom, capi.traits(5.0 / 3.0, True, ndim), bcs, mgs, use_fused=use_fused)
     sim.reconstructionOrder_, sim.stopTime_, sim.cflNumber_, sim.maxTimesteps_ = 3, 0.1, 0.3, 20000
     dx, dy = geom.dx[0], geom.dx[1]
     g = 5.0 / 3.0
@@ -739,7 +742,7 @@ def blast2d_problem(ctx: Context, n: int = 64, ndim: int = 2, nz: int = 4, max_g
     return sim
 
 
-def quirk_problem(ctx: Context, ndim: int = 2) -> HydroSimulation:
+def quirk_problem(ctx: Context, ndim: int = 2, use_fused=False) -> HydroSimulation:
     """reference src/problems/HydroQuirk/test_quirk.cpp + tests/quirk.in: a Mach-5ish shock on 128 x 16 (x 16) cells with a sawtooth perturbation
     of the post-shock column (odd-even decoupling test), PLM, constant states beyond both x faces, periodic in y (and z)."""
     n_cell = [128, 16, 16 if ndim == 3 else 1]
@@ -749,7 +752,7 @@ def quirk_problem(ctx: Context, ndim: int = 2) -> HydroSimulation:
     dl, ul, pl, dr, ur, pr = 3.692, -0.625, 26.85, 1.0, -5.0, 0.6
     left = [dl, dl * ul, 0.0, 0.0, pl / (g - 1.0) + 0.5 * dl * ul * ul, pl / (g - 1.0)]
     right = [dr, dr * ur, 0.0, 0.0, pr / (g - 1.0) + 0.5 * dr * ur * ur, pr / (g - 1.0)]
-    sim = HydroSimulation(ctx, geom, capi.traits(g, False, ndim), bcs, [128, 16, 16], dirichlet={(0, 0): left, (0, 1): right}, use_fused=False)
+    sim = HydroSimulation(ctx, geom, capi.traits(g, False, ndim), bcs, [128, 16, 16], dirichlet={(0, 0): left, (0, 1): right}, use_fused=use_fused)
     sim.reconstructionOrder_, sim.stopTime_, sim.cflNumber_, sim.maxTimesteps_ = 2, 0.4, 0.4, 2000
     dx = geom.dx[0]
     ishock = 0
@@ -828,7 +831,7 @@ def scalar_contact_problem(ctx: Context, nx: int = 128, nscalars: int = 1, ndim:
     return sim
 
 
-def hydro1d_problem(ctx: Context, spec: dict, nx: int, hi: float, max_timesteps: int, max_grid_size: Optional[int] = None) -> HydroSimulation:
+def hydro1d_problem(ctx: Context, spec: dict, nx: int, hi: float, max_timesteps: int, max_grid_size: Optional[int] = None, use_fused=False) -> HydroSimulation:
     """The 1-D hydro test family of the reference with tabulated solutions (HydroLeblanc, HydroVacuum, HydroShuOsher, HydroHighMach;
     src/problems/Hydro*/): gamma-law gas, P / (gamma - 1) energies, constant states beyond both x faces or a periodic box.
     `spec` as oracle/problems.hpp::Hydro1DSpec (tests/hydro1d_cases.py holds the four cases with their reference lines)."""
@@ -845,7 +848,7 @@ def hydro1d_problem(ctx: Context, spec: dict, nx: int, hi: float, max_timesteps:
         bcs[0] = ([capi.BC_EXT_DIR, 0, 0], [capi.BC_EXT_DIR, 0, 0])
         dirichlet = {(0, 0): cons(*spec["left"]), (0, 1): cons(*spec["right"])}
     geom = Geometry(1, [nx], [0.0, 0.0, 0.0], [hi, 1.0, 1.0], [0 if dirichlet else 1, 1, 1])
-    sim = HydroSimulation(ctx, geom, capi.traits(g, True, 1), bcs, [max_grid_size or nx, 1, 1], dirichlet=dirichlet, use_fused=False)
+    sim = HydroSimulation(ctx, geom, capi.traits(g, True, 1), bcs, [max_grid_size or nx, 1, 1], dirichlet=dirichlet, use_fused=use_fused)
     sim.cflNumber_, sim.stopTime_, sim.maxTimesteps_ = spec["cfl"], spec["stop_time"], max_timesteps
     if spec.get("max_dt", -1.0) > 0:
         sim.maxDt_ = spec["max_dt"]

@@ -53,12 +53,16 @@ def test_quirk_2d_meets_the_reference_criterion(oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("order", [3, 2, 1])
-def test_blast2d_steps_bit_exact_on_gpu(ctx, oracle, order):
+def test_blast2d_steps_bit_exact_on_gpu(ctx, oracle, order, fused):
+    """fused = True: the fused stage of a 2-D build — k_pre3 on the single plane (no z coefficient), x sweep, y sweep through the index-swap view
+    carrying the epilogue — instead of the ~40 reference-shaped launches per stage"""
     from quokka_amd.simulation import blast2d_problem
     N, nsteps = 64, 25
     so = oracle.sim(BLAST2D, 2, [N, N, 1], [0, 0, 0], [1.0, 1.0, 1.0], [0, 0, 0], max_grid_size=[32, 32, 1], reconstruction_order=order)
-    sg = blast2d_problem(ctx, N, 2, max_grid_size=[32, 32, 1])
+    sg = blast2d_problem(ctx, N, 2, max_grid_size=[32, 32, 1], use_fused=fused)
+    assert sg.use_fused == fused
     sg.reconstructionOrder_ = order
     assert so.nboxes == sg.lev.nboxes == 4
     for b in range(4):
@@ -79,10 +83,11 @@ def test_blast2d_steps_bit_exact_on_gpu(ctx, oracle, order):
 
 
 @pytest.mark.gpu
-def test_quirk_2d_on_gpu_matches_oracle_and_criterion(ctx, oracle):
+@pytest.mark.parametrize("fused", [False, True])
+def test_quirk_2d_on_gpu_matches_oracle_and_criterion(ctx, oracle, fused):
     from quokka_amd.simulation import quirk_problem
     so = oracle.sim(QUIRK, 2, [128, 16, 1], [0, 0, 0], [1.0, 0.125, 1.0], [0, 1, 1], max_grid_size=[128, 16, 1])
-    sg = quirk_problem(ctx, 2)
+    sg = quirk_problem(ctx, 2, use_fused=fused)
     assert np.array_equal(so.valid(0), sg.state_new_cc_.valid(0).cpu().numpy())
     dmax = 0.0
     while sg.tNew_ < 0.4 and sg.istep < 2000:

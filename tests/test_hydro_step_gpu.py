@@ -116,10 +116,13 @@ def test_fofc_and_retries_match_oracle(ctx, oracle):
     assert np.array_equal(gather_oracle(so, N), gather_gpu(sg, N))
 
 
-def test_sod_shocktube_full_run_matches_golden(ctx):
-    """BASELINE config 1 (1-D Sod, 1024 cells, single box, Dirichlet x-boundaries) run to t = 0.4 with the
-    reference-shaped operators; compared with the committed oracle state and the exact solution."""
-    sim = sod_problem(ctx, 1024)
+@pytest.mark.parametrize("fused", [False, True])
+def test_sod_shocktube_full_run_matches_golden(ctx, fused):
+    """BASELINE config 1 (1-D Sod, 1024 cells, single box, Dirichlet x-boundaries) run to t = 0.4 with the reference-shaped operators
+    (fused = False) and with the fused stage of a 1-D build (k_pre3 + the x sweep carrying the epilogue: 2 launches per stage instead of
+    ~30); compared with the committed oracle state and the exact solution."""
+    sim = sod_problem(ctx, 1024, use_fused=fused)
+    assert sim.use_fused == fused
     assert sim.evolve()
     assert abs(sim.tNew_ - 0.4) < 1e-12
     sol = sim.gather_valid_local()[0][:, 0, 0, :]
@@ -245,7 +248,7 @@ def test_sum_boundary_is_the_transpose_of_fill_boundary(ctx, periodic):
 
 @pytest.mark.parametrize("ndim,nscalars,nsteps", [(1, 1, 300), (3, 2, 12), (3, 1, 6), (3, 3, 6)])
 def test_passive_scalars_match_oracle(ctx, oracle, ndim, nscalars, nsteps):
-    """Passive scalars through the reference-shaped operators (hydro_system.hpp:340-343 cons->prim, HLLC.hpp:126-136 flux,
+    """Passive scalars through the fused stage (hydro_system.hpp:340-343 cons->prim, HLLC.hpp:126-136 flux,
     hydro_system.hpp:1062-1076 viscosity term, :713-722 density floor): the advected contact of the PassiveScalar problem,
     several boxes, every component bit for bit; the scalar's integral is conserved to round-off."""
     from oracle.pyoracle import SCALARS
@@ -254,8 +257,8 @@ def test_passive_scalars_match_oracle(ctx, oracle, ndim, nscalars, nsteps):
     mgs = [64, 1, 1] if ndim == 1 else [16, 16, 16]
     so = oracle.sim(SCALARS, ndim, n_cell, [0, 0, 0], [1.0, 1.0, 1.0], [1, 1, 1], max_grid_size=mgs, nscalars=nscalars)
     sg = scalar_contact_problem(ctx, n_cell[0], nscalars=nscalars, ndim=ndim, max_grid_size=mgs)
-    # 3-D: the fused stage (instantiated for up to 3 passive scalars); 1-D: the reference-shaped operators
-    assert sg.use_fused == (ndim == 3) and sg.state_new_cc_.ncomp == 6 + nscalars
+    # the fused stage (instantiated for up to 3 passive scalars): 3-D and, since round 3, the 1-D build (x sweep + epilogue)
+    assert sg.use_fused and sg.state_new_cc_.ncomp == 6 + nscalars
     sg_ops = None
     if sg.use_fused:  # the same run through the operator path: must agree with the fused stage in every bit
         sg_ops = scalar_contact_problem(ctx, n_cell[0], nscalars=nscalars, ndim=ndim, max_grid_size=mgs)
@@ -295,7 +298,8 @@ def test_tabulated_1d_known_answers_on_the_gpu_path(ctx, oracle, name):
     from quokka_amd.simulation import hydro1d_problem
     c = H.CASES[name]
     so = H.oracle_sim(oracle, name)
-    sg = hydro1d_problem(ctx, c["spec"], c["nx"], c["hi"], c["max_timesteps"], c.get("mgs"))
+    sg = hydro1d_problem(ctx, c["spec"], c["nx"], c["hi"], c["max_timesteps"], c.get("mgs"), use_fused=True)  # the fused stage of a 1-D build
+    assert sg.use_fused
     for b in range(so.nboxes):
         assert np.allclose(sg.state_new_cc_.fab_numpy(b), so.state(b, 0), rtol=1e-14, atol=1e-300)  # the generators agree to libm accuracy
         sg.state_new_cc_.set_fab(b, so.state(b, 0))
