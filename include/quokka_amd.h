@@ -225,6 +225,14 @@ typedef struct qk_hydro_stage_args {
 				  *    halfVel are neither written nor read (they may be NULL), so flux_rk2 does not exist: excludes store_flux_rk2,
 				  *    and a stage-2 first-order flux correction must recompute F1 from U_old with qk_hydro_ComputeFluxes */
 	qk_array4 *rhs1;	 /* rk2_carry_rhs: cell-centred, no ghost cells, 6 + nscalars + 1 components; must survive from stage 1 to stage 2 */
+	int fofc_pass;		 /* 0: the stage proper.  1: the FIRST-ORDER FLUX CORRECTION of a stage whose first pass counted flagged cells (reference
+				  * src/QuokkaSimulation.hpp:1144-1184, :1232-1270), as ONE more fused pass: `redoFlag` is an INPUT here (as the first pass left
+				  * it, with its one ghost cell filled: qk_FillBoundary_*_int) — a face that touches a flagged cell takes the first-order flux of
+				  * U_old (donor cell + LLF, evaluated on demand; in stage 2 it replaces flux_rk2 of that face), a flagged cell takes the
+				  * cell-centred velocity divergence in its P dV term (hydro_system.hpp:804-808); halfFlux keeps the uncorrected stage-1 fluxes;
+				  * d_redo_count (zeroed by the caller) receives the cells that are STILL invalid; no flags are written.  Bit-identical to the
+				  * reference-shaped operators (qk_hydro_ComputeFluxes(LLF) + qk_replaceFluxes + ...).  Requires K_visc == 0; in the carried-rhs
+				  * form only stage 1 (the stage-1 pass ran with rk2_carry_rhs = 1; pass rk2_carry_rhs = 0 or 1 here: rhs1 is not touched) */
 } qk_hydro_stage_args;
 
 /* One RK stage of advanceHydroAtLevel (reference src/QuokkaSimulation.hpp:1099-1198 / 1202-1287) WITHOUT the

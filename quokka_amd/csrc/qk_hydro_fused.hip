@@ -57,6 +57,7 @@ struct SweepArgs {
 	double *max_signal; // optional double[2], see qk_hydro_stage_args::d_max_signal
 	double inv_dx; // 1/dx of the sweep direction
 	double dx;
+	double dx3[3]; // (FOFC pass: the cell-centred velocity divergence of a flagged cell)
 	double dt;
 	double densityFloor, tempFloor;
 	double K_visc;
@@ -312,6 +313,52 @@ QK_DEV void flattenEdges(double chi, double mean, double &am, double &ap)
 	ap = chi * ap + (1. - chi) * mean;
 }
 
+// ---------------------------------------------------------------------------------------------- first-order flux correction, fused
+// A stage whose first pass flagged cells (PredictStep left rho <= 0 somewhere) is repeated by the SAME kernels with FOFC = true (qk_hydro_stage_args::
+// fofc_pass): a face that touches a flagged cell takes the first-order flux of the OLD state — donor-cell states + LLF, computeFOHydroFluxes
+// (QuokkaSimulation.hpp:1520-1568) evaluated on demand for just those faces — instead of the high-order one (replaceFluxes, :1324-1368; in stage 2 it
+// replaces flux_rk2 as a whole); a flagged cell takes the cell-centred velocity divergence in its P dV term (hydro_system.hpp:804-808); the pass
+// counts the cells that are still invalid and writes no flags (they are its input).  Same device functions as the reference-shaped operators: the
+// result equals the operator path bit for bit.  Not instantiated for the carried-rhs form (its stage 2 has no F1 to average at the other faces) and
+// only taken for K_visc == 0 (the viscosity term of a first-order face needs the transverse differences of the old state).
+template <int NS> QK_DEV void primOfCell(RA4 const &U, Eos const &eos, bool re, int i, int j, int k, double q[NVAR + NS])
+{
+	const int64_t u = U.idx(i, j, k);
+	double Uc[NVAR];
+#pragma unroll
+	for (int n = 0; n < NVAR; ++n) {
+		Uc[n] = U.p[u + U.ns * n];
+	}
+	consToPrim(eos, re, Uc, q);
+#pragma unroll
+	for (int n = NVAR; n < NVAR + NS; ++n) {
+		q[n] = U.p[u + U.ns * n];
+	}
+}
+template <int DIR, int NS, bool TWOD, int NDIM>
+QK_DEV void firstOrderFlux(Eos const &eos, bool re, const double qL[NVAR + NS], const double qR[NVAR + NS], double F[NVAR + NS], double &vf)
+{
+	Wave wv;
+	faceFlux<DIR, QK_RIEMANN_LLF, TWOD>(eos, re, NDIM, qL, qR, 0., 0., 0., 0., 0., 0., F, vf, NS > 0 ? &wv : nullptr);
+#pragma unroll
+	for (int n = NVAR; n < NVAR + NS; ++n) {
+		F[n] = scalarFlux<QK_RIEMANN_LLF>(wv, qL[n], qR[n]);
+	}
+}
+// hydro_system.hpp:804-808: 0.5 * sum_d (v_d(+1) - v_d(-1)) / dx_d from the conserved variables (ComputeVelocityX1..3)
+template <int NDIM> QK_DEV auto cellCentredDivV(RA4 const &U, int i, int j, int k, const double dx[3]) -> double
+{
+	auto vel = [&](int ii, int jj, int kk, int d) { return U(ii, jj, kk, MX + d) / U(ii, jj, kk, RHO); };
+	double s = (vel(i + 1, j, k, 0) - vel(i - 1, j, k, 0)) / dx[0];
+	if (NDIM >= 2) {
+		s = s + (vel(i, j + 1, k, 1) - vel(i, j - 1, k, 1)) / dx[1];
+	}
+	if (NDIM == 3) {
+		s = s + (vel(i, j, k + 1, 2) - vel(i, j, k - 1, 2)) / dx[2];
+	}
+	return 0.5 * s;
+}
+
 // epilogue of one cell (AddInternalEnergyPdV + PredictStep + EnforceLimits + SyncDualEnergy + the two CFL signal speeds), same operations
 // as the per-cell functions of qk_device.hpp (which the reference-shaped operators call) with the ~30 divisions grouped by denominator:
 // rho_old x4, rho_new x12, 2 rho_new x1, k_B and k_B_user (constants: their reciprocals are refined once per thread, EpiConst) — every further
@@ -350,12 +397,17 @@ QK_DEV auto epiEint(Eos const &eos, EpiConst const &ec, double rho, double T) ->
 // U holds the old state of the cell on entry
 // CS (carry stage): 0 the reference's flux average (rhs already holds div flux_rk2); 1: stage 1 of the carried-rhs mode, rhs / div_v are
 // stored for stage 2; 2: stage 2, `rhs1` holds what stage 1 stored and the update uses 0.5 rhs1 + 0.5 rhs
-template <int NS, int CS>
+template <int NS, int CS, bool FOFC = false, int NDIM = 3>
 QK_DEV void updateCellFrom(SweepArgs const &a, Eos const &eos, EpiConst const &ec, int b, int i, int j, int k, double U[NVAR + NS], const double rhs_sweeps[NVAR + NS],
 			   double div_v, const double rhs1[NVAR + NS + 1], double &sig0, double &sig1)
 {
 	WA4 Un(a.U_out[b]);
 	IA4 flag(a.redoFlag[b]);
+	if constexpr (FOFC) {
+		if (flag(i, j, k) != 0) { // flagged by the first pass
+			div_v = cellCentredDivV<NDIM>(RA4(a.U_old[b]), i, j, k, a.dx3);
+		}
+	}
 	double rhs[NVAR + NS];
 #pragma unroll
 	for (int n = 0; n < NVAR + NS; ++n) {
@@ -407,7 +459,9 @@ QK_DEV void updateCellFrom(SweepArgs const &a, Eos const &eos, EpiConst const &e
 		U[n] = U[n] + a.dt * rhs[n];
 	}
 	const int bad = (U[RHO] > 0.) ? 0 : 1;
-	flag(i, j, k) = bad;
+	if constexpr (!FOFC) {
+		flag(i, j, k) = bad;
+	}
 	if (bad != 0) {
 		atomicAdd(a.redo_count, 1ULL);
 	}
@@ -476,8 +530,9 @@ constexpr int XOUT = 250; // cells updated per workgroup (3 halo cells on each s
 
 // NDIM: AMREX_SPACEDIM of the build.  In a 1-D build the x sweep is the only one and carries the epilogue (P dV, PredictStep, flags, limits, dual
 // energy, CFL maxima) the z sweep carries in 3-D; in 2-D the y sweep does (k_sweep_march<1, ..., LAST, TWOD>).
-template <int ORDER, int STAGE, int NS, bool CARRY, int NDIM = 3> __global__ void __launch_bounds__(XB) k_sweep_x(SweepArgs a, Eos eos)
+template <int ORDER, int STAGE, int NS, bool CARRY, int NDIM = 3, bool FOFC = false> __global__ void __launch_bounds__(XB) k_sweep_x(SweepArgs a, Eos eos)
 {
+	static_assert(!(FOFC && CARRY), "the first-order flux correction pass exists for the reference's form of the RK2 average");
 	constexpr int NV = NVAR + NS; // hydro variables + passive scalars
 	constexpr int RHS_DIVV = S_RHS + NV;
 	__shared__ double s_q[NV][XB];  // primitives, later reused for the face fluxes
@@ -562,8 +617,36 @@ template <int ORDER, int STAGE, int NS, bool CARRY, int NDIM = 3> __global__ voi
 
 	const bool validRow = inside;
 	const bool isFace = validRow && (i >= bx.lo[0]) && (i <= bx.hi[0] + 1) && (t >= 3) && (t <= XB - 3);
+	// FOFC pass: does this face touch a cell the first pass flagged? (redoFlag carries one filled ghost cell)
+	bool firstOrder = false;
+	if constexpr (FOFC) {
+		if (isFace) {
+			CIA4 flag(a.redoFlag[b]);
+			firstOrder = (flag(i - 1, j, k) != 0) || (flag(i, j, k) != 0);
+		}
+	}
+	auto replaceByFirstOrder = [&]() { // replaceFluxes (QuokkaSimulation.hpp:1324-1368) for this face, the first-order flux evaluated on demand
+		double qLo[NV], qRo[NV];
+		if (STAGE == 1) { // the old state is the input state: its primitives are in LDS
+#pragma unroll
+			for (int n = 0; n < NV; ++n) {
+				qLo[n] = s_q[n][tm1];
+				qRo[n] = q0[n];
+			}
+		} else {
+			RA4 Uold(a.U_old[b]);
+			primOfCell<NS>(Uold, eos, a.reconstruct_eint, i - 1, j, k, qLo);
+			primOfCell<NS>(Uold, eos, a.reconstruct_eint, i, j, k, qRo);
+		}
+		firstOrderFlux<0, NS, false, NDIM>(eos, a.reconstruct_eint, qLo, qRo, F, vf);
+	};
 	if (CARRY) {
 		// carried right-hand side: neither stage touches the face arrays
+	} else if (STAGE == 1 && FOFC) {
+		// (halfFlux keeps the UNCORRECTED stage-1 flux the first pass stored: flux_rk2 is formed from it, QuokkaSimulation.hpp:1105-1108)
+		if (firstOrder) {
+			replaceByFirstOrder();
+		}
 	} else if (STAGE == 1) {
 		if (isFace) {
 			WA4 HF(a.halfFlux[b]);
@@ -586,6 +669,9 @@ template <int ORDER, int STAGE, int NS, bool CARRY, int NDIM = 3> __global__ voi
 				F[n] = 0.5 * HF.p[o + HF.ns * n] + 0.5 * F[n];
 			}
 			vf = 0.5 * HV(i, j, k) + 0.5 * vf;
+			if (FOFC && firstOrder) {
+				replaceByFirstOrder(); // flux_rk2 of this face as a whole
+			}
 			if (a.store_rk2) {
 				WA4 RF(a.rk2Flux[b]);
 				const int64_t o2 = RF.idx(i, j, k);
@@ -633,7 +719,7 @@ template <int ORDER, int STAGE, int NS, bool CARRY, int NDIM = 3> __global__ voi
 				}
 			}
 			const EpiConst ec = epiConst(eos);
-			updateCellFrom<NS, CARRY ? STAGE : 0>(a, eos, ec, b, i, j, k, Uo, rhs, div_v, r1, sig0, sig1);
+			updateCellFrom<NS, CARRY ? STAGE : 0, FOFC, 1>(a, eos, ec, b, i, j, k, Uo, rhs, div_v, r1, sig0, sig1);
 		}
 		if (a.max_signal != nullptr) { // every lane takes part in the wave reduction (no early exit above for lanes of a live workgroup)
 			for (int off = 32; off > 0; off >>= 1) {
@@ -663,9 +749,10 @@ template <int ORDER, int STAGE, int NS, bool CARRY, int NDIM = 3> __global__ voi
 #endif
 constexpr int MARCH_BY = QK_MARCH_BY; // rows of the other transverse axis per workgroup (64 x MARCH_BY threads)
 // TWOD: the y sweep of an AMREX_SPACEDIM == 2 build — the X2 view is the index swap of ArrayView_2d.hpp (view-j = x, view-k = z), and it is the last sweep
-template <int DIR, int ORDER, int STAGE, bool LAST, int NS, bool CARRY, bool TWOD = false>
+template <int DIR, int ORDER, int STAGE, bool LAST, int NS, bool CARRY, bool TWOD = false, bool FOFC = false>
 __global__ void __launch_bounds__(64 * MARCH_BY) k_sweep_march(SweepArgs a, Eos eos)
 {
+	static_assert(!(FOFC && CARRY), "the first-order flux correction pass exists for the reference's form of the RK2 average");
 	static_assert(!TWOD || (DIR == 1 && LAST), "the 2-D build has one marching sweep: y, carrying the epilogue");
 	constexpr int NV = NVAR + NS; // hydro variables + passive scalars
 	constexpr int RHS_DIVV = S_RHS + NV;
@@ -835,8 +922,36 @@ __global__ void __launch_bounds__(64 * MARCH_BY) k_sweep_march(SweepArgs a, Eos 
 					F[n] = scalarFlux<QK_RIEMANN_HLLC>(wv, apPrev[n], am[n]);
 				}
 			}
+			// FOFC pass: a face that touches a cell the first pass flagged takes the first-order flux of the old state (see firstOrderFlux)
+			bool firstOrder = false;
+			if constexpr (FOFC) {
+				CIA4 flag(a.redoFlag[b]);
+				int fm[3] = {fidx[0], fidx[1], fidx[2]};
+				fm[DIR] -= 1;
+				firstOrder = (flag(fm[0], fm[1], fm[2]) != 0) || (flag(fidx[0], fidx[1], fidx[2]) != 0);
+			}
+			auto replaceByFirstOrder = [&]() {
+				double qLo[NV], qRo[NV];
+				if (STAGE == 1) { // the old state is the input state: the window holds its primitives (cells cc - 1 and cc)
+#pragma unroll
+					for (int n = 0; n < NV; ++n) {
+						qLo[n] = q[1][n];
+						qRo[n] = q[2][n];
+					}
+				} else {
+					int fm[3] = {fidx[0], fidx[1], fidx[2]};
+					fm[DIR] -= 1;
+					primOfCell<NS>(Uold, eos, a.reconstruct_eint, fm[0], fm[1], fm[2], qLo);
+					primOfCell<NS>(Uold, eos, a.reconstruct_eint, fidx[0], fidx[1], fidx[2], qRo);
+				}
+				firstOrderFlux<DIR, NS, TWOD, TWOD ? 2 : 3>(eos, a.reconstruct_eint, qLo, qRo, F, vf);
+			};
 			if (CARRY) {
 				// carried right-hand side: no face arrays
+			} else if (STAGE == 1 && FOFC) {
+				if (firstOrder) { // (halfFlux keeps the uncorrected stage-1 flux of the first pass)
+					replaceByFirstOrder();
+				}
 			} else if (STAGE == 1) {
 				if (live) {
 					WA4 HF(a.halfFlux[b]);
@@ -854,6 +969,9 @@ __global__ void __launch_bounds__(64 * MARCH_BY) k_sweep_march(SweepArgs a, Eos 
 					F[n] = 0.5 * F1[n] + 0.5 * F[n];
 				}
 				vf = 0.5 * F1[NV] + 0.5 * vf;
+				if (FOFC && firstOrder) {
+					replaceByFirstOrder(); // flux_rk2 of this face as a whole
+				}
 				if (a.store_rk2 && live) {
 					WA4 RF(a.rk2Flux[b]);
 					const int64_t o2 = RF.idx(fidx[0], fidx[1], fidx[2]);
@@ -878,7 +996,7 @@ __global__ void __launch_bounds__(64 * MARCH_BY) k_sweep_march(SweepArgs a, Eos 
 					u[OT] = ot;
 					u[DIR] = lo + (step - 6);
 					if (live) {
-						updateCellFrom<NS, CARRY ? STAGE : 0>(a, eos, ec, b, u[0], u[1], u[2], Uo, rhs, div_v, F1, sig0, sig1);
+						updateCellFrom<NS, CARRY ? STAGE : 0, FOFC, TWOD ? 2 : 3>(a, eos, ec, b, u[0], u[1], u[2], Uo, rhs, div_v, F1, sig0, sig1);
 					}
 				} else if (live) {
 #pragma unroll
@@ -952,7 +1070,7 @@ auto buildGeom(qk_level *lev) -> int
 	return QK_OK;
 }
 
-template <int ORDER, int STAGE, int NS, bool CARRY> void launchSweeps(qk_level *lev, hipStream_t s, SweepArgs a, Eos eos, const qk_hydro_stage_args *args)
+template <int ORDER, int STAGE, int NS, bool CARRY, bool FOFC = false> void launchSweeps(qk_level *lev, hipStream_t s, SweepArgs a, Eos eos, const qk_hydro_stage_args *args)
 {
 	// X
 	{
@@ -966,12 +1084,12 @@ template <int ORDER, int STAGE, int NS, bool CARRY> void launchSweeps(qk_level *
 		const dim3 grid(static_cast<unsigned>((slab + XOUT - 1) / XOUT), static_cast<unsigned>(lev->maxlen[2]), static_cast<unsigned>(lev->nboxes));
 		ProfScope ps(lev->ctx, s, "k_sweep_x");
 		if (lev->ndim == 3) {
-			hipLaunchKernelGGL((k_sweep_x<ORDER, STAGE, NS, CARRY, 3>), grid, dim3(XB), 0, s, ax, eos);
+			hipLaunchKernelGGL((k_sweep_x<ORDER, STAGE, NS, CARRY, 3, FOFC>), grid, dim3(XB), 0, s, ax, eos);
 		} else if constexpr (!CARRY) { // (1-D / 2-D builds: the reference's form of the RK2 average only)
 			if (lev->ndim == 2) {
-				hipLaunchKernelGGL((k_sweep_x<ORDER, STAGE, NS, false, 2>), grid, dim3(XB), 0, s, ax, eos);
+				hipLaunchKernelGGL((k_sweep_x<ORDER, STAGE, NS, false, 2, FOFC>), grid, dim3(XB), 0, s, ax, eos);
 			} else {
-				hipLaunchKernelGGL((k_sweep_x<ORDER, STAGE, NS, false, 1>), grid, dim3(XB), 0, s, ax, eos); // + epilogue: the stage is complete
+				hipLaunchKernelGGL((k_sweep_x<ORDER, STAGE, NS, false, 1, FOFC>), grid, dim3(XB), 0, s, ax, eos); // + epilogue: the stage is complete
 			}
 		}
 	}
@@ -990,7 +1108,7 @@ template <int ORDER, int STAGE, int NS, bool CARRY> void launchSweeps(qk_level *
 			ay.nseg = marchSegments(lev, 1, 2);
 			const dim3 grid((lev->maxlen[0] + 63) / 64, (lev->maxlen[2] + MARCH_BY - 1) / MARCH_BY, lev->nboxes * ay.nseg);
 			ProfScope ps(lev->ctx, s, "k_sweep_y");
-			hipLaunchKernelGGL((k_sweep_march<1, ORDER, STAGE, true, NS, false, true>), grid, dim3(64, MARCH_BY), 0, s, ay, eos);
+			hipLaunchKernelGGL((k_sweep_march<1, ORDER, STAGE, true, NS, false, true, FOFC>), grid, dim3(64, MARCH_BY), 0, s, ay, eos);
 		}
 		return;
 	}
@@ -1005,7 +1123,7 @@ template <int ORDER, int STAGE, int NS, bool CARRY> void launchSweeps(qk_level *
 		ay.nseg = marchSegments(lev, 1, 2);
 		const dim3 grid((lev->maxlen[0] + 63) / 64, (lev->maxlen[2] + MARCH_BY - 1) / MARCH_BY, lev->nboxes * ay.nseg);
 		ProfScope ps(lev->ctx, s, "k_sweep_y");
-		hipLaunchKernelGGL((k_sweep_march<1, ORDER, STAGE, false, NS, CARRY>), grid, dim3(64, MARCH_BY), 0, s, ay, eos);
+		hipLaunchKernelGGL((k_sweep_march<1, ORDER, STAGE, false, NS, CARRY, false, FOFC>), grid, dim3(64, MARCH_BY), 0, s, ay, eos);
 	}
 	// Z (+ epilogue)
 	{
@@ -1019,7 +1137,7 @@ template <int ORDER, int STAGE, int NS, bool CARRY> void launchSweeps(qk_level *
 		az.nseg = marchSegments(lev, 2, 1);
 		const dim3 grid((lev->maxlen[0] + 63) / 64, (lev->maxlen[1] + MARCH_BY - 1) / MARCH_BY, lev->nboxes * az.nseg);
 		ProfScope ps(lev->ctx, s, "k_sweep_z");
-		hipLaunchKernelGGL((k_sweep_march<2, ORDER, STAGE, true, NS, CARRY>), grid, dim3(64, MARCH_BY), 0, s, az, eos);
+		hipLaunchKernelGGL((k_sweep_march<2, ORDER, STAGE, true, NS, CARRY, false, FOFC>), grid, dim3(64, MARCH_BY), 0, s, az, eos);
 	}
 }
 
@@ -1076,6 +1194,8 @@ int qk_hydro_stage_fused(qk_level *lev, qk_stream stream, const qk_hydro_traits 
 	QK_REQUIRE(ctx, args->reconstruction_order >= 1 && args->reconstruction_order <= 3, "qk_hydro_stage_fused: reconstruction_order must be 1..3");
 	QK_REQUIRE(ctx, args->U_in && args->U_old && args->U_out && args->redoFlag && args->d_redo_count && args->d_error_flag && args->scratch,
 		   "qk_hydro_stage_fused: NULL array");
+	QK_REQUIRE(ctx, args->fofc_pass == 0 || (args->K_visc == 0.0 && (args->rk2_carry_rhs == 0 || args->stage == 1)),
+		   "qk_hydro_stage_fused: the fused first-order flux correction pass needs K_visc == 0 and, in the carried-rhs form, stage 1 (use the reference-shaped operators otherwise)");
 	QK_REQUIRE(ctx, args->rk2_carry_rhs == 0 || (args->rhs1 != nullptr && args->store_flux_rk2 == 0),
 		   "qk_hydro_stage_fused: rk2_carry_rhs needs rhs1 and excludes store_flux_rk2 (flux_rk2 is never formed in that mode)");
 	for (int d = 0; d < t->ndim; ++d) {
@@ -1132,9 +1252,18 @@ int qk_hydro_stage_fused(qk_level *lev, qk_stream stream, const qk_hydro_traits 
 	a.reconstruct_eint = re;
 	a.store_rk2 = (args->store_flux_rk2 != 0);
 	a.rhs1 = args->rhs1;
+	for (int d = 0; d < 3; ++d) {
+		a.dx3[d] = args->dx[d];
+	}
 
 #define QK_LAUNCH_NS(ORDER, NS)                                                                                                                      \
-	if (args->rk2_carry_rhs != 0) {                                                                                                              \
+	if (args->fofc_pass != 0) {                                                                                                                  \
+		if (args->stage == 1) {                                                                                                              \
+			launchSweeps<ORDER, 1, NS, false, true>(lev, s, a, eos, args);                                                               \
+		} else {                                                                                                                             \
+			launchSweeps<ORDER, 2, NS, false, true>(lev, s, a, eos, args);                                                               \
+		}                                                                                                                                    \
+	} else if (args->rk2_carry_rhs != 0) {                                                                                                              \
 		if (args->stage == 1) {                                                                                                              \
 			launchSweeps<ORDER, 1, NS, true>(lev, s, a, eos, args);                                                                      \
 		} else {                                                                                                                             \

@@ -1576,6 +1576,10 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		hpp.query("use_dual_energy", useDualEnergy_);
 		hpp.query("abort_on_fofc_failure", abortOnFofcFailure_);
 		hpp.query("artificial_viscosity_coefficient", artificialViscosityK_);
+		{
+			amrex::ParmParse qpp("qk");
+			qpp.query("fused_fofc", fusedFofc_);
+		}
 		hpp.query("rk2_carry_rhs", rk2CarryRhs_); // extension of this host: the carried-rhs form of the RK2 average (<= 1e-12; quokka_amd.h)
 		amrex::ParmParse rpp("radiation"); // reference src/QuokkaSimulation.hpp:353-358
 		rpp.query("reconstruction_order", radiationReconstructionOrder_);
@@ -2131,6 +2135,22 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		return readCount();
 	}
 
+	// redoFlag.FillBoundary(geom.periodicity()) (reference src/QuokkaSimulation.hpp:1157), across ranks as the state's
+	void fillFlagGhosts()
+	{
+		for (size_t k = 0; k < flagPeers_.peer.size(); ++k) {
+			qkhost::check(qk_FillBoundary_pack_int(flagPlan_, nullptr, static_cast<int>(k), qkhost::itab(redoFlag_), static_cast<int *>(flagPeers_.send[k])),
+				      "redoFlag pack");
+		}
+		qkhost::Comm::get().exchangeBegin(flagPeers_.peer, flagPeers_.send, flagPeers_.nsend, flagPeers_.recv, flagPeers_.nrecv, sizeof(int), nullptr);
+		qkhost::check(qk_FillBoundary_local_int(flagPlan_, nullptr, qkhost::itab(redoFlag_)), "redoFlag.FillBoundary");
+		qkhost::Comm::get().exchangeEnd(nullptr);
+		for (size_t k = 0; k < flagPeers_.peer.size(); ++k) {
+			qkhost::check(qk_FillBoundary_unpack_int(flagPlan_, nullptr, static_cast<int>(k), qkhost::itab(redoFlag_), static_cast<const int *>(flagPeers_.recv[k])),
+				      "redoFlag unpack");
+		}
+	}
+
 	// one RK stage exactly as the reference (src/QuokkaSimulation.hpp:1099-1198 / 1202-1287), reference-shaped operators
 	auto stageUnfused(int stageNo, amrex::MultiFab const &U_in, amrex::MultiFab const &U_old, amrex::MultiFab &U_out, double dt) -> bool
 	{
@@ -2160,19 +2180,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		if (nbad > 0) { // first-order flux correction
 			++fofcStages_;
 			computeFOHydroFluxes(U_old);
-			// redoFlag.FillBoundary(geom.periodicity()) (reference src/QuokkaSimulation.hpp:1157), across ranks as the state's
-			for (size_t k = 0; k < flagPeers_.peer.size(); ++k) {
-				qkhost::check(qk_FillBoundary_pack_int(flagPlan_, nullptr, static_cast<int>(k), qkhost::itab(redoFlag_), static_cast<int *>(flagPeers_.send[k])),
-					      "redoFlag pack");
-			}
-			qkhost::Comm::get().exchangeBegin(flagPeers_.peer, flagPeers_.send, flagPeers_.nsend, flagPeers_.recv, flagPeers_.nrecv, sizeof(int), nullptr);
-			qkhost::check(qk_FillBoundary_local_int(flagPlan_, nullptr, qkhost::itab(redoFlag_)), "redoFlag.FillBoundary");
-			qkhost::Comm::get().exchangeEnd(nullptr);
-			for (size_t k = 0; k < flagPeers_.peer.size(); ++k) {
-				qkhost::check(qk_FillBoundary_unpack_int(flagPlan_, nullptr, static_cast<int>(k), qkhost::itab(redoFlag_),
-									 static_cast<const int *>(flagPeers_.recv[k])),
-					      "redoFlag unpack");
-			}
+			fillFlagGhosts();
 			for (int d = 0; d < AMREX_SPACEDIM; ++d) {
 				qkhost::check(qk_replaceFluxes(lev, nullptr, d, qkhost::tab((*fl)[d]), qkhost::tab(FOflux_[d]), qkhost::itab(redoFlag_), ncompHydro_),
 					      "replaceFluxes");
@@ -2278,7 +2286,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		}
 	}
 	// one fused stage over all local boxes (group < 0) or over one group of the overlapped fill
-	void fusedLaunch(int stageNo, amrex::MultiFab const &U_in, amrex::MultiFab const &U_old, amrex::MultiFab &U_out, double dt, int group = -1)
+	void fusedLaunch(int stageNo, amrex::MultiFab const &U_in, amrex::MultiFab const &U_old, amrex::MultiFab &U_out, double dt, int group = -1, bool fofc = false)
 	{
 		auto t = qkhost::traits<problem_t>();
 		auto sel = [&](qk_array4 *full) { return group < 0 ? full : groupTable(group, full); };
@@ -2317,6 +2325,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 			a.rk2_carry_rhs = 1;
 			a.rhs1 = sel(qkhost::tab(rhs1_));
 		}
+		a.fofc_pass = fofc ? 1 : 0;
 		qkhost::check(qk_hydro_stage_fused(group < 0 ? qkhost::Runtime::get().lev : groups_[group].lev, qkhost::Runtime::get().computeStream(), &t, &a),
 			      "qk_hydro_stage_fused");
 	}
@@ -2352,6 +2361,25 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		return stageUnfused(stageNo, U_in, U_old, U_out, dt);
 	}
 
+	// the fused first pass of a stage flagged cells: first-order flux correction (reference src/QuokkaSimulation.hpp:1144-1184, :1232-1270) as ONE
+	// more fused pass (qk_hydro_stage_args::fofc_pass) where it applies — no artificial viscosity, not stage 2 of the carried-rhs form, not forward
+	// Euler feeding flux registers (whose halfFlux must hold the corrected flux) —, the whole stage on the operators otherwise
+	auto correctStage(int stageNo, amrex::MultiFab const &U_in, amrex::MultiFab const &U_old, amrex::MultiFab &U_out, double dt) -> bool
+	{
+		if (stageNo == 1) {
+			stage1LeftF1_ = !carryActive();
+		}
+		bool const applies = fusedFofc_ != 0 && artificialViscosityK_ == 0.0 && !(carryActive() && stageNo == 2) && !(integratorOrder_ == 1 && storeFluxRk2_);
+		if (!applies) {
+			return redoStageUnfused(stageNo, U_in, U_old, U_out, dt);
+		}
+		++fofcStages_;
+		fillFlagGhosts();
+		fusedBegin(stageNo);
+		fusedLaunch(stageNo, U_in, U_old, U_out, dt, -1, true);
+		return !(fusedEnd(stageNo) > 0 && abortOnFofcFailure_ != 0);
+	}
+
 	auto stage(int stageNo, amrex::MultiFab const &U_in, amrex::MultiFab const &U_old, amrex::MultiFab &U_out, double dt) -> bool
 	{
 		if constexpr (fusedEligible()) {
@@ -2360,6 +2388,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 			if (fusedEnd(stageNo) == 0) {
 				return true;
 			}
+			return correctStage(stageNo, U_in, U_old, U_out, dt);
 		}
 		return redoStageUnfused(stageNo, U_in, U_old, U_out, dt);
 	}
@@ -2377,13 +2406,14 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 				if (fusedEnd(stageNo) == 0) {
 					return true;
 				}
-				return redoStageUnfused(stageNo, U_in, U_old, U_out, dt);
+				return correctStage(stageNo, U_in, U_old, U_out, dt);
 			}
 		}
 		this->fillBoundaryConditions(U_in);
 		return stage(stageNo, U_in, U_old, U_out, dt);
 	}
 	int rk2CarryRhs_ = 0;	   // deck: hydro.rk2_carry_rhs
+	int fusedFofc_ = 1;	   // deck: qk.fused_fofc (0: a flagged stage is redone on the reference-shaped operators; tests)
 	bool stage1LeftF1_ = true; // halfFlux_ holds the stage-1 fluxes of the current step
 	amrex::MultiFab rhs1_;
 };

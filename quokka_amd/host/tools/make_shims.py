@@ -15,7 +15,9 @@ QUOKKA = ["QuokkaSimulation.hpp", "simulation.hpp", "SimulationData.hpp", "physi
           "radiation/radiation_system.hpp", "radiation/radiation_dust_system.hpp", "fundamental_constants.H", "hyperbolic_system.hpp", "grid.hpp", "math/math_impl.hpp"]
 COMPAT = {"util/fextract.hpp": "compat/util_compat.hpp", "util/ArrayUtil.hpp": "compat/util_compat.hpp", "util/valarray.hpp": "compat/util_compat.hpp",
           "fmt/format.h": "compat/mini_fmt.hpp", "fmt/core.h": "compat/mini_fmt.hpp", "radiation/planck_integral.hpp": "compat/planck_integral.hpp",
-          "hydro/NSCBC_inflow.hpp": "compat/nscbc.hpp", "hydro/NSCBC_outflow.hpp": "compat/nscbc.hpp"}
+          "hydro/NSCBC_inflow.hpp": "compat/nscbc.hpp", "hydro/NSCBC_outflow.hpp": "compat/nscbc.hpp",
+          "math/ODEIntegrate.hpp": "compat/ode_integrate.hpp",
+          "eos.H": "compat/microphysics_stub.hpp", "extern_parameters.H": "compat/microphysics_stub.hpp"}
 ADVECTION = ["linear_advection/AdvectionSimulation.hpp", "linear_advection/linear_advection.hpp"]
 EMPTY = ["util/matplotlibcpp.h"]
 

@@ -517,8 +517,9 @@ class HydroSimulation:
         if self._is_final(stage):
             self.dev_signal.zero_()
 
-    def _fused_launch(self, stage: int, U_in, U_old, U_out, dt, group=None):
-        """one fused stage over all local boxes (group None) or over a sub-level (Level, [local box indices])"""
+    def _fused_launch(self, stage: int, U_in, U_old, U_out, dt, group=None, fofc: bool = False):
+        """one fused stage over all local boxes (group None) or over a sub-level (Level, [local box indices]); fofc: the first-order flux
+        correction pass of a stage whose first pass flagged cells (qk_hydro_stage_args::fofc_pass)"""
         lev, idx = (self.lev, None) if group is None else group
         tab = (lambda mf: mf.ptr) if idx is None else (lambda mf: mf.subset_ptr(idx))
         a = capi.StageArgs()
@@ -544,6 +545,7 @@ class HydroSimulation:
         if self._carry_active():
             a.rk2_carry_rhs = 1
             a.rhs1 = tab(self.rhs1())
+        a.fofc_pass = int(fofc)
         c = self.ctx
         c.check(c.L.qk_hydro_stage_fused(lev.h, c.stream(), C.byref(self.traits), C.byref(a)), "qk_hydro_stage_fused")
 
@@ -601,7 +603,7 @@ class HydroSimulation:
         if self._fused_end(stage) == 0:
             self._stage1_left_F1 = (stage == 1 and not self._carry_active())
             return True
-        return self._redo_stage_unfused(stage, U_in, U_old, U_out, dt)
+        return self._correct_stage(stage, U_in, U_old, U_out, dt)
 
     def _stage(self, stage, U_in, U_old, U_out, dt) -> bool:
         if self.use_fused:
@@ -609,8 +611,32 @@ class HydroSimulation:
             if nbad == 0:
                 self._stage1_left_F1 = (stage == 1 and not self._carry_active())
                 return True
-            # first-order flux correction needed: redo the stage with the reference-shaped operators
+            return self._correct_stage(stage, U_in, U_old, U_out, dt)
         return self._redo_stage_unfused(stage, U_in, U_old, U_out, dt)
+
+    def _correct_stage(self, stage, U_in, U_old, U_out, dt) -> bool:
+        """the fused first pass of a stage flagged cells: first-order flux correction, fused where it applies, on the operators otherwise"""
+        if stage == 1:
+            self._stage1_left_F1 = not self._carry_active()  # (the first pass stored the uncorrected F1, which is what stage 2 averages)
+        ok = self._fofc_fused(stage, U_in, U_old, U_out, dt)
+        if ok is not None:
+            return ok
+        return self._redo_stage_unfused(stage, U_in, U_old, U_out, dt)
+
+    def _fofc_fused(self, stage, U_in, U_old, U_out, dt):
+        """First-order flux correction as ONE more fused pass (reference src/QuokkaSimulation.hpp:1144-1184, :1232-1270): redoFlag — as the first
+        pass left it, ghost cells exchanged — selects the faces that take the first-order flux of the old state and the cells that take the
+        cell-centred velocity divergence; the pass counts what is still invalid.  Returns None where the pass does not apply (artificial
+        viscosity, stage 2 of the carried-rhs form, forward Euler feeding flux registers): the caller redoes the stage on the operators."""
+        if (not getattr(self, "fused_fofc", True) or float(self.artificialViscosityK_) != 0.0 or (self._carry_active() and stage == 2)
+                or (self.integratorOrder_ == 1 and getattr(self, "store_flux_rk2", False))):
+            return None
+        self.counters["fofc1_stages" if stage == 1 else "fofc2_stages"] += 1
+        self._fill_flag_ghosts()
+        self._fused_begin(stage)
+        self._fused_launch(stage, U_in, U_old, U_out, dt, fofc=True)
+        nbad = self._fused_end(stage)
+        return not (nbad > 0 and self.abortOnFofcFailure_ != 0)
 
     def _redo_stage_unfused(self, stage, U_in, U_old, U_out, dt) -> bool:
         """a stage whose fused attempt flagged cells, on the reference-shaped operators.  Stage 2 forms 0.5 F1 + 0.5 F2 from halfFlux: after a

@@ -41,7 +41,8 @@ def test_config4_radhydro_shell_256_runs_its_50_steps(ctx):
     assert sim.cellUpdates_ == 50 * 256 ** 3 and sim.radiationCellUpdates_ % sim.cellUpdates_ == 0
     substeps = sim.radiationCellUpdates_ // sim.cellUpdates_
     assert 5 <= substeps <= 11, substeps  # chat / (v + cs) with the substep limit of 10 (+1)
-    assert c["solves"] == calls, (c["solves"], calls)  # no cell skipped its solve
+    # every cell solves at least once per call; the outer (work-term) iteration repeats the Newton-Raphson solve where the gas moves (<= 5 times)
+    assert calls <= c["solves"] <= 2 * calls, (c["solves"], calls)
     per_solve = c["newton_iterations"] / c["solves"]
     assert 1.0 <= per_solve <= 6.0 and c["max_newton_iterations"] < 50, (per_solve, c["max_newton_iterations"])
     print(f"shell 256^3: {substeps} radiation substeps per step, {per_solve:.2f} Newton iterations per solve (max {c['max_newton_iterations']}), "

@@ -98,12 +98,16 @@ def test_ghost_fill_matches_oracle(ctx, oracle):
         assert np.array_equal(so.state(b), sg.state_new_cc_.fab_numpy(b)), f"box {b}"
 
 
-def test_fofc_and_retries_match_oracle(ctx, oracle):
+@pytest.mark.parametrize("fused_fofc", [True, False])
+def test_fofc_and_retries_match_oracle(ctx, oracle, fused_fofc):
     """A 6x over-CFL step: first-order flux correction fires in both stages and the advance is retried with dt/2^n
-    (reference src/QuokkaSimulation.hpp:911-964, 1144-1184, 1232-1270)."""
+    (reference src/QuokkaSimulation.hpp:911-964, 1144-1184, 1232-1270).  fused_fofc: the correction as one more fused pass
+    (qk_hydro_stage_args::fofc_pass — first-order fluxes of the flagged faces evaluated on demand inside the sweeps) or the whole stage
+    redone on the reference-shaped operators; either way every bit of the oracle's state."""
     N, mgs = 16, 8
     so = oracle.sim(SEDOV, 3, [N] * 3, [0, 0, 0], [1.2] * 3, [0, 0, 0], max_grid_size=[mgs] * 3)
     sg = sedov_problem(ctx, N, max_grid_size=mgs)
+    sg.fused_fofc = fused_fofc
     for _ in range(3):
         assert so.step() and sg.step()
     dt = so.compute_dt() * 6.0
