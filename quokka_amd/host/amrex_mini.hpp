@@ -57,10 +57,12 @@
 			amrex::Abort("assertion failed: " #x);                                                                                       \
 		}                                                                                                                                    \
 	} while (0)
+// (usable inside __host__ __device__ hooks that kernels now call — RadTophat's opacity: the message is passed as the literal it is, so that the
+// device overload of amrex::Abort applies there)
 #define AMREX_ALWAYS_ASSERT_WITH_MESSAGE(x, msg)                                                                                                     \
 	do {                                                                                                                                         \
 		if (!(x)) {                                                                                                                          \
-			amrex::Abort(std::string("assertion failed: " #x " : ") + (msg));                                                            \
+			amrex::Abort(msg);                                                                                                           \
 		}                                                                                                                                    \
 	} while (0)
 #define AMREX_ASSERT_WITH_MESSAGE(x, msg) ((void)0)
@@ -85,6 +87,11 @@ template <typename T> using Vector = std::vector<T>;
 
 // inside kernels: stop the wave (the reference's device-side amrex::Abort traps as well)
 __device__ inline void Abort(char const * /*msg*/) { __builtin_trap(); }
+[[noreturn]] __host__ inline void Abort(char const *msg)
+{
+	std::fprintf(stderr, "amrex::Abort: %s\n", msg);
+	std::exit(2);
+}
 [[noreturn]] inline void Abort(std::string const &msg)
 {
 	std::fprintf(stderr, "amrex::Abort: %s\n", msg.c_str());

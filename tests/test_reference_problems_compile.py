@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "quokka_amd", "host")
 REF = "/root/reference/src/problems"
 MUST = {"HydroBlast3D", "HydroShocktube", "RadhydroShell"}
-MIN_COUNT = 49
+MIN_COUNT = 54
 
 
 def spacedim(pdir):
@@ -53,3 +53,16 @@ def test_reference_problem_files_compile_unchanged():
     print(f"{len(ok)} of {len(ok) + len(bad)} compile unchanged: {ok}")
     assert MUST <= set(ok), {k: bad[k] for k in MUST if k in bad}
     assert len(ok) >= MIN_COUNT
+
+
+def test_unmodified_ode_integration_problem_passes_on_the_host():
+    """src/problems/ODEIntegration/test_ode.cpp, unchanged, against the host mirror's adaptive RK integrator (host/compat/ode_integrate.hpp) and
+    gamma-law quokka::EOS: a cooling gas integrated over ten cooling times must end within 1e-4 of T = 160.526 K.  Host code only — no GPU —, so
+    this runs wherever the binary was built (bin/ref_ODEIntegration; __graft_entry__.build() builds it where the reference tree exists)."""
+    exe = os.path.join(HOST, "bin", "ref_ODEIntegration")
+    if not os.path.exists(exe):
+        pytest.skip("bin/ref_ODEIntegration not built (needs the reference tree at build time)")
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-500:]
+    m = re.search(r"Relative error: ([0-9.eE+-]+)", p.stdout)
+    assert m and float(m.group(1)) < 1.0e-4, p.stdout[-500:]
