@@ -56,9 +56,14 @@ using Real = amrex::Real;
 AMREX_GPU_HOST_DEVICE inline auto clamp(double v, double lo, double hi) -> double { return (v < lo) ? lo : (hi < v) ? hi : v; }
 template <typename T> AMREX_GPU_HOST_DEVICE constexpr auto sgn(T val) -> int { return (T(0) < val) - (val < T(0)); }
 
-struct Physics_NumVars {
+struct Physics_NumVars { // reference src/physics_numVars.hpp
 	static const int numHydroVars = 6;
 	static const int numRadVars = 4;
+	// face-centred (declarations only: no face-centred state is evolved by this build — MHD is out of scope)
+	static const int numMHDVars_per_dim = 1;
+	static const int numVelVars_per_dim = 1;
+	static const int numMHDVars_tot = AMREX_SPACEDIM * numMHDVars_per_dim;
+	static const int numVelVars_tot = AMREX_SPACEDIM * numVelVars_per_dim;
 };
 
 template <typename problem_t> struct Physics_Traits {
@@ -86,6 +91,23 @@ template <typename problem_t> struct Physics_Indices {
 	static const int hydroFirstIndex = 0;
 	static const int pscalarFirstIndex = Physics_NumVars::numHydroVars;
 	static const int radFirstIndex = pscalarFirstIndex + Physics_Traits<problem_t>::numPassiveScalars;
+	// face-centred (reference src/physics_info.hpp:43-49; declarations, see Physics_NumVars)
+	static const int nvarPerDim_fc = Physics_NumVars::numVelVars_per_dim * static_cast<int>(Physics_Traits<problem_t>::is_hydro_enabled) +
+					 Physics_NumVars::numMHDVars_per_dim * static_cast<int>(Physics_Traits<problem_t>::is_mhd_enabled);
+	static const int nvarTotal_fc = AMREX_SPACEDIM * nvarPerDim_fc;
+	static const int velFirstIndex = 0;
+	static const int mhdFirstIndex = velFirstIndex + Physics_NumVars::numVelVars_per_dim;
+};
+
+// reference src/hydro/mhd_system.hpp: the index bookkeeping of the face-centred magnetic field (nothing else exists there either)
+template <typename problem_t> class MHDSystem
+{
+      public:
+	static constexpr int nvar_per_dim_ = Physics_NumVars::numMHDVars_per_dim;
+	static constexpr int nvar_tot_ = Physics_NumVars::numMHDVars_tot;
+	enum varIndex_perDim {
+		bfield_index = Physics_Indices<problem_t>::mhdFirstIndex,
+	};
 };
 
 namespace quokka

@@ -11,7 +11,7 @@ AMReX_FabArrayUtility.H AMReX_Geometry.H AMReX_GpuAsyncArray.H AMReX_GpuContaine
 AMReX_MFParallelFor.H AMReX_MultiFab.H AMReX_MultiFabUtil.H AMReX_ParallelContext.H AMReX_ParallelDescriptor.H AMReX_ParmParse.H AMReX_PlotFileUtil.H AMReX_Print.H
 AMReX_REAL.H AMReX_Reduce.H AMReX_SPACE.H AMReX_TableData.H AMReX_TagBox.H AMReX_ValLocPair.H AMReX_Vector.H AMReX_iMultiFab.H AMReX_GpuControl.H AMReX_Gpu.H
 AMReX_Random.H AMReX_RandomEngine.H AMReX_GpuLaunch.H AMReX_Utility.H AMReX_INT.H AMReX_Dim3.H AMReX_RealBox.H AMReX_Math.H""".split()
-QUOKKA = ["QuokkaSimulation.hpp", "simulation.hpp", "SimulationData.hpp", "physics_info.hpp", "hydro/hydro_system.hpp", "hydro/EOS.hpp", "hydro/HydroState.hpp",
+QUOKKA = ["QuokkaSimulation.hpp", "simulation.hpp", "SimulationData.hpp", "hydro/mhd_system.hpp", "physics_numVars.hpp", "physics_info.hpp", "hydro/hydro_system.hpp", "hydro/EOS.hpp", "hydro/HydroState.hpp",
           "radiation/radiation_system.hpp", "radiation/radiation_dust_system.hpp", "fundamental_constants.H", "hyperbolic_system.hpp", "grid.hpp", "math/math_impl.hpp"]
 COMPAT = {"util/fextract.hpp": "compat/util_compat.hpp", "util/ArrayUtil.hpp": "compat/util_compat.hpp", "util/valarray.hpp": "compat/util_compat.hpp",
           "fmt/format.h": "compat/mini_fmt.hpp", "fmt/core.h": "compat/mini_fmt.hpp", "radiation/planck_integral.hpp": "compat/planck_integral.hpp",
