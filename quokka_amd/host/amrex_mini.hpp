@@ -726,7 +726,7 @@ template <typename T> class FabArrayT
 		for (size_t n = 0; n < ba.size(); ++n) {
 			tab.emplace_back(d_data_ + offsets_[n], fabboxes_[n], ncomp);
 		}
-		QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_table_), sizeof(Array4<T>) * ba.size()));
+		QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_table_), sizeof(Array4<T>) * std::max<size_t>(ba.size(), 1))); // (never null: a level may be empty on this rank)
 		QK_HOST_HIP(hipMemcpy(d_table_, tab.data(), sizeof(Array4<T>) * ba.size(), hipMemcpyHostToDevice));
 	}
 	[[nodiscard]] auto size() const -> int { return static_cast<int>(boxes_.size()); }
@@ -752,6 +752,7 @@ template <typename T> class FabArrayT
 		std::vector<T> h(static_cast<size_t>(total_), v);
 		QK_HOST_HIP(hipMemcpy(d_data_, h.data(), sizeof(T) * total_, hipMemcpyHostToDevice));
 	}
+	void setZeroAsync(hipStream_t s) { QK_HOST_HIP(hipMemsetAsync(d_data_, 0, sizeof(T) * std::max<Long>(total_, 1), s)); }
 	// host staging copies of one fab
 	[[nodiscard]] auto copyToHost(int b) const -> std::vector<T>
 	{

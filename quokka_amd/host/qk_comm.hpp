@@ -14,6 +14,7 @@
 #ifndef QK_COMM_HPP_
 #define QK_COMM_HPP_
 
+#include <algorithm>
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -194,6 +195,36 @@ class Comm
 				a = (op == Op::sum) ? a + b : (op == Op::max ? (a > b ? a : b) : (a < b ? a : b));
 			}
 			v[i] = a;
+		}
+		barrier(); // every rank has read every file
+		std::remove(msgPath("r", rank, -1, seq_).c_str());
+	}
+	// element-wise maximum of an int array of any length (the tile flags of a regrid: every rank clusters the same global flags)
+	void allReduceMaxInts(int *v, size_t n)
+	{
+		if (size == 1 || n == 0) {
+			return;
+		}
+		if (backend == Backend::rccl) {
+			int *d = nullptr;
+			hipCheck(hipMalloc(reinterpret_cast<void **>(&d), sizeof(int) * n), "hipMalloc");
+			hipCheck(hipMemcpyAsync(d, v, sizeof(int) * n, hipMemcpyHostToDevice, stream_), "hipMemcpyAsync");
+			ncclCheck(ncclAllReduce(d, d, n, ncclInt, ncclMax, nccl_, stream_), "ncclAllReduce");
+			hipCheck(hipMemcpyAsync(v, d, sizeof(int) * n, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync");
+			hipCheck(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+			hipCheck(hipFree(d), "hipFree");
+			return;
+		}
+		++seq_;
+		writeFile(msgPath("r", rank, -1, seq_), v, sizeof(int) * n);
+		std::vector<int> other(n);
+		for (int r = 0; r < size; ++r) {
+			if (r != rank) {
+				readFile(msgPath("r", r, -1, seq_), other.data(), sizeof(int) * n);
+				for (size_t i = 0; i < n; ++i) {
+					v[i] = std::max(v[i], other[i]);
+				}
+			}
 		}
 		barrier(); // every rank has read every file
 		std::remove(msgPath("r", rank, -1, seq_).c_str());

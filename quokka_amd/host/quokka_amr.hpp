@@ -6,7 +6,11 @@
 // plan, stage scratch); the base object (level 0, built from the deck) owns the finer ones through this driver.  Every cell is
 // touched by a kernel behind include/quokka_amd.h; the grids come from qk_amr_tile_flags + qk_amr_cluster_tiles (tile clustering,
 // not AMReX's Berger-Rigoutsos: unpinned).  Same algorithm as quokka_amd/amr_simulation.py, which the GPU tests pin by
-// properties (full-coverage == uniform fine run, conservation with reflux, nesting); single rank.
+// properties (full-coverage == uniform fine run, conservation with reflux, nesting).
+// Several ranks (one process per GPU): the level-0 boxes are distributed by the base object; a refined box lives on the rank of its level-0
+// ancestor, so grids are clustered inside each level-0 box, and interpolation, average-down and regrid copies stay on the GPU that owns the
+// data.  Only the ordinary ghost exchange of every level and the reflux increments (register cells next to a box of another rank: folded with
+// qk_SumBoundary_*) cross ranks; tile flags are all-reduced so that every rank builds the same hierarchy.
 #ifndef QK_HOST_QUOKKA_AMR_HPP_
 #define QK_HOST_QUOKKA_AMR_HPP_
 
@@ -33,6 +37,10 @@ template <typename problem_t> class AmrDriver
 		amrex::ParmParse pp;
 		pp.query("do_reflux", do_reflux);
 		pp.query("grid_eff", grid_eff);
+		multi_ = qkhost::Comm::get().size > 1;
+		clusterWithinParent_ = multi_ ? 1 : 0;
+		amrex::ParmParse("qk").query("cluster_within_parent", clusterWithinParent_); // (tests: one rank building the grids several ranks build)
+		AMREX_ALWAYS_ASSERT(!multi_ || clusterWithinParent_ != 0);
 		istep.assign(max_level + 1, 0);
 		last_regrid_step.assign(max_level + 1, 0);
 		dt_.assign(max_level + 1, 1.e100);
@@ -48,6 +56,8 @@ template <typename problem_t> class AmrDriver
 	std::vector<amrex::Long> cellUpdatesEachLevel_;
 	amrex::Long cellUpdates_ = 0;
 	double tNew_ = 0.0, elapsedSeconds_ = 0.0;
+	bool multi_ = false;
+	int clusterWithinParent_ = 0;
 
 	[[nodiscard]] auto finestLevel() const -> int { return static_cast<int>(finer_.size()); }
 	auto level(int l) -> Sim & { return l == 0 ? base_ : *finer_[l - 1]->sim; }
@@ -118,7 +128,7 @@ template <typename problem_t> class AmrDriver
 		double const us = 1.0e6 * elapsedSeconds_ / static_cast<double>(cellUpdates_);
 		amrex::Print() << "Performance figure-of-merit: " << us << " μs/zone-update [" << 1.0 / us << " Mupdates/s]\n";
 		for (int l = 0; l <= finestLevel(); ++l) {
-			amrex::Print() << "Zone-updates on level " << l << ": " << cellUpdatesEachLevel_[l] << " (" << level(l).grids_.size() << " grids)\n";
+			amrex::Print() << "Zone-updates on level " << l << ": " << cellUpdatesEachLevel_[l] << " (" << level(l).allGrids_.size() << " grids)\n";
 		}
 	}
 
@@ -159,7 +169,7 @@ template <typename problem_t> class AmrDriver
 				double s = 0, c = 0;
 				amrex::HostFor(mf.validbox(b), [&](int i, int j, int k) {
 					if (l < finestLevel()) {
-						for (auto const &fb : level(l + 1).grids_) {
+						for (auto const &fb : level(l + 1).allGrids_) {
 							if (fb.contains(2 * i, 2 * j, 2 * k)) {
 								return;
 							}
@@ -173,7 +183,7 @@ template <typename problem_t> class AmrDriver
 				total += s * vol;
 			}
 		}
-		return total;
+		return qkhost::Comm::get().allReduceSum(total);
 	}
 
       private:
@@ -183,6 +193,15 @@ template <typename problem_t> class AmrDriver
 		qk_fluxreg *fluxreg = nullptr;
 		qk_fluxreg *fluxregRad = nullptr; // the radiation block of the state (expandFluxArrays, reference src/QuokkaSimulation.hpp:1758)
 		qk_avgdown_plan *avgdown = nullptr;
+		// several ranks: the reflux increments of the PARENT level (valid + 1 ghost cell: a register cell may belong to a neighbouring rank's box),
+		// folded onto their owners by SumBoundary over a 1-ghost plan of the parent's grids, then added to the parent's state
+		struct Fold {
+			amrex::MultiFab inc;
+			qk_ghost_plan *plan = nullptr;
+			qkhost::PeerBuffers peers;
+			~Fold() { qk_ghost_plan_destroy(plan); }
+		};
+		std::unique_ptr<Fold> fold, foldRad;
 		~Finer()
 		{
 			qk_interp_plan_destroy(interp);
@@ -228,6 +247,18 @@ template <typename problem_t> class AmrDriver
 		}
 		s.boxes = boxes;
 		s.level = lev;
+		if (multi_) { // a box of level lev >= 1 lives on the rank of the level-0 box that contains it
+			for (auto const &b : boxes) {
+				int owner = -1;
+				for (size_t n = 0; n < base_.allGrids_.size() && owner < 0; ++n) {
+					if (base_.allGrids_[n].contains(b.lo[0] >> lev, b.lo[1] >> lev, b.lo[2] >> lev)) {
+						owner = base_.owner_[n];
+					}
+				}
+				AMREX_ALWAYS_ASSERT(owner >= 0); // (a fine box without a level-0 ancestor)
+				s.owner.push_back(owner);
+			}
+		}
 		return s;
 	}
 
@@ -246,13 +277,36 @@ template <typename problem_t> class AmrDriver
 		int const ratio[3] = {2, 2, 2};
 		auto gf = qgeom(me.geom[0]);
 		auto gc = qgeom(parent.geom[0]);
-		qkhost::check(qk_interp_plan_create(parent.levelHandle(), me.levelHandle(), &gf, me.nghost_cc_, ratio, 0, 0, nullptr, &f.interp), "qk_interp_plan_create");
-		qkhost::check(qk_fluxreg_create(parent.levelHandle(), me.levelHandle(), &gc, ratio, Sim::ncompHydro_, 0, nullptr, 0, &f.fluxreg), "qk_fluxreg_create");
+		// several ranks: the plans are told the fine boxes of ALL ranks (a ghost cell under a remote fine box is filled by the fine-fine exchange;
+		// a register cell owned by another rank is kept in a ghost cell of a local coarse box)
+		int const nAll = multi_ ? static_cast<int>(me.allBoxes_.size()) : 0;
+		qk_box const *all = multi_ ? me.allBoxes_.data() : nullptr;
+		int const regGhost = multi_ ? 1 : 0;
+		qkhost::check(qk_interp_plan_create(parent.levelHandle(), me.levelHandle(), &gf, me.nghost_cc_, ratio, 0, nAll, all, &f.interp), "qk_interp_plan_create");
+		qkhost::check(qk_fluxreg_create(parent.levelHandle(), me.levelHandle(), &gc, ratio, Sim::ncompHydro_, nAll, all, regGhost, &f.fluxreg), "qk_fluxreg_create");
 		qkhost::check(qk_avgdown_plan_create(parent.levelHandle(), me.levelHandle(), ratio, &f.avgdown), "qk_avgdown_plan_create");
+		f.fold.reset();
+		f.foldRad.reset();
+		auto makeFold = [&](int ncomp) {
+			auto fo = std::make_unique<typename Finer::Fold>();
+			fo->inc.define(parent.grids_, ncomp, 1);
+			qkhost::check(qk_ghost_plan_create(parent.levelHandle(), &fo->plan, &gc, 1, ncomp, static_cast<int>(parent.allBoxes_.size()), parent.allBoxes_.data(),
+							   parent.owner_.data(), qkhost::Comm::get().rank),
+				      "qk_ghost_plan_create(reflux)");
+			fo->peers.build(fo->plan, sizeof(double));
+			return fo;
+		};
+		if (multi_) {
+			f.fold = makeFold(Sim::ncompHydro_);
+		}
 		if constexpr (Physics_Traits<problem_t>::is_radiation_enabled) {
-			qkhost::check(qk_fluxreg_create(parent.levelHandle(), me.levelHandle(), &gc, ratio, RadSystem<problem_t>::nvarHyperbolic_, 0, nullptr, 0, &f.fluxregRad),
+			qkhost::check(qk_fluxreg_create(parent.levelHandle(), me.levelHandle(), &gc, ratio, RadSystem<problem_t>::nvarHyperbolic_, nAll, all, regGhost, &f.fluxregRad),
 				      "qk_fluxreg_create");
-			qkhost::check(qk_fluxreg_set_state_component(f.fluxregRad, RadSystem<problem_t>::nstartHyperbolic_), "qk_fluxreg_set_state_component");
+			if (multi_) {
+				f.foldRad = makeFold(RadSystem<problem_t>::nvarHyperbolic_);
+			} else {
+				qkhost::check(qk_fluxreg_set_state_component(f.fluxregRad, RadSystem<problem_t>::nstartHyperbolic_), "qk_fluxreg_set_state_component");
+			}
 		}
 		Finer *fp = &f;
 		// FillPatchTwoLevels: the ghost cells no fine box covers come from the parent, interpolated in space and time
@@ -413,6 +467,7 @@ template <typename problem_t> class AmrDriver
 		qk_box qd{{dom.lo[0], dom.lo[1], dom.lo[2]}, {dom.hi[0], dom.hi[1], dom.hi[2]}};
 		qkhost::check(qk_amr_tile_flags(S.levelHandle(), nullptr, reinterpret_cast<qk_carray4 *>(tags.arrays()), &qd, n_error_buf, tile, flags.data()),
 			      "qk_amr_tile_flags");
+		qkhost::Comm::get().allReduceMaxInts(flags.data(), flags.size()); // every rank clusters the same global flags
 		auto at = [&](int i, int j, int k) -> int & { return flags[static_cast<size_t>(i) + static_cast<size_t>(nt[0]) * (j + static_cast<size_t>(nt[1]) * k)]; };
 		if (finerBoxes != nullptr) { // level lev+2 boxes: their level-lev footprint grown by 2 cells must be refined (proper nesting)
 			for (auto const &b : *finerBoxes) {
@@ -444,7 +499,7 @@ template <typename problem_t> class AmrDriver
 					}
 				}
 			}
-			for (auto const &b : level(base).grids_) {
+			for (auto const &b : level(base).allGrids_) {
 				for (int k = b.lo[2] * r / tile; k <= (b.hi[2] * r + r - 1) / tile; ++k) {
 					for (int j = b.lo[1] * r / tile; j <= (b.hi[1] * r + r - 1) / tile; ++j) {
 						for (int i = b.lo[0] * r / tile; i <= (b.hi[0] * r + r - 1) / tile; ++i) {
@@ -472,18 +527,53 @@ template <typename problem_t> class AmrDriver
 				}
 			}
 		}
-		std::vector<qk_box> out(flags.size() + 1);
 		// amr.grid_eff > 0: Berger-Rigoutsos clustering as amrex::AmrMesh::MakeNewGrids (default, the deck's 0.7); <= 0: the round-1 tile rule
-		int const n = (grid_eff > 0.0) ? qk_amr_cluster_berger_rigoutsos(flags.data(), allowed.data(), nt, AMREX_SPACEDIM, blocking_factor, max_grid_size, grid_eff, out.data(),
-										   static_cast<int>(out.size()))
-					       : qk_amr_cluster_tiles(flags.data(), nt, AMREX_SPACEDIM, blocking_factor, max_grid_size, 0, out.data(), static_cast<int>(out.size()));
-		AMREX_ALWAYS_ASSERT(n >= 0);
-		std::vector<amrex::Box> boxes(n);
-		for (int b = 0; b < n; ++b) {
-			for (int d = 0; d < 3; ++d) {
-				boxes[b].lo[d] = out[b].lo[d];
-				boxes[b].hi[d] = out[b].hi[d];
+		auto cluster = [&](std::vector<int> const &fl, std::vector<int> const &al, int const n3[3], int const origin[3], std::vector<amrex::Box> &boxes) {
+			std::vector<qk_box> out(fl.size() + 1);
+			int const n = (grid_eff > 0.0) ? qk_amr_cluster_berger_rigoutsos(fl.data(), al.data(), n3, AMREX_SPACEDIM, blocking_factor, max_grid_size, grid_eff, out.data(),
+											   static_cast<int>(out.size()))
+						       : qk_amr_cluster_tiles(fl.data(), n3, AMREX_SPACEDIM, blocking_factor, max_grid_size, 0, out.data(), static_cast<int>(out.size()));
+			AMREX_ALWAYS_ASSERT(n >= 0);
+			for (int b = 0; b < n; ++b) {
+				amrex::Box bx;
+				for (int d = 0; d < 3; ++d) { // (boxes come back in level lev+1 cells relative to the lattice handed in)
+					bx.lo[d] = out[b].lo[d] + origin[d];
+					bx.hi[d] = out[b].hi[d] + origin[d];
+				}
+				boxes.push_back(bx);
 			}
+		};
+		std::vector<amrex::Box> boxes;
+		if (clusterWithinParent_ == 0) {
+			int const origin[3] = {0, 0, 0};
+			cluster(flags, allowed, nt, origin, boxes);
+			return boxes;
+		}
+		// every level is clustered inside its level-0 ancestors (one rank each): the level-0 boxes of ALL ranks, in the same order everywhere
+		int const s = 1 << lev;
+		for (auto const &b0 : base_.allGrids_) {
+			int a[3] = {0, 0, 0}, e[3] = {0, 0, 0}, n3[3] = {1, 1, 1}, origin[3] = {0, 0, 0};
+			for (int d = 0; d < AMREX_SPACEDIM; ++d) {
+				int const lo = b0.lo[d] * s, hi = b0.hi[d] * s + s - 1;
+				AMREX_ALWAYS_ASSERT(lo % tile == 0 && (hi + 1) % tile == 0); // (level-0 boxes are whole tiles: max_grid_size is a multiple of blocking_factor)
+				a[d] = lo / tile;
+				e[d] = hi / tile;
+				n3[d] = e[d] - a[d] + 1;
+				origin[d] = 2 * lo;
+			}
+			std::vector<int> fl, al;
+			fl.reserve(static_cast<size_t>(n3[0]) * n3[1] * n3[2]);
+			al.reserve(fl.capacity());
+			for (int k = a[2]; k <= e[2]; ++k) {
+				for (int j = a[1]; j <= e[1]; ++j) {
+					for (int i = a[0]; i <= e[0]; ++i) {
+						size_t const idx = static_cast<size_t>(i) + static_cast<size_t>(nt[0]) * (j + static_cast<size_t>(nt[1]) * k);
+						fl.push_back(flags[idx]);
+						al.push_back(allowed[idx]);
+					}
+				}
+			}
+			cluster(fl, al, n3, origin, boxes);
 		}
 		return boxes;
 	}
@@ -525,7 +615,7 @@ template <typename problem_t> class AmrDriver
 				break;
 			}
 			bool const existed = lev <= finestLevel();
-			if (existed && sameBoxes(level(lev).grids_, boxes)) {
+			if (existed && sameBoxes(level(lev).allGrids_, boxes)) {
 				continue;
 			}
 			std::unique_ptr<Finer> old;
@@ -575,6 +665,37 @@ template <typename problem_t> class AmrDriver
 		}
 		for (int lev = baseLev; lev <= finestLevel(); ++lev) {
 			level(lev).FixupState(); // reference src/simulation.hpp:1257-1259
+		}
+	}
+
+	// flux_reg_[lev+1]->Reflux(state_new_cc_[lev]) (reference src/simulation.hpp:1308).  One rank: straight into the state.  Several ranks: the
+	// increments land in a zeroed array with one ghost cell, SumBoundary carries them to their owners (the strips travel in the opposite
+	// direction of a ghost fill: receive buffers are sent, send buffers receive), then state(comp0 + n) += increment(n)
+	void reflux(Sim &S, qk_fluxreg *reg, typename Finer::Fold *fold, int comp0)
+	{
+		if (fold == nullptr) {
+			qkhost::check(qk_fluxreg_Reflux(reg, nullptr, qkhost::tab(S.state_new_cc_[0])), "qk_fluxreg_Reflux");
+			return;
+		}
+		S.activate();
+		hipStream_t const cs = qkhost::Runtime::get().computeStream();
+		fold->inc.setZeroAsync(cs);
+		qkhost::check(qk_fluxreg_Reflux(reg, cs, qkhost::tab(fold->inc)), "qk_fluxreg_Reflux");
+		auto &pb = fold->peers;
+		for (size_t k = 0; k < pb.peer.size(); ++k) {
+			qkhost::check(qk_SumBoundary_pack(fold->plan, cs, static_cast<int>(k), qkhost::tab(fold->inc), static_cast<double *>(pb.recv[k])), "SumBoundary_pack");
+		}
+		qkhost::Comm::get().exchangeBegin(pb.peer, pb.recv, pb.nrecv, pb.send, pb.nsend, sizeof(double), cs);
+		qkhost::check(qk_SumBoundary_local(fold->plan, cs, qkhost::tab(fold->inc)), "SumBoundary_local");
+		qkhost::Comm::get().exchangeEnd(cs);
+		for (size_t k = 0; k < pb.peer.size(); ++k) {
+			qkhost::check(qk_SumBoundary_unpack(fold->plan, cs, static_cast<int>(k), qkhost::tab(fold->inc), static_cast<const double *>(pb.send[k])), "SumBoundary_unpack");
+		}
+		int const nc = fold->inc.nComp();
+		for (int b = 0; b < fold->inc.size(); ++b) {
+			auto const st = S.state_new_cc_[0].array(b);
+			auto const inc = fold->inc.const_array(b);
+			amrex::ParallelFor(fold->inc.validbox(b), nc, [=] AMREX_GPU_DEVICE(int i, int j, int k, int n) { st(i, j, k, comp0 + n) += inc(i, j, k, n); });
 		}
 	}
 
@@ -646,9 +767,11 @@ template <typename problem_t> class AmrDriver
 			}
 			if (lev < finestLevel()) {
 				if (do_reflux != 0) {
-					qkhost::check(qk_fluxreg_Reflux(finer_[lev]->fluxreg, nullptr, qkhost::tab(S.state_new_cc_[0])), "qk_fluxreg_Reflux");
+					reflux(S, finer_[lev]->fluxreg, finer_[lev]->fold.get(), 0);
 					if (finer_[lev]->fluxregRad != nullptr) {
-						qkhost::check(qk_fluxreg_Reflux(finer_[lev]->fluxregRad, nullptr, qkhost::tab(S.state_new_cc_[0])), "qk_fluxreg_Reflux(rad)");
+						if constexpr (Physics_Traits<problem_t>::is_radiation_enabled) {
+							reflux(S, finer_[lev]->fluxregRad, finer_[lev]->foldRad.get(), RadSystem<problem_t>::nstartHyperbolic_);
+						}
 					}
 				}
 				averageDownTo(lev);

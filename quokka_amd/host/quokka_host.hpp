@@ -1056,6 +1056,26 @@ inline auto distributeBoxes(int const nb[3], int nranks) -> std::vector<int>
 	return owner;
 }
 
+// rank = Morton index of the box mod nranks (quokka_amd/simulation.py distribute_boxes_interleaved): every neighbourhood of the box lattice is
+// spread over all ranks
+inline auto distributeBoxesInterleaved(int const nb[3], int nranks) -> std::vector<int>
+{
+	std::vector<int> owner;
+	for (int kb = 0; kb < nb[2]; ++kb) {
+		for (int jb = 0; jb < nb[1]; ++jb) {
+			for (int ib = 0; ib < nb[0]; ++ib) {
+				unsigned m = 0;
+				for (int bit = 0; bit < 10; ++bit) {
+					m |= ((static_cast<unsigned>(ib) >> bit) & 1U) << (3 * bit) | ((static_cast<unsigned>(jb) >> bit) & 1U) << (3 * bit + 1) |
+					     ((static_cast<unsigned>(kb) >> bit) & 1U) << (3 * bit + 2);
+				}
+				owner.push_back(static_cast<int>(m % static_cast<unsigned>(nranks)));
+			}
+		}
+	}
+	return owner;
+}
+
 // device send / receive buffers for the peers of a ghost plan (qk_ghost_plan_peer: rank and strip sizes in elements)
 struct PeerBuffers {
 	std::vector<int> peer;
@@ -1119,6 +1139,7 @@ struct LevelSpec {
 	amrex::Geometry geom;
 	std::vector<amrex::Box> boxes;
 	int level = 0;
+	std::vector<int> owner; // rank of every box (several ranks: a refined box lives on the rank of its level-0 ancestor); empty: all on rank 0
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1209,9 +1230,6 @@ template <typename problem_t> class AMRSimulation
 		auto &g = geom[0];
 		grids_.clear();
 		int nb[3] = {1, 1, 1};
-		if (spec != nullptr && comm.size > 1) {
-			amrex::Abort("the AMR driver of the host mirror is single-rank (uniform-grid runs distribute their boxes over the ranks)");
-		}
 		if (spec != nullptr) {
 			g = spec->geom;
 			grids_ = spec->boxes;
@@ -1264,7 +1282,19 @@ template <typename problem_t> class AMRSimulation
 		}
 		// the whole level and its box -> rank map (every rank computes the same); this rank keeps the boxes it owns, in global order
 		allGrids_ = grids_;
-		owner_ = (spec != nullptr) ? std::vector<int>(allGrids_.size(), 0) : qkhost::distributeBoxes(nb, comm.size);
+		if (spec != nullptr) {
+			owner_ = spec->owner.empty() ? std::vector<int>(allGrids_.size(), 0) : spec->owner;
+			AMREX_ALWAYS_ASSERT(owner_.size() == allGrids_.size());
+		} else {
+			// an AMR hierarchy keeps every refined box on the rank of its level-0 ancestor: "interleaved" (rank = Morton index of the level-0 box
+			// mod nranks; the default there, as in quokka_amd/amr_simulation.py) lands a refined region on every rank, "bricks" keeps level 0
+			// compact (fewest remote ghost strips: the uniform-grid default)
+			int maxLevel = 0;
+			amrex::ParmParse("amr").query("max_level", maxLevel);
+			std::string how = (maxLevel > 0 && comm.size > 1) ? "interleaved" : "bricks";
+			amrex::ParmParse("qk").query("level0_distribution", how);
+			owner_ = (how == "interleaved") ? qkhost::distributeBoxesInterleaved(nb, comm.size) : qkhost::distributeBoxes(nb, comm.size);
+		}
 		allBoxes_.clear();
 		for (auto const &b : allGrids_) {
 			allBoxes_.push_back({{b.lo[0], b.lo[1], b.lo[2]}, {b.hi[0], b.hi[1], b.hi[2]}});
@@ -1277,7 +1307,7 @@ template <typename problem_t> class AMRSimulation
 				qb.push_back(allBoxes_[n]);
 			}
 		}
-		if (grids_.empty()) {
+		if (grids_.empty() && spec == nullptr) { // (a refined level may well have no box on this rank: every operator on it is then a no-op)
 			amrex::Abort("this rank owns no boxes: fewer boxes than ranks (lower amr.max_grid_size)");
 		}
 		qkhost::check(qk_level_create(rt.ctx, &myLev_, AMREX_SPACEDIM, static_cast<int>(qb.size()), qb.data()), "qk_level_create");
@@ -2082,7 +2112,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		auto t = qkhost::traits<problem_t>();
 		if constexpr (HydroSystem<problem_t>::nscalars_ <= 3 && Physics_Traits<problem_t>::numMassScalars == 0 && Physics_Traits<problem_t>::is_hydro_enabled) {
 			scratchBytes_ = qk_hydro_stage_scratch_bytes(qkhost::Runtime::get().lev, &t);
-			QK_HOST_HIP(hipMalloc(&scratch_, static_cast<size_t>(scratchBytes_)));
+			QK_HOST_HIP(hipMalloc(&scratch_, std::max<size_t>(static_cast<size_t>(scratchBytes_), 8))); // (never null: a level may be empty on this rank)
 		}
 		// redoFlag.FillBoundary plan (1 ghost, 1 comp)
 		auto const &g = geom[0];

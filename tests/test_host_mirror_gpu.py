@@ -317,6 +317,48 @@ def test_overlapped_fill_schedule_of_the_cxx_host_equals_one_rank(tmp_path, nran
             assert np.array_equal(chunk, one[b]), (extra, b, r, np.abs(chunk - one[b]).max())
 
 
+@pytest.mark.parametrize("nranks,distribution,mgs", [(2, "interleaved", 8), (4, "interleaved", 8), (2, "bricks", 16)])
+def test_amr_hierarchy_of_the_cxx_host_across_ranks_matches_one_rank(tmp_path, nranks, distribution, mgs):
+    """BASELINE config 5's structure (Sedov, amr.max_level = 2, subcycling, reflux, regrid every 2 steps) in the C++17 host on several ranks
+    (quokka_amr.hpp): a refined box lives on the rank of its level-0 ancestor, grids are clustered inside each level-0 box, tile flags are
+    all-reduced, reflux increments cross ranks through SumBoundary.  32^3 base grid; with 8^3 level-0 boxes the refined region around the blast
+    (which the problem puts in the corner cell of the octant) spans level-0 boxes of several ranks on both finer levels; with 16^3 boxes it
+    stays inside one, so the other ranks hold EMPTY levels 1 and 2 and still take part in every collective step.  Against ONE rank building the
+    same grids (qk.cluster_within_parent = 1): same time steps, same number of grids and zone updates on every level, level-0 state (which holds
+    the average of every finer level) equal to rounding — the reflux additions are reassociated —, energy conserved to the problem's own 2e-15."""
+    from quokka_amd.simulation import chop_domain, distribute_boxes, distribute_boxes_interleaved
+    import re
+    args = ["geometry.prob_lo=0 0 0", "geometry.prob_hi=1.2 1.2 1.2", "geometry.is_periodic=0 0 0", "amr.n_cell=32 32 32", f"amr.max_grid_size={mgs}",
+            "amr.max_level=2", "amr.blocking_factor=8", "amr.n_error_buf=3", "do_reflux=1", "max_timesteps=8"]
+    (one,), outs1 = run_ranks("ref_HydroBlast3D", args + ["qk.cluster_within_parent=1"], tmp_path, 1, 29651)
+    parts, outs = run_ranks("ref_HydroBlast3D", args + [f"qk.level0_distribution={distribution}"], tmp_path, nranks, 29651 + 3 * nranks + len(distribution))
+    zone = re.compile(r"Zone-updates on level (\d): (\d+) \((\d+) grids\)")
+    z1 = zone.findall(outs1[0])
+    assert len(z1) == 3 and zone.findall(outs[0]) == z1, (zone.findall(outs[0]), z1)
+    assert int(z1[1][2]) >= (8 if mgs == 8 else 1), z1  # (8 level-1 grids: one in each of the 2 x 2 x 2 level-0 boxes around the corner)
+    boxes = chop_domain([32, 32, 32], [mgs] * 3)
+    fn = distribute_boxes_interleaved if distribution == "interleaved" else distribute_boxes
+    owner = fn(boxes, nranks, [32, 32, 32], [mgs] * 3)
+    assert sorted(set(owner)) == list(range(nranks))
+    if mgs == 8 and distribution == "interleaved":  # the level-0 boxes under the refined region belong to more than one rank
+        under = {owner[ib + 4 * (jb + 4 * kb)] for ib in range(2) for jb in range(2) for kb in range(2)}
+        assert len(under) > 1, under
+    nb, n3 = len(boxes), mgs ** 3
+    one = one.reshape(nb, 6, mgs, mgs, mgs)
+    cursor = [0] * nranks
+    worst = 0.0
+    for b, r in enumerate(owner):
+        chunk = parts[r][cursor[r]:cursor[r] + 6 * n3].reshape(6, mgs, mgs, mgs)
+        cursor[r] += 6 * n3
+        for n in range(6):
+            worst = max(worst, float(np.abs(chunk[n] - one[b][n]).max() / np.abs(one[:, n]).max()))
+    assert all(cursor[r] == parts[r].size for r in range(nranks))
+    assert worst <= 1e-13, worst
+    assert "Energy conservation is OK." in outs[0] and "Energy conservation is OK." in outs1[0]
+    dump1, dumpn = str(tmp_path / "state_n1_shm.bin"), str(tmp_path / f"state_n{nranks}_shm.bin")
+    assert open(dump1 + ".meta").read().split()[:3] == open(dumpn + ".rank0.meta").read().split()[:3]  # steps, time, dt
+
+
 def test_sedov_on_several_gpus_over_rccl(tmp_path):
     """the production transport (ncclSend / ncclRecv on the library-owned stream, ncclAllReduce): needs one GPU per rank — skipped on a
     one-GPU box, where the test above covers everything but the transport itself"""
