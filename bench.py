@@ -41,7 +41,10 @@ ALG_BYTES_PRE = 72.0
 ALG_BYTES_STEP = 1496.0
 FP64_VALU_PEAK = 256 * 64 * 2.4e9  # FP64 vector lane-instructions per second without FMA contraction (256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz)
 # radiation transport update kernels: doubles per cell they must move (state in / out + the face fluxes of three directions)
-RAD_STREAM_WORDS = {"rad_PredictStep": 22, "rad_AddFluxesRK2": 24}
+RAD_STREAM_WORDS = {"rad_PredictStep": 22, "rad_AddFluxesRK2": 24,
+                    # qk_rad_stage_fused: X reads the state and writes the accumulator; Y reads both and writes the accumulator; Z reads state,
+                    # accumulator and (stage 2) the old state and writes the state
+                    "rad_sweep_x": 8, "rad_sweep_y": 12, "rad_sweep_z": 14}
 # Newton-Raphson exchange kernel (radSourceCell, single group, constant opacity): VALU instructions per cell outside / inside the Newton loop,
 # counted in the gfx950 ISA of qk_rad_ops.hip (profiles/round3/README.md)
 RAD_SOURCE_VALU_FIXED, RAD_SOURCE_VALU_PER_ITERATION = 900.0, 420.0
@@ -558,15 +561,16 @@ def main():
     if not args.no_secondary:
         if world == 1 and ncell == 256:
             # (a) developed-run figure: the default timed region sits at sim-time ~6e-5; >= 100 + 100 steps moves the shock further out
-            simL, _, elL, _ = run_sedov(ctx, torch, dist, rank, world, 256, mgs, args.long_steps, args.long_steps, profile=False)
+            carry = args.rk2_mode == "carry"  # every secondary Sedov figure uses the headline's form of the RK2 average
+            simL, _, elL, _ = run_sedov(ctx, torch, dist, rank, world, 256, mgs, args.long_steps, args.long_steps, profile=False, carry=carry)
             out["long_run"] = {"value": 256 ** 3 * args.long_steps / elL / 1e6, "unit": "Mcell-updates/s", "steps": args.long_steps, "warmup": args.long_steps,
                                "ms_per_step": elL / args.long_steps * 1e3, "sim_time": simL.tNew_,
                                "fofc_stages": simL.counters["fofc1_stages"] + simL.counters["fofc2_stages"]}
             del simL
             torch.cuda.empty_cache()
             # (b) 512^3 on the one GPU: the size of north_star's roofline target
-            s5, n5, el5, k5 = run_sedov(ctx, torch, dist, rank, world, 512, mgs, 8, 2)
-            out["ncell512"] = {"value": 512 ** 3 * 8 / el5 / 1e6, "unit": "Mcell-updates/s", "steps": 8, "warmup": 2, "ms_per_step": el5 / 8 * 1e3,
+            s5, n5, el5, k5 = run_sedov(ctx, torch, dist, rank, world, 512, mgs, 8, 2, carry=carry)
+            out["ncell512"] = {"rk2_mode": args.rk2_mode, "value": 512 ** 3 * 8 / el5 / 1e6, "unit": "Mcell-updates/s", "steps": 8, "warmup": 2, "ms_per_step": el5 / 8 * 1e3,
                                "boxes": s5.lev.nboxes, "roofline": roofline_of(k5, s5.lev.num_cells(), 512 ** 3, 8, el5, 1, 512, mgs)}
             del s5
             torch.cuda.empty_cache()
@@ -590,7 +594,7 @@ def main():
             out["amr_maxlev2"] = compact(run_amr(ctx, torch, dist, rank, world, 256, 50, 5))
             torch.cuda.empty_cache()
         elif world > 1 and ncell != 256:
-            sW, nW, elW, _ = run_sedov(ctx, torch, dist, rank, world, 256, mgs, args.steps, args.warmup, profile=False)
+            sW, nW, elW, _ = run_sedov(ctx, torch, dist, rank, world, 256, mgs, args.steps, args.warmup, profile=False, carry=(args.rk2_mode == "carry"))
             out["weak_256_per_gpu"] = {"value": nW[0] * nW[1] * nW[2] * args.steps / elW / 1e6, "unit": "Mcell-updates/s", "ms_per_step": elW / args.steps * 1e3,
                                        "workload": f"{nW[0]}x{nW[1]}x{nW[2]}, 8 boxes of 128^3 per GPU"}
             del sW

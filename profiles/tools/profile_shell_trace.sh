@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/v4_shell; mkdir -p $O; cd $R
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-v4_shell}; mkdir -p $O; cd $R
 rocprofv3 --kernel-trace --stats -d $O/kt -- python bench.py --workload shell --steps 5 --warmup 2 --no-cpu-baseline > $O/kt.log 2>&1
 f=$(find $O/kt -name "*.db" | head -1); python profiles/summarize_rocpd.py "$f" > $O/kt.txt 2>&1
 find $O -name "*.db" -delete; rm -rf $O/kt

@@ -229,6 +229,7 @@ class RadAmrLevelSim(AmrLevelSim, RadhydroSimulation):
         RadhydroSimulation.__init__(self, amr.ctx, geom, amr.traits, amr.rad_traits, amr.bcs, None, rank=amr.rank, nranks=amr.nranks, dirichlet=amr.dirichlet,
                                     boxes=boxes, owner=owner)
         self.fluxreg_rad: Optional[FluxRegister] = None
+        self.store_rad_flux = True  # the flux registers read the face fluxes of both stages
         self.is_hydro_enabled = amr.is_hydro_enabled
         for name in ("radiationCflNumber_", "maxSubsteps_", "radiationReconstructionOrder_"):
             setattr(self, name, getattr(amr, name))

@@ -329,6 +329,309 @@ template <int DIR, int ORDER> void launchRadMarchFlux(qk_level *lev, qk_stream s
 	hipLaunchKernelGGL((k_rad_flux_march<DIR, ORDER, STRIP>), grid, dim3(64, 4), 0, static_cast<hipStream_t>(s), lev->d_boxes, rad, cons_t, flux_t, notb);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// One transport stage without the face-flux round trip (qk_rad_stage_fused): the flux kernels above with the flux divergence taken where the
+// fluxes are produced, as the hydro sweeps do.  X: acc = (dt/dx)(F_i - F_i+1); Y: acc += (dt/dy)(...); Z: d = acc + (dt/dz)(...), then the
+// update of PredictStep (stage 1) or AddFluxesRK2 (stage 2) and the validity repair — the same operands in the same association as the
+// separate kernels, so the state is the same in every bit.  The face fluxes are stored only on request (flux registers).
+struct RadSweep {
+	const qk_array4 *U_in; // state whose fluxes are taken (ghost cells filled)
+	const qk_array4 *U0;   // state at the start of the substep (stage 1: the same arrays as U_in)
+	qk_array4 *U_new;      // may alias U_in: the Z sweep marches every column in one thread and touches no other column
+	qk_array4 *acc;	       // NRAD components per cell, no ghost cells needed
+	qk_array4 *flux[3];    // each NULL or the face-centred array that receives the fluxes
+	double dtdx[3];
+};
+
+constexpr int RXCELLS = RXB - 7; // cells updated per workgroup of the X sweep: threads 3 .. RXB-4 (their right neighbour holds the other face)
+
+template <int ORDER, bool STORE> __global__ void __launch_bounds__(RXB) k_rad_sweep_x(const qk_box *boxes, Rad rad, RadSweep a)
+{
+	__shared__ double s_p[NRAD][RXB];
+	__shared__ double s_e[NRAD][RXB];
+	__shared__ double s_c[NRAD][RXB];
+	__shared__ double s_f[NRAD][RXB]; // flux at the left face of the thread's cell
+	const int b = static_cast<int>(blockIdx.z);
+	const qk_box bx = boxes[b];
+	const int k = bx.lo[2] + static_cast<int>(blockIdx.y);
+	if (k > bx.hi[2]) {
+		return; // uniform for the workgroup
+	}
+	RA4 U(a.U_in[b]);
+	const int t = threadIdx.x;
+	const int64_t rowlen = U.js;
+	const int64_t slablen = rowlen * (bx.hi[1] - bx.lo[1] + 1);
+	const int64_t f = static_cast<int64_t>(blockIdx.x) * RXCELLS + t - 3;
+	const bool inside = (f >= 0) && (f < slablen);
+	const int64_t fc = inside ? f : 0;
+	const int jj = static_cast<int>(fc / rowlen);
+	const int i = U.bx + static_cast<int>(fc - jj * rowlen);
+	const int j = bx.lo[1] + jj;
+	const int64_t o = U.idx(i, j, k);
+	double c0[NRAD], p0[NRAD];
+#pragma unroll
+	for (int n = 0; n < NRAD; ++n) {
+		c0[n] = U.p[o + U.ns * (RAD0 + n)];
+	}
+	radPrim(rad, c0, p0);
+#pragma unroll
+	for (int n = 0; n < NRAD; ++n) {
+		s_c[n][t] = c0[n];
+		s_p[n][t] = p0[n];
+	}
+	__syncthreads();
+	const int tm2 = max(t - 2, 0), tm1 = max(t - 1, 0), tp1 = min(t + 1, RXB - 1), tp2 = min(t + 2, RXB - 1);
+	double edgeL[NRAD];
+#pragma unroll
+	for (int n = 0; n < NRAD; ++n) {
+		if (ORDER == 3) {
+			double am, ap;
+			ppmEdges(s_p[n][tm2], s_p[n][tm1], p0[n], s_p[n][tp1], s_p[n][tp2], am, ap);
+			edgeL[n] = am;
+			s_e[n][t] = ap;
+		} else if (ORDER == 2) {
+			const double slope = MC(s_p[n][tp1] - p0[n], p0[n] - s_p[n][tm1]);
+			edgeL[n] = p0[n] - 0.25 * slope;
+			s_e[n][t] = slope;
+		} else {
+			edgeL[n] = p0[n];
+		}
+	}
+	__syncthreads();
+	const bool isFace = inside && (i >= bx.lo[0]) && (i <= bx.hi[0] + 1) && (t >= 3) && (t <= RXB - 3);
+	double Fo[NRAD] = {0.0, 0.0, 0.0, 0.0};
+	if (isFace) {
+		double pL[NRAD], cL[NRAD];
+#pragma unroll
+		for (int n = 0; n < NRAD; ++n) {
+			cL[n] = s_c[n][tm1];
+			if (ORDER == 3) {
+				pL[n] = s_e[n][tm1];
+			} else if (ORDER == 2) {
+				pL[n] = s_p[n][tm1] + 0.25 * s_e[n][tm1];
+			} else {
+				pL[n] = s_p[n][tm1];
+			}
+		}
+		radFaceFlux<0>(rad, pL, edgeL, cL, c0, Fo);
+#pragma unroll
+		for (int n = 0; n < NRAD; ++n) {
+			s_f[n][t] = Fo[n];
+		}
+	}
+	__syncthreads();
+	if (!isFace || t > RXB - 4) {
+		return;
+	}
+	if (STORE) {
+		WA4 F(a.flux[0][b]);
+		const int64_t of = F.idx(i, j, k);
+#pragma unroll
+		for (int n = 0; n < NRAD; ++n) {
+			F.p[of + F.ns * n] = Fo[n];
+		}
+	}
+	if (i <= bx.hi[0]) { // a cell of the box: its right face is the next thread's
+		WA4 A(a.acc[b]);
+		const int64_t oa = A.idx(i, j, k);
+#pragma unroll
+		for (int n = 0; n < NRAD; ++n) {
+			A.p[oa + A.ns * n] = a.dtdx[0] * (Fo[n] - s_f[n][t + 1]);
+		}
+	}
+}
+
+// Y and Z sweeps: one thread marches `strip` cells of a pencil along DIR (strip + 1 faces) with the rolling window of k_rad_flux_march.
+// EPI 0: acc += term (Y); 1: PredictStep update; 2: AddFluxesRK2 update (Z; the strip is the whole pencil then, see RadSweep::U_new).
+template <int DIR, int ORDER, int EPI, bool STORE>
+__global__ void __launch_bounds__(256) k_rad_sweep_march(const qk_box *boxes, Rad rad, RadSweep a, int notb, int strip)
+{
+	static_assert(DIR == 1 || DIR == 2, "marching sweep: strided directions only");
+	static_assert((0.5 - IMEX_a32) == 0.0, "the fused stage drops the old-state fluxes of AddFluxesRK2: PD-ARS only");
+	constexpr int OT = 3 - DIR;
+	const int b = static_cast<int>(blockIdx.z);
+	const qk_box bx = boxes[b];
+	const int i = bx.lo[0] + static_cast<int>(blockIdx.x) * 64 + static_cast<int>(threadIdx.x);
+	const int oblk = static_cast<int>(blockIdx.y) % notb, sno = static_cast<int>(blockIdx.y) / notb;
+	const int ot = bx.lo[OT] + oblk * 4 + static_cast<int>(threadIdx.y);
+	const int c0 = bx.lo[DIR] + sno * strip;
+	if (i > bx.hi[0] || ot > bx.hi[OT] || c0 > bx.hi[DIR]) {
+		return;
+	}
+	const int c1 = min(c0 + strip - 1, bx.hi[DIR]); // last cell of this strip
+	RA4 U(a.U_in[b]);
+	constexpr int M0 = (ORDER == 3) ? 0 : (ORDER == 2) ? 1 : 2;
+	constexpr int M1 = (ORDER == 3) ? 5 : (ORDER == 2) ? 4 : 3;
+	double c[6][NRAD], p[6][NRAD];
+	double carry[NRAD];
+	double Fprev[NRAD];
+	double nextc[NRAD]; // the cell that enters the window at the next face: loaded one face ahead, so that its latency hides behind a flux
+	double accv[NRAD];  // accumulator of the cell that is completed at this face: loaded before the flux, used after it
+	double u0v[NRAD];   // (Z) and its state at the start of the substep
+	int pos[3];
+	pos[0] = i;
+	pos[OT] = ot;
+	WA4 A(a.acc[b]);
+	auto loadCons = [&](int cell, double out[NRAD]) {
+		pos[DIR] = cell;
+		const int64_t o = U.idx(pos[0], pos[1], pos[2]);
+#pragma unroll
+		for (int n = 0; n < NRAD; ++n) {
+			out[n] = U.p[o + U.ns * (RAD0 + n)];
+		}
+	};
+#pragma unroll
+	for (int m = M0; m <= M1; ++m) {
+		loadCons(c0 + (m - 3), c[m]);
+		radPrim(rad, c[m], p[m]);
+	}
+#pragma unroll
+	for (int n = 0; n < NRAD; ++n) {
+		if (ORDER == 3) {
+			double am, ap;
+			ppmEdges(p[0][n], p[1][n], p[2][n], p[3][n], p[4][n], am, ap);
+			carry[n] = ap;
+		} else if (ORDER == 2) {
+			carry[n] = MC(p[3][n] - p[2][n], p[2][n] - p[1][n]);
+		}
+	}
+	for (int face = c0; face <= c1 + 1; ++face) {
+		if (face > c0) {
+#pragma unroll
+			for (int m = M0; m < M1; ++m) {
+#pragma unroll
+				for (int n = 0; n < NRAD; ++n) {
+					c[m][n] = c[m + 1][n];
+					p[m][n] = p[m + 1][n];
+				}
+			}
+#pragma unroll
+			for (int n = 0; n < NRAD; ++n) {
+				c[M1][n] = nextc[n];
+			}
+			radPrim(rad, c[M1], p[M1]);
+			pos[DIR] = face - 1;
+			const int64_t oa = A.idx(pos[0], pos[1], pos[2]);
+#pragma unroll
+			for (int n = 0; n < NRAD; ++n) {
+				accv[n] = A.p[oa + A.ns * n];
+			}
+			if (EPI != 0) {
+				RA4 Uo(a.U0[b]);
+				const int64_t oo = Uo.idx(pos[0], pos[1], pos[2]);
+#pragma unroll
+				for (int n = 0; n < NRAD; ++n) {
+					u0v[n] = Uo.p[oo + Uo.ns * (RAD0 + n)];
+				}
+			}
+		}
+		if (face <= c1) {
+			loadCons(face + 1 + (M1 - 3), nextc); // (ahead of every cell this thread writes)
+		}
+		double pL[NRAD], pR[NRAD], Fo[NRAD];
+#pragma unroll
+		for (int n = 0; n < NRAD; ++n) {
+			if (ORDER == 3) {
+				double am, ap;
+				ppmEdges(p[1][n], p[2][n], p[3][n], p[4][n], p[5][n], am, ap);
+				pL[n] = carry[n];
+				pR[n] = am;
+				carry[n] = ap;
+			} else if (ORDER == 2) {
+				const double rslope = MC(p[4][n] - p[3][n], p[3][n] - p[2][n]);
+				pL[n] = p[2][n] + 0.25 * carry[n];
+				pR[n] = p[3][n] - 0.25 * rslope;
+				carry[n] = rslope;
+			} else {
+				pL[n] = p[2][n];
+				pR[n] = p[3][n];
+			}
+		}
+		radFaceFlux<DIR>(rad, pL, pR, c[2], c[3], Fo);
+		if (STORE && (face <= c1 || c1 == bx.hi[DIR])) { // (the face after the strip belongs to the next strip, except at the end of the pencil)
+			WA4 F(a.flux[DIR][b]);
+			pos[DIR] = face;
+			const int64_t of = F.idx(pos[0], pos[1], pos[2]);
+#pragma unroll
+			for (int n = 0; n < NRAD; ++n) {
+				F.p[of + F.ns * n] = Fo[n];
+			}
+		}
+		if (face > c0) { // cell face-1 has both its faces now
+			pos[DIR] = face - 1;
+			double cons[NRAD];
+#pragma unroll
+			for (int n = 0; n < NRAD; ++n) {
+				cons[n] = accv[n] + a.dtdx[DIR] * (Fprev[n] - Fo[n]);
+			}
+			if (EPI == 0) {
+				const int64_t oa = A.idx(pos[0], pos[1], pos[2]);
+#pragma unroll
+				for (int n = 0; n < NRAD; ++n) {
+					A.p[oa + A.ns * n] = cons[n];
+				}
+			} else {
+#pragma unroll
+				for (int n = 0; n < NRAD; ++n) {
+					if (EPI == 1) {
+						cons[n] = u0v[n] + cons[n]; // radiation_system.hpp:681-690
+					} else {
+						const double U_0 = u0v[n];
+						const double U_1 = c[2][n]; // the cell left of this face: still in the window
+						cons[n] = (1.0 - IMEX_a32) * U_0 + IMEX_a32 * U_1 + (0.5 * (cons[n])); // :758-759 with the zero-weight term dropped
+					}
+				}
+				if (!radStateValid(rad, cons)) {
+					amendRadState(rad, cons);
+				}
+				WA4 Un(a.U_new[b]);
+				const int64_t on = Un.idx(pos[0], pos[1], pos[2]);
+#pragma unroll
+				for (int n = 0; n < NRAD; ++n) {
+					Un.p[on + Un.ns * (RAD0 + n)] = cons[n];
+				}
+			}
+		}
+#pragma unroll
+		for (int n = 0; n < NRAD; ++n) {
+			Fprev[n] = Fo[n];
+		}
+	}
+}
+
+template <int ORDER, int STAGE, bool STORE> void launchRadSweeps(qk_level *lev, qk_stream s, Rad rad, RadSweep const &a, int nghost)
+{
+	if (lev->nboxes == 0) {
+		return;
+	}
+	auto const st = static_cast<hipStream_t>(s);
+	{
+		const int64_t slab = static_cast<int64_t>(lev->maxlen[0] + 2 * nghost) * lev->maxlen[1];
+		const dim3 grid(static_cast<unsigned>((slab + RXCELLS - 1) / RXCELLS), static_cast<unsigned>(lev->maxlen[2]), static_cast<unsigned>(lev->nboxes));
+		ProfScope ps(lev->ctx, st, "rad_sweep_x");
+		hipLaunchKernelGGL((k_rad_sweep_x<ORDER, STORE>), grid, dim3(RXB), 0, st, lev->d_boxes, rad, a);
+	}
+	{
+		constexpr int STRIP = 16;
+		const int notb = (lev->maxlen[2] + 3) / 4;
+		const int nstrips = (lev->maxlen[1] + STRIP - 1) / STRIP;
+		const dim3 grid((lev->maxlen[0] + 63) / 64, notb * nstrips, lev->nboxes);
+		ProfScope ps(lev->ctx, st, "rad_sweep_y");
+		hipLaunchKernelGGL((k_rad_sweep_march<1, ORDER, 0, STORE>), grid, dim3(64, 4), 0, st, lev->d_boxes, rad, a, notb, STRIP);
+	}
+	{
+		// written in place (stage 2 of the drivers: U_new is U_in), a pencil is one thread's: the cells behind its march are the only ones it
+		// has overwritten.  Otherwise strips, for more waves in flight.
+		const int strip = (a.U_new == a.U_in) ? lev->maxlen[2] : 32;
+		const int notb = (lev->maxlen[1] + 3) / 4;
+		const int nstrips = (lev->maxlen[2] + strip - 1) / strip;
+		const dim3 grid((lev->maxlen[0] + 63) / 64, notb * nstrips, lev->nboxes);
+		ProfScope ps(lev->ctx, st, "rad_sweep_z");
+		hipLaunchKernelGGL((k_rad_sweep_march<2, ORDER, STAGE, STORE>), grid, dim3(64, 4), 0, st, lev->d_boxes, rad, a, notb, strip);
+	}
+}
+
 } // namespace
 
 extern "C" {
@@ -613,6 +916,59 @@ int qk_rad_AddFluxesRK2(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int
 		run(std::integral_constant<int, 1>{});
 	}
 	return radStatus(lev, "rad AddFluxesRK2");
+}
+
+
+int qk_rad_stage_fused(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int order, int stage, const qk_array4 *U_in, const qk_array4 *U0, qk_array4 *U_new,
+		       qk_array4 *acc, qk_array4 *const flux_out[3], double dt, const double dx_in[3])
+{
+	if (lev == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	if (int rc = checkRad(lev->ctx, rt); rc != QK_OK) {
+		return rc;
+	}
+	QK_REQUIRE(lev->ctx, U_in && U0 && U_new && acc && dx_in, "rad stage_fused: NULL array");
+	QK_REQUIRE(lev->ctx, order >= 1 && order <= 3, "rad stage_fused: reconstruction order must be 1..3");
+	QK_REQUIRE(lev->ctx, stage == 1 || stage == 2, "rad stage_fused: stage must be 1 or 2");
+	if (lev->ndim != 3 || rt->ngroups > 1) {
+		return setError(lev->ctx, QK_ERR_UNSUPPORTED, "rad stage_fused: 3-D levels and one photon group (otherwise computeRadiationFluxes + PredictStep / AddFluxesRK2)");
+	}
+	const bool store = flux_out != nullptr && (flux_out[0] != nullptr || flux_out[1] != nullptr || flux_out[2] != nullptr);
+	QK_REQUIRE(lev->ctx, !store || (flux_out[0] && flux_out[1] && flux_out[2]), "rad stage_fused: the face fluxes are stored in all directions or in none");
+	const Rad rad(*rt);
+	RadSweep a{};
+	a.U_in = U_in;
+	a.U0 = U0;
+	a.U_new = U_new;
+	a.acc = acc;
+	for (int d = 0; d < 3; ++d) {
+		a.flux[d] = store ? flux_out[d] : nullptr;
+		a.dtdx[d] = dt / dx_in[d];
+	}
+#define QK_RAD_SWEEPS(O)                                                                                                                             \
+	if (stage == 1) {                                                                                                                            \
+		if (store) {                                                                                                                         \
+			launchRadSweeps<O, 1, true>(lev, s, rad, a, 4);                                                                              \
+		} else {                                                                                                                             \
+			launchRadSweeps<O, 1, false>(lev, s, rad, a, 4);                                                                             \
+		}                                                                                                                                    \
+	} else {                                                                                                                                     \
+		if (store) {                                                                                                                         \
+			launchRadSweeps<O, 2, true>(lev, s, rad, a, 4);                                                                              \
+		} else {                                                                                                                             \
+			launchRadSweeps<O, 2, false>(lev, s, rad, a, 4);                                                                             \
+		}                                                                                                                                    \
+	}
+	if (order == 3) {
+		QK_RAD_SWEEPS(3)
+	} else if (order == 2) {
+		QK_RAD_SWEEPS(2)
+	} else {
+		QK_RAD_SWEEPS(1)
+	}
+#undef QK_RAD_SWEEPS
+	return radStatus(lev, "rad stage_fused");
 }
 
 } // extern "C"

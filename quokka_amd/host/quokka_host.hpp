@@ -893,6 +893,22 @@ template <typename problem_t> class RadSystem : public HyperbolicSystem<problem_
 		qkhost::check(qk_rad_PredictStep(lev(), nullptr, &rt, AMREX_SPACEDIM, qkhost::tab(consVarOld), qkhost::tab(consVarNew), f, dt, d3),
 			      "RadSystem::PredictStep");
 	}
+	// one transport stage with the flux divergence taken inside the flux kernels (qk_rad_stage_fused): computeRadiationFluxes(U_in) +
+	// PredictStep (stage 1) / AddFluxesRK2 (stage 2); `fluxOut`: where the face fluxes are stored, or nullptr when nothing reads them
+	static void stageFused(int stage, int order, amrex::MultiFab const &U_in, amrex::MultiFab const &U0, amrex::MultiFab &U_new, amrex::MultiFab &acc,
+			       std::array<amrex::MultiFab, AMREX_SPACEDIM> *fluxOut, double dt, amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> dx)
+	{
+		auto rt = traits();
+		qk_array4 *f[3] = {nullptr, nullptr, nullptr};
+		double d3[3];
+		if (fluxOut != nullptr) {
+			flux3(*fluxOut, f);
+		}
+		dx3(dx, d3);
+		qkhost::check(qk_rad_stage_fused(lev(), nullptr, &rt, order, stage, qkhost::tab(U_in), qkhost::tab(U0), qkhost::tab(U_new), qkhost::tab(acc),
+						 fluxOut != nullptr ? f : nullptr, dt, d3),
+			      "RadSystem::stageFused");
+	}
 	// :712-771
 	static void AddFluxesRK2(amrex::MultiFab &U_new, amrex::MultiFab const &U0, amrex::MultiFab const &U1,
 				 std::array<amrex::MultiFab, AMREX_SPACEDIM> const &fluxArrayOld, std::array<amrex::MultiFab, AMREX_SPACEDIM> const &fluxArray, double dt,
@@ -1957,9 +1973,9 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	{
 		fillRadEnergySource(time + dt);
 		if constexpr (Physics_Traits<problem_t>::nGroups <= 1) { // :1875-1881
-			RadSystem<problem_t>::AddSourceTermsSingleGroup(state_new_cc_[0], radEnergySource_, dt, stage, d_radCounter_, d_radFailure_);
+			RadSystem<problem_t>::AddSourceTermsSingleGroup(state_new_cc_[0], radEnergySource_, dt, stage, d_radCounter_ + 4 * radCounterSlot_, d_radFailure_);
 		} else {
-			RadSystem<problem_t>::AddSourceTermsMultiGroup(state_new_cc_[0], radEnergySource_, dt, stage, d_radCounter_, d_radFailure_);
+			RadSystem<problem_t>::AddSourceTermsMultiGroup(state_new_cc_[0], radEnergySource_, dt, stage, d_radCounter_ + 4 * radCounterSlot_, d_radFailure_);
 		}
 	}
 
@@ -1967,8 +1983,13 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	{
 		fillTime_ = radTime_; // (a refined level: its ghost cells come from the parent at the time of the substep, :1743)
 		this->fillRadiationGhosts(state_old_cc_[0]);
-		RadSystem<problem_t>::computeRadiationFluxes(state_old_cc_[0], radFluxOld_, radiationReconstructionOrder_);
-		RadSystem<problem_t>::PredictStep(state_old_cc_[0], state_new_cc_[0], radFluxOld_, dt_radiation, geom[0].CellSizeArray());
+		if (radFusedActive()) {
+			RadSystem<problem_t>::stageFused(1, radiationReconstructionOrder_, state_old_cc_[0], state_old_cc_[0], state_new_cc_[0], radAcc_,
+							 afterRadStage_ ? &radFluxOld_ : nullptr, dt_radiation, geom[0].CellSizeArray());
+		} else {
+			RadSystem<problem_t>::computeRadiationFluxes(state_old_cc_[0], radFluxOld_, radiationReconstructionOrder_);
+			RadSystem<problem_t>::PredictStep(state_old_cc_[0], state_new_cc_[0], radFluxOld_, dt_radiation, geom[0].CellSizeArray());
+		}
 		if (afterRadStage_) {
 			afterRadStage_(radFluxOld_, dt_radiation); // incrementFluxRegisters(..., 0.5 * dt_radiation) (:1818)
 		}
@@ -1978,11 +1999,34 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	{
 		fillTime_ = radTime_ + dt_radiation; // :1764
 		this->fillRadiationGhosts(state_new_cc_[0]);
-		RadSystem<problem_t>::computeRadiationFluxes(state_new_cc_[0], radFlux_, radiationReconstructionOrder_);
-		RadSystem<problem_t>::AddFluxesRK2(state_new_cc_[0], state_old_cc_[0], state_new_cc_[0], radFluxOld_, radFlux_, dt_radiation, geom[0].CellSizeArray());
+		if (radFusedActive()) { // (the Z sweep writes state_new in place: it marches every column in one thread and reads no other column)
+			RadSystem<problem_t>::stageFused(2, radiationReconstructionOrder_, state_new_cc_[0], state_old_cc_[0], state_new_cc_[0], radAcc_,
+							 afterRadStage_ ? &radFlux_ : nullptr, dt_radiation, geom[0].CellSizeArray());
+		} else {
+			RadSystem<problem_t>::computeRadiationFluxes(state_new_cc_[0], radFlux_, radiationReconstructionOrder_);
+			RadSystem<problem_t>::AddFluxesRK2(state_new_cc_[0], state_old_cc_[0], state_new_cc_[0], radFluxOld_, radFlux_, dt_radiation, geom[0].CellSizeArray());
+		}
 		if (afterRadStage_) {
 			afterRadStage_(radFlux_, dt_radiation); // :1854
 		}
+	}
+
+	// qk_rad_stage_fused serves 3-D builds with one photon group (deck: qk.fused_radiation = 0 keeps the separate operators; tests)
+	amrex::MultiFab radAcc_;
+	int radFused_ = -1;
+	auto radFusedActive() -> bool
+	{
+		if (radFused_ < 0) {
+			radFused_ = 0;
+			if constexpr (AMREX_SPACEDIM == 3 && Physics_Traits<problem_t>::nGroups == 1) {
+				radFused_ = 1;
+				amrex::ParmParse("qk").query("fused_radiation", radFused_);
+				if (radFused_ != 0) {
+					radAcc_.define(grids_, RadSystem<problem_t>::nvarHyperbolic_, 0);
+				}
+			}
+		}
+		return radFused_ == 1;
 	}
 
 	void subcycleRadiationAtLevel(double time, double dt_lev_hydro)
@@ -1999,44 +2043,53 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		haveSignal_ = false; // the source terms change the gas state
 		double time_subcycle = time;
 		int const r0 = RadSystem<problem_t>::nstartHyperbolic_;
+		// Newton counters: one slot of 4 ints per substep (a slot stays below 2^31 at any box size); one host read per level advance
+		if (nsubSteps > radCounterSlots_) {
+			(void)hipFree(d_radCounter_);
+			QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_radCounter_), 4 * sizeof(int) * static_cast<size_t>(nsubSteps)));
+			radCounterSlots_ = nsubSteps;
+		}
+		QK_HOST_HIP(hipMemsetAsync(d_radCounter_, 0, 4 * sizeof(int) * static_cast<size_t>(nsubSteps), qkhost::Runtime::get().computeStream()));
+		QK_HOST_HIP(hipMemsetAsync(d_radFailure_, 0, 3 * sizeof(int), qkhost::Runtime::get().computeStream()));
 		for (int i = 0; i < nsubSteps; ++i) {
 			if (i > 0) { // swapRadiationState (:1783-1788)
 				amrex::MultiFab::Copy(state_old_cc_[0], state_new_cc_[0], r0, r0, RadSystem<problem_t>::nvarHyperbolic_, 0);
 			}
-			QK_HOST_HIP(hipMemset(d_radCounter_, 0, 4 * sizeof(int)));
-			QK_HOST_HIP(hipMemset(d_radFailure_, 0, 3 * sizeof(int)));
+			radCounterSlot_ = i;
 			radTime_ = time_subcycle;
 			advanceRadiationForwardEuler(dt_radiation);
 			operatorSplitSourceTerms(time_subcycle, dt_radiation, 1); // IMEX_a22 > 0
 			advanceRadiationMidpointRK2(dt_radiation);
 			operatorSplitSourceTerms(time_subcycle, dt_radiation, 2);
-			int cnt[4], fail[3];
-			QK_HOST_HIP(hipMemcpy(cnt, d_radCounter_, sizeof(cnt), hipMemcpyDeviceToHost));
-			QK_HOST_HIP(hipMemcpy(fail, d_radFailure_, sizeof(fail), hipMemcpyDeviceToHost));
-			if (qkhost::Comm::get().size > 1) { // counters over all ranks (the reference reduces them when it prints them, QuokkaSimulation.hpp:1690-1720)
-				double v[7] = {double(cnt[0]), double(cnt[1]), double(fail[0]), double(fail[1]), double(fail[2]), 0, 0};
-				qkhost::Comm::get().allReduce(v, 5, qkhost::Comm::Op::sum);
-				cnt[0] = int(v[0]);
-				cnt[1] = int(v[1]);
-				fail[0] = int(v[2]);
-				fail[1] = int(v[3]);
-				fail[2] = int(v[4]);
-				cnt[2] = qkhost::Comm::get().allReduceMax(cnt[2]);
-			}
-			radSolves_ += cnt[0];
-			radNewtonIterations_ += cnt[1];
-			radMaxNewtonIterations_ = std::max(radMaxNewtonIterations_, cnt[2]);
-			if (fail[1] > 0) {
-				amrex::Abort("Newton-Raphson iteration for dust temperature failed to converge or dust temperature is negative!");
-			}
-			if (fail[0] > 0) {
-				amrex::Abort("Newton-Raphson iteration for matter-radiation coupling failed to converge!");
-			}
-			if (fail[2] > 0) {
-				amrex::Abort("Outer iteration for matter-radiation coupling failed to converge!");
-			}
 			time_subcycle += dt_radiation;
 			radiationCellUpdates_ += this->CountCells(0);
+		}
+		std::vector<int> cnt(4 * static_cast<size_t>(nsubSteps));
+		int fail[3];
+		QK_HOST_HIP(hipMemcpy(cnt.data(), d_radCounter_, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost));
+		QK_HOST_HIP(hipMemcpy(fail, d_radFailure_, sizeof(fail), hipMemcpyDeviceToHost));
+		double v[5] = {0, 0, double(fail[0]), double(fail[1]), double(fail[2])};
+		int maxIt = 0;
+		for (int i = 0; i < nsubSteps; ++i) {
+			v[0] += cnt[4 * i];
+			v[1] += cnt[4 * i + 1];
+			maxIt = std::max(maxIt, cnt[4 * i + 2]);
+		}
+		if (qkhost::Comm::get().size > 1) { // counters over all ranks (the reference reduces them when it prints them, QuokkaSimulation.hpp:1690-1720)
+			qkhost::Comm::get().allReduce(v, 5, qkhost::Comm::Op::sum);
+			maxIt = qkhost::Comm::get().allReduceMax(maxIt);
+		}
+		radSolves_ += static_cast<int64_t>(v[0]);
+		radNewtonIterations_ += static_cast<int64_t>(v[1]);
+		radMaxNewtonIterations_ = std::max(radMaxNewtonIterations_, maxIt);
+		if (v[3] > 0) {
+			amrex::Abort("Newton-Raphson iteration for dust temperature failed to converge or dust temperature is negative!");
+		}
+		if (v[2] > 0) {
+			amrex::Abort("Newton-Raphson iteration for matter-radiation coupling failed to converge!");
+		}
+		if (v[4] > 0) {
+			amrex::Abort("Outer iteration for matter-radiation coupling failed to converge!");
 		}
 	}
 
@@ -2060,6 +2113,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	std::array<amrex::MultiFab, AMREX_SPACEDIM> radFluxOld_, radFlux_;
 	amrex::MultiFab radEnergySource_;
 	int *d_radCounter_ = nullptr, *d_radFailure_ = nullptr;
+	int radCounterSlots_ = 1, radCounterSlot_ = 0;
 	bool radSourceFilled_ = false;
 
 	[[nodiscard]] auto minDx() const -> double

@@ -56,11 +56,18 @@ class RadhydroSimulation(HydroSimulation):
         lev, nd = self.lev, geom.ndim
         self.radFluxOld = [MultiFab(lev, self.nrad, 0, facedir=d) for d in range(nd)]
         self.radFlux = [MultiFab(lev, self.nrad, 0, facedir=d) for d in range(nd)]
+        # One transport stage as three sweeps that take the flux divergence where the fluxes are produced (qk_rad_stage_fused): 3-D, one
+        # photon group; the face fluxes are stored only when something reads them (store_rad_flux: the flux registers of a refined hierarchy)
+        self.use_fused_rad = bool(use_fused) and nd == 3 and self.nGroups == 1
+        self.store_rad_flux = False
+        self._rad_acc: Optional[MultiFab] = None
         self.radEnergySource = MultiFab(lev, self.nGroups, 0, fill=0.0)  # QuokkaSimulation.hpp:1866-1869
         self.SetRadEnergySource: Optional[Callable] = None  # fn(i, j, k, time) -> array on the valid box
         self._source_time_independent = True
         self._source_set = False
+        # Newton counters: one slot of 4 ints per radiation substep (a slot stays below 2^31 at any box size), read once per level advance
         self.dev_rad_counter = torch.zeros(4, dtype=torch.int32, device=ctx.device)
+        self._rad_counter_slot = 0
         self.dev_rad_failure = torch.zeros(3, dtype=torch.int32, device=ctx.device)
         self.rad_counters = {"solves": 0, "newton_iterations": 0, "max_newton_iterations": 0, "decoupled": 0}
 
@@ -106,7 +113,7 @@ class RadhydroSimulation(HydroSimulation):
         fn, name = ((c.L.qk_rad_AddSourceTermsSingleGroup, "qk_rad_AddSourceTermsSingleGroup") if self.nGroups <= 1
                     else (c.L.qk_rad_AddSourceTermsMultiGroup, "qk_rad_AddSourceTermsMultiGroup"))
         c.check(fn(self.lev.h, c.stream(), C.byref(self.rad_traits), C.byref(self.traits), self.state_new_cc_.ptr, self.radEnergySource.ptr, float(dt), stage,
-                   C.c_void_p(self.dev_rad_counter.data_ptr()), C.c_void_p(self.dev_rad_failure.data_ptr())), name)
+                   C.c_void_p(self.dev_rad_counter.data_ptr() + 16 * self._rad_counter_slot), C.c_void_p(self.dev_rad_failure.data_ptr())), name)
 
     def _fill_rad_ghosts(self, state: MultiFab):
         """fillBoundaryConditions for the transport kernels, which read only the radiation components of the ghost cells: the same-rank
@@ -118,8 +125,19 @@ class RadhydroSimulation(HydroSimulation):
         finally:
             self.ctx.check(L.qk_ghost_plan_set_components(h, 0, -1), "qk_ghost_plan_set_components")
 
+    def _rad_stage_fused(self, stage: int, U_in: MultiFab, U0: MultiFab, U_new: MultiFab, flux_out, dt_radiation: float):
+        if self._rad_acc is None:
+            self._rad_acc = MultiFab(self.lev, self.nrad, 0)
+        c = self.ctx
+        c.check(c.L.qk_rad_stage_fused(self.lev.h, c.stream(), C.byref(self.rad_traits), self.radiationReconstructionOrder_, stage, U_in.ptr, U0.ptr,
+                                       U_new.ptr, self._rad_acc.ptr, _p3(flux_out) if self.store_rad_flux else None, float(dt_radiation),
+                                       _d3(self.geom.dx)), "qk_rad_stage_fused")
+
     def advanceRadiationForwardEuler(self, dt_radiation: float):
         self._fill_rad_ghosts(self.state_old_cc_)
+        if self.use_fused_rad:
+            self._rad_stage_fused(1, self.state_old_cc_, self.state_old_cc_, self.state_new_cc_, self.radFluxOld, dt_radiation)
+            return
         self._rad_fluxes(self.state_old_cc_, self.radFluxOld)
         c = self.ctx
         c.check(c.L.qk_rad_PredictStep(self.lev.h, c.stream(), C.byref(self.rad_traits), self.geom.ndim, self.state_old_cc_.ptr, self.state_new_cc_.ptr,
@@ -127,6 +145,9 @@ class RadhydroSimulation(HydroSimulation):
 
     def advanceRadiationMidpointRK2(self, dt_radiation: float):
         self._fill_rad_ghosts(self.state_new_cc_)
+        if self.use_fused_rad:  # (the Z sweep writes state_new in place: it marches every column in one thread and reads no other column)
+            self._rad_stage_fused(2, self.state_new_cc_, self.state_old_cc_, self.state_new_cc_, self.radFlux, dt_radiation)
+            return
         # fluxes of the old state: identical to the ones of the forward-Euler stage (state_old_cc_ and its ghosts are unchanged)
         self._rad_fluxes(self.state_new_cc_, self.radFlux)
         c = self.ctx
@@ -135,8 +156,9 @@ class RadhydroSimulation(HydroSimulation):
                 "qk_rad_AddFluxesRK2")
 
     def swapRadiationState(self):
+        # (components are the outermost index of a fab: the radiation block of a box, ghost cells included, is one contiguous run)
         for b in range(self.lev.nboxes):
-            self.state_old_cc_.valid(b)[RAD0:RAD0 + self.nrad].copy_(self.state_new_cc_.valid(b)[RAD0:RAD0 + self.nrad])
+            self.state_old_cc_.fabs[b][RAD0:RAD0 + self.nrad].copy_(self.state_new_cc_.fabs[b][RAD0:RAD0 + self.nrad])
 
     def subcycleRadiationAtLevel(self, time: float, dt_lev_hydro: float) -> bool:
         if self.is_hydro_enabled and not (self.constantDt_ > 0.0):  # reference src/QuokkaSimulation.hpp:1583: radiation-only problems take ONE step
@@ -148,29 +170,35 @@ class RadhydroSimulation(HydroSimulation):
             raise capi.QkError(f"radiation substep assertion failed: nsubSteps = {nsub} (reference src/QuokkaSimulation.hpp:1596-1598)")
         self._signal_of_state_new = None  # the source terms change the gas state
         time_subcycle = time
+        if self.dev_rad_counter.numel() < 4 * nsub:
+            self.dev_rad_counter = torch.zeros(4 * nsub, dtype=torch.int32, device=self.ctx.device)
+        self.dev_rad_counter.zero_()
+        self.dev_rad_failure.zero_()
         for i in range(nsub):
             if i > 0:
                 self.swapRadiationState()
-            self.dev_rad_counter.zero_()
-            self.dev_rad_failure.zero_()
+            self._rad_counter_slot = i
             self.advanceRadiationForwardEuler(dt_rad)
             self.operatorSplitSourceTerms(time_subcycle, dt_rad, 1)  # IMEX_a22 > 0
             self.advanceRadiationMidpointRK2(dt_rad)
             self.operatorSplitSourceTerms(time_subcycle, dt_rad, 2)
-            fail = self._allreduce_sum_list(self.dev_rad_failure.tolist())
-            cnt = self.dev_rad_counter.tolist()
-            self.rad_counters["solves"] += cnt[0]
-            self.rad_counters["newton_iterations"] += cnt[1]
-            self.rad_counters["max_newton_iterations"] = max(self.rad_counters["max_newton_iterations"], cnt[2])
-            self.rad_counters["decoupled"] += cnt[3]  # multigroup dust model: solves on the decoupled gas-dust branch
-            if fail[1] > 0:
-                raise capi.QkError("Newton-Raphson iteration for dust temperature failed to converge or dust temperature is negative!")
-            if fail[0] > 0:
-                raise capi.QkError("Newton-Raphson iteration for matter-radiation coupling failed to converge!")
-            if fail[2] > 0:
-                raise capi.QkError("Outer iteration for matter-radiation coupling failed to converge!")
             time_subcycle += dt_rad
             self.radiationCellUpdates_ += self.CountCells()
+        # one host read per level advance (the reference aborts inside the kernel launch that fails; here the flags of all substeps are
+        # looked at together, before anything uses the state)
+        fail = self._allreduce_sum_list(self.dev_rad_failure.tolist())
+        cnt = self.dev_rad_counter[:4 * nsub].view(nsub, 4).to(torch.int64)
+        tot, mx = cnt.sum(dim=0).tolist(), int(cnt[:, 2].max().item())
+        self.rad_counters["solves"] += tot[0]
+        self.rad_counters["newton_iterations"] += tot[1]
+        self.rad_counters["max_newton_iterations"] = max(self.rad_counters["max_newton_iterations"], mx)
+        self.rad_counters["decoupled"] += tot[3]  # multigroup dust model: solves on the decoupled gas-dust branch
+        if fail[1] > 0:
+            raise capi.QkError("Newton-Raphson iteration for dust temperature failed to converge or dust temperature is negative!")
+        if fail[0] > 0:
+            raise capi.QkError("Newton-Raphson iteration for matter-radiation coupling failed to converge!")
+        if fail[2] > 0:
+            raise capi.QkError("Outer iteration for matter-radiation coupling failed to converge!")
         return True
 
     def _allreduce_sum_list(self, vals):

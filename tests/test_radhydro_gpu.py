@@ -331,3 +331,30 @@ def test_floored_power_law_opacity_matches_oracle(ctx, oracle):
     for it in range(3000):
         assert sp.step()
     assert np.allclose(sp.state_new_cc_.valid(0).cpu().numpy(), U, rtol=1e-10, atol=0)
+
+
+@pytest.mark.parametrize("rad_order", [1, 2, 3])
+def test_fused_radiation_stage_equals_the_separate_operators(ctx, rad_order):
+    """qk_rad_stage_fused (three sweeps that take the flux divergence where the fluxes are produced; the Z sweep finishes PredictStep /
+    AddFluxesRK2 and writes the stage-2 state in place) against computeRadiationFluxes + PredictStep / AddFluxesRK2: every component of the
+    state and, when they are asked for (flux registers), the face fluxes of both stages, bit for bit.  The shell at 16^3 in 8^3 boxes and in a
+    single 16^3 box (the Y sweep marches strips of 16 cells; tests/test_full_size_configs_gpu.py runs 128^3 boxes: eight strips per pencil)."""
+    for mgs in (8, 16):
+        sims = []
+        for fused in (True, False):
+            s = shell_problem(ctx, 16, table(), max_grid_size=mgs, pow_mode=1)
+            s.radiationReconstructionOrder_ = rad_order
+            assert s.use_fused_rad
+            s.use_fused_rad = fused
+            s.store_rad_flux = True
+            for _ in range(2):
+                assert s.step()
+            sims.append(s)
+        a, b = sims
+        for x, y in zip(a.gather_valid_local(), b.gather_valid_local()):
+            assert np.array_equal(x, y)
+        for d in range(3):
+            for fa, fb in ((a.radFluxOld[d], b.radFluxOld[d]), (a.radFlux[d], b.radFlux[d])):
+                for n in range(a.lev.nboxes):
+                    assert torch.equal(fa.fabs[n], fb.fabs[n]), (mgs, d, n)
+        assert a.rad_counters == b.rad_counters
