@@ -12,6 +12,7 @@
 #define QK_HOST_QUOKKA_IO_HPP_
 
 #include <chrono>
+#include <cstdio>
 #include <filesystem>
 #include <fstream>
 #include <iomanip>
@@ -226,7 +227,27 @@ inline auto VisMFRead(std::string const &prefix) -> VisMFData
 		amrex::Abort("quokka::io::VisMFRead: cannot open " + prefix + "_H");
 	}
 	int vers = 0, how = 0;
-	hdr >> vers >> how >> r.ncomp >> r.nghost;
+	hdr >> vers >> how >> r.ncomp;
+	// m_ngrow: AMReX writes one integer when the count is the same in every direction and the IntVect "(a,b,c)" otherwise (VisMF::Header's
+	// operator<<); both are read, an anisotropic count is refused
+	hdr >> std::ws;
+	if (hdr.peek() == '(') {
+		std::string iv;
+		std::getline(hdr, iv);
+		int g[3] = {0, 0, 0};
+		int const n = std::sscanf(iv.c_str(), "(%d,%d,%d)", &g[0], &g[1], &g[2]);
+		for (int d = 1; d < n; ++d) {
+			if (g[d] != g[0]) {
+				amrex::Abort("quokka::io::VisMFRead: anisotropic ghost-cell counts are not supported: " + iv);
+			}
+		}
+		if (n < 1) {
+			amrex::Abort("quokka::io::VisMFRead: malformed m_ngrow " + iv);
+		}
+		r.nghost = g[0];
+	} else {
+		hdr >> r.nghost;
+	}
 	r.boxes = readBoxArray(hdr);
 	long nfod = 0;
 	hdr >> nfod;

@@ -136,6 +136,14 @@ def test_checkpoint_restart_reproduces_the_plotfile(tmp_path, amr):
     assert h.istep[0] == 6 and h.finest_level == first.finest_level or amr  # (the hierarchy may have a different depth at step 6)
     assert lev[0].nghost == 4 and lev[0].fabs[0].shape == (6, 24, 24, 24)
 
+    # VisMF::Header writes m_ngrow as one integer when it is isotropic and as an IntVect otherwise; a reader must take both:
+    # the level-0 header of the checkpoint is rewritten in the IntVect form before the restart
+    cell_h = os.path.join(wd, "chk00006", "Level_0", "Cell_H")
+    lines = open(cell_h).read().split("\n")
+    assert lines[3] == "4"
+    lines[3] = "(4,4,4)"
+    open(cell_h, "w").write("\n".join(lines))
+    assert plotfile.read_checkpoint(os.path.join(wd, "chk00006"))[1][0].nghost == 4
     data2, meta2, out2 = run("ref_HydroBlast3D", common + ["max_timesteps=12", "restartfile=chk00006"], tmp_path, allow_fail=True, cwd=wd)
     assert int(meta2[0]) == 12 and meta2[1] == meta[1]
     olds = [d for d in os.listdir(wd) if d.startswith("plt00012.old.")]
@@ -146,8 +154,8 @@ def test_checkpoint_restart_reproduces_the_plotfile(tmp_path, amr):
 
 
 def test_radiative_shock_executable_meets_the_reference_criterion_and_matches_oracle(tmp_path, oracle):
-    """The reference's RadhydroShockCGS ctest through the C++ mirror (1-D build; opacity kappa = k0 / rho and the Eddington
-    approximation sampled from the problem's hooks, Dirichlet states from setCustomBoundaryConditions): exit status 0 == relative L1
+    """The reference's RadhydroShockCGS ctest through the C++ mirror (1-D build; the problem's opacity hooks kappa = k0 / rho are
+    compiled device code, the Eddington approximation is a trait, Dirichlet states come from setCustomBoundaryConditions): exit status 0 == relative L1
     error of T_rad against Lowrie & Edwards' solution <= 0.005 after ~6000 hydro steps x 10 radiation substeps — and, with the shared
     T^4 evaluation, the final state equals the oracle's full run in every bit."""
     from oracle.pyoracle import RADSHOCK
@@ -181,8 +189,9 @@ def test_uniform_advecting_executable_matches_oracle(tmp_path, oracle):
 
 
 def test_marshak_executable_meets_the_reference_criterion_and_matches_oracle(tmp_path, oracle):
-    """the reference's RadMarshak ctest through the C++ mirror: the mirror recognises the Marshak half-range condition and the T^4
-    material by sampling the problem's hooks (quokka_host.hpp buildDirichletModel / eosTemperatureModel); exit status 0 == radiation
+    """the reference's RadMarshak ctest through the C++ mirror: the problem's setCustomBoundaryConditions (the Marshak half-range
+    condition) runs as device code for every ghost cell beyond the face; its T^4 material is recognised on probe points and served by the
+    library's arithmetic (quokka_host.hpp eosTemperatureModel; anything else would be compiled, QK_HOOK_COMPILED); exit status 0 == radiation
     temperature within 2 per cent of Su & Olson's solution; the final state after 10135 steps equals the oracle's bit for bit."""
     from oracle.pyoracle import MARSHAK
     cwd = extern_tree(tmp_path, {"SuOlson/100pt_tau10p0.dat": "SuOlson_100pt_tau10p0.dat"})
@@ -195,7 +204,7 @@ def test_marshak_executable_meets_the_reference_criterion_and_matches_oracle(tmp
 
 def test_radiation_force_executable_meets_the_reference_criterion_and_matches_oracle(tmp_path, oracle):
     """the reference's RadForce ctest through the C++ mirror: isothermal EOS_Traits (gamma = 1, cs_isothermal), Planck opacity 0 with a
-    flux-mean opacity, inflow face sampled from setCustomBoundaryConditions (the upper face stays with its BCRec); exit status 0 ==
+    flux-mean opacity, inflow face filled by the problem's setCustomBoundaryConditions on the device (the upper face stays with its BCRec); exit status 0 ==
     Mach number within 0.002 of the steady wind; the final state after 9520 steps equals the oracle's bit for bit."""
     from oracle.pyoracle import RADFORCE
     cwd = extern_tree(tmp_path, {"pressure_tube/optically_thin_wind.txt": "optically_thin_wind.txt"})
@@ -207,9 +216,9 @@ def test_radiation_force_executable_meets_the_reference_criterion_and_matches_or
 
 
 def test_marshak_asymptotic_executable_meets_the_reference_criterion(tmp_path, oracle):
-    """the reference's RadMarshakAsymptotic ctest through the C++ mirror: the temperature power law of the opacity hooks is recognised by
-    sampling (opacity_model 2; T_ref = 1 K, so the product differs from the problem's own expression by rounding — no bit-level claim
-    here, that is tests/test_radhydro_gpu.py's); exit status 0 == gas temperature within 9 per cent of the similarity solution after
+    """the reference's RadMarshakAsymptotic ctest through the C++ mirror: the problem's opacity hooks (a temperature power law) are compiled
+    device code inside the Newton-Raphson kernel (quokka_amd/host/qk_problem_kernels.hpp), the oracle uses the closed power-law form of the
+    library — equal to rounding, no bit-level claim here (that is tests/test_radhydro_gpu.py's); exit status 0 == gas temperature within 9 per cent of the similarity solution after
     90847 steps, and the state agrees with the oracle's to 1e-6."""
     from oracle.pyoracle import MARSHAK_ASYMPTOTIC
     cwd = extern_tree(tmp_path, {"marshak_similarity.csv": "marshak_similarity.csv"})

@@ -171,8 +171,8 @@ def test_unmodified_two_group_marshak_wave_with_dust_meets_the_reference_criteri
 
 
 def test_unmodified_line_cooling_problem_meets_the_reference_criterion(tmp_path):
-    """RadLineCooling, unchanged: the problem's DefineNetCoolingRate / ...TempDerivative / DefineCosmicRayHeatingRate specialisations are sampled on the
-    host into the closed set (cooling linear in T, constant heating).  Exit status 0 = within 0.0005 of the analytic cooling curve."""
+    """RadLineCooling, unchanged: the problem's DefineNetCoolingRate / ...TempDerivative / DefineCosmicRayHeatingRate specialisations are
+    compiled into the single-group Newton-Raphson kernel of the problem's translation unit (qk_problem_kernels.hpp).  Exit status 0 = within 0.0005 of the analytic cooling curve."""
     rc, out = run([exe("ref_RadLineCooling"), os.path.join(HOST, "decks", "RadLineCooling.in")], str(tmp_path))
     assert rc == 0, out[-2500:]
 
