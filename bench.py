@@ -45,9 +45,12 @@ RAD_STREAM_WORDS = {"rad_PredictStep": 22, "rad_AddFluxesRK2": 24,
                     # qk_rad_stage_fused: X reads the state and writes the accumulator; Y reads both and writes the accumulator; Z reads state,
                     # accumulator and (stage 2) the old state and writes the state
                     "rad_sweep_x": 8, "rad_sweep_y": 12, "rad_sweep_z": 14}
-# Newton-Raphson exchange kernel (radSourceCell, single group, constant opacity): VALU instructions per cell outside / inside the Newton loop,
-# counted in the gfx950 ISA of qk_rad_ops.hip (profiles/round3/README.md)
-RAD_SOURCE_VALU_FIXED, RAD_SOURCE_VALU_PER_ITERATION = 900.0, 420.0
+# Newton-Raphson exchange kernel (radSourceCell, single group, constant opacity): VALU instructions per cell and call.  Measured: SQ_INSTS_VALU
+# = 1829 per cell at the shell's 2.65 Newton iterations per solve (profiles/round3/v2_shell256_pmc_SQ.txt); the split into a part outside and
+# a part inside the Newton loop follows the instruction count of the gfx950 ISA (profiles/tools/isa_count.py) scaled to that total
+RAD_SOURCE_VALU_FIXED, RAD_SOURCE_VALU_PER_ITERATION = 818.0, 382.0
+# qk_rad_stage_fused sweeps: measured SQ_INSTS_VALU per cell (same file), PLM
+RAD_SWEEP_VALU = {"rad_sweep_x": 618.0, "rad_sweep_y": 544.0, "rad_sweep_z": 620.0}
 
 
 def parse():
@@ -233,6 +236,9 @@ def run_shell(ctx, torch, ncell, mgs, steps, warmup, pow_mode):
         if k in per and per[k] > 0:
             roof[k] = {"bound": "hbm", "alg_bytes_per_cell": 8.0 * words, "ms_per_launch": per[k], "launches": launches[k],
                        "frac": 8.0 * words * total_cells / (per[k] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            if k in RAD_SWEEP_VALU:  # these are closer to the FP64 issue ceiling than to the HBM one: both fractions are reported
+                roof[k]["valu_instructions_per_cell"] = RAD_SWEEP_VALU[k]
+                roof[k]["frac_fp64_valu"] = RAD_SWEEP_VALU[k] * total_cells / (per[k] * 1e-3) / FP64_VALU_PEAK
     if per.get("rad_AddSourceTerms", 0) > 0:
         it = sim.rad_counters["newton_iterations"] / max(sim.rad_counters["solves"], 1)
         ops = RAD_SOURCE_VALU_FIXED + RAD_SOURCE_VALU_PER_ITERATION * it
@@ -249,7 +255,7 @@ def run_shell(ctx, torch, ncell, mgs, steps, warmup, pow_mode):
                        "solves_per_cell_and_source_call": sim.rad_counters["solves"] / max(2 * sim.radiationCellUpdates_, 1),
                        "max_newton_iterations": sim.rad_counters["max_newton_iterations"], "pow_mode": pow_mode, "sim_time": sim.tNew_,
                        "relative_mass_change": abs(mass1 - mass0) / mass0},
-            "roofline": {"kernels": roof, "note": "streaming kernels against 8 TB/s HBM; the Newton-Raphson kernel against the FP64 VALU issue rate"},
+            "roofline": {"kernels": roof, "note": "transport sweeps against 8 TB/s HBM (frac) and against the FP64 VALU issue rate (frac_fp64_valu; PLM instruction counts); the Newton-Raphson kernel against the FP64 VALU issue rate"},
             "kernels_ms_per_launch": per, "kernels_launches": launches,
             "reference_published_a100_1gpu": 39.04}
 
