@@ -301,11 +301,16 @@ class HydroSimulation:
         self.halfFlux = [MultiFab(lev, self.hydro.nvar_, 0, facedir=d) for d in range(nd)]
         self.halfVel = [MultiFab(lev, 1, 0, facedir=d) for d in range(nd)]
         self.redoFlag = MultiFab(lev, 1, 1, dtype=torch.int32, fill=0)
-        self.dev_counters = torch.zeros(2, dtype=torch.int64, device=ctx.device)  # [redo_count, (unused)]
-        self.dev_error = torch.zeros(1, dtype=torch.int32, device=ctx.device)
+        # the words a fused stage reports in — [max signal, max signal for dt] (double), [redo count] (int64) and the error flag of SyncDualEnergy
+        # (int32 in the fourth word) — share one allocation: one fill before the stage, one device -> host copy after it
+        self._dev_words = torch.zeros(4, dtype=torch.int64, device=ctx.device)
+        self.dev_counters = self._dev_words[2:3]  # [redo_count]
+        self.dev_error = self._dev_words[3:4].view(torch.int32)[0:1]
+        self._err_latched = False   # an error flag seen by a fused stage of the current advance (the words are cleared before every stage)
+        self._unfused_ran = False   # the reference-shaped operators ran in the current advance: they leave their flag in dev_error
         self.dev_max = torch.zeros(1, dtype=torch.float64, device=ctx.device)
         # [0] max(cs + sqrt(2KE/rho)), [1] max(cs + |v|) over state_new_cc_, written by the final fused stage
-        self.dev_signal = torch.zeros(2, dtype=torch.float64, device=ctx.device)
+        self.dev_signal = self._dev_words[0:2].view(torch.float64)
         self._signal_of_state_new = None  # (sig0, sig1) if the device values describe the current state_new_cc_
         self.scratch = None
         if self.use_fused:
@@ -453,6 +458,7 @@ class HydroSimulation:
     # ------------------------------------------------------------------ one RK stage
     def _stage_unfused(self, stage: int, U_in, U_old, U_out, dt, with_fofc: bool) -> bool:
         """One stage exactly as reference src/QuokkaSimulation.hpp:1099-1198 (stage 1) / 1202-1287 (stage 2)."""
+        self._unfused_ran = True
         t, lev, nd = self._tmp(), self.lev, self.geom.ndim
         self.computeHydroFluxes(U_in, t["flux"], t["vel"])
         if stage == 1:
@@ -513,9 +519,9 @@ class HydroSimulation:
         return (stage == 2) or (self.integratorOrder_ == 1)
 
     def _fused_begin(self, stage: int):
-        self.dev_counters.zero_()
-        if self._is_final(stage):
-            self.dev_signal.zero_()
+        if self._unfused_ran and not self._err_latched:  # (rare: an operator-path stage of this advance may have raised the flag)
+            self._err_latched = int(self.dev_error.item()) != 0
+        self._dev_words.zero_()  # (the signal words are only handed to the final stage; clearing them before stage 1 is harmless)
 
     def _fused_launch(self, stage: int, U_in, U_old, U_out, dt, group=None, fofc: bool = False):
         """one fused stage over all local boxes (group None) or over a sub-level (Level, [local box indices]); fofc: the first-order flux
@@ -554,13 +560,17 @@ class HydroSimulation:
         device->host copy, and with several ranks ONE all-reduce(MAX) of [sig0, sig1, count] instead of the three scalar
         collectives of the reference (dt, CFL check, redo count)"""
         final = self._is_final(stage)
-        v = torch.cat([self.dev_signal, self.dev_counters[0:1].to(torch.float64)]) if final else self.dev_counters[0:1].to(torch.float64)
         if self.nranks > 1:
             import torch.distributed as dist
             from . import comm
+            v = torch.cat([self.dev_signal, self._dev_words[2:4].to(torch.float64)])  # [sig0, sig1, redo count, error flag]
             comm.all_reduce(v, dist.ReduceOp.MAX)
-        vals = v.tolist()
-        nbad = int(vals[-1])
+            vals = v.tolist()
+        else:  # one copy of the four words, no conversion kernels
+            h = self._dev_words.cpu()
+            vals = h[0:2].view(torch.float64).tolist() + [float(int(h[2])), float(int(h[3]) & 0xFFFFFFFF)]
+        self._err_latched = self._err_latched or vals[3] != 0.0
+        nbad = int(vals[2])
         if final and nbad == 0:
             self._signal_of_state_new = (vals[0], vals[1])  # global maxima
         return nbad
@@ -651,6 +661,7 @@ class HydroSimulation:
     # ------------------------------------------------------------------ advance
     def advanceHydroAtLevel(self, state_old_tmp: MultiFab, dt_lev: float) -> bool:
         self._signal_of_state_new = None  # state_new_cc_ is about to be overwritten
+        self._err_latched, self._unfused_ran = False, False
         if not self._fill_and_stage(1, state_old_tmp, state_old_tmp, self.state_inter_cc_, dt_lev):
             return False
         if self.integratorOrder_ == 2:
@@ -659,7 +670,7 @@ class HydroSimulation:
         else:
             for b in range(self.lev.nboxes):
                 self.state_new_cc_.valid(b)[0:6].copy_(self.state_inter_cc_.valid(b)[0:6])  # ncompHydro_ comps only (QuokkaSimulation.hpp:1289)
-        if int(self.dev_error.item()) != 0:
+        if self._err_latched or (self._unfused_ran and int(self.dev_error.item()) != 0):
             raise capi.QkError("density is negative in SyncDualEnergy! abort!! (reference src/hydro/hydro_system.hpp:834-836)")
         return not self.isCflViolated(dt_lev)
 
