@@ -175,6 +175,11 @@ int qk_hydro_maxSignalSpeedLocal(qk_level *lev, qk_stream s, const qk_hydro_trai
 int qk_replaceFluxes(qk_level *lev, qk_stream s, int dir, qk_array4 *flux, const qk_array4 *FOflux, const qk_iarray4 *redoFlag, int face_ncomp);
 /* MultiFab::Saxpy(dst, a, src, 0, 0, ncomp, 0) on the face boxes of `dir` (dir = -1: cell boxes)   reference src/QuokkaSimulation.hpp:1105-1108 */
 int qk_Saxpy(qk_level *lev, qk_stream s, int dir, qk_array4 *dst, double a, const qk_array4 *src, int ncomp);
+/* FixupState(lev) = EnforceLimits + SyncDualEnergy (use_dual_energy == 1) in one pass, with the CFL maxima of the result — maxSignalSpeedLocal
+ * which = 0 into d_max_signal[0], which = 1 into [1], cleared first; NULL: not computed      reference src/QuokkaSimulation.hpp:761-770 */
+int qk_hydro_FixupState(qk_level *lev, qk_stream s, const qk_hydro_traits *t, double densityFloor, double tempFloor, int use_dual_energy, qk_array4 *state,
+			int *d_error_flag, double *d_max_signal);
+
 
 /* ------------------------------------------------------------------ LinearAdvectionSystem<problem_t> (reference src/linear_advection/linear_advection.hpp)
  * the scalar advection solver shares HyperbolicSystem's reconstruction (qk_ReconstructStates*); its own operators: */

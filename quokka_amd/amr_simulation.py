@@ -215,8 +215,7 @@ class AmrLevelSim(HydroSimulation):
         return False
 
     def FixupState(self):
-        self._limits_and_sync(self.state_new_cc_)
-        self._signal_of_state_new = None
+        self._fixup_state(self.state_new_cc_)
 
 
 class RadAmrLevelSim(AmrLevelSim, RadhydroSimulation):

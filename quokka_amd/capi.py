@@ -157,6 +157,7 @@ def lib() -> C.CDLL:
     L.qk_rad_computeRadiationFluxes.argtypes = [vp, vp, R, ci, ci, vp, P(vp)]
     L.qk_rad_PredictStep.argtypes = [vp, vp, R, ci, vp, vp, P(vp), cd, P(cd)]
     L.qk_rad_AddFluxesRK2.argtypes = [vp, vp, R, ci, vp, vp, vp, P(vp), P(vp), cd, P(cd)]
+    L.qk_hydro_FixupState.argtypes = [vp, vp, T, cd, cd, ci, vp, vp, vp]
     L.qk_rad_stage_fused.argtypes = [vp, vp, R, ci, ci, vp, vp, vp, vp, P(vp), cd, P(cd)]
     L.qk_rad_AddSourceTermsSingleGroup.argtypes = [vp, vp, R, T, vp, vp, cd, ci, vp, vp]
     L.qk_rad_AddSourceTermsMultiGroup.argtypes = [vp, vp, R, T, vp, vp, cd, ci, vp, vp]
@@ -231,7 +232,7 @@ DECLARED_SYMBOLS = [
     "qk_hydro_ConservedToPrimitive", "qk_hydro_ComputeFlatteningCoefficients", "qk_hydro_FlattenShocks",
     "qk_hydro_ComputeFluxes", "qk_hydro_ComputeRhsFromFluxes", "qk_hydro_AddInternalEnergyPdV", "qk_hydro_PredictStep",
     "qk_hydro_EnforceLimits", "qk_hydro_SyncDualEnergy", "qk_hydro_ComputeMaxSignalSpeed", "qk_hydro_maxSignalSpeedLocal",
-    "qk_replaceFluxes", "qk_Saxpy", "qk_hydro_stage_scratch_bytes", "qk_hydro_stage_fused",
+    "qk_replaceFluxes", "qk_Saxpy", "qk_hydro_FixupState", "qk_hydro_stage_scratch_bytes", "qk_hydro_stage_fused",
     "qk_rad_ConservedToPrimitive", "qk_rad_ComputeFluxes", "qk_rad_computeRadiationFluxes", "qk_rad_PredictStep", "qk_rad_AddFluxesRK2", "qk_rad_stage_fused",
     "qk_rad_AddSourceTermsSingleGroup", "qk_rad_AddSourceTermsMultiGroup", "qk_rad_mg_planck_fractions",
     "qk_ghost_plan_create", "qk_ghost_plan_destroy", "qk_ghost_plan_num_peers", "qk_ghost_plan_peer", "qk_ghost_plan_num_items", "qk_ghost_plan_item",

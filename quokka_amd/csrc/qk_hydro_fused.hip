@@ -1034,6 +1034,24 @@ __global__ void __launch_bounds__(64 * MARCH_BY) k_sweep_march(SweepArgs a, Eos 
 
 // segments along the march axis `dir` (transverse axes 0 and `ot`): enough threads to fill the chip when the level has few columns, at
 // least 16 cells per segment (each segment re-marches 6 cells of warm-up); 1 for the large levels (one column per thread is enough)
+inline auto smallLevelCells() -> int64_t
+{
+	static const int64_t v = [] {
+		const char *e = std::getenv("QK_SMALL_LEVEL_CELLS");
+		return (e != nullptr) ? static_cast<int64_t>(std::atoll(e)) : static_cast<int64_t>(2) << 20;
+	}();
+	return v;
+}
+
+inline auto smallMinLen() -> int
+{
+	static const int v = [] {
+		const char *e = std::getenv("QK_SMALL_MINLEN");
+		return (e != nullptr) ? std::max(1, std::atoi(e)) : 4;
+	}();
+	return v;
+}
+
 auto marchSegments(const qk_level *lev, int dir, int ot) -> int
 {
 	if (const char *e = std::getenv("QK_MARCH_SEGMENTS")) {
@@ -1041,7 +1059,10 @@ auto marchSegments(const qk_level *lev, int dir, int ot) -> int
 	}
 	const int64_t cols = static_cast<int64_t>(lev->nboxes) * lev->maxlen[0] * lev->maxlen[ot];
 	const int64_t want = (131072 + cols - 1) / std::max<int64_t>(cols, 1);
-	const int cap = std::max(1, lev->maxlen[dir] / 16);
+	// a small level (the refined levels of a young hierarchy: a few 32^3 boxes) is bound by the length of one thread's march, not by the
+	// redundant warm-up cells: segments of 4 cells there (8 -> 4: +2 % on the young Sedov hierarchy, 2 no better)
+	const int minlen = (cols * lev->maxlen[dir] < smallLevelCells()) ? smallMinLen() : 16;
+	const int cap = std::max(1, lev->maxlen[dir] / minlen);
 	return static_cast<int>(std::min<int64_t>(std::max<int64_t>(want, 1), std::min(cap, 16)));
 }
 
@@ -1222,8 +1243,10 @@ int qk_hydro_stage_fused(qk_level *lev, qk_stream stream, const qk_hydro_traits 
 		ProfScope ps(ctx, s, "k_pre");
 		const int xt = (lev->maxlen[0] + 2 + PT_X - 1) / PT_X, yt = (lev->maxlen[1] + 2 + PT_Y - 1) / PT_Y;
 		// enough workgroups for ~4 per CU; every z segment pays 6 planes of warm-up (own columns only), so keep >= 24 planes per segment
+		// (a small level: shorter segments, see marchSegments)
+		const bool small = static_cast<int64_t>(lev->nboxes) * lev->maxlen[0] * lev->maxlen[1] * lev->maxlen[2] < smallLevelCells();
 		int nseg = static_cast<int>(std::min<int64_t>((1024 + static_cast<int64_t>(xt) * yt * lev->nboxes - 1) / (static_cast<int64_t>(xt) * yt * lev->nboxes),
-							      std::max(1, (lev->maxlen[2] + 2) / 24)));
+							      std::max(1, (lev->maxlen[2] + 2) / (small ? smallMinLen() : 24))));
 		if (const char *e = std::getenv("QK_PRE_SEGMENTS")) {
 			nseg = std::max(1, std::atoi(e));
 		}

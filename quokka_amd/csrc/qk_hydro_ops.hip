@@ -612,12 +612,105 @@ __global__ void __launch_bounds__(256) k_maxSignal(const qk_box *boxes, const qk
 		const double v = signalSpeed(eos, which, U.p[c + U.ns * RHO], U.p[c + U.ns * MX], U.p[c + U.ns * MY], U.p[c + U.ns * MZ], U.p[c + U.ns * ENE]);
 		m = smax(m, v);
 	}
-	// wave reduction (64 lanes), then one atomic per wave
+	// wave reduction (64 lanes), workgroup reduction, then one atomic per workgroup (atomics on one word serialise: one per wave made this
+	// kernel three times slower than its memory traffic)
+	__shared__ double red[4];
 	for (int off = 32; off > 0; off >>= 1) {
 		m = smax(m, __shfl_xor(m, off));
 	}
 	if ((threadIdx.x & 63) == 0) {
-		atomicMaxNonNeg(result, m);
+		red[threadIdx.x >> 6] = m;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		atomicMaxNonNeg(result, smax(smax(red[0], red[1]), smax(red[2], red[3])));
+	}
+}
+
+__global__ void __launch_bounds__(256) k_fixupState(const qk_box *boxes, qk_array4 *state_t, Eos eos, double densityFloor, double tempFloor, int use_dual_energy,
+						    int nscalars, int nmscalars, int *d_error_flag, double *result)
+{
+	const int b = blockIdx.y;
+	const qk_box bx = boxes[b];
+	const int len0 = bx.hi[0] - bx.lo[0] + 1, len1 = bx.hi[1] - bx.lo[1] + 1, len2 = bx.hi[2] - bx.lo[2] + 1;
+	const int64_t ncell = static_cast<int64_t>(len0) * len1 * len2;
+	WA4 S(state_t[b]);
+	double m0 = 0.0, m1 = 0.0;
+	for (int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < ncell; t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+		const int k = static_cast<int>(t / (static_cast<int64_t>(len0) * len1));
+		const int r = static_cast<int>(t - static_cast<int64_t>(k) * len0 * len1);
+		const int j = r / len0;
+		const int i = r - j * len0;
+		const int64_t c = S.idx(bx.lo[0] + i, bx.lo[1] + j, bx.lo[2] + k);
+		double U[NVAR];
+#pragma unroll
+		for (int n = 0; n < NVAR; ++n) {
+			U[n] = S.p[c + S.ns * n];
+		}
+		// EnforceLimits (hydro_system.hpp:700-773), as qk_hydro_EnforceLimits
+		if (nscalars > 0 && U[RHO] < densityFloor) {
+			for (int n = 0; n < nscalars; ++n) {
+				auto &q = S.p[c + S.ns * (NVAR + n)];
+				q = (densityFloor == 0.0) ? 0.0 : q * (U[RHO] / densityFloor);
+			}
+		}
+		if (nmscalars > 0) {
+			const double rho_new = (U[RHO] < densityFloor) ? densityFloor : U[RHO];
+			double sp_sum = 0.0;
+			for (int idx = 0; idx < nmscalars; ++idx) {
+				auto &q = S.p[c + S.ns * (NVAR + idx)];
+				if (q < 0.0) {
+					q = 1.0e-30 * rho_new;
+				}
+				sp_sum += q;
+			}
+			if ((sp_sum > 2.2250738585072014e-308) && (rho_new > 2.2250738585072014e-308)) {
+				sp_sum /= rho_new;
+				for (int idx = 0; idx < nmscalars; ++idx) {
+					S.p[c + S.ns * (NVAR + idx)] /= sp_sum;
+				}
+			}
+		}
+		enforceLimits(eos, densityFloor, tempFloor, U);
+		// SyncDualEnergy (:825-849), as qk_hydro_SyncDualEnergy: a cell with rho <= 0 raises the flag and keeps its energies
+		if (use_dual_energy == 1) {
+			double V[NVAR];
+#pragma unroll
+			for (int n = 0; n < NVAR; ++n) {
+				V[n] = U[n];
+			}
+			if (!syncDualEnergy(V)) {
+				if (d_error_flag != nullptr) {
+					*d_error_flag = 1;
+				}
+			} else {
+				U[ENE] = V[ENE];
+				U[EINT] = V[EINT];
+			}
+		}
+		S.p[c + S.ns * RHO] = U[RHO];
+		S.p[c + S.ns * ENE] = U[ENE];
+		S.p[c + S.ns * EINT] = U[EINT];
+		if (result != nullptr) {
+			m0 = smax(m0, signalSpeed(eos, 0, U[RHO], U[MX], U[MY], U[MZ], U[ENE]));
+			m1 = smax(m1, signalSpeed(eos, 1, U[RHO], U[MX], U[MY], U[MZ], U[ENE]));
+		}
+	}
+	if (result != nullptr) { // wave, then workgroup, then one pair of atomics per workgroup (they serialise on the two result words)
+		__shared__ double red[2][4];
+		for (int off = 32; off > 0; off >>= 1) {
+			m0 = smax(m0, __shfl_xor(m0, off));
+			m1 = smax(m1, __shfl_xor(m1, off));
+		}
+		if ((threadIdx.x & 63) == 0) {
+			red[0][threadIdx.x >> 6] = m0;
+			red[1][threadIdx.x >> 6] = m1;
+		}
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			atomicMaxNonNeg(result, smax(smax(red[0][0], red[0][1]), smax(red[0][2], red[0][3])));
+			atomicMaxNonNeg(result + 1, smax(smax(red[1][0], red[1][1]), smax(red[1][2], red[1][3])));
+		}
 	}
 }
 } // namespace
@@ -655,13 +748,43 @@ int qk_hydro_maxSignalSpeedLocal(qk_level *lev, qk_stream s, const qk_hydro_trai
 	const Eos eos(*t);
 	QK_HIP_CHECK(lev->ctx, hipMemsetAsync(d_result, 0, sizeof(double), static_cast<hipStream_t>(s)));
 	const int64_t ncell = static_cast<int64_t>(lev->maxlen[0]) * lev->maxlen[1] * lev->maxlen[2];
-	const unsigned gx = static_cast<unsigned>(std::min<int64_t>((ncell + 255) / 256, 1024));
+	const unsigned gx = static_cast<unsigned>(std::min<int64_t>((ncell + 255) / 256, 512));
 	if (lev->nboxes == 0) {
 		return QK_OK;
 	}
 	hipLaunchKernelGGL(k_maxSignal, dim3(gx, lev->nboxes, 1), dim3(256, 1, 1), 0, static_cast<hipStream_t>(s), lev->d_boxes, cons_t, eos, which,
 			   d_result);
 	return launchStatus(lev, "maxSignalSpeedLocal");
+}
+
+// FixupState of a level (reference src/QuokkaSimulation.hpp:761-770): EnforceLimits, then SyncDualEnergy, in one pass over the state, with the
+// two CFL maxima of the result (maxSignalSpeedLocal which = 0 / 1) reduced on the way out — what an AMR hierarchy runs on every level after
+// reflux + average-down and then needs for the next time step.  Per cell the statements of the two operators above in their order.
+int qk_hydro_FixupState(qk_level *lev, qk_stream s, const qk_hydro_traits *t, double densityFloor, double tempFloor, int use_dual_energy, qk_array4 *state_t,
+			int *d_error_flag, double *d_max_signal)
+{
+	if (lev == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	if (int rc = checkTraits(lev->ctx, t); rc != QK_OK) {
+		return rc;
+	}
+	if (int rc = needsLibraryEos(lev->ctx, t, "FixupState"); rc != QK_OK) {
+		return rc;
+	}
+	QK_REQUIRE(lev->ctx, state_t, "FixupState: NULL array");
+	if (d_max_signal != nullptr) {
+		QK_HIP_CHECK(lev->ctx, hipMemsetAsync(d_max_signal, 0, 2 * sizeof(double), static_cast<hipStream_t>(s)));
+	}
+	if (lev->nboxes == 0) {
+		return QK_OK;
+	}
+	const Eos eos(*t);
+	const int64_t ncell = static_cast<int64_t>(lev->maxlen[0]) * lev->maxlen[1] * lev->maxlen[2];
+	const unsigned gx = static_cast<unsigned>(std::min<int64_t>((ncell + 255) / 256, 512)); // (grid-stride: a few thousand workgroups in all)
+	hipLaunchKernelGGL(k_fixupState, dim3(gx, lev->nboxes, 1), dim3(256, 1, 1), 0, static_cast<hipStream_t>(s), lev->d_boxes, state_t, eos, densityFloor, tempFloor,
+			   use_dual_energy, t->nscalars, t->nmscalars, d_error_flag, d_max_signal);
+	return launchStatus(lev, "FixupState");
 }
 
 // ------------------------------------------------------------------------------------------------

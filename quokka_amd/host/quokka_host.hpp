@@ -1597,11 +1597,34 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 			return;
 		}
 		this->activate();
-		HydroSystem<problem_t>::EnforceLimits(densityFloor_, tempFloor_, state_new_cc_[0]);
-		if (useDualEnergy_ == 1) {
-			HydroSystem<problem_t>::SyncDualEnergy(state_new_cc_[0], d_error_);
+		// EnforceLimits + SyncDualEnergy in one pass that also reduces the CFL maxima of the result (qk_hydro_FixupState); they stay on the device
+		// until the next time step asks for them (resolveSignal)
+		if (d_fixSignal_ == nullptr) {
+			QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_fixSignal_), 2 * sizeof(double)));
 		}
+		auto t = qkhost::traits<problem_t>();
+		qkhost::check(qk_hydro_FixupState(this->levelHandle(), nullptr, &t, densityFloor_, tempFloor_, useDualEnergy_, qkhost::tab(state_new_cc_[0]), d_error_,
+						  d_fixSignal_),
+			      "qk_hydro_FixupState");
+		invalidateSignal();
+		signalPending_ = true;
+	}
+	void invalidateSignal()
+	{
 		haveSignal_ = false;
+		signalPending_ = false;
+	}
+	// the CFL maxima FixupState left on the device, over all ranks (every rank calls this at the same points: computeTimestepAtLevel)
+	void resolveSignal()
+	{
+		if (!haveSignal_ && signalPending_) {
+			QK_HOST_HIP(hipMemcpy(signal_, d_fixSignal_, 2 * sizeof(double), hipMemcpyDeviceToHost));
+			if (qkhost::Comm::get().size > 1) {
+				qkhost::Comm::get().allReduce(signal_, 2, qkhost::Comm::Op::max);
+			}
+			haveSignal_ = true;
+			signalPending_ = false;
+		}
 	}
 	// CFL time step of this level alone (reference src/simulation.hpp:703-720)
 	[[nodiscard]] auto computeTimestepAtLevel() -> double
@@ -1611,6 +1634,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		if constexpr (!Physics_Traits<problem_t>::is_hydro_enabled) { // radiation only (reference src/QuokkaSimulation.hpp:421-424)
 			m = RadSystem<problem_t>::c_hat_;
 		} else {
+			resolveSignal();
 			m = (haveSignal_ ? signal_[1] : HydroSystem<problem_t>::maxSignalSpeedLocal(state_new_cc_[0], 1));
 		}
 		if constexpr (is_radiation_enabled_ && Physics_Traits<problem_t>::is_hydro_enabled) { // :421-434
@@ -1738,19 +1762,19 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	void createInitialParticles();
 	void computeBeforeTimestep();
 	// the two user hooks as the drivers call them: a specialised hook may change the state, so the signal speeds cached by the last stage are dropped
-	void dropCachedSignal() { haveSignal_ = false; }
+	void dropCachedSignal() { invalidateSignal(); }
 	void callAfterTimestep()
 	{
 		computeAfterTimestep();
 		if (!afterTimestepIsDefault_) {
-			haveSignal_ = false;
+			invalidateSignal();
 		}
 	}
 	void callBeforeTimestep()
 	{
 		computeBeforeTimestep();
 		if (!beforeTimestepIsDefault_) {
-			haveSignal_ = false;
+			invalidateSignal();
 		}
 	}
 	void computeReferenceSolution(amrex::MultiFab & /*ref*/, amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> const & /*dx*/,
@@ -1766,6 +1790,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 			static_assert(is_radiation_enabled_, "At least one of hydro or radiation must be enabled! Cannot compute a time step.");
 			m = RadSystem<problem_t>::c_hat_;
 		} else {
+			resolveSignal();
 			m = (haveSignal_ ? signal_[1] : HydroSystem<problem_t>::maxSignalSpeedLocal(state_new_cc_[0], 1));
 		}
 		if constexpr (is_radiation_enabled_ && Physics_Traits<problem_t>::is_hydro_enabled) {
@@ -1904,7 +1929,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 
 	auto advanceHydroAtLevel(amrex::MultiFab &state_old_cc_tmp, double time, double dt_lev) -> bool
 	{
-		haveSignal_ = false;
+		invalidateSignal();
 		// first half of the Strang-split source terms, on the (temporary) old state (reference src/QuokkaSimulation.hpp:1048)
 		addStrangSplitSources(state_old_cc_tmp, 0, time, 0.5 * dt_lev);
 		fillTime_ = time; // reference src/QuokkaSimulation.hpp:1076 (stage 1), :1204 (stage 2: time + dt_lev)
@@ -1929,7 +1954,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		if (ok) { // second half, on the new state (:1318)
 			addStrangSplitSources(state_new_cc_[0], 0, time + dt_lev, 0.5 * dt_lev);
 			if (!strangSourcesAreDefault_) {
-				haveSignal_ = false;
+				invalidateSignal();
 			}
 		}
 		if (ok && afterAdvance_) {
@@ -1940,6 +1965,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 
 	auto isCflViolated(double dt_actual) -> bool // reference src/QuokkaSimulation.hpp:992-1013
 	{
+		resolveSignal();
 		double const max_signal = haveSignal_ ? signal_[0] : HydroSystem<problem_t>::maxSignalSpeedLocal(state_new_cc_[0], 0);
 		double const dt_cfl = cflNumber_ * (minDx() / max_signal);
 		return dt_actual > (1.1 * dt_cfl);
@@ -2040,7 +2066,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		if (!(nsubSteps >= 1 && nsubSteps <= maxSubsteps_ + 1 && dt_radiation > 0.0)) {
 			amrex::Abort("radiation substep assertion failed (reference src/QuokkaSimulation.hpp:1596-1598)");
 		}
-		haveSignal_ = false; // the source terms change the gas state
+		invalidateSignal(); // the source terms change the gas state
 		double time_subcycle = time;
 		int const r0 = RadSystem<problem_t>::nstartHyperbolic_;
 		// Newton counters: one slot of 4 ints per substep (a slot stays below 2^31 at any box size); one host read per level advance
@@ -2106,6 +2132,8 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	int64_t scratchBytes_ = 0;
 	double signal_[2] = {0, 0};
 	bool haveSignal_ = false;
+	bool signalPending_ = false; // d_fixSignal_ holds the maxima of the current state_new_cc_
+	double *d_fixSignal_ = nullptr;
 	// Set by the DEFAULT addStrangSplitSources (which does nothing else), known after the first call.  Without a specialised hook the advance
 	// needs no private copy of the old state (nothing modifies it: the stages read U_old and write elsewhere) and the signal speeds of the
 	// final stage's epilogue stay valid for the next computeTimestep: 0.4 ms (copy) + 0.4 ms (k_maxSignal) per Sedov 256^3 step.

@@ -75,7 +75,7 @@ class RadhydroSimulation(HydroSimulation):
     def computeTimestepAtLevel(self) -> float:
         if not self.is_hydro_enabled:  # QuokkaSimulation.hpp:421-424, radiation only: the signal speed is c_hat in every cell
             return self.cflNumber_ * (self.min_dx() / self.rad_traits.c_hat)
-        if self._signal_of_state_new is not None:
+        if self._signal() is not None:
             m = self._signal_of_state_new[1]
         else:
             m = float(self.hydro.maxSignalSpeedLocal(self.lev, self.state_new_cc_, which=1, out=self.dev_max).item())

@@ -311,6 +311,10 @@ class HydroSimulation:
         self.dev_max = torch.zeros(1, dtype=torch.float64, device=ctx.device)
         # [0] max(cs + sqrt(2KE/rho)), [1] max(cs + |v|) over state_new_cc_, written by the final fused stage
         self.dev_signal = self._dev_words[0:2].view(torch.float64)
+        # FixupState (an AMR hierarchy, after reflux + average-down) leaves its CFL maxima and error flag in words of its own: [sig0, sig1]
+        # (double), [error flag] (sticky); they are read when the next time step is computed
+        self._dev_fix = torch.zeros(4, dtype=torch.int64, device=ctx.device)
+        self._fix_words_pending = False
         self._signal_of_state_new = None  # (sig0, sig1) if the device values describe the current state_new_cc_
         self.scratch = None
         if self.use_fused:
@@ -357,8 +361,36 @@ class HydroSimulation:
         return min(self.geom.dx[: self.geom.ndim])
 
     # ------------------------------------------------------------------ time step control
+    @property
+    def _signal_of_state_new(self):
+        return self.__dict__.get("_sig_cache")
+
+    @_signal_of_state_new.setter
+    def _signal_of_state_new(self, v):  # (None: state_new_cc_ changed — whatever FixupState left on the device no longer describes it)
+        self.__dict__["_sig_cache"] = v
+        self._fix_words_pending = False
+
+    def _fixup_state(self, state: MultiFab):
+        """FixupState (reference src/QuokkaSimulation.hpp:761-770): EnforceLimits + SyncDualEnergy in one pass that also reduces the CFL maxima of
+        the result; they stay on the device until _signal() is asked"""
+        c = self.ctx
+        c.check(c.L.qk_hydro_FixupState(self.lev.h, c.stream(), C.byref(self.traits), float(self.densityFloor_), float(self.tempFloor_), int(self.useDualEnergy_),
+                                        state.ptr, C.c_void_p(self._dev_fix.data_ptr() + 16), C.c_void_p(self._dev_fix.data_ptr())), "qk_hydro_FixupState")
+        self._signal_of_state_new = None
+        self._fix_words_pending = state is self.state_new_cc_
+
+    def _signal(self):
+        """(max signal of maxSignalSpeedLocal, of ComputeMaxSignalSpeed) over all ranks if known for the current state_new_cc_, else None"""
+        if self._signal_of_state_new is None and self._fix_words_pending:
+            h = self._dev_fix.cpu()
+            if int(h[2]) & 0xFFFFFFFF:
+                raise capi.QkError("density is negative in SyncDualEnergy! abort!! (reference src/hydro/hydro_system.hpp:834-836)")
+            sig = h[0:2].view(torch.float64).tolist()
+            self._signal_of_state_new = (self._allreduce_max(sig[0]), self._allreduce_max(sig[1]))
+        return self._signal_of_state_new
+
     def computeTimestepAtLevel(self) -> float:
-        if self._signal_of_state_new is not None:
+        if self._signal() is not None:
             m = self._signal_of_state_new[1]  # already reduced over ranks
         else:
             m = self._allreduce_max(float(self.hydro.maxSignalSpeedLocal(self.lev, self.state_new_cc_, which=1, out=self.dev_max).item()))
@@ -379,7 +411,7 @@ class HydroSimulation:
         self.dt_ = dt_0
 
     def isCflViolated(self, dt_actual: float) -> bool:
-        if self._signal_of_state_new is not None:
+        if self._signal() is not None:
             m = self._signal_of_state_new[0]  # already reduced over ranks
         else:
             m = self._allreduce_max(float(self.hydro.maxSignalSpeedLocal(self.lev, self.state_new_cc_, which=0, out=self.dev_max).item()))

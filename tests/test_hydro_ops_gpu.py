@@ -1,4 +1,5 @@
 """GPU parity of every reference-shaped hydro operator (C-ABI) against the CPU oracle: bit-exact."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -160,3 +161,44 @@ def test_hlld_stub_fluxes_bit_exact_random_3d(ctx, oracle, reconstruct_eint):
         assert not np.array_equal(Fg[d][:5], Fc[d][:5])
         # same physics: the two approximate solvers agree to a few per cent of the flux scale on these smooth random states
         assert np.abs(Fg[d][:5] - Fc[d][:5]).sum() < 0.2 * np.abs(Fc[d][:5]).sum()
+
+
+@pytest.mark.parametrize("nscalars,dual", [(0, 1), (2, 1), (0, 0)])
+def test_fixup_state_equals_its_three_operators(ctx, nscalars, dual):
+    """qk_hydro_FixupState (EnforceLimits + SyncDualEnergy in one pass, CFL maxima reduced on the way out: what every level of an AMR hierarchy
+    runs after reflux + average-down, reference src/QuokkaSimulation.hpp:761-770) against qk_hydro_EnforceLimits, qk_hydro_SyncDualEnergy and
+    qk_hydro_maxSignalSpeedLocal(0 / 1) on a state with cells under the density floor, under the temperature floor and on both branches of the
+    dual-energy switch: state and both maxima bit for bit, two boxes, ghost cells untouched."""
+    rng = np.random.default_rng(11)
+    tr = capi.traits(1.4, True, 3)
+    tr.nscalars = nscalars
+    nc = 6 + nscalars
+    boxes = [([0, 0, 0], [15, 11, 9]), ([16, 0, 0], [31, 11, 9])]
+    lev = Level(ctx, 3, boxes)
+    hs = HydroSystem(tr)
+    A, B = MultiFab(lev, nc, 4), MultiFab(lev, nc, 4)
+    for b, (lo, hi) in enumerate(boxes):
+        shape = tuple(hi[d] - lo[d] + 1 + 8 for d in (2, 1, 0))
+        U = np.zeros((nc,) + shape)
+        U[:6] = random_state(rng, shape)
+        U[0] = np.where(rng.random(shape) < 0.1, 1e-4, U[0])            # below the density floor
+        U[4] = np.where(rng.random(shape) < 0.1, 0.5 * (U[1] ** 2 + U[2] ** 2 + U[3] ** 2) / U[0] * (1 + 1e-6), U[4])  # Eint_cons <= eta Etot; cold
+        for n in range(nscalars):
+            U[6 + n] = rng.random(shape)
+        A.set_fab(b, U)
+        B.set_fab(b, U)
+    rho_floor, T_floor = 1e-2, 1.2e-8  # (code units: T = P / rho x 1.2e-8 K here, so part of the cells is colder)
+    err = torch.zeros(1, dtype=torch.int32, device=ctx.device)
+    hs.EnforceLimits(lev, rho_floor, T_floor, A)
+    if dual:
+        hs.SyncDualEnergy(lev, A, err)
+    want = [float(hs.maxSignalSpeedLocal(lev, A, which=w).item()) for w in (0, 1)]
+    sig = torch.full((2,), -1.0, dtype=torch.float64, device=ctx.device)
+    err2 = torch.zeros(1, dtype=torch.int32, device=ctx.device)
+    ctx.check(ctx.L.qk_hydro_FixupState(lev.h, ctx.stream(), C.byref(tr), rho_floor, T_floor, dual, B.ptr, C.c_void_p(err2.data_ptr()), C.c_void_p(sig.data_ptr())),
+              "qk_hydro_FixupState")
+    torch.cuda.synchronize()
+    for b in range(2):
+        assert np.array_equal(A.fab_numpy(b), B.fab_numpy(b)), b
+    assert sig.tolist() == want and int(err.item()) == int(err2.item()) == 0
+    assert float((B.valid(0)[0] == rho_floor).sum()) > 0  # the floor acted
