@@ -719,7 +719,17 @@ template <typename T> class FabArrayT
 			offsets_.push_back(total_);
 			total_ += fb.numPts() * ncomp;
 		}
-		QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_data_), sizeof(T) * std::max<Long>(total_, 1)));
+		// Some of the reference's problem files initialise the radiation components of a state that has none (HydroBlast2D's
+		// setInitialConditionsOnGrid writes radEnergy_index .. x3RadFlux_index with is_radiation_enabled = false): four components past the end
+		// of the fab.  AMReX's arena hands out fabs from large chunks, so the stray writes land in memory nobody reads; here the last fab of a
+		// cell-centred state array is followed by the same amount of slack instead of the end of the allocation.
+		Long slack = 0;
+		if (facedir < 0 && ncomp >= 5) {
+			for (auto const &fb : fabboxes_) {
+				slack = std::max<Long>(slack, 4 * fb.numPts());
+			}
+		}
+		QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_data_), sizeof(T) * std::max<Long>(total_ + slack, 1)));
 		// fresh storage reads as zero (what the Python drivers' MultiFab(fill = 0) gives); QK_POISON=1 fills it with NaN bit patterns
 		// instead, which makes any read of a cell that was never written visible in the results (debugging aid)
 		QK_HOST_HIP(hipMemset(d_data_, std::getenv("QK_POISON") != nullptr ? 0xFF : 0, sizeof(T) * std::max<Long>(total_, 1)));

@@ -787,7 +787,7 @@ template <typename problem_t> void QuokkaSimulation<problem_t>::setInitialCondit
 	int max_level = 0;
 	amrex::ParmParse pa("amr");
 	pa.query("max_level", max_level);
-	if (max_level > 0 && AMREX_SPACEDIM != 2) {
+	if (max_level > 0) {
 		amr_ = std::make_shared<AmrDriver<problem_t>>(*this);
 		amr_->setInitialConditions();
 	} else {

@@ -167,3 +167,62 @@ def test_flux_register_conserves_the_composite_integral_with_random_fluxes(ctx, 
             near &= ((k >= clo[2]) & (k <= chi[2])) | ((k + 16 >= clo[2]) & (k + 16 <= chi[2])) | ((k - 16 >= clo[2]) & (k - 16 <= chi[2]))
             far &= ~near
     assert far.sum() > 0 and np.array_equal(after[:, far], Uc[:, far])
+
+
+def test_flux_register_conserves_the_composite_integral_in_two_dimensions(ctx):
+    """the same brute-force audit on a 2-D hierarchy (AMREX_SPACEDIM = 2 builds: two fine faces per coarse face, four children per parent)"""
+    nc, nd = 3, 2
+    dom_c, dom_f = [32, 16, 1], [64, 32, 1]
+    crse_boxes = [([0, 0, 0], [15, 15, 0]), ([16, 0, 0], [31, 15, 0])]
+    fine_boxes = [([0, 8, 0], [15, 23, 0]), ([16, 8, 0], [39, 23, 0]), ([24, 0, 0], [47, 7, 0])]
+    crse, fine = Level(ctx, 2, crse_boxes), Level(ctx, 2, fine_boxes)
+    cgeom = Geometry(2, dom_c, [0.0] * 3, [2.0, 1.0, 1.0], [1, 1, 0])
+    dxc = cgeom.dx
+    dxf = [dxc[0] / 2, dxc[1] / 2, 1.0]
+    rng = np.random.default_rng(34)
+
+    def global_faces(dom):
+        return [rng.standard_normal((nc, 1, dom[1], dom[0])) for _ in range(nd)]
+
+    def div(F, dx):
+        out = np.zeros_like(F[0])
+        for d in range(nd):
+            out += (F[d] - np.roll(F[d], -1, axis=3 - d)) / dx[d]
+        return out
+
+    def to_boxes(F, lev, boxes, dom):
+        mfs = [MultiFab(lev, nc, 0, facedir=d) for d in range(nd)]
+        for d in range(nd):
+            for b, (lo, hi) in enumerate(boxes):
+                idx = [np.arange(lo[e], hi[e] + 1 + (1 if e == d else 0)) % dom[e] for e in range(3)]
+                mfs[d].set_fab(b, F[d][:, idx[2][:, None, None], idx[1][None, :, None], idx[0][None, None, :]])
+        return mfs
+
+    Fc, Ff1, Ff2 = global_faces(dom_c), global_faces(dom_f), global_faces(dom_f)
+    Uc0 = rng.standard_normal((nc, 1, dom_c[1], dom_c[0])) + 5.0
+    Uf0 = np.repeat(np.repeat(Uc0, 2, axis=2), 2, axis=3)
+    dtc = 0.013
+    Uc = Uc0 + dtc * div(Fc, dxc)
+    Uf = Uf0 + (dtc / 2) * div(Ff1, dxf) + (dtc / 2) * div(Ff2, dxf)
+    for with_reflux in (True, False):
+        fr = FluxRegister(crse, fine, cgeom, nc, ratio=(2, 2, 1))
+        fr.reset()
+        fr.CrseAdd(to_boxes(Fc, crse, crse_boxes, dom_c), dxc, dtc)
+        fr.FineAdd(to_boxes(Ff1, fine, fine_boxes, dom_f), dxf, dtc / 2)
+        fr.FineAdd(to_boxes(Ff2, fine, fine_boxes, dom_f), dxf, dtc / 2)
+        Uc_mf = MultiFab(crse, nc, 4, fill=0.0)
+        for b, (lo, hi) in enumerate(crse_boxes):
+            Uc_mf.valid(b).copy_(torch.from_numpy(np.ascontiguousarray(Uc[:, :, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1])))
+        if with_reflux:
+            fr.Reflux(Uc_mf)
+        Uf_mf = MultiFab(fine, nc, 4, fill=0.0)
+        for b, (lo, hi) in enumerate(fine_boxes):
+            Uf_mf.valid(b).copy_(torch.from_numpy(np.ascontiguousarray(Uf[:, :, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1])))
+        AverageDown(crse, fine, ratio=(2, 2, 1))(Uf_mf, Uc_mf, 0, nc)
+        torch.cuda.synchronize()
+        after = np.zeros_like(Uc0)
+        for b, (lo, hi) in enumerate(crse_boxes):
+            after[:, :, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1] = Uc_mf.valid(b).cpu().numpy()
+        for n in range(nc):
+            drift = abs(after[n].sum() - Uc0[n].sum()) / abs(Uc0[n].sum())
+            assert (drift <= 1e-14) if with_reflux else (drift > 1e-6), (with_reflux, n, drift)
