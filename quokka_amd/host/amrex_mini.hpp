@@ -84,6 +84,7 @@ namespace amrex
 using Real = double;
 using Long = long;
 template <typename T> using Vector = std::vector<T>;
+template <class T, std::size_t N> using Array = std::array<T, N>;
 
 // inside kernels: stop the wave (the reference's device-side amrex::Abort traps as well)
 __device__ inline void Abort(char const * /*msg*/) { __builtin_trap(); }
@@ -668,6 +669,7 @@ class BoxArray : public std::vector<Box>
 	BoxArray(std::vector<Box> const &v) : std::vector<Box>(v) {} // NOLINT
 	explicit BoxArray(Box const &b) : std::vector<Box>{b} {}
 	void maxSize(int /*n*/) {}
+	int facedir = -1; // index type of the boxes: cell-centred, or nodal in this direction (the BoxArray of a face-centred MultiFab)
 };
 
 // FabArray<T> with device storage: one allocation for all boxes + the device table of Array4 descriptors
@@ -677,6 +679,8 @@ template <typename T> class FabArrayT
 	FabArrayT() = default;
 	FabArrayT(std::vector<Box> const &ba, int ncomp, int nghost, int facedir = -1) { define(ba, ncomp, nghost, facedir); }
 	FabArrayT(std::vector<Box> const &ba, DistributionMapping const & /*dm*/, int ncomp, int nghost) { define(ba, ncomp, nghost, -1); }
+	// (`ba` as boxArray() of another array hands it out: index type included)
+	FabArrayT(BoxArray const &ba, DistributionMapping const & /*dm*/, int ncomp, int nghost) { define(ba, ncomp, nghost, ba.facedir); }
 	FabArrayT(FabArrayT const &) = delete;
 	auto operator=(FabArrayT const &) -> FabArrayT & = delete;
 	FabArrayT(FabArrayT &&o) noexcept { *this = std::move(o); }
@@ -701,7 +705,8 @@ template <typename T> class FabArrayT
 	void define(std::vector<Box> const &ba, int ncomp, int nghost, int facedir = -1)
 	{
 		release();
-		boxes_ = ba;
+		static_cast<std::vector<Box> &>(boxes_) = ba;
+		boxes_.facedir = facedir;
 		ncomp_ = ncomp;
 		nghost_ = nghost;
 		facedir_ = facedir;
@@ -740,9 +745,10 @@ template <typename T> class FabArrayT
 		QK_HOST_HIP(hipMemcpy(d_table_, tab.data(), sizeof(Array4<T>) * ba.size(), hipMemcpyHostToDevice));
 	}
 	[[nodiscard]] auto size() const -> int { return static_cast<int>(boxes_.size()); }
+	[[nodiscard]] auto faceDir() const -> int { return facedir_; }
 	[[nodiscard]] auto nComp() const -> int { return ncomp_; }
 	[[nodiscard]] auto nGrow() const -> int { return nghost_; }
-	[[nodiscard]] auto boxArray() const -> std::vector<Box> const & { return boxes_; }
+	[[nodiscard]] auto boxArray() const -> BoxArray const & { return boxes_; }
 	[[nodiscard]] auto validbox(int b) const -> Box const & { return boxes_[b]; }
 	[[nodiscard]] auto fabbox(int b) const -> Box const & { return fabboxes_[b]; }
 	// host copy of one descriptor (device data pointer)
@@ -753,7 +759,7 @@ template <typename T> class FabArrayT
 	{
 		return const_array(mfi.index());
 	}
-	[[nodiscard]] auto DistributionMap() const -> int { return 0; }
+	[[nodiscard]] auto DistributionMap() const -> DistributionMapping { return DistributionMapping{}; }
 	// device pointer to the descriptor table (MultiFab::arrays())
 	[[nodiscard]] auto arrays() const -> Array4<T> * { return d_table_; }
 	[[nodiscard]] auto const_arrays() const -> Array4<T const> const * { return reinterpret_cast<Array4<T const> const *>(d_table_); }
@@ -788,6 +794,31 @@ template <typename T> class FabArrayT
 					      hipMemcpyDeviceToDevice));
 		}
 	}
+	// MultiFab::Subtract(dst, src, srccomp, dstcomp, numcomp, nghost): dst -= src (whole fabs: same layout required)
+	static void Subtract(FabArrayT &dst, FabArrayT const &src, int srccomp, int dstcomp, int numcomp, int /*nghost*/)
+	{
+		for (int b = 0; b < src.size(); ++b) {
+			auto const d = dst.array(b);
+			auto const s = src.const_array(b);
+			ParallelFor(dst.fabbox(b), numcomp, [=] __device__(int i, int j, int k, int n) { d(i, j, k, dstcomp + n) -= s(i, j, k, srccomp + n); });
+		}
+	}
+	// MultiFab::norm1(comp): sum of |value| over the valid region (faces of a face-centred array: the nodal valid box), all ranks
+	[[nodiscard]] auto norm1(int n) const -> double
+	{
+		double s = 0;
+		QK_HOST_HIP(hipDeviceSynchronize());
+		for (int b = 0; b < size(); ++b) {
+			auto h = copyToHost(b);
+			Array4<T> a(h.data(), fabboxes_[b], ncomp_);
+			Box vb = boxes_[b];
+			if (facedir_ >= 0) {
+				vb.hi[facedir_] += 1;
+			}
+			HostFor(vb, [&](int i, int j, int k) { s += std::abs(static_cast<double>(a(i, j, k, n))); });
+		}
+		return qkhost::Comm::get().allReduceSum(s);
+	}
 	// sum / norm over valid cells of component n (host reduction: diagnostics only, not on the timed path)
 	[[nodiscard]] auto sum(int n) const -> double
 	{
@@ -818,7 +849,8 @@ template <typename T> class FabArrayT
 		d_data_ = nullptr;
 		d_table_ = nullptr;
 	}
-	std::vector<Box> boxes_, fabboxes_;
+	BoxArray boxes_;
+	std::vector<Box> fabboxes_;
 	std::vector<Long> offsets_;
 	int ncomp_ = 0, nghost_ = 0, facedir_ = -1;
 	Long total_ = 0;

@@ -796,23 +796,54 @@ template <typename problem_t> void QuokkaSimulation<problem_t>::setInitialCondit
 	outputAfterInitialConditions();
 }
 
-// AMRSimulation::WritePlotFile (reference src/simulation.hpp:2294-2336): state_new_cc_ of every level, no derived variables
+// AMRSimulation::WritePlotFile (reference src/simulation.hpp:2294-2336): state_new_cc_ of every level — followed, for problems with a
+// face-centred state, by its cell-centre averages 0.5 (f_i + f_i+1) per direction (PlotFileMFAtLevel + AverageFCToCC, :2031-2100) —, no derived
+// variables
 template <typename problem_t> void QuokkaSimulation<problem_t>::WritePlotFile()
 {
 	int const nlev = amr_ ? amr_->finestLevel() + 1 : 1;
 	std::vector<amrex::MultiFab const *> mf;
+	std::vector<amrex::MultiFab> combined; // (kept alive until the file is written)
 	std::vector<amrex::Geometry> geoms;
 	std::vector<int> steps;
+	std::vector<std::string> names = this->componentNames_cc_;
+	constexpr int nfc = qkhost::hasFaceState<problem_t>() ? Physics_Indices<problem_t>::nvarTotal_fc : 0;
+	if constexpr (nfc > 0) {
+		combined.resize(nlev);
+		for (auto const &n : componentNames_fc()) {
+			names.push_back(n);
+		}
+	}
 	for (int l = 0; l < nlev; ++l) {
 		auto &S = amr_ ? amr_->level(l) : *this;
-		mf.push_back(&S.state_new_cc_[0]);
+		if constexpr (nfc > 0) {
+			int const ncc = S.state_new_cc_[0].nComp();
+			constexpr int per = Physics_Indices<problem_t>::nvarPerDim_fc;
+			combined[l].define(S.grids_, ncc + nfc, 0);
+			for (int b = 0; b < combined[l].size(); ++b) {
+				auto const out = combined[l].array(b);
+				auto const cc = S.state_new_cc_[0].const_array(b);
+				amrex::ParallelFor(combined[l].validbox(b), ncc, [=] AMREX_GPU_DEVICE(int i, int j, int k, int n) { out(i, j, k, n) = cc(i, j, k, n); });
+				for (int idim = 0; idim < AMREX_SPACEDIM; ++idim) {
+					auto const fc = S.state_new_fc_[0][idim].const_array(b);
+					int const di = (idim == 0) ? 1 : 0, dj = (idim == 1) ? 1 : 0, dk = (idim == 2) ? 1 : 0;
+					int const dst = ncc + idim * per;
+					amrex::ParallelFor(combined[l].validbox(b), per, [=] AMREX_GPU_DEVICE(int i, int j, int k, int n) {
+						out(i, j, k, dst + n) = 0.5 * (fc(i, j, k, n) + fc(i + di, j + dj, k + dk, n));
+					});
+				}
+			}
+			mf.push_back(&combined[l]);
+		} else {
+			mf.push_back(&S.state_new_cc_[0]);
+		}
 		geoms.push_back(S.geom[0]);
 		steps.push_back(amr_ ? amr_->istep[l] : istep[0]);
 	}
 	std::string const name = quokka::io::Concatenate(this->plot_file, istep[0], 5);
 	amrex::Print() << "Writing plotfile " << name << "\n";
 	QK_HOST_HIP(hipDeviceSynchronize());
-	quokka::io::WriteMultiLevelPlotfile(name, nlev, mf, this->componentNames_cc_, geoms, tNew_[0], steps);
+	quokka::io::WriteMultiLevelPlotfile(name, nlev, mf, names, geoms, tNew_[0], steps);
 	quokka::io::WriteMetadataFile(name + "/metadata.yaml");
 }
 
@@ -823,6 +854,7 @@ template <typename problem_t> void QuokkaSimulation<problem_t>::WriteCheckpointF
 	h.finest_level = amr_ ? amr_->finestLevel() : 0;
 	int const nmax = amr_ ? amr_->max_level + 1 : 1; // istep, dt_, tNew_ have one entry per level that may exist
 	std::vector<amrex::MultiFab const *> state;
+	std::vector<std::array<amrex::MultiFab const *, AMREX_SPACEDIM>> faces; // Level_<l>/Face_x|y|z of problems with a face-centred state
 	for (int l = 0; l < nmax; ++l) {
 		bool const live = l <= h.finest_level;
 		h.istep.push_back(amr_ ? amr_->istep[l] : istep[0]);
@@ -832,12 +864,19 @@ template <typename problem_t> void QuokkaSimulation<problem_t>::WriteCheckpointF
 			auto &S = amr_ ? amr_->level(l) : *this;
 			h.grids.push_back(S.grids_);
 			state.push_back(&S.state_new_cc_[0]);
+			if constexpr (qkhost::hasFaceState<problem_t>()) {
+				std::array<amrex::MultiFab const *, AMREX_SPACEDIM> f{};
+				for (int d = 0; d < AMREX_SPACEDIM; ++d) {
+					f[d] = &S.state_new_fc_[0][d];
+				}
+				faces.push_back(f);
+			}
 		}
 	}
 	std::string const name = quokka::io::Concatenate(this->chk_file, istep[0], 5);
 	amrex::Print() << "Writing checkpoint " << name << "\n";
 	QK_HOST_HIP(hipDeviceSynchronize());
-	quokka::io::WriteCheckpointFile(name, h, state);
+	quokka::io::WriteCheckpointFile(name, h, state, faces);
 }
 
 template <typename problem_t>

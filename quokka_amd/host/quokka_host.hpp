@@ -99,6 +99,17 @@ template <typename problem_t> struct Physics_Indices {
 	static const int mhdFirstIndex = velFirstIndex + Physics_NumVars::numVelVars_per_dim;
 };
 
+namespace qkhost
+{
+// Problems whose face-centred state this host carries: those with the MHD index bookkeeping (FCQuantities).  The reference allocates one face
+// velocity per direction for every hydro problem as well (for tracer particles; zero unless do_tracers, written to every plotfile as
+// x/y/z-velocity and to every checkpoint as Level_<l>/Face_*): those zero-valued arrays are not carried here.
+template <typename problem_t> constexpr auto hasFaceState() -> bool
+{
+	return Physics_Indices<problem_t>::nvarTotal_fc > 0 && Physics_Traits<problem_t>::is_mhd_enabled;
+}
+} // namespace qkhost
+
 // reference src/hydro/mhd_system.hpp: the index bookkeeping of the face-centred magnetic field (nothing else exists there either)
 template <typename problem_t> class MHDSystem
 {
@@ -163,13 +174,15 @@ template <typename problem_t> struct EOS {
 		return e * rho * kB_ / C::k_B;
 	}
 };
-enum class centering { cc = 0, fc };
 enum class direction { na = -1, x, y, z };
+enum class centering { cc = 0, fc, ec };
 // reference src/grid.hpp
 struct grid {
 	amrex::Array4<double> array_;
 	amrex::Box indexRange_;
 	amrex::GpuArray<double, AMREX_SPACEDIM> dx_, prob_lo_, prob_hi_;
+	centering cen_ = centering::cc;
+	direction dir_ = direction::na;
 };
 } // namespace quokka
 
@@ -1205,6 +1218,7 @@ template <typename problem_t> class AMRSimulation
 	static constexpr int nvarTotal_cc_ = Physics_Indices<problem_t>::nvarTotal_cc;
 
 	explicit AMRSimulation(amrex::Vector<amrex::BCRec> &BCs_cc) : BCs_cc_(BCs_cc) { initialize(nullptr); }
+	AMRSimulation(amrex::Vector<amrex::BCRec> &BCs_cc, amrex::Vector<amrex::BCRec> &BCs_fc) : BCs_cc_(BCs_cc), BCs_fc_(BCs_fc) { initialize(nullptr); }
 	AMRSimulation(amrex::Vector<amrex::BCRec> &BCs_cc, LevelSpec const &spec) : BCs_cc_(BCs_cc) { initialize(&spec); }
 	virtual ~AMRSimulation()
 	{
@@ -1401,8 +1415,86 @@ template <typename problem_t> class AMRSimulation
 		}
 		fillBoundaryConditions(state_new_cc_[0]);
 		amrex::MultiFab::Copy(state_old_cc_[0], state_new_cc_[0]);
+		if (restart_chkfile.empty()) {
+			setInitialConditionsAtLevel_fc();
+		} else {
+			readFaceCentredState();
+		}
 		areInitialConditionsDefined_ = true;
 	}
+	// the face-centred part of ReadCheckpointFile (reference src/simulation.hpp:2779-2815)
+	void readFaceCentredState()
+	{
+		if constexpr (qkhost::hasFaceState<problem_t>()) {
+			defineFaceCentredState();
+			char const *dirName[3] = {"x", "y", "z"};
+			for (int idim = 0; idim < AMREX_SPACEDIM; ++idim) {
+				quokka::io::VisMFReadInto(state_new_fc_[0][idim], restart_chkfile + "/Level_0/Face_" + dirName[idim]);
+				amrex::MultiFab::Copy(state_old_fc_[0][idim], state_new_fc_[0][idim]);
+			}
+		}
+	}
+	// setInitialConditionsAtLevel_fc (reference src/simulation.hpp:1628-1651): the face-centred state of problems that carry one
+	// (Physics_Indices::nvarTotal_fc > 0: face velocities, the magnetic field of the MHD index bookkeeping).  The arrays exist, take the
+	// problem's initial conditions and travel through checkpoints and plotfiles; their ghost faces are NOT filled — no operator of this host
+	// reads them (the reference's MHD update does not exist either: hydro/mhd_system.hpp holds indices only).
+	void defineFaceCentredState()
+	{
+		if constexpr (qkhost::hasFaceState<problem_t>()) {
+			if (state_new_fc_.empty()) {
+				state_new_fc_.resize(1);
+				state_old_fc_.resize(1);
+				for (int idim = 0; idim < AMREX_SPACEDIM; ++idim) {
+					state_new_fc_[0][idim].define(grids_, Physics_Indices<problem_t>::nvarPerDim_fc, nghost_fc_, idim);
+					state_old_fc_[0][idim].define(grids_, Physics_Indices<problem_t>::nvarPerDim_fc, nghost_fc_, idim);
+				}
+			}
+		}
+	}
+	void setInitialConditionsAtLevel_fc()
+	{
+		if constexpr (qkhost::hasFaceState<problem_t>()) {
+			defineFaceCentredState();
+			for (int idim = 0; idim < AMREX_SPACEDIM; ++idim) {
+				auto &mf = state_new_fc_[0][idim];
+				mf.setVal(0.);
+				for (int b = 0; b < mf.size(); ++b) {
+					amrex::Box faces = mf.validbox(b); // iter.validbox() of a face-centred MultiFab: nodal in idim
+					faces.hi[idim] += 1;
+					quokka::grid grid_elem{mf.array(b),	  faces, geom[0].CellSizeArray(), geom[0].ProbLoArray(), geom[0].ProbHiArray(), quokka::centering::fc,
+							       static_cast<quokka::direction>(idim)};
+					setInitialConditionsOnGridFaceVars(grid_elem);
+				}
+				amrex::MultiFab::Copy(state_old_fc_[0][idim], mf);
+			}
+		}
+	}
+	virtual void setInitialConditionsOnGridFaceVars(quokka::grid const & /*grid_elem*/) {}
+	// componentNames_fc_ (reference src/QuokkaSimulation.hpp:310-321: the face velocities of every direction, then the field components — the
+	// order of the reference's labels, kept although PlotFileMFAtLevel stores the averages direction by direction)
+	[[nodiscard]] static auto componentNames_fc() -> std::vector<std::string>
+	{
+		char const *dirName[3] = {"x", "y", "z"};
+		std::vector<std::string> names;
+		if constexpr (qkhost::hasFaceState<problem_t>()) {
+			if constexpr (Physics_Traits<problem_t>::is_hydro_enabled) {
+				for (int idim = 0; idim < AMREX_SPACEDIM; ++idim) {
+					names.push_back(std::string(dirName[idim]) + "-velocity");
+				}
+			}
+			if constexpr (Physics_Traits<problem_t>::is_mhd_enabled) {
+				for (int idim = 0; idim < AMREX_SPACEDIM; ++idim) {
+					names.push_back(std::string(dirName[idim]) + "-BField");
+				}
+			}
+		}
+		return names;
+	}
+	[[nodiscard]] auto getNewMF_fc() const -> amrex::Vector<amrex::Array<amrex::MultiFab, AMREX_SPACEDIM>> const & { return state_new_fc_; }
+	void setChkFile(std::string const &chkfile_number) { restart_chkfile = chkfile_number; } // reference src/simulation.hpp:410
+	amrex::Vector<amrex::Array<amrex::MultiFab, AMREX_SPACEDIM>> state_new_fc_, state_old_fc_;
+	amrex::Vector<amrex::BCRec> BCs_fc_;
+	int nghost_fc_ = Physics_Traits<problem_t>::is_mhd_enabled ? 4 : 2; // reference src/simulation.hpp:364
 
 	// setInitialConditionsAtLevel_cc (reference src/simulation.hpp:1608-1626): the problem's initial conditions on this level's boxes
 	void setInitialConditionsAtLevel()
@@ -1413,6 +1505,7 @@ template <typename problem_t> class AMRSimulation
 			setInitialConditionsOnGrid(grid_elem);
 		}
 		amrex::MultiFab::Copy(state_old_cc_[0], state_new_cc_[0]);
+		setInitialConditionsAtLevel_fc();
 		areInitialConditionsDefined_ = true;
 	}
 
@@ -1554,6 +1647,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	static constexpr int ncompHydro_ = HydroSystem<problem_t>::nvar_;
 
 	explicit QuokkaSimulation(amrex::Vector<amrex::BCRec> &BCs_cc) : AMRSimulation<problem_t>(BCs_cc) { construct(); }
+	QuokkaSimulation(amrex::Vector<amrex::BCRec> &BCs_cc, amrex::Vector<amrex::BCRec> &BCs_fc) : AMRSimulation<problem_t>(BCs_cc, BCs_fc) { construct(); }
 	// one level of an AMR hierarchy (quokka_amr.hpp)
 	QuokkaSimulation(amrex::Vector<amrex::BCRec> &BCs_cc, LevelSpec const &spec) : AMRSimulation<problem_t>(BCs_cc, spec) { construct(); }
 
@@ -1750,6 +1844,8 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	}
 
 	void setInitialConditionsOnGrid(quokka::grid const &grid_elem) override;
+	void setInitialConditionsOnGridFaceVars(quokka::grid const &grid_elem) override; // (a problem with a face-centred state specialises it)
+	using AMRSimulation<problem_t>::componentNames_fc;
 	void preCalculateInitialConditions() override;
 	void computeAfterEvolve(amrex::Vector<amrex::Real> &initSumCons) override;
 	void computeAfterTimestep(); // reference src/simulation.hpp:228, :890 (default: nothing)
@@ -2553,6 +2649,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 };
 
 template <typename problem_t> void QuokkaSimulation<problem_t>::preCalculateInitialConditions() {}
+template <typename problem_t> void QuokkaSimulation<problem_t>::setInitialConditionsOnGridFaceVars(quokka::grid const & /*grid_elem*/) {}
 
 // (a problem that specialises one of these hooks never sets the flag: the driver then drops its cached signal speeds after the call)
 template <typename problem_t> void QuokkaSimulation<problem_t>::computeAfterTimestep() { afterTimestepIsDefault_ = true; }

@@ -34,9 +34,14 @@ inline auto Concatenate(std::string const &root, int num, int mindigits = 5) -> 
 	return s.str();
 }
 
-// operator<<(std::ostream&, amrex::Box const&): ((lo) (hi) (type)), cell-centred type = 0 in each direction
-inline void printBox(std::ostream &os, amrex::Box const &b)
+// operator<<(std::ostream&, amrex::Box const&): ((lo) (hi) (type)), cell-centred type = 0 in each direction; a face-centred box (`b` is then
+// the cell box it belongs to) is nodal in `facedir`: one more index there, type 1
+inline void printBox(std::ostream &os, amrex::Box const &cellBox, int facedir = -1)
 {
+	amrex::Box b = cellBox;
+	if (facedir >= 0) {
+		b.hi[facedir] += 1;
+	}
 	auto vec = [&](int const *v) {
 		os << '(';
 		for (int d = 0; d < AMREX_SPACEDIM; ++d) {
@@ -44,13 +49,13 @@ inline void printBox(std::ostream &os, amrex::Box const &b)
 		}
 		os << ')';
 	};
-	int const zero[3] = {0, 0, 0};
+	int const type[3] = {facedir == 0 ? 1 : 0, facedir == 1 ? 1 : 0, facedir == 2 ? 1 : 0};
 	os << '(';
 	vec(b.lo);
 	os << ' ';
 	vec(b.hi);
 	os << ' ';
-	vec(zero);
+	vec(type);
 	os << ')';
 }
 
@@ -84,11 +89,11 @@ inline auto readBox(std::istream &is) -> amrex::Box
 }
 
 // amrex::BoxArray::writeOn / readFrom
-inline void writeBoxArray(std::ostream &os, std::vector<amrex::Box> const &ba)
+inline void writeBoxArray(std::ostream &os, std::vector<amrex::Box> const &ba, int facedir = -1)
 {
 	os << '(' << ba.size() << ' ' << 0 << '\n';
 	for (auto const &b : ba) {
-		printBox(os, b);
+		printBox(os, b, facedir);
 		os << '\n';
 	}
 	os << ')';
@@ -156,7 +161,11 @@ inline void VisMFWrite(amrex::MultiFab const &mf, std::string const &prefix, boo
 	for (int b = 0; b < mf.size(); ++b) {
 		auto h = mf.copyToHost(b);
 		amrex::Box const src = mf.fabbox(b);
-		amrex::Box const out = amrex::grow(mf.validbox(b), ng);
+		amrex::Box out = mf.validbox(b);
+		if (mf.faceDir() >= 0) { // the stored box of a face-centred fab: nodal in that direction (one more index)
+			out.hi[mf.faceDir()] += 1;
+		}
+		out = amrex::grow(out, ng);
 		std::vector<double> buf(static_cast<size_t>(out.numPts()) * nc);
 		amrex::Array4<double> s(h.data(), src, nc), d(buf.data(), out, nc);
 		std::vector<double> mn(nc, std::numeric_limits<double>::max()), mx(nc, std::numeric_limits<double>::lowest());
@@ -171,7 +180,13 @@ inline void VisMFWrite(amrex::MultiFab const &mf, std::string const &prefix, boo
 		offsets.push_back(static_cast<long>(data.tellp()));
 		std::ostringstream hss;
 		hss << "FAB " << nativeRealDescriptor();
-		printBox(hss, out);
+		{
+			amrex::Box cellOut = out;
+			if (mf.faceDir() >= 0) {
+				cellOut.hi[mf.faceDir()] -= 1;
+			}
+			printBox(hss, cellOut, mf.faceDir());
+		}
 		hss << ' ' << nc << '\n';
 		data << hss.str();
 		data.write(reinterpret_cast<char const *>(buf.data()), static_cast<std::streamsize>(sizeof(double) * buf.size()));
@@ -189,7 +204,7 @@ inline void VisMFWrite(amrex::MultiFab const &mf, std::string const &prefix, boo
 	hdr << 1 << '\n';  // VisMF::How::NFiles
 	hdr << nc << '\n'; // m_ncomp
 	hdr << ng << '\n'; // m_ngrow (same in every direction)
-	writeBoxArray(hdr, mf.boxArray());
+	writeBoxArray(hdr, mf.boxArray(), mf.faceDir());
 	hdr << '\n';
 	hdr << mf.size() << '\n';
 	for (int b = 0; b < mf.size(); ++b) {
@@ -427,7 +442,9 @@ struct CheckpointHeader {
 
 // AMRSimulation::WriteCheckpointFile (reference src/simulation.hpp:2564-2666): Header (title, finest_level, istep[], dt[], t_new[],
 // one BoxArray per level), metadata.yaml, Level_<l>/Cell = state_new_cc_[l] with its ghost cells, and the `last_chk` symlink
-inline void WriteCheckpointFile(std::string const &name, CheckpointHeader const &h, std::vector<amrex::MultiFab const *> const &state)
+// `faces` (optional): per level the AMREX_SPACEDIM face-centred arrays, written as Level_<l>/Face_x|y|z (reference src/simulation.hpp:2645-2652)
+inline void WriteCheckpointFile(std::string const &name, CheckpointHeader const &h, std::vector<amrex::MultiFab const *> const &state,
+				std::vector<std::array<amrex::MultiFab const *, AMREX_SPACEDIM>> const &faces = {})
 {
 	int const nlevels = h.finest_level + 1;
 	preBuildDirectoryHierarchy(name, "Level_", nlevels);
@@ -458,6 +475,12 @@ inline void WriteCheckpointFile(std::string const &name, CheckpointHeader const 
 	WriteMetadataFile(name + "/metadata.yaml");
 	for (int lev = 0; lev <= h.finest_level; ++lev) {
 		VisMFWrite(*state[lev], name + "/Level_" + std::to_string(lev) + "/Cell", /*with_ghost=*/true);
+		if (lev < static_cast<int>(faces.size())) {
+			char const *dirName[3] = {"x", "y", "z"};
+			for (int d = 0; d < AMREX_SPACEDIM; ++d) {
+				VisMFWrite(*faces[lev][d], name + "/Level_" + std::to_string(lev) + "/Face_" + dirName[d], /*with_ghost=*/true);
+			}
+		}
 	}
 	// SetLastCheckpointSymlink (reference src/simulation.hpp:2543-2562)
 	namespace fs = std::filesystem;

@@ -343,3 +343,35 @@ def test_unmodified_blast2d_problem_on_a_two_dimensional_hierarchy(tmp_path, max
     assert rc == 0 and f"Zone-updates on level {max_level}" in out, out[-2500:]
     dm, de = errors(out)
     assert abs(dm) <= 1e-14 and abs(de) <= 2e-2, (dm, de)
+
+
+def test_unmodified_face_centred_quantities_problem_round_trips_its_checkpoint(tmp_path):
+    """FCQuantities, unchanged (the reference's ctest of the same name, deck tests/fc_hydro_wave.in): a face-centred state (one face velocity and
+    one field component per direction: Physics_Indices::nvarPerDim_fc = 2) initialised by setInitialConditionsOnGridFaceVars, written to
+    chk00000 as Level_0/Face_x|y|z next to Level_0/Cell (nodal boxes: one more index in the face direction, index type 1 there), read back by
+    a second simulation object; the problem aborts unless the two agree exactly.  Also: the Face_* files as amrex::VisMF lays them out, and the
+    plotfile carries the cell-centre averages 0.5 (f_i + f_i+1) after the cell-centred components."""
+    from quokka_amd import plotfile
+    rc, out = run([exe("ref_FCQuantities"), os.path.join(HOST, "decks", "fc_hydro_wave.in")], str(tmp_path))
+    assert rc == 0 and "Accumulated error in MFs read from chk-file: 0" in out, out[-2500:]
+    lvl = tmp_path / "chk00000" / "Level_0"
+    for d, name in enumerate("xyz"):
+        hdr = open(lvl / f"Face_{name}_H").read().split("\n")
+        hi = [99, 39, 3]
+        hi[d] += 1
+        typ = ["0", "0", "0"]
+        typ[d] = "1"
+        assert hdr[:4] == ["1", "1", "2", "4"] and hdr[5] == f"((0,0,0) ({hi[0]},{hi[1]},{hi[2]}) ({','.join(typ)}))", hdr[:7]
+        mf = plotfile.read_vismf(str(lvl / f"Face_{name}"))
+        (lo, fhi), a = mf.fabboxes[0], mf.fabs[0]
+        assert lo == [-4, -4, -4] and a.shape == (2,) + tuple(fhi[e] - lo[e] + 1 for e in (2, 1, 0))
+        valid = a[:, 4:-4, 4:-4, 4:-4]
+        idx = np.arange(hi[d] + 1) % 2
+        want = (d + 1.0) + idx.reshape([-1 if e == d else 1 for e in (2, 1, 0)])  # 1 + i % 2, 2 + j % 2, 3 + k % 2 on the field component
+        assert np.array_equal(valid[1], np.broadcast_to(want, valid[1].shape)) and not valid[0].any()
+    plt = plotfile.read_plotfile(str(tmp_path / "plt00000"))
+    assert plt.varnames[6:] == ["x-velocity", "y-velocity", "z-velocity", "x-BField", "y-BField", "z-BField"]
+    fab = plt.levels[0].fabs[0]
+    assert fab.shape == (12, 4, 40, 100)
+    for d in range(3):  # per direction: [face velocity, field] averaged to the cell centre
+        assert not fab[6 + 2 * d].any() and np.all(fab[7 + 2 * d] == d + 1.5)
