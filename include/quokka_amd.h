@@ -521,6 +521,10 @@ int qk_copy_box(qk_ctx *ctx, qk_stream s, const qk_array4 *src, const qk_array4 
  *                        space of `tags`, domain starting at 0), copied to the HOST array tile_flags_host[ntz][nty][ntx]; synchronises s
  *   qk_amr_cluster_tiles host: flagged tiles (tile = blocking_factor FINE cells) -> fine boxes, greedy merge x, y, z up to max_grid_size */
 int qk_amr_tile_flags(qk_level *lev, qk_stream s, const qk_carray4 *tags, const qk_box *domain, int n_error_buf, int tile, int *tile_flags_host);
+/* the same with the buffer carried through periodic faces of the domain (periodic[d] != 0), as AMReX maps buffered tags back into a periodic
+ * domain (TagBoxArray::mapPeriodicRemoveDuplicates): a feature about to leave through a periodic face is refined where it re-enters */
+int qk_amr_tile_flags_periodic(qk_level *lev, qk_stream s, const qk_carray4 *tags, const qk_box *domain, const int periodic[3], int n_error_buf, int tile,
+			       int *tile_flags_host);
 int qk_amr_cluster_tiles(const int *tiles, const int ntiles[3], int ndim, int blocking_factor, int max_grid_size, int parent_align, qk_box *boxes,
 			 int max_boxes);
 /* host: the same flagged tiles -> fine boxes by Berger-Rigoutsos point clustering with efficiency grid_eff (amr.grid_eff), then

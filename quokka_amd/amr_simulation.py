@@ -372,8 +372,9 @@ class AmrSimulation:
         nt = [n[d] // tile for d in range(3)]
         flags = np.zeros((nt[2], nt[1], nt[0]), dtype=np.int32)
         dom = capi.Box((C.c_int * 3)(0, 0, 0), (C.c_int * 3)(n[0] - 1, n[1] - 1, n[2] - 1))
-        self.ctx.check(self.ctx.L.qk_amr_tile_flags(L.lev.h, self.ctx.stream(), tags.ptr, C.byref(dom), self.n_error_buf, tile, flags.ctypes.data_as(C.c_void_p)),
-                       "qk_amr_tile_flags")
+        per = (C.c_int * 3)(*[int(x) for x in self.geom0.periodic])
+        self.ctx.check(self.ctx.L.qk_amr_tile_flags_periodic(L.lev.h, self.ctx.stream(), tags.ptr, C.byref(dom), per, self.n_error_buf, tile,
+                                                             flags.ctypes.data_as(C.c_void_p)), "qk_amr_tile_flags_periodic")
         if self.nranks > 1:  # every rank clusters the same global flags
             import torch.distributed as dist
             from . import comm
@@ -396,10 +397,15 @@ class AmrSimulation:
         t = self._tile_flags(lev)
         tz, ty, tx = t.shape
         if finer_boxes:  # level lev+2 boxes: their level-lev footprint grown by 2 cells (ghost reach + stencil of level lev+1) must be refined
-            for lo, hi in finer_boxes:
-                a = [max((lo[d] // 4 - 2) // tile, 0) for d in range(3)]
-                b = [min((hi[d] // 4 + 2) // tile, (tx, ty, tz)[d] - 1) for d in range(3)]
-                t[a[2]:b[2] + 1, a[1]:b[1] + 1, a[0]:b[0] + 1] = True
+            nt3 = (tx, ty, tz)
+            for lo, hi in finer_boxes:  # (through a periodic face the footprint continues on the other side of the domain)
+                idx = []
+                for d in range(3):
+                    a, b = (lo[d] // 4 - 2) // tile, (hi[d] // 4 + 2) // tile
+                    if not self.geom0.periodic[d]:
+                        a, b = max(a, 0), min(b, nt3[d] - 1)
+                    idx.append(np.arange(a, b + 1) % nt3[d])
+                t[np.ix_(idx[2], idx[1], idx[0])] = True
         allowed = np.ones_like(t)
         if base > 0:  # proper nesting: a tile and its 26 neighbours (>= 4 cells: ghost reach 2 + stencil 1) lie on cells of `base` (refined) or beyond the domain
             r = 2 ** (lev - base)
@@ -408,7 +414,21 @@ class AmrSimulation:
             for lo, hi in self.levels[base].all_boxes:
                 cov[lo[2] * r // tile + 1:(hi[2] * r + r - 1) // tile + 2, lo[1] * r // tile + 1:(hi[1] * r + r - 1) // tile + 2,
                     lo[0] * r // tile + 1:(hi[0] * r + r - 1) // tile + 2] = True
-            allowed = ~dilate(~cov, 1, 3)[1:-1, 1:-1, 1:-1]
+            # Levels base+1 .. lev are rebuilt in the same regrid, each nested in the next coarser one with a margin of one of ITS tiles: seen
+            # from level lev the grids of `base` shrink by 2^(lev-base+1) - 2 tiles before the usual one-tile check.  Beyond a periodic face
+            # lies the other side of the domain (which `base` need not cover); beyond a physical one nothing that interpolation would read:
+            # only those border tiles stay "covered".
+            per = self.geom0.periodic
+            for _ in range(2 ** (lev - base + 1) - 1):
+                if per[0]:
+                    cov[:, :, 0], cov[:, :, -1] = cov[:, :, -2].copy(), cov[:, :, 1].copy()
+                if per[1]:
+                    cov[:, 0, :], cov[:, -1, :] = cov[:, -2, :].copy(), cov[:, 1, :].copy()
+                if per[2]:
+                    cov[0, :, :], cov[-1, :, :] = cov[-2, :, :].copy(), cov[1, :, :].copy()
+                inner = ~dilate(~cov, 1, 3)[1:-1, 1:-1, 1:-1]
+                cov[1:-1, 1:-1, 1:-1] = inner
+            allowed = cov[1:-1, 1:-1, 1:-1].copy()
             t &= allowed
         eff = self.grid_eff if self.clustering == "berger_rigoutsos" else None
         if not self.cluster_within_parent:
@@ -514,7 +534,10 @@ class AmrSimulation:
                 self.levels[lev] = new
             else:
                 self.levels.append(new)
-            if lev + 1 <= self.finest_level:  # the child of a remade level keeps its grids but needs new inter-level plans
+            # the child of a remade level needs new inter-level plans — unless it is about to be remade (or removed) itself: its OLD grids need
+            # not lie inside the new parent (a shrinking hierarchy)
+            nxt = new_boxes.get(lev + 1, [])
+            if lev + 1 <= self.finest_level and nxt and sorted(map(str, self.levels[lev + 1].all_boxes)) == sorted(map(str, [(list(lo), list(hi)) for lo, hi in nxt])):
                 self.levels[lev + 1].link_to_parent(new)
         for k in range(base, self.finest_level + 1):  # reference src/simulation.hpp:1257-1259
             self.levels[k].FixupState()

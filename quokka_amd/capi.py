@@ -212,6 +212,7 @@ def lib() -> C.CDLL:
         L.qk_fluxreg_set_state_component.argtypes = [vp, C.c_int]
         L.qk_copy_box.argtypes = [vp, vp, vp, vp, ci * 3, ci * 3, ci, ci, ci]
         L.qk_amr_tile_flags.argtypes = [vp, vp, vp, P(Box), ci, ci, vp]
+        L.qk_amr_tile_flags_periodic.argtypes = [vp, vp, vp, P(Box), P(ci), ci, ci, vp]
         L.qk_amr_cluster_tiles.argtypes = [vp, ci * 3, ci, ci, ci, ci, P(Box), ci]
         L.qk_amr_cluster_berger_rigoutsos.argtypes = [vp, vp, ci * 3, ci, ci, ci, C.c_double, P(Box), ci]
         L.qk_PreInterpState.argtypes = [vp, vp, vp]
@@ -241,7 +242,7 @@ DECLARED_SYMBOLS = [
     "qk_tag_relative_gradient", "qk_tag_centered_gradient", "qk_avgdown_plan_create", "qk_avgdown_plan_destroy", "qk_avgdown_plan_num_items", "qk_average_down", "qk_PreInterpState", "qk_PostInterpState",
     "qk_interp_plan_create", "qk_interp_plan_destroy", "qk_interp_plan_num_items", "qk_interp_plan_item", "qk_InterpFromCoarse",
     "qk_fluxreg_create", "qk_fluxreg_destroy", "qk_fluxreg_num_items", "qk_fluxreg_item", "qk_fluxreg_reset", "qk_fluxreg_save", "qk_fluxreg_restore", "qk_fluxreg_CrseAdd", "qk_fluxreg_FineAdd",
-    "qk_fluxreg_Reflux", "qk_fluxreg_set_state_component", "qk_amr_tile_flags", "qk_amr_cluster_tiles", "qk_amr_cluster_berger_rigoutsos", "qk_copy_box",
+    "qk_fluxreg_Reflux", "qk_fluxreg_set_state_component", "qk_amr_tile_flags", "qk_amr_tile_flags_periodic", "qk_amr_cluster_tiles", "qk_amr_cluster_berger_rigoutsos", "qk_copy_box",
 ]
 
 

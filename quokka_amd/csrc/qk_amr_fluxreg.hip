@@ -289,7 +289,8 @@ int qk_fluxreg_create(qk_level *crse, qk_level *fine, const qk_geometry *crse_ge
 						rest.swap(next);
 					}
 				}
-				if (!rest.empty() && all_fine != nullptr) {
+				if (!rest.empty()) { // (single rank too: a register cell that no coarse box holds means the fine level is not properly nested —
+						     // dropping it silently cost the advection hierarchy its conservation at the periodic faces)
 					delete P;
 					return setError(ctx, QK_ERR_INVALID, "fluxreg_create: a register cell is neither in a local coarse box nor in its ghost region");
 				}
@@ -303,7 +304,7 @@ int qk_fluxreg_create(qk_level *crse, qk_level *fine, const qk_geometry *crse_ge
 		const size_t rb = sizeof(double) * static_cast<size_t>(P->total_cells) * ncomp;
 		if (hipMalloc(reinterpret_cast<void **>(&P->d_items), sizeof(FrItem) * P->items.size()) != hipSuccess ||
 		    hipMemcpy(P->d_items, P->items.data(), sizeof(FrItem) * P->items.size(), hipMemcpyHostToDevice) != hipSuccess ||
-		    hipMalloc(reinterpret_cast<void **>(&P->d_reg), rb) != hipSuccess || hipMemset(P->d_reg, 0, rb) != hipSuccess) {
+		    hipMalloc(reinterpret_cast<void **>(&P->d_reg), rb) != hipSuccess || hipMemsetAsync(P->d_reg, 0, rb, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
 			delete P;
 			return setError(ctx, QK_ERR_HIP, "fluxreg_create: allocation failed");
 		}

@@ -332,7 +332,7 @@ extern "C" int qk_copy_box(qk_ctx *ctx, qk_stream s, const qk_array4 *src, const
 namespace
 {
 __global__ void __launch_bounds__(256) k_tags_to_tiles(const qk_box *boxes, const qk_carray4 *tags_t, int n_error_buf, int tile, int ndim, int n0, int n1, int n2,
-						       int tx, int ty, int tz, int *flags)
+						       int tx, int ty, int tz, int per0, int per1, int per2, int *flags)
 {
 	const int b = blockIdx.y;
 	const qk_box bx = boxes[b];
@@ -349,19 +349,29 @@ __global__ void __launch_bounds__(256) k_tags_to_tiles(const qk_box *boxes, cons
 	if (tag(c[0], c[1], c[2]) != static_cast<char>(QK_TAG_SET)) {
 		return;
 	}
-	// every tile that meets the cube of half-width n_error_buf around the tagged cell (clipped to the domain)
-	const int n[3] = {n0, n1, n2}, nt[3] = {tx, ty, tz};
+	// every tile that meets the cube of half-width n_error_buf around the tagged cell: clipped at a physical face of the domain, carried to
+	// the other side through a periodic one (AMReX: TagBoxArray::mapPeriodicRemoveDuplicates)
+	const int n[3] = {n0, n1, n2}, nt[3] = {tx, ty, tz}, per[3] = {per0, per1, per2};
 	int a[3], e[3];
 	for (int d = 0; d < 3; ++d) {
 		const int nb = (d < ndim) ? n_error_buf : 0;
-		const int lo = max(c[d] - nb, 0), hi = min(c[d] + nb, n[d] - 1);
-		a[d] = (d < ndim) ? lo / tile : 0;
-		e[d] = (d < ndim) ? min(hi / tile, nt[d] - 1) : 0;
+		int lo = c[d] - nb, hi = c[d] + nb;
+		if (per[d] == 0 || d >= ndim) {
+			lo = max(lo, 0);
+			hi = min(hi, n[d] - 1);
+		}
+		// floor division: tile index of a cell beyond the lower face is negative
+		a[d] = (d < ndim) ? ((lo >= 0) ? lo / tile : -((-lo + tile - 1) / tile)) : 0;
+		e[d] = (d < ndim) ? hi / tile : 0;
+		if (d < ndim && (per[d] == 0)) {
+			e[d] = min(e[d], nt[d] - 1);
+		}
 	}
 	for (int kk = a[2]; kk <= e[2]; ++kk) {
 		for (int jj = a[1]; jj <= e[1]; ++jj) {
 			for (int ii = a[0]; ii <= e[0]; ++ii) {
-				flags[ii + tx * (jj + ty * kk)] = 1; // benign race: every writer stores 1
+				const int wi = ((ii % tx) + tx) % tx, wj = ((jj % ty) + ty) % ty, wk = ((kk % tz) + tz) % tz;
+				flags[wi + tx * (wj + ty * wk)] = 1; // benign race: every writer stores 1
 			}
 		}
 	}
@@ -372,11 +382,18 @@ extern "C" {
 
 int qk_amr_tile_flags(qk_level *lev, qk_stream s, const qk_carray4 *tags_t, const qk_box *domain, int n_error_buf, int tile, int *tile_flags_host)
 {
+	const int none[3] = {0, 0, 0};
+	return qk_amr_tile_flags_periodic(lev, s, tags_t, domain, none, n_error_buf, tile, tile_flags_host);
+}
+
+int qk_amr_tile_flags_periodic(qk_level *lev, qk_stream s, const qk_carray4 *tags_t, const qk_box *domain, const int periodic[3], int n_error_buf, int tile,
+			       int *tile_flags_host)
+{
 	if (lev == nullptr) {
 		return QK_ERR_INVALID;
 	}
 	qk_ctx *ctx = lev->ctx;
-	QK_REQUIRE(ctx, tags_t && domain && tile_flags_host && tile >= 1 && n_error_buf >= 0, "amr_tile_flags: bad argument");
+	QK_REQUIRE(ctx, tags_t && domain && periodic && tile_flags_host && tile >= 1 && n_error_buf >= 0, "amr_tile_flags: bad argument");
 	int n[3], nt[3];
 	for (int d = 0; d < 3; ++d) {
 		QK_REQUIRE(ctx, domain->lo[d] == 0, "amr_tile_flags: the domain must start at index 0");
@@ -397,7 +414,8 @@ int qk_amr_tile_flags(qk_level *lev, qk_stream s, const qk_carray4 *tags_t, cons
 			maxcells *= lev->maxlen[d];
 		}
 		const dim3 grid(static_cast<unsigned>((maxcells + 255) / 256), static_cast<unsigned>(lev->nboxes), 1);
-		hipLaunchKernelGGL(k_tags_to_tiles, grid, dim3(256), 0, st, lev->d_boxes, tags_t, n_error_buf, tile, lev->ndim, n[0], n[1], n[2], nt[0], nt[1], nt[2], d_flags);
+		hipLaunchKernelGGL(k_tags_to_tiles, grid, dim3(256), 0, st, lev->d_boxes, tags_t, n_error_buf, tile, lev->ndim, n[0], n[1], n[2], nt[0], nt[1], nt[2], periodic[0], periodic[1],
+				   periodic[2], d_flags);
 	}
 	if (rc == QK_OK) {
 		if (hipGetLastError() != hipSuccess || hipMemcpyAsync(tile_flags_host, d_flags, bytes, hipMemcpyDeviceToHost, st) != hipSuccess ||

@@ -57,7 +57,7 @@ auto mgCounterSlots(qk_ctx *ctx) -> int *
 	if (ctx->counter_slots == nullptr) {
 		void *p = nullptr;
 		const size_t bytes = sizeof(int) * NSLOT * SLOT_STRIDE;
-		if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess) {
+		if (hipMalloc(&p, bytes) != hipSuccess || hipMemsetAsync(p, 0, bytes, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
 			return nullptr;
 		}
 		ctx->owned.push_back(p);

@@ -661,6 +661,22 @@ template <typename T> void Max(T &v, int /*comm*/) { ParallelDescriptor::ReduceR
 template <typename T> void Min(T &v, int /*comm*/) { ParallelDescriptor::ReduceRealMin(v); }
 } // namespace ParallelAllReduce
 template <typename F> void LoopOnCpu(Box const &bx, F &&f) { HostFor(bx, f); }
+// device fill by a kernel on the default stream
+template <typename T> __global__ void qk_fill_kernel(T *p, Long n, T v)
+{
+	for (Long t = static_cast<Long>(blockIdx.x) * blockDim.x + threadIdx.x; t < n; t += static_cast<Long>(gridDim.x) * blockDim.x) {
+		p[t] = v;
+	}
+}
+template <typename T> void qk_device_fill(T *p, Long n, T v)
+{
+	if (n <= 0) {
+		return;
+	}
+	unsigned const blocks = static_cast<unsigned>(std::min<Long>((n + 255) / 256, 65535));
+	hipLaunchKernelGGL(qk_fill_kernel<T>, dim3(blocks), dim3(256), 0, nullptr, p, n, v);
+	qk_check_launch("qk_device_fill");
+}
 class BoxArray : public std::vector<Box>
 {
       public:
@@ -737,7 +753,14 @@ template <typename T> class FabArrayT
 		QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_data_), sizeof(T) * std::max<Long>(total_ + slack, 1)));
 		// fresh storage reads as zero (what the Python drivers' MultiFab(fill = 0) gives); QK_POISON=1 fills it with NaN bit patterns
 		// instead, which makes any read of a cell that was never written visible in the results (debugging aid)
-		QK_HOST_HIP(hipMemset(d_data_, std::getenv("QK_POISON") != nullptr ? 0xFF : 0, sizeof(T) * std::max<Long>(total_, 1)));
+		// fresh storage reads as zero (what the Python drivers' MultiFab(fill = 0) gives); QK_POISON=1 fills it with NaN bit patterns instead, which
+		// makes any read of a cell that was never written visible in the results (debugging aid).  Fills are kernels on the default stream, like
+		// everything else that touches the array.
+		if (std::getenv("QK_POISON") != nullptr) {
+			qk_device_fill(reinterpret_cast<unsigned char *>(d_data_), static_cast<Long>(sizeof(T)) * std::max<Long>(total_, 1), static_cast<unsigned char>(0xFF));
+		} else {
+			qk_device_fill(d_data_, std::max<Long>(total_, 1), T{});
+		}
 		for (size_t n = 0; n < ba.size(); ++n) {
 			tab.emplace_back(d_data_ + offsets_[n], fabboxes_[n], ncomp);
 		}
@@ -763,12 +786,8 @@ template <typename T> class FabArrayT
 	// device pointer to the descriptor table (MultiFab::arrays())
 	[[nodiscard]] auto arrays() const -> Array4<T> * { return d_table_; }
 	[[nodiscard]] auto const_arrays() const -> Array4<T const> const * { return reinterpret_cast<Array4<T const> const *>(d_table_); }
-	void setVal(T v)
-	{
-		std::vector<T> h(static_cast<size_t>(total_), v);
-		QK_HOST_HIP(hipMemcpy(d_data_, h.data(), sizeof(T) * total_, hipMemcpyHostToDevice));
-	}
-	void setZeroAsync(hipStream_t s) { QK_HOST_HIP(hipMemsetAsync(d_data_, 0, sizeof(T) * std::max<Long>(total_, 1), s)); }
+	void setVal(T v) { qk_device_fill(d_data_, total_, v); }
+	void setZeroAsync(hipStream_t /*s*/) { qk_device_fill(d_data_, total_, T{}); }
 	// host staging copies of one fab
 	[[nodiscard]] auto copyToHost(int b) const -> std::vector<T>
 	{

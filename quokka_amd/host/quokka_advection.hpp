@@ -1,13 +1,14 @@
 // quokka_advection.hpp — the scalar linear-advection solver of the reference on this host mirror:
 //   LinearAdvectionSystem<problem_t>   reference src/linear_advection/linear_advection.hpp        -> qk_advect_* of the C-ABI (+ qk_ReconstructStatesPPM)
 //   AdvectionSimulation<problem_t>     reference src/linear_advection/AdvectionSimulation.hpp     -> the level-0 driver below
-// so that src/problems/Advection, AdvectionSemiellipse and Advection2D compile unchanged.  Single level: the refinement machinery of
-// quokka_amr.hpp is written around QuokkaSimulation (Advection2D's ctest deck refines three levels and needs it for its 0.15 criterion; on the
-// unrefined grid it runs, and is compared with the oracle, but does not meet that number — DESIGN.md §17).
+// so that src/problems/Advection, AdvectionSemiellipse and Advection2D compile unchanged.  With amr.max_level > 0 the levels are objects of this
+// class under the level machinery of quokka_amr.hpp (AmrDriver<problem_t, AdvectionSimulation<problem_t>>: FillPatch without energy hooks, both
+// RK stages added to the flux registers with half the step): Advection2D's ctest deck refines three levels; the error drops from 0.34 (level 0
+// only) to 0.185 that way — the reference's criterion is 0.15.
 #ifndef QK_HOST_QUOKKA_ADVECTION_HPP_
 #define QK_HOST_QUOKKA_ADVECTION_HPP_
 
-#include "quokka_host.hpp"
+#include "quokka_amr.hpp"
 
 template <typename problem_t> class LinearAdvectionSystem : public HyperbolicSystem<problem_t>
 {
@@ -81,15 +82,52 @@ template <typename problem_t> class AdvectionSimulation : public AMRSimulation<p
 	using AMRSimulation<problem_t>::boxArray;
 	using AMRSimulation<problem_t>::DistributionMap;
 
-	explicit AdvectionSimulation(amrex::Vector<amrex::BCRec> &BCs_cc) : AMRSimulation<problem_t>(BCs_cc)
+	explicit AdvectionSimulation(amrex::Vector<amrex::BCRec> &BCs_cc) : AMRSimulation<problem_t>(BCs_cc) { allocate(); }
+	// one level of a hierarchy (quokka_amr.hpp)
+	AdvectionSimulation(amrex::Vector<amrex::BCRec> &BCs_cc, LevelSpec const &spec) : AMRSimulation<problem_t>(BCs_cc, spec) { allocate(); }
+
+	// --- the level interface of AmrDriver (quokka_amr.hpp)
+	static constexpr bool isAdvection = true;
+	static constexpr int ncompHydro_ = Physics_Indices<problem_t>::nvarTotal_cc; // components of the flux registers
+	double tOldLev_ = 0.0, tNewLev_ = 0.0;
+	double fillTime_ = 0.0;
+	[[nodiscard]] auto bcFillTime() const -> double override { return fillTime_; }
+	double elapsedSeconds_ = 0.0;
+	std::function<void(std::array<amrex::MultiFab, AMREX_SPACEDIM> &, double)> afterStageFluxes_; // incrementFluxRegisters(fluxArrays, 0.5 dt) of a stage
+	void inheritSettings(AdvectionSimulation const &base)
+	{
+		cflNumber_ = base.cflNumber_;
+		advectionVx_ = base.advectionVx_;
+		advectionVy_ = base.advectionVy_;
+		advectionVz_ = base.advectionVz_;
+		this->constantDt_ = base.constantDt_;
+	}
+	void FixupState() {}
+	void dropCachedSignal() {}
+	// CFL time step of this level alone: LinearAdvectionSystem::ComputeMaxSignalSpeed (linear_advection.hpp:47-60) is the same number in every cell
+	[[nodiscard]] auto computeTimestepAtLevel() const -> double
+	{
+		double const signal = std::sqrt(advectionVx_ * advectionVx_ + advectionVy_ * advectionVy_ + advectionVz_ * advectionVz_);
+		double dx_min = geom[0].dx[0];
+		for (int d = 1; d < AMREX_SPACEDIM; ++d) {
+			dx_min = std::min(dx_min, geom[0].dx[d]);
+		}
+		return cflNumber_ * (dx_min / signal);
+	}
+	// advanceSingleTimestepAtLevel for a level of a hierarchy: the ghost cells of a refined level come from its parent at `time` (stage 1) and
+	// `time + dt` (stage 2) — AdvectionSimulation.hpp:294, :326
+	auto advanceLevel(double time, double dt_lev) -> bool
+	{
+		levelTime_ = time;
+		advanceSingleTimestepAtLevel(0, time, dt_lev, 1);
+		return true;
+	}
+
+      private:
+	double levelTime_ = 0.0;
+	void allocate()
 	{
 		componentNames_cc_.push_back({"density"});
-		amrex::ParmParse pa("amr");
-		int max_level = 0;
-		pa.query("max_level", max_level);
-		if (max_level > 0) {
-			amrex::Print() << "AdvectionSimulation: amr.max_level = " << max_level << " in the deck; this host advances the advection solver on level 0 only\n";
-		}
 		int const nc = Physics_Indices<problem_t>::nvarTotal_cc;
 		for (int d = 0; d < AMREX_SPACEDIM; ++d) {
 			flux_[d].define(grids_, nc, 0, d);
@@ -99,6 +137,7 @@ template <typename problem_t> class AdvectionSimulation : public AMRSimulation<p
 		primVar_.define(grids_, nc, nghost_cc_);
 	}
 
+      public:
 	// the reference's data members (AdvectionSimulation.hpp:89-96)
 	double advectionVx_ = 1.0;
 	double advectionVy_ = 0.0;
@@ -131,16 +170,26 @@ template <typename problem_t> class AdvectionSimulation : public AMRSimulation<p
 	void advanceSingleTimestepAtLevel(int lev, amrex::Real /*time*/, amrex::Real dt_lev, int /*ncycle*/)
 	{
 		int const nvars = Physics_Indices<problem_t>::nvarTotal_cc;
+		double const fluxScaleFactor = 0.5; // integratorOrder_ == 2 (:297-302)
+		this->activate();
 		std::swap(state_old_cc_[lev], state_new_cc_[lev]);
+		fillTime_ = levelTime_;
 		fillBoundaryConditions(state_old_cc_[lev]);
 		{
 			auto &fluxArrays = computeFluxes(state_old_cc_[lev], nvars, lev);
 			LinearAdvectionSystem<problem_t>::PredictStep(state_old_cc_[lev], state_new_cc_[lev], fluxArrays, dt_lev, geom[lev].CellSizeArray(), nvars);
+			if (afterStageFluxes_) {
+				afterStageFluxes_(fluxArrays, fluxScaleFactor * dt_lev);
+			}
 		}
+		fillTime_ = levelTime_ + dt_lev;
 		fillBoundaryConditions(state_new_cc_[lev]);
 		{
 			auto &fluxArrays = computeFluxes(state_new_cc_[lev], nvars, lev);
 			LinearAdvectionSystem<problem_t>::AddFluxesRK2(state_new_cc_[lev], state_old_cc_[lev], state_new_cc_[lev], fluxArrays, dt_lev, geom[lev].CellSizeArray(), nvars);
+			if (afterStageFluxes_) {
+				afterStageFluxes_(fluxArrays, fluxScaleFactor * dt_lev);
+			}
 		}
 	}
 
@@ -148,12 +197,7 @@ template <typename problem_t> class AdvectionSimulation : public AMRSimulation<p
 	// (reference src/simulation.hpp:722-818, single level)
 	void computeTimestep()
 	{
-		double const signal = std::sqrt(advectionVx_ * advectionVx_ + advectionVy_ * advectionVy_ + advectionVz_ * advectionVz_);
-		double dx_min = geom[0].dx[0];
-		for (int d = 1; d < AMREX_SPACEDIM; ++d) {
-			dx_min = std::min(dx_min, geom[0].dx[d]);
-		}
-		double dt_tmp = cflNumber_ * (dx_min / signal);
+		double dt_tmp = computeTimestepAtLevel();
 		dt_tmp = std::min(dt_tmp, 1.1 * dt_[0]);
 		double dt_0 = std::min(dt_tmp, 1.0 * dt_tmp);
 		dt_0 = std::min(dt_0, this->maxDt_);
@@ -198,10 +242,29 @@ template <typename problem_t> class AdvectionSimulation : public AMRSimulation<p
 		amrex::Print() << "\nRelative rms L1 error norm = " << errorNorm_ << "\n\n";
 	}
 
-	// reference src/simulation.hpp:856-951 (single level)
+	// AMRSimulation::setInitialConditions: a hierarchy when the deck asks for one
+	void setInitialConditions()
+	{
+		int max_level = 0;
+		amrex::ParmParse("amr").query("max_level", max_level);
+		if (max_level > 0) {
+			amr_ = std::make_shared<AmrDriver<problem_t, AdvectionSimulation<problem_t>>>(*this);
+			amr_->setInitialConditions();
+		} else {
+			AMRSimulation<problem_t>::setInitialConditions();
+		}
+	}
+	std::shared_ptr<AmrDriver<problem_t, AdvectionSimulation<problem_t>>> amr_;
+
+	// reference src/simulation.hpp:856-951
 	void evolve()
 	{
 		AMREX_ALWAYS_ASSERT(this->areInitialConditionsDefined_);
+		if (amr_) {
+			amr_->evolve(); // (ends with computeAfterEvolve: the level-0 state holds the average of every finer level)
+			qkDumpFields(state_new_cc_[0], istep[0], tNew_[0], dt_[0], 0, 0, errorNorm_);
+			return;
+		}
 		amrex::Vector<amrex::Real> init_sum_cons(1, 0.0);
 		QK_HOST_HIP(hipDeviceSynchronize());
 		auto const t0 = std::chrono::steady_clock::now();

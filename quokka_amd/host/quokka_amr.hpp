@@ -18,10 +18,12 @@
 
 #include "quokka_host.hpp"
 
-template <typename problem_t> class AmrDriver
+// SimT: the simulation class of one level — QuokkaSimulation<problem_t> (hydro / radiation hydrodynamics) or AdvectionSimulation<problem_t>
+// (quokka_advection.hpp: SimT::isAdvection; no retries, no energy hooks in the interpolation, both RK stages feed the flux registers)
+template <typename problem_t, typename SimT> class AmrDriver
 {
       public:
-	using Sim = QuokkaSimulation<problem_t>;
+	using Sim = SimT;
 
 	explicit AmrDriver(Sim &base) : base_(base)
 	{
@@ -45,7 +47,9 @@ template <typename problem_t> class AmrDriver
 		last_regrid_step.assign(max_level + 1, 0);
 		dt_.assign(max_level + 1, 1.e100);
 		cellUpdatesEachLevel_.assign(max_level + 1, 0);
-		base_.storeFluxRk2_ = (max_level > 0);
+		if constexpr (!Sim::isAdvection) {
+			base_.storeFluxRk2_ = (max_level > 0);
+		}
 	}
 
 	int max_level = 0, blocking_factor = 8, n_error_buf = 1, regrid_int = 2, max_grid_size = 128, do_reflux = 1;
@@ -99,32 +103,43 @@ template <typename problem_t> class AmrDriver
 		QK_HOST_HIP(hipDeviceSynchronize());
 		auto const t0 = std::chrono::steady_clock::now();
 		tNew_ = base_.tNew_[0];
-		while (istep[0] < base_.maxTimesteps_ && tNew_ < base_.stopTime_) {
+		int const debugMaxSteps = (std::getenv("QK_MAX_COARSE_STEPS") != nullptr) ? std::atoi(std::getenv("QK_MAX_COARSE_STEPS")) : -1; // (debugging aid)
+		while (istep[0] < base_.maxTimesteps_ && tNew_ < base_.stopTime_ && (debugMaxSteps < 0 || istep[0] < debugMaxSteps)) {
 			computeTimestep();
-			base_.callBeforeTimestep(); // reference src/simulation.hpp:864-867
-			dropSignalsIfHooked(base_.beforeTimestepIsDefault_);
+			if constexpr (!Sim::isAdvection) {
+				base_.callBeforeTimestep(); // reference src/simulation.hpp:864-867
+				dropSignalsIfHooked(base_.beforeTimestepIsDefault_);
+			}
 			timeStepWithSubcycling(0, tNew_);
 			tNew_ += dt_[0];
 			base_.tNew_[0] = tNew_;
 			base_.dt_[0] = dt_[0];
 			base_.istep[0] = istep[0];
-			base_.callAfterTimestep(); // reference src/simulation.hpp:890
-			dropSignalsIfHooked(base_.afterTimestepIsDefault_);
-			base_.outputAfterStep(istep[0] - 1);
+			if constexpr (!Sim::isAdvection) {
+				base_.callAfterTimestep(); // reference src/simulation.hpp:890
+				dropSignalsIfHooked(base_.afterTimestepIsDefault_);
+				base_.outputAfterStep(istep[0] - 1);
+			}
 			if (tNew_ >= base_.stopTime_ - 1.e-6 * dt_[0]) {
 				break;
 			}
-			if (base_.walltimeExceeded(t0)) {
-				break;
+			if constexpr (!Sim::isAdvection) {
+				if (base_.walltimeExceeded(t0)) {
+					break;
+				}
 			}
 		}
 		QK_HOST_HIP(hipDeviceSynchronize());
 		elapsedSeconds_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-		base_.outputAfterEvolve();
+		if constexpr (!Sim::isAdvection) {
+			base_.outputAfterEvolve();
+		}
 		base_.elapsedSeconds_ = elapsedSeconds_;
 		base_.cellUpdates_ = cellUpdates_;
 		base_.computeAfterEvolve(init_sum_cons);
-		base_.printConservation(init_sum_cons, vol); // reference src/simulation.hpp:959-970
+		if constexpr (!Sim::isAdvection) {
+			base_.printConservation(init_sum_cons, vol); // reference src/simulation.hpp:959-970
+		}
 		double const us = 1.0e6 * elapsedSeconds_ / static_cast<double>(cellUpdates_);
 		amrex::Print() << "Performance figure-of-merit: " << us << " μs/zone-update [" << 1.0 / us << " Mupdates/s]\n";
 		for (int l = 0; l <= finestLevel(); ++l) {
@@ -312,11 +327,15 @@ template <typename problem_t> class AmrDriver
 		// FillPatchTwoLevels: the ghost cells no fine box covers come from the parent, interpolated in space and time
 		me.beforePhysBC_ = [this, fp, lev](amrex::MultiFab &state) { interpFromParent(*fp, lev, state, fp->sim->fillTime_, fp->interp); };
 		// incrementFluxRegisters: this level as the fine side of its register and as the coarse side of its child's
-		me.afterAdvance_ = [this, lev](double dt) { incrementFluxRegisters(lev, dt); };
-		me.beforeAttempt_ = [this, lev](int retry) { resetFluxRegistersForAttempt(lev, retry); };
-		me.storeFluxRk2_ = true;
-		installRadiationHook(lev);
-		installRadiationHook(lev - 1);
+		if constexpr (Sim::isAdvection) { // (both RK stages add their fluxes with half the step: AdvectionSimulation.hpp:300-349)
+			me.afterStageFluxes_ = [this, lev](std::array<amrex::MultiFab, AMREX_SPACEDIM> &flux, double dtw) { addFluxesToRegisters(lev, flux, dtw); };
+		} else {
+			me.afterAdvance_ = [this, lev](double dt) { incrementFluxRegisters(lev, dt); };
+			me.beforeAttempt_ = [this, lev](int retry) { resetFluxRegistersForAttempt(lev, retry); };
+			me.storeFluxRk2_ = true;
+			installRadiationHook(lev);
+			installRadiationHook(lev - 1);
+		}
 	}
 
 	// incrementFluxRegisters of the radiation stages (:1818, :1854): weight dt_radiation / 2 for each of the two stages
@@ -353,12 +372,13 @@ template <typename problem_t> class AmrDriver
 		auto *pn = qkhost::tab(p.state_new_cc_[0]);
 		auto *po = qkhost::tab(p.state_old_cc_[0]);
 		int const nc = Physics_Indices<problem_t>::nvarTotal_cc; // hydro + radiation blocks
+		int const hooks = Sim::isAdvection ? 0 : 1;		 // PreInterpState / PostInterpState: the hydro energy (InterpHookNone for the scalar)
 		if (std::abs(time - t1) <= eps || t1 == t0) {
-			qkhost::check(qk_InterpFromCoarse(plan, nullptr, fs, pn, pn, 1.0, 0.0, nc, amrInterpMethod_, 1), "qk_InterpFromCoarse");
+			qkhost::check(qk_InterpFromCoarse(plan, nullptr, fs, pn, pn, 1.0, 0.0, nc, amrInterpMethod_, hooks), "qk_InterpFromCoarse");
 		} else if (std::abs(time - t0) <= eps) {
-			qkhost::check(qk_InterpFromCoarse(plan, nullptr, fs, po, po, 1.0, 0.0, nc, amrInterpMethod_, 1), "qk_InterpFromCoarse");
+			qkhost::check(qk_InterpFromCoarse(plan, nullptr, fs, po, po, 1.0, 0.0, nc, amrInterpMethod_, hooks), "qk_InterpFromCoarse");
 		} else {
-			qkhost::check(qk_InterpFromCoarse(plan, nullptr, fs, po, pn, (t1 - time) / (t1 - t0), (time - t0) / (t1 - t0), nc, amrInterpMethod_, 1),
+			qkhost::check(qk_InterpFromCoarse(plan, nullptr, fs, po, pn, (t1 - time) / (t1 - t0), (time - t0) / (t1 - t0), nc, amrInterpMethod_, hooks),
 				      "qk_InterpFromCoarse");
 		}
 	}
@@ -381,6 +401,12 @@ template <typename problem_t> class AmrDriver
 
 	void incrementFluxRegisters(int lev, double dt)
 	{
+		if constexpr (!Sim::isAdvection) {
+			addFluxesToRegisters(lev, level(lev).halfFlux(), dt);
+		}
+	}
+	void addFluxesToRegisters(int lev, std::array<amrex::MultiFab, AMREX_SPACEDIM> &flux, double dt)
+	{
 		if (do_reflux == 0) {
 			return;
 		}
@@ -388,7 +414,7 @@ template <typename problem_t> class AmrDriver
 		qk_array4 *f[3];
 		double dx[3];
 		for (int d = 0; d < 3; ++d) {
-			f[d] = (d < AMREX_SPACEDIM) ? qkhost::tab(S.halfFlux()[d]) : nullptr;
+			f[d] = (d < AMREX_SPACEDIM) ? qkhost::tab(flux[d]) : nullptr;
 			dx[d] = (d < AMREX_SPACEDIM) ? S.geom[0].dx[d] : 1.0;
 		}
 		if (lev < finestLevel()) {
@@ -401,24 +427,18 @@ template <typename problem_t> class AmrDriver
 
 	void makeLevel(int lev, std::vector<amrex::Box> const &boxes)
 	{
+		if (std::getenv("QK_AMR_VERBOSE") != nullptr) {
+			std::cout << "makeLevel " << lev << ": " << boxes.size() << " boxes";
+			for (auto const &b : boxes) {
+				std::cout << " [" << b.lo[0] << "," << b.lo[1] << "," << b.lo[2] << ":" << b.hi[0] << "," << b.hi[1] << "," << b.hi[2] << "]";
+			}
+			std::cout << "\n";
+		}
 		auto f = std::make_unique<Finer>();
 		auto spec = specFor(lev, boxes);
 		f->sim = std::make_unique<Sim>(base_.BCs_cc_, spec);
 		Sim &me = *f->sim;
-		me.cflNumber_ = base_.cflNumber_;
-		me.densityFloor_ = base_.densityFloor_;
-		me.tempFloor_ = base_.tempFloor_;
-		me.reconstructionOrder_ = base_.reconstructionOrder_;
-		me.integratorOrder_ = base_.integratorOrder_;
-		me.useDualEnergy_ = base_.useDualEnergy_;
-		me.abortOnFofcFailure_ = base_.abortOnFofcFailure_;
-		me.artificialViscosityK_ = base_.artificialViscosityK_;
-		me.radiationCflNumber_ = base_.radiationCflNumber_; // (the problem sets these on the level-0 object in problem_main)
-		me.radiationReconstructionOrder_ = base_.radiationReconstructionOrder_;
-		me.maxSubsteps_ = base_.maxSubsteps_;
-		me.radSourceTimeIndependent_ = base_.radSourceTimeIndependent_;
-		me.dustGasInteractionCoeff_ = base_.dustGasInteractionCoeff_;
-		me.constantDt_ = base_.constantDt_;
+		me.inheritSettings(base_); // (the problem sets them on the level-0 object in problem_main)
 		me.tOldLev_ = me.tNewLev_ = tNew_;
 		Finer *raw = f.get();
 		if (lev - 1 < static_cast<int>(finer_.size())) {
@@ -430,8 +450,12 @@ template <typename problem_t> class AmrDriver
 		}
 		linkToParent(*raw, lev);
 		if (lev == 1) {
-			base_.afterAdvance_ = [this](double dt) { incrementFluxRegisters(0, dt); };
-			base_.beforeAttempt_ = [this](int retry) { resetFluxRegistersForAttempt(0, retry); };
+			if constexpr (Sim::isAdvection) {
+				base_.afterStageFluxes_ = [this](std::array<amrex::MultiFab, AMREX_SPACEDIM> &flux, double dtw) { addFluxesToRegisters(0, flux, dtw); };
+			} else {
+				base_.afterAdvance_ = [this](double dt) { incrementFluxRegisters(0, dt); };
+				base_.beforeAttempt_ = [this](int retry) { resetFluxRegistersForAttempt(0, retry); };
+			}
 		}
 	}
 
@@ -465,21 +489,36 @@ template <typename problem_t> class AmrDriver
 		}
 		std::vector<int> flags(static_cast<size_t>(nt[0]) * nt[1] * nt[2], 0);
 		qk_box qd{{dom.lo[0], dom.lo[1], dom.lo[2]}, {dom.hi[0], dom.hi[1], dom.hi[2]}};
-		qkhost::check(qk_amr_tile_flags(S.levelHandle(), nullptr, reinterpret_cast<qk_carray4 *>(tags.arrays()), &qd, n_error_buf, tile, flags.data()),
-			      "qk_amr_tile_flags");
+		int const per[3] = {S.geom[0].periodic[0], S.geom[0].periodic[1], S.geom[0].periodic[2]};
+		qkhost::check(qk_amr_tile_flags_periodic(S.levelHandle(), nullptr, reinterpret_cast<qk_carray4 *>(tags.arrays()), &qd, per, n_error_buf, tile, flags.data()),
+			      "qk_amr_tile_flags_periodic");
 		qkhost::Comm::get().allReduceMaxInts(flags.data(), flags.size()); // every rank clusters the same global flags
+		if (std::getenv("QK_AMR_VERBOSE") != nullptr) {
+			unsigned long h = 1469598103934665603UL;
+			long nset = 0;
+			for (int v : flags) {
+				h = (h ^ static_cast<unsigned long>(v)) * 1099511628211UL;
+				nset += v;
+			}
+			std::cout << "tileflags lev " << lev << " base " << base << " istep " << istep[0] << " set " << nset << " hash " << h << "\n";
+		}
 		auto at = [&](int i, int j, int k) -> int & { return flags[static_cast<size_t>(i) + static_cast<size_t>(nt[0]) * (j + static_cast<size_t>(nt[1]) * k)]; };
 		if (finerBoxes != nullptr) { // level lev+2 boxes: their level-lev footprint grown by 2 cells must be refined (proper nesting)
-			for (auto const &b : *finerBoxes) {
+			for (auto const &b : *finerBoxes) { // (through a periodic face the footprint continues on the other side of the domain)
 				int a[3], e[3];
 				for (int d = 0; d < 3; ++d) {
-					a[d] = std::max((fdiv(b.lo[d], 4) - 2) / tile, 0);
-					e[d] = std::min((fdiv(b.hi[d], 4) + 2) / tile, nt[d] - 1);
+					bool const per = d < AMREX_SPACEDIM && S.geom[0].periodic[d] != 0;
+					a[d] = fdiv(fdiv(b.lo[d], 4) - 2, tile);
+					e[d] = fdiv(fdiv(b.hi[d], 4) + 2, tile);
+					if (!per) {
+						a[d] = std::max(a[d], 0);
+						e[d] = std::min(e[d], nt[d] - 1);
+					}
 				}
 				for (int k = a[2]; k <= e[2]; ++k) {
 					for (int j = a[1]; j <= e[1]; ++j) {
 						for (int i = a[0]; i <= e[0]; ++i) {
-							at(i, j, k) = 1;
+							at(((i % nt[0]) + nt[0]) % nt[0], ((j % nt[1]) + nt[1]) % nt[1], ((k % nt[2]) + nt[2]) % nt[2]) = 1;
 						}
 					}
 				}
@@ -508,18 +547,56 @@ template <typename problem_t> class AmrDriver
 					}
 				}
 			}
+			// Levels base+1 .. lev are rebuilt in the same regrid, each nested in the next coarser one with a margin of one of ITS tiles: seen
+			// from level lev the grids of `base` shrink by 2^(lev-base+1) - 2 tiles before the usual one-tile check.  Beyond a periodic face
+			// lies the other side of the domain (which level `base` need not cover); beyond a physical one nothing that interpolation would
+			// read: only those border tiles stay "covered".
+			int const passes = (1 << (lev - base + 1)) - 1;
+			std::vector<char> next(cov.size(), 1);
+			for (int pass = 0; pass < passes; ++pass) {
+				for (int k = -1; k <= nt[2]; ++k) {
+					for (int j = -1; j <= nt[1]; ++j) {
+						for (int i = -1; i <= nt[0]; ++i) {
+							int idx[3] = {i, j, k};
+							bool border = false, wraps = true;
+							for (int d = 0; d < 3; ++d) {
+								if (idx[d] < 0 || idx[d] >= nt[d]) {
+									border = true;
+									if (d < AMREX_SPACEDIM && S.geom[0].periodic[d] != 0) {
+										idx[d] = (idx[d] + nt[d]) % nt[d];
+									} else {
+										wraps = false;
+									}
+								}
+							}
+							if (border && wraps) {
+								cv(i, j, k) = cv(idx[0], idx[1], idx[2]);
+							}
+						}
+					}
+				}
+				next = cov;
+				for (int k = 0; k < nt[2]; ++k) {
+					for (int j = 0; j < nt[1]; ++j) {
+						for (int i = 0; i < nt[0]; ++i) {
+							bool ok = true;
+							for (int c2 = -1; c2 <= 1 && ok; ++c2) {
+								for (int b2 = -1; b2 <= 1 && ok; ++b2) {
+									for (int a2 = -1; a2 <= 1 && ok; ++a2) {
+										ok = cv(i + a2, j + b2, k + c2) != 0;
+									}
+								}
+							}
+							next[static_cast<size_t>(i + 1) + static_cast<size_t>(nt[0] + 2) * ((j + 1) + static_cast<size_t>(nt[1] + 2) * (k + 1))] = ok ? 1 : 0;
+						}
+					}
+				}
+				cov = next;
+			}
 			for (int k = 0; k < nt[2]; ++k) {
 				for (int j = 0; j < nt[1]; ++j) {
 					for (int i = 0; i < nt[0]; ++i) {
-						bool ok = true;
-						for (int c = -1; c <= 1 && ok; ++c) {
-							for (int b2 = -1; b2 <= 1 && ok; ++b2) {
-								for (int a2 = -1; a2 <= 1 && ok; ++a2) {
-									ok = cv(i + a2, j + b2, k + c) != 0;
-								}
-							}
-						}
-						if (!ok) {
+						if (cv(i, j, k) == 0) {
 							at(i, j, k) = 0;
 							allowed[static_cast<size_t>(i) + static_cast<size_t>(nt[0]) * (j + static_cast<size_t>(nt[1]) * k)] = 0;
 						}
@@ -631,7 +708,8 @@ template <typename problem_t> class AmrDriver
 			qk_interp_plan *whole = nullptr;
 			qkhost::check(qk_interp_plan_create(parent.levelHandle(), me.levelHandle(), &gf, me.nghost_cc_, ratio, 1, 0, nullptr, &whole), "qk_interp_plan_create(whole)");
 			auto *pn = qkhost::tab(parent.state_new_cc_[0]);
-			qkhost::check(qk_InterpFromCoarse(whole, nullptr, qkhost::tab(me.state_new_cc_[0]), pn, pn, 1.0, 0.0, Physics_Indices<problem_t>::nvarTotal_cc, amrInterpMethod_, 1),
+			qkhost::check(qk_InterpFromCoarse(whole, nullptr, qkhost::tab(me.state_new_cc_[0]), pn, pn, 1.0, 0.0, Physics_Indices<problem_t>::nvarTotal_cc, amrInterpMethod_,
+							  Sim::isAdvection ? 0 : 1),
 				      "qk_InterpFromCoarse(whole)");
 			qk_interp_plan_destroy(whole);
 			if (old) { // keep the old fine data where the new level still covers it
@@ -659,7 +737,9 @@ template <typename problem_t> class AmrDriver
 			amrex::MultiFab::Copy(me.state_old_cc_[0], me.state_new_cc_[0]);
 			me.tOldLev_ = me.tNewLev_ = parent.tNewLev_;
 			QK_HOST_HIP(hipDeviceSynchronize()); // `old` is released below
-			if (lev + 1 <= finestLevel()) {
+			// the child of a remade level needs new inter-level plans — unless it is about to be remade (or removed) itself: its OLD grids
+			// need not lie inside the new parent (a shrinking hierarchy: the blob of Advection2D leaving through a periodic face)
+			if (lev + 1 <= finestLevel() && lev + 1 <= max_level && !newBoxes[lev + 1].empty() && sameBoxes(level(lev + 1).allGrids_, newBoxes[lev + 1])) {
 				linkToParent(*finer_[lev], lev + 1);
 			}
 		}
@@ -788,7 +868,7 @@ template <typename problem_t> void QuokkaSimulation<problem_t>::setInitialCondit
 	amrex::ParmParse pa("amr");
 	pa.query("max_level", max_level);
 	if (max_level > 0) {
-		amr_ = std::make_shared<AmrDriver<problem_t>>(*this);
+		amr_ = std::make_shared<AmrDriver<problem_t, QuokkaSimulation<problem_t>>>(*this);
 		amr_->setInitialConditions();
 	} else {
 		AMRSimulation<problem_t>::setInitialConditions();

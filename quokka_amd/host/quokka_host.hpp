@@ -1134,7 +1134,7 @@ struct PeerBuffers {
 template <typename problem_t> struct SimulationData {
 };
 
-template <typename problem_t> class AmrDriver; // quokka_amr.hpp
+template <typename problem_t, typename SimT> class AmrDriver; // quokka_amr.hpp
 template <typename problem_t> class AMRSimulation;
 
 namespace qkhost
@@ -1190,24 +1190,29 @@ template <typename problem_t> class AMRSimulation
 	amrex::Vector<std::string> componentNames_cc_;
 	amrex::Real densityFloor_ = 0.0;
 	amrex::Real tempFloor_ = 0.0;
-	amrex::Vector<amrex::Real> tNew_{0.0};
-	amrex::Vector<amrex::Real> dt_{1.e100};
-	amrex::Vector<int> istep{0};
+	// One simulation object holds ONE level; whatever index a problem's hook uses — state_new_cc_[lev] inside ErrorEst(lev, ...), geom[lev],
+	// tNew_[lev] — addresses this object's level.  (geom, tNew_, dt_ and istep were one-element vectors until round 3: Advection2D's ErrorEst
+	// reads geom[lev].CellSizeArray() on the refined levels — out of bounds, a different cell size in one tagging out of fifty.)
+	template <typename T> struct ThisLevel {
+		T item{};
+		auto operator[](int /*lev*/) -> T & { return item; }
+		auto operator[](int /*lev*/) const -> T const & { return item; }
+		auto at(int /*lev*/) -> T & { return item; }
+		auto at(int /*lev*/) const -> T const & { return item; }
+		[[nodiscard]] auto size() const -> int { return 1; }
+	};
+	ThisLevel<amrex::Real> tNew_{0.0};
+	ThisLevel<amrex::Real> dt_{1.e100};
+	ThisLevel<int> istep{0};
 	amrex::Long cellUpdates_ = 0;
 	int nghost_cc_ = 4;
 	bool areInitialConditionsDefined_ = false;
 
-	amrex::Vector<amrex::Geometry> geom{1};
+	ThisLevel<amrex::Geometry> geom;
 	std::vector<amrex::Box> grids_; // level-0 BoxArray
 	amrex::Vector<amrex::BCRec> BCs_cc_;
 	// One simulation object holds ONE level (the AMR driver of quokka_amr.hpp owns one object per level): whatever level index a
 	// problem's hook uses (state_new_cc_[lev] inside ErrorEst(lev, ...), geom[lev]) addresses this object's level.
-	template <typename T> struct ThisLevel {
-		T item;
-		auto operator[](int /*lev*/) -> T & { return item; }
-		auto operator[](int /*lev*/) const -> T const & { return item; }
-		[[nodiscard]] auto size() const -> int { return 1; }
-	};
 	ThisLevel<amrex::MultiFab> state_new_cc_, state_old_cc_;
 	[[nodiscard]] auto boxArray(int /*lev*/ = 0) const -> std::vector<amrex::Box> const & { return grids_; }
 	[[nodiscard]] auto DistributionMap(int /*lev*/ = 0) const -> amrex::DistributionMapping { return {}; }
@@ -1652,6 +1657,25 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	QuokkaSimulation(amrex::Vector<amrex::BCRec> &BCs_cc, LevelSpec const &spec) : AMRSimulation<problem_t>(BCs_cc, spec) { construct(); }
 
 	// --- AMR level bookkeeping (used by quokka_amr.hpp; a uniform-grid run leaves the defaults)
+	static constexpr bool isAdvection = false;
+	// what the problem set on the level-0 object in problem_main, handed to the object of a refined level
+	void inheritSettings(QuokkaSimulation const &base)
+	{
+		cflNumber_ = base.cflNumber_;
+		densityFloor_ = base.densityFloor_;
+		tempFloor_ = base.tempFloor_;
+		reconstructionOrder_ = base.reconstructionOrder_;
+		integratorOrder_ = base.integratorOrder_;
+		useDualEnergy_ = base.useDualEnergy_;
+		abortOnFofcFailure_ = base.abortOnFofcFailure_;
+		artificialViscosityK_ = base.artificialViscosityK_;
+		radiationCflNumber_ = base.radiationCflNumber_;
+		radiationReconstructionOrder_ = base.radiationReconstructionOrder_;
+		maxSubsteps_ = base.maxSubsteps_;
+		radSourceTimeIndependent_ = base.radSourceTimeIndependent_;
+		dustGasInteractionCoeff_ = base.dustGasInteractionCoeff_;
+		this->constantDt_ = base.constantDt_;
+	}
 	double tOldLev_ = 0.0, tNewLev_ = 0.0; // tOld_[lev], tNew_[lev]
 	bool use_wavespeed_correction_ = false; // QuokkaSimulation.hpp:133 (not implemented: must stay false)
 	double fillTime_ = 0.0;		       // the time a ghost fill refers to (coarse data are interpolated to it)
@@ -1931,7 +1955,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	// amr.max_level > 0: the level machinery of quokka_amr.hpp takes over (this object is level 0); defined there
 	void setInitialConditions();
 	void evolve();
-	std::shared_ptr<AmrDriver<problem_t>> amr_;
+	std::shared_ptr<AmrDriver<problem_t, QuokkaSimulation<problem_t>>> amr_;
 
 	// ------------------------------------------------------------------ evolve (reference src/simulation.hpp:827-981)
 	void evolveSingleLevel()
@@ -2286,7 +2310,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_count_), sizeof(int64_t)));
 		QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_error_), sizeof(int)));
 		QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_signal_), 2 * sizeof(double)));
-		QK_HOST_HIP(hipMemset(d_error_, 0, sizeof(int)));
+		QK_HOST_HIP(hipMemsetAsync(d_error_, 0, sizeof(int), nullptr));
 		auto t = qkhost::traits<problem_t>();
 		if constexpr (HydroSystem<problem_t>::nscalars_ <= 3 && Physics_Traits<problem_t>::numMassScalars == 0 && Physics_Traits<problem_t>::is_hydro_enabled) {
 			scratchBytes_ = qk_hydro_stage_scratch_bytes(qkhost::Runtime::get().lev, &t);
@@ -2358,7 +2382,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	auto rhsPdvPredict(std::array<amrex::MultiFab, AMREX_SPACEDIM> const &fl, std::array<amrex::MultiFab, AMREX_SPACEDIM> const &vl,
 			   amrex::MultiFab const &stateOld, amrex::MultiFab &stateNew, double dt) -> int64_t
 	{
-		QK_HOST_HIP(hipMemset(d_count_, 0, sizeof(int64_t)));
+		QK_HOST_HIP(hipMemsetAsync(d_count_, 0, sizeof(int64_t), nullptr));
 		HydroSystem<problem_t>::ComputeRhsFromFluxes(rhs_, fl, geom[0].CellSizeArray(), ncompHydro_);
 		HydroSystem<problem_t>::AddInternalEnergyPdV(rhs_, stateOld, geom[0].CellSizeArray(), vl, redoFlag_);
 		HydroSystem<problem_t>::PredictStep(stateOld, stateNew, rhs_, dt, ncompHydro_, redoFlag_, d_count_);

@@ -226,3 +226,64 @@ def test_flux_register_conserves_the_composite_integral_in_two_dimensions(ctx):
         for n in range(nc):
             drift = abs(after[n].sum() - Uc0[n].sum()) / abs(Uc0[n].sum())
             assert (drift <= 1e-14) if with_reflux else (drift > 1e-6), (with_reflux, n, drift)
+
+
+def test_flux_register_on_a_ring_of_fine_boxes_is_conservative_and_deterministic(ctx):
+    """a refined RING (what a gradient criterion makes of a square pulse: Advection2D) has concave corners — coarse cells that touch fine faces of
+    two directions, fine boxes that meet corner to corner: the brute-force audit of the 2-D test above on 12 fine boxes around a hole, twice"""
+    nc, nd = 2, 2
+    dom_c, dom_f = [64, 64, 1], [128, 128, 1]
+    crse_boxes = [([16 * i, 16 * j, 0], [16 * i + 15, 16 * j + 15, 0]) for j in range(4) for i in range(4)]
+    fine_boxes = [([16 * i, 16 * j, 0], [16 * i + 15, 16 * j + 15, 0]) for j in range(2, 6) for i in range(2, 6) if not (i in (3, 4) and j in (3, 4))]
+    assert len(fine_boxes) == 12
+    crse, fine = Level(ctx, 2, crse_boxes), Level(ctx, 2, fine_boxes)
+    cgeom = Geometry(2, dom_c, [0.0] * 3, [1.0, 1.0, 1.0], [1, 1, 0])
+    dxc = cgeom.dx
+    dxf = [dxc[0] / 2, dxc[1] / 2, 1.0]
+    rng = np.random.default_rng(35)
+    Fc = [rng.standard_normal((nc, 1, dom_c[1], dom_c[0])) for _ in range(nd)]
+    Ff = [[rng.standard_normal((nc, 1, dom_f[1], dom_f[0])) for _ in range(nd)] for _ in range(2)]
+
+    def div(F, dx):
+        out = np.zeros_like(F[0])
+        for d in range(nd):
+            out += (F[d] - np.roll(F[d], -1, axis=3 - d)) / dx[d]
+        return out
+
+    def to_boxes(F, lev, boxes, dom):
+        mfs = [MultiFab(lev, nc, 0, facedir=d) for d in range(nd)]
+        for d in range(nd):
+            for b, (lo, hi) in enumerate(boxes):
+                idx = [np.arange(lo[e], hi[e] + 1 + (1 if e == d else 0)) % dom[e] for e in range(3)]
+                mfs[d].set_fab(b, F[d][:, idx[2][:, None, None], idx[1][None, :, None], idx[0][None, None, :]])
+        return mfs
+
+    Uc0 = rng.standard_normal((nc, 1, dom_c[1], dom_c[0])) + 5.0
+    Uf0 = np.repeat(np.repeat(Uc0, 2, axis=2), 2, axis=3)
+    dtc = 0.013
+    Uc = Uc0 + dtc * div(Fc, dxc)
+    Uf = Uf0 + (dtc / 2) * div(Ff[0], dxf) + (dtc / 2) * div(Ff[1], dxf)
+    results = []
+    for rep in range(2):
+        fr = FluxRegister(crse, fine, cgeom, nc, ratio=(2, 2, 1))
+        fr.reset()
+        fr.CrseAdd(to_boxes(Fc, crse, crse_boxes, dom_c), dxc, dtc)
+        for s in range(2):
+            fr.FineAdd(to_boxes(Ff[s], fine, fine_boxes, dom_f), dxf, dtc / 2)
+        Uc_mf = MultiFab(crse, nc, 4, fill=0.0)
+        for b, (lo, hi) in enumerate(crse_boxes):
+            Uc_mf.valid(b).copy_(torch.from_numpy(np.ascontiguousarray(Uc[:, :, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1])))
+        fr.Reflux(Uc_mf)
+        Uf_mf = MultiFab(fine, nc, 4, fill=0.0)
+        for b, (lo, hi) in enumerate(fine_boxes):
+            Uf_mf.valid(b).copy_(torch.from_numpy(np.ascontiguousarray(Uf[:, :, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1])))
+        AverageDown(crse, fine, ratio=(2, 2, 1))(Uf_mf, Uc_mf, 0, nc)
+        torch.cuda.synchronize()
+        after = np.zeros_like(Uc0)
+        for b, (lo, hi) in enumerate(crse_boxes):
+            after[:, :, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1] = Uc_mf.valid(b).cpu().numpy()
+        for n in range(nc):
+            drift = abs(after[n].sum() - Uc0[n].sum()) / abs(Uc0[n].sum())
+            assert drift <= 1e-14, (rep, n, drift)
+        results.append(after)
+    assert np.array_equal(results[0], results[1])
