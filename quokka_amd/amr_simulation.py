@@ -485,6 +485,17 @@ class AmrSimulation:
                 break
             self.levels.append(self._make_level(lev + 1, boxes))
             self._set_level_ic(lev + 1)
+        # AmrMesh::MakeNewGrids(time) iterates at start-up: once a level exists, the levels below it are rebuilt around it (top-down, with
+        # the nesting footprints), which may make room for one more level — a level whose first grids were too narrow to hold a child
+        # (the ring around a sharp pulse) gets its child in the next pass.  Every (re)built level takes the problem's initial conditions.
+        if self.static_fine_boxes is None:
+            for _ in range(self.max_level + 1):
+                before = [sorted(map(str, L.all_boxes)) for L in self.levels]
+                self.regrid(0)
+                for lev in range(1, self.finest_level + 1):
+                    self._set_level_ic(lev)
+                if [sorted(map(str, L.all_boxes)) for L in self.levels] == before:
+                    break
         for lev in range(self.finest_level - 1, -1, -1):
             self.AverageDownTo(lev)
 

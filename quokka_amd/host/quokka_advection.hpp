@@ -3,8 +3,8 @@
 //   AdvectionSimulation<problem_t>     reference src/linear_advection/AdvectionSimulation.hpp     -> the level-0 driver below
 // so that src/problems/Advection, AdvectionSemiellipse and Advection2D compile unchanged.  With amr.max_level > 0 the levels are objects of this
 // class under the level machinery of quokka_amr.hpp (AmrDriver<problem_t, AdvectionSimulation<problem_t>>: FillPatch without energy hooks, both
-// RK stages added to the flux registers with half the step): Advection2D's ctest deck refines three levels; the error drops from 0.34 (level 0
-// only) to 0.185 that way — the reference's criterion is 0.15.
+// RK stages added to the flux registers with half the step): Advection2D's ctest deck refines three levels and meets its 0.15 criterion that
+// way (0.1447; 0.34 on level 0 alone — DESIGN.md §17).
 #ifndef QK_HOST_QUOKKA_ADVECTION_HPP_
 #define QK_HOST_QUOKKA_ADVECTION_HPP_
 

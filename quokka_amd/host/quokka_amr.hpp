@@ -87,6 +87,24 @@ template <typename problem_t, typename SimT> class AmrDriver
 			makeLevel(lev + 1, boxes);
 			level(lev + 1).setInitialConditionsAtLevel();
 		}
+		// AmrMesh::MakeNewGrids(time) iterates at start-up: once a level exists, the levels below it are rebuilt around it (top-down, with the
+		// nesting footprints), which may make room for one more level — a level whose first grids were too narrow to hold a child (the ring
+		// around a sharp pulse: Advection2D) gets its child in the next pass.  Every (re)built level takes the problem's initial conditions.
+		for (int pass = 0; pass <= max_level; ++pass) {
+			std::vector<std::vector<amrex::Box>> before;
+			for (int l = 1; l <= finestLevel(); ++l) {
+				before.push_back(level(l).allGrids_);
+			}
+			regrid(0);
+			bool same = static_cast<int>(before.size()) == finestLevel();
+			for (int l = 1; l <= finestLevel(); ++l) {
+				level(l).setInitialConditionsAtLevel();
+				same = same && sameBoxes(before[l - 1], level(l).allGrids_);
+			}
+			if (same) {
+				break;
+			}
+		}
 		for (int lev = finestLevel() - 1; lev >= 0; --lev) {
 			averageDownTo(lev);
 		}

@@ -381,11 +381,11 @@ def test_unmodified_advection2d_problem_with_its_three_level_ctest_deck(tmp_path
     """Advection2D, unchanged, with the reference's ctest deck (tests/advection2d_amr.in: 64^2 base grid, amr.max_level = 3, subcycling, reflux,
     periodic): the advection solver on a 2-D hierarchy — AdvectionSimulation objects as the levels of AmrDriver (quokka_advection.hpp).  The
     square pulse crosses the periodic faces once; the hierarchy shrinks and regrows on the way (tags buffered through the periodic faces,
-    proper nesting across them, the margins of levels rebuilt together).  Checked: all four levels advance; the scalar is conserved to rounding —
-    also through the regrids: the interpolation of new fine cells carries no energy hook here —; two runs agree in every bit (they did not while
-    geom[lev] of a level object read past a one-element vector: quokka_host.hpp ThisLevel); the error against the exact solution drops from 0.34 (level 0
-    only) to 0.185.  The reference's criterion is 0.15 — 0.138 of which is the difference between the point-sampled reference solution on
-    level 0 and the exact cell averages; this hierarchy does not get that close: exit status 1, not 0."""
+    proper nesting across them, the margins of levels rebuilt together, the start-up iteration that gives the narrow ring of level 2 its
+    child).  EXIT STATUS 0: the reference's criterion — relative L1 error against its point-sampled solution <= 0.15, of which 0.138 is the
+    difference between point samples and exact cell averages on level 0 — is met with 0.1447 (0.34 on level 0 alone).  Also: all four levels
+    advance; the scalar is conserved to rounding through every regrid and through the periodic faces; two runs agree in every bit (they did not
+    while geom[lev] of a level object read past a one-element vector: quokka_host.hpp ThisLevel)."""
     import re
     args = [exe("ref_Advection2D"), os.path.join(HOST, "decks", "advection2d_amr.in")]
     dumps = []
@@ -393,7 +393,7 @@ def test_unmodified_advection2d_problem_with_its_three_level_ctest_deck(tmp_path
         dump = str(tmp_path / f"{name}.bin")
         p = subprocess.run(args + [f"qk.dump_state={dump}"], capture_output=True, text=True, timeout=900, cwd=str(tmp_path), env=dict(os.environ, **env))
         out = p.stdout + p.stderr
-        assert p.returncode in (0, 1), out[-2500:]
+        assert p.returncode == 0, out[-2500:]  # (t0, no step taken, passes as well: the initial hierarchy is 0.129 from the point samples)
         dumps.append((np.fromfile(dump, dtype=np.float64), out))
     (u0, _), (ua, out), (ub, _) = dumps
     assert np.array_equal(ua, ub)
@@ -401,4 +401,4 @@ def test_unmodified_advection2d_problem_with_its_three_level_ctest_deck(tmp_path
     assert len(updates) == 4 and all(u > 0 for u in updates) and updates[0] == 227 * 64 * 64, updates
     assert abs(ua.sum() - u0.sum()) <= 1e-13 * u0.sum(), (ua.sum(), u0.sum())
     err = float(re.search(r"Relative rms L1 error norm = (\S+)", out).group(1))
-    assert 0.138 < err < 0.20, err
+    assert 0.138 < err <= 0.15, err
