@@ -402,3 +402,34 @@ def test_unmodified_advection2d_problem_with_its_three_level_ctest_deck(tmp_path
     assert abs(ua.sum() - u0.sum()) <= 1e-13 * u0.sum(), (ua.sum(), u0.sum())
     err = float(re.search(r"Relative rms L1 error norm = (\S+)", out).group(1))
     assert 0.138 < err <= 0.15, err
+
+
+def test_unmodified_shocktube_cma_problem_with_its_refined_ctest_deck(tmp_path):
+    """HydroShocktubeCMA, unchanged, with the reference's ctest deck (tests/shocktube_cma.in: three mass scalars with the consistent multi-fluid
+    advection of the partial densities, artificial viscosity, one refined level with subcycling and reflux — nine components through
+    interpolation, flux registers and average-down; mass scalars keep a level off the fused stage: the reference-shaped operators run).  Exit
+    status 0: after every step the partial densities sum to the density to 1e-13 on level 0, which holds the average of the refined level
+    (test_hydro_shocktube_cma.cpp:205-235)."""
+    rc, out = run([exe("ref_HydroShocktubeCMA"), os.path.join(HOST, "decks", "shocktube_cma.in")], str(tmp_path))
+    assert rc == 0, out[-2500:]
+    import re
+    updates = [int(x) for x in re.findall(r"Zone-updates on level \d: (\d+) ", out)]
+    assert len(updates) == 2 and updates[1] > updates[0] > 0, updates
+
+
+@pytest.mark.parametrize("name,deck", [("RadBeam", "beam.in"), ("RadShadow", "shadow.in")])
+def test_unmodified_radiation_problems_on_two_dimensional_hierarchies(tmp_path, name, deck):
+    """RadBeam and RadShadow, unchanged, with the reference's decks (tests/beam.in, tests/shadow.in: 2-D, amr.max_level = 2, subcycling, reflux;
+    radiation only — is_hydro_enabled = false —, custom boundary functions on the device): the radiation block through FillPatch, the second
+    flux register of a level and average-down on 2-D hierarchies.  The reference gives these problems no pass criterion (they return 0): 40
+    coarse steps here, every level advances and the state stays finite."""
+    import re
+    dump = str(tmp_path / "state.bin")
+    p = subprocess.run([exe(f"ref_{name}"), os.path.join(HOST, "decks", deck), "plotfile_interval=-1", "checkpoint_interval=-1", f"qk.dump_state={dump}"],
+                       capture_output=True, text=True, timeout=900, cwd=str(tmp_path), env=dict(os.environ, QK_MAX_COARSE_STEPS="40"))
+    out = p.stdout + p.stderr
+    assert p.returncode == 0, out[-2500:]
+    updates = [int(x) for x in re.findall(r"Zone-updates on level \d: (\d+) ", out)]
+    assert len(updates) == 3 and all(u > 0 for u in updates), updates
+    u = np.fromfile(dump, dtype=np.float64)
+    assert np.isfinite(u).all()
