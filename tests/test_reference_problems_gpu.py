@@ -433,3 +433,38 @@ def test_unmodified_radiation_problems_on_two_dimensional_hierarchies(tmp_path, 
     assert len(updates) == 3 and all(u > 0 for u in updates), updates
     u = np.fromfile(dump, dtype=np.float64)
     assert np.isfinite(u).all()
+
+
+MORE_CTESTS = [  # (problem directory, deck of its add_test line, {extern path the problem opens: committed copy under tests/golden}, slow)
+    ("HydroHighMach", "HighMach.in", {"highmach_reference.txt": "highmach_reference.txt"}, False),
+    ("HydroLeblanc", "leblanc.in", {"ppm1d/leblanc.dat": "ppm1d_leblanc.dat"}, False),
+    ("HydroSMS", "SlowMovingShock.in", {}, False),
+    ("HydroShuOsher", "ShuOsher.in", {"ShuOsher_athena_3c_hllc_vl.txt": "ShuOsher_athena_3c_hllc_vl.txt"}, False),
+    ("HydroVacuum", "vacuum.in", {"Toro/e1rpex.out": "Toro_e1rpex.out"}, False),
+    ("HydroWave", "hydro_wave.in", {}, False),
+    ("RadSuOlson", "SuOlson.in", {}, False),
+    ("RadhydroShock", "radshock_dimensionless.in", {"LowrieEdwards/shock.txt": "LowrieEdwards_shock.txt"}, False),
+    ("RadMarshakCGS", "MarshakCGS.in", {"SuOlson/100pt_tau10p0.dat": "SuOlson_100pt_tau10p0.dat"}, False),
+    ("RadPulse", "RadPulse.in", {}, False),
+    ("RadhydroBB", "RadhydroBB.in", {"Doppler-spectrum/exact_flux_density.csv": "Doppler_exact_flux_density.csv"}, False),
+    ("RadhydroPulse", "RadhydroPulse.in", {}, False),
+    ("RadhydroPulseDyn", "RadhydroPulseDyn.in", {}, False),
+    ("RadhydroPulseGrey", "RadhydroPulseGrey.in", {}, False),
+    # one-cell problems of ~1e5 steps: bound by launch latency, about four minutes each — run with QK_SLOW_TESTS=1 (both exit 0: 2.4e-7 / 3.3e-5
+    # against their 1e-5 / ... criteria on the builder's box)
+    ("RadMatterCoupling", "energyexchange.in", {}, True),
+    ("RadMatterCouplingRSLA", "MatterEnergyExchangeRSLA.in", {}, True),
+]
+
+
+@pytest.mark.parametrize("name,deck,extern,slow", MORE_CTESTS, ids=[c[0] for c in MORE_CTESTS])
+def test_unmodified_reference_ctest_exits_zero(tmp_path, name, deck, extern, slow):
+    """The reference's ctest of that name: its problem file compiled unchanged against the host mirror, run from the reference's own deck in a
+    working directory laid out like the reference's tests/ (data tables under ../extern), and held to the pass criterion coded in the problem
+    file — exit status 0.  (The CPU oracle meets the same criteria in tests/test_oracle_known_answers.py; this is the GPU path through the C++17
+    host, hooks compiled as device code.)"""
+    if slow and os.environ.get("QK_SLOW_TESTS") != "1":
+        pytest.skip("about four minutes of launch latency; QK_SLOW_TESTS=1 runs it")
+    cwd = extern_tree(tmp_path, extern)
+    rc, out = run([exe(f"ref_{name}"), os.path.join(HOST, "decks", deck), "plotfile_interval=-1", "checkpoint_interval=-1"], cwd)
+    assert rc == 0, out[-2500:]
