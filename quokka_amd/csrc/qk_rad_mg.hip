@@ -2,162 +2,12 @@
 // One thread per cell, the NG per-group vectors in registers (one kernel instantiation per supported NG).  Arithmetic in qk_rad_mg_device.hpp.
 #include "qk_internal.hpp"
 #include "qk_rad_mg_device.hpp"
+#include "qk_rad_mg_launch.hpp"
 
 using namespace qk;
 
 namespace
 {
-
-// the spread counter slots of qk_rad_ops.hip (same layout, same finishing kernel semantics)
-constexpr int NSLOT = 1024, SLOT_STRIDE = 32;
-
-__global__ void __launch_bounds__(NSLOT) k_mg_counters_finish(int *slots, int *it, int *fail)
-{
-	__shared__ int red[NSLOT / 64][5];
-	int *slot = slots + static_cast<size_t>(threadIdx.x) * SLOT_STRIDE;
-	int v[5];
-#pragma unroll
-	for (int n = 0; n < 5; ++n) {
-		v[n] = slot[n];
-		slot[n] = 0;
-	}
-	for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-		for (int n = 0; n < 5; ++n) {
-			const int o = __shfl_xor(v[n], off);
-			v[n] = (n == 2) ? max(v[n], o) : v[n] + o;
-		}
-	}
-	if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-		for (int n = 0; n < 5; ++n) {
-			red[threadIdx.x / 64][n] = v[n];
-		}
-	}
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		int t[5] = {0, 0, 0, 0, 0};
-		for (int w = 0; w < NSLOT / 64; ++w) {
-#pragma unroll
-			for (int n = 0; n < 5; ++n) {
-				t[n] = (n == 2) ? max(t[n], red[w][n]) : t[n] + red[w][n];
-			}
-		}
-		it[0] += t[0];
-		it[1] += t[1];
-		it[2] = max(it[2], t[2]);
-		fail[0] += t[3];
-		fail[2] += t[4];
-	}
-}
-
-auto mgCounterSlots(qk_ctx *ctx) -> int *
-{
-	std::lock_guard<std::mutex> lock(ctx->mtx);
-	if (ctx->counter_slots == nullptr) {
-		void *p = nullptr;
-		const size_t bytes = sizeof(int) * NSLOT * SLOT_STRIDE;
-		if (hipMalloc(&p, bytes) != hipSuccess || hipMemsetAsync(p, 0, bytes, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
-			return nullptr;
-		}
-		ctx->owned.push_back(p);
-		ctx->counter_slots = static_cast<int *>(p);
-	}
-	return ctx->counter_slots;
-}
-
-template <int NG, bool DUST>
-__global__ void __launch_bounds__(256, 1) k_rad_source_mg(const qk_box *boxes, Rad rad, RadMG<NG> mg, Eos eos, qk_array4 *cons_t, const qk_array4 *src_t, double dt, int stage,
-							   int *slots, int *d_iteration_counter, int *d_failure_counter)
-{
-	const int b = blockIdx.y;
-	const qk_box bx = boxes[b];
-	const int len0 = bx.hi[0] - bx.lo[0] + 1, len1 = bx.hi[1] - bx.lo[1] + 1, len2 = bx.hi[2] - bx.lo[2] + 1;
-	const int64_t t_raw = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-	const int64_t n01 = static_cast<int64_t>(len0) * len1;
-	const bool valid = t_raw < n01 * len2; // lanes past the end stay alive for the wave reduction of the counters
-	const int64_t t = valid ? t_raw : 0;
-	const int k = static_cast<int>(t / n01);
-	const int rr = static_cast<int>(t - k * n01);
-	const int j = rr / len0;
-	const int i = rr - j * len0;
-	int ntot = 0, nmax = 0, nsolve = 0, fnewton = 0, fouter = 0, ndecoupled = 0, fdust = 0;
-	if (valid) {
-		WA4 S(cons_t[b]);
-		RA4 Q(src_t[b]);
-		const int64_t c = S.idx(bx.lo[0] + i, bx.lo[1] + j, bx.lo[2] + k);
-		constexpr int NC = RAD0 + NRAD * NG;
-		double U[NC], srcval[NG];
-#pragma unroll
-		for (int n = 0; n < NC; ++n) {
-			U[n] = S.p[c + S.ns * n];
-		}
-#pragma unroll
-		for (int g = 0; g < NG; ++g) {
-			srcval[g] = Q(bx.lo[0] + i, bx.lo[1] + j, bx.lo[2] + k, g);
-		}
-		radSourceCellMG<NG, DUST>(rad, mg, eos, U, srcval, dt, stage, ntot, nmax, nsolve, fnewton, fouter, &ndecoupled, &fdust);
-#pragma unroll
-		for (int n = 1; n < NC; ++n) { // rho (comp 0) is never modified
-			S.p[c + S.ns * n] = U[n];
-		}
-	}
-	int wsolve = nsolve, wtot = ntot, wmax = nmax, wfn = fnewton, wfo = fouter;
-	for (int off = 32; off > 0; off >>= 1) {
-		wsolve += __shfl_xor(wsolve, off);
-		wtot += __shfl_xor(wtot, off);
-		wmax = max(wmax, __shfl_xor(wmax, off));
-		wfn += __shfl_xor(wfn, off);
-		wfo += __shfl_xor(wfo, off);
-	}
-	if ((threadIdx.x & 63) == 0) {
-		const unsigned wave = (blockIdx.x + gridDim.x * blockIdx.y) * (blockDim.x / 64) + threadIdx.x / 64;
-		int *slot = slots + static_cast<size_t>(wave % NSLOT) * SLOT_STRIDE;
-		atomicAdd(&slot[0], wsolve);
-		atomicAdd(&slot[1], wtot);
-		atomicMax(&slot[2], wmax);
-		if (wfn != 0) {
-			atomicAdd(&slot[3], wfn);
-		}
-		if (wfo != 0) {
-			atomicAdd(&slot[4], wfo);
-		}
-	}
-	if constexpr (DUST) { // p_iteration_counter[3] (decoupled solves) and p_iteration_failure_counter[1] (negative dust temperature), one atomic per wave
-		int wdec = ndecoupled, wfd = fdust;
-		for (int off = 32; off > 0; off >>= 1) {
-			wdec += __shfl_xor(wdec, off);
-			wfd += __shfl_xor(wfd, off);
-		}
-		if ((threadIdx.x & 63) == 0) {
-			if (wdec != 0) {
-				atomicAdd(&d_iteration_counter[3], wdec);
-			}
-			if (wfd != 0) {
-				atomicAdd(&d_failure_counter[1], wfd);
-			}
-		}
-	}
-}
-
-template <int NG>
-auto launchSourceMG(qk_level *lev, qk_stream s, const qk_rad_traits *rt, const qk_hydro_traits *t, qk_array4 *cons_t, const qk_array4 *src_t, double dt, int stage,
-		    int *slots, int *d_it, int *d_fail) -> void
-{
-	Rad rad(*rt);
-	rad.mean_molecular_mass = t->mean_molecular_weight;
-	const RadMG<NG> mg(*rt, t->boltzmann_constant);
-	const Eos eos(*t);
-	const CellLaunch L = cellLaunch(lev, 0, -1);
-	ProfScope ps(lev->ctx, static_cast<hipStream_t>(s), "rad_AddSourceTermsMultiGroup");
-	if (rt->enable_dust_gas_thermal_coupling_model != 0) {
-		hipLaunchKernelGGL((k_rad_source_mg<NG, true>), L.grid, L.block, 0, static_cast<hipStream_t>(s), lev->d_boxes, rad, mg, eos, cons_t, src_t, dt, stage, slots,
-				   d_it, d_fail);
-	} else {
-		hipLaunchKernelGGL((k_rad_source_mg<NG, false>), L.grid, L.block, 0, static_cast<hipStream_t>(s), lev->d_boxes, rad, mg, eos, cons_t, src_t, dt, stage, slots,
-				   d_it, d_fail);
-	}
-}
 
 template <int NG> __global__ void k_mg_planck_fractions(Rad rad, RadMG<NG> mg, int n, const double *T, double *frac_out, double *E_out)
 {
@@ -193,6 +43,10 @@ auto checkMG(qk_ctx *ctx, const qk_rad_traits *rt) -> int
 	if (rt->mg_opacity_model < MG_PIECEWISE_CONSTANT || rt->mg_opacity_model > MG_PPL_FULL_SPECTRUM) {
 		return setError(ctx, QK_ERR_UNSUPPORTED,
 				"mg_opacity_model must be 1 (piecewise_constant_opacity), 2 (PPL_opacity_fixed_slope_spectrum) or 3 (PPL_opacity_full_spectrum)");
+	}
+	if (rt->opacity_model == QK_HOOK_COMPILED) {
+		return setError(ctx, QK_ERR_UNSUPPORTED,
+				"multigroup: a compiled DefineOpacityExponentsAndLowerValues hook exists only in the problem's own translation unit (qk_problem_kernels.hpp)");
 	}
 	if (rt->beta_order != 0 && rt->beta_order != 1) {
 		return setError(ctx, QK_ERR_UNSUPPORTED, "multigroup source term: beta_order must be 0 or 1 (source_terms_multi_group.hpp:526)");
@@ -277,17 +131,9 @@ int qk_rad_AddSourceTermsMultiGroup(qk_level *lev, qk_stream s, const qk_rad_tra
 	QK_REQUIRE(lev->ctx, cons_t && src_t && d_iteration_counter && d_failure_counter, "AddSourceTermsMultiGroup: NULL");
 	QK_REQUIRE(lev->ctx, stage == 1 || stage == 2, "AddSourceTermsMultiGroup: stage must be 1 or 2");
 	QK_REQUIRE(lev->ctx, t->nscalars == 0 && t->nmscalars == 0, "AddSourceTermsMultiGroup: radFirstIndex is 6 (no passive scalars beside radiation)");
-	int *slots = mgCounterSlots(lev->ctx);
-	QK_REQUIRE(lev->ctx, slots != nullptr, "AddSourceTermsMultiGroup: cannot allocate the counter slots");
-	if (lev->nboxes > 0) {
-		QK_MG_DISPATCH(rt->ngroups, (launchSourceMG<NG>(lev, s, rt, t, cons_t, src_t, dt, stage, slots, d_iteration_counter, d_failure_counter)))
-	}
-	hipLaunchKernelGGL(k_mg_counters_finish, dim3(1), dim3(NSLOT), 0, static_cast<hipStream_t>(s), slots, d_iteration_counter, d_failure_counter);
-	const hipError_t e = hipGetLastError();
-	if (e != hipSuccess) {
-		return setError(lev->ctx, QK_ERR_HIP, "AddSourceTermsMultiGroup", hipGetErrorString(e));
-	}
-	return QK_OK;
+	int rc_launch = QK_OK;
+	QK_MG_DISPATCH(rt->ngroups, (rc_launch = radSourceMGImpl<NG>(lev, s, rt, t, cons_t, src_t, dt, stage, d_iteration_counter, d_failure_counter)))
+	return rc_launch;
 }
 
 int qk_rad_mg_planck_fractions(qk_ctx *ctx, const qk_rad_traits *rt, double kB, int n, const double *T, double *fractions, double *Erad_g)

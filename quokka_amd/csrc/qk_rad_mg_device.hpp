@@ -81,6 +81,10 @@ template <int NG> struct RadMG {
 			cool[g] = t.cooling_linear_coeff[g];
 		}
 	}
+	// DefineOpacityExponentsAndLowerValues(rad_boundaries, rho, Tgas) is about to be read at (rho, Tgas): nothing to do for the closed set (the
+	// exponents are constants, the lower values are scaled in lower()).  A type derived from this one in a problem's translation unit
+	// (quokka_amd/host/qk_problem_kernels.hpp: ProblemRadMG) refreshes kexp / klow from the problem's compiled hook here.
+	QK_DEV void at(double /*rho*/, double /*T*/) {}
 	// DefineOpacityExponentsAndLowerValues(rad_boundaries, rho, Tgas): the factor every lower value carries
 	QK_DEV auto lowerScale(double rho, double T) const -> double
 	{
@@ -255,10 +259,11 @@ template <int NG> struct OpacityTermsMG {
 };
 
 // source_terms_multi_group.hpp:7-60 (kappaF / delta terms of `ot` are left alone: they are recomputed before they are read)
-template <int NG>
-QK_DEV void kappaEAndKappaP(RadMG<NG> const &m, double T, double rho, const double ratios[NG], const double fourPiBoverC[NG], const double Erad[NG], int n_iter,
+template <int NG, class M>
+QK_DEV void kappaEAndKappaP(M &m, double T, double rho, const double ratios[NG], const double fourPiBoverC[NG], const double Erad[NG], int n_iter,
 			    OpacityTermsMG<NG> &ot)
 {
+	m.at(rho, T); // :16
 	double lower[NG + 1];
 #pragma unroll
 	for (int g = 0; g < NG + 1; ++g) {
@@ -300,8 +305,9 @@ QK_DEV void kappaEAndKappaP(RadMG<NG> const &m, double T, double rho, const doub
 }
 
 // source_terms_multi_group.hpp:62-96 + ComputeDiffusionFluxMeanOpacity (radiation_system.hpp:1328-1352)
-template <int NG> QK_DEV void kappaFAndDeltaTerms(Rad const &r, RadMG<NG> const &m, double T, double rho, const double fourPiBoverC[NG], OpacityTermsMG<NG> &ot)
+template <int NG, class M> QK_DEV void kappaFAndDeltaTerms(Rad const &r, M &m, double T, double rho, const double fourPiBoverC[NG], OpacityTermsMG<NG> &ot)
 {
+	m.at(rho, T); // :70 (the work term that follows the n == 0 call reads the exponents of the same point, :266)
 	double delta_nu_B_at_edge[NG];
 	// B at the group edges: each interior edge is the right edge of one group and the left edge of the next (same operands, evaluated once)
 	double B_edge[NG + 1];
@@ -358,8 +364,8 @@ template <int NG> struct NewtonResultMG {
 };
 
 // source_terms_multi_group.hpp:149-358 (+ ComputeJacobianForGas :98-147 and SolveLinearEqs, radiation_system.hpp:547-558, in line)
-template <int NG>
-QK_DEV void solveGasRadiationEnergyExchange(Rad const &r, RadMG<NG> const &m, Eos const &eos, double Egas0, const double Erad0Vec[NG], double rho, double dt,
+template <int NG, class M>
+QK_DEV void solveGasRadiationEnergyExchange(Rad const &r, M &m, Eos const &eos, double Egas0, const double Erad0Vec[NG], double rho, double dt,
 					    int n_outer_iter, const double work[NG], const double vel_times_F[NG], const double Src[NG], NewtonResultMG<NG> &res,
 					    int &n_newton_total, int &n_newton_max, int &n_solves, int &fail_newton)
 {
@@ -522,8 +528,8 @@ QK_DEV void solveGasRadiationEnergyExchange(Rad const &r, RadMG<NG> const &m, Eo
 
 // radiation_system.hpp:1420-1483 (nGroups_ > 1), n_step == 0: the dust temperature at which absorption, emission and the gas-dust exchange balance,
 // by BackwardEulerOneVariable (:1387-1418)
-template <int NG>
-QK_DEV auto dustTemperatureBateKetoMG(Rad const &r, RadMG<NG> const &m, double T_gas, double T_d_init, double rho, const double Erad[NG], double N_d, double dt,
+template <int NG, class M>
+QK_DEV auto dustTemperatureBateKetoMG(Rad const &r, M &m, double T_gas, double T_d_init, double rho, const double Erad[NG], double N_d, double dt,
 				      const double ratios[NG]) -> double
 {
 	const double Lambda_compare = N_d * sqrt(T_gas) * T_gas;
@@ -576,8 +582,8 @@ QK_DEV auto dustTemperatureBateKetoMG(Rad const &r, RadMG<NG> const &m, double T
 // radiation_dust_system.hpp:228-576 (+ ComputeJacobianForGasAndDust :22-83, ...Decoupled :85-128, SolveLinearEqs in line; net cooling and cosmic-ray
 // heating are the defaults, zero).  dust_model 1: gas, dust and the groups in one system; dust_model 2 (weak gas-dust exchange): the dust temperature and
 // the groups are iterated with the exchange rate frozen, the gas energy follows from it afterwards.
-template <int NG>
-QK_DEV void solveGasDustRadiationEnergyExchange(Rad const &r, RadMG<NG> const &m, Eos const &eos, double Egas0, const double Erad0Vec[NG], double rho, double coeff_n,
+template <int NG, class M>
+QK_DEV void solveGasDustRadiationEnergyExchange(Rad const &r, M &m, Eos const &eos, double Egas0, const double Erad0Vec[NG], double rho, double coeff_n,
 						double dt, int n_outer_iter, const double work[NG], const double vel_times_F[NG], const double Src[NG],
 						NewtonResultMG<NG> &res, int &n_newton_total, int &n_newton_max, int &n_solves, int &n_decoupled, int &fail_newton,
 						int &fail_dust)
@@ -959,8 +965,8 @@ QK_DEV void solveGasDustRadiationEnergyExchange(Rad const &r, RadMG<NG> const &m
 
 // source_terms_multi_group.hpp:522-813 for one cell (UpdateFlux :360-520 in line).  U[6 + 4 NG] in place; counters as in the reference.
 // DUST: ISM_Traits::enable_dust_gas_thermal_coupling_model (its own instantiation, as in the single-group kernel)
-template <int NG, bool DUST = false>
-QK_DEV void radSourceCellMG(Rad const &r, RadMG<NG> const &m, Eos const &eos, double U[RAD0 + NRAD * NG], const double srcval[NG], double dt_radiation, int stage,
+template <int NG, bool DUST = false, class M>
+QK_DEV void radSourceCellMG(Rad const &r, M &m, Eos const &eos, double U[RAD0 + NRAD * NG], const double srcval[NG], double dt_radiation, int stage,
 			    int &n_newton_total, int &n_newton_max, int &n_solves, int &fail_newton, int &fail_outer, int *n_decoupled = nullptr,
 			    int *fail_dust = nullptr)
 {
@@ -1032,6 +1038,7 @@ QK_DEV void radSourceCellMG(Rad const &r, RadMG<NG> const &m, Eos const &eos, do
 			}
 		} else {
 			double lower[NG + 1], ratios[NG], am1[NG];
+			m.at(rho, __builtin_nan("")); // :733
 #pragma unroll
 			for (int g = 0; g < NG + 1; ++g) {
 				lower[g] = m.lower(g, rho, __builtin_nan(""));
@@ -1073,6 +1080,7 @@ QK_DEV void radSourceCellMG(Rad const &r, RadMG<NG> const &m, Eos const &eos, do
 			}
 		} else {
 			double frac[NG], fourPiBoverC[NG];
+			m.at(rho, en.T_d); // :428 (the exponents of the pressure and work terms below)
 			planckEnergyFractions<NG>(m, en.T_d, frac);
 			thermalRadiationMG<NG, DUST>(r, frac, en.T_d, fourPiBoverC);
 #pragma unroll

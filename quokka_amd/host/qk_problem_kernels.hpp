@@ -17,6 +17,7 @@
 #ifndef QK_PROBLEM_KERNELS_HPP_
 #define QK_PROBLEM_KERNELS_HPP_
 
+#include "../csrc/qk_rad_mg_launch.hpp"
 #include "../csrc/qk_rad_source_launch.hpp"
 
 namespace qkhost
@@ -77,6 +78,53 @@ auto addSourceTermsSingleGroup(qk_level *lev, const qk_rad_traits *rt, const qk_
 		return qk::radSourceImpl<true, true, R, EC>(lev, nullptr, rt, t, cons_t, src_t, dt, stage, d_iteration_counter, d_failure_counter);
 	}
 	return qk::radSourceImpl<true, false, R, EC>(lev, nullptr, rt, t, cons_t, src_t, dt, stage, d_iteration_counter, d_failure_counter);
+}
+
+// RadSystem<problem_t>::DefineOpacityExponentsAndLowerValues (radiation_system.hpp:281) as the multigroup kernel sees it in ONE cell: the
+// exponents and lower values are whatever the problem's compiled hook returns at the (rho, T) the reference evaluates it at
+// (source_terms_multi_group.hpp:16, :70, :266, :428, :731-733) — exponents that depend on the temperature included (RadhydroPulseMGint).
+template <typename problem_t, int NG> struct ProblemRadMG : qk::RadMG<NG> {
+	using RS = RadSystem<problem_t>;
+	QK_DEV explicit ProblemRadMG(qk::RadMG<NG> const &m) : qk::RadMG<NG>(m)
+	{
+		this->k_rho_exp = 0.0; // lower(g, rho, T) returns klow[g] as at() left it
+		this->k_T_exp = 0.0;
+	}
+	QK_DEV void at(double rho, double T)
+	{
+		amrex::GpuArray<double, NG + 1> b{};
+#pragma unroll
+		for (int g = 0; g < NG + 1; ++g) {
+			b[g] = this->bnd[g];
+		}
+		auto const v = RS::DefineOpacityExponentsAndLowerValues(b, rho, T);
+#pragma unroll
+		for (int g = 0; g < NG + 1; ++g) {
+			this->kexp[g] = v[0][g];
+			this->klow[g] = v[1][g];
+		}
+	}
+};
+
+// RadSystem<problem_t>::AddSourceTermsMultiGroup (reference src/radiation/source_terms_multi_group.hpp:522-813) with the problem's compiled
+// DefineOpacityExponentsAndLowerValues; the emission hooks and the EOS are the library's (the mirror has recognised the defaults)
+template <typename problem_t>
+auto addSourceTermsMultiGroup(qk_level *lev, const qk_rad_traits *rt, const qk_hydro_traits *t, qk_array4 *cons_t, const qk_array4 *src_t, double dt, int stage,
+			      int *d_iteration_counter, int *d_failure_counter) -> int
+{
+	constexpr int NG = Physics_Traits<problem_t>::nGroups;
+	if constexpr (NG > 1 && NG <= QK_MAX_GROUPS) {
+		if (lev == nullptr || rt == nullptr || t == nullptr || cons_t == nullptr || src_t == nullptr || d_iteration_counter == nullptr || d_failure_counter == nullptr ||
+		    (stage != 1 && stage != 2) || rt->ngroups != NG) {
+			return QK_ERR_INVALID;
+		}
+		if (t->eos_temperature_model == kHookCompiled || t->nscalars != 0 || t->nmscalars != 0) {
+			return qk::setError(lev->ctx, QK_ERR_UNSUPPORTED, "multigroup source term with a compiled opacity hook: library EOS, no passive scalars");
+		}
+		return qk::radSourceMGImpl<NG, ProblemRadMG<problem_t, NG>>(lev, nullptr, rt, t, cons_t, src_t, dt, stage, d_iteration_counter, d_failure_counter);
+	} else {
+		return QK_ERR_UNSUPPORTED;
+	}
 }
 
 } // namespace qkhost

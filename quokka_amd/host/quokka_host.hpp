@@ -807,8 +807,15 @@ template <typename problem_t> class RadSystem : public HyperbolicSystem<problem_
 			}
 		}
 		if (!ok) {
-			amrex::Abort("RadSystem: DefineOpacityExponentsAndLowerValues is not expressible in the C-ABI's closed set (exponents independent of "
-				     "rho and T; lower values k_g rho^a T^b with a = 0 or -1)");
+			// not in the closed set (e.g. exponents that follow the temperature, RadhydroPulseMGint): the hook itself is compiled into the
+			// source-term kernel of this translation unit (qk_problem_kernels.hpp: ProblemRadMG); the library's entry refuses this value
+			rt.opacity_model = QK_HOOK_COMPILED;
+			rt.mg_kappa_rho_exponent = 0.0;
+			rt.mg_kappa_T_exponent = 0.0;
+			for (int g = 0; g < nGroups_ + 1; ++g) {
+				rt.mg_kappa_exponent[g] = 0.0;
+				rt.mg_kappa_lower[g] = 0.0;
+			}
 		}
 		// the thermal-emission hooks (:483-497, :505-513): the defaults, or RadDustMG's linearised a T / a (test_rad_dust_MG.cpp:83-104)
 		{
@@ -953,6 +960,12 @@ template <typename problem_t> class RadSystem : public HyperbolicSystem<problem_
 	{
 		auto rt = traits();
 		auto t = qkhost::traits<problem_t>();
+		if (rt.opacity_model == QK_HOOK_COMPILED) { // the kernel is instantiated HERE, with this problem's DefineOpacityExponentsAndLowerValues
+			qkhost::check(qkhost::addSourceTermsMultiGroup<problem_t>(lev(), &rt, &t, qkhost::tab(consVar), qkhost::tab(radEnergySource), dt, stage,
+										   p_iteration_counter, p_iteration_failure_counter),
+				      "RadSystem::AddSourceTermsMultiGroup (compiled opacity hook)");
+			return;
+		}
 		qkhost::check(qk_rad_AddSourceTermsMultiGroup(lev(), nullptr, &rt, &t, qkhost::tab(consVar), qkhost::tab(radEnergySource), dt, stage,
 							      p_iteration_counter, p_iteration_failure_counter),
 			      "RadSystem::AddSourceTermsMultiGroup");

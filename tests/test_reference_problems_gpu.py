@@ -450,6 +450,7 @@ MORE_CTESTS = [  # (problem directory, deck of its add_test line, {extern path t
     ("RadhydroPulse", "RadhydroPulse.in", {}, False),
     ("RadhydroPulseDyn", "RadhydroPulseDyn.in", {}, False),
     ("RadhydroPulseGrey", "RadhydroPulseGrey.in", {}, False),
+    ("RadhydroPulseMGint", "RadhydroPulse.in", {}, False),  # opacity exponents that follow T: the problem's hook compiled into the multigroup kernel
     # one-cell problems of ~1e5 steps: bound by launch latency, about four minutes each — run with QK_SLOW_TESTS=1 (both exit 0: 2.4e-7 / 3.3e-5
     # against their 1e-5 / ... criteria on the builder's box)
     ("RadMatterCoupling", "energyexchange.in", {}, True),
