@@ -337,6 +337,13 @@ int qk_rad_AddFluxesRK2(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int
  * (Newton failures, dust (unused), outer-iteration failures) — counted, never aborted, exactly as the reference. */
 int qk_rad_AddSourceTermsSingleGroup(qk_level *lev, qk_stream s, const qk_rad_traits *rt, const qk_hydro_traits *t, qk_array4 *consVar,
 				     const qk_array4 *radEnergySource, double dt, int stage, int *d_iteration_counter, int *d_failure_counter);
+/* The same update, and the new radiation components (6 .. 9) of every valid cell stored into `mirror` as well: the swapRadiationState() that opens
+ * the NEXT radiation substep (reference src/QuokkaSimulation.hpp:1783-1788: state_old <- state_new, radiation components) from the registers of
+ * this kernel instead of a copy of 4 components through HBM.  Ghost cells of `mirror` are not written: advanceRadiationForwardEuler fills
+ * all of them before it reads any (:1790-1795). */
+int qk_rad_AddSourceTermsSingleGroupMirror(qk_level *lev, qk_stream s, const qk_rad_traits *rt, const qk_hydro_traits *t, qk_array4 *consVar,
+					   const qk_array4 *radEnergySource, double dt, int stage, int *d_iteration_counter, int *d_failure_counter,
+					   qk_array4 *mirror);
 /* ngroups in {2, 3, 4, 5, 6, 8} (each is its own kernel instantiation: the per-group vectors live in registers); gas + radiation only (no dust /
  * photoelectric / cooling models, ISM_Traits defaults) */
 int qk_rad_AddSourceTermsMultiGroup(qk_level *lev, qk_stream s, const qk_rad_traits *rt, const qk_hydro_traits *t, qk_array4 *consVar,

@@ -160,6 +160,7 @@ def lib() -> C.CDLL:
     L.qk_hydro_FixupState.argtypes = [vp, vp, T, cd, cd, ci, vp, vp, vp]
     L.qk_rad_stage_fused.argtypes = [vp, vp, R, ci, ci, vp, vp, vp, vp, P(vp), cd, P(cd)]
     L.qk_rad_AddSourceTermsSingleGroup.argtypes = [vp, vp, R, T, vp, vp, cd, ci, vp, vp]
+    L.qk_rad_AddSourceTermsSingleGroupMirror.argtypes = [vp, vp, R, T, vp, vp, cd, ci, vp, vp, vp]
     L.qk_rad_AddSourceTermsMultiGroup.argtypes = [vp, vp, R, T, vp, vp, cd, ci, vp, vp]
     L.qk_rad_mg_planck_fractions.argtypes = [vp, R, cd, ci, P(cd), P(cd), P(cd)]
     if hasattr(L, "qk_hydro_stage_fused"):
@@ -235,7 +236,7 @@ DECLARED_SYMBOLS = [
     "qk_hydro_EnforceLimits", "qk_hydro_SyncDualEnergy", "qk_hydro_ComputeMaxSignalSpeed", "qk_hydro_maxSignalSpeedLocal",
     "qk_replaceFluxes", "qk_Saxpy", "qk_hydro_FixupState", "qk_hydro_stage_scratch_bytes", "qk_hydro_stage_fused",
     "qk_rad_ConservedToPrimitive", "qk_rad_ComputeFluxes", "qk_rad_computeRadiationFluxes", "qk_rad_PredictStep", "qk_rad_AddFluxesRK2", "qk_rad_stage_fused",
-    "qk_rad_AddSourceTermsSingleGroup", "qk_rad_AddSourceTermsMultiGroup", "qk_rad_mg_planck_fractions",
+    "qk_rad_AddSourceTermsSingleGroup", "qk_rad_AddSourceTermsSingleGroupMirror", "qk_rad_AddSourceTermsMultiGroup", "qk_rad_mg_planck_fractions",
     "qk_ghost_plan_create", "qk_ghost_plan_destroy", "qk_ghost_plan_num_peers", "qk_ghost_plan_peer", "qk_ghost_plan_num_items", "qk_ghost_plan_item",
     "qk_FillBoundary_local", "qk_FillBoundary_local_int", "qk_FillBoundary_pack", "qk_FillBoundary_unpack", "qk_FillBoundary_pack_int", "qk_FillBoundary_unpack_int", "qk_SumBoundary_local", "qk_SumBoundary_pack", "qk_SumBoundary_unpack", "qk_FillPhysicalBoundary",
     "qk_FillPhysicalBoundary_subset", "qk_ghost_plan_set_components", "qk_ghost_plan_box_is_remote", "qk_ghost_plan_set_box_remote",

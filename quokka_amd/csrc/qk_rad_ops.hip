@@ -973,10 +973,10 @@ int qk_rad_stage_fused(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int 
 
 } // extern "C"
 
-extern "C" {
-
-int qk_rad_AddSourceTermsSingleGroup(qk_level *lev, qk_stream s, const qk_rad_traits *rt, const qk_hydro_traits *t, qk_array4 *cons_t,
-				     const qk_array4 *src_t, double dt, int stage, int *d_iteration_counter, int *d_failure_counter)
+namespace
+{
+auto addSourceTermsSingleGroup(qk_level *lev, qk_stream s, const qk_rad_traits *rt, const qk_hydro_traits *t, qk_array4 *cons_t, const qk_array4 *src_t, double dt, int stage,
+			       int *d_iteration_counter, int *d_failure_counter, qk_array4 *mirror_t) -> int
 {
 	if (lev == nullptr) {
 		return QK_ERR_INVALID;
@@ -1004,12 +1004,30 @@ int qk_rad_AddSourceTermsSingleGroup(qk_level *lev, qk_stream s, const qk_rad_tr
 	QK_REQUIRE(lev->ctx, rt->enable_photoelectric_heating == 0, "AddSourceTermsSingleGroup: photoelectric heating is a multigroup model (radiation_dust_system.hpp)");
 	if (rt->enable_dust_gas_thermal_coupling_model != 0) {
 		QK_REQUIRE(lev->ctx, rt->dust_gas_interaction_coeff > 0.0 && t->mean_molecular_weight > 0.0, "dust model: needs dust_gas_interaction_coeff > 0");
-		return (rt->opacity_model == 2) ? radSourceImpl<true, true>(lev, s, rt, t, cons_t, src_t, dt, stage, d_iteration_counter, d_failure_counter)
-						: radSourceImpl<false, true>(lev, s, rt, t, cons_t, src_t, dt, stage, d_iteration_counter, d_failure_counter);
+		return (rt->opacity_model == 2) ? radSourceImpl<true, true>(lev, s, rt, t, cons_t, src_t, dt, stage, d_iteration_counter, d_failure_counter, mirror_t)
+						: radSourceImpl<false, true>(lev, s, rt, t, cons_t, src_t, dt, stage, d_iteration_counter, d_failure_counter, mirror_t);
 	}
 	// the temperature-dependent opacities get their own instantiation: the constant-opacity kernel keeps its register budget
-	return (rt->opacity_model == 2) ? radSourceImpl<true>(lev, s, rt, t, cons_t, src_t, dt, stage, d_iteration_counter, d_failure_counter)
-					: radSourceImpl<false>(lev, s, rt, t, cons_t, src_t, dt, stage, d_iteration_counter, d_failure_counter);
+	return (rt->opacity_model == 2) ? radSourceImpl<true>(lev, s, rt, t, cons_t, src_t, dt, stage, d_iteration_counter, d_failure_counter, mirror_t)
+					: radSourceImpl<false>(lev, s, rt, t, cons_t, src_t, dt, stage, d_iteration_counter, d_failure_counter, mirror_t);
+}
+} // namespace
+
+extern "C" {
+
+int qk_rad_AddSourceTermsSingleGroup(qk_level *lev, qk_stream s, const qk_rad_traits *rt, const qk_hydro_traits *t, qk_array4 *cons_t,
+				     const qk_array4 *src_t, double dt, int stage, int *d_iteration_counter, int *d_failure_counter)
+{
+	return addSourceTermsSingleGroup(lev, s, rt, t, cons_t, src_t, dt, stage, d_iteration_counter, d_failure_counter, nullptr);
+}
+
+int qk_rad_AddSourceTermsSingleGroupMirror(qk_level *lev, qk_stream s, const qk_rad_traits *rt, const qk_hydro_traits *t, qk_array4 *cons_t,
+					   const qk_array4 *src_t, double dt, int stage, int *d_iteration_counter, int *d_failure_counter, qk_array4 *mirror_t)
+{
+	if (lev != nullptr && mirror_t == nullptr) {
+		return setError(lev->ctx, QK_ERR_INVALID, "AddSourceTermsSingleGroupMirror", "mirror is NULL");
+	}
+	return addSourceTermsSingleGroup(lev, s, rt, t, cons_t, src_t, dt, stage, d_iteration_counter, d_failure_counter, mirror_t);
 }
 
 } // extern "C"

@@ -122,7 +122,7 @@ inline auto radStatus(qk_level *lev, const char *name) -> int
 // RadT / EosT as in radSourceCell: Rad + EosCell inside the library (closed hook sets), the problem's compiled hooks in a problem's translation unit
 template <bool TDEP, bool DUST = false, class RadT = Rad, class EosT = EosCell>
 static auto radSourceImpl(qk_level *lev, qk_stream s, const qk_rad_traits *rt, const qk_hydro_traits *t, qk_array4 *cons_t, const qk_array4 *src_t, double dt,
-			  int stage, int *d_iteration_counter, int *d_failure_counter) -> int
+			  int stage, int *d_iteration_counter, int *d_failure_counter, qk_array4 *mirror_t = nullptr) -> int
 {
 	RadT rad(*rt);
 	rad.mean_molecular_mass = t->mean_molecular_weight;
@@ -148,6 +148,14 @@ static auto radSourceImpl(qk_level *lev, qk_stream s, const qk_rad_traits *rt, c
 #pragma unroll
 			for (int n = 1; n < 10; ++n) {
 				S.p[c + S.ns * n] = U[n];
+			}
+			if (mirror_t != nullptr) { // the next substep's swapRadiationState, valid cells (QuokkaSimulation.hpp:1783-1788), from registers
+				WA4 M(mirror_t[b]);
+				const int64_t cm = M.idx(i, j, k);
+#pragma unroll
+				for (int n = RAD0; n < RAD0 + NRAD; ++n) {
+					M.p[cm + M.ns * n] = U[n];
+				}
 			}
 		}
 		// counters: wave-level reduction, then one atomic set per wave into one of NSLOT cache-line-sized slots.  (The

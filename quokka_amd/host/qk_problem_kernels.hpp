@@ -63,7 +63,7 @@ template <typename problem_t> struct ProblemEosCell {
 // RadSystem<problem_t>::AddSourceTermsSingleGroup (reference src/radiation/source_terms_single_group.hpp:10-564) with the problem's hooks
 template <typename problem_t>
 auto addSourceTermsSingleGroup(qk_level *lev, const qk_rad_traits *rt, const qk_hydro_traits *t, qk_array4 *cons_t, const qk_array4 *src_t, double dt, int stage,
-			       int *d_iteration_counter, int *d_failure_counter) -> int
+			       int *d_iteration_counter, int *d_failure_counter, qk_array4 *mirror_t = nullptr) -> int
 {
 	using R = ProblemRad<problem_t>;
 	using EC = ProblemEosCell<problem_t>;
@@ -75,9 +75,9 @@ auto addSourceTermsSingleGroup(qk_level *lev, const qk_rad_traits *rt, const qk_
 		if (!(rt->dust_gas_interaction_coeff > 0.0 && t->mean_molecular_weight > 0.0)) {
 			return qk::setError(lev->ctx, QK_ERR_INVALID, "dust model: needs dust_gas_interaction_coeff > 0 and a mean molecular weight");
 		}
-		return qk::radSourceImpl<true, true, R, EC>(lev, nullptr, rt, t, cons_t, src_t, dt, stage, d_iteration_counter, d_failure_counter);
+		return qk::radSourceImpl<true, true, R, EC>(lev, nullptr, rt, t, cons_t, src_t, dt, stage, d_iteration_counter, d_failure_counter, mirror_t);
 	}
-	return qk::radSourceImpl<true, false, R, EC>(lev, nullptr, rt, t, cons_t, src_t, dt, stage, d_iteration_counter, d_failure_counter);
+	return qk::radSourceImpl<true, false, R, EC>(lev, nullptr, rt, t, cons_t, src_t, dt, stage, d_iteration_counter, d_failure_counter, mirror_t);
 }
 
 // RadSystem<problem_t>::DefineOpacityExponentsAndLowerValues (radiation_system.hpp:281) as the multigroup kernel sees it in ONE cell: the

@@ -944,14 +944,17 @@ template <typename problem_t> class RadSystem : public HyperbolicSystem<problem_
 			      "RadSystem::AddFluxesRK2");
 	}
 	// src/radiation/source_terms_single_group.hpp:10-564
+	// mirror (an extension of this host): the new radiation components of the valid cells are stored there too — the swapRadiationState() of the
+	// next substep from the registers of this kernel (include/quokka_amd.h: qk_rad_AddSourceTermsSingleGroupMirror)
 	static void AddSourceTermsSingleGroup(amrex::MultiFab &consVar, amrex::MultiFab const &radEnergySource, double dt, int stage, int *p_iteration_counter,
-					      int *p_iteration_failure_counter)
+					      int *p_iteration_failure_counter, amrex::MultiFab *mirror = nullptr)
 	{
 		auto rt = traits();
 		auto t = qkhost::traits<problem_t>();
 		// the kernel is instantiated HERE, with this problem's compiled opacity / emission / EOS / ISM hooks (qk_problem_kernels.hpp)
 		qkhost::check(qkhost::addSourceTermsSingleGroup<problem_t>(lev(), &rt, &t, qkhost::tab(consVar), qkhost::tab(radEnergySource), dt, stage,
-									    p_iteration_counter, p_iteration_failure_counter),
+									    p_iteration_counter, p_iteration_failure_counter,
+									    mirror != nullptr ? qkhost::tab(*mirror) : nullptr),
 			      "RadSystem::AddSourceTermsSingleGroup");
 	}
 	// src/radiation/source_terms_multi_group.hpp:522-813
@@ -2128,11 +2131,12 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		radSourceFilled_ = true;
 	}
 
-	void operatorSplitSourceTerms(double time, double dt, int stage)
+	void operatorSplitSourceTerms(double time, double dt, int stage, bool mirror = false)
 	{
 		fillRadEnergySource(time + dt);
 		if constexpr (Physics_Traits<problem_t>::nGroups <= 1) { // :1875-1881
-			RadSystem<problem_t>::AddSourceTermsSingleGroup(state_new_cc_[0], radEnergySource_, dt, stage, d_radCounter_ + 4 * radCounterSlot_, d_radFailure_);
+			RadSystem<problem_t>::AddSourceTermsSingleGroup(state_new_cc_[0], radEnergySource_, dt, stage, d_radCounter_ + 4 * radCounterSlot_, d_radFailure_,
+									mirror ? &state_old_cc_[0] : nullptr);
 		} else {
 			RadSystem<problem_t>::AddSourceTermsMultiGroup(state_new_cc_[0], radEnergySource_, dt, stage, d_radCounter_ + 4 * radCounterSlot_, d_radFailure_);
 		}
@@ -2188,6 +2192,12 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		return radFused_ == 1;
 	}
 
+	bool radMirror_ = [] {
+		int v = 1;
+		amrex::ParmParse("qk").query("rad_mirror", v);
+		return v != 0;
+	}();
+
 	void subcycleRadiationAtLevel(double time, double dt_lev_hydro)
 	{
 		int nsubSteps = 1;
@@ -2210,8 +2220,9 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		}
 		QK_HOST_HIP(hipMemsetAsync(d_radCounter_, 0, 4 * sizeof(int) * static_cast<size_t>(nsubSteps), qkhost::Runtime::get().computeStream()));
 		QK_HOST_HIP(hipMemsetAsync(d_radFailure_, 0, 3 * sizeof(int), qkhost::Runtime::get().computeStream()));
+		bool mirrored = false; // swapRadiationState already done by the source-term kernel of the substep before (`qk.rad_mirror`, default 1)
 		for (int i = 0; i < nsubSteps; ++i) {
-			if (i > 0) { // swapRadiationState (:1783-1788)
+			if (i > 0 && !mirrored) { // swapRadiationState (:1783-1788)
 				amrex::MultiFab::Copy(state_old_cc_[0], state_new_cc_[0], r0, r0, RadSystem<problem_t>::nvarHyperbolic_, 0);
 			}
 			radCounterSlot_ = i;
@@ -2219,7 +2230,8 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 			advanceRadiationForwardEuler(dt_radiation);
 			operatorSplitSourceTerms(time_subcycle, dt_radiation, 1); // IMEX_a22 > 0
 			advanceRadiationMidpointRK2(dt_radiation);
-			operatorSplitSourceTerms(time_subcycle, dt_radiation, 2);
+			mirrored = radMirror_ && Physics_Traits<problem_t>::nGroups <= 1 && i < nsubSteps - 1;
+			operatorSplitSourceTerms(time_subcycle, dt_radiation, 2, mirrored);
 			time_subcycle += dt_radiation;
 			radiationCellUpdates_ += this->CountCells(0);
 		}

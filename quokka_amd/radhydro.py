@@ -15,6 +15,7 @@ HLL flux run as one kernel per direction; Newton counters are reduced per wave a
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 from typing import Callable, Optional
 
@@ -60,6 +61,8 @@ class RadhydroSimulation(HydroSimulation):
         # photon group; the face fluxes are stored only when something reads them (store_rad_flux: the flux registers of a refined hierarchy)
         self.use_fused_rad = bool(use_fused) and nd == 3 and self.nGroups == 1
         self.store_rad_flux = False
+        # swapRadiationState() of substeps 2 .. n folded into the source-term kernel of the substep before (its registers hold the values)
+        self.use_rad_mirror = os.environ.get("QK_RAD_MIRROR", "1") != "0"  # (the environment variable: same-box A/B, profiles/tools/ab_env.sh)
         self._rad_acc: Optional[MultiFab] = None
         self.radEnergySource = MultiFab(lev, self.nGroups, 0, fill=0.0)  # QuokkaSimulation.hpp:1866-1869
         self.SetRadEnergySource: Optional[Callable] = None  # fn(i, j, k, time) -> array on the valid box
@@ -106,9 +109,17 @@ class RadhydroSimulation(HydroSimulation):
                 self.radEnergySource.fabs[b].copy_(torch.from_numpy(src))
         self._source_set = True
 
-    def operatorSplitSourceTerms(self, time: float, dt: float, stage: int):
+    def operatorSplitSourceTerms(self, time: float, dt: float, stage: int, mirror: bool = False):
+        """mirror: the new radiation state also goes to state_old_cc_ (valid cells) — the swapRadiationState() of the next substep, stored from
+        the registers of the source-term kernel (qk_rad_AddSourceTermsSingleGroupMirror)"""
         self._fill_source(time + dt)
         c = self.ctx
+        if mirror:
+            c.check(c.L.qk_rad_AddSourceTermsSingleGroupMirror(
+                self.lev.h, c.stream(), C.byref(self.rad_traits), C.byref(self.traits), self.state_new_cc_.ptr, self.radEnergySource.ptr, float(dt), stage,
+                C.c_void_p(self.dev_rad_counter.data_ptr() + 16 * self._rad_counter_slot), C.c_void_p(self.dev_rad_failure.data_ptr()),
+                self.state_old_cc_.ptr), "qk_rad_AddSourceTermsSingleGroupMirror")
+            return
         # QuokkaSimulation.hpp:1875-1881
         fn, name = ((c.L.qk_rad_AddSourceTermsSingleGroup, "qk_rad_AddSourceTermsSingleGroup") if self.nGroups <= 1
                     else (c.L.qk_rad_AddSourceTermsMultiGroup, "qk_rad_AddSourceTermsMultiGroup"))
@@ -174,14 +185,16 @@ class RadhydroSimulation(HydroSimulation):
             self.dev_rad_counter = torch.zeros(4 * nsub, dtype=torch.int32, device=self.ctx.device)
         self.dev_rad_counter.zero_()
         self.dev_rad_failure.zero_()
+        mirrored = False
         for i in range(nsub):
-            if i > 0:
+            if i > 0 and not mirrored:
                 self.swapRadiationState()
             self._rad_counter_slot = i
             self.advanceRadiationForwardEuler(dt_rad)
             self.operatorSplitSourceTerms(time_subcycle, dt_rad, 1)  # IMEX_a22 > 0
             self.advanceRadiationMidpointRK2(dt_rad)
-            self.operatorSplitSourceTerms(time_subcycle, dt_rad, 2)
+            mirrored = self.use_rad_mirror and self.nGroups <= 1 and i < nsub - 1
+            self.operatorSplitSourceTerms(time_subcycle, dt_rad, 2, mirror=mirrored)
             time_subcycle += dt_rad
             self.radiationCellUpdates_ += self.CountCells()
         # one host read per level advance (the reference aborts inside the kernel launch that fails; here the flags of all substeps are

@@ -358,3 +358,29 @@ def test_fused_radiation_stage_equals_the_separate_operators(ctx, rad_order):
                 for n in range(a.lev.nboxes):
                     assert torch.equal(fa.fabs[n], fb.fabs[n]), (mgs, d, n)
         assert a.rad_counters == b.rad_counters
+
+
+@pytest.mark.gpu
+def test_mirrored_radiation_swap_equals_the_copy(ctx):
+    """qk_rad_AddSourceTermsSingleGroupMirror: the stage-2 source-term kernel of substep i stores the new radiation components of the valid
+    cells into state_old as well, which is what swapRadiationState() (reference src/QuokkaSimulation.hpp:1783-1788) copies when substep i + 1
+    opens; the ghost cells it does not write are all filled by advanceRadiationForwardEuler before anything reads them.  Both ways: every
+    component of the new state, the radiation components of the valid cells of the old state and the Newton counters, bit for bit; and the
+    run takes several substeps per step (otherwise nothing is tested)."""
+    sims = []
+    for mirror in (True, False):
+        s = shell_problem(ctx, 16, table(), max_grid_size=8, pow_mode=1)
+        assert s.use_rad_mirror
+        s.use_rad_mirror = mirror
+        for _ in range(3):
+            assert s.step()
+        sims.append(s)
+    a, b = sims
+    assert a.rad_counters == b.rad_counters and a.rad_counters["solves"] > 2 * 3 * 16 ** 3  # more than one substep per step
+    for x, y in zip(a.gather_valid_local(), b.gather_valid_local()):
+        assert np.array_equal(x, y)
+    ng = a.state_old_cc_.nghost
+    for n in range(a.lev.nboxes):
+        va = a.state_old_cc_.fabs[n][6:10, ng:-ng, ng:-ng, ng:-ng]
+        vb = b.state_old_cc_.fabs[n][6:10, ng:-ng, ng:-ng, ng:-ng]
+        assert torch.equal(va, vb), n
