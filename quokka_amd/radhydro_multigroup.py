@@ -64,15 +64,15 @@ class RadShockMGConstants:
 
 
 def radshock_mg_problem(ctx: Context, nx: int = 64, opacity_model: int = PPL_FIXED_SLOPE, pow_mode: int = 0, three_d: bool = False,
-                        max_grid_size=None) -> RadhydroSimulation:
+                        max_grid_size=None, nyz: int = 4) -> RadhydroSimulation:
     """5 photon groups over 1e15..1e20 Hz, grey absorption coefficient 577 cm^-1 (exponent 0, lower value 577 / rho), Eddington closure,
     constant states beyond both x faces (deck tests/radshockMG.in: 64 cells; three_d: the deck's own 64 x 4 x 4 cells, periodic in y and z)."""
     S = RadShockMGConstants
     ng = len(S.boundaries) - 1
     ncomp = RAD0 + 4 * ng
     if three_d:
-        geom = Geometry(3, [nx, 4, 4], [0.0, 0.0, 0.0], [S.Lx, 0.001575, 1.0], [0, 1, 1])
-        mgs = max_grid_size if max_grid_size is not None else [nx, 4, 4]
+        geom = Geometry(3, [nx, nyz, nyz], [0.0, 0.0, 0.0], [S.Lx, 0.001575, 1.0], [0, 1, 1])  # (nyz > 4: kernel timing, profiles/tools/mg_kernel_time.py)
+        mgs = max_grid_size if max_grid_size is not None else [nx, nyz, nyz]
     else:
         geom = Geometry(1, [nx], [0.0, 0.0, 0.0], [S.Lx, 1.0, 1.0], [0, 1, 1])
         mgs = [nx, 1, 1]
