@@ -202,7 +202,7 @@ def read_profile(ctx):
     return kernels
 
 
-def run_shell(ctx, torch, ncell, mgs, steps, warmup, pow_mode):
+def run_shell(ctx, torch, ncell, mgs, steps, warmup, pow_mode, carry=False):
     """BASELINE config 4: RadhydroShell (tests/radhydro_shell_256.in; the reference problem runs 50 steps, test_radhydro_shell.cpp:431), one update =
     hydro RK2 + all radiation substeps.  Returns the JSON object of the line (headline with --workload shell, `shell256` block otherwise)."""
     import numpy as np
@@ -210,6 +210,7 @@ def run_shell(ctx, torch, ncell, mgs, steps, warmup, pow_mode):
     tab = np.loadtxt(os.path.join(ROOT, "tests", "golden", "dust_shell_initial_conditions.txt"), skiprows=1)
     sim = shell_problem(ctx, ncell, (tab[:, 0], tab[:, 2], tab[:, 3]), max_grid_size=mgs, pow_mode=pow_mode)
     sim.maxTimesteps_ = 10 ** 9
+    sim.rk2_carry_rhs = bool(carry)  # the hydro stage pair of the shell in the headline's form of the RK2 average (--rk2-mode)
     mass0 = sum(float(sim.state_new_cc_.valid(b)[0].sum().item()) for b in range(sim.lev.nboxes))
     for _ in range(warmup):
         assert sim.step()
@@ -254,6 +255,7 @@ def run_shell(ctx, torch, ncell, mgs, steps, warmup, pow_mode):
                        "newton_iterations_per_solve": sim.rad_counters["newton_iterations"] / max(sim.rad_counters["solves"], 1),
                        "solves_per_cell_and_source_call": sim.rad_counters["solves"] / max(2 * sim.radiationCellUpdates_, 1),
                        "max_newton_iterations": sim.rad_counters["max_newton_iterations"], "pow_mode": pow_mode, "sim_time": sim.tNew_,
+                       "rk2_mode": "carry" if carry else "exact",
                        "relative_mass_change": abs(mass1 - mass0) / mass0},
             "roofline": {"kernels": roof, "note": "transport sweeps against 8 TB/s HBM (frac) and against the FP64 VALU issue rate (frac_fp64_valu; PLM instruction counts); the Newton-Raphson kernel against the FP64 VALU issue rate"},
             "kernels_ms_per_launch": per, "kernels_launches": launches,
@@ -531,7 +533,8 @@ def main():
 
     if args.workload == "shell":
         assert world == 1, "the shell line is single-GPU"
-        out = run_shell(ctx, torch, args.ncell if args.ncell is not None else 256, args.max_grid_size, args.steps, args.warmup, args.pow_mode)
+        out = run_shell(ctx, torch, args.ncell if args.ncell is not None else 256, args.max_grid_size, args.steps, args.warmup, args.pow_mode,
+                        carry=(args.rk2_mode == "carry"))
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_shell()
         print(json.dumps(out), flush=True)
@@ -594,7 +597,7 @@ def main():
             # builder-authored driver quokka_amd/host/drivers/sedov_bench.cpp, its own process)
             out["cxx_host"] = cxx_host_block(args, 256)
             # (d) BASELINE config 4 at its full size: RadhydroShell 256^3, the 50 steps the reference problem runs (test_radhydro_shell.cpp:431)
-            out["shell256"] = compact(run_shell(ctx, torch, 256, 128, 50, 2, 0))
+            out["shell256"] = compact(run_shell(ctx, torch, 256, 128, 50, 2, 0, carry=(args.rk2_mode == "carry")))
             torch.cuda.empty_cache()
             # (e) BASELINE config 5 geometry at its full size on the one GPU: blast_amr_maxlev2.in, 256^3 base grid + 2 levels
             out["amr_maxlev2"] = compact(run_amr(ctx, torch, dist, rank, world, 256, 50, 5))
