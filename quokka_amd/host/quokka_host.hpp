@@ -806,7 +806,9 @@ template <typename problem_t> class RadSystem : public HyperbolicSystem<problem_
 				}
 			}
 		}
-		if (!ok) {
+		int force_compiled = 0; // deck `qk.mg_compiled_hook = 1`: the compiled hook also where the closed set would do (tests: same bits)
+		amrex::ParmParse("qk").query("mg_compiled_hook", force_compiled);
+		if (!ok || force_compiled != 0) {
 			// not in the closed set (e.g. exponents that follow the temperature, RadhydroPulseMGint): the hook itself is compiled into the
 			// source-term kernel of this translation unit (qk_problem_kernels.hpp: ProblemRadMG); the library's entry refuses this value
 			rt.opacity_model = QK_HOOK_COMPILED;

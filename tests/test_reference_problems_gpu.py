@@ -136,6 +136,27 @@ def test_unmodified_multigroup_shock_meets_the_reference_criterion(tmp_path):
     assert rc == 0, out[-2500:]
 
 
+@pytest.mark.parametrize("name,deck,extern,steps", [
+    ("RadhydroShockMultigroup", "radshockMG.in", {"LowrieEdwards/shock.txt": "LowrieEdwards_shock.txt"}, 400),  # 5 groups, fixed-slope spectrum, beta_order 1
+    ("RadMarshakVaytet", "MarshakVaytet.in", {}, 400),  # 6 groups, full spectrum (slopes re-fitted in every Newton iteration), kappa ~ nu^-2
+])
+def test_compiled_multigroup_opacity_hook_equals_the_closed_set(tmp_path, name, deck, extern, steps):
+    """The multigroup kernel with the problem's DefineOpacityExponentsAndLowerValues COMPILED in (qkhost::ProblemRadMG: at(rho, T) refreshes the
+    exponents and lower values at the five places the reference evaluates the hook) against the library's closed-set instantiation, on problems
+    both can express (`qk.mg_compiled_hook = 1` forces the former): the final state of the unchanged reference problem, bit for bit.  What
+    only the compiled hook can express is RadhydroPulseMGint (MORE_CTESTS)."""
+    dumps = []
+    for forced in (0, 1):
+        cwd = extern_tree(tmp_path / f"w{forced}", extern)
+        dump = os.path.join(cwd, "state.bin")
+        rc, out = run([exe(f"ref_{name}"), os.path.join(HOST, "decks", deck), f"max_timesteps={steps}", f"qk.mg_compiled_hook={forced}",
+                       f"qk.dump_state={dump}", "plotfile_interval=-1", "checkpoint_interval=-1"], cwd)
+        assert os.path.exists(dump), out[-2500:]  # (the truncated run may miss the problem's own criterion: only the state is compared)
+        dumps.append(np.fromfile(dump, dtype=np.float64))
+    assert dumps[0].size > 0 and np.isfinite(dumps[0]).all()
+    assert np.array_equal(dumps[0], dumps[1])
+
+
 def test_unmodified_radiation_tube_meets_the_reference_criterion(tmp_path):
     """RadTube, unchanged: 2 groups, piecewise-constant opacity, table-interpolated initial conditions (preCalculateInitialConditions ->
     Gpu::DeviceVector), a boundary functor that reads the first valid cell.  Exit status 0 = T_rad within 0.003 of the static solution."""
