@@ -199,6 +199,13 @@ class Comm
 		barrier(); // every rank has read every file
 		std::remove(msgPath("r", rank, -1, seq_).c_str());
 	}
+	// any length, 64 values at a time (the per-fab minima / maxima of a MultiFab header written by rank 0)
+	void allReduceMany(double *v, size_t n, Op op)
+	{
+		for (size_t i = 0; i < n; i += 64) {
+			allReduce(v + i, static_cast<int>(std::min<size_t>(64, n - i)), op);
+		}
+	}
 	// element-wise maximum of an int array of any length (the tile flags of a regrid: every rank clusters the same global flags)
 	void allReduceMaxInts(int *v, size_t n)
 	{

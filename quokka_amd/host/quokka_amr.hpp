@@ -904,6 +904,7 @@ template <typename problem_t> void QuokkaSimulation<problem_t>::WritePlotFile()
 	std::vector<amrex::MultiFab> combined; // (kept alive until the file is written)
 	std::vector<amrex::Geometry> geoms;
 	std::vector<int> steps;
+	std::vector<quokka::io::Distribution> dists; // several ranks: every rank writes its own fabs, rank 0 the headers
 	std::vector<std::string> names = this->componentNames_cc_;
 	constexpr int nfc = qkhost::hasFaceState<problem_t>() ? Physics_Indices<problem_t>::nvarTotal_fc : 0;
 	if constexpr (nfc > 0) {
@@ -937,12 +938,15 @@ template <typename problem_t> void QuokkaSimulation<problem_t>::WritePlotFile()
 		}
 		geoms.push_back(S.geom[0]);
 		steps.push_back(amr_ ? amr_->istep[l] : istep[0]);
+		dists.push_back({S.allGrids_, S.owner_});
 	}
 	std::string const name = quokka::io::Concatenate(this->plot_file, istep[0], 5);
 	amrex::Print() << "Writing plotfile " << name << "\n";
 	QK_HOST_HIP(hipDeviceSynchronize());
-	quokka::io::WriteMultiLevelPlotfile(name, nlev, mf, names, geoms, tNew_[0], steps);
-	quokka::io::WriteMetadataFile(name + "/metadata.yaml");
+	quokka::io::WriteMultiLevelPlotfile(name, nlev, mf, names, geoms, tNew_[0], steps, 2, &dists);
+	if (qkhost::Comm::get().rank == 0) {
+		quokka::io::WriteMetadataFile(name + "/metadata.yaml");
+	}
 }
 
 // AMRSimulation::WriteCheckpointFile (reference src/simulation.hpp:2564-2666)
@@ -953,6 +957,7 @@ template <typename problem_t> void QuokkaSimulation<problem_t>::WriteCheckpointF
 	int const nmax = amr_ ? amr_->max_level + 1 : 1; // istep, dt_, tNew_ have one entry per level that may exist
 	std::vector<amrex::MultiFab const *> state;
 	std::vector<std::array<amrex::MultiFab const *, AMREX_SPACEDIM>> faces; // Level_<l>/Face_x|y|z of problems with a face-centred state
+	std::vector<quokka::io::Distribution> dists;
 	for (int l = 0; l < nmax; ++l) {
 		bool const live = l <= h.finest_level;
 		h.istep.push_back(amr_ ? amr_->istep[l] : istep[0]);
@@ -960,7 +965,8 @@ template <typename problem_t> void QuokkaSimulation<problem_t>::WriteCheckpointF
 		h.tNew.push_back(live ? (amr_ ? amr_->level(l).tNewLev_ : tNew_[0]) : 0.0);
 		if (live) {
 			auto &S = amr_ ? amr_->level(l) : *this;
-			h.grids.push_back(S.grids_);
+			h.grids.push_back(S.allGrids_); // (the boxes of the whole level: with several ranks grids_ holds the local ones)
+			dists.push_back({S.allGrids_, S.owner_});
 			state.push_back(&S.state_new_cc_[0]);
 			if constexpr (qkhost::hasFaceState<problem_t>()) {
 				std::array<amrex::MultiFab const *, AMREX_SPACEDIM> f{};
@@ -974,7 +980,7 @@ template <typename problem_t> void QuokkaSimulation<problem_t>::WriteCheckpointF
 	std::string const name = quokka::io::Concatenate(this->chk_file, istep[0], 5);
 	amrex::Print() << "Writing checkpoint " << name << "\n";
 	QK_HOST_HIP(hipDeviceSynchronize());
-	quokka::io::WriteCheckpointFile(name, h, state, faces);
+	quokka::io::WriteCheckpointFile(name, h, state, faces, &dists);
 }
 
 template <typename problem_t>

@@ -143,14 +143,38 @@ inline void preBuildDirectoryHierarchy(std::string const &name, std::string cons
 	}
 }
 
+// Several ranks: the boxes of the whole level and the rank each one lives on (a MultiFab of this mirror holds the local ones, in the order of
+// their global indices).  VisMF::Write with NFiles = number of ranks: rank r writes <prefix>_D_<r> with its fabs, rank 0 the header, whose
+// FabOnDisk offsets follow from the box list alone (fab header + ncomp x points doubles) and whose minima / maxima are reduced over the ranks.
+struct Distribution {
+	std::vector<amrex::Box> all;
+	std::vector<int> owner;
+	[[nodiscard]] auto several() const -> bool { return qkhost::Comm::get().size > 1; }
+};
+
+// `FAB <RealDescriptor><box> <ncomp>\n`
+inline auto fabHeader(amrex::Box out, int facedir, int nc) -> std::string
+{
+	std::ostringstream hss;
+	hss << "FAB " << nativeRealDescriptor();
+	if (facedir >= 0) {
+		out.hi[facedir] -= 1;
+	}
+	printBox(hss, out, facedir);
+	hss << ' ' << nc << '\n';
+	return hss.str();
+}
+
 // amrex::VisMF::Write(mf, prefix): <prefix>_H (Version_v1, How::NFiles, per-fab minima and maxima) and <prefix>_D_00000 holding every
 // fab (one rank writes one file), each as `FAB <RealDescriptor><box> <ncomp>\n` followed by the native doubles, component outermost.
 // with_ghost = false strips the ghost cells (amrex::WriteMultiLevelPlotfile copies to a MultiFab without ghost cells first).
-inline void VisMFWrite(amrex::MultiFab const &mf, std::string const &prefix, bool with_ghost)
+inline void VisMFWrite(amrex::MultiFab const &mf, std::string const &prefix, bool with_ghost, Distribution const *dist = nullptr)
 {
 	int const nc = mf.nComp();
 	int const ng = with_ghost ? mf.nGrow() : 0;
-	std::string const dataName = prefix + "_D_00000";
+	bool const several = dist != nullptr && dist->several();
+	int const myRank = several ? qkhost::Comm::get().rank : 0;
+	std::string const dataName = prefix + "_D_" + Concatenate("", myRank, 5);
 	std::string const baseName = std::filesystem::path(dataName).filename().string();
 	std::ofstream data(dataName, std::ofstream::out | std::ofstream::trunc | std::ofstream::binary);
 	if (!data.good()) {
@@ -178,22 +202,54 @@ inline void VisMFWrite(amrex::MultiFab const &mf, std::string const &prefix, boo
 			});
 		}
 		offsets.push_back(static_cast<long>(data.tellp()));
-		std::ostringstream hss;
-		hss << "FAB " << nativeRealDescriptor();
-		{
-			amrex::Box cellOut = out;
-			if (mf.faceDir() >= 0) {
-				cellOut.hi[mf.faceDir()] -= 1;
-			}
-			printBox(hss, cellOut, mf.faceDir());
-		}
-		hss << ' ' << nc << '\n';
-		data << hss.str();
+		data << fabHeader(out, mf.faceDir(), nc);
 		data.write(reinterpret_cast<char const *>(buf.data()), static_cast<std::streamsize>(sizeof(double) * buf.size()));
 		mins.push_back(mn);
 		maxs.push_back(mx);
 	}
 	data.close();
+
+	std::vector<amrex::Box> const &headerBoxes = several ? dist->all : mf.boxArray();
+	std::vector<std::string> fileOf(headerBoxes.size(), baseName);
+	if (several) { // the tables of the header for ALL boxes: offsets from the box list, minima / maxima reduced over the ranks
+		auto &comm = qkhost::Comm::get();
+		size_t const nb = dist->all.size();
+		std::vector<long> off(nb, 0), next(static_cast<size_t>(comm.size), 0);
+		std::vector<double> mn(nb * nc, std::numeric_limits<double>::max()), mx(nb * nc, std::numeric_limits<double>::lowest());
+		size_t local = 0;
+		std::string const stem = std::filesystem::path(prefix).filename().string();
+		for (size_t n = 0; n < nb; ++n) {
+			amrex::Box out = dist->all[n];
+			if (mf.faceDir() >= 0) {
+				out.hi[mf.faceDir()] += 1;
+			}
+			out = amrex::grow(out, ng);
+			int const r = dist->owner[n];
+			off[n] = next[r];
+			next[r] += static_cast<long>(fabHeader(out, mf.faceDir(), nc).size()) + static_cast<long>(sizeof(double)) * out.numPts() * nc;
+			fileOf[n] = stem + "_D_" + Concatenate("", r, 5);
+			if (r == comm.rank) {
+				if (local >= offsets.size() || offsets[local] != off[n]) {
+					amrex::Abort("quokka::io::VisMFWrite: the local fabs are not the boxes this rank owns, in their global order");
+				}
+				std::copy(mins[local].begin(), mins[local].end(), mn.begin() + static_cast<long>(n * nc));
+				std::copy(maxs[local].begin(), maxs[local].end(), mx.begin() + static_cast<long>(n * nc));
+				++local;
+			}
+		}
+		comm.allReduceMany(mn.data(), mn.size(), qkhost::Comm::Op::min);
+		comm.allReduceMany(mx.data(), mx.size(), qkhost::Comm::Op::max);
+		if (comm.rank != 0) {
+			return;
+		}
+		offsets = off;
+		mins.assign(nb, std::vector<double>(nc));
+		maxs.assign(nb, std::vector<double>(nc));
+		for (size_t n = 0; n < nb; ++n) {
+			std::copy(mn.begin() + static_cast<long>(n * nc), mn.begin() + static_cast<long>((n + 1) * nc), mins[n].begin());
+			std::copy(mx.begin() + static_cast<long>(n * nc), mx.begin() + static_cast<long>((n + 1) * nc), maxs[n].begin());
+		}
+	}
 
 	std::ofstream hdr(prefix + "_H", std::ios::out | std::ios::trunc);
 	if (!hdr.good()) {
@@ -204,11 +260,11 @@ inline void VisMFWrite(amrex::MultiFab const &mf, std::string const &prefix, boo
 	hdr << 1 << '\n';  // VisMF::How::NFiles
 	hdr << nc << '\n'; // m_ncomp
 	hdr << ng << '\n'; // m_ngrow (same in every direction)
-	writeBoxArray(hdr, mf.boxArray(), mf.faceDir());
+	writeBoxArray(hdr, headerBoxes, mf.faceDir());
 	hdr << '\n';
-	hdr << mf.size() << '\n';
-	for (int b = 0; b < mf.size(); ++b) {
-		hdr << "FabOnDisk: " << baseName << ' ' << offsets[b] << '\n';
+	hdr << headerBoxes.size() << '\n';
+	for (size_t b = 0; b < headerBoxes.size(); ++b) {
+		hdr << "FabOnDisk: " << fileOf[b] << ' ' << offsets[b] << '\n';
 	}
 	hdr << '\n';
 	hdr.precision(16);
@@ -359,15 +415,29 @@ inline void VisMFReadInto(amrex::MultiFab &dst, std::string const &prefix)
 // amrex::WriteMultiLevelPlotfile(name, nlevels, mf, varnames, geom, time, level_steps, ref_ratio): version HyperCLaw-V1.1,
 // Level_<l>/Cell.  Header layout as in the reference's Write2DPlotfileHeader (src/io/DiagFramePlane.cpp:321-386).
 inline void WriteMultiLevelPlotfile(std::string const &name, int nlevels, std::vector<amrex::MultiFab const *> const &mf, std::vector<std::string> const &varnames,
-				    std::vector<amrex::Geometry> const &geom, double time, std::vector<int> const &level_steps, int ref_ratio = 2)
+				    std::vector<amrex::Geometry> const &geom, double time, std::vector<int> const &level_steps, int ref_ratio = 2,
+				    std::vector<Distribution> const *dists = nullptr)
 {
 	std::string const levelPrefix = "Level_", mfPrefix = "Cell";
-	preBuildDirectoryHierarchy(name, levelPrefix, nlevels);
-	int const finest_level = nlevels - 1;
-	std::ofstream H(name + "/Header", std::ofstream::out | std::ofstream::trunc | std::ofstream::binary);
-	if (!H.good()) {
-		amrex::Abort("quokka::io::WriteMultiLevelPlotfile: cannot open " + name + "/Header");
+	// several ranks (dists): rank 0 makes the directories and writes the Header, every rank its own data file per level
+	bool const several = dists != nullptr && qkhost::Comm::get().size > 1;
+	bool const root = !several || qkhost::Comm::get().rank == 0;
+	if (root) {
+		preBuildDirectoryHierarchy(name, levelPrefix, nlevels);
 	}
+	if (several) {
+		qkhost::Comm::get().barrier();
+	}
+	int const finest_level = nlevels - 1;
+	std::ofstream Hfile;
+	std::ostringstream Hnone;
+	if (root) {
+		Hfile.open(name + "/Header", std::ofstream::out | std::ofstream::trunc | std::ofstream::binary);
+		if (!Hfile.good()) {
+			amrex::Abort("quokka::io::WriteMultiLevelPlotfile: cannot open " + name + "/Header");
+		}
+	}
+	std::ostream &H = root ? static_cast<std::ostream &>(Hfile) : static_cast<std::ostream &>(Hnone);
 	H.precision(17);
 	H << "HyperCLaw-V1.1" << '\n';
 	H << varnames.size() << '\n';
@@ -407,7 +477,7 @@ inline void WriteMultiLevelPlotfile(std::string const &name, int nlevels, std::v
 	H << 0 << '\n'; // Geometry::Coord(): cartesian
 	H << "0\n";	// boundary width
 	for (int level = 0; level <= finest_level; ++level) {
-		auto const &ba = mf[level]->boxArray();
+		auto const &ba = several ? (*dists)[level].all : mf[level]->boxArray();
 		H << level << ' ' << ba.size() << ' ' << time << '\n';
 		H << level_steps[level] << '\n';
 		for (auto const &b : ba) {
@@ -419,9 +489,14 @@ inline void WriteMultiLevelPlotfile(std::string const &name, int nlevels, std::v
 		}
 		H << levelPrefix << level << '/' << mfPrefix << '\n'; // amrex::MultiFabHeaderPath
 	}
-	H.close();
+	if (root) {
+		Hfile.close();
+	}
 	for (int level = 0; level <= finest_level; ++level) {
-		VisMFWrite(*mf[level], name + "/" + levelPrefix + std::to_string(level) + "/" + mfPrefix, /*with_ghost=*/false);
+		VisMFWrite(*mf[level], name + "/" + levelPrefix + std::to_string(level) + "/" + mfPrefix, /*with_ghost=*/false, several ? &(*dists)[level] : nullptr);
+	}
+	if (several) {
+		qkhost::Comm::get().barrier(); // the file is complete when any rank returns
 	}
 }
 
@@ -444,14 +519,27 @@ struct CheckpointHeader {
 // one BoxArray per level), metadata.yaml, Level_<l>/Cell = state_new_cc_[l] with its ghost cells, and the `last_chk` symlink
 // `faces` (optional): per level the AMREX_SPACEDIM face-centred arrays, written as Level_<l>/Face_x|y|z (reference src/simulation.hpp:2645-2652)
 inline void WriteCheckpointFile(std::string const &name, CheckpointHeader const &h, std::vector<amrex::MultiFab const *> const &state,
-				std::vector<std::array<amrex::MultiFab const *, AMREX_SPACEDIM>> const &faces = {})
+				std::vector<std::array<amrex::MultiFab const *, AMREX_SPACEDIM>> const &faces = {}, std::vector<Distribution> const *dists = nullptr)
 {
 	int const nlevels = h.finest_level + 1;
-	preBuildDirectoryHierarchy(name, "Level_", nlevels);
-	std::ofstream H(name + "/Header", std::ofstream::out | std::ofstream::trunc | std::ofstream::binary);
-	if (!H.good()) {
-		amrex::Abort("quokka::io::WriteCheckpointFile: cannot open " + name + "/Header");
+	// several ranks (dists; h.grids then holds the boxes of the whole level): as WriteMultiLevelPlotfile
+	bool const several = dists != nullptr && qkhost::Comm::get().size > 1;
+	bool const root = !several || qkhost::Comm::get().rank == 0;
+	if (root) {
+		preBuildDirectoryHierarchy(name, "Level_", nlevels);
 	}
+	if (several) {
+		qkhost::Comm::get().barrier();
+	}
+	std::ofstream Hfile;
+	std::ostringstream Hnone;
+	if (root) {
+		Hfile.open(name + "/Header", std::ofstream::out | std::ofstream::trunc | std::ofstream::binary);
+		if (!Hfile.good()) {
+			amrex::Abort("quokka::io::WriteCheckpointFile: cannot open " + name + "/Header");
+		}
+	}
+	std::ostream &H = root ? static_cast<std::ostream &>(Hfile) : static_cast<std::ostream &>(Hnone);
 	H.precision(17);
 	H << "Checkpoint file for QuokkaCode\n";
 	H << h.finest_level << "\n";
@@ -471,16 +559,25 @@ inline void WriteCheckpointFile(std::string const &name, CheckpointHeader const 
 		writeBoxArray(H, h.grids[lev]);
 		H << '\n';
 	}
-	H.close();
-	WriteMetadataFile(name + "/metadata.yaml");
+	if (root) {
+		Hfile.close();
+		WriteMetadataFile(name + "/metadata.yaml");
+	}
 	for (int lev = 0; lev <= h.finest_level; ++lev) {
-		VisMFWrite(*state[lev], name + "/Level_" + std::to_string(lev) + "/Cell", /*with_ghost=*/true);
+		Distribution const *dist = several ? &(*dists)[lev] : nullptr;
+		VisMFWrite(*state[lev], name + "/Level_" + std::to_string(lev) + "/Cell", /*with_ghost=*/true, dist);
 		if (lev < static_cast<int>(faces.size())) {
 			char const *dirName[3] = {"x", "y", "z"};
 			for (int d = 0; d < AMREX_SPACEDIM; ++d) {
-				VisMFWrite(*faces[lev][d], name + "/Level_" + std::to_string(lev) + "/Face_" + dirName[d], /*with_ghost=*/true);
+				VisMFWrite(*faces[lev][d], name + "/Level_" + std::to_string(lev) + "/Face_" + dirName[d], /*with_ghost=*/true, dist);
 			}
 		}
+	}
+	if (several) {
+		qkhost::Comm::get().barrier();
+	}
+	if (!root) {
+		return;
 	}
 	// SetLastCheckpointSymlink (reference src/simulation.hpp:2543-2562)
 	namespace fs = std::filesystem;

@@ -368,6 +368,67 @@ def test_amr_hierarchy_of_the_cxx_host_across_ranks_matches_one_rank(tmp_path, n
     assert open(dump1 + ".meta").read().split()[:3] == open(dumpn + ".rank0.meta").read().split()[:3]  # steps, time, dt
 
 
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_plotfile_and_checkpoint_written_by_several_ranks(tmp_path, nranks):
+    """AMRSimulation::WritePlotFile / WriteCheckpointFile of the C++17 host on several ranks (quokka_io.hpp: VisMF::Write with one data file per
+    rank — Cell_D_00000 .. — and ONE header by rank 0 that lists the boxes of the whole level, each with the file of its owner and an offset
+    that follows from the box list; per-fab minima / maxima reduced over the ranks; Header, metadata and the last_chk link by rank 0).  The
+    three-level Sedov hierarchy of the test above: the plotfile and the checkpoint of N ranks hold the same grids as the one-rank files and the
+    same data to rounding (the reflux additions are reassociated across ranks), the header tables are those of the data, every rank's file is
+    referenced, and a restart from the N-rank checkpoint — on N ranks and on ONE rank — continues to the same final state as the uninterrupted
+    N-rank run (bit for bit on N ranks)."""
+    from quokka_amd import plotfile as pf
+    base = ["geometry.prob_lo=0 0 0", "geometry.prob_hi=1.2 1.2 1.2", "geometry.is_periodic=0 0 0", "amr.n_cell=32 32 32", "amr.max_grid_size=8",
+            "amr.max_level=2", "amr.blocking_factor=8", "amr.n_error_buf=3", "do_reflux=1"]
+    out1, outn = tmp_path / "one", tmp_path / "many"
+    os.makedirs(out1)
+    os.makedirs(outn)
+    io1 = [f"plotfile_prefix={out1}/plt", f"checkpoint_prefix={out1}/chk", "plotfile_interval=4", "checkpoint_interval=4", "max_timesteps=4"]
+    ion = [f"plotfile_prefix={outn}/plt", f"checkpoint_prefix={outn}/chk", "plotfile_interval=4", "checkpoint_interval=4", "max_timesteps=4"]
+    for sub in ("w", "r", "s"):
+        os.makedirs(tmp_path / sub)
+    run_ranks("ref_HydroBlast3D", base + io1 + ["qk.cluster_within_parent=1"], tmp_path, 1, 29711)
+    run_ranks("ref_HydroBlast3D", base + ion + ["qk.level0_distribution=interleaved"], tmp_path, nranks, 29711 + nranks)
+    # the plotfile
+    A, B = pf.read_plotfile(str(out1 / "plt00004")), pf.read_plotfile(str(outn / "plt00004"))
+    assert B.finest_level == 2 and A.finest_level == 2
+    for la, lb in zip(A.levels, B.levels):
+        assert la.boxes == lb.boxes
+        for n, fab in enumerate(lb.fabs):  # the header's tables are those of the data
+            assert np.array_equal(lb.minima[n], fab.reshape(fab.shape[0], -1).min(axis=1)) and np.array_equal(lb.maxima[n], fab.reshape(fab.shape[0], -1).max(axis=1))
+    files = {ln.split()[1] for ln in open(outn / "plt00004" / "Level_0" / "Cell_H") if ln.startswith("FabOnDisk:")}
+    assert files == {f"Cell_D_{r:05d}" for r in range(nranks)}
+    diff = pf.compare_plotfiles(str(out1 / "plt00004"), str(outn / "plt00004"))
+    scale = {v: max(float(np.abs(f[i]).max()) for f in A.levels[0].fabs) for i, v in enumerate(A.varnames)}
+    assert all(diff[v] <= 1e-13 * max(scale[v], 1e-300) or diff[v] <= 1e-13 * scale["gasEnergy"] for v in A.varnames), diff
+    # the checkpoint: global grids in the Header, ghost cells kept
+    h1, c1 = pf.read_checkpoint(str(out1 / "chk00004"))
+    hn, cn = pf.read_checkpoint(str(outn / "chk00004"))
+    assert hn.finest_level == 2 and hn.grids == h1.grids and hn.istep == h1.istep and hn.dt == h1.dt
+    assert all(a.boxes == b.boxes and a.nghost == b.nghost == 4 for a, b in zip(c1, cn))
+    assert os.path.islink(outn / "last_chk")
+    # restart from the N-rank checkpoint: N ranks and one rank, against the uninterrupted N-rank run
+    more = base + ["plotfile_interval=-1", "checkpoint_interval=-1", "max_timesteps=8", "qk.level0_distribution=interleaved"]
+    whole, _ = run_ranks("ref_HydroBlast3D", more, tmp_path / "w", nranks, 29731 + nranks)
+    again, _ = run_ranks("ref_HydroBlast3D", more + [f"restartfile={outn}/chk00004"], tmp_path / "r", nranks, 29751 + nranks)
+    for r in range(nranks):
+        assert np.array_equal(whole[r], again[r]), r
+    (single,), _ = run_ranks("ref_HydroBlast3D", base + ["plotfile_interval=-1", "checkpoint_interval=-1", "max_timesteps=8", "qk.cluster_within_parent=1",
+                                                            f"restartfile={outn}/chk00004"], tmp_path / "s", 1, 29771)
+    from quokka_amd.simulation import chop_domain, distribute_boxes_interleaved
+    boxes = chop_domain([32, 32, 32], [8, 8, 8])
+    owner = distribute_boxes_interleaved(boxes, nranks, [32, 32, 32], [8, 8, 8])
+    single = single.reshape(len(boxes), 6, 8, 8, 8)
+    cursor = [0] * nranks
+    worst = 0.0
+    for b, r in enumerate(owner):  # the level-0 state (which holds the averages of the finer levels) of the one-rank restart, to rounding
+        chunk = whole[r][cursor[r]:cursor[r] + 6 * 512].reshape(6, 8, 8, 8)
+        cursor[r] += 6 * 512
+        for n in range(6):
+            worst = max(worst, float(np.abs(chunk[n] - single[b][n]).max() / np.abs(single[:, n]).max()))
+    assert all(cursor[r] == whole[r].size for r in range(nranks)) and worst <= 1e-13, worst
+
+
 def test_sedov_on_several_gpus_over_rccl(tmp_path):
     """the production transport (ncclSend / ncclRecv on the library-owned stream, ncclAllReduce): needs one GPU per rank — skipped on a
     one-GPU box, where the test above covers everything but the transport itself"""
