@@ -443,11 +443,8 @@ QK_DEV void solveGasRadiationEnergyExchange(Rad const &r, M &m, Eos const &eos, 
 			}
 		}
 
-		double d_fourpiboverc_d_t[NG];
-		thermalRadiationTempDerivativeMG<NG>(r, frac, T_d, d_fourpiboverc_d_t);
-		const double c_v = ec.eintTempDerivative(T_gas);
-
-		// ComputeJacobianForGas
+		// ComputeJacobianForGas: the residuals first — the converged iteration (the last one of every solve) needs neither the emission
+		// derivative nor the Jacobian entries, which the reference evaluates before it tests the residuals (:98-147, :300-303); same values
 		const double Egas_diff = Egas_guess - Egas0;
 		const double CR_heating = 0.0 * dt;
 		const double F0 = Egas_diff + cscale * sumOf<NG>(Rvec) - CR_heating;
@@ -461,6 +458,13 @@ QK_DEV void solveGasRadiationEnergyExchange(Rad const &r, M &m, Eos const &eos, 
 				Fg_abs_sum += fabs(Fg[g]);
 			}
 		}
+		if ((fabs(F0 / Etot0) < resid_tol) && (cscale * Fg_abs_sum / Etot0 < resid_tol)) {
+			break;
+		}
+
+		double d_fourpiboverc_d_t[NG];
+		thermalRadiationTempDerivativeMG<NG>(r, frac, T_d, d_fourpiboverc_d_t);
+		const double c_v = ec.eintTempDerivative(T_gas);
 #pragma unroll
 		for (int g = 0; g < NG; ++g) {
 			const double dEg_dT = ot.kappaPoverE[g] * d_fourpiboverc_d_t[g];
@@ -472,10 +476,6 @@ QK_DEV void solveGasRadiationEnergyExchange(Rad const &r, M &m, Eos const &eos, 
 			}
 		}
 		const double J00 = 1.0;
-
-		if ((fabs(F0 / Etot0) < resid_tol) && (cscale * Fg_abs_sum / Etot0 < resid_tol)) {
-			break;
-		}
 
 		// SolveLinearEqs (J0g = cscale for every group)
 		double s1 = 0, s2 = 0;
