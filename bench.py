@@ -322,6 +322,35 @@ def cxx_host_block(args, ncell):
     return blk
 
 
+def cxx_shell_block(args, steps=22):
+    """BASELINE config 4 through the C++17 host: the reference's OWN problem file (src/problems/RadhydroShell, compiled unchanged against the host
+    mirror by __graft_entry__.build(), where the reference tree exists) with the deck of the config; the figure of merit the executable prints
+    (AMRSimulation::evolve: all steps of the run, the first ones included)."""
+    import re
+    import subprocess
+    host = os.path.join(ROOT, "quokka_amd", "host")
+    exe = os.path.join(host, "bin", "ref_RadhydroShell")
+    if not os.path.exists(exe):
+        return {"error": "quokka_amd/host/bin/ref_RadhydroShell is not built (needs the reference tree at build time)"}
+    gold = os.path.join(ROOT, "tests", "golden", "dust_shell_initial_conditions.txt")
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        import shutil
+        shutil.copy(gold, os.path.join(tmp, "initial_conditions.txt"))  # the problem opens ./initial_conditions.txt
+        cmd = [exe, os.path.join(host, "decks", "radhydro_shell_256.in"), f"max_timesteps={steps}", "plotfile_interval=-1", "checkpoint_interval=-1",
+               "radiation.source_is_time_independent=1", f"hydro.rk2_carry_rhs={1 if args.rk2_mode == 'carry' else 0}"]
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=tmp)
+            m = re.search(r"Performance figure-of-merit: ([0-9.eE+-]+) .s/zone-update \[([0-9.eE+-]+) Mupdates/s\]", p.stdout)
+            if m is None:
+                return {"error": "no figure of merit in the output", "tail": p.stdout[-300:]}
+        except Exception as e:  # noqa: BLE001 - a secondary block must not take the headline down
+            return {"error": f"{type(e).__name__}: {e}"}
+    return {"value": float(m.group(2)), "unit": "Mcell-updates/s", "steps": steps, "rk2_mode": args.rk2_mode,
+            "driver": "the reference's test_radhydro_shell.cpp, unchanged, through QuokkaSimulation<problem_t> (C++17 host mirror), deck radhydro_shell_256.in; "
+                      "the executable's own figure of merit over all steps of the run"}
+
+
 def compact(block, keep=("value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline", "kernels_ms_per_launch")):
     """a secondary block of the default line: the figures of a workload's own line without the contract boilerplate"""
     return {k: block[k] for k in keep if k in block}
@@ -598,6 +627,7 @@ def main():
             out["cxx_host"] = cxx_host_block(args, 256)
             # (d) BASELINE config 4 at its full size: RadhydroShell 256^3, the 50 steps the reference problem runs (test_radhydro_shell.cpp:431)
             out["shell256"] = compact(run_shell(ctx, torch, 256, 128, 50, 2, 0, carry=(args.rk2_mode == "carry")))
+            out["cxx_shell256"] = cxx_shell_block(args)
             torch.cuda.empty_cache()
             # (e) BASELINE config 5 geometry at its full size on the one GPU: blast_amr_maxlev2.in, 256^3 base grid + 2 levels
             out["amr_maxlev2"] = compact(run_amr(ctx, torch, dist, rank, world, 256, 50, 5))
