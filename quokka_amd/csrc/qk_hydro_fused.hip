@@ -539,6 +539,7 @@ template <int ORDER, int STAGE, int NS, bool CARRY, int NDIM = 3, bool FOFC = fa
 	__shared__ double s_e[NV][XB];  // right-edge states a_plus
 	__shared__ double s_d[3][XB];	  // D_V, D_W, face velocity
 
+	// (no XCD-contiguous remap here — qk_device.hpp: measured 2 % slower; the kernel is bound by FP64 issue, not by the halo lines it re-fetches)
 	const int b = blockIdx.z;
 	const qk_box bx = a.boxes[b];
 	const SGeom g = a.geom[b];
@@ -757,13 +758,16 @@ __global__ void __launch_bounds__(64 * MARCH_BY) k_sweep_march(SweepArgs a, Eos 
 	constexpr int NV = NVAR + NS; // hydro variables + passive scalars
 	constexpr int RHS_DIVV = S_RHS + NV;
 	static_assert(DIR == 1 || DIR == 2, "marching sweeps are the strided directions");
-	const int b = static_cast<int>(blockIdx.z) / a.nseg;
-	const int seg = static_cast<int>(blockIdx.z) - b * a.nseg;
+	// (the two 64-cell chunks of a row share a cache line, and so do consecutive rows: qk_device.hpp)
+	const BlockId blk = xcdContiguousBlock();
+	const int bix = blk.x, biy = blk.y, biz = blk.z;
+	const int b = biz / a.nseg;
+	const int seg = biz - b * a.nseg;
 	const qk_box bx = a.boxes[b];
 	const SGeom g = a.geom[b];
 	constexpr int OT = (DIR == 1) ? 2 : 1; // the other transverse axis (besides x)
-	const int i_raw = bx.lo[0] + blockIdx.x * 64 + threadIdx.x;
-	const int ot_raw = bx.lo[OT] + blockIdx.y * MARCH_BY + threadIdx.y;
+	const int i_raw = bx.lo[0] + bix * 64 + threadIdx.x;
+	const int ot_raw = bx.lo[OT] + biy * MARCH_BY + threadIdx.y;
 	// lanes beyond the box stay in the wave (clamped addresses, masked stores) so that wave reductions are well defined
 	const bool live = (i_raw <= bx.hi[0]) && (ot_raw <= bx.hi[OT]);
 	const int i = min(i_raw, bx.hi[0]);

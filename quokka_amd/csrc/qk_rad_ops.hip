@@ -352,7 +352,7 @@ template <int ORDER, bool STORE> __global__ void __launch_bounds__(RXB) k_rad_sw
 	__shared__ double s_e[NRAD][RXB];
 	__shared__ double s_c[NRAD][RXB];
 	__shared__ double s_f[NRAD][RXB]; // flux at the left face of the thread's cell
-	const int b = static_cast<int>(blockIdx.z);
+	const int b = static_cast<int>(blockIdx.z); // (no XCD-contiguous remap: measured 5 % slower here, qk_device.hpp)
 	const qk_box bx = boxes[b];
 	const int k = bx.lo[2] + static_cast<int>(blockIdx.y);
 	if (k > bx.hi[2]) {
@@ -450,10 +450,11 @@ __global__ void __launch_bounds__(256) k_rad_sweep_march(const qk_box *boxes, Ra
 	static_assert(DIR == 1 || DIR == 2, "marching sweep: strided directions only");
 	static_assert((0.5 - IMEX_a32) == 0.0, "the fused stage drops the old-state fluxes of AddFluxesRK2: PD-ARS only");
 	constexpr int OT = 3 - DIR;
-	const int b = static_cast<int>(blockIdx.z);
+	const BlockId blk = xcdContiguousBlock(); // (the two chunks of a row, and consecutive rows, share cache lines: qk_device.hpp)
+	const int b = blk.z;
 	const qk_box bx = boxes[b];
-	const int i = bx.lo[0] + static_cast<int>(blockIdx.x) * 64 + static_cast<int>(threadIdx.x);
-	const int oblk = static_cast<int>(blockIdx.y) % notb, sno = static_cast<int>(blockIdx.y) / notb;
+	const int i = bx.lo[0] + blk.x * 64 + static_cast<int>(threadIdx.x);
+	const int oblk = blk.y % notb, sno = blk.y / notb;
 	const int ot = bx.lo[OT] + oblk * 4 + static_cast<int>(threadIdx.y);
 	const int c0 = bx.lo[DIR] + sno * strip;
 	if (i > bx.hi[0] || ot > bx.hi[OT] || c0 > bx.hi[DIR]) {
