@@ -256,6 +256,8 @@ def run_shell(ctx, torch, ncell, mgs, steps, warmup, pow_mode, carry=False):
                        "solves_per_cell_and_source_call": sim.rad_counters["solves"] / max(2 * sim.radiationCellUpdates_, 1),
                        "max_newton_iterations": sim.rad_counters["max_newton_iterations"], "pow_mode": pow_mode, "sim_time": sim.tNew_,
                        "rk2_mode": "carry" if carry else "exact",
+                       "rad_energy_source": "evaluated ONCE on the host (numpy; the shell's source is constant before t0) — the reference launches "
+                                            "SetRadEnergySource before every source-term call: see cxx_shell256, which does",
                        "relative_mass_change": abs(mass1 - mass0) / mass0},
             "roofline": {"kernels": roof, "note": "transport sweeps against 8 TB/s HBM (frac) and against the FP64 VALU issue rate (frac_fp64_valu; PLM instruction counts); the Newton-Raphson kernel against the FP64 VALU issue rate"},
             "kernels_ms_per_launch": per, "kernels_launches": launches,
@@ -322,10 +324,77 @@ def cxx_host_block(args, ncell):
     return blk
 
 
+def full_run_block(args):
+    """The metric as the reference counts it (src/simulation.hpp:972-981, :1285): bin/ref_HydroBlast3D — the reference's own problem file,
+    compiled unchanged against the C++17 host — with the deck of BASELINE config 2 (blast_unigrid_256.in: max_timesteps = 1000), cell-updates
+    divided by the wall time of the WHOLE evolve as the executable prints it, both forms of the RK2 average, plus how often the first-order flux
+    correction and the retry loop ran (a line this host adds after the figure of merit)."""
+    import subprocess
+    host = os.path.join(ROOT, "quokka_amd", "host")
+    exe = os.path.join(host, "bin", "ref_HydroBlast3D")
+    if not os.path.exists(exe):
+        return {"error": "quokka_amd/host/bin/ref_HydroBlast3D is not built (needs the reference tree at build time)"}
+    out = {"unit": "Mcell-updates/s", "deck": "quokka_amd/host/decks/blast_unigrid_256.in (the keys of the reference's tests/blast_unigrid_256.in), unchanged: 1000 steps",
+           "driver": "the reference's test_hydro3d_blast.cpp, unchanged, through QuokkaSimulation<problem_t> (C++17 host mirror); the executable's own "
+                     "figure of merit: all cell-updates / wall time of evolve()"}
+    for mode in (args.rk2_mode, "exact" if args.rk2_mode == "carry" else "carry"):
+        cmd = [exe, os.path.join(host, "decks", "blast_unigrid_256.in"), f"hydro.rk2_carry_rhs={1 if mode == 'carry' else 0}", "plotfile_interval=-1",
+               "checkpoint_interval=-1"]
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=host)
+            m = re.search(r"Performance figure-of-merit: ([0-9.eE+-]+) .s/zone-update \[([0-9.eE+-]+) Mupdates/s\]", p.stdout)
+            c = re.search(r"qk counters: steps=(\d+) fofc_stages=(\d+) retries=(\d+) elapsed_s=([0-9.eE+-]+) sim_time=([0-9.eE+-]+)", p.stdout)
+            if m is None or c is None:
+                out[mode] = {"error": "no figure of merit in the output", "rc": p.returncode, "tail": p.stdout[-300:]}
+                continue
+            out[mode] = {"value": float(m.group(2)), "steps": int(c.group(1)), "fofc_stages": int(c.group(2)), "retries": int(c.group(3)),
+                         "elapsed_s": float(c.group(4)), "sim_time": float(c.group(5)), "ms_per_step": 1e3 * float(c.group(4)) / max(int(c.group(1)), 1),
+                         "energy_conservation_ok": "Energy conservation is OK." in p.stdout}
+        except Exception as e:  # noqa: BLE001 - a secondary block must not take the headline down
+            out[mode] = {"error": f"{type(e).__name__}: {e}"}
+    if "value" in out.get(args.rk2_mode, {}):
+        out["value"], out["rk2_mode"] = out[args.rk2_mode]["value"], args.rk2_mode
+    return out
+
+
+def developed_block(ctx, torch, ncell, mgs, steps, warmup, carry):
+    """Sedov geometry started from a DEVELOPED blast (quokka_amd.simulation.developed_state: a Mach-3 shell at 0.62 of the box edge, hot
+    interior, rippled — the state tests/test_bench_geometry_gpu.py pins to the oracle bit for bit): every limiter / flattening / HLLC-fan branch
+    fires in a large share of the cells, which the deck's first 1000 steps (an almost uniform ambient medium) do not do."""
+    from quokka_amd.simulation import developed_state, sedov_problem
+    sim = sedov_problem(ctx, ncell, max_grid_size=mgs)
+    sim.maxTimesteps_ = 10 ** 9
+    sim.rk2_carry_rhs = bool(carry)
+    for b, (lo, hi) in enumerate(sim.my_boxes):
+        sim.state_new_cc_.set_fab(b, developed_state(ncell, lo, hi))
+    sim._signal_of_state_new = None
+    for _ in range(warmup):
+        assert sim.step()
+    L = ctx.L
+    L.qk_profile_reset(ctx.h)
+    L.qk_profile_enable(ctx.h, 1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        assert sim.step(), "hydro advance failed"
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    L.qk_profile_enable(ctx.h, 0)
+    k = read_profile(ctx)
+    rho = torch.cat([sim.state_new_cc_.valid(b)[0].reshape(-1) for b in range(sim.lev.nboxes)])
+    return {"value": ncell ** 3 * steps / el / 1e6, "unit": "Mcell-updates/s", "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3,
+            "rk2_mode": "carry" if carry else "exact", "fofc_stages": sim.counters["fofc1_stages"] + sim.counters["fofc2_stages"],
+            "retries": sim.counters["retries"], "sim_time": sim.tNew_, "density_min_max": [float(rho.min().item()), float(rho.max().item())],
+            "kernels_ms_per_launch": {n: v[1] / max(v[0], 1) for n, v in sorted(k.items())},
+            "initial_state": "quokka_amd.simulation.developed_state (tests/test_bench_geometry_gpu.py)"}
+
+
 def cxx_shell_block(args, steps=22):
     """BASELINE config 4 through the C++17 host: the reference's OWN problem file (src/problems/RadhydroShell, compiled unchanged against the host
     mirror by __graft_entry__.build(), where the reference tree exists) with the deck of the config; the figure of merit the executable prints
-    (AMRSimulation::evolve: all steps of the run, the first ones included)."""
+    (AMRSimulation::evolve: all steps of the run, the first ones included).  `value`: SetRadEnergySource evaluated before every source-term call
+    as the reference does (QuokkaSimulation.hpp:1866-1873); `source_evaluated_once`: the same run with this host's extension
+    radiation.source_is_time_independent = 1 (the shell's source does not change before t0: same result, one launch instead of 2 per substep)."""
     import re
     import subprocess
     host = os.path.join(ROOT, "quokka_amd", "host")
@@ -334,21 +403,25 @@ def cxx_shell_block(args, steps=22):
         return {"error": "quokka_amd/host/bin/ref_RadhydroShell is not built (needs the reference tree at build time)"}
     gold = os.path.join(ROOT, "tests", "golden", "dust_shell_initial_conditions.txt")
     import tempfile
+    vals = {}
     with tempfile.TemporaryDirectory() as tmp:
         import shutil
         shutil.copy(gold, os.path.join(tmp, "initial_conditions.txt"))  # the problem opens ./initial_conditions.txt
-        cmd = [exe, os.path.join(host, "decks", "radhydro_shell_256.in"), f"max_timesteps={steps}", "plotfile_interval=-1", "checkpoint_interval=-1",
-               "radiation.source_is_time_independent=1", f"hydro.rk2_carry_rhs={1 if args.rk2_mode == 'carry' else 0}"]
-        try:
-            p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=tmp)
-            m = re.search(r"Performance figure-of-merit: ([0-9.eE+-]+) .s/zone-update \[([0-9.eE+-]+) Mupdates/s\]", p.stdout)
-            if m is None:
-                return {"error": "no figure of merit in the output", "tail": p.stdout[-300:]}
-        except Exception as e:  # noqa: BLE001 - a secondary block must not take the headline down
-            return {"error": f"{type(e).__name__}: {e}"}
-    return {"value": float(m.group(2)), "unit": "Mcell-updates/s", "steps": steps, "rk2_mode": args.rk2_mode,
-            "driver": "the reference's test_radhydro_shell.cpp, unchanged, through QuokkaSimulation<problem_t> (C++17 host mirror), deck radhydro_shell_256.in; "
-                      "the executable's own figure of merit over all steps of the run"}
+        for flag in (0, 1):
+            cmd = [exe, os.path.join(host, "decks", "radhydro_shell_256.in"), f"max_timesteps={steps}", "plotfile_interval=-1", "checkpoint_interval=-1",
+                   f"radiation.source_is_time_independent={flag}", f"hydro.rk2_carry_rhs={1 if args.rk2_mode == 'carry' else 0}"]
+            try:
+                p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=tmp)
+                m = re.search(r"Performance figure-of-merit: ([0-9.eE+-]+) .s/zone-update \[([0-9.eE+-]+) Mupdates/s\]", p.stdout)
+                if m is None:
+                    return {"error": "no figure of merit in the output", "tail": p.stdout[-300:]}
+                vals[flag] = float(m.group(2))
+            except Exception as e:  # noqa: BLE001 - a secondary block must not take the headline down
+                return {"error": f"{type(e).__name__}: {e}"}
+    return {"value": vals[0], "unit": "Mcell-updates/s", "steps": steps, "rk2_mode": args.rk2_mode,
+            "source_evaluated_once": {"value": vals[1], "flag": "radiation.source_is_time_independent=1 (an extension of this host, not a reference key)"},
+            "driver": "the reference's test_radhydro_shell.cpp, unchanged, through QuokkaSimulation<problem_t> (C++17 host mirror), deck radhydro_shell_256.in, "
+                      "SetRadEnergySource evaluated before every source-term call as in the reference; the executable's own figure of merit over all steps of the run"}
 
 
 def compact(block, keep=("value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline", "kernels_ms_per_launch")):
@@ -625,6 +698,11 @@ def main():
             # (c2) the same measurement through the C++17 host mirror (quokka_amd/host: QuokkaSimulation<problem_t> as a problem file drives it;
             # builder-authored driver quokka_amd/host/drivers/sedov_bench.cpp, its own process)
             out["cxx_host"] = cxx_host_block(args, 256)
+            # (c3) the metric as the reference counts it: the unchanged problem file + deck, 1000 steps, the executable's own figure of merit
+            out["full_run"] = full_run_block(args)
+            # (c4) developed flow: 50 steps from a strong shell at 0.62 of the box edge
+            out["developed"] = developed_block(ctx, torch, 256, mgs, 50, 3, carry)
+            torch.cuda.empty_cache()
             # (d) BASELINE config 4 at its full size: RadhydroShell 256^3, the 50 steps the reference problem runs (test_radhydro_shell.cpp:431)
             out["shell256"] = compact(run_shell(ctx, torch, 256, 128, 50, 2, 0, carry=(args.rk2_mode == "carry")))
             out["cxx_shell256"] = cxx_shell_block(args)

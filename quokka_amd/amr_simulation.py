@@ -205,8 +205,7 @@ class AmrLevelSim(HydroSimulation):
             success = True
             for substep in range(nsubsteps):
                 if substep > 0:
-                    for b in range(self.lev.nboxes):
-                        self.state_old_tmp.fabs[b][0:6].copy_(self.state_new_cc_.fabs[b][0:6])
+                    self.state_old_tmp.copy_comps_from(self.state_new_cc_, 0, 6)
                 success = self.advanceHydroAtLevel(old, dt_step)
                 if not success:
                     break
@@ -283,8 +282,7 @@ class RadAmrLevelSim(AmrLevelSim, RadhydroSimulation):
         else:  # :681-685: the hydro variables are carried over
             self._signal_of_state_new = None
             self.state_old_cc_, self.state_new_cc_ = self.state_new_cc_, self.state_old_cc_
-            for b in range(self.lev.nboxes):
-                self.state_new_cc_.fabs[b][:RAD0].copy_(self.state_old_cc_.fabs[b][:RAD0])
+            self.state_new_cc_.copy_comps_from(self.state_old_cc_, 0, RAD0)
         self._rad_time = time
         return self.subcycleRadiationAtLevel(time, dt_lev)
 

@@ -11,7 +11,10 @@
 //   * std::pow(cs, 2) (hydro_system.hpp:602) is cs*cs;
 //   * the divisions of the Riemann path that share a denominator share its refined reciprocal (recipOf / divBy below):
 //     the same operations on the same operands as the compiler's expansion of `/`, i.e. the same bits for normal-range
-//     operands; a zero quotient may differ in sign, a zero / subnormal / infinite denominator gives NaN instead of +-inf.
+//     operands; a zero quotient may differ in sign, a zero / subnormal / infinite denominator gives NaN instead of +-inf.  Since round 4
+//     EVERY division of the Riemann path takes this form (divN / recipExact for denominators used once: 7-8 instructions against the 11 of
+//     `/`), the division by the run-time constant kB_user goes through a reciprocal formed on the host, and the square roots are sqrtN
+//     (15 instructions against 22: no range scaling for arguments below 2^-767) — 7 square roots and 10 lone divisions per face.
 #ifndef QK_DEVICE_HPP_
 #define QK_DEVICE_HPP_
 
@@ -81,18 +84,85 @@ template <int DIR, bool TWOD = false> struct Axes {
 
 QK_DEV auto unit(int axis, int comp) -> int { return axis == comp ? 1 : 0; }
 
+// Correctly rounded FP64 division with the refined reciprocal of the denominator SHARED between numerators.
+// hipcc expands `n / d` to  div_scale x2, rcp, two Newton steps (4 fma), q = n * r, e = fma(-d, q, n), div_fmas(e, r, q),
+// div_fixup  — 11 instructions, one of them quarter rate, in one dependency chain.  The Riemann solver divides 4 numerators
+// by rho_L, 4 by rho_R, 2 + 2 by (gamma-1) rho and 6 by S_K - S*: with the reciprocal refined once per denominator every
+// further quotient is mul + 2 fma, the SAME three operations on the SAME operands as the tail of the expansion, hence the
+// same bits whenever div_scale does not rescale and div_fixup does not intervene: denominator and quotient in the normal
+// range (roughly |d|, |n / d| in [2^-1020, 2^1020] with exponents of n and d less than 768 apart).  Outside it: a zero
+// quotient may come out as +0 where IEEE gives -0; a zero, infinite or subnormal DENOMINATOR (rho, (gamma-1) rho, S_K - S*)
+// yields NaN where IEEE gives +-inf or a rounded subnormal quotient — such a state is invalid in the reference as well (the
+// cell is flagged and the step retried), it just fails with a different non-number.  A per-face range guard with a plain-
+// division fallback was measured: the second code path costs more than the shared reciprocals save.
+struct Recip {
+	double d, r;
+};
+QK_DEV auto recipOf(double d) -> Recip
+{
+	Recip R;
+	R.d = d;
+	const double r0 = __builtin_amdgcn_rcp(d);
+	double e = __builtin_fma(-d, r0, 1.0);
+	const double r1 = __builtin_fma(r0, e, r0);
+	e = __builtin_fma(-d, r1, 1.0);
+	R.r = __builtin_fma(r1, e, r1);
+	return R;
+}
+QK_DEV auto divBy(double n, Recip const &R) -> double
+{
+	const double q = n * R.r;
+	const double e = __builtin_fma(-R.d, q, n);
+	return __builtin_fma(e, R.r, q);
+}
+
+// Correctly rounded FP64 square root without the range scaling of hipcc's expansion.  `sqrt(x)` compiles to 22 VALU instructions: compare
+// against 2^-767, select a scale, ldexp, v_rsq_f64, two multiplies and seven fma of Goldschmidt / Newton refinement, ldexp back, and the class test
+// that returns x itself for +-0 and +inf.  The seven-instruction tail around the refinement only serves arguments below 2^-767 (1e-231): no
+// density, c_s^2 or v^2 of a valid state comes near.  This is the same refinement on the same operands (the same bits for x >= 2^-767) plus the
+// class test — sqrt(0) = 0 matters: |v| of gas at rest —, 15 instructions; a PPM + HLLC face takes seven square roots.
+QK_DEV auto sqrtN(double x) -> double
+{
+	const double y = __builtin_amdgcn_rsq(x);
+	double g = x * y;
+	double h = y * 0.5;
+	const double r = __builtin_fma(-h, g, 0.5);
+	g = __builtin_fma(g, r, g);
+	double d = __builtin_fma(-g, g, x);
+	h = __builtin_fma(h, r, h);
+	g = __builtin_fma(d, h, g);
+	d = __builtin_fma(-g, g, x);
+	g = __builtin_fma(d, h, g);
+	return __builtin_amdgcn_class(x, 0x260) ? x : g; // +-0, +inf
+}
+// 1 / d, correctly rounded (recipOf + the two-fma tail of divBy with numerator 1)
+QK_DEV auto recipExact(double d) -> double
+{
+	const double r0 = __builtin_amdgcn_rcp(d);
+	double e = __builtin_fma(-d, r0, 1.0);
+	const double r1 = __builtin_fma(r0, e, r0);
+	e = __builtin_fma(-d, r1, 1.0);
+	const double r = __builtin_fma(r1, e, r1);
+	e = __builtin_fma(-d, r, 1.0);
+	return __builtin_fma(e, r, r);
+}
+// n / d for a single numerator: the reciprocal refined for this quotient alone (8 instructions against the 11 of `/`: no div_scale / div_fixup)
+QK_DEV auto divN(double n, double d) -> double { return divBy(n, recipOf(d)); }
+
 // quokka::EOS<problem_t>, gamma-law, direct association (oracle/eos.hpp variant 0)
 struct Eos {
 	double gamma, gm1, cs_iso, mu, kB_ratio_num, kB_user; // mu = mean_molecular_weight / m_u
 	bool isothermal;
 	int tmodel;   // temperature hooks: 0 gamma-law, 1 E_int = (alpha / 4) T^4
 	double alpha;
+	Recip RkBu;   // 1 / kB_user: a run-time constant, its reciprocal (correctly rounded by the constructor's IEEE division) arrives in scalar registers
 	static constexpr double k_B = 1.380649e-16;
 	static constexpr double m_u = 1.6605390666e-24;
 
 	__host__ __device__ explicit Eos(qk_hydro_traits const &t)
 	    : gamma(t.gamma), gm1(t.gamma - 1.0), cs_iso(t.cs_isothermal), mu(t.mean_molecular_weight / m_u), kB_ratio_num(k_B),
-	      kB_user(t.boltzmann_constant), isothermal(t.gamma == 1.0), tmodel(t.eos_temperature_model), alpha(t.eos_alpha)
+	      kB_user(t.boltzmann_constant), isothermal(t.gamma == 1.0), tmodel(t.eos_temperature_model), alpha(t.eos_alpha),
+	      RkBu{t.boltzmann_constant, 1.0 / t.boltzmann_constant}
 	{
 	}
 	// EOS.hpp:304-348 : e = Eint/rho (0 if rho == 0) ; p = (gamma-1) rho e
@@ -182,38 +252,6 @@ QK_DEV auto smin1(double a) -> double
 }
 // (v < lo) ? lo : (hi < v) ? hi : v for lo <= hi
 QK_DEV auto clampd(double v, double lo, double hi) -> double { return smin(smax(v, lo), hi); }
-
-// Correctly rounded FP64 division with the refined reciprocal of the denominator SHARED between numerators.
-// hipcc expands `n / d` to  div_scale x2, rcp, two Newton steps (4 fma), q = n * r, e = fma(-d, q, n), div_fmas(e, r, q),
-// div_fixup  — 11 instructions, one of them quarter rate, in one dependency chain.  The Riemann solver divides 4 numerators
-// by rho_L, 4 by rho_R, 2 + 2 by (gamma-1) rho and 6 by S_K - S*: with the reciprocal refined once per denominator every
-// further quotient is mul + 2 fma, the SAME three operations on the SAME operands as the tail of the expansion, hence the
-// same bits whenever div_scale does not rescale and div_fixup does not intervene: denominator and quotient in the normal
-// range (roughly |d|, |n / d| in [2^-1020, 2^1020] with exponents of n and d less than 768 apart).  Outside it: a zero
-// quotient may come out as +0 where IEEE gives -0; a zero, infinite or subnormal DENOMINATOR (rho, (gamma-1) rho, S_K - S*)
-// yields NaN where IEEE gives +-inf or a rounded subnormal quotient — such a state is invalid in the reference as well (the
-// cell is flagged and the step retried), it just fails with a different non-number.  A per-face range guard with a plain-
-// division fallback was measured: the second code path costs more than the shared reciprocals save.
-struct Recip {
-	double d, r;
-};
-QK_DEV auto recipOf(double d) -> Recip
-{
-	Recip R;
-	R.d = d;
-	const double r0 = __builtin_amdgcn_rcp(d);
-	double e = __builtin_fma(-d, r0, 1.0);
-	const double r1 = __builtin_fma(r0, e, r0);
-	e = __builtin_fma(-d, r1, 1.0);
-	R.r = __builtin_fma(r1, e, r1);
-	return R;
-}
-QK_DEV auto divBy(double n, Recip const &R) -> double
-{
-	const double q = n * R.r;
-	const double e = __builtin_fma(-R.d, q, n);
-	return __builtin_fma(e, R.r, q);
-}
 
 // hydro_system.hpp:138-196 ConservedToPrimitive for one cell: q = (rho, vx, vy, vz, P | e, Eint | e_aux); the quotients by rho share its
 // refined reciprocal (same bits as `/` for a normal-range rho, see recipOf)
@@ -351,7 +389,7 @@ template <int DIR, bool TWOD = false> QK_DEV auto makeState(Eos const &eos, bool
 			P = q[PPRES];
 			Eint = q[PEINT];
 		}
-		cs = sqrt(divBy(eos.gamma * P, Rrho)); // eos.soundSpeed
+		cs = sqrtN(divBy(eos.gamma * P, Rrho)); // eos.soundSpeed
 		E = divBy(P, Rg) * rho + ke;	     // eos.eintFromPres
 	}
 	s.rho = rho;
@@ -396,9 +434,9 @@ template <int RIEMANN> QK_DEV auto scalarFlux(Wave const &wv, double qL, double 
 QK_DEV void hllc(Eos const &eos, HState const &sL, HState const &sR, double du, double dw, double F[NVAR], Recip const &RL, Recip const &RR,
 		 Recip const &GL, Recip const &GR, Wave *wv = nullptr)
 {
-	const double wl = sqrt(sL.rho);
-	const double wr = sqrt(sR.rho);
-	const double norm = 1. / (wl + wr);
+	const double wl = sqrtN(sL.rho);
+	const double wr = sqrtN(sR.rho);
+	const double norm = recipExact(wl + wr);
 	const double u_tilde = (wl * sL.u + wr * sR.u) * norm;
 	const double dU = sL.u - sR.u;
 	double S_L, S_R;
@@ -413,8 +451,8 @@ QK_DEV void hllc(Eos const &eos, HState const &sL, HState const &sR, double du, 
 		//   dedr = 0, dedp = 1/dpde = 1/((gamma-1) rho), drdp = 1/((p/rho) * k_B / k_B_user), G = (gamma+1)/2
 		const double dedp_L = divBy(1.0, GL);
 		const double dedp_R = divBy(1.0, GR);
-		const double drdp_L = 1.0 / (divBy(sL.P, RL) * Eos::k_B / eos.kB_user);
-		const double drdp_R = 1.0 / (divBy(sR.P, RR) * Eos::k_B / eos.kB_user);
+		const double drdp_L = recipExact(divBy(divBy(sL.P, RL) * Eos::k_B, eos.RkBu));
+		const double drdp_R = recipExact(divBy(divBy(sR.P, RR) * Eos::k_B, eos.RkBu));
 		const double G = 0.5 * (1.0 + eos.gamma);
 		const double eL = divBy(sL.Eint, RL);
 		const double eR = divBy(sR.Eint, RR);
@@ -425,7 +463,7 @@ QK_DEV void hllc(Eos const &eos, HState const &sL, HState const &sR, double du, 
 		if (cs_exp <= 0) {
 			cs_tilde = 0.5 * (sL.cs + sR.cs);
 		} else {
-			cs_tilde = sqrt(cs_exp / C_tilde_P);
+			cs_tilde = sqrtN(divN(cs_exp, C_tilde_P));
 		}
 		const double s_NL = 0.5 * G * smax0(dU);
 		const double s_NR = s_NL;
@@ -442,17 +480,17 @@ QK_DEV void hllc(Eos const &eos, HState const &sL, HState const &sR, double du, 
 
 	// :91-93 carbuncle switch
 	const double cs_max = smax(sL.cs, sR.cs);
-	const double tp = smin1((cs_max - smin0(du)) / (cs_max - smin0(dw)));
+	const double tp = smin1(divN(cs_max - smin0(du), cs_max - smin0(dw)));
 	const double theta = tp * tp * tp * tp;
 
 	// :97-98
 	const double S_star =
-	    (theta * (sR.P - sL.P) + (sL.rho * sL.u * (S_L - sL.u) - sR.rho * sR.u * (S_R - sR.u))) / (sL.rho * (S_L - sL.u) - sR.rho * (S_R - sR.u));
+	    divN(theta * (sR.P - sL.P) + (sL.rho * sL.u * (S_L - sL.u) - sR.rho * sR.u * (S_R - sR.u)), sL.rho * (S_L - sL.u) - sR.rho * (S_R - sR.u));
 
 	// :102-107
-	const double vmag_L = sqrt(sL.u * sL.u + sL.v * sL.v + sL.w * sL.w);
-	const double vmag_R = sqrt(sR.u * sR.u + sR.v * sR.v + sR.w * sR.w);
-	const double chi = smin1(smax(vmag_L, vmag_R) / cs_max);
+	const double vmag_L = sqrtN(sL.u * sL.u + sL.v * sL.v + sL.w * sL.w);
+	const double vmag_R = sqrtN(sR.u * sR.u + sR.v * sR.v + sR.w * sR.w);
+	const double chi = smin1(divN(smax(vmag_L, vmag_R), cs_max));
 	const double phi = chi * (2. - chi);
 	const double P_LR = 0.5 * (sL.P + sR.P) + 0.5 * phi * (sL.rho * (S_L - sL.u) * (S_star - sL.u) + sR.rho * (S_R - sR.u) * (S_star - sR.u));
 
@@ -514,190 +552,90 @@ QK_DEV void hllc(Eos const &eos, HState const &sL, HState const &sR, double du, 
 	}
 }
 
-// HLLD.hpp:26-334 (Miyoshi & Kusano 2005).  The reference reaches it only through its MHD stub, with bx = 0 and zero transverse fields
-// (hydro_system.hpp:987-1003, :1044-1048); written for general fields, statement by statement as oracle/hydro.hpp restates it.  F[6] in canonical
-// order (rho, mom_n, mom_v, mom_w, E, 0): no flux of the auxiliary internal energy and none of the passive scalars (:331-332).
-struct ConsHydro1D { // HLLD.hpp:21-29
-	double rho, mx, my, mz, E, by, bz;
+// HLLD (Miyoshi & Kusano 2005; reference src/hydro/HLLD.hpp) as the reference USES it: only through its MHD stub, which hands the solver
+// bx = by = bz = 0 "for testing purposes" (hydro_system.hpp:987-1003, :1044-1048).  This is that B = 0 specialisation, derived by putting zero
+// fields into the solver and dropping what then multiplies or adds an exact zero (x + 0, x - 0, 0 * finite; the sign of a zero result may differ):
+//   * the fast magnetosonic speed collapses to sqrt(0.5 (gamma P + sqrt((gamma P)^2)) / rho);
+//   * both Alfven speeds coincide with the contact speed S_M, so the double-star states never reach the interface and the five-wave fan is the
+//     three-wave one: F = f_L | f_L + S_L (U*_L - U_L) | f_R + S_R (U*_R - U_R) | f_R;
+//   * the star states keep the transverse velocities of their side, E* = (a E - P u + p* S_M) / (S_K - S_M) with a = S_K - u.
+// The general solver stays restated in oracle/hydro.hpp; tests/test_hydro_ops_gpu.py::test_hlld_stub_fluxes_bit_exact_random_3d pins this function
+// to it bit for bit.  Association of every retained operation follows the reference (the reciprocal of S_K - S_M is formed first and multiplied,
+// HLLD.hpp:137-140).  F[6] in canonical order (rho, mom_n, mom_v, mom_w, E, 0): no flux of the auxiliary internal energy, none of the passive
+// scalars (HLLD.hpp:331-332).
+struct HlldSide {
+	double U[5], f[5]; // conserved state and physical flux (rho, m_n, m_v, m_w, E)
+	double a;	   // S_K - u_K
 };
-QK_DEV auto fastMagnetoSonicSpeed(double gamma, double P, double rho, double by, double bz, const double bx) -> double // HLLD.hpp:31-42
+QK_DEV auto hlldFastSpeed(double gamma, HState const &s) -> double
 {
-	double gp = gamma * P;
-	double bx_sq = bx * bx;
-	double byz_sq = by * by + bz * bz;
-	double b_sq = bx_sq + byz_sq;
-	double bgp_p = b_sq + gp;
-	double bgp_m = b_sq - gp;
-	return sqrt(0.5 * (bgp_p + sqrt(bgp_m * bgp_m + 4.0 * gp * byz_sq)) / rho);
+	const double gp = gamma * s.P;
+	return sqrt(0.5 * (gp + sqrt(gp * gp)) / s.rho);
 }
-QK_DEV void hlld(HState const &sL, HState const &sR, const double gamma, const double bx, const double by_L, const double bz_L, const double by_R, const double bz_R,
-		 double F[NVAR])
+QK_DEV void hlldSide(double gamma, HState const &s, HlldSide &k)
 {
-	constexpr double DELTA = 1.0e-4; // :18
-	auto SQUARE = [](double x) { return x * x; };
-	ConsHydro1D u_L{}, u_R{}, f_x{}, f_L{}, f_R{}, u_star_L{}, u_dstar_L{}, u_dstar_R{}, u_star_R{};
-	double spds[5] = {0., 0., 0., 0., 0.};
-	double const bx_sq = SQUARE(bx);
-	// :75-96 left and right conserved states
-	double const pb_L = 0.5 * (bx_sq + (SQUARE(by_L) + SQUARE(bz_L)));
-	double const pb_R = 0.5 * (bx_sq + (SQUARE(by_R) + SQUARE(bz_R)));
-	double const ke_L = 0.5 * sL.rho * (SQUARE(sL.u) + (SQUARE(sL.v) + SQUARE(sL.w)));
-	double const ke_R = 0.5 * sR.rho * (SQUARE(sR.u) + (SQUARE(sR.v) + SQUARE(sR.w)));
-	u_L.rho = sL.rho;
-	u_L.mx = sL.u * u_L.rho;
-	u_L.my = sL.v * u_L.rho;
-	u_L.mz = sL.w * u_L.rho;
-	u_L.E = ke_L + pb_L + sL.P / (gamma - 1.0);
-	u_L.by = by_L;
-	u_L.bz = bz_L;
-	u_R.rho = sR.rho;
-	u_R.mx = sR.u * u_R.rho;
-	u_R.my = sR.v * u_R.rho;
-	u_R.mz = sR.w * u_R.rho;
-	u_R.E = ke_R + pb_R + sR.P / (gamma - 1.0);
-	u_R.by = by_R;
-	u_R.bz = bz_R;
-	// :100-104 outer wave speeds
-	const double cfs_L = fastMagnetoSonicSpeed(gamma, sL.P, sL.rho, by_L, bz_L, bx);
-	const double cfs_R = fastMagnetoSonicSpeed(gamma, sR.P, sR.rho, by_R, bz_R, bx);
-	spds[0] = smin(sL.u - cfs_L, sR.u - cfs_R);
-	spds[4] = smax(sL.u + cfs_L, sR.u + cfs_R);
-	// :108-125 left and right fluxes
-	double ptot_L = sL.P + pb_L;
-	double ptot_R = sR.P + pb_R;
-	f_L.rho = u_L.mx;
-	f_L.mx = u_L.mx * sL.u + ptot_L - bx_sq;
-	f_L.my = u_L.my * sL.u + bx * u_L.by;
-	f_L.mz = u_L.mz * sL.u + bx * u_L.bz;
-	f_L.E = sL.u * (u_L.E + ptot_L - bx_sq) - bx * (sL.v * u_L.by + sL.w * u_L.bz);
-	f_L.by = u_L.by * sL.u - bx * sL.v;
-	f_L.bz = u_L.bz * sL.u - bx * sL.w;
-	f_R.rho = u_R.mx;
-	f_R.mx = u_R.mx * sR.u + ptot_R - bx_sq;
-	f_R.my = u_R.my * sR.u + bx * u_R.by;
-	f_R.mz = u_R.mz * sR.u + bx * u_R.bz;
-	f_R.E = sR.u * (u_R.E + ptot_R - bx_sq) - bx * (sR.v * u_R.by + sR.w * u_R.bz);
-	f_R.by = u_R.by * sR.u - bx * sR.v;
-	f_R.bz = u_R.bz * sR.u - bx * sR.w;
-	// :129-145 middle and Alfven wave speeds
-	double siui_L = spds[0] - sL.u;
-	double siui_R = spds[4] - sR.u;
-	spds[2] = (siui_R * u_R.mx - siui_L * u_L.mx + (ptot_L - ptot_R)) / (siui_R * u_R.rho - siui_L * u_L.rho);
-	double sism_L = spds[0] - spds[2];
-	double sism_R = spds[4] - spds[2];
-	double sism_inv_L = 1.0 / sism_L;
-	double sism_inv_R = 1.0 / sism_R;
-	u_star_L.rho = u_L.rho * siui_L * sism_inv_L;
-	u_star_R.rho = u_R.rho * siui_R * sism_inv_R;
-	double u_star_rho_inv_L = 1.0 / u_star_L.rho;
-	double u_star_rho_inv_R = 1.0 / u_star_R.rho;
-	double rho_sqrt_L = sqrt(u_star_L.rho);
-	double rho_sqrt_R = sqrt(u_star_R.rho);
-	spds[1] = spds[2] - fabs(bx) / rho_sqrt_L;
-	spds[3] = spds[2] + fabs(bx) / rho_sqrt_R;
-	// :149-152 star-region total pressure
-	double ptot_star_L = ptot_L - u_L.rho * siui_L * (spds[2] - sL.u);
-	double ptot_star_R = ptot_R - u_R.rho * siui_R * (spds[2] - sR.u);
-	double ptot_star = 0.5 * (ptot_star_L + ptot_star_R);
-	// :154-174 left star state
-	u_star_L.mx = u_star_L.rho * spds[2];
-	if (fabs(u_L.rho * siui_L * sism_L - bx_sq) < (DELTA)*ptot_star) {
-		u_star_L.my = u_star_L.rho * sL.v;
-		u_star_L.mz = u_star_L.rho * sL.w;
-		u_star_L.by = u_L.by;
-		u_star_L.bz = u_L.bz;
-	} else {
-		double tmp = bx * (siui_L - sism_L) / (u_L.rho * siui_L * sism_L - bx_sq);
-		u_star_L.my = u_star_L.rho * (sL.v - u_L.by * tmp);
-		u_star_L.mz = u_star_L.rho * (sL.w - u_L.bz * tmp);
-		tmp = (u_L.rho * SQUARE(siui_L) - bx_sq) / (u_L.rho * siui_L * sism_L - bx_sq);
-		u_star_L.by = u_L.by * tmp;
-		u_star_L.bz = u_L.bz * tmp;
+	const double ke = 0.5 * s.rho * (s.u * s.u + (s.v * s.v + s.w * s.w));
+	k.U[0] = s.rho;
+	k.U[1] = s.u * s.rho;
+	k.U[2] = s.v * s.rho;
+	k.U[3] = s.w * s.rho;
+	k.U[4] = ke + s.P / (gamma - 1.0);
+	k.f[0] = k.U[1];
+	k.f[1] = k.U[1] * s.u + s.P;
+	k.f[2] = k.U[2] * s.u;
+	k.f[3] = k.U[3] * s.u;
+	k.f[4] = s.u * (k.U[4] + s.P);
+}
+// f_K + S_K (U*_K - U_K): the flux on the K side of the contact
+QK_DEV void hlldStarFlux(HState const &s, HlldSide const &k, double S_K, double S_M, double rhoStar, double invSM, double pStar, double F[NVAR])
+{
+	double Ustar[5];
+	Ustar[0] = rhoStar;
+	Ustar[1] = rhoStar * S_M;
+	Ustar[2] = rhoStar * s.v;
+	Ustar[3] = rhoStar * s.w;
+	Ustar[4] = (k.a * k.U[4] - s.P * s.u + pStar * S_M) * invSM;
+#pragma unroll
+	for (int n = 0; n < 5; ++n) {
+		F[n] = k.f[n] + S_K * (Ustar[n] - k.U[n]);
 	}
-	double vb_star_L = (u_star_L.mx * bx + (u_star_L.my * u_star_L.by + u_star_L.mz * u_star_L.bz)) * u_star_rho_inv_L;
-	u_star_L.E = (siui_L * u_L.E - ptot_L * sL.u + ptot_star * spds[2] + bx * (sL.u * bx + (sL.v * u_L.by + sL.w * u_L.bz) - vb_star_L)) * sism_inv_L;
-	// :176-196 right star state
-	u_star_R.mx = u_star_R.rho * spds[2];
-	if (fabs(u_R.rho * siui_R * sism_R - bx_sq) < (DELTA)*ptot_star) {
-		u_star_R.my = u_star_R.rho * sR.v;
-		u_star_R.mz = u_star_R.rho * sR.w;
-		u_star_R.by = u_R.by;
-		u_star_R.bz = u_R.bz;
-	} else {
-		double tmp = bx * (siui_R - sism_R) / (u_R.rho * siui_R * sism_R - bx_sq);
-		u_star_R.my = u_star_R.rho * (sR.v - u_R.by * tmp);
-		u_star_R.mz = u_star_R.rho * (sR.w - u_R.bz * tmp);
-		tmp = (u_R.rho * SQUARE(siui_R) - bx_sq) / (u_R.rho * siui_R * sism_R - bx_sq);
-		u_star_R.by = u_R.by * tmp;
-		u_star_R.bz = u_R.bz * tmp;
-	}
-	double vb_star_R = (u_star_R.mx * bx + (u_star_R.my * u_star_R.by + u_star_R.mz * u_star_R.bz)) * u_star_rho_inv_R;
-	u_star_R.E = (siui_R * u_R.E - ptot_R * sR.u + ptot_star * spds[2] + bx * (sR.u * bx + (sR.v * u_R.by + sR.w * u_R.bz) - vb_star_R)) * sism_inv_R;
-	// :198-237 double-star states
-	if (0.5 * bx_sq < (DELTA)*ptot_star) {
-		u_dstar_L = u_star_L;
-		u_dstar_R = u_star_R;
-	} else {
-		double rho_sum_inv = 1.0 / (rho_sqrt_L + rho_sqrt_R);
-		double bx_sign = (bx > 0.0 ? 1.0 : -1.0);
-		u_dstar_L.rho = u_star_L.rho;
-		u_dstar_R.rho = u_star_R.rho;
-		u_dstar_L.mx = u_star_L.mx;
-		u_dstar_R.mx = u_star_R.mx;
-		double tmp = rho_sum_inv * (rho_sqrt_L * (u_star_L.my * u_star_rho_inv_L) + rho_sqrt_R * (u_star_R.my * u_star_rho_inv_R) +
-					    bx_sign * (u_star_R.by - u_star_L.by));
-		u_dstar_L.my = u_dstar_L.rho * tmp;
-		u_dstar_R.my = u_dstar_R.rho * tmp;
-		tmp = rho_sum_inv *
-		      (rho_sqrt_L * (u_star_L.mz * u_star_rho_inv_L) + rho_sqrt_R * (u_star_R.mz * u_star_rho_inv_R) + bx_sign * (u_star_R.bz - u_star_L.bz));
-		u_dstar_L.mz = u_dstar_L.rho * tmp;
-		u_dstar_R.mz = u_dstar_R.rho * tmp;
-		tmp = rho_sum_inv * (rho_sqrt_L * u_star_R.by + rho_sqrt_R * u_star_L.by +
-				     bx_sign * rho_sqrt_L * rho_sqrt_R * ((u_star_R.my * u_star_rho_inv_R) - (u_star_L.my * u_star_rho_inv_L)));
-		u_dstar_L.by = tmp;
-		u_dstar_R.by = tmp;
-		tmp = rho_sum_inv * (rho_sqrt_L * u_star_R.bz + rho_sqrt_R * u_star_L.bz +
-				     bx_sign * rho_sqrt_L * rho_sqrt_R * ((u_star_R.mz * u_star_rho_inv_R) - (u_star_L.mz * u_star_rho_inv_L)));
-		u_dstar_L.bz = tmp;
-		u_dstar_R.bz = tmp;
-		tmp = spds[2] * bx + (u_dstar_L.my * u_dstar_L.by + u_dstar_L.mz * u_dstar_L.bz) / u_dstar_L.rho;
-		u_dstar_L.E = u_star_L.E - rho_sqrt_L * bx_sign * (vb_star_L - tmp);
-		u_dstar_R.E = u_star_R.E + rho_sqrt_R * bx_sign * (vb_star_R - tmp);
-	}
-	// :241-271 flux increments across the waves (the states are overwritten by them)
-	auto jump = [](double s, ConsHydro1D const &a, ConsHydro1D const &b) {
-		return ConsHydro1D{s * (a.rho - b.rho), s * (a.mx - b.mx), s * (a.my - b.my), s * (a.mz - b.mz), s * (a.E - b.E), s * (a.by - b.by), s * (a.bz - b.bz)};
-	};
-	u_dstar_L = jump(spds[1], u_dstar_L, u_star_L);
-	u_star_L = jump(spds[0], u_star_L, u_L);
-	u_dstar_R = jump(spds[3], u_dstar_R, u_star_R);
-	u_star_R = jump(spds[4], u_star_R, u_R);
-	// :273-329 the flux at the interface
-	auto add2 = [](ConsHydro1D const &a, ConsHydro1D const &b) {
-		return ConsHydro1D{a.rho + b.rho, a.mx + b.mx, a.my + b.my, a.mz + b.mz, a.E + b.E, a.by + b.by, a.bz + b.bz};
-	};
-	auto add3 = [](ConsHydro1D const &a, ConsHydro1D const &b, ConsHydro1D const &c) {
-		return ConsHydro1D{a.rho + b.rho + c.rho, a.mx + b.mx + c.mx, a.my + b.my + c.my, a.mz + b.mz + c.mz, a.E + b.E + c.E, a.by + b.by + c.by, a.bz + b.bz + c.bz};
-	};
-	if (spds[0] >= 0.0) {
-		f_x = f_L;
-	} else if (spds[4] <= 0.0) {
-		f_x = f_R;
-	} else if (spds[1] >= 0.0) {
-		f_x = add2(f_L, u_star_L);
-	} else if (spds[2] >= 0.0) {
-		f_x = add3(f_L, u_star_L, u_dstar_L);
-	} else if (spds[3] > 0.0) {
-		f_x = add3(f_R, u_star_R, u_dstar_R);
-	} else {
-		f_x = add2(f_R, u_star_R);
-	}
-	F[0] = f_x.rho;
-	F[1] = f_x.mx;
-	F[2] = f_x.my;
-	F[3] = f_x.mz;
-	F[4] = f_x.E;
+}
+QK_DEV void hlldHydro(HState const &sL, HState const &sR, const double gamma, double F[NVAR])
+{
+	HlldSide L, R;
+	hlldSide(gamma, sL, L);
+	hlldSide(gamma, sR, R);
+	const double cL = hlldFastSpeed(gamma, sL), cR = hlldFastSpeed(gamma, sR);
+	const double S_L = smin(sL.u - cL, sR.u - cR);
+	const double S_R = smax(sL.u + cL, sR.u + cR);
+	L.a = S_L - sL.u;
+	R.a = S_R - sR.u;
+	const double S_M = (R.a * R.U[1] - L.a * L.U[1] + (sL.P - sR.P)) / (R.a * R.U[0] - L.a * L.U[0]);
+	const double invL = 1.0 / (S_L - S_M), invR = 1.0 / (S_R - S_M);
+	const double rhoStarL = L.U[0] * L.a * invL, rhoStarR = R.U[0] * R.a * invR;
+	const double pStar = 0.5 * ((sL.P - L.U[0] * L.a * (S_M - sL.u)) + (sR.P - R.U[0] * R.a * (S_M - sR.u)));
 	F[5] = 0.0;
+	if (S_L >= 0.0) {
+#pragma unroll
+		for (int n = 0; n < 5; ++n) {
+			F[n] = L.f[n];
+		}
+	} else if (S_R <= 0.0) {
+#pragma unroll
+		for (int n = 0; n < 5; ++n) {
+			F[n] = R.f[n];
+		}
+	} else if (S_M >= 0.0) {
+		hlldStarFlux(sL, L, S_L, S_M, rhoStarL, invL, pStar, F);
+		if (!(rhoStarL > 0.0)) { // the left Alfven speed S_M - 0 / sqrt(rho*_L) is not a number: every component of the reference's sum is NaN
+#pragma unroll
+			for (int n = 0; n < 5; ++n) {
+				F[n] = __builtin_nan("");
+			}
+		}
+	} else {
+		hlldStarFlux(sR, R, S_R, S_M, rhoStarR, invR, pStar, F);
+	}
 }
 
 // LLF.hpp:16-43
@@ -753,7 +691,7 @@ QK_DEV void faceFlux(Eos const &eos, bool reconstruct_eint, int ndim, const doub
 	if (RIEMANN == QK_RIEMANN_HLLC) {
 		hllc(eos, sL, sR, du, dw, Fc, RL, RR, GL, GR, wv);
 	} else if (RIEMANN == QK_RIEMANN_HLLD) {
-		hlld(sL, sR, eos.gamma, 0.0, 0.0, 0.0, 0.0, 0.0, Fc); // hydro_system.hpp:987-1003, :1047: bx = by = bz = 0 "for testing purposes"
+		hlldHydro(sL, sR, eos.gamma, Fc); // hydro_system.hpp:987-1003, :1047: the reference hands HLLD bx = by = bz = 0
 	} else {
 		llf(sL, sR, Fc, wv);
 	}

@@ -17,6 +17,7 @@
 #include "qk_device.hpp"
 #include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 #include "qk_internal.hpp"
 
@@ -32,7 +33,8 @@ struct SGeom {
 	int64_t off;   // offset of this box in cells (scratch arrays are [array][box][comp][cell])
 	int glo[3];    // lower corner including ghosts
 	int n[3];      // extent including ghosts
-	int64_t ncell; // n0*n1*n2
+	int pitch;     // doubles between consecutive rows (>= n[0]; see rowPitchAligned)
+	int64_t ncell; // pitch*n1*n2
 };
 
 // scratch arrays (in units of "components over total_cells")
@@ -136,6 +138,24 @@ QK_DEV auto planeCell(Eos const &eos, bool re, PlaneRaw const &r) -> PlaneCell
 	return c;
 }
 
+// The flattening coefficient of a cell that IS compressive along the direction (v(+1) < v(-1)); it is 1 elsewhere (hydro_system.hpp:620-622), which
+// the callers decide first — in smooth or expanding flow (all of the ambient medium of a young blast) the whole evaluation, K_S = rho c_s^2 with its
+// square root included, is skipped by every lane of a wave.  Same operations as flatteningChiKS (qk_device.hpp), the three quotients on refined
+// reciprocals (recipOf / divBy: the same bits as `/` for normal-range operands): |dP| / K_S shares 1 / K_S between the directions, the division by
+// beta_max - beta_min is by a constant; (Zmax - Z) / (Zmax - Zmin) is a division by 0.5, exact as a multiplication.
+QK_DEV auto chiCompressive(double Pm2, double Pm1, double Pp1, double Pp2, Recip const &RKS, Recip const &Rbeta) -> double
+{
+	constexpr double beta_max = 0.85;
+	constexpr double Zmax = 0.75;
+	constexpr double Zmin = 0.25;
+	const double dP1 = fabs(Pp1 - Pm1);
+	const double beta_denom = fabs(Pp2 - Pm2);
+	const double beta = (beta_denom != 0) ? divBy(dP1, recipOf(beta_denom)) : 0;
+	const double chi_min = smax0(smin1(divBy(beta_max - beta, Rbeta)));
+	const double Z = divBy(dP1, RKS);
+	return smax(chi_min, smin1((Zmax - Z) / (Zmax - Zmin)));
+}
+
 // Workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2; tiles that are neighbours in y read each other's halo rows.  The
 // linear id is remapped so that every XCD works through one contiguous run of tiles (x fastest, then y, then box / segment): the halo rows
 // of a tile are then found in the L2 of the XCD that just read them for the tile before.
@@ -204,7 +224,8 @@ __global__ void __launch_bounds__(PT_THREADS, 4) k_pre3(const qk_box *boxes, con
 	const bool rimY = (h >= 0) && (hy == -1 || hy == PT_Y);
 	const int rx = hx, ry = hy;
 
-	double Pz[5] = {1., 1., 1., 1., 1.}, vzw[5] = {0., 0., 0., 0., 0.}, ksz[3] = {1., 1., 1.}, chz[3] = {1., 1., 1.};
+	double Pz[5] = {1., 1., 1., 1., 1.}, vzw[5] = {0., 0., 0., 0., 0.}, rhoz[3] = {1., 1., 1.}, chz[3] = {1., 1., 1.};
+	const Recip Rbeta = recipOf(0.85 - 0.75); // beta_max - beta_min (hydro_system.hpp:596-597, :609)
 	double fm[4] = {1., 1., 1., 1.}, fdx[4] = {0., 0., 0., 0.}, fdy[4] = {0., 0., 0., 0.}; // in-plane results of planes k-3 .. k
 	double *Sout = scratch + g.off;
 	// (requesting the next plane's conserved values one plane ahead was measured: +20 registers, spills under the 128-register cap that two
@@ -224,11 +245,11 @@ __global__ void __launch_bounds__(PT_THREADS, 4) k_pre3(const qk_box *boxes, con
 		}
 		Pz[4] = c.P;
 		vzw[4] = c.vz;
-		// rho c_s^2 of the cell: the denominator of the shock-strength ratio, the same for chi_x, chi_y (this plane) and chi_z (two planes on)
-		const double KS = flatteningKS(eos, c.rho, c.P);
-		ksz[0] = ksz[1];
-		ksz[1] = ksz[2];
-		ksz[2] = KS;
+		// (rho c_s^2 of a cell — the denominator of the shock-strength ratio, the same for chi_x, chi_y in this plane and chi_z two planes on — is
+		// evaluated only where a direction is compressive: the z window keeps rho, not K_S)
+		rhoz[0] = rhoz[1];
+		rhoz[1] = rhoz[2];
+		rhoz[2] = c.rho;
 #pragma unroll
 		for (int m = 0; m < 3; ++m) {
 			fm[m] = fm[m + 1];
@@ -254,18 +275,36 @@ __global__ void __launch_bounds__(PT_THREADS, 4) k_pre3(const qk_box *boxes, con
 			}
 			__syncthreads();
 			if (own) {
-				const double *Pr = &s_P[ty + 3][tx + 3];
-				s_cx[ty][tx + 1] = flatteningChiKS(Pr[-2], Pr[-1], Pr[1], Pr[2], KS, s_vx[ty][tx + 1], s_vx[ty][tx + 3]);
-				s_cy[ty + 1][tx] = (ndim >= 2) ? flatteningChiKS(s_P[ty + 1][tx + 3], s_P[ty + 2][tx + 3], s_P[ty + 4][tx + 3], s_P[ty + 5][tx + 3], KS, s_vy[ty + 1][tx], s_vy[ty + 3][tx])
-							     : 1.0;
+				const bool cx = s_vx[ty][tx + 3] < s_vx[ty][tx + 1];
+				const bool cy = (ndim >= 2) && (s_vy[ty + 3][tx] < s_vy[ty + 1][tx]);
+				double chx = 1.0, chy = 1.0;
+				if (cx || cy) {
+					const Recip RKS = recipOf(flatteningKS(eos, c.rho, c.P));
+					if (cx) {
+						const double *Pr = &s_P[ty + 3][tx + 3];
+						chx = chiCompressive(Pr[-2], Pr[-1], Pr[1], Pr[2], RKS, Rbeta);
+					}
+					if (cy) {
+						chy = chiCompressive(s_P[ty + 1][tx + 3], s_P[ty + 2][tx + 3], s_P[ty + 4][tx + 3], s_P[ty + 5][tx + 3], RKS, Rbeta);
+					}
+				}
+				s_cx[ty][tx + 1] = chx;
+				s_cy[ty + 1][tx] = chy;
 			}
 			if (rimX) {
-				const double *Pr = &s_P[ry + 3][rx + 3];
-				s_cx[ry][rx + 1] = flatteningChiKS(Pr[-2], Pr[-1], Pr[1], Pr[2], flatteningKS(eos, hc.rho, hc.P), s_vx[ry][rx + 1], s_vx[ry][rx + 3]);
+				double chx = 1.0;
+				if (s_vx[ry][rx + 3] < s_vx[ry][rx + 1]) {
+					const double *Pr = &s_P[ry + 3][rx + 3];
+					chx = chiCompressive(Pr[-2], Pr[-1], Pr[1], Pr[2], recipOf(flatteningKS(eos, hc.rho, hc.P)), Rbeta);
+				}
+				s_cx[ry][rx + 1] = chx;
 			} else if (rimY) {
-				s_cy[ry + 1][rx] = (ndim >= 2) ? flatteningChiKS(s_P[ry + 1][rx + 3], s_P[ry + 2][rx + 3], s_P[ry + 4][rx + 3], s_P[ry + 5][rx + 3],
-										 flatteningKS(eos, hc.rho, hc.P), s_vy[ry + 1][rx], s_vy[ry + 3][rx])
-							       : 1.0;
+				double chy = 1.0;
+				if ((ndim >= 2) && (s_vy[ry + 3][rx] < s_vy[ry + 1][rx])) {
+					chy = chiCompressive(s_P[ry + 1][rx + 3], s_P[ry + 2][rx + 3], s_P[ry + 4][rx + 3], s_P[ry + 5][rx + 3],
+							     recipOf(flatteningKS(eos, hc.rho, hc.P)), Rbeta);
+				}
+				s_cy[ry + 1][rx] = chy;
 			}
 			__syncthreads();
 			if (own) {
@@ -280,10 +319,13 @@ __global__ void __launch_bounds__(PT_THREADS, 4) k_pre3(const qk_box *boxes, con
 		// z direction: chi_z of plane k-2 from P(k-4, k-3, k-1, k), rho c_s^2 (k-2), v_z(k-3), v_z(k-1)
 		chz[0] = chz[1];
 		chz[1] = chz[2];
-		chz[2] = (ndim == 3) ? flatteningChiKS(Pz[0], Pz[1], Pz[3], Pz[4], ksz[0], vzw[1], vzw[3]) : 1.0;
+		chz[2] = 1.0;
+		if ((ndim == 3) && (vzw[3] < vzw[1])) {
+			chz[2] = chiCompressive(Pz[0], Pz[1], Pz[3], Pz[4], recipOf(flatteningKS(eos, rhoz[0], Pz[2])), Rbeta);
+		}
 		const int ko = k - 3;
 		if (ko >= zfirst && ko <= zlast && ownOut) {
-			const int64_t cc = (oi - g.glo[0]) + static_cast<int64_t>(g.n[0]) * ((oj - g.glo[1]) + static_cast<int64_t>(g.n[1]) * (ko - g.glo[2]));
+			const int64_t cc = (oi - g.glo[0]) + static_cast<int64_t>(g.pitch) * ((oj - g.glo[1]) + static_cast<int64_t>(g.n[1]) * (ko - g.glo[2]));
 			Sout[(S_AUX + 0) * T + cc] = smin(fm[0], smin(smin(chz[0], chz[1]), chz[2]));
 			Sout[(S_AUX + 1) * T + cc] = fdx[0];
 			Sout[(S_AUX + 2) * T + cc] = fdy[0];
@@ -465,9 +507,14 @@ QK_DEV void updateCellFrom(SweepArgs const &a, Eos const &eos, EpiConst const &e
 	if (bad != 0) {
 		atomicAdd(a.redo_count, 1ULL);
 	}
+	// A cell the FIRST pass leaves invalid is recomputed (correction pass or retry): its limits are skipped.  The correction pass is the stage's
+	// last word: with abort_on_fofc_failure = 0 the reference goes on to EnforceLimits + SyncDualEnergy on EVERY cell (QuokkaSimulation.hpp:1180-1192,
+	// :1267-1279) — the density floor is what repairs a cell that is still at rho <= 0 — and SyncDualEnergy aborts where it is not repaired
+	// (hydro_system.hpp:834-836: the error flag here).
+	const bool fix = FOFC || (bad == 0);
 	// EnforceLimits (hydro_system.hpp:702-771) : density floor, then the temperature floors on E and on the auxiliary internal energy
 	double rho_new = U[RHO];
-	if (bad == 0 && U[RHO] < a.densityFloor) {
+	if (fix && U[RHO] < a.densityFloor) {
 #pragma unroll
 		for (int n = NVAR; n < NVAR + NS; ++n) { // hydro_system.hpp:713-722 (as the reference-shaped operator, qk_hydro_EnforceLimits)
 			U[n] = (a.densityFloor == 0.0) ? 0.0 : U[n] * (U[RHO] / a.densityFloor);
@@ -478,7 +525,7 @@ QK_DEV void updateCellFrom(SweepArgs const &a, Eos const &eos, EpiConst const &e
 	const Recip Rn = recipOf(rho_new);
 	const double px = U[MX], py = U[MY], pz = U[MZ];
 	const double vx = divBy(px, Rn), vy = divBy(py, Rn), vz = divBy(pz, Rn);
-	if (bad == 0) {
+	if (fix) {
 		if ((rho_new > 2.2250738585072014e-308) && !eos.isothermal) {
 			const double Ekin = 0.5 * rho_new * (vx * vx + vy * vy + vz * vz);
 			const double Etot = U[ENE];
@@ -491,8 +538,14 @@ QK_DEV void updateCellFrom(SweepArgs const &a, Eos const &eos, EpiConst const &e
 		}
 	}
 	// SyncDualEnergy (:825-849)
-	const double Ekin2 = (px * px + py * py + pz * pz) / (2.0 * rho_new);
-	if (bad == 0 && a.use_dual_energy != 0) {
+	// (a / (2 rho) == 0.5 (a / rho): scaling by two is exact)
+	const double Ekin2 = 0.5 * divBy(px * px + py * py + pz * pz, Rn);
+	if constexpr (FOFC) {
+		if (a.use_dual_energy != 0 && !(rho_new > 0.)) {
+			*a.error_flag = 1; // "density is negative in SyncDualEnergy! abort!!"
+		}
+	}
+	if (fix && a.use_dual_energy != 0 && (!FOFC || rho_new > 0.)) {
 		const double Etot = U[ENE];
 		const double Eint_aux = U[EINT];
 		const double Eint_cons = Etot - Ekin2;
@@ -517,10 +570,10 @@ QK_DEV void updateCellFrom(SweepArgs const &a, Eos const &eos, EpiConst const &e
 			const double thermal_energy = U[ENE] - 0.5 * rho_new * (vx * vx + vy * vy + vz * vz);
 			const double e = (rho_new == 0.0) ? 0.0 : divBy(thermal_energy, Rn);
 			const double P = eos.gm1 * rho_new * e;
-			cs = sqrt(divBy(eos.gamma * P, Rn));
+			cs = sqrtN(divBy(eos.gamma * P, Rn));
 		}
-		sig0 = smax(sig0, cs + sqrt(divBy(2.0 * Ekin2, Rn)));
-		sig1 = smax(sig1, cs + sqrt(vx * vx + vy * vy + vz * vz));
+		sig0 = smax(sig0, cs + sqrtN(divBy(2.0 * Ekin2, Rn)));
+		sig1 = smax(sig1, cs + sqrtN(vx * vx + vy * vy + vz * vz));
 	}
 }
 
@@ -549,15 +602,15 @@ template <int ORDER, int STAGE, int NS, bool CARRY, int NDIM = 3, bool FOFC = fa
 		return; // uniform for the whole workgroup
 	}
 	// flat slab: rows j = lo.y .. hi.y of plane k are contiguous
+	// (flat over the n[0] cells of a row — the pad columns of an aligned row pitch are skipped; the scratch index goes through the pitch)
 	const int64_t rowlen = g.n[0];
-	const int64_t slab0 = rowlen * ((bx.lo[1] - g.glo[1]) + static_cast<int64_t>(g.n[1]) * (k - g.glo[2]));
 	const int64_t slablen = rowlen * (bx.hi[1] - bx.lo[1] + 1);
 	const int64_t f = static_cast<int64_t>(blockIdx.x) * XOUT + t - 3; // flat position inside the slab
 	const bool inside = (f >= 0) && (f < slablen);
-	const int64_t c = slab0 + (inside ? f : 0);
 	const int jj = static_cast<int>((inside ? f : 0) / rowlen);
 	const int i = g.glo[0] + static_cast<int>((inside ? f : 0) - jj * rowlen);
 	const int j = bx.lo[1] + jj;
+	const int64_t c = (i - g.glo[0]) + static_cast<int64_t>(g.pitch) * ((j - g.glo[1]) + static_cast<int64_t>(g.n[1]) * (k - g.glo[2]));
 
 	const double *S = a.scratch + g.off;
 	const int64_t T = a.total_cells;
@@ -774,7 +827,7 @@ __global__ void __launch_bounds__(64 * MARCH_BY) k_sweep_march(SweepArgs a, Eos 
 	const int ot = min(ot_raw, bx.hi[OT]);
 	double sig0 = 0., sig1 = 0.;
 	const int64_t T = a.total_cells;
-	const int64_t st[3] = {1, g.n[0], static_cast<int64_t>(g.n[0]) * g.n[1]};
+	const int64_t st[3] = {1, g.pitch, static_cast<int64_t>(g.pitch) * g.n[1]};
 	const int64_t ms = st[DIR]; // march stride
 	// this segment's cells [lo, hi] of the box's march range; its faces lo .. hi+1 (a face between two segments is evaluated by both:
 	// same value, stage-1 flux read-only in stage 2)
@@ -1070,28 +1123,54 @@ auto marchSegments(const qk_level *lev, int dir, int ot) -> int
 	return static_cast<int>(std::min<int64_t>(std::max<int64_t>(want, 1), std::min(cap, 16)));
 }
 
+// Row pitch of the scratch arrays.  A dense row of a 128-cell box is 136 doubles = 8.5 cache lines and its first valid cell sits 32 bytes into a
+// line: a wave's 512-byte access straddles 5 lines, neighbouring rows and chunks share lines.  With QK_ROW_ALIGN (default 1) rows are 16-double
+// multiples apart and every box starts 12 doubles past a line boundary, so that valid cell 0 of EVERY row of every component begins a 128-byte
+// line: the marching sweeps (which never touch the x ghost cells of the scratch arrays) move whole lines only.  The state arrays get the same
+// layout from the hosts (any stride is legal in a qk_array4); QK_ROW_ALIGN=0 restores dense rows for A/B runs.
+inline auto rowAlign() -> bool
+{
+	static const bool v = [] {
+		const char *e = std::getenv("QK_ROW_ALIGN"); // 0: dense everywhere, 1 (default): state + scratch aligned, 2: state only, 3: scratch only
+		return e == nullptr || std::atoi(e) == 1 || std::atoi(e) == 3;
+	}();
+	return v;
+}
+
+// geometry of the scratch arrays of a level: per box (offset, extents, pitch), total doubles per component
+auto scratchGeom(const qk_level *lev, std::vector<SGeom> &g) -> int64_t
+{
+	g.resize(lev->nboxes);
+	const bool al = rowAlign();
+	int64_t off = 0;
+	for (int b = 0; b < lev->nboxes; ++b) {
+		for (int d = 0; d < 3; ++d) {
+			g[b].glo[d] = lev->boxes[b].lo[d] - NG;
+			g[b].n[d] = lev->boxes[b].hi[d] - lev->boxes[b].lo[d] + 1 + 2 * NG;
+		}
+		g[b].pitch = al ? (g[b].n[0] + 15) / 16 * 16 : g[b].n[0];
+		if (al) {
+			off = (off + 15) / 16 * 16 + (16 - NG); // cell NG of a row (the first valid one) on a line boundary
+		}
+		g[b].off = off;
+		g[b].ncell = static_cast<int64_t>(g[b].pitch) * g[b].n[1] * g[b].n[2];
+		off += g[b].ncell;
+	}
+	return al ? (off + 15) / 16 * 16 : off;
+}
+
 auto buildGeom(qk_level *lev) -> int
 {
 	if (lev->d_sgeom != nullptr) {
 		return QK_OK;
 	}
-	std::vector<SGeom> g(lev->nboxes);
-	int64_t off = 0;
-	for (int b = 0; b < lev->nboxes; ++b) {
-		g[b].off = off;
-		g[b].ncell = 1;
-		for (int d = 0; d < 3; ++d) {
-			g[b].glo[d] = lev->boxes[b].lo[d] - NG;
-			g[b].n[d] = lev->boxes[b].hi[d] - lev->boxes[b].lo[d] + 1 + 2 * NG;
-			g[b].ncell *= g[b].n[d];
-		}
-		off += g[b].ncell;
-	}
+	std::vector<SGeom> g;
+	const int64_t total = scratchGeom(lev, g);
 	void *d = nullptr;
 	QK_HIP_CHECK(lev->ctx, hipMalloc(&d, sizeof(SGeom) * lev->nboxes));
 	QK_HIP_CHECK(lev->ctx, hipMemcpy(d, g.data(), sizeof(SGeom) * lev->nboxes, hipMemcpyHostToDevice));
 	lev->d_sgeom = d;
-	lev->sgeom_total_cells = off;
+	lev->sgeom_total_cells = total;
 	return QK_OK;
 }
 
@@ -1178,14 +1257,8 @@ int64_t qk_hydro_stage_scratch_bytes(qk_level *lev, const qk_hydro_traits *t)
 	if (int rc = checkTraits(lev->ctx, t); rc != QK_OK) {
 		return rc;
 	}
-	int64_t cells = 0;
-	for (int b = 0; b < lev->nboxes; ++b) {
-		int64_t n = 1;
-		for (int d = 0; d < 3; ++d) {
-			n *= lev->boxes[b].hi[d] - lev->boxes[b].lo[d] + 1 + 2 * NG;
-		}
-		cells += n;
-	}
+	std::vector<SGeom> g;
+	const int64_t cells = scratchGeom(lev, g);
 	return cells * scratchComps(t->nscalars) * static_cast<int64_t>(sizeof(double));
 }
 

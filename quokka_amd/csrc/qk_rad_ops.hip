@@ -239,7 +239,7 @@ template <int ORDER> __global__ void __launch_bounds__(RXB) k_rad_flux_x(const q
 	}
 	RA4 U(cons_t[b]);
 	const int t = threadIdx.x;
-	const int64_t rowlen = U.js; // x extent of the array, ghost cells included
+	const int64_t rowlen = cons_t[b].end[0] - cons_t[b].begin[0]; // x extent of the array, ghost cells included (the row PITCH, U.js, may be larger)
 	const int64_t slablen = rowlen * (bx.hi[1] - bx.lo[1] + 1);
 	const int64_t f = static_cast<int64_t>(blockIdx.x) * RXOUT + t - 3; // flat position inside the slab of plane k
 	const bool inside = (f >= 0) && (f < slablen);
@@ -360,7 +360,7 @@ template <int ORDER, bool STORE> __global__ void __launch_bounds__(RXB) k_rad_sw
 	}
 	RA4 U(a.U_in[b]);
 	const int t = threadIdx.x;
-	const int64_t rowlen = U.js;
+	const int64_t rowlen = a.U_in[b].end[0] - a.U_in[b].begin[0]; // cells of a row, ghost cells included (not the row pitch U.js)
 	const int64_t slablen = rowlen * (bx.hi[1] - bx.lo[1] + 1);
 	const int64_t f = static_cast<int64_t>(blockIdx.x) * RXCELLS + t - 3;
 	const bool inside = (f >= 0) && (f < slablen);

@@ -2028,6 +2028,9 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		double const microseconds_per_update = 1.0e6 * elapsedSeconds_ / static_cast<double>(this->cellUpdates_);
 		amrex::Print() << "Performance figure-of-merit: " << microseconds_per_update << " μs/zone-update [" << 1.0 / microseconds_per_update
 			       << " Mupdates/s]\n";
+		// (not in the reference's output: how often the first-order flux correction and the retry loop ran — bench.py's full_run block reads it)
+		amrex::Print() << "qk counters: steps=" << istep[0] << " fofc_stages=" << fofcStages_ << " retries=" << retries_ << " elapsed_s=" << elapsedSeconds_
+			       << " sim_time=" << tNew_[0] << "\n";
 	}
 
 	// ------------------------------------------------------------------ hydro advance (reference src/QuokkaSimulation.hpp:885-1322)

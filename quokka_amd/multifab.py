@@ -6,6 +6,7 @@ the descriptor table handed to the C-ABI is an array of amrex::Array4-compatible
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -109,30 +110,63 @@ class MultiFab:
     One contiguous allocation holds all boxes (288 GB of HBM: size for few, large allocations).
     """
 
-    def __init__(self, level: Level, ncomp: int, nghost: int, facedir: int = -1, dtype=torch.float64, fill: Optional[float] = None):
+    def __init__(self, level: Level, ncomp: int, nghost: int, facedir: int = -1, dtype=torch.float64, fill: Optional[float] = None,
+                 align_rows: Optional[bool] = None):
         self.level, self.ncomp, self.nghost, self.facedir, self.dtype = level, ncomp, nghost, facedir, dtype
         ctx = level.ctx
-        self.shapes, self.begins, offsets, total = [], [], [], 0
+        # Row pitch (cell-centred FP64 arrays; QK_ROW_ALIGN=0 restores dense rows for A/B runs): rows 16-double multiples apart, every fab offset
+        # so that the first VALID cell of every row of every component begins a 128-byte line.  A dense row of a 128-cell box with 4 ghost
+        # cells is 8.5 lines long and starts 32 bytes into a line — the marching sweeps' 512-byte wave accesses then straddle 5 lines and share
+        # lines with neighbouring rows and chunks (csrc/qk_hydro_fused.hip: scratchGeom uses the same layout for the scratch arrays).  Any stride
+        # is legal in a qk_array4 / amrex::Array4.
+        if align_rows is None:
+            align_rows = os.environ.get("QK_ROW_ALIGN", "1") in ("1", "2")  # (2: state arrays only, 3: the library's scratch arrays only)
+        self.aligned = bool(align_rows) and facedir == -1 and dtype == torch.float64
+        self.shapes, self.begins, self.pitches, offsets, total = [], [], [], [], 0
         for lo, hi in level.boxes:
             n = [hi[d] - lo[d] + 1 + (1 if d == facedir else 0) + (2 * nghost if d < level.ndim else 0) for d in range(3)]
+            pitch = (n[0] + 15) // 16 * 16 if self.aligned else n[0]
+            if self.aligned:
+                total = (total + 15) // 16 * 16 + (16 - nghost) % 16
             self.shapes.append((ncomp, n[2], n[1], n[0]))
+            self.pitches.append(pitch)
             self.begins.append([lo[d] - (nghost if d < level.ndim else 0) for d in range(3)])
             offsets.append(total)
-            total += ncomp * n[0] * n[1] * n[2]
+            total += ncomp * pitch * n[1] * n[2]
+        self.offsets = offsets
         self.storage = torch.empty(max(total, 1), dtype=dtype, device=ctx.device)  # (never a NULL pointer, also for a rank without boxes)
         if fill is not None:
             self.storage.fill_(fill)
-        self.fabs: List[torch.Tensor] = [self.storage[o:o + int(np.prod(s))].view(s) for o, s in zip(offsets, self.shapes)]
+        elif self.aligned:
+            self.storage.zero_()  # pad columns are copied along with whole-storage copies: keep them finite
+        self.fabs: List[torch.Tensor] = [
+            torch.as_strided(self.storage, s, (p * s[2] * s[1], p * s[2], p, 1), o) for o, s, p in zip(offsets, self.shapes, self.pitches)]
         tab = np.zeros(max(level.nboxes, 1), dtype=_A4_DTYPE)
-        for b, (fab, shp, beg) in enumerate(zip(self.fabs, self.shapes, self.begins)):
+        for b, (fab, shp, beg, pitch) in enumerate(zip(self.fabs, self.shapes, self.begins, self.pitches)):
             nx, ny, nz = shp[3], shp[2], shp[1]
             tab[b]["p"] = fab.data_ptr()
-            tab[b]["jstride"], tab[b]["kstride"], tab[b]["nstride"] = nx, nx * ny, nx * ny * nz
+            tab[b]["jstride"], tab[b]["kstride"], tab[b]["nstride"] = pitch, pitch * ny, pitch * ny * nz
             tab[b]["begin"] = beg
             tab[b]["end"] = [beg[0] + nx, beg[1] + ny, beg[2] + nz]
             tab[b]["ncomp"] = ncomp
         self.host_table = tab
         self.table = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(ctx.device)
+
+    def comp_span(self, b: int, c0: int, c1: int) -> torch.Tensor:
+        """components [c0, c1) of fab b as ONE contiguous run of the storage (pad columns included): the fast way to copy whole components
+        between MultiFabs of the same shape (a sliced fab of an aligned MultiFab is a strided view: its copy_ is an element-wise gather)"""
+        shp, p = self.shapes[b], self.pitches[b]
+        n = p * shp[2] * shp[1]
+        return self.storage[self.offsets[b] + c0 * n: self.offsets[b] + c1 * n]
+
+    def copy_comps_from(self, other: "MultiFab", c0: int, c1: int):
+        """amrex::MultiFab::Copy(dst, src, c0, c0, c1 - c0, nghost) for two MultiFabs of the same BoxArray, ghost width and layout"""
+        assert self.shapes == other.shapes and self.pitches == other.pitches
+        if c0 == 0 and c1 == self.ncomp == other.ncomp:
+            self.storage.copy_(other.storage)
+            return
+        for b in range(len(self.shapes)):
+            self.comp_span(b, c0, c1).copy_(other.comp_span(b, c0, c1))
 
     @property
     def ptr(self) -> C.c_void_p:
@@ -159,7 +193,7 @@ class MultiFab:
         self.fabs[b].copy_(torch.from_numpy(np.ascontiguousarray(a)).to(self.dtype))
 
     def fab_numpy(self, b: int) -> np.ndarray:
-        return self.fabs[b].cpu().numpy()
+        return self.fabs[b].contiguous().cpu().numpy()
 
     def copy_from(self, other: "MultiFab"):
         self.storage.copy_(other.storage)

@@ -130,9 +130,11 @@ def _vismf_layout(boxes: Sequence[Box], owner: Sequence[int], ncomp: int, nghost
 
 
 def write_vismf(prefix: str, boxes: Sequence[Box], owner: Sequence[int], rank: int, local_fabs: Sequence[np.ndarray], ncomp: int, nghost: int, ndim: int,
-                all_reduce_minmax=None):
+                all_reduce_minmax=None, slice_layout: bool = False):
     """amrex::VisMF::Write.  boxes/owner: the whole level; local_fabs: this rank's fabs ([comp, k, j, i] over the box grown by nghost)
-    in the order of its boxes.  all_reduce_minmax(min_table, max_table) completes the per-fab tables across ranks (None: one rank)."""
+    in the order of its boxes.  all_reduce_minmax(min_table, max_table) completes the per-fab tables across ranks (None: one rank).
+    slice_layout: the header as the reference's own 2-D slice writer prints it (src/io/DiagFramePlane.cpp:517-572, Write2DMFHeader) — identical
+    except for a blank after the closing parenthesis of the box list (:554); tests/test_plotfile_reference_layout.py types that file by hand."""
     layout = _vismf_layout(boxes, owner, ncomp, nghost, ndim)
     mins = np.full((len(boxes), ncomp), np.inf)
     maxs = np.full((len(boxes), ncomp), -np.inf)
@@ -153,7 +155,7 @@ def write_vismf(prefix: str, boxes: Sequence[Box], owner: Sequence[int], rank: i
         return
     with open(prefix + "_H", "w") as f:
         f.write(f"1\n1\n{ncomp}\n{nghost}\n")
-        f.write(_boxarray_str(boxes, ndim) + "\n")
+        f.write(_boxarray_str(boxes, ndim) + (" \n" if slice_layout else "\n"))
         f.write(f"{len(boxes)}\n")
         for name, off, _, _ in layout:
             f.write(f"FabOnDisk: {name} {off}\n")

@@ -168,8 +168,7 @@ class RadhydroSimulation(HydroSimulation):
 
     def swapRadiationState(self):
         # (components are the outermost index of a fab: the radiation block of a box, ghost cells included, is one contiguous run)
-        for b in range(self.lev.nboxes):
-            self.state_old_cc_.fabs[b][RAD0:RAD0 + self.nrad].copy_(self.state_new_cc_.fabs[b][RAD0:RAD0 + self.nrad])
+        self.state_old_cc_.copy_comps_from(self.state_new_cc_, RAD0, RAD0 + self.nrad)
 
     def subcycleRadiationAtLevel(self, time: float, dt_lev_hydro: float) -> bool:
         if self.is_hydro_enabled and not (self.constantDt_ > 0.0):  # reference src/QuokkaSimulation.hpp:1583: radiation-only problems take ONE step
@@ -235,8 +234,7 @@ class RadhydroSimulation(HydroSimulation):
         if self.is_hydro_enabled:
             ok = self.advanceHydroAtLevelWithRetries(self.dt_)
         else:  # QuokkaSimulation.hpp:681-685: copy hydro vars from state_old_cc_ to state_new_cc_
-            for b in range(self.lev.nboxes):
-                self.state_new_cc_.fabs[b][:RAD0].copy_(self.state_old_cc_.fabs[b][:RAD0])
+            self.state_new_cc_.copy_comps_from(self.state_old_cc_, 0, RAD0)
             ok = True
         if ok:
             ok = self.subcycleRadiationAtLevel(time, self.dt_)

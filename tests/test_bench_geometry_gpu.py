@@ -10,36 +10,9 @@ import numpy as np
 import pytest
 
 from oracle.pyoracle import SEDOV
-from quokka_amd.simulation import sedov_problem
+from quokka_amd.simulation import developed_state, sedov_problem
 
 pytestmark = pytest.mark.gpu
-
-
-def developed_state(N, lo, hi, ng=4, R=0.62):
-    """(6, nz, ny, nx) conserved state of the ghosted fab [lo-ng, hi+ng]: a dense shell of radius R (in units of the domain edge) running
-    outwards at Mach ~3 into ambient gas, hot inside, with a 1e-3 random ripple (same numbers for both sides: the array is handed to the
-    oracle and to the GPU).  Ghost values are overwritten by the first ghost fill."""
-    idx = [np.arange(lo[d] - ng, hi[d] + ng + 1) for d in range(3)]
-    k, j, i = np.meshgrid(idx[2], idx[1], idx[0], indexing="ij")
-    x, y, z = ((a + 0.5) / N for a in (i, j, k))
-    r = np.sqrt(x * x + y * y + z * z)
-    w = 2.5 / N
-    shell = np.exp(-((r - R) / w) ** 2)
-    inside = 0.5 * (1.0 - np.tanh((r - R) / w))
-    # the ripple is a function of the GLOBAL cell index, so that every box sees the same field
-    h = (i * 73856093) ^ (j * 19349663) ^ (k * 83492791)
-    ripple = 1.0 + 1.0e-3 * (((h % 2001) - 1000) / 1000.0)
-    rho = (1.0 + 3.0 * shell) * ripple
-    vr = 1.8 * inside * (r / R) + 2.5 * shell
-    rs = np.maximum(r, 1e-12)
-    vx, vy, vz = vr * x / rs, vr * y / rs, vr * z / rs
-    P = 0.05 + 2.0 * inside + 1.0 * shell
-    U = np.zeros((6,) + r.shape)
-    U[0] = rho
-    U[1], U[2], U[3] = rho * vx, rho * vy, rho * vz
-    U[5] = P / 0.4
-    U[4] = U[5] + 0.5 * rho * (vx * vx + vy * vy + vz * vz)
-    return U
 
 
 def gather(boxes, vals, N):

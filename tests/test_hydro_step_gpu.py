@@ -120,6 +120,30 @@ def test_fofc_and_retries_match_oracle(ctx, oracle, fused_fofc):
     assert np.array_equal(gather_oracle(so, N), gather_gpu(sg, N))
 
 
+def test_fused_fofc_pass_floors_cells_it_could_not_repair(ctx):
+    """abort_on_fofc_failure = 0 with a density floor: cells still at rho <= 0 after the first-order flux correction are handed to EnforceLimits
+    and SyncDualEnergy like every other cell (reference src/QuokkaSimulation.hpp:1180-1192, :1267-1279) — the floor is what repairs them.  The
+    fused correction pass must leave the same state as the stage redone on the reference-shaped operators: no non-positive density, same bits."""
+    N, mgs = 16, 8
+    sims = []
+    for fused_fofc in (True, False):
+        sg = sedov_problem(ctx, N, max_grid_size=mgs)
+        sg.fused_fofc = fused_fofc
+        for _ in range(3):
+            assert sg.step()
+        sg.abortOnFofcFailure_ = 0
+        sg.densityFloor_ = 1.0e-3
+        dt = sg.computeTimestepAtLevel() * 40.0  # far over the CFL limit: first-order fluxes cannot keep every cell positive either
+        sg.state_old_cc_, sg.state_new_cc_ = sg.state_new_cc_, sg.state_old_cc_
+        sg.advanceHydroAtLevel(sg.state_old_cc_, dt)  # (returns False: the CFL check fails afterwards, as it would in the reference)
+        assert sg.counters["fofc1_stages"] > 0
+        sims.append(sg)
+    Uf, Uo = gather_gpu(sims[0], N), gather_gpu(sims[1], N)
+    assert np.isfinite(Uo).all() and Uo[0].min() >= 1.0e-3
+    assert (Uo[0] == 1.0e-3).any(), "no cell was floored: the test state does not exercise the branch"
+    assert np.array_equal(Uf, Uo), f"rel L1 {np.abs(Uf - Uo).sum() / np.abs(Uo).sum()}"
+
+
 @pytest.mark.parametrize("fused", [False, True])
 def test_sod_shocktube_full_run_matches_golden(ctx, fused):
     """BASELINE config 1 (1-D Sod, 1024 cells, single box, Dirichlet x-boundaries) run to t = 0.4 with the reference-shaped operators
@@ -133,8 +157,8 @@ def test_sod_shocktube_full_run_matches_golden(ctx, fused):
     gold = np.load(os.path.join(HERE, "golden", "sod_1024_final.npy"))
     assert rel_l1(sol, gold) <= 1e-12
     assert np.array_equal(sol, gold)
-    from test_oracle_known_answers import rel_rms_l1, sod_reference
-    assert rel_rms_l1(sod_reference(), sol) < 0.0021
+    # (the reference's 0.002 criterion belongs to the deck's one-refined-level geometry and is asserted there:
+    # tests/test_reference_problems_gpu.py::test_unmodified_shocktube_problem_meets_the_reference_criterion)
 
 
 def test_sedov_conservation_gpu(ctx):

@@ -50,14 +50,16 @@ def sod_reference(nx=1024):
 
 
 def test_sod_shocktube_vs_exact_solution(oracle):
-    """BASELINE config 1: tests/shocktube.in as a single 1024-cell box (max_level = 0).  The reference's ctest runs
-    the deck with amr.max_level = 1 and passes at 0.002; on the unrefined 1024 grid the same scheme gives 0.00204."""
+    """BASELINE config 1: tests/shocktube.in.  The reference's criterion (relative L1 error <= 0.002) belongs to the geometry its ctest runs — the
+    deck's amr.max_level = 1 — and is asserted THERE, on the GPU, through the unchanged problem file with its own computeReferenceSolution
+    (tests/test_reference_problems_gpu.py::test_unmodified_shocktube_problem_meets_the_reference_criterion).  BASELINE's single 1024-cell box
+    has no criterion in the reference: its error is printed for information (0.00204) and the state is pinned bit for bit by the golden file."""
     s = oracle.sim(SOD, 1, [1024], [0, 0, 0], [5, 1, 1], [0, 1, 1])
     assert s.evolve()
     assert abs(s.time - 0.4) < 1e-12
     err = rel_rms_l1(sod_reference(), s.valid()[:, 0, 0, :])
-    assert err < 0.0021, err
-    # refined twice as fine, the reference's own tolerance holds with margin
+    print(f"Sod, single 1024-cell box (informational): relative L1 error {err:.5f}")
+    # at the resolution the deck's refined level has, the reference's own tolerance holds with margin
     s2 = oracle.sim(SOD, 1, [2048], [0, 0, 0], [5, 1, 1], [0, 1, 1])
     assert s2.evolve()
     err2 = rel_rms_l1(sod_reference(2048), s2.valid()[:, 0, 0, :])
