@@ -224,9 +224,11 @@ typedef struct qk_hydro_stage_args {
 				  * sweep evaluates the face between two of its tiles in both of them, and both need the stage-1 flux intact */
 	int rk2_carry_rhs;	 /* 0: flux_rk2 = 0.5 F1 + 0.5 F2 face by face, as the reference forms it (QuokkaSimulation.hpp:1106, :1220) — bit-identical
 				  *    to the reference-shaped operators;
-				  * 1: the RK2 average is taken on the cell's right-hand side instead: stage 1 stores div F1 and div v1 in `rhs1`,
-				  *    stage 2 updates with 0.5 rhs1 + 0.5 rhs2.  Equal in exact arithmetic, rounded differently (~1e-16 relative per
-				  *    step; within the 1e-12 of the parity contract, tests/test_hydro_step_gpu.py); the face arrays halfFlux /
+				  * 1: the RK2 average is taken on the cell instead of on the faces: stage 1 stores the HALF STEP
+				  *    S = U_old + (dt / 2) rhs_1 (its own right-hand side, P dV term included) and P(U_old) in `rhs1`, stage 2 finishes
+				  *    U_new = S + (dt / 2) rhs_2 with the P dV term on the stored pressure and reads neither U_old nor a second
+				  *    right-hand side (dt must be the same in both stages).  U_old + dt (rhs_1 + rhs_2) / 2 in exact arithmetic, rounded
+				  *    differently (~1e-16 relative per step; within the 1e-12 of the parity contract, tests/test_hydro_step_gpu.py); the face arrays halfFlux /
 				  *    halfVel are neither written nor read (they may be NULL), so flux_rk2 does not exist: excludes store_flux_rk2,
 				  *    and a stage-2 first-order flux correction must recompute F1 from U_old with qk_hydro_ComputeFluxes */
 	qk_array4 *rhs1;	 /* rk2_carry_rhs: cell-centred, no ghost cells, 6 + nscalars + 1 components; must survive from stage 1 to stage 2 */

@@ -160,9 +160,8 @@ class AmrLevelSim(HydroSimulation):
         else:  # amrex::FillPatch time interpolation: ((t1 - t) old + (t - t0) new) / (t1 - t0)
             plan(state, p.state_old_cc_, p.state_new_cc_, (t1 - time) / (t1 - t0), (time - t0) / (t1 - t0), self.ncomp_cc, self.amr.amrInterpMethod_, True)
 
-    def _fill_and_stage(self, stage, U_in, U_old, U_out, dt) -> bool:
+    def _before_fill(self, stage: int, dt: float):
         self._fill_time = self._t_adv + (dt if stage == 2 else 0.0)  # reference src/QuokkaSimulation.hpp:1076, :1204
-        return super()._fill_and_stage(stage, U_in, U_old, U_out, dt)
 
     def advanceHydroAtLevel(self, state_old_tmp: MultiFab, dt_lev: float) -> bool:
         ok = super().advanceHydroAtLevel(state_old_tmp, dt_lev)

@@ -9,8 +9,10 @@
 // Two ways to form the RK2 average (qk_hydro_stage_args::rk2_carry_rhs):
 //   0  the reference's: flux_rk2 = 0.5 F1 + 0.5 F2 face by face — stage 1 stores F1 (7 doubles per face and direction), stage 2 reads
 //      it back; bit-identical to the reference-shaped operators, needed when flux registers or the first-order correction consume flux_rk2;
-//   1  carried right-hand side: stage 1 stores div F1 and div v1 per CELL (7 doubles once instead of 3 x 7), stage 2 averages
-//      0.5 rhs1 + 0.5 rhs2 — the same quantity in exact arithmetic, a different rounding (~1e-16 per step; north_star allows 1e-12).
+//   1  carried half step: stage 1 stores, per CELL, S = U_old + (dt/2) rhs_1 (the right-hand side of stage 1 with its P dV term) and P(U_old)
+//      — 7 doubles once instead of 3 x 7 face values —, stage 2 finishes U_new = S + (dt/2) rhs_2 with the P dV term on the stored pressure:
+//      U_old + dt (rhs_1 + rhs_2) / 2 in exact arithmetic, a different rounding (~1e-16 per step; north_star allows 1e-12).  Stage 2 reads
+//      neither the old state nor a second right-hand side: 29 instead of 35 doubles per cell in its final sweep.
 // Measured characteristics (profiles/round2, round3): the X sweep is FP64-issue bound (~1160 VALU instructions per cell at
 // 5 waves per SIMD), the marching sweeps (228-251 VGPRs, 2 waves per SIMD) move their real HBM traffic at ~5 TB/s.
 // All arithmetic lives in qk_device.hpp, shared with the reference-shaped operators -> identical bits.
@@ -68,7 +70,7 @@ struct SweepArgs {
 	bool same_old; // U_old is U_in (stage 1): the final sweep keeps the conserved state of its last three march positions in LDS instead of re-reading it
 	bool store_rk2; // stage 2: write flux_rk2 = 0.5 F1 + 0.5 F2 to rk2Flux (never over F1: tile-boundary faces of the x sweep are evaluated twice)
 	qk_array4 *rk2Flux;
-	qk_array4 *rhs1; // carried right-hand side (rk2_carry_rhs): per cell div F1 (nv components) + div v1, written by stage 1, read by stage 2
+	qk_array4 *rhs1; // carried half step (rk2_carry_rhs): per cell U_old + (dt/2) rhs_1 (nv components) + P(U_old), written by stage 1, read by stage 2
 	int nseg; // segments along the march axis (marching sweeps; see k_pre_march)
 };
 
@@ -436,12 +438,12 @@ QK_DEV auto epiEint(Eos const &eos, EpiConst const &ec, double rho, double T) ->
 	return divBy(e * rho * eos.kB_user, ec.RkB);
 }
 
-// U holds the old state of the cell on entry
-// CS (carry stage): 0 the reference's flux average (rhs already holds div flux_rk2); 1: stage 1 of the carried-rhs mode, rhs / div_v are
-// stored for stage 2; 2: stage 2, `rhs1` holds what stage 1 stored and the update uses 0.5 rhs1 + 0.5 rhs
+// U holds the old state of the cell on entry (CS == 2: not read — the carried half step replaces it)
+// CS (carry stage): 0 the reference's flux average (rhs already holds div flux_rk2); 1: stage 1 of the carried form — besides its own update the cell
+// stores S = U_old + (dt/2) r_1 and P(U_old) in `a.rhs1`; 2: stage 2 — `half` holds what stage 1 stored and the update is S + (dt/2) r_2
 template <int NS, int CS, bool FOFC = false, int NDIM = 3>
 QK_DEV void updateCellFrom(SweepArgs const &a, Eos const &eos, EpiConst const &ec, int b, int i, int j, int k, double U[NVAR + NS], const double rhs_sweeps[NVAR + NS],
-			   double div_v, const double rhs1[NVAR + NS + 1], double &sig0, double &sig1)
+			   double div_v, const double half[NVAR + NS + 1], double &sig0, double &sig1)
 {
 	WA4 Un(a.U_out[b]);
 	IA4 flag(a.redoFlag[b]);
@@ -455,25 +457,11 @@ QK_DEV void updateCellFrom(SweepArgs const &a, Eos const &eos, EpiConst const &e
 	for (int n = 0; n < NVAR + NS; ++n) {
 		rhs[n] = rhs_sweeps[n];
 	}
-	if (CS == 1) {
-		WA4 R1(a.rhs1[b]);
-		const int64_t c1 = R1.idx(i, j, k);
-#pragma unroll
-		for (int n = 0; n < NVAR + NS; ++n) {
-			R1.p[c1 + R1.ns * n] = rhs[n];
-		}
-		R1.p[c1 + R1.ns * (NVAR + NS)] = div_v;
-	}
-	if (CS == 2) {
-#pragma unroll
-		for (int n = 0; n < NVAR + NS; ++n) {
-			rhs[n] = 0.5 * rhs1[n] + 0.5 * rhs[n];
-		}
-		div_v = 0.5 * rhs1[NVAR + NS] + 0.5 * div_v;
-	}
 	// hydro_system.hpp:797-812 (redoFlag == none branch): P(U_old) = ComputePressure(cons)
 	double Pgas;
-	{
+	if (CS == 2) {
+		Pgas = half[NVAR + NS];
+	} else {
 		const double rho = U[RHO];
 		if (eos.isothermal) {
 			Pgas = rho * eos.cs_iso * eos.cs_iso;
@@ -491,14 +479,32 @@ QK_DEV void updateCellFrom(SweepArgs const &a, Eos const &eos, EpiConst const &e
 		r[n] = rhs[n];
 	}
 	r[EINT] += -Pgas * div_v;
-	// hydro_system.hpp:487-495
+	if (CS == 1) {
+		WA4 R1(a.rhs1[b]);
+		const int64_t c1 = R1.idx(i, j, k);
+		const double hdt = 0.5 * a.dt;
 #pragma unroll
-	for (int n = 0; n < NVAR; ++n) {
-		U[n] = U[n] + a.dt * r[n];
+		for (int n = 0; n < NVAR + NS; ++n) {
+			R1.p[c1 + R1.ns * n] = U[n] + hdt * ((n < NVAR) ? r[n] : rhs[n]);
+		}
+		R1.p[c1 + R1.ns * (NVAR + NS)] = Pgas;
 	}
+	if (CS == 2) {
+		const double hdt = 0.5 * a.dt;
 #pragma unroll
-	for (int n = NVAR; n < NVAR + NS; ++n) { // passive scalars: PredictStep loops over all hydro variables
-		U[n] = U[n] + a.dt * rhs[n];
+		for (int n = 0; n < NVAR + NS; ++n) {
+			U[n] = half[n] + hdt * ((n < NVAR) ? r[n] : rhs[n]);
+		}
+	} else {
+		// hydro_system.hpp:487-495
+#pragma unroll
+		for (int n = 0; n < NVAR; ++n) {
+			U[n] = U[n] + a.dt * r[n];
+		}
+#pragma unroll
+		for (int n = NVAR; n < NVAR + NS; ++n) { // passive scalars: PredictStep loops over all hydro variables
+			U[n] = U[n] + a.dt * rhs[n];
+		}
 	}
 	const int bad = (U[RHO] > 0.) ? 0 : 1;
 	if constexpr (!FOFC) {
@@ -926,7 +932,7 @@ __global__ void __launch_bounds__(64 * MARCH_BY) k_sweep_march(SweepArgs a, Eos 
 			for (int n = 0; n < NV + 1; ++n) {
 				rhs_in[n] = S[(S_RHS + n) * T + cu];
 			}
-			if (LAST && !ring) { // the old state of the cell this step completes
+			if (LAST && !ring && !(CARRY && STAGE == 2)) { // the old state of the cell this step completes (stage 2 of the carried form: S replaces it)
 				int uc[3];
 				uc[0] = i;
 				uc[OT] = ot;
@@ -937,7 +943,7 @@ __global__ void __launch_bounds__(64 * MARCH_BY) k_sweep_march(SweepArgs a, Eos 
 					Uo[n] = Uold.p[co + Uold.ns * n];
 				}
 			}
-			if (CARRY && LAST && STAGE == 2) { // what stage 1 stored for this cell (F1[] is free in this mode)
+			if (CARRY && LAST && STAGE == 2) { // the half step and the pressure stage 1 stored for this cell (F1[] is free in this mode)
 				RA4 R1(a.rhs1[b]);
 				int uc[3];
 				uc[0] = i;

@@ -14,6 +14,7 @@
 #define QK_HOST_QUOKKA_HOST_HPP_
 
 #include <chrono>
+#include <cstring>
 #include <functional>
 #include <limits>
 #include <memory>
@@ -2073,11 +2074,21 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		invalidateSignal();
 		// first half of the Strang-split source terms, on the (temporary) old state (reference src/QuokkaSimulation.hpp:1048)
 		addStrangSplitSources(state_old_cc_tmp, 0, time, 0.5 * dt_lev);
-		fillTime_ = time; // reference src/QuokkaSimulation.hpp:1076 (stage 1), :1204 (stage 2: time + dt_lev)
-		if (!fillAndStage(1, state_old_cc_tmp, state_old_cc_tmp, state_inter_cc_, dt_lev)) {
-			return false;
+		int pair = -1;
+		if constexpr (fusedEligible()) {
+			if (integratorOrder_ == 2 && speculateStage2_ != 0) {
+				pair = stagePairSpeculative(state_old_cc_tmp, time, dt_lev);
+				if (pair == 0) {
+					return false;
+				}
+			}
 		}
-		if (integratorOrder_ == 2) {
+		fillTime_ = time; // reference src/QuokkaSimulation.hpp:1076 (stage 1), :1204 (stage 2: time + dt_lev)
+		if (pair == 1) {
+			// (both stages done)
+		} else if (!fillAndStage(1, state_old_cc_tmp, state_old_cc_tmp, state_inter_cc_, dt_lev)) {
+			return false;
+		} else if (integratorOrder_ == 2) {
 			fillTime_ = time + dt_lev;
 			if (!fillAndStage(2, state_inter_cc_, state_old_cc_tmp, state_new_cc_[0], dt_lev)) {
 				return false;
@@ -2085,11 +2096,14 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		} else {
 			amrex::MultiFab::Copy(state_new_cc_[0], state_inter_cc_);
 		}
-		int err = 0;
-		QK_HOST_HIP(hipMemcpy(&err, d_error_, sizeof(int), hipMemcpyDeviceToHost));
-		err = qkhost::Comm::get().allReduceMax(err);
-		if (err != 0) {
-			amrex::Abort("density is negative in SyncDualEnergy! abort!!");
+		if (unfusedRan_) { // (a fused stage reports its error flag with its redo count: fusedEnd)
+			unfusedRan_ = false;
+			int err = 0;
+			QK_HOST_HIP(hipMemcpy(&err, d_error_, sizeof(int), hipMemcpyDeviceToHost));
+			err = qkhost::Comm::get().allReduceMax(err);
+			if (err != 0) {
+				amrex::Abort("density is negative in SyncDualEnergy! abort!!");
+			}
 		}
 		bool const ok = !isCflViolated(dt_lev);
 		if (ok) { // second half, on the new state (:1318)
@@ -2275,9 +2289,19 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	std::array<amrex::MultiFab, AMREX_SPACEDIM> halfFlux_, halfVel_, flux_, vel_, FOflux_, FOvel_, rk2flux_, rk2vel_, leftState_, rightState_;
 	amrex::iMultiFab redoFlag_;
 	qk_ghost_plan *flagPlan_ = nullptr;
-	int64_t *d_count_ = nullptr;
+	// The words a fused stage reports in — [max signal, max signal for dt] (double), [redo count] (int64), [error flag of SyncDualEnergy] (int) —
+	// in TWO slots of one allocation: an RK2 step enqueues both stages before it reads either (stage 1 reports in slot 0, stage 2 in slot 1:
+	// one device -> host copy and one host synchronisation per step instead of four); everything else uses slot 0.
+	int64_t *d_words_ = nullptr;
+	int64_t *d_count_ = nullptr; // = slot 0
 	int *d_error_ = nullptr;
 	double *d_signal_ = nullptr;
+	struct StageWords {
+		double sig[2];
+		int64_t count;
+		int64_t err;
+	};
+	int speculateStage2_ = 1; // deck: qk.speculate_stage2 (0: the stages are read back one by one; tests)
 	void *scratch_ = nullptr;
 	int64_t scratchBytes_ = 0;
 	double signal_[2] = {0, 0};
@@ -2337,10 +2361,15 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 			QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_radCounter_), 4 * sizeof(int)));
 			QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_radFailure_), 3 * sizeof(int)));
 		}
-		QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_count_), sizeof(int64_t)));
-		QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_error_), sizeof(int)));
-		QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_signal_), 2 * sizeof(double)));
-		QK_HOST_HIP(hipMemsetAsync(d_error_, 0, sizeof(int), nullptr));
+		QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_words_), 8 * sizeof(int64_t)));
+		QK_HOST_HIP(hipMemsetAsync(d_words_, 0, 8 * sizeof(int64_t), nullptr));
+		d_signal_ = reinterpret_cast<double *>(d_words_);
+		d_count_ = d_words_ + 2;
+		d_error_ = reinterpret_cast<int *>(d_words_ + 3);
+		{
+			amrex::ParmParse pq("qk");
+			pq.query("speculate_stage2", speculateStage2_);
+		}
 		auto t = qkhost::traits<problem_t>();
 		if constexpr (HydroSystem<problem_t>::nscalars_ <= 3 && Physics_Traits<problem_t>::numMassScalars == 0 && Physics_Traits<problem_t>::is_hydro_enabled) {
 			scratchBytes_ = qk_hydro_stage_scratch_bytes(qkhost::Runtime::get().lev, &t);
@@ -2436,8 +2465,10 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	}
 
 	// one RK stage exactly as the reference (src/QuokkaSimulation.hpp:1099-1198 / 1202-1287), reference-shaped operators
+	bool unfusedRan_ = false; // the reference-shaped operators ran in the current advance: SyncDualEnergy leaves its flag in d_error_
 	auto stageUnfused(int stageNo, amrex::MultiFab const &U_in, amrex::MultiFab const &U_old, amrex::MultiFab &U_out, double dt) -> bool
 	{
+		unfusedRan_ = true;
 		auto *lev = qkhost::Runtime::get().lev;
 		computeHydroFluxes(U_in);
 		auto *fl = &flux_;
@@ -2561,16 +2592,40 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		return static_cast<D *>(it->second);
 	}
 
-	void fusedBegin(int stageNo)
+	void fusedBegin(int stageNo, bool bothSlots = false)
 	{
 		hipStream_t const cs = qkhost::Runtime::get().computeStream();
-		QK_HOST_HIP(hipMemsetAsync(d_count_, 0, sizeof(int64_t), cs));
-		if (isFinalStage(stageNo)) {
-			QK_HOST_HIP(hipMemsetAsync(d_signal_, 0, 2 * sizeof(double), cs));
+		(void)stageNo;
+		// (sig0, sig1, count of slot 0 — or of both slots; the error flags are sticky: a set flag ends the run)
+		QK_HOST_HIP(hipMemsetAsync(d_words_, 0, 3 * sizeof(int64_t), cs));
+		if (bothSlots) {
+			QK_HOST_HIP(hipMemsetAsync(d_words_ + 4, 0, 3 * sizeof(int64_t), cs));
+		}
+	}
+	// both slots in ONE blocking device -> host copy; with several ranks ONE all-reduce(MAX) (a count is only ever compared with zero)
+	void readWords(StageWords w[2])
+	{
+		int64_t h[8];
+		QK_HOST_HIP(hipMemcpy(h, d_words_, sizeof(h), hipMemcpyDeviceToHost));
+		double v[8];
+		for (int sl = 0; sl < 2; ++sl) {
+			std::memcpy(&v[4 * sl], &h[4 * sl], 2 * sizeof(double));
+			v[4 * sl + 2] = static_cast<double>(h[4 * sl + 2]);
+			v[4 * sl + 3] = static_cast<double>(h[4 * sl + 3] & 0xFFFFFFFFLL);
+		}
+		if (qkhost::Comm::get().size > 1) {
+			qkhost::Comm::get().allReduce(v, 8, qkhost::Comm::Op::max);
+		}
+		for (int sl = 0; sl < 2; ++sl) {
+			w[sl].sig[0] = v[4 * sl];
+			w[sl].sig[1] = v[4 * sl + 1];
+			w[sl].count = static_cast<int64_t>(v[4 * sl + 2]);
+			w[sl].err = static_cast<int64_t>(v[4 * sl + 3]);
 		}
 	}
 	// one fused stage over all local boxes (group < 0) or over one group of the overlapped fill
-	void fusedLaunch(int stageNo, amrex::MultiFab const &U_in, amrex::MultiFab const &U_old, amrex::MultiFab &U_out, double dt, int group = -1, bool fofc = false)
+	void fusedLaunch(int stageNo, amrex::MultiFab const &U_in, amrex::MultiFab const &U_old, amrex::MultiFab &U_out, double dt, int group = -1, bool fofc = false,
+			 int slot = 0)
 	{
 		auto t = qkhost::traits<problem_t>();
 		auto sel = [&](qk_array4 *full) { return group < 0 ? full : groupTable(group, full); };
@@ -2584,10 +2639,10 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 			a.dx[d] = (d < AMREX_SPACEDIM) ? geom[0].dx[d] : 1.0;
 		}
 		a.redoFlag = group < 0 ? qkhost::itab(redoFlag_) : groupTable(group, qkhost::itab(redoFlag_));
-		a.d_redo_count = d_count_;
-		a.d_error_flag = d_error_;
+		a.d_redo_count = d_words_ + 4 * slot + 2;
+		a.d_error_flag = reinterpret_cast<int *>(d_words_ + 4 * slot + 3);
 		if (isFinalStage(stageNo)) {
-			a.d_max_signal = d_signal_;
+			a.d_max_signal = reinterpret_cast<double *>(d_words_ + 4 * slot);
 		}
 		a.scratch = scratch_;
 		a.scratch_bytes = scratchBytes_;
@@ -2614,14 +2669,22 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 			      "qk_hydro_stage_fused");
 	}
 	// flagged cells of the stage (all ranks); after a clean final stage the two CFL maxima are kept for computeTimestep / isCflViolated
-	auto fusedEnd(int stageNo) -> int64_t
+	auto fusedEnd(int stageNo, StageWords const *given = nullptr) -> int64_t
 	{
-		int64_t const nbad = readCount();
+		StageWords w[2];
+		if (given == nullptr) {
+			readWords(w);
+			given = &w[0];
+		}
+		if (given->err != 0) {
+			amrex::Abort("density is negative in SyncDualEnergy! abort!!");
+		}
+		int64_t const nbad = given->count;
 		if (nbad == 0) {
 			stage1LeftF1_ = (stageNo == 1) ? !carryActive() : stage1LeftF1_;
 			if (isFinalStage(stageNo)) {
-				QK_HOST_HIP(hipMemcpy(signal_, d_signal_, 2 * sizeof(double), hipMemcpyDeviceToHost));
-				qkhost::Comm::get().allReduce(signal_, 2, qkhost::Comm::Op::max);
+				signal_[0] = given->sig[0];
+				signal_[1] = given->sig[1];
 				haveSignal_ = true;
 			}
 		}
@@ -2685,8 +2748,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		if constexpr (fusedEligible()) {
 			if (overlapActive()) {
 				fusedBegin(stageNo);
-				this->fillBoundaryConditions(U_in, [&]() { fusedLaunch(stageNo, U_in, U_old, U_out, dt, 0); });
-				fusedLaunch(stageNo, U_in, U_old, U_out, dt, 1);
+				launchStage(stageNo, U_in, U_old, U_out, dt, 0);
 				if (fusedEnd(stageNo) == 0) {
 					return true;
 				}
@@ -2695,6 +2757,37 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		}
 		this->fillBoundaryConditions(U_in);
 		return stage(stageNo, U_in, U_old, U_out, dt);
+	}
+	// fillBoundaryConditions(U_in) + the fused launches of one stage (early / late groups where boxes wait for other ranks), nothing read back
+	void launchStage(int stageNo, amrex::MultiFab &U_in, amrex::MultiFab const &U_old, amrex::MultiFab &U_out, double dt, int slot)
+	{
+		if (overlapActive()) {
+			this->fillBoundaryConditions(U_in, [&]() { fusedLaunch(stageNo, U_in, U_old, U_out, dt, 0, false, slot); });
+			fusedLaunch(stageNo, U_in, U_old, U_out, dt, 1, false, slot);
+			return;
+		}
+		this->fillBoundaryConditions(U_in);
+		fusedLaunch(stageNo, U_in, U_old, U_out, dt, -1, false, slot);
+	}
+	// Both stages of an RK2 step enqueued before either redo count is read: the GPU does not idle through device -> host round trips between the
+	// stages.  Stage 2 is speculative — if stage 1 flagged cells (rare) its work is discarded and the caller redoes the stages in order; the old
+	// state is untouched by either stage, so the result is the same.  Returns 1: both stages done, 0: the step failed, -1: redo in order.
+	auto stagePairSpeculative(amrex::MultiFab &U_old, double time, double dt) -> int
+	{
+		fusedBegin(1, true);
+		fillTime_ = time;
+		launchStage(1, U_old, U_old, state_inter_cc_, dt, 0);
+		fillTime_ = time + dt;
+		launchStage(2, state_inter_cc_, U_old, state_new_cc_[0], dt, 1);
+		StageWords w[2];
+		readWords(w);
+		if (fusedEnd(1, &w[0]) != 0) {
+			return -1;
+		}
+		if (fusedEnd(2, &w[1]) == 0) {
+			return 1;
+		}
+		return correctStage(2, state_inter_cc_, U_old, state_new_cc_[0], dt) ? 1 : 0;
 	}
 	int rk2CarryRhs_ = 0;	   // deck: hydro.rk2_carry_rhs
 	int fusedFofc_ = 1;	   // deck: qk.fused_fofc (0: a flagged stage is redone on the reference-shaped operators; tests)

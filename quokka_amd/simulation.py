@@ -144,6 +144,7 @@ class GhostExchange:
                     vals = vals["values"]
                 for n, v in enumerate(vals):
                     f.values[n] = v
+        self.exposed_events = None  # a list: fill() records (before, after) events around the wait for the peers' strips
         self.peers = []
         for k in range(L.qk_ghost_plan_num_peers(h)):
             r, ns, nr = C.c_int(), C.c_int64(), C.c_int64()
@@ -191,7 +192,16 @@ class GhostExchange:
                 physbc(capi.BOXES_LOCAL_ONLY)
             between()
         if pending is not None:
-            pending.wait()
+            if self.exposed_events is not None:
+                # how long the compute stream stalls for the strips: an event behind the work enqueued so far (the early boxes' stage),
+                # one behind the wait — bench.py's ghost_exchange block
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                pending.wait()
+                e1.record()
+                self.exposed_events.append((e0, e1))
+            else:
+                pending.wait()
         for k, r, sbuf, rbuf in self.peers:
             unpack(k, rbuf)
         if before_physbc is not None:  # AMR: coarse -> fine interpolation of the ghost cells no fine box covers (FillPatchTwoLevels)
@@ -303,7 +313,10 @@ class HydroSimulation:
         self.redoFlag = MultiFab(lev, 1, 1, dtype=torch.int32, fill=0)
         # the words a fused stage reports in — [max signal, max signal for dt] (double), [redo count] (int64) and the error flag of SyncDualEnergy
         # (int32 in the fourth word) — share one allocation: one fill before the stage, one device -> host copy after it
-        self._dev_words = torch.zeros(4, dtype=torch.int64, device=ctx.device)
+        # Two such slots: an RK2 step enqueues BOTH stages before it reads either (stage 1 reports in slot 0, stage 2 in slot 1 — one host
+        # synchronisation per step instead of two, `speculate_stage2`); everything else uses slot 0.
+        self._dev_words = torch.zeros(8, dtype=torch.int64, device=ctx.device)
+        self.speculate_stage2 = True
         self.dev_counters = self._dev_words[2:3]  # [redo_count]
         self.dev_error = self._dev_words[3:4].view(torch.int32)[0:1]
         self._err_latched = False   # an error flag seen by a fused stage of the current advance (the words are cleared before every stage)
@@ -550,14 +563,15 @@ class HydroSimulation:
     def _is_final(self, stage: int) -> bool:
         return (stage == 2) or (self.integratorOrder_ == 1)
 
-    def _fused_begin(self, stage: int):
+    def _fused_begin(self, stage: int, slot: int = 0, both: bool = False):
         if self._unfused_ran and not self._err_latched:  # (rare: an operator-path stage of this advance may have raised the flag)
             self._err_latched = int(self.dev_error.item()) != 0
-        self._dev_words.zero_()  # (the signal words are only handed to the final stage; clearing them before stage 1 is harmless)
+        # (the signal words are only handed to the final stage; clearing them before stage 1 is harmless)
+        (self._dev_words if both else self._dev_words[4 * slot:4 * slot + 4]).zero_()
 
-    def _fused_launch(self, stage: int, U_in, U_old, U_out, dt, group=None, fofc: bool = False):
+    def _fused_launch(self, stage: int, U_in, U_old, U_out, dt, group=None, fofc: bool = False, slot: int = 0):
         """one fused stage over all local boxes (group None) or over a sub-level (Level, [local box indices]); fofc: the first-order flux
-        correction pass of a stage whose first pass flagged cells (qk_hydro_stage_args::fofc_pass)"""
+        correction pass of a stage whose first pass flagged cells (qk_hydro_stage_args::fofc_pass); slot: the device words it reports in"""
         lev, idx = (self.lev, None) if group is None else group
         tab = (lambda mf: mf.ptr) if idx is None else (lambda mf: mf.subset_ptr(idx))
         a = capi.StageArgs()
@@ -568,10 +582,11 @@ class HydroSimulation:
             a.halfVel[d] = tab(self.halfVel[d]) if d < nd else None
             a.dx[d] = self.geom.dx[d] if d < nd else 1.0
         a.redoFlag = tab(self.redoFlag)
-        a.d_redo_count = C.c_void_p(self.dev_counters.data_ptr())
-        a.d_error_flag = C.c_void_p(self.dev_error.data_ptr())
+        w = self._dev_words.data_ptr() + 32 * slot
+        a.d_redo_count = C.c_void_p(w + 16)
+        a.d_error_flag = C.c_void_p(w + 24)
         if self._is_final(stage):
-            a.d_max_signal = C.c_void_p(self.dev_signal.data_ptr())
+            a.d_max_signal = C.c_void_p(w)
         a.scratch = C.c_void_p(self.scratch.data_ptr())
         a.scratch_bytes = self.scratch.numel() * 8
         a.dt, a.stage, a.reconstruction_order = dt, stage, self.reconstructionOrder_
@@ -587,30 +602,30 @@ class HydroSimulation:
         c = self.ctx
         c.check(c.L.qk_hydro_stage_fused(lev.h, c.stream(), C.byref(self.traits), C.byref(a)), "qk_hydro_stage_fused")
 
-    def _fused_end(self, stage: int) -> int:
-        """redo count of the stage (only ever compared with 0) and, after the final stage, the two CFL maxima: ONE
-        device->host copy, and with several ranks ONE all-reduce(MAX) of [sig0, sig1, count] instead of the three scalar
-        collectives of the reference (dt, CFL check, redo count)"""
-        final = self._is_final(stage)
+    def _read_words(self):
+        """both slots of device words in ONE device->host copy (several ranks: ONE all-reduce(MAX) instead of the three scalar collectives of
+        the reference — dt, CFL check, redo count): per slot [sig0, sig1, redo count, error flag]"""
         if self.nranks > 1:
             import torch.distributed as dist
             from . import comm
-            v = torch.cat([self.dev_signal, self._dev_words[2:4].to(torch.float64)])  # [sig0, sig1, redo count, error flag]
+            w = self._dev_words.view(2, 4)
+            v = torch.cat([w[:, 0:2].reshape(-1).view(torch.float64).view(2, 2), w[:, 2:3].to(torch.float64),
+                           (w[:, 3:4] & 0xFFFFFFFF).to(torch.float64)], dim=1).reshape(-1)
             comm.all_reduce(v, dist.ReduceOp.MAX)
             vals = v.tolist()
-        else:  # one copy of the four words, no conversion kernels
-            h = self._dev_words.cpu()
-            vals = h[0:2].view(torch.float64).tolist() + [float(int(h[2])), float(int(h[3]) & 0xFFFFFFFF)]
+            return [vals[0:4], vals[4:8]]
+        h = self._dev_words.cpu()  # one copy of the eight words, no conversion kernels
+        return [h[4 * s:4 * s + 2].view(torch.float64).tolist() + [float(int(h[4 * s + 2])), float(int(h[4 * s + 3]) & 0xFFFFFFFF)] for s in (0, 1)]
+
+    def _fused_end(self, stage: int, slot: int = 0, vals=None) -> int:
+        """redo count of the stage (only ever compared with 0) and, after the final stage, the two CFL maxima"""
+        final = self._is_final(stage)
+        vals = (self._read_words() if vals is None else vals)[slot]
         self._err_latched = self._err_latched or vals[3] != 0.0
         nbad = int(vals[2])
         if final and nbad == 0:
             self._signal_of_state_new = (vals[0], vals[1])  # global maxima
         return nbad
-
-    def _stage_fused(self, stage: int, U_in, U_old, U_out, dt) -> int:
-        self._fused_begin(stage)
-        self._fused_launch(stage, U_in, U_old, U_out, dt)
-        return self._fused_end(stage)
 
     def overlap_groups(self):
         """(early, late) sub-levels for the overlapped ghost fill: boxes whose ghost cells are all filled on this GPU /
@@ -630,30 +645,45 @@ class HydroSimulation:
             self._groups_key = key
         return self._groups
 
-    def _fill_and_stage(self, stage, U_in, U_old, U_out, dt) -> bool:
-        """fillBoundaryConditions(U_in) + one RK stage.  With more than one rank the boxes that need nothing from other
-        ranks are advanced while the strips of the others are on the wire (north_star: FillBoundary overlapped with the
+    def _before_fill(self, stage: int, dt: float):
+        """hook: a refined level sets the time its coarse-fine ghost cells are interpolated to"""
+
+    def _launch_stage(self, stage, U_in, U_old, U_out, dt, slot: int = 0):
+        """fillBoundaryConditions(U_in) + the fused launches of one RK stage, nothing read back.  With more than one rank the boxes that need
+        nothing from other ranks are advanced while the strips of the others are on the wire (north_star: FillBoundary overlapped with the
         update on a second stream — RCCL's); the reference's fill is blocking (src/QuokkaSimulation.hpp:1099, :1202)."""
-        groups = self.overlap_groups() if self.use_fused else None
+        self._before_fill(stage, dt)
+        groups = self.overlap_groups()
         if groups is None:
             self.fillBoundaryConditions(U_in)
-            return self._stage(stage, U_in, U_old, U_out, dt)
+            self._fused_launch(stage, U_in, U_old, U_out, dt, slot=slot)
+            return
         early, late = groups
-        self._fused_begin(stage)
-        self.ghost.fill(U_in, between=lambda: self._fused_launch(stage, U_in, U_old, U_out, dt, early))
-        self._fused_launch(stage, U_in, U_old, U_out, dt, late)
-        if self._fused_end(stage) == 0:
+        self.ghost.fill(U_in, between=lambda: self._fused_launch(stage, U_in, U_old, U_out, dt, early, slot=slot))
+        self._fused_launch(stage, U_in, U_old, U_out, dt, late, slot=slot)
+
+    def _finish_stage(self, stage, U_in, U_old, U_out, dt, nbad: int) -> bool:
+        if nbad == 0:
             self._stage1_left_F1 = (stage == 1 and not self._carry_active())
             return True
         return self._correct_stage(stage, U_in, U_old, U_out, dt)
 
+    def _fill_and_stage(self, stage, U_in, U_old, U_out, dt) -> bool:
+        """fillBoundaryConditions(U_in) + one RK stage, its redo count read back"""
+        if not self.use_fused:
+            self._before_fill(stage, dt)
+            self.fillBoundaryConditions(U_in)
+            return self._redo_stage_unfused(stage, U_in, U_old, U_out, dt)
+        self._fused_begin(stage)
+        self._launch_stage(stage, U_in, U_old, U_out, dt)
+        return self._finish_stage(stage, U_in, U_old, U_out, dt, self._fused_end(stage))
+
     def _stage(self, stage, U_in, U_old, U_out, dt) -> bool:
+        """one RK stage on a state whose ghost cells are filled"""
         if self.use_fused:
-            nbad = self._stage_fused(stage, U_in, U_old, U_out, dt)
-            if nbad == 0:
-                self._stage1_left_F1 = (stage == 1 and not self._carry_active())
-                return True
-            return self._correct_stage(stage, U_in, U_old, U_out, dt)
+            self._fused_begin(stage)
+            self._fused_launch(stage, U_in, U_old, U_out, dt)
+            return self._finish_stage(stage, U_in, U_old, U_out, dt, self._fused_end(stage))
         return self._redo_stage_unfused(stage, U_in, U_old, U_out, dt)
 
     def _correct_stage(self, stage, U_in, U_old, U_out, dt) -> bool:
@@ -694,9 +724,28 @@ class HydroSimulation:
     def advanceHydroAtLevel(self, state_old_tmp: MultiFab, dt_lev: float) -> bool:
         self._signal_of_state_new = None  # state_new_cc_ is about to be overwritten
         self._err_latched, self._unfused_ran = False, False
-        if not self._fill_and_stage(1, state_old_tmp, state_old_tmp, self.state_inter_cc_, dt_lev):
+        pair_done = False
+        if self.use_fused and self.integratorOrder_ == 2 and self.speculate_stage2:
+            # Both stages are enqueued before either redo count is read: the GPU does not idle through a device -> host round trip between the
+            # stages.  Stage 2 is speculative — if stage 1 flagged cells (rare: strong shocks at too large a step) its work is discarded
+            # and the stages are redone in order below; the old state is untouched by either stage, so the result is the same.
+            inter, new = self.state_inter_cc_, self.state_new_cc_
+            self._fused_begin(1, both=True)
+            self._launch_stage(1, state_old_tmp, state_old_tmp, inter, dt_lev, slot=0)
+            self._launch_stage(2, inter, state_old_tmp, new, dt_lev, slot=1)
+            vals = self._read_words()
+            if self._fused_end(1, 0, vals) == 0:
+                self._stage1_left_F1 = not self._carry_active()
+                if not self._finish_stage(2, inter, state_old_tmp, new, dt_lev, self._fused_end(2, 1, vals)):
+                    return False
+                pair_done = True
+            else:
+                self._err_latched = False  # (whatever stage 2 reported belongs to the discarded attempt)
+        if pair_done:
+            pass
+        elif not self._fill_and_stage(1, state_old_tmp, state_old_tmp, self.state_inter_cc_, dt_lev):
             return False
-        if self.integratorOrder_ == 2:
+        elif self.integratorOrder_ == 2:
             if not self._fill_and_stage(2, self.state_inter_cc_, state_old_tmp, self.state_new_cc_, dt_lev):
                 return False
         else:
