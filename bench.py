@@ -431,9 +431,11 @@ def compact(block, keep=("value", "unit", "steps", "warmup", "ms_per_step", "con
 
 
 # ---------------------------------------------------------------------------------------------------------------- N > 1 self-test
-def selftest(ctx, torch, dist, rank, world, carry):
+def selftest(ctx, torch, dist, rank, world, carry, inline=False):
     """the first thing to run on a multi-GPU lease: does the RCCL path (strip pack -> P2P send / recv -> unpack, early / late schedule, fused
-    all-reduce of dt and counters) reproduce the one-rank state bit for bit?  A hang becomes a FAIL line after `limit` seconds."""
+    all-reduce of dt and counters) reproduce the one-rank state bit for bit?  A hang becomes a FAIL line after `limit` seconds.
+    inline: called by the N > 1 bench run before its timed region — the verdict goes into the bench line (`selftest`) instead of on its own
+    line, and the process group stays up."""
     import hashlib
     import signal
     from quokka_amd.simulation import sedov_problem
@@ -479,10 +481,12 @@ def selftest(ctx, torch, dist, rank, world, carry):
                    "workload": f"3D Sedov {n_cell[0]}x{n_cell[1]}x{n_cell[2]}, {mgs}^3 boxes, {steps} steps, rk2_mode {'carry' if carry else 'exact'}",
                    "boxes": len(want), "boxes_differing_from_one_rank": len(bad), "first_differing_boxes": bad[:4], "dt_equal_on_all_ranks": dt_ok,
                    "peers_rank0": len(sim.ghost.peers), "early_late_boxes_rank0": None if groups is None else [len(groups[0][1]), len(groups[1][1])]}
-        print(json.dumps(verdict), flush=True)
+        if not inline:
+            print(json.dumps(verdict), flush=True)
     signal.alarm(0)
     dist.barrier()
-    dist.destroy_process_group()
+    if not inline:
+        dist.destroy_process_group()
     return verdict
 
 
@@ -507,6 +511,8 @@ def run_sedov(ctx, torch, dist, rank, world, ncell, mgs, steps, warmup, profile=
     if profile:
         L.qk_profile_reset(ctx.h)
         L.qk_profile_enable(ctx.h, 1)
+    if world > 1:
+        sim.ghost.exposed_events = []  # (two event records per fill: how long the compute stream stalls for the peers' strips)
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -516,9 +522,18 @@ def run_sedov(ctx, torch, dist, rank, world, ncell, mgs, steps, warmup, profile=
     if profile:
         L.qk_profile_enable(ctx.h, 0)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        from quokka_amd import comm
+        ev = sim.ghost.exposed_events
+        sim.ghost.exposed_events = None
+        exposed = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
+        sent = float(sum(sbuf.numel() * sbuf.element_size() for _, _, sbuf, _ in sim.ghost.peers))
+        t = torch.tensor([elapsed, exposed, sent], dtype=torch.float64, device=ctx.device)
+        comm.all_reduce(t, dist.ReduceOp.MAX)
+        elapsed = float(t[0].item())
+        sim.exchange_stats = {"fills_timed": len(ev), "exposed_ms_per_fill_max_over_ranks": float(t[1].item()), "exposed_ms_per_fill_rank0": exposed,
+                              "bytes_sent_per_fill_max_over_ranks": float(t[2].item()), "bytes_sent_per_fill_rank0": sent,
+                              "note": "exposed = time the compute stream waits for the peers' strips after the boxes that need nothing remote were "
+                                      "advanced (HIP events around the wait); bytes = packed ghost strips one rank sends per fill, all components"}
     kernels = {}
     if profile:  # per-kernel HIP-event durations recorded on the launch stream during the timed region
         for k in range(L.qk_profile_num_kernels(ctx.h)):
@@ -572,10 +587,10 @@ def main():
     # QK_BENCH_ONE_GPU_TEST=1 (tests/test_multirank_one_gpu.py only): all ranks share cuda:0 and talk over gloo with host-staged buffers
     # (quokka_amd/comm.py) — RCCL refuses two ranks on one device.  Never a measurement: refused unless --selftest.
     share = os.environ.get("QK_BENCH_ONE_GPU_TEST") == "1"
-    if share:
-        if not args.selftest:
-            raise SystemExit("QK_BENCH_ONE_GPU_TEST is for --selftest only")
+    if share:  # never a measurement: --selftest, or a DRY RUN of the N > 1 line on a small problem (marked `dry_run` in the line)
         local_rank = 0
+        if not args.selftest and args.ncell is None:
+            args.ncell, args.max_grid_size = 64, 32
     if torch.cuda.device_count() < (local_rank + 1):
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPUs are visible (one rank per GPU)")
     torch.cuda.set_device(local_rank)
@@ -598,6 +613,10 @@ def main():
         v = selftest(ctx, torch, dist, rank, world, carry=(args.rk2_mode == "carry"))
         sys.exit(0 if (rank != 0 or v["selftest"] == "PASS") else 1)
     ncell = args.ncell if args.ncell is not None else (256 if world == 1 else 512)
+    selftest_verdict = None
+    if world > 1 and args.workload == "sedov":
+        # the exchange path proves itself before it is timed: N ranks against one rank, bit for bit (a hang becomes a FAIL line, see selftest)
+        selftest_verdict = selftest(ctx, torch, dist, rank, world, carry=(args.rk2_mode == "carry"), inline=True)
     if args.workload == "shell_amr":
         import numpy as np
         from quokka_amd.amr_simulation import shell_amr_problem
@@ -656,8 +675,9 @@ def main():
         "config": {"workload": f"3D Sedov blast {n_cell[0]}x{n_cell[1]}x{n_cell[2]} unigrid (tests/blast_unigrid_256.in scaled to {ncell}^3 cells per GPU), "
                                f"{mgs}^3 boxes, PPM+HLLC RK2, gamma=1.4, CFL 0.3, reflecting octant",
                    "cells_per_gpu": ncell ** 3, "boxes_per_gpu": sim.lev.nboxes, "parallelism": f"box-decomposition x{world}",
-                   "ghost_exchange": None if world == 1 else {"backend": dist.get_backend(), "peers_rank0": len(sim.ghost.peers),
-                                                              "overlap_early_late_boxes_rank0": None if groups is None else [len(groups[0][1]), len(groups[1][1])]},
+                   "ghost_exchange": None if world == 1 else dict({"backend": dist.get_backend(), "peers_rank0": len(sim.ghost.peers),
+                                                                   "overlap_early_late_boxes_rank0": None if groups is None else [len(groups[0][1]), len(groups[1][1])]},
+                                                                  **getattr(sim, "exchange_stats", {})),
                    "rk2_mode": args.rk2_mode,
                    "fofc_stages": sim.counters["fofc1_stages"] + sim.counters["fofc2_stages"], "retries": sim.counters["retries"],
                    "sim_time": sim.tNew_,
@@ -667,6 +687,10 @@ def main():
         # context only (other hardware, reference implementation): paper/performance_a100.csv:2 = 254.05 Mzones/s on 1x A100
         "reference_published_a100_1gpu": 254.05,
     }
+    if world > 1:
+        out["selftest"] = selftest_verdict  # (rank 0's; None on the other ranks, which do not print)
+    if share:
+        out["dry_run"] = f"{world} ranks share cuda:0 and talk over gloo with host-staged buffers: the SHAPE of the N > 1 line on a small problem, never a measurement"
     del sim
     torch.cuda.empty_cache()
     if not args.no_secondary:
@@ -710,11 +734,17 @@ def main():
             # (e) BASELINE config 5 geometry at its full size on the one GPU: blast_amr_maxlev2.in, 256^3 base grid + 2 levels
             out["amr_maxlev2"] = compact(run_amr(ctx, torch, dist, rank, world, 256, 50, 5))
             torch.cuda.empty_cache()
-        elif world > 1 and ncell != 256:
-            sW, nW, elW, _ = run_sedov(ctx, torch, dist, rank, world, 256, mgs, args.steps, args.warmup, profile=False, carry=(args.rk2_mode == "carry"))
-            out["weak_256_per_gpu"] = {"value": nW[0] * nW[1] * nW[2] * args.steps / elW / 1e6, "unit": "Mcell-updates/s", "ms_per_step": elW / args.steps * 1e3,
-                                       "workload": f"{nW[0]}x{nW[1]}x{nW[2]}, 8 boxes of 128^3 per GPU"}
-            del sW
+        elif world > 1:
+            if ncell not in (256, 64):
+                sW, nW, elW, _ = run_sedov(ctx, torch, dist, rank, world, 256, mgs, args.steps, args.warmup, profile=False, carry=(args.rk2_mode == "carry"))
+                out["weak_256_per_gpu"] = {"value": nW[0] * nW[1] * nW[2] * args.steps / elW / 1e6, "unit": "Mcell-updates/s", "ms_per_step": elW / args.steps * 1e3,
+                                           "workload": f"{nW[0]}x{nW[1]}x{nW[2]}, 8 boxes of 128^3 per GPU"}
+                del sW
+                torch.cuda.empty_cache()
+            # BASELINE config 5 on the same ranks: blast_amr_maxlev2.in, the SAME hierarchy on N GPUs (strong scaling)
+            blk = run_amr(ctx, torch, dist, rank, world, 64 if share else 256, 4 if share else 30, 1 if share else 5)
+            out["amr_maxlev2"] = compact(blk, keep=("value", "unit", "steps", "warmup", "ms_per_step", "scaling", "config"))
+            torch.cuda.empty_cache()
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_ncell, args.cpu_steps)

@@ -90,7 +90,11 @@ QK_DEV auto sarr(SweepArgs const &a, int comp) -> double * { return a.scratch + 
 //     planes in a register FIFO until the z window has caught up with them.
 // Halo cells are converted by the threads left over after every thread converted its own cell (900 conversions per 462 outputs and
 // plane); their loads hit L2 (the neighbouring tiles read the same rows), so HBM sees each conserved value about once.
-constexpr int PT_X = 66, PT_Y = 7, PT_THREADS = 512; // 2 x-tiles cover the 130 columns of a 128-cell box + rim
+#ifndef QK_PT_Y
+#define QK_PT_Y 7
+#define QK_PT_THREADS 512
+#endif
+constexpr int PT_X = 66, PT_Y = QK_PT_Y, PT_THREADS = QK_PT_THREADS; // 2 x-tiles cover the 130 columns of a 128-cell box + rim
 constexpr int PT_OWN = PT_X * PT_Y;		     // 462 threads own a column
 constexpr int PT_HALO_Y = 6 * PT_X;		     // rows -3..-1 and PT_Y..PT_Y+2
 constexpr int PT_HALO = PT_HALO_Y + 6 * PT_Y;	     // + columns -3..-1 and PT_X..PT_X+2 of the tile's rows

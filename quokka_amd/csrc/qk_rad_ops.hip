@@ -624,7 +624,9 @@ template <int ORDER, int STAGE, bool STORE> void launchRadSweeps(qk_level *lev, 
 	{
 		// written in place (stage 2 of the drivers: U_new is U_in), a pencil is one thread's: the cells behind its march are the only ones it
 		// has overwritten.  Otherwise strips, for more waves in flight.
-		const int strip = (a.U_new == a.U_in) ? lev->maxlen[2] : 32;
+		// (Aliasing cannot be seen from the table POINTERS alone — two tables may describe the same storage, e.g. a sub-level's gathered
+		// descriptors — so stage 2, the stage the drivers run in place, always marches whole pencils; stage 1 does when the tables are the same.)
+		const int strip = (STAGE == 2 || a.U_new == a.U_in) ? lev->maxlen[2] : 32;
 		const int notb = (lev->maxlen[1] + 3) / 4;
 		const int nstrips = (lev->maxlen[2] + strip - 1) / strip;
 		const dim3 grid((lev->maxlen[0] + 63) / 64, notb * nstrips, lev->nboxes);

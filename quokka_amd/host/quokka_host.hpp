@@ -2531,7 +2531,8 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	[[nodiscard]] auto isFinalStage(int stageNo) const -> bool { return (stageNo == 2) || (integratorOrder_ == 1); }
 	// the carried-right-hand-side form of the RK2 average (qk_hydro_stage_args::rk2_carry_rhs; deck: hydro.rk2_carry_rhs = 1, default 0): only
 	// where nothing consumes flux_rk2 (no flux registers) and the integrator has two stages
-	[[nodiscard]] auto carryActive() const -> bool { return AMREX_SPACEDIM == 3 && rk2CarryRhs_ != 0 && integratorOrder_ == 2 && !storeFluxRk2_; }
+	[[nodiscard]] auto carryActive() const -> bool { return AMREX_SPACEDIM == 3 && rk2CarryRhs_ != 0 && integratorOrder_ == 2 && !storeFluxRk2_ && !forceExactForm_; }
+	bool forceExactForm_ = false; // (set while stage 2 of the carried form is redone in the exact form: correctStage)
 
 	// Boxes of this rank in two groups for the overlapped ghost fill: [0] early — every ghost cell is filled on this GPU —, [1] late — waits
 	// for strips from other ranks (qk_ghost_plan_box_is_remote).  Each group is a sub-level whose descriptor tables alias the level's arrays.
@@ -2716,9 +2717,30 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		if (stageNo == 1) {
 			stage1LeftF1_ = !carryActive();
 		}
-		bool const applies = fusedFofc_ != 0 && artificialViscosityK_ == 0.0 && !(carryActive() && stageNo == 2) && !(integratorOrder_ == 1 && storeFluxRk2_);
+		bool const applies = fusedFofc_ != 0 && artificialViscosityK_ == 0.0 && !(integratorOrder_ == 1 && storeFluxRk2_);
 		if (!applies) {
 			return redoStageUnfused(stageNo, U_in, U_old, U_out, dt);
+		}
+		if (carryActive() && stageNo == 2) {
+			// The correction replaces flux_rk2 = 0.5 F1 + 0.5 F2 of a face as a whole, and the carried form never stored F1: the stage is redone in
+			// the reference's form, still on the fused kernels — the stage-1 sweeps once more over the old state (ghost cells still filled) to
+			// leave F1 in halfFlux_ (the state they write is discarded), stage 2 in the exact form, then its correction pass.
+			++fofcStages_;
+			forceExactForm_ = true;
+			fusedBegin(1);
+			fusedLaunch(1, U_old, U_old, U_out, dt);
+			stage1LeftF1_ = true;
+			fusedBegin(2);
+			fusedLaunch(2, U_in, U_old, U_out, dt);
+			int64_t nbad = fusedEnd(2);
+			if (nbad > 0) {
+				fillFlagGhosts();
+				fusedBegin(2);
+				fusedLaunch(2, U_in, U_old, U_out, dt, -1, true);
+				nbad = fusedEnd(2);
+			}
+			forceExactForm_ = false;
+			return !(nbad > 0 && abortOnFofcFailure_ != 0);
 		}
 		++fofcStages_;
 		fillFlagGhosts();

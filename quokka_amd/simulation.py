@@ -552,7 +552,7 @@ class HydroSimulation:
         """the carried-right-hand-side form of the RK2 average (qk_hydro_stage_args::rk2_carry_rhs; `rk2_carry_rhs` attribute, default off):
         only where nothing consumes flux_rk2 (no flux registers) and the integrator has two stages"""
         return (bool(getattr(self, "rk2_carry_rhs", False)) and self.integratorOrder_ == 2 and not getattr(self, "store_flux_rk2", False)
-                and self.geom.ndim == 3)
+                and self.geom.ndim == 3 and not getattr(self, "_force_exact_form", False))
 
     def rhs1(self):
         """div F1 and div v1 per cell, written by stage 1 and read by stage 2 in the carried-rhs mode"""
@@ -700,14 +700,40 @@ class HydroSimulation:
         pass left it, ghost cells exchanged — selects the faces that take the first-order flux of the old state and the cells that take the
         cell-centred velocity divergence; the pass counts what is still invalid.  Returns None where the pass does not apply (artificial
         viscosity, stage 2 of the carried-rhs form, forward Euler feeding flux registers): the caller redoes the stage on the operators."""
-        if (not getattr(self, "fused_fofc", True) or float(self.artificialViscosityK_) != 0.0 or (self._carry_active() and stage == 2)
+        if (not getattr(self, "fused_fofc", True) or float(self.artificialViscosityK_) != 0.0
                 or (self.integratorOrder_ == 1 and getattr(self, "store_flux_rk2", False))):
             return None
+        if self._carry_active() and stage == 2:
+            return self._fofc_stage2_of_carried_form(U_in, U_old, U_out, dt)
         self.counters["fofc1_stages" if stage == 1 else "fofc2_stages"] += 1
         self._fill_flag_ghosts()
         self._fused_begin(stage)
         self._fused_launch(stage, U_in, U_old, U_out, dt, fofc=True)
         nbad = self._fused_end(stage)
+        return not (nbad > 0 and self.abortOnFofcFailure_ != 0)
+
+    def _fofc_stage2_of_carried_form(self, U_in, U_old, U_out, dt) -> bool:
+        """Stage 2 of the carried form flagged cells.  The correction replaces flux_rk2 = 0.5 F1 + 0.5 F2 of a face as a whole, and the carried form
+        never stored F1: the stage is redone in the reference's form, still on the fused kernels — (1) the stage-1 sweeps once more over the old
+        state (its ghost cells are still filled) just to leave F1 in halfFlux, the state they write is discarded; (2) stage 2 in the exact form
+        (first pass: the flags); (3) its correction pass.  Twelve fused launches where round 3 redid the stage on ~60 reference-shaped operators.
+        The result is the exact form's (what the oracle computes): within rounding of what the carried form would have given."""
+        self.counters["fofc2_stages"] += 1
+        self._force_exact_form = True
+        try:
+            self._fused_begin(1)
+            self._fused_launch(1, U_old, U_old, U_out, dt)  # (U_out is overwritten by stage 2 below; stage 1 was clean, so was this pass)
+            self._stage1_left_F1 = True
+            self._fused_begin(2)
+            self._fused_launch(2, U_in, U_old, U_out, dt)
+            nbad = self._fused_end(2)
+            if nbad > 0:
+                self._fill_flag_ghosts()
+                self._fused_begin(2)
+                self._fused_launch(2, U_in, U_old, U_out, dt, fofc=True)
+                nbad = self._fused_end(2)
+        finally:
+            self._force_exact_form = False
         return not (nbad > 0 and self.abortOnFofcFailure_ != 0)
 
     def _redo_stage_unfused(self, stage, U_in, U_old, U_out, dt) -> bool:

@@ -486,8 +486,10 @@ def test_carried_rhs_mode_stays_within_the_parity_tolerance(ctx, oracle, mgs):
 
 
 def test_carried_rhs_mode_with_first_order_flux_correction(ctx, oracle):
-    """the carried mode when the fused stages flag cells: the stage is redone on the reference-shaped operators, which need F1 in halfFlux —
-    never stored in this mode, recomputed from the old state.  Same over-CFL step as test_fofc_and_retries_match_oracle."""
+    """the carried mode when the fused stages flag cells: stage 1 takes the fused correction pass; stage 2 — whose correction replaces
+    flux_rk2 = 0.5 F1 + 0.5 F2 of a face as a whole, with F1 never stored in this mode — is redone in the exact form on the FUSED kernels (F1
+    from one more run of the stage-1 sweeps over the old state).  No reference-shaped operator runs.  Same over-CFL step as
+    test_fofc_and_retries_match_oracle."""
     N, mgs = 16, 8
     so = oracle.sim(SEDOV, 3, [N] * 3, [0, 0, 0], [1.2] * 3, [0, 0, 0], max_grid_size=[mgs] * 3)
     sg = sedov_problem(ctx, N, max_grid_size=mgs)
@@ -496,9 +498,13 @@ def test_carried_rhs_mode_with_first_order_flux_correction(ctx, oracle):
         assert so.step() and sg.step()
     dt = so.compute_dt() * 6.0
     assert so.advance_fixed_dt(dt)
+    def no_operators(*a, **k):
+        raise AssertionError("a stage fell back to the reference-shaped operators")
+    sg._redo_stage_unfused = no_operators
     assert sg.step(dt)
     co = so.counters()
     assert sg.counters["retries"] == co["retries"] and sg.counters["fofc1_stages"] > 0 and sg.counters["fofc2_stages"] > 0
+    assert sg._unfused_tmp is None  # (the operator path's temporaries were never even allocated)
     assert rel_l1(gather_gpu(sg, N), gather_oracle(so, N)) <= 1e-12
 
 

@@ -269,3 +269,25 @@ def test_bench_selftest_passes_on_ranks_sharing_the_gpu(world):
     v = json.loads(lines[0])
     assert v["selftest"] == "PASS" and v["n_gpus"] == world and v["boxes_differing_from_one_rank"] == 0 and v["dt_equal_on_all_ranks"], v
     assert v["boxes"] == 8 * world and v["early_late_boxes_rank0"] is not None, v
+
+
+def test_bench_multi_gpu_line_dry_run_with_eight_ranks():
+    """`python bench.py --gpus 8` as the driver launches it on an 8-GPU node, DRY: the eight ranks share this GPU over gloo on a small blast
+    (QK_BENCH_ONE_GPU_TEST; marked `dry_run` in the line).  The complete line shape: the self-test verdict first (N ranks == one rank, bit for
+    bit), the ghost_exchange block (bytes per fill, exposed milliseconds, peers), config 5 (amr_maxlev2, strong scaling) on the same ranks."""
+    import json
+    import subprocess
+    world = 8
+    env = dict(os.environ, QK_BENCH_ONE_GPU_TEST="1", OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert p.returncode == 0 and len(lines) == 1, p.stdout[-1500:] + p.stderr[-2500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["steps"] == 3 and d["scaling"] == "weak" and "dry_run" in d
+    assert d["selftest"]["selftest"] == "PASS" and d["selftest"]["boxes_differing_from_one_rank"] == 0, d["selftest"]
+    g = d["config"]["ghost_exchange"]
+    assert g["peers_rank0"] >= 3 and g["bytes_sent_per_fill_rank0"] > 0 and g["fills_timed"] == 2 * 3 and g["exposed_ms_per_fill_max_over_ranks"] >= 0.0, g
+    a = d["amr_maxlev2"]
+    assert a["scaling"] == "strong" and a["value"] > 0 and len(a["config"]["cells_per_level"]) == 3, a
