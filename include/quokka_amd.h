@@ -111,6 +111,11 @@ int qk_profile_reset(qk_ctx *ctx);
 int qk_profile_num_kernels(qk_ctx *ctx);
 int qk_profile_get(qk_ctx *ctx, int k, const char **name, long *count, double *total_ms);
 
+/* hipMemsetAsync on the caller's stream: the device words a fused stage reports in (redo count, CFL maxima) are cleared by the library's own
+ * call instead of a host-framework fill kernel (the reference clears its counters with amrex::Gpu fills, e.g. redoFlag.setVal(none),
+ * src/QuokkaSimulation.hpp:1087).  `device_ptr` must be a device allocation. */
+int qk_clear_bytes(qk_ctx *ctx, qk_stream s, void *device_ptr, int64_t nbytes);
+
 /* BoxArray of one level owned by this rank (valid, cell-centred boxes). */
 int qk_level_create(qk_ctx *ctx, qk_level **lev, int ndim, int nboxes, const qk_box *valid_boxes);
 int qk_level_destroy(qk_level *lev);

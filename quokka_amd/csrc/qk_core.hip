@@ -104,6 +104,16 @@ int qk_level_destroy(qk_level *lev)
 	return QK_OK;
 }
 
+int qk_clear_bytes(qk_ctx *ctx, qk_stream s, void *device_ptr, int64_t nbytes)
+{
+	if (ctx == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	QK_REQUIRE(ctx, device_ptr != nullptr && nbytes >= 0, "qk_clear_bytes: NULL pointer or negative size");
+	QK_HIP_CHECK(ctx, hipMemsetAsync(device_ptr, 0, static_cast<size_t>(nbytes), static_cast<hipStream_t>(s)));
+	return QK_OK;
+}
+
 int qk_profile_enable(qk_ctx *ctx, int on)
 {
 	if (ctx == nullptr) {

@@ -567,7 +567,8 @@ class HydroSimulation:
         if self._unfused_ran and not self._err_latched:  # (rare: an operator-path stage of this advance may have raised the flag)
             self._err_latched = int(self.dev_error.item()) != 0
         # (the signal words are only handed to the final stage; clearing them before stage 1 is harmless)
-        (self._dev_words if both else self._dev_words[4 * slot:4 * slot + 4]).zero_()
+        c = self.ctx
+        c.check(c.L.qk_clear_bytes(c.h, c.stream(), C.c_void_p(self._dev_words.data_ptr() + (0 if both else 32 * slot)), 64 if both else 32), "qk_clear_bytes")
 
     def _fused_launch(self, stage: int, U_in, U_old, U_out, dt, group=None, fofc: bool = False, slot: int = 0):
         """one fused stage over all local boxes (group None) or over a sub-level (Level, [local box indices]); fofc: the first-order flux

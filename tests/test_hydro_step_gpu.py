@@ -508,6 +508,38 @@ def test_carried_rhs_mode_with_first_order_flux_correction(ctx, oracle):
     assert rel_l1(gather_gpu(sg, N), gather_oracle(so, N)) <= 1e-12
 
 
+def test_drift_of_the_carried_form_is_that_of_a_one_ulp_perturbation(ctx):
+    """How far the carried half step drifts from the exact form over a long run, with a yardstick: a third run in the EXACT form whose blast energy is
+    one unit in the last place higher (relative 2e-16: the size of one rounding difference).  128^3, lockstep.  Through the 1000 steps the deck of
+    BASELINE config 2 runs, the carried form stays within 1e-12 (measured 3e-15) — and wherever it later does not, the perturbed exact run has left
+    the exact run just as far: the blast amplifies rounding-level differences by ~10^14 in 5000 steps (profiles/round4/carry_drift_128.txt), so a
+    cell-by-cell tolerance over the reference ctest's 12 000 steps pins nothing but that instability."""
+    N = 128
+    a, b, c = (sedov_problem(ctx, N, max_grid_size=128) for _ in range(3))
+    b.rk2_carry_rhs = True
+    v = c.state_new_cc_.valid(0)
+    e = v[4, 0, 0, 0].item()
+    v[4, 0, 0, 0] = float(np.nextafter(e, 2 * e))
+    c.fillBoundaryConditions(c.state_new_cc_)
+
+    def dist(x, y):
+        worst = 0.0
+        for n in range(6):
+            p, q = x.state_new_cc_.valid(0)[n], y.state_new_cc_.valid(0)[n]
+            worst = max(worst, float((p - q).abs().sum(dtype=torch.float64)) / max(float(p.abs().sum(dtype=torch.float64)), 1e-300))
+        return worst
+
+    for it in range(1, 3001):
+        assert a.step() and b.step() and c.step()
+        if it in (100, 1000, 2000, 3000):
+            carry, ulp = dist(a, b), dist(a, c)
+            print(f"step {it}: carried vs exact {carry:.2e}; exact with the blast energy one ulp up vs exact {ulp:.2e}")
+            assert carry <= max(1e-12, 10.0 * ulp), (it, carry, ulp)
+            if it <= 1000:
+                assert carry <= 1e-12, (it, carry)
+    assert b.counters["fofc1_stages"] + b.counters["fofc2_stages"] + b.counters["retries"] == 0
+
+
 def test_carried_rhs_mode_with_passive_scalars_and_lower_orders(ctx):
     """every instantiation of the carried mode (PPM / PLM / donor cell, 0 and 2 passive scalars) against the exact mode of the same build"""
     from quokka_amd.simulation import sedov_problem as mk

@@ -45,6 +45,30 @@ def test_unmodified_sedov_problem_matches_the_oracle_state_and_its_own_criteria(
     assert "Energy conservation is OK." in out and "Kinetic energy production is OK." in out
 
 
+def test_carried_form_over_the_whole_run_of_the_reference_ctest(tmp_path):
+    """The headline's form of the RK2 average (hydro.rk2_carry_rhs = 1: the carried half step) over a WHOLE run, not 25 or 40 steps: the
+    reference's HydroBlast3D ctest — 128^3 to t = 1, ~12 000 steps — through the unchanged problem file in both forms.  Both meet both criteria of
+    the reference (energy to 2e-15, kinetic-energy fraction within 1 % of 0.218729: exit status 0).  The final STATES are not comparable cell by
+    cell: the blast amplifies a one-ulp difference by 10^14 within 5000 steps, in either form (tests/test_hydro_step_gpu.py::
+    test_drift_of_the_carried_form_is_that_of_a_one_ulp_perturbation measures it, profiles/round4/carry_drift_128.txt) — their difference is printed."""
+    import re
+    states, steps = {}, {}
+    for mode in (0, 1):
+        dump = str(tmp_path / f"state{mode}.bin")
+        rc, out = run([exe("ref_HydroBlast3D"), os.path.join(HOST, "decks", "blast_unigrid_256.in"), "amr.n_cell=128 128 128", "amr.max_grid_size=128",
+                       "max_timesteps=20000", f"hydro.rk2_carry_rhs={mode}", f"qk.dump_state={dump}"], str(tmp_path))
+        assert rc == 0, out[-2000:]
+        assert "Energy conservation is OK." in out and "Kinetic energy production is OK." in out
+        m = re.search(r"qk counters: steps=(\d+) fofc_stages=(\d+) retries=(\d+)", out)
+        assert m, out[-1500:]
+        steps[mode] = tuple(int(x) for x in m.groups())
+        states[mode] = np.fromfile(dump, dtype=np.float64).reshape(6, 128, 128, 128)
+    assert min(steps[0][0], steps[1][0]) > 5000 and abs(steps[0][0] - steps[1][0]) < 0.1 * steps[0][0], steps
+    worst = max(np.abs(states[1][n] - states[0][n]).sum() / np.abs(states[0][n]).sum() for n in (0, 4))
+    print(f"carried half step vs exact form, HydroBlast3D 128^3 to t = 1: steps / fofc stages / retries {steps[0]} vs {steps[1]}; "
+          f"relative L1 of density and energy at t = 1: {worst:.2e} (chaotic amplification of rounding, see the docstring)")
+
+
 def test_unmodified_sedov_problem_with_its_own_error_estimator_on_three_levels(tmp_path):
     """blast_amr_maxlev2.in (BASELINE config 5): the problem's ErrorEst — a device lambda over MFIter boxes calling HydroSystem::ComputePressure —
     drives the regridding; energy is conserved across levels"""
