@@ -691,6 +691,26 @@ def main():
         out["selftest"] = selftest_verdict  # (rank 0's; None on the other ranks, which do not print)
     if share:
         out["dry_run"] = f"{world} ranks share cuda:0 and talk over gloo with host-staged buffers: the SHAPE of the N > 1 line on a small problem, never a measurement"
+    # the same measurement twice more on the same run (the box's HBM rate drifts by several percent within minutes: profiles/round4/README.md)
+    reps = []
+    for _ in range(2):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            assert sim.step(), "hydro advance failed"
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        reps.append(time.perf_counter() - t0)
+    if world > 1:
+        t = torch.tensor(reps, dtype=torch.float64, device=ctx.device)
+        from quokka_amd import comm
+        comm.all_reduce(t, dist.ReduceOp.MAX)
+        reps = t.tolist()
+    out["repeats"] = {"values": [total_cells * args.steps / r / 1e6 for r in reps], "unit": "Mcell-updates/s", "steps_each": args.steps,
+                      "note": "the timed region repeated twice on the continuing run, after `value` was taken"}
     del sim
     torch.cuda.empty_cache()
     if not args.no_secondary:

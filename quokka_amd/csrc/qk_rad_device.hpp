@@ -76,8 +76,8 @@ struct Rad {
 			return (1. / 3.);
 		}
 		const double f = clampd(f_in, 0., 1.);
-		const double f_fac = sqrt(4.0 - 3.0 * (f * f));
-		return (3.0 + 4.0 * (f * f)) / (5.0 + 2.0 * f_fac);
+		const double f_fac = sqrtN(4.0 - 3.0 * (f * f));
+		return divN(3.0 + 4.0 * (f * f), 5.0 + 2.0 * f_fac);
 	}
 	// pow_mode 0 stands for the reference's std::pow(T, 4) / std::pow(T, 3), which glibc rounds correctly in all but a vanishing fraction of
 	// cases.  Evaluated here as compensated products (T^2 = hi + lo exactly by one fma; the product of the pair carried with its rounding
@@ -123,7 +123,7 @@ struct Rad {
 // radiation_system.hpp:873-916: row `row` of the Eddington tensor, plus T[row][row] via Tn[row]
 QK_DEV void eddingtonTensor(Rad const &r, double fx, double fy, double fz, double T[3][3])
 {
-	const double f = sqrt(fx * fx + fy * fy + fz * fz);
+	const double f = sqrtN(fx * fx + fy * fy + fz * fz);
 	const double fv[3] = {fx, fy, fz};
 	const Recip Rf = recipOf(f); // (f == 0: the NaN quotients are discarded by the select below)
 	double n[3];
@@ -152,8 +152,8 @@ template <int DIR> QK_DEV void radFaceFlux(Rad const &r, const double pL[NRAD], 
 	double fx_L = pL[1], fx_R = pR[1];
 	double fy_L = pL[2], fy_R = pR[2];
 	double fz_L = pL[3], fz_R = pR[3];
-	double f_L = sqrt(fx_L * fx_L + fy_L * fy_L + fz_L * fz_L);
-	double f_R = sqrt(fx_R * fx_R + fy_R * fy_R + fz_R * fz_R);
+	double f_L = sqrtN(fx_L * fx_L + fy_L * fy_L + fz_L * fz_L);
+	double f_R = sqrtN(fx_R * fx_R + fy_R * fy_R + fz_R * fz_R);
 	double Fx_L = fx_L * (r.c * erad_L);
 	double Fx_R = fx_R * (r.c * erad_R);
 	double Fy_L = fy_L * (r.c * erad_L);
@@ -175,8 +175,8 @@ template <int DIR> QK_DEV void radFaceFlux(Rad const &r, const double pL[NRAD], 
 		fy_R = Fy_R / (r.c * erad_R);
 		fz_L = Fz_L / (r.c * erad_L);
 		fz_R = Fz_R / (r.c * erad_R);
-		f_L = sqrt(fx_L * fx_L + fy_L * fy_L + fz_L * fz_L);
-		f_R = sqrt(fx_R * fx_R + fy_R * fy_R + fz_R * fz_R);
+		f_L = sqrtN(fx_L * fx_L + fy_L * fy_L + fz_L * fz_L);
+		f_R = sqrtN(fx_R * fx_R + fy_R * fy_R + fz_R * fz_R);
 	}
 	double TL[3][3], TR[3][3];
 	eddingtonTensor(r, fx_L, fy_L, fz_L, TL);
@@ -185,8 +185,8 @@ template <int DIR> QK_DEV void radFaceFlux(Rad const &r, const double pL[NRAD], 
 	const double FnR = (DIR == 0) ? Fx_R : (DIR == 1) ? Fy_R : Fz_R;
 	double FL[NRAD] = {FnL, TL[DIR][0] * erad_L, TL[DIR][1] * erad_L, TL[DIR][2] * erad_L};
 	double FR[NRAD] = {FnR, TR[DIR][0] * erad_R, TR[DIR][1] * erad_R, TR[DIR][2] * erad_R};
-	double S_L = smax(0.1, sqrt(TL[DIR][DIR]));
-	double S_R = smax(0.1, sqrt(TR[DIR][DIR]));
+	double S_L = smax(0.1, sqrtN(TL[DIR][DIR]));
+	double S_R = smax(0.1, sqrtN(TR[DIR][DIR]));
 	S_L *= -1.;
 	FL[0] *= r.chat / r.c;
 	FR[0] *= r.chat / r.c;
@@ -211,8 +211,8 @@ template <int DIR> QK_DEV void radFaceFlux(Rad const &r, const double pL[NRAD], 
 // radiation_system.hpp:626-665
 QK_DEV auto radStateValid(Rad const &r, const double U[NRAD]) -> bool
 {
-	const double Fnorm = sqrt(U[1] * U[1] + U[2] * U[2] + U[3] * U[3]);
-	const double f = Fnorm / (r.c * U[0]);
+	const double Fnorm = sqrtN(U[1] * U[1] + U[2] * U[2] + U[3] * U[3]);
+	const double f = divN(Fnorm, r.c * U[0]);
 	return (U[0] > 0.) && (f <= 1.);
 }
 QK_DEV void amendRadState(Rad const &r, double U[NRAD])

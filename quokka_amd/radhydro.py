@@ -182,8 +182,9 @@ class RadhydroSimulation(HydroSimulation):
         time_subcycle = time
         if self.dev_rad_counter.numel() < 4 * nsub:
             self.dev_rad_counter = torch.zeros(4 * nsub, dtype=torch.int32, device=self.ctx.device)
-        self.dev_rad_counter.zero_()
-        self.dev_rad_failure.zero_()
+        c = self.ctx
+        c.check(c.L.qk_clear_bytes(c.h, c.stream(), C.c_void_p(self.dev_rad_counter.data_ptr()), 4 * self.dev_rad_counter.numel()), "qk_clear_bytes")
+        c.check(c.L.qk_clear_bytes(c.h, c.stream(), C.c_void_p(self.dev_rad_failure.data_ptr()), 4 * self.dev_rad_failure.numel()), "qk_clear_bytes")
         mirrored = False
         for i in range(nsub):
             if i > 0 and not mirrored:
@@ -201,6 +202,8 @@ class RadhydroSimulation(HydroSimulation):
         fail = self._allreduce_sum_list(self.dev_rad_failure.tolist())
         cnt = self.dev_rad_counter[:4 * nsub].view(nsub, 4).to(torch.int64)
         tot, mx = cnt.sum(dim=0).tolist(), int(cnt[:, 2].max().item())
+        if self.nranks > 1:  # (the C++ host reduces its counters over the ranks too: quokka_host.hpp subcycleRadiationAtLevel)
+            tot, mx = self._allreduce_sum_list([int(x) for x in tot]), int(self._allreduce_max(float(mx)))
         self.rad_counters["solves"] += tot[0]
         self.rad_counters["newton_iterations"] += tot[1]
         self.rad_counters["max_newton_iterations"] = max(self.rad_counters["max_newton_iterations"], mx)

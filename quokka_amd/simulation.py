@@ -391,15 +391,27 @@ class HydroSimulation:
                                         state.ptr, C.c_void_p(self._dev_fix.data_ptr() + 16), C.c_void_p(self._dev_fix.data_ptr())), "qk_hydro_FixupState")
         self._signal_of_state_new = None
         self._fix_words_pending = state is self.state_new_cc_
+        self._fix_error_pending = True  # (its own flag: invalidating the signal must not make the error word unread)
 
     def _signal(self):
-        """(max signal of maxSignalSpeedLocal, of ComputeMaxSignalSpeed) over all ranks if known for the current state_new_cc_, else None"""
-        if self._signal_of_state_new is None and self._fix_words_pending:
+        """(max signal of maxSignalSpeedLocal, of ComputeMaxSignalSpeed) over all ranks if known for the current state_new_cc_, else None.
+        Also where FixupState's error word (rho <= 0 in SyncDualEnergy) is read: together with the maxima, reduced over the ranks in the same
+        collective, so that every rank raises (a rank that raised alone would leave the others waiting in the all-reduce)."""
+        take = self._signal_of_state_new is None and self._fix_words_pending
+        if take or getattr(self, "_fix_error_pending", False):
             h = self._dev_fix.cpu()
-            if int(h[2]) & 0xFFFFFFFF:
+            vals = h[0:2].view(torch.float64).tolist() + [float(int(h[2]) & 0xFFFFFFFF)]
+            if self.nranks > 1:
+                import torch.distributed as dist
+                from . import comm
+                t = torch.tensor(vals, dtype=torch.float64, device=self.ctx.device)
+                comm.all_reduce(t, dist.ReduceOp.MAX)
+                vals = t.tolist()
+            self._fix_error_pending = False
+            if vals[2] != 0.0:
                 raise capi.QkError("density is negative in SyncDualEnergy! abort!! (reference src/hydro/hydro_system.hpp:834-836)")
-            sig = h[0:2].view(torch.float64).tolist()
-            self._signal_of_state_new = (self._allreduce_max(sig[0]), self._allreduce_max(sig[1]))
+            if take:
+                self._signal_of_state_new = (vals[0], vals[1])
         return self._signal_of_state_new
 
     def computeTimestepAtLevel(self) -> float:
