@@ -156,13 +156,15 @@ struct Eos {
 	int tmodel;   // temperature hooks: 0 gamma-law, 1 E_int = (alpha / 4) T^4
 	double alpha;
 	Recip RkBu;   // 1 / kB_user: a run-time constant, its reciprocal (correctly rounded by the constructor's IEEE division) arrives in scalar registers
+	Recip RkB, Rmu; // 1 / k_B, 1 / (mu m_u): likewise (the matter-radiation exchange and the temperature floors divide by them in every cell)
 	static constexpr double k_B = 1.380649e-16;
 	static constexpr double m_u = 1.6605390666e-24;
 
 	__host__ __device__ explicit Eos(qk_hydro_traits const &t)
 	    : gamma(t.gamma), gm1(t.gamma - 1.0), cs_iso(t.cs_isothermal), mu(t.mean_molecular_weight / m_u), kB_ratio_num(k_B),
 	      kB_user(t.boltzmann_constant), isothermal(t.gamma == 1.0), tmodel(t.eos_temperature_model), alpha(t.eos_alpha),
-	      RkBu{t.boltzmann_constant, 1.0 / t.boltzmann_constant}
+	      RkBu{t.boltzmann_constant, 1.0 / t.boltzmann_constant}, RkB{k_B, 1.0 / k_B},
+	      Rmu{(t.mean_molecular_weight / m_u) * m_u, 1.0 / ((t.mean_molecular_weight / m_u) * m_u)}
 	{
 	}
 	// EOS.hpp:304-348 : e = Eint/rho (0 if rho == 0) ; p = (gamma-1) rho e

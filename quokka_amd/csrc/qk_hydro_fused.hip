@@ -419,9 +419,9 @@ struct EpiConst {
 QK_DEV auto epiConst(Eos const &eos) -> EpiConst
 {
 	EpiConst c;
-	c.RkB = recipOf(Eos::k_B);
-	c.RkBu = recipOf(eos.kB_user);
-	c.Rmu = recipOf(eos.mu * Eos::m_u);
+	c.RkB = eos.RkB; // (formed on the host: qk::Eos)
+	c.RkBu = eos.RkBu;
+	c.Rmu = eos.Rmu;
 	return c;
 }
 // Eos::tgasFromEint / eintFromTgas (EOS.hpp:74-159) with the shared reciprocals
@@ -869,6 +869,10 @@ __global__ void __launch_bounds__(64 * MARCH_BY) k_sweep_march(SweepArgs a, Eos 
 	double vfPrev = 0., dVprev = 0., dWprev = 0.;
 	// The cell a step completes (march position p - 3) was loaded as the newest cell three steps earlier: when the old state IS the input
 	// state (stage 1) its conserved values wait in a per-lane ring of three LDS slots (no barriers: a lane only touches its own slots).
+	// (Measured and rejected in round 4, profiles/round4/ab6_*: the newest cell's conserved values requested ONE STEP AHEAD through LDS-direct loads —
+	// three global_load_lds_dwordx4 per wave and step into a 3-KiB slot, read out at the top of the next step, no register held meanwhile.  Y sweep
+	// 0.722 ms with it, 0.721 ms without, on the same box: the sweep is bound by the rate at which the box's HBM delivers its bytes, not by the
+	// latency of that load.  The Z sweep, at 248 VGPRs, spilled with it: 0.92 -> 1.11 ms.)
 	constexpr bool RING = LAST && (STAGE == 1);
 	__shared__ double s_ring[RING ? 3 : 1][RING ? NV : 1][RING ? 64 * MARCH_BY : 1];
 	const int tid = threadIdx.y * 64 + threadIdx.x;

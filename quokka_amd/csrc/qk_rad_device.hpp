@@ -28,6 +28,9 @@ struct Rad {
 	int pe_on; // ISM_Traits::enable_photoelectric_heating
 	double mean_molecular_mass = 0.; // EOS_Traits::mean_molecular_weight as given (ComputeNumberDensityH; set by the source-term launcher)
 	int thermal_model; // 0: a T^4; 1: a T (RadDust's hooks; DUST instantiation only)
+	// quotients of run-time constants, formed once by the constructor's IEEE divisions instead of once per cell: 1 / (c c_hat) (the momentum exchange),
+	// c / c_hat and its reciprocal, 1 / c^2 (the work term)
+	double r_cchat, cscale, inv_cscale, r_cc;
 	__host__ __device__ explicit Rad(qk_rad_traits const &t)
 	    : c(t.c_light), chat(t.c_hat), arad(t.radiation_constant),
 	      Erad_floor(t.Erad_floor / ((t.ngroups > 1) ? t.ngroups : 1)), // Erad_floor_ = RadSystem_Traits::Erad_floor / nGroups_ (radiation_system.hpp:211)
@@ -35,7 +38,8 @@ struct Rad {
 	      beta_order(t.beta_order), pow_mode(t.pow_mode), opacity_model(t.opacity_model), eddington_model(t.eddington_model),
 	      ngroups((t.ngroups > 1) ? t.ngroups : 1), dust_coeff(t.dust_gas_interaction_coeff), dust_threshold(t.gas_dust_coupling_threshold),
 	      cool0(t.cooling_linear_coeff[0]), cr_heat(t.cr_heating_rate), pe_rate(t.pe_heating_E1_derivative), pe_on(t.enable_photoelectric_heating),
-	      thermal_model(t.thermal_model)
+	      thermal_model(t.thermal_model), r_cchat(1.0 / (t.c_light * t.c_hat)), cscale(t.c_light / t.c_hat), inv_cscale(1 / (t.c_light / t.c_hat)),
+	      r_cc(1.0 / (t.c_light * t.c_light))
 	{
 	}
 	// problem hooks ComputePlanckOpacity / ComputeEnergyMeanOpacity / ComputeFluxMeanOpacity (radiation_system.hpp:1141-1154):
@@ -250,11 +254,9 @@ QK_DEV auto eintTempDerivative(Eos const &eos, double rho, double T) -> double
 struct EosCell {
 	Eos const &eos;
 	double rho;
-	Recip Rrho, Rg, RkB, Rmu, RkBu;
-	QK_DEV EosCell(Eos const &e, double rho_)
-	    : eos(e), rho(rho_), Rrho(recipOf(rho_)), Rg(recipOf(e.gm1 * rho_)), RkB(recipOf(Eos::k_B)), Rmu(recipOf(e.mu * Eos::m_u)), RkBu(recipOf(e.kB_user))
-	{
-	}
+	Recip Rrho, Rg;
+	Recip const &RkB, &Rmu, &RkBu; // run-time constants: their reciprocals come with the Eos (formed on the host, scalar registers)
+	QK_DEV EosCell(Eos const &e, double rho_) : eos(e), rho(rho_), Rrho(recipOf(rho_)), Rg(recipOf(e.gm1 * rho_)), RkB(e.RkB), Rmu(e.Rmu), RkBu(e.RkBu) {}
 	QK_DEV auto tgasFromEint(double Eint) const -> double
 	{
 		if (eos.tmodel == 1) {
@@ -288,6 +290,15 @@ QK_DEV auto egasFromEint(double rho, double px, double py, double pz, double Ein
 	const double p_sq = px * px + py * py + pz * pz;
 	const double Ekin = p_sq / (2.0 * rho);
 	return Eint + Ekin;
+}
+// the same two with the refined reciprocal of rho: a / (2 rho) == 0.5 (a / rho), scaling by two is exact
+QK_DEV auto eintFromEgas(Recip const &Rrho, double px, double py, double pz, double Etot) -> double
+{
+	return Etot - 0.5 * divBy(px * px + py * py + pz * pz, Rrho);
+}
+QK_DEV auto egasFromEint(Recip const &Rrho, double px, double py, double pz, double Eint) -> double
+{
+	return Eint + 0.5 * divBy(px * px + py * py + pz * pz, Rrho);
 }
 
 // source_terms_single_group.hpp:29-563 for one cell.  U[10] in place; counters as in the reference:
@@ -360,12 +371,14 @@ QK_DEV void radSourceCell(RadT const &r, Eos const &eos, double U[10], double sr
 	double work = 0.0, work_prev = 0.0;
 	double dMomentum[3] = {0., 0., 0.};
 	double Frad_t1[3] = {0., 0., 0.};
-	const double cscale = c / chat;
-	const Recip Rcc = recipOf(c * chat);
+	const double cscale = r.cscale;       // c / chat
+	const Recip Rcc{c * chat, r.r_cchat}; // (host-made reciprocals of run-time constants)
+	const Recip Rc2{c * c, r.r_cc};
+	const Recip Rrho = recipOf(rho); // (the same value EosCell refines: merged by the compiler)
 	const EosT ec(eos, rho);
 
 	if (gamma_ne_1) {
-		Egas0 = eintFromEgas(rho, x1GasMom0, x2GasMom0, x3GasMom0, Egastot0);
+		Egas0 = eintFromEgas(Rrho, x1GasMom0, x2GasMom0, x3GasMom0, Egastot0);
 		Etot0 = Egas0 + cscale * (Erad0 + Src);
 	}
 	double gas_update_factor = 1.0;
@@ -436,8 +449,8 @@ QK_DEV void radSourceCell(RadT const &r, Eos const &eos, double U[10], double sr
 					kappaF = r.template kappaF<TDEP>(rho, T_d);
 					if (beta_order != 0) { // include_work_term_in_source = true
 						if (ite == 0) {
-							work = (x1GasMom0 * Frad_t0[0] + x2GasMom0 * Frad_t0[1] + x3GasMom0 * Frad_t0[2]) * (2.0 * kappaE - kappaF) * chat /
-							       (c * c) * lorentz_factor_v * dt;
+							work = divBy((x1GasMom0 * Frad_t0[0] + x2GasMom0 * Frad_t0[1] + x3GasMom0 * Frad_t0[2]) * (2.0 * kappaE - kappaF) * chat, Rc2) *
+							       lorentz_factor_v * dt;
 						}
 					}
 					tau0 = dt * rho * kappaP * chat * lorentz_factor;
@@ -480,7 +493,7 @@ QK_DEV void radSourceCell(RadT const &r, Eos const &eos, double U[10], double sr
 				if constexpr (!DUST) {
 					J00 = 1.0 + divBy(cooling_derivative * dt, Rcv);
 					J01 = cscale;
-					J10 = divBy(1.0, Rcv) * dEg_dT - (1 / cscale) * cooling_derivative * dt;
+					J10 = divBy(1.0, Rcv) * dEg_dT - r.inv_cscale * cooling_derivative * dt;
 					if (tau <= 0.0) {
 						J11 = -__builtin_inf();
 					} else {
@@ -536,9 +549,9 @@ QK_DEV void radSourceCell(RadT const &r, Eos const &eos, double U[10], double sr
 			// :351-356: the energy the line cooled away goes to the radiation
 			if constexpr (DUST) {
 				const double cooling_tend = r.netCoolingRate(T_gas, H_num_den) * dt;
-				Erad_guess += (1 / cscale) * cooling_tend;
+				Erad_guess += r.inv_cscale * cooling_tend;
 			} else {
-				Erad_guess += (1 / cscale) * (0.0 * dt);
+				Erad_guess += r.inv_cscale * (0.0 * dt);
 			}
 			if (n > 0) {
 				kappaF = r.template kappaF<TDEP>(rho, T_d);
@@ -618,7 +631,7 @@ QK_DEV void radSourceCell(RadT const &r, Eos const &eos, double U[10], double sr
 
 		// 3. work term
 		if (gamma_ne_1 && (beta_order != 0)) {
-			const double Egastot1 = egasFromEint(rho, x1GasMom1, x2GasMom1, x3GasMom1, Egas_guess);
+			const double Egastot1 = egasFromEint(Rrho, x1GasMom1, x2GasMom1, x3GasMom1, Egas_guess);
 			const double Ekin1 = Egastot1 - Egas_guess;
 			const double dEkin_work = Ekin1 - Ekin0;
 			Egas_guess -= dEkin_work;
@@ -627,7 +640,7 @@ QK_DEV void radSourceCell(RadT const &r, Eos const &eos, double U[10], double sr
 			break;
 		}
 		work_prev = work;
-		work = (x1GasMom1 * Frad_t1[0] + x2GasMom1 * Frad_t1[1] + x3GasMom1 * Frad_t1[2]) * chat / (c * c) * lorentz_factor_v * (2.0 * kappaE - kappaF) * dt;
+		work = divBy((x1GasMom1 * Frad_t1[0] + x2GasMom1 * Frad_t1[1] + x3GasMom1 * Frad_t1[2]) * chat, Rc2) * lorentz_factor_v * (2.0 * kappaE - kappaF) * dt;
 		const double lag_tol = 1.0e-13;
 		if ((fabs(work) == 0.0) || (cscale * fabs(work - work_prev) < lag_tol * Etot0) || (fabs(work - work_prev) <= lag_tol * R) ||
 		    (fabs(work - work_prev) <= 1.0e-8 * fabs(work))) {
@@ -648,7 +661,7 @@ QK_DEV void radSourceCell(RadT const &r, Eos const &eos, double U[10], double sr
 	if (gamma_ne_1) {
 		Egas_guess = Egas0 + (Egas_guess - Egas0) * gas_update_factor;
 		U[EINT] = Egas_guess;
-		U[ENE] = egasFromEint(rho, x1GasMom1, x2GasMom1, x3GasMom1, Egas_guess);
+		U[ENE] = egasFromEint(Rrho, x1GasMom1, x2GasMom1, x3GasMom1, Egas_guess);
 		U[RAD0] = Erad_guess;
 	}
 	U[RAD0 + 1] = Frad_t1[0];
