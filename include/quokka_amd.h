@@ -237,6 +237,11 @@ typedef struct qk_hydro_stage_args {
 				  *    halfVel are neither written nor read (they may be NULL), so flux_rk2 does not exist: excludes store_flux_rk2,
 				  *    and a stage-2 first-order flux correction must recompute F1 from U_old with qk_hydro_ComputeFluxes */
 	qk_array4 *rhs1;	 /* rk2_carry_rhs: cell-centred, no ghost cells, 6 + nscalars + 1 components; must survive from stage 1 to stage 2 */
+	const struct qk_carray4 *flux_mask; /* (qk_carray4: the byte-array descriptor declared with the AMR entries below) rk2_carry_rhs only, optional (NULL: none): cell-centred bytes with ONE ghost cell.  A face with a non-zero byte on
+				  * either side is treated as the reference's form treats every face: stage 1 stores F1 in halfFlux[d], stage 2 writes
+				  * flux_rk2 = 0.5 F1 + 0.5 F2 to fluxRk2[d] (both required then).  For a level with refined children: mark the coarse
+				  * cells along the coarse-fine interface (the items of its flux register) and incrementFluxRegisters
+				  * (src/simulation.hpp:1345-1387) finds flux_rk2 where it reads it, while the 99.9 % other faces stay carried. */
 	int fofc_pass;		 /* 0: the stage proper.  1: the FIRST-ORDER FLUX CORRECTION of a stage whose first pass counted flagged cells (reference
 				  * src/QuokkaSimulation.hpp:1144-1184, :1232-1270), as ONE more fused pass: `redoFlag` is an INPUT here (as the first pass left
 				  * it, with its one ghost cell filled: qk_FillBoundary_*_int) — a face that touches a flagged cell takes the first-order flux of

@@ -123,11 +123,28 @@ class AmrLevelSim(HydroSimulation):
         self.cf_interp = InterpFromCoarse(parent.lev, self.lev, self.geom, NGHOST_CC, all_fine_boxes=self.all_boxes if multi else None)
         self.fluxreg = FluxRegister(parent.lev, self.lev, parent.geom, 6, all_fine_boxes=self.all_boxes if multi else None, reg_nghost=1 if multi else 0)
         self.avgdown = AverageDown(parent.lev, self.lev)
+        parent._update_flux_mask(self.fluxreg)
         if multi and parent.reflux_inc is None:
             from .simulation import GhostExchange
             parent.reflux_inc = MultiFab(parent.lev, 6, 1, fill=0.0)
             per = [([capi.BC_INT_DIR] * 3, [capi.BC_INT_DIR] * 3)] * 6
             parent.reflux_ghost = GhostExchange(parent.lev, parent.geom, 6, 1, parent.all_boxes, parent.owner, self.amr.rank, per)
+
+    def _update_flux_mask(self, child_fluxreg: FluxRegister):
+        """The carried form on a level with refined children (AmrSimulation.rk2_carry_rhs; level 0 only: the one level whose size makes the form of
+        the RK2 average matter).  incrementFluxRegisters reads flux_rk2 on the coarse-fine faces alone: the coarse cells of the register's items are
+        marked (qk_hydro_stage_args::flux_mask), the fused stage keeps F1 and writes flux_rk2 on their faces exactly as the reference's form does
+        on every face, and every other face — 99.9 % of them — stays carried.  Rebuilt whenever the child level is (re)linked."""
+        if not (getattr(self.amr, "rk2_carry_rhs", False) and self.ilev == 0 and self.integratorOrder_ == 2):
+            return
+        m = MultiFab(self.lev, 1, 1, dtype=torch.int8, fill=0)
+        for _d, _side, _fb, cb, lo, hi, sh in child_fluxreg.items():
+            beg = m.begins[cb]
+            sl = tuple(slice(lo[k] + sh[k] - beg[k], hi[k] + sh[k] - beg[k] + 1) for k in (2, 1, 0))
+            m.fabs[cb][0][sl] = 1
+        self.flux_mask = m
+        self.store_flux_rk2 = False
+        self.rk2_carry_rhs = True
 
     def reflux_from(self, child: "AmrLevelSim"):
         """flux_reg_[lev+1]->Reflux(state_new_cc_[lev]) (reference src/simulation.hpp:1308).  One rank: straight into the state.  Several
@@ -615,6 +632,16 @@ class AmrSimulation:
                 break
 
     # ------------------------------------------------------------------ diagnostics
+    def use_carried_form(self, on: bool = True):
+        """hydro.rk2_carry_rhs for the hierarchy: level 0 advances in the carried form of the RK2 average and forms flux_rk2 only on its coarse-fine
+        faces (AmrLevelSim._update_flux_mask); refined levels — small, and read by both neighbours' registers — keep the reference's form"""
+        self.rk2_carry_rhs = bool(on)
+        L0 = self.levels[0]
+        if on and self.finest_level >= 1:
+            L0._update_flux_mask(self.levels[1].fluxreg)
+        elif not on:
+            L0.flux_mask, L0.store_flux_rk2, L0.rk2_carry_rhs = None, True, False
+
     def composite_sum(self, comp: int) -> float:
         """volume integral of a conserved component over the composite grid (cells under a finer level are not counted): every level's
         own sum minus, for each (local box, box of the next level) pair, the part of the local box that the finer box covers — the

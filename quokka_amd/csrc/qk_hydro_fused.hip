@@ -71,6 +71,7 @@ struct SweepArgs {
 	bool store_rk2; // stage 2: write flux_rk2 = 0.5 F1 + 0.5 F2 to rk2Flux (never over F1: tile-boundary faces of the x sweep are evaluated twice)
 	qk_array4 *rk2Flux;
 	qk_array4 *rhs1; // carried half step (rk2_carry_rhs): per cell U_old + (dt/2) rhs_1 (nv components) + P(U_old), written by stage 1, read by stage 2
+	const qk_carray4 *fluxMask; // carried form only, optional: cells whose faces keep F1 (stage 1 -> halfFlux) and receive flux_rk2 (stage 2 -> rk2Flux)
 	int nseg; // segments along the march axis (marching sweeps; see k_pre_march)
 };
 
@@ -361,6 +362,30 @@ QK_DEV void flattenEdges(double chi, double mean, double &am, double &ap)
 {
 	am = chi * am + (1. - chi) * mean;
 	ap = chi * ap + (1. - chi) * mean;
+}
+
+// The carried form on a level that has refined children (qk_hydro_stage_args::flux_mask): the flux registers of the hierarchy need flux_rk2 = 0.5 F1 +
+// 0.5 F2 on the coarse-fine faces — a few thousand faces of 50 million.  A face with a marked cell on either side keeps F1 in halfFlux (stage 1) and
+// gets flux_rk2 written to rk2Flux (stage 2), exactly the values the reference's form stores on EVERY face; the cell updates stay carried.
+using CA4 = A4<const char, qk_carray4>;
+template <int STAGE, int NV> QK_DEV void maskedFaceFlux(SweepArgs const &a, int b, int i, int j, int k, const double F[NV])
+{
+	if (STAGE == 1) {
+		WA4 HF(a.halfFlux[b]);
+		const int64_t o = HF.idx(i, j, k);
+#pragma unroll
+		for (int n = 0; n < NV; ++n) {
+			HF.p[o + HF.ns * n] = F[n];
+		}
+	} else {
+		RA4 HF(a.halfFlux[b]);
+		WA4 RF(a.rk2Flux[b]);
+		const int64_t o = HF.idx(i, j, k), o2 = RF.idx(i, j, k);
+#pragma unroll
+		for (int n = 0; n < NV; ++n) {
+			RF.p[o2 + RF.ns * n] = 0.5 * HF.p[o + HF.ns * n] + 0.5 * F[n]; // (0 + 0.5 F1) + 0.5 F2 (QuokkaSimulation.hpp:1106, :1220)
+		}
+	}
 }
 
 // ---------------------------------------------------------------------------------------------- first-order flux correction, fused
@@ -707,7 +732,13 @@ template <int ORDER, int STAGE, int NS, bool CARRY, int NDIM = 3, bool FOFC = fa
 		firstOrderFlux<0, NS, false, NDIM>(eos, a.reconstruct_eint, qLo, qRo, F, vf);
 	};
 	if (CARRY) {
-		// carried right-hand side: neither stage touches the face arrays
+		// carried right-hand side: neither stage touches the face arrays — except on the marked faces of a level with refined children
+		if (a.fluxMask != nullptr && isFace) {
+			CA4 M(a.fluxMask[b]);
+			if ((M(i - 1, j, k) | M(i, j, k)) != 0) {
+				maskedFaceFlux<STAGE, NV>(a, b, i, j, k, F);
+			}
+		}
 	} else if (STAGE == 1 && FOFC) {
 		// (halfFlux keeps the UNCORRECTED stage-1 flux the first pass stored: flux_rk2 is formed from it, QuokkaSimulation.hpp:1105-1108)
 		if (firstOrder) {
@@ -1020,7 +1051,15 @@ __global__ void __launch_bounds__(64 * MARCH_BY) k_sweep_march(SweepArgs a, Eos 
 				firstOrderFlux<DIR, NS, TWOD, TWOD ? 2 : 3>(eos, a.reconstruct_eint, qLo, qRo, F, vf);
 			};
 			if (CARRY) {
-				// carried right-hand side: no face arrays
+				// carried right-hand side: no face arrays — except on the marked faces of a level with refined children
+				if (a.fluxMask != nullptr && live) {
+					CA4 M(a.fluxMask[b]);
+					int fm[3] = {fidx[0], fidx[1], fidx[2]};
+					fm[DIR] -= 1;
+					if ((M(fm[0], fm[1], fm[2]) | M(fidx[0], fidx[1], fidx[2])) != 0) {
+						maskedFaceFlux<STAGE, NV>(a, b, fidx[0], fidx[1], fidx[2], F);
+					}
+				}
 			} else if (STAGE == 1 && FOFC) {
 				if (firstOrder) { // (halfFlux keeps the uncorrected stage-1 flux of the first pass)
 					replaceByFirstOrder();
@@ -1311,7 +1350,13 @@ int qk_hydro_stage_fused(qk_level *lev, qk_stream stream, const qk_hydro_traits 
 	QK_REQUIRE(ctx, args->fofc_pass == 0 || (args->K_visc == 0.0 && (args->rk2_carry_rhs == 0 || args->stage == 1)),
 		   "qk_hydro_stage_fused: the fused first-order flux correction pass needs K_visc == 0 and, in the carried-rhs form, stage 1 (use the reference-shaped operators otherwise)");
 	QK_REQUIRE(ctx, args->rk2_carry_rhs == 0 || (args->rhs1 != nullptr && args->store_flux_rk2 == 0),
-		   "qk_hydro_stage_fused: rk2_carry_rhs needs rhs1 and excludes store_flux_rk2 (flux_rk2 is never formed in that mode)");
+		   "qk_hydro_stage_fused: rk2_carry_rhs needs rhs1 and excludes store_flux_rk2 (flux_rk2 is formed on the faces flux_mask marks, nowhere else)");
+	if (args->rk2_carry_rhs != 0 && args->flux_mask != nullptr) {
+		for (int d = 0; d < t->ndim; ++d) {
+			QK_REQUIRE(ctx, args->halfFlux[d] != nullptr && args->fluxRk2[d] != nullptr && args->fluxRk2[d] != args->halfFlux[d],
+				   "qk_hydro_stage_fused: flux_mask needs halfFlux[d] and a distinct fluxRk2[d]");
+		}
+	}
 	for (int d = 0; d < t->ndim; ++d) {
 		QK_REQUIRE(ctx, args->rk2_carry_rhs != 0 || (args->halfFlux[d] && args->halfVel[d]), "qk_hydro_stage_fused: NULL halfFlux/halfVel");
 		QK_REQUIRE(ctx, args->store_flux_rk2 == 0 || args->stage != 2 || (args->fluxRk2[d] != nullptr && args->fluxRk2[d] != args->halfFlux[d]),
@@ -1368,6 +1413,7 @@ int qk_hydro_stage_fused(qk_level *lev, qk_stream stream, const qk_hydro_traits 
 	a.reconstruct_eint = re;
 	a.store_rk2 = (args->store_flux_rk2 != 0);
 	a.rhs1 = args->rhs1;
+	a.fluxMask = (args->rk2_carry_rhs != 0) ? args->flux_mask : nullptr;
 	for (int d = 0; d < 3; ++d) {
 		a.dx3[d] = args->dx[d];
 	}

@@ -545,7 +545,7 @@ class HydroSimulation:
             if nbad > 0 and self.abortOnFofcFailure_ != 0:
                 return False
         self._limits_and_sync(U_out)
-        if stage == 2 and getattr(self, "store_flux_rk2", False):
+        if stage == 2 and self._needs_flux_rk2():
             for d in range(nd):  # what the flux registers accumulate (possibly FOFC-corrected), where the fused stage leaves it
                 self.fluxRk2()[d].copy_from(fl[d])
         elif stage == 1 and self.integratorOrder_ == 1 and getattr(self, "store_flux_rk2", False):
@@ -559,6 +559,10 @@ class HydroSimulation:
         if getattr(self, "_fluxRk2", None) is None:
             self._fluxRk2 = [MultiFab(self.lev, self.hydro.nvar_, 0, facedir=d, fill=0.0) for d in range(self.geom.ndim)]
         return self._fluxRk2
+
+    def _needs_flux_rk2(self) -> bool:
+        """something consumes flux_rk2 after the advance (the flux registers of an AMR hierarchy)"""
+        return bool(getattr(self, "store_flux_rk2", False)) or getattr(self, "flux_mask", None) is not None
 
     def _carry_active(self) -> bool:
         """the carried-right-hand-side form of the RK2 average (qk_hydro_stage_args::rk2_carry_rhs; `rk2_carry_rhs` attribute, default off):
@@ -604,13 +608,17 @@ class HydroSimulation:
         a.scratch_bytes = self.scratch.numel() * 8
         a.dt, a.stage, a.reconstruction_order = dt, stage, self.reconstructionOrder_
         a.densityFloor, a.tempFloor, a.use_dual_energy, a.K_visc = self.densityFloor_, self.tempFloor_, self.useDualEnergy_, float(self.artificialViscosityK_)
-        a.store_flux_rk2 = int(getattr(self, "store_flux_rk2", False))
-        if a.store_flux_rk2:
-            for d in range(nd):
-                a.fluxRk2[d] = tab(self.fluxRk2()[d])
+        mask = getattr(self, "flux_mask", None)  # a level with refined children in the carried form: flux_rk2 only on the marked faces
         if self._carry_active():
             a.rk2_carry_rhs = 1
             a.rhs1 = tab(self.rhs1())
+            if mask is not None:
+                a.flux_mask = tab(mask)
+        else:  # (also the carried form forced into the exact one for a stage-2 correction: then flux_rk2 on every face, as the reference)
+            a.store_flux_rk2 = int(self._needs_flux_rk2())
+        if a.store_flux_rk2 or a.flux_mask:
+            for d in range(nd):
+                a.fluxRk2[d] = tab(self.fluxRk2()[d])
         a.fofc_pass = int(fofc)
         c = self.ctx
         c.check(c.L.qk_hydro_stage_fused(lev.h, c.stream(), C.byref(self.traits), C.byref(a)), "qk_hydro_stage_fused")

@@ -111,3 +111,36 @@ def test_three_levels_nested_and_conservative(ctx):
     m1, e1 = amr.composite_sum(0), amr.composite_sum(4)
     assert abs(m1 - m0) / m0 <= 2e-13 and abs(e1 - e0) / e0 <= 2e-13, (abs(m1 - m0) / m0, abs(e1 - e0) / e0)
     assert amr.cellUpdatesEachLevel_[2] > 0
+
+
+def test_carried_form_on_level_zero_with_flux_rk2_on_the_coarse_fine_faces_only(ctx):
+    """AmrSimulation.use_carried_form: level 0 advances in the carried form of the RK2 average (qk_hydro_stage_args::rk2_carry_rhs) and forms
+    flux_rk2 = 0.5 F1 + 0.5 F2 only on the faces of the cells its flux register marks (flux_mask) — what incrementFluxRegisters reads
+    (reference src/simulation.hpp:1345-1387).  Dynamic three-level blast, 20 coarse steps: the grids and time steps of the exact-form
+    hierarchy, every level's state within 1e-12 relative L1 of it, composite mass and energy conserved as well as there."""
+    def run(carry):
+        amr = sedov_amr_problem(ctx, 32, 2, max_grid_size=16, blocking_factor=8)
+        if carry:
+            amr.use_carried_form(True)
+            L0 = amr.levels[0]
+            assert L0.flux_mask is not None and L0._carry_active() and not L0.store_flux_rk2
+            marked = sum(int(L0.flux_mask.fabs[b].sum().item()) for b in range(L0.lev.nboxes))
+            assert 0 < marked < 0.25 * 32 ** 3, marked
+            assert all(not L._carry_active() for L in amr.levels[1:])
+        E0, M0 = amr.composite_sum(4), amr.composite_sum(0)
+        for _ in range(20):
+            amr.step()
+        return amr, abs(amr.composite_sum(4) - E0) / abs(E0), abs(amr.composite_sum(0) - M0) / abs(M0)
+
+    a, dEa, dMa = run(False)
+    b, dEb, dMb = run(True)
+    assert a.finest_level == b.finest_level == 2
+    assert [L.all_boxes for L in a.levels] == [L.all_boxes for L in b.levels]
+    assert all(abs(x - y) <= 1e-13 * x for x, y in zip(a.dt_, b.dt_))
+    for la, lb in zip(a.levels, b.levels):
+        for n in (0, 1, 4, 5):
+            num = sum(float((la.state_new_cc_.valid(k)[n] - lb.state_new_cc_.valid(k)[n]).abs().sum(dtype=torch.float64)) for k in range(la.lev.nboxes))
+            den = sum(float(la.state_new_cc_.valid(k)[n].abs().sum(dtype=torch.float64)) for k in range(la.lev.nboxes))
+            assert num <= 1e-12 * den, (la.ilev, n, num / den)
+    print(f"composite |dE/E|, |dM/M| after 20 coarse steps: exact {dEa:.1e} {dMa:.1e}, carried level 0 {dEb:.1e} {dMb:.1e}")
+    assert dEb <= max(4.0 * dEa, 5e-15) and dMb <= max(4.0 * dMa, 5e-14), (dEa, dEb, dMa, dMb)
