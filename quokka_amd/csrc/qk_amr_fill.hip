@@ -94,76 +94,112 @@ QK_DEV auto crseValue(RA4 const &Co, RA4 const &Cn, double w_old, double w_new, 
 	return tv(n);
 }
 
-__global__ void __launch_bounds__(256) k_interp(const InterpItem *items, qk_array4 *fine_t, const qk_array4 *crse_old_t, const qk_array4 *crse_new_t,
-						double w_old, double w_new, int ncomp, int method, int hooks, int ndim, int r0, int r1, int r2)
+// One thread per (COARSE cell under the region, component): threadIdx.x runs over coarse cells, threadIdx.y over components.  The coarse value, its
+// 27-point neighbourhood, the three limited slopes and the monotonicity factor alpha depend on the coarse cell alone; the r0 r1 r2 fine children take
+// them with their own offsets.  (Round 3 had one thread per FINE cell loop over the components: 27 coarse reads — 135 for the energy with its hook — per
+// fine value, eight times over for the eight children of a coarse cell: 68 us per fill of a 64^3 box's ghost shell, 11 % of the GPU time of the Sedov
+// hierarchy.)  The components of a fine cell meet in LDS for PostInterpState, which rebuilds the total energy from the interpolated density, momenta
+// and specific internal energy.  Same arithmetic per value: bit-identical.
+constexpr int IT_CELLS = 64, IT_MAXCOMP = 16;
+__global__ void __launch_bounds__(IT_CELLS *IT_MAXCOMP) k_interp(const InterpItem *items, qk_array4 *fine_t, const qk_array4 *crse_old_t, const qk_array4 *crse_new_t,
+								 double w_old, double w_new, int ncomp, int method, int hooks, int ndim, int r0, int r1, int r2)
 {
+	__shared__ double s_val[IT_MAXCOMP][IT_CELLS];
 	const InterpItem it = items[blockIdx.y];
-	const int n0 = it.hi[0] - it.lo[0] + 1, n1 = it.hi[1] - it.lo[1] + 1, n2 = it.hi[2] - it.lo[2] + 1;
-	const int64_t ncell = static_cast<int64_t>(n0) * n1 * n2;
+	const int rr[3] = {r0, r1, r2};
+	int clo[3];
+	unsigned m[3];
+	for (int d = 0; d < 3; ++d) {
+		const int lo = (it.lo[d] >= 0) ? it.lo[d] / rr[d] : -((-it.lo[d] + rr[d] - 1) / rr[d]);
+		const int hi = (it.hi[d] >= 0) ? it.hi[d] / rr[d] : -((-it.hi[d] + rr[d] - 1) / rr[d]);
+		clo[d] = lo;
+		m[d] = static_cast<unsigned>(hi - lo + 1);
+	}
+	const unsigned m01 = m[0] * m[1], ncc = m01 * m[2]; // (a piece of a ghost shell: far below 2^31 cells)
 	WA4 F(fine_t[it.fine_box]);
 	RA4 Co(crse_old_t[it.crse_box]);
 	RA4 Cn(crse_new_t[it.crse_box]);
-	const int rr[3] = {r0, r1, r2};
-	for (int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < ncell; t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-		const int kk = static_cast<int>(t / (static_cast<int64_t>(n0) * n1));
-		const int r = static_cast<int>(t - static_cast<int64_t>(kk) * n0 * n1);
-		const int jj = r / n0;
-		const int idx[3] = {it.lo[0] + (r - jj * n0), it.lo[1] + jj, it.lo[2] + kk};
-		int ic[3];
-		double off[3];
-		for (int d = 0; d < 3; ++d) {
-			ic[d] = (idx[d] >= 0) ? idx[d] / rr[d] : -((-idx[d] + rr[d] - 1) / rr[d]);
-			off[d] = (idx[d] - ic[d] * rr[d] + 0.5) / rr[d] - 0.5;
+	const bool hk = (hooks != 0);
+	// components in chunks of blockDim.y (<= IT_MAXCOMP; all of them at once up to 16 components: hydro 6, radiation-hydro 10; multigroup states take
+	// several chunks — the hydro block, which the energy hook needs together, is in the first)
+	for (int nbase = 0; nbase < ncomp; nbase += static_cast<int>(blockDim.y))
+	for (unsigned base = blockIdx.x * IT_CELLS; base < ncc; base += gridDim.x * IT_CELLS) {
+		const int n_raw = nbase + static_cast<int>(threadIdx.y);
+		const bool comp_live = n_raw < ncomp;
+		const int n = comp_live ? n_raw : ncomp - 1;
+		const bool post = hk && ncomp > ENE && nbase == 0; // (uniform)
+		const unsigned t = base + threadIdx.x;
+		const bool live = t < ncc;
+		const unsigned tc = live ? t : 0;
+		const unsigned kk = tc / m01;
+		const unsigned r = tc - kk * m01;
+		const unsigned jj = r / m[0];
+		const int ic[3] = {clo[0] + static_cast<int>(r - jj * m[0]), clo[1] + static_cast<int>(jj), clo[2] + static_cast<int>(kk)};
+		const double u = crseValue(Co, Cn, w_old, w_new, ic[0], ic[1], ic[2], n, hk);
+		double s[3] = {0., 0., 0.};
+		double alpha = 1.0;
+		if (method == 1) {
+			double umax = u, umin = u;
+			const int k0 = (ndim == 3) ? -1 : 0, k1 = (ndim == 3) ? 1 : 0;
+			const int j0 = (ndim >= 2) ? -1 : 0, j1 = (ndim >= 2) ? 1 : 0;
+			double nb[3][3][3];
+			for (int c = k0; c <= k1; ++c) {
+				for (int b = j0; b <= j1; ++b) {
+					for (int a = -1; a <= 1; ++a) {
+						const double v = (a == 0 && b == 0 && c == 0) ? u : crseValue(Co, Cn, w_old, w_new, ic[0] + a, ic[1] + b, ic[2] + c, n, hk);
+						nb[c + 1][b + 1][a + 1] = v;
+						umax = smax(umax, v);
+						umin = smin(umin, v);
+					}
+				}
+			}
+			s[0] = 0.5 * (nb[1][1][2] - nb[1][1][0]);
+			if (ndim >= 2) {
+				s[1] = 0.5 * (nb[1][2][1] - nb[1][0][1]);
+			}
+			if (ndim == 3) {
+				s[2] = 0.5 * (nb[2][1][1] - nb[0][1][1]);
+			}
+			if (s[0] != 0.0 || s[1] != 0.0 || s[2] != 0.0) {
+				const double dumax = fabs(s[0]) * static_cast<double>(rr[0] - 1) / (2.0 * rr[0]) + fabs(s[1]) * static_cast<double>(rr[1] - 1) / (2.0 * rr[1]) +
+						     fabs(s[2]) * static_cast<double>(rr[2] - 1) / (2.0 * rr[2]);
+				if (dumax * alpha > (umax - u)) {
+					alpha = (umax - u) / dumax;
+				}
+				if (dumax * alpha > (u - umin)) {
+					alpha = (u - umin) / dumax;
+				}
+			}
 		}
-		for (int n = 0; n < ncomp; ++n) {
-			const bool hk = (hooks != 0);
-			const double u = crseValue(Co, Cn, w_old, w_new, ic[0], ic[1], ic[2], n, hk);
-			double val = u;
-			if (method == 1) {
-				double s[3] = {0., 0., 0.};
-				double umax = u, umin = u;
-				const int k0 = (ndim == 3) ? -1 : 0, k1 = (ndim == 3) ? 1 : 0;
-				const int j0 = (ndim >= 2) ? -1 : 0, j1 = (ndim >= 2) ? 1 : 0;
-				double nb[3][3][3];
-				for (int c = k0; c <= k1; ++c) {
-					for (int b = j0; b <= j1; ++b) {
-						for (int a = -1; a <= 1; ++a) {
-							const double v = (a == 0 && b == 0 && c == 0) ? u : crseValue(Co, Cn, w_old, w_new, ic[0] + a, ic[1] + b, ic[2] + c, n, hk);
-							nb[c + 1][b + 1][a + 1] = v;
-							umax = smax(umax, v);
-							umin = smin(umin, v);
+		// the fine children of the coarse cell that lie inside the region
+		for (int cz = 0; cz < r2; ++cz) {
+			for (int cy = 0; cy < r1; ++cy) {
+				for (int cx = 0; cx < r0; ++cx) {
+					const int idx[3] = {ic[0] * r0 + cx, ic[1] * r1 + cy, ic[2] * r2 + cz};
+					const bool inside = live && idx[0] >= it.lo[0] && idx[0] <= it.hi[0] && idx[1] >= it.lo[1] && idx[1] <= it.hi[1] && idx[2] >= it.lo[2] &&
+							    idx[2] <= it.hi[2];
+					double val = u;
+					if (method == 1) {
+						const double off0 = (cx + 0.5) / r0 - 0.5, off1 = (cy + 0.5) / r1 - 0.5, off2 = (cz + 0.5) / r2 - 0.5;
+						val = u + off0 * (s[0] * alpha) + off1 * (s[1] * alpha) + off2 * (s[2] * alpha);
+					}
+					if (post) { // PostInterpState on the new fine cell: E = rho e + kinetic energy of the INTERPOLATED density and momenta
+						__syncthreads(); // (the previous child's readers are done)
+						s_val[n][threadIdx.x] = val;
+						__syncthreads();
+						if (n == ENE) {
+							const double rho = s_val[RHO][threadIdx.x];
+							const double px = s_val[MX][threadIdx.x], py = s_val[MY][threadIdx.x], pz = s_val[MZ][threadIdx.x];
+							const double Eint = rho * val;
+							const double kinetic_energy = (px * px + py * py + pz * pz) / (2.0 * rho);
+							val = Eint + kinetic_energy;
 						}
 					}
-				}
-				s[0] = 0.5 * (nb[1][1][2] - nb[1][1][0]);
-				if (ndim >= 2) {
-					s[1] = 0.5 * (nb[1][2][1] - nb[1][0][1]);
-				}
-				if (ndim == 3) {
-					s[2] = 0.5 * (nb[2][1][1] - nb[0][1][1]);
-				}
-				double alpha = 1.0;
-				if (s[0] != 0.0 || s[1] != 0.0 || s[2] != 0.0) {
-					const double dumax = fabs(s[0]) * static_cast<double>(rr[0] - 1) / (2.0 * rr[0]) + fabs(s[1]) * static_cast<double>(rr[1] - 1) / (2.0 * rr[1]) +
-							     fabs(s[2]) * static_cast<double>(rr[2] - 1) / (2.0 * rr[2]);
-					if (dumax * alpha > (umax - u)) {
-						alpha = (umax - u) / dumax;
-					}
-					if (dumax * alpha > (u - umin)) {
-						alpha = (u - umin) / dumax;
+					if (inside && comp_live) {
+						F(idx[0], idx[1], idx[2], n) = val;
 					}
 				}
-				val = u + off[0] * (s[0] * alpha) + off[1] * (s[1] * alpha) + off[2] * (s[2] * alpha);
 			}
-			F(idx[0], idx[1], idx[2], n) = val;
-		}
-		if (hooks != 0 && ncomp > ENE) { // PostInterpState on the new fine cell
-			const double rho = F(idx[0], idx[1], idx[2], RHO);
-			const double px = F(idx[0], idx[1], idx[2], MX), py = F(idx[0], idx[1], idx[2], MY), pz = F(idx[0], idx[1], idx[2], MZ);
-			const double e = F(idx[0], idx[1], idx[2], ENE);
-			const double Eint = rho * e;
-			const double kinetic_energy = (px * px + py * py + pz * pz) / (2.0 * rho);
-			F(idx[0], idx[1], idx[2], ENE) = Eint + kinetic_energy;
 		}
 	}
 }
@@ -325,8 +361,8 @@ int qk_InterpFromCoarse(qk_interp_plan *plan, qk_stream s, qk_array4 *fine_t, co
 	if (plan->items.empty()) {
 		return QK_OK;
 	}
-	const dim3 grid(static_cast<unsigned>(std::min<int64_t>((plan->max_cells + 255) / 256, 4096)), static_cast<unsigned>(plan->items.size()), 1);
-	hipLaunchKernelGGL(k_interp, grid, dim3(256), 0, static_cast<hipStream_t>(s), plan->d_items, fine_t, crse_old_t, crse_new_t, w_old, w_new, ncomp, method,
+	const dim3 grid(static_cast<unsigned>(std::min<int64_t>((plan->max_cells + IT_CELLS - 1) / IT_CELLS, 16384)), static_cast<unsigned>(plan->items.size()), 1);
+	hipLaunchKernelGGL(k_interp, grid, dim3(IT_CELLS, static_cast<unsigned>(std::min(ncomp, IT_MAXCOMP))), 0, static_cast<hipStream_t>(s), plan->d_items, fine_t, crse_old_t, crse_new_t, w_old, w_new, ncomp, method,
 			   energy_hooks, plan->crse->ndim, plan->ratio[0], plan->ratio[1], plan->ratio[2]);
 	QK_HIP_CHECK(ctx, hipGetLastError());
 	return QK_OK;
