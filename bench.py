@@ -427,6 +427,30 @@ def cxx_shell_block(args, steps=22):
                       "SetRadEnergySource evaluated before every source-term call as in the reference; the executable's own figure of merit over all steps of the run"}
 
 
+def cxx_amr_block(args, steps=55):
+    """BASELINE config 5 geometry through the C++17 host: the reference's unchanged test_hydro3d_blast.cpp on the deck of the config
+    (blast_amr_maxlev2.in), the executable's own figure of merit over the whole evolve (initial regrids and every step included)."""
+    import subprocess
+    host = os.path.join(ROOT, "quokka_amd", "host")
+    exe = os.path.join(host, "bin", "ref_HydroBlast3D")
+    if not os.path.exists(exe):
+        return {"error": "quokka_amd/host/bin/ref_HydroBlast3D is not built (needs the reference tree at build time)"}
+    carry = 1 if args.rk2_mode == "carry" else 0
+    cmd = [exe, os.path.join(host, "decks", "blast_amr_maxlev2.in"), f"max_timesteps={steps}", f"hydro.rk2_carry_rhs={carry}", "plotfile_interval=-1", "checkpoint_interval=-1"]
+    try:
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=host)
+        m = re.search(r"Performance figure-of-merit: ([0-9.eE+-]+) .s/zone-update \[([0-9.eE+-]+) Mupdates/s\]", p.stdout)
+        if m is None:
+            return {"error": "no figure of merit in the output", "tail": p.stdout[-300:]}
+        lv = re.findall(r"Zone-updates on level (\d): (\d+) \((\d+) grids\)", p.stdout)
+    except Exception as e:  # noqa: BLE001 - a secondary block must not take the headline down
+        return {"error": f"{type(e).__name__}: {e}"}
+    return {"value": float(m.group(2)), "unit": "Mcell-updates/s", "coarse_steps": steps, "level0_rk2_mode": "carry + flux_rk2 on coarse-fine faces only" if carry else "exact",
+            "zone_updates_per_level": [int(x[1]) for x in lv], "energy_conservation_ok": "Energy conservation is OK." in p.stdout,
+            "driver": "the reference's test_hydro3d_blast.cpp, unchanged, through QuokkaSimulation<problem_t> + AmrDriver (C++17 host mirror), deck blast_amr_maxlev2.in; "
+                      "the executable's own figure of merit over the whole evolve"}
+
+
 def compact(block, keep=("value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline", "kernels_ms_per_launch")):
     """a secondary block of the default line: the figures of a workload's own line without the contract boilerplate"""
     return {k: block[k] for k in keep if k in block}
@@ -755,8 +779,9 @@ def main():
             out["cxx_shell256"] = cxx_shell_block(args)
             torch.cuda.empty_cache()
             # (e) BASELINE config 5 geometry at its full size on the one GPU: blast_amr_maxlev2.in, 256^3 base grid + 2 levels
-            out["amr_maxlev2"] = compact(run_amr(ctx, torch, dist, rank, world, 256, 50, 5))
+            out["amr_maxlev2"] = compact(run_amr(ctx, torch, dist, rank, world, 256, 50, 5, carry=(args.rk2_mode == "carry")))
             torch.cuda.empty_cache()
+            out["cxx_amr_maxlev2"] = cxx_amr_block(args)
         elif world > 1:
             if ncell not in (256, 64):
                 sW, nW, elW, _ = run_sedov(ctx, torch, dist, rank, world, 256, mgs, args.steps, args.warmup, profile=False, carry=(args.rk2_mode == "carry"))

@@ -351,6 +351,9 @@ template <typename problem_t, typename SimT> class AmrDriver
 			me.afterAdvance_ = [this, lev](double dt) { incrementFluxRegisters(lev, dt); };
 			me.beforeAttempt_ = [this, lev](int retry) { resetFluxRegistersForAttempt(lev, retry); };
 			me.storeFluxRk2_ = true;
+			if (lev == 1 && parent.wantsCarriedForm()) {
+				parent.setFluxMaskFrom(f.fluxreg); // the base level in the carried form, flux_rk2 on its coarse-fine faces only
+			}
 			installRadiationHook(lev);
 			installRadiationHook(lev - 1);
 		}

@@ -1700,6 +1700,35 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	double fillTime_ = 0.0;		       // the time a ghost fill refers to (coarse data are interpolated to it)
 	[[nodiscard]] auto bcFillTime() const -> double override { return fillTime_; }
 	bool storeFluxRk2_ = false;	       // keep flux_rk2 = 0.5 F1 + 0.5 F2 (rk2flux_) for the flux registers
+	// The carried form on a level with refined children (hydro.rk2_carry_rhs = 1 on the base level of a hierarchy): flux_rk2 is formed only on the faces
+	// of the cells the child's flux register marks (qk_hydro_stage_args::flux_mask); set by AmrDriver when it links level 1 (quokka_amr.hpp)
+	amrex::TagBoxArray fluxMask_;
+	[[nodiscard]] auto needsFluxRk2() const -> bool { return storeFluxRk2_ || fluxMask_.size() > 0; }
+	[[nodiscard]] auto wantsCarriedForm() const -> bool { return AMREX_SPACEDIM == 3 && rk2CarryRhs_ != 0 && integratorOrder_ == 2; }
+	void setFluxMaskFrom(qk_fluxreg *reg)
+	{
+		fluxMask_.define(grids_, 1, 1);
+		std::vector<std::vector<char>> h(static_cast<size_t>(fluxMask_.size()));
+		for (int b = 0; b < fluxMask_.size(); ++b) {
+			h[b].assign(static_cast<size_t>(fluxMask_.fabbox(b).numPts()), 0);
+		}
+		for (int n = 0; n < qk_fluxreg_num_items(reg); ++n) {
+			int dir = 0, side = 0, fb = 0, cb = 0, lo[3], hi[3], sh[3];
+			qkhost::check(qk_fluxreg_item(reg, n, &dir, &side, &fb, &cb, lo, hi, sh), "qk_fluxreg_item");
+			amrex::Array4<char> a(h[cb].data(), fluxMask_.fabbox(cb), 1);
+			for (int k = lo[2]; k <= hi[2]; ++k) {
+				for (int j = lo[1]; j <= hi[1]; ++j) {
+					for (int i = lo[0]; i <= hi[0]; ++i) {
+						a(i + sh[0], j + sh[1], k + sh[2]) = 1;
+					}
+				}
+			}
+		}
+		for (int b = 0; b < fluxMask_.size(); ++b) {
+			fluxMask_.copyFromHost(b, h[b]);
+		}
+		storeFluxRk2_ = false;
+	}
 	std::function<void(double)> afterAdvance_; // incrementFluxRegisters(dt) after every successful advanceHydroAtLevel
 	// a level of a hierarchy with radiation: the radiation fluxes of a stage go to the flux registers of the radiation block
 	std::function<void(std::array<amrex::MultiFab, AMREX_SPACEDIM> &, double)> afterRadStage_;
@@ -2654,9 +2683,14 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		a.tempFloor = tempFloor_;
 		a.use_dual_energy = useDualEnergy_;
 		a.K_visc = artificialViscosityK_;
-		a.store_flux_rk2 = storeFluxRk2_ ? 1 : 0;
+		bool const masked = carryActive() && fluxMask_.size() > 0;
+		a.store_flux_rk2 = (!carryActive() && needsFluxRk2()) ? 1 : 0; // (also the carried form forced into the exact one for a stage-2 correction)
 		for (int d = 0; d < 3; ++d) {
-			a.fluxRk2[d] = (storeFluxRk2_ && d < AMREX_SPACEDIM) ? sel(qkhost::tab(rk2flux_[d])) : nullptr;
+			a.fluxRk2[d] = ((a.store_flux_rk2 != 0 || masked) && d < AMREX_SPACEDIM) ? sel(qkhost::tab(rk2flux_[d])) : nullptr;
+		}
+		if (masked) {
+			auto *full = reinterpret_cast<qk_carray4 *>(fluxMask_.arrays());
+			a.flux_mask = group < 0 ? full : groupTable(group, full);
 		}
 		if (carryActive()) {
 			if (rhs1_.size() == 0) {
