@@ -685,6 +685,83 @@ struct Device {
 };
 } // namespace Gpu
 
+// amrex::TableData<T, N> (AMReX_TableData.H): an N-dimensional table with inclusive index bounds, first index fastest, in device memory or — built
+// with The_Pinned_Arena() — in host memory; table() / const_table() hand out the accessor a kernel captures by value.  Only what the reference's
+// problem files use: N = 3, copy() from a host table, the accessors.
+struct Arena {
+	bool host;
+};
+inline auto The_Pinned_Arena() -> Arena *
+{
+	static Arena a{true};
+	return &a;
+}
+inline auto The_Arena() -> Arena *
+{
+	static Arena a{false};
+	return &a;
+}
+template <typename T> struct Table3D {
+	T *p = nullptr;
+	Long jstride = 0, kstride = 0;
+	int lo0 = 0, lo1 = 0, lo2 = 0;
+	QK_HD auto operator()(int i, int j, int k) const -> T & { return p[(i - lo0) + jstride * (j - lo1) + kstride * (k - lo2)]; }
+};
+template <typename T, int N> class TableData
+{
+	static_assert(N == 3, "amrex_mini: TableData is built for three indices (what the reference's problems use)");
+
+      public:
+	TableData(Array<int, N> const &lo, Array<int, N> const &hi, Arena *arena = nullptr) : lo_(lo), hi_(hi), host_(arena != nullptr && arena->host)
+	{
+		n_ = 1;
+		for (int d = 0; d < N; ++d) {
+			n_ *= static_cast<Long>(hi[d] - lo[d] + 1);
+		}
+		if (host_) {
+			hbuf_.assign(static_cast<size_t>(n_), T{});
+		} else {
+			QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_), sizeof(T) * static_cast<size_t>(std::max<Long>(n_, 1))));
+		}
+	}
+	TableData(TableData const &) = delete;
+	auto operator=(TableData const &) -> TableData & = delete;
+	~TableData()
+	{
+		if (d_ != nullptr) {
+			(void)hipFree(d_);
+		}
+	}
+	[[nodiscard]] auto table() -> Table3D<T> { return make<T>(); }
+	[[nodiscard]] auto table() const -> Table3D<T const> { return make<T const>(); }
+	[[nodiscard]] auto const_table() const -> Table3D<T const> { return make<T const>(); }
+	[[nodiscard]] auto size() const -> Long { return n_; }
+	void copy(TableData const &src) // same bounds; any combination of host and device storage
+	{
+		AMREX_ALWAYS_ASSERT(src.n_ == n_);
+		QK_HOST_HIP(hipMemcpy(data(), src.data(), sizeof(T) * static_cast<size_t>(n_), hipMemcpyDefault));
+	}
+
+      private:
+	[[nodiscard]] auto data() const -> T * { return host_ ? const_cast<T *>(hbuf_.data()) : d_; }
+	template <typename U> [[nodiscard]] auto make() const -> Table3D<U>
+	{
+		Table3D<U> t;
+		t.p = data();
+		t.jstride = hi_[0] - lo_[0] + 1;
+		t.kstride = t.jstride * (hi_[1] - lo_[1] + 1);
+		t.lo0 = lo_[0];
+		t.lo1 = lo_[1];
+		t.lo2 = lo_[2];
+		return t;
+	}
+	Array<int, N> lo_, hi_;
+	bool host_;
+	Long n_ = 0;
+	T *d_ = nullptr;
+	std::vector<T> hbuf_;
+};
+
 // one process per GPU; the problem-side reductions of the reference are over one rank here
 // one process per GPU: the reductions a problem file or the driver performs over ranks go through qkhost::Comm (qk_comm.hpp); with one rank
 // every function returns its argument

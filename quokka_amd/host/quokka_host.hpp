@@ -1839,6 +1839,16 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 			qpp.query("fused_fofc", fusedFofc_);
 		}
 		hpp.query("rk2_carry_rhs", rk2CarryRhs_); // extension of this host: the carried-rhs form of the RK2 average (<= 1e-12; quokka_amd.h)
+		{
+			// cooling.enabled (reference src/QuokkaSimulation.hpp:352-366): the Strang-split tabulated / Grackle-like cooling source reads Cloudy
+			// tables from HDF5 files; neither src/cooling nor an HDF5 reader exists on this side.  A deck that asks for it is refused rather than
+			// run as pure hydrodynamics under the reference's name.
+			int coolingEnabled = 0;
+			amrex::ParmParse("cooling").query("enabled", coolingEnabled);
+			if (coolingEnabled != 0) {
+				amrex::Abort("cooling.enabled = 1: tabulated cooling (src/cooling, Cloudy HDF5 tables) is not built in quokka_amd/host");
+			}
+		}
 		amrex::ParmParse rpp("radiation"); // reference src/QuokkaSimulation.hpp:353-358
 		rpp.query("reconstruction_order", radiationReconstructionOrder_);
 		rpp.query("cfl", radiationCflNumber_);

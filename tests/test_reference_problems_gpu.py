@@ -520,3 +520,15 @@ def test_unmodified_reference_ctest_exits_zero(tmp_path, name, deck, extern, slo
     cwd = extern_tree(tmp_path, extern)
     rc, out = run([exe(f"ref_{name}"), os.path.join(HOST, "decks", deck), "plotfile_interval=-1", "checkpoint_interval=-1"], cwd)
     assert rc == 0, out[-2500:]
+
+
+def test_cooling_problem_compiles_unchanged_and_runs_without_its_cooling_source(tmp_path):
+    """src/problems/Cooling, unchanged: amrex::TableData (the random phases of its initial perturbation, filled on the host, copied to the device,
+    read by the initial-condition kernel) and its custom boundary pair (extrapolation below, Dirichlet above).  The reference's deck switches the
+    tabulated cooling source on (cooling.enabled = 1, Cloudy HDF5 tables): src/cooling is not built on this side, and the host REFUSES such a deck
+    instead of running it as pure hydrodynamics; with cooling.enabled = 0 the problem advances (no pass criterion in the reference: exit 0)."""
+    deck = os.path.join(HOST, "decks", "Cooling.in")
+    rc, out = run([exe("ref_Cooling"), deck, "max_timesteps=5", "plotfile_interval=-1"], str(tmp_path))
+    assert rc != 0 and "cooling.enabled = 1" in out, out[-1500:]
+    rc, out = run([exe("ref_Cooling"), deck, "cooling.enabled=0", "max_timesteps=20", "plotfile_interval=-1"], str(tmp_path))
+    assert rc == 0 and "Performance figure-of-merit" in out, out[-2000:]
