@@ -1,1630 +1,17 @@
-// quokka_host.hpp — C++17 host mirror of the reference's operator surface on the hydro and radiation path:
-//   Physics_Traits / Physics_Indices            reference src/physics_info.hpp:8-47
-//   quokka::EOS_Traits, HydroSystem_Traits       reference src/hydro/EOS.hpp:32-37, src/hydro/hydro_system.hpp:38-41
-//   HyperbolicSystem<problem_t>, HydroSystem<problem_t>   static methods with the reference's names and arguments; every body is ONE
-//                                                call into the C-ABI (include/quokka_amd.h) — no arithmetic on the host
-//   RadSystem_Traits, RadSystem<problem_t>       indices, constants, opacity / source hooks, radiation operators (reference src/radiation/radiation_system.hpp)
-//   AMRSimulation<problem_t> / QuokkaSimulation<problem_t>   uniform-grid (max_level = 0) evolve loop, dt control, level-0 ghost fill,
-//                                                RK2 + FOFC + retries, radiation subcycle
-//                                                (reference src/simulation.hpp:703-981,1704-1785, src/QuokkaSimulation.hpp:885-1961)
-// Problems specialise the same trait structs and member templates as in the reference (setInitialConditionsOnGrid,
-// setCustomBoundaryConditions, computeAfterEvolve, ...).  Device hooks are evaluated on host staging data: ICs run on a host
-// buffer that is uploaded; setCustomBoundaryConditions is sampled to build the constant-Dirichlet face model of the C-ABI.
+// quokka_host.hpp — C++17 host mirror of the reference's operator surface on the hydro and radiation path, in four parts:
+//   quokka_hydro_system.hpp     constants, Physics_Traits / Physics_Indices, quokka::EOS, HyperbolicSystem<problem_t>, HydroSystem<problem_t>
+//   quokka_rad_system.hpp       RadSystem_Traits, RadSystem<problem_t>
+//   quokka_amr_simulation.hpp   AMRSimulation<problem_t>: decks, geometry, arrays, ghost fill, output, problem hooks
+//   this file                   QuokkaSimulation<problem_t>: the evolve loop and dt control (reference src/simulation.hpp:703-981), and THE HOT-PATH SCHEDULE —
+//                               advanceHydroAtLevelWithRetries / advanceHydroAtLevel (RK2 + first-order flux correction + retries, reference
+//                               src/QuokkaSimulation.hpp:885-1322), the fused stage pair with one read-back per step (stagePairSpeculative), the early / late
+//                               ghost-exchange overlap (launchStage), the radiation subcycle (:1570-1961).
+// Problems specialise the same trait structs and member templates as in the reference (setInitialConditionsOnGrid, setCustomBoundaryConditions,
+// computeAfterEvolve, ...); their device lambdas and hook functions are compiled by hipcc in the problem's translation unit and run as kernels.
 #ifndef QK_HOST_QUOKKA_HOST_HPP_
 #define QK_HOST_QUOKKA_HOST_HPP_
 
-#include <chrono>
-#include <cstring>
-#include <functional>
-#include <limits>
-#include <memory>
-
-#include "amrex_mini.hpp"
-#include "compat/planck_integral.hpp"
-#include "compat/util_compat.hpp"
-#include "qk_comm.hpp"
-#include "quokka_io.hpp"
-
-// Microphysics fundamental_constants.H (CODATA 2018, cgs)
-namespace C
-{
-constexpr double k_B = 1.380649e-16;
-constexpr double m_u = 1.6605390666e-24;
-constexpr double m_p = 1.67262192369e-24;
-constexpr double m_e = 9.1093837015e-28;
-constexpr double m_n = 1.67492749804e-24;
-constexpr double c_light = 2.99792458e10;
-constexpr double sigma_SB = 5.670374419e-5;
-constexpr double a_rad = 4.0 * sigma_SB / c_light;
-constexpr double hplanck = 6.62607015e-27;
-constexpr double hbar = 1.054571817e-27;
-constexpr double n_A = 6.02214076e23;
-constexpr double q_e = 4.80320471e-10;
-constexpr double Gconst = 6.67430e-8;
-constexpr double ev2erg = 1.602176634e-12;
-constexpr double MeV2eV = 1.0e6;
-constexpr double MeV2erg = MeV2eV * ev2erg;
-constexpr double parsec = 3.085677581467192e18;
-constexpr double AU = 1.495978707e13;
-constexpr double M_solar = 1.98841e33;
-constexpr double R_solar = 6.957e10;
-constexpr double L_solar = 3.828e33;
-} // namespace C
-
-using Real = amrex::Real;
-
-// reference src/math/math_impl.hpp:15-18
-AMREX_GPU_HOST_DEVICE inline auto clamp(double v, double lo, double hi) -> double { return (v < lo) ? lo : (hi < v) ? hi : v; }
-template <typename T> AMREX_GPU_HOST_DEVICE constexpr auto sgn(T val) -> int { return (T(0) < val) - (val < T(0)); }
-
-struct Physics_NumVars { // reference src/physics_numVars.hpp
-	static const int numHydroVars = 6;
-	static const int numRadVars = 4;
-	// face-centred (declarations only: no face-centred state is evolved by this build — MHD is out of scope)
-	static const int numMHDVars_per_dim = 1;
-	static const int numVelVars_per_dim = 1;
-	static const int numMHDVars_tot = AMREX_SPACEDIM * numMHDVars_per_dim;
-	static const int numVelVars_tot = AMREX_SPACEDIM * numVelVars_per_dim;
-};
-
-template <typename problem_t> struct Physics_Traits {
-	static constexpr bool is_hydro_enabled = false;
-	static constexpr int numMassScalars = 0;
-	static constexpr int numPassiveScalars = numMassScalars + 0;
-	static constexpr bool is_radiation_enabled = false;
-	static constexpr bool is_mhd_enabled = false;
-	static constexpr int nGroups = 1;
-};
-
-template <typename problem_t> struct Physics_Indices {
-	// reference src/physics_info.hpp:20-38: neither hydro nor radiation -> the single variable of an advection problem
-	static constexpr int nvarTotal_cc_adv = 1;
-	static constexpr int nvarTotal_cc_radhydro = []() constexpr {
-		if constexpr (Physics_Traits<problem_t>::is_radiation_enabled) { // (nGroups is only read where radiation is on: advection problems do not define it)
-			return Physics_Traits<problem_t>::numPassiveScalars + Physics_NumVars::numHydroVars + Physics_NumVars::numRadVars * Physics_Traits<problem_t>::nGroups;
-		} else if constexpr (Physics_Traits<problem_t>::is_hydro_enabled) {
-			return Physics_Traits<problem_t>::numPassiveScalars + Physics_NumVars::numHydroVars;
-		} else {
-			return 0;
-		}
-	}();
-	static constexpr int nvarTotal_cc = nvarTotal_cc_radhydro > 0 ? nvarTotal_cc_radhydro : nvarTotal_cc_adv;
-	static const int hydroFirstIndex = 0;
-	static const int pscalarFirstIndex = Physics_NumVars::numHydroVars;
-	static const int radFirstIndex = pscalarFirstIndex + Physics_Traits<problem_t>::numPassiveScalars;
-	// face-centred (reference src/physics_info.hpp:43-49; declarations, see Physics_NumVars)
-	static const int nvarPerDim_fc = Physics_NumVars::numVelVars_per_dim * static_cast<int>(Physics_Traits<problem_t>::is_hydro_enabled) +
-					 Physics_NumVars::numMHDVars_per_dim * static_cast<int>(Physics_Traits<problem_t>::is_mhd_enabled);
-	static const int nvarTotal_fc = AMREX_SPACEDIM * nvarPerDim_fc;
-	static const int velFirstIndex = 0;
-	static const int mhdFirstIndex = velFirstIndex + Physics_NumVars::numVelVars_per_dim;
-};
-
-namespace qkhost
-{
-// Problems whose face-centred state this host carries: those with the MHD index bookkeeping (FCQuantities).  The reference allocates one face
-// velocity per direction for every hydro problem as well (for tracer particles; zero unless do_tracers, written to every plotfile as
-// x/y/z-velocity and to every checkpoint as Level_<l>/Face_*): those zero-valued arrays are not carried here.
-template <typename problem_t> constexpr auto hasFaceState() -> bool
-{
-	return Physics_Indices<problem_t>::nvarTotal_fc > 0 && Physics_Traits<problem_t>::is_mhd_enabled;
-}
-} // namespace qkhost
-
-// reference src/hydro/mhd_system.hpp: the index bookkeeping of the face-centred magnetic field (nothing else exists there either)
-template <typename problem_t> class MHDSystem
-{
-      public:
-	static constexpr int nvar_per_dim_ = Physics_NumVars::numMHDVars_per_dim;
-	static constexpr int nvar_tot_ = Physics_NumVars::numMHDVars_tot;
-	enum varIndex_perDim {
-		bfield_index = Physics_Indices<problem_t>::mhdFirstIndex,
-	};
-};
-
-namespace quokka
-{
-template <typename problem_t> struct EOS_Traits {
-	static constexpr double gamma = 5. / 3.;
-	static constexpr double cs_isothermal = std::numeric_limits<double>::quiet_NaN();
-	static constexpr double mean_molecular_weight = std::numeric_limits<double>::quiet_NaN();
-	static constexpr double boltzmann_constant = C::k_B;
-};
-// quokka::EOS<problem_t> (reference src/hydro/EOS.hpp:40-244), host side, for problem generators: the direct gamma-law forms the
-// kernels use (p = (gamma - 1) rho e, e = p / ((gamma - 1) rho); DESIGN.md section 4 on the un-vendored Microphysics EOS)
-template <typename problem_t> struct EOS {
-	static constexpr int nmscalars_ = Physics_Traits<problem_t>::numMassScalars;
-	using MassScalars = std::optional<amrex::GpuArray<amrex::Real, nmscalars_>>; // EOS.hpp:45-66 (the gamma-law EOS ignores them)
-	static constexpr double gamma_ = EOS_Traits<problem_t>::gamma;
-	static constexpr double mu_ = EOS_Traits<problem_t>::mean_molecular_weight / C::m_u;
-	static constexpr double kB_ = EOS_Traits<problem_t>::boltzmann_constant;
-	AMREX_GPU_HOST_DEVICE static auto ComputeEintFromPres(double rho, double Pressure, MassScalars const & /*massScalars*/ = {}) -> double
-	{
-		double const e = Pressure / ((gamma_ - 1.0) * rho);
-		return e * rho;
-	}
-	AMREX_GPU_HOST_DEVICE static auto ComputePressure(double rho, double Eint, MassScalars const & /*massScalars*/ = {}) -> double
-	{
-		double const e = Eint / rho;
-		return ((gamma_ - 1.0) * rho * e) * kB_ / C::k_B;
-	}
-	AMREX_GPU_HOST_DEVICE static auto ComputeSoundSpeed(double rho, double Pressure, MassScalars const & /*massScalars*/ = {}) -> double
-	{
-		return std::sqrt(gamma_ * Pressure / rho); // EOS.hpp:143-175 for the gamma law
-	}
-	AMREX_GPU_HOST_DEVICE static auto ComputeTgasFromEint(double rho, double Eint, MassScalars const & /*massScalars*/ = {}) -> double
-	{
-		double const e = Eint / rho;
-		return (e * mu_ * C::m_u * (gamma_ - 1.0) / C::k_B) * C::k_B / kB_;
-	}
-	AMREX_GPU_HOST_DEVICE static auto ComputeEintFromTgas(double rho, double Tgas, MassScalars const & /*massScalars*/ = {}) -> double
-	{
-		return gammaLawEintFromTgas(rho, Tgas);
-	}
-	AMREX_GPU_HOST_DEVICE static auto ComputeEintTempDerivative(double rho, double Tgas, MassScalars const & /*massScalars*/ = {}) -> double
-	{
-		double const p = rho * Tgas * C::k_B / (mu_ * C::m_u);
-		double const e = p / ((gamma_ - 1.0) * rho);
-		return (e / Tgas) * rho * kB_ / C::k_B;
-	}
-	// (not a hook: what ComputeEintFromTgas is unless a problem specialises it — qkhost::traits() tells the two apart with it)
-	AMREX_GPU_HOST_DEVICE static auto gammaLawEintFromTgas(double rho, double Tgas) -> double
-	{
-		double const p = rho * Tgas * C::k_B / (mu_ * C::m_u);
-		double const e = p / ((gamma_ - 1.0) * rho);
-		return e * rho * kB_ / C::k_B;
-	}
-};
-enum class direction { na = -1, x, y, z };
-enum class centering { cc = 0, fc, ec };
-// reference src/grid.hpp
-struct grid {
-	amrex::Array4<double> array_;
-	amrex::Box indexRange_;
-	amrex::GpuArray<double, AMREX_SPACEDIM> dx_, prob_lo_, prob_hi_;
-	centering cen_ = centering::cc;
-	direction dir_ = direction::na;
-};
-} // namespace quokka
-
-template <typename problem_t> struct HydroSystem_Traits {
-	static constexpr bool reconstruct_eint = true;
-};
-
-enum class FluxDir { X1 = 0, X2 = 1, X3 = 2 };
-enum SlopeLimiter { minmod = 0, MC };
-enum class RiemannSolver { HLLC, LLF, HLLD };
-
-// process-wide C-ABI handles (amrex::Initialize analogue)
-namespace qkhost
-{
-struct Runtime {
-	qk_ctx *ctx = nullptr;
-	qk_level *lev = nullptr; // the level the static operators act on (every simulation object activates its own before it launches)
-	// The compute stream of the ghost fill and the fused stages.  A BLOCKING stream: the legacy default stream — which the problem files'
-	// ParallelFor lambdas and the reference-shaped operators use — orders itself against it in both directions, so nothing else needs to know;
-	// the communication stream of qk_comm.hpp is non-blocking and is ordered against this one by events only (exchangeBegin / exchangeEnd).
-	hipStream_t compute = nullptr;
-	auto computeStream() -> hipStream_t
-	{
-		if (compute == nullptr) {
-			if (hipStreamCreate(&compute) != hipSuccess) {
-				amrex::Abort("hipStreamCreate (compute stream) failed");
-			}
-		}
-		return compute;
-	}
-	static auto get() -> Runtime &
-	{
-		static Runtime r;
-		return r;
-	}
-};
-inline void check(int rc, const char *what)
-{
-	if (rc != QK_OK) {
-		amrex::Abort(std::string(what) + ": " + qk_last_error(Runtime::get().ctx));
-	}
-}
-inline auto tab(amrex::MultiFab const &mf) -> qk_array4 * { return reinterpret_cast<qk_array4 *>(mf.arrays()); }
-inline auto itab(amrex::iMultiFab const &mf) -> qk_iarray4 * { return reinterpret_cast<qk_iarray4 *>(mf.arrays()); }
-// The temperature hooks of quokka::EOS<problem_t> (reference src/hydro/EOS.hpp:74-244) run on the device in the reference.  A problem that did
-// not specialise them — or specialised them to the Su & Olson material E_int = alpha / 4 T^4 — is recognised on probe points and served by the
-// library's own arithmetic (qk_hydro_traits::eos_temperature_model 0 / 1: shared reciprocals, bit-identical to the CPU oracle); any other
-// specialisation is compiled into the source-term kernel of the problem's translation unit (QK_HOOK_COMPILED, qk_problem_kernels.hpp).
-template <typename problem_t> auto eosTemperatureModel() -> std::pair<int, double>
-{
-	using E = quokka::EOS<problem_t>;
-	const double rs[3] = {1.0, 7.0, 2.0e-7}, Ts[3] = {1.0, 2.0, 3.0e3};
-	bool gammaLaw = true, fourth = true;
-	double const alpha = 4.0 * E::ComputeEintFromTgas(rs[0], Ts[0]);
-	for (double r : rs) {
-		for (double T : Ts) {
-			double const e = E::ComputeEintFromTgas(r, T);
-			gammaLaw = gammaLaw && (e == E::gammaLawEintFromTgas(r, T) || (std::isnan(e) && std::isnan(E::gammaLawEintFromTgas(r, T))));
-			double const want = (alpha / 4.0) * std::pow(T, 4);
-			fourth = fourth && std::abs(e - want) <= 1e-14 * std::abs(want) && std::abs(E::ComputeEintTempDerivative(r, T) - alpha * std::pow(T, 3)) <= 1e-14 * alpha * std::pow(T, 3) &&
-				 std::abs(E::ComputeTgasFromEint(r, e) - T) <= 1e-13 * T;
-		}
-	}
-	if (gammaLaw) {
-		return {0, 0.0};
-	}
-	if (fourth && alpha > 0.0) {
-		return {1, alpha};
-	}
-	// anything else: the problem's compiled hooks (qk_problem_kernels.hpp); the library entry points that would have to evaluate them refuse
-	return {QK_HOOK_COMPILED, 0.0};
-}
-// members a problem's EOS_Traits specialisation may leave out (the reference only reads them in the branches that need them)
-template <typename T, typename = void> struct CsIsoOf {
-	static constexpr double value = std::numeric_limits<double>::quiet_NaN();
-};
-template <typename T> struct CsIsoOf<T, std::void_t<decltype(T::cs_isothermal)>> {
-	static constexpr double value = T::cs_isothermal;
-};
-template <typename T, typename = void> struct MuOf {
-	static constexpr double value = std::numeric_limits<double>::quiet_NaN();
-};
-template <typename T> struct MuOf<T, std::void_t<decltype(T::mean_molecular_weight)>> {
-	static constexpr double value = T::mean_molecular_weight;
-};
-template <typename T, typename = void> struct KbOf {
-	static constexpr double value = C::k_B;
-};
-template <typename T> struct KbOf<T, std::void_t<decltype(T::boltzmann_constant)>> {
-	static constexpr double value = T::boltzmann_constant;
-};
-template <typename problem_t> auto traits() -> qk_hydro_traits
-{
-	return {quokka::EOS_Traits<problem_t>::gamma,
-		CsIsoOf<quokka::EOS_Traits<problem_t>>::value,
-		MuOf<quokka::EOS_Traits<problem_t>>::value,
-		KbOf<quokka::EOS_Traits<problem_t>>::value,
-		HydroSystem_Traits<problem_t>::reconstruct_eint ? 1 : 0,
-		Physics_Traits<problem_t>::numPassiveScalars,
-		Physics_Traits<problem_t>::numMassScalars,
-		AMREX_SPACEDIM,
-		eosTemperatureModel<problem_t>().first,
-		eosTemperatureModel<problem_t>().second};
-}
-} // namespace qkhost
-
-template <typename problem_t> class HyperbolicSystem
-{
-      public:
-	template <FluxDir DIR> static void ReconstructStatesConstant(amrex::MultiFab const &q, amrex::MultiFab &l, amrex::MultiFab &r, int nghost, int nvars)
-	{
-		qkhost::check(qk_ReconstructStatesConstant(qkhost::Runtime::get().lev, nullptr, static_cast<int>(DIR), qkhost::tab(q), qkhost::tab(l), qkhost::tab(r),
-							   nghost, nvars),
-			      "ReconstructStatesConstant");
-	}
-	template <FluxDir DIR, SlopeLimiter limiter>
-	static void ReconstructStatesPLM(amrex::MultiFab const &q, amrex::MultiFab &l, amrex::MultiFab &r, int nghost, int nvars)
-	{
-		qkhost::check(qk_ReconstructStatesPLM(qkhost::Runtime::get().lev, nullptr, static_cast<int>(DIR), static_cast<int>(limiter), qkhost::tab(q),
-						      qkhost::tab(l), qkhost::tab(r), nghost, nvars),
-			      "ReconstructStatesPLM");
-	}
-	template <FluxDir DIR>
-	static void ReconstructStatesPPM(amrex::MultiFab const &q, amrex::MultiFab &l, amrex::MultiFab &r, int nghost, int nvars, int iReadFrom = 0,
-					 int iWriteFrom = 0)
-	{
-		qkhost::check(qk_ReconstructStatesPPM(qkhost::Runtime::get().lev, nullptr, static_cast<int>(DIR), qkhost::tab(q), qkhost::tab(l), qkhost::tab(r), nghost,
-						      nvars, iReadFrom, iWriteFrom),
-			      "ReconstructStatesPPM");
-	}
-};
-
-template <typename problem_t> class HydroSystem : public HyperbolicSystem<problem_t>
-{
-      public:
-	static constexpr int nmscalars_ = Physics_Traits<problem_t>::numMassScalars;
-	static constexpr int nscalars_ = Physics_Traits<problem_t>::numPassiveScalars;
-	static constexpr int nvar_ = Physics_NumVars::numHydroVars + nscalars_;
-	enum consVarIndex { density_index = 0, x1Momentum_index, x2Momentum_index, x3Momentum_index, energy_index, internalEnergy_index, scalar0_index };
-	enum primVarIndex { primDensity_index = 0, x1Velocity_index, x2Velocity_index, x3Velocity_index, pressure_index, primEint_index, primScalar0_index };
-	static constexpr double gamma_ = quokka::EOS_Traits<problem_t>::gamma;
-	static constexpr bool reconstruct_eint = HydroSystem_Traits<problem_t>::reconstruct_eint;
-
-	static auto lev() -> qk_level * { return qkhost::Runtime::get().lev; }
-
-	// per-cell functions problems call inside their own device lambdas (ErrorEst, diagnostics): hydro_system.hpp:349-394, with the direct
-	// gamma-law forms of the library (qk_device.hpp consPressure / Eos::soundSpeed)
-	AMREX_GPU_HOST_DEVICE static auto ComputePressure(amrex::Array4<const amrex::Real> const &cons, int i, int j, int k) -> amrex::Real
-	{
-		const auto rho = cons(i, j, k, density_index);
-		if constexpr (gamma_ == 1.0) {
-			return rho * qkhost::CsIsoOf<quokka::EOS_Traits<problem_t>>::value * qkhost::CsIsoOf<quokka::EOS_Traits<problem_t>>::value;
-		}
-		const auto vx = cons(i, j, k, x1Momentum_index) / rho;
-		const auto vy = cons(i, j, k, x2Momentum_index) / rho;
-		const auto vz = cons(i, j, k, x3Momentum_index) / rho;
-		const auto kinetic_energy = 0.5 * rho * (vx * vx + vy * vy + vz * vz);
-		const auto thermal_energy = cons(i, j, k, energy_index) - kinetic_energy;
-		const auto e = (rho == 0.0) ? 0.0 : thermal_energy / rho;
-		return (gamma_ - 1.0) * rho * e;
-	}
-	// hydro_system.hpp:294-347: primitive <-> conserved state of one cell (boundary functors: NSCBC)
-	AMREX_GPU_HOST_DEVICE static auto ComputePrimVars(amrex::Array4<const amrex::Real> const &cons, int i, int j, int k) -> quokka::valarray<amrex::Real, nvar_>
-	{
-		const auto rho = cons(i, j, k, density_index);
-		const auto vx = cons(i, j, k, x1Momentum_index) / rho;
-		const auto vy = cons(i, j, k, x2Momentum_index) / rho;
-		const auto vz = cons(i, j, k, x3Momentum_index) / rho;
-		quokka::valarray<amrex::Real, nvar_> primVars{rho, vx, vy, vz, ComputePressure(cons, i, j, k), cons(i, j, k, internalEnergy_index)};
-		for (int n = 0; n < nscalars_; ++n) {
-			primVars[primScalar0_index + n] = cons(i, j, k, scalar0_index + n);
-		}
-		return primVars;
-	}
-	AMREX_GPU_HOST_DEVICE static auto ComputeConsVars(quokka::valarray<amrex::Real, nvar_> const &prim) -> quokka::valarray<amrex::Real, nvar_>
-	{
-		amrex::Real const rho = prim[0], v1 = prim[1], v2 = prim[2], v3 = prim[3];
-		amrex::Real const Eint = quokka::EOS<problem_t>::ComputeEintFromPres(rho, prim[4]);
-		amrex::Real const Egas = Eint + 0.5 * rho * (v1 * v1 + v2 * v2 + v3 * v3);
-		quokka::valarray<amrex::Real, nvar_> consVars{rho, rho * v1, rho * v2, rho * v3, Egas, prim[5]};
-		for (int n = 0; n < nscalars_; ++n) {
-			consVars[scalar0_index + n] = prim[primScalar0_index + n];
-		}
-		return consVars;
-	}
-	AMREX_GPU_HOST_DEVICE static auto ComputeSoundSpeed(amrex::Array4<const amrex::Real> const &cons, int i, int j, int k) -> amrex::Real
-	{
-		if constexpr (gamma_ == 1.0) {
-			return qkhost::CsIsoOf<quokka::EOS_Traits<problem_t>>::value;
-		}
-		return std::sqrt(gamma_ * ComputePressure(cons, i, j, k) / cons(i, j, k, density_index));
-	}
-	AMREX_GPU_HOST_DEVICE static auto ComputeVelocityX1(amrex::Array4<const amrex::Real> const &cons, int i, int j, int k) -> amrex::Real
-	{
-		return cons(i, j, k, x1Momentum_index) / cons(i, j, k, density_index);
-	}
-	AMREX_GPU_HOST_DEVICE static auto ComputeVelocityX2(amrex::Array4<const amrex::Real> const &cons, int i, int j, int k) -> amrex::Real
-	{
-		return cons(i, j, k, x2Momentum_index) / cons(i, j, k, density_index);
-	}
-	AMREX_GPU_HOST_DEVICE static auto ComputeVelocityX3(amrex::Array4<const amrex::Real> const &cons, int i, int j, int k) -> amrex::Real
-	{
-		return cons(i, j, k, x3Momentum_index) / cons(i, j, k, density_index);
-	}
-
-	static void ConservedToPrimitive(amrex::MultiFab const &cons, amrex::MultiFab &prim, int nghost)
-	{
-		auto t = qkhost::traits<problem_t>();
-		qkhost::check(qk_hydro_ConservedToPrimitive(lev(), nullptr, &t, qkhost::tab(cons), qkhost::tab(prim), nghost), "ConservedToPrimitive");
-	}
-	template <FluxDir DIR> static void ComputeFlatteningCoefficients(amrex::MultiFab const &prim, amrex::MultiFab &chi, int nghost)
-	{
-		auto t = qkhost::traits<problem_t>();
-		qkhost::check(qk_hydro_ComputeFlatteningCoefficients(lev(), nullptr, &t, static_cast<int>(DIR), qkhost::tab(prim), qkhost::tab(chi), nghost),
-			      "ComputeFlatteningCoefficients");
-	}
-	template <FluxDir DIR>
-	static void FlattenShocks(amrex::MultiFab const &q, amrex::MultiFab const &c1, amrex::MultiFab const &c2, amrex::MultiFab const &c3, amrex::MultiFab &l,
-				  amrex::MultiFab &r, int nghost, int nvars)
-	{
-		auto t = qkhost::traits<problem_t>();
-		qkhost::check(qk_hydro_FlattenShocks(lev(), nullptr, &t, static_cast<int>(DIR), qkhost::tab(q), qkhost::tab(c1), qkhost::tab(c2), qkhost::tab(c3),
-						     qkhost::tab(l), qkhost::tab(r), nghost, nvars),
-			      "FlattenShocks");
-	}
-	template <RiemannSolver RIEMANN, FluxDir DIR>
-	static void ComputeFluxes(amrex::MultiFab &flux, amrex::MultiFab &fvel, amrex::MultiFab const &l, amrex::MultiFab const &r, amrex::MultiFab const &prim,
-				  amrex::Real K_visc)
-	{
-		// (HLLD: the reference's MHD stub — zero magnetic field, hydro_system.hpp:987-1003, :1044-1048)
-		constexpr int riemann = (RIEMANN == RiemannSolver::LLF) ? QK_RIEMANN_LLF : (RIEMANN == RiemannSolver::HLLD) ? QK_RIEMANN_HLLD : QK_RIEMANN_HLLC;
-		auto t = qkhost::traits<problem_t>();
-		qkhost::check(qk_hydro_ComputeFluxes(lev(), nullptr, &t, riemann, static_cast<int>(DIR),
-						     qkhost::tab(flux), qkhost::tab(fvel), qkhost::tab(l), qkhost::tab(r), qkhost::tab(prim), K_visc),
-			      "ComputeFluxes");
-	}
-	static void ComputeRhsFromFluxes(amrex::MultiFab &rhs, std::array<amrex::MultiFab, AMREX_SPACEDIM> const &fluxArray,
-					 amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> dx, int nvars)
-	{
-		auto t = qkhost::traits<problem_t>();
-		const qk_array4 *f[3] = {nullptr, nullptr, nullptr};
-		double d3[3] = {1, 1, 1};
-		for (int d = 0; d < AMREX_SPACEDIM; ++d) {
-			f[d] = qkhost::tab(fluxArray[d]);
-			d3[d] = dx[d];
-		}
-		qkhost::check(qk_hydro_ComputeRhsFromFluxes(lev(), nullptr, &t, qkhost::tab(rhs), f, d3, nvars), "ComputeRhsFromFluxes");
-	}
-	static void AddInternalEnergyPdV(amrex::MultiFab &rhs, amrex::MultiFab const &cons, amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> dx,
-					 std::array<amrex::MultiFab, AMREX_SPACEDIM> const &faceVel, amrex::iMultiFab const &redoFlag)
-	{
-		auto t = qkhost::traits<problem_t>();
-		const qk_array4 *v[3] = {nullptr, nullptr, nullptr};
-		double d3[3] = {1, 1, 1};
-		for (int d = 0; d < AMREX_SPACEDIM; ++d) {
-			v[d] = qkhost::tab(faceVel[d]);
-			d3[d] = dx[d];
-		}
-		qkhost::check(qk_hydro_AddInternalEnergyPdV(lev(), nullptr, &t, qkhost::tab(rhs), qkhost::tab(cons), d3, v, qkhost::itab(redoFlag)),
-			      "AddInternalEnergyPdV");
-	}
-	static void PredictStep(amrex::MultiFab const &old, amrex::MultiFab &neu, amrex::MultiFab const &rhs, double dt, int nvars, amrex::iMultiFab &redoFlag,
-				int64_t *d_redo_count = nullptr)
-	{
-		auto t = qkhost::traits<problem_t>();
-		qkhost::check(qk_hydro_PredictStep(lev(), nullptr, &t, qkhost::tab(old), qkhost::tab(neu), qkhost::tab(rhs), dt, nvars, qkhost::itab(redoFlag),
-						   d_redo_count),
-			      "PredictStep");
-	}
-	static void EnforceLimits(amrex::Real densityFloor, amrex::Real tempFloor, amrex::MultiFab &state)
-	{
-		auto t = qkhost::traits<problem_t>();
-		qkhost::check(qk_hydro_EnforceLimits(lev(), nullptr, &t, densityFloor, tempFloor, qkhost::tab(state)), "EnforceLimits");
-	}
-	static void SyncDualEnergy(amrex::MultiFab &cons, int *d_error_flag = nullptr)
-	{
-		auto t = qkhost::traits<problem_t>();
-		qkhost::check(qk_hydro_SyncDualEnergy(lev(), nullptr, &t, qkhost::tab(cons), d_error_flag), "SyncDualEnergy");
-	}
-	// ParReduce max over the local valid cells (result on the host)
-	static auto maxSignalSpeedLocal(amrex::MultiFab const &cons, int which = 0) -> amrex::Real
-	{
-		auto t = qkhost::traits<problem_t>();
-		static double *d_res = nullptr;
-		if (d_res == nullptr) {
-			QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_res), sizeof(double)));
-		}
-		qkhost::check(qk_hydro_maxSignalSpeedLocal(lev(), nullptr, &t, which, qkhost::tab(cons), d_res), "maxSignalSpeedLocal");
-		double h = 0;
-		QK_HOST_HIP(hipMemcpy(&h, d_res, sizeof(double), hipMemcpyDeviceToHost));
-		return qkhost::Comm::get().allReduceMax(h); // ParallelDescriptor::ReduceRealMax (reference src/simulation.hpp:1003)
-	}
-};
-
-// physical constants in CGS units, as problem files name them (reference src/radiation/radiation_system.hpp:58-61)
-static constexpr double c_light_cgs_ = C::c_light;
-static constexpr double radiation_constant_cgs_ = C::a_rad;
-static constexpr double inf = std::numeric_limits<double>::max();
-
-// this struct is specialized by the user application code (reference src/radiation/radiation_system.hpp:73-82)
-// radiation_system.hpp:63-70
-enum class OpacityModel { single_group = 0, piecewise_constant_opacity, PPL_opacity_fixed_slope_spectrum, PPL_opacity_full_spectrum };
-
-// radiation_system.hpp:86-90
-template <typename problem_t> struct ISM_Traits {
-	static constexpr bool enable_dust_gas_thermal_coupling_model = false;
-	static constexpr bool enable_photoelectric_heating = false;
-	static constexpr double gas_dust_coupling_threshold = 1.0e-6;
-};
-
-template <typename problem_t> struct RadSystem_Traits {
-	static constexpr double c_light = c_light_cgs_;
-	static constexpr double c_hat = c_light_cgs_;
-	static constexpr double radiation_constant = radiation_constant_cgs_;
-	static constexpr double Erad_floor = 0.;
-	static constexpr double energy_unit = C::ev2erg;
-	static constexpr amrex::GpuArray<double, Physics_Traits<problem_t>::nGroups + 1> radBoundaries = {0., inf};
-	static constexpr double beta_order = 1;
-	static constexpr OpacityModel opacity_model = OpacityModel::single_group;
-};
-
-// members a specialisation of RadSystem_Traits may leave out (reference radiation_system.hpp:147-154 does this for opacity_model)
-namespace qkhost
-{
-template <typename P, typename = void> struct RadHasOpacityModel : std::false_type {
-};
-template <typename P> struct RadHasOpacityModel<P, std::void_t<decltype(RadSystem_Traits<P>::opacity_model)>> : std::true_type {
-};
-template <typename P, typename = void> struct RadHasEnergyUnit : std::false_type {
-};
-template <typename P> struct RadHasEnergyUnit<P, std::void_t<decltype(RadSystem_Traits<P>::energy_unit)>> : std::true_type {
-};
-template <typename P> constexpr auto radEnergyUnit() -> double
-{
-	if constexpr (RadHasEnergyUnit<P>::value) {
-		return RadSystem_Traits<P>::energy_unit;
-	} else {
-		return C::ev2erg;
-	}
-}
-} // namespace qkhost
-template <typename problem_t> using RadSystem_Has_Opacity_Model = qkhost::RadHasOpacityModel<problem_t>;
-
-// RadSystem<problem_t>: indices, constants, the problem's device hooks and the operators of the radiation update, each ONE
-// call into the C-ABI (reference src/radiation/radiation_system.hpp:150-330).  Single group, OpacityModel::single_group.
-template <typename problem_t> class RadSystem;
-#include "qk_problem_kernels.hpp" // the source-term kernel instantiated with this problem's compiled hooks
-
-template <typename problem_t> class RadSystem : public HyperbolicSystem<problem_t>
-{
-      public:
-	using array_t = amrex::Array4<amrex::Real>;
-	using arrayconst_t = amrex::Array4<const amrex::Real>;
-	enum gasVarIndex { gasDensity_index = 0, x1GasMomentum_index, x2GasMomentum_index, x3GasMomentum_index, gasEnergy_index, gasInternalEnergy_index, scalar0_index };
-	static constexpr int nvarHyperbolic_ = Physics_NumVars::numRadVars * Physics_Traits<problem_t>::nGroups;
-	static constexpr int nstartHyperbolic_ = Physics_Indices<problem_t>::radFirstIndex;
-	static constexpr int nvar_ = nstartHyperbolic_ + nvarHyperbolic_;
-	enum radVarIndex { radEnergy_index = nstartHyperbolic_, x1RadFlux_index, x2RadFlux_index, x3RadFlux_index };
-
-	static constexpr double c_light_ = RadSystem_Traits<problem_t>::c_light;
-	static constexpr double c_hat_ = RadSystem_Traits<problem_t>::c_hat;
-	static constexpr double radiation_constant_ = RadSystem_Traits<problem_t>::radiation_constant;
-	static constexpr int beta_order_ = static_cast<int>(RadSystem_Traits<problem_t>::beta_order);
-	static constexpr int numRadVars_ = Physics_NumVars::numRadVars;
-	static constexpr int nmscalars_ = Physics_Traits<problem_t>::numMassScalars;
-	enum primVarIndex { primRadEnergy_index = 0, x1ReducedFlux_index, x2ReducedFlux_index, x3ReducedFlux_index };
-
-	// :195-231
-	static constexpr bool enable_dust_gas_thermal_coupling_model_ = ISM_Traits<problem_t>::enable_dust_gas_thermal_coupling_model;
-	static constexpr bool enable_photoelectric_heating_ = ISM_Traits<problem_t>::enable_photoelectric_heating;
-	static constexpr int nGroups_ = Physics_Traits<problem_t>::nGroups;
-	static constexpr amrex::GpuArray<double, nGroups_ + 1> radBoundaries_ = []() constexpr {
-		if constexpr (nGroups_ > 1) {
-			return RadSystem_Traits<problem_t>::radBoundaries;
-		} else {
-			amrex::GpuArray<double, 2> boundaries{0., inf};
-			return boundaries;
-		}
-	}();
-	static constexpr double Erad_floor_ = RadSystem_Traits<problem_t>::Erad_floor / nGroups_;
-	static constexpr OpacityModel opacity_model_ = []() constexpr {
-		if constexpr (RadSystem_Has_Opacity_Model<problem_t>::value) {
-			return RadSystem_Traits<problem_t>::opacity_model;
-		} else {
-			return OpacityModel::single_group;
-		}
-	}();
-	static_assert(((nGroups_ > 1 && opacity_model_ != OpacityModel::single_group) || (nGroups_ == 1 && opacity_model_ == OpacityModel::single_group)),
-		      "OpacityModel::single_group MUST be used when nGroups_ == 1. If nGroups_ > 1, you MUST set opacity_model.");
-	static_assert(!(nGroups_ < 3 && opacity_model_ == OpacityModel::PPL_opacity_full_spectrum), "PPL_opacity_full_spectrum requires at least 3 photon groups.");
-	static constexpr double mean_molecular_mass_ = quokka::EOS_Traits<problem_t>::mean_molecular_weight;
-	static constexpr double boltzmann_constant_ = quokka::EOS_Traits<problem_t>::boltzmann_constant;
-	static constexpr double gamma_ = quokka::EOS_Traits<problem_t>::gamma;
-	static constexpr double energy_unit_ = qkhost::radEnergyUnit<problem_t>();
-
-	// device hooks a problem may specialise (:1141-1167, :471-513, :582-587)
-	// multigroup: exponents and lower values of the piecewise power-law opacity at the group edges (default: NaN, :1155-1167)
-	AMREX_GPU_HOST_DEVICE static auto DefineOpacityExponentsAndLowerValues(amrex::GpuArray<double, nGroups_ + 1> rad_boundaries, double rho, double Tgas)
-	    -> amrex::GpuArray<amrex::GpuArray<double, nGroups_ + 1>, 2>;
-	AMREX_GPU_HOST_DEVICE static auto ComputeThermalRadiationSingleGroup(amrex::Real temperature) -> amrex::Real;
-	AMREX_GPU_HOST_DEVICE static auto ComputeThermalRadiationTempDerivativeSingleGroup(amrex::Real temperature) -> amrex::Real;
-	// :430-461: energy fractions of a Planck spectrum in the groups (what problem files call for initial and boundary states)
-	AMREX_GPU_HOST_DEVICE static auto ComputePlanckEnergyFractions(amrex::GpuArray<double, nGroups_ + 1> const &boundaries, amrex::Real temperature)
-	    -> quokka::valarray<amrex::Real, nGroups_>
-	{
-		quokka::valarray<amrex::Real, nGroups_> radEnergyFractions{};
-		if constexpr (nGroups_ == 1) {
-			radEnergyFractions[0] = 1.0;
-			return radEnergyFractions;
-		} else {
-			amrex::Real const energy_unit_over_kT = energy_unit_ / (boltzmann_constant_ * temperature);
-			amrex::Real y = NAN;
-			amrex::Real previous = 0.0;
-			for (int g = 0; g < nGroups_ - 1; ++g) {
-				const amrex::Real x = boundaries[g + 1] * energy_unit_over_kT;
-				y = (x >= 100.) ? 1.0 : integrate_planck_from_0_to_x(x);
-				radEnergyFractions[g] = y - previous;
-				previous = y;
-			}
-			y = 1.0;
-			radEnergyFractions[nGroups_ - 1] = y - previous;
-			return radEnergyFractions;
-		}
-	}
-	// :483-497
-	AMREX_GPU_HOST_DEVICE static auto ComputeThermalRadiationMultiGroup(amrex::Real temperature, amrex::GpuArray<double, nGroups_ + 1> const &boundaries)
-	    -> quokka::valarray<amrex::Real, nGroups_>
-	{
-		const double power = radiation_constant_ * std::pow(temperature, 4);
-		const auto radEnergyFractions = ComputePlanckEnergyFractions(boundaries, temperature);
-		auto Erad_g = power * radEnergyFractions;
-		for (int g = 0; g < nGroups_; ++g) {
-			if (Erad_g[g] < Erad_floor_) {
-				Erad_g[g] = Erad_floor_;
-			}
-		}
-		return Erad_g;
-	}
-	// :505-513
-	AMREX_GPU_HOST_DEVICE static auto ComputeThermalRadiationTempDerivativeMultiGroup(amrex::Real temperature,
-											  amrex::GpuArray<double, nGroups_ + 1> const &boundaries)
-	    -> quokka::valarray<amrex::Real, nGroups_>
-	{
-		auto radEnergyFractions = ComputePlanckEnergyFractions(boundaries, temperature);
-		double d_power_dt = 4. * radiation_constant_ * std::pow(temperature, 3);
-		return d_power_dt * radEnergyFractions;
-	}
-	// :1311-1326 (4 pi B(nu) / c)
-	AMREX_GPU_HOST_DEVICE static auto PlanckFunction(const double nu, const double T) -> double
-	{
-		double const coeff = energy_unit_ / (boltzmann_constant_ * T);
-		double const x = coeff * nu;
-		if (x > 100.) {
-			return 0.0;
-		}
-		double const planck_integral = (x <= 1.0e-10) ? x * x - x * x * x / 2. : std::pow(x, 3) / (std::exp(x) - 1.0);
-		return coeff / (std::pow(PI, 4) / 15.0) * (radiation_constant_ * std::pow(T, 4)) * planck_integral;
-	}
-	// :1367-1385: the radiation flux of each group in the diffusion limit for gas moving at `vel`
-	AMREX_GPU_HOST_DEVICE static auto ComputeFluxInDiffusionLimit(const amrex::GpuArray<double, nGroups_ + 1> rad_boundaries, const double T, const double vel)
-	    -> amrex::GpuArray<double, nGroups_>
-	{
-		double const coeff = energy_unit_ / (boltzmann_constant_ * T);
-		amrex::GpuArray<double, nGroups_ + 1> edge_values{};
-		amrex::GpuArray<double, nGroups_> flux{};
-		for (int g = 0; g < nGroups_ + 1; ++g) {
-			auto x = coeff * rad_boundaries[g];
-			edge_values[g] = 4. / 3. * integrate_planck_from_0_to_x(x) - 1. / 3. * x * (std::pow(x, 3) / (std::exp(x) - 1.0)) / gInf;
-		}
-		for (int g = 0; g < nGroups_; ++g) {
-			flux[g] = vel * radiation_constant_ * std::pow(T, 4) * (edge_values[g + 1] - edge_values[g]);
-		}
-		return flux;
-	}
-	// :1354-1365
-	AMREX_GPU_HOST_DEVICE static auto ComputeBinCenterOpacity(amrex::GpuArray<double, nGroups_ + 1> rad_boundaries,
-								  amrex::GpuArray<amrex::GpuArray<double, nGroups_ + 1>, 2> kappa_expo_and_lower_value)
-	    -> quokka::valarray<double, nGroups_>
-	{
-		quokka::valarray<double, nGroups_> kappa_center{};
-		for (int g = 0; g < nGroups_; ++g) {
-			kappa_center[g] = kappa_expo_and_lower_value[1][g] * std::pow(rad_boundaries[g + 1] / rad_boundaries[g], 0.5 * kappa_expo_and_lower_value[0][g]);
-		}
-		return kappa_center;
-	}
-	// radiation_system.hpp:1289-1308
-	AMREX_GPU_HOST_DEVICE static auto ComputeEintFromEgas(double density, double X1GasMom, double X2GasMom, double X3GasMom, double Etot) -> double
-	{
-		const double p_sq = X1GasMom * X1GasMom + X2GasMom * X2GasMom + X3GasMom * X3GasMom;
-		return Etot - p_sq / (2.0 * density);
-	}
-	AMREX_GPU_HOST_DEVICE static auto ComputeEgasFromEint(double density, double X1GasMom, double X2GasMom, double X3GasMom, double Eint) -> double
-	{
-		const double p_sq = X1GasMom * X1GasMom + X2GasMom * X2GasMom + X3GasMom * X3GasMom;
-		return Eint + p_sq / (2.0 * density);
-	}
-	AMREX_GPU_HOST_DEVICE static auto ComputePlanckOpacity(double rho, double Tgas) -> amrex::Real;
-	// the ISM heating / cooling hooks (radiation_system.hpp:344-353; defaults zero, :524-545 and radiation_dust_system.hpp:7-12)
-	AMREX_GPU_HOST_DEVICE static auto DefinePhotoelectricHeatingE1Derivative(amrex::Real temperature, amrex::Real num_density) -> amrex::Real;
-	AMREX_GPU_HOST_DEVICE static auto DefineNetCoolingRate(amrex::Real temperature, amrex::Real num_density) -> quokka::valarray<double, nGroups_>;
-	AMREX_GPU_HOST_DEVICE static auto DefineNetCoolingRateTempDerivative(amrex::Real temperature, amrex::Real num_density) -> quokka::valarray<double, nGroups_>;
-	AMREX_GPU_HOST_DEVICE static auto DefineCosmicRayHeatingRate(amrex::Real num_density) -> double;
-	// ... sampled on the host into the closed set of qk_rad_traits (cooling linear in T, the two heating rates constant); aborts otherwise
-	static void ismHooks(qk_rad_traits &rt)
-	{
-		auto close = [](double a, double b) { return a == b || std::abs(a - b) <= 1e-13 * std::abs(b); };
-		bool ok = true, any = false;
-		auto const c1 = DefineNetCoolingRate(1.0, 1.0);
-		double const cr = DefineCosmicRayHeatingRate(1.0);
-		double const pe = DefinePhotoelectricHeatingE1Derivative(1.0, 1.0);
-		for (int g = 0; g < nGroups_; ++g) {
-			rt.cooling_linear_coeff[g] = c1[g];
-			any = any || c1[g] != 0.0;
-		}
-		for (double T : {0.3, 7.0, 4.0e4}) {
-			for (double n : {1.0e-3, 1.0, 5.0e7}) {
-				auto const c = DefineNetCoolingRate(T, n);
-				auto const d = DefineNetCoolingRateTempDerivative(T, n);
-				for (int g = 0; g < nGroups_; ++g) {
-					ok = ok && close(c[g], c1[g] * T) && close(d[g], c1[g]);
-				}
-				ok = ok && DefineCosmicRayHeatingRate(n) == cr && DefinePhotoelectricHeatingE1Derivative(T, n) == pe;
-			}
-		}
-		if (!ok) {
-			amrex::Abort("RadSystem: the DefineNetCoolingRate / DefineCosmicRayHeatingRate / DefinePhotoelectricHeatingE1Derivative hooks are not in "
-				     "the C-ABI's closed set (cooling linear in T, constant heating rates)");
-		}
-		rt.cr_heating_rate = cr;
-		rt.enable_photoelectric_heating = enable_photoelectric_heating_ ? 1 : 0;
-		rt.pe_heating_E1_derivative = enable_photoelectric_heating_ ? pe : 0.0;
-		if ((any || cr != 0.0 || enable_photoelectric_heating_) && !enable_dust_gas_thermal_coupling_model_) {
-			amrex::Abort("RadSystem: the ISM heating / cooling hooks are carried by the C-ABI together with the dust model only");
-		}
-		if (enable_photoelectric_heating_ && nGroups_ == 1) {
-			amrex::Abort("RadSystem: photoelectric heating is a multigroup model (radiation_dust_system.hpp)");
-		}
-	}
-	AMREX_GPU_HOST_DEVICE static auto ComputeFluxMeanOpacity(double rho, double Tgas) -> amrex::Real;
-	AMREX_GPU_HOST_DEVICE static auto ComputeEnergyMeanOpacity(double rho, double Tgas) -> amrex::Real;
-	AMREX_GPU_HOST_DEVICE static auto ComputeEddingtonFactor(double f) -> double; // :773-790 (default: Levermore closure)
-	static void SetRadEnergySource(array_t &radEnergySource, amrex::Box const &indexRange, amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> const &dx,
-				       amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> const &prob_lo, amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> const &prob_hi,
-				       amrex::Real time);
-
-	// The opacity and closure hooks run on the device in the reference; the C-ABI carries them as a closed, parametrised set
-	// (opacity model 0: constants, model 1: kappa = k0 / rho; closure 0: Levermore, 1: chi = 1/3).  The hooks are sampled on the host:
-	// anything outside the set is refused, never approximated.
-	// closure hook -> closed set (0: Levermore, 1: chi = 1/3); pow_mode from the deck
-	static auto closureAndPowMode(int &eddington_model, int &pow_mode) -> void
-	{
-		bool lev = true, third = true;
-		for (double f : {0.0, 0.3, 0.77, 1.0}) {
-			double const ff = std::sqrt(4.0 - 3.0 * (f * f));
-			lev = lev && ComputeEddingtonFactor(f) == (3.0 + 4.0 * (f * f)) / (5.0 + 2.0 * ff);
-			third = third && ComputeEddingtonFactor(f) == (1. / 3.);
-		}
-		eddington_model = lev ? 0 : (third ? 1 : -1);
-		if (eddington_model < 0) {
-			amrex::Abort("RadSystem: ComputeEddingtonFactor is neither the Levermore closure nor the Eddington approximation");
-		}
-		pow_mode = 0;
-		amrex::ParmParse pp("radiation");
-		pp.query("pow_mode", pow_mode); // 0: pow(T, 4) like the reference's std::pow; 1: repeated multiplication
-	}
-
-	// Multigroup: RadSystem_Traits::radBoundaries / energy_unit / opacity_model and the DefineOpacityExponentsAndLowerValues hook sampled on
-	// the host into the C-ABI's closed set (exponent per edge; lower value = k_g rho^a (T / 1 K)^b with a in {0, -1}); anything else is refused.
-	static auto multigroupTraits() -> qk_rad_traits
-	{
-		static_assert(nGroups_ <= QK_MAX_GROUPS, "at most QK_MAX_GROUPS photon groups");
-		qk_rad_traits rt{};
-		rt.c_light = c_light_;
-		rt.c_hat = c_hat_;
-		rt.radiation_constant = radiation_constant_;
-		rt.Erad_floor = RadSystem_Traits<problem_t>::Erad_floor;
-		rt.beta_order = beta_order_;
-		closureAndPowMode(rt.eddington_model, rt.pow_mode);
-		rt.ngroups = nGroups_;
-		rt.mg_opacity_model = static_cast<int>(opacity_model_);
-		rt.energy_unit = energy_unit_;
-		for (int g = 0; g < nGroups_ + 1; ++g) {
-			rt.rad_boundaries[g] = radBoundaries_[g];
-		}
-		const bool pc = (opacity_model_ == OpacityModel::piecewise_constant_opacity); // (its last edge entry is never read and may be unset)
-		const int nedge = pc ? nGroups_ : nGroups_ + 1;
-		const double r0 = 1.0, T0 = 1.0e3;
-		auto const base = DefineOpacityExponentsAndLowerValues(radBoundaries_, r0, T0);
-		auto close = [](double a, double b) { return a == b || std::abs(a - b) <= 1e-12 * std::abs(b); };
-		// density exponent: 0 or -1; temperature exponent: nearest multiple of 1/2 of the sampled slope
-		auto const r2 = DefineOpacityExponentsAndLowerValues(radBoundaries_, 2.0 * r0, T0);
-		auto const T2 = DefineOpacityExponentsAndLowerValues(radBoundaries_, r0, 1.0e6);
-		int e = 0; // the probe: the first edge with a non-zero lower value (all zero — a transparent medium — is the constant 0)
-		while (e < nedge - 1 && base[1][e] == 0.0) {
-			++e;
-		}
-		double a = std::numeric_limits<double>::quiet_NaN();
-		if (close(r2[1][e], base[1][e])) {
-			a = 0.0;
-		} else if (close(r2[1][e], 0.5 * base[1][e])) {
-			a = -1.0;
-		}
-		const double slope = (base[1][e] == 0.0 && T2[1][e] == 0.0) ? 0.0 : std::log(T2[1][e] / base[1][e]) / std::log(1.0e6 / T0);
-		const double b = std::round(2.0 * slope) / 2.0;
-		bool ok = std::isfinite(a) && std::isfinite(b) && std::abs(slope - b) < 1e-9;
-		rt.mg_kappa_rho_exponent = a;
-		rt.mg_kappa_T_ref = 1.0;
-		rt.mg_kappa_T_exponent = b;
-		for (int g = 0; g < nedge && ok; ++g) {
-			rt.mg_kappa_exponent[g] = base[0][g];
-			rt.mg_kappa_lower[g] = base[1][g] / (std::pow(r0, a) * std::pow(T0, b));
-		}
-		for (double r : {1.0, 1.0e-24, 3.7e-19, 2.0e-3}) {
-			for (double T : {3.0, 1.1e3, 4.0e7}) {
-				auto const v = DefineOpacityExponentsAndLowerValues(radBoundaries_, r, T);
-				for (int g = 0; g < nedge && ok; ++g) {
-					const double expect = (a == -1.0 && b == 0.0) ? rt.mg_kappa_lower[g] / r
-									     : (a == 0.0 && b == 0.0) ? rt.mg_kappa_lower[g]
-												       : rt.mg_kappa_lower[g] * std::pow(r, a) * std::pow(T, b);
-					ok = ok && v[0][g] == base[0][g] && close(v[1][g], expect);
-				}
-			}
-		}
-		int force_compiled = 0; // deck `qk.mg_compiled_hook = 1`: the compiled hook also where the closed set would do (tests: same bits)
-		amrex::ParmParse("qk").query("mg_compiled_hook", force_compiled);
-		if (!ok || force_compiled != 0) {
-			// not in the closed set (e.g. exponents that follow the temperature, RadhydroPulseMGint): the hook itself is compiled into the
-			// source-term kernel of this translation unit (qk_problem_kernels.hpp: ProblemRadMG); the library's entry refuses this value
-			rt.opacity_model = QK_HOOK_COMPILED;
-			rt.mg_kappa_rho_exponent = 0.0;
-			rt.mg_kappa_T_exponent = 0.0;
-			for (int g = 0; g < nGroups_ + 1; ++g) {
-				rt.mg_kappa_exponent[g] = 0.0;
-				rt.mg_kappa_lower[g] = 0.0;
-			}
-		}
-		// the thermal-emission hooks (:483-497, :505-513): the defaults, or RadDustMG's linearised a T / a (test_rad_dust_MG.cpp:83-104)
-		{
-			bool quartic = true, linear = true;
-			for (double T : {0.7, 3.0e2, 4.0e6}) {
-				auto const e = ComputeThermalRadiationMultiGroup(T, radBoundaries_);
-				auto const d = ComputeThermalRadiationTempDerivativeMultiGroup(T, radBoundaries_);
-				auto const f = ComputePlanckEnergyFractions(radBoundaries_, T);
-				for (int g = 0; g < nGroups_; ++g) {
-					quartic = quartic && e[g] == std::max(radiation_constant_ * std::pow(T, 4) * f[g], Erad_floor_) &&
-						  d[g] == 4. * radiation_constant_ * std::pow(T, 3) * f[g];
-					linear = linear && e[g] == radiation_constant_ * T * f[g] && d[g] == radiation_constant_ * f[g];
-				}
-			}
-			if (!quartic && !linear) {
-				amrex::Abort("RadSystem: the ComputeThermalRadiationMultiGroup hooks are neither a T^4 nor RadDustMG's linearised a T");
-			}
-			rt.thermal_model = quartic ? 0 : 1;
-		}
-		if (enable_dust_gas_thermal_coupling_model_) { // radiation_dust_system.hpp; the coefficient is QuokkaSimulation::dustGasInteractionCoeff_
-			rt.enable_dust_gas_thermal_coupling_model = 1;
-			rt.gas_dust_coupling_threshold = ISM_Traits<problem_t>::gas_dust_coupling_threshold;
-			rt.dust_gas_interaction_coeff = 2.5e-34;
-			amrex::ParmParse rpp("radiation");
-			rpp.query("dust_gas_interaction_coeff", rt.dust_gas_interaction_coeff);
-		} else if (rt.thermal_model != 0) {
-			amrex::Abort("RadSystem: the linearised thermal-emission hook is carried by the C-ABI together with the dust model only");
-		}
-		ismHooks(rt);
-		return rt;
-	}
-
-	static auto traits() -> qk_rad_traits
-	{
-		if constexpr (nGroups_ > 1) {
-			return multigroupTraits();
-		}
-		// Single group: the opacity hooks are compiled into the source-term kernel of this translation unit (qk_problem_kernels.hpp): nothing to
-		// describe to the library, whose transport operators never evaluate an opacity.
-		int eddington_model = -1, pow_mode = 0;
-		closureAndPowMode(eddington_model, pow_mode);
-		double const nan = std::numeric_limits<double>::quiet_NaN();
-		qk_rad_traits rt{c_light_, c_hat_, radiation_constant_, Erad_floor_, beta_order_, QK_HOOK_COMPILED, nan, nan, nan, pow_mode, eddington_model, 0.0, 0.0, 0.0};
-		// the thermal-emission hooks (:471-479, :499-503): a problem that did not specialise them gets the library's a T^4 (floored) / 4 a T^3,
-		// which honours radiation.pow_mode — recognised by exact agreement with the defining formula on probe points; anything else is the
-		// problem's compiled hook
-		{
-			bool quartic = true;
-			for (double T : {0.7, 3.0e2, 4.0e6}) {
-				const double e = ComputeThermalRadiationSingleGroup(T), d = ComputeThermalRadiationTempDerivativeSingleGroup(T);
-				quartic = quartic && e == std::max(radiation_constant_ * std::pow(T, 4), Erad_floor_) && d == 4. * radiation_constant_ * std::pow(T, 3);
-			}
-			rt.thermal_model = quartic ? 0 : QK_HOOK_COMPILED;
-		}
-		if (enable_dust_gas_thermal_coupling_model_) { // ISM_Traits; the coefficient is QuokkaSimulation::dustGasInteractionCoeff_ (QuokkaSimulation.hpp:127, :392)
-			rt.enable_dust_gas_thermal_coupling_model = 1;
-			rt.dust_gas_interaction_coeff = 2.5e-34;
-			amrex::ParmParse rpp("radiation");
-			rpp.query("dust_gas_interaction_coeff", rt.dust_gas_interaction_coeff);
-		}
-		return rt; // (the ISM heating / cooling hooks of the single-group source term are compiled as well)
-	}
-	static auto lev() -> qk_level * { return qkhost::Runtime::get().lev; }
-	static void flux3(std::array<amrex::MultiFab, AMREX_SPACEDIM> const &f, qk_array4 *out[3])
-	{
-		for (int d = 0; d < 3; ++d) {
-			out[d] = (d < AMREX_SPACEDIM) ? qkhost::tab(f[d]) : nullptr;
-		}
-	}
-	static void dx3(amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> const &dx, double out[3])
-	{
-		for (int d = 0; d < 3; ++d) {
-			out[d] = (d < AMREX_SPACEDIM) ? dx[d] : 1.0;
-		}
-	}
-
-	// computeRadiationFluxes + fluxFunction<DIR> (reference src/QuokkaSimulation.hpp:1884-1961): cons -> prim, reconstruction, HLL
-	static void computeRadiationFluxes(amrex::MultiFab const &consVar, std::array<amrex::MultiFab, AMREX_SPACEDIM> &flux, int reconstructionOrder)
-	{
-		auto rt = traits();
-		qk_array4 *f[3];
-		flux3(flux, f);
-		qkhost::check(qk_rad_computeRadiationFluxes(lev(), nullptr, &rt, AMREX_SPACEDIM, reconstructionOrder, qkhost::tab(consVar), f),
-			      "RadSystem::computeRadiationFluxes");
-	}
-	// :667-710
-	static void PredictStep(amrex::MultiFab const &consVarOld, amrex::MultiFab &consVarNew, std::array<amrex::MultiFab, AMREX_SPACEDIM> const &fluxArray,
-				double dt, amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> dx)
-	{
-		auto rt = traits();
-		qk_array4 *f[3];
-		double d3[3];
-		flux3(fluxArray, f);
-		dx3(dx, d3);
-		qkhost::check(qk_rad_PredictStep(lev(), nullptr, &rt, AMREX_SPACEDIM, qkhost::tab(consVarOld), qkhost::tab(consVarNew), f, dt, d3),
-			      "RadSystem::PredictStep");
-	}
-	// one transport stage with the flux divergence taken inside the flux kernels (qk_rad_stage_fused): computeRadiationFluxes(U_in) +
-	// PredictStep (stage 1) / AddFluxesRK2 (stage 2); `fluxOut`: where the face fluxes are stored, or nullptr when nothing reads them
-	static void stageFused(int stage, int order, amrex::MultiFab const &U_in, amrex::MultiFab const &U0, amrex::MultiFab &U_new, amrex::MultiFab &acc,
-			       std::array<amrex::MultiFab, AMREX_SPACEDIM> *fluxOut, double dt, amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> dx)
-	{
-		auto rt = traits();
-		qk_array4 *f[3] = {nullptr, nullptr, nullptr};
-		double d3[3];
-		if (fluxOut != nullptr) {
-			flux3(*fluxOut, f);
-		}
-		dx3(dx, d3);
-		qkhost::check(qk_rad_stage_fused(lev(), nullptr, &rt, order, stage, qkhost::tab(U_in), qkhost::tab(U0), qkhost::tab(U_new), qkhost::tab(acc),
-						 fluxOut != nullptr ? f : nullptr, dt, d3),
-			      "RadSystem::stageFused");
-	}
-	// :712-771
-	static void AddFluxesRK2(amrex::MultiFab &U_new, amrex::MultiFab const &U0, amrex::MultiFab const &U1,
-				 std::array<amrex::MultiFab, AMREX_SPACEDIM> const &fluxArrayOld, std::array<amrex::MultiFab, AMREX_SPACEDIM> const &fluxArray, double dt,
-				 amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> dx)
-	{
-		auto rt = traits();
-		qk_array4 *f0[3], *f1[3];
-		double d3[3];
-		flux3(fluxArrayOld, f0);
-		flux3(fluxArray, f1);
-		dx3(dx, d3);
-		qkhost::check(qk_rad_AddFluxesRK2(lev(), nullptr, &rt, AMREX_SPACEDIM, qkhost::tab(U_new), qkhost::tab(U0), qkhost::tab(U1), f0, f1, dt, d3),
-			      "RadSystem::AddFluxesRK2");
-	}
-	// src/radiation/source_terms_single_group.hpp:10-564
-	// mirror (an extension of this host): the new radiation components of the valid cells are stored there too — the swapRadiationState() of the
-	// next substep from the registers of this kernel (include/quokka_amd.h: qk_rad_AddSourceTermsSingleGroupMirror)
-	static void AddSourceTermsSingleGroup(amrex::MultiFab &consVar, amrex::MultiFab const &radEnergySource, double dt, int stage, int *p_iteration_counter,
-					      int *p_iteration_failure_counter, amrex::MultiFab *mirror = nullptr)
-	{
-		auto rt = traits();
-		auto t = qkhost::traits<problem_t>();
-		// the kernel is instantiated HERE, with this problem's compiled opacity / emission / EOS / ISM hooks (qk_problem_kernels.hpp)
-		qkhost::check(qkhost::addSourceTermsSingleGroup<problem_t>(lev(), &rt, &t, qkhost::tab(consVar), qkhost::tab(radEnergySource), dt, stage,
-									    p_iteration_counter, p_iteration_failure_counter,
-									    mirror != nullptr ? qkhost::tab(*mirror) : nullptr),
-			      "RadSystem::AddSourceTermsSingleGroup");
-	}
-	// src/radiation/source_terms_multi_group.hpp:522-813
-	static void AddSourceTermsMultiGroup(amrex::MultiFab &consVar, amrex::MultiFab const &radEnergySource, double dt, int stage, int *p_iteration_counter,
-					     int *p_iteration_failure_counter)
-	{
-		auto rt = traits();
-		auto t = qkhost::traits<problem_t>();
-		if (rt.opacity_model == QK_HOOK_COMPILED) { // the kernel is instantiated HERE, with this problem's DefineOpacityExponentsAndLowerValues
-			qkhost::check(qkhost::addSourceTermsMultiGroup<problem_t>(lev(), &rt, &t, qkhost::tab(consVar), qkhost::tab(radEnergySource), dt, stage,
-										   p_iteration_counter, p_iteration_failure_counter),
-				      "RadSystem::AddSourceTermsMultiGroup (compiled opacity hook)");
-			return;
-		}
-		qkhost::check(qk_rad_AddSourceTermsMultiGroup(lev(), nullptr, &rt, &t, qkhost::tab(consVar), qkhost::tab(radEnergySource), dt, stage,
-							      p_iteration_counter, p_iteration_failure_counter),
-			      "RadSystem::AddSourceTermsMultiGroup");
-	}
-};
-
-// the defaults of the hooks (reference radiation_system.hpp:471-479, :499-503, :1155-1167)
-template <typename problem_t> AMREX_GPU_HOST_DEVICE auto RadSystem<problem_t>::ComputeThermalRadiationSingleGroup(amrex::Real temperature) -> amrex::Real
-{
-	double power = radiation_constant_ * std::pow(temperature, 4);
-	if (power < Erad_floor_) {
-		power = Erad_floor_;
-	}
-	return power;
-}
-template <typename problem_t> AMREX_GPU_HOST_DEVICE auto RadSystem<problem_t>::ComputeThermalRadiationTempDerivativeSingleGroup(amrex::Real temperature) -> amrex::Real
-{
-	return 4. * radiation_constant_ * std::pow(temperature, 3);
-}
-template <typename problem_t>
-AMREX_GPU_HOST_DEVICE auto RadSystem<problem_t>::DefineOpacityExponentsAndLowerValues(amrex::GpuArray<double, nGroups_ + 1> /*rad_boundaries*/, const double /*rho*/,
-										      const double /*Tgas*/) -> amrex::GpuArray<amrex::GpuArray<double, nGroups_ + 1>, 2>
-{
-	amrex::GpuArray<amrex::GpuArray<double, nGroups_ + 1>, 2> exponents_and_values{};
-	for (int g = 0; g < nGroups_ + 1; ++g) {
-		exponents_and_values[0][g] = NAN;
-		exponents_and_values[1][g] = NAN;
-	}
-	return exponents_and_values;
-}
-
-template <typename problem_t>
-AMREX_GPU_HOST_DEVICE auto RadSystem<problem_t>::DefinePhotoelectricHeatingE1Derivative(amrex::Real const /*temperature*/, amrex::Real const /*num_density*/) -> amrex::Real
-{
-	return 0.0;
-}
-template <typename problem_t>
-AMREX_GPU_HOST_DEVICE auto RadSystem<problem_t>::DefineNetCoolingRate(amrex::Real const /*temperature*/, amrex::Real const /*num_density*/)
-    -> quokka::valarray<double, nGroups_>
-{
-	quokka::valarray<double, nGroups_> cooling{};
-	cooling.fillin(0.0);
-	return cooling;
-}
-template <typename problem_t>
-AMREX_GPU_HOST_DEVICE auto RadSystem<problem_t>::DefineNetCoolingRateTempDerivative(amrex::Real const /*temperature*/, amrex::Real const /*num_density*/)
-    -> quokka::valarray<double, nGroups_>
-{
-	quokka::valarray<double, nGroups_> cooling{};
-	cooling.fillin(0.0);
-	return cooling;
-}
-template <typename problem_t> AMREX_GPU_HOST_DEVICE auto RadSystem<problem_t>::DefineCosmicRayHeatingRate(amrex::Real const /*num_density*/) -> double { return 0.0; }
-
-template <typename problem_t> AMREX_GPU_HOST_DEVICE auto RadSystem<problem_t>::ComputePlanckOpacity(const double /*rho*/, const double /*Tgas*/) -> amrex::Real
-{
-	return std::numeric_limits<double>::quiet_NaN();
-}
-template <typename problem_t> AMREX_GPU_HOST_DEVICE auto RadSystem<problem_t>::ComputeFluxMeanOpacity(const double rho, const double Tgas) -> amrex::Real
-{
-	return ComputePlanckOpacity(rho, Tgas);
-}
-template <typename problem_t> AMREX_GPU_HOST_DEVICE auto RadSystem<problem_t>::ComputeEnergyMeanOpacity(const double rho, const double Tgas) -> amrex::Real
-{
-	return ComputePlanckOpacity(rho, Tgas);
-}
-template <typename problem_t> AMREX_GPU_HOST_DEVICE auto RadSystem<problem_t>::ComputeEddingtonFactor(double f_in) -> double
-{
-	// f is the reduced flux == |F|/cE; compute Levermore (1984) closure [Eq. 25] (reference src/radiation/radiation_system.hpp:773-790)
-	const double f = std::clamp(f_in, 0., 1.);
-	const double f_fac = std::sqrt(4.0 - 3.0 * (f * f));
-	return (3.0 + 4.0 * (f * f)) / (5.0 + 2.0 * f_fac);
-}
-template <typename problem_t>
-void RadSystem<problem_t>::SetRadEnergySource(array_t & /*radEnergySource*/, amrex::Box const & /*indexRange*/,
-					      amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> const & /*dx*/,
-					      amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> const & /*prob_lo*/,
-					      amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> const & /*prob_hi*/, amrex::Real /*time*/)
-{
-	// do nothing -- user implemented
-}
-
-namespace qkhost
-{
-// Locality-preserving box -> rank map (the role of AMReX's SFC DistributionMapping; the same rule as quokka_amd/simulation.py
-// distribute_boxes): the box lattice nb[0] x nb[1] x nb[2] is cut into `nranks` bricks by repeatedly halving its longest axis
-// (2 x 2 x 2 bricks for 8 ranks); lattices that cannot be cut that way fall back to contiguous blocks of boxes.
-inline auto distributeBoxes(int const nb[3], int nranks) -> std::vector<int>
-{
-	int const nboxes = nb[0] * nb[1] * nb[2];
-	std::vector<int> owner(static_cast<size_t>(nboxes), 0);
-	if (nranks <= 1) {
-		return owner;
-	}
-	int parts[3] = {1, 1, 1};
-	int r = nranks;
-	while (r > 1) {
-		int d = 0;
-		for (int a = 1; a < 3; ++a) {
-			if (static_cast<double>(nb[a]) / parts[a] > static_cast<double>(nb[d]) / parts[d]) {
-				d = a;
-			}
-		}
-		if (r % 2 != 0 || nb[d] / (parts[d] * 2) < 1) {
-			break;
-		}
-		parts[d] *= 2;
-		r /= 2;
-	}
-	if (parts[0] * parts[1] * parts[2] != nranks) {
-		int const per = (nboxes + nranks - 1) / nranks;
-		for (int i = 0; i < nboxes; ++i) {
-			owner[i] = std::min(i / per, nranks - 1);
-		}
-		return owner;
-	}
-	int n = 0;
-	for (int kb = 0; kb < nb[2]; ++kb) {
-		for (int jb = 0; jb < nb[1]; ++jb) {
-			for (int ib = 0; ib < nb[0]; ++ib) {
-				int const idx[3] = {ib, jb, kb};
-				int p[3];
-				for (int d = 0; d < 3; ++d) {
-					p[d] = std::min(idx[d] * parts[d] / nb[d], parts[d] - 1);
-				}
-				owner[n++] = p[0] + parts[0] * (p[1] + parts[1] * p[2]);
-			}
-		}
-	}
-	return owner;
-}
-
-// rank = Morton index of the box mod nranks (quokka_amd/simulation.py distribute_boxes_interleaved): every neighbourhood of the box lattice is
-// spread over all ranks
-inline auto distributeBoxesInterleaved(int const nb[3], int nranks) -> std::vector<int>
-{
-	std::vector<int> owner;
-	for (int kb = 0; kb < nb[2]; ++kb) {
-		for (int jb = 0; jb < nb[1]; ++jb) {
-			for (int ib = 0; ib < nb[0]; ++ib) {
-				unsigned m = 0;
-				for (int bit = 0; bit < 10; ++bit) {
-					m |= ((static_cast<unsigned>(ib) >> bit) & 1U) << (3 * bit) | ((static_cast<unsigned>(jb) >> bit) & 1U) << (3 * bit + 1) |
-					     ((static_cast<unsigned>(kb) >> bit) & 1U) << (3 * bit + 2);
-				}
-				owner.push_back(static_cast<int>(m % static_cast<unsigned>(nranks)));
-			}
-		}
-	}
-	return owner;
-}
-
-// device send / receive buffers for the peers of a ghost plan (qk_ghost_plan_peer: rank and strip sizes in elements)
-struct PeerBuffers {
-	std::vector<int> peer;
-	std::vector<void *> send, recv;
-	std::vector<int64_t> nsend, nrecv;
-	void build(qk_ghost_plan *plan, size_t elemBytes)
-	{
-		int const np = qk_ghost_plan_num_peers(plan);
-		for (int k = 0; k < np; ++k) {
-			int r = 0;
-			int64_t ns = 0, nr = 0;
-			check(qk_ghost_plan_peer(plan, k, &r, &ns, &nr), "qk_ghost_plan_peer");
-			void *s = nullptr, *rv = nullptr;
-			QK_HOST_HIP(hipMalloc(&s, std::max<size_t>(static_cast<size_t>(ns) * elemBytes, 8)));
-			QK_HOST_HIP(hipMalloc(&rv, std::max<size_t>(static_cast<size_t>(nr) * elemBytes, 8)));
-			peer.push_back(r);
-			send.push_back(s);
-			recv.push_back(rv);
-			nsend.push_back(ns);
-			nrecv.push_back(nr);
-		}
-	}
-};
-} // namespace qkhost
-
-// per-problem user data a problem may specialise (reference src/simulation.hpp: SimulationData<problem_t> userData_)
-template <typename problem_t> struct SimulationData {
-};
-
-template <typename problem_t, typename SimT> class AmrDriver; // quokka_amr.hpp
-template <typename problem_t> class AMRSimulation;
-
-namespace qkhost
-{
-template <typename problem_t>
-__global__ void customBcKernel(amrex::Array4<amrex::Real> dest, amrex::Box fab, amrex::GeometryData geom, amrex::Real time, const amrex::BCRec *bcr, int ncomp, int per0,
-			       int per1, int per2)
-{
-	const amrex::Long n = static_cast<amrex::Long>(blockIdx.x) * blockDim.x + threadIdx.x;
-	if (n >= fab.numPts()) {
-		return;
-	}
-	const int nx = fab.length(0), ny = fab.length(1);
-	const int k = static_cast<int>(n / (static_cast<amrex::Long>(nx) * ny));
-	const int r = static_cast<int>(n - static_cast<amrex::Long>(k) * nx * ny);
-	const int j = r / nx;
-	const amrex::IntVect iv(fab.lo[0] + (r - j * nx), fab.lo[1] + j, fab.lo[2] + k);
-	const int per[3] = {per0, per1, per2};
-	bool outside = false;
-	for (int d = 0; d < AMREX_SPACEDIM; ++d) {
-		outside = outside || (per[d] == 0 && (iv[d] < geom.domain.lo[d] || iv[d] > geom.domain.hi[d]));
-	}
-	if (outside) {
-		AMRSimulation<problem_t>::setCustomBoundaryConditions(iv, dest, 0, ncomp, geom, time, bcr, 0, 0);
-	}
-}
-} // namespace qkhost
-
-// one refinement level handed to a simulation object by the AMR driver (quokka_amr.hpp): geometry of that level and its boxes
-struct LevelSpec {
-	amrex::Geometry geom;
-	std::vector<amrex::Box> boxes;
-	int level = 0;
-	std::vector<int> owner; // rank of every box (several ranks: a refined box lives on the rank of its level-0 ancestor); empty: all on rank 0
-};
-
-// ---------------------------------------------------------------------------------------------------------------
-template <typename problem_t> class AMRSimulation
-{
-      public:
-	// public data members (reference src/simulation.hpp:144-173)
-	amrex::Real maxDt_ = std::numeric_limits<double>::max();
-	amrex::Real initDt_ = std::numeric_limits<double>::max();
-	amrex::Real constantDt_ = 0.0;
-	amrex::Real stopTime_ = 1.0;
-	amrex::Real cflNumber_ = 0.3;
-	amrex::Long maxTimesteps_ = 10000;
-	int plotfileInterval_ = -1;   // -1 == no output
-	int checkpointInterval_ = -1; // -1 == no output
-	std::string plot_file{"plt"}; // plotfile prefix
-	std::string chk_file{"chk"};  // checkpoint prefix
-	std::string restart_chkfile;  // `restartfile = <checkpoint directory>`
-	amrex::Vector<std::string> componentNames_cc_;
-	amrex::Real densityFloor_ = 0.0;
-	amrex::Real tempFloor_ = 0.0;
-	// One simulation object holds ONE level; whatever index a problem's hook uses — state_new_cc_[lev] inside ErrorEst(lev, ...), geom[lev],
-	// tNew_[lev] — addresses this object's level.  (geom, tNew_, dt_ and istep were one-element vectors until round 3: Advection2D's ErrorEst
-	// reads geom[lev].CellSizeArray() on the refined levels — out of bounds, a different cell size in one tagging out of fifty.)
-	template <typename T> struct ThisLevel {
-		T item{};
-		auto operator[](int /*lev*/) -> T & { return item; }
-		auto operator[](int /*lev*/) const -> T const & { return item; }
-		auto at(int /*lev*/) -> T & { return item; }
-		auto at(int /*lev*/) const -> T const & { return item; }
-		[[nodiscard]] auto size() const -> int { return 1; }
-	};
-	ThisLevel<amrex::Real> tNew_{0.0};
-	ThisLevel<amrex::Real> dt_{1.e100};
-	ThisLevel<int> istep{0};
-	amrex::Long cellUpdates_ = 0;
-	int nghost_cc_ = 4;
-	bool areInitialConditionsDefined_ = false;
-
-	ThisLevel<amrex::Geometry> geom;
-	std::vector<amrex::Box> grids_; // level-0 BoxArray
-	amrex::Vector<amrex::BCRec> BCs_cc_;
-	// One simulation object holds ONE level (the AMR driver of quokka_amr.hpp owns one object per level): whatever level index a
-	// problem's hook uses (state_new_cc_[lev] inside ErrorEst(lev, ...), geom[lev]) addresses this object's level.
-	ThisLevel<amrex::MultiFab> state_new_cc_, state_old_cc_;
-	[[nodiscard]] auto boxArray(int /*lev*/ = 0) const -> std::vector<amrex::Box> const & { return grids_; }
-	[[nodiscard]] auto DistributionMap(int /*lev*/ = 0) const -> amrex::DistributionMapping { return {}; }
-	[[nodiscard]] auto finestLevel() const -> int { return 0; }
-	[[nodiscard]] auto Geom(int /*lev*/ = 0) const -> amrex::Geometry const & { return geom[0]; }
-	[[nodiscard]] auto Geom(int /*lev*/ = 0) -> amrex::Geometry & { return geom[0]; }
-	SimulationData<problem_t> userData_;
-	static constexpr int nvarTotal_cc_ = Physics_Indices<problem_t>::nvarTotal_cc;
-
-	explicit AMRSimulation(amrex::Vector<amrex::BCRec> &BCs_cc) : BCs_cc_(BCs_cc) { initialize(nullptr); }
-	AMRSimulation(amrex::Vector<amrex::BCRec> &BCs_cc, amrex::Vector<amrex::BCRec> &BCs_fc) : BCs_cc_(BCs_cc), BCs_fc_(BCs_fc) { initialize(nullptr); }
-	AMRSimulation(amrex::Vector<amrex::BCRec> &BCs_cc, LevelSpec const &spec) : BCs_cc_(BCs_cc) { initialize(&spec); }
-	virtual ~AMRSimulation()
-	{
-		if (plan_ != nullptr) {
-			qk_ghost_plan_destroy(plan_);
-		}
-		if (myLev_ != nullptr) {
-			if (qkhost::Runtime::get().lev == myLev_) {
-				qkhost::Runtime::get().lev = nullptr;
-			}
-			qk_level_destroy(myLev_);
-		}
-	}
-	// the static operators (HydroSystem<problem_t>::..., RadSystem<problem_t>::...) act on the active level
-	void activate() const { qkhost::Runtime::get().lev = myLev_; }
-	[[nodiscard]] auto levelHandle() const -> qk_level * { return myLev_; }
-	int amrLevel_ = 0;
-	// called between FillBoundary and the physical boundaries: the AMR driver interpolates the uncovered ghost cells here
-	std::function<void(amrex::MultiFab &)> beforePhysBC_;
-
-	// device hook a problem may specialise (reference src/simulation.hpp:1550-1561); host mode: evaluated on host staging data
-	AMREX_GPU_DEVICE static void setCustomBoundaryConditions(const amrex::IntVect & /*iv*/, amrex::Array4<amrex::Real> const & /*dest*/, int /*dcomp*/, int /*numcomp*/,
-						amrex::GeometryData const & /*geom*/, amrex::Real /*time*/, const amrex::BCRec * /*bcr*/, int /*bcomp*/,
-						int /*orig_comp*/)
-	{
-	}
-
-	void initialize(LevelSpec const *spec)
-	{
-		readParameters();
-		auto &comm = qkhost::Comm::get();
-		comm.init(); // one process per GPU: selects this rank's device (reference src/main.cpp:22-46)
-		auto &rt = qkhost::Runtime::get();
-		if (rt.ctx == nullptr) {
-			int dev = 0;
-			QK_HOST_HIP(hipGetDevice(&dev));
-			qkhost::check(qk_ctx_create(&rt.ctx, dev), "qk_ctx_create");
-		}
-		auto &g = geom[0];
-		grids_.clear();
-		int nb[3] = {1, 1, 1};
-		if (spec != nullptr) {
-			g = spec->geom;
-			grids_ = spec->boxes;
-			amrLevel_ = spec->level;
-		} else {
-			// geometry + BoxArray from the deck (amrex.n_cell, geometry.*, amr.max_grid_size)
-			amrex::ParmParse pg("geometry");
-			amrex::ParmParse pa("amr");
-			std::vector<double> plo{0, 0, 0}, phi{1, 1, 1};
-			std::vector<int> per{0, 0, 0}, ncell{32, 32, 32}, mgs;
-			pg.queryarr("prob_lo", plo);
-			pg.queryarr("prob_hi", phi);
-			pg.queryarr("is_periodic", per);
-			pa.queryarr("n_cell", ncell);
-			if (!pa.queryarr("max_grid_size", mgs) || mgs.empty()) {
-				mgs = {128};
-			}
-			while (mgs.size() < 3) {
-				mgs.push_back(mgs.back());
-			}
-			for (int d = 0; d < 3; ++d) {
-				bool const active = d < AMREX_SPACEDIM;
-				g.domain.lo[d] = 0;
-				g.domain.hi[d] = active ? ncell[d] - 1 : 0;
-				g.periodic[d] = active ? per[d] : 0;
-				if (active) {
-					g.prob_lo[d] = plo[d];
-					g.prob_hi[d] = phi[d];
-					g.dx[d] = (phi[d] - plo[d]) / ncell[d];
-				}
-			}
-			for (int d = 0; d < 3; ++d) {
-				nb[d] = (d < AMREX_SPACEDIM) ? (g.domain.length(d) + mgs[d] - 1) / mgs[d] : 1;
-			}
-			for (int kb = 0; kb < nb[2]; ++kb) {
-				for (int jb = 0; jb < nb[1]; ++jb) {
-					for (int ib = 0; ib < nb[0]; ++ib) {
-						int const idx[3] = {ib, jb, kb};
-						amrex::Box b;
-						for (int d = 0; d < 3; ++d) {
-							int const len = g.domain.length(d);
-							int const base = len / nb[d], rem = len % nb[d];
-							b.lo[d] = idx[d] * base + std::min(idx[d], rem);
-							b.hi[d] = b.lo[d] + base + (idx[d] < rem ? 1 : 0) - 1;
-						}
-						grids_.push_back(b);
-					}
-				}
-			}
-		}
-		// the whole level and its box -> rank map (every rank computes the same); this rank keeps the boxes it owns, in global order
-		allGrids_ = grids_;
-		if (spec != nullptr) {
-			owner_ = spec->owner.empty() ? std::vector<int>(allGrids_.size(), 0) : spec->owner;
-			AMREX_ALWAYS_ASSERT(owner_.size() == allGrids_.size());
-		} else {
-			// an AMR hierarchy keeps every refined box on the rank of its level-0 ancestor: "interleaved" (rank = Morton index of the level-0 box
-			// mod nranks; the default there, as in quokka_amd/amr_simulation.py) lands a refined region on every rank, "bricks" keeps level 0
-			// compact (fewest remote ghost strips: the uniform-grid default)
-			int maxLevel = 0;
-			amrex::ParmParse("amr").query("max_level", maxLevel);
-			std::string how = (maxLevel > 0 && comm.size > 1) ? "interleaved" : "bricks";
-			amrex::ParmParse("qk").query("level0_distribution", how);
-			owner_ = (how == "interleaved") ? qkhost::distributeBoxesInterleaved(nb, comm.size) : qkhost::distributeBoxes(nb, comm.size);
-		}
-		allBoxes_.clear();
-		for (auto const &b : allGrids_) {
-			allBoxes_.push_back({{b.lo[0], b.lo[1], b.lo[2]}, {b.hi[0], b.hi[1], b.hi[2]}});
-		}
-		grids_.clear();
-		std::vector<qk_box> qb;
-		for (size_t n = 0; n < allGrids_.size(); ++n) {
-			if (owner_[n] == comm.rank) {
-				grids_.push_back(allGrids_[n]);
-				qb.push_back(allBoxes_[n]);
-			}
-		}
-		if (grids_.empty() && spec == nullptr) { // (a refined level may well have no box on this rank: every operator on it is then a no-op)
-			amrex::Abort("this rank owns no boxes: fewer boxes than ranks (lower amr.max_grid_size)");
-		}
-		qkhost::check(qk_level_create(rt.ctx, &myLev_, AMREX_SPACEDIM, static_cast<int>(qb.size()), qb.data()), "qk_level_create");
-		rt.lev = myLev_;
-		int const nc = Physics_Indices<problem_t>::nvarTotal_cc;
-		state_new_cc_[0].define(grids_, nc, nghost_cc_);
-		state_old_cc_[0].define(grids_, nc, nghost_cc_);
-		// ghost-exchange plan: same-rank copies, strips packed for / unpacked from the peers, physical-boundary shells
-		for (int d = 0; d < 3; ++d) {
-			qgeom_.domain.lo[d] = g.domain.lo[d];
-			qgeom_.domain.hi[d] = g.domain.hi[d];
-			qgeom_.periodic[d] = g.periodic[d];
-		}
-		qgeom_.ndim = AMREX_SPACEDIM;
-		qkhost::check(qk_ghost_plan_create(myLev_, &plan_, &qgeom_, nghost_cc_, nc, static_cast<int>(allBoxes_.size()), allBoxes_.data(), owner_.data(),
-						   comm.rank),
-			      "qk_ghost_plan_create");
-		peers_.build(plan_, sizeof(double));
-	}
-	// level description shared by every plan of this level
-	std::vector<amrex::Box> allGrids_;
-	std::vector<qk_box> allBoxes_;
-	std::vector<int> owner_;
-	qk_geometry qgeom_{};
-	qkhost::PeerBuffers peers_;
-
-	void readParameters() // reference src/simulation.hpp:541-636 (the keys the config decks use)
-	{
-		amrex::ParmParse pp;
-		pp.query("max_timesteps", maxTimesteps_);
-		pp.query("cfl", cflNumber_);
-		pp.query("stop_time", stopTime_);
-		pp.query("plotfile_interval", plotfileInterval_);
-		pp.query("checkpoint_interval", checkpointInterval_);
-		pp.query("plotfile_prefix", plot_file);
-		pp.query("checkpoint_prefix", chk_file);
-		pp.query("restartfile", restart_chkfile);
-		pp.query("density_floor", densityFloor_);
-		pp.query("temperature_floor", tempFloor_);
-	}
-
-	[[nodiscard]] auto CountCells(int /*lev*/) const -> amrex::Long // (all ranks)
-	{
-		amrex::Long n = 0;
-		for (auto const &b : allGrids_) {
-			n += b.numPts();
-		}
-		return n;
-	}
-
-	// user hooks (specialised per problem)
-	virtual void setInitialConditionsOnGrid(quokka::grid const &grid_elem) = 0;
-	virtual void preCalculateInitialConditions() {}
-	virtual void computeAfterEvolve(amrex::Vector<amrex::Real> & /*initSumCons*/) {}
-
-	// reference src/simulation.hpp:1608-1626
-	void setInitialConditions()
-	{
-		preCalculateInitialConditions();
-		auto &mf = state_new_cc_[0];
-		if (restart_chkfile.empty()) {
-			for (int b = 0; b < mf.size(); ++b) {
-				// device mode: the problem's ParallelFor runs as a kernel on the level's own arrays
-				quokka::grid grid_elem{mf.array(b), mf.validbox(b), geom[0].CellSizeArray(), geom[0].ProbLoArray(), geom[0].ProbHiArray()};
-				setInitialConditionsOnGrid(grid_elem);
-			}
-		} else {
-			// level 0 of ReadCheckpointFile (reference src/simulation.hpp:2736-2801): the BoxArray comes from the deck, the data by
-			// ParallelCopy from the file's boxes
-			auto const h = quokka::io::ReadCheckpointHeader(restart_chkfile);
-			istep[0] = h.istep.at(0);
-			dt_[0] = h.dt.at(0);
-			tNew_[0] = h.tNew.at(0);
-			quokka::io::VisMFReadInto(mf, restart_chkfile + "/Level_0/Cell");
-		}
-		fillBoundaryConditions(state_new_cc_[0]);
-		amrex::MultiFab::Copy(state_old_cc_[0], state_new_cc_[0]);
-		if (restart_chkfile.empty()) {
-			setInitialConditionsAtLevel_fc();
-		} else {
-			readFaceCentredState();
-		}
-		areInitialConditionsDefined_ = true;
-	}
-	// the face-centred part of ReadCheckpointFile (reference src/simulation.hpp:2779-2815)
-	void readFaceCentredState()
-	{
-		if constexpr (qkhost::hasFaceState<problem_t>()) {
-			defineFaceCentredState();
-			char const *dirName[3] = {"x", "y", "z"};
-			for (int idim = 0; idim < AMREX_SPACEDIM; ++idim) {
-				quokka::io::VisMFReadInto(state_new_fc_[0][idim], restart_chkfile + "/Level_0/Face_" + dirName[idim]);
-				amrex::MultiFab::Copy(state_old_fc_[0][idim], state_new_fc_[0][idim]);
-			}
-		}
-	}
-	// setInitialConditionsAtLevel_fc (reference src/simulation.hpp:1628-1651): the face-centred state of problems that carry one
-	// (Physics_Indices::nvarTotal_fc > 0: face velocities, the magnetic field of the MHD index bookkeeping).  The arrays exist, take the
-	// problem's initial conditions and travel through checkpoints and plotfiles; their ghost faces are NOT filled — no operator of this host
-	// reads them (the reference's MHD update does not exist either: hydro/mhd_system.hpp holds indices only).
-	void defineFaceCentredState()
-	{
-		if constexpr (qkhost::hasFaceState<problem_t>()) {
-			if (state_new_fc_.empty()) {
-				state_new_fc_.resize(1);
-				state_old_fc_.resize(1);
-				for (int idim = 0; idim < AMREX_SPACEDIM; ++idim) {
-					state_new_fc_[0][idim].define(grids_, Physics_Indices<problem_t>::nvarPerDim_fc, nghost_fc_, idim);
-					state_old_fc_[0][idim].define(grids_, Physics_Indices<problem_t>::nvarPerDim_fc, nghost_fc_, idim);
-				}
-			}
-		}
-	}
-	void setInitialConditionsAtLevel_fc()
-	{
-		if constexpr (qkhost::hasFaceState<problem_t>()) {
-			defineFaceCentredState();
-			for (int idim = 0; idim < AMREX_SPACEDIM; ++idim) {
-				auto &mf = state_new_fc_[0][idim];
-				mf.setVal(0.);
-				for (int b = 0; b < mf.size(); ++b) {
-					amrex::Box faces = mf.validbox(b); // iter.validbox() of a face-centred MultiFab: nodal in idim
-					faces.hi[idim] += 1;
-					quokka::grid grid_elem{mf.array(b),	  faces, geom[0].CellSizeArray(), geom[0].ProbLoArray(), geom[0].ProbHiArray(), quokka::centering::fc,
-							       static_cast<quokka::direction>(idim)};
-					setInitialConditionsOnGridFaceVars(grid_elem);
-				}
-				amrex::MultiFab::Copy(state_old_fc_[0][idim], mf);
-			}
-		}
-	}
-	virtual void setInitialConditionsOnGridFaceVars(quokka::grid const & /*grid_elem*/) {}
-	// componentNames_fc_ (reference src/QuokkaSimulation.hpp:310-321: the face velocities of every direction, then the field components — the
-	// order of the reference's labels, kept although PlotFileMFAtLevel stores the averages direction by direction)
-	[[nodiscard]] static auto componentNames_fc() -> std::vector<std::string>
-	{
-		char const *dirName[3] = {"x", "y", "z"};
-		std::vector<std::string> names;
-		if constexpr (qkhost::hasFaceState<problem_t>()) {
-			if constexpr (Physics_Traits<problem_t>::is_hydro_enabled) {
-				for (int idim = 0; idim < AMREX_SPACEDIM; ++idim) {
-					names.push_back(std::string(dirName[idim]) + "-velocity");
-				}
-			}
-			if constexpr (Physics_Traits<problem_t>::is_mhd_enabled) {
-				for (int idim = 0; idim < AMREX_SPACEDIM; ++idim) {
-					names.push_back(std::string(dirName[idim]) + "-BField");
-				}
-			}
-		}
-		return names;
-	}
-	[[nodiscard]] auto getNewMF_fc() const -> amrex::Vector<amrex::Array<amrex::MultiFab, AMREX_SPACEDIM>> const & { return state_new_fc_; }
-	void setChkFile(std::string const &chkfile_number) { restart_chkfile = chkfile_number; } // reference src/simulation.hpp:410
-	amrex::Vector<amrex::Array<amrex::MultiFab, AMREX_SPACEDIM>> state_new_fc_, state_old_fc_;
-	amrex::Vector<amrex::BCRec> BCs_fc_;
-	int nghost_fc_ = Physics_Traits<problem_t>::is_mhd_enabled ? 4 : 2; // reference src/simulation.hpp:364
-
-	// setInitialConditionsAtLevel_cc (reference src/simulation.hpp:1608-1626): the problem's initial conditions on this level's boxes
-	void setInitialConditionsAtLevel()
-	{
-		auto &mf = state_new_cc_[0];
-		for (int b = 0; b < mf.size(); ++b) {
-			quokka::grid grid_elem{mf.array(b), mf.validbox(b), geom[0].CellSizeArray(), geom[0].ProbLoArray(), geom[0].ProbHiArray()};
-			setInitialConditionsOnGrid(grid_elem);
-		}
-		amrex::MultiFab::Copy(state_old_cc_[0], state_new_cc_[0]);
-		setInitialConditionsAtLevel_fc();
-		areInitialConditionsDefined_ = true;
-	}
-
-	// fillBoundaryConditions for the radiation transport kernels, which read only the radiation components of the ghost cells
-	void fillRadiationGhosts(amrex::MultiFab &state)
-	{
-		int const first = Physics_Indices<problem_t>::radFirstIndex;
-		qkhost::check(qk_ghost_plan_set_components(plan_, first, state.nComp() - first), "qk_ghost_plan_set_components");
-		fillBoundaryConditions(state);
-		qkhost::check(qk_ghost_plan_set_components(plan_, 0, -1), "qk_ghost_plan_set_components");
-	}
-	// level-0 branch of fillBoundaryConditions (reference src/simulation.hpp:1751-1776).
-	// `between` (optional; the multi-GPU schedule of north_star): called while the strips of the other ranks are on the wire — RCCL moves them on
-	// its own HIP stream (qk_comm.hpp) —, after the boxes that receive nothing remote have been completed (same-rank copies + their own
-	// physical-boundary slabs).  The caller advances exactly those boxes in it; the rest follows after the unpack.
-	void fillBoundaryConditions(amrex::MultiFab &state, std::function<void()> const &between = {})
-	{
-		activate();
-		hipStream_t const cs = qkhost::Runtime::get().computeStream();
-		// state.FillBoundary(geom.periodicity()) (reference src/simulation.hpp:1755): strips for the other ranks are packed, sent peer to peer
-		// while the same-rank copies run, and unpacked
-		for (size_t k = 0; k < peers_.peer.size(); ++k) {
-			qkhost::check(qk_FillBoundary_pack(plan_, cs, static_cast<int>(k), qkhost::tab(state), static_cast<double *>(peers_.send[k])),
-				      "FillBoundary_pack");
-		}
-		qkhost::Comm::get().exchangeBegin(peers_.peer, peers_.send, peers_.nsend, peers_.recv, peers_.nrecv, sizeof(double), cs);
-		qkhost::check(qk_FillBoundary_local(plan_, cs, qkhost::tab(state)), "FillBoundary");
-		bool const physical = !geom[0].isAllPeriodic();
-		std::vector<qk_bcrec> bcs(BCs_cc_.size());
-		for (size_t n = 0; n < BCs_cc_.size(); ++n) {
-			for (int d = 0; d < 3; ++d) {
-				bcs[n].lo[d] = (d < AMREX_SPACEDIM) ? BCs_cc_[n].lo(d) : 0;
-				bcs[n].hi[d] = (d < AMREX_SPACEDIM) ? BCs_cc_[n].hi(d) : 0;
-			}
-		}
-		auto physbc = [&](int which) {
-			if (physical) {
-				qkhost::check(qk_FillPhysicalBoundary_subset(plan_, cs, qkhost::tab(state), bcs.data(), nullptr, which), "FillPhysicalBoundary");
-				customBoundaryConditionsOnDevice(state, which);
-			}
-		};
-		if (between) {
-			AMREX_ALWAYS_ASSERT(!beforePhysBC_); // (a refined level interpolates its uncovered ghost cells first: no split there)
-			physbc(QK_BOXES_LOCAL_ONLY);
-			between();
-		}
-		qkhost::Comm::get().exchangeEnd(cs);
-		for (size_t k = 0; k < peers_.peer.size(); ++k) {
-			qkhost::check(qk_FillBoundary_unpack(plan_, cs, static_cast<int>(k), qkhost::tab(state), static_cast<const double *>(peers_.recv[k])),
-				      "FillBoundary_unpack");
-		}
-		if (beforePhysBC_) {
-			beforePhysBC_(state);
-		}
-		physbc(between ? QK_BOXES_REMOTE_DEPENDENT : QK_BOXES_ALL);
-	}
-	// setCustomBoundaryConditions as the reference runs it (simulation.hpp:297-299, :1550-1561; amrex::GpuBndryFuncFab): the problem's
-	// DEVICE function is called for every ghost cell that lies outside the domain in a non-periodic direction, after the mathematical
-	// boundary types have been filled.  One kernel instantiated with the problem type per box — arbitrary boundary code, not the closed
-	// Dirichlet / Marshak set of the C-ABI (which host-mode problems are sampled into).
-	void customBoundaryConditionsOnDevice(amrex::MultiFab &state, int which = QK_BOXES_ALL)
-	{
-		if (d_bcrec_ == nullptr) {
-			QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_bcrec_), sizeof(amrex::BCRec) * BCs_cc_.size()));
-			QK_HOST_HIP(hipMemcpy(d_bcrec_, BCs_cc_.data(), sizeof(amrex::BCRec) * BCs_cc_.size(), hipMemcpyHostToDevice));
-		}
-		auto const gd = geom[0].data();
-		int per[3] = {1, 1, 1};
-		for (int d = 0; d < AMREX_SPACEDIM; ++d) {
-			per[d] = geom[0].isPeriodic(d) ? 1 : 0;
-		}
-		for (int b = 0; b < state.size(); ++b) {
-			amrex::Box const fb = state.fabbox(b);
-			bool touches = false;
-			for (int d = 0; d < AMREX_SPACEDIM; ++d) {
-				touches = touches || (per[d] == 0 && (fb.lo[d] < gd.domain.lo[d] || fb.hi[d] > gd.domain.hi[d]));
-			}
-			if (!touches) {
-				continue;
-			}
-			if (which != QK_BOXES_ALL && (qk_ghost_plan_box_is_remote(plan_, b) == 1) != (which == QK_BOXES_REMOTE_DEPENDENT)) {
-				continue; // the other group of an overlapped fill
-			}
-			amrex::Long const n = fb.numPts();
-			hipLaunchKernelGGL(qkhost::customBcKernel<problem_t>, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, qkhost::Runtime::get().computeStream(), state.array(b), fb, gd,
-					   bcFillTime(), d_bcrec_, state.nComp(), per[0], per[1], per[2]);
-		}
-	}
-	amrex::BCRec *d_bcrec_ = nullptr;
-	[[nodiscard]] virtual auto bcFillTime() const -> double { return tNew_[0]; }
-
-      protected:
-	qk_level *myLev_ = nullptr;
-	qk_ghost_plan *plan_ = nullptr;
-};
+#include "quokka_amr_simulation.hpp"
 
 template <typename problem_t> class QuokkaSimulation : public AMRSimulation<problem_t>
 {
