@@ -37,6 +37,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 # algorithmic bytes per cell-sweep of the fused PPM+HLLC sweep kernels and of the flattening pre-pass
 ALG_BYTES = {"k_sweep_x": 128.0, "k_sweep_y": 184.0, "k_sweep_z": 184.0}
+DOMINANT_KERNEL = "k_sweep_z"  # the Z sweep + epilogue: the longest kernel of a stage in every line since round 1 (checked against the full table below)
 ALG_BYTES_PRE = 72.0
 ALG_BYTES_STEP = 1496.0
 FP64_VALU_PEAK = 256 * 64 * 2.4e9  # FP64 vector lane-instructions per second without FMA contraction (256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz)
@@ -536,7 +537,10 @@ def run_sedov(ctx, torch, dist, rank, world, ncell, mgs, steps, warmup, profile=
         assert sim.step()
     L = ctx.L
     if profile:
+        # HIP events on the launch stream around the DOMINANT kernel only (two event records per timed launch cost ~6 us of GPU time: with all 14
+        # launches of a step timed, the events themselves were 1.5 % of the step); the other kernels are timed in a separate pass (main: repeats)
         L.qk_profile_reset(ctx.h)
+        L.qk_profile_only(ctx.h, DOMINANT_KERNEL.encode() if profile is True else None)  # (profile="all": every kernel — the secondary blocks)
         L.qk_profile_enable(ctx.h, 1)
     if world > 1:
         sim.ghost.exposed_events = []  # (two event records per fill: how long the compute stream stalls for the peers' strips)
@@ -548,6 +552,7 @@ def run_sedov(ctx, torch, dist, rank, world, ncell, mgs, steps, warmup, profile=
     elapsed = time.perf_counter() - t0
     if profile:
         L.qk_profile_enable(ctx.h, 0)
+        L.qk_profile_only(ctx.h, None)
     if world > 1:
         from quokka_amd import comm
         ev = sim.ghost.exposed_events
@@ -570,23 +575,38 @@ def run_sedov(ctx, torch, dist, rank, world, ncell, mgs, steps, warmup, profile=
     return sim, n_cell, elapsed, kernels
 
 
-def roofline_of(kernels, cells_local, total_cells, steps, elapsed, world, ncell, mgs):
-    sweeps = {}
-    for k, alg in ALG_BYTES.items():
-        if k in kernels and kernels[k][0] > 0:
-            avg_s = kernels[k][1] / kernels[k][0] * 1e-3
-            sweeps[k] = {"alg_bytes_per_cell": alg, "avg_launch_ms": avg_s * 1e3, "launches": kernels[k][0],
-                         "achieved_GBs": alg * cells_local / avg_s / 1e9, "frac": alg * cells_local / avg_s / 1e9 / HBM_PEAK_GBS}
-    if not sweeps:
+def roofline_of(kernels, cells_local, total_cells, steps, elapsed, world, ncell, mgs, kernels_all=None):
+    """kernels: HIP-event durations of the TIMED region (the dominant kernel only, see run_sedov); kernels_all: every kernel, timed in a separate
+    pass over the same number of steps (None: `kernels` holds them all)"""
+    def table(ks):
+        out = {}
+        for k, alg in ALG_BYTES.items():
+            if k in ks and ks[k][0] > 0:
+                avg_s = ks[k][1] / ks[k][0] * 1e-3
+                out[k] = {"alg_bytes_per_cell": alg, "avg_launch_ms": avg_s * 1e3, "launches": ks[k][0],
+                          "achieved_GBs": alg * cells_local / avg_s / 1e9, "frac": alg * cells_local / avg_s / 1e9 / HBM_PEAK_GBS}
+        return out
+    timed = table(kernels)
+    if not timed:
         return None
-    dom = max(sweeps, key=lambda k: sweeps[k]["avg_launch_ms"])
+    dom = max(timed, key=lambda k: timed[k]["avg_launch_ms"])
+    sweeps = table(kernels_all) if kernels_all is not None else dict(timed)
+    if kernels_all is not None:
+        longest = max(sweeps, key=lambda k: sweeps[k]["avg_launch_ms"]) if sweeps else dom
+        sweeps[dom] = dict(timed[dom], separate_pass_avg_launch_ms=sweeps.get(dom, {}).get("avg_launch_ms"))
+        kernels = dict(kernels_all, **{dom: kernels[dom]})
+    else:
+        longest = dom
     traffic, source = pmc_traffic(ncell) if mgs == 128 else (None, None)
     pre_ms = sum(v[1] / max(v[0], 1) for k, v in kernels.items() if k.startswith("k_pre"))
     d = sweeps[dom]
     r = {"bound": "hbm", "kernel": dom, "achieved": d["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["frac"],
          "traffic": traffic.get(dom) if traffic else None, "traffic_unit": "bytes per launch (PMC, FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": source,
          "alg_bytes_per_launch": d["alg_bytes_per_cell"] * cells_local, "avg_launch_ms": d["avg_launch_ms"], "launches": d["launches"],
-         "sweeps": sweeps,
+         "sweeps": sweeps, "longest_kernel_of_the_full_table": longest,
+         "sweeps_note": None if kernels_all is None else f"{dom}: HIP events over the timed region; the other kernels: HIP events over a separate pass of the same "
+                                                         "number of steps right after it (every event pair costs ~6 us of GPU time: timing all 14 launches of a "
+                                                         "step inside the measured region made the measurement 1.5 % slower than the run)",
          "pre_pass": {"alg_bytes_per_cell": ALG_BYTES_PRE, "ms_per_stage": pre_ms,
                       "frac": (ALG_BYTES_PRE * cells_local / (pre_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if pre_ms > 0 else None},
          "traffic_all_kernels": traffic,
@@ -693,7 +713,6 @@ def main():
     sim, n_cell, elapsed, kernels = run_sedov(ctx, torch, dist, rank, world, ncell, mgs, args.steps, args.warmup, carry=(args.rk2_mode == "carry"))
     cells_local = sim.lev.num_cells()
     total_cells = n_cell[0] * n_cell[1] * n_cell[2]
-    roofline = roofline_of(kernels, cells_local, total_cells, args.steps, elapsed, world, ncell, mgs)
     groups = sim.overlap_groups() if world > 1 else None
     out = {
         "metric": "Mcell-updates/s on 3D Sedov unigrid", "value": total_cells * args.steps / elapsed / 1e6, "unit": "Mcell-updates/s", "n_gpus": world,
@@ -710,7 +729,7 @@ def main():
                    "sim_time": sim.tNew_,
                    "note": "N = 1 runs BASELINE config 2 (256^3); N > 1 runs 512^3 cells per GPU (N = 8: config 3, 1024^3); "
                            "weak_256_per_gpu is the same geometry as N = 1 on every rank"},
-        "roofline": roofline,
+        "roofline": None,  # (filled below, after the pass that times every kernel)
         # context only (other hardware, reference implementation): paper/performance_a100.csv:2 = 254.05 Mzones/s on 1x A100
         "reference_published_a100_1gpu": 254.05,
     }
@@ -720,7 +739,12 @@ def main():
         out["dry_run"] = f"{world} ranks share cuda:0 and talk over gloo with host-staged buffers: the SHAPE of the N > 1 line on a small problem, never a measurement"
     # the same measurement twice more on the same run (the box's HBM rate drifts by several percent within minutes: profiles/round4/README.md)
     reps = []
-    for _ in range(2):
+    kernels_all = None
+    for rep in range(2):
+        if rep == 0:  # this pass times EVERY kernel with HIP events (the table of the roofline object); the second one none
+            ctx.L.qk_profile_reset(ctx.h)
+            ctx.L.qk_profile_only(ctx.h, None)
+            ctx.L.qk_profile_enable(ctx.h, 1)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -731,13 +755,18 @@ def main():
         if world > 1:
             dist.barrier()
         reps.append(time.perf_counter() - t0)
+        if rep == 0:
+            ctx.L.qk_profile_enable(ctx.h, 0)
+            kernels_all = read_profile(ctx)
+    out["roofline"] = roofline_of(kernels, cells_local, total_cells, args.steps, elapsed, world, ncell, mgs, kernels_all=kernels_all)
     if world > 1:
         t = torch.tensor(reps, dtype=torch.float64, device=ctx.device)
         from quokka_amd import comm
         comm.all_reduce(t, dist.ReduceOp.MAX)
         reps = t.tolist()
     out["repeats"] = {"values": [total_cells * args.steps / r / 1e6 for r in reps], "unit": "Mcell-updates/s", "steps_each": args.steps,
-                      "note": "the timed region repeated twice on the continuing run, after `value` was taken"}
+                      "note": "the timed region repeated twice on the continuing run, after `value` was taken: the first with HIP events around every "
+                              "kernel (the roofline table), the second with none"}
     del sim
     torch.cuda.empty_cache()
     if not args.no_secondary:
@@ -751,14 +780,14 @@ def main():
             del simL
             torch.cuda.empty_cache()
             # (b) 512^3 on the one GPU: the size of north_star's roofline target
-            s5, n5, el5, k5 = run_sedov(ctx, torch, dist, rank, world, 512, mgs, 8, 2, carry=carry)
+            s5, n5, el5, k5 = run_sedov(ctx, torch, dist, rank, world, 512, mgs, 8, 2, carry=carry, profile="all")
             out["ncell512"] = {"rk2_mode": args.rk2_mode, "value": 512 ** 3 * 8 / el5 / 1e6, "unit": "Mcell-updates/s", "steps": 8, "warmup": 2, "ms_per_step": el5 / 8 * 1e3,
                                "boxes": s5.lev.nboxes, "roofline": roofline_of(k5, s5.lev.num_cells(), 512 ** 3, 8, el5, 1, 512, mgs)}
             del s5
             torch.cuda.empty_cache()
             # (c) the other form of the RK2 average, same run (headline: --rk2-mode, default carry; `rk2_other_mode`: the remaining one)
             other = "exact" if args.rk2_mode == "carry" else "carry"
-            sO, _, elO, kO = run_sedov(ctx, torch, dist, rank, world, 256, mgs, args.steps, args.warmup, carry=(other == "carry"))
+            sO, _, elO, kO = run_sedov(ctx, torch, dist, rank, world, 256, mgs, args.steps, args.warmup, carry=(other == "carry"), profile="all")
             out["rk2_other_mode"] = {"rk2_mode": other, "value": 256 ** 3 * args.steps / elO / 1e6, "unit": "Mcell-updates/s", "ms_per_step": elO / args.steps * 1e3,
                                      "kernels_ms_per_launch": {k: v[1] / max(v[0], 1) for k, v in sorted(kO.items())},
                                      "note": "exact = flux_rk2 = 0.5 F1 + 0.5 F2 face by face (bit-identical to the CPU oracle); carry = the average taken on the "

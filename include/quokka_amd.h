@@ -107,6 +107,9 @@ const char *qk_version(void);
 /* Optional per-kernel timing with HIP events recorded on the launch stream (used by bench.py for the roofline
  * figure).  qk_profile_num_kernels / qk_profile_get synchronise on the recorded events. */
 int qk_profile_enable(qk_ctx *ctx, int on);
+/* restrict the timing to the kernel of that name (NULL or "": every kernel).  Each timed launch costs two event records on the stream (~3 us of GPU
+ * time each): bench.py times its measured region with events around the dominant kernel only and fills the per-kernel table in a separate pass. */
+int qk_profile_only(qk_ctx *ctx, const char *kernel_name);
 int qk_profile_reset(qk_ctx *ctx);
 int qk_profile_num_kernels(qk_ctx *ctx);
 int qk_profile_get(qk_ctx *ctx, int k, const char **name, long *count, double *total_ms);

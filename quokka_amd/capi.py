@@ -131,6 +131,7 @@ def lib() -> C.CDLL:
     L.qk_upload_array4_table.argtypes = [vp, ci, P(Array4), P(vp)]
     L.qk_upload_iarray4_table.argtypes = [vp, ci, P(Array4), P(vp)]
     L.qk_profile_enable.argtypes = [vp, ci]
+    L.qk_profile_only.argtypes = [vp, C.c_char_p]
     L.qk_clear_bytes.argtypes = [vp, vp, vp, C.c_int64]
     L.qk_profile_reset.argtypes = [vp]
     L.qk_profile_num_kernels.argtypes = [vp]
@@ -230,7 +231,7 @@ TAGFIELD_PRESSURE = -1
 
 DECLARED_SYMBOLS = [
     "qk_ctx_create", "qk_ctx_destroy", "qk_last_error", "qk_version", "qk_level_create", "qk_level_destroy",
-    "qk_upload_array4_table", "qk_upload_iarray4_table", "qk_clear_bytes", "qk_profile_enable", "qk_profile_reset", "qk_profile_num_kernels", "qk_profile_get",
+    "qk_upload_array4_table", "qk_upload_iarray4_table", "qk_clear_bytes", "qk_profile_enable", "qk_profile_only", "qk_profile_reset", "qk_profile_num_kernels", "qk_profile_get",
     "qk_ReconstructStatesConstant", "qk_ReconstructStatesPLM", "qk_ReconstructStatesPPM",
     "qk_hydro_ConservedToPrimitive", "qk_hydro_ComputeFlatteningCoefficients", "qk_hydro_FlattenShocks",
     "qk_hydro_ComputeFluxes", "qk_hydro_ComputeRhsFromFluxes", "qk_hydro_AddInternalEnergyPdV", "qk_hydro_PredictStep",

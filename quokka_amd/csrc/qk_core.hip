@@ -123,6 +123,15 @@ int qk_profile_enable(qk_ctx *ctx, int on)
 	return QK_OK;
 }
 
+int qk_profile_only(qk_ctx *ctx, const char *kernel_name)
+{
+	if (ctx == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	ctx->prof_only = (kernel_name != nullptr) ? kernel_name : "";
+	return QK_OK;
+}
+
 // folds finished event pairs into the per-kernel totals (synchronises on the recorded events)
 static void profCollect(qk_ctx *ctx)
 {

@@ -28,6 +28,7 @@ struct qk_ctx {
 	std::mutex mtx;
 	// optional per-kernel HIP-event timing (qk_profile_*): events are recorded on the launch stream
 	bool profiling = false;
+	std::string prof_only; // qk_profile_only: time this kernel alone (empty: all)
 	std::vector<qk_prof_slot> prof_slots;
 	std::vector<qk_prof_pending> prof_pending;
 	std::vector<hipEvent_t> prof_free_events;
@@ -134,7 +135,7 @@ struct ProfScope {
 	int idx = -1;
 	ProfScope(qk_ctx *c, hipStream_t stream, const char *name) : ctx(c), s(stream)
 	{
-		if (ctx == nullptr || !ctx->profiling) {
+		if (ctx == nullptr || !ctx->profiling || (!ctx->prof_only.empty() && ctx->prof_only != name)) {
 			return;
 		}
 		int slot = -1;

@@ -635,8 +635,16 @@ class HydroSimulation:
             comm.all_reduce(v, dist.ReduceOp.MAX)
             vals = v.tolist()
             return [vals[0:4], vals[4:8]]
-        h = self._dev_words.cpu()  # one copy of the eight words, no conversion kernels
-        return [h[4 * s:4 * s + 2].view(torch.float64).tolist() + [float(int(h[4 * s + 2])), float(int(h[4 * s + 3]) & 0xFFFFFFFF)] for s in (0, 1)]
+        # one copy of the eight words into pinned host memory (no allocation, no conversion kernels), one stream synchronisation
+        hw = self.__dict__.get("_host_words")
+        if hw is None:
+            hw = self.__dict__["_host_words"] = torch.zeros(8, dtype=torch.int64).pin_memory()
+            self.__dict__["_host_words_np"] = hw.numpy()
+        hw.copy_(self._dev_words, non_blocking=True)
+        torch.cuda.current_stream(self.ctx.device).synchronize()
+        a = self.__dict__["_host_words_np"]
+        f = a.view(np.float64)
+        return [[float(f[4 * s]), float(f[4 * s + 1]), float(a[4 * s + 2]), float(int(a[4 * s + 3]) & 0xFFFFFFFF)] for s in (0, 1)]
 
     def _fused_end(self, stage: int, slot: int = 0, vals=None) -> int:
         """redo count of the stage (only ever compared with 0) and, after the final stage, the two CFL maxima"""
