@@ -614,6 +614,10 @@ def roofline_of(kernels, cells_local, total_cells, steps, elapsed, world, ncell,
                         "achieved_GBs": ALG_BYTES_STEP * total_cells * steps / elapsed / 1e9 / world,
                         "frac": ALG_BYTES_STEP * total_cells * steps / elapsed / 1e9 / world / HBM_PEAK_GBS},
          "all_kernels_ms_per_launch": {k: v[1] / max(v[0], 1) for k, v in sorted(kernels.items())}}
+    # every kernel of the step is in the table (the dominant one from the timed region, the others from the separate pass): what the host adds
+    if kernels_all is not None and steps > 0:
+        per_step = sum(v[1] for v in kernels.values()) / steps
+        r["step_minus_sum_of_kernels_ms"] = elapsed * 1e3 / steps - per_step
     return r
 
 

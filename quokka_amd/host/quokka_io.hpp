@@ -290,7 +290,9 @@ struct VisMFData {
 };
 
 // amrex::VisMF::Read(mf, prefix)
-inline auto VisMFRead(std::string const &prefix) -> VisMFData
+// wanted: the boxes the caller will copy into.  An entry of the file whose stored box (valid box grown by m_ngrow) meets none of them is
+// not opened: on restart each rank reads the fabs under its own boxes, not the whole level.
+inline auto VisMFRead(std::string const &prefix, std::vector<amrex::Box> const *wanted = nullptr) -> VisMFData
 {
 	VisMFData r;
 	std::ifstream hdr(prefix + "_H");
@@ -329,6 +331,18 @@ inline auto VisMFRead(std::string const &prefix) -> VisMFData
 		hdr >> tag >> name >> head;
 		if (tag != "FabOnDisk:") {
 			amrex::Abort("quokka::io::VisMFRead: malformed FabOnDisk entry in " + prefix + "_H");
+		}
+		if (wanted != nullptr && static_cast<size_t>(n) < r.boxes.size()) {
+			amrex::Box const stored = amrex::grow(r.boxes[n], r.nghost);
+			bool meets = false;
+			for (auto const &w : *wanted) {
+				meets = meets || (stored & w).ok();
+			}
+			if (!meets) {
+				r.fabboxes.push_back(stored);
+				r.fabs.emplace_back(); // not read
+				continue;
+			}
 		}
 		std::ifstream data(dir + "/" + name, std::ifstream::in | std::ifstream::binary);
 		if (!data.good()) {
@@ -381,7 +395,11 @@ inline auto VisMFRead(std::string const &prefix) -> VisMFData
 // the file's ghost data elsewhere.
 inline void VisMFReadInto(amrex::MultiFab &dst, std::string const &prefix)
 {
-	VisMFData const src = VisMFRead(prefix);
+	std::vector<amrex::Box> mine;
+	for (int b = 0; b < dst.size(); ++b) {
+		mine.push_back(dst.fabbox(b));
+	}
+	VisMFData const src = VisMFRead(prefix, &mine);
 	if (src.ncomp != dst.nComp()) {
 		amrex::Abort("quokka::io::VisMFReadInto: component count of " + prefix + " does not match");
 	}
@@ -391,6 +409,9 @@ inline void VisMFReadInto(amrex::MultiFab &dst, std::string const &prefix)
 		amrex::Array4<double> d(h.data(), dst.fabbox(b), nc);
 		for (int pass = 0; pass < 2; ++pass) { // 0: everything stored, 1: valid cells on top
 			for (size_t f = 0; f < src.fabs.size(); ++f) {
+				if (src.fabs[f].empty()) {
+					continue; // outside every box of this rank
+				}
 				amrex::Box const &from = (pass == 0) ? src.fabboxes[f] : src.boxes[f];
 				amrex::Box isect;
 				bool ok = true;
