@@ -557,6 +557,41 @@ int qk_amr_cluster_tiles(const int *tiles, const int ntiles[3], int ndim, int bl
 int qk_amr_cluster_berger_rigoutsos(const int *tiles, const int *allowed, const int ntiles[3], int ndim, int blocking_factor, int max_grid_size, double grid_eff,
 				    qk_box *boxes, int max_boxes);
 
+/* ------------------------------------------------------------------ optically-thin cooling from Cloudy tables (Strang-split source)
+ * The five arrays of quokka::TabulatedCooling::cloudy_tables (reference src/cooling/TabulatedCooling.hpp:54-73): log10 n_H (n_nH values,
+ * uniformly spaced), log10 T (n_Tgas values), and three n_nH x n_Tgas tables with the n_H index running fastest — FastMath::log10 of the cooling
+ * and heating rates in units of (1.67e-24 g)^2, and the dimensionless mean molecular weight —; the temperature and mean-molecular-weight ranges. */
+typedef struct qk_cloudy_tables {
+	const double *log_nH;
+	const double *log_Tgas;
+	const double *cooling;
+	const double *heating;
+	const double *mean_mol_weight;
+	int n_nH, n_Tgas;
+	double T_min, T_max;
+	double mmw_min, mmw_max;
+} qk_cloudy_tables;
+/* readCloudyData(hdf5_file, cloudyTables) (reference src/cooling/TabulatedCooling.cpp:9-31 with initialize_cloudy_data,
+ * src/cooling/CloudyDataReader.cpp:24-200): reads /Cooling (attributes Rank, Dimension), /Heating, /MMW, /Parameter1, /Temperature of a
+ * cloudy_cooling_tools file — with the library's own reader of the HDF5 file format, libhdf5 is not needed — into HOST arrays owned by the library
+ * (qk_cloudy_tables_free releases them).  The caller copies them to device memory and passes a struct of device pointers to the two kernels. */
+int qk_cloudy_tables_read(qk_ctx *ctx, const char *path, qk_cloudy_tables *host_tables);
+int qk_cloudy_tables_free(qk_cloudy_tables *host_tables);
+/* quokka::TabulatedCooling::computeCooling<problem_t>(mf, dt, cloudyTables, T_floor) (reference src/cooling/TabulatedCooling.hpp:258-317), which
+ * addStrangSplitSourcesWithBuiltin calls with dt = dt_lev / 2 before and after the hydro update (src/QuokkaSimulation.hpp:520-547,1048,1318):
+ * dE_int/dt = (rho X)^2 (Gamma - Lambda)(n_H, T(E_int)) integrated over dt in every valid cell with the adaptive Heun integrator of
+ * src/math/ODEIntegrate.hpp (rtol 1e-4, abstol 0.01 E(T_floor)); gas energy and auxiliary internal energy take the change.
+ * d_counters (device, cleared by the caller): [0] the largest number of substeps any cell took, [1] their sum.  [0] == 2000
+ * (maxStepsODEIntegrate) means the integration failed in some cell: the reference retries the hydro step with a smaller dt. */
+int qk_cooling_tabulated(qk_level *lev, qk_stream s, const qk_hydro_traits *t, qk_array4 *state, const qk_cloudy_tables *device_tables, double dt, double T_floor,
+			 long long *d_counters);
+/* The per-cell functions of src/cooling/TabulatedCooling.hpp a problem evaluates in its own kernels, over n (rho, value) pairs in device memory:
+ * ComputeTgasFromEgas (:117-174; value = E_int), ComputeEgasFromTgas (:101-115; value = T), ComputeMMW (:206-220; value = E_int),
+ * ComputeCoolingLength (:176-204; value = E_int), cloudy_cooling_function (:82-99; value = T). */
+enum { QK_COOLING_TGAS_FROM_EGAS = 0, QK_COOLING_EGAS_FROM_TGAS = 1, QK_COOLING_MMW = 2, QK_COOLING_LENGTH = 3, QK_COOLING_NET_HEATING = 4 };
+int qk_cooling_evaluate(qk_ctx *ctx, qk_stream s, const qk_cloudy_tables *device_tables, double gamma, int what, int64_t n, const double *d_rho, const double *d_value,
+			double *d_out);
+
 #ifdef __cplusplus
 }
 #endif

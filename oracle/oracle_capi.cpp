@@ -9,6 +9,7 @@
 #include <memory>
 
 #include "amr.hpp"
+#include "cooling.hpp"
 #include "hydro_sim.hpp"
 #include "problems.hpp"
 
@@ -505,6 +506,70 @@ void orc_average_down(const double *fine, const int *flo, const int *fhi, double
 	Array4<const double> f(fine, fb, ncomp_total);
 	Array4<double> c(crse, cb, ncomp_total);
 	averageDown(f, c, region, scomp, ncomp, ratio);
+}
+
+// ------------------------------------------------------------------ tabulated cooling (cooling.hpp)
+// the five datasets of a cloudy_cooling_tools file as H5Dread delivers them (Parameter1[n0], Temperature[n1], Cooling / Heating / MMW [n0][n1])
+void *orc_cloudy_create(int n0, int n1, const double *parameter1, const double *temperature, const double *cooling_rate, const double *heating_rate, const double *mmw)
+{
+	return new cooling::cloudy_tables(cooling::prepare_tables(n0, n1, parameter1, temperature, cooling_rate, heating_rate, mmw));
+}
+void orc_cloudy_destroy(void *p) { delete static_cast<cooling::cloudy_tables *>(p); }
+// out: T_min, T_max, mmw_min, mmw_max
+void orc_cloudy_ranges(void *p, double *out)
+{
+	auto const &t = *static_cast<cooling::cloudy_tables *>(p);
+	out[0] = t.T_min;
+	out[1] = t.T_max;
+	out[2] = t.mmw_min;
+	out[3] = t.mmw_max;
+}
+// the prepared arrays: which = 0 log_nH, 1 log_Tgas, 2 cooling, 3 heating, 4 mean molecular weight (n_H fastest)
+void orc_cloudy_get(void *p, int which, double *out)
+{
+	auto const &t = *static_cast<cooling::cloudy_tables *>(p);
+	std::vector<double> const *v[5] = {&t.log_nH_v, &t.log_Tgas_v, &t.cool_v, &t.heat_v, &t.mmw_v};
+	std::copy(v[which]->begin(), v[which]->end(), out);
+}
+// what: 0 ComputeTgasFromEgas, 1 ComputeEgasFromTgas, 2 ComputeMMW, 3 ComputeCoolingLength, 4 cloudy_cooling_function (val = E_int, T, E_int, E_int, T)
+void orc_cloudy_evaluate(void *p, double gamma, int what, long n, const double *rho, const double *val, double *out)
+{
+	auto const &t = *static_cast<cooling::cloudy_tables *>(p);
+	_Pragma("omp parallel for schedule(dynamic, 64)")
+	for (long i = 0; i < n; ++i) {
+		switch (what) {
+		case 0:
+			out[i] = cooling::ComputeTgasFromEgas(rho[i], val[i], gamma, t);
+			break;
+		case 1:
+			out[i] = cooling::ComputeEgasFromTgas(rho[i], val[i], gamma, t);
+			break;
+		case 2:
+			out[i] = cooling::ComputeMMW(rho[i], val[i], gamma, t);
+			break;
+		case 3:
+			out[i] = cooling::ComputeCoolingLength(rho[i], val[i], gamma, t);
+			break;
+		default:
+			out[i] = cooling::cloudy_cooling_function(rho[i], val[i], t);
+			break;
+		}
+	}
+}
+// computeCooling over n cells: U[6][n] = (rho, x1Mom, x2Mom, x3Mom, Egas, Eint_aux), component outermost; nsteps[n]
+void orc_cloudy_compute_cooling(void *p, double gamma, double dt, double T_floor, long n, double *U, int *nsteps)
+{
+	auto const &t = *static_cast<cooling::cloudy_tables *>(p);
+	_Pragma("omp parallel for schedule(dynamic, 16)")
+	for (long i = 0; i < n; ++i) {
+		double cell[6];
+		for (int c = 0; c < 6; ++c) {
+			cell[c] = U[c * n + i];
+		}
+		nsteps[i] = cooling::computeCoolingCell(cell, dt, t, T_floor, gamma);
+		U[4 * n + i] = cell[4];
+		U[5 * n + i] = cell[5];
+	}
 }
 
 } // extern "C"

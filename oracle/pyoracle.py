@@ -403,3 +403,57 @@ class OracleSim:
         out = (C.c_long * 3)()
         self.o.lib.orc_sim_counters(self.h, out)
         return {"fofc1_cells": out[0], "fofc2_cells": out[1], "retries": out[2]}
+
+
+class OracleCloudy:
+    """oracle/cooling.hpp: the reference's tabulated cooling on the arrays of a cloudy_cooling_tools file (Parameter1, Temperature, Cooling,
+    Heating, MMW as H5Dread delivers them)"""
+    TGAS_FROM_EGAS, EGAS_FROM_TGAS, MMW, COOLING_LENGTH, NET_HEATING = range(5)
+
+    def __init__(self, arrays: dict, variant: str = "direct"):
+        self.o = Oracle(variant)
+        L = self.lib = self.o.lib
+        L.orc_cloudy_create.restype = C.c_void_p
+        DP = C.POINTER(C.c_double)
+        L.orc_cloudy_create.argtypes = [C.c_int, C.c_int, DP, DP, DP, DP, DP]
+        L.orc_cloudy_destroy.argtypes = [C.c_void_p]
+        L.orc_cloudy_ranges.argtypes = [C.c_void_p, DP]
+        L.orc_cloudy_get.argtypes = [C.c_void_p, C.c_int, DP]
+        L.orc_cloudy_evaluate.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_long, DP, DP, DP]
+        L.orc_cloudy_compute_cooling.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_long, DP, C.POINTER(C.c_int)]
+        a = {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in arrays.items()}
+        self.n0, self.n1 = a["Cooling"].shape
+        self.h = C.c_void_p(L.orc_cloudy_create(self.n0, self.n1, _dp(a["Parameter1"]), _dp(a["Temperature"]), _dp(a["Cooling"]), _dp(a["Heating"]), _dp(a["MMW"])))
+
+    def __del__(self):
+        try:
+            self.lib.orc_cloudy_destroy(self.h)
+        except Exception:
+            pass
+
+    def ranges(self):
+        """(T_min, T_max, mmw_min, mmw_max)"""
+        r = np.zeros(4)
+        self.lib.orc_cloudy_ranges(self.h, _dp(r))
+        return tuple(float(v) for v in r)
+
+    def prepared(self, which: int) -> np.ndarray:
+        """0 log_nH, 1 log_Tgas, 2 cooling, 3 heating, 4 mean molecular weight (n_H fastest)"""
+        out = np.zeros([self.n0, self.n1, self.n0 * self.n1, self.n0 * self.n1, self.n0 * self.n1][which])
+        self.lib.orc_cloudy_get(self.h, which, _dp(out))
+        return out
+
+    def evaluate(self, what: int, rho, val, gamma: float) -> np.ndarray:
+        rho = np.ascontiguousarray(rho, dtype=np.float64)
+        val = np.ascontiguousarray(val, dtype=np.float64)
+        out = np.zeros_like(rho)
+        self.lib.orc_cloudy_evaluate(self.h, gamma, what, rho.size, _dp(rho), _dp(val), _dp(out))
+        return out
+
+    def compute_cooling(self, U: np.ndarray, gamma: float, dt: float, T_floor: float):
+        """U[6, n] = (rho, x1Mom, x2Mom, x3Mom, Egas, Eint_aux): returns (U after computeCooling, substeps per cell)"""
+        U = np.ascontiguousarray(U, dtype=np.float64).copy()
+        n = U.shape[1]
+        ns = np.zeros(n, dtype=np.int32)
+        self.lib.orc_cloudy_compute_cooling(self.h, gamma, dt, T_floor, n, _dp(U), ns.ctypes.data_as(C.POINTER(C.c_int)))
+        return U, ns

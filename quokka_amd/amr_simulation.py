@@ -180,8 +180,8 @@ class AmrLevelSim(HydroSimulation):
     def _before_fill(self, stage: int, dt: float):
         self._fill_time = self._t_adv + (dt if stage == 2 else 0.0)  # reference src/QuokkaSimulation.hpp:1076, :1204
 
-    def advanceHydroAtLevel(self, state_old_tmp: MultiFab, dt_lev: float) -> bool:
-        ok = super().advanceHydroAtLevel(state_old_tmp, dt_lev)
+    def advanceHydroAtLevel(self, state_old_tmp: MultiFab, dt_lev: float, time=None) -> bool:
+        ok = super().advanceHydroAtLevel(state_old_tmp, dt_lev, self._t_adv if time is None else time)
         if ok:  # incrementFluxRegisters (reference src/QuokkaSimulation.hpp:1303-1306, src/simulation.hpp:1369-1386)
             amr, l = self.amr, self.ilev
             # integratorOrder_ == 1: the step's fluxes are the stage-1 fluxes (scale 1), which stay in halfFlux
@@ -215,8 +215,9 @@ class AmrLevelSim(HydroSimulation):
                 if fr_as_fine is not None:
                     fr_as_fine.restore()
             self._t_adv = time
-            old = self.state_old_cc_ if nsubsteps == 1 else self.state_old_tmp
-            if nsubsteps > 1:
+            in_place = nsubsteps == 1 and not self.strang_sources  # (a Strang-split source changes the old state: then always the copy)
+            old = self.state_old_cc_ if in_place else self.state_old_tmp
+            if not in_place:
                 self.state_old_tmp.copy_from(self.state_old_cc_)
             success = True
             for substep in range(nsubsteps):

@@ -87,6 +87,12 @@ class RadTraits(C.Structure):
         return self
 
 
+class CloudyTables(C.Structure):
+    """qk_cloudy_tables: five arrays (host pointers from qk_cloudy_tables_read, or device pointers for the kernels) + ranges"""
+    _fields_ = [("log_nH", C.c_void_p), ("log_Tgas", C.c_void_p), ("cooling", C.c_void_p), ("heating", C.c_void_p), ("mean_mol_weight", C.c_void_p),
+                ("n_nH", C.c_int), ("n_Tgas", C.c_int), ("T_min", C.c_double), ("T_max", C.c_double), ("mmw_min", C.c_double), ("mmw_max", C.c_double)]
+
+
 class StageArgs(C.Structure):
     _fields_ = [("U_in", C.c_void_p), ("U_old", C.c_void_p), ("U_out", C.c_void_p),
                 ("halfFlux", C.c_void_p * 3), ("halfVel", C.c_void_p * 3),
@@ -134,6 +140,10 @@ def lib() -> C.CDLL:
     L.qk_profile_only.argtypes = [vp, C.c_char_p]
     L.qk_clear_bytes.argtypes = [vp, vp, vp, C.c_int64]
     L.qk_profile_reset.argtypes = [vp]
+    L.qk_cloudy_tables_read.argtypes = [vp, C.c_char_p, P(CloudyTables)]
+    L.qk_cloudy_tables_free.argtypes = [P(CloudyTables)]
+    L.qk_cooling_tabulated.argtypes = [vp, vp, P(HydroTraits), vp, P(CloudyTables), cd, cd, vp]
+    L.qk_cooling_evaluate.argtypes = [vp, vp, P(CloudyTables), cd, ci, C.c_int64, vp, vp, vp]
     L.qk_profile_num_kernels.argtypes = [vp]
     L.qk_profile_get.argtypes = [vp, ci, P(C.c_char_p), P(C.c_long), P(cd)]
     T = P(HydroTraits)
@@ -246,6 +256,7 @@ DECLARED_SYMBOLS = [
     "qk_interp_plan_create", "qk_interp_plan_destroy", "qk_interp_plan_num_items", "qk_interp_plan_item", "qk_InterpFromCoarse",
     "qk_fluxreg_create", "qk_fluxreg_destroy", "qk_fluxreg_num_items", "qk_fluxreg_item", "qk_fluxreg_reset", "qk_fluxreg_save", "qk_fluxreg_restore", "qk_fluxreg_CrseAdd", "qk_fluxreg_FineAdd",
     "qk_fluxreg_Reflux", "qk_fluxreg_set_state_component", "qk_amr_tile_flags", "qk_amr_tile_flags_periodic", "qk_amr_cluster_tiles", "qk_amr_cluster_berger_rigoutsos", "qk_copy_box",
+    "qk_cloudy_tables_read", "qk_cloudy_tables_free", "qk_cooling_tabulated", "qk_cooling_evaluate",
 ]
 
 

@@ -1,0 +1,476 @@
+// qk_cooling_device.hpp — optically-thin cooling from Cloudy tables, per cell (host + device).
+//
+// What the reference does (src/cooling/TabulatedCooling.hpp): the Strang-split source integrates dE_int/dt = n_H^2 (Gamma - Lambda)(n_H, T) over
+// dt/2 in every cell with an adaptive Heun integrator (src/math/ODEIntegrate.hpp); T follows from E_int through the tabulated mean molecular
+// weight mu(n_H, T), an implicit relation solved with Alefeld, Potra & Shi's Algorithm 748 (ACM TOMS 21, 327 (1995); src/math/root_finding.hpp)
+// to a relative bracket width of 1e-5 — the returned temperature is the MIDPOINT of the final bracket, so the sequence of bracketing points is
+// part of the result and is followed here step for step (same interpolation points, same guards, same order of the floating-point operations).
+// Functions are QK_HD: the library's kernel (qk_cooling.hip) and the host mirror's quokka::TabulatedCooling functions, which the problem files call
+// from their own device lambdas (host/compat/tabulated_cooling.hpp), share them.
+#ifndef QK_COOLING_DEVICE_HPP_
+#define QK_COOLING_DEVICE_HPP_
+
+#include <cfloat>
+#include <cmath>
+
+#ifndef QK_HD
+#if defined(__HIPCC__)
+#define QK_HD __host__ __device__ inline
+#else
+#define QK_HD inline
+#endif
+#endif
+
+namespace qk
+{
+namespace cool
+{
+
+// the tables as the kernels see them: log10 n_H (n_nH values, uniformly spaced), log10 T (n_T values), and three n_nH x n_T tables with the
+// n_H index running fastest — the layout of the reference's transposed TableData (CloudyDataReader.cpp:206-222)
+struct Tables {
+	const double *log_nH;
+	const double *log_T;
+	const double *cool; // FastMath::log10 of Lambda / CoolUnit
+	const double *heat;
+	const double *mmw; // dimensionless mean molecular weight
+	int n_nH, n_T;
+	double T_min, T_max;
+	double mmw_min, mmw_max;
+	// constants of fundamental_constants.H the relations use: m_p + m_e and k_B (cgs)
+	double m_H, k_B;
+};
+
+// "abundances ism" of Cloudy: n_He / n_H = 0.098 (TabulatedCooling.hpp:32)
+constexpr double H_mass_fraction = 1. / (1. + 0.098 * 3.971);
+
+QK_HD auto clampd(double v, double lo, double hi) -> double { return (v < lo) ? lo : (hi < v) ? hi : v; }
+QK_HD auto clampi(int v, int lo, int hi) -> int { return (v < lo) ? lo : (hi < v) ? hi : v; }
+QK_HD auto signOf(double v) -> int { return (0.0 < v) - (v < 0.0); }
+QK_HD auto isNan(double v) -> bool { return v != v; }
+
+// FastMath::pow10 (src/math/FastMath.hpp:42-49,68-72): 2^x with the fractional part of x taken linearly
+QK_HD auto fastPow10(double x) -> double
+{
+	constexpr double LOG10OLOG2 = 3.321928094887362626;
+	const double x2 = LOG10OLOG2 * x;
+	const int flr = static_cast<int>(floor(x2)); // (the reference stores std::floor in an int)
+	const double remainder = x2 - flr;
+	const double mantissa = 0.5 * (remainder + 1);
+	return ldexp(mantissa, flr + 1);
+}
+// FastMath::log10 (FastMath.hpp:33-40,62-66): frexp's exponent + the mantissa taken linearly
+QK_HD auto fastLog10(double x) -> double
+{
+	constexpr double LOG2OLOG10 = 0.301029995663981195;
+	int n = 0;
+	const double y = frexp(x, &n);
+	return LOG2OLOG10 * (2 * (y - 1) + n);
+}
+
+// interpolate2d (src/math/Interpolate2D.hpp:14-80) on a uniformly spaced table.  The reference's degenerate-cell tests compare the first ORDINATE
+// `yi` with the upper INDEX `iiy`; they are kept as written, since they decide the weights on the last row / column of the table.
+QK_HD auto interp2d(double x, double y, const double *xv, int nx, const double *yv, int ny, const double *table) -> double
+{
+	const double xi = xv[0], xf = xv[nx - 1];
+	const double yi = yv[0], yf = yv[ny - 1];
+	const double dx = (xf - xi) / static_cast<double>(nx - 1);
+	const double dy = (yf - yi) / static_cast<double>(ny - 1);
+	x = clampd(x, xi, xf);
+	y = clampd(y, yi, yf);
+	const int ix = clampi(static_cast<int>(floor((x - xi) / dx)), 0, nx - 1);
+	const int iy = clampi(static_cast<int>(floor((y - yi) / dy)), 0, ny - 1);
+	const int iix = (ix == nx - 1) ? ix : ix + 1;
+	const int iiy = (iy == ny - 1) ? iy : iy + 1;
+	const double x1 = xv[ix], x2 = xv[iix], y1 = yv[iy], y2 = yv[iiy];
+	double w11 = 0, w12 = 0, w21 = 0, w22 = 0;
+	const bool yEdge = (yi == static_cast<double>(iiy)); // sic
+	if (ix != iix && iy != iiy) {
+		const double vol = ((x2 - x1) * (y2 - y1));
+		w11 = (x2 - x) * (y2 - y) / vol;
+		w12 = (x2 - x) * (y - y1) / vol;
+		w21 = (x - x1) * (y2 - y) / vol;
+		w22 = (x - x1) * (y - y1) / vol;
+	} else if (ix == iix && !yEdge) {
+		const double vol = (y2 - y1);
+		w11 = (y2 - y) / vol;
+		w12 = (y - y1) / vol;
+	} else if (ix != iix && yEdge) {
+		const double vol = (x2 - x1);
+		w11 = (x2 - x) / vol;
+		w21 = (x - x1) / vol;
+	} else {
+		w11 = 1.0;
+	}
+	const double A = table[ix + nx * iy];
+	const double B = table[ix + nx * iiy];
+	const double C = table[iix + nx * iy];
+	const double D = table[iix + nx * iiy];
+	return w11 * A + w12 * B + w21 * C + w22 * D;
+}
+
+QK_HD auto lookup(Tables const &t, const double *table, double log_nH, double log_T) -> double
+{
+	return interp2d(log_nH, log_T, t.log_nH, t.n_nH, t.log_T, t.n_T, table);
+}
+
+// cloudy_cooling_function (TabulatedCooling.hpp:82-99): net heating rate per volume, (rho X)^2 (10^heat - 10^cool)
+QK_HD auto netHeating(Tables const &t, double rho, double T) -> double
+{
+	const double rhoH = rho * H_mass_fraction;
+	const double nH = rhoH / t.m_H;
+	const double log_nH = log10(nH);
+	const double log_T = log10(T);
+	const double logCool = lookup(t, t.cool, log_nH, log_T);
+	const double logHeat = lookup(t, t.heat, log_nH, log_T);
+	const double netLambda = fastPow10(logHeat) - fastPow10(logCool);
+	return (rhoH * rhoH) * netLambda;
+}
+
+// ComputeEgasFromTgas (TabulatedCooling.hpp:101-115)
+QK_HD auto egasFromTgas(Tables const &t, double rho, double Tgas, double gamma) -> double
+{
+	const double rhoH = rho * H_mass_fraction;
+	const double nH = rhoH / t.m_H;
+	const double mu = lookup(t, t.mmw, log10(nH), log10(Tgas));
+	const double n = rho / (t.m_H * mu);
+	const double Pgas = n * t.k_B * Tgas;
+	return Pgas / (gamma - 1.);
+}
+
+// ---- Algorithm 748: a bracket [a, b] with f(a) f(b) < 0 and the two points that left it last (d, e)
+struct Bracket748 {
+	double a, b, fa, fb, d, fd, e, fe;
+
+	// secant point, pulled to the midpoint when it falls within 5 eps of an end (root_finding.hpp:134-145)
+	QK_HD auto secantPoint() const -> double
+	{
+		const double tol = DBL_EPSILON * 5;
+		const double c = a - (fa / (fb - fa)) * (b - a);
+		if ((c <= a + fabs(a) * tol) || (c >= b - fabs(b) * tol)) {
+			return (a + b) / 2;
+		}
+		return c;
+	}
+	// quotient that returns r instead of overflowing (root_finding.hpp:120-132)
+	QK_HD static auto guardedQuotient(double num, double denom, double r) -> double
+	{
+		if (fabs(denom) < 1) {
+			if (fabs(denom * DBL_MAX) <= fabs(num)) {
+				return r;
+			}
+		}
+		return num / denom;
+	}
+	// zero of the parabola through (a, b, d) by `count` Newton steps from the end where it has the sign of the curvature (root_finding.hpp:147-176)
+	QK_HD auto parabolaPoint(unsigned count) const -> double
+	{
+		const double B = guardedQuotient(fb - fa, b - a, DBL_MAX);
+		double A = guardedQuotient(fd - fb, d - b, DBL_MAX);
+		A = guardedQuotient(A - B, d - a, 0.0);
+		if (A == 0) {
+			return secantPoint();
+		}
+		double c = (signOf(A) * signOf(fa) > 0) ? a : b;
+		for (unsigned i = 1; i <= count; ++i) {
+			c -= guardedQuotient(fa + (B + A * (c - b)) * (c - a), B + A * (2 * c - a - b), 1 + c - a);
+		}
+		if ((c <= a) || (c >= b)) {
+			c = secantPoint();
+		}
+		return c;
+	}
+	// inverse cubic interpolation through (a, b, d, e) (root_finding.hpp:178-208)
+	QK_HD auto inverseCubicPoint() const -> double
+	{
+		const double q11 = (d - e) * fd / (fe - fd);
+		const double q21 = (b - d) * fb / (fd - fb);
+		const double q31 = (a - b) * fa / (fb - fa);
+		const double d21 = (b - d) * fd / (fd - fb);
+		const double d31 = (a - b) * fb / (fb - fa);
+		const double q22 = (d21 - q11) * fb / (fe - fb);
+		const double q32 = (d31 - q21) * fa / (fd - fa);
+		const double d32 = (d31 - q21) * fd / (fd - fa);
+		const double q33 = (d32 - q22) * fa / (fe - fa);
+		double c = q31 + q32 + q33 + a;
+		if ((c <= a) || (c >= b)) {
+			c = parabolaPoint(3);
+		}
+		return c;
+	}
+	// two function values closer than 32 denormal minima: the cubic's divided differences would overflow (root_finding.hpp:272-274)
+	QK_HD auto valuesCoincide() const -> bool
+	{
+		const double min_diff = DBL_MIN * 32;
+		return (fabs(fa - fb) < min_diff) || (fabs(fa - fd) < min_diff) || (fabs(fa - fe) < min_diff) || (fabs(fb - fd) < min_diff) ||
+		       (fabs(fb - fe) < min_diff) || (fabs(fd - fe) < min_diff);
+	}
+	// evaluate f at c (kept 2 eps inside the bracket) and keep the half that still brackets the root (root_finding.hpp:84-118)
+	template <class F> QK_HD void shrinkAt(F const &f, double c)
+	{
+		const double tol = DBL_EPSILON * 2;
+		if ((b - a) < 2 * tol * a) {
+			c = a + (b - a) / 2;
+		} else if (c <= a + fabs(a) * tol) {
+			c = a + fabs(a) * tol;
+		} else if (c >= b - fabs(b) * tol) {
+			c = b - fabs(b) * tol;
+		}
+		const double fc = f(c);
+		if (fc == 0) {
+			a = c;
+			fa = 0;
+			d = 0;
+			fd = 0;
+			return;
+		}
+		if (signOf(fa) * signOf(fc) < 0) {
+			d = b;
+			fd = fb;
+			b = c;
+			fb = fc;
+		} else {
+			d = a;
+			fd = fa;
+			a = c;
+			fa = fc;
+		}
+	}
+	QK_HD auto narrow(double eps) const -> bool { return fabs(a - b) <= (eps * fmin(fabs(a), fabs(b))); }
+};
+
+// toms748_solve(f, ax, bx, tol, max_iter) (root_finding.hpp:212-340): on return [lo, hi] brackets the root, iterations = function evaluations used
+// (the two at the ends included).  ax < bx and f(ax) f(bx) <= 0 are the caller's responsibility, as in the reference (which asserts them).
+template <class F> QK_HD void solve748(F const &f, double ax, double bx, double eps, int max_iter, double &lo, double &hi, int &iterations)
+{
+	int budget = max_iter - 2;
+	int count = budget;
+	Bracket748 s;
+	s.a = ax;
+	s.b = bx;
+	s.fa = f(ax);
+	s.fb = f(bx);
+	if (s.narrow(eps) || (s.fa == 0) || (s.fb == 0)) {
+		if (s.fa == 0) {
+			s.b = s.a;
+		} else if (s.fb == 0) {
+			s.a = s.b;
+		}
+		lo = s.a;
+		hi = s.b;
+		iterations = 2;
+		return;
+	}
+	s.fe = s.e = s.fd = 1e5F;
+	s.d = 0; // (never read before the first shrinkAt sets it)
+	// two opening steps: secant, then the parabola
+	s.shrinkAt(f, s.secantPoint());
+	--count;
+	if (count != 0 && (s.fa != 0) && !s.narrow(eps)) {
+		const double c = s.parabolaPoint(2);
+		s.e = s.d;
+		s.fe = s.fd;
+		s.shrinkAt(f, c);
+		--count;
+	}
+	while (count != 0 && (s.fa != 0) && !s.narrow(eps)) {
+		const double a0 = s.a, b0 = s.b;
+		// two interpolation steps: the cubic where its divided differences exist, else the parabola (2, then 3 Newton steps)
+		double c = s.valuesCoincide() ? s.parabolaPoint(2) : s.inverseCubicPoint();
+		s.e = s.d;
+		s.fe = s.fd;
+		s.shrinkAt(f, c);
+		if ((0 == --count) || (s.fa == 0) || s.narrow(eps)) {
+			break;
+		}
+		c = s.valuesCoincide() ? s.parabolaPoint(3) : s.inverseCubicPoint();
+		s.shrinkAt(f, c);
+		if ((0 == --count) || (s.fa == 0) || s.narrow(eps)) {
+			break;
+		}
+		// a double-length secant step from the end with the smaller |f|, not farther than half the bracket
+		double u, fu;
+		if (fabs(s.fa) < fabs(s.fb)) {
+			u = s.a;
+			fu = s.fa;
+		} else {
+			u = s.b;
+			fu = s.fb;
+		}
+		c = u - 2 * (fu / (s.fb - s.fa)) * (s.b - s.a);
+		if (fabs(c - u) > (s.b - s.a) / 2) {
+			c = s.a + (s.b - s.a) / 2;
+		}
+		s.e = s.d;
+		s.fe = s.fd;
+		s.shrinkAt(f, c);
+		if ((0 == --count) || (s.fa == 0) || s.narrow(eps)) {
+			break;
+		}
+		// the three steps together must halve the bracket; bisect when they did not
+		if ((s.b - s.a) < 0.5 * (b0 - a0)) {
+			continue;
+		}
+		s.e = s.d;
+		s.fe = s.fd;
+		s.shrinkAt(f, s.a + (s.b - s.a) / 2);
+		--count;
+	}
+	if (s.fa == 0) {
+		s.b = s.a;
+	} else if (s.fb == 0) {
+		s.a = s.b;
+	}
+	lo = s.a;
+	hi = s.b;
+	iterations = (budget - count) + 2;
+}
+
+// ComputeTgasFromEgas (TabulatedCooling.hpp:117-174): T with mu(n_H, T) C = T, C = (gamma - 1) E / (k_B rho / m_H); NaN when the bracket is empty or
+// the iteration limit is reached
+QK_HD auto tgasFromEgas(Tables const &t, double rho, double Egas, double gamma) -> double
+{
+	const double Eint_min = egasFromTgas(t, rho, t.T_min, gamma);
+	const double Eint_max = egasFromTgas(t, rho, t.T_max, gamma);
+	if (Egas <= Eint_min) {
+		return t.T_min;
+	}
+	if (Egas >= Eint_max) {
+		return t.T_max;
+	}
+	const double rhoH = rho * H_mass_fraction;
+	const double nH = rhoH / t.m_H;
+	const double log_nH = log10(nH);
+	const double C = (gamma - 1.) * Egas / (t.k_B * (rho / t.m_H));
+	const double reltol = 1.0e-5;
+	const int maxIterLimit = 100;
+	auto f = [&](double T) {
+		const double log_T = clampd(log10(T), 1., 9.);
+		const double mu = lookup(t, t.mmw, log_nH, log_T);
+		return C * mu - T;
+	};
+	const double T_lo = clampd(C * t.mmw_min, t.T_min, t.T_max);
+	const double T_hi = clampd(C * t.mmw_max, t.T_min, t.T_max);
+	double T_sol = NAN;
+	if (T_lo < T_hi) {
+		double lo, hi;
+		int used = 0;
+		solve748(f, T_lo, T_hi, reltol, maxIterLimit, lo, hi, used);
+		T_sol = 0.5 * (lo + hi);
+		if ((used >= maxIterLimit) || isNan(T_sol)) {
+			T_sol = NAN;
+		}
+	}
+	return T_sol;
+}
+
+// ComputeMMW (TabulatedCooling.hpp:206-220)
+QK_HD auto meanMolecularWeight(Tables const &t, double rho, double Egas, double gamma) -> double
+{
+	const double Tgas = tgasFromEgas(t, rho, Egas, gamma);
+	const double rhoH = rho * H_mass_fraction;
+	const double nH = rhoH / t.m_H;
+	return lookup(t, t.mmw, log10(nH), log10(Tgas));
+}
+
+// ComputeCoolingLength (TabulatedCooling.hpp:176-204): c_s t_cool with the cooling part of the table only
+QK_HD auto coolingLength(Tables const &t, double rho, double Egas, double gamma) -> double
+{
+	const double Tgas = tgasFromEgas(t, rho, Egas, gamma);
+	const double rhoH = rho * H_mass_fraction;
+	const double nH = rhoH / t.m_H;
+	const double log_nH = log10(nH);
+	const double log_T = log10(Tgas);
+	const double logCool = lookup(t, t.cool, log_nH, log_T);
+	const double LambdaCool = fastPow10(logCool);
+	const double Edot = (rhoH * rhoH) * LambdaCool;
+	const double t_cool = Egas / Edot;
+	const double mu = lookup(t, t.mmw, log_nH, log_T);
+	const double c_s = sqrt(gamma * t.k_B * Tgas / (mu * t.m_H));
+	return c_s * t_cool;
+}
+
+// user_rhs (TabulatedCooling.hpp:222-256): dE_int/dt; false when the temperature iteration failed
+QK_HD auto heatingRate(Tables const &t, double rho, double gamma, double Eint, double &rate) -> bool
+{
+	const double Eint_min = egasFromTgas(t, rho, t.T_min, gamma);
+	const double Eint_max = egasFromTgas(t, rho, t.T_max, gamma);
+	if (Eint <= Eint_min) {
+		rate = netHeating(t, rho, t.T_min);
+	} else if (Eint >= Eint_max) {
+		rate = netHeating(t, rho, t.T_max);
+	} else {
+		const double T = tgasFromEgas(t, rho, Eint, gamma);
+		if (isNan(T)) {
+			rate = NAN;
+			return false;
+		}
+		rate = netHeating(t, rho, T);
+	}
+	return true;
+}
+
+constexpr int maxSubsteps = 2000; // maxStepsODEIntegrate (ODEIntegrate.hpp:122)
+
+// rk_adaptive_integrate with rk12_single_step for one unknown (ODEIntegrate.hpp:20-53,105-226): Heun's method with the embedded Euler solution,
+// step-size factor eps^(-1/2) limited to 20 after a clean step, 1 after a retry, 0.3 on the second failure, [0.1, 0.3] afterwards, 0.5 after a
+// failed right-hand side; 7 attempts per step.  Returns the number of steps; maxSubsteps = failure.
+QK_HD auto integrateCooling(Tables const &t, double rho, double gamma, double &E, double dt_total, double reltol, double abstol) -> int
+{
+	double rate0 = NAN;
+	heatingRate(t, rho, gamma, E, rate0);
+	const double dt_guess = 0.1 * fabs(E / rate0);
+	double time = 0;
+	double dt = isNan(dt_guess) ? dt_total : dt_guess;
+	for (int i = 0; i < maxSubsteps; ++i) {
+		if ((time + dt) > dt_total) {
+			dt = dt_total - time;
+		}
+		bool stepped = false;
+		for (int k = 0; k < 7; ++k) {
+			double eta = NAN;
+			double k1 = NAN, k2 = NAN;
+			bool ok = heatingRate(t, rho, gamma, E, k1);
+			if (ok) {
+				k1 *= dt;
+				ok = heatingRate(t, rho, gamma, E + k1, k2);
+			}
+			if (!ok) {
+				eta = 0.5;
+			} else {
+				k2 *= dt;
+				const double Enew = E + 0.5 * k1 + 0.5 * k2;
+				const double Eerr = -0.5 * k1 + 0.5 * k2;
+				const double w = 1. / (reltol * E + abstol);
+				const double epsilon = sqrt(((Eerr * Eerr) * (w * w)) / 1);
+				eta = pow(epsilon, -1.0 / 2.0);
+				if (epsilon < 1.0) {
+					E = Enew;
+					time += dt;
+					eta = fmin(eta, (k == 0) ? 20. : 1.0);
+					dt *= eta;
+					stepped = true;
+					break;
+				}
+			}
+			if (k == 1) {
+				eta = fmin(eta, 0.3);
+			} else if (k > 1) {
+				eta = clampd(eta, 0.1, 0.3);
+			}
+			dt *= eta;
+		}
+		if (!stepped) {
+			return maxSubsteps;
+		}
+		if (time >= dt_total) {
+			return i + 1;
+		}
+	}
+	return maxSubsteps;
+}
+
+} // namespace cool
+} // namespace qk
+
+#endif // QK_COOLING_DEVICE_HPP_

@@ -304,6 +304,7 @@ class HydroSimulation:
         self.istep = 0
         self.cellUpdates_ = 0
         self.counters = {"fofc1_stages": 0, "fofc2_stages": 0, "retries": 0}
+        self.strang_sources = []  # add_strang_source
         self.ghost = GhostExchange(lev, geom, self.ncomp_cc, NGHOST_CC, self.all_boxes, self.owner, rank, bcs, dirichlet)
         self.flag_ghost = None  # built lazily: only FOFC needs redoFlag.FillBoundary
         nd = geom.ndim
@@ -776,7 +777,22 @@ class HydroSimulation:
         return self._stage_unfused(stage, U_in, U_old, U_out, dt, with_fofc=True)
 
     # ------------------------------------------------------------------ advance
-    def advanceHydroAtLevel(self, state_old_tmp: MultiFab, dt_lev: float) -> bool:
+    def add_strang_source(self, source) -> None:
+        """source(state, time, dt) -> bool, applied to the valid cells of `state` over dt = dt_lev / 2 before and after the hydro update
+        (addStrangSplitSourcesWithBuiltin, reference src/QuokkaSimulation.hpp:520-547,1048,1318); False = the source's integrator failed and the
+        step is retried with a smaller dt.  quokka_amd.cooling.TabulatedCooling is one."""
+        self.strang_sources.append(source)
+
+    def _strang_sources(self, state: MultiFab, time: float, dt: float) -> bool:
+        ok = True
+        for src in self.strang_sources:
+            ok = src(state, time, dt) and ok
+        return ok
+
+    def advanceHydroAtLevel(self, state_old_tmp: MultiFab, dt_lev: float, time: Optional[float] = None) -> bool:
+        time = (self.tNew_ - self.dt_) if time is None else time
+        if self.strang_sources and not self._strang_sources(state_old_tmp, time, 0.5 * dt_lev):
+            return False
         self._signal_of_state_new = None  # state_new_cc_ is about to be overwritten
         self._err_latched, self._unfused_ran = False, False
         pair_done = False
@@ -808,6 +824,10 @@ class HydroSimulation:
                 self.state_new_cc_.valid(b)[0:6].copy_(self.state_inter_cc_.valid(b)[0:6])  # ncompHydro_ comps only (QuokkaSimulation.hpp:1289)
         if self._err_latched or (self._unfused_ran and int(self.dev_error.item()) != 0):
             raise capi.QkError("density is negative in SyncDualEnergy! abort!! (reference src/hydro/hydro_system.hpp:834-836)")
+        if self.strang_sources:
+            ok = self._strang_sources(self.state_new_cc_, time + dt_lev, 0.5 * dt_lev)
+            self._signal_of_state_new = None  # the sources changed the energies: the signal speeds FixupState left no longer describe the state
+            return (not self.isCflViolated(dt_lev)) and ok
         return not self.isCflViolated(dt_lev)
 
     def advanceHydroAtLevelWithRetries(self, dt_lev: float) -> bool:
@@ -821,14 +841,16 @@ class HydroSimulation:
             # The reference advances a ghost-filled COPY of the old state (QuokkaSimulation.hpp:939-940).  The advance
             # only ever writes the ghost cells of that array, so the first attempt works on state_old_cc_ in place and
             # the 966 MB copy is paid only by retries with substeps.
-            old = self.state_old_cc_ if nsubsteps == 1 else self.state_old_tmp
-            if nsubsteps > 1:
+            # (A Strang-split source changes the old state before the update: then every attempt works on the copy, as the reference does.)
+            in_place = nsubsteps == 1 and not self.strang_sources
+            old = self.state_old_cc_ if in_place else self.state_old_tmp
+            if not in_place:
                 self.state_old_tmp.copy_from(self.state_old_cc_)
             for substep in range(nsubsteps):
                 if substep > 0:
                     # amrex::Copy(tmp, state_new, 0, 0, ncompHydro_, nghost) (QuokkaSimulation.hpp:947)
                     self.state_old_tmp.copy_comps_from(self.state_new_cc_, 0, self.hydro.nvar_)
-                success = self.advanceHydroAtLevel(old, dt_step)
+                success = self.advanceHydroAtLevel(old, dt_step, (self.tNew_ - self.dt_) + substep * dt_step)
                 if not success:
                     break
             if success:
