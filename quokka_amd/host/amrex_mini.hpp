@@ -32,6 +32,7 @@
 #include <string>
 #include <type_traits>
 #include <utility>
+#include <random>
 #include <vector>
 
 #include "quokka_amd.h"
@@ -39,6 +40,10 @@
 #ifndef AMREX_SPACEDIM
 #define AMREX_SPACEDIM 3
 #endif
+// BL_PROFILE("name") declares a timer object in AMReX; the problem files write it as a statement, some as `const BL_PROFILE(...)`
+#define QK_CAT2(a, b) a##b
+#define QK_CAT(a, b) QK_CAT2(a, b)
+#define BL_PROFILE(name) int QK_CAT(qk_bl_profile_, __LINE__) = 0
 #define AMREX_GPU_DEVICE __device__
 #define AMREX_GPU_HOST_DEVICE __host__ __device__
 #define AMREX_GPU_HOST __host__
@@ -82,6 +87,7 @@
 namespace amrex
 {
 using Real = double;
+
 using Long = long;
 template <typename T> using Vector = std::vector<T>;
 template <class T, std::size_t N> using Array = std::array<T, N>;
@@ -388,6 +394,16 @@ QK_HD inline auto Random(RandomEngine const &e) -> Real
 	z ^= z >> 31;
 	return static_cast<Real>(z >> 11) * (1.0 / 9007199254740992.0);
 }
+// amrex::InitRandom / Random() / RandomPoisson on the host (AMReX_Random.H): one seeded generator per process; every rank seeded alike draws the
+// same sequence, which the problems that use it rely on ("all ranks should produce the same values")
+inline auto qk_host_rng() -> std::mt19937_64 &
+{
+	static std::mt19937_64 g(42);
+	return g;
+}
+inline void InitRandom(unsigned long long seed, int /*nprocs*/ = 1) { qk_host_rng().seed(seed); }
+inline auto Random() -> Real { return std::uniform_real_distribution<Real>(0.0, 1.0)(qk_host_rng()); }
+inline auto RandomPoisson(Real lambda) -> unsigned int { return static_cast<unsigned int>(std::poisson_distribution<long>(lambda)(qk_host_rng())); }
 // key of a cell's stream: splitmix64 over (launch number, i, j, k) — every ParallelForRNG call draws a different field (a global launch counter,
 // the same on every rank as long as the ranks make the same calls; the cell index is global, so the field does not depend on the box layout),
 // negative / ghost indices and indices beyond 2^21 do not alias
@@ -463,6 +479,15 @@ class Geometry
 	[[nodiscard]] auto ProbHiArray() const -> GpuArray<Real, AMREX_SPACEDIM> { return prob_hi; }
 	[[nodiscard]] auto ProbLo(int d) const -> Real { return prob_lo[d]; }
 	[[nodiscard]] auto CellSize(int d) const -> Real { return dx[d]; }
+	[[nodiscard]] auto ProbLength(int d) const -> Real { return prob_hi[d] - prob_lo[d]; }
+	[[nodiscard]] auto ProbSize() const -> Real
+	{
+		Real v = 1.0;
+		for (int d = 0; d < AMREX_SPACEDIM; ++d) {
+			v *= prob_hi[d] - prob_lo[d];
+		}
+		return v;
+	}
 	[[nodiscard]] auto isPeriodic(int d) const -> bool { return periodic[d] != 0; }
 	[[nodiscard]] auto isAllPeriodic() const -> bool
 	{
@@ -501,6 +526,11 @@ class ParmParse
 		std::istringstream v(line.substr(eq + 1));
 		std::vector<std::string> vals;
 		for (std::string tok; v >> tok;) {
+			// a value in double quotes is the text between them (AMReX's ParmParse: `file = "./table.h5"`); quoted values with blanks inside
+			// do not occur in the reference's decks
+			if (tok.size() >= 2 && tok.front() == '"' && tok.back() == '"') {
+				tok = tok.substr(1, tok.size() - 2);
+			}
 			vals.push_back(tok);
 		}
 		if (!key.empty()) {
@@ -687,7 +717,7 @@ struct Device {
 
 // amrex::TableData<T, N> (AMReX_TableData.H): an N-dimensional table with inclusive index bounds, first index fastest, in device memory or — built
 // with The_Pinned_Arena() — in host memory; table() / const_table() hand out the accessor a kernel captures by value.  Only what the reference's
-// problem files use: N = 3, copy() from a host table, the accessors.
+// problem files use: N = 1 ... 3, copy() from a host table, the accessors.
 struct Arena {
 	bool host;
 };
@@ -701,15 +731,36 @@ inline auto The_Arena() -> Arena *
 	static Arena a{false};
 	return &a;
 }
+template <typename T> struct Table1D {
+	T *p = nullptr;
+	int begin = 0, end = 0; // [begin, end)
+	QK_HD auto operator()(int i) const -> T & { return p[i - begin]; }
+};
+template <typename T> struct Table2D {
+	T *p = nullptr;
+	Long jstride = 0;
+	int lo0 = 0, lo1 = 0;
+	QK_HD auto operator()(int i, int j) const -> T & { return p[(i - lo0) + jstride * (j - lo1)]; }
+};
 template <typename T> struct Table3D {
 	T *p = nullptr;
 	Long jstride = 0, kstride = 0;
 	int lo0 = 0, lo1 = 0, lo2 = 0;
 	QK_HD auto operator()(int i, int j, int k) const -> T & { return p[(i - lo0) + jstride * (j - lo1) + kstride * (k - lo2)]; }
 };
+template <typename T, int N> struct TableAccessor;
+template <typename T> struct TableAccessor<T, 1> {
+	using type = Table1D<T>;
+};
+template <typename T> struct TableAccessor<T, 2> {
+	using type = Table2D<T>;
+};
+template <typename T> struct TableAccessor<T, 3> {
+	using type = Table3D<T>;
+};
 template <typename T, int N> class TableData
 {
-	static_assert(N == 3, "amrex_mini: TableData is built for three indices (what the reference's problems use)");
+	static_assert(N >= 1 && N <= 3, "amrex_mini: TableData is built for one, two or three indices");
 
       public:
 	TableData(Array<int, N> const &lo, Array<int, N> const &hi, Arena *arena = nullptr) : lo_(lo), hi_(hi), host_(arena != nullptr && arena->host)
@@ -718,10 +769,12 @@ template <typename T, int N> class TableData
 		for (int d = 0; d < N; ++d) {
 			n_ *= static_cast<Long>(hi[d] - lo[d] + 1);
 		}
-		if (host_) {
-			hbuf_.assign(static_cast<size_t>(n_), T{});
+		size_t const bytes = sizeof(T) * static_cast<size_t>(std::max<Long>(n_, 1));
+		if (host_) { // The_Pinned_Arena(): page-locked host memory, the same pointer on the host and in kernels
+			QK_HOST_HIP(hipHostMalloc(reinterpret_cast<void **>(&d_), bytes, hipHostMallocDefault));
+			std::memset(d_, 0, bytes);
 		} else {
-			QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_), sizeof(T) * static_cast<size_t>(std::max<Long>(n_, 1))));
+			QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_), bytes));
 		}
 	}
 	TableData(TableData const &) = delete;
@@ -729,12 +782,12 @@ template <typename T, int N> class TableData
 	~TableData()
 	{
 		if (d_ != nullptr) {
-			(void)hipFree(d_);
+			(void)(host_ ? hipHostFree(d_) : hipFree(d_));
 		}
 	}
-	[[nodiscard]] auto table() -> Table3D<T> { return make<T>(); }
-	[[nodiscard]] auto table() const -> Table3D<T const> { return make<T const>(); }
-	[[nodiscard]] auto const_table() const -> Table3D<T const> { return make<T const>(); }
+	[[nodiscard]] auto table() -> typename TableAccessor<T, N>::type { return make<T>(); }
+	[[nodiscard]] auto table() const -> typename TableAccessor<T const, N>::type { return make<T const>(); }
+	[[nodiscard]] auto const_table() const -> typename TableAccessor<T const, N>::type { return make<T const>(); }
 	[[nodiscard]] auto size() const -> Long { return n_; }
 	void copy(TableData const &src) // same bounds; any combination of host and device storage
 	{
@@ -743,23 +796,29 @@ template <typename T, int N> class TableData
 	}
 
       private:
-	[[nodiscard]] auto data() const -> T * { return host_ ? const_cast<T *>(hbuf_.data()) : d_; }
-	template <typename U> [[nodiscard]] auto make() const -> Table3D<U>
+	[[nodiscard]] auto data() const -> T * { return d_; }
+	template <typename U> [[nodiscard]] auto make() const -> typename TableAccessor<U, N>::type
 	{
-		Table3D<U> t;
+		typename TableAccessor<U, N>::type t;
 		t.p = data();
-		t.jstride = hi_[0] - lo_[0] + 1;
-		t.kstride = t.jstride * (hi_[1] - lo_[1] + 1);
-		t.lo0 = lo_[0];
-		t.lo1 = lo_[1];
-		t.lo2 = lo_[2];
+		if constexpr (N == 1) {
+			t.begin = lo_[0];
+			t.end = hi_[0] + 1;
+		} else {
+			t.jstride = hi_[0] - lo_[0] + 1;
+			t.lo0 = lo_[0];
+			t.lo1 = lo_[1];
+			if constexpr (N == 3) {
+				t.kstride = t.jstride * (hi_[1] - lo_[1] + 1);
+				t.lo2 = lo_[2];
+			}
+		}
 		return t;
 	}
 	Array<int, N> lo_, hi_;
 	bool host_;
 	Long n_ = 0;
 	T *d_ = nullptr;
-	std::vector<T> hbuf_;
 };
 
 // one process per GPU; the problem-side reductions of the reference are over one rank here
@@ -901,6 +960,10 @@ template <typename T> class FabArrayT
 	[[nodiscard]] auto faceDir() const -> int { return facedir_; }
 	[[nodiscard]] auto nComp() const -> int { return ncomp_; }
 	[[nodiscard]] auto nGrow() const -> int { return nghost_; }
+	[[nodiscard]] auto nGrowVect() const -> IntVect
+	{
+		return {nghost_, AMREX_SPACEDIM >= 2 ? nghost_ : 0, AMREX_SPACEDIM >= 3 ? nghost_ : 0};
+	}
 	[[nodiscard]] auto boxArray() const -> BoxArray const & { return boxes_; }
 	[[nodiscard]] auto validbox(int b) const -> Box const & { return boxes_[b]; }
 	[[nodiscard]] auto fabbox(int b) const -> Box const & { return fabboxes_[b]; }
@@ -950,6 +1013,15 @@ template <typename T> class FabArrayT
 			auto const d = dst.array(b);
 			auto const s = src.const_array(b);
 			ParallelFor(dst.fabbox(b), numcomp, [=] __device__(int i, int j, int k, int n) { d(i, j, k, dstcomp + n) -= s(i, j, k, srccomp + n); });
+		}
+	}
+	// MultiFab::Multiply(dst, src, srccomp, dstcomp, numcomp, nghost): dst *= src (whole fabs: same layout required)
+	static void Multiply(FabArrayT &dst, FabArrayT const &src, int srccomp, int dstcomp, int numcomp, int /*nghost*/)
+	{
+		for (int b = 0; b < src.size(); ++b) {
+			auto const d = dst.array(b);
+			auto const s = src.const_array(b);
+			ParallelFor(dst.fabbox(b), numcomp, [=] __device__(int i, int j, int k, int n) { d(i, j, k, dstcomp + n) *= s(i, j, k, srccomp + n); });
 		}
 	}
 	// MultiFab::norm1(comp): sum of |value| over the valid region (faces of a face-centred array: the nodal valid box), all ranks
@@ -1006,6 +1078,25 @@ template <typename T> class FabArrayT
 	T *d_data_ = nullptr;
 	Array4<T> *d_table_ = nullptr;
 };
+// amrex::BaseFab<T>: one box of values in host memory (what computePlaneProjection returns: reference src/simulation.hpp:2394-2450)
+template <typename T> class BaseFab
+{
+      public:
+	BaseFab() = default;
+	BaseFab(Box const &b, int ncomp, Arena * /*arena*/ = nullptr) : box_(b), ncomp_(ncomp), v_(static_cast<size_t>(b.numPts()) * static_cast<size_t>(ncomp), T{}) {}
+	[[nodiscard]] auto box() const -> Box const & { return box_; }
+	[[nodiscard]] auto nComp() const -> int { return ncomp_; }
+	[[nodiscard]] auto size() const -> Long { return static_cast<Long>(v_.size()); }
+	[[nodiscard]] auto dataPtr() -> T * { return v_.data(); }
+	[[nodiscard]] auto dataPtr() const -> T const * { return v_.data(); }
+	[[nodiscard]] auto array() -> Array4<T> { return Array4<T>(v_.data(), box_, ncomp_); }
+	[[nodiscard]] auto const_array() const -> Array4<T const> { return Array4<T const>(v_.data(), box_, ncomp_); }
+
+      private:
+	Box box_;
+	int ncomp_ = 0;
+	std::vector<T> v_;
+};
 // amrex::MFIter over the local boxes of a FabArray
 class MFIter
 {
@@ -1058,6 +1149,30 @@ template <typename T> void FabArrayT<T>::ParallelCopy(FabArrayT<T> const &src)
 	QK_HOST_HIP(hipDeviceSynchronize());
 }
 using MultiFab = FabArrayT<Real>;
+// amrex::ReduceOpSum / ReduceOpMin as tags of computePlaneProjection<ReduceOp>
+struct ReduceOpSum {
+};
+struct ReduceOpMin {
+};
+// amrex::GetVecOfConstPtrs / amrex::volumeWeightedSum (AMReX_MultiFabUtil.H) for what a simulation object of this mirror holds: ONE level, so no
+// finer level masks any of it — the sum over valid cells times the cell volume
+template <typename A> auto GetVecOfConstPtrs(A const &a) -> std::vector<FabArrayT<Real> const *>
+{
+	std::vector<FabArrayT<Real> const *> v;
+	for (int i = 0; i < static_cast<int>(a.size()); ++i) {
+		v.push_back(&a[i]);
+	}
+	return v;
+}
+template <typename G, typename R> auto volumeWeightedSum(std::vector<FabArrayT<Real> const *> const &mf, int comp, G const &geom, R const & /*ratio*/) -> Real
+{
+	auto const dx = geom[0].CellSizeArray();
+	Real vol = 1.0;
+	for (int d = 0; d < AMREX_SPACEDIM; ++d) {
+		vol *= dx[d];
+	}
+	return mf[0]->sum(comp) * vol;
+}
 using iMultiFab = FabArrayT<int>;
 // amrex::TagBoxArray: one char per cell (amrex::TagBox::CLEAR = 0, BUF = 1, SET = 2)
 using TagBoxArray = FabArrayT<char>;
@@ -1065,6 +1180,18 @@ struct TagBox {
 	enum TagVal : char { CLEAR = 0, BUF = 1, SET = 2 };
 };
 
+} // namespace amrex
+
+// amrex::literals (AMReX_REAL.H): 0._rt is an amrex::Real.  AMReX declares them so that they are found without a using-directive (the problem files
+// write `0._rt` after `using amrex::Real;` only): global scope here.
+constexpr auto operator""_rt(long double x) -> amrex::Real { return static_cast<amrex::Real>(x); }
+constexpr auto operator""_rt(unsigned long long int x) -> amrex::Real { return static_cast<amrex::Real>(x); }
+namespace amrex
+{
+namespace literals
+{
+using ::operator""_rt;
+}
 } // namespace amrex
 
 #endif // QK_HOST_AMREX_MINI_HPP_

@@ -4,6 +4,9 @@
 #ifndef QK_HOST_QUOKKA_AMR_SIMULATION_HPP_
 #define QK_HOST_QUOKKA_AMR_SIMULATION_HPP_
 
+#include <unordered_map>
+#include <variant>
+
 #include "quokka_rad_system.hpp"
 
 namespace qkhost
@@ -188,6 +191,65 @@ template <typename problem_t> class AMRSimulation
 	[[nodiscard]] auto boxArray(int /*lev*/ = 0) const -> std::vector<amrex::Box> const & { return grids_; }
 	[[nodiscard]] auto DistributionMap(int /*lev*/ = 0) const -> amrex::DistributionMapping { return {}; }
 	[[nodiscard]] auto finestLevel() const -> int { return 0; }
+	int finest_level = 0;			     // amrex::AmrMesh::finest_level as a problem's loop over levels reads it: this object's one level
+	ThisLevel<amrex::IntVect> ref_ratio{amrex::IntVect(2, 2, 2)};
+	// values a problem keeps across restarts (reference src/simulation.hpp:103,175; written to / read from metadata.yaml there — kept in memory here)
+	using variant_t = std::variant<amrex::Real, std::string>;
+	std::unordered_map<std::string, variant_t> simulationMetadata_;
+	amrex::Vector<std::string> derivedNames_; // deck: derived_vars (reference src/simulation.hpp:367,607)
+
+	// integral of user_f(i, j, k, state) over the volume (reference src/simulation.hpp:1966-1991)
+	template <typename F> auto computeVolumeIntegral(F const &user_f) -> amrex::Real
+	{
+		amrex::MultiFab q;
+		q.define(grids_, 1, 0);
+		for (int b = 0; b < q.size(); ++b) {
+			auto const state = state_new_cc_[0].const_array(b);
+			auto const result = q.array(b);
+			amrex::ParallelFor(q.validbox(b), [=] AMREX_GPU_DEVICE(int i, int j, int k) { result(i, j, k) = user_f(i, j, k, state); });
+		}
+		amrex::Gpu::streamSynchronize();
+		std::vector<amrex::MultiFab const *> const v{&q};
+		return amrex::volumeWeightedSum(v, 0, geom, ref_ratio);
+	}
+	// projection of user_f(i, j, k, state) dx[dir] along `dir` onto the plane of the domain (reference src/simulation.hpp:2394-2450): a host
+	// reduction (diagnostics, not on the timed path), summed / minimised over ranks
+	template <typename ReduceOp, typename F> auto computePlaneProjection(F const &user_f, const int dir) const -> amrex::BaseFab<amrex::Real>
+	{
+		amrex::MultiFab q;
+		q.define(grids_, 1, 0);
+		for (int b = 0; b < q.size(); ++b) {
+			auto const state = state_new_cc_[0].const_array(b);
+			auto const result = q.array(b);
+			amrex::ParallelFor(q.validbox(b), [=] AMREX_GPU_DEVICE(int i, int j, int k) { result(i, j, k) = user_f(i, j, k, state); });
+		}
+		amrex::Gpu::streamSynchronize();
+		amrex::Box plane = geom[0].Domain();
+		plane.lo[dir] = 0;
+		plane.hi[dir] = 0;
+		constexpr bool isSum = std::is_same<ReduceOp, amrex::ReduceOpSum>::value;
+		amrex::BaseFab<amrex::Real> proj(plane, 1);
+		auto P = proj.array();
+		double const init = isSum ? 0.0 : std::numeric_limits<double>::max();
+		amrex::HostFor(plane, [&](int i, int j, int k) { P(i, j, k) = init; });
+		double const dxdir = geom[0].CellSize(dir);
+		for (int b = 0; b < q.size(); ++b) {
+			auto h = q.copyToHost(b);
+			amrex::Array4<amrex::Real> a(h.data(), q.fabbox(b), 1);
+			amrex::HostFor(q.validbox(b), [&](int i, int j, int k) {
+				int idx[3] = {i, j, k};
+				idx[dir] = 0;
+				double const v = dxdir * a(i, j, k);
+				double &dst = P(idx[0], idx[1], idx[2]);
+				dst = isSum ? dst + v : std::min(dst, v);
+			});
+		}
+		for (amrex::Long n = 0; n < proj.size(); ++n) {
+			double &v = proj.dataPtr()[n];
+			v = isSum ? qkhost::Comm::get().allReduceSum(v) : qkhost::Comm::get().allReduceMin(v);
+		}
+		return proj;
+	}
 	[[nodiscard]] auto Geom(int /*lev*/ = 0) const -> amrex::Geometry const & { return geom[0]; }
 	[[nodiscard]] auto Geom(int /*lev*/ = 0) -> amrex::Geometry & { return geom[0]; }
 	SimulationData<problem_t> userData_;

@@ -12,6 +12,8 @@
 #define QK_HOST_QUOKKA_HOST_HPP_
 
 #include "quokka_amr_simulation.hpp"
+#include "compat/grackle_like_cooling.hpp"
+#include "compat/tabulated_cooling.hpp"
 
 template <typename problem_t> class QuokkaSimulation : public AMRSimulation<problem_t>
 {
@@ -42,6 +44,12 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	bool computeReferenceSolution_ = false;
 	amrex::Real errorNorm_ = std::numeric_limits<double>::quiet_NaN();
 	amrex::Real pressureFloor_ = 0.;
+	// cooling (reference src/QuokkaSimulation.hpp:110-118)
+	int enableCooling_ = 0;
+	quokka::GrackleLikeCooling::grackle_tables grackleTables_; // (declared only: compat/grackle_like_cooling.hpp)
+	quokka::TabulatedCooling::cloudy_tables cloudyTables_;
+	std::string coolingTableType_{};
+	std::string coolingTableFilename_{};
 	long fofcStages_ = 0, retries_ = 0;
 	double elapsedSeconds_ = 0.0;
 	// radiation (reference src/QuokkaSimulation.hpp:127-131)
@@ -209,6 +217,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		if constexpr (is_radiation_enabled_) { // :693
 			subcycleRadiationAtLevel(time, dt_lev);
 		}
+		callAfterLevelAdvance(time, dt_lev);
 		return true;
 	}
 
@@ -227,13 +236,25 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		}
 		hpp.query("rk2_carry_rhs", rk2CarryRhs_); // extension of this host: the carried-rhs form of the RK2 average (<= 1e-12; quokka_amd.h)
 		{
-			// cooling.enabled (reference src/QuokkaSimulation.hpp:352-366): the Strang-split tabulated / Grackle-like cooling source reads Cloudy
-			// tables from HDF5 files; neither src/cooling nor an HDF5 reader exists on this side.  A deck that asks for it is refused rather than
-			// run as pure hydrodynamics under the reference's name.
-			int coolingEnabled = 0;
-			amrex::ParmParse("cooling").query("enabled", coolingEnabled);
-			if (coolingEnabled != 0) {
-				amrex::Abort("cooling.enabled = 1: tabulated cooling (src/cooling, Cloudy HDF5 tables) is not built in quokka_amd/host");
+			// cooling.* (reference src/QuokkaSimulation.hpp:352-376): the Strang-split source from tabulated cooling curves.  The Cloudy tables of the
+			// cloudy_cooling_tools are read by the library's own reader of the HDF5 format; Grackle's table files are not in the reference tree
+			// (extern/grackle_data_files is an empty submodule) and that table type is refused.
+			amrex::ParmParse cpp("cooling");
+			int alwaysReadTables = 0;
+			cpp.query("enabled", enableCooling_);
+			cpp.query("read_tables_even_if_disabled", alwaysReadTables);
+			cpp.query("cooling_table_type", coolingTableType_);
+			cpp.query("hdf5_data_file", coolingTableFilename_);
+			if ((enableCooling_ == 1) || (alwaysReadTables == 1)) {
+				if (coolingTableType_ == "cloudy_cooling_tools") {
+					amrex::Print() << "Reading cloudy-cooling-tools tables...\n";
+					quokka::TabulatedCooling::readCloudyData(coolingTableFilename_, cloudyTables_);
+				} else if (coolingTableType_ == "grackle") {
+					amrex::Print() << "Reading Grackle tables...\n";
+					quokka::GrackleLikeCooling::readGrackleData(coolingTableFilename_, grackleTables_); // (refuses: not built)
+				} else {
+					amrex::Abort("Invalid cooling table type!");
+				}
 			}
 		}
 		amrex::ParmParse rpp("radiation"); // reference src/QuokkaSimulation.hpp:353-358
@@ -318,6 +339,10 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	void preCalculateInitialConditions() override;
 	void computeAfterEvolve(amrex::Vector<amrex::Real> &initSumCons) override;
 	void computeAfterTimestep(); // reference src/simulation.hpp:228, :890 (default: nothing)
+	// output hooks (reference src/QuokkaSimulation.hpp:190-196,550-566): derived plot variables, projections, statistics — defaults do nothing
+	void ComputeDerivedVar(int lev, std::string const &dname, amrex::MultiFab &mf, int ncomp) const;
+	[[nodiscard]] auto ComputeProjections(int dir) const -> std::unordered_map<std::string, amrex::BaseFab<amrex::Real>>;
+	auto ComputeStatistics() -> std::map<std::string, amrex::Real>;
 	// the mean of user_f(i, j, k, state) over the planes normal to `axis` (QuokkaSimulation.hpp:843-881): evaluated on every level, averaged
 	// down, summed on level 0.  Defined in quokka_amr.hpp.
 	template <typename F> auto computeAxisAlignedProfile(int axis, F const &user_f) -> amrex::Gpu::HostVector<amrex::Real>;
@@ -332,6 +357,15 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	{
 		computeAfterTimestep();
 		if (!afterTimestepIsDefault_) {
+			invalidateSignal();
+		}
+	}
+	// operator-split work of the problem after a level has advanced (reference src/QuokkaSimulation.hpp:184,508,699-700; default: nothing)
+	void computeAfterLevelAdvance(int lev, amrex::Real time, amrex::Real dt_lev, int ncycle);
+	void callAfterLevelAdvance(double time, double dt_lev)
+	{
+		computeAfterLevelAdvance(this->amrLevel_, time, dt_lev, 1);
+		if (!afterLevelAdvanceIsDefault_) {
 			invalidateSignal();
 		}
 	}
@@ -434,6 +468,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 			if constexpr (is_radiation_enabled_) { // advanceSingleTimestepAtLevel (reference src/QuokkaSimulation.hpp:653-707)
 				subcycleRadiationAtLevel(time, dt_[0]);
 			}
+			callAfterLevelAdvance(time, dt_[0]);
 			++istep[0];
 			this->cellUpdates_ += this->CountCells(0);
 			cur_time += dt_[0];
@@ -475,7 +510,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 			if (beforeAttempt_) {
 				beforeAttempt_(retry_count); // reference src/QuokkaSimulation.hpp:894-900 (save), :919-929 (reset / restore)
 			}
-			bool const direct = strangSourcesAreDefault_ && nsubsteps == 1;
+			bool const direct = strangSourcesAreDefault_ && enableCooling_ == 0 && nsubsteps == 1;
 			if (!direct) {
 				amrex::MultiFab::Copy(state_old_tmp_, state_old_cc_[0]);
 			}
@@ -495,11 +530,28 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		return success;
 	}
 
+	// reference src/QuokkaSimulation.hpp:519-547: the built-in cooling source, then the problem's own; false = the cooling integrator failed
+	auto addStrangSplitSourcesWithBuiltin(amrex::MultiFab &state, int lev, amrex::Real time, amrex::Real dt) -> bool
+	{
+		bool cool_success = true;
+		if (enableCooling_ == 1) {
+			if (coolingTableType_ == "cloudy_cooling_tools") {
+				cool_success = quokka::TabulatedCooling::computeCooling<problem_t>(state, dt, cloudyTables_, tempFloor_);
+			} else {
+				amrex::Abort("Invalid cooling table type!");
+			}
+		}
+		addStrangSplitSources(state, lev, time, dt);
+		return cool_success;
+	}
+
 	auto advanceHydroAtLevel(amrex::MultiFab &state_old_cc_tmp, double time, double dt_lev) -> bool
 	{
 		invalidateSignal();
-		// first half of the Strang-split source terms, on the (temporary) old state (reference src/QuokkaSimulation.hpp:1048)
-		addStrangSplitSources(state_old_cc_tmp, 0, time, 0.5 * dt_lev);
+		// first half of the Strang-split source terms, on the (temporary) old state (reference src/QuokkaSimulation.hpp:1048-1054)
+		if (!addStrangSplitSourcesWithBuiltin(state_old_cc_tmp, 0, time, 0.5 * dt_lev)) {
+			return false;
+		}
 		int pair = -1;
 		if constexpr (fusedEligible()) {
 			if (integratorOrder_ == 2 && speculateStage2_ != 0) {
@@ -531,10 +583,10 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 				amrex::Abort("density is negative in SyncDualEnergy! abort!!");
 			}
 		}
-		bool const ok = !isCflViolated(dt_lev);
-		if (ok) { // second half, on the new state (:1318)
-			addStrangSplitSources(state_new_cc_[0], 0, time + dt_lev, 0.5 * dt_lev);
-			if (!strangSourcesAreDefault_) {
+		bool ok = !isCflViolated(dt_lev);
+		if (ok) { // second half, on the new state (:1318-1321)
+			ok = addStrangSplitSourcesWithBuiltin(state_new_cc_[0], 0, time + dt_lev, 0.5 * dt_lev);
+			if (!strangSourcesAreDefault_ || enableCooling_ == 1) {
 				invalidateSignal();
 			}
 		}
@@ -738,6 +790,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	// needs no private copy of the old state (nothing modifies it: the stages read U_old and write elsewhere) and the signal speeds of the
 	// final stage's epilogue stay valid for the next computeTimestep: 0.4 ms (copy) + 0.4 ms (k_maxSignal) per Sedov 256^3 step.
 	bool strangSourcesAreDefault_ = false;
+	bool afterLevelAdvanceIsDefault_ = false;
 	std::array<amrex::MultiFab, AMREX_SPACEDIM> radFluxOld_, radFlux_;
 	amrex::MultiFab radEnergySource_;
 	int *d_radCounter_ = nullptr, *d_radFailure_ = nullptr;
@@ -1255,6 +1308,21 @@ template <typename problem_t> void QuokkaSimulation<problem_t>::setInitialCondit
 template <typename problem_t> void QuokkaSimulation<problem_t>::computeAfterTimestep() { afterTimestepIsDefault_ = true; }
 template <typename problem_t> void QuokkaSimulation<problem_t>::computeBeforeTimestep() { beforeTimestepIsDefault_ = true; }
 template <typename problem_t> void QuokkaSimulation<problem_t>::createInitialParticles() {}
+template <typename problem_t>
+void QuokkaSimulation<problem_t>::computeAfterLevelAdvance(int /*lev*/, amrex::Real /*time*/, amrex::Real /*dt_lev*/, int /*ncycle*/)
+{
+	afterLevelAdvanceIsDefault_ = true;
+}
+template <typename problem_t>
+void QuokkaSimulation<problem_t>::ComputeDerivedVar(int /*lev*/, std::string const & /*dname*/, amrex::MultiFab & /*mf*/, const int /*ncomp*/) const
+{
+}
+template <typename problem_t>
+auto QuokkaSimulation<problem_t>::ComputeProjections(int /*dir*/) const -> std::unordered_map<std::string, amrex::BaseFab<amrex::Real>>
+{
+	return std::unordered_map<std::string, amrex::BaseFab<amrex::Real>>{};
+}
+template <typename problem_t> auto QuokkaSimulation<problem_t>::ComputeStatistics() -> std::map<std::string, amrex::Real> { return std::map<std::string, amrex::Real>{}; }
 template <typename problem_t>
 void QuokkaSimulation<problem_t>::addStrangSplitSources(amrex::MultiFab & /*state*/, int /*lev*/, amrex::Real /*time*/, amrex::Real /*dt_lev*/)
 {

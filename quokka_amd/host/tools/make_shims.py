@@ -12,11 +12,12 @@ AMReX_MFParallelFor.H AMReX_MultiFab.H AMReX_MultiFabUtil.H AMReX_ParallelContex
 AMReX_REAL.H AMReX_Reduce.H AMReX_SPACE.H AMReX_TableData.H AMReX_TagBox.H AMReX_ValLocPair.H AMReX_Vector.H AMReX_iMultiFab.H AMReX_GpuControl.H AMReX_Gpu.H
 AMReX_Random.H AMReX_RandomEngine.H AMReX_GpuLaunch.H AMReX_Utility.H AMReX_INT.H AMReX_Dim3.H AMReX_RealBox.H AMReX_Math.H""".split()
 QUOKKA = ["QuokkaSimulation.hpp", "simulation.hpp", "SimulationData.hpp", "hydro/mhd_system.hpp", "physics_numVars.hpp", "physics_info.hpp", "hydro/hydro_system.hpp", "hydro/EOS.hpp", "hydro/HydroState.hpp",
-          "radiation/radiation_system.hpp", "radiation/radiation_dust_system.hpp", "fundamental_constants.H", "hyperbolic_system.hpp", "grid.hpp", "math/math_impl.hpp"]
+          "radiation/radiation_system.hpp", "radiation/radiation_dust_system.hpp", "fundamental_constants.H", "hyperbolic_system.hpp", "grid.hpp", "math/math_impl.hpp",
+          "cooling/TabulatedCooling.hpp", "cooling/GrackleLikeCooling.hpp"]
 COMPAT = {"util/fextract.hpp": "compat/util_compat.hpp", "util/ArrayUtil.hpp": "compat/util_compat.hpp", "util/valarray.hpp": "compat/util_compat.hpp",
           "fmt/format.h": "compat/mini_fmt.hpp", "fmt/core.h": "compat/mini_fmt.hpp", "radiation/planck_integral.hpp": "compat/planck_integral.hpp",
           "hydro/NSCBC_inflow.hpp": "compat/nscbc.hpp", "hydro/NSCBC_outflow.hpp": "compat/nscbc.hpp",
-          "math/ODEIntegrate.hpp": "compat/ode_integrate.hpp",
+          "math/ODEIntegrate.hpp": "compat/ode_integrate.hpp", "math/quadrature.hpp": "compat/quadrature.hpp",
           "eos.H": "compat/microphysics_stub.hpp", "extern_parameters.H": "compat/microphysics_stub.hpp"}
 ADVECTION = ["linear_advection/AdvectionSimulation.hpp", "linear_advection/linear_advection.hpp"]
 EMPTY = ["util/matplotlibcpp.h"]

@@ -5,6 +5,7 @@ reference's own pass criteria.  The binaries are built in the build container (w
 box with quokka_amd/host/bin/MANIFEST; the sources do not.  A binary the MANIFEST lists but that is missing is a FAILURE; the module
 skips only where nothing was ever built (no MANIFEST)."""
 import os
+import re
 import shutil
 import subprocess
 
@@ -522,13 +523,70 @@ def test_unmodified_reference_ctest_exits_zero(tmp_path, name, deck, extern, slo
     assert rc == 0, out[-2500:]
 
 
-def test_cooling_problem_compiles_unchanged_and_runs_without_its_cooling_source(tmp_path):
+def conservation_error(out, component):
+    """relative conservation error the executable prints for that component after evolve (None: the line is not there)"""
+    m = re.search(r"Initial " + re.escape(component) + r" = \S+\s+absolute conservation error = \S+\s+relative conservation error = (\S+)", out)
+    return float(m.group(1)) if m else None
+
+
+CLOUDY_TABLE = os.path.join(ROOT, "tests", "golden", "isrf_1000Go_grains.h5")
+
+
+def test_cooling_problem_unchanged_with_the_tabulated_cooling_source(tmp_path):
     """src/problems/Cooling, unchanged: amrex::TableData (the random phases of its initial perturbation, filled on the host, copied to the device,
-    read by the initial-condition kernel) and its custom boundary pair (extrapolation below, Dirichlet above).  The reference's deck switches the
-    tabulated cooling source on (cooling.enabled = 1, Cloudy HDF5 tables): src/cooling is not built on this side, and the host REFUSES such a deck
-    instead of running it as pure hydrodynamics; with cooling.enabled = 0 the problem advances (no pass criterion in the reference: exit 0)."""
+    read by the initial-condition kernel), its custom boundary pair (extrapolation below, Dirichlet above) and the Strang-split cooling source.
+    The reference's deck names a Grackle table (an empty submodule of the reference tree) and no cooling.cooling_table_type — which the reference's
+    own constructor answers with "Invalid cooling table type!" (src/QuokkaSimulation.hpp:362-374); so does this host.  Grackle tables are refused
+    by name; with the Cloudy table of the cloudy_cooling_tools (the reference's extern/cooling/isrf_1000Go_grains.h5) the problem runs WITH its
+    cooling source: substeps are reported from every source call and the gas loses thermal energy that the run without cooling keeps."""
     deck = os.path.join(HOST, "decks", "Cooling.in")
-    rc, out = run([exe("ref_Cooling"), deck, "max_timesteps=5", "plotfile_interval=-1"], str(tmp_path))
-    assert rc != 0 and "cooling.enabled = 1" in out, out[-1500:]
-    rc, out = run([exe("ref_Cooling"), deck, "cooling.enabled=0", "max_timesteps=20", "plotfile_interval=-1"], str(tmp_path))
-    assert rc == 0 and "Performance figure-of-merit" in out, out[-2000:]
+    common = ["max_timesteps=20", "plotfile_interval=-1", "checkpoint_interval=-1"]
+    rc, out = run([exe("ref_Cooling"), deck] + common, str(tmp_path))
+    assert rc != 0 and "Invalid cooling table type!" in out, out[-1500:]
+    rc, out = run([exe("ref_Cooling"), deck, "cooling.cooling_table_type=grackle"] + common, str(tmp_path))
+    assert rc != 0 and "Grackle-like cooling" in out and "not built" in out, out[-1500:]
+    cloudy = ["cooling.cooling_table_type=cloudy_cooling_tools", f"cooling.hdf5_data_file={CLOUDY_TABLE}"]
+    rc, cooled = run([exe("ref_Cooling"), deck] + cloudy + common, str(tmp_path))
+    assert rc == 0 and "Performance figure-of-merit" in cooled, cooled[-2000:]
+    assert cooled.count("cooling substeps (per cell)") >= 40  # two source calls per step
+    rc, adiabatic = run([exe("ref_Cooling"), deck, "cooling.enabled=0"] + common, str(tmp_path))
+    assert rc == 0 and "cooling substeps" not in adiabatic, adiabatic[-2000:]
+    e_cool, e_adia = conservation_error(cooled, "gasInternalEnergy"), conservation_error(adiabatic, "gasInternalEnergy")
+    assert e_cool is not None and e_adia is not None and e_cool < e_adia - 1.0e-6, (e_cool, e_adia)  # (signed: final minus initial)
+
+
+def test_shockcloud_unchanged_with_its_cloudy_table(tmp_path):
+    """src/problems/ShockCloud, unchanged, on the geometry and parameters of the reference's tests/ShockCloud_32.in: a shocked wind overruns a cold
+    cloud; both cool through the Cloudy table (read by the library's own HDF5 reader).  The problem calls the table functions from host code
+    (problem_main: cloud temperature, cooling length), from its own kernels (ErrorEst, derived variables) and through the Strang source; NSCBC
+    inflow / outflow in x, mass scalars for cloud and wind material, the cloud-tracking frame shift after every step (volume integrals,
+    simulationMetadata_).  No pass criterion in the reference (a regression test there): exit 0, a cooling report from every source call, the cloud's
+    partial density conserved to rounding while wind material enters through the inflow boundary."""
+    cwd = str(tmp_path)
+    os.symlink(CLOUDY_TABLE, os.path.join(cwd, "isrf_1000Go_grains.h5"))  # the deck names ./isrf_1000Go_grains.h5, as the reference's
+    rc, out = run([exe("ref_ShockCloud"), os.path.join(HOST, "decks", "shockcloud_32.in"), "max_timesteps=60"], cwd)
+    assert rc == 0 and "Performance figure-of-merit" in out, out[-2500:]
+    assert "Reading cloudy-cooling-tools tables" in out and out.count("cooling substeps (per cell)") >= 120
+    cloud = conservation_error(out, "component7")  # scalar 1: the cloud's partial density (cloud.cpp:106-108)
+    assert cloud is not None and abs(cloud) < 1.0e-12, cloud
+    assert conservation_error(out, "gasDensity") > 1.0e-3  # the wind blows in
+    m = re.search(r"retries=(\d+)", out)
+    assert m and int(m.group(1)) <= 4
+
+
+def test_randomblast_unchanged_without_its_grackle_cooling(tmp_path):
+    """src/problems/RandomBlast, unchanged.  Its deck cools with Grackle's tables, which are not in the reference tree: that deck is refused by name.
+    With cooling off the problem is supernova injection into a periodic box — Poisson-distributed explosions drawn on the host
+    (amrex::RandomPoisson / Random after InitRandom(42)), their positions handed to the injection kernel through pinned-memory
+    amrex::TableData<Real, 1>, deposited through a Wendland kernel in computeAfterLevelAdvance.  Mass is conserved exactly (ejecta mass 0) and the
+    energy in the box grows by exactly what the problem reports as injected."""
+    deck = os.path.join(HOST, "decks", "randomblast_hydro.in")
+    rc, out = run([exe("ref_RandomBlast"), deck, "cooling.enabled=1", "cooling.cooling_table_type=grackle", "cooling.hdf5_data_file=none.h5", "max_timesteps=3"], str(tmp_path))
+    assert rc != 0 and "Grackle-like cooling" in out, out[-1500:]
+    rc, out = run([exe("ref_RandomBlast"), deck, "max_timesteps=40"], str(tmp_path))
+    assert rc == 0, out[-2500:]
+    injected = float(re.search(r"Cumulative injected energy = (\S+)", out).group(1))
+    assert injected > 0 and injected % 1.0e51 == 0  # whole supernovae of 1e51 erg
+    m = re.search(r"Initial gasEnergy = (\S+)\s+absolute conservation error = (\S+)", out)
+    assert abs(float(m.group(2)) / injected - 1.0) < 1.0e-9, (m.group(2), injected)
+    assert conservation_error(out, "gasDensity") == 0.0
