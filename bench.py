@@ -77,6 +77,7 @@ def parse():
                          "(a watchdog turns a hang into a FAIL line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (ncell512, long_run, weak_256_per_gpu)")
+    ap.add_argument("--cooling-only", action="store_true", help="only the cooling128 block (its own JSON line; profiling)")
     ap.add_argument("--long-steps", type=int, default=100, help="steps (and warm-up steps) of the long_run secondary figure")
     ap.add_argument("--cpu-ncell", type=int, default=128)
     ap.add_argument("--cpu-steps", type=int, default=24)  # ~15 s of CPU work on 16 cores
@@ -393,6 +394,78 @@ def developed_block(ctx, torch, ncell, mgs, steps, warmup, carry):
             "initial_state": "quokka_amd.simulation.developed_state (tests/test_bench_geometry_gpu.py)"}
 
 
+def cooling_block(ctx, torch, ncell=128, calls=6, cpu_cells=400000):
+    """The Strang-split tabulated-cooling source (qk_cooling_tabulated, reference src/cooling/TabulatedCooling.hpp:258-317) on a multiphase medium:
+    n_H 1e-3 ... 1e3 cm^-3, T 10 ... 1e8 K, log-uniform, over 2000 yr — from a fraction of a substep per cell to > 1000.  A cell costs what its
+    substeps cost (two right-hand sides each: two table look-ups for the energy bounds + one Algorithm-748 solve of ~8 function values + the two
+    rate look-ups), so the figure is cell-SUBSTEPS per second beside cells per second; the kernel is bound by FP64 / transcendental issue and by
+    the divergence of the substep counts inside a wave, not by HBM (48 B per cell).  `cpu_port`: the oracle on a bounded sample of the same cells."""
+    import ctypes as C
+    import numpy as np
+    from quokka_amd import capi
+    from quokka_amd.cooling import CloudyTables, TabulatedCooling
+    from quokka_amd.simulation import Geometry, HydroSimulation
+    table = os.path.join(ROOT, "tests", "golden", "isrf_1000Go_grains.h5")
+    kpc, gamma = 3.0857e21, 5.0 / 3.0
+    geom = Geometry(3, [ncell] * 3, [0.0] * 3, [kpc] * 3, [1, 1, 1])
+    bcs = [([capi.BC_INT_DIR] * 3, [capi.BC_INT_DIR] * 3) for _ in range(6)]
+    sim = HydroSimulation(ctx, geom, capi.traits(gamma, False, 3), bcs, [min(ncell, 128)] * 3)
+    cool = TabulatedCooling(sim, CloudyTables(ctx, table), T_floor=10.0)
+    g = torch.Generator(device=ctx.device).manual_seed(5)
+    k_B, m_H = 1.380649e-16, 1.67262192369e-24 + 9.1093837015e-28
+    for b in range(sim.lev.nboxes):
+        v = sim.state_new_cc_.valid(b)
+        shape = v[0].shape
+        rho = 10 ** (torch.rand(shape, generator=g, device=ctx.device, dtype=torch.float64) * 6.0 - 27.0)
+        T = 10 ** (torch.rand(shape, generator=g, device=ctx.device, dtype=torch.float64) * 7.0 + 1.0)
+        E = cool.evaluate(1, rho.reshape(-1), T.reshape(-1)).reshape(shape)  # ComputeEgasFromTgas
+        v[0], v[4], v[5] = rho, E, E
+        v[1:4] = 0.0
+    sim.state_old_cc_.copy_from(sim.state_new_cc_)
+    dt = 3.15e7 * 2.0e3
+    L = ctx.L
+    assert cool(sim.state_new_cc_, 0.0, dt)  # warm-up
+    navg, nmax = cool.last
+    L.qk_profile_reset(ctx.h)
+    L.qk_profile_only(ctx.h, None)
+    L.qk_profile_enable(ctx.h, 1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        sim.state_new_cc_.copy_from(sim.state_old_cc_)  # the same work every call
+        assert cool(sim.state_new_cc_, 0.0, dt)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    L.qk_profile_enable(ctx.h, 0)
+    k = read_profile(ctx)
+    cnt, ms = k.get("cooling_tabulated", (0, 0.0))
+    kernel_ms = ms / max(cnt, 1)
+    cells = ncell ** 3
+    out = {"value": cells / (kernel_ms * 1e-3) / 1e6 if kernel_ms > 0 else None, "unit": "Mcells/s (one source call)", "kernel_ms": kernel_ms, "calls": cnt,
+           "wall_ms_per_call_with_state_copy_and_readback": el / calls * 1e3, "substeps_per_cell_avg": navg, "substeps_max": nmax,
+           "Msubsteps_per_s": cells * navg / (kernel_ms * 1e-3) / 1e6 if kernel_ms > 0 else None, "dt_yr": 2000.0,
+           "workload": f"{ncell}^3 cells, n_H 1e-3..1e3 cm^-3, T 10..1e8 K log-uniform, Cloudy table isrf_1000Go_grains.h5, T_floor 10 K", "bound": "FP64 issue / divergence"}
+    try:  # the oracle on a sample of the same distribution (cells are independent: no geometry)
+        from mini_hdf5 import cloudy_file_arrays  # noqa: E402  (tests/ on the path below)
+    except ImportError:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from mini_hdf5 import cloudy_file_arrays
+    from oracle.pyoracle import OracleCloudy
+    orc = OracleCloudy(cloudy_file_arrays(table))
+    r = np.random.default_rng(5)
+    rho_c, T_c = 10 ** r.uniform(-27.0, -21.0, cpu_cells), 10 ** r.uniform(1.0, 8.0, cpu_cells)
+    U = np.zeros((6, cpu_cells))
+    U[0] = rho_c
+    U[4] = U[5] = orc.evaluate(orc.EGAS_FROM_TGAS, rho_c, T_c, gamma)
+    threads, note = usable_cores()
+    t0 = time.perf_counter()
+    _, ns = orc.compute_cooling(U, gamma, dt, 10.0)
+    elc = time.perf_counter() - t0
+    out["cpu_port"] = {"value": cpu_cells / elc / 1e6, "unit": "Mcells/s", "Msubsteps_per_s": float(ns.sum()) / elc / 1e6, "cores": threads,
+                       "sample": f"{cpu_cells} cells of the same distribution in {elc:.1f} s, OpenMP over cells ({note})", "substeps_per_cell_avg": float(ns.mean())}
+    return out
+
+
 def cxx_shell_block(args, steps=22):
     """BASELINE config 4 through the C++17 host: the reference's OWN problem file (src/problems/RadhydroShell, compiled unchanged against the host
     mirror by __graft_entry__.build(), where the reference tree exists) with the deck of the config; the figure of merit the executable prints
@@ -658,6 +731,9 @@ def main():
     from quokka_amd.multifab import Context
 
     ctx = Context(local_rank)
+    if args.cooling_only:
+        print(json.dumps({"cooling128": cooling_block(ctx, torch)}), flush=True)
+        return
     if args.selftest:
         if world == 1:
             raise SystemExit("--selftest compares N > 1 ranks with one rank: use --gpus N")
@@ -815,6 +891,12 @@ def main():
             out["amr_maxlev2"] = compact(run_amr(ctx, torch, dist, rank, world, 256, 50, 5, carry=(args.rk2_mode == "carry")))
             torch.cuda.empty_cache()
             out["cxx_amr_maxlev2"] = cxx_amr_block(args)
+            # (f) the Strang-split cooling source on a multiphase medium
+            try:
+                out["cooling128"] = cooling_block(ctx, torch)
+            except Exception as e:  # noqa: BLE001 - a secondary block must not take the headline down
+                out["cooling128"] = {"error": repr(e)[:300]}
+            torch.cuda.empty_cache()
         elif world > 1:
             if ncell not in (256, 64):
                 sW, nW, elW, _ = run_sedov(ctx, torch, dist, rank, world, 256, mgs, args.steps, args.warmup, profile=False, carry=(args.rk2_mode == "carry"))

@@ -3,8 +3,8 @@
 //   qk_cooling_tabulated     computeCooling<problem_t> (src/cooling/TabulatedCooling.hpp:258-317)
 //   qk_cooling_evaluate      the per-cell functions a problem calls from its own kernels (ComputeTgasFromEgas, ComputeMMW, ComputeCoolingLength,
 //                            cloudy_cooling_function, ComputeEgasFromTgas; TabulatedCooling.hpp:82-220) over arrays, for hosts without device lambdas
-// One thread per cell; the number of Heun substeps of a cell is data dependent (a few in the hot wind, hundreds at the cloud's cooling front), so a
-// wave runs as long as its slowest cell.  The three 25 x 161 tables (97 KB) stay in L2; every lookup is four loads at a computed index.
+// The number of Heun substeps of a cell is data dependent (a few in the hot wind, hundreds at the cloud's cooling front): the kernel runs persistent
+// lanes over a queue of cells (k_cooling_tabulated).  The three 25 x 161 tables (97 KB) stay in L2; every lookup is four loads at a computed index.
 #include "qk_cooling_device.hpp"
 #include "qk_device.hpp"
 #include "qk_hdf5_mini.hpp"
@@ -38,38 +38,77 @@ auto tablesOf(const qk_cloudy_tables *t) -> cool::Tables
 	return r;
 }
 
-__global__ void __launch_bounds__(256) k_cooling_tabulated(const qk_box *boxes, qk_array4 *state_t, cool::Tables tab, double gamma, double dt, double T_floor,
-							   long long *counters)
+// Persistent lanes over a queue of cells.  The number of Heun substeps of a cell is data dependent (a few in the hot wind, hundreds at a cooling
+// front): with one cell per thread a wave runs as long as its slowest lane while the others idle (6x on a log-uniform multiphase medium).  Here a
+// lane that finishes its cell stores it and takes the next cell index from a global counter; every trip of the loop is one attempt of a substep
+// (cool::heunAttempt) of whatever cell the lane holds, so the lanes of a wave stay busy until the queue is empty.  Cells are numbered box by box
+// with the largest box's extents (indices outside a smaller box are skipped).
+__global__ void __launch_bounds__(256) k_cooling_tabulated(const qk_box *boxes, int nboxes, int max0, int max1, int max2, qk_array4 *state_t, cool::Tables tab, double gamma,
+							   double dt, double T_floor, long long *counters, unsigned long long *queue)
 {
-	const int b = blockIdx.y;
-	const qk_box bx = boxes[b];
-	const int len0 = bx.hi[0] - bx.lo[0] + 1, len1 = bx.hi[1] - bx.lo[1] + 1, len2 = bx.hi[2] - bx.lo[2] + 1;
-	const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-	int nsteps = 0;
-	if (t < static_cast<int64_t>(len0) * len1 * len2) {
-		const int k = static_cast<int>(t / (static_cast<int64_t>(len0) * len1));
-		const int r = static_cast<int>(t - static_cast<int64_t>(k) * len0 * len1);
-		const int j = r / len0;
-		const int i = r - j * len0;
-		WA4 S(state_t[b]);
-		const int64_t c = S.idx(bx.lo[0] + i, bx.lo[1] + j, bx.lo[2] + k);
-		const double rho = S.p[c + S.ns * RHO];
-		const double px = S.p[c + S.ns * MX], py = S.p[c + S.ns * MY], pz = S.p[c + S.ns * MZ];
-		const double Egas = S.p[c + S.ns * ENE];
-		// RadSystem::ComputeEintFromEgas (radiation_system.hpp:1113-1121)
-		const double Ekin = (px * px + py * py + pz * pz) / (2.0 * rho);
-		const double Eint = Egas - Ekin;
-		const double reltol_floor = 0.01, rtol = 1.0e-4;
-		const double abstol = reltol_floor * cool::egasFromTgas(tab, rho, T_floor, gamma);
-		double E = Eint;
-		nsteps = cool::integrateCooling(tab, rho, gamma, E, dt, rtol, abstol);
-		const double dEint = E - Eint;
-		S.p[c + S.ns * ENE] += dEint;
-		S.p[c + S.ns * EINT] += dEint;
+	const long long perBox = static_cast<long long>(max0) * max1 * max2;
+	const long long total = perBox * nboxes;
+	const double reltol_floor = 0.01, rtol = 1.0e-4;
+	cool::HeunState s;
+	s.nsteps = 0;
+	bool have = false;
+	cool::CellCool cc{};
+	double Eint0 = 0.0, abstol = 0.0;
+	WA4::GT *pE = nullptr, *pEint = nullptr; // (global address space: plain global_load / global_store)
+	int mx = 0;
+	long long sum = 0;
+	bool more = true;
+	while (true) {
+		if (!have && more) {
+			// take the next cell that exists
+			while (true) {
+				const long long id = static_cast<long long>(atomicAdd(queue, 1ULL));
+				if (id >= total) {
+					more = false;
+					break;
+				}
+				const int b = static_cast<int>(id / perBox);
+				const long long r = id - b * perBox;
+				const int k = static_cast<int>(r / (static_cast<long long>(max0) * max1));
+				const int r2 = static_cast<int>(r - static_cast<long long>(k) * max0 * max1);
+				const int j = r2 / max0;
+				const int i = r2 - j * max0;
+				const qk_box bx = boxes[b];
+				if (i > bx.hi[0] - bx.lo[0] || j > bx.hi[1] - bx.lo[1] || k > bx.hi[2] - bx.lo[2]) {
+					continue;
+				}
+				WA4 S(state_t[b]);
+				const int64_t c = S.idx(bx.lo[0] + i, bx.lo[1] + j, bx.lo[2] + k);
+				const double rho = S.p[c + S.ns * RHO];
+				const double px = S.p[c + S.ns * MX], py = S.p[c + S.ns * MY], pz = S.p[c + S.ns * MZ];
+				pE = &S.p[c + S.ns * ENE];
+				pEint = &S.p[c + S.ns * EINT];
+				// RadSystem::ComputeEintFromEgas (radiation_system.hpp:1288-1297)
+				const double Ekin = (px * px + py * py + pz * pz) / (2.0 * rho);
+				Eint0 = *pE - Ekin;
+				cc = cool::cellCool(tab, rho, gamma);
+				abstol = reltol_floor * cool::egasFromTgasAt(tab, rho, cc.log_nH, T_floor, gamma);
+				cool::heunBegin(tab, cc, Eint0, dt, s);
+				have = true;
+				break;
+			}
+		}
+		if (!__any(have)) {
+			break; // the queue is empty and every lane of the wave has stored its last cell
+		}
+		if (have) {
+			cool::heunAttempt(tab, cc, dt, rtol, abstol, s);
+			if (s.nsteps >= 0) {
+				const double dEint = s.E - Eint0;
+				*pE += dEint;
+				*pEint += dEint;
+				mx = max(mx, s.nsteps);
+				sum += s.nsteps;
+				have = false;
+			}
+		}
 	}
 	// max and sum of the substep counts (the reference's iMultiFab max / sum)
-	int mx = nsteps;
-	long long sum = nsteps;
 	for (int off = 32; off > 0; off >>= 1) {
 		mx = max(mx, __shfl_xor(mx, off));
 		sum += __shfl_xor(sum, off);
@@ -222,10 +261,27 @@ int qk_cooling_tabulated(qk_level *lev, qk_stream s, const qk_hydro_traits *t, q
 	if (lev->nboxes == 0) {
 		return QK_OK;
 	}
-	const CellLaunch L = cellLaunch(lev, 0, -1);
+	// the queue word of the persistent kernel: owned by the context, cleared on the stream before every launch
+	unsigned long long *queue = nullptr;
+	{
+		std::lock_guard<std::mutex> lock(lev->ctx->mtx);
+		if (lev->ctx->cooling_queue == nullptr) {
+			void *p = nullptr;
+			if (hipMalloc(&p, sizeof(unsigned long long)) != hipSuccess) {
+				return setError(lev->ctx, QK_ERR_HIP, "cooling_tabulated", "cannot allocate the queue word");
+			}
+			lev->ctx->owned.push_back(p);
+			lev->ctx->cooling_queue = static_cast<unsigned long long *>(p);
+		}
+		queue = lev->ctx->cooling_queue;
+	}
+	QK_HIP_CHECK(lev->ctx, hipMemsetAsync(queue, 0, sizeof(unsigned long long), static_cast<hipStream_t>(s)));
+	// enough resident waves to fill the chip (the kernel holds ~100 VGPRs: 4 waves per SIMD), never more lanes than cells
+	const long long cells = static_cast<long long>(lev->maxlen[0]) * lev->maxlen[1] * lev->maxlen[2] * lev->nboxes;
+	const unsigned blocks = static_cast<unsigned>(std::max<long long>(1, std::min<long long>(256LL * 8, (cells + 255) / 256)));
 	ProfScope ps(lev->ctx, static_cast<hipStream_t>(s), "cooling_tabulated");
-	hipLaunchKernelGGL(k_cooling_tabulated, L.grid, L.block, 0, static_cast<hipStream_t>(s), lev->d_boxes, state_t, tablesOf(device_tables), t->gamma, dt, T_floor,
-			   d_counters);
+	hipLaunchKernelGGL(k_cooling_tabulated, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(s), lev->d_boxes, lev->nboxes, lev->maxlen[0], lev->maxlen[1],
+			   lev->maxlen[2], state_t, tablesOf(device_tables), t->gamma, dt, T_floor, d_counters, queue);
 	const hipError_t e = hipGetLastError();
 	return (e == hipSuccess) ? QK_OK : setError(lev->ctx, QK_ERR_HIP, "cooling_tabulated", hipGetErrorString(e));
 }

@@ -114,28 +114,53 @@ QK_HD auto lookup(Tables const &t, const double *table, double log_nH, double lo
 	return interp2d(log_nH, log_T, t.log_nH, t.n_nH, t.log_T, t.n_T, table);
 }
 
+// What the functions below recompute from the density alone, formed once per cell by the integrator (the same expressions: the same bits):
+// rho X, log10 n_H, the energies at the ends of the temperature axis, k_B rho / m_H
+struct CellCool {
+	double rho, gamma, rhoH, log_nH, Emin, Emax, kBn;
+};
+
 // cloudy_cooling_function (TabulatedCooling.hpp:82-99): net heating rate per volume, (rho X)^2 (10^heat - 10^cool)
-QK_HD auto netHeating(Tables const &t, double rho, double T) -> double
+QK_HD auto netHeatingAt(Tables const &t, double rhoH, double log_nH, double T) -> double
 {
-	const double rhoH = rho * H_mass_fraction;
-	const double nH = rhoH / t.m_H;
-	const double log_nH = log10(nH);
 	const double log_T = log10(T);
 	const double logCool = lookup(t, t.cool, log_nH, log_T);
 	const double logHeat = lookup(t, t.heat, log_nH, log_T);
 	const double netLambda = fastPow10(logHeat) - fastPow10(logCool);
 	return (rhoH * rhoH) * netLambda;
 }
+QK_HD auto netHeating(Tables const &t, double rho, double T) -> double
+{
+	const double rhoH = rho * H_mass_fraction;
+	const double nH = rhoH / t.m_H;
+	return netHeatingAt(t, rhoH, log10(nH), T);
+}
 
 // ComputeEgasFromTgas (TabulatedCooling.hpp:101-115)
+QK_HD auto egasFromTgasAt(Tables const &t, double rho, double log_nH, double Tgas, double gamma) -> double
+{
+	const double mu = lookup(t, t.mmw, log_nH, log10(Tgas));
+	const double n = rho / (t.m_H * mu);
+	const double Pgas = n * t.k_B * Tgas;
+	return Pgas / (gamma - 1.);
+}
 QK_HD auto egasFromTgas(Tables const &t, double rho, double Tgas, double gamma) -> double
 {
 	const double rhoH = rho * H_mass_fraction;
 	const double nH = rhoH / t.m_H;
-	const double mu = lookup(t, t.mmw, log10(nH), log10(Tgas));
-	const double n = rho / (t.m_H * mu);
-	const double Pgas = n * t.k_B * Tgas;
-	return Pgas / (gamma - 1.);
+	return egasFromTgasAt(t, rho, log10(nH), Tgas, gamma);
+}
+QK_HD auto cellCool(Tables const &t, double rho, double gamma) -> CellCool
+{
+	CellCool c;
+	c.rho = rho;
+	c.gamma = gamma;
+	c.rhoH = rho * H_mass_fraction;
+	c.log_nH = log10(c.rhoH / t.m_H);
+	c.Emin = egasFromTgasAt(t, rho, c.log_nH, t.T_min, gamma);
+	c.Emax = egasFromTgasAt(t, rho, c.log_nH, t.T_max, gamma);
+	c.kBn = t.k_B * (rho / t.m_H);
+	return c;
 }
 
 // ---- Algorithm 748: a bracket [a, b] with f(a) f(b) < 0 and the two points that left it last (d, e)
@@ -328,20 +353,10 @@ template <class F> QK_HD void solve748(F const &f, double ax, double bx, double 
 
 // ComputeTgasFromEgas (TabulatedCooling.hpp:117-174): T with mu(n_H, T) C = T, C = (gamma - 1) E / (k_B rho / m_H); NaN when the bracket is empty or
 // the iteration limit is reached
-QK_HD auto tgasFromEgas(Tables const &t, double rho, double Egas, double gamma) -> double
+QK_HD auto tgasInTable(Tables const &t, CellCool const &c, double Egas) -> double // (Emin < Egas < Emax)
 {
-	const double Eint_min = egasFromTgas(t, rho, t.T_min, gamma);
-	const double Eint_max = egasFromTgas(t, rho, t.T_max, gamma);
-	if (Egas <= Eint_min) {
-		return t.T_min;
-	}
-	if (Egas >= Eint_max) {
-		return t.T_max;
-	}
-	const double rhoH = rho * H_mass_fraction;
-	const double nH = rhoH / t.m_H;
-	const double log_nH = log10(nH);
-	const double C = (gamma - 1.) * Egas / (t.k_B * (rho / t.m_H));
+	const double log_nH = c.log_nH;
+	const double C = (c.gamma - 1.) * Egas / c.kBn;
 	const double reltol = 1.0e-5;
 	const int maxIterLimit = 100;
 	auto f = [&](double T) {
@@ -362,6 +377,17 @@ QK_HD auto tgasFromEgas(Tables const &t, double rho, double Egas, double gamma) 
 		}
 	}
 	return T_sol;
+}
+QK_HD auto tgasFromEgas(Tables const &t, double rho, double Egas, double gamma) -> double
+{
+	const CellCool c = cellCool(t, rho, gamma);
+	if (Egas <= c.Emin) {
+		return t.T_min;
+	}
+	if (Egas >= c.Emax) {
+		return t.T_max;
+	}
+	return tgasInTable(t, c, Egas);
 }
 
 // ComputeMMW (TabulatedCooling.hpp:206-220)
@@ -391,21 +417,19 @@ QK_HD auto coolingLength(Tables const &t, double rho, double Egas, double gamma)
 }
 
 // user_rhs (TabulatedCooling.hpp:222-256): dE_int/dt; false when the temperature iteration failed
-QK_HD auto heatingRate(Tables const &t, double rho, double gamma, double Eint, double &rate) -> bool
+QK_HD auto heatingRate(Tables const &t, CellCool const &c, double Eint, double &rate) -> bool
 {
-	const double Eint_min = egasFromTgas(t, rho, t.T_min, gamma);
-	const double Eint_max = egasFromTgas(t, rho, t.T_max, gamma);
-	if (Eint <= Eint_min) {
-		rate = netHeating(t, rho, t.T_min);
-	} else if (Eint >= Eint_max) {
-		rate = netHeating(t, rho, t.T_max);
+	if (Eint <= c.Emin) {
+		rate = netHeatingAt(t, c.rhoH, c.log_nH, t.T_min);
+	} else if (Eint >= c.Emax) {
+		rate = netHeatingAt(t, c.rhoH, c.log_nH, t.T_max);
 	} else {
-		const double T = tgasFromEgas(t, rho, Eint, gamma);
+		const double T = tgasInTable(t, c, Eint);
 		if (isNan(T)) {
 			rate = NAN;
 			return false;
 		}
-		rate = netHeating(t, rho, T);
+		rate = netHeatingAt(t, c.rhoH, c.log_nH, T);
 	}
 	return true;
 }
@@ -414,60 +438,84 @@ constexpr int maxSubsteps = 2000; // maxStepsODEIntegrate (ODEIntegrate.hpp:122)
 
 // rk_adaptive_integrate with rk12_single_step for one unknown (ODEIntegrate.hpp:20-53,105-226): Heun's method with the embedded Euler solution,
 // step-size factor eps^(-1/2) limited to 20 after a clean step, 1 after a retry, 0.3 on the second failure, [0.1, 0.3] afterwards, 0.5 after a
-// failed right-hand side; 7 attempts per step.  Returns the number of steps; maxSubsteps = failure.
-QK_HD auto integrateCooling(Tables const &t, double rho, double gamma, double &E, double dt_total, double reltol, double abstol) -> int
+// failed right-hand side; 7 attempts per step, maxSubsteps steps.  Written as a state and ONE ATTEMPT at a time, so that the kernel can keep every
+// lane of a wave busy with an attempt of ITS cell (qk_cooling.hip: a lane that finishes a cell takes the next one from a queue) — the sequence
+// of operations on a cell is the reference's loop nest.
+struct HeunState {
+	double E, time, dt;
+	int step, retry;
+	int nsteps; // >= 0: finished (the number of steps; maxSubsteps = failure)
+};
+QK_HD void heunBegin(Tables const &t, CellCool const &c, double E0, double dt_total, HeunState &s)
 {
 	double rate0 = NAN;
-	heatingRate(t, rho, gamma, E, rate0);
-	const double dt_guess = 0.1 * fabs(E / rate0);
-	double time = 0;
-	double dt = isNan(dt_guess) ? dt_total : dt_guess;
-	for (int i = 0; i < maxSubsteps; ++i) {
-		if ((time + dt) > dt_total) {
-			dt = dt_total - time;
-		}
-		bool stepped = false;
-		for (int k = 0; k < 7; ++k) {
-			double eta = NAN;
-			double k1 = NAN, k2 = NAN;
-			bool ok = heatingRate(t, rho, gamma, E, k1);
-			if (ok) {
-				k1 *= dt;
-				ok = heatingRate(t, rho, gamma, E + k1, k2);
+	heatingRate(t, c, E0, rate0);
+	const double dt_guess = 0.1 * fabs(E0 / rate0);
+	s.E = E0;
+	s.time = 0;
+	s.dt = isNan(dt_guess) ? dt_total : dt_guess;
+	s.step = 0;
+	s.retry = 0;
+	s.nsteps = -1;
+}
+QK_HD void heunAttempt(Tables const &t, CellCool const &c, double dt_total, double reltol, double abstol, HeunState &s)
+{
+	if (s.retry == 0 && (s.time + s.dt) > dt_total) { // (the head of the step loop)
+		s.dt = dt_total - s.time;
+	}
+	const int k = s.retry;
+	double eta = NAN;
+	double k1 = NAN, k2 = NAN;
+	bool ok = heatingRate(t, c, s.E, k1);
+	if (ok) {
+		k1 *= s.dt;
+		ok = heatingRate(t, c, s.E + k1, k2);
+	}
+	if (!ok) {
+		eta = 0.5;
+	} else {
+		k2 *= s.dt;
+		const double Enew = s.E + 0.5 * k1 + 0.5 * k2;
+		const double Eerr = -0.5 * k1 + 0.5 * k2;
+		const double w = 1. / (reltol * s.E + abstol);
+		const double epsilon = sqrt(((Eerr * Eerr) * (w * w)) / 1);
+		eta = pow(epsilon, -1.0 / 2.0);
+		if (epsilon < 1.0) { // accepted
+			s.E = Enew;
+			s.time += s.dt;
+			eta = fmin(eta, (k == 0) ? 20. : 1.0);
+			s.dt *= eta;
+			s.retry = 0;
+			s.step += 1;
+			if (s.time >= dt_total) {
+				s.nsteps = s.step;
+			} else if (s.step >= maxSubsteps) {
+				s.nsteps = maxSubsteps;
 			}
-			if (!ok) {
-				eta = 0.5;
-			} else {
-				k2 *= dt;
-				const double Enew = E + 0.5 * k1 + 0.5 * k2;
-				const double Eerr = -0.5 * k1 + 0.5 * k2;
-				const double w = 1. / (reltol * E + abstol);
-				const double epsilon = sqrt(((Eerr * Eerr) * (w * w)) / 1);
-				eta = pow(epsilon, -1.0 / 2.0);
-				if (epsilon < 1.0) {
-					E = Enew;
-					time += dt;
-					eta = fmin(eta, (k == 0) ? 20. : 1.0);
-					dt *= eta;
-					stepped = true;
-					break;
-				}
-			}
-			if (k == 1) {
-				eta = fmin(eta, 0.3);
-			} else if (k > 1) {
-				eta = clampd(eta, 0.1, 0.3);
-			}
-			dt *= eta;
-		}
-		if (!stepped) {
-			return maxSubsteps;
-		}
-		if (time >= dt_total) {
-			return i + 1;
+			return;
 		}
 	}
-	return maxSubsteps;
+	if (k == 1) {
+		eta = fmin(eta, 0.3);
+	} else if (k > 1) {
+		eta = clampd(eta, 0.1, 0.3);
+	}
+	s.dt *= eta;
+	s.retry = k + 1;
+	if (s.retry >= 7) {
+		s.nsteps = maxSubsteps; // no attempt of this step was accepted
+	}
+}
+QK_HD auto integrateCooling(Tables const &t, double rho, double gamma, double &E, double dt_total, double reltol, double abstol) -> int
+{
+	const CellCool c = cellCool(t, rho, gamma);
+	HeunState s;
+	heunBegin(t, c, E, dt_total, s);
+	while (s.nsteps < 0) {
+		heunAttempt(t, c, dt_total, reltol, abstol, s);
+	}
+	E = s.E;
+	return s.nsteps;
 }
 
 } // namespace cool

@@ -33,6 +33,7 @@ struct qk_ctx {
 	std::vector<qk_prof_pending> prof_pending;
 	std::vector<hipEvent_t> prof_free_events;
 	int *counter_slots = nullptr; // qk_rad_ops.hip: spread iteration / failure counters (owned)
+	unsigned long long *cooling_queue = nullptr; // qk_cooling.hip: the next-cell counter of the persistent kernel (owned)
 };
 
 struct qk_level {
