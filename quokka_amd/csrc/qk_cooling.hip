@@ -21,7 +21,7 @@ constexpr double M_H = 1.67262192369e-24 + 9.1093837015e-28; // C::m_p + C::m_e 
 
 auto tablesOf(const qk_cloudy_tables *t) -> cool::Tables
 {
-	cool::Tables r;
+	cool::Tables r{};
 	r.log_nH = t->log_nH;
 	r.log_T = t->log_Tgas;
 	r.cool = t->cooling;
@@ -35,6 +35,7 @@ auto tablesOf(const qk_cloudy_tables *t) -> cool::Tables
 	r.mmw_max = t->mmw_max;
 	r.m_H = M_H;
 	r.k_B = Eos::k_B;
+	r.prepared = 0; // (the arrays are in device memory: the kernels call cool::prepare)
 	return r;
 }
 
@@ -46,6 +47,7 @@ auto tablesOf(const qk_cloudy_tables *t) -> cool::Tables
 __global__ void __launch_bounds__(256) k_cooling_tabulated(const qk_box *boxes, int nboxes, int max0, int max1, int max2, qk_array4 *state_t, cool::Tables tab, double gamma,
 							   double dt, double T_floor, long long *counters, unsigned long long *queue)
 {
+	cool::prepare(tab); // (axis ends and spacing: once per lane)
 	const long long perBox = static_cast<long long>(max0) * max1 * max2;
 	const long long total = perBox * nboxes;
 	const double reltol_floor = 0.01, rtol = 1.0e-4;
@@ -87,7 +89,7 @@ __global__ void __launch_bounds__(256) k_cooling_tabulated(const qk_box *boxes, 
 				const double Ekin = (px * px + py * py + pz * pz) / (2.0 * rho);
 				Eint0 = *pE - Ekin;
 				cc = cool::cellCool(tab, rho, gamma);
-				abstol = reltol_floor * cool::egasFromTgasAt(tab, rho, cc.log_nH, T_floor, gamma);
+				abstol = reltol_floor * cool::egasFromTgasAt(tab, rho, cc.X, T_floor, gamma);
 				cool::heunBegin(tab, cc, Eint0, dt, s);
 				have = true;
 				break;
@@ -125,6 +127,7 @@ __global__ void __launch_bounds__(256) k_cooling_evaluate(cool::Tables tab, doub
 	if (t >= n) {
 		return;
 	}
+	cool::prepare(tab);
 	switch (what) {
 	case QK_COOLING_TGAS_FROM_EGAS:
 		out[t] = cool::tgasFromEgas(tab, rho[t], val[t], gamma);

@@ -39,6 +39,10 @@ struct Tables {
 	double mmw_min, mmw_max;
 	// constants of fundamental_constants.H the relations use: m_p + m_e and k_B (cgs)
 	double m_H, k_B;
+	// filled by prepare(): the ends and the spacing of the two axes — what interpolate2d recomputes from the axis arrays in every call
+	double xi, xf, yi, yf;
+	double dx, dy, rdx, rdy; // spacing and (device) its refined reciprocal
+	int prepared;
 };
 
 // "abundances ism" of Cloudy: n_He / n_H = 0.098 (TabulatedCooling.hpp:32)
@@ -68,88 +72,176 @@ QK_HD auto fastLog10(double x) -> double
 	return LOG2OLOG10 * (2 * (y - 1) + n);
 }
 
-// interpolate2d (src/math/Interpolate2D.hpp:14-80) on a uniformly spaced table.  The reference's degenerate-cell tests compare the first ORDINATE
-// `yi` with the upper INDEX `iiy`; they are kept as written, since they decide the weights on the last row / column of the table.
-QK_HD auto interp2d(double x, double y, const double *xv, int nx, const double *yv, int ny, const double *table) -> double
+// Quotients.  The reference divides; a correctly rounded quotient does not depend on how it is formed.  On the device a divisor shared by several
+// quotients (the cell volume of the four interpolation weights, the axis spacing) is inverted once — v_rcp_f64 refined by two Newton steps — and
+// each quotient is the product with that reciprocal corrected by its fma residual: the IEEE quotient for operands in the normal range (all of them
+// here are differences of table ordinates, O(0.01 ... 10)), 3 instructions instead of the ~35 of a division.  The host divides.
+struct Den {
+	double d, r;
+};
+QK_HD auto denOf(double d) -> Den
 {
-	const double xi = xv[0], xf = xv[nx - 1];
-	const double yi = yv[0], yf = yv[ny - 1];
-	const double dx = (xf - xi) / static_cast<double>(nx - 1);
-	const double dy = (yf - yi) / static_cast<double>(ny - 1);
-	x = clampd(x, xi, xf);
-	y = clampd(y, yi, yf);
-	const int ix = clampi(static_cast<int>(floor((x - xi) / dx)), 0, nx - 1);
-	const int iy = clampi(static_cast<int>(floor((y - yi) / dy)), 0, ny - 1);
-	const int iix = (ix == nx - 1) ? ix : ix + 1;
-	const int iiy = (iy == ny - 1) ? iy : iy + 1;
-	const double x1 = xv[ix], x2 = xv[iix], y1 = yv[iy], y2 = yv[iiy];
-	double w11 = 0, w12 = 0, w21 = 0, w22 = 0;
-	const bool yEdge = (yi == static_cast<double>(iiy)); // sic
-	if (ix != iix && iy != iiy) {
-		const double vol = ((x2 - x1) * (y2 - y1));
-		w11 = (x2 - x) * (y2 - y) / vol;
-		w12 = (x2 - x) * (y - y1) / vol;
-		w21 = (x - x1) * (y2 - y) / vol;
-		w22 = (x - x1) * (y - y1) / vol;
-	} else if (ix == iix && !yEdge) {
-		const double vol = (y2 - y1);
-		w11 = (y2 - y) / vol;
-		w12 = (y - y1) / vol;
-	} else if (ix != iix && yEdge) {
-		const double vol = (x2 - x1);
-		w11 = (x2 - x) / vol;
-		w21 = (x - x1) / vol;
-	} else {
-		w11 = 1.0;
-	}
-	const double A = table[ix + nx * iy];
-	const double B = table[ix + nx * iiy];
-	const double C = table[iix + nx * iy];
-	const double D = table[iix + nx * iiy];
-	return w11 * A + w12 * B + w21 * C + w22 * D;
+	Den D;
+	D.d = d;
+#if defined(__HIP_DEVICE_COMPILE__)
+	const double r0 = __builtin_amdgcn_rcp(d);
+	double e = __builtin_fma(-d, r0, 1.0);
+	const double r1 = __builtin_fma(r0, e, r0);
+	e = __builtin_fma(-d, r1, 1.0);
+	D.r = __builtin_fma(r1, e, r1);
+#else
+	D.r = 0.0;
+#endif
+	return D;
+}
+QK_HD auto over(double n, Den const &D) -> double
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	const double q = n * D.r;
+	const double e = __builtin_fma(-D.d, q, n);
+	return __builtin_fma(e, D.r, q);
+#else
+	return n / D.d;
+#endif
 }
 
-QK_HD auto lookup(Tables const &t, const double *table, double log_nH, double log_T) -> double
+QK_HD auto quo(double n, double d) -> double { return over(n, denOf(d)); } // a lone quotient: 11 instructions on the device
+
+// the ends and the spacing of the axes (Interpolate2D.hpp:18-24), once per kernel thread / host call instead of once per look-up
+QK_HD void prepare(Tables &t)
 {
-	return interp2d(log_nH, log_T, t.log_nH, t.n_nH, t.log_T, t.n_T, table);
+	t.xi = t.log_nH[0];
+	t.xf = t.log_nH[t.n_nH - 1];
+	t.yi = t.log_T[0];
+	t.yf = t.log_T[t.n_T - 1];
+	t.dx = (t.xf - t.xi) / static_cast<double>(t.n_nH - 1);
+	t.dy = (t.yf - t.yi) / static_cast<double>(t.n_T - 1);
+	t.rdx = denOf(t.dx).r;
+	t.rdy = denOf(t.dy).r;
+	t.prepared = 1;
+}
+QK_HD auto preparedCopy(Tables const &t) -> Tables
+{
+	Tables p = t;
+	if (p.prepared != 1) {
+		prepare(p);
+	}
+	return p;
+}
+
+// interpolate2d (src/math/Interpolate2D.hpp:14-80) on a uniformly spaced table, in three parts: the position on one axis (clamped ordinate, the
+// two indices, their ordinates), the four weights of a point, the weighted sum over a table — so that the density axis is resolved once per cell,
+// and the weights once per point for the cooling and the heating table.  The reference's degenerate-cell tests compare the first ORDINATE `yi` with
+// the upper INDEX `iiy`; they are kept as written, since they decide the weights on the last row / column of the table.
+struct AxisPos {
+	int i0, i1;
+	double v, v1, v2; // the clamped ordinate and the ordinates of the two indices
+};
+QK_HD auto axisPos(const double *av, int n, double lo, double hi, double da, double rda, double a) -> AxisPos
+{
+	AxisPos p;
+	p.v = clampd(a, lo, hi);
+	const Den D{da, rda};
+	p.i0 = clampi(static_cast<int>(floor(over(p.v - lo, D))), 0, n - 1);
+	p.i1 = (p.i0 == n - 1) ? p.i0 : p.i0 + 1;
+	p.v1 = av[p.i0];
+	p.v2 = av[p.i1];
+	return p;
+}
+struct Weights {
+	int ix, iix, iy, iiy;
+	double w11, w12, w21, w22;
+};
+QK_HD auto weightsOf(Tables const &t, AxisPos const &X, AxisPos const &Y) -> Weights
+{
+	Weights W;
+	W.ix = X.i0;
+	W.iix = X.i1;
+	W.iy = Y.i0;
+	W.iiy = Y.i1;
+	W.w11 = 0;
+	W.w12 = 0;
+	W.w21 = 0;
+	W.w22 = 0;
+	const double x = X.v, x1 = X.v1, x2 = X.v2, y = Y.v, y1 = Y.v1, y2 = Y.v2;
+	const bool yEdge = (t.yi == static_cast<double>(W.iiy)); // sic
+	if (W.ix != W.iix && W.iy != W.iiy) {
+		const Den vol = denOf((x2 - x1) * (y2 - y1));
+		W.w11 = over((x2 - x) * (y2 - y), vol);
+		W.w12 = over((x2 - x) * (y - y1), vol);
+		W.w21 = over((x - x1) * (y2 - y), vol);
+		W.w22 = over((x - x1) * (y - y1), vol);
+	} else if (W.ix == W.iix && !yEdge) {
+		const Den vol = denOf(y2 - y1);
+		W.w11 = over(y2 - y, vol);
+		W.w12 = over(y - y1, vol);
+	} else if (W.ix != W.iix && yEdge) {
+		const Den vol = denOf(x2 - x1);
+		W.w11 = over(x2 - x, vol);
+		W.w21 = over(x - x1, vol);
+	} else {
+		W.w11 = 1.0;
+	}
+	return W;
+}
+QK_HD auto weighted(Tables const &t, const double *table, Weights const &W) -> double
+{
+	const int nx = t.n_nH;
+	const double A = table[W.ix + nx * W.iy];
+	const double B = table[W.ix + nx * W.iiy];
+	const double C = table[W.iix + nx * W.iy];
+	const double D = table[W.iix + nx * W.iiy];
+	return W.w11 * A + W.w12 * B + W.w21 * C + W.w22 * D;
+}
+QK_HD auto densityAxis(Tables const &t, double log_nH) -> AxisPos { return axisPos(t.log_nH, t.n_nH, t.xi, t.xf, t.dx, t.rdx, log_nH); }
+QK_HD auto temperatureAxis(Tables const &t, double log_T) -> AxisPos { return axisPos(t.log_T, t.n_T, t.yi, t.yf, t.dy, t.rdy, log_T); }
+// (t prepared)
+QK_HD auto lookup(Tables const &t, const double *table, AxisPos const &X, double log_T) -> double
+{
+	return weighted(t, table, weightsOf(t, X, temperatureAxis(t, log_T)));
 }
 
 // What the functions below recompute from the density alone, formed once per cell by the integrator (the same expressions: the same bits):
-// rho X, log10 n_H, the energies at the ends of the temperature axis, k_B rho / m_H
+// rho X, log10 n_H and its position on the density axis, the energies at the ends of the temperature axis, k_B rho / m_H
 struct CellCool {
 	double rho, gamma, rhoH, log_nH, Emin, Emax, kBn;
+	AxisPos X;
 };
 
-// cloudy_cooling_function (TabulatedCooling.hpp:82-99): net heating rate per volume, (rho X)^2 (10^heat - 10^cool)
-QK_HD auto netHeatingAt(Tables const &t, double rhoH, double log_nH, double T) -> double
+// cloudy_cooling_function (TabulatedCooling.hpp:82-99): net heating rate per volume, (rho X)^2 (10^heat - 10^cool); one set of weights serves both
+// tables (t prepared)
+QK_HD auto netHeatingAt(Tables const &t, double rhoH, AxisPos const &X, double T) -> double
 {
-	const double log_T = log10(T);
-	const double logCool = lookup(t, t.cool, log_nH, log_T);
-	const double logHeat = lookup(t, t.heat, log_nH, log_T);
+	const Weights W = weightsOf(t, X, temperatureAxis(t, log10(T)));
+	const double logCool = weighted(t, t.cool, W);
+	const double logHeat = weighted(t, t.heat, W);
 	const double netLambda = fastPow10(logHeat) - fastPow10(logCool);
 	return (rhoH * rhoH) * netLambda;
 }
-QK_HD auto netHeating(Tables const &t, double rho, double T) -> double
+QK_HD auto netHeating(Tables const &t0, double rho, double T) -> double
 {
+	const Tables t = preparedCopy(t0);
 	const double rhoH = rho * H_mass_fraction;
 	const double nH = rhoH / t.m_H;
-	return netHeatingAt(t, rhoH, log10(nH), T);
+	return netHeatingAt(t, rhoH, densityAxis(t, log10(nH)), T);
 }
 
-// ComputeEgasFromTgas (TabulatedCooling.hpp:101-115)
-QK_HD auto egasFromTgasAt(Tables const &t, double rho, double log_nH, double Tgas, double gamma) -> double
+// ComputeEgasFromTgas (TabulatedCooling.hpp:101-115) (t prepared)
+QK_HD auto egasFromTgasAt(Tables const &t, double rho, AxisPos const &X, double Tgas, double gamma) -> double
 {
-	const double mu = lookup(t, t.mmw, log_nH, log10(Tgas));
+	const double mu = lookup(t, t.mmw, X, log10(Tgas));
 	const double n = rho / (t.m_H * mu);
 	const double Pgas = n * t.k_B * Tgas;
 	return Pgas / (gamma - 1.);
 }
-QK_HD auto egasFromTgas(Tables const &t, double rho, double Tgas, double gamma) -> double
+QK_HD auto egasFromTgas(Tables const &t0, double rho, double Tgas, double gamma) -> double
 {
+	const Tables t = preparedCopy(t0);
 	const double rhoH = rho * H_mass_fraction;
 	const double nH = rhoH / t.m_H;
-	return egasFromTgasAt(t, rho, log10(nH), Tgas, gamma);
+	return egasFromTgasAt(t, rho, densityAxis(t, log10(nH)), Tgas, gamma);
 }
+// (t prepared)
 QK_HD auto cellCool(Tables const &t, double rho, double gamma) -> CellCool
 {
 	CellCool c;
@@ -157,8 +249,9 @@ QK_HD auto cellCool(Tables const &t, double rho, double gamma) -> CellCool
 	c.gamma = gamma;
 	c.rhoH = rho * H_mass_fraction;
 	c.log_nH = log10(c.rhoH / t.m_H);
-	c.Emin = egasFromTgasAt(t, rho, c.log_nH, t.T_min, gamma);
-	c.Emax = egasFromTgasAt(t, rho, c.log_nH, t.T_max, gamma);
+	c.X = densityAxis(t, c.log_nH);
+	c.Emin = egasFromTgasAt(t, rho, c.X, t.T_min, gamma);
+	c.Emax = egasFromTgasAt(t, rho, c.X, t.T_max, gamma);
 	c.kBn = t.k_B * (rho / t.m_H);
 	return c;
 }
@@ -171,7 +264,7 @@ struct Bracket748 {
 	QK_HD auto secantPoint() const -> double
 	{
 		const double tol = DBL_EPSILON * 5;
-		const double c = a - (fa / (fb - fa)) * (b - a);
+		const double c = a - quo(fa, fb - fa) * (b - a);
 		if ((c <= a + fabs(a) * tol) || (c >= b - fabs(b) * tol)) {
 			return (a + b) / 2;
 		}
@@ -185,7 +278,7 @@ struct Bracket748 {
 				return r;
 			}
 		}
-		return num / denom;
+		return quo(num, denom);
 	}
 	// zero of the parabola through (a, b, d) by `count` Newton steps from the end where it has the sign of the curvature (root_finding.hpp:147-176)
 	QK_HD auto parabolaPoint(unsigned count) const -> double
@@ -208,15 +301,17 @@ struct Bracket748 {
 	// inverse cubic interpolation through (a, b, d, e) (root_finding.hpp:178-208)
 	QK_HD auto inverseCubicPoint() const -> double
 	{
-		const double q11 = (d - e) * fd / (fe - fd);
-		const double q21 = (b - d) * fb / (fd - fb);
-		const double q31 = (a - b) * fa / (fb - fa);
-		const double d21 = (b - d) * fd / (fd - fb);
-		const double d31 = (a - b) * fb / (fb - fa);
-		const double q22 = (d21 - q11) * fb / (fe - fb);
-		const double q32 = (d31 - q21) * fa / (fd - fa);
-		const double d32 = (d31 - q21) * fd / (fd - fa);
-		const double q33 = (d32 - q22) * fa / (fe - fa);
+		// (nine quotients over six distinct denominators)
+		const Den Dfdfb = denOf(fd - fb), Dfbfa = denOf(fb - fa), Dfdfa = denOf(fd - fa);
+		const double q11 = quo((d - e) * fd, fe - fd);
+		const double q21 = over((b - d) * fb, Dfdfb);
+		const double q31 = over((a - b) * fa, Dfbfa);
+		const double d21 = over((b - d) * fd, Dfdfb);
+		const double d31 = over((a - b) * fb, Dfbfa);
+		const double q22 = quo((d21 - q11) * fb, fe - fb);
+		const double q32 = over((d31 - q21) * fa, Dfdfa);
+		const double d32 = over((d31 - q21) * fd, Dfdfa);
+		const double q33 = quo((d32 - q22) * fa, fe - fa);
 		double c = q31 + q32 + q33 + a;
 		if ((c <= a) || (c >= b)) {
 			c = parabolaPoint(3);
@@ -322,7 +417,7 @@ template <class F> QK_HD void solve748(F const &f, double ax, double bx, double 
 			u = s.b;
 			fu = s.fb;
 		}
-		c = u - 2 * (fu / (s.fb - s.fa)) * (s.b - s.a);
+		c = u - 2 * quo(fu, s.fb - s.fa) * (s.b - s.a);
 		if (fabs(c - u) > (s.b - s.a) / 2) {
 			c = s.a + (s.b - s.a) / 2;
 		}
@@ -355,13 +450,12 @@ template <class F> QK_HD void solve748(F const &f, double ax, double bx, double 
 // the iteration limit is reached
 QK_HD auto tgasInTable(Tables const &t, CellCool const &c, double Egas) -> double // (Emin < Egas < Emax)
 {
-	const double log_nH = c.log_nH;
 	const double C = (c.gamma - 1.) * Egas / c.kBn;
 	const double reltol = 1.0e-5;
 	const int maxIterLimit = 100;
 	auto f = [&](double T) {
 		const double log_T = clampd(log10(T), 1., 9.);
-		const double mu = lookup(t, t.mmw, log_nH, log_T);
+		const double mu = lookup(t, t.mmw, c.X, log_T);
 		return C * mu - T;
 	};
 	const double T_lo = clampd(C * t.mmw_min, t.T_min, t.T_max);
@@ -378,8 +472,9 @@ QK_HD auto tgasInTable(Tables const &t, CellCool const &c, double Egas) -> doubl
 	}
 	return T_sol;
 }
-QK_HD auto tgasFromEgas(Tables const &t, double rho, double Egas, double gamma) -> double
+QK_HD auto tgasFromEgas(Tables const &t0, double rho, double Egas, double gamma) -> double
 {
+	const Tables t = preparedCopy(t0);
 	const CellCool c = cellCool(t, rho, gamma);
 	if (Egas <= c.Emin) {
 		return t.T_min;
@@ -391,27 +486,28 @@ QK_HD auto tgasFromEgas(Tables const &t, double rho, double Egas, double gamma) 
 }
 
 // ComputeMMW (TabulatedCooling.hpp:206-220)
-QK_HD auto meanMolecularWeight(Tables const &t, double rho, double Egas, double gamma) -> double
+QK_HD auto meanMolecularWeight(Tables const &t0, double rho, double Egas, double gamma) -> double
 {
+	const Tables t = preparedCopy(t0);
 	const double Tgas = tgasFromEgas(t, rho, Egas, gamma);
 	const double rhoH = rho * H_mass_fraction;
 	const double nH = rhoH / t.m_H;
-	return lookup(t, t.mmw, log10(nH), log10(Tgas));
+	return lookup(t, t.mmw, densityAxis(t, log10(nH)), log10(Tgas));
 }
 
 // ComputeCoolingLength (TabulatedCooling.hpp:176-204): c_s t_cool with the cooling part of the table only
-QK_HD auto coolingLength(Tables const &t, double rho, double Egas, double gamma) -> double
+QK_HD auto coolingLength(Tables const &t0, double rho, double Egas, double gamma) -> double
 {
+	const Tables t = preparedCopy(t0);
 	const double Tgas = tgasFromEgas(t, rho, Egas, gamma);
 	const double rhoH = rho * H_mass_fraction;
 	const double nH = rhoH / t.m_H;
-	const double log_nH = log10(nH);
-	const double log_T = log10(Tgas);
-	const double logCool = lookup(t, t.cool, log_nH, log_T);
+	const Weights W = weightsOf(t, densityAxis(t, log10(nH)), temperatureAxis(t, log10(Tgas)));
+	const double logCool = weighted(t, t.cool, W);
 	const double LambdaCool = fastPow10(logCool);
 	const double Edot = (rhoH * rhoH) * LambdaCool;
 	const double t_cool = Egas / Edot;
-	const double mu = lookup(t, t.mmw, log_nH, log_T);
+	const double mu = weighted(t, t.mmw, W);
 	const double c_s = sqrt(gamma * t.k_B * Tgas / (mu * t.m_H));
 	return c_s * t_cool;
 }
@@ -420,16 +516,16 @@ QK_HD auto coolingLength(Tables const &t, double rho, double Egas, double gamma)
 QK_HD auto heatingRate(Tables const &t, CellCool const &c, double Eint, double &rate) -> bool
 {
 	if (Eint <= c.Emin) {
-		rate = netHeatingAt(t, c.rhoH, c.log_nH, t.T_min);
+		rate = netHeatingAt(t, c.rhoH, c.X, t.T_min);
 	} else if (Eint >= c.Emax) {
-		rate = netHeatingAt(t, c.rhoH, c.log_nH, t.T_max);
+		rate = netHeatingAt(t, c.rhoH, c.X, t.T_max);
 	} else {
 		const double T = tgasInTable(t, c, Eint);
 		if (isNan(T)) {
 			rate = NAN;
 			return false;
 		}
-		rate = netHeatingAt(t, c.rhoH, c.log_nH, T);
+		rate = netHeatingAt(t, c.rhoH, c.X, T);
 	}
 	return true;
 }
@@ -506,8 +602,9 @@ QK_HD void heunAttempt(Tables const &t, CellCool const &c, double dt_total, doub
 		s.nsteps = maxSubsteps; // no attempt of this step was accepted
 	}
 }
-QK_HD auto integrateCooling(Tables const &t, double rho, double gamma, double &E, double dt_total, double reltol, double abstol) -> int
+QK_HD auto integrateCooling(Tables const &t0, double rho, double gamma, double &E, double dt_total, double reltol, double abstol) -> int
 {
+	const Tables t = preparedCopy(t0);
 	const CellCool c = cellCool(t, rho, gamma);
 	HeunState s;
 	heunBegin(t, c, E, dt_total, s);

@@ -103,6 +103,7 @@ class cloudy_tables
 		t.mmw_max = c.mmw_max;
 		t.m_H = C::m_p + C::m_e;
 		t.k_B = C::k_B;
+		t.prepared = 0; // (the per-cell functions prepare a copy where they run: host pointers on the host, device pointers in a kernel)
 		return t;
 	}
 	void release()

@@ -125,10 +125,10 @@ extern "C" {
 struct T5 { const double *a, *b, *c, *d, *e; int n0, n1; double tmin, tmax, mmin, mmax; };
 static qk::cool::Tables mk(const T5 *t)
 {
-	qk::cool::Tables r;
+	qk::cool::Tables r{};
 	r.log_nH = t->a; r.log_T = t->b; r.cool = t->c; r.heat = t->d; r.mmw = t->e; r.n_nH = t->n0; r.n_T = t->n1;
 	r.T_min = t->tmin; r.T_max = t->tmax; r.mmw_min = t->mmin; r.mmw_max = t->mmax;
-	r.m_H = 1.67262192369e-24 + 9.1093837015e-28; r.k_B = 1.380649e-16;
+	r.m_H = 1.67262192369e-24 + 9.1093837015e-28; r.k_B = 1.380649e-16; r.prepared = 0;
 	return r;
 }
 void hc_eval(const T5 *t, double gamma, int what, long n, const double *rho, const double *val, double *out)
