@@ -1380,11 +1380,35 @@ int qk_hydro_stage_fused(qk_level *lev, qk_stream stream, const qk_hydro_traits 
 	{
 		ProfScope ps(ctx, s, "k_pre");
 		const int xt = (lev->maxlen[0] + 2 + PT_X - 1) / PT_X, yt = (lev->maxlen[1] + 2 + PT_Y - 1) / PT_Y;
-		// enough workgroups for ~4 per CU; every z segment pays 6 planes of warm-up (own columns only), so keep >= 24 planes per segment
-		// (a small level: shorter segments, see marchSegments)
+		// Segments along z.  Every segment pays 6 planes of warm-up (own columns only), a CU holds two workgroups (512 slots on the chip), and
+		// short segments keep the workgroups of neighbouring tiles at the same z, where their halo rows are still in the XCD's L2.  Measured
+		// (profiles/round4/ab7_prepass_segments.txt): 256^3 in 128^3 boxes (304 tiles) 3 / 4 / 5 / 6 segments 0.419 / 0.428 / 0.405 / 0.423 ms —
+		// the order of (idle share of the last round of workgroups) x (warm-up share); 512^3 (2432 tiles) 1 / 2 / 3 / 4 / 5 / 6 segments 3.10 /
+		// 3.00 / 2.96 / 2.88 / 2.99 / 3.02 ms.  So: segments of about 30 planes; with few rounds of workgroups the neighbour count that wastes
+		// least.  (A small level: shorter segments, see marchSegments.)
 		const bool small = static_cast<int64_t>(lev->nboxes) * lev->maxlen[0] * lev->maxlen[1] * lev->maxlen[2] < smallLevelCells();
-		int nseg = static_cast<int>(std::min<int64_t>((1024 + static_cast<int64_t>(xt) * yt * lev->nboxes - 1) / (static_cast<int64_t>(xt) * yt * lev->nboxes),
-							      std::max(1, (lev->maxlen[2] + 2) / (small ? smallMinLen() : 24))));
+		const int64_t tiles = static_cast<int64_t>(xt) * yt * lev->nboxes;
+		const int nplanes = lev->maxlen[2] + 2;
+		int nseg;
+		if (small) {
+			nseg = static_cast<int>(std::min<int64_t>((1024 + tiles - 1) / tiles, std::max(1, nplanes / smallMinLen())));
+		} else {
+			const int base = std::max(1, std::min(8, (nplanes + 15) / 30));
+			nseg = base;
+			const double slots = 512.0;
+			if (static_cast<double>(tiles) * base / slots < 6.0) {
+				double best = 1e300;
+				for (int c = std::max(1, base - 1); c <= base + 1; ++c) {
+					const double rounds = static_cast<double>(tiles) * c / slots;
+					const int seglen = (nplanes + c - 1) / c;
+					const double cost = (std::ceil(rounds) / rounds) * (static_cast<double>(seglen + 6) / seglen);
+					if (cost < best) {
+						best = cost;
+						nseg = c;
+					}
+				}
+			}
+		}
 		if (const char *e = std::getenv("QK_PRE_SEGMENTS")) {
 			nseg = std::max(1, std::atoi(e));
 		}
