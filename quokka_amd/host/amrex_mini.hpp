@@ -473,6 +473,8 @@ class Geometry
 	Box domain;
 	GpuArray<Real, AMREX_SPACEDIM> prob_lo{}, prob_hi{}, dx{};
 	int periodic[3] = {0, 0, 0};
+	Geometry() = default;
+	explicit Geometry(Box const &dom) : domain(dom) {} // amrex::Geometry(domain): the physical box comes from the deck (geometry.prob_lo / prob_hi)
 	[[nodiscard]] auto Domain() const -> Box const & { return domain; }
 	[[nodiscard]] auto CellSizeArray() const -> GpuArray<Real, AMREX_SPACEDIM> { return dx; }
 	[[nodiscard]] auto ProbLoArray() const -> GpuArray<Real, AMREX_SPACEDIM> { return prob_lo; }
@@ -746,6 +748,13 @@ template <typename T> struct Table3D {
 	T *p = nullptr;
 	Long jstride = 0, kstride = 0;
 	int lo0 = 0, lo1 = 0, lo2 = 0;
+	GpuArray<int, 3> begin{{0, 0, 0}}, end{{0, 0, 0}}; // [begin, end) as AMReX names them
+	Table3D() = default;
+	// amrex::Table3D(p, lo, hi): hi is one past the last index
+	Table3D(T *ptr, GpuArray<int, 3> const &lo, GpuArray<int, 3> const &hi)
+	    : p(ptr), jstride(hi[0] - lo[0]), kstride(static_cast<Long>(hi[0] - lo[0]) * (hi[1] - lo[1])), lo0(lo[0]), lo1(lo[1]), lo2(lo[2]), begin(lo), end(hi)
+	{
+	}
 	QK_HD auto operator()(int i, int j, int k) const -> T & { return p[(i - lo0) + jstride * (j - lo1) + kstride * (k - lo2)]; }
 };
 template <typename T, int N> struct TableAccessor;
@@ -763,6 +772,18 @@ template <typename T, int N> class TableData
 	static_assert(N >= 1 && N <= 3, "amrex_mini: TableData is built for one, two or three indices");
 
       public:
+	TableData() = default;
+	TableData(TableData &&o) noexcept : lo_(o.lo_), hi_(o.hi_), host_(o.host_), n_(o.n_), d_(o.d_) { o.d_ = nullptr; }
+	[[nodiscard]] auto lo() const -> Array<int, N> const & { return lo_; }
+	[[nodiscard]] auto hi() const -> Array<int, N> const & { return hi_; }
+	void resize(Array<int, N> const &lo, Array<int, N> const &hi, Arena *arena = nullptr)
+	{
+		if (d_ != nullptr) {
+			(void)(host_ ? hipHostFree(d_) : hipFree(d_));
+			d_ = nullptr;
+		}
+		new (this) TableData(lo, hi, arena);
+	}
 	TableData(Array<int, N> const &lo, Array<int, N> const &hi, Arena *arena = nullptr) : lo_(lo), hi_(hi), host_(arena != nullptr && arena->host)
 	{
 		n_ = 1;
@@ -811,12 +832,14 @@ template <typename T, int N> class TableData
 			if constexpr (N == 3) {
 				t.kstride = t.jstride * (hi_[1] - lo_[1] + 1);
 				t.lo2 = lo_[2];
+				t.begin = {{lo_[0], lo_[1], lo_[2]}};
+				t.end = {{hi_[0] + 1, hi_[1] + 1, hi_[2] + 1}};
 			}
 		}
 		return t;
 	}
-	Array<int, N> lo_, hi_;
-	bool host_;
+	Array<int, N> lo_{}, hi_{};
+	bool host_ = false;
 	Long n_ = 0;
 	T *d_ = nullptr;
 };
@@ -837,6 +860,21 @@ template <typename T> void ReduceRealMin(T &v) { v = static_cast<T>(qkhost::Comm
 inline void ReduceIntSum(int &v) { v = static_cast<int>(qkhost::Comm::get().allReduceSum(static_cast<int64_t>(v))); }
 inline void ReduceLongSum(long &v) { v = static_cast<long>(qkhost::Comm::get().allReduceSum(static_cast<int64_t>(v))); }
 inline void Abort() { std::exit(2); }
+// MPI plumbing a problem may name: the type map of a broadcast, the I/O rank, the communicator (AMReX_ParallelDescriptor.H)
+template <typename T> struct Mpi_typemap {
+	static auto type() -> int { return static_cast<int>(sizeof(T)); }
+};
+constexpr int ioProcessor = 0;
+inline auto Communicator() -> int { return 0; }
+template <typename T> void Bcast(T *v, size_t n, int /*type*/, int root, int /*comm*/)
+{
+	for (size_t i = 0; i < n; ++i) { // (a sum of the root's value and zeros: the collectives this host has)
+		double const mine = (qkhost::Comm::get().rank == root && v[i] == v[i]) ? static_cast<double>(v[i]) : 0.0;
+		double const isnan_root = (qkhost::Comm::get().rank == root && v[i] != v[i]) ? 1.0 : 0.0;
+		double const s = qkhost::Comm::get().allReduceSum(mine);
+		v[i] = (qkhost::Comm::get().allReduceSum(isnan_root) > 0) ? static_cast<T>(std::numeric_limits<double>::quiet_NaN()) : static_cast<T>(s);
+	}
+}
 } // namespace ParallelDescriptor
 namespace ParallelContext
 {

@@ -1028,6 +1028,9 @@ auto QuokkaSimulation<problem_t>::computeAxisAlignedProfile(const int axis, F co
 
 template <typename problem_t> void QuokkaSimulation<problem_t>::evolve()
 {
+	if (this->doPoissonSolve_ != 0) {
+		amrex::Abort("doPoissonSolve_ = 1: self-gravity (the MLMG Poisson solve of reference src/simulation.hpp:1014-1095) is not built in quokka_amd/host");
+	}
 	if (amr_) {
 		amr_->evolve();
 	} else {

@@ -7,6 +7,7 @@
 #include <unordered_map>
 #include <variant>
 
+#include "compat/particles_decl.hpp"
 #include "quokka_rad_system.hpp"
 
 namespace qkhost
@@ -191,6 +192,12 @@ template <typename problem_t> class AMRSimulation
 	[[nodiscard]] auto boxArray(int /*lev*/ = 0) const -> std::vector<amrex::Box> const & { return grids_; }
 	[[nodiscard]] auto DistributionMap(int /*lev*/ = 0) const -> amrex::DistributionMapping { return {}; }
 	[[nodiscard]] auto finestLevel() const -> int { return 0; }
+	// self-gravity (reference src/simulation.hpp:169,392,1014-1095: a Poisson solve with amrex::MLMG per coarse step): NOT built — the members exist
+	// so that the problems that set them compile; evolve() refuses a run that asks for the solve
+	int doPoissonSolve_ = 0;
+	amrex::Real Gconst_ = C::Gconst;
+	amrex::Vector<amrex::MultiFab> phi;				   // the potential of that solve: never filled
+	std::unique_ptr<quokka::CICParticleContainer> CICParticles; // never created (compat/particles_decl.hpp)
 	int finest_level = 0;			     // amrex::AmrMesh::finest_level as a problem's loop over levels reads it: this object's one level
 	ThisLevel<amrex::IntVect> ref_ratio{amrex::IntVect(2, 2, 2)};
 	// values a problem keeps across restarts (reference src/simulation.hpp:103,175; written to / read from metadata.yaml there — kept in memory here)

@@ -10,7 +10,7 @@ AMReX_BoxArray.H AMReX_Config.H AMReX_CoordSys.H AMReX_DistributionMapping.H AMR
 AMReX_FabArrayUtility.H AMReX_Geometry.H AMReX_GpuAsyncArray.H AMReX_GpuContainers.H AMReX_GpuDevice.H AMReX_GpuQualifiers.H AMReX_IntVect.H AMReX_Loop.H
 AMReX_MFParallelFor.H AMReX_MultiFab.H AMReX_MultiFabUtil.H AMReX_ParallelContext.H AMReX_ParallelDescriptor.H AMReX_ParmParse.H AMReX_PlotFileUtil.H AMReX_Print.H
 AMReX_REAL.H AMReX_Reduce.H AMReX_SPACE.H AMReX_TableData.H AMReX_TagBox.H AMReX_ValLocPair.H AMReX_Vector.H AMReX_iMultiFab.H AMReX_GpuControl.H AMReX_Gpu.H
-AMReX_Random.H AMReX_RandomEngine.H AMReX_GpuLaunch.H AMReX_Utility.H AMReX_INT.H AMReX_Dim3.H AMReX_RealBox.H AMReX_Math.H""".split()
+AMReX_Random.H AMReX_RandomEngine.H AMReX_ccse-mpi.H AMReX_Particles.H AMReX_AmrParticles.H AMReX_ParIter.H AMReX_ParticleInterpolators.H AMReX_ParticleReal.H AMReX_GpuLaunch.H AMReX_Utility.H AMReX_INT.H AMReX_Dim3.H AMReX_RealBox.H AMReX_Math.H""".split()
 QUOKKA = ["QuokkaSimulation.hpp", "simulation.hpp", "SimulationData.hpp", "hydro/mhd_system.hpp", "physics_numVars.hpp", "physics_info.hpp", "hydro/hydro_system.hpp", "hydro/EOS.hpp", "hydro/HydroState.hpp",
           "radiation/radiation_system.hpp", "radiation/radiation_dust_system.hpp", "fundamental_constants.H", "hyperbolic_system.hpp", "grid.hpp", "math/math_impl.hpp",
           "cooling/TabulatedCooling.hpp", "cooling/GrackleLikeCooling.hpp"]
@@ -18,6 +18,7 @@ COMPAT = {"util/fextract.hpp": "compat/util_compat.hpp", "util/ArrayUtil.hpp": "
           "fmt/format.h": "compat/mini_fmt.hpp", "fmt/core.h": "compat/mini_fmt.hpp", "radiation/planck_integral.hpp": "compat/planck_integral.hpp",
           "hydro/NSCBC_inflow.hpp": "compat/nscbc.hpp", "hydro/NSCBC_outflow.hpp": "compat/nscbc.hpp",
           "math/ODEIntegrate.hpp": "compat/ode_integrate.hpp", "math/quadrature.hpp": "compat/quadrature.hpp",
+          "turbulence/TurbDataReader.hpp": "compat/turb_data_reader.hpp", "particles/CICParticles.hpp": "compat/particles_decl.hpp",
           "eos.H": "compat/microphysics_stub.hpp", "extern_parameters.H": "compat/microphysics_stub.hpp"}
 ADVECTION = ["linear_advection/AdvectionSimulation.hpp", "linear_advection/linear_advection.hpp"]
 EMPTY = ["util/matplotlibcpp.h"]

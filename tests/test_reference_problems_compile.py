@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "quokka_amd", "host")
 REF = "/root/reference/src/problems"
 MUST = {"HydroBlast3D", "HydroShocktube", "RadhydroShell"}
-MIN_COUNT = 58
+MIN_COUNT = 61
 
 
 def spacedim(pdir):
