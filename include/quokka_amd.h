@@ -244,7 +244,10 @@ typedef struct qk_hydro_stage_args {
 				  * either side is treated as the reference's form treats every face: stage 1 stores F1 in halfFlux[d], stage 2 writes
 				  * flux_rk2 = 0.5 F1 + 0.5 F2 to fluxRk2[d] (both required then).  For a level with refined children: mark the coarse
 				  * cells along the coarse-fine interface (the items of its flux register) and incrementFluxRegisters
-				  * (src/simulation.hpp:1345-1387) finds flux_rk2 where it reads it, while the 99.9 % other faces stay carried. */
+				  * (src/simulation.hpp:1345-1387) finds flux_rk2 where it reads it, while the 99.9 % other faces stay carried.
+				  * A box's descriptor may be a WINDOW of its array (same p-relative memory and strides, begin / end cropped to the bounding
+				  * box of the marked cells; end <= begin: none): cells outside [begin, end) count as unmarked and are not read — pass
+				  * windows, or every face of the level waits for two byte loads. */
 	int fofc_pass;		 /* 0: the stage proper.  1: the FIRST-ORDER FLUX CORRECTION of a stage whose first pass counted flagged cells (reference
 				  * src/QuokkaSimulation.hpp:1144-1184, :1232-1270), as ONE more fused pass: `redoFlag` is an INPUT here (as the first pass left
 				  * it, with its one ghost cell filled: qk_FillBoundary_*_int) — a face that touches a flagged cell takes the first-order flux of

@@ -138,10 +138,24 @@ class AmrLevelSim(HydroSimulation):
         if not (getattr(self.amr, "rk2_carry_rhs", False) and self.ilev == 0 and self.integratorOrder_ == 2):
             return
         m = MultiFab(self.lev, 1, 1, dtype=torch.int8, fill=0)
+        win = {}  # box -> bounding box of its marked cells
         for _d, _side, _fb, cb, lo, hi, sh in child_fluxreg.items():
             beg = m.begins[cb]
             sl = tuple(slice(lo[k] + sh[k] - beg[k], hi[k] + sh[k] - beg[k] + 1) for k in (2, 1, 0))
             m.fabs[cb][0][sl] = 1
+            wlo, whi = win.setdefault(cb, ([2 ** 30] * 3, [-2 ** 30] * 3))
+            for k in range(3):
+                wlo[k], whi[k] = min(wlo[k], lo[k] + sh[k]), max(whi[k], hi[k] + sh[k])
+        # the descriptors the kernels see are WINDOWS (include/quokka_amd.h, flux_mask): the bounding box of a box's marked cells, none for a box
+        # without — a face outside the window is dropped without reading a byte
+        tab = m.host_table
+        for b in range(len(m.fabs)):
+            beg = [int(x) for x in tab[b]["begin"]]
+            wlo, whi = win.get(b, (beg, [x - 1 for x in beg]))
+            tab[b]["p"] = int(tab[b]["p"]) + (wlo[0] - beg[0]) + int(tab[b]["jstride"]) * (wlo[1] - beg[1]) + int(tab[b]["kstride"]) * (wlo[2] - beg[2])
+            tab[b]["begin"], tab[b]["end"] = wlo, [x + 1 for x in whi]
+        m.table = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(m.table.device)
+        m.__dict__.pop("_subtables", None)
         self.flux_mask = m
         self.store_flux_rk2 = False
         self.rk2_carry_rhs = True
@@ -197,6 +211,7 @@ class AmrLevelSim(HydroSimulation):
         """advanceSingleTimestepAtLevel: state_new <- advance(state_old = previous state_new), with the retries of
         advanceHydroAtLevelWithRetries (reference src/QuokkaSimulation.hpp:885-990); every attempt restarts at `time`"""
         self._signal_of_state_new = None
+        self._old_ghosts_filled = False
         self.state_old_cc_, self.state_new_cc_ = self.state_new_cc_, self.state_old_cc_
         amr, l = self.amr, self.ilev
         fr_as_fine = self.fluxreg if (amr.do_reflux and l > 0) else None
@@ -227,6 +242,10 @@ class AmrLevelSim(HydroSimulation):
                 if not success:
                     break
             if success:
+                # the stage-1 fill of an in-place attempt was applied to state_old_cc_ itself (at `time`, from the parent's unchanged states) and
+                # nothing writes the old state afterwards: timeStepWithSubcycling need not fill it again for the children (hydro only: the
+                # radiation subcycle mirrors its substeps into the old state)
+                self._old_ghosts_filled = in_place and not isinstance(self, RadhydroSimulation)
                 return True
         return False
 
@@ -610,6 +629,8 @@ class AmrSimulation:
         if lev < self.finest_level:
             # the children interpolate their ghost cells from this level's old and new states: both need their own ghost cells
             for st, t in ((L.state_old_cc_, L.t_old), (L.state_new_cc_, L.t_new)):
+                if st is L.state_old_cc_ and getattr(L, "_old_ghosts_filled", False):
+                    continue
                 L._fill_time = t
                 L.fillBoundaryConditions(st)
             for i in range(2):

@@ -368,6 +368,17 @@ QK_DEV void flattenEdges(double chi, double mean, double &am, double &ap)
 // 0.5 F2 on the coarse-fine faces — a few thousand faces of 50 million.  A face with a marked cell on either side keeps F1 in halfFlux (stage 1) and
 // gets flux_rk2 written to rk2Flux (stage 2), exactly the values the reference's form stores on EVERY face; the cell updates stay carried.
 using CA4 = A4<const char, qk_carray4>;
+// The mask descriptor of a box may describe a WINDOW of the box only — the bounding box of its marked cells, the same memory and strides with begin /
+// end cropped (an empty window: no cell) —: cells outside [begin, end) are unmarked and their bytes are never read.  The marked cells of a level are the
+// two cell layers along the coarse-fine interfaces; with whole-box descriptors every face of the level waited for two byte loads before its
+// flux could be dropped (the sweeps of BASELINE config 5's base level: X +9 %, Y +25 %, Z +17 % against the unigrid level).
+QK_DEV auto maskByte(qk_carray4 const &d, int i, int j, int k) -> int
+{
+	if (i < d.begin[0] || i >= d.end[0] || j < d.begin[1] || j >= d.end[1] || k < d.begin[2] || k >= d.end[2]) {
+		return 0;
+	}
+	return CA4(d)(i, j, k);
+}
 template <int STAGE, int NV> QK_DEV void maskedFaceFlux(SweepArgs const &a, int b, int i, int j, int k, const double F[NV])
 {
 	if (STAGE == 1) {
@@ -734,8 +745,8 @@ template <int ORDER, int STAGE, int NS, bool CARRY, int NDIM = 3, bool FOFC = fa
 	if (CARRY) {
 		// carried right-hand side: neither stage touches the face arrays — except on the marked faces of a level with refined children
 		if (a.fluxMask != nullptr && isFace) {
-			CA4 M(a.fluxMask[b]);
-			if ((M(i - 1, j, k) | M(i, j, k)) != 0) {
+			const qk_carray4 md = a.fluxMask[b];
+			if ((maskByte(md, i - 1, j, k) | maskByte(md, i, j, k)) != 0) {
 				maskedFaceFlux<STAGE, NV>(a, b, i, j, k, F);
 			}
 		}
@@ -904,6 +915,15 @@ __global__ void __launch_bounds__(64 * MARCH_BY) k_sweep_march(SweepArgs a, Eos 
 	// three global_load_lds_dwordx4 per wave and step into a 3-KiB slot, read out at the top of the next step, no register held meanwhile.  Y sweep
 	// 0.722 ms with it, 0.721 ms without, on the same box: the sweep is bound by the rate at which the box's HBM delivers its bytes, not by the
 	// latency of that load.  The Z sweep, at 248 VGPRs, spilled with it: 0.92 -> 1.11 ms.)
+	// the carried form on a level with refined children: can this column (i, ot) hold marked cells, and where along the march (maskByte)
+	bool maskCol = false;
+	int maskLo = 0, maskHi = -1;
+	if (CARRY && a.fluxMask != nullptr) {
+		const qk_carray4 md = a.fluxMask[b];
+		maskCol = live && i >= md.begin[0] && i < md.end[0] && ot >= md.begin[OT] && ot < md.end[OT];
+		maskLo = md.begin[DIR];
+		maskHi = md.end[DIR] - 1;
+	}
 	constexpr bool RING = LAST && (STAGE == 1);
 	__shared__ double s_ring[RING ? 3 : 1][RING ? NV : 1][RING ? 64 * MARCH_BY : 1];
 	const int tid = threadIdx.y * 64 + threadIdx.x;
@@ -1052,11 +1072,13 @@ __global__ void __launch_bounds__(64 * MARCH_BY) k_sweep_march(SweepArgs a, Eos 
 			};
 			if (CARRY) {
 				// carried right-hand side: no face arrays — except on the marked faces of a level with refined children
-				if (a.fluxMask != nullptr && live) {
+				if (maskCol && fidx[DIR] >= maskLo && fidx[DIR] - 1 <= maskHi) { // the face's cells fidx - 1 and fidx along the march
 					CA4 M(a.fluxMask[b]);
 					int fm[3] = {fidx[0], fidx[1], fidx[2]};
 					fm[DIR] -= 1;
-					if ((M(fm[0], fm[1], fm[2]) | M(fidx[0], fidx[1], fidx[2])) != 0) {
+					const int m0 = (fm[DIR] >= maskLo) ? M(fm[0], fm[1], fm[2]) : 0;
+					const int m1 = (fidx[DIR] <= maskHi) ? M(fidx[0], fidx[1], fidx[2]) : 0;
+					if ((m0 | m1) != 0) {
 						maskedFaceFlux<STAGE, NV>(a, b, fidx[0], fidx[1], fidx[2], F);
 					}
 				}

@@ -604,6 +604,124 @@ class ParmParse
 		}                                                                                                                                    \
 	} while (0)
 
+// The device arena of the host mirror (what amrex::The_Arena() is to the reference: src/main.cpp initialises AMReX with its pooled arena, and every
+// MultiFab of a regrid comes out of it).  hipMalloc / hipFree cost tens to hundreds of microseconds each and hipFree waits for the device; a
+// hierarchy that regrids every other step re-creates the tag arrays, the fine-level states and their plans every time.  Blocks are kept in exact-size
+// free lists instead (a regrid asks for the sizes the one before released).  A released block may still be read by kernels in flight: it becomes
+// reusable when an event recorded on the null stream at release time has completed (every stream of the host mirror that touches fab data is a
+// blocking stream, so the null stream's event follows all of them).  QK_DEVICE_ARENA=0: plain hipMalloc / hipFree.
+class DeviceArena
+{
+      public:
+	static auto get() -> DeviceArena &
+	{
+		static auto *a = new DeviceArena; // (never destroyed: objects with static storage may release blocks after main returns)
+		return *a;
+	}
+	auto alloc(std::size_t bytes) -> void *
+	{
+		std::size_t const n = roundUp(bytes);
+		void *p = nullptr;
+		if (pooled_) {
+			reclaim(0);
+			auto it = free_.find(n);
+			if (it == free_.end() || it->second.empty()) {
+				reclaim(n); // wait for a released block of this size rather than growing
+				it = free_.find(n);
+			}
+			if (it != free_.end() && !it->second.empty()) {
+				p = it->second.back();
+				it->second.pop_back();
+				cached_ -= n;
+				return p;
+			}
+		}
+		if (hipMalloc(&p, n) != hipSuccess) {
+			trim(); // give the cache back to the driver and try once more
+			hipError_t const e = hipMalloc(&p, n);
+			if (e != hipSuccess) {
+				std::fprintf(stderr, "DeviceArena: hipMalloc(%zu): %s\n", n, hipGetErrorString(e));
+				std::abort();
+			}
+		}
+		if (pooled_) {
+			size_[p] = n;
+		}
+		return p;
+	}
+	void free(void *p)
+	{
+		if (p == nullptr) {
+			return;
+		}
+		auto const it = size_.find(p);
+		if (!pooled_ || it == size_.end()) {
+			(void)hipFree(p);
+			return;
+		}
+		hipEvent_t ev = nullptr;
+		if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, nullptr) != hipSuccess) {
+			(void)hipGetLastError(); // (the runtime is shutting down: nothing reuses the block)
+			return;
+		}
+		pending_.push_back({p, it->second, ev});
+	}
+
+      private:
+	struct Pending {
+		void *p;
+		std::size_t n;
+		hipEvent_t ev;
+	};
+	DeviceArena()
+	{
+		char const *e = std::getenv("QK_DEVICE_ARENA");
+		pooled_ = (e == nullptr) || std::atoi(e) != 0;
+	}
+	static auto roundUp(std::size_t b) -> std::size_t { return (std::max<std::size_t>(b, 1) + 511) / 512 * 512; }
+	// released blocks whose event has completed join the free lists; waitFor != 0: block on the oldest pending release of that size
+	void reclaim(std::size_t waitFor)
+	{
+		for (std::size_t k = 0; k < pending_.size();) {
+			Pending const q = pending_[k];
+			bool done = hipEventQuery(q.ev) == hipSuccess;
+			if (!done && waitFor != 0 && q.n == waitFor) {
+				done = hipEventSynchronize(q.ev) == hipSuccess;
+				waitFor = 0;
+			}
+			if (done) {
+				(void)hipEventDestroy(q.ev);
+				free_[q.n].push_back(q.p);
+				cached_ += q.n;
+				pending_[k] = pending_.back();
+				pending_.pop_back();
+			} else {
+				++k;
+			}
+		}
+		(void)hipGetLastError(); // (hipEventQuery reports hipErrorNotReady through the sticky error too)
+		if (cached_ > (static_cast<std::size_t>(8) << 30)) {
+			trim();
+		}
+	}
+	void trim()
+	{
+		for (auto &kv : free_) {
+			for (void *p : kv.second) {
+				size_.erase(p);
+				(void)hipFree(p);
+			}
+			kv.second.clear();
+		}
+		cached_ = 0;
+	}
+	bool pooled_ = true;
+	std::map<std::size_t, std::vector<void *>> free_;
+	std::map<void *, std::size_t> size_;
+	std::vector<Pending> pending_;
+	std::size_t cached_ = 0;
+};
+
 // amrex::launch(box, f(Box const &tbx)): the reference uses it on single-cell boxes; one thread gets the whole box
 template <typename F> __global__ void qk_launch_kernel(Box bx, F f) { f(bx); }
 template <typename F> void launch(Box const &bx, F const &f)
@@ -617,12 +735,12 @@ template <typename T> class AsyncArray
       public:
 	AsyncArray(T const *h, std::size_t n) : n_(n)
 	{
-		QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_), sizeof(T) * (n > 0 ? n : 1)));
+		d_ = static_cast<T *>(DeviceArena::get().alloc(sizeof(T) * (n > 0 ? n : 1)));
 		QK_HOST_HIP(hipMemcpy(d_, h, sizeof(T) * n, hipMemcpyHostToDevice));
 	}
 	AsyncArray(AsyncArray const &) = delete;
 	auto operator=(AsyncArray const &) -> AsyncArray & = delete;
-	~AsyncArray() { (void)hipFree(d_); }
+	~AsyncArray() { DeviceArena::get().free(d_); }
 	[[nodiscard]] auto data() const -> T * { return d_; }
 	void copyToHost(T *h, std::size_t n) const { QK_HOST_HIP(hipMemcpy(h, d_, sizeof(T) * n, hipMemcpyDeviceToHost)); }
 
@@ -977,7 +1095,7 @@ template <typename T> class FabArrayT
 				slack = std::max<Long>(slack, 4 * fb.numPts());
 			}
 		}
-		QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_data_), sizeof(T) * std::max<Long>(total_ + slack, 1)));
+		d_data_ = static_cast<T *>(DeviceArena::get().alloc(sizeof(T) * static_cast<std::size_t>(std::max<Long>(total_ + slack, 1))));
 		// fresh storage reads as zero (what the Python drivers' MultiFab(fill = 0) gives); QK_POISON=1 fills it with NaN bit patterns
 		// instead, which makes any read of a cell that was never written visible in the results (debugging aid)
 		// fresh storage reads as zero (what the Python drivers' MultiFab(fill = 0) gives); QK_POISON=1 fills it with NaN bit patterns instead, which
@@ -991,7 +1109,7 @@ template <typename T> class FabArrayT
 		for (size_t n = 0; n < ba.size(); ++n) {
 			tab.emplace_back(d_data_ + offsets_[n], fabboxes_[n], ncomp);
 		}
-		QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_table_), sizeof(Array4<T>) * std::max<size_t>(ba.size(), 1))); // (never null: a level may be empty on this rank)
+		d_table_ = static_cast<Array4<T> *>(DeviceArena::get().alloc(sizeof(Array4<T>) * std::max<size_t>(ba.size(), 1))); // (never null: a level may be empty on this rank)
 		QK_HOST_HIP(hipMemcpy(d_table_, tab.data(), sizeof(Array4<T>) * ba.size(), hipMemcpyHostToDevice));
 	}
 	[[nodiscard]] auto size() const -> int { return static_cast<int>(boxes_.size()); }
@@ -1016,6 +1134,27 @@ template <typename T> class FabArrayT
 	[[nodiscard]] auto DistributionMap() const -> DistributionMapping { return DistributionMapping{}; }
 	// device pointer to the descriptor table (MultiFab::arrays())
 	[[nodiscard]] auto arrays() const -> Array4<T> * { return d_table_; }
+	// Restrict the DEVICE descriptors (arrays()) to a window of every fab: the same memory and strides, begin / end cropped to win[b] (an empty box:
+	// no cell).  For byte arrays a kernel only consults inside a bounding box (qk_hydro_stage_args::flux_mask); array(b) keeps describing the whole fab.
+	void cropDeviceTable(std::vector<Box> const &win)
+	{
+		std::vector<Array4<T>> tab;
+		for (int b = 0; b < size(); ++b) {
+			Array4<T> a = array(b);
+			Box const &w = win[static_cast<size_t>(b)];
+			if (w.ok()) {
+				a.p += (w.lo[0] - a.begin.x) + a.jstride * (w.lo[1] - a.begin.y) + a.kstride * (w.lo[2] - a.begin.z);
+				a.begin = Dim3{w.lo[0], w.lo[1], w.lo[2]};
+				a.end = Dim3{w.hi[0] + 1, w.hi[1] + 1, w.hi[2] + 1};
+			} else {
+				a.end = a.begin;
+			}
+			tab.push_back(a);
+		}
+		if (!tab.empty()) {
+			QK_HOST_HIP(hipMemcpy(d_table_, tab.data(), sizeof(Array4<T>) * tab.size(), hipMemcpyHostToDevice));
+		}
+	}
 	[[nodiscard]] auto const_arrays() const -> Array4<T const> const * { return reinterpret_cast<Array4<T const> const *>(d_table_); }
 	void setVal(T v) { qk_device_fill(d_data_, total_, v); }
 	void setZeroAsync(hipStream_t /*s*/) { qk_device_fill(d_data_, total_, T{}); }
@@ -1099,12 +1238,8 @@ template <typename T> class FabArrayT
       private:
 	void release()
 	{
-		if (d_data_ != nullptr) {
-			(void)hipFree(d_data_);
-		}
-		if (d_table_ != nullptr) {
-			(void)hipFree(d_table_);
-		}
+		DeviceArena::get().free(d_data_);
+		DeviceArena::get().free(d_table_);
 		d_data_ = nullptr;
 		d_table_ = nullptr;
 	}

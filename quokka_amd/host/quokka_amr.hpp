@@ -14,6 +14,8 @@
 #ifndef QK_HOST_QUOKKA_AMR_HPP_
 #define QK_HOST_QUOKKA_AMR_HPP_
 
+#include <chrono>
+#include <map>
 #include <memory>
 
 #include "quokka_host.hpp"
@@ -110,6 +112,33 @@ template <typename problem_t, typename SimT> class AmrDriver
 		}
 	}
 
+	// QK_AMR_HOSTPROF=1: wall time of the phases of a coarse step, the device drained before and after each (so the phases do not overlap and the
+	// total is larger than an unprofiled run's); printed after the figure of merit.  A debugging aid for the host side of the hierarchy.
+	struct Phase {
+		Phase(AmrDriver &d, std::string name) : d_(d), name_(std::move(name)), on_(d.hostProf_)
+		{
+			if (on_) {
+				(void)hipDeviceSynchronize();
+				t0_ = std::chrono::steady_clock::now();
+			}
+		}
+		~Phase()
+		{
+			if (on_) {
+				(void)hipDeviceSynchronize();
+				d_.phaseSeconds_[name_] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0_).count();
+			}
+		}
+		Phase(Phase const &) = delete;
+		auto operator=(Phase const &) -> Phase & = delete;
+		AmrDriver &d_;
+		std::string name_;
+		bool on_;
+		std::chrono::steady_clock::time_point t0_;
+	};
+	bool hostProf_ = std::getenv("QK_AMR_HOSTPROF") != nullptr;
+	std::map<std::string, double> phaseSeconds_;
+
 	void evolve()
 	{
 		int const nc = Physics_Indices<problem_t>::nvarTotal_cc;
@@ -123,7 +152,10 @@ template <typename problem_t, typename SimT> class AmrDriver
 		tNew_ = base_.tNew_[0];
 		int const debugMaxSteps = (std::getenv("QK_MAX_COARSE_STEPS") != nullptr) ? std::atoi(std::getenv("QK_MAX_COARSE_STEPS")) : -1; // (debugging aid)
 		while (istep[0] < base_.maxTimesteps_ && tNew_ < base_.stopTime_ && (debugMaxSteps < 0 || istep[0] < debugMaxSteps)) {
-			computeTimestep();
+			{
+				Phase const ph(*this, "computeTimestep");
+				computeTimestep();
+			}
 			if constexpr (!Sim::isAdvection) {
 				base_.callBeforeTimestep(); // reference src/simulation.hpp:864-867
 				dropSignalsIfHooked(base_.beforeTimestepIsDefault_);
@@ -162,6 +194,9 @@ template <typename problem_t, typename SimT> class AmrDriver
 		amrex::Print() << "Performance figure-of-merit: " << us << " μs/zone-update [" << 1.0 / us << " Mupdates/s]\n";
 		for (int l = 0; l <= finestLevel(); ++l) {
 			amrex::Print() << "Zone-updates on level " << l << ": " << cellUpdatesEachLevel_[l] << " (" << level(l).allGrids_.size() << " grids)\n";
+		}
+		for (auto const &kv : phaseSeconds_) {
+			amrex::Print() << "host phase " << kv.first << ": " << kv.second << " s\n";
 		}
 	}
 
@@ -837,6 +872,7 @@ template <typename problem_t, typename SimT> class AmrDriver
 	void timeStepWithSubcycling(int lev, double time)
 	{
 		if (regrid_int > 0 && lev < max_level && istep[lev] > last_regrid_step[lev] && istep[lev] % regrid_int == 0) {
+			Phase const ph(*this, "regrid");
 			regrid(lev);
 			for (int k = lev; k <= finestLevel(); ++k) {
 				last_regrid_step[k] = istep[k];
@@ -851,22 +887,31 @@ template <typename problem_t, typename SimT> class AmrDriver
 				qkhost::check(qk_fluxreg_reset(finer_[lev]->fluxregRad, nullptr), "qk_fluxreg_reset(rad)");
 			}
 		}
-		if (!S.advanceLevel(time, dt_[lev])) {
-			amrex::Abort("QUOKKA FATAL ERROR: Hydro update exceeded max_retries on level " + std::to_string(lev));
+		{
+			Phase const ph(*this, "advance level " + std::to_string(lev));
+			if (!S.advanceLevel(time, dt_[lev])) {
+				amrex::Abort("QUOKKA FATAL ERROR: Hydro update exceeded max_retries on level " + std::to_string(lev));
+			}
 		}
 		++istep[lev];
 		cellUpdates_ += S.CountCells(0);
 		cellUpdatesEachLevel_[lev] += S.CountCells(0);
 		if (lev < finestLevel()) {
 			// the children interpolate their ghost cells from this level's old and new states: both need their own ghost cells
-			fillGhosts(lev, S.state_old_cc_[0], S.tOldLev_);
-			fillGhosts(lev, S.state_new_cc_[0], S.tNewLev_);
+			{
+				Phase const ph(*this, "parent ghost fills");
+				if (!S.oldStateGhostsFilled_) { // (a direct hydro advance filled them in its first stage, at the same time from the same parent data)
+					fillGhosts(lev, S.state_old_cc_[0], S.tOldLev_);
+				}
+				fillGhosts(lev, S.state_new_cc_[0], S.tNewLev_);
+			}
 			for (int i = 1; i <= 2; ++i) {
 				if (lev < finestLevel()) {
 					timeStepWithSubcycling(lev + 1, time + (i - 1) * dt_[lev + 1]);
 				}
 			}
 			if (lev < finestLevel()) {
+				Phase const ph(*this, "reflux + average down + fixup");
 				if (do_reflux != 0) {
 					reflux(S, finer_[lev]->fluxreg, finer_[lev]->fold.get(), 0);
 					if (finer_[lev]->fluxregRad != nullptr) {

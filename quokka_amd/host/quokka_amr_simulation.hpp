@@ -613,6 +613,18 @@ template <typename problem_t> class AMRSimulation
 	// Dirichlet / Marshak set of the C-ABI (which host-mode problems are sampled into).
 	void customBoundaryConditionsOnDevice(amrex::MultiFab &state, int which = QK_BOXES_ALL)
 	{
+		// amrex::GpuBndryFuncFab calls the user function on the cells beyond a face only where a component's boundary type there is ext_dir
+		// (the domain is grown across every other kind of face first): a problem without ext_dir faces (HydroBlast3D: reflecting / outflow)
+		// launches nothing — it was one whole-fab kernel per box and fill, 62 empty launches per coarse step of the config-5 hierarchy
+		bool anyExtDir = false;
+		for (auto const &bc : BCs_cc_) {
+			for (int d = 0; d < AMREX_SPACEDIM; ++d) {
+				anyExtDir = anyExtDir || bc.lo(d) == amrex::BCType::ext_dir || bc.hi(d) == amrex::BCType::ext_dir;
+			}
+		}
+		if (!anyExtDir) {
+			return;
+		}
 		if (d_bcrec_ == nullptr) {
 			QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_bcrec_), sizeof(amrex::BCRec) * BCs_cc_.size()));
 			QK_HOST_HIP(hipMemcpy(d_bcrec_, BCs_cc_.data(), sizeof(amrex::BCRec) * BCs_cc_.size(), hipMemcpyHostToDevice));
@@ -641,6 +653,9 @@ template <typename problem_t> class AMRSimulation
 	}
 	amrex::BCRec *d_bcrec_ = nullptr;
 	[[nodiscard]] virtual auto bcFillTime() const -> double { return tNew_[0]; }
+	// set by a level's advance when the ghost cells of state_old_cc_ hold the fill at the old time already (AmrDriver then skips its own fill of
+	// the old state before the children interpolate from it)
+	bool oldStateGhostsFilled_ = false;
 
       protected:
 	qk_level *myLev_ = nullptr;

@@ -107,10 +107,20 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		for (int b = 0; b < fluxMask_.size(); ++b) {
 			h[b].assign(static_cast<size_t>(fluxMask_.fabbox(b).numPts()), 0);
 		}
+		std::vector<amrex::Box> win(static_cast<size_t>(fluxMask_.size())); // bounding box of the marked cells of every box
+		for (auto &w : win) {
+			w.hi[0] = w.hi[1] = w.hi[2] = -1; // (empty until an item marks a cell: a default Box is the cell (0, 0, 0))
+		}
 		for (int n = 0; n < qk_fluxreg_num_items(reg); ++n) {
 			int dir = 0, side = 0, fb = 0, cb = 0, lo[3], hi[3], sh[3];
 			qkhost::check(qk_fluxreg_item(reg, n, &dir, &side, &fb, &cb, lo, hi, sh), "qk_fluxreg_item");
 			amrex::Array4<char> a(h[cb].data(), fluxMask_.fabbox(cb), 1);
+			amrex::Box &w = win[static_cast<size_t>(cb)];
+			bool const first = !w.ok();
+			for (int d = 0; d < 3; ++d) {
+				w.lo[d] = first ? lo[d] + sh[d] : std::min(w.lo[d], lo[d] + sh[d]);
+				w.hi[d] = first ? hi[d] + sh[d] : std::max(w.hi[d], hi[d] + sh[d]);
+			}
 			for (int k = lo[2]; k <= hi[2]; ++k) {
 				for (int j = lo[1]; j <= hi[1]; ++j) {
 					for (int i = lo[0]; i <= hi[0]; ++i) {
@@ -121,6 +131,14 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		}
 		for (int b = 0; b < fluxMask_.size(); ++b) {
 			fluxMask_.copyFromHost(b, h[b]);
+		}
+		fluxMask_.cropDeviceTable(win); // (the kernels drop a face outside the window without reading a byte: include/quokka_amd.h, flux_mask)
+		for (auto &g : groups_) { // descriptors gathered per box group from an earlier mask at the same address are stale
+			auto it = g.tables.find(static_cast<const void *>(fluxMask_.arrays()));
+			if (it != g.tables.end()) {
+				(void)hipFree(it->second);
+				g.tables.erase(it);
+			}
 		}
 		storeFluxRk2_ = false;
 	}
@@ -207,6 +225,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	auto advanceLevel(double time, double dt_lev) -> bool
 	{
 		std::swap(state_old_cc_[0], state_new_cc_[0]);
+		this->oldStateGhostsFilled_ = false;
 		if constexpr (Physics_Traits<problem_t>::is_hydro_enabled) {
 			if (!advanceHydroAtLevelWithRetries(time, dt_lev)) {
 				return false;
@@ -524,6 +543,9 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 				}
 			}
 			if (success) {
+				// the stage-1 fill of a direct attempt was applied to state_old_cc_ itself: its ghost cells hold the fill at `time`, and nothing
+				// writes the old state afterwards (hydro only: the radiation subcycle mirrors its substeps into it)
+				this->oldStateGhostsFilled_ = direct && !is_radiation_enabled_;
 				break;
 			}
 		}
