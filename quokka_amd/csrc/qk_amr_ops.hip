@@ -401,8 +401,14 @@ int qk_amr_tile_flags_periodic(qk_level *lev, qk_stream s, const qk_carray4 *tag
 		nt[d] = (d < lev->ndim) ? (n[d] + tile - 1) / tile : 1;
 	}
 	const size_t bytes = sizeof(int) * static_cast<size_t>(nt[0]) * nt[1] * nt[2];
-	int *d_flags = nullptr;
-	QK_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void **>(&d_flags), bytes));
+	if (lev->tile_flags_bytes < bytes) { // (kept on the level: a hierarchy regrids every other step, and hipMalloc / hipFree drain the device)
+		(void)hipFree(lev->d_tile_flags);
+		lev->d_tile_flags = nullptr;
+		lev->tile_flags_bytes = 0;
+		QK_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void **>(&lev->d_tile_flags), bytes));
+		lev->tile_flags_bytes = bytes;
+	}
+	int *d_flags = lev->d_tile_flags;
 	auto st = static_cast<hipStream_t>(s);
 	int rc = QK_OK;
 	if (hipMemsetAsync(d_flags, 0, bytes, st) != hipSuccess) {
@@ -423,7 +429,6 @@ int qk_amr_tile_flags_periodic(qk_level *lev, qk_stream s, const qk_carray4 *tag
 			rc = setError(ctx, QK_ERR_HIP, "amr_tile_flags: kernel or copy failed");
 		}
 	}
-	(void)hipFree(d_flags);
 	return rc;
 }
 

@@ -46,6 +46,9 @@ struct qk_level {
 	// cache of the fused path (ghost-4 scratch geometry of every box), built on first use
 	void *d_sgeom = nullptr;
 	int64_t sgeom_total_cells = 0;
+	// device buffer of qk_amr_tile_flags (one int per blocking-factor tile of the domain), kept between regrids
+	int *d_tile_flags = nullptr;
+	size_t tile_flags_bytes = 0;
 };
 
 namespace qk

@@ -114,27 +114,27 @@ template <typename problem_t> class AMRSimulation;
 
 namespace qkhost
 {
+// one slab of ghost cells beyond a non-periodic face of the domain: box index into the array's descriptor table + the cells
+struct BcShell {
+	int box;
+	int lo[3];
+	int hi[3];
+};
+// setCustomBoundaryConditions on every cell of every slab of a fill: ONE launch per fill (blockIdx.y: the slab), threads over ghost cells only
 template <typename problem_t>
-__global__ void customBcKernel(amrex::Array4<amrex::Real> dest, amrex::Box fab, amrex::GeometryData geom, amrex::Real time, const amrex::BCRec *bcr, int ncomp, int per0,
-			       int per1, int per2)
+__global__ void customBcKernel(const BcShell *shells, const amrex::Array4<amrex::Real> *tab, amrex::GeometryData geom, amrex::Real time, const amrex::BCRec *bcr, int ncomp)
 {
+	const BcShell sh = shells[blockIdx.y];
+	const int nx = sh.hi[0] - sh.lo[0] + 1, ny = sh.hi[1] - sh.lo[1] + 1, nz = sh.hi[2] - sh.lo[2] + 1;
 	const amrex::Long n = static_cast<amrex::Long>(blockIdx.x) * blockDim.x + threadIdx.x;
-	if (n >= fab.numPts()) {
+	if (n >= static_cast<amrex::Long>(nx) * ny * nz) {
 		return;
 	}
-	const int nx = fab.length(0), ny = fab.length(1);
 	const int k = static_cast<int>(n / (static_cast<amrex::Long>(nx) * ny));
 	const int r = static_cast<int>(n - static_cast<amrex::Long>(k) * nx * ny);
 	const int j = r / nx;
-	const amrex::IntVect iv(fab.lo[0] + (r - j * nx), fab.lo[1] + j, fab.lo[2] + k);
-	const int per[3] = {per0, per1, per2};
-	bool outside = false;
-	for (int d = 0; d < AMREX_SPACEDIM; ++d) {
-		outside = outside || (per[d] == 0 && (iv[d] < geom.domain.lo[d] || iv[d] > geom.domain.hi[d]));
-	}
-	if (outside) {
-		AMRSimulation<problem_t>::setCustomBoundaryConditions(iv, dest, 0, ncomp, geom, time, bcr, 0, 0);
-	}
+	const amrex::IntVect iv(sh.lo[0] + (r - j * nx), sh.lo[1] + j, sh.lo[2] + k);
+	AMRSimulation<problem_t>::setCustomBoundaryConditions(iv, tab[sh.box], 0, ncomp, geom, time, bcr, 0, 0);
 }
 } // namespace qkhost
 
@@ -267,6 +267,10 @@ template <typename problem_t> class AMRSimulation
 	AMRSimulation(amrex::Vector<amrex::BCRec> &BCs_cc, LevelSpec const &spec) : BCs_cc_(BCs_cc) { initialize(&spec); }
 	virtual ~AMRSimulation()
 	{
+		for (auto &kv : bcShells_) {
+			(void)hipFree(kv.second.d);
+		}
+		(void)hipFree(d_bcrec_);
 		if (plan_ != nullptr) {
 			qk_ghost_plan_destroy(plan_);
 		}
@@ -613,44 +617,68 @@ template <typename problem_t> class AMRSimulation
 	// Dirichlet / Marshak set of the C-ABI (which host-mode problems are sampled into).
 	void customBoundaryConditionsOnDevice(amrex::MultiFab &state, int which = QK_BOXES_ALL)
 	{
-		// amrex::GpuBndryFuncFab calls the user function on the cells beyond a face only where a component's boundary type there is ext_dir
-		// (the domain is grown across every other kind of face first): a problem without ext_dir faces (HydroBlast3D: reflecting / outflow)
-		// launches nothing — it was one whole-fab kernel per box and fill, 62 empty launches per coarse step of the config-5 hierarchy
-		bool anyExtDir = false;
-		for (auto const &bc : BCs_cc_) {
-			for (int d = 0; d < AMREX_SPACEDIM; ++d) {
-				anyExtDir = anyExtDir || bc.lo(d) == amrex::BCType::ext_dir || bc.hi(d) == amrex::BCType::ext_dir;
-			}
-		}
-		if (!anyExtDir) {
-			return;
-		}
 		if (d_bcrec_ == nullptr) {
 			QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_bcrec_), sizeof(amrex::BCRec) * BCs_cc_.size()));
 			QK_HOST_HIP(hipMemcpy(d_bcrec_, BCs_cc_.data(), sizeof(amrex::BCRec) * BCs_cc_.size(), hipMemcpyHostToDevice));
 		}
 		auto const gd = geom[0].data();
-		int per[3] = {1, 1, 1};
-		for (int d = 0; d < AMREX_SPACEDIM; ++d) {
-			per[d] = geom[0].isPeriodic(d) ? 1 : 0;
+		// The slabs of ghost cells beyond the non-periodic faces, disjoint (x slabs over the whole y-z extent of the fab, y slabs over the x range
+		// inside the domain, z slabs over the x and y ranges inside), listed once per ghost width and box group: every cell-centred array of a
+		// level has the same boxes.  It was one whole-fab launch per box and fill (62 per coarse step of the config-5 hierarchy, each testing
+		// 2.5 M cells to find 0.3 M).
+		auto const key = std::make_pair(state.nGrow(), which);
+		auto it = bcShells_.find(key);
+		if (it == bcShells_.end()) {
+			std::vector<qkhost::BcShell> h;
+			amrex::Long most = 0;
+			for (int b = 0; b < state.size(); ++b) {
+				if (which != QK_BOXES_ALL && (qk_ghost_plan_box_is_remote(plan_, b) == 1) != (which == QK_BOXES_REMOTE_DEPENDENT)) {
+					continue; // the other group of an overlapped fill
+				}
+				amrex::Box rest = state.fabbox(b);
+				for (int d = 0; d < AMREX_SPACEDIM; ++d) {
+					if (geom[0].isPeriodic(d)) {
+						continue;
+					}
+					for (int side = 0; side < 2; ++side) {
+						amrex::Box sl = rest;
+						if (side == 0) {
+							sl.hi[d] = std::min(rest.hi[d], gd.domain.lo[d] - 1);
+						} else {
+							sl.lo[d] = std::max(rest.lo[d], gd.domain.hi[d] + 1);
+						}
+						if (sl.ok()) {
+							qkhost::BcShell e{b, {sl.lo[0], sl.lo[1], sl.lo[2]}, {sl.hi[0], sl.hi[1], sl.hi[2]}};
+							h.push_back(e);
+							most = std::max(most, sl.numPts());
+						}
+					}
+					rest.lo[d] = std::max(rest.lo[d], gd.domain.lo[d]);
+					rest.hi[d] = std::min(rest.hi[d], gd.domain.hi[d]);
+				}
+			}
+			BcShellList l;
+			l.count = static_cast<int>(h.size());
+			l.most = most;
+			if (l.count > 0) {
+				QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&l.d), sizeof(qkhost::BcShell) * h.size()));
+				QK_HOST_HIP(hipMemcpy(l.d, h.data(), sizeof(qkhost::BcShell) * h.size(), hipMemcpyHostToDevice));
+			}
+			it = bcShells_.emplace(key, l).first;
 		}
-		for (int b = 0; b < state.size(); ++b) {
-			amrex::Box const fb = state.fabbox(b);
-			bool touches = false;
-			for (int d = 0; d < AMREX_SPACEDIM; ++d) {
-				touches = touches || (per[d] == 0 && (fb.lo[d] < gd.domain.lo[d] || fb.hi[d] > gd.domain.hi[d]));
-			}
-			if (!touches) {
-				continue;
-			}
-			if (which != QK_BOXES_ALL && (qk_ghost_plan_box_is_remote(plan_, b) == 1) != (which == QK_BOXES_REMOTE_DEPENDENT)) {
-				continue; // the other group of an overlapped fill
-			}
-			amrex::Long const n = fb.numPts();
-			hipLaunchKernelGGL(qkhost::customBcKernel<problem_t>, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, qkhost::Runtime::get().computeStream(), state.array(b), fb, gd,
-					   bcFillTime(), d_bcrec_, state.nComp(), per[0], per[1], per[2]);
+		auto const &l = it->second;
+		if (l.count == 0) {
+			return;
 		}
+		hipLaunchKernelGGL(qkhost::customBcKernel<problem_t>, dim3(static_cast<unsigned>((l.most + 255) / 256), static_cast<unsigned>(l.count)), dim3(256), 0,
+				   qkhost::Runtime::get().computeStream(), l.d, state.arrays(), gd, bcFillTime(), d_bcrec_, state.nComp());
 	}
+	struct BcShellList {
+		qkhost::BcShell *d = nullptr;
+		int count = 0;
+		amrex::Long most = 0;
+	};
+	std::map<std::pair<int, int>, BcShellList> bcShells_; // (ghost width, box group) -> slabs; lives as long as the level object
 	amrex::BCRec *d_bcrec_ = nullptr;
 	[[nodiscard]] virtual auto bcFillTime() const -> double { return tNew_[0]; }
 	// set by a level's advance when the ghost cells of state_old_cc_ hold the fill at the old time already (AmrDriver then skips its own fill of

@@ -193,14 +193,20 @@ namespace qkhost
 struct Runtime {
 	qk_ctx *ctx = nullptr;
 	qk_level *lev = nullptr; // the level the static operators act on (every simulation object activates its own before it launches)
-	// The compute stream of the ghost fill and the fused stages.  A BLOCKING stream: the legacy default stream — which the problem files'
-	// ParallelFor lambdas and the reference-shaped operators use — orders itself against it in both directions, so nothing else needs to know;
-	// the communication stream of qk_comm.hpp is non-blocking and is ordered against this one by events only (exchangeBegin / exchangeEnd).
+	// The compute stream of the ghost fill and the fused stages: the legacy default stream, the one the problem files' ParallelFor lambdas, the
+	// reference-shaped operators and the level machinery (interpolation, flux registers, average-down) run on.  It used to be a BLOCKING stream of
+	// its own, which the default stream orders itself against in both directions — correct, but every hand-over between the two is a dependency
+	// across two hardware queues: 15–45 us of idle GPU before each k_interp / k_physbc / k_fluxreg / memset of a refined level's step (1 900 such
+	// gaps, 60 ms of a 630 ms config-5 run: profiles/tools/gpu_gaps.py).  QK_OWN_COMPUTE_STREAM=1 restores the separate stream (A/B runs).  The
+	// communication stream of qk_comm.hpp is non-blocking and is ordered against this one by events only (exchangeBegin / exchangeEnd).
 	hipStream_t compute = nullptr;
+	bool computeChosen = false;
 	auto computeStream() -> hipStream_t
 	{
-		if (compute == nullptr) {
-			if (hipStreamCreate(&compute) != hipSuccess) {
+		if (!computeChosen) {
+			computeChosen = true;
+			char const *e = std::getenv("QK_OWN_COMPUTE_STREAM");
+			if (e != nullptr && std::atoi(e) != 0 && hipStreamCreate(&compute) != hipSuccess) {
 				amrex::Abort("hipStreamCreate (compute stream) failed");
 			}
 		}
