@@ -149,7 +149,7 @@ class AmrLevelSim(HydroSimulation):
         # the descriptors the kernels see are WINDOWS (include/quokka_amd.h, flux_mask): the bounding box of a box's marked cells, none for a box
         # without — a face outside the window is dropped without reading a byte
         tab = m.host_table
-        for b in range(len(m.fabs)):
+        for b in range(len(m.fabs) if getattr(self.amr, "flux_mask_windows", True) else 0):  # (False: whole-box descriptors — tests)
             beg = [int(x) for x in tab[b]["begin"]]
             wlo, whi = win.get(b, (beg, [x - 1 for x in beg]))
             tab[b]["p"] = int(tab[b]["p"]) + (wlo[0] - beg[0]) + int(tab[b]["jstride"]) * (wlo[1] - beg[1]) + int(tab[b]["kstride"]) * (wlo[2] - beg[2])

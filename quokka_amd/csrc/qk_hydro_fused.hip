@@ -626,8 +626,11 @@ QK_DEV void updateCellFrom(SweepArgs const &a, Eos const &eos, EpiConst const &e
 }
 
 // ---------------------------------------------------------------------------------------------- X sweep (flat + LDS)
-constexpr int XB = 256;	 // threads per workgroup
-constexpr int XOUT = 250; // cells updated per workgroup (3 halo cells on each side)
+#ifndef QK_XB
+#define QK_XB 256 // (A/B knob)
+#endif
+constexpr int XB = QK_XB;	 // threads per workgroup
+constexpr int XOUT = XB - 6; // cells updated per workgroup (3 halo cells on each side)
 
 // NDIM: AMREX_SPACEDIM of the build.  In a 1-D build the x sweep is the only one and carries the epilogue (P dV, PredictStep, flags, limits, dual
 // energy, CFL maxima) the z sweep carries in 3-D; in 2-D the y sweep does (k_sweep_march<1, ..., LAST, TWOD>).

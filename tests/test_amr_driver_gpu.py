@@ -113,6 +113,29 @@ def test_three_levels_nested_and_conservative(ctx):
     assert amr.cellUpdatesEachLevel_[2] > 0
 
 
+def test_flux_mask_windows_equal_whole_box_descriptors_bit_for_bit(ctx):
+    """qk_hydro_stage_args::flux_mask: a box's descriptor may be a window of its byte array (the bounding box of the marked cells; cells
+    outside count as unmarked and are not read).  The same dynamic three-level blast with windows (the hosts' default) and with whole-box
+    descriptors: the same grids, and every level's state equal in every bit — the windows drop exactly the faces the bytes would have."""
+    def run(windows):
+        amr = sedov_amr_problem(ctx, 32, 2, max_grid_size=16, blocking_factor=8)
+        amr.flux_mask_windows = windows
+        amr.use_carried_form(True)
+        tab = amr.levels[0].flux_mask.host_table
+        cropped = sum(int(np.prod(np.maximum(tab[b]["end"] - tab[b]["begin"], 0))) for b in range(amr.levels[0].lev.nboxes))
+        for _ in range(12):
+            amr.step()
+        return amr, cropped
+
+    a, whole = run(False)
+    b, cropped = run(True)
+    assert 0 < cropped < 0.5 * whole, (cropped, whole)  # (some boxes have no marked cell at all: an empty window)
+    assert [L.all_boxes for L in a.levels] == [L.all_boxes for L in b.levels]
+    for la, lb in zip(a.levels, b.levels):
+        for k in range(la.lev.nboxes):
+            assert torch.equal(la.state_new_cc_.valid(k), lb.state_new_cc_.valid(k)), (la.ilev, k)
+
+
 def test_carried_form_on_level_zero_with_flux_rk2_on_the_coarse_fine_faces_only(ctx):
     """AmrSimulation.use_carried_form: level 0 advances in the carried form of the RK2 average (qk_hydro_stage_args::rk2_carry_rhs) and forms
     flux_rk2 = 0.5 F1 + 0.5 F2 only on the faces of the cells its flux register marks (flux_mask) — what incrementFluxRegisters reads
