@@ -30,6 +30,30 @@ namespace
 
 constexpr int NG = 4; // nghost_cc_ (reference src/simulation.hpp:363)
 
+// Non-temporal hints on the streams a launch touches exactly once: the stores of the flux-divergence accumulator (X, Y), of the new state and of the
+// carried half step (final sweep), and the loads of the accumulator (Y, final sweep).  Measured same-box (profiles/round4/ab12_*): Z -1.3 ... -1.5 %,
+// Y -1 %, 512^3 headline +1.6 %.  Not on the state reads (neighbouring lanes and sweeps share their lines) and not on the pre-pass's outputs
+// (measured: the pre-pass 5 - 8 % slower with them).  QK_NT=0: no hints, 1: stores only.
+#ifndef QK_NT
+#define QK_NT 2
+#endif
+template <class P> QK_DEV void streamStore(P *p, double v)
+{
+#if QK_NT >= 1
+	__builtin_nontemporal_store(v, p);
+#else
+	*p = v;
+#endif
+}
+template <class P> QK_DEV auto streamLoad(P *p) -> double
+{
+#if QK_NT >= 2
+	return __builtin_nontemporal_load(p);
+#else
+	return *p;
+#endif
+}
+
 // geometry of the ghost-4 scratch fab of one box
 struct SGeom {
 	int64_t off;   // offset of this box in cells (scratch arrays are [array][box][comp][cell])
@@ -527,9 +551,9 @@ QK_DEV void updateCellFrom(SweepArgs const &a, Eos const &eos, EpiConst const &e
 		const double hdt = 0.5 * a.dt;
 #pragma unroll
 		for (int n = 0; n < NVAR + NS; ++n) {
-			R1.p[c1 + R1.ns * n] = U[n] + hdt * ((n < NVAR) ? r[n] : rhs[n]);
+			streamStore(&R1.p[c1 + R1.ns * n], U[n] + hdt * ((n < NVAR) ? r[n] : rhs[n]));
 		}
-		R1.p[c1 + R1.ns * (NVAR + NS)] = Pgas;
+		streamStore(&R1.p[c1 + R1.ns * (NVAR + NS)], Pgas);
 	}
 	if (CS == 2) {
 		const double hdt = 0.5 * a.dt;
@@ -607,7 +631,7 @@ QK_DEV void updateCellFrom(SweepArgs const &a, Eos const &eos, EpiConst const &e
 	const int64_t cn = Un.idx(i, j, k);
 #pragma unroll
 	for (int n = 0; n < NVAR + NS; ++n) {
-		Un.p[cn + Un.ns * n] = U[n];
+		streamStore(&Un.p[cn + Un.ns * n], U[n]);
 	}
 	if (a.max_signal != nullptr) {
 		// maxSignalSpeedLocal (:206-219) and ComputeMaxSignalSpeed (:227-250) of the new state
@@ -847,7 +871,7 @@ template <int ORDER, int STAGE, int NS, bool CARRY, int NDIM = 3, bool FOFC = fa
 #pragma unroll
 		for (int n = 0; n < NV; ++n) {
 			// hydro_system.hpp:469
-			R[(S_RHS + n) * T] = a.inv_dx * (F[n] - s_q[n][tp1]);
+			streamStore(&R[(S_RHS + n) * T], a.inv_dx * (F[n] - s_q[n][tp1]));
 		}
 		// hydro_system.hpp:803
 		R[RHS_DIVV * T] = (s_d[2][tp1] - vf) / a.dx;
@@ -994,7 +1018,7 @@ __global__ void __launch_bounds__(64 * MARCH_BY) k_sweep_march(SweepArgs a, Eos 
 			const int64_t cu = cc - ms;
 #pragma unroll
 			for (int n = 0; n < NV + 1; ++n) {
-				rhs_in[n] = S[(S_RHS + n) * T + cu];
+				rhs_in[n] = streamLoad(&S[(S_RHS + n) * T + cu]);
 			}
 			if (LAST && !ring && !(CARRY && STAGE == 2)) { // the old state of the cell this step completes (stage 2 of the carried form: S replaces it)
 				int uc[3];
@@ -1138,9 +1162,9 @@ __global__ void __launch_bounds__(64 * MARCH_BY) k_sweep_march(SweepArgs a, Eos 
 				} else if (live) {
 #pragma unroll
 					for (int n = 0; n < NV; ++n) {
-						Sw[(S_RHS + n) * T + cu] = rhs[n];
+						streamStore(&Sw[(S_RHS + n) * T + cu], rhs[n]);
 					}
-					Sw[RHS_DIVV * T + cu] = div_v;
+					streamStore(&Sw[RHS_DIVV * T + cu], div_v);
 				}
 			}
 #pragma unroll
