@@ -344,6 +344,29 @@ struct RadSweep {
 	double dtdx[3];
 };
 
+// Non-temporal hints on the flux-divergence accumulator of the fused transport stage where they pay: the X sweep's stores and the Z sweep's loads
+// (same box: Z -3.5 %, X -1.5 %).  The Y sweep, which reads AND rewrites the accumulator, is 5 % slower with them and keeps plain accesses.
+// QK_RAD_NT=0: none.
+#ifndef QK_RAD_NT
+#define QK_RAD_NT 1
+#endif
+template <class P> QK_DEV void radStreamStore(P *p, double v)
+{
+#if QK_RAD_NT
+	__builtin_nontemporal_store(v, p);
+#else
+	*p = v;
+#endif
+}
+template <class P> QK_DEV auto radStreamLoad(P *p) -> double
+{
+#if QK_RAD_NT
+	return __builtin_nontemporal_load(p);
+#else
+	return *p;
+#endif
+}
+
 constexpr int RXCELLS = RXB - 7; // cells updated per workgroup of the X sweep: threads 3 .. RXB-4 (their right neighbour holds the other face)
 
 template <int ORDER, bool STORE> __global__ void __launch_bounds__(RXB) k_rad_sweep_x(const qk_box *boxes, Rad rad, RadSweep a)
@@ -437,7 +460,7 @@ template <int ORDER, bool STORE> __global__ void __launch_bounds__(RXB) k_rad_sw
 		const int64_t oa = A.idx(i, j, k);
 #pragma unroll
 		for (int n = 0; n < NRAD; ++n) {
-			A.p[oa + A.ns * n] = a.dtdx[0] * (Fo[n] - s_f[n][t + 1]);
+			radStreamStore(&A.p[oa + A.ns * n], a.dtdx[0] * (Fo[n] - s_f[n][t + 1]));
 		}
 	}
 }
@@ -516,7 +539,7 @@ __global__ void __launch_bounds__(256) k_rad_sweep_march(const qk_box *boxes, Ra
 			const int64_t oa = A.idx(pos[0], pos[1], pos[2]);
 #pragma unroll
 			for (int n = 0; n < NRAD; ++n) {
-				accv[n] = A.p[oa + A.ns * n];
+				accv[n] = (EPI == 0) ? A.p[oa + A.ns * n] : radStreamLoad(&A.p[oa + A.ns * n]);
 			}
 			if (EPI != 0) {
 				RA4 Uo(a.U0[b]);
