@@ -346,9 +346,9 @@ struct RadSweep {
 
 // Non-temporal hints on the flux-divergence accumulator of the fused transport stage where they pay: the X sweep's stores and the Z sweep's loads
 // (same box: Z -3.5 %, X -1.5 %).  The Y sweep, which reads AND rewrites the accumulator, is 5 % slower with them and keeps plain accesses.
-// QK_RAD_NT=0: none.
+// Level 2 (default) adds the Z sweep's stores of the new radiation state and its loads of the substep's starting state (Z another -2 %).  QK_RAD_NT=0: none.
 #ifndef QK_RAD_NT
-#define QK_RAD_NT 1
+#define QK_RAD_NT 2
 #endif
 template <class P> QK_DEV void radStreamStore(P *p, double v)
 {
@@ -361,6 +361,23 @@ template <class P> QK_DEV void radStreamStore(P *p, double v)
 template <class P> QK_DEV auto radStreamLoad(P *p) -> double
 {
 #if QK_RAD_NT
+	return __builtin_nontemporal_load(p);
+#else
+	return *p;
+#endif
+}
+
+template <class P> QK_DEV void radStreamStore2(P *p, double v)
+{
+#if QK_RAD_NT >= 2
+	__builtin_nontemporal_store(v, p);
+#else
+	*p = v;
+#endif
+}
+template <class P> QK_DEV auto radStreamLoad2(P *p) -> double
+{
+#if QK_RAD_NT >= 2
 	return __builtin_nontemporal_load(p);
 #else
 	return *p;
@@ -546,7 +563,7 @@ __global__ void __launch_bounds__(256) k_rad_sweep_march(const qk_box *boxes, Ra
 				const int64_t oo = Uo.idx(pos[0], pos[1], pos[2]);
 #pragma unroll
 				for (int n = 0; n < NRAD; ++n) {
-					u0v[n] = Uo.p[oo + Uo.ns * (RAD0 + n)];
+					u0v[n] = radStreamLoad2(&Uo.p[oo + Uo.ns * (RAD0 + n)]);
 				}
 			}
 		}
@@ -613,7 +630,7 @@ __global__ void __launch_bounds__(256) k_rad_sweep_march(const qk_box *boxes, Ra
 				const int64_t on = Un.idx(pos[0], pos[1], pos[2]);
 #pragma unroll
 				for (int n = 0; n < NRAD; ++n) {
-					Un.p[on + Un.ns * (RAD0 + n)] = cons[n];
+					radStreamStore2(&Un.p[on + Un.ns * (RAD0 + n)], cons[n]);
 				}
 			}
 		}
