@@ -212,6 +212,7 @@ class AmrLevelSim(HydroSimulation):
         advanceHydroAtLevelWithRetries (reference src/QuokkaSimulation.hpp:885-990); every attempt restarts at `time`"""
         self._signal_of_state_new = None
         self._old_ghosts_filled = False
+        self._new_ghosts_filled = False
         self.state_old_cc_, self.state_new_cc_ = self.state_new_cc_, self.state_old_cc_
         amr, l = self.amr, self.ilev
         fr_as_fine = self.fluxreg if (amr.do_reflux and l > 0) else None
@@ -317,6 +318,7 @@ class RadAmrLevelSim(AmrLevelSim, RadhydroSimulation):
                 return False
         else:  # :681-685: the hydro variables are carried over
             self._signal_of_state_new = None
+            self._old_ghosts_filled = self._new_ghosts_filled = False
             self.state_old_cc_, self.state_new_cc_ = self.state_new_cc_, self.state_old_cc_
             self.state_new_cc_.copy_comps_from(self.state_old_cc_, 0, RAD0)
         self._rad_time = time
@@ -376,12 +378,21 @@ class AmrSimulation:
     def CountCells(self, lev: int) -> int:
         return self.levels[lev].CountCells()  # all boxes of the level (every rank counts the global work, as the reference does)
 
+    def _ensure_new_ghosts(self, l: int):
+        """ghost cells of level l's new state at its new time — filled unless they are current: timeStepWithSubcycling fills level l for its children
+        just before the children's regrid runs, and regrid(0) tags two levels that both need level 0 (one whole-level fill per coarse step and a
+        half).  Every writer of state_new_cc_ clears the flag (advance_level, reflux / AverageDownTo / FixupState, the end of a regrid)."""
+        L = self.levels[l]
+        if not getattr(L, "_new_ghosts_filled", False):
+            L._fill_time = L.t_new
+            L.fillBoundaryConditions(L.state_new_cc_)
+            L._new_ghosts_filled = True
+
     # ------------------------------------------------------------------ hierarchy construction
     def _tags_on_level(self, lev: int) -> np.ndarray:
         from .amr import TagBoxArray
         for l in range(lev + 1):  # ghost cells of every level up to lev (a refined level interpolates from its parent's ghost-filled state)
-            self.levels[l]._fill_time = self.levels[l].t_new
-            self.levels[l].fillBoundaryConditions(self.levels[l].state_new_cc_)
+            self._ensure_new_ghosts(l)
         L = self.levels[lev]
         tags = TagBoxArray(L.lev)
         self.ErrorEst(self, lev, tags)
@@ -397,8 +408,7 @@ class AmrSimulation:
         import ctypes as C
         from .amr import TagBoxArray
         for l in range(lev + 1):
-            self.levels[l]._fill_time = self.levels[l].t_new
-            self.levels[l].fillBoundaryConditions(self.levels[l].state_new_cc_)
+            self._ensure_new_ghosts(l)
         L = self.levels[lev]
         tags = TagBoxArray(L.lev)
         self.ErrorEst(self, lev, tags)
@@ -539,6 +549,7 @@ class AmrSimulation:
         for b, (lo, hi) in enumerate(L.my_boxes):
             k, j, i = np.meshgrid(np.arange(lo[2], hi[2] + 1), np.arange(lo[1], hi[1] + 1), np.arange(lo[0], hi[0] + 1), indexing="ij")
             L.state_new_cc_.valid(b).copy_(torch.from_numpy(np.ascontiguousarray(fn(i, j, k))))
+        L._new_ghosts_filled = False
         L.state_old_cc_.copy_from(L.state_new_cc_)
         L.t_old = L.t_new = self.tNew_
 
@@ -586,11 +597,13 @@ class AmrSimulation:
                 self.levels[lev + 1].link_to_parent(new)
         for k in range(base, self.finest_level + 1):  # reference src/simulation.hpp:1257-1259
             self.levels[k].FixupState()
+            self.levels[k]._new_ghosts_filled = False
 
     # ------------------------------------------------------------------ inter-level operators
     def AverageDownTo(self, crse_lev: int):
         f = self.levels[crse_lev + 1]
         f.avgdown(f.state_new_cc_, self.levels[crse_lev].state_new_cc_, 0, f.ncomp_cc)
+        self.levels[crse_lev]._new_ghosts_filled = False
 
     # ------------------------------------------------------------------ time stepping
     def computeTimestep(self):
@@ -633,6 +646,8 @@ class AmrSimulation:
                     continue
                 L._fill_time = t
                 L.fillBoundaryConditions(st)
+                if st is L.state_new_cc_:
+                    L._new_ghosts_filled = True
             for i in range(2):
                 if lev < self.finest_level:
                     self.timeStepWithSubcycling(lev + 1, time + i * self.dt_[lev + 1])
@@ -641,6 +656,7 @@ class AmrSimulation:
                     L.reflux_from(self.levels[lev + 1])
                 self.AverageDownTo(lev)
                 L.FixupState()
+                L._new_ghosts_filled = False
 
     def step(self):
         self.computeTimestep()

@@ -285,9 +285,11 @@ template <typename problem_t, typename SimT> class AmrDriver
 	void dropSignalsIfHooked(bool hookIsDefault)
 	{
 		if (!hookIsDefault) {
+			base_.newStateGhostsFilled_ = false;
 			for (auto *f : finer_) {
 				if (f != nullptr) {
 					f->sim->dropCachedSignal();
+					f->sim->newStateGhostsFilled_ = false;
 				}
 			}
 		}
@@ -520,6 +522,9 @@ template <typename problem_t, typename SimT> class AmrDriver
 		Sim &S = level(lev);
 		S.fillTime_ = time;
 		S.fillBoundaryConditions(state);
+		if (&state == &S.state_new_cc_[0] && time == S.tNewLev_) {
+			S.newStateGhostsFilled_ = true; // until something writes the new state (every writer below clears the flag)
+		}
 	}
 
 	// ErrorEst -> buffered tags -> blocking-factor tiles -> boxes of level lev+1.  baseLev: the level whose regrid this is (AmrCore::regrid):
@@ -529,7 +534,11 @@ template <typename problem_t, typename SimT> class AmrDriver
 	{
 		int const base = (baseLev < 0) ? lev : baseLev;
 		for (int l = 0; l <= lev; ++l) {
-			fillGhosts(l, level(l).state_new_cc_[0], level(l).tNewLev_);
+			// (not again where the ghost cells are current: level 0 was filled for its children just before regrid(1) runs, and regrid(0) tags two
+			// levels that both need it — one whole-level fill per coarse step and a half, 2 % of the step)
+			if (!level(l).newStateGhostsFilled_) {
+				fillGhosts(l, level(l).state_new_cc_[0], level(l).tNewLev_);
+			}
 		}
 		Sim &S = level(lev);
 		amrex::TagBoxArray tags;
@@ -801,6 +810,7 @@ template <typename problem_t, typename SimT> class AmrDriver
 		}
 		for (int lev = baseLev; lev <= finestLevel(); ++lev) {
 			level(lev).FixupState(); // reference src/simulation.hpp:1257-1259
+			level(lev).newStateGhostsFilled_ = false;
 		}
 	}
 
@@ -887,6 +897,7 @@ template <typename problem_t, typename SimT> class AmrDriver
 				qkhost::check(qk_fluxreg_reset(finer_[lev]->fluxregRad, nullptr), "qk_fluxreg_reset(rad)");
 			}
 		}
+		S.newStateGhostsFilled_ = false; // (the advance swaps the states and writes the new one)
 		{
 			Phase const ph(*this, "advance level " + std::to_string(lev));
 			if (!S.advanceLevel(time, dt_[lev])) {
@@ -922,6 +933,7 @@ template <typename problem_t, typename SimT> class AmrDriver
 				}
 				averageDownTo(lev);
 				S.FixupState();
+				S.newStateGhostsFilled_ = false;
 			}
 		}
 	}

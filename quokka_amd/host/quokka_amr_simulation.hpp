@@ -684,6 +684,8 @@ template <typename problem_t> class AMRSimulation
 	// set by a level's advance when the ghost cells of state_old_cc_ hold the fill at the old time already (AmrDriver then skips its own fill of
 	// the old state before the children interpolate from it)
 	bool oldStateGhostsFilled_ = false;
+	// the ghost cells of state_new_cc_ hold the fill at the level's new time (set by AmrDriver::fillGhosts, cleared by whatever writes the state)
+	bool newStateGhostsFilled_ = false;
 
       protected:
 	qk_level *myLev_ = nullptr;
