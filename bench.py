@@ -142,7 +142,10 @@ def cpu_baseline(ncell: int, steps: int):
     for _ in range(steps):
         assert s.step()
     el = time.perf_counter() - t0
-    return {"value": ncell ** 3 * steps / el / 1e6, "unit": "Mcell-updates/s", "cores": threads, "kind": "port",
+    value = ncell ** 3 * steps / el / 1e6
+    m = re.search(r"cgroup quota ([\d.]+) CPUs", note)
+    cpus = min(float(threads), float(m.group(1))) if m else float(threads)  # the CPU time actually granted: the quota when it is below the thread count
+    return {"value": value, "unit": "Mcell-updates/s", "cores": threads, "kind": "port", "cpus_granted": cpus, "value_per_granted_cpu": value / cpus,
             "sample": f"Sedov {ncell}^3 in 32^3 boxes, {steps} RK2 steps in {el:.1f} s, OpenMP over (box, 4-plane slab) tasks, {threads} threads ({note}); "
                       "CPU restatement of the reference algorithm, not the reference binary"}
 
