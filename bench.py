@@ -271,13 +271,13 @@ def run_shell(ctx, torch, ncell, mgs, steps, warmup, pow_mode, carry=False):
 
 def run_amr(ctx, torch, dist, rank, world, ncell, steps, warmup, carry=True):
     """BASELINE config 5 geometry: tests/blast_amr_maxlev2.in (256^3 base grid, max_level 2, blocking_factor 32, subcycling + reflux).
-    Several GPUs: the SAME hierarchy (strong scaling).  Fine boxes live on the rank of their level-0 ancestor, so the level-0 boxes are made
-    smaller (64^3 instead of the deck's 128^3) and interleaved over the ranks: the refined shell around the blast then spreads over all of
-    them (amr_simulation.py, level0_distribution)."""
+    Several GPUs: the SAME hierarchy and the deck's own 128^3 boxes (strong scaling).  Every level has a box -> rank map of its own — a
+    space-filling curve over the level's boxes, a level with fewer boxes than ranks chopped until every rank owns one (AMReX's
+    refine_grid_layout; amr_simulation.py: chop_grids, distribute_sfc) — so the refined work is shared by all ranks wherever the blast sits."""
     from quokka_amd.amr_simulation import sedov_amr_problem
-    mgs = 128 if world == 1 else 64
+    mgs = min(128, ncell // 2)  # (the deck: 256^3 in 128^3 boxes; the dry run of the line scales it down)
     amr = sedov_amr_problem(ctx, ncell, 2, max_grid_size=mgs, blocking_factor=32, rank=rank, nranks=world)
-    if carry and world == 1:  # level 0 in the headline's form of the RK2 average, flux_rk2 formed on its coarse-fine faces only
+    if carry:  # level 0 in the headline's form of the RK2 average, flux_rk2 formed on its coarse-fine faces only
         amr.use_carried_form(True)
     E0, M0 = amr.composite_sum(4), amr.composite_sum(0)
     for _ in range(warmup):
@@ -306,7 +306,10 @@ def run_amr(ctx, torch, dist, rank, world, ncell, steps, warmup, carry=True):
                                    "(tests/blast_amr_maxlev2.in), subcycling + reflux",
                        "clustering": getattr(amr, "clustering", "tiles"),
                        "level0_rk2_mode": "carry + flux_rk2 on coarse-fine faces only" if getattr(amr, "rk2_carry_rhs", False) else "exact",
-                       "boxes_per_level_rank0": [L.lev.nboxes for L in amr.levels], "boxes_per_level": [len(L.all_boxes) for L in amr.levels],
+                       "boxes_per_level": [len(L.all_boxes) for L in amr.levels],
+                       "boxes_per_level_per_rank": [[sum(1 for o in L.owner if o == r) for L in amr.levels] for r in range(world)],
+                       "cells_per_level_per_rank": [[sum(int((hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1) * (hi[2] - lo[2] + 1)) for (lo, hi), o in zip(L.all_boxes, L.owner)
+                                                         if o == r) for L in amr.levels] for r in range(world)],
                        "cells_per_level": [amr.CountCells(l) for l in range(amr.finest_level + 1)], "sim_time": amr.tNew_,
                        "coarse_steps_total": steps + warmup,
                        "composite_energy_relative_change": abs(E1 - E0) / abs(E0), "composite_mass_relative_change": abs(M1 - M0) / abs(M0)}}

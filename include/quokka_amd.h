@@ -537,6 +537,37 @@ int qk_fluxreg_Reflux(qk_fluxreg *fr, qk_stream s, qk_array4 *crse_state);
  * the radiation fluxes at nstartHyperbolic_ of a full-width flux array): Reflux adds register component n to state component comp0 + n. */
 int qk_fluxreg_set_state_component(qk_fluxreg *fr, int comp0);
 
+/* The COARSE side of a register whose fine level is distributed independently of the coarse one (AMReX hands every level its own
+ * DistributionMapping, reference src/simulation.hpp:1421-1500; amrex::YAFluxRegister keeps m_crse_data on the coarse level's distribution and
+ * m_cfpatch on the fine level's): `fine` is a level object holding the fine boxes of ALL ranks (box metadata only), register cells that no LOCAL
+ * coarse box holds are skipped — their owner builds them.  Takes CrseAdd and Reflux (straight into the local coarse state).  The FINE side is an
+ * ordinary qk_fluxreg_create(crse = the coarsened local fine boxes ("shadow" level), fine = the local fine boxes, all_fine, reg_nghost = 1):
+ * FineAdd, then Reflux into a zeroed shadow array whose one-cell ghost ring travels to the coarse owners with qk_ParallelCopy_* (add = 1). */
+int qk_fluxreg_create_crse_part(qk_level *crse, qk_level *all_fine_level, const qk_geometry *crse_geom, const int ratio[3], int ncomp, qk_fluxreg **fr);
+
+/* amrex::FabArray::ParallelCopy / ParallelAdd between two box layouts with independent owners (qk_amr_pcopy.hip): every cell of the destination
+ * boxes grown by dst_nghost (minus dst_holes[b], if given: a box per destination box whose cells are NOT wanted) takes the value of the source
+ * cell with the same index — or its periodic image — found in a source box grown by src_nghost (src_ring_only != 0: in its ghost ring alone).
+ * add = 0: copy (the source pieces must not overlap: src_nghost = 0); add != 0: accumulate (atomic: pieces of several source boxes may meet in
+ * one cell).  The box lists and owners describe ALL ranks and are the same everywhere; the tables passed to the data calls hold this rank's boxes
+ * of each list, in list order.  Peer buffers hold `ncomp` values per cell (send_count / recv_count of qk_pcopy_plan_peer are values); the calls
+ * move components [scomp_src, scomp_src + ncomp) to [scomp_dst, ...).  Same wire protocol as the ghost plan: pack -> one send / recv pair per
+ * peer -> local -> unpack.  Reference: the FillPatchTwoLevels / average_down / YAFluxRegister::Reflux / RemakeLevel data motion of
+ * src/simulation.hpp:1789-1858, :1949-1964, :1308, :1672-1685 when levels have their own DistributionMapping (:1421-1500, :1657-1702). */
+typedef struct qk_pcopy_plan qk_pcopy_plan;
+int qk_pcopy_plan_create(qk_ctx *ctx, const qk_geometry *geom, int n_src, const qk_box *src_boxes, const int *src_owner, int src_nghost, int src_ring_only,
+			 int n_dst, const qk_box *dst_boxes, const int *dst_owner, int dst_nghost, const qk_box *dst_holes, int ncomp, int my_rank,
+			 qk_pcopy_plan **plan);
+int qk_pcopy_plan_destroy(qk_pcopy_plan *plan);
+int qk_pcopy_plan_num_peers(qk_pcopy_plan *plan);
+int qk_pcopy_plan_peer(qk_pcopy_plan *plan, int k, int *rank, int64_t *send_count, int64_t *recv_count);
+/* introspection: kind 0 same-rank items, 1 packed for peer k, 2 unpacked from peer k (regions in the destination index space) */
+int qk_pcopy_plan_num_items(qk_pcopy_plan *plan, int kind, int k);
+int qk_pcopy_plan_item(qk_pcopy_plan *plan, int kind, int k, int idx, int *dst_box, int *src_box, int lo[3], int hi[3], int shift[3], int64_t *offset);
+int qk_ParallelCopy_local(qk_pcopy_plan *plan, qk_stream s, const qk_array4 *src, qk_array4 *dst, int scomp_src, int scomp_dst, int add);
+int qk_ParallelCopy_pack(qk_pcopy_plan *plan, qk_stream s, int k, const qk_array4 *src, int scomp_src, double *sendbuf);
+int qk_ParallelCopy_unpack(qk_pcopy_plan *plan, qk_stream s, int k, qk_array4 *dst, int scomp_dst, const double *recvbuf, int add);
+
 /* copy the region [lo, hi] (same index space) between two arrays given by HOST copies of their descriptors (device data):
  * the old-level data a remade level keeps (RemakeLevel's FillPatch copies fine data where it exists, reference src/simulation.hpp:1672-1685) */
 int qk_copy_box(qk_ctx *ctx, qk_stream s, const qk_array4 *src, const qk_array4 *dst, const int lo[3], const int hi[3], int scomp, int dcomp, int ncomp);

@@ -8,8 +8,10 @@
 
 Host orchestration only: every cell is touched by a kernel behind include/quokka_amd.h (quokka_amd/amr.py wraps them).
 Grid generation: Berger-Rigoutsos clustering with amr.grid_eff on the device-buffered tags (qk_amr_cluster_berger_rigoutsos; "tiles" keeps the
-round-1 rule).  Several ranks: a fine box lives on the rank of its level-0 ancestor (AmrSimulation.__init__).  With rad_traits the levels are
-RadAmrLevelSim: hydro advance + radiation subcycle + a second flux register for the radiation block (one rank).
+round-1 rule).  Several ranks: every level has a box -> rank map of its own (space-filling curve over the level's boxes, a level chopped until every
+rank owns a box: distribute_sfc / chop_grids, as AMReX hands AMRSimulation a BoxArray + DistributionMapping per level, reference
+src/simulation.hpp:1421-1500, :1657-1702); coarse data reach the fine boxes, averaged and refluxed data the coarse boxes, through CoarseShadow.
+With rad_traits the levels are RadAmrLevelSim: hydro advance + radiation subcycle + a second flux register for the radiation block.
 """
 from __future__ import annotations
 
@@ -19,10 +21,10 @@ import numpy as np
 import torch
 
 from . import capi
-from .amr import AverageDown, FluxRegister, InterpFromCoarse
-from .multifab import Context, MultiFab
+from .amr import AverageDown, DistFluxRegister, FluxRegister, InterpFromCoarse, ParallelCopy
+from .multifab import Context, Level, MultiFab
 from .radhydro import RAD0, RadhydroSimulation
-from .simulation import NGHOST_CC, Geometry, HydroSimulation, chop_domain
+from .simulation import NGHOST_CC, Geometry, GhostExchange, HydroSimulation, chop_domain
 
 Box = Tuple[List[int], List[int]]
 
@@ -92,6 +94,157 @@ def covered_mask(boxes: Sequence[Box], shape) -> np.ndarray:
     return m
 
 
+# ------------------------------------------------------------------------------------------------ boxes -> ranks (host)
+def max_size(boxes: Sequence[Box], chunk: Sequence[int], blocking_factor: int) -> List[Box]:
+    """amrex::BoxArray::maxSize(chunk): every box longer than chunk[d] is cut into ceil(len / chunk) nearly equal pieces (in units of the blocking
+    factor, which divides every box edge), x fastest"""
+    out: List[Box] = []
+    for lo, hi in boxes:
+        cuts = []
+        for d in range(3):
+            n = hi[d] - lo[d] + 1
+            if n <= chunk[d]:
+                cuts.append([(lo[d], hi[d])])
+                continue
+            unit = blocking_factor if n % blocking_factor == 0 else 1
+            m, nb = n // unit, -(-n // chunk[d])
+            base, rem = divmod(m, nb)
+            pieces, a = [], lo[d]
+            for i in range(nb):
+                ln = (base + (1 if i < rem else 0)) * unit
+                pieces.append((a, a + ln - 1))
+                a += ln
+            cuts.append(pieces)
+        for kz in cuts[2]:
+            for ky in cuts[1]:
+                for kx in cuts[0]:
+                    out.append(([kx[0], ky[0], kz[0]], [kx[1], ky[1], kz[1]]))
+    return out
+
+
+def chop_grids(boxes: Sequence[Box], target: int, max_grid_size: int, blocking_factor: int, domain_len: Sequence[int], ndim: int = 3) -> List[Box]:
+    """amrex::AmrMesh::ChopGrids (refine_grid_layout = 1, AMReX's default, which the reference does not change): while a level has fewer boxes than
+    there are ranks, halve the chunk size — the longest direction first — as long as the halved size is a multiple of the blocking factor, and
+    re-apply maxSize.  Restated from AMReX's source as documented (AMReX is not vendored): unpinned, like the rest of grid generation."""
+    boxes = [(list(lo), list(hi)) for lo, hi in boxes]
+    chunk = [min(max_grid_size, domain_len[d]) if d < ndim else 1 for d in range(3)]
+    while len(boxes) < target:
+        prev = list(chunk)
+        for d in sorted(range(ndim), key=lambda a: (-chunk[a], -a)):  # largest chunk first (ties: the highest dimension, as the reversed stable sort)
+            new = chunk[d] // 2
+            if len(boxes) < target and new > 0 and new % blocking_factor == 0:
+                chunk[d] = new
+                boxes = max_size(boxes, chunk, blocking_factor)
+        if chunk == prev:
+            break
+    return boxes
+
+
+def _morton(i: int, j: int, k: int) -> int:
+    m = 0
+    for bit in range(20):
+        m |= ((i >> bit) & 1) << (3 * bit) | ((j >> bit) & 1) << (3 * bit + 1) | ((k >> bit) & 1) << (3 * bit + 2)
+    return m
+
+
+def distribute_sfc(boxes: Sequence[Box], nranks: int, rank_load: Optional[Sequence[int]] = None, unit: int = 1) -> List[int]:
+    """amrex::DistributionMapping::SFCProcessorMap as AMReX's default strategy does it: the boxes in Morton order of their low corner are cut
+    into nranks contiguous runs of about equal volume (a run that the last box pushed over the mean gives that box back), and the runs are dealt,
+    heaviest first, to the ranks in order of how little they already hold (`rank_load`: cells of the coarser levels) — a level with fewer boxes
+    than ranks lands on the least loaded ranks.  Restated (AMReX not vendored): unpinned; deterministic and identical on every rank."""
+    n = len(boxes)
+    if nranks == 1:
+        return [0] * n
+    vol = [int(np.prod([hi[d] - lo[d] + 1 for d in range(3)])) for lo, hi in boxes]
+    order = sorted(range(n), key=lambda b: (_morton(*[boxes[b][0][d] // unit for d in range(3)]), b))
+    per = sum(vol) / nranks
+    runs: List[List[int]] = []
+    K, total = 0, 0.0
+    for i in range(nranks):
+        run, v = [], 0.0
+        while K < n and (i == nranks - 1 or v < per):
+            v += vol[order[K]]
+            run.append(order[K])
+            K += 1
+        total += v
+        if total / (i + 1) > per and len(run) > 1 and i < nranks - 1:
+            K -= 1
+            total -= vol[run.pop()]
+        runs.append(run)
+    load = list(rank_load) if rank_load is not None else [0] * nranks
+    ranks = sorted(range(nranks), key=lambda r: (load[r], r))  # LeastUsedCPUs
+    heavy = sorted(range(nranks), key=lambda i: (-sum(vol[b] for b in runs[i]), i))
+    owner = [0] * n
+    for r, i in zip(ranks, heavy):
+        for b in runs[i]:
+            owner[b] = r
+    return owner
+
+
+def _coarsen(box: Box, r: int = 2) -> Box:
+    return [x // r for x in box[0]], [x // r for x in box[1]]
+
+
+class CoarseShadow:
+    """The coarse-level data a refined level needs and produces, on the FINE level's distribution — what AMReX builds inside
+    FillPatchTwoLevels (the coarse patch under the fine boxes' ghost cells, filled by ParallelCopy + the coarse physical boundary conditions,
+    then interpolated locally), average_down (the coarsened fine MultiFab, then ParallelCopy to the coarse level) and YAFluxRegister (m_cfpatch).
+    Boxes: the local fine boxes coarsened; 3 ghost cells (2 under the fine ghost cells + 1 of interpolation stencil).  Only several ranks use
+    it: with one rank the plans read and write the parent's arrays directly."""
+    NG = 3
+
+    def __init__(self, amr: "AmrSimulation", parent: "AmrLevelSim", child: "AmrLevelSim"):
+        ctx, rank = amr.ctx, amr.rank
+        self.parent, self.child, self.ncomp = parent, child, child.ncomp_cc
+        self.boxes = [_coarsen(b) for b in child.all_boxes]
+        self.owner = list(child.owner)
+        mine = [b for b, o in zip(self.boxes, self.owner) if o == rank]
+        self.lev = Level(ctx, parent.geom.ndim, mine)
+        self.old = MultiFab(self.lev, self.ncomp, self.NG, fill=0.0)
+        self.new = MultiFab(self.lev, self.ncomp, self.NG, fill=0.0)
+        self._key_old = self._key_new = None
+        # ghost-cell interpolation reads the three ghost layers and the outermost valid layer of a shadow box, the reflecting boundary conditions of
+        # the ghost layers the three outermost valid layers: the rest is a hole in the plan
+        holes = [([lo[d] + self.NG for d in range(3)], [hi[d] - self.NG for d in range(3)]) for lo, hi in self.boxes]
+        self.from_parent = ParallelCopy(ctx, parent.geom, parent.all_boxes, parent.owner, self.boxes, self.owner, self.ncomp, rank, dst_nghost=self.NG, dst_holes=holes)
+        self._from_parent_whole: Optional[ParallelCopy] = None
+        self.to_parent = ParallelCopy(ctx, parent.geom, self.boxes, self.owner, parent.all_boxes, parent.owner, self.ncomp, rank)
+        # physical boundary conditions of the coarse patch (the cbc of FillPatchTwoLevels): the level-0 kernel over the shadow's ghost slabs
+        self.bc = GhostExchange(self.lev, parent.geom, self.ncomp, self.NG, mine, [rank] * len(mine), rank, amr.bcs, amr.dirichlet) if mine else None
+        self.interp = InterpFromCoarse(self.lev, child.lev, child.geom, NGHOST_CC, all_fine_boxes=child.all_boxes)
+        self.avgdown = AverageDown(self.lev, child.lev)
+
+    def _fill(self, dst: MultiFab, src: MultiFab, plan: ParallelCopy):
+        plan(src, dst)
+        if self.bc is not None and not self.parent.geom.is_all_periodic():
+            c = self.lev.ctx
+            c.check(c.L.qk_FillPhysicalBoundary_subset(self.bc.h, c.stream(), dst.ptr, self.bc.bcs, self.bc.dirichlet, capi.BOXES_ALL), "FillPhysicalBoundary(shadow)")
+
+    def ensure(self, which: str):
+        """the parent's old / new state under this rank's fine boxes — fetched once per version of the parent's state"""
+        p = self.parent
+        src = p.state_old_cc_ if which == "old" else p.state_new_cc_
+        key = (id(src), p._state_gen)
+        if getattr(self, "_key_" + which) != key:
+            self._fill(self.old if which == "old" else self.new, src, self.from_parent)
+            setattr(self, "_key_" + which, key)
+        return self.old if which == "old" else self.new
+
+    def fill_whole_new(self) -> MultiFab:
+        """every cell of the grown shadow boxes from the parent's new state (a (re)made level interpolates all of its cells)"""
+        if self._from_parent_whole is None:
+            p, rank = self.parent, self.parent.amr.rank
+            self._from_parent_whole = ParallelCopy(self.lev.ctx, p.geom, p.all_boxes, p.owner, self.boxes, self.owner, self.ncomp, rank, dst_nghost=self.NG)
+        self._fill(self.new, self.parent.state_new_cc_, self._from_parent_whole)
+        self._key_new = None
+        return self.new
+
+    def average_down(self, fine_state: MultiFab, crse_state: MultiFab):
+        self.avgdown(fine_state, self.new, 0, self.ncomp)
+        self._key_new = None
+        self.to_parent(self.new, crse_state)
+
+
 # ------------------------------------------------------------------------------------------------ one level
 class AmrLevelSim(HydroSimulation):
     """HydroSimulation over the boxes of one AMR level: same advance (fused stages, FOFC, retries); the ghost fill of a refined level
@@ -104,8 +257,8 @@ class AmrLevelSim(HydroSimulation):
         self._init_simulation(geom, boxes, owner)
         self.min_overlap_cells = 1 << 62  # the early/late split of the uniform-grid exchange is not combined with the coarse-fine fill
         self.store_flux_rk2 = True
-        self.reflux_inc: Optional[MultiFab] = None  # several ranks: reflux increments of THIS level (valid + 1 ghost cell), folded by SumBoundary
-        self.reflux_ghost = None
+        self.shadow: Optional[CoarseShadow] = None  # several ranks: the parent's data under this level's boxes, on this level's distribution
+        self._state_gen = 0  # bumped by every writer of state_new_cc_ / state_old_cc_ (the _new_ghosts_filled setter): versions the shadows' copies
         self.t_old = self.t_new = 0.0
         self._fill_time = 0.0
         self.cf_interp: Optional[InterpFromCoarse] = None
@@ -118,17 +271,28 @@ class AmrLevelSim(HydroSimulation):
         amr = self.amr
         HydroSimulation.__init__(self, amr.ctx, geom, amr.traits, amr.bcs, None, amr.dirichlet, rank=amr.rank, nranks=amr.nranks, boxes=boxes, owner=owner)
 
+    @property
+    def _new_ghosts_filled(self) -> bool:
+        return self.__dict__.get("_ngf", False)
+
+    @_new_ghosts_filled.setter
+    def _new_ghosts_filled(self, v: bool):  # every writer of the level's states clears the flag: that is also what versions the children's shadows
+        self.__dict__["_ngf"] = bool(v)
+        if not v:
+            self._state_gen = self.__dict__.get("_state_gen", 0) + 1
+
     def link_to_parent(self, parent: "AmrLevelSim"):
-        multi = self.amr.nranks > 1
-        self.cf_interp = InterpFromCoarse(parent.lev, self.lev, self.geom, NGHOST_CC, all_fine_boxes=self.all_boxes if multi else None)
-        self.fluxreg = FluxRegister(parent.lev, self.lev, parent.geom, 6, all_fine_boxes=self.all_boxes if multi else None, reg_nghost=1 if multi else 0)
-        self.avgdown = AverageDown(parent.lev, self.lev)
+        amr = self.amr
+        if amr.nranks == 1:  # the parent's arrays are local: the plans read and write them directly
+            self.cf_interp = InterpFromCoarse(parent.lev, self.lev, self.geom, NGHOST_CC)
+            self.fluxreg = FluxRegister(parent.lev, self.lev, parent.geom, 6)
+            self.avgdown = AverageDown(parent.lev, self.lev)
+        else:
+            self.shadow = CoarseShadow(amr, parent, self)
+            self.cf_interp, self.avgdown = self.shadow.interp, None
+            self.fluxreg = DistFluxRegister(amr.ctx, parent.lev, parent.geom, parent.all_boxes, parent.owner, self.lev, self.all_boxes, self.owner,
+                                            self.shadow.lev, self.shadow.boxes, 6, amr.rank)
         parent._update_flux_mask(self.fluxreg)
-        if multi and parent.reflux_inc is None:
-            from .simulation import GhostExchange
-            parent.reflux_inc = MultiFab(parent.lev, 6, 1, fill=0.0)
-            per = [([capi.BC_INT_DIR] * 3, [capi.BC_INT_DIR] * 3)] * 6
-            parent.reflux_ghost = GhostExchange(parent.lev, parent.geom, 6, 1, parent.all_boxes, parent.owner, self.amr.rank, per)
 
     def _update_flux_mask(self, child_fluxreg: FluxRegister):
         """The carried form on a level with refined children (AmrSimulation.rk2_carry_rhs; level 0 only: the one level whose size makes the form of
@@ -161,17 +325,9 @@ class AmrLevelSim(HydroSimulation):
         self.rk2_carry_rhs = True
 
     def reflux_from(self, child: "AmrLevelSim"):
-        """flux_reg_[lev+1]->Reflux(state_new_cc_[lev]) (reference src/simulation.hpp:1308).  One rank: straight into the state.  Several
-        ranks: the increments land in a zeroed array with one ghost cell (a register cell may belong to a neighbouring rank's box),
-        SumBoundary carries them to their owners, then state += increments."""
-        if self.reflux_inc is None:
-            child.fluxreg.Reflux(self.state_new_cc_)
-            return
-        from .hydro_system import Saxpy
-        self.reflux_inc.storage.zero_()
-        child.fluxreg.Reflux(self.reflux_inc)
-        self.reflux_ghost.sum_boundary(self.reflux_inc)
-        Saxpy(self.lev, -1, self.state_new_cc_, 1.0, self.reflux_inc, 6)
+        """flux_reg_[lev+1]->Reflux(state_new_cc_[lev]) (reference src/simulation.hpp:1308).  Several ranks (DistFluxRegister): the coarse part
+        goes straight into the local state, the fine part travels from the fine boxes' ranks to the owners of the coarse cells (ParallelAdd)."""
+        child.fluxreg.Reflux(self.state_new_cc_)
 
     # --- ghost fill (FillPatchTwoLevels)
     def fillBoundaryConditions(self, state: MultiFab):
@@ -184,12 +340,17 @@ class AmrLevelSim(HydroSimulation):
         p = self.amr.levels[self.ilev - 1]
         t0, t1 = p.t_old, p.t_new
         eps = 1.0e-10 * max(abs(t1 - t0), 1.0e-300)
+        sh = self.shadow  # several ranks: the parent's states as this rank's copy under its fine boxes (same values: the same interpolated bits)
+        old = (lambda: sh.ensure("old")) if sh is not None else (lambda: p.state_old_cc_)
+        new = (lambda: sh.ensure("new")) if sh is not None else (lambda: p.state_new_cc_)
         if abs(time - t1) <= eps or t1 == t0:
-            plan(state, p.state_new_cc_, p.state_new_cc_, 1.0, 0.0, self.ncomp_cc, self.amr.amrInterpMethod_, True)
+            c = new()
+            plan(state, c, c, 1.0, 0.0, self.ncomp_cc, self.amr.amrInterpMethod_, True)
         elif abs(time - t0) <= eps:
-            plan(state, p.state_old_cc_, p.state_old_cc_, 1.0, 0.0, self.ncomp_cc, self.amr.amrInterpMethod_, True)
+            c = old()
+            plan(state, c, c, 1.0, 0.0, self.ncomp_cc, self.amr.amrInterpMethod_, True)
         else:  # amrex::FillPatch time interpolation: ((t1 - t) old + (t - t0) new) / (t1 - t0)
-            plan(state, p.state_old_cc_, p.state_new_cc_, (t1 - time) / (t1 - t0), (time - t0) / (t1 - t0), self.ncomp_cc, self.amr.amrInterpMethod_, True)
+            plan(state, old(), new(), (t1 - time) / (t1 - t0), (time - t0) / (t1 - t0), self.ncomp_cc, self.amr.amrInterpMethod_, True)
 
     def _before_fill(self, stage: int, dt: float):
         self._fill_time = self._t_adv + (dt if stage == 2 else 0.0)  # reference src/QuokkaSimulation.hpp:1076, :1204
@@ -272,27 +433,17 @@ class RadAmrLevelSim(AmrLevelSim, RadhydroSimulation):
 
     def link_to_parent(self, parent: "AmrLevelSim"):
         AmrLevelSim.link_to_parent(self, parent)
-        multi = self.amr.nranks > 1
-        self.fluxreg_rad = FluxRegister(parent.lev, self.lev, parent.geom, self.nrad, all_fine_boxes=self.all_boxes if multi else None,
-                                        reg_nghost=1 if multi else 0)
-        if not multi:
+        amr = self.amr
+        if amr.nranks == 1:
+            self.fluxreg_rad = FluxRegister(parent.lev, self.lev, parent.geom, self.nrad)
             self.fluxreg_rad.set_state_component(RAD0)
-        elif getattr(parent, "reflux_inc_rad", None) is None:  # several ranks: the increments of the radiation block, folded by SumBoundary
-            from .simulation import GhostExchange
-            parent.reflux_inc_rad = MultiFab(parent.lev, self.nrad, 1, fill=0.0)
-            per = [([capi.BC_INT_DIR] * 3, [capi.BC_INT_DIR] * 3)] * self.nrad
-            parent.reflux_ghost_rad = GhostExchange(parent.lev, parent.geom, self.nrad, 1, parent.all_boxes, parent.owner, self.amr.rank, per)
+        else:  # the register of the radiation block, distributed like the hydro one (register component n <-> state component RAD0 + n)
+            self.fluxreg_rad = DistFluxRegister(amr.ctx, parent.lev, parent.geom, parent.all_boxes, parent.owner, self.lev, self.all_boxes, self.owner,
+                                                self.shadow.lev, self.shadow.boxes, self.nrad, amr.rank, state_comp0=RAD0)
 
     def reflux_from(self, child: "AmrLevelSim"):
         AmrLevelSim.reflux_from(self, child)
-        if getattr(self, "reflux_inc_rad", None) is None:
-            child.fluxreg_rad.Reflux(self.state_new_cc_)
-            return
-        self.reflux_inc_rad.storage.zero_()
-        child.fluxreg_rad.Reflux(self.reflux_inc_rad)
-        self.reflux_ghost_rad.sum_boundary(self.reflux_inc_rad)
-        for b in range(self.lev.nboxes):
-            self.state_new_cc_.valid(b)[RAD0:RAD0 + self.nrad] += self.reflux_inc_rad.valid(b)
+        child.fluxreg_rad.Reflux(self.state_new_cc_)
 
     def _rad_registers(self, flux, dt_radiation: float):
         amr, l = self.amr, self.ilev
@@ -342,14 +493,15 @@ class AmrSimulation:
         self.rad_source: Optional[Callable] = None  # SetRadEnergySource of the problem, per level geometry
         self.radiationCflNumber_, self.maxSubsteps_, self.radiationReconstructionOrder_ = 0.3, 10, 3
         self.rank, self.nranks = rank, nranks
-        # Several ranks: a fine box lives on the rank of the level-0 box it sits in (so interpolation, average-down and regrid copies are
-        # local and only the reflux increments and the ordinary ghost exchange cross ranks); grids are therefore clustered inside each
-        # parent box.  One rank clusters globally unless asked to mimic that (tests compare the two).
-        self.cluster_within_parent = (nranks > 1) if cluster_within_parent is None else cluster_within_parent
-        # Load balance under that rule: no box migrates, so the level-0 map decides where refined work lands.  "interleaved" (rank =
-        # Morton index of the level-0 box mod nranks) puts every neighbourhood of level-0 boxes on all ranks; "bricks" keeps level 0
-        # compact (cheapest level-0 exchange) and leaves a localised refined region on one rank.
-        self.level0_distribution = "interleaved"
+        # Several ranks: every level has its own box -> rank map (distribute_sfc over the level's boxes, least loaded ranks first), and a level
+        # with fewer boxes than ranks is chopped until every rank owns one (chop_grids: AMReX's refine_grid_layout) — the grids are clustered
+        # globally, as with one rank.  `refine_grid_layout_target`: the box count to chop for (None: the number of ranks; tests give a one-rank
+        # run the target of the several-rank run it is compared with).  cluster_within_parent = True keeps round 3's rule for comparison runs
+        # (grids clustered inside each level-0 box).
+        self.cluster_within_parent = False if cluster_within_parent is None else cluster_within_parent
+        self.refine_grid_layout_target: Optional[int] = None
+        # level 0: "bricks" (compact, cheapest exchange) or "interleaved" (rank = Morton index of the box mod nranks)
+        self.level0_distribution = "bricks"
         self.max_level, self.max_grid_size, self.blocking_factor = max_level, max_grid_size, blocking_factor
         self.n_error_buf, self.regrid_int = n_error_buf, regrid_int
         # amr.grid_eff (reference tests/blast_amr_maxlev2.in: 0.7): Berger-Rigoutsos clustering as amrex::AmrMesh::MakeNewGrids does it.
@@ -489,27 +641,37 @@ class AmrSimulation:
                 boxes.append(([blo[d] + 2 * lo[d] for d in range(3)], [bhi[d] + 2 * lo[d] for d in range(3)]))
         return boxes
 
+    def _chop(self, lev: int, boxes: List[Box]) -> List[Box]:
+        """AmrMesh::ChopGrids: a level with fewer boxes than ranks is cut until every rank can own one (as far as the blocking factor allows)"""
+        target = self.nranks if self.refine_grid_layout_target is None else self.refine_grid_layout_target
+        if target <= 1 or len(boxes) >= target or not boxes:
+            return boxes
+        g0 = self.geom0
+        return chop_grids(boxes, target, self.max_grid_size, self.blocking_factor, [g0.n_cell[d] * 2 ** lev for d in range(3)], g0.ndim)
+
     def _owners_of(self, lev: int, boxes: List[Box]) -> List[int]:
-        """a box of level lev >= 1 lives on the rank of the level-0 box that contains it"""
+        """box -> rank map of a refined level: space-filling curve over the level's boxes, the least loaded ranks (cells of the coarser levels) first"""
         if self.nranks == 1:
             return [0] * len(boxes)
-        P = self.levels[0]
-        s = 2 ** lev
-        out = []
-        for lo, hi in boxes:
-            c = [lo[d] // s for d in range(3)]
-            owner = next((o for (plo, phi), o in zip(P.all_boxes, P.owner) if all(plo[d] <= c[d] <= phi[d] for d in range(3))), None)
-            assert owner is not None, "fine box without a level-0 ancestor"
-            out.append(owner)
-        return out
+        load = [0] * self.nranks
+        for L in self.levels[:lev]:
+            for (lo, hi), o in zip(L.all_boxes, L.owner):
+                load[o] += int(np.prod([hi[d] - lo[d] + 1 for d in range(3)]))
+        return distribute_sfc(boxes, self.nranks, load, unit=self.blocking_factor)
 
     def _make_level(self, lev: int, boxes: List[Box]) -> AmrLevelSim:
         if lev == 0:
             from .simulation import distribute_boxes, distribute_boxes_interleaved
             fn = distribute_boxes_interleaved if self.level0_distribution == "interleaved" else distribute_boxes
-            owner = fn(boxes, self.nranks, self.geom0.n_cell, [self.max_grid_size] * 3) if self.nranks > 1 else [0] * len(boxes)
+            lattice = int(np.prod([-(-self.geom0.n_cell[d] // self.max_grid_size) for d in range(self.geom0.ndim)]))
+            if self.nranks == 1:
+                owner = [0] * len(boxes)
+            elif len(boxes) == lattice:
+                owner = fn(boxes, self.nranks, self.geom0.n_cell, [self.max_grid_size] * 3)
+            else:  # level 0 was chopped below max_grid_size (fewer boxes than ranks): no box lattice to cut into bricks
+                owner = distribute_sfc(boxes, self.nranks, None, unit=self.blocking_factor)
         else:
-            owner = self._owners_of(lev, boxes)
+            owner = self._owners_of(lev, boxes)  # (`boxes` are chopped by the caller: _chop)
         L = (RadAmrLevelSim if self.rad_traits is not None else AmrLevelSim)(self, lev, boxes, owner)
         if self.rad_traits is not None and self.rad_source is not None:
             L.SetRadEnergySource = self.rad_source(L.geom)  # fn(geom of the level) -> fn(i, j, k, time)
@@ -521,10 +683,10 @@ class AmrSimulation:
         """AmrCore::InitFromScratch: level 0, then finer levels from the tags of the initial conditions (MakeNewLevelFromScratch uses
         the problem's initial conditions on every level, reference src/simulation.hpp:1656-1702), then AverageDown"""
         g0 = self.geom0
-        self.levels = [self._make_level(0, chop_domain(g0.n_cell, [self.max_grid_size] * 3))]
+        self.levels = [self._make_level(0, self._chop(0, chop_domain(g0.n_cell, [self.max_grid_size] * 3)))]
         self._set_level_ic(0)
         for lev in range(self.max_level):
-            boxes = self._new_grids(lev, None)
+            boxes = self._chop(lev + 1, self._new_grids(lev, None))
             if not boxes:
                 break
             self.levels.append(self._make_level(lev + 1, boxes))
@@ -567,6 +729,7 @@ class AmrSimulation:
             boxes = self._new_grids(lev, finer if lev + 2 <= self.max_level else None, base)
             new_boxes[lev + 1] = boxes
             finer = boxes if boxes else None
+        new_boxes = {lev: self._chop(lev, boxes) for lev, boxes in new_boxes.items()}
         for lev in range(base + 1, self.max_level + 1):
             boxes = new_boxes.get(lev, [])
             if not boxes:
@@ -577,12 +740,19 @@ class AmrSimulation:
                 continue
             new = self._make_level(lev, boxes)
             parent = self.levels[lev - 1]
-            parent._fill_time = parent.t_new
-            parent.fillBoundaryConditions(parent.state_new_cc_)
-            whole = InterpFromCoarse(parent.lev, new.lev, new.geom, NGHOST_CC, whole_fab=True)
-            whole(new.state_new_cc_, parent.state_new_cc_, parent.state_new_cc_, 1.0, 0.0, new.ncomp_cc, self.amrInterpMethod_, True)
-            if old is not None:
-                _copy_overlap(old.state_new_cc_, old.my_boxes, new.state_new_cc_, new.my_boxes)
+            if new.shadow is None:
+                parent._fill_time = parent.t_new
+                parent.fillBoundaryConditions(parent.state_new_cc_)
+                whole = InterpFromCoarse(parent.lev, new.lev, new.geom, NGHOST_CC, whole_fab=True)
+                whole(new.state_new_cc_, parent.state_new_cc_, parent.state_new_cc_, 1.0, 0.0, new.ncomp_cc, self.amrInterpMethod_, True)
+                if old is not None:
+                    _copy_overlap(old.state_new_cc_, old.my_boxes, new.state_new_cc_, new.my_boxes)
+            else:  # several ranks: the parent's cells under the new boxes arrive in the shadow; the old level's cells from their owners
+                c = new.shadow.fill_whole_new()
+                whole = InterpFromCoarse(new.shadow.lev, new.lev, new.geom, NGHOST_CC, whole_fab=True)
+                whole(new.state_new_cc_, c, c, 1.0, 0.0, new.ncomp_cc, self.amrInterpMethod_, True)
+                if old is not None:
+                    ParallelCopy(self.ctx, new.geom, old.all_boxes, old.owner, new.all_boxes, new.owner, new.ncomp_cc, self.rank)(old.state_new_cc_, new.state_new_cc_)
             new.state_old_cc_.copy_from(new.state_new_cc_)
             new.t_old, new.t_new = parent.t_new, parent.t_new
             new.dt_ = old.dt_ if old is not None else 1.0e100
@@ -602,7 +772,10 @@ class AmrSimulation:
     # ------------------------------------------------------------------ inter-level operators
     def AverageDownTo(self, crse_lev: int):
         f = self.levels[crse_lev + 1]
-        f.avgdown(f.state_new_cc_, self.levels[crse_lev].state_new_cc_, 0, f.ncomp_cc)
+        if f.shadow is None:
+            f.avgdown(f.state_new_cc_, self.levels[crse_lev].state_new_cc_, 0, f.ncomp_cc)
+        else:  # averaged on the fine boxes' ranks, then to the owners of the coarse cells
+            f.shadow.average_down(f.state_new_cc_, self.levels[crse_lev].state_new_cc_)
         self.levels[crse_lev]._new_ghosts_filled = False
 
     # ------------------------------------------------------------------ time stepping
@@ -640,8 +813,9 @@ class AmrSimulation:
         self.cellUpdates_ += self.CountCells(lev)
         self.cellUpdatesEachLevel_[lev] += self.CountCells(lev)
         if lev < self.finest_level:
-            # the children interpolate their ghost cells from this level's old and new states: both need their own ghost cells
-            for st, t in ((L.state_old_cc_, L.t_old), (L.state_new_cc_, L.t_new)):
+            # the children interpolate their ghost cells from this level's old and new states: both need their own ghost cells (one rank; with
+            # several the children's shadows take the valid cells and apply the boundary conditions themselves)
+            for st, t in ((L.state_old_cc_, L.t_old), (L.state_new_cc_, L.t_new)) if self.nranks == 1 else ():
                 if st is L.state_old_cc_ and getattr(L, "_old_ghosts_filled", False):
                     continue
                 L._fill_time = t
@@ -720,7 +894,7 @@ def _copy_overlap(src: MultiFab, src_boxes, dst: MultiFab, dst_boxes):
 
 
 def sedov_amr_problem(ctx: Context, n: int, max_level: int, max_grid_size: int = 128, blocking_factor: int = 32, static_fine_boxes=None, rank: int = 0,
-                      nranks: int = 1, cluster_within_parent=None, level0_distribution: str = "interleaved") -> AmrSimulation:
+                      nranks: int = 1, cluster_within_parent=None, level0_distribution: str = "bricks", refine_grid_layout_target=None) -> AmrSimulation:
     """reference src/problems/HydroBlast3D/test_hydro3d_blast.cpp + tests/blast_amr_maxlev2.in (BASELINE config 5)"""
     geom = Geometry(3, [n, n, n], [0.0, 0.0, 0.0], [1.2, 1.2, 1.2], [0, 0, 0])
     bcs = []
@@ -730,6 +904,7 @@ def sedov_amr_problem(ctx: Context, n: int, max_level: int, max_grid_size: int =
     amr = AmrSimulation(ctx, geom, capi.traits(1.4, False, 3), bcs, max_level, max_grid_size, blocking_factor, rank=rank, nranks=nranks,
                         cluster_within_parent=cluster_within_parent)
     amr.level0_distribution = level0_distribution
+    amr.refine_grid_layout_target = refine_grid_layout_target
     amr.static_fine_boxes = static_fine_boxes
     E_blast = 0.851072 / 8.0
 
@@ -755,7 +930,7 @@ def sedov_amr_problem(ctx: Context, n: int, max_level: int, max_grid_size: int =
 
 def rad_pulse_amr_problem(ctx: Context, n: int, max_level: int, max_grid_size: int = 32, blocking_factor: int = 8, static_fine_boxes=None,
                           hydro: bool = False, kappa: float = 4.0, rank: int = 0, nranks: int = 1, cluster_within_parent=None,
-                          tag_threshold: float = 1.5) -> AmrSimulation:
+                          tag_threshold: float = 1.5, refine_grid_layout_target=None) -> AmrSimulation:
     """A radiation pulse in a periodic box of gas at rest (units c = c_hat = a_rad = k_B = mu = 1, rho = 1, T = 1, kappa constant): a Gaussian excess
     of radiation energy at the centre spreads across the coarse-fine interfaces and heats the gas — the radiation operators, the exchange and the
     radiation flux registers on every level.  Not a reference problem: a property test (see tests/test_amr_radiation_gpu.py)."""
@@ -766,6 +941,7 @@ def rad_pulse_amr_problem(ctx: Context, n: int, max_level: int, max_grid_size: i
     amr = AmrSimulation(ctx, geom, traits, bcs, max_level, max_grid_size, blocking_factor, rad_traits=rt, rank=rank, nranks=nranks,
                         cluster_within_parent=cluster_within_parent)
     amr.is_hydro_enabled = hydro
+    amr.refine_grid_layout_target = refine_grid_layout_target
     amr.static_fine_boxes = static_fine_boxes
     amr.radiationCflNumber_ = 0.3
 

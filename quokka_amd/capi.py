@@ -230,6 +230,16 @@ def lib() -> C.CDLL:
         L.qk_amr_cluster_berger_rigoutsos.argtypes = [vp, vp, ci * 3, ci, ci, ci, C.c_double, P(Box), ci]
         L.qk_PreInterpState.argtypes = [vp, vp, vp]
         L.qk_PostInterpState.argtypes = [vp, vp, vp]
+        L.qk_fluxreg_create_crse_part.argtypes = [vp, vp, P(Geometry), ci * 3, ci, P(vp)]
+        L.qk_pcopy_plan_create.argtypes = [vp, P(Geometry), ci, P(Box), P(ci), ci, ci, ci, P(Box), P(ci), ci, vp, ci, ci, P(vp)]
+        L.qk_pcopy_plan_destroy.argtypes = [vp]
+        L.qk_pcopy_plan_num_peers.argtypes = [vp]
+        L.qk_pcopy_plan_peer.argtypes = [vp, ci, P(ci), P(C.c_int64), P(C.c_int64)]
+        L.qk_pcopy_plan_num_items.argtypes = [vp, ci, ci]
+        L.qk_pcopy_plan_item.argtypes = [vp, ci, ci, ci, P(ci), P(ci), ci * 3, ci * 3, ci * 3, P(C.c_int64)]
+        L.qk_ParallelCopy_local.argtypes = [vp, vp, vp, vp, ci, ci, ci]
+        L.qk_ParallelCopy_pack.argtypes = [vp, vp, ci, vp, ci, vp]
+        L.qk_ParallelCopy_unpack.argtypes = [vp, vp, ci, vp, ci, vp, ci]
     _lib = L
     return L
 
@@ -257,6 +267,8 @@ DECLARED_SYMBOLS = [
     "qk_fluxreg_create", "qk_fluxreg_destroy", "qk_fluxreg_num_items", "qk_fluxreg_item", "qk_fluxreg_reset", "qk_fluxreg_save", "qk_fluxreg_restore", "qk_fluxreg_CrseAdd", "qk_fluxreg_FineAdd",
     "qk_fluxreg_Reflux", "qk_fluxreg_set_state_component", "qk_amr_tile_flags", "qk_amr_tile_flags_periodic", "qk_amr_cluster_tiles", "qk_amr_cluster_berger_rigoutsos", "qk_copy_box",
     "qk_cloudy_tables_read", "qk_cloudy_tables_free", "qk_cooling_tabulated", "qk_cooling_evaluate",
+    "qk_fluxreg_create_crse_part", "qk_pcopy_plan_create", "qk_pcopy_plan_destroy", "qk_pcopy_plan_num_peers", "qk_pcopy_plan_peer", "qk_pcopy_plan_num_items",
+    "qk_pcopy_plan_item", "qk_ParallelCopy_local", "qk_ParallelCopy_pack", "qk_ParallelCopy_unpack",
 ]
 
 

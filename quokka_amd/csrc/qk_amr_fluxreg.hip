@@ -139,10 +139,9 @@ __global__ void __launch_bounds__(256) k_fluxreg(const FrItem *items, double *re
 
 } // namespace
 
-extern "C" {
-
-int qk_fluxreg_create(qk_level *crse, qk_level *fine, const qk_geometry *crse_geom, const int ratio[3], int ncomp, int n_all_fine, const qk_box *all_fine,
-		      int reg_nghost, qk_fluxreg **fr)
+// skip_missing: a register cell that no local coarse box holds belongs to another rank's coarse part (qk_fluxreg_create_crse_part)
+static int fluxregCreate(qk_level *crse, qk_level *fine, const qk_geometry *crse_geom, const int ratio[3], int ncomp, int n_all_fine, const qk_box *all_fine,
+			 int reg_nghost, bool skip_missing, qk_fluxreg **fr)
 {
 	if (crse == nullptr || fine == nullptr || fr == nullptr || ratio == nullptr || crse_geom == nullptr) {
 		return QK_ERR_INVALID;
@@ -289,7 +288,7 @@ int qk_fluxreg_create(qk_level *crse, qk_level *fine, const qk_geometry *crse_ge
 						rest.swap(next);
 					}
 				}
-				if (!rest.empty()) { // (single rank too: a register cell that no coarse box holds means the fine level is not properly nested —
+				if (!rest.empty() && !skip_missing) { // (single rank too: a register cell that no coarse box holds means the fine level is not properly nested —
 						     // dropping it silently cost the advection hierarchy its conservation at the periodic faces)
 					delete P;
 					return setError(ctx, QK_ERR_INVALID, "fluxreg_create: a register cell is neither in a local coarse box nor in its ghost region");
@@ -311,6 +310,19 @@ int qk_fluxreg_create(qk_level *crse, qk_level *fine, const qk_geometry *crse_ge
 	}
 	*fr = P;
 	return QK_OK;
+}
+
+extern "C" {
+
+int qk_fluxreg_create(qk_level *crse, qk_level *fine, const qk_geometry *crse_geom, const int ratio[3], int ncomp, int n_all_fine, const qk_box *all_fine,
+		      int reg_nghost, qk_fluxreg **fr)
+{
+	return fluxregCreate(crse, fine, crse_geom, ratio, ncomp, n_all_fine, all_fine, reg_nghost, false, fr);
+}
+
+int qk_fluxreg_create_crse_part(qk_level *crse, qk_level *all_fine_level, const qk_geometry *crse_geom, const int ratio[3], int ncomp, qk_fluxreg **fr)
+{
+	return fluxregCreate(crse, all_fine_level, crse_geom, ratio, ncomp, 0, nullptr, 0, true, fr);
 }
 
 int qk_fluxreg_destroy(qk_fluxreg *fr)

@@ -118,7 +118,7 @@ def test_ranks_sharing_one_gpu_reproduce_the_single_process_run(ctx, world, over
     assert np.array_equal(got, want), f"max abs diff {np.abs(got - want).max()}"
 
 
-def amr_worker(rank, world, port, N, nsteps, q, distribution="interleaved"):
+def amr_worker(rank, world, port, N, nsteps, q, distribution="bricks", mgs=16):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -126,7 +126,7 @@ def amr_worker(rank, world, port, N, nsteps, q, distribution="interleaved"):
         from quokka_amd.amr_simulation import sedov_amr_problem
         from quokka_amd.multifab import Context
         ctx = Context(0)
-        amr = sedov_amr_problem(ctx, N, 2, max_grid_size=16, blocking_factor=8, rank=rank, nranks=world, level0_distribution=distribution)
+        amr = sedov_amr_problem(ctx, N, 2, max_grid_size=mgs, blocking_factor=8, rank=rank, nranks=world, level0_distribution=distribution)
         m0, e0 = amr.composite_sum(0), amr.composite_sum(4)
         for _ in range(nsteps):
             amr.step()
@@ -139,21 +139,24 @@ def amr_worker(rank, world, port, N, nsteps, q, distribution="interleaved"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,distribution", [(2, "interleaved"), (4, "interleaved"), (4, "bricks")])
-def test_amr_hierarchy_across_ranks_matches_one_rank(ctx, world, distribution):
-    """Sedov, max_level = 2, 32^3 base grid in 16^3 boxes (8 level-0 boxes over 2 / 4 ranks): fine boxes live on the rank of their level-0
-    ancestor, reflux increments cross ranks through SumBoundary.  Same grids and time steps as the single-rank run with the same
-    per-parent clustering; states agree to rounding (the reflux additions are reassociated), mass and energy are conserved."""
+@pytest.mark.parametrize("world,distribution,N,mgs", [(2, "interleaved", 32, 16), (4, "interleaved", 32, 16), (4, "bricks", 32, 16), (8, "bricks", 64, 32)])
+def test_amr_hierarchy_across_ranks_matches_one_rank(ctx, world, distribution, N, mgs):
+    """Sedov, max_level = 2.  32^3 base grid in 16^3 boxes over 2 / 4 ranks, and the geometry of tests/blast_amr_maxlev2.in (BASELINE config 5: 256^3
+    in 128^3 boxes, blocking factor 32, 8 ranks) scaled by four: 64^3 in 32^3 boxes, blocking factor 8, 8 ranks sharing the GPU.  Every level has a
+    box -> rank map of its own (space-filling curve; a level with fewer boxes than ranks is chopped, AMReX's refine_grid_layout): the parent's
+    data reach the fine boxes, averaged-down and refluxed data the coarse boxes, through pack -> point-to-point -> unpack plans (CoarseShadow,
+    DistFluxRegister).  Same grids and time steps as ONE rank chopping for the same box count; states agree to rounding (the two parts of a
+    flux register are added to the state one after the other), mass and energy are conserved; with 8 ranks every rank owns a box of every level."""
     from quokka_amd.amr_simulation import sedov_amr_problem
-    N, nsteps = 32, 6
-    ref = sedov_amr_problem(ctx, N, 2, max_grid_size=16, blocking_factor=8, cluster_within_parent=True)
+    nsteps = 6
+    ref = sedov_amr_problem(ctx, N, 2, max_grid_size=mgs, blocking_factor=8, refine_grid_layout_target=world)
     for _ in range(nsteps):
         ref.step()
     assert ref.finest_level == 2
     mpctx = mp.get_context("spawn")
     q = mpctx.Queue()
     port = free_port()
-    procs = [mpctx.Process(target=run_amr_worker, args=(r, world, port, N, nsteps, q, distribution)) for r in range(world)]
+    procs = [mpctx.Process(target=run_amr_worker, args=(r, world, port, N, nsteps, q, distribution, mgs)) for r in range(world)]
     for p in procs:
         p.start()
     results = collect(procs, q, world)
@@ -175,14 +178,18 @@ def test_amr_hierarchy_across_ranks_matches_one_rank(ctx, world, distribution):
             assert sorted(map(str, all_boxes)) == sorted(map(str, [(list(lo), list(hi)) for lo, hi in L.all_boxes])), f"level {l}: grids differ on rank {rank}"
             assert [b for b, o in zip(all_boxes, owner) if o == rank] == mine
             owners_seen.update(owner)
+            if world == 8:
+                assert mine, f"rank {rank} owns no box of level {l} ({len(all_boxes)} boxes)"
             for (lo, hi), v in zip(mine, vals):
                 got[:, lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1] = v
         assert np.array_equal(np.isnan(got), np.isnan(want)), f"level {l}: coverage differs"
         m = ~np.isnan(want)
         scale = np.abs(want[m]).max()
         worst = max(worst, float(np.abs(got[m] - want[m]).max() / scale))
-        if l == 0:
+        if l == 0 or world == 8:
             assert len(owners_seen) == world
+        elif l > 0:
+            assert len(owners_seen) > 1, f"level {l} lives on one rank"
     assert worst <= 1e-13, worst
 
 
@@ -213,12 +220,12 @@ def run_rad_amr_worker(rank, *args):
 
 @pytest.mark.parametrize("world", [2, 4])
 def test_radiation_amr_hierarchy_across_ranks_matches_one_rank(ctx, world):
-    """The radiation pulse on a dynamically refined hierarchy (32^3 base grid in 16^3 boxes over 2 / 4 ranks): the reflux increments of the
-    radiation block cross ranks through their own SumBoundary.  Same grids and time steps as one rank with per-parent clustering, states to
-    rounding, E_int + E_rad of the composite grid at the Newton tolerance."""
+    """The radiation pulse on a dynamically refined hierarchy (32^3 base grid in 16^3 boxes over 2 / 4 ranks), the refined level with a box -> rank
+    map of its own: the fine part of the radiation block's flux register travels to the coarse owners like the hydro block's.  Same grids and
+    time steps as one rank, states to rounding, E_int + E_rad of the composite grid at the Newton tolerance."""
     from quokka_amd.amr_simulation import rad_pulse_amr_problem
     N, nsteps = 32, 8
-    ref = rad_pulse_amr_problem(ctx, N, 1, max_grid_size=16, blocking_factor=8, cluster_within_parent=True, tag_threshold=1.02)
+    ref = rad_pulse_amr_problem(ctx, N, 1, max_grid_size=16, blocking_factor=8, tag_threshold=1.02, refine_grid_layout_target=world)
     for _ in range(nsteps):
         ref.step()
     assert ref.finest_level == 1
