@@ -137,3 +137,43 @@ def test_berger_rigoutsos_respects_the_nesting_domain():
     for lo, hi in boxes:
         cover[lo[2] // 8:hi[2] // 8 + 1, lo[1] // 8:hi[1] // 8 + 1, lo[0] // 8:hi[0] // 8 + 1] = True
     assert not cover[0, 1, 1]
+
+
+# ------------------------------------------------------------------------------------------------ boxes -> ranks (levels with their own distribution)
+def test_chop_grids_gives_every_rank_a_box_of_the_config5_levels():
+    """AmrMesh::ChopGrids as restated in amr_simulation.chop_grids: the one 64^3 box that levels 1 and 2 of tests/blast_amr_maxlev2.in are for
+    the first ~55 coarse steps (max_grid_size 128, blocking_factor 32) becomes 8 boxes of 32^3 on 8 ranks, 2 / 4 boxes on 2 / 4 ranks; boxes stay
+    disjoint, blocking-factor aligned and cover the same cells; a level that already has enough boxes, or one rank, is left alone."""
+    from quokka_amd.amr_simulation import chop_grids
+    one = [([0, 0, 0], [63, 63, 63])]
+    for target, want in ((1, 1), (2, 2), (4, 4), (8, 8), (16, 8)):  # (32^3 cannot be halved again with blocking_factor 32)
+        got = chop_grids(one, target, 128, 32, [512] * 3)
+        assert len(got) == want, (target, got)
+        cover = np.zeros((64, 64, 64), dtype=np.int32)
+        for lo, hi in got:
+            assert all(lo[d] % 32 == 0 and (hi[d] + 1) % 32 == 0 for d in range(3))
+            cover[lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1] += 1
+        assert (cover == 1).all()
+    many = [([32 * i, 0, 0], [32 * i + 31, 31, 31]) for i in range(8)]
+    assert chop_grids(many, 8, 128, 32, [512] * 3) == many
+    # an L of two boxes, 4 ranks: both boxes are cut, the longest direction first
+    got = chop_grids([([0, 0, 0], [63, 31, 31]), ([0, 32, 0], [31, 63, 31])], 4, 64, 16, [128] * 3)
+    assert len(got) >= 4 and sum(np.prod([hi[d] - lo[d] + 1 for d in range(3)]) for lo, hi in got) == 64 * 32 * 32 + 32 * 32 * 32
+
+
+def test_sfc_distribution_balances_cells_and_fills_the_least_loaded_ranks():
+    from quokka_amd.amr_simulation import chop_grids, distribute_sfc
+    boxes = chop_grids([([0, 0, 0], [63, 63, 63])], 8, 128, 32, [512] * 3)
+    own = distribute_sfc(boxes, 8, [128 ** 3] * 8, unit=32)
+    assert sorted(own) == list(range(8))  # one box per rank
+    # fewer boxes than ranks: they go to the ranks that hold the least so far
+    own = distribute_sfc(boxes[:3], 8, [5, 9, 1, 9, 9, 0, 9, 9], unit=32)
+    assert sorted(own) == [0, 2, 5]
+    # many equal boxes: contiguous runs along the curve, equal counts
+    grid = [([16 * i, 16 * j, 16 * k], [16 * i + 15, 16 * j + 15, 16 * k + 15]) for k in range(4) for j in range(4) for i in range(4)]
+    own = distribute_sfc(grid, 8, None, unit=16)
+    assert [own.count(r) for r in range(8)] == [8] * 8
+    for r in range(8):  # a run of the Morton curve through a 4^3 lattice of boxes = one 2x2x2 block
+        mine = [grid[b][0] for b in range(64) if own[b] == r]
+        assert all(max(m[d] for m in mine) - min(m[d] for m in mine) == 16 for d in range(3))
+    assert distribute_sfc(grid, 1) == [0] * 64

@@ -199,3 +199,121 @@ def test_bench_geometry_plans_are_consistent(world):
             sent = [(tuple(lo), tuple(hi), tuple(sh), off) for db, sb, lo, hi, sh, off in ex.items(1, k)]
             recv = [(tuple(lo), tuple(hi), tuple(sh), off) for db, sb, lo, hi, sh, off in pex.items(2, kk[0])]
             assert sent == recv, f"wire order differs between ranks {r} -> {peer}"
+
+
+# ------------------------------------------------------------------------------------------------ ParallelCopy between two distributions
+def pcopy_worker(rank, world, port, periodic, q):
+    """A refined level distributed independently of its parent (quokka_amd/amr_simulation.py: CoarseShadow): the parent's valid cells reach
+    the grown coarsened fine boxes (copy, periodic images included), and the one-cell ghost ring of the coarsened fine boxes is ADDED to the
+    parent's valid cells (the fine part of a flux register on its way to the coarse owners).  numpy moves the bytes of the plan's items."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from quokka_amd.amr import ParallelCopy
+        from quokka_amd.amr_simulation import chop_grids, distribute_sfc
+        from quokka_amd.multifab import PlanningContext
+        from quokka_amd.simulation import Geometry, chop_domain, distribute_boxes
+
+        N, nc, ng = 32, 2, 3
+        geom = Geometry(3, [N] * 3, [0.0] * 3, [1.0] * 3, list(periodic))
+        pboxes = chop_domain(geom.n_cell, [16] * 3)
+        powner = distribute_boxes(pboxes, world, geom.n_cell, [16] * 3)
+        # shadow boxes (already coarsened): a block at the low corner and one that touches the high faces, chopped so that every rank owns some
+        sboxes = chop_grids([([0, 0, 0], [15, 15, 7]), ([16, 24, 24], [31, 31, 31])], 2 * world, 16, 4, [N] * 3)
+        sowner = distribute_sfc(sboxes, world, [powner.count(r) * 16 ** 3 for r in range(world)], unit=4)
+        assert sorted(set(sowner)) == list(range(world))
+        ctx = PlanningContext()
+
+        def field(i, j, k, n):  # a function of the wrapped global index: what every copy of a cell must hold
+            return ((i % N) + 100.0 * (j % N) + 10000.0 * (k % N)) * (n + 1)
+
+        def make(boxes, owner, g, fill):
+            out = []
+            for (lo, hi), o in zip(boxes, owner):
+                if o != rank:
+                    continue
+                beg = [lo[d] - g for d in range(3)]
+                shp = [hi[d] - lo[d] + 1 + 2 * g for d in range(3)]
+                k, j, i = np.meshgrid(*[np.arange(beg[d], beg[d] + shp[d]) for d in (2, 1, 0)], indexing="ij")
+                a = np.stack([field(i, j, k, n) for n in range(nc)]) if fill else np.full((nc, shp[2], shp[1], shp[0]), np.nan)
+                out.append((a, beg, (lo, hi)))
+            return out
+
+        def run(plan, src, dst, add):
+            def pack(k, sbuf):
+                buf = sbuf.numpy()
+                for db, sb, lo, hi, sh, off in plan.items(1, k):
+                    r = region(src[sb][0], src[sb][1], lo, hi, sh)
+                    buf[off:off + r.size] = r.reshape(-1)
+
+            def local():
+                for db, sb, lo, hi, sh, off in plan.items(0):
+                    r = region(dst[db][0], dst[db][1], lo, hi)
+                    v = region(src[sb][0], src[sb][1], lo, hi, sh)
+                    r[...] = r + v if add else v
+
+            def unpack(k, rbuf):
+                buf = rbuf.numpy()
+                for db, sb, lo, hi, sh, off in plan.items(2, k):
+                    r = region(dst[db][0], dst[db][1], lo, hi)
+                    v = buf[off:off + r.size].reshape(r.shape)
+                    r[...] = r + v if add else v
+            plan.run(pack, local, unpack)
+
+        # (1) parent valid -> shadow grown by 3
+        parent = make(pboxes, powner, 0, True)
+        shadow = make(sboxes, sowner, ng, False)
+        fill = ParallelCopy(ctx, geom, pboxes, powner, sboxes, sowner, nc, rank, dst_nghost=ng)
+        run(fill, parent, shadow, False)
+        bad = 0
+        for a, beg, (lo, hi) in shadow:
+            k, j, i = np.meshgrid(*[np.arange(beg[d], beg[d] + a.shape[3 - d]) for d in (2, 1, 0)], indexing="ij")
+            inside = np.ones(i.shape, dtype=bool)
+            for d, x in enumerate((i, j, k)):
+                if not periodic[d]:
+                    inside &= (x >= 0) & (x < N)
+            want = np.stack([field(i, j, k, n) for n in range(nc)])
+            bad += int((a[:, inside] != want[:, inside]).sum()) + int((~np.isnan(a[:, ~inside])).sum())
+        # (2) ring of the shadow boxes, added to the parent's valid cells: every parent cell ends up with (number of shadow boxes whose ring
+        # holds the cell or a periodic image of it) x its own field value
+        ring = make(sboxes, sowner, 1, True)
+        for a, beg, (lo, hi) in ring:
+            a[:, 1:-1, 1:-1, 1:-1] = 1.0e300  # valid cells of a shadow box must never travel
+        acc = [(np.zeros_like(a), beg, b) for a, beg, b in make(pboxes, powner, 0, True)]
+        add = ParallelCopy(ctx, geom, sboxes, sowner, pboxes, powner, nc, rank, src_nghost=1, src_ring_only=True)
+        run(add, ring, acc, True)
+        count = np.zeros((N + 2, N + 2, N + 2))
+        for lo, hi in sboxes:
+            g = np.zeros_like(count)
+            g[lo[2]:hi[2] + 3, lo[1]:hi[1] + 3, lo[0]:hi[0] + 3] = 1.0
+            g[lo[2] + 1:hi[2] + 2, lo[1] + 1:hi[1] + 2, lo[0] + 1:hi[0] + 2] = 0.0
+            count += g
+        c = count[1:-1, 1:-1, 1:-1].copy()  # index [k, j, i]; the rim of `count` is one cell beyond the domain: through a periodic face it wraps
+        # (rims of corners through several periodic faces do not occur for these boxes with periodic = x only)
+        if periodic[0]:
+            c[:, :, N - 1] += count[1:-1, 1:-1, 0]
+            c[:, :, 0] += count[1:-1, 1:-1, N + 1]
+        for a, beg, (lo, hi) in acc:
+            k, j, i = np.meshgrid(*[np.arange(lo[d], hi[d] + 1) for d in (2, 1, 0)], indexing="ij")
+            want = np.stack([field(i, j, k, n) * c[k, j, i] for n in range(nc)])
+            bad += int((a != want).sum())
+        q.put((rank, bad, len(fill.peers), len(add.peers)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,periodic", [(2, [0, 0, 0]), (4, [1, 0, 0])])
+def test_parallel_copy_and_add_between_independent_distributions(world, periodic):
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    port = free_port()
+    procs = [mpctx.Process(target=pcopy_worker, args=(r, world, port, periodic, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, bad, npeers_fill, npeers_add in sorted(results):
+        assert bad == 0, f"rank {rank}: {bad} values differ"
+    assert sum(r[2] for r in results) > 0 and sum(r[3] for r in results) > 0, "nothing crossed ranks"
