@@ -279,7 +279,14 @@ def run_amr(ctx, torch, dist, rank, world, ncell, steps, warmup, carry=True):
     amr = sedov_amr_problem(ctx, ncell, 2, max_grid_size=mgs, blocking_factor=32, rank=rank, nranks=world)
     if carry:  # level 0 in the headline's form of the RK2 average, flux_rk2 formed on its coarse-fine faces only
         amr.use_carried_form(True)
+    amr.overlap_children = os.environ.get("QK_AMR_OVERLAP", "1") == "1"  # (one rank: the children beside the far boxes of level 0)
     E0, M0 = amr.composite_sum(4), amr.composite_sum(0)
+    hp = os.environ.get("QK_AMR_MAIN_PRIORITY", "")
+    if hp:  # (experiment: the whole evolve on a stream of the given priority instead of the default stream)
+        least, greatest = torch.cuda.Stream.priority_range()
+        st = torch.cuda.Stream(device=ctx.device, priority={"low": least, "high": greatest}[hp])
+        st.wait_stream(torch.cuda.current_stream(ctx.device))
+        torch.cuda.set_stream(st)
     for _ in range(warmup):
         amr.step()
 
@@ -311,7 +318,7 @@ def run_amr(ctx, torch, dist, rank, world, ncell, steps, warmup, carry=True):
                        "cells_per_level_per_rank": [[sum(int((hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1) * (hi[2] - lo[2] + 1)) for (lo, hi), o in zip(L.all_boxes, L.owner)
                                                          if o == r) for L in amr.levels] for r in range(world)],
                        "cells_per_level": [amr.CountCells(l) for l in range(amr.finest_level + 1)], "sim_time": amr.tNew_,
-                       "coarse_steps_total": steps + warmup,
+                       "coarse_steps_total": steps + warmup, "children_beside_far_boxes": dict(amr.overlap_stats),
                        "composite_energy_relative_change": abs(E1 - E0) / abs(E0), "composite_mass_relative_change": abs(M1 - M0) / abs(M0)}}
 
 

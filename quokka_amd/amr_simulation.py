@@ -414,6 +414,70 @@ class AmrLevelSim(HydroSimulation):
     def FixupState(self):
         self._fixup_state(self.state_new_cc_)
 
+    # --- the children beside the far boxes (AmrSimulation.overlap_children)
+    def advance_level_begin(self, time: float, dt_lev: float, near: List[int], far: List[int]):
+        """advance_level with the verdict deferred: ghost fill + stage 1 of all boxes, ghost fill + stage 2 of the `near` boxes (the ones the
+        children read) on the compute stream, stage 2 of the `far` boxes on a second stream with a scratch array of its own; the physical
+        boundaries of the near boxes' new state and the coarse side of the child's flux register follow on the compute stream, so that the
+        children can be enqueued at once.  Nothing is read back: advance_level_join() gives the verdict."""
+        self._signal_of_state_new = None
+        self._old_ghosts_filled = False
+        self._new_ghosts_filled = False
+        self.state_old_cc_, self.state_new_cc_ = self.state_new_cc_, self.state_old_cc_
+        amr = self.amr
+        self._t_adv = time
+        old, inter, new = self.state_old_cc_, self.state_inter_cc_, self.state_new_cc_
+        self._err_latched, self._unfused_ran = False, False
+        if getattr(self, "_far_groups_key", None) != (tuple(near), tuple(far)):
+            mk = lambda idx: (Level(self.ctx, self.geom.ndim, [self.my_boxes[b] for b in idx]), list(idx))
+            self._near_group, self._far_group = mk(near), mk(far)
+            nbytes = self.ctx.L.qk_hydro_stage_scratch_bytes(self._far_group[0].h, __import__("ctypes").byref(self.traits))
+            self._far_scratch = torch.empty(max(nbytes // 8, 1), dtype=torch.float64, device=self.ctx.device)
+            # the far boxes fill whatever the children's small kernels leave idle: the LOWEST priority the device offers (the compute stream
+            # keeps its own), so that a child kernel is dispatched as soon as it is ready
+            import os as _os
+            least, greatest = torch.cuda.Stream.priority_range()
+            prio = {"low": least, "high": greatest}.get(_os.environ.get("QK_AMR_FAR_PRIORITY", "low"), 0)
+            self._far_stream = torch.cuda.Stream(device=self.ctx.device, priority=prio)
+            for b in range(self.lev.nboxes):  # the physical-boundary slabs of the near boxes first ("local only" subset of the ghost plan)
+                self.ghost.set_box_remote(b, b in set(far))
+            self._far_groups_key = (tuple(near), tuple(far))
+        self._fused_begin(1, both=True)
+        self._before_fill(1, dt_lev)
+        self.fillBoundaryConditions(old)
+        self._fused_launch(1, old, old, inter, dt_lev, slot=0)
+        self._before_fill(2, dt_lev)
+        self.fillBoundaryConditions(inter)
+        main = torch.cuda.current_stream(self.ctx.device)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self._fused_launch(2, inter, old, new, dt_lev, group=self._near_group, slot=1)
+        with torch.cuda.stream(self._far_stream):
+            self._far_stream.wait_event(ev)
+            self._fused_launch(2, inter, old, new, dt_lev, group=self._far_group, slot=1, scratch=self._far_scratch)
+            self._far_done = torch.cuda.Event()
+            self._far_done.record(self._far_stream)
+        # what the children read of the new state beyond the near boxes' valid cells lies beyond the domain (AmrSimulation._overlap_split)
+        c = self.ctx
+        c.check(c.L.qk_FillPhysicalBoundary_subset(self.ghost.h, c.stream(), new.ptr, self.ghost.bcs, self.ghost.dirichlet, capi.BOXES_LOCAL_ONLY),
+                "FillPhysicalBoundary(near)")
+        if amr.do_reflux:  # incrementFluxRegisters, coarse side: the register cells lie in the near boxes
+            amr.levels[self.ilev + 1].fluxreg.CrseAdd(self.fluxRk2() if self.integratorOrder_ == 2 else self.halfFlux, self.geom.dx, dt_lev)
+        self._t_adv += dt_lev
+        self._join_dt = dt_lev
+
+    def advance_level_join(self) -> bool:
+        """the verdict of advance_level_begin: both stages clean on every box, no error flag, no CFL violation"""
+        torch.cuda.current_stream(self.ctx.device).wait_event(self._far_done)
+        vals = self._read_words()
+        ok = self._fused_end(1, 0, vals) == 0 and self._fused_end(2, 1, vals) == 0
+        if self._err_latched:
+            raise capi.QkError("density is negative in SyncDualEnergy! abort!! (reference src/hydro/hydro_system.hpp:834-836)")
+        if ok:
+            self._stage1_left_F1 = not self._carry_active()
+            ok = not self.isCflViolated(self._join_dt)
+        return ok
+
 
 class RadAmrLevelSim(AmrLevelSim, RadhydroSimulation):
     """One AMR level of a radiation-hydrodynamics run: the hydro advance of AmrLevelSim, then the radiation subcycle of RadhydroSimulation
@@ -508,6 +572,13 @@ class AmrSimulation:
         # clustering = "tiles": the round-1 rule (every flagged tile refined, greedy merge) — more refined cells, no efficiency parameter
         self.grid_eff, self.clustering = 0.7, "berger_rigoutsos"
         self.do_reflux, self.do_subcycle = True, True
+        # One rank, hydro: while the boxes of a level that no child reads ("far") finish their second stage on a side stream, the children
+        # advance on the compute stream — chains of small latency-bound kernels beside a launch that fills the GPU.  The level's verdict
+        # (redo counts, CFL check) then arrives after the children have run: they run speculatively and are rolled back if it is bad
+        # (_snapshot_above / _restore_above; the level is redone the ordinary way).  Same kernels on the same data: same bits.
+        self.overlap_children = False
+        self.overlap_max_fine_fraction = 0.25  # speculate only while the finer levels are small (their snapshot and their kernels)
+        self.overlap_stats = {"overlapped": 0, "rolled_back": 0}
         self.amrInterpMethod_ = 1
         self.cflNumber_, self.densityFloor_, self.tempFloor_ = 0.3, 0.0, 0.0
         self.reconstructionOrder_, self.integratorOrder_, self.useDualEnergy_, self.abortOnFofcFailure_ = 3, 2, 1, 1
@@ -535,6 +606,8 @@ class AmrSimulation:
         just before the children's regrid runs, and regrid(0) tags two levels that both need level 0 (one whole-level fill per coarse step and a
         half).  Every writer of state_new_cc_ clears the flag (advance_level, reflux / AverageDownTo / FixupState, the end of a regrid)."""
         L = self.levels[l]
+        if getattr(L, "_children_beside_far_boxes", False):
+            return  # (its far boxes are still in flight; what the children read of it is complete: _overlap_split)
         if not getattr(L, "_new_ghosts_filled", False):
             L._fill_time = L.t_new
             L.fillBoundaryConditions(L.state_new_cc_)
@@ -795,6 +868,68 @@ class AmrSimulation:
         for l in range(1, self.max_level + 1):
             self.dt_[l] = self.dt_[l - 1] / 2.0
 
+    # ------------------------------------------------------------------ children beside the far boxes
+    def _overlap_split(self, lev: int):
+        """(near, far) local boxes of level lev if its children can be advanced beside the second stage of the far boxes, else None.
+        near: every box the child level reads — the coarse cells under its ghost-cell interpolation (stencil included), the register cells of
+        its flux register, the cells it averages down to.  Required of every interpolation item: the coarse cells it reads lie in the VALID
+        region of its coarse box or beyond a physical boundary (never in ghost cells another box fills — those wait for the far boxes)."""
+        L = self.levels[lev]
+        if not (self.overlap_children and lev == 0 and self.nranks == 1 and self.rad_traits is None and lev < self.finest_level and self.do_reflux
+                and L.use_fused and L.integratorOrder_ == 2 and L.speculate_stage2 and not L.strang_sources and L.lev.nboxes > 1):
+            return None
+        fine_cells = sum(self.CountCells(l) for l in range(lev + 1, self.finest_level + 1))
+        if fine_cells > self.overlap_max_fine_fraction * self.CountCells(lev):
+            return None
+        child = self.levels[lev + 1]
+        key = (id(L), id(child), id(child.cf_interp))
+        cached = self.__dict__.get("_split_cache")
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        near, ok = set(), True
+        per, dom = L.geom.periodic, L.geom.n_cell
+        for fb, cb, lo, hi in child.cf_interp.items():
+            near.add(cb)
+            vlo, vhi = L.my_boxes[cb]
+            for d in range(3):
+                clo, chi = lo[d] // 2 - 1, hi[d] // 2 + 1
+                if clo < vlo[d] and not (vlo[d] == 0 and not per[d]):
+                    ok = False
+                if chi > vhi[d] and not (vhi[d] == dom[d] - 1 and not per[d]):
+                    ok = False
+        for _d, _side, _fb, cb, _lo, _hi, _sh in child.fluxreg.items():
+            near.add(cb)
+        for (flo, fhi) in child.all_boxes:  # the cells AverageDown writes
+            for b, (vlo, vhi) in enumerate(L.my_boxes):
+                if all(flo[d] // 2 <= vhi[d] and fhi[d] // 2 >= vlo[d] for d in range(3)):
+                    near.add(b)
+        far = [b for b in range(L.lev.nboxes) if b not in near]
+        out = (sorted(near), far) if ok and far and near else None
+        self._split_cache = (key, out)
+        return out
+
+    def _snapshot_above(self, lev: int):
+        per = []
+        for L in self.levels[lev + 1:]:
+            per.append((L, L.state_new_cc_, L.state_old_cc_, L.state_new_cc_.storage.clone(), L.t_old, L.t_new, L.dt_, dict(L.counters), L.istep))
+        return {"levels": list(self.levels), "istep": list(self.istep), "last": list(self.last_regrid_step), "cu": self.cellUpdates_,
+                "cul": list(self.cellUpdatesEachLevel_), "per": per}
+
+    def _restore_above(self, lev: int, snap):
+        self.levels = list(snap["levels"])
+        self.istep, self.last_regrid_step = list(snap["istep"]), list(snap["last"])
+        self.cellUpdates_, self.cellUpdatesEachLevel_ = snap["cu"], list(snap["cul"])
+        for L, new, old, data, t_old, t_new, dt, counters, istep in snap["per"]:
+            L.state_new_cc_, L.state_old_cc_ = new, old
+            new.storage.copy_(data)
+            L.t_old, L.t_new, L.dt_, L.counters, L.istep = t_old, t_new, dt, counters, istep
+            L._signal_of_state_new = None
+            L._old_ghosts_filled = False
+            L._new_ghosts_filled = False
+        for l in range(lev + 1, self.finest_level + 1):  # plans a regrid of the discarded attempt may have re-pointed
+            self.levels[l].link_to_parent(self.levels[l - 1])
+        self.__dict__.pop("_split_cache", None)
+
     def timeStepWithSubcycling(self, lev: int, time: float):
         if self.regrid_int > 0 and lev < self.max_level and self.istep[lev] > self.last_regrid_step[lev] and self.istep[lev] % self.regrid_int == 0:
             self.regrid(lev)
@@ -807,6 +942,38 @@ class AmrSimulation:
             self.levels[lev + 1].fluxreg.reset()
             if self.rad_traits is not None:
                 self.levels[lev + 1].fluxreg_rad.reset()
+        split = self._overlap_split(lev)
+        if split is not None:
+            snap = self._snapshot_above(lev)
+            L.advance_level_begin(time, self.dt_[lev], *split)
+            L._children_beside_far_boxes = True
+            try:
+                for i in range(2):
+                    self.timeStepWithSubcycling(lev + 1, time + i * self.dt_[lev + 1])
+            finally:
+                L._children_beside_far_boxes = False
+            ok = L.advance_level_join()
+            if getattr(self, "_force_speculation_failure", False):  # (tests: the rollback path)
+                self._force_speculation_failure, ok = False, False
+            if ok:
+                self.overlap_stats["overlapped"] += 1
+                self.istep[lev] += 1
+                self.cellUpdates_ += self.CountCells(lev)
+                self.cellUpdatesEachLevel_[lev] += self.CountCells(lev)
+                if self.do_reflux:
+                    L.reflux_from(self.levels[lev + 1])
+                self.AverageDownTo(lev)
+                L.FixupState()
+                L._new_ghosts_filled = False
+                return
+            # the level's step was not clean: the children advanced on a state that will not stand.  Back to the start of the step, then the
+            # ordinary order (first-order flux correction / retries, then the children).
+            self.overlap_stats["rolled_back"] += 1
+            self._restore_above(lev, snap)
+            L = self.levels[lev]
+            L.state_old_cc_, L.state_new_cc_ = L.state_new_cc_, L.state_old_cc_
+            L._signal_of_state_new = None
+            self.levels[lev + 1].fluxreg.reset()
         if not L.advance_level(time, self.dt_[lev]):
             raise capi.QkError(f"QUOKKA FATAL ERROR: Hydro update exceeded max_retries on level {lev}")
         self.istep[lev] += 1

@@ -30,6 +30,7 @@ struct qk_interp_plan {
 	std::vector<InterpItem> items;
 	InterpItem *d_items = nullptr;
 	int64_t max_cells = 0;
+	int64_t max_ccells = 0; // coarse cells under the largest item
 };
 
 namespace
@@ -76,35 +77,21 @@ void boxDiff(HBox a, HBox const &b, std::vector<HBox> &out)
 
 auto floorDiv(int a, int r) -> int { return (a >= 0) ? a / r : -((-a + r - 1) / r); }
 
-// one coarse stencil value of component n, time-interpolated, with PreInterpState applied to the energy
-QK_DEV auto crseValue(RA4 const &Co, RA4 const &Cn, double w_old, double w_new, int i, int j, int k, int n, bool hooks) -> double
-{
-	auto tv = [&](int c) -> double {
-		const double a = Co(i, j, k, c);
-		if (w_new == 0.0) {
-			return a;
-		}
-		return w_old * a + w_new * Cn(i, j, k, c);
-	};
-	if (hooks && n == ENE) {
-		const double rho = tv(RHO), px = tv(MX), py = tv(MY), pz = tv(MZ), Etot = tv(ENE);
-		const double kinetic_energy = (px * px + py * py + pz * pz) / (2.0 * rho);
-		return (Etot - kinetic_energy) / rho;
-	}
-	return tv(n);
-}
-
 // One thread per (COARSE cell under the region, component): threadIdx.x runs over coarse cells, threadIdx.y over components.  The coarse value, its
 // 27-point neighbourhood, the three limited slopes and the monotonicity factor alpha depend on the coarse cell alone; the r0 r1 r2 fine children take
-// them with their own offsets.  (Round 3 had one thread per FINE cell loop over the components: 27 coarse reads — 135 for the energy with its hook — per
-// fine value, eight times over for the eight children of a coarse cell: 68 us per fill of a 64^3 box's ghost shell, 11 % of the GPU time of the Sedov
-// hierarchy.)  The components of a fine cell meet in LDS for PostInterpState, which rebuilds the total energy from the interpolated density, momenta
-// and specific internal energy.  Same arithmetic per value: bit-identical.
+// them with their own offsets.  (Round 3 had one thread per FINE cell loop over the components: 68 us per fill of a 64^3 box's ghost shell.)
+// Round 5: the energy hook made the wave of the energy component do five times the work of the others — for each of its 27 neighbours the five
+// hydro components (ten with time interpolation) and a division, 36 us per fill, the longest kernel of a small level's step.  The threads of the
+// density, the momenta and the energy have just loaded exactly those values: they meet in LDS, plane by plane of the stencil, the specific internal
+// energies of a plane's nine neighbours are computed by the block's component threads side by side, and the energy thread picks them up.  The same
+// for PostInterpState: the children's densities and momenta go through LDS once, not once per child.  Same arithmetic per value: bit-identical.
 constexpr int IT_CELLS = 64, IT_MAXCOMP = 16;
 __global__ void __launch_bounds__(IT_CELLS *IT_MAXCOMP) k_interp(const InterpItem *items, qk_array4 *fine_t, const qk_array4 *crse_old_t, const qk_array4 *crse_new_t,
 								 double w_old, double w_new, int ncomp, int method, int hooks, int ndim, int r0, int r1, int r2)
 {
-	__shared__ double s_val[IT_MAXCOMP][IT_CELLS];
+	__shared__ double s_nb[5][9][IT_CELLS]; // rho, px, py, pz, E of one stencil plane
+	__shared__ double s_e[9][IT_CELLS];	// specific internal energy of that plane
+	__shared__ double s_val[4][8][IT_CELLS]; // rho, px, py, pz of the (up to 8) children
 	const InterpItem it = items[blockIdx.y];
 	const int rr[3] = {r0, r1, r2};
 	int clo[3];
@@ -120,14 +107,15 @@ __global__ void __launch_bounds__(IT_CELLS *IT_MAXCOMP) k_interp(const InterpIte
 	RA4 Co(crse_old_t[it.crse_box]);
 	RA4 Cn(crse_new_t[it.crse_box]);
 	const bool hk = (hooks != 0);
+	const int tx = static_cast<int>(threadIdx.x), ty = static_cast<int>(threadIdx.y), ny = static_cast<int>(blockDim.y);
 	// components in chunks of blockDim.y (<= IT_MAXCOMP; all of them at once up to 16 components: hydro 6, radiation-hydro 10; multigroup states take
 	// several chunks — the hydro block, which the energy hook needs together, is in the first)
-	for (int nbase = 0; nbase < ncomp; nbase += static_cast<int>(blockDim.y))
+	for (int nbase = 0; nbase < ncomp; nbase += ny)
 	for (unsigned base = blockIdx.x * IT_CELLS; base < ncc; base += gridDim.x * IT_CELLS) {
-		const int n_raw = nbase + static_cast<int>(threadIdx.y);
+		const int n_raw = nbase + ty;
 		const bool comp_live = n_raw < ncomp;
 		const int n = comp_live ? n_raw : ncomp - 1;
-		const bool post = hk && ncomp > ENE && nbase == 0; // (uniform)
+		const bool hooked = hk && ncomp > ENE && nbase == 0; // (uniform) this chunk holds the hydro block and the energy hooks apply
 		const unsigned t = base + threadIdx.x;
 		const bool live = t < ncc;
 		const unsigned tc = live ? t : 0;
@@ -135,21 +123,84 @@ __global__ void __launch_bounds__(IT_CELLS *IT_MAXCOMP) k_interp(const InterpIte
 		const unsigned r = tc - kk * m01;
 		const unsigned jj = r / m[0];
 		const int ic[3] = {clo[0] + static_cast<int>(r - jj * m[0]), clo[1] + static_cast<int>(jj), clo[2] + static_cast<int>(kk)};
-		const double u = crseValue(Co, Cn, w_old, w_new, ic[0], ic[1], ic[2], n, hk);
+		auto tv = [&](int i, int j, int k) -> double { // FillPatch time interpolation of this thread's component
+			const double a = Co(i, j, k, n);
+			if (w_new == 0.0) {
+				return a;
+			}
+			return w_old * a + w_new * Cn(i, j, k, n);
+		};
+		// (every index into nb / val below is a compile-time constant after unrolling: dimensions a build does not have are masked, not looped
+		// away — a run-time loop bound would put the arrays into scratch memory, which is what made this kernel take 33 us for 6500 cells)
+		double nb[3][3][3];
+		const bool lin = (method == 1);
+#pragma unroll
+		for (int c = -1; c <= 1; ++c) {
+#pragma unroll
+			for (int b = -1; b <= 1; ++b) {
+#pragma unroll
+				for (int a = -1; a <= 1; ++a) {
+					const bool used = (a == 0 && b == 0 && c == 0) || (lin && (c == 0 || ndim == 3) && (b == 0 || ndim >= 2));
+					nb[c + 1][b + 1][a + 1] = used ? tv(ic[0] + a, ic[1] + b, ic[2] + c) : 0.0;
+				}
+			}
+		}
+		if (hooked) { // PreInterpState on the stencil: the energy thread's values become (E - |p|^2 / (2 rho)) / rho
+#pragma unroll
+			for (int c = -1; c <= 1; ++c) {
+				if (c != 0 && !(lin && ndim == 3)) { // (uniform)
+					continue;
+				}
+				__syncthreads(); // (the previous plane's readers are done)
+				if (n_raw <= ENE) {
+#pragma unroll
+					for (int b = -1; b <= 1; ++b) {
+#pragma unroll
+						for (int a = -1; a <= 1; ++a) {
+							s_nb[n_raw][(b + 1) * 3 + (a + 1)][tx] = nb[c + 1][b + 1][a + 1];
+						}
+					}
+				}
+				__syncthreads();
+				for (int q = ty; q < 9; q += ny) { // the plane's neighbours dealt to the block's component threads
+					const int b = q / 3 - 1, a = q % 3 - 1;
+					const bool used = (a == 0 && b == 0 && c == 0) || (lin && (b == 0 || ndim >= 2));
+					if (used) {
+						const double rho = s_nb[RHO][q][tx], px = s_nb[MX][q][tx], py = s_nb[MY][q][tx], pz = s_nb[MZ][q][tx], Etot = s_nb[ENE][q][tx];
+						const double kinetic_energy = (px * px + py * py + pz * pz) / (2.0 * rho);
+						s_e[q][tx] = (Etot - kinetic_energy) / rho;
+					} else {
+						s_e[q][tx] = 0.0;
+					}
+				}
+				__syncthreads();
+				if (n_raw == ENE) {
+#pragma unroll
+					for (int b = -1; b <= 1; ++b) {
+#pragma unroll
+						for (int a = -1; a <= 1; ++a) {
+							nb[c + 1][b + 1][a + 1] = s_e[(b + 1) * 3 + (a + 1)][tx];
+						}
+					}
+				}
+			}
+		}
+		const double u = nb[1][1][1];
 		double s[3] = {0., 0., 0.};
 		double alpha = 1.0;
 		if (method == 1) {
 			double umax = u, umin = u;
-			const int k0 = (ndim == 3) ? -1 : 0, k1 = (ndim == 3) ? 1 : 0;
-			const int j0 = (ndim >= 2) ? -1 : 0, j1 = (ndim >= 2) ? 1 : 0;
-			double nb[3][3][3];
-			for (int c = k0; c <= k1; ++c) {
-				for (int b = j0; b <= j1; ++b) {
+#pragma unroll
+			for (int c = -1; c <= 1; ++c) {
+#pragma unroll
+				for (int b = -1; b <= 1; ++b) {
+#pragma unroll
 					for (int a = -1; a <= 1; ++a) {
-						const double v = (a == 0 && b == 0 && c == 0) ? u : crseValue(Co, Cn, w_old, w_new, ic[0] + a, ic[1] + b, ic[2] + c, n, hk);
-						nb[c + 1][b + 1][a + 1] = v;
-						umax = smax(umax, v);
-						umin = smin(umin, v);
+						if ((c == 0 || ndim == 3) && (b == 0 || ndim >= 2)) {
+							const double v = nb[c + 1][b + 1][a + 1];
+							umax = smax(umax, v);
+							umin = smin(umin, v);
+						}
 					}
 				}
 			}
@@ -171,32 +222,54 @@ __global__ void __launch_bounds__(IT_CELLS *IT_MAXCOMP) k_interp(const InterpIte
 				}
 			}
 		}
-		// the fine children of the coarse cell that lie inside the region
-		for (int cz = 0; cz < r2; ++cz) {
-			for (int cy = 0; cy < r1; ++cy) {
-				for (int cx = 0; cx < r0; ++cx) {
-					const int idx[3] = {ic[0] * r0 + cx, ic[1] * r1 + cy, ic[2] * r2 + cz};
-					const bool inside = live && idx[0] >= it.lo[0] && idx[0] <= it.hi[0] && idx[1] >= it.lo[1] && idx[1] <= it.hi[1] && idx[2] >= it.lo[2] &&
-							    idx[2] <= it.hi[2];
-					double val = u;
+		// the fine children of the coarse cell (at most 2 x 2 x 2)
+		double val[8]; // child (cx, cy, cz) at index (cz * 2 + cy) * 2 + cx; children a ratio of 1 does not have are never stored
+#pragma unroll
+		for (int cz = 0; cz < 2; ++cz) {
+#pragma unroll
+			for (int cy = 0; cy < 2; ++cy) {
+#pragma unroll
+				for (int cx = 0; cx < 2; ++cx) {
+					double v = u;
 					if (method == 1) {
 						const double off0 = (cx + 0.5) / r0 - 0.5, off1 = (cy + 0.5) / r1 - 0.5, off2 = (cz + 0.5) / r2 - 0.5;
-						val = u + off0 * (s[0] * alpha) + off1 * (s[1] * alpha) + off2 * (s[2] * alpha);
+						v = u + off0 * (s[0] * alpha) + off1 * (s[1] * alpha) + off2 * (s[2] * alpha);
 					}
-					if (post) { // PostInterpState on the new fine cell: E = rho e + kinetic energy of the INTERPOLATED density and momenta
-						__syncthreads(); // (the previous child's readers are done)
-						s_val[n][threadIdx.x] = val;
-						__syncthreads();
-						if (n == ENE) {
-							const double rho = s_val[RHO][threadIdx.x];
-							const double px = s_val[MX][threadIdx.x], py = s_val[MY][threadIdx.x], pz = s_val[MZ][threadIdx.x];
-							const double Eint = rho * val;
-							const double kinetic_energy = (px * px + py * py + pz * pz) / (2.0 * rho);
-							val = Eint + kinetic_energy;
-						}
-					}
+					val[(cz * 2 + cy) * 2 + cx] = v;
+				}
+			}
+		}
+		if (hooked) { // PostInterpState on the new fine cells: E = rho e + kinetic energy of the INTERPOLATED density and momenta
+			__syncthreads(); // (the readers of the previous chunk of cells are done)
+			if (n_raw < ENE) {
+#pragma unroll
+				for (int c = 0; c < 8; ++c) {
+					s_val[n_raw][c][tx] = val[c];
+				}
+			}
+			__syncthreads();
+			if (n_raw == ENE) {
+#pragma unroll
+				for (int c = 0; c < 8; ++c) {
+					const double rho = s_val[RHO][c][tx];
+					const double px = s_val[MX][c][tx], py = s_val[MY][c][tx], pz = s_val[MZ][c][tx];
+					const double Eint = rho * val[c];
+					const double kinetic_energy = (px * px + py * py + pz * pz) / (2.0 * rho);
+					val[c] = Eint + kinetic_energy;
+				}
+			}
+		}
+#pragma unroll
+		for (int cz = 0; cz < 2; ++cz) {
+#pragma unroll
+			for (int cy = 0; cy < 2; ++cy) {
+#pragma unroll
+				for (int cx = 0; cx < 2; ++cx) {
+					const int idx[3] = {ic[0] * r0 + cx, ic[1] * r1 + cy, ic[2] * r2 + cz};
+					const bool inside = live && cx < r0 && cy < r1 && cz < r2 && idx[0] >= it.lo[0] && idx[0] <= it.hi[0] && idx[1] >= it.lo[1] &&
+							    idx[1] <= it.hi[1] && idx[2] >= it.lo[2] && idx[2] <= it.hi[2];
 					if (inside && comp_live) {
-						F(idx[0], idx[1], idx[2], n) = val;
+						F(idx[0], idx[1], idx[2], n) = val[(cz * 2 + cy) * 2 + cx];
 					}
 				}
 			}
@@ -216,6 +289,9 @@ int qk_interp_plan_create(qk_level *crse, qk_level *fine, const qk_geometry *fin
 	}
 	qk_ctx *ctx = crse->ctx;
 	QK_REQUIRE(ctx, crse->ctx == fine->ctx && crse->ndim == fine->ndim && nghost >= 0, "interp_plan_create: bad argument");
+	for (int d = 0; d < fine->ndim; ++d) {
+		QK_REQUIRE(ctx, ratio[d] == 1 || ratio[d] == 2, "interp_plan_create: refinement ratio must be 1 or 2 per direction");
+	}
 	auto *P = new qk_interp_plan;
 	P->crse = crse;
 	P->fine = fine;
@@ -298,6 +374,11 @@ int qk_interp_plan_create(qk_level *crse, qk_level *fine, const qk_geometry *fin
 						P->items.push_back(it);
 						P->max_cells = std::max<int64_t>(P->max_cells, static_cast<int64_t>(piece.hi[0] - piece.lo[0] + 1) * (piece.hi[1] - piece.lo[1] + 1) *
 												       (piece.hi[2] - piece.lo[2] + 1));
+						int64_t cc = 1;
+						for (int d = 0; d < 3; ++d) {
+							cc *= floorDiv(piece.hi[d], P->ratio[d]) - floorDiv(piece.lo[d], P->ratio[d]) + 1;
+						}
+						P->max_ccells = std::max(P->max_ccells, cc);
 						boxDiff(t, rc, rest);
 					} else {
 						rest.push_back(t);
@@ -361,7 +442,8 @@ int qk_InterpFromCoarse(qk_interp_plan *plan, qk_stream s, qk_array4 *fine_t, co
 	if (plan->items.empty()) {
 		return QK_OK;
 	}
-	const dim3 grid(static_cast<unsigned>(std::min<int64_t>((plan->max_cells + IT_CELLS - 1) / IT_CELLS, 16384)), static_cast<unsigned>(plan->items.size()), 1);
+	// a block covers IT_CELLS COARSE cells (round 4 sized the grid for the fine cells: seven of eight blocks returned at once)
+	const dim3 grid(static_cast<unsigned>(std::min<int64_t>((plan->max_ccells + IT_CELLS - 1) / IT_CELLS, 16384)), static_cast<unsigned>(plan->items.size()), 1);
 	hipLaunchKernelGGL(k_interp, grid, dim3(IT_CELLS, static_cast<unsigned>(std::min(ncomp, IT_MAXCOMP))), 0, static_cast<hipStream_t>(s), plan->d_items, fine_t, crse_old_t, crse_new_t, w_old, w_new, ncomp, method,
 			   energy_hooks, plan->crse->ndim, plan->ratio[0], plan->ratio[1], plan->ratio[2]);
 	QK_HIP_CHECK(ctx, hipGetLastError());

@@ -83,11 +83,21 @@ auto floorDiv(int a, int r) -> int { return (a >= 0) ? a / r : -((-a + r - 1) / 
 enum { FR_CRSE_ADD = 0, FR_FINE_ADD = 1, FR_REFLUX = 2 };
 
 // blockIdx.y = item of one (dir, side) group
+// One launch over the items of ALL (dir, side) groups (round 5: three to six launches of a few microseconds each per call were 6 % of a small
+// level's step).  CrseAdd / FineAdd write one register slot per (item, cell, component): no two items share a slot.  Reflux adds to state cells:
+// two items can meet in one cell only if they belong to different groups (a coarse cell with fine boxes on two of its faces) — those launches
+// stay separate per group (frLaunch).
+struct FrFlux {
+	const qk_array4 *t[3];
+	double fac[3];
+};
 template <int MODE>
-__global__ void __launch_bounds__(256) k_fluxreg(const FrItem *items, double *reg, int64_t total_cells, int ncomp, const qk_array4 *flux_t, qk_array4 *state_t,
-						 double fac, int r0, int r1, int r2, int scomp)
+__global__ void __launch_bounds__(256) k_fluxreg(const FrItem *items, double *reg, int64_t total_cells, int ncomp, FrFlux fx, qk_array4 *state_t, int r0, int r1, int r2,
+						 int scomp)
 {
 	const FrItem it = items[blockIdx.y];
+	const qk_array4 *flux_t = fx.t[it.dir];
+	const double fac = fx.fac[it.dir];
 	const int n0 = it.hi[0] - it.lo[0] + 1, n1 = it.hi[1] - it.lo[1] + 1, n2 = it.hi[2] - it.lo[2] + 1;
 	const int64_t ncell = static_cast<int64_t>(n0) * n1 * n2;
 	const int rr[3] = {r0, r1, r2};
@@ -405,23 +415,33 @@ int qk_fluxreg_restore(qk_fluxreg *fr, qk_stream s)
 static int frLaunch(qk_fluxreg *fr, qk_stream s, int mode, const qk_array4 *const flux[3], qk_array4 *state, const double fac[3])
 {
 	qk_ctx *ctx = fr->crse->ctx;
-	for (int g = 0; g < 6; ++g) {
-		const int first = fr->group_begin[g], count = fr->group_begin[g + 1] - first;
-		if (count == 0) {
-			continue;
+	auto st = static_cast<hipStream_t>(s);
+	FrFlux fx{};
+	for (int d = 0; d < 3; ++d) {
+		fx.t[d] = (flux != nullptr) ? flux[d] : nullptr;
+		fx.fac[d] = fac[d];
+	}
+	const auto gridOf = [&](int count) {
+		return dim3(static_cast<unsigned>(std::min<int64_t>((fr->max_cells * fr->ncomp + 255) / 256, 1024)), static_cast<unsigned>(count), 1);
+	};
+	if (mode != FR_REFLUX) { // one slot per (item, cell, component): every group in one launch
+		const int count = fr->group_begin[6];
+		if (count > 0) {
+			if (mode == FR_CRSE_ADD) {
+				hipLaunchKernelGGL(k_fluxreg<FR_CRSE_ADD>, gridOf(count), dim3(256), 0, st, fr->d_items, fr->d_reg, fr->total_cells, fr->ncomp, fx, nullptr, fr->ratio[0],
+						   fr->ratio[1], fr->ratio[2], fr->state_comp0);
+			} else {
+				hipLaunchKernelGGL(k_fluxreg<FR_FINE_ADD>, gridOf(count), dim3(256), 0, st, fr->d_items, fr->d_reg, fr->total_cells, fr->ncomp, fx, nullptr, fr->ratio[0],
+						   fr->ratio[1], fr->ratio[2], fr->state_comp0);
+			}
 		}
-		const int d = g / 2;
-		const dim3 grid(static_cast<unsigned>(std::min<int64_t>((fr->max_cells * fr->ncomp + 255) / 256, 1024)), static_cast<unsigned>(count), 1);
-		auto st = static_cast<hipStream_t>(s);
-		if (mode == FR_CRSE_ADD) {
-			hipLaunchKernelGGL(k_fluxreg<FR_CRSE_ADD>, grid, dim3(256), 0, st, fr->d_items + first, fr->d_reg, fr->total_cells, fr->ncomp, flux[d], nullptr, fac[d],
-					   fr->ratio[0], fr->ratio[1], fr->ratio[2], fr->state_comp0);
-		} else if (mode == FR_FINE_ADD) {
-			hipLaunchKernelGGL(k_fluxreg<FR_FINE_ADD>, grid, dim3(256), 0, st, fr->d_items + first, fr->d_reg, fr->total_cells, fr->ncomp, flux[d], nullptr, fac[d],
-					   fr->ratio[0], fr->ratio[1], fr->ratio[2], fr->state_comp0);
-		} else {
-			hipLaunchKernelGGL(k_fluxreg<FR_REFLUX>, grid, dim3(256), 0, st, fr->d_items + first, fr->d_reg, fr->total_cells, fr->ncomp, nullptr, state, 0.0,
-					   fr->ratio[0], fr->ratio[1], fr->ratio[2], fr->state_comp0);
+	} else {
+		for (int g = 0; g < 6; ++g) { // (a state cell can take increments from several groups: one launch per group, in order)
+			const int first = fr->group_begin[g], count = fr->group_begin[g + 1] - first;
+			if (count > 0) {
+				hipLaunchKernelGGL(k_fluxreg<FR_REFLUX>, gridOf(count), dim3(256), 0, st, fr->d_items + first, fr->d_reg, fr->total_cells, fr->ncomp, fx, state,
+						   fr->ratio[0], fr->ratio[1], fr->ratio[2], fr->state_comp0);
+			}
 		}
 	}
 	QK_HIP_CHECK(ctx, hipGetLastError());

@@ -587,9 +587,10 @@ class HydroSimulation:
         c = self.ctx
         c.check(c.L.qk_clear_bytes(c.h, c.stream(), C.c_void_p(self._dev_words.data_ptr() + (0 if both else 32 * slot)), 64 if both else 32), "qk_clear_bytes")
 
-    def _fused_launch(self, stage: int, U_in, U_old, U_out, dt, group=None, fofc: bool = False, slot: int = 0):
+    def _fused_launch(self, stage: int, U_in, U_old, U_out, dt, group=None, fofc: bool = False, slot: int = 0, scratch=None):
         """one fused stage over all local boxes (group None) or over a sub-level (Level, [local box indices]); fofc: the first-order flux
-        correction pass of a stage whose first pass flagged cells (qk_hydro_stage_args::fofc_pass); slot: the device words it reports in"""
+        correction pass of a stage whose first pass flagged cells (qk_hydro_stage_args::fofc_pass); slot: the device words it reports in;
+        scratch: a scratch array of its own for a launch that runs beside another one of this level (two streams)"""
         lev, idx = (self.lev, None) if group is None else group
         tab = (lambda mf: mf.ptr) if idx is None else (lambda mf: mf.subset_ptr(idx))
         a = capi.StageArgs()
@@ -605,8 +606,9 @@ class HydroSimulation:
         a.d_error_flag = C.c_void_p(w + 24)
         if self._is_final(stage):
             a.d_max_signal = C.c_void_p(w)
-        a.scratch = C.c_void_p(self.scratch.data_ptr())
-        a.scratch_bytes = self.scratch.numel() * 8
+        sc = self.scratch if scratch is None else scratch
+        a.scratch = C.c_void_p(sc.data_ptr())
+        a.scratch_bytes = sc.numel() * 8
         a.dt, a.stage, a.reconstruction_order = dt, stage, self.reconstructionOrder_
         a.densityFloor, a.tempFloor, a.use_dual_energy, a.K_visc = self.densityFloor_, self.tempFloor_, self.useDualEnergy_, float(self.artificialViscosityK_)
         mask = getattr(self, "flux_mask", None)  # a level with refined children in the carried form: flux_rk2 only on the marked faces

@@ -167,3 +167,34 @@ def test_carried_form_on_level_zero_with_flux_rk2_on_the_coarse_fine_faces_only(
             assert num <= 1e-12 * den, (la.ilev, n, num / den)
     print(f"composite |dE/E|, |dM/M| after 20 coarse steps: exact {dEa:.1e} {dMa:.1e}, carried level 0 {dEb:.1e} {dMb:.1e}")
     assert dEb <= max(4.0 * dEa, 5e-15) and dMb <= max(4.0 * dMa, 5e-14), (dEa, dEb, dMa, dMb)
+
+
+@pytest.mark.parametrize("carry", [False, True])
+def test_children_beside_the_far_boxes_and_the_rollback_are_bit_identical(ctx, carry):
+    """AmrSimulation.overlap_children: stage 2 of the level-0 boxes no child reads runs on a second stream while the children advance; level 0's
+    verdict (redo counts, CFL check) arrives after them, so they run speculatively and are rolled back — states, times, grids of a regrid in
+    between, step counters — when it is bad.  The blast of tests/blast_amr_maxlev2.in scaled down (64^3 in 32^3 boxes, blocking factor 8: the two
+    refined levels sit in one level-0 box), 12 coarse steps: the ordinary order, the overlapped one, and the overlapped one with the verdicts of
+    steps 3 and 8 forced bad — same grids, same time steps, every level's state equal in every bit."""
+    def run(overlap, fail_at=()):
+        amr = sedov_amr_problem(ctx, 64, 2, max_grid_size=32, blocking_factor=8)
+        if carry:
+            amr.use_carried_form(True)
+        amr.overlap_children = overlap
+        for n in range(12):
+            if n in fail_at:
+                amr._force_speculation_failure = True
+            amr.step()
+        return amr
+
+    a, b, c = run(False), run(True), run(True, fail_at=(3, 8))
+    assert a.overlap_stats == {"overlapped": 0, "rolled_back": 0}
+    assert b.overlap_stats["overlapped"] >= 10 and b.overlap_stats["rolled_back"] == 0, b.overlap_stats
+    assert c.overlap_stats["rolled_back"] == 2 and c.overlap_stats["overlapped"] >= 8, c.overlap_stats
+    assert a.finest_level == 2
+    for other in (b, c):
+        assert other.tNew_ == a.tNew_ and other.istep == a.istep and other.dt_ == a.dt_ and other.cellUpdates_ == a.cellUpdates_
+        assert [L.all_boxes for L in a.levels] == [L.all_boxes for L in other.levels]
+        for la, lo in zip(a.levels, other.levels):
+            for k in range(la.lev.nboxes):
+                assert torch.equal(la.state_new_cc_.valid(k), lo.state_new_cc_.valid(k)), (la.ilev, k)
