@@ -371,6 +371,8 @@ class AmrLevelSim(HydroSimulation):
     def advance_level(self, time: float, dt_lev: float) -> bool:
         """advanceSingleTimestepAtLevel: state_new <- advance(state_old = previous state_new), with the retries of
         advanceHydroAtLevelWithRetries (reference src/QuokkaSimulation.hpp:885-990); every attempt restarts at `time`"""
+        if self.amr._spec_entries is not None and self._can_defer_verdict():
+            return self._advance_level_deferred(time, dt_lev)
         self._signal_of_state_new = None
         self._old_ghosts_filled = False
         self._new_ghosts_filled = False
@@ -414,6 +416,38 @@ class AmrLevelSim(HydroSimulation):
     def FixupState(self):
         self._fixup_state(self.state_new_cc_)
 
+    # --- a speculative coarse step (AmrSimulation.overlap_children): verdicts are read once, at its end
+    def _can_defer_verdict(self) -> bool:
+        return (self.use_fused and self.integratorOrder_ == 2 and self.speculate_stage2 and not self.strang_sources and type(self) is AmrLevelSim
+                and len(self.amr._spec_entries) < self.amr._spec_words.shape[0])
+
+    def _advance_level_deferred(self, time: float, dt_lev: float) -> bool:
+        """advance_level inside a speculative coarse step: both stages and the register increments are enqueued, the eight words the stages
+        report in are copied to a slot of the hierarchy's log, and the step counts as good until AmrSimulation reads the log — a bad verdict there
+        rolls the whole coarse step back and redoes it in the ordinary order (first-order flux correction, retries)."""
+        amr, l = self.amr, self.ilev
+        self._signal_of_state_new = None
+        self._new_ghosts_filled = False
+        self.state_old_cc_, self.state_new_cc_ = self.state_new_cc_, self.state_old_cc_
+        self._t_adv = time
+        old, inter, new = self.state_old_cc_, self.state_inter_cc_, self.state_new_cc_
+        self._err_latched, self._unfused_ran = False, False
+        self._fused_begin(1, both=True)
+        self._launch_stage(1, old, old, inter, dt_lev, slot=0)
+        self._launch_stage(2, inter, old, new, dt_lev, slot=1)
+        k = len(amr._spec_entries)
+        amr._spec_words[k].copy_(self._dev_words, non_blocking=True)
+        amr._spec_entries.append((self, dt_lev, k))
+        self._stage1_left_F1 = not self._carry_active()
+        flux = self.fluxRk2()
+        if amr.do_reflux and l < amr.finest_level:
+            amr.levels[l + 1].fluxreg.CrseAdd(flux, self.geom.dx, dt_lev)
+        if amr.do_reflux and l > 0:
+            self.fluxreg.FineAdd(flux, self.geom.dx, dt_lev)
+        self._t_adv += dt_lev
+        self._old_ghosts_filled = True  # (stage 1 filled the old state's ghost cells in place)
+        return True
+
     # --- the children beside the far boxes (AmrSimulation.overlap_children)
     def advance_level_begin(self, time: float, dt_lev: float, near: List[int], far: List[int]):
         """advance_level with the verdict deferred: ghost fill + stage 1 of all boxes, ghost fill + stage 2 of the `near` boxes (the ones the
@@ -455,6 +489,14 @@ class AmrLevelSim(HydroSimulation):
         with torch.cuda.stream(self._far_stream):
             self._far_stream.wait_event(ev)
             self._fused_launch(2, inter, old, new, dt_lev, group=self._far_group, slot=1, scratch=self._far_scratch)
+            # FixupState of the far boxes (reference src/simulation.hpp:1308-1312: after Reflux and AverageDownTo — neither touches a far box, so
+            # for these cells it may as well run now, beside the children); its maxima wait in words 4, 5 for the near boxes' (_fixup_near)
+            if amr.overlap_fixup:
+                c = self.ctx
+                import ctypes as C
+                c.check(c.L.qk_hydro_FixupState(self._far_group[0].h, c.stream(), C.byref(self.traits), float(self.densityFloor_), float(self.tempFloor_),
+                                                int(self.useDualEnergy_), new.subset_ptr(self._far_group[1]), C.c_void_p(self._dev_fix.data_ptr() + 16),
+                                                C.c_void_p(self._dev_fix.data_ptr() + 32)), "qk_hydro_FixupState(far)")
             self._far_done = torch.cuda.Event()
             self._far_done.record(self._far_stream)
         # what the children read of the new state beyond the near boxes' valid cells lies beyond the domain (AmrSimulation._overlap_split)
@@ -465,6 +507,16 @@ class AmrLevelSim(HydroSimulation):
             amr.levels[self.ilev + 1].fluxreg.CrseAdd(self.fluxRk2() if self.integratorOrder_ == 2 else self.halfFlux, self.geom.dx, dt_lev)
         self._t_adv += dt_lev
         self._join_dt = dt_lev
+
+    def _fixup_near(self):
+        """FixupState of the near boxes after Reflux and AverageDownTo; with the far boxes' (advance_level_begin) the whole level has had it"""
+        import ctypes as C
+        c = self.ctx
+        c.check(c.L.qk_hydro_FixupState(self._near_group[0].h, c.stream(), C.byref(self.traits), float(self.densityFloor_), float(self.tempFloor_),
+                                        int(self.useDualEnergy_), self.state_new_cc_.subset_ptr(self._near_group[1]), C.c_void_p(self._dev_fix.data_ptr() + 16),
+                                        C.c_void_p(self._dev_fix.data_ptr())), "qk_hydro_FixupState(near)")
+        self._signal_of_state_new = None
+        self._fix_words_pending, self._fix_far_words, self._fix_error_pending = True, True, True
 
     def advance_level_join(self) -> bool:
         """the verdict of advance_level_begin: both stages clean on every box, no error flag, no CFL violation"""
@@ -577,8 +629,12 @@ class AmrSimulation:
         # (redo counts, CFL check) then arrives after the children have run: they run speculatively and are rolled back if it is bad
         # (_snapshot_above / _restore_above; the level is redone the ordinary way).  Same kernels on the same data: same bits.
         self.overlap_children = False
+        self.overlap_fixup = True  # (with overlap_children: FixupState of the far boxes on the side stream as well)
         self.overlap_max_fine_fraction = 0.25  # speculate only while the finer levels are small (their snapshot and their kernels)
         self.overlap_stats = {"overlapped": 0, "rolled_back": 0}
+        self.defer_child_verdicts = True  # (with overlap_children: one device -> host read per coarse step instead of one per level step)
+        self._spec_entries: Optional[list] = None  # inside a speculative coarse step: (level, dt, slot of _spec_words) per deferred level step
+        self._spec_words = None  # (32 slots of eight words on the device, made on first use)
         self.amrInterpMethod_ = 1
         self.cflNumber_, self.densityFloor_, self.tempFloor_ = 0.3, 0.0, 0.0
         self.reconstructionOrder_, self.integratorOrder_, self.useDualEnergy_, self.abortOnFofcFailure_ = 3, 2, 1, 1
@@ -908,6 +964,34 @@ class AmrSimulation:
         self._split_cache = (key, out)
         return out
 
+    def _deferred_verdicts(self, entries) -> bool:
+        """the verdicts of the level steps a speculative coarse step deferred (AmrLevelSim._advance_level_deferred): both stages clean, no error
+        flag, no CFL violation — one device -> host copy for all of them.  A level whose state nothing has changed since (the finest one) takes
+        the CFL maxima of its last step, as the ordinary advance leaves them."""
+        if not entries:
+            return True
+        n = len(entries)
+        h = self._spec_words[:n].cpu()
+        f = h.view(torch.float64)
+        last = {}
+        for L, dt, k in entries:
+            nbad1, nbad2 = int(h[k, 2]), int(h[k, 6])
+            err = (int(h[k, 3]) | int(h[k, 7])) & 0xFFFFFFFF
+            sig0, sig1 = float(f[k, 4]), float(f[k, 5])
+            if nbad1 != 0 or nbad2 != 0:
+                self.overlap_stats.setdefault("reasons", []).append(f"level {L.ilev}: {nbad1} / {nbad2} cells flagged for the first-order flux correction")
+                return False
+            if err != 0:
+                raise capi.QkError("density is negative in SyncDualEnergy! abort!! (reference src/hydro/hydro_system.hpp:834-836)")
+            if dt > 1.1 * (L.cflNumber_ * (L.min_dx() / sig0)):  # isCflViolated
+                self.overlap_stats.setdefault("reasons", []).append(f"level {L.ilev}: CFL violated")
+                return False
+            last[id(L)] = (L, sig0, sig1)
+        for L, sig0, sig1 in last.values():
+            if L in self.levels and not L._fix_words_pending and L._signal_of_state_new is None:
+                L._signal_of_state_new = (sig0, sig1)
+        return True
+
     def _snapshot_above(self, lev: int):
         per = []
         for L in self.levels[lev + 1:]:
@@ -947,12 +1031,20 @@ class AmrSimulation:
             snap = self._snapshot_above(lev)
             L.advance_level_begin(time, self.dt_[lev], *split)
             L._children_beside_far_boxes = True
+            if self.defer_child_verdicts and self._spec_words is None:
+                self._spec_words = torch.zeros(32, 8, dtype=torch.int64, device=self.ctx.device)
+            self._spec_entries = [] if self.defer_child_verdicts else None
             try:
                 for i in range(2):
                     self.timeStepWithSubcycling(lev + 1, time + i * self.dt_[lev + 1])
+                entries = self._spec_entries
             finally:
                 L._children_beside_far_boxes = False
+                self._spec_entries = None
             ok = L.advance_level_join()
+            if not ok:
+                self.overlap_stats.setdefault("reasons", []).append(f"level {lev}: verdict of the level itself")
+            ok = ok and self._deferred_verdicts(entries)
             if getattr(self, "_force_speculation_failure", False):  # (tests: the rollback path)
                 self._force_speculation_failure, ok = False, False
             if ok:
@@ -963,12 +1055,16 @@ class AmrSimulation:
                 if self.do_reflux:
                     L.reflux_from(self.levels[lev + 1])
                 self.AverageDownTo(lev)
-                L.FixupState()
+                if self.overlap_fixup:
+                    L._fixup_near()
+                else:
+                    L.FixupState()
                 L._new_ghosts_filled = False
                 return
             # the level's step was not clean: the children advanced on a state that will not stand.  Back to the start of the step, then the
             # ordinary order (first-order flux correction / retries, then the children).
             self.overlap_stats["rolled_back"] += 1
+            L._dev_fix[2:3].zero_()  # (whatever FixupState of the far boxes flagged belongs to the discarded attempt)
             self._restore_above(lev, snap)
             L = self.levels[lev]
             L.state_old_cc_, L.state_new_cc_ = L.state_new_cc_, L.state_old_cc_

@@ -327,7 +327,8 @@ class HydroSimulation:
         self.dev_signal = self._dev_words[0:2].view(torch.float64)
         # FixupState (an AMR hierarchy, after reflux + average-down) leaves its CFL maxima and error flag in words of its own: [sig0, sig1]
         # (double), [error flag] (sticky); they are read when the next time step is computed
-        self._dev_fix = torch.zeros(4, dtype=torch.int64, device=ctx.device)
+        self._dev_fix = torch.zeros(8, dtype=torch.int64, device=ctx.device)  # (words 4, 5: the maxima of a sub-level fixed up earlier, AmrLevelSim)
+        self._fix_far_words = False
         self._fix_words_pending = False
         self._signal_of_state_new = None  # (sig0, sig1) if the device values describe the current state_new_cc_
         self.scratch = None
@@ -392,6 +393,7 @@ class HydroSimulation:
                                         state.ptr, C.c_void_p(self._dev_fix.data_ptr() + 16), C.c_void_p(self._dev_fix.data_ptr())), "qk_hydro_FixupState")
         self._signal_of_state_new = None
         self._fix_words_pending = state is self.state_new_cc_
+        self._fix_far_words = False
         self._fix_error_pending = True  # (its own flag: invalidating the signal must not make the error word unread)
 
     def _signal(self):
@@ -402,6 +404,9 @@ class HydroSimulation:
         if take or getattr(self, "_fix_error_pending", False):
             h = self._dev_fix.cpu()
             vals = h[0:2].view(torch.float64).tolist() + [float(int(h[2]) & 0xFFFFFFFF)]
+            if self._fix_far_words:  # the level was fixed up in two parts: the maxima of the other part
+                far = h[4:6].view(torch.float64).tolist()
+                vals[0], vals[1] = max(vals[0], far[0]), max(vals[1], far[1])
             if self.nranks > 1:
                 import torch.distributed as dist
                 from . import comm
