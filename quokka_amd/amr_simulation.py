@@ -486,6 +486,9 @@ class AmrLevelSim(HydroSimulation):
         ev = torch.cuda.Event()
         ev.record(main)
         self._fused_launch(2, inter, old, new, dt_lev, group=self._near_group, slot=1)
+        if __import__("os").environ.get("QK_AMR_FAR_AFTER_NEAR", "0") == "1":  # (experiment: the far boxes start when the near boxes are done)
+            ev = torch.cuda.Event()
+            ev.record(main)
         with torch.cuda.stream(self._far_stream):
             self._far_stream.wait_event(ev)
             self._fused_launch(2, inter, old, new, dt_lev, group=self._far_group, slot=1, scratch=self._far_scratch)

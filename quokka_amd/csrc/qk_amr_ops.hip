@@ -111,6 +111,10 @@ int qk_tag_relative_gradient(qk_level *lev, qk_stream s, const qk_hydro_traits *
 			return U(ii, jj, kk, field);
 		};
 		const double c = q(i, j, k);
+		const bool above = (min_inclusive != 0) ? (c >= q_min) : (c > q_min);
+		if (!above) { // (the tag needs both conditions: a cell below the threshold never reads its neighbours — ambient gas costs one pressure, not seven)
+			return;
+		}
 		// del_d = max(|q+ - q|, |q - q-|);  indicator = max(del_x, del_y, del_z) / q   (std::max: first argument on ties)
 		double del = smax(fabs(q(i + 1, j, k) - c), fabs(c - q(i - 1, j, k)));
 		if (ndim >= 2) {
@@ -120,8 +124,7 @@ int qk_tag_relative_gradient(qk_level *lev, qk_stream s, const qk_hydro_traits *
 			del = smax(del, smax(fabs(q(i, j, k + 1) - c), fabs(c - q(i, j, k - 1))));
 		}
 		const double gradient_indicator = del / c;
-		const bool above = (min_inclusive != 0) ? (c >= q_min) : (c > q_min);
-		if ((gradient_indicator > eta_threshold) && above) {
+		if (gradient_indicator > eta_threshold) {
 			tag(i, j, k) = static_cast<char>(QK_TAG_SET);
 		}
 	};
