@@ -14,9 +14,11 @@
 // Gas + radiation, and gas + dust + radiation (ISM_Traits::enable_dust_gas_thermal_coupling_model).  No photoelectric heating / line cooling /
 // cosmic-ray heating (their hooks default to zero and are written as zeros; SolveGasDustRadiationEnergyExchangeWithPE is not restated).
 //
-// The 1000-point table of the incomplete Planck integral is quokka_amd/data/planck_integral_table.inc, computed from the definition by
-// tools/make_planck_table.py (17 digits).  The reference lists the same function to 15 digits; the two agree to <= 5e-14 relative
-// (tests/test_multigroup_oracle.py), which is the size of the difference this restatement can show against the reference itself in the Planck fractions.
+// The 1000-point table of the incomplete Planck integral is computed by the oracle itself (planck_table.hpp: series in 113-bit arithmetic, each sample
+// rounded once to double); the product ships the same function as a data file computed by another program with another method
+// (tools/make_planck_table.py: quadrature at 50 digits) — tests/test_multigroup_oracle.py holds the two equal in every bit.  The reference lists the
+// function to 15 digits; it agrees with both to <= 5e-14 relative, which is the size of the difference this restatement can show against the
+// reference itself in the Planck fractions.
 #ifndef ORACLE_RADIATION_MULTIGROUP_HPP_
 #define ORACLE_RADIATION_MULTIGROUP_HPP_
 
@@ -25,6 +27,7 @@
 #include <cmath>
 #include <limits>
 
+#include "planck_table.hpp"
 #include "radiation.hpp"
 
 namespace oracle
@@ -36,9 +39,8 @@ namespace planck
 constexpr int INTERP_SIZE = 1000;
 constexpr double LOG_X_MIN = -3.;
 constexpr double LOG_X_MAX = 2.;
-inline const double Y_interp[INTERP_SIZE] = {
-#include "../quokka_amd/data/planck_integral_table.inc"
-};
+// (computed by the oracle itself when the library loads — planck_table.hpp: series in 113-bit arithmetic — NOT read from the product's data file)
+inline const std::array<double, INTERP_SIZE> Y_interp = computePlanckTable();
 constexpr double PI = M_PI;
 constexpr double gInf = PI * PI * PI * PI / 15.0;
 

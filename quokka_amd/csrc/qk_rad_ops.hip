@@ -500,7 +500,18 @@ __global__ void __launch_bounds__(256) k_rad_sweep_march(const qk_box *boxes, Ra
 	if (i > bx.hi[0] || ot > bx.hi[OT] || c0 > bx.hi[DIR]) {
 		return;
 	}
-	const int c1 = min(c0 + strip - 1, bx.hi[DIR]); // last cell of this strip
+	int c1 = min(c0 + strip - 1, bx.hi[DIR]); // last cell of this strip
+	if (EPI != 0) {
+		// The final sweep writes U_new.  Written IN PLACE (the fab of U_new is the fab of U_in — seen here from the fab pointers themselves: two
+		// descriptor tables may describe one storage, which the host cannot tell from the table pointers) a pencil must be one thread's: the
+		// cells behind its march are then the only ones it has overwritten.  The first strip takes the whole pencil, the others leave.
+		if (a.U_new[b].p == a.U_in[b].p && strip <= bx.hi[DIR] - bx.lo[DIR]) {
+			if (sno != 0) {
+				return;
+			}
+			c1 = bx.hi[DIR];
+		}
+	}
 	RA4 U(a.U_in[b]);
 	constexpr int M0 = (ORDER == 3) ? 0 : (ORDER == 2) ? 1 : 2;
 	constexpr int M1 = (ORDER == 3) ? 5 : (ORDER == 2) ? 4 : 3;
@@ -665,7 +676,8 @@ template <int ORDER, int STAGE, bool STORE> void launchRadSweeps(qk_level *lev, 
 		// written in place (stage 2 of the drivers: U_new is U_in), a pencil is one thread's: the cells behind its march are the only ones it
 		// has overwritten.  Otherwise strips, for more waves in flight.
 		// (Aliasing cannot be seen from the table POINTERS alone — two tables may describe the same storage, e.g. a sub-level's gathered
-		// descriptors — so stage 2, the stage the drivers run in place, always marches whole pencils; stage 1 does when the tables are the same.)
+		// descriptors.  Stage 2, the stage the drivers run in place, always marches whole pencils; stage 1 does when the tables are the same —
+		// and when two tables over one storage reach the kernel after all, it sees the equal fab pointers and falls back to whole pencils itself.)
 		const int strip = (STAGE == 2 || a.U_new == a.U_in) ? lev->maxlen[2] : 32;
 		const int notb = (lev->maxlen[1] + 3) / 4;
 		const int nstrips = (lev->maxlen[2] + strip - 1) / strip;

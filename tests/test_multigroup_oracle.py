@@ -30,7 +30,9 @@ def test_planck_table_is_the_function_it_says(oracle):
     for j in (0, 1, 137, 500, 640, 777, 900, 999):
         x = 10.0 ** (-3 + j * 5 / 999)
         assert abs(tab[j] - planck_Y(x)) <= 1e-14 * tab[j], j  # (x itself is rounded here: Y ~ x^3 carries 3 ulp of it)
-    # the shipped include file is what the library was built from
+    # two computations of one function: the oracle's own table (oracle/planck_table.hpp: Bernoulli series / exponential series in 113-bit
+    # arithmetic, made when liboracle.so loads) and the data file the product is built from (tools/make_planck_table.py: mpmath quadrature at
+    # 50 digits) — every one of the 1000 doubles is the correctly rounded value of the function, so they are equal in every bit
     txt = open(os.path.join(os.path.dirname(HERE), "quokka_amd", "data", "planck_integral_table.inc")).read()
     vals = np.array([float(v) for v in re.findall(r"^([0-9.e+-]+),$", txt, flags=re.M)])
     assert np.array_equal(vals, tab)

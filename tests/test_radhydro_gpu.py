@@ -360,6 +360,39 @@ def test_fused_radiation_stage_equals_the_separate_operators(ctx, rad_order):
         assert a.rad_counters == b.rad_counters
 
 
+def test_fused_radiation_stage_in_place_through_two_tables_over_one_storage(ctx):
+    """qk_rad_stage_fused, stage 1 (the Z sweep marches strips of 32 cells when U_new is not U_in), called with U_new = a SECOND descriptor table
+    over the storage of U_in (MultiFab.subset_ptr: the same fab pointers at another table address — what the host cannot tell from the table
+    pointers): the kernel sees the equal fab pointers and gives a pencil to one thread; the result is the out-of-place stage's, bit for bit.
+    One 64^3 box (two strips per pencil), all three reconstruction orders."""
+    import ctypes as C
+    from quokka_amd.multifab import MultiFab
+    from quokka_amd.radhydro import _d3
+    for order in (1, 2, 3):
+        s = shell_problem(ctx, 64, table(), max_grid_size=64, pow_mode=1)
+        s.radiationReconstructionOrder_ = order
+        assert s.step()
+        U = s.state_new_cc_
+        s._fill_rad_ghosts(U)
+        out = MultiFab(s.lev, U.ncomp, U.nghost, fill=0.0)
+        out.copy_from(U)
+        acc = MultiFab(s.lev, s.nrad, 0)
+        dt = 0.3 * s.geom.dx[0] / s.rad_traits.c_hat
+        c = ctx
+
+        def stage(U_new_ptr):
+            c.check(c.L.qk_rad_stage_fused(s.lev.h, c.stream(), C.byref(s.rad_traits), order, 1, U.ptr, U.ptr, U_new_ptr, acc.ptr, None, float(dt),
+                                           _d3(s.geom.dx)), "qk_rad_stage_fused")
+        stage(out.ptr)  # out of place: strips
+        want = [out.valid(b).clone() for b in range(s.lev.nboxes)]
+        alias = U.subset_ptr(list(range(s.lev.nboxes)))
+        assert alias.value != U.ptr.value
+        stage(alias)  # in place through another table
+        for b in range(s.lev.nboxes):
+            assert torch.equal(U.valid(b), want[b]), (order, b)
+        assert not torch.equal(want[0][6], s.state_old_cc_.valid(0)[6])  # (the stage changed the radiation energy)
+
+
 @pytest.mark.gpu
 def test_mirrored_radiation_swap_equals_the_copy(ctx):
     """qk_rad_AddSourceTermsSingleGroupMirror: the stage-2 source-term kernel of substep i stores the new radiation components of the valid
