@@ -264,20 +264,16 @@ int qk_cooling_tabulated(qk_level *lev, qk_stream s, const qk_hydro_traits *t, q
 	if (lev->nboxes == 0) {
 		return QK_OK;
 	}
-	// the queue word of the persistent kernel: owned by the context, cleared on the stream before every launch
-	unsigned long long *queue = nullptr;
-	{
-		std::lock_guard<std::mutex> lock(lev->ctx->mtx);
-		if (lev->ctx->cooling_queue == nullptr) {
-			void *p = nullptr;
-			if (hipMalloc(&p, sizeof(unsigned long long)) != hipSuccess) {
-				return setError(lev->ctx, QK_ERR_HIP, "cooling_tabulated", "cannot allocate the queue word");
-			}
-			lev->ctx->owned.push_back(p);
-			lev->ctx->cooling_queue = static_cast<unsigned long long *>(p);
+	// the queue word of the persistent kernel: owned by the LEVEL, cleared on the stream before every launch (the calls of one level are ordered by
+	// its stream; levels on different streams do not share a counter)
+	if (lev->d_cooling_queue == nullptr) {
+		void *p = nullptr;
+		if (hipMalloc(&p, sizeof(unsigned long long)) != hipSuccess) {
+			return setError(lev->ctx, QK_ERR_HIP, "cooling_tabulated", "cannot allocate the queue word");
 		}
-		queue = lev->ctx->cooling_queue;
+		lev->d_cooling_queue = static_cast<unsigned long long *>(p);
 	}
+	unsigned long long *queue = lev->d_cooling_queue;
 	QK_HIP_CHECK(lev->ctx, hipMemsetAsync(queue, 0, sizeof(unsigned long long), static_cast<hipStream_t>(s)));
 	// enough resident waves to fill the chip (the kernel holds ~100 VGPRs: 4 waves per SIMD), never more lanes than cells
 	const long long cells = static_cast<long long>(lev->maxlen[0]) * lev->maxlen[1] * lev->maxlen[2] * lev->nboxes;

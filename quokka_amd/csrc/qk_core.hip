@@ -101,6 +101,7 @@ int qk_level_destroy(qk_level *lev)
 	(void)hipFree(lev->d_boxes);
 	(void)hipFree(lev->d_sgeom);
 	(void)hipFree(lev->d_tile_flags);
+	(void)hipFree(lev->d_cooling_queue);
 	delete lev;
 	return QK_OK;
 }

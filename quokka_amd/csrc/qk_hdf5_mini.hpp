@@ -156,6 +156,7 @@ class File
 					ds.raw.assign(d_.begin() + static_cast<std::ptrdiff_t>(addr), d_.begin() + static_cast<std::ptrdiff_t>(addr + size));
 				} else if (b[1] == 0) { // compact
 					uint64_t const size = static_cast<uint64_t>(b[2]) | (static_cast<uint64_t>(b[3]) << 8);
+					within(m, 4 + size, name);
 					ds.raw.assign(b + 4, b + 4 + size);
 				} else {
 					throw std::runtime_error("hdf5: /" + name + " is chunked: not read");
@@ -170,9 +171,11 @@ class File
 					throw std::runtime_error("hdf5: /" + name + ": only version-1 attribute messages are read");
 				}
 				auto pad = [](size_t n) { return (n + 7) / 8 * 8; };
+				within(m, 8, name);
 				size_t const nsz = rd16(b + 2), dsz = rd16(b + 4), ssz = rd16(b + 6);
 				size_t p = 8;
-				std::string const aname(reinterpret_cast<char const *>(b + p));
+				within(m, p + pad(nsz) + pad(dsz) + pad(ssz), name); // every size below comes from the file: nothing is read beyond the message
+				std::string const aname(reinterpret_cast<char const *>(b + p), strnlen(reinterpret_cast<char const *>(b + p), nsz));
 				p += pad(nsz);
 				Attribute a;
 				a.type = datatype(b + p, dsz);
@@ -181,8 +184,15 @@ class File
 				p += pad(ssz);
 				size_t n = 1;
 				for (auto dd : a.dims) {
+					if (dd > m.size) { // (an attribute's values live inside its message)
+						throw std::runtime_error("hdf5: /" + name + ": attribute " + aname + " is larger than its message");
+					}
 					n *= static_cast<size_t>(dd);
 				}
+				if (a.type.size < 0) {
+					throw std::runtime_error("hdf5: /" + name + ": attribute " + aname + " has a negative element size");
+				}
+				within(m, p + n * static_cast<size_t>(a.type.size), name);
 				a.raw.assign(b + p, b + p + n * static_cast<size_t>(a.type.size));
 				ds.attrs[aname] = a;
 				break;
@@ -205,6 +215,13 @@ class File
 	std::vector<unsigned char> d_;
 	std::map<std::string, uint64_t> objects_; // name in the root group -> object header address
 
+	// [0, n) of message m lies inside the message (its extent inside the file was checked when the header was walked)
+	static void within(Msg const &m, uint64_t n, std::string const &name)
+	{
+		if (n > m.size) {
+			throw std::runtime_error("hdf5: /" + name + ": a size field points beyond its header message (truncated or malformed file)");
+		}
+	}
 	void need(uint64_t at, uint64_t n) const
 	{
 		if (at + n > d_.size() || at + n < at) {
@@ -243,6 +260,7 @@ class File
 	}
 	void walk(uint64_t node, uint64_t names, int depth)
 	{
+		need(node, 24);
 		if (depth > 8 || !tag(node, "TREE") || d_[node + 4] != 0) {
 			throw std::runtime_error("hdf5: group B-tree node expected");
 		}
@@ -263,7 +281,7 @@ class File
 				uint64_t const e = child + 8 + 40 * static_cast<uint64_t>(s);
 				uint64_t const nameAt = names + u64(e);
 				need(nameAt, 1);
-				std::string const name(reinterpret_cast<char const *>(d_.data() + nameAt));
+				std::string const name(reinterpret_cast<char const *>(d_.data() + nameAt), strnlen(reinterpret_cast<char const *>(d_.data() + nameAt), d_.size() - nameAt));
 				objects_[name] = u64(e + 8);
 			}
 		}
@@ -301,6 +319,9 @@ class File
 		}
 		int const rank = b[1];
 		size_t const off = (b[0] == 1) ? 8 : 4;
+		if (off + 8 * static_cast<size_t>(rank) > size) {
+			throw std::runtime_error("hdf5: dataspace message shorter than its rank says");
+		}
 		std::vector<uint64_t> dims(static_cast<size_t>(rank));
 		for (int r = 0; r < rank; ++r) {
 			dims[static_cast<size_t>(r)] = rd64(b + off + 8 * static_cast<size_t>(r));

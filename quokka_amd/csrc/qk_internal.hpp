@@ -33,7 +33,6 @@ struct qk_ctx {
 	std::vector<qk_prof_pending> prof_pending;
 	std::vector<hipEvent_t> prof_free_events;
 	int *counter_slots = nullptr; // qk_rad_ops.hip: spread iteration / failure counters (owned)
-	unsigned long long *cooling_queue = nullptr; // qk_cooling.hip: the next-cell counter of the persistent kernel (owned)
 };
 
 struct qk_level {
@@ -49,6 +48,9 @@ struct qk_level {
 	// device buffer of qk_amr_tile_flags (one int per blocking-factor tile of the domain), kept between regrids
 	int *d_tile_flags = nullptr;
 	size_t tile_flags_bytes = 0;
+	// qk_cooling.hip: the next-cell counter of the persistent kernel — one per level (a level is used from one stream at a time,
+	// include/quokka_amd.h: two levels cooling on two streams each clear and count their own word)
+	unsigned long long *d_cooling_queue = nullptr;
 };
 
 namespace qk

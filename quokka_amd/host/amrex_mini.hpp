@@ -608,8 +608,10 @@ class ParmParse
 // MultiFab of a regrid comes out of it).  hipMalloc / hipFree cost tens to hundreds of microseconds each and hipFree waits for the device; a
 // hierarchy that regrids every other step re-creates the tag arrays, the fine-level states and their plans every time.  Blocks are kept in exact-size
 // free lists instead (a regrid asks for the sizes the one before released).  A released block may still be read by kernels in flight: it becomes
-// reusable when an event recorded on the null stream at release time has completed (every stream of the host mirror that touches fab data is a
-// blocking stream, so the null stream's event follows all of them).  QK_DEVICE_ARENA=0: plain hipMalloc / hipFree.
+// reusable when an event recorded on the null stream at release time has completed.  The blocking streams of the host mirror (the compute stream)
+// order themselves with the null stream; a NON-blocking stream that touches fab data — the RCCL stream of qk_comm.hpp — is registered
+// (alsoWaitFor) and the null stream is made to wait for what it has queued before the event is recorded.  A reused block is not fresh from
+// hipMalloc: nothing may rely on zeroed memory (FabArray fills what it needs).  QK_DEVICE_ARENA=0: plain hipMalloc / hipFree.
 class DeviceArena
 {
       public:
@@ -649,6 +651,13 @@ class DeviceArena
 		}
 		return p;
 	}
+	// a non-blocking stream whose work may read or write arena blocks (the null stream's release event does not cover it by itself)
+	void alsoWaitFor(hipStream_t s)
+	{
+		if (s != nullptr && std::find(extra_.begin(), extra_.end(), s) == extra_.end()) {
+			extra_.push_back(s);
+		}
+	}
 	void free(void *p)
 	{
 		if (p == nullptr) {
@@ -658,6 +667,16 @@ class DeviceArena
 		if (!pooled_ || it == size_.end()) {
 			(void)hipFree(p);
 			return;
+		}
+		alsoWaitFor(qkhost::Comm::get().commStream());
+		for (hipStream_t s : extra_) { // the null stream follows whatever the registered streams have queued so far
+			hipEvent_t es = nullptr;
+			if (hipEventCreateWithFlags(&es, hipEventDisableTiming) == hipSuccess) {
+				if (hipEventRecord(es, s) == hipSuccess) {
+					(void)hipStreamWaitEvent(nullptr, es, 0);
+				}
+				(void)hipEventDestroy(es);
+			}
 		}
 		hipEvent_t ev = nullptr;
 		if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, nullptr) != hipSuccess) {
@@ -716,6 +735,7 @@ class DeviceArena
 		cached_ = 0;
 	}
 	bool pooled_ = true;
+	std::vector<hipStream_t> extra_;
 	std::map<std::size_t, std::vector<void *>> free_;
 	std::map<void *, std::size_t> size_;
 	std::vector<Pending> pending_;

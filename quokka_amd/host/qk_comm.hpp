@@ -45,6 +45,9 @@ class Comm
 		return c;
 	}
 
+	// the RCCL stream (non-blocking), nullptr before init() on several ranks: what else must be waited for before fab memory is reused
+	[[nodiscard]] auto commStream() const -> hipStream_t { return stream_; }
+
 	// reads the launcher's environment, selects the device of this rank, opens the communicator (idempotent)
 	void init()
 	{
@@ -284,7 +287,7 @@ class Comm
 	bool initialised_ = false;
 	std::string tag_;
 	ncclComm_t nccl_ = nullptr;
-	hipStream_t stream_ = nullptr;
+	hipStream_t stream_ = nullptr; // (non-blocking: amrex::DeviceArena asks for it — commStream() — before it lets a released block be reused)
 	hipEvent_t evReady_ = nullptr, evDone_ = nullptr;
 	double *d_scratch_ = nullptr;
 	uint64_t seq_ = 0;

@@ -605,11 +605,18 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 				amrex::Abort("density is negative in SyncDualEnergy! abort!!");
 			}
 		}
-		bool ok = !isCflViolated(dt_lev);
-		if (ok) { // second half, on the new state (:1318-1321)
+		// second half of the Strang-split sources on the new state, THEN the CFL check on what they left (reference :1318-1321: the sources run
+		// unconditionally and `return !isCflViolated(...) && burn_success` sees the post-source state — a heating source can raise the signal
+		// speed past the limit).  Default sources that change nothing keep the signal the final stage reduced.
+		bool ok = true;
+		if (!strangSourcesAreDefault_ || enableCooling_ == 1) {
 			ok = addStrangSplitSourcesWithBuiltin(state_new_cc_[0], 0, time + dt_lev, 0.5 * dt_lev);
-			if (!strangSourcesAreDefault_ || enableCooling_ == 1) {
-				invalidateSignal();
+			invalidateSignal();
+			ok = !isCflViolated(dt_lev) && ok;
+		} else {
+			ok = !isCflViolated(dt_lev);
+			if (ok) {
+				ok = addStrangSplitSourcesWithBuiltin(state_new_cc_[0], 0, time + dt_lev, 0.5 * dt_lev);
 			}
 		}
 		if (ok && afterAdvance_) {

@@ -75,6 +75,45 @@ def test_library_reader_equals_the_independent_reader_and_the_oracle_s_preparati
     L.qk_ctx_destroy(ctx)
 
 
+def test_truncated_and_corrupted_table_files_are_refused_not_read_out_of_bounds(tmp_path):
+    """qk_hdf5_mini.hpp trusts no size it reads from the file: the table file cut short at many lengths, and with bytes of its header region
+    overwritten (sizes of attribute / layout / dataspace messages, heap offsets), either still reads — the damage missed everything the reader
+    looks at — or comes back as an error with a message.  (A reader that ran past its buffer would crash the test process.)"""
+    from quokka_amd import capi
+    L = capi.lib()
+    ctx = C.c_void_p()
+    capi.check(None, L.qk_ctx_create(C.byref(ctx), -1), "qk_ctx_create")
+    data = open(TABLE, "rb").read()
+    t = capi.CloudyTables()
+    refused = 0
+    cuts = sorted(set([0, 7, 8, 95, 96, 200, 511, 1024, 2048, 4096, len(data) // 2, len(data) - 4096, len(data) - 1] + list(range(600, 6000, 397))))
+    for n in cuts:
+        f = tmp_path / f"cut_{n}.h5"
+        f.write_bytes(data[:n])
+        rc = L.qk_cloudy_tables_read(ctx, str(f).encode(), C.byref(t))
+        if rc == 0:
+            L.qk_cloudy_tables_free(C.byref(t))
+        else:
+            refused += 1
+            assert L.qk_last_error(ctx)
+    assert refused >= len(cuts) - 2
+    rng = np.random.default_rng(7)
+    outcomes = [0, 0]
+    for trial in range(150):  # header / heap / B-tree / object-header region: the first 8 KiB hold every size field the reader follows
+        b = bytearray(data)
+        for _ in range(int(rng.integers(1, 4))):
+            at = int(rng.integers(8, 8192))
+            b[at] = int(rng.choice([0xFF, 0x7F, 0x00, int(rng.integers(0, 256))]))
+        f = tmp_path / "corrupt.h5"
+        f.write_bytes(bytes(b))
+        rc = L.qk_cloudy_tables_read(ctx, str(f).encode(), C.byref(t))
+        outcomes[1 if rc else 0] += 1
+        if rc == 0:
+            L.qk_cloudy_tables_free(C.byref(t))
+    assert outcomes[1] > 0, outcomes
+    L.qk_ctx_destroy(ctx)
+
+
 def test_temperature_energy_round_trip_and_limits(orc):
     rho, T = sample(20000)
     E = orc.evaluate(orc.EGAS_FROM_TGAS, rho, T, GAMMA)
