@@ -22,6 +22,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 #include <map>
@@ -348,6 +349,103 @@ template <typename F> __global__ void qk_parfor_kernel_n(Box bx, int ncomp, F f)
 	f(bx.lo[0] + (r - j * nx), bx.lo[1] + j, bx.lo[2] + k, comp);
 }
 inline auto qk_parfor_row_block(int nx) -> unsigned { return nx >= 256 ? 256U : static_cast<unsigned>((nx + 63) / 64 * 64); }
+
+// Batched launches.  A problem hook like RadSystem<problem_t>::SetRadEnergySource is a HOST function that calls ParallelFor on ONE box; the driver
+// calls it once per box, every call a launch of a few microseconds of work (RadhydroShell: 8 boxes x 2 calls x 10 substeps per step, 9.75 % of the
+// step).  Inside a qk_parfor_batch_scope the row-mapped ParallelFor(Box, f) calls with the SAME lambda type are collected — box and closure by value,
+// up to what the 4 KiB of kernel arguments hold — and leave as ONE launch (blockIdx.z = the call) when the scope ends, the pack is full or another
+// kind of launch arrives.  The calls of a scope must not depend on one another (one hook, one box each); nothing else is enqueued inside the scope.
+struct qk_parfor_batch_state {
+	int depth = 0;
+	void (*flush)() = nullptr;
+};
+inline auto qk_parfor_batch() -> qk_parfor_batch_state &
+{
+	static thread_local qk_parfor_batch_state s;
+	return s;
+}
+inline void qk_parfor_batch_flush()
+{
+	auto &st = qk_parfor_batch();
+	if (st.flush != nullptr) {
+		auto *f = st.flush;
+		st.flush = nullptr;
+		f();
+	}
+}
+struct qk_parfor_batch_scope {
+	qk_parfor_batch_scope() { ++qk_parfor_batch().depth; }
+	~qk_parfor_batch_scope()
+	{
+		if (--qk_parfor_batch().depth == 0) {
+			qk_parfor_batch_flush();
+		}
+	}
+	qk_parfor_batch_scope(qk_parfor_batch_scope const &) = delete;
+	auto operator=(qk_parfor_batch_scope const &) -> qk_parfor_batch_scope & = delete;
+};
+template <typename F, int N> struct qk_parfor_pack {
+	int n;
+	Box bx[N];
+	alignas(F) unsigned char f[N][sizeof(F)];
+};
+template <typename F, int N> __global__ void qk_parfor_rows_batch(qk_parfor_pack<F, N> p)
+{
+	const Box bx = p.bx[blockIdx.z];
+	const int i = bx.lo[0] + static_cast<int>(blockIdx.x * blockDim.x + threadIdx.x);
+	const unsigned ny = static_cast<unsigned>(bx.length(1)), r = blockIdx.y;
+	if (i > bx.hi[0] || r >= ny * static_cast<unsigned>(bx.length(2))) {
+		return;
+	}
+	const unsigned k = r / ny;
+	(*reinterpret_cast<F const *>(p.f[blockIdx.z]))(i, bx.lo[1] + static_cast<int>(r - k * ny), bx.lo[2] + static_cast<int>(k));
+}
+template <typename F> constexpr auto qk_parfor_pack_size() -> int
+{
+	constexpr size_t per = sizeof(Box) + ((sizeof(F) + alignof(F) - 1) / alignof(F)) * alignof(F);
+	constexpr size_t n = (3584 - 64) / per; // (kernel arguments: 4 KiB, some of it the runtime's)
+	return n >= 16 ? 16 : static_cast<int>(n);
+}
+template <typename F> auto qk_parfor_try_batch(Box const &bx, F const &f) -> bool
+{
+	constexpr int N = qk_parfor_pack_size<F>();
+	if constexpr (N < 2 || !std::is_trivially_copyable_v<F>) {
+		return false;
+	} else {
+		static thread_local qk_parfor_pack<F, N> pack{};
+		auto launch = +[]() {
+			if (pack.n == 0) {
+				return;
+			}
+			unsigned nx = 0, rows = 0;
+			for (int q = 0; q < pack.n; ++q) {
+				nx = std::max(nx, static_cast<unsigned>(pack.bx[q].length(0)));
+				rows = std::max(rows, static_cast<unsigned>(pack.bx[q].length(1)) * static_cast<unsigned>(pack.bx[q].length(2)));
+			}
+			const unsigned tb = qk_parfor_row_block(static_cast<int>(nx));
+			hipLaunchKernelGGL((qk_parfor_rows_batch<F, N>), dim3((nx + tb - 1) / tb, rows, static_cast<unsigned>(pack.n)), dim3(tb), 0, nullptr, pack);
+			pack.n = 0;
+			qk_check_launch("amrex::ParallelFor (batched)");
+		};
+		auto &st = qk_parfor_batch();
+		if (st.flush != nullptr && st.flush != launch) {
+			qk_parfor_batch_flush(); // a pack of another lambda type is pending
+		}
+		if (static_cast<Long>(bx.length(1)) * bx.length(2) > 65535) { // (rows of the batch kernel live in gridDim.y)
+			qk_parfor_batch_flush();
+			return false;
+		}
+		pack.bx[pack.n] = bx;
+		std::memcpy(pack.f[pack.n], &f, sizeof(F));
+		++pack.n;
+		st.flush = launch;
+		if (pack.n == N) {
+			qk_parfor_batch_flush();
+		}
+		return true;
+	}
+}
+
 template <typename F> void ParallelFor(Box const &bx, F const &f)
 {
 	const Long n = bx.numPts();
@@ -355,6 +453,12 @@ template <typename F> void ParallelFor(Box const &bx, F const &f)
 		return;
 	}
 	const int nx = bx.length(0);
+	if (qk_parfor_batch().depth > 0) {
+		if (nx >= 32 && qk_parfor_try_batch(bx, f)) {
+			return;
+		}
+		qk_parfor_batch_flush(); // (keeps the order of the launches)
+	}
 	if (nx >= 32 && bx.length(1) <= 65535 && bx.length(2) <= 65535) {
 		const unsigned tb = qk_parfor_row_block(nx);
 		hipLaunchKernelGGL(qk_parfor_rows<F>, dim3((static_cast<unsigned>(nx) + tb - 1) / tb, static_cast<unsigned>(bx.length(1)), static_cast<unsigned>(bx.length(2))),

@@ -649,12 +649,22 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		if (radSourceTimeIndependent_ && radSourceFilled_) {
 			return;
 		}
+		// The hook is a function of (box, dx, prob_lo, prob_hi, time): a call with the time of the last evaluation finds its values in the array.
+		// Both stages of a substep pass time_subcycle + dt_radiation (reference :1638, :1656 -> :1872), so the second is free — nothing is assumed
+		// about how the source depends on time.
+		if (radSourceFilled_ && time == radSourceTime_) {
+			return;
+		}
 		auto const &g = geom[0];
-		for (int b = 0; b < radEnergySource_.size(); ++b) {
-			auto arr = radEnergySource_.array(b);
-			RadSystem<problem_t>::SetRadEnergySource(arr, radEnergySource_.validbox(b), g.CellSizeArray(), g.ProbLoArray(), g.ProbHiArray(), time);
+		{
+			amrex::qk_parfor_batch_scope batch; // the hook's one-box ParallelFor calls leave as one launch over all boxes (amrex_mini.hpp)
+			for (int b = 0; b < radEnergySource_.size(); ++b) {
+				auto arr = radEnergySource_.array(b);
+				RadSystem<problem_t>::SetRadEnergySource(arr, radEnergySource_.validbox(b), g.CellSizeArray(), g.ProbLoArray(), g.ProbHiArray(), time);
+			}
 		}
 		radSourceFilled_ = true;
+		radSourceTime_ = time;
 	}
 
 	void operatorSplitSourceTerms(double time, double dt, int stage, bool mirror = false)
@@ -825,6 +835,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	int *d_radCounter_ = nullptr, *d_radFailure_ = nullptr;
 	int radCounterSlots_ = 1, radCounterSlot_ = 0;
 	bool radSourceFilled_ = false;
+	double radSourceTime_ = 0.0; // the time argument of the last SetRadEnergySource evaluation (fillRadEnergySource)
 
 	[[nodiscard]] auto minDx() const -> double
 	{
