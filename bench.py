@@ -78,6 +78,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (ncell512, long_run, weak_256_per_gpu)")
     ap.add_argument("--cooling-only", action="store_true", help="only the cooling128 block (its own JSON line; profiling)")
+    ap.add_argument("--developed-only", action="store_true", help="only the `developed` block (its own JSON line; profiling the kernels in developed flow)")
     ap.add_argument("--long-steps", type=int, default=100, help="steps (and warm-up steps) of the long_run secondary figure")
     ap.add_argument("--cpu-ncell", type=int, default=128)
     ap.add_argument("--cpu-steps", type=int, default=24)  # ~15 s of CPU work on 16 cores
@@ -746,6 +747,9 @@ def main():
     ctx = Context(local_rank)
     if args.cooling_only:
         print(json.dumps({"cooling128": cooling_block(ctx, torch)}), flush=True)
+        return
+    if args.developed_only:
+        print(json.dumps({"developed": developed_block(ctx, torch, args.ncell or 256, args.max_grid_size, args.steps, args.warmup, args.rk2_mode == "carry")}), flush=True)
         return
     if args.selftest:
         if world == 1:
