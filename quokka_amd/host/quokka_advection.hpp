@@ -4,7 +4,7 @@
 // so that src/problems/Advection, AdvectionSemiellipse and Advection2D compile unchanged.  With amr.max_level > 0 the levels are objects of this
 // class under the level machinery of quokka_amr.hpp (AmrDriver<problem_t, AdvectionSimulation<problem_t>>: FillPatch without energy hooks, both
 // RK stages added to the flux registers with half the step): Advection2D's ctest deck refines three levels and meets its 0.15 criterion that
-// way (0.1447; 0.34 on level 0 alone — DESIGN.md §17).
+// way (0.1447; 0.34 on level 0 alone — docs/DESIGN_ROUNDS_1_4.md §17).
 #ifndef QK_HOST_QUOKKA_ADVECTION_HPP_
 #define QK_HOST_QUOKKA_ADVECTION_HPP_
 
