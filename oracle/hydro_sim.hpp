@@ -17,6 +17,11 @@
 
 #include <functional>
 #include <array>
+#include <chrono>
+#include <cstdlib>
+#include <map>
+#include <optional>
+#include <string>
 #include <cmath>
 #include <cstdio>
 #include <limits>
@@ -26,6 +31,7 @@
 #include "boundary.hpp"
 #include "grid.hpp"
 #include "hydro.hpp"
+#include "hydro_fused.hpp"
 #include "radiation.hpp"
 #include "radiation_multigroup.hpp"
 
@@ -169,8 +175,39 @@ struct HydroSim {
 	}
 
 	// QuokkaSimulation.hpp:1403-1490
+	// the fused, vectorised form of computeHydroFluxes (hydro_fused.hpp; bench.py's cpu_baseline leg): same fluxes in every bit, one pass per box
+	bool use_fused_fluxes = false;
+	auto computeHydroFluxesFused(MultiFab const &consVar, int nvars) const -> std::pair<FluxArrays, FluxArrays>
+	{
+		FluxArrays flux, facevel;
+		if (!pool_.fluxes.empty() && pool_.fluxes.back().first[0].nc == nvars) { // every face is overwritten below: nothing to clear
+			flux = std::move(pool_.fluxes.back().first);
+			facevel = std::move(pool_.fluxes.back().second);
+			pool_.fluxes.pop_back();
+		} else {
+			for (int idim = 0; idim < 3; ++idim) {
+				flux[idim] = MultiFab(grids, nvars, 0, ndim(), idim);
+				facevel[idim] = MultiFab(grids, 1, 0, ndim(), idim);
+			}
+		}
+		const int nb = consVar.size();
+		_Pragma("omp parallel")
+		{
+			fused::Work work; // (one set of box-sized scratch arrays per thread)
+			_Pragma("omp for schedule(dynamic)")
+			for (int b = 0; b < nb; ++b) {
+				fusedHydroFluxesBox(hydro.tr, consVar.const_array(b), grids[b], {flux[0].array(b), flux[1].array(b), flux[2].array(b)},
+						    {facevel[0].array(b), facevel[1].array(b), facevel[2].array(b)}, artificialViscosityK_, work);
+			}
+		}
+		return std::make_pair(std::move(flux), std::move(facevel));
+	}
+
 	auto computeHydroFluxes(MultiFab const &consVar, int nvars) const -> std::pair<FluxArrays, FluxArrays>
 	{
+		if (use_fused_fluxes && consVar.ng == 4 && fusedHydroFluxesApplicable(hydro.tr, reconstructionOrder_, is_mhd_enabled)) {
+			return computeHydroFluxesFused(consVar, nvars);
+		}
 		const int flatteningGhost = 2;
 		const int reconstructGhost = 1;
 		MultiFab primVar(grids, nvars, nghost_cc, ndim());
@@ -367,47 +404,135 @@ struct HydroSim {
 	}
 
 	// QuokkaSimulation.hpp:1032-1322 (no Strang sources, no flux registers, no tracers)
+	// wall time per phase of advanceHydroAtLevel (ORACLE_PROF=1; printed by the destructor): where a CPU step spends its time
+	mutable std::map<std::string, double> profSeconds_;
+	bool const prof_ = std::getenv("ORACLE_PROF") != nullptr;
+	struct ProfScope {
+		HydroSim const *s;
+		const char *name;
+		std::chrono::steady_clock::time_point t0;
+		ProfScope(HydroSim const *sim, const char *n) : s(sim), name(n), t0(std::chrono::steady_clock::now()) {}
+		~ProfScope()
+		{
+			if (s->prof_) {
+				s->profSeconds_[name] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+			}
+		}
+	};
+	~HydroSim()
+	{
+		if (prof_) {
+			for (auto const &kv : profSeconds_) {
+				std::fprintf(stderr, "[oracle prof] %-28s %9.3f s\n", kv.first.c_str(), kv.second);
+			}
+		}
+	}
+
+	// The fused leg keeps the temporaries of a step between steps (the reference takes them from AMReX's pooled arena; plain std::vector
+	// allocations of this size come back from the kernel as fresh zero pages, whose first touch cost more than the arithmetic of the step):
+	// same sizes, cleared where the step accumulates into them — the same values as fresh arrays.
+	struct StepPool {
+		std::optional<MultiFab> inter, rhs, oldTmp;
+		std::optional<iMultiFab> redo;
+		FluxArrays flux_rk2, avgVel;
+		std::vector<std::pair<FluxArrays, FluxArrays>> fluxes; // (flux, face velocity) sets handed out by computeHydroFluxesFused and given back
+		bool defined = false;
+	};
+	mutable StepPool pool_;
+
 	auto advanceHydroAtLevel(MultiFab &state_old_cc_tmp, double time, double dt_lev) -> bool
 	{
 		const int nc = ncompHydro();
-		MultiFab state_inter_cc_(grids, ncomp_cc, nghost_cc, ndim());
+		std::optional<ProfScope> psAlloc;
+		psAlloc.emplace(this, "allocate + clear");
+		const bool pooled = use_fused_fluxes;
+		std::optional<MultiFab> localInter;
+		if (pooled && !pool_.inter) {
+			pool_.inter.emplace(grids, ncomp_cc, nghost_cc, ndim());
+		}
+		if (!pooled) {
+			localInter.emplace(grids, ncomp_cc, nghost_cc, ndim());
+		}
+		MultiFab &state_inter_cc_ = pooled ? *pool_.inter : *localInter;
 		state_inter_cc_.setVal(0);
 
-		FluxArrays flux_rk2, avgFaceVel;
+		FluxArrays localRk2, localVel;
+		FluxArrays &flux_rk2 = pooled ? pool_.flux_rk2 : localRk2;
+		FluxArrays &avgFaceVel = pooled ? pool_.avgVel : localVel;
 		// The reference allocates avgFaceVel with 2 ghost faces "for tracer particles"
 		// (QuokkaSimulation.hpp:1061); the ghosts only feed tracers (out of scope) and make
 		// replaceFluxes read FOfaceVel out of bounds (:1352 `contains` on the ghosted array), so
 		// the oracle allocates none.  Valid faces are unaffected.
 		const int nghost_vel = 0;
 		for (int idim = 0; idim < ndim(); ++idim) {
-			flux_rk2[idim] = MultiFab(grids, nc, 0, ndim(), idim);
+			if (!(pooled && pool_.defined)) {
+				flux_rk2[idim] = MultiFab(grids, nc, 0, ndim(), idim);
+				avgFaceVel[idim] = MultiFab(grids, 1, nghost_vel, ndim(), idim);
+			}
 			flux_rk2[idim].setVal(0);
-			avgFaceVel[idim] = MultiFab(grids, 1, nghost_vel, ndim(), idim);
 			avgFaceVel[idim].setVal(0);
 		}
+		if (pooled && !pool_.defined) {
+			pool_.rhs.emplace(grids, nc, 0, ndim());
+			pool_.redo.emplace(grids, 1, 1, ndim());
+			pool_.defined = true;
+		}
+		psAlloc.reset();
 
 		// :1076 update ghost zones [old timestep]
-		fillBC(state_old_cc_tmp, time);
+		{
+			ProfScope const ps(this, "fill ghosts");
+			fillBC(state_old_cc_tmp, time);
+		}
 
-		// :1096
-		auto [FOfluxArrays, FOfaceVel] = computeFOHydroFluxes(state_old_cc_tmp, nc);
+		// :1096 — the first-order fluxes of the old state.  The reference evaluates them before stage 1 whether or not a stage needs them; they
+		// depend on the old state alone, which no stage changes, so the fused leg (use_fused_fluxes) evaluates them when a stage first flags
+		// cells — the same values, in the deck's 1000 steps never needed
+		std::optional<std::pair<FluxArrays, FluxArrays>> FO;
+		auto needFO = [&]() -> std::pair<FluxArrays, FluxArrays> & {
+			if (!FO) {
+				ProfScope const ps(this, "first-order fluxes");
+				FO.emplace(computeFOHydroFluxes(state_old_cc_tmp, nc));
+			}
+			return *FO;
+		};
+		if (!use_fused_fluxes) {
+			needFO();
+		}
 
 		// Stage 1 of RK2-SSP (:1099-1198)
 		{
 			auto const &stateOld = state_old_cc_tmp;
 			auto &stateNew = state_inter_cc_;
-			auto [fluxArrays, faceVel] = computeHydroFluxes(stateOld, nc);
+			auto fv1 = [&] {
+				ProfScope const ps(this, "hydro fluxes");
+				return computeHydroFluxes(stateOld, nc);
+			}();
+			auto &fluxArrays = fv1.first;
+			auto &faceVel = fv1.second;
 
-			for (int idim = 0; idim < ndim(); ++idim) {
-				Saxpy(flux_rk2[idim], 0.5, fluxArrays[idim], nc);
-				Saxpy(avgFaceVel[idim], 0.5, faceVel[idim], 1);
+			{
+				ProfScope const ps(this, "flux_rk2 += 0.5 F");
+				for (int idim = 0; idim < ndim(); ++idim) {
+					Saxpy(flux_rk2[idim], 0.5, fluxArrays[idim], nc);
+					Saxpy(avgFaceVel[idim], 0.5, faceVel[idim], 1);
+				}
 			}
 
-			MultiFab rhs(grids, nc, 0, ndim());
-			iMultiFab redoFlag(grids, 1, 1, ndim());
+			std::optional<MultiFab> localRhs;
+			std::optional<iMultiFab> localRedo;
+			if (!pooled) {
+				localRhs.emplace(grids, nc, 0, ndim());
+				localRedo.emplace(grids, 1, 1, ndim());
+			}
+			MultiFab &rhs = pooled ? *pool_.rhs : *localRhs;
+			iMultiFab &redoFlag = pooled ? *pool_.redo : *localRedo;
 			redoFlag.setVal(redo_none);
 
-			rhsPdvPredict(rhs, fluxArrays, faceVel, stateOld, stateNew, dt_lev, redoFlag);
+			{
+				ProfScope const ps(this, "rhs + PdV + PredictStep");
+				rhsPdvPredict(rhs, fluxArrays, faceVel, stateOld, stateNew, dt_lev, redoFlag);
+			}
 
 			long const ncells_bad = sumFlags(redoFlag);
 			if (ncells_bad > 0) {
@@ -416,8 +541,8 @@ struct HydroSim {
 					std::printf("[FOFC-1] flux correcting %ld cells\n", ncells_bad);
 				}
 				FillBoundary(redoFlag, geom);
-				replaceFluxes(fluxArrays, FOfluxArrays, redoFlag);
-				replaceFluxes(faceVel, FOfaceVel, redoFlag);
+				replaceFluxes(fluxArrays, needFO().first, redoFlag);
+				replaceFluxes(faceVel, needFO().second, redoFlag);
 				rhsPdvPredict(rhs, fluxArrays, faceVel, stateOld, stateNew, dt_lev, redoFlag);
 				long const ncells_bad2 = sumFlags(redoFlag);
 				if (ncells_bad2 > 0) {
@@ -426,28 +551,54 @@ struct HydroSim {
 					}
 				}
 			}
-			limitsAndSync(stateNew);
+			{
+				ProfScope const ps(this, "limits + dual energy");
+				limitsAndSync(stateNew);
+			}
+			if (pooled) {
+				pool_.fluxes.push_back(std::move(fv1)); // (handed out again by the next flux evaluation)
+			}
 		}
 
 		// Stage 2 of RK2-SSP (:1202-1287)
 		if (integratorOrder_ == 2) {
-			fillBC(state_inter_cc_, time + dt_lev);
+			{
+				ProfScope const ps(this, "fill ghosts");
+				fillBC(state_inter_cc_, time + dt_lev);
+			}
 
 			auto const &stateOld = state_old_cc_tmp;
 			auto const &stateInter = state_inter_cc_;
 			auto &stateFinal = state_new_cc_;
-			auto [fluxArrays, faceVel] = computeHydroFluxes(stateInter, nc);
+			auto fv2 = [&] {
+				ProfScope const ps(this, "hydro fluxes");
+				return computeHydroFluxes(stateInter, nc);
+			}();
+			auto &fluxArrays = fv2.first;
+			auto &faceVel = fv2.second;
 
-			for (int idim = 0; idim < ndim(); ++idim) {
-				Saxpy(flux_rk2[idim], 0.5, fluxArrays[idim], nc);
-				Saxpy(avgFaceVel[idim], 0.5, faceVel[idim], 1);
+			{
+				ProfScope const ps(this, "flux_rk2 += 0.5 F");
+				for (int idim = 0; idim < ndim(); ++idim) {
+					Saxpy(flux_rk2[idim], 0.5, fluxArrays[idim], nc);
+					Saxpy(avgFaceVel[idim], 0.5, faceVel[idim], 1);
+				}
 			}
 
-			MultiFab rhs(grids, nc, 0, ndim());
-			iMultiFab redoFlag(grids, 1, 1, ndim());
+			std::optional<MultiFab> localRhs;
+			std::optional<iMultiFab> localRedo;
+			if (!pooled) {
+				localRhs.emplace(grids, nc, 0, ndim());
+				localRedo.emplace(grids, 1, 1, ndim());
+			}
+			MultiFab &rhs = pooled ? *pool_.rhs : *localRhs;
+			iMultiFab &redoFlag = pooled ? *pool_.redo : *localRedo;
 			redoFlag.setVal(redo_none);
 
-			rhsPdvPredict(rhs, flux_rk2, avgFaceVel, stateOld, stateFinal, dt_lev, redoFlag);
+			{
+				ProfScope const ps(this, "rhs + PdV + PredictStep");
+				rhsPdvPredict(rhs, flux_rk2, avgFaceVel, stateOld, stateFinal, dt_lev, redoFlag);
+			}
 
 			long const ncells_bad = sumFlags(redoFlag);
 			if (ncells_bad > 0) {
@@ -456,8 +607,8 @@ struct HydroSim {
 					std::printf("[FOFC-2] flux correcting %ld cells\n", ncells_bad);
 				}
 				FillBoundary(redoFlag, geom);
-				replaceFluxes(flux_rk2, FOfluxArrays, redoFlag);
-				replaceFluxes(avgFaceVel, FOfaceVel, redoFlag);
+				replaceFluxes(flux_rk2, needFO().first, redoFlag);
+				replaceFluxes(avgFaceVel, needFO().second, redoFlag);
 				rhsPdvPredict(rhs, flux_rk2, avgFaceVel, stateOld, stateFinal, dt_lev, redoFlag);
 				long const ncells_bad2 = sumFlags(redoFlag);
 				if (ncells_bad2 > 0) {
@@ -466,7 +617,13 @@ struct HydroSim {
 					}
 				}
 			}
-			limitsAndSync(stateFinal);
+			{
+				ProfScope const ps(this, "limits + dual energy");
+				limitsAndSync(stateFinal);
+			}
+			if (pooled) {
+				pool_.fluxes.push_back(std::move(fv2));
+			}
 		} else {
 			// :1289 forward Euler: copy hydro comps of the valid region
 			copyValid(state_new_cc_, state_inter_cc_, nc);
@@ -506,8 +663,22 @@ struct HydroSim {
 			if (retry_count > 0) {
 				++retries;
 			}
-			// :939-940 temporary copy of the old state (with ghosts)
-			MultiFab state_old_cc_tmp = state_old_cc_;
+			// :939-940 temporary copy of the old state (with ghosts); the fused leg copies into an array it keeps (StepPool)
+			std::optional<MultiFab> localTmp;
+			if (use_fused_fluxes) {
+				if (!pool_.oldTmp) {
+					pool_.oldTmp.emplace(state_old_cc_);
+				} else {
+					const int nb = state_old_cc_.size();
+					_Pragma("omp parallel for schedule(static)")
+					for (int b = 0; b < nb; ++b) {
+						std::copy(state_old_cc_.fabs[b].d.begin(), state_old_cc_.fabs[b].d.end(), pool_.oldTmp->fabs[b].d.begin());
+					}
+				}
+			} else {
+				localTmp.emplace(state_old_cc_);
+			}
+			MultiFab &state_old_cc_tmp = use_fused_fluxes ? *pool_.oldTmp : *localTmp;
 			for (int substep = 0; substep < nsubsteps; ++substep) {
 				if (substep > 0) {
 					// :947 amrex::Copy(state_old_cc_tmp, state_new_cc_, 0, 0, ncompHydro_, nghost_cc_)

@@ -385,6 +385,23 @@ void orc_sim_rad_transport_only(void *p, double dt_radiation)
 	s->advanceRadiationForwardEuler(s->tNew_, dt_radiation);
 	s->advanceRadiationMidpointRK2(s->tNew_, dt_radiation);
 }
+// the fused, vectorised flux evaluation (hydro_fused.hpp) instead of the operator sequence: same bits (tests/test_oracle_fused_cpu.py)
+void orc_sim_set_fused_fluxes(void *p, int on) { static_cast<HydroSim *>(p)->use_fused_fluxes = (on != 0); }
+// both forms of the flux evaluation on the sim's CURRENT state_new (ghost cells filled here): flux[d] as [6][faces] + face velocity [faces], x fastest
+int orc_sim_hydro_fluxes(void *p, int fused, int b, int dir, double *flux_out, double *vel_out)
+{
+	auto *s = static_cast<HydroSim *>(p);
+	s->fillBC(s->state_new_cc_, s->tNew_);
+	bool const keep = s->use_fused_fluxes;
+	s->use_fused_fluxes = (fused != 0);
+	auto fv = s->computeHydroFluxes(s->state_new_cc_, s->ncompHydro());
+	s->use_fused_fluxes = keep;
+	auto const &F = fv.first[dir].fabs[b].d;
+	auto const &V = fv.second[dir].fabs[b].d;
+	std::copy(F.begin(), F.end(), flux_out);
+	std::copy(V.begin(), V.end(), vel_out);
+	return static_cast<int>(V.size());
+}
 // one coarse step with the reference's own dt control; returns 1 on success
 int orc_sim_step(void *p)
 {

@@ -354,6 +354,22 @@ class OracleSim:
     def evolve(self) -> bool:
         return bool(self.o.lib.orc_sim_evolve(self.h))
 
+    def set_fused_fluxes(self, on: bool):
+        """the fused, vectorised flux evaluation (oracle/hydro_fused.hpp) instead of the operator sequence: the same bits, one pass per box"""
+        self.o.lib.orc_sim_set_fused_fluxes.argtypes = [C.c_void_p, C.c_int]
+        self.o.lib.orc_sim_set_fused_fluxes(self.h, int(bool(on)))
+
+    def hydro_fluxes(self, b: int, direction: int, fused: bool):
+        """(flux[6, faces...], face velocity) of box b from the current state_new (ghost cells filled here), by either form"""
+        lo, hi = self.box(b)
+        n = [hi[d] - lo[d] + 1 + (1 if d == direction else 0) for d in range(3)]
+        F = np.empty((6, n[2], n[1], n[0]))
+        V = np.empty((n[2], n[1], n[0]))
+        f = self.o.lib.orc_sim_hydro_fluxes
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        assert f(self.h, int(bool(fused)), int(b), int(direction), _dp(F), _dp(V)) == V.size
+        return F, V
+
     def rad_transport_only(self, dt_radiation: float):
         self.o.lib.orc_sim_rad_transport_only(self.h, float(dt_radiation))
 
