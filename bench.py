@@ -81,7 +81,7 @@ def parse():
     ap.add_argument("--developed-only", action="store_true", help="only the `developed` block (its own JSON line; profiling the kernels in developed flow)")
     ap.add_argument("--long-steps", type=int, default=100, help="steps (and warm-up steps) of the long_run secondary figure")
     ap.add_argument("--cpu-ncell", type=int, default=128)
-    ap.add_argument("--cpu-steps", type=int, default=24)  # ~15 s of CPU work on 16 cores
+    ap.add_argument("--cpu-steps", type=int, default=400)  # at most; the sample ends after ~12 s of wall time (cpu_baseline)
     return ap.parse_args()
 
 
@@ -115,7 +115,8 @@ def weak_scaled_cells(n: int, ngpus: int):
 
 def usable_cores():
     """(threads to use, description): the affinity mask, capped by the cgroup CPU quota (the GPU boxes show 256 CPUs but
-    grant 16 CPUs' worth of time; running more threads than ~2x the quota gets throttled and is slower)"""
+    grant 16 CPUs' worth of time; one thread per granted CPU is fastest — profiles/round5/cpu_leg_v1.txt: 49 / 32 / 18 M cell-updates/s with
+    16 / 32 / 64 threads, the extra threads spend the quota early in each period and the whole job is throttled)"""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     note = f"{n} schedulable CPUs"
     try:
@@ -123,14 +124,18 @@ def usable_cores():
         if quota != "max":
             q = float(quota) / float(period)
             note += f", cgroup quota {q:g} CPUs"
-            n = max(1, min(n, int(round(2 * q))))
+            n = max(1, min(n, int(round(q))))
     except (OSError, ValueError):
         pass
     return n, note
 
 
-def cpu_baseline(ncell: int, steps: int):
-    """Oracle (port of the reference algorithm, built with g++ -O3 -ffp-contract=off -fopenmp) on the host cores."""
+def cpu_baseline(ncell: int, steps: int, seconds: float = 12.0):
+    """Oracle (port of the reference algorithm, built with g++ -O3 -ffp-contract=off -fopenmp) on the host cores, in its fused form: per box one
+    pass forms the primitives and flattening coefficients into L2-sized scratch, sweeps the three directions row by row with x innermost (PPM
+    edges in row buffers, HLLC with selects, AVX-512 / AVX2 clones picked at load time), adds 0.5 F to the RK2 flux sum while F is in registers and
+    applies the update, the limits and the dual-energy sync (oracle/hydro_fused.hpp).  Bit-identical to the operator-at-a-time form every GPU
+    parity test is held to (tests/test_oracle_fused_cpu.py) — what the reference's "MPI + vectorised CPU" build does with AMReX tiling."""
     from oracle.pyoracle import SEDOV, Oracle
     threads, note = usable_cores()
     if "OMP_NUM_THREADS" in os.environ:
@@ -138,16 +143,22 @@ def cpu_baseline(ncell: int, steps: int):
     os.environ["OMP_NUM_THREADS"] = str(threads)
     o = Oracle("direct")
     s = o.sim(SEDOV, 3, [ncell] * 3, [0, 0, 0], [1.2] * 3, [0, 0, 0], max_grid_size=[32] * 3)
-    assert s.step()  # warm-up (page-in)
-    t0 = time.perf_counter()
-    for _ in range(steps):
+    s.set_fused_fluxes(True)
+    for _ in range(2):  # warm-up: page-in, and the step's temporaries enter the sim's pool
         assert s.step()
+    t0 = time.perf_counter()
+    done = 0
+    while done < steps and time.perf_counter() - t0 < seconds:  # a bounded sample: `steps` steps or `seconds` of wall time, whichever first
+        assert s.step()
+        done += 1
     el = time.perf_counter() - t0
+    steps = done
     value = ncell ** 3 * steps / el / 1e6
     m = re.search(r"cgroup quota ([\d.]+) CPUs", note)
     cpus = min(float(threads), float(m.group(1))) if m else float(threads)  # the CPU time actually granted: the quota when it is below the thread count
     return {"value": value, "unit": "Mcell-updates/s", "cores": threads, "kind": "port", "cpus_granted": cpus, "value_per_granted_cpu": value / cpus,
-            "sample": f"Sedov {ncell}^3 in 32^3 boxes, {steps} RK2 steps in {el:.1f} s, OpenMP over (box, 4-plane slab) tasks, {threads} threads ({note}); "
+            "form": "fused per box, x-vectorised (oracle/hydro_fused.hpp); bit-identical to the operator-at-a-time oracle",
+            "sample": f"Sedov {ncell}^3 in 32^3 boxes, {steps} RK2 steps in {el:.1f} s, OpenMP over boxes, {threads} threads ({note}); "
                       "CPU restatement of the reference algorithm, not the reference binary"}
 
 

@@ -97,9 +97,15 @@ __attribute__((always_inline)) inline void edgesRow(const double *__restrict q, 
 // One row of faces: left states L[6][*] (right edges of the cells before the faces), right states R[6][*] (left edges of the cells after them);
 // pR[c] = the primitive component c at the cell AFTER the first face, its neighbour before the face is sd earlier, the transverse neighbours of the
 // carbuncle differences sV / sW away.  hydro_system.hpp:881-1110 + HLLC.hpp:22-153, DIR selects the velocity permutation (:954-976).
-template <int DIR>
+//
+// MODE: what becomes of the row's fluxes F and face velocities v (QuokkaSimulation.hpp:1117-1127, :1219-1229: flux_rk2 += 0.5 F after every stage's
+// flux evaluation, here done while the row is in registers):
+//   0  F, v stored
+//   1  F, v stored and the accumulators SET to 0.0 + 0.5 F (what Saxpy onto the cleared flux_rk2 computes, sign of zero included)
+//   2  the accumulators += 0.5 F; F and v themselves are not kept (stage 2 needs only the sum)
+template <int DIR, int MODE>
 __attribute__((always_inline)) inline void fluxRow(double gamma, double kB_user, double K_visc, int n, const double *const *L, const double *const *R, const double *const *pR, int64_t sd, int64_t sV, int64_t sW,
-		    double *const *Fout, double *__restrict Vout)
+		    double *const *Fout, double *__restrict Vout, double *const *Acc, double *__restrict Vacc)
 {
 	constexpr int velN = x1Velocity_index + DIR, velV = x1Velocity_index + (DIR + 1) % 3, velW = x1Velocity_index + (DIR + 2) % 3;
 	const double gm1 = gamma - 1.0;
@@ -202,10 +208,27 @@ __attribute__((always_inline)) inline void fluxRow(double gamma, double kB_user,
 		F[velN] = Fc[x1Momentum_index];
 		F[velV] = Fc[x2Momentum_index];
 		F[velW] = Fc[x3Momentum_index];
-		Vout[e] = (F[density_index] >= 0.) ? (F[density_index] / rho_R) : (F[density_index] / rho_L);
+		const double vface = (F[density_index] >= 0.) ? (F[density_index] / rho_R) : (F[density_index] / rho_L);
+		if constexpr (MODE != 2) {
+			Vout[e] = vface;
 #pragma GCC unroll 6
-		for (int m = 0; m < 6; ++m) {
-			Fout[m][e] = F[m];
+			for (int m = 0; m < 6; ++m) {
+				Fout[m][e] = F[m];
+			}
+		}
+		if constexpr (MODE == 1) {
+			Vacc[e] = 0.0 + 0.5 * vface;
+#pragma GCC unroll 6
+			for (int m = 0; m < 6; ++m) {
+				Acc[m][e] = 0.0 + 0.5 * F[m];
+			}
+		}
+		if constexpr (MODE == 2) {
+			Vacc[e] = Vacc[e] + 0.5 * vface;
+#pragma GCC unroll 6
+			for (int m = 0; m < 6; ++m) {
+				Acc[m][e] = Acc[m][e] + 0.5 * F[m];
+			}
 		}
 	}
 }
@@ -220,18 +243,33 @@ inline auto fusedHydroFluxesApplicable(HydroTraits const &tr, int reconstruction
 	       reconstructionOrder == 3 && !is_mhd;
 }
 
-// fluxes and face velocities of one box from its ghost-filled conserved state (4 ghost cells); F[d], V[d]: nodal in d, no ghost cells
+// fluxes and face velocities of one box from its ghost-filled conserved state (4 ghost cells); F[d], V[d]: nodal in d, no ghost cells.
+// mode 0: F, V written.  mode 1: F, V written and Facc, Vacc = 0.0 + 0.5 F (stage 1 of RK2: the Saxpy onto the cleared flux_rk2).
+// mode 2: Facc, Vacc += 0.5 F and F, V are not touched (stage 2).
 void fusedHydroFluxesBox(HydroTraits const &tr, Array4<const double> const &U, Box const &vb, std::array<Array4<double>, 3> const &F,
-			 std::array<Array4<double>, 3> const &V, double K_visc, fused::Work &w);
+			 std::array<Array4<double>, 3> const &V, double K_visc, fused::Work &w, int mode = 0, std::array<Array4<double>, 3> const &Facc = {},
+			 std::array<Array4<double>, 3> const &Vacc = {});
+
+// What follows a stage's flux evaluation for the cells of one box (HydroSimulation::rhsPdvPredict + limitsAndSync; reference
+// src/hydro/hydro_system.hpp:448-497 ComputeRhsFromFluxes + PredictStep, :775-814 AddInternalEnergyPdV, :696-773 EnforceLimits, :816-850
+// SyncDualEnergy) in ONE pass over rows of x: Unew = limits(Uold + dt * rhs(F, V)), redo(i,j,k) = the flag PredictStep sets from the state BEFORE
+// the limits.  Returns the number of flagged cells; when any box returns non-zero the caller discards Unew and takes the operator path
+// (first-order flux correction), which rewrites every cell this function wrote.
+auto fusedHydroUpdateBox(HydroTraits const &tr, Array4<const double> const &Uold, Array4<double> const &Unew, Box const &vb,
+			 std::array<Array4<const double>, 3> const &F, std::array<Array4<const double>, 3> const &V, double const dx[3], double dt, double densityFloor,
+			 double tempFloor, bool dualEnergy, Array4<int> const &redo) -> long;
 
 #ifdef ORACLE_FUSED_IMPL
 // fluxes and face velocities of one box from its ghost-filled conserved state (4 ghost cells); F[d], V[d]: nodal in d, no ghost cells.
 // One clone per vector ISA, chosen when the library loads (the .so is built in one container and run on another machine's host cores); vector
 // width changes no bit: every lane does the scalar arithmetic, and -ffp-contract=off keeps multiply-adds apart in every clone.
-__attribute__((target_clones("avx512f", "avx2", "default"))) void fusedHydroFluxesBox(HydroTraits const &tr, Array4<const double> const &U, Box const &vb, std::array<Array4<double>, 3> const &F,
-				std::array<Array4<double>, 3> const &V, double K_visc, fused::Work &w)
+namespace fused
 {
-	using namespace fused;
+template <int MODE>
+__attribute__((always_inline)) inline void fluxesBoxImpl(HydroTraits const &tr, Array4<const double> const &U, Box const &vb, std::array<Array4<double>, 3> const &F,
+						       std::array<Array4<double>, 3> const &V, double K_visc, fused::Work &w, std::array<Array4<double>, 3> const &Facc,
+						       std::array<Array4<double>, 3> const &Vacc)
+{
 	const double gamma = tr.gamma();
 	const double gm1 = gamma - 1.0;
 	const double kBu = tr.eos.tr.boltzmann_constant;
@@ -336,14 +374,20 @@ __attribute__((target_clones("avx512f", "avx2", "default"))) void fusedHydroFlux
 				edgesRow(P[n] + o, sx, w.chim.data() + o, n0 + 2, am[n], ap[n]);
 			}
 			const double *Lp[6], *Rp[6], *pR[6];
-			double *Fo[6];
+			double *Fo[6] = {}, *Ao[6] = {};
 			for (int n = 0; n < 6; ++n) {
 				Lp[n] = ap[n];	   // cell lo-1+e is the cell before face lo+e
 				Rp[n] = am[n] + 1; // cell lo+e
 				pR[n] = P[n] + o + 1;
-				Fo[n] = &F[0](vb.lo[0], j, k, n);
+				if constexpr (MODE != 2) {
+					Fo[n] = &F[0](vb.lo[0], j, k, n);
+				}
+				if constexpr (MODE != 0) {
+					Ao[n] = &Facc[0](vb.lo[0], j, k, n);
+				}
 			}
-			fluxRow<0>(gamma, kBu, K_visc, n0 + 1, Lp, Rp, pR, sx, sy, sz, Fo, &V[0](vb.lo[0], j, k, 0));
+			fluxRow<0, MODE>(gamma, kBu, K_visc, n0 + 1, Lp, Rp, pR, sx, sy, sz, Fo, (MODE != 2) ? &V[0](vb.lo[0], j, k, 0) : nullptr, Ao,
+					 (MODE != 0) ? &Vacc[0](vb.lo[0], j, k, 0) : nullptr);
 		}
 	}
 	// ---- Y and Z: march along the direction, rows of x; the right edges of the previous row are the left states of the faces between the rows
@@ -360,22 +404,145 @@ __attribute__((target_clones("avx512f", "avx2", "default"))) void fusedHydroFlux
 				}
 				if (m >= vb.lo[d]) { // the face between rows m-1 and m
 					const double *Lp[6], *Rp[6], *pR[6];
-					double *Fo[6];
+					double *Fo[6] = {}, *Ao[6] = {};
 					for (int n = 0; n < 6; ++n) {
 						Lp[n] = apPrev[n];
 						Rp[n] = am[n];
 						pR[n] = P[n] + o;
-						Fo[n] = &F[d](vb.lo[0], j, k, n);
+						if constexpr (MODE != 2) {
+							Fo[n] = &F[d](vb.lo[0], j, k, n);
+						}
+						if constexpr (MODE != 0) {
+							Ao[n] = &Facc[d](vb.lo[0], j, k, n);
+						}
 					}
+					double *const Vo = (MODE != 2) ? &V[d](vb.lo[0], j, k, 0) : nullptr;
+					double *const Va = (MODE != 0) ? &Vacc[d](vb.lo[0], j, k, 0) : nullptr;
 					if (d == 1) {
-						fluxRow<1>(gamma, kBu, K_visc, n0, Lp, Rp, pR, sy, sz, sx, Fo, &V[1](vb.lo[0], j, k, 0));
+						fluxRow<1, MODE>(gamma, kBu, K_visc, n0, Lp, Rp, pR, sy, sz, sx, Fo, Vo, Ao, Va);
 					} else {
-						fluxRow<2>(gamma, kBu, K_visc, n0, Lp, Rp, pR, sz, sx, sy, Fo, &V[2](vb.lo[0], j, k, 0));
+						fluxRow<2, MODE>(gamma, kBu, K_visc, n0, Lp, Rp, pR, sz, sx, sy, Fo, Vo, Ao, Va);
 					}
 				}
 			}
 		}
 	}
+}
+} // namespace fused
+
+__attribute__((target_clones("avx512f", "avx2", "default"))) void fusedHydroFluxesBox(HydroTraits const &tr, Array4<const double> const &U, Box const &vb, std::array<Array4<double>, 3> const &F,
+				std::array<Array4<double>, 3> const &V, double K_visc, fused::Work &w, int mode, std::array<Array4<double>, 3> const &Facc,
+				std::array<Array4<double>, 3> const &Vacc)
+{
+	if (mode == 1) {
+		fused::fluxesBoxImpl<1>(tr, U, vb, F, V, K_visc, w, Facc, Vacc);
+	} else if (mode == 2) {
+		fused::fluxesBoxImpl<2>(tr, U, vb, F, V, K_visc, w, Facc, Vacc);
+	} else {
+		fused::fluxesBoxImpl<0>(tr, U, vb, F, V, K_visc, w, Facc, Vacc);
+	}
+}
+
+__attribute__((target_clones("avx512f", "avx2", "default"))) auto fusedHydroUpdateBox(HydroTraits const &tr, Array4<const double> const &Uold, Array4<double> const &Unew, Box const &vb,
+				std::array<Array4<const double>, 3> const &F, std::array<Array4<const double>, 3> const &V, double const dx[3], double dt,
+				double densityFloor, double tempFloor, bool dualEnergy, Array4<int> const &redo) -> long
+{
+	const double gamma = tr.gamma();
+	const double gm1 = gamma - 1.0;
+	const double kBu = tr.eos.tr.boltzmann_constant;
+	const double mu = tr.eos.tr.mean_molecular_weight / C::m_u; // (estate.mu of EOS.hpp:74-159)
+	const double m_nucleon = C::m_u;
+	const double idx0 = 1.0 / dx[0], idx1 = 1.0 / dx[1], idx2 = 1.0 / dx[2];
+	const double dx0 = dx[0], dx1 = dx[1], dx2 = dx[2];
+	constexpr double tiny = std::numeric_limits<double>::min();
+	constexpr double eta = 1.0e-3;
+	const int n0 = vb.length(0);
+	const int64_t nso = Uold.nstride, nsn = Unew.nstride;
+	long nbad = 0;
+	for (int k = vb.lo[2]; k <= vb.hi[2]; ++k) {
+		for (int j = vb.lo[1]; j <= vb.hi[1]; ++j) {
+			const double *__restrict uo = &Uold(vb.lo[0], j, k, 0);
+			double *__restrict un = &Unew(vb.lo[0], j, k, 0);
+			int *__restrict rf = &redo(vb.lo[0], j, k);
+			const double *fx[6], *fy[6], *fyp[6], *fz[6], *fzp[6];
+			for (int m = 0; m < 6; ++m) {
+				fx[m] = &F[0](vb.lo[0], j, k, m);
+				fy[m] = &F[1](vb.lo[0], j, k, m);
+				fyp[m] = &F[1](vb.lo[0], j + 1, k, m);
+				fz[m] = &F[2](vb.lo[0], j, k, m);
+				fzp[m] = &F[2](vb.lo[0], j, k + 1, m);
+			}
+			const double *__restrict vx = &V[0](vb.lo[0], j, k, 0);
+			const double *__restrict vy = &V[1](vb.lo[0], j, k, 0);
+			const double *__restrict vyp = &V[1](vb.lo[0], j + 1, k, 0);
+			const double *__restrict vz = &V[2](vb.lo[0], j, k, 0);
+			const double *__restrict vzp = &V[2](vb.lo[0], j, k + 1, 0);
+			long bad = 0;
+#pragma omp simd reduction(+ : bad)
+			for (int e = 0; e < n0; ++e) {
+				const double rho = uo[e], px = uo[e + nso], py = uo[e + 2 * nso], pz = uo[e + 3 * nso], E = uo[e + 4 * nso], Eaux = uo[e + 5 * nso];
+				const double old[6] = {rho, px, py, pz, E, Eaux};
+				// ---- ComputeRhsFromFluxes (:448-473)
+				double r[6];
+#pragma GCC unroll 6
+				for (int m = 0; m < 6; ++m) {
+					double q = idx0 * (fx[m][e] - fx[m][e + 1]);
+					q = q + idx1 * (fy[m][e] - fyp[m][e]);
+					q = q + idx2 * (fz[m][e] - fzp[m][e]);
+					r[m] = q;
+				}
+				// ---- AddInternalEnergyPdV (:775-814), the branch of an unflagged cell (every flag is redo_none when a stage starts)
+				const double ux = px / rho, uy = py / rho, uz = pz / rho;
+				const double kinetic_energy = 0.5 * rho * (ux * ux + uy * uy + uz * uz);
+				const double thermal_energy = E - kinetic_energy;
+				const double es = (rho == 0.0) ? 0.0 : thermal_energy / rho;
+				const double Pgas = gm1 * rho * es;
+				double div_v = (vx[e + 1] - vx[e]) / dx0;
+				div_v = div_v + (vyp[e] - vy[e]) / dx1;
+				div_v = div_v + (vzp[e] - vz[e]) / dx2;
+				r[5] = r[5] + (-Pgas * div_v);
+				// ---- PredictStep (:475-497)
+				double s[6];
+#pragma GCC unroll 6
+				for (int m = 0; m < 6; ++m) {
+					s[m] = old[m] + dt * r[m];
+				}
+				const bool valid = s[0] > 0.;
+				rf[e] = valid ? redo_none : redo_redo;
+				bad += valid ? 0 : 1;
+				// ---- EnforceLimits (:696-773; no scalars)
+				const double rho_new = (s[0] < densityFloor) ? densityFloor : s[0];
+				{
+					const double w1 = s[1] / rho_new, w2 = s[2] / rho_new, w3 = s[3] / rho_new;
+					const double Ekin = 0.5 * rho_new * (w1 * w1 + w2 * w2 + w3 * w3);
+					// ComputeTgasFromEint (EOS.hpp:74-114): T = e mu m_u (gamma - 1) / k_B with e = Eint / rho; Tgas = T k_B / k_B_user
+					const double primTemp = ((((((s[4] - Ekin) / rho_new) * mu) * m_nucleon) * gm1) / C::k_B) * C::k_B / kBu;
+					// ComputeEintFromTgas (EOS.hpp:116-159): p = rho T k_B / (mu m_u), e = p / ((gamma - 1) rho); Eint = e rho k_B_user / k_B
+					const double floorEint = (((((rho_new * tempFloor) * C::k_B) / (mu * m_nucleon)) / (gm1 * rho_new)) * rho_new) * kBu / C::k_B;
+					const double auxTemp = (((((s[5] / rho_new) * mu) * m_nucleon) * gm1) / C::k_B) * C::k_B / kBu;
+					const bool lim = rho_new > tiny;
+					s[4] = (lim && (primTemp < tempFloor)) ? (Ekin + floorEint) : s[4];
+					s[5] = (lim && (auxTemp < tempFloor)) ? floorEint : s[5];
+				}
+				s[0] = rho_new;
+				// ---- SyncDualEnergy (:816-850; its abort on a non-positive density is the operator path's to raise: such a cell is flagged above)
+				if (dualEnergy) {
+					const double Ekin = (s[1] * s[1] + s[2] * s[2] + s[3] * s[3]) / (2.0 * s[0]);
+					const double Eint_cons = s[4] - Ekin;
+					const bool keep = Eint_cons > eta * s[4];
+					const double Eint_aux = s[5];
+					s[5] = keep ? Eint_cons : Eint_aux;
+					s[4] = keep ? s[4] : (Eint_aux + Ekin);
+				}
+#pragma GCC unroll 6
+				for (int m = 0; m < 6; ++m) {
+					un[e + m * nsn] = s[m];
+				}
+			}
+			nbad += bad;
+		}
+	}
+	return nbad;
 }
 
 #endif // ORACLE_FUSED_IMPL

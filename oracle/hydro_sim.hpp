@@ -177,19 +177,12 @@ struct HydroSim {
 	// QuokkaSimulation.hpp:1403-1490
 	// the fused, vectorised form of computeHydroFluxes (hydro_fused.hpp; bench.py's cpu_baseline leg): same fluxes in every bit, one pass per box
 	bool use_fused_fluxes = false;
+	bool use_fused_stages = true; // with use_fused_fluxes: the whole stage box by box (fusedStage) where it applies
 	auto computeHydroFluxesFused(MultiFab const &consVar, int nvars) const -> std::pair<FluxArrays, FluxArrays>
 	{
-		FluxArrays flux, facevel;
-		if (!pool_.fluxes.empty() && pool_.fluxes.back().first[0].nc == nvars) { // every face is overwritten below: nothing to clear
-			flux = std::move(pool_.fluxes.back().first);
-			facevel = std::move(pool_.fluxes.back().second);
-			pool_.fluxes.pop_back();
-		} else {
-			for (int idim = 0; idim < 3; ++idim) {
-				flux[idim] = MultiFab(grids, nvars, 0, ndim(), idim);
-				facevel[idim] = MultiFab(grids, 1, 0, ndim(), idim);
-			}
-		}
+		auto fv = takeFluxSet(nvars); // every face is overwritten below: nothing to clear
+		FluxArrays &flux = fv.first;
+		FluxArrays &facevel = fv.second;
 		const int nb = consVar.size();
 		_Pragma("omp parallel")
 		{
@@ -198,6 +191,55 @@ struct HydroSim {
 			for (int b = 0; b < nb; ++b) {
 				fusedHydroFluxesBox(hydro.tr, consVar.const_array(b), grids[b], {flux[0].array(b), flux[1].array(b), flux[2].array(b)},
 						    {facevel[0].array(b), facevel[1].array(b), facevel[2].array(b)}, artificialViscosityK_, work);
+			}
+		}
+		return fv;
+	}
+
+	// One RK stage of the fused leg, box by box with no pass over the level in between: the stage's fluxes of `fluxInput` (stage 1: kept in `fv` and
+	// flux_rk2 = 0.5 F; stage 2: flux_rk2 += 0.5 F), then the update stateNew = limits(stateOld + dt rhs) from `fv` (stage 1) or from the
+	// accumulated flux_rk2 / avgFaceVel (stage 2).  Returns the number of cells PredictStep flagged (then the caller takes the operator path).
+	auto fusedStage(int stage, MultiFab const &fluxInput, MultiFab const &stateOld, MultiFab &stateNew, std::pair<FluxArrays, FluxArrays> &fv, FluxArrays &flux_rk2,
+			FluxArrays &avgFaceVel, double dt_lev, iMultiFab &redoFlag) const -> long
+	{
+		const int nb = fluxInput.size();
+		long nbad = 0;
+		_Pragma("omp parallel")
+		{
+			fused::Work work; // (one set of box-sized scratch arrays per thread)
+			_Pragma("omp for schedule(dynamic) reduction(+ : nbad)")
+			for (int b = 0; b < nb; ++b) {
+				std::array<Array4<double>, 3> F{}, V{};
+				if (stage == 1) {
+					F = {fv.first[0].array(b), fv.first[1].array(b), fv.first[2].array(b)};
+					V = {fv.second[0].array(b), fv.second[1].array(b), fv.second[2].array(b)};
+				}
+				std::array<Array4<double>, 3> const Fa{flux_rk2[0].array(b), flux_rk2[1].array(b), flux_rk2[2].array(b)};
+				std::array<Array4<double>, 3> const Va{avgFaceVel[0].array(b), avgFaceVel[1].array(b), avgFaceVel[2].array(b)};
+				fusedHydroFluxesBox(hydro.tr, fluxInput.const_array(b), grids[b], F, V, artificialViscosityK_, work, stage, Fa, Va);
+				FluxArrays const &uf = (stage == 1) ? fv.first : flux_rk2;
+				FluxArrays const &uv = (stage == 1) ? fv.second : avgFaceVel;
+				nbad += fusedHydroUpdateBox(hydro.tr, stateOld.const_array(b), stateNew.array(b), grids[b],
+							    {uf[0].const_array(b), uf[1].const_array(b), uf[2].const_array(b)},
+							    {uv[0].const_array(b), uv[1].const_array(b), uv[2].const_array(b)}, geom.dx, dt_lev, densityFloor_, tempFloor_,
+							    useDualEnergy_ == 1, redoFlag.array(b));
+			}
+		}
+		return nbad;
+	}
+
+	// a (flux, face velocity) set whose every face the caller overwrites: from the pool when one is there
+	auto takeFluxSet(int nvars) const -> std::pair<FluxArrays, FluxArrays>
+	{
+		FluxArrays flux, facevel;
+		if (!pool_.fluxes.empty() && pool_.fluxes.back().first[0].nc == nvars) {
+			flux = std::move(pool_.fluxes.back().first);
+			facevel = std::move(pool_.fluxes.back().second);
+			pool_.fluxes.pop_back();
+		} else {
+			for (int idim = 0; idim < 3; ++idim) {
+				flux[idim] = MultiFab(grids, nvars, 0, ndim(), idim);
+				facevel[idim] = MultiFab(grids, 1, 0, ndim(), idim);
 			}
 		}
 		return std::make_pair(std::move(flux), std::move(facevel));
@@ -405,7 +447,8 @@ struct HydroSim {
 
 	// QuokkaSimulation.hpp:1032-1322 (no Strang sources, no flux registers, no tracers)
 	// wall time per phase of advanceHydroAtLevel (ORACLE_PROF=1; printed by the destructor): where a CPU step spends its time
-	mutable std::map<std::string, double> profSeconds_;
+	mutable std::map<std::string, double> profSeconds_, profMin_;
+	mutable std::map<std::string, long> profCalls_;
 	bool const prof_ = std::getenv("ORACLE_PROF") != nullptr;
 	struct ProfScope {
 		HydroSim const *s;
@@ -415,7 +458,13 @@ struct HydroSim {
 		~ProfScope()
 		{
 			if (s->prof_) {
-				s->profSeconds_[name] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+				double const el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+				s->profSeconds_[name] += el;
+				auto it = s->profMin_.find(name);
+				if (it == s->profMin_.end() || el < it->second) {
+					s->profMin_[name] = el;
+				}
+				++s->profCalls_[name];
 			}
 		}
 	};
@@ -423,7 +472,8 @@ struct HydroSim {
 	{
 		if (prof_) {
 			for (auto const &kv : profSeconds_) {
-				std::fprintf(stderr, "[oracle prof] %-28s %9.3f s\n", kv.first.c_str(), kv.second);
+				std::fprintf(stderr, "[oracle prof] %-28s %9.3f s in %5ld calls, fastest call %8.3f ms\n", kv.first.c_str(), kv.second, profCalls_[kv.first],
+					     1e3 * profMin_[kv.first]);
 			}
 		}
 	}
@@ -454,7 +504,13 @@ struct HydroSim {
 			localInter.emplace(grids, ncomp_cc, nghost_cc, ndim());
 		}
 		MultiFab &state_inter_cc_ = pooled ? *pool_.inter : *localInter;
-		state_inter_cc_.setVal(0);
+		// whole stages box by box (fusedStage) where the fused flux evaluation applies and the state is the six hydro variables
+		const bool stagesFused = pooled && use_fused_stages && state_old_cc_tmp.ng == 4 && ncomp_cc == nc && nc == 6 &&
+					 fusedHydroFluxesApplicable(hydro.tr, reconstructionOrder_, is_mhd_enabled);
+		if (!(stagesFused && pool_.defined)) { // (a fused stage writes every valid cell and the ghost fill the same ghost cells every step: what is
+						       //  never written stays the zero of the first step's clear)
+			state_inter_cc_.setVal(0);
+		}
 
 		FluxArrays localRk2, localVel;
 		FluxArrays &flux_rk2 = pooled ? pool_.flux_rk2 : localRk2;
@@ -469,8 +525,10 @@ struct HydroSim {
 				flux_rk2[idim] = MultiFab(grids, nc, 0, ndim(), idim);
 				avgFaceVel[idim] = MultiFab(grids, 1, nghost_vel, ndim(), idim);
 			}
-			flux_rk2[idim].setVal(0);
-			avgFaceVel[idim].setVal(0);
+			if (!stagesFused) { // (stage 1 of the fused leg SETS them to 0.0 + 0.5 F)
+				flux_rk2[idim].setVal(0);
+				avgFaceVel[idim].setVal(0);
+			}
 		}
 		if (pooled && !pool_.defined) {
 			pool_.rhs.emplace(grids, nc, 0, ndim());
@@ -505,13 +563,16 @@ struct HydroSim {
 			auto const &stateOld = state_old_cc_tmp;
 			auto &stateNew = state_inter_cc_;
 			auto fv1 = [&] {
+				if (stagesFused) {
+					return takeFluxSet(nc);
+				}
 				ProfScope const ps(this, "hydro fluxes");
 				return computeHydroFluxes(stateOld, nc);
 			}();
 			auto &fluxArrays = fv1.first;
 			auto &faceVel = fv1.second;
 
-			{
+			if (!stagesFused) {
 				ProfScope const ps(this, "flux_rk2 += 0.5 F");
 				for (int idim = 0; idim < ndim(); ++idim) {
 					Saxpy(flux_rk2[idim], 0.5, fluxArrays[idim], nc);
@@ -529,12 +590,15 @@ struct HydroSim {
 			iMultiFab &redoFlag = pooled ? *pool_.redo : *localRedo;
 			redoFlag.setVal(redo_none);
 
-			{
+			long ncells_bad = 0;
+			if (stagesFused) {
+				ProfScope const ps(this, "fused stage");
+				ncells_bad = fusedStage(1, stateOld, stateOld, stateNew, fv1, flux_rk2, avgFaceVel, dt_lev, redoFlag);
+			} else {
 				ProfScope const ps(this, "rhs + PdV + PredictStep");
 				rhsPdvPredict(rhs, fluxArrays, faceVel, stateOld, stateNew, dt_lev, redoFlag);
+				ncells_bad = sumFlags(redoFlag);
 			}
-
-			long const ncells_bad = sumFlags(redoFlag);
 			if (ncells_bad > 0) {
 				fofc1_cells += ncells_bad;
 				if (verbose != 0) {
@@ -551,7 +615,7 @@ struct HydroSim {
 					}
 				}
 			}
-			{
+			if (!stagesFused || ncells_bad > 0) { // (a fused stage applied them itself; after a flux correction the operator path redid the cells)
 				ProfScope const ps(this, "limits + dual energy");
 				limitsAndSync(stateNew);
 			}
@@ -570,14 +634,17 @@ struct HydroSim {
 			auto const &stateOld = state_old_cc_tmp;
 			auto const &stateInter = state_inter_cc_;
 			auto &stateFinal = state_new_cc_;
-			auto fv2 = [&] {
+			auto fv2 = [&]() -> std::pair<FluxArrays, FluxArrays> {
+				if (stagesFused) {
+					return {}; // (stage 2 of the fused leg adds 0.5 F to flux_rk2 as it forms F and keeps no F)
+				}
 				ProfScope const ps(this, "hydro fluxes");
 				return computeHydroFluxes(stateInter, nc);
 			}();
 			auto &fluxArrays = fv2.first;
 			auto &faceVel = fv2.second;
 
-			{
+			if (!stagesFused) {
 				ProfScope const ps(this, "flux_rk2 += 0.5 F");
 				for (int idim = 0; idim < ndim(); ++idim) {
 					Saxpy(flux_rk2[idim], 0.5, fluxArrays[idim], nc);
@@ -595,12 +662,15 @@ struct HydroSim {
 			iMultiFab &redoFlag = pooled ? *pool_.redo : *localRedo;
 			redoFlag.setVal(redo_none);
 
-			{
+			long ncells_bad = 0;
+			if (stagesFused) {
+				ProfScope const ps(this, "fused stage");
+				ncells_bad = fusedStage(2, stateInter, stateOld, stateFinal, fv2, flux_rk2, avgFaceVel, dt_lev, redoFlag);
+			} else {
 				ProfScope const ps(this, "rhs + PdV + PredictStep");
 				rhsPdvPredict(rhs, flux_rk2, avgFaceVel, stateOld, stateFinal, dt_lev, redoFlag);
+				ncells_bad = sumFlags(redoFlag);
 			}
-
-			long const ncells_bad = sumFlags(redoFlag);
 			if (ncells_bad > 0) {
 				fofc2_cells += ncells_bad;
 				if (verbose != 0) {
@@ -617,11 +687,11 @@ struct HydroSim {
 					}
 				}
 			}
-			{
+			if (!stagesFused || ncells_bad > 0) {
 				ProfScope const ps(this, "limits + dual energy");
 				limitsAndSync(stateFinal);
 			}
-			if (pooled) {
+			if (pooled && !stagesFused) {
 				pool_.fluxes.push_back(std::move(fv2));
 			}
 		} else {
@@ -630,6 +700,7 @@ struct HydroSim {
 		}
 
 		// :1321
+		ProfScope const ps(this, "isCflViolated");
 		return !isCflViolated(dt_lev);
 	}
 
@@ -665,6 +736,8 @@ struct HydroSim {
 			}
 			// :939-940 temporary copy of the old state (with ghosts); the fused leg copies into an array it keeps (StepPool)
 			std::optional<MultiFab> localTmp;
+			std::optional<ProfScope> psCopy;
+			psCopy.emplace(this, "copy of the old state");
 			if (use_fused_fluxes) {
 				if (!pool_.oldTmp) {
 					pool_.oldTmp.emplace(state_old_cc_);
@@ -679,6 +752,7 @@ struct HydroSim {
 				localTmp.emplace(state_old_cc_);
 			}
 			MultiFab &state_old_cc_tmp = use_fused_fluxes ? *pool_.oldTmp : *localTmp;
+			psCopy.reset();
 			for (int substep = 0; substep < nsubsteps; ++substep) {
 				if (substep > 0) {
 					// :947 amrex::Copy(state_old_cc_tmp, state_new_cc_, 0, 0, ncompHydro_, nghost_cc_)
@@ -1016,7 +1090,11 @@ struct HydroSim {
 	auto step() -> bool
 	{
 		g_spacedim = ndim(); // (the reference's AMREX_SPACEDIM: a 2-D build permutes the X2 views differently, hyperbolic.hpp)
-		computeTimestep();
+		ProfScope const psStep(this, "WHOLE STEP");
+		{
+			ProfScope const ps(this, "computeTimestep");
+			computeTimestep();
+		}
 		double const time = tNew_;
 		tNew_ += dt_;
 		std::swap(state_old_cc_, state_new_cc_);

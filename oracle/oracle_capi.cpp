@@ -386,7 +386,18 @@ void orc_sim_rad_transport_only(void *p, double dt_radiation)
 	s->advanceRadiationMidpointRK2(s->tNew_, dt_radiation);
 }
 // the fused, vectorised flux evaluation (hydro_fused.hpp) instead of the operator sequence: same bits (tests/test_oracle_fused_cpu.py)
-void orc_sim_set_fused_fluxes(void *p, int on) { static_cast<HydroSim *>(p)->use_fused_fluxes = (on != 0); }
+// the floors of EnforceLimits (QuokkaSimulation.hpp densityFloor_, tempFloor_: 0 by default)
+void orc_sim_set_limits(void *p, double densityFloor, double tempFloor)
+{
+	static_cast<HydroSim *>(p)->densityFloor_ = densityFloor;
+	static_cast<HydroSim *>(p)->tempFloor_ = tempFloor;
+}
+// on: 0 operator form; 1 fused flux evaluation only; 3 whole stages box by box as well (HydroSim::fusedStage)
+void orc_sim_set_fused_fluxes(void *p, int on)
+{
+	static_cast<HydroSim *>(p)->use_fused_fluxes = ((on & 1) != 0);
+	static_cast<HydroSim *>(p)->use_fused_stages = ((on & 2) != 0);
+}
 // both forms of the flux evaluation on the sim's CURRENT state_new (ghost cells filled here): flux[d] as [6][faces] + face velocity [faces], x fastest
 int orc_sim_hydro_fluxes(void *p, int fused, int b, int dir, double *flux_out, double *vel_out)
 {

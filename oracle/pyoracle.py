@@ -354,10 +354,16 @@ class OracleSim:
     def evolve(self) -> bool:
         return bool(self.o.lib.orc_sim_evolve(self.h))
 
-    def set_fused_fluxes(self, on: bool):
-        """the fused, vectorised flux evaluation (oracle/hydro_fused.hpp) instead of the operator sequence: the same bits, one pass per box"""
+    def set_limits(self, density_floor: float = 0.0, temp_floor: float = 0.0):
+        """the floors EnforceLimits applies after every stage (0: none, the default)"""
+        self.o.lib.orc_sim_set_limits.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        self.o.lib.orc_sim_set_limits(self.h, float(density_floor), float(temp_floor))
+
+    def set_fused_fluxes(self, on: bool, stages: bool = True):
+        """the fused, vectorised flux evaluation (oracle/hydro_fused.hpp) instead of the operator sequence: the same bits, one pass per box;
+        stages: the update, the limits and the dual-energy sync of a stage in the same pass over the box as well (HydroSim::fusedStage)"""
         self.o.lib.orc_sim_set_fused_fluxes.argtypes = [C.c_void_p, C.c_int]
-        self.o.lib.orc_sim_set_fused_fluxes(self.h, int(bool(on)))
+        self.o.lib.orc_sim_set_fused_fluxes(self.h, (1 if on else 0) | (2 if (on and stages) else 0))
 
     def hydro_fluxes(self, b: int, direction: int, fused: bool):
         """(flux[6, faces...], face velocity) of box b from the current state_new (ghost cells filled here), by either form"""

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from oracle.pyoracle import SEDOV, Oracle  # noqa: E402
+from oracle.pyoracle import K_B, M_U, SEDOV, Oracle  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -65,11 +65,53 @@ def test_fused_fluxes_equal_the_operator_form_bit_for_bit(oracle):
     check_fluxes(s, "random")
 
 
-def test_whole_runs_in_the_fused_form_equal_the_operator_form(oracle):
+@pytest.mark.parametrize("stages", [False, True])
+def test_whole_runs_in_the_fused_form_equal_the_operator_form(oracle, stages):
+    """stages: the update, the limits and the dual-energy sync of a stage in the same pass over the box as the fluxes (HydroSim::fusedStage,
+    fusedHydroUpdateBox), flux_rk2 accumulated while the fluxes are in registers; ghost cells compared too (the next step's stage inputs)"""
     a, b = mk(oracle, 32, 16), mk(oracle, 32, 16)
-    b.set_fused_fluxes(True)
+    b.set_fused_fluxes(True, stages=stages)
     for it in range(40):
         assert a.step() and b.step()
         assert a.dt == b.dt, it
     for k in range(a.nboxes):
         assert same_bits(a.state(k), b.state(k)), k
+    assert a.counters() == b.counters()
+
+
+@pytest.mark.parametrize("stages", [False, True])
+def test_flux_correction_and_retries_from_the_fused_form(oracle, stages):
+    """A 6x over-CFL step (tests/test_hydro_step_gpu.py::test_fofc_and_retries_match_oracle): PredictStep flags cells in both stages, the
+    first-order flux correction runs and the advance is retried with dt / 2^n.  The fused stage hands such a stage to the operator path
+    (which rewrites every cell the fused pass wrote): same flags, same counters, same state in every bit."""
+    a, b = mk(oracle, 16, 8), mk(oracle, 16, 8)
+    b.set_fused_fluxes(True, stages=stages)
+    for _ in range(3):
+        assert a.step() and b.step()
+    dt = a.compute_dt() * 6.0
+    assert b.compute_dt() * 6.0 == dt
+    assert a.advance_fixed_dt(dt) and b.advance_fixed_dt(dt)
+    co = a.counters()
+    assert co["fofc1_cells"] > 0 and co["fofc2_cells"] > 0 and co["retries"] > 0, co
+    assert b.counters() == co
+    for _ in range(3):
+        assert a.step() and b.step()
+        assert a.dt == b.dt
+    for k in range(a.nboxes):
+        assert same_bits(a.state(k), b.state(k)), k
+
+
+def test_limits_inside_the_fused_stage(oracle):
+    """density and temperature floors that bite (EnforceLimits, reference src/hydro/hydro_system.hpp:696-773) inside the fused stage"""
+    a, b = mk(oracle, 16, 16), mk(oracle, 16, 16)
+    b.set_fused_fluxes(True, stages=True)
+    for s in (a, b):
+        s.set_limits(density_floor=0.9, temp_floor=1.0e-6 * M_U * 0.4 / K_B)  # (e = 1e-6: above the ambient gas, far below the blast)
+    ref = mk(oracle, 16, 16)
+    for _ in range(12):
+        assert a.step() and b.step() and ref.step()
+        assert a.dt == b.dt
+    assert same_bits(a.state(0), b.state(0))
+    U, R = a.state(0)[:, 4:-4, 4:-4, 4:-4], ref.state(0)[:, 4:-4, 4:-4, 4:-4]
+    assert U[0].min() == 0.9 and R[0].min() < 0.9  # both floors did bite
+    assert (U[5] / U[0]).min() >= 1.0e-6 * (1 - 1e-12) and (R[5] / R[0]).min() < 1.0e-7
