@@ -256,6 +256,14 @@ typedef struct qk_hydro_stage_args {
 				  * d_redo_count (zeroed by the caller) receives the cells that are STILL invalid; no flags are written.  Bit-identical to the
 				  * reference-shaped operators (qk_hydro_ComputeFluxes(LLF) + qk_replaceFluxes + ...).  Requires K_visc == 0; in the carried-rhs
 				  * form only stage 1 (the stage-1 pass ran with rk2_carry_rhs = 1; pass rk2_carry_rhs = 0 or 1 here: rhs1 is not touched) */
+	int prim_out;		 /* stage 1 only.  1: U_out receives, per valid cell, the PRIMITIVES of the state the stage would have stored — (rho, v_x, v_y, v_z,
+				  * P, E_int_aux) in components 0..5, HydroSystem::ConservedToPrimitive of it (src/hydro/hydro_system.hpp:138-196), passive scalars
+				  * unchanged — which costs the final sweep one pressure (its limits already formed the velocities).  Ghost cells of such an array
+				  * are filled by the same copies and the same reflect / extrapolate rules component by component (the momenta's parity is the
+				  * velocities'); Dirichlet functors that write conserved values do not apply.  gamma law, reconstruct_eint = 0, no correction
+				  * pass: a step in which either stage counts flagged cells is redone without the hand-off (U_old is untouched by both stages). */
+	int prim_in;		 /* stage 2 only.  1: U_in holds what a stage 1 with prim_out stored: the pre-pass and the three sweeps read their primitives
+				  * instead of converting the conserved state four times over (4.9 conversions per cell); same bytes, same bits. */
 } qk_hydro_stage_args;
 
 /* One RK stage of advanceHydroAtLevel (reference src/QuokkaSimulation.hpp:1099-1198 / 1202-1287) WITHOUT the

@@ -100,7 +100,8 @@ class StageArgs(C.Structure):
                 ("scratch", C.c_void_p), ("scratch_bytes", C.c_int64),
                 ("dx", C.c_double * 3), ("dt", C.c_double), ("stage", C.c_int), ("reconstruction_order", C.c_int),
                 ("densityFloor", C.c_double), ("tempFloor", C.c_double), ("use_dual_energy", C.c_int), ("K_visc", C.c_double),
-                ("store_flux_rk2", C.c_int), ("fluxRk2", C.c_void_p * 3), ("rk2_carry_rhs", C.c_int), ("rhs1", C.c_void_p), ("flux_mask", C.c_void_p), ("fofc_pass", C.c_int)]
+                ("store_flux_rk2", C.c_int), ("fluxRk2", C.c_void_p * 3), ("rk2_carry_rhs", C.c_int), ("rhs1", C.c_void_p), ("flux_mask", C.c_void_p), ("fofc_pass", C.c_int),
+                ("prim_out", C.c_int), ("prim_in", C.c_int)]
 
 
 def traits(gamma=1.4, reconstruct_eint=True, ndim=3, mean_molecular_weight=M_U, boltzmann_constant=K_B,

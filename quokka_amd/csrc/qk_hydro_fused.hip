@@ -97,6 +97,10 @@ struct SweepArgs {
 	qk_array4 *rhs1; // carried half step (rk2_carry_rhs): per cell U_old + (dt/2) rhs_1 (nv components) + P(U_old), written by stage 1, read by stage 2
 	const qk_carray4 *fluxMask; // carried form only, optional: cells whose faces keep F1 (stage 1 -> halfFlux) and receive flux_rk2 (stage 2 -> rk2Flux)
 	int nseg; // segments along the march axis (marching sweeps; see k_pre_march)
+	// the primitive hand-off between the stages of a step (qk_hydro_stage_args::prim_out / prim_in): the final sweep of stage 1 stores
+	// (rho, v, P, E_int) of the cell it completes — consToPrim of the state it would have stored, whose quotients its limits already formed — and
+	// every kernel of stage 2 reads its input as primitives: no conversion in the pre-pass, the three sweeps (4.9 per cell and stage), same bytes
+	bool prim_in, prim_out;
 };
 
 QK_DEV auto sarr(SweepArgs const &a, int comp) -> double * { return a.scratch + static_cast<int64_t>(comp) * a.total_cells; }
@@ -193,7 +197,7 @@ QK_DEV auto chiCompressive(double Pm2, double Pm1, double Pp1, double Pp2, Recip
 // ndim < 3: the fab has no ghost cells in the inactive dimensions — rows / planes outside it take the neutral state and the flattening coefficient of
 // an inactive direction is 1 (FlattenShocks takes the minimum over the AMREX_SPACEDIM active directions only, hydro_system.hpp:655-669).
 __global__ void __launch_bounds__(PT_THREADS, 4) k_pre3(const qk_box *boxes, const SGeom *geom, const qk_array4 *U_t, double *scratch, int64_t T, Eos eos, bool re, int nseg,
-							    int xt, int yt, int ndim)
+							    int xt, int yt, int ndim, bool prim_in)
 {
 	const unsigned nblk = gridDim.x, lin = blockIdx.x;
 	const unsigned q8 = nblk / 8, r8 = nblk % 8, xcd = lin % 8, slot = lin / 8;
@@ -263,14 +267,16 @@ __global__ void __launch_bounds__(PT_THREADS, 4) k_pre3(const qk_box *boxes, con
 	double *Sout = scratch + g.off;
 	// (requesting the next plane's conserved values one plane ahead was measured: +20 registers, spills under the 128-register cap that two
 	// workgroups per CU need, 15 % slower — the kernel is issue-bound, not latency-bound)
-	const PlaneRaw neutral{1., 0., 0., 0., 1. / eos.gm1};
+	const PlaneRaw neutral{1., 0., 0., 0., prim_in ? 1. : 1. / eos.gm1};
+	// prim_in: the array holds (rho, v_x, v_y, v_z, P, E_int) — what planeCell would form (stage 2 after a stage 1 with prim_out)
+	auto cellOf = [&](PlaneRaw const &r) -> PlaneCell { return prim_in ? PlaneCell{r.rho, r.mx, r.my, r.mz, r.E} : planeCell(eos, re, r); };
 	int64_t uo = ownIn ? U.idx(oi, oj, zfirst - 3) : 0;
 	int64_t uh = haloIn ? U.idx(hi_, hj, zfirst - 3) : 0;
 
 	for (int k = zfirst - 3; k <= zlast + 3; ++k, uo += U.ks, uh += U.ks) {
 		const bool inPlane = (k >= zfirst) && (k <= zlast); // uniform: this plane's x / y results are somebody's output
 		const bool kIn = (k >= fzlo) && (k <= fzhi);	      // uniform: the plane exists in the fab
-		const PlaneCell c = planeCell(eos, re, (ownIn && kIn) ? planeLoad(U, uo) : neutral);
+		const PlaneCell c = cellOf((ownIn && kIn) ? planeLoad(U, uo) : neutral);
 #pragma unroll
 		for (int m = 0; m < 4; ++m) {
 			Pz[m] = Pz[m + 1];
@@ -297,7 +303,7 @@ __global__ void __launch_bounds__(PT_THREADS, 4) k_pre3(const qk_box *boxes, con
 				s_vy[ty + 2][tx] = c.vy;
 			}
 			if (h >= 0) {
-				hc = planeCell(eos, re, (haloIn && kIn) ? planeLoad(U, uh) : neutral);
+				hc = cellOf((haloIn && kIn) ? planeLoad(U, uh) : neutral);
 				s_P[hy + 3][hx + 3] = hc.P;
 				if (hy >= 0 && hy < PT_Y && hx >= -2 && hx < PT_X + 2) {
 					s_vx[hy][hx + 2] = hc.vx;
@@ -629,9 +635,26 @@ QK_DEV void updateCellFrom(SweepArgs const &a, Eos const &eos, EpiConst const &e
 		}
 	}
 	const int64_t cn = Un.idx(i, j, k);
+	if (a.prim_out) {
+		// consToPrim of the state this cell would have stored: rho_new, the three quotients on its reciprocal formed above, the pressure of the
+		// final energy (gamma law, reconstruct_eint off: qk_hydro_stage_fused checks); the auxiliary internal energy and the scalars as they are
+		const double Eint_cons = U[ENE] - 0.5 * rho_new * (vx * vx + vy * vy + vz * vz);
+		const double e = (rho_new == 0.0) ? 0.0 : divBy(Eint_cons, Rn);
+		streamStore(&Un.p[cn + Un.ns * PRHO], rho_new);
+		streamStore(&Un.p[cn + Un.ns * PVX], vx);
+		streamStore(&Un.p[cn + Un.ns * PVY], vy);
+		streamStore(&Un.p[cn + Un.ns * PVZ], vz);
+		streamStore(&Un.p[cn + Un.ns * PPRES], eos.gm1 * rho_new * e);
+		streamStore(&Un.p[cn + Un.ns * PEINT], U[EINT]);
 #pragma unroll
-	for (int n = 0; n < NVAR + NS; ++n) {
-		streamStore(&Un.p[cn + Un.ns * n], U[n]);
+		for (int n = NVAR; n < NVAR + NS; ++n) {
+			streamStore(&Un.p[cn + Un.ns * n], U[n]);
+		}
+	} else {
+#pragma unroll
+		for (int n = 0; n < NVAR + NS; ++n) {
+			streamStore(&Un.p[cn + Un.ns * n], U[n]);
+		}
 	}
 	if (a.max_signal != nullptr) {
 		// maxSignalSpeedLocal (:206-219) and ComputeMaxSignalSpeed (:227-250) of the new state
@@ -698,7 +721,14 @@ template <int ORDER, int STAGE, int NS, bool CARRY, int NDIM = 3, bool FOFC = fa
 		for (int n = 0; n < NVAR; ++n) {
 			Uc[n] = U.p[u + U.ns * n];
 		}
-		consToPrim(eos, a.reconstruct_eint, Uc, q0);
+		if (a.prim_in) { // (uniform) the input array holds the primitives
+#pragma unroll
+			for (int n = 0; n < NVAR; ++n) {
+				q0[n] = Uc[n];
+			}
+		} else {
+			consToPrim(eos, a.reconstruct_eint, Uc, q0);
+		}
 #pragma unroll
 		for (int n = NVAR; n < NV; ++n) { // hydro_system.hpp:340-343: passive scalars are reconstructed as they are stored
 			q0[n] = U.p[u + U.ns * n];
@@ -982,7 +1012,14 @@ __global__ void __launch_bounds__(64 * MARCH_BY) k_sweep_march(SweepArgs a, Eos 
 			for (int n = 0; n < NVAR; ++n) {
 				Uc[n] = Uin.p[u + Uin.ns * n];
 			}
-			consToPrim(eos, a.reconstruct_eint, Uc, q[4]);
+			if (a.prim_in) { // (uniform) the input array holds the primitives
+#pragma unroll
+				for (int n = 0; n < NVAR; ++n) {
+					q[4][n] = Uc[n];
+				}
+			} else {
+				consToPrim(eos, a.reconstruct_eint, Uc, q[4]);
+			}
 #pragma unroll
 			for (int n = NVAR; n < NV; ++n) { // passive scalars are reconstructed as they are stored
 				q[4][n] = Uin.p[u + Uin.ns * n];
@@ -1413,6 +1450,13 @@ int qk_hydro_stage_fused(qk_level *lev, qk_stream stream, const qk_hydro_traits 
 		QK_REQUIRE(ctx, lev->maxlen[d] >= 1, "qk_hydro_stage_fused: empty box");
 	}
 	QK_REQUIRE(ctx, args->scratch_bytes >= qk_hydro_stage_scratch_bytes(lev, t), "qk_hydro_stage_fused: scratch too small");
+	if (args->prim_in != 0 || args->prim_out != 0) {
+		QK_REQUIRE(ctx, t->reconstruct_eint == 0 && !Eos(*t).isothermal && t->eos_temperature_model == 0,
+			   "qk_hydro_stage_fused: the primitive hand-off is the gamma-law, reconstruct_eint = 0 form");
+		QK_REQUIRE(ctx, args->fofc_pass == 0, "qk_hydro_stage_fused: the primitive hand-off has no correction pass (redo the step without it)");
+		QK_REQUIRE(ctx, (args->prim_out == 0 || args->stage == 1) && (args->prim_in == 0 || (args->stage == 2 && args->U_in != args->U_old)),
+			   "qk_hydro_stage_fused: prim_out belongs to stage 1, prim_in to stage 2 (whose old state is a different array)");
+	}
 
 	if (int rc = buildGeom(lev); rc != QK_OK) {
 		return rc;
@@ -1462,7 +1506,7 @@ int qk_hydro_stage_fused(qk_level *lev, qk_stream stream, const qk_hydro_traits 
 			nseg = std::max(1, std::atoi(e));
 		}
 		const dim3 grid(static_cast<unsigned>(xt) * yt * lev->nboxes * nseg);
-		hipLaunchKernelGGL(k_pre3, grid, dim3(PT_THREADS), 0, s, boxes, geom, args->U_in, scratch, T, eos, re, nseg, xt, yt, t->ndim);
+		hipLaunchKernelGGL(k_pre3, grid, dim3(PT_THREADS), 0, s, boxes, geom, args->U_in, scratch, T, eos, re, nseg, xt, yt, t->ndim, args->prim_in != 0);
 	}
 
 	// 4. sweeps
@@ -1487,6 +1531,8 @@ int qk_hydro_stage_fused(qk_level *lev, qk_stream stream, const qk_hydro_traits 
 	a.store_rk2 = (args->store_flux_rk2 != 0);
 	a.rhs1 = args->rhs1;
 	a.fluxMask = (args->rk2_carry_rhs != 0) ? args->flux_mask : nullptr;
+	a.prim_in = (args->prim_in != 0);
+	a.prim_out = (args->prim_out != 0);
 	for (int d = 0; d < 3; ++d) {
 		a.dx3[d] = args->dx[d];
 	}

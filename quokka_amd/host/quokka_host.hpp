@@ -511,7 +511,8 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 			       << " Mupdates/s]\n";
 		// (not in the reference's output: how often the first-order flux correction and the retry loop ran — bench.py's full_run block reads it)
 		amrex::Print() << "qk counters: steps=" << istep[0] << " fofc_stages=" << fofcStages_ << " retries=" << retries_ << " elapsed_s=" << elapsedSeconds_
-			       << " sim_time=" << tNew_[0] << "\n";
+			       << " sim_time=" << tNew_[0] << " prim_handoff=" << ((primHandoffChecked_ && primHandoffOk_) ? 1 : 0)
+			       << " prim_handoff_dropped=" << primHandoffDropped_ << "\n";
 	}
 
 	// ------------------------------------------------------------------ hydro advance (reference src/QuokkaSimulation.hpp:885-1322)
@@ -1190,6 +1191,10 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 			a.rhs1 = sel(qkhost::tab(rhs1_));
 		}
 		a.fofc_pass = fofc ? 1 : 0;
+		if (primNow_ && !fofc) { // the primitive hand-off between the two stages of this step (stagePairSpeculative)
+			a.prim_out = (stageNo == 1) ? 1 : 0;
+			a.prim_in = (stageNo == 2) ? 1 : 0;
+		}
 		qkhost::check(qk_hydro_stage_fused(group < 0 ? qkhost::Runtime::get().lev : groups_[group].lev, qkhost::Runtime::get().computeStream(), &t, &a),
 			      "qk_hydro_stage_fused");
 	}
@@ -1320,6 +1325,27 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	// state is untouched by either stage, so the result is the same.  Returns 1: both stages done, 0: the step failed, -1: redo in order.
 	auto stagePairSpeculative(amrex::MultiFab &U_old, double time, double dt) -> int
 	{
+		if (primHandoffApplies()) {
+			// The primitive hand-off (qk_hydro_stage_args::prim_out / prim_in): stage 1 stores the primitives of the intermediate state, stage 2
+			// reads them — no conversion in its pre-pass and sweeps, same bytes, same bits.  It has no correction pass: when either stage flags
+			// a cell the attempt is dropped (the old state is untouched by both stages) and the step proceeds below as it does without it.
+			primNow_ = true;
+			fusedBegin(1, true);
+			fillTime_ = time;
+			launchStage(1, U_old, U_old, state_inter_cc_, dt, 0);
+			fillTime_ = time + dt;
+			launchStage(2, state_inter_cc_, U_old, state_new_cc_[0], dt, 1);
+			primNow_ = false;
+			StageWords w[2];
+			readWords(w);
+			if (w[0].count == 0 && w[1].count == 0) {
+				fusedEnd(1, &w[0]);
+				fusedEnd(2, &w[1]);
+				return 1;
+			}
+			++primHandoffDropped_;
+			invalidateSignal();
+		}
 		fusedBegin(1, true);
 		fillTime_ = time;
 		launchStage(1, U_old, U_old, state_inter_cc_, dt, 0);
@@ -1335,6 +1361,33 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		}
 		return correctStage(2, state_inter_cc_, U_old, state_new_cc_[0], dt) ? 1 : 0;
 	}
+	// The primitive hand-off applies to a plain hydro level: no hierarchy around it, no radiation variables in the state, gamma law with
+	// reconstruct_eint off, and boundary rules that act component by component (reflect / extrapolate / periodic: the momenta's parity is the
+	// velocities'); a problem with ext_dir faces writes CONSERVED values through its functor.
+	[[nodiscard]] auto primHandoffApplies() -> bool
+	{
+		if (primHandoffChecked_) {
+			return primHandoffOk_;
+		}
+		primHandoffChecked_ = true;
+		int on = 1, maxLevel = 0;
+		amrex::ParmParse("qk").query("prim_handoff", on);
+		amrex::ParmParse("amr").query("max_level", maxLevel);
+		auto const t = qkhost::traits<problem_t>();
+		bool ok = on != 0 && maxLevel == 0 && this->amrLevel_ == 0 && amr_ == nullptr && !is_radiation_enabled_ && t.reconstruct_eint == 0 &&
+			  t.eos_temperature_model == 0 && !(t.cs_isothermal == t.cs_isothermal) && t.gamma != 1.0 &&
+			  Physics_Indices<problem_t>::nvarTotal_cc == ncompHydro_;
+		for (auto const &bc : this->BCs_cc_) {
+			for (int d = 0; d < AMREX_SPACEDIM; ++d) {
+				ok = ok && bc.lo(d) != amrex::BCType::ext_dir && bc.hi(d) != amrex::BCType::ext_dir && bc.lo(d) != amrex::BCType::hoextrap &&
+				     bc.hi(d) != amrex::BCType::hoextrap;
+			}
+		}
+		primHandoffOk_ = ok;
+		return ok;
+	}
+	bool primHandoffChecked_ = false, primHandoffOk_ = false, primNow_ = false;
+	long primHandoffDropped_ = 0;
 	int rk2CarryRhs_ = 0;	   // deck: hydro.rk2_carry_rhs
 	int fusedFofc_ = 1;	   // deck: qk.fused_fofc (0: a flagged stage is redone on the reference-shaped operators; tests)
 	bool stage1LeftF1_ = true; // halfFlux_ holds the stage-1 fluxes of the current step

@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Sequence, Tuple
 
@@ -318,6 +319,10 @@ class HydroSimulation:
         # synchronisation per step instead of two, `speculate_stage2`); everything else uses slot 0.
         self._dev_words = torch.zeros(8, dtype=torch.int64, device=ctx.device)
         self.speculate_stage2 = True
+        # the primitive hand-off between the stages of a step (qk_hydro_stage_args::prim_out / prim_in; _prim_handoff_applies)
+        self.prim_handoff = os.environ.get("QK_PRIM_HANDOFF", "1") == "1"  # (0: the conserved intermediate state, for A/B runs)
+        self._prim_now = False
+        self._has_dirichlet = dirichlet is not None
         self.dev_counters = self._dev_words[2:3]  # [redo_count]
         self.dev_error = self._dev_words[3:4].view(torch.int32)[0:1]
         self._err_latched = False   # an error flag seen by a fused stage of the current advance (the words are cleared before every stage)
@@ -582,6 +587,13 @@ class HydroSimulation:
             self._rhs1 = MultiFab(self.lev, self.hydro.nvar_ + 1, 0, fill=0.0)
         return self._rhs1
 
+    def _prim_handoff_applies(self) -> bool:
+        """a plain hydro level (no hierarchy around it, no radiation variables), gamma law with reconstruct_eint off, boundary rules that act
+        component by component (no Dirichlet faces: their values are conserved ones)"""
+        t = self.traits
+        return (self.prim_handoff and type(self) is HydroSimulation and not self._has_dirichlet and self.ncomp_cc == self.hydro.nvar_
+                and t.reconstruct_eint == 0 and t.cs_isothermal != t.cs_isothermal and t.eos_temperature_model == 0 and t.gamma != 1.0)
+
     def _is_final(self, stage: int) -> bool:
         return (stage == 2) or (self.integratorOrder_ == 1)
 
@@ -628,6 +640,8 @@ class HydroSimulation:
             for d in range(nd):
                 a.fluxRk2[d] = tab(self.fluxRk2()[d])
         a.fofc_pass = int(fofc)
+        if self._prim_now and not fofc:  # the primitive hand-off between the two stages of this advance (prim_handoff)
+            a.prim_out, a.prim_in = int(stage == 1), int(stage == 2)
         c = self.ctx
         c.check(c.L.qk_hydro_stage_fused(lev.h, c.stream(), C.byref(self.traits), C.byref(a)), "qk_hydro_stage_fused")
 
@@ -803,7 +817,31 @@ class HydroSimulation:
         self._signal_of_state_new = None  # state_new_cc_ is about to be overwritten
         self._err_latched, self._unfused_ran = False, False
         pair_done = False
-        if self.use_fused and self.integratorOrder_ == 2 and self.speculate_stage2:
+        self._prim_now = False
+        if self.use_fused and self.integratorOrder_ == 2 and self.speculate_stage2 and self._prim_handoff_applies():
+            # The primitive hand-off (qk_hydro_stage_args::prim_out / prim_in): stage 1 stores the primitives of the intermediate state, stage 2
+            # reads them.  It has no correction pass: if either stage flags a cell the attempt is dropped — the old state is untouched by both
+            # stages — and the advance proceeds below as it does without the hand-off.
+            inter, new = self.state_inter_cc_, self.state_new_cc_
+            self._prim_now = True
+            try:
+                self._fused_begin(1, both=True)
+                self._launch_stage(1, state_old_tmp, state_old_tmp, inter, dt_lev, slot=0)
+                self._launch_stage(2, inter, state_old_tmp, new, dt_lev, slot=1)
+            finally:
+                self._prim_now = False
+            vals = self._read_words()
+            latched = self._err_latched
+            if self._fused_end(1, 0, vals) == 0 and self._fused_end(2, 1, vals) == 0:
+                self._stage1_left_F1 = not self._carry_active()
+                pair_done = True
+            else:
+                self._err_latched = latched  # (whatever the dropped attempt reported)
+                self._signal_of_state_new = None
+                self.counters["prim_handoff_dropped"] = self.counters.get("prim_handoff_dropped", 0) + 1
+        if pair_done:
+            pass
+        elif self.use_fused and self.integratorOrder_ == 2 and self.speculate_stage2:
             # Both stages are enqueued before either redo count is read: the GPU does not idle through a device -> host round trip between the
             # stages.  Stage 2 is speculative — if stage 1 flagged cells (rare: strong shocks at too large a step) its work is discarded
             # and the stages are redone in order below; the old state is untouched by either stage, so the result is the same.

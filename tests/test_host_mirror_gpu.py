@@ -68,14 +68,18 @@ def test_sod_shocktube_amr_meets_the_reference_ctest_criterion(tmp_path):
     assert not np.array_equal(data.reshape(6, 1024), gold)
 
 
-def test_sedov_executable_matches_golden(tmp_path):
-    """32^3 Sedov, 10 steps, through the C++ mirror (3-D build, fused path) == committed oracle state"""
+@pytest.mark.parametrize("handoff", [1, 0])
+def test_sedov_executable_matches_golden(tmp_path, handoff):
+    """32^3 Sedov, 10 steps, through the C++ mirror (3-D build, fused path) == committed oracle state; handoff: the primitive hand-off between
+    the stages of a step (qk_hydro_stage_args::prim_out / prim_in; the default of a plain hydro level) or the conserved intermediate state"""
     data, meta, out = run("ref_HydroBlast3D", ["geometry.prob_lo=0 0 0", "geometry.prob_hi=1.2 1.2 1.2", "geometry.is_periodic=0 0 0",
-                                                 "amr.n_cell=32 32 32", "amr.max_grid_size=32", "max_timesteps=10"], tmp_path, allow_fail=True)
+                                                 "amr.n_cell=32 32 32", "amr.max_grid_size=32", "max_timesteps=10", f"qk.prim_handoff={handoff}"],
+                          tmp_path, allow_fail=True)
     gold = np.load(os.path.join(ROOT, "tests", "golden", "sedov_32_step10.npy"))
     assert int(meta[0]) == 10
     assert np.array_equal(data.reshape(6, 32, 32, 32), gold)
     assert "Energy conservation is OK." in out
+    assert f"prim_handoff={handoff} prim_handoff_dropped=0" in out
 
 
 def test_sedov_amr_executable_matches_python_driver(tmp_path, ctx):

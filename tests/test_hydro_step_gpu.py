@@ -550,3 +550,40 @@ def test_carried_rhs_mode_with_passive_scalars_and_lower_orders(ctx):
         for _ in range(10):
             assert a.step() and b.step()
         assert rel_l1(gather_gpu(b, 32), gather_gpu(a, 32)) <= 1e-12, order
+
+
+# ------------------------------------------------------------------ the primitive hand-off between the stages of a step (prim_out / prim_in)
+@pytest.mark.gpu
+def test_primitive_handoff_between_the_stages_changes_no_bit(ctx, oracle):
+    """qk_hydro_stage_args::prim_out / prim_in: the final sweep of stage 1 stores the primitives of the intermediate state (one pressure more: its
+    limits already formed the velocities), the pre-pass and the three sweeps of stage 2 read them instead of converting the conserved state 4.9
+    times per cell.  Same bytes, same bits: the exact form against the oracle, the carried form against itself without the hand-off; and a step
+    whose stages flag cells (6x over-CFL: first-order flux correction + retries) drops the attempt and proceeds as without it."""
+    N, mgs = 32, 16
+    so = oracle.sim(SEDOV, 3, [N] * 3, [0, 0, 0], [1.2] * 3, [0, 0, 0], max_grid_size=[mgs] * 3)
+    sg = sedov_problem(ctx, N, max_grid_size=mgs)
+    sg.prim_handoff = True
+    assert sg._prim_handoff_applies()
+    for it in range(12):
+        assert so.step() and sg.step()
+        assert so.dt == sg.dt_, it
+    assert np.array_equal(gather_oracle(so, N), gather_gpu(sg, N))
+    assert sg.counters.get("prim_handoff_dropped", 0) == 0
+    # flagged cells: the attempt is dropped, the correction runs as it does without the hand-off
+    dt = so.compute_dt() * 6.0
+    assert so.advance_fixed_dt(dt) and sg.step(dt)
+    co = so.counters()
+    assert co["fofc1_cells"] > 0 and co["retries"] > 0 and sg.counters["prim_handoff_dropped"] > 0
+    assert sg.counters["retries"] == co["retries"]
+    for it in range(3):
+        assert so.step() and sg.step()
+    assert np.array_equal(gather_oracle(so, N), gather_gpu(sg, N))
+    # the carried form
+    a, b = sedov_problem(ctx, N, max_grid_size=mgs), sedov_problem(ctx, N, max_grid_size=mgs)
+    a.rk2_carry_rhs = b.rk2_carry_rhs = True
+    b.prim_handoff = True
+    for it in range(12):
+        assert a.step() and b.step()
+        assert a.dt_ == b.dt_
+    assert np.array_equal(gather_gpu(a, N), gather_gpu(b, N))
+    assert b.counters.get("prim_handoff_dropped", 0) == 0
