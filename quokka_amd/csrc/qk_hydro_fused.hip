@@ -196,9 +196,18 @@ QK_DEV auto chiCompressive(double Pm2, double Pm1, double Pp1, double Pp2, Recip
 // of a tile are then found in the L2 of the XCD that just read them for the tile before.
 // ndim < 3: the fab has no ghost cells in the inactive dimensions — rows / planes outside it take the neutral state and the flattening coefficient of
 // an inactive direction is 1 (FlattenShocks takes the minimum over the AMREX_SPACEDIM active directions only, hydro_system.hpp:655-669).
+// QK_PRE_PREFETCH (A/B knob, default 0): the next plane's values requested one plane ahead — 1 in both stages, 2 only in the stage that reads
+// primitives (whose conversion-free body needs 112 registers instead of 118).  Measured in round 5 (profiles/round5/ab6_pre_prefetch.txt): the 20
+// registers of the two in-flight cells spill 24 / 80 bytes per lane under the 128-register cap: 0.39 -> 0.42 ms (2), -> 0.53 ms (1) per launch.
+#ifndef QK_PRE_PREFETCH
+#define QK_PRE_PREFETCH 0
+#endif
+template <bool PRIM>
 __global__ void __launch_bounds__(PT_THREADS, 4) k_pre3(const qk_box *boxes, const SGeom *geom, const qk_array4 *U_t, double *scratch, int64_t T, Eos eos, bool re, int nseg,
-							    int xt, int yt, int ndim, bool prim_in)
+							    int xt, int yt, int ndim)
 {
+	constexpr bool prim_in = PRIM;
+	constexpr bool PF = (QK_PRE_PREFETCH == 1) || (QK_PRE_PREFETCH == 2 && PRIM); // the next plane's values requested one plane ahead
 	const unsigned nblk = gridDim.x, lin = blockIdx.x;
 	const unsigned q8 = nblk / 8, r8 = nblk % 8, xcd = lin % 8, slot = lin / 8;
 	const unsigned logical = (xcd < r8) ? xcd * (q8 + 1) + slot : r8 * (q8 + 1) + (xcd - r8) * q8 + slot;
@@ -272,11 +281,28 @@ __global__ void __launch_bounds__(PT_THREADS, 4) k_pre3(const qk_box *boxes, con
 	auto cellOf = [&](PlaneRaw const &r) -> PlaneCell { return prim_in ? PlaneCell{r.rho, r.mx, r.my, r.mz, r.E} : planeCell(eos, re, r); };
 	int64_t uo = ownIn ? U.idx(oi, oj, zfirst - 3) : 0;
 	int64_t uh = haloIn ? U.idx(hi_, hj, zfirst - 3) : 0;
+	PlaneRaw nextOwn = neutral, nextHalo = neutral;
+	if constexpr (PF) {
+		const bool k0In = (zfirst - 3 >= fzlo) && (zfirst - 3 <= fzhi);
+		nextOwn = (ownIn && k0In) ? planeLoad(U, uo) : neutral;
+		nextHalo = (haloIn && k0In && (zfirst - 3 >= zfirst)) ? planeLoad(U, uh) : neutral;
+	}
 
 	for (int k = zfirst - 3; k <= zlast + 3; ++k, uo += U.ks, uh += U.ks) {
 		const bool inPlane = (k >= zfirst) && (k <= zlast); // uniform: this plane's x / y results are somebody's output
 		const bool kIn = (k >= fzlo) && (k <= fzhi);	      // uniform: the plane exists in the fab
-		const PlaneCell c = cellOf((ownIn && kIn) ? planeLoad(U, uo) : neutral);
+		PlaneRaw rawOwn, rawHalo = neutral;
+		if constexpr (PF) {
+			rawOwn = nextOwn;
+			rawHalo = nextHalo;
+			const int kn = k + 1;
+			const bool knIn = (kn >= fzlo) && (kn <= fzhi) && (kn <= zlast + 3);
+			nextOwn = (ownIn && knIn) ? planeLoad(U, uo + U.ks) : neutral;
+			nextHalo = (haloIn && knIn && (kn >= zfirst) && (kn <= zlast)) ? planeLoad(U, uh + U.ks) : neutral;
+		} else {
+			rawOwn = (ownIn && kIn) ? planeLoad(U, uo) : neutral;
+		}
+		const PlaneCell c = cellOf(rawOwn);
 #pragma unroll
 		for (int m = 0; m < 4; ++m) {
 			Pz[m] = Pz[m + 1];
@@ -303,7 +329,7 @@ __global__ void __launch_bounds__(PT_THREADS, 4) k_pre3(const qk_box *boxes, con
 				s_vy[ty + 2][tx] = c.vy;
 			}
 			if (h >= 0) {
-				hc = cellOf((haloIn && kIn) ? planeLoad(U, uh) : neutral);
+				hc = cellOf(PF ? rawHalo : ((haloIn && kIn) ? planeLoad(U, uh) : neutral));
 				s_P[hy + 3][hx + 3] = hc.P;
 				if (hy >= 0 && hy < PT_Y && hx >= -2 && hx < PT_X + 2) {
 					s_vx[hy][hx + 2] = hc.vx;
@@ -1506,7 +1532,11 @@ int qk_hydro_stage_fused(qk_level *lev, qk_stream stream, const qk_hydro_traits 
 			nseg = std::max(1, std::atoi(e));
 		}
 		const dim3 grid(static_cast<unsigned>(xt) * yt * lev->nboxes * nseg);
-		hipLaunchKernelGGL(k_pre3, grid, dim3(PT_THREADS), 0, s, boxes, geom, args->U_in, scratch, T, eos, re, nseg, xt, yt, t->ndim, args->prim_in != 0);
+		if (args->prim_in != 0) {
+			hipLaunchKernelGGL(k_pre3<true>, grid, dim3(PT_THREADS), 0, s, boxes, geom, args->U_in, scratch, T, eos, re, nseg, xt, yt, t->ndim);
+		} else {
+			hipLaunchKernelGGL(k_pre3<false>, grid, dim3(PT_THREADS), 0, s, boxes, geom, args->U_in, scratch, T, eos, re, nseg, xt, yt, t->ndim);
+		}
 	}
 
 	// 4. sweeps
