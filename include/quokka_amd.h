@@ -462,6 +462,13 @@ int qk_ghost_plan_set_components(qk_ghost_plan *plan, int scomp, int ncomp);
 int qk_ghost_plan_box_is_remote(qk_ghost_plan *plan, int local_box); /* 1 / 0, < 0 on error */
 /* move a box into / out of the late group by hand (load balancing between the two launches; single-GPU tests of the split) */
 int qk_ghost_plan_set_box_remote(qk_ghost_plan *plan, int local_box, int flag);
+/* AMRSimulation::fillBoundaryConditions, level-0 branch (reference src/simulation.hpp:1751-1776), as ONE launch: state.FillBoundary(periodicity)
+ * and the mathematical boundary rules of PhysBCFunct (reflect_even / reflect_odd / foextrap, AMReX_FilCC composed over the dimensions) evaluated as
+ * a gather — every ghost cell reads the valid cell its value comes from, through the mirror / clamp of its index and the neighbour that owns the
+ * image.  Same values as qk_FillBoundary_local followed by qk_FillPhysicalBoundary (tested cell by cell).  Returns QK_OK when the fill is done,
+ * 1 when the form does not apply and nothing was written — boxes on other ranks, a face whose components mix reflecting and extrapolating rules or
+ * use ext_dir (a Dirichlet functor), a level whose ghost cells the copies do not cover (coarse-fine boundaries): then call the two entries. */
+int qk_FillBoundary_gather(qk_ghost_plan *plan, qk_stream s, qk_array4 *state, const qk_bcrec *bcs);
 int qk_FillPhysicalBoundary_subset(qk_ghost_plan *plan, qk_stream s, qk_array4 *state, const qk_bcrec *bcs, const qk_dirichlet_face *dirichlet,
 				   int which);
 

@@ -120,6 +120,9 @@ struct BcShell {
 	int lo[3];
 	int hi[3];
 };
+// set by the DEFAULT AMRSimulation<problem_t>::setCustomBoundaryConditions (a problem that specialises the hook never sets it): after the first
+// fill the host knows the hook does nothing, stops launching it and may fill the ghost cells with one gather launch (qk_FillBoundary_gather)
+static __device__ int g_defaultCustomBcRan = 0;
 // setCustomBoundaryConditions on every cell of every slab of a fill: ONE launch per fill (blockIdx.y: the slab), threads over ghost cells only
 template <typename problem_t>
 __global__ void customBcKernel(const BcShell *shells, const amrex::Array4<amrex::Real> *tab, amrex::GeometryData geom, amrex::Real time, const amrex::BCRec *bcr, int ncomp)
@@ -293,6 +296,7 @@ template <typename problem_t> class AMRSimulation
 						amrex::GeometryData const & /*geom*/, amrex::Real /*time*/, const amrex::BCRec * /*bcr*/, int /*bcomp*/,
 						int /*orig_comp*/)
 	{
+		qkhost::g_defaultCustomBcRan = 1; // (see customBoundaryConditionsOnDevice)
 	}
 
 	void initialize(LevelSpec const *spec)
@@ -574,6 +578,24 @@ template <typename problem_t> class AMRSimulation
 	{
 		activate();
 		hipStream_t const cs = qkhost::Runtime::get().computeStream();
+		if (!between && !beforePhysBC_ && peers_.peer.empty() && customBcIsDefault_ == 1 && ghostGather_ != 0) {
+			// every box on this rank, no functor: copies + reflecting / extrapolating faces as ONE gather launch (1: the form does not apply)
+			std::vector<qk_bcrec> bcs(BCs_cc_.size());
+			for (size_t n = 0; n < BCs_cc_.size(); ++n) {
+				for (int d = 0; d < 3; ++d) {
+					bcs[n].lo[d] = (d < AMREX_SPACEDIM) ? BCs_cc_[n].lo(d) : 0;
+					bcs[n].hi[d] = (d < AMREX_SPACEDIM) ? BCs_cc_[n].hi(d) : 0;
+				}
+			}
+			int const rc = qk_FillBoundary_gather(plan_, cs, qkhost::tab(state), bcs.data());
+			if (rc == QK_OK) {
+				return;
+			}
+			if (rc != 1) {
+				qkhost::check(rc, "FillBoundary_gather");
+			}
+			ghostGather_ = 0;
+		}
 		// state.FillBoundary(geom.periodicity()) (reference src/simulation.hpp:1755): strips for the other ranks are packed, sent peer to peer
 		// while the same-rank copies run, and unpacked
 		for (size_t k = 0; k < peers_.peer.size(); ++k) {
@@ -617,6 +639,9 @@ template <typename problem_t> class AMRSimulation
 	// Dirichlet / Marshak set of the C-ABI (which host-mode problems are sampled into).
 	void customBoundaryConditionsOnDevice(amrex::MultiFab &state, int which = QK_BOXES_ALL)
 	{
+		if (customBcIsDefault_ == 1) {
+			return; // the hook is the default (an empty body): known since the first fill
+		}
 		if (d_bcrec_ == nullptr) {
 			QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_bcrec_), sizeof(amrex::BCRec) * BCs_cc_.size()));
 			QK_HOST_HIP(hipMemcpy(d_bcrec_, BCs_cc_.data(), sizeof(amrex::BCRec) * BCs_cc_.size(), hipMemcpyHostToDevice));
@@ -670,9 +695,26 @@ template <typename problem_t> class AMRSimulation
 		if (l.count == 0) {
 			return;
 		}
+		if (customBcIsDefault_ < 0) { // (the flag is one per executable: another problem type's object may have raised it)
+			int const zero = 0;
+			QK_HOST_HIP(hipStreamSynchronize(qkhost::Runtime::get().computeStream()));
+			QK_HOST_HIP(hipMemcpyToSymbol(HIP_SYMBOL(qkhost::g_defaultCustomBcRan), &zero, sizeof(int)));
+		}
 		hipLaunchKernelGGL(qkhost::customBcKernel<problem_t>, dim3(static_cast<unsigned>((l.most + 255) / 256), static_cast<unsigned>(l.count)), dim3(256), 0,
 				   qkhost::Runtime::get().computeStream(), l.d, state.arrays(), gd, bcFillTime(), d_bcrec_, state.nComp());
+		if (customBcIsDefault_ < 0) { // first launch: did the default body run?
+			int ran = 0;
+			QK_HOST_HIP(hipStreamSynchronize(qkhost::Runtime::get().computeStream()));
+			QK_HOST_HIP(hipMemcpyFromSymbol(&ran, HIP_SYMBOL(qkhost::g_defaultCustomBcRan), sizeof(int)));
+			customBcIsDefault_ = (ran != 0) ? 1 : 0;
+		}
 	}
+	int customBcIsDefault_ = -1; // -1 unknown, 0 the problem specialised setCustomBoundaryConditions, 1 it is the empty default
+	int ghostGather_ = [] {
+		int v = 0; // (measured: one launch less, no faster — profiles/round5/ab7_ghost_gather.txt; the two kernels stay the default)
+		amrex::ParmParse("qk").query("ghost_gather", v);
+		return v;
+	}();
 	struct BcShellList {
 		qkhost::BcShell *d = nullptr;
 		int count = 0;

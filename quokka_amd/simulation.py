@@ -145,6 +145,9 @@ class GhostExchange:
                     vals = vals["values"]
                 for n, v in enumerate(vals):
                     f.values[n] = v
+        # the fill as ONE gather launch (qk_FillBoundary_gather): same values, one launch less — and no faster (profiles/round5/ab7_ghost_gather.txt:
+        # 0.134 ms against 0.060 + 0.091 ms at 256^3; the 4-cell-wide x slabs use a quarter of every cache line either way): off by default
+        self.use_gather = os.environ.get("QK_GHOST_GATHER", "0") == "1"
         self.exposed_events = None  # a list: fill() records (before, after) events around the wait for the peers' strips
         self.peers = []
         for k in range(L.qk_ghost_plan_num_peers(h)):
@@ -158,6 +161,13 @@ class GhostExchange:
         ctx = self.lev.ctx
         L = ctx.L
         s = ctx.stream()
+        if self.use_gather and not self.peers and self.dirichlet is None and between is None and before_physbc is None:
+            # copies + reflecting / extrapolating faces as ONE gather launch; 1: the form does not apply to this plan (two kernels below)
+            rc = L.qk_FillBoundary_gather(self.h, s, state.ptr, self.bcs)
+            if rc == 0:
+                return
+            if rc != 1:
+                ctx.check(rc, "FillBoundary_gather")
 
         def pack(k, sbuf):
             ctx.check(L.qk_FillBoundary_pack(self.h, s, k, state.ptr, C.c_void_p(sbuf.data_ptr())), "FillBoundary_pack")

@@ -587,3 +587,60 @@ def test_primitive_handoff_between_the_stages_changes_no_bit(ctx, oracle):
         assert a.dt_ == b.dt_
     assert np.array_equal(gather_gpu(a, N), gather_gpu(b, N))
     assert b.counters.get("prim_handoff_dropped", 0) == 0
+
+
+# ------------------------------------------------------------------ the ghost fill as one gather launch (qk_FillBoundary_gather)
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["reflecting octant", "periodic y", "extrapolating", "small boxes", "2-D", "mixed rules"])
+def test_ghost_fill_as_one_gather_equals_copies_then_boundary_rules(ctx, case):
+    """qk_FillBoundary_gather — every ghost cell reads the valid cell its value comes from (index mirrored / clamped per dimension, the neighbour
+    that owns the image as source box, sign per component) — against qk_FillBoundary_local followed by qk_FillPhysicalBoundary on random data:
+    every ghost cell of every component equal; where the form does not apply (a face whose components mix reflecting and extrapolating rules)
+    the entry reports so and writes nothing."""
+    from quokka_amd import capi
+    from quokka_amd.multifab import Level, MultiFab
+    from quokka_amd.simulation import GhostExchange, Geometry, chop_domain
+    nd, N, mgs, ng, nc, periodic = 3, [16, 16, 16], [8, 8, 8], 4, 6, [0, 0, 0]
+    EV, OD, FO = capi.BC_REFLECT_EVEN, capi.BC_REFLECT_ODD, capi.BC_FOEXTRAP
+    bcs = [([OD if n == 1 + d else EV for d in range(3)], [OD if n == 1 + d else EV for d in range(3)]) for n in range(nc)]
+    applies = True
+    if case == "periodic y":
+        periodic = [0, 1, 0]
+        bcs = [([lo[0], capi.BC_INT_DIR, lo[2]], [hi[0], capi.BC_INT_DIR, hi[2]]) for lo, hi in bcs]
+    elif case == "extrapolating":  # outflow at the upper faces, walls at the lower ones
+        bcs = [(lo, [FO, FO, FO]) for lo, hi in bcs]
+    elif case == "small boxes":  # boxes as wide as the ghost region: images reach the far side of a box, corners come from diagonal neighbours
+        N, mgs = [12, 8, 8], [4, 4, 4]
+    elif case == "2-D":
+        nd, N, mgs = 2, [16, 16, 1], [8, 8, 1]
+        bcs = [(lo[:2] + [capi.BC_INT_DIR], hi[:2] + [capi.BC_INT_DIR]) for lo, hi in bcs]
+    elif case == "mixed rules":
+        bcs[2] = ([FO, EV, EV], bcs[2][1])
+        applies = False
+    geom = Geometry(nd, N, [0.0] * 3, [1.0] * 3, periodic)
+    boxes = chop_domain(N, mgs)
+    lev = Level(ctx, nd, boxes)
+    ex = GhostExchange(lev, geom, nc, ng, boxes, [0] * len(boxes), 0, bcs)
+    a, b = MultiFab(lev, nc, ng), MultiFab(lev, nc, ng)
+    rng = np.random.default_rng(11)
+    for k, shp in enumerate(a.shapes):
+        h = rng.normal(size=shp)
+        a.set_fab(k, h)
+        b.set_fab(k, h)
+    ex.use_gather = False
+    ex.fill(a)
+    L = ctx.L
+    rc = L.qk_FillBoundary_gather(ex.h, ctx.stream(), b.ptr, ex.bcs)
+    torch.cuda.synchronize()
+    assert rc == (0 if applies else 1)
+    for k in range(len(boxes)):
+        if applies:
+            assert np.array_equal(a.fab_numpy(k), b.fab_numpy(k)), f"{case}: box {k}"
+        else:
+            assert not np.array_equal(a.fab_numpy(k), b.fab_numpy(k))  # (nothing written: the ghost cells still hold the random data)
+    # and through GhostExchange.fill, which takes the gather where it applies and the two kernels where it does not
+    ex.use_gather = True
+    ex.fill(b)
+    torch.cuda.synchronize()
+    for k in range(len(boxes)):
+        assert np.array_equal(a.fab_numpy(k), b.fab_numpy(k)), f"{case}: box {k} (fill)"
