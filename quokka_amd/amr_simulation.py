@@ -476,6 +476,10 @@ class AmrLevelSim(HydroSimulation):
             for b in range(self.lev.nboxes):  # the physical-boundary slabs of the near boxes first ("local only" subset of the ghost plan)
                 self.ghost.set_box_remote(b, b in set(far))
             self._far_groups_key = (tuple(near), tuple(far))
+        # Level 0 has no coarse-fine ghost cells: its intermediate state may travel as primitives (qk_hydro_stage_args::prim_out / prim_in, as on
+        # a plain level).  A flagged cell in either stage makes advance_level_join() fail: the coarse step is then redone in the ordinary
+        # order, which does not use the hand-off.
+        self._prim_now = self.ilev == 0 and type(self) is AmrLevelSim and self._prim_handoff_state_ok()
         self._fused_begin(1, both=True)
         self._before_fill(1, dt_lev)
         self.fillBoundaryConditions(old)
@@ -492,6 +496,7 @@ class AmrLevelSim(HydroSimulation):
         with torch.cuda.stream(self._far_stream):
             self._far_stream.wait_event(ev)
             self._fused_launch(2, inter, old, new, dt_lev, group=self._far_group, slot=1, scratch=self._far_scratch)
+            self._prim_now = False
             # FixupState of the far boxes (reference src/simulation.hpp:1308-1312: after Reflux and AverageDownTo — neither touches a far box, so
             # for these cells it may as well run now, beside the children); its maxima wait in words 4, 5 for the near boxes' (_fixup_near)
             if amr.overlap_fixup:

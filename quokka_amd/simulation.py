@@ -600,8 +600,11 @@ class HydroSimulation:
     def _prim_handoff_applies(self) -> bool:
         """a plain hydro level (no hierarchy around it, no radiation variables), gamma law with reconstruct_eint off, boundary rules that act
         component by component (no Dirichlet faces: their values are conserved ones)"""
+        return type(self) is HydroSimulation and self._prim_handoff_state_ok()
+
+    def _prim_handoff_state_ok(self) -> bool:
         t = self.traits
-        return (self.prim_handoff and type(self) is HydroSimulation and not self._has_dirichlet and self.ncomp_cc == self.hydro.nvar_
+        return (self.prim_handoff and not self._has_dirichlet and self.ncomp_cc == self.hydro.nvar_
                 and t.reconstruct_eint == 0 and t.cs_isothermal != t.cs_isothermal and t.eos_temperature_model == 0 and t.gamma != 1.0)
 
     def _is_final(self, stage: int) -> bool:
