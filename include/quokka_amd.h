@@ -118,6 +118,11 @@ int qk_profile_get(qk_ctx *ctx, int k, const char **name, long *count, double *t
  * call instead of a host-framework fill kernel (the reference clears its counters with amrex::Gpu fills, e.g. redoFlag.setVal(none),
  * src/QuokkaSimulation.hpp:1087).  `device_ptr` must be a device allocation. */
 int qk_clear_bytes(qk_ctx *ctx, qk_stream s, void *device_ptr, int64_t nbytes);
+/* A HIP stream whose kernels run only on the compute units whose bit is set in cu_mask (bit i of word i / 32: CU i; hipExtStreamCreateWithCUMask).
+ * Any stream is a legal qk_stream; this is only how to make one that shares the chip by compute units instead of by wave slots (measured for the
+ * AMR driver's side stream and not used by default: profiles/round5/ab8_amr_cu_mask_rejected.txt). */
+int qk_stream_create_cu_mask(qk_ctx *ctx, const uint32_t *cu_mask, int nwords, qk_stream *stream_out);
+int qk_stream_destroy(qk_ctx *ctx, qk_stream s);
 
 /* BoxArray of one level owned by this rank (valid, cell-centred boxes). */
 int qk_level_create(qk_ctx *ctx, qk_level **lev, int ndim, int nboxes, const qk_box *valid_boxes);

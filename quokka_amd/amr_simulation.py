@@ -465,6 +465,11 @@ class AmrLevelSim(HydroSimulation):
         if getattr(self, "_far_groups_key", None) != (tuple(near), tuple(far)):
             mk = lambda idx: (Level(self.ctx, self.geom.ndim, [self.my_boxes[b] for b in idx]), list(idx))
             self._near_group, self._far_group = mk(near), mk(far)
+            # the far boxes as up to 8 launch sets one after the other on the side stream, each holding its share of the wave slots only: the
+            # children's small kernels find free slots sooner (QK_AMR_FAR_SPLIT; profiles/round5/ab9_amr_far_split.txt: 1 / 2 / 3 / 7 sets
+            # 2217 / 2206 / 2226 / 2253 M on config 5's geometry, 7 far boxes)
+            nsplit = max(1, min(len(far), int(__import__("os").environ.get("QK_AMR_FAR_SPLIT", "8"))))
+            self._far_parts = [self._far_group] if nsplit == 1 else [mk(far[k::nsplit]) for k in range(nsplit)]
             nbytes = self.ctx.L.qk_hydro_stage_scratch_bytes(self._far_group[0].h, __import__("ctypes").byref(self.traits))
             self._far_scratch = torch.empty(max(nbytes // 8, 1), dtype=torch.float64, device=self.ctx.device)
             # the far boxes fill whatever the children's small kernels leave idle: the LOWEST priority the device offers (the compute stream
@@ -473,6 +478,21 @@ class AmrLevelSim(HydroSimulation):
             least, greatest = torch.cuda.Stream.priority_range()
             prio = {"low": least, "high": greatest}.get(_os.environ.get("QK_AMR_FAR_PRIORITY", "low"), 0)
             self._far_stream = torch.cuda.Stream(device=self.ctx.device, priority=prio)
+            # (Measured and rejected, profiles/round5/ab8_amr_cu_mask_rejected.txt: the far boxes on a stream that leaves every 8th / 4th / 16th
+            # compute unit alone (qk_stream_create_cu_mask), so that a child kernel need not wait for the wave slots the far boxes' long marching
+            # waves hold: 2220 -> 1936 / 1937 / 1649 M — a CU-masked queue runs the far kernels far slower than the CUs it loses.)
+            keep_free = int(_os.environ.get("QK_AMR_FAR_CU_MASK", "0"))
+            if keep_free > 1:
+                import ctypes as C
+                ncu = torch.cuda.get_device_properties(self.ctx.device).multi_processor_count
+                words = (ncu + 31) // 32
+                mask = (C.c_uint32 * words)()
+                for cu in range(ncu):
+                    if cu % keep_free != keep_free - 1:
+                        mask[cu // 32] |= 1 << (cu % 32)
+                h = C.c_void_p()
+                self.ctx.check(self.ctx.L.qk_stream_create_cu_mask(self.ctx.h, mask, words, C.byref(h)), "qk_stream_create_cu_mask")
+                self._far_stream = torch.cuda.ExternalStream(h.value, device=self.ctx.device)
             for b in range(self.lev.nboxes):  # the physical-boundary slabs of the near boxes first ("local only" subset of the ghost plan)
                 self.ghost.set_box_remote(b, b in set(far))
             self._far_groups_key = (tuple(near), tuple(far))
@@ -495,7 +515,8 @@ class AmrLevelSim(HydroSimulation):
             ev.record(main)
         with torch.cuda.stream(self._far_stream):
             self._far_stream.wait_event(ev)
-            self._fused_launch(2, inter, old, new, dt_lev, group=self._far_group, slot=1, scratch=self._far_scratch)
+            for part in self._far_parts:
+                self._fused_launch(2, inter, old, new, dt_lev, group=part, slot=1, scratch=self._far_scratch)
             self._prim_now = False
             # FixupState of the far boxes (reference src/simulation.hpp:1308-1312: after Reflux and AverageDownTo — neither touches a far box, so
             # for these cells it may as well run now, beside the children); its maxima wait in words 4, 5 for the near boxes' (_fixup_near)
