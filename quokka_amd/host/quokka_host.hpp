@@ -1361,7 +1361,8 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		}
 		return correctStage(2, state_inter_cc_, U_old, state_new_cc_[0], dt) ? 1 : 0;
 	}
-	// The primitive hand-off applies to a plain hydro level: no hierarchy around it, no radiation variables in the state, gamma law with
+	// The primitive hand-off applies to a hydro level without coarse-fine ghost cells (a plain level, or level 0 of a hierarchy: its children
+	// interpolate from its old and new states, never from the intermediate one): no radiation variables in the state, gamma law with
 	// reconstruct_eint off, and boundary rules that act component by component (reflect / extrapolate / periodic: the momenta's parity is the
 	// velocities'); a problem with ext_dir faces writes CONSERVED values through its functor.
 	[[nodiscard]] auto primHandoffApplies() -> bool
@@ -1370,11 +1371,10 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 			return primHandoffOk_;
 		}
 		primHandoffChecked_ = true;
-		int on = 1, maxLevel = 0;
+		int on = 1;
 		amrex::ParmParse("qk").query("prim_handoff", on);
-		amrex::ParmParse("amr").query("max_level", maxLevel);
 		auto const t = qkhost::traits<problem_t>();
-		bool ok = on != 0 && maxLevel == 0 && this->amrLevel_ == 0 && amr_ == nullptr && !is_radiation_enabled_ && t.reconstruct_eint == 0 &&
+		bool ok = on != 0 && this->amrLevel_ == 0 && !is_radiation_enabled_ && t.reconstruct_eint == 0 &&
 			  t.eos_temperature_model == 0 && !(t.cs_isothermal == t.cs_isothermal) && t.gamma != 1.0 &&
 			  Physics_Indices<problem_t>::nvarTotal_cc == ncompHydro_;
 		for (auto const &bc : this->BCs_cc_) {
