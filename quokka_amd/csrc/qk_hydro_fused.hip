@@ -541,7 +541,7 @@ QK_DEV auto epiEint(Eos const &eos, EpiConst const &ec, double rho, double T) ->
 // stores S = U_old + (dt/2) r_1 and P(U_old) in `a.rhs1`; 2: stage 2 — `half` holds what stage 1 stored and the update is S + (dt/2) r_2
 template <int NS, int CS, bool FOFC = false, int NDIM = 3>
 QK_DEV void updateCellFrom(SweepArgs const &a, Eos const &eos, EpiConst const &ec, int b, int i, int j, int k, double U[NVAR + NS], const double rhs_sweeps[NVAR + NS],
-			   double div_v, const double half[NVAR + NS + 1], double &sig0, double &sig1)
+			   double div_v, const double half[NVAR + NS + 1], double &sig0, double &sig1, bool haveP = false, double Pknown = 0.)
 {
 	WA4 Un(a.U_out[b]);
 	IA4 flag(a.redoFlag[b]);
@@ -559,6 +559,10 @@ QK_DEV void updateCellFrom(SweepArgs const &a, Eos const &eos, EpiConst const &e
 	double Pgas;
 	if (CS == 2) {
 		Pgas = half[NVAR + NS];
+	} else if (haveP) {
+		// (uniform) the old state is the sweep's input state and the marching window holds this cell's primitives: its pressure there is
+		// ComputePressure of these conserved values, formed by the same operations on the same operands (consToPrim, reconstruct_eint off)
+		Pgas = Pknown;
 	} else {
 		const double rho = U[RHO];
 		if (eos.isothermal) {
@@ -1220,7 +1224,8 @@ __global__ void __launch_bounds__(64 * MARCH_BY) k_sweep_march(SweepArgs a, Eos 
 					u[OT] = ot;
 					u[DIR] = lo + (step - 6);
 					if (live) {
-						updateCellFrom<NS, CARRY ? STAGE : 0, FOFC, TWOD ? 2 : 3>(a, eos, ec, b, u[0], u[1], u[2], Uo, rhs, div_v, F1, sig0, sig1);
+						updateCellFrom<NS, CARRY ? STAGE : 0, FOFC, TWOD ? 2 : 3>(a, eos, ec, b, u[0], u[1], u[2], Uo, rhs, div_v, F1, sig0, sig1,
+													    (STAGE == 1) && a.same_old && !a.reconstruct_eint && !a.prim_in, q[1][PPRES]);
 					}
 				} else if (live) {
 #pragma unroll
