@@ -202,6 +202,9 @@ QK_DEV auto chiCompressive(double Pm2, double Pm1, double Pp1, double Pp2, Recip
 #ifndef QK_PRE_PREFETCH
 #define QK_PRE_PREFETCH 0
 #endif
+#ifndef QK_PRE_HALO_DIET
+#define QK_PRE_HALO_DIET 1 // (A/B knob)
+#endif
 template <bool PRIM>
 __global__ void __launch_bounds__(PT_THREADS, 4) k_pre3(const qk_box *boxes, const SGeom *geom, const qk_array4 *U_t, double *scratch, int64_t T, Eos eos, bool re, int nseg,
 							    int xt, int yt, int ndim)
@@ -329,7 +332,25 @@ __global__ void __launch_bounds__(PT_THREADS, 4) k_pre3(const qk_box *boxes, con
 				s_vy[ty + 2][tx] = c.vy;
 			}
 			if (h >= 0) {
-				hc = cellOf(PF ? rawHalo : ((haloIn && kIn) ? planeLoad(U, uh) : neutral));
+				if constexpr (PRIM && !PF && QK_PRE_HALO_DIET != 0) {
+					// a halo cell of the primitive form is needed for its pressure; its v_x only in the tile's rows within two columns of the tile,
+					// its v_y only in the tile's columns within two rows, its density only on the rim (the shock-strength ratio of chi there):
+					// 2.3 loads per halo cell instead of 5 (the conserved form needs all five to form the pressure)
+					if (haloIn && kIn) {
+						hc.P = U.p[uh + U.ns * ENE];
+						if (hy >= 0 && hy < PT_Y && hx >= -2 && hx < PT_X + 2) {
+							hc.vx = U.p[uh + U.ns * MX];
+						}
+						if (hx >= 0 && hx < PT_X && hy >= -2 && hy < PT_Y + 2) {
+							hc.vy = U.p[uh + U.ns * MY];
+						}
+						if (rimX || rimY) {
+							hc.rho = U.p[uh + U.ns * RHO];
+						}
+					}
+				} else {
+					hc = cellOf(PF ? rawHalo : ((haloIn && kIn) ? planeLoad(U, uh) : neutral));
+				}
 				s_P[hy + 3][hx + 3] = hc.P;
 				if (hy >= 0 && hy < PT_Y && hx >= -2 && hx < PT_X + 2) {
 					s_vx[hy][hx + 2] = hc.vx;
