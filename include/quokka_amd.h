@@ -350,7 +350,8 @@ int qk_rad_computeRadiationFluxes(qk_level *lev, qk_stream s, const qk_rad_trait
  * + AddFluxesRK2(U_new; U0, U1 = U_in) (stage 2, PD-ARS: the old-state fluxes have weight 0) with the flux divergence taken inside the flux
  * kernels (X, Y accumulate into `acc`: 4 components per cell, no ghost cells; Z finishes the update and repairs invalid states) — the state
  * equals the separate calls' in every bit.  U_new may be the arrays of U_in.  flux_out: NULL or three face-centred arrays that receive the
- * fluxes (flux registers).  3-D levels, one photon group; anything else: QK_ERR_UNSUPPORTED (the separate calls serve it).
+ * fluxes (flux registers).  3-D levels; with several photon groups (acc and the face arrays hold 4 components per group) one set of sweeps per group —
+ * the groups are transported independently.  1-D / 2-D levels: QK_ERR_UNSUPPORTED (the separate calls serve them).
  *                                                    reference src/QuokkaSimulation.hpp:1726-1882, src/radiation/radiation_system.hpp:667-775 */
 int qk_rad_stage_fused(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int reconstruction_order, int stage, const qk_array4 *U_in, const qk_array4 *U0,
 		       qk_array4 *U_new, qk_array4 *acc, qk_array4 *const flux_out[3], double dt, const double dx[3]);

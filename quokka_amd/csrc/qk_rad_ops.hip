@@ -342,6 +342,7 @@ struct RadSweep {
 	qk_array4 *acc;	       // NRAD components per cell, no ghost cells needed
 	qk_array4 *flux[3];    // each NULL or the face-centred array that receives the fluxes
 	double dtdx[3];
+	int pg; // component offset of the photon group these launches advance (NRAD * group): the groups are transported independently of each other
 };
 
 // Non-temporal hints on the flux-divergence accumulator of the fused transport stage where they pay: the X sweep's stores and the Z sweep's loads
@@ -412,7 +413,7 @@ template <int ORDER, bool STORE> __global__ void __launch_bounds__(RXB) k_rad_sw
 	double c0[NRAD], p0[NRAD];
 #pragma unroll
 	for (int n = 0; n < NRAD; ++n) {
-		c0[n] = U.p[o + U.ns * (RAD0 + n)];
+		c0[n] = U.p[o + U.ns * (RAD0 + a.pg + n)];
 	}
 	radPrim(rad, c0, p0);
 #pragma unroll
@@ -469,7 +470,7 @@ template <int ORDER, bool STORE> __global__ void __launch_bounds__(RXB) k_rad_sw
 		const int64_t of = F.idx(i, j, k);
 #pragma unroll
 		for (int n = 0; n < NRAD; ++n) {
-			F.p[of + F.ns * n] = Fo[n];
+			F.p[of + F.ns * (a.pg + n)] = Fo[n];
 		}
 	}
 	if (i <= bx.hi[0]) { // a cell of the box: its right face is the next thread's
@@ -477,7 +478,7 @@ template <int ORDER, bool STORE> __global__ void __launch_bounds__(RXB) k_rad_sw
 		const int64_t oa = A.idx(i, j, k);
 #pragma unroll
 		for (int n = 0; n < NRAD; ++n) {
-			radStreamStore(&A.p[oa + A.ns * n], a.dtdx[0] * (Fo[n] - s_f[n][t + 1]));
+			radStreamStore(&A.p[oa + A.ns * (a.pg + n)], a.dtdx[0] * (Fo[n] - s_f[n][t + 1]));
 		}
 	}
 }
@@ -530,7 +531,7 @@ __global__ void __launch_bounds__(256) k_rad_sweep_march(const qk_box *boxes, Ra
 		const int64_t o = U.idx(pos[0], pos[1], pos[2]);
 #pragma unroll
 		for (int n = 0; n < NRAD; ++n) {
-			out[n] = U.p[o + U.ns * (RAD0 + n)];
+			out[n] = U.p[o + U.ns * (RAD0 + a.pg + n)];
 		}
 	};
 #pragma unroll
@@ -567,14 +568,14 @@ __global__ void __launch_bounds__(256) k_rad_sweep_march(const qk_box *boxes, Ra
 			const int64_t oa = A.idx(pos[0], pos[1], pos[2]);
 #pragma unroll
 			for (int n = 0; n < NRAD; ++n) {
-				accv[n] = (EPI == 0) ? A.p[oa + A.ns * n] : radStreamLoad(&A.p[oa + A.ns * n]);
+				accv[n] = (EPI == 0) ? A.p[oa + A.ns * (a.pg + n)] : radStreamLoad(&A.p[oa + A.ns * (a.pg + n)]);
 			}
 			if (EPI != 0) {
 				RA4 Uo(a.U0[b]);
 				const int64_t oo = Uo.idx(pos[0], pos[1], pos[2]);
 #pragma unroll
 				for (int n = 0; n < NRAD; ++n) {
-					u0v[n] = radStreamLoad2(&Uo.p[oo + Uo.ns * (RAD0 + n)]);
+					u0v[n] = radStreamLoad2(&Uo.p[oo + Uo.ns * (RAD0 + a.pg + n)]);
 				}
 			}
 		}
@@ -607,7 +608,7 @@ __global__ void __launch_bounds__(256) k_rad_sweep_march(const qk_box *boxes, Ra
 			const int64_t of = F.idx(pos[0], pos[1], pos[2]);
 #pragma unroll
 			for (int n = 0; n < NRAD; ++n) {
-				F.p[of + F.ns * n] = Fo[n];
+				F.p[of + F.ns * (a.pg + n)] = Fo[n];
 			}
 		}
 		if (face > c0) { // cell face-1 has both its faces now
@@ -621,7 +622,7 @@ __global__ void __launch_bounds__(256) k_rad_sweep_march(const qk_box *boxes, Ra
 				const int64_t oa = A.idx(pos[0], pos[1], pos[2]);
 #pragma unroll
 				for (int n = 0; n < NRAD; ++n) {
-					A.p[oa + A.ns * n] = cons[n];
+					A.p[oa + A.ns * (a.pg + n)] = cons[n];
 				}
 			} else {
 #pragma unroll
@@ -641,7 +642,7 @@ __global__ void __launch_bounds__(256) k_rad_sweep_march(const qk_box *boxes, Ra
 				const int64_t on = Un.idx(pos[0], pos[1], pos[2]);
 #pragma unroll
 				for (int n = 0; n < NRAD; ++n) {
-					radStreamStore2(&Un.p[on + Un.ns * (RAD0 + n)], cons[n]);
+					radStreamStore2(&Un.p[on + Un.ns * (RAD0 + a.pg + n)], cons[n]);
 				}
 			}
 		}
@@ -986,8 +987,8 @@ int qk_rad_stage_fused(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int 
 	QK_REQUIRE(lev->ctx, U_in && U0 && U_new && acc && dx_in, "rad stage_fused: NULL array");
 	QK_REQUIRE(lev->ctx, order >= 1 && order <= 3, "rad stage_fused: reconstruction order must be 1..3");
 	QK_REQUIRE(lev->ctx, stage == 1 || stage == 2, "rad stage_fused: stage must be 1 or 2");
-	if (lev->ndim != 3 || rt->ngroups > 1) {
-		return setError(lev->ctx, QK_ERR_UNSUPPORTED, "rad stage_fused: 3-D levels and one photon group (otherwise computeRadiationFluxes + PredictStep / AddFluxesRK2)");
+	if (lev->ndim != 3) {
+		return setError(lev->ctx, QK_ERR_UNSUPPORTED, "rad stage_fused: 3-D levels (otherwise computeRadiationFluxes + PredictStep / AddFluxesRK2)");
 	}
 	const bool store = flux_out != nullptr && (flux_out[0] != nullptr || flux_out[1] != nullptr || flux_out[2] != nullptr);
 	QK_REQUIRE(lev->ctx, !store || (flux_out[0] && flux_out[1] && flux_out[2]), "rad stage_fused: the face fluxes are stored in all directions or in none");
@@ -1001,7 +1002,10 @@ int qk_rad_stage_fused(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int 
 		a.flux[d] = store ? flux_out[d] : nullptr;
 		a.dtdx[d] = dt / dx_in[d];
 	}
+	// the photon groups are transported independently (radiation_system.hpp:667-771 loops over them inside one kernel): one set of sweeps per group
 #define QK_RAD_SWEEPS(O)                                                                                                                             \
+	for (int g = 0; g < rad.ngroups; ++g) {                                                                                                      \
+	a.pg = NRAD * g;                                                                                                                             \
 	if (stage == 1) {                                                                                                                            \
 		if (store) {                                                                                                                         \
 			launchRadSweeps<O, 1, true>(lev, s, rad, a, 4);                                                                              \
@@ -1014,6 +1018,7 @@ int qk_rad_stage_fused(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int 
 		} else {                                                                                                                             \
 			launchRadSweeps<O, 2, false>(lev, s, rad, a, 4);                                                                             \
 		}                                                                                                                                    \
+	}                                                                                                                                            \
 	}
 	if (order == 3) {
 		QK_RAD_SWEEPS(3)

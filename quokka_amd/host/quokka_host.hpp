@@ -711,14 +711,14 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		}
 	}
 
-	// qk_rad_stage_fused serves 3-D builds with one photon group (deck: qk.fused_radiation = 0 keeps the separate operators; tests)
+	// qk_rad_stage_fused serves 3-D builds (one set of sweeps per photon group; deck: qk.fused_radiation = 0 keeps the separate operators; tests)
 	amrex::MultiFab radAcc_;
 	int radFused_ = -1;
 	auto radFusedActive() -> bool
 	{
 		if (radFused_ < 0) {
 			radFused_ = 0;
-			if constexpr (AMREX_SPACEDIM == 3 && Physics_Traits<problem_t>::nGroups == 1) {
+			if constexpr (AMREX_SPACEDIM == 3) {
 				radFused_ = 1;
 				amrex::ParmParse("qk").query("fused_radiation", radFused_);
 				if (radFused_ != 0) {

@@ -57,9 +57,9 @@ class RadhydroSimulation(HydroSimulation):
         lev, nd = self.lev, geom.ndim
         self.radFluxOld = [MultiFab(lev, self.nrad, 0, facedir=d) for d in range(nd)]
         self.radFlux = [MultiFab(lev, self.nrad, 0, facedir=d) for d in range(nd)]
-        # One transport stage as three sweeps that take the flux divergence where the fluxes are produced (qk_rad_stage_fused): 3-D, one
-        # photon group; the face fluxes are stored only when something reads them (store_rad_flux: the flux registers of a refined hierarchy)
-        self.use_fused_rad = bool(use_fused) and nd == 3 and self.nGroups == 1
+        # One transport stage as three sweeps that take the flux divergence where the fluxes are produced (qk_rad_stage_fused; one set of sweeps
+        # per photon group): 3-D; the face fluxes are stored only when something reads them (store_rad_flux: the flux registers of a hierarchy)
+        self.use_fused_rad = bool(use_fused) and nd == 3 and os.environ.get("QK_RAD_FUSED", "1") == "1"
         self.store_rad_flux = False
         # swapRadiationState() of substeps 2 .. n folded into the source-term kernel of the substep before (its registers hold the values)
         self.use_rad_mirror = os.environ.get("QK_RAD_MIRROR", "1") != "0"  # (the environment variable: same-box A/B, profiles/tools/ab_env.sh)

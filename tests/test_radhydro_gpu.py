@@ -438,3 +438,58 @@ def test_shell_with_the_carried_rk2_average_stays_within_tolerance(ctx):
             den = np.abs(x[n]).sum()
             if den > 0:
                 assert np.abs(x[n] - y[n]).sum() <= 1e-12 * den, n
+
+
+@pytest.mark.parametrize("rad_order", [2, 3])
+def test_fused_radiation_stage_with_four_photon_groups(ctx, rad_order):
+    """qk_rad_stage_fused with ngroups > 1 (one set of sweeps per photon group: the groups are transported independently, reference
+    src/radiation/radiation_system.hpp:667-771) against computeRadiationFluxes + PredictStep / AddFluxesRK2 on a 3-D level of eight boxes with
+    rough, valid radiation states in every group: both stages, every component and every stored face flux, bit for bit."""
+    from quokka_amd import capi
+    from quokka_amd.radhydro import RAD0, RadhydroSimulation
+    from quokka_amd.radhydro_multigroup import H_PLANCK, PPL_FIXED_SLOPE, PulseMGConstants as S
+    from quokka_amd.simulation import Geometry
+    ng, n = 4, 16
+    ncomp = RAD0 + 4 * ng
+    geom = Geometry(3, [n] * 3, [0.0] * 3, [1024.0] * 3, [1, 1, 1])
+    bcs = [([capi.BC_INT_DIR] * 3, [capi.BC_INT_DIR] * 3) for _ in range(ncomp)]
+    traits = capi.traits(5.0 / 3.0, True, 3, mean_molecular_weight=S.mu, boltzmann_constant=capi.K_B)
+    sims = []
+    for fused in (True, False):
+        rt = capi.RadTraits(S.c, S.chat, S.a_rad, S.erad_floor, 1, 0, S.kappa0, S.kappa0, S.kappa0, 1, 0)
+        rt.set_groups(S.boundaries, H_PLANCK, PPL_FIXED_SLOPE, [0.0] * (ng + 1), [S.kappa0] * (ng + 1))
+        s = RadhydroSimulation(ctx, geom, traits, rt, bcs, [8] * 3)
+        assert s.nGroups == ng and s.use_fused_rad
+        s.use_fused_rad = fused
+        s.store_rad_flux = True
+        s.radiationReconstructionOrder_ = rad_order
+        rng = np.random.default_rng(3)
+
+        def ic(i, j, k):
+            U = np.zeros((ncomp,) + i.shape)
+            U[0], U[4], U[5] = 1.0, 1.0, 1.0
+            for g in range(ng):
+                E = S.Erad0 * rng.uniform(0.1, 10.0, i.shape)
+                f = rng.uniform(-0.55, 0.55, (3,) + i.shape)  # |F| <= 0.95 c E
+                U[RAD0 + 4 * g] = E
+                for d in range(3):
+                    U[RAD0 + 4 * g + 1 + d] = f[d] * S.c * E
+            return U
+
+        s.set_initial_conditions(ic)
+        s.state_old_cc_.copy_from(s.state_new_cc_)
+        dt = 0.3 * geom.dx[0] / S.chat
+        s.advanceRadiationForwardEuler(dt)
+        s.advanceRadiationMidpointRK2(dt)
+        sims.append(s)
+    a, b = sims
+    for x, y in zip(a.gather_valid_local(), b.gather_valid_local()):
+        assert np.array_equal(x, y)
+    for d in range(3):
+        for fa, fb in ((a.radFluxOld[d], b.radFluxOld[d]), (a.radFlux[d], b.radFlux[d])):
+            for k in range(a.lev.nboxes):
+                assert torch.equal(fa.fabs[k], fb.fabs[k]), (d, k)
+    # the transport did change every group
+    new, old = a.state_new_cc_.valid(0).cpu().numpy(), a.state_old_cc_.valid(0).cpu().numpy()
+    for g in range(ng):
+        assert not np.array_equal(new[RAD0 + 4 * g], old[RAD0 + 4 * g])
