@@ -655,12 +655,16 @@ def run_sedov(ctx, torch, dist, rank, world, ncell, mgs, steps, warmup, profile=
         from quokka_amd import comm
         ev = sim.ghost.exposed_events
         sim.ghost.exposed_events = None
-        exposed = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
+        waits = [a.elapsed_time(b) for a, b in ev]
+        exposed = sum(waits) / max(len(waits), 1)
+        edges = [0.05, 0.2, 1.0, 5.0]  # ms
+        hist = [sum(1 for w in waits if (lo <= w < hi)) for lo, hi in zip([0.0] + edges, edges + [float("inf")])]
         sent = float(sum(sbuf.numel() * sbuf.element_size() for _, _, sbuf, _ in sim.ghost.peers))
         t = torch.tensor([elapsed, exposed, sent], dtype=torch.float64, device=ctx.device)
         comm.all_reduce(t, dist.ReduceOp.MAX)
         elapsed = float(t[0].item())
         sim.exchange_stats = {"fills_timed": len(ev), "exposed_ms_per_fill_max_over_ranks": float(t[1].item()), "exposed_ms_per_fill_rank0": exposed,
+                              "exposed_ms_histogram_rank0": {"edges_ms": edges, "fills": hist, "max_ms": max(waits) if waits else 0.0},
                               "bytes_sent_per_fill_max_over_ranks": float(t[2].item()), "bytes_sent_per_fill_rank0": sent,
                               "note": "exposed = time the compute stream waits for the peers' strips after the boxes that need nothing remote were "
                                       "advanced (HIP events around the wait); bytes = packed ghost strips one rank sends per fill, all components"}
