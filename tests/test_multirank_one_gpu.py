@@ -296,5 +296,6 @@ def test_bench_multi_gpu_line_dry_run_with_eight_ranks():
     assert d["selftest"]["selftest"] == "PASS" and d["selftest"]["boxes_differing_from_one_rank"] == 0, d["selftest"]
     g = d["config"]["ghost_exchange"]
     assert g["peers_rank0"] >= 3 and g["bytes_sent_per_fill_rank0"] > 0 and g["fills_timed"] == 2 * 3 and g["exposed_ms_per_fill_max_over_ranks"] >= 0.0, g
+    assert sum(g["exposed_ms_histogram_rank0"]["fills"]) == g["fills_timed"]
     a = d["amr_maxlev2"]
     assert a["scaling"] == "strong" and a["value"] > 0 and len(a["config"]["cells_per_level"]) == 3, a
