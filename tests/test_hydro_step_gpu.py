@@ -644,3 +644,45 @@ def test_ghost_fill_as_one_gather_equals_copies_then_boundary_rules(ctx, case):
     torch.cuda.synchronize()
     for k in range(len(boxes)):
         assert np.array_equal(a.fab_numpy(k), b.fab_numpy(k)), f"{case}: box {k} (fill)"
+
+
+@pytest.mark.gpu
+def test_cu_masked_stream_is_a_legal_qk_stream(ctx):
+    """qk_stream_create_cu_mask: a HIP stream restricted to a subset of the compute units (hipExtStreamCreateWithCUMask) takes the library's
+    launches like any other stream (here: a clear of device words and a ghost copy), then is destroyed"""
+    import ctypes as C
+    from quokka_amd import capi
+    from quokka_amd.multifab import Level, MultiFab
+    from quokka_amd.simulation import GhostExchange, Geometry, chop_domain
+    ncu = torch.cuda.get_device_properties(ctx.device).multi_processor_count
+    words = (ncu + 31) // 32
+    mask = (C.c_uint32 * words)()
+    for cu in range(ncu):
+        if cu % 8 != 7:
+            mask[cu // 32] |= 1 << (cu % 32)
+    h = C.c_void_p()
+    ctx.check(ctx.L.qk_stream_create_cu_mask(ctx.h, mask, words, C.byref(h)), "qk_stream_create_cu_mask")
+    assert h.value
+    t = torch.full((16,), 7, dtype=torch.int64, device=ctx.device)
+    torch.cuda.synchronize()
+    ctx.check(ctx.L.qk_clear_bytes(ctx.h, h, C.c_void_p(t.data_ptr()), 64), "qk_clear_bytes")
+    boxes = chop_domain([16] * 3, [8] * 3)
+    lev = Level(ctx, 3, boxes)
+    geom = Geometry(3, [16] * 3, [0.0] * 3, [1.0] * 3, [1, 1, 1])
+    ex = GhostExchange(lev, geom, 2, 2, boxes, [0] * len(boxes), 0, [([capi.BC_INT_DIR] * 3, [capi.BC_INT_DIR] * 3)] * 2)
+    a, b = MultiFab(lev, 2, 2), MultiFab(lev, 2, 2)
+    rng = np.random.default_rng(2)
+    for k, shp in enumerate(a.shapes):
+        v = rng.normal(size=shp)
+        a.set_fab(k, v)
+        b.set_fab(k, v)
+    torch.cuda.synchronize()
+    ctx.check(ctx.L.qk_FillBoundary_local(ex.h, h, a.ptr), "FillBoundary_local on the masked stream")
+    ex.fill(b)
+    ext = torch.cuda.ExternalStream(h.value, device=ctx.device)
+    ext.synchronize()
+    torch.cuda.synchronize()
+    assert t[:8].eq(0).all() and t[8:].eq(7).all()
+    for k in range(len(boxes)):
+        assert np.array_equal(a.fab_numpy(k), b.fab_numpy(k))
+    ctx.check(ctx.L.qk_stream_destroy(ctx.h, h), "qk_stream_destroy")
