@@ -118,11 +118,6 @@ int qk_profile_get(qk_ctx *ctx, int k, const char **name, long *count, double *t
  * call instead of a host-framework fill kernel (the reference clears its counters with amrex::Gpu fills, e.g. redoFlag.setVal(none),
  * src/QuokkaSimulation.hpp:1087).  `device_ptr` must be a device allocation. */
 int qk_clear_bytes(qk_ctx *ctx, qk_stream s, void *device_ptr, int64_t nbytes);
-/* A HIP stream whose kernels run only on the compute units whose bit is set in cu_mask (bit i of word i / 32: CU i; hipExtStreamCreateWithCUMask).
- * Any stream is a legal qk_stream; this is only how to make one that shares the chip by compute units instead of by wave slots (measured for the
- * AMR driver's side stream and not used by default: profiles/round5/ab8_amr_cu_mask_rejected.txt). */
-int qk_stream_create_cu_mask(qk_ctx *ctx, const uint32_t *cu_mask, int nwords, qk_stream *stream_out);
-int qk_stream_destroy(qk_ctx *ctx, qk_stream s);
 
 /* BoxArray of one level owned by this rank (valid, cell-centred boxes). */
 int qk_level_create(qk_ctx *ctx, qk_level **lev, int ndim, int nboxes, const qk_box *valid_boxes);
@@ -468,13 +463,6 @@ int qk_ghost_plan_set_components(qk_ghost_plan *plan, int scomp, int ncomp);
 int qk_ghost_plan_box_is_remote(qk_ghost_plan *plan, int local_box); /* 1 / 0, < 0 on error */
 /* move a box into / out of the late group by hand (load balancing between the two launches; single-GPU tests of the split) */
 int qk_ghost_plan_set_box_remote(qk_ghost_plan *plan, int local_box, int flag);
-/* AMRSimulation::fillBoundaryConditions, level-0 branch (reference src/simulation.hpp:1751-1776), as ONE launch: state.FillBoundary(periodicity)
- * and the mathematical boundary rules of PhysBCFunct (reflect_even / reflect_odd / foextrap, AMReX_FilCC composed over the dimensions) evaluated as
- * a gather — every ghost cell reads the valid cell its value comes from, through the mirror / clamp of its index and the neighbour that owns the
- * image.  Same values as qk_FillBoundary_local followed by qk_FillPhysicalBoundary (tested cell by cell).  Returns QK_OK when the fill is done,
- * 1 when the form does not apply and nothing was written — boxes on other ranks, a face whose components mix reflecting and extrapolating rules or
- * use ext_dir (a Dirichlet functor), a level whose ghost cells the copies do not cover (coarse-fine boundaries): then call the two entries. */
-int qk_FillBoundary_gather(qk_ghost_plan *plan, qk_stream s, qk_array4 *state, const qk_bcrec *bcs);
 int qk_FillPhysicalBoundary_subset(qk_ghost_plan *plan, qk_stream s, qk_array4 *state, const qk_bcrec *bcs, const qk_dirichlet_face *dirichlet,
 				   int which);
 

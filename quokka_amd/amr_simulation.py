@@ -478,21 +478,8 @@ class AmrLevelSim(HydroSimulation):
             least, greatest = torch.cuda.Stream.priority_range()
             prio = {"low": least, "high": greatest}.get(_os.environ.get("QK_AMR_FAR_PRIORITY", "low"), 0)
             self._far_stream = torch.cuda.Stream(device=self.ctx.device, priority=prio)
-            # (Measured and rejected, profiles/round5/ab8_amr_cu_mask_rejected.txt: the far boxes on a stream that leaves every 8th / 4th / 16th
-            # compute unit alone (qk_stream_create_cu_mask), so that a child kernel need not wait for the wave slots the far boxes' long marching
-            # waves hold: 2220 -> 1936 / 1937 / 1649 M — a CU-masked queue runs the far kernels far slower than the CUs it loses.)
-            keep_free = int(_os.environ.get("QK_AMR_FAR_CU_MASK", "0"))
-            if keep_free > 1:
-                import ctypes as C
-                ncu = torch.cuda.get_device_properties(self.ctx.device).multi_processor_count
-                words = (ncu + 31) // 32
-                mask = (C.c_uint32 * words)()
-                for cu in range(ncu):
-                    if cu % keep_free != keep_free - 1:
-                        mask[cu // 32] |= 1 << (cu % 32)
-                h = C.c_void_p()
-                self.ctx.check(self.ctx.L.qk_stream_create_cu_mask(self.ctx.h, mask, words, C.byref(h)), "qk_stream_create_cu_mask")
-                self._far_stream = torch.cuda.ExternalStream(h.value, device=self.ctx.device)
+            # (Measured and rejected in round 5, profiles/round5/ab8_amr_cu_mask_rejected.txt: the far boxes on a CU-masked stream that leaves every
+            # 8th / 4th / 16th compute unit to the children: 2220 -> 1936 / 1937 / 1649 M.)
             for b in range(self.lev.nboxes):  # the physical-boundary slabs of the near boxes first ("local only" subset of the ghost plan)
                 self.ghost.set_box_remote(b, b in set(far))
             self._far_groups_key = (tuple(near), tuple(far))
@@ -1039,6 +1026,12 @@ class AmrSimulation:
             L._signal_of_state_new = None
             L._old_ghosts_filled = False
             L._new_ghosts_filled = False
+            # whatever FixupState flagged on this level belongs to the discarded attempt (a deferred child stage is not corrected: its negative
+            # densities reach FixupState through AverageDownTo): the sticky error word and the pending reads go with it
+            L._dev_fix[2:3].zero_()
+            L._fix_error_pending = False
+            L._fix_far_words = False
+            L._fix_words_pending = False
         for l in range(lev + 1, self.finest_level + 1):  # plans a regrid of the discarded attempt may have re-pointed
             self.levels[l].link_to_parent(self.levels[l - 1])
         self.__dict__.pop("_split_cache", None)

@@ -140,8 +140,6 @@ def lib() -> C.CDLL:
     L.qk_profile_enable.argtypes = [vp, ci]
     L.qk_profile_only.argtypes = [vp, C.c_char_p]
     L.qk_clear_bytes.argtypes = [vp, vp, vp, C.c_int64]
-    L.qk_stream_create_cu_mask.argtypes = [vp, P(C.c_uint32), ci, P(vp)]
-    L.qk_stream_destroy.argtypes = [vp, vp]
     L.qk_profile_reset.argtypes = [vp]
     L.qk_cloudy_tables_read.argtypes = [vp, C.c_char_p, P(CloudyTables)]
     L.qk_cloudy_tables_free.argtypes = [P(CloudyTables)]
@@ -200,7 +198,6 @@ def lib() -> C.CDLL:
         L.qk_FillBoundary_unpack_int.argtypes = [vp, vp, ci, vp, vp]
         L.qk_FillPhysicalBoundary.argtypes = [vp, vp, vp, P(BCRec), P(DirichletFace)]
         L.qk_FillPhysicalBoundary_subset.argtypes = [vp, vp, vp, P(BCRec), P(DirichletFace), C.c_int]
-        L.qk_FillBoundary_gather.argtypes = [vp, vp, vp, P(BCRec)]
         L.qk_ghost_plan_set_components.argtypes = [vp, C.c_int, C.c_int]
         L.qk_ghost_plan_box_is_remote.argtypes = [vp, C.c_int]
         L.qk_ghost_plan_set_box_remote.argtypes = [vp, C.c_int, C.c_int]
@@ -265,7 +262,7 @@ DECLARED_SYMBOLS = [
     "qk_rad_AddSourceTermsSingleGroup", "qk_rad_AddSourceTermsSingleGroupMirror", "qk_rad_AddSourceTermsMultiGroup", "qk_rad_mg_planck_fractions",
     "qk_ghost_plan_create", "qk_ghost_plan_destroy", "qk_ghost_plan_num_peers", "qk_ghost_plan_peer", "qk_ghost_plan_num_items", "qk_ghost_plan_item",
     "qk_FillBoundary_local", "qk_FillBoundary_local_int", "qk_FillBoundary_pack", "qk_FillBoundary_unpack", "qk_FillBoundary_pack_int", "qk_FillBoundary_unpack_int", "qk_SumBoundary_local", "qk_SumBoundary_pack", "qk_SumBoundary_unpack", "qk_FillPhysicalBoundary",
-    "qk_FillPhysicalBoundary_subset", "qk_FillBoundary_gather", "qk_stream_create_cu_mask", "qk_stream_destroy", "qk_ghost_plan_set_components", "qk_ghost_plan_box_is_remote", "qk_ghost_plan_set_box_remote",
+    "qk_FillPhysicalBoundary_subset", "qk_ghost_plan_set_components", "qk_ghost_plan_box_is_remote", "qk_ghost_plan_set_box_remote",
     "qk_tag_relative_gradient", "qk_tag_centered_gradient", "qk_avgdown_plan_create", "qk_avgdown_plan_destroy", "qk_avgdown_plan_num_items", "qk_average_down", "qk_PreInterpState", "qk_PostInterpState",
     "qk_interp_plan_create", "qk_interp_plan_destroy", "qk_interp_plan_num_items", "qk_interp_plan_item", "qk_InterpFromCoarse",
     "qk_fluxreg_create", "qk_fluxreg_destroy", "qk_fluxreg_num_items", "qk_fluxreg_item", "qk_fluxreg_reset", "qk_fluxreg_save", "qk_fluxreg_restore", "qk_fluxreg_CrseAdd", "qk_fluxreg_FineAdd",

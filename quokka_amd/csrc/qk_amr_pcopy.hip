@@ -32,6 +32,7 @@ struct PcItem {
 struct PcPeer {
 	int rank = -1;
 	std::vector<PcItem> send, recv;
+	std::vector<int> recv_groups; // (see addGroups)
 	int64_t send_count = 0, recv_count = 0;
 	int64_t max_send_cells = 0, max_recv_cells = 0;
 	PcItem *d_send = nullptr, *d_recv = nullptr;
@@ -81,7 +82,9 @@ inline auto cells(PcItem const &c) -> int64_t { return static_cast<int64_t>(c.hi
 enum { PC_LOCAL = 0, PC_PACK = 1, PC_UNPACK = 2 };
 
 // blockIdx.y = item; grid-stride over region cells x ncomp (32-bit index arithmetic, as k_copy of the ghost plan).  ADD: the value is added to
-// the destination — several source pieces may land on one destination cell (the rings of two fine boxes around one coarse cell), hence atomics.
+// the destination.  Several source pieces may land on one destination cell (the rings of two or three fine boxes around one coarse cell): the
+// items of a plan are sorted into groups whose destination regions are disjoint (addGroups) and an add is one launch per group, in order —
+// plain read-add-write, the same sum in the same order on every run (atomics gave (s + a) + b or (s + b) + a as the scheduler pleased).
 template <int MODE, bool ADD>
 __global__ void __launch_bounds__(256) k_pcopy(const PcItem *items, const qk_array4 *src_t, qk_array4 *dst_t, double *buf, int ncomp, int scomp_src, int scomp_dst)
 {
@@ -109,7 +112,8 @@ __global__ void __launch_bounds__(256) k_pcopy(const PcItem *items, const qk_arr
 		} else {
 			WA4 D(dst_t[it.dst_box]);
 			if (ADD) {
-				atomicAdd(D.ptr(di, dj, dk, scomp_dst + n), v);
+				double *d = D.ptr(di, dj, dk, scomp_dst + n);
+				*d = *d + v;
 			} else {
 				D(di, dj, dk, scomp_dst + n) = v;
 			}
@@ -122,6 +126,61 @@ inline auto gridFor(int64_t values, int nitems) -> dim3
 	const int64_t gx = std::max<int64_t>(1, std::min<int64_t>((values + 255) / 256, 256));
 	return dim3(static_cast<unsigned>(gx), static_cast<unsigned>(nitems), 1);
 }
+constexpr int PC_MAX_ITEMS_PER_LAUNCH = 65535; // (the items of a launch live in gridDim.y)
+
+// Stable-sorts `items` into groups in which no two items touch the same destination cell (greedy colouring in the canonical item order: an item takes
+// the first group none of whose members overlaps it) and returns the group boundaries [0, g1, g2, ..., n].  Host box algebra, identical on every rank.
+auto addGroups(std::vector<PcItem> &items) -> std::vector<int>
+{
+	const int n = static_cast<int>(items.size());
+	std::vector<int> colour(n, 0);
+	int ncol = (n > 0) ? 1 : 0;
+	for (int i = 0; i < n; ++i) {
+		std::vector<char> used(static_cast<size_t>(ncol) + 1, 0);
+		for (int j = 0; j < i; ++j) {
+			if (items[j].dst_box != items[i].dst_box) {
+				continue;
+			}
+			bool hit = true;
+			for (int d = 0; d < 3; ++d) {
+				hit = hit && items[j].lo[d] <= items[i].hi[d] && items[i].lo[d] <= items[j].hi[d];
+			}
+			if (hit) {
+				used[colour[j]] = 1;
+			}
+		}
+		int c = 0;
+		while (used[c] != 0) {
+			++c;
+		}
+		colour[i] = c;
+		ncol = std::max(ncol, c + 1);
+	}
+	std::vector<int> order(n);
+	for (int i = 0; i < n; ++i) {
+		order[i] = i;
+	}
+	std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return colour[a] < colour[b]; });
+	std::vector<PcItem> sorted(n);
+	std::vector<int> bounds{0};
+	for (int q = 0; q < n; ++q) {
+		sorted[q] = items[order[q]];
+		if (q > 0 && colour[order[q]] != colour[order[q - 1]]) {
+			bounds.push_back(q);
+		}
+	}
+	bounds.push_back(n);
+	items.swap(sorted);
+	return bounds;
+}
+
+// one launch per run of at most 65535 items of [first, last)
+template <class Launch> void forItemChunks(int first, int last, Launch &&launch)
+{
+	for (int a = first; a < last; a += PC_MAX_ITEMS_PER_LAUNCH) {
+		launch(a, std::min(last - a, PC_MAX_ITEMS_PER_LAUNCH));
+	}
+}
 
 } // namespace
 
@@ -130,6 +189,7 @@ struct qk_pcopy_plan {
 	int ncomp = 0; // values per cell in the peer buffers (fixed at creation, like the ghost plan's)
 	int nsrc_local = 0, ndst_local = 0;
 	std::vector<PcItem> local;
+	std::vector<int> local_groups; // add groups of `local` (addGroups)
 	PcItem *d_local = nullptr;
 	int64_t max_local_cells = 0;
 	std::vector<PcPeer> peers;
@@ -268,8 +328,10 @@ int qk_pcopy_plan_create(qk_ctx *ctx, const qk_geometry *geom, int n_src, const 
 		QK_HIP_CHECK(ctx, hipMemcpy(*d, v.data(), sizeof(PcItem) * v.size(), hipMemcpyHostToDevice));
 		return QK_OK;
 	};
+	P->local_groups = addGroups(P->local);
 	int rc = upload(P->local, &P->d_local);
 	for (auto &kv : peers) {
+		kv.second.recv_groups = addGroups(kv.second.recv); // (the offsets into the peer buffer travel with the items)
 		if (rc == QK_OK) {
 			rc = upload(kv.second.send, &kv.second.d_send);
 		}
@@ -359,13 +421,18 @@ int qk_ParallelCopy_local(qk_pcopy_plan *plan, qk_stream s, const qk_array4 *src
 		return QK_OK;
 	}
 	ProfScope ps(ctx, static_cast<hipStream_t>(s), "pcopy_local");
-	const dim3 grid = gridFor(plan->max_local_cells * ncomp, static_cast<int>(plan->local.size()));
 	if (add != 0) {
-		hipLaunchKernelGGL((k_pcopy<PC_LOCAL, true>), grid, dim3(256), 0, static_cast<hipStream_t>(s), plan->d_local, src_t, dst_t, static_cast<double *>(nullptr), ncomp,
-				   scomp_src, scomp_dst);
+		for (size_t g = 0; g + 1 < plan->local_groups.size(); ++g) {
+			forItemChunks(plan->local_groups[g], plan->local_groups[g + 1], [&](int first, int n) {
+				hipLaunchKernelGGL((k_pcopy<PC_LOCAL, true>), gridFor(plan->max_local_cells * ncomp, n), dim3(256), 0, static_cast<hipStream_t>(s),
+						   plan->d_local + first, src_t, dst_t, static_cast<double *>(nullptr), ncomp, scomp_src, scomp_dst);
+			});
+		}
 	} else {
-		hipLaunchKernelGGL((k_pcopy<PC_LOCAL, false>), grid, dim3(256), 0, static_cast<hipStream_t>(s), plan->d_local, src_t, dst_t, static_cast<double *>(nullptr), ncomp,
-				   scomp_src, scomp_dst);
+		forItemChunks(0, static_cast<int>(plan->local.size()), [&](int first, int n) {
+			hipLaunchKernelGGL((k_pcopy<PC_LOCAL, false>), gridFor(plan->max_local_cells * ncomp, n), dim3(256), 0, static_cast<hipStream_t>(s),
+					   plan->d_local + first, src_t, dst_t, static_cast<double *>(nullptr), ncomp, scomp_src, scomp_dst);
+		});
 	}
 	QK_HIP_CHECK(ctx, hipGetLastError());
 	return QK_OK;
@@ -383,8 +450,10 @@ int qk_ParallelCopy_pack(qk_pcopy_plan *plan, qk_stream s, int k, const qk_array
 	if (pp.send.empty()) {
 		return QK_OK;
 	}
-	hipLaunchKernelGGL((k_pcopy<PC_PACK, false>), gridFor(pp.max_send_cells * ncomp, static_cast<int>(pp.send.size())), dim3(256), 0, static_cast<hipStream_t>(s), pp.d_send,
-			   src_t, static_cast<qk_array4 *>(nullptr), sendbuf, ncomp, scomp_src, 0);
+	forItemChunks(0, static_cast<int>(pp.send.size()), [&](int first, int n) {
+		hipLaunchKernelGGL((k_pcopy<PC_PACK, false>), gridFor(pp.max_send_cells * ncomp, n), dim3(256), 0, static_cast<hipStream_t>(s), pp.d_send + first, src_t,
+				   static_cast<qk_array4 *>(nullptr), sendbuf, ncomp, scomp_src, 0);
+	});
 	QK_HIP_CHECK(ctx, hipGetLastError());
 	return QK_OK;
 }
@@ -401,13 +470,18 @@ int qk_ParallelCopy_unpack(qk_pcopy_plan *plan, qk_stream s, int k, qk_array4 *d
 	if (pp.recv.empty()) {
 		return QK_OK;
 	}
-	const dim3 grid = gridFor(pp.max_recv_cells * ncomp, static_cast<int>(pp.recv.size()));
 	if (add != 0) {
-		hipLaunchKernelGGL((k_pcopy<PC_UNPACK, true>), grid, dim3(256), 0, static_cast<hipStream_t>(s), pp.d_recv, static_cast<const qk_array4 *>(nullptr), dst_t,
-				   const_cast<double *>(recvbuf), ncomp, 0, scomp_dst);
+		for (size_t g = 0; g + 1 < pp.recv_groups.size(); ++g) {
+			forItemChunks(pp.recv_groups[g], pp.recv_groups[g + 1], [&](int first, int n) {
+				hipLaunchKernelGGL((k_pcopy<PC_UNPACK, true>), gridFor(pp.max_recv_cells * ncomp, n), dim3(256), 0, static_cast<hipStream_t>(s), pp.d_recv + first,
+						   static_cast<const qk_array4 *>(nullptr), dst_t, const_cast<double *>(recvbuf), ncomp, 0, scomp_dst);
+			});
+		}
 	} else {
-		hipLaunchKernelGGL((k_pcopy<PC_UNPACK, false>), grid, dim3(256), 0, static_cast<hipStream_t>(s), pp.d_recv, static_cast<const qk_array4 *>(nullptr), dst_t,
-				   const_cast<double *>(recvbuf), ncomp, 0, scomp_dst);
+		forItemChunks(0, static_cast<int>(pp.recv.size()), [&](int first, int n) {
+			hipLaunchKernelGGL((k_pcopy<PC_UNPACK, false>), gridFor(pp.max_recv_cells * ncomp, n), dim3(256), 0, static_cast<hipStream_t>(s), pp.d_recv + first,
+					   static_cast<const qk_array4 *>(nullptr), dst_t, const_cast<double *>(recvbuf), ncomp, 0, scomp_dst);
+		});
 	}
 	QK_HIP_CHECK(ctx, hipGetLastError());
 	return QK_OK;

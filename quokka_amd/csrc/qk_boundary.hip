@@ -64,12 +64,6 @@ struct qk_ghost_plan {
 	qk_bcrec *d_bcs = nullptr;
 	int d_bcs_n = 0;
 	qk_dirichlet_face *d_dir = nullptr;
-	// the whole fill as ONE gather (qk_FillBoundary_gather): built on first use for the BCRecs of that call, rebuilt when they change
-	void *d_gather = nullptr, *d_gather_blocks = nullptr;
-	int n_gather = 0, n_gather_blocks = 0;
-	int64_t max_gather_cells = 0;
-	int gather_state = 0; // 0 not built, 1 ready, 2 does not apply to this plan / these boundary types
-	std::vector<qk_bcrec> gather_bcs;
 };
 
 namespace
@@ -255,258 +249,6 @@ __global__ void __launch_bounds__(256) k_physbc(const CopyItem *items, qk_array4
 			}
 		}
 	}
-}
-
-// ---------------------------------------------------------------------------------------------- the fill as one gather
-// state.FillBoundary + PhysBCFunct (reference src/simulation.hpp:1755-1773) in ONE launch.  The two-kernel form orders "copies, then the mirror
-// rules" because a mirrored source may itself be a ghost cell the copies fill.  Here every ghost cell reads the VALID cell its value comes from:
-// a cell beyond a reflecting / extrapolating face has its index mirrored (or clamped) into the domain per dimension — AMReX's FilccCell rules
-// composed over the dimensions, exactly what k_physbc evaluates — and the image lies either in the box's own valid region or in a region one of
-// the plan's copy items fills from a neighbour's valid region, so the item is (destination region, source box, per dimension src = a i + b, sign
-// per component).  No item reads what another writes.  Applies when every box is on this rank and, per face, all components reflect or all
-// extrapolate (Dirichlet / Marshak functors, mixed rules, coarse-fine levels whose ghost cells the copies do not cover: the two-kernel form).
-struct GatherItem {
-	int dst_box, src_box;
-	int lo[3], hi[3]; // destination region
-	int a[3], b[3];	  // source index = a * destination index + b  (a = 1: copy with shift, -1: mirror, 0: clamp to the face cell)
-	unsigned long long neg; // bit n: component n changes sign (an odd number of reflect_odd mirrors)
-};
-
-// One workgroup per (item, chunk) pair of a table made with the items: an item of V values gets ceil(V / 2048) workgroups (a y-z face of a 128^3
-// box 192, a corner one) — with a (chunks of the largest item) x (items) grid 95 % of the workgroups of a fill found nothing to do.
-struct GatherBlock {
-	int item, chunk, nchunks;
-};
-
-__global__ void __launch_bounds__(256) k_gather(const GatherItem *items, const GatherBlock *blocks, qk_array4 *state_t, int ncomp, int scomp)
-{
-	const GatherBlock gb = blocks[blockIdx.x];
-	const GatherItem it = items[gb.item];
-	const unsigned n0 = static_cast<unsigned>(it.hi[0] - it.lo[0] + 1), n1 = static_cast<unsigned>(it.hi[1] - it.lo[1] + 1),
-		       n2 = static_cast<unsigned>(it.hi[2] - it.lo[2] + 1);
-	const unsigned n01 = n0 * n1;
-	const unsigned ncell = n01 * n2;
-	const unsigned total = ncell * static_cast<unsigned>(ncomp);
-	A4<double, qk_array4> Dst(state_t[it.dst_box]);
-	A4<double, qk_array4> Src(state_t[it.src_box]);
-	const unsigned stride = static_cast<unsigned>(gb.nchunks) * 256u;
-	for (unsigned t = static_cast<unsigned>(gb.chunk) * 256u + threadIdx.x; t < total; t += stride) {
-		const unsigned un = t / ncell;
-		const unsigned c = t - un * ncell;
-		const unsigned uk = c / n01;
-		const unsigned r = c - uk * n01;
-		const unsigned uj = r / n0;
-		const int n = scomp + static_cast<int>(un);
-		const int di = it.lo[0] + static_cast<int>(r - uj * n0), dj = it.lo[1] + static_cast<int>(uj), dk = it.lo[2] + static_cast<int>(uk);
-		const double v = Src(it.a[0] * di + it.b[0], it.a[1] * dj + it.b[1], it.a[2] * dk + it.b[2], n);
-		Dst(di, dj, dk, n) = (((it.neg >> n) & 1ull) != 0) ? -v : v;
-	}
-}
-
-// builds plan->d_gather for `bcs`; plan->gather_state = 1 (ready) or 2 (does not apply)
-auto buildGather(qk_ghost_plan *P, const qk_bcrec *bcs) -> int
-{
-	qk_ctx *ctx = P->lev->ctx;
-	qk_level *lev = P->lev;
-	const qk_geometry &geom = P->geom;
-	P->gather_bcs.assign(bcs, bcs + P->ncomp);
-	P->gather_state = 2;
-	if (P->d_gather != nullptr) {
-		QK_HIP_CHECK(ctx, hipFree(P->d_gather));
-		QK_HIP_CHECK(ctx, hipFree(P->d_gather_blocks));
-		P->d_gather = nullptr;
-		P->d_gather_blocks = nullptr;
-	}
-	if (!P->peers.empty() || P->ncomp > 64) {
-		return QK_OK;
-	}
-	// per face: 1 mirror, 2 clamp, 0 the gather does not apply; the components that change sign there
-	int mode[3][2];
-	unsigned long long odd[3][2];
-	for (int d = 0; d < 3; ++d) {
-		for (int sd = 0; sd < 2; ++sd) {
-			mode[d][sd] = -1;
-			odd[d][sd] = 0;
-			if (d >= geom.ndim || geom.periodic[d] != 0) {
-				continue;
-			}
-			for (int n = 0; n < P->ncomp; ++n) {
-				const int type = (sd == 0) ? bcs[n].lo[d] : bcs[n].hi[d];
-				const int m = (type == QK_BC_REFLECT_EVEN || type == QK_BC_REFLECT_ODD) ? 1 : (type == QK_BC_FOEXTRAP ? 2 : 0);
-				if (mode[d][sd] == -1) {
-					mode[d][sd] = m;
-				} else if (mode[d][sd] != m) {
-					mode[d][sd] = 0;
-				}
-				if (type == QK_BC_REFLECT_ODD) {
-					odd[d][sd] |= 1ull << n;
-				}
-			}
-		}
-	}
-	std::vector<GatherItem> items;
-	// the same-rank copies as they are
-	for (auto const &c : P->local) {
-		GatherItem g{};
-		g.dst_box = c.dst_box;
-		g.src_box = c.src_box;
-		for (int d = 0; d < 3; ++d) {
-			g.lo[d] = c.lo[d];
-			g.hi[d] = c.hi[d];
-			g.a[d] = 1;
-			g.b[d] = -c.shift[d];
-		}
-		items.push_back(g);
-	}
-	for (int b = 0; b < lev->nboxes; ++b) {
-		qk_box grown = lev->boxes[b];
-		for (int d = 0; d < geom.ndim; ++d) {
-			grown.lo[d] -= P->nghost;
-			grown.hi[d] += P->nghost;
-		}
-		// what fills the part of the grown box inside the domain: the box itself and the copy items that target it
-		struct Piece {
-			int src_box, lo[3], hi[3], shift[3];
-		};
-		std::vector<Piece> pieces;
-		{
-			Piece own{};
-			own.src_box = b;
-			for (int d = 0; d < 3; ++d) {
-				own.lo[d] = lev->boxes[b].lo[d];
-				own.hi[d] = lev->boxes[b].hi[d];
-			}
-			pieces.push_back(own);
-			for (auto const &c : P->local) {
-				if (c.dst_box == b) {
-					Piece q{};
-					q.src_box = c.src_box;
-					for (int d = 0; d < 3; ++d) {
-						q.lo[d] = c.lo[d];
-						q.hi[d] = c.hi[d];
-						q.shift[d] = c.shift[d];
-					}
-					pieces.push_back(q);
-				}
-			}
-		}
-		for (int oz = -1; oz <= 1; ++oz) {
-			for (int oy = -1; oy <= 1; ++oy) {
-				for (int ox = -1; ox <= 1; ++ox) {
-					const int o[3] = {ox, oy, oz};
-					if (ox == 0 && oy == 0 && oz == 0) {
-						continue;
-					}
-					int slo[3], shi[3], a[3], bb[3];
-					unsigned long long neg = 0;
-					bool ok = true, applies = true;
-					for (int d = 0; d < 3 && ok; ++d) {
-						const bool wall = d < geom.ndim && geom.periodic[d] == 0;
-						if (o[d] != 0 && !wall) {
-							ok = false;
-						} else if (o[d] < 0) {
-							slo[d] = grown.lo[d];
-							shi[d] = std::min(grown.hi[d], geom.domain.lo[d] - 1);
-						} else if (o[d] > 0) {
-							slo[d] = std::max(grown.lo[d], geom.domain.hi[d] + 1);
-							shi[d] = grown.hi[d];
-						} else {
-							slo[d] = wall ? std::max(grown.lo[d], geom.domain.lo[d]) : grown.lo[d];
-							shi[d] = wall ? std::min(grown.hi[d], geom.domain.hi[d]) : grown.hi[d];
-						}
-						ok = ok && shi[d] >= slo[d];
-						if (ok && o[d] != 0) {
-							const int sd = (o[d] > 0) ? 1 : 0;
-							const int edge = (sd == 0) ? geom.domain.lo[d] : geom.domain.hi[d];
-							if (mode[d][sd] == 1) { // AMReX_FilCC: q(lo - 1 - m) = +-q(lo + m), q(hi + 1 + m) = +-q(hi - m)
-								a[d] = -1;
-								bb[d] = (sd == 0) ? (2 * edge - 1) : (2 * edge + 1);
-								neg ^= odd[d][sd];
-							} else if (mode[d][sd] == 2) {
-								a[d] = 0;
-								bb[d] = edge;
-							} else {
-								applies = false;
-							}
-						} else if (ok) {
-							a[d] = 1;
-							bb[d] = 0;
-						}
-					}
-					if (!ok) {
-						continue;
-					}
-					if (!applies) {
-						return QK_OK; // (gather_state stays 2)
-					}
-					int64_t want = 1, have = 0;
-					for (int d = 0; d < 3; ++d) {
-						want *= shi[d] - slo[d] + 1;
-					}
-					for (auto const &pc : pieces) {
-						GatherItem g{};
-						g.dst_box = b;
-						g.src_box = pc.src_box;
-						g.neg = neg;
-						bool hit = true;
-						for (int d = 0; d < 3 && hit; ++d) {
-							// the image of the slab along d and its overlap with the piece, mapped back to destination indices
-							if (a[d] == 1) {
-								g.lo[d] = std::max(slo[d], pc.lo[d]);
-								g.hi[d] = std::min(shi[d], pc.hi[d]);
-							} else if (a[d] == -1) {
-								const int ilo = bb[d] - shi[d], ihi = bb[d] - slo[d]; // image range
-								const int jlo = std::max(ilo, pc.lo[d]), jhi = std::min(ihi, pc.hi[d]);
-								g.lo[d] = bb[d] - jhi;
-								g.hi[d] = bb[d] - jlo;
-							} else {
-								g.lo[d] = slo[d];
-								g.hi[d] = (bb[d] >= pc.lo[d] && bb[d] <= pc.hi[d]) ? shi[d] : slo[d] - 1;
-							}
-							hit = g.hi[d] >= g.lo[d];
-							g.a[d] = a[d];
-							g.b[d] = bb[d] - pc.shift[d]; // (a piece's cell j holds the neighbour's cell j - shift)
-						}
-						if (hit) {
-							have += regionCells(CopyItem{0, 0, {g.lo[0], g.lo[1], g.lo[2]}, {g.hi[0], g.hi[1], g.hi[2]}, {0, 0, 0}, 0});
-							items.push_back(g);
-						}
-					}
-					if (have != want) {
-						return QK_OK; // some image cell is filled by neither the box nor a copy (a level that does not cover the domain)
-					}
-				}
-			}
-		}
-	}
-	if (items.empty()) {
-		return QK_OK;
-	}
-	int64_t biggest = 0;
-	for (auto const &g : items) {
-		biggest = std::max<int64_t>(biggest, static_cast<int64_t>(g.hi[0] - g.lo[0] + 1) * (g.hi[1] - g.lo[1] + 1) * (g.hi[2] - g.lo[2] + 1));
-	}
-	if (biggest * P->ncomp >= (int64_t{1} << 31)) {
-		return QK_OK;
-	}
-	std::vector<GatherBlock> blocks;
-	for (size_t k = 0; k < items.size(); ++k) {
-		auto const &g = items[k];
-		const int64_t values = static_cast<int64_t>(g.hi[0] - g.lo[0] + 1) * (g.hi[1] - g.lo[1] + 1) * (g.hi[2] - g.lo[2] + 1) * P->ncomp;
-		const int nchunks = static_cast<int>((values + 2047) / 2048);
-		for (int c = 0; c < nchunks; ++c) {
-			blocks.push_back({static_cast<int>(k), c, nchunks});
-		}
-	}
-	QK_HIP_CHECK(ctx, hipMalloc(&P->d_gather, sizeof(GatherItem) * items.size()));
-	QK_HIP_CHECK(ctx, hipMemcpy(P->d_gather, items.data(), sizeof(GatherItem) * items.size(), hipMemcpyHostToDevice));
-	QK_HIP_CHECK(ctx, hipMalloc(&P->d_gather_blocks, sizeof(GatherBlock) * blocks.size()));
-	QK_HIP_CHECK(ctx, hipMemcpy(P->d_gather_blocks, blocks.data(), sizeof(GatherBlock) * blocks.size(), hipMemcpyHostToDevice));
-	P->n_gather_blocks = static_cast<int>(blocks.size());
-	P->n_gather = static_cast<int>(items.size());
-	P->max_gather_cells = biggest;
-	P->gather_state = 1;
-	return QK_OK;
 }
 
 auto uploadItems(qk_ctx *ctx, std::vector<CopyItem> const &v, CopyItem **d) -> int
@@ -712,8 +454,6 @@ int qk_ghost_plan_destroy(qk_ghost_plan *plan)
 	(void)hipFree(plan->d_bcs);
 	(void)hipFree(plan->d_dir);
 	(void)hipFree(plan->d_physbc);
-	(void)hipFree(plan->d_gather);
-	(void)hipFree(plan->d_gather_blocks);
 	delete plan;
 	return QK_OK;
 }
@@ -950,35 +690,6 @@ int qk_ghost_plan_set_box_remote(qk_ghost_plan *plan, int local_box, int flag)
 	if (plan->d_shells != nullptr && !plan->shells.empty()) {
 		QK_HIP_CHECK(ctx, hipMemcpy(plan->d_shells, plan->shells.data(), sizeof(CopyItem) * plan->shells.size(), hipMemcpyHostToDevice));
 	}
-	return QK_OK;
-}
-
-int qk_FillBoundary_gather(qk_ghost_plan *plan, qk_stream s, qk_array4 *state_t, const qk_bcrec *bcs)
-{
-	if (plan == nullptr) {
-		return QK_ERR_INVALID;
-	}
-	qk_ctx *ctx = plan->lev->ctx;
-	QK_REQUIRE(ctx, state_t && bcs, "FillBoundary_gather: NULL argument");
-	if (ctx->device < 0) {
-		return 1;
-	}
-	if (plan->gather_state == 0 || std::memcmp(plan->gather_bcs.data(), bcs, sizeof(qk_bcrec) * plan->ncomp) != 0) {
-		if (plan->gather_state == 1) { // other boundary types than last time: kernels of this plan still queued read the old items
-			QK_HIP_CHECK(ctx, hipStreamSynchronize(static_cast<hipStream_t>(s)));
-		}
-		if (int rc = buildGather(plan, bcs); rc != QK_OK) {
-			return rc;
-		}
-	}
-	if (plan->gather_state != 1) {
-		return 1;
-	}
-	const int nc = (plan->active_ncomp < 0) ? plan->ncomp : plan->active_ncomp;
-	ProfScope ps(ctx, static_cast<hipStream_t>(s), "ghost_gather");
-	hipLaunchKernelGGL(k_gather, dim3(static_cast<unsigned>(plan->n_gather_blocks)), dim3(256), 0, static_cast<hipStream_t>(s),
-			   static_cast<const GatherItem *>(plan->d_gather), static_cast<const GatherBlock *>(plan->d_gather_blocks), state_t, nc, plan->active_scomp);
-	QK_HIP_CHECK(ctx, hipGetLastError());
 	return QK_OK;
 }
 

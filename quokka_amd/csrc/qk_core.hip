@@ -116,27 +116,6 @@ int qk_clear_bytes(qk_ctx *ctx, qk_stream s, void *device_ptr, int64_t nbytes)
 	return QK_OK;
 }
 
-int qk_stream_create_cu_mask(qk_ctx *ctx, const uint32_t *cu_mask, int nwords, qk_stream *stream_out)
-{
-	if (ctx == nullptr) {
-		return QK_ERR_INVALID;
-	}
-	QK_REQUIRE(ctx, cu_mask != nullptr && nwords > 0 && stream_out != nullptr, "qk_stream_create_cu_mask: NULL argument");
-	hipStream_t s = nullptr;
-	QK_HIP_CHECK(ctx, hipExtStreamCreateWithCUMask(&s, static_cast<uint32_t>(nwords), cu_mask));
-	*stream_out = s;
-	return QK_OK;
-}
-
-int qk_stream_destroy(qk_ctx *ctx, qk_stream s)
-{
-	if (ctx == nullptr) {
-		return QK_ERR_INVALID;
-	}
-	QK_HIP_CHECK(ctx, hipStreamDestroy(static_cast<hipStream_t>(s)));
-	return QK_OK;
-}
-
 int qk_profile_enable(qk_ctx *ctx, int on)
 {
 	if (ctx == nullptr) {

@@ -14,6 +14,7 @@
 #ifndef QK_RAD_MG_DEVICE_HPP_
 #define QK_RAD_MG_DEVICE_HPP_
 
+#include "qk_planck.hpp"
 #include "qk_rad_device.hpp"
 
 namespace qk
@@ -27,39 +28,11 @@ __device__ const double d_planck_Y[PLANCK_INTERP_SIZE] = {
 #include "../data/planck_integral_table.inc"
 };
 
-// planck_integral.hpp:22-262 (USE_SECOND_ORDER = false)
-QK_DEV auto integratePlanckFrom0ToX(double x) -> double
-{
-	if (x <= 0.) {
-		return 0.;
-	}
-	const double logx = log10(x);
-	double y;
-	if (logx < PLANCK_LOG_X_MIN) {
-		y = (-4 + x) * x + 8 * log((2 + x) / 2);
-		const double Y_INTERP_MIN = d_planck_Y[0];
-		if (y > Y_INTERP_MIN) {
-			y = Y_INTERP_MIN;
-		} else if (y < 0.) {
-			y = 0.;
-		}
-	} else if (logx >= PLANCK_LOG_X_MAX) {
-		return 1.0;
-	} else {
-		const int arr_len = PLANCK_INTERP_SIZE;
-		const int j = static_cast<int>((logx - PLANCK_LOG_X_MIN) / (PLANCK_LOG_X_MAX - PLANCK_LOG_X_MIN) * (arr_len - 1));
-		const double gap = (PLANCK_LOG_X_MAX - PLANCK_LOG_X_MIN) / (arr_len - 1);
-		if (j < 0) {
-			return 0.0;
-		}
-		if (j >= arr_len - 1) {
-			return 1.0;
-		}
-		const double slope = (d_planck_Y[j + 1] - d_planck_Y[j]) / gap;
-		y = slope * (logx - (PLANCK_LOG_X_MIN + j * gap)) + d_planck_Y[j];
-	}
-	return y;
-}
+// planck_integral.hpp:22-262 (USE_SECOND_ORDER = false): the body shared with the host mirror (qk_planck.hpp) on the device-resident table
+struct DevicePlanckTable {
+	QK_DEV auto operator[](int j) const -> double { return d_planck_Y[j]; }
+};
+QK_DEV auto integratePlanckFrom0ToX(double x) -> double { return planck::fractionBelow(x, DevicePlanckTable{}); }
 
 // the multigroup part of RadSystem_Traits + the DefineOpacityExponentsAndLowerValues closed set (include/quokka_amd.h)
 template <int NG> struct RadMG {
@@ -115,22 +88,7 @@ template <int NG> struct RadMG {
 // radiation_system.hpp:430-461
 template <int NG> QK_DEV void planckEnergyFractions(RadMG<NG> const &m, double T, double f[NG])
 {
-	const double energy_unit_over_kT = m.energy_unit / (m.kB * T);
-	double y;
-	double previous = 0.0;
-#pragma unroll
-	for (int g = 0; g < NG - 1; ++g) {
-		const double x = m.bnd[g + 1] * energy_unit_over_kT;
-		if (x >= 100.) {
-			y = 1.0;
-		} else {
-			y = integratePlanckFrom0ToX(x);
-		}
-		f[g] = y - previous;
-		previous = y;
-	}
-	y = 1.0;
-	f[NG - 1] = y - previous;
+	planck::groupFractions<NG>(m.bnd, m.energy_unit / (m.kB * T), DevicePlanckTable{}, f);
 }
 
 // :483-497 and :505-513 from one set of fractions (the reference evaluates the fractions twice at the same temperature)
@@ -236,22 +194,11 @@ template <int NG> QK_DEV void groupMeanOpacity(RadMG<NG> const &m, const double 
 	}
 }
 
-// :1311-1326 (4 pi B(nu) / c)
+// :1311-1326 (4 pi B(nu) / c); x^3 and T^4 are std::pow(x, 3) / std::pow(T, 4), faithfully rounded (qk_rad_device.hpp)
 template <int NG> QK_DEV auto planckFunction(Rad const &r, RadMG<NG> const &m, double nu, double T) -> double
 {
-	const double coeff = m.energy_unit / (m.kB * T);
-	const double x = coeff * nu;
-	if (x > 100.) {
-		return 0.0;
-	}
-	double planck_integral;
-	if (x <= 1.0e-10) {
-		planck_integral = x * x - x * x * x / 2.;
-	} else {
-		planck_integral = Rad::pow3Faithful(x) / (exp(x) - 1.0); // std::pow(x, 3), faithfully rounded (qk_rad_device.hpp)
-	}
 	constexpr double PI4 = 97.40909103400242; // std::pow(M_PI, 4): the fourth power of the double nearest pi, correctly rounded
-	return coeff / (PI4 / 15.0) * (r.arad * Rad::pow4Faithful(T)) * planck_integral;
+	return planck::spectralDensity(m.energy_unit / (m.kB * T), nu, PI4 / 15.0, r.arad * Rad::pow4Faithful(T), [](double x) { return Rad::pow3Faithful(x); });
 }
 
 template <int NG> struct OpacityTermsMG {

@@ -354,7 +354,9 @@ inline auto qk_parfor_row_block(int nx) -> unsigned { return nx >= 256 ? 256U : 
 // calls it once per box, every call a launch of a few microseconds of work (RadhydroShell: 8 boxes x 2 calls x 10 substeps per step, 9.75 % of the
 // step).  Inside a qk_parfor_batch_scope the row-mapped ParallelFor(Box, f) calls with the SAME lambda type are collected — box and closure by value,
 // up to what the 4 KiB of kernel arguments hold — and leave as ONE launch (blockIdx.z = the call) when the scope ends, the pack is full or another
-// kind of launch arrives.  The calls of a scope must not depend on one another (one hook, one box each); nothing else is enqueued inside the scope.
+// kind of launch, a copy, an allocation or a synchronisation of the mirror arrives (QK_HOST_HIP, the other ParallelFor forms, launch, fills: each flushes
+// first, so a hook that mixes launch kinds or synchronises and reads on the host sees its launches in order).  The calls of a pack must not depend on
+// one another (one hook, one box each) and must not capture device buffers that die before the scope ends.
 struct qk_parfor_batch_state {
 	int depth = 0;
 	void (*flush)() = nullptr;
@@ -474,6 +476,7 @@ template <typename F> void ParallelFor(Box const &bx, int ncomp, F const &f)
 	if (n <= 0) {
 		return;
 	}
+	qk_parfor_batch_flush(); // (keeps the order of the launches; only the three-index form is batched)
 	const int nx = bx.length(0);
 	if (nx >= 32 && bx.length(1) <= 65535 && static_cast<Long>(bx.length(2)) * ncomp <= 65535) {
 		const unsigned tb = qk_parfor_row_block(nx);
@@ -700,8 +703,11 @@ class ParmParse
 };
 
 #define QK_HOST_HIP_DEFINED_BELOW 1
+// (every synchronisation, copy and allocation of the mirror goes through here: a pack of batched ParallelFor calls still pending — qk_parfor_batch_scope —
+// leaves first, so that a hook which launches, synchronises and reads on the host sees its launches in order)
 #define QK_HOST_HIP(expr)                                                                                                                            \
 	do {                                                                                                                                         \
+		::amrex::qk_parfor_batch_flush();                                                                                                    \
 		hipError_t e_ = (expr);                                                                                                              \
 		if (e_ != hipSuccess) {                                                                                                              \
 			amrex::Abort(std::string(#expr) + ": " + hipGetErrorString(e_));                                                             \
@@ -850,6 +856,7 @@ class DeviceArena
 template <typename F> __global__ void qk_launch_kernel(Box bx, F f) { f(bx); }
 template <typename F> void launch(Box const &bx, F const &f)
 {
+	qk_parfor_batch_flush();
 	hipLaunchKernelGGL(qk_launch_kernel<F>, dim3(1), dim3(1), 0, nullptr, bx, f);
 	qk_check_launch("amrex::launch");
 }
@@ -1143,6 +1150,7 @@ template <typename T> void qk_device_fill(T *p, Long n, T v)
 		return;
 	}
 	unsigned const blocks = static_cast<unsigned>(std::min<Long>((n + 255) / 256, 65535));
+	qk_parfor_batch_flush();
 	hipLaunchKernelGGL(qk_fill_kernel<T>, dim3(blocks), dim3(256), 0, nullptr, p, n, v);
 	qk_check_launch("qk_device_fill");
 }

@@ -121,7 +121,7 @@ struct BcShell {
 	int hi[3];
 };
 // set by the DEFAULT AMRSimulation<problem_t>::setCustomBoundaryConditions (a problem that specialises the hook never sets it): after the first
-// fill the host knows the hook does nothing, stops launching it and may fill the ghost cells with one gather launch (qk_FillBoundary_gather)
+// fill the host knows the hook does nothing and stops launching it
 static __device__ int g_defaultCustomBcRan = 0;
 // setCustomBoundaryConditions on every cell of every slab of a fill: ONE launch per fill (blockIdx.y: the slab), threads over ghost cells only
 template <typename problem_t>
@@ -578,24 +578,6 @@ template <typename problem_t> class AMRSimulation
 	{
 		activate();
 		hipStream_t const cs = qkhost::Runtime::get().computeStream();
-		if (!between && !beforePhysBC_ && peers_.peer.empty() && customBcIsDefault_ == 1 && ghostGather_ != 0) {
-			// every box on this rank, no functor: copies + reflecting / extrapolating faces as ONE gather launch (1: the form does not apply)
-			std::vector<qk_bcrec> bcs(BCs_cc_.size());
-			for (size_t n = 0; n < BCs_cc_.size(); ++n) {
-				for (int d = 0; d < 3; ++d) {
-					bcs[n].lo[d] = (d < AMREX_SPACEDIM) ? BCs_cc_[n].lo(d) : 0;
-					bcs[n].hi[d] = (d < AMREX_SPACEDIM) ? BCs_cc_[n].hi(d) : 0;
-				}
-			}
-			int const rc = qk_FillBoundary_gather(plan_, cs, qkhost::tab(state), bcs.data());
-			if (rc == QK_OK) {
-				return;
-			}
-			if (rc != 1) {
-				qkhost::check(rc, "FillBoundary_gather");
-			}
-			ghostGather_ = 0;
-		}
 		// state.FillBoundary(geom.periodicity()) (reference src/simulation.hpp:1755): strips for the other ranks are packed, sent peer to peer
 		// while the same-rank copies run, and unpacked
 		for (size_t k = 0; k < peers_.peer.size(); ++k) {
@@ -710,11 +692,6 @@ template <typename problem_t> class AMRSimulation
 		}
 	}
 	int customBcIsDefault_ = -1; // -1 unknown, 0 the problem specialised setCustomBoundaryConditions, 1 it is the empty default
-	int ghostGather_ = [] {
-		int v = 0; // (measured: one launch less, no faster — profiles/round5/ab7_ghost_gather.txt; the two kernels stay the default)
-		amrex::ParmParse("qk").query("ghost_gather", v);
-		return v;
-	}();
 	struct BcShellList {
 		qkhost::BcShell *d = nullptr;
 		int count = 0;

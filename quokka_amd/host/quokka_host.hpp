@@ -1325,7 +1325,9 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	// state is untouched by either stage, so the result is the same.  Returns 1: both stages done, 0: the step failed, -1: redo in order.
 	auto stagePairSpeculative(amrex::MultiFab &U_old, double time, double dt) -> int
 	{
-		if (primHandoffApplies()) {
+		if (primBackoff_ > 0) { // (a recent attempt was dropped: see below)
+			--primBackoff_;
+		} else if (primHandoffApplies()) {
 			// The primitive hand-off (qk_hydro_stage_args::prim_out / prim_in): stage 1 stores the primitives of the intermediate state, stage 2
 			// reads them — no conversion in its pre-pass and sweeps, same bytes, same bits.  It has no correction pass: when either stage flags
 			// a cell the attempt is dropped (the old state is untouched by both stages) and the step proceeds below as it does without it.
@@ -1341,9 +1343,14 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 			if (w[0].count == 0 && w[1].count == 0) {
 				fusedEnd(1, &w[0]);
 				fusedEnd(2, &w[1]);
+				primBackoffLen_ = 0;
 				return 1;
 			}
 			++primHandoffDropped_;
+			// a flow that flags cells step after step would pay both stages twice every time: the hand-off sits out the next 4, 8, ... 64
+			// advances after a drop and comes back after a clean attempt
+			primBackoffLen_ = std::min(64, std::max(4, 2 * primBackoffLen_));
+			primBackoff_ = primBackoffLen_;
 			invalidateSignal();
 		}
 		fusedBegin(1, true);
@@ -1370,11 +1377,16 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		if (primHandoffChecked_) {
 			return primHandoffOk_;
 		}
+		// customBcKernel runs a specialised setCustomBoundaryConditions on every ghost slab whatever the BCRec says: a problem that specialises
+		// the hook writes CONSERVED values — the hand-off waits until the first fill has shown that the hook is the empty default
+		if (this->customBcIsDefault_ < 0) {
+			return false; // (not known yet: ask again after the first fill)
+		}
 		primHandoffChecked_ = true;
 		int on = 1;
 		amrex::ParmParse("qk").query("prim_handoff", on);
 		auto const t = qkhost::traits<problem_t>();
-		bool ok = on != 0 && this->amrLevel_ == 0 && !is_radiation_enabled_ && t.reconstruct_eint == 0 &&
+		bool ok = on != 0 && this->customBcIsDefault_ == 1 && this->amrLevel_ == 0 && !is_radiation_enabled_ && t.reconstruct_eint == 0 &&
 			  t.eos_temperature_model == 0 && !(t.cs_isothermal == t.cs_isothermal) && t.gamma != 1.0 &&
 			  Physics_Indices<problem_t>::nvarTotal_cc == ncompHydro_;
 		for (auto const &bc : this->BCs_cc_) {
@@ -1388,6 +1400,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	}
 	bool primHandoffChecked_ = false, primHandoffOk_ = false, primNow_ = false;
 	long primHandoffDropped_ = 0;
+	int primBackoff_ = 0, primBackoffLen_ = 0;
 	int rk2CarryRhs_ = 0;	   // deck: hydro.rk2_carry_rhs
 	int fusedFofc_ = 1;	   // deck: qk.fused_fofc (0: a flagged stage is redone on the reference-shaped operators; tests)
 	bool stage1LeftF1_ = true; // halfFlux_ holds the stage-1 fluxes of the current step

@@ -113,100 +113,65 @@ template <typename problem_t> class RadSystem : public HyperbolicSystem<problem_
 	    -> amrex::GpuArray<amrex::GpuArray<double, nGroups_ + 1>, 2>;
 	AMREX_GPU_HOST_DEVICE static auto ComputeThermalRadiationSingleGroup(amrex::Real temperature) -> amrex::Real;
 	AMREX_GPU_HOST_DEVICE static auto ComputeThermalRadiationTempDerivativeSingleGroup(amrex::Real temperature) -> amrex::Real;
-	// :430-461: energy fractions of a Planck spectrum in the groups (what problem files call for initial and boundary states)
+	// The Planck-spectrum members problem files call for initial and boundary states: each forwards to the body the HIP library's multigroup kernels
+	// use themselves (csrc/qk_planck.hpp; host + device), with std::pow where the reference's members use it.
+	// :430-461: energy fractions of a Planck spectrum in the groups
 	AMREX_GPU_HOST_DEVICE static auto ComputePlanckEnergyFractions(amrex::GpuArray<double, nGroups_ + 1> const &boundaries, amrex::Real temperature)
 	    -> quokka::valarray<amrex::Real, nGroups_>
 	{
-		quokka::valarray<amrex::Real, nGroups_> radEnergyFractions{};
-		if constexpr (nGroups_ == 1) {
-			radEnergyFractions[0] = 1.0;
-			return radEnergyFractions;
-		} else {
-			amrex::Real const energy_unit_over_kT = energy_unit_ / (boltzmann_constant_ * temperature);
-			amrex::Real y = NAN;
-			amrex::Real previous = 0.0;
-			for (int g = 0; g < nGroups_ - 1; ++g) {
-				const amrex::Real x = boundaries[g + 1] * energy_unit_over_kT;
-				y = (x >= 100.) ? 1.0 : integrate_planck_from_0_to_x(x);
-				radEnergyFractions[g] = y - previous;
-				previous = y;
-			}
-			y = 1.0;
-			radEnergyFractions[nGroups_ - 1] = y - previous;
-			return radEnergyFractions;
-		}
+		quokka::valarray<amrex::Real, nGroups_> out{};
+		qk::planck::groupFractions<nGroups_>(boundaries.data(), energy_unit_ / (boltzmann_constant_ * temperature), qk::planck::LocalTable{}, &out[0]);
+		return out;
 	}
-	// :483-497
+	// :483-497: a T^4 in the groups, floored
 	AMREX_GPU_HOST_DEVICE static auto ComputeThermalRadiationMultiGroup(amrex::Real temperature, amrex::GpuArray<double, nGroups_ + 1> const &boundaries)
 	    -> quokka::valarray<amrex::Real, nGroups_>
 	{
-		const double power = radiation_constant_ * std::pow(temperature, 4);
-		const auto radEnergyFractions = ComputePlanckEnergyFractions(boundaries, temperature);
-		auto Erad_g = power * radEnergyFractions;
-		for (int g = 0; g < nGroups_; ++g) {
-			if (Erad_g[g] < Erad_floor_) {
-				Erad_g[g] = Erad_floor_;
-			}
-		}
-		return Erad_g;
+		auto out = ComputePlanckEnergyFractions(boundaries, temperature);
+		qk::planck::scaleFloored<nGroups_>(radiation_constant_ * std::pow(temperature, 4), Erad_floor_, &out[0]);
+		return out;
 	}
-	// :505-513
+	// :505-513: its temperature derivative
 	AMREX_GPU_HOST_DEVICE static auto ComputeThermalRadiationTempDerivativeMultiGroup(amrex::Real temperature,
 											  amrex::GpuArray<double, nGroups_ + 1> const &boundaries)
 	    -> quokka::valarray<amrex::Real, nGroups_>
 	{
-		auto radEnergyFractions = ComputePlanckEnergyFractions(boundaries, temperature);
-		double d_power_dt = 4. * radiation_constant_ * std::pow(temperature, 3);
-		return d_power_dt * radEnergyFractions;
+		auto out = ComputePlanckEnergyFractions(boundaries, temperature);
+		qk::planck::scale<nGroups_>(4. * radiation_constant_ * std::pow(temperature, 3), &out[0]);
+		return out;
 	}
 	// :1311-1326 (4 pi B(nu) / c)
 	AMREX_GPU_HOST_DEVICE static auto PlanckFunction(const double nu, const double T) -> double
 	{
-		double const coeff = energy_unit_ / (boltzmann_constant_ * T);
-		double const x = coeff * nu;
-		if (x > 100.) {
-			return 0.0;
-		}
-		double const planck_integral = (x <= 1.0e-10) ? x * x - x * x * x / 2. : std::pow(x, 3) / (std::exp(x) - 1.0);
-		return coeff / (std::pow(PI, 4) / 15.0) * (radiation_constant_ * std::pow(T, 4)) * planck_integral;
+		return qk::planck::spectralDensity(energy_unit_ / (boltzmann_constant_ * T), nu, std::pow(PI, 4) / 15.0, radiation_constant_ * std::pow(T, 4),
+						   [](double x) { return std::pow(x, 3); });
 	}
 	// :1367-1385: the radiation flux of each group in the diffusion limit for gas moving at `vel`
 	AMREX_GPU_HOST_DEVICE static auto ComputeFluxInDiffusionLimit(const amrex::GpuArray<double, nGroups_ + 1> rad_boundaries, const double T, const double vel)
 	    -> amrex::GpuArray<double, nGroups_>
 	{
-		double const coeff = energy_unit_ / (boltzmann_constant_ * T);
-		amrex::GpuArray<double, nGroups_ + 1> edge_values{};
-		amrex::GpuArray<double, nGroups_> flux{};
-		for (int g = 0; g < nGroups_ + 1; ++g) {
-			auto x = coeff * rad_boundaries[g];
-			edge_values[g] = 4. / 3. * integrate_planck_from_0_to_x(x) - 1. / 3. * x * (std::pow(x, 3) / (std::exp(x) - 1.0)) / gInf;
-		}
-		for (int g = 0; g < nGroups_; ++g) {
-			flux[g] = vel * radiation_constant_ * std::pow(T, 4) * (edge_values[g + 1] - edge_values[g]);
-		}
-		return flux;
+		amrex::GpuArray<double, nGroups_> out{};
+		qk::planck::diffusionLimitFluxes<nGroups_>(rad_boundaries.data(), energy_unit_ / (boltzmann_constant_ * T), gInf, vel * radiation_constant_, std::pow(T, 4),
+							   qk::planck::LocalTable{}, [](double x) { return std::pow(x, 3); }, out.data());
+		return out;
 	}
 	// :1354-1365
 	AMREX_GPU_HOST_DEVICE static auto ComputeBinCenterOpacity(amrex::GpuArray<double, nGroups_ + 1> rad_boundaries,
 								  amrex::GpuArray<amrex::GpuArray<double, nGroups_ + 1>, 2> kappa_expo_and_lower_value)
 	    -> quokka::valarray<double, nGroups_>
 	{
-		quokka::valarray<double, nGroups_> kappa_center{};
-		for (int g = 0; g < nGroups_; ++g) {
-			kappa_center[g] = kappa_expo_and_lower_value[1][g] * std::pow(rad_boundaries[g + 1] / rad_boundaries[g], 0.5 * kappa_expo_and_lower_value[0][g]);
-		}
-		return kappa_center;
+		quokka::valarray<double, nGroups_> out{};
+		qk::planck::binCentreOpacity<nGroups_>(rad_boundaries.data(), kappa_expo_and_lower_value[0].data(), kappa_expo_and_lower_value[1].data(), &out[0]);
+		return out;
 	}
 	// radiation_system.hpp:1289-1308
 	AMREX_GPU_HOST_DEVICE static auto ComputeEintFromEgas(double density, double X1GasMom, double X2GasMom, double X3GasMom, double Etot) -> double
 	{
-		const double p_sq = X1GasMom * X1GasMom + X2GasMom * X2GasMom + X3GasMom * X3GasMom;
-		return Etot - p_sq / (2.0 * density);
+		return Etot - qk::planck::kineticEnergy(density, X1GasMom, X2GasMom, X3GasMom);
 	}
 	AMREX_GPU_HOST_DEVICE static auto ComputeEgasFromEint(double density, double X1GasMom, double X2GasMom, double X3GasMom, double Eint) -> double
 	{
-		const double p_sq = X1GasMom * X1GasMom + X2GasMom * X2GasMom + X3GasMom * X3GasMom;
-		return Eint + p_sq / (2.0 * density);
+		return Eint + qk::planck::kineticEnergy(density, X1GasMom, X2GasMom, X3GasMom);
 	}
 	AMREX_GPU_HOST_DEVICE static auto ComputePlanckOpacity(double rho, double Tgas) -> amrex::Real;
 	// the ISM heating / cooling hooks (radiation_system.hpp:344-353; defaults zero, :524-545 and radiation_dust_system.hpp:7-12)

@@ -145,9 +145,7 @@ class GhostExchange:
                     vals = vals["values"]
                 for n, v in enumerate(vals):
                     f.values[n] = v
-        # the fill as ONE gather launch (qk_FillBoundary_gather): same values, one launch less — and no faster (profiles/round5/ab7_ghost_gather.txt:
-        # 0.134 ms against 0.060 + 0.091 ms at 256^3; the 4-cell-wide x slabs use a quarter of every cache line either way): off by default
-        self.use_gather = os.environ.get("QK_GHOST_GATHER", "0") == "1"
+        # (round 5 measured the fill as ONE gather launch: same values, no faster — profiles/round5/ab7_ghost_gather.txt; removed in round 6)
         self.exposed_events = None  # a list: fill() records (before, after) events around the wait for the peers' strips
         self.peers = []
         for k in range(L.qk_ghost_plan_num_peers(h)):
@@ -161,14 +159,6 @@ class GhostExchange:
         ctx = self.lev.ctx
         L = ctx.L
         s = ctx.stream()
-        if self.use_gather and not self.peers and self.dirichlet is None and between is None and before_physbc is None:
-            # copies + reflecting / extrapolating faces as ONE gather launch; 1: the form does not apply to this plan (two kernels below)
-            rc = L.qk_FillBoundary_gather(self.h, s, state.ptr, self.bcs)
-            if rc == 0:
-                return
-            if rc != 1:
-                ctx.check(rc, "FillBoundary_gather")
-
         def pack(k, sbuf):
             ctx.check(L.qk_FillBoundary_pack(self.h, s, k, state.ptr, C.c_void_p(sbuf.data_ptr())), "FillBoundary_pack")
 
@@ -831,7 +821,9 @@ class HydroSimulation:
         self._err_latched, self._unfused_ran = False, False
         pair_done = False
         self._prim_now = False
-        if self.use_fused and self.integratorOrder_ == 2 and self.speculate_stage2 and self._prim_handoff_applies():
+        if getattr(self, "_prim_backoff", 0) > 0:  # (a recent attempt was dropped: see below)
+            self._prim_backoff -= 1
+        elif self.use_fused and self.integratorOrder_ == 2 and self.speculate_stage2 and self._prim_handoff_applies():
             # The primitive hand-off (qk_hydro_stage_args::prim_out / prim_in): stage 1 stores the primitives of the intermediate state, stage 2
             # reads them.  It has no correction pass: if either stage flags a cell the attempt is dropped — the old state is untouched by both
             # stages — and the advance proceeds below as it does without the hand-off.
@@ -848,7 +840,12 @@ class HydroSimulation:
             if self._fused_end(1, 0, vals) == 0 and self._fused_end(2, 1, vals) == 0:
                 self._stage1_left_F1 = not self._carry_active()
                 pair_done = True
+                self._prim_backoff_len = 0
             else:
+                # a flow that flags cells step after step (strong shocks) would pay both stages twice every time: the hand-off sits out the next
+                # 4, 8, ... 64 advances after a drop and comes back after a clean attempt
+                self._prim_backoff_len = min(64, max(4, 2 * getattr(self, "_prim_backoff_len", 0)))
+                self._prim_backoff = self._prim_backoff_len
                 self._err_latched = latched  # (whatever the dropped attempt reported)
                 self._signal_of_state_new = None
                 self.counters["prim_handoff_dropped"] = self.counters.get("prim_handoff_dropped", 0) + 1

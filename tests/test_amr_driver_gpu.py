@@ -202,3 +202,34 @@ def test_children_beside_the_far_boxes_and_the_rollback_are_bit_identical(ctx, c
         for la, lo in zip(a.levels, other.levels):
             for k in range(la.lev.nboxes):
                 assert torch.equal(la.state_new_cc_.valid(k), lo.state_new_cc_.valid(k)), (la.ilev, k)
+
+
+def test_rollback_discards_the_error_words_of_the_discarded_attempt(ctx):
+    """A deferred child stage is not corrected: what it leaves can reach FixupState of an intermediate level through AverageDownTo and raise that
+    level's sticky error word (rho <= 0 in SyncDualEnergy) — for an attempt the rollback then discards.  The restored levels must not carry the
+    word (or the pending read of it) into the redone step.  Here the words of every child level are raised by hand just before the rollback."""
+    def run(poison):
+        amr = sedov_amr_problem(ctx, 64, 2, max_grid_size=32, blocking_factor=8)
+        amr.overlap_children = True
+        if poison:
+            restore = amr._restore_above
+
+            def poisoned(lev, snap):
+                for L in amr.levels[lev + 1:]:
+                    L._dev_fix[2:3].fill_(1)
+                    L._fix_error_pending = True
+                return restore(lev, snap)
+            amr._restore_above = poisoned
+        for n in range(6):
+            if n in (2, 4):
+                amr._force_speculation_failure = True
+            amr.step()  # (would raise "density is negative in SyncDualEnergy" at the children's next _signal())
+        return amr
+
+    a, b = run(False), run(True)
+    assert b.overlap_stats["rolled_back"] >= 2
+    assert a.tNew_ == b.tNew_ and a.dt_ == b.dt_
+    for la, lb in zip(a.levels, b.levels):
+        assert int(lb._dev_fix[2].item()) == 0
+        for k in range(la.lev.nboxes):
+            assert torch.equal(la.state_new_cc_.valid(k), lb.state_new_cc_.valid(k)), (la.ilev, k)

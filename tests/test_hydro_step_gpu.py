@@ -587,102 +587,3 @@ def test_primitive_handoff_between_the_stages_changes_no_bit(ctx, oracle):
         assert a.dt_ == b.dt_
     assert np.array_equal(gather_gpu(a, N), gather_gpu(b, N))
     assert b.counters.get("prim_handoff_dropped", 0) == 0
-
-
-# ------------------------------------------------------------------ the ghost fill as one gather launch (qk_FillBoundary_gather)
-@pytest.mark.gpu
-@pytest.mark.parametrize("case", ["reflecting octant", "periodic y", "extrapolating", "small boxes", "2-D", "mixed rules"])
-def test_ghost_fill_as_one_gather_equals_copies_then_boundary_rules(ctx, case):
-    """qk_FillBoundary_gather — every ghost cell reads the valid cell its value comes from (index mirrored / clamped per dimension, the neighbour
-    that owns the image as source box, sign per component) — against qk_FillBoundary_local followed by qk_FillPhysicalBoundary on random data:
-    every ghost cell of every component equal; where the form does not apply (a face whose components mix reflecting and extrapolating rules)
-    the entry reports so and writes nothing."""
-    from quokka_amd import capi
-    from quokka_amd.multifab import Level, MultiFab
-    from quokka_amd.simulation import GhostExchange, Geometry, chop_domain
-    nd, N, mgs, ng, nc, periodic = 3, [16, 16, 16], [8, 8, 8], 4, 6, [0, 0, 0]
-    EV, OD, FO = capi.BC_REFLECT_EVEN, capi.BC_REFLECT_ODD, capi.BC_FOEXTRAP
-    bcs = [([OD if n == 1 + d else EV for d in range(3)], [OD if n == 1 + d else EV for d in range(3)]) for n in range(nc)]
-    applies = True
-    if case == "periodic y":
-        periodic = [0, 1, 0]
-        bcs = [([lo[0], capi.BC_INT_DIR, lo[2]], [hi[0], capi.BC_INT_DIR, hi[2]]) for lo, hi in bcs]
-    elif case == "extrapolating":  # outflow at the upper faces, walls at the lower ones
-        bcs = [(lo, [FO, FO, FO]) for lo, hi in bcs]
-    elif case == "small boxes":  # boxes as wide as the ghost region: images reach the far side of a box, corners come from diagonal neighbours
-        N, mgs = [12, 8, 8], [4, 4, 4]
-    elif case == "2-D":
-        nd, N, mgs = 2, [16, 16, 1], [8, 8, 1]
-        bcs = [(lo[:2] + [capi.BC_INT_DIR], hi[:2] + [capi.BC_INT_DIR]) for lo, hi in bcs]
-    elif case == "mixed rules":
-        bcs[2] = ([FO, EV, EV], bcs[2][1])
-        applies = False
-    geom = Geometry(nd, N, [0.0] * 3, [1.0] * 3, periodic)
-    boxes = chop_domain(N, mgs)
-    lev = Level(ctx, nd, boxes)
-    ex = GhostExchange(lev, geom, nc, ng, boxes, [0] * len(boxes), 0, bcs)
-    a, b = MultiFab(lev, nc, ng), MultiFab(lev, nc, ng)
-    rng = np.random.default_rng(11)
-    for k, shp in enumerate(a.shapes):
-        h = rng.normal(size=shp)
-        a.set_fab(k, h)
-        b.set_fab(k, h)
-    ex.use_gather = False
-    ex.fill(a)
-    L = ctx.L
-    rc = L.qk_FillBoundary_gather(ex.h, ctx.stream(), b.ptr, ex.bcs)
-    torch.cuda.synchronize()
-    assert rc == (0 if applies else 1)
-    for k in range(len(boxes)):
-        if applies:
-            assert np.array_equal(a.fab_numpy(k), b.fab_numpy(k)), f"{case}: box {k}"
-        else:
-            assert not np.array_equal(a.fab_numpy(k), b.fab_numpy(k))  # (nothing written: the ghost cells still hold the random data)
-    # and through GhostExchange.fill, which takes the gather where it applies and the two kernels where it does not
-    ex.use_gather = True
-    ex.fill(b)
-    torch.cuda.synchronize()
-    for k in range(len(boxes)):
-        assert np.array_equal(a.fab_numpy(k), b.fab_numpy(k)), f"{case}: box {k} (fill)"
-
-
-@pytest.mark.gpu
-def test_cu_masked_stream_is_a_legal_qk_stream(ctx):
-    """qk_stream_create_cu_mask: a HIP stream restricted to a subset of the compute units (hipExtStreamCreateWithCUMask) takes the library's
-    launches like any other stream (here: a clear of device words and a ghost copy), then is destroyed"""
-    import ctypes as C
-    from quokka_amd import capi
-    from quokka_amd.multifab import Level, MultiFab
-    from quokka_amd.simulation import GhostExchange, Geometry, chop_domain
-    ncu = torch.cuda.get_device_properties(ctx.device).multi_processor_count
-    words = (ncu + 31) // 32
-    mask = (C.c_uint32 * words)()
-    for cu in range(ncu):
-        if cu % 8 != 7:
-            mask[cu // 32] |= 1 << (cu % 32)
-    h = C.c_void_p()
-    ctx.check(ctx.L.qk_stream_create_cu_mask(ctx.h, mask, words, C.byref(h)), "qk_stream_create_cu_mask")
-    assert h.value
-    t = torch.full((16,), 7, dtype=torch.int64, device=ctx.device)
-    torch.cuda.synchronize()
-    ctx.check(ctx.L.qk_clear_bytes(ctx.h, h, C.c_void_p(t.data_ptr()), 64), "qk_clear_bytes")
-    boxes = chop_domain([16] * 3, [8] * 3)
-    lev = Level(ctx, 3, boxes)
-    geom = Geometry(3, [16] * 3, [0.0] * 3, [1.0] * 3, [1, 1, 1])
-    ex = GhostExchange(lev, geom, 2, 2, boxes, [0] * len(boxes), 0, [([capi.BC_INT_DIR] * 3, [capi.BC_INT_DIR] * 3)] * 2)
-    a, b = MultiFab(lev, 2, 2), MultiFab(lev, 2, 2)
-    rng = np.random.default_rng(2)
-    for k, shp in enumerate(a.shapes):
-        v = rng.normal(size=shp)
-        a.set_fab(k, v)
-        b.set_fab(k, v)
-    torch.cuda.synchronize()
-    ctx.check(ctx.L.qk_FillBoundary_local(ex.h, h, a.ptr), "FillBoundary_local on the masked stream")
-    ex.fill(b)
-    ext = torch.cuda.ExternalStream(h.value, device=ctx.device)
-    ext.synchronize()
-    torch.cuda.synchronize()
-    assert t[:8].eq(0).all() and t[8:].eq(7).all()
-    for k in range(len(boxes)):
-        assert np.array_equal(a.fab_numpy(k), b.fab_numpy(k))
-    ctx.check(ctx.L.qk_stream_destroy(ctx.h, h), "qk_stream_destroy")
