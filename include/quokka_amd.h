@@ -333,14 +333,24 @@ typedef struct qk_rad_traits {
 
 /* ConservedToPrimitive(cons, primVar, indexRange = valid grown by nghost); primVar has 4 * ngroups comps   reference src/radiation/radiation_system.hpp:589-614 */
 int qk_rad_ConservedToPrimitive(qk_level *lev, qk_stream s, const qk_rad_traits *rt, const qk_array4 *cons, qk_array4 *primVar, int nghost);
+/* RadSystem::ComputeCellOpticalDepth<DIR> for every face, and what the use_wavespeed_correction branch of ComputeFluxes makes of it: eps[d] (face-centred
+ * in d, no ghost cells, ngroups components) receives epsilon = min(1, 1 / tau_cell) on the faces whose i + j + k is even and 1 on the others, tau_cell the
+ * harmonic mean of dl rho kappa of the face's two cells (kappa: ComputeFluxMeanOpacity for one group, ComputeBinCenterOpacity of
+ * DefineOpacityExponentsAndLowerValues for several) with the gas temperature of quokka::EOS.  The transport entries below take these arrays as
+ * `wavespeed_eps` (NULL = use_wavespeed_correction false, the reference's default, QuokkaSimulation.hpp:133).  Closed hook sets of qk_rad_traits; a
+ * problem with compiled hooks instantiates the same kernel in its own translation unit (host/qk_problem_kernels.hpp).
+ *                                                                       reference src/radiation/radiation_system.hpp:803-871, :1019-1022, :1098-1109 */
+int qk_rad_ComputeWavespeedCorrection(qk_level *lev, qk_stream s, const qk_rad_traits *rt, const qk_hydro_traits *t, int ndim, const qk_array4 *consVar,
+				      const double dx[3], qk_array4 *const eps[3]);
 /* ComputeFluxes<DIR>(x1Flux, x1FluxDiffusive (unused downstream: not produced), x1LeftState, x1RightState, x1FluxRange, consVar, dx,
- * use_wavespeed_correction = false)                                                              reference src/radiation/radiation_system.hpp:985-1139 */
+ * use_wavespeed_correction); wavespeed_eps: NULL (false) or the array of direction `dir` from qk_rad_ComputeWavespeedCorrection(consVar)
+ *                                                                                                reference src/radiation/radiation_system.hpp:985-1139 */
 int qk_rad_ComputeFluxes(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int dir, qk_array4 *x1Flux, const qk_array4 *x1LeftState,
-			 const qk_array4 *x1RightState, const qk_array4 *consVar);
+			 const qk_array4 *x1RightState, const qk_array4 *consVar, const qk_array4 *wavespeed_eps);
 /* computeRadiationFluxes + fluxFunction<DIR> fused: cons -> (prim, reconstruction of `order` 1/2(MC)/3, HLL flux) in one kernel per direction
  *                                                                                                reference src/QuokkaSimulation.hpp:1884-1961 */
 int qk_rad_computeRadiationFluxes(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int ndim, int reconstruction_order, const qk_array4 *consVar,
-				  qk_array4 *const flux[3]);
+				  qk_array4 *const flux[3], const qk_array4 *const wavespeed_eps[3] /* NULL: no wavespeed correction */);
 /* One transport stage without the face-flux round trip: computeRadiationFluxes(U_in) + PredictStep(U0 -> U_new) (stage 1) or
  * + AddFluxesRK2(U_new; U0, U1 = U_in) (stage 2, PD-ARS: the old-state fluxes have weight 0) with the flux divergence taken inside the flux
  * kernels (X, Y accumulate into `acc`: 4 components per cell, no ghost cells; Z finishes the update and repairs invalid states) — the state
@@ -349,7 +359,8 @@ int qk_rad_computeRadiationFluxes(qk_level *lev, qk_stream s, const qk_rad_trait
  * the groups are transported independently.  1-D / 2-D levels: QK_ERR_UNSUPPORTED (the separate calls serve them).
  *                                                    reference src/QuokkaSimulation.hpp:1726-1882, src/radiation/radiation_system.hpp:667-775 */
 int qk_rad_stage_fused(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int reconstruction_order, int stage, const qk_array4 *U_in, const qk_array4 *U0,
-		       qk_array4 *U_new, qk_array4 *acc, qk_array4 *const flux_out[3], double dt, const double dx[3]);
+		       qk_array4 *U_new, qk_array4 *acc, qk_array4 *const flux_out[3], double dt, const double dx[3],
+		       const qk_array4 *const wavespeed_eps[3] /* NULL: no wavespeed correction; else of U_in */);
 /* PredictStep(consVarOld, consVarNew, fluxArray, dt, dx, indexRange)                             reference src/radiation/radiation_system.hpp:667-710 */
 int qk_rad_PredictStep(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int ndim, const qk_array4 *consVarOld, qk_array4 *consVarNew,
 		       const qk_array4 *const fluxArray[3], double dt, const double dx[3]);

@@ -91,6 +91,7 @@ struct HydroSim {
 	double radiationCflNumber_ = 0.3;
 	int maxSubsteps_ = 10;
 	int radiationReconstructionOrder_ = 3;
+	bool use_wavespeed_correction_ = false; // QuokkaSimulation.hpp:133
 	// RadSystem<problem_t>::SetRadEnergySource(radEnergySource, indexRange, dx, prob_lo, prob_hi, time): user hook
 	std::function<void(Array4<double> const &, Box const &, Geometry const &, double)> SetRadEnergySource;
 	long radiationCellUpdates_ = 0;
@@ -873,7 +874,7 @@ struct HydroSim {
 			out.flux[dir] = Fab<double>(x1FluxRange, nvars);
 			out.fluxDiffusive[dir] = Fab<double>(x1FluxRange, nvars);
 			rad.ComputeFluxes(dir, out.flux[dir].array(), out.fluxDiffusive[dir].array(), x1LeftState.const_array(), x1RightState.const_array(),
-					  x1FluxRange, consVar);
+					  x1FluxRange, consVar, geom.dx, use_wavespeed_correction_); // (:1958-1960)
 		}
 		return out;
 	}

@@ -356,6 +356,7 @@ void orc_sim_fill_ghosts(void *p, int which, double time)
 	s->fillBC((which == 0) ? s->state_new_cc_ : s->state_old_cc_, time);
 }
 void orc_sim_set_rad_reconstruction_order(void *p, int order) { static_cast<HydroSim *>(p)->radiationReconstructionOrder_ = order; }
+void orc_sim_set_wavespeed_correction(void *p, int on) { static_cast<HydroSim *>(p)->use_wavespeed_correction_ = (on != 0); }
 double orc_sim_time(void *p) { return static_cast<HydroSim *>(p)->tNew_; }
 double orc_sim_dt(void *p) { return static_cast<HydroSim *>(p)->dt_; }
 long orc_sim_istep(void *p) { return static_cast<HydroSim *>(p)->istep; }

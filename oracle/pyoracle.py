@@ -383,6 +383,11 @@ class OracleSim:
         self.o.lib.orc_sim_set_rad_reconstruction_order.argtypes = [C.c_void_p, C.c_int]
         self.o.lib.orc_sim_set_rad_reconstruction_order(self.h, int(order))
 
+    def set_wavespeed_correction(self, on: bool):
+        """QuokkaSimulation::use_wavespeed_correction_ (reference src/QuokkaSimulation.hpp:133): ComputeCellOpticalDepth + S_corr on even faces"""
+        self.o.lib.orc_sim_set_wavespeed_correction.argtypes = [C.c_void_p, C.c_int]
+        self.o.lib.orc_sim_set_wavespeed_correction(self.h, int(bool(on)))
+
     def run_record(self, nsteps: int, b=0, cell=(0, 0, 0)):
         """nsteps steps; returns (times, states[nsteps, ncomp]) of one valid cell after every step"""
         t = np.zeros(nsteps)

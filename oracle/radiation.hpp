@@ -323,9 +323,60 @@ struct RadSystem {
 		}
 	}
 
-	// :985-1139 (use_wavespeed_correction = false: QuokkaSimulation.hpp:133)
+	// :803-871  interface-averaged cell optical depth of every photon group at the left face of cell (i, j, k) of the view
+	void ComputeCellOpticalDepth(int dir, View<const double> const &consVar, double const dx[3], int i, int j, int k, double *optical_depths) const
+	{
+		// piecewise-constant reconstruction (gas components 0..4: Physics_Indices::hydroFirstIndex = 0)
+		const double rho_L = consVar(i - 1, j, k, 0);
+		const double rho_R = consVar(i, j, k, 0);
+		const double x1GasMom_L = consVar(i - 1, j, k, 1);
+		const double x1GasMom_R = consVar(i, j, k, 1);
+		const double x2GasMom_L = consVar(i - 1, j, k, 2);
+		const double x2GasMom_R = consVar(i, j, k, 2);
+		const double x3GasMom_L = consVar(i - 1, j, k, 3);
+		const double x3GasMom_R = consVar(i, j, k, 3);
+		const double Egas_L = consVar(i - 1, j, k, 4);
+		const double Egas_R = consVar(i, j, k, 4);
+
+		double Eint_L = NAN;
+		double Eint_R = NAN;
+		double Tgas_L = NAN;
+		double Tgas_R = NAN;
+		if (eos.tr.gamma != 1.0) { // :842-847
+			Eint_L = ComputeEintFromEgas(rho_L, x1GasMom_L, x2GasMom_L, x3GasMom_L, Egas_L);
+			Eint_R = ComputeEintFromEgas(rho_R, x1GasMom_R, x2GasMom_R, x3GasMom_R, Egas_R);
+			Tgas_L = eos.ComputeTgasFromEint(rho_L, Eint_L);
+			Tgas_R = eos.ComputeTgasFromEint(rho_R, Eint_R);
+		}
+		const double dl = dx[dir]; // :849-856
+
+		if (nGroups_() == 1) { // :859-862
+			const auto &fluxMean = ComputeFluxMeanOpacity ? ComputeFluxMeanOpacity : ComputePlanckOpacity; // (:1146: the default hook is the Planck mean)
+			const double tau_L = dl * rho_L * fluxMean(rho_L, Tgas_L);
+			const double tau_R = dl * rho_R * fluxMean(rho_R, Tgas_R);
+			optical_depths[0] = (tau_L * tau_R * 2.) / (tau_L + tau_R); // harmonic mean
+		} else { // :863-868  DefineOpacityExponentsAndLowerValues + ComputeBinCenterOpacity (:1354-1365) either side
+			const int ng = nGroups_();
+			std::vector<double> expo_L(ng + 1, NAN), lower_L(ng + 1, NAN), expo_R(ng + 1, NAN), lower_R(ng + 1, NAN); // (default hook: NaN, :1155-1167)
+			if (DefineOpacityExponentsAndLowerValues) {
+				DefineOpacityExponentsAndLowerValues(rt.radBoundaries.data(), rho_L, Tgas_L, expo_L.data(), lower_L.data());
+				DefineOpacityExponentsAndLowerValues(rt.radBoundaries.data(), rho_R, Tgas_R, expo_R.data(), lower_R.data());
+			}
+			for (int g = 0; g < ng; ++g) {
+				const double ratio = rt.radBoundaries[g + 1] / rt.radBoundaries[g];
+				const double kappa_L = lower_L[g] * std::pow(ratio, 0.5 * expo_L[g]);
+				const double kappa_R = lower_R[g] * std::pow(ratio, 0.5 * expo_R[g]);
+				const double tau_L = dl * rho_L * kappa_L;
+				const double tau_R = dl * rho_R * kappa_R;
+				optical_depths[g] = (tau_L * tau_R * 2.) / (tau_L + tau_R);
+			}
+		}
+	}
+
+	// :985-1139; use_wavespeed_correction (QuokkaSimulation.hpp:133, default false) with the cell widths it needs
 	void ComputeFluxes(int dir, Array4<double> const &x1Flux_in, Array4<double> const &x1FluxDiffusive_in, Array4<const double> const &x1LeftState_in,
-			   Array4<const double> const &x1RightState_in, Box const &indexRange, Array4<const double> const &consVar_in) const
+			   Array4<const double> const &x1RightState_in, Box const &indexRange, Array4<const double> const &consVar_in, double const *dx = nullptr,
+			   bool const use_wavespeed_correction = false) const
 	{
 		View<const double> x1LeftState(x1LeftState_in, dir);
 		View<const double> x1RightState(x1RightState_in, dir);
@@ -339,6 +390,12 @@ struct RadSystem {
 			for (int j_in = indexRange.lo[1]; j_in <= indexRange.hi[1]; ++j_in) {
 				for (int i_in = indexRange.lo[0]; i_in <= indexRange.hi[0]; ++i_in) {
 					auto [i, j, k] = reorderMultiIndex(dir, i_in, j_in, k_in);
+
+					// :1019-1022
+					double tau_cell[kMaxGroups] = {};
+					if (use_wavespeed_correction) {
+						ComputeCellOpticalDepth(dir, consVar, dx, i, j, k, tau_cell);
+					}
 
 					for (int g = 0; g < nGroups_(); ++g) {
 						const int pg = kNumRadVars * g; // component offset of group g
@@ -398,7 +455,14 @@ struct RadSystem {
 
 						const std::array<double, 4> U_L = {erad_L, Fx_L, Fy_L, Fz_L};
 						const std::array<double, 4> U_R = {erad_R, Fx_R, Fy_R, Fz_R};
-						const std::array<double, 4> epsilon = {1.0, 1.0, 1.0, 1.0};
+						std::array<double, 4> epsilon = {1.0, 1.0, 1.0, 1.0};
+						if (use_wavespeed_correction) { // :1103-1109
+							// no correction for odd zones
+							if ((i + j + k) % 2 == 0) {
+								const double S_corr = std::min(1.0, 1.0 / tau_cell[g]); // Skinner et al.
+								epsilon = {S_corr, 1.0, 1.0, 1.0};
+							}
+						}
 
 						// :1116-1117, :1130-1131
 						for (int n = 0; n < kNumRadVars; ++n) {

@@ -166,12 +166,13 @@ def lib() -> C.CDLL:
     L.qk_Saxpy.argtypes = [vp, vp, ci, vp, cd, vp, ci]
     R = P(RadTraits)
     L.qk_rad_ConservedToPrimitive.argtypes = [vp, vp, R, vp, vp, ci]
-    L.qk_rad_ComputeFluxes.argtypes = [vp, vp, R, ci, vp, vp, vp, vp]
-    L.qk_rad_computeRadiationFluxes.argtypes = [vp, vp, R, ci, ci, vp, P(vp)]
+    L.qk_rad_ComputeFluxes.argtypes = [vp, vp, R, ci, vp, vp, vp, vp, vp]
+    L.qk_rad_computeRadiationFluxes.argtypes = [vp, vp, R, ci, ci, vp, P(vp), P(vp)]
+    L.qk_rad_ComputeWavespeedCorrection.argtypes = [vp, vp, R, T, ci, vp, P(cd), P(vp)]
     L.qk_rad_PredictStep.argtypes = [vp, vp, R, ci, vp, vp, P(vp), cd, P(cd)]
     L.qk_rad_AddFluxesRK2.argtypes = [vp, vp, R, ci, vp, vp, vp, P(vp), P(vp), cd, P(cd)]
     L.qk_hydro_FixupState.argtypes = [vp, vp, T, cd, cd, ci, vp, vp, vp]
-    L.qk_rad_stage_fused.argtypes = [vp, vp, R, ci, ci, vp, vp, vp, vp, P(vp), cd, P(cd)]
+    L.qk_rad_stage_fused.argtypes = [vp, vp, R, ci, ci, vp, vp, vp, vp, P(vp), cd, P(cd), P(vp)]
     L.qk_rad_AddSourceTermsSingleGroup.argtypes = [vp, vp, R, T, vp, vp, cd, ci, vp, vp]
     L.qk_rad_AddSourceTermsSingleGroupMirror.argtypes = [vp, vp, R, T, vp, vp, cd, ci, vp, vp, vp]
     L.qk_rad_AddSourceTermsMultiGroup.argtypes = [vp, vp, R, T, vp, vp, cd, ci, vp, vp]
@@ -258,7 +259,7 @@ DECLARED_SYMBOLS = [
     "qk_hydro_ComputeFluxes", "qk_hydro_ComputeRhsFromFluxes", "qk_hydro_AddInternalEnergyPdV", "qk_hydro_PredictStep",
     "qk_hydro_EnforceLimits", "qk_hydro_SyncDualEnergy", "qk_hydro_ComputeMaxSignalSpeed", "qk_hydro_maxSignalSpeedLocal",
     "qk_replaceFluxes", "qk_Saxpy", "qk_hydro_FixupState", "qk_hydro_stage_scratch_bytes", "qk_hydro_stage_fused",
-    "qk_rad_ConservedToPrimitive", "qk_rad_ComputeFluxes", "qk_rad_computeRadiationFluxes", "qk_rad_PredictStep", "qk_rad_AddFluxesRK2", "qk_rad_stage_fused",
+    "qk_rad_ConservedToPrimitive", "qk_rad_ComputeWavespeedCorrection", "qk_rad_ComputeFluxes", "qk_rad_computeRadiationFluxes", "qk_rad_PredictStep", "qk_rad_AddFluxesRK2", "qk_rad_stage_fused",
     "qk_rad_AddSourceTermsSingleGroup", "qk_rad_AddSourceTermsSingleGroupMirror", "qk_rad_AddSourceTermsMultiGroup", "qk_rad_mg_planck_fractions",
     "qk_ghost_plan_create", "qk_ghost_plan_destroy", "qk_ghost_plan_num_peers", "qk_ghost_plan_peer", "qk_ghost_plan_num_items", "qk_ghost_plan_item",
     "qk_FillBoundary_local", "qk_FillBoundary_local_int", "qk_FillBoundary_pack", "qk_FillBoundary_unpack", "qk_FillBoundary_pack_int", "qk_FillBoundary_unpack_int", "qk_SumBoundary_local", "qk_SumBoundary_pack", "qk_SumBoundary_unpack", "qk_FillPhysicalBoundary",

@@ -150,7 +150,9 @@ QK_DEV void eddingtonTensor(Rad const &r, double fx, double fy, double fz, doubl
 
 // radiation_system.hpp:918-983 + :1054-1131: HLL flux at one face from the L/R primitive states (E, fx, fy, fz);
 // `consL/consR` are the cell-centred conserved radiation states either side (first-order fallback).
-template <int DIR> QK_DEV void radFaceFlux(Rad const &r, const double pL[NRAD], const double pR[NRAD], const double consL[NRAD], const double consR[NRAD], double F[NRAD])
+// `eps0`: the factor of the optional wavespeed correction on the dissipative part of the ENERGY flux (:1098-1117; epsilon = {S_corr, 1, 1, 1}), 1 without it
+template <int DIR>
+QK_DEV void radFaceFlux(Rad const &r, const double pL[NRAD], const double pR[NRAD], const double consL[NRAD], const double consR[NRAD], double F[NRAD], double eps0 = 1.0)
 {
 	double erad_L = pL[0], erad_R = pR[0];
 	double fx_L = pL[1], fx_R = pR[1];
@@ -207,9 +209,19 @@ template <int DIR> QK_DEV void radFaceFlux(Rad const &r, const double pL[NRAD], 
 	const double sR_over = divBy(S_R, RS), sL_over = divBy(S_L, RS), sRL_over = divBy(S_R * S_L, RS);
 #pragma unroll
 	for (int n = 0; n < NRAD; ++n) {
-		// :1116-1117 with epsilon = 1 (use_wavespeed_correction = false)
-		F[n] = sR_over * FL[n] - sL_over * FR[n] + 1.0 * sRL_over * (UR[n] - UL[n]);
+		// :1116-1117
+		const double epsilon = (n == 0) ? eps0 : 1.0;
+		F[n] = sR_over * FL[n] - sL_over * FR[n] + epsilon * sRL_over * (UR[n] - UL[n]);
 	}
+}
+
+// epsilon of face (i, j, k) and photon group g from the arrays qk_rad_ComputeWavespeedCorrection filled (NULL: no correction)
+QK_DEV auto faceEpsilon(const qk_array4 *eps_t, int b, int i, int j, int k, int g) -> double
+{
+	if (eps_t == nullptr) {
+		return 1.0;
+	}
+	return RA4(eps_t[b])(i, j, k, g);
 }
 
 // radiation_system.hpp:626-665

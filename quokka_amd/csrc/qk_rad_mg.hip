@@ -3,6 +3,7 @@
 #include "qk_internal.hpp"
 #include "qk_rad_mg_device.hpp"
 #include "qk_rad_mg_launch.hpp"
+#include "qk_rad_wavespeed_launch.hpp"
 
 using namespace qk;
 
@@ -133,6 +134,39 @@ int qk_rad_AddSourceTermsMultiGroup(qk_level *lev, qk_stream s, const qk_rad_tra
 	QK_REQUIRE(lev->ctx, t->nscalars == 0 && t->nmscalars == 0, "AddSourceTermsMultiGroup: radFirstIndex is 6 (no passive scalars beside radiation)");
 	int rc_launch = QK_OK;
 	QK_MG_DISPATCH(rt->ngroups, (rc_launch = radSourceMGImpl<NG>(lev, s, rt, t, cons_t, src_t, dt, stage, d_iteration_counter, d_failure_counter)))
+	return rc_launch;
+}
+
+// RadSystem::ComputeCellOpticalDepth + the S_corr of ComputeFluxes (radiation_system.hpp:803-871, :1098-1109) for every face and photon group
+int qk_rad_ComputeWavespeedCorrection(qk_level *lev, qk_stream s, const qk_rad_traits *rt, const qk_hydro_traits *t, int ndim, const qk_array4 *cons_t,
+				      const double dx[3], qk_array4 *const eps[3])
+{
+	if (lev == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	QK_REQUIRE(lev->ctx, rt != nullptr && cons_t != nullptr && dx != nullptr && eps != nullptr, "ComputeWavespeedCorrection: NULL argument");
+	QK_REQUIRE(lev->ctx, ndim == lev->ndim && eps[0] != nullptr && (ndim < 2 || eps[1] != nullptr) && (ndim < 3 || eps[2] != nullptr),
+		   "ComputeWavespeedCorrection: one face array per direction of the level");
+	if (int rc = checkTraits(lev->ctx, t); rc != QK_OK) {
+		return rc;
+	}
+	if (int rc = needsLibraryEos(lev->ctx, t, "ComputeWavespeedCorrection"); rc != QK_OK) {
+		return rc;
+	}
+	if (rt->opacity_model == QK_HOOK_COMPILED) {
+		return setError(lev->ctx, QK_ERR_UNSUPPORTED, "ComputeWavespeedCorrection",
+				"the opacity hooks of this problem are compiled device code: instantiate the kernel in the problem's translation unit "
+				"(quokka_amd/host/qk_problem_kernels.hpp)");
+	}
+	if (rt->ngroups <= 1) {
+		QK_REQUIRE(lev->ctx, rt->opacity_model >= 0 && rt->opacity_model <= 2, "ComputeWavespeedCorrection: opacity_model must be 0, 1 or 2");
+		return (rt->opacity_model == 2) ? radWavespeedImpl<true>(lev, s, rt, t, ndim, cons_t, dx, eps) : radWavespeedImpl<false>(lev, s, rt, t, ndim, cons_t, dx, eps);
+	}
+	if (int rc = checkMG(lev->ctx, rt); rc != QK_OK) {
+		return rc;
+	}
+	int rc_launch = QK_OK;
+	QK_MG_DISPATCH(rt->ngroups, (rc_launch = radWavespeedMGImpl<NG>(lev, s, rt, t, ndim, cons_t, dx, eps)))
 	return rc_launch;
 }
 

@@ -36,7 +36,9 @@ inline auto checkRad(qk_ctx *ctx, const qk_rad_traits *rt) -> int
 	return QK_OK;
 }
 
-template <int DIR> void launchRadComputeFluxes(qk_level *lev, qk_stream s, Rad rad, qk_array4 *flux_t, const qk_array4 *left_t, const qk_array4 *right_t, const qk_array4 *cons_t)
+template <int DIR>
+void launchRadComputeFluxes(qk_level *lev, qk_stream s, Rad rad, qk_array4 *flux_t, const qk_array4 *left_t, const qk_array4 *right_t, const qk_array4 *cons_t,
+			    const qk_array4 *eps_t)
 {
 	launchRad(lev, s, 0, DIR, "rad_ComputeFluxes", [=] __device__(int b, int i, int j, int k, bool valid) {
 		if (!valid) {
@@ -56,7 +58,7 @@ template <int DIR> void launchRadComputeFluxes(qk_level *lev, qk_stream s, Rad r
 			cL[n] = U(im, jm, km, RAD0 + pg + n);
 			cR[n] = U(i, j, k, RAD0 + pg + n);
 		}
-		radFaceFlux<DIR>(rad, pL, pR, cL, cR, Fo);
+		radFaceFlux<DIR>(rad, pL, pR, cL, cR, Fo, faceEpsilon(eps_t, b, i, j, k, static_cast<int>(blockIdx.z)));
 #pragma unroll
 		for (int n = 0; n < NRAD; ++n) {
 			F(i, j, k, pg + n) = Fo[n];
@@ -74,7 +76,7 @@ QK_DEV void radPrim(Rad const &r, const double c[NRAD], double p[NRAD])
 	p[3] = divBy(c[3], RcE);
 }
 
-template <int DIR, int ORDER> void launchRadFusedFlux(qk_level *lev, qk_stream s, Rad rad, const qk_array4 *cons_t, qk_array4 *flux_t)
+template <int DIR, int ORDER> void launchRadFusedFlux(qk_level *lev, qk_stream s, Rad rad, const qk_array4 *cons_t, qk_array4 *flux_t, const qk_array4 *eps_t)
 {
 	launchRad(lev, s, 0, DIR, "rad_fluxFunction", [=] __device__(int b, int i, int j, int k, bool valid) {
 		if (!valid) {
@@ -117,7 +119,7 @@ template <int DIR, int ORDER> void launchRadFusedFlux(qk_level *lev, qk_stream s
 				pR[n] = p[3][n];
 			}
 		}
-		radFaceFlux<DIR>(rad, pL, pR, c[2], c[3], Fo);
+		radFaceFlux<DIR>(rad, pL, pR, c[2], c[3], Fo, faceEpsilon(eps_t, b, i, j, k, static_cast<int>(blockIdx.z)));
 		const int64_t o = F.idx(i, j, k);
 #pragma unroll
 		for (int n = 0; n < NRAD; ++n) {
@@ -130,7 +132,7 @@ template <int DIR, int ORDER> void launchRadFusedFlux(qk_level *lev, qk_stream s
 // edge states are evaluated once per strip instead of once per face that touches it (the per-face kernel above is FP64-issue bound:
 // 4-6 cons->prim conversions and two reconstructions per face).  Same functions, same operands: identical fluxes.
 template <int DIR, int ORDER, int STRIP>
-__global__ void __launch_bounds__(256) k_rad_flux_march(const qk_box *boxes, Rad rad, const qk_array4 *cons_t, qk_array4 *flux_t, int notb)
+__global__ void __launch_bounds__(256) k_rad_flux_march(const qk_box *boxes, Rad rad, const qk_array4 *cons_t, qk_array4 *flux_t, int notb, const qk_array4 *eps_t)
 {
 	static_assert(DIR == 1 || DIR == 2, "marching flux kernel: strided directions only");
 	constexpr int OT = 3 - DIR;
@@ -210,8 +212,8 @@ __global__ void __launch_bounds__(256) k_rad_flux_march(const qk_box *boxes, Rad
 				pR[n] = p[3][n];
 			}
 		}
-		radFaceFlux<DIR>(rad, pL, pR, c[2], c[3], Fo);
 		pos[DIR] = face;
+		radFaceFlux<DIR>(rad, pL, pR, c[2], c[3], Fo, faceEpsilon(eps_t, b, pos[0], pos[1], pos[2], pg / NRAD));
 		const int64_t o = F.idx(pos[0], pos[1], pos[2]);
 #pragma unroll
 		for (int n = 0; n < NRAD; ++n) {
@@ -225,7 +227,7 @@ __global__ void __launch_bounds__(256) k_rad_flux_march(const qk_box *boxes, Rad
 // cell instead of 4-6 and 2 per face.  250 faces per 256-thread workgroup (3 halo cells on each side).  Same functions, same operands.
 constexpr int RXB = 256, RXOUT = 250;
 
-template <int ORDER> __global__ void __launch_bounds__(RXB) k_rad_flux_x(const qk_box *boxes, Rad rad, const qk_array4 *cons_t, qk_array4 *flux_t)
+template <int ORDER> __global__ void __launch_bounds__(RXB) k_rad_flux_x(const qk_box *boxes, Rad rad, const qk_array4 *cons_t, qk_array4 *flux_t, const qk_array4 *eps_t)
 {
 	__shared__ double s_p[NRAD][RXB]; // primitives
 	__shared__ double s_e[NRAD][RXB]; // PPM: right edge a_plus of the cell; PLM: its limited slope
@@ -294,7 +296,7 @@ template <int ORDER> __global__ void __launch_bounds__(RXB) k_rad_flux_x(const q
 			pL[n] = s_p[n][tm1];
 		}
 	}
-	radFaceFlux<0>(rad, pL, edgeL, cL, c0, Fo);
+	radFaceFlux<0>(rad, pL, edgeL, cL, c0, Fo, faceEpsilon(eps_t, b, i, j, k, pg / NRAD));
 	WA4 F(flux_t[b]);
 	const int64_t of = F.idx(i, j, k);
 #pragma unroll
@@ -303,7 +305,7 @@ template <int ORDER> __global__ void __launch_bounds__(RXB) k_rad_flux_x(const q
 	}
 }
 
-template <int ORDER> void launchRadXFlux(qk_level *lev, qk_stream s, Rad rad, const qk_array4 *cons_t, qk_array4 *flux_t, int nghost)
+template <int ORDER> void launchRadXFlux(qk_level *lev, qk_stream s, Rad rad, const qk_array4 *cons_t, qk_array4 *flux_t, int nghost, const qk_array4 *eps_t)
 {
 	if (lev->nboxes == 0) {
 		return;
@@ -312,10 +314,10 @@ template <int ORDER> void launchRadXFlux(qk_level *lev, qk_stream s, Rad rad, co
 	const dim3 grid(static_cast<unsigned>((slab + RXOUT - 1) / RXOUT), static_cast<unsigned>(lev->maxlen[2]),
 			static_cast<unsigned>(lev->nboxes * rad.ngroups));
 	ProfScope ps(lev->ctx, static_cast<hipStream_t>(s), "rad_fluxFunction");
-	hipLaunchKernelGGL((k_rad_flux_x<ORDER>), grid, dim3(RXB), 0, static_cast<hipStream_t>(s), lev->d_boxes, rad, cons_t, flux_t);
+	hipLaunchKernelGGL((k_rad_flux_x<ORDER>), grid, dim3(RXB), 0, static_cast<hipStream_t>(s), lev->d_boxes, rad, cons_t, flux_t, eps_t);
 }
 
-template <int DIR, int ORDER> void launchRadMarchFlux(qk_level *lev, qk_stream s, Rad rad, const qk_array4 *cons_t, qk_array4 *flux_t)
+template <int DIR, int ORDER> void launchRadMarchFlux(qk_level *lev, qk_stream s, Rad rad, const qk_array4 *cons_t, qk_array4 *flux_t, const qk_array4 *eps_t)
 {
 	if (lev->nboxes == 0) {
 		return;
@@ -326,7 +328,7 @@ template <int DIR, int ORDER> void launchRadMarchFlux(qk_level *lev, qk_stream s
 	const int nstrips = (lev->maxlen[DIR] + 1 + STRIP - 1) / STRIP;
 	const dim3 grid((lev->maxlen[0] + 63) / 64, notb * nstrips, lev->nboxes * rad.ngroups);
 	ProfScope ps(lev->ctx, static_cast<hipStream_t>(s), "rad_fluxFunction");
-	hipLaunchKernelGGL((k_rad_flux_march<DIR, ORDER, STRIP>), grid, dim3(64, 4), 0, static_cast<hipStream_t>(s), lev->d_boxes, rad, cons_t, flux_t, notb);
+	hipLaunchKernelGGL((k_rad_flux_march<DIR, ORDER, STRIP>), grid, dim3(64, 4), 0, static_cast<hipStream_t>(s), lev->d_boxes, rad, cons_t, flux_t, notb, eps_t);
 }
 
 
@@ -342,6 +344,7 @@ struct RadSweep {
 	qk_array4 *acc;	       // NRAD components per cell, no ghost cells needed
 	qk_array4 *flux[3];    // each NULL or the face-centred array that receives the fluxes
 	double dtdx[3];
+	const qk_array4 *eps[3]; // each NULL or the wavespeed-correction factors of the faces of that direction (qk_rad_ComputeWavespeedCorrection)
 	int pg; // component offset of the photon group these launches advance (NRAD * group): the groups are transported independently of each other
 };
 
@@ -455,7 +458,7 @@ template <int ORDER, bool STORE> __global__ void __launch_bounds__(RXB) k_rad_sw
 				pL[n] = s_p[n][tm1];
 			}
 		}
-		radFaceFlux<0>(rad, pL, edgeL, cL, c0, Fo);
+		radFaceFlux<0>(rad, pL, edgeL, cL, c0, Fo, faceEpsilon(a.eps[0], b, i, j, k, a.pg / NRAD));
 #pragma unroll
 		for (int n = 0; n < NRAD; ++n) {
 			s_f[n][t] = Fo[n];
@@ -601,7 +604,8 @@ __global__ void __launch_bounds__(256) k_rad_sweep_march(const qk_box *boxes, Ra
 				pR[n] = p[3][n];
 			}
 		}
-		radFaceFlux<DIR>(rad, pL, pR, c[2], c[3], Fo);
+		pos[DIR] = face;
+		radFaceFlux<DIR>(rad, pL, pR, c[2], c[3], Fo, faceEpsilon(a.eps[DIR], b, pos[0], pos[1], pos[2], a.pg / NRAD));
 		if (STORE && (face <= c1 || c1 == bx.hi[DIR])) { // (the face after the strip belongs to the next strip, except at the end of the pencil)
 			WA4 F(a.flux[DIR][b]);
 			pos[DIR] = face;
@@ -724,7 +728,7 @@ int qk_rad_ConservedToPrimitive(qk_level *lev, qk_stream s, const qk_rad_traits 
 }
 
 int qk_rad_ComputeFluxes(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int dir, qk_array4 *flux_t, const qk_array4 *left_t,
-			 const qk_array4 *right_t, const qk_array4 *cons_t)
+			 const qk_array4 *right_t, const qk_array4 *cons_t, const qk_array4 *wavespeed_eps)
 {
 	if (lev == nullptr) {
 		return QK_ERR_INVALID;
@@ -736,13 +740,13 @@ int qk_rad_ComputeFluxes(qk_level *lev, qk_stream s, const qk_rad_traits *rt, in
 	const Rad rad(*rt);
 	switch (dir) {
 	case 0:
-		launchRadComputeFluxes<0>(lev, s, rad, flux_t, left_t, right_t, cons_t);
+		launchRadComputeFluxes<0>(lev, s, rad, flux_t, left_t, right_t, cons_t, wavespeed_eps);
 		break;
 	case 1:
-		launchRadComputeFluxes<1>(lev, s, rad, flux_t, left_t, right_t, cons_t);
+		launchRadComputeFluxes<1>(lev, s, rad, flux_t, left_t, right_t, cons_t, wavespeed_eps);
 		break;
 	case 2:
-		launchRadComputeFluxes<2>(lev, s, rad, flux_t, left_t, right_t, cons_t);
+		launchRadComputeFluxes<2>(lev, s, rad, flux_t, left_t, right_t, cons_t, wavespeed_eps);
 		break;
 	default:
 		return setError(lev->ctx, QK_ERR_INVALID, "rad ComputeFluxes: bad direction");
@@ -751,8 +755,10 @@ int qk_rad_ComputeFluxes(qk_level *lev, qk_stream s, const qk_rad_traits *rt, in
 }
 
 int qk_rad_computeRadiationFluxes(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int ndim, int order, const qk_array4 *cons_t,
-				  qk_array4 *const flux[3])
+				  qk_array4 *const flux[3], const qk_array4 *const wavespeed_eps[3])
 {
+	const qk_array4 *const no_eps[3] = {nullptr, nullptr, nullptr};
+	const qk_array4 *const *eps = (wavespeed_eps != nullptr) ? wavespeed_eps : no_eps;
 	if (lev == nullptr) {
 		return QK_ERR_INVALID;
 	}
@@ -765,21 +771,21 @@ int qk_rad_computeRadiationFluxes(qk_level *lev, qk_stream s, const qk_rad_trait
 	const Rad rad(*rt);
 #define QK_RAD_DIR(D)                                                                                                                                \
 	if (order == 3) {                                                                                                                            \
-		launchRadFusedFlux<D, 3>(lev, s, rad, cons_t, flux[D]);                                                                              \
+		launchRadFusedFlux<D, 3>(lev, s, rad, cons_t, flux[D], eps[D]);                                                                              \
 	} else if (order == 2) {                                                                                                                     \
-		launchRadFusedFlux<D, 2>(lev, s, rad, cons_t, flux[D]);                                                                              \
+		launchRadFusedFlux<D, 2>(lev, s, rad, cons_t, flux[D], eps[D]);                                                                              \
 	} else {                                                                                                                                     \
-		launchRadFusedFlux<D, 1>(lev, s, rad, cons_t, flux[D]);                                                                              \
+		launchRadFusedFlux<D, 1>(lev, s, rad, cons_t, flux[D], eps[D]);                                                                              \
 	}
 	// 2-D builds: the radiation fluxes do not permute components with the direction (radiation_system.hpp:1026-1040), so the X2 view of
 	// ArrayView_2d.hpp and the cyclic one of the 3-D build address the same cells: the 3-D kernels on a single plane.
 	if (ndim >= 2) { // (state arrays carry nghost_cc = 4 ghost cells throughout the library; the slab below is sized for that)
 		if (order == 3) {
-			launchRadXFlux<3>(lev, s, rad, cons_t, flux[0], 4);
+			launchRadXFlux<3>(lev, s, rad, cons_t, flux[0], 4, eps[0]);
 		} else if (order == 2) {
-			launchRadXFlux<2>(lev, s, rad, cons_t, flux[0], 4);
+			launchRadXFlux<2>(lev, s, rad, cons_t, flux[0], 4, eps[0]);
 		} else {
-			launchRadXFlux<1>(lev, s, rad, cons_t, flux[0], 4);
+			launchRadXFlux<1>(lev, s, rad, cons_t, flux[0], 4, eps[0]);
 		}
 	} else {
 		QK_RAD_DIR(0)
@@ -787,11 +793,11 @@ int qk_rad_computeRadiationFluxes(qk_level *lev, qk_stream s, const qk_rad_trait
 #undef QK_RAD_DIR
 #define QK_RAD_MARCH(D)                                                                                                                              \
 	if (order == 3) {                                                                                                                            \
-		launchRadMarchFlux<D, 3>(lev, s, rad, cons_t, flux[D]);                                                                              \
+		launchRadMarchFlux<D, 3>(lev, s, rad, cons_t, flux[D], eps[D]);                                                                              \
 	} else if (order == 2) {                                                                                                                     \
-		launchRadMarchFlux<D, 2>(lev, s, rad, cons_t, flux[D]);                                                                              \
+		launchRadMarchFlux<D, 2>(lev, s, rad, cons_t, flux[D], eps[D]);                                                                              \
 	} else {                                                                                                                                     \
-		launchRadMarchFlux<D, 1>(lev, s, rad, cons_t, flux[D]);                                                                              \
+		launchRadMarchFlux<D, 1>(lev, s, rad, cons_t, flux[D], eps[D]);                                                                              \
 	}
 	if (ndim >= 2) {
 		QK_RAD_MARCH(1)
@@ -976,7 +982,7 @@ int qk_rad_AddFluxesRK2(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int
 
 
 int qk_rad_stage_fused(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int order, int stage, const qk_array4 *U_in, const qk_array4 *U0, qk_array4 *U_new,
-		       qk_array4 *acc, qk_array4 *const flux_out[3], double dt, const double dx_in[3])
+		       qk_array4 *acc, qk_array4 *const flux_out[3], double dt, const double dx_in[3], const qk_array4 *const wavespeed_eps[3])
 {
 	if (lev == nullptr) {
 		return QK_ERR_INVALID;
@@ -1001,6 +1007,7 @@ int qk_rad_stage_fused(qk_level *lev, qk_stream s, const qk_rad_traits *rt, int 
 	for (int d = 0; d < 3; ++d) {
 		a.flux[d] = store ? flux_out[d] : nullptr;
 		a.dtdx[d] = dt / dx_in[d];
+		a.eps[d] = (wavespeed_eps != nullptr) ? wavespeed_eps[d] : nullptr;
 	}
 	// the photon groups are transported independently (radiation_system.hpp:667-771 loops over them inside one kernel): one set of sweeps per group
 #define QK_RAD_SWEEPS(O)                                                                                                                             \

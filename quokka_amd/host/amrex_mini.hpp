@@ -31,6 +31,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <cctype>
 #include <type_traits>
 #include <utility>
 #include <random>
@@ -670,9 +671,27 @@ class ParmParse
 		if (it == table().end() || it->second.empty()) {
 			return false;
 		}
-		std::istringstream s(it->second[0]);
-		s >> val;
-		return true;
+		if constexpr (std::is_same_v<T, bool>) { // amrex::ParmParse reads a bool from true / t / false / f (any case) or a number
+			std::string w = it->second[0];
+			for (auto &c : w) {
+				c = static_cast<char>(std::tolower(static_cast<unsigned char>(c)));
+			}
+			if (w == "true" || w == "t") {
+				val = true;
+			} else if (w == "false" || w == "f") {
+				val = false;
+			} else {
+				double num = 0.0;
+				std::istringstream s(w);
+				s >> num;
+				val = (num != 0.0);
+			}
+			return true;
+		} else {
+			std::istringstream s(it->second[0]);
+			s >> val;
+			return true;
+		}
 	}
 	template <typename T> auto queryarr(std::string const &name, std::vector<T> &vals) const -> bool
 	{

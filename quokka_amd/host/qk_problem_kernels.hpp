@@ -19,6 +19,7 @@
 
 #include "../csrc/qk_rad_mg_launch.hpp"
 #include "../csrc/qk_rad_source_launch.hpp"
+#include "../csrc/qk_rad_wavespeed_launch.hpp"
 
 namespace qkhost
 {
@@ -122,6 +123,27 @@ auto addSourceTermsMultiGroup(qk_level *lev, const qk_rad_traits *rt, const qk_h
 			return qk::setError(lev->ctx, QK_ERR_UNSUPPORTED, "multigroup source term with a compiled opacity hook: library EOS, no passive scalars");
 		}
 		return qk::radSourceMGImpl<NG, ProblemRadMG<problem_t, NG>>(lev, nullptr, rt, t, cons_t, src_t, dt, stage, d_iteration_counter, d_failure_counter);
+	} else {
+		return QK_ERR_UNSUPPORTED;
+	}
+}
+
+// RadSystem<problem_t>::ComputeCellOpticalDepth<DIR> + the wavespeed-correction factor of ComputeFluxes<DIR> (reference radiation_system.hpp:803-871,
+// :1098-1109) on every face, with the problem's ComputeFluxMeanOpacity / quokka::EOS (one group) or DefineOpacityExponentsAndLowerValues (several)
+template <typename problem_t>
+auto computeWavespeedCorrection(qk_level *lev, const qk_rad_traits *rt, const qk_hydro_traits *t, const qk_array4 *cons_t, const double dx[3], qk_array4 *const eps[3]) -> int
+{
+	constexpr int NG = Physics_Traits<problem_t>::nGroups;
+	if (lev == nullptr || rt == nullptr || t == nullptr || cons_t == nullptr || dx == nullptr || eps == nullptr) {
+		return QK_ERR_INVALID;
+	}
+	if constexpr (NG <= 1) {
+		return qk::radWavespeedImpl<true, ProblemRad<problem_t>, ProblemEosCell<problem_t>>(lev, nullptr, rt, t, AMREX_SPACEDIM, cons_t, dx, eps);
+	} else if constexpr (NG <= QK_MAX_GROUPS) {
+		if (rt->opacity_model == kHookCompiled) {
+			return qk::radWavespeedMGImpl<NG, ProblemRadMG<problem_t, NG>>(lev, nullptr, rt, t, AMREX_SPACEDIM, cons_t, dx, eps);
+		}
+		return qk::radWavespeedMGImpl<NG>(lev, nullptr, rt, t, AMREX_SPACEDIM, cons_t, dx, eps);
 	} else {
 		return QK_ERR_UNSUPPORTED;
 	}

@@ -85,13 +85,14 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		artificialViscosityK_ = base.artificialViscosityK_;
 		radiationCflNumber_ = base.radiationCflNumber_;
 		radiationReconstructionOrder_ = base.radiationReconstructionOrder_;
+		use_wavespeed_correction_ = base.use_wavespeed_correction_;
 		maxSubsteps_ = base.maxSubsteps_;
 		radSourceTimeIndependent_ = base.radSourceTimeIndependent_;
 		dustGasInteractionCoeff_ = base.dustGasInteractionCoeff_;
 		this->constantDt_ = base.constantDt_;
 	}
 	double tOldLev_ = 0.0, tNewLev_ = 0.0; // tOld_[lev], tNew_[lev]
-	bool use_wavespeed_correction_ = false; // QuokkaSimulation.hpp:133 (not implemented: must stay false)
+	bool use_wavespeed_correction_ = false; // QuokkaSimulation.hpp:133 (ComputeCellOpticalDepth + S_corr on the even faces: wavespeedEps below)
 	double fillTime_ = 0.0;		       // the time a ghost fill refers to (coarse data are interpolated to it)
 	[[nodiscard]] auto bcFillTime() const -> double override { return fillTime_; }
 	bool storeFluxRk2_ = false;	       // keep flux_rk2 = 0.5 F1 + 0.5 F2 (rk2flux_) for the flux registers
@@ -679,15 +680,42 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		}
 	}
 
+	// use_wavespeed_correction_ (:133, :1958-1960): the factors of ComputeFluxes<DIR>'s optional correction for the state whose fluxes are about to be
+	// taken (its ghost cells filled in EVERY component: ComputeCellOpticalDepth reads the gas either side of a face); nullptr when off
+	std::array<amrex::MultiFab, AMREX_SPACEDIM> radEps_;
+	bool radEpsDefined_ = false;
+	auto wavespeedEps(amrex::MultiFab const &state) -> std::array<amrex::MultiFab, AMREX_SPACEDIM> const *
+	{
+		if (!use_wavespeed_correction_) {
+			return nullptr;
+		}
+		if (!radEpsDefined_) {
+			radEpsDefined_ = true;
+			for (int d = 0; d < AMREX_SPACEDIM; ++d) {
+				radEps_[d].define(grids_, Physics_Traits<problem_t>::nGroups > 1 ? Physics_Traits<problem_t>::nGroups : 1, 0, d);
+			}
+		}
+		RadSystem<problem_t>::ComputeWavespeedCorrection(state, geom[0].CellSizeArray(), radEps_);
+		return &radEps_;
+	}
+	void fillGhostsForTransport(amrex::MultiFab &state)
+	{
+		if (use_wavespeed_correction_) {
+			this->fillBoundaryConditions(state);
+		} else {
+			this->fillRadiationGhosts(state);
+		}
+	}
+
 	void advanceRadiationForwardEuler(double dt_radiation) // :1790-1821
 	{
 		fillTime_ = radTime_; // (a refined level: its ghost cells come from the parent at the time of the substep, :1743)
-		this->fillRadiationGhosts(state_old_cc_[0]);
+		fillGhostsForTransport(state_old_cc_[0]);
 		if (radFusedActive()) {
 			RadSystem<problem_t>::stageFused(1, radiationReconstructionOrder_, state_old_cc_[0], state_old_cc_[0], state_new_cc_[0], radAcc_,
-							 afterRadStage_ ? &radFluxOld_ : nullptr, dt_radiation, geom[0].CellSizeArray());
+							 afterRadStage_ ? &radFluxOld_ : nullptr, dt_radiation, geom[0].CellSizeArray(), wavespeedEps(state_old_cc_[0]));
 		} else {
-			RadSystem<problem_t>::computeRadiationFluxes(state_old_cc_[0], radFluxOld_, radiationReconstructionOrder_);
+			RadSystem<problem_t>::computeRadiationFluxes(state_old_cc_[0], radFluxOld_, radiationReconstructionOrder_, wavespeedEps(state_old_cc_[0]));
 			RadSystem<problem_t>::PredictStep(state_old_cc_[0], state_new_cc_[0], radFluxOld_, dt_radiation, geom[0].CellSizeArray());
 		}
 		if (afterRadStage_) {
@@ -698,12 +726,12 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	void advanceRadiationMidpointRK2(double dt_radiation) // :1823-1857 (the fluxes of the old state are reused, not recomputed)
 	{
 		fillTime_ = radTime_ + dt_radiation; // :1764
-		this->fillRadiationGhosts(state_new_cc_[0]);
+		fillGhostsForTransport(state_new_cc_[0]);
 		if (radFusedActive()) { // (the Z sweep writes state_new in place: it marches every column in one thread and reads no other column)
 			RadSystem<problem_t>::stageFused(2, radiationReconstructionOrder_, state_new_cc_[0], state_old_cc_[0], state_new_cc_[0], radAcc_,
-							 afterRadStage_ ? &radFlux_ : nullptr, dt_radiation, geom[0].CellSizeArray());
+							 afterRadStage_ ? &radFlux_ : nullptr, dt_radiation, geom[0].CellSizeArray(), wavespeedEps(state_new_cc_[0]));
 		} else {
-			RadSystem<problem_t>::computeRadiationFluxes(state_new_cc_[0], radFlux_, radiationReconstructionOrder_);
+			RadSystem<problem_t>::computeRadiationFluxes(state_new_cc_[0], radFlux_, radiationReconstructionOrder_, wavespeedEps(state_new_cc_[0]));
 			RadSystem<problem_t>::AddFluxesRK2(state_new_cc_[0], state_old_cc_[0], state_new_cc_[0], radFluxOld_, radFlux_, dt_radiation, geom[0].CellSizeArray());
 		}
 		if (afterRadStage_) {

@@ -389,13 +389,32 @@ template <typename problem_t> class RadSystem : public HyperbolicSystem<problem_
 	}
 
 	// computeRadiationFluxes + fluxFunction<DIR> (reference src/QuokkaSimulation.hpp:1884-1961): cons -> prim, reconstruction, HLL
-	static void computeRadiationFluxes(amrex::MultiFab const &consVar, std::array<amrex::MultiFab, AMREX_SPACEDIM> &flux, int reconstructionOrder)
+	// `eps`: nullptr (use_wavespeed_correction false) or the factors ComputeWavespeedCorrection(consVar) left
+	static void computeRadiationFluxes(amrex::MultiFab const &consVar, std::array<amrex::MultiFab, AMREX_SPACEDIM> &flux, int reconstructionOrder,
+					   std::array<amrex::MultiFab, AMREX_SPACEDIM> const *eps = nullptr)
 	{
 		auto rt = traits();
-		qk_array4 *f[3];
+		qk_array4 *f[3], *e[3] = {nullptr, nullptr, nullptr};
 		flux3(flux, f);
-		qkhost::check(qk_rad_computeRadiationFluxes(lev(), nullptr, &rt, AMREX_SPACEDIM, reconstructionOrder, qkhost::tab(consVar), f),
+		if (eps != nullptr) {
+			flux3(*eps, e);
+		}
+		qkhost::check(qk_rad_computeRadiationFluxes(lev(), nullptr, &rt, AMREX_SPACEDIM, reconstructionOrder, qkhost::tab(consVar), f, eps != nullptr ? e : nullptr),
 			      "RadSystem::computeRadiationFluxes");
+	}
+	// ComputeCellOpticalDepth<DIR> on every face and what the use_wavespeed_correction branch of ComputeFluxes<DIR> makes of it (:803-871, :1019-1022,
+	// :1098-1109): eps[d] = min(1, 1 / tau_cell) on the even faces of direction d, 1 on the odd ones.  Instantiated HERE with this problem's compiled
+	// opacity and EOS hooks (qk_problem_kernels.hpp).
+	static void ComputeWavespeedCorrection(amrex::MultiFab const &consVar, amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> dx,
+					       std::array<amrex::MultiFab, AMREX_SPACEDIM> &eps)
+	{
+		auto rt = traits();
+		auto t = qkhost::traits<problem_t>();
+		qk_array4 *e[3];
+		double d3[3];
+		flux3(eps, e);
+		dx3(dx, d3);
+		qkhost::check(qkhost::computeWavespeedCorrection<problem_t>(lev(), &rt, &t, qkhost::tab(consVar), d3, e), "RadSystem::ComputeCellOpticalDepth");
 	}
 	// :667-710
 	static void PredictStep(amrex::MultiFab const &consVarOld, amrex::MultiFab &consVarNew, std::array<amrex::MultiFab, AMREX_SPACEDIM> const &fluxArray,
@@ -412,17 +431,21 @@ template <typename problem_t> class RadSystem : public HyperbolicSystem<problem_
 	// one transport stage with the flux divergence taken inside the flux kernels (qk_rad_stage_fused): computeRadiationFluxes(U_in) +
 	// PredictStep (stage 1) / AddFluxesRK2 (stage 2); `fluxOut`: where the face fluxes are stored, or nullptr when nothing reads them
 	static void stageFused(int stage, int order, amrex::MultiFab const &U_in, amrex::MultiFab const &U0, amrex::MultiFab &U_new, amrex::MultiFab &acc,
-			       std::array<amrex::MultiFab, AMREX_SPACEDIM> *fluxOut, double dt, amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> dx)
+			       std::array<amrex::MultiFab, AMREX_SPACEDIM> *fluxOut, double dt, amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> dx,
+			       std::array<amrex::MultiFab, AMREX_SPACEDIM> const *eps = nullptr)
 	{
 		auto rt = traits();
-		qk_array4 *f[3] = {nullptr, nullptr, nullptr};
+		qk_array4 *f[3] = {nullptr, nullptr, nullptr}, *e[3] = {nullptr, nullptr, nullptr};
 		double d3[3];
 		if (fluxOut != nullptr) {
 			flux3(*fluxOut, f);
 		}
+		if (eps != nullptr) {
+			flux3(*eps, e);
+		}
 		dx3(dx, d3);
 		qkhost::check(qk_rad_stage_fused(lev(), nullptr, &rt, order, stage, qkhost::tab(U_in), qkhost::tab(U0), qkhost::tab(U_new), qkhost::tab(acc),
-						 fluxOut != nullptr ? f : nullptr, dt, d3),
+						 fluxOut != nullptr ? f : nullptr, dt, d3, eps != nullptr ? e : nullptr),
 			      "RadSystem::stageFused");
 	}
 	// :712-771

@@ -54,6 +54,8 @@ class RadhydroSimulation(HydroSimulation):
         self.maxSubsteps_ = 10
         self.radiationReconstructionOrder_ = 3
         self.radiationCellUpdates_ = 0
+        self.use_wavespeed_correction_ = False  # QuokkaSimulation.hpp:133
+        self._rad_eps = None
         lev, nd = self.lev, geom.ndim
         self.radFluxOld = [MultiFab(lev, self.nrad, 0, facedir=d) for d in range(nd)]
         self.radFlux = [MultiFab(lev, self.nrad, 0, facedir=d) for d in range(nd)]
@@ -92,10 +94,23 @@ class RadhydroSimulation(HydroSimulation):
         return int(math.ceil(dt_lev_hydro / dtrad_tmp))
 
     # ------------------------------------------------------------------ pieces
+    def _wavespeed_eps(self, state: MultiFab):
+        """use_wavespeed_correction_ (reference src/QuokkaSimulation.hpp:133, :1958-1960): the factors ComputeFluxes<DIR> puts on the dissipative part
+        of the radiation-energy flux, from ComputeCellOpticalDepth<DIR> of `state` (ghost cells filled, gas components included); None when off"""
+        if not self.use_wavespeed_correction_:
+            return None
+        if self._rad_eps is None:
+            self._rad_eps = [MultiFab(self.lev, self.nGroups, 0, facedir=d) for d in range(self.geom.ndim)]
+        c = self.ctx
+        c.check(c.L.qk_rad_ComputeWavespeedCorrection(self.lev.h, c.stream(), C.byref(self.rad_traits), C.byref(self.traits), self.geom.ndim, state.ptr,
+                                                      _d3(self.geom.dx), _p3(self._rad_eps)), "qk_rad_ComputeWavespeedCorrection")
+        return _p3(self._rad_eps)
+
     def _rad_fluxes(self, state: MultiFab, out):
         c = self.ctx
         c.check(c.L.qk_rad_computeRadiationFluxes(self.lev.h, c.stream(), C.byref(self.rad_traits), self.geom.ndim,
-                                                  self.radiationReconstructionOrder_, state.ptr, _p3(out)), "qk_rad_computeRadiationFluxes")
+                                                  self.radiationReconstructionOrder_, state.ptr, _p3(out), self._wavespeed_eps(state)),
+                "qk_rad_computeRadiationFluxes")
 
     def _fill_source(self, time: float):
         if self.SetRadEnergySource is None or (self._source_set and self._source_time_independent):
@@ -130,6 +145,9 @@ class RadhydroSimulation(HydroSimulation):
         """fillBoundaryConditions for the transport kernels, which read only the radiation components of the ghost cells: the same-rank
         copies and the physical BCs are restricted to them (strips to other ranks carry everything; the reference fills all components)"""
         L, h = self.ctx.L, self.ghost.h
+        if self.use_wavespeed_correction_:  # ComputeCellOpticalDepth reads the gas state either side of every face: all components
+            self.fillBoundaryConditions(state)
+            return
         self.ctx.check(L.qk_ghost_plan_set_components(h, RAD0, self.nrad), "qk_ghost_plan_set_components")
         try:
             self.fillBoundaryConditions(state)
@@ -142,7 +160,7 @@ class RadhydroSimulation(HydroSimulation):
         c = self.ctx
         c.check(c.L.qk_rad_stage_fused(self.lev.h, c.stream(), C.byref(self.rad_traits), self.radiationReconstructionOrder_, stage, U_in.ptr, U0.ptr,
                                        U_new.ptr, self._rad_acc.ptr, _p3(flux_out) if self.store_rad_flux else None, float(dt_radiation),
-                                       _d3(self.geom.dx)), "qk_rad_stage_fused")
+                                       _d3(self.geom.dx), self._wavespeed_eps(U_in)), "qk_rad_stage_fused")
 
     def advanceRadiationForwardEuler(self, dt_radiation: float):
         self._fill_rad_ghosts(self.state_old_cc_)

@@ -235,6 +235,26 @@ def test_marshak_asymptotic_executable_meets_the_reference_criterion(tmp_path, o
         assert float(np.abs(A[n] - B[n]).sum() / np.abs(B[n]).sum()) < 1e-6
 
 
+def test_marshak_asymptotic_executable_with_the_wavespeed_correction(tmp_path, oracle):
+    """the reference's ctest RadMarshakAsymptoticCorr (tests/MarshakAsymptoticCorr.in = MarshakAsymptotic.in + marshak.use_wavespeed_correction = true)
+    through the C++ mirror: QuokkaSimulation::use_wavespeed_correction_ set by the unchanged problem file, ComputeCellOpticalDepth instantiated in the
+    problem's translation unit with its compiled opacity hook (qk_problem_kernels.hpp).  Exit status 0 == within 9 per cent of the similarity
+    solution; the state agrees with the oracle's corrected run to 1e-6 (compiled std::pow against the closed power-law form) and differs from the
+    uncorrected one."""
+    from oracle.pyoracle import MARSHAK_ASYMPTOTIC
+    cwd = extern_tree(tmp_path, {"marshak_similarity.csv": "marshak_similarity.csv"})
+    data, meta, out = run("ref_RadMarshakAsymptotic", [os.path.join(HOST, "decks", "MarshakAsymptotic.in"), "marshak.use_wavespeed_correction=true"], tmp_path, cwd=cwd)
+    so = oracle.sim(MARSHAK_ASYMPTOTIC, 1, [60, 1, 1], [0, 0, 0], [0.66, 1, 1], [0, 1, 1], max_grid_size=[60, 1, 1])
+    so.set_wavespeed_correction(True)
+    assert so.evolve() and int(meta[0]) == so.istep
+    A, B = data.reshape(10, 60), so.valid(0).reshape(10, 60)
+    for n in (4, 6):
+        assert float(np.abs(A[n] - B[n]).sum() / np.abs(B[n]).sum()) < 1e-6
+    plain = oracle.sim(MARSHAK_ASYMPTOTIC, 1, [60, 1, 1], [0, 0, 0], [0.66, 1, 1], [0, 1, 1], max_grid_size=[60, 1, 1])
+    assert plain.evolve()
+    assert float(np.abs(A[6] - plain.valid(0).reshape(10, 60)[6]).sum() / np.abs(A[6]).sum()) > 1e-6
+
+
 def test_passive_scalar_executable_meets_the_reference_criteria(tmp_path):
     """the reference's PassiveScalar ctest (tests/PassiveScalar.in: one refined level on the density gradient, subcycled, refluxed;
     src/problems/PassiveScalar/test_scalars.cpp): scalar conserved to 1e-14 and relative rms L1 error <= 0.008 after four box

@@ -340,3 +340,50 @@ def test_photoelectric_heating_front_matches_oracle_and_criterion(ctx, oracle, d
     assert sg.rad_counters["solves"] == co["solves"] and sg.rad_counters["decoupled"] == co["decoupled"]
     err = marshak_dust_pe_error(sg.state_new_cc_.valid(0).cpu().numpy()[:, 0, 0, :], sg.tNew_)
     assert err < 0.01, err
+
+
+def test_multigroup_transport_with_the_wavespeed_correction_matches_oracle(ctx, oracle):
+    """use_wavespeed_correction_ with several photon groups (reference src/radiation/radiation_system.hpp:863-868: DefineOpacityExponentsAndLowerValues +
+    ComputeBinCenterOpacity either side of the face, one optical depth per group): RadhydroShockMultigroup's five groups on 64 x 4 x 4 cells in two
+    boxes, a rippled radiation state over a gas density roughened across six decades (optical depths per cell on both sides of 1), transport only.
+    The bin-centre opacity is a std::pow: 1e-12 relative L1 per radiation component (bit for bit where the exponents vanish), and the correction
+    does change the fluxes."""
+    from quokka_amd.radhydro_multigroup import RadShockMGConstants as S, radshock_mg_problem
+    n = [64, 4, 4]
+    ng = 5
+    results = []
+    for corr in (True, False):
+        so = oracle.sim(RADSHOCK_MG, 3, n, [0, 0, 0], [S.Lx, 0.001575, 1.0], [0, 1, 1], max_grid_size=[32, 4, 4])
+        sg = radshock_mg_problem(ctx, 64, three_d=True, max_grid_size=[32, 4, 4])
+        rng = np.random.default_rng(21)
+        for b in range(so.nboxes):
+            U = so.state(b, 0).copy()
+            shp = U.shape[1:]
+            U[0:6] *= 10.0 ** rng.uniform(-3.0, 3.0, shp)
+            for g in range(ng):
+                E = U[6 + 4 * g] * (1.0 + 0.3 * rng.random(shp))
+                U[6 + 4 * g] = E
+                f = 0.8 * rng.random(shp)
+                d = rng.normal(size=(3,) + shp)
+                d /= np.sqrt((d * d).sum(axis=0))
+                for a in range(3):
+                    U[6 + 4 * g + 1 + a] = f * d[a] * S.c * E
+            so.set_state(U, b, 0)
+            so.set_state(U, b, 1)
+            sg.state_new_cc_.set_fab(b, U)
+            sg.state_old_cc_.set_fab(b, U)
+        so.set_wavespeed_correction(corr)
+        sg.use_wavespeed_correction_ = corr
+        dt = 0.3 * min(sg.geom.dx) / S.chat
+        so.rad_transport_only(dt)
+        sg.advanceRadiationForwardEuler(dt)
+        sg.advanceRadiationMidpointRK2(dt)
+        out = []
+        for b in range(so.nboxes):
+            a, g_ = so.valid(b), sg.state_new_cc_.valid(b).cpu().numpy()
+            for c in range(6, 6 + 4 * ng):
+                den = np.abs(a[c]).sum()
+                assert np.abs(a[c] - g_[c]).sum() <= 1e-12 * max(den, 1e-300), (corr, b, c)
+            out.append(g_)
+        results.append(out)
+    assert any(not np.array_equal(x[6], y[6]) for x, y in zip(*results))

@@ -375,6 +375,21 @@ def test_marshak_wave_in_the_diffusion_limit_meets_the_reference_criterion(oracl
     assert 1e-3 < err < 0.09, err
 
 
+def test_marshak_wave_with_the_wavespeed_correction_meets_the_reference_criterion(oracle):
+    """RadMarshakAsymptotic on the deck tests/MarshakAsymptoticCorr.in (marshak.use_wavespeed_correction = true: ComputeCellOpticalDepth and the
+    factor min(1, 1 / tau_cell) on the dissipative part of the energy flux at the even faces, reference src/radiation/radiation_system.hpp:803-871,
+    :1098-1109): the same criterion as without it — gas temperature within 9 per cent of the similarity solution —, and a different answer."""
+    from oracle.pyoracle import MARSHAK_ASYMPTOTIC
+    s = oracle.sim(MARSHAK_ASYMPTOTIC, 1, [60, 1, 1], [0, 0, 0], [0.66, 1, 1], [0, 1, 1], max_grid_size=[60, 1, 1])
+    s.set_wavespeed_correction(True)
+    assert s.evolve()
+    c = s.rad_counters()
+    assert c["fail_coupling"] == c["fail_outer"] == 0
+    err = marshak_asymptotic_error(s.valid(0))
+    assert 1e-3 < err < 0.09, err
+    print(f"RadMarshakAsymptotic with use_wavespeed_correction: {s.istep} steps, relative L1 error {err:.5f}")
+
+
 def test_linear_diffusion_of_a_radiation_pulse_meets_the_reference_criterion(oracle):
     """RadPulse (src/problems/RadPulse/test_radiation_pulse.cpp, deck tests/RadPulse.in): opacity (kappa0 / rho) max((T / T0)^3, 1) — the
     floored member of the power-law opacities —, ~1e5 optical depths per cell: the asymptotic-preserving limit of the IMEX scheme.

@@ -3,6 +3,7 @@
 The radiation update contains pow(T, 4) / pow(T, 3) (std::pow in the reference): glibc and the device libm agree to
 <= 1 ulp, not bit-for-bit, so the default build is compared with the tolerance north_star states (1e-12 relative L1 on
 every conserved component).  With pow_mode = 1 (repeated multiplication on both sides) everything else is bit-exact."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -382,7 +383,7 @@ def test_fused_radiation_stage_in_place_through_two_tables_over_one_storage(ctx)
 
         def stage(U_new_ptr):
             c.check(c.L.qk_rad_stage_fused(s.lev.h, c.stream(), C.byref(s.rad_traits), order, 1, U.ptr, U.ptr, U_new_ptr, acc.ptr, None, float(dt),
-                                           _d3(s.geom.dx)), "qk_rad_stage_fused")
+                                           _d3(s.geom.dx), None), "qk_rad_stage_fused")
         stage(out.ptr)  # out of place: strips
         want = [out.valid(b).clone() for b in range(s.lev.nboxes)]
         alias = U.subset_ptr(list(range(s.lev.nboxes)))
@@ -493,3 +494,101 @@ def test_fused_radiation_stage_with_four_photon_groups(ctx, rad_order):
     new, old = a.state_new_cc_.valid(0).cpu().numpy(), a.state_old_cc_.valid(0).cpu().numpy()
     for g in range(ng):
         assert not np.array_equal(new[RAD0 + 4 * g], old[RAD0 + 4 * g])
+
+
+# ------------------------------------------------------------------ use_wavespeed_correction (ComputeCellOpticalDepth + S_corr on the even faces)
+def test_wavespeed_correction_factors_match_the_defining_formula(ctx):
+    """qk_rad_ComputeWavespeedCorrection (reference src/radiation/radiation_system.hpp:803-871, :1098-1109) on a rough gas state, constant flux-mean
+    opacity (tau = dl rho kappa: no libm): epsilon = min(1, 1 / harmonic mean of the two cells' optical depths) on the faces with i + j + k even, 1
+    on the others — every face of every direction equal in every bit to the same IEEE operations in numpy; both sides of tau = 1 occur."""
+    from quokka_amd.multifab import MultiFab
+    from quokka_amd.radhydro import _d3, _p3
+    s = shell_problem(ctx, 16, table(), max_grid_size=8, pow_mode=1)
+    rng = np.random.default_rng(5)
+    N, ng = 16, 4
+    # optical depths per cell between 0.01 and 100 (periodic box: the ghost-inclusive field is built by wrapping)
+    rho = 10.0 ** rng.uniform(-2.0, 2.0, (N + 2 * ng,) * 3) / (float(s.geom.dx[0]) * float(s.rad_traits.kappaF))
+    idx = (np.arange(-ng, N + ng)) % N
+    rho = rho[ng:-ng, ng:-ng, ng:-ng][np.ix_(idx, idx, idx)]
+    for b, (lo, hi) in enumerate(s.my_boxes):
+        U = s.state_new_cc_.fabs[b].cpu().numpy().copy()
+        sl = tuple(slice(lo[d], hi[d] + 1 + 2 * ng) for d in (2, 1, 0))
+        U[0] = rho[sl]
+        s.state_new_cc_.set_fab(b, U)
+    eps = [MultiFab(s.lev, 1, 0, facedir=d) for d in range(3)]
+    c = ctx
+    c.check(c.L.qk_rad_ComputeWavespeedCorrection(s.lev.h, c.stream(), C.byref(s.rad_traits), C.byref(s.traits), 3, s.state_new_cc_.ptr, _d3(s.geom.dx), _p3(eps)),
+            "qk_rad_ComputeWavespeedCorrection")
+    kappaF = float(s.rad_traits.kappaF)
+    assert int(s.rad_traits.opacity_model) == 0
+    below = above = 0
+    for d in range(3):
+        dl = float(s.geom.dx[d])
+        for b, (lo, hi) in enumerate(s.my_boxes):
+            got = eps[d].fabs[b][0].cpu().numpy()  # [k, j, i], nodal in d
+            n = [hi[a] - lo[a] + 1 + (1 if a == d else 0) for a in range(3)]
+            k, j, i = np.meshgrid(*(np.arange(lo[a], lo[a] + n[a]) for a in (2, 1, 0)), indexing="ij")
+            sh = [0, 0, 0]
+            sh[d] = 1
+            rR = rho[k + ng, j + ng, i + ng]
+            rL = rho[k + ng - sh[2], j + ng - sh[1], i + ng - sh[0]]
+            tL, tR = dl * rL * kappaF, dl * rR * kappaF
+            tau = (tL * tR * 2.0) / (tL + tR)
+            inv = 1.0 / tau
+            want = np.where((i + j + k) % 2 == 0, np.where(inv < 1.0, inv, 1.0), 1.0)
+            assert got.shape == want.shape and np.array_equal(got, want), (d, b)
+            below += int(((want < 1.0)).sum())
+            above += int(((want == 1.0) & ((i + j + k) % 2 == 0)).sum())
+    assert below > 100 and above > 100, (below, above)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_wavespeed_corrected_transport_matches_oracle_in_3d(ctx, oracle, fused):
+    """use_wavespeed_correction_ = true (reference src/QuokkaSimulation.hpp:133, :1958-1960) through the three flux kernels of a 3-D level — the fused
+    sweeps and the separate operators —: the shell at 16^3 in 8^3 boxes with the gas density roughened over four decades (cell optical depths on both
+    sides of 1), three coupled steps, every component bit for bit against the oracle's restatement; and the correction does change the answer."""
+    N = 16
+    finals = []
+    for corr in (True, False):
+        so, sg = make_pair(ctx, oracle, N, 8, 1)
+        rng = np.random.default_rng(9)
+        fac = 10.0 ** rng.uniform(-2.0, 2.0, (N, N, N))
+        for b in range(so.nboxes):
+            lo, hi = so.box(b)
+            U = so.state(b, 0).copy()
+            f = np.ones(U.shape[1:])
+            f[4:-4, 4:-4, 4:-4] = fac[lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1]
+            U[0:6] *= f  # (rho, momenta and energies together: velocities and temperature as before)
+            so.set_state(U, b, 0)
+            so.set_state(U, b, 1)
+        so.set_wavespeed_correction(corr)
+        sg.use_wavespeed_correction_ = corr
+        sg.use_fused_rad = fused
+        seed_from_oracle(so, sg)
+        for it in range(3):
+            assert so.step() and sg.step()
+            assert so.dt == sg.dt_, (it, so.dt, sg.dt_)
+        Uo = gather([so.box(b) for b in range(so.nboxes)], [so.valid(b) for b in range(so.nboxes)], N)
+        Ug = gather(sg.my_boxes, sg.gather_valid_local(), N)
+        assert not np.isnan(Ug).any()
+        assert np.array_equal(Uo, Ug), f"corr={corr}: rel L1 per component {rel_l1(Ug, Uo)}"
+        finals.append(Ug)
+    assert not np.array_equal(finals[0][6], finals[1][6]), "the correction changed nothing: the test state never reaches tau > 1 on an even face"
+
+
+def test_wavespeed_corrected_marshak_wave_matches_oracle(ctx, oracle):
+    """tests/MarshakAsymptoticCorr.in (marshak.use_wavespeed_correction = true): the temperature power-law opacity inside ComputeCellOpticalDepth
+    (`opacity_model = 2`, ~1e5 optical depths per cell: epsilon << 1 on every even face), 2500 steps bit for bit (pow_mode 1)."""
+    from oracle.pyoracle import MARSHAK_ASYMPTOTIC
+    from quokka_amd.radhydro import marshak_asymptotic_problem
+    so = oracle.sim(MARSHAK_ASYMPTOTIC, 1, [60, 1, 1], [0, 0, 0], [0.66, 1, 1], [0, 1, 1], max_grid_size=[60, 1, 1], rad_pow_mode=1)
+    sg = marshak_asymptotic_problem(ctx, 60, pow_mode=1)
+    so.set_wavespeed_correction(True)
+    sg.use_wavespeed_correction_ = True
+    ref = marshak_asymptotic_problem(ctx, 60, pow_mode=1)
+    for it in range(2500):
+        assert so.step() and sg.step() and ref.step()
+        assert so.dt == sg.dt_, (it, so.dt, sg.dt_)
+    U = sg.state_new_cc_.valid(0).cpu().numpy()
+    assert np.array_equal(so.valid(0), U)
+    assert not np.array_equal(U[6], ref.state_new_cc_.valid(0).cpu().numpy()[6])
