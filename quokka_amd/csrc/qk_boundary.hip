@@ -6,6 +6,7 @@
 // the wire order of a (sender, receiver) pair is (dst global box, src global box, shift) ascending on
 // both sides, so the caller only has to move `send_count` doubles with RCCL p2p.
 #include <algorithm>
+#include <cstdlib>
 #include <array>
 #include <map>
 #include <cstring>
@@ -317,6 +318,13 @@ int qk_ghost_plan_create(qk_level *lev, qk_ghost_plan **plan_out, const qk_geome
 		}
 	}
 
+	// QK_GHOST_LOOPBACK=1 (self-test of the production transport on ONE GPU): the pairs of this rank's own boxes are not items of the copy kernel
+	// but strips for a peer whose rank is this rank's own — packed, sent to and received from itself (RCCL copies a grouped self send / recv on the
+	// communication stream), unpacked: the stream ordering of pack -> send / recv -> unpack runs on hardware without a second GPU.
+	const bool loopback = [] {
+		const char *e = std::getenv("QK_GHOST_LOOPBACK");
+		return e != nullptr && std::atoi(e) != 0;
+	}();
 	std::map<int, PeerPlan> peers;
 	// canonical order: dst global box, src global box, shift
 	for (int gd = 0; gd < n_all; ++gd) {
@@ -348,7 +356,17 @@ int qk_ghost_plan_create(qk_level *lev, qk_ghost_plan **plan_out, const qk_geome
 				}
 				it.dst_box = local_of[gd];
 				it.src_box = local_of[gs];
-				if (dst_mine && src_mine) {
+				if (dst_mine && src_mine && loopback) {
+					PeerPlan &pp = peers[my_rank]; // the same strip in the same place of both buffers
+					pp.rank = my_rank;
+					it.offset = pp.recv_count;
+					pp.recv_count += regionCells(it) * ncomp;
+					pp.send_count = pp.recv_count;
+					pp.max_recv_cells = std::max<int64_t>(pp.max_recv_cells, regionCells(it));
+					pp.max_send_cells = pp.max_recv_cells;
+					pp.recv.push_back(it);
+					pp.send.push_back(it);
+				} else if (dst_mine && src_mine) {
 					P->local.push_back(it);
 					P->max_local_cells = std::max<int64_t>(P->max_local_cells, regionCells(it));
 				} else if (dst_mine) {

@@ -65,10 +65,19 @@ class Comm
 		// rendezvous names are unique per launch: the launcher's port and its process id (the parent of every rank)
 		char const *port = std::getenv("MASTER_PORT");
 		tag_ = std::string("qkcomm_") + ((port != nullptr) ? port : "0") + "_" + std::to_string(static_cast<long>(getppid()));
-		if (size <= 1) {
+		// QK_GHOST_LOOPBACK=1 on one rank (self-test of the production transport on ONE GPU): the ghost plan routes the pairs of this rank's own
+		// boxes through a peer that is this rank itself (csrc/qk_boundary.hip) and the 1-rank communicator below moves them with grouped
+		// ncclSend / ncclRecv to self on the communication stream
+		loopback_ = size <= 1 && envInt("QK_GHOST_LOOPBACK", 0) != 0;
+		if (size <= 1 && !loopback_) {
 			size = 1;
 			rank = 0;
 			return;
+		}
+		if (loopback_) {
+			size = 1;
+			rank = 0;
+			local_rank = 0;
 		}
 		char const *be = std::getenv("QK_COMM_BACKEND");
 		backend = (be != nullptr && std::string(be) == "shm") ? Backend::shm : Backend::rccl;
@@ -96,6 +105,9 @@ class Comm
 			if (rank == 0) {
 				std::remove(path.c_str());
 			}
+			if (loopback_) {
+				std::printf("qkhost::Comm: QK_GHOST_LOOPBACK — ghost strips of this rank's own boxes travel through ncclSend / ncclRecv to self\n");
+			}
 		} else {
 			hipCheck(hipSetDevice(local_rank % ndev), "hipSetDevice");
 		}
@@ -114,7 +126,7 @@ class Comm
 	// the data.
 	void exchangeEnd(hipStream_t compute)
 	{
-		if (size > 1 && backend == Backend::rccl && inFlight_) {
+		if (backend == Backend::rccl && inFlight_) {
 			hipCheck(hipStreamWaitEvent(compute, evDone_, 0), "hipStreamWaitEvent");
 		}
 		inFlight_ = false;
@@ -122,7 +134,7 @@ class Comm
 	void exchangeBegin(std::vector<int> const &peer, std::vector<void *> const &send, std::vector<int64_t> const &nsend, std::vector<void *> const &recv,
 		      std::vector<int64_t> const &nrecv, size_t elemBytes, hipStream_t compute)
 	{
-		if (size == 1) {
+		if (size == 1 && !loopback_) {
 			return;
 		}
 		if (backend == Backend::shm) {
@@ -285,6 +297,7 @@ class Comm
 
       private:
 	bool initialised_ = false;
+	bool loopback_ = false;
 	std::string tag_;
 	ncclComm_t nccl_ = nullptr;
 	hipStream_t stream_ = nullptr; // (non-blocking: amrex::DeviceArena asks for it — commStream() — before it lets a released block be reused)

@@ -123,3 +123,65 @@ def test_carried_rhs_mode_at_the_benchmarked_geometry(ctx):
     print(f"carried-rhs vs exact form, 256^3, 25 steps: worst relative L1 = {worst:.2e}")
     assert 0.0 < worst <= 1e-12
     assert b.counters["fofc1_stages"] + b.counters["fofc2_stages"] == 0
+
+
+def test_512_cubed_in_128_boxes_is_gated(ctx):
+    """512^3 in sixty-four 128^3 boxes: the size north_star states its roofline target on and the per-rank size of every N > 1 run of bench.py
+    (64 boxes per launch, 14 GB of scratch, component offsets past 2^31 doubles).  Three steps from the developed blast (a Mach-3 shell at 0.62 of
+    the box edge: limiters, flattening and every HLLC fan are active) —
+      * the exact form in 128^3 boxes == the same problem in eight 256^3 boxes, every cell in every bit (faces shared by two boxes are computed
+        twice from the same ghost-filled operands — the oracle's own invariant, tests/test_oracle_known_answers.py), same time steps;
+      * total energy conserved to the reference's HydroBlast3D criterion |dE/E| <= 2e-15 (reflecting walls; test_hydro3d_blast.cpp:181-199);
+      * the carried form of the RK2 average (bench.py's headline mode, primitive hand-off on) within 1e-12 relative L1 of the exact form;
+      * no first-order flux correction, no retry in any of the runs."""
+    import gc
+    from quokka_amd.simulation import developed_state, sedov_problem
+    N, nsteps = 512, 3
+
+    def run(mgs, carry):
+        sim = sedov_problem(ctx, N, max_grid_size=mgs)
+        sim.maxTimesteps_ = 10 ** 9
+        sim.rk2_carry_rhs = carry
+        for b, (lo, hi) in enumerate(sim.my_boxes):
+            sim.state_new_cc_.set_fab(b, developed_state(N, lo, hi))
+        sim._signal_of_state_new = None
+        assert sim.lev.nboxes == (N // mgs) ** 3
+        U = torch.empty((6, N, N, N), dtype=torch.float64, device=ctx.device)
+
+        def energy():
+            return sum(float(sim.state_new_cc_.valid(b)[4].sum(dtype=torch.float64).item()) for b in range(sim.lev.nboxes))
+
+        E0 = energy()
+        dts = []
+        for _ in range(nsteps):
+            assert sim.step()
+            dts.append(sim.dt_)
+        dE = abs(energy() - E0) / abs(E0)
+        for b, (lo, hi) in enumerate(sim.my_boxes):
+            U[:, lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1] = sim.state_new_cc_.valid(b)
+        counters = dict(sim.counters)
+        del sim
+        gc.collect()
+        torch.cuda.empty_cache()
+        return U, dts, dE, counters
+
+    A, dtA, dEA, cA = run(128, False)
+    assert bool(torch.isfinite(A).all())
+    assert cA["fofc1_stages"] + cA["fofc2_stages"] == 0 and cA["retries"] == 0, cA
+    assert dEA <= 2e-15, dEA
+    B, dtB, dEB, cB = run(256, False)
+    assert dtA == dtB, (dtA, dtB)
+    assert torch.equal(A, B), "512^3: 128^3 boxes and 256^3 boxes differ"
+    assert cB["fofc1_stages"] + cB["fofc2_stages"] == 0 and cB["retries"] == 0 and dEB <= 2e-15, (cB, dEB)
+    del B
+    torch.cuda.empty_cache()
+    Cc, dtC, dEC, cC = run(128, True)
+    assert cC["fofc1_stages"] + cC["fofc2_stages"] == 0 and cC["retries"] == 0 and cC.get("prim_handoff_dropped", 0) == 0, cC
+    assert all(abs(x - y) <= 1e-13 * x for x, y in zip(dtA, dtC)), (dtA, dtC)
+    worst = 0.0
+    for n in range(6):
+        num = float((A[n] - Cc[n]).abs().sum(dtype=torch.float64))
+        den = float(A[n].abs().sum(dtype=torch.float64))
+        worst = max(worst, num / max(den, 1e-300))
+    print(f"512^3, {nsteps} steps from the developed blast: |dE/E| exact {dEA:.1e} / 256^3 boxes {dEB:.1e} / carried {dEC:.1e}; carried vs exact worst relative L1 {worst:.2e}")
+    assert 0.0 < worst <= 1e-12 and dEC <= 2e-15, (worst, dEC)

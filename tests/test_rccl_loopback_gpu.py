@@ -1,0 +1,109 @@
+"""The production ghost-exchange transport on ONE GPU: RCCL point-to-point on device buffers, looped back.
+
+Every N > 1 run moves its ghost strips as pack kernel -> ncclSend / ncclRecv (one group per fill) -> unpack kernel, the RCCL work on a
+communication stream ordered against the compute stream (torch's ProcessGroupNCCL in the Python host, events in host/qk_comm.hpp).  A box with
+one GPU cannot hold two RCCL ranks, and the gloo / shm tests stage every buffer through the host: the stream ordering — the part that breaks —
+never ran on hardware.  QK_GHOST_LOOPBACK=1 makes the ghost plan route the pairs of a rank's OWN boxes (periodic images of a box included)
+through a peer that is the rank itself: a 1-rank communicator, grouped self send / recv on device buffers, the same kernels, streams and events
+as between two GPUs.  The result must equal the local-copy fill (reference src/simulation.hpp:1755 state.FillBoundary) in every bit."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "quokka_amd", "host")
+
+WORKER = r"""
+import os, sys, json
+import numpy as np, torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+from quokka_amd.multifab import Context
+from quokka_amd.simulation import sedov_problem
+from quokka_amd.radhydro import shell_problem
+ctx = Context(0)
+tab = np.loadtxt(os.path.join({root!r}, "tests", "golden", "dust_shell_initial_conditions.txt"), skiprows=1)
+
+def runs():
+    out = {{}}
+    s = sedov_problem(ctx, 64, max_grid_size=32)            # reflecting octant, 8 boxes: box-to-box strips + physical boundaries after the unpack
+    s.rk2_carry_rhs = True
+    for _ in range(6):
+        assert s.step()
+    out["sedov"] = (np.stack(s.gather_valid_local()), len(s.ghost.peers), s.ghost.peers[0][1] if s.ghost.peers else -1)
+    p = shell_problem(ctx, 32, (tab[:, 0], tab[:, 2], tab[:, 3]), max_grid_size=32, pow_mode=1)  # periodic, ONE box: only images of itself
+    for _ in range(2):
+        assert p.step()
+    out["shell_one_box"] = (np.stack(p.gather_valid_local()), len(p.ghost.peers), p.ghost.peers[0][1] if p.ghost.peers else -1)
+    q = shell_problem(ctx, 32, (tab[:, 0], tab[:, 2], tab[:, 3]), max_grid_size=16, pow_mode=1)  # periodic, 8 boxes, ~20 fills per step (radiation substeps)
+    for _ in range(2):
+        assert q.step()
+    out["shell"] = (np.stack(q.gather_valid_local()), len(q.ghost.peers), q.ghost.peers[0][1] if q.ghost.peers else -1)
+    return out
+
+plain = runs()
+assert all(v[1] == 0 for v in plain.values())
+os.environ["QK_GHOST_LOOPBACK"] = "1"
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT={port!r}, HSA_ENABLE_IPC_MODE_LEGACY="0")
+import torch.distributed as dist
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+looped = runs()
+torch.cuda.synchronize()
+res = {{}}
+for k in plain:
+    assert looped[k][1] == 1 and looped[k][2] == 0, (k, looped[k][1:])      # one peer: this rank
+    res[k] = bool(np.array_equal(plain[k][0], looped[k][0]))
+    assert not np.isnan(looped[k][0]).any()
+print("LOOPBACK", json.dumps({{"equal": res, "backend": dist.get_backend()}}))
+dist.destroy_process_group()
+"""
+
+
+def test_python_host_ghost_fill_through_rccl_to_self_equals_the_local_copies(tmp_path):
+    from test_multirank_one_gpu import free_port
+    script = tmp_path / "loop.py"
+    script.write_text(WORKER.format(root=ROOT, port=str(free_port())))
+    env = dict(os.environ)
+    env.pop("QK_GHOST_LOOPBACK", None)
+    p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("LOOPBACK")][-1]
+    import json
+    r = json.loads(line[len("LOOPBACK"):])
+    assert r["backend"] == "nccl" and all(r["equal"].values()), r
+
+
+def _run_exe(name, args, tmp_path, tag, loopback):
+    dump = str(tmp_path / f"{tag}.bin")
+    env = dict(os.environ)
+    env.pop("QK_GHOST_LOOPBACK", None)
+    if loopback:
+        env["QK_GHOST_LOOPBACK"] = "1"
+    p = subprocess.run([os.path.join(HOST, "bin", name)] + args + [f"qk.dump_state={dump}"], capture_output=True, text=True, timeout=900, env=env,
+                       cwd=str(tmp_path))
+    # (the exit status is the problem's own verdict on its END state — HydroBlast3D compares with the Sedov solution —, not asked for after a dozen steps)
+    assert "Performance figure-of-merit" in p.stdout and os.path.exists(dump), p.stdout[-2000:] + p.stderr[-2000:]
+    assert ("ncclSend / ncclRecv to self" in p.stdout) == bool(loopback)
+    return np.fromfile(dump, dtype=np.float64), open(dump + ".meta").read().split()
+
+
+@pytest.mark.parametrize("case", ["sedov", "shell"])
+def test_cxx_host_ghost_fill_through_rccl_to_self_equals_the_local_copies(tmp_path, case):
+    """host/qk_comm.hpp: ncclSend / ncclRecv to self in one group on the library-owned non-blocking stream, ordered against the compute stream by
+    events (exchangeBegin / exchangeEnd) — the reference's unchanged problem files, with and without the loop-back."""
+    import shutil
+    if case == "sedov":  # reflecting octant: 8 boxes of 32^3
+        name = "ref_HydroBlast3D"
+        args = [os.path.join(HOST, "decks", "blast_unigrid_256.in"), "amr.n_cell=64 64 64", "amr.max_grid_size=32", "amr.blocking_factor=32", "max_timesteps=12",
+                "hydro.rk2_carry_rhs=1"]
+    else:  # periodic box: 8 boxes of 16^3, radiation substeps (component-restricted local fills beside full-state strips)
+        name = "ref_RadhydroShell"
+        args = [os.path.join(HOST, "decks", "radhydro_shell_256.in"), "amr.n_cell=32 32 32", "amr.max_grid_size=16", "max_timesteps=3"]
+        shutil.copy(os.path.join(ROOT, "tests", "golden", "dust_shell_initial_conditions.txt"), tmp_path / "initial_conditions.txt")
+    a, ma = _run_exe(name, args, tmp_path, "plain", False)
+    b, mb = _run_exe(name, args, tmp_path, "loop", True)
+    assert ma[0] == mb[0] and ma[1] == mb[1], (ma, mb)
+    assert a.size == b.size and a.size > 0 and np.array_equal(a, b)
