@@ -36,8 +36,16 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 # algorithmic bytes per cell-sweep of the fused PPM+HLLC sweep kernels and of the flattening pre-pass
-ALG_BYTES = {"k_sweep_x": 128.0, "k_sweep_y": 184.0, "k_sweep_z": 184.0}
-DOMINANT_KERNEL = "k_sweep_z"  # the Z sweep + epilogue: the longest kernel of a stage in every line since round 1 (checked against the full table below)
+# k_sweep_xy (round 6): the X sweep folded into the Y march — ONE kernel does the work of §8(d)'s x row (128 B) and y row (184 B); by this design's own
+# count it has to move 136 B per cell (state 48 + chi, D_x, D_y, D_z 32 + accumulator out 56), reported beside the §8(d) figure
+ALG_BYTES = {"k_sweep_x": 128.0, "k_sweep_y": 184.0, "k_sweep_z": 184.0, "k_sweep_xy": 312.0}
+ALG_BYTES_THIS_DESIGN = {"k_sweep_xy": 136.0, "k_sweep_z": 232.0, "k_sweep_y": 184.0, "k_sweep_x": 128.0}
+
+
+def dominant_kernel(carry: bool) -> str:
+    """the longest kernel of a stage, timed by HIP events inside the measured region (checked against the full table of the separate pass): the fused
+    X + Y sweep where it runs (carried form, no passive scalars, boxes a multiple of 64 cells wide, QK_FUSEX != 0), else the Z sweep + epilogue"""
+    return "k_sweep_xy" if (carry and os.environ.get("QK_FUSEX", "1") != "0") else "k_sweep_z"
 ALG_BYTES_PRE = 72.0
 ALG_BYTES_STEP = 1496.0
 FP64_VALU_PEAK = 256 * 64 * 2.4e9  # FP64 vector lane-instructions per second without FMA contraction (256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz)
@@ -167,8 +175,10 @@ def kernel_key(name: str):
     """bench.py's name of a fused-stage kernel from its rocprofv3 display name"""
     if "k_sweep_x" in name:
         return "k_sweep_x"
-    m = re.search(r"k_sweep_march<(\d)", name)
+    m = re.search(r"k_sweep_march<(\d)([^>]*)>", name)
     if m:
+        if m.group(1) == "1" and m.group(2).replace(" ", "").endswith(",true") and m.group(2).count(",") >= 8:
+            return "k_sweep_xy"  # (the ninth template argument, FUSEX)
         return {"1": "k_sweep_y", "2": "k_sweep_z"}.get(m.group(1))
     if "k_pre" in name:
         return "k_pre"
@@ -638,7 +648,7 @@ def run_sedov(ctx, torch, dist, rank, world, ncell, mgs, steps, warmup, profile=
         # HIP events on the launch stream around the DOMINANT kernel only (two event records per timed launch cost ~6 us of GPU time: with all 14
         # launches of a step timed, the events themselves were 1.5 % of the step); the other kernels are timed in a separate pass (main: repeats)
         L.qk_profile_reset(ctx.h)
-        L.qk_profile_only(ctx.h, DOMINANT_KERNEL.encode() if profile is True else None)  # (profile="all": every kernel — the secondary blocks)
+        L.qk_profile_only(ctx.h, dominant_kernel(bool(carry)).encode() if profile is True else None)  # (profile="all": every kernel — the secondary blocks)
         L.qk_profile_enable(ctx.h, 1)
     if world > 1:
         sim.ghost.exposed_events = []  # (two event records per fill: how long the compute stream stalls for the peers' strips)
@@ -685,7 +695,7 @@ def roofline_of(kernels, cells_local, total_cells, steps, elapsed, world, ncell,
         for k, alg in ALG_BYTES.items():
             if k in ks and ks[k][0] > 0:
                 avg_s = ks[k][1] / ks[k][0] * 1e-3
-                out[k] = {"alg_bytes_per_cell": alg, "avg_launch_ms": avg_s * 1e3, "launches": ks[k][0],
+                out[k] = {"alg_bytes_per_cell": alg, "alg_bytes_per_cell_this_design": ALG_BYTES_THIS_DESIGN.get(k), "avg_launch_ms": avg_s * 1e3, "launches": ks[k][0],
                           "achieved_GBs": alg * cells_local / avg_s / 1e9, "frac": alg * cells_local / avg_s / 1e9 / HBM_PEAK_GBS}
         return out
     timed = table(kernels)

@@ -85,6 +85,7 @@ struct SweepArgs {
 	double *max_signal; // optional double[2], see qk_hydro_stage_args::d_max_signal
 	double inv_dx; // 1/dx of the sweep direction
 	double dx;
+	double inv_dx0, dx0; // the x spacing (the Y sweep that carries the X sweep: FUSEX)
 	double dx3[3]; // (FOFC pass: the cell-centred velocity divergence of a flagged cell)
 	double dt;
 	double densityFloor, tempFloor;
@@ -965,9 +966,26 @@ template <int ORDER, int STAGE, int NS, bool CARRY, int NDIM = 3, bool FOFC = fa
 #endif
 constexpr int MARCH_BY = QK_MARCH_BY; // rows of the other transverse axis per workgroup (64 x MARCH_BY threads)
 // TWOD: the y sweep of an AMREX_SPACEDIM == 2 build — the X2 view is the index swap of ArrayView_2d.hpp (view-j = x, view-k = z), and it is the last sweep
-template <int DIR, int ORDER, int STAGE, bool LAST, int NS, bool CARRY, bool TWOD = false, bool FOFC = false>
+// FUSEX (the Y sweep of a 3-D level, carried form without flux mask): the X sweep folded into the march.  The lanes of a wave run along x and hold the
+// primitives of their cells of the row the step completes: the +-2 stencil of the reconstruction, the edge state of the left neighbour and the flux of
+// the right face are in the neighbouring lanes and travel through a few hundred bytes of wave-private LDS (no barrier: a wave's LDS operations
+// are executed in order; the fences only keep the compiler from moving a read above the write it depends on).  The X flux divergence starts the
+// accumulator in registers: no X launch, no 72 + 56 B per cell read and written by it, no 56 B read back by Y.
+constexpr int XW = 64 + 8; // slots of a row buffer: 64 cells + 2 halo cells either side (+ padding)
+#ifndef QK_XROWS
+#define QK_XROWS 16
+#endif
+constexpr int XROWS = QK_XROWS; // rows per batch of wave-edge faces (2 * XROWS lanes of the wave work in a batch pass)
+static_assert(XROWS == 8 || XROWS == 16 || XROWS == 32, "the batch maps rows and sides onto the lanes of one wave");
+QK_DEV void waveFence()
+{
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+}
+template <int DIR, int ORDER, int STAGE, bool LAST, int NS, bool CARRY, bool TWOD = false, bool FOFC = false, bool FUSEX = false>
 __global__ void __launch_bounds__(64 * MARCH_BY) k_sweep_march(SweepArgs a, Eos eos)
 {
+	static_assert(!FUSEX || (DIR == 1 && !LAST && !TWOD && !FOFC && CARRY), "the X sweep rides on the Y sweep of a 3-D level in the carried form");
 	static_assert(!(FOFC && CARRY), "the first-order flux correction pass exists for the reference's form of the RK2 average");
 	static_assert(!TWOD || (DIR == 1 && LAST), "the 2-D build has one marching sweep: y, carrying the epilogue");
 	constexpr int NV = NVAR + NS; // hydro variables + passive scalars
@@ -1034,6 +1052,30 @@ __global__ void __launch_bounds__(64 * MARCH_BY) k_sweep_march(SweepArgs a, Eos 
 	}
 	constexpr bool RING = LAST && (STAGE == 1);
 	__shared__ double s_ring[RING ? 3 : 1][RING ? NV : 1][RING ? 64 * MARCH_BY : 1];
+	__shared__ double s_fx[FUSEX ? MARCH_BY : 1][FUSEX ? NV + 2 : 1][FUSEX ? XW : 1];
+	// FUSEX, the two faces of a row a wave cannot form from its own lanes (64 cells have 65 faces, and the edge state left of lane 0 belongs to a cell
+	// outside the wave): formed 32 rows at a time — lanes 0..31 the left faces, 32..63 the right faces of the next 32 rows — and parked here with
+	// the primitives of the two cells beyond either end of the row, which the reconstruction of the end lanes reads
+	// entries of a row: 0, 1 the cells x0 - 2, x0 - 1; 2, 3 the cells x0 + 64, x0 + 65; 4 the right face (x0 + 64); 5 the left face (x0).  A row's entries are
+	// copied into six spare slots of the wave's row buffer one step ahead (stageEdgeRow), off the dependency chain of the step that reads them.
+	__shared__ double s_edge[FUSEX ? MARCH_BY : 1][FUSEX ? XROWS : 1][6][FUSEX ? NV + 1 : 1];
+	double chiPrev = 1.;
+	const int lself = (FUSEX && threadIdx.x == 0) ? 69 : static_cast<int>(threadIdx.x) + 2;
+	const int lnext = (FUSEX && threadIdx.x == 63) ? 68 : static_cast<int>(threadIdx.x) + 3;
+	// lanes 0..5 copy entry `lane` of row r of the batch into slots 0, 1, 66, 67 (halo cells), 68 (right face), 69 (left face) of the wave's row buffer
+	auto stageEdgeRow = [&](int r) {
+		if constexpr (FUSEX) {
+			const int t6 = static_cast<int>(threadIdx.x);
+			if (t6 < 6) {
+				const int slot = (t6 < 2) ? t6 : 64 + t6;
+				const double *src = s_edge[threadIdx.y][r][t6];
+#pragma unroll
+				for (int n = 0; n < NV + 1; ++n) {
+					s_fx[threadIdx.y][n][slot] = src[n];
+				}
+			}
+		}
+	};
 	const int tid = threadIdx.y * 64 + threadIdx.x;
 	const bool ring = RING && a.same_old;
 	int slot = 0;
@@ -1104,9 +1146,137 @@ __global__ void __launch_bounds__(64 * MARCH_BY) k_sweep_march(SweepArgs a, Eos 
 		fidx[DIR] = lo + (step - 5);
 		if (step >= 6) {
 			const int64_t cu = cc - ms;
+			if constexpr (FUSEX) {
+				// the X sweep of the row this step completes (cell cu = cc - 1: primitives q[1], chi of the step before, D_z = dVprev)
+				double(*sx)[XW] = s_fx[threadIdx.y];
+				const int tx = static_cast<int>(threadIdx.x);
+				const int l = tx + 2;
+				const int rr = (step - 6) & (XROWS - 1);
+				if (rr == 0) { // (uniform) the wave-edge faces and halo primitives of the next XROWS rows
+					const int side = (tx / XROWS) & 1; // (lanes beyond 2 * XROWS repeat the work of the first ones: same values to the same slots)
+					const int brow = tx & (XROWS - 1);
+					const int mrow = min(lo + (step - 6) + brow, hi);
+					const int f = bx.lo[0] + bix * 64 + 64 * side; // the face: between cells f - 1 and f
+					int64_t ub = Uin.idx(f - 3, mrow, ot);
+					double qb[6][NV];
+#pragma unroll
+					for (int m = 0; m < 6; ++m, ++ub) {
+						double Uc[NVAR];
+#pragma unroll
+						for (int n = 0; n < NVAR; ++n) {
+							Uc[n] = Uin.p[ub + Uin.ns * n];
+						}
+						if (a.prim_in) {
+#pragma unroll
+							for (int n = 0; n < NVAR; ++n) {
+								qb[m][n] = Uc[n];
+							}
+						} else {
+							consToPrim(eos, a.reconstruct_eint, Uc, qb[m]);
+						}
+#pragma unroll
+						for (int n = NVAR; n < NV; ++n) {
+							qb[m][n] = Uin.p[ub + Uin.ns * n];
+						}
+					}
+					const int64_t cb = (f - 1 - g.glo[0]) + (mrow - g.glo[1]) * st[1] + (ot - g.glo[2]) * st[2];
+					const double chiL = S[cb], chiR = S[cb + 1];
+					const double DyL = S[(S_AUX + 2) * T + cb], DyR = S[(S_AUX + 2) * T + cb + 1];
+					const double DzL = S[(S_AUX + 3) * T + cb], DzR = S[(S_AUX + 3) * T + cb + 1];
+					double qLb[NV], qRb[NV], Fb[NV], vfb;
+#pragma unroll
+					for (int n = 0; n < NV; ++n) {
+						double am_, ap_;
+						cellEdges<ORDER>(qb[0][n], qb[1][n], qb[2][n], qb[3][n], qb[4][n], am_, ap_);
+						flattenEdges(chiL, qb[2][n], am_, ap_);
+						qLb[n] = ap_;
+						cellEdges<ORDER>(qb[1][n], qb[2][n], qb[3][n], qb[4][n], qb[5][n], am_, ap_);
+						flattenEdges(chiR, qb[3][n], am_, ap_);
+						qRb[n] = am_;
+					}
+					{
+						Wave wv;
+						faceFlux<0, QK_RIEMANN_HLLC>(eos, a.reconstruct_eint, 3, qLb, qRb, qb[3][PVX] - qb[2][PVX], DyL, DyR, DzL, DzR, a.K_visc, Fb, vfb,
+									     NS > 0 ? &wv : nullptr);
+#pragma unroll
+						for (int n = NVAR; n < NV; ++n) {
+							Fb[n] = scalarFlux<QK_RIEMANN_HLLC>(wv, qLb[n], qRb[n]);
+						}
+					}
+					double(*ed)[NV + 1] = s_edge[threadIdx.y][brow];
+					double *ef = ed[5 - side];
+#pragma unroll
+					for (int n = 0; n < NV; ++n) {
+						ef[n] = Fb[n];
+					}
+					ef[NV] = vfb;
+					// halo cells of the row: x0 - 2, x0 - 1 (left face: cells f - 2, f - 1) and x0 + 64, x0 + 65 (right face: cells f, f + 1)
+#pragma unroll
+					for (int n = 0; n < NV; ++n) {
+						ed[2 * side][n] = (side != 0) ? qb[3][n] : qb[1][n];
+						ed[2 * side + 1][n] = (side != 0) ? qb[4][n] : qb[2][n];
+					}
+					waveFence();
+					stageEdgeRow(0);
+				}
+				const double Dy = S[(S_AUX + 2) * T + cu];
+#pragma unroll
+				for (int n = 0; n < NV; ++n) {
+					sx[n][l] = q[1][n];
+				}
+				waveFence();
+				double amx[NV], apx[NV];
+#pragma unroll
+				for (int n = 0; n < NV; ++n) {
+					cellEdges<ORDER>(sx[n][l - 2], sx[n][l - 1], q[1][n], sx[n][l + 1], sx[n][l + 2], amx[n], apx[n]);
+					flattenEdges(chiPrev, q[1][n], amx[n], apx[n]);
+				}
+				const double uLeft = sx[PVX][l - 1];
+				waveFence();
+#pragma unroll
+				for (int n = 0; n < NV; ++n) {
+					sx[n][l] = apx[n];
+				}
+				sx[NV][l] = Dy;
+				sx[NV + 1][l] = dVprev;
+				waveFence();
+				double qLx[NV], Fx[NV], vfx;
+#pragma unroll
+				for (int n = 0; n < NV; ++n) {
+					qLx[n] = sx[n][l - 1];
+				}
+				const double dvl = sx[NV][l - 1], dwl = sx[NV + 1][l - 1];
+				{
+					Wave wv;
+					faceFlux<0, QK_RIEMANN_HLLC>(eos, a.reconstruct_eint, 3, qLx, amx, q[1][PVX] - uLeft, dvl, Dy, dwl, dVprev, a.K_visc, Fx, vfx, NS > 0 ? &wv : nullptr);
+#pragma unroll
+					for (int n = NVAR; n < NV; ++n) {
+						Fx[n] = scalarFlux<QK_RIEMANN_HLLC>(wv, qLx[n], amx[n]);
+					}
+				}
+				waveFence();
+#pragma unroll
+				for (int n = 0; n < NV; ++n) {
+					sx[n][l] = Fx[n];
+				}
+				sx[NV][l] = vfx;
+				waveFence();
+				// every lane reads the fluxes of its two faces back: its own slot and its right neighbour's — but lane 0 its left face from slot 69 and
+				// lane 63 its right face from slot 68, where the batch's faces were staged a step ago (no branch, no select on 64-bit values)
+#pragma unroll
+				for (int n = 0; n < NV; ++n) {
+					rhs_in[n] = a.inv_dx0 * (sx[n][lself] - sx[n][lnext]); // hydro_system.hpp:469
+				}
+				rhs_in[NV] = (sx[NV][lnext] - sx[NV][lself]) / a.dx0; // :803
+				waveFence();
+				if (rr + 1 < XROWS) {
+					stageEdgeRow(rr + 1);
+				}
+			} else {
 #pragma unroll
 			for (int n = 0; n < NV + 1; ++n) {
 				rhs_in[n] = streamLoad(&S[(S_RHS + n) * T + cu]);
+			}
 			}
 			if (LAST && !ring && !(CARRY && STAGE == 2)) { // the old state of the cell this step completes (stage 2 of the carried form: S replaces it)
 				int uc[3];
@@ -1268,6 +1438,7 @@ __global__ void __launch_bounds__(64 * MARCH_BY) k_sweep_march(SweepArgs a, Eos 
 		}
 		dVprev = dV;
 		dWprev = dW;
+		chiPrev = chi;
 	}
 	if (LAST && a.max_signal != nullptr) {
 		// wave reduction (64 lanes), one atomic per wave; max is exact, so the result is deterministic
@@ -1369,8 +1540,18 @@ auto buildGeom(qk_level *lev) -> int
 
 template <int ORDER, int STAGE, int NS, bool CARRY, bool FOFC = false> void launchSweeps(qk_level *lev, hipStream_t s, SweepArgs a, Eos eos, const qk_hydro_stage_args *args)
 {
+	// the X sweep inside the Y sweep (FUSEX): 3-D, carried form without a flux mask, every box a whole number of 64-cell waves wide
+	bool fusex = false;
+	if constexpr (CARRY && !FOFC && NS == 0) { // (with passive scalars the fused kernel needs more than 256 registers: one wave per SIMD)
+		const char *e = std::getenv("QK_FUSEX"); // (read per launch: tests and A/B runs switch it inside one process)
+		const int want = (e != nullptr) ? std::atoi(e) : 1;
+		fusex = want != 0 && lev->ndim == 3 && a.fluxMask == nullptr;
+		for (int b = 0; fusex && b < lev->nboxes; ++b) {
+			fusex = (lev->boxes[b].hi[0] - lev->boxes[b].lo[0] + 1) % 64 == 0;
+		}
+	}
 	// X
-	{
+	if (!fusex) {
 		SweepArgs ax = a;
 		ax.halfFlux = args->halfFlux[0];
 		ax.halfVel = args->halfVel[0];
@@ -1418,9 +1599,19 @@ template <int ORDER, int STAGE, int NS, bool CARRY, bool FOFC = false> void laun
 		ay.inv_dx = 1.0 / args->dx[1];
 		ay.dx = args->dx[1];
 		ay.nseg = marchSegments(lev, 1, 2);
+		ay.inv_dx0 = 1.0 / args->dx[0];
+		ay.dx0 = args->dx[0];
 		const dim3 grid((lev->maxlen[0] + 63) / 64, (lev->maxlen[2] + MARCH_BY - 1) / MARCH_BY, lev->nboxes * ay.nseg);
-		ProfScope ps(lev->ctx, s, "k_sweep_y");
-		hipLaunchKernelGGL((k_sweep_march<1, ORDER, STAGE, false, NS, CARRY, false, FOFC>), grid, dim3(64, MARCH_BY), 0, s, ay, eos);
+		if constexpr (CARRY && !FOFC && NS == 0) {
+			if (fusex) {
+				ProfScope ps(lev->ctx, s, "k_sweep_xy");
+				hipLaunchKernelGGL((k_sweep_march<1, ORDER, STAGE, false, NS, CARRY, false, FOFC, true>), grid, dim3(64, MARCH_BY), 0, s, ay, eos);
+			}
+		}
+		if (!fusex) {
+			ProfScope ps(lev->ctx, s, "k_sweep_y");
+			hipLaunchKernelGGL((k_sweep_march<1, ORDER, STAGE, false, NS, CARRY, false, FOFC>), grid, dim3(64, MARCH_BY), 0, s, ay, eos);
+		}
 	}
 	// Z (+ epilogue)
 	{

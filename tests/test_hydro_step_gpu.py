@@ -587,3 +587,35 @@ def test_primitive_handoff_between_the_stages_changes_no_bit(ctx, oracle):
         assert a.dt_ == b.dt_
     assert np.array_equal(gather_gpu(a, N), gather_gpu(b, N))
     assert b.counters.get("prim_handoff_dropped", 0) == 0
+
+
+# ------------------------------------------------------------------ the X sweep folded into the Y march (FUSEX)
+@pytest.mark.parametrize("N,mgs,handoff", [(128, 64, True), (128, 128, True), (128, 128, False), (64, 64, True)])
+def test_x_sweep_inside_the_y_march_changes_no_bit(ctx, N, mgs, handoff):
+    """k_sweep_march<Y, ..., FUSEX>: the X sweep of a row is formed inside the Y march from the neighbouring lanes (wave-private LDS), the two
+    faces a wave cannot form from its own 64 lanes come from a batch pass every 32 rows — the X launch, its 128 B per cell and the 56 B per
+    cell Y used to read back are gone.  Same device functions on the same operands: the carried form with QK_FUSEX=1 equals QK_FUSEX=0 in
+    every bit — from the developed blast (every limiter and HLLC fan active), boxes one and two waves wide, a single box marched in several
+    segments, with and without the primitive hand-off; six steps."""
+    import os
+    from quokka_amd.simulation import developed_state, sedov_problem
+    finals = []
+    try:
+        for fusex in ("0", "1"):
+            os.environ["QK_FUSEX"] = fusex
+            s = sedov_problem(ctx, N, max_grid_size=mgs)
+            s.rk2_carry_rhs = True
+            s.prim_handoff = handoff
+            for b, (lo, hi) in enumerate(s.my_boxes):
+                s.state_new_cc_.set_fab(b, developed_state(N, lo, hi))
+            s._signal_of_state_new = None
+            dts = []
+            for _ in range(6):
+                assert s.step()
+                dts.append(s.dt_)
+            assert s.counters["fofc1_stages"] + s.counters["fofc2_stages"] == 0
+            finals.append((gather_gpu(s, N), dts))
+    finally:
+        os.environ.pop("QK_FUSEX", None)
+    assert finals[0][1] == finals[1][1]
+    assert np.array_equal(finals[0][0], finals[1][0])
