@@ -397,6 +397,60 @@ def full_run_block(args):
     return out
 
 
+class ClockSampler:
+    """shader clock (and board power) of the GPU this process runs on, read from the amdgpu hwmon files of its PCI device every few milliseconds
+    while a timed block runs — by a separate PROCESS (a shell loop: a Python thread would take the interpreter lock from the launch loop it
+    observes; measured: 5.13 -> 5.45 ms per step).  A MEASUREMENT of what round 5 inferred from SQ_BUSY_CYCLES per microsecond.  None where the
+    files are missing."""
+
+    def __init__(self, torch, device_index=0):
+        self.files, self.proc, self.out = None, None, None
+        try:
+            p = torch.cuda.get_device_properties(device_index)
+            self.bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+            hw = glob.glob(f"/sys/bus/pci/devices/{self.bdf}/hwmon/hwmon*")
+            if hw and os.path.exists(os.path.join(hw[0], "freq1_input")):
+                self.files = (os.path.join(hw[0], "freq1_input"), os.path.join(hw[0], "power1_input"))
+        except Exception:  # noqa: BLE001
+            self.files = None
+
+    def __enter__(self):
+        import subprocess
+        import tempfile
+        if self.files is not None:
+            self.out = tempfile.NamedTemporaryFile(prefix="qk_clock_", suffix=".txt", delete=False)
+            loop = f'while :; do read f < {self.files[0]}; read p < {self.files[1]} 2>/dev/null || p=0; echo "$f $p"; sleep 0.004; done'
+            self.proc = subprocess.Popen(["bash", "-c", loop], stdout=self.out, stderr=subprocess.DEVNULL)
+        return self
+
+    def __exit__(self, *exc):
+        if self.proc is not None:
+            self.proc.kill()
+            self.proc.wait()
+            self.proc = None
+
+    def summary(self):
+        if self.out is None:
+            return None
+        self.out.close()
+        mhz, watts = [], []
+        for line in open(self.out.name):
+            w = line.split()
+            if len(w) == 2 and w[0].isdigit():
+                mhz.append(int(w[0]) / 1e6)
+                if w[1].isdigit() and int(w[1]) > 0:
+                    watts.append(int(w[1]) / 1e6)
+        os.unlink(self.out.name)
+        if not mhz:
+            return None
+        m = sorted(mhz)
+        out = {"sclk_mhz_mean": sum(m) / len(m), "sclk_mhz_min": m[0], "sclk_mhz_median": m[len(m) // 2], "sclk_mhz_max": m[-1], "samples": len(m),
+               "source": f"/sys/bus/pci/devices/{self.bdf}/hwmon/*/freq1_input, a shell loop in its own process during the timed steps"}
+        if watts:
+            out["power_w_mean"] = sum(watts) / len(watts)
+        return out
+
+
 def developed_block(ctx, torch, ncell, mgs, steps, warmup, carry):
     """Sedov geometry started from a DEVELOPED blast (quokka_amd.simulation.developed_state: a Mach-3 shell at 0.62 of the box edge, hot
     interior, rippled — the state tests/test_bench_geometry_gpu.py pins to the oracle bit for bit): every limiter / flattening / HLLC-fan branch
@@ -414,15 +468,18 @@ def developed_block(ctx, torch, ncell, mgs, steps, warmup, carry):
     L.qk_profile_reset(ctx.h)
     L.qk_profile_enable(ctx.h, 1)
     torch.cuda.synchronize()
+    clk = ClockSampler(torch)
     t0 = time.perf_counter()
-    for _ in range(steps):
-        assert sim.step(), "hydro advance failed"
-    torch.cuda.synchronize()
+    with clk:
+        for _ in range(steps):
+            assert sim.step(), "hydro advance failed"
+        torch.cuda.synchronize()
     el = time.perf_counter() - t0
     L.qk_profile_enable(ctx.h, 0)
     k = read_profile(ctx)
     rho = torch.cat([sim.state_new_cc_.valid(b)[0].reshape(-1) for b in range(sim.lev.nboxes)])
     return {"value": ncell ** 3 * steps / el / 1e6, "unit": "Mcell-updates/s", "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3,
+            "clock": clk.summary(),
             "rk2_mode": "carry" if carry else "exact", "fofc_stages": sim.counters["fofc1_stages"] + sim.counters["fofc2_stages"],
             "retries": sim.counters["retries"], "sim_time": sim.tNew_, "density_min_max": [float(rho.min().item()), float(rho.max().item())],
             "kernels_ms_per_launch": {n: v[1] / max(v[0], 1) for n, v in sorted(k.items())},
@@ -653,11 +710,14 @@ def run_sedov(ctx, torch, dist, rank, world, ncell, mgs, steps, warmup, profile=
     if world > 1:
         sim.ghost.exposed_events = []  # (two event records per fill: how long the compute stream stalls for the peers' strips)
     barrier()
+    clk = ClockSampler(torch, ctx.device.index if hasattr(ctx.device, "index") and ctx.device.index is not None else 0)
     t0 = time.perf_counter()
-    for _ in range(steps):
-        assert sim.step(), "hydro advance failed"
-    barrier()
+    with clk:
+        for _ in range(steps):
+            assert sim.step(), "hydro advance failed"
+        barrier()
     elapsed = time.perf_counter() - t0
+    sim.clock_during_timed_steps = clk.summary()
     if profile:
         L.qk_profile_enable(ctx.h, 0)
         L.qk_profile_only(ctx.h, None)
@@ -852,6 +912,8 @@ def main():
                                             "them (qk_hydro_stage_args::prim_out / prim_in): same bytes, same bits, 4.9 conversions per cell less"},
                    "fofc_stages": sim.counters["fofc1_stages"] + sim.counters["fofc2_stages"], "retries": sim.counters["retries"],
                    "sim_time": sim.tNew_,
+                   "x_sweep_in_y_march": os.environ.get("QK_FUSEX", "1") != "0" and args.rk2_mode == "carry" and mgs % 64 == 0,
+                   "clock": getattr(sim, "clock_during_timed_steps", None),
                    "note": "N = 1 runs BASELINE config 2 (256^3); N > 1 runs 512^3 cells per GPU (N = 8: config 3, 1024^3); "
                            "weak_256_per_gpu is the same geometry as N = 1 on every rank"},
         "roofline": None,  # (filled below, after the pass that times every kernel)

@@ -355,7 +355,10 @@ template <bool TDEP, class RadT> QK_DEV auto dustTemperatureBateKeto(RadT const 
 // (gamma law or the T^4 material); a problem's translation unit instantiates the same function with objects whose members call the problem's
 // compiled ComputePlanckOpacity / ComputeEnergyMeanOpacity / ComputeFluxMeanOpacity / ComputeThermalRadiation* / quokka::EOS hooks
 // (quokka_amd/host/qk_problem_kernels.hpp) — radiation_system.hpp:1141-1154, EOS.hpp:74-244.
-template <bool TDEP = false, bool DUST = false, class RadT = Rad, class EosT = EosCell>
+// BETA: RadSystem_Traits::beta_order as a compile-time constant (0 or 1; -1: read from the traits at run time) — what the reference's kernel sees,
+// whose beta_order is a constexpr of the problem.  The Lorentz factors are then the literal 1.0 (x * 1.0 is x: same bits) and the std::pow / 3 x 3
+// solve of the beta_order >= 2 branches leave the kernel.
+template <bool TDEP = false, bool DUST = false, class RadT = Rad, class EosT = EosCell, int BETA = -1>
 QK_DEV void radSourceCell(RadT const &r, Eos const &eos, double U[10], double srcval, double dt_radiation, int stage, int &n_newton_total, int &n_newton_max,
 			  int &n_solves, int &fail_newton, int &fail_outer, int *fail_dust = nullptr)
 {
@@ -373,7 +376,7 @@ QK_DEV void radSourceCell(RadT const &r, Eos const &eos, double U[10], double sr
 	const double Src = srcval * dt * chat;
 	const double Frad_t0[3] = {U[RAD0 + 1], U[RAD0 + 2], U[RAD0 + 3]};
 	const bool gamma_ne_1 = !eos.isothermal;
-	const int beta_order = r.beta_order;
+	const int beta_order = (BETA >= 0) ? BETA : r.beta_order;
 
 	double Egas0 = __builtin_nan(""), Ekin0 = __builtin_nan(""), Etot0 = __builtin_nan(""), Egas_guess = __builtin_nan("");
 	double T_gas = __builtin_nan(""), T_d = __builtin_nan("");

@@ -149,10 +149,18 @@ template <class P> QK_DEV auto srcStreamLoad(P *p) -> double
 }
 
 // RadT / EosT as in radSourceCell: Rad + EosCell inside the library (closed hook sets), the problem's compiled hooks in a problem's translation unit
-template <bool TDEP, bool DUST = false, class RadT = Rad, class EosT = EosCell>
+template <bool TDEP, bool DUST = false, class RadT = Rad, class EosT = EosCell, int BETA = -1>
 static auto radSourceImpl(qk_level *lev, qk_stream s, const qk_rad_traits *rt, const qk_hydro_traits *t, qk_array4 *cons_t, const qk_array4 *src_t, double dt,
 			  int stage, int *d_iteration_counter, int *d_failure_counter, qk_array4 *mirror_t = nullptr) -> int
 {
+	if constexpr (BETA < 0 && !DUST) { // beta_order 1 (and 0): an instantiation of its own, as the reference compiles its kernel per problem
+		if (rt->beta_order == 1) {
+			return radSourceImpl<TDEP, DUST, RadT, EosT, 1>(lev, s, rt, t, cons_t, src_t, dt, stage, d_iteration_counter, d_failure_counter, mirror_t);
+		}
+		if (rt->beta_order == 0) {
+			return radSourceImpl<TDEP, DUST, RadT, EosT, 0>(lev, s, rt, t, cons_t, src_t, dt, stage, d_iteration_counter, d_failure_counter, mirror_t);
+		}
+	}
 	RadT rad(*rt);
 	rad.mean_molecular_mass = t->mean_molecular_weight;
 	const Eos eos(*t);
@@ -169,7 +177,7 @@ static auto radSourceImpl(qk_level *lev, qk_stream s, const qk_rad_traits *rt, c
 			for (int n = 0; n < 10; ++n) {
 				U[n] = srcStreamLoad(&S.p[c + S.ns * n]);
 			}
-			radSourceCell<TDEP, DUST, RadT, EosT>(rad, eos, U, Q(i, j, k), dt, stage, ntot, nmax, nsolve, fnewton, fouter, DUST ? &fdust : nullptr);
+			radSourceCell<TDEP, DUST, RadT, EosT, BETA>(rad, eos, U, Q(i, j, k), dt, stage, ntot, nmax, nsolve, fnewton, fouter, DUST ? &fdust : nullptr);
 			if (DUST && fdust != 0) {
 				atomicAdd(&d_failure_counter[1], fdust); // (rare: a negative dust temperature; the reference counts it the same way, :172-174)
 			}
