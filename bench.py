@@ -593,28 +593,42 @@ def cxx_shell_block(args, steps=22):
                       "SetRadEnergySource evaluated before every source-term call as in the reference; the executable's own figure of merit over all steps of the run"}
 
 
-def cxx_amr_block(args, steps=55):
+def cxx_amr_block(args, steps=55, skip=5):
     """BASELINE config 5 geometry through the C++17 host: the reference's unchanged test_hydro3d_blast.cpp on the deck of the config
-    (blast_amr_maxlev2.in), the executable's own figure of merit over the whole evolve (initial regrids and every step included)."""
+    (blast_amr_maxlev2.in).  `value`: the executable's own figure of merit over the whole evolve of `steps` coarse steps (start-up — code-object
+    loading at the first launches, plans, the first step's retry — included: ~50 ms of a 500 ms run); `steady_value`: the same window bench.py's
+    Python block times (coarse steps skip + 1 .. steps), from the difference of two runs."""
     import subprocess
     host = os.path.join(ROOT, "quokka_amd", "host")
     exe = os.path.join(host, "bin", "ref_HydroBlast3D")
     if not os.path.exists(exe):
         return {"error": "quokka_amd/host/bin/ref_HydroBlast3D is not built (needs the reference tree at build time)"}
     carry = 1 if args.rk2_mode == "carry" else 0
-    cmd = [exe, os.path.join(host, "decks", "blast_amr_maxlev2.in"), f"max_timesteps={steps}", f"hydro.rk2_carry_rhs={carry}", "plotfile_interval=-1", "checkpoint_interval=-1"]
-    try:
+
+    def run(n):
+        cmd = [exe, os.path.join(host, "decks", "blast_amr_maxlev2.in"), f"max_timesteps={n}", f"hydro.rk2_carry_rhs={carry}", "plotfile_interval=-1", "checkpoint_interval=-1"]
         p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=host)
         m = re.search(r"Performance figure-of-merit: ([0-9.eE+-]+) .s/zone-update \[([0-9.eE+-]+) Mupdates/s\]", p.stdout)
         if m is None:
-            return {"error": "no figure of merit in the output", "tail": p.stdout[-300:]}
+            raise RuntimeError("no figure of merit in the output: " + p.stdout[-300:])
         lv = re.findall(r"Zone-updates on level (\d): (\d+) \((\d+) grids\)", p.stdout)
+        sp = re.search(r"speculative coarse steps: overlapped=(\d+) rolled_back=(\d+)", p.stdout)
+        updates = sum(int(x[1]) for x in lv)
+        return {"fom": float(m.group(2)), "updates": updates, "seconds": updates / (float(m.group(2)) * 1e6), "levels": [int(x[1]) for x in lv],
+                "ok": "Energy conservation is OK." in p.stdout, "spec": (int(sp.group(1)), int(sp.group(2))) if sp else None}
+
+    try:
+        full = run(steps)
+        head = run(skip)
     except Exception as e:  # noqa: BLE001 - a secondary block must not take the headline down
         return {"error": f"{type(e).__name__}: {e}"}
-    return {"value": float(m.group(2)), "unit": "Mcell-updates/s", "coarse_steps": steps, "level0_rk2_mode": "carry + flux_rk2 on coarse-fine faces only" if carry else "exact",
-            "zone_updates_per_level": [int(x[1]) for x in lv], "energy_conservation_ok": "Energy conservation is OK." in p.stdout,
+    steady = (full["updates"] - head["updates"]) / max(full["seconds"] - head["seconds"], 1e-9) / 1e6
+    return {"value": full["fom"], "unit": "Mcell-updates/s", "coarse_steps": steps, "steady_value": steady, "steady_window": f"coarse steps {skip + 1} .. {steps} (two runs)",
+            "level0_rk2_mode": "carry + flux_rk2 on coarse-fine faces only" if carry else "exact",
+            "zone_updates_per_level": full["levels"], "energy_conservation_ok": full["ok"],
+            "speculative_coarse_steps": None if full["spec"] is None else {"overlapped": full["spec"][0], "rolled_back": full["spec"][1]},
             "driver": "the reference's test_hydro3d_blast.cpp, unchanged, through QuokkaSimulation<problem_t> + AmrDriver (C++17 host mirror), deck blast_amr_maxlev2.in; "
-                      "the executable's own figure of merit over the whole evolve"}
+                      "value = the executable's own figure of merit over the whole evolve"}
 
 
 def compact(block, keep=("value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline", "kernels_ms_per_launch")):

@@ -195,6 +195,9 @@ template <typename problem_t, typename SimT> class AmrDriver
 		for (int l = 0; l <= finestLevel(); ++l) {
 			amrex::Print() << "Zone-updates on level " << l << ": " << cellUpdatesEachLevel_[l] << " (" << level(l).allGrids_.size() << " grids)\n";
 		}
+		if (specOverlapped_ + specRolledBack_ > 0) {
+			amrex::Print() << "speculative coarse steps: overlapped=" << specOverlapped_ << " rolled_back=" << specRolledBack_ << "\n";
+		}
 		for (auto const &kv : phaseSeconds_) {
 			amrex::Print() << "host phase " << kv.first << ": " << kv.second << " s\n";
 		}
@@ -279,7 +282,7 @@ template <typename problem_t, typename SimT> class AmrDriver
 		}
 	};
 	Sim &base_;
-	std::vector<std::unique_ptr<Finer>> finerOwned_;
+	std::vector<std::shared_ptr<Finer>> finerOwned_; // (shared: the snapshot of a speculative coarse step keeps the levels a regrid inside it replaces)
 	std::vector<Finer *> finer_; // finer_[l-1] = level l
 	// a specialised user hook may have changed the state of any level: none of them may reuse the signal speeds its last stage cached
 	void dropSignalsIfHooked(bool hookIsDefault)
@@ -760,9 +763,9 @@ template <typename problem_t, typename SimT> class AmrDriver
 			if (existed && sameBoxes(level(lev).allGrids_, boxes)) {
 				continue;
 			}
-			std::unique_ptr<Finer> old;
+			std::shared_ptr<Finer> old;
 			if (existed) {
-				old = std::move(finerOwned_[lev - 1]);
+				old = finerOwned_[lev - 1];
 			}
 			makeLevel(lev, boxes);
 			Sim &me = level(lev);
@@ -879,6 +882,191 @@ template <typename problem_t, typename SimT> class AmrDriver
 		}
 	}
 
+	// ------------------------------------------------------------------ the children beside the far boxes (speculative coarse step)
+	// Same schedule as quokka_amd/amr_simulation.py (AmrSimulation.overlap_children): stage 2 of the level-0 boxes no child reads runs on a second
+	// stream while the children advance; the verdicts — level 0's and those of the children's own level steps — are read once, at the end of the
+	// coarse step; a bad one restores states, times, step counters and the grids of a regrid in between and redoes the step in the ordinary order.
+	int overlapChildren_ = [] {
+		int v = 1;
+		amrex::ParmParse("qk").query("overlap_children", v);
+		return v;
+	}();
+	double overlapMaxFineFraction_ = 0.5;
+	int forceSpeculationFailureAt_ = [] { // (tests: the rollback path — the verdict of this coarse step is declared bad)
+		int v = -1;
+		amrex::ParmParse("qk").query("force_speculation_failure_at", v);
+		return v;
+	}();
+	amrex::Long specOverlapped_ = 0, specRolledBack_ = 0;
+	static constexpr int specCap_ = 32;
+	int64_t *d_specLog_ = nullptr;
+	struct SpecEntry {
+		Sim *S;
+		double dt;
+		int slot;
+	};
+	std::vector<SpecEntry> specEntries_;
+	bool deferring_ = false;
+	struct SplitCache {
+		void const *child = nullptr, *interp = nullptr;
+		bool ok = false;
+		std::vector<int> near, far;
+	} splitCache_;
+
+	// (near, far) boxes of level lev if its children can be advanced beside the second stage of the far boxes.  near: every box the child level
+	// reads — the coarse cells under its ghost-cell interpolation (stencil included), the register cells of its flux register, the cells it
+	// averages down to.  Required of every interpolation item: the coarse cells it reads lie in the VALID region of its coarse box or beyond a
+	// physical boundary (never in ghost cells another box fills: those wait for the far boxes).
+	auto speculativeSplit(int lev) -> bool
+	{
+		if constexpr (Sim::isAdvection) {
+			return false;
+		} else {
+			Sim &L = level(lev);
+			if (overlapChildren_ == 0 || lev != 0 || multi_ || lev >= finestLevel() || do_reflux == 0 || !L.canSpeculate() || L.grids_.size() < 2) {
+				return false;
+			}
+			amrex::Long fine = 0;
+			for (int l = lev + 1; l <= finestLevel(); ++l) {
+				fine += level(l).CountCells(0);
+			}
+			if (static_cast<double>(fine) > overlapMaxFineFraction_ * static_cast<double>(L.CountCells(0))) {
+				return false;
+			}
+			Finer &f = *finer_[lev];
+			if (splitCache_.child == &f && splitCache_.interp == f.interp) {
+				return splitCache_.ok;
+			}
+			splitCache_ = SplitCache{};
+			splitCache_.child = &f;
+			splitCache_.interp = f.interp;
+			std::vector<char> isNear(L.grids_.size(), 0);
+			bool ok = true;
+			auto const &g = L.geom[0];
+			for (int n = 0; n < qk_interp_plan_num_items(f.interp); ++n) {
+				int fb = 0, cb = 0, lo[3], hi[3];
+				qkhost::check(qk_interp_plan_item(f.interp, n, &fb, &cb, lo, hi), "qk_interp_plan_item");
+				isNear[static_cast<size_t>(cb)] = 1;
+				auto const &v = L.grids_[static_cast<size_t>(cb)];
+				for (int d = 0; d < 3; ++d) {
+					int const clo = (lo[d] >> 1) - 1, chi = (hi[d] >> 1) + 1; // (arithmetic shift: floor division for the negative ghost indices)
+					if (clo < v.lo[d] && !(v.lo[d] == g.domain.lo[d] && g.periodic[d] == 0)) {
+						ok = false;
+					}
+					if (chi > v.hi[d] && !(v.hi[d] == g.domain.hi[d] && g.periodic[d] == 0)) {
+						ok = false;
+					}
+				}
+			}
+			for (int n = 0; n < qk_fluxreg_num_items(f.fluxreg); ++n) {
+				int dir = 0, side = 0, fb = 0, cb = 0, lo[3], hi[3], sh[3];
+				qkhost::check(qk_fluxreg_item(f.fluxreg, n, &dir, &side, &fb, &cb, lo, hi, sh), "qk_fluxreg_item");
+				isNear[static_cast<size_t>(cb)] = 1;
+			}
+			for (auto const &fbx : f.sim->allGrids_) { // the cells AverageDown writes
+				for (size_t b = 0; b < L.grids_.size(); ++b) {
+					bool hit = true;
+					for (int d = 0; d < 3; ++d) {
+						hit = hit && (fbx.lo[d] >> 1) <= L.grids_[b].hi[d] && (fbx.hi[d] >> 1) >= L.grids_[b].lo[d];
+					}
+					if (hit) {
+						isNear[b] = 1;
+					}
+				}
+			}
+			for (size_t b = 0; b < isNear.size(); ++b) {
+				(isNear[b] != 0 ? splitCache_.near : splitCache_.far).push_back(static_cast<int>(b));
+			}
+			splitCache_.ok = ok && !splitCache_.near.empty() && !splitCache_.far.empty();
+			if (splitCache_.ok) {
+				L.setSpeculativeSplit(splitCache_.near, splitCache_.far);
+			}
+			return splitCache_.ok;
+		}
+	}
+
+	// what a rollback must bring back of the levels above `lev`
+	struct LevelSnapshot {
+		Sim *S;
+		amrex::MultiFab data; // state_new_cc_ (the old state is overwritten by the next advance anyway)
+		double tOld, tNew;
+	};
+	struct Snapshot {
+		std::vector<std::shared_ptr<Finer>> owned;
+		std::vector<Finer *> raw;
+		std::vector<int> istep, lastRegrid;
+		amrex::Long cu;
+		std::vector<amrex::Long> cul;
+		std::vector<LevelSnapshot> levels;
+	};
+	auto snapshotAbove(int lev) -> Snapshot
+	{
+		Snapshot sn{finerOwned_, finer_, istep, last_regrid_step, cellUpdates_, cellUpdatesEachLevel_, {}};
+		for (int l = lev + 1; l <= finestLevel(); ++l) {
+			Sim &S = level(l);
+			LevelSnapshot ls{&S, amrex::MultiFab(), S.tOldLev_, S.tNewLev_};
+			ls.data.define(S.grids_, S.state_new_cc_[0].nComp(), S.state_new_cc_[0].nGrow());
+			amrex::MultiFab::Copy(ls.data, S.state_new_cc_[0]);
+			sn.levels.push_back(std::move(ls));
+		}
+		return sn;
+	}
+	void restoreAbove(int lev, Snapshot &sn)
+	{
+		QK_HOST_HIP(hipDeviceSynchronize()); // (levels made by a regrid of the discarded attempt are released below)
+		finerOwned_ = sn.owned;
+		finer_ = sn.raw;
+		istep = sn.istep;
+		last_regrid_step = sn.lastRegrid;
+		cellUpdates_ = sn.cu;
+		cellUpdatesEachLevel_ = sn.cul;
+		for (auto &ls : sn.levels) {
+			Sim &S = *ls.S;
+			amrex::MultiFab::Copy(S.state_new_cc_[0], ls.data);
+			S.tOldLev_ = ls.tOld;
+			S.tNewLev_ = ls.tNew;
+			S.oldStateGhostsFilled_ = false;
+			S.newStateGhostsFilled_ = false;
+			S.clearErrorWords(); // (whatever the discarded attempt flagged: the sticky error word, the cached signal speeds)
+		}
+		for (int l = lev + 1; l <= finestLevel(); ++l) { // plans a regrid of the discarded attempt may have re-pointed
+			linkToParent(*finer_[l - 1], l);
+		}
+		splitCache_ = SplitCache{};
+	}
+	// the verdicts of the level steps a speculative coarse step deferred: both stages clean, no error flag, no CFL violation — one device -> host copy
+	auto deferredVerdicts() -> bool
+	{
+		if (specEntries_.empty()) {
+			return true;
+		}
+		std::vector<int64_t> h(static_cast<size_t>(8 * specEntries_.size()));
+		QK_HOST_HIP(hipMemcpy(h.data(), d_specLog_, h.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+		bool ok = true;
+		std::map<Sim *, std::pair<double, double>> last;
+		for (auto const &e : specEntries_) {
+			int64_t const *w = &h[static_cast<size_t>(8 * e.slot)];
+			int64_t const nbad1 = w[2], nbad2 = w[6];
+			int64_t const err = (w[3] | w[7]) & 0xFFFFFFFFLL;
+			double sig[2];
+			std::memcpy(sig, &w[4], 2 * sizeof(double));
+			if (err != 0) {
+				amrex::Abort("density is negative in SyncDualEnergy! abort!!");
+			}
+			if (nbad1 != 0 || nbad2 != 0 || e.dt > 1.1 * e.S->cflLimitFor(sig[0])) {
+				ok = false;
+				break;
+			}
+			last[e.S] = {sig[0], sig[1]};
+		}
+		if (ok) {
+			for (auto &kv : last) {
+				kv.first->adoptDeferredSignal(kv.second.first, kv.second.second);
+			}
+		}
+		return ok;
+	}
+
 	void timeStepWithSubcycling(int lev, double time)
 	{
 		if (regrid_int > 0 && lev < max_level && istep[lev] > last_regrid_step[lev] && istep[lev] % regrid_int == 0) {
@@ -898,7 +1086,60 @@ template <typename problem_t, typename SimT> class AmrDriver
 			}
 		}
 		S.newStateGhostsFilled_ = false; // (the advance swaps the states and writes the new one)
-		{
+		if constexpr (!Sim::isAdvection) {
+			if (!deferring_ && speculativeSplit(lev)) {
+				Phase const ph(*this, "speculative coarse step");
+				Snapshot snap = snapshotAbove(lev);
+				if (d_specLog_ == nullptr) {
+					QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_specLog_), 8 * specCap_ * sizeof(int64_t)));
+				}
+				S.advanceLevelBegin(time, dt_[lev]);
+				deferring_ = true;
+				specEntries_.clear();
+				for (int i = 1; i <= 2; ++i) {
+					timeStepWithSubcycling(lev + 1, time + (i - 1) * dt_[lev + 1]);
+				}
+				deferring_ = false;
+				bool ok = S.advanceLevelJoin(dt_[lev]);
+				ok = deferredVerdicts() && ok;
+				if (forceSpeculationFailureAt_ >= 0 && istep[lev] == forceSpeculationFailureAt_) {
+					forceSpeculationFailureAt_ = -1;
+					ok = false;
+				}
+				if (ok) {
+					++specOverlapped_;
+					++istep[lev];
+					cellUpdates_ += S.CountCells(0);
+					cellUpdatesEachLevel_[lev] += S.CountCells(0);
+					if (do_reflux != 0) {
+						reflux(S, finer_[lev]->fluxreg, finer_[lev]->fold.get(), 0);
+					}
+					averageDownTo(lev);
+					S.fixupNear();
+					S.newStateGhostsFilled_ = false;
+					return;
+				}
+				// the level's step (or a child's) was not clean: the children advanced on a state that will not stand.  Back to the start of the step,
+				// then the ordinary order (first-order flux correction / retries, then the children).
+				++specRolledBack_;
+				S.rollBackSpeculativeStep();
+				restoreAbove(lev, snap);
+				if (do_reflux != 0 && lev < finestLevel()) {
+					qkhost::check(qk_fluxreg_reset(finer_[lev]->fluxreg, nullptr), "qk_fluxreg_reset");
+				}
+			}
+			if (deferring_ && lev > 0 && S.canSpeculate() && static_cast<int>(specEntries_.size()) < specCap_) {
+				// a level step inside a speculative coarse step: its verdict is deferred too
+				int const slot = static_cast<int>(specEntries_.size());
+				S.advanceLevelDeferred(time, dt_[lev], d_specLog_ + 8 * slot);
+				specEntries_.push_back({&S, dt_[lev], slot});
+			} else {
+				Phase const ph(*this, "advance level " + std::to_string(lev));
+				if (!S.advanceLevel(time, dt_[lev])) {
+					amrex::Abort("QUOKKA FATAL ERROR: Hydro update exceeded max_retries on level " + std::to_string(lev));
+				}
+			}
+		} else {
 			Phase const ph(*this, "advance level " + std::to_string(lev));
 			if (!S.advanceLevel(time, dt_[lev])) {
 				amrex::Abort("QUOKKA FATAL ERROR: Hydro update exceeded max_retries on level " + std::to_string(lev));

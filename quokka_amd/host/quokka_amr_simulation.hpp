@@ -615,6 +615,40 @@ template <typename problem_t> class AMRSimulation
 		}
 		physbc(between ? QK_BOXES_REMOTE_DEPENDENT : QK_BOXES_ALL);
 	}
+	// The physical-boundary rules alone (PhysBCFunct + the problem's hook) on one group of boxes of `state` — QK_BOXES_LOCAL_ONLY: the boxes not marked
+	// by setBoxGroups —: what the children of a speculative coarse step read of the parent's new state beyond its near boxes lies beyond the domain.
+	void fillPhysicalBoundaries(amrex::MultiFab &state, int which)
+	{
+		activate();
+		if (geom[0].isAllPeriodic()) {
+			return;
+		}
+		std::vector<qk_bcrec> bcs(BCs_cc_.size());
+		for (size_t n = 0; n < BCs_cc_.size(); ++n) {
+			for (int d = 0; d < 3; ++d) {
+				bcs[n].lo[d] = (d < AMREX_SPACEDIM) ? BCs_cc_[n].lo(d) : 0;
+				bcs[n].hi[d] = (d < AMREX_SPACEDIM) ? BCs_cc_[n].hi(d) : 0;
+			}
+		}
+		qkhost::check(qk_FillPhysicalBoundary_subset(plan_, qkhost::Runtime::get().computeStream(), qkhost::tab(state), bcs.data(), nullptr, which), "FillPhysicalBoundary");
+		customBoundaryConditionsOnDevice(state, which);
+	}
+	// marks the boxes of the second group ("remote" in the ghost plan's vocabulary: their physical-boundary slabs are filled by
+	// QK_BOXES_REMOTE_DEPENDENT, the others' by QK_BOXES_LOCAL_ONLY); the slab lists cached per group are dropped
+	void setBoxGroups(std::vector<char> const &second)
+	{
+		for (int b = 0; b < static_cast<int>(second.size()); ++b) {
+			qkhost::check(qk_ghost_plan_set_box_remote(plan_, b, second[b] != 0 ? 1 : 0), "qk_ghost_plan_set_box_remote");
+		}
+		for (auto it = bcShells_.begin(); it != bcShells_.end();) {
+			if (it->first.second != QK_BOXES_ALL) {
+				(void)hipFree(it->second.d);
+				it = bcShells_.erase(it);
+			} else {
+				++it;
+			}
+		}
+	}
 	// setCustomBoundaryConditions as the reference runs it (simulation.hpp:297-299, :1550-1561; amrex::GpuBndryFuncFab): the problem's
 	// DEVICE function is called for every ghost cell that lies outside the domain in a non-periodic direction, after the mathematical
 	// boundary types have been filled.  One kernel instantiated with the problem type per box — arbitrary boundary code, not the closed

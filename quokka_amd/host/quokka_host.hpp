@@ -193,12 +193,20 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	{
 		haveSignal_ = false;
 		signalPending_ = false;
+		fixFarPending_ = false;
 	}
 	// the CFL maxima FixupState left on the device, over all ranks (every rank calls this at the same points: computeTimestepAtLevel)
 	void resolveSignal()
 	{
 		if (!haveSignal_ && signalPending_) {
 			QK_HOST_HIP(hipMemcpy(signal_, d_fixSignal_, 2 * sizeof(double), hipMemcpyDeviceToHost));
+			if (fixFarPending_) { // the level was fixed up in two parts (fixupNear): the maxima of the other part
+				double far[2];
+				QK_HOST_HIP(hipMemcpy(far, d_fixFar_, 2 * sizeof(double), hipMemcpyDeviceToHost));
+				signal_[0] = std::max(signal_[0], far[0]);
+				signal_[1] = std::max(signal_[1], far[1]);
+				fixFarPending_ = false;
+			}
 			if (qkhost::Comm::get().size > 1) {
 				qkhost::Comm::get().allReduce(signal_, 2, qkhost::Comm::Op::max);
 			}
@@ -222,6 +230,202 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		}
 		return cflNumber_ * (minDx() / m);
 	}
+	// ------------------------------------------------------------------------------------------------------------------------------------------
+	// A coarse step whose verdict is read AFTER its children have been advanced (AmrDriver::timeStepWithSubcycling; quokka_amd/amr_simulation.py
+	// has the same schedule).  Level 0 of a young hierarchy holds 8 boxes of which one is refined: stage 2 of the 7 boxes no child reads ("far")
+	// runs on a second stream with a scratch array of its own while the children — chains of 20-60 us kernels that leave the chip nearly empty
+	// — are advanced on the compute stream.  Level 0's redo counts and CFL maxima then arrive after the children: they run speculatively, and
+	// so do their own level steps (advanceLevelDeferred: the eight words a step reports in go to a device log, read once per coarse step).
+	// A bad verdict anywhere rolls the coarse step back (AmrDriver) and redoes it in the ordinary order.
+	[[nodiscard]] auto canSpeculate() const -> bool
+	{
+		if constexpr (!fusedEligible() || is_radiation_enabled_ || !Physics_Traits<problem_t>::is_hydro_enabled || AMREX_SPACEDIM != 3) {
+			return false;
+		} else {
+			return integratorOrder_ == 2 && speculateStage2_ != 0 && strangSourcesAreDefault_ && afterLevelAdvanceIsDefault_ && enableCooling_ == 0 &&
+			       this->customBcIsDefault_ == 1;
+		}
+	}
+	// a level step inside a speculative coarse step: both stages and the register increments enqueued, the words copied to `d_log` (8 x int64)
+	void advanceLevelDeferred(double time, double dt_lev, int64_t *d_log)
+	{
+		std::swap(state_old_cc_[0], state_new_cc_[0]);
+		this->activate();
+		invalidateSignal();
+		if (beforeAttempt_) {
+			beforeAttempt_(0);
+		}
+		fusedBegin(1, true);
+		fillTime_ = time;
+		launchStage(1, state_old_cc_[0], state_old_cc_[0], state_inter_cc_, dt_lev, 0);
+		fillTime_ = time + dt_lev;
+		launchStage(2, state_inter_cc_, state_old_cc_[0], state_new_cc_[0], dt_lev, 1);
+		QK_HOST_HIP(hipMemcpyAsync(d_log, d_words_, 8 * sizeof(int64_t), hipMemcpyDeviceToDevice, qkhost::Runtime::get().computeStream()));
+		stage1LeftF1_ = !carryActive();
+		if (afterAdvance_) {
+			afterAdvance_(dt_lev);
+		}
+		this->oldStateGhostsFilled_ = true; // (stage 1 filled the old state's ghost cells in place, at `time`)
+	}
+	// what a deferred step's log entry said (AmrDriver::deferredVerdicts): the CFL maxima of the final stage, kept if nothing has changed the state since
+	void adoptDeferredSignal(double sig0, double sig1)
+	{
+		if (!signalPending_ && !haveSignal_) {
+			signal_[0] = sig0;
+			signal_[1] = sig1;
+			haveSignal_ = true;
+		}
+	}
+	[[nodiscard]] auto cflLimitFor(double max_signal) const -> double { return cflNumber_ * (minDx() / max_signal); }
+
+	// near: the boxes the child level reads (AmrDriver::speculativeSplit); far: the others, as up to eight launch sets (each holds its share of the
+	// wave slots only: the children's small kernels find free slots sooner — profiles/round5/ab9_amr_far_split.txt)
+	void setSpeculativeSplit(std::vector<int> const &near, std::vector<int> const &far)
+	{
+		auto make = [&](OverlapGroup &G, std::vector<int> const &idx) {
+			releaseGroup(G);
+			G.idx = idx;
+			std::vector<qk_box> qb;
+			for (int b : idx) {
+				qb.push_back({{grids_[b].lo[0], grids_[b].lo[1], grids_[b].lo[2]}, {grids_[b].hi[0], grids_[b].hi[1], grids_[b].hi[2]}});
+			}
+			qkhost::check(qk_level_create(qkhost::Runtime::get().ctx, &G.lev, AMREX_SPACEDIM, static_cast<int>(qb.size()), qb.data()), "qk_level_create");
+		};
+		make(specNear_, near);
+		make(specFar_, far);
+		for (auto &G : specFarParts_) {
+			releaseGroup(G);
+		}
+		int nsplit = 8;
+		amrex::ParmParse("qk").query("amr_far_split", nsplit);
+		nsplit = std::max(1, std::min<int>(static_cast<int>(far.size()), nsplit));
+		specFarParts_.assign(static_cast<size_t>(nsplit), OverlapGroup{});
+		for (int k = 0; k < nsplit; ++k) {
+			std::vector<int> part;
+			for (size_t n = static_cast<size_t>(k); n < far.size(); n += static_cast<size_t>(nsplit)) {
+				part.push_back(far[n]);
+			}
+			make(specFarParts_[static_cast<size_t>(k)], part);
+		}
+		auto t = qkhost::traits<problem_t>();
+		int64_t const need = qk_hydro_stage_scratch_bytes(specFar_.lev, &t);
+		if (need > farScratchBytes_) {
+			(void)hipFree(farScratch_);
+			QK_HOST_HIP(hipMalloc(&farScratch_, static_cast<size_t>(need)));
+			farScratchBytes_ = need;
+		}
+		if (farStream_ == nullptr) {
+			int least = 0, greatest = 0;
+			QK_HOST_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+			QK_HOST_HIP(hipStreamCreateWithPriority(&farStream_, hipStreamNonBlocking, least)); // the far boxes fill what the children leave idle
+			QK_HOST_HIP(hipEventCreateWithFlags(&evInterReady_, hipEventDisableTiming));
+			QK_HOST_HIP(hipEventCreateWithFlags(&evFarDone_, hipEventDisableTiming));
+			QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_fixFar_), 2 * sizeof(double)));
+		}
+		std::vector<char> second(grids_.size(), 0);
+		for (int b : far) {
+			second[static_cast<size_t>(b)] = 1;
+		}
+		this->setBoxGroups(second);
+	}
+	// advanceLevel with the verdict deferred: ghost fill + stage 1 of all boxes, ghost fill + stage 2 of the near boxes on the compute stream, stage 2
+	// (and FixupState) of the far boxes on the side stream; the physical boundaries of the near boxes' new state and the coarse side of the child's
+	// flux register follow on the compute stream, so that the children can be enqueued at once.  Nothing is read back.
+	void advanceLevelBegin(double time, double dt_lev)
+	{
+		std::swap(state_old_cc_[0], state_new_cc_[0]);
+		this->oldStateGhostsFilled_ = false;
+		this->activate();
+		invalidateSignal();
+		hipStream_t const cs = qkhost::Runtime::get().computeStream();
+		if (beforeAttempt_) {
+			beforeAttempt_(0);
+		}
+		primNow_ = primBackoff_ == 0 && primHandoffApplies();
+		fusedBegin(1, true);
+		fillTime_ = time;
+		this->fillBoundaryConditions(state_old_cc_[0]);
+		fusedLaunch(1, state_old_cc_[0], state_old_cc_[0], state_inter_cc_, dt_lev, -1, false, 0);
+		fillTime_ = time + dt_lev;
+		this->fillBoundaryConditions(state_inter_cc_);
+		QK_HOST_HIP(hipEventRecord(evInterReady_, cs));
+		fusedLaunch(2, state_inter_cc_, state_old_cc_[0], state_new_cc_[0], dt_lev, -1, false, 1, &specNear_);
+		QK_HOST_HIP(hipStreamWaitEvent(farStream_, evInterReady_, 0));
+		for (auto &part : specFarParts_) {
+			fusedLaunch(2, state_inter_cc_, state_old_cc_[0], state_new_cc_[0], dt_lev, -1, false, 1, &part, farScratch_, farScratchBytes_, farStream_);
+		}
+		primNow_ = false;
+		{ // FixupState of the far boxes (after Reflux and AverageDownTo in the reference, src/simulation.hpp:1308-1312 — neither touches a far box)
+			auto t = qkhost::traits<problem_t>();
+			qkhost::check(qk_hydro_FixupState(specFar_.lev, farStream_, &t, densityFloor_, tempFloor_, useDualEnergy_, groupTableOf(specFar_, qkhost::tab(state_new_cc_[0])),
+							  d_error_, d_fixFar_),
+				      "qk_hydro_FixupState(far)");
+		}
+		QK_HOST_HIP(hipEventRecord(evFarDone_, farStream_));
+		this->fillPhysicalBoundaries(state_new_cc_[0], QK_BOXES_LOCAL_ONLY);
+		stage1LeftF1_ = !carryActive();
+		if (afterAdvance_) {
+			afterAdvance_(dt_lev); // incrementFluxRegisters, coarse side: the register cells lie in the near boxes
+		}
+		this->oldStateGhostsFilled_ = true;
+	}
+	// the verdict of advanceLevelBegin: both stages clean on every box, no error flag, no CFL violation
+	auto advanceLevelJoin(double dt_lev) -> bool
+	{
+		this->activate();
+		QK_HOST_HIP(hipStreamWaitEvent(qkhost::Runtime::get().computeStream(), evFarDone_, 0));
+		StageWords w[2];
+		readWords(w);
+		if (w[0].err != 0 || w[1].err != 0) {
+			amrex::Abort("density is negative in SyncDualEnergy! abort!!");
+		}
+		if (w[0].count != 0 || w[1].count != 0) {
+			if (primHandoffChecked_ && primHandoffOk_) {
+				++primHandoffDropped_;
+				primBackoffLen_ = std::min(64, std::max(4, 2 * primBackoffLen_));
+				primBackoff_ = primBackoffLen_;
+			}
+			return false;
+		}
+		primBackoffLen_ = 0;
+		signal_[0] = w[1].sig[0];
+		signal_[1] = w[1].sig[1];
+		haveSignal_ = true;
+		return !isCflViolated(dt_lev);
+	}
+	// FixupState of the near boxes after Reflux and AverageDownTo; with the far boxes' (advanceLevelBegin) the whole level has had it
+	void fixupNear()
+	{
+		this->activate();
+		if (d_fixSignal_ == nullptr) {
+			QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_fixSignal_), 2 * sizeof(double)));
+		}
+		auto t = qkhost::traits<problem_t>();
+		hipStream_t const cs = qkhost::Runtime::get().computeStream();
+		qkhost::check(qk_hydro_FixupState(specNear_.lev, cs, &t, densityFloor_, tempFloor_, useDualEnergy_, groupTableOf(specNear_, qkhost::tab(state_new_cc_[0])), d_error_,
+						  d_fixSignal_),
+			      "qk_hydro_FixupState(near)");
+		invalidateSignal();
+		signalPending_ = true;
+		fixFarPending_ = true; // (the far boxes' maxima wait in d_fixFar_: resolveSignal takes the larger)
+	}
+	// the speculative step did not stand: the states as they were before advanceLevelBegin (the old state was never written), the sticky error
+	// words of the discarded attempt cleared
+	void rollBackSpeculativeStep()
+	{
+		QK_HOST_HIP(hipStreamWaitEvent(qkhost::Runtime::get().computeStream(), evFarDone_, 0));
+		std::swap(state_old_cc_[0], state_new_cc_[0]);
+		QK_HOST_HIP(hipMemsetAsync(d_words_, 0, 8 * sizeof(int64_t), qkhost::Runtime::get().computeStream()));
+		invalidateSignal();
+		this->oldStateGhostsFilled_ = false;
+		this->newStateGhostsFilled_ = false;
+	}
+	void clearErrorWords()
+	{
+		QK_HOST_HIP(hipMemsetAsync(d_words_, 0, 8 * sizeof(int64_t), qkhost::Runtime::get().computeStream()));
+		invalidateSignal();
+	}
+
 	// advanceSingleTimestepAtLevel for a hydro level of a hierarchy: state_new <- advance(previous state_new) starting at `time`
 	auto advanceLevel(double time, double dt_lev) -> bool
 	{
@@ -1090,6 +1294,27 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		std::map<const void *, void *> tables; // descriptor table of a MultiFab -> the same descriptors of this group's boxes, contiguous
 	};
 	OverlapGroup groups_[2];
+	// the speculative coarse step (advanceLevelBegin): near / far sub-levels, the far boxes' launch sets, their stream, scratch and words
+	OverlapGroup specNear_, specFar_;
+	std::vector<OverlapGroup> specFarParts_;
+	hipStream_t farStream_ = nullptr;
+	hipEvent_t evInterReady_ = nullptr, evFarDone_ = nullptr;
+	void *farScratch_ = nullptr;
+	int64_t farScratchBytes_ = 0;
+	double *d_fixFar_ = nullptr;
+	bool fixFarPending_ = false;
+	static void releaseGroup(OverlapGroup &G)
+	{
+		for (auto &kv : G.tables) {
+			(void)hipFree(kv.second);
+		}
+		G.tables.clear();
+		if (G.lev != nullptr) {
+			qk_level_destroy(G.lev);
+			G.lev = nullptr;
+		}
+		G.idx.clear();
+	}
 	int overlapState_ = 0; // 0: not examined, 1: active, 2: not worth it / not possible
 	amrex::Long minOverlapCells_ = 8L * 128 * 128 * 128; // a launch fills the chip from ~8 boxes of 128^3 on (the marching sweeps expose one wave per 64 cells of a pencil)
 
@@ -1123,18 +1348,19 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		return overlapState_ == 1;
 	}
 	// the descriptors of group g's boxes out of a MultiFab's table (64 bytes each), gathered once per table
-	template <typename D> auto groupTable(int g, D *full) -> D *
+	template <typename D> auto groupTable(int g, D *full) -> D * { return groupTableOf(groups_[g], full); }
+	template <typename D> static auto groupTableOf(OverlapGroup &G, D *full) -> D *
 	{
 		if (full == nullptr) {
 			return nullptr;
 		}
-		auto &m = groups_[g].tables;
+		auto &m = G.tables;
 		auto it = m.find(full);
 		if (it == m.end()) {
 			void *p = nullptr;
-			QK_HOST_HIP(hipMalloc(&p, sizeof(D) * groups_[g].idx.size()));
-			for (size_t n = 0; n < groups_[g].idx.size(); ++n) {
-				QK_HOST_HIP(hipMemcpy(static_cast<D *>(p) + n, full + groups_[g].idx[n], sizeof(D), hipMemcpyDeviceToDevice));
+			QK_HOST_HIP(hipMalloc(&p, sizeof(D) * G.idx.size()));
+			for (size_t n = 0; n < G.idx.size(); ++n) {
+				QK_HOST_HIP(hipMemcpy(static_cast<D *>(p) + n, full + G.idx[n], sizeof(D), hipMemcpyDeviceToDevice));
 			}
 			it = m.emplace(full, p).first;
 		}
@@ -1173,11 +1399,15 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		}
 	}
 	// one fused stage over all local boxes (group < 0) or over one group of the overlapped fill
+	// grp / scratch / stream: a sub-level of its own with its own stage scratch on its own stream (the far boxes of a speculative coarse step)
 	void fusedLaunch(int stageNo, amrex::MultiFab const &U_in, amrex::MultiFab const &U_old, amrex::MultiFab &U_out, double dt, int group = -1, bool fofc = false,
-			 int slot = 0)
+			 int slot = 0, OverlapGroup *grp = nullptr, void *scratch = nullptr, int64_t scratchBytes = 0, hipStream_t stream = nullptr)
 	{
 		auto t = qkhost::traits<problem_t>();
-		auto sel = [&](qk_array4 *full) { return group < 0 ? full : groupTable(group, full); };
+		if (grp == nullptr && group >= 0) {
+			grp = &groups_[group];
+		}
+		auto sel = [&](qk_array4 *full) { return grp == nullptr ? full : groupTableOf(*grp, full); };
 		qk_hydro_stage_args a{};
 		a.U_in = sel(qkhost::tab(U_in));
 		a.U_old = sel(qkhost::tab(U_old));
@@ -1187,14 +1417,14 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 			a.halfVel[d] = (d < AMREX_SPACEDIM) ? sel(qkhost::tab(halfVel_[d])) : nullptr;
 			a.dx[d] = (d < AMREX_SPACEDIM) ? geom[0].dx[d] : 1.0;
 		}
-		a.redoFlag = group < 0 ? qkhost::itab(redoFlag_) : groupTable(group, qkhost::itab(redoFlag_));
+		a.redoFlag = grp == nullptr ? qkhost::itab(redoFlag_) : groupTableOf(*grp, qkhost::itab(redoFlag_));
 		a.d_redo_count = d_words_ + 4 * slot + 2;
 		a.d_error_flag = reinterpret_cast<int *>(d_words_ + 4 * slot + 3);
 		if (isFinalStage(stageNo)) {
 			a.d_max_signal = reinterpret_cast<double *>(d_words_ + 4 * slot);
 		}
-		a.scratch = scratch_;
-		a.scratch_bytes = scratchBytes_;
+		a.scratch = (scratch != nullptr) ? scratch : scratch_;
+		a.scratch_bytes = (scratch != nullptr) ? scratchBytes : scratchBytes_;
 		a.dt = dt;
 		a.stage = stageNo;
 		a.reconstruction_order = reconstructionOrder_;
@@ -1209,7 +1439,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		}
 		if (masked) {
 			auto *full = reinterpret_cast<qk_carray4 *>(fluxMask_.arrays());
-			a.flux_mask = group < 0 ? full : groupTable(group, full);
+			a.flux_mask = grp == nullptr ? full : groupTableOf(*grp, full);
 		}
 		if (carryActive()) {
 			if (rhs1_.size() == 0) {
@@ -1223,7 +1453,7 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 			a.prim_out = (stageNo == 1) ? 1 : 0;
 			a.prim_in = (stageNo == 2) ? 1 : 0;
 		}
-		qkhost::check(qk_hydro_stage_fused(group < 0 ? qkhost::Runtime::get().lev : groups_[group].lev, qkhost::Runtime::get().computeStream(), &t, &a),
+		qkhost::check(qk_hydro_stage_fused(grp == nullptr ? qkhost::Runtime::get().lev : grp->lev, stream != nullptr ? stream : qkhost::Runtime::get().computeStream(), &t, &a),
 			      "qk_hydro_stage_fused");
 	}
 	// flagged cells of the stage (all ranks); after a clean final stage the two CFL maxima are kept for computeTimestep / isCflViolated

@@ -590,3 +590,33 @@ def test_randomblast_unchanged_without_its_grackle_cooling(tmp_path):
     m = re.search(r"Initial gasEnergy = (\S+)\s+absolute conservation error = (\S+)", out)
     assert abs(float(m.group(2)) / injected - 1.0) < 1.0e-9, (m.group(2), injected)
     assert conservation_error(out, "gasDensity") == 0.0
+
+
+def test_cxx_host_children_beside_the_far_boxes_and_the_rollback_are_bit_identical(tmp_path):
+    """The speculative coarse step of the C++ host (host/quokka_amr.hpp: AmrDriver::speculativeSplit / snapshotAbove / deferredVerdicts,
+    QuokkaSimulation::advanceLevelBegin / advanceLevelDeferred — the schedule quokka_amd/amr_simulation.py introduced in round 5): stage 2 of the
+    level-0 boxes no child reads on a second stream while the children advance, every verdict read once at the end of the coarse step, a bad one
+    rolled back (states, times, step counters, the grids of a regrid in between) and redone in the ordinary order.  The reference's unchanged
+    HydroBlast3D on blast_amr_maxlev2.in scaled down (64^3 in 32^3 boxes, blocking factor 8), 14 coarse steps: the ordinary order, the
+    overlapped one, the overlapped one with the verdict of coarse step 5 forced bad — the same zone-update counts per level and the level-0
+    state equal in every bit; exact and carried form of the RK2 average."""
+    import re
+    deck = os.path.join(HOST, "decks", "blast_amr_maxlev2.in")
+    common = [deck, "amr.n_cell=64 64 64", "amr.max_grid_size=32", "amr.blocking_factor=8", "max_timesteps=14"]
+    for form in ([], ["hydro.rk2_carry_rhs=1"]):
+        results = []
+        for tag, extra in (("plain", ["qk.overlap_children=0"]), ("overlap", ["qk.overlap_children=1"]),
+                           ("rollback", ["qk.overlap_children=1", "qk.force_speculation_failure_at=5"])):
+            dump = str(tmp_path / f"{tag}{len(form)}.bin")
+            rc, out = run([exe("ref_HydroBlast3D")] + common + form + extra + [f"qk.dump_state={dump}"], str(tmp_path))
+            assert "Energy conservation is OK." in out, out[-2500:]
+            zones = re.findall(r"Zone-updates on level (\d): (\d+)", out)
+            m = re.search(r"speculative coarse steps: overlapped=(\d+) rolled_back=(\d+)", out)
+            results.append((np.fromfile(dump, dtype=np.float64), zones, (int(m.group(1)), int(m.group(2))) if m else (0, 0), open(dump + ".meta").read().split()[:3]))
+        plain, over, roll = results
+        assert len(plain[1]) == 3 and int(plain[1][2][1]) > 0  # a level 2 exists and was advanced
+        assert plain[2] == (0, 0) and over[2][0] >= 10 and over[2][1] <= 2, (plain[2], over[2])
+        assert roll[2][1] == over[2][1] + 1, (over[2], roll[2])
+        for other in (over, roll):
+            assert other[1] == plain[1] and other[3] == plain[3], (plain[1], other[1], plain[3], other[3])
+            assert np.array_equal(plain[0], other[0])
