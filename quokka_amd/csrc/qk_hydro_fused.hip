@@ -1017,6 +1017,11 @@ __global__ void __launch_bounds__(64 * MARCH_BY) k_sweep_march(SweepArgs a, Eos 
 	if (nvalid <= 0) {
 		return; // uniform for the workgroup
 	}
+	if constexpr (FUSEX) {
+		if (bx.lo[0] + bix * 64 > bx.hi[0]) {
+			return; // (uniform) a 64-cell chunk beyond a box narrower than the level's widest: nothing to do, and its edge faces would lie outside the fab
+		}
+	}
 	// scratch index of march position p = lo - 3
 	int pos[3];
 	pos[0] = i;
