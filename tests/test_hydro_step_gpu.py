@@ -619,3 +619,35 @@ def test_x_sweep_inside_the_y_march_changes_no_bit(ctx, N, mgs, handoff):
         os.environ.pop("QK_FUSEX", None)
     assert finals[0][1] == finals[1][1]
     assert np.array_equal(finals[0][0], finals[1][0])
+
+
+def test_x_sweep_inside_the_y_march_with_boxes_of_two_widths(ctx):
+    """FUSEX on a level whose boxes are 128 and 64 cells wide (192 x 64 x 64 cells chopped at 128): the launch is sized for the widest box, the
+    64-cell chunk beyond a narrow box leaves at once (its edge faces would lie outside the fab).  Equal to QK_FUSEX=0 in every bit."""
+    import os
+    from quokka_amd import capi
+    from quokka_amd.simulation import Geometry, HydroSimulation, developed_state
+    finals = []
+    try:
+        for fusex in ("0", "1"):
+            os.environ["QK_FUSEX"] = fusex
+            geom = Geometry(3, [192, 64, 64], [0.0, 0.0, 0.0], [3.6, 1.2, 1.2], [0, 0, 0])
+            bcs = []
+            for c in range(6):
+                lo = [capi.BC_REFLECT_ODD if c == 1 + d else capi.BC_REFLECT_EVEN for d in range(3)]
+                bcs.append((lo, list(lo)))
+            boxes = [([0, 0, 0], [127, 63, 63]), ([128, 0, 0], [191, 63, 63])]
+            s = HydroSimulation(ctx, geom, capi.traits(1.4, False, 3), bcs, [128, 64, 64], boxes=boxes, owner=[0, 0])
+            s.reconstructionOrder_, s.stopTime_, s.cflNumber_ = 3, 1.0, 0.3
+            assert sorted({hi[0] - lo[0] + 1 for lo, hi in s.my_boxes}) == [64, 128]
+            s.rk2_carry_rhs = True
+            for b, (lo, hi) in enumerate(s.my_boxes):
+                s.state_new_cc_.set_fab(b, developed_state(64, lo, hi))
+            s._signal_of_state_new = None
+            for _ in range(5):
+                assert s.step()
+            finals.append([v.copy() for v in s.gather_valid_local()])
+    finally:
+        os.environ.pop("QK_FUSEX", None)
+    for a, b in zip(*finals):
+        assert np.array_equal(a, b)
