@@ -270,7 +270,10 @@ typedef struct qk_hydro_stage_args {
  * FOFC branch: computeHydroFluxes + Saxpy + ComputeRhsFromFluxes + AddInternalEnergyPdV + PredictStep +
  * EnforceLimits + SyncDualEnergy, fused per sweep direction.  If *d_redo_count > 0 afterwards the caller runs
  * the reference-shaped operators above for the FOFC correction (results are bit-identical where no flux is
- * replaced). */
+ * replaced).
+ * Launches per stage: the flattening pre-pass, the X, Y and Z sweeps — or, in the carried form (rk2_carry_rhs) of a 3-D level without passive scalars
+ * and flux mask whose boxes are all a multiple of 64 cells wide, the pre-pass, ONE sweep that forms the x fluxes inside the y march, and the Z sweep:
+ * same bits, 142 B per cell less HBM traffic.  Environment (read per call; A/B runs and tests): QK_FUSEX=0 keeps the four launches. */
 int64_t qk_hydro_stage_scratch_bytes(qk_level *lev, const qk_hydro_traits *t);
 int qk_hydro_stage_fused(qk_level *lev, qk_stream s, const qk_hydro_traits *t, const qk_hydro_stage_args *a);
 
