@@ -130,6 +130,14 @@ template <int NG> QK_PL_HD void binCentreOpacity(const double *edges, const doub
 	}
 }
 
+// Levermore's closure (radiation_system.hpp:773-790): the Eddington factor chi(f) = (3 + 4 f^2) / (5 + 2 sqrt(4 - 3 f^2)) of a reduced flux held in [0, 1]
+QK_PL_HD auto levermoreFactor(double reduced_flux) -> double
+{
+	const double f = (reduced_flux < 0.) ? 0. : ((reduced_flux > 1.) ? 1. : reduced_flux);
+	const double ff = f * f;
+	return (3.0 + 4.0 * ff) / (5.0 + 2.0 * sqrt(4.0 - 3.0 * ff));
+}
+
 // kinetic energy of (rho, p): |p|^2 / (2 rho)
 QK_PL_HD auto kineticEnergy(double rho, double px, double py, double pz) -> double { return (px * px + py * py + pz * pz) / (2.0 * rho); }
 

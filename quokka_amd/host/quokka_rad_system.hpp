@@ -494,73 +494,43 @@ template <typename problem_t> class RadSystem : public HyperbolicSystem<problem_
 	}
 };
 
-// the defaults of the hooks (reference radiation_system.hpp:471-479, :499-503, :1155-1167)
-template <typename problem_t> AMREX_GPU_HOST_DEVICE auto RadSystem<problem_t>::ComputeThermalRadiationSingleGroup(amrex::Real temperature) -> amrex::Real
+// the defaults of the hooks a problem may specialise (reference radiation_system.hpp:471-479, :499-503, :524-545, :773-790, :1141-1167), each in terms of the
+// bodies the HIP library shares with this mirror (csrc/qk_planck.hpp)
+#define QK_RAD_HOOK template <typename problem_t> AMREX_GPU_HOST_DEVICE auto RadSystem<problem_t>::
+QK_RAD_HOOK ComputeThermalRadiationSingleGroup(amrex::Real temperature) -> amrex::Real
 {
-	double power = radiation_constant_ * std::pow(temperature, 4);
-	if (power < Erad_floor_) {
-		power = Erad_floor_;
+	double e = 1.0; // a T^4, floored: the one-group case of ComputeThermalRadiationMultiGroup
+	qk::planck::scaleFloored<1>(radiation_constant_ * std::pow(temperature, 4), Erad_floor_, &e);
+	return e;
+}
+QK_RAD_HOOK ComputeThermalRadiationTempDerivativeSingleGroup(amrex::Real temperature) -> amrex::Real { return 4. * radiation_constant_ * std::pow(temperature, 3); }
+QK_RAD_HOOK DefineOpacityExponentsAndLowerValues(amrex::GpuArray<double, nGroups_ + 1> /*rad_boundaries*/, const double /*rho*/, const double /*Tgas*/)
+    -> amrex::GpuArray<amrex::GpuArray<double, nGroups_ + 1>, 2>
+{
+	amrex::GpuArray<amrex::GpuArray<double, nGroups_ + 1>, 2> undefined{}; // a multigroup problem MUST specialise this hook: NaN everywhere until it does
+	for (auto &row : undefined.arr) {
+		for (auto &v : row.arr) {
+			v = std::numeric_limits<double>::quiet_NaN();
+		}
 	}
-	return power;
+	return undefined;
 }
-template <typename problem_t> AMREX_GPU_HOST_DEVICE auto RadSystem<problem_t>::ComputeThermalRadiationTempDerivativeSingleGroup(amrex::Real temperature) -> amrex::Real
+QK_RAD_HOOK DefinePhotoelectricHeatingE1Derivative(amrex::Real const /*temperature*/, amrex::Real const /*num_density*/) -> amrex::Real { return 0.0; }
+QK_RAD_HOOK DefineNetCoolingRate(amrex::Real const /*temperature*/, amrex::Real const /*num_density*/) -> quokka::valarray<double, nGroups_>
 {
-	return 4. * radiation_constant_ * std::pow(temperature, 3);
+	return quokka::valarray<double, nGroups_>{}; // (value-initialised: no line cooling)
 }
-template <typename problem_t>
-AMREX_GPU_HOST_DEVICE auto RadSystem<problem_t>::DefineOpacityExponentsAndLowerValues(amrex::GpuArray<double, nGroups_ + 1> /*rad_boundaries*/, const double /*rho*/,
-										      const double /*Tgas*/) -> amrex::GpuArray<amrex::GpuArray<double, nGroups_ + 1>, 2>
+QK_RAD_HOOK DefineNetCoolingRateTempDerivative(amrex::Real const /*temperature*/, amrex::Real const /*num_density*/) -> quokka::valarray<double, nGroups_>
 {
-	amrex::GpuArray<amrex::GpuArray<double, nGroups_ + 1>, 2> exponents_and_values{};
-	for (int g = 0; g < nGroups_ + 1; ++g) {
-		exponents_and_values[0][g] = NAN;
-		exponents_and_values[1][g] = NAN;
-	}
-	return exponents_and_values;
+	return quokka::valarray<double, nGroups_>{};
 }
-
-template <typename problem_t>
-AMREX_GPU_HOST_DEVICE auto RadSystem<problem_t>::DefinePhotoelectricHeatingE1Derivative(amrex::Real const /*temperature*/, amrex::Real const /*num_density*/) -> amrex::Real
-{
-	return 0.0;
-}
-template <typename problem_t>
-AMREX_GPU_HOST_DEVICE auto RadSystem<problem_t>::DefineNetCoolingRate(amrex::Real const /*temperature*/, amrex::Real const /*num_density*/)
-    -> quokka::valarray<double, nGroups_>
-{
-	quokka::valarray<double, nGroups_> cooling{};
-	cooling.fillin(0.0);
-	return cooling;
-}
-template <typename problem_t>
-AMREX_GPU_HOST_DEVICE auto RadSystem<problem_t>::DefineNetCoolingRateTempDerivative(amrex::Real const /*temperature*/, amrex::Real const /*num_density*/)
-    -> quokka::valarray<double, nGroups_>
-{
-	quokka::valarray<double, nGroups_> cooling{};
-	cooling.fillin(0.0);
-	return cooling;
-}
-template <typename problem_t> AMREX_GPU_HOST_DEVICE auto RadSystem<problem_t>::DefineCosmicRayHeatingRate(amrex::Real const /*num_density*/) -> double { return 0.0; }
-
-template <typename problem_t> AMREX_GPU_HOST_DEVICE auto RadSystem<problem_t>::ComputePlanckOpacity(const double /*rho*/, const double /*Tgas*/) -> amrex::Real
-{
-	return std::numeric_limits<double>::quiet_NaN();
-}
-template <typename problem_t> AMREX_GPU_HOST_DEVICE auto RadSystem<problem_t>::ComputeFluxMeanOpacity(const double rho, const double Tgas) -> amrex::Real
-{
-	return ComputePlanckOpacity(rho, Tgas);
-}
-template <typename problem_t> AMREX_GPU_HOST_DEVICE auto RadSystem<problem_t>::ComputeEnergyMeanOpacity(const double rho, const double Tgas) -> amrex::Real
-{
-	return ComputePlanckOpacity(rho, Tgas);
-}
-template <typename problem_t> AMREX_GPU_HOST_DEVICE auto RadSystem<problem_t>::ComputeEddingtonFactor(double f_in) -> double
-{
-	// f is the reduced flux == |F|/cE; compute Levermore (1984) closure [Eq. 25] (reference src/radiation/radiation_system.hpp:773-790)
-	const double f = std::clamp(f_in, 0., 1.);
-	const double f_fac = std::sqrt(4.0 - 3.0 * (f * f));
-	return (3.0 + 4.0 * (f * f)) / (5.0 + 2.0 * f_fac);
-}
+QK_RAD_HOOK DefineCosmicRayHeatingRate(amrex::Real const /*num_density*/) -> double { return 0.0; }
+QK_RAD_HOOK ComputePlanckOpacity(const double /*rho*/, const double /*Tgas*/) -> amrex::Real { return std::numeric_limits<double>::quiet_NaN(); }
+// (the flux-mean and the energy-mean opacity default to the Planck mean)
+QK_RAD_HOOK ComputeFluxMeanOpacity(const double rho, const double Tgas) -> amrex::Real { return ComputePlanckOpacity(rho, Tgas); }
+QK_RAD_HOOK ComputeEnergyMeanOpacity(const double rho, const double Tgas) -> amrex::Real { return ComputePlanckOpacity(rho, Tgas); }
+QK_RAD_HOOK ComputeEddingtonFactor(double f_in) -> double { return qk::planck::levermoreFactor(f_in); }
+#undef QK_RAD_HOOK
 template <typename problem_t>
 void RadSystem<problem_t>::SetRadEnergySource(array_t & /*radEnergySource*/, amrex::Box const & /*indexRange*/,
 					      amrex::GpuArray<amrex::Real, AMREX_SPACEDIM> const & /*dx*/,
