@@ -177,3 +177,96 @@ def test_sfc_distribution_balances_cells_and_fills_the_least_loaded_ranks():
         mine = [grid[b][0] for b in range(64) if own[b] == r]
         assert all(max(m[d] for m in mine) - min(m[d] for m in mine) == 16 for d in range(3))
     assert distribute_sfc(grid, 1) == [0] * 64
+
+
+_LAYOUT_DRIVER = r"""
+#include <cstdio>
+#include <iostream>
+#include "qk_grid_layout.hpp"
+struct B { int lo[3], hi[3]; };
+int main() {  // stdin: what (chop|sfc), the parameters, the boxes; stdout: boxes or owners
+    std::string what;
+    while (std::cin >> what) {
+        int n = 0;
+        if (what == "chop") {
+            int target, mgs, bf, ndim; std::array<int, 3> dom{};
+            std::cin >> target >> mgs >> bf >> ndim >> dom[0] >> dom[1] >> dom[2] >> n;
+            std::vector<B> boxes(n);
+            for (auto &b : boxes) std::cin >> b.lo[0] >> b.lo[1] >> b.lo[2] >> b.hi[0] >> b.hi[1] >> b.hi[2];
+            auto out = qkhost::chopGrids(boxes, target, mgs, bf, dom, ndim);
+            std::printf("%zu", out.size());
+            for (auto const &b : out) std::printf(" %d %d %d %d %d %d", b.lo[0], b.lo[1], b.lo[2], b.hi[0], b.hi[1], b.hi[2]);
+            std::printf("\n");
+        } else {
+            int nranks, unit, nload;
+            std::cin >> nranks >> unit >> nload;
+            std::vector<long long> load(nload);
+            for (auto &l : load) std::cin >> l;
+            std::cin >> n;
+            std::vector<B> boxes(n);
+            for (auto &b : boxes) std::cin >> b.lo[0] >> b.lo[1] >> b.lo[2] >> b.hi[0] >> b.hi[1] >> b.hi[2];
+            auto own = qkhost::distributeSfc(boxes, nranks, load, unit);
+            std::printf("%zu", own.size());
+            for (int o : own) std::printf(" %d", o);
+            std::printf("\n");
+        }
+    }
+    return 0;
+}
+"""
+
+
+def test_cxx_host_grid_layout_equals_the_python_host(tmp_path):
+    """quokka_amd/host/qk_grid_layout.hpp (maxSize / chopGrids / distributeSfc of the C++17 host's distributed levels) against
+    amr_simulation.chop_grids / distribute_sfc on the same inputs: the fixed cases above plus seeded random box lists, every output equal."""
+    import os
+    import subprocess
+    from quokka_amd.amr_simulation import chop_grids, distribute_sfc
+    src = tmp_path / "layout.cpp"
+    src.write_text(_LAYOUT_DRIVER)
+    exe = tmp_path / "layout"
+    host = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "quokka_amd", "host")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I", host, str(src), "-o", str(exe)], check=True)
+    rng = np.random.default_rng(7)
+
+    def fmt(boxes):
+        return f"{len(boxes)} " + " ".join(" ".join(map(str, list(lo) + list(hi))) for lo, hi in boxes)
+
+    cases, want = [], []
+
+    def chop(boxes, target, mgs, bf, dom, ndim=3):
+        cases.append(f"chop {target} {mgs} {bf} {ndim} {dom[0]} {dom[1]} {dom[2]} {fmt(boxes)}")
+        out = chop_grids(boxes, target, mgs, bf, dom, ndim)
+        want.append([len(out)] + [x for lo, hi in out for x in list(lo) + list(hi)])
+        return out
+
+    def sfc(boxes, nranks, load, unit):
+        cases.append(f"sfc {nranks} {unit} {len(load or [])} {' '.join(map(str, load or []))} {fmt(boxes)}")
+        out = distribute_sfc(boxes, nranks, load, unit=unit)
+        want.append([len(out)] + out)
+
+    one = [([0, 0, 0], [63, 63, 63])]
+    for target in (1, 2, 4, 8, 16):
+        sfc(chop(one, target, 128, 32, [512] * 3), 8, [128 ** 3] * 8, 32)
+    chop([([0, 0, 0], [63, 31, 31]), ([0, 32, 0], [31, 63, 31])], 4, 64, 16, [128] * 3)
+    chop([([0, 0, 0], [47, 31, 0])], 6, 64, 8, [64, 64, 1], ndim=2)
+    grid = [([16 * i, 16 * j, 16 * k], [16 * i + 15, 16 * j + 15, 16 * k + 15]) for k in range(4) for j in range(4) for i in range(4)]
+    sfc(grid, 8, None, 16)
+    sfc(grid[:3], 8, [5, 9, 1, 9, 9, 0, 9, 9], 16)
+    for _ in range(40):  # disjoint boxes of a random lattice with random extents (blocking factor 8), random loads
+        bf = 8
+        cells = [(i, j, k) for k in range(4) for j in range(4) for i in range(4)]
+        pick = rng.choice(len(cells), size=int(rng.integers(1, 12)), replace=False)
+        boxes = []
+        for c in pick:
+            lo = [32 * x for x in cells[c]]
+            ext = [bf * int(rng.integers(1, 5)) for _ in range(3)]
+            boxes.append((lo, [lo[d] + ext[d] - 1 for d in range(3)]))
+        nranks = int(rng.integers(2, 9))
+        out = chop(boxes, int(rng.integers(1, 17)), int(rng.choice([16, 32, 64])), bf, [128] * 3)
+        sfc(out, nranks, [int(x) for x in rng.integers(0, 5, size=nranks) * 4096] if rng.random() < 0.7 else None, bf)
+    res = subprocess.run([str(exe)], input="\n".join(cases) + "\n", capture_output=True, text=True, check=True)
+    got = [[int(x) for x in ln.split()] for ln in res.stdout.strip().split("\n")]
+    assert len(got) == len(want)
+    for c, g, w in zip(cases, got, want):
+        assert g == w, (c, g, w)
