@@ -140,6 +140,13 @@ class Comm
 		if (backend == Backend::shm) {
 			++seq_; // (every rank counts every collective step, with or without peers of its own)
 		}
+		if (trace_) { // QK_COMM_TRACE=1: every exchange of every rank on stderr (who diverged from whom)
+			std::string line = "qkcomm[" + std::to_string(rank) + "] exchange " + std::to_string(seq_) + " (" + (label != nullptr ? label : "") + "):";
+			for (size_t k = 0; k < peer.size(); ++k) {
+				line += " " + std::to_string(peer[k]) + ":s" + std::to_string(nsend[k]) + "/r" + std::to_string(nrecv[k]);
+			}
+			std::fprintf(stderr, "%s\n", line.c_str());
+		}
 		if (peer.empty()) {
 			return;
 		}
@@ -192,6 +199,9 @@ class Comm
 			return;
 		}
 		++seq_;
+		if (trace_) {
+			std::fprintf(stderr, "qkcomm[%d] allReduce %ld (%d doubles)\n", rank, static_cast<long>(seq_), n);
+		}
 		writeFile(msgPath("r", rank, -1, seq_), v, sizeof(double) * n);
 		// summation in rank order on every rank: all ranks obtain the same bits
 		std::vector<std::vector<double>> all(static_cast<size_t>(size));
@@ -238,6 +248,9 @@ class Comm
 			return;
 		}
 		++seq_;
+		if (trace_) {
+			std::fprintf(stderr, "qkcomm[%d] allReduceMaxInts %ld (%zu ints)\n", rank, static_cast<long>(seq_), n);
+		}
 		writeFile(msgPath("r", rank, -1, seq_), v, sizeof(int) * n);
 		std::vector<int> other(n);
 		for (int r = 0; r < size; ++r) {
@@ -295,7 +308,10 @@ class Comm
 		lastBarrier_[1] = seq_;
 	}
 
+	char const *label = nullptr; // what the next exchange is (QK_COMM_TRACE output only)
+
       private:
+	bool trace_ = std::getenv("QK_COMM_TRACE") != nullptr;
 	bool initialised_ = false;
 	bool loopback_ = false;
 	std::string tag_;
@@ -343,13 +359,18 @@ class Comm
 			die("cannot rename " + tmp);
 		}
 	}
+	static auto waitSeconds() -> int // QK_COMM_TIMEOUT: how long a rank waits for a peer's message before it gives up (default 300 s)
+	{
+		static int const s = (std::getenv("QK_COMM_TIMEOUT") != nullptr) ? std::max(1, std::atoi(std::getenv("QK_COMM_TIMEOUT"))) : 300;
+		return s;
+	}
 	static void readFile(std::string const &path, void *data, size_t bytes)
 	{
 		auto const t0 = std::chrono::steady_clock::now();
 		struct stat st {
 		};
 		while (stat(path.c_str(), &st) != 0) {
-			if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(300)) {
+			if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(waitSeconds())) {
 				die("timed out waiting for " + path);
 			}
 			std::this_thread::sleep_for(std::chrono::microseconds(50));

@@ -11,6 +11,11 @@
 // ancestor, so grids are clustered inside each level-0 box, and interpolation, average-down and regrid copies stay on the GPU that owns the
 // data.  Only the ordinary ghost exchange of every level and the reflux increments (register cells next to a box of another rank: folded with
 // qk_SumBoundary_*) cross ranks; tile flags are all-reduced so that every rank builds the same hierarchy.
+// qk.distribute_levels = 1: every level has its own box -> rank map instead, as AMReX hands AMRSimulation a BoxArray + DistributionMapping per level
+// (reference src/simulation.hpp:1421-1500, :1657-1702) — grids clustered globally as with one rank, a level with fewer boxes than ranks chopped until
+// every rank can own one (qk_grid_layout.hpp: chopGrids, distributeSfc), and the coarse data a refined level needs and produces kept on the FINE
+// level's ranks (Shadow below: the coarse patch of FillPatchTwoLevels, the coarsened fine array of average_down, the cfpatch of YAFluxRegister), moved
+// between the two distributions by ParallelCopy plans (qk_pcopy.hpp).  The schedule of quokka_amd/amr_simulation.py (CoarseShadow, DistFluxRegister).
 #ifndef QK_HOST_QUOKKA_AMR_HPP_
 #define QK_HOST_QUOKKA_AMR_HPP_
 
@@ -18,6 +23,8 @@
 #include <map>
 #include <memory>
 
+#include "qk_grid_layout.hpp"
+#include "qk_pcopy.hpp"
 #include "quokka_host.hpp"
 
 // SimT: the simulation class of one level — QuokkaSimulation<problem_t> (hydro / radiation hydrodynamics) or AdvectionSimulation<problem_t>
@@ -42,9 +49,13 @@ template <typename problem_t, typename SimT> class AmrDriver
 		pp.query("do_reflux", do_reflux);
 		pp.query("grid_eff", grid_eff);
 		multi_ = qkhost::Comm::get().size > 1;
-		clusterWithinParent_ = multi_ ? 1 : 0;
-		amrex::ParmParse("qk").query("cluster_within_parent", clusterWithinParent_); // (tests: one rank building the grids several ranks build)
-		AMREX_ALWAYS_ASSERT(!multi_ || clusterWithinParent_ != 0);
+		amrex::ParmParse pq("qk");
+		pq.query("distribute_levels", distLevels_);		      // every level with its own box -> rank map (any number of ranks: one rank runs the same plans)
+		pq.query("refine_grid_layout_target", refineTarget_); // (tests: one rank building the grids N ranks build)
+		clusterWithinParent_ = (multi_ && distLevels_ == 0) ? 1 : 0;
+		pq.query("cluster_within_parent", clusterWithinParent_); // (tests: one rank building the grids several ranks build)
+		AMREX_ALWAYS_ASSERT(!multi_ || distLevels_ != 0 || clusterWithinParent_ != 0);
+		AMREX_ALWAYS_ASSERT(distLevels_ == 0 || clusterWithinParent_ == 0);
 		istep.assign(max_level + 1, 0);
 		last_regrid_step.assign(max_level + 1, 0);
 		dt_.assign(max_level + 1, 1.e100);
@@ -64,13 +75,22 @@ template <typename problem_t, typename SimT> class AmrDriver
 	double tNew_ = 0.0, elapsedSeconds_ = 0.0;
 	bool multi_ = false;
 	int clusterWithinParent_ = 0;
+	int distLevels_ = 0;	 // qk.distribute_levels
+	int refineTarget_ = -1; // qk.refine_grid_layout_target: the box count ChopGrids aims for (default: the number of ranks)
 
 	[[nodiscard]] auto finestLevel() const -> int { return static_cast<int>(finer_.size()); }
 	auto level(int l) -> Sim & { return l == 0 ? base_ : *finer_[l - 1]->sim; }
 	// amrex::average_down of an auxiliary cell-centred field living on the grids of levels crseLev + 1 and crseLev
 	void averageDownField(int crseLev, amrex::MultiFab const &fine, amrex::MultiFab &crse)
 	{
-		qkhost::check(qk_average_down(finer_[crseLev]->avgdown, nullptr, qkhost::tab(fine), qkhost::tab(crse), 0, crse.nComp()), "qk_average_down");
+		Finer &f = *finer_[crseLev];
+		if (f.shadow) { // averaged on the fine boxes' ranks, then to the owners of the coarse cells
+			amrex::MultiFab tmp(f.shadow->mine, crse.nComp(), 0);
+			qkhost::check(qk_average_down(f.avgdown, nullptr, qkhost::tab(fine), qkhost::tab(tmp), 0, crse.nComp()), "qk_average_down");
+			f.shadow->toParent(crse.nComp())(tmp, crse);
+			return;
+		}
+		qkhost::check(qk_average_down(f.avgdown, nullptr, qkhost::tab(fine), qkhost::tab(crse), 0, crse.nComp()), "qk_average_down");
 	}
 
 	// AmrCore::InitFromScratch + AverageDown (reference src/simulation.hpp:1656-1702)
@@ -82,7 +102,7 @@ template <typename problem_t, typename SimT> class AmrDriver
 			return;
 		}
 		for (int lev = 0; lev < max_level; ++lev) {
-			auto boxes = newGrids(lev, nullptr);
+			auto boxes = chop(lev + 1, newGrids(lev, nullptr));
 			if (boxes.empty()) {
 				break;
 			}
@@ -194,6 +214,17 @@ template <typename problem_t, typename SimT> class AmrDriver
 		amrex::Print() << "Performance figure-of-merit: " << us << " μs/zone-update [" << 1.0 / us << " Mupdates/s]\n";
 		for (int l = 0; l <= finestLevel(); ++l) {
 			amrex::Print() << "Zone-updates on level " << l << ": " << cellUpdatesEachLevel_[l] << " (" << level(l).allGrids_.size() << " grids)\n";
+			if (distLevels_ != 0) {
+				std::vector<int> per(static_cast<size_t>(qkhost::Comm::get().size), 0);
+				for (int const o : level(l).owner_) {
+					++per[static_cast<size_t>(o)];
+				}
+				amrex::Print() << "Boxes of level " << l << " per rank:";
+				for (int const n : per) {
+					amrex::Print() << " " << n;
+				}
+				amrex::Print() << "\n";
+			}
 		}
 		if (specOverlapped_ + specRolledBack_ > 0) {
 			amrex::Print() << "speculative coarse steps: overlapped=" << specOverlapped_ << " rolled_back=" << specRolledBack_ << "\n";
@@ -258,12 +289,156 @@ template <typename problem_t, typename SimT> class AmrDriver
 	}
 
       private:
+	// qk.distribute_levels: the coarse-level data a refined level needs and produces, on the FINE level's distribution — what AMReX builds inside
+	// FillPatchTwoLevels (the coarse patch under the fine boxes' ghost cells: ParallelCopy + the coarse physical boundary conditions, then interpolated
+	// locally), average_down (the coarsened fine MultiFab, then ParallelCopy to the coarse level) and YAFluxRegister (m_cfpatch).  Boxes: this rank's
+	// fine boxes coarsened; 3 ghost cells (2 under the fine ghost cells + 1 of interpolation stencil).  quokka_amd/amr_simulation.py CoarseShadow.
+	struct Shadow {
+		static constexpr int NG = 3;
+		Sim &parent;
+		qk_geometry gc;
+		std::vector<qk_box> boxes; // the fine boxes of ALL ranks, coarsened; owners: the fine level's
+		std::vector<int> owner;
+		std::vector<amrex::Box> mine;
+		std::vector<qk_box> mineQ;
+		qk_level *lev = nullptr;
+		qk_ghost_plan *bcPlan = nullptr; // the physical-boundary slabs of the coarse patch (the cbc of FillPatchTwoLevels)
+		amrex::MultiFab oldS, newS;
+		std::unique_ptr<qkhost::PcopyPlan> fromParent, fromParentWhole;
+		std::map<int, std::unique_ptr<qkhost::PcopyPlan>> toParent_; // by component count
+		typename Sim::BcShellCache bcShells;
+		// which version of the parent's states the copies hold (descriptor table of the source array, AMRSimulation::GhostFlag::version)
+		void const *srcOld = nullptr, *srcNew = nullptr;
+		std::uint64_t verOld = 0, verNew = 0;
+
+		Shadow(Sim &parent_, Sim &child) : parent(parent_), gc(qgeom(parent_.geom[0])), owner(child.owner_)
+		{
+			int const rank = qkhost::Comm::get().rank;
+			int const nc = parent.state_new_cc_[0].nComp();
+			std::vector<qk_box> holes;
+			for (size_t n = 0; n < child.allBoxes_.size(); ++n) {
+				qk_box c{}, h{};
+				for (int d = 0; d < 3; ++d) {
+					c.lo[d] = (d < AMREX_SPACEDIM) ? child.allBoxes_[n].lo[d] >> 1 : 0;
+					c.hi[d] = (d < AMREX_SPACEDIM) ? child.allBoxes_[n].hi[d] >> 1 : 0;
+					// ghost-cell interpolation reads the three ghost layers and the outermost valid layer of a shadow box, the reflecting boundary
+					// conditions of the ghost layers the three outermost valid layers: the rest is a hole in the plan
+					h.lo[d] = (d < AMREX_SPACEDIM) ? c.lo[d] + NG : 0;
+					h.hi[d] = (d < AMREX_SPACEDIM) ? c.hi[d] - NG : 0;
+				}
+				boxes.push_back(c);
+				holes.push_back(h);
+				if (owner[n] == rank) {
+					amrex::Box b;
+					for (int d = 0; d < 3; ++d) {
+						b.lo[d] = c.lo[d];
+						b.hi[d] = c.hi[d];
+					}
+					mine.push_back(b);
+					mineQ.push_back(c);
+				}
+			}
+			qk_box const none{};
+			qkhost::check(qk_level_create(qkhost::Runtime::get().ctx, &lev, AMREX_SPACEDIM, static_cast<int>(mineQ.size()), mineQ.empty() ? &none : mineQ.data()), "qk_level_create(shadow)");
+			oldS.define(mine, nc, NG);
+			newS.define(mine, nc, NG);
+			fromParent = std::make_unique<qkhost::PcopyPlan>(gc, parent.allBoxes_, parent.owner_, 0, false, boxes, owner, NG, &holes, nc);
+			fromParent->name = "shadow <- parent";
+			// (only its physical-boundary slabs are used; told the shadow boxes of every rank because a plan wants at least one box)
+			qkhost::check(qk_ghost_plan_create(lev, &bcPlan, &gc, NG, nc, static_cast<int>(boxes.size()), boxes.data(), owner.data(), rank), "qk_ghost_plan_create(shadow)");
+		}
+		Shadow(Shadow const &) = delete;
+		auto operator=(Shadow const &) -> Shadow & = delete;
+		~Shadow()
+		{
+			for (auto &kv : bcShells) {
+				(void)hipFree(kv.second.d);
+			}
+			qk_ghost_plan_destroy(bcPlan);
+			qk_level_destroy(lev);
+		}
+		auto toParent(int ncomp) -> qkhost::PcopyPlan &
+		{
+			auto &p = toParent_[ncomp];
+			if (!p) {
+				p = std::make_unique<qkhost::PcopyPlan>(gc, boxes, owner, 0, false, parent.allBoxes_, parent.owner_, 0, nullptr, ncomp);
+				p->name = "shadow -> parent (average down)";
+			}
+			return *p;
+		}
+		void fill(amrex::MultiFab &dst, amrex::MultiFab const &src, qkhost::PcopyPlan &plan, double time)
+		{
+			plan(src, dst);
+			if (!parent.geom[0].isAllPeriodic()) {
+				auto const bcs = parent.boundaryRecords();
+				qkhost::check(qk_FillPhysicalBoundary_subset(bcPlan, qkhost::Runtime::get().computeStream(), qkhost::tab(dst), bcs.data(), nullptr, QK_BOXES_ALL),
+					      "FillPhysicalBoundary(shadow)");
+				parent.customBoundaryConditionsOn(dst, QK_BOXES_ALL, bcPlan, parent.geom[0], bcShells, time);
+			}
+		}
+		// the parent's old / new state under this rank's fine boxes — fetched once per version of the parent's state
+		auto ensure(bool old) -> amrex::MultiFab &
+		{
+			amrex::MultiFab &src = old ? parent.state_old_cc_[0] : parent.state_new_cc_[0];
+			amrex::MultiFab &dst = old ? oldS : newS;
+			void const *&have = old ? srcOld : srcNew;
+			std::uint64_t &ver = old ? verOld : verNew;
+			if (have != static_cast<void const *>(src.arrays()) || ver != parent.newStateGhostsFilled_.version) {
+				fill(dst, src, *fromParent, old ? parent.tOldLev_ : parent.tNewLev_);
+				have = static_cast<void const *>(src.arrays());
+				ver = parent.newStateGhostsFilled_.version;
+			}
+			return dst;
+		}
+		// every cell of the grown shadow boxes from the parent's new state (a (re)made level interpolates all of its cells)
+		auto fillWholeNew() -> amrex::MultiFab &
+		{
+			if (!fromParentWhole) {
+				fromParentWhole = std::make_unique<qkhost::PcopyPlan>(gc, parent.allBoxes_, parent.owner_, 0, false, boxes, owner, NG, nullptr, newS.nComp());
+				fromParentWhole->name = "whole shadow <- parent";
+			}
+			fill(newS, parent.state_new_cc_[0], *fromParentWhole, parent.tNewLev_);
+			srcNew = nullptr;
+			return newS;
+		}
+	};
+	// the fine part of a distributed flux register (m_cfpatch): increments in the one-cell ghost ring of the shadow boxes, sent to the owners of the coarse cells
+	struct RingIncrement {
+		amrex::MultiFab inc;
+		std::unique_ptr<qkhost::PcopyPlan> toCrse;
+	};
 	struct Finer {
 		std::unique_ptr<Sim> sim;
 		qk_interp_plan *interp = nullptr;
 		qk_fluxreg *fluxreg = nullptr;
 		qk_fluxreg *fluxregRad = nullptr; // the radiation block of the state (expandFluxArrays, reference src/QuokkaSimulation.hpp:1758)
 		qk_avgdown_plan *avgdown = nullptr;
+		// qk.distribute_levels (quokka_amd/amr.py DistFluxRegister): fluxreg / fluxregRad above are the COARSE part (m_crse_data: lives with the coarse
+		// boxes, takes CrseAdd), these the FINE part (lives with the fine boxes, takes FineAdd, is saved / restored around retries); otherwise both
+		// names mean the one register
+		qk_fluxreg *fluxregFinePart = nullptr, *fluxregRadFinePart = nullptr;
+		qk_level *allFine = nullptr; // box metadata of the whole fine level (the coarse part is built against it)
+		std::unique_ptr<Shadow> shadow;
+		std::unique_ptr<RingIncrement> ring, ringRad;
+		[[nodiscard]] auto fineSide() const -> qk_fluxreg * { return fluxregFinePart != nullptr ? fluxregFinePart : fluxreg; }
+		[[nodiscard]] auto fineSideRad() const -> qk_fluxreg * { return fluxregRadFinePart != nullptr ? fluxregRadFinePart : fluxregRad; }
+		void dropPlans()
+		{
+			qk_interp_plan_destroy(interp);
+			qk_fluxreg_destroy(fluxreg);
+			qk_fluxreg_destroy(fluxregRad);
+			qk_fluxreg_destroy(fluxregFinePart);
+			qk_fluxreg_destroy(fluxregRadFinePart);
+			qk_avgdown_plan_destroy(avgdown);
+			qk_level_destroy(allFine);
+			interp = nullptr;
+			fluxreg = fluxregRad = fluxregFinePart = fluxregRadFinePart = nullptr;
+			avgdown = nullptr;
+			allFine = nullptr;
+			ring.reset();
+			ringRad.reset();
+			shadow.reset();
+		}
 		// several ranks: the reflux increments of the PARENT level (valid + 1 ghost cell: a register cell may belong to a neighbouring rank's box),
 		// folded onto their owners by SumBoundary over a 1-ghost plan of the parent's grids, then added to the parent's state
 		struct Fold {
@@ -273,13 +448,7 @@ template <typename problem_t, typename SimT> class AmrDriver
 			~Fold() { qk_ghost_plan_destroy(plan); }
 		};
 		std::unique_ptr<Fold> fold, foldRad;
-		~Finer()
-		{
-			qk_interp_plan_destroy(interp);
-			qk_fluxreg_destroy(fluxreg);
-			qk_fluxreg_destroy(fluxregRad);
-			qk_avgdown_plan_destroy(avgdown);
-		}
+		~Finer() { dropPlans(); }
 	};
 	Sim &base_;
 	std::vector<std::shared_ptr<Finer>> finerOwned_; // (shared: the snapshot of a speculative coarse step keeps the levels a regrid inside it replaces)
@@ -310,6 +479,20 @@ template <typename problem_t, typename SimT> class AmrDriver
 		return q;
 	}
 
+	// AmrMesh::ChopGrids: a level with fewer boxes than ranks is cut until every rank can own one (as far as the blocking factor allows)
+	auto chop(int lev, std::vector<amrex::Box> boxes) -> std::vector<amrex::Box>
+	{
+		int const target = (refineTarget_ > 0) ? refineTarget_ : (distLevels_ != 0 ? qkhost::Comm::get().size : 1);
+		if (target <= 1 || static_cast<int>(boxes.size()) >= target || boxes.empty()) {
+			return boxes;
+		}
+		std::array<int, 3> len{};
+		for (int d = 0; d < 3; ++d) {
+			len[d] = (d < AMREX_SPACEDIM) ? base_.geom[0].domain.length(d) * (1 << lev) : 1;
+		}
+		return qkhost::chopGrids(std::move(boxes), target, max_grid_size, blocking_factor, len, AMREX_SPACEDIM);
+	}
+
 	auto specFor(int lev, std::vector<amrex::Box> const &boxes) -> LevelSpec
 	{
 		LevelSpec s;
@@ -320,7 +503,17 @@ template <typename problem_t, typename SimT> class AmrDriver
 		}
 		s.boxes = boxes;
 		s.level = lev;
-		if (multi_) { // a box of level lev >= 1 lives on the rank of the level-0 box that contains it
+		if (distLevels_ != 0) { // the level's own map: space-filling curve over its boxes, the least loaded ranks (cells of the coarser levels) first
+			int const nranks = qkhost::Comm::get().size;
+			std::vector<long long> load(static_cast<size_t>(nranks), 0);
+			for (int l = 0; l < lev; ++l) {
+				Sim &L = level(l);
+				for (size_t n = 0; n < L.allGrids_.size(); ++n) {
+					load[static_cast<size_t>(L.owner_[n])] += L.allGrids_[n].numPts();
+				}
+			}
+			s.owner = qkhost::distributeSfc(boxes, nranks, load, blocking_factor);
+		} else if (multi_) { // a box of level lev >= 1 lives on the rank of the level-0 box that contains it
 			for (auto const &b : boxes) {
 				int owner = -1;
 				for (size_t n = 0; n < base_.allGrids_.size() && owner < 0; ++n) {
@@ -337,19 +530,17 @@ template <typename problem_t, typename SimT> class AmrDriver
 
 	void linkToParent(Finer &f, int lev)
 	{
-		qk_interp_plan_destroy(f.interp);
-		qk_fluxreg_destroy(f.fluxreg);
-		qk_fluxreg_destroy(f.fluxregRad);
-		qk_avgdown_plan_destroy(f.avgdown);
-		f.interp = nullptr;
-		f.fluxreg = nullptr;
-		f.fluxregRad = nullptr;
-		f.avgdown = nullptr;
+		f.dropPlans();
 		Sim &parent = level(lev - 1);
 		Sim &me = *f.sim;
 		int const ratio[3] = {2, 2, 2};
 		auto gf = qgeom(me.geom[0]);
 		auto gc = qgeom(parent.geom[0]);
+		if (distLevels_ != 0) {
+			linkToParentDistributed(f, parent, me, gf, gc);
+			installLevelHooks(f, lev);
+			return;
+		}
 		// several ranks: the plans are told the fine boxes of ALL ranks (a ghost cell under a remote fine box is filled by the fine-fine exchange;
 		// a register cell owned by another rank is kept in a ghost cell of a local coarse box)
 		int const nAll = multi_ ? static_cast<int>(me.allBoxes_.size()) : 0;
@@ -381,6 +572,40 @@ template <typename problem_t, typename SimT> class AmrDriver
 				qkhost::check(qk_fluxreg_set_state_component(f.fluxregRad, RadSystem<problem_t>::nstartHyperbolic_), "qk_fluxreg_set_state_component");
 			}
 		}
+		installLevelHooks(f, lev);
+	}
+
+	// the plans between a level and its parent when both have their own box -> rank map (quokka_amd/amr_simulation.py AmrLevelSim.link_to_parent)
+	void linkToParentDistributed(Finer &f, Sim &parent, Sim &me, qk_geometry const &gf, qk_geometry const &gc)
+	{
+		int const ratio[3] = {2, 2, 2};
+		f.shadow = std::make_unique<Shadow>(parent, me);
+		Shadow &sh = *f.shadow;
+		int const nAll = static_cast<int>(me.allBoxes_.size());
+		qk_box const *all = me.allBoxes_.data();
+		qkhost::check(qk_interp_plan_create(sh.lev, me.levelHandle(), &gf, me.nghost_cc_, ratio, 0, nAll, all, &f.interp), "qk_interp_plan_create");
+		qkhost::check(qk_avgdown_plan_create(sh.lev, me.levelHandle(), ratio, &f.avgdown), "qk_avgdown_plan_create");
+		qkhost::check(qk_level_create(qkhost::Runtime::get().ctx, &f.allFine, AMREX_SPACEDIM, nAll, all), "qk_level_create(all fine boxes)");
+		auto makeRegister = [&](int ncomp, qk_fluxreg **crsePart, qk_fluxreg **finePart) {
+			qkhost::check(qk_fluxreg_create_crse_part(parent.levelHandle(), f.allFine, &gc, ratio, ncomp, crsePart), "qk_fluxreg_create_crse_part");
+			qkhost::check(qk_fluxreg_create(sh.lev, me.levelHandle(), &gc, ratio, ncomp, nAll, all, 1, finePart), "qk_fluxreg_create(fine part)");
+			auto r = std::make_unique<RingIncrement>();
+			r->inc.define(sh.mine, ncomp, 1);
+			r->toCrse = std::make_unique<qkhost::PcopyPlan>(gc, sh.boxes, sh.owner, 1, true, parent.allBoxes_, parent.owner_, 0, nullptr, ncomp);
+			r->toCrse->name = "register ring -> coarse owners";
+			return r;
+		};
+		f.ring = makeRegister(Sim::ncompHydro_, &f.fluxreg, &f.fluxregFinePart);
+		if constexpr (Physics_Traits<problem_t>::is_radiation_enabled) {
+			f.ringRad = makeRegister(RadSystem<problem_t>::nvarHyperbolic_, &f.fluxregRad, &f.fluxregRadFinePart);
+			qkhost::check(qk_fluxreg_set_state_component(f.fluxregRad, RadSystem<problem_t>::nstartHyperbolic_), "qk_fluxreg_set_state_component");
+		}
+	}
+
+	void installLevelHooks(Finer &f, int lev)
+	{
+		Sim &parent = level(lev - 1);
+		Sim &me = *f.sim;
 		Finer *fp = &f;
 		// FillPatchTwoLevels: the ghost cells no fine box covers come from the parent, interpolated in space and time
 		me.beforePhysBC_ = [this, fp, lev](amrex::MultiFab &state) { interpFromParent(*fp, lev, state, fp->sim->fillTime_, fp->interp); };
@@ -418,20 +643,23 @@ template <typename problem_t, typename SimT> class AmrDriver
 					qkhost::check(qk_fluxreg_CrseAdd(finer_[lev]->fluxregRad, nullptr, f, dx, 0.5 * dt_radiation), "qk_fluxreg_CrseAdd(rad)");
 				}
 				if (lev > 0 && finer_[lev - 1]->fluxregRad != nullptr) {
-					qkhost::check(qk_fluxreg_FineAdd(finer_[lev - 1]->fluxregRad, nullptr, f, dx, 0.5 * dt_radiation), "qk_fluxreg_FineAdd(rad)");
+					qkhost::check(qk_fluxreg_FineAdd(finer_[lev - 1]->fineSideRad(), nullptr, f, dx, 0.5 * dt_radiation), "qk_fluxreg_FineAdd(rad)");
 				}
 			};
 		}
 	}
 
-	void interpFromParent(Finer & /*f*/, int lev, amrex::MultiFab &state, double time, qk_interp_plan *plan)
+	void interpFromParent(Finer &f, int lev, amrex::MultiFab &state, double time, qk_interp_plan *plan)
 	{
 		Sim &p = level(lev - 1);
 		double const t0 = p.tOldLev_, t1 = p.tNewLev_;
 		double const eps = 1.0e-10 * std::max(std::abs(t1 - t0), 1.0e-300);
 		auto *fs = qkhost::tab(state);
-		auto *pn = qkhost::tab(p.state_new_cc_[0]);
-		auto *po = qkhost::tab(p.state_old_cc_[0]);
+		bool const atNew = std::abs(time - t1) <= eps || t1 == t0;
+		bool const atOld = !atNew && std::abs(time - t0) <= eps;
+		// distributed levels: the parent's states as this rank's copy under its fine boxes (same values: the same interpolated bits)
+		auto *pn = (f.shadow && !atOld) ? qkhost::tab(f.shadow->ensure(false)) : qkhost::tab(p.state_new_cc_[0]);
+		auto *po = (f.shadow && !atNew) ? qkhost::tab(f.shadow->ensure(true)) : qkhost::tab(p.state_old_cc_[0]);
 		int const nc = Physics_Indices<problem_t>::nvarTotal_cc; // hydro + radiation blocks
 		int const hooks = Sim::isAdvection ? 0 : 1;		 // PreInterpState / PostInterpState: the hydro energy (InterpHookNone for the scalar)
 		if (std::abs(time - t1) <= eps || t1 == t0) {
@@ -453,10 +681,11 @@ template <typename problem_t, typename SimT> class AmrDriver
 			return;
 		}
 		if (lev > 0 && finer_[lev - 1] && finer_[lev - 1]->fluxreg != nullptr) {
-			qkhost::check(retry == 0 ? qk_fluxreg_save(finer_[lev - 1]->fluxreg, nullptr) : qk_fluxreg_restore(finer_[lev - 1]->fluxreg, nullptr), "qk_fluxreg_save/restore");
+			qk_fluxreg *fine = finer_[lev - 1]->fineSide();
+			qkhost::check(retry == 0 ? qk_fluxreg_save(fine, nullptr) : qk_fluxreg_restore(fine, nullptr), "qk_fluxreg_save/restore");
 		}
 		if (retry > 0 && lev < finestLevel() && finer_[lev] && finer_[lev]->fluxreg != nullptr) {
-			qkhost::check(qk_fluxreg_reset(finer_[lev]->fluxreg, nullptr), "qk_fluxreg_reset");
+			resetRegister(*finer_[lev], false);
 		}
 	}
 
@@ -482,7 +711,17 @@ template <typename problem_t, typename SimT> class AmrDriver
 			qkhost::check(qk_fluxreg_CrseAdd(finer_[lev]->fluxreg, nullptr, f, dx, dt), "qk_fluxreg_CrseAdd");
 		}
 		if (lev > 0) {
-			qkhost::check(qk_fluxreg_FineAdd(finer_[lev - 1]->fluxreg, nullptr, f, dx, dt), "qk_fluxreg_FineAdd");
+			qkhost::check(qk_fluxreg_FineAdd(finer_[lev - 1]->fineSide(), nullptr, f, dx, dt), "qk_fluxreg_FineAdd");
+		}
+	}
+	// both parts of a level's register (one register unless the levels are distributed)
+	void resetRegister(Finer &f, bool radiation)
+	{
+		qk_fluxreg *crse = radiation ? f.fluxregRad : f.fluxreg;
+		qk_fluxreg *fine = radiation ? f.fluxregRadFinePart : f.fluxregFinePart;
+		qkhost::check(qk_fluxreg_reset(crse, nullptr), "qk_fluxreg_reset");
+		if (fine != nullptr) {
+			qkhost::check(qk_fluxreg_reset(fine, nullptr), "qk_fluxreg_reset(fine part)");
 		}
 	}
 
@@ -752,6 +991,9 @@ template <typename problem_t, typename SimT> class AmrDriver
 			newBoxes[lev + 1] = newGrids(lev, (lev + 2 <= max_level) ? finerB : nullptr, baseLev);
 			finerB = newBoxes[lev + 1].empty() ? nullptr : &newBoxes[lev + 1];
 		}
+		for (int lev = baseLev + 1; lev <= max_level; ++lev) { // (after the nesting footprints: they follow from the clustered boxes)
+			newBoxes[lev] = chop(lev, std::move(newBoxes[lev]));
+		}
 		for (int lev = baseLev + 1; lev <= max_level; ++lev) {
 			auto const &boxes = newBoxes[lev];
 			if (boxes.empty()) {
@@ -770,17 +1012,31 @@ template <typename problem_t, typename SimT> class AmrDriver
 			makeLevel(lev, boxes);
 			Sim &me = level(lev);
 			Sim &parent = level(lev - 1);
-			fillGhosts(lev - 1, parent.state_new_cc_[0], parent.tNewLev_);
+			Shadow *sh = finer_[lev - 1]->shadow.get();
 			int const ratio[3] = {2, 2, 2};
 			auto gf = qgeom(me.geom[0]);
 			qk_interp_plan *whole = nullptr;
-			qkhost::check(qk_interp_plan_create(parent.levelHandle(), me.levelHandle(), &gf, me.nghost_cc_, ratio, 1, 0, nullptr, &whole), "qk_interp_plan_create(whole)");
-			auto *pn = qkhost::tab(parent.state_new_cc_[0]);
+			// distributed levels: the parent's cells under the new boxes arrive in the shadow (with the coarse physical boundaries); the old level's
+			// cells from their owners
+			amrex::MultiFab *crse = &parent.state_new_cc_[0];
+			if (sh != nullptr) {
+				crse = &sh->fillWholeNew();
+			} else {
+				fillGhosts(lev - 1, parent.state_new_cc_[0], parent.tNewLev_);
+			}
+			qkhost::check(qk_interp_plan_create(sh != nullptr ? sh->lev : parent.levelHandle(), me.levelHandle(), &gf, me.nghost_cc_, ratio, 1, 0, nullptr, &whole),
+				      "qk_interp_plan_create(whole)");
+			auto *pn = qkhost::tab(*crse);
 			qkhost::check(qk_InterpFromCoarse(whole, nullptr, qkhost::tab(me.state_new_cc_[0]), pn, pn, 1.0, 0.0, Physics_Indices<problem_t>::nvarTotal_cc, amrInterpMethod_,
 							  Sim::isAdvection ? 0 : 1),
 				      "qk_InterpFromCoarse(whole)");
 			qk_interp_plan_destroy(whole);
-			if (old) { // keep the old fine data where the new level still covers it
+			if (old && sh != nullptr) {
+				Sim &o = *old->sim;
+				qkhost::PcopyPlan keep(gf, o.allBoxes_, o.owner_, 0, false, me.allBoxes_, me.owner_, 0, nullptr, me.state_new_cc_[0].nComp());
+				keep.name = "old level -> new level";
+				keep(o.state_new_cc_[0], me.state_new_cc_[0]);
+			} else if (old) { // keep the old fine data where the new level still covers it
 				Sim &o = *old->sim;
 				for (int sb = 0; sb < o.state_new_cc_[0].size(); ++sb) {
 					for (int db = 0; db < me.state_new_cc_[0].size(); ++db) {
@@ -820,8 +1076,18 @@ template <typename problem_t, typename SimT> class AmrDriver
 	// flux_reg_[lev+1]->Reflux(state_new_cc_[lev]) (reference src/simulation.hpp:1308).  One rank: straight into the state.  Several ranks: the
 	// increments land in a zeroed array with one ghost cell, SumBoundary carries them to their owners (the strips travel in the opposite
 	// direction of a ghost fill: receive buffers are sent, send buffers receive), then state(comp0 + n) += increment(n)
-	void reflux(Sim &S, qk_fluxreg *reg, typename Finer::Fold *fold, int comp0)
+	void reflux(Sim &S, qk_fluxreg *reg, typename Finer::Fold *fold, int comp0, qk_fluxreg *finePart = nullptr, RingIncrement *ring = nullptr)
 	{
+		if (ring != nullptr) { // distributed levels (quokka_amd/amr.py DistFluxRegister.Reflux): the coarse part goes straight into the local state, the
+			// fine part travels from the fine boxes' ranks to the owners of the coarse cells (ParallelAdd)
+			S.activate();
+			hipStream_t const cs = qkhost::Runtime::get().computeStream();
+			qkhost::check(qk_fluxreg_Reflux(reg, cs, qkhost::tab(S.state_new_cc_[0])), "qk_fluxreg_Reflux(coarse part)");
+			ring->inc.setZeroAsync(cs);
+			qkhost::check(qk_fluxreg_Reflux(finePart, cs, qkhost::tab(ring->inc)), "qk_fluxreg_Reflux(fine part)");
+			(*ring->toCrse)(ring->inc, S.state_new_cc_[0], 0, comp0, true);
+			return;
+		}
 		if (fold == nullptr) {
 			qkhost::check(qk_fluxreg_Reflux(reg, nullptr, qkhost::tab(S.state_new_cc_[0])), "qk_fluxreg_Reflux");
 			return;
@@ -852,8 +1118,14 @@ template <typename problem_t, typename SimT> class AmrDriver
 	{
 		Sim &f = level(crseLev + 1);
 		Sim &c = level(crseLev);
-		qkhost::check(qk_average_down(finer_[crseLev]->avgdown, nullptr, qkhost::tab(f.state_new_cc_[0]), qkhost::tab(c.state_new_cc_[0]), 0, Physics_Indices<problem_t>::nvarTotal_cc),
-			      "qk_average_down");
+		int const nc = Physics_Indices<problem_t>::nvarTotal_cc;
+		if (Shadow *sh = finer_[crseLev]->shadow.get()) { // averaged on the fine boxes' ranks, then to the owners of the coarse cells
+			qkhost::check(qk_average_down(finer_[crseLev]->avgdown, nullptr, qkhost::tab(f.state_new_cc_[0]), qkhost::tab(sh->newS), 0, nc), "qk_average_down");
+			sh->srcNew = nullptr; // (the copy of the parent's new state is gone)
+			sh->toParent(nc)(sh->newS, c.state_new_cc_[0]);
+			return;
+		}
+		qkhost::check(qk_average_down(finer_[crseLev]->avgdown, nullptr, qkhost::tab(f.state_new_cc_[0]), qkhost::tab(c.state_new_cc_[0]), 0, nc), "qk_average_down");
 	}
 
 	// reference src/simulation.hpp:744-818 with do_subcycle = 1
@@ -923,7 +1195,7 @@ template <typename problem_t, typename SimT> class AmrDriver
 			return false;
 		} else {
 			Sim &L = level(lev);
-			if (overlapChildren_ == 0 || lev != 0 || multi_ || lev >= finestLevel() || do_reflux == 0 || !L.canSpeculate() || L.grids_.size() < 2) {
+			if (overlapChildren_ == 0 || lev != 0 || multi_ || distLevels_ != 0 || lev >= finestLevel() || do_reflux == 0 || !L.canSpeculate() || L.grids_.size() < 2) {
 				return false;
 			}
 			amrex::Long fine = 0;
@@ -1080,9 +1352,9 @@ template <typename problem_t, typename SimT> class AmrDriver
 		S.tOldLev_ = S.tNewLev_;
 		S.tNewLev_ += dt_[lev];
 		if (do_reflux != 0 && lev < finestLevel()) {
-			qkhost::check(qk_fluxreg_reset(finer_[lev]->fluxreg, nullptr), "qk_fluxreg_reset");
+			resetRegister(*finer_[lev], false);
 			if (finer_[lev]->fluxregRad != nullptr) {
-				qkhost::check(qk_fluxreg_reset(finer_[lev]->fluxregRad, nullptr), "qk_fluxreg_reset(rad)");
+				resetRegister(*finer_[lev], true);
 			}
 		}
 		S.newStateGhostsFilled_ = false; // (the advance swaps the states and writes the new one)
@@ -1165,10 +1437,11 @@ template <typename problem_t, typename SimT> class AmrDriver
 			if (lev < finestLevel()) {
 				Phase const ph(*this, "reflux + average down + fixup");
 				if (do_reflux != 0) {
-					reflux(S, finer_[lev]->fluxreg, finer_[lev]->fold.get(), 0);
-					if (finer_[lev]->fluxregRad != nullptr) {
+					Finer &fc = *finer_[lev];
+					reflux(S, fc.fluxreg, fc.fold.get(), 0, fc.fluxregFinePart, fc.ring.get());
+					if (fc.fluxregRad != nullptr) {
 						if constexpr (Physics_Traits<problem_t>::is_radiation_enabled) {
-							reflux(S, finer_[lev]->fluxregRad, finer_[lev]->foldRad.get(), RadSystem<problem_t>::nstartHyperbolic_);
+							reflux(S, fc.fluxregRad, fc.foldRad.get(), RadSystem<problem_t>::nstartHyperbolic_, fc.fluxregRadFinePart, fc.ringRad.get());
 						}
 					}
 				}

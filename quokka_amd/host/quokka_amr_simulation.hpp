@@ -284,6 +284,12 @@ template <typename problem_t> class AMRSimulation
 			qk_level_destroy(myLev_);
 		}
 	}
+	struct BcShellList {
+		qkhost::BcShell *d = nullptr;
+		int count = 0;
+		amrex::Long most = 0;
+	};
+	using BcShellCache = std::map<std::pair<int, int>, BcShellList>;
 	// the static operators (HydroSystem<problem_t>::..., RadSystem<problem_t>::...) act on the active level
 	void activate() const { qkhost::Runtime::get().lev = myLev_; }
 	[[nodiscard]] auto levelHandle() const -> qk_level * { return myLev_; }
@@ -560,6 +566,7 @@ template <typename problem_t> class AMRSimulation
 		amrex::MultiFab::Copy(state_old_cc_[0], state_new_cc_[0]);
 		setInitialConditionsAtLevel_fc();
 		areInitialConditionsDefined_ = true;
+		newStateGhostsFilled_ = false;
 	}
 
 	// fillBoundaryConditions for the radiation transport kernels, which read only the radiation components of the ghost cells
@@ -569,6 +576,18 @@ template <typename problem_t> class AMRSimulation
 		qkhost::check(qk_ghost_plan_set_components(plan_, first, state.nComp() - first), "qk_ghost_plan_set_components");
 		fillBoundaryConditions(state);
 		qkhost::check(qk_ghost_plan_set_components(plan_, 0, -1), "qk_ghost_plan_set_components");
+	}
+	// BCs_cc_ as the C-ABI takes them
+	[[nodiscard]] auto boundaryRecords() const -> std::vector<qk_bcrec>
+	{
+		std::vector<qk_bcrec> bcs(BCs_cc_.size());
+		for (size_t n = 0; n < BCs_cc_.size(); ++n) {
+			for (int d = 0; d < 3; ++d) {
+				bcs[n].lo[d] = (d < AMREX_SPACEDIM) ? BCs_cc_[n].lo(d) : 0;
+				bcs[n].hi[d] = (d < AMREX_SPACEDIM) ? BCs_cc_[n].hi(d) : 0;
+			}
+		}
+		return bcs;
 	}
 	// level-0 branch of fillBoundaryConditions (reference src/simulation.hpp:1751-1776).
 	// `between` (optional; the multi-GPU schedule of north_star): called while the strips of the other ranks are on the wire — RCCL moves them on
@@ -587,13 +606,7 @@ template <typename problem_t> class AMRSimulation
 		qkhost::Comm::get().exchangeBegin(peers_.peer, peers_.send, peers_.nsend, peers_.recv, peers_.nrecv, sizeof(double), cs);
 		qkhost::check(qk_FillBoundary_local(plan_, cs, qkhost::tab(state)), "FillBoundary");
 		bool const physical = !geom[0].isAllPeriodic();
-		std::vector<qk_bcrec> bcs(BCs_cc_.size());
-		for (size_t n = 0; n < BCs_cc_.size(); ++n) {
-			for (int d = 0; d < 3; ++d) {
-				bcs[n].lo[d] = (d < AMREX_SPACEDIM) ? BCs_cc_[n].lo(d) : 0;
-				bcs[n].hi[d] = (d < AMREX_SPACEDIM) ? BCs_cc_[n].hi(d) : 0;
-			}
-		}
+		auto const bcs = boundaryRecords();
 		auto physbc = [&](int which) {
 			if (physical) {
 				qkhost::check(qk_FillPhysicalBoundary_subset(plan_, cs, qkhost::tab(state), bcs.data(), nullptr, which), "FillPhysicalBoundary");
@@ -623,13 +636,7 @@ template <typename problem_t> class AMRSimulation
 		if (geom[0].isAllPeriodic()) {
 			return;
 		}
-		std::vector<qk_bcrec> bcs(BCs_cc_.size());
-		for (size_t n = 0; n < BCs_cc_.size(); ++n) {
-			for (int d = 0; d < 3; ++d) {
-				bcs[n].lo[d] = (d < AMREX_SPACEDIM) ? BCs_cc_[n].lo(d) : 0;
-				bcs[n].hi[d] = (d < AMREX_SPACEDIM) ? BCs_cc_[n].hi(d) : 0;
-			}
-		}
+		auto const bcs = boundaryRecords();
 		qkhost::check(qk_FillPhysicalBoundary_subset(plan_, qkhost::Runtime::get().computeStream(), qkhost::tab(state), bcs.data(), nullptr, which), "FillPhysicalBoundary");
 		customBoundaryConditionsOnDevice(state, which);
 	}
@@ -655,6 +662,12 @@ template <typename problem_t> class AMRSimulation
 	// Dirichlet / Marshak set of the C-ABI (which host-mode problems are sampled into).
 	void customBoundaryConditionsOnDevice(amrex::MultiFab &state, int which = QK_BOXES_ALL)
 	{
+		customBoundaryConditionsOn(state, which, plan_, geom[0], bcShells_, bcFillTime());
+	}
+	// ... on any array of cells of a level with geometry `g` (this level's own state, or the coarse patch a child on another rank keeps of it:
+	// AmrDriver::Shadow, whose slab lists live in `cache`)
+	void customBoundaryConditionsOn(amrex::MultiFab &state, int which, qk_ghost_plan *plan, amrex::Geometry const &g, BcShellCache &cache, double time)
+	{
 		if (customBcIsDefault_ == 1) {
 			return; // the hook is the default (an empty body): known since the first fill
 		}
@@ -662,23 +675,23 @@ template <typename problem_t> class AMRSimulation
 			QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&d_bcrec_), sizeof(amrex::BCRec) * BCs_cc_.size()));
 			QK_HOST_HIP(hipMemcpy(d_bcrec_, BCs_cc_.data(), sizeof(amrex::BCRec) * BCs_cc_.size(), hipMemcpyHostToDevice));
 		}
-		auto const gd = geom[0].data();
+		auto const gd = g.data();
 		// The slabs of ghost cells beyond the non-periodic faces, disjoint (x slabs over the whole y-z extent of the fab, y slabs over the x range
 		// inside the domain, z slabs over the x and y ranges inside), listed once per ghost width and box group: every cell-centred array of a
 		// level has the same boxes.  It was one whole-fab launch per box and fill (62 per coarse step of the config-5 hierarchy, each testing
 		// 2.5 M cells to find 0.3 M).
 		auto const key = std::make_pair(state.nGrow(), which);
-		auto it = bcShells_.find(key);
-		if (it == bcShells_.end()) {
+		auto it = cache.find(key);
+		if (it == cache.end()) {
 			std::vector<qkhost::BcShell> h;
 			amrex::Long most = 0;
 			for (int b = 0; b < state.size(); ++b) {
-				if (which != QK_BOXES_ALL && (qk_ghost_plan_box_is_remote(plan_, b) == 1) != (which == QK_BOXES_REMOTE_DEPENDENT)) {
+				if (which != QK_BOXES_ALL && (qk_ghost_plan_box_is_remote(plan, b) == 1) != (which == QK_BOXES_REMOTE_DEPENDENT)) {
 					continue; // the other group of an overlapped fill
 				}
 				amrex::Box rest = state.fabbox(b);
 				for (int d = 0; d < AMREX_SPACEDIM; ++d) {
-					if (geom[0].isPeriodic(d)) {
+					if (g.isPeriodic(d)) {
 						continue;
 					}
 					for (int side = 0; side < 2; ++side) {
@@ -705,7 +718,7 @@ template <typename problem_t> class AMRSimulation
 				QK_HOST_HIP(hipMalloc(reinterpret_cast<void **>(&l.d), sizeof(qkhost::BcShell) * h.size()));
 				QK_HOST_HIP(hipMemcpy(l.d, h.data(), sizeof(qkhost::BcShell) * h.size(), hipMemcpyHostToDevice));
 			}
-			it = bcShells_.emplace(key, l).first;
+			it = cache.emplace(key, l).first;
 		}
 		auto const &l = it->second;
 		if (l.count == 0) {
@@ -717,7 +730,7 @@ template <typename problem_t> class AMRSimulation
 			QK_HOST_HIP(hipMemcpyToSymbol(HIP_SYMBOL(qkhost::g_defaultCustomBcRan), &zero, sizeof(int)));
 		}
 		hipLaunchKernelGGL(qkhost::customBcKernel<problem_t>, dim3(static_cast<unsigned>((l.most + 255) / 256), static_cast<unsigned>(l.count)), dim3(256), 0,
-				   qkhost::Runtime::get().computeStream(), l.d, state.arrays(), gd, bcFillTime(), d_bcrec_, state.nComp());
+				   qkhost::Runtime::get().computeStream(), l.d, state.arrays(), gd, time, d_bcrec_, state.nComp());
 		if (customBcIsDefault_ < 0) { // first launch: did the default body run?
 			int ran = 0;
 			QK_HOST_HIP(hipStreamSynchronize(qkhost::Runtime::get().computeStream()));
@@ -726,19 +739,29 @@ template <typename problem_t> class AMRSimulation
 		}
 	}
 	int customBcIsDefault_ = -1; // -1 unknown, 0 the problem specialised setCustomBoundaryConditions, 1 it is the empty default
-	struct BcShellList {
-		qkhost::BcShell *d = nullptr;
-		int count = 0;
-		amrex::Long most = 0;
-	};
-	std::map<std::pair<int, int>, BcShellList> bcShells_; // (ghost width, box group) -> slabs; lives as long as the level object
+	BcShellCache bcShells_; // (ghost width, box group) -> slabs; lives as long as the level object
 	amrex::BCRec *d_bcrec_ = nullptr;
 	[[nodiscard]] virtual auto bcFillTime() const -> double { return tNew_[0]; }
 	// set by a level's advance when the ghost cells of state_old_cc_ hold the fill at the old time already (AmrDriver then skips its own fill of
 	// the old state before the children interpolate from it)
 	bool oldStateGhostsFilled_ = false;
-	// the ghost cells of state_new_cc_ hold the fill at the level's new time (set by AmrDriver::fillGhosts, cleared by whatever writes the state)
-	bool newStateGhostsFilled_ = false;
+	// the ghost cells of state_new_cc_ hold the fill at the level's new time (set by AmrDriver::fillGhosts, cleared by whatever writes the state).
+	// Every clearing also counts a new VERSION of the level's states: the copies of them that the children of a hierarchy with distributed levels
+	// keep on their own ranks (AmrDriver::Shadow) are fetched once per version.
+	struct GhostFlag {
+		bool filled = false;
+		std::uint64_t version = 0;
+		auto operator=(bool v) -> GhostFlag &
+		{
+			filled = v;
+			if (!v) {
+				++version;
+			}
+			return *this;
+		}
+		operator bool() const { return filled; } // NOLINT
+	};
+	GhostFlag newStateGhostsFilled_;
 
       protected:
 	qk_level *myLev_ = nullptr;

@@ -473,3 +473,55 @@ def test_sedov_on_several_gpus_over_rccl(tmp_path):
         chunk = parts[r][cursor[r]:cursor[r] + 6 * 32 ** 3].reshape(6, 32, 32, 32)
         cursor[r] += 6 * 32 ** 3
         assert np.array_equal(chunk, one[b]), (b, r)
+
+
+def _level0_state_by_box(parts, owner, nb, n3, mgs):
+    """per-rank dumps (this rank's level-0 boxes in global order) -> one array indexed by global box"""
+    out = np.empty((nb, 6, mgs, mgs, mgs))
+    cursor = [0] * len(parts)
+    for b, r in enumerate(owner):
+        out[b] = parts[r][cursor[r]:cursor[r] + 6 * n3].reshape(6, mgs, mgs, mgs)
+        cursor[r] += 6 * n3
+    assert all(cursor[r] == parts[r].size for r in range(len(parts)))
+    return out
+
+
+@pytest.mark.parametrize("nranks", [2, 4, 8])
+def test_amr_levels_with_their_own_distribution_in_the_cxx_host(tmp_path, nranks):
+    """qk.distribute_levels = 1 (quokka_amr.hpp Shadow / RingIncrement, qk_pcopy.hpp, qk_grid_layout.hpp): every level of the three-level Sedov
+    hierarchy has its own box -> rank map — grids clustered globally as with one rank, a level with fewer boxes than ranks chopped (AMReX's
+    refine_grid_layout), boxes dealt along the space-filling curve to the least loaded ranks —, the parent's data reach the fine boxes, averaged-down
+    and refluxed data the coarse boxes through ParallelCopy plans.  Against ONE rank chopping for the same box count, in the ordinary data path
+    and in the distributed one (every plan then has same-rank items only): same grids, zone updates, time steps; level-0 state (which holds the
+    averages of every finer level) to rounding — the two parts of a flux register are added one after the other —; energy conserved; the finer
+    levels live on more than one rank."""
+    import re
+    from quokka_amd.simulation import chop_domain, distribute_boxes
+    mgs = 16
+    args = ["geometry.prob_lo=0 0 0", "geometry.prob_hi=1.2 1.2 1.2", "geometry.is_periodic=0 0 0", "amr.n_cell=32 32 32", f"amr.max_grid_size={mgs}",
+            "amr.max_level=2", "amr.blocking_factor=8", "amr.n_error_buf=3", "do_reflux=1", "max_timesteps=8", f"qk.refine_grid_layout_target={nranks}"]
+    for sub in ("a", "b", "c"):
+        os.makedirs(tmp_path / sub)
+    (one,), outs1 = run_ranks("ref_HydroBlast3D", args, tmp_path / "a", 1, 29811)
+    (shadowed,), outs2 = run_ranks("ref_HydroBlast3D", args + ["qk.distribute_levels=1"], tmp_path / "b", 1, 29813)
+    parts, outs = run_ranks("ref_HydroBlast3D", args + ["qk.distribute_levels=1", "qk.level0_distribution=bricks"], tmp_path / "c", nranks, 29815 + nranks)
+    zone = re.compile(r"Zone-updates on level (\d): (\d+) \((\d+) grids\)")
+    z1 = zone.findall(outs1[0])
+    assert len(z1) == 3 and zone.findall(outs[0]) == z1 and zone.findall(outs2[0]) == z1, (zone.findall(outs[0]), zone.findall(outs2[0]), z1)
+    assert int(z1[1][2]) >= 2 and int(z1[2][2]) >= 2, z1  # chopped (as far as the blocking factor allows: the refined region is 16^3 - 32^3 cells wide)
+    per = {int(l): [int(x) for x in c.split()] for l, c in re.findall(r"Boxes of level (\d) per rank:((?: \d+)+)", outs[0])}
+    assert set(per) == {0, 1, 2} and all(len(per[l]) == nranks for l in per)
+    assert all(sum(1 for n in per[l] if n > 0) > 1 for l in (1, 2)), per
+    boxes = chop_domain([32, 32, 32], [mgs] * 3)
+    owner = distribute_boxes(boxes, nranks, [32, 32, 32], [mgs] * 3)
+    nb, n3 = len(boxes), mgs ** 3
+    one = one.reshape(nb, 6, mgs, mgs, mgs)
+    shadowed = shadowed.reshape(nb, 6, mgs, mgs, mgs)
+    many = _level0_state_by_box(parts, owner, nb, n3, mgs)
+    for name, got in (("one rank, distributed data path", shadowed), (f"{nranks} ranks", many)):
+        worst = max(float(np.abs(got[:, n] - one[:, n]).max() / np.abs(one[:, n]).max()) for n in range(6))
+        assert worst <= 1e-13, (name, worst)
+    for o in (outs1[0], outs2[0], outs[0]):
+        assert "Energy conservation is OK." in o
+    metas = [open(str(tmp_path / d / f) + ".meta").read().split()[:3] for d, f in (("a", "state_n1_shm.bin"), ("b", "state_n1_shm.bin"), ("c", f"state_n{nranks}_shm.bin.rank0"))]
+    assert metas[0] == metas[1] == metas[2], metas  # steps, time, dt
