@@ -50,7 +50,8 @@ template <typename problem_t, typename SimT> class AmrDriver
 		pp.query("grid_eff", grid_eff);
 		multi_ = qkhost::Comm::get().size > 1;
 		amrex::ParmParse pq("qk");
-		pq.query("distribute_levels", distLevels_);		      // every level with its own box -> rank map (any number of ranks: one rank runs the same plans)
+		distLevels_ = multi_ ? 1 : 0; // several ranks: every level with its own box -> rank map, as AMReX distributes them (0: refined boxes stay on the rank
+		pq.query("distribute_levels", distLevels_); // of their level-0 ancestor — the round-5 scheme; 1 on one rank: the same plans, same-rank items only)
 		pq.query("refine_grid_layout_target", refineTarget_); // (tests: one rank building the grids N ranks build)
 		clusterWithinParent_ = (multi_ && distLevels_ == 0) ? 1 : 0;
 		pq.query("cluster_within_parent", clusterWithinParent_); // (tests: one rank building the grids several ranks build)
@@ -1421,8 +1422,9 @@ template <typename problem_t, typename SimT> class AmrDriver
 		cellUpdates_ += S.CountCells(0);
 		cellUpdatesEachLevel_[lev] += S.CountCells(0);
 		if (lev < finestLevel()) {
-			// the children interpolate their ghost cells from this level's old and new states: both need their own ghost cells
-			{
+			// the children interpolate their ghost cells from this level's old and new states: both need their own ghost cells (distributed levels:
+			// the children fetch this level's VALID cells into their shadows and apply the physical boundaries there — nothing to fill here)
+			if (distLevels_ == 0) {
 				Phase const ph(*this, "parent ghost fills");
 				if (!S.oldStateGhostsFilled_) { // (a direct hydro advance filled them in its first stage, at the same time from the same parent data)
 					fillGhosts(lev, S.state_old_cc_[0], S.tOldLev_);

@@ -276,11 +276,15 @@ def test_contact_wave_executable_error_is_exactly_zero(tmp_path):
     assert not U[1:4].any() and not U[6:].any() and np.array_equal(U[4], U[5])
 
 
+_RENDEZVOUS = __import__("itertools").count()
+
+
 def run_ranks(name, args, tmp_path, nranks, port, backend="shm"):
     """N processes of one executable sharing this GPU: the multi-rank layer of the host mirror (quokka_amd/host/qk_comm.hpp) with its test
     transport (QK_COMM_BACKEND=shm: buffers staged through the host; RCCL refuses two ranks on one device).  Returns the per-rank dumps."""
     dump = str(tmp_path / f"state_n{nranks}_{backend}.bin")
     procs = []
+    port = 29000 + next(_RENDEZVOUS)  # (one tag per call: the files two runs leave under /dev/shm must never meet, whatever port the caller suggested)
     for r in range(nranks):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(nranks), LOCAL_RANK=str(r), MASTER_PORT=str(port), MASTER_ADDR="127.0.0.1",
                    QK_COMM_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -353,7 +357,8 @@ def test_overlapped_fill_schedule_of_the_cxx_host_equals_one_rank(tmp_path, nran
 @pytest.mark.parametrize("nranks,distribution,mgs", [(2, "interleaved", 8), (4, "interleaved", 8), (2, "bricks", 16)])
 def test_amr_hierarchy_of_the_cxx_host_across_ranks_matches_one_rank(tmp_path, nranks, distribution, mgs):
     """BASELINE config 5's structure (Sedov, amr.max_level = 2, subcycling, reflux, regrid every 2 steps) in the C++17 host on several ranks
-    (quokka_amr.hpp): a refined box lives on the rank of its level-0 ancestor, grids are clustered inside each level-0 box, tile flags are
+    (quokka_amr.hpp) in the scheme that keeps a refined box on the rank of its level-0 ancestor (qk.distribute_levels = 0; the default on several ranks is
+    a box -> rank map per level: test_amr_levels_with_their_own_distribution_in_the_cxx_host): grids are clustered inside each level-0 box, tile flags are
     all-reduced, reflux increments cross ranks through SumBoundary.  32^3 base grid; with 8^3 level-0 boxes the refined region around the blast
     (which the problem puts in the corner cell of the octant) spans level-0 boxes of several ranks on both finer levels; with 16^3 boxes it
     stays inside one, so the other ranks hold EMPTY levels 1 and 2 and still take part in every collective step.  Against ONE rank building the
@@ -364,7 +369,8 @@ def test_amr_hierarchy_of_the_cxx_host_across_ranks_matches_one_rank(tmp_path, n
     args = ["geometry.prob_lo=0 0 0", "geometry.prob_hi=1.2 1.2 1.2", "geometry.is_periodic=0 0 0", "amr.n_cell=32 32 32", f"amr.max_grid_size={mgs}",
             "amr.max_level=2", "amr.blocking_factor=8", "amr.n_error_buf=3", "do_reflux=1", "max_timesteps=8"]
     (one,), outs1 = run_ranks("ref_HydroBlast3D", args + ["qk.cluster_within_parent=1"], tmp_path, 1, 29651)
-    parts, outs = run_ranks("ref_HydroBlast3D", args + [f"qk.level0_distribution={distribution}"], tmp_path, nranks, 29651 + 3 * nranks + len(distribution))
+    parts, outs = run_ranks("ref_HydroBlast3D", args + [f"qk.level0_distribution={distribution}", "qk.distribute_levels=0"], tmp_path, nranks,
+                            29651 + 3 * nranks + len(distribution))
     zone = re.compile(r"Zone-updates on level (\d): (\d+) \((\d+) grids\)")
     z1 = zone.findall(outs1[0])
     assert len(z1) == 3 and zone.findall(outs[0]) == z1, (zone.findall(outs[0]), z1)
@@ -392,16 +398,20 @@ def test_amr_hierarchy_of_the_cxx_host_across_ranks_matches_one_rank(tmp_path, n
     assert open(dump1 + ".meta").read().split()[:3] == open(dumpn + ".rank0.meta").read().split()[:3]  # steps, time, dt
 
 
-@pytest.mark.parametrize("nranks", [2, 4])
-def test_plotfile_and_checkpoint_written_by_several_ranks(tmp_path, nranks):
+@pytest.mark.parametrize("nranks,scheme", [(2, "ancestor"), (4, "ancestor"), (4, "per_level")])
+def test_plotfile_and_checkpoint_written_by_several_ranks(tmp_path, nranks, scheme):
     """AMRSimulation::WritePlotFile / WriteCheckpointFile of the C++17 host on several ranks (quokka_io.hpp: VisMF::Write with one data file per
     rank — Cell_D_00000 .. — and ONE header by rank 0 that lists the boxes of the whole level, each with the file of its owner and an offset
     that follows from the box list; per-fab minima / maxima reduced over the ranks; Header, metadata and the last_chk link by rank 0).  The
     three-level Sedov hierarchy of the test above: the plotfile and the checkpoint of N ranks hold the same grids as the one-rank files and the
     same data to rounding (the reflux additions are reassociated across ranks), the header tables are those of the data, every rank's file is
     referenced, and a restart from the N-rank checkpoint — on N ranks and on ONE rank — continues to the same final state as the uninterrupted
-    N-rank run (bit for bit on N ranks)."""
+    N-rank run (bit for bit on N ranks).  scheme: where the refined boxes live — on the rank of their level-0 ancestor (qk.distribute_levels = 0, the one-rank
+    reference clusters inside the level-0 boxes too) or by a box -> rank map per level (the default on several ranks; the one-rank reference chops its
+    levels for N boxes)."""
     from quokka_amd import plotfile as pf
+    many = ["qk.level0_distribution=interleaved", "qk.distribute_levels=0"] if scheme == "ancestor" else ["qk.level0_distribution=bricks"]
+    single = ["qk.cluster_within_parent=1"] if scheme == "ancestor" else [f"qk.refine_grid_layout_target={nranks}"]
     base = ["geometry.prob_lo=0 0 0", "geometry.prob_hi=1.2 1.2 1.2", "geometry.is_periodic=0 0 0", "amr.n_cell=32 32 32", "amr.max_grid_size=8",
             "amr.max_level=2", "amr.blocking_factor=8", "amr.n_error_buf=3", "do_reflux=1"]
     out1, outn = tmp_path / "one", tmp_path / "many"
@@ -411,8 +421,8 @@ def test_plotfile_and_checkpoint_written_by_several_ranks(tmp_path, nranks):
     ion = [f"plotfile_prefix={outn}/plt", f"checkpoint_prefix={outn}/chk", "plotfile_interval=4", "checkpoint_interval=4", "max_timesteps=4"]
     for sub in ("w", "r", "s"):
         os.makedirs(tmp_path / sub)
-    run_ranks("ref_HydroBlast3D", base + io1 + ["qk.cluster_within_parent=1"], tmp_path, 1, 29711)
-    run_ranks("ref_HydroBlast3D", base + ion + ["qk.level0_distribution=interleaved"], tmp_path, nranks, 29711 + nranks)
+    run_ranks("ref_HydroBlast3D", base + io1 + single, tmp_path, 1, 29711 + 20 * len(scheme))
+    run_ranks("ref_HydroBlast3D", base + ion + many, tmp_path, nranks, 29711 + nranks + 20 * len(scheme))
     # the plotfile
     A, B = pf.read_plotfile(str(out1 / "plt00004")), pf.read_plotfile(str(outn / "plt00004"))
     assert B.finest_level == 2 and A.finest_level == 2
@@ -432,16 +442,16 @@ def test_plotfile_and_checkpoint_written_by_several_ranks(tmp_path, nranks):
     assert all(a.boxes == b.boxes and a.nghost == b.nghost == 4 for a, b in zip(c1, cn))
     assert os.path.islink(outn / "last_chk")
     # restart from the N-rank checkpoint: N ranks and one rank, against the uninterrupted N-rank run
-    more = base + ["plotfile_interval=-1", "checkpoint_interval=-1", "max_timesteps=8", "qk.level0_distribution=interleaved"]
-    whole, _ = run_ranks("ref_HydroBlast3D", more, tmp_path / "w", nranks, 29731 + nranks)
-    again, _ = run_ranks("ref_HydroBlast3D", more + [f"restartfile={outn}/chk00004"], tmp_path / "r", nranks, 29751 + nranks)
+    more = base + ["plotfile_interval=-1", "checkpoint_interval=-1", "max_timesteps=8"] + many
+    whole, _ = run_ranks("ref_HydroBlast3D", more, tmp_path / "w", nranks, 29731 + nranks + 20 * len(scheme))
+    again, _ = run_ranks("ref_HydroBlast3D", more + [f"restartfile={outn}/chk00004"], tmp_path / "r", nranks, 29751 + nranks + 20 * len(scheme))
     for r in range(nranks):
         assert np.array_equal(whole[r], again[r]), r
-    (single,), _ = run_ranks("ref_HydroBlast3D", base + ["plotfile_interval=-1", "checkpoint_interval=-1", "max_timesteps=8", "qk.cluster_within_parent=1",
-                                                            f"restartfile={outn}/chk00004"], tmp_path / "s", 1, 29771)
-    from quokka_amd.simulation import chop_domain, distribute_boxes_interleaved
+    (single,), _ = run_ranks("ref_HydroBlast3D", base + ["plotfile_interval=-1", "checkpoint_interval=-1", "max_timesteps=8", f"restartfile={outn}/chk00004"] + single,
+                             tmp_path / "s", 1, 29771 + 20 * len(scheme))
+    from quokka_amd.simulation import chop_domain, distribute_boxes, distribute_boxes_interleaved
     boxes = chop_domain([32, 32, 32], [8, 8, 8])
-    owner = distribute_boxes_interleaved(boxes, nranks, [32, 32, 32], [8, 8, 8])
+    owner = (distribute_boxes_interleaved if scheme == "ancestor" else distribute_boxes)(boxes, nranks, [32, 32, 32], [8, 8, 8])
     single = single.reshape(len(boxes), 6, 8, 8, 8)
     cursor = [0] * nranks
     worst = 0.0
@@ -523,5 +533,52 @@ def test_amr_levels_with_their_own_distribution_in_the_cxx_host(tmp_path, nranks
         assert worst <= 1e-13, (name, worst)
     for o in (outs1[0], outs2[0], outs[0]):
         assert "Energy conservation is OK." in o
+    metas = [open(str(tmp_path / d / f) + ".meta").read().split()[:3] for d, f in (("a", "state_n1_shm.bin"), ("b", "state_n1_shm.bin"), ("c", f"state_n{nranks}_shm.bin.rank0"))]
+    assert metas[0] == metas[1] == metas[2], metas  # steps, time, dt
+
+
+@pytest.mark.parametrize("name,deck,extra,n_cell,mgs,steps", [("ref_Advection2D", "advection2d_amr.in", [], (64, 64), 16, 40),
+                                                              ("ref_RadBeam", "beam.in", ["amr.max_grid_size=32"], (128, 128), 32, 8)],
+                         ids=["advection_periodic_four_levels", "radiation_custom_boundaries"])
+def test_distributed_levels_of_other_solvers_in_the_cxx_host(tmp_path, monkeypatch, name, deck, extra, n_cell, mgs, steps):
+    """qk.distribute_levels = 1 beyond the hydro blast, with the reference's own decks on 2-D hierarchies: Advection2D (AdvectionSimulation levels,
+    four levels, periodic: the ParallelCopy plans and the nesting across the periodic faces, both RK stages feeding the two-part register) and
+    RadBeam (radiation only: the second register of a level with its own ring, the problem's custom boundary function evaluated on the coarse
+    patch a child keeps on its rank).  One rank in the ordinary data path against one rank and four ranks in the distributed one, all chopping
+    for four boxes: same grids, same time steps, level-0 state to rounding.  (Eight coarse steps of the beam: the two parts of a register are added
+    to the state one after the other, and the sharp front of the streaming beam amplifies that rounding — 1e-16 after three coarse steps, 4e-9 after
+    twenty, measured per level with profiles/tools/compare_plotfiles.py.)"""
+    import re
+    from quokka_amd.simulation import chop_domain, distribute_boxes
+    monkeypatch.setenv("QK_MAX_COARSE_STEPS", str(steps))
+    nranks = 4
+    args = [os.path.join(HOST, "decks", deck), "plotfile_interval=-1", "checkpoint_interval=-1", f"qk.refine_grid_layout_target={nranks}"] + extra
+    for sub in ("a", "b", "c"):
+        os.makedirs(tmp_path / sub)
+    port = 29851 + 10 * len(name)  # (the rendezvous files of two tests must not meet)
+    (one,), outs1 = run_ranks(name, args, tmp_path / "a", 1, port)
+    (shadowed,), outs2 = run_ranks(name, args + ["qk.distribute_levels=1"], tmp_path / "b", 1, port + 1)
+    parts, outs = run_ranks(name, args + ["qk.distribute_levels=1", "qk.level0_distribution=bricks"], tmp_path / "c", nranks, port + 2)
+    zone = re.compile(r"Zone-updates on level (\d): (\d+) \((\d+) grids\)")
+    z1 = zone.findall(outs1[0])
+    assert len(z1) >= 3 and all(int(u) > 0 for _, u, _ in z1) and zone.findall(outs[0]) == z1 and zone.findall(outs2[0]) == z1, (zone.findall(outs[0]), z1)
+    per = {int(l): [int(x) for x in c.split()] for l, c in re.findall(r"Boxes of level (\d) per rank:((?: \d+)+)", outs[0])}
+    assert all(sum(1 for n in per[l] if n > 0) > 1 for l in per), per  # every level lives on more than one rank
+    boxes = chop_domain([n_cell[0], n_cell[1], 1], [mgs, mgs, mgs])
+    owner = distribute_boxes(boxes, nranks, [n_cell[0], n_cell[1], 1], [mgs, mgs, mgs])
+    nb, cells = len(boxes), mgs * mgs
+    ncomp = one.size // (nb * cells)
+    assert one.size == nb * ncomp * cells and sum(p.size for p in parts) == one.size
+    many, cursor = [], [0] * nranks
+    for r in owner:
+        many.append(parts[r][cursor[r]:cursor[r] + ncomp * cells])
+        cursor[r] += ncomp * cells
+    assert all(cursor[r] == parts[r].size for r in range(nranks))
+    one = one.reshape(nb, ncomp, cells)
+    assert np.isfinite(one).all()
+    for label, got in (("one rank, distributed data path", shadowed.reshape(nb, ncomp, cells)), ("four ranks", np.concatenate(many).reshape(nb, ncomp, cells))):
+        for n in range(ncomp):
+            scale = np.abs(one[:, n]).max()
+            assert np.abs(got[:, n] - one[:, n]).max() <= 1e-12 * scale, (label, n, float(np.abs(got[:, n] - one[:, n]).max()), float(scale))
     metas = [open(str(tmp_path / d / f) + ".meta").read().split()[:3] for d, f in (("a", "state_n1_shm.bin"), ("b", "state_n1_shm.bin"), ("c", f"state_n{nranks}_shm.bin.rank0"))]
     assert metas[0] == metas[1] == metas[2], metas  # steps, time, dt
