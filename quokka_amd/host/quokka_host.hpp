@@ -1015,6 +1015,10 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 			v[1] += cnt[4 * i + 1];
 			maxIt = std::max(maxIt, cnt[4 * i + 2]);
 		}
+		if (fail[0] + fail[1] + fail[2] > 0 && std::getenv("QK_AMR_VERBOSE") != nullptr) { // (which level, which rank: before the counts are reduced)
+			std::fprintf(stderr, "rank %d level %d (%d boxes here): radiation source term failures %d %d %d in %d substeps at t = %.17g\n", qkhost::Comm::get().rank,
+				     this->amrLevel_, static_cast<int>(this->grids_.size()), fail[0], fail[1], fail[2], nsubSteps, time_subcycle);
+		}
 		if (qkhost::Comm::get().size > 1) { // counters over all ranks (the reference reduces them when it prints them, QuokkaSimulation.hpp:1690-1720)
 			qkhost::Comm::get().allReduce(v, 5, qkhost::Comm::Op::sum);
 			maxIt = qkhost::Comm::get().allReduceMax(maxIt);
