@@ -16,4 +16,10 @@ for l, (la, lb) in enumerate(zip(A.levels, B.levels)):
             if d.max() > worst:
                 worst = float(d.max()); where = (bi, np.unravel_index(d.argmax(), d.shape), float(np.abs(fa[n]).max()))
         if worst > 0:
-            print("   ", v, worst, where)
+            cells = []
+            for bi, (fa, fb) in enumerate(zip(la.fabs, lb.fabs)):
+                lo = la.boxes[bi][0]
+                for idx in np.argwhere(fa[n] != fb[n]):
+                    cells.append((int(idx[2]) + lo[0], int(idx[1]) + lo[1], int(idx[0]) + lo[2]))
+            c = np.array(cells)
+            print("   ", v, worst, where, "differing cells:", len(cells), "bounding box", c.min(axis=0).tolist(), c.max(axis=0).tolist())

@@ -1348,6 +1348,15 @@ template <typename problem_t, typename SimT> class AmrDriver
 			for (int k = lev; k <= finestLevel(); ++k) {
 				last_regrid_step[k] = istep[k];
 			}
+			if constexpr (!Sim::isAdvection) {
+				if (lev == 0 && std::getenv("QK_PLOT_AFTER_REGRID") != nullptr) { // (debugging aid: the hierarchy as the regrid left it, afterregrid<step>)
+					std::string const keep = base_.plot_file;
+					base_.plot_file = "afterregrid";
+					base_.istep[0] = istep[0];
+					base_.WritePlotFile();
+					base_.plot_file = keep;
+				}
+			}
 		}
 		Sim &S = level(lev);
 		S.tOldLev_ = S.tNewLev_;

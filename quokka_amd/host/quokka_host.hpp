@@ -1029,10 +1029,10 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 		if (v[3] > 0) {
 			amrex::Abort("Newton-Raphson iteration for dust temperature failed to converge or dust temperature is negative!");
 		}
-		if (v[2] > 0) {
+		if (v[2] > 0 && std::getenv("QK_IGNORE_RAD_FAILURE") == nullptr) { // (the variable: a debugging aid — run on, to look at the state that failed)
 			amrex::Abort("Newton-Raphson iteration for matter-radiation coupling failed to converge!");
 		}
-		if (v[4] > 0) {
+		if (v[4] > 0 && std::getenv("QK_IGNORE_RAD_FAILURE") == nullptr) {
 			amrex::Abort("Outer iteration for matter-radiation coupling failed to converge!");
 		}
 	}
