@@ -497,7 +497,7 @@ def _level0_state_by_box(parts, owner, nb, n3, mgs):
 
 
 @pytest.mark.parametrize("nranks", [2, 4, 8])
-def test_amr_levels_with_their_own_distribution_in_the_cxx_host(tmp_path, nranks):
+def test_amr_levels_with_their_own_distribution_in_the_cxx_host(tmp_path, ctx, nranks):
     """qk.distribute_levels = 1 (quokka_amr.hpp Shadow / RingIncrement, qk_pcopy.hpp, qk_grid_layout.hpp): every level of the three-level Sedov
     hierarchy has its own box -> rank map — grids clustered globally as with one rank, a level with fewer boxes than ranks chopped (AMReX's
     refine_grid_layout), boxes dealt along the space-filling curve to the least loaded ranks —, the parent's data reach the fine boxes, averaged-down
@@ -509,7 +509,8 @@ def test_amr_levels_with_their_own_distribution_in_the_cxx_host(tmp_path, nranks
     from quokka_amd.simulation import chop_domain, distribute_boxes
     mgs = 16
     args = ["geometry.prob_lo=0 0 0", "geometry.prob_hi=1.2 1.2 1.2", "geometry.is_periodic=0 0 0", "amr.n_cell=32 32 32", f"amr.max_grid_size={mgs}",
-            "amr.max_level=2", "amr.blocking_factor=8", "amr.n_error_buf=3", "do_reflux=1", "max_timesteps=8", f"qk.refine_grid_layout_target={nranks}"]
+            "amr.max_level=2", "amr.blocking_factor=8", "amr.n_error_buf=3", "do_reflux=1", "max_timesteps=8", f"qk.refine_grid_layout_target={nranks}",
+            "plotfile_interval=100", f"plotfile_prefix={tmp_path}/c/plt"]
     for sub in ("a", "b", "c"):
         os.makedirs(tmp_path / sub)
     (one,), outs1 = run_ranks("ref_HydroBlast3D", args, tmp_path / "a", 1, 29811)
@@ -535,6 +536,22 @@ def test_amr_levels_with_their_own_distribution_in_the_cxx_host(tmp_path, nranks
         assert "Energy conservation is OK." in o
     metas = [open(str(tmp_path / d / f) + ".meta").read().split()[:3] for d, f in (("a", "state_n1_shm.bin"), ("b", "state_n1_shm.bin"), ("c", f"state_n{nranks}_shm.bin.rank0"))]
     assert metas[0] == metas[1] == metas[2], metas  # steps, time, dt
+    # the PYTHON host on one rank, chopping for the same count: the N-rank plotfile of the C++ host (one data file per rank; the last of the three runs above
+    # wrote it) holds the same grids on every level and the same data to rounding — the two hosts build the same distributed hierarchy (chopGrids /
+    # distributeSfc are pinned function by function in tests/test_amr_grids.py)
+    from quokka_amd import plotfile
+    from quokka_amd.amr_simulation import sedov_amr_problem
+    amr = sedov_amr_problem(ctx, 32, 2, max_grid_size=mgs, blocking_factor=8, refine_grid_layout_target=nranks)
+    for _ in range(8):
+        amr.step()
+    plotfile.WritePlotFile(amr, str(tmp_path / "py_plt00008"))
+    cpp, py = plotfile.read_plotfile(str(tmp_path / "c" / "plt00008")), plotfile.read_plotfile(str(tmp_path / "py_plt00008"))
+    assert cpp.finest_level == py.finest_level == 2 and (cpp.time, cpp.level_steps) == (py.time, py.level_steps)
+    for l, (la, lb) in enumerate(zip(cpp.levels, py.levels)):
+        assert la.boxes == lb.boxes, (l, la.boxes, lb.boxes)
+    diff = plotfile.compare_plotfiles(str(tmp_path / "c" / "plt00008"), str(tmp_path / "py_plt00008"))
+    scale = {v: max(float(np.abs(f[i]).max()) for f in py.levels[0].fabs) for i, v in enumerate(py.varnames)}
+    assert all(diff[v] <= 1e-13 * max(scale[v], scale["gasEnergy"]) for v in py.varnames), diff
 
 
 @pytest.mark.parametrize("name,deck,extra,n_cell,mgs,steps", [("ref_Advection2D", "advection2d_amr.in", [], (64, 64), 16, 40),
