@@ -40,13 +40,18 @@ def exchange(pairs: Sequence[Tuple[int, torch.Tensor, torch.Tensor]]) -> _Pendin
     NCCL work is stream-ordered after the kernels that filled the send buffers; wait() orders the consumer after the receives."""
     ops, staged = [], []
     stage = _staged()
-    for peer, sbuf, rbuf in pairs:
+    for peer, sbuf, rbuf in pairs:  # (a ParallelCopy plan often moves data one way only: an empty direction is skipped — on both sides, this rank's
+        send, recv = sbuf.numel() > 0, rbuf.numel() > 0  # receive count from a peer being that peer's send count to this rank)
         if stage and sbuf.is_cuda:
-            hs, hr = sbuf.cpu(), torch.empty(rbuf.shape, dtype=rbuf.dtype)
-            staged.append((hr, rbuf))
-            ops.append(dist.P2POp(dist.isend, hs, peer))
-            ops.append(dist.P2POp(dist.irecv, hr, peer))
+            if send:
+                ops.append(dist.P2POp(dist.isend, sbuf.cpu(), peer))
+            if recv:
+                hr = torch.empty(rbuf.shape, dtype=rbuf.dtype)
+                staged.append((hr, rbuf))
+                ops.append(dist.P2POp(dist.irecv, hr, peer))
         else:
-            ops.append(dist.P2POp(dist.isend, sbuf, peer))
-            ops.append(dist.P2POp(dist.irecv, rbuf, peer))
+            if send:
+                ops.append(dist.P2POp(dist.isend, sbuf, peer))
+            if recv:
+                ops.append(dist.P2POp(dist.irecv, rbuf, peer))
     return _Pending(dist.batch_isend_irecv(ops) if ops else [], staged)

@@ -154,9 +154,13 @@ class Comm
 			hipCheck(hipEventRecord(evReady_, compute), "hipEventRecord");
 			hipCheck(hipStreamWaitEvent(stream_, evReady_, 0), "hipStreamWaitEvent");
 			ncclCheck(ncclGroupStart(), "ncclGroupStart");
-			for (size_t k = 0; k < peer.size(); ++k) {
-				ncclCheck(ncclSend(send[k], static_cast<size_t>(nsend[k]) * elemBytes, ncclChar, peer[k], nccl_, stream_), "ncclSend");
-				ncclCheck(ncclRecv(recv[k], static_cast<size_t>(nrecv[k]) * elemBytes, ncclChar, peer[k], nccl_, stream_), "ncclRecv");
+			for (size_t k = 0; k < peer.size(); ++k) { // (a ParallelCopy plan often moves data one way only: the empty direction is skipped on both sides —
+				if (nsend[k] > 0) {		  // this rank's nrecv from a peer is that peer's nsend to this rank)
+					ncclCheck(ncclSend(send[k], static_cast<size_t>(nsend[k]) * elemBytes, ncclChar, peer[k], nccl_, stream_), "ncclSend");
+				}
+				if (nrecv[k] > 0) {
+					ncclCheck(ncclRecv(recv[k], static_cast<size_t>(nrecv[k]) * elemBytes, ncclChar, peer[k], nccl_, stream_), "ncclRecv");
+				}
 			}
 			ncclCheck(ncclGroupEnd(), "ncclGroupEnd");
 			hipCheck(hipEventRecord(evDone_, stream_), "hipEventRecord");
