@@ -275,13 +275,17 @@ static int fluxregCreate(qk_level *crse, qk_level *fine, const qk_geometry *crse
 						}
 					}
 				}
-				// pass 1: owned by another rank — accumulate in a ghost cell of a local coarse box; SumBoundary carries it to the owner
+				// pass 1: owned by another rank — accumulate in a ghost cell of a local coarse box; SumBoundary carries it to the owner.  The box must
+				// hold the FACE between the register cell and the fine box (CrseAdd reads the coarse flux there): the one whose valid region the cell
+				// adjoins in direction d — the coarse cell on the other side of the face lies under the fine box, hence in a local coarse box.  (Until
+				// round 6 any box with the cell in its ghost ring was taken: a cell in a CORNER of the first box's ring made CrseAdd read that box's flux
+				// array one row beyond its end — RadBeam on four ranks, profiles/round6/dist1.)
 				if (reg_nghost > 0) {
 					const int zero[3] = {0, 0, 0};
 					for (int c = 0; c < crse->nboxes && !rest.empty(); ++c) {
 						HBox gb{};
 						for (int e = 0; e < 3; ++e) {
-							const int g = (e < ndim) ? reg_nghost : 0;
+							const int g = (e == d) ? reg_nghost : 0;
 							gb.lo[e] = crse->boxes[c].lo[e] - g;
 							gb.hi[e] = crse->boxes[c].hi[e] + g;
 						}

@@ -661,6 +661,20 @@ template <typename problem_t, typename SimT> class AmrDriver
 		// distributed levels: the parent's states as this rank's copy under its fine boxes (same values: the same interpolated bits)
 		auto *pn = (f.shadow && !atOld) ? qkhost::tab(f.shadow->ensure(false)) : qkhost::tab(p.state_new_cc_[0]);
 		auto *po = (f.shadow && !atNew) ? qkhost::tab(f.shadow->ensure(true)) : qkhost::tab(p.state_old_cc_[0]);
+		// debugging aid: QK_DUMP_COARSE_FOR_INTERP="<level> <tmin> <prefix> [skip]" writes the parent's old and new state as the (skip + 1)-th ghost
+		// interpolation of that level at time >= tmin reads them (ghost cells included; ancestor scheme: the parent's own arrays)
+		if (char const *e = std::getenv("QK_DUMP_COARSE_FOR_INTERP")) {
+			int l = -1, skip = 0;
+			double tmin = 0;
+			char prefix[512];
+			static int seen = 0;
+			if (!f.shadow && std::sscanf(e, "%d %lf %500s %d", &l, &tmin, prefix, &skip) >= 3 && l == lev && time >= tmin && seen++ == skip) {
+				std::ostringstream head;
+				head << "time " << std::setprecision(17) << time << " t0 " << t0 << " t1 " << t1;
+				qkhost::dumpFabs(prefix, head.str(), {&p.state_old_cc_[0]});
+				qkhost::dumpFabs(std::string(prefix) + "_new", head.str(), {&p.state_new_cc_[0]});
+			}
+		}
 		int const nc = Physics_Indices<problem_t>::nvarTotal_cc; // hydro + radiation blocks
 		int const hooks = Sim::isAdvection ? 0 : 1;		 // PreInterpState / PostInterpState: the hydro energy (InterpHookNone for the scalar)
 		if (std::abs(time - t1) <= eps || t1 == t0) {

@@ -105,6 +105,30 @@ struct PeerBuffers {
 };
 } // namespace qkhost
 
+namespace qkhost
+{
+// debugging aid (QK_DUMP_BEFORE_SOURCE, QK_DUMP_COARSE_FOR_INTERP): every fab of the arrays, ghost cells included, to <prefix>.rank<r>.bin (doubles, array
+// after array); <prefix>.rank<r>.txt: a header line ending in the component count of the FIRST array, then the fab boxes of the first array.
+// profiles/tools/compare_source_inputs.py reads two such dumps and lists the cells that differ.
+inline void dumpFabs(std::string const &prefix, std::string const &header, std::vector<amrex::MultiFab const *> const &arrays)
+{
+	std::string const base = prefix + ".rank" + std::to_string(Comm::get().rank);
+	std::ofstream meta(base + ".txt"), data(base + ".bin", std::ios::binary);
+	meta << header << " ncomp " << arrays.front()->nComp() << "\n";
+	QK_HOST_HIP(hipDeviceSynchronize());
+	for (auto const *mf : arrays) {
+		for (int b = 0; b < mf->size(); ++b) {
+			if (mf == arrays.front()) {
+				auto const fb = mf->fabbox(b);
+				meta << fb.lo[0] << " " << fb.lo[1] << " " << fb.lo[2] << " " << fb.hi[0] << " " << fb.hi[1] << " " << fb.hi[2] << "\n";
+			}
+			auto const h = mf->copyToHost(b);
+			data.write(reinterpret_cast<char const *>(h.data()), static_cast<std::streamsize>(sizeof(double) * h.size()));
+		}
+	}
+}
+} // namespace qkhost
+
 // per-problem user data a problem may specialise (reference src/simulation.hpp: SimulationData<problem_t> userData_)
 template <typename problem_t> struct SimulationData {
 };

@@ -876,6 +876,20 @@ template <typename problem_t> class QuokkaSimulation : public AMRSimulation<prob
 	void operatorSplitSourceTerms(double time, double dt, int stage, bool mirror = false)
 	{
 		fillRadEnergySource(time + dt);
+		// debugging aid: QK_DUMP_BEFORE_SOURCE="<level> <tmin> <prefix>" writes what the first source-term launch of that level at time >= tmin is about to read —
+		// every fab of the state with its ghost cells, then the source array — to <prefix>.rank<r>.bin (doubles; boxes in <prefix>.rank<r>.txt)
+		if (char const *e = std::getenv("QK_DUMP_BEFORE_SOURCE")) {
+			int lev = -1;
+			double tmin = 0;
+			char prefix[512];
+			static bool dumped = false;
+			if (!dumped && std::sscanf(e, "%d %lf %500s", &lev, &tmin, prefix) == 3 && lev == this->amrLevel_ && time >= tmin) {
+				dumped = true;
+				std::ostringstream head;
+				head << "time " << std::setprecision(17) << time << " dt " << dt << " stage " << stage;
+				qkhost::dumpFabs(prefix, head.str(), {&state_new_cc_[0], &radEnergySource_});
+			}
+		}
 		if constexpr (Physics_Traits<problem_t>::nGroups <= 1) { // :1875-1881
 			RadSystem<problem_t>::AddSourceTermsSingleGroup(state_new_cc_[0], radEnergySource_, dt, stage, d_radCounter_ + 4 * radCounterSlot_, d_radFailure_,
 									mirror ? &state_old_cc_[0] : nullptr);

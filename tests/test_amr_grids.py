@@ -270,3 +270,33 @@ def test_cxx_host_grid_layout_equals_the_python_host(tmp_path):
     assert len(got) == len(want)
     for c, g, w in zip(cases, got, want):
         assert g == w, (c, g, w)
+
+
+def test_register_cells_of_another_rank_sit_beside_the_face_their_coarse_flux_lives_on():
+    """qk_fluxreg_create with reg_nghost = 1 (several ranks, a refined box on the rank of its level-0 ancestor): a register cell owned by another rank is
+    kept in a ghost cell of a LOCAL coarse box, and CrseAdd reads the coarse flux on the face between that cell and the fine box from the same box's
+    flux array — so the box must be the one whose valid region the cell adjoins in the direction of the face, never one that merely has the cell in a
+    corner of its ghost ring.  The layout RadBeam reaches on four ranks after its second regrid (2-D; level 1 = four 8^2 boxes on this rank, level 2
+    covering all of them): until round 6 the cells (16, 8) and (8, 16) — at the seam of two local boxes — went to the box below / left of the seam and
+    CrseAdd read one row beyond the end of its flux array (profiles/round6/dist1_cxx_distributed_levels.txt)."""
+    from quokka_amd.amr import FluxRegister
+    from quokka_amd.multifab import Level, PlanningContext
+    from quokka_amd.simulation import Geometry
+    ctx = PlanningContext()
+    crse_boxes = [([0, 0, 0], [7, 7, 0]), ([8, 0, 0], [15, 7, 0]), ([0, 8, 0], [7, 15, 0]), ([8, 8, 0], [15, 15, 0])]
+    fine_boxes = [([8 * i, 8 * j, 0], [8 * i + 7, 8 * j + 7, 0]) for j in range(4) for i in range(4)]
+    crse, fine = Level(ctx, 2, crse_boxes), Level(ctx, 2, fine_boxes)
+    geom = Geometry(2, [256, 256, 1], [0, 0, 0], [2, 2, 2], [0, 0, 0])
+    fr = FluxRegister(crse, fine, geom, 4, all_fine_boxes=fine_boxes, reg_nghost=1)
+    items = fr.items()
+    cells = set()
+    for d, side, fb, cb, lo, hi, sh in items:
+        blo, bhi = crse_boxes[cb]
+        for e in range(2):  # inside the box in every direction but d; in d: the valid box or the one ghost cell beyond it
+            g = 1 if e == d else 0
+            assert blo[e] - g <= lo[e] and hi[e] <= bhi[e] + g, (d, side, fb, cb, lo, hi)
+        for j in range(lo[1], hi[1] + 1):
+            for i in range(lo[0], hi[0] + 1):
+                assert (d, i, j) not in cells
+                cells.add((d, i, j))
+    assert cells == {(0, 16, j) for j in range(16)} | {(1, i, 16) for i in range(16)}  # every register cell of the fine region's two open sides, once
