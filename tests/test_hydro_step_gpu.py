@@ -651,3 +651,37 @@ def test_x_sweep_inside_the_y_march_with_boxes_of_two_widths(ctx):
         os.environ.pop("QK_FUSEX", None)
     for a, b in zip(*finals):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("shape", [(64, 8, 8), (64, 24, 40), (128, 40, 24), (64, 72, 8), (192, 8, 56), (64, 16, 136)])
+def test_x_sweep_inside_the_y_march_on_boxes_of_odd_heights(ctx, shape):
+    """FUSEX on the boxes a hierarchy with amr.blocking_factor = 8 produces: 64-cell multiples wide, but 8, 24, 40, 72 ... rows high and deep — fewer rows than one
+    batch of wave-edge faces (16), a last batch that is not full, marches shorter than one segment.  One box, reflecting walls, the developed blast; equal to
+    QK_FUSEX=0 in every bit after four steps."""
+    import os
+    from quokka_amd import capi
+    from quokka_amd.simulation import Geometry, HydroSimulation, developed_state
+    finals = []
+    try:
+        for fusex in ("0", "1"):
+            os.environ["QK_FUSEX"] = fusex
+            geom = Geometry(3, list(shape), [0.0, 0.0, 0.0], [1.2 * shape[0] / 64, 1.2 * shape[1] / 64, 1.2 * shape[2] / 64], [0, 0, 0])
+            bcs = []
+            for c in range(6):
+                lo = [capi.BC_REFLECT_ODD if c == 1 + d else capi.BC_REFLECT_EVEN for d in range(3)]
+                bcs.append((lo, list(lo)))
+            boxes = [([0, 0, 0], [shape[0] - 1, shape[1] - 1, shape[2] - 1])]
+            s = HydroSimulation(ctx, geom, capi.traits(1.4, False, 3), bcs, list(shape), boxes=boxes, owner=[0])
+            s.reconstructionOrder_, s.stopTime_, s.cflNumber_ = 3, 1.0, 0.3
+            s.rk2_carry_rhs = True
+            for b, (lo, hi) in enumerate(s.my_boxes):
+                s.state_new_cc_.set_fab(b, developed_state(64, lo, hi))
+            s._signal_of_state_new = None
+            for _ in range(4):
+                assert s.step()
+            finals.append(([v.copy() for v in s.gather_valid_local()], dict(s.counters)))
+    finally:
+        os.environ.pop("QK_FUSEX", None)
+    assert finals[0][1] == finals[1][1]
+    for a, b in zip(finals[0][0], finals[1][0]):
+        assert np.isfinite(a).all() and np.array_equal(a, b)
