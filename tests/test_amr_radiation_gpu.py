@@ -127,3 +127,27 @@ def test_dynamic_regridding_follows_the_pulse_and_conserves(ctx):
         E = L0.state_new_cc_.valid(0)[6].cpu().numpy()
         tagged_uncovered = int(((E > amr.tag_threshold) & ~cover).sum())
     assert tagged_uncovered == 0
+
+
+@pytest.mark.parametrize("hydro", [False, True])
+def test_fused_radiation_stage_on_the_boxes_of_a_hierarchy(ctx, hydro):
+    """qk_rad_stage_fused against the separate operators on boxes that are not cubes: a static two-level hierarchy around the pulse whose refined level is an
+    L of three boxes 40 x 8 x 16, 8 x 24 x 16 and 16 x 16 x 8 fine cells (the shapes a blocking factor of 8 produces), level 0 in 16^3 boxes.  Both levels with
+    the fused stage, then both with computeRadiationFluxes + PredictStep / AddFluxesRK2: four coarse steps (subcycled radiation, flux registers of the
+    radiation block fed by either form), every component of every level equal in every bit."""
+    fine = [([24, 24, 24], [63, 31, 39]), ([24, 32, 24], [31, 55, 39]), ([32, 32, 32], [47, 47, 39])]
+    runs = []
+    for fused in (True, False):
+        amr = rad_pulse_amr_problem(ctx, 32, 1, max_grid_size=16, static_fine_boxes=[fine], hydro=hydro)
+        assert amr.finest_level == 1 and [tuple(map(tuple, b)) for b in amr.levels[1].all_boxes] == [tuple(map(tuple, b)) for b in fine]
+        for L in amr.levels:
+            assert L.use_fused_rad
+            L.use_fused_rad = fused
+        for _ in range(4):
+            amr.step()
+        runs.append([[v.copy() for v in L.gather_valid_local()] for L in amr.levels])
+    for la, lb in zip(*runs):
+        for a, b in zip(la, lb):
+            assert np.isfinite(a).all() and np.array_equal(a, b)
+    U = runs[0][1][0]
+    assert np.abs(U[7:10]).max() > 1e-4  # (the pulse has reached the refined boxes: fluxes are not zero there)
