@@ -22,6 +22,10 @@ CASES = [  # name, executable, deck, overrides, ranks, coarse steps
     ("beam8", "ref_RadBeam", "beam.in", ["amr.max_grid_size=8"], 4, 8),
     ("shell_amr", "ref_RadhydroShell", "radhydro_shell_amr.in", ["amr.n_cell=32 32 32", "amr.max_level=1", "amr.max_grid_size=8", "amr.blocking_factor=8", "max_timesteps=4", "plotfile_interval=2"], 4, 4),
     ("shocktube_cma", "ref_HydroShocktubeCMA", "shocktube_cma.in", ["amr.max_grid_size=32"], 2, 40),
+    ("uniform_xy", "ref_HydroBlast3D", None, ["geometry.prob_lo=0 0 0", "geometry.prob_hi=1.2 1.2 1.2", "geometry.is_periodic=0 0 0", "amr.n_cell=128 128 128", "amr.max_grid_size=64",
+                                             "amr.max_level=0", "hydro.rk2_carry_rhs=1", "qk.min_overlap_cells=1", "max_timesteps=10"], 4, 10),  # fused XY sweep + early / late exchange
+    ("periodic3d", "ref_HydroBlast3D", None, ["geometry.prob_lo=0 0 0", "geometry.prob_hi=1.2 1.2 1.2", "geometry.is_periodic=1 1 1", "amr.n_cell=32 32 32", "amr.max_grid_size=8",
+                                             "amr.max_level=2", "amr.blocking_factor=8", "amr.n_error_buf=3", "do_reflux=1"], 4, 10),  # the blast in the corner: every level wraps through three faces
     ("blast3d", "ref_HydroBlast3D", None, ["geometry.prob_lo=0 0 0", "geometry.prob_hi=1.2 1.2 1.2", "geometry.is_periodic=0 0 0", "amr.n_cell=32 32 32", "amr.max_grid_size=8",
                                           "amr.max_level=2", "amr.blocking_factor=8", "amr.n_error_buf=3", "do_reflux=1"], 8, 8),
 ]
