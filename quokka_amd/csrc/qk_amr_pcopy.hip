@@ -10,6 +10,7 @@
 // box, source global box, source piece, shift) and travel as one RCCL send / recv pair.
 #include <algorithm>
 #include <array>
+#include <cstdlib>
 #include <map>
 #include <vector>
 
@@ -256,6 +257,13 @@ int qk_pcopy_plan_create(qk_ctx *ctx, const qk_geometry *geom, int n_src, const 
 	}
 	std::map<int, PcPeer> peers;
 	int64_t biggest = 0;
+	// QK_GHOST_LOOPBACK=1 (as in qk_ghost_plan_create: the production transport on ONE GPU): same-rank pairs are not items of the copy kernel but regions
+	// packed for / unpacked from a peer whose rank is this rank's own — the stream ordering of pack -> send / recv -> unpack of a ParallelCopy / ParallelAdd
+	// runs on hardware without a second GPU
+	const bool loopback = [] {
+		const char *e = std::getenv("QK_GHOST_LOOPBACK");
+		return e != nullptr && std::atoi(e) != 0;
+	}();
 	for (int gd = 0; gd < n_dst; ++gd) {
 		std::vector<HB> dst_pieces;
 		HB const g = grown(dst_boxes[gd], dst_nghost);
@@ -292,7 +300,17 @@ int qk_pcopy_plan_create(qk_ctx *ctx, const qk_geometry *geom, int n_src, const 
 						it.src_box = src_local[gs];
 						const int64_t nc = cells(it);
 						biggest = std::max(biggest, nc);
-						if (dst_mine && src_mine) {
+						if (dst_mine && src_mine && loopback) { // sent to and received from this rank itself: the same offset on either side
+							PcPeer &pp = peers[my_rank];
+							pp.rank = my_rank;
+							it.offset = pp.recv_count;
+							pp.recv_count += nc * ncomp;
+							pp.send_count += nc * ncomp;
+							pp.max_recv_cells = std::max(pp.max_recv_cells, nc);
+							pp.max_send_cells = std::max(pp.max_send_cells, nc);
+							pp.recv.push_back(it);
+							pp.send.push_back(it);
+						} else if (dst_mine && src_mine) {
 							P->local.push_back(it);
 							P->max_local_cells = std::max(P->max_local_cells, nc);
 						} else if (dst_mine) {

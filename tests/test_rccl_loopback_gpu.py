@@ -107,3 +107,19 @@ def test_cxx_host_ghost_fill_through_rccl_to_self_equals_the_local_copies(tmp_pa
     b, mb = _run_exe(name, args, tmp_path, "loop", True)
     assert ma[0] == mb[0] and ma[1] == mb[1], (ma, mb)
     assert a.size == b.size and a.size > 0 and np.array_equal(a, b)
+
+
+def test_cxx_host_parallel_copies_of_distributed_levels_through_rccl_to_self(tmp_path):
+    """qk.distribute_levels = 1 on ONE rank with the loop-back: every same-rank pair of every ParallelCopy / ParallelAdd plan (the parent's cells into the
+    shadows, average-down back, the register rings, the old level's cells at a regrid) is packed, sent to and received from the rank itself through RCCL on the
+    communication stream, and unpacked — beside the ghost strips.  The three-level Sedov hierarchy, 8 coarse steps: same time steps, level-0 state equal to the
+    run with local copies to rounding (a coarse cell that takes register increments from two fine boxes adds them in the order of the unpack groups)."""
+    args = ["geometry.prob_lo=0 0 0", "geometry.prob_hi=1.2 1.2 1.2", "geometry.is_periodic=0 0 0", "amr.n_cell=32 32 32", "amr.max_grid_size=16", "amr.max_level=2",
+            "amr.blocking_factor=8", "amr.n_error_buf=3", "do_reflux=1", "max_timesteps=8", "qk.distribute_levels=1", "qk.refine_grid_layout_target=4"]
+    a, ma = _run_exe("ref_HydroBlast3D", args, tmp_path, "plain", False)
+    b, mb = _run_exe("ref_HydroBlast3D", args, tmp_path, "loop", True)
+    assert ma[:3] == mb[:3], (ma, mb)  # steps, time, dt
+    assert a.size == b.size and a.size > 0
+    a, b = a.reshape(8, 6, -1), b.reshape(8, 6, -1)
+    worst = max(float(np.abs(a[:, n] - b[:, n]).max() / np.abs(a[:, n]).max()) for n in range(6))
+    assert worst <= 1e-13, worst
