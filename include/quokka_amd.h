@@ -576,7 +576,9 @@ int qk_fluxreg_create_crse_part(qk_level *crse, qk_level *all_fine_level, const 
  * of each list, in list order.  Peer buffers hold `ncomp` values per cell (send_count / recv_count of qk_pcopy_plan_peer are values); the calls
  * move components [scomp_src, scomp_src + ncomp) to [scomp_dst, ...).  Same wire protocol as the ghost plan: pack -> one send / recv pair per
  * peer -> local -> unpack.  Reference: the FillPatchTwoLevels / average_down / YAFluxRegister::Reflux / RemakeLevel data motion of
- * src/simulation.hpp:1789-1858, :1949-1964, :1308, :1672-1685 when levels have their own DistributionMapping (:1421-1500, :1657-1702). */
+ * src/simulation.hpp:1789-1858, :1949-1964, :1308, :1672-1685 when levels have their own DistributionMapping (:1421-1500, :1657-1702).
+ * QK_GHOST_LOOPBACK=1 (environment, read at plan creation as by qk_ghost_plan_create): same-rank pairs become regions of a peer whose rank is my_rank —
+ * the pack -> send / recv -> unpack ordering of a plan on the production transport with ONE GPU (tests/test_rccl_loopback_gpu.py). */
 typedef struct qk_pcopy_plan qk_pcopy_plan;
 int qk_pcopy_plan_create(qk_ctx *ctx, const qk_geometry *geom, int n_src, const qk_box *src_boxes, const int *src_owner, int src_nghost, int src_ring_only,
 			 int n_dst, const qk_box *dst_boxes, const int *dst_owner, int dst_nghost, const qk_box *dst_holes, int ncomp, int my_rank,
