@@ -63,44 +63,49 @@ def compare(a, b):
     return f"levels {A.finest_level + 1}, boxes {[len(l.boxes) for l in A.levels]}, worst relative difference {worst[w]:.2e} ({w})" + (" NaN!" if nan else "")
 
 
-only = sys.argv[1] if len(sys.argv) > 1 else ""
-for name, exe, deck, over, nranks, steps in CASES:
-    if only and only not in name:
-        continue
-    base = ([os.path.join(HOST, "decks", deck)] if deck else []) + ([] if any(o.startswith("plotfile_interval") for o in over) else ["plotfile_interval=100000"])
-    base += ["checkpoint_interval=-1", "qk.dump_state=s.bin", "qk.level0_distribution=bricks"] + over
-    for scheme in ("per_level", "ancestor"):
-        one_args = [f"qk.refine_grid_layout_target={nranks}"] if scheme == "per_level" else ["qk.cluster_within_parent=1"]
-        many_args = ["qk.distribute_levels=1"] if scheme == "per_level" else ["qk.distribute_levels=0"]
-        with tempfile.TemporaryDirectory() as d1, tempfile.TemporaryDirectory() as dn:
-            rc1, o1, p1 = run(exe, base + one_args, d1, 1, steps)
-            rcn, on, pn = run(exe, base + many_args, dn, nranks, steps)
-            if all(r in (0, 1) for r in rc1 + rcn) and not (p1 and pn):  # no plotfile (the problem sets its own interval): the level-0 dumps instead
-                from quokka_amd.simulation import chop_domain, distribute_boxes
-                kv = dict(o.split("=", 1) for o in over if "=" in o)
-                n_cell = [int(x) for x in kv["amr.n_cell"].split()]
-                mgs = int(kv["amr.max_grid_size"])
-                boxes = chop_domain(n_cell, [mgs] * 3)
-                owner = distribute_boxes(boxes, nranks, n_cell, [mgs] * 3)
-                one = np.fromfile(os.path.join(d1, "s.bin"))
-                parts = [np.fromfile(os.path.join(dn, f"s.bin.rank{r}")) for r in range(nranks)]
-                per = one.size // len(boxes)
-                cur, many = [0] * nranks, []
-                for r in owner:
-                    many.append(parts[r][cur[r]:cur[r] + per])
-                    cur[r] += per
-                many = np.concatenate(many).reshape(len(boxes), -1, mgs ** 3)
-                one = one.reshape(many.shape)
-                rel = [float(np.abs(many[:, n] - one[:, n]).max() / max(np.abs(one[:, n]).max(), 1e-300)) for n in range(one.shape[1])]
-                zone = re.findall(r"Zone-updates on level \d: \d+ \((\d+) grids\)", on[0])
-                same = zone == re.findall(r"Zone-updates on level \d: \d+ \((\d+) grids\)", o1[0])
-                print(f"{name:14s} {scheme:9s} {nranks} ranks: level-0 dump, grids per level {zone} (same as one rank: {same}), worst relative difference {max(rel):.2e}"
-                      + (" NaN!" if np.isnan(many).any() else ""), flush=True)
-                continue
-            ok = all(r in (0, 1) for r in rc1 + rcn) and p1 and pn
-            if not ok:
-                bad = next((o for r, o in zip(rc1 + rcn, o1 + on) if r not in (0, 1)), "")
-                why = [ln for ln in bad.splitlines() if "Abort" in ln or "qkhost" in ln or "rror" in ln][:2]
-                print(f"{name:14s} {scheme:9s} {nranks} ranks: FAILED rc {rc1} {rcn}: {why}", flush=True)
-                continue
-            print(f"{name:14s} {scheme:9s} {nranks} ranks: {compare(p1, pn)}", flush=True)
+def main():
+    only = sys.argv[1] if len(sys.argv) > 1 else ""
+    for name, exe, deck, over, nranks, steps in CASES:
+        if only and only not in name:
+            continue
+        base = ([os.path.join(HOST, "decks", deck)] if deck else []) + ([] if any(o.startswith("plotfile_interval") for o in over) else ["plotfile_interval=100000"])
+        base += ["checkpoint_interval=-1", "qk.dump_state=s.bin", "qk.level0_distribution=bricks"] + over
+        for scheme in ("per_level", "ancestor"):
+            one_args = [f"qk.refine_grid_layout_target={nranks}"] if scheme == "per_level" else ["qk.cluster_within_parent=1"]
+            many_args = ["qk.distribute_levels=1"] if scheme == "per_level" else ["qk.distribute_levels=0"]
+            with tempfile.TemporaryDirectory() as d1, tempfile.TemporaryDirectory() as dn:
+                rc1, o1, p1 = run(exe, base + one_args, d1, 1, steps)
+                rcn, on, pn = run(exe, base + many_args, dn, nranks, steps)
+                if all(r in (0, 1) for r in rc1 + rcn) and not (p1 and pn):  # no plotfile (the problem sets its own interval): the level-0 dumps instead
+                    from quokka_amd.simulation import chop_domain, distribute_boxes
+                    kv = dict(o.split("=", 1) for o in over if "=" in o)
+                    n_cell = [int(x) for x in kv["amr.n_cell"].split()]
+                    mgs = int(kv["amr.max_grid_size"])
+                    boxes = chop_domain(n_cell, [mgs] * 3)
+                    owner = distribute_boxes(boxes, nranks, n_cell, [mgs] * 3)
+                    one = np.fromfile(os.path.join(d1, "s.bin"))
+                    parts = [np.fromfile(os.path.join(dn, f"s.bin.rank{r}")) for r in range(nranks)]
+                    per = one.size // len(boxes)
+                    cur, many = [0] * nranks, []
+                    for r in owner:
+                        many.append(parts[r][cur[r]:cur[r] + per])
+                        cur[r] += per
+                    many = np.concatenate(many).reshape(len(boxes), -1, mgs ** 3)
+                    one = one.reshape(many.shape)
+                    rel = [float(np.abs(many[:, n] - one[:, n]).max() / max(np.abs(one[:, n]).max(), 1e-300)) for n in range(one.shape[1])]
+                    zone = re.findall(r"Zone-updates on level \d: \d+ \((\d+) grids\)", on[0])
+                    same = zone == re.findall(r"Zone-updates on level \d: \d+ \((\d+) grids\)", o1[0])
+                    print(f"{name:14s} {scheme:9s} {nranks} ranks: level-0 dump, grids per level {zone} (same as one rank: {same}), worst relative difference {max(rel):.2e}"
+                          + (" NaN!" if np.isnan(many).any() else ""), flush=True)
+                    continue
+                ok = all(r in (0, 1) for r in rc1 + rcn) and p1 and pn
+                if not ok:
+                    bad = next((o for r, o in zip(rc1 + rcn, o1 + on) if r not in (0, 1)), "")
+                    why = [ln for ln in bad.splitlines() if "Abort" in ln or "qkhost" in ln or "rror" in ln][:2]
+                    print(f"{name:14s} {scheme:9s} {nranks} ranks: FAILED rc {rc1} {rcn}: {why}", flush=True)
+                    continue
+                print(f"{name:14s} {scheme:9s} {nranks} ranks: {compare(p1, pn)}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
