@@ -8,7 +8,7 @@ import sys
 
 here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "quokka_amd", "csrc")
 f = sys.argv[1]
-cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-I../../include", "-I.",
+cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", *os.environ.get("QK_RU_FLAGS", "").split(), "-I../../include", "-I.",
        "-Rpass-analysis=kernel-resource-usage", "-c", f, "-o", "/tmp/ru.o"]
 out = subprocess.run(cmd, cwd=here, capture_output=True, text=True).stderr
 rows, cur = [], {}

@@ -203,6 +203,9 @@ QK_DEV auto chiCompressive(double Pm2, double Pm1, double Pp1, double Pp2, Recip
 #ifndef QK_PRE_PREFETCH
 #define QK_PRE_PREFETCH 0
 #endif
+#ifndef QK_MARCH_PREFETCH
+#define QK_MARCH_PREFETCH 1
+#endif
 #ifndef QK_PRE_HALO_DIET
 #define QK_PRE_HALO_DIET 1 // (A/B knob)
 #endif
@@ -1095,6 +1098,19 @@ __global__ void __launch_bounds__(64 * MARCH_BY) k_sweep_march(SweepArgs a, Eos 
 		}
 	}
 
+	// QK_MARCH_PREFETCH (A/B knob, default 1): the newest cell of the NEXT step is requested one step ahead (the fab holds the cell one beyond the last one a
+	// march converts: 4 ghost cells, 3 of them read), so that a wave does not park on the round trip of the cell it is about to convert.  Six more doubles in
+	// flight: not for the fused XY sweep, which sits at the 256-register limit of two waves per SIMD.  Same loads, same arithmetic: no bit changes.
+	// Measured (profiles/round6/ab6_march_prefetch.txt): the Z sweep 0.873 -> 0.837 ms at 256^3, 6.61 -> 6.31 ms at 512^3 (234 -> 246 registers, no
+	// scratch); requesting the pre-pass results (chi, D_v, D_w) of the next cell as well gives the gain back (252 registers).
+	constexpr bool PFQ = (QK_MARCH_PREFETCH != 0) && !FUSEX && NS == 0; // (with passive scalars the six doubles push 21 instantiations past 256 registers: one wave per SIMD)
+	double Un[NVAR];
+	if constexpr (PFQ) {
+#pragma unroll
+		for (int n = 0; n < NVAR; ++n) {
+			Un[n] = Uin.p[u + Uin.ns * n];
+		}
+	}
 	for (int step = 0; step < nvalid + 6; ++step, c += ms, u += ums) {
 		// shift the window; U(p) -> primitives of the newest cell
 #pragma unroll
@@ -1106,9 +1122,17 @@ __global__ void __launch_bounds__(64 * MARCH_BY) k_sweep_march(SweepArgs a, Eos 
 		}
 		{
 			double Uc[NVAR];
+			if constexpr (PFQ) {
 #pragma unroll
-			for (int n = 0; n < NVAR; ++n) {
-				Uc[n] = Uin.p[u + Uin.ns * n];
+				for (int n = 0; n < NVAR; ++n) {
+					Uc[n] = Un[n];
+					Un[n] = Uin.p[u + ums + Uin.ns * n];
+				}
+			} else {
+#pragma unroll
+				for (int n = 0; n < NVAR; ++n) {
+					Uc[n] = Uin.p[u + Uin.ns * n];
+				}
 			}
 			if (a.prim_in) { // (uniform) the input array holds the primitives
 #pragma unroll
