@@ -26,6 +26,8 @@ CASES = [  # name, executable, deck, overrides, ranks, coarse steps
                                              "amr.max_level=0", "hydro.rk2_carry_rhs=1", "qk.min_overlap_cells=1", "max_timesteps=10"], 4, 10),  # fused XY sweep + early / late exchange
     ("periodic3d", "ref_HydroBlast3D", None, ["geometry.prob_lo=0 0 0", "geometry.prob_hi=1.2 1.2 1.2", "geometry.is_periodic=1 1 1", "amr.n_cell=32 32 32", "amr.max_grid_size=8",
                                              "amr.max_level=2", "amr.blocking_factor=8", "amr.n_error_buf=3", "do_reflux=1"], 4, 10),  # the blast in the corner: every level wraps through three faces
+    ("four_levels", "ref_HydroBlast3D", None, ["geometry.prob_lo=0 0 0", "geometry.prob_hi=1.2 1.2 1.2", "geometry.is_periodic=0 0 0", "amr.n_cell=32 32 32", "amr.max_grid_size=16",
+                                              "amr.max_level=3", "amr.blocking_factor=8", "amr.n_error_buf=2", "do_reflux=1"], 4, 6),  # a shadow of a level that has a shadow itself
     ("blast3d", "ref_HydroBlast3D", None, ["geometry.prob_lo=0 0 0", "geometry.prob_hi=1.2 1.2 1.2", "geometry.is_periodic=0 0 0", "amr.n_cell=32 32 32", "amr.max_grid_size=8",
                                           "amr.max_level=2", "amr.blocking_factor=8", "amr.n_error_buf=3", "do_reflux=1"], 8, 8),
 ]
