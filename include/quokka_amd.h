@@ -541,7 +541,8 @@ int qk_InterpFromCoarse(qk_interp_plan *plan, qk_stream s, qk_array4 *fine, cons
  * (AMReX's kernel is restated). */
 typedef struct qk_fluxreg qk_fluxreg;
 /* all_fine as for qk_interp_plan_create.  reg_nghost > 0: a register cell owned by another rank is kept in a ghost cell (within
- * reg_nghost) of a local coarse box; Reflux must then target a zeroed increment array with that many ghost cells, to be folded with
+ * reg_nghost) of the local coarse box it adjoins IN THE DIRECTION OF ITS FACE — the box whose flux array holds the face CrseAdd reads (never a box that
+ * merely has the cell in a corner of its ghost ring); Reflux must then target a zeroed increment array with that many ghost cells, to be folded with
  * qk_SumBoundary_* and added to the state (quokka_amd/amr_simulation.py).  reg_nghost = 0: single rank, Reflux straight into the state. */
 int qk_fluxreg_create(qk_level *crse, qk_level *fine, const qk_geometry *crse_geom, const int ratio[3], int ncomp, int n_all_fine, const qk_box *all_fine,
 		      int reg_nghost, qk_fluxreg **fr);

@@ -2,9 +2,9 @@ import os, sys, re, numpy as np, pathlib, tempfile
 sys.path.insert(0, "/root/repo/tests"); sys.path.insert(0, "/root/repo")
 import test_host_mirror_gpu as T
 from quokka_amd.simulation import chop_domain, distribute_boxes
-N, mgs, nranks, steps = 64, 16, 8, 30
+N, mgs, nranks, steps, bf = (int(os.environ.get(k, d)) for k, d in (("N", 64), ("MGS", 16), ("RANKS", 8), ("STEPS", 30), ("BF", 8)))
 args = ["geometry.prob_lo=0 0 0", "geometry.prob_hi=1.2 1.2 1.2", "geometry.is_periodic=0 0 0", f"amr.n_cell={N} {N} {N}", f"amr.max_grid_size={mgs}",
-        "amr.max_level=2", "amr.blocking_factor=8", "amr.n_error_buf=3", "do_reflux=1", f"max_timesteps={steps}", f"qk.refine_grid_layout_target={nranks}"]
+        "amr.max_level=2", f"amr.blocking_factor={bf}", "amr.n_error_buf=3", "do_reflux=1", f"max_timesteps={steps}", f"qk.refine_grid_layout_target={nranks}"]
 tmp = pathlib.Path(tempfile.mkdtemp())
 for s in "ab": os.makedirs(tmp / s)
 (one,), o1 = T.run_ranks("ref_HydroBlast3D", args, tmp / "a", 1, 0)
