@@ -554,6 +554,28 @@ def test_amr_levels_with_their_own_distribution_in_the_cxx_host(tmp_path, ctx, n
     diff = plotfile.compare_plotfiles(str(tmp_path / "c" / "plt00008"), str(tmp_path / "py_plt00008"))
     scale = {v: max(float(np.abs(f[i]).max()) for f in py.levels[0].fabs) for i, v in enumerate(py.varnames)}
     assert all(diff[v] <= 1e-13 * max(scale[v], scale["gasEnergy"]) for v in py.varnames), diff
+    if nranks == 4:
+        # ... and the PYTHON host on the same number of ranks (gloo, the ranks sharing this GPU; tests/test_multirank_one_gpu.py): both hosts drive the same plans in the
+        # same order — level 0 agrees in every bit, rank by rank
+        import torch.multiprocessing as mp
+        from test_multirank_one_gpu import collect, free_port, run_amr_worker
+        mpctx = mp.get_context("spawn")
+        q = mpctx.Queue()
+        port = free_port()
+        procs = [mpctx.Process(target=run_amr_worker, args=(r, nranks, port, 32, 8, q, "bricks", mgs)) for r in range(nranks)]
+        for p in procs:
+            p.start()
+        results = sorted(collect(procs, q, nranks), key=lambda r: r[0])
+        pyl0 = np.full((6, 32, 32, 32), np.nan)
+        for rank, levels, tnew, drift, istep in results:
+            all_boxes, own, mine, vals = levels[0]
+            assert own == owner
+            for (lo, hi), v in zip(mine, vals):
+                pyl0[:, lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1] = v
+        cxx = np.full_like(pyl0, np.nan)
+        for b, (lo, hi) in enumerate(boxes):
+            cxx[:, lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1] = many[b].reshape(6, mgs, mgs, mgs)
+        assert not np.isnan(pyl0).any() and np.array_equal(cxx, pyl0), float(np.abs(cxx - pyl0).max())
 
 
 @pytest.mark.parametrize("name,deck,extra,n_cell,mgs,steps", [("ref_Advection2D", "advection2d_amr.in", [], (64, 64), 16, 40),
